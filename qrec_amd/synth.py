@@ -1,0 +1,135 @@
+"""Deterministic synthetic interaction matrices (SURVEY.md §8d "synthetic generator").
+
+The reference ships no ML-1M / Yelp2018 data (/root/reference/.MISSING_LARGE_BLOBS), so the
+bench and the parity tests use matrices of the named *shapes*, generated here:
+
+* users / items get Zipf-like popularity p_k ∝ k^-alpha (alpha_user=0.4, alpha_item=0.6),
+  randomly permuted;
+* one edge per user and per item first (coverage), then 1.25·E random (u,i) pairs,
+  de-duplicated keeping the first occurrence, truncated to E;
+* rating = 1; rows are emitted **user-major in first-appearance order**, the order the
+  reference's ``Rating`` data model assigns ids in (data/rating.py:48-54), so row r of the
+  CSR is user id r and item ids are first-appearance ids as well.
+
+Everything is numpy on the host; nothing here is on the timed path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SHAPES = {
+    # name: (users, items, train_edges, test_edges, seed)
+    "ml1m": (6040, 3706, 1000209, 0, 1000),
+    "yelp2018": (31668, 38048, 1237259, 324147, 2018),
+    "tiny": (300, 200, 6000, 1500, 7),
+    "small": (2000, 1500, 60000, 15000, 11),
+}
+
+
+def _zipf_probs(n: int, alpha: float, rng: np.random.Generator) -> np.ndarray:
+    p = np.arange(1, n + 1, dtype=np.float64) ** (-alpha)
+    p /= p.sum()
+    return p[rng.permutation(n)]
+
+
+def gen_edges(n_users: int, n_items: int, n_edges: int, seed: int,
+              alpha_user: float = 0.4, alpha_item: float = 0.6):
+    """Return (u, i) int64 arrays of exactly ``n_edges`` distinct pairs covering every
+    user and every item at least once (needs n_edges >= n_users + n_items)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pu = _zipf_probs(n_users, alpha_user, rng)
+    pi = _zipf_probs(n_items, alpha_item, rng)
+    # coverage edges
+    cu = np.arange(n_users, dtype=np.int64)
+    ci = rng.choice(n_items, size=n_users, p=pi)
+    du = rng.choice(n_users, size=n_items, p=pu)
+    di = np.arange(n_items, dtype=np.int64)
+    m = int(1.25 * n_edges)
+    ru = rng.choice(n_users, size=m, p=pu)
+    ri = rng.choice(n_items, size=m, p=pi)
+    u = np.concatenate([cu, du, ru])
+    i = np.concatenate([ci, di, ri])
+    key = u * np.int64(n_items) + i
+    _, first = np.unique(key, return_index=True)
+    first.sort()
+    if first.size < n_edges:
+        raise ValueError("not enough distinct pairs; raise the oversampling factor")
+    first = first[:n_edges]
+    return u[first], i[first]
+
+
+def relabel_first_appearance(u: np.ndarray, i: np.ndarray):
+    """Relabel users/items by first appearance while walking the rows in order — exactly
+    the id assignment of the reference data model (data/rating.py:48-54)."""
+    def relabel(x):
+        _, first_idx, inv = np.unique(x, return_index=True, return_inverse=True)
+        order = np.argsort(first_idx, kind="stable")
+        rank = np.empty_like(order)
+        rank[order] = np.arange(order.size)
+        return rank[inv].astype(np.int64)
+    return relabel(u), relabel(i)
+
+
+def make_dataset(shape: str = "yelp2018", *, test_fraction: float | None = None):
+    """Build train/test COO arrays for a named shape.
+
+    Returns dict(n_users, n_items, train_u, train_i, test_u, test_i).  Train rows are
+    user-major (grouped by user, users in first-appearance order); ids are
+    first-appearance ids *of the train file*, as the reference would assign them.
+    The test split takes the last ``test_fraction`` of each user's edges (Yelp2018 ratio
+    324147/1561406 by default when the shape has test edges).
+    """
+    n_users, n_items, e_train, e_test, seed = SHAPES[shape]
+    total = e_train + e_test
+    u, i = gen_edges(n_users, n_items, total, seed)
+    # group by user, stable (keeps each user's draw order)
+    order = np.argsort(u, kind="stable")
+    u, i = u[order], i[order]
+    if e_test > 0:
+        frac = e_test / total if test_fraction is None else test_fraction
+        counts = np.bincount(u, minlength=n_users)
+        starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+        pos = np.arange(total) - np.repeat(starts, counts)
+        n_test_u = np.floor(counts * frac).astype(np.int64)
+        n_test_u = np.minimum(n_test_u, counts - 1)  # keep >=1 train edge per user
+        is_test = pos >= np.repeat(counts - n_test_u, counts)
+    else:
+        is_test = np.zeros(total, dtype=bool)
+    tr_u, tr_i = u[~is_test], i[~is_test]
+    te_u, te_i = u[is_test], i[is_test]
+    # the reference assigns ids walking the TRAIN file; items only seen in test keep no id
+    # (they can never be recommended).  Relabel train, map test through the same tables.
+    _, fu, inv_u = np.unique(tr_u, return_index=True, return_inverse=True)
+    ou = np.argsort(fu, kind="stable"); ru = np.empty_like(ou); ru[ou] = np.arange(ou.size)
+    uniq_i, fi, inv_i = np.unique(tr_i, return_index=True, return_inverse=True)
+    oi = np.argsort(fi, kind="stable"); ri = np.empty_like(oi); ri[oi] = np.arange(oi.size)
+    train_u = ru[inv_u].astype(np.int32)
+    train_i = ri[inv_i].astype(np.int32)
+    uniq_u = np.unique(tr_u)
+    # map test ids; drop test rows whose item never appears in train
+    pos_i = np.searchsorted(uniq_i, te_i)
+    pos_i = np.clip(pos_i, 0, uniq_i.size - 1)
+    ok = uniq_i[pos_i] == te_i
+    pos_u = np.searchsorted(uniq_u, te_u)
+    test_u = ru[pos_u[ok]].astype(np.int32)
+    test_i = ri[pos_i[ok]].astype(np.int32)
+    return dict(n_users=int(uniq_u.size), n_items=int(uniq_i.size),
+                train_u=train_u, train_i=train_i, test_u=test_u, test_i=test_i,
+                shape=shape, seed=seed)
+
+
+def to_csr(n_rows: int, rows: np.ndarray, cols: np.ndarray):
+    """Row-grouped COO -> (indptr int64, indices int32), keeping within-row order."""
+    order = np.argsort(rows, kind="stable")
+    counts = np.bincount(rows, minlength=n_rows)
+    indptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(counts, out=indptr[1:])
+    return indptr, cols[order].astype(np.int32)
+
+
+def write_rating_file(path: str, u: np.ndarray, i: np.ndarray) -> None:
+    """Emit the reference's on-disk format, one ``"user item 1"`` row per line
+    (read by util/io.py:31-76).  Names are the integer ids prefixed so that user and
+    item name spaces cannot be confused."""
+    with open(path, "w") as f:
+        f.write("".join(f"u{a} i{b} 1\n" for a, b in zip(u.tolist(), i.tolist())))

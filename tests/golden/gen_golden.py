@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the UNMODIFIED reference (Coder-Yu/QRec) in-process.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+
+Needs /root/reference (present only in the build container, never on the GPU box); the
+fixtures it writes next to this file are committed and are what the tests read.
+
+How the reference is made importable without editing it:
+  * ``sys.modules`` stubs for ``numba`` (jit = identity), ``mkl`` and ``tensorflow``
+    (none are installed; only the numpy path and the pure-python sampler / scipy
+    adjacency builder are executed);
+  * cwd = scratch dir holding a ``dataset -> /root/reference/dataset`` symlink, because
+    conf paths, ./log and ./results are cwd-relative;
+  * RNGs seeded (the reference never seeds): ``random.seed(s); np.random.seed(s)``.
+
+What is captured, per case: the (u,i,j) index stream of every SGD step, P/Q and the loss
+after every epoch, the learning-rate schedule, the python ``random`` state at the end, the
+recommendation lists and the measure strings.  Big arrays are stored as .npz; streams that
+would be large are stored as a sha256 plus a head/tail sample.
+"""
+import hashlib
+import io
+import json
+import os
+import random
+import sys
+import tempfile
+import types
+from contextlib import redirect_stdout
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def install_stubs():
+    nb = types.ModuleType("numba"); nb.jit = lambda *a, **k: (lambda f: f)
+    mkl = types.ModuleType("mkl"); mkl.set_num_threads = lambda n: None; mkl.get_max_threads = lambda: 1
+    tf = types.ModuleType("tensorflow")
+    sys.modules.update(numba=nb, mkl=mkl, tensorflow=tf)
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def write_conf(path, **kv):
+    with open(path, "w") as f:
+        for k, v in kv.items():
+            f.write(f"{k.replace('__', '.')}={v}\n")
+
+
+def run_numpy_model(conf_path, seed, model_mod, model_name, hook_attr):
+    """Run QRec(conf) end to end with instrumentation of the per-sample step."""
+    from QRec import QRec
+    from util.config import ModelConf
+    import importlib
+    mod = importlib.import_module(model_mod)
+    cls = getattr(mod, model_name)
+    rec = {"steps": [], "epochs": []}
+
+    if hook_attr == "optimization":       # BPR: record (u,i,j)
+        orig = cls.optimization
+        def optimization(self, u, i, j):
+            rec["steps"].append((u, i, j)); return orig(self, u, i, j)
+        cls.optimization = optimization
+    orig_conv = cls.isConverged
+    def isConverged(self, epoch):
+        loss_before = self.loss; lr_used = self.lRate
+        r = orig_conv(self, epoch)
+        rec["epochs"].append(dict(epoch=epoch, loss=float(loss_before), lr_used=float(lr_used),
+                                  lr_next=float(self.lRate), converged=bool(r),
+                                  P=self.P.copy(), Q=self.Q.copy(),
+                                  order=[(self.data.user[a], self.data.item[b], c)
+                                         for a, b, c in self.data.trainingData]
+                                  if hook_attr == "mf" else None))
+        return r
+    cls.isConverged = isConverged
+    orig_init = cls.initModel
+    def initModel(self):
+        orig_init(self); rec["P0"] = self.P.copy(); rec["Q0"] = self.Q.copy()
+        rec["order0"] = [(self.data.user[a], self.data.item[b], c) for a, b, c in self.data.trainingData]
+    cls.initModel = initModel
+    orig_eval = cls.evalRanking
+    holder = {}
+    import base.recommender as br
+    orig_rm = br.Measure.rankingMeasure
+    def rankingMeasure(origin, res, N):
+        holder["recList"] = res; holder["origin"] = origin
+        return orig_rm(origin, res, N)
+    br.Measure.rankingMeasure = staticmethod(rankingMeasure)
+
+    random.seed(seed); np.random.seed(seed)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        q = QRec(ModelConf(conf_path))
+        # QRec.execute() instantiates through eval(); do the same thing by hand to keep
+        # a handle on the model object
+        m = cls(q.config, q.trainingData, q.testData)
+        measure = m.execute()
+    cls.isConverged = orig_conv; cls.initModel = orig_init
+    br.Measure.rankingMeasure = staticmethod(orig_rm)
+    if hook_attr == "optimization":
+        cls.optimization = orig
+    rec["model"] = m; rec["measure"] = measure; rec["holder"] = holder
+    rec["py_state"] = random.getstate()
+    rec["train_rows"] = q.trainingData; rec["test_rows"] = q.testData
+    return rec
+
+
+def pack_bpr(rec, name, keep_full_stream):
+    m = rec["model"]
+    steps = np.array(rec["steps"], dtype=np.int32).reshape(-1, 3)
+    n_per_epoch = steps.shape[0] // len(rec["epochs"])
+    # training data as the reference loaded/split it (ids as assigned by data/rating.py)
+    tr = np.array([(m.data.user[a], m.data.item[b]) for a, b, _ in rec["order0"]], dtype=np.int32) \
+        if False else None
+    train_uid = np.array([m.data.user[r[0]] for r in rec["train_rows"]], dtype=np.int32)
+    train_iid = np.array([m.data.item[r[1]] for r in rec["train_rows"]], dtype=np.int32)
+    train_r = np.array([r[2] for r in rec["train_rows"]], dtype=np.float64)
+    # test rows: names may be unknown to the train id maps -> -1
+    test_uid = np.array([m.data.user.get(r[0], -1) for r in rec["test_rows"]], dtype=np.int32)
+    test_iid = np.array([m.data.item.get(r[1], -1) for r in rec["test_rows"]], dtype=np.int32)
+    test_uname = np.array([r[0] for r in rec["test_rows"]]); test_iname = np.array([r[1] for r in rec["test_rows"]])
+    arrays = dict(P0=rec["P0"], Q0=rec["Q0"], train_uid=train_uid, train_iid=train_iid,
+                  train_r=train_r, test_uid=test_uid, test_iid=test_iid,
+                  test_uname=test_uname, test_iname=test_iname,
+                  py_state=np.array(rec["py_state"][1], dtype=np.uint32))
+    for k, e in enumerate(rec["epochs"]):
+        arrays[f"P{k+1}"] = e["P"]; arrays[f"Q{k+1}"] = e["Q"]
+    if keep_full_stream:
+        arrays["steps"] = steps
+    else:
+        arrays["steps_head"] = steps[:4096]; arrays["steps_tail"] = steps[-4096:]
+    # recommendation lists (ids + scores) in testSet_u order
+    rl = rec["holder"]["recList"]
+    users = list(rl.keys())
+    N = max(len(v) for v in rl.values())
+    ids = np.full((len(users), N), -1, dtype=np.int32); sc = np.zeros((len(users), N))
+    for a, un in enumerate(users):
+        for b, (iname, s) in enumerate(rl[un]):
+            ids[a, b] = m.data.item[iname]; sc[a, b] = s
+    arrays["rec_users"] = np.array([m.data.user.get(un, -1) for un in users], dtype=np.int32)
+    arrays["rec_user_names"] = np.array(users)
+    arrays["rec_ids"] = ids; arrays["rec_scores"] = sc
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    meta = dict(name=name, n_users=len(m.data.user), n_items=len(m.data.item),
+                n_train=len(rec["train_rows"]), n_test=len(rec["test_rows"]),
+                triplets_per_epoch=int(n_per_epoch), stream_sha256=sha(steps),
+                epochs=[{k: v for k, v in e.items() if k not in ("P", "Q", "order")} for e in rec["epochs"]],
+                measure=rec["measure"], emb_size=m.emb_size, regU=m.regU, regI=m.regI,
+                topN=m.ranking["-topN"])
+    return meta
+
+
+def case_bpr_filmtrust(tmp):
+    conf = os.path.join(tmp, "bpr_ft.conf")
+    write_conf(conf, ratings="./dataset/FilmTrust/trainset.txt", ratings__setup="-columns 0 1 2",
+               model__name="BPR", evaluation__setup="-testSet ./dataset/FilmTrust/testset.txt -b 1",
+               item__ranking="on -topN 10,20", num__factors="8", num__max__epoch="3",
+               batch_size="1500", learnRate="-init 0.05 -max 1",
+               reg__lambda="-u 0.01 -i 0.01 -b 0.2 -s 0.2", output__setup="off -dir ./results/")
+    rec = run_numpy_model(conf, 20260923, "model.ranking.BPR", "BPR", "optimization")
+    meta = pack_bpr(rec, "bpr_filmtrust", keep_full_stream=True)
+    meta["seed"] = 20260923; meta["conf"] = open(conf).read()
+    return meta
+
+
+def case_bpr_lastfm(tmp):
+    conf = os.path.join(tmp, "bpr_lfm.conf")
+    # stock config/BPR.conf with fewer epochs / factors so that the fixture stays small
+    write_conf(conf, ratings="./dataset/lastfm/ratings.txt", ratings__setup="-columns 0 1 2",
+               model__name="BPR", evaluation__setup="-ap 0.2 -b 1", item__ranking="on -topN 20",
+               num__factors="16", num__max__epoch="2", batch_size="1500",
+               learnRate="-init 0.01 -max 1", reg__lambda="-u 0.001 -i 0.001 -b 0.2 -s 0.2",
+               output__setup="off -dir ./results/")
+    rec = run_numpy_model(conf, 7, "model.ranking.BPR", "BPR", "optimization")
+    # keep the fixture small: P0/Q0 are regenerable (np.random.seed(7); rand(U,d)/3;
+    # rand(I,d)/3 -- base/iterativeRecommender.py:37-38), so store only their sha256;
+    # keep the final P in full and every 4th row of the final Q plus its sha256.
+    last = len(rec["epochs"])
+    meta = pack_bpr(rec, "bpr_lastfm", keep_full_stream=False)
+    z = dict(np.load(os.path.join(OUT, "bpr_lastfm.npz")))
+    for k in range(1, last):
+        z.pop(f"P{k}"); z.pop(f"Q{k}")
+    meta["P0_sha256"] = sha(z.pop("P0")); meta["Q0_sha256"] = sha(z.pop("Q0"))
+    meta["Qlast_sha256"] = sha(z[f"Q{last}"])
+    z[f"Q{last}_every4"] = z.pop(f"Q{last}")[::4].copy()
+    # which raw rows the -ap split sent to the test set (util/dataSplit.py:9-26)
+    n_raw = len(rec["train_rows"]) + len(rec["test_rows"])
+    mask = np.zeros(n_raw, dtype=bool); a = b = 0
+    from util.io import FileIO
+    from util.config import ModelConf
+    with redirect_stdout(io.StringIO()):
+        raw = FileIO.loadDataSet(ModelConf(conf), "./dataset/lastfm/ratings.txt", binarized=True, threshold=1.0)
+    assert len(raw) == n_raw
+    for k, row in enumerate(raw):
+        if b < len(rec["test_rows"]) and rec["test_rows"][b] == row:
+            mask[k] = True; b += 1
+        else:
+            assert rec["train_rows"][a] == row; a += 1
+    z["split_is_test"] = mask
+    np.savez_compressed(os.path.join(OUT, "bpr_lastfm.npz"), **z)
+    meta["seed"] = 7; meta["conf"] = open(conf).read(); meta["kept_epochs"] = [last]
+    return meta
+
+
+def case_basicmf(tmp):
+    conf = os.path.join(tmp, "mf.conf")
+    # BASELINE.json config #1: BasicMF on FilmTrust, d=10, reference numpy path (no -tf)
+    write_conf(conf, ratings="./dataset/FilmTrust/trainset.txt", ratings__setup="-columns 0 1 2",
+               model__name="BasicMF", evaluation__setup="-testSet ./dataset/FilmTrust/testset.txt",
+               item__ranking="off -topN 10", num__factors="10", num__max__epoch="3",
+               batch_size="1024", learnRate="-init 0.03 -max 1",
+               reg__lambda="-u 0.05 -i 0.05 -b 0.1 -s 0.1", output__setup="off -dir ./results/")
+    rec = run_numpy_model(conf, 1, "model.rating.BasicMF", "BasicMF", "mf")
+    m = rec["model"]
+    arrays = dict(P0=rec["P0"], Q0=rec["Q0"],
+                  order0=np.array([(a, b) for a, b, _ in rec["order0"]], dtype=np.int32),
+                  rating0=np.array([c for _, _, c in rec["order0"]], dtype=np.float64),
+                  py_state=np.array(rec["py_state"][1], dtype=np.uint32))
+    for k, e in enumerate(rec["epochs"]):
+        arrays[f"P{k+1}"] = e["P"]; arrays[f"Q{k+1}"] = e["Q"]
+        arrays[f"order{k+1}"] = np.array([(a, b) for a, b, _ in e["order"]], dtype=np.int32)
+    # test predictions appended by evalRatings: [user,item,rating,pred]
+    arrays["test_pred"] = np.array([r[3] for r in m.data.testData], dtype=np.float64)
+    arrays["test_rating"] = np.array([r[2] for r in m.data.testData], dtype=np.float64)
+    arrays["test_uid"] = np.array([m.data.user.get(r[0], -1) for r in m.data.testData], dtype=np.int32)
+    arrays["test_iid"] = np.array([m.data.item.get(r[1], -1) for r in m.data.testData], dtype=np.int32)
+    np.savez_compressed(os.path.join(OUT, "basicmf_filmtrust.npz"), **arrays)
+    return dict(name="basicmf_filmtrust", seed=1, conf=open(conf).read(),
+                n_users=len(m.data.user), n_items=len(m.data.item), n_train=len(rec["train_rows"]),
+                epochs=[{k: v for k, v in e.items() if k not in ("P", "Q", "order")} for e in rec["epochs"]],
+                measure=rec["measure"], globalMean=m.data.globalMean,
+                rScale=[float(x) for x in m.data.rScale])
+
+
+def case_pairwise_and_adj(tmp):
+    """base/deepRecommender.py:29-52 sampler and base/graphRecommender.py:10-29 adjacency,
+    both pure python/scipy -> executable with the tensorflow stub."""
+    from QRec import QRec
+    from util.config import ModelConf
+    from model.ranking.LightGCN import LightGCN
+    conf = os.path.join(tmp, "lgcn.conf")
+    write_conf(conf, ratings="./dataset/FilmTrust/trainset.txt", ratings__setup="-columns 0 1 2",
+               model__name="LightGCN", evaluation__setup="-testSet ./dataset/FilmTrust/testset.txt -b 1",
+               item__ranking="on -topN 20", num__factors="8", num__max__epoch="1", batch_size="2000",
+               learnRate="-init 0.001 -max 1", LightGCN="-n_layer 2",
+               reg__lambda="-u 0.001 -i 0.001 -b 0.2 -s 0.2", output__setup="off -dir ./results/")
+    random.seed(3); np.random.seed(3)
+    with redirect_stdout(io.StringIO()):
+        q = QRec(ModelConf(conf))
+        m = LightGCN(q.config, q.trainingData, q.testData)
+        m.readConfiguration()
+    train_uid = np.array([m.data.user[r[0]] for r in m.data.trainingData], dtype=np.int32)
+    train_iid = np.array([m.data.item[r[1]] for r in m.data.trainingData], dtype=np.int32)
+    batches = []
+    for ep in range(2):
+        for b in m.next_batch_pairwise():
+            batches.append(np.array(b, dtype=np.int32).T)  # [B,3]
+    stream = np.concatenate(batches)
+    adj = m.create_joint_sparse_adjaceny().tocsr()
+    adj.sort_indices()
+    row, col = m.create_joint_sparse_adjaceny().nonzero()
+    np.savez_compressed(os.path.join(OUT, "pairwise_adj_filmtrust.npz"),
+                        train_uid=train_uid, train_iid=train_iid, stream=stream,
+                        batch_sizes=np.array([b.shape[0] for b in batches], dtype=np.int32),
+                        adj_indptr=adj.indptr.astype(np.int64), adj_indices=adj.indices.astype(np.int32),
+                        adj_data=adj.data.astype(np.float32), nz_row=row.astype(np.int32),
+                        nz_col=col.astype(np.int32),
+                        py_state=np.array(random.getstate()[1], dtype=np.uint32))
+    return dict(name="pairwise_adj_filmtrust", seed=3, conf=open(conf).read(),
+                n_users=len(m.data.user), n_items=len(m.data.item), n_train=len(m.data.trainingData),
+                batch_size=m.batch_size, epochs_sampled=2, stream_sha256=sha(stream),
+                adj_dtype=str(adj.dtype), adj_nnz=int(adj.nnz))
+
+
+def main():
+    install_stubs()
+    tmp = tempfile.mkdtemp(prefix="qrec_golden_")
+    os.symlink(os.path.join(REF, "dataset"), os.path.join(tmp, "dataset"))
+    os.chdir(tmp)
+    metas = [case_bpr_filmtrust(tmp), case_bpr_lastfm(tmp), case_basicmf(tmp),
+             case_pairwise_and_adj(tmp)]
+    with open(os.path.join(OUT, "golden_meta.json"), "w") as f:
+        json.dump({m["name"]: m for m in metas}, f, indent=1, sort_keys=True)
+    for m in metas:
+        print(m["name"], "ok", {k: m[k] for k in ("n_users", "n_items", "n_train") if k in m})
+
+
+if __name__ == "__main__":
+    main()

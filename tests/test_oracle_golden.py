@@ -1,0 +1,179 @@
+"""Pin the CPU oracle (oracle/qrec_oracle.c) against golden vectors produced by the
+UNMODIFIED reference run in-process (tests/golden/gen_golden.py).
+
+Index streams must match bit-exact; fp64 state to 1e-11 relative (numpy's BLAS ddot sums
+in a different order than the oracle's sequential loop, so bitwise equality of doubles is
+not expected after thousands of dependent updates)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c as O
+from qrec_amd.interactions import user_item_csr
+
+
+def _load(golden_dir, name):
+    meta = json.load(open(os.path.join(golden_dir, "golden_meta.json")))[name]
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    return meta, z
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _bpr_replay(meta, z, P, Q, mt, check_epoch):
+    """Replay model/ranking/BPR.py:19-43 + base/iterativeRecommender.py:82-102 with the
+    oracle; calls check_epoch(k, stream_k, P, Q, loss, lr_next) per epoch."""
+    U, I = meta["n_users"], meta["n_items"]
+    pos = user_item_csr(z["train_uid"], z["train_iid"], z["train_r"], U, I, min_rating=1)
+    u = pos.row_ids(); i = pos.indices
+    assert pos.nnz == meta["triplets_per_epoch"]
+    lr = meta["epochs"][0]["lr_used"]; max_lr = 1.0
+    last_loss = 0.0
+    streams = []
+    for k, ep in enumerate(meta["epochs"]):
+        j = O.bpr_sample_epoch(mt, pos.indptr, i, I)
+        loss = O.bpr_sgd(P, Q, u, i, j, lr, meta["regU"], meta["regI"])
+        loss += meta["regU"] * O.sumsq(P) + meta["regI"] * O.sumsq(Q)
+        assert lr == pytest.approx(ep["lr_used"], rel=1e-15)
+        # isConverged: lr update then shuffle(trainingData)
+        delta = last_loss - loss
+        if not abs(delta) < 1e-3:
+            if ep["epoch"] > 1:
+                lr = lr * 1.05 if abs(last_loss) > abs(loss) else lr * 0.5
+            if lr > max_lr > 0:
+                lr = max_lr
+        last_loss = loss
+        mt.shuffle(meta["n_train"])
+        st = np.stack([u, i, j], axis=1)
+        streams.append(st)
+        check_epoch(k, st, P, Q, loss, lr, ep)
+    return np.concatenate(streams)
+
+
+def test_bpr_filmtrust_stream_and_state(golden_dir):
+    meta, z = _load(golden_dir, "bpr_filmtrust")
+    P, Q = z["P0"].copy(), z["Q0"].copy()
+    # tables: np.random.seed(s); rand(U,d)/3; rand(I,d)/3 (base/iterativeRecommender.py:37-38)
+    m_np = O.MT.numpy_seed(meta["seed"])
+    assert np.array_equal(m_np.numpy_rand(*P.shape) / 3, P)
+    assert np.array_equal(m_np.numpy_rand(*Q.shape) / 3, Q)
+    mt = O.MT.cpython_seed(meta["seed"])
+
+    def chk(k, st, P, Q, loss, lr, ep):
+        np.testing.assert_allclose(P, z[f"P{k+1}"], rtol=1e-11, atol=1e-14)
+        np.testing.assert_allclose(Q, z[f"Q{k+1}"], rtol=1e-11, atol=1e-14)
+        assert loss == pytest.approx(ep["loss"], rel=1e-12)
+        assert lr == pytest.approx(ep["lr_next"], rel=1e-15)
+
+    stream = _bpr_replay(meta, z, P, Q, mt, chk)
+    assert np.array_equal(stream, z["steps"])                 # bit-exact index stream
+    assert _sha(stream.astype(np.int32)) == meta["stream_sha256"]
+    assert np.array_equal(mt.words625(), z["py_state"])       # generator ends in the same state
+
+
+def test_bpr_lastfm_split_stream_and_state(golden_dir):
+    meta, z = _load(golden_dir, "bpr_lastfm")
+    seed = meta["seed"]
+    mt = O.MT.cpython_seed(seed)
+    # -ap 0.2 split: util/dataSplit.py:9-26, one random() per raw row
+    mask = mt.data_split(z["split_is_test"].size, 0.2)
+    assert np.array_equal(mask, z["split_is_test"])
+    U, I, d = meta["n_users"], meta["n_items"], meta["emb_size"]
+    m_np = O.MT.numpy_seed(seed)
+    P = m_np.numpy_rand(U, d) / 3; Q = m_np.numpy_rand(I, d) / 3
+    assert _sha(P) == meta["P0_sha256"] and _sha(Q) == meta["Q0_sha256"]
+    last = len(meta["epochs"])
+
+    def chk(k, st, P, Q, loss, lr, ep):
+        assert loss == pytest.approx(ep["loss"], rel=1e-12)
+        assert lr == pytest.approx(ep["lr_next"], rel=1e-15)
+        if k + 1 == last:
+            np.testing.assert_allclose(P, z[f"P{last}"], rtol=1e-11, atol=1e-14)
+            np.testing.assert_allclose(Q[::4], z[f"Q{last}_every4"], rtol=1e-11, atol=1e-14)
+
+    stream = _bpr_replay(meta, z, P, Q, mt, chk)
+    assert _sha(stream.astype(np.int32)) == meta["stream_sha256"]
+    assert np.array_equal(stream[:4096], z["steps_head"]) and np.array_equal(stream[-4096:], z["steps_tail"])
+    assert np.array_equal(mt.words625(), z["py_state"])
+
+
+def test_basicmf_filmtrust(golden_dir):
+    """BASELINE.json config #1 through the oracle: model/rating/BasicMF.py:9-26."""
+    meta, z = _load(golden_dir, "basicmf_filmtrust")
+    P, Q = z["P0"].copy(), z["Q0"].copy()
+    mt = O.MT.cpython_seed(meta["seed"])
+    n = z["order0"].shape[0]
+    perm = np.arange(n, dtype=np.int64)
+    u0 = np.ascontiguousarray(z["order0"][:, 0]); i0 = np.ascontiguousarray(z["order0"][:, 1]); r0 = z["rating0"]
+    lr = meta["epochs"][0]["lr_used"]; last_loss = 0.0
+    for k, ep in enumerate(meta["epochs"]):
+        u = np.ascontiguousarray(u0[perm]); i = np.ascontiguousarray(i0[perm]); r = np.ascontiguousarray(r0[perm])
+        assert np.array_equal(np.stack([u, i], 1), z[f"order{k}"])
+        loss = O.mf_sgd(P, Q, u, i, r, lr)
+        assert loss == pytest.approx(ep["loss"], rel=1e-11)
+        np.testing.assert_allclose(P, z[f"P{k+1}"], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(Q, z[f"Q{k+1}"], rtol=1e-10, atol=1e-13)
+        if not abs(last_loss - loss) < 1e-3:
+            if ep["epoch"] > 1:
+                lr = lr * 1.05 if abs(last_loss) > abs(loss) else lr * 0.5
+            lr = min(lr, 1.0)
+        assert lr == pytest.approx(ep["lr_next"], rel=1e-15)
+        last_loss = loss
+        mt.shuffle(n, perm)       # base/iterativeRecommender.py:101
+    assert np.array_equal(np.stack([u0[perm], i0[perm]], 1), z[f"order{len(meta['epochs'])}"])
+    assert np.array_equal(mt.words625(), z["py_state"])
+    # test-set predictions: P[u].Q[i] clipped to the rating scale and round(.,3)
+    # (base/recommender.py:88-110, base/iterativeRecommender.py:65-73)
+    tu, ti = z["test_uid"], z["test_iid"]
+    ok = (tu >= 0) & (ti >= 0)
+    pred = np.einsum("nd,nd->n", P[tu[ok]], Q[ti[ok]])
+    lo, hi = meta["rScale"][0], meta["rScale"][-1]
+    want = z["test_pred"][ok]
+    got = np.where(pred > hi, hi, np.where(pred < lo, lo, np.round(pred, 3)))
+    np.testing.assert_allclose(got, want, atol=1.01e-3)  # round() boundary cases may flip the last digit
+
+
+def test_pairwise_sampler_stream(golden_dir):
+    """base/deepRecommender.py:29-52 over two epochs: shuffle(trainingData) then one
+    negative per row, membership against ALL train items of the user."""
+    meta, z = _load(golden_dir, "pairwise_adj_filmtrust")
+    U, I = meta["n_users"], meta["n_items"]
+    uid, iid = z["train_uid"], z["train_iid"]
+    rated = user_item_csr(uid, iid, np.ones(uid.size), U, I).sorted_rows()
+    mt = O.MT.cpython_seed(meta["seed"])
+    perm = np.arange(uid.size, dtype=np.int64)
+    out = []
+    for ep in range(meta["epochs_sampled"]):
+        mt.shuffle(uid.size, perm)
+        ru = np.ascontiguousarray(uid[perm]); ri = np.ascontiguousarray(iid[perm])
+        neg = O.pairwise_sample_epoch(mt, ru, rated.indptr, rated.indices, I)
+        out.append(np.stack([ru, ri, neg], 1))
+    stream = np.concatenate(out)
+    assert np.array_equal(stream, z["stream"])
+    assert np.array_equal(mt.words625(), z["py_state"])
+    bs = z["batch_sizes"]; B = meta["batch_size"]
+    assert (bs[bs != B] < B).all() and bs.sum() == stream.shape[0]
+
+
+def test_find_k_largest_on_reference_reclists(golden_dir):
+    """util/qmath.py:134-146 + mask-to-0 (base/recommender.py:147-149) reproduce the
+    reference's recommendation lists from the reference's final P,Q."""
+    meta, z = _load(golden_dir, "bpr_filmtrust")
+    last = len(meta["epochs"])
+    P, Q = z[f"P{last}"], z[f"Q{last}"]
+    U, I = meta["n_users"], meta["n_items"]
+    rated = user_item_csr(z["train_uid"], z["train_iid"], z["train_r"], U, I)
+    N = z["rec_ids"].shape[1]
+    for row, u in enumerate(z["rec_users"][:300]):
+        if u < 0:
+            continue
+        cand = Q.dot(P[u])
+        cand[rated.indices[rated.indptr[u]:rated.indptr[u + 1]]] = 0
+        ids, sc = O.find_k_largest(N, cand)
+        assert np.array_equal(ids, z["rec_ids"][row])
+        np.testing.assert_allclose(sc, z["rec_scores"][row], rtol=1e-12)
