@@ -1,0 +1,135 @@
+/*
+ * qrec_hip.h -- C ABI of libqrec_hip.so, the MI355X (gfx950) implementation of QRec's
+ * embedding-training hot path.
+ *
+ * The reference (Coder-Yu/QRec) is pure Python and has no FFI of its own; its only
+ * extension seam is the Recommender template-method API (base/recommender.py:181-212).
+ * Each entry point below replaces the body of one reference function; the Python model
+ * classes in qrec_amd/ (and the stub a QRec maintainer would add)
+ * bind these symbols with ctypes.  Plain C types only: pointers, sizes, scalars.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; qrec_last_error() gives the text
+ *     (thread-local).  The reference reports errors with print+exit(-1)
+ *     (util/config.py:8-10, base/iterativeRecommender.py:84-86); the Python wrapper maps
+ *     error codes to that behaviour.
+ *   - pointers named d_* are DEVICE pointers (from qrec_malloc or any HIP allocation,
+ *     e.g. a torch tensor's data_ptr()); h_* are HOST pointers, borrowed for the call.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ *     asynchronous on that stream unless stated otherwise.
+ *   - embedding tables are row-major [rows][ld] with ld >= d, ld a multiple of 4 (fp32) and
+ *     the pad columns zero; dtype is QREC_F32 or QREC_F64.
+ *   - a handle is not thread-safe; one process drives one device.
+ */
+#ifndef QREC_HIP_H
+#define QREC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QREC_OK 0
+#define QREC_ERR_INVALID (-1)  /* bad argument */
+#define QREC_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define QREC_ERR_NAN (-3)      /* loss is NaN/Inf (base/iterativeRecommender.py:84-86) */
+#define QREC_ERR_UNSUPPORTED (-4)
+
+#define QREC_F32 0
+#define QREC_F64 1
+
+/* ---- runtime ------------------------------------------------------------------------ */
+int qrec_version(void);
+const char *qrec_last_error(void);
+int qrec_device_count(int *n);
+/* Select the device for this process.  Deliberately NOT called from any constructor:
+ * QRec builds model objects in the parent and forks per CV fold (QRec.py:76-89). */
+int qrec_init(int device);
+int qrec_device_info(char *name, int name_len, int *n_cu, int64_t *hbm_bytes, char *arch,
+                     int arch_len);
+int qrec_malloc(int64_t bytes, void **d_ptr);
+int qrec_free(void *d_ptr);
+int qrec_memcpy_h2d(void *d_dst, const void *h_src, int64_t bytes, void *stream);
+int qrec_memcpy_d2h(void *h_dst, const void *d_src, int64_t bytes, void *stream);
+int qrec_memcpy_d2d(void *d_dst, const void *d_src, int64_t bytes, void *stream);
+int qrec_memset(void *d_dst, int byte, int64_t bytes, void *stream);
+int qrec_stream_create(void **stream);
+int qrec_stream_destroy(void *stream);
+int qrec_stream_sync(void *stream);
+int qrec_device_sync(void);
+int qrec_event_create(void **ev);
+int qrec_event_destroy(void *ev);
+int qrec_event_record(void *ev, void *stream);
+int qrec_event_sync(void *ev);
+int qrec_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms);
+
+/* ---- exact (bit-reproducible) sampler, host side ------------------------------------- *
+ * Replays CPython's `random` (MT19937) word for word.  `state625` is
+ * random.getstate()[1] (624 words + index) and is advanced in place so the Python host
+ * can random.setstate() it back and stay in lock-step with the reference.            */
+
+/* model/ranking/BPR.py:28-38: one negative per entry of the PositiveSet CSR, users in id
+ * order, items in row order; redraw while the item is a positive of the user. */
+int qrec_mt_bpr_sample_epoch(uint32_t *state625, const int64_t *h_pos_indptr,
+                             const int32_t *h_pos_indices, int32_t n_users, int32_t n_items,
+                             int32_t *h_j_out);
+/* random.shuffle of a length-n list (base/iterativeRecommender.py:101,
+ * base/deepRecommender.py:30).  h_perm (int64[n]) is permuted in place; NULL only
+ * advances the generator. */
+int qrec_mt_shuffle(uint32_t *state625, int64_t n, int64_t *h_perm);
+/* base/deepRecommender.py:41-49 over rows already in shuffled order: one negative per
+ * row, redraw while the item is in trainSet_u[user].  rated CSR rows must be sorted. */
+int qrec_mt_pairwise_sample_epoch(uint32_t *state625, const int32_t *h_row_user, int64_t n_rows,
+                                  const int64_t *h_rated_indptr, const int32_t *h_rated_sorted,
+                                  int32_t n_items, int32_t *h_neg_out);
+
+/* ---- throughput sampler, device side -------------------------------------------------- *
+ * Same distribution as BPR.py:35-37 (uniform over the items that are not positives of
+ * the user, by rejection), counter-based Philox4x32-10 keyed by (seed, epoch, triplet
+ * index): reproducible and order-independent, but NOT the CPython stream.              */
+int qrec_philox_bpr_sample(const int64_t *d_pos_indptr, const int32_t *d_pos_sorted,
+                           const int32_t *d_row_user, int64_t n, int32_t n_items, uint64_t seed,
+                           uint64_t epoch, int32_t *d_j_out, void *stream);
+
+/* ---- BPR SGD: model/ranking/BPR.py:45-53 --------------------------------------------- */
+
+/* Order-exact mode: the n triplets are applied strictly one after another, in array
+ * order, each seeing all earlier writes -- the reference's semantics.  One wavefront
+ * walks the list (the dependency chain of an epoch is ~n/6 long).
+ * *d_loss (double) receives sum(-log(sigmoid(x))) (overwritten).                        */
+int qrec_bpr_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
+                         const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int64_t n,
+                         double lr, double regU, double regI, double *d_loss, void *stream);
+
+/* Throughput mode (fp32): triplets are cut into chunks of `chunk` consecutive entries;
+ * one 16-lane (d<=64) / 32-lane (d<=128) group owns a chunk, keeps P[u] in registers
+ * along a user run, and applies every row update as an atomic add of the exact
+ * per-sample delta, so no update is lost; concurrent chunks read rows that may lag by
+ * the in-flight updates (Hogwild).  With grid_groups==1 the kernel degenerates to the
+ * sequential recurrence.  *d_loss (double) is ACCUMULATED into (zero it first).
+ * `variant` selects the memory policy (QREC_HW_*), 0 = library default.                  */
+#define QREC_HW_DEFAULT 0
+#define QREC_HW_PLAIN_RMW 1     /* plain loads, plain stores (racy read-modify-write)     */
+#define QREC_HW_SC1_RMW 2       /* sc1 loads, sc1 write-through stores                    */
+#define QREC_HW_ATOMIC 3        /* plain loads, f32 atomic-add deltas                     */
+#define QREC_HW_SC1_ATOMIC 4    /* sc1 loads, f32 atomic-add deltas                       */
+int qrec_bpr_sgd_hogwild(float *d_P, float *d_Q, int32_t d, int32_t ld, const int32_t *d_u,
+                         const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
+                         int32_t grid_groups, float lr, float regU, float regI, double *d_loss,
+                         int variant, void *stream);
+
+/* model/rating/BasicMF.py:9-26, order-exact (config #1 parity on device). */
+int qrec_mf_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
+                        const int32_t *d_u, const int32_t *d_i, const double *d_rating, int64_t n,
+                        double lr, double *d_loss, void *stream);
+
+/* sum(x*x) over rows x d of a table (epoch-end regulariser, BPR.py:40); *d_out
+ * (double) is overwritten. */
+int qrec_sumsq(const void *d_x, int dtype, int64_t rows, int32_t d, int32_t ld, double *d_out,
+               void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QREC_HIP_H */

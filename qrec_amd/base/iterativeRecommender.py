@@ -1,0 +1,140 @@
+"""Iterative (SGD) recommenders: conf parsing, fp64 ``P``/``Q`` tables, the bold-driver
+learning-rate schedule, the convergence test and the in-training ranking evaluation of the
+reference's ``IterativeRecommender`` (base/iterativeRecommender.py:7-185)."""
+from __future__ import annotations
+
+import random
+import sys
+from math import isnan
+
+import numpy as np
+
+from .. import capi
+from ..util import config
+from ..util.measure import Measure
+from .recommender import Recommender
+
+
+class IterativeRecommender(Recommender):
+    def __init__(self, conf, trainingSet, testSet, fold="[1]"):
+        super().__init__(conf, trainingSet, testSet, fold)
+        self.bestPerformance = []
+        self.earlyStop = 0
+
+    def readConfiguration(self):
+        super().readConfiguration()
+        self.emb_size = int(self.config["num.factors"])
+        self.maxEpoch = int(self.config["num.max.epoch"])
+        rate = config.OptionConf(self.config["learnRate"])
+        self.lRate, self.maxLRate = float(rate["-init"]), float(rate["-max"])
+        if self.evalSettings.contains("-tf"):
+            self.batch_size = int(self.config["batch_size"])
+        reg = config.OptionConf(self.config["reg.lambda"])
+        self.regU, self.regI, self.regB = float(reg["-u"]), float(reg["-i"]), float(reg["-b"])
+
+    def printAlgorConfig(self):
+        super().printAlgorConfig()
+        print("Embedding Dimension:", self.emb_size)
+        print("Maximum Epoch:", self.maxEpoch)
+        print("Regularization parameter: regU %.3f, regI %.3f, regB %.3f" % (self.regU, self.regI, self.regB))
+        print("=" * 80)
+
+    def initModel(self):
+        # global numpy RNG, uniform[0,1)/3, float64 (base/iterativeRecommender.py:37-38)
+        self.P = np.random.rand(len(self.data.user), self.emb_size) / 3
+        self.Q = np.random.rand(len(self.data.item), self.emb_size) / 3
+        self.loss, self.lastLoss = 0, 0
+
+    def updateLearningRate(self, epoch):
+        if epoch > 1:
+            self.lRate *= 1.05 if abs(self.lastLoss) > abs(self.loss) else 0.5
+        if self.lRate > self.maxLRate > 0:
+            self.lRate = self.maxLRate
+
+    def predictForRating(self, u, i):
+        has_u, has_i = self.data.containsUser(u), self.data.containsItem(i)
+        if has_u and has_i:
+            return self.P[self.data.user[u]].dot(self.Q[self.data.item[i]])
+        if has_u:
+            return self.data.userMeans[u]
+        if has_i:
+            return self.data.itemMeans[i]
+        return self.data.globalMean
+
+    def predictForRanking(self, u):
+        if self.data.containsUser(u):
+            return self.Q.dot(self.P[self.data.user[u]])
+        return [self.data.globalMean] * self.num_items
+
+    def shuffle_training_data(self):
+        """``shuffle(self.data.trainingData)`` (base/iterativeRecommender.py:101) with the
+        exact CPython draw sequence, done natively: a 1.2 M-row list takes ~1 s in
+        ``random.shuffle`` and ~10 ms here.  The Python generator state is advanced in
+        lock-step so later ``random`` calls agree with the reference."""
+        n = len(self.data.trainingData)
+        state = random.getstate()
+        words = capi.state_from_python(state)
+        perm = np.arange(n, dtype=np.int64)
+        capi.mt_shuffle(words, n, perm)
+        random.setstate(capi.state_to_python(words, state[2]))
+        rows = self.data.trainingData
+        self.data.trainingData = [rows[k] for k in perm]
+        return perm
+
+    def isConverged(self, epoch):
+        if isnan(self.loss):
+            print("Loss = NaN or Infinity: current settings does not fit the recommender! Change the settings and try again!")
+            sys.exit(-1)
+        deltaLoss = self.lastLoss - self.loss
+        if self.ranking.isMainOn():
+            print("%s %s epoch %d: loss = %.4f, delta_loss = %.5f learning_Rate = %.5f"
+                  % (self.modelName, self.foldInfo, epoch, self.loss, deltaLoss, self.lRate))
+        else:
+            measure = self.rating_performance()
+            print("%s %s epoch %d: loss = %.4f, delta_loss = %.5f learning_Rate = %.5f %5s %5s"
+                  % (self.modelName, self.foldInfo, epoch, self.loss, deltaLoss, self.lRate,
+                     measure[0].strip()[:11], measure[1].strip()[:12]))
+        converged = abs(deltaLoss) < 1e-3
+        if not converged:
+            self.updateLearningRate(epoch)
+        self.lastLoss = self.loss
+        self.shuffle_training_data()
+        return converged
+
+    def rating_performance(self):
+        res = [[user, item, rating, self.checkRatingBoundary(self.predictForRating(user, item))]
+               for user, item, rating in self.data.testData]
+        self.measure = Measure.ratingMeasure(res)
+        return self.measure
+
+    def ranking_performance(self, epoch):
+        """Evaluation during training (base/iterativeRecommender.py:115-185): top-max(N)
+        only, remembers the best epoch and snapshots the model through saveModel()."""
+        N = max(int(x) for x in self.ranking["-topN"].split(","))
+        print("Evaluating...")
+        recList = self.rank_all_test_users(N)
+        measure = Measure.rankingMeasure(self.data.testSet_u, recList, [N])
+        performance = {}
+        for m in measure[1:]:
+            k, v = m.strip().split(":")
+            performance[k] = float(v)
+        if self.bestPerformance:
+            worse = sum(1 if self.bestPerformance[1][k] > performance[k] else -1 for k in self.bestPerformance[1])
+            if worse < 0:
+                self.bestPerformance = [epoch + 1, performance]
+                self.saveModel()
+        else:
+            self.bestPerformance = [epoch + 1, performance]
+            self.saveModel()
+        print("-" * 120)
+        print("Quick Ranking Performance " + self.foldInfo + " (Top-" + str(N) + "Item Recommendation)")
+        measure = [m.strip() for m in measure[1:]]
+        print("*Current Performance*")
+        print("Epoch:", str(epoch + 1) + ",", " | ".join(measure))
+        best = self.bestPerformance[1]
+        print("*Best Performance* ")
+        print("Epoch:", str(self.bestPerformance[0]) + ",",
+              "Precision:" + str(best["Precision"]) + " | Recall:" + str(best["Recall"]) +
+              " | F1:" + str(best["F1"]) + " | MDCG:" + str(best["NDCG"]))
+        print("-" * 120)
+        return measure

@@ -1,0 +1,320 @@
+"""ctypes binding of libqrec_hip.so (include/qrec_hip.h) -- the only door to the device.
+
+There is deliberately NO CPU fallback: if the shared library is missing or a call fails,
+this module raises.  numpy arrays cross the boundary as borrowed host pointers; device
+memory is an opaque ``DeviceBuffer`` (or any raw device pointer, e.g. ``tensor.data_ptr()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqrec_hip.so")
+
+F32, F64 = 0, 1
+HW_DEFAULT, HW_PLAIN_RMW, HW_SC1_RMW, HW_ATOMIC, HW_SC1_ATOMIC = 0, 1, 2, 3, 4
+
+_vp, _i32, _i64, _u64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
+
+# name -> argtypes; every function returns int (0 = ok) unless listed in _RESTYPES
+_SIGNATURES = {
+    "qrec_version": [],
+    "qrec_last_error": [],
+    "qrec_device_count": [_vp],
+    "qrec_init": [C.c_int],
+    "qrec_device_info": [_vp, C.c_int, _vp, _vp, _vp, C.c_int],
+    "qrec_malloc": [_i64, _vp],
+    "qrec_free": [_vp],
+    "qrec_memcpy_h2d": [_vp, _vp, _i64, _vp],
+    "qrec_memcpy_d2h": [_vp, _vp, _i64, _vp],
+    "qrec_memcpy_d2d": [_vp, _vp, _i64, _vp],
+    "qrec_memset": [_vp, C.c_int, _i64, _vp],
+    "qrec_stream_create": [_vp],
+    "qrec_stream_destroy": [_vp],
+    "qrec_stream_sync": [_vp],
+    "qrec_device_sync": [],
+    "qrec_event_create": [_vp],
+    "qrec_event_destroy": [_vp],
+    "qrec_event_record": [_vp, _vp],
+    "qrec_event_sync": [_vp],
+    "qrec_event_elapsed_ms": [_vp, _vp, _vp],
+    "qrec_mt_bpr_sample_epoch": [_vp, _vp, _vp, _i32, _i32, _vp],
+    "qrec_mt_shuffle": [_vp, _i64, _vp],
+    "qrec_mt_pairwise_sample_epoch": [_vp, _vp, _i64, _vp, _vp, _i32, _vp],
+    "qrec_philox_bpr_sample": [_vp, _vp, _vp, _i64, _i32, _u64, _u64, _vp, _vp],
+    "qrec_bpr_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _vp, _vp],
+    "qrec_bpr_sgd_hogwild": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _vp, C.c_int, _vp],
+    "qrec_mf_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _vp, _vp],
+    "qrec_sumsq": [_vp, C.c_int, _i64, _i32, _i32, _vp, _vp],
+}
+_RESTYPES = {"qrec_last_error": C.c_char_p}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class QRecError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libqrec_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """dlopen libqrec_hip.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C qrec_amd/csrc).  There is no CPU fallback for the hot path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, args in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, C.c_int)
+        _lib = lib
+    return _lib
+
+
+def _check(code: int):
+    if code != 0:
+        raise QRecError(code, load().qrec_last_error().decode(errors="replace"))
+
+
+def _hp(a: np.ndarray):
+    """borrowed host pointer of a C-contiguous numpy array"""
+    if not (isinstance(a, np.ndarray) and a.flags.c_contiguous):
+        raise TypeError("need a C-contiguous numpy array")
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _req(a, dtype, name):
+    if not (isinstance(a, np.ndarray) and a.dtype == np.dtype(dtype) and a.flags.c_contiguous):
+        raise TypeError(f"{name}: need C-contiguous {np.dtype(dtype)}, got "
+                        f"{getattr(a, 'dtype', type(a))}")
+    return a
+
+
+# ---- runtime ------------------------------------------------------------------------------
+_initialised = False
+
+
+def init(device: int | None = None):
+    """Select the device (env QREC_DEVICE, default 0).  Never called at import or from a
+    model constructor: QRec forks per CV fold after constructing models (QRec.py:76-89)."""
+    global _initialised
+    if device is None:
+        device = int(os.environ.get("QREC_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    _check(load().qrec_init(device))
+    _initialised = True
+
+
+def ensure_init():
+    if not _initialised:
+        init()
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _check(load().qrec_device_count(C.byref(n)))
+    return n.value
+
+
+def device_info() -> dict:
+    name = C.create_string_buffer(256); arch = C.create_string_buffer(64)
+    ncu = C.c_int(0); hbm = C.c_int64(0)
+    _check(load().qrec_device_info(name, 256, C.byref(ncu), C.byref(hbm), arch, 64))
+    return dict(name=name.value.decode(), arch=arch.value.decode(), n_cu=ncu.value, hbm_bytes=hbm.value)
+
+
+def device_sync():
+    _check(load().qrec_device_sync())
+
+
+class Stream:
+    def __init__(self):
+        ensure_init()
+        h = C.c_void_p()
+        _check(load().qrec_stream_create(C.byref(h)))
+        self.handle = h.value
+
+    def sync(self):
+        _check(load().qrec_stream_sync(self.handle))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                load().qrec_stream_destroy(self.handle); self.handle = None
+        except Exception:
+            pass
+
+
+def _sh(stream):
+    if stream is None:
+        return None
+    return stream.handle if isinstance(stream, Stream) else int(stream)
+
+
+class Event:
+    def __init__(self):
+        ensure_init()
+        h = C.c_void_p()
+        _check(load().qrec_event_create(C.byref(h)))
+        self.handle = h.value
+
+    def record(self, stream=None):
+        _check(load().qrec_event_record(self.handle, _sh(stream)))
+
+    def sync(self):
+        _check(load().qrec_event_sync(self.handle))
+
+    def elapsed_ms_since(self, start: "Event") -> float:
+        ms = C.c_float(0)
+        _check(load().qrec_event_elapsed_ms(start.handle, self.handle, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                load().qrec_event_destroy(self.handle); self.handle = None
+        except Exception:
+            pass
+
+
+class DeviceBuffer:
+    """Owning handle on device memory with a numpy-like shape/dtype tag."""
+
+    def __init__(self, shape, dtype):
+        ensure_init()
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        _check(load().qrec_malloc(self.nbytes, C.byref(p)))
+        self.ptr = p.value or 0
+
+    @classmethod
+    def from_numpy(cls, a: np.ndarray, stream=None) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a)
+        b = cls(a.shape, a.dtype)
+        b.upload(a, stream)
+        return b
+
+    @classmethod
+    def zeros(cls, shape, dtype, stream=None) -> "DeviceBuffer":
+        b = cls(shape, dtype)
+        b.fill_bytes(0, stream)
+        return b
+
+    def upload(self, a: np.ndarray, stream=None):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if a.nbytes != self.nbytes:
+            raise ValueError(f"upload size mismatch: {a.nbytes} vs {self.nbytes}")
+        _check(load().qrec_memcpy_h2d(self.ptr, _hp(a), self.nbytes, _sh(stream)))
+
+    def numpy(self, stream=None) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        _check(load().qrec_memcpy_d2h(_hp(out), self.ptr, self.nbytes, _sh(stream)))
+        return out
+
+    def copy_from(self, other: "DeviceBuffer", stream=None):
+        if other.nbytes != self.nbytes:
+            raise ValueError("copy_from size mismatch")
+        _check(load().qrec_memcpy_d2d(self.ptr, other.ptr, self.nbytes, _sh(stream)))
+
+    def fill_bytes(self, byte: int = 0, stream=None):
+        _check(load().qrec_memset(self.ptr, byte, self.nbytes, _sh(stream)))
+
+    def free(self):
+        if getattr(self, "ptr", 0):
+            load().qrec_free(self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _dp(x):
+    """device pointer of a DeviceBuffer / int / object with data_ptr() (torch tensor)"""
+    if x is None:
+        return None
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    return int(x)
+
+
+# ---- exact sampler (host) ---------------------------------------------------------------------
+def state_from_python(state) -> np.ndarray:
+    """random.getstate() -> uint32[625]"""
+    return np.array(state[1], dtype=np.uint32)
+
+
+def state_to_python(words: np.ndarray, gauss_next=None):
+    return (3, tuple(int(x) for x in words), gauss_next)
+
+
+def mt_bpr_sample_epoch(state625: np.ndarray, pos_indptr, pos_indices, n_items: int) -> np.ndarray:
+    _req(state625, np.uint32, "state625"); _req(pos_indptr, np.int64, "pos_indptr")
+    _req(pos_indices, np.int32, "pos_indices")
+    j = np.empty(pos_indices.size, dtype=np.int32)
+    _check(load().qrec_mt_bpr_sample_epoch(_hp(state625), _hp(pos_indptr), _hp(pos_indices),
+                                           pos_indptr.size - 1, n_items, _hp(j)))
+    return j
+
+
+def mt_shuffle(state625: np.ndarray, n: int, perm: np.ndarray | None = None):
+    _req(state625, np.uint32, "state625")
+    if perm is not None:
+        _req(perm, np.int64, "perm")
+        if perm.size != n:
+            raise ValueError("perm size mismatch")
+    _check(load().qrec_mt_shuffle(_hp(state625), n, _hp(perm) if perm is not None else None))
+    return perm
+
+
+def mt_pairwise_sample_epoch(state625, row_user, rated_indptr, rated_sorted, n_items: int) -> np.ndarray:
+    _req(state625, np.uint32, "state625"); _req(row_user, np.int32, "row_user")
+    _req(rated_indptr, np.int64, "rated_indptr"); _req(rated_sorted, np.int32, "rated_sorted")
+    neg = np.empty(row_user.size, dtype=np.int32)
+    _check(load().qrec_mt_pairwise_sample_epoch(_hp(state625), _hp(row_user), row_user.size,
+                                                _hp(rated_indptr), _hp(rated_sorted), n_items, _hp(neg)))
+    return neg
+
+
+# ---- device ops ---------------------------------------------------------------------------------
+def philox_bpr_sample(d_indptr, d_sorted, d_row_user, n: int, n_items: int, seed: int, epoch: int,
+                      d_j_out, stream=None):
+    _check(load().qrec_philox_bpr_sample(_dp(d_indptr), _dp(d_sorted), _dp(d_row_user), n, n_items,
+                                         seed & (2**64 - 1), epoch & (2**64 - 1), _dp(d_j_out), _sh(stream)))
+
+
+def bpr_sgd_ordered(d_P, d_Q, dtype: int, d: int, ld: int, d_u, d_i, d_j, n: int, lr: float,
+                    regU: float, regI: float, d_loss, stream=None):
+    _check(load().qrec_bpr_sgd_ordered(_dp(d_P), _dp(d_Q), dtype, d, ld, _dp(d_u), _dp(d_i), _dp(d_j),
+                                       n, lr, regU, regI, _dp(d_loss), _sh(stream)))
+
+
+def bpr_sgd_hogwild(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int, chunk: int, grid_groups: int,
+                    lr: float, regU: float, regI: float, d_loss, variant: int = HW_DEFAULT, stream=None):
+    _check(load().qrec_bpr_sgd_hogwild(_dp(d_P), _dp(d_Q), d, ld, _dp(d_u), _dp(d_i), _dp(d_j), n,
+                                       chunk, grid_groups, lr, regU, regI, _dp(d_loss), variant, _sh(stream)))
+
+
+def mf_sgd_ordered(d_P, d_Q, dtype: int, d: int, ld: int, d_u, d_i, d_rating, n: int, lr: float,
+                   d_loss, stream=None):
+    _check(load().qrec_mf_sgd_ordered(_dp(d_P), _dp(d_Q), dtype, d, ld, _dp(d_u), _dp(d_i), _dp(d_rating),
+                                      n, lr, _dp(d_loss), _sh(stream)))
+
+
+def sumsq(d_x, dtype: int, rows: int, d: int, ld: int, d_out, stream=None):
+    _check(load().qrec_sumsq(_dp(d_x), dtype, rows, d, ld, _dp(d_out), _sh(stream)))

@@ -1,0 +1,388 @@
+// BPR SGD on embedding rows: model/ranking/BPR.py:45-53 (+ sigmoid util/qmath.py:127-128).
+//
+//   x = P[u].Q[i] - P[u].Q[j];  s = 1/(1+exp(-x));  g = lr*(1-s)
+//   P[u] += g*(Q[i]-Q[j]);  Q[i] += g*P[u];  Q[j] -= g*P[u]      (P[u] already updated)
+//   P[u] -= lr*regU*P[u];   Q[i] -= lr*regI*Q[i];   Q[j] -= lr*regI*Q[j];   loss += -log(s)
+//
+// Two kernels:
+//  * bpr_ordered_kernel  -- the reference's semantics: triplets applied strictly in array
+//    order.  The conflict DAG of an epoch is ~n/6 deep (every user run is a chain through
+//    P[u], popular items link the runs), so the order-exact mode has no exploitable
+//    parallelism beyond the d lanes of one row; ONE wavefront walks the list, with the
+//    next triplet's rows prefetched and patched from registers when they alias.  This is
+//    the parity mode (fp64 or fp32).
+//  * bpr_hogwild_kernel  -- throughput mode.  HBM/L2-latency bound gather + scatter:
+//    a group of LPR lanes (16 for d<=64: lane r holds columns r, r+16, r+32, r+48 of one
+//    256-B row, 4 rows per wavefront) owns a chunk of consecutive triplets, keeps P[u] in
+//    registers along the user run, and applies every row update as the exact per-sample
+//    delta (atomic f32 add, so concurrent chunks never lose an update).  Index tiles are
+//    staged through LDS per wavefront; dot products reduce inside the LPR-lane row.
+//    Algorithmic bytes per triplet: 6*d*4 + 12.
+#include <cmath>
+
+#include "common.h"
+
+using namespace qrec;
+
+namespace {
+
+// ------------------------------------------------------------------------------------
+// order-exact kernel
+// ------------------------------------------------------------------------------------
+template <typename T> __device__ inline T dev_exp(T x);
+template <> __device__ inline float dev_exp<float>(float x) { return expf(x); }
+template <> __device__ inline double dev_exp<double>(double x) { return exp(x); }
+
+template <typename T>
+__device__ inline T wave_allreduce_sum(T v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+
+// EPL = elements per lane; lane l owns columns l, l+64, ...  (d <= 64*EPL)
+template <typename T, int EPL>
+__global__ __launch_bounds__(64) void bpr_ordered_kernel(
+    T *__restrict__ P, T *__restrict__ Q, int d, int ld, const int32_t *__restrict__ u_idx,
+    const int32_t *__restrict__ i_idx, const int32_t *__restrict__ j_idx, int64_t n, T lr, T cu,
+    T ci, double *__restrict__ loss_out) {
+#pragma clang fp contract(off)  // numpy rounds every product and sum separately
+    const int lane = threadIdx.x;
+    bool valid[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) valid[e] = (lane + 64 * e) < d;
+
+    auto load_row = [&](const T *tab, int row, T (&dst)[EPL]) {
+        const T *p = tab + (int64_t)row * ld + lane;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) dst[e] = valid[e] ? p[64 * e] : T(0);
+    };
+    auto store_row = [&](T *tab, int row, const T (&src)[EPL]) {
+        T *p = tab + (int64_t)row * ld + lane;
+#pragma unroll
+        for (int e = 0; e < EPL; e++)
+            if (valid[e]) p[64 * e] = src[e];
+    };
+
+    T pu[EPL], qi[EPL], qj[EPL], nqi[EPL], nqj[EPL];
+    double loss = 0.0;
+    int cur_u = -1;
+    if (n > 0) { load_row(Q, i_idx[0], qi); load_row(Q, j_idx[0], qj); }
+    for (int64_t t = 0; t < n; t++) {
+        const int ut = u_idx[t], it = i_idx[t], jt = j_idx[t];
+        if (ut != cur_u) {
+            if (cur_u >= 0) store_row(P, cur_u, pu);
+            load_row(P, ut, pu);
+            cur_u = ut;
+        }
+        int in = -1, jn = -1;
+        if (t + 1 < n) {  // prefetch the next triplet's item rows under this one's math
+            in = i_idx[t + 1]; jn = j_idx[t + 1];
+            load_row(Q, in, nqi); load_row(Q, jn, nqj);
+        }
+        T di = 0, dj = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) { di += pu[e] * qi[e]; dj += pu[e] * qj[e]; }
+        di = wave_allreduce_sum(di); dj = wave_allreduce_sum(dj);
+        const T s = T(1) / (T(1) + dev_exp<T>(-(di - dj)));
+        const T g = lr * (T(1) - s);
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            pu[e] += g * (qi[e] - qj[e]);
+            qi[e] += g * pu[e];
+            qj[e] -= g * pu[e];
+            pu[e] -= cu * pu[e];
+            qi[e] -= ci * qi[e];
+            qj[e] -= ci * qj[e];
+        }
+        store_row(Q, it, qi); store_row(Q, jt, qj);
+        loss += -log((double)s);
+        if (t + 1 < n) {  // rows just written supersede what the prefetch saw
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                T a = nqi[e], b = nqj[e];
+                if (in == it) a = qi[e]; else if (in == jt) a = qj[e];
+                if (jn == it) b = qi[e]; else if (jn == jt) b = qj[e];
+                qi[e] = a; qj[e] = b;
+            }
+        }
+    }
+    if (cur_u >= 0) store_row(P, cur_u, pu);
+    if (lane == 0) *loss_out = loss;
+}
+
+// model/rating/BasicMF.py:9-26, order-exact, same structure.
+template <typename T, int EPL>
+__global__ __launch_bounds__(64) void mf_ordered_kernel(
+    T *__restrict__ P, T *__restrict__ Q, int d, int ld, const int32_t *__restrict__ u_idx,
+    const int32_t *__restrict__ i_idx, const double *__restrict__ rating, int64_t n, T lr,
+    double *__restrict__ loss_out) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x;
+    double loss = 0.0;
+    for (int64_t t = 0; t < n; t++) {
+        T *p = P + (int64_t)u_idx[t] * ld + lane;
+        T *q = Q + (int64_t)i_idx[t] * ld + lane;
+        T pv[EPL], qv[EPL], dot = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const bool ok = (lane + 64 * e) < d;
+            pv[e] = ok ? p[64 * e] : T(0);
+            qv[e] = ok ? q[64 * e] : T(0);
+            dot += pv[e] * qv[e];
+        }
+        dot = wave_allreduce_sum(dot);
+        const T err = (T)rating[t] - dot;
+        loss += (double)err * (double)err;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            pv[e] += (lr * err) * qv[e];   // P[u] += lr*error*q          (:22)
+            qv[e] += (lr * err) * pv[e];   // Q[i] += lr*error*p, p is a view of the NEW P[u] (:23)
+            if ((lane + 64 * e) < d) { p[64 * e] = pv[e]; q[64 * e] = qv[e]; }
+        }
+    }
+    if (lane == 0) *loss_out = loss;
+}
+
+// ------------------------------------------------------------------------------------
+// throughput kernel
+// ------------------------------------------------------------------------------------
+// Register layout: a group of LPR lanes owns one row of ld = LPR*E floats; lane r holds
+// columns r, r+LPR, ..., r+(E-1)*LPR.  Every load / atomic instruction therefore touches
+// one CONTIGUOUS 4*LPR-byte segment per group (64 B for d=64).  Measured on MI355X
+// (tools/ubench/atomics.hip): the L2 atomic units retire ~1 dword/clk/channel when a
+// request covers a contiguous 64-B segment, 4x less when the same dwords are strided by
+// 16 B (the float4-per-lane layout) -- atomic cost is per request, not per byte.
+constexpr int kMaxChunk = 64;
+
+enum : int { LD_PLAIN = 0, LD_SC1 = 1 };
+enum : int { UP_STORE = 0, UP_STORE_SC1 = 1, UP_ATOMIC = 2 };
+
+template <int E> struct Row { float v[E]; };
+
+template <int LPR, int E, int LOADP>
+__device__ inline Row<E> hw_load_row(__amdgpu_buffer_rsrc_t rs, int row, int r) {
+    constexpr int aux = (LOADP == LD_SC1) ? kAuxSc1 : kAuxPlain;
+    const uint32_t off = ((uint32_t)row * (uint32_t)(LPR * E) + (uint32_t)r) * 4u;
+    Row<E> out;
+#pragma unroll
+    for (int e = 0; e < E; e++)
+        out.v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(off + 4u * LPR * e), 0, aux));
+    return out;
+}
+
+template <int LPR, int E, int UPD>
+__device__ inline void hw_update_row(__amdgpu_buffer_rsrc_t rs, int row, int r, const Row<E> &oldv,
+                                     const Row<E> &newv) {
+    const uint32_t off = ((uint32_t)row * (uint32_t)(LPR * E) + (uint32_t)r) * 4u;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        if constexpr (UPD == UP_ATOMIC) {
+            // exact per-sample delta (new-old is exact when |delta| << |value|)
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(newv.v[e] - oldv.v[e], rs, (int)(off + 4u * LPR * e), 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, newv.v[e]), rs, (int)(off + 4u * LPR * e), 0,
+                                                  UPD == UP_STORE_SC1 ? kAuxSc1 : kAuxPlain);
+        }
+    }
+}
+
+template <int LPR, int E, int LOADP, int UPD>
+__global__ __launch_bounds__(256) void bpr_hogwild_kernel(
+    float *__restrict__ P, float *__restrict__ Q, uint32_t p_bytes, uint32_t q_bytes,
+    const int32_t *__restrict__ u_idx, const int32_t *__restrict__ i_idx,
+    const int32_t *__restrict__ j_idx, int64_t n, int chunk, int64_t n_chunks,
+    int64_t groups_active, float lr, float cu, float ci, double *__restrict__ loss_out) {
+    constexpr int GPW = kWave / LPR;  // groups (rows) per wavefront
+    __shared__ int32_t s_idx[4][GPW][3][kMaxChunk];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane / LPR, r = lane % LPR;
+    const int64_t gid = ((int64_t)blockIdx.x * 4 + wave) * GPW + g;
+    int32_t *su = s_idx[wave][g][0], *si = s_idx[wave][g][1], *sj = s_idx[wave][g][2];
+
+    const __amdgpu_buffer_rsrc_t rsP = make_rsrc(P, p_bytes), rsQ = make_rsrc(Q, q_bytes);
+    float loss = 0.f;
+    double loss_acc = 0.0;
+
+    for (int64_t c = gid; c < n_chunks && gid < groups_active; c += groups_active) {
+        const int64_t t0 = c * chunk;
+        const int len = (int)((n - t0) < chunk ? (n - t0) : chunk);
+        // stage this group's (u,i,j) tile in LDS: coalesced 4*LPR-byte segments
+        for (int k = r; k < len; k += LPR) {
+            su[k] = u_idx[t0 + k]; si[k] = i_idx[t0 + k]; sj[k] = j_idx[t0 + k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        int cur_u = -1, it = si[0], jt = sj[0];
+        Row<E> pu, pu0;
+#pragma unroll
+        for (int e = 0; e < E; e++) pu.v[e] = pu0.v[e] = 0.f;
+        Row<E> qi = hw_load_row<LPR, E, LOADP>(rsQ, it, r);
+        Row<E> qj = hw_load_row<LPR, E, LOADP>(rsQ, jt, r);
+        for (int k = 0; k < len; k++) {
+            const int ut = su[k];
+            if (ut != cur_u) {
+                if (cur_u >= 0) hw_update_row<LPR, E, UPD>(rsP, cur_u, r, pu0, pu);
+                pu = hw_load_row<LPR, E, LOADP>(rsP, ut, r);
+                pu0 = pu; cur_u = ut;
+            }
+            int in = it, jn = jt;
+            Row<E> nqi = qi, nqj = qj;
+            const bool more = (k + 1 < len);
+            if (more) {  // next triplet's rows are in flight under this one's math
+                in = si[k + 1]; jn = sj[k + 1];
+                nqi = hw_load_row<LPR, E, LOADP>(rsQ, in, r);
+                nqj = hw_load_row<LPR, E, LOADP>(rsQ, jn, r);
+            }
+            float di = 0.f, dj = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; e++) { di += pu.v[e] * qi.v[e]; dj += pu.v[e] * qj.v[e]; }
+            di = row_allreduce_sum<LPR>(di); dj = row_allreduce_sum<LPR>(dj);
+            const float s = 1.0f / (1.0f + expf(-(di - dj)));
+            const float gsc = lr * (1.0f - s);
+            Row<E> qin, qjn;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const float pun = pu.v[e] + gsc * (qi.v[e] - qj.v[e]);
+                float a = qi.v[e] + gsc * pun, b = qj.v[e] - gsc * pun;
+                qin.v[e] = a - ci * a; qjn.v[e] = b - ci * b;
+                pu.v[e] = pun - cu * pun;
+            }
+            hw_update_row<LPR, E, UPD>(rsQ, it, r, qi, qin);
+            hw_update_row<LPR, E, UPD>(rsQ, jt, r, qj, qjn);
+            loss += -logf(s);
+            if (more) {  // rows this group just changed supersede the prefetched copy
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    if (in == it) nqi.v[e] = qin.v[e]; else if (in == jt) nqi.v[e] = qjn.v[e];
+                    if (jn == it) nqj.v[e] = qin.v[e]; else if (jn == jt) nqj.v[e] = qjn.v[e];
+                }
+            }
+            qi = nqi; qj = nqj; it = in; jt = jn;
+        }
+        if (cur_u >= 0) hw_update_row<LPR, E, UPD>(rsP, cur_u, r, pu0, pu);
+        loss_acc += (double)loss; loss = 0.f;  // <=64 fp32 terms per chunk, fp64 across chunks
+        __builtin_amdgcn_wave_barrier();       // tile is re-staged by the next chunk
+    }
+    if (r != 0) loss_acc = 0.0;  // every lane of a group carries the same value
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) loss_acc += __shfl_xor(loss_acc, m, kWave);
+    if (lane == 0 && loss_acc != 0.0) atomicAdd(loss_out, loss_acc);  // one f64 atomic per wavefront
+}
+
+template <int LPR, int E>
+int launch_hogwild(float *P, float *Q, uint32_t pb, uint32_t qb, const int32_t *u,
+                   const int32_t *i, const int32_t *j, int64_t n, int chunk, int64_t groups,
+                   float lr, float cu, float ci, double *loss, int variant, hipStream_t st) {
+    constexpr int GPW = kWave / LPR;
+    const int64_t n_chunks = (n + chunk - 1) / chunk;
+    if (groups <= 0 || groups > n_chunks) groups = n_chunks;
+    const int64_t max_groups = (int64_t)256 * 8 * 4 * GPW;  // 8 blocks of 4 waves per CU
+    if (groups > max_groups) groups = max_groups;
+    const unsigned blocks = (unsigned)((groups + 4 * GPW - 1) / (4 * GPW));
+#define QREC_HW_LAUNCH(LOADP, UPD)                                                              \
+    hipLaunchKernelGGL((bpr_hogwild_kernel<LPR, E, LOADP, UPD>), dim3(blocks), dim3(256), 0, st, \
+                       P, Q, pb, qb, u, i, j, n, chunk, n_chunks, groups, lr, cu, ci, loss)
+    switch (variant) {
+        case QREC_HW_PLAIN_RMW: QREC_HW_LAUNCH(LD_PLAIN, UP_STORE); break;
+        case QREC_HW_SC1_RMW: QREC_HW_LAUNCH(LD_SC1, UP_STORE_SC1); break;
+        case QREC_HW_DEFAULT:
+        case QREC_HW_ATOMIC: QREC_HW_LAUNCH(LD_PLAIN, UP_ATOMIC); break;
+        case QREC_HW_SC1_ATOMIC: QREC_HW_LAUNCH(LD_SC1, UP_ATOMIC); break;
+        default: set_error("qrec_bpr_sgd_hogwild: unknown variant %d", variant); return QREC_ERR_INVALID;
+    }
+#undef QREC_HW_LAUNCH
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+template <typename T>
+int launch_ordered(void *P, void *Q, int d, int ld, const int32_t *u, const int32_t *i,
+                   const int32_t *j, int64_t n, double lr, double regU, double regI, double *loss,
+                   hipStream_t st) {
+    const T tlr = (T)lr, cu = (T)lr * (T)regU, ci = (T)lr * (T)regI;  // numpy: (lr*reg)*row
+#define QREC_ORD_LAUNCH(EPL)                                                                   \
+    hipLaunchKernelGGL((bpr_ordered_kernel<T, EPL>), dim3(1), dim3(64), 0, st, (T *)P, (T *)Q, d, \
+                       ld, u, i, j, n, tlr, cu, ci, loss)
+    if (d <= 64) QREC_ORD_LAUNCH(1);
+    else if (d <= 128) QREC_ORD_LAUNCH(2);
+    else QREC_ORD_LAUNCH(4);
+#undef QREC_ORD_LAUNCH
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+template <typename T>
+int launch_mf_ordered(void *P, void *Q, int d, int ld, const int32_t *u, const int32_t *i,
+                      const double *r, int64_t n, double lr, double *loss, hipStream_t st) {
+#define QREC_MF_LAUNCH(EPL)                                                                   \
+    hipLaunchKernelGGL((mf_ordered_kernel<T, EPL>), dim3(1), dim3(64), 0, st, (T *)P, (T *)Q, d, \
+                       ld, u, i, r, n, (T)lr, loss)
+    if (d <= 64) QREC_MF_LAUNCH(1);
+    else if (d <= 128) QREC_MF_LAUNCH(2);
+    else QREC_MF_LAUNCH(4);
+#undef QREC_MF_LAUNCH
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qrec_bpr_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
+                         const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int64_t n,
+                         double lr, double regU, double regI, double *d_loss, void *stream) {
+    QREC_REQUIRE(d_P && d_Q && d_loss && n >= 0, "qrec_bpr_sgd_ordered: null argument");
+    QREC_REQUIRE(n == 0 || (d_u && d_i && d_j), "qrec_bpr_sgd_ordered: null index array");
+    QREC_REQUIRE(d >= 1 && d <= 256 && ld >= d, "qrec_bpr_sgd_ordered: need 1 <= d <= 256, ld >= d (got d=%d ld=%d)", d, ld);
+    QREC_REQUIRE(dtype == QREC_F32 || dtype == QREC_F64, "qrec_bpr_sgd_ordered: bad dtype %d", dtype);
+    hipStream_t st = as_stream(stream);
+    if (n == 0) { QREC_HIP_CHECK(hipMemsetAsync(d_loss, 0, sizeof(double), st)); return QREC_OK; }
+    return dtype == QREC_F64
+               ? launch_ordered<double>(d_P, d_Q, d, ld, d_u, d_i, d_j, n, lr, regU, regI, d_loss, st)
+               : launch_ordered<float>(d_P, d_Q, d, ld, d_u, d_i, d_j, n, lr, regU, regI, d_loss, st);
+}
+
+int qrec_mf_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
+                        const int32_t *d_u, const int32_t *d_i, const double *d_rating, int64_t n,
+                        double lr, double *d_loss, void *stream) {
+    QREC_REQUIRE(d_P && d_Q && d_loss && n >= 0, "qrec_mf_sgd_ordered: null argument");
+    QREC_REQUIRE(n == 0 || (d_u && d_i && d_rating), "qrec_mf_sgd_ordered: null index array");
+    QREC_REQUIRE(d >= 1 && d <= 256 && ld >= d, "qrec_mf_sgd_ordered: need 1 <= d <= 256, ld >= d");
+    QREC_REQUIRE(dtype == QREC_F32 || dtype == QREC_F64, "qrec_mf_sgd_ordered: bad dtype %d", dtype);
+    hipStream_t st = as_stream(stream);
+    if (n == 0) { QREC_HIP_CHECK(hipMemsetAsync(d_loss, 0, sizeof(double), st)); return QREC_OK; }
+    return dtype == QREC_F64 ? launch_mf_ordered<double>(d_P, d_Q, d, ld, d_u, d_i, d_rating, n, lr, d_loss, st)
+                             : launch_mf_ordered<float>(d_P, d_Q, d, ld, d_u, d_i, d_rating, n, lr, d_loss, st);
+}
+
+int qrec_bpr_sgd_hogwild(float *d_P, float *d_Q, int32_t d, int32_t ld, const int32_t *d_u,
+                         const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
+                         int32_t grid_groups, float lr, float regU, float regI, double *d_loss,
+                         int variant, void *stream) {
+    QREC_REQUIRE(d_P && d_Q && d_loss && n >= 0, "qrec_bpr_sgd_hogwild: null argument");
+    QREC_REQUIRE(n == 0 || (d_u && d_i && d_j), "qrec_bpr_sgd_hogwild: null index array");
+    QREC_REQUIRE(ld >= d && d >= 1, "qrec_bpr_sgd_hogwild: need ld >= d >= 1");
+    QREC_REQUIRE(ld == 32 || ld == 64 || ld == 128 || ld == 256,
+                 "qrec_bpr_sgd_hogwild: row stride must be 32, 64, 128 or 256 floats (pad d=%d up; got ld=%d)", d, ld);
+    QREC_REQUIRE(chunk >= 1 && chunk <= kMaxChunk, "qrec_bpr_sgd_hogwild: chunk must be in 1..%d", kMaxChunk);
+    if (n == 0) return QREC_OK;
+    // Buffer descriptors address 32 bits: callers with bigger tables shard them (one
+    // shard per GPU is far below this) -- rows are only bounds-checked, never wrapped.
+    // The row count is not known here; the caller guarantees ids < rows; we bound by 4 GiB.
+    const uint32_t full = 0xffffffffu;
+    hipStream_t st = as_stream(stream);
+    const float cu = lr * regU, ci = lr * regI;
+    switch (ld) {
+        case 32: return launch_hogwild<16, 2>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, lr, cu, ci, d_loss, variant, st);
+        case 64: return launch_hogwild<16, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, lr, cu, ci, d_loss, variant, st);
+        case 128: return launch_hogwild<32, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, lr, cu, ci, d_loss, variant, st);
+        default: return launch_hogwild<64, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, lr, cu, ci, d_loss, variant, st);
+    }
+}
+
+}  // extern "C"

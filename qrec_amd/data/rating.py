@@ -1,0 +1,179 @@
+"""The rating data model: same public surface as the reference's ``Rating``
+(data/rating.py:5-190) -- name<->id maps in first-appearance order, ``trainSet_u/i``,
+``testSet_u/i``, means, rating scale -- plus the array/CSR views the device kernels use
+(``train_uid``, ``train_iid``, ``positive_csr()``, ``rated_csr()``).
+"""
+from __future__ import annotations
+
+import random
+from collections import defaultdict
+
+import numpy as np
+
+from ..interactions import CSR, user_item_csr
+from ..util.config import OptionConf
+
+
+class Rating:
+    def __init__(self, config, trainingSet, testSet):
+        self.config = config
+        self.evalSettings = OptionConf(config["evaluation.setup"])
+        self.user, self.item, self.id2user, self.id2item = {}, {}, {}, {}
+        self.userMeans, self.itemMeans, self.globalMean = {}, {}, 0
+        self.trainSet_u, self.trainSet_i = defaultdict(dict), defaultdict(dict)
+        self.testSet_u, self.testSet_i = defaultdict(dict), defaultdict(dict)
+        self.rScale = []
+        self.trainingData = trainingSet[:]
+        self.testData = testSet[:]
+        self._ingest()
+        self._means()
+        if self.evalSettings.contains("-cold"):
+            self._keep_cold_start_users(int(self.evalSettings["-cold"]))
+        self._csr_cache = {}
+
+    # ---- construction -----------------------------------------------------------------
+    def _ingest(self):
+        if self.evalSettings.contains("-val"):
+            # validation split carved out of the training rows (data/rating.py:37-41)
+            random.shuffle(self.trainingData)
+            cut = int(len(self.trainingData) * float(self.evalSettings["-val"]))
+            self.testData = self.trainingData[:cut]
+            self.trainingData = self.trainingData[cut:]
+        user, item = self.user, self.item
+        scale = set()
+        for userName, itemName, rating in self.trainingData:
+            if userName not in user:
+                user[userName] = len(user)
+            if itemName not in item:
+                item[itemName] = len(item)
+            self.trainSet_u[userName][itemName] = rating
+            self.trainSet_i[itemName][userName] = rating
+            scale.add(float(rating))
+        self.id2user = {v: k for k, v in user.items()}
+        self.id2item = {v: k for k, v in item.items()}
+        self.rScale = sorted(scale)
+        predict_only = self.evalSettings.contains("-predict")
+        for entry in self.testData:
+            if predict_only:
+                self.testSet_u[entry] = {}
+            else:
+                userName, itemName, rating = entry
+                self.testSet_u[userName][itemName] = rating
+                self.testSet_i[itemName][userName] = rating
+
+    def _means(self):
+        for u in self.user:
+            row = self.trainSet_u[u]
+            self.userMeans[u] = sum(row.values()) / len(row)
+        for i in self.item:
+            col = self.trainSet_i[i]
+            self.itemMeans[i] = sum(col.values()) / len(col)
+        total = sum(self.userMeans.values())
+        self.globalMean = 0 if total == 0 else total / len(self.userMeans)
+
+    def _keep_cold_start_users(self, threshold: int):
+        warm = {u for u in self.testSet_u if u in self.trainSet_u and len(self.trainSet_u[u]) > threshold}
+        for u in warm:
+            del self.testSet_u[u]
+        self.testData = [row for row in self.testData if row[0] not in warm]
+
+    # ---- reference accessors -------------------------------------------------------------
+    def getUserId(self, u):
+        return self.user.get(u)
+
+    def getItemId(self, i):
+        return self.item.get(i)
+
+    def trainingSize(self):
+        return (len(self.user), len(self.item), len(self.trainingData))
+
+    def testSize(self):
+        return (len(self.testSet_u), len(self.testSet_i), len(self.testData))
+
+    def contains(self, u, i):
+        return u in self.user and i in self.trainSet_u[u]
+
+    def containsUser(self, u):
+        return u in self.user
+
+    def containsItem(self, i):
+        return i in self.item
+
+    def userRated(self, u):
+        row = self.trainSet_u[u]
+        return list(row.keys()), list(row.values())
+
+    def itemRated(self, i):
+        col = self.trainSet_i[i]
+        return list(col.keys()), list(col.values())
+
+    def row(self, u):
+        vec = np.zeros(len(self.item))
+        for name, r in self.trainSet_u[u].items():
+            vec[self.item[name]] = r
+        return vec
+
+    def col(self, i):
+        vec = np.zeros(len(self.user))
+        for name, r in self.trainSet_i[i].items():
+            vec[self.user[name]] = r
+        return vec
+
+    def matrix(self):
+        m = np.zeros((len(self.user), len(self.item)))
+        for u, uid in self.user.items():
+            m[uid] = self.row(u)
+        return m
+
+    def sRow(self, u):
+        return self.trainSet_u[u]
+
+    def sCol(self, c):
+        return self.trainSet_i[c]
+
+    def rating(self, u, c):
+        return self.trainSet_u[u][c] if self.contains(u, c) else -1
+
+    def ratingScale(self):
+        return (self.rScale[0], self.rScale[1])
+
+    def elemCount(self):
+        return len(self.trainingData)
+
+    # ---- array views for the kernels -----------------------------------------------------
+    def training_arrays(self):
+        """(uid int32[n], iid int32[n], rating float64[n]) of ``trainingData`` in its
+        CURRENT order (isConverged reshuffles that list every epoch)."""
+        n = len(self.trainingData)
+        uid = np.fromiter((self.user[r[0]] for r in self.trainingData), dtype=np.int32, count=n)
+        iid = np.fromiter((self.item[r[1]] for r in self.trainingData), dtype=np.int32, count=n)
+        rat = np.fromiter((r[2] for r in self.trainingData), dtype=np.float64, count=n)
+        return uid, iid, rat
+
+    def _dict_csr(self, min_rating):
+        # walk the dicts themselves: their iteration order IS the contract
+        nu = len(self.user)
+        counts = np.zeros(nu + 1, dtype=np.int64)
+        cols, vals = [], []
+        for u, uid in self.user.items():  # id order == insertion order
+            row = self.trainSet_u[u]
+            if min_rating is None:
+                items = list(row.items())
+            else:
+                items = [(i, r) for i, r in row.items() if r >= min_rating]
+            counts[uid + 1] = len(items)
+            cols.extend(self.item[i] for i, _ in items)
+            vals.extend(r for _, r in items)
+        return CSR(np.cumsum(counts), np.asarray(cols, dtype=np.int32), np.asarray(vals, dtype=np.float64))
+
+    def positive_csr(self) -> CSR:
+        """BPR's PositiveSet (rating >= 1) in its iteration order (model/ranking/BPR.py:21-33)."""
+        if "pos" not in self._csr_cache:
+            self._csr_cache["pos"] = self._dict_csr(1)
+        return self._csr_cache["pos"]
+
+    def rated_csr(self) -> CSR:
+        """All train items per user, dict order (mask list of evalRanking, sampler membership)."""
+        if "rated" not in self._csr_cache:
+            self._csr_cache["rated"] = self._dict_csr(None)
+        return self._csr_cache["rated"]

@@ -1,0 +1,127 @@
+"""Device-side state and epoch drivers of the embedding-training hot path.
+
+``DeviceTables`` keeps the user/item embedding tables resident in HBM for the whole
+training run (row-major, row stride ``ld`` padded so one row is a whole number of 64-byte
+segments); ``BprSgd`` / ``MfSgd`` run one epoch per call through the C ABI
+(include/qrec_hip.h).  Nothing here computes on the host: a missing or failing
+libqrec_hip.so raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import capi
+from .capi import DeviceBuffer
+from .interactions import CSR
+
+
+def padded_ld(d: int, dtype) -> int:
+    """Row stride in elements.  fp32 tables use 32/64/128/256 so that the throughput kernel
+    can map a row onto 16/32/64 lanes; fp64 (order-exact kernel only) needs no padding."""
+    if np.dtype(dtype) == np.float64:
+        return d
+    for ld in (32, 64, 128, 256):
+        if d <= ld:
+            return ld
+    raise ValueError(f"embedding size {d} > 256 is not supported by the fp32 kernels")
+
+
+class DeviceTables:
+    def __init__(self, P: np.ndarray, Q: np.ndarray, dtype=np.float32):
+        self.dtype = np.dtype(dtype)
+        self.code = capi.F64 if self.dtype == np.float64 else capi.F32
+        self.n_users, self.d = P.shape
+        self.n_items = Q.shape[0]
+        assert Q.shape[1] == self.d
+        self.ld = padded_ld(self.d, self.dtype)
+        if max(self.n_users, self.n_items) * self.ld * self.dtype.itemsize >= 2 ** 32:
+            raise ValueError("a table exceeds the 4 GiB buffer-descriptor range; shard it across GPUs")
+        self.P = DeviceBuffer.from_numpy(self._pad(P))
+        self.Q = DeviceBuffer.from_numpy(self._pad(Q))
+
+    def _pad(self, a: np.ndarray) -> np.ndarray:
+        out = np.zeros((a.shape[0], self.ld), dtype=self.dtype)
+        out[:, :self.d] = a
+        return out
+
+    def upload(self, P: np.ndarray, Q: np.ndarray):
+        self.P.upload(self._pad(P)); self.Q.upload(self._pad(Q))
+
+    def download(self, dtype=np.float64):
+        """(P, Q) as host arrays [rows, d] (pad columns dropped)."""
+        return (np.ascontiguousarray(self.P.numpy()[:, :self.d], dtype=dtype),
+                np.ascontiguousarray(self.Q.numpy()[:, :self.d], dtype=dtype))
+
+    def sumsq(self, scratch: DeviceBuffer, stream=None):
+        """(sum P*P, sum Q*Q) -- model/ranking/BPR.py:40."""
+        capi.sumsq(self.P, self.code, self.n_users, self.d, self.ld, scratch, stream)
+        p = float(scratch.numpy(stream)[0])
+        capi.sumsq(self.Q, self.code, self.n_items, self.d, self.ld, scratch, stream)
+        return p, float(scratch.numpy(stream)[0])
+
+
+class BprSgd:
+    """One BPR epoch per call over a fixed (u, i) triplet list (user-major PositiveSet
+    order, model/ranking/BPR.py:31-34); negatives ``j`` come per epoch either from the
+    host (exact CPython stream) or from the device Philox sampler."""
+
+    def __init__(self, tables: DeviceTables, u: np.ndarray, i: np.ndarray, pos: CSR | None = None):
+        self.t = tables
+        self.n = int(u.size)
+        self.d_u = DeviceBuffer.from_numpy(np.ascontiguousarray(u, dtype=np.int32))
+        self.d_i = DeviceBuffer.from_numpy(np.ascontiguousarray(i, dtype=np.int32))
+        self.d_j = DeviceBuffer(max(self.n, 1), np.int32)
+        self.d_loss = DeviceBuffer.zeros(1, np.float64)
+        self._pos_dev = None
+        if pos is not None:
+            srt = pos.sorted_rows()
+            self._pos_dev = (DeviceBuffer.from_numpy(srt.indptr), DeviceBuffer.from_numpy(srt.indices))
+
+    # -- negatives ---------------------------------------------------------------------------
+    def set_negatives(self, j: np.ndarray, stream=None):
+        self.d_j.upload(np.ascontiguousarray(j, dtype=np.int32), stream)
+
+    def sample_negatives_device(self, seed: int, epoch: int, stream=None):
+        if self._pos_dev is None:
+            raise RuntimeError("BprSgd was built without the positives CSR")
+        capi.philox_bpr_sample(self._pos_dev[0], self._pos_dev[1], self.d_u, self.n, self.t.n_items,
+                               seed, epoch, self.d_j, stream)
+
+    # -- epochs ------------------------------------------------------------------------------------
+    def epoch_ordered(self, lr: float, regU: float, regI: float, stream=None) -> float:
+        """Strictly sequential pass (reference semantics).  Returns sum(-log sigmoid)."""
+        capi.bpr_sgd_ordered(self.t.P, self.t.Q, self.t.code, self.t.d, self.t.ld, self.d_u, self.d_i,
+                             self.d_j, self.n, lr, regU, regI, self.d_loss, stream)
+        return float(self.d_loss.numpy(stream)[0])
+
+    def epoch_throughput_async(self, lr: float, regU: float, regI: float, chunk: int = 32,
+                               variant: int = capi.HW_DEFAULT, stream=None):
+        """Hogwild pass (fp32 tables); enqueue only -- read the loss with ``loss()``."""
+        if self.t.dtype != np.float32:
+            raise TypeError("throughput mode needs fp32 tables")
+        self.d_loss.fill_bytes(0, stream)
+        capi.bpr_sgd_hogwild(self.t.P, self.t.Q, self.t.d, self.t.ld, self.d_u, self.d_i, self.d_j,
+                             self.n, chunk, 0, lr, regU, regI, self.d_loss, variant, stream)
+
+    def loss(self, stream=None) -> float:
+        return float(self.d_loss.numpy(stream)[0])
+
+
+class MfSgd:
+    """model/rating/BasicMF.py:9-26 on the device, order-exact."""
+
+    def __init__(self, tables: DeviceTables, n: int):
+        self.t = tables
+        self.n = n
+        self.d_u = DeviceBuffer(max(n, 1), np.int32)
+        self.d_i = DeviceBuffer(max(n, 1), np.int32)
+        self.d_r = DeviceBuffer(max(n, 1), np.float64)
+        self.d_loss = DeviceBuffer.zeros(1, np.float64)
+
+    def epoch(self, u, i, r, lr: float, stream=None) -> float:
+        self.d_u.upload(np.ascontiguousarray(u, dtype=np.int32), stream)
+        self.d_i.upload(np.ascontiguousarray(i, dtype=np.int32), stream)
+        self.d_r.upload(np.ascontiguousarray(r, dtype=np.float64), stream)
+        capi.mf_sgd_ordered(self.t.P, self.t.Q, self.t.code, self.t.d, self.t.ld, self.d_u, self.d_i,
+                            self.d_r, self.n, lr, self.d_loss, stream)
+        return float(self.d_loss.numpy(stream)[0])

@@ -1,0 +1,78 @@
+"""BPR-MF (Rendle et al.) behind the reference's class name and hooks
+(model/ranking/BPR.py:8-104), trained on the MI355X.
+
+Two execution modes, chosen by the optional conf key ``qrec.mode`` or env ``QREC_MODE``:
+
+``exact`` (default)
+    The reference's numpy-path semantics: negatives from the CPython ``random`` stream
+    (bit-identical (u,i,j) sequence), triplets applied strictly in order by the
+    order-exact kernel, fp64 tables (``QREC_DTYPE=f32`` for fp32).  Same loss, learning
+    rate schedule, P and Q as the reference to rounding.
+``throughput``
+    Device Philox sampler + Hogwild kernel (fp32, exact per-sample deltas applied with
+    atomic adds).  Same algorithm and sampling distribution, not the same random stream;
+    judged on Recall@N.
+"""
+from __future__ import annotations
+
+import os
+import random
+
+import numpy as np
+
+from ... import capi
+from ...base.iterativeRecommender import IterativeRecommender
+from ...engine import BprSgd, DeviceTables
+
+
+class BPR(IterativeRecommender):
+    def __init__(self, conf, trainingSet=None, testSet=None, fold="[1]"):
+        super().__init__(conf, trainingSet, testSet, fold)
+
+    def readConfiguration(self):
+        super().readConfiguration()
+        mode = self.config["qrec.mode"] if self.config.contains("qrec.mode") else os.environ.get("QREC_MODE", "exact")
+        if mode not in ("exact", "throughput"):
+            print("parameter qrec.mode is invalid!")
+            raise SystemExit(-1)
+        self.mode = mode
+        dt = os.environ.get("QREC_DTYPE", "f64" if mode == "exact" else "f32")
+        self.table_dtype = np.float64 if (dt == "f64" and mode == "exact") else np.float32
+        self.sampler_seed = int(os.environ.get("QREC_SEED", "0"))
+
+    def initModel(self):
+        super().initModel()
+
+    def trainModel(self):
+        print("Preparing item sets...")
+        pos = self.data.positive_csr()           # PositiveSet, BPR.py:21-25
+        u, i = pos.row_ids(), pos.indices
+        print("training...")
+        tables = DeviceTables(self.P, self.Q, self.table_dtype)
+        sgd = BprSgd(tables, u, i, pos)
+        scratch = capi.DeviceBuffer.zeros(1, np.float64)
+        n_items = len(self.data.item)
+        epoch = 0
+        while epoch < self.maxEpoch:
+            if self.mode == "exact":
+                state = random.getstate()
+                words = capi.state_from_python(state)
+                j = capi.mt_bpr_sample_epoch(words, pos.indptr, pos.indices, n_items)
+                random.setstate(capi.state_to_python(words, state[2]))
+                sgd.set_negatives(j)
+                self.loss = sgd.epoch_ordered(self.lRate, self.regU, self.regI)
+            else:
+                sgd.sample_negatives_device(self.sampler_seed, epoch)
+                sgd.epoch_throughput_async(self.lRate, self.regU, self.regI)
+                self.loss = sgd.loss()
+            sp, sq = tables.sumsq(scratch)
+            self.loss += self.regU * sp + self.regI * sq
+            epoch += 1
+            if self.isConverged(epoch):
+                break
+        self.P, self.Q = tables.download(np.float64)
+
+    def predictForRanking(self, u):
+        if self.data.containsUser(u):
+            return self.Q.dot(self.P[self.data.getUserId(u)])
+        return [self.data.globalMean] * self.num_items

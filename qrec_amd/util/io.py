@@ -1,0 +1,62 @@
+"""Dataset text I/O with the reference's on-disk format and options (util/io.py:31-76):
+``user item rating`` rows split on space / comma / tab (or ``-delim``), ``-columns`` picks
+the fields, ``-header`` skips the first line, and ``-b t`` (binarize) drops rows whose
+rating is below ``t`` and sets the rest to 1.
+"""
+from __future__ import annotations
+
+import os
+import re
+import sys
+
+from .config import OptionConf
+
+
+class FileIO:
+    @staticmethod
+    def writeFile(dir: str, file: str, content, op: str = "w") -> None:
+        os.makedirs(dir, exist_ok=True)
+        with open(dir + file, op) as fh:
+            fh.writelines(content)
+
+    @staticmethod
+    def deleteFile(filePath: str) -> None:
+        if os.path.exists(filePath):
+            os.remove(filePath)
+
+    @staticmethod
+    def loadDataSet(conf, file: str, bTest: bool = False, binarized: bool = False,
+                    threshold: float = 3.0):
+        setup = OptionConf(conf["ratings.setup"])
+        print("loading test data..." if bTest else "loading training data...")
+        with open(file) as fh:
+            lines = fh.readlines()
+        if setup.contains("-header"):
+            lines = lines[1:]
+        cols = [int(c) for c in setup["-columns"].strip().split()]
+        splitter = re.compile(setup["-delim"] if setup.contains("-delim") else " |,|\t")
+        if not bTest and len(cols) < 2:
+            print("The rating file is not in a correct format. Error: Line num %d" % 0)
+            sys.exit(-1)
+        has_rating = len(cols) >= 3
+        rows = []
+        for line in lines:
+            fields = splitter.split(line.strip())
+            try:
+                user, item = fields[cols[0]], fields[cols[1]]
+                rating = fields[cols[2]] if has_rating else 1
+                if binarized:
+                    if float(fields[cols[2]]) < threshold:
+                        continue
+                    rating = 1
+                rows.append([user, item, float(rating)])
+            except ValueError:
+                print("Error! Have you added the option -header to the rating.setup?")
+                sys.exit(-1)
+        return rows
+
+    @staticmethod
+    def loadUserList(filepath: str):
+        print("loading user List...")
+        with open(filepath) as fh:
+            return [line.strip().split()[0] for line in fh]

@@ -1,0 +1,190 @@
+"""CPU-only tests of the host side: conf parsing, data model order, measures, the exact
+(CPython-stream) sampler shipped in libqrec_hip.so, and the C-ABI surface."""
+import io
+import json
+import os
+import random
+import re
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+from oracle import c as O
+from qrec_amd import capi
+from qrec_amd.interactions import user_item_csr
+from qrec_amd.util.config import ModelConf, OptionConf
+from qrec_amd.util.measure import Measure
+from qrec_amd.util.qmath import find_k_largest
+
+from helpers import GOLDEN, ROOT, conf_from_text, load_golden, rows_from_golden
+
+
+def test_abi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "qrec_hip.h")).read()
+    declared = set(re.findall(r"\b(qrec_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = capi.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/qrec_hip.h but not exported"
+    assert declared == set(capi.EXPORTED_SYMBOLS), declared ^ set(capi.EXPORTED_SYMBOLS)
+    assert lib.qrec_version() >= 100
+
+
+def test_option_conf_matches_reference_on_all_stock_conf_lines():
+    cases = json.load(open(os.path.join(GOLDEN, "optionconf_cases.json")))
+    assert len(cases) > 100
+    for line, want in cases.items():
+        got = OptionConf(line)
+        assert got.isMainOn() == want["main"], line
+        assert got.options == want["options"], line
+
+
+def test_model_conf_errors_like_reference(tmp_path, capsys):
+    p = tmp_path / "a.conf"
+    p.write_text("model.name=BPR\n\nbad line without equals\nnum.factors=8\n")
+    c = ModelConf(str(p))
+    assert c["model.name"] == "BPR" and c["num.factors"] == "8" and not c.contains("bad")
+    with pytest.raises(SystemExit) as e:
+        c["nope"]
+    assert e.value.code == -1 and "parameter nope is invalid!" in capsys.readouterr().out
+    with pytest.raises(IOError):
+        ModelConf(str(tmp_path / "missing.conf"))
+
+
+def test_rating_model_reproduces_reference_ids_and_positive_order():
+    from qrec_amd.data.rating import Rating
+    meta, z = load_golden("bpr_filmtrust")
+    train, test = rows_from_golden(z)
+    data = Rating(conf_from_text(meta["conf"]), train, test)
+    assert data.trainingSize() == (meta["n_users"], meta["n_items"], meta["n_train"])
+    uid, iid, _ = data.training_arrays()
+    assert np.array_equal(uid, z["train_uid"]) and np.array_equal(iid, z["train_iid"])
+    pos = data.positive_csr()
+    st = z["steps"][:meta["triplets_per_epoch"]]
+    assert np.array_equal(pos.row_ids(), st[:, 0]) and np.array_equal(pos.indices, st[:, 1])
+    # array-only construction gives the same CSR as walking the dicts
+    pos2 = user_item_csr(z["train_uid"], z["train_iid"], z["train_r"], meta["n_users"], meta["n_items"], 1)
+    assert np.array_equal(pos.indptr, pos2.indptr) and np.array_equal(pos.indices, pos2.indices)
+
+
+@pytest.mark.parametrize("case", ["bpr_filmtrust", "bpr_lastfm"])
+def test_product_exact_sampler_reproduces_reference_stream(case):
+    """libqrec_hip.so's host sampler (qrec_mt_*) vs the reference's recorded (u,i,j) stream."""
+    meta, z = load_golden(case)
+    U, I = meta["n_users"], meta["n_items"]
+    pos = user_item_csr(z["train_uid"], z["train_iid"], z["train_r"], U, I, min_rating=1)
+    random.seed(meta["seed"])
+    if case == "bpr_lastfm":  # -ap split draws one random() per raw row first
+        for _ in range(z["split_is_test"].size):
+            random.random()
+    st = capi.state_from_python(random.getstate())
+    chunks = []
+    for _ in meta["epochs"]:
+        j = capi.mt_bpr_sample_epoch(st, pos.indptr, pos.indices, I)
+        capi.mt_shuffle(st, meta["n_train"])
+        chunks.append(np.stack([pos.row_ids(), pos.indices, j], 1))
+    stream = np.concatenate(chunks)
+    if "steps" in z.files:
+        assert np.array_equal(stream, z["steps"])
+    else:
+        assert np.array_equal(stream[:4096], z["steps_head"]) and np.array_equal(stream[-4096:], z["steps_tail"])
+    import hashlib
+    assert hashlib.sha256(stream.astype(np.int32).tobytes()).hexdigest() == meta["stream_sha256"]
+    assert np.array_equal(st, z["py_state"])
+
+
+def test_product_pairwise_sampler_and_shuffle_reproduce_reference():
+    meta, z = load_golden("pairwise_adj_filmtrust")
+    U, I = meta["n_users"], meta["n_items"]
+    uid, iid = z["train_uid"], z["train_iid"]
+    rated = user_item_csr(uid, iid, np.ones(uid.size), U, I).sorted_rows()
+    random.seed(meta["seed"])
+    st = capi.state_from_python(random.getstate())
+    perm = np.arange(uid.size, dtype=np.int64)
+    out = []
+    for _ in range(meta["epochs_sampled"]):
+        capi.mt_shuffle(st, uid.size, perm)
+        ru = np.ascontiguousarray(uid[perm]); ri = np.ascontiguousarray(iid[perm])
+        out.append(np.stack([ru, ri, capi.mt_pairwise_sample_epoch(st, ru, rated.indptr, rated.indices, I)], 1))
+    assert np.array_equal(np.concatenate(out), z["stream"])
+    assert np.array_equal(st, z["py_state"])
+
+
+def test_exact_sampler_edge_cases():
+    st = capi.state_from_python(random.Random(3).getstate())
+    # empty epoch, single item universe impossible (user positive on every item) -> error
+    assert capi.mt_bpr_sample_epoch(st.copy(), np.zeros(1, np.int64), np.zeros(0, np.int32), 5).size == 0
+    with pytest.raises(capi.QRecError):
+        capi.mt_bpr_sample_epoch(st.copy(), np.array([0, 2], np.int64), np.array([0, 1], np.int32), 2)
+    with pytest.raises(capi.QRecError):   # item id out of range
+        capi.mt_bpr_sample_epoch(st.copy(), np.array([0, 1], np.int64), np.array([7], np.int32), 3)
+    # shuffle of 0/1 elements consumes nothing
+    a = st.copy(); capi.mt_shuffle(a, 1); capi.mt_shuffle(a, 0); assert np.array_equal(a, st)
+    # ragged users incl. empty rows: never returns a positive, matches python's own stream
+    rng = random.Random(11)
+    indptr = np.array([0, 0, 3, 3, 4], np.int64); ind = np.array([1, 2, 0, 3], np.int32)
+    ref = []
+    r2 = random.Random(5); s2 = capi.state_from_python(r2.getstate())
+    for u in range(4):
+        posu = set(ind[indptr[u]:indptr[u + 1]].tolist())
+        for _ in range(indptr[u + 1] - indptr[u]):
+            x = r2.choice(range(4))
+            while x in posu:
+                x = r2.choice(range(4))
+            ref.append(x)
+    assert capi.mt_bpr_sample_epoch(s2, indptr, ind, 4).tolist() == ref
+    assert np.array_equal(s2, capi.state_from_python(r2.getstate()))
+
+
+def test_measures_reproduce_reference_numbers():
+    meta, z = load_golden("bpr_filmtrust")
+    train, test = rows_from_golden(z)
+    origin = {}
+    for u, i, r in test:
+        origin.setdefault(u, {})[i] = r
+    names = z["rec_user_names"].tolist()
+    # golden recLists are keyed by the reference's user names; translate to ours
+    name_of = {}
+    for (u, i, r), un in zip(test, z["test_uname"].tolist()):
+        name_of[un] = u
+    res = {name_of[un]: [(f"i{iid}", sc) for iid, sc in zip(ids.tolist(), scs.tolist())]
+           for un, ids, scs in zip(names, z["rec_ids"], z["rec_scores"])}
+    got = Measure.rankingMeasure(origin, res, [int(x) for x in meta["topN"].split(",")])
+    assert len(got) == len(meta["measure"])
+    for g, w in zip(got, meta["measure"]):
+        if ":" in w:
+            assert g.split(":")[0] == w.split(":")[0]
+            assert float(g.split(":")[1]) == pytest.approx(float(w.split(":")[1]), rel=1e-12)
+        else:
+            assert g == w
+    meta2, z2 = load_golden("basicmf_filmtrust")
+    res2 = [[None, None, r, p] for r, p in zip(z2["test_rating"].tolist(), z2["test_pred"].tolist())]
+    got2 = Measure.ratingMeasure(res2)
+    for g, w in zip(got2, meta2["measure"]):
+        assert float(g.split(":")[1]) == pytest.approx(float(w.split(":")[1]), rel=1e-12)
+
+
+def test_find_k_largest_host_matches_oracle_with_ties():
+    rng = np.random.default_rng(0)
+    for trial in range(100):
+        n = int(rng.integers(1, 120)); K = int(rng.integers(1, 30))
+        c = rng.integers(-2, 3, n).astype(np.float64)
+        ids, sc = find_k_largest(K, c)
+        oi, os_ = O.find_k_largest(K, c)
+        assert ids == oi.tolist() and sc == os_.tolist()
+
+
+def test_native_shuffle_of_training_data_matches_python(monkeypatch):
+    from qrec_amd.base.iterativeRecommender import IterativeRecommender
+    meta, z = load_golden("basicmf_filmtrust")
+    rows = [[f"u{a}", f"i{b}", float(r)] for (a, b), r in zip(z["order0"].tolist(), z["rating0"].tolist())]
+    with redirect_stdout(io.StringIO()):
+        m = IterativeRecommender(conf_from_text(meta["conf"]), rows, [])
+    random.seed(meta["seed"])
+    m.shuffle_training_data()
+    got = np.array([(m.data.user[a], m.data.item[b]) for a, b, _ in m.data.trainingData], dtype=np.int32)
+    assert np.array_equal(got, z["order1"])
+    want = list(rows)
+    random.seed(meta["seed"]); random.shuffle(want)
+    assert m.data.trainingData == want
