@@ -1,0 +1,258 @@
+"""GPU parity tests of the BPR / BasicMF hot path, through the C ABI (libqrec_hip.so),
+against the CPU oracle and the golden vectors recorded from the reference.
+
+Tolerances (BASELINE.json north_star): index streams bit-exact; fp32 embeddings / loss
+within 1e-5 relative of the fp64 reference path; the fp64 kernel is held to 1e-11."""
+import io
+import random
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+from oracle import c as O
+from qrec_amd import capi
+from qrec_amd.capi import DeviceBuffer as DB
+from qrec_amd.engine import BprSgd, DeviceTables, MfSgd, padded_ld
+from qrec_amd.interactions import user_item_csr
+from qrec_amd.synth import make_dataset, to_csr
+
+from helpers import conf_from_text, load_golden, pad_cols, rel_err, rows_from_golden
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-5     # north_star: "within 1e-5 relative on fp32 embeddings/loss"
+F64_TOL = 1e-11
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    capi.init(0)
+    info = capi.device_info()
+    assert info["arch"].startswith("gfx950"), info
+    yield
+
+
+def _synthetic(shape, seed=5):
+    d = make_dataset(shape)
+    indptr, ind = to_csr(d["n_users"], d["train_u"], d["train_i"])
+    u = np.repeat(np.arange(d["n_users"], dtype=np.int32), np.diff(indptr)).astype(np.int32)
+    j = O.bpr_sample_epoch(O.MT.cpython_seed(seed), indptr, ind, d["n_items"])
+    return d, indptr, ind, u, j
+
+
+@pytest.mark.parametrize("dim", [64, 50, 10, 128, 200])
+def test_ordered_kernel_matches_oracle(dim):
+    d, indptr, ind, u, j = _synthetic("small")
+    U, I, n = d["n_users"], d["n_items"], ind.size
+    rng = np.random.default_rng(dim)
+    P0 = rng.random((U, dim)) / 3; Q0 = rng.random((I, dim)) / 3
+    lr, ru, ri = 0.05, 0.01, 0.02
+    Pr, Qr = P0.copy(), Q0.copy()
+    lref = O.bpr_sgd(Pr, Qr, u, ind, j, lr, ru, ri)
+    for dtype, tol in ((np.float64, F64_TOL), (np.float32, F32_TOL)):
+        t = DeviceTables(P0, Q0, dtype)
+        sgd = BprSgd(t, u, ind)
+        sgd.set_negatives(j)
+        loss = sgd.epoch_ordered(lr, ru, ri)
+        Pg, Qg = t.download()
+        assert rel_err(Pg, Pr) < tol and rel_err(Qg, Qr) < tol
+        assert abs(loss - lref) / lref < tol
+        np.testing.assert_allclose(Pg, Pr, rtol=100 * tol, atol=tol)
+        assert (t.P.numpy()[:, dim:] == 0).all() and (t.Q.numpy()[:, dim:] == 0).all()  # pad stays zero
+
+
+def test_ordered_kernel_edge_cases():
+    rng = np.random.default_rng(1)
+    P0 = rng.random((5, 8)) / 3; Q0 = rng.random((7, 8)) / 3
+    t = DeviceTables(P0, Q0, np.float64)
+    # empty epoch: tables untouched, loss 0
+    sgd = BprSgd(t, np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert sgd.epoch_ordered(0.1, 0.1, 0.1) == 0.0
+    P, Q = t.download(); assert np.array_equal(P, P0) and np.array_equal(Q, Q0)
+    # adversarial aliasing: the same rows over and over, user switching back and forth,
+    # next triplet's rows equal to the ones just written (prefetch patch path)
+    u = np.array([0, 0, 1, 0, 0, 2, 2, 2], np.int32)
+    i = np.array([1, 2, 1, 3, 1, 1, 2, 1], np.int32)
+    j = np.array([2, 1, 2, 1, 3, 2, 1, 2], np.int32)
+    Pr, Qr = P0.copy(), Q0.copy(); lref = O.bpr_sgd(Pr, Qr, u, i, j, 0.3, 0.05, 0.07)
+    sgd = BprSgd(t, u, i); sgd.set_negatives(j)
+    loss = sgd.epoch_ordered(0.3, 0.05, 0.07)
+    P, Q = t.download()
+    np.testing.assert_allclose(P, Pr, rtol=1e-13); np.testing.assert_allclose(Q, Qr, rtol=1e-13)
+    assert loss == pytest.approx(lref, rel=1e-13)
+    # bad arguments are refused with an error, not a crash
+    with pytest.raises(capi.QRecError):
+        capi.bpr_sgd_ordered(t.P, t.Q, 7, 8, 8, sgd.d_u, sgd.d_i, sgd.d_j, 8, 0.1, 0, 0, sgd.d_loss)
+    with pytest.raises(capi.QRecError):
+        capi.bpr_sgd_ordered(t.P, t.Q, capi.F64, 300, 300, sgd.d_u, sgd.d_i, sgd.d_j, 8, 0.1, 0, 0, sgd.d_loss)
+
+
+def test_bpr_model_end_to_end_reproduces_reference_run():
+    """The drop-in BPR class, exact mode, on the reference's own FilmTrust run: same index
+    stream (hence same loss / lr schedule), same P,Q, same recommendation lists and the same
+    measure strings as the unmodified reference (tests/golden/gen_golden.py)."""
+    from qrec_amd.model.ranking.BPR import BPR
+    meta, z = load_golden("bpr_filmtrust")
+    train, test = rows_from_golden(z)
+    conf = conf_from_text(meta["conf"])
+    random.seed(meta["seed"]); np.random.seed(meta["seed"])
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        m = BPR(conf, train, test)
+        captured = {}
+        orig = m.isConverged
+        def spy(epoch):
+            captured[epoch] = (float(m.loss), float(m.lRate))
+            return orig(epoch)
+        m.isConverged = spy
+        measure = m.execute()
+    for ep in meta["epochs"]:
+        loss, lr = captured[ep["epoch"]]
+        assert loss == pytest.approx(ep["loss"], rel=1e-11)
+        assert lr == pytest.approx(ep["lr_used"], rel=1e-14)
+    last = len(meta["epochs"])
+    np.testing.assert_allclose(m.P, z[f"P{last}"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(m.Q, z[f"Q{last}"], rtol=1e-10, atol=1e-13)
+    assert np.array_equal(capi.state_from_python(random.getstate()), z["py_state"])
+    for g, w in zip(measure, meta["measure"]):
+        if ":" in w:
+            assert float(g.split(":")[1]) == pytest.approx(float(w.split(":")[1]), rel=1e-9), (g, w)
+        else:
+            assert g == w
+
+
+def test_basicmf_model_end_to_end_reproduces_reference_run():
+    """BASELINE.json config #1 (BasicMF, FilmTrust, d=10) through the drop-in class."""
+    from qrec_amd.model.rating.BasicMF import BasicMF
+    meta, z = load_golden("basicmf_filmtrust")
+    rows = [[f"u{a}", f"i{b}", float(r)] for (a, b), r in zip(z["order0"].tolist(), z["rating0"].tolist())]
+    test = [[f"u{a}" if a >= 0 else f"xu{k}", f"i{b}" if b >= 0 else f"xi{k}", float(r)]
+            for k, (a, b, r) in enumerate(zip(z["test_uid"].tolist(), z["test_iid"].tolist(), z["test_rating"].tolist()))]
+    random.seed(meta["seed"]); np.random.seed(meta["seed"])
+    with redirect_stdout(io.StringIO()):
+        m = BasicMF(conf_from_text(meta["conf"]), rows, test)
+        measure = m.execute()
+    last = len(meta["epochs"])
+    np.testing.assert_allclose(m.P, z[f"P{last}"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(m.Q, z[f"Q{last}"], rtol=1e-10, atol=1e-13)
+    assert m.lastLoss == pytest.approx(meta["epochs"][-1]["loss"], rel=1e-11)
+    for g, w in zip(measure, meta["measure"]):   # MAE / RMSE
+        assert float(g.split(":")[1]) == pytest.approx(float(w.split(":")[1]), rel=1e-9)
+    assert np.array_equal(capi.state_from_python(random.getstate()), z["py_state"])
+
+
+@pytest.mark.parametrize("dim", [64, 50, 128, 8, 200])
+@pytest.mark.parametrize("variant", [capi.HW_ATOMIC, capi.HW_SC1_ATOMIC])
+def test_hogwild_single_group_is_the_sequential_recurrence(dim, variant):
+    """With one group the throughput kernel must reproduce the reference recurrence."""
+    d, indptr, ind, u, j = _synthetic("small")
+    U, I, n = d["n_users"], d["n_items"], ind.size
+    rng = np.random.default_rng(dim)
+    P0 = rng.random((U, dim)) / 3; Q0 = rng.random((I, dim)) / 3
+    Pr, Qr = P0.copy(), Q0.copy()
+    lref = O.bpr_sgd(Pr, Qr, u, ind, j, 0.05, 0.01, 0.02)
+    for chunk in (64, 7, 1):
+        t = DeviceTables(P0, Q0, np.float32)
+        sgd = BprSgd(t, u, ind); sgd.set_negatives(j)
+        sgd.d_loss.fill_bytes(0)
+        capi.bpr_sgd_hogwild(t.P, t.Q, dim, t.ld, sgd.d_u, sgd.d_i, sgd.d_j, n, chunk, 1, 0.05, 0.01, 0.02, sgd.d_loss, variant)
+        Pg, Qg = t.download()
+        assert rel_err(Pg, Pr) < F32_TOL and rel_err(Qg, Qr) < F32_TOL
+        assert abs(sgd.loss() - lref) / lref < F32_TOL
+        assert (t.P.numpy()[:, dim:] == 0).all() and (t.Q.numpy()[:, dim:] == 0).all()
+
+
+def test_hogwild_full_grid_conflict_free_input_is_exact():
+    """Every user owns a private block of items (positives and negatives), one chunk per
+    user: no two groups ever share a row, so the parallel result must equal the sequential
+    one to fp32 rounding -- at full occupancy (40k groups in flight)."""
+    U, per, dim = 40_000, 8, 64
+    I = U * 2 * per
+    u = np.repeat(np.arange(U, dtype=np.int32), per)
+    base = (np.arange(U, dtype=np.int64) * 2 * per).repeat(per)
+    i = (base + np.tile(np.arange(per), U)).astype(np.int32)
+    j = (base + per + np.tile(np.arange(per)[::-1], U)).astype(np.int32)
+    rng = np.random.default_rng(2)
+    P0 = (rng.random((U, dim)) / 3).astype(np.float32); Q0 = (rng.random((I, dim)) / 3).astype(np.float32)
+    Pr, Qr = P0.astype(np.float64), Q0.astype(np.float64)
+    lref = O.bpr_sgd(Pr, Qr, u, i, j, 0.05, 0.01, 0.02)
+    t = DeviceTables(P0, Q0, np.float32)
+    sgd = BprSgd(t, u, i); sgd.set_negatives(j)
+    sgd.epoch_throughput_async(0.05, 0.01, 0.02, chunk=per)
+    Pg, Qg = t.download()
+    assert rel_err(Pg, Pr) < F32_TOL and rel_err(Qg, Qr) < F32_TOL
+    assert abs(sgd.loss() - lref) / lref < F32_TOL
+
+
+def test_hogwild_full_size_properties_yelp_shape():
+    """BASELINE.json's bench configuration (Yelp2018 shape, d=64, 1.25 M triplets/epoch)."""
+    d, indptr, ind, u, j = _synthetic("yelp2018", seed=1)
+    U, I, n, dim = d["n_users"], d["n_items"], ind.size, 64
+    rng = np.random.default_rng(0)
+    P0 = (rng.random((U, dim)) / 3).astype(np.float32); Q0 = (rng.random((I, dim)) / 3).astype(np.float32)
+    t = DeviceTables(P0, Q0, np.float32)
+    sgd = BprSgd(t, u, ind); sgd.set_negatives(j)
+    # (1) lr = 0: tables bit-identical, loss = the static BPR loss of the tables
+    sgd.epoch_throughput_async(0.0, 0.001, 0.001)
+    Pg, Qg = t.download(np.float32)
+    assert np.array_equal(Pg, P0) and np.array_equal(Qg, Q0)
+    Pz, Qz = P0.astype(np.float64), Q0.astype(np.float64)
+    lz = O.bpr_sgd(Pz, Qz, u, ind, j, 0.0, 0.001, 0.001)
+    assert abs(sgd.loss() - lz) / lz < F32_TOL
+    # (2) one real epoch: no update lost -> within 1% of the strictly sequential result
+    #     (the racy read-modify-write variants sit at ~9%)
+    Pr, Qr = P0.astype(np.float64), Q0.astype(np.float64)
+    lref = O.bpr_sgd(Pr, Qr, u, ind, j, 0.01, 0.001, 0.001)
+    sgd.epoch_throughput_async(0.01, 0.001, 0.001)
+    Pg, Qg = t.download()
+    assert np.isfinite(Pg).all() and np.isfinite(Qg).all()
+    assert rel_err(Pg, Pr) < 0.01 and rel_err(Qg, Qr) < 0.01
+    assert abs(sgd.loss() - lref) / lref < 0.01
+    # (3) untouched rows stay bit-identical (items never sampled nor positive this epoch)
+    touched = np.zeros(I, bool); touched[ind] = True; touched[j] = True
+    if (~touched).any():
+        assert np.array_equal(t.Q.numpy()[~touched][:, :dim], Q0[~touched])
+    # (4) the order-exact kernel at full size against the oracle
+    t2 = DeviceTables(P0, Q0, np.float32)
+    s2 = BprSgd(t2, u, ind); s2.set_negatives(j)
+    loss = s2.epoch_ordered(0.01, 0.001, 0.001)
+    Pg, Qg = t2.download()
+    assert rel_err(Pg, Pr) < F32_TOL and rel_err(Qg, Qr) < F32_TOL and abs(loss - lref) / lref < F32_TOL
+
+
+def test_philox_sampler_properties():
+    d, indptr, ind, u, _ = _synthetic("small")
+    U, I, n = d["n_users"], d["n_items"], ind.size
+    pos = user_item_csr(u, ind, np.ones(n), U, I, 1)
+    t = DeviceTables(np.zeros((U, 8)), np.zeros((I, 8)), np.float32)
+    sgd = BprSgd(t, u, ind, pos)
+    sgd.sample_negatives_device(1234, 0); j0 = sgd.d_j.numpy()
+    sgd.sample_negatives_device(1234, 0); assert np.array_equal(j0, sgd.d_j.numpy())   # deterministic
+    sgd.sample_negatives_device(1234, 1); j1 = sgd.d_j.numpy()
+    sgd.sample_negatives_device(99, 0); j2 = sgd.d_j.numpy()
+    assert (j0 >= 0).all() and (j0 < I).all()
+    key = set((u.astype(np.int64) * I + ind).tolist())
+    for jj in (j0, j1, j2):
+        assert not any((a * I + b) in key for a, b in zip(u.tolist(), jj.tolist()))   # never a positive
+    assert (j0 != j1).mean() > 0.99 and (j0 != j2).mean() > 0.99
+    # uniform over the non-positive items: chi-square over 50 equal-width bins of item id
+    allj = np.concatenate([j0, j1, j2])
+    hist = np.bincount(allj * 50 // I, minlength=50).astype(np.float64)
+    expect = np.bincount(np.arange(I) * 50 // I, minlength=50) / I * allj.size
+    chi2 = ((hist - expect) ** 2 / expect).sum()
+    assert chi2 < 120, chi2   # 49 dof; positives thin some bins slightly
+
+
+def test_sumsq_and_runtime_errors():
+    rng = np.random.default_rng(0)
+    for dtype in (np.float32, np.float64):
+        a = rng.standard_normal((1000, 50)).astype(dtype)
+        ld = 64
+        buf = DB.from_numpy(pad_cols(a, ld)); out = DB.zeros(1, np.float64)
+        capi.sumsq(buf, capi.F64 if dtype == np.float64 else capi.F32, 1000, 50, ld, out)
+        assert out.numpy()[0] == pytest.approx((a.astype(np.float64) ** 2).sum(), rel=1e-12)
+    with pytest.raises(capi.QRecError):
+        capi._check(capi.load().qrec_init(99))
+    with pytest.raises(capi.QRecError):   # hogwild refuses a row stride it has no lane mapping for
+        capi.bpr_sgd_hogwild(buf, buf, 50, 50, buf, buf, buf, 10, 16, 0, 0.1, 0.0, 0.0, out)
