@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- BPR triplet-updates/sec on the MI355X hot path (BASELINE.json metric).
+
+One *step* = one full pass of the reference's BPR epoch (model/ranking/BPR.py:29-43) over
+the synthetic Yelp2018-shape interaction matrix (31,668 x 38,048, ~1.25 M train triplets,
+d=64): negative sampling for every triplet (device Philox sampler) -> fused gather / dot /
+sigmoid / SGD scatter kernel (throughput mode) -> epoch-end regulariser reductions ->
+loss read-back -> bold-driver learning-rate update on the host (the reference's
+isConverged, minus the data shuffle BPR never looks at).  Inputs are resident in HBM
+before the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1 (weak scaling): every rank owns its own population of 31,668 users (its rows of P
+and its 1.25 M triplets per step); the item table Q is replicated and re-synchronised
+every step by one all-reduce of the per-rank Q deltas over RCCL/xGMI.  `value` counts
+the triplets of all ranks over the max-over-ranks time.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     -- the SGD kernel's algorithmic bytes/launch over its mean launch time
+                  (HIP events on the launch stream) against 8 TB/s HBM peak;
+  cpu_baseline -- the CPU port of the same epoch (oracle/, plain C, fp64, 1 thread) timed
+                  on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from qrec_amd import capi  # noqa: E402
+from qrec_amd.capi import DeviceBuffer  # noqa: E402
+from qrec_amd.engine import BprSgd, DeviceTables  # noqa: E402
+from qrec_amd.interactions import CSR  # noqa: E402
+from qrec_amd.synth import make_dataset, to_csr  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+DIM = 64
+LR0, MAX_LR, REG_U, REG_I = 0.01, 1.0, 0.001, 0.001   # config/BPR.conf:9-10
+CHUNK = 32
+
+
+def bytes_per_triplet(d: int) -> int:
+    """3 rows read + 3 rows written (fp32) + 3 int32 ids."""
+    return 6 * d * 4 + 12
+
+
+def cpu_baseline(u, i, indptr, n_items, U, seconds=12.0):
+    """The same epoch on the host: oracle sampler (CPython MT19937 replay) + the plain-C
+    fp64 restatement of BPR.optimization, single thread, repeated for ~`seconds`."""
+    from oracle import c as O
+    rng = np.random.default_rng(0)
+    P = rng.random((U, DIM)) / 3
+    Q = rng.random((n_items, DIM)) / 3
+    mt = O.MT.cpython_seed(0)
+    done, t0 = 0, time.perf_counter()
+    epochs = 0
+    while True:
+        j = O.bpr_sample_epoch(mt, indptr, i, n_items)
+        O.bpr_sgd(P, Q, u, i, j, LR0, REG_U, REG_I)
+        O.sumsq(P); O.sumsq(Q)
+        done += u.size; epochs += 1
+        if time.perf_counter() - t0 >= seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "triplet-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{epochs} full epochs ({done} triplets, {dt:.1f} s) of the same Yelp2018-shape workload; "
+                      "plain-C fp64 port of model/ranking/BPR.py:29-53 incl. the CPython-stream sampler "
+                      "(the Python reference itself cannot travel to this box; it measured 58.9k/s on 1 core, BASELINE.md)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--shape", default="yelp2018")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=capi.HW_DEFAULT)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    capi.init(local_rank)
+
+    # ---- workload: resident in HBM before timing ------------------------------------------
+    data = make_dataset(args.shape)
+    U, I = data["n_users"], data["n_items"]
+    indptr, items = to_csr(U, data["train_u"], data["train_i"])
+    u = np.repeat(np.arange(U, dtype=np.int32), np.diff(indptr)).astype(np.int32)
+    n = int(items.size)
+    rng = np.random.default_rng(1000 + rank)
+    P0 = (rng.random((U, DIM)) / 3).astype(np.float32)          # rand/3, iterativeRecommender.py:37-38
+    Q0 = (np.random.default_rng(999).random((I, DIM)) / 3).astype(np.float32)  # same on all ranks
+    tables = DeviceTables(P0, Q0, np.float32)
+    sgd = BprSgd(tables, u, items, CSR(indptr, items))
+    scratch = DeviceBuffer.zeros(1, np.float64)
+    total = args.warmup + args.steps
+    ev = [(capi.Event(), capi.Event()) for _ in range(total)]
+
+    q_view = q_start = None
+    if world > 1:
+        q_view = torch.as_tensor(tables.Q, device=torch.device("cuda", local_rank))
+        q_start = q_view.clone()
+
+    state = {"lr": LR0, "last": 0.0, "loss": 0.0}
+
+    def step(k: int):
+        sgd.sample_negatives_device(2018, k)                       # BPR.py:35-37
+        sgd.d_loss.fill_bytes(0)
+        ev[k][0].record()
+        capi.bpr_sgd_hogwild(tables.P, tables.Q, DIM, tables.ld, sgd.d_u, sgd.d_i, sgd.d_j, n, CHUNK, 0,
+                             state["lr"], REG_U, REG_I, sgd.d_loss, args.variant)   # BPR.py:45-53
+        ev[k][1].record()
+        if world > 1:   # replicated item table: sum the ranks' deltas (one all-reduce per step)
+            delta = q_view - q_start
+            dist.all_reduce(delta)
+            q_start.add_(delta)
+            q_view.copy_(q_start)
+        sp, sq = tables.sumsq(scratch)                              # BPR.py:40
+        loss = sgd.loss() + REG_U * sp + REG_I * sq
+        if not np.isfinite(loss):
+            raise SystemExit("Loss = NaN or Infinity")            # iterativeRecommender.py:84-86
+        # isConverged -> updateLearningRate (iterativeRecommender.py:56-63,96-100)
+        if k > 0:
+            state["lr"] *= 1.05 if abs(state["last"]) > abs(loss) else 0.5
+        state["lr"] = min(state["lr"], MAX_LR)
+        state["last"] = state["loss"] = loss
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        capi.device_sync()
+
+    for k in range(args.warmup):
+        step(k)
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, total):
+        step(k)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    kernel_ms = [ev[k][1].elapsed_ms_since(ev[k][0]) for k in range(args.warmup, total)]
+    avg_kernel_ms = float(np.mean(kernel_ms))
+    alg_bytes = n * bytes_per_triplet(DIM)
+
+    if rank == 0:
+        value = world * n * args.steps / elapsed
+        achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile):
+            tj = json.load(open(tfile))
+            if tj.get("workload") == f"bpr-{args.shape}-d{DIM}":
+                traffic = tj.get("bytes_per_launch")
+        out = {
+            "metric": "BPR triplet-updates/sec", "value": value, "unit": "triplet-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BPR d={DIM} on synthetic Yelp2018-shape ({U}x{I}, {n} train triplets/epoch), "
+                                   "throughput mode (device Philox sampler + Hogwild atomic-delta SGD)",
+                       "triplets_per_step_per_gpu": n, "chunk": CHUNK,
+                       "parallelism": "1 GPU" if world == 1 else f"user-sharded x{world}, replicated item table, per-step delta all-reduce (RCCL)",
+                       "lr": LR0, "reg": REG_U, "final_loss": state["loss"]},
+            "roofline": {"bound": "hbm", "kernel": "bpr_hogwild_kernel<16,4,plain-load,atomic>",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_kernel_ms,
+                         "note": "tables (17.8 MB) are L2/Infinity-Cache resident at this shape; the binding "
+                                 "resource is the L2 atomic units (~1 dword/clk/channel), see DESIGN.md"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(u, items, indptr, I, U)
+            out["vs_cpu_port"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

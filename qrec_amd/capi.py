@@ -211,6 +211,12 @@ class DeviceBuffer:
         b.fill_bytes(0, stream)
         return b
 
+    @property
+    def __cuda_array_interface__(self):
+        """zero-copy view for torch.as_tensor(buf, device="cuda") (multi-GPU collectives)"""
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False),
+                "version": 2, "strides": None}
+
     def upload(self, a: np.ndarray, stream=None):
         a = np.ascontiguousarray(a, dtype=self.dtype)
         if a.nbytes != self.nbytes:
