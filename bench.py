@@ -113,7 +113,6 @@ def main():
     Q0 = (np.random.default_rng(999).random((I, DIM)) / 3).astype(np.float32)  # same on all ranks
     tables = DeviceTables(P0, Q0, np.float32)
     sgd = BprSgd(tables, u, items, CSR(indptr, items))
-    scratch = DeviceBuffer.zeros(1, np.float64)
     total = args.warmup + args.steps
     ev = [(capi.Event(), capi.Event()) for _ in range(total)]
 
@@ -125,19 +124,20 @@ def main():
     state = {"lr": LR0, "last": 0.0, "loss": 0.0}
 
     def step(k: int):
-        sgd.sample_negatives_device(2018, k)                       # BPR.py:35-37
-        sgd.d_loss.fill_bytes(0)
+        sgd.take_prefetched_negatives(k)                            # BPR.py:35-37 (sampled under step k-1)
+        capi._check(capi.load().qrec_memset(sgd.d_stats.ptr, 0, 8, None))
         ev[k][0].record()
         capi.bpr_sgd_hogwild(tables.P, tables.Q, DIM, tables.ld, sgd.d_u, sgd.d_i, sgd.d_j, n, CHUNK, 0,
-                             state["lr"], REG_U, REG_I, sgd.d_loss, args.variant)   # BPR.py:45-53
+                             state["lr"], REG_U, REG_I, sgd.d_stats, args.variant)   # BPR.py:45-53
         ev[k][1].record()
+        sgd.prefetch_negatives_device(2018, k + 1)                  # side stream, under the SGD kernel
         if world > 1:   # replicated item table: sum the ranks' deltas (one all-reduce per step)
             delta = q_view - q_start
             dist.all_reduce(delta)
             q_start.add_(delta)
             q_view.copy_(q_start)
-        sp, sq = tables.sumsq(scratch)                              # BPR.py:40
-        loss = sgd.loss() + REG_U * sp + REG_I * sq
+        nll, sp, sq = sgd.epoch_stats()                             # BPR.py:40; the step's one host sync
+        loss = nll + REG_U * sp + REG_I * sq
         if not np.isfinite(loss):
             raise SystemExit("Loss = NaN or Infinity")            # iterativeRecommender.py:84-86
         # isConverged -> updateLearningRate (iterativeRecommender.py:56-63,96-100)
@@ -152,6 +152,7 @@ def main():
             torch.cuda.synchronize()
         capi.device_sync()
 
+    sgd.prefetch_negatives_device(2018, 0)
     for k in range(args.warmup):
         step(k)
     sync_all()

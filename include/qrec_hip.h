@@ -62,6 +62,8 @@ int qrec_event_create(void **ev);
 int qrec_event_destroy(void *ev);
 int qrec_event_record(void *ev, void *stream);
 int qrec_event_sync(void *ev);
+/* make `stream` wait (on the device) for work recorded in `ev` */
+int qrec_stream_wait_event(void *stream, void *ev);
 int qrec_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms);
 
 /* ---- exact (bit-reproducible) sampler, host side ------------------------------------- *

@@ -40,6 +40,7 @@ _SIGNATURES = {
     "qrec_event_destroy": [_vp],
     "qrec_event_record": [_vp, _vp],
     "qrec_event_sync": [_vp],
+    "qrec_stream_wait_event": [_vp, _vp],
     "qrec_event_elapsed_ms": [_vp, _vp, _vp],
     "qrec_mt_bpr_sample_epoch": [_vp, _vp, _vp, _i32, _i32, _vp],
     "qrec_mt_shuffle": [_vp, _i64, _vp],
@@ -136,6 +137,11 @@ def device_sync():
     _check(load().qrec_device_sync())
 
 
+def stream_wait_event(stream, ev: "Event"):
+    """make `stream` (None = the null stream) wait on the device for `ev`"""
+    _check(load().qrec_stream_wait_event(_sh(stream), ev.handle))
+
+
 class Stream:
     def __init__(self):
         ensure_init()
@@ -145,6 +151,9 @@ class Stream:
 
     def sync(self):
         _check(load().qrec_stream_sync(self.handle))
+
+    def wait_event(self, ev: "Event"):
+        _check(load().qrec_stream_wait_event(self.handle, ev.handle))
 
     def __del__(self):
         try:

@@ -1,21 +1,27 @@
 // Full-table reductions used by the epoch-end loss terms (model/ranking/BPR.py:40:
-// regU*(P*P).sum() + regI*(Q*Q).sum()).  Pure streaming read: HBM-bound, 4 B/element.
+// regU*(P*P).sum() + regI*(Q*Q).sum()).  Pure streaming read: 4 B/element, 16 B per lane per
+// load.  The pad columns [d, ld) of a table are zero by contract (include/qrec_hip.h), so
+// the whole [rows x ld] block is summed without any column test.
 #include "common.h"
 
 using namespace qrec;
 
 namespace {
 
-template <typename T>
-__global__ __launch_bounds__(256) void sumsq_kernel(const T *__restrict__ x, int64_t rows, int d,
-                                                    int ld, double *__restrict__ out) {
-    // one wavefront per row slice keeps the loads coalesced even when ld > d
+template <typename T, typename V4>
+__global__ __launch_bounds__(256) void sumsq_kernel(const T *__restrict__ x, int64_t n_elems,
+                                                    double *__restrict__ out) {
     double acc = 0.0;
-    const int64_t total = rows * (int64_t)ld;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total;
+    const int64_t n4 = n_elems >> 2;
+    const V4 *x4 = reinterpret_cast<const V4 *>(x);
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4;
          k += (int64_t)gridDim.x * blockDim.x) {
-        const int col = (int)(k % ld);
-        if (col < d) { const double v = (double)x[k]; acc += v * v; }
+        const V4 v = x4[k];
+        acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n_elems & 3)) {  // tail (ld is a multiple of 4 for fp32)
+        const double v = (double)x[(n4 << 2) + threadIdx.x];
+        acc += v * v;
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, kWave);
@@ -35,14 +41,16 @@ extern "C" int qrec_sumsq(const void *d_x, int dtype, int64_t rows, int32_t d, i
     QREC_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(double), st));
     if (rows == 0) return QREC_OK;
     QREC_REQUIRE(d_x, "qrec_sumsq: null table");
-    int64_t blocks = (rows * ld + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    const int64_t n = rows * (int64_t)ld;
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
     if (dtype == QREC_F32)
-        hipLaunchKernelGGL(sumsq_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st,
-                           (const float *)d_x, rows, d, ld, d_out);
+        hipLaunchKernelGGL((sumsq_kernel<float, float4>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           (const float *)d_x, n, d_out);
     else
-        hipLaunchKernelGGL(sumsq_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st,
-                           (const double *)d_x, rows, d, ld, d_out);
+        hipLaunchKernelGGL((sumsq_kernel<double, double4>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           (const double *)d_x, n, d_out);
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }

@@ -131,6 +131,11 @@ int qrec_event_sync(void *ev) {
     QREC_HIP_CHECK(hipEventSynchronize((hipEvent_t)ev));
     return QREC_OK;
 }
+int qrec_stream_wait_event(void *stream, void *ev) {
+    QREC_REQUIRE(ev, "qrec_stream_wait_event: null event");
+    QREC_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), (hipEvent_t)ev, 0));
+    return QREC_OK;
+}
 int qrec_event_elapsed_ms(void *a, void *b, float *ms) {
     QREC_REQUIRE(a && b && ms, "qrec_event_elapsed_ms: bad arguments");
     QREC_HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));

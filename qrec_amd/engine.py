@@ -63,7 +63,13 @@ class DeviceTables:
 class BprSgd:
     """One BPR epoch per call over a fixed (u, i) triplet list (user-major PositiveSet
     order, model/ranking/BPR.py:31-34); negatives ``j`` come per epoch either from the
-    host (exact CPython stream) or from the device Philox sampler."""
+    host (exact CPython stream) or from the device Philox sampler.
+
+    Device-side epoch statistics live in one 3-double buffer (sum -log sigma, sum P*P,
+    sum Q*Q) so that an epoch costs a single 24-byte read-back.  The Philox sampler for
+    epoch k+1 runs on a side stream underneath the SGD kernel of epoch k (double-buffered
+    negatives); the SGD kernel is bound by the L2 atomic units, the sampler by integer ALU,
+    so they overlap almost perfectly."""
 
     def __init__(self, tables: DeviceTables, u: np.ndarray, i: np.ndarray, pos: CSR | None = None):
         self.t = tables
@@ -71,8 +77,13 @@ class BprSgd:
         self.d_u = DeviceBuffer.from_numpy(np.ascontiguousarray(u, dtype=np.int32))
         self.d_i = DeviceBuffer.from_numpy(np.ascontiguousarray(i, dtype=np.int32))
         self.d_j = DeviceBuffer(max(self.n, 1), np.int32)
-        self.d_loss = DeviceBuffer.zeros(1, np.float64)
+        self.d_j_next = None
+        self.d_stats = DeviceBuffer.zeros(3, np.float64)
+        self.d_loss = self.d_stats          # element 0
         self._pos_dev = None
+        self._side = None
+        self._sampled = None
+        self._prefetched_epoch = None
         if pos is not None:
             srt = pos.sorted_rows()
             self._pos_dev = (DeviceBuffer.from_numpy(srt.indptr), DeviceBuffer.from_numpy(srt.indices))
@@ -87,24 +98,53 @@ class BprSgd:
         capi.philox_bpr_sample(self._pos_dev[0], self._pos_dev[1], self.d_u, self.n, self.t.n_items,
                                seed, epoch, self.d_j, stream)
 
+    def prefetch_negatives_device(self, seed: int, epoch: int):
+        """Enqueue the sampler for `epoch` on the side stream into the spare buffer."""
+        if self._pos_dev is None:
+            raise RuntimeError("BprSgd was built without the positives CSR")
+        if self._side is None:
+            self._side = capi.Stream(); self._sampled = capi.Event()
+            self.d_j_next = DeviceBuffer(max(self.n, 1), np.int32)
+        capi.philox_bpr_sample(self._pos_dev[0], self._pos_dev[1], self.d_u, self.n, self.t.n_items,
+                               seed, epoch, self.d_j_next, self._side)
+        self._sampled.record(self._side)
+        self._prefetched_epoch = epoch
+
+    def take_prefetched_negatives(self, epoch: int, stream=None):
+        """Make `stream` wait for the prefetched negatives of `epoch` and switch to them."""
+        if self._prefetched_epoch != epoch:
+            raise RuntimeError(f"negatives of epoch {epoch} were not prefetched")
+        capi.stream_wait_event(stream, self._sampled)
+        self.d_j, self.d_j_next = self.d_j_next, self.d_j
+        self._prefetched_epoch = None
+
     # -- epochs ------------------------------------------------------------------------------------
     def epoch_ordered(self, lr: float, regU: float, regI: float, stream=None) -> float:
         """Strictly sequential pass (reference semantics).  Returns sum(-log sigmoid)."""
         capi.bpr_sgd_ordered(self.t.P, self.t.Q, self.t.code, self.t.d, self.t.ld, self.d_u, self.d_i,
-                             self.d_j, self.n, lr, regU, regI, self.d_loss, stream)
-        return float(self.d_loss.numpy(stream)[0])
+                             self.d_j, self.n, lr, regU, regI, self.d_stats, stream)
+        return float(self.d_stats.numpy(stream)[0])
 
     def epoch_throughput_async(self, lr: float, regU: float, regI: float, chunk: int = 32,
                                variant: int = capi.HW_DEFAULT, stream=None):
         """Hogwild pass (fp32 tables); enqueue only -- read the loss with ``loss()``."""
         if self.t.dtype != np.float32:
             raise TypeError("throughput mode needs fp32 tables")
-        self.d_loss.fill_bytes(0, stream)
+        capi._check(capi.load().qrec_memset(self.d_stats.ptr, 0, 8, capi._sh(stream)))
         capi.bpr_sgd_hogwild(self.t.P, self.t.Q, self.t.d, self.t.ld, self.d_u, self.d_i, self.d_j,
-                             self.n, chunk, 0, lr, regU, regI, self.d_loss, variant, stream)
+                             self.n, chunk, 0, lr, regU, regI, self.d_stats, variant, stream)
+
+    def epoch_stats(self, stream=None):
+        """(sum -log sigma, sum P*P, sum Q*Q) after the enqueued epoch -- BPR.py:40,53.
+        One read-back; this is the epoch's only host synchronisation."""
+        t = self.t
+        capi.sumsq(t.P, t.code, t.n_users, t.d, t.ld, self.d_stats.ptr + 8, stream)
+        capi.sumsq(t.Q, t.code, t.n_items, t.d, t.ld, self.d_stats.ptr + 16, stream)
+        s = self.d_stats.numpy(stream)
+        return float(s[0]), float(s[1]), float(s[2])
 
     def loss(self, stream=None) -> float:
-        return float(self.d_loss.numpy(stream)[0])
+        return float(self.d_stats.numpy(stream)[0])
 
 
 class MfSgd:

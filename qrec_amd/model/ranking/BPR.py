@@ -50,9 +50,10 @@ class BPR(IterativeRecommender):
         print("training...")
         tables = DeviceTables(self.P, self.Q, self.table_dtype)
         sgd = BprSgd(tables, u, i, pos)
-        scratch = capi.DeviceBuffer.zeros(1, np.float64)
         n_items = len(self.data.item)
         epoch = 0
+        if self.mode == "throughput":
+            sgd.prefetch_negatives_device(self.sampler_seed, 0)
         while epoch < self.maxEpoch:
             if self.mode == "exact":
                 state = random.getstate()
@@ -60,13 +61,13 @@ class BPR(IterativeRecommender):
                 j = capi.mt_bpr_sample_epoch(words, pos.indptr, pos.indices, n_items)
                 random.setstate(capi.state_to_python(words, state[2]))
                 sgd.set_negatives(j)
-                self.loss = sgd.epoch_ordered(self.lRate, self.regU, self.regI)
+                sgd.epoch_ordered(self.lRate, self.regU, self.regI)
             else:
-                sgd.sample_negatives_device(self.sampler_seed, epoch)
+                sgd.take_prefetched_negatives(epoch)
                 sgd.epoch_throughput_async(self.lRate, self.regU, self.regI)
-                self.loss = sgd.loss()
-            sp, sq = tables.sumsq(scratch)
-            self.loss += self.regU * sp + self.regI * sq
+                sgd.prefetch_negatives_device(self.sampler_seed, epoch + 1)   # overlaps the SGD kernel
+            nll, sp, sq = sgd.epoch_stats()
+            self.loss = nll + self.regU * sp + self.regI * sq
             epoch += 1
             if self.isConverged(epoch):
                 break
