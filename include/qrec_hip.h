@@ -131,6 +131,20 @@ int qrec_mf_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
 int qrec_sumsq(const void *d_x, int dtype, int64_t rows, int32_t d, int32_t ld, double *d_out,
                void *stream);
 
+/* ---- full-rank evaluation: base/recommender.py:143-150 + util/qmath.py:134-146 -------- *
+ * For each of the n_batch_users users (ids into the user table): scores = V . U[user]
+ * (MFMA), scores of the user's rated train items set to 0 (rated CSR over ALL users, may be
+ * NULL), then the reference's find_k_largest: min-heap of (score,id) seeded with the first
+ * N items, strict '>' replacement, stable descending sort -- ties included, so ids are
+ * bit-identical to the reference's.  Outputs [n_batch_users][N] (ids -1 padded when
+ * n_items < N).  d_scratch holds the transposed score block; size it with
+ * qrec_score_topk_scratch_bytes.  N <= 100 as in base/recommender.py:132-134.          */
+int qrec_score_topk_scratch_bytes(int dtype, int32_t n_items, int32_t n_batch_users, int64_t *bytes);
+int qrec_score_topk(const void *d_U, const void *d_V, int dtype, int32_t d, int32_t ld, int32_t n_items,
+                    const int32_t *d_user_ids, int32_t n_batch_users, const int64_t *d_rated_indptr,
+                    const int32_t *d_rated_items, int32_t N, void *d_scratch, int32_t *d_ids_out,
+                    void *d_scores_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

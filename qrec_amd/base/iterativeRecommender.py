@@ -66,6 +66,38 @@ class IterativeRecommender(Recommender):
             return self.Q.dot(self.P[self.data.user[u]])
         return [self.data.globalMean] * self.num_items
 
+    def ranking_tables(self):
+        """(user table, item table) that ``predictForRanking`` multiplies, as host arrays of
+        one float dtype -- numpy-path models score ``Q.dot(P[u])`` in fp64
+        (base/iterativeRecommender.py:75-80), the TF-path ones ``V.dot(U[u])`` in fp32."""
+        if hasattr(self, "U") and hasattr(self, "V"):
+            return self.U, self.V
+        return self.P, self.Q
+
+    def rank_all_test_users(self, N):
+        """The evalRanking inner loop (base/recommender.py:143-150) for all test users at
+        once on the device: MFMA scoring, rated items -> 0, reference heap top-N (ties
+        included).  Users unknown to the training set get the reference's constant-score
+        list (base/iterativeRecommender.py:79-80) on the host."""
+        from ..ranking import DeviceRanker
+        from ..util.qmath import find_k_largest
+        U, V = self.ranking_tables()
+        users = list(self.data.testSet_u)
+        warm = [u for u in users if self.data.containsUser(u)]
+        recList = {}
+        if warm:
+            ranker = DeviceRanker(np.ascontiguousarray(U), np.ascontiguousarray(V), self.data.rated_csr())
+            uid = np.fromiter((self.data.user[u] for u in warm), dtype=np.int32, count=len(warm))
+            ids, scores = ranker.topk(uid, min(N, self.num_items))
+            id2item = self.data.id2item
+            for u, row_i, row_s in zip(warm, ids.tolist(), scores.tolist()):
+                recList[u] = [(id2item[i], s) for i, s in zip(row_i, row_s)]
+        for u in users:
+            if u not in recList:
+                k_ids, k_sc = find_k_largest(N, [self.data.globalMean] * self.num_items)
+                recList[u] = [(self.data.id2item[i], s) for i, s in zip(k_ids, k_sc)]
+        return {u: recList[u] for u in users}   # testSet_u order, as the reference builds it
+
     def shuffle_training_data(self):
         """``shuffle(self.data.trainingData)`` (base/iterativeRecommender.py:101) with the
         exact CPython draw sequence, done natively: a 1.2 M-row list takes ~1 s in

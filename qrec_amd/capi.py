@@ -50,6 +50,8 @@ _SIGNATURES = {
     "qrec_bpr_sgd_hogwild": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _vp, C.c_int, _vp],
     "qrec_mf_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _vp, _vp],
     "qrec_sumsq": [_vp, C.c_int, _i64, _i32, _i32, _vp, _vp],
+    "qrec_score_topk_scratch_bytes": [C.c_int, _i32, _i32, _vp],
+    "qrec_score_topk": [_vp, _vp, C.c_int, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
 }
 _RESTYPES = {"qrec_last_error": C.c_char_p}
 
@@ -333,3 +335,16 @@ def mf_sgd_ordered(d_P, d_Q, dtype: int, d: int, ld: int, d_u, d_i, d_rating, n:
 
 def sumsq(d_x, dtype: int, rows: int, d: int, ld: int, d_out, stream=None):
     _check(load().qrec_sumsq(_dp(d_x), dtype, rows, d, ld, _dp(d_out), _sh(stream)))
+
+
+def score_topk_scratch_bytes(dtype: int, n_items: int, n_batch_users: int) -> int:
+    out = C.c_int64(0)
+    _check(load().qrec_score_topk_scratch_bytes(dtype, n_items, n_batch_users, C.byref(out)))
+    return out.value
+
+
+def score_topk(d_U, d_V, dtype: int, d: int, ld: int, n_items: int, d_user_ids, n_batch_users: int,
+               d_rated_indptr, d_rated_items, N: int, d_scratch, d_ids_out, d_scores_out, stream=None):
+    _check(load().qrec_score_topk(_dp(d_U), _dp(d_V), dtype, d, ld, n_items, _dp(d_user_ids), n_batch_users,
+                                  _dp(d_rated_indptr), _dp(d_rated_items), N, _dp(d_scratch), _dp(d_ids_out),
+                                  _dp(d_scores_out), _sh(stream)))

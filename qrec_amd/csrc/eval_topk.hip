@@ -1,0 +1,318 @@
+// Full-rank evaluation: score every item for a batch of users, mask the user's rated items
+// to 0, keep the N largest -- base/recommender.py:143-150, util/qmath.py:134-146.
+//
+//   (1) score_kernel   S_T[item][b] = V[item] . U[user_ids[b]]       MFMA (the one GEMM on
+//       the path): v_mfma_f32_32x32x2_f32 for fp32 tables, v_mfma_f64_16x16x4_f64 for the
+//       fp64 tables of the numpy-path models.  A wavefront keeps its 32 (16) users' U
+//       fragment in registers and streams item tiles; V (<= tens of MB) is L2/MALL resident.
+//       The block is written TRANSPOSED (item-major) so that step (3) reads coalesced.
+//   (2) mask_kernel    S_T[item][b] = 0 for the user's rated train items -- to ZERO, not -inf:
+//       the reference lets rated items compete with negative scores (recommender.py:147-149).
+//   (3) heap_topk_kernel   one lane per user walks the items in id order and keeps the
+//       reference's min-heap of (score, id) tuples -- CPython heapq's exact sift order,
+//       strict '>' replacement, stable descending sort -- so ties resolve exactly as in the
+//       reference (bit-exact ids).  Per user this is 1 load + 1 compare per item; ~N ln(I/N)
+//       heap updates.
+//
+// Bytes: (1) writes I*B*s, reads V once per user tile from cache; (3) reads I*B*s.
+// FLOPs: 2*B*I*d on the matrix pipe.
+#include "common.h"
+
+using namespace qrec;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// ---- (1) fp32: 32 items x 32 users per MFMA tile, K consumed 2 slots x 32 columns per 64-chunk.
+// lane l: row = l&31, slot h = l>>5 owns columns [64c + 32h, 64c + 32h + 32) of chunk c.
+// (the dot product does not care which physical column sits in which MFMA k-slot as long as
+//  A and B agree.)
+__global__ __launch_bounds__(256) void score_kernel_f32(
+    const float *__restrict__ U, const float *__restrict__ V, int d, int ld, int n_items,
+    const int32_t *__restrict__ user_ids, int n_b, int b_pad, int item_tiles_per_wave,
+    float *__restrict__ S_T) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int utile = blockIdx.x;                       // 32 users
+    const int b = utile * 32 + r;
+    const int uid = (b < n_b) ? user_ids[b] : -1;
+    const int n_chunks = (ld + 63) / 64;                // 64 columns per chunk
+    const int n_item_tiles = (n_items + 31) / 32;
+    const int t_begin = (blockIdx.y * 4 + wave) * item_tiles_per_wave;
+    int t_end = t_begin + item_tiles_per_wave;
+    if (t_end > n_item_tiles) t_end = n_item_tiles;
+    if (t_begin >= t_end) return;
+
+    for (int c = 0; c < n_chunks; c++) {
+        float ub[32];
+        const int col0 = 64 * c + 32 * h;
+#pragma unroll
+        for (int s = 0; s < 32; s++) {
+            const int col = col0 + s;
+            ub[s] = (uid >= 0 && col < d) ? U[(int64_t)uid * ld + col] : 0.f;
+        }
+        for (int t = t_begin; t < t_end; t++) {
+            const int item = t * 32 + r;
+            float va[32];
+#pragma unroll
+            for (int s = 0; s < 32; s++) {
+                const int col = col0 + s;
+                va[s] = (item < n_items && col < d) ? V[(int64_t)item * ld + col] : 0.f;
+            }
+            f32x16 acc;
+            float *out = S_T + (int64_t)(t * 32) * b_pad + utile * 32;
+            if (c == 0) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc[q] = 0.f;
+            } else {  // accumulate across column chunks through the output block
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+                    acc[q] = (t * 32 + row < n_items) ? out[(int64_t)row * b_pad + r] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 32; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s], ub[s], acc, 0, 0, 0);
+            // C/D: col = lane&31 (user), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (item)
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (t * 32 + row < n_items) out[(int64_t)row * b_pad + r] = acc[q];
+            }
+        }
+    }
+}
+
+// ---- (1) fp64: 16 items x 16 users per MFMA tile, 4 slots x 16 columns per 64-chunk.
+__global__ __launch_bounds__(256) void score_kernel_f64(
+    const double *__restrict__ U, const double *__restrict__ V, int d, int ld, int n_items,
+    const int32_t *__restrict__ user_ids, int n_b, int b_pad, int item_tiles_per_wave,
+    double *__restrict__ S_T) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, h = lane >> 4;
+    const int utile = blockIdx.x;                       // 16 users
+    const int b = utile * 16 + r;
+    const int uid = (b < n_b) ? user_ids[b] : -1;
+    const int n_chunks = (ld + 63) / 64;
+    const int n_item_tiles = (n_items + 15) / 16;
+    const int t_begin = (blockIdx.y * 4 + wave) * item_tiles_per_wave;
+    int t_end = t_begin + item_tiles_per_wave;
+    if (t_end > n_item_tiles) t_end = n_item_tiles;
+    if (t_begin >= t_end) return;
+
+    for (int c = 0; c < n_chunks; c++) {
+        double ub[16];
+        const int col0 = 64 * c + 16 * h;
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const int col = col0 + s;
+            ub[s] = (uid >= 0 && col < d) ? U[(int64_t)uid * ld + col] : 0.0;
+        }
+        for (int t = t_begin; t < t_end; t++) {
+            const int item = t * 16 + r;
+            double va[16];
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                const int col = col0 + s;
+                va[s] = (item < n_items && col < d) ? V[(int64_t)item * ld + col] : 0.0;
+            }
+            f64x4 acc;
+            double *out = S_T + (int64_t)(t * 16) * b_pad + utile * 16;
+            if (c == 0) {
+                acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int row = h + 4 * q;
+                    acc[q] = (t * 16 + row < n_items) ? out[(int64_t)row * b_pad + r] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 16; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[s], ub[s], acc, 0, 0, 0);
+            // f64 C/D: col = lane&15 (user), row = (lane>>4) + 4*reg (item)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int row = h + 4 * q;
+                if (t * 16 + row < n_items) out[(int64_t)row * b_pad + r] = acc[q];
+            }
+        }
+    }
+}
+
+// ---- (2) rated train items -> score 0
+template <typename T>
+__global__ __launch_bounds__(256) void mask_kernel(const int32_t *__restrict__ user_ids, int n_b,
+                                                   const int64_t *__restrict__ rated_indptr,
+                                                   const int32_t *__restrict__ rated_items, int b_pad,
+                                                   T *__restrict__ S_T) {
+    // one wavefront per user of the batch
+    const int b = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (b >= n_b) return;
+    const int uid = user_ids[b];
+    const int64_t beg = rated_indptr[uid], end = rated_indptr[uid + 1];
+    for (int64_t e = beg + (threadIdx.x & 63); e < end; e += 64) S_T[(int64_t)rated_items[e] * b_pad + b] = T(0);
+}
+
+// ---- (3) the reference's heap top-K, one lane per user ------------------------------------
+constexpr int kHeapThreads = 64;
+
+template <typename T>
+struct Heap {  // column-per-thread layout in LDS: element k of thread t at [k*64 + t]
+    T *s;
+    int32_t *id;
+    int t;
+    __device__ T S(int k) const { return s[k * kHeapThreads + t]; }
+    __device__ int32_t I(int k) const { return id[k * kHeapThreads + t]; }
+    __device__ void set(int k, T sv, int32_t iv) { s[k * kHeapThreads + t] = sv; id[k * kHeapThreads + t] = iv; }
+};
+
+// Python tuple order on (score, id)
+template <typename T>
+__device__ inline bool tuple_lt(T sa, int32_t ia, T sb, int32_t ib) {
+    return (sa < sb) || (sa == sb && ia < ib);
+}
+
+// heapq._siftdown(heap, startpos, pos)
+template <typename T>
+__device__ inline void sift_down(Heap<T> &hp, int startpos, int pos) {
+    const T ns = hp.S(pos); const int32_t ni = hp.I(pos);
+    while (pos > startpos) {
+        const int parent = (pos - 1) >> 1;
+        const T ps = hp.S(parent); const int32_t pi = hp.I(parent);
+        if (tuple_lt(ns, ni, ps, pi)) { hp.set(pos, ps, pi); pos = parent; continue; }
+        break;
+    }
+    hp.set(pos, ns, ni);
+}
+// heapq._siftup(heap, pos): bubble the smaller child up to a leaf, then sift the item down
+template <typename T>
+__device__ inline void sift_up(Heap<T> &hp, int n, int pos) {
+    const int startpos = pos;
+    const T ns = hp.S(pos); const int32_t ni = hp.I(pos);
+    int child = 2 * pos + 1;
+    while (child < n) {
+        const int right = child + 1;
+        if (right < n && !tuple_lt(hp.S(child), hp.I(child), hp.S(right), hp.I(right))) child = right;
+        hp.set(pos, hp.S(child), hp.I(child));
+        pos = child;
+        child = 2 * pos + 1;
+    }
+    hp.set(pos, ns, ni);
+    sift_down(hp, startpos, pos);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kHeapThreads) void heap_topk_kernel(const T *__restrict__ S_T, int n_items,
+                                                                 int b_pad, int n_b, int K,
+                                                                 int32_t *__restrict__ ids_out,
+                                                                 T *__restrict__ scores_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *hs = reinterpret_cast<T *>(smem);
+    int32_t *hi = reinterpret_cast<int32_t *>(smem + (size_t)K * kHeapThreads * sizeof(T));
+    const int b = blockIdx.x * kHeapThreads + threadIdx.x;
+    if (b >= n_b) return;
+    Heap<T> hp{hs, hi, (int)threadIdx.x};
+    const T *col = S_T + b;
+    const int k = K < n_items ? K : n_items;
+    for (int t = 0; t < k; t++) hp.set(t, col[(int64_t)t * b_pad], t);
+    for (int t = k / 2 - 1; t >= 0; t--) sift_up(hp, k, t);  // heapify
+    T root = hp.S(0);
+    int t = k;
+    // main scan: unrolled by 8 so the loads run ahead of the (rarely taken) heap update
+    for (; t + 8 <= n_items; t += 8) {
+        T v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = col[(int64_t)(t + q) * b_pad];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if (v[q] > root) { hp.set(0, v[q], t + q); sift_up(hp, k, 0); root = hp.S(0); }
+        }
+    }
+    for (; t < n_items; t++) {
+        const T v = col[(int64_t)t * b_pad];
+        if (v > root) { hp.set(0, v, t); sift_up(hp, k, 0); root = hp.S(0); }
+    }
+    // list.sort(key=score, reverse=True): stable insertion sort, descending
+    for (int a = 1; a < k; a++) {
+        const T xs = hp.S(a); const int32_t xi = hp.I(a);
+        int c = a - 1;
+        while (c >= 0 && hp.S(c) < xs) { hp.set(c + 1, hp.S(c), hp.I(c)); c--; }
+        hp.set(c + 1, xs, xi);
+    }
+    for (int a = 0; a < k; a++) {
+        ids_out[(int64_t)b * K + a] = hp.I(a);
+        scores_out[(int64_t)b * K + a] = hp.S(a);
+    }
+    for (int a = k; a < K; a++) { ids_out[(int64_t)b * K + a] = -1; scores_out[(int64_t)b * K + a] = T(0); }
+}
+
+template <typename T>
+int run_score_topk(const void *U, const void *V, int d, int ld, int n_items, const int32_t *user_ids,
+                   int n_b, const int64_t *rated_indptr, const int32_t *rated_items, int K, void *scratch,
+                   int32_t *ids_out, void *scores_out, hipStream_t st) {
+    constexpr int TILE = sizeof(T) == 4 ? 32 : 16;
+    const int b_pad = (n_b + 63) / 64 * 64;
+    const int n_utiles = (n_b + TILE - 1) / TILE;
+    const int n_item_tiles = (n_items + TILE - 1) / TILE;
+    // enough waves to fill 256 CUs x 4 SIMDs a few times over, each streaming >= 8 item tiles
+    int splits = (4096 + n_utiles - 1) / n_utiles;          // item-range splits per user tile, in waves
+    int per_wave = (n_item_tiles + splits - 1) / splits;
+    if (per_wave < 8) per_wave = n_item_tiles < 8 ? n_item_tiles : 8;
+    const int waves_per_utile = (n_item_tiles + per_wave - 1) / per_wave;
+    const dim3 grid((unsigned)n_utiles, (unsigned)((waves_per_utile + 3) / 4));
+    T *S_T = static_cast<T *>(scratch);
+    if constexpr (sizeof(T) == 4)
+        hipLaunchKernelGGL(score_kernel_f32, grid, dim3(256), 0, st, (const float *)U, (const float *)V, d, ld,
+                           n_items, user_ids, n_b, b_pad, per_wave, S_T);
+    else
+        hipLaunchKernelGGL(score_kernel_f64, grid, dim3(256), 0, st, (const double *)U, (const double *)V, d, ld,
+                           n_items, user_ids, n_b, b_pad, per_wave, S_T);
+    QREC_LAUNCH_CHECK();
+    if (rated_indptr) {
+        hipLaunchKernelGGL(mask_kernel<T>, dim3((unsigned)((n_b + 3) / 4)), dim3(256), 0, st, user_ids, n_b,
+                           rated_indptr, rated_items, b_pad, S_T);
+        QREC_LAUNCH_CHECK();
+    }
+    const size_t lds = (size_t)K * kHeapThreads * (sizeof(T) + sizeof(int32_t));
+    QREC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&heap_topk_kernel<T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(heap_topk_kernel<T>, dim3((unsigned)((n_b + kHeapThreads - 1) / kHeapThreads)),
+                       dim3(kHeapThreads), lds, st, S_T, n_items, b_pad, n_b, K, ids_out, (T *)scores_out);
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qrec_score_topk_scratch_bytes(int dtype, int32_t n_items, int32_t n_batch_users, int64_t *bytes) {
+    QREC_REQUIRE(bytes && n_items >= 0 && n_batch_users >= 0, "qrec_score_topk_scratch_bytes: bad arguments");
+    QREC_REQUIRE(dtype == QREC_F32 || dtype == QREC_F64, "qrec_score_topk_scratch_bytes: bad dtype %d", dtype);
+    const int64_t b_pad = ((int64_t)n_batch_users + 63) / 64 * 64;
+    const int64_t rows = ((int64_t)n_items + 31) / 32 * 32;
+    *bytes = rows * b_pad * (dtype == QREC_F64 ? 8 : 4);
+    return QREC_OK;
+}
+
+int qrec_score_topk(const void *d_U, const void *d_V, int dtype, int32_t d, int32_t ld, int32_t n_items,
+                    const int32_t *d_user_ids, int32_t n_batch_users, const int64_t *d_rated_indptr,
+                    const int32_t *d_rated_items, int32_t K, void *d_scratch, int32_t *d_ids_out,
+                    void *d_scores_out, void *stream) {
+    QREC_REQUIRE(d_U && d_V && d_user_ids && d_scratch && d_ids_out && d_scores_out, "qrec_score_topk: null argument");
+    QREC_REQUIRE(dtype == QREC_F32 || dtype == QREC_F64, "qrec_score_topk: bad dtype %d", dtype);
+    QREC_REQUIRE(d >= 1 && ld >= d && n_items >= 1 && n_batch_users >= 0, "qrec_score_topk: bad sizes");
+    QREC_REQUIRE(K >= 1 && K <= 100, "qrec_score_topk: N must be in 1..100 (base/recommender.py:132-134)");
+    QREC_REQUIRE((d_rated_indptr == nullptr) == (d_rated_items == nullptr), "qrec_score_topk: rated CSR incomplete");
+    if (n_batch_users == 0) return QREC_OK;
+    hipStream_t st = as_stream(stream);
+    return dtype == QREC_F64
+               ? run_score_topk<double>(d_U, d_V, d, ld, n_items, d_user_ids, n_batch_users, d_rated_indptr,
+                                        d_rated_items, K, d_scratch, d_ids_out, d_scores_out, st)
+               : run_score_topk<float>(d_U, d_V, d, ld, n_items, d_user_ids, n_batch_users, d_rated_indptr,
+                                       d_rated_items, K, d_scratch, d_ids_out, d_scores_out, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+"""GPU parity tests of full-rank evaluation (MFMA scoring + mask-to-0 + heap top-N)."""
+import numpy as np
+import pytest
+
+from oracle import c as O
+from qrec_amd import capi
+from qrec_amd.interactions import CSR, user_item_csr
+from qrec_amd.ranking import DeviceRanker
+
+from helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    capi.init(0)
+    yield
+
+
+def _oracle_topk(U, V, rated, users, N):
+    ids = np.empty((len(users), N), np.int32); sc = np.empty((len(users), N), np.float64)
+    for r, u in enumerate(users):
+        cand = (V.astype(np.float64) @ U[u].astype(np.float64)) if U.dtype == np.float64 else (V @ U[u]).astype(np.float64)
+        if rated is not None:
+            cand[rated.indices[rated.indptr[u]:rated.indptr[u + 1]]] = 0
+        i, s = O.find_k_largest(N, cand)
+        ids[r, :i.size] = i; sc[r, :s.size] = s
+    return ids, sc
+
+
+def test_reference_reclists_fp64():
+    """The reference's own recommendation lists (FilmTrust run) from its final P, Q."""
+    meta, z = load_golden("bpr_filmtrust")
+    last = len(meta["epochs"])
+    P, Q = z[f"P{last}"], z[f"Q{last}"]
+    rated = user_item_csr(z["train_uid"], z["train_iid"], z["train_r"], meta["n_users"], meta["n_items"])
+    ok = z["rec_users"] >= 0
+    users = z["rec_users"][ok]
+    ids, sc = DeviceRanker(P, Q, rated).topk(users, z["rec_ids"].shape[1])
+    assert np.array_equal(ids, z["rec_ids"][ok])
+    np.testing.assert_allclose(sc, z["rec_scores"][ok], rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(70, 33, 8), (300, 1000, 64), (129, 257, 50), (64, 40, 128), (40, 20, 200)])
+def test_ties_negative_scores_and_masked_zeros(dtype, shape):
+    """Small-integer embeddings: scores are exact integers in every precision, so ties are
+    everywhere, many scores are negative (masked zeros outrank them) -- the id lists must
+    still be bit-identical to the reference's heap procedure."""
+    n_users, n_items, d = shape
+    rng = np.random.default_rng(n_users * 7 + d)
+    U = rng.integers(-2, 3, (n_users, d)).astype(dtype); V = rng.integers(-2, 3, (n_items, d)).astype(dtype)
+    uu = rng.integers(0, n_users, 4 * n_users); ii = rng.integers(0, n_items, 4 * n_users)
+    rated = user_item_csr(uu, ii, np.ones(uu.size), n_users, n_items)
+    users = np.arange(n_users, dtype=np.int32)
+    for N in (1, 10, 20, 100):
+        k = min(N, n_items)
+        ids, sc = DeviceRanker(U, V, rated).topk(users, k)
+        oi, os_ = _oracle_topk(U, V, rated, users, k)
+        assert np.array_equal(ids, oi), (dtype, shape, N)
+        assert np.array_equal(sc.astype(np.float64), os_)
+
+
+def test_random_embeddings_fp32_within_tolerance_and_no_mask():
+    rng = np.random.default_rng(5)
+    U = rng.standard_normal((500, 64)).astype(np.float32); V = rng.standard_normal((3000, 64)).astype(np.float32)
+    users = rng.permutation(500)[:333].astype(np.int32)       # ragged batch, arbitrary order
+    ids, sc = DeviceRanker(U, V, None).topk(users, 20)
+    ref = V.astype(np.float64) @ U[users].astype(np.float64).T           # [items, users]
+    for r in range(users.size):
+        col = ref[:, r]
+        np.testing.assert_allclose(sc[r], col[ids[r]], rtol=1e-5, atol=1e-5)   # scores are the items' scores
+        assert (np.diff(sc[r]) <= 0).all()
+        kth = np.sort(col)[-20]
+        assert (col[ids[r]] >= kth - 1e-4).all()                               # and they are the top 20
+    with pytest.raises(ValueError):
+        DeviceRanker(U, V, None).topk(np.array([500], np.int32), 5)
+    assert DeviceRanker(U, V, None).topk(np.zeros(0, np.int32), 5)[0].shape == (0, 5)
+
+
+def test_yelp_shape_full_eval_properties():
+    """Eval at the bench shape: 31,668 users x 38,048 items, d=64, N=20 (154 GFLOP)."""
+    from qrec_amd.synth import make_dataset, to_csr
+    d = make_dataset("yelp2018")
+    U_, I_ = d["n_users"], d["n_items"]
+    rng = np.random.default_rng(1)
+    U = (rng.random((U_, 64)) / 3 - 0.1).astype(np.float32); V = (rng.random((I_, 64)) / 3 - 0.1).astype(np.float32)
+    indptr, ind = to_csr(U_, d["train_u"], d["train_i"])
+    rated = CSR(indptr, ind)
+    users = np.arange(U_, dtype=np.int32)
+    ids, sc = DeviceRanker(U, V, rated).topk(users, 20)
+    assert ids.shape == (U_, 20) and (ids >= 0).all() and (ids < I_).all()
+    assert (np.diff(sc, axis=1) <= 0).all()
+    # spot-check 200 users against the oracle procedure on fp32 scores recomputed in fp64
+    pick = rng.permutation(U_)[:200]
+    for u in pick:
+        col = V.astype(np.float64) @ U[u].astype(np.float64)
+        col[ind[indptr[u]:indptr[u + 1]]] = 0
+        np.testing.assert_allclose(sc[u], col[ids[u]], rtol=2e-5, atol=2e-6)
+        assert (col[ids[u]] >= np.sort(col)[-20] - 1e-5).all()
+    # a rated item can only appear with score exactly 0
+    for u in pick[:50]:
+        r = set(ind[indptr[u]:indptr[u + 1]].tolist())
+        for i, s in zip(ids[u], sc[u]):
+            assert (i not in r) or s == 0.0
