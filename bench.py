@@ -54,28 +54,53 @@ def bytes_per_triplet(d: int) -> int:
     return 6 * d * 4 + 12
 
 
-def cpu_baseline(u, i, indptr, n_items, U, seconds=12.0):
-    """The same epoch on the host: oracle sampler (CPython MT19937 replay) + the plain-C
-    fp64 restatement of BPR.optimization, single thread, repeated for ~`seconds`."""
+def recall_at_n(ids: np.ndarray, users: np.ndarray, test_u: np.ndarray, test_i: np.ndarray, n_items: int) -> float:
+    """util/measure.py:106-109: mean over test users of |top-N ∩ test items| / |test items|."""
+    test_keys = np.unique(test_u.astype(np.int64) * n_items + test_i)
+    rec_keys = (users.astype(np.int64)[:, None] * n_items + ids).ravel()
+    hit = np.isin(rec_keys, test_keys).reshape(ids.shape).sum(1)
+    cnt = np.bincount(test_u, minlength=int(users.max()) + 1)[users]
+    return float((hit / cnt).mean())
+
+
+def evaluate_recall(P, Q, data, indptr, items, N=20):
+    """Recall@N of (P, Q) on the held-out edges through the product's device ranker."""
+    from qrec_amd.ranking import DeviceRanker
+    users = np.unique(data["test_u"]).astype(np.int32)
+    ids, _ = DeviceRanker(np.ascontiguousarray(P, dtype=np.float32), np.ascontiguousarray(Q, dtype=np.float32),
+                          CSR(indptr, items)).topk(users, N)
+    return recall_at_n(ids, users, data["test_u"], data["test_i"], data["n_items"])
+
+
+def cpu_baseline(u, i, indptr, n_items, U, P0, Q0, epochs_like_gpu, seconds=12.0):
+    """The same epochs on the host: oracle sampler (CPython MT19937 replay) + the plain-C fp64
+    restatement of BPR.optimization + the bold-driver schedule, single thread.  It first runs
+    exactly as many epochs as the GPU did from the same initial tables (its result is the
+    Recall@20 reference), then keeps going until ~`seconds` of CPU work are timed."""
     from oracle import c as O
-    rng = np.random.default_rng(0)
-    P = rng.random((U, DIM)) / 3
-    Q = rng.random((n_items, DIM)) / 3
+    P, Q = P0.astype(np.float64), Q0.astype(np.float64)
     mt = O.MT.cpython_seed(0)
-    done, t0 = 0, time.perf_counter()
-    epochs = 0
+    lr, last = LR0, 0.0
+    done, epochs, t0 = 0, 0, time.perf_counter()
+    snap = None
     while True:
         j = O.bpr_sample_epoch(mt, indptr, i, n_items)
-        O.bpr_sgd(P, Q, u, i, j, LR0, REG_U, REG_I)
-        O.sumsq(P); O.sumsq(Q)
+        loss = O.bpr_sgd(P, Q, u, i, j, lr, REG_U, REG_I) + REG_U * O.sumsq(P) + REG_I * O.sumsq(Q)
+        if epochs > 0:
+            lr *= 1.05 if abs(last) > abs(loss) else 0.5
+        lr = min(lr, MAX_LR); last = loss
         done += u.size; epochs += 1
-        if time.perf_counter() - t0 >= seconds:
+        if epochs == epochs_like_gpu:
+            snap = (P.copy(), Q.copy(), loss)
+        if epochs >= epochs_like_gpu and time.perf_counter() - t0 >= seconds:
             break
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "triplet-updates/s", "cores": 1, "kind": "port",
-            "sample": f"{epochs} full epochs ({done} triplets, {dt:.1f} s) of the same Yelp2018-shape workload; "
-                      "plain-C fp64 port of model/ranking/BPR.py:29-53 incl. the CPython-stream sampler "
-                      "(the Python reference itself cannot travel to this box; it measured 58.9k/s on 1 core, BASELINE.md)"}
+    out = {"value": done / dt, "unit": "triplet-updates/s", "cores": 1, "kind": "port",
+           "sample": f"{epochs} full epochs ({done} triplets, {dt:.1f} s) of the same Yelp2018-shape workload; "
+                     "plain-C fp64 port of model/ranking/BPR.py:29-53 incl. the CPython-stream sampler and the "
+                     "bold-driver schedule (the Python reference itself cannot travel to this box; it measured "
+                     "58.9k/s on 1 core, BASELINE.md)"}
+    return out, snap
 
 
 def main():
@@ -95,11 +120,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     dist = torch = None
-    if world > 1:
+    # QREC_FORCE_DIST=1 drives the torch.distributed/RCCL branch with world size 1 (the gpurun
+    # boxes have one GPU): same code path as N>1, the all-reduce degenerates to a copy.
+    use_dist = world > 1 or os.environ.get("QREC_FORCE_DIST") == "1"
+    if use_dist:
         import torch
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     capi.init(local_rank)
 
     # ---- workload: resident in HBM before timing ------------------------------------------
@@ -116,10 +146,10 @@ def main():
     total = args.warmup + args.steps
     ev = [(capi.Event(), capi.Event()) for _ in range(total)]
 
-    q_view = q_start = None
-    if world > 1:
-        q_view = torch.as_tensor(tables.Q, device=torch.device("cuda", local_rank))
-        q_start = q_view.clone()
+    q_sync = None
+    if use_dist:   # replicated item table, reconciled once per step (qrec_amd/dist.py)
+        from qrec_amd.dist import ReplicatedTableSync
+        q_sync = ReplicatedTableSync(torch.as_tensor(tables.Q, device=torch.device("cuda", local_rank)))
 
     state = {"lr": LR0, "last": 0.0, "loss": 0.0}
 
@@ -131,11 +161,8 @@ def main():
                              state["lr"], REG_U, REG_I, sgd.d_stats, args.variant)   # BPR.py:45-53
         ev[k][1].record()
         sgd.prefetch_negatives_device(2018, k + 1)                  # side stream, under the SGD kernel
-        if world > 1:   # replicated item table: sum the ranks' deltas (one all-reduce per step)
-            delta = q_view - q_start
-            dist.all_reduce(delta)
-            q_start.add_(delta)
-            q_view.copy_(q_start)
+        if q_sync is not None:   # sum the ranks' Q deltas: the path's one collective (RCCL all-reduce)
+            q_sync.sync()
         nll, sp, sq = sgd.epoch_stats()                             # BPR.py:40; the step's one host sync
         loss = nll + REG_U * sp + REG_I * sq
         if not np.isfinite(loss):
@@ -147,7 +174,7 @@ def main():
         state["last"] = state["loss"] = loss
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
         capi.device_sync()
@@ -161,7 +188,7 @@ def main():
         step(k)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -197,10 +224,19 @@ def main():
                                  "resource is the L2 atomic units (~1 dword/clk/channel), see DESIGN.md"},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(u, items, indptr, I, U)
-            out["vs_cpu_port"] = value / out["cpu_baseline"]["value"]
+            cpu, snap = cpu_baseline(u, items, indptr, I, U, P0, Q0, total)
+            out["cpu_baseline"] = cpu
+            out["vs_cpu_port"] = value / cpu["value"]
+            # Recall@20 (the metric's second half): GPU throughput mode vs the order-exact CPU port,
+            # same initial tables, same number of epochs, same schedule; both ranked on the device.
+            Pg, Qg = tables.download(np.float32)
+            r_gpu = evaluate_recall(Pg, Qg, data, indptr, items)
+            r_cpu = evaluate_recall(snap[0], snap[1], data, indptr, items)
+            out["recall_at_20"] = {"gpu_throughput_mode": r_gpu, "cpu_port_exact_order": r_cpu,
+                                   "abs_diff": abs(r_gpu - r_cpu), "epochs": total,
+                                   "final_loss_gpu": state["loss"], "final_loss_cpu": snap[2]}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -108,7 +108,8 @@ int qrec_bpr_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
  * one 16-lane (d<=64) / 32-lane (d<=128) group owns a chunk, keeps P[u] in registers
  * along a user run, and applies every row update as an atomic add of the exact
  * per-sample delta, so no update is lost; concurrent chunks read rows that may lag by
- * the in-flight updates (Hogwild).  With grid_groups==1 the kernel degenerates to the
+ * the in-flight updates (Hogwild).  grid_groups = number of groups in flight (0 = library
+ * default: one 256-thread block per CU); with grid_groups==1 the kernel degenerates to the
  * sequential recurrence.  *d_loss (double) is ACCUMULATED into (zero it first).
  * `variant` selects the memory policy (QREC_HW_*), 0 = library default.                  */
 #define QREC_HW_DEFAULT 0

@@ -256,3 +256,62 @@ def test_sumsq_and_runtime_errors():
         capi._check(capi.load().qrec_init(99))
     with pytest.raises(capi.QRecError):   # hogwild refuses a row stride it has no lane mapping for
         capi.bpr_sgd_hogwild(buf, buf, 50, 50, buf, buf, buf, 10, 16, 0, 0.1, 0.0, 0.0, out)
+
+
+@pytest.mark.parametrize("lr0", [0.01, 0.05])
+def test_throughput_mode_recall_matches_exact_order_training(lr0):
+    """north_star: Recall@20 within +-0.002 of the reference.  Same data, same initial tables,
+    same epochs and LR schedule: order-exact fp64 training (CPU port with the CPython-stream
+    sampler) vs the GPU throughput mode (Philox sampler + Hogwild kernel); both evaluated by the
+    device ranker on the held-out edges of the Yelp2018-shape set."""
+    from qrec_amd.interactions import CSR
+    from qrec_amd.ranking import DeviceRanker
+    d = make_dataset("yelp2018")
+    U, I, dim, epochs = d["n_users"], d["n_items"], 64, 12
+    indptr, ind = to_csr(U, d["train_u"], d["train_i"])
+    u = np.repeat(np.arange(U, dtype=np.int32), np.diff(indptr)).astype(np.int32)
+    rng = np.random.default_rng(3)
+    P0 = (rng.random((U, dim)) / 3).astype(np.float32); Q0 = (rng.random((I, dim)) / 3).astype(np.float32)
+    reg = 0.001          # lr0 = 0.01 is config/BPR.conf's -init; 0.05 stresses Hogwild staleness
+
+    def schedule(lr, k, last, loss):
+        if k > 0:
+            lr *= 1.05 if abs(last) > abs(loss) else 0.5
+        return min(lr, 1.0)
+
+    # exact order on the host
+    Pc, Qc = P0.astype(np.float64), Q0.astype(np.float64)
+    mt = O.MT.cpython_seed(0); lr, last = lr0, 0.0
+    for k in range(epochs):
+        j = O.bpr_sample_epoch(mt, indptr, ind, I)
+        loss = O.bpr_sgd(Pc, Qc, u, ind, j, lr, reg, reg) + reg * O.sumsq(Pc) + reg * O.sumsq(Qc)
+        lr = schedule(lr, k, last, loss); last = loss
+    loss_cpu = last
+    # throughput mode on the device
+    t = DeviceTables(P0, Q0, np.float32)
+    sgd = BprSgd(t, u, ind, CSR(indptr, ind)); lr, last = lr0, 0.0
+    sgd.prefetch_negatives_device(7, 0)
+    for k in range(epochs):
+        sgd.take_prefetched_negatives(k)
+        sgd.epoch_throughput_async(lr, reg, reg)
+        sgd.prefetch_negatives_device(7, k + 1)
+        nll, sp, sq = sgd.epoch_stats()
+        loss = nll + reg * sp + reg * sq
+        lr = schedule(lr, k, last, loss); last = loss
+    Pg, Qg = t.download(np.float32)
+    print('loss exact-order', loss_cpu, 'throughput', last)
+    assert abs(last - loss_cpu) / loss_cpu < 0.05     # same optimisation trajectory
+
+    users = np.unique(d["test_u"]).astype(np.int32)
+    test_keys = np.unique(d["test_u"].astype(np.int64) * I + d["test_i"])
+    cnt = np.bincount(d["test_u"], minlength=U)[users]
+
+    def recall(P, Q):
+        ids, _ = DeviceRanker(np.ascontiguousarray(P, np.float32), np.ascontiguousarray(Q, np.float32), CSR(indptr, ind)).topk(users, 20)
+        hit = np.isin((users.astype(np.int64)[:, None] * I + ids).ravel(), test_keys).reshape(ids.shape).sum(1)
+        return float((hit / cnt).mean())
+
+    r_cpu, r_gpu = recall(Pc, Qc), recall(Pg, Qg)
+    print("Recall@20 exact-order", r_cpu, "throughput", r_gpu)
+    assert r_cpu > 0.01                                 # the model learned something
+    assert abs(r_cpu - r_gpu) <= 0.002
