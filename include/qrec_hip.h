@@ -132,6 +132,39 @@ int qrec_mf_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
 int qrec_sumsq(const void *d_x, int dtype, int64_t rows, int32_t d, int32_t ld, double *d_out,
                void *stream);
 
+/* ---- graph recommenders (LightGCN family), TF-1.14 op semantics ----------------------- */
+
+/* tf.sparse_tensor_dense_matmul(norm_adj, X) (model/ranking/LightGCN.py:17, NGCF.py:28,
+ * SimGCL.py:25,33):  Y = A X  [+ addend_scale * addend]  and, if d_accum, accum += Y (the
+ * running layer sum of LightGCN.py:19).  A is CSR (d_indices/d_values) cut by the host into
+ * SEGMENTS of at most a few hundred non-zeros so that heavy rows do not serialise:
+ * segment s covers non-zeros [seg_beg, seg_beg+seg_len) of row seg_row; seg_slot < 0 means
+ * "the whole row, write Y directly", otherwise the partial sum goes to scratch slot
+ * seg_slot of d_partial and long row k (long_row[k]) is the in-order sum of its
+ * long_count[k] slots starting at long_first[k].  X, Y, addend, accum: [rows][ld] fp32,
+ * ld in {32,64,128,256}.  Deterministic (no float atomics).                            */
+int qrec_spmm_csr(const int32_t *d_seg_row, const int64_t *d_seg_beg, const int32_t *d_seg_len,
+                  const int32_t *d_seg_slot, int64_t n_segs, const int32_t *d_long_row,
+                  const int32_t *d_long_first, const int32_t *d_long_count, int32_t n_long,
+                  const int32_t *d_indices, const float *d_values, const float *d_X, float *d_Y,
+                  float *d_partial, int32_t ld, const float *d_addend, float addend_scale, float *d_accum,
+                  void *stream);
+
+/* embedding_lookup x3 + util/loss.py:3-6 bpr_loss + the batch l2 term and all their gradients
+ * (LightGCN.py:22-30): rows are S[row]/div (div = n_layers+1 folds the layer mean in), users
+ * at rows [0,n_users), items at n_users+id.  dE (pre-zeroed, [n_rows][ld]) receives the
+ * scatter-added row gradients; *d_loss (double) is ACCUMULATED into.                    */
+int qrec_bpr_batch_loss_grad(const float *d_S, float div, int32_t n_users, int64_t n_rows, int32_t ld,
+                             const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int32_t B, float eps,
+                             float reg, float *d_dE, double *d_loss, void *stream);
+
+/* tf.train.AdamOptimizer dense update (LightGCN.py:31-32) in TF 1.14's ApplyAdam form, fp32,
+ * with g = grad_scale * d_grad:  m += (g-m)(1-beta1); v += (g*g-v)(1-beta2);
+ * theta -= (m*alpha)/(sqrt(v)+eps).  alpha = lr*sqrt(1-beta2^t)/(1-beta1^t) is supplied by
+ * the host, which keeps the fp32 beta powers like TF does.                               */
+int qrec_adam_step(float *d_theta, float *d_m, float *d_v, const float *d_grad, int64_t n_elems, float grad_scale,
+                   float alpha, float beta1, float beta2, float eps, void *stream);
+
 /* ---- full-rank evaluation: base/recommender.py:143-150 + util/qmath.py:134-146 -------- *
  * For each of the n_batch_users users (ids into the user table): scores = V . U[user]
  * (MFMA), scores of the user's rated train items set to 0 (rated CSR over ALL users, may be

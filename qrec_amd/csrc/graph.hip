@@ -1,0 +1,277 @@
+// Graph-recommender kernels (LightGCN family): the TF-1.14 ops the reference strings together in
+// model/ranking/LightGCN.py:11-41, as hand-written gfx950 kernels.
+//
+//   spmm_kernel            tf.sparse_tensor_dense_matmul(norm_adj, E)         LightGCN.py:17
+//   bpr_batch_kernel       embedding_lookup x3 + bpr_loss + batch l2_loss and their gradients
+//                          (scatter-add of the lookups' backward)  LightGCN.py:22-30, util/loss.py:3-6
+//   adam_kernel            tf.train.AdamOptimizer.apply_gradients (dense)        LightGCN.py:31-32
+//
+// All HBM/L2-bandwidth bound (<= 0.5 FLOP/B): no MFMA here by design.
+#include "common.h"
+
+using namespace qrec;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// CSR SpMM  Y = A X  (+ addend_scale * addend) ; optionally accum += Y.
+// One group of LPR lanes (float4 per lane -> one whole row of ld = 4*LPR floats per group per
+// load) walks one SEGMENT: a row, or a <= seg_len slice of a long row (the adjacency of an
+// implicit-feedback graph is heavy-tailed: 6k-neighbour items next to 35-neighbour averages).
+// A slice writes its partial sum to a scratch slot; a second tiny kernel adds a long row's
+// partials in slice order, so the result is deterministic (no float atomics).
+// (col, val) pairs are fetched LPR at a time with one coalesced load per lane and broadcast
+// inside the group; the gathers of X rows are independent and issued 4 deep.
+// Products and sums are not contracted: the scipy/TF CPU kernels round a*x and the add apart.
+// Algorithmic bytes: nnz*(4+4) + 8*(rows+1) + 2*rows*d*4; the gathered operand
+// (nnz*d*4 B of L2/MALL traffic) is reported separately.
+// ---------------------------------------------------------------------------------------
+template <int LPR>
+__device__ inline f32x4 ld_row4(const float *__restrict__ X, int row, int r) {
+    return *reinterpret_cast<const f32x4 *>(X + (int64_t)row * (4 * LPR) + 4 * r);
+}
+
+template <int LPR>
+__device__ inline void spmm_epilogue(f32x4 acc, int row, int r, float *__restrict__ Y,
+                                     const float *__restrict__ addend, float addend_scale,
+                                     float *__restrict__ accum) {
+#pragma clang fp contract(off)
+    const int64_t off = (int64_t)row * (4 * LPR) + 4 * r;
+    if (addend) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(addend + off);
+        acc = acc + addend_scale * a;
+    }
+    *reinterpret_cast<f32x4 *>(Y + off) = acc;
+    if (accum) {
+        f32x4 s = *reinterpret_cast<const f32x4 *>(accum + off);
+        s = s + acc;
+        *reinterpret_cast<f32x4 *>(accum + off) = s;
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_kernel(
+    const int32_t *__restrict__ seg_row, const int64_t *__restrict__ seg_beg,
+    const int32_t *__restrict__ seg_len, const int32_t *__restrict__ seg_slot, int64_t n_segs,
+    const int32_t *__restrict__ indices, const float *__restrict__ values,
+    const float *__restrict__ X, float *__restrict__ Y, float *__restrict__ partial,
+    const float *__restrict__ addend, float addend_scale, float *__restrict__ accum) {
+#pragma clang fp contract(off)
+    constexpr int GPW = kWave / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
+    const int64_t gid = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
+    const int64_t n_groups = (int64_t)gridDim.x * 4 * GPW;
+    for (int64_t s = gid; s < n_segs; s += n_groups) {
+        const int64_t beg = seg_beg[s];
+        const int len = seg_len[s];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int e0 = 0; e0 < len; e0 += LPR) {
+            const int mine = e0 + r;
+            const int my_c = mine < len ? indices[beg + mine] : 0;
+            const float my_v = mine < len ? values[beg + mine] : 0.f;
+            const int cnt = (len - e0) < LPR ? (len - e0) : LPR;
+            int k = 0;
+            for (; k + 4 <= cnt; k += 4) {
+                const int c0 = __shfl(my_c, g * LPR + k, kWave), c1 = __shfl(my_c, g * LPR + k + 1, kWave);
+                const int c2 = __shfl(my_c, g * LPR + k + 2, kWave), c3 = __shfl(my_c, g * LPR + k + 3, kWave);
+                const float v0 = __shfl(my_v, g * LPR + k, kWave), v1 = __shfl(my_v, g * LPR + k + 1, kWave);
+                const float v2 = __shfl(my_v, g * LPR + k + 2, kWave), v3 = __shfl(my_v, g * LPR + k + 3, kWave);
+                const f32x4 x0 = ld_row4<LPR>(X, c0, r), x1 = ld_row4<LPR>(X, c1, r);
+                const f32x4 x2 = ld_row4<LPR>(X, c2, r), x3 = ld_row4<LPR>(X, c3, r);
+                acc = acc + v0 * x0; acc = acc + v1 * x1; acc = acc + v2 * x2; acc = acc + v3 * x3;
+            }
+            for (; k < cnt; k++) {
+                const int c = __shfl(my_c, g * LPR + k, kWave);
+                const float v = __shfl(my_v, g * LPR + k, kWave);
+                acc = acc + v * ld_row4<LPR>(X, c, r);
+            }
+        }
+        const int slot = seg_slot[s];
+        if (slot < 0) spmm_epilogue<LPR>(acc, seg_row[s], r, Y, addend, addend_scale, accum);
+        else *reinterpret_cast<f32x4 *>(partial + (int64_t)slot * (4 * LPR) + 4 * r) = acc;
+    }
+}
+
+// long rows: Y[row] = partial[first] + partial[first+1] + ... (slice order), then the epilogue
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restrict__ long_row,
+                                                         const int32_t *__restrict__ long_first,
+                                                         const int32_t *__restrict__ long_count, int n_long,
+                                                         const float *__restrict__ partial, float *__restrict__ Y,
+                                                         const float *__restrict__ addend, float addend_scale,
+                                                         float *__restrict__ accum) {
+#pragma clang fp contract(off)
+    constexpr int GPW = kWave / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
+    const int64_t gid = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
+    if (gid >= n_long) return;
+    const int first = long_first[gid], cnt = long_count[gid];
+    f32x4 acc = *reinterpret_cast<const f32x4 *>(partial + (int64_t)first * (4 * LPR) + 4 * r);
+    for (int k = 1; k < cnt; k++)
+        acc = acc + *reinterpret_cast<const f32x4 *>(partial + (int64_t)(first + k) * (4 * LPR) + 4 * r);
+    spmm_epilogue<LPR>(acc, long_row[gid], r, Y, addend, addend_scale, accum);
+}
+
+// ---------------------------------------------------------------------------------------
+// Batch BPR loss + gradients.  Per triplet b (a group of LPR lanes; lane r holds columns
+// r, r+LPR, ... so that every atomic covers one contiguous 4*LPR-byte segment -- see
+// bpr_sgd.hip):
+//   ub = S[u]/div, ib = S[nu+i]/div, jb = S[nu+j]/div            (mean over layers folded in)
+//   score = ub.ib - ub.jb ; s = sigmoid(score)
+//   loss += -log(s + eps) + reg/2 * (|ub|^2 + |ib|^2 + |jb|^2)
+//   g = -s(1-s)/(s+eps)
+//   dE[u] += g (ib - jb) + reg ub ;  dE[nu+i] += g ub + reg ib ;  dE[nu+j] += -g ub + reg jb
+// Bytes: 3 rows read + 3 rows of atomics per triplet.
+// ---------------------------------------------------------------------------------------
+template <int LPR, int E>
+__global__ __launch_bounds__(256) void bpr_batch_kernel(
+    const float *__restrict__ S, float div, int n_users, const int32_t *__restrict__ u_idx,
+    const int32_t *__restrict__ i_idx, const int32_t *__restrict__ j_idx, int B, float eps, float reg,
+    float *__restrict__ dE, uint32_t de_bytes, double *__restrict__ loss_out) {
+    constexpr int GPW = kWave / LPR;
+    constexpr int LD = LPR * E;
+    const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
+    const int64_t gid = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
+    const int64_t n_groups = (int64_t)gridDim.x * 4 * GPW;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(dE, de_bytes);
+    double loss = 0.0;
+    for (int64_t b = gid; b < B; b += n_groups) {
+        const int ru = u_idx[b], ri = n_users + i_idx[b], rj = n_users + j_idx[b];
+        float ub[E], ib[E], jb[E];
+        float di = 0.f, dj = 0.f, sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            ub[e] = S[(int64_t)ru * LD + r + LPR * e] / div;
+            ib[e] = S[(int64_t)ri * LD + r + LPR * e] / div;
+            jb[e] = S[(int64_t)rj * LD + r + LPR * e] / div;
+            di += ub[e] * ib[e]; dj += ub[e] * jb[e];
+            sq += ub[e] * ub[e] + ib[e] * ib[e] + jb[e] * jb[e];
+        }
+        di = row_allreduce_sum<LPR>(di); dj = row_allreduce_sum<LPR>(dj); sq = row_allreduce_sum<LPR>(sq);
+        const float s = 1.0f / (1.0f + expf(-(di - dj)));
+        const float gsc = -(s * (1.0f - s)) / (s + eps);
+        if (r == 0) loss += (double)(-logf(s + eps)) + 0.5 * (double)reg * (double)sq;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const uint32_t col = (uint32_t)(r + LPR * e) * 4u;
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(gsc * (ib[e] - jb[e]) + reg * ub[e], rs, (int)((uint32_t)ru * LD * 4u + col), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(gsc * ub[e] + reg * ib[e], rs, (int)((uint32_t)ri * LD * 4u + col), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(-gsc * ub[e] + reg * jb[e], rs, (int)((uint32_t)rj * LD * 4u + col), 0, 0);
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) loss += __shfl_xor(loss, m, kWave);
+    if (lane == 0 && loss != 0.0) atomicAdd(loss_out, loss);
+}
+
+// ---------------------------------------------------------------------------------------
+// Dense Adam in the form of TF 1.14's ApplyAdam functor (training_ops.cc), all fp32, g = gscale*G:
+//   m += (g - m) * (1 - beta1) ; v += (g*g - v) * (1 - beta2) ; theta -= (m * alpha) / (sqrt(v) + eps)
+// alpha = lr*sqrt(1-beta2_power)/(1-beta1_power) comes from the host (fp32 beta powers, as TF keeps
+// them).  Streams theta, m, v, G in and theta, m, v out: 7 * 4 B per element.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ theta, float *__restrict__ m,
+                                                   float *__restrict__ v, const float *__restrict__ G,
+                                                   int64_t n4, float gscale, float alpha, float b1, float b2,
+                                                   float eps) {
+#pragma clang fp contract(off)
+    f32x4 *t4 = reinterpret_cast<f32x4 *>(theta), *m4 = reinterpret_cast<f32x4 *>(m), *v4 = reinterpret_cast<f32x4 *>(v);
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(G);
+    const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 g = gscale * g4[k];
+        f32x4 mm = m4[k], vv = v4[k], th = t4[k];
+        mm = mm + (g - mm) * omb1;
+        vv = vv + (g * g - vv) * omb2;
+        th.x -= (mm.x * alpha) / (sqrtf(vv.x) + eps); th.y -= (mm.y * alpha) / (sqrtf(vv.y) + eps);
+        th.z -= (mm.z * alpha) / (sqrtf(vv.z) + eps); th.w -= (mm.w * alpha) / (sqrtf(vv.w) + eps);
+        m4[k] = mm; v4[k] = vv; t4[k] = th;
+    }
+}
+
+template <int LPR>
+int launch_spmm(const int32_t *seg_row, const int64_t *seg_beg, const int32_t *seg_len, const int32_t *seg_slot,
+                int64_t n_segs, const int32_t *long_row, const int32_t *long_first, const int32_t *long_count,
+                int n_long, const int32_t *indices, const float *values, const float *X, float *Y, float *partial,
+                const float *addend, float addend_scale, float *accum, hipStream_t st) {
+    constexpr int GPW = kWave / LPR;
+    int64_t blocks = (n_segs + 4 * GPW - 1) / (4 * GPW);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL((spmm_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, seg_row, seg_beg, seg_len,
+                       seg_slot, n_segs, indices, values, X, Y, partial, addend, addend_scale, accum);
+    QREC_LAUNCH_CHECK();
+    if (n_long > 0) {
+        hipLaunchKernelGGL((spmm_fixup_kernel<LPR>), dim3((unsigned)((n_long + 4 * GPW - 1) / (4 * GPW))), dim3(256),
+                           0, st, long_row, long_first, long_count, n_long, partial, Y, addend, addend_scale, accum);
+        QREC_LAUNCH_CHECK();
+    }
+    return QREC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qrec_spmm_csr(const int32_t *d_seg_row, const int64_t *d_seg_beg, const int32_t *d_seg_len,
+                  const int32_t *d_seg_slot, int64_t n_segs, const int32_t *d_long_row,
+                  const int32_t *d_long_first, const int32_t *d_long_count, int32_t n_long,
+                  const int32_t *d_indices, const float *d_values, const float *d_X, float *d_Y,
+                  float *d_partial, int32_t ld, const float *d_addend, float addend_scale, float *d_accum,
+                  void *stream) {
+    QREC_REQUIRE(d_seg_row && d_seg_beg && d_seg_len && d_seg_slot && d_indices && d_values && d_X && d_Y,
+                 "qrec_spmm_csr: null argument");
+    QREC_REQUIRE(n_long == 0 || (d_long_row && d_long_first && d_long_count && d_partial), "qrec_spmm_csr: long-row plan incomplete");
+    QREC_REQUIRE(d_X != d_Y, "qrec_spmm_csr: in-place SpMM is not supported");
+    if (n_segs == 0) return QREC_OK;
+    hipStream_t st = as_stream(stream);
+#define QREC_SPMM(LPR) return launch_spmm<LPR>(d_seg_row, d_seg_beg, d_seg_len, d_seg_slot, n_segs, d_long_row, d_long_first, \
+                                               d_long_count, n_long, d_indices, d_values, d_X, d_Y, d_partial, d_addend,       \
+                                               addend_scale, d_accum, st)
+    switch (ld) {
+        case 32: QREC_SPMM(8);
+        case 64: QREC_SPMM(16);
+        case 128: QREC_SPMM(32);
+        case 256: QREC_SPMM(64);
+        default: set_error("qrec_spmm_csr: row stride must be 32, 64, 128 or 256 floats (got %d)", ld); return QREC_ERR_INVALID;
+    }
+#undef QREC_SPMM
+}
+
+int qrec_bpr_batch_loss_grad(const float *d_S, float div, int32_t n_users, int64_t n_rows, int32_t ld,
+                             const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int32_t B, float eps,
+                             float reg, float *d_dE, double *d_loss, void *stream) {
+    QREC_REQUIRE(d_S && d_dE && d_loss && B >= 0 && div != 0.f, "qrec_bpr_batch_loss_grad: bad argument");
+    QREC_REQUIRE(B == 0 || (d_u && d_i && d_j), "qrec_bpr_batch_loss_grad: null index array");
+    QREC_REQUIRE(n_rows * (int64_t)ld * 4 < ((int64_t)1 << 32), "qrec_bpr_batch_loss_grad: table exceeds 4 GiB");
+    if (B == 0) return QREC_OK;
+    hipStream_t st = as_stream(stream);
+    const uint32_t bytes = (uint32_t)(n_rows * ld * 4);
+#define QREC_BB(LPR, E)                                                                                          \
+    hipLaunchKernelGGL((bpr_batch_kernel<LPR, E>), dim3((unsigned)((B + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), \
+                       dim3(256), 0, st, d_S, div, n_users, d_u, d_i, d_j, B, eps, reg, d_dE, bytes, d_loss)
+    switch (ld) {
+        case 32: QREC_BB(16, 2); break;
+        case 64: QREC_BB(16, 4); break;
+        case 128: QREC_BB(32, 4); break;
+        case 256: QREC_BB(64, 4); break;
+        default: set_error("qrec_bpr_batch_loss_grad: row stride must be 32, 64, 128 or 256 floats (got %d)", ld); return QREC_ERR_INVALID;
+    }
+#undef QREC_BB
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+int qrec_adam_step(float *d_theta, float *d_m, float *d_v, const float *d_grad, int64_t n_elems, float grad_scale,
+                   float alpha, float beta1, float beta2, float eps, void *stream) {
+    QREC_REQUIRE(d_theta && d_m && d_v && d_grad && n_elems >= 0, "qrec_adam_step: bad argument");
+    QREC_REQUIRE(n_elems % 4 == 0, "qrec_adam_step: element count must be a multiple of 4 (row stride is)");
+    if (n_elems == 0) return QREC_OK;
+    int64_t blocks = (n_elems / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), d_theta, d_m, d_v,
+                       d_grad, n_elems / 4, grad_scale, alpha, beta1, beta2, eps);
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+}  // extern "C"

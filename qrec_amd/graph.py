@@ -1,0 +1,143 @@
+"""Graph side of the LightGCN-family hot path: the joint normalized adjacency
+(base/graphRecommender.py:10-29), its segmented-CSR launch plan, and the per-batch training
+step of model/ranking/LightGCN.py:11-41 driven entirely through the C ABI."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import capi
+from .capi import DeviceBuffer
+from .engine import padded_ld
+
+
+def joint_norm_adjacency(n_users: int, n_items: int, uid: np.ndarray, iid: np.ndarray):
+    """CSR (indptr int64, indices int32, values float32) of  D^-1/2 (R + R^T) D^-1/2  over
+    the N = n_users + n_items nodes, with the reference's arithmetic: entries of R are
+    float32 ones and duplicated (u,i) rows add up, degrees are float32 row sums,
+    d = float32(rowsum ** -0.5) with inf -> 0, and each value is fl32(fl32(d_r * a) * d_c)
+    (base/graphRecommender.py:15-28).  Columns ascending inside each row."""
+    n = n_users + n_items
+    uid = np.asarray(uid, dtype=np.int64); iid = np.asarray(iid, dtype=np.int64) + n_users
+    rows = np.concatenate([uid, iid]); cols = np.concatenate([iid, uid])
+    key = rows * n + cols
+    uniq, counts = np.unique(key, return_counts=True)          # sorted by (row, col); duplicates summed
+    r = (uniq // n).astype(np.int64); c = (uniq % n).astype(np.int32)
+    a = counts.astype(np.float32)
+    rowsum = np.bincount(r, weights=a, minlength=n).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        d_inv = np.power(rowsum, -0.5)                          # float32 ** python float -> float32
+    d_inv[np.isinf(d_inv)] = 0.0
+    vals = (d_inv[r] * a).astype(np.float32) * d_inv[c]
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(r, minlength=n), out=indptr[1:])
+    return indptr, c, vals.astype(np.float32)
+
+
+class SpmmPlan:
+    """Device-resident CSR plus its segment decomposition (include/qrec_hip.h, qrec_spmm_csr)."""
+
+    def __init__(self, indptr: np.ndarray, indices: np.ndarray, values: np.ndarray, ld: int, seg_len: int = 128):
+        n_rows = indptr.size - 1
+        nnz_row = np.diff(indptr)
+        n_seg_row = np.maximum(1, -(-nnz_row // seg_len)).astype(np.int64)     # ceil, >=1 (empty rows write zeros)
+        seg_row = np.repeat(np.arange(n_rows, dtype=np.int32), n_seg_row)
+        first_seg = np.concatenate([[0], np.cumsum(n_seg_row)[:-1]])
+        k_in_row = np.arange(seg_row.size, dtype=np.int64) - np.repeat(first_seg, n_seg_row)
+        seg_beg = indptr[seg_row] + k_in_row * seg_len
+        seg_len_arr = np.minimum(seg_len, indptr[seg_row.astype(np.int64) + 1] - seg_beg).astype(np.int32)
+        is_long = np.repeat(n_seg_row > 1, n_seg_row)
+        seg_slot = np.full(seg_row.size, -1, dtype=np.int32)
+        seg_slot[is_long] = np.arange(int(is_long.sum()), dtype=np.int32)
+        long_rows = np.nonzero(n_seg_row > 1)[0].astype(np.int32)
+        long_count = n_seg_row[long_rows].astype(np.int32)
+        long_first = np.concatenate([[0], np.cumsum(long_count)[:-1]]).astype(np.int32) if long_rows.size else np.zeros(0, np.int32)
+        # longest segments first: the heavy work starts early, the tail is made of short rows
+        order = np.argsort(-seg_len_arr, kind="stable")
+        self.n_rows, self.nnz, self.ld = n_rows, int(indices.size), ld
+        self.n_segs, self.n_long = int(seg_row.size), int(long_rows.size)
+        up = DeviceBuffer.from_numpy
+        self.seg_row, self.seg_beg = up(seg_row[order]), up(seg_beg[order].astype(np.int64))
+        self.seg_len, self.seg_slot = up(seg_len_arr[order]), up(seg_slot[order])
+        self.long_row = up(long_rows) if self.n_long else None
+        self.long_first = up(long_first) if self.n_long else None
+        self.long_count = up(long_count) if self.n_long else None
+        self.partial = DeviceBuffer((max(int(is_long.sum()), 1), ld), np.float32)
+        self.indices, self.values = up(indices.astype(np.int32)), up(values.astype(np.float32))
+
+    def bytes_algorithmic(self, d: int) -> int:
+        """nnz*(4+4) + 4*(N+1) + 2*N*d*4 (every dense row read once, written once)."""
+        return self.nnz * 8 + 4 * (self.n_rows + 1) + 2 * self.n_rows * d * 4
+
+
+class LightGCNTrainer:
+    """E = [U;V] resident in HBM; one ``train_step`` = forward propagation (L SpMMs with the
+    layer sum fused in), batch BPR loss + gradient scatter, backward propagation (L SpMMs,
+    A symmetric), dense TF-1.14 Adam."""
+
+    def __init__(self, U0: np.ndarray, V0: np.ndarray, adj, n_layers: int, lr: float, reg: float,
+                 loss_eps: float = 1e-7):
+        self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
+        self.n = self.nu + self.ni
+        self.ld = padded_ld(self.d, np.float32)
+        self.L, self.lr, self.reg, self.loss_eps = n_layers, lr, reg, loss_eps
+        self.plan = SpmmPlan(adj[0], adj[1], adj[2], self.ld)
+        E0 = np.zeros((self.n, self.ld), np.float32)
+        E0[:self.nu, :self.d] = U0; E0[self.nu:, :self.d] = V0
+        self.E = DeviceBuffer.from_numpy(E0)
+        z = lambda: DeviceBuffer.zeros((self.n, self.ld), np.float32)
+        self.m, self.v, self.S, self.dE, self.A, self.B = z(), z(), z(), z(), z(), z()
+        self.d_loss = DeviceBuffer.zeros(1, np.float64)
+        self.t = 0
+        f = np.float32
+        self.b1, self.b2, self.adam_eps = f(0.9), f(0.999), f(1e-8)
+        self.b1p, self.b2p = self.b1, self.b2          # fp32 beta powers, as TF keeps them
+
+    # ---- pieces -----------------------------------------------------------------------------
+    def forward_sum(self, stream=None):
+        """S = E0 + E1 + ... + EL  (divide by L+1 at the point of use)."""
+        self.S.copy_from(self.E, stream)
+        x = self.E
+        for k in range(self.L):
+            y = self.A if k % 2 == 0 else self.B
+            capi.spmm_csr(self.plan, x, y, self.ld, d_accum=self.S, stream=stream)
+            x = y
+
+    def backward_from_dE(self, stream=None):
+        """H_L with H_0 = dE, H_{k+1} = dE + A H_k; the gradient of E is H_L / (L+1)."""
+        x = self.dE
+        for k in range(self.L):
+            y = self.A if k % 2 == 0 else self.B
+            capi.spmm_csr(self.plan, x, y, self.ld, d_addend=self.dE, addend_scale=1.0, stream=stream)
+            x = y
+        return x
+
+    def adam_alpha(self) -> float:
+        """lr * sqrt(1 - beta2_power) / (1 - beta1_power), evaluated in fp32 (TF ApplyAdam)."""
+        f = np.float32
+        return float(f(f(self.lr) * np.sqrt(f(1) - self.b2p, dtype=f) / (f(1) - self.b1p)))
+
+    def train_step_async(self, d_u, d_i, d_j, B: int, stream=None):
+        """u/i/j: device pointers (int32[B]); enqueue only, read the loss with ``loss()``."""
+        self.forward_sum(stream)
+        self.dE.fill_bytes(0, stream)
+        self.d_loss.fill_bytes(0, stream)
+        capi.bpr_batch_loss_grad(self.S, float(self.L + 1), self.nu, self.n, self.ld, d_u, d_i, d_j, B,
+                                 self.loss_eps, self.reg, self.dE, self.d_loss, stream)
+        g = self.backward_from_dE(stream)
+        capi.adam_step(self.E, self.m, self.v, g, self.n * self.ld, 1.0 / (self.L + 1), self.adam_alpha(),
+                       float(self.b1), float(self.b2), float(self.adam_eps), stream)
+        self.t += 1
+        self.b1p = np.float32(self.b1p * self.b1); self.b2p = np.float32(self.b2p * self.b2)
+
+    def loss(self, stream=None) -> float:
+        return float(self.d_loss.numpy(stream)[0])
+
+    def final_embeddings(self):
+        """(U, V) = split(mean(E0..EL)) as float32 host arrays (LightGCN.py:41)."""
+        self.forward_sum()
+        Ebar = (self.S.numpy()[:, :self.d] / np.float32(self.L + 1)).astype(np.float32)
+        return np.ascontiguousarray(Ebar[:self.nu]), np.ascontiguousarray(Ebar[self.nu:])
+
+    def ego_embeddings(self):
+        E = self.E.numpy()
+        return E[:self.nu, :self.d].copy(), E[self.nu:, :self.d].copy()

@@ -1,0 +1,44 @@
+"""LightGCN behind the reference's class name and hooks (model/ranking/LightGCN.py:5-49):
+``-n_layer`` propagation layers over the joint adjacency, mean of the layer outputs, batch
+BPR loss + batch L2, Adam -- every batch re-propagates the whole graph forward and backward,
+so the SpMM kernel is the hot loop."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from ... import capi
+from ...base.graphRecommender import GraphRecommender
+from ...capi import DeviceBuffer
+from ...graph import LightGCNTrainer
+from ...util.config import OptionConf
+
+
+class LightGCN(GraphRecommender):
+    def __init__(self, conf, trainingSet=None, testSet=None, fold="[1]"):
+        super().__init__(conf, trainingSet, testSet, fold)
+        self.n_layers = int(OptionConf(self.config["LightGCN"])["-n_layer"])
+
+    def initModel(self):
+        super().initModel()
+        self.trainer = LightGCNTrainer(self.user_embeddings, self.item_embeddings,
+                                       self.create_joint_sparse_adjaceny(), self.n_layers, self.lRate, self.regU)
+
+    def trainModel(self):
+        quiet = os.environ.get("QREC_QUIET") == "1"
+        tr = self.trainer
+        for epoch in range(self.maxEpoch):
+            u, i, j = self.sample_epoch_pairwise()                 # base/deepRecommender.py:29-52
+            d_u, d_i, d_j = DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i), DeviceBuffer.from_numpy(j)
+            for n, s in enumerate(range(0, u.size, self.batch_size)):
+                B = min(self.batch_size, u.size - s)
+                tr.train_step_async(d_u.ptr + 4 * s, d_i.ptr + 4 * s, d_j.ptr + 4 * s, B)
+                if not quiet:                                        # the reference prints every batch
+                    print(self.foldInfo, "training:", epoch + 1, "batch", n, "loss:", tr.loss())
+        self.U, self.V = tr.final_embeddings()
+
+    def predictForRanking(self, u):
+        if self.data.containsUser(u):
+            return self.V.dot(self.U[self.data.getUserId(u)])
+        return [self.data.globalMean] * self.num_items

@@ -188,3 +188,16 @@ def test_native_shuffle_of_training_data_matches_python(monkeypatch):
     want = list(rows)
     random.seed(meta["seed"]); random.shuffle(want)
     assert m.data.trainingData == want
+
+
+def test_product_adjacency_builder_matches_reference_scipy_output_bitwise():
+    from qrec_amd.graph import joint_norm_adjacency
+    meta, z = load_golden("pairwise_adj_filmtrust")
+    indptr, indices, values = joint_norm_adjacency(meta["n_users"], meta["n_items"], z["train_uid"], z["train_iid"])
+    assert values.dtype == np.float32
+    assert np.array_equal(indptr, z["adj_indptr"]) and np.array_equal(indices, z["adj_indices"])
+    assert np.array_equal(values, z["adj_data"])
+    # isolated nodes (no edges) get an all-zero row, like the reference's inf -> 0 rule
+    ip, ix, vals = joint_norm_adjacency(3, 3, np.array([0, 0, 2]), np.array([1, 1, 0]))
+    assert ip.tolist() == [0, 1, 1, 2, 3, 4, 4] and np.isfinite(vals).all()
+    assert vals[0] == np.float32(np.float32(np.float32(2) ** np.float32(-0.5) * np.float32(2)) * np.float32(2) ** np.float32(-0.5))

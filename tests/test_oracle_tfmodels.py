@@ -1,0 +1,93 @@
+"""Checks of the numpy restatement of the TF-path models (oracle/tfmodels.py):
+adjacency pinned to the live reference's scipy output; hand-derived gradients vs torch-CPU
+autograd of the same graph; Adam vs torch.optim.Adam's closed form where they coincide."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from oracle import tfmodels as T
+
+from helpers import load_golden
+
+
+def test_adjacency_matches_reference_scipy_output():
+    meta, z = load_golden("pairwise_adj_filmtrust")
+    A = T.joint_norm_adjacency(meta["n_users"], meta["n_items"], z["train_uid"], z["train_iid"])
+    A.sort_indices()
+    assert A.dtype == np.float32 and A.nnz == meta["adj_nnz"]
+    assert np.array_equal(A.indptr, z["adj_indptr"]) and np.array_equal(A.indices, z["adj_indices"])
+    assert np.array_equal(A.data, z["adj_data"])            # bit-exact fp32 values
+    # duplicated (u,i) rows in the file sum to 2 before normalisation (csr_matrix semantics)
+    assert (A != A.T).nnz == 0
+
+
+def _torch_lightgcn_loss(E, adj_t, nu, L, u, i, j, reg):
+    layers = [E]
+    for _ in range(L):
+        layers.append(torch.sparse.mm(adj_t, layers[-1]))
+    Ebar = torch.stack(layers).mean(0)
+    ub, ib, jb = Ebar[u], Ebar[i + nu], Ebar[j + nu]
+    score = (ub * ib).sum(1) - (ub * jb).sum(1)
+    loss = -torch.log(torch.sigmoid(score) + 1e-7).sum()
+    return loss + reg * 0.5 * ((ub ** 2).sum() + (ib ** 2).sum() + (jb ** 2).sum())
+
+
+@pytest.mark.parametrize("L", [1, 2, 3])
+def test_lightgcn_gradient_matches_autograd(L):
+    rng = np.random.default_rng(L)
+    nu, ni, d, B = 40, 30, 8, 64
+    uid = rng.integers(0, nu, 300); iid = rng.integers(0, ni, 300)
+    adj = T.joint_norm_adjacency(nu, ni, uid, iid)
+    U0 = rng.standard_normal((nu, d)).astype(np.float32) * 0.1; V0 = rng.standard_normal((ni, d)).astype(np.float32) * 0.1
+    u = rng.integers(0, nu, B); i = rng.integers(0, ni, B); j = rng.integers(0, ni, B)   # duplicates on purpose
+    m = T.LightGCN(U0, V0, adj, L, lr=0.001, reg=0.01)
+    loss, g = m.loss_and_grad(u, i, j)
+    coo = adj.tocoo()
+    adj_t = torch.sparse_coo_tensor(np.vstack([coo.row, coo.col]), coo.data.astype(np.float64), adj.shape).coalesce()
+    E = torch.tensor(np.concatenate([U0, V0]).astype(np.float64), requires_grad=True)
+    tl = _torch_lightgcn_loss(E, adj_t, nu, L, torch.tensor(u), torch.tensor(i), torch.tensor(j), 0.01)
+    tl.backward()
+    assert loss == pytest.approx(float(tl), rel=2e-6)
+    np.testing.assert_allclose(g, E.grad.numpy(), rtol=2e-4, atol=2e-6)
+
+
+def test_adam_matches_closed_form():
+    """fp32 ApplyAdam form vs the textbook formula in float64 (they differ only by rounding)."""
+    rng = np.random.default_rng(0)
+    theta = rng.standard_normal((5, 4)).astype(np.float32); th = theta.astype(np.float64)
+    opt = T.AdamTF114(theta.shape, lr=0.01)
+    m = np.zeros_like(th); v = np.zeros_like(th)
+    for t in range(1, 8):
+        g = rng.standard_normal(theta.shape).astype(np.float32)
+        opt.step(theta, g)
+        g = g.astype(np.float64)
+        m = 0.9 * m + 0.1 * g; v = 0.999 * v + 0.001 * g * g
+        th -= 0.01 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m / (np.sqrt(v) + 1e-8)
+    np.testing.assert_allclose(theta, th, rtol=2e-4, atol=1e-6)
+
+
+def test_lightgcn_training_reduces_loss_and_bpr_grad_finite_difference():
+    rng = np.random.default_rng(3)
+    nu, ni, d = 50, 40, 8
+    uid = rng.integers(0, nu, 400); iid = rng.integers(0, ni, 400)
+    adj = T.joint_norm_adjacency(nu, ni, uid, iid)
+    m = T.LightGCN(rng.standard_normal((nu, d)).astype(np.float32) * 0.01, rng.standard_normal((ni, d)).astype(np.float32) * 0.01, adj, 2, 0.01, 1e-4)
+    j = rng.integers(0, ni, 400)
+    first = m.train_step(uid, iid, j)
+    for _ in range(30):
+        last = m.train_step(uid, iid, j)
+    assert last < first
+    # finite differences on the batch loss (float64 re-evaluation)
+    ub, ib, jb = [rng.standard_normal((6, d)) for _ in range(3)]
+    loss, du, di, dj = T.bpr_batch_loss_and_grads(ub.astype(np.float32), ib.astype(np.float32), jb.astype(np.float32), 0.05)
+    def f(ub, ib, jb):
+        s = 1 / (1 + np.exp(-((ub * ib).sum(1) - (ub * jb).sum(1))))
+        return -np.log(s + 1e-7).sum() + 0.05 * 0.5 * ((ub ** 2).sum() + (ib ** 2).sum() + (jb ** 2).sum())
+    h = 1e-6
+    for arr, grad in ((ub, du), (ib, di), (jb, dj)):
+        for idx in [(0, 0), (3, 5), (5, 7)]:
+            a = arr.copy(); a[idx] += h
+            args = [a if x is arr else x for x in (ub, ib, jb)]
+            num = (f(*args) - f(ub, ib, jb)) / h
+            assert grad[idx] == pytest.approx(num, rel=2e-3, abs=2e-5)
