@@ -165,6 +165,26 @@ int qrec_bpr_batch_loss_grad(const float *d_S, float div, int32_t n_users, int64
 int qrec_adam_step(float *d_theta, float *d_m, float *d_v, const float *d_grad, int64_t n_elems, float grad_scale,
                    float alpha, float beta1, float beta2, float eps, void *stream);
 
+/* ---- SimGCL (model/ranking/SimGCL.py) ---------------------------------------------------- */
+
+/* perturbed_LightGCN_encoder's noise step (SimGCL.py:33-35), in place on one layer output:
+ * emb += sign(emb) * l2_normalize(noise, axis=1) * eps, then (if d_accum) accum += emb.
+ * d_noise = [n_rows][ld] U[0,1) numbers, or NULL to draw them on the device with
+ * Philox4x32-10(key=seed, counter={row, lane, stream_id}) -- same distribution as
+ * tf.random.uniform, not TF's stream.                                                    */
+int qrec_perturb_rows(float *d_emb, int64_t n_rows, int32_t d, int32_t ld, float eps, const float *d_noise,
+                      uint64_t seed, uint64_t stream_id, float *d_accum, void *stream);
+
+/* One side (users or items) of SimGCL.calc_cl_loss (SimGCL.py:60-90) with its gradients.
+ * x1 = S1[rows]/div, x2 = S2[rows]/div (the two perturbed views' rows of the batch's UNIQUE
+ * nodes, n <= 16384, ids distinct); z = l2_normalize(x); loss = -sum log(exp(z1.z2/tau) /
+ * sum_cols exp(z1 z2^T/tau)).  *d_loss (double) += loss (unscaled); d_out[rows] += cl_rate *
+ * (dloss/dx1 + dloss/dx2).  The n x n block runs on the f32 MFMA.                        */
+int qrec_info_nce_workspace_bytes(int32_t n, int32_t ld, int64_t *bytes);
+int qrec_info_nce_loss_grad(const float *d_S1, const float *d_S2, float div, const int32_t *d_rows, int32_t n,
+                            int32_t ld, float tau, float cl_rate, void *d_workspace, float *d_out, double *d_loss,
+                            void *stream);
+
 /* ---- full-rank evaluation: base/recommender.py:143-150 + util/qmath.py:134-146 -------- *
  * For each of the n_batch_users users (ids into the user table): scores = V . U[user]
  * (MFMA), scores of the user's rated train items set to 0 (rated CSR over ALL users, may be

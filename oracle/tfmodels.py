@@ -127,3 +127,103 @@ class LightGCN:
     def final_embeddings(self):
         Ebar = self.propagate()
         return Ebar[:self.nu], Ebar[self.nu:]                               # LightGCN.py:41
+
+
+# ======================================================================================
+# SimGCL  (model/ranking/SimGCL.py:15-118)
+# ======================================================================================
+def l2_normalize_rows(x, eps=np.float32(1e-12)):
+    """tf.nn.l2_normalize(x, 1) = x * rsqrt(max(sum(x^2), 1e-12)); returns (z, inv_norm)."""
+    ss = (x * x).sum(1, dtype=np.float32)
+    inv = (np.float32(1) / np.sqrt(np.maximum(ss, eps), dtype=np.float32)).astype(np.float32)
+    return (x * inv[:, None]).astype(np.float32), inv
+
+
+def info_nce_loss_and_grads(x1, x2, tau=np.float32(0.2)):
+    """One side (users or items) of SimGCL.calc_cl_loss (SimGCL.py:60-90) on already gathered
+    rows x1, x2 [n, d] of the two perturbed views:
+        z = l2_normalize(x);  pos = exp(sum(z1*z2)/tau);  ttl = sum_cols exp(z1 z2^T / tau)
+        loss = -sum log(pos / ttl)
+    Returns (loss, dx1, dx2) with hand-derived gradients (fp32)."""
+    f = np.float32
+    z1, r1 = l2_normalize_rows(x1); z2, r2 = l2_normalize_rows(x2)
+    S = (z1 @ z2.T).astype(f) / f(tau)
+    Ex = np.exp(S, dtype=f)
+    ttl = Ex.sum(1, dtype=f)
+    pos = np.exp((z1 * z2).sum(1, dtype=f) / f(tau), dtype=f)
+    loss = float(-np.log(pos / ttl, dtype=f).sum(dtype=np.float64))
+    G = (Ex / ttl[:, None]).astype(f)                       # row softmax
+    G[np.arange(G.shape[0]), np.arange(G.shape[0])] -= f(1)
+    dz1 = (G @ z2).astype(f) / f(tau)
+    dz2 = (G.T @ z1).astype(f) / f(tau)
+    # back through z = x * inv:  dx = (dz - z (z.dz)) * inv     (clamp inactive for non-zero rows)
+    dx1 = ((dz1 - z1 * (z1 * dz1).sum(1, dtype=f)[:, None]) * r1[:, None]).astype(f)
+    dx2 = ((dz2 - z2 * (z2 * dz2).sum(1, dtype=f)[:, None]) * r2[:, None]).astype(f)
+    return loss, dx1, dx2
+
+
+def unique_first_appearance(idx):
+    """tf.unique(x)[0]: distinct values in order of first occurrence."""
+    idx = np.asarray(idx)
+    _, first = np.unique(idx, return_index=True)
+    return idx[np.sort(first)]
+
+
+class SimGCL:
+    """model/ranking/SimGCL.py restated.  ``noise`` for a step is a list of 2*L arrays [N, d]
+    of U[0,1) draws (views 1 and 2, layer by layer); TF draws them inside the graph, tests
+    inject them so that both sides see the same numbers."""
+
+    def __init__(self, U0, V0, adj: sp.csr_matrix, n_layers, lr, reg, cl_rate, eps):
+        self.nu, self.ni = U0.shape[0], V0.shape[0]
+        self.E = np.concatenate([U0, V0]).astype(np.float32)
+        self.adj = adj.astype(np.float32).tocsr()
+        self.L, self.reg, self.cl_rate, self.eps = n_layers, reg, np.float32(cl_rate), np.float32(eps)
+        self.opt = AdamTF114(self.E.shape, lr)
+
+    def encoder(self, noises=None):
+        """LightGCN_encoder / perturbed_LightGCN_encoder (SimGCL.py:22-38): mean over the L
+        propagated layers (ego layer excluded); with noise, emb += sign(emb)*normalize(noise)*eps
+        after every layer and the perturbed emb feeds the next one."""
+        emb = self.E
+        acc = np.zeros_like(emb)
+        for k in range(self.L):
+            emb = self.adj.dot(emb).astype(np.float32)
+            if noises is not None:
+                nz, _ = l2_normalize_rows(noises[k].astype(np.float32))
+                emb = (emb + (np.sign(emb) * nz) * self.eps).astype(np.float32)
+            acc += emb
+        return (acc / np.float32(self.L)).astype(np.float32)
+
+    def loss_and_grad(self, u_idx, i_idx, j_idx, noises):
+        nu = self.nu
+        main = self.encoder()
+        p1 = self.encoder(noises[:self.L]); p2 = self.encoder(noises[self.L:])
+        ui, ii, ji = np.asarray(u_idx), np.asarray(i_idx) + nu, np.asarray(j_idx) + nu
+        rec, du, di, dj = bpr_batch_loss_and_grads(main[ui], main[ii], main[ji], self.reg)
+        d_out = np.zeros_like(main)                     # gradients w.r.t. the three encoder outputs, summed:
+        np.add.at(d_out, ui, du); np.add.at(d_out, ii, di); np.add.at(d_out, ji, dj)
+        uu = unique_first_appearance(u_idx); vv = unique_first_appearance(i_idx) + nu
+        cl = 0.0
+        for rows in (uu, vv):
+            l, d1, d2 = info_nce_loss_and_grads(p1[rows], p2[rows])
+            cl += l
+            d_out[rows] += self.cl_rate * d1 + self.cl_rate * d2   # both views back-propagate through the same linear map
+        cl *= float(self.cl_rate)
+        # encoder backward (identical for clean and perturbed: sign() has zero derivative):
+        # dE0 = (1/L) sum_{k=1..L} A^k d_out
+        c = d_out / np.float32(self.L)
+        W = c.copy()
+        for _ in range(self.L - 1):
+            W = (c + self.adj.T.dot(W)).astype(np.float32)
+        G = self.adj.T.dot(W).astype(np.float32)
+        return rec + cl, rec, cl, G
+
+    def train_step(self, u_idx, i_idx, j_idx, noises):
+        loss, rec, cl, g = self.loss_and_grad(u_idx, i_idx, j_idx, noises)
+        self.opt.step(self.E, g)
+        return loss, rec, cl
+
+    def final_embeddings(self):
+        m = self.encoder()
+        return m[:self.nu], m[self.nu:]

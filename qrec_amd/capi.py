@@ -53,6 +53,9 @@ _SIGNATURES = {
     "qrec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp],
     "qrec_bpr_batch_loss_grad": [_vp, _f32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp],
     "qrec_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp],
+    "qrec_perturb_rows": [_vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp],
+    "qrec_info_nce_workspace_bytes": [_i32, _i32, _vp],
+    "qrec_info_nce_loss_grad": [_vp, _vp, _f32, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
     "qrec_score_topk_scratch_bytes": [C.c_int, _i32, _i32, _vp],
     "qrec_score_topk": [_vp, _vp, C.c_int, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
 }
@@ -371,3 +374,21 @@ def adam_step(d_theta, d_m, d_v, d_grad, n_elems: int, grad_scale: float, alpha:
               beta2: float = 0.999, eps: float = 1e-8, stream=None):
     _check(load().qrec_adam_step(_dp(d_theta), _dp(d_m), _dp(d_v), _dp(d_grad), n_elems, grad_scale, alpha, beta1,
                                  beta2, eps, _sh(stream)))
+
+
+def perturb_rows(d_emb, n_rows: int, d: int, ld: int, eps: float, d_noise=None, seed: int = 0, stream_id: int = 0,
+                 d_accum=None, stream=None):
+    _check(load().qrec_perturb_rows(_dp(d_emb), n_rows, d, ld, eps, _dp(d_noise), seed & (2**64 - 1),
+                                    stream_id & (2**64 - 1), _dp(d_accum), _sh(stream)))
+
+
+def info_nce_workspace_bytes(n: int, ld: int) -> int:
+    out = C.c_int64(0)
+    _check(load().qrec_info_nce_workspace_bytes(n, ld, C.byref(out)))
+    return out.value
+
+
+def info_nce_loss_grad(d_S1, d_S2, div: float, d_rows, n: int, ld: int, tau: float, cl_rate: float, d_workspace,
+                       d_out, d_loss, stream=None):
+    _check(load().qrec_info_nce_loss_grad(_dp(d_S1), _dp(d_S2), div, _dp(d_rows), n, ld, tau, cl_rate,
+                                          _dp(d_workspace), _dp(d_out), _dp(d_loss), _sh(stream)))

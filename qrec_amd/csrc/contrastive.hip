@@ -1,0 +1,290 @@
+// SimGCL extras (model/ranking/SimGCL.py): the noise perturbation of the two augmented views
+// (:29-38) and the InfoNCE contrastive loss with its gradients (:60-90).
+//
+//   perturb_kernel          emb += sign(emb) * l2_normalize(noise) * eps ; accum += emb
+//   gather_normalize_kernel z = l2_normalize(S[row]/div) for the batch's unique rows, both views
+//   exp_logits_kernel       ExT[b][a] = exp(z1[a].z2[b] / tau)               (MFMA f32 32x32x2)
+//   row_stats_kernel        ttl[a] = sum_b Ex[a][b];  loss += -log(exp(z1[a].z2[a]/tau) / ttl[a])
+//   grad_z_kernel           dz1 = (P - I) z2 / tau ; dz2 = (P - I)^T z1 / tau , P = Ex / ttl   (MFMA)
+//   normalize_bwd_kernel    d_out[row] += cl_rate * (dx1 + dx2),  dx = (dz - z (z.dz)) / |x|
+//
+// The n x n logits block (n <= batch size) is the only GEMM-shaped work: 3 products of
+// 2 n^2 d FLOP; everything else streams rows.
+#include "common.h"
+
+using namespace qrec;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- Philox4x32-10 (same generator as the negative sampler) ---------------------------------
+__device__ __forceinline__ void philox10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+        const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+        const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// One group of LPR lanes per row, float4 per lane (ld = 4*LPR).
+//   noise != nullptr : use the given U[0,1) numbers (parity tests inject TF-side noise)
+//   noise == nullptr : Philox(counter = {row, lane, stream_lo, stream_hi}, key = seed) -> 4 x 24-bit uniforms
+template <int LPR>
+__global__ __launch_bounds__(256) void perturb_kernel(float *__restrict__ emb, int64_t n_rows, int d, float eps,
+                                                      const float *__restrict__ noise, uint64_t seed, uint64_t stream_id,
+                                                      float *__restrict__ accum) {
+    constexpr int GPW = kWave / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
+    const int64_t gid = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
+    const int64_t n_groups = (int64_t)gridDim.x * 4 * GPW;
+    for (int64_t row = gid; row < n_rows; row += n_groups) {
+        const int64_t off = row * (4 * LPR) + 4 * r;
+        f32x4 nz;
+        if (noise) {
+            nz = *reinterpret_cast<const f32x4 *>(noise + off);
+        } else {
+            uint32_t c[4] = {(uint32_t)row, (uint32_t)(row >> 32) ^ ((uint32_t)r << 8), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+            philox10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+            nz.x = (float)(c[0] >> 8) * 0x1p-24f; nz.y = (float)(c[1] >> 8) * 0x1p-24f;
+            nz.z = (float)(c[2] >> 8) * 0x1p-24f; nz.w = (float)(c[3] >> 8) * 0x1p-24f;
+        }
+        if (4 * r + 0 >= d) nz.x = 0.f;
+        if (4 * r + 1 >= d) nz.y = 0.f;
+        if (4 * r + 2 >= d) nz.z = 0.f;
+        if (4 * r + 3 >= d) nz.w = 0.f;
+        float ss = nz.x * nz.x + nz.y * nz.y + nz.z * nz.z + nz.w * nz.w;
+        ss = row_allreduce_sum<LPR>(ss);
+        const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));     // tf.nn.l2_normalize epsilon
+        f32x4 e = *reinterpret_cast<const f32x4 *>(emb + off);
+        auto sgn = [](float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); };
+        e.x += sgn(e.x) * (nz.x * inv) * eps; e.y += sgn(e.y) * (nz.y * inv) * eps;
+        e.z += sgn(e.z) * (nz.z * inv) * eps; e.w += sgn(e.w) * (nz.w * inv) * eps;
+        *reinterpret_cast<f32x4 *>(emb + off) = e;
+        if (accum) {
+            f32x4 s = *reinterpret_cast<const f32x4 *>(accum + off);
+            s = s + e;
+            *reinterpret_cast<f32x4 *>(accum + off) = s;
+        }
+    }
+}
+
+// z[k] = l2_normalize(S[rows[k]] / div) for both views; r = 1/|x|; dotp = z1.z2
+template <int LPR>
+__global__ __launch_bounds__(256) void gather_normalize_kernel(const float *__restrict__ S1, const float *__restrict__ S2,
+                                                               float div, const int32_t *__restrict__ rows, int n,
+                                                               float *__restrict__ z1, float *__restrict__ z2,
+                                                               float *__restrict__ r1, float *__restrict__ r2,
+                                                               float *__restrict__ dotp) {
+    constexpr int GPW = kWave / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
+    const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
+    if (k >= n) return;
+    const int64_t src = (int64_t)rows[k] * (4 * LPR) + 4 * r, dst = k * (4 * LPR) + 4 * r;
+    f32x4 a = *reinterpret_cast<const f32x4 *>(S1 + src), b = *reinterpret_cast<const f32x4 *>(S2 + src);
+    a.x /= div; a.y /= div; a.z /= div; a.w /= div; b.x /= div; b.y /= div; b.z /= div; b.w /= div;
+    float sa = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w, sb = b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+    sa = row_allreduce_sum<LPR>(sa); sb = row_allreduce_sum<LPR>(sb);
+    const float ia = 1.0f / sqrtf(fmaxf(sa, 1e-12f)), ib = 1.0f / sqrtf(fmaxf(sb, 1e-12f));
+    a = a * ia; b = b * ib;
+    float dp = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    dp = row_allreduce_sum<LPR>(dp);
+    *reinterpret_cast<f32x4 *>(z1 + dst) = a; *reinterpret_cast<f32x4 *>(z2 + dst) = b;
+    if (r == 0) { r1[k] = ia; r2[k] = ib; dotp[k] = dp; }
+}
+
+// ExT[b][a] = exp(z1[a].z2[b] * inv_tau): one wavefront per 32x32 tile, f32 MFMA.
+// lane l: row index r = l&31, k-slot h = l>>5 owns columns [64c+32h, 64c+32h+32) of chunk c.
+__global__ __launch_bounds__(256) void exp_logits_kernel(const float *__restrict__ z1, const float *__restrict__ z2,
+                                                         int n, int n_pad, int ld, float inv_tau,
+                                                         float *__restrict__ ExT) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int a0 = blockIdx.x * 32, b0 = (blockIdx.y * 4 + wave) * 32;
+    if (b0 >= n_pad) return;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = 0.f;
+    for (int c = 0; c < ld; c += 64) {
+        const int col0 = c + 32 * h;
+#pragma unroll
+        for (int s = 0; s < 32; s++) {
+            const int col = col0 + s;
+            const float vb = (b0 + r < n && col < ld) ? z2[(int64_t)(b0 + r) * ld + col] : 0.f;   // A: rows b
+            const float va = (a0 + r < n && col < ld) ? z1[(int64_t)(a0 + r) * ld + col] : 0.f;   // B: cols a
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, va, acc, 0, 0, 0);
+        }
+    }
+    // C/D: col = lane&31 -> a, row = (q&3) + 8*(q>>2) + 4*h -> b
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int b = b0 + (q & 3) + 8 * (q >> 2) + 4 * h, a = a0 + r;
+        ExT[(int64_t)b * n_pad + a] = (a < n && b < n) ? expf(acc[q] * inv_tau) : 0.f;
+    }
+}
+
+// ttl[a] = sum_b ExT[b][a]  (thread per a, coalesced);  loss_a = -log(exp(dotp[a]*inv_tau) / ttl[a])
+__global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ ExT, int n, int n_pad,
+                                                        const float *__restrict__ dotp, float inv_tau,
+                                                        float *__restrict__ inv_ttl, double *__restrict__ loss_out) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    double l = 0.0;
+    if (a < n) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = 0;
+        for (; b + 4 <= n; b += 4) {
+            s0 += ExT[(int64_t)b * n_pad + a]; s1 += ExT[(int64_t)(b + 1) * n_pad + a];
+            s2 += ExT[(int64_t)(b + 2) * n_pad + a]; s3 += ExT[(int64_t)(b + 3) * n_pad + a];
+        }
+        for (; b < n; b++) s0 += ExT[(int64_t)b * n_pad + a];
+        const float ttl = (s0 + s1) + (s2 + s3);
+        inv_ttl[a] = 1.0f / ttl;
+        l = (double)(-logf(expf(dotp[a] * inv_tau) / ttl));
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) l += __shfl_xor(l, m, kWave);
+    if ((threadIdx.x & 63) == 0 && l != 0.0) atomicAdd(loss_out, l);
+}
+
+// G[a][b] = ExT[b][a]*inv_ttl[a] - (a==b).
+// MODE 0: out[a][:] = inv_tau * sum_b G[a][b] z[b][:]      (dz1, z = z2)   A[i=a][k=b] = G[a][b]
+// MODE 1: out[b][:] = inv_tau * sum_a G[a][b] z[a][:]      (dz2, z = z1)   A[i=b][k=a] = G[a][b]
+// one wavefront per (32 output rows) x (32 output columns); K = n in chunks of 64 (2 slots x 32).
+template <int MODE>
+__global__ __launch_bounds__(64) void grad_z_kernel(const float *__restrict__ ExT, const float *__restrict__ inv_ttl,
+                                                    const float *__restrict__ z, int n, int n_pad, int ld, float inv_tau,
+                                                    float *__restrict__ out) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    const int i = i0 + r;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = 0.f;
+    const float my_inv = (MODE == 0 && i < n) ? inv_ttl[i] : 0.f;
+    for (int c = 0; c < n_pad; c += 64) {
+        const int k0 = c + 32 * h;
+#pragma unroll 8
+        for (int s = 0; s < 32; s++) {
+            const int k = k0 + s;
+            float ga = 0.f;
+            if (i < n && k < n) {
+                if (MODE == 0) ga = ExT[(int64_t)k * n_pad + i] * my_inv - (k == i ? 1.f : 0.f);
+                else ga = ExT[(int64_t)i * n_pad + k] * inv_ttl[k] - (k == i ? 1.f : 0.f);
+            }
+            const float zb = (k < n && j0 + r < ld) ? z[(int64_t)k * ld + j0 + r] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, zb, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int row = i0 + (q & 3) + 8 * (q >> 2) + 4 * h, col = j0 + r;
+        if (row < n && col < ld) out[(int64_t)row * ld + col] = acc[q] * inv_tau;
+    }
+}
+
+// d_out[rows[k]] += scale * ( (dz1 - z1 (z1.dz1)) r1 + (dz2 - z2 (z2.dz2)) r2 )
+template <int LPR>
+__global__ __launch_bounds__(256) void normalize_bwd_kernel(const float *__restrict__ z1, const float *__restrict__ z2,
+                                                            const float *__restrict__ dz1, const float *__restrict__ dz2,
+                                                            const float *__restrict__ r1, const float *__restrict__ r2,
+                                                            const int32_t *__restrict__ rows, int n, float scale,
+                                                            float *__restrict__ d_out) {
+    constexpr int GPW = kWave / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
+    const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
+    if (k >= n) return;
+    const int64_t src = k * (4 * LPR) + 4 * r, dst = (int64_t)rows[k] * (4 * LPR) + 4 * r;
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(z1 + src), b = *reinterpret_cast<const f32x4 *>(z2 + src);
+    const f32x4 da = *reinterpret_cast<const f32x4 *>(dz1 + src), db = *reinterpret_cast<const f32x4 *>(dz2 + src);
+    float pa = a.x * da.x + a.y * da.y + a.z * da.z + a.w * da.w, pb = b.x * db.x + b.y * db.y + b.z * db.z + b.w * db.w;
+    pa = row_allreduce_sum<LPR>(pa); pb = row_allreduce_sum<LPR>(pb);
+    const f32x4 dxa = (da - a * pa) * r1[k], dxb = (db - b * pb) * r2[k];
+    f32x4 o = *reinterpret_cast<const f32x4 *>(d_out + dst);     // rows[] are distinct: plain read-modify-write
+    o = o + scale * dxa + scale * dxb;
+    *reinterpret_cast<f32x4 *>(d_out + dst) = o;
+}
+
+template <int LPR>
+int run_info_nce(const float *S1, const float *S2, float div, const int32_t *rows, int n, int ld, float tau,
+                 float cl_rate, float *ws, float *d_out, double *loss, hipStream_t st) {
+    constexpr int GPW = kWave / LPR;
+    const int n_pad = (n + 63) / 64 * 64;
+    float *z1 = ws, *z2 = z1 + (int64_t)n_pad * ld, *dz1 = z2 + (int64_t)n_pad * ld, *dz2 = dz1 + (int64_t)n_pad * ld;
+    float *r1 = dz2 + (int64_t)n_pad * ld, *r2 = r1 + n_pad, *dotp = r2 + n_pad, *inv_ttl = dotp + n_pad;
+    float *ExT = inv_ttl + n_pad;
+    const float inv_tau = 1.0f / tau;
+    const unsigned row_blocks = (unsigned)((n + 4 * GPW - 1) / (4 * GPW));
+    hipLaunchKernelGGL((gather_normalize_kernel<LPR>), dim3(row_blocks), dim3(256), 0, st, S1, S2, div, rows, n, z1, z2, r1, r2, dotp);
+    QREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(exp_logits_kernel, dim3((unsigned)(n_pad / 32), (unsigned)((n_pad / 32 + 3) / 4)), dim3(256), 0, st,
+                       z1, z2, n, n_pad, ld, inv_tau, ExT);
+    QREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ExT, n, n_pad, dotp, inv_tau, inv_ttl, loss);
+    QREC_LAUNCH_CHECK();
+    const dim3 gg((unsigned)(n_pad / 32), (unsigned)((ld + 31) / 32));
+    hipLaunchKernelGGL((grad_z_kernel<0>), gg, dim3(64), 0, st, ExT, inv_ttl, z2, n, n_pad, ld, inv_tau, dz1);
+    QREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL((grad_z_kernel<1>), gg, dim3(64), 0, st, ExT, inv_ttl, z1, n, n_pad, ld, inv_tau, dz2);
+    QREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL((normalize_bwd_kernel<LPR>), dim3(row_blocks), dim3(256), 0, st, z1, z2, dz1, dz2, r1, r2, rows, n, cl_rate, d_out);
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qrec_perturb_rows(float *d_emb, int64_t n_rows, int32_t d, int32_t ld, float eps, const float *d_noise,
+                      uint64_t seed, uint64_t stream_id, float *d_accum, void *stream) {
+    QREC_REQUIRE(d_emb && n_rows >= 0 && d >= 1 && ld >= d, "qrec_perturb_rows: bad argument");
+    if (n_rows == 0) return QREC_OK;
+    hipStream_t st = as_stream(stream);
+    int64_t blocks;
+#define QREC_PT(LPR)                                                                                              \
+    blocks = (n_rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)); if (blocks > 2048) blocks = 2048;                    \
+    hipLaunchKernelGGL((perturb_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, d_emb, n_rows, d, eps, d_noise, \
+                       seed, stream_id, d_accum)
+    switch (ld) {
+        case 32: QREC_PT(8); break;
+        case 64: QREC_PT(16); break;
+        case 128: QREC_PT(32); break;
+        case 256: QREC_PT(64); break;
+        default: set_error("qrec_perturb_rows: row stride must be 32, 64, 128 or 256 floats (got %d)", ld); return QREC_ERR_INVALID;
+    }
+#undef QREC_PT
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+int qrec_info_nce_workspace_bytes(int32_t n, int32_t ld, int64_t *bytes) {
+    QREC_REQUIRE(bytes && n >= 0 && ld > 0, "qrec_info_nce_workspace_bytes: bad argument");
+    const int64_t n_pad = ((int64_t)n + 63) / 64 * 64;
+    *bytes = 4 * (4 * n_pad * ld + 4 * n_pad + n_pad * n_pad);
+    return QREC_OK;
+}
+
+int qrec_info_nce_loss_grad(const float *d_S1, const float *d_S2, float div, const int32_t *d_rows, int32_t n,
+                            int32_t ld, float tau, float cl_rate, void *d_workspace, float *d_out, double *d_loss,
+                            void *stream) {
+    QREC_REQUIRE(d_S1 && d_S2 && d_workspace && d_out && d_loss && n >= 0 && div != 0.f && tau > 0.f,
+                 "qrec_info_nce_loss_grad: bad argument");
+    QREC_REQUIRE(n == 0 || d_rows, "qrec_info_nce_loss_grad: null row list");
+    QREC_REQUIRE(n <= 16384, "qrec_info_nce_loss_grad: at most 16384 unique rows per call");
+    if (n == 0) return QREC_OK;
+    hipStream_t st = as_stream(stream);
+    float *ws = static_cast<float *>(d_workspace);
+    switch (ld) {
+        case 32: return run_info_nce<8>(d_S1, d_S2, div, d_rows, n, ld, tau, cl_rate, ws, d_out, d_loss, st);
+        case 64: return run_info_nce<16>(d_S1, d_S2, div, d_rows, n, ld, tau, cl_rate, ws, d_out, d_loss, st);
+        case 128: return run_info_nce<32>(d_S1, d_S2, div, d_rows, n, ld, tau, cl_rate, ws, d_out, d_loss, st);
+        case 256: return run_info_nce<64>(d_S1, d_S2, div, d_rows, n, ld, tau, cl_rate, ws, d_out, d_loss, st);
+        default: set_error("qrec_info_nce_loss_grad: row stride must be 32, 64, 128 or 256 floats (got %d)", ld); return QREC_ERR_INVALID;
+    }
+}
+
+}  // extern "C"

@@ -106,9 +106,17 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restri
     const int64_t gid = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
     if (gid >= n_long) return;
     const int first = long_first[gid], cnt = long_count[gid];
-    f32x4 acc = *reinterpret_cast<const f32x4 *>(partial + (int64_t)first * (4 * LPR) + 4 * r);
-    for (int k = 1; k < cnt; k++)
-        acc = acc + *reinterpret_cast<const f32x4 *>(partial + (int64_t)(first + k) * (4 * LPR) + 4 * r);
+    const float *p = partial + (int64_t)first * (4 * LPR) + 4 * r;
+    f32x4 acc = *reinterpret_cast<const f32x4 *>(p);
+    int k = 1;
+    for (; k + 8 <= cnt; k += 8) {  // 8 independent loads in flight, then add in slice order
+        f32x4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = *reinterpret_cast<const f32x4 *>(p + (int64_t)(k + q) * (4 * LPR));
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc = acc + v[q];
+    }
+    for (; k < cnt; k++) acc = acc + *reinterpret_cast<const f32x4 *>(p + (int64_t)k * (4 * LPR));
     spmm_epilogue<LPR>(acc, long_row[gid], r, Y, addend, addend_scale, accum);
 }
 

@@ -36,7 +36,7 @@ def joint_norm_adjacency(n_users: int, n_items: int, uid: np.ndarray, iid: np.nd
 class SpmmPlan:
     """Device-resident CSR plus its segment decomposition (include/qrec_hip.h, qrec_spmm_csr)."""
 
-    def __init__(self, indptr: np.ndarray, indices: np.ndarray, values: np.ndarray, ld: int, seg_len: int = 128):
+    def __init__(self, indptr: np.ndarray, indices: np.ndarray, values: np.ndarray, ld: int, seg_len: int = 256):
         n_rows = indptr.size - 1
         nnz_row = np.diff(indptr)
         n_seg_row = np.maximum(1, -(-nnz_row // seg_len)).astype(np.int64)     # ceil, >=1 (empty rows write zeros)
@@ -137,6 +137,108 @@ class LightGCNTrainer:
         self.forward_sum()
         Ebar = (self.S.numpy()[:, :self.d] / np.float32(self.L + 1)).astype(np.float32)
         return np.ascontiguousarray(Ebar[:self.nu]), np.ascontiguousarray(Ebar[self.nu:])
+
+    def ego_embeddings(self):
+        E = self.E.numpy()
+        return E[:self.nu, :self.d].copy(), E[self.nu:, :self.d].copy()
+
+
+def unique_first_appearance(idx: np.ndarray) -> np.ndarray:
+    """tf.unique(x)[0]: distinct values in order of first occurrence (SimGCL.py:61-64)."""
+    _, first = np.unique(idx, return_index=True)
+    return idx[np.sort(first)]
+
+
+class SimGCLTrainer:
+    """model/ranking/SimGCL.py:15-111 on the device: a clean LightGCN encoder (no ego layer in
+    the mean) plus two noise-perturbed ones, batch BPR loss on the clean view, InfoNCE between
+    the perturbed views on the batch's unique users / items, one shared backward pass (the
+    three encoders have the same linear backward operator, so their output gradients are
+    summed first: L SpMMs instead of 3L), dense TF-1.14 Adam."""
+
+    def __init__(self, U0, V0, adj, n_layers: int, lr: float, reg: float, cl_rate: float, eps: float,
+                 tau: float = 0.2, loss_eps: float = 1e-7, seed: int = 0, max_unique: int = 4096):
+        self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
+        self.n = self.nu + self.ni
+        self.ld = padded_ld(self.d, np.float32)
+        self.L, self.lr, self.reg, self.cl_rate, self.eps, self.tau = n_layers, lr, reg, cl_rate, eps, tau
+        self.loss_eps, self.seed = loss_eps, seed
+        self.plan = SpmmPlan(adj[0], adj[1], adj[2], self.ld)
+        E0 = np.zeros((self.n, self.ld), np.float32)
+        E0[:self.nu, :self.d] = U0; E0[self.nu:, :self.d] = V0
+        self.E = DeviceBuffer.from_numpy(E0)
+        z = lambda: DeviceBuffer.zeros((self.n, self.ld), np.float32)
+        self.m, self.v = z(), z()
+        self.Sm, self.S1, self.S2, self.dOut, self.A, self.B = z(), z(), z(), z(), z(), z()
+        self.d_loss = DeviceBuffer.zeros(2, np.float64)         # [rec, cl (unscaled)]
+        self.max_unique = max_unique
+        self.ws = DeviceBuffer(capi.info_nce_workspace_bytes(max_unique, self.ld), np.uint8)
+        f = np.float32
+        self.b1, self.b2, self.adam_eps = f(0.9), f(0.999), f(1e-8)
+        self.b1p, self.b2p = self.b1, self.b2
+        self.step_no = 0
+
+    def _encode(self, S, view: int, noises=None, stream=None):
+        """S = sum_k emb_k over the L propagated layers (view 0 = clean; 1, 2 = perturbed)."""
+        S.fill_bytes(0, stream)
+        x = self.E
+        for k in range(self.L):
+            y = self.A if k % 2 == 0 else self.B
+            if view == 0:
+                capi.spmm_csr(self.plan, x, y, self.ld, d_accum=S, stream=stream)
+            else:
+                capi.spmm_csr(self.plan, x, y, self.ld, stream=stream)
+                noise = None if noises is None else noises[(view - 1) * self.L + k]
+                capi.perturb_rows(y, self.n, self.d, self.ld, self.eps, noise, self.seed,
+                                  (self.step_no * 2 + (view - 1)) * 64 + k, d_accum=S, stream=stream)
+            x = y
+
+    def adam_alpha(self) -> float:
+        f = np.float32
+        return float(f(f(self.lr) * np.sqrt(f(1) - self.b2p, dtype=f) / (f(1) - self.b1p)))
+
+    def train_step_async(self, d_u, d_i, d_j, B: int, d_uniq_users, n_uu: int, d_uniq_items, n_ui: int,
+                         noises=None, stream=None):
+        """u/i/j int32[B]; d_uniq_users: distinct user rows; d_uniq_items: distinct item rows
+        ALREADY offset by n_users; noises: optional list of 2L device buffers [N][ld] (tests)."""
+        if max(n_uu, n_ui) > self.max_unique:
+            raise ValueError("more unique rows in the batch than the InfoNCE workspace holds")
+        L = float(self.L)
+        self._encode(self.Sm, 0, stream=stream)
+        self._encode(self.S1, 1, noises, stream)
+        self._encode(self.S2, 2, noises, stream)
+        self.dOut.fill_bytes(0, stream)
+        self.d_loss.fill_bytes(0, stream)
+        capi.bpr_batch_loss_grad(self.Sm, L, self.nu, self.n, self.ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
+                                 self.dOut, self.d_loss, stream)
+        cl = self.d_loss.ptr + 8
+        capi.info_nce_loss_grad(self.S1, self.S2, L, d_uniq_users, n_uu, self.ld, self.tau, self.cl_rate, self.ws,
+                                self.dOut, cl, stream)
+        capi.info_nce_loss_grad(self.S1, self.S2, L, d_uniq_items, n_ui, self.ld, self.tau, self.cl_rate, self.ws,
+                                self.dOut, cl, stream)
+        # dE0 = (1/L) sum_{k=1..L} A^k dOut :  W_0 = dOut, W_k = dOut + A W_{k-1}, G = A W_{L-1}
+        x = self.dOut
+        for k in range(self.L - 1):
+            y = self.A if k % 2 == 0 else self.B
+            capi.spmm_csr(self.plan, x, y, self.ld, d_addend=self.dOut, addend_scale=1.0, stream=stream)
+            x = y
+        g = self.B if x is self.A else self.A
+        capi.spmm_csr(self.plan, x, g, self.ld, stream=stream)
+        capi.adam_step(self.E, self.m, self.v, g, self.n * self.ld, 1.0 / L, self.adam_alpha(), float(self.b1),
+                       float(self.b2), float(self.adam_eps), stream)
+        self.b1p = np.float32(self.b1p * self.b1); self.b2p = np.float32(self.b2p * self.b2)
+        self.step_no += 1
+
+    def losses(self, stream=None):
+        """(total, rec_loss, cl_loss) like the reference prints them (SimGCL.py:104-107)."""
+        rec, cl = self.d_loss.numpy(stream)
+        cl *= self.cl_rate
+        return float(rec + cl), float(rec), float(cl)
+
+    def main_embeddings(self):
+        self._encode(self.Sm, 0)
+        m = (self.Sm.numpy()[:, :self.d] / np.float32(self.L)).astype(np.float32)
+        return np.ascontiguousarray(m[:self.nu]), np.ascontiguousarray(m[self.nu:])
 
     def ego_embeddings(self):
         E = self.E.numpy()

@@ -1,0 +1,72 @@
+"""SimGCL behind the reference's class name and hooks (model/ranking/SimGCL.py:12-118):
+LightGCN encoder without the ego layer, two noise-perturbed views contrasted with InfoNCE
+(tau = 0.2) on the batch's unique users and items, BPR on the clean view, Adam; evaluated
+after every epoch, best epoch kept."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from ...base.graphRecommender import GraphRecommender
+from ...capi import DeviceBuffer
+from ...graph import SimGCLTrainer, unique_first_appearance
+from ...util import config
+
+
+def xavier_uniform(shape) -> np.ndarray:
+    """tf.contrib.layers.xavier_initializer(): U(+-sqrt(6/(fan_in+fan_out))) (SimGCL.py:42-44);
+    drawn from numpy's global RNG (TF's stream is not reproducible outside TF)."""
+    lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+    return np.random.uniform(-lim, lim, shape).astype(np.float32)
+
+
+class SimGCL(GraphRecommender):
+    def __init__(self, conf, trainingSet=None, testSet=None, fold="[1]"):
+        super().__init__(conf, trainingSet, testSet, fold)
+
+    def readConfiguration(self):
+        super().readConfiguration()
+        args = config.OptionConf(self.config["SimGCL"])
+        self.cl_rate = float(args["-lambda"])
+        self.eps = float(args["-eps"])
+        self.n_layers = int(args["-n_layer"])
+
+    def initModel(self):
+        super().initModel()
+        self.user_embeddings = xavier_uniform((self.num_users, self.emb_size))
+        self.item_embeddings = xavier_uniform((self.num_items, self.emb_size))
+        self.trainer = SimGCLTrainer(self.user_embeddings, self.item_embeddings, self.create_joint_sparse_adjaceny(),
+                                     self.n_layers, self.lRate, self.regU, self.cl_rate, self.eps,
+                                     seed=int(os.environ.get("QREC_SEED", "0")), max_unique=max(self.batch_size, 64))
+
+    def saveModel(self):
+        self.bestU, self.bestV = self.U, self.V
+
+    def trainModel(self):
+        quiet = os.environ.get("QREC_QUIET") == "1"
+        tr, nu = self.trainer, self.num_users
+        for epoch in range(self.maxEpoch):
+            u, i, j = self.sample_epoch_pairwise()
+            d_u, d_i, d_j = DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i), DeviceBuffer.from_numpy(j)
+            # tf.unique per batch, for the whole epoch in one upload
+            starts = list(range(0, u.size, self.batch_size))
+            uu = [unique_first_appearance(u[s:s + self.batch_size]) for s in starts]
+            vv = [unique_first_appearance(i[s:s + self.batch_size]) + nu for s in starts]
+            off_u = np.concatenate([[0], np.cumsum([x.size for x in uu])]); off_v = np.concatenate([[0], np.cumsum([x.size for x in vv])])
+            d_uu = DeviceBuffer.from_numpy(np.concatenate(uu).astype(np.int32)); d_vv = DeviceBuffer.from_numpy(np.concatenate(vv).astype(np.int32))
+            for n, s in enumerate(starts):
+                B = min(self.batch_size, u.size - s)
+                tr.train_step_async(d_u.ptr + 4 * s, d_i.ptr + 4 * s, d_j.ptr + 4 * s, B,
+                                    d_uu.ptr + 4 * int(off_u[n]), uu[n].size, d_vv.ptr + 4 * int(off_v[n]), vv[n].size)
+                if not quiet:
+                    l, rec_l, cl_l = tr.losses()
+                    print("training:", epoch + 1, "batch", n, "total_loss:", l, "rec_loss:", rec_l, "cl_loss", cl_l)
+            self.U, self.V = tr.main_embeddings()
+            self.ranking_performance(epoch)
+        self.U, self.V = self.bestU, self.bestV
+
+    def predictForRanking(self, u):
+        if self.data.containsUser(u):
+            return self.V.dot(self.U[self.data.getUserId(u)])
+        return [self.data.globalMean] * self.num_items

@@ -157,3 +157,116 @@ def test_lightgcn_class_end_to_end_against_restatement_with_reference_sampler_st
     Ur, Vr = ref.final_embeddings()
     assert rel_err(m.U, Ur) < 1e-4 and rel_err(m.V, Vr) < 1e-4
     assert np.array_equal(capi.state_from_python(random.getstate()), z["py_state"])   # sampler stayed in lock-step
+
+
+# ---------------------------------------------------------------------------------------------
+# SimGCL
+# ---------------------------------------------------------------------------------------------
+from qrec_amd.graph import SimGCLTrainer, unique_first_appearance  # noqa: E402
+
+
+@pytest.mark.parametrize("dim,ld", [(64, 64), (50, 64), (8, 32), (100, 128)])
+def test_perturb_rows_matches_restatement_and_philox_is_uniform(dim, ld):
+    rng = np.random.default_rng(dim)
+    n = 1000
+    emb = rng.standard_normal((n, dim)).astype(np.float32); emb[5, :3] = 0      # sign(0) = 0
+    noise = rng.random((n, dim)).astype(np.float32)
+    acc0 = rng.standard_normal((n, dim)).astype(np.float32)
+    nz, _ = T.l2_normalize_rows(noise)
+    want = (emb + (np.sign(emb) * nz) * np.float32(0.1)).astype(np.float32)
+    dE, dN, dA = DB.from_numpy(pad_cols(emb, ld)), DB.from_numpy(pad_cols(noise, ld)), DB.from_numpy(pad_cols(acc0, ld))
+    capi.perturb_rows(dE, n, dim, ld, 0.1, dN, d_accum=dA)
+    got = dE.numpy()
+    assert rel_err(got[:, :dim], want) < TOL and (got[:, dim:] == 0).all()
+    assert rel_err(dA.numpy()[:, :dim], acc0 + want) < TOL
+    # device-drawn noise: |delta| = eps * unit vector, all components same sign as emb, reproducible
+    dE2 = DB.from_numpy(pad_cols(emb, ld)); capi.perturb_rows(dE2, n, dim, ld, 0.1, None, seed=3, stream_id=7)
+    delta = dE2.numpy()[:, :dim] - emb
+    np.testing.assert_allclose(np.linalg.norm(delta[np.abs(emb).min(1) > 0], axis=1), 0.1, rtol=1e-4)
+    assert (delta * np.sign(emb) >= 0).all() and (dE2.numpy()[:, dim:] == 0).all()
+    dE3 = DB.from_numpy(pad_cols(emb, ld)); capi.perturb_rows(dE3, n, dim, ld, 0.1, None, seed=3, stream_id=7)
+    assert np.array_equal(dE2.numpy(), dE3.numpy())
+    dE4 = DB.from_numpy(pad_cols(emb, ld)); capi.perturb_rows(dE4, n, dim, ld, 0.1, None, seed=3, stream_id=8)
+    assert not np.array_equal(dE2.numpy(), dE4.numpy())
+    # implied uniforms: delta/eps * |noise| ... check the direction's components are spread like U[0,1) draws
+    u = np.abs(delta) / 0.1
+    u = u / u.max(1, keepdims=True)
+    assert 0.3 < u.mean() < 0.8
+
+
+@pytest.mark.parametrize("n,dim,ld", [(1, 64, 64), (37, 50, 64), (300, 64, 64), (2048, 64, 64), (129, 8, 32), (200, 128, 128)])
+def test_info_nce_matches_restatement(n, dim, ld):
+    rng = np.random.default_rng(n + dim)
+    N = max(3 * n, 10)
+    S1 = rng.standard_normal((N, dim)).astype(np.float32); S2 = (S1 + 0.5 * rng.standard_normal((N, dim))).astype(np.float32)
+    rows = rng.permutation(N)[:n].astype(np.int32)
+    div = np.float32(2)
+    loss, d1, d2 = T.info_nce_loss_and_grads((S1[rows] / div).astype(np.float32), (S2[rows] / div).astype(np.float32))
+    base = rng.standard_normal((N, dim)).astype(np.float32)
+    want = base.copy(); want[rows] += np.float32(0.5) * d1 + np.float32(0.5) * d2
+    dOut, dl = DB.from_numpy(pad_cols(base, ld)), DB.zeros(1, np.float64)
+    ws = DB(capi.info_nce_workspace_bytes(n, ld), np.uint8)
+    capi.info_nce_loss_grad(DB.from_numpy(pad_cols(S1, ld)), DB.from_numpy(pad_cols(S2, ld)), 2.0, DB.from_numpy(rows), n, ld,
+                            0.2, 0.5, ws, dOut, dl)
+    got = dOut.numpy()
+    assert abs(dl.numpy()[0] - loss) <= 2e-5 * max(abs(loss), 1.0)
+    assert rel_err(got[:, :dim] - base, want - base) < 5e-5 and (got[:, dim:] == 0).all()
+    untouched = np.ones(N, bool); untouched[rows] = False
+    assert np.array_equal(got[untouched][:, :dim], base[untouched])
+
+
+@pytest.mark.parametrize("L", [1, 2, 3])
+def test_simgcl_training_steps_match_restatement(L):
+    d, adj, A = _graph("small")
+    nu, ni, dim, B = d["n_users"], d["n_items"], 64, 1024
+    N = nu + ni
+    rng = np.random.default_rng(20 + L)
+    lim = np.sqrt(6.0 / (nu + dim))
+    U0 = rng.uniform(-lim, lim, (nu, dim)).astype(np.float32); V0 = rng.uniform(-lim, lim, (ni, dim)).astype(np.float32)
+    ref = T.SimGCL(U0, V0, A, L, lr=0.001, reg=1e-4, cl_rate=0.5, eps=0.1)
+    tr = SimGCLTrainer(U0, V0, adj, L, lr=0.001, reg=1e-4, cl_rate=0.5, eps=0.1, max_unique=B)
+    for step in range(5):
+        sel = rng.integers(0, d["train_u"].size, B)
+        u = d["train_u"][sel].astype(np.int32); i = d["train_i"][sel].astype(np.int32); j = rng.integers(0, ni, B).astype(np.int32)
+        noises = [rng.random((N, dim)).astype(np.float32) for _ in range(2 * L)]
+        lref, rec_ref, cl_ref = ref.train_step(u, i, j, noises)
+        uu = unique_first_appearance(u); vv = (unique_first_appearance(i) + nu).astype(np.int32)
+        tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, DB.from_numpy(uu), uu.size,
+                            DB.from_numpy(vv), vv.size, noises=[DB.from_numpy(x) for x in noises])
+        tot, rec, cl = tr.losses()
+        assert abs(rec - rec_ref) / abs(rec_ref) < 2e-5 and abs(cl - cl_ref) / abs(cl_ref) < 2e-5
+    Ug, Vg = tr.ego_embeddings()
+    E0 = np.concatenate([U0, V0])
+    # Adam divides by sqrt(v): on coordinates whose gradient is at rounding-noise level the step is
+    # +-alpha whatever the implementation, so two correct fp32 pipelines (different summation order
+    # in the SpMM / MFMA) drift apart by ~alpha*sqrt(steps) there.  Losses above are held to 2e-5;
+    # the tables to 5e-5 after 5 steps.
+    assert rel_err(np.concatenate([Ug, Vg]) - E0, ref.E - E0) < 2e-3
+    assert rel_err(np.concatenate([Ug, Vg]), ref.E) < 5e-5
+    Um, Vm = tr.main_embeddings(); Ur, Vr = ref.final_embeddings()
+    assert rel_err(Um, Ur) < 1e-4 and rel_err(Vm, Vr) < 1e-4
+
+
+def test_simgcl_class_runs_stock_conf_shape_and_keeps_best_epoch():
+    """Drop-in SimGCL class on the FilmTrust rows with config/SimGCL.conf's hyper-parameters
+    (smaller d / epochs): trains with device-drawn noise, evaluates every epoch, returns the
+    best epoch's embeddings, loss decreases."""
+    from qrec_amd.model.ranking.SimGCL import SimGCL
+    meta, z = load_golden("bpr_filmtrust")
+    train, test = rows_from_golden(z)
+    conf = conf_from_text(meta["conf"])
+    conf["model.name"] = "SimGCL"; conf["SimGCL"] = "-n_layer 2 -lambda 0.5 -eps 0.1"; conf["num.factors"] = "16"
+    conf["num.max.epoch"] = "3"; conf["batch_size"] = "2048"; conf["learnRate"] = "-init 0.001 -max 1"
+    conf["reg.lambda"] = "-u 0.0001 -i 0.0001 -b 0.2 -s 0.2"; conf["item.ranking"] = "on -topN 20"
+    random.seed(1); np.random.seed(1)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        m = SimGCL(conf, train, test)
+        measure = m.execute()
+    out = buf.getvalue()
+    tot = [float(l.split("total_loss:")[1].split()[0]) for l in out.splitlines() if "total_loss:" in l]
+    assert len(tot) == 3 * 16 and tot[-1] < tot[0] and np.isfinite(tot).all()
+    assert out.count("Quick Ranking Performance") == 3 and m.bestPerformance[0] in (1, 2, 3)
+    rec = [float(x.split(":")[1]) for x in measure if x.startswith("Recall")][0]
+    assert 0.0 < rec <= 1.0
+    assert m.U is m.bestU and m.U.shape == (meta["n_users"], 16)

@@ -91,3 +91,47 @@ def test_lightgcn_training_reduces_loss_and_bpr_grad_finite_difference():
             args = [a if x is arr else x for x in (ub, ib, jb)]
             num = (f(*args) - f(ub, ib, jb)) / h
             assert grad[idx] == pytest.approx(num, rel=2e-3, abs=2e-5)
+
+
+def _torch_simgcl_loss(E, adj_t, nu, L, u, i, j, reg, cl_rate, eps, noises):
+    def enc(ns):
+        emb, outs = E, []
+        for k in range(L):
+            emb = torch.sparse.mm(adj_t, emb)
+            if ns is not None:
+                nz = torch.nn.functional.normalize(ns[k], dim=1, eps=1e-6)
+                emb = emb + torch.sign(emb) * nz * eps
+            outs.append(emb)
+        return torch.stack(outs).mean(0)
+    main, p1, p2 = enc(None), enc(noises[:L]), enc(noises[L:])
+    ub, ib, jb = main[u], main[i + nu], main[j + nu]
+    score = (ub * ib).sum(1) - (ub * jb).sum(1)
+    rec = -torch.log(torch.sigmoid(score) + 1e-7).sum() + reg * 0.5 * ((ub ** 2).sum() + (ib ** 2).sum() + (jb ** 2).sum())
+    cl = 0
+    for rows in (torch.unique(u), torch.unique(i) + nu):
+        z1 = torch.nn.functional.normalize(p1[rows], dim=1, eps=1e-6); z2 = torch.nn.functional.normalize(p2[rows], dim=1, eps=1e-6)
+        pos = torch.exp((z1 * z2).sum(1) / 0.2); ttl = torch.exp(z1 @ z2.T / 0.2).sum(1)
+        cl = cl - torch.log(pos / ttl).sum()
+    return rec + cl_rate * cl, rec, cl_rate * cl
+
+
+@pytest.mark.parametrize("L", [1, 2, 3])
+def test_simgcl_gradient_matches_autograd(L):
+    rng = np.random.default_rng(10 + L)
+    nu, ni, d, B = 40, 30, 8, 48
+    uid = rng.integers(0, nu, 300); iid = rng.integers(0, ni, 300)
+    adj = T.joint_norm_adjacency(nu, ni, uid, iid)
+    U0 = rng.standard_normal((nu, d)).astype(np.float32) * 0.1; V0 = rng.standard_normal((ni, d)).astype(np.float32) * 0.1
+    u = rng.integers(0, nu, B); i = rng.integers(0, ni, B); j = rng.integers(0, ni, B)
+    noises = [rng.random((nu + ni, d)).astype(np.float32) for _ in range(2 * L)]
+    m = T.SimGCL(U0, V0, adj, L, lr=0.001, reg=1e-3, cl_rate=0.5, eps=0.1)
+    loss, rec, cl, g = m.loss_and_grad(u, i, j, noises)
+    coo = adj.tocoo()
+    adj_t = torch.sparse_coo_tensor(np.vstack([coo.row, coo.col]), coo.data.astype(np.float64), adj.shape).coalesce()
+    E = torch.tensor(np.concatenate([U0, V0]).astype(np.float64), requires_grad=True)
+    tl, trec, tcl = _torch_simgcl_loss(E, adj_t, nu, L, torch.tensor(u), torch.tensor(i), torch.tensor(j), 1e-3, 0.5, 0.1,
+                                       [torch.tensor(n.astype(np.float64)) for n in noises])
+    tl.backward()
+    assert rec == pytest.approx(float(trec.detach()), rel=1e-5) and cl == pytest.approx(float(tcl.detach()), rel=1e-5)
+    np.testing.assert_allclose(g, E.grad.numpy(), rtol=2e-3, atol=2e-5)
+    assert np.array_equal(T.unique_first_appearance([3, 1, 3, 2, 1]), [3, 1, 2])
