@@ -72,35 +72,43 @@ def evaluate_recall(P, Q, data, indptr, items, N=20):
     return recall_at_n(ids, users, data["test_u"], data["test_i"], data["n_items"])
 
 
-def cpu_baseline(u, i, indptr, n_items, U, P0, Q0, epochs_like_gpu, seconds=12.0):
-    """The same epochs on the host: oracle sampler (CPython MT19937 replay) + the plain-C fp64
-    restatement of BPR.optimization + the bold-driver schedule, single thread.  It first runs
-    exactly as many epochs as the GPU did from the same initial tables (its result is the
-    Recall@20 reference), then keeps going until ~`seconds` of CPU work are timed."""
+def cpu_baseline(u, i, indptr, n_items, U, seconds=12.0):
+    """The same epochs on the host, timed: oracle sampler (CPython MT19937 replay) + the plain-C fp64
+    restatement of BPR.optimization + the epoch-end reductions, single thread, ~`seconds` of work."""
     from oracle import c as O
-    P, Q = P0.astype(np.float64), Q0.astype(np.float64)
+    rng = np.random.default_rng(0)
+    P = rng.random((U, DIM)) / 3; Q = rng.random((n_items, DIM)) / 3
     mt = O.MT.cpython_seed(0)
-    lr, last = LR0, 0.0
     done, epochs, t0 = 0, 0, time.perf_counter()
-    snap = None
     while True:
         j = O.bpr_sample_epoch(mt, indptr, i, n_items)
-        loss = O.bpr_sgd(P, Q, u, i, j, lr, REG_U, REG_I) + REG_U * O.sumsq(P) + REG_I * O.sumsq(Q)
-        if epochs > 0:
-            lr *= 1.05 if abs(last) > abs(loss) else 0.5
-        lr = min(lr, MAX_LR); last = loss
+        O.bpr_sgd(P, Q, u, i, j, LR0, REG_U, REG_I)
+        O.sumsq(P); O.sumsq(Q)
         done += u.size; epochs += 1
-        if epochs == epochs_like_gpu:
-            snap = (P.copy(), Q.copy(), loss)
-        if epochs >= epochs_like_gpu and time.perf_counter() - t0 >= seconds:
+        if time.perf_counter() - t0 >= seconds:
             break
     dt = time.perf_counter() - t0
-    out = {"value": done / dt, "unit": "triplet-updates/s", "cores": 1, "kind": "port",
-           "sample": f"{epochs} full epochs ({done} triplets, {dt:.1f} s) of the same Yelp2018-shape workload; "
-                     "plain-C fp64 port of model/ranking/BPR.py:29-53 incl. the CPython-stream sampler and the "
-                     "bold-driver schedule (the Python reference itself cannot travel to this box; it measured "
-                     "58.9k/s on 1 core, BASELINE.md)"}
-    return out, snap
+    return {"value": done / dt, "unit": "triplet-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{epochs} full epochs ({done} triplets, {dt:.1f} s) of the same Yelp2018-shape workload; "
+                      "plain-C fp64 port of model/ranking/BPR.py:29-53 incl. the CPython-stream sampler "
+                      "(the Python reference itself cannot travel to this box; it measured 58.9k/s on 1 core, BASELINE.md)"}
+
+
+def cpu_exact_order_reference(sgd, u, i, n_items, P0, Q0, epochs, seed):
+    """Recall@20 reference: order-exact fp64 training on the host for the same number of epochs, from
+    the same initial tables, with the reference's bold-driver schedule and -- paired design -- the very
+    negatives the GPU run used (the device Philox stream for (seed, epoch) is re-generated and read back)."""
+    from oracle import c as O
+    P, Q = P0.astype(np.float64), Q0.astype(np.float64)
+    lr, last = LR0, 0.0
+    for k in range(epochs):
+        sgd.sample_negatives_device(seed, k)
+        j = sgd.d_j.numpy()
+        loss = O.bpr_sgd(P, Q, u, i, j, lr, REG_U, REG_I) + REG_U * O.sumsq(P) + REG_I * O.sumsq(Q)
+        if k > 0:
+            lr *= 1.05 if abs(last) > abs(loss) else 0.5
+        lr = min(lr, MAX_LR); last = loss
+    return P, Q, last
 
 
 def main():
@@ -224,17 +232,17 @@ def main():
                                  "resource is the L2 atomic units (~1 dword/clk/channel), see DESIGN.md"},
         }
         if not args.no_cpu_baseline and world == 1:
-            cpu, snap = cpu_baseline(u, items, indptr, I, U, P0, Q0, total)
-            out["cpu_baseline"] = cpu
-            out["vs_cpu_port"] = value / cpu["value"]
-            # Recall@20 (the metric's second half): GPU throughput mode vs the order-exact CPU port,
-            # same initial tables, same number of epochs, same schedule; both ranked on the device.
+            out["cpu_baseline"] = cpu_baseline(u, items, indptr, I, U)
+            out["vs_cpu_port"] = value / out["cpu_baseline"]["value"]
+            # Recall@20 (the metric's second half): GPU throughput mode vs the order-exact CPU port on the
+            # same negatives, same initial tables, same epochs and schedule; both ranked by the device ranker.
             Pg, Qg = tables.download(np.float32)
+            Pc, Qc, loss_c = cpu_exact_order_reference(sgd, u, items, I, P0, Q0, total, 2018)
             r_gpu = evaluate_recall(Pg, Qg, data, indptr, items)
-            r_cpu = evaluate_recall(snap[0], snap[1], data, indptr, items)
+            r_cpu = evaluate_recall(Pc, Qc, data, indptr, items)
             out["recall_at_20"] = {"gpu_throughput_mode": r_gpu, "cpu_port_exact_order": r_cpu,
                                    "abs_diff": abs(r_gpu - r_cpu), "epochs": total,
-                                   "final_loss_gpu": state["loss"], "final_loss_cpu": snap[2]}
+                                   "final_loss_gpu": state["loss"], "final_loss_cpu": loss_c}
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

@@ -294,7 +294,9 @@ double orc_bpr_sgd_f32(float *P, float *Q, int32_t d, const int32_t *u_idx,
         for (c = 0; c < d; c++) pu[c] -= (lr * regU) * pu[c];
         for (c = 0; c < d; c++) qi[c] -= (lr * regI) * qi[c];
         for (c = 0; c < d; c++) qj[c] -= (lr * regI) * qj[c];
-        loss += -log((double)s);
+        /* -log(sigmoid(x)) in the overflow-free form: fp32 sigmoid underflows to 0 below
+         * x = -88.7 where the reference's fp64 expression is still finite */
+        { double xd = (double)(xi - xj); loss += xd >= 0 ? log1p(exp(-xd)) : -xd + log1p(exp(xd)); }
     }
     return loss;
 }

@@ -33,6 +33,16 @@ template <typename T> __device__ inline T dev_exp(T x);
 template <> __device__ inline float dev_exp<float>(float x) { return expf(x); }
 template <> __device__ inline double dev_exp<double>(double x) { return exp(x); }
 
+// -log(sigmoid(x)) = softplus(-x), evaluated without forming sigmoid first: in fp32 sigmoid(x)
+// underflows to 0 for x < -88.7 and -log(0) = inf, while the reference's fp64 value (= -x) is
+// finite down to x ~ -745.  Same value to rounding wherever the direct form is finite.
+__device__ inline float neg_log_sigmoid(float x) {
+    return x >= 0.f ? log1pf(expf(-x)) : (-x + log1pf(expf(x)));
+}
+__device__ inline double neg_log_sigmoid(double x) {
+    return x >= 0.0 ? log1p(exp(-x)) : (-x + log1p(exp(x)));
+}
+
 template <typename T>
 __device__ inline T wave_allreduce_sum(T v) {
 #pragma unroll
@@ -96,7 +106,9 @@ __global__ __launch_bounds__(64) void bpr_ordered_kernel(
             qj[e] -= ci * qj[e];
         }
         store_row(Q, it, qi); store_row(Q, jt, qj);
-        loss += -log((double)s);
+        // fp64 tables: the reference's own expression (model/ranking/BPR.py:53); fp32: stable form
+        if constexpr (sizeof(T) == 8) loss += -log((double)s);
+        else loss += neg_log_sigmoid((double)(di - dj));
         if (t + 1 < n) {  // rows just written supersede what the prefetch saw
 #pragma unroll
             for (int e = 0; e < EPL; e++) {
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(256) void bpr_hogwild_kernel(
             }
             hw_update_row<LPR, E, UPD>(rsQ, it, r, qi, qin);
             hw_update_row<LPR, E, UPD>(rsQ, jt, r, qj, qjn);
-            loss += -logf(s);
+            loss += neg_log_sigmoid(di - dj);
             if (more) {  // rows this group just changed supersede the prefetched copy
 #pragma unroll
                 for (int e = 0; e < E; e++) {

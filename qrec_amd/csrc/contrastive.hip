@@ -4,8 +4,8 @@
 //   perturb_kernel          emb += sign(emb) * l2_normalize(noise) * eps ; accum += emb
 //   gather_normalize_kernel z = l2_normalize(S[row]/div) for the batch's unique rows, both views
 //   exp_logits_kernel       ExT[b][a] = exp(z1[a].z2[b] / tau)               (MFMA f32 32x32x2)
-//   row_stats_kernel        ttl[a] = sum_b Ex[a][b];  loss += -log(exp(z1[a].z2[a]/tau) / ttl[a])
-//   grad_z_kernel           dz1 = (P - I) z2 / tau ; dz2 = (P - I)^T z1 / tau , P = Ex / ttl   (MFMA)
+//   row_stats_kernel        ttl[a] = sum_b Ex[a][b] (from per-tile partial sums);  loss += -log(exp(z1[a].z2[a]/tau) / ttl[a])
+//   grad_z_kernel           dz1 = (P - I) z2 / tau ; dz2 = (P - I)^T z1 / tau , P = Ex / ttl   (MFMA, split-K x16)
 //   normalize_bwd_kernel    d_out[row] += cl_rate * (dx1 + dx2),  dx = (dz - z (z.dz)) / |x|
 //
 // The n x n logits block (n <= batch size) is the only GEMM-shaped work: 3 products of
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void gather_normalize_kernel(const float *__re
 // lane l: row index r = l&31, k-slot h = l>>5 owns columns [64c+32h, 64c+32h+32) of chunk c.
 __global__ __launch_bounds__(256) void exp_logits_kernel(const float *__restrict__ z1, const float *__restrict__ z2,
                                                          int n, int n_pad, int ld, float inv_tau,
-                                                         float *__restrict__ ExT) {
+                                                         float *__restrict__ ExT, float *__restrict__ psum) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int a0 = blockIdx.x * 32, b0 = (blockIdx.y * 4 + wave) * 32;
@@ -120,28 +120,27 @@ __global__ __launch_bounds__(256) void exp_logits_kernel(const float *__restrict
         }
     }
     // C/D: col = lane&31 -> a, row = (q&3) + 8*(q>>2) + 4*h -> b
+    float part = 0.f;   // sum over this tile's 32 b's for column a (fixed order: deterministic)
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const int b = b0 + (q & 3) + 8 * (q >> 2) + 4 * h, a = a0 + r;
-        ExT[(int64_t)b * n_pad + a] = (a < n && b < n) ? expf(acc[q] * inv_tau) : 0.f;
+        const float e = (a < n && b < n) ? expf(acc[q] * inv_tau) : 0.f;
+        ExT[(int64_t)b * n_pad + a] = e;
+        part += e;
     }
+    part += __shfl_xor(part, 32, kWave);
+    if (h == 0) psum[(int64_t)(b0 / 32) * n_pad + a0 + r] = part;
 }
 
-// ttl[a] = sum_b ExT[b][a]  (thread per a, coalesced);  loss_a = -log(exp(dotp[a]*inv_tau) / ttl[a])
-__global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ ExT, int n, int n_pad,
+// ttl[a] = sum over b-tiles of psum[tile][a];  loss_a = -log(exp(dotp[a]*inv_tau) / ttl[a])
+__global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ psum, int n, int n_pad,
                                                         const float *__restrict__ dotp, float inv_tau,
                                                         float *__restrict__ inv_ttl, double *__restrict__ loss_out) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     double l = 0.0;
     if (a < n) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int b = 0;
-        for (; b + 4 <= n; b += 4) {
-            s0 += ExT[(int64_t)b * n_pad + a]; s1 += ExT[(int64_t)(b + 1) * n_pad + a];
-            s2 += ExT[(int64_t)(b + 2) * n_pad + a]; s3 += ExT[(int64_t)(b + 3) * n_pad + a];
-        }
-        for (; b < n; b++) s0 += ExT[(int64_t)b * n_pad + a];
-        const float ttl = (s0 + s1) + (s2 + s3);
+        float ttl = 0.f;
+        for (int t = 0; t < n_pad / 32; t++) ttl += psum[(int64_t)t * n_pad + a];
         inv_ttl[a] = 1.0f / ttl;
         l = (double)(-logf(expf(dotp[a] * inv_tau) / ttl));
     }
@@ -154,18 +153,23 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict_
 // MODE 0: out[a][:] = inv_tau * sum_b G[a][b] z[b][:]      (dz1, z = z2)   A[i=a][k=b] = G[a][b]
 // MODE 1: out[b][:] = inv_tau * sum_a G[a][b] z[a][:]      (dz2, z = z1)   A[i=b][k=a] = G[a][b]
 // one wavefront per (32 output rows) x (32 output columns); K = n in chunks of 64 (2 slots x 32).
+constexpr int kSplitK = 16;   // K = n is cut into 16 slices -> 16x more wavefronts; partials summed by the consumer
+
 template <int MODE>
-__global__ __launch_bounds__(64) void grad_z_kernel(const float *__restrict__ ExT, const float *__restrict__ inv_ttl,
-                                                    const float *__restrict__ z, int n, int n_pad, int ld, float inv_tau,
-                                                    float *__restrict__ out) {
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+__global__ __launch_bounds__(256) void grad_z_kernel(const float *__restrict__ ExT, const float *__restrict__ inv_ttl,
+                                                     const float *__restrict__ z, int n, int n_pad, int ld, float inv_tau,
+                                                     float *__restrict__ out_parts) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    const int ks = blockIdx.z * 4 + wave;                 // K slice
     const int i = i0 + r;
+    const int k_per = ((n_pad / 64 + kSplitK - 1) / kSplitK) * 64;
+    const int c_beg = ks * k_per, c_end = (c_beg + k_per) < n_pad ? (c_beg + k_per) : n_pad;
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; q++) acc[q] = 0.f;
     const float my_inv = (MODE == 0 && i < n) ? inv_ttl[i] : 0.f;
-    for (int c = 0; c < n_pad; c += 64) {
+    for (int c = c_beg; c < c_end; c += 64) {
         const int k0 = c + 32 * h;
 #pragma unroll 8
         for (int s = 0; s < 32; s++) {
@@ -179,10 +183,11 @@ __global__ __launch_bounds__(64) void grad_z_kernel(const float *__restrict__ Ex
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, zb, acc, 0, 0, 0);
         }
     }
+    float *out = out_parts + (int64_t)ks * n_pad * ld;
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const int row = i0 + (q & 3) + 8 * (q >> 2) + 4 * h, col = j0 + r;
-        if (row < n && col < ld) out[(int64_t)row * ld + col] = acc[q] * inv_tau;
+        if (row < n_pad && col < ld) out[(int64_t)row * ld + col] = acc[q] * inv_tau;
     }
 }
 
@@ -191,15 +196,20 @@ template <int LPR>
 __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float *__restrict__ z1, const float *__restrict__ z2,
                                                             const float *__restrict__ dz1, const float *__restrict__ dz2,
                                                             const float *__restrict__ r1, const float *__restrict__ r2,
-                                                            const int32_t *__restrict__ rows, int n, float scale,
-                                                            float *__restrict__ d_out) {
+                                                            const int32_t *__restrict__ rows, int n, int64_t part_stride,
+                                                            float scale, float *__restrict__ d_out) {
     constexpr int GPW = kWave / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
     const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
     if (k >= n) return;
     const int64_t src = k * (4 * LPR) + 4 * r, dst = (int64_t)rows[k] * (4 * LPR) + 4 * r;
     const f32x4 a = *reinterpret_cast<const f32x4 *>(z1 + src), b = *reinterpret_cast<const f32x4 *>(z2 + src);
-    const f32x4 da = *reinterpret_cast<const f32x4 *>(dz1 + src), db = *reinterpret_cast<const f32x4 *>(dz2 + src);
+    f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da;
+#pragma unroll
+    for (int ks = 0; ks < kSplitK; ks++) {
+        da = da + *reinterpret_cast<const f32x4 *>(dz1 + (int64_t)ks * part_stride + src);
+        db = db + *reinterpret_cast<const f32x4 *>(dz2 + (int64_t)ks * part_stride + src);
+    }
     float pa = a.x * da.x + a.y * da.y + a.z * da.z + a.w * da.w, pb = b.x * db.x + b.y * db.y + b.z * db.z + b.w * db.w;
     pa = row_allreduce_sum<LPR>(pa); pb = row_allreduce_sum<LPR>(pb);
     const f32x4 dxa = (da - a * pa) * r1[k], dxb = (db - b * pb) * r2[k];
@@ -213,24 +223,26 @@ int run_info_nce(const float *S1, const float *S2, float div, const int32_t *row
                  float cl_rate, float *ws, float *d_out, double *loss, hipStream_t st) {
     constexpr int GPW = kWave / LPR;
     const int n_pad = (n + 63) / 64 * 64;
-    float *z1 = ws, *z2 = z1 + (int64_t)n_pad * ld, *dz1 = z2 + (int64_t)n_pad * ld, *dz2 = dz1 + (int64_t)n_pad * ld;
-    float *r1 = dz2 + (int64_t)n_pad * ld, *r2 = r1 + n_pad, *dotp = r2 + n_pad, *inv_ttl = dotp + n_pad;
-    float *ExT = inv_ttl + n_pad;
+    const int64_t tab = (int64_t)n_pad * ld;
+    float *z1 = ws, *z2 = z1 + tab, *dz1 = z2 + tab, *dz2 = dz1 + kSplitK * tab;
+    float *r1 = dz2 + kSplitK * tab, *r2 = r1 + n_pad, *dotp = r2 + n_pad, *inv_ttl = dotp + n_pad;
+    float *psum = inv_ttl + n_pad;                       // [n_pad/32][n_pad]
+    float *ExT = psum + (int64_t)(n_pad / 32) * n_pad;   // [n_pad][n_pad]
     const float inv_tau = 1.0f / tau;
     const unsigned row_blocks = (unsigned)((n + 4 * GPW - 1) / (4 * GPW));
     hipLaunchKernelGGL((gather_normalize_kernel<LPR>), dim3(row_blocks), dim3(256), 0, st, S1, S2, div, rows, n, z1, z2, r1, r2, dotp);
     QREC_LAUNCH_CHECK();
     hipLaunchKernelGGL(exp_logits_kernel, dim3((unsigned)(n_pad / 32), (unsigned)((n_pad / 32 + 3) / 4)), dim3(256), 0, st,
-                       z1, z2, n, n_pad, ld, inv_tau, ExT);
+                       z1, z2, n, n_pad, ld, inv_tau, ExT, psum);
     QREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ExT, n, n_pad, dotp, inv_tau, inv_ttl, loss);
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, psum, n, n_pad, dotp, inv_tau, inv_ttl, loss);
     QREC_LAUNCH_CHECK();
-    const dim3 gg((unsigned)(n_pad / 32), (unsigned)((ld + 31) / 32));
-    hipLaunchKernelGGL((grad_z_kernel<0>), gg, dim3(64), 0, st, ExT, inv_ttl, z2, n, n_pad, ld, inv_tau, dz1);
+    const dim3 gg((unsigned)(n_pad / 32), (unsigned)((ld + 31) / 32), (unsigned)(kSplitK / 4));
+    hipLaunchKernelGGL((grad_z_kernel<0>), gg, dim3(256), 0, st, ExT, inv_ttl, z2, n, n_pad, ld, inv_tau, dz1);
     QREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL((grad_z_kernel<1>), gg, dim3(64), 0, st, ExT, inv_ttl, z1, n, n_pad, ld, inv_tau, dz2);
+    hipLaunchKernelGGL((grad_z_kernel<1>), gg, dim3(256), 0, st, ExT, inv_ttl, z1, n, n_pad, ld, inv_tau, dz2);
     QREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL((normalize_bwd_kernel<LPR>), dim3(row_blocks), dim3(256), 0, st, z1, z2, dz1, dz2, r1, r2, rows, n, cl_rate, d_out);
+    hipLaunchKernelGGL((normalize_bwd_kernel<LPR>), dim3(row_blocks), dim3(256), 0, st, z1, z2, dz1, dz2, r1, r2, rows, n, tab, cl_rate, d_out);
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }
@@ -264,7 +276,7 @@ int qrec_perturb_rows(float *d_emb, int64_t n_rows, int32_t d, int32_t ld, float
 int qrec_info_nce_workspace_bytes(int32_t n, int32_t ld, int64_t *bytes) {
     QREC_REQUIRE(bytes && n >= 0 && ld > 0, "qrec_info_nce_workspace_bytes: bad argument");
     const int64_t n_pad = ((int64_t)n + 63) / 64 * 64;
-    *bytes = 4 * (4 * n_pad * ld + 4 * n_pad + n_pad * n_pad);
+    *bytes = 4 * ((2 + 2 * 16) * n_pad * ld + 4 * n_pad + (n_pad / 32) * n_pad + n_pad * n_pad);
     return QREC_OK;
 }
 
