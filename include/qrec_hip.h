@@ -159,11 +159,12 @@ int qrec_bpr_batch_loss_grad(const float *d_S, float div, int32_t n_users, int64
                              float reg, float *d_dE, double *d_loss, void *stream);
 
 /* tf.train.AdamOptimizer dense update (LightGCN.py:31-32) in TF 1.14's ApplyAdam form, fp32,
- * with g = grad_scale * d_grad:  m += (g-m)(1-beta1); v += (g*g-v)(1-beta2);
+ * with g = grad_scale * d_grad + grad_l2 * theta (grad_l2 = reg folds in d/dtheta of
+ * reg*tf.nn.l2_loss(theta), model/ranking/BPR.py:83):  m += (g-m)(1-beta1); v += (g*g-v)(1-beta2);
  * theta -= (m*alpha)/(sqrt(v)+eps).  alpha = lr*sqrt(1-beta2^t)/(1-beta1^t) is supplied by
  * the host, which keeps the fp32 beta powers like TF does.                               */
 int qrec_adam_step(float *d_theta, float *d_m, float *d_v, const float *d_grad, int64_t n_elems, float grad_scale,
-                   float alpha, float beta1, float beta2, float eps, void *stream);
+                   float grad_l2, float alpha, float beta1, float beta2, float eps, void *stream);
 
 /* ---- SimGCL (model/ranking/SimGCL.py) ---------------------------------------------------- */
 

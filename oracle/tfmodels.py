@@ -227,3 +227,28 @@ class SimGCL:
     def final_embeddings(self):
         m = self.encoder()
         return m[:self.nu], m[self.nu:]
+
+
+# ======================================================================================
+# BPR, TensorFlow variant  (model/ranking/BPR.py:77-96)
+# ======================================================================================
+class BprTF:
+    """loss = -sum log(sigmoid(y) + 1e-6) + reg*(l2_loss(U) + l2_loss(V)) on the FULL tables;
+    gradients = batch scatter + reg*theta; dense Adam on U and V."""
+
+    def __init__(self, U0, V0, lr, reg):
+        self.nu = U0.shape[0]
+        self.E = np.concatenate([U0, V0]).astype(np.float32)
+        self.reg = np.float32(reg)
+        self.opt = AdamTF114(self.E.shape, lr)
+
+    def train_step(self, u_idx, i_idx, j_idx):
+        f = np.float32
+        ui, ii, ji = np.asarray(u_idx), np.asarray(i_idx) + self.nu, np.asarray(j_idx) + self.nu
+        loss, du, di, dj = bpr_batch_loss_and_grads(self.E[ui], self.E[ii], self.E[ji], 0.0, eps=f(1e-6))
+        loss += float(self.reg) * 0.5 * float((self.E.astype(np.float64) ** 2).sum())
+        g = np.zeros_like(self.E)
+        np.add.at(g, ui, du); np.add.at(g, ii, di); np.add.at(g, ji, dj)
+        g = (g + self.reg * self.E).astype(f)
+        self.opt.step(self.E, g)
+        return loss

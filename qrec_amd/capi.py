@@ -52,7 +52,7 @@ _SIGNATURES = {
     "qrec_sumsq": [_vp, C.c_int, _i64, _i32, _i32, _vp, _vp],
     "qrec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp],
     "qrec_bpr_batch_loss_grad": [_vp, _f32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp],
-    "qrec_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp],
+    "qrec_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
     "qrec_perturb_rows": [_vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp],
     "qrec_info_nce_workspace_bytes": [_i32, _i32, _vp],
     "qrec_info_nce_loss_grad": [_vp, _vp, _f32, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
@@ -371,9 +371,9 @@ def bpr_batch_loss_grad(d_S, div: float, n_users: int, n_rows: int, ld: int, d_u
 
 
 def adam_step(d_theta, d_m, d_v, d_grad, n_elems: int, grad_scale: float, alpha: float, beta1: float = 0.9,
-              beta2: float = 0.999, eps: float = 1e-8, stream=None):
-    _check(load().qrec_adam_step(_dp(d_theta), _dp(d_m), _dp(d_v), _dp(d_grad), n_elems, grad_scale, alpha, beta1,
-                                 beta2, eps, _sh(stream)))
+              beta2: float = 0.999, eps: float = 1e-8, stream=None, grad_l2: float = 0.0):
+    _check(load().qrec_adam_step(_dp(d_theta), _dp(d_m), _dp(d_v), _dp(d_grad), n_elems, grad_scale, grad_l2, alpha,
+                                 beta1, beta2, eps, _sh(stream)))
 
 
 def perturb_rows(d_emb, n_rows: int, d: int, ld: int, eps: float, d_noise=None, seed: int = 0, stream_id: int = 0,

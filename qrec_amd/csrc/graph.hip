@@ -173,22 +173,23 @@ __global__ __launch_bounds__(256) void bpr_batch_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// Dense Adam in the form of TF 1.14's ApplyAdam functor (training_ops.cc), all fp32, g = gscale*G:
+// Dense Adam in the form of TF 1.14's ApplyAdam functor (training_ops.cc), all fp32,
+// g = gscale*G + l2*theta (l2 != 0 folds in the gradient of reg*tf.nn.l2_loss(theta), BPR.py:83):
 //   m += (g - m) * (1 - beta1) ; v += (g*g - v) * (1 - beta2) ; theta -= (m * alpha) / (sqrt(v) + eps)
 // alpha = lr*sqrt(1-beta2_power)/(1-beta1_power) comes from the host (fp32 beta powers, as TF keeps
 // them).  Streams theta, m, v, G in and theta, m, v out: 7 * 4 B per element.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ theta, float *__restrict__ m,
                                                    float *__restrict__ v, const float *__restrict__ G,
-                                                   int64_t n4, float gscale, float alpha, float b1, float b2,
-                                                   float eps) {
+                                                   int64_t n4, float gscale, float l2, float alpha, float b1,
+                                                   float b2, float eps) {
 #pragma clang fp contract(off)
     f32x4 *t4 = reinterpret_cast<f32x4 *>(theta), *m4 = reinterpret_cast<f32x4 *>(m), *v4 = reinterpret_cast<f32x4 *>(v);
     const f32x4 *g4 = reinterpret_cast<const f32x4 *>(G);
     const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += (int64_t)gridDim.x * blockDim.x) {
-        const f32x4 g = gscale * g4[k];
         f32x4 mm = m4[k], vv = v4[k], th = t4[k];
+        const f32x4 g = gscale * g4[k] + l2 * th;
         mm = mm + (g - mm) * omb1;
         vv = vv + (g * g - vv) * omb2;
         th.x -= (mm.x * alpha) / (sqrtf(vv.x) + eps); th.y -= (mm.y * alpha) / (sqrtf(vv.y) + eps);
@@ -270,14 +271,14 @@ int qrec_bpr_batch_loss_grad(const float *d_S, float div, int32_t n_users, int64
 }
 
 int qrec_adam_step(float *d_theta, float *d_m, float *d_v, const float *d_grad, int64_t n_elems, float grad_scale,
-                   float alpha, float beta1, float beta2, float eps, void *stream) {
+                   float grad_l2, float alpha, float beta1, float beta2, float eps, void *stream) {
     QREC_REQUIRE(d_theta && d_m && d_v && d_grad && n_elems >= 0, "qrec_adam_step: bad argument");
     QREC_REQUIRE(n_elems % 4 == 0, "qrec_adam_step: element count must be a multiple of 4 (row stride is)");
     if (n_elems == 0) return QREC_OK;
     int64_t blocks = (n_elems / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), d_theta, d_m, d_v,
-                       d_grad, n_elems / 4, grad_scale, alpha, beta1, beta2, eps);
+                       d_grad, n_elems / 4, grad_scale, grad_l2, alpha, beta1, beta2, eps);
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }

@@ -143,6 +143,47 @@ class LightGCNTrainer:
         return E[:self.nu, :self.d].copy(), E[self.nu:, :self.d].copy()
 
 
+class BprTfTrainer:
+    """BPR.trainModel_tf (model/ranking/BPR.py:77-96): batch loss
+    -sum log(sigmoid(y) + 1e-6) + reg*(l2_loss(U) + l2_loss(V)) over the FULL tables, Adam.
+    Same kernels as LightGCN with zero propagation layers; the full-table L2 gradient reg*theta is
+    folded into the Adam kernel and its loss term comes from qrec_sumsq."""
+
+    def __init__(self, U0, V0, lr: float, reg: float, loss_eps: float = 1e-6):
+        self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
+        self.n = self.nu + self.ni
+        self.ld = padded_ld(self.d, np.float32)
+        self.lr, self.reg, self.loss_eps = lr, reg, loss_eps
+        E0 = np.zeros((self.n, self.ld), np.float32)
+        E0[:self.nu, :self.d] = U0; E0[self.nu:, :self.d] = V0
+        self.E = DeviceBuffer.from_numpy(E0)
+        z = lambda: DeviceBuffer.zeros((self.n, self.ld), np.float32)
+        self.m, self.v, self.dE = z(), z(), z()
+        self.d_loss = DeviceBuffer.zeros(2, np.float64)      # [batch term, sum theta^2]
+        f = np.float32
+        self.b1, self.b2, self.adam_eps = f(0.9), f(0.999), f(1e-8)
+        self.b1p, self.b2p = self.b1, self.b2
+
+    def train_step_async(self, d_u, d_i, d_j, B: int, stream=None):
+        f = np.float32
+        self.dE.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
+        capi.bpr_batch_loss_grad(self.E, 1.0, self.nu, self.n, self.ld, d_u, d_i, d_j, B, self.loss_eps, 0.0,
+                                 self.dE, self.d_loss, stream)
+        capi.sumsq(self.E, capi.F32, self.n, self.d, self.ld, self.d_loss.ptr + 8, stream)   # loss is of the pre-update tables
+        alpha = float(f(f(self.lr) * np.sqrt(f(1) - self.b2p, dtype=f) / (f(1) - self.b1p)))
+        capi.adam_step(self.E, self.m, self.v, self.dE, self.n * self.ld, 1.0, alpha, float(self.b1), float(self.b2),
+                       float(self.adam_eps), stream, grad_l2=self.reg)
+        self.b1p = f(self.b1p * self.b1); self.b2p = f(self.b2p * self.b2)
+
+    def loss(self, stream=None) -> float:
+        batch, ss = self.d_loss.numpy(stream)
+        return float(batch + self.reg * 0.5 * ss)
+
+    def tables(self):
+        E = self.E.numpy()
+        return E[:self.nu, :self.d].copy(), E[self.nu:, :self.d].copy()
+
+
 def unique_first_appearance(idx: np.ndarray) -> np.ndarray:
     """tf.unique(x)[0]: distinct values in order of first occurrence (SimGCL.py:61-64)."""
     _, first = np.unique(idx, return_index=True)

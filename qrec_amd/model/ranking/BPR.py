@@ -73,6 +73,35 @@ class BPR(IterativeRecommender):
                 break
         self.P, self.Q = tables.download(np.float64)
 
+    def trainModel_tf(self):
+        """The reference's TensorFlow variant (model/ranking/BPR.py:77-96), taken when the conf has
+        ``-tf``: truncated-normal(0.005) tables (base/iterativeRecommender.py:47-48), batches are
+        consecutive slices of ``trainingData`` in its current order (``next_batch`` does NOT shuffle,
+        BPR.py:55-65) with one negative per row drawn from the CPython stream, Adam at a constant
+        learning rate, no convergence test."""
+        from ...base.deepRecommender import truncated_normal
+        from ...capi import DeviceBuffer
+        from ...graph import BprTfTrainer
+        self.batch_size = int(self.config["batch_size"])
+        U0 = truncated_normal((self.num_users, self.emb_size), 0.005)
+        V0 = truncated_normal((self.num_items, self.emb_size), 0.005)
+        tr = self._tf_trainer = BprTfTrainer(U0, V0, self.lRate, self.regU)
+        rated = self.data.rated_csr().sorted_rows()
+        quiet = os.environ.get("QREC_QUIET") == "1"
+        for epoch in range(self.maxEpoch):
+            u, i, _ = self.data.training_arrays()
+            state = random.getstate()
+            words = capi.state_from_python(state)
+            j = capi.mt_pairwise_sample_epoch(words, u, rated.indptr, rated.indices, self.num_items)
+            random.setstate(capi.state_to_python(words, state[2]))
+            d_u, d_i, d_j = DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i), DeviceBuffer.from_numpy(j)
+            for n, s in enumerate(range(0, u.size, self.batch_size)):
+                B = min(self.batch_size, u.size - s)
+                tr.train_step_async(d_u.ptr + 4 * s, d_i.ptr + 4 * s, d_j.ptr + 4 * s, B)
+                if not quiet:
+                    print("training:", epoch + 1, "batch", n, "loss:", tr.loss())
+        self.P, self.Q = tr.tables()
+
     def predictForRanking(self, u):
         if self.data.containsUser(u):
             return self.Q.dot(self.P[self.data.getUserId(u)])

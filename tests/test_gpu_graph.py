@@ -270,3 +270,33 @@ def test_simgcl_class_runs_stock_conf_shape_and_keeps_best_epoch():
     rec = [float(x.split(":")[1]) for x in measure if x.startswith("Recall")][0]
     assert 0.0 < rec <= 1.0
     assert m.U is m.bestU and m.U.shape == (meta["n_users"], 16)
+
+
+def test_bpr_tf_variant_matches_restatement_and_runs_from_conf():
+    """model/ranking/BPR.py:77-96 (the `-tf` path): per-step losses and tables vs the restatement,
+    then the drop-in class with `-tf` in evaluation.setup."""
+    from qrec_amd.graph import BprTfTrainer
+    rng = np.random.default_rng(5)
+    nu, ni, dim, B = 400, 300, 50, 512
+    U0 = (rng.standard_normal((nu, dim)) * 0.005).astype(np.float32); V0 = (rng.standard_normal((ni, dim)) * 0.005).astype(np.float32)
+    ref = T.BprTF(U0, V0, lr=0.01, reg=0.001); tr = BprTfTrainer(U0, V0, 0.01, 0.001)
+    for step in range(6):
+        u = rng.integers(0, nu, B).astype(np.int32); i = rng.integers(0, ni, B).astype(np.int32); j = rng.integers(0, ni, B).astype(np.int32)
+        lref = ref.train_step(u, i, j)
+        tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B)
+        assert abs(tr.loss() - lref) / abs(lref) < TOL
+    Ug, Vg = tr.tables()
+    assert rel_err(np.concatenate([Ug, Vg]), ref.E) < 5e-5
+    # through the class: `-tf` selects trainModel_tf (base/recommender.py:194-201)
+    from qrec_amd.model.ranking.BPR import BPR
+    meta, z = load_golden("bpr_filmtrust")
+    train, test = rows_from_golden(z)
+    conf = conf_from_text(meta["conf"]); conf["evaluation.setup"] = conf["evaluation.setup"] + " -tf"
+    conf["num.max.epoch"] = "2"; conf["batch_size"] = "4096"; conf["learnRate"] = "-init 0.01 -max 1"
+    random.seed(2); np.random.seed(2)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        m = BPR(conf, train, test); measure = m.execute()
+    losses = [float(l.split("loss:")[1]) for l in buf.getvalue().splitlines() if l.startswith("training:")]
+    assert len(losses) == 2 * 8 and losses[-1] < losses[0] and m.P.dtype == np.float32
+    assert any(x.startswith("Recall") for x in measure)
