@@ -186,6 +186,32 @@ int qrec_info_nce_loss_grad(const float *d_S1, const float *d_S2, float div, con
                             int32_t ld, float tau, float cl_rate, void *d_workspace, float *d_out, double *d_loss,
                             void *stream);
 
+/* ---- NGCF dense layers (model/ranking/NGCF.py:27-42) ------------------------------------ *
+ * Tables [rows][ld] fp32, ld in {32,64,128}; weights zero-padded to [ld][ld].             */
+
+/* pre = (side + E) W1 + (E * side) W2   (NGCF.py:29-31; side = A E from qrec_spmm_csr). f32 MFMA. */
+int qrec_ngcf_dense_fwd(const float *d_E, const float *d_side, const float *d_W1, const float *d_W2, int64_t n_rows,
+                        int32_t ld, float *d_pre, void *stream);
+/* In place on d_pre_gate (in: pre, out: backward gate): nxt = dropout(leaky_relu(pre, 0.2), keep)
+ * (NGCF.py:32-38; keep = 1 for the inference graph; d_mask = injected 0/1 keep decisions or NULL
+ * for device Philox draws), z = l2_normalize(nxt) written to columns [col_off, col_off+d) of the
+ * wide table (the concat of NGCF.py:42), 1/|nxt| to d_inv_norm.                          */
+int qrec_ngcf_activate(float *d_pre_gate, int64_t n_rows, int32_t d, int32_t ld, float keep, const float *d_mask,
+                       uint64_t seed, uint64_t stream_id, float *d_next, float *d_wide, int32_t wide_ld,
+                       int32_t col_off, float *d_inv_norm, void *stream);
+/* Backward of one layer: dnxt = dE_next (may be NULL) + normalize_bwd(dWide block); dpre = dnxt*gate;
+ * dside = dpre W1^T + (dpre W2^T)*E ; dE = dpre W1^T + (dpre W2^T)*side (caller adds A^T dside);
+ * gW1 = (side+E)^T dpre, gW2 = (E*side)^T dpre (deterministic two-stage reduction over nodes).  */
+int qrec_ngcf_layer_bwd(const float *d_dE_next, const float *d_dWide, const float *d_wide, int32_t wide_ld,
+                        int32_t col_off, const float *d_inv_norm, const float *d_gate, const float *d_E,
+                        const float *d_side, const float *d_W1, const float *d_W2, int64_t n_rows, int32_t d,
+                        int32_t ld, float *d_dpre, float *d_dside, float *d_dE, float *d_partial, float *d_gW1,
+                        float *d_gW2, void *stream);
+int qrec_ngcf_wgrad_partial_bytes(int64_t n_rows, int32_t ld, int64_t *bytes);
+/* dst[row][c] (=|+=) src[row][src_col_off + c], c < d : moves the ego block in and out of the wide table */
+int qrec_copy_cols(float *d_dst, int32_t dst_ld, const float *d_src, int32_t src_ld, int32_t src_col_off, int64_t n_rows,
+                   int32_t d, int32_t accumulate, void *stream);
+
 /* ---- full-rank evaluation: base/recommender.py:143-150 + util/qmath.py:134-146 -------- *
  * For each of the n_batch_users users (ids into the user table): scores = V . U[user]
  * (MFMA), scores of the user's rated train items set to 0 (rated CSR over ALL users, may be

@@ -252,3 +252,88 @@ class BprTF:
         g = (g + self.reg * self.E).astype(f)
         self.opt.step(self.E, g)
         return loss
+
+
+# ======================================================================================
+# NGCF  (model/ranking/NGCF.py:9-71)
+# ======================================================================================
+def leaky_relu(x, alpha=np.float32(0.2)):
+    """tf.nn.leaky_relu (default alpha = 0.2) = max(alpha*x, x)."""
+    return np.maximum(alpha * x, x).astype(np.float32)
+
+
+class NGCF:
+    """Two propagation layers (fixed, NGCF.py:19) with weights W1_k, W2_k (d x d, Xavier):
+        side = A E_k ;  pre = (side + E_k) W1_k + (E_k * side) W2_k ;  E_{k+1} = dropout(leaky_relu(pre), keep .9)
+        out  = concat[E_0, l2_normalize(E_1), l2_normalize(E_2)]                 (N x 3d)
+    batch BPR loss + batch L2 on the 3d-wide rows, Adam on U, V and the four weight matrices.
+    ``masks`` for a step: two arrays [N, d] of 0/1 (the dropout keep decisions) or None for the
+    inference graph (isTraining = 0)."""
+
+    KEEP = np.float32(0.9)
+
+    def __init__(self, U0, V0, W, adj: sp.csr_matrix, lr, reg):
+        self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
+        self.E = np.concatenate([U0, V0]).astype(np.float32)
+        self.W = [[w.astype(np.float32).copy() for w in pair] for pair in W]      # [[W1_0, W2_0], [W1_1, W2_1]]
+        self.adj = adj.astype(np.float32).tocsr()
+        self.reg = reg
+        self.optE = AdamTF114(self.E.shape, lr)
+        self.optW = [[AdamTF114(w.shape, lr) for w in pair] for pair in self.W]
+
+    def forward(self, masks=None, keep_cache=False):
+        f = np.float32
+        E = self.E
+        outs = [E]
+        cache = []
+        for k in range(2):
+            side = self.adj.dot(E).astype(f)
+            A1 = (side + E).astype(f); A2 = (E * side).astype(f)
+            pre = (A1 @ self.W[k][0] + A2 @ self.W[k][1]).astype(f)
+            act = leaky_relu(pre)
+            if masks is not None:
+                fac = (masks[k].astype(f) / self.KEEP).astype(f)
+                nxt = (act * fac).astype(f)
+            else:
+                fac = np.ones_like(act); nxt = act
+            z, inv = l2_normalize_rows(nxt)
+            outs.append(z)
+            if keep_cache:
+                cache.append(dict(E=E, side=side, A1=A1, A2=A2, pre=pre, fac=fac, nxt=nxt, z=z, inv=inv))
+            E = nxt
+        return np.concatenate(outs, axis=1).astype(f), cache
+
+    def loss_and_grads(self, u_idx, i_idx, j_idx, masks):
+        f = np.float32
+        d, nu = self.d, self.nu
+        allE, cache = self.forward(masks, keep_cache=True)
+        ui, ii, ji = np.asarray(u_idx), np.asarray(i_idx) + nu, np.asarray(j_idx) + nu
+        loss, du, di, dj = bpr_batch_loss_and_grads(allE[ui], allE[ii], allE[ji], self.reg)
+        dAll = np.zeros_like(allE)
+        np.add.at(dAll, ui, du); np.add.at(dAll, ii, di); np.add.at(dAll, ji, dj)
+        dE_next = np.zeros((allE.shape[0], d), f)          # gradient w.r.t. E_{k+1} from later layers
+        gW = [[None, None], [None, None]]
+        for k in (1, 0):
+            c = cache[k]
+            dz = dAll[:, (k + 1) * d:(k + 2) * d]
+            dnxt = dE_next + ((dz - c["z"] * (c["z"] * dz).sum(1, dtype=f)[:, None]) * c["inv"][:, None]).astype(f)
+            dpre = (dnxt * c["fac"] * np.where(c["pre"] > 0, f(1), f(0.2))).astype(f)
+            gW[k][0] = (c["A1"].T @ dpre).astype(f); gW[k][1] = (c["A2"].T @ dpre).astype(f)
+            dA1 = (dpre @ self.W[k][0].T).astype(f); dA2 = (dpre @ self.W[k][1].T).astype(f)
+            dside = (dA1 + dA2 * c["E"]).astype(f)
+            dE_next = (dA1 + dA2 * c["side"] + self.adj.T.dot(dside)).astype(f)
+        gE = (dE_next + dAll[:, :d]).astype(f)
+        return loss, gE, gW
+
+    def train_step(self, u_idx, i_idx, j_idx, masks):
+        loss, gE, gW = self.loss_and_grads(u_idx, i_idx, j_idx, masks)
+        self.optE.step(self.E, gE)
+        for k in range(2):
+            for t in range(2):
+                self.optW[k][t].step(self.W[k][t], gW[k][t])
+        return loss
+
+    def inference_embeddings(self):
+        """the 3d-wide tables the reference scores with at test time (isTraining = 0, NGCF.py:65-69)"""
+        allE, _ = self.forward(None)
+        return allE[:self.nu], allE[self.nu:]

@@ -56,6 +56,11 @@ _SIGNATURES = {
     "qrec_perturb_rows": [_vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp],
     "qrec_info_nce_workspace_bytes": [_i32, _i32, _vp],
     "qrec_info_nce_loss_grad": [_vp, _vp, _f32, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
+    "qrec_ngcf_dense_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
+    "qrec_ngcf_activate": [_vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _i32, _i32, _vp, _vp],
+    "qrec_ngcf_layer_bwd": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "qrec_ngcf_wgrad_partial_bytes": [_i64, _i32, _vp],
+    "qrec_copy_cols": [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _i32, _vp],
     "qrec_score_topk_scratch_bytes": [C.c_int, _i32, _i32, _vp],
     "qrec_score_topk": [_vp, _vp, C.c_int, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
 }
@@ -392,3 +397,34 @@ def info_nce_loss_grad(d_S1, d_S2, div: float, d_rows, n: int, ld: int, tau: flo
                        d_out, d_loss, stream=None):
     _check(load().qrec_info_nce_loss_grad(_dp(d_S1), _dp(d_S2), div, _dp(d_rows), n, ld, tau, cl_rate,
                                           _dp(d_workspace), _dp(d_out), _dp(d_loss), _sh(stream)))
+
+
+def ngcf_dense_fwd(d_E, d_side, d_W1, d_W2, n_rows: int, ld: int, d_pre, stream=None):
+    _check(load().qrec_ngcf_dense_fwd(_dp(d_E), _dp(d_side), _dp(d_W1), _dp(d_W2), n_rows, ld, _dp(d_pre), _sh(stream)))
+
+
+def ngcf_activate(d_pre_gate, n_rows: int, d: int, ld: int, keep: float, d_mask, seed: int, stream_id: int, d_next,
+                  d_wide, wide_ld: int, col_off: int, d_inv_norm, stream=None):
+    _check(load().qrec_ngcf_activate(_dp(d_pre_gate), n_rows, d, ld, keep, _dp(d_mask), seed & (2**64 - 1),
+                                     stream_id & (2**64 - 1), _dp(d_next), _dp(d_wide), wide_ld, col_off,
+                                     _dp(d_inv_norm), _sh(stream)))
+
+
+def ngcf_layer_bwd(d_dE_next, d_dWide, d_wide, wide_ld: int, col_off: int, d_inv_norm, d_gate, d_E, d_side, d_W1, d_W2,
+                   n_rows: int, d: int, ld: int, d_dpre, d_dside, d_dE, d_partial, d_gW1, d_gW2, stream=None):
+    _check(load().qrec_ngcf_layer_bwd(_dp(d_dE_next), _dp(d_dWide), _dp(d_wide), wide_ld, col_off, _dp(d_inv_norm),
+                                      _dp(d_gate), _dp(d_E), _dp(d_side), _dp(d_W1), _dp(d_W2), n_rows, d, ld,
+                                      _dp(d_dpre), _dp(d_dside), _dp(d_dE), _dp(d_partial), _dp(d_gW1), _dp(d_gW2),
+                                      _sh(stream)))
+
+
+def ngcf_wgrad_partial_bytes(n_rows: int, ld: int) -> int:
+    out = C.c_int64(0)
+    _check(load().qrec_ngcf_wgrad_partial_bytes(n_rows, ld, C.byref(out)))
+    return out.value
+
+
+def copy_cols(d_dst, dst_ld: int, d_src, src_ld: int, src_col_off: int, n_rows: int, d: int, accumulate: bool,
+              stream=None):
+    _check(load().qrec_copy_cols(_dp(d_dst), dst_ld, _dp(d_src), src_ld, src_col_off, n_rows, d, 1 if accumulate else 0,
+                                 _sh(stream)))

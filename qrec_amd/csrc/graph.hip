@@ -230,7 +230,7 @@ int qrec_spmm_csr(const int32_t *d_seg_row, const int64_t *d_seg_beg, const int3
     QREC_REQUIRE(d_seg_row && d_seg_beg && d_seg_len && d_seg_slot && d_indices && d_values && d_X && d_Y,
                  "qrec_spmm_csr: null argument");
     QREC_REQUIRE(n_long == 0 || (d_long_row && d_long_first && d_long_count && d_partial), "qrec_spmm_csr: long-row plan incomplete");
-    QREC_REQUIRE(d_X != d_Y, "qrec_spmm_csr: in-place SpMM is not supported");
+    QREC_REQUIRE(d_X != d_Y, "qrec_spmm_csr: in-place SpMM is not supported (Y may alias addend, not X)");
     if (n_segs == 0) return QREC_OK;
     hipStream_t st = as_stream(stream);
 #define QREC_SPMM(LPR) return launch_spmm<LPR>(d_seg_row, d_seg_beg, d_seg_len, d_seg_slot, n_segs, d_long_row, d_long_first, \

@@ -1,0 +1,360 @@
+// NGCF's dense propagation layers (model/ranking/NGCF.py:27-42) and their backward pass.
+//
+//   side = A E (qrec_spmm_csr)
+//   pre  = (side + E) W1 + (E * side) W2                       dense_fwd_kernel      (f32 MFMA)
+//   act  = leaky_relu(pre, 0.2); nxt = dropout(act, keep); z = l2_normalize(nxt)
+//                                                              activate_rows_kernel
+//   backward:
+//   dnxt = dE_next + normalize_bwd(dz);  dpre = dnxt * gate     dpre_rows_kernel
+//   dA1 = dpre W1^T, dA2 = dpre W2^T;  dside = dA1 + dA2*E;  dE = dA1 + dA2*side
+//                                                              dense_bwd_kernel      (f32 MFMA)
+//   dW1 = (side+E)^T dpre, dW2 = (E*side)^T dpre               wgrad_kernel + wgrad_reduce_kernel (MFMA)
+//   dE += A^T dside (qrec_spmm_csr with addend)
+//
+// Tables are [rows][ld] fp32 with ld in {32, 64, 128}; the d x d weights are stored zero-padded as
+// [ld][ld].  The N x d x d products are the only GEMM-shaped work (2 N d^2 FLOP each, K = d small):
+// one wavefront per 32 rows holds its A fragments in registers and sweeps the output column tiles.
+#include "common.h"
+
+using namespace qrec;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void philox10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+        const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+        const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
+__device__ __forceinline__ int cd_row(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
+
+// pre[32 rows][ld] = (side + E) W1 + (E*side) W2      NT = ld/32 output column tiles
+template <int NT>
+__global__ __launch_bounds__(256) void dense_fwd_kernel(const float *__restrict__ E, const float *__restrict__ side,
+                                                        const float *__restrict__ W1, const float *__restrict__ W2,
+                                                        int64_t n_rows, float *__restrict__ pre) {
+    constexpr int LD = 32 * NT;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+    if (row0 >= n_rows) return;
+    const int64_t row = row0 + r;
+    const bool ok = row < n_rows;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
+    for (int c = 0; c < LD; c += 64) {
+        const int k0 = c + 32 * h;   // ld = 32: the upper k-slot has no columns and feeds zeros (no divergence:
+                                     // every lane must issue every MFMA)
+        float a1[32], a2[32];
+#pragma unroll
+        for (int s = 0; s < 32; s++) {
+            const bool in = ok && (k0 + s < LD);
+            const float e = in ? E[row * LD + k0 + s] : 0.f, sd = in ? side[row * LD + k0 + s] : 0.f;
+            a1[s] = sd + e; a2[s] = e * sd;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+#pragma unroll
+            for (int s = 0; s < 32; s++) {
+                const bool in = k0 + s < LD;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], in ? W1[(k0 + s) * LD + 32 * t + r] : 0.f, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], in ? W2[(k0 + s) * LD + 32 * t + r] : 0.f, acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int64_t orow = row0 + cd_row(q, h);
+            if (orow < n_rows) pre[orow * LD + 32 * t + r] = acc[t][q];
+        }
+}
+
+// One group of LPR lanes per row (float4 per lane).  In place on `pre_gate`: reads pre, writes the
+// backward gate = (mask/keep) * (pre > 0 ? 1 : 0.2).  Writes nxt, z = l2_normalize(nxt) into the wide
+// output table at column offset `out_off` (row stride out_ld), and 1/|nxt|.
+template <int LPR>
+__global__ __launch_bounds__(256) void activate_rows_kernel(float *__restrict__ pre_gate, int64_t n_rows, int d, float keep,
+                                                            const float *__restrict__ mask, uint64_t seed, uint64_t stream_id,
+                                                            float *__restrict__ nxt, float *__restrict__ out, int out_ld,
+                                                            int out_off, float *__restrict__ inv_norm) {
+    constexpr int GPW = kWave / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
+    const int64_t gid = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
+    const int64_t n_groups = (int64_t)gridDim.x * 4 * GPW;
+    for (int64_t row = gid; row < n_rows; row += n_groups) {
+        const int64_t off = row * (4 * LPR) + 4 * r;
+        const f32x4 p = *reinterpret_cast<const f32x4 *>(pre_gate + off);
+        f32x4 fac = {1.f, 1.f, 1.f, 1.f};
+        if (keep < 1.f) {
+            f32x4 u;
+            if (mask) {
+                u = *reinterpret_cast<const f32x4 *>(mask + off);       // injected 0/1 keep decisions
+                fac = u / keep;
+            } else {
+                uint32_t c[4] = {(uint32_t)row, (uint32_t)(row >> 32) ^ ((uint32_t)r << 8), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+                philox10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+                // tf.nn.dropout: keep iff uniform >= 1 - keep_prob
+                fac.x = ((float)(c[0] >> 8) * 0x1p-24f >= 1.f - keep) ? 1.f / keep : 0.f;
+                fac.y = ((float)(c[1] >> 8) * 0x1p-24f >= 1.f - keep) ? 1.f / keep : 0.f;
+                fac.z = ((float)(c[2] >> 8) * 0x1p-24f >= 1.f - keep) ? 1.f / keep : 0.f;
+                fac.w = ((float)(c[3] >> 8) * 0x1p-24f >= 1.f - keep) ? 1.f / keep : 0.f;
+            }
+        }
+        auto lrelu = [](float x) { return fmaxf(0.2f * x, x); };
+        f32x4 y = {lrelu(p.x) * fac.x, lrelu(p.y) * fac.y, lrelu(p.z) * fac.z, lrelu(p.w) * fac.w};
+        f32x4 gate = {fac.x * (p.x > 0.f ? 1.f : 0.2f), fac.y * (p.y > 0.f ? 1.f : 0.2f),
+                      fac.z * (p.z > 0.f ? 1.f : 0.2f), fac.w * (p.w > 0.f ? 1.f : 0.2f)};
+        if (4 * r + 0 >= d) { y.x = 0.f; gate.x = 0.f; }
+        if (4 * r + 1 >= d) { y.y = 0.f; gate.y = 0.f; }
+        if (4 * r + 2 >= d) { y.z = 0.f; gate.z = 0.f; }
+        if (4 * r + 3 >= d) { y.w = 0.f; gate.w = 0.f; }
+        float ss = y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+        ss = row_allreduce_sum<LPR>(ss);
+        const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        *reinterpret_cast<f32x4 *>(pre_gate + off) = gate;
+        *reinterpret_cast<f32x4 *>(nxt + off) = y;
+        float *o = out + row * out_ld + out_off + 4 * r;      // out_off is not 16-byte aligned in general
+        if (4 * r + 0 < d) o[0] = y.x * inv;
+        if (4 * r + 1 < d) o[1] = y.y * inv;
+        if (4 * r + 2 < d) o[2] = y.z * inv;
+        if (4 * r + 3 < d) o[3] = y.w * inv;
+        if (r == 0) inv_norm[row] = inv;
+    }
+}
+
+// dpre = (dE_next + (dz - z (z.dz)) * inv) * gate        (dz, z: wide tables at column offset `off`)
+template <int LPR>
+__global__ __launch_bounds__(256) void dpre_rows_kernel(const float *__restrict__ dE_next, const float *__restrict__ dAll,
+                                                        const float *__restrict__ All, int wide_ld, int col_off,
+                                                        const float *__restrict__ inv_norm, const float *__restrict__ gate,
+                                                        int64_t n_rows, int d, float *__restrict__ dpre) {
+    constexpr int GPW = kWave / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
+    const int64_t gid = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
+    const int64_t n_groups = (int64_t)gridDim.x * 4 * GPW;
+    for (int64_t row = gid; row < n_rows; row += n_groups) {
+        const int64_t off = row * (4 * LPR) + 4 * r;
+        const float *dzp = dAll + row * wide_ld + col_off + 4 * r, *zp = All + row * wide_ld + col_off + 4 * r;
+        f32x4 dz = {0.f, 0.f, 0.f, 0.f}, z = dz;
+        if (4 * r + 0 < d) { dz.x = dzp[0]; z.x = zp[0]; }
+        if (4 * r + 1 < d) { dz.y = dzp[1]; z.y = zp[1]; }
+        if (4 * r + 2 < d) { dz.z = dzp[2]; z.z = zp[2]; }
+        if (4 * r + 3 < d) { dz.w = dzp[3]; z.w = zp[3]; }
+        float dot = z.x * dz.x + z.y * dz.y + z.z * dz.z + z.w * dz.w;
+        dot = row_allreduce_sum<LPR>(dot);
+        f32x4 dn = (dz - z * dot) * inv_norm[row];
+        if (dE_next) dn = dn + *reinterpret_cast<const f32x4 *>(dE_next + off);
+        const f32x4 gt = *reinterpret_cast<const f32x4 *>(gate + off);
+        *reinterpret_cast<f32x4 *>(dpre + off) = dn * gt;
+    }
+}
+
+// dA1 = dpre W1^T, dA2 = dpre W2^T;  dside = dA1 + dA2*E ;  dE = dA1 + dA2*side
+template <int NT>
+__global__ __launch_bounds__(256) void dense_bwd_kernel(const float *__restrict__ dpre, const float *__restrict__ W1,
+                                                        const float *__restrict__ W2, const float *__restrict__ E,
+                                                        const float *__restrict__ side, int64_t n_rows,
+                                                        float *__restrict__ dside, float *__restrict__ dE) {
+    constexpr int LD = 32 * NT;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+    if (row0 >= n_rows) return;
+    const int64_t row = row0 + r;
+    const bool ok = row < n_rows;
+    f32x16 a1[NT], a2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) { a1[t][q] = 0.f; a2[t][q] = 0.f; }
+    for (int c = 0; c < LD; c += 64) {
+        const int k0 = c + 32 * h;
+        float g[32];
+#pragma unroll
+        for (int s = 0; s < 32; s++) g[s] = (ok && k0 + s < LD) ? dpre[row * LD + k0 + s] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+#pragma unroll
+            for (int s = 0; s < 32; s++) {
+                const int k = k0 + s;   // B[k][j] = W[j][k]
+                const float b1 = k < LD ? W1[(32 * t + r) * LD + k] : 0.f, b2 = k < LD ? W2[(32 * t + r) * LD + k] : 0.f;
+                a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[s], b1, a1[t], 0, 0, 0);
+                a2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[s], b2, a2[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int64_t orow = row0 + cd_row(q, h);
+            if (orow < n_rows) {
+                const int64_t o = orow * LD + 32 * t + r;
+                const float e = E[o], sd = side[o];
+                dside[o] = a1[t][q] + a2[t][q] * e;
+                dE[o] = a1[t][q] + a2[t][q] * sd;
+            }
+        }
+}
+
+// partial[slab][which][i][j] = sum over the slab's rows n of A_which[n][i] * dpre[n][j]
+//   which = 0: A = side + E ; 1: A = E * side.     One wavefront per (slab, which, 32x32 tile).
+constexpr int kSlabRows = 512;
+__global__ __launch_bounds__(64) void wgrad_kernel(const float *__restrict__ E, const float *__restrict__ side,
+                                                   const float *__restrict__ dpre, int64_t n_rows, int ld,
+                                                   float *__restrict__ partial) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int nt = ld / 32;
+    const int slab = blockIdx.x, which = blockIdx.y, ti = blockIdx.z / nt, tj = blockIdx.z % nt;
+    const int64_t n0 = (int64_t)slab * kSlabRows;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = 0.f;
+    for (int c = 0; c < kSlabRows; c += 64) {
+#pragma unroll 8
+        for (int s = 0; s < 32; s++) {
+            const int64_t n = n0 + c + 32 * h + s;
+            float a = 0.f, b = 0.f;
+            if (n < n_rows) {
+                const float e = E[n * ld + 32 * ti + r], sd = side[n * ld + 32 * ti + r];
+                a = which == 0 ? sd + e : e * sd;
+                b = dpre[n * ld + 32 * tj + r];
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    float *out = partial + (((int64_t)slab * 2 + which) * ld + 32 * ti) * ld + 32 * tj;
+#pragma unroll
+    for (int q = 0; q < 16; q++) out[(int64_t)cd_row(q, h) * ld + r] = acc[q];
+}
+
+// gW[which][i][j] = sum_slab partial[slab][which][i][j]   (slab order: deterministic)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int n_slabs, int ld,
+                                                           float *__restrict__ gW1, float *__restrict__ gW2) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * ld * ld) return;
+    const int which = idx / (ld * ld), ij = idx % (ld * ld);
+    float acc = 0.f;
+    for (int s = 0; s < n_slabs; s++) acc += partial[((int64_t)s * 2 + which) * ld * ld + ij];
+    (which == 0 ? gW1 : gW2)[ij] = acc;
+}
+
+// dst[row][c] += src[row][off + c], c < d     (gradient of the ego block of the wide table)
+__global__ __launch_bounds__(256) void add_cols_kernel(float *__restrict__ dst, int dst_ld, const float *__restrict__ src,
+                                                       int src_ld, int off, int64_t n_rows, int d, int assign) {
+    const int64_t total = n_rows * d;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = k / d; const int c = (int)(k % d);
+        const float v = src[row * src_ld + off + c];
+        if (assign) dst[row * dst_ld + c] = v; else dst[row * dst_ld + c] += v;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int qrec_ngcf_dense_fwd(const float *d_E, const float *d_side, const float *d_W1, const float *d_W2, int64_t n_rows,
+                        int32_t ld, float *d_pre, void *stream) {
+    QREC_REQUIRE(d_E && d_side && d_W1 && d_W2 && d_pre && n_rows >= 0, "qrec_ngcf_dense_fwd: bad argument");
+    if (n_rows == 0) return QREC_OK;
+    const unsigned blocks = (unsigned)((n_rows + 127) / 128);
+    hipStream_t st = as_stream(stream);
+    switch (ld) {
+        case 32: hipLaunchKernelGGL(dense_fwd_kernel<1>, dim3(blocks), dim3(256), 0, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre); break;
+        case 64: hipLaunchKernelGGL(dense_fwd_kernel<2>, dim3(blocks), dim3(256), 0, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre); break;
+        case 128: hipLaunchKernelGGL(dense_fwd_kernel<4>, dim3(blocks), dim3(256), 0, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre); break;
+        default: set_error("qrec_ngcf_dense_fwd: row stride must be 32, 64 or 128 floats (got %d)", ld); return QREC_ERR_INVALID;
+    }
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+int qrec_ngcf_activate(float *d_pre_gate, int64_t n_rows, int32_t d, int32_t ld, float keep, const float *d_mask,
+                       uint64_t seed, uint64_t stream_id, float *d_next, float *d_wide, int32_t wide_ld,
+                       int32_t col_off, float *d_inv_norm, void *stream) {
+    QREC_REQUIRE(d_pre_gate && d_next && d_wide && d_inv_norm && n_rows >= 0 && d >= 1 && ld >= d && keep > 0.f && keep <= 1.f,
+                 "qrec_ngcf_activate: bad argument");
+    QREC_REQUIRE(col_off >= 0 && col_off + d <= wide_ld, "qrec_ngcf_activate: column block outside the wide table");
+    if (n_rows == 0) return QREC_OK;
+    hipStream_t st = as_stream(stream);
+    int64_t blocks;
+#define QREC_ACT(LPR)                                                                                              \
+    blocks = (n_rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)); if (blocks > 2048) blocks = 2048;                     \
+    hipLaunchKernelGGL((activate_rows_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, d_pre_gate, n_rows, d, keep, \
+                       d_mask, seed, stream_id, d_next, d_wide, wide_ld, col_off, d_inv_norm)
+    switch (ld) {
+        case 32: QREC_ACT(8); break;
+        case 64: QREC_ACT(16); break;
+        case 128: QREC_ACT(32); break;
+        default: set_error("qrec_ngcf_activate: row stride must be 32, 64 or 128 floats (got %d)", ld); return QREC_ERR_INVALID;
+    }
+#undef QREC_ACT
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+int qrec_ngcf_layer_bwd(const float *d_dE_next, const float *d_dWide, const float *d_wide, int32_t wide_ld,
+                        int32_t col_off, const float *d_inv_norm, const float *d_gate, const float *d_E,
+                        const float *d_side, const float *d_W1, const float *d_W2, int64_t n_rows, int32_t d,
+                        int32_t ld, float *d_dpre, float *d_dside, float *d_dE, float *d_partial, float *d_gW1,
+                        float *d_gW2, void *stream) {
+    QREC_REQUIRE(d_dWide && d_wide && d_inv_norm && d_gate && d_E && d_side && d_W1 && d_W2 && d_dpre && d_dside && d_dE &&
+                     d_partial && d_gW1 && d_gW2 && n_rows > 0, "qrec_ngcf_layer_bwd: bad argument");
+    hipStream_t st = as_stream(stream);
+    int64_t blocks;
+#define QREC_DP(LPR)                                                                                              \
+    blocks = (n_rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)); if (blocks > 2048) blocks = 2048;                    \
+    hipLaunchKernelGGL((dpre_rows_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, d_dE_next, d_dWide, d_wide, \
+                       wide_ld, col_off, d_inv_norm, d_gate, n_rows, d, d_dpre)
+    const unsigned gblocks = (unsigned)((n_rows + 127) / 128);
+    switch (ld) {
+        case 32: QREC_DP(8); hipLaunchKernelGGL(dense_bwd_kernel<1>, dim3(gblocks), dim3(256), 0, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE); break;
+        case 64: QREC_DP(16); hipLaunchKernelGGL(dense_bwd_kernel<2>, dim3(gblocks), dim3(256), 0, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE); break;
+        case 128: QREC_DP(32); hipLaunchKernelGGL(dense_bwd_kernel<4>, dim3(gblocks), dim3(256), 0, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE); break;
+        default: set_error("qrec_ngcf_layer_bwd: row stride must be 32, 64 or 128 floats (got %d)", ld); return QREC_ERR_INVALID;
+    }
+#undef QREC_DP
+    QREC_LAUNCH_CHECK();
+    const int n_slabs = (int)((n_rows + kSlabRows - 1) / kSlabRows), nt = ld / 32;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)n_slabs, 2, (unsigned)(nt * nt)), dim3(64), 0, st, d_E, d_side, d_dpre,
+                       n_rows, ld, d_partial);
+    QREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((2 * ld * ld + 255) / 256)), dim3(256), 0, st, d_partial, n_slabs,
+                       ld, d_gW1, d_gW2);
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+int qrec_ngcf_wgrad_partial_bytes(int64_t n_rows, int32_t ld, int64_t *bytes) {
+    QREC_REQUIRE(bytes && n_rows >= 0 && ld > 0, "qrec_ngcf_wgrad_partial_bytes: bad argument");
+    *bytes = ((n_rows + kSlabRows - 1) / kSlabRows) * 2 * (int64_t)ld * ld * 4;
+    return QREC_OK;
+}
+
+int qrec_copy_cols(float *d_dst, int32_t dst_ld, const float *d_src, int32_t src_ld, int32_t src_col_off, int64_t n_rows,
+                   int32_t d, int32_t accumulate, void *stream) {
+    QREC_REQUIRE(d_dst && d_src && n_rows >= 0 && d >= 1 && d <= dst_ld && src_col_off >= 0 && src_col_off + d <= src_ld,
+                 "qrec_copy_cols: bad argument");
+    if (n_rows == 0) return QREC_OK;
+    int64_t blocks = (n_rows * d + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(add_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), d_dst, dst_ld, d_src, src_ld,
+                       src_col_off, n_rows, d, accumulate ? 0 : 1);
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+}  // extern "C"

@@ -284,3 +284,103 @@ class SimGCLTrainer:
     def ego_embeddings(self):
         E = self.E.numpy()
         return E[:self.nu, :self.d].copy(), E[self.nu:, :self.d].copy()
+
+
+class _Adam:
+    """host-side bookkeeping of one TF-1.14 Adam slot set (fp32 beta powers)"""
+
+    def __init__(self, theta: DeviceBuffer, lr: float):
+        self.theta = theta
+        self.m = DeviceBuffer.zeros(theta.shape, np.float32); self.v = DeviceBuffer.zeros(theta.shape, np.float32)
+        f = np.float32
+        self.lr, self.b1, self.b2, self.eps = f(lr), f(0.9), f(0.999), f(1e-8)
+        self.b1p, self.b2p = self.b1, self.b2
+        self.n = int(np.prod(theta.shape))
+
+    def step(self, grad, grad_scale=1.0, stream=None):
+        f = np.float32
+        alpha = float(f(self.lr * np.sqrt(f(1) - self.b2p, dtype=f) / (f(1) - self.b1p)))
+        capi.adam_step(self.theta, self.m, self.v, grad, self.n, grad_scale, alpha, float(self.b1), float(self.b2),
+                       float(self.eps), stream)
+        self.b1p = f(self.b1p * self.b1); self.b2p = f(self.b2p * self.b2)
+
+
+class NGCFTrainer:
+    """model/ranking/NGCF.py:9-63 on the device: two layers of
+    side = A E; E' = dropout(leaky_relu((side+E) W1 + (E*side) W2)); out = [E0 | norm(E1) | norm(E2)],
+    batch BPR loss + batch L2 on the 3d-wide rows, Adam on U, V and the four d x d weights."""
+
+    KEEP = 0.9
+    N_LAYERS = 2
+
+    def __init__(self, U0, V0, W, adj, lr: float, reg: float, loss_eps: float = 1e-7, seed: int = 0):
+        self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
+        self.n = self.nu + self.ni
+        if 3 * self.d > 256:
+            raise ValueError("NGCF on the device supports embedding sizes up to 85 (3d <= 256)")
+        self.ld = padded_ld(self.d, np.float32)
+        self.wide_d, self.wide_ld = 3 * self.d, padded_ld(3 * self.d, np.float32)
+        self.lr, self.reg, self.loss_eps, self.seed = lr, reg, loss_eps, seed
+        self.plan = SpmmPlan(adj[0], adj[1], adj[2], self.ld)
+        E0 = np.zeros((self.n, self.ld), np.float32)
+        E0[:self.nu, :self.d] = U0; E0[self.nu:, :self.d] = V0
+        z = lambda: DeviceBuffer.zeros((self.n, self.ld), np.float32)
+        self.E = [DeviceBuffer.from_numpy(E0), z(), z()]          # E_0 (parameters), E_1, E_2
+        self.side = [z(), z()]; self.gate = [z(), z()]
+        self.inv = [DeviceBuffer.zeros(self.n, np.float32), DeviceBuffer.zeros(self.n, np.float32)]
+        self.dpre, self.dside, self.dEa, self.dEb = z(), z(), z(), z()
+        self.All = DeviceBuffer.zeros((self.n, self.wide_ld), np.float32)
+        self.dAll = DeviceBuffer.zeros((self.n, self.wide_ld), np.float32)
+        pad = lambda w: np.pad(np.asarray(w, np.float32), ((0, self.ld - self.d), (0, self.ld - self.d)))
+        self.W = [[DeviceBuffer.from_numpy(pad(w)) for w in pair] for pair in W]
+        self.gW = [[DeviceBuffer.zeros((self.ld, self.ld), np.float32) for _ in range(2)] for _ in range(2)]
+        self.partial = DeviceBuffer(capi.ngcf_wgrad_partial_bytes(self.n, self.ld), np.uint8)
+        self.optE = _Adam(self.E[0], lr)
+        self.optW = [[_Adam(w, lr) for w in pair] for pair in self.W]
+        self.d_loss = DeviceBuffer.zeros(1, np.float64)
+        self.step_no = 0
+
+    def forward(self, training: bool, masks=None, stream=None):
+        """fills E_1, E_2, side, gate, inv and the wide table All = [E_0 | z_1 | z_2]"""
+        n, d, ld = self.n, self.d, self.ld
+        capi.copy_cols(self.All, self.wide_ld, self.E[0], ld, 0, n, d, False, stream)
+        for k in range(self.N_LAYERS):
+            capi.spmm_csr(self.plan, self.E[k], self.side[k], ld, stream=stream)
+            capi.ngcf_dense_fwd(self.E[k], self.side[k], self.W[k][0], self.W[k][1], n, ld, self.gate[k], stream)
+            capi.ngcf_activate(self.gate[k], n, d, ld, self.KEEP if training else 1.0,
+                               None if masks is None else masks[k], self.seed, self.step_no * 8 + k, self.E[k + 1],
+                               self.All, self.wide_ld, (k + 1) * d, self.inv[k], stream)
+
+    def train_step_async(self, d_u, d_i, d_j, B: int, masks=None, stream=None):
+        n, d, ld = self.n, self.d, self.ld
+        self.forward(True, masks, stream)
+        self.dAll.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
+        capi.bpr_batch_loss_grad(self.All, 1.0, self.nu, n, self.wide_ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
+                                 self.dAll, self.d_loss, stream)
+        dnext = None
+        for k in (1, 0):
+            dE = self.dEa if k == 1 else self.dEb
+            capi.ngcf_layer_bwd(dnext, self.dAll, self.All, self.wide_ld, (k + 1) * d, self.inv[k], self.gate[k], self.E[k],
+                                self.side[k], self.W[k][0], self.W[k][1], n, d, ld, self.dpre, self.dside, dE, self.partial,
+                                self.gW[k][0], self.gW[k][1], stream)
+            capi.spmm_csr(self.plan, self.dside, dE, ld, d_addend=dE, addend_scale=1.0, stream=stream)   # dE += A^T dside
+            dnext = dE
+        capi.copy_cols(dnext, ld, self.dAll, self.wide_ld, 0, n, d, True, stream)                    # + ego block of the concat
+        self.optE.step(dnext, stream=stream)
+        for k in range(2):
+            for t in range(2):
+                self.optW[k][t].step(self.gW[k][t], stream=stream)
+        self.step_no += 1
+
+    def loss(self, stream=None) -> float:
+        return float(self.d_loss.numpy(stream)[0])
+
+    def inference_embeddings(self):
+        """3d-wide (U, V) of the inference graph (isTraining = 0, NGCF.py:65-69)."""
+        self.forward(False)
+        A = self.All.numpy()[:, :self.wide_d]
+        return np.ascontiguousarray(A[:self.nu]), np.ascontiguousarray(A[self.nu:])
+
+    def parameters(self):
+        E = self.E[0].numpy()[:, :self.d]
+        return E[:self.nu].copy(), E[self.nu:].copy(), [[w.numpy()[:self.d, :self.d].copy() for w in pair] for pair in self.W]

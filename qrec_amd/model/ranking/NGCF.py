@@ -1,0 +1,48 @@
+"""NGCF behind the reference's class name and hooks (model/ranking/NGCF.py:4-71): two
+neighbourhood-aggregation layers with d x d weights, LeakyReLU(0.2), message dropout 0.1 while
+training, L2-normalised layer outputs concatenated with the ego embeddings (3d wide), batch BPR
+loss + batch L2, Adam.  Test-time scores come from the inference graph (no dropout)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from ...base.graphRecommender import GraphRecommender
+from ...capi import DeviceBuffer
+from ...graph import NGCFTrainer
+from .SimGCL import xavier_uniform
+
+
+class NGCF(GraphRecommender):
+    def __init__(self, conf, trainingSet=None, testSet=None, fold="[1]"):
+        super().__init__(conf, trainingSet, testSet, fold)
+
+    def initModel(self):
+        super().initModel()
+        d = self.emb_size
+        self.n_layers = 2                                                   # NGCF.py:19
+        self.weights = [[xavier_uniform((d, d)), xavier_uniform((d, d))] for _ in range(self.n_layers)]   # W_k_1, W_k_2
+        self.trainer = NGCFTrainer(self.user_embeddings, self.item_embeddings, self.weights,
+                                   self.create_joint_sparse_adjaceny(), self.lRate, self.regU,
+                                   seed=int(os.environ.get("QREC_SEED", "0")))
+
+    def trainModel(self):
+        quiet = os.environ.get("QREC_QUIET") == "1"
+        tr = self.trainer
+        for epoch in range(self.maxEpoch):
+            u, i, j = self.sample_epoch_pairwise()
+            d_u, d_i, d_j = DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i), DeviceBuffer.from_numpy(j)
+            for n, s in enumerate(range(0, u.size, self.batch_size)):
+                B = min(self.batch_size, u.size - s)
+                tr.train_step_async(d_u.ptr + 4 * s, d_i.ptr + 4 * s, d_j.ptr + 4 * s, B)
+                if not quiet:
+                    print("training:", epoch + 1, "batch", n, "loss:", tr.loss())
+        # the reference scores with sess.run(self.test, isTraining=0) per user (NGCF.py:65-69);
+        # here the inference-graph tables are materialised once and ranked in one batch
+        self.U, self.V = tr.inference_embeddings()
+
+    def predictForRanking(self, u):
+        if self.data.containsUser(u):
+            return self.V.dot(self.U[self.data.getUserId(u)])
+        return [self.data.globalMean] * self.num_items

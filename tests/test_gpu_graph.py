@@ -300,3 +300,66 @@ def test_bpr_tf_variant_matches_restatement_and_runs_from_conf():
     losses = [float(l.split("loss:")[1]) for l in buf.getvalue().splitlines() if l.startswith("training:")]
     assert len(losses) == 2 * 8 and losses[-1] < losses[0] and m.P.dtype == np.float32
     assert any(x.startswith("Recall") for x in measure)
+
+
+# ---------------------------------------------------------------------------------------------
+# NGCF
+# ---------------------------------------------------------------------------------------------
+from qrec_amd.graph import NGCFTrainer  # noqa: E402
+
+
+@pytest.mark.parametrize("dim", [64, 50, 8])
+def test_ngcf_gradients_and_training_steps_match_restatement(dim):
+    d, adj, A = _graph("small")
+    nu, ni, B = d["n_users"], d["n_items"], 1024
+    N = nu + ni
+    rng = np.random.default_rng(dim)
+    U0 = (rng.standard_normal((nu, dim)) * 0.1).astype(np.float32); V0 = (rng.standard_normal((ni, dim)) * 0.1).astype(np.float32)
+    lim = np.sqrt(6.0 / (2 * dim))
+    W = [[rng.uniform(-lim, lim, (dim, dim)).astype(np.float32) for _ in range(2)] for _ in range(2)]
+    ref = T.NGCF(U0, V0, W, A, lr=0.002, reg=1e-3)
+    tr = NGCFTrainer(U0, V0, W, adj, lr=0.002, reg=1e-3)
+    ld = tr.ld
+    for step in range(4):
+        sel = rng.integers(0, d["train_u"].size, B)
+        u = d["train_u"][sel].astype(np.int32); i = d["train_i"][sel].astype(np.int32); j = rng.integers(0, ni, B).astype(np.int32)
+        masks = [(rng.random((N, dim)) < 0.9).astype(np.float32) for _ in range(2)]
+        if step == 0:   # gradients of the first step, before any update
+            loss0, gE, gW = ref.loss_and_grads(u, i, j, masks)
+        lref = ref.train_step(u, i, j, masks)
+        tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, masks=[DB.from_numpy(pad_cols(m, ld)) for m in masks])
+        assert abs(tr.loss() - lref) / abs(lref) < 2e-5
+        if step == 0:
+            assert rel_err(tr.dEb.numpy()[:, :dim], gE) < 1e-4
+            for k in range(2):
+                for t in range(2):
+                    got = tr.gW[k][t].numpy()
+                    assert rel_err(got[:dim, :dim], gW[k][t]) < 1e-4 and (got[dim:] == 0).all() and (got[:, dim:] == 0).all()
+    Ug, Vg, Wg = tr.parameters()
+    assert rel_err(np.concatenate([Ug, Vg]), ref.E) < 5e-5
+    for k in range(2):
+        for t in range(2):
+            assert rel_err(Wg[k][t], ref.W[k][t]) < 5e-5
+    Ui, Vi = tr.inference_embeddings(); Ur, Vr = ref.inference_embeddings()
+    assert Ui.shape == (nu, 3 * dim) and rel_err(Ui, Ur) < 1e-4 and rel_err(Vi, Vr) < 1e-4
+
+
+def test_ngcf_class_trains_and_evaluates_with_device_dropout():
+    from qrec_amd.model.ranking.NGCF import NGCF
+    meta, z = load_golden("bpr_filmtrust")
+    train, test = rows_from_golden(z)
+    conf = conf_from_text(meta["conf"])
+    conf["model.name"] = "NGCF"; conf["num.factors"] = "16"; conf["num.max.epoch"] = "3"; conf["batch_size"] = "1500"
+    conf["learnRate"] = "-init 0.002 -max 1"; conf["reg.lambda"] = "-u 0.001 -i 0.001 -b 0.2 -s 0.2"; conf["item.ranking"] = "on -topN 5,10"
+    random.seed(4); np.random.seed(4)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        m = NGCF(conf, train, test); measure = m.execute()
+    losses = [float(l.split("loss:")[1]) for l in buf.getvalue().splitlines() if l.startswith("training:")]
+    assert len(losses) == 3 * 22 and np.isfinite(losses).all() and np.mean(losses[-22:]) < np.mean(losses[:22])
+    assert m.U.shape == (meta["n_users"], 48) and m.V.shape == (meta["n_items"], 48)
+    assert measure[0] == "Top 5\n" and any(x.startswith("Recall") for x in measure)
+    # dropout really drops ~10% of the activations while training
+    m.trainer.forward(True)
+    E1 = m.trainer.E[1].numpy()[:, :16]
+    assert 0.05 < (E1 == 0).mean() < 0.2

@@ -135,3 +135,41 @@ def test_simgcl_gradient_matches_autograd(L):
     assert rec == pytest.approx(float(trec.detach()), rel=1e-5) and cl == pytest.approx(float(tcl.detach()), rel=1e-5)
     np.testing.assert_allclose(g, E.grad.numpy(), rtol=2e-3, atol=2e-5)
     assert np.array_equal(T.unique_first_appearance([3, 1, 3, 2, 1]), [3, 1, 2])
+
+
+def test_ngcf_gradients_match_autograd():
+    rng = np.random.default_rng(42)
+    nu, ni, d, B = 30, 25, 8, 40
+    uid = rng.integers(0, nu, 200); iid = rng.integers(0, ni, 200)
+    adj = T.joint_norm_adjacency(nu, ni, uid, iid)
+    U0 = rng.standard_normal((nu, d)).astype(np.float32) * 0.3; V0 = rng.standard_normal((ni, d)).astype(np.float32) * 0.3
+    W = [[rng.standard_normal((d, d)).astype(np.float32) * 0.4 for _ in range(2)] for _ in range(2)]
+    masks = [(rng.random((nu + ni, d)) < 0.9).astype(np.float32) for _ in range(2)]
+    u = rng.integers(0, nu, B); i = rng.integers(0, ni, B); j = rng.integers(0, ni, B)
+    m = T.NGCF(U0, V0, W, adj, lr=0.002, reg=0.01)
+    loss, gE, gW = m.loss_and_grads(u, i, j, masks)
+    coo = adj.tocoo()
+    A = torch.sparse_coo_tensor(np.vstack([coo.row, coo.col]), coo.data.astype(np.float64), adj.shape).coalesce()
+    E = torch.tensor(np.concatenate([U0, V0]).astype(np.float64), requires_grad=True)
+    Wt = [[torch.tensor(w.astype(np.float64), requires_grad=True) for w in pair] for pair in W]
+    cur, outs = E, [E]
+    for k in range(2):
+        side = torch.sparse.mm(A, cur)
+        pre = (side + cur) @ Wt[k][0] + (cur * side) @ Wt[k][1]
+        cur = torch.nn.functional.leaky_relu(pre, 0.2) * torch.tensor(masks[k].astype(np.float64)) / 0.9
+        outs.append(torch.nn.functional.normalize(cur, dim=1, eps=1e-6))
+    allE = torch.cat(outs, 1)
+    ub, ib, jb = allE[torch.tensor(u)], allE[torch.tensor(i) + nu], allE[torch.tensor(j) + nu]
+    score = (ub * ib).sum(1) - (ub * jb).sum(1)
+    tl = -torch.log(torch.sigmoid(score) + 1e-7).sum() + 0.01 * 0.5 * ((ub ** 2).sum() + (ib ** 2).sum() + (jb ** 2).sum())
+    tl.backward()
+    assert loss == pytest.approx(float(tl.detach()), rel=1e-5)
+    np.testing.assert_allclose(gE, E.grad.numpy(), rtol=2e-3, atol=2e-5)
+    for k in range(2):
+        for t in range(2):
+            np.testing.assert_allclose(gW[k][t], Wt[k][t].grad.numpy(), rtol=2e-3, atol=2e-5)
+    first = m.train_step(u, i, j, masks)
+    for _ in range(20):
+        last = m.train_step(u, i, j, masks)
+    assert last < first
+    Uf, Vf = m.inference_embeddings(); assert Uf.shape == (nu, 3 * d) and Vf.shape == (ni, 3 * d)
