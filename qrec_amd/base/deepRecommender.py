@@ -41,7 +41,6 @@ class DeepRecommender(IterativeRecommender):
         arrays in visiting order: ``shuffle(trainingData)``, then one negative per row, with
         the exact CPython draw sequence (done natively; the Python generator stays in
         lock-step).  Batches are consecutive ``batch_size`` slices; the last one is short."""
-        n = len(self.data.trainingData)
         self.shuffle_training_data()
         u, i, _ = self.data.training_arrays()
         rated = self._rated_sorted()
@@ -50,6 +49,22 @@ class DeepRecommender(IterativeRecommender):
         j = capi.mt_pairwise_sample_epoch(words, u, rated.indptr, rated.indices, self.num_items)
         random.setstate(capi.state_to_python(words, state[2]))
         return u, i, j
+
+    def iter_epoch_samples(self, n_epochs: int):
+        """Yield ``sample_epoch_pairwise()`` for epochs 0..n_epochs-1, computing epoch k+1 on a worker
+        thread while the caller trains on epoch k.  The draw sequence does not depend on the model, so
+        running it ahead leaves the CPython stream exactly where the reference's would be; nothing is
+        drawn beyond the last epoch."""
+        from concurrent.futures import ThreadPoolExecutor
+        if n_epochs <= 0:
+            return
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            pending = pool.submit(self.sample_epoch_pairwise)
+            for epoch in range(n_epochs):
+                sample = pending.result()
+                if epoch + 1 < n_epochs:
+                    pending = pool.submit(self.sample_epoch_pairwise)
+                yield sample
 
     def next_batch_pairwise(self):
         """Generator with the reference's signature: yields (u_idx, i_idx, j_idx) lists."""

@@ -103,14 +103,13 @@ class IterativeRecommender(Recommender):
         exact CPython draw sequence, done natively: a 1.2 M-row list takes ~1 s in
         ``random.shuffle`` and ~10 ms here.  The Python generator state is advanced in
         lock-step so later ``random`` calls agree with the reference."""
-        n = len(self.data.trainingData)
+        n = self.data.elemCount()
         state = random.getstate()
         words = capi.state_from_python(state)
         perm = np.arange(n, dtype=np.int64)
         capi.mt_shuffle(words, n, perm)
         random.setstate(capi.state_to_python(words, state[2]))
-        rows = self.data.trainingData
-        self.data.trainingData = [rows[k] for k in perm]
+        self.data.permute_training_data(perm)      # the Python list is rebuilt only if someone reads it
         return perm
 
     def isConverged(self, epoch):

@@ -23,13 +23,40 @@ class Rating:
         self.trainSet_u, self.trainSet_i = defaultdict(dict), defaultdict(dict)
         self.testSet_u, self.testSet_i = defaultdict(dict), defaultdict(dict)
         self.rScale = []
-        self.trainingData = trainingSet[:]
+        self._rows = trainingSet[:]          # the list form of trainingData (kept in sync lazily)
+        self._order = None                   # pending permutation of _rows (see permute_training_data)
+        self._arrays = None                  # (uid, iid, rating) of _rows in list order
         self.testData = testSet[:]
         self._ingest()
         self._means()
         if self.evalSettings.contains("-cold"):
             self._keep_cold_start_users(int(self.evalSettings["-cold"]))
         self._csr_cache = {}
+
+    # ``trainingData`` is the reference's public list (data/rating.py:24).  isConverged /
+    # next_batch_pairwise reshuffle it every epoch (base/iterativeRecommender.py:101,
+    # base/deepRecommender.py:30); rebuilding a 1.2 M-row Python list and re-deriving id arrays from it
+    # costs ~0.7 s per epoch, so the order lives in a permutation over cached id arrays and the list
+    # itself is only rebuilt when somebody reads it.
+    @property
+    def trainingData(self):
+        if self._order is not None:
+            rows = self._rows
+            self._rows = [rows[k] for k in self._order]
+            if self._arrays is not None:
+                self._arrays = tuple(a[self._order] for a in self._arrays)
+            self._order = None
+        return self._rows
+
+    @trainingData.setter
+    def trainingData(self, rows):
+        self._rows = rows
+        self._order = None
+        self._arrays = None
+
+    def permute_training_data(self, perm: np.ndarray):
+        """new_list[k] = old_list[perm[k]] -- applied lazily."""
+        self._order = perm if self._order is None else self._order[perm]
 
     # ---- construction -----------------------------------------------------------------
     def _ingest(self):
@@ -85,7 +112,7 @@ class Rating:
         return self.item.get(i)
 
     def trainingSize(self):
-        return (len(self.user), len(self.item), len(self.trainingData))
+        return (len(self.user), len(self.item), len(self._rows))
 
     def testSize(self):
         return (len(self.testSet_u), len(self.testSet_i), len(self.testData))
@@ -138,17 +165,21 @@ class Rating:
         return (self.rScale[0], self.rScale[1])
 
     def elemCount(self):
-        return len(self.trainingData)
+        return len(self._rows)
 
     # ---- array views for the kernels -----------------------------------------------------
     def training_arrays(self):
         """(uid int32[n], iid int32[n], rating float64[n]) of ``trainingData`` in its
         CURRENT order (isConverged reshuffles that list every epoch)."""
-        n = len(self.trainingData)
-        uid = np.fromiter((self.user[r[0]] for r in self.trainingData), dtype=np.int32, count=n)
-        iid = np.fromiter((self.item[r[1]] for r in self.trainingData), dtype=np.int32, count=n)
-        rat = np.fromiter((r[2] for r in self.trainingData), dtype=np.float64, count=n)
-        return uid, iid, rat
+        if self._arrays is None:
+            rows = self._rows
+            n = len(rows)
+            self._arrays = (np.fromiter((self.user[r[0]] for r in rows), dtype=np.int32, count=n),
+                            np.fromiter((self.item[r[1]] for r in rows), dtype=np.int32, count=n),
+                            np.fromiter((r[2] for r in rows), dtype=np.float64, count=n))
+        if self._order is None:
+            return tuple(a.copy() for a in self._arrays)
+        return tuple(np.ascontiguousarray(a[self._order]) for a in self._arrays)
 
     def _dict_csr(self, min_rating):
         # walk the dicts themselves: their iteration order IS the contract

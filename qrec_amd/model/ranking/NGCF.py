@@ -30,8 +30,7 @@ class NGCF(GraphRecommender):
     def trainModel(self):
         quiet = os.environ.get("QREC_QUIET") == "1"
         tr = self.trainer
-        for epoch in range(self.maxEpoch):
-            u, i, j = self.sample_epoch_pairwise()
+        for epoch, (u, i, j) in enumerate(self.iter_epoch_samples(self.maxEpoch)):
             d_u, d_i, d_j = DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i), DeviceBuffer.from_numpy(j)
             for n, s in enumerate(range(0, u.size, self.batch_size)):
                 B = min(self.batch_size, u.size - s)

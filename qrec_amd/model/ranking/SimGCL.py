@@ -46,8 +46,7 @@ class SimGCL(GraphRecommender):
     def trainModel(self):
         quiet = os.environ.get("QREC_QUIET") == "1"
         tr, nu = self.trainer, self.num_users
-        for epoch in range(self.maxEpoch):
-            u, i, j = self.sample_epoch_pairwise()
+        for epoch, (u, i, j) in enumerate(self.iter_epoch_samples(self.maxEpoch)):
             d_u, d_i, d_j = DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i), DeviceBuffer.from_numpy(j)
             # tf.unique per batch, for the whole epoch in one upload
             starts = list(range(0, u.size, self.batch_size))
