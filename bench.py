@@ -47,6 +47,7 @@ HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 
 DIM = 64
 LR0, MAX_LR, REG_U, REG_I = 0.01, 1.0, 0.001, 0.001   # config/BPR.conf:9-10
 CHUNK = 32
+FLUSH_EVERY = 8
 
 
 def bytes_per_triplet(d: int) -> int:
@@ -103,7 +104,7 @@ def cpu_exact_order_reference(sgd, u, i, n_items, P0, Q0, epochs, seed):
     lr, last = LR0, 0.0
     for k in range(epochs):
         sgd.sample_negatives_device(seed, k)
-        j = sgd.d_j.numpy()
+        j = sgd.negatives_reference_order()          # same j for the same (u, i), whatever the GPU's visiting order
         loss = O.bpr_sgd(P, Q, u, i, j, lr, REG_U, REG_I) + REG_U * O.sumsq(P) + REG_I * O.sumsq(Q)
         if k > 0:
             lr *= 1.05 if abs(last) > abs(loss) else 0.5
@@ -119,6 +120,8 @@ def main():
     ap.add_argument("--shape", default="yelp2018")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=capi.HW_DEFAULT)
+    ap.add_argument("--schedule", choices=("item", "user"), default="item",
+                    help="visiting order of the epoch's triplets in the Hogwild kernel (DESIGN.md s4)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,7 +153,7 @@ def main():
     P0 = (rng.random((U, DIM)) / 3).astype(np.float32)          # rand/3, iterativeRecommender.py:37-38
     Q0 = (np.random.default_rng(999).random((I, DIM)) / 3).astype(np.float32)  # same on all ranks
     tables = DeviceTables(P0, Q0, np.float32)
-    sgd = BprSgd(tables, u, items, CSR(indptr, items))
+    sgd = BprSgd(tables, u, items, CSR(indptr, items), schedule=args.schedule)
     total = args.warmup + args.steps
     ev = [(capi.Event(), capi.Event()) for _ in range(total)]
 
@@ -165,8 +168,12 @@ def main():
         sgd.take_prefetched_negatives(k)                            # BPR.py:35-37 (sampled under step k-1)
         capi._check(capi.load().qrec_memset(sgd.d_stats.ptr, 0, 8, None))
         ev[k][0].record()
-        capi.bpr_sgd_hogwild(tables.P, tables.Q, DIM, tables.ld, sgd.d_u, sgd.d_i, sgd.d_j, n, CHUNK, 0,
-                             state["lr"], REG_U, REG_I, sgd.d_stats, args.variant)   # BPR.py:45-53
+        if args.schedule == "item":
+            capi.bpr_sgd_hogwild_item_major(tables.P, tables.Q, DIM, tables.ld, sgd.d_u, sgd.d_i, sgd.d_j, n, CHUNK, 0,
+                                            FLUSH_EVERY, state["lr"], REG_U, REG_I, sgd.d_stats)   # BPR.py:45-53
+        else:
+            capi.bpr_sgd_hogwild(tables.P, tables.Q, DIM, tables.ld, sgd.d_u, sgd.d_i, sgd.d_j, n, CHUNK, 0,
+                                 state["lr"], REG_U, REG_I, sgd.d_stats, args.variant)
         ev[k][1].record()
         sgd.prefetch_negatives_device(2018, k + 1)                  # side stream, under the SGD kernel
         if q_sync is not None:   # sum the ranks' Q deltas: the path's one collective (RCCL all-reduce)
@@ -212,7 +219,7 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):
             tj = json.load(open(tfile))
-            if tj.get("workload") == f"bpr-{args.shape}-d{DIM}":
+            if tj.get("workload") == f"bpr-{args.shape}-d{DIM}-{args.schedule}":
                 traffic = tj.get("bytes_per_launch")
         out = {
             "metric": "BPR triplet-updates/sec", "value": value, "unit": "triplet-updates/s",
@@ -220,11 +227,11 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BPR d={DIM} on synthetic Yelp2018-shape ({U}x{I}, {n} train triplets/epoch), "
-                                   "throughput mode (device Philox sampler + Hogwild atomic-delta SGD)",
+                                   f"throughput mode (device Philox sampler + Hogwild atomic-delta SGD, {args.schedule}-major schedule)",
                        "triplets_per_step_per_gpu": n, "chunk": CHUNK,
                        "parallelism": "1 GPU" if world == 1 else f"user-sharded x{world}, replicated item table, per-step delta all-reduce (RCCL)",
                        "lr": LR0, "reg": REG_U, "final_loss": state["loss"]},
-            "roofline": {"bound": "hbm", "kernel": "bpr_hogwild_kernel<16,4,plain-load,atomic>",
+            "roofline": {"bound": "hbm", "kernel": "bpr_hogwild_item_kernel<16,4>" if args.schedule == "item" else "bpr_hogwild_kernel<16,4,plain-load,atomic>",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_kernel_ms,

@@ -122,6 +122,18 @@ int qrec_bpr_sgd_hogwild(float *d_P, float *d_Q, int32_t d, int32_t ld, const in
                          int32_t grid_groups, float lr, float regU, float regI, double *d_loss,
                          int variant, void *stream);
 
+/* The same Hogwild epoch, ITEM-major: the caller passes the triplets sorted by positive item (stable
+ * within an item); Q[i] stays in registers along an item run (flushed as one atomic delta and re-read
+ * every `flush_every` triplets), P[u] and Q[j] take the per-sample atomic deltas.  Moves the
+ * per-triplet atomics off the hot item rows (Zipf 0.6) onto user rows (Zipf 0.4) and uniform
+ * negatives, which the L2 atomic units retire ~25% faster.  Chunks are visited in a golden-ratio
+ * stride order so that the chunks of one hot item are spread over the epoch.  With grid_groups == 1
+ * and chunk order aside, each row still sees exactly the reference recurrence.              */
+int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int32_t d, int32_t ld, const int32_t *d_u,
+                                    const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
+                                    int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
+                                    double *d_loss, void *stream);
+
 /* model/rating/BasicMF.py:9-26, order-exact (config #1 parity on device). */
 int qrec_mf_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
                         const int32_t *d_u, const int32_t *d_i, const double *d_rating, int64_t n,

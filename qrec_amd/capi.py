@@ -48,6 +48,7 @@ _SIGNATURES = {
     "qrec_philox_bpr_sample": [_vp, _vp, _vp, _i64, _i32, _u64, _u64, _vp, _vp],
     "qrec_bpr_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _vp, _vp],
     "qrec_bpr_sgd_hogwild": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _vp, C.c_int, _vp],
+    "qrec_bpr_sgd_hogwild_item_major": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp],
     "qrec_mf_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _vp, _vp],
     "qrec_sumsq": [_vp, C.c_int, _i64, _i32, _i32, _vp, _vp],
     "qrec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp],
@@ -428,3 +429,9 @@ def copy_cols(d_dst, dst_ld: int, d_src, src_ld: int, src_col_off: int, n_rows: 
               stream=None):
     _check(load().qrec_copy_cols(_dp(d_dst), dst_ld, _dp(d_src), src_ld, src_col_off, n_rows, d, 1 if accumulate else 0,
                                  _sh(stream)))
+
+
+def bpr_sgd_hogwild_item_major(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int, chunk: int, grid_groups: int,
+                               flush_every: int, lr: float, regU: float, regI: float, d_loss, stream=None):
+    _check(load().qrec_bpr_sgd_hogwild_item_major(_dp(d_P), _dp(d_Q), d, ld, _dp(d_u), _dp(d_i), _dp(d_j), n, chunk,
+                                                  grid_groups, flush_every, lr, regU, regI, _dp(d_loss), _sh(stream)))

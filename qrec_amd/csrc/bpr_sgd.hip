@@ -285,6 +285,125 @@ __global__ __launch_bounds__(256) void bpr_hogwild_kernel(
     if (lane == 0 && loss_acc != 0.0) atomicAdd(loss_out, loss_acc);  // one f64 atomic per wavefront
 }
 
+// ------------------------------------------------------------------------------------
+// Item-major schedule of the same Hogwild epoch.
+// The triplets arrive sorted by positive item; a group keeps Q[i] in registers along an item run
+// (exact chain on that row), and applies the per-sample deltas of P[u] and Q[j] atomically.
+// Why: the atomic units serialise same-line requests.  In the user-major schedule the per-triplet
+// atomics land on Q[i] ~ Zipf(0.6) (6.3k touches on the top item per epoch) and Q[j] ~ uniform:
+// 3.8 G row-updates/s.  Item-major moves them to P[u] ~ Zipf(0.4) (max 1.35k) and Q[j]: 4.8 G/s,
+// the uniform-address rate (tools/ubench/atomics3.hip).  Q[i] itself is flushed as one delta every
+// `flush_every` triplets and re-read, so that concurrent runs of the same hot item see each other.
+// Chunk c of the item-major list is executed at time slot s with c = (s * stride) mod n_chunks
+// (stride coprime to n_chunks, ~0.618 n_chunks), which spreads the ~200 chunks of a hot item over
+// the whole epoch instead of running them all at once.
+// ------------------------------------------------------------------------------------
+template <int LPR, int E>
+__global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
+    float *__restrict__ P, float *__restrict__ Q, uint32_t p_bytes, uint32_t q_bytes,
+    const int32_t *__restrict__ u_idx, const int32_t *__restrict__ i_idx,
+    const int32_t *__restrict__ j_idx, int64_t n, int chunk, int64_t n_chunks, int64_t chunk_stride,
+    int64_t groups_active, int flush_every, float lr, float cu, float ci, double *__restrict__ loss_out) {
+    constexpr int GPW = kWave / LPR;
+    __shared__ int32_t s_idx[4][GPW][3][kMaxChunk];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane / LPR, r = lane % LPR;
+    const int64_t gid = ((int64_t)blockIdx.x * 4 + wave) * GPW + g;
+    int32_t *su = s_idx[wave][g][0], *si = s_idx[wave][g][1], *sj = s_idx[wave][g][2];
+    const __amdgpu_buffer_rsrc_t rsP = make_rsrc(P, p_bytes), rsQ = make_rsrc(Q, q_bytes);
+    float loss = 0.f;
+    double loss_acc = 0.0;
+
+    for (int64_t slot = gid; slot < n_chunks && gid < groups_active; slot += groups_active) {
+        const int64_t c = (int64_t)(((unsigned __int128)slot * (unsigned __int128)chunk_stride) % (unsigned __int128)n_chunks);
+        const int64_t t0 = c * chunk;
+        const int len = (int)((n - t0) < chunk ? (n - t0) : chunk);
+        for (int k = r; k < len; k += LPR) { su[k] = u_idx[t0 + k]; si[k] = i_idx[t0 + k]; sj[k] = j_idx[t0 + k]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        int cur_i = -1, since_flush = 0;
+        Row<E> qi, qi0;
+#pragma unroll
+        for (int e = 0; e < E; e++) qi.v[e] = qi0.v[e] = 0.f;
+        int ut = su[0], jt = sj[0];
+        Row<E> pu = hw_load_row<LPR, E, LD_PLAIN>(rsP, ut, r);
+        Row<E> qj = hw_load_row<LPR, E, LD_PLAIN>(rsQ, jt, r);
+        for (int k = 0; k < len; k++) {
+            const int it = si[k];
+            if (it != cur_i || since_flush >= flush_every) {
+                if (cur_i >= 0) hw_update_row<LPR, E, UP_ATOMIC>(rsQ, cur_i, r, qi0, qi);
+                qi = hw_load_row<LPR, E, LD_SC1>(rsQ, it, r);      // bypass L1: pick up other runs' flushes
+                qi0 = qi; cur_i = it; since_flush = 0;
+            }
+            int un = ut, jn = jt;
+            Row<E> npu = pu, nqj = qj;
+            const bool more = (k + 1 < len);
+            if (more) {
+                un = su[k + 1]; jn = sj[k + 1];
+                npu = hw_load_row<LPR, E, LD_PLAIN>(rsP, un, r);
+                nqj = hw_load_row<LPR, E, LD_PLAIN>(rsQ, jn, r);
+            }
+            float di = 0.f, dj = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; e++) { di += pu.v[e] * qi.v[e]; dj += pu.v[e] * qj.v[e]; }
+            di = row_allreduce_sum<LPR>(di); dj = row_allreduce_sum<LPR>(dj);
+            const float s = 1.0f / (1.0f + expf(-(di - dj)));
+            const float gsc = lr * (1.0f - s);
+            Row<E> pun, qjn;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const float p1 = pu.v[e] + gsc * (qi.v[e] - qj.v[e]);
+                float a = qi.v[e] + gsc * p1, b = qj.v[e] - gsc * p1;
+                qi.v[e] = a - ci * a; qjn.v[e] = b - ci * b;
+                pun.v[e] = p1 - cu * p1;
+            }
+            hw_update_row<LPR, E, UP_ATOMIC>(rsP, ut, r, pu, pun);
+            hw_update_row<LPR, E, UP_ATOMIC>(rsQ, jt, r, qj, qjn);
+            loss += neg_log_sigmoid(di - dj);
+            since_flush++;
+            if (more) {   // rows this group just changed supersede the prefetched copy
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    if (un == ut) npu.v[e] = pun.v[e];
+                    if (jn == jt) nqj.v[e] = qjn.v[e]; else if (jn == cur_i) nqj.v[e] = qi.v[e];
+                }
+            }
+            pu = npu; qj = nqj; ut = un; jt = jn;
+        }
+        if (cur_i >= 0) hw_update_row<LPR, E, UP_ATOMIC>(rsQ, cur_i, r, qi0, qi);
+        loss_acc += (double)loss; loss = 0.f;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (r != 0) loss_acc = 0.0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) loss_acc += __shfl_xor(loss_acc, m, kWave);
+    if (lane == 0 && loss_acc != 0.0) atomicAdd(loss_out, loss_acc);
+}
+
+template <int LPR, int E>
+int launch_hogwild_item(float *P, float *Q, uint32_t pb, uint32_t qb, const int32_t *u, const int32_t *i,
+                        const int32_t *j, int64_t n, int chunk, int64_t groups, int flush_every, float lr, float cu,
+                        float ci, double *loss, hipStream_t st) {
+    constexpr int GPW = kWave / LPR;
+    const int64_t n_chunks = (n + chunk - 1) / chunk;
+    const int64_t default_groups = (int64_t)256 * 4 * GPW, max_groups = (int64_t)256 * 8 * 4 * GPW;
+    if (groups <= 0) groups = default_groups;
+    if (groups > max_groups) groups = max_groups;
+    if (groups > n_chunks) groups = n_chunks;
+    // stride ~ 0.618 n_chunks, made coprime with n_chunks: consecutive time slots visit far-apart chunks
+    int64_t stride = (int64_t)((double)n_chunks * 0.6180339887498949);
+    if (stride < 1) stride = 1;
+    auto gcd = [](int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; };
+    while (gcd(stride, n_chunks) != 1) stride++;
+    const unsigned blocks = (unsigned)((groups + 4 * GPW - 1) / (4 * GPW));
+    hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, chunk,
+                       n_chunks, stride, groups, flush_every, lr, cu, ci, loss);
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
 template <int LPR, int E>
 int launch_hogwild(float *P, float *Q, uint32_t pb, uint32_t qb, const int32_t *u,
                    const int32_t *i, const int32_t *j, int64_t n, int chunk, int64_t groups,
@@ -401,6 +520,28 @@ int qrec_bpr_sgd_hogwild(float *d_P, float *d_Q, int32_t d, int32_t ld, const in
         case 64: return launch_hogwild<16, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, lr, cu, ci, d_loss, variant, st);
         case 128: return launch_hogwild<32, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, lr, cu, ci, d_loss, variant, st);
         default: return launch_hogwild<64, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, lr, cu, ci, d_loss, variant, st);
+    }
+}
+
+int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int32_t d, int32_t ld, const int32_t *d_u,
+                                    const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
+                                    int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
+                                    double *d_loss, void *stream) {
+    QREC_REQUIRE(d_P && d_Q && d_loss && n >= 0, "qrec_bpr_sgd_hogwild_item_major: null argument");
+    QREC_REQUIRE(n == 0 || (d_u && d_i && d_j), "qrec_bpr_sgd_hogwild_item_major: null index array");
+    QREC_REQUIRE(ld >= d && d >= 1, "qrec_bpr_sgd_hogwild_item_major: need ld >= d >= 1");
+    QREC_REQUIRE(ld == 32 || ld == 64 || ld == 128 || ld == 256,
+                 "qrec_bpr_sgd_hogwild_item_major: row stride must be 32, 64, 128 or 256 floats (got ld=%d)", ld);
+    QREC_REQUIRE(chunk >= 1 && chunk <= kMaxChunk && flush_every >= 1, "qrec_bpr_sgd_hogwild_item_major: bad chunk / flush interval");
+    if (n == 0) return QREC_OK;
+    const uint32_t full = 0xffffffffu;
+    hipStream_t st = as_stream(stream);
+    const float cu = lr * regU, ci = lr * regI;
+    switch (ld) {
+        case 32: return launch_hogwild_item<16, 2>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, lr, cu, ci, d_loss, st);
+        case 64: return launch_hogwild_item<16, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, lr, cu, ci, d_loss, st);
+        case 128: return launch_hogwild_item<32, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, lr, cu, ci, d_loss, st);
+        default: return launch_hogwild_item<64, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, lr, cu, ci, d_loss, st);
     }
 }
 

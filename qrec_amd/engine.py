@@ -71,11 +71,23 @@ class BprSgd:
     negatives); the SGD kernel is bound by the L2 atomic units, the sampler by integer ALU,
     so they overlap almost perfectly."""
 
-    def __init__(self, tables: DeviceTables, u: np.ndarray, i: np.ndarray, pos: CSR | None = None):
+    def __init__(self, tables: DeviceTables, u: np.ndarray, i: np.ndarray, pos: CSR | None = None,
+                 schedule: str = "user"):
+        """``schedule``: "user" keeps the reference's user-major order (required by the order-exact
+        kernel); "item" stores the same triplets sorted by positive item for the item-major
+        throughput kernel (``self.perm`` maps scheduled position -> reference position)."""
+        if schedule not in ("user", "item"):
+            raise ValueError("schedule must be 'user' or 'item'")
         self.t = tables
         self.n = int(u.size)
-        self.d_u = DeviceBuffer.from_numpy(np.ascontiguousarray(u, dtype=np.int32))
-        self.d_i = DeviceBuffer.from_numpy(np.ascontiguousarray(i, dtype=np.int32))
+        self.schedule = schedule
+        self.perm = None
+        u = np.ascontiguousarray(u, dtype=np.int32); i = np.ascontiguousarray(i, dtype=np.int32)
+        if schedule == "item":
+            self.perm = np.argsort(i, kind="stable")
+            u, i = np.ascontiguousarray(u[self.perm]), np.ascontiguousarray(i[self.perm])
+        self.d_u = DeviceBuffer.from_numpy(u)
+        self.d_i = DeviceBuffer.from_numpy(i)
         self.d_j = DeviceBuffer(max(self.n, 1), np.int32)
         self.d_j_next = None
         self.d_stats = DeviceBuffer.zeros(3, np.float64)
@@ -90,7 +102,19 @@ class BprSgd:
 
     # -- negatives ---------------------------------------------------------------------------
     def set_negatives(self, j: np.ndarray, stream=None):
-        self.d_j.upload(np.ascontiguousarray(j, dtype=np.int32), stream)
+        """``j`` in the reference's (user-major) triplet order; re-ordered to the schedule's."""
+        j = np.ascontiguousarray(j, dtype=np.int32)
+        if self.perm is not None:
+            j = np.ascontiguousarray(j[self.perm])
+        self.d_j.upload(j, stream)
+
+    def negatives_reference_order(self) -> np.ndarray:
+        """current negatives as a host array in the reference's triplet order"""
+        j = self.d_j.numpy()
+        if self.perm is None:
+            return j
+        out = np.empty_like(j); out[self.perm] = j
+        return out
 
     def sample_negatives_device(self, seed: int, epoch: int, stream=None):
         if self._pos_dev is None:
@@ -121,18 +145,27 @@ class BprSgd:
     # -- epochs ------------------------------------------------------------------------------------
     def epoch_ordered(self, lr: float, regU: float, regI: float, stream=None) -> float:
         """Strictly sequential pass (reference semantics).  Returns sum(-log sigmoid)."""
+        if self.schedule != "user":
+            raise RuntimeError("the order-exact kernel needs the reference's user-major order")
         capi.bpr_sgd_ordered(self.t.P, self.t.Q, self.t.code, self.t.d, self.t.ld, self.d_u, self.d_i,
                              self.d_j, self.n, lr, regU, regI, self.d_stats, stream)
         return float(self.d_stats.numpy(stream)[0])
 
     def epoch_throughput_async(self, lr: float, regU: float, regI: float, chunk: int = 32,
-                               variant: int = capi.HW_DEFAULT, stream=None):
-        """Hogwild pass (fp32 tables); enqueue only -- read the loss with ``loss()``."""
+                               variant: int = capi.HW_DEFAULT, stream=None, groups: int = 0, flush_every: int = 8):
+        """Hogwild pass (fp32 tables); enqueue only -- read the loss with ``loss()``/``epoch_stats()``.
+        User-major schedule: P[u] register-resident, atomics on Q[i], Q[j].  Item-major schedule:
+        Q[i] register-resident (flushed + re-read every ``flush_every`` triplets), atomics on P[u],
+        Q[j] -- ~20% faster because the atomic units see flatter target rows."""
         if self.t.dtype != np.float32:
             raise TypeError("throughput mode needs fp32 tables")
         capi._check(capi.load().qrec_memset(self.d_stats.ptr, 0, 8, capi._sh(stream)))
-        capi.bpr_sgd_hogwild(self.t.P, self.t.Q, self.t.d, self.t.ld, self.d_u, self.d_i, self.d_j,
-                             self.n, chunk, 0, lr, regU, regI, self.d_stats, variant, stream)
+        if self.schedule == "item":
+            capi.bpr_sgd_hogwild_item_major(self.t.P, self.t.Q, self.t.d, self.t.ld, self.d_u, self.d_i, self.d_j,
+                                            self.n, chunk, groups, flush_every, lr, regU, regI, self.d_stats, stream)
+        else:
+            capi.bpr_sgd_hogwild(self.t.P, self.t.Q, self.t.d, self.t.ld, self.d_u, self.d_i, self.d_j,
+                                 self.n, chunk, groups, lr, regU, regI, self.d_stats, variant, stream)
 
     def epoch_stats(self, stream=None):
         """(sum -log sigma, sum P*P, sum Q*Q) after the enqueued epoch -- BPR.py:40,53.

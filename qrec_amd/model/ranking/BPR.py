@@ -11,7 +11,8 @@ Two execution modes, chosen by the optional conf key ``qrec.mode`` or env ``QREC
 ``throughput``
     Device Philox sampler + Hogwild kernel (fp32, exact per-sample deltas applied with
     atomic adds).  Same algorithm and sampling distribution, not the same random stream;
-    judged on Recall@N.
+    judged on Recall@N.  ``QREC_SCHEDULE=item`` (default; triplets visited item-major, faster)
+    or ``user`` (the reference's user-major visiting order).
 """
 from __future__ import annotations
 
@@ -39,6 +40,7 @@ class BPR(IterativeRecommender):
         dt = os.environ.get("QREC_DTYPE", "f64" if mode == "exact" else "f32")
         self.table_dtype = np.float64 if (dt == "f64" and mode == "exact") else np.float32
         self.sampler_seed = int(os.environ.get("QREC_SEED", "0"))
+        self.schedule = os.environ.get("QREC_SCHEDULE", "item") if mode == "throughput" else "user"
 
     def initModel(self):
         super().initModel()
@@ -49,7 +51,7 @@ class BPR(IterativeRecommender):
         u, i = pos.row_ids(), pos.indices
         print("training...")
         tables = DeviceTables(self.P, self.Q, self.table_dtype)
-        sgd = BprSgd(tables, u, i, pos)
+        sgd = BprSgd(tables, u, i, pos, schedule=self.schedule)
         n_items = len(self.data.item)
         epoch = 0
         if self.mode == "throughput":

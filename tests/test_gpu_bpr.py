@@ -329,3 +329,114 @@ def test_loss_is_finite_where_fp32_sigmoid_underflows():
     assert sgd.loss() == pytest.approx(120.0, rel=1e-6)
     P32, Q32 = P0.copy(), Q0.copy()
     assert O.bpr_sgd(P32, Q32, u, i, j, 0.0, 0.0, 0.0) == pytest.approx(120.0, rel=1e-6)   # fp32 comparator too
+
+
+# ---------------------------------------------------------------------------------------------
+# item-major schedule of the throughput kernel
+# ---------------------------------------------------------------------------------------------
+def _item_major_visit_order(i_sorted_len, chunk):
+    """the kernel's visiting order: time slot s -> chunk (s*stride) mod n_chunks, stride ~ 0.618 n_chunks
+    made coprime with n_chunks (qrec_amd/csrc/bpr_sgd.hip: launch_hogwild_item)"""
+    from math import gcd
+    n_chunks = -(-i_sorted_len // chunk)
+    stride = max(1, int(n_chunks * 0.6180339887498949))
+    while gcd(stride, n_chunks) != 1:
+        stride += 1
+    order = []
+    for s in range(n_chunks):
+        c = (s * stride) % n_chunks
+        order.extend(range(c * chunk, min((c + 1) * chunk, i_sorted_len)))
+    return np.array(order, dtype=np.int64)
+
+
+@pytest.mark.parametrize("dim", [64, 50, 128, 8])
+@pytest.mark.parametrize("chunk,flush", [(32, 8), (7, 3), (64, 64)])
+def test_item_major_single_group_is_the_sequential_recurrence_in_its_visiting_order(dim, chunk, flush):
+    d, indptr, ind, u, j = _synthetic("small")
+    U, I, n = d["n_users"], d["n_items"], ind.size
+    rng = np.random.default_rng(dim)
+    P0 = rng.random((U, dim)) / 3; Q0 = rng.random((I, dim)) / 3
+    t = DeviceTables(P0, Q0, np.float32)
+    sgd = BprSgd(t, u, ind, schedule="item"); sgd.set_negatives(j)
+    us, is_, js = sgd.d_u.numpy(), sgd.d_i.numpy(), sgd.d_j.numpy()
+    assert (np.diff(is_) >= 0).all() and np.array_equal(js, j[sgd.perm]) and np.array_equal(sgd.negatives_reference_order(), j)
+    order = _item_major_visit_order(n, chunk)
+    assert np.array_equal(np.sort(order), np.arange(n))            # every triplet exactly once
+    Pr, Qr = P0.copy(), Q0.copy()
+    lref = O.bpr_sgd(Pr, Qr, np.ascontiguousarray(us[order]), np.ascontiguousarray(is_[order]), np.ascontiguousarray(js[order]), 0.05, 0.01, 0.02)
+    sgd.d_stats.fill_bytes(0)
+    capi.bpr_sgd_hogwild_item_major(t.P, t.Q, dim, t.ld, sgd.d_u, sgd.d_i, sgd.d_j, n, chunk, 1, flush, 0.05, 0.01, 0.02, sgd.d_stats)
+    Pg, Qg = t.download()
+    assert rel_err(Pg, Pr) < F32_TOL and rel_err(Qg, Qr) < F32_TOL
+    assert abs(sgd.loss() - lref) / lref < F32_TOL
+    assert (t.P.numpy()[:, dim:] == 0).all() and (t.Q.numpy()[:, dim:] == 0).all()
+
+
+def test_item_major_full_grid_properties_yelp_shape():
+    d, indptr, ind, u, j = _synthetic("yelp2018", seed=1)
+    U, I, n, dim = d["n_users"], d["n_items"], ind.size, 64
+    rng = np.random.default_rng(0)
+    P0 = (rng.random((U, dim)) / 3).astype(np.float32); Q0 = (rng.random((I, dim)) / 3).astype(np.float32)
+    t = DeviceTables(P0, Q0, np.float32)
+    sgd = BprSgd(t, u, ind, schedule="item"); sgd.set_negatives(j)
+    # lr = 0: nothing moves, loss = static loss
+    sgd.epoch_throughput_async(0.0, 0.001, 0.001)
+    Pg, Qg = t.download(np.float32)
+    assert np.array_equal(Pg, P0) and np.array_equal(Qg, Q0)
+    Pz, Qz = P0.astype(np.float64), Q0.astype(np.float64)
+    lz = O.bpr_sgd(Pz, Qz, u, ind, j, 0.0, 0.001, 0.001)
+    assert abs(sgd.loss() - lz) / lz < F32_TOL
+    # one real epoch: no update is lost -> a few percent from the sequential result in the same visiting order
+    order = _item_major_visit_order(n, 32)
+    us, is_, js = sgd.d_u.numpy()[order], sgd.d_i.numpy()[order], sgd.d_j.numpy()[order]
+    Pr, Qr = P0.astype(np.float64), Q0.astype(np.float64)
+    lref = O.bpr_sgd(Pr, Qr, np.ascontiguousarray(us), np.ascontiguousarray(is_), np.ascontiguousarray(js), 0.01, 0.001, 0.001)
+    sgd.epoch_throughput_async(0.01, 0.001, 0.001)
+    Pg, Qg = t.download()
+    assert np.isfinite(Pg).all() and np.isfinite(Qg).all()
+    assert rel_err(Pg, Pr) < 0.02 and rel_err(Qg, Qr) < 0.04 and abs(sgd.loss() - lref) / lref < 0.02
+    touched = np.zeros(I, bool); touched[ind] = True; touched[j] = True
+    if (~touched).any():
+        assert np.array_equal(t.Q.numpy()[~touched][:, :dim], Q0[~touched])
+    with pytest.raises(RuntimeError):
+        sgd.epoch_ordered(0.01, 0.0, 0.0)          # the order-exact kernel refuses a non-reference order
+
+
+@pytest.mark.parametrize("lr0,seed", [(0.01, 7), (0.05, 7)])
+def test_item_major_recall_matches_exact_order_training(lr0, seed):
+    """Same paired design as above for the (default) item-major schedule: the CPU port runs the
+    reference's user-major order with the same negative for every (u, i)."""
+    from qrec_amd.interactions import CSR
+    from qrec_amd.ranking import DeviceRanker
+    d = make_dataset("yelp2018")
+    U, I, dim, epochs, reg = d["n_users"], d["n_items"], 64, 12, 0.001
+    indptr, ind = to_csr(U, d["train_u"], d["train_i"])
+    u = np.repeat(np.arange(U, dtype=np.int32), np.diff(indptr)).astype(np.int32)
+    rng = np.random.default_rng(3)
+    P0 = (rng.random((U, dim)) / 3).astype(np.float32); Q0 = (rng.random((I, dim)) / 3).astype(np.float32)
+    Pc, Qc = P0.astype(np.float64), Q0.astype(np.float64)
+    t = DeviceTables(P0, Q0, np.float32)
+    sgd = BprSgd(t, u, ind, CSR(indptr, ind), schedule="item")
+    lr_c = lr_g = lr0; last_c = last_g = 0.0
+    for k in range(epochs):
+        sgd.sample_negatives_device(seed, k)
+        j = sgd.negatives_reference_order()
+        sgd.epoch_throughput_async(lr_g, reg, reg)
+        nll, sp, sq = sgd.epoch_stats(); loss_g = nll + reg * sp + reg * sq
+        loss_c = O.bpr_sgd(Pc, Qc, u, ind, j, lr_c, reg, reg) + reg * O.sumsq(Pc) + reg * O.sumsq(Qc)
+        if k > 0:
+            lr_g *= 1.05 if abs(last_g) > abs(loss_g) else 0.5
+            lr_c *= 1.05 if abs(last_c) > abs(loss_c) else 0.5
+        last_g, last_c = loss_g, loss_c
+    assert lr_g == pytest.approx(lr_c, rel=1e-12) and abs(last_g - last_c) / last_c < 0.04
+    Pg, Qg = t.download(np.float32)
+    users = np.unique(d["test_u"]).astype(np.int32)
+    test_keys = np.unique(d["test_u"].astype(np.int64) * I + d["test_i"]); cnt = np.bincount(d["test_u"], minlength=U)[users]
+
+    def recall(P, Q):
+        ids, _ = DeviceRanker(np.ascontiguousarray(P, np.float32), np.ascontiguousarray(Q, np.float32), CSR(indptr, ind)).topk(users, 20)
+        return float((np.isin((users.astype(np.int64)[:, None] * I + ids).ravel(), test_keys).reshape(ids.shape).sum(1) / cnt).mean())
+
+    r_cpu, r_gpu = recall(Pc, Qc), recall(Pg, Qg)
+    print("item-major Recall@20 exact-order", r_cpu, "throughput", r_gpu, "loss", last_c, last_g)
+    assert abs(r_cpu - r_gpu) <= 0.002

@@ -24,7 +24,7 @@ for sub, ctr in (("prof_fetch", "FETCH_SIZE"), ("prof_write", "WRITE_SIZE")):
     for name, n, avg in q(db, f"select kernel_name, count(*), avg(value) from counters_collection where counter_name='{ctr}' group by kernel_name"):
         out["counters"].setdefault(name[:160], {})[ctr + "_KB_avg"] = avg
         out["counters"][name[:160]]["dispatches_" + ctr] = n
-hot = [k for k in out["counters"] if "bpr_hogwild_kernel" in k]
+hot = [k for k in out["counters"] if "bpr_hogwild" in k]
 if hot:
     c = out["counters"][hot[0]]
     # MI355X_MICROARCH.md "HBM": on gfx950 FETCH_SIZE reports 1/2 of the bytes read (verified for
