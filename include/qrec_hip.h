@@ -154,21 +154,24 @@ int qrec_sumsq(const void *d_x, int dtype, int64_t rows, int32_t d, int32_t ld, 
  * "the whole row, write Y directly", otherwise the partial sum goes to scratch slot
  * seg_slot of d_partial and long row k (long_row[k]) is the in-order sum of its
  * long_count[k] slots starting at long_first[k].  X, Y, addend, accum: [rows][ld] fp32,
- * ld in {32,64,128,256}.  Deterministic (no float atomics).                            */
+ * ld in {32,64,128,256}.  Deterministic (no float atomics).  d_x_row_mask (may be NULL):
+ * bitmap, bit c set iff row c of X is non-zero; clear rows are skipped (bit-identical result,
+ * less traffic) -- used for the first backward SpMM, whose operand is the sparse batch gradient. */
 int qrec_spmm_csr(const int32_t *d_seg_row, const int64_t *d_seg_beg, const int32_t *d_seg_len,
                   const int32_t *d_seg_slot, int64_t n_segs, const int32_t *d_long_row,
                   const int32_t *d_long_first, const int32_t *d_long_count, int32_t n_long,
                   const int32_t *d_indices, const float *d_values, const float *d_X, float *d_Y,
                   float *d_partial, int32_t ld, const float *d_addend, float addend_scale, float *d_accum,
-                  void *stream);
+                  const uint32_t *d_x_row_mask, void *stream);
 
 /* embedding_lookup x3 + util/loss.py:3-6 bpr_loss + the batch l2 term and all their gradients
  * (LightGCN.py:22-30): rows are S[row]/div (div = n_layers+1 folds the layer mean in), users
  * at rows [0,n_users), items at n_users+id.  dE (pre-zeroed, [n_rows][ld]) receives the
- * scatter-added row gradients; *d_loss (double) is ACCUMULATED into.                    */
+ * scatter-added row gradients; *d_loss (double) is ACCUMULATED into.  d_row_mask (may be NULL;
+ * pre-zeroed, (n_rows+31)/32 words): bit r is set for every row of dE that receives a gradient. */
 int qrec_bpr_batch_loss_grad(const float *d_S, float div, int32_t n_users, int64_t n_rows, int32_t ld,
                              const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int32_t B, float eps,
-                             float reg, float *d_dE, double *d_loss, void *stream);
+                             float reg, float *d_dE, double *d_loss, uint32_t *d_row_mask, void *stream);
 
 /* tf.train.AdamOptimizer dense update (LightGCN.py:31-32) in TF 1.14's ApplyAdam form, fp32,
  * with g = grad_scale * d_grad + grad_l2 * theta (grad_l2 = reg folds in d/dtheta of

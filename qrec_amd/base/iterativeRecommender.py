@@ -86,7 +86,12 @@ class IterativeRecommender(Recommender):
         warm = [u for u in users if self.data.containsUser(u)]
         recList = {}
         if warm:
-            ranker = DeviceRanker(np.ascontiguousarray(U), np.ascontiguousarray(V), self.data.rated_csr())
+            U, V = np.ascontiguousarray(U), np.ascontiguousarray(V)
+            ranker = getattr(self, "_ranker", None)
+            if ranker is not None and (ranker.n_users, ranker.n_items, ranker.d, ranker.dtype) == (U.shape[0], V.shape[0], U.shape[1], U.dtype):
+                ranker.update_tables(U, V)             # per-epoch evaluation: keep buffers, re-upload tables
+            else:
+                ranker = self._ranker = DeviceRanker(U, V, self.data.rated_csr())
             uid = np.fromiter((self.data.user[u] for u in warm), dtype=np.int32, count=len(warm))
             ids, scores = ranker.topk(uid, min(N, self.num_items))
             id2item = self.data.id2item

@@ -51,8 +51,8 @@ _SIGNATURES = {
     "qrec_bpr_sgd_hogwild_item_major": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp],
     "qrec_mf_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _vp, _vp],
     "qrec_sumsq": [_vp, C.c_int, _i64, _i32, _i32, _vp, _vp],
-    "qrec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp],
-    "qrec_bpr_batch_loss_grad": [_vp, _f32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp],
+    "qrec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _vp],
+    "qrec_bpr_batch_loss_grad": [_vp, _f32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
     "qrec_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
     "qrec_perturb_rows": [_vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp],
     "qrec_info_nce_workspace_bytes": [_i32, _i32, _vp],
@@ -362,18 +362,20 @@ def score_topk(d_U, d_V, dtype: int, d: int, ld: int, n_items: int, d_user_ids, 
                                   _dp(d_scores_out), _sh(stream)))
 
 
-def spmm_csr(plan, d_X, d_Y, ld: int, d_addend=None, addend_scale: float = 0.0, d_accum=None, stream=None):
+def spmm_csr(plan, d_X, d_Y, ld: int, d_addend=None, addend_scale: float = 0.0, d_accum=None, stream=None,
+             d_x_row_mask=None):
     """plan: qrec_amd.graph.SpmmPlan (device-resident segment arrays)"""
     _check(load().qrec_spmm_csr(_dp(plan.seg_row), _dp(plan.seg_beg), _dp(plan.seg_len), _dp(plan.seg_slot),
                                 plan.n_segs, _dp(plan.long_row), _dp(plan.long_first), _dp(plan.long_count),
                                 plan.n_long, _dp(plan.indices), _dp(plan.values), _dp(d_X), _dp(d_Y),
-                                _dp(plan.partial), ld, _dp(d_addend), addend_scale, _dp(d_accum), _sh(stream)))
+                                _dp(plan.partial), ld, _dp(d_addend), addend_scale, _dp(d_accum), _dp(d_x_row_mask),
+                                _sh(stream)))
 
 
 def bpr_batch_loss_grad(d_S, div: float, n_users: int, n_rows: int, ld: int, d_u, d_i, d_j, B: int, eps: float,
-                        reg: float, d_dE, d_loss, stream=None):
+                        reg: float, d_dE, d_loss, stream=None, d_row_mask=None):
     _check(load().qrec_bpr_batch_loss_grad(_dp(d_S), div, n_users, n_rows, ld, _dp(d_u), _dp(d_i), _dp(d_j), B,
-                                           eps, reg, _dp(d_dE), _dp(d_loss), _sh(stream)))
+                                           eps, reg, _dp(d_dE), _dp(d_loss), _dp(d_row_mask), _sh(stream)))
 
 
 def adam_step(d_theta, d_m, d_v, d_grad, n_elems: int, grad_scale: float, alpha: float, beta1: float = 0.9,

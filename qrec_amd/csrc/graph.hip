@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void spmm_kernel(
     const int32_t *__restrict__ seg_len, const int32_t *__restrict__ seg_slot, int64_t n_segs,
     const int32_t *__restrict__ indices, const float *__restrict__ values,
     const float *__restrict__ X, float *__restrict__ Y, float *__restrict__ partial,
-    const float *__restrict__ addend, float addend_scale, float *__restrict__ accum) {
+    const float *__restrict__ addend, float addend_scale, float *__restrict__ accum,
+    const uint32_t *__restrict__ x_row_mask) {
 #pragma clang fp contract(off)
     constexpr int GPW = kWave / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
@@ -67,10 +68,32 @@ __global__ __launch_bounds__(256) void spmm_kernel(
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int e0 = 0; e0 < len; e0 += LPR) {
             const int mine = e0 + r;
-            const int my_c = mine < len ? indices[beg + mine] : 0;
+            int my_c = mine < len ? indices[beg + mine] : 0;
             const float my_v = mine < len ? values[beg + mine] : 0.f;
             const int cnt = (len - e0) < LPR ? (len - e0) : LPR;
             int k = 0;
+            if (x_row_mask) {
+                // sparse operand (first backward SpMM: X = the batch gradient, <= 3B non-zero rows): a
+                // clear mask bit means the row is exactly zero; it is not fetched and contributes +0
+                // (bit-identical result, ~90% fewer row gathers)
+                if (mine < len && !((x_row_mask[my_c >> 5] >> (my_c & 31)) & 1u)) my_c = -1;
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                for (; k + 4 <= cnt; k += 4) {
+                    const int c0 = __shfl(my_c, g * LPR + k, kWave), c1 = __shfl(my_c, g * LPR + k + 1, kWave);
+                    const int c2 = __shfl(my_c, g * LPR + k + 2, kWave), c3 = __shfl(my_c, g * LPR + k + 3, kWave);
+                    const float v0 = __shfl(my_v, g * LPR + k, kWave), v1 = __shfl(my_v, g * LPR + k + 1, kWave);
+                    const float v2 = __shfl(my_v, g * LPR + k + 2, kWave), v3 = __shfl(my_v, g * LPR + k + 3, kWave);
+                    const f32x4 x0 = c0 >= 0 ? ld_row4<LPR>(X, c0, r) : zero, x1 = c1 >= 0 ? ld_row4<LPR>(X, c1, r) : zero;
+                    const f32x4 x2 = c2 >= 0 ? ld_row4<LPR>(X, c2, r) : zero, x3 = c3 >= 0 ? ld_row4<LPR>(X, c3, r) : zero;
+                    acc = acc + v0 * x0; acc = acc + v1 * x1; acc = acc + v2 * x2; acc = acc + v3 * x3;
+                }
+                for (; k < cnt; k++) {
+                    const int c = __shfl(my_c, g * LPR + k, kWave);
+                    const float v = __shfl(my_v, g * LPR + k, kWave);
+                    acc = acc + v * (c >= 0 ? ld_row4<LPR>(X, c, r) : zero);
+                }
+                continue;
+            }
             for (; k + 4 <= cnt; k += 4) {
                 const int c0 = __shfl(my_c, g * LPR + k, kWave), c1 = __shfl(my_c, g * LPR + k + 1, kWave);
                 const int c2 = __shfl(my_c, g * LPR + k + 2, kWave), c3 = __shfl(my_c, g * LPR + k + 3, kWave);
@@ -135,7 +158,7 @@ template <int LPR, int E>
 __global__ __launch_bounds__(256) void bpr_batch_kernel(
     const float *__restrict__ S, float div, int n_users, const int32_t *__restrict__ u_idx,
     const int32_t *__restrict__ i_idx, const int32_t *__restrict__ j_idx, int B, float eps, float reg,
-    float *__restrict__ dE, uint32_t de_bytes, double *__restrict__ loss_out) {
+    float *__restrict__ dE, uint32_t de_bytes, double *__restrict__ loss_out, uint32_t *__restrict__ row_mask) {
     constexpr int GPW = kWave / LPR;
     constexpr int LD = LPR * E;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
@@ -158,7 +181,13 @@ __global__ __launch_bounds__(256) void bpr_batch_kernel(
         di = row_allreduce_sum<LPR>(di); dj = row_allreduce_sum<LPR>(dj); sq = row_allreduce_sum<LPR>(sq);
         const float s = 1.0f / (1.0f + expf(-(di - dj)));
         const float gsc = -(s * (1.0f - s)) / (s + eps);
-        if (r == 0) loss += (double)(-logf(s + eps)) + 0.5 * (double)reg * (double)sq;
+        if (r == 0) {
+            loss += (double)(-logf(s + eps)) + 0.5 * (double)reg * (double)sq;
+            if (row_mask) {   // rows of dE that become non-zero (for the sparse-operand SpMM)
+                atomicOr(row_mask + (ru >> 5), 1u << (ru & 31)); atomicOr(row_mask + (ri >> 5), 1u << (ri & 31));
+                atomicOr(row_mask + (rj >> 5), 1u << (rj & 31));
+            }
+        }
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const uint32_t col = (uint32_t)(r + LPR * e) * 4u;
@@ -202,12 +231,12 @@ template <int LPR>
 int launch_spmm(const int32_t *seg_row, const int64_t *seg_beg, const int32_t *seg_len, const int32_t *seg_slot,
                 int64_t n_segs, const int32_t *long_row, const int32_t *long_first, const int32_t *long_count,
                 int n_long, const int32_t *indices, const float *values, const float *X, float *Y, float *partial,
-                const float *addend, float addend_scale, float *accum, hipStream_t st) {
+                const float *addend, float addend_scale, float *accum, const uint32_t *x_row_mask, hipStream_t st) {
     constexpr int GPW = kWave / LPR;
     int64_t blocks = (n_segs + 4 * GPW - 1) / (4 * GPW);
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL((spmm_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, seg_row, seg_beg, seg_len,
-                       seg_slot, n_segs, indices, values, X, Y, partial, addend, addend_scale, accum);
+                       seg_slot, n_segs, indices, values, X, Y, partial, addend, addend_scale, accum, x_row_mask);
     QREC_LAUNCH_CHECK();
     if (n_long > 0) {
         hipLaunchKernelGGL((spmm_fixup_kernel<LPR>), dim3((unsigned)((n_long + 4 * GPW - 1) / (4 * GPW))), dim3(256),
@@ -226,7 +255,7 @@ int qrec_spmm_csr(const int32_t *d_seg_row, const int64_t *d_seg_beg, const int3
                   const int32_t *d_long_first, const int32_t *d_long_count, int32_t n_long,
                   const int32_t *d_indices, const float *d_values, const float *d_X, float *d_Y,
                   float *d_partial, int32_t ld, const float *d_addend, float addend_scale, float *d_accum,
-                  void *stream) {
+                  const uint32_t *d_x_row_mask, void *stream) {
     QREC_REQUIRE(d_seg_row && d_seg_beg && d_seg_len && d_seg_slot && d_indices && d_values && d_X && d_Y,
                  "qrec_spmm_csr: null argument");
     QREC_REQUIRE(n_long == 0 || (d_long_row && d_long_first && d_long_count && d_partial), "qrec_spmm_csr: long-row plan incomplete");
@@ -235,7 +264,7 @@ int qrec_spmm_csr(const int32_t *d_seg_row, const int64_t *d_seg_beg, const int3
     hipStream_t st = as_stream(stream);
 #define QREC_SPMM(LPR) return launch_spmm<LPR>(d_seg_row, d_seg_beg, d_seg_len, d_seg_slot, n_segs, d_long_row, d_long_first, \
                                                d_long_count, n_long, d_indices, d_values, d_X, d_Y, d_partial, d_addend,       \
-                                               addend_scale, d_accum, st)
+                                               addend_scale, d_accum, d_x_row_mask, st)
     switch (ld) {
         case 32: QREC_SPMM(8);
         case 64: QREC_SPMM(16);
@@ -248,7 +277,7 @@ int qrec_spmm_csr(const int32_t *d_seg_row, const int64_t *d_seg_beg, const int3
 
 int qrec_bpr_batch_loss_grad(const float *d_S, float div, int32_t n_users, int64_t n_rows, int32_t ld,
                              const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int32_t B, float eps,
-                             float reg, float *d_dE, double *d_loss, void *stream) {
+                             float reg, float *d_dE, double *d_loss, uint32_t *d_row_mask, void *stream) {
     QREC_REQUIRE(d_S && d_dE && d_loss && B >= 0 && div != 0.f, "qrec_bpr_batch_loss_grad: bad argument");
     QREC_REQUIRE(B == 0 || (d_u && d_i && d_j), "qrec_bpr_batch_loss_grad: null index array");
     QREC_REQUIRE(n_rows * (int64_t)ld * 4 < ((int64_t)1 << 32), "qrec_bpr_batch_loss_grad: table exceeds 4 GiB");
@@ -257,7 +286,7 @@ int qrec_bpr_batch_loss_grad(const float *d_S, float div, int32_t n_users, int64
     const uint32_t bytes = (uint32_t)(n_rows * ld * 4);
 #define QREC_BB(LPR, E)                                                                                          \
     hipLaunchKernelGGL((bpr_batch_kernel<LPR, E>), dim3((unsigned)((B + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), \
-                       dim3(256), 0, st, d_S, div, n_users, d_u, d_i, d_j, B, eps, reg, d_dE, bytes, d_loss)
+                       dim3(256), 0, st, d_S, div, n_users, d_u, d_i, d_j, B, eps, reg, d_dE, bytes, d_loss, d_row_mask)
     switch (ld) {
         case 32: QREC_BB(16, 2); break;
         case 64: QREC_BB(16, 4); break;

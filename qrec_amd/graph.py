@@ -36,7 +36,7 @@ def joint_norm_adjacency(n_users: int, n_items: int, uid: np.ndarray, iid: np.nd
 class SpmmPlan:
     """Device-resident CSR plus its segment decomposition (include/qrec_hip.h, qrec_spmm_csr)."""
 
-    def __init__(self, indptr: np.ndarray, indices: np.ndarray, values: np.ndarray, ld: int, seg_len: int = 256):
+    def __init__(self, indptr: np.ndarray, indices: np.ndarray, values: np.ndarray, ld: int, seg_len: int = 128):
         n_rows = indptr.size - 1
         nnz_row = np.diff(indptr)
         n_seg_row = np.maximum(1, -(-nnz_row // seg_len)).astype(np.int64)     # ceil, >=1 (empty rows write zeros)
@@ -87,6 +87,7 @@ class LightGCNTrainer:
         z = lambda: DeviceBuffer.zeros((self.n, self.ld), np.float32)
         self.m, self.v, self.S, self.dE, self.A, self.B = z(), z(), z(), z(), z(), z()
         self.d_loss = DeviceBuffer.zeros(1, np.float64)
+        self.row_mask = DeviceBuffer.zeros((self.n + 31) // 32, np.uint32)   # non-zero rows of the batch gradient
         self.t = 0
         f = np.float32
         self.b1, self.b2, self.adam_eps = f(0.9), f(0.999), f(1e-8)
@@ -107,7 +108,9 @@ class LightGCNTrainer:
         x = self.dE
         for k in range(self.L):
             y = self.A if k % 2 == 0 else self.B
-            capi.spmm_csr(self.plan, x, y, self.ld, d_addend=self.dE, addend_scale=1.0, stream=stream)
+            # the first operand is the batch gradient itself: <= 3B non-zero rows, the rest is skipped
+            capi.spmm_csr(self.plan, x, y, self.ld, d_addend=self.dE, addend_scale=1.0, stream=stream,
+                          d_x_row_mask=self.row_mask if k == 0 else None)
             x = y
         return x
 
@@ -121,8 +124,9 @@ class LightGCNTrainer:
         self.forward_sum(stream)
         self.dE.fill_bytes(0, stream)
         self.d_loss.fill_bytes(0, stream)
+        self.row_mask.fill_bytes(0, stream)
         capi.bpr_batch_loss_grad(self.S, float(self.L + 1), self.nu, self.n, self.ld, d_u, d_i, d_j, B,
-                                 self.loss_eps, self.reg, self.dE, self.d_loss, stream)
+                                 self.loss_eps, self.reg, self.dE, self.d_loss, stream, d_row_mask=self.row_mask)
         g = self.backward_from_dE(stream)
         capi.adam_step(self.E, self.m, self.v, g, self.n * self.ld, 1.0 / (self.L + 1), self.adam_alpha(),
                        float(self.b1), float(self.b2), float(self.adam_eps), stream)
@@ -212,6 +216,7 @@ class SimGCLTrainer:
         self.m, self.v = z(), z()
         self.Sm, self.S1, self.S2, self.dOut, self.A, self.B = z(), z(), z(), z(), z(), z()
         self.d_loss = DeviceBuffer.zeros(2, np.float64)         # [rec, cl (unscaled)]
+        self.row_mask = DeviceBuffer.zeros((self.n + 31) // 32, np.uint32)   # non-zero rows of dOut (batch rows)
         self.max_unique = max_unique
         self.ws = DeviceBuffer(capi.info_nce_workspace_bytes(max_unique, self.ld), np.uint8)
         f = np.float32
@@ -250,8 +255,10 @@ class SimGCLTrainer:
         self._encode(self.S2, 2, noises, stream)
         self.dOut.fill_bytes(0, stream)
         self.d_loss.fill_bytes(0, stream)
+        self.row_mask.fill_bytes(0, stream)
+        # the InfoNCE rows (unique batch users / positive items) are a subset of the rows marked here
         capi.bpr_batch_loss_grad(self.Sm, L, self.nu, self.n, self.ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
-                                 self.dOut, self.d_loss, stream)
+                                 self.dOut, self.d_loss, stream, d_row_mask=self.row_mask)
         cl = self.d_loss.ptr + 8
         capi.info_nce_loss_grad(self.S1, self.S2, L, d_uniq_users, n_uu, self.ld, self.tau, self.cl_rate, self.ws,
                                 self.dOut, cl, stream)
@@ -261,10 +268,11 @@ class SimGCLTrainer:
         x = self.dOut
         for k in range(self.L - 1):
             y = self.A if k % 2 == 0 else self.B
-            capi.spmm_csr(self.plan, x, y, self.ld, d_addend=self.dOut, addend_scale=1.0, stream=stream)
+            capi.spmm_csr(self.plan, x, y, self.ld, d_addend=self.dOut, addend_scale=1.0, stream=stream,
+                          d_x_row_mask=self.row_mask if k == 0 else None)      # operand = sparse batch gradient
             x = y
         g = self.B if x is self.A else self.A
-        capi.spmm_csr(self.plan, x, g, self.ld, stream=stream)
+        capi.spmm_csr(self.plan, x, g, self.ld, stream=stream, d_x_row_mask=self.row_mask if self.L == 1 else None)
         capi.adam_step(self.E, self.m, self.v, g, self.n * self.ld, 1.0 / L, self.adam_alpha(), float(self.b1),
                        float(self.b2), float(self.adam_eps), stream)
         self.b1p = np.float32(self.b1p * self.b1); self.b2p = np.float32(self.b2p * self.b2)
@@ -338,6 +346,7 @@ class NGCFTrainer:
         self.optE = _Adam(self.E[0], lr)
         self.optW = [[_Adam(w, lr) for w in pair] for pair in self.W]
         self.d_loss = DeviceBuffer.zeros(1, np.float64)
+        self.row_mask = DeviceBuffer.zeros((self.n + 31) // 32, np.uint32)
         self.step_no = 0
 
     def forward(self, training: bool, masks=None, stream=None):
@@ -354,16 +363,19 @@ class NGCFTrainer:
     def train_step_async(self, d_u, d_i, d_j, B: int, masks=None, stream=None):
         n, d, ld = self.n, self.d, self.ld
         self.forward(True, masks, stream)
-        self.dAll.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
+        self.dAll.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream); self.row_mask.fill_bytes(0, stream)
         capi.bpr_batch_loss_grad(self.All, 1.0, self.nu, n, self.wide_ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
-                                 self.dAll, self.d_loss, stream)
+                                 self.dAll, self.d_loss, stream, d_row_mask=self.row_mask)
         dnext = None
         for k in (1, 0):
             dE = self.dEa if k == 1 else self.dEb
             capi.ngcf_layer_bwd(dnext, self.dAll, self.All, self.wide_ld, (k + 1) * d, self.inv[k], self.gate[k], self.E[k],
                                 self.side[k], self.W[k][0], self.W[k][1], n, d, ld, self.dpre, self.dside, dE, self.partial,
                                 self.gW[k][0], self.gW[k][1], stream)
-            capi.spmm_csr(self.plan, self.dside, dE, ld, d_addend=dE, addend_scale=1.0, stream=stream)   # dE += A^T dside
+            # dE += A^T dside.  For the last layer dside is non-zero only on the batch rows (its gradient
+            # comes from the concat block alone), so that SpMM skips the other operand rows.
+            capi.spmm_csr(self.plan, self.dside, dE, ld, d_addend=dE, addend_scale=1.0, stream=stream,
+                          d_x_row_mask=self.row_mask if k == 1 else None)
             dnext = dE
         capi.copy_cols(dnext, ld, self.dAll, self.wide_ld, 0, n, d, True, stream)                    # + ego block of the concat
         self.optE.step(dnext, stream=stream)

@@ -26,10 +26,18 @@ class DeviceRanker:
         self.n_users, self.n_items = U.shape[0], V.shape[0]
         self.dU = DeviceBuffer.from_numpy(np.ascontiguousarray(U))
         self.dV = DeviceBuffer.from_numpy(np.ascontiguousarray(V))
+        self._scratch = self._d_ids = self._d_sc = None
+        self._cap = (0, 0)
         self.rated = None
         if rated is not None:
             self.rated = (DeviceBuffer.from_numpy(rated.indptr.astype(np.int64)),
                           DeviceBuffer.from_numpy(rated.indices.astype(np.int32)))
+
+    def update_tables(self, U: np.ndarray, V: np.ndarray):
+        """New embeddings of the same shape/dtype (per-epoch evaluation): re-upload only."""
+        if U.shape != (self.n_users, self.d) or V.shape != (self.n_items, self.d) or U.dtype != self.dtype or V.dtype != self.dtype:
+            raise ValueError("update_tables: shape/dtype differ from the ranker's")
+        self.dU.upload(np.ascontiguousarray(U)); self.dV.upload(np.ascontiguousarray(V))
 
     def topk(self, user_ids: np.ndarray, N: int):
         """(ids int32 [n, N], scores [n, N]) in the reference's order (descending score,
@@ -44,9 +52,14 @@ class DeviceRanker:
             raise ValueError("user id out of range")
         per_user = capi.score_topk_scratch_bytes(self.code, self.n_items, 64) // 64
         batch = int(max(64, min(n, (_SCRATCH_BUDGET // max(per_user, 1)) // 64 * 64)))
-        scratch = DeviceBuffer(capi.score_topk_scratch_bytes(self.code, self.n_items, min(batch, n)), np.uint8)
-        d_ids = DeviceBuffer((min(batch, n), N), np.int32)
-        d_sc = DeviceBuffer((min(batch, n), N), self.dtype)
+        nb = min(batch, n)
+        if self._cap[0] < nb or self._cap[1] < N:      # the 4-10 GB score block is kept across calls
+            self._scratch = DeviceBuffer(capi.score_topk_scratch_bytes(self.code, self.n_items, nb), np.uint8)
+            self._d_ids = DeviceBuffer((nb, N), np.int32); self._d_sc = DeviceBuffer((nb, N), self.dtype)
+            self._cap = (nb, N)
+        scratch, d_ids, d_sc = self._scratch, self._d_ids, self._d_sc
+        if d_ids.shape[1] != N:                         # smaller N than the cached buffers: use exact-size views
+            d_ids = DeviceBuffer((nb, N), np.int32); d_sc = DeviceBuffer((nb, N), self.dtype)
         for s in range(0, n, batch):
             chunk = user_ids[s:s + batch]
             d_users = DeviceBuffer.from_numpy(chunk)

@@ -363,3 +363,20 @@ def test_ngcf_class_trains_and_evaluates_with_device_dropout():
     m.trainer.forward(True)
     E1 = m.trainer.E[1].numpy()[:, :16]
     assert 0.05 < (E1 == 0).mean() < 0.2
+
+
+def test_spmm_sparse_operand_mask_is_bit_identical():
+    d, adj, A = _graph("small")
+    n = A.shape[0]
+    rng = np.random.default_rng(9)
+    X = np.zeros((n, 64), np.float32)
+    nz = rng.permutation(n)[:n // 12]
+    X[nz] = rng.standard_normal((nz.size, 64)).astype(np.float32)
+    mask = np.zeros((n + 31) // 32, np.uint32)
+    np.bitwise_or.at(mask, nz >> 5, (np.uint32(1) << (nz & 31).astype(np.uint32)))
+    plan = SpmmPlan(adj[0], adj[1], adj[2], 64)
+    dX, dY1, dY2 = DB.from_numpy(X), DB.zeros((n, 64), np.float32), DB.zeros((n, 64), np.float32)
+    capi.spmm_csr(plan, dX, dY1, 64, d_addend=dX, addend_scale=1.0)
+    capi.spmm_csr(plan, dX, dY2, 64, d_addend=dX, addend_scale=1.0, d_x_row_mask=DB.from_numpy(mask))
+    assert np.array_equal(dY1.numpy(), dY2.numpy())
+    assert rel_err(dY1.numpy(), A.dot(X) + X) < TOL
