@@ -86,6 +86,10 @@ int qrec_mt_pairwise_sample_epoch(uint32_t *state625, const int32_t *h_row_user,
                                   const int64_t *h_rated_indptr, const int32_t *h_rated_sorted,
                                   int32_t n_items, int32_t *h_neg_out);
 
+/* random.sample(range(n), k) (model/ranking/SGL.py:118-135: kept edges / dropped nodes of an
+ * augmented sub-graph), same generator, same draws as CPython 3.10. */
+int qrec_mt_sample_range(uint32_t *state625, int64_t n, int64_t k, int64_t *h_out);
+
 /* ---- throughput sampler, device side -------------------------------------------------- *
  * Same distribution as BPR.py:35-37 (uniform over the items that are not positives of
  * the user, by rejection), counter-based Philox4x32-10 keyed by (seed, epoch, triplet
@@ -195,11 +199,13 @@ int qrec_perturb_rows(float *d_emb, int64_t n_rows, int32_t d, int32_t ld, float
  * x1 = S1[rows]/div, x2 = S2[rows]/div (the two perturbed views' rows of the batch's UNIQUE
  * nodes, n <= 16384, ids distinct); z = l2_normalize(x); loss = -sum log(exp(z1.z2/tau) /
  * sum_cols exp(z1 z2^T/tau)).  *d_loss (double) += loss (unscaled); d_out[rows] += cl_rate *
- * (dloss/dx1 + dloss/dx2).  The n x n block runs on the f32 MFMA.                        */
+ * (dloss/dx1 + dloss/dx2), or, when d_out2 is given (SGL: the two views have different backward
+ * operators, model/ranking/SGL.py:192-217), d_out += cl_rate*dloss/dx1 and d_out2 += cl_rate*dloss/dx2.
+ * The n x n block runs on the f32 MFMA.                                                   */
 int qrec_info_nce_workspace_bytes(int32_t n, int32_t ld, int64_t *bytes);
 int qrec_info_nce_loss_grad(const float *d_S1, const float *d_S2, float div, const int32_t *d_rows, int32_t n,
-                            int32_t ld, float tau, float cl_rate, void *d_workspace, float *d_out, double *d_loss,
-                            void *stream);
+                            int32_t ld, float tau, float cl_rate, void *d_workspace, float *d_out, float *d_out2,
+                            double *d_loss, void *stream);
 
 /* ---- NGCF dense layers (model/ranking/NGCF.py:27-42) ------------------------------------ *
  * Tables [rows][ld] fp32, ld in {32,64,128}; weights zero-padded to [ld][ld].             */

@@ -39,6 +39,7 @@ def lib():
         L.orc_randbelow.argtypes = [vp, u32]; L.orc_randbelow.restype = u32
         L.orc_shuffle.argtypes = [vp, vp, i64]
         L.orc_data_split.argtypes = [vp, i64, f64, vp]
+        L.orc_sample_range.argtypes = [vp, i64, i64, vp]
         L.orc_bpr_sample_epoch.argtypes = [vp, vp, vp, i32, i32, vp]
         L.orc_bpr_sample_epoch.restype = i64
         L.orc_pairwise_sample_epoch.argtypes = [vp, vp, i64, vp, vp, i32, vp]
@@ -120,6 +121,12 @@ class MT:
             _chk(perm, np.int64); assert perm.size == n
         lib().orc_shuffle(self.ptr, _p(perm) if perm is not None else None, n)
         return perm
+
+    def sample_range(self, n: int, k: int) -> np.ndarray:
+        """random.sample(range(n), k)"""
+        out = np.empty(k, dtype=np.int64)
+        lib().orc_sample_range(self.ptr, n, k, _p(out))
+        return out
 
     def data_split(self, n: int, ratio: float) -> np.ndarray:
         out = np.zeros(n, dtype=np.uint8)

@@ -161,6 +161,46 @@ void orc_shuffle(orc_mt *s, int64_t *perm, int64_t n) {
     }
 }
 
+/* random.sample(range(n), k) (Lib/random.py, CPython 3.10): used by model/ranking/SGL.py:118-135 to
+ * pick the kept edges / dropped nodes of an augmented sub-graph.
+ *   setsize = 21; if k > 5: setsize += 4 ** ceil(log(k*3, 4))
+ *   if n <= setsize:  pool = list(range(n)); for i in range(k): j = randbelow(n-i); out[i] = pool[j];
+ *                     pool[j] = pool[n-i-1]
+ *   else:             selected = set(); for i in range(k): j = randbelow(n); while j in selected: redraw;
+ *                     add j; out[i] = j                                                               */
+static int64_t sample_setsize(int64_t k) {
+    int64_t setsize = 21;
+    if (k > 5) {
+        /* 4 ** ceil(log(k*3, 4)) with Python's float log: smallest power of 4 >= 3k, computed the same way */
+        double e = ceil(log((double)k * 3.0) / log(4.0));
+        setsize += (int64_t)pow(4.0, e);
+    }
+    return setsize;
+}
+void orc_sample_range(orc_mt *s, int64_t n, int64_t k, int64_t *out) {
+    int64_t i;
+    if (n <= sample_setsize(k)) {
+        int64_t *pool = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+        for (i = 0; i < n; i++) pool[i] = i;
+        for (i = 0; i < k; i++) {
+            uint32_t m = (uint32_t)(n - i);
+            uint32_t j = mt_randbelow(s, m, bit_length_u32(m));
+            out[i] = pool[j];
+            pool[j] = pool[n - i - 1];
+        }
+        free(pool);
+    } else {
+        uint8_t *sel = (uint8_t *)calloc((size_t)n, 1);
+        int kb = bit_length_u32((uint32_t)n);
+        for (i = 0; i < k; i++) {
+            uint32_t j = mt_randbelow(s, (uint32_t)n, kb);
+            while (sel[j]) j = mt_randbelow(s, (uint32_t)n, kb);
+            sel[j] = 1; out[i] = j;
+        }
+        free(sel);
+    }
+}
+
 /* util/dataSplit.py:9-26 DataSplit.dataSplit: one random() per row; row goes to the
  * test set iff random() < test_ratio.  (binarized rows have rating 1 -> kept.) */
 void orc_data_split(orc_mt *s, int64_t n, double test_ratio, uint8_t *is_test) {

@@ -337,3 +337,62 @@ class NGCF:
         """the 3d-wide tables the reference scores with at test time (isTraining = 0, NGCF.py:65-69)"""
         allE, _ = self.forward(None)
         return allE[:self.nu], allE[self.nu:]
+
+
+# ======================================================================================
+# SGL  (model/ranking/SGL.py:10-293)
+# ======================================================================================
+class SGL:
+    """Three LightGCN views (mean over [E0..EL], ego layer included): the recommendation view on the full
+    adjacency and two views on per-epoch augmented sub-graphs (``mats1[k]``, ``mats2[k]`` = the matrix of
+    layer k; the same matrix for every k with node/edge dropout, a fresh one per layer with random walk).
+    BPR loss on the main view, InfoNCE (calc_ssl_loss_v3: users and items of the batch merged into ONE
+    contrast set, temperature -temp) between the two sub-graph views, weighted by -lambda; Adam."""
+
+    def __init__(self, U0, V0, adj: sp.csr_matrix, n_layers, lr, reg, ssl_reg, temp):
+        self.nu, self.ni = U0.shape[0], V0.shape[0]
+        self.E = np.concatenate([U0, V0]).astype(np.float32)
+        self.adj = adj.astype(np.float32).tocsr()
+        self.L, self.reg, self.ssl_reg, self.temp = n_layers, reg, np.float32(ssl_reg), np.float32(temp)
+        self.opt = AdamTF114(self.E.shape, lr)
+
+    def view(self, mats):
+        layers = [self.E]
+        for k in range(self.L):
+            layers.append(mats[k].dot(layers[-1]).astype(np.float32))
+        acc = layers[0].copy()
+        for x in layers[1:]:
+            acc += x
+        return (acc / np.float32(self.L + 1)).astype(np.float32)
+
+    def _view_backward(self, mats, d_out):
+        c = d_out / np.float32(self.L + 1)
+        G = c.copy()
+        for k in range(self.L - 1, -1, -1):          # E_{k+1} = M_k E_k  =>  dE_k = c + M_k^T dE_{k+1}
+            G = (c + mats[k].T.dot(G)).astype(np.float32)
+        return G
+
+    def loss_and_grad(self, u_idx, i_idx, j_idx, mats1, mats2):
+        nu = self.nu
+        main_mats = [self.adj] * self.L
+        main, s1, s2 = self.view(main_mats), self.view(mats1), self.view(mats2)
+        ui, ii, ji = np.asarray(u_idx), np.asarray(i_idx) + nu, np.asarray(j_idx) + nu
+        rec, du, di, dj = bpr_batch_loss_and_grads(main[ui], main[ii], main[ji], self.reg)
+        d_main = np.zeros_like(main)
+        np.add.at(d_main, ui, du); np.add.at(d_main, ii, di); np.add.at(d_main, ji, dj)
+        rows = np.concatenate([unique_first_appearance(u_idx), unique_first_appearance(i_idx) + nu])
+        l, d1, d2 = info_nce_loss_and_grads(s1[rows], s2[rows], tau=self.temp)
+        d_s1 = np.zeros_like(main); d_s2 = np.zeros_like(main)
+        d_s1[rows] = self.ssl_reg * d1; d_s2[rows] = self.ssl_reg * d2
+        g = self._view_backward(main_mats, d_main) + self._view_backward(mats1, d_s1) + self._view_backward(mats2, d_s2)
+        ssl = float(self.ssl_reg) * l
+        return rec + ssl, rec, ssl, g.astype(np.float32)
+
+    def train_step(self, u_idx, i_idx, j_idx, mats1, mats2):
+        loss, rec, ssl, g = self.loss_and_grad(u_idx, i_idx, j_idx, mats1, mats2)
+        self.opt.step(self.E, g)
+        return loss, rec, ssl
+
+    def final_embeddings(self):
+        m = self.view([self.adj] * self.L)
+        return m[:self.nu], m[self.nu:]

@@ -50,20 +50,21 @@ class DeepRecommender(IterativeRecommender):
         random.setstate(capi.state_to_python(words, state[2]))
         return u, i, j
 
-    def iter_epoch_samples(self, n_epochs: int):
-        """Yield ``sample_epoch_pairwise()`` for epochs 0..n_epochs-1, computing epoch k+1 on a worker
-        thread while the caller trains on epoch k.  The draw sequence does not depend on the model, so
-        running it ahead leaves the CPython stream exactly where the reference's would be; nothing is
-        drawn beyond the last epoch."""
+    def iter_epoch_samples(self, n_epochs: int, draw=None):
+        """Yield ``draw()`` (default ``sample_epoch_pairwise``) for epochs 0..n_epochs-1, computing epoch
+        k+1 on a worker thread while the caller trains on epoch k.  The draw sequence does not depend on
+        the model, so running it ahead leaves the CPython stream exactly where the reference's would be;
+        nothing is drawn beyond the last epoch."""
         from concurrent.futures import ThreadPoolExecutor
+        draw = draw or self.sample_epoch_pairwise
         if n_epochs <= 0:
             return
         with ThreadPoolExecutor(max_workers=1) as pool:
-            pending = pool.submit(self.sample_epoch_pairwise)
+            pending = pool.submit(draw)
             for epoch in range(n_epochs):
                 sample = pending.result()
                 if epoch + 1 < n_epochs:
-                    pending = pool.submit(self.sample_epoch_pairwise)
+                    pending = pool.submit(draw)
                 yield sample
 
     def next_batch_pairwise(self):

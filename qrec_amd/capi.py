@@ -44,6 +44,7 @@ _SIGNATURES = {
     "qrec_event_elapsed_ms": [_vp, _vp, _vp],
     "qrec_mt_bpr_sample_epoch": [_vp, _vp, _vp, _i32, _i32, _vp],
     "qrec_mt_shuffle": [_vp, _i64, _vp],
+    "qrec_mt_sample_range": [_vp, _i64, _i64, _vp],
     "qrec_mt_pairwise_sample_epoch": [_vp, _vp, _i64, _vp, _vp, _i32, _vp],
     "qrec_philox_bpr_sample": [_vp, _vp, _vp, _i64, _i32, _u64, _u64, _vp, _vp],
     "qrec_bpr_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _vp, _vp],
@@ -56,7 +57,7 @@ _SIGNATURES = {
     "qrec_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
     "qrec_perturb_rows": [_vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp],
     "qrec_info_nce_workspace_bytes": [_i32, _i32, _vp],
-    "qrec_info_nce_loss_grad": [_vp, _vp, _f32, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
+    "qrec_info_nce_loss_grad": [_vp, _vp, _f32, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "qrec_ngcf_dense_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
     "qrec_ngcf_activate": [_vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _i32, _i32, _vp, _vp],
     "qrec_ngcf_layer_bwd": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -397,9 +398,9 @@ def info_nce_workspace_bytes(n: int, ld: int) -> int:
 
 
 def info_nce_loss_grad(d_S1, d_S2, div: float, d_rows, n: int, ld: int, tau: float, cl_rate: float, d_workspace,
-                       d_out, d_loss, stream=None):
+                       d_out, d_loss, stream=None, d_out2=None):
     _check(load().qrec_info_nce_loss_grad(_dp(d_S1), _dp(d_S2), div, _dp(d_rows), n, ld, tau, cl_rate,
-                                          _dp(d_workspace), _dp(d_out), _dp(d_loss), _sh(stream)))
+                                          _dp(d_workspace), _dp(d_out), _dp(d_out2), _dp(d_loss), _sh(stream)))
 
 
 def ngcf_dense_fwd(d_E, d_side, d_W1, d_W2, n_rows: int, ld: int, d_pre, stream=None):
@@ -437,3 +438,11 @@ def bpr_sgd_hogwild_item_major(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int,
                                flush_every: int, lr: float, regU: float, regI: float, d_loss, stream=None):
     _check(load().qrec_bpr_sgd_hogwild_item_major(_dp(d_P), _dp(d_Q), d, ld, _dp(d_u), _dp(d_i), _dp(d_j), n, chunk,
                                                   grid_groups, flush_every, lr, regU, regI, _dp(d_loss), _sh(stream)))
+
+
+def mt_sample_range(state625: np.ndarray, n: int, k: int) -> np.ndarray:
+    """random.sample(range(n), k) with the exact CPython draw sequence"""
+    _req(state625, np.uint32, "state625")
+    out = np.empty(k, dtype=np.int64)
+    _check(load().qrec_mt_sample_range(_hp(state625), n, k, _hp(out)))
+    return out

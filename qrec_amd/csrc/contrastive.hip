@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float *__restr
                                                             const float *__restrict__ dz1, const float *__restrict__ dz2,
                                                             const float *__restrict__ r1, const float *__restrict__ r2,
                                                             const int32_t *__restrict__ rows, int n, int64_t part_stride,
-                                                            float scale, float *__restrict__ d_out) {
+                                                            float scale, float *__restrict__ d_out, float *__restrict__ d_out2) {
     constexpr int GPW = kWave / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
     const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
@@ -214,13 +214,19 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float *__restr
     pa = row_allreduce_sum<LPR>(pa); pb = row_allreduce_sum<LPR>(pb);
     const f32x4 dxa = (da - a * pa) * r1[k], dxb = (db - b * pb) * r2[k];
     f32x4 o = *reinterpret_cast<const f32x4 *>(d_out + dst);     // rows[] are distinct: plain read-modify-write
-    o = o + scale * dxa + scale * dxb;
+    if (d_out2) {   // the two views back-propagate through different operators (SGL): separate accumulators
+        f32x4 o2 = *reinterpret_cast<const f32x4 *>(d_out2 + dst);
+        o = o + scale * dxa; o2 = o2 + scale * dxb;
+        *reinterpret_cast<f32x4 *>(d_out2 + dst) = o2;
+    } else {
+        o = o + scale * dxa + scale * dxb;
+    }
     *reinterpret_cast<f32x4 *>(d_out + dst) = o;
 }
 
 template <int LPR>
 int run_info_nce(const float *S1, const float *S2, float div, const int32_t *rows, int n, int ld, float tau,
-                 float cl_rate, float *ws, float *d_out, double *loss, hipStream_t st) {
+                 float cl_rate, float *ws, float *d_out, float *d_out2, double *loss, hipStream_t st) {
     constexpr int GPW = kWave / LPR;
     const int n_pad = (n + 63) / 64 * 64;
     const int64_t tab = (int64_t)n_pad * ld;
@@ -242,7 +248,7 @@ int run_info_nce(const float *S1, const float *S2, float div, const int32_t *row
     QREC_LAUNCH_CHECK();
     hipLaunchKernelGGL((grad_z_kernel<1>), gg, dim3(256), 0, st, ExT, inv_ttl, z1, n, n_pad, ld, inv_tau, dz2);
     QREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL((normalize_bwd_kernel<LPR>), dim3(row_blocks), dim3(256), 0, st, z1, z2, dz1, dz2, r1, r2, rows, n, tab, cl_rate, d_out);
+    hipLaunchKernelGGL((normalize_bwd_kernel<LPR>), dim3(row_blocks), dim3(256), 0, st, z1, z2, dz1, dz2, r1, r2, rows, n, tab, cl_rate, d_out, d_out2);
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }
@@ -281,8 +287,8 @@ int qrec_info_nce_workspace_bytes(int32_t n, int32_t ld, int64_t *bytes) {
 }
 
 int qrec_info_nce_loss_grad(const float *d_S1, const float *d_S2, float div, const int32_t *d_rows, int32_t n,
-                            int32_t ld, float tau, float cl_rate, void *d_workspace, float *d_out, double *d_loss,
-                            void *stream) {
+                            int32_t ld, float tau, float cl_rate, void *d_workspace, float *d_out, float *d_out2,
+                            double *d_loss, void *stream) {
     QREC_REQUIRE(d_S1 && d_S2 && d_workspace && d_out && d_loss && n >= 0 && div != 0.f && tau > 0.f,
                  "qrec_info_nce_loss_grad: bad argument");
     QREC_REQUIRE(n == 0 || d_rows, "qrec_info_nce_loss_grad: null row list");
@@ -291,10 +297,10 @@ int qrec_info_nce_loss_grad(const float *d_S1, const float *d_S2, float div, con
     hipStream_t st = as_stream(stream);
     float *ws = static_cast<float *>(d_workspace);
     switch (ld) {
-        case 32: return run_info_nce<8>(d_S1, d_S2, div, d_rows, n, ld, tau, cl_rate, ws, d_out, d_loss, st);
-        case 64: return run_info_nce<16>(d_S1, d_S2, div, d_rows, n, ld, tau, cl_rate, ws, d_out, d_loss, st);
-        case 128: return run_info_nce<32>(d_S1, d_S2, div, d_rows, n, ld, tau, cl_rate, ws, d_out, d_loss, st);
-        case 256: return run_info_nce<64>(d_S1, d_S2, div, d_rows, n, ld, tau, cl_rate, ws, d_out, d_loss, st);
+        case 32: return run_info_nce<8>(d_S1, d_S2, div, d_rows, n, ld, tau, cl_rate, ws, d_out, d_out2, d_loss, st);
+        case 64: return run_info_nce<16>(d_S1, d_S2, div, d_rows, n, ld, tau, cl_rate, ws, d_out, d_out2, d_loss, st);
+        case 128: return run_info_nce<32>(d_S1, d_S2, div, d_rows, n, ld, tau, cl_rate, ws, d_out, d_out2, d_loss, st);
+        case 256: return run_info_nce<64>(d_S1, d_S2, div, d_rows, n, ld, tau, cl_rate, ws, d_out, d_out2, d_loss, st);
         default: set_error("qrec_info_nce_loss_grad: row stride must be 32, 64, 128 or 256 floats (got %d)", ld); return QREC_ERR_INVALID;
     }
 }

@@ -33,6 +33,30 @@ def joint_norm_adjacency(n_users: int, n_items: int, uid: np.ndarray, iid: np.nd
     return indptr, c, vals.astype(np.float32)
 
 
+def sample_subgraph_edges(state625: np.ndarray, uid: np.ndarray, iid: np.ndarray, n_users: int, n_items: int,
+                          aug_type: int, drop_rate: float):
+    """The kept edges of one augmented sub-graph, drawn like model/ranking/SGL.py:118-135 from the CPython
+    generator (``state625`` is advanced in place):
+      aug_type 0 (node dropout): random.sample of int(U*rate) users, then of int(I*rate) items; an edge
+                 survives iff both end points do;
+      aug_type 1 / 2 (edge dropout / random walk): random.sample of int(E*(1-rate)) edge positions of the
+                 CURRENT trainingData order.
+    Returns (uid_kept, iid_kept); duplicates stay in (they add up in the adjacency, as in the reference)."""
+    if drop_rate <= 0:
+        return uid, iid
+    if aug_type == 0:
+        drop_u = capi.mt_sample_range(state625, n_users, int(n_users * drop_rate))
+        drop_i = capi.mt_sample_range(state625, n_items, int(n_items * drop_rate))
+        keep_u = np.ones(n_users, bool); keep_u[drop_u] = False
+        keep_i = np.ones(n_items, bool); keep_i[drop_i] = False
+        keep = keep_u[uid] & keep_i[iid]
+        return uid[keep], iid[keep]
+    if aug_type in (1, 2):
+        keep_idx = capi.mt_sample_range(state625, uid.size, int(uid.size * (1 - drop_rate)))
+        return uid[keep_idx], iid[keep_idx]
+    raise ValueError("aug_type must be 0 (node dropout), 1 (edge dropout) or 2 (random walk)")
+
+
 class SpmmPlan:
     """Device-resident CSR plus its segment decomposition (include/qrec_hip.h, qrec_spmm_csr)."""
 
@@ -396,3 +420,100 @@ class NGCFTrainer:
     def parameters(self):
         E = self.E[0].numpy()[:, :self.d]
         return E[:self.nu].copy(), E[self.nu:].copy(), [[w.numpy()[:self.d, :self.d].copy() for w in pair] for pair in self.W]
+
+
+class SGLTrainer:
+    """model/ranking/SGL.py on the device: the recommendation view (LightGCN over the full adjacency) plus
+    two views over per-epoch augmented sub-graphs, BPR on the main view, InfoNCE (users and items of the
+    batch merged into one contrast set, SGL.py:192-217) between the sub-graph views, Adam.
+    ``set_subgraphs`` installs the epoch's sub-adjacencies: one CSR per view (node / edge dropout) or one
+    per view and layer (random walk)."""
+
+    def __init__(self, U0, V0, adj, n_layers: int, lr: float, reg: float, ssl_reg: float, temp: float,
+                 loss_eps: float = 1e-7, max_unique: int = 8192):
+        self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
+        self.n = self.nu + self.ni
+        self.ld = padded_ld(self.d, np.float32)
+        self.L, self.reg, self.ssl_reg, self.temp, self.loss_eps = n_layers, reg, ssl_reg, temp, loss_eps
+        self.main_plan = SpmmPlan(adj[0], adj[1], adj[2], self.ld)
+        self.plans = [None, None]                 # per view: list of L plans
+        E0 = np.zeros((self.n, self.ld), np.float32)
+        E0[:self.nu, :self.d] = U0; E0[self.nu:, :self.d] = V0
+        self.E = DeviceBuffer.from_numpy(E0)
+        z = lambda: DeviceBuffer.zeros((self.n, self.ld), np.float32)
+        self.S = [z(), z(), z()]                  # layer sums of main, view 1, view 2
+        self.dOut = [z(), z(), z()]
+        self.G, self.A, self.B = z(), z(), z()
+        self.opt = _Adam(self.E, lr)
+        self.d_loss = DeviceBuffer.zeros(2, np.float64)     # [rec, ssl (unscaled)]
+        self.row_mask = DeviceBuffer.zeros((self.n + 31) // 32, np.uint32)
+        self.max_unique = max_unique
+        self.ws = DeviceBuffer(capi.info_nce_workspace_bytes(max_unique, self.ld), np.uint8)
+
+    def set_subgraphs(self, adjs1, adjs2):
+        """adjs*: one (indptr, indices, values) triple, or a list of L of them (random walk)."""
+        def plans(adjs):
+            if isinstance(adjs, tuple):
+                p = SpmmPlan(adjs[0], adjs[1], adjs[2], self.ld)
+                return [p] * self.L
+            assert len(adjs) == self.L
+            return [SpmmPlan(a[0], a[1], a[2], self.ld) for a in adjs]
+        self.plans = [plans(adjs1), plans(adjs2)]
+
+    def _view_plans(self, v):
+        return [self.main_plan] * self.L if v == 0 else self.plans[v - 1]
+
+    def _forward(self, v, stream=None):
+        S = self.S[v]
+        S.copy_from(self.E, stream)
+        x = self.E
+        for k, plan in enumerate(self._view_plans(v)):
+            y = self.A if k % 2 == 0 else self.B
+            capi.spmm_csr(plan, x, y, self.ld, d_accum=S, stream=stream)
+            x = y
+
+    def _backward(self, v, stream=None):
+        """G += sum_k (prod of the view's matrices)^T applied to dOut[v]  (times 1/(L+1) in Adam)."""
+        d = self.dOut[v]
+        plans = self._view_plans(v)
+        if self.L == 0:
+            raise ValueError("SGL needs at least one layer")
+        x = d
+        for step, k in enumerate(range(self.L - 1, -1, -1)):      # dE_k = dOut + M_k^T dE_{k+1}; matrices are symmetric
+            last = (k == 0)
+            y = self.A if step % 2 == 0 else self.B
+            capi.spmm_csr(plans[k], x, y, self.ld, d_addend=d, addend_scale=1.0, d_accum=self.G if last else None,
+                          stream=stream, d_x_row_mask=self.row_mask if step == 0 else None)
+            x = y
+
+    def train_step_async(self, d_u, d_i, d_j, B: int, d_rows, n_rows: int, stream=None):
+        """d_rows: the batch's unique users followed by its unique positive items (+n_users), distinct."""
+        if self.plans[0] is None:
+            raise RuntimeError("set_subgraphs() first")
+        if n_rows > self.max_unique:
+            raise ValueError("more unique rows in the batch than the InfoNCE workspace holds")
+        div = float(self.L + 1)
+        for v in range(3):
+            self._forward(v, stream)
+            self.dOut[v].fill_bytes(0, stream)
+        self.G.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream); self.row_mask.fill_bytes(0, stream)
+        capi.bpr_batch_loss_grad(self.S[0], div, self.nu, self.n, self.ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
+                                 self.dOut[0], self.d_loss, stream, d_row_mask=self.row_mask)
+        capi.info_nce_loss_grad(self.S[1], self.S[2], div, d_rows, n_rows, self.ld, self.temp, self.ssl_reg, self.ws,
+                                self.dOut[1], self.d_loss.ptr + 8, stream, d_out2=self.dOut[2])
+        for v in range(3):
+            self._backward(v, stream)
+        self.opt.step(self.G, grad_scale=1.0 / div, stream=stream)
+
+    def losses(self, stream=None):
+        rec, ssl = self.d_loss.numpy(stream)
+        return float(rec + self.ssl_reg * ssl), float(rec), float(self.ssl_reg * ssl)
+
+    def main_embeddings(self):
+        self._forward(0)
+        m = (self.S[0].numpy()[:, :self.d] / np.float32(self.L + 1)).astype(np.float32)
+        return np.ascontiguousarray(m[:self.nu]), np.ascontiguousarray(m[self.nu:])
+
+    def ego_embeddings(self):
+        E = self.E.numpy()
+        return E[:self.nu, :self.d].copy(), E[self.nu:, :self.d].copy()

@@ -279,13 +279,54 @@ def case_pairwise_and_adj(tmp):
                 adj_dtype=str(adj.dtype), adj_nnz=int(adj.nnz))
 
 
+def case_sgl_subgraph(tmp):
+    """model/ranking/SGL.py:113-155 _create_adj_mat(is_subgraph=True): node dropout (aug 0) and edge
+    dropout (aug 1) sub-adjacencies, drawn with random.sample from the seeded CPython generator."""
+    from QRec import QRec
+    from util.config import ModelConf
+    from model.ranking.SGL import SGL
+    conf = os.path.join(tmp, "sgl.conf")
+    write_conf(conf, ratings="./dataset/FilmTrust/trainset.txt", ratings__setup="-columns 0 1 2",
+               model__name="SGL", evaluation__setup="-testSet ./dataset/FilmTrust/testset.txt -b 1",
+               item__ranking="on -topN 20", num__factors="8", num__max__epoch="1", batch_size="2048",
+               learnRate="-init 0.001 -max 1", SGL="-n_layer 2 -lambda 0.1 -droprate 0.1 -augtype 1 -temp 0.2",
+               reg__lambda="-u 0.001 -i 0.001 -b 0.2 -s 0.2", output__setup="off -dir ./results/")
+    random.seed(11); np.random.seed(11)
+    with redirect_stdout(io.StringIO()):
+        q = QRec(ModelConf(conf))
+        m = SGL(q.config, q.trainingData, q.testData)
+        m.readConfiguration()
+    arrays = dict(train_uid=np.array([m.data.user[r[0]] for r in m.data.trainingData], dtype=np.int32),
+                  train_iid=np.array([m.data.item[r[1]] for r in m.data.trainingData], dtype=np.int32))
+    for tag, aug in (("node", 0), ("edge", 1), ("edge2", 1)):
+        arrays[f"state_before_{tag}"] = np.array(random.getstate()[1], dtype=np.uint32)
+        A = m._create_adj_mat(is_subgraph=True, aug_type=aug).tocsr(); A.sort_indices()
+        arrays[f"{tag}_indptr"] = A.indptr.astype(np.int64); arrays[f"{tag}_indices"] = A.indices.astype(np.int32)
+        arrays[f"{tag}_data"] = A.data.astype(np.float32)
+    arrays["state_after"] = np.array(random.getstate()[1], dtype=np.uint32)
+    np.savez_compressed(os.path.join(OUT, "sgl_subgraph_filmtrust.npz"), **arrays)
+    return dict(name="sgl_subgraph_filmtrust", seed=11, conf=open(conf).read(), n_users=len(m.data.user),
+                n_items=len(m.data.item), n_train=len(m.data.trainingData), drop_rate=m.drop_rate)
+
+
 def main():
     install_stubs()
     tmp = tempfile.mkdtemp(prefix="qrec_golden_")
     os.symlink(os.path.join(REF, "dataset"), os.path.join(tmp, "dataset"))
     os.chdir(tmp)
-    metas = [case_bpr_filmtrust(tmp), case_bpr_lastfm(tmp), case_basicmf(tmp),
-             case_pairwise_and_adj(tmp)]
+    only = sys.argv[1:]
+    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pairwise_and_adj, case_sgl_subgraph]
+    if only:   # regenerate a subset, keep the other entries of golden_meta.json
+        cases = [c for c in cases if c.__name__ in only]
+        old = json.load(open(os.path.join(OUT, "golden_meta.json")))
+        metas = [c(tmp) for c in cases]
+        old.update({m["name"]: m for m in metas})
+        with open(os.path.join(OUT, "golden_meta.json"), "w") as f:
+            json.dump(old, f, indent=1, sort_keys=True)
+        for m in metas:
+            print(m["name"], "ok")
+        return
+    metas = [c(tmp) for c in cases]
     with open(os.path.join(OUT, "golden_meta.json"), "w") as f:
         json.dump({m["name"]: m for m in metas}, f, indent=1, sort_keys=True)
     for m in metas:

@@ -380,3 +380,85 @@ def test_spmm_sparse_operand_mask_is_bit_identical():
     capi.spmm_csr(plan, dX, dY2, 64, d_addend=dX, addend_scale=1.0, d_x_row_mask=DB.from_numpy(mask))
     assert np.array_equal(dY1.numpy(), dY2.numpy())
     assert rel_err(dY1.numpy(), A.dot(X) + X) < TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# SGL
+# ---------------------------------------------------------------------------------------------
+from qrec_amd.graph import SGLTrainer  # noqa: E402
+
+
+@pytest.mark.parametrize("per_layer", [False, True])
+def test_sgl_training_steps_match_restatement(per_layer):
+    d, adj, A = _graph("small")
+    nu, ni, dim, B, L = d["n_users"], d["n_items"], 64, 1024, 2
+    rng = np.random.default_rng(31)
+    E_n = d["train_u"].size
+    def sub():
+        keep = rng.permutation(E_n)[:int(E_n * 0.9)]
+        a = joint_norm_adjacency(nu, ni, d["train_u"][keep], d["train_i"][keep])
+        return a, sp.csr_matrix((a[2], a[1], a[0]), shape=(nu + ni,) * 2)
+    s1 = [sub() for _ in range(L)] if per_layer else [sub()] * L
+    s2 = [sub() for _ in range(L)] if per_layer else [sub()] * L
+    U0 = (rng.standard_normal((nu, dim)) * 0.01).astype(np.float32); V0 = (rng.standard_normal((ni, dim)) * 0.01).astype(np.float32)
+    ref = T.SGL(U0, V0, A, L, lr=0.001, reg=1e-3, ssl_reg=0.1, temp=0.2)
+    tr = SGLTrainer(U0, V0, adj, L, lr=0.001, reg=1e-3, ssl_reg=0.1, temp=0.2, max_unique=2 * B)
+    tr.set_subgraphs([x[0] for x in s1] if per_layer else s1[0][0], [x[0] for x in s2] if per_layer else s2[0][0])
+    for step in range(5):
+        sel = rng.integers(0, E_n, B)
+        u = d["train_u"][sel].astype(np.int32); i = d["train_i"][sel].astype(np.int32); j = rng.integers(0, ni, B).astype(np.int32)
+        lref, rec_ref, ssl_ref = ref.train_step(u, i, j, [x[1] for x in s1], [x[1] for x in s2])
+        rows = np.concatenate([unique_first_appearance(u), unique_first_appearance(i) + nu]).astype(np.int32)
+        tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, DB.from_numpy(rows), rows.size)
+        tot, rec, ssl = tr.losses()
+        assert abs(rec - rec_ref) / abs(rec_ref) < 2e-5 and abs(ssl - ssl_ref) / abs(ssl_ref) < 2e-5
+    Ug, Vg = tr.ego_embeddings(); E0 = np.concatenate([U0, V0])
+    assert rel_err(np.concatenate([Ug, Vg]) - E0, ref.E - E0) < 2e-3
+    assert rel_err(np.concatenate([Ug, Vg]), ref.E) < 5e-5
+    Um, Vm = tr.main_embeddings(); Ur, Vr = ref.final_embeddings()
+    assert rel_err(Um, Ur) < 1e-4 and rel_err(Vm, Vr) < 1e-4
+
+
+@pytest.mark.parametrize("aug", [1, 0, 2])
+def test_sgl_class_runs_and_stays_in_lock_step_with_the_generator(aug):
+    """Drop-in SGL with config/SGL.conf's keys: per-epoch sub-graphs drawn from the CPython stream, then
+    the batch stream -- the generator must end exactly where a pure-Python replay of the same draws ends."""
+    from qrec_amd.model.ranking.SGL import SGL
+    meta, z = load_golden("bpr_filmtrust")
+    train, test = rows_from_golden(z)
+    conf = conf_from_text(meta["conf"])
+    conf["model.name"] = "SGL"; conf["SGL"] = f"-n_layer 2 -lambda 0.1 -droprate 0.1 -augtype {aug} -temp 0.2"
+    conf["num.factors"] = "16"; conf["num.max.epoch"] = "2"; conf["batch_size"] = "2048"; conf["learnRate"] = "-init 0.001 -max 1"
+    conf["reg.lambda"] = "-u 0.001 -i 0.001 -b 0.2 -s 0.2"; conf["item.ranking"] = "on -topN 20"
+    random.seed(6); np.random.seed(6)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        m = SGL(conf, train, test); measure = m.execute()
+    out = buf.getvalue()
+    rec = [float(l.split("rec_loss:")[1].split()[0]) for l in out.splitlines() if "rec_loss:" in l]
+    assert len(rec) == 2 * 16 and np.isfinite(rec).all() and rec[-1] < rec[0]
+    assert out.count("Quick Ranking Performance") == 2 and any(x.startswith("Recall") for x in measure)
+    # pure-Python replay of the same random consumption (SGL.py:233-251 + deepRecommender.py:29-52)
+    U, I, E = meta["n_users"], meta["n_items"], meta["n_train"]
+    random.seed(6)
+    rows = list(range(E)); item_of = z["train_iid"].tolist(); user_of = z["train_uid"].tolist()
+    rated = {}
+    for uu, ii in zip(user_of, item_of):
+        rated.setdefault(uu, set()).add(ii)
+    for ep in range(2):
+        n_sub = 2 if aug in (0, 1) else 4
+        for _ in range(n_sub):
+            if aug == 0:
+                random.sample(list(range(U)), int(U * 0.1)); random.sample(list(range(I)), int(I * 0.1))
+            else:
+                random.sample(list(range(E)), int(E * 0.9))
+        random.shuffle(rows)
+        for r in rows:
+            neg = random.choice(range(I))
+            while neg in rated[user_of[r]]:
+                neg = random.choice(range(I))
+    want = capi.state_from_python(random.getstate())
+    random.seed(6); np.random.seed(6)
+    with redirect_stdout(io.StringIO()):
+        m2 = SGL(conf, train, test); m2.execute()
+    assert np.array_equal(capi.state_from_python(random.getstate()), want)

@@ -201,3 +201,26 @@ def test_product_adjacency_builder_matches_reference_scipy_output_bitwise():
     ip, ix, vals = joint_norm_adjacency(3, 3, np.array([0, 0, 2]), np.array([1, 1, 0]))
     assert ip.tolist() == [0, 1, 1, 2, 3, 4, 4] and np.isfinite(vals).all()
     assert vals[0] == np.float32(np.float32(np.float32(2) ** np.float32(-0.5) * np.float32(2)) * np.float32(2) ** np.float32(-0.5))
+
+
+def test_sgl_subgraphs_match_reference_bitwise():
+    """model/ranking/SGL.py:113-155: the product's random.sample replay + sub-adjacency builder vs the
+    reference's own output (node dropout, edge dropout twice), generator state included."""
+    from qrec_amd.graph import joint_norm_adjacency, sample_subgraph_edges
+    meta, z = load_golden("sgl_subgraph_filmtrust")
+    U, I = meta["n_users"], meta["n_items"]
+    uid, iid = z["train_uid"], z["train_iid"]
+    st = z["state_before_node"].copy()
+    for tag, aug in (("node", 0), ("edge", 1), ("edge2", 1)):
+        assert np.array_equal(st, z[f"state_before_{tag}"])
+        ku, ki = sample_subgraph_edges(st, uid, iid, U, I, aug, meta["drop_rate"])
+        indptr, indices, values = joint_norm_adjacency(U, I, ku, ki)
+        assert np.array_equal(indptr, z[f"{tag}_indptr"]) and np.array_equal(indices, z[f"{tag}_indices"])
+        assert np.array_equal(values, z[f"{tag}_data"])
+    assert np.array_equal(st, z["state_after"])
+    # oracle restatement of random.sample on the same stream
+    m = O.MT.from_python_state((3, tuple(int(x) for x in z["state_before_edge"]), None))
+    st2 = z["state_before_edge"].copy()
+    k = int(uid.size * (1 - meta["drop_rate"]))
+    assert np.array_equal(m.sample_range(uid.size, k), capi.mt_sample_range(st2, uid.size, k))
+    assert np.array_equal(m.words625(), st2)

@@ -173,3 +173,38 @@ def test_ngcf_gradients_match_autograd():
         last = m.train_step(u, i, j, masks)
     assert last < first
     Uf, Vf = m.inference_embeddings(); assert Uf.shape == (nu, 3 * d) and Vf.shape == (ni, 3 * d)
+
+
+@pytest.mark.parametrize("per_layer", [False, True])
+def test_sgl_gradient_matches_autograd(per_layer):
+    rng = np.random.default_rng(77)
+    nu, ni, d, B, L = 40, 30, 8, 48, 2
+    uid = rng.integers(0, nu, 400); iid = rng.integers(0, ni, 400)
+    adj = T.joint_norm_adjacency(nu, ni, uid, iid)
+    def sub():
+        keep = rng.permutation(400)[:360]
+        return T.joint_norm_adjacency(nu, ni, uid[keep], iid[keep])
+    mats1 = [sub() for _ in range(L)] if per_layer else [sub()] * L
+    mats2 = [sub() for _ in range(L)] if per_layer else [sub()] * L
+    U0 = rng.standard_normal((nu, d)).astype(np.float32) * 0.1; V0 = rng.standard_normal((ni, d)).astype(np.float32) * 0.1
+    u = rng.integers(0, nu, B); i = rng.integers(0, ni, B); j = rng.integers(0, ni, B)
+    m = T.SGL(U0, V0, adj, L, lr=0.001, reg=1e-3, ssl_reg=0.1, temp=0.2)
+    loss, rec, ssl, g = m.loss_and_grad(u, i, j, mats1, mats2)
+    def tsp(a):
+        coo = a.tocoo(); return torch.sparse_coo_tensor(np.vstack([coo.row, coo.col]), coo.data.astype(np.float64), a.shape).coalesce()
+    E = torch.tensor(np.concatenate([U0, V0]).astype(np.float64), requires_grad=True)
+    def view(mats):
+        layers = [E]
+        for k in range(L):
+            layers.append(torch.sparse.mm(tsp(mats[k]), layers[-1]))
+        return torch.stack(layers).mean(0)
+    main, s1, s2 = view([adj] * L), view(mats1), view(mats2)
+    tu, ti, tj = torch.tensor(u), torch.tensor(i), torch.tensor(j)
+    ub, ib, jb = main[tu], main[ti + nu], main[tj + nu]
+    trec = -torch.log(torch.sigmoid((ub * ib).sum(1) - (ub * jb).sum(1)) + 1e-7).sum() + 1e-3 * 0.5 * ((ub ** 2).sum() + (ib ** 2).sum() + (jb ** 2).sum())
+    rows = torch.cat([torch.unique(tu), torch.unique(ti) + nu])
+    z1 = torch.nn.functional.normalize(s1[rows], dim=1, eps=1e-6); z2 = torch.nn.functional.normalize(s2[rows], dim=1, eps=1e-6)
+    tssl = -0.1 * torch.log(torch.exp((z1 * z2).sum(1) / 0.2) / torch.exp(z1 @ z2.T / 0.2).sum(1)).sum()
+    (trec + tssl).backward()
+    assert rec == pytest.approx(float(trec.detach()), rel=1e-5) and ssl == pytest.approx(float(tssl.detach()), rel=1e-5)
+    np.testing.assert_allclose(g, E.grad.numpy(), rtol=2e-3, atol=2e-5)
