@@ -157,10 +157,11 @@ def main():
     total = args.warmup + args.steps
     ev = [(capi.Event(), capi.Event()) for _ in range(total)]
 
-    q_sync = None
+    q_sync = stats_view = None
     if use_dist:   # replicated item table, reconciled once per step (qrec_amd/dist.py)
         from qrec_amd.dist import ReplicatedTableSync
         q_sync = ReplicatedTableSync(torch.as_tensor(tables.Q, device=torch.device("cuda", local_rank)))
+        stats_view = torch.as_tensor(sgd.d_stats, device=torch.device("cuda", local_rank))   # [nll, sum P^2, sum Q^2] f64
 
     state = {"lr": LR0, "last": 0.0, "loss": 0.0}
 
@@ -178,7 +179,10 @@ def main():
         sgd.prefetch_negatives_device(2018, k + 1)                  # side stream, under the SGD kernel
         if q_sync is not None:   # sum the ranks' Q deltas: the path's one collective (RCCL all-reduce)
             q_sync.sync()
-        nll, sp, sq = sgd.epoch_stats()                             # BPR.py:40; the step's one host sync
+        sgd.enqueue_epoch_stats()                                   # BPR.py:40
+        if stats_view is not None:   # global loss: sum(-log sigma) and sum P^2 add up over ranks, Q is replicated;
+            dist.all_reduce(stats_view[0:2])   # every rank then takes the same bold-driver decision
+        nll, sp, sq = sgd.read_epoch_stats()                        # the step's one host sync
         loss = nll + REG_U * sp + REG_I * sq
         if not np.isfinite(loss):
             raise SystemExit("Loss = NaN or Infinity")            # iterativeRecommender.py:84-86

@@ -167,14 +167,21 @@ class BprSgd:
             capi.bpr_sgd_hogwild(self.t.P, self.t.Q, self.t.d, self.t.ld, self.d_u, self.d_i, self.d_j,
                                  self.n, chunk, groups, lr, regU, regI, self.d_stats, variant, stream)
 
-    def epoch_stats(self, stream=None):
-        """(sum -log sigma, sum P*P, sum Q*Q) after the enqueued epoch -- BPR.py:40,53.
-        One read-back; this is the epoch's only host synchronisation."""
+    def enqueue_epoch_stats(self, stream=None):
+        """sum P*P and sum Q*Q into the stats buffer, next to the epoch's sum(-log sigma) -- BPR.py:40,53"""
         t = self.t
         capi.sumsq(t.P, t.code, t.n_users, t.d, t.ld, self.d_stats.ptr + 8, stream)
         capi.sumsq(t.Q, t.code, t.n_items, t.d, t.ld, self.d_stats.ptr + 16, stream)
+
+    def read_epoch_stats(self, stream=None):
         s = self.d_stats.numpy(stream)
         return float(s[0]), float(s[1]), float(s[2])
+
+    def epoch_stats(self, stream=None):
+        """(sum -log sigma, sum P*P, sum Q*Q) after the enqueued epoch.  One read-back; this is the epoch's
+        only host synchronisation."""
+        self.enqueue_epoch_stats(stream)
+        return self.read_epoch_stats(stream)
 
     def loss(self, stream=None) -> float:
         return float(self.d_stats.numpy(stream)[0])
