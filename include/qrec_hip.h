@@ -138,10 +138,14 @@ int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int32_t d, int32_t l
                                     int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
                                     double *d_loss, void *stream);
 
-/* model/rating/BasicMF.py:9-26, order-exact (config #1 parity on device). */
+/* Rating-prediction MF family, order-exact: variant 0 = model/rating/BasicMF.py:9-26 (config #1),
+ * 1 = model/rating/PMF.py:9-28 (regU, regI), 2 = model/rating/SVD.py:13-35 (biases d_Bu/d_Bi of the
+ * tables' dtype, regB, global mean).  Rows are visited in array order (the caller passes the current
+ * trainingData order); *d_loss receives sum(error^2).                                          */
 int qrec_mf_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
                         const int32_t *d_u, const int32_t *d_i, const double *d_rating, int64_t n,
-                        double lr, double *d_loss, void *stream);
+                        double lr, double *d_loss, int variant, double regU, double regI, void *d_Bu,
+                        void *d_Bi, double regB, double global_mean, void *stream);
 
 /* sum(x*x) over rows x d of a table (epoch-end regulariser, BPR.py:40); *d_out
  * (double) is overwritten. */

@@ -50,6 +50,8 @@ def lib():
         L.orc_sumsq_f64.argtypes = [vp, i64]; L.orc_sumsq_f64.restype = f64
         L.orc_mf_sgd_f64.argtypes = [vp, vp, i32, vp, vp, vp, i64, f64]
         L.orc_mf_sgd_f64.restype = f64
+        L.orc_mf_sgd_var_f64.argtypes = [C.c_int, vp, vp, vp, vp, i32, vp, vp, vp, i64, f64, f64, f64, f64, f64]
+        L.orc_mf_sgd_var_f64.restype = f64
         L.orc_find_k_largest.argtypes = [i32, vp, i32, vp, vp]
         L.orc_find_k_largest.restype = C.c_int
         _lib = L
@@ -173,6 +175,16 @@ def mf_sgd(P, Q, u, i, r, lr) -> float:
     _chk(P, np.float64); _chk(Q, np.float64); _chk(u, np.int32); _chk(i, np.int32)
     _chk(r, np.float64)
     return lib().orc_mf_sgd_f64(_p(P), _p(Q), P.shape[1], _p(u), _p(i), _p(r), u.size, lr)
+
+
+def mf_sgd_variant(variant: int, P, Q, u, i, r, lr, regU=0.0, regI=0.0, Bu=None, Bi=None, regB=0.0, gmean=0.0) -> float:
+    """variant 1 = model/rating/PMF.py:9-28, 2 = model/rating/SVD.py:13-35 (fp64, in place)."""
+    _chk(P, np.float64); _chk(Q, np.float64); _chk(u, np.int32); _chk(i, np.int32); _chk(r, np.float64)
+    if variant == 2:
+        _chk(Bu, np.float64); _chk(Bi, np.float64)
+    return lib().orc_mf_sgd_var_f64(variant, _p(P), _p(Q), _p(Bu) if Bu is not None else None,
+                                    _p(Bi) if Bi is not None else None, P.shape[1], _p(u), _p(i), _p(r), u.size,
+                                    lr, regU, regI, regB, gmean)
 
 
 def find_k_largest(K: int, cand):

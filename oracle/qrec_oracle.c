@@ -371,6 +371,33 @@ double orc_mf_sgd_f64(double *P, double *Q, int32_t d, const int32_t *u_idx,
     return loss;
 }
 
+/* model/rating/PMF.py:9-28 (variant 1) and model/rating/SVD.py:13-35 (variant 2), same walk as BasicMF:
+ *   PMF:  error = r - P[u].Q[i];  P[u] += lr*(error*q - regU*p);  Q[i] += lr*(error*p - regI*q)   (p: UPDATED view)
+ *   SVD:  error = r - (((P[u].Q[i] + globalMean) + Bi[i]) + Bu[u])   (SVD.py:76-80), same P/Q updates,
+ *         Bu[u] += lr*(error - regB*bu);  Bi[i] += lr*(error - regB*bi)    (bu, bi: values read BEFORE the updates)
+ * Returns sum(error^2); the epoch-end regularisers are orc_sumsq_f64. */
+double orc_mf_sgd_var_f64(int variant, double *P, double *Q, double *Bu, double *Bi, int32_t d,
+                          const int32_t *u_idx, const int32_t *i_idx, const double *rating, int64_t n,
+                          double lr, double regU, double regI, double regB, double gmean) {
+    double loss = 0.0;
+    int64_t t;
+    int c;
+    for (t = 0; t < n; t++) {
+        const int32_t u = u_idx[t], i = i_idx[t];
+        double *p = P + (int64_t)u * d, *q = Q + (int64_t)i * d;
+        double dot = 0.0, pred, err, bu = 0.0, bi = 0.0;
+        for (c = 0; c < d; c++) dot += p[c] * q[c];
+        pred = dot;
+        if (variant == 2) { bu = Bu[u]; bi = Bi[i]; pred = ((dot + gmean) + bi) + bu; }
+        err = rating[t] - pred;
+        loss += err * err;
+        for (c = 0; c < d; c++) p[c] += lr * (err * q[c] - regU * p[c]);
+        for (c = 0; c < d; c++) q[c] += lr * (err * p[c] - regI * q[c]);
+        if (variant == 2) { Bu[u] += lr * (err - regB * bu); Bi[i] += lr * (err - regB * bi); }
+    }
+    return loss;
+}
+
 /* ------------------------------------------------------------------------------------
  * a-15  find_k_largest: util/qmath.py:134-146, including CPython heapq's exact sift
  * order (Lib/heapq.py) because ties are resolved by the heap layout:

@@ -50,7 +50,7 @@ _SIGNATURES = {
     "qrec_bpr_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _vp, _vp],
     "qrec_bpr_sgd_hogwild": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _vp, C.c_int, _vp],
     "qrec_bpr_sgd_hogwild_item_major": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp],
-    "qrec_mf_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _vp, _vp],
+    "qrec_mf_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _vp, C.c_int, _f64, _f64, _vp, _vp, _f64, _f64, _vp],
     "qrec_sumsq": [_vp, C.c_int, _i64, _i32, _i32, _vp, _vp],
     "qrec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _vp],
     "qrec_bpr_batch_loss_grad": [_vp, _f32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
@@ -340,10 +340,15 @@ def bpr_sgd_hogwild(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int, chunk: int
                                        chunk, grid_groups, lr, regU, regI, _dp(d_loss), variant, _sh(stream)))
 
 
+MF_BASIC, MF_PMF, MF_SVD = 0, 1, 2
+
+
 def mf_sgd_ordered(d_P, d_Q, dtype: int, d: int, ld: int, d_u, d_i, d_rating, n: int, lr: float,
-                   d_loss, stream=None):
+                   d_loss, stream=None, variant: int = MF_BASIC, regU: float = 0.0, regI: float = 0.0, d_Bu=None,
+                   d_Bi=None, regB: float = 0.0, global_mean: float = 0.0):
     _check(load().qrec_mf_sgd_ordered(_dp(d_P), _dp(d_Q), dtype, d, ld, _dp(d_u), _dp(d_i), _dp(d_rating),
-                                      n, lr, _dp(d_loss), _sh(stream)))
+                                      n, lr, _dp(d_loss), variant, regU, regI, _dp(d_Bu), _dp(d_Bi), regB,
+                                      global_mean, _sh(stream)))
 
 
 def sumsq(d_x, dtype: int, rows: int, d: int, ld: int, d_out, stream=None):

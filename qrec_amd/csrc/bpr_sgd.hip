@@ -123,18 +123,24 @@ __global__ __launch_bounds__(64) void bpr_ordered_kernel(
     if (lane == 0) *loss_out = loss;
 }
 
-// model/rating/BasicMF.py:9-26, order-exact, same structure.
-template <typename T, int EPL>
+// Rating-prediction MF family, order-exact, same structure (one wavefront, lane = column):
+//   VAR 0  model/rating/BasicMF.py:9-26   P[u] += (lr*e)*q ;            Q[i] += (lr*e)*p
+//   VAR 1  model/rating/PMF.py:9-28       P[u] += lr*(e*q - regU*p) ;   Q[i] += lr*(e*p - regI*q)
+//   VAR 2  model/rating/SVD.py:13-35      as PMF with e = r - (((P[u].Q[i] + mean) + Bi[i]) + Bu[u]),
+//                                         Bu[u] += lr*(e - regB*bu) ; Bi[i] += lr*(e - regB*bi)
+// p is a VIEW of P[u] in the reference, so the Q[i] update sees the already updated P[u].
+template <typename T, int EPL, int VAR>
 __global__ __launch_bounds__(64) void mf_ordered_kernel(
-    T *__restrict__ P, T *__restrict__ Q, int d, int ld, const int32_t *__restrict__ u_idx,
-    const int32_t *__restrict__ i_idx, const double *__restrict__ rating, int64_t n, T lr,
-    double *__restrict__ loss_out) {
+    T *__restrict__ P, T *__restrict__ Q, T *__restrict__ Bu, T *__restrict__ Bi, int d, int ld,
+    const int32_t *__restrict__ u_idx, const int32_t *__restrict__ i_idx, const double *__restrict__ rating,
+    int64_t n, T lr, T regU, T regI, T regB, T gmean, double *__restrict__ loss_out) {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x;
     double loss = 0.0;
     for (int64_t t = 0; t < n; t++) {
-        T *p = P + (int64_t)u_idx[t] * ld + lane;
-        T *q = Q + (int64_t)i_idx[t] * ld + lane;
+        const int u = u_idx[t], i = i_idx[t];
+        T *p = P + (int64_t)u * ld + lane;
+        T *q = Q + (int64_t)i * ld + lane;
         T pv[EPL], qv[EPL], dot = 0;
 #pragma unroll
         for (int e = 0; e < EPL; e++) {
@@ -144,13 +150,23 @@ __global__ __launch_bounds__(64) void mf_ordered_kernel(
             dot += pv[e] * qv[e];
         }
         dot = wave_allreduce_sum(dot);
-        const T err = (T)rating[t] - dot;
+        T pred = dot, bu = 0, bi = 0;
+        if constexpr (VAR == 2) { bu = Bu[u]; bi = Bi[i]; pred = ((dot + gmean) + bi) + bu; }
+        const T err = (T)rating[t] - pred;
         loss += (double)err * (double)err;
 #pragma unroll
         for (int e = 0; e < EPL; e++) {
-            pv[e] += (lr * err) * qv[e];   // P[u] += lr*error*q          (:22)
-            qv[e] += (lr * err) * pv[e];   // Q[i] += lr*error*p, p is a view of the NEW P[u] (:23)
+            if constexpr (VAR == 0) {
+                pv[e] += (lr * err) * qv[e];
+                qv[e] += (lr * err) * pv[e];
+            } else {
+                pv[e] += lr * (err * qv[e] - regU * pv[e]);
+                qv[e] += lr * (err * pv[e] - regI * qv[e]);
+            }
             if ((lane + 64 * e) < d) { p[64 * e] = pv[e]; q[64 * e] = qv[e]; }
+        }
+        if constexpr (VAR == 2) {
+            if (lane == 0) { Bu[u] = bu + lr * (err - regB * bu); Bi[i] = bi + lr * (err - regB * bi); }
         }
     }
     if (lane == 0) *loss_out = loss;
@@ -453,18 +469,30 @@ int launch_ordered(void *P, void *Q, int d, int ld, const int32_t *u, const int3
     return QREC_OK;
 }
 
-template <typename T>
-int launch_mf_ordered(void *P, void *Q, int d, int ld, const int32_t *u, const int32_t *i,
-                      const double *r, int64_t n, double lr, double *loss, hipStream_t st) {
-#define QREC_MF_LAUNCH(EPL)                                                                   \
-    hipLaunchKernelGGL((mf_ordered_kernel<T, EPL>), dim3(1), dim3(64), 0, st, (T *)P, (T *)Q, d, \
-                       ld, u, i, r, n, (T)lr, loss)
+template <typename T, int VAR>
+int launch_mf_ordered(void *P, void *Q, void *Bu, void *Bi, int d, int ld, const int32_t *u, const int32_t *i,
+                      const double *r, int64_t n, double lr, double regU, double regI, double regB, double gmean,
+                      double *loss, hipStream_t st) {
+#define QREC_MF_LAUNCH(EPL)                                                                             \
+    hipLaunchKernelGGL((mf_ordered_kernel<T, EPL, VAR>), dim3(1), dim3(64), 0, st, (T *)P, (T *)Q, (T *)Bu, \
+                       (T *)Bi, d, ld, u, i, r, n, (T)lr, (T)regU, (T)regI, (T)regB, (T)gmean, loss)
     if (d <= 64) QREC_MF_LAUNCH(1);
     else if (d <= 128) QREC_MF_LAUNCH(2);
     else QREC_MF_LAUNCH(4);
 #undef QREC_MF_LAUNCH
     QREC_LAUNCH_CHECK();
     return QREC_OK;
+}
+
+template <typename T>
+int dispatch_mf(int variant, void *P, void *Q, void *Bu, void *Bi, int d, int ld, const int32_t *u, const int32_t *i,
+                const double *r, int64_t n, double lr, double regU, double regI, double regB, double gmean,
+                double *loss, hipStream_t st) {
+    switch (variant) {
+        case 0: return launch_mf_ordered<T, 0>(P, Q, Bu, Bi, d, ld, u, i, r, n, lr, regU, regI, regB, gmean, loss, st);
+        case 1: return launch_mf_ordered<T, 1>(P, Q, Bu, Bi, d, ld, u, i, r, n, lr, regU, regI, regB, gmean, loss, st);
+        default: return launch_mf_ordered<T, 2>(P, Q, Bu, Bi, d, ld, u, i, r, n, lr, regU, regI, regB, gmean, loss, st);
+    }
 }
 
 }  // namespace
@@ -487,15 +515,18 @@ int qrec_bpr_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
 
 int qrec_mf_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
                         const int32_t *d_u, const int32_t *d_i, const double *d_rating, int64_t n,
-                        double lr, double *d_loss, void *stream) {
+                        double lr, double *d_loss, int variant, double regU, double regI, void *d_Bu,
+                        void *d_Bi, double regB, double global_mean, void *stream) {
     QREC_REQUIRE(d_P && d_Q && d_loss && n >= 0, "qrec_mf_sgd_ordered: null argument");
     QREC_REQUIRE(n == 0 || (d_u && d_i && d_rating), "qrec_mf_sgd_ordered: null index array");
     QREC_REQUIRE(d >= 1 && d <= 256 && ld >= d, "qrec_mf_sgd_ordered: need 1 <= d <= 256, ld >= d");
     QREC_REQUIRE(dtype == QREC_F32 || dtype == QREC_F64, "qrec_mf_sgd_ordered: bad dtype %d", dtype);
+    QREC_REQUIRE(variant >= 0 && variant <= 2, "qrec_mf_sgd_ordered: variant must be 0 (BasicMF), 1 (PMF) or 2 (SVD)");
+    QREC_REQUIRE(variant != 2 || (d_Bu && d_Bi), "qrec_mf_sgd_ordered: SVD needs the bias vectors");
     hipStream_t st = as_stream(stream);
     if (n == 0) { QREC_HIP_CHECK(hipMemsetAsync(d_loss, 0, sizeof(double), st)); return QREC_OK; }
-    return dtype == QREC_F64 ? launch_mf_ordered<double>(d_P, d_Q, d, ld, d_u, d_i, d_rating, n, lr, d_loss, st)
-                             : launch_mf_ordered<float>(d_P, d_Q, d, ld, d_u, d_i, d_rating, n, lr, d_loss, st);
+    return dtype == QREC_F64 ? dispatch_mf<double>(variant, d_P, d_Q, d_Bu, d_Bi, d, ld, d_u, d_i, d_rating, n, lr, regU, regI, regB, global_mean, d_loss, st)
+                             : dispatch_mf<float>(variant, d_P, d_Q, d_Bu, d_Bi, d, ld, d_u, d_i, d_rating, n, lr, regU, regI, regB, global_mean, d_loss, st);
 }
 
 int qrec_bpr_sgd_hogwild(float *d_P, float *d_Q, int32_t d, int32_t ld, const int32_t *d_u,

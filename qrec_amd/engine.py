@@ -188,20 +188,43 @@ class BprSgd:
 
 
 class MfSgd:
-    """model/rating/BasicMF.py:9-26 on the device, order-exact."""
+    """Rating-prediction MF family on the device, order-exact: BasicMF (model/rating/BasicMF.py:9-26),
+    PMF (model/rating/PMF.py:9-28), SVD (model/rating/SVD.py:13-35)."""
 
-    def __init__(self, tables: DeviceTables, n: int):
+    def __init__(self, tables: DeviceTables, n: int, variant: int = capi.MF_BASIC, Bu=None, Bi=None):
         self.t = tables
         self.n = n
+        self.variant = variant
         self.d_u = DeviceBuffer(max(n, 1), np.int32)
         self.d_i = DeviceBuffer(max(n, 1), np.int32)
         self.d_r = DeviceBuffer(max(n, 1), np.float64)
-        self.d_loss = DeviceBuffer.zeros(1, np.float64)
+        self.d_stats = DeviceBuffer.zeros(5, np.float64)      # err^2, sum P^2, sum Q^2, sum Bu^2, sum Bi^2
+        self.d_Bu = self.d_Bi = None
+        if variant == capi.MF_SVD:
+            self.d_Bu = DeviceBuffer.from_numpy(np.ascontiguousarray(Bu, dtype=tables.dtype))
+            self.d_Bi = DeviceBuffer.from_numpy(np.ascontiguousarray(Bi, dtype=tables.dtype))
 
-    def epoch(self, u, i, r, lr: float, stream=None) -> float:
+    def epoch(self, u, i, r, lr: float, regU: float = 0.0, regI: float = 0.0, regB: float = 0.0,
+              global_mean: float = 0.0, stream=None) -> float:
+        """one pass over the rows in the given order; returns sum(error^2)"""
         self.d_u.upload(np.ascontiguousarray(u, dtype=np.int32), stream)
         self.d_i.upload(np.ascontiguousarray(i, dtype=np.int32), stream)
         self.d_r.upload(np.ascontiguousarray(r, dtype=np.float64), stream)
         capi.mf_sgd_ordered(self.t.P, self.t.Q, self.t.code, self.t.d, self.t.ld, self.d_u, self.d_i,
-                            self.d_r, self.n, lr, self.d_loss, stream)
-        return float(self.d_loss.numpy(stream)[0])
+                            self.d_r, self.n, lr, self.d_stats, stream, self.variant, regU, regI, self.d_Bu,
+                            self.d_Bi, regB, global_mean)
+        return float(self.d_stats.numpy(stream)[0])
+
+    def sumsq_terms(self, stream=None):
+        """(sum P^2, sum Q^2, sum Bu^2, sum Bi^2) for the epoch-end regularisers (PMF.py:25, SVD.py:32-33)"""
+        t = self.t
+        capi.sumsq(t.P, t.code, t.n_users, t.d, t.ld, self.d_stats.ptr + 8, stream)
+        capi.sumsq(t.Q, t.code, t.n_items, t.d, t.ld, self.d_stats.ptr + 16, stream)
+        if self.d_Bu is not None:
+            capi.sumsq(self.d_Bu, t.code, t.n_users, 1, 1, self.d_stats.ptr + 24, stream)
+            capi.sumsq(self.d_Bi, t.code, t.n_items, 1, 1, self.d_stats.ptr + 32, stream)
+        s = self.d_stats.numpy(stream)
+        return float(s[1]), float(s[2]), float(s[3]), float(s[4])
+
+    def biases(self):
+        return self.d_Bu.numpy().astype(np.float64), self.d_Bi.numpy().astype(np.float64)

@@ -15,7 +15,7 @@ class BasicMF(IterativeRecommender):
 
     def trainModel(self):
         tables = DeviceTables(self.P, self.Q, np.float64)
-        sgd = MfSgd(tables, len(self.data.trainingData))
+        sgd = MfSgd(tables, self.data.elemCount())
         epoch = 0
         while epoch < self.maxEpoch:
             u, i, r = self.data.training_arrays()

@@ -75,6 +75,7 @@ def run_numpy_model(conf_path, seed, model_mod, model_name, hook_attr):
         rec["epochs"].append(dict(epoch=epoch, loss=float(loss_before), lr_used=float(lr_used),
                                   lr_next=float(self.lRate), converged=bool(r),
                                   P=self.P.copy(), Q=self.Q.copy(),
+                                  **({"Bu": self.Bu.copy(), "Bi": self.Bi.copy()} if hasattr(self, "Bu") else {}),
                                   order=[(self.data.user[a], self.data.item[b], c)
                                          for a, b, c in self.data.trainingData]
                                   if hook_attr == "mf" else None))
@@ -83,6 +84,8 @@ def run_numpy_model(conf_path, seed, model_mod, model_name, hook_attr):
     orig_init = cls.initModel
     def initModel(self):
         orig_init(self); rec["P0"] = self.P.copy(); rec["Q0"] = self.Q.copy()
+        if hasattr(self, "Bu"):
+            rec["Bu0"] = self.Bu.copy(); rec["Bi0"] = self.Bi.copy()
         rec["order0"] = [(self.data.user[a], self.data.item[b], c) for a, b, c in self.data.trainingData]
     cls.initModel = initModel
     orig_eval = cls.evalRanking
@@ -209,15 +212,14 @@ def case_bpr_lastfm(tmp):
     return meta
 
 
-def case_basicmf(tmp):
-    conf = os.path.join(tmp, "mf.conf")
-    # BASELINE.json config #1: BasicMF on FilmTrust, d=10, reference numpy path (no -tf)
+def _case_rating_mf(tmp, model, fixture, seed, factors, lr, reg, epochs=3):
+    conf = os.path.join(tmp, fixture + ".conf")
     write_conf(conf, ratings="./dataset/FilmTrust/trainset.txt", ratings__setup="-columns 0 1 2",
-               model__name="BasicMF", evaluation__setup="-testSet ./dataset/FilmTrust/testset.txt",
-               item__ranking="off -topN 10", num__factors="10", num__max__epoch="3",
-               batch_size="1024", learnRate="-init 0.03 -max 1",
-               reg__lambda="-u 0.05 -i 0.05 -b 0.1 -s 0.1", output__setup="off -dir ./results/")
-    rec = run_numpy_model(conf, 1, "model.rating.BasicMF", "BasicMF", "mf")
+               model__name=model, evaluation__setup="-testSet ./dataset/FilmTrust/testset.txt",
+               item__ranking="off -topN 10", num__factors=str(factors), num__max__epoch=str(epochs),
+               batch_size="1024", learnRate="-init %s -max 1" % lr,
+               reg__lambda=reg, output__setup="off -dir ./results/")
+    rec = run_numpy_model(conf, seed, "model.rating." + model, model, "mf")
     m = rec["model"]
     arrays = dict(P0=rec["P0"], Q0=rec["Q0"],
                   order0=np.array([(a, b) for a, b, _ in rec["order0"]], dtype=np.int32),
@@ -226,17 +228,34 @@ def case_basicmf(tmp):
     for k, e in enumerate(rec["epochs"]):
         arrays[f"P{k+1}"] = e["P"]; arrays[f"Q{k+1}"] = e["Q"]
         arrays[f"order{k+1}"] = np.array([(a, b) for a, b, _ in e["order"]], dtype=np.int32)
+        if "Bu" in e:
+            arrays[f"Bu{k+1}"] = e["Bu"]; arrays[f"Bi{k+1}"] = e["Bi"]
+    if "Bu0" in rec:
+        arrays["Bu0"] = rec["Bu0"]; arrays["Bi0"] = rec["Bi0"]
     # test predictions appended by evalRatings: [user,item,rating,pred]
     arrays["test_pred"] = np.array([r[3] for r in m.data.testData], dtype=np.float64)
     arrays["test_rating"] = np.array([r[2] for r in m.data.testData], dtype=np.float64)
     arrays["test_uid"] = np.array([m.data.user.get(r[0], -1) for r in m.data.testData], dtype=np.int32)
     arrays["test_iid"] = np.array([m.data.item.get(r[1], -1) for r in m.data.testData], dtype=np.int32)
-    np.savez_compressed(os.path.join(OUT, "basicmf_filmtrust.npz"), **arrays)
-    return dict(name="basicmf_filmtrust", seed=1, conf=open(conf).read(),
+    np.savez_compressed(os.path.join(OUT, fixture + ".npz"), **arrays)
+    return dict(name=fixture, seed=seed, conf=open(conf).read(),
                 n_users=len(m.data.user), n_items=len(m.data.item), n_train=len(rec["train_rows"]),
-                epochs=[{k: v for k, v in e.items() if k not in ("P", "Q", "order")} for e in rec["epochs"]],
+                epochs=[{k: v for k, v in e.items() if k not in ("P", "Q", "order", "Bu", "Bi")} for e in rec["epochs"]],
                 measure=rec["measure"], globalMean=m.data.globalMean,
-                rScale=[float(x) for x in m.data.rScale])
+                rScale=[float(x) for x in m.data.rScale], regU=m.regU, regI=m.regI, regB=m.regB)
+
+
+def case_basicmf(tmp):
+    # BASELINE.json config #1: BasicMF on FilmTrust, d=10, reference numpy path (no -tf)
+    return _case_rating_mf(tmp, "BasicMF", "basicmf_filmtrust", 1, 10, 0.03, "-u 0.05 -i 0.05 -b 0.1 -s 0.1")
+
+
+def case_pmf(tmp):
+    return _case_rating_mf(tmp, "PMF", "pmf_filmtrust", 2, 10, 0.02, "-u 0.01 -i 0.01 -b 0.1 -s 0.1")
+
+
+def case_svd(tmp):
+    return _case_rating_mf(tmp, "SVD", "svd_filmtrust", 3, 10, 0.005, "-u 0.01 -i 0.02 -b 0.02 -s 0.1")
 
 
 def case_pairwise_and_adj(tmp):
@@ -315,7 +334,7 @@ def main():
     os.symlink(os.path.join(REF, "dataset"), os.path.join(tmp, "dataset"))
     os.chdir(tmp)
     only = sys.argv[1:]
-    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pairwise_and_adj, case_sgl_subgraph]
+    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pmf, case_svd, case_pairwise_and_adj, case_sgl_subgraph]
     if only:   # regenerate a subset, keep the other entries of golden_meta.json
         cases = [c for c in cases if c.__name__ in only]
         old = json.load(open(os.path.join(OUT, "golden_meta.json")))

@@ -142,6 +142,62 @@ def test_basicmf_model_end_to_end_reproduces_reference_run():
     assert np.array_equal(capi.state_from_python(random.getstate()), z["py_state"])
 
 
+@pytest.mark.parametrize("variant", [capi.MF_BASIC, capi.MF_PMF, capi.MF_SVD])
+@pytest.mark.parametrize("dim,dtype", [(10, np.float64), (64, np.float64), (200, np.float64), (50, np.float32)])
+def test_mf_family_kernel_matches_oracle(variant, dim, dtype):
+    """BasicMF / PMF / SVD recurrences (model/rating/{BasicMF,PMF,SVD}.py) on synthetic ratings."""
+    rng = np.random.default_rng(100 + dim + variant)
+    U, I, n = 300, 500, 20_000
+    u = rng.integers(0, U, n, dtype=np.int32); i = rng.integers(0, I, n, dtype=np.int32)
+    r = rng.integers(1, 11, n).astype(np.float64) / 2
+    P0 = rng.random((U, dim)) / 3; Q0 = rng.random((I, dim)) / 3
+    Bu0 = rng.random(U) / 5; Bi0 = rng.random(I) / 5
+    lr, regU, regI, regB, gm = 0.01, 0.01, 0.02, 0.05, float(r.mean())
+    Pr, Qr, Bur, Bir = P0.copy(), Q0.copy(), Bu0.copy(), Bi0.copy()
+    if variant == capi.MF_BASIC:
+        want = O.mf_sgd(Pr, Qr, u, i, r, lr)
+    else:
+        want = O.mf_sgd_variant(variant, Pr, Qr, u, i, r, lr, regU, regI, Bur, Bir, regB, gm)
+    t = DeviceTables(P0, Q0, dtype)
+    sgd = MfSgd(t, n, variant, Bu0, Bi0)
+    got = sgd.epoch(u, i, r, lr, regU, regI, regB, gm)
+    Pg, Qg = t.download(np.float64)
+    tol = F64_TOL if dtype == np.float64 else 2e-5   # 20k sequential fp32 updates on 300 rows
+    assert rel_err(Pg, Pr) < tol and rel_err(Qg, Qr) < tol
+    assert abs(got - want) / want < tol
+    if variant == capi.MF_SVD:
+        Bug, Big = sgd.biases()
+        assert rel_err(Bug, Bur) < tol and rel_err(Big, Bir) < tol
+        sp, sq, sbu, sbi = sgd.sumsq_terms()
+        assert sbu == pytest.approx(O.sumsq(Bug), rel=1e-6 if dtype == np.float32 else 1e-12)
+        assert sbi == pytest.approx(O.sumsq(Big), rel=1e-6 if dtype == np.float32 else 1e-12)
+
+
+@pytest.mark.parametrize("name", ["PMF", "SVD"])
+def test_pmf_svd_model_end_to_end_reproduces_reference_run(name):
+    """model/rating/PMF.py, SVD.py on FilmTrust through the drop-in classes, against the recorded runs."""
+    import importlib
+    cls = getattr(importlib.import_module(f"qrec_amd.model.rating.{name}"), name)
+    meta, z = load_golden(f"{name.lower()}_filmtrust")
+    rows = [[f"u{a}", f"i{b}", float(r)] for (a, b), r in zip(z["order0"].tolist(), z["rating0"].tolist())]
+    test = [[f"u{a}" if a >= 0 else f"xu{k}", f"i{b}" if b >= 0 else f"xi{k}", float(r)]
+            for k, (a, b, r) in enumerate(zip(z["test_uid"].tolist(), z["test_iid"].tolist(), z["test_rating"].tolist()))]
+    random.seed(meta["seed"]); np.random.seed(meta["seed"])
+    with redirect_stdout(io.StringIO()):
+        m = cls(conf_from_text(meta["conf"]), rows, test)
+        measure = m.execute()
+    last = len(meta["epochs"])
+    np.testing.assert_allclose(m.P, z[f"P{last}"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(m.Q, z[f"Q{last}"], rtol=1e-10, atol=1e-13)
+    if name == "SVD":
+        np.testing.assert_allclose(m.Bu, z[f"Bu{last}"], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(m.Bi, z[f"Bi{last}"], rtol=1e-10, atol=1e-13)
+    assert m.lastLoss == pytest.approx(meta["epochs"][-1]["loss"], rel=1e-11)
+    for g, w in zip(measure, meta["measure"]):
+        assert float(g.split(":")[1]) == pytest.approx(float(w.split(":")[1]), rel=1e-9)
+    assert np.array_equal(capi.state_from_python(random.getstate()), z["py_state"])
+
+
 @pytest.mark.parametrize("dim", [64, 50, 128, 8, 200])
 @pytest.mark.parametrize("variant", [capi.HW_ATOMIC, capi.HW_SC1_ATOMIC])
 def test_hogwild_single_group_is_the_sequential_recurrence(dim, variant):

@@ -138,6 +138,58 @@ def test_basicmf_filmtrust(golden_dir):
     np.testing.assert_allclose(got, want, atol=1.01e-3)  # round() boundary cases may flip the last digit
 
 
+def _bold_driver(lr, last_loss, loss, epoch):
+    """base/iterativeRecommender.py:59-63,91-99 (learning-rate update inside isConverged)"""
+    if not abs(last_loss - loss) < 1e-3:
+        if epoch > 1:
+            lr = lr * 1.05 if abs(last_loss) > abs(loss) else lr * 0.5
+        lr = min(lr, 1.0)
+    return lr
+
+
+@pytest.mark.parametrize("name,variant", [("pmf_filmtrust", 1), ("svd_filmtrust", 2)])
+def test_pmf_svd_filmtrust(golden_dir, name, variant):
+    """model/rating/PMF.py:9-28 and model/rating/SVD.py:13-35 through the oracle, against the recorded
+    reference runs (tables, biases, losses, learning-rate schedule, shuffle stream, predictions)."""
+    meta, z = _load(golden_dir, name)
+    P, Q = z["P0"].copy(), z["Q0"].copy()
+    Bu = z["Bu0"].copy() if variant == 2 else None
+    Bi = z["Bi0"].copy() if variant == 2 else None
+    regU, regI, regB, gm = meta["regU"], meta["regI"], meta["regB"], meta["globalMean"]
+    mt = O.MT.cpython_seed(meta["seed"])
+    n = z["order0"].shape[0]
+    perm = np.arange(n, dtype=np.int64)
+    u0 = np.ascontiguousarray(z["order0"][:, 0]); i0 = np.ascontiguousarray(z["order0"][:, 1]); r0 = z["rating0"]
+    lr = meta["epochs"][0]["lr_used"]; last_loss = 0.0
+    for k, ep in enumerate(meta["epochs"]):
+        u = np.ascontiguousarray(u0[perm]); i = np.ascontiguousarray(i0[perm]); r = np.ascontiguousarray(r0[perm])
+        assert np.array_equal(np.stack([u, i], 1), z[f"order{k}"])
+        assert lr == pytest.approx(ep["lr_used"], rel=1e-15)
+        loss = O.mf_sgd_variant(variant, P, Q, u, i, r, lr, regU, regI, Bu, Bi, regB, gm)
+        loss += regU * O.sumsq(P) + regI * O.sumsq(Q)
+        if variant == 2:
+            loss += regB * (O.sumsq(Bu) + O.sumsq(Bi))
+        assert loss == pytest.approx(ep["loss"], rel=1e-11)
+        np.testing.assert_allclose(P, z[f"P{k+1}"], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(Q, z[f"Q{k+1}"], rtol=1e-10, atol=1e-13)
+        if variant == 2:
+            np.testing.assert_allclose(Bu, z[f"Bu{k+1}"], rtol=1e-10, atol=1e-13)
+            np.testing.assert_allclose(Bi, z[f"Bi{k+1}"], rtol=1e-10, atol=1e-13)
+        lr = _bold_driver(lr, last_loss, loss, ep["epoch"])
+        assert lr == pytest.approx(ep["lr_next"], rel=1e-15)
+        last_loss = loss
+        mt.shuffle(n, perm)
+    assert np.array_equal(mt.words625(), z["py_state"])
+    tu, ti = z["test_uid"], z["test_iid"]
+    ok = (tu >= 0) & (ti >= 0)
+    pred = np.einsum("nd,nd->n", P[tu[ok]], Q[ti[ok]])
+    if variant == 2:
+        pred = pred + gm + Bi[ti[ok]] + Bu[tu[ok]]
+    lo, hi = meta["rScale"][0], meta["rScale"][-1]
+    got = np.where(pred > hi, hi, np.where(pred < lo, lo, np.round(pred, 3)))
+    np.testing.assert_allclose(got, z["test_pred"][ok], atol=1.01e-3)
+
+
 def test_pairwise_sampler_stream(golden_dir):
     """base/deepRecommender.py:29-52 over two epochs: shuffle(trainingData) then one
     negative per row, membership against ALL train items of the user."""
