@@ -165,7 +165,9 @@ def main():
 
     state = {"lr": LR0, "last": 0.0, "loss": 0.0}
 
-    def step(k: int):
+    def step_dist(k: int):
+        """N > 1: the ranks' Q deltas and loss terms are summed between the SGD kernel and the learning-rate
+        decision, so the epoch close runs on the host (one 24-byte read-back per step)."""
         sgd.take_prefetched_negatives(k)                            # BPR.py:35-37 (sampled under step k-1)
         capi._check(capi.load().qrec_memset(sgd.d_stats.ptr, 0, 8, None))
         ev[k][0].record()
@@ -176,12 +178,12 @@ def main():
             capi.bpr_sgd_hogwild(tables.P, tables.Q, DIM, tables.ld, sgd.d_u, sgd.d_i, sgd.d_j, n, CHUNK, 0,
                                  state["lr"], REG_U, REG_I, sgd.d_stats, args.variant)
         ev[k][1].record()
+        sgd.mark_negatives_consumed()
         sgd.prefetch_negatives_device(2018, k + 1)                  # side stream, under the SGD kernel
-        if q_sync is not None:   # sum the ranks' Q deltas: the path's one collective (RCCL all-reduce)
-            q_sync.sync()
+        q_sync.sync()            # sum the ranks' Q deltas: the path's one collective (RCCL all-reduce)
         sgd.enqueue_epoch_stats()                                   # BPR.py:40
-        if stats_view is not None:   # global loss: sum(-log sigma) and sum P^2 add up over ranks, Q is replicated;
-            dist.all_reduce(stats_view[0:2])   # every rank then takes the same bold-driver decision
+        # global loss: sum(-log sigma) and sum P^2 add up over ranks, Q is replicated;
+        dist.all_reduce(stats_view[0:2])   # every rank then takes the same bold-driver decision
         nll, sp, sq = sgd.read_epoch_stats()                        # the step's one host sync
         loss = nll + REG_U * sp + REG_I * sq
         if not np.isfinite(loss):
@@ -191,6 +193,18 @@ def main():
             state["lr"] *= 1.05 if abs(state["last"]) > abs(loss) else 0.5
         state["lr"] = min(state["lr"], MAX_LR)
         state["last"] = state["loss"] = loss
+
+    def step_single(k: int):
+        """N = 1: sampler (side stream) | SGD kernel -> epoch close (BPR.py:40 loss terms, isConverged,
+        updateLearningRate) all on the device; the host only enqueues.  tol = 0: the K timed steps all run."""
+        sgd.take_prefetched_negatives(k)                            # BPR.py:35-37 (sampled under step k-1)
+        sgd.epoch_device_async(REG_U, REG_I, MAX_LR, tol=0.0, chunk=CHUNK, variant=args.variant,
+                               flush_every=FLUSH_EVERY, events=ev[k])   # BPR.py:45-53,40 + iterativeRecommender.py:88-104
+        sgd.prefetch_negatives_device(2018, k + 1)                  # side stream, under the SGD kernel
+
+    step = step_dist if use_dist else step_single
+    if not use_dist:
+        sgd.start_device_driver(LR0, log_capacity=total)
 
     def sync_all():
         if use_dist:
@@ -212,6 +226,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    if not use_dist:
+        drv = sgd.driver_state()
+        if drv["failed"]:
+            raise SystemExit("Loss = NaN or Infinity")            # iterativeRecommender.py:84-86
+        assert drv["epochs"] == total and not drv["converged"], drv
+        log = sgd.driver_log()
+        state["loss"], state["lr"] = float(log[-1, 0]), drv["lr"]
+        state["lr_schedule"] = [float(x) for x in log[:, 1]]
     kernel_ms = [ev[k][1].elapsed_ms_since(ev[k][0]) for k in range(args.warmup, total)]
     avg_kernel_ms = float(np.mean(kernel_ms))
     alg_bytes = n * bytes_per_triplet(DIM)
@@ -234,7 +256,8 @@ def main():
                                    f"throughput mode (device Philox sampler + Hogwild atomic-delta SGD, {args.schedule}-major schedule)",
                        "triplets_per_step_per_gpu": n, "chunk": CHUNK,
                        "parallelism": "1 GPU" if world == 1 else f"user-sharded x{world}, replicated item table, per-step delta all-reduce (RCCL)",
-                       "lr": LR0, "reg": REG_U, "final_loss": state["loss"]},
+                       "lr": LR0, "reg": REG_U, "final_loss": state["loss"], "final_lr": state["lr"],
+                       "epoch_close": "host (24-byte read-back per step)" if use_dist else "device (no host sync inside the timed region)"},
             "roofline": {"bound": "hbm", "kernel": "bpr_hogwild_item_kernel<16,4>" if args.schedule == "item" else "bpr_hogwild_kernel<16,4,plain-load,atomic>",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

@@ -124,7 +124,7 @@ int qrec_bpr_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
 int qrec_bpr_sgd_hogwild(float *d_P, float *d_Q, int32_t d, int32_t ld, const int32_t *d_u,
                          const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
                          int32_t grid_groups, float lr, float regU, float regI, double *d_loss,
-                         int variant, void *stream);
+                         int variant, const double *d_driver_state, void *stream);
 
 /* The same Hogwild epoch, ITEM-major: the caller passes the triplets sorted by positive item (stable
  * within an item); Q[i] stays in registers along an item run (flushed as one atomic delta and re-read
@@ -136,7 +136,32 @@ int qrec_bpr_sgd_hogwild(float *d_P, float *d_Q, int32_t d, int32_t ld, const in
 int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int32_t d, int32_t ld, const int32_t *d_u,
                                     const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
                                     int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
-                                    double *d_loss, void *stream);
+                                    double *d_loss, const double *d_driver_state, void *stream);
+
+/* Device-resident epoch close of the numpy-path models: model/ranking/BPR.py:40 (loss += regU*sum(P*P) +
+ * regI*sum(Q*Q)) followed by isConverged / updateLearningRate (base/iterativeRecommender.py:56-63,88-104),
+ * so that a run can be enqueued epoch after epoch without a host round trip.
+ *   d_stats : double[QREC_STATS_WORDS], zero before the first epoch: [0] the epoch's sum(-log sigma) (the SGD
+ *             kernels accumulate into it; cleared again by the call), [1] sum P*P, [2] sum Q*Q (left for the
+ *             caller), [3] ticket counter, then the per-block partial sums.
+ *   d_state : double[QREC_DRV_WORDS], the bold-driver state below; initialise LR, everything else 0.
+ *   d_log   : optional double[log_capacity][QREC_DRV_LOG_WORDS] = {loss, lr used, sum(-log sigma),
+ *             lastLoss - loss, sum P*P, sum Q*Q, -, -} per epoch.
+ * A SGD entry point given d_driver_state takes its learning rate from d_state[QREC_DRV_LR] and becomes a
+ * no-op once CONVERGED or FAILED is set (tol = 1e-3 in the reference; 0 never converges; max_lr <= 0 = no cap). */
+#define QREC_DRV_LR 0         /* learning rate of the NEXT epoch (lRate)             */
+#define QREC_DRV_LAST_LOSS 1  /* lastLoss                                            */
+#define QREC_DRV_EPOCHS 2     /* epochs closed so far                                */
+#define QREC_DRV_CONVERGED 3  /* 1 once |lastLoss - loss| < tol                      */
+#define QREC_DRV_FAILED 4     /* 1 once the loss is NaN/Inf (the reference exits)    */
+#define QREC_DRV_WORDS 8
+#define QREC_DRV_LOG_WORDS 8
+#define QREC_STATS_MAX_BLOCKS 256
+#define QREC_STATS_PARTIALS 8
+#define QREC_STATS_WORDS (QREC_STATS_PARTIALS + 2 * QREC_STATS_MAX_BLOCKS)
+int qrec_epoch_close(const void *d_P, int64_t p_rows, const void *d_Q, int64_t q_rows, int dtype, int32_t ld,
+                     double *d_stats, double *d_state, double regU, double regI, double max_lr, double tol,
+                     double *d_log, int64_t log_capacity, void *stream);
 
 /* Rating-prediction MF family, order-exact: variant 0 = model/rating/BasicMF.py:9-26 (config #1),
  * 1 = model/rating/PMF.py:9-28 (regU, regI), 2 = model/rating/SVD.py:13-35 (biases d_Bu/d_Bi of the

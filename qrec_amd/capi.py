@@ -48,8 +48,9 @@ _SIGNATURES = {
     "qrec_mt_pairwise_sample_epoch": [_vp, _vp, _i64, _vp, _vp, _i32, _vp],
     "qrec_philox_bpr_sample": [_vp, _vp, _vp, _i64, _i32, _u64, _u64, _vp, _vp],
     "qrec_bpr_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _vp, _vp],
-    "qrec_bpr_sgd_hogwild": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _vp, C.c_int, _vp],
-    "qrec_bpr_sgd_hogwild_item_major": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp],
+    "qrec_bpr_sgd_hogwild": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _vp, C.c_int, _vp, _vp],
+    "qrec_bpr_sgd_hogwild_item_major": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp],
+    "qrec_epoch_close": [_vp, _i64, _vp, _i64, C.c_int, _i32, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
     "qrec_mf_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _vp, C.c_int, _f64, _f64, _vp, _vp, _f64, _f64, _vp],
     "qrec_sumsq": [_vp, C.c_int, _i64, _i32, _i32, _vp, _vp],
     "qrec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _vp],
@@ -252,6 +253,18 @@ class DeviceBuffer:
         _check(load().qrec_memcpy_d2h(_hp(out), self.ptr, self.nbytes, _sh(stream)))
         return out
 
+    def head(self, n: int, stream=None) -> np.ndarray:
+        """the first ``n`` elements (flat) -- small read-backs of a larger buffer"""
+        out = np.empty(n, dtype=self.dtype)
+        _check(load().qrec_memcpy_d2h(_hp(out), self.ptr, out.nbytes, _sh(stream)))
+        return out
+
+    def upload_head(self, a: np.ndarray, stream=None):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if a.nbytes > self.nbytes:
+            raise ValueError("upload_head: larger than the buffer")
+        _check(load().qrec_memcpy_h2d(self.ptr, _hp(a), a.nbytes, _sh(stream)))
+
     def copy_from(self, other: "DeviceBuffer", stream=None):
         if other.nbytes != self.nbytes:
             raise ValueError("copy_from size mismatch")
@@ -335,9 +348,11 @@ def bpr_sgd_ordered(d_P, d_Q, dtype: int, d: int, ld: int, d_u, d_i, d_j, n: int
 
 
 def bpr_sgd_hogwild(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int, chunk: int, grid_groups: int,
-                    lr: float, regU: float, regI: float, d_loss, variant: int = HW_DEFAULT, stream=None):
+                    lr: float, regU: float, regI: float, d_loss, variant: int = HW_DEFAULT, stream=None,
+                    d_driver_state=None):
     _check(load().qrec_bpr_sgd_hogwild(_dp(d_P), _dp(d_Q), d, ld, _dp(d_u), _dp(d_i), _dp(d_j), n,
-                                       chunk, grid_groups, lr, regU, regI, _dp(d_loss), variant, _sh(stream)))
+                                       chunk, grid_groups, lr, regU, regI, _dp(d_loss), variant,
+                                       _dp(d_driver_state), _sh(stream)))
 
 
 MF_BASIC, MF_PMF, MF_SVD = 0, 1, 2
@@ -440,9 +455,21 @@ def copy_cols(d_dst, dst_ld: int, d_src, src_ld: int, src_col_off: int, n_rows: 
 
 
 def bpr_sgd_hogwild_item_major(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int, chunk: int, grid_groups: int,
-                               flush_every: int, lr: float, regU: float, regI: float, d_loss, stream=None):
+                               flush_every: int, lr: float, regU: float, regI: float, d_loss, stream=None,
+                               d_driver_state=None):
     _check(load().qrec_bpr_sgd_hogwild_item_major(_dp(d_P), _dp(d_Q), d, ld, _dp(d_u), _dp(d_i), _dp(d_j), n, chunk,
-                                                  grid_groups, flush_every, lr, regU, regI, _dp(d_loss), _sh(stream)))
+                                                  grid_groups, flush_every, lr, regU, regI, _dp(d_loss),
+                                                  _dp(d_driver_state), _sh(stream)))
+
+
+DRV_LR, DRV_LAST_LOSS, DRV_EPOCHS, DRV_CONVERGED, DRV_FAILED, DRV_WORDS = 0, 1, 2, 3, 4, 8
+DRV_LOG_WORDS, STATS_WORDS = 8, 8 + 2 * 256
+
+
+def epoch_close(d_P, p_rows: int, d_Q, q_rows: int, dtype: int, ld: int, d_stats, d_state, regU: float, regI: float,
+                max_lr: float, tol: float, d_log=None, log_capacity: int = 0, stream=None):
+    _check(load().qrec_epoch_close(_dp(d_P), p_rows, _dp(d_Q), q_rows, dtype, ld, _dp(d_stats), _dp(d_state), regU, regI,
+                                   max_lr, tol, _dp(d_log), log_capacity, _sh(stream)))
 
 
 def mt_sample_range(state625: np.ndarray, n: int, k: int) -> np.ndarray:

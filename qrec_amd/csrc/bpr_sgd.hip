@@ -215,13 +215,33 @@ __device__ inline void hw_update_row(__amdgpu_buffer_rsrc_t rs, int row, int r, 
     }
 }
 
+// Learning rate of a throughput epoch: either the host's value, or -- when `state` is given -- the device-resident
+// bold-driver state written by epoch_close_kernel (reduce.hip; layout in include/qrec_hip.h), so that a whole
+// training run can be enqueued without a host round trip per epoch.  A converged / failed run turns the
+// remaining enqueued epochs into no-ops.
+struct HwRate {
+    float lr, regU, regI;
+    const double *state;
+};
+__device__ inline bool hw_rate_resolve(const HwRate &rt, float &lr, float &cu, float &ci) {
+    lr = rt.lr;
+    if (rt.state) {
+        if (rt.state[QREC_DRV_CONVERGED] != 0.0 || rt.state[QREC_DRV_FAILED] != 0.0) return false;
+        lr = (float)rt.state[QREC_DRV_LR];
+    }
+    cu = lr * rt.regU; ci = lr * rt.regI;
+    return true;
+}
+
 template <int LPR, int E, int LOADP, int UPD>
 __global__ __launch_bounds__(256) void bpr_hogwild_kernel(
     float *__restrict__ P, float *__restrict__ Q, uint32_t p_bytes, uint32_t q_bytes,
     const int32_t *__restrict__ u_idx, const int32_t *__restrict__ i_idx,
     const int32_t *__restrict__ j_idx, int64_t n, int chunk, int64_t n_chunks,
-    int64_t groups_active, float lr, float cu, float ci, double *__restrict__ loss_out) {
+    int64_t groups_active, HwRate rate, double *__restrict__ loss_out) {
     constexpr int GPW = kWave / LPR;  // groups (rows) per wavefront
+    float lr, cu, ci;
+    if (!hw_rate_resolve(rate, lr, cu, ci)) return;
     __shared__ int32_t s_idx[4][GPW][3][kMaxChunk];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -319,8 +339,10 @@ __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
     float *__restrict__ P, float *__restrict__ Q, uint32_t p_bytes, uint32_t q_bytes,
     const int32_t *__restrict__ u_idx, const int32_t *__restrict__ i_idx,
     const int32_t *__restrict__ j_idx, int64_t n, int chunk, int64_t n_chunks, int64_t chunk_stride,
-    int64_t groups_active, int flush_every, float lr, float cu, float ci, double *__restrict__ loss_out) {
+    int64_t groups_active, int flush_every, HwRate rate, double *__restrict__ loss_out) {
     constexpr int GPW = kWave / LPR;
+    float lr, cu, ci;
+    if (!hw_rate_resolve(rate, lr, cu, ci)) return;
     __shared__ int32_t s_idx[4][GPW][3][kMaxChunk];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane / LPR, r = lane % LPR;
@@ -400,8 +422,8 @@ __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
 
 template <int LPR, int E>
 int launch_hogwild_item(float *P, float *Q, uint32_t pb, uint32_t qb, const int32_t *u, const int32_t *i,
-                        const int32_t *j, int64_t n, int chunk, int64_t groups, int flush_every, float lr, float cu,
-                        float ci, double *loss, hipStream_t st) {
+                        const int32_t *j, int64_t n, int chunk, int64_t groups, int flush_every, HwRate rate,
+                        double *loss, hipStream_t st) {
     constexpr int GPW = kWave / LPR;
     const int64_t n_chunks = (n + chunk - 1) / chunk;
     const int64_t default_groups = (int64_t)256 * 4 * GPW, max_groups = (int64_t)256 * 8 * 4 * GPW;
@@ -415,7 +437,7 @@ int launch_hogwild_item(float *P, float *Q, uint32_t pb, uint32_t qb, const int3
     while (gcd(stride, n_chunks) != 1) stride++;
     const unsigned blocks = (unsigned)((groups + 4 * GPW - 1) / (4 * GPW));
     hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, chunk,
-                       n_chunks, stride, groups, flush_every, lr, cu, ci, loss);
+                       n_chunks, stride, groups, flush_every, rate, loss);
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }
@@ -423,7 +445,7 @@ int launch_hogwild_item(float *P, float *Q, uint32_t pb, uint32_t qb, const int3
 template <int LPR, int E>
 int launch_hogwild(float *P, float *Q, uint32_t pb, uint32_t qb, const int32_t *u,
                    const int32_t *i, const int32_t *j, int64_t n, int chunk, int64_t groups,
-                   float lr, float cu, float ci, double *loss, int variant, hipStream_t st) {
+                   HwRate rate, double *loss, int variant, hipStream_t st) {
     constexpr int GPW = kWave / LPR;
     const int64_t n_chunks = (n + chunk - 1) / chunk;
     // Groups in flight.  The kernel is bound by the L2 atomic units, not by latency: measured at
@@ -439,7 +461,7 @@ int launch_hogwild(float *P, float *Q, uint32_t pb, uint32_t qb, const int32_t *
     const unsigned blocks = (unsigned)((groups + 4 * GPW - 1) / (4 * GPW));
 #define QREC_HW_LAUNCH(LOADP, UPD)                                                              \
     hipLaunchKernelGGL((bpr_hogwild_kernel<LPR, E, LOADP, UPD>), dim3(blocks), dim3(256), 0, st, \
-                       P, Q, pb, qb, u, i, j, n, chunk, n_chunks, groups, lr, cu, ci, loss)
+                       P, Q, pb, qb, u, i, j, n, chunk, n_chunks, groups, rate, loss)
     switch (variant) {
         case QREC_HW_PLAIN_RMW: QREC_HW_LAUNCH(LD_PLAIN, UP_STORE); break;
         case QREC_HW_SC1_RMW: QREC_HW_LAUNCH(LD_SC1, UP_STORE_SC1); break;
@@ -532,7 +554,7 @@ int qrec_mf_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
 int qrec_bpr_sgd_hogwild(float *d_P, float *d_Q, int32_t d, int32_t ld, const int32_t *d_u,
                          const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
                          int32_t grid_groups, float lr, float regU, float regI, double *d_loss,
-                         int variant, void *stream) {
+                         int variant, const double *d_driver_state, void *stream) {
     QREC_REQUIRE(d_P && d_Q && d_loss && n >= 0, "qrec_bpr_sgd_hogwild: null argument");
     QREC_REQUIRE(n == 0 || (d_u && d_i && d_j), "qrec_bpr_sgd_hogwild: null index array");
     QREC_REQUIRE(ld >= d && d >= 1, "qrec_bpr_sgd_hogwild: need ld >= d >= 1");
@@ -545,19 +567,19 @@ int qrec_bpr_sgd_hogwild(float *d_P, float *d_Q, int32_t d, int32_t ld, const in
     // The row count is not known here; the caller guarantees ids < rows; we bound by 4 GiB.
     const uint32_t full = 0xffffffffu;
     hipStream_t st = as_stream(stream);
-    const float cu = lr * regU, ci = lr * regI;
+    const HwRate rate{lr, regU, regI, d_driver_state};
     switch (ld) {
-        case 32: return launch_hogwild<16, 2>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, lr, cu, ci, d_loss, variant, st);
-        case 64: return launch_hogwild<16, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, lr, cu, ci, d_loss, variant, st);
-        case 128: return launch_hogwild<32, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, lr, cu, ci, d_loss, variant, st);
-        default: return launch_hogwild<64, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, lr, cu, ci, d_loss, variant, st);
+        case 32: return launch_hogwild<16, 2>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, rate, d_loss, variant, st);
+        case 64: return launch_hogwild<16, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, rate, d_loss, variant, st);
+        case 128: return launch_hogwild<32, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, rate, d_loss, variant, st);
+        default: return launch_hogwild<64, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, rate, d_loss, variant, st);
     }
 }
 
 int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int32_t d, int32_t ld, const int32_t *d_u,
                                     const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
                                     int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
-                                    double *d_loss, void *stream) {
+                                    double *d_loss, const double *d_driver_state, void *stream) {
     QREC_REQUIRE(d_P && d_Q && d_loss && n >= 0, "qrec_bpr_sgd_hogwild_item_major: null argument");
     QREC_REQUIRE(n == 0 || (d_u && d_i && d_j), "qrec_bpr_sgd_hogwild_item_major: null index array");
     QREC_REQUIRE(ld >= d && d >= 1, "qrec_bpr_sgd_hogwild_item_major: need ld >= d >= 1");
@@ -567,12 +589,12 @@ int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int32_t d, int32_t l
     if (n == 0) return QREC_OK;
     const uint32_t full = 0xffffffffu;
     hipStream_t st = as_stream(stream);
-    const float cu = lr * regU, ci = lr * regI;
+    const HwRate rate{lr, regU, regI, d_driver_state};
     switch (ld) {
-        case 32: return launch_hogwild_item<16, 2>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, lr, cu, ci, d_loss, st);
-        case 64: return launch_hogwild_item<16, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, lr, cu, ci, d_loss, st);
-        case 128: return launch_hogwild_item<32, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, lr, cu, ci, d_loss, st);
-        default: return launch_hogwild_item<64, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, lr, cu, ci, d_loss, st);
+        case 32: return launch_hogwild_item<16, 2>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, st);
+        case 64: return launch_hogwild_item<16, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, st);
+        case 128: return launch_hogwild_item<32, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, st);
+        default: return launch_hogwild_item<64, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, st);
     }
 }
 

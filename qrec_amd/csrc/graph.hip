@@ -115,7 +115,10 @@ __global__ __launch_bounds__(256) void spmm_kernel(
     }
 }
 
-// long rows: Y[row] = partial[first] + partial[first+1] + ... (slice order), then the epilogue
+// long rows: Y[row] = sum of the row's partial slots, then the epilogue.  One WAVEFRONT per long row: the
+// row's slots are dealt round-robin to the wavefront's GPW groups (8 independent loads in flight each), each
+// group adds its slots in slice order, and the group sums are folded in a fixed butterfly -- deterministic,
+// and the dependent-load chain of a 6k-neighbour row (49 slots) is 2 rounds instead of 7.
 template <int LPR>
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restrict__ long_row,
                                                          const int32_t *__restrict__ long_first,
@@ -126,21 +129,26 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restri
 #pragma clang fp contract(off)
     constexpr int GPW = kWave / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
-    const int64_t gid = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
-    if (gid >= n_long) return;
-    const int first = long_first[gid], cnt = long_count[gid];
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= n_long) return;
+    const int first = long_first[wid], cnt = long_count[wid];
     const float *p = partial + (int64_t)first * (4 * LPR) + 4 * r;
-    f32x4 acc = *reinterpret_cast<const f32x4 *>(p);
-    int k = 1;
-    for (; k + 8 <= cnt; k += 8) {  // 8 independent loads in flight, then add in slice order
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int k = g;
+    for (; k + 7 * GPW < cnt; k += 8 * GPW) {
         f32x4 v[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = *reinterpret_cast<const f32x4 *>(p + (int64_t)(k + q) * (4 * LPR));
+        for (int q = 0; q < 8; q++) v[q] = *reinterpret_cast<const f32x4 *>(p + (int64_t)(k + q * GPW) * (4 * LPR));
 #pragma unroll
         for (int q = 0; q < 8; q++) acc = acc + v[q];
     }
-    for (; k < cnt; k++) acc = acc + *reinterpret_cast<const f32x4 *>(p + (int64_t)k * (4 * LPR));
-    spmm_epilogue<LPR>(acc, long_row[gid], r, Y, addend, addend_scale, accum);
+    for (; k < cnt; k += GPW) acc = acc + *reinterpret_cast<const f32x4 *>(p + (int64_t)k * (4 * LPR));
+#pragma unroll
+    for (int m = LPR; m < kWave; m <<= 1) {
+        acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
+        acc.z += __shfl_xor(acc.z, m, kWave); acc.w += __shfl_xor(acc.w, m, kWave);
+    }
+    if (g == 0) spmm_epilogue<LPR>(acc, long_row[wid], r, Y, addend, addend_scale, accum);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -239,7 +247,7 @@ int launch_spmm(const int32_t *seg_row, const int64_t *seg_beg, const int32_t *s
                        seg_slot, n_segs, indices, values, X, Y, partial, addend, addend_scale, accum, x_row_mask);
     QREC_LAUNCH_CHECK();
     if (n_long > 0) {
-        hipLaunchKernelGGL((spmm_fixup_kernel<LPR>), dim3((unsigned)((n_long + 4 * GPW - 1) / (4 * GPW))), dim3(256),
+        hipLaunchKernelGGL((spmm_fixup_kernel<LPR>), dim3((unsigned)((n_long + 3) / 4)), dim3(256),
                            0, st, long_row, long_first, long_count, n_long, partial, Y, addend, addend_scale, accum);
         QREC_LAUNCH_CHECK();
     }

@@ -31,7 +31,113 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const T *__restrict__ x, int
     if (threadIdx.x == 0) atomicAdd(out, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
 
+// Epoch close of the numpy-path models, entirely on the device (model/ranking/BPR.py:40 + isConverged /
+// updateLearningRate, base/iterativeRecommender.py:56-63,88-104):
+//   loss = stats[0] + regU*sum(P*P) + regI*sum(Q*Q);  NaN/Inf -> failed (the reference exits)
+//   converged = |lastLoss - loss| < tol;  if not: epoch > 1 -> lr *= 1.05 if |lastLoss| > |loss| else 0.5, cap at max_lr
+// Every block reduces its share of both tables; the last block to arrive (ticket counter) takes the decision,
+// appends the epoch to the log and clears the accumulators for the next epoch.
+template <typename T, typename V4>
+__device__ inline double block_sumsq(const T *__restrict__ x, int64_t n_elems, double *s_part) {
+    double acc = 0.0;
+    const int64_t n4 = n_elems >> 2;
+    const V4 *x4 = reinterpret_cast<const V4 *>(x);
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += (int64_t)gridDim.x * blockDim.x) {
+        const V4 v = x4[k];
+        acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, kWave);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    return s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+template <typename T, typename V4>
+__global__ __launch_bounds__(256) void epoch_close_kernel(const T *__restrict__ P, int64_t p_elems,
+                                                          const T *__restrict__ Q, int64_t q_elems,
+                                                          double *__restrict__ stats, double *__restrict__ state,
+                                                          double regU, double regI, double max_lr, double tol,
+                                                          double *__restrict__ log, int64_t log_capacity) {
+    if (state[QREC_DRV_CONVERGED] != 0.0 || state[QREC_DRV_FAILED] != 0.0) return;
+    __shared__ double s_part[4];
+    __shared__ bool s_last;
+    const double sp = block_sumsq<T, V4>(P, p_elems, s_part);
+    const double sq = block_sumsq<T, V4>(Q, q_elems, s_part);
+    // per-block partials in the stats buffer (plain stores, made visible by the fence), ONE same-address
+    // atomic per block (the ticket); the last block adds the partials in block order: deterministic sums
+    double *part = stats + QREC_STATS_PARTIALS;
+    unsigned int *ticket = reinterpret_cast<unsigned int *>(stats + 3);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(part + 2 * blockIdx.x, sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(part + 2 * blockIdx.x + 1, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    double tp = 0.0, tq = 0.0;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
+        tp += __hip_atomic_load(part + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tq += __hip_atomic_load(part + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { tp += __shfl_xor(tp, m, kWave); tq += __shfl_xor(tq, m, kWave); }
+    __shared__ double s_tot[2][4];
+    if ((threadIdx.x & 63) == 0) { s_tot[0][threadIdx.x >> 6] = tp; s_tot[1][threadIdx.x >> 6] = tq; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    tp = s_tot[0][0] + s_tot[0][1] + s_tot[0][2] + s_tot[0][3];
+    tq = s_tot[1][0] + s_tot[1][1] + s_tot[1][2] + s_tot[1][3];
+    const double nll = atomicAdd(stats + 0, 0.0);     // the SGD kernels' f64 atomics live memory-side
+    const double loss = nll + regU * tp + regI * tq;
+    const double last = state[QREC_DRV_LAST_LOSS], lr_used = state[QREC_DRV_LR];
+    const int64_t epoch = (int64_t)state[QREC_DRV_EPOCHS] + 1;
+    double lr = lr_used;
+    const bool finite = loss == loss && fabs(loss) <= 1.79769313486231570e308;
+    const bool converged = finite && fabs(last - loss) < tol;
+    if (finite && !converged) {
+        if (epoch > 1) lr *= fabs(last) > fabs(loss) ? 1.05 : 0.5;
+        if (max_lr > 0.0 && lr > max_lr) lr = max_lr;
+    }
+    state[QREC_DRV_LR] = lr;
+    state[QREC_DRV_LAST_LOSS] = loss;
+    state[QREC_DRV_EPOCHS] = (double)epoch;
+    state[QREC_DRV_CONVERGED] = converged ? 1.0 : 0.0;
+    state[QREC_DRV_FAILED] = finite ? 0.0 : 1.0;
+    if (log && epoch <= log_capacity) {
+        double *e = log + (epoch - 1) * QREC_DRV_LOG_WORDS;
+        e[0] = loss; e[1] = lr_used; e[2] = nll; e[3] = last - loss; e[4] = tp; e[5] = tq;
+    }
+    stats[0] = 0.0; stats[1] = tp; stats[2] = tq;
+    *ticket = 0u;
+}
+
 }  // namespace
+
+extern "C" int qrec_epoch_close(const void *d_P, int64_t p_rows, const void *d_Q, int64_t q_rows, int dtype, int32_t ld,
+                                double *d_stats, double *d_state, double regU, double regI, double max_lr,
+                                double tol, double *d_log, int64_t log_capacity, void *stream) {
+    QREC_REQUIRE(d_P && d_Q && d_stats && d_state && p_rows >= 0 && q_rows >= 0 && ld >= 4 && ld % 4 == 0,
+                 "qrec_epoch_close: bad arguments");
+    QREC_REQUIRE(dtype == QREC_F32 || dtype == QREC_F64, "qrec_epoch_close: bad dtype %d", dtype);
+    QREC_REQUIRE(log_capacity == 0 || d_log, "qrec_epoch_close: log capacity without a log");
+    hipStream_t st = as_stream(stream);
+    const int64_t pe = p_rows * (int64_t)ld, qe = q_rows * (int64_t)ld;
+    int64_t blocks = ((pe > qe ? pe : qe) / 4 + 255) / 256;
+    if (blocks > QREC_STATS_MAX_BLOCKS) blocks = QREC_STATS_MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    if (dtype == QREC_F32)
+        hipLaunchKernelGGL((epoch_close_kernel<float, float4>), dim3((unsigned)blocks), dim3(256), 0, st, (const float *)d_P, pe,
+                           (const float *)d_Q, qe, d_stats, d_state, regU, regI, max_lr, tol, d_log, log_capacity);
+    else
+        hipLaunchKernelGGL((epoch_close_kernel<double, double4>), dim3((unsigned)blocks), dim3(256), 0, st, (const double *)d_P, pe,
+                           (const double *)d_Q, qe, d_stats, d_state, regU, regI, max_lr, tol, d_log, log_capacity);
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
 
 extern "C" int qrec_sumsq(const void *d_x, int dtype, int64_t rows, int32_t d, int32_t ld,
                           double *d_out, void *stream) {

@@ -65,8 +65,10 @@ class BprSgd:
     order, model/ranking/BPR.py:31-34); negatives ``j`` come per epoch either from the
     host (exact CPython stream) or from the device Philox sampler.
 
-    Device-side epoch statistics live in one 3-double buffer (sum -log sigma, sum P*P,
-    sum Q*Q) so that an epoch costs a single 24-byte read-back.  The Philox sampler for
+    Device-side epoch statistics live in one small buffer (sum -log sigma, sum P*P, sum Q*Q, ticket) so
+    that an epoch costs a single 24-byte read-back -- or none at all: with ``start_device_driver`` the
+    epoch's loss, the convergence test and the bold-driver learning-rate update (BPR.py:40,
+    base/iterativeRecommender.py:56-63,88-104) run on the device and epochs are enqueued back to back.  The Philox sampler for
     epoch k+1 runs on a side stream underneath the SGD kernel of epoch k (double-buffered
     negatives); the SGD kernel is bound by the L2 atomic units, the sampler by integer ALU,
     so they overlap almost perfectly."""
@@ -90,12 +92,17 @@ class BprSgd:
         self.d_i = DeviceBuffer.from_numpy(i)
         self.d_j = DeviceBuffer(max(self.n, 1), np.int32)
         self.d_j_next = None
-        self.d_stats = DeviceBuffer.zeros(3, np.float64)
+        self.d_stats = DeviceBuffer.zeros(capi.STATS_WORDS, np.float64)
         self.d_loss = self.d_stats          # element 0
         self._pos_dev = None
         self._side = None
         self._sampled = None
         self._prefetched_epoch = None
+        self._sgd_start = None
+        self._own_events = None
+        self._consumed = [None, None]        # events: "the SGD kernel that read [d_j, d_j_next] has finished"
+        self.d_drv = self.d_log = None
+        self._log_capacity = 0
         if pos is not None:
             srt = pos.sorted_rows()
             self._pos_dev = (DeviceBuffer.from_numpy(srt.indptr), DeviceBuffer.from_numpy(srt.indices))
@@ -129,6 +136,10 @@ class BprSgd:
         if self._side is None:
             self._side = capi.Stream(); self._sampled = capi.Event()
             self.d_j_next = DeviceBuffer(max(self.n, 1), np.int32)
+        if self._consumed[1] is not None:      # the spare buffer may still be read by an enqueued SGD kernel
+            capi.stream_wait_event(self._side, self._consumed[1])
+        if self._sgd_start is not None:
+            capi.stream_wait_event(self._side, self._sgd_start)
         capi.philox_bpr_sample(self._pos_dev[0], self._pos_dev[1], self.d_u, self.n, self.t.n_items,
                                seed, epoch, self.d_j_next, self._side)
         self._sampled.record(self._side)
@@ -140,7 +151,15 @@ class BprSgd:
             raise RuntimeError(f"negatives of epoch {epoch} were not prefetched")
         capi.stream_wait_event(stream, self._sampled)
         self.d_j, self.d_j_next = self.d_j_next, self.d_j
+        self._consumed.reverse()
         self._prefetched_epoch = None
+
+    def mark_negatives_consumed(self, stream=None):
+        """Record, after enqueueing the SGD kernel that reads the current negatives, that their buffer is
+        free again once the stream gets here (only needed when epochs are enqueued without host syncs)."""
+        if self._consumed[0] is None:
+            self._consumed[0] = capi.Event()
+        self._consumed[0].record(stream)
 
     # -- epochs ------------------------------------------------------------------------------------
     def epoch_ordered(self, lr: float, regU: float, regI: float, stream=None) -> float:
@@ -149,7 +168,7 @@ class BprSgd:
             raise RuntimeError("the order-exact kernel needs the reference's user-major order")
         capi.bpr_sgd_ordered(self.t.P, self.t.Q, self.t.code, self.t.d, self.t.ld, self.d_u, self.d_i,
                              self.d_j, self.n, lr, regU, regI, self.d_stats, stream)
-        return float(self.d_stats.numpy(stream)[0])
+        return float(self.d_stats.head(1, stream)[0])
 
     def epoch_throughput_async(self, lr: float, regU: float, regI: float, chunk: int = 32,
                                variant: int = capi.HW_DEFAULT, stream=None, groups: int = 0, flush_every: int = 8):
@@ -167,6 +186,54 @@ class BprSgd:
             capi.bpr_sgd_hogwild(self.t.P, self.t.Q, self.t.d, self.t.ld, self.d_u, self.d_i, self.d_j,
                                  self.n, chunk, groups, lr, regU, regI, self.d_stats, variant, stream)
 
+    # -- device-resident loss / convergence / learning-rate schedule ------------------------------------
+    def start_device_driver(self, lr0: float, log_capacity: int = 1024):
+        """Put the bold-driver state (include/qrec_hip.h QREC_DRV_*) on the device: lRate = lr0, lastLoss = 0."""
+        st = np.zeros(capi.DRV_WORDS, np.float64); st[capi.DRV_LR] = lr0
+        self.d_drv = DeviceBuffer.from_numpy(st)
+        self.d_log = DeviceBuffer.zeros((max(log_capacity, 1), capi.DRV_LOG_WORDS), np.float64)
+        self._log_capacity = log_capacity
+        self._own_events = [capi.Event() for _ in range(4)]
+        self.d_stats.fill_bytes(0)
+
+    def epoch_device_async(self, regU: float, regI: float, max_lr: float, tol: float = 1e-3, chunk: int = 32,
+                           variant: int = capi.HW_DEFAULT, stream=None, groups: int = 0, flush_every: int = 8,
+                           events=None):
+        """One throughput epoch with everything after it (BPR.py:40 loss terms, isConverged,
+        updateLearningRate) enqueued on the device: no host synchronisation.  ``events`` = (before, after)
+        capi.Event pair recorded around the SGD kernel."""
+        if self.d_drv is None:
+            raise RuntimeError("call start_device_driver() first")
+        t = self.t
+        # Two event records per epoch.  `start` (before the SGD grid) releases the next epoch's sampler: it is
+        # dispatched just after this epoch's SGD grid -- measured, a sampler that already sits on the CUs when
+        # the (one block per CU, persistent) SGD grid arrives skews its placement and costs 30% (0.78 vs 0.59 ms).
+        # `end` (after it) frees the negatives buffer for the sampler after next.
+        start, end = events if events else (self._own_events[0], self._own_events[1])
+        start.record(stream)
+        self._sgd_start = start
+        if self.schedule == "item":
+            capi.bpr_sgd_hogwild_item_major(t.P, t.Q, t.d, t.ld, self.d_u, self.d_i, self.d_j, self.n, chunk, groups,
+                                            flush_every, 0.0, regU, regI, self.d_stats, stream, self.d_drv)
+        else:
+            capi.bpr_sgd_hogwild(t.P, t.Q, t.d, t.ld, self.d_u, self.d_i, self.d_j, self.n, chunk, groups, 0.0, regU,
+                                 regI, self.d_stats, variant, stream, self.d_drv)
+        end.record(stream)
+        self._consumed[0] = end
+        self._own_events.reverse()
+        capi.epoch_close(t.P, t.n_users, t.Q, t.n_items, t.code, t.ld, self.d_stats, self.d_drv, regU, regI, max_lr,
+                         tol, self.d_log, self._log_capacity, stream)
+
+    def driver_state(self, stream=None) -> dict:
+        s = self.d_drv.numpy(stream)
+        return {"lr": float(s[capi.DRV_LR]), "last_loss": float(s[capi.DRV_LAST_LOSS]), "epochs": int(s[capi.DRV_EPOCHS]),
+                "converged": bool(s[capi.DRV_CONVERGED]), "failed": bool(s[capi.DRV_FAILED])}
+
+    def driver_log(self, stream=None) -> np.ndarray:
+        """rows {loss, lr used, sum(-log sigma), lastLoss - loss, sum P*P, sum Q*Q, -, -} of the epochs closed so far"""
+        n = min(self.driver_state(stream)["epochs"], self._log_capacity)
+        return self.d_log.numpy(stream)[:n].copy()
+
     def enqueue_epoch_stats(self, stream=None):
         """sum P*P and sum Q*Q into the stats buffer, next to the epoch's sum(-log sigma) -- BPR.py:40,53"""
         t = self.t
@@ -174,7 +241,7 @@ class BprSgd:
         capi.sumsq(t.Q, t.code, t.n_items, t.d, t.ld, self.d_stats.ptr + 16, stream)
 
     def read_epoch_stats(self, stream=None):
-        s = self.d_stats.numpy(stream)
+        s = self.d_stats.head(3, stream)
         return float(s[0]), float(s[1]), float(s[2])
 
     def epoch_stats(self, stream=None):
@@ -184,7 +251,7 @@ class BprSgd:
         return self.read_epoch_stats(stream)
 
     def loss(self, stream=None) -> float:
-        return float(self.d_stats.numpy(stream)[0])
+        return float(self.d_stats.head(1, stream)[0])
 
 
 class MfSgd:
@@ -213,7 +280,7 @@ class MfSgd:
         capi.mf_sgd_ordered(self.t.P, self.t.Q, self.t.code, self.t.d, self.t.ld, self.d_u, self.d_i,
                             self.d_r, self.n, lr, self.d_stats, stream, self.variant, regU, regI, self.d_Bu,
                             self.d_Bi, regB, global_mean)
-        return float(self.d_stats.numpy(stream)[0])
+        return float(self.d_stats.head(1, stream)[0])
 
     def sumsq_terms(self, stream=None):
         """(sum P^2, sum Q^2, sum Bu^2, sum Bi^2) for the epoch-end regularisers (PMF.py:25, SVD.py:32-33)"""

@@ -54,6 +54,10 @@ class BPR(IterativeRecommender):
         sgd = BprSgd(tables, u, i, pos, schedule=self.schedule)
         n_items = len(self.data.item)
         epoch = 0
+        if self.mode == "throughput" and self.ranking.isMainOn():
+            self._train_throughput_pipelined(sgd)
+            self.P, self.Q = tables.download(np.float64)
+            return
         if self.mode == "throughput":
             sgd.prefetch_negatives_device(self.sampler_seed, 0)
         while epoch < self.maxEpoch:
@@ -74,6 +78,46 @@ class BPR(IterativeRecommender):
             if self.isConverged(epoch):
                 break
         self.P, self.Q = tables.download(np.float64)
+
+    def _train_throughput_pipelined(self, sgd, depth: int = 3):
+        """Throughput mode without a host round trip per epoch: the epoch's loss (BPR.py:40,53), isConverged and
+        updateLearningRate (base/iterativeRecommender.py:56-63,88-104) run on the device (qrec_epoch_close); the
+        host enqueues epochs ``depth`` ahead and prints the reference's per-epoch line from the device log as the
+        epochs retire.  Epochs enqueued past the converged one are no-ops on the device, so the tables are
+        those of the converged epoch exactly as if the loop had stopped there.  (The reference's per-epoch
+        ``shuffle(trainingData)`` has no effect on this model's visiting order and is not replayed here.)"""
+        sgd.start_device_driver(self.lRate, log_capacity=self.maxEpoch)
+        sgd.prefetch_negatives_device(self.sampler_seed, 0)
+        closed = []
+
+        def retire(k):
+            """print epoch k+1 once the device has closed it; True when training is over"""
+            closed[k].sync()
+            st = sgd.driver_state()
+            if st["failed"]:
+                print("Loss = NaN or Infinity: current settings does not fit the recommender! Change the settings and try again!")
+                raise SystemExit(-1)
+            if st["epochs"] <= k:            # an earlier epoch converged: this one never ran
+                return True
+            loss, lr_used, _, delta = sgd.d_log.numpy()[k, :4]
+            self.loss, self.lastLoss = float(loss), float(loss)
+            print("%s %s epoch %d: loss = %.4f, delta_loss = %.5f learning_Rate = %.5f"
+                  % (self.modelName, self.foldInfo, k + 1, loss, delta, lr_used))
+            return st["converged"] and st["epochs"] == k + 1
+
+        done, retired = False, 0
+        for epoch in range(self.maxEpoch):
+            sgd.take_prefetched_negatives(epoch)
+            sgd.epoch_device_async(self.regU, self.regI, self.maxLRate, tol=1e-3)
+            sgd.prefetch_negatives_device(self.sampler_seed, epoch + 1)      # released under this epoch's SGD kernel
+            ev = capi.Event(); ev.record(); closed.append(ev)
+            if epoch >= depth:
+                done = retire(retired); retired += 1
+                if done:
+                    break
+        while not done and retired < len(closed):
+            done = retire(retired); retired += 1
+        self.lRate = sgd.driver_state()["lr"]
 
     def trainModel_tf(self):
         """The reference's TensorFlow variant (model/ranking/BPR.py:77-96), taken when the conf has
