@@ -276,6 +276,16 @@ int qrec_score_topk(const void *d_U, const void *d_V, int dtype, int32_t d, int3
                     const int32_t *d_rated_items, int32_t N, void *d_scratch, int32_t *d_ids_out,
                     void *d_scores_out, void *stream);
 
+/* Measure.hits (util/measure.py:15-21) + the DCG sum of Measure.NDCG (util/measure.py:70-82) over the lists of a
+ * previous qrec_score_topk, still on the device: for batch row b (user d_user_ids[b]) and its first n_cut ids,
+ * d_hits_out[b] = how many are among the user's test items (CSR over ALL users, item ids ascending inside a
+ * row, items unknown to the training set left out), d_dcg_out[b] = sum of d_discount[pos] over the hit
+ * positions, added in rank order.  The caller passes discount[pos] = 1/log(pos+2) as ITS doubles, so the
+ * per-user values -- and the Precision/Recall/NDCG strings built from them -- equal the reference's bit for bit. */
+int qrec_rank_hits(const int32_t *d_ids, int32_t n_batch_users, int32_t row_stride, int32_t n_cut,
+                   const int32_t *d_user_ids, const int64_t *d_test_indptr, const int32_t *d_test_items,
+                   const double *d_discount, int32_t *d_hits_out, double *d_dcg_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,11 +87,7 @@ class IterativeRecommender(Recommender):
         recList = {}
         if warm:
             U, V = np.ascontiguousarray(U), np.ascontiguousarray(V)
-            ranker = getattr(self, "_ranker", None)
-            if ranker is not None and (ranker.n_users, ranker.n_items, ranker.d, ranker.dtype) == (U.shape[0], V.shape[0], U.shape[1], U.dtype):
-                ranker.update_tables(U, V)             # per-epoch evaluation: keep buffers, re-upload tables
-            else:
-                ranker = self._ranker = DeviceRanker(U, V, self.data.rated_csr())
+            ranker = self._device_ranker(U, V)
             uid = np.fromiter((self.data.user[u] for u in warm), dtype=np.int32, count=len(warm))
             ids, scores = ranker.topk(uid, min(N, self.num_items))
             id2item = self.data.id2item
@@ -102,6 +98,64 @@ class IterativeRecommender(Recommender):
                 k_ids, k_sc = find_k_largest(N, [self.data.globalMean] * self.num_items)
                 recList[u] = [(self.data.id2item[i], s) for i, s in zip(k_ids, k_sc)]
         return {u: recList[u] for u in users}   # testSet_u order, as the reference builds it
+
+    def _device_ranker(self, U, V):
+        ranker = getattr(self, "_ranker", None)
+        if ranker is not None and (ranker.n_users, ranker.n_items, ranker.d, ranker.dtype) == (U.shape[0], V.shape[0], U.shape[1], U.dtype):
+            ranker.update_tables(U, V)             # per-epoch evaluation: keep buffers, re-upload tables
+        else:
+            from ..ranking import DeviceRanker
+            ranker = self._ranker = DeviceRanker(U, V, self.data.rated_csr())
+        return ranker
+
+    def rank_measure_all_test_users(self, top, N):
+        """Measure.rankingMeasure(testSet_u, recList, top) (base/recommender.py:167, util/measure.py:24-49) without
+        the recList: per-user hit counts and DCG sums are taken from the top-N lists on the device
+        (qrec_rank_hits), cold users (constant-score lists, base/iterativeRecommender.py:79-80) on the host."""
+        from ..interactions import user_item_csr
+        from ..ranking import ranking_measure_strings
+        from ..util.qmath import find_k_largest
+        import math
+        U, V = self.ranking_tables()
+        U, V = np.ascontiguousarray(U), np.ascontiguousarray(V)
+        users = list(self.data.testSet_u)
+        cache = getattr(self, "_test_cache", None)
+        if cache is None:
+            warm_pos = [k for k, u in enumerate(users) if self.data.containsUser(u)]
+            uid, iid = [], []
+            for k in warm_pos:
+                row = self.data.user[users[k]]
+                for item in self.data.testSet_u[users[k]]:
+                    if item in self.data.item:
+                        uid.append(row); iid.append(self.data.item[item])
+            test = user_item_csr(np.array(uid, np.int32), np.array(iid, np.int32), np.ones(len(uid)), U.shape[0], V.shape[0])
+            cache = self._test_cache = dict(
+                warm_pos=np.array(warm_pos, np.int64), test=test, lens=[len(self.data.testSet_u[u]) for u in users],
+                warm_uid=np.fromiter((self.data.user[users[k]] for k in warm_pos), dtype=np.int32, count=len(warm_pos)))
+        cuts = sorted({min(n, N, self.num_items) for n in top})
+        per_n = {n: ([0] * len(users), [0.0] * len(users)) for n in top}
+        if cache["warm_uid"].size:
+            ranker = self._device_ranker(U, V)
+            if ranker.test is None:
+                ranker.set_test(cache["test"])
+            _, _, per_cut = ranker.topk(cache["warm_uid"], min(N, self.num_items), cuts=cuts, want_lists=False)
+            for n in top:
+                hits, dcg = per_cut[min(n, N, self.num_items)]
+                for k, h, x in zip(cache["warm_pos"].tolist(), hits.tolist(), dcg.tolist()):
+                    per_n[n][0][k] = h; per_n[n][1][k] = x
+        warm = set(cache["warm_pos"].tolist())
+        for k, u in enumerate(users):
+            if k in warm:
+                continue
+            ids, _ = find_k_largest(N, [self.data.globalMean] * self.num_items)
+            truth = self.data.testSet_u[u]
+            for n in top:
+                h, x = 0, 0.0
+                for pos, iid in enumerate(ids[:n]):
+                    if self.data.id2item[iid] in truth:
+                        h += 1; x += 1.0 / math.log(pos + 2)
+                per_n[n][0][k] = h; per_n[n][1][k] = x
+        return ranking_measure_strings(cache["lens"], per_n, top)
 
     def shuffle_training_data(self):
         """``shuffle(self.data.trainingData)`` (base/iterativeRecommender.py:101) with the
@@ -148,8 +202,9 @@ class IterativeRecommender(Recommender):
         only, remembers the best epoch and snapshots the model through saveModel()."""
         N = max(int(x) for x in self.ranking["-topN"].split(","))
         print("Evaluating...")
-        recList = self.rank_all_test_users(N)
-        measure = Measure.rankingMeasure(self.data.testSet_u, recList, [N])
+        measure = self.rank_measure_all_test_users([N], N)
+        if measure is None:
+            measure = Measure.rankingMeasure(self.data.testSet_u, self.rank_all_test_users(N), [N])
         performance = {}
         for m in measure[1:]:
             k, v = m.strip().split(":")

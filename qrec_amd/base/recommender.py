@@ -149,8 +149,27 @@ class Recommender:
                 print(self.modelName, self.foldInfo, "progress:" + str(pos) + "/" + str(total))
         return recList
 
+    def rank_measure_all_test_users(self, top, N):
+        """Measure strings for all test users without materialising the lists, or None when the model has no
+        device-resident tables (the generic host loop then runs)."""
+        return None
+
+    def _publish_measure(self, stamp):
+        self.log.add("###Evaluation Results###")
+        self.log.add(self.measure)
+        FileIO.writeFile(self.output["-dir"], self.config["model.name"] + "@" + stamp + "-measure" + self.foldInfo + ".txt", self.measure)
+        print("The result of %s %s:\n%s" % (self.modelName, self.foldInfo, "".join(self.measure)))
+
     def evalRanking(self):
         top, N = self._top_n_setting()
+        if not self.isOutput and not self.evalSettings.contains("-predict"):
+            # nobody reads the lists (no result file, no -predict): hits and DCG sums come straight from the
+            # device-resident top-N lists, the strings are the reference's to the last digit
+            fast = self.rank_measure_all_test_users(top, N)
+            if fast is not None:
+                self.measure = fast
+                self._publish_measure(strftime("%Y-%m-%d %H-%M-%S", localtime(time())))
+                return
         self.recOutput.append("userId: recommendations in (itemId, ranking score) pairs, * means the item matches.\n")
         recList = self.rank_all_test_users(N)
         for user, recs in recList.items():
@@ -165,10 +184,7 @@ class Recommender:
         if self.evalSettings.contains("-predict"):
             sys.exit(0)
         self.measure = Measure.rankingMeasure(self.data.testSet_u, recList, top)
-        self.log.add("###Evaluation Results###")
-        self.log.add(self.measure)
-        FileIO.writeFile(outDir, self.config["model.name"] + "@" + stamp + "-measure" + self.foldInfo + ".txt", self.measure)
-        print("The result of %s %s:\n%s" % (self.modelName, self.foldInfo, "".join(self.measure)))
+        self._publish_measure(stamp)
 
     # ---- template method ------------------------------------------------------------------------------
     def execute(self):

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "qrec_copy_cols": [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _i32, _vp],
     "qrec_score_topk_scratch_bytes": [C.c_int, _i32, _i32, _vp],
     "qrec_score_topk": [_vp, _vp, C.c_int, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
+    "qrec_rank_hits": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 _RESTYPES = {"qrec_last_error": C.c_char_p}
 
@@ -381,6 +382,12 @@ def score_topk(d_U, d_V, dtype: int, d: int, ld: int, n_items: int, d_user_ids, 
     _check(load().qrec_score_topk(_dp(d_U), _dp(d_V), dtype, d, ld, n_items, _dp(d_user_ids), n_batch_users,
                                   _dp(d_rated_indptr), _dp(d_rated_items), N, _dp(d_scratch), _dp(d_ids_out),
                                   _dp(d_scores_out), _sh(stream)))
+
+
+def rank_hits(d_ids, n_batch_users: int, row_stride: int, n_cut: int, d_user_ids, d_test_indptr, d_test_items,
+              d_discount, d_hits_out, d_dcg_out, stream=None):
+    _check(load().qrec_rank_hits(_dp(d_ids), n_batch_users, row_stride, n_cut, _dp(d_user_ids), _dp(d_test_indptr),
+                                 _dp(d_test_items), _dp(d_discount), _dp(d_hits_out), _dp(d_dcg_out), _sh(stream)))
 
 
 def spmm_csr(plan, d_X, d_Y, ld: int, d_addend=None, addend_scale: float = 0.0, d_accum=None, stream=None,

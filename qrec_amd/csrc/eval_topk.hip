@@ -284,6 +284,36 @@ int run_score_topk(const void *U, const void *V, int d, int ld, int n_items, con
     return QREC_OK;
 }
 
+// Measure.hits (util/measure.py:15-21) and the DCG sum of Measure.NDCG (util/measure.py:70-82) for the lists a
+// previous qrec_score_topk left on the device: one lane per user walks its first n_cut recommendations in rank
+// order, looks each id up in the user's sorted test items and adds the caller's discount[pos] (the host passes
+// Python's own 1/math.log(pos+2) doubles) in that order -- the same sequential fp64 sum the reference runs.
+__global__ __launch_bounds__(256) void rank_hits_kernel(const int32_t *__restrict__ ids, int n_users, int row_stride,
+                                                        int n_cut, const int32_t *__restrict__ user_ids,
+                                                        const int64_t *__restrict__ test_indptr,
+                                                        const int32_t *__restrict__ test_items,
+                                                        const double *__restrict__ discount,
+                                                        int32_t *__restrict__ hits_out, double *__restrict__ dcg_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_users) return;
+    const int u = user_ids[b];
+    const int64_t lo0 = test_indptr[u], hi0 = test_indptr[u + 1];
+    int hits = 0;
+    double dcg = 0.0;
+    for (int pos = 0; pos < n_cut; pos++) {
+        const int item = ids[(int64_t)b * row_stride + pos];
+        if (item < 0) break;                       // -1 padding: fewer than N items exist
+        int64_t lo = lo0, hi = hi0;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (test_items[mid] < item) lo = mid + 1; else hi = mid;
+        }
+        if (lo < hi0 && test_items[lo] == item) { hits++; dcg += discount[pos]; }
+    }
+    hits_out[b] = hits;
+    dcg_out[b] = dcg;
+}
+
 }  // namespace
 
 extern "C" {
@@ -313,6 +343,19 @@ int qrec_score_topk(const void *d_U, const void *d_V, int dtype, int32_t d, int3
                                         d_rated_items, K, d_scratch, d_ids_out, d_scores_out, st)
                : run_score_topk<float>(d_U, d_V, d, ld, n_items, d_user_ids, n_batch_users, d_rated_indptr,
                                        d_rated_items, K, d_scratch, d_ids_out, d_scores_out, st);
+}
+
+int qrec_rank_hits(const int32_t *d_ids, int32_t n_batch_users, int32_t row_stride, int32_t n_cut,
+                   const int32_t *d_user_ids, const int64_t *d_test_indptr, const int32_t *d_test_items,
+                   const double *d_discount, int32_t *d_hits_out, double *d_dcg_out, void *stream) {
+    QREC_REQUIRE(d_ids && d_user_ids && d_test_indptr && d_discount && d_hits_out && d_dcg_out, "qrec_rank_hits: null argument");
+    QREC_REQUIRE(n_batch_users >= 0 && n_cut >= 1 && row_stride >= n_cut, "qrec_rank_hits: bad sizes");
+    if (n_batch_users == 0) return QREC_OK;
+    hipLaunchKernelGGL(rank_hits_kernel, dim3((unsigned)((n_batch_users + 255) / 256)), dim3(256), 0, as_stream(stream), d_ids,
+                       n_batch_users, row_stride, n_cut, d_user_ids, d_test_indptr, d_test_items, d_discount, d_hits_out,
+                       d_dcg_out);
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
 }
 
 }  // extern "C"

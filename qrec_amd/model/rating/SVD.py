@@ -51,3 +51,6 @@ class SVD(IterativeRecommender):
     def rank_all_test_users(self, N):
         from ...base.recommender import Recommender
         return Recommender.rank_all_test_users(self, N)
+
+    def rank_measure_all_test_users(self, top, N):
+        return None

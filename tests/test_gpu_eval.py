@@ -104,3 +104,53 @@ def test_yelp_shape_full_eval_properties():
         r = set(ind[indptr[u]:indptr[u + 1]].tolist())
         for i, s in zip(ids[u], sc[u]):
             assert (i not in r) or s == 0.0
+
+
+def test_rank_hits_kernel_equals_python_measures():
+    """qrec_rank_hits on device-resident lists vs Measure.hits / Measure.NDCG (util/measure.py:15-21,70-82)
+    evaluated on the same lists: hit counts equal, DCG sums bit-identical, for several list lengths."""
+    import math
+    rng = np.random.default_rng(5)
+    U_, I_, d, N = 700, 900, 16, 20
+    U = rng.standard_normal((U_, d)).astype(np.float32); V = rng.standard_normal((I_, d)).astype(np.float32)
+    tu = rng.integers(0, U_, 6000).astype(np.int32); ti = rng.integers(0, I_, 6000).astype(np.int32)
+    test = user_item_csr(tu, ti, np.ones(tu.size), U_, I_)
+    rk = DeviceRanker(U, V, None); rk.set_test(test)
+    users = rng.permutation(U_)[:650].astype(np.int32)
+    ids, sc, per_cut = rk.topk(users, N, cuts=[1, 7, 20])
+    srt = test.sorted_rows()
+    for c in (1, 7, 20):
+        hits, dcg = per_cut[c]
+        for b, u in enumerate(users.tolist()):
+            truth = set(srt.indices[srt.indptr[u]:srt.indptr[u + 1]].tolist())
+            want_h = len(truth.intersection(ids[b, :c].tolist()))
+            want_d = sum(1.0 / math.log(pos + 2) for pos, it in enumerate(ids[b, :c].tolist()) if it in truth)
+            assert hits[b] == want_h and dcg[b] == want_d
+    _, _, again = rk.topk(users, N, cuts=[7], want_lists=False)
+    assert np.array_equal(again[7][0], per_cut[7][0]) and np.array_equal(again[7][1], per_cut[7][1])
+
+
+def test_fast_measures_equal_rankingMeasure_strings_incl_cold_users_and_unknown_items():
+    """evalRanking's fast path (no result file wanted) must print exactly what Measure.rankingMeasure prints for
+    the lists of rank_all_test_users: warm users on the device, cold users and unknown test items included."""
+    import io
+    from contextlib import redirect_stdout
+    from qrec_amd.model.ranking.BPR import BPR
+    from qrec_amd.util.measure import Measure
+    from helpers import conf_from_text
+    rng = np.random.default_rng(8)
+    train = [[f"u{u}", f"i{i}", 1.0] for u, i in zip(rng.integers(0, 300, 6000).tolist(), rng.integers(0, 400, 6000).tolist())]
+    test = [[f"u{u}", f"i{i}", 1.0] for u, i in zip(rng.integers(0, 300, 1500).tolist(), rng.integers(0, 400, 1500).tolist())]
+    test += [["cold_a", "i3", 1.0], ["cold_a", "i5", 1.0], ["cold_b", "never_seen", 1.0], ["u1", "never_seen", 1.0]]
+    conf = conf_from_text("ratings=./x.txt\nmodel.name=BPR\nratings.setup=-columns 0 1 2\nevaluation.setup=-testSet x\nitem.ranking=on -topN 5,10,20\n"
+                          "num.factors=16\nnum.max.epoch=2\nlearnRate=-init 0.05 -max 1\nreg.lambda=-u 0.01 -i 0.01 -b 0.2 -s 0.2\n"
+                          "output.setup=off -dir ./results/")
+    import random
+    random.seed(1); np.random.seed(1)
+    with redirect_stdout(io.StringIO()):
+        m = BPR(conf, train, test)
+        got = m.execute()                                      # fast path (output off)
+        want = Measure.rankingMeasure(m.data.testSet_u, m.rank_all_test_users(20), [5, 10, 20])
+        quick = m.ranking_performance(0)
+    assert got == want
+    assert quick == [x.strip() for x in want[11:]]             # in-training variant: top-max(N) only
