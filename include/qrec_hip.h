@@ -80,6 +80,9 @@ int qrec_mt_bpr_sample_epoch(uint32_t *state625, const int64_t *h_pos_indptr,
  * base/deepRecommender.py:30).  h_perm (int64[n]) is permuted in place; NULL only
  * advances the generator. */
 int qrec_mt_shuffle(uint32_t *state625, int64_t n, int64_t *h_perm);
+/* DataSplit.dataSplit (util/dataSplit.py:9-25): one random() per row of the loaded file, in row order; is_test_out[k]
+ * = 1 when random() < ratio.  Same draws as the reference's loop, so the -ap split is the reference's split. */
+int qrec_mt_data_split(uint32_t *state625, int64_t n, double ratio, uint8_t *is_test_out);
 /* base/deepRecommender.py:41-49 over rows already in shuffled order: one negative per
  * row, redraw while the item is in trainSet_u[user].  rated CSR rows must be sorted. */
 int qrec_mt_pairwise_sample_epoch(uint32_t *state625, const int32_t *h_row_user, int64_t n_rows,
@@ -285,6 +288,23 @@ int qrec_score_topk(const void *d_U, const void *d_V, int dtype, int32_t d, int3
 int qrec_rank_hits(const int32_t *d_ids, int32_t n_batch_users, int32_t row_stride, int32_t n_cut,
                    const int32_t *d_user_ids, const int64_t *d_test_indptr, const int32_t *d_test_items,
                    const double *d_discount, int32_t *d_hits_out, double *d_dcg_out, void *stream);
+
+/* ---- the on-disk rating format: util/io.py:31-76 (FileIO.loadDataSet) --------------------------- *
+ * "user item rating" text, one record per line, fields split on every single character of `delims`
+ * (NULL = the reference's " ,\t"), columns picked by index (col_rating < 0: no rating column, rating = 1),
+ * skip_header drops the first line, binarize drops records rated below `threshold` and sets the rest to 1.
+ * The result holds dense ids in first-appearance order, the ratings and the '\n'-joined name tables
+ * (which: 0 = users, 1 = items).  Host code, no GPU.  QREC_ERR_UNSUPPORTED = the file needs CPython's own
+ * parsing rules (non-ASCII text, exotic float literals, short records): the caller then runs the Python path. */
+typedef struct qrec_ratings qrec_ratings;
+int qrec_ratings_load(const char *path, const char *delims, int32_t col_user, int32_t col_item, int32_t col_rating,
+                      int32_t skip_header, int32_t binarize, double threshold, qrec_ratings **out);
+int64_t qrec_ratings_rows(const qrec_ratings *h);
+int32_t qrec_ratings_count(const qrec_ratings *h, int32_t which);
+int64_t qrec_ratings_names_bytes(const qrec_ratings *h, int32_t which);
+int qrec_ratings_copy(const qrec_ratings *h, int32_t *user_out, int32_t *item_out, double *rating_out);
+int qrec_ratings_names(const qrec_ratings *h, int32_t which, char *out);
+void qrec_ratings_free(qrec_ratings *h);
 
 #ifdef __cplusplus
 }

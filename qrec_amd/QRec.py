@@ -5,6 +5,7 @@ one process per fold."""
 from __future__ import annotations
 
 import importlib
+import os
 import sys
 from multiprocessing import Manager, Process
 from time import localtime, strftime, time
@@ -24,7 +25,12 @@ def resolve_model(name: str):
     raise ImportError(f"model {name} is not provided by qrec_amd (hot-path models: BPR, BasicMF, PMF, SVD, LightGCN, NGCF, SimGCL, SGL)")
 
 
-def _run_fold(results, model, order):
+def _run_fold(results, model, order, spread=False):
+    # one process <-> one device: with ``-cv k -p`` the folds run side by side (QRec.py:76-89), so they are dealt
+    # round-robin over the node's GPUs unless the user pinned QREC_DEVICE
+    if spread and "QREC_DEVICE" not in os.environ:
+        from . import capi
+        os.environ["QREC_DEVICE"] = str((order - 1) % max(capi.device_count(), 1))
     results[order] = model.execute()
 
 
@@ -68,7 +74,7 @@ class QRec:
         tasks = []
         for order, (train, test) in enumerate(DataSplit.crossValidation(self.trainingData, k, binarized=binarized), 1):
             model = cls(self.config, train, test, "[" + str(order) + "]")   # built in the parent, run in the child
-            tasks.append(Process(target=_run_fold, args=(results, model, order)))
+            tasks.append(Process(target=_run_fold, args=(results, model, order, ev.contains("-p"))))
         for p in tasks:
             p.start()
             if not ev.contains("-p"):

@@ -67,8 +67,18 @@ _SIGNATURES = {
     "qrec_score_topk_scratch_bytes": [C.c_int, _i32, _i32, _vp],
     "qrec_score_topk": [_vp, _vp, C.c_int, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "qrec_rank_hits": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "qrec_mt_data_split": [_vp, _i64, _f64, _vp],
+    "qrec_ratings_load": [C.c_char_p, C.c_char_p, _i32, _i32, _i32, _i32, _i32, _f64, _vp],
+    "qrec_ratings_rows": [_vp],
+    "qrec_ratings_count": [_vp, _i32],
+    "qrec_ratings_names_bytes": [_vp, _i32],
+    "qrec_ratings_copy": [_vp, _vp, _vp, _vp],
+    "qrec_ratings_names": [_vp, _i32, _vp],
+    "qrec_ratings_free": [_vp],
 }
-_RESTYPES = {"qrec_last_error": C.c_char_p}
+_RESTYPES = {"qrec_last_error": C.c_char_p, "qrec_ratings_rows": C.c_int64, "qrec_ratings_count": C.c_int32,
+             "qrec_ratings_names_bytes": C.c_int64, "qrec_ratings_free": None}
+ERR_UNSUPPORTED = -4
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -314,6 +324,40 @@ def mt_bpr_sample_epoch(state625: np.ndarray, pos_indptr, pos_indices, n_items: 
     _check(load().qrec_mt_bpr_sample_epoch(_hp(state625), _hp(pos_indptr), _hp(pos_indices),
                                            pos_indptr.size - 1, n_items, _hp(j)))
     return j
+
+
+def mt_data_split(state625: np.ndarray, n: int, ratio: float) -> np.ndarray:
+    """util/dataSplit.py:14-22: mask[k] = (random() < ratio) for n consecutive draws of the CPython stream"""
+    _req(state625, np.uint32, "state625")
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    _check(load().qrec_mt_data_split(_hp(state625), n, ratio, _hp(mask)))
+    return mask[:n].astype(bool)
+
+
+def ratings_load(path: str, delims: str | None, col_user: int, col_item: int, col_rating: int, skip_header: bool,
+                 binarize: bool, threshold: float):
+    """util/io.py:31-76 natively.  Returns (user_idx int32[n], item_idx int32[n], rating float64[n], user_names,
+    item_names) with ids in first-appearance order, or None when the file needs CPython's own parsing rules."""
+    lib = load()
+    h = C.c_void_p()
+    rc = lib.qrec_ratings_load(os.fsencode(path), delims.encode() if delims else None, col_user, col_item, col_rating,
+                               int(skip_header), int(binarize), threshold, C.byref(h))
+    if rc == ERR_UNSUPPORTED:
+        return None
+    _check(rc)
+    try:
+        n = lib.qrec_ratings_rows(h)
+        u = np.empty(n, np.int32); i = np.empty(n, np.int32); r = np.empty(n, np.float64)
+        _check(lib.qrec_ratings_copy(h, _hp(u), _hp(i), _hp(r)))
+        names = []
+        for which in (0, 1):
+            buf = C.create_string_buffer(max(int(lib.qrec_ratings_names_bytes(h, which)), 1))
+            _check(lib.qrec_ratings_names(h, which, buf))
+            cnt = lib.qrec_ratings_count(h, which)
+            names.append(buf.raw[:lib.qrec_ratings_names_bytes(h, which)].decode("ascii").split("\n") if cnt else [])
+        return u, i, r, names[0], names[1]
+    finally:
+        lib.qrec_ratings_free(h)
 
 
 def mt_shuffle(state625: np.ndarray, n: int, perm: np.ndarray | None = None):

@@ -10,8 +10,53 @@ from collections import defaultdict
 
 import numpy as np
 
-from ..interactions import CSR, user_item_csr
+from ..interactions import CSR, dedup_user_item, user_item_csr
 from ..util.config import OptionConf
+from .rows import RatingRows
+
+
+class _LazyNested(dict):
+    """``trainSet_u`` / ``trainSet_i`` / ``testSet_i`` of the array-backed data model: the reference's dict of
+    dicts (data/rating.py:14-17), built from the arrays the first time anybody looks inside."""
+
+    def __init__(self, build):
+        super().__init__()
+        self._build = build
+
+    def _fill(self):
+        if self._build is not None:
+            build, self._build = self._build, None
+            dict.update(self, build())
+
+    def _wrap(name):
+        def method(self, *a, **kw):
+            self._fill()
+            return getattr(dict, name)(self, *a, **kw)
+        method.__name__ = name
+        return method
+
+    for _m in ("__getitem__", "__contains__", "__iter__", "__len__", "keys", "values", "items", "get", "__repr__",
+               "__eq__", "__setitem__", "__delitem__", "pop", "setdefault", "update", "copy"):
+        locals()[_m] = _wrap(_m)
+    del _m, _wrap
+
+    def __missing__(self, key):              # defaultdict(dict) behaviour of the reference
+        row = self[key] = {}
+        return row
+
+
+def _nested(outer_names, outer_idx, inner_names, inner_idx, values):
+    """{outer: {inner: value}} with the reference's insertion orders (rows in file order)."""
+    order = np.argsort(outer_idx, kind="stable")
+    bounds = np.flatnonzero(np.diff(outer_idx[order])) + 1
+    inner_sorted = [inner_names[k] for k in inner_idx[order].tolist()]
+    val_sorted = values[order].tolist()
+    starts = [0] + bounds.tolist() + [order.size]
+    firsts = outer_idx[order][[s for s in starts[:-1]]].tolist() if order.size else []
+    groups = {g: dict(zip(inner_sorted[a:b], val_sorted[a:b])) for g, a, b in zip(firsts, starts[:-1], starts[1:])}
+    # outer keys in order of first appearance
+    _, first = np.unique(outer_idx, return_index=True)
+    return {outer_names[g]: groups[g] for g in outer_idx[np.sort(first)].tolist()}
 
 
 class Rating:
@@ -23,15 +68,73 @@ class Rating:
         self.trainSet_u, self.trainSet_i = defaultdict(dict), defaultdict(dict)
         self.testSet_u, self.testSet_i = defaultdict(dict), defaultdict(dict)
         self.rScale = []
-        self._rows = trainingSet[:]          # the list form of trainingData (kept in sync lazily)
         self._order = None                   # pending permutation of _rows (see permute_training_data)
         self._arrays = None                  # (uid, iid, rating) of _rows in list order
+        self._csr_cache = {}
+        self._dedup = None
+        special = any(self.evalSettings.contains(k) for k in ("-val", "-cold", "-predict"))
+        if isinstance(trainingSet, RatingRows) and isinstance(testSet, RatingRows) and not special:
+            self._rows = trainingSet
+            self._test_rows = testSet
+            self._ingest_compact(trainingSet, testSet)
+            return
+        # list form (also what the options that rewrite the lists themselves work on)
+        if isinstance(trainingSet, RatingRows):
+            trainingSet = trainingSet.to_list()
+        if isinstance(testSet, RatingRows):
+            testSet = testSet.to_list()
+        self._rows = trainingSet[:]          # the list form of trainingData (kept in sync lazily)
+        self._test_rows = None
         self.testData = testSet[:]
         self._ingest()
         self._means()
         if self.evalSettings.contains("-cold"):
             self._keep_cold_start_users(int(self.evalSettings["-cold"]))
-        self._csr_cache = {}
+
+    # ``testData`` (data/rating.py:25): a plain list in the list-backed model; materialised on first use in the
+    # array-backed one (evalRatings appends the prediction to every row, base/recommender.py:105-110)
+    @property
+    def testData(self):
+        if self._test_list is None and self._test_rows is not None:
+            self._test_list = self._test_rows.to_list()
+        return self._test_list
+
+    @testData.setter
+    def testData(self, rows):
+        self._test_list = rows
+
+    _test_list = None
+
+    def _ingest_compact(self, tr: RatingRows, te: RatingRows):
+        """``_ingest`` + ``_means`` on arrays: same ids (first appearance in the TRAINING rows, data/rating.py:48-54),
+        same dict orders, same floating-point sums (sequential, in dict order) -- without touching 1.2 M Python rows."""
+        uorder, uremap = RatingRows.first_appearance(tr.user_idx, len(tr.user_names))
+        iorder, iremap = RatingRows.first_appearance(tr.item_idx, len(tr.item_names))
+        unames = [tr.user_names[f] for f in uorder.tolist()]
+        inames = [tr.item_names[f] for f in iorder.tolist()]
+        self.user = dict(zip(unames, range(len(unames))))
+        self.item = dict(zip(inames, range(len(inames))))
+        self.id2user = dict(enumerate(unames))
+        self.id2item = dict(enumerate(inames))
+        uid, iid, r = uremap[tr.user_idx], iremap[tr.item_idx], tr.rating
+        self._arrays = (np.ascontiguousarray(uid), np.ascontiguousarray(iid), r.copy())
+        self.rScale = np.unique(r).tolist()
+        nu, ni = len(unames), len(inames)
+        du, di, dr = self._dedup = dedup_user_item(uid, iid, r, max(ni, 1))
+        # means: sum(row.values()) / len(row) in dict order == bincount's sequential accumulation in row order
+        with np.errstate(invalid="ignore", divide="ignore"):
+            um = np.bincount(du, weights=dr, minlength=nu) / np.bincount(du, minlength=nu)
+            im = np.bincount(di, weights=dr, minlength=ni) / np.bincount(di, minlength=ni)
+        self.userMeans = dict(zip(unames, um.tolist()))
+        self.itemMeans = dict(zip(inames, im.tolist()))
+        total = sum(self.userMeans.values())
+        self.globalMean = 0 if total == 0 else total / len(self.userMeans)
+        self.trainSet_u = _LazyNested(lambda: _nested(unames, du, inames, di, dr))
+        self.trainSet_i = _LazyNested(lambda: _nested(inames, di, unames, du, dr))
+        # test side: names stay names (test users/items may be unknown to the training set)
+        tun, tin = te.user_names, te.item_names
+        self.testSet_u = _nested(tun, te.user_idx, tin, te.item_idx, te.rating) if len(te) else {}
+        self.testSet_i = _LazyNested(lambda: _nested(tin, te.item_idx, tun, te.user_idx, te.rating) if len(te) else {})
 
     # ``trainingData`` is the reference's public list (data/rating.py:24).  isConverged /
     # next_batch_pairwise reshuffle it every epoch (base/iterativeRecommender.py:101,
@@ -42,7 +145,7 @@ class Rating:
     def trainingData(self):
         if self._order is not None:
             rows = self._rows
-            self._rows = [rows[k] for k in self._order]
+            self._rows = rows.take(self._order) if isinstance(rows, RatingRows) else [rows[k] for k in self._order]
             if self._arrays is not None:
                 self._arrays = tuple(a[self._order] for a in self._arrays)
             self._order = None
@@ -182,6 +285,9 @@ class Rating:
         return tuple(np.ascontiguousarray(a[self._order]) for a in self._arrays)
 
     def _dict_csr(self, min_rating):
+        if self._dedup is not None:       # array-backed model: the same orders from the de-duplicated arrays
+            du, di, dr = self._dedup
+            return user_item_csr(du, di, dr, len(self.user), len(self.item), min_rating, assume_unique=True)
         # walk the dicts themselves: their iteration order IS the contract
         nu = len(self.user)
         counts = np.zeros(nu + 1, dtype=np.int64)

@@ -53,19 +53,26 @@ def dedup_user_item(uid: np.ndarray, iid: np.ndarray, rating: np.ndarray, n_item
     the FIRST occurrence, rating of the LAST.  Returns (u, i, r) in global first-occurrence
     order (which, grouped stably by u, is each user's dict order)."""
     key = uid.astype(np.int64) * np.int64(n_items) + iid.astype(np.int64)
-    uniq, first = np.unique(key, return_index=True)
-    n = key.size
-    _, last_rev = np.unique(key[::-1], return_index=True)
-    last = n - 1 - last_rev
-    order = np.argsort(first, kind="stable")
-    first, last = first[order], last[order]
+    order = np.argsort(key, kind="stable")            # one sort; equal keys stay in file order
+    ks = key[order]
+    start = np.ones(ks.size, dtype=bool)
+    start[1:] = ks[1:] != ks[:-1]
+    if start.all():                                   # no duplicate (user, item) rows: nothing to do
+        return uid, iid, rating
+    first = order[start]                              # first occurrence of each key
+    last = order[np.append(start[1:], True)]          # last occurrence
+    by_first = np.argsort(first, kind="stable")
+    first, last = first[by_first], last[by_first]
     return uid[first], iid[first], rating[last]
 
 
-def user_item_csr(uid, iid, rating, n_users: int, n_items: int, min_rating: float | None = None) -> CSR:
+def user_item_csr(uid, iid, rating, n_users: int, n_items: int, min_rating: float | None = None,
+                  assume_unique: bool = False) -> CSR:
     """CSR of ``trainSet_u`` (``min_rating=None``) or of BPR's ``PositiveSet``
     (``min_rating=1``, model/ranking/BPR.py:21-25) in the reference's iteration order."""
-    u, i, r = dedup_user_item(np.asarray(uid), np.asarray(iid), np.asarray(rating, dtype=np.float64), n_items)
+    u, i, r = np.asarray(uid), np.asarray(iid), np.asarray(rating, dtype=np.float64)
+    if not assume_unique:
+        u, i, r = dedup_user_item(u, i, r, n_items)
     if min_rating is not None:
         keep = r >= min_rating
         u, i, r = u[keep], i[keep], r[keep]

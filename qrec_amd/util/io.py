@@ -29,6 +29,9 @@ class FileIO:
                     threshold: float = 3.0):
         setup = OptionConf(conf["ratings.setup"])
         print("loading test data..." if bTest else "loading training data...")
+        rows = FileIO._load_native(setup, file, bTest, binarized, threshold)
+        if rows is not None:
+            return rows
         with open(file) as fh:
             lines = fh.readlines()
         if setup.contains("-header"):
@@ -54,6 +57,33 @@ class FileIO:
                 print("Error! Have you added the option -header to the rating.setup?")
                 sys.exit(-1)
         return rows
+
+    @staticmethod
+    def _load_native(setup, file, bTest, binarized, threshold):
+        """The same rows through libqrec_hip's parser (qrec_ratings_load), as a ``RatingRows``; None whenever the
+        conf or the file asks for something only the Python path reproduces exactly (regex ``-delim``, non-ASCII
+        text, unusual float literals, malformed records, a missing file): the loop below then runs -- and fails --
+        as the reference's does."""
+        import os
+        if os.environ.get("QREC_NATIVE_LOADER", "1") == "0" or not os.path.isfile(file):
+            return None
+        delims = None
+        if setup.contains("-delim"):
+            parts = setup["-delim"].split("|")
+            if not parts or any(len(p) != 1 or p in "\\^$.*+?()[]{}" for p in parts):
+                return None                      # a real regular expression
+            delims = "".join(parts)
+        try:
+            cols = [int(c) for c in setup["-columns"].strip().split()]
+        except ValueError:
+            return None
+        if len(cols) < 2 or any(c < 0 for c in cols):
+            return None
+        from .. import capi
+        from ..data.rows import RatingRows
+        got = capi.ratings_load(file, delims, cols[0], cols[1], cols[2] if len(cols) >= 3 else -1,
+                                setup.contains("-header"), binarized, threshold)
+        return None if got is None else RatingRows(*got)
 
     @staticmethod
     def loadUserList(filepath: str):

@@ -632,3 +632,46 @@ def test_bpr_model_throughput_mode_pipelined_epochs():
     _, _, recall_e = run("exact", E)
     print("Recall@N throughput", recall_t, "exact", recall_e)
     assert abs(recall_t - recall_e) < 0.02 and recall_t > 0.5 * recall_e
+
+
+@pytest.mark.parametrize("evaluation", ["-ap 0.2 -b 1", "-testSet TEST"])
+def test_main_flow_from_files_native_loader_equals_python_loader(tmp_path, monkeypatch, evaluation):
+    """QRec(conf).execute() (QRec.py:11-60) from rating files on disk: the native loader + array-backed data model
+    must give the very run the list-backed Python path gives -- same split, ids, index stream, tables, measures."""
+    from qrec_amd.QRec import QRec
+    from qrec_amd.util.config import ModelConf
+    rng = np.random.default_rng(12)
+    n = 6000
+    rows = [f"user{u},item{i},{r}" for u, i, r in zip(rng.integers(0, 300, n), rng.integers(0, 400, n), rng.choice([1, 2, 3, 4, 5], n))]
+    (tmp_path / "ratings.txt").write_text("u,i,r\n" + "\n".join(rows) + "\n")
+    (tmp_path / "test.txt").write_text("u,i,r\n" + "\n".join(rows[:900]) + "\nstranger,item1,5\n")
+    conf = ModelConf.from_dict({
+        "ratings": str(tmp_path / "ratings.txt"), "ratings.setup": "-columns 0 1 2 -header", "model.name": "BPR",
+        "evaluation.setup": evaluation.replace("TEST", str(tmp_path / "test.txt")), "item.ranking": "on -topN 10,20",
+        "num.factors": "16", "num.max.epoch": "3", "learnRate": "-init 0.05 -max 1",
+        "reg.lambda": "-u 0.01 -i 0.01 -b 0.2 -s 0.2", "output.setup": "off -dir " + str(tmp_path / "results") + "/"})
+    monkeypatch.chdir(tmp_path)
+
+    def run(native):
+        monkeypatch.setenv("QREC_NATIVE_LOADER", "1" if native else "0")
+        random.seed(21); np.random.seed(21)
+        captured = {}
+        import qrec_amd.model.ranking.BPR as mod
+        orig = mod.BPR.trainModel
+        def spy(self):
+            orig(self); captured["P"], captured["Q"], captured["data"] = self.P.copy(), self.Q.copy(), self.data
+        monkeypatch.setattr(mod.BPR, "trainModel", spy)
+        with redirect_stdout(io.StringIO()):
+            q = QRec(conf)
+            measure = q.execute()
+        monkeypatch.setattr(mod.BPR, "trainModel", orig)
+        return q, measure, captured, random.getstate()
+
+    q_py, m_py, c_py, s_py = run(False)
+    q_nat, m_nat, c_nat, s_nat = run(True)
+    from qrec_amd.data.rows import RatingRows
+    assert isinstance(q_py.trainingData, list) and isinstance(q_nat.trainingData, RatingRows)
+    assert q_nat.trainingData == q_py.trainingData and q_nat.testData == q_py.testData
+    assert m_nat == m_py and s_nat == s_py
+    assert np.array_equal(c_nat["P"], c_py["P"]) and np.array_equal(c_nat["Q"], c_py["Q"])
+    assert list(c_nat["data"].user.items()) == list(c_py["data"].user.items())

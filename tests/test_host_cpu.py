@@ -274,3 +274,141 @@ def test_product_never_imports_the_oracle():
     import subprocess
     deps = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in deps
+
+
+# ---------------------------------------------------------------------------------------------
+# native loader (qrec_ratings_load) + array-backed data model vs the reference-shaped Python path
+# ---------------------------------------------------------------------------------------------
+def _loader_conf(setup, evaluation="-testSet x"):
+    from qrec_amd.util.config import ModelConf
+    return ModelConf.from_dict({"ratings.setup": setup, "evaluation.setup": evaluation})
+
+
+def _load_both(tmp_path, text, setup, monkeypatch, **kw):
+    import io
+    from contextlib import redirect_stdout
+    from qrec_amd.util.io import FileIO
+    f = tmp_path / "r.txt"
+    f.write_bytes(text.encode() if isinstance(text, str) else text)
+    conf = _loader_conf(setup)
+    with redirect_stdout(io.StringIO()):
+        monkeypatch.setenv("QREC_NATIVE_LOADER", "0")
+        py = FileIO.loadDataSet(conf, str(f), **kw)
+        monkeypatch.setenv("QREC_NATIVE_LOADER", "1")
+        nat = FileIO.loadDataSet(conf, str(f), **kw)
+    return py, nat
+
+
+def test_native_loader_equals_python_loader(tmp_path, monkeypatch):
+    """util/io.py:31-76: every single delimiter splits (empty fields shift the columns), -columns, -header, -b,
+    universal newlines, float literals."""
+    from qrec_amd.data.rows import RatingRows
+    rng = np.random.default_rng(0)
+    lines = [f"u{u} i{i} {r}" for u, i, r in zip(rng.integers(0, 50, 400), rng.integers(0, 70, 400), rng.choice(["1", "2.5", "4", "0.5", "5.0", "1e0", ".5", "+3"], 400))]
+    text = "\n".join(lines) + "\n"
+    py, nat = _load_both(tmp_path, text, "-columns 0 1 2", monkeypatch)
+    assert isinstance(py, list) and isinstance(nat, RatingRows) and nat == py and len(nat) == 400
+    assert nat[7] == py[7] and nat[3:9] == py[3:9] and list(nat)[-1] == py[-1]
+    # mixed delimiters, CRLF, a lone CR, trailing blanks, no final newline, swapped columns
+    text2 = "a,b\t3\r\nc d,4.5  \r\n  e\tf 2\rg,h,1"
+    py, nat = _load_both(tmp_path, text2, "-columns 1 0 2", monkeypatch)
+    assert isinstance(nat, RatingRows) and nat == py == [["b", "a", 3.0], ["d", "c", 4.5], ["f", "e", 2.0], ["h", "g", 1.0]]
+    # two blanks in a row make an empty field: column 1 is '' for the second record -- as re.split does
+    py, nat = _load_both(tmp_path, "u1 i1 3 9\nu2  i2 4\n", "-columns 0 1 3", monkeypatch)
+    assert isinstance(nat, RatingRows) and nat == py == [["u1", "i1", 9.0], ["u2", "", 4.0]]
+    # header, no rating column, binarize
+    py, nat = _load_both(tmp_path, "user item\nu1 i1\nu2 i1\n", "-columns 0 1 -header", monkeypatch)
+    assert isinstance(nat, RatingRows) and nat == py == [["u1", "i1", 1.0], ["u2", "i1", 1.0]]
+    py, nat = _load_both(tmp_path, text, "-columns 0 1 2", monkeypatch, binarized=True, threshold=2.5)
+    assert isinstance(nat, RatingRows) and nat == py and 0 < len(py) < 400 and all(r[2] == 1.0 for r in py)
+    py, nat = _load_both(tmp_path, text, "-columns 0 1 2", monkeypatch, bTest=True)
+    assert nat == py
+    # single-character custom delimiters
+    py, nat = _load_both(tmp_path, "u1;i1;3\nu2;i2;4\n", "-columns 0 1 2 -delim ;", monkeypatch)
+    assert isinstance(nat, RatingRows) and nat == py
+    # empty file
+    py, nat = _load_both(tmp_path, "", "-columns 0 1 2", monkeypatch)
+    assert len(nat) == 0 and py == []
+
+
+def test_native_loader_hands_unusual_files_to_the_python_path(tmp_path, monkeypatch):
+    """Whatever CPython would parse by its own rules is parsed by CPython: same rows, or the same failure."""
+    py, nat = _load_both(tmp_path, "üser i1 3\nu2 i2 4\n", "-columns 0 1 2", monkeypatch)
+    assert isinstance(nat, list) and nat == py                      # non-ASCII names
+    py, nat = _load_both(tmp_path, "u1 i1 nan\nu2 i2 1_0\n", "-columns 0 1 2", monkeypatch)
+    assert isinstance(nat, list) and nat[1] == ["u2", "i2", 10.0] and np.isnan(nat[0][2])   # float()'s own literals
+    py, nat = _load_both(tmp_path, "u1  i1   3\n", "-columns 0 1 2 -delim \\s+", monkeypatch)
+    assert isinstance(nat, list) and nat == py == [["u1", "i1", 3.0]]                        # a real regex
+    for bad, exc in (("u1 i1 3\n\nu2 i2 4\n", IndexError), ("u1 i1 x\n", SystemExit)):
+        (tmp_path / "b.txt").write_text(bad)
+        from qrec_amd.util.io import FileIO
+        with pytest.raises(exc):                                     # blank line / non-numeric rating: as the reference
+            FileIO.loadDataSet(_loader_conf("-columns 0 1 2"), str(tmp_path / "b.txt"))
+
+
+def _rating_pair(train_rows, test_rows, evaluation="-testSet x"):
+    """the same data through the list-backed and the array-backed Rating"""
+    from qrec_amd.data.rating import Rating
+    from qrec_amd.data.rows import RatingRows
+    from qrec_amd.interactions import first_appearance_ids
+
+    def rows(lst):
+        u, un = first_appearance_ids(np.array([r[0] for r in lst])) if lst else (np.zeros(0, np.int32), [])
+        i, inn = first_appearance_ids(np.array([r[1] for r in lst])) if lst else (np.zeros(0, np.int32), [])
+        return RatingRows(u, i, np.array([r[2] for r in lst], np.float64), [str(x) for x in un], [str(x) for x in inn])
+    conf = _loader_conf("-columns 0 1 2", evaluation)
+    return Rating(conf, [r[:] for r in train_rows], [r[:] for r in test_rows]), Rating(conf, rows(train_rows), rows(test_rows))
+
+
+def test_array_backed_rating_equals_list_backed_rating():
+    """data/rating.py:33-67 on arrays: ids, dict contents AND orders, means (bit for bit), scale, CSR views."""
+    rng = np.random.default_rng(3)
+    n = 3000
+    train = [[f"u{u}", f"i{i}", float(r)] for u, i, r in zip(rng.integers(0, 120, n), rng.integers(0, 150, n), rng.choice([0.5, 1, 2, 3.5, 5], n))]
+    train += [train[5][:2] + [4.0], train[5][:2] + [0.5], train[17][:2] + [2.0]]          # duplicates: first position, last value
+    test = [[f"u{u}", f"i{i}", 1.0] for u, i in zip(rng.integers(0, 140, 600), rng.integers(0, 170, 600))]   # incl. unknown users/items
+    a, b = _rating_pair(train, test)
+    assert list(a.user.items()) == list(b.user.items()) and list(a.item.items()) == list(b.item.items())
+    assert a.id2user == b.id2user and a.id2item == b.id2item and a.rScale == b.rScale
+    assert list(a.userMeans.items()) == list(b.userMeans.items()) and list(a.itemMeans.items()) == list(b.itemMeans.items())
+    assert a.globalMean == b.globalMean
+    assert a.trainingSize() == b.trainingSize() and a.testSize() == b.testSize() and a.elemCount() == b.elemCount()
+    for x, y in ((a.trainSet_u, b.trainSet_u), (a.trainSet_i, b.trainSet_i), (a.testSet_u, b.testSet_u), (a.testSet_i, b.testSet_i)):
+        assert list(x) == list(y)
+        for k in x:
+            assert list(x[k].items()) == list(y[k].items())
+    for f in ("positive_csr", "rated_csr"):
+        ca, cb = getattr(a, f)(), getattr(b, f)()
+        assert np.array_equal(ca.indptr, cb.indptr) and np.array_equal(ca.indices, cb.indices) and np.array_equal(ca.values, cb.values)
+    for x, y in zip(a.training_arrays(), b.training_arrays()):
+        assert np.array_equal(x, y)
+    assert b.trainingData == a.trainingData and b.testData == a.testData
+    assert a.contains("u5", "i7") == b.contains("u5", "i7") and b.userRated("u3") == a.userRated("u3")
+    assert b.trainSet_u["nobody"] == {} and b.rating("u1", "nothing") == -1
+    perm = rng.permutation(len(train))
+    a.permute_training_data(perm); b.permute_training_data(perm)
+    assert b.trainingData == a.trainingData
+    for x, y in zip(a.training_arrays(), b.training_arrays()):
+        assert np.array_equal(x, y)
+    # options that rewrite the row lists take the list-backed route
+    c, d = _rating_pair(train, test, "-testSet x -cold 5")
+    assert list(c.testSet_u) == list(d.testSet_u) and c.testData == d.testData
+
+
+def test_splits_on_rating_rows_equal_the_reference_loops():
+    """util/dataSplit.py:9-44 on arrays: same random() draws, same rows on both sides, generator left in the same state."""
+    import random
+    from qrec_amd.data.rows import RatingRows
+    from qrec_amd.util.dataSplit import DataSplit
+    rng = np.random.default_rng(4)
+    n = 5000
+    lst = [[f"u{u}", f"i{i}", float(r)] for u, i, r in zip(rng.integers(0, 200, n), rng.integers(0, 300, n), rng.choice([0.0, 1.0, 3.0], n))]
+    from qrec_amd.interactions import first_appearance_ids
+    u, un = first_appearance_ids(np.array([r[0] for r in lst])); i, inn = first_appearance_ids(np.array([r[1] for r in lst]))
+    rows = RatingRows(u, i, np.array([r[2] for r in lst]), [str(x) for x in un], [str(x) for x in inn])
+    for binarized in (False, True):
+        random.seed(11); tr_l, te_l = DataSplit.dataSplit(lst, test_ratio=0.2, binarized=binarized); s_l = random.getstate()
+        random.seed(11); tr_r, te_r = DataSplit.dataSplit(rows, test_ratio=0.2, binarized=binarized); s_r = random.getstate()
+        assert isinstance(tr_r, RatingRows) and tr_r == tr_l and te_r == te_l and s_l == s_r
+        for (a_tr, a_te), (b_tr, b_te) in zip(DataSplit.crossValidation(lst, 3, binarized=binarized), DataSplit.crossValidation(rows, 3, binarized=binarized)):
+            assert b_tr == a_tr and b_te == a_te
