@@ -165,46 +165,25 @@ def main():
 
     state = {"lr": LR0, "last": 0.0, "loss": 0.0}
 
-    def step_dist(k: int):
-        """N > 1: the ranks' Q deltas and loss terms are summed between the SGD kernel and the learning-rate
-        decision, so the epoch close runs on the host (one 24-byte read-back per step)."""
-        sgd.take_prefetched_negatives(k)                            # BPR.py:35-37 (sampled under step k-1)
-        capi._check(capi.load().qrec_memset(sgd.d_stats.ptr, 0, 8, None))
-        ev[k][0].record()
-        if args.schedule == "item":
-            capi.bpr_sgd_hogwild_item_major(tables.P, tables.Q, DIM, tables.ld, sgd.d_u, sgd.d_i, sgd.d_j, n, CHUNK, 0,
-                                            FLUSH_EVERY, state["lr"], REG_U, REG_I, sgd.d_stats)   # BPR.py:45-53
+    def between(stage: str):
+        """N > 1, enqueue only: after the SGD kernel the ranks' Q deltas are summed (the path's one collective, RCCL
+        all-reduce), after the local loss sums sum(-log sigma) and sum P*P are added over ranks (Q is replicated), so
+        every rank's device-side driver takes the same decision."""
+        if stage == "tables":
+            q_sync.sync()
         else:
-            capi.bpr_sgd_hogwild(tables.P, tables.Q, DIM, tables.ld, sgd.d_u, sgd.d_i, sgd.d_j, n, CHUNK, 0,
-                                 state["lr"], REG_U, REG_I, sgd.d_stats, args.variant)
-        ev[k][1].record()
-        sgd.mark_negatives_consumed()
-        sgd.prefetch_negatives_device(2018, k + 1)                  # side stream, under the SGD kernel
-        q_sync.sync()            # sum the ranks' Q deltas: the path's one collective (RCCL all-reduce)
-        sgd.enqueue_epoch_stats()                                   # BPR.py:40
-        # global loss: sum(-log sigma) and sum P^2 add up over ranks, Q is replicated;
-        dist.all_reduce(stats_view[0:2])   # every rank then takes the same bold-driver decision
-        nll, sp, sq = sgd.read_epoch_stats()                        # the step's one host sync
-        loss = nll + REG_U * sp + REG_I * sq
-        if not np.isfinite(loss):
-            raise SystemExit("Loss = NaN or Infinity")            # iterativeRecommender.py:84-86
-        # isConverged -> updateLearningRate (iterativeRecommender.py:56-63,96-100)
-        if k > 0:
-            state["lr"] *= 1.05 if abs(state["last"]) > abs(loss) else 0.5
-        state["lr"] = min(state["lr"], MAX_LR)
-        state["last"] = state["loss"] = loss
+            dist.all_reduce(stats_view[0:2])
 
-    def step_single(k: int):
-        """N = 1: sampler (side stream) | SGD kernel -> epoch close (BPR.py:40 loss terms, isConverged,
-        updateLearningRate) all on the device; the host only enqueues.  tol = 0: the K timed steps all run."""
+    def step(k: int):
+        """sampler (side stream) | SGD kernel -> [N > 1: delta all-reduce] -> epoch close (BPR.py:40 loss terms,
+        isConverged, updateLearningRate) all on the device; the host only enqueues.  tol = 0: the K timed steps all run."""
         sgd.take_prefetched_negatives(k)                            # BPR.py:35-37 (sampled under step k-1)
         sgd.epoch_device_async(REG_U, REG_I, MAX_LR, tol=0.0, chunk=CHUNK, variant=args.variant,
-                               flush_every=FLUSH_EVERY, events=ev[k])   # BPR.py:45-53,40 + iterativeRecommender.py:88-104
+                               flush_every=FLUSH_EVERY, events=ev[k],   # BPR.py:45-53,40 + iterativeRecommender.py:88-104
+                               between=between if use_dist else None)
         sgd.prefetch_negatives_device(2018, k + 1)                  # side stream, under the SGD kernel
 
-    step = step_dist if use_dist else step_single
-    if not use_dist:
-        sgd.start_device_driver(LR0, log_capacity=total)
+    sgd.start_device_driver(LR0, log_capacity=total)
 
     def sync_all():
         if use_dist:
@@ -226,14 +205,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    if not use_dist:
-        drv = sgd.driver_state()
-        if drv["failed"]:
-            raise SystemExit("Loss = NaN or Infinity")            # iterativeRecommender.py:84-86
-        assert drv["epochs"] == total and not drv["converged"], drv
-        log = sgd.driver_log()
-        state["loss"], state["lr"] = float(log[-1, 0]), drv["lr"]
-        state["lr_schedule"] = [float(x) for x in log[:, 1]]
+    drv = sgd.driver_state()
+    if drv["failed"]:
+        raise SystemExit("Loss = NaN or Infinity")            # iterativeRecommender.py:84-86
+    assert drv["epochs"] == total and not drv["converged"], drv
+    log = sgd.driver_log()
+    state["loss"], state["lr"] = float(log[-1, 0]), drv["lr"]
     kernel_ms = [ev[k][1].elapsed_ms_since(ev[k][0]) for k in range(args.warmup, total)]
     avg_kernel_ms = float(np.mean(kernel_ms))
     alg_bytes = n * bytes_per_triplet(DIM)
@@ -257,7 +234,7 @@ def main():
                        "triplets_per_step_per_gpu": n, "chunk": CHUNK,
                        "parallelism": "1 GPU" if world == 1 else f"user-sharded x{world}, replicated item table, per-step delta all-reduce (RCCL)",
                        "lr": LR0, "reg": REG_U, "final_loss": state["loss"], "final_lr": state["lr"],
-                       "epoch_close": "host (24-byte read-back per step)" if use_dist else "device (no host sync inside the timed region)"},
+                       "epoch_close": "device (no host sync inside the timed region)"},
             "roofline": {"bound": "hbm", "kernel": "bpr_hogwild_item_kernel<16,4>" if args.schedule == "item" else "bpr_hogwild_kernel<16,4,plain-load,atomic>",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

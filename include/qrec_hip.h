@@ -165,6 +165,14 @@ int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int32_t d, int32_t l
 int qrec_epoch_close(const void *d_P, int64_t p_rows, const void *d_Q, int64_t q_rows, int dtype, int32_t ld,
                      double *d_stats, double *d_state, double regU, double regI, double max_lr, double tol,
                      double *d_log, int64_t log_capacity, void *stream);
+/* The two halves, for runs whose loss terms are summed over ranks in between (one process per GPU): qrec_epoch_sums
+ * leaves sum P*P / sum Q*Q in d_stats[1..2] (d_state may be NULL; a converged/failed state makes it a no-op), the
+ * caller all-reduces d_stats[0..1] (sum(-log sigma) and sum P*P add up over user shards, Q is replicated), and
+ * qrec_epoch_decide takes the reference's decision from d_stats[0..2] exactly as qrec_epoch_close does. */
+int qrec_epoch_sums(const void *d_P, int64_t p_rows, const void *d_Q, int64_t q_rows, int dtype, int32_t ld,
+                    double *d_stats, const double *d_state, void *stream);
+int qrec_epoch_decide(double *d_stats, double *d_state, double regU, double regI, double max_lr, double tol,
+                      double *d_log, int64_t log_capacity, void *stream);
 
 /* Rating-prediction MF family, order-exact: variant 0 = model/rating/BasicMF.py:9-26 (config #1),
  * 1 = model/rating/PMF.py:9-28 (regU, regI), 2 = model/rating/SVD.py:13-35 (biases d_Bu/d_Bi of the

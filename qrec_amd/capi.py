@@ -51,6 +51,8 @@ _SIGNATURES = {
     "qrec_bpr_sgd_hogwild": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _vp, C.c_int, _vp, _vp],
     "qrec_bpr_sgd_hogwild_item_major": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp],
     "qrec_epoch_close": [_vp, _i64, _vp, _i64, C.c_int, _i32, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
+    "qrec_epoch_sums": [_vp, _i64, _vp, _i64, C.c_int, _i32, _vp, _vp, _vp],
+    "qrec_epoch_decide": [_vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
     "qrec_mf_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _vp, C.c_int, _f64, _f64, _vp, _vp, _f64, _f64, _vp],
     "qrec_sumsq": [_vp, C.c_int, _i64, _i32, _i32, _vp, _vp],
     "qrec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _vp],
@@ -426,6 +428,16 @@ def score_topk(d_U, d_V, dtype: int, d: int, ld: int, n_items: int, d_user_ids, 
     _check(load().qrec_score_topk(_dp(d_U), _dp(d_V), dtype, d, ld, n_items, _dp(d_user_ids), n_batch_users,
                                   _dp(d_rated_indptr), _dp(d_rated_items), N, _dp(d_scratch), _dp(d_ids_out),
                                   _dp(d_scores_out), _sh(stream)))
+
+
+def epoch_sums(d_P, p_rows: int, d_Q, q_rows: int, dtype: int, ld: int, d_stats, d_state=None, stream=None):
+    _check(load().qrec_epoch_sums(_dp(d_P), p_rows, _dp(d_Q), q_rows, dtype, ld, _dp(d_stats), _dp(d_state), _sh(stream)))
+
+
+def epoch_decide(d_stats, d_state, regU: float, regI: float, max_lr: float, tol: float, d_log=None,
+                 log_capacity: int = 0, stream=None):
+    _check(load().qrec_epoch_decide(_dp(d_stats), _dp(d_state), regU, regI, max_lr, tol, _dp(d_log), log_capacity,
+                                    _sh(stream)))
 
 
 def rank_hits(d_ids, n_batch_users: int, row_stride: int, n_cut: int, d_user_ids, d_test_indptr, d_test_items,

@@ -37,6 +37,34 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const T *__restrict__ x, int
 //   converged = |lastLoss - loss| < tol;  if not: epoch > 1 -> lr *= 1.05 if |lastLoss| > |loss| else 0.5, cap at max_lr
 // Every block reduces its share of both tables; the last block to arrive (ticket counter) takes the decision,
 // appends the epoch to the log and clears the accumulators for the next epoch.
+// The reference's decision at an epoch boundary (base/iterativeRecommender.py:56-63,88-104), from
+// stats = {sum(-log sigma), sum P*P, sum Q*Q}: one thread.
+__device__ inline void driver_decide(double *__restrict__ stats, double *__restrict__ state, double regU, double regI,
+                                     double max_lr, double tol, double *__restrict__ log, int64_t log_capacity) {
+    const double nll = atomicAdd(stats + 0, 0.0);     // the SGD kernels' f64 atomics live memory-side
+    const double tp = stats[1], tq = stats[2];
+    const double loss = nll + regU * tp + regI * tq;
+    const double last = state[QREC_DRV_LAST_LOSS], lr_used = state[QREC_DRV_LR];
+    const int64_t epoch = (int64_t)state[QREC_DRV_EPOCHS] + 1;
+    double lr = lr_used;
+    const bool finite = loss == loss && fabs(loss) <= 1.79769313486231570e308;
+    const bool converged = finite && fabs(last - loss) < tol;
+    if (finite && !converged) {
+        if (epoch > 1) lr *= fabs(last) > fabs(loss) ? 1.05 : 0.5;
+        if (max_lr > 0.0 && lr > max_lr) lr = max_lr;
+    }
+    state[QREC_DRV_LR] = lr;
+    state[QREC_DRV_LAST_LOSS] = loss;
+    state[QREC_DRV_EPOCHS] = (double)epoch;
+    state[QREC_DRV_CONVERGED] = converged ? 1.0 : 0.0;
+    state[QREC_DRV_FAILED] = finite ? 0.0 : 1.0;
+    if (log && epoch <= log_capacity) {
+        double *e = log + (epoch - 1) * QREC_DRV_LOG_WORDS;
+        e[0] = loss; e[1] = lr_used; e[2] = nll; e[3] = last - loss; e[4] = tp; e[5] = tq;
+    }
+    stats[0] = 0.0;
+}
+
 template <typename T, typename V4>
 __device__ inline double block_sumsq(const T *__restrict__ x, int64_t n_elems, double *s_part) {
     double acc = 0.0;
@@ -59,8 +87,8 @@ __global__ __launch_bounds__(256) void epoch_close_kernel(const T *__restrict__ 
                                                           const T *__restrict__ Q, int64_t q_elems,
                                                           double *__restrict__ stats, double *__restrict__ state,
                                                           double regU, double regI, double max_lr, double tol,
-                                                          double *__restrict__ log, int64_t log_capacity) {
-    if (state[QREC_DRV_CONVERGED] != 0.0 || state[QREC_DRV_FAILED] != 0.0) return;
+                                                          double *__restrict__ log, int64_t log_capacity, int decide) {
+    if (state && (state[QREC_DRV_CONVERGED] != 0.0 || state[QREC_DRV_FAILED] != 0.0)) return;
     __shared__ double s_part[4];
     __shared__ bool s_last;
     const double sp = block_sumsq<T, V4>(P, p_elems, s_part);
@@ -91,30 +119,36 @@ __global__ __launch_bounds__(256) void epoch_close_kernel(const T *__restrict__ 
     if (threadIdx.x != 0) return;
     tp = s_tot[0][0] + s_tot[0][1] + s_tot[0][2] + s_tot[0][3];
     tq = s_tot[1][0] + s_tot[1][1] + s_tot[1][2] + s_tot[1][3];
-    const double nll = atomicAdd(stats + 0, 0.0);     // the SGD kernels' f64 atomics live memory-side
-    const double loss = nll + regU * tp + regI * tq;
-    const double last = state[QREC_DRV_LAST_LOSS], lr_used = state[QREC_DRV_LR];
-    const int64_t epoch = (int64_t)state[QREC_DRV_EPOCHS] + 1;
-    double lr = lr_used;
-    const bool finite = loss == loss && fabs(loss) <= 1.79769313486231570e308;
-    const bool converged = finite && fabs(last - loss) < tol;
-    if (finite && !converged) {
-        if (epoch > 1) lr *= fabs(last) > fabs(loss) ? 1.05 : 0.5;
-        if (max_lr > 0.0 && lr > max_lr) lr = max_lr;
-    }
-    state[QREC_DRV_LR] = lr;
-    state[QREC_DRV_LAST_LOSS] = loss;
-    state[QREC_DRV_EPOCHS] = (double)epoch;
-    state[QREC_DRV_CONVERGED] = converged ? 1.0 : 0.0;
-    state[QREC_DRV_FAILED] = finite ? 0.0 : 1.0;
-    if (log && epoch <= log_capacity) {
-        double *e = log + (epoch - 1) * QREC_DRV_LOG_WORDS;
-        e[0] = loss; e[1] = lr_used; e[2] = nll; e[3] = last - loss; e[4] = tp; e[5] = tq;
-    }
-    stats[0] = 0.0; stats[1] = tp; stats[2] = tq;
+    stats[1] = tp; stats[2] = tq;
     *ticket = 0u;
+    if (decide) driver_decide(stats, state, regU, regI, max_lr, tol, log, log_capacity);
 }
 
+__global__ void epoch_decide_kernel(double *__restrict__ stats, double *__restrict__ state, double regU, double regI,
+                                    double max_lr, double tol, double *__restrict__ log, int64_t log_capacity) {
+    if (state[QREC_DRV_CONVERGED] != 0.0 || state[QREC_DRV_FAILED] != 0.0) return;
+    driver_decide(stats, state, regU, regI, max_lr, tol, log, log_capacity);
+}
+
+}  // namespace
+
+namespace {
+int launch_epoch_close(const void *d_P, int64_t p_rows, const void *d_Q, int64_t q_rows, int dtype, int32_t ld,
+                       double *d_stats, double *d_state, double regU, double regI, double max_lr, double tol,
+                       double *d_log, int64_t log_capacity, int decide, hipStream_t st) {
+    const int64_t pe = p_rows * (int64_t)ld, qe = q_rows * (int64_t)ld;
+    int64_t blocks = ((pe > qe ? pe : qe) / 4 + 255) / 256;
+    if (blocks > QREC_STATS_MAX_BLOCKS) blocks = QREC_STATS_MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    if (dtype == QREC_F32)
+        hipLaunchKernelGGL((epoch_close_kernel<float, float4>), dim3((unsigned)blocks), dim3(256), 0, st, (const float *)d_P, pe,
+                           (const float *)d_Q, qe, d_stats, d_state, regU, regI, max_lr, tol, d_log, log_capacity, decide);
+    else
+        hipLaunchKernelGGL((epoch_close_kernel<double, double4>), dim3((unsigned)blocks), dim3(256), 0, st, (const double *)d_P, pe,
+                           (const double *)d_Q, qe, d_stats, d_state, regU, regI, max_lr, tol, d_log, log_capacity, decide);
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
 }  // namespace
 
 extern "C" int qrec_epoch_close(const void *d_P, int64_t p_rows, const void *d_Q, int64_t q_rows, int dtype, int32_t ld,
@@ -124,17 +158,25 @@ extern "C" int qrec_epoch_close(const void *d_P, int64_t p_rows, const void *d_Q
                  "qrec_epoch_close: bad arguments");
     QREC_REQUIRE(dtype == QREC_F32 || dtype == QREC_F64, "qrec_epoch_close: bad dtype %d", dtype);
     QREC_REQUIRE(log_capacity == 0 || d_log, "qrec_epoch_close: log capacity without a log");
-    hipStream_t st = as_stream(stream);
-    const int64_t pe = p_rows * (int64_t)ld, qe = q_rows * (int64_t)ld;
-    int64_t blocks = ((pe > qe ? pe : qe) / 4 + 255) / 256;
-    if (blocks > QREC_STATS_MAX_BLOCKS) blocks = QREC_STATS_MAX_BLOCKS;
-    if (blocks < 1) blocks = 1;
-    if (dtype == QREC_F32)
-        hipLaunchKernelGGL((epoch_close_kernel<float, float4>), dim3((unsigned)blocks), dim3(256), 0, st, (const float *)d_P, pe,
-                           (const float *)d_Q, qe, d_stats, d_state, regU, regI, max_lr, tol, d_log, log_capacity);
-    else
-        hipLaunchKernelGGL((epoch_close_kernel<double, double4>), dim3((unsigned)blocks), dim3(256), 0, st, (const double *)d_P, pe,
-                           (const double *)d_Q, qe, d_stats, d_state, regU, regI, max_lr, tol, d_log, log_capacity);
+    return launch_epoch_close(d_P, p_rows, d_Q, q_rows, dtype, ld, d_stats, d_state, regU, regI, max_lr, tol, d_log,
+                              log_capacity, 1, as_stream(stream));
+}
+
+// The two halves of qrec_epoch_close for runs whose loss terms are summed over ranks in between (multi-GPU:
+// all-reduce d_stats[0..1] = {sum(-log sigma), sum P*P} after the sums, Q is replicated).
+extern "C" int qrec_epoch_sums(const void *d_P, int64_t p_rows, const void *d_Q, int64_t q_rows, int dtype, int32_t ld,
+                               double *d_stats, const double *d_state, void *stream) {
+    QREC_REQUIRE(d_P && d_Q && d_stats && p_rows >= 0 && q_rows >= 0 && ld >= 4 && ld % 4 == 0, "qrec_epoch_sums: bad arguments");
+    QREC_REQUIRE(dtype == QREC_F32 || dtype == QREC_F64, "qrec_epoch_sums: bad dtype %d", dtype);
+    return launch_epoch_close(d_P, p_rows, d_Q, q_rows, dtype, ld, d_stats, const_cast<double *>(d_state), 0, 0, 0, 0,
+                              nullptr, 0, 0, as_stream(stream));
+}
+extern "C" int qrec_epoch_decide(double *d_stats, double *d_state, double regU, double regI, double max_lr, double tol,
+                                 double *d_log, int64_t log_capacity, void *stream) {
+    QREC_REQUIRE(d_stats && d_state, "qrec_epoch_decide: null argument");
+    QREC_REQUIRE(log_capacity == 0 || d_log, "qrec_epoch_decide: log capacity without a log");
+    hipLaunchKernelGGL(epoch_decide_kernel, dim3(1), dim3(1), 0, as_stream(stream), d_stats, d_state, regU, regI, max_lr, tol,
+                       d_log, log_capacity);
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }

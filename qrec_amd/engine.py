@@ -198,10 +198,12 @@ class BprSgd:
 
     def epoch_device_async(self, regU: float, regI: float, max_lr: float, tol: float = 1e-3, chunk: int = 32,
                            variant: int = capi.HW_DEFAULT, stream=None, groups: int = 0, flush_every: int = 8,
-                           events=None):
+                           events=None, between=None):
         """One throughput epoch with everything after it (BPR.py:40 loss terms, isConverged,
         updateLearningRate) enqueued on the device: no host synchronisation.  ``events`` = (before, after)
-        capi.Event pair recorded around the SGD kernel."""
+        capi.Event pair recorded around the SGD kernel.  ``between(stage)`` (one process per GPU) is called with
+        "tables" right after the SGD kernel (reconcile replicated tables) and with "stats" after the local sums
+        (all-reduce ``d_stats[0:2]``); both must only ENQUEUE work on the same stream."""
         if self.d_drv is None:
             raise RuntimeError("call start_device_driver() first")
         t = self.t
@@ -221,8 +223,14 @@ class BprSgd:
         end.record(stream)
         self._consumed[0] = end
         self._own_events.reverse()
-        capi.epoch_close(t.P, t.n_users, t.Q, t.n_items, t.code, t.ld, self.d_stats, self.d_drv, regU, regI, max_lr,
-                         tol, self.d_log, self._log_capacity, stream)
+        if between is None:
+            capi.epoch_close(t.P, t.n_users, t.Q, t.n_items, t.code, t.ld, self.d_stats, self.d_drv, regU, regI, max_lr,
+                             tol, self.d_log, self._log_capacity, stream)
+        else:    # multi-GPU: reconcile the replicas / sum the loss terms over ranks between the sums and the decision
+            between("tables")
+            capi.epoch_sums(t.P, t.n_users, t.Q, t.n_items, t.code, t.ld, self.d_stats, self.d_drv, stream)
+            between("stats")
+            capi.epoch_decide(self.d_stats, self.d_drv, regU, regI, max_lr, tol, self.d_log, self._log_capacity, stream)
 
     def driver_state(self, stream=None) -> dict:
         s = self.d_drv.numpy(stream)

@@ -513,8 +513,9 @@ def _host_driver(lr, last, loss, epoch, max_lr, tol):
     return lr, conv
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_epoch_close_follows_the_reference_schedule(dtype):
+def test_epoch_close_follows_the_reference_schedule(dtype, split):
     rng = np.random.default_rng(3)
     U, I, d = 700, 900, 24
     P0 = rng.random((U, d)) / 3; Q0 = rng.random((I, d)) / 3
@@ -532,9 +533,15 @@ def test_epoch_close_follows_the_reference_schedule(dtype):
         lr_used = lr
         lr, conv = _host_driver(lr, last, loss, k + 1, max_lr, tol)
         want.append((loss, lr_used, nll, last - loss)); last = loss
+    def close(log_cap):
+        if split:     # the multi-GPU form: sums, (all-reduce of stats[0:2] would go here), decision
+            capi.epoch_sums(t.P, U, t.Q, I, t.code, t.ld, sgd.d_stats, sgd.d_drv)
+            capi.epoch_decide(sgd.d_stats, sgd.d_drv, regU, regI, max_lr, tol, sgd.d_log, log_cap)
+        else:
+            capi.epoch_close(t.P, U, t.Q, I, t.code, t.ld, sgd.d_stats, sgd.d_drv, regU, regI, max_lr, tol, sgd.d_log, log_cap)
     for nll in nlls:
         sgd.d_stats.upload_head(np.array([nll], np.float64))
-        capi.epoch_close(t.P, U, t.Q, I, t.code, t.ld, sgd.d_stats, sgd.d_drv, regU, regI, max_lr, tol, sgd.d_log, 16)
+        close(16)
     st = sgd.driver_state()
     assert st["converged"] and not st["failed"] and st["epochs"] == len(nlls) - 1
     assert st["lr"] == pytest.approx(lr, rel=1e-15) and st["last_loss"] == pytest.approx(last, rel=1e-12)
@@ -550,7 +557,7 @@ def test_epoch_close_follows_the_reference_schedule(dtype):
     # NaN loss: the reference prints and exits (iterativeRecommender.py:84-86) -> FAILED, later epochs ignored
     sgd.start_device_driver(0.01, 4)
     sgd.d_stats.upload_head(np.array([np.nan], np.float64))
-    capi.epoch_close(t.P, U, t.Q, I, t.code, t.ld, sgd.d_stats, sgd.d_drv, regU, regI, max_lr, tol, sgd.d_log, 4)
+    close(4)
     assert sgd.driver_state()["failed"]
 
 
