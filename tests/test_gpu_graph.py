@@ -462,3 +462,71 @@ def test_sgl_class_runs_and_stays_in_lock_step_with_the_generator(aug):
     with redirect_stdout(io.StringIO()):
         m2 = SGL(conf, train, test); m2.execute()
     assert np.array_equal(capi.state_from_python(random.getstate()), want)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json full size (config #3 / #5 shape: 31,668 x 38,048, nnz(adj) = 2.5 M, d = 64)
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def yelp_graph():
+    return _graph("yelp2018")
+
+
+def test_spmm_yelp_shape_vs_scipy_and_operator_properties(yelp_graph):
+    """The propagation operator at the bench shape: against scipy on the whole result, and through properties that
+    do not need a reference at all -- linearity, symmetry of the normalised adjacency (<Ax, y> = <x, Ay>), and
+    A 1 = row sums; rows that are not split are bit-identical to the sequential CSR sum."""
+    d, adj, A = yelp_graph
+    n = A.shape[0]
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((n, 64)).astype(np.float32); Y = rng.standard_normal((n, 64)).astype(np.float32)
+    plan = SpmmPlan(adj[0], adj[1], adj[2], 64)
+    dX, dY, dO, dO2 = DB.from_numpy(X), DB.from_numpy(Y), DB.zeros((n, 64), np.float32), DB.zeros((n, 64), np.float32)
+    capi.spmm_csr(plan, dX, dO, 64); AX = dO.numpy()
+    ref = A.dot(X)
+    assert rel_err(AX, ref) < TOL
+    whole = np.diff(adj[0]) <= 128
+    assert whole.sum() > 0.95 * n and np.array_equal(AX[whole], ref[whole])
+    capi.spmm_csr(plan, dY, dO2, 64); AY = dO2.numpy()
+    dS = DB.from_numpy(X + Y); capi.spmm_csr(plan, dS, dO, 64)
+    assert rel_err(dO.numpy(), AX + AY) < 2e-6                                   # linearity
+    lhs = float((AX.astype(np.float64) * Y).sum()); rhs = float((X.astype(np.float64) * AY).sum())
+    assert abs(lhs - rhs) / max(abs(lhs), 1.0) < 1e-5                            # symmetry
+    ones = DB.from_numpy(np.ones((n, 64), np.float32)); capi.spmm_csr(plan, ones, dO, 64)
+    np.testing.assert_allclose(dO.numpy()[:, 0], np.asarray(A.sum(axis=1)).ravel(), rtol=2e-6)
+
+
+def test_lightgcn_and_simgcl_steps_at_yelp_shape_match_restatement(yelp_graph):
+    """One config-#3 LightGCN step (L=3, batch 2048) and one config-#5 SimGCL step (L=2, lambda 0.5, eps 0.1) at the
+    full graph against the numpy/scipy restatement: losses to 2e-5, the Adam update direction on every coordinate
+    whose gradient is not rounding noise."""
+    d, adj, A = yelp_graph
+    nu, ni, dim, B = d["n_users"], d["n_items"], 64, 2048
+    N = nu + ni
+    rng = np.random.default_rng(7)
+    sel = rng.integers(0, d["train_u"].size, B)
+    u = d["train_u"][sel].astype(np.int32); i = d["train_i"][sel].astype(np.int32); j = rng.integers(0, ni, B).astype(np.int32)
+    du, di, dj = DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j)
+    U0 = (rng.standard_normal((nu, dim)) * 0.005).astype(np.float32); V0 = (rng.standard_normal((ni, dim)) * 0.005).astype(np.float32)
+    E0 = np.concatenate([U0, V0])
+    ref = T.LightGCN(U0, V0, A, 3, lr=0.001, reg=1e-4)
+    tr = LightGCNTrainer(U0, V0, adj, 3, lr=0.001, reg=1e-4)
+    lref = ref.train_step(u, i, j)
+    tr.train_step_async(du, di, dj, B)
+    assert abs(tr.loss() - lref) / abs(lref) < 2e-5
+    Eg = np.concatenate(tr.ego_embeddings())
+    step_ref, step_gpu = ref.E - E0, Eg - E0
+    solid = np.abs(ref.opt.m) > 1e-3 * np.abs(ref.opt.m).max()        # first Adam step = -lr*sign(g): compare where g is not noise
+    assert solid.mean() > 0.2 and np.array_equal(np.sign(step_gpu[solid]), np.sign(step_ref[solid]))
+    np.testing.assert_allclose(step_gpu[solid], step_ref[solid], rtol=1e-3)
+    # SimGCL
+    lim = np.sqrt(6.0 / (nu + dim))
+    U1 = rng.uniform(-lim, lim, (nu, dim)).astype(np.float32); V1 = rng.uniform(-lim, lim, (ni, dim)).astype(np.float32)
+    ref2 = T.SimGCL(U1, V1, A, 2, lr=0.001, reg=1e-4, cl_rate=0.5, eps=0.1)
+    tr2 = SimGCLTrainer(U1, V1, adj, 2, lr=0.001, reg=1e-4, cl_rate=0.5, eps=0.1, max_unique=B)
+    noises = [rng.random((N, dim)).astype(np.float32) for _ in range(4)]
+    _, rec_ref, cl_ref = ref2.train_step(u, i, j, noises)
+    uu = unique_first_appearance(u); vv = (unique_first_appearance(i) + nu).astype(np.int32)
+    tr2.train_step_async(du, di, dj, B, DB.from_numpy(uu), uu.size, DB.from_numpy(vv), vv.size, noises=[DB.from_numpy(x) for x in noises])
+    _, rec, cl = tr2.losses()
+    assert abs(rec - rec_ref) / abs(rec_ref) < 2e-5 and abs(cl - cl_ref) / abs(cl_ref) < 2e-5
