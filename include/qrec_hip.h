@@ -200,13 +200,19 @@ int qrec_sumsq(const void *d_x, int dtype, int64_t rows, int32_t d, int32_t ld, 
  * long_count[k] slots starting at long_first[k].  X, Y, addend, accum: [rows][ld] fp32,
  * ld in {32,64,128,256}.  Deterministic (no float atomics).  d_x_row_mask (may be NULL):
  * bitmap, bit c set iff row c of X is non-zero; clear rows are skipped (bit-identical result,
- * less traffic) -- used for the first backward SpMM, whose operand is the sparse batch gradient. */
+ * less traffic) -- used for the first backward SpMM, whose operand is the sparse batch gradient.
+ * d_y_row_mask (may be NULL): bitmap of the OUTPUT rows that are wanted; the others are neither computed nor
+ * written (Y, accum keep what they held) -- the last propagation layer of a training step is only read at the
+ * batch's rows (embedding_lookup, LightGCN.py:22-24; qrec_mark_batch_rows builds the bitmap).          */
 int qrec_spmm_csr(const int32_t *d_seg_row, const int64_t *d_seg_beg, const int32_t *d_seg_len,
                   const int32_t *d_seg_slot, int64_t n_segs, const int32_t *d_long_row,
                   const int32_t *d_long_first, const int32_t *d_long_count, int32_t n_long,
                   const int32_t *d_indices, const float *d_values, const float *d_X, float *d_Y,
                   float *d_partial, int32_t ld, const float *d_addend, float addend_scale, float *d_accum,
-                  const uint32_t *d_x_row_mask, void *stream);
+                  const uint32_t *d_x_row_mask, const uint32_t *d_y_row_mask, void *stream);
+/* d_row_mask |= bits of rows u[b], n_users+i[b], n_users+j[b] (bitmap over the joint [U;V] row space; clear it first) */
+int qrec_mark_batch_rows(const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int32_t B, int32_t n_users,
+                         uint32_t *d_row_mask, void *stream);
 
 /* embedding_lookup x3 + util/loss.py:3-6 bpr_loss + the batch l2 term and all their gradients
  * (LightGCN.py:22-30): rows are S[row]/div (div = n_layers+1 folds the layer mean in), users

@@ -55,7 +55,8 @@ _SIGNATURES = {
     "qrec_epoch_decide": [_vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
     "qrec_mf_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _vp, C.c_int, _f64, _f64, _vp, _vp, _f64, _f64, _vp],
     "qrec_sumsq": [_vp, C.c_int, _i64, _i32, _i32, _vp, _vp],
-    "qrec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _vp],
+    "qrec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _vp, _vp],
+    "qrec_mark_batch_rows": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "qrec_bpr_batch_loss_grad": [_vp, _f32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
     "qrec_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
     "qrec_perturb_rows": [_vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp],
@@ -446,14 +447,18 @@ def rank_hits(d_ids, n_batch_users: int, row_stride: int, n_cut: int, d_user_ids
                                  _dp(d_test_items), _dp(d_discount), _dp(d_hits_out), _dp(d_dcg_out), _sh(stream)))
 
 
+def mark_batch_rows(d_u, d_i, d_j, B: int, n_users: int, d_row_mask, stream=None):
+    _check(load().qrec_mark_batch_rows(_dp(d_u), _dp(d_i), _dp(d_j), B, n_users, _dp(d_row_mask), _sh(stream)))
+
+
 def spmm_csr(plan, d_X, d_Y, ld: int, d_addend=None, addend_scale: float = 0.0, d_accum=None, stream=None,
-             d_x_row_mask=None):
+             d_x_row_mask=None, d_y_row_mask=None):
     """plan: qrec_amd.graph.SpmmPlan (device-resident segment arrays)"""
     _check(load().qrec_spmm_csr(_dp(plan.seg_row), _dp(plan.seg_beg), _dp(plan.seg_len), _dp(plan.seg_slot),
                                 plan.n_segs, _dp(plan.long_row), _dp(plan.long_first), _dp(plan.long_count),
                                 plan.n_long, _dp(plan.indices), _dp(plan.values), _dp(d_X), _dp(d_Y),
                                 _dp(plan.partial), ld, _dp(d_addend), addend_scale, _dp(d_accum), _dp(d_x_row_mask),
-                                _sh(stream)))
+                                _dp(d_y_row_mask), _sh(stream)))
 
 
 def bpr_batch_loss_grad(d_S, div: float, n_users: int, n_rows: int, ld: int, d_u, d_i, d_j, B: int, eps: float,

@@ -56,13 +56,17 @@ __global__ __launch_bounds__(256) void spmm_kernel(
     const int32_t *__restrict__ indices, const float *__restrict__ values,
     const float *__restrict__ X, float *__restrict__ Y, float *__restrict__ partial,
     const float *__restrict__ addend, float addend_scale, float *__restrict__ accum,
-    const uint32_t *__restrict__ x_row_mask) {
+    const uint32_t *__restrict__ x_row_mask, const uint32_t *__restrict__ y_row_mask) {
 #pragma clang fp contract(off)
     constexpr int GPW = kWave / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
     const int64_t gid = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
     const int64_t n_groups = (int64_t)gridDim.x * 4 * GPW;
     for (int64_t s = gid; s < n_segs; s += n_groups) {
+        if (y_row_mask) {   // only the marked output rows are wanted (last propagation layer: the batch's rows)
+            const int row = seg_row[s];
+            if (!((y_row_mask[row >> 5] >> (row & 31)) & 1u)) continue;
+        }
         const int64_t beg = seg_beg[s];
         const int len = seg_len[s];
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -125,12 +129,16 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restri
                                                          const int32_t *__restrict__ long_count, int n_long,
                                                          const float *__restrict__ partial, float *__restrict__ Y,
                                                          const float *__restrict__ addend, float addend_scale,
-                                                         float *__restrict__ accum) {
+                                                         float *__restrict__ accum, const uint32_t *__restrict__ y_row_mask) {
 #pragma clang fp contract(off)
     constexpr int GPW = kWave / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
     const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wid >= n_long) return;
+    if (y_row_mask) {
+        const int row = long_row[wid];
+        if (!((y_row_mask[row >> 5] >> (row & 31)) & 1u)) return;
+    }
     const int first = long_first[wid], cnt = long_count[wid];
     const float *p = partial + (int64_t)first * (4 * LPR) + 4 * r;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -149,6 +157,19 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restri
         acc.z += __shfl_xor(acc.z, m, kWave); acc.w += __shfl_xor(acc.w, m, kWave);
     }
     if (g == 0) spmm_epilogue<LPR>(acc, long_row[wid], r, Y, addend, addend_scale, accum);
+}
+
+// Bitmap of the rows a batch touches: users u, items n_users+i and n_users+j (the caller clears it first).  These
+// are the only rows of the LAST propagation layer anybody reads (embedding_lookup, LightGCN.py:22-24) and the
+// only non-zero rows of the batch gradient (first backward SpMM).
+__global__ void mark_batch_rows_kernel(const int32_t *__restrict__ u, const int32_t *__restrict__ i,
+                                       const int32_t *__restrict__ j, int B, int n_users, uint32_t *__restrict__ mask) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int ru = u[b], ri = n_users + i[b], rj = n_users + j[b];
+    atomicOr(mask + (ru >> 5), 1u << (ru & 31));
+    atomicOr(mask + (ri >> 5), 1u << (ri & 31));
+    atomicOr(mask + (rj >> 5), 1u << (rj & 31));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -239,16 +260,17 @@ template <int LPR>
 int launch_spmm(const int32_t *seg_row, const int64_t *seg_beg, const int32_t *seg_len, const int32_t *seg_slot,
                 int64_t n_segs, const int32_t *long_row, const int32_t *long_first, const int32_t *long_count,
                 int n_long, const int32_t *indices, const float *values, const float *X, float *Y, float *partial,
-                const float *addend, float addend_scale, float *accum, const uint32_t *x_row_mask, hipStream_t st) {
+                const float *addend, float addend_scale, float *accum, const uint32_t *x_row_mask,
+                const uint32_t *y_row_mask, hipStream_t st) {
     constexpr int GPW = kWave / LPR;
     int64_t blocks = (n_segs + 4 * GPW - 1) / (4 * GPW);
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL((spmm_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, seg_row, seg_beg, seg_len,
-                       seg_slot, n_segs, indices, values, X, Y, partial, addend, addend_scale, accum, x_row_mask);
+                       seg_slot, n_segs, indices, values, X, Y, partial, addend, addend_scale, accum, x_row_mask, y_row_mask);
     QREC_LAUNCH_CHECK();
     if (n_long > 0) {
         hipLaunchKernelGGL((spmm_fixup_kernel<LPR>), dim3((unsigned)((n_long + 3) / 4)), dim3(256),
-                           0, st, long_row, long_first, long_count, n_long, partial, Y, addend, addend_scale, accum);
+                           0, st, long_row, long_first, long_count, n_long, partial, Y, addend, addend_scale, accum, y_row_mask);
         QREC_LAUNCH_CHECK();
     }
     return QREC_OK;
@@ -263,7 +285,7 @@ int qrec_spmm_csr(const int32_t *d_seg_row, const int64_t *d_seg_beg, const int3
                   const int32_t *d_long_first, const int32_t *d_long_count, int32_t n_long,
                   const int32_t *d_indices, const float *d_values, const float *d_X, float *d_Y,
                   float *d_partial, int32_t ld, const float *d_addend, float addend_scale, float *d_accum,
-                  const uint32_t *d_x_row_mask, void *stream) {
+                  const uint32_t *d_x_row_mask, const uint32_t *d_y_row_mask, void *stream) {
     QREC_REQUIRE(d_seg_row && d_seg_beg && d_seg_len && d_seg_slot && d_indices && d_values && d_X && d_Y,
                  "qrec_spmm_csr: null argument");
     QREC_REQUIRE(n_long == 0 || (d_long_row && d_long_first && d_long_count && d_partial), "qrec_spmm_csr: long-row plan incomplete");
@@ -272,7 +294,7 @@ int qrec_spmm_csr(const int32_t *d_seg_row, const int64_t *d_seg_beg, const int3
     hipStream_t st = as_stream(stream);
 #define QREC_SPMM(LPR) return launch_spmm<LPR>(d_seg_row, d_seg_beg, d_seg_len, d_seg_slot, n_segs, d_long_row, d_long_first, \
                                                d_long_count, n_long, d_indices, d_values, d_X, d_Y, d_partial, d_addend,       \
-                                               addend_scale, d_accum, d_x_row_mask, st)
+                                               addend_scale, d_accum, d_x_row_mask, d_y_row_mask, st)
     switch (ld) {
         case 32: QREC_SPMM(8);
         case 64: QREC_SPMM(16);
@@ -281,6 +303,17 @@ int qrec_spmm_csr(const int32_t *d_seg_row, const int64_t *d_seg_beg, const int3
         default: set_error("qrec_spmm_csr: row stride must be 32, 64, 128 or 256 floats (got %d)", ld); return QREC_ERR_INVALID;
     }
 #undef QREC_SPMM
+}
+
+int qrec_mark_batch_rows(const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int32_t B, int32_t n_users,
+                         uint32_t *d_row_mask, void *stream) {
+    QREC_REQUIRE(d_row_mask && B >= 0 && n_users >= 0, "qrec_mark_batch_rows: bad argument");
+    QREC_REQUIRE(B == 0 || (d_u && d_i && d_j), "qrec_mark_batch_rows: null index array");
+    if (B == 0) return QREC_OK;
+    hipLaunchKernelGGL(mark_batch_rows_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, as_stream(stream), d_u, d_i,
+                       d_j, B, n_users, d_row_mask);
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
 }
 
 int qrec_bpr_batch_loss_grad(const float *d_S, float div, int32_t n_users, int64_t n_rows, int32_t ld,

@@ -118,13 +118,16 @@ class LightGCNTrainer:
         self.b1p, self.b2p = self.b1, self.b2          # fp32 beta powers, as TF keeps them
 
     # ---- pieces -----------------------------------------------------------------------------
-    def forward_sum(self, stream=None):
-        """S = E0 + E1 + ... + EL  (divide by L+1 at the point of use)."""
+    def forward_sum(self, stream=None, last_rows=None):
+        """S = E0 + E1 + ... + EL  (divide by L+1 at the point of use).  ``last_rows`` (row bitmap): the last
+        layer is only computed at those rows -- a training step reads S at the batch's rows and nowhere else
+        (embedding_lookup, LightGCN.py:22-24), and E_L feeds nothing further."""
         self.S.copy_from(self.E, stream)
         x = self.E
         for k in range(self.L):
             y = self.A if k % 2 == 0 else self.B
-            capi.spmm_csr(self.plan, x, y, self.ld, d_accum=self.S, stream=stream)
+            capi.spmm_csr(self.plan, x, y, self.ld, d_accum=self.S, stream=stream,
+                          d_y_row_mask=last_rows if k == self.L - 1 else None)
             x = y
 
     def backward_from_dE(self, stream=None):
@@ -145,10 +148,11 @@ class LightGCNTrainer:
 
     def train_step_async(self, d_u, d_i, d_j, B: int, stream=None):
         """u/i/j: device pointers (int32[B]); enqueue only, read the loss with ``loss()``."""
-        self.forward_sum(stream)
+        self.row_mask.fill_bytes(0, stream)
+        capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)    # rows {u, nu+i, nu+j} of the batch
+        self.forward_sum(stream, last_rows=self.row_mask)
         self.dE.fill_bytes(0, stream)
         self.d_loss.fill_bytes(0, stream)
-        self.row_mask.fill_bytes(0, stream)
         capi.bpr_batch_loss_grad(self.S, float(self.L + 1), self.nu, self.n, self.ld, d_u, d_i, d_j, B,
                                  self.loss_eps, self.reg, self.dE, self.d_loss, stream, d_row_mask=self.row_mask)
         g = self.backward_from_dE(stream)
@@ -248,16 +252,19 @@ class SimGCLTrainer:
         self.b1p, self.b2p = self.b1, self.b2
         self.step_no = 0
 
-    def _encode(self, S, view: int, noises=None, stream=None):
-        """S = sum_k emb_k over the L propagated layers (view 0 = clean; 1, 2 = perturbed)."""
+    def _encode(self, S, view: int, noises=None, stream=None, last_rows=None):
+        """S = sum_k emb_k over the L propagated layers (view 0 = clean; 1, 2 = perturbed).  ``last_rows``: row
+        bitmap of the batch -- the last layer is computed there only (the lookups of SimGCL.py:53-55,66-69 read
+        nothing else; rows outside the bitmap keep stale values that nobody reads)."""
         S.fill_bytes(0, stream)
         x = self.E
         for k in range(self.L):
             y = self.A if k % 2 == 0 else self.B
+            ymask = last_rows if k == self.L - 1 else None
             if view == 0:
-                capi.spmm_csr(self.plan, x, y, self.ld, d_accum=S, stream=stream)
+                capi.spmm_csr(self.plan, x, y, self.ld, d_accum=S, stream=stream, d_y_row_mask=ymask)
             else:
-                capi.spmm_csr(self.plan, x, y, self.ld, stream=stream)
+                capi.spmm_csr(self.plan, x, y, self.ld, stream=stream, d_y_row_mask=ymask)
                 noise = None if noises is None else noises[(view - 1) * self.L + k]
                 capi.perturb_rows(y, self.n, self.d, self.ld, self.eps, noise, self.seed,
                                   (self.step_no * 2 + (view - 1)) * 64 + k, d_accum=S, stream=stream)
@@ -274,13 +281,14 @@ class SimGCLTrainer:
         if max(n_uu, n_ui) > self.max_unique:
             raise ValueError("more unique rows in the batch than the InfoNCE workspace holds")
         L = float(self.L)
-        self._encode(self.Sm, 0, stream=stream)
-        self._encode(self.S1, 1, noises, stream)
-        self._encode(self.S2, 2, noises, stream)
+        self.row_mask.fill_bytes(0, stream)
+        capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)
+        self._encode(self.Sm, 0, stream=stream, last_rows=self.row_mask)
+        self._encode(self.S1, 1, noises, stream, last_rows=self.row_mask)
+        self._encode(self.S2, 2, noises, stream, last_rows=self.row_mask)
         self.dOut.fill_bytes(0, stream)
         self.d_loss.fill_bytes(0, stream)
-        self.row_mask.fill_bytes(0, stream)
-        # the InfoNCE rows (unique batch users / positive items) are a subset of the rows marked here
+        # the InfoNCE rows (unique batch users / positive items) are a subset of the rows marked above
         capi.bpr_batch_loss_grad(self.Sm, L, self.nu, self.n, self.ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
                                  self.dOut, self.d_loss, stream, d_row_mask=self.row_mask)
         cl = self.d_loss.ptr + 8
@@ -373,12 +381,16 @@ class NGCFTrainer:
         self.row_mask = DeviceBuffer.zeros((self.n + 31) // 32, np.uint32)
         self.step_no = 0
 
-    def forward(self, training: bool, masks=None, stream=None):
-        """fills E_1, E_2, side, gate, inv and the wide table All = [E_0 | z_1 | z_2]"""
+    def forward(self, training: bool, masks=None, stream=None, last_rows=None):
+        """fills E_1, E_2, side, gate, inv and the wide table All = [E_0 | z_1 | z_2].  ``last_rows`` (training):
+        the last layer's neighbourhood sum is only formed at the batch's rows -- its output block z_2 is read there
+        and nowhere else, and its backward only touches rows with a non-zero gradient, which are the same rows
+        (the other rows of side/gate/E_2 keep older, finite values whose gradient weight is exactly 0)."""
         n, d, ld = self.n, self.d, self.ld
         capi.copy_cols(self.All, self.wide_ld, self.E[0], ld, 0, n, d, False, stream)
         for k in range(self.N_LAYERS):
-            capi.spmm_csr(self.plan, self.E[k], self.side[k], ld, stream=stream)
+            capi.spmm_csr(self.plan, self.E[k], self.side[k], ld, stream=stream,
+                          d_y_row_mask=last_rows if k == self.N_LAYERS - 1 else None)
             capi.ngcf_dense_fwd(self.E[k], self.side[k], self.W[k][0], self.W[k][1], n, ld, self.gate[k], stream)
             capi.ngcf_activate(self.gate[k], n, d, ld, self.KEEP if training else 1.0,
                                None if masks is None else masks[k], self.seed, self.step_no * 8 + k, self.E[k + 1],
@@ -386,8 +398,10 @@ class NGCFTrainer:
 
     def train_step_async(self, d_u, d_i, d_j, B: int, masks=None, stream=None):
         n, d, ld = self.n, self.d, self.ld
-        self.forward(True, masks, stream)
-        self.dAll.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream); self.row_mask.fill_bytes(0, stream)
+        self.row_mask.fill_bytes(0, stream)
+        capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)
+        self.forward(True, masks, stream, last_rows=self.row_mask)
+        self.dAll.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
         capi.bpr_batch_loss_grad(self.All, 1.0, self.nu, n, self.wide_ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
                                  self.dAll, self.d_loss, stream, d_row_mask=self.row_mask)
         dnext = None
@@ -463,13 +477,15 @@ class SGLTrainer:
     def _view_plans(self, v):
         return [self.main_plan] * self.L if v == 0 else self.plans[v - 1]
 
-    def _forward(self, v, stream=None):
+    def _forward(self, v, stream=None, last_rows=None):
         S = self.S[v]
         S.copy_from(self.E, stream)
         x = self.E
-        for k, plan in enumerate(self._view_plans(v)):
+        plans = self._view_plans(v)
+        for k, plan in enumerate(plans):
             y = self.A if k % 2 == 0 else self.B
-            capi.spmm_csr(plan, x, y, self.ld, d_accum=S, stream=stream)
+            capi.spmm_csr(plan, x, y, self.ld, d_accum=S, stream=stream,
+                          d_y_row_mask=last_rows if k == len(plans) - 1 else None)   # last layer: batch rows only
             x = y
 
     def _backward(self, v, stream=None):
@@ -493,10 +509,12 @@ class SGLTrainer:
         if n_rows > self.max_unique:
             raise ValueError("more unique rows in the batch than the InfoNCE workspace holds")
         div = float(self.L + 1)
+        self.row_mask.fill_bytes(0, stream)
+        capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)
         for v in range(3):
-            self._forward(v, stream)
+            self._forward(v, stream, last_rows=self.row_mask)
             self.dOut[v].fill_bytes(0, stream)
-        self.G.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream); self.row_mask.fill_bytes(0, stream)
+        self.G.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
         capi.bpr_batch_loss_grad(self.S[0], div, self.nu, self.n, self.ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
                                  self.dOut[0], self.d_loss, stream, d_row_mask=self.row_mask)
         capi.info_nce_loss_grad(self.S[1], self.S[2], div, d_rows, n_rows, self.ld, self.temp, self.ssl_reg, self.ws,

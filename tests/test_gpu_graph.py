@@ -530,3 +530,33 @@ def test_lightgcn_and_simgcl_steps_at_yelp_shape_match_restatement(yelp_graph):
     tr2.train_step_async(du, di, dj, B, DB.from_numpy(uu), uu.size, DB.from_numpy(vv), vv.size, noises=[DB.from_numpy(x) for x in noises])
     _, rec, cl = tr2.losses()
     assert abs(rec - rec_ref) / abs(rec_ref) < 2e-5 and abs(cl - cl_ref) / abs(cl_ref) < 2e-5
+
+
+@pytest.mark.parametrize("seg_len", [128, 7])
+def test_spmm_output_row_mask_computes_exactly_the_marked_rows(seg_len):
+    """d_y_row_mask: marked rows equal the unmasked product bit for bit (long rows included), all other rows of Y
+    and of the accumulator keep what they held; qrec_mark_batch_rows marks {u, nu+i, nu+j}."""
+    d, adj, A = _graph("small")
+    n, nu, ni = A.shape[0], d["n_users"], d["n_items"]
+    rng = np.random.default_rng(13)
+    X = rng.standard_normal((n, 64)).astype(np.float32)
+    B = 300
+    u = rng.integers(0, nu, B).astype(np.int32); i = rng.integers(0, ni, B).astype(np.int32); j = rng.integers(0, ni, B).astype(np.int32)
+    heavy = int(np.argmax(np.diff(adj[0])[nu:]))              # make sure a multi-segment row is among the marked ones
+    i[0] = heavy
+    mask = DB.zeros((n + 31) // 32, np.uint32)
+    capi.mark_batch_rows(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, nu, mask)
+    rows = np.unique(np.concatenate([u, nu + i, nu + j]))
+    bits = mask.numpy()
+    want_bits = np.zeros_like(bits); np.bitwise_or.at(want_bits, rows >> 5, (np.uint32(1) << (rows & 31).astype(np.uint32)))
+    assert np.array_equal(bits, want_bits)
+    plan = SpmmPlan(adj[0], adj[1], adj[2], 64, seg_len=seg_len)
+    dX, full = DB.from_numpy(X), DB.zeros((n, 64), np.float32)
+    capi.spmm_csr(plan, dX, full, 64)
+    Y0 = rng.standard_normal((n, 64)).astype(np.float32); S0 = rng.standard_normal((n, 64)).astype(np.float32)
+    dY, dS = DB.from_numpy(Y0), DB.from_numpy(S0)
+    capi.spmm_csr(plan, dX, dY, 64, d_accum=dS, d_y_row_mask=mask)
+    Y, S, F = dY.numpy(), dS.numpy(), full.numpy()
+    other = np.setdiff1d(np.arange(n), rows)
+    assert np.array_equal(Y[rows], F[rows]) and np.array_equal(Y[other], Y0[other])
+    assert np.array_equal(S[rows], S0[rows] + F[rows]) and np.array_equal(S[other], S0[other])
