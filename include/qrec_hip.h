@@ -233,13 +233,14 @@ int qrec_adam_step(float *d_theta, float *d_m, float *d_v, const float *d_grad, 
 
 /* ---- SimGCL (model/ranking/SimGCL.py) ---------------------------------------------------- */
 
-/* perturbed_LightGCN_encoder's noise step (SimGCL.py:33-35), in place on one layer output:
- * emb += sign(emb) * l2_normalize(noise, axis=1) * eps, then (if d_accum) accum += emb.
+/* perturbed_LightGCN_encoder's noise step (SimGCL.py:33-35) on one layer output: with x = d_src (or d_emb itself
+ * when d_src is NULL: in place)  emb = x + sign(x) * l2_normalize(noise, axis=1) * eps, then (if d_accum) accum += emb.
+ * The out-of-place form lets the two perturbed encoders share the first product A E with the clean one.
  * d_noise = [n_rows][ld] U[0,1) numbers, or NULL to draw them on the device with
  * Philox4x32-10(key=seed, counter={row, lane, stream_id}) -- same distribution as
  * tf.random.uniform, not TF's stream.                                                    */
-int qrec_perturb_rows(float *d_emb, int64_t n_rows, int32_t d, int32_t ld, float eps, const float *d_noise,
-                      uint64_t seed, uint64_t stream_id, float *d_accum, void *stream);
+int qrec_perturb_rows(float *d_emb, const float *d_src, int64_t n_rows, int32_t d, int32_t ld, float eps,
+                      const float *d_noise, uint64_t seed, uint64_t stream_id, float *d_accum, void *stream);
 
 /* One side (users or items) of SimGCL.calc_cl_loss (SimGCL.py:60-90) with its gradients.
  * x1 = S1[rows]/div, x2 = S2[rows]/div (the two perturbed views' rows of the batch's UNIQUE

@@ -59,7 +59,7 @@ _SIGNATURES = {
     "qrec_mark_batch_rows": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "qrec_bpr_batch_loss_grad": [_vp, _f32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
     "qrec_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
-    "qrec_perturb_rows": [_vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp],
+    "qrec_perturb_rows": [_vp, _vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp],
     "qrec_info_nce_workspace_bytes": [_i32, _i32, _vp],
     "qrec_info_nce_loss_grad": [_vp, _vp, _f32, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "qrec_ngcf_dense_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
@@ -474,8 +474,8 @@ def adam_step(d_theta, d_m, d_v, d_grad, n_elems: int, grad_scale: float, alpha:
 
 
 def perturb_rows(d_emb, n_rows: int, d: int, ld: int, eps: float, d_noise=None, seed: int = 0, stream_id: int = 0,
-                 d_accum=None, stream=None):
-    _check(load().qrec_perturb_rows(_dp(d_emb), n_rows, d, ld, eps, _dp(d_noise), seed & (2**64 - 1),
+                 d_accum=None, stream=None, d_src=None):
+    _check(load().qrec_perturb_rows(_dp(d_emb), _dp(d_src), n_rows, d, ld, eps, _dp(d_noise), seed & (2**64 - 1),
                                     stream_id & (2**64 - 1), _dp(d_accum), _sh(stream)))
 
 

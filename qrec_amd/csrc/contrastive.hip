@@ -35,9 +35,9 @@ __device__ __forceinline__ void philox10(uint32_t (&c)[4], uint32_t k0, uint32_t
 //   noise != nullptr : use the given U[0,1) numbers (parity tests inject TF-side noise)
 //   noise == nullptr : Philox(counter = {row, lane, stream_lo, stream_hi}, key = seed) -> 4 x 24-bit uniforms
 template <int LPR>
-__global__ __launch_bounds__(256) void perturb_kernel(float *__restrict__ emb, int64_t n_rows, int d, float eps,
-                                                      const float *__restrict__ noise, uint64_t seed, uint64_t stream_id,
-                                                      float *__restrict__ accum) {
+__global__ __launch_bounds__(256) void perturb_kernel(float *__restrict__ emb, const float *__restrict__ src, int64_t n_rows,
+                                                      int d, float eps, const float *__restrict__ noise, uint64_t seed,
+                                                      uint64_t stream_id, float *__restrict__ accum) {
     constexpr int GPW = kWave / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
     const int64_t gid = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void perturb_kernel(float *__restrict__ emb, i
         float ss = nz.x * nz.x + nz.y * nz.y + nz.z * nz.z + nz.w * nz.w;
         ss = row_allreduce_sum<LPR>(ss);
         const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));     // tf.nn.l2_normalize epsilon
-        f32x4 e = *reinterpret_cast<const f32x4 *>(emb + off);
+        f32x4 e = *reinterpret_cast<const f32x4 *>((src ? src : emb) + off);
         auto sgn = [](float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); };
         e.x += sgn(e.x) * (nz.x * inv) * eps; e.y += sgn(e.y) * (nz.y * inv) * eps;
         e.z += sgn(e.z) * (nz.z * inv) * eps; e.w += sgn(e.w) * (nz.w * inv) * eps;
@@ -257,15 +257,15 @@ int run_info_nce(const float *S1, const float *S2, float div, const int32_t *row
 
 extern "C" {
 
-int qrec_perturb_rows(float *d_emb, int64_t n_rows, int32_t d, int32_t ld, float eps, const float *d_noise,
-                      uint64_t seed, uint64_t stream_id, float *d_accum, void *stream) {
+int qrec_perturb_rows(float *d_emb, const float *d_src, int64_t n_rows, int32_t d, int32_t ld, float eps,
+                      const float *d_noise, uint64_t seed, uint64_t stream_id, float *d_accum, void *stream) {
     QREC_REQUIRE(d_emb && n_rows >= 0 && d >= 1 && ld >= d, "qrec_perturb_rows: bad argument");
     if (n_rows == 0) return QREC_OK;
     hipStream_t st = as_stream(stream);
     int64_t blocks;
 #define QREC_PT(LPR)                                                                                              \
     blocks = (n_rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)); if (blocks > 2048) blocks = 2048;                    \
-    hipLaunchKernelGGL((perturb_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, d_emb, n_rows, d, eps, d_noise, \
+    hipLaunchKernelGGL((perturb_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, d_emb, d_src, n_rows, d, eps, d_noise, \
                        seed, stream_id, d_accum)
     switch (ld) {
         case 32: QREC_PT(8); break;

@@ -243,6 +243,7 @@ class SimGCLTrainer:
         z = lambda: DeviceBuffer.zeros((self.n, self.ld), np.float32)
         self.m, self.v = z(), z()
         self.Sm, self.S1, self.S2, self.dOut, self.A, self.B = z(), z(), z(), z(), z(), z()
+        self.V = [[z(), z()], [z(), z()]]                      # ping-pong layer buffers of the two perturbed views
         self.d_loss = DeviceBuffer.zeros(2, np.float64)         # [rec, cl (unscaled)]
         self.row_mask = DeviceBuffer.zeros((self.n + 31) // 32, np.uint32)   # non-zero rows of dOut (batch rows)
         self.max_unique = max_unique
@@ -270,6 +271,31 @@ class SimGCLTrainer:
                                   (self.step_no * 2 + (view - 1)) * 64 + k, d_accum=S, stream=stream)
             x = y
 
+    def _encode_three(self, noises, stream, last_rows):
+        """The clean and the two perturbed encoders of one training step (SimGCL.py:23-36).  All three start from the
+        same E, so the first product A E is formed once and perturbed twice (out of place); from the second layer on
+        each view has its own operand: 3L-2 SpMMs instead of 3L (L=2: 1 full + 3 row-masked instead of 3 + 3)."""
+        for S in (self.Sm, self.S1, self.S2):
+            S.fill_bytes(0, stream)
+        x = [self.E, self.E, self.E]
+        for k in range(self.L):
+            ymask = last_rows if k == self.L - 1 else None
+            y0 = self.A if k % 2 == 0 else self.B
+            capi.spmm_csr(self.plan, x[0], y0, self.ld, d_accum=self.Sm, stream=stream, d_y_row_mask=ymask)
+            for v in (1, 2):
+                yv = self.V[v - 1][k % 2]
+                noise = None if noises is None else noises[(v - 1) * self.L + k]
+                sid = (self.step_no * 2 + (v - 1)) * 64 + k
+                if k == 0:      # same operand as the clean view: reuse its product
+                    capi.perturb_rows(yv, self.n, self.d, self.ld, self.eps, noise, self.seed, sid, d_accum=[self.S1, self.S2][v - 1],
+                                      stream=stream, d_src=y0)
+                else:
+                    capi.spmm_csr(self.plan, x[v], yv, self.ld, stream=stream, d_y_row_mask=ymask)
+                    capi.perturb_rows(yv, self.n, self.d, self.ld, self.eps, noise, self.seed, sid, d_accum=[self.S1, self.S2][v - 1],
+                                      stream=stream)
+                x[v] = yv
+            x[0] = y0
+
     def adam_alpha(self) -> float:
         f = np.float32
         return float(f(f(self.lr) * np.sqrt(f(1) - self.b2p, dtype=f) / (f(1) - self.b1p)))
@@ -283,9 +309,7 @@ class SimGCLTrainer:
         L = float(self.L)
         self.row_mask.fill_bytes(0, stream)
         capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)
-        self._encode(self.Sm, 0, stream=stream, last_rows=self.row_mask)
-        self._encode(self.S1, 1, noises, stream, last_rows=self.row_mask)
-        self._encode(self.S2, 2, noises, stream, last_rows=self.row_mask)
+        self._encode_three(noises, stream, self.row_mask)
         self.dOut.fill_bytes(0, stream)
         self.d_loss.fill_bytes(0, stream)
         # the InfoNCE rows (unique batch users / positive items) are a subset of the rows marked above
