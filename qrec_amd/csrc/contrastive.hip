@@ -76,14 +76,20 @@ __global__ __launch_bounds__(256) void perturb_kernel(float *__restrict__ emb, c
 // z[k] = l2_normalize(S[rows[k]] / div) for both views; r = 1/|x|; dotp = z1.z2
 template <int LPR>
 __global__ __launch_bounds__(256) void gather_normalize_kernel(const float *__restrict__ S1, const float *__restrict__ S2,
-                                                               float div, const int32_t *__restrict__ rows, int n,
+                                                               float div, const int32_t *__restrict__ rows, int n, int n_pad,
                                                                float *__restrict__ z1, float *__restrict__ z2,
                                                                float *__restrict__ r1, float *__restrict__ r2,
                                                                float *__restrict__ dotp) {
     constexpr int GPW = kWave / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
     const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
-    if (k >= n) return;
+    if (k >= n_pad) return;
+    if (k >= n) {   // pad rows: zeros, so that the MFMA kernels can load whole tiles unconditionally
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4 *>(z1 + k * (4 * LPR) + 4 * r) = zero; *reinterpret_cast<f32x4 *>(z2 + k * (4 * LPR) + 4 * r) = zero;
+        if (r == 0) { r1[k] = 0.f; r2[k] = 0.f; dotp[k] = 0.f; }
+        return;
+    }
     const int64_t src = (int64_t)rows[k] * (4 * LPR) + 4 * r, dst = k * (4 * LPR) + 4 * r;
     f32x4 a = *reinterpret_cast<const f32x4 *>(S1 + src), b = *reinterpret_cast<const f32x4 *>(S2 + src);
     a.x /= div; a.y /= div; a.z /= div; a.w /= div; b.x /= div; b.y /= div; b.z /= div; b.w /= div;
@@ -98,7 +104,8 @@ __global__ __launch_bounds__(256) void gather_normalize_kernel(const float *__re
 }
 
 // ExT[b][a] = exp(z1[a].z2[b] * inv_tau): one wavefront per 32x32 tile, f32 MFMA.
-// lane l: row index r = l&31, k-slot h = l>>5 owns columns [64c+32h, 64c+32h+32) of chunk c.
+// lane l: row index r = l&31, k-slot h = l>>5 owns columns [64c+32h, 64c+32h+32) of chunk c: 32 consecutive floats of
+// ITS row for each operand, fetched as 8 unconditional float4 loads (z1, z2 are zero-padded to n_pad rows).
 __global__ __launch_bounds__(256) void exp_logits_kernel(const float *__restrict__ z1, const float *__restrict__ z2,
                                                          int n, int n_pad, int ld, float inv_tau,
                                                          float *__restrict__ ExT, float *__restrict__ psum) {
@@ -111,12 +118,19 @@ __global__ __launch_bounds__(256) void exp_logits_kernel(const float *__restrict
     for (int q = 0; q < 16; q++) acc[q] = 0.f;
     for (int c = 0; c < ld; c += 64) {
         const int col0 = c + 32 * h;
+        const bool kv = col0 < ld;                                  // ld = 32: the second k-slot has no columns
+        const f32x4 *pb = reinterpret_cast<const f32x4 *>(z2 + (int64_t)(b0 + r) * ld + (kv ? col0 : 0));   // A: rows b
+        const f32x4 *pa = reinterpret_cast<const f32x4 *>(z1 + (int64_t)(a0 + r) * ld + (kv ? col0 : 0));   // B: cols a
+        f32x4 vb[8], va[8];
 #pragma unroll
-        for (int s = 0; s < 32; s++) {
-            const int col = col0 + s;
-            const float vb = (b0 + r < n && col < ld) ? z2[(int64_t)(b0 + r) * ld + col] : 0.f;   // A: rows b
-            const float va = (a0 + r < n && col < ld) ? z1[(int64_t)(a0 + r) * ld + col] : 0.f;   // B: cols a
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, va, acc, 0, 0, 0);
+        for (int q = 0; q < 8; q++) { vb[q] = pb[q]; va[q] = pa[q]; }
+        const float keep = kv ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[q].x * keep, va[q].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[q].y * keep, va[q].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[q].z * keep, va[q].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[q].w * keep, va[q].w, acc, 0, 0, 0);
         }
     }
     // C/D: col = lane&31 -> a, row = (q&3) + 8*(q>>2) + 4*h -> b
@@ -138,6 +152,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict_
                                                         float *__restrict__ inv_ttl, double *__restrict__ loss_out) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     double l = 0.0;
+    if (a >= n && a < n_pad) inv_ttl[a] = 0.f;       // pad entries are read (and multiplied by 0) by grad_z_kernel
     if (a < n) {
         float ttl = 0.f;
         for (int t = 0; t < n_pad / 32; t++) ttl += psum[(int64_t)t * n_pad + a];
@@ -168,19 +183,33 @@ __global__ __launch_bounds__(256) void grad_z_kernel(const float *__restrict__ E
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; q++) acc[q] = 0.f;
-    const float my_inv = (MODE == 0 && i < n) ? inv_ttl[i] : 0.f;
+    // all loads are unconditional: ExT, inv_ttl and z are zero in their pad rows/entries
+    const float my_inv = MODE == 0 ? inv_ttl[i] : 0.f;
+    const float *zcol = z + j0 + r;
     for (int c = c_beg; c < c_end; c += 64) {
         const int k0 = c + 32 * h;
+        if (MODE == 0) {
+            // A[i][k] = ExT[k][i]: consecutive lanes read consecutive i -> one coalesced dword load per k
 #pragma unroll 8
-        for (int s = 0; s < 32; s++) {
-            const int k = k0 + s;
-            float ga = 0.f;
-            if (i < n && k < n) {
-                if (MODE == 0) ga = ExT[(int64_t)k * n_pad + i] * my_inv - (k == i ? 1.f : 0.f);
-                else ga = ExT[(int64_t)i * n_pad + k] * inv_ttl[k] - (k == i ? 1.f : 0.f);
+            for (int s = 0; s < 32; s++) {
+                const int k = k0 + s;
+                const float ga = ExT[(int64_t)k * n_pad + i] * my_inv - ((k == i && i < n) ? 1.f : 0.f);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, zcol[(int64_t)k * ld], acc, 0, 0, 0);
             }
-            const float zb = (k < n && j0 + r < ld) ? z[(int64_t)k * ld + j0 + r] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, zb, acc, 0, 0, 0);
+        } else {
+            // A[i][k] = ExT[i][k]: 32 consecutive floats of the lane's own row -> 8 float4 loads (+ inv_ttl[k..])
+            const f32x4 *pe = reinterpret_cast<const f32x4 *>(ExT + (int64_t)i * n_pad + k0);
+            const f32x4 *pt = reinterpret_cast<const f32x4 *>(inv_ttl + k0);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const f32x4 e = pe[q], t = pt[q];
+                const int k = k0 + 4 * q;
+                const float dgl = i < n ? 1.f : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e.x * t.x - (k + 0 == i ? dgl : 0.f), zcol[(int64_t)(k + 0) * ld], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e.y * t.y - (k + 1 == i ? dgl : 0.f), zcol[(int64_t)(k + 1) * ld], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e.z * t.z - (k + 2 == i ? dgl : 0.f), zcol[(int64_t)(k + 2) * ld], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e.w * t.w - (k + 3 == i ? dgl : 0.f), zcol[(int64_t)(k + 3) * ld], acc, 0, 0, 0);
+            }
         }
     }
     float *out = out_parts + (int64_t)ks * n_pad * ld;
@@ -235,13 +264,13 @@ int run_info_nce(const float *S1, const float *S2, float div, const int32_t *row
     float *psum = inv_ttl + n_pad;                       // [n_pad/32][n_pad]
     float *ExT = psum + (int64_t)(n_pad / 32) * n_pad;   // [n_pad][n_pad]
     const float inv_tau = 1.0f / tau;
-    const unsigned row_blocks = (unsigned)((n + 4 * GPW - 1) / (4 * GPW));
-    hipLaunchKernelGGL((gather_normalize_kernel<LPR>), dim3(row_blocks), dim3(256), 0, st, S1, S2, div, rows, n, z1, z2, r1, r2, dotp);
+    const unsigned row_blocks = (unsigned)((n + 4 * GPW - 1) / (4 * GPW)), pad_blocks = (unsigned)((n_pad + 4 * GPW - 1) / (4 * GPW));
+    hipLaunchKernelGGL((gather_normalize_kernel<LPR>), dim3(pad_blocks), dim3(256), 0, st, S1, S2, div, rows, n, n_pad, z1, z2, r1, r2, dotp);
     QREC_LAUNCH_CHECK();
     hipLaunchKernelGGL(exp_logits_kernel, dim3((unsigned)(n_pad / 32), (unsigned)((n_pad / 32 + 3) / 4)), dim3(256), 0, st,
                        z1, z2, n, n_pad, ld, inv_tau, ExT, psum);
     QREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, psum, n, n_pad, dotp, inv_tau, inv_ttl, loss);
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, psum, n, n_pad, dotp, inv_tau, inv_ttl, loss);
     QREC_LAUNCH_CHECK();
     const dim3 gg((unsigned)(n_pad / 32), (unsigned)((ld + 31) / 32), (unsigned)(kSplitK / 4));
     hipLaunchKernelGGL((grad_z_kernel<0>), gg, dim3(256), 0, st, ExT, inv_ttl, z2, n, n_pad, ld, inv_tau, dz1);

@@ -30,6 +30,7 @@ capi.device_sync()
 # whole step
 t0 = time.perf_counter()
 for k in range(a.steps): step(k)
+t_host = (time.perf_counter() - t0) / a.steps
 capi.device_sync(); dt = (time.perf_counter() - t0) / a.steps
 # with per-step loss read-back (what the reference's print forces)
 t0 = time.perf_counter()
@@ -45,7 +46,7 @@ for rep in range(20):
     e0.record(); capi.adam_step(tr.E, tr.m, tr.v, tr.A, N * tr.ld, 0.25, 1e-9); e1.record(); e1.sync(); ts.append(e1.elapsed_ms_since(e0))
 adam_ms = float(np.median(ts))
 alg = tr.plan.bytes_algorithmic(a.dim) + N * a.dim * 4   # + accum RMW read
-out = dict(workload=f"LightGCN L={a.layers} d={a.dim} batch={B} Yelp2018-shape N={N} nnz={nnz}", ms_per_step=dt * 1e3, ms_per_step_with_loss_readback=dt_sync * 1e3,
+out = dict(workload=f"LightGCN L={a.layers} d={a.dim} batch={B} Yelp2018-shape N={N} nnz={nnz}", ms_per_step=dt * 1e3, host_enqueue_ms_per_step=t_host * 1e3, ms_per_step_with_loss_readback=dt_sync * 1e3,
            triplets_per_s=B / dt, steps_per_epoch=-(-n // B), epoch_s=dt * -(-n // B),
            spmm_ms=spmm_ms, spmm_algorithmic_GBps=alg / spmm_ms / 1e6, spmm_gather_GBps=(nnz * (8 + a.dim * 4) + 2 * N * a.dim * 4) / spmm_ms / 1e6,
            spmm_gflops=2 * nnz * a.dim / spmm_ms / 1e6, adam_ms=adam_ms, adam_GBps=7 * 4 * N * tr.ld / adam_ms / 1e6, segments=tr.plan.n_segs, long_rows=tr.plan.n_long)
