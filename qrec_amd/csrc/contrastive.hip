@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void gather_normalize_kernel(const float *__re
 // ITS row for each operand, fetched as 8 unconditional float4 loads (z1, z2 are zero-padded to n_pad rows).
 __global__ __launch_bounds__(256) void exp_logits_kernel(const float *__restrict__ z1, const float *__restrict__ z2,
                                                          int n, int n_pad, int ld, float inv_tau,
-                                                         float *__restrict__ ExT, float *__restrict__ psum) {
+                                                         float *__restrict__ ExT, float *__restrict__ Ex,
+                                                         float *__restrict__ psum) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int a0 = blockIdx.x * 32, b0 = (blockIdx.y * 4 + wave) * 32;
@@ -134,13 +135,21 @@ __global__ __launch_bounds__(256) void exp_logits_kernel(const float *__restrict
         }
     }
     // C/D: col = lane&31 -> a, row = (q&3) + 8*(q>>2) + 4*h -> b
+    // Both orientations are stored: each gradient product then reads its A operand along its own rows (float4).
     float part = 0.f;   // sum over this tile's 32 b's for column a (fixed order: deterministic)
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const int b = b0 + (q & 3) + 8 * (q >> 2) + 4 * h, a = a0 + r;
-        const float e = (a < n && b < n) ? expf(acc[q] * inv_tau) : 0.f;
-        ExT[(int64_t)b * n_pad + a] = e;
-        part += e;
+    for (int g4 = 0; g4 < 4; g4++) {
+        const int a = a0 + r, bq = b0 + 8 * g4 + 4 * h;
+        f32x4 e4;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int b = bq + t;
+            const float e = (a < n && b < n) ? expf(acc[4 * g4 + t] * inv_tau) : 0.f;
+            ExT[(int64_t)b * n_pad + a] = e;
+            e4[t] = e;
+            part += e;
+        }
+        *reinterpret_cast<f32x4 *>(Ex + (int64_t)a * n_pad + bq) = e4;
     }
     part += __shfl_xor(part, 32, kWave);
     if (h == 0) psum[(int64_t)(b0 / 32) * n_pad + a0 + r] = part;
@@ -150,14 +159,19 @@ __global__ __launch_bounds__(256) void exp_logits_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ psum, int n, int n_pad,
                                                         const float *__restrict__ dotp, float inv_tau,
                                                         float *__restrict__ inv_ttl, double *__restrict__ loss_out) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    // 8 lanes per column a: lane t adds tiles t, t+8, ... in order, the 8 partial sums are folded in a fixed butterfly
+    const int a = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, t0 = threadIdx.x & 7;
     double l = 0.0;
-    if (a >= n && a < n_pad) inv_ttl[a] = 0.f;       // pad entries are read (and multiplied by 0) by grad_z_kernel
-    if (a < n) {
-        float ttl = 0.f;
-        for (int t = 0; t < n_pad / 32; t++) ttl += psum[(int64_t)t * n_pad + a];
-        inv_ttl[a] = 1.0f / ttl;
-        l = (double)(-logf(expf(dotp[a] * inv_tau) / ttl));
+    float ttl = 0.f;
+    if (a < n)
+        for (int t = t0; t < n_pad / 32; t += 8) ttl += psum[(int64_t)t * n_pad + a];
+    ttl += __shfl_xor(ttl, 1, kWave); ttl += __shfl_xor(ttl, 2, kWave); ttl += __shfl_xor(ttl, 4, kWave);
+    if (t0 == 0) {
+        if (a >= n && a < n_pad) inv_ttl[a] = 0.f;       // pad entries are read (and multiplied by 0) by grad_z_kernel
+        if (a < n) {
+            inv_ttl[a] = 1.0f / ttl;
+            l = (double)(-logf(expf(dotp[a] * inv_tau) / ttl));
+        }
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) l += __shfl_xor(l, m, kWave);
@@ -171,7 +185,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict_
 constexpr int kSplitK = 16;   // K = n is cut into 16 slices -> 16x more wavefronts; partials summed by the consumer
 
 template <int MODE>
-__global__ __launch_bounds__(256) void grad_z_kernel(const float *__restrict__ ExT, const float *__restrict__ inv_ttl,
+__global__ __launch_bounds__(256) void grad_z_kernel(const float *__restrict__ EA, const float *__restrict__ inv_ttl,
                                                      const float *__restrict__ z, int n, int n_pad, int ld, float inv_tau,
                                                      float *__restrict__ out_parts) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -188,28 +202,21 @@ __global__ __launch_bounds__(256) void grad_z_kernel(const float *__restrict__ E
     const float *zcol = z + j0 + r;
     for (int c = c_beg; c < c_end; c += 64) {
         const int k0 = c + 32 * h;
-        if (MODE == 0) {
-            // A[i][k] = ExT[k][i]: consecutive lanes read consecutive i -> one coalesced dword load per k
-#pragma unroll 8
-            for (int s = 0; s < 32; s++) {
-                const int k = k0 + s;
-                const float ga = ExT[(int64_t)k * n_pad + i] * my_inv - ((k == i && i < n) ? 1.f : 0.f);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, zcol[(int64_t)k * ld], acc, 0, 0, 0);
-            }
-        } else {
-            // A[i][k] = ExT[i][k]: 32 consecutive floats of the lane's own row -> 8 float4 loads (+ inv_ttl[k..])
-            const f32x4 *pe = reinterpret_cast<const f32x4 *>(ExT + (int64_t)i * n_pad + k0);
-            const f32x4 *pt = reinterpret_cast<const f32x4 *>(inv_ttl + k0);
+        // A[i][k] = EA[i][k] * scale - (i == k), EA = Ex (MODE 0, scale = 1/ttl[i]) or ExT (MODE 1, scale = 1/ttl[k]):
+        // 32 consecutive floats of the lane's own row -> 8 float4 loads
+        const f32x4 *pe = reinterpret_cast<const f32x4 *>(EA + (int64_t)i * n_pad + k0);
+        const f32x4 *pt = reinterpret_cast<const f32x4 *>(inv_ttl + k0);
+        const float dgl = i < n ? 1.f : 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const f32x4 e = pe[q], t = pt[q];
-                const int k = k0 + 4 * q;
-                const float dgl = i < n ? 1.f : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e.x * t.x - (k + 0 == i ? dgl : 0.f), zcol[(int64_t)(k + 0) * ld], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e.y * t.y - (k + 1 == i ? dgl : 0.f), zcol[(int64_t)(k + 1) * ld], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e.z * t.z - (k + 2 == i ? dgl : 0.f), zcol[(int64_t)(k + 2) * ld], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e.w * t.w - (k + 3 == i ? dgl : 0.f), zcol[(int64_t)(k + 3) * ld], acc, 0, 0, 0);
-            }
+        for (int q = 0; q < 8; q++) {
+            const f32x4 e = pe[q];
+            f32x4 t = {my_inv, my_inv, my_inv, my_inv};
+            if (MODE == 1) t = pt[q];
+            const int k = k0 + 4 * q;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e.x * t.x - (k + 0 == i ? dgl : 0.f), zcol[(int64_t)(k + 0) * ld], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e.y * t.y - (k + 1 == i ? dgl : 0.f), zcol[(int64_t)(k + 1) * ld], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e.z * t.z - (k + 2 == i ? dgl : 0.f), zcol[(int64_t)(k + 2) * ld], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e.w * t.w - (k + 3 == i ? dgl : 0.f), zcol[(int64_t)(k + 3) * ld], acc, 0, 0, 0);
         }
     }
     float *out = out_parts + (int64_t)ks * n_pad * ld;
@@ -263,17 +270,18 @@ int run_info_nce(const float *S1, const float *S2, float div, const int32_t *row
     float *r1 = dz2 + kSplitK * tab, *r2 = r1 + n_pad, *dotp = r2 + n_pad, *inv_ttl = dotp + n_pad;
     float *psum = inv_ttl + n_pad;                       // [n_pad/32][n_pad]
     float *ExT = psum + (int64_t)(n_pad / 32) * n_pad;   // [n_pad][n_pad]
+    float *Ex = ExT + (int64_t)n_pad * n_pad;            // [n_pad][n_pad], the other orientation
     const float inv_tau = 1.0f / tau;
     const unsigned row_blocks = (unsigned)((n + 4 * GPW - 1) / (4 * GPW)), pad_blocks = (unsigned)((n_pad + 4 * GPW - 1) / (4 * GPW));
     hipLaunchKernelGGL((gather_normalize_kernel<LPR>), dim3(pad_blocks), dim3(256), 0, st, S1, S2, div, rows, n, n_pad, z1, z2, r1, r2, dotp);
     QREC_LAUNCH_CHECK();
     hipLaunchKernelGGL(exp_logits_kernel, dim3((unsigned)(n_pad / 32), (unsigned)((n_pad / 32 + 3) / 4)), dim3(256), 0, st,
-                       z1, z2, n, n_pad, ld, inv_tau, ExT, psum);
+                       z1, z2, n, n_pad, ld, inv_tau, ExT, Ex, psum);
     QREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, psum, n, n_pad, dotp, inv_tau, inv_ttl, loss);
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((n_pad * 8 + 255) / 256)), dim3(256), 0, st, psum, n, n_pad, dotp, inv_tau, inv_ttl, loss);
     QREC_LAUNCH_CHECK();
     const dim3 gg((unsigned)(n_pad / 32), (unsigned)((ld + 31) / 32), (unsigned)(kSplitK / 4));
-    hipLaunchKernelGGL((grad_z_kernel<0>), gg, dim3(256), 0, st, ExT, inv_ttl, z2, n, n_pad, ld, inv_tau, dz1);
+    hipLaunchKernelGGL((grad_z_kernel<0>), gg, dim3(256), 0, st, Ex, inv_ttl, z2, n, n_pad, ld, inv_tau, dz1);
     QREC_LAUNCH_CHECK();
     hipLaunchKernelGGL((grad_z_kernel<1>), gg, dim3(256), 0, st, ExT, inv_ttl, z1, n, n_pad, ld, inv_tau, dz2);
     QREC_LAUNCH_CHECK();
@@ -311,7 +319,7 @@ int qrec_perturb_rows(float *d_emb, const float *d_src, int64_t n_rows, int32_t 
 int qrec_info_nce_workspace_bytes(int32_t n, int32_t ld, int64_t *bytes) {
     QREC_REQUIRE(bytes && n >= 0 && ld > 0, "qrec_info_nce_workspace_bytes: bad argument");
     const int64_t n_pad = ((int64_t)n + 63) / 64 * 64;
-    *bytes = 4 * ((2 + 2 * 16) * n_pad * ld + 4 * n_pad + (n_pad / 32) * n_pad + n_pad * n_pad);
+    *bytes = 4 * ((2 + 2 * 16) * n_pad * ld + 4 * n_pad + (n_pad / 32) * n_pad + 2 * n_pad * n_pad);
     return QREC_OK;
 }
 
