@@ -53,23 +53,33 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const float *__restrict_
     for (int t = 0; t < NT; t++)
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
+    // Operand fetch without branches: the lane's own row (clamped to the last row; rows past the end are not stored)
+    // as 8 float4 loads per table, the weight rows as coalesced dwords.  ld = 32: the upper k-slot has no columns
+    // and feeds zeros (every lane must issue every MFMA).
+    const int64_t rowc = ok ? row : n_rows - 1;
     for (int c = 0; c < LD; c += 64) {
-        const int k0 = c + 32 * h;   // ld = 32: the upper k-slot has no columns and feeds zeros (no divergence:
-                                     // every lane must issue every MFMA)
+        const int k0 = c + 32 * h;
+        const bool kv = k0 < LD;
+        const int kb = kv ? k0 : 0;
+        const float keep = kv ? 1.f : 0.f;
+        const f32x4 *pe = reinterpret_cast<const f32x4 *>(E + rowc * LD + kb);
+        const f32x4 *ps = reinterpret_cast<const f32x4 *>(side + rowc * LD + kb);
         float a1[32], a2[32];
 #pragma unroll
-        for (int s = 0; s < 32; s++) {
-            const bool in = ok && (k0 + s < LD);
-            const float e = in ? E[row * LD + k0 + s] : 0.f, sd = in ? side[row * LD + k0 + s] : 0.f;
-            a1[s] = sd + e; a2[s] = e * sd;
+        for (int q = 0; q < 8; q++) {
+            const f32x4 e = pe[q], sd = ps[q];
+            a1[4 * q + 0] = (sd.x + e.x) * keep; a2[4 * q + 0] = (e.x * sd.x) * keep;
+            a1[4 * q + 1] = (sd.y + e.y) * keep; a2[4 * q + 1] = (e.y * sd.y) * keep;
+            a1[4 * q + 2] = (sd.z + e.z) * keep; a2[4 * q + 2] = (e.z * sd.z) * keep;
+            a1[4 * q + 3] = (sd.w + e.w) * keep; a2[4 * q + 3] = (e.w * sd.w) * keep;
         }
 #pragma unroll
         for (int t = 0; t < NT; t++) {
+            const float *w1 = W1 + (int64_t)kb * LD + 32 * t + r, *w2 = W2 + (int64_t)kb * LD + 32 * t + r;
 #pragma unroll
             for (int s = 0; s < 32; s++) {
-                const bool in = k0 + s < LD;
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], in ? W1[(k0 + s) * LD + 32 * t + r] : 0.f, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], in ? W2[(k0 + s) * LD + 32 * t + r] : 0.f, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], w1[s * LD], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], w2[s * LD], acc[t], 0, 0, 0);
             }
         }
     }
@@ -179,19 +189,35 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const float *__restrict_
     for (int t = 0; t < NT; t++)
 #pragma unroll
         for (int q = 0; q < 16; q++) { a1[t][q] = 0.f; a2[t][q] = 0.f; }
+    const int64_t rowc = ok ? row : n_rows - 1;
     for (int c = 0; c < LD; c += 64) {
         const int k0 = c + 32 * h;
+        const bool kv = k0 < LD;
+        const int kb = kv ? k0 : 0;
+        const float keep = kv ? 1.f : 0.f;
+        const f32x4 *pg = reinterpret_cast<const f32x4 *>(dpre + rowc * LD + kb);
         float g[32];
 #pragma unroll
-        for (int s = 0; s < 32; s++) g[s] = (ok && k0 + s < LD) ? dpre[row * LD + k0 + s] : 0.f;
+        for (int q = 0; q < 8; q++) {
+            const f32x4 v = pg[q];
+            g[4 * q] = v.x * keep; g[4 * q + 1] = v.y * keep; g[4 * q + 2] = v.z * keep; g[4 * q + 3] = v.w * keep;
+        }
 #pragma unroll
         for (int t = 0; t < NT; t++) {
+            // B[k][j] = W[j][k]: 32 consecutive floats of the lane's weight row j = 32t + r
+            const f32x4 *p1 = reinterpret_cast<const f32x4 *>(W1 + (int64_t)(32 * t + r) * LD + kb);
+            const f32x4 *p2 = reinterpret_cast<const f32x4 *>(W2 + (int64_t)(32 * t + r) * LD + kb);
 #pragma unroll
-            for (int s = 0; s < 32; s++) {
-                const int k = k0 + s;   // B[k][j] = W[j][k]
-                const float b1 = k < LD ? W1[(32 * t + r) * LD + k] : 0.f, b2 = k < LD ? W2[(32 * t + r) * LD + k] : 0.f;
-                a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[s], b1, a1[t], 0, 0, 0);
-                a2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[s], b2, a2[t], 0, 0, 0);
+            for (int q = 0; q < 8; q++) {
+                const f32x4 b1 = p1[q], b2 = p2[q];
+                a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[4 * q + 0], b1.x, a1[t], 0, 0, 0);
+                a2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[4 * q + 0], b2.x, a2[t], 0, 0, 0);
+                a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[4 * q + 1], b1.y, a1[t], 0, 0, 0);
+                a2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[4 * q + 1], b2.y, a2[t], 0, 0, 0);
+                a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[4 * q + 2], b1.z, a1[t], 0, 0, 0);
+                a2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[4 * q + 2], b2.z, a2[t], 0, 0, 0);
+                a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[4 * q + 3], b1.w, a1[t], 0, 0, 0);
+                a2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[4 * q + 3], b2.w, a2[t], 0, 0, 0);
             }
         }
     }
@@ -222,33 +248,39 @@ __global__ __launch_bounds__(64) void wgrad_kernel(const float *__restrict__ E, 
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; q++) acc[q] = 0.f;
+    // 32 k-steps' operands are fetched first (96 independent, unconditional, coalesced dword loads), then the 32
+    // MFMAs run: one wavefront per SIMD cannot hide a load behind every MFMA.  Rows past the end feed a = 0.
+    const float *pe = E + 32 * ti + r, *ps = side + 32 * ti + r, *pd = dpre + 32 * tj + r;
     for (int c = 0; c < kSlabRows; c += 64) {
-#pragma unroll 8
+        float a[32], b[32];
+#pragma unroll
         for (int s = 0; s < 32; s++) {
             const int64_t n = n0 + c + 32 * h + s;
-            float a = 0.f, b = 0.f;
-            if (n < n_rows) {
-                const float e = E[n * ld + 32 * ti + r], sd = side[n * ld + 32 * ti + r];
-                a = which == 0 ? sd + e : e * sd;
-                b = dpre[n * ld + 32 * tj + r];
-            }
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            const int64_t nc = n < n_rows ? n : n_rows - 1;
+            const float e = pe[nc * ld], sd = ps[nc * ld];
+            a[s] = (which == 0 ? sd + e : e * sd) * (n < n_rows ? 1.f : 0.f);
+            b[s] = pd[nc * ld];
         }
+#pragma unroll
+        for (int s = 0; s < 32; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
     }
     float *out = partial + (((int64_t)slab * 2 + which) * ld + 32 * ti) * ld + 32 * tj;
 #pragma unroll
     for (int q = 0; q < 16; q++) out[(int64_t)cd_row(q, h) * ld + r] = acc[q];
 }
 
-// gW[which][i][j] = sum_slab partial[slab][which][i][j]   (slab order: deterministic)
+// gW[which][i][j] = sum_slab partial[slab][which][i][j]: 8 lanes per element (lane t adds slabs t, t+8, ... in
+// order), folded in a fixed butterfly -- deterministic, 8x shorter dependent chain
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int n_slabs, int ld,
                                                            float *__restrict__ gW1, float *__restrict__ gW2) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 2 * ld * ld) return;
-    const int which = idx / (ld * ld), ij = idx % (ld * ld);
+    const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, t0 = threadIdx.x & 7;
+    const bool ok = idx < 2 * ld * ld;
+    const int which = ok ? idx / (ld * ld) : 0, ij = ok ? idx % (ld * ld) : 0;
     float acc = 0.f;
-    for (int s = 0; s < n_slabs; s++) acc += partial[((int64_t)s * 2 + which) * ld * ld + ij];
-    (which == 0 ? gW1 : gW2)[ij] = acc;
+    if (ok)
+        for (int s = t0; s < n_slabs; s += 8) acc += partial[((int64_t)s * 2 + which) * ld * ld + ij];
+    acc += __shfl_xor(acc, 1, kWave); acc += __shfl_xor(acc, 2, kWave); acc += __shfl_xor(acc, 4, kWave);
+    if (ok && t0 == 0) (which == 0 ? gW1 : gW2)[ij] = acc;
 }
 
 // dst[row][c] += src[row][off + c], c < d     (gradient of the ego block of the wide table)
@@ -332,7 +364,7 @@ int qrec_ngcf_layer_bwd(const float *d_dE_next, const float *d_dWide, const floa
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)n_slabs, 2, (unsigned)(nt * nt)), dim3(64), 0, st, d_E, d_side, d_dpre,
                        n_rows, ld, d_partial);
     QREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((2 * ld * ld + 255) / 256)), dim3(256), 0, st, d_partial, n_slabs,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((2 * ld * ld * 8 + 255) / 256)), dim3(256), 0, st, d_partial, n_slabs,
                        ld, d_gW1, d_gW2);
     QREC_LAUNCH_CHECK();
     return QREC_OK;
