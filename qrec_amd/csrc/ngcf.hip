@@ -38,58 +38,67 @@ __device__ __forceinline__ void philox10(uint32_t (&c)[4], uint32_t k0, uint32_t
 __device__ __forceinline__ int cd_row(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
 
 // pre[32 rows][ld] = (side + E) W1 + (E*side) W2      NT = ld/32 output column tiles
+// Persistent blocks: the two weight matrices are staged in LDS once per block (2 x LD*LD floats) and every
+// wavefront walks 32-row tiles.  A operand: the lane's own row, 8 float4 loads per table and 64-column chunk;
+// B operand: ds_read_b32 of W[k][32t + r] (consecutive lanes, consecutive banks).  The first version read every B
+// value from global memory right before its MFMA (the compiler keeps such loads one MFMA ahead): ~400 clocks of
+// load latency per 64-clock MFMA, 51 us for 1.1 GFLOP.
 template <int NT>
 __global__ __launch_bounds__(256) void dense_fwd_kernel(const float *__restrict__ E, const float *__restrict__ side,
                                                         const float *__restrict__ W1, const float *__restrict__ W2,
                                                         int64_t n_rows, float *__restrict__ pre) {
     constexpr int LD = 32 * NT;
+    extern __shared__ float s_w[];                  // [2][LD][LD]
+    for (int k = threadIdx.x; k < LD * LD / 4; k += blockDim.x) {
+        reinterpret_cast<f32x4 *>(s_w)[k] = reinterpret_cast<const f32x4 *>(W1)[k];
+        reinterpret_cast<f32x4 *>(s_w + LD * LD)[k] = reinterpret_cast<const f32x4 *>(W2)[k];
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
-    if (row0 >= n_rows) return;
-    const int64_t row = row0 + r;
-    const bool ok = row < n_rows;
-    f32x16 acc[NT];
+    const int64_t n_tiles = (n_rows + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = tile * 32, row = row0 + r;
+        const int64_t rowc = row < n_rows ? row : n_rows - 1;      // rows past the end are computed on a copy, not stored
+        f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; t++)
+        for (int t = 0; t < NT; t++)
 #pragma unroll
-        for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
-    // Operand fetch without branches: the lane's own row (clamped to the last row; rows past the end are not stored)
-    // as 8 float4 loads per table, the weight rows as coalesced dwords.  ld = 32: the upper k-slot has no columns
-    // and feeds zeros (every lane must issue every MFMA).
-    const int64_t rowc = ok ? row : n_rows - 1;
-    for (int c = 0; c < LD; c += 64) {
-        const int k0 = c + 32 * h;
-        const bool kv = k0 < LD;
-        const int kb = kv ? k0 : 0;
-        const float keep = kv ? 1.f : 0.f;
-        const f32x4 *pe = reinterpret_cast<const f32x4 *>(E + rowc * LD + kb);
-        const f32x4 *ps = reinterpret_cast<const f32x4 *>(side + rowc * LD + kb);
-        float a1[32], a2[32];
+            for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const f32x4 e = pe[q], sd = ps[q];
-            a1[4 * q + 0] = (sd.x + e.x) * keep; a2[4 * q + 0] = (e.x * sd.x) * keep;
-            a1[4 * q + 1] = (sd.y + e.y) * keep; a2[4 * q + 1] = (e.y * sd.y) * keep;
-            a1[4 * q + 2] = (sd.z + e.z) * keep; a2[4 * q + 2] = (e.z * sd.z) * keep;
-            a1[4 * q + 3] = (sd.w + e.w) * keep; a2[4 * q + 3] = (e.w * sd.w) * keep;
-        }
+        for (int c = 0; c < LD; c += 64) {
+            const int k0 = c + 32 * h;
+            const bool kv = k0 < LD;                 // ld = 32: the upper k-slot has no columns and feeds zeros
+            const int kb = kv ? k0 : 0;
+            const float keep = kv ? 1.f : 0.f;
+            const f32x4 *pe = reinterpret_cast<const f32x4 *>(E + rowc * LD + kb);
+            const f32x4 *ps = reinterpret_cast<const f32x4 *>(side + rowc * LD + kb);
+            float a1[32], a2[32];
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            const float *w1 = W1 + (int64_t)kb * LD + 32 * t + r, *w2 = W2 + (int64_t)kb * LD + 32 * t + r;
+            for (int q = 0; q < 8; q++) {
+                const f32x4 e = pe[q], sd = ps[q];
+                a1[4 * q + 0] = (sd.x + e.x) * keep; a2[4 * q + 0] = (e.x * sd.x) * keep;
+                a1[4 * q + 1] = (sd.y + e.y) * keep; a2[4 * q + 1] = (e.y * sd.y) * keep;
+                a1[4 * q + 2] = (sd.z + e.z) * keep; a2[4 * q + 2] = (e.z * sd.z) * keep;
+                a1[4 * q + 3] = (sd.w + e.w) * keep; a2[4 * q + 3] = (e.w * sd.w) * keep;
+            }
 #pragma unroll
-            for (int s = 0; s < 32; s++) {
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], w1[s * LD], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], w2[s * LD], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; t++) {
+                const float *w1 = s_w + kb * LD + 32 * t + r, *w2 = w1 + LD * LD;
+#pragma unroll
+                for (int s = 0; s < 32; s++) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], w1[s * LD], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], w2[s * LD], acc[t], 0, 0, 0);
+                }
             }
         }
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int64_t orow = row0 + cd_row(q, h);
+                if (orow < n_rows) pre[orow * LD + 32 * t + r] = acc[t][q];
+            }
     }
-#pragma unroll
-    for (int t = 0; t < NT; t++)
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int64_t orow = row0 + cd_row(q, h);
-            if (orow < n_rows) pre[orow * LD + 32 * t + r] = acc[t][q];
-        }
 }
 
 // One group of LPR lanes per row (float4 per lane).  In place on `pre_gate`: reads pre, writes the
@@ -173,100 +182,120 @@ __global__ __launch_bounds__(256) void dpre_rows_kernel(const float *__restrict_
 }
 
 // dA1 = dpre W1^T, dA2 = dpre W2^T;  dside = dA1 + dA2*E ;  dE = dA1 + dA2*side
+// Same structure as dense_fwd_kernel; B[k][j] = W[j][k], so the weights are TRANSPOSED on their way into LDS
+// (s_wt[k][j]) and the B reads are again consecutive lanes on consecutive banks.
 template <int NT>
 __global__ __launch_bounds__(256) void dense_bwd_kernel(const float *__restrict__ dpre, const float *__restrict__ W1,
                                                         const float *__restrict__ W2, const float *__restrict__ E,
                                                         const float *__restrict__ side, int64_t n_rows,
                                                         float *__restrict__ dside, float *__restrict__ dE) {
     constexpr int LD = 32 * NT;
+    extern __shared__ float s_w[];                  // [2][LD][LD], transposed
+    for (int k = threadIdx.x; k < LD * LD; k += blockDim.x) {
+        const int j = k / LD, c = k % LD;           // coalesced read of W[j][c], scattered write to s_wt[c][j] (once per block)
+        s_w[c * LD + j] = W1[k];
+        s_w[LD * LD + c * LD + j] = W2[k];
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
-    if (row0 >= n_rows) return;
-    const int64_t row = row0 + r;
-    const bool ok = row < n_rows;
-    f32x16 a1[NT], a2[NT];
+    const int64_t n_tiles = (n_rows + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = tile * 32, row = row0 + r;
+        const int64_t rowc = row < n_rows ? row : n_rows - 1;
+        f32x16 a1[NT], a2[NT];
 #pragma unroll
-    for (int t = 0; t < NT; t++)
+        for (int t = 0; t < NT; t++)
 #pragma unroll
-        for (int q = 0; q < 16; q++) { a1[t][q] = 0.f; a2[t][q] = 0.f; }
-    const int64_t rowc = ok ? row : n_rows - 1;
-    for (int c = 0; c < LD; c += 64) {
-        const int k0 = c + 32 * h;
-        const bool kv = k0 < LD;
-        const int kb = kv ? k0 : 0;
-        const float keep = kv ? 1.f : 0.f;
-        const f32x4 *pg = reinterpret_cast<const f32x4 *>(dpre + rowc * LD + kb);
-        float g[32];
+            for (int q = 0; q < 16; q++) { a1[t][q] = 0.f; a2[t][q] = 0.f; }
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const f32x4 v = pg[q];
-            g[4 * q] = v.x * keep; g[4 * q + 1] = v.y * keep; g[4 * q + 2] = v.z * keep; g[4 * q + 3] = v.w * keep;
-        }
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            // B[k][j] = W[j][k]: 32 consecutive floats of the lane's weight row j = 32t + r
-            const f32x4 *p1 = reinterpret_cast<const f32x4 *>(W1 + (int64_t)(32 * t + r) * LD + kb);
-            const f32x4 *p2 = reinterpret_cast<const f32x4 *>(W2 + (int64_t)(32 * t + r) * LD + kb);
+        for (int c = 0; c < LD; c += 64) {
+            const int k0 = c + 32 * h;
+            const bool kv = k0 < LD;
+            const int kb = kv ? k0 : 0;
+            const float keep = kv ? 1.f : 0.f;
+            const f32x4 *pg = reinterpret_cast<const f32x4 *>(dpre + rowc * LD + kb);
+            float g[32];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
-                const f32x4 b1 = p1[q], b2 = p2[q];
-                a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[4 * q + 0], b1.x, a1[t], 0, 0, 0);
-                a2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[4 * q + 0], b2.x, a2[t], 0, 0, 0);
-                a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[4 * q + 1], b1.y, a1[t], 0, 0, 0);
-                a2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[4 * q + 1], b2.y, a2[t], 0, 0, 0);
-                a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[4 * q + 2], b1.z, a1[t], 0, 0, 0);
-                a2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[4 * q + 2], b2.z, a2[t], 0, 0, 0);
-                a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[4 * q + 3], b1.w, a1[t], 0, 0, 0);
-                a2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[4 * q + 3], b2.w, a2[t], 0, 0, 0);
+                const f32x4 v = pg[q];
+                g[4 * q] = v.x * keep; g[4 * q + 1] = v.y * keep; g[4 * q + 2] = v.z * keep; g[4 * q + 3] = v.w * keep;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const float *w1 = s_w + kb * LD + 32 * t + r, *w2 = w1 + LD * LD;
+#pragma unroll
+                for (int s = 0; s < 32; s++) {
+                    a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[s], w1[s * LD], a1[t], 0, 0, 0);
+                    a2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[s], w2[s * LD], a2[t], 0, 0, 0);
+                }
             }
         }
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int64_t orow = row0 + cd_row(q, h);
+                if (orow < n_rows) {
+                    const int64_t o = orow * LD + 32 * t + r;
+                    const float e = E[o], sd = side[o];
+                    dside[o] = a1[t][q] + a2[t][q] * e;
+                    dE[o] = a1[t][q] + a2[t][q] * sd;
+                }
+            }
     }
-#pragma unroll
-    for (int t = 0; t < NT; t++)
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int64_t orow = row0 + cd_row(q, h);
-            if (orow < n_rows) {
-                const int64_t o = orow * LD + 32 * t + r;
-                const float e = E[o], sd = side[o];
-                dside[o] = a1[t][q] + a2[t][q] * e;
-                dE[o] = a1[t][q] + a2[t][q] * sd;
-            }
-        }
 }
 
 // partial[slab][which][i][j] = sum over the slab's rows n of A_which[n][i] * dpre[n][j]
-//   which = 0: A = side + E ; 1: A = E * side.     One wavefront per (slab, which, 32x32 tile).
-constexpr int kSlabRows = 512;
+//   which = 0: A = side + E ; 1: A = E * side.
+// One wavefront per (slab of 128 rows, 32-column block ti of A): it forms BOTH products for ALL NT column tiles of
+// dpre, i.e. 2*NT MFMAs per k-step from 2 + NT coalesced dword loads (the first version issued 3 loads per MFMA from
+// one wavefront per SIMD and sat in load latency: 98 us for 1.1 GFLOP).  A chunk's 32 k-steps are fetched first, then
+// its MFMAs run.  Rows past the end feed a = 0.
+constexpr int kSlabRows = 128;
+template <int NT>
 __global__ __launch_bounds__(64) void wgrad_kernel(const float *__restrict__ E, const float *__restrict__ side,
-                                                   const float *__restrict__ dpre, int64_t n_rows, int ld,
+                                                   const float *__restrict__ dpre, int64_t n_rows,
                                                    float *__restrict__ partial) {
+    constexpr int LD = 32 * NT;
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int nt = ld / 32;
-    const int slab = blockIdx.x, which = blockIdx.y, ti = blockIdx.z / nt, tj = blockIdx.z % nt;
+    const int slab = blockIdx.x, ti = blockIdx.y;
     const int64_t n0 = (int64_t)slab * kSlabRows;
-    f32x16 acc;
+    f32x16 acc[2][NT];
 #pragma unroll
-    for (int q = 0; q < 16; q++) acc[q] = 0.f;
-    // 32 k-steps' operands are fetched first (96 independent, unconditional, coalesced dword loads), then the 32
-    // MFMAs run: one wavefront per SIMD cannot hide a load behind every MFMA.  Rows past the end feed a = 0.
-    const float *pe = E + 32 * ti + r, *ps = side + 32 * ti + r, *pd = dpre + 32 * tj + r;
+    for (int w = 0; w < 2; w++)
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[w][t][q] = 0.f;
+    const float *pe = E + 32 * ti + r, *ps = side + 32 * ti + r, *pd = dpre + r;
     for (int c = 0; c < kSlabRows; c += 64) {
-        float a[32], b[32];
+        float a0[32], a1[32], b[NT][32];
 #pragma unroll
         for (int s = 0; s < 32; s++) {
             const int64_t n = n0 + c + 32 * h + s;
             const int64_t nc = n < n_rows ? n : n_rows - 1;
-            const float e = pe[nc * ld], sd = ps[nc * ld];
-            a[s] = (which == 0 ? sd + e : e * sd) * (n < n_rows ? 1.f : 0.f);
-            b[s] = pd[nc * ld];
+            const float keep = n < n_rows ? 1.f : 0.f;
+            const float e = pe[nc * LD], sd = ps[nc * LD];
+            a0[s] = (sd + e) * keep; a1[s] = (e * sd) * keep;
+#pragma unroll
+            for (int t = 0; t < NT; t++) b[t][s] = pd[nc * LD + 32 * t];
         }
 #pragma unroll
-        for (int s = 0; s < 32; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
-    }
-    float *out = partial + (((int64_t)slab * 2 + which) * ld + 32 * ti) * ld + 32 * tj;
+        for (int s = 0; s < 32; s++)
 #pragma unroll
-    for (int q = 0; q < 16; q++) out[(int64_t)cd_row(q, h) * ld + r] = acc[q];
+            for (int t = 0; t < NT; t++) {
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b[t][s], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b[t][s], acc[1][t], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int w = 0; w < 2; w++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            float *out = partial + (((int64_t)slab * 2 + w) * LD + 32 * ti) * LD + 32 * t;
+#pragma unroll
+            for (int q = 0; q < 16; q++) out[(int64_t)cd_row(q, h) * LD + r] = acc[w][t][q];
+        }
 }
 
 // gW[which][i][j] = sum_slab partial[slab][which][i][j]: 8 lanes per element (lane t adds slabs t, t+8, ... in
@@ -294,6 +323,17 @@ __global__ __launch_bounds__(256) void add_cols_kernel(float *__restrict__ dst, 
     }
 }
 
+// persistent grid of the dense-layer kernels: every block stages the weights in LDS once, so no more blocks than
+// the chip keeps resident (2 per CU; 1 when the weights take 128 KB), and never more than there are 128-row groups
+unsigned dense_grid(int64_t n_rows, int ld) {
+    const int64_t groups = (n_rows + 127) / 128;
+    const int64_t resident = ld >= 128 ? 256 : 512;
+    return (unsigned)(groups < resident ? groups : resident);
+}
+hipError_t allow_big_lds(const void *kernel, size_t bytes) {
+    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 }  // namespace
 
 extern "C" {
@@ -302,12 +342,15 @@ int qrec_ngcf_dense_fwd(const float *d_E, const float *d_side, const float *d_W1
                         int32_t ld, float *d_pre, void *stream) {
     QREC_REQUIRE(d_E && d_side && d_W1 && d_W2 && d_pre && n_rows >= 0, "qrec_ngcf_dense_fwd: bad argument");
     if (n_rows == 0) return QREC_OK;
-    const unsigned blocks = (unsigned)((n_rows + 127) / 128);
     hipStream_t st = as_stream(stream);
+    const unsigned blocks = dense_grid(n_rows, ld);
+    const size_t lds = (size_t)2 * ld * ld * sizeof(float);
     switch (ld) {
-        case 32: hipLaunchKernelGGL(dense_fwd_kernel<1>, dim3(blocks), dim3(256), 0, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre); break;
-        case 64: hipLaunchKernelGGL(dense_fwd_kernel<2>, dim3(blocks), dim3(256), 0, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre); break;
-        case 128: hipLaunchKernelGGL(dense_fwd_kernel<4>, dim3(blocks), dim3(256), 0, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre); break;
+        case 32: hipLaunchKernelGGL(dense_fwd_kernel<1>, dim3(blocks), dim3(256), lds, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre); break;
+        case 64: hipLaunchKernelGGL(dense_fwd_kernel<2>, dim3(blocks), dim3(256), lds, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre); break;
+        case 128:
+            QREC_HIP_CHECK(allow_big_lds(reinterpret_cast<const void *>(&dense_fwd_kernel<4>), lds));
+            hipLaunchKernelGGL(dense_fwd_kernel<4>, dim3(blocks), dim3(256), lds, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre); break;
         default: set_error("qrec_ngcf_dense_fwd: row stride must be 32, 64 or 128 floats (got %d)", ld); return QREC_ERR_INVALID;
     }
     QREC_LAUNCH_CHECK();
@@ -351,18 +394,23 @@ int qrec_ngcf_layer_bwd(const float *d_dE_next, const float *d_dWide, const floa
     blocks = (n_rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)); if (blocks > 2048) blocks = 2048;                    \
     hipLaunchKernelGGL((dpre_rows_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, d_dE_next, d_dWide, d_wide, \
                        wide_ld, col_off, d_inv_norm, d_gate, n_rows, d, d_dpre)
-    const unsigned gblocks = (unsigned)((n_rows + 127) / 128);
+    const unsigned gblocks = dense_grid(n_rows, ld);
+    const size_t lds = (size_t)2 * ld * ld * sizeof(float);
     switch (ld) {
-        case 32: QREC_DP(8); hipLaunchKernelGGL(dense_bwd_kernel<1>, dim3(gblocks), dim3(256), 0, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE); break;
-        case 64: QREC_DP(16); hipLaunchKernelGGL(dense_bwd_kernel<2>, dim3(gblocks), dim3(256), 0, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE); break;
-        case 128: QREC_DP(32); hipLaunchKernelGGL(dense_bwd_kernel<4>, dim3(gblocks), dim3(256), 0, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE); break;
+        case 32: QREC_DP(8); hipLaunchKernelGGL(dense_bwd_kernel<1>, dim3(gblocks), dim3(256), lds, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE); break;
+        case 64: QREC_DP(16); hipLaunchKernelGGL(dense_bwd_kernel<2>, dim3(gblocks), dim3(256), lds, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE); break;
+        case 128:
+            QREC_DP(32);
+            QREC_HIP_CHECK(allow_big_lds(reinterpret_cast<const void *>(&dense_bwd_kernel<4>), lds));
+            hipLaunchKernelGGL(dense_bwd_kernel<4>, dim3(gblocks), dim3(256), lds, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE); break;
         default: set_error("qrec_ngcf_layer_bwd: row stride must be 32, 64 or 128 floats (got %d)", ld); return QREC_ERR_INVALID;
     }
 #undef QREC_DP
     QREC_LAUNCH_CHECK();
     const int n_slabs = (int)((n_rows + kSlabRows - 1) / kSlabRows), nt = ld / 32;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)n_slabs, 2, (unsigned)(nt * nt)), dim3(64), 0, st, d_E, d_side, d_dpre,
-                       n_rows, ld, d_partial);
+    if (nt == 1) hipLaunchKernelGGL(wgrad_kernel<1>, dim3((unsigned)n_slabs, 1), dim3(64), 0, st, d_E, d_side, d_dpre, n_rows, d_partial);
+    else if (nt == 2) hipLaunchKernelGGL(wgrad_kernel<2>, dim3((unsigned)n_slabs, 2), dim3(64), 0, st, d_E, d_side, d_dpre, n_rows, d_partial);
+    else hipLaunchKernelGGL(wgrad_kernel<4>, dim3((unsigned)n_slabs, 4), dim3(64), 0, st, d_E, d_side, d_dpre, n_rows, d_partial);
     QREC_LAUNCH_CHECK();
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((2 * ld * ld * 8 + 255) / 256)), dim3(256), 0, st, d_partial, n_slabs,
                        ld, d_gW1, d_gW2);
