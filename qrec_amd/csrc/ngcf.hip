@@ -189,12 +189,12 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const float *__restrict_
                                                         const float *__restrict__ W2, const float *__restrict__ E,
                                                         const float *__restrict__ side, int64_t n_rows,
                                                         float *__restrict__ dside, float *__restrict__ dE) {
-    constexpr int LD = 32 * NT;
-    extern __shared__ float s_w[];                  // [2][LD][LD], transposed
+    constexpr int LD = 32 * NT, LDP = LD + 1;       // padded rows: the transposing writes below fall on distinct banks
+    extern __shared__ float s_w[];                  // [2][LD][LDP], transposed
     for (int k = threadIdx.x; k < LD * LD; k += blockDim.x) {
-        const int j = k / LD, c = k % LD;           // coalesced read of W[j][c], scattered write to s_wt[c][j] (once per block)
-        s_w[c * LD + j] = W1[k];
-        s_w[LD * LD + c * LD + j] = W2[k];
+        const int j = k / LD, c = k % LD;           // coalesced read of W[j][c], write to s_wt[c][j]
+        s_w[c * LDP + j] = W1[k];
+        s_w[LD * LDP + c * LDP + j] = W2[k];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
@@ -222,11 +222,11 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const float *__restrict_
             }
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                const float *w1 = s_w + kb * LD + 32 * t + r, *w2 = w1 + LD * LD;
+                const float *w1 = s_w + kb * LDP + 32 * t + r, *w2 = w1 + LD * LDP;
 #pragma unroll
                 for (int s = 0; s < 32; s++) {
-                    a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[s], w1[s * LD], a1[t], 0, 0, 0);
-                    a2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[s], w2[s * LD], a2[t], 0, 0, 0);
+                    a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[s], w1[s * LDP], a1[t], 0, 0, 0);
+                    a2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[s], w2[s * LDP], a2[t], 0, 0, 0);
                 }
             }
         }
@@ -251,15 +251,17 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const float *__restrict_
 // dpre, i.e. 2*NT MFMAs per k-step from 2 + NT coalesced dword loads (the first version issued 3 loads per MFMA from
 // one wavefront per SIMD and sat in load latency: 98 us for 1.1 GFLOP).  A chunk's 32 k-steps are fetched first, then
 // its MFMAs run.  Rows past the end feed a = 0.
-constexpr int kSlabRows = 128;
+constexpr int kWaveRows = 128;                 // rows one wavefront accumulates
+constexpr int kSlabRows = 4 * kWaveRows;       // rows per block = per partial slab (4 wavefronts, summed through LDS)
 template <int NT>
-__global__ __launch_bounds__(64) void wgrad_kernel(const float *__restrict__ E, const float *__restrict__ side,
-                                                   const float *__restrict__ dpre, int64_t n_rows,
-                                                   float *__restrict__ partial) {
+__global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ E, const float *__restrict__ side,
+                                                    const float *__restrict__ dpre, int64_t n_rows,
+                                                    float *__restrict__ partial) {
     constexpr int LD = 32 * NT;
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    extern __shared__ float s_acc[];               // [4 waves][2*NT tiles][16][64 lanes]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int slab = blockIdx.x, ti = blockIdx.y;
-    const int64_t n0 = (int64_t)slab * kSlabRows;
+    const int64_t n0 = (int64_t)slab * kSlabRows + (int64_t)wave * kWaveRows;
     f32x16 acc[2][NT];
 #pragma unroll
     for (int w = 0; w < 2; w++)
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(64) void wgrad_kernel(const float *__restrict__ E, 
 #pragma unroll
             for (int q = 0; q < 16; q++) acc[w][t][q] = 0.f;
     const float *pe = E + 32 * ti + r, *ps = side + 32 * ti + r, *pd = dpre + r;
-    for (int c = 0; c < kSlabRows; c += 64) {
+    for (int c = 0; c < kWaveRows; c += 64) {
         float a0[32], a1[32], b[NT][32];
 #pragma unroll
         for (int s = 0; s < 32; s++) {
@@ -288,14 +290,20 @@ __global__ __launch_bounds__(64) void wgrad_kernel(const float *__restrict__ E, 
                 acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b[t][s], acc[1][t], 0, 0, 0);
             }
     }
+    // the block's four wavefronts hold the same tiles over different rows: sum them in wave order (deterministic)
 #pragma unroll
     for (int w = 0; w < 2; w++)
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            float *out = partial + (((int64_t)slab * 2 + w) * LD + 32 * ti) * LD + 32 * t;
+        for (int t = 0; t < NT; t++)
 #pragma unroll
-            for (int q = 0; q < 16; q++) out[(int64_t)cd_row(q, h) * LD + r] = acc[w][t][q];
-        }
+            for (int q = 0; q < 16; q++) s_acc[((wave * 2 * NT + w * NT + t) * 16 + q) * 64 + lane] = acc[w][t][q];
+    __syncthreads();
+    constexpr int kPerWave = 2 * NT * 16 * 64;     // floats one wavefront deposited
+    for (int k = threadIdx.x; k < kPerWave; k += 256) {
+        const float v = ((s_acc[k] + s_acc[kPerWave + k]) + s_acc[2 * kPerWave + k]) + s_acc[3 * kPerWave + k];
+        const int ln = k & 63, q = (k >> 6) & 15, wt = k >> 10, w = wt / NT, t = wt % NT;
+        partial[(((int64_t)slab * 2 + w) * LD + 32 * ti + cd_row(q, ln >> 5)) * LD + 32 * t + (ln & 31)] = v;
+    }
 }
 
 // gW[which][i][j] = sum_slab partial[slab][which][i][j]: 8 lanes per element (lane t adds slabs t, t+8, ... in
@@ -395,7 +403,7 @@ int qrec_ngcf_layer_bwd(const float *d_dE_next, const float *d_dWide, const floa
     hipLaunchKernelGGL((dpre_rows_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, d_dE_next, d_dWide, d_wide, \
                        wide_ld, col_off, d_inv_norm, d_gate, n_rows, d, d_dpre)
     const unsigned gblocks = dense_grid(n_rows, ld);
-    const size_t lds = (size_t)2 * ld * ld * sizeof(float);
+    const size_t lds = (size_t)2 * ld * (ld + 1) * sizeof(float);
     switch (ld) {
         case 32: QREC_DP(8); hipLaunchKernelGGL(dense_bwd_kernel<1>, dim3(gblocks), dim3(256), lds, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE); break;
         case 64: QREC_DP(16); hipLaunchKernelGGL(dense_bwd_kernel<2>, dim3(gblocks), dim3(256), lds, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE); break;
@@ -408,9 +416,13 @@ int qrec_ngcf_layer_bwd(const float *d_dE_next, const float *d_dWide, const floa
 #undef QREC_DP
     QREC_LAUNCH_CHECK();
     const int n_slabs = (int)((n_rows + kSlabRows - 1) / kSlabRows), nt = ld / 32;
-    if (nt == 1) hipLaunchKernelGGL(wgrad_kernel<1>, dim3((unsigned)n_slabs, 1), dim3(64), 0, st, d_E, d_side, d_dpre, n_rows, d_partial);
-    else if (nt == 2) hipLaunchKernelGGL(wgrad_kernel<2>, dim3((unsigned)n_slabs, 2), dim3(64), 0, st, d_E, d_side, d_dpre, n_rows, d_partial);
-    else hipLaunchKernelGGL(wgrad_kernel<4>, dim3((unsigned)n_slabs, 4), dim3(64), 0, st, d_E, d_side, d_dpre, n_rows, d_partial);
+    const size_t wlds = (size_t)4 * 2 * nt * 16 * 64 * sizeof(float);
+    if (nt == 1) hipLaunchKernelGGL(wgrad_kernel<1>, dim3((unsigned)n_slabs, 1), dim3(256), wlds, st, d_E, d_side, d_dpre, n_rows, d_partial);
+    else if (nt == 2) hipLaunchKernelGGL(wgrad_kernel<2>, dim3((unsigned)n_slabs, 2), dim3(256), wlds, st, d_E, d_side, d_dpre, n_rows, d_partial);
+    else {
+        QREC_HIP_CHECK(allow_big_lds(reinterpret_cast<const void *>(&wgrad_kernel<4>), wlds));
+        hipLaunchKernelGGL(wgrad_kernel<4>, dim3((unsigned)n_slabs, 4), dim3(256), wlds, st, d_E, d_side, d_dpre, n_rows, d_partial);
+    }
     QREC_LAUNCH_CHECK();
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((2 * ld * ld * 8 + 255) / 256)), dim3(256), 0, st, d_partial, n_slabs,
                        ld, d_gW1, d_gW2);
