@@ -207,17 +207,22 @@ __global__ __launch_bounds__(256) void grad_z_kernel(const float *__restrict__ E
         const f32x4 *pe = reinterpret_cast<const f32x4 *>(EA + (int64_t)i * n_pad + k0);
         const f32x4 *pt = reinterpret_cast<const f32x4 *>(inv_ttl + k0);
         const float dgl = i < n ? 1.f : 0.f;
+        // a chunk's operands first (8 float4 of the lane's E row, 32 coalesced dwords of z), then its 32 MFMAs: with
+        // one load issued per MFMA the compiler keeps it a single MFMA ahead and the wavefront sits in load latency
+        float ga[32], zb[32];
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const f32x4 e = pe[q];
             f32x4 t = {my_inv, my_inv, my_inv, my_inv};
             if (MODE == 1) t = pt[q];
             const int k = k0 + 4 * q;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e.x * t.x - (k + 0 == i ? dgl : 0.f), zcol[(int64_t)(k + 0) * ld], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e.y * t.y - (k + 1 == i ? dgl : 0.f), zcol[(int64_t)(k + 1) * ld], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e.z * t.z - (k + 2 == i ? dgl : 0.f), zcol[(int64_t)(k + 2) * ld], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e.w * t.w - (k + 3 == i ? dgl : 0.f), zcol[(int64_t)(k + 3) * ld], acc, 0, 0, 0);
+            ga[4 * q + 0] = e.x * t.x - (k + 0 == i ? dgl : 0.f); ga[4 * q + 1] = e.y * t.y - (k + 1 == i ? dgl : 0.f);
+            ga[4 * q + 2] = e.z * t.z - (k + 2 == i ? dgl : 0.f); ga[4 * q + 3] = e.w * t.w - (k + 3 == i ? dgl : 0.f);
         }
+#pragma unroll
+        for (int s = 0; s < 32; s++) zb[s] = zcol[(int64_t)(k0 + s) * ld];
+#pragma unroll
+        for (int s = 0; s < 32; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[s], zb[s], acc, 0, 0, 0);
     }
     float *out = out_parts + (int64_t)ks * n_pad * ld;
 #pragma unroll
