@@ -280,6 +280,23 @@ int qrec_ngcf_wgrad_partial_bytes(int64_t n_rows, int32_t ld, int64_t *bytes);
 int qrec_copy_cols(float *d_dst, int32_t dst_ld, const float *d_src, int32_t src_ld, int32_t src_col_off, int64_t n_rows,
                    int32_t d, int32_t accumulate, void *stream);
 
+/* ---- BUIR (model/ranking/BUIR.py) ------------------------------------------------------------------ *
+ * The propagation of both encoders is qrec_spmm_csr on the epoch's two sub-graphs.  What the model adds:      */
+
+/* Per batch element b (u = d_u[b], i = n_users + d_i[b]), with x = S_online[row]/div, t = S_target[row]/div
+ * (div = n_layers + 1 folds the layer mean in): q = tanh(x W + bias) (BUIR.py:105-107),
+ * *d_loss += [(1 - cos(q_u, t_i)) + (1 - cos(q_i, t_u))] / 2 (:127-129, tf.math.l2_normalize eps 1e-12), the gradient
+ * w.r.t. the online mean rows is scatter-added into d_dS (un-divided: the caller folds 1/div into its optimizer
+ * step), and the (x, dpre) pairs go to d_X / d_dPre rows b (user side) and B + b (item side) for qrec_buir_wgrad.
+ * d_W [ld][ld], d_bias [ld], zero-padded; tables [rows][ld], ld in {32, 64, 128}.                        */
+int qrec_buir_batch_loss_grad(const float *d_S_online, const float *d_S_target, float div, int32_t n_users, int32_t ld,
+                              const float *d_W, const float *d_bias, const int32_t *d_u, const int32_t *d_i, int32_t B,
+                              float *d_dS, float *d_X, float *d_dPre, double *d_loss, void *stream);
+/* d_gW = X^T dPre, d_gb = column sums of dPre over n_rows (= 2B) pairs; deterministic.                    */
+int qrec_buir_wgrad(const float *d_X, const float *d_dPre, int32_t n_rows, int32_t ld, float *d_gW, float *d_gb, void *stream);
+/* target = target*tau + online*(1 - tau) (BUIR.py:120-123, run after every optimizer step :159)           */
+int qrec_ema_update(float *d_target, const float *d_online, float tau, int64_t n_elems, void *stream);
+
 /* ---- full-rank evaluation: base/recommender.py:143-150 + util/qmath.py:134-146 -------- *
  * For each of the n_batch_users users (ids into the user table): scores = V . U[user]
  * (MFMA), scores of the user's rated train items set to 0 (rated CSR over ALL users, may be

@@ -396,3 +396,80 @@ class SGL:
     def final_embeddings(self):
         m = self.view([self.adj] * self.L)
         return m[:self.nu], m[self.nu:]
+
+
+class BUIR:
+    """model/ranking/BUIR.py:13-172 restated (TF 1.14 absent: parity unpinned, gradients cross-checked against
+    torch autograd in tests/test_oracle_tfmodels.py).
+
+    Online encoder: LightGCN over this epoch's sub-graph ``mat_o`` (mean over [E0..EL], BUIR.py:90-103), then
+    q = tanh(online W + b) (:105-107).  Target encoder: the same propagation of the TARGET tables over ``mat_t``,
+    no gradient (:98-100,109-113).  Loss (:127-130): sum_b [ (1 - cos(q[u_b], tar[i_b])) + (1 - cos(q[i_b], tar[u_b])) ] / 2
+    with tf.math.l2_normalize (x / sqrt(max(sum x^2, 1e-12))).  Adam on the online tables, W and b (the target
+    tables receive no gradient); after every step target = target*tau + online*(1 - tau) (:120-123,159)."""
+
+    def __init__(self, U0, V0, W0, b0, n_layers, lr, tau):
+        f = np.float32
+        self.nu, self.ni = U0.shape[0], V0.shape[0]
+        self.E = np.concatenate([U0, V0]).astype(f)          # online tables
+        self.T = self.E.copy()                                # target tables (initialized_value of the online ones)
+        self.W, self.b = W0.astype(f).copy(), b0.astype(f).reshape(1, -1).copy()
+        self.L, self.tau = n_layers, f(tau)
+        self.optE, self.optW, self.optb = AdamTF114(self.E.shape, lr), AdamTF114(self.W.shape, lr), AdamTF114(self.b.shape, lr)
+
+    def _mean_prop(self, mat, X):
+        acc, x = X.copy(), X
+        for _ in range(self.L):
+            x = mat.dot(x).astype(np.float32)
+            acc += x
+        return (acc / np.float32(self.L + 1)).astype(np.float32)
+
+    def _mean_prop_backward(self, mat, d_out):
+        c = (d_out / np.float32(self.L + 1)).astype(np.float32)
+        G = c.copy()
+        for _ in range(self.L):
+            G = (c + mat.T.dot(G)).astype(np.float32)
+        return G
+
+    @staticmethod
+    def _cos_loss_grad(q, t):
+        """sum_b (1 - qhat.that)/2 and its gradient w.r.t. q (t is constant)"""
+        f = np.float32
+        nq = np.sqrt(np.maximum((q * q).sum(1, dtype=f), f(1e-12)), dtype=f)[:, None]
+        nt = np.sqrt(np.maximum((t * t).sum(1, dtype=f), f(1e-12)), dtype=f)[:, None]
+        qh, th = q / nq, t / nt
+        c = (qh * th).sum(1, dtype=f)[:, None]
+        loss = float(((f(1) - c[:, 0]) * f(0.5)).sum(dtype=np.float64))
+        dq = -(th - c * qh) / nq * f(0.5)
+        return loss, dq.astype(f)
+
+    def loss_and_grads(self, u_idx, i_idx, mat_o, mat_t):
+        f = np.float32
+        nu = self.nu
+        ui, ii = np.asarray(u_idx), np.asarray(i_idx) + nu
+        online = self._mean_prop(mat_o, self.E)
+        target = self._mean_prop(mat_t, self.T)
+        xu, xi = online[ui], online[ii]
+        qu = np.tanh(xu @ self.W + self.b, dtype=f); qi = np.tanh(xi @ self.W + self.b, dtype=f)
+        l1, dqu = self._cos_loss_grad(qu, target[ii])
+        l2, dqi = self._cos_loss_grad(qi, target[ui])
+        dpu = dqu * (f(1) - qu * qu); dpi = dqi * (f(1) - qi * qi)        # through tanh
+        gW = (xu.T @ dpu + xi.T @ dpi).astype(f)
+        gb = (dpu.sum(0, dtype=f) + dpi.sum(0, dtype=f)).reshape(1, -1).astype(f)
+        d_online = np.zeros_like(online)
+        np.add.at(d_online, ui, (dpu @ self.W.T).astype(f)); np.add.at(d_online, ii, (dpi @ self.W.T).astype(f))
+        gE = self._mean_prop_backward(mat_o, d_online)
+        return l1 + l2, gE, gW, gb
+
+    def train_step(self, u_idx, i_idx, mat_o, mat_t):
+        loss, gE, gW, gb = self.loss_and_grads(u_idx, i_idx, mat_o, mat_t)
+        self.optE.step(self.E, gE); self.optW.step(self.W, gW); self.optb.step(self.b, gb)
+        self.T = (self.T * self.tau + self.E * (np.float32(1) - self.tau)).astype(np.float32)     # BUIR.py:120-123,159
+        return loss
+
+    def final_tables(self, adj):
+        """(q_user, q_item, o_user, o_item) on the full adjacency (BUIR.py:160-167); score(u, .) =
+        q_item . o_user[u] + o_item . q_user[u] (:172)"""
+        online = self._mean_prop(adj, self.E)
+        q = np.tanh(online @ self.W + self.b, dtype=np.float32)
+        return q[:self.nu], q[self.nu:], online[:self.nu], online[self.nu:]

@@ -70,6 +70,9 @@ _SIGNATURES = {
     "qrec_score_topk_scratch_bytes": [C.c_int, _i32, _i32, _vp],
     "qrec_score_topk": [_vp, _vp, C.c_int, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "qrec_rank_hits": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "qrec_buir_batch_loss_grad": [_vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
+    "qrec_buir_wgrad": [_vp, _vp, _i32, _i32, _vp, _vp, _vp],
+    "qrec_ema_update": [_vp, _vp, _f32, _i64, _vp],
     "qrec_mt_data_split": [_vp, _i64, _f64, _vp],
     "qrec_ratings_load": [C.c_char_p, C.c_char_p, _i32, _i32, _i32, _i32, _i32, _f64, _vp],
     "qrec_ratings_rows": [_vp],
@@ -439,6 +442,20 @@ def epoch_decide(d_stats, d_state, regU: float, regI: float, max_lr: float, tol:
                  log_capacity: int = 0, stream=None):
     _check(load().qrec_epoch_decide(_dp(d_stats), _dp(d_state), regU, regI, max_lr, tol, _dp(d_log), log_capacity,
                                     _sh(stream)))
+
+
+def buir_batch_loss_grad(d_S_on, d_S_tar, div: float, n_users: int, ld: int, d_W, d_bias, d_u, d_i, B: int, d_dS, d_X,
+                         d_dPre, d_loss, stream=None):
+    _check(load().qrec_buir_batch_loss_grad(_dp(d_S_on), _dp(d_S_tar), div, n_users, ld, _dp(d_W), _dp(d_bias), _dp(d_u),
+                                            _dp(d_i), B, _dp(d_dS), _dp(d_X), _dp(d_dPre), _dp(d_loss), _sh(stream)))
+
+
+def buir_wgrad(d_X, d_dPre, n_rows: int, ld: int, d_gW, d_gb, stream=None):
+    _check(load().qrec_buir_wgrad(_dp(d_X), _dp(d_dPre), n_rows, ld, _dp(d_gW), _dp(d_gb), _sh(stream)))
+
+
+def ema_update(d_target, d_online, tau: float, n_elems: int, stream=None):
+    _check(load().qrec_ema_update(_dp(d_target), _dp(d_online), tau, n_elems, _sh(stream)))
 
 
 def rank_hits(d_ids, n_batch_users: int, row_stride: int, n_cut: int, d_user_ids, d_test_indptr, d_test_items,

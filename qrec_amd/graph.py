@@ -559,3 +559,99 @@ class SGLTrainer:
     def ego_embeddings(self):
         E = self.E.numpy()
         return E[:self.nu, :self.d].copy(), E[self.nu:, :self.d].copy()
+
+
+class BUIRTrainer:
+    """model/ranking/BUIR.py:13-172 on the device.  Online encoder = LightGCN mean over this epoch's sub-graph O plus
+    q = tanh(. W + b); target encoder = the same propagation of the momentum tables over sub-graph T (no gradient);
+    loss = symmetric (1 - cosine) between q of one side and the target of the other; Adam on the online tables, W, b;
+    target <- target*tau + online*(1 - tau) after every step.  Only the batch's rows of q are ever looked up, so the
+    linear layer runs on <= 2B rows (qrec_buir_batch_loss_grad) and the last propagation layer of both encoders is
+    computed at the batch's rows only."""
+
+    def __init__(self, U0, V0, W0, b0, n_layers: int, lr: float, tau: float):
+        self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
+        self.n = self.nu + self.ni
+        self.ld = padded_ld(self.d, np.float32)
+        if self.ld > 128:
+            raise ValueError("BUIR kernels support embedding sizes up to 128")
+        if n_layers < 1:
+            raise ValueError("BUIR needs at least one propagation layer")
+        self.L, self.tau = n_layers, float(np.float32(tau))
+        E0 = np.zeros((self.n, self.ld), np.float32)
+        E0[:self.nu, :self.d] = U0; E0[self.nu:, :self.d] = V0
+        self.E, self.T = DeviceBuffer.from_numpy(E0), DeviceBuffer.from_numpy(E0)      # target starts as a copy (BUIR.py:85-86)
+        Wp = np.zeros((self.ld, self.ld), np.float32); Wp[:self.d, :self.d] = W0
+        bp = np.zeros(self.ld, np.float32); bp[:self.d] = np.asarray(b0, np.float32).reshape(-1)
+        self.W, self.b = DeviceBuffer.from_numpy(Wp), DeviceBuffer.from_numpy(bp)
+        z = lambda: DeviceBuffer.zeros((self.n, self.ld), np.float32)
+        self.S_on, self.S_tar, self.dS, self.A, self.B = z(), z(), z(), z(), z()
+        self.gW, self.gb = DeviceBuffer.zeros((self.ld, self.ld), np.float32), DeviceBuffer.zeros(self.ld, np.float32)
+        self.optE, self.optW, self.optb = _Adam(self.E, lr), _Adam(self.W, lr), _Adam(self.b, lr)
+        self.row_mask = DeviceBuffer.zeros((self.n + 31) // 32, np.uint32)
+        self.d_loss = DeviceBuffer.zeros(1, np.float64)
+        self.plan_o = self.plan_t = None
+        self._cap = 0
+        self.Xb = self.Gb = None
+
+    def set_subgraphs(self, adj_o, adj_t):
+        """this epoch's two normalized sub-graph adjacencies (CSR triples), BUIR.py:139-146"""
+        self.plan_o = SpmmPlan(adj_o[0], adj_o[1], adj_o[2], self.ld)
+        self.plan_t = SpmmPlan(adj_t[0], adj_t[1], adj_t[2], self.ld)
+
+    def _mean_sum(self, plan, X, S, stream=None, last_rows=None):
+        """S = X + A X + ... + A^L X (the mean's 1/(L+1) is applied where S is used)"""
+        S.copy_from(X, stream)
+        x = X
+        for k in range(self.L):
+            y = self.A if k % 2 == 0 else self.B
+            capi.spmm_csr(plan, x, y, self.ld, d_accum=S, stream=stream, d_y_row_mask=last_rows if k == self.L - 1 else None)
+            x = y
+
+    def train_step_async(self, d_u, d_i, B: int, stream=None):
+        if self.plan_o is None:
+            raise RuntimeError("set_subgraphs() first")
+        if B > self._cap:
+            self.Xb, self.Gb = DeviceBuffer((2 * B, self.ld), np.float32), DeviceBuffer((2 * B, self.ld), np.float32)
+            self._cap = B
+        div = float(self.L + 1)
+        self.row_mask.fill_bytes(0, stream)
+        capi.mark_batch_rows(d_u, d_i, d_i, B, self.nu, self.row_mask, stream)           # rows {u, nu+i}
+        self._mean_sum(self.plan_o, self.E, self.S_on, stream, self.row_mask)
+        self._mean_sum(self.plan_t, self.T, self.S_tar, stream, self.row_mask)
+        self.dS.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
+        capi.buir_batch_loss_grad(self.S_on, self.S_tar, div, self.nu, self.ld, self.W, self.b, d_u, d_i, B, self.dS, self.Xb,
+                                  self.Gb, self.d_loss, stream)
+        capi.buir_wgrad(self.Xb, self.Gb, 2 * B, self.ld, self.gW, self.gb, stream)
+        # d online tables = (1/(L+1)) (I + A + ... + A^L) dS  (A symmetric): H_0 = dS, H_{k+1} = dS + A H_k
+        x = self.dS
+        for k in range(self.L):
+            y = self.A if k % 2 == 0 else self.B
+            capi.spmm_csr(self.plan_o, x, y, self.ld, d_addend=self.dS, addend_scale=1.0, stream=stream,
+                          d_x_row_mask=self.row_mask if k == 0 else None)
+            x = y
+        self.optE.step(x, grad_scale=1.0 / div, stream=stream)
+        self.optW.step(self.gW, stream=stream); self.optb.step(self.gb, stream=stream)
+        capi.ema_update(self.T, self.E, self.tau, self.n * self.ld, stream)
+
+    def loss(self, stream=None) -> float:
+        return float(self.d_loss.numpy(stream)[0])
+
+    def online_tables(self):
+        E = self.E.numpy(); return E[:, :self.d].copy()
+
+    def target_tables(self):
+        T = self.T.numpy(); return T[:, :self.d].copy()
+
+    def weights(self):
+        return self.W.numpy()[:self.d, :self.d].copy(), self.b.numpy()[:self.d].copy()
+
+    def final_tables(self, adj):
+        """(q_user, q_item, o_user, o_item) over the FULL adjacency (BUIR.py:160-167).  The linear layer on all N rows
+        runs once per training run: it reuses the batch kernel's forward on the host-side numpy copy."""
+        plan = SpmmPlan(adj[0], adj[1], adj[2], self.ld)
+        self._mean_sum(plan, self.E, self.S_on)
+        online = (self.S_on.numpy()[:, :self.d] / np.float32(self.L + 1)).astype(np.float32)
+        W, b = self.weights()
+        q = np.tanh(online @ W + b[None, :], dtype=np.float32)
+        return q[:self.nu], q[self.nu:], online[:self.nu], online[self.nu:]

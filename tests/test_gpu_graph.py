@@ -560,3 +560,82 @@ def test_spmm_output_row_mask_computes_exactly_the_marked_rows(seg_len):
     other = np.setdiff1d(np.arange(n), rows)
     assert np.array_equal(Y[rows], F[rows]) and np.array_equal(Y[other], Y0[other])
     assert np.array_equal(S[rows], S0[rows] + F[rows]) and np.array_equal(S[other], S0[other])
+
+
+# ---------------------------------------------------------------------------------------------
+# BUIR
+# ---------------------------------------------------------------------------------------------
+from qrec_amd.graph import BUIRTrainer  # noqa: E402
+
+
+@pytest.mark.parametrize("L,dim", [(2, 50), (1, 64), (3, 20)])
+def test_buir_training_steps_match_restatement(L, dim):
+    """model/ranking/BUIR.py on the device vs the numpy restatement (oracle/tfmodels.py BUIR): losses, the online
+    tables, the linear layer and the momentum tables over several steps on two different sub-graphs."""
+    d, adj, A = _graph("small")
+    nu, ni, B = d["n_users"], d["n_items"], 1024
+    rng = np.random.default_rng(40 + L)
+    n = d["train_u"].size
+    def sub():
+        keep = rng.permutation(n)[:n // 2]
+        a = joint_norm_adjacency(nu, ni, d["train_u"][keep], d["train_i"][keep])
+        return a, sp.csr_matrix((a[2], a[1], a[0]), shape=(nu + ni,) * 2)
+    (ao, Ao), (at, At) = sub(), sub()
+    lim = np.sqrt(6.0 / (nu + dim))
+    U0 = rng.uniform(-lim, lim, (nu, dim)).astype(np.float32); V0 = rng.uniform(-lim, lim, (ni, dim)).astype(np.float32)
+    W0 = rng.uniform(-0.3, 0.3, (dim, dim)).astype(np.float32); b0 = rng.uniform(-0.3, 0.3, (1, dim)).astype(np.float32)
+    ref = T.BUIR(U0, V0, W0, b0, L, lr=0.001, tau=0.995)
+    tr = BUIRTrainer(U0, V0, W0, b0, L, lr=0.001, tau=0.995)
+    tr.set_subgraphs(ao, at)
+    for step in range(6):
+        sel = rng.integers(0, n, B)
+        u = d["train_u"][sel].astype(np.int32); i = d["train_i"][sel].astype(np.int32)
+        lref = ref.train_step(u, i, Ao, At)
+        tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), B)
+        assert abs(tr.loss() - lref) / abs(lref) < 2e-5
+    E0 = np.concatenate([U0, V0])
+    Eg, Tg = tr.online_tables(), tr.target_tables()
+    Wg, bg = tr.weights()
+    assert rel_err(Eg - E0, ref.E - E0) < 2e-3 and rel_err(Eg, ref.E) < 5e-5       # Adam: see the SimGCL test's note
+    assert rel_err(Tg, ref.T) < 5e-5
+    assert rel_err(Wg, ref.W) < 5e-5 and rel_err(bg, ref.b.ravel()) < 5e-4
+    got, want = tr.final_tables(adj), ref.final_tables(A)
+    for g, w in zip(got, want):
+        assert rel_err(g, w) < 1e-4
+
+
+def test_buir_class_runs_stock_conf_shape_and_replays_the_generator():
+    """The drop-in BUIR class with the stock conf's options (-n_layer 2 -tau 0.995 -drop_rate 0.5): trains, ranks with
+    the concatenated [o|q] tables, and leaves the CPython generator where the reference's draw sequence would
+    (two random.sample sub-graphs, then shuffle + negatives, per epoch)."""
+    from qrec_amd.model.ranking.BUIR import BUIR
+    train, test = rows_from_golden(load_golden("bpr_filmtrust")[1])
+    conf = conf_from_text("ratings=./x.txt\nratings.setup=-columns 0 1 2\nmodel.name=BUIR\nevaluation.setup=-testSet x -b 1\n"
+                          "item.ranking=on -topN 10\nnum.factors=50\nnum.max.epoch=3\nbatch_size=2000\nlearnRate=-init 0.001 -max 1\n"
+                          "BUIR=-n_layer 2 -tau 0.995 -drop_rate 0.5\nreg.lambda=-u 0.001 -i 0.001 -b 0.2 -s 0.2\noutput.setup=off -dir ./results/")
+    random.seed(5); np.random.seed(5)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        m = BUIR(conf, train, test)
+        measure = m.execute()
+    losses = [float(l.rsplit("loss:", 1)[1]) for l in buf.getvalue().splitlines() if "training:" in l]
+    n_batches = -(-len(train) // 2000)
+    assert len(losses) == 3 * n_batches and losses[-1] < losses[0] and all(np.isfinite(losses))
+    assert any(x.startswith("Recall:") for x in measure)
+    # replay of the host-side draws with Python's own generator
+    random.seed(5)
+    n = len(train)
+    rated = {}
+    for u, i, _ in train:
+        rated.setdefault(u, set()).add(i)
+    rows = [r[:] for r in train]
+    items = list(dict.fromkeys(r[1] for r in train))
+    for _ in range(3):
+        random.sample(list(range(n)), int(n * 0.5)); random.sample(list(range(n)), int(n * 0.5))
+        random.shuffle(rows)
+        for u, _, _ in rows:
+            neg = random.choice(items)
+            while neg in rated[u]:
+                neg = random.choice(items)
+    want_state = random.getstate()
+    assert np.array_equal(capi.state_from_python(want_state), capi.state_from_python(m._final_py_state))

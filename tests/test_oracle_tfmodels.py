@@ -208,3 +208,51 @@ def test_sgl_gradient_matches_autograd(per_layer):
     (trec + tssl).backward()
     assert rec == pytest.approx(float(trec.detach()), rel=1e-5) and ssl == pytest.approx(float(tssl.detach()), rel=1e-5)
     np.testing.assert_allclose(g, E.grad.numpy(), rtol=2e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("L", [1, 2])
+def test_buir_gradient_matches_autograd(L):
+    """model/ranking/BUIR.py:88-130: hand-derived gradients of the online tables, W and b vs torch autograd; the
+    target side carries no gradient; the momentum update follows the Adam step."""
+    rng = np.random.default_rng(91)
+    nu, ni, d, B = 40, 30, 8, 48
+    uid = rng.integers(0, nu, 400); iid = rng.integers(0, ni, 400)
+    adj = T.joint_norm_adjacency(nu, ni, uid, iid)
+    def sub():
+        keep = rng.permutation(400)[:200]
+        return T.joint_norm_adjacency(nu, ni, uid[keep], iid[keep])
+    mo, mt = sub(), sub()
+    U0 = rng.standard_normal((nu, d)).astype(np.float32) * 0.3; V0 = rng.standard_normal((ni, d)).astype(np.float32) * 0.3
+    W0 = rng.standard_normal((d, d)).astype(np.float32) * 0.4; b0 = rng.standard_normal((1, d)).astype(np.float32) * 0.1
+    u = rng.integers(0, nu, B); i = rng.integers(0, ni, B)
+    m = T.BUIR(U0, V0, W0, b0, L, lr=0.001, tau=0.995)
+    m.T = (m.T + rng.standard_normal(m.T.shape).astype(np.float32) * 0.05).astype(np.float32)   # target != online, as after some steps
+    loss, gE, gW, gb = m.loss_and_grads(u, i, mo, mt)
+    def tsp(a):
+        coo = a.tocoo(); return torch.sparse_coo_tensor(np.vstack([coo.row, coo.col]), coo.data.astype(np.float64), a.shape).coalesce()
+    E = torch.tensor(m.E.astype(np.float64), requires_grad=True); Tt = torch.tensor(m.T.astype(np.float64))
+    W = torch.tensor(W0.astype(np.float64), requires_grad=True); b = torch.tensor(b0.astype(np.float64), requires_grad=True)
+    def mean_prop(mat, X):
+        layers = [X]
+        for _ in range(L):
+            layers.append(torch.sparse.mm(tsp(mat), layers[-1]))
+        return torch.stack(layers).mean(0)
+    online, target = mean_prop(mo, E), mean_prop(mt, Tt)
+    q = torch.tanh(online @ W + b)
+    tu, ti = torch.tensor(u), torch.tensor(i) + nu
+    nz = lambda x: torch.nn.functional.normalize(x, dim=1, eps=1e-6)
+    tl = ((1 - (nz(q[tu]) * nz(target[ti])).sum(1)) + (1 - (nz(q[ti]) * nz(target[tu])).sum(1))).sum() / 2
+    tl.backward()
+    assert loss == pytest.approx(float(tl.detach()), rel=1e-5)
+    np.testing.assert_allclose(gE, E.grad.numpy(), rtol=2e-3, atol=2e-6)
+    np.testing.assert_allclose(gW, W.grad.numpy(), rtol=2e-3, atol=2e-6)
+    np.testing.assert_allclose(gb, b.grad.numpy(), rtol=2e-3, atol=2e-6)
+    E_before, T_before = m.E.copy(), m.T.copy()
+    first = m.train_step(u, i, mo, mt)
+    np.testing.assert_allclose(m.T, T_before * np.float32(0.995) + m.E * np.float32(0.005), rtol=1e-6)   # EMA of the UPDATED online tables
+    assert not np.array_equal(m.E, E_before)
+    for _ in range(30):
+        last = m.train_step(u, i, mo, mt)
+    assert last < first
+    qu, qi, ou, oi = m.final_tables(adj)
+    assert qu.shape == (nu, d) and qi.shape == (ni, d) and ou.shape == (nu, d) and oi.shape == (ni, d)
