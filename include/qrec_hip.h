@@ -292,8 +292,11 @@ int qrec_copy_cols(float *d_dst, int32_t dst_ld, const float *d_src, int32_t src
 int qrec_buir_batch_loss_grad(const float *d_S_online, const float *d_S_target, float div, int32_t n_users, int32_t ld,
                               const float *d_W, const float *d_bias, const int32_t *d_u, const int32_t *d_i, int32_t B,
                               float *d_dS, float *d_X, float *d_dPre, double *d_loss, void *stream);
-/* d_gW = X^T dPre, d_gb = column sums of dPre over n_rows (= 2B) pairs; deterministic.                    */
-int qrec_buir_wgrad(const float *d_X, const float *d_dPre, int32_t n_rows, int32_t ld, float *d_gW, float *d_gb, void *stream);
+/* d_gW = X^T dPre, d_gb = column sums of dPre over n_rows (= 2B) pairs; deterministic two-stage sum through
+ * d_scratch (qrec_buir_wgrad_scratch_bytes).                                                              */
+int qrec_buir_wgrad_scratch_bytes(int32_t ld, int64_t *bytes);
+int qrec_buir_wgrad(const float *d_X, const float *d_dPre, int32_t n_rows, int32_t ld, float *d_scratch, float *d_gW,
+                    float *d_gb, void *stream);
 /* target = target*tau + online*(1 - tau) (BUIR.py:120-123, run after every optimizer step :159)           */
 int qrec_ema_update(float *d_target, const float *d_online, float tau, int64_t n_elems, void *stream);
 

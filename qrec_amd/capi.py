@@ -71,7 +71,8 @@ _SIGNATURES = {
     "qrec_score_topk": [_vp, _vp, C.c_int, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "qrec_rank_hits": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "qrec_buir_batch_loss_grad": [_vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
-    "qrec_buir_wgrad": [_vp, _vp, _i32, _i32, _vp, _vp, _vp],
+    "qrec_buir_wgrad_scratch_bytes": [_i32, _vp],
+    "qrec_buir_wgrad": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
     "qrec_ema_update": [_vp, _vp, _f32, _i64, _vp],
     "qrec_mt_data_split": [_vp, _i64, _f64, _vp],
     "qrec_ratings_load": [C.c_char_p, C.c_char_p, _i32, _i32, _i32, _i32, _i32, _f64, _vp],
@@ -450,8 +451,14 @@ def buir_batch_loss_grad(d_S_on, d_S_tar, div: float, n_users: int, ld: int, d_W
                                             _dp(d_i), B, _dp(d_dS), _dp(d_X), _dp(d_dPre), _dp(d_loss), _sh(stream)))
 
 
-def buir_wgrad(d_X, d_dPre, n_rows: int, ld: int, d_gW, d_gb, stream=None):
-    _check(load().qrec_buir_wgrad(_dp(d_X), _dp(d_dPre), n_rows, ld, _dp(d_gW), _dp(d_gb), _sh(stream)))
+def buir_wgrad_scratch_bytes(ld: int) -> int:
+    out = C.c_int64(0)
+    _check(load().qrec_buir_wgrad_scratch_bytes(ld, C.byref(out)))
+    return out.value
+
+
+def buir_wgrad(d_X, d_dPre, n_rows: int, ld: int, d_scratch, d_gW, d_gb, stream=None):
+    _check(load().qrec_buir_wgrad(_dp(d_X), _dp(d_dPre), n_rows, ld, _dp(d_scratch), _dp(d_gW), _dp(d_gb), _sh(stream)))
 
 
 def ema_update(d_target, d_online, tau: float, n_elems: int, stream=None):

@@ -94,24 +94,39 @@ __global__ __launch_bounds__(256) void buir_batch_kernel(
     if (lane == 0 && loss != 0.0) atomicAdd(loss_out, loss);
 }
 
-// gW[k][c] = sum_rows Xb[row][k] * Gb[row][c] ; block k (one per row of W) ; block LD: gb[c] = sum_rows Gb[row][c].
-// 256 threads = (256/LD) row partitions x LD columns; partitions are combined in order through LDS.
+// gW[k][c] = sum_rows Xb[row][k] * Gb[row][c] (k < ld), gb[c] = sum_rows Gb[row][c] (k == ld).
+// Stage 1: block (k, slice) adds its slice of the rows (kWgradSlices slices; 256 threads = (256/ld) interleaved row
+// partitions x ld columns, combined in order through LDS) into part[slice][k][c].  Stage 2 adds the slices in order.
+// (One block per k over all 4,000 rows was a 1,000-deep dependent-load loop: 298 us.)
+constexpr int kWgradSlices = 16;
 __global__ __launch_bounds__(256) void buir_wgrad_kernel(const float *__restrict__ Xb, const float *__restrict__ Gb,
-                                                         int n_rows, int ld, float *__restrict__ gW, float *__restrict__ gb) {
+                                                         int n_rows, int ld, float *__restrict__ part) {
     __shared__ float s_part[256];
-    const int k = blockIdx.x, c = threadIdx.x % ld, part = threadIdx.x / ld, n_parts = 256 / ld;
+    const int k = blockIdx.x, slice = blockIdx.y, c = threadIdx.x % ld, p = threadIdx.x / ld, n_parts = 256 / ld;
+    const int per = (n_rows + kWgradSlices - 1) / kWgradSlices;
+    const int r0 = slice * per, r1 = (r0 + per) < n_rows ? (r0 + per) : n_rows;
     float acc = 0.f;
-    for (int row = part; row < n_rows; row += n_parts) {
+#pragma unroll 8
+    for (int row = r0 + p; row < r1; row += n_parts) {
         const float xv = k < ld ? Xb[(int64_t)row * ld + k] : 1.f;
         acc += xv * Gb[(int64_t)row * ld + c];
     }
     s_part[threadIdx.x] = acc;
     __syncthreads();
-    if (part == 0) {
+    if (p == 0) {
         float tot = 0.f;
-        for (int p = 0; p < n_parts; p++) tot += s_part[p * ld + c];
-        if (k < ld) gW[k * ld + c] = tot; else gb[c] = tot;
+        for (int q = 0; q < n_parts; q++) tot += s_part[q * ld + c];
+        part[((int64_t)slice * (ld + 1) + k) * ld + c] = tot;
     }
+}
+__global__ __launch_bounds__(256) void buir_wgrad_reduce_kernel(const float *__restrict__ part, int ld, float *__restrict__ gW,
+                                                                float *__restrict__ gb) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (ld + 1) * ld) return;
+    float tot = 0.f;
+#pragma unroll
+    for (int s = 0; s < kWgradSlices; s++) tot += part[(int64_t)s * (ld + 1) * ld + idx];
+    if (idx < ld * ld) gW[idx] = tot; else gb[idx - ld * ld] = tot;
 }
 
 __global__ __launch_bounds__(256) void ema_kernel(float *__restrict__ target, const float *__restrict__ online, float tau,
@@ -159,10 +174,20 @@ int qrec_buir_batch_loss_grad(const float *d_S_online, const float *d_S_target, 
     }
 }
 
-int qrec_buir_wgrad(const float *d_X, const float *d_dPre, int32_t n_rows, int32_t ld, float *d_gW, float *d_gb, void *stream) {
-    QREC_REQUIRE(d_X && d_dPre && d_gW && d_gb && n_rows >= 0, "qrec_buir_wgrad: bad argument");
+int qrec_buir_wgrad_scratch_bytes(int32_t ld, int64_t *bytes) {
+    QREC_REQUIRE(bytes && ld > 0, "qrec_buir_wgrad_scratch_bytes: bad argument");
+    *bytes = (int64_t)kWgradSlices * (ld + 1) * ld * sizeof(float);
+    return QREC_OK;
+}
+
+int qrec_buir_wgrad(const float *d_X, const float *d_dPre, int32_t n_rows, int32_t ld, float *d_scratch, float *d_gW,
+                    float *d_gb, void *stream) {
+    QREC_REQUIRE(d_X && d_dPre && d_scratch && d_gW && d_gb && n_rows >= 0, "qrec_buir_wgrad: bad argument");
     QREC_REQUIRE(ld == 32 || ld == 64 || ld == 128, "qrec_buir_wgrad: row stride must be 32, 64 or 128 floats (got %d)", ld);
-    hipLaunchKernelGGL(buir_wgrad_kernel, dim3((unsigned)(ld + 1)), dim3(256), 0, as_stream(stream), d_X, d_dPre, n_rows, ld, d_gW, d_gb);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(buir_wgrad_kernel, dim3((unsigned)(ld + 1), kWgradSlices), dim3(256), 0, st, d_X, d_dPre, n_rows, ld, d_scratch);
+    QREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(buir_wgrad_reduce_kernel, dim3((unsigned)(((ld + 1) * ld + 255) / 256)), dim3(256), 0, st, d_scratch, ld, d_gW, d_gb);
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }

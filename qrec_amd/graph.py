@@ -587,6 +587,7 @@ class BUIRTrainer:
         z = lambda: DeviceBuffer.zeros((self.n, self.ld), np.float32)
         self.S_on, self.S_tar, self.dS, self.A, self.B = z(), z(), z(), z(), z()
         self.gW, self.gb = DeviceBuffer.zeros((self.ld, self.ld), np.float32), DeviceBuffer.zeros(self.ld, np.float32)
+        self.wscratch = DeviceBuffer(capi.buir_wgrad_scratch_bytes(self.ld), np.uint8)
         self.optE, self.optW, self.optb = _Adam(self.E, lr), _Adam(self.W, lr), _Adam(self.b, lr)
         self.row_mask = DeviceBuffer.zeros((self.n + 31) // 32, np.uint32)
         self.d_loss = DeviceBuffer.zeros(1, np.float64)
@@ -622,7 +623,7 @@ class BUIRTrainer:
         self.dS.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
         capi.buir_batch_loss_grad(self.S_on, self.S_tar, div, self.nu, self.ld, self.W, self.b, d_u, d_i, B, self.dS, self.Xb,
                                   self.Gb, self.d_loss, stream)
-        capi.buir_wgrad(self.Xb, self.Gb, 2 * B, self.ld, self.gW, self.gb, stream)
+        capi.buir_wgrad(self.Xb, self.Gb, 2 * B, self.ld, self.wscratch, self.gW, self.gb, stream)
         # d online tables = (1/(L+1)) (I + A + ... + A^L) dS  (A symmetric): H_0 = dS, H_{k+1} = dS + A H_k
         x = self.dS
         for k in range(self.L):

@@ -45,4 +45,20 @@ capi.device_sync(); t0 = time.perf_counter()
 for k in range(60): tr.train_step_async(du.ptr + 4 * k * B, di.ptr + 4 * k * B, dj.ptr + 4 * k * B, B)
 capi.device_sync(); dt = (time.perf_counter() - t0) / 60
 out["ngcf_step"] = dict(ms_per_step=dt * 1e3, triplets_per_s=B / dt, epoch_s=dt * -(-nn // B), loss=tr.loss())
+# BUIR step (config/BUIR.conf options: 2 layers, tau 0.995, drop 0.5, batch 2000), Yelp shape, d=50
+from qrec_amd.graph import BUIRTrainer
+def sub():
+    keep = rng.permutation(nn)[:nn // 2]
+    return joint_norm_adjacency(nu, ni, d["train_u"][keep], d["train_i"][keep])
+lim = np.sqrt(6 / (nu + 50))
+bt = BUIRTrainer(rng.uniform(-lim, lim, (nu, 50)).astype(np.float32), rng.uniform(-lim, lim, (ni, 50)).astype(np.float32),
+                 rng.uniform(-0.24, 0.24, (50, 50)).astype(np.float32), rng.uniform(-0.3, 0.3, (1, 50)).astype(np.float32), 2, 0.001, 0.995)
+t0 = time.perf_counter(); so, st_ = sub(), sub(); t_sub = time.perf_counter() - t0
+t0 = time.perf_counter(); bt.set_subgraphs(so, st_); t_plan = time.perf_counter() - t0
+B = 2000
+for k in range(5): bt.train_step_async(du.ptr + 4 * k * B, di.ptr + 4 * k * B, B)
+capi.device_sync(); t0 = time.perf_counter()
+for k in range(60): bt.train_step_async(du.ptr + 4 * k * B, di.ptr + 4 * k * B, B)
+capi.device_sync(); dt = (time.perf_counter() - t0) / 60
+out["buir_step"] = dict(ms_per_step=dt * 1e3, pairs_per_s=B / dt, epoch_s=dt * -(-nn // B), loss=bt.loss(), host_two_subgraphs_s=t_sub, host_plan_upload_s=t_plan)
 print(json.dumps(out))
