@@ -306,7 +306,8 @@ int qrec_ema_update(float *d_target, const float *d_online, float tau, int64_t n
  * NULL), then the reference's find_k_largest: min-heap of (score,id) seeded with the first
  * N items, strict '>' replacement, stable descending sort -- ties included, so ids are
  * bit-identical to the reference's.  Outputs [n_batch_users][N] (ids -1 padded when
- * n_items < N).  d_scratch holds the transposed score block; size it with
+ * n_items < N).  Tables are [rows][ld] with ld a multiple of 32 floats / 16 doubles and columns [d, ld) zero.
+ * d_scratch holds the transposed score block; size it with
  * qrec_score_topk_scratch_bytes.  N <= 100 as in base/recommender.py:132-134.          */
 int qrec_score_topk_scratch_bytes(int dtype, int32_t n_items, int32_t n_batch_users, int64_t *bytes);
 int qrec_score_topk(const void *d_U, const void *d_V, int dtype, int32_t d, int32_t ld, int32_t n_items,

@@ -25,19 +25,25 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
+// Operand fetch (both kernels): the tables are zero-padded to the row stride ld (a multiple of the slot width: 32
+// floats / 16 doubles), so a lane reads ITS row's slot with unconditional 16-byte loads; rows past the end are
+// clamped (their results are not stored).  The next item tile's operands are requested before the current tile's
+// MFMAs.  (First version: one guarded dword load per element, 81 loads and 99 branches per 32 MFMAs.)
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
 // ---- (1) fp32: 32 items x 32 users per MFMA tile, K consumed 2 slots x 32 columns per 64-chunk.
 // lane l: row = l&31, slot h = l>>5 owns columns [64c + 32h, 64c + 32h + 32) of chunk c.
 // (the dot product does not care which physical column sits in which MFMA k-slot as long as
 //  A and B agree.)
 __global__ __launch_bounds__(256) void score_kernel_f32(
-    const float *__restrict__ U, const float *__restrict__ V, int d, int ld, int n_items,
+    const float *__restrict__ U, const float *__restrict__ V, int ld, int n_items,
     const int32_t *__restrict__ user_ids, int n_b, int b_pad, int item_tiles_per_wave,
     float *__restrict__ S_T) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int utile = blockIdx.x;                       // 32 users
     const int b = utile * 32 + r;
-    const int uid = (b < n_b) ? user_ids[b] : -1;
+    const int64_t uid = user_ids[b < n_b ? b : n_b - 1];   // columns b >= n_b of the block are never read
     const int n_chunks = (ld + 63) / 64;                // 64 columns per chunk
     const int n_item_tiles = (n_items + 31) / 32;
     const int t_begin = (blockIdx.y * 4 + wave) * item_tiles_per_wave;
@@ -46,20 +52,30 @@ __global__ __launch_bounds__(256) void score_kernel_f32(
     if (t_begin >= t_end) return;
 
     for (int c = 0; c < n_chunks; c++) {
-        float ub[32];
         const int col0 = 64 * c + 32 * h;
+        const bool kv = col0 < ld;                      // ld = 32 (mod 64): the last chunk's upper slot is empty
+        const int kb = kv ? col0 : 0;
+        const float keep = kv ? 1.f : 0.f;
+        f32x4 ub[8], va[8], vn[8];
+        {
+            const f32x4 *pu = reinterpret_cast<const f32x4 *>(U + uid * ld + kb);
 #pragma unroll
-        for (int s = 0; s < 32; s++) {
-            const int col = col0 + s;
-            ub[s] = (uid >= 0 && col < d) ? U[(int64_t)uid * ld + col] : 0.f;
+            for (int q = 0; q < 8; q++) ub[q] = pu[q] * keep;
+        }
+        auto tile_ptr = [&](int t) {
+            const int item = t * 32 + r;
+            return reinterpret_cast<const f32x4 *>(V + (int64_t)(item < n_items ? item : n_items - 1) * ld + kb);
+        };
+        {
+            const f32x4 *pv = tile_ptr(t_begin);
+#pragma unroll
+            for (int q = 0; q < 8; q++) va[q] = pv[q];
         }
         for (int t = t_begin; t < t_end; t++) {
-            const int item = t * 32 + r;
-            float va[32];
+            if (t + 1 < t_end) {
+                const f32x4 *pv = tile_ptr(t + 1);
 #pragma unroll
-            for (int s = 0; s < 32; s++) {
-                const int col = col0 + s;
-                va[s] = (item < n_items && col < d) ? V[(int64_t)item * ld + col] : 0.f;
+                for (int q = 0; q < 8; q++) vn[q] = pv[q];
             }
             f32x16 acc;
             float *out = S_T + (int64_t)(t * 32) * b_pad + utile * 32;
@@ -74,27 +90,34 @@ __global__ __launch_bounds__(256) void score_kernel_f32(
                 }
             }
 #pragma unroll
-            for (int s = 0; s < 32; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s], ub[s], acc, 0, 0, 0);
+            for (int q = 0; q < 8; q++) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[q].x, ub[q].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[q].y, ub[q].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[q].z, ub[q].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[q].w, ub[q].w, acc, 0, 0, 0);
+            }
             // C/D: col = lane&31 (user), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (item)
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
                 if (t * 32 + row < n_items) out[(int64_t)row * b_pad + r] = acc[q];
             }
+#pragma unroll
+            for (int q = 0; q < 8; q++) va[q] = vn[q];
         }
     }
 }
 
 // ---- (1) fp64: 16 items x 16 users per MFMA tile, 4 slots x 16 columns per 64-chunk.
 __global__ __launch_bounds__(256) void score_kernel_f64(
-    const double *__restrict__ U, const double *__restrict__ V, int d, int ld, int n_items,
+    const double *__restrict__ U, const double *__restrict__ V, int ld, int n_items,
     const int32_t *__restrict__ user_ids, int n_b, int b_pad, int item_tiles_per_wave,
     double *__restrict__ S_T) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, h = lane >> 4;
     const int utile = blockIdx.x;                       // 16 users
     const int b = utile * 16 + r;
-    const int uid = (b < n_b) ? user_ids[b] : -1;
+    const int64_t uid = user_ids[b < n_b ? b : n_b - 1];
     const int n_chunks = (ld + 63) / 64;
     const int n_item_tiles = (n_items + 15) / 16;
     const int t_begin = (blockIdx.y * 4 + wave) * item_tiles_per_wave;
@@ -103,20 +126,30 @@ __global__ __launch_bounds__(256) void score_kernel_f64(
     if (t_begin >= t_end) return;
 
     for (int c = 0; c < n_chunks; c++) {
-        double ub[16];
         const int col0 = 64 * c + 16 * h;
+        const bool kv = col0 < ld;
+        const int kb = kv ? col0 : 0;
+        const double keep = kv ? 1.0 : 0.0;
+        f64x2 ub[8], va[8], vn[8];
+        {
+            const f64x2 *pu = reinterpret_cast<const f64x2 *>(U + uid * ld + kb);
 #pragma unroll
-        for (int s = 0; s < 16; s++) {
-            const int col = col0 + s;
-            ub[s] = (uid >= 0 && col < d) ? U[(int64_t)uid * ld + col] : 0.0;
+            for (int q = 0; q < 8; q++) ub[q] = pu[q] * keep;
+        }
+        auto tile_ptr = [&](int t) {
+            const int item = t * 16 + r;
+            return reinterpret_cast<const f64x2 *>(V + (int64_t)(item < n_items ? item : n_items - 1) * ld + kb);
+        };
+        {
+            const f64x2 *pv = tile_ptr(t_begin);
+#pragma unroll
+            for (int q = 0; q < 8; q++) va[q] = pv[q];
         }
         for (int t = t_begin; t < t_end; t++) {
-            const int item = t * 16 + r;
-            double va[16];
+            if (t + 1 < t_end) {
+                const f64x2 *pv = tile_ptr(t + 1);
 #pragma unroll
-            for (int s = 0; s < 16; s++) {
-                const int col = col0 + s;
-                va[s] = (item < n_items && col < d) ? V[(int64_t)item * ld + col] : 0.0;
+                for (int q = 0; q < 8; q++) vn[q] = pv[q];
             }
             f64x4 acc;
             double *out = S_T + (int64_t)(t * 16) * b_pad + utile * 16;
@@ -130,13 +163,18 @@ __global__ __launch_bounds__(256) void score_kernel_f64(
                 }
             }
 #pragma unroll
-            for (int s = 0; s < 16; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[s], ub[s], acc, 0, 0, 0);
+            for (int q = 0; q < 8; q++) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[q].x, ub[q].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[q].y, ub[q].y, acc, 0, 0, 0);
+            }
             // f64 C/D: col = lane&15 (user), row = (lane>>4) + 4*reg (item)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int row = h + 4 * q;
                 if (t * 16 + row < n_items) out[(int64_t)row * b_pad + r] = acc[q];
             }
+#pragma unroll
+            for (int q = 0; q < 8; q++) va[q] = vn[q];
         }
     }
 }
@@ -220,13 +258,15 @@ __global__ __launch_bounds__(kHeapThreads) void heap_topk_kernel(const T *__rest
     for (int t = k / 2 - 1; t >= 0; t--) sift_up(hp, k, t);  // heapify
     T root = hp.S(0);
     int t = k;
-    // main scan: unrolled by 8 so the loads run ahead of the (rarely taken) heap update
-    for (; t + 8 <= n_items; t += 8) {
-        T v[8];
+    // main scan: 32 (fp32) / 16 (fp64) loads in flight per lane ahead of the (rarely taken) heap update -- there is
+    // less than one wavefront per SIMD here (one lane per user), so latency is hidden by depth, not by occupancy
+    constexpr int kAhead = sizeof(T) == 4 ? 32 : 16;
+    for (; t + kAhead <= n_items; t += kAhead) {
+        T v[kAhead];
 #pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = col[(int64_t)(t + q) * b_pad];
+        for (int q = 0; q < kAhead; q++) v[q] = col[(int64_t)(t + q) * b_pad];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
+        for (int q = 0; q < kAhead; q++) {
             if (v[q] > root) { hp.set(0, v[q], t + q); sift_up(hp, k, 0); root = hp.S(0); }
         }
     }
@@ -264,10 +304,10 @@ int run_score_topk(const void *U, const void *V, int d, int ld, int n_items, con
     const dim3 grid((unsigned)n_utiles, (unsigned)((waves_per_utile + 3) / 4));
     T *S_T = static_cast<T *>(scratch);
     if constexpr (sizeof(T) == 4)
-        hipLaunchKernelGGL(score_kernel_f32, grid, dim3(256), 0, st, (const float *)U, (const float *)V, d, ld,
+        hipLaunchKernelGGL(score_kernel_f32, grid, dim3(256), 0, st, (const float *)U, (const float *)V, ld,
                            n_items, user_ids, n_b, b_pad, per_wave, S_T);
     else
-        hipLaunchKernelGGL(score_kernel_f64, grid, dim3(256), 0, st, (const double *)U, (const double *)V, d, ld,
+        hipLaunchKernelGGL(score_kernel_f64, grid, dim3(256), 0, st, (const double *)U, (const double *)V, ld,
                            n_items, user_ids, n_b, b_pad, per_wave, S_T);
     QREC_LAUNCH_CHECK();
     if (rated_indptr) {
@@ -334,6 +374,8 @@ int qrec_score_topk(const void *d_U, const void *d_V, int dtype, int32_t d, int3
     QREC_REQUIRE(d_U && d_V && d_user_ids && d_scratch && d_ids_out && d_scores_out, "qrec_score_topk: null argument");
     QREC_REQUIRE(dtype == QREC_F32 || dtype == QREC_F64, "qrec_score_topk: bad dtype %d", dtype);
     QREC_REQUIRE(d >= 1 && ld >= d && n_items >= 1 && n_batch_users >= 0, "qrec_score_topk: bad sizes");
+    QREC_REQUIRE(ld % (dtype == QREC_F64 ? 16 : 32) == 0,
+                 "qrec_score_topk: the row stride must be a multiple of 32 floats / 16 doubles, pad columns zero (got ld=%d)", ld);
     QREC_REQUIRE(K >= 1 && K <= 100, "qrec_score_topk: N must be in 1..100 (base/recommender.py:132-134)");
     QREC_REQUIRE((d_rated_indptr == nullptr) == (d_rated_items == nullptr), "qrec_score_topk: rated CSR incomplete");
     if (n_batch_users == 0) return QREC_OK;

@@ -29,8 +29,10 @@ class DeviceRanker:
         self.d = U.shape[1]
         assert V.shape[1] == self.d
         self.n_users, self.n_items = U.shape[0], V.shape[0]
-        self.dU = DeviceBuffer.from_numpy(np.ascontiguousarray(U))
-        self.dV = DeviceBuffer.from_numpy(np.ascontiguousarray(V))
+        slot = 16 if self.dtype == np.float64 else 32          # MFMA k-slot width of the scoring kernels
+        self.ld = -(-self.d // slot) * slot                     # zero-padded row stride (include/qrec_hip.h)
+        self.dU = DeviceBuffer.from_numpy(self._pad(U))
+        self.dV = DeviceBuffer.from_numpy(self._pad(V))
         self._scratch = self._d_ids = self._d_sc = None
         self._cap = (0, 0)
         self.rated = None
@@ -39,11 +41,18 @@ class DeviceRanker:
             self.rated = (DeviceBuffer.from_numpy(rated.indptr.astype(np.int64)),
                           DeviceBuffer.from_numpy(rated.indices.astype(np.int32)))
 
+    def _pad(self, a: np.ndarray) -> np.ndarray:
+        if a.shape[1] == self.ld:
+            return np.ascontiguousarray(a)
+        out = np.zeros((a.shape[0], self.ld), dtype=self.dtype)
+        out[:, :self.d] = a
+        return out
+
     def update_tables(self, U: np.ndarray, V: np.ndarray):
         """New embeddings of the same shape/dtype (per-epoch evaluation): re-upload only."""
         if U.shape != (self.n_users, self.d) or V.shape != (self.n_items, self.d) or U.dtype != self.dtype or V.dtype != self.dtype:
             raise ValueError("update_tables: shape/dtype differ from the ranker's")
-        self.dU.upload(np.ascontiguousarray(U)); self.dV.upload(np.ascontiguousarray(V))
+        self.dU.upload(self._pad(U)); self.dV.upload(self._pad(V))
 
     def set_test(self, test: CSR):
         """held-out items per user (CSR over ALL users of the table, ids ascending inside a row)"""
@@ -87,7 +96,7 @@ class DeviceRanker:
         for s in range(0, n, batch):
             chunk = user_ids[s:s + batch]
             d_users = DeviceBuffer.from_numpy(chunk)
-            capi.score_topk(self.dU, self.dV, self.code, self.d, self.d, self.n_items, d_users, chunk.size,
+            capi.score_topk(self.dU, self.dV, self.code, self.d, self.ld, self.n_items, d_users, chunk.size,
                             self.rated[0] if self.rated else None, self.rated[1] if self.rated else None,
                             N, scratch, d_ids, d_sc)
             if want_lists:
