@@ -682,3 +682,32 @@ def test_main_flow_from_files_native_loader_equals_python_loader(tmp_path, monke
     assert m_nat == m_py and s_nat == s_py
     assert np.array_equal(c_nat["P"], c_py["P"]) and np.array_equal(c_nat["Q"], c_py["Q"])
     assert list(c_nat["data"].user.items()) == list(c_py["data"].user.items())
+
+
+@pytest.mark.parametrize("parallel", [False, True])
+def test_cross_validation_folds_run_in_child_processes(tmp_path, parallel):
+    """QRec.py:62-101 through ``python -m qrec_amd.main <conf>`` (a fresh interpreter, like the reference's main.py):
+    ``-cv k`` builds the fold models in the parent and runs each in its own forked process (``-p``: all at once).
+    Nothing may touch the device before the fork (the native loader is host code), every child initialises its own
+    device context, and the averaged measure file is written."""
+    import os, subprocess, sys
+    rng = np.random.default_rng(31)
+    n = 4000
+    rows = [f"user{u} item{i} {r}" for u, i, r in zip(rng.integers(0, 200, n), rng.integers(0, 300, n), rng.choice([1, 2, 3, 4, 5], n))]
+    (tmp_path / "ratings.txt").write_text("\n".join(rows) + "\n")
+    conf = {"ratings": "./ratings.txt", "ratings.setup": "-columns 0 1 2", "model.name": "BPR",
+            "evaluation.setup": "-cv 3 -b 1" + (" -p on" if parallel else ""), "item.ranking": "on -topN 10",
+            "num.factors": "16", "num.max.epoch": "2", "learnRate": "-init 0.05 -max 1",
+            "reg.lambda": "-u 0.01 -i 0.01 -b 0.2 -s 0.2", "output.setup": "off -dir ./results/"}
+    (tmp_path / "BPR.conf").write_text("".join(f"{k}={v}\n" for k, v in conf.items()))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    run = subprocess.run([sys.executable, "-m", "qrec_amd.main", "BPR.conf"], cwd=tmp_path, env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    assert "The result of 3-fold cross validation:" in run.stdout
+    out = list((tmp_path / "results").glob("BPR@*-3-fold-cv.txt"))
+    assert len(out) == 1
+    res = out[0].read_text().splitlines()
+    assert [r.split(":")[0] for r in res] == ["Top 10", "Precision", "Recall", "F1", "NDCG"]
+    assert all(0.0 <= float(r.split(":")[1]) <= 1.0 for r in res[1:])
