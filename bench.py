@@ -39,14 +39,13 @@ sys.path.insert(0, ROOT)
 
 from qrec_amd import capi  # noqa: E402
 from qrec_amd.capi import DeviceBuffer  # noqa: E402
-from qrec_amd.engine import BprSgd, DeviceTables  # noqa: E402
+from qrec_amd.engine import BprSgd, DeviceTables, balanced_chunk  # noqa: E402
 from qrec_amd.interactions import CSR  # noqa: E402
 from qrec_amd.synth import make_dataset, to_csr  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 DIM = 64
 LR0, MAX_LR, REG_U, REG_I = 0.01, 1.0, 0.001, 0.001   # config/BPR.conf:9-10
-CHUNK = 32
 FLUSH_EVERY = 8
 
 
@@ -155,6 +154,7 @@ def main():
     tables = DeviceTables(P0, Q0, np.float32)
     sgd = BprSgd(tables, u, items, CSR(indptr, items), schedule=args.schedule)
     total = args.warmup + args.steps
+    CHUNK = balanced_chunk(n)     # triplets per work item: the count that spreads evenly over the 4,096 persistent groups
     ev = [(capi.Event(), capi.Event()) for _ in range(total)]
 
     q_sync = stats_view = None

@@ -86,6 +86,8 @@ class BPR(IterativeRecommender):
         epochs retire.  Epochs enqueued past the converged one are no-ops on the device, so the tables are
         those of the converged epoch exactly as if the loop had stopped there.  (The reference's per-epoch
         ``shuffle(trainingData)`` has no effect on this model's visiting order and is not replayed here.)"""
+        from ...engine import balanced_chunk
+        chunk = balanced_chunk(sgd.n)
         sgd.start_device_driver(self.lRate, log_capacity=self.maxEpoch)
         sgd.prefetch_negatives_device(self.sampler_seed, 0)
         closed = []
@@ -108,7 +110,7 @@ class BPR(IterativeRecommender):
         done, retired = False, 0
         for epoch in range(self.maxEpoch):
             sgd.take_prefetched_negatives(epoch)
-            sgd.epoch_device_async(self.regU, self.regI, self.maxLRate, tol=1e-3)
+            sgd.epoch_device_async(self.regU, self.regI, self.maxLRate, tol=1e-3, chunk=chunk)
             sgd.prefetch_negatives_device(self.sampler_seed, epoch + 1)      # released under this epoch's SGD kernel
             ev = capi.Event(); ev.record(); closed.append(ev)
             if epoch >= depth:

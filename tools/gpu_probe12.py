@@ -16,8 +16,8 @@ rng = np.random.default_rng(0)
 P0 = (rng.random((U, 64)) / 3).astype(np.float32); Q0 = (rng.random((I, 64)) / 3).astype(np.float32)
 e0, e1 = capi.Event(), capi.Event()
 out = {}
-for chunk in (32, 64):
-    for flush in (4, 8, 16, 32, 64):
+for chunk in (28, 30, 31, 32, 33, 34, 35, 36, 40, 48):
+    for flush in (8,):
         if flush > chunk: continue
         for groups in (0,):
             t = DeviceTables(P0, Q0, np.float32); sgd = BprSgd(t, u, items, CSR(indptr, items), schedule="item")
