@@ -176,7 +176,8 @@ int qrec_epoch_decide(double *d_stats, double *d_state, double regU, double regI
 
 /* Rating-prediction MF family, order-exact: variant 0 = model/rating/BasicMF.py:9-26 (config #1),
  * 1 = model/rating/PMF.py:9-28 (regU, regI), 2 = model/rating/SVD.py:13-35 (biases d_Bu/d_Bi of the
- * tables' dtype, regB, global mean).  Rows are visited in array order (the caller passes the current
+ * tables' dtype, regB, global mean), 3 = model/rating/EE.py:15-34 (Euclidean embedding; *d_loss then also
+ * carries the per-rating regU*|P[u]-Q[i]|^2 term of EE.py:25).  Rows are visited in array order (the caller passes the current
  * trainingData order); *d_loss receives sum(error^2).                                          */
 int qrec_mf_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
                         const int32_t *d_u, const int32_t *d_i, const double *d_rating, int64_t n,

@@ -178,9 +178,9 @@ def mf_sgd(P, Q, u, i, r, lr) -> float:
 
 
 def mf_sgd_variant(variant: int, P, Q, u, i, r, lr, regU=0.0, regI=0.0, Bu=None, Bi=None, regB=0.0, gmean=0.0) -> float:
-    """variant 1 = model/rating/PMF.py:9-28, 2 = model/rating/SVD.py:13-35 (fp64, in place)."""
+    """variant 1 = model/rating/PMF.py:9-28, 2 = model/rating/SVD.py:13-35, 3 = model/rating/EE.py:15-34 (fp64, in place)."""
     _chk(P, np.float64); _chk(Q, np.float64); _chk(u, np.int32); _chk(i, np.int32); _chk(r, np.float64)
-    if variant == 2:
+    if variant in (2, 3):
         _chk(Bu, np.float64); _chk(Bi, np.float64)
     return lib().orc_mf_sgd_var_f64(variant, _p(P), _p(Q), _p(Bu) if Bu is not None else None,
                                     _p(Bi) if Bi is not None else None, P.shape[1], _p(u), _p(i), _p(r), u.size,

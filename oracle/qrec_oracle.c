@@ -375,7 +375,10 @@ double orc_mf_sgd_f64(double *P, double *Q, int32_t d, const int32_t *u_idx,
  *   PMF:  error = r - P[u].Q[i];  P[u] += lr*(error*q - regU*p);  Q[i] += lr*(error*p - regI*q)   (p: UPDATED view)
  *   SVD:  error = r - (((P[u].Q[i] + globalMean) + Bi[i]) + Bu[u])   (SVD.py:76-80), same P/Q updates,
  *         Bu[u] += lr*(error - regB*bu);  Bi[i] += lr*(error - regB*bi)    (bu, bi: values read BEFORE the updates)
- * Returns sum(error^2); the epoch-end regularisers are orc_sumsq_f64. */
+ *   EE (variant 3, model/rating/EE.py:15-34,80-84): diff = P[u]-Q[i]; error = r - (((globalMean + Bi[i]) + Bu[u]) - diff.diff);
+ *         the returned loss also carries regU*diff.diff per rating (EE.py:25);
+ *         P[u] -= (lr*(error+regU))*diff;  Q[i] += (lr*(error+regI))*(P[u]-Q[i])  (UPDATED P[u]);  biases as SVD.
+ * Returns sum(error^2) (+ the EE term); the epoch-end regularisers are orc_sumsq_f64. */
 double orc_mf_sgd_var_f64(int variant, double *P, double *Q, double *Bu, double *Bi, int32_t d,
                           const int32_t *u_idx, const int32_t *i_idx, const double *rating, int64_t n,
                           double lr, double regU, double regI, double regB, double gmean) {
@@ -386,6 +389,20 @@ double orc_mf_sgd_var_f64(int variant, double *P, double *Q, double *Bu, double 
         const int32_t u = u_idx[t], i = i_idx[t];
         double *p = P + (int64_t)u * d, *q = Q + (int64_t)i * d;
         double dot = 0.0, pred, err, bu = 0.0, bi = 0.0;
+        if (variant == 3) {
+            double cu, ci;
+            for (c = 0; c < d; c++) { const double df = p[c] - q[c]; dot += df * df; }
+            bu = Bu[u]; bi = Bi[i];
+            pred = ((gmean + bi) + bu) - dot;
+            err = rating[t] - pred;
+            loss += err * err;
+            loss += regU * dot;
+            cu = lr * (err + regU); ci = lr * (err + regI);
+            for (c = 0; c < d; c++) p[c] -= cu * (p[c] - q[c]);
+            for (c = 0; c < d; c++) q[c] += ci * (p[c] - q[c]);
+            Bu[u] += lr * (err - regB * bu); Bi[i] += lr * (err - regB * bi);
+            continue;
+        }
         for (c = 0; c < d; c++) dot += p[c] * q[c];
         pred = dot;
         if (variant == 2) { bu = Bu[u]; bi = Bi[i]; pred = ((dot + gmean) + bi) + bu; }

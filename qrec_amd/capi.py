@@ -407,7 +407,7 @@ def bpr_sgd_hogwild(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int, chunk: int
                                        _dp(d_driver_state), _sh(stream)))
 
 
-MF_BASIC, MF_PMF, MF_SVD = 0, 1, 2
+MF_BASIC, MF_PMF, MF_SVD, MF_EE = 0, 1, 2, 3
 
 
 def mf_sgd_ordered(d_P, d_Q, dtype: int, d: int, ld: int, d_u, d_i, d_rating, n: int, lr: float,

@@ -128,6 +128,9 @@ __global__ __launch_bounds__(64) void bpr_ordered_kernel(
 //   VAR 1  model/rating/PMF.py:9-28       P[u] += lr*(e*q - regU*p) ;   Q[i] += lr*(e*p - regI*q)
 //   VAR 2  model/rating/SVD.py:13-35      as PMF with e = r - (((P[u].Q[i] + mean) + Bi[i]) + Bu[u]),
 //                                         Bu[u] += lr*(e - regB*bu) ; Bi[i] += lr*(e - regB*bi)
+//   VAR 3  model/rating/EE.py:15-34       diff = P[u]-Q[i]; e = r - (((mean + Bi[i]) + Bu[u]) - diff.diff);
+//                                         loss += e*e + regU*diff.diff; P[u] -= (lr*(e+regU))*diff;
+//                                         Q[i] += (lr*(e+regI))*(P[u]-Q[i]); biases as SVD
 // p is a VIEW of P[u] in the reference, so the Q[i] update sees the already updated P[u].
 template <typename T, int EPL, int VAR>
 __global__ __launch_bounds__(64) void mf_ordered_kernel(
@@ -147,25 +150,31 @@ __global__ __launch_bounds__(64) void mf_ordered_kernel(
             const bool ok = (lane + 64 * e) < d;
             pv[e] = ok ? p[64 * e] : T(0);
             qv[e] = ok ? q[64 * e] : T(0);
-            dot += pv[e] * qv[e];
+            if constexpr (VAR == 3) { const T df = pv[e] - qv[e]; dot += df * df; }
+            else dot += pv[e] * qv[e];
         }
         dot = wave_allreduce_sum(dot);
         T pred = dot, bu = 0, bi = 0;
         if constexpr (VAR == 2) { bu = Bu[u]; bi = Bi[i]; pred = ((dot + gmean) + bi) + bu; }
+        if constexpr (VAR == 3) { bu = Bu[u]; bi = Bi[i]; pred = ((gmean + bi) + bu) - dot; }
         const T err = (T)rating[t] - pred;
         loss += (double)err * (double)err;
+        if constexpr (VAR == 3) loss += (double)(regU * dot);
 #pragma unroll
         for (int e = 0; e < EPL; e++) {
             if constexpr (VAR == 0) {
                 pv[e] += (lr * err) * qv[e];
                 qv[e] += (lr * err) * pv[e];
+            } else if constexpr (VAR == 3) {
+                pv[e] -= (lr * (err + regU)) * (pv[e] - qv[e]);
+                qv[e] += (lr * (err + regI)) * (pv[e] - qv[e]);
             } else {
                 pv[e] += lr * (err * qv[e] - regU * pv[e]);
                 qv[e] += lr * (err * pv[e] - regI * qv[e]);
             }
             if ((lane + 64 * e) < d) { p[64 * e] = pv[e]; q[64 * e] = qv[e]; }
         }
-        if constexpr (VAR == 2) {
+        if constexpr (VAR >= 2) {
             if (lane == 0) { Bu[u] = bu + lr * (err - regB * bu); Bi[i] = bi + lr * (err - regB * bi); }
         }
     }
@@ -513,7 +522,8 @@ int dispatch_mf(int variant, void *P, void *Q, void *Bu, void *Bi, int d, int ld
     switch (variant) {
         case 0: return launch_mf_ordered<T, 0>(P, Q, Bu, Bi, d, ld, u, i, r, n, lr, regU, regI, regB, gmean, loss, st);
         case 1: return launch_mf_ordered<T, 1>(P, Q, Bu, Bi, d, ld, u, i, r, n, lr, regU, regI, regB, gmean, loss, st);
-        default: return launch_mf_ordered<T, 2>(P, Q, Bu, Bi, d, ld, u, i, r, n, lr, regU, regI, regB, gmean, loss, st);
+        case 2: return launch_mf_ordered<T, 2>(P, Q, Bu, Bi, d, ld, u, i, r, n, lr, regU, regI, regB, gmean, loss, st);
+        default: return launch_mf_ordered<T, 3>(P, Q, Bu, Bi, d, ld, u, i, r, n, lr, regU, regI, regB, gmean, loss, st);
     }
 }
 
@@ -543,8 +553,8 @@ int qrec_mf_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
     QREC_REQUIRE(n == 0 || (d_u && d_i && d_rating), "qrec_mf_sgd_ordered: null index array");
     QREC_REQUIRE(d >= 1 && d <= 256 && ld >= d, "qrec_mf_sgd_ordered: need 1 <= d <= 256, ld >= d");
     QREC_REQUIRE(dtype == QREC_F32 || dtype == QREC_F64, "qrec_mf_sgd_ordered: bad dtype %d", dtype);
-    QREC_REQUIRE(variant >= 0 && variant <= 2, "qrec_mf_sgd_ordered: variant must be 0 (BasicMF), 1 (PMF) or 2 (SVD)");
-    QREC_REQUIRE(variant != 2 || (d_Bu && d_Bi), "qrec_mf_sgd_ordered: SVD needs the bias vectors");
+    QREC_REQUIRE(variant >= 0 && variant <= 3, "qrec_mf_sgd_ordered: variant must be 0 (BasicMF), 1 (PMF), 2 (SVD) or 3 (EE)");
+    QREC_REQUIRE(variant < 2 || (d_Bu && d_Bi), "qrec_mf_sgd_ordered: SVD and EE need the bias vectors");
     hipStream_t st = as_stream(stream);
     if (n == 0) { QREC_HIP_CHECK(hipMemsetAsync(d_loss, 0, sizeof(double), st)); return QREC_OK; }
     return dtype == QREC_F64 ? dispatch_mf<double>(variant, d_P, d_Q, d_Bu, d_Bi, d, ld, d_u, d_i, d_rating, n, lr, regU, regI, regB, global_mean, d_loss, st)

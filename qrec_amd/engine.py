@@ -284,7 +284,7 @@ class BprSgd:
 
 class MfSgd:
     """Rating-prediction MF family on the device, order-exact: BasicMF (model/rating/BasicMF.py:9-26),
-    PMF (model/rating/PMF.py:9-28), SVD (model/rating/SVD.py:13-35)."""
+    PMF (model/rating/PMF.py:9-28), SVD (model/rating/SVD.py:13-35), EE (model/rating/EE.py:15-34)."""
 
     def __init__(self, tables: DeviceTables, n: int, variant: int = capi.MF_BASIC, Bu=None, Bi=None):
         self.t = tables
@@ -295,7 +295,7 @@ class MfSgd:
         self.d_r = DeviceBuffer(max(n, 1), np.float64)
         self.d_stats = DeviceBuffer.zeros(5, np.float64)      # err^2, sum P^2, sum Q^2, sum Bu^2, sum Bi^2
         self.d_Bu = self.d_Bi = None
-        if variant == capi.MF_SVD:
+        if variant in (capi.MF_SVD, capi.MF_EE):
             self.d_Bu = DeviceBuffer.from_numpy(np.ascontiguousarray(Bu, dtype=tables.dtype))
             self.d_Bi = DeviceBuffer.from_numpy(np.ascontiguousarray(Bi, dtype=tables.dtype))
 

@@ -258,6 +258,10 @@ def case_svd(tmp):
     return _case_rating_mf(tmp, "SVD", "svd_filmtrust", 3, 10, 0.005, "-u 0.01 -i 0.02 -b 0.02 -s 0.1")
 
 
+def case_ee(tmp):
+    return _case_rating_mf(tmp, "EE", "ee_filmtrust", 4, 10, 0.005, "-u 0.005 -i 0.005 -b 0.005 -s 0.1")
+
+
 def case_pairwise_and_adj(tmp):
     """base/deepRecommender.py:29-52 sampler and base/graphRecommender.py:10-29 adjacency,
     both pure python/scipy -> executable with the tensorflow stub."""
@@ -334,7 +338,7 @@ def main():
     os.symlink(os.path.join(REF, "dataset"), os.path.join(tmp, "dataset"))
     os.chdir(tmp)
     only = sys.argv[1:]
-    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pmf, case_svd, case_pairwise_and_adj, case_sgl_subgraph]
+    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pmf, case_svd, case_ee, case_pairwise_and_adj, case_sgl_subgraph]
     if only:   # regenerate a subset, keep the other entries of golden_meta.json
         cases = [c for c in cases if c.__name__ in only]
         old = json.load(open(os.path.join(OUT, "golden_meta.json")))

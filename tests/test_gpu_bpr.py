@@ -142,7 +142,7 @@ def test_basicmf_model_end_to_end_reproduces_reference_run():
     assert np.array_equal(capi.state_from_python(random.getstate()), z["py_state"])
 
 
-@pytest.mark.parametrize("variant", [capi.MF_BASIC, capi.MF_PMF, capi.MF_SVD])
+@pytest.mark.parametrize("variant", [capi.MF_BASIC, capi.MF_PMF, capi.MF_SVD, capi.MF_EE])
 @pytest.mark.parametrize("dim,dtype", [(10, np.float64), (64, np.float64), (200, np.float64), (50, np.float32)])
 def test_mf_family_kernel_matches_oracle(variant, dim, dtype):
     """BasicMF / PMF / SVD recurrences (model/rating/{BasicMF,PMF,SVD}.py) on synthetic ratings."""
@@ -165,7 +165,7 @@ def test_mf_family_kernel_matches_oracle(variant, dim, dtype):
     tol = F64_TOL if dtype == np.float64 else 2e-5   # 20k sequential fp32 updates on 300 rows
     assert rel_err(Pg, Pr) < tol and rel_err(Qg, Qr) < tol
     assert abs(got - want) / want < tol
-    if variant == capi.MF_SVD:
+    if variant in (capi.MF_SVD, capi.MF_EE):
         Bug, Big = sgd.biases()
         assert rel_err(Bug, Bur) < tol and rel_err(Big, Bir) < tol
         sp, sq, sbu, sbi = sgd.sumsq_terms()
@@ -173,7 +173,7 @@ def test_mf_family_kernel_matches_oracle(variant, dim, dtype):
         assert sbi == pytest.approx(O.sumsq(Big), rel=1e-6 if dtype == np.float32 else 1e-12)
 
 
-@pytest.mark.parametrize("name", ["PMF", "SVD"])
+@pytest.mark.parametrize("name", ["PMF", "SVD", "EE"])
 def test_pmf_svd_model_end_to_end_reproduces_reference_run(name):
     """model/rating/PMF.py, SVD.py on FilmTrust through the drop-in classes, against the recorded runs."""
     import importlib
@@ -189,7 +189,7 @@ def test_pmf_svd_model_end_to_end_reproduces_reference_run(name):
     last = len(meta["epochs"])
     np.testing.assert_allclose(m.P, z[f"P{last}"], rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(m.Q, z[f"Q{last}"], rtol=1e-10, atol=1e-13)
-    if name == "SVD":
+    if name in ("SVD", "EE"):
         np.testing.assert_allclose(m.Bu, z[f"Bu{last}"], rtol=1e-10, atol=1e-13)
         np.testing.assert_allclose(m.Bi, z[f"Bi{last}"], rtol=1e-10, atol=1e-13)
     assert m.lastLoss == pytest.approx(meta["epochs"][-1]["loss"], rel=1e-11)

@@ -147,14 +147,14 @@ def _bold_driver(lr, last_loss, loss, epoch):
     return lr
 
 
-@pytest.mark.parametrize("name,variant", [("pmf_filmtrust", 1), ("svd_filmtrust", 2)])
+@pytest.mark.parametrize("name,variant", [("pmf_filmtrust", 1), ("svd_filmtrust", 2), ("ee_filmtrust", 3)])
 def test_pmf_svd_filmtrust(golden_dir, name, variant):
     """model/rating/PMF.py:9-28 and model/rating/SVD.py:13-35 through the oracle, against the recorded
     reference runs (tables, biases, losses, learning-rate schedule, shuffle stream, predictions)."""
     meta, z = _load(golden_dir, name)
     P, Q = z["P0"].copy(), z["Q0"].copy()
-    Bu = z["Bu0"].copy() if variant == 2 else None
-    Bi = z["Bi0"].copy() if variant == 2 else None
+    Bu = z["Bu0"].copy() if variant >= 2 else None
+    Bi = z["Bi0"].copy() if variant >= 2 else None
     regU, regI, regB, gm = meta["regU"], meta["regI"], meta["regB"], meta["globalMean"]
     mt = O.MT.cpython_seed(meta["seed"])
     n = z["order0"].shape[0]
@@ -166,13 +166,16 @@ def test_pmf_svd_filmtrust(golden_dir, name, variant):
         assert np.array_equal(np.stack([u, i], 1), z[f"order{k}"])
         assert lr == pytest.approx(ep["lr_used"], rel=1e-15)
         loss = O.mf_sgd_variant(variant, P, Q, u, i, r, lr, regU, regI, Bu, Bi, regB, gm)
-        loss += regU * O.sumsq(P) + regI * O.sumsq(Q)
+        if variant != 3:
+            loss += regU * O.sumsq(P) + regI * O.sumsq(Q)
         if variant == 2:
             loss += regB * (O.sumsq(Bu) + O.sumsq(Bi))
+        if variant == 3:
+            loss += regB * O.sumsq(Bu) + regB * O.sumsq(Bi)
         assert loss == pytest.approx(ep["loss"], rel=1e-11)
         np.testing.assert_allclose(P, z[f"P{k+1}"], rtol=1e-10, atol=1e-13)
         np.testing.assert_allclose(Q, z[f"Q{k+1}"], rtol=1e-10, atol=1e-13)
-        if variant == 2:
+        if variant >= 2:
             np.testing.assert_allclose(Bu, z[f"Bu{k+1}"], rtol=1e-10, atol=1e-13)
             np.testing.assert_allclose(Bi, z[f"Bi{k+1}"], rtol=1e-10, atol=1e-13)
         lr = _bold_driver(lr, last_loss, loss, ep["epoch"])
@@ -185,6 +188,9 @@ def test_pmf_svd_filmtrust(golden_dir, name, variant):
     pred = np.einsum("nd,nd->n", P[tu[ok]], Q[ti[ok]])
     if variant == 2:
         pred = pred + gm + Bi[ti[ok]] + Bu[tu[ok]]
+    if variant == 3:
+        diff = P[tu[ok]] - Q[ti[ok]]
+        pred = gm + Bi[ti[ok]] + Bu[tu[ok]] - np.einsum("nd,nd->n", diff, diff)
     lo, hi = meta["rScale"][0], meta["rScale"][-1]
     got = np.where(pred > hi, hi, np.where(pred < lo, lo, np.round(pred, 3)))
     np.testing.assert_allclose(got, z["test_pred"][ok], atol=1.01e-3)
