@@ -133,13 +133,23 @@ def main():
     # QREC_FORCE_DIST=1 drives the torch.distributed/RCCL branch with world size 1 (the gpurun
     # boxes have one GPU): same code path as N>1, the all-reduce degenerates to a copy.
     use_dist = world > 1 or os.environ.get("QREC_FORCE_DIST") == "1"
+    # Test hook for the 1-GPU development boxes: QREC_DIST_TEST_ONE_DEVICE=1 puts every rank on device 0 and uses the
+    # gloo backend (RCCL refuses two ranks on one device), so that the N > 1 code path -- user sharding, delta
+    # all-reduce, summed loss terms, per-rank device-side driver -- runs end to end on real hardware.  Numbers from
+    # such a run are NOT bench results (the ranks share one GPU); the output line says so.
+    one_device = os.environ.get("QREC_DIST_TEST_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     if use_dist:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29571")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     capi.init(local_rank)
 
     # ---- workload: resident in HBM before timing ------------------------------------------
@@ -211,6 +221,9 @@ def main():
     assert drv["epochs"] == total and not drv["converged"], drv
     log = sgd.driver_log()
     state["loss"], state["lr"] = float(log[-1, 0]), drv["lr"]
+    if os.environ.get("QREC_DIST_TEST_DUMP"):     # functional tests: every rank leaves its replica and its driver log behind
+        np.savez(os.path.join(os.environ["QREC_DIST_TEST_DUMP"], f"rank{rank}.npz"), Q=tables.Q.numpy(), P=tables.P.numpy(),
+                 log=log, lr=drv["lr"])
     kernel_ms = [ev[k][1].elapsed_ms_since(ev[k][0]) for k in range(args.warmup, total)]
     avg_kernel_ms = float(np.mean(kernel_ms))
     alg_bytes = n * bytes_per_triplet(DIM)
@@ -225,6 +238,7 @@ def main():
             if tj.get("workload") == f"bpr-{args.shape}-d{DIM}-{args.schedule}":
                 traffic = tj.get("bytes_per_launch")
         out = {
+            **({"INVALID_AS_BENCH": "QREC_DIST_TEST_ONE_DEVICE: all ranks shared one GPU over gloo (functional test only)"} if one_device else {}),
             "metric": "BPR triplet-updates/sec", "value": value, "unit": "triplet-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
