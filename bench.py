@@ -46,7 +46,7 @@ from qrec_amd.synth import make_dataset, to_csr  # noqa: E402
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 DIM = 64
 LR0, MAX_LR, REG_U, REG_I = 0.01, 1.0, 0.001, 0.001   # config/BPR.conf:9-10
-FLUSH_EVERY = 8
+FLUSH_EVERY = 16
 
 
 def bytes_per_triplet(d: int) -> int:
@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--shape", default="yelp2018")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=capi.HW_DEFAULT)
+    ap.add_argument("--flush-every", type=int, default=0, help="item-major schedule: triplets between flushes of the register-resident Q[i] (0 = default)")
     ap.add_argument("--schedule", choices=("item", "user"), default="item",
                     help="visiting order of the epoch's triplets in the Hogwild kernel (DESIGN.md s4)")
     args = ap.parse_args()
@@ -164,6 +165,7 @@ def main():
     tables = DeviceTables(P0, Q0, np.float32)
     sgd = BprSgd(tables, u, items, CSR(indptr, items), schedule=args.schedule)
     total = args.warmup + args.steps
+    flush_every = args.flush_every or FLUSH_EVERY
     CHUNK = balanced_chunk(n)     # triplets per work item: the count that spreads evenly over the 4,096 persistent groups
     ev = [(capi.Event(), capi.Event()) for _ in range(total)]
 
@@ -189,7 +191,7 @@ def main():
         isConverged, updateLearningRate) all on the device; the host only enqueues.  tol = 0: the K timed steps all run."""
         sgd.take_prefetched_negatives(k)                            # BPR.py:35-37 (sampled under step k-1)
         sgd.epoch_device_async(REG_U, REG_I, MAX_LR, tol=0.0, chunk=CHUNK, variant=args.variant,
-                               flush_every=FLUSH_EVERY, events=ev[k],   # BPR.py:45-53,40 + iterativeRecommender.py:88-104
+                               flush_every=flush_every, events=ev[k],   # BPR.py:45-53,40 + iterativeRecommender.py:88-104
                                between=between if use_dist else None)
         sgd.prefetch_negatives_device(2018, k + 1)                  # side stream, under the SGD kernel
 

@@ -191,7 +191,7 @@ class BprSgd:
         return float(self.d_stats.head(1, stream)[0])
 
     def epoch_throughput_async(self, lr: float, regU: float, regI: float, chunk: int = 32,
-                               variant: int = capi.HW_DEFAULT, stream=None, groups: int = 0, flush_every: int = 8):
+                               variant: int = capi.HW_DEFAULT, stream=None, groups: int = 0, flush_every: int = 16):
         """Hogwild pass (fp32 tables); enqueue only -- read the loss with ``loss()``/``epoch_stats()``.
         User-major schedule: P[u] register-resident, atomics on Q[i], Q[j].  Item-major schedule:
         Q[i] register-resident (flushed + re-read every ``flush_every`` triplets), atomics on P[u],
@@ -217,7 +217,7 @@ class BprSgd:
         self.d_stats.fill_bytes(0)
 
     def epoch_device_async(self, regU: float, regI: float, max_lr: float, tol: float = 1e-3, chunk: int = 32,
-                           variant: int = capi.HW_DEFAULT, stream=None, groups: int = 0, flush_every: int = 8,
+                           variant: int = capi.HW_DEFAULT, stream=None, groups: int = 0, flush_every: int = 16,
                            events=None, between=None):
         """One throughput epoch with everything after it (BPR.py:40 loss terms, isConverged,
         updateLearningRate) enqueued on the device: no host synchronisation.  ``events`` = (before, after)

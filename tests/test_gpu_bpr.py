@@ -458,8 +458,9 @@ def test_item_major_full_grid_properties_yelp_shape():
         sgd.epoch_ordered(0.01, 0.0, 0.0)          # the order-exact kernel refuses a non-reference order
 
 
+@pytest.mark.parametrize("flush", [8, 16, 34])
 @pytest.mark.parametrize("lr0,seed", [(0.01, 7), (0.05, 7)])
-def test_item_major_recall_matches_exact_order_training(lr0, seed):
+def test_item_major_recall_matches_exact_order_training(lr0, seed, flush):
     """Same paired design as above for the (default) item-major schedule: the CPU port runs the
     reference's user-major order with the same negative for every (u, i)."""
     from qrec_amd.interactions import CSR
@@ -477,7 +478,7 @@ def test_item_major_recall_matches_exact_order_training(lr0, seed):
     for k in range(epochs):
         sgd.sample_negatives_device(seed, k)
         j = sgd.negatives_reference_order()
-        sgd.epoch_throughput_async(lr_g, reg, reg)
+        sgd.epoch_throughput_async(lr_g, reg, reg, chunk=34, flush_every=flush)
         nll, sp, sq = sgd.epoch_stats(); loss_g = nll + reg * sp + reg * sq
         loss_c = O.bpr_sgd(Pc, Qc, u, ind, j, lr_c, reg, reg) + reg * O.sumsq(Pc) + reg * O.sumsq(Qc)
         if k > 0:
@@ -494,7 +495,7 @@ def test_item_major_recall_matches_exact_order_training(lr0, seed):
         return float((np.isin((users.astype(np.int64)[:, None] * I + ids).ravel(), test_keys).reshape(ids.shape).sum(1) / cnt).mean())
 
     r_cpu, r_gpu = recall(Pc, Qc), recall(Pg, Qg)
-    print("item-major Recall@20 exact-order", r_cpu, "throughput", r_gpu, "loss", last_c, last_g)
+    print("item-major flush", flush, "lr0", lr0, "Recall@20 exact-order", r_cpu, "throughput", r_gpu, "loss", last_c, last_g)
     assert abs(r_cpu - r_gpu) <= 0.002
 
 
