@@ -133,7 +133,7 @@ class IterativeRecommender(Recommender):
                 warm_pos=np.array(warm_pos, np.int64), test=test, lens=[len(self.data.testSet_u[u]) for u in users],
                 warm_uid=np.fromiter((self.data.user[users[k]] for k in warm_pos), dtype=np.int32, count=len(warm_pos)))
         cuts = sorted({min(n, N, self.num_items) for n in top})
-        per_n = {n: ([0] * len(users), [0.0] * len(users)) for n in top}
+        per_n = {n: (np.zeros(len(users), np.int64), np.zeros(len(users), np.float64)) for n in top}
         if cache["warm_uid"].size:
             ranker = self._device_ranker(U, V)
             if ranker.test is None:
@@ -141,20 +141,20 @@ class IterativeRecommender(Recommender):
             _, _, per_cut = ranker.topk(cache["warm_uid"], min(N, self.num_items), cuts=cuts, want_lists=False)
             for n in top:
                 hits, dcg = per_cut[min(n, N, self.num_items)]
-                for k, h, x in zip(cache["warm_pos"].tolist(), hits.tolist(), dcg.tolist()):
+                per_n[n][0][cache["warm_pos"]] = hits; per_n[n][1][cache["warm_pos"]] = dcg
+        if cache["warm_pos"].size < len(users):
+            warm = set(cache["warm_pos"].tolist())
+            ids, _ = find_k_largest(N, [self.data.globalMean] * self.num_items)      # cold users: one constant-score list
+            for k, u in enumerate(users):
+                if k in warm:
+                    continue
+                truth = self.data.testSet_u[u]
+                for n in top:
+                    h, x = 0, 0.0
+                    for pos, iid in enumerate(ids[:n]):
+                        if self.data.id2item[iid] in truth:
+                            h += 1; x += 1.0 / math.log(pos + 2)
                     per_n[n][0][k] = h; per_n[n][1][k] = x
-        warm = set(cache["warm_pos"].tolist())
-        for k, u in enumerate(users):
-            if k in warm:
-                continue
-            ids, _ = find_k_largest(N, [self.data.globalMean] * self.num_items)
-            truth = self.data.testSet_u[u]
-            for n in top:
-                h, x = 0, 0.0
-                for pos, iid in enumerate(ids[:n]):
-                    if self.data.id2item[iid] in truth:
-                        h += 1; x += 1.0 / math.log(pos + 2)
-                per_n[n][0][k] = h; per_n[n][1][k] = x
         return ranking_measure_strings(cache["lens"], per_n, top)
 
     def shuffle_training_data(self):

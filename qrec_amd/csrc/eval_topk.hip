@@ -212,23 +212,23 @@ __device__ inline bool tuple_lt(T sa, int32_t ia, T sb, int32_t ib) {
     return (sa < sb) || (sa == sb && ia < ib);
 }
 
-// heapq._siftdown(heap, startpos, pos)
-template <typename T>
-__device__ inline void sift_down(Heap<T> &hp, int startpos, int pos) {
-    const T ns = hp.S(pos); const int32_t ni = hp.I(pos);
+// heapq._siftdown(heap, startpos, pos)   (H: any heap view with S(k), I(k), set(k, score, id))
+template <typename H>
+__device__ inline void sift_down(H &hp, int startpos, int pos) {
+    const auto ns = hp.S(pos); const int32_t ni = hp.I(pos);
     while (pos > startpos) {
         const int parent = (pos - 1) >> 1;
-        const T ps = hp.S(parent); const int32_t pi = hp.I(parent);
+        const auto ps = hp.S(parent); const int32_t pi = hp.I(parent);
         if (tuple_lt(ns, ni, ps, pi)) { hp.set(pos, ps, pi); pos = parent; continue; }
         break;
     }
     hp.set(pos, ns, ni);
 }
 // heapq._siftup(heap, pos): bubble the smaller child up to a leaf, then sift the item down
-template <typename T>
-__device__ inline void sift_up(Heap<T> &hp, int n, int pos) {
+template <typename H>
+__device__ inline void sift_up(H &hp, int n, int pos) {
     const int startpos = pos;
-    const T ns = hp.S(pos); const int32_t ni = hp.I(pos);
+    const auto ns = hp.S(pos); const int32_t ni = hp.I(pos);
     int child = 2 * pos + 1;
     while (child < n) {
         const int right = child + 1;
@@ -245,12 +245,17 @@ template <typename T>
 __global__ __launch_bounds__(kHeapThreads) void heap_topk_kernel(const T *__restrict__ S_T, int n_items,
                                                                  int b_pad, int n_b, int K,
                                                                  int32_t *__restrict__ ids_out,
-                                                                 T *__restrict__ scores_out) {
+                                                                 T *__restrict__ scores_out,
+                                                                 const int32_t *__restrict__ flags,
+                                                                 const int32_t *__restrict__ n_flagged, int many) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *hs = reinterpret_cast<T *>(smem);
     int32_t *hi = reinterpret_cast<int32_t *>(smem + (size_t)K * kHeapThreads * sizeof(T));
     const int b = blockIdx.x * kHeapThreads + threadIdx.x;
     if (b >= n_b) return;
+    // as the fallback of the sliced path: only when MANY users need the sequential emulation (then this coalesced
+    // lane-per-user scan is the cheapest way), and only for those users
+    if (flags && (*n_flagged <= many || !flags[b])) return;
     Heap<T> hp{hs, hi, (int)threadIdx.x};
     const T *col = S_T + b;
     const int k = K < n_items ? K : n_items;
@@ -288,6 +293,208 @@ __global__ __launch_bounds__(kHeapThreads) void heap_topk_kernel(const T *__rest
     for (int a = k; a < K; a++) { ids_out[(int64_t)b * K + a] = -1; scores_out[(int64_t)b * K + a] = T(0); }
 }
 
+// ---- (3b) sliced top-N: the fast path ---------------------------------------------------------
+// The lane-per-user scan above leaves half the chip idle (31,668 users = 495 wavefronts for 1,024 SIMDs) and is
+// bound by the bytes one lane can keep in flight (0.95 TB/s).  The reference's heap result is history-dependent only
+// through TIES: if a user's N+1 largest scores are pairwise distinct, find_k_largest returns exactly the N
+// largest in descending order (every one of them enters the heap and stays; the stable sort has nothing to break).
+// So: (a) prefix_topk_kernel + filter_kernel -- the exact top-(N+1) heap of the first 2,048 items gives every user a
+// threshold tau that his final N+1 best all reach; kSlices lanes per user then stream the rest of the catalogue and
+// keep only the scores >= tau (a per-slice heap was tried first: with 64 users per wavefront some lane updates its
+// heap in almost every step of the warm-up, 6x the heap work of the single scan, 3.1 ms); (b) merge_topk_kernel -- one
+// lane per user continues the prefix heap with the ~400 survivors into the global top-(N+1) (as a multiset of values
+// it is exact whatever the ties), writes the N best, and FLAGS the user if two of the N+1 values are equal or a slice
+// overflowed; (c) flagged users are redone with the exact
+// sequential emulation: few of them -> one wavefront each (exact_wave_kernel: 64 items per step, ballot for the
+// first item above the heap root, lane 0 runs heapq's sift), many -> the lane-per-user kernel above.
+constexpr int kSlices = 16;
+constexpr int kMaxM = 101;        // N <= 100 (base/recommender.py:132-134) -> N+1 candidates per slice
+__host__ inline size_t score_block_bytes(size_t elem, int n_items, int n_b) {
+    const size_t b_pad = ((size_t)n_b + 63) / 64 * 64, rows = ((size_t)n_items + 31) / 32 * 32;
+    return rows * b_pad * elem;
+}
+
+// (a1) exact top-M heap of the first `prefix` items, lane per user: its root tau[b] (the M-th largest of the prefix) is
+//      a lower bound of the user's global M-th largest score; the heap's content goes to candidate rows [0, M).
+template <typename T>
+__global__ __launch_bounds__(kHeapThreads) void prefix_topk_kernel(const T *__restrict__ S_T, int b_pad, int n_b, int M, int prefix,
+                                                                   T *__restrict__ cand_s, int32_t *__restrict__ cand_i,
+                                                                   T *__restrict__ tau) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *hs = reinterpret_cast<T *>(smem);
+    int32_t *hi = reinterpret_cast<int32_t *>(smem + (size_t)M * kHeapThreads * sizeof(T));
+    const int b = blockIdx.x * kHeapThreads + threadIdx.x;
+    if (b >= n_b) return;
+    Heap<T> hp{hs, hi, (int)threadIdx.x};
+    const T *col = S_T + b;
+    for (int a = 0; a < M; a++) hp.set(a, col[(int64_t)a * b_pad], a);
+    for (int a = M / 2 - 1; a >= 0; a--) sift_up(hp, M, a);
+    T rs = hp.S(0);
+    int32_t ri = hp.I(0);
+    constexpr int kAhead = sizeof(T) == 4 ? 16 : 8;
+    int t = M;
+    for (; t + kAhead <= prefix; t += kAhead) {
+        T v[kAhead];
+#pragma unroll
+        for (int q = 0; q < kAhead; q++) v[q] = col[(int64_t)(t + q) * b_pad];
+#pragma unroll
+        for (int q = 0; q < kAhead; q++)
+            if (tuple_lt(rs, ri, v[q], t + q)) { hp.set(0, v[q], t + q); sift_up(hp, M, 0); rs = hp.S(0); ri = hp.I(0); }
+    }
+    for (; t < prefix; t++) {
+        const T v = col[(int64_t)t * b_pad];
+        if (tuple_lt(rs, ri, v, t)) { hp.set(0, v, t); sift_up(hp, M, 0); rs = hp.S(0); ri = hp.I(0); }
+    }
+    for (int a = 0; a < M; a++) {
+        cand_s[(int64_t)a * b_pad + b] = hp.S(a);
+        cand_i[(int64_t)a * b_pad + b] = hp.I(a);
+    }
+    tau[b] = rs;
+}
+
+// (a2) the rest of the catalogue, kSlices lanes per user: pure streaming -- an item whose score reaches tau[b] is
+//      appended to the lane's candidate rows (expected: (N+1)/prefix of the items, ~20 per lane); more than kSliceCap
+//      of them (a plateau of ties at tau) overflows and sends the user to the exact emulation.
+constexpr int kSliceCap = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void filter_kernel(const T *__restrict__ S_T, int n_items, int b_pad, int n_b, int M, int prefix,
+                                                     int items_per_slice, const T *__restrict__ tau, T *__restrict__ cand_s,
+                                                     int32_t *__restrict__ cand_i, int32_t *__restrict__ cand_n) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x, slice = blockIdx.y;
+    if (b >= n_b) return;
+    const T *col = S_T + b;
+    const T th = tau[b];
+    const int t0 = prefix + slice * items_per_slice;
+    int t1 = t0 + items_per_slice;
+    if (t1 > n_items) t1 = n_items;
+    const int64_t row0 = (int64_t)M + (int64_t)slice * kSliceCap;
+    int cnt = 0;
+    constexpr int kAhead = sizeof(T) == 4 ? 16 : 8;
+    int t = t0;
+    for (; t + kAhead <= t1; t += kAhead) {
+        T v[kAhead];
+#pragma unroll
+        for (int q = 0; q < kAhead; q++) v[q] = col[(int64_t)(t + q) * b_pad];
+#pragma unroll
+        for (int q = 0; q < kAhead; q++)
+            if (v[q] >= th) {
+                if (cnt < kSliceCap) { cand_s[(row0 + cnt) * b_pad + b] = v[q]; cand_i[(row0 + cnt) * b_pad + b] = t + q; }
+                cnt++;
+            }
+    }
+    for (; t < t1; t++) {
+        const T v = col[(int64_t)t * b_pad];
+        if (v >= th) {
+            if (cnt < kSliceCap) { cand_s[(row0 + cnt) * b_pad + b] = v; cand_i[(row0 + cnt) * b_pad + b] = t; }
+            cnt++;
+        }
+    }
+    cand_n[(int64_t)slice * b_pad + b] = cnt;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kHeapThreads) void merge_topk_kernel(const T *__restrict__ cand_s, const int32_t *__restrict__ cand_i,
+                                                                  const int32_t *__restrict__ cand_n, int b_pad, int n_b, int K,
+                                                                  int32_t *__restrict__ ids_out, T *__restrict__ scores_out,
+                                                                  int32_t *__restrict__ flags, int32_t *__restrict__ n_flagged,
+                                                                  int32_t *__restrict__ flagged_list) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int M = K + 1;
+    T *hs = reinterpret_cast<T *>(smem);
+    int32_t *hi = reinterpret_cast<int32_t *>(smem + (size_t)M * kHeapThreads * sizeof(T));
+    const int b = blockIdx.x * kHeapThreads + threadIdx.x;
+    if (b >= n_b) return;
+    Heap<T> hp{hs, hi, (int)threadIdx.x};
+    // the prefix heap IS a valid heap of M (score, id) tuples: continue it with the slices' candidates
+    for (int a = 0; a < M; a++) hp.set(a, cand_s[(int64_t)a * b_pad + b], cand_i[(int64_t)a * b_pad + b]);
+    T rs = hp.S(0);
+    int32_t ri = hp.I(0);
+    bool tie = false;
+    for (int sl = 0; sl < kSlices; sl++) {
+        int n = cand_n[(int64_t)sl * b_pad + b];
+        if (n > kSliceCap) { tie = true; n = kSliceCap; }          // overflow: a plateau at tau -> exact emulation
+        const int64_t row0 = (int64_t)M + (int64_t)sl * kSliceCap;
+        for (int c = 0; c < n; c++) {
+            const T v = cand_s[(row0 + c) * b_pad + b];
+            const int32_t id = cand_i[(row0 + c) * b_pad + b];
+            if (tuple_lt(rs, ri, v, id)) { hp.set(0, v, id); sift_up(hp, M, 0); rs = hp.S(0); ri = hp.I(0); }
+        }
+    }
+    for (int a = 1; a < M; a++) {                   // descending insertion sort (tuple order)
+        const T xs = hp.S(a); const int32_t xi = hp.I(a);
+        int c = a - 1;
+        while (c >= 0 && tuple_lt(hp.S(c), hp.I(c), xs, xi)) { hp.set(c + 1, hp.S(c), hp.I(c)); c--; }
+        hp.set(c + 1, xs, xi);
+    }
+    for (int a = 1; a < M; a++) tie |= hp.S(a) == hp.S(a - 1);
+    for (int a = 0; a < K; a++) {
+        ids_out[(int64_t)b * K + a] = hp.I(a);
+        scores_out[(int64_t)b * K + a] = hp.S(a);
+    }
+    flags[b] = tie ? 1 : 0;
+    if (tie) flagged_list[atomicAdd(n_flagged, 1)] = b;
+}
+
+// Exact sequential emulation for ONE user per wavefront (the users merge_topk_kernel flagged, when they are few).
+// Same algorithm as heap_topk_kernel, 64 items per step: every lane holds one score, a ballot finds the first lane
+// whose score beats the heap root, lane 0 performs heapq's replace in LDS, the root is re-read and the remaining
+// lanes of the step are tested again.  The user's scores are b_pad*sizeof(T) bytes apart (64 cache lines per step):
+// fine for a handful of users, 16x read amplification if used for all -- hence the `many` gate.
+template <typename T>
+__global__ __launch_bounds__(64) void exact_wave_kernel(const T *__restrict__ S_T, int n_items, int b_pad, int K,
+                                                        const int32_t *__restrict__ n_flagged, const int32_t *__restrict__ flagged_list,
+                                                        int many, int32_t *__restrict__ ids_out, T *__restrict__ scores_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nf = *n_flagged;
+    if (nf > many || (int)blockIdx.x >= nf) return;
+    const int b = flagged_list[blockIdx.x], lane = threadIdx.x;
+    T *hs = reinterpret_cast<T *>(smem);                                       // heap of this wavefront: [K] scores, [K] ids
+    int32_t *hi = reinterpret_cast<int32_t *>(smem + (size_t)K * sizeof(T));
+    struct WHeap {   // same interface as Heap<T>, one heap per block
+        T *s; int32_t *id;
+        __device__ T S(int k) const { return s[k]; }
+        __device__ int32_t I(int k) const { return id[k]; }
+        __device__ void set(int k, T sv, int32_t iv) { s[k] = sv; id[k] = iv; }
+    } hp{hs, hi};
+    const T *col = S_T + b;
+    const int k = K < n_items ? K : n_items;
+    for (int t = lane; t < k; t += 64) hp.set(t, col[(int64_t)t * b_pad], t);
+    __syncthreads();
+    if (lane == 0)
+        for (int t = k / 2 - 1; t >= 0; t--) sift_up(hp, k, t);
+    __syncthreads();
+    T root = hp.S(0);
+    for (int t0 = k; t0 < n_items; t0 += 64) {
+        const int t = t0 + lane;
+        const T v = t < n_items ? col[(int64_t)t * b_pad] : T(0);
+        bool live = t < n_items;
+        while (true) {
+            const unsigned long long mask = __ballot(live && v > root);
+            if (!mask) break;
+            const int first = __builtin_ctzll(mask);
+            const T fv = __shfl(v, first, kWave);
+            if (lane == 0) { hp.set(0, fv, t0 + first); sift_up(hp, k, 0); }
+            __syncthreads();
+            root = hp.S(0);
+            live = live && lane > first;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        for (int a = 1; a < k; a++) {               // list.sort(key=score, reverse=True): stable, descending
+            const T xs = hp.S(a); const int32_t xi = hp.I(a);
+            int c = a - 1;
+            while (c >= 0 && hp.S(c) < xs) { hp.set(c + 1, hp.S(c), hp.I(c)); c--; }
+            hp.set(c + 1, xs, xi);
+        }
+    }
+    __syncthreads();
+    for (int a = lane; a < K; a += 64) {
+        ids_out[(int64_t)b * K + a] = a < k ? hp.I(a) : -1;
+        scores_out[(int64_t)b * K + a] = a < k ? hp.S(a) : T(0);
+    }
+}
+
 template <typename T>
 int run_score_topk(const void *U, const void *V, int d, int ld, int n_items, const int32_t *user_ids,
                    int n_b, const int64_t *rated_indptr, const int32_t *rated_items, int K, void *scratch,
@@ -318,8 +525,50 @@ int run_score_topk(const void *U, const void *V, int d, int ld, int n_items, con
     const size_t lds = (size_t)K * kHeapThreads * (sizeof(T) + sizeof(int32_t));
     QREC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&heap_topk_kernel<T>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(heap_topk_kernel<T>, dim3((unsigned)((n_b + kHeapThreads - 1) / kHeapThreads)),
-                       dim3(kHeapThreads), lds, st, S_T, n_items, b_pad, n_b, K, ids_out, (T *)scores_out);
+    const unsigned user_blocks = (unsigned)((n_b + kHeapThreads - 1) / kHeapThreads);
+    const int M = K + 1;
+    constexpr int kPrefix = 2048;
+    if (n_items < 4 * kPrefix) {      // short catalogue: nothing to gain, the sequential emulation for everybody
+        hipLaunchKernelGGL(heap_topk_kernel<T>, dim3(user_blocks), dim3(kHeapThreads), lds, st, S_T, n_items, b_pad, n_b, K,
+                           ids_out, (T *)scores_out, nullptr, nullptr, 0);
+        QREC_LAUNCH_CHECK();
+        return QREC_OK;
+    }
+    const int per_slice = (n_items - kPrefix + kSlices - 1) / kSlices;
+    // scratch behind the score block: candidate rows [M + kSlices*kSliceCap][b_pad] (scores, ids), per-slice counts, tau,
+    // flags, flagged list, counter
+    unsigned char *extra = static_cast<unsigned char *>(scratch) + score_block_bytes(sizeof(T), n_items, n_b);
+    const size_t cand_rows = (size_t)kMaxM + (size_t)kSlices * kSliceCap;
+    T *cand_s = reinterpret_cast<T *>(extra);
+    T *tau = cand_s + cand_rows * b_pad;
+    int32_t *cand_i = reinterpret_cast<int32_t *>(tau + b_pad);
+    int32_t *cand_n = cand_i + cand_rows * b_pad;
+    int32_t *flags = cand_n + (size_t)kSlices * b_pad;
+    int32_t *flagged_list = flags + b_pad;
+    int32_t *n_flagged = flagged_list + b_pad;
+    QREC_HIP_CHECK(hipMemsetAsync(n_flagged, 0, sizeof(int32_t), st));
+    const size_t lds_m = (size_t)M * kHeapThreads * (sizeof(T) + sizeof(int32_t));
+    QREC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&prefix_topk_kernel<T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+    QREC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_topk_kernel<T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+    hipLaunchKernelGGL(prefix_topk_kernel<T>, dim3(user_blocks), dim3(kHeapThreads), lds_m, st, S_T, b_pad, n_b, M, kPrefix, cand_s,
+                       cand_i, tau);
+    QREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(filter_kernel<T>, dim3((unsigned)((n_b + 255) / 256), kSlices), dim3(256), 0, st, S_T, n_items, b_pad, n_b, M,
+                       kPrefix, per_slice, tau, cand_s, cand_i, cand_n);
+    QREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(merge_topk_kernel<T>, dim3(user_blocks), dim3(kHeapThreads), lds_m, st, cand_s, cand_i, cand_n, b_pad, n_b, K,
+                       ids_out, (T *)scores_out, flags, n_flagged, flagged_list);
+    QREC_LAUNCH_CHECK();
+    // users whose N+1 best scores are not pairwise distinct: exact emulation (device-side choice of the regime)
+    const int many = n_b / 16 > 256 ? n_b / 16 : 256;
+    const int wave_blocks = n_b < many ? n_b : many;
+    hipLaunchKernelGGL(exact_wave_kernel<T>, dim3((unsigned)wave_blocks), dim3(64), (size_t)K * (sizeof(T) + sizeof(int32_t)), st, S_T,
+                       n_items, b_pad, K, n_flagged, flagged_list, many, ids_out, (T *)scores_out);
+    QREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(heap_topk_kernel<T>, dim3(user_blocks), dim3(kHeapThreads), lds, st, S_T, n_items, b_pad, n_b, K, ids_out,
+                       (T *)scores_out, flags, n_flagged, many);
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }
@@ -362,8 +611,10 @@ int qrec_score_topk_scratch_bytes(int dtype, int32_t n_items, int32_t n_batch_us
     QREC_REQUIRE(bytes && n_items >= 0 && n_batch_users >= 0, "qrec_score_topk_scratch_bytes: bad arguments");
     QREC_REQUIRE(dtype == QREC_F32 || dtype == QREC_F64, "qrec_score_topk_scratch_bytes: bad dtype %d", dtype);
     const int64_t b_pad = ((int64_t)n_batch_users + 63) / 64 * 64;
-    const int64_t rows = ((int64_t)n_items + 31) / 32 * 32;
-    *bytes = rows * b_pad * (dtype == QREC_F64 ? 8 : 4);
+    const int64_t elem = dtype == QREC_F64 ? 8 : 4;
+    // the transposed score block, then the sliced top-N's candidates (scores + ids), flags, flagged list, counter
+    *bytes = (int64_t)score_block_bytes((size_t)elem, n_items, n_batch_users) +
+             ((int64_t)kMaxM + (int64_t)kSlices * kSliceCap) * b_pad * (elem + 4) + b_pad * elem + (kSlices + 2) * b_pad * 4 + 64;
     return QREC_OK;
 }
 

@@ -113,23 +113,22 @@ class DeviceRanker:
 def ranking_measure_strings(test_lens, per_n: dict, Ns) -> list:
     """The strings of Measure.rankingMeasure (util/measure.py:24-49) from per-user hit counts and DCG sums:
     ``per_n[n] = (hits, dcg)`` sequences in testSet_u order, ``test_lens[k] = len(testSet_u[user_k])``.  Same
-    operations in the same order as the reference (Python-float sequential sums), hence the same digits."""
+    operations in the same order as the reference: its ``sum()`` calls are left-to-right fp64 additions, which is what
+    ``np.cumsum(...)[-1]`` computes (a scan, not numpy's pairwise ``sum``), so the digits are the same."""
     out = []
-    lens = [int(x) for x in test_lens]
+    lens = np.asarray(test_lens, dtype=np.int64)
+    n_users = lens.size
     for n in Ns:
-        hits, dcg = per_n[n]
-        hits = [int(h) for h in hits]; dcg = [float(x) for x in dcg]
-        prec = sum(hits) / (len(hits) * n)
-        per_user = [h / l for h, l in zip(hits, lens)]
-        rec = sum(per_user) / len(per_user)
+        hits = np.asarray(per_n[n][0], dtype=np.int64); dcg = np.asarray(per_n[n][1], dtype=np.float64)
+        prec = int(hits.sum()) / (n_users * n)                                   # exact integer sum
+        rec = float(np.cumsum(hits / lens)[-1]) / n_users if n_users else 0.0
         f1 = 2 * prec * rec / (prec + rec) if (prec + rec) != 0 else 0
         prefix, acc = [0], 0
         for pos in range(n):
             acc += 1.0 / math.log(pos + 2)
             prefix.append(acc)
-        total = 0
-        for x, l in zip(dcg, lens):
-            total += x / prefix[min(l, n)]
+        idcg = np.asarray(prefix, dtype=np.float64)[np.minimum(lens, n)]
+        ndcg = float(np.cumsum(dcg / idcg)[-1]) / n_users if n_users else 0.0
         out += ["Top " + str(n) + "\n", "Precision:" + str(prec) + "\n", "Recall:" + str(rec) + "\n",
-                "F1:" + str(f1) + "\n", "NDCG:" + str(total / len(dcg)) + "\n"]
+                "F1:" + str(f1) + "\n", "NDCG:" + str(ndcg) + "\n"]
     return out

@@ -154,3 +154,34 @@ def test_fast_measures_equal_rankingMeasure_strings_incl_cold_users_and_unknown_
         quick = m.ranking_performance(0)
     assert got == want
     assert quick == [x.strip() for x in want[11:]]             # in-training variant: top-max(N) only
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n_tied_users", [0, 7, 96])
+@pytest.mark.parametrize("N", [1, 20, 100])
+def test_sliced_topk_and_its_exact_fallbacks(dtype, n_tied_users, N):
+    """The sliced top-N (kernels 3b) on a catalogue long enough to be sliced, with exactly known scores: user k's
+    embedding is the k-th unit vector, so score(i, k) = V[i][k].  Users with pairwise distinct scores take the fast
+    path; users whose best N+1 scores contain ties are redone by the exact emulation -- a few of them through the
+    wavefront-per-user kernel, all of them through the lane-per-user kernel -- and every list must equal the
+    reference's heap procedure, ids included."""
+    n_users, n_items = 96, 40_000
+    rng = np.random.default_rng(N * 131 + n_tied_users)
+    V = np.empty((n_items, n_users), dtype)
+    for k in range(n_users):
+        V[:, k] = rng.permutation(n_items) - n_items // 3                  # distinct, some negative
+    tied = rng.permutation(n_users)[:n_tied_users]
+    for k in tied:
+        V[:, k] = rng.integers(-5, 40, n_items)                             # heavy ties, also inside the top N
+    if n_tied_users:                                                        # one user whose ONLY tie is at the N / N+1 boundary
+        k = int(tied[0]); col = rng.permutation(n_items).astype(dtype); order = np.argsort(-col)
+        col[order[min(N, n_items - 1)]] = col[order[N - 1]]
+        V[:, k] = col
+    U = np.eye(n_users, dtype=dtype)
+    uu = rng.integers(0, n_users, 500); ii = rng.integers(0, n_items, 500)
+    rated = user_item_csr(uu, ii, np.ones(uu.size), n_users, n_items)
+    users = rng.permutation(n_users).astype(np.int32)
+    ids, sc = DeviceRanker(U, V, rated).topk(users, N)
+    oi, os_ = _oracle_topk(U, V, rated, users, N)
+    assert np.array_equal(ids, oi)
+    assert np.array_equal(sc.astype(np.float64), os_)

@@ -22,7 +22,10 @@ with redirect_stdout(io.StringIO()):
     m = BPR(conf, train, test); m.readConfiguration(); m.initModel()
     m.P = m.P.astype(np.float32); m.Q = m.Q.astype(np.float32)          # TF-path models rank fp32 tables
     m.rank_measure_all_test_users([20], 20)                              # warm-up: ranker, test CSR
-    t0 = time.perf_counter(); fast = m.rank_measure_all_test_users([20], 20); out["device_hits_s"] = time.perf_counter() - t0
+    m.rank_measure_all_test_users([20], 20)
+    t0 = time.perf_counter()
+    for _ in range(5): fast = m.rank_measure_all_test_users([20], 20)
+    out["device_hits_s"] = (time.perf_counter() - t0) / 5                # steady state (per-epoch evaluation)
     t0 = time.perf_counter(); rec = m.rank_all_test_users(20); t1 = time.perf_counter()
     slow = Measure.rankingMeasure(m.data.testSet_u, rec, [20]); t2 = time.perf_counter()
 out["host_lists_s"], out["host_measure_s"] = t1 - t0, t2 - t1
