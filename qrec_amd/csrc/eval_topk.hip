@@ -298,76 +298,92 @@ __global__ __launch_bounds__(kHeapThreads) void heap_topk_kernel(const T *__rest
 // bound by the bytes one lane can keep in flight (0.95 TB/s).  The reference's heap result is history-dependent only
 // through TIES: if a user's N+1 largest scores are pairwise distinct, find_k_largest returns exactly the N
 // largest in descending order (every one of them enters the heap and stays; the stable sort has nothing to break).
-// So: (a) prefix_topk_kernel + filter_kernel -- the exact top-(N+1) heap of the first 2,048 items gives every user a
-// threshold tau that his final N+1 best all reach; kSlices lanes per user then stream the rest of the catalogue and
-// keep only the scores >= tau (a per-slice heap was tried first: with 64 users per wavefront some lane updates its
-// heap in almost every step of the warm-up, 6x the heap work of the single scan, 3.1 ms); (b) merge_topk_kernel -- one
-// lane per user continues the prefix heap with the ~400 survivors into the global top-(N+1) (as a multiset of values
+// So: (a) group_max_kernel + threshold_kernel + filter_kernel -- two streaming passes: the (N+1)-th largest of 64
+// per-range maxima is a threshold tau that the user's N+1 best all reach, and the second pass keeps the scores >= tau
+// (tried before: a per-slice heap -- with 64 users per wavefront some lane updates its heap in almost every step of
+// the warm-up, 6x the heap work of the single scan, 3.1 ms -- and the exact heap of a 2,048-item prefix as threshold,
+// 1.5 ms of lane-per-user latency plus 400 survivors to merge); (b) merge_topk_kernel -- one
+// lane per user builds the global top-(N+1) from the few dozen survivors (as a multiset of values
 // it is exact whatever the ties), writes the N best, and FLAGS the user if two of the N+1 values are equal or a slice
 // overflowed; (c) flagged users are redone with the exact
 // sequential emulation: few of them -> one wavefront each (exact_wave_kernel: 64 items per step, ballot for the
 // first item above the heap root, lane 0 runs heapq's sift), many -> the lane-per-user kernel above.
 constexpr int kSlices = 16;
-constexpr int kMaxM = 101;        // N <= 100 (base/recommender.py:132-134) -> N+1 candidates per slice
 __host__ inline size_t score_block_bytes(size_t elem, int n_items, int n_b) {
     const size_t b_pad = ((size_t)n_b + 63) / 64 * 64, rows = ((size_t)n_items + 31) / 32 * 32;
     return rows * b_pad * elem;
 }
 
-// (a1) exact top-M heap of the first `prefix` items, lane per user: its root tau[b] (the M-th largest of the prefix) is
-//      a lower bound of the user's global M-th largest score; the heap's content goes to candidate rows [0, M).
+// (a1) per-user maxima over kGroups disjoint item ranges (pure streaming, kGroups lanes per user), then tau[b] = the
+//      M-th largest of them: M DIFFERENT items reach tau, so the user's M best scores all do -- a valid threshold, and a
+//      tight one (about 1.5 M items of 38 k survive it).
+constexpr int kGroups = 64;
 template <typename T>
-__global__ __launch_bounds__(kHeapThreads) void prefix_topk_kernel(const T *__restrict__ S_T, int b_pad, int n_b, int M, int prefix,
-                                                                   T *__restrict__ cand_s, int32_t *__restrict__ cand_i,
-                                                                   T *__restrict__ tau) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T *hs = reinterpret_cast<T *>(smem);
-    int32_t *hi = reinterpret_cast<int32_t *>(smem + (size_t)M * kHeapThreads * sizeof(T));
-    const int b = blockIdx.x * kHeapThreads + threadIdx.x;
+__global__ __launch_bounds__(256) void group_max_kernel(const T *__restrict__ S_T, int n_items, int b_pad, int n_b,
+                                                        int items_per_group, T *__restrict__ gmax) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x, grp = blockIdx.y;
     if (b >= n_b) return;
-    Heap<T> hp{hs, hi, (int)threadIdx.x};
     const T *col = S_T + b;
-    for (int a = 0; a < M; a++) hp.set(a, col[(int64_t)a * b_pad], a);
-    for (int a = M / 2 - 1; a >= 0; a--) sift_up(hp, M, a);
-    T rs = hp.S(0);
-    int32_t ri = hp.I(0);
+    const int t0 = grp * items_per_group;
+    int t1 = t0 + items_per_group;
+    if (t1 > n_items) t1 = n_items;
+    T best = col[(int64_t)t0 * b_pad];             // every group is non-empty (host guarantees)
     constexpr int kAhead = sizeof(T) == 4 ? 16 : 8;
-    int t = M;
-    for (; t + kAhead <= prefix; t += kAhead) {
+    int t = t0 + 1;
+    for (; t + kAhead <= t1; t += kAhead) {
         T v[kAhead];
 #pragma unroll
         for (int q = 0; q < kAhead; q++) v[q] = col[(int64_t)(t + q) * b_pad];
 #pragma unroll
-        for (int q = 0; q < kAhead; q++)
-            if (tuple_lt(rs, ri, v[q], t + q)) { hp.set(0, v[q], t + q); sift_up(hp, M, 0); rs = hp.S(0); ri = hp.I(0); }
+        for (int q = 0; q < kAhead; q++) best = v[q] > best ? v[q] : best;
     }
-    for (; t < prefix; t++) {
-        const T v = col[(int64_t)t * b_pad];
-        if (tuple_lt(rs, ri, v, t)) { hp.set(0, v, t); sift_up(hp, M, 0); rs = hp.S(0); ri = hp.I(0); }
+    for (; t < t1; t++) { const T v = col[(int64_t)t * b_pad]; best = v > best ? v : best; }
+    gmax[(int64_t)grp * b_pad + b] = best;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void fill_neg_inf_kernel(T *__restrict__ rows, int b_pad, int n_b) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n_b) rows[(int64_t)blockIdx.y * b_pad + b] = -__builtin_huge_val();
+}
+template <typename T>
+__global__ __launch_bounds__(256) void threshold_kernel(const T *__restrict__ gmax, int b_pad, int n_b, int M, T *__restrict__ tau) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_b) return;
+    T v[kGroups];
+#pragma unroll
+    for (int g = 0; g < kGroups; g++) v[g] = gmax[(int64_t)g * b_pad + b];
+    // M-th largest of kGroups values: M rounds of "take the maximum out"
+    T th = T(0);
+    for (int r = 0; r < M; r++) {
+        int arg = 0;
+        T best = v[0];
+#pragma unroll
+        for (int g = 1; g < kGroups; g++)
+            if (v[g] > best) { best = v[g]; arg = g; }
+        th = best;
+#pragma unroll
+        for (int g = 0; g < kGroups; g++)
+            if (g == arg) v[g] = -__builtin_huge_val();
     }
-    for (int a = 0; a < M; a++) {
-        cand_s[(int64_t)a * b_pad + b] = hp.S(a);
-        cand_i[(int64_t)a * b_pad + b] = hp.I(a);
-    }
-    tau[b] = rs;
+    tau[b] = th;
 }
 
-// (a2) the rest of the catalogue, kSlices lanes per user: pure streaming -- an item whose score reaches tau[b] is
-//      appended to the lane's candidate rows (expected: (N+1)/prefix of the items, ~20 per lane); more than kSliceCap
-//      of them (a plateau of ties at tau) overflows and sends the user to the exact emulation.
-constexpr int kSliceCap = 64;
+// (a2) kSlices lanes per user stream the catalogue again: an item whose score reaches tau[b] is appended to the lane's
+//      candidate rows (a handful per lane); more than kSliceCap of them (a plateau of ties at tau) overflows and sends
+//      the user to the exact emulation.
+constexpr int kSliceCap = 32;
 template <typename T>
-__global__ __launch_bounds__(256) void filter_kernel(const T *__restrict__ S_T, int n_items, int b_pad, int n_b, int M, int prefix,
+__global__ __launch_bounds__(256) void filter_kernel(const T *__restrict__ S_T, int n_items, int b_pad, int n_b,
                                                      int items_per_slice, const T *__restrict__ tau, T *__restrict__ cand_s,
                                                      int32_t *__restrict__ cand_i, int32_t *__restrict__ cand_n) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x, slice = blockIdx.y;
     if (b >= n_b) return;
     const T *col = S_T + b;
     const T th = tau[b];
-    const int t0 = prefix + slice * items_per_slice;
+    const int t0 = slice * items_per_slice;
     int t1 = t0 + items_per_slice;
     if (t1 > n_items) t1 = n_items;
-    const int64_t row0 = (int64_t)M + (int64_t)slice * kSliceCap;
+    const int64_t row0 = (int64_t)slice * kSliceCap;
     int cnt = 0;
     constexpr int kAhead = sizeof(T) == 4 ? 16 : 8;
     int t = t0;
@@ -405,20 +421,32 @@ __global__ __launch_bounds__(kHeapThreads) void merge_topk_kernel(const T *__res
     const int b = blockIdx.x * kHeapThreads + threadIdx.x;
     if (b >= n_b) return;
     Heap<T> hp{hs, hi, (int)threadIdx.x};
-    // the prefix heap IS a valid heap of M (score, id) tuples: continue it with the slices' candidates
-    for (int a = 0; a < M; a++) hp.set(a, cand_s[(int64_t)a * b_pad + b], cand_i[(int64_t)a * b_pad + b]);
-    T rs = hp.S(0);
-    int32_t ri = hp.I(0);
+    // at least M items reach tau, so (unless a slice overflowed) the survivors fill the heap
+    int m = 0;
+    T rs = T(0);
+    int32_t ri = 0;
     bool tie = false;
     for (int sl = 0; sl < kSlices; sl++) {
         int n = cand_n[(int64_t)sl * b_pad + b];
         if (n > kSliceCap) { tie = true; n = kSliceCap; }          // overflow: a plateau at tau -> exact emulation
-        const int64_t row0 = (int64_t)M + (int64_t)sl * kSliceCap;
+        const int64_t row0 = (int64_t)sl * kSliceCap;
         for (int c = 0; c < n; c++) {
             const T v = cand_s[(row0 + c) * b_pad + b];
             const int32_t id = cand_i[(row0 + c) * b_pad + b];
-            if (tuple_lt(rs, ri, v, id)) { hp.set(0, v, id); sift_up(hp, M, 0); rs = hp.S(0); ri = hp.I(0); }
+            if (m < M) {
+                hp.set(m, v, id);
+                if (++m == M) {
+                    for (int a = M / 2 - 1; a >= 0; a--) sift_up(hp, M, a);
+                    rs = hp.S(0); ri = hp.I(0);
+                }
+            } else if (tuple_lt(rs, ri, v, id)) {
+                hp.set(0, v, id); sift_up(hp, M, 0); rs = hp.S(0); ri = hp.I(0);
+            }
         }
+    }
+    if (m < M) {                                    // only possible after an overflow: pad, the user is flagged anyway
+        tie = true;
+        for (; m < M; m++) hp.set(m, -__builtin_huge_val(), -1);
     }
     for (int a = 1; a < M; a++) {                   // descending insertion sort (tuple order)
         const T xs = hp.S(a); const int32_t xi = hp.I(a);
@@ -527,36 +555,42 @@ int run_score_topk(const void *U, const void *V, int d, int ld, int n_items, con
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned user_blocks = (unsigned)((n_b + kHeapThreads - 1) / kHeapThreads);
     const int M = K + 1;
-    constexpr int kPrefix = 2048;
-    if (n_items < 4 * kPrefix) {      // short catalogue: nothing to gain, the sequential emulation for everybody
+    if (n_items < 8192 || M > kGroups) {   // short catalogue, or more candidates wanted than there are group maxima:
+                                           // the sequential emulation for everybody
         hipLaunchKernelGGL(heap_topk_kernel<T>, dim3(user_blocks), dim3(kHeapThreads), lds, st, S_T, n_items, b_pad, n_b, K,
                            ids_out, (T *)scores_out, nullptr, nullptr, 0);
         QREC_LAUNCH_CHECK();
         return QREC_OK;
     }
-    const int per_slice = (n_items - kPrefix + kSlices - 1) / kSlices;
-    // scratch behind the score block: candidate rows [M + kSlices*kSliceCap][b_pad] (scores, ids), per-slice counts, tau,
-    // flags, flagged list, counter
+    const int per_group = (n_items + kGroups - 1) / kGroups, n_groups_used = (n_items + per_group - 1) / per_group;
+    const int per_slice = (n_items + kSlices - 1) / kSlices;
+    // scratch behind the score block: group maxima [kGroups][b_pad], tau, candidate rows [kSlices*kSliceCap][b_pad] (scores,
+    // ids), per-slice counts, flags, flagged list, counter
     unsigned char *extra = static_cast<unsigned char *>(scratch) + score_block_bytes(sizeof(T), n_items, n_b);
-    const size_t cand_rows = (size_t)kMaxM + (size_t)kSlices * kSliceCap;
-    T *cand_s = reinterpret_cast<T *>(extra);
-    T *tau = cand_s + cand_rows * b_pad;
-    int32_t *cand_i = reinterpret_cast<int32_t *>(tau + b_pad);
+    const size_t cand_rows = (size_t)kSlices * kSliceCap;
+    T *gmax = reinterpret_cast<T *>(extra);
+    T *tau = gmax + (size_t)kGroups * b_pad;
+    T *cand_s = tau + b_pad;
+    int32_t *cand_i = reinterpret_cast<int32_t *>(cand_s + cand_rows * b_pad);
     int32_t *cand_n = cand_i + cand_rows * b_pad;
     int32_t *flags = cand_n + (size_t)kSlices * b_pad;
     int32_t *flagged_list = flags + b_pad;
     int32_t *n_flagged = flagged_list + b_pad;
     QREC_HIP_CHECK(hipMemsetAsync(n_flagged, 0, sizeof(int32_t), st));
     const size_t lds_m = (size_t)M * kHeapThreads * (sizeof(T) + sizeof(int32_t));
-    QREC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&prefix_topk_kernel<T>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
     QREC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_topk_kernel<T>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-    hipLaunchKernelGGL(prefix_topk_kernel<T>, dim3(user_blocks), dim3(kHeapThreads), lds_m, st, S_T, b_pad, n_b, M, kPrefix, cand_s,
-                       cand_i, tau);
+    const unsigned lane_blocks = (unsigned)((n_b + 255) / 256);
+    if (n_groups_used < kGroups)      // ranges past the end (n_items not a multiple): -inf maxima
+        hipLaunchKernelGGL(fill_neg_inf_kernel<T>, dim3(lane_blocks, kGroups - n_groups_used), dim3(256), 0, st,
+                           gmax + (size_t)n_groups_used * b_pad, b_pad, n_b);
+    hipLaunchKernelGGL(group_max_kernel<T>, dim3(lane_blocks, (unsigned)n_groups_used), dim3(256), 0, st, S_T, n_items, b_pad, n_b,
+                       per_group, gmax);
     QREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(filter_kernel<T>, dim3((unsigned)((n_b + 255) / 256), kSlices), dim3(256), 0, st, S_T, n_items, b_pad, n_b, M,
-                       kPrefix, per_slice, tau, cand_s, cand_i, cand_n);
+    hipLaunchKernelGGL(threshold_kernel<T>, dim3(lane_blocks), dim3(256), 0, st, gmax, b_pad, n_b, M, tau);
+    QREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(filter_kernel<T>, dim3(lane_blocks, kSlices), dim3(256), 0, st, S_T, n_items, b_pad, n_b, per_slice, tau,
+                       cand_s, cand_i, cand_n);
     QREC_LAUNCH_CHECK();
     hipLaunchKernelGGL(merge_topk_kernel<T>, dim3(user_blocks), dim3(kHeapThreads), lds_m, st, cand_s, cand_i, cand_n, b_pad, n_b, K,
                        ids_out, (T *)scores_out, flags, n_flagged, flagged_list);
@@ -613,8 +647,8 @@ int qrec_score_topk_scratch_bytes(int dtype, int32_t n_items, int32_t n_batch_us
     const int64_t b_pad = ((int64_t)n_batch_users + 63) / 64 * 64;
     const int64_t elem = dtype == QREC_F64 ? 8 : 4;
     // the transposed score block, then the sliced top-N's candidates (scores + ids), flags, flagged list, counter
-    *bytes = (int64_t)score_block_bytes((size_t)elem, n_items, n_batch_users) +
-             ((int64_t)kMaxM + (int64_t)kSlices * kSliceCap) * b_pad * (elem + 4) + b_pad * elem + (kSlices + 2) * b_pad * 4 + 64;
+    *bytes = (int64_t)score_block_bytes((size_t)elem, n_items, n_batch_users) + (int64_t)(kGroups + 1) * b_pad * elem +
+             (int64_t)kSlices * kSliceCap * b_pad * (elem + 4) + (kSlices + 2) * b_pad * 4 + 64;
     return QREC_OK;
 }
 
