@@ -56,7 +56,14 @@ class SGL(GraphRecommender):
             for _ in range(self.n_layers):
                 s1.append(self._create_adj_mat(True, self.aug_type)); s2.append(self._create_adj_mat(True, self.aug_type))
             subs = (s1, s2)
-        return subs, self.sample_epoch_pairwise()
+        u, i, j = self.sample_epoch_pairwise()
+        # tf.unique of every batch (merged user + item rows, SGL.py calc_ssl_loss_v3), also on the sampler thread
+        nu = self.num_users
+        starts = list(range(0, u.size, self.batch_size))
+        rows = [np.concatenate([unique_first_appearance(u[s:s + self.batch_size]),
+                                unique_first_appearance(i[s:s + self.batch_size]) + nu]).astype(np.int32) for s in starts]
+        off = np.concatenate([[0], np.cumsum([r.size for r in rows])])
+        return subs, (u, i, j, starts, np.concatenate(rows), off)
 
     def saveModel(self):
         self.bestU, self.bestV = self.U, self.V
@@ -64,17 +71,13 @@ class SGL(GraphRecommender):
     def trainModel(self):
         quiet = os.environ.get("QREC_QUIET") == "1"
         tr, nu = self.trainer, self.num_users
-        for epoch, (subs, (u, i, j)) in enumerate(self.iter_epoch_samples(self.maxEpoch, self._draw_epoch)):
+        for epoch, (subs, (u, i, j, starts, rows, off)) in enumerate(self.iter_epoch_samples(self.maxEpoch, self._draw_epoch)):
             tr.set_subgraphs(*subs)
             d_u, d_i, d_j = DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i), DeviceBuffer.from_numpy(j)
-            starts = list(range(0, u.size, self.batch_size))
-            rows = [np.concatenate([unique_first_appearance(u[s:s + self.batch_size]),
-                                    unique_first_appearance(i[s:s + self.batch_size]) + nu]).astype(np.int32) for s in starts]
-            off = np.concatenate([[0], np.cumsum([r.size for r in rows])])
-            d_rows = DeviceBuffer.from_numpy(np.concatenate(rows))
+            d_rows = DeviceBuffer.from_numpy(rows)
             for n, s in enumerate(starts):
                 B = min(self.batch_size, u.size - s)
-                tr.train_step_async(d_u.ptr + 4 * s, d_i.ptr + 4 * s, d_j.ptr + 4 * s, B, d_rows.ptr + 4 * int(off[n]), rows[n].size)
+                tr.train_step_async(d_u.ptr + 4 * s, d_i.ptr + 4 * s, d_j.ptr + 4 * s, B, d_rows.ptr + 4 * int(off[n]), int(off[n + 1] - off[n]))
                 if not quiet:
                     _, rec_l, ssl_l = tr.losses()
                     print("training:", epoch + 1, "batch", n, "rec_loss:", rec_l, "ssl_loss", ssl_l)

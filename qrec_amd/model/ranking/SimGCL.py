@@ -43,21 +43,30 @@ class SimGCL(GraphRecommender):
     def saveModel(self):
         self.bestU, self.bestV = self.U, self.V
 
+    def _draw_epoch(self):
+        """One epoch of host-side work, done on the sampler thread one epoch ahead of the device: the reference's batch
+        stream (shuffle + negatives, base/deepRecommender.py:29-52) and tf.unique of every batch's users and positive
+        items (SimGCL.py:61-64) -- 1,210 np.unique calls per epoch at the Yelp shape, ~0.1 s that used to sit between
+        two epochs with the GPU idle."""
+        u, i, j = self.sample_epoch_pairwise()
+        nu = self.num_users
+        starts = list(range(0, u.size, self.batch_size))
+        uu = [unique_first_appearance(u[s:s + self.batch_size]) for s in starts]
+        vv = [unique_first_appearance(i[s:s + self.batch_size]) + nu for s in starts]
+        off_u = np.concatenate([[0], np.cumsum([x.size for x in uu])]); off_v = np.concatenate([[0], np.cumsum([x.size for x in vv])])
+        return (u, i, j, starts, np.concatenate(uu).astype(np.int32), off_u, np.concatenate(vv).astype(np.int32), off_v)
+
     def trainModel(self):
         quiet = os.environ.get("QREC_QUIET") == "1"
-        tr, nu = self.trainer, self.num_users
-        for epoch, (u, i, j) in enumerate(self.iter_epoch_samples(self.maxEpoch)):
+        tr = self.trainer
+        for epoch, (u, i, j, starts, uu, off_u, vv, off_v) in enumerate(self.iter_epoch_samples(self.maxEpoch, self._draw_epoch)):
             d_u, d_i, d_j = DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i), DeviceBuffer.from_numpy(j)
-            # tf.unique per batch, for the whole epoch in one upload
-            starts = list(range(0, u.size, self.batch_size))
-            uu = [unique_first_appearance(u[s:s + self.batch_size]) for s in starts]
-            vv = [unique_first_appearance(i[s:s + self.batch_size]) + nu for s in starts]
-            off_u = np.concatenate([[0], np.cumsum([x.size for x in uu])]); off_v = np.concatenate([[0], np.cumsum([x.size for x in vv])])
-            d_uu = DeviceBuffer.from_numpy(np.concatenate(uu).astype(np.int32)); d_vv = DeviceBuffer.from_numpy(np.concatenate(vv).astype(np.int32))
+            d_uu, d_vv = DeviceBuffer.from_numpy(uu), DeviceBuffer.from_numpy(vv)
             for n, s in enumerate(starts):
                 B = min(self.batch_size, u.size - s)
                 tr.train_step_async(d_u.ptr + 4 * s, d_i.ptr + 4 * s, d_j.ptr + 4 * s, B,
-                                    d_uu.ptr + 4 * int(off_u[n]), uu[n].size, d_vv.ptr + 4 * int(off_v[n]), vv[n].size)
+                                    d_uu.ptr + 4 * int(off_u[n]), int(off_u[n + 1] - off_u[n]),
+                                    d_vv.ptr + 4 * int(off_v[n]), int(off_v[n + 1] - off_v[n]))
                 if not quiet:
                     l, rec_l, cl_l = tr.losses()
                     print("training:", epoch + 1, "batch", n, "total_loss:", l, "rec_loss:", rec_l, "cl_loss", cl_l)
