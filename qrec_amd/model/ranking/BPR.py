@@ -11,8 +11,10 @@ Two execution modes, chosen by the optional conf key ``qrec.mode`` or env ``QREC
 ``throughput``
     Device Philox sampler + Hogwild kernel (fp32, exact per-sample deltas applied with
     atomic adds).  Same algorithm and sampling distribution, not the same random stream;
-    judged on Recall@N.  ``QREC_SCHEDULE=item`` (default; triplets visited item-major, faster)
-    or ``user`` (the reference's user-major visiting order).
+    judged on Recall@N.  ``QREC_SCHEDULE=auto`` (default), ``item`` (triplets visited item-major) or ``user`` (the
+    reference's user-major visiting order): item-major wins when a few items collect most interactions (their rows
+    would take the per-triplet atomics), user-major when popularity is flat (measured: 2.1 vs 1.6 G/s at the
+    Zipf-0.6 Yelp2018 shape, 1.16 vs 1.21 G/s on a uniform 1 M-item catalogue); ``auto`` looks at max/mean item degree.
 """
 from __future__ import annotations
 
@@ -40,7 +42,10 @@ class BPR(IterativeRecommender):
         dt = os.environ.get("QREC_DTYPE", "f64" if mode == "exact" else "f32")
         self.table_dtype = np.float64 if (dt == "f64" and mode == "exact") else np.float32
         self.sampler_seed = int(os.environ.get("QREC_SEED", "0"))
-        self.schedule = os.environ.get("QREC_SCHEDULE", "item") if mode == "throughput" else "user"
+        self.schedule = os.environ.get("QREC_SCHEDULE", "auto") if mode == "throughput" else "user"
+        if self.schedule not in ("auto", "item", "user"):
+            print("QREC_SCHEDULE must be auto, item or user")
+            raise SystemExit(-1)
 
     def initModel(self):
         super().initModel()
@@ -51,7 +56,11 @@ class BPR(IterativeRecommender):
         u, i = pos.row_ids(), pos.indices
         print("training...")
         tables = DeviceTables(self.P, self.Q, self.table_dtype)
-        sgd = BprSgd(tables, u, i, pos, schedule=self.schedule)
+        schedule = self.schedule
+        if schedule == "auto":
+            deg = np.bincount(i, minlength=len(self.data.item))
+            schedule = "item" if deg.size and deg.max() > 20 * max(deg.mean(), 1e-9) else "user"
+        sgd = BprSgd(tables, u, i, pos, schedule=schedule)
         n_items = len(self.data.item)
         epoch = 0
         if self.mode == "throughput" and self.ranking.isMainOn():
