@@ -117,14 +117,16 @@ int qrec_bpr_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
  * per-sample delta, so no update is lost; concurrent chunks read rows that may lag by
  * the in-flight updates (Hogwild).  grid_groups = number of groups in flight (0 = library
  * default: one 256-thread block per CU); with grid_groups==1 the kernel degenerates to the
- * sequential recurrence.  *d_loss (double) is ACCUMULATED into (zero it first).
+ * sequential recurrence.  *d_loss (double) is ACCUMULATED into (zero it first).  n_users / n_items = rows of
+ * d_P / d_Q: tables below 4 GiB are addressed through a buffer descriptor of exactly that size (a row id past the
+ * end is dropped by the hardware bounds check), larger ones through 64-bit addresses (2-5% slower).
  * `variant` selects the memory policy (QREC_HW_*), 0 = library default.                  */
 #define QREC_HW_DEFAULT 0
 #define QREC_HW_PLAIN_RMW 1     /* plain loads, plain stores (racy read-modify-write)     */
 #define QREC_HW_SC1_RMW 2       /* sc1 loads, sc1 write-through stores                    */
 #define QREC_HW_ATOMIC 3        /* plain loads, f32 atomic-add deltas                     */
 #define QREC_HW_SC1_ATOMIC 4    /* sc1 loads, f32 atomic-add deltas                       */
-int qrec_bpr_sgd_hogwild(float *d_P, float *d_Q, int32_t d, int32_t ld, const int32_t *d_u,
+int qrec_bpr_sgd_hogwild(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld, const int32_t *d_u,
                          const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
                          int32_t grid_groups, float lr, float regU, float regI, double *d_loss,
                          int variant, const double *d_driver_state, void *stream);
@@ -136,8 +138,8 @@ int qrec_bpr_sgd_hogwild(float *d_P, float *d_Q, int32_t d, int32_t ld, const in
  * negatives, which the L2 atomic units retire ~25% faster.  Chunks are visited in a golden-ratio
  * stride order so that the chunks of one hot item are spread over the epoch.  With grid_groups == 1
  * and chunk order aside, each row still sees exactly the reference recurrence.              */
-int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int32_t d, int32_t ld, const int32_t *d_u,
-                                    const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
+int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld,
+                                    const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
                                     int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
                                     double *d_loss, const double *d_driver_state, void *stream);
 

@@ -48,8 +48,8 @@ _SIGNATURES = {
     "qrec_mt_pairwise_sample_epoch": [_vp, _vp, _i64, _vp, _vp, _i32, _vp],
     "qrec_philox_bpr_sample": [_vp, _vp, _vp, _i64, _i32, _u64, _u64, _vp, _vp],
     "qrec_bpr_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _vp, _vp],
-    "qrec_bpr_sgd_hogwild": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _vp, C.c_int, _vp, _vp],
-    "qrec_bpr_sgd_hogwild_item_major": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp],
+    "qrec_bpr_sgd_hogwild": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _vp, C.c_int, _vp, _vp],
+    "qrec_bpr_sgd_hogwild_item_major": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp],
     "qrec_epoch_close": [_vp, _i64, _vp, _i64, C.c_int, _i32, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
     "qrec_epoch_sums": [_vp, _i64, _vp, _i64, C.c_int, _i32, _vp, _vp, _vp],
     "qrec_epoch_decide": [_vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
@@ -277,6 +277,17 @@ class DeviceBuffer:
         _check(load().qrec_memcpy_d2h(_hp(out), self.ptr, out.nbytes, _sh(stream)))
         return out
 
+    def read_rows(self, row0: int, n_rows: int, stream=None) -> np.ndarray:
+        """rows [row0, row0 + n_rows) of a 2-D buffer, without reading the rest back"""
+        width = self.shape[1]
+        out = np.empty((n_rows, width), dtype=self.dtype)
+        _check(load().qrec_memcpy_d2h(_hp(out), self.ptr + row0 * width * self.dtype.itemsize, out.nbytes, _sh(stream)))
+        return out
+
+    def write_rows(self, row0: int, a: np.ndarray, stream=None):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        _check(load().qrec_memcpy_h2d(self.ptr + row0 * self.shape[1] * self.dtype.itemsize, _hp(a), a.nbytes, _sh(stream)))
+
     def upload_head(self, a: np.ndarray, stream=None):
         a = np.ascontiguousarray(a, dtype=self.dtype)
         if a.nbytes > self.nbytes:
@@ -399,10 +410,15 @@ def bpr_sgd_ordered(d_P, d_Q, dtype: int, d: int, ld: int, d_u, d_i, d_j, n: int
                                        n, lr, regU, regI, _dp(d_loss), _sh(stream)))
 
 
+def _table_rows(buf, ld: int) -> int:
+    """rows of a [rows][ld] fp32 table held in a DeviceBuffer"""
+    return int(buf.nbytes // (4 * ld))
+
+
 def bpr_sgd_hogwild(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int, chunk: int, grid_groups: int,
                     lr: float, regU: float, regI: float, d_loss, variant: int = HW_DEFAULT, stream=None,
                     d_driver_state=None):
-    _check(load().qrec_bpr_sgd_hogwild(_dp(d_P), _dp(d_Q), d, ld, _dp(d_u), _dp(d_i), _dp(d_j), n,
+    _check(load().qrec_bpr_sgd_hogwild(_dp(d_P), _dp(d_Q), _table_rows(d_P, ld), _table_rows(d_Q, ld), d, ld, _dp(d_u), _dp(d_i), _dp(d_j), n,
                                        chunk, grid_groups, lr, regU, regI, _dp(d_loss), variant,
                                        _dp(d_driver_state), _sh(stream)))
 
@@ -549,7 +565,7 @@ def copy_cols(d_dst, dst_ld: int, d_src, src_ld: int, src_col_off: int, n_rows: 
 def bpr_sgd_hogwild_item_major(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int, chunk: int, grid_groups: int,
                                flush_every: int, lr: float, regU: float, regI: float, d_loss, stream=None,
                                d_driver_state=None):
-    _check(load().qrec_bpr_sgd_hogwild_item_major(_dp(d_P), _dp(d_Q), d, ld, _dp(d_u), _dp(d_i), _dp(d_j), n, chunk,
+    _check(load().qrec_bpr_sgd_hogwild_item_major(_dp(d_P), _dp(d_Q), _table_rows(d_P, ld), _table_rows(d_Q, ld), d, ld, _dp(d_u), _dp(d_i), _dp(d_j), n, chunk,
                                                   grid_groups, flush_every, lr, regU, regI, _dp(d_loss),
                                                   _dp(d_driver_state), _sh(stream)))
 

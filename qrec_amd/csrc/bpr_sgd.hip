@@ -191,36 +191,70 @@ __global__ __launch_bounds__(64) void mf_ordered_kernel(
 // request covers a contiguous 64-B segment, 4x less when the same dwords are strided by
 // 16 B (the float4-per-lane layout) -- atomic cost is per request, not per byte.
 constexpr int kMaxChunk = 64;
+constexpr int64_t kBufLimit = (int64_t)1 << 32;   // a buffer descriptor addresses 32-bit byte offsets
 
 enum : int { LD_PLAIN = 0, LD_SC1 = 1 };
 enum : int { UP_STORE = 0, UP_STORE_SC1 = 1, UP_ATOMIC = 2 };
 
 template <int E> struct Row { float v[E]; };
 
+// Row access of the throughput kernels, two flavours chosen by table size:
+//   TabBuf  a buffer descriptor sized to the table (32-bit byte offsets, so < 4 GiB): out-of-range row ids are
+//           dropped by the hardware bounds check instead of corrupting memory, and address arithmetic is one VALU op;
+//   TabPtr  64-bit global addressing for tables of 4 GiB and more (measured 2-5% slower: tools/bench_configs.py).
+struct TabBuf {
+    __amdgpu_buffer_rsrc_t rs;
+    static __device__ inline TabBuf make(float *p, int64_t bytes) { return TabBuf{make_rsrc(p, (uint32_t)bytes)}; }
+};
+struct TabPtr {
+    float *base;
+    static __device__ inline TabPtr make(float *p, int64_t) { return TabPtr{p}; }
+};
+
 template <int LPR, int E, int LOADP>
-__device__ inline Row<E> hw_load_row(__amdgpu_buffer_rsrc_t rs, int row, int r) {
+__device__ inline Row<E> hw_load_row(TabBuf t, int row, int r) {
     constexpr int aux = (LOADP == LD_SC1) ? kAuxSc1 : kAuxPlain;
     const uint32_t off = ((uint32_t)row * (uint32_t)(LPR * E) + (uint32_t)r) * 4u;
     Row<E> out;
 #pragma unroll
     for (int e = 0; e < E; e++)
-        out.v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(off + 4u * LPR * e), 0, aux));
+        out.v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.rs, (int)(off + 4u * LPR * e), 0, aux));
+    return out;
+}
+template <int LPR, int E, int LOADP>
+__device__ inline Row<E> hw_load_row(TabPtr t, int row, int r) {
+    const float *p = t.base + (int64_t)row * (LPR * E) + r;
+    Row<E> out;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        if constexpr (LOADP == LD_SC1) out.v[e] = __hip_atomic_load(p + LPR * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_load ... sc1
+        else out.v[e] = p[LPR * e];
+    }
     return out;
 }
 
 template <int LPR, int E, int UPD>
-__device__ inline void hw_update_row(__amdgpu_buffer_rsrc_t rs, int row, int r, const Row<E> &oldv,
-                                     const Row<E> &newv) {
+__device__ inline void hw_update_row(TabBuf t, int row, int r, const Row<E> &oldv, const Row<E> &newv) {
     const uint32_t off = ((uint32_t)row * (uint32_t)(LPR * E) + (uint32_t)r) * 4u;
 #pragma unroll
     for (int e = 0; e < E; e++) {
         if constexpr (UPD == UP_ATOMIC) {
             // exact per-sample delta (new-old is exact when |delta| << |value|)
-            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(newv.v[e] - oldv.v[e], rs, (int)(off + 4u * LPR * e), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(newv.v[e] - oldv.v[e], t.rs, (int)(off + 4u * LPR * e), 0, 0);
         } else {
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, newv.v[e]), rs, (int)(off + 4u * LPR * e), 0,
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, newv.v[e]), t.rs, (int)(off + 4u * LPR * e), 0,
                                                   UPD == UP_STORE_SC1 ? kAuxSc1 : kAuxPlain);
         }
+    }
+}
+template <int LPR, int E, int UPD>
+__device__ inline void hw_update_row(TabPtr t, int row, int r, const Row<E> &oldv, const Row<E> &newv) {
+    float *p = t.base + (int64_t)row * (LPR * E) + r;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        if constexpr (UPD == UP_ATOMIC) (void)__hip_atomic_fetch_add(p + LPR * e, newv.v[e] - oldv.v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if constexpr (UPD == UP_STORE_SC1) __hip_atomic_store(p + LPR * e, newv.v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else p[LPR * e] = newv.v[e];
     }
 }
 
@@ -242,9 +276,9 @@ __device__ inline bool hw_rate_resolve(const HwRate &rt, float &lr, float &cu, f
     return true;
 }
 
-template <int LPR, int E, int LOADP, int UPD>
+template <int LPR, int E, int LOADP, int UPD, typename TAB>
 __global__ __launch_bounds__(256) void bpr_hogwild_kernel(
-    float *__restrict__ P, float *__restrict__ Q, uint32_t p_bytes, uint32_t q_bytes,
+    float *__restrict__ P, float *__restrict__ Q, int64_t p_bytes, int64_t q_bytes,
     const int32_t *__restrict__ u_idx, const int32_t *__restrict__ i_idx,
     const int32_t *__restrict__ j_idx, int64_t n, int chunk, int64_t n_chunks,
     int64_t groups_active, HwRate rate, double *__restrict__ loss_out) {
@@ -258,7 +292,7 @@ __global__ __launch_bounds__(256) void bpr_hogwild_kernel(
     const int64_t gid = ((int64_t)blockIdx.x * 4 + wave) * GPW + g;
     int32_t *su = s_idx[wave][g][0], *si = s_idx[wave][g][1], *sj = s_idx[wave][g][2];
 
-    const __amdgpu_buffer_rsrc_t rsP = make_rsrc(P, p_bytes), rsQ = make_rsrc(Q, q_bytes);
+    const TAB rsP = TAB::make(P, p_bytes), rsQ = TAB::make(Q, q_bytes);
     float loss = 0.f;
     double loss_acc = 0.0;
 
@@ -343,9 +377,9 @@ __global__ __launch_bounds__(256) void bpr_hogwild_kernel(
 // (stride coprime to n_chunks, ~0.618 n_chunks), which spreads the ~200 chunks of a hot item over
 // the whole epoch instead of running them all at once.
 // ------------------------------------------------------------------------------------
-template <int LPR, int E>
+template <int LPR, int E, typename TAB>
 __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
-    float *__restrict__ P, float *__restrict__ Q, uint32_t p_bytes, uint32_t q_bytes,
+    float *__restrict__ P, float *__restrict__ Q, int64_t p_bytes, int64_t q_bytes,
     const int32_t *__restrict__ u_idx, const int32_t *__restrict__ i_idx,
     const int32_t *__restrict__ j_idx, int64_t n, int chunk, int64_t n_chunks, int64_t chunk_stride,
     int64_t groups_active, int flush_every, HwRate rate, double *__restrict__ loss_out) {
@@ -357,7 +391,7 @@ __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
     const int g = lane / LPR, r = lane % LPR;
     const int64_t gid = ((int64_t)blockIdx.x * 4 + wave) * GPW + g;
     int32_t *su = s_idx[wave][g][0], *si = s_idx[wave][g][1], *sj = s_idx[wave][g][2];
-    const __amdgpu_buffer_rsrc_t rsP = make_rsrc(P, p_bytes), rsQ = make_rsrc(Q, q_bytes);
+    const TAB rsP = TAB::make(P, p_bytes), rsQ = TAB::make(Q, q_bytes);
     float loss = 0.f;
     double loss_acc = 0.0;
 
@@ -430,7 +464,7 @@ __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
 }
 
 template <int LPR, int E>
-int launch_hogwild_item(float *P, float *Q, uint32_t pb, uint32_t qb, const int32_t *u, const int32_t *i,
+int launch_hogwild_item(float *P, float *Q, int64_t pb, int64_t qb, const int32_t *u, const int32_t *i,
                         const int32_t *j, int64_t n, int chunk, int64_t groups, int flush_every, HwRate rate,
                         double *loss, hipStream_t st) {
     constexpr int GPW = kWave / LPR;
@@ -445,14 +479,18 @@ int launch_hogwild_item(float *P, float *Q, uint32_t pb, uint32_t qb, const int3
     auto gcd = [](int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; };
     while (gcd(stride, n_chunks) != 1) stride++;
     const unsigned blocks = (unsigned)((groups + 4 * GPW - 1) / (4 * GPW));
-    hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, chunk,
-                       n_chunks, stride, groups, flush_every, rate, loss);
+    if (pb < kBufLimit && qb < kBufLimit)
+        hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E, TabBuf>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, chunk,
+                           n_chunks, stride, groups, flush_every, rate, loss);
+    else
+        hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E, TabPtr>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, chunk,
+                           n_chunks, stride, groups, flush_every, rate, loss);
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }
 
 template <int LPR, int E>
-int launch_hogwild(float *P, float *Q, uint32_t pb, uint32_t qb, const int32_t *u,
+int launch_hogwild(float *P, float *Q, int64_t pb, int64_t qb, const int32_t *u,
                    const int32_t *i, const int32_t *j, int64_t n, int chunk, int64_t groups,
                    HwRate rate, double *loss, int variant, hipStream_t st) {
     constexpr int GPW = kWave / LPR;
@@ -468,9 +506,15 @@ int launch_hogwild(float *P, float *Q, uint32_t pb, uint32_t qb, const int32_t *
     if (groups > max_groups) groups = max_groups;
     if (groups > n_chunks) groups = n_chunks;
     const unsigned blocks = (unsigned)((groups + 4 * GPW - 1) / (4 * GPW));
-#define QREC_HW_LAUNCH(LOADP, UPD)                                                              \
-    hipLaunchKernelGGL((bpr_hogwild_kernel<LPR, E, LOADP, UPD>), dim3(blocks), dim3(256), 0, st, \
-                       P, Q, pb, qb, u, i, j, n, chunk, n_chunks, groups, rate, loss)
+#define QREC_HW_LAUNCH(LOADP, UPD)                                                                          \
+    do {                                                                                                    \
+        if (pb < kBufLimit && qb < kBufLimit)                                                               \
+            hipLaunchKernelGGL((bpr_hogwild_kernel<LPR, E, LOADP, UPD, TabBuf>), dim3(blocks), dim3(256), 0, st, \
+                               P, Q, pb, qb, u, i, j, n, chunk, n_chunks, groups, rate, loss);              \
+        else                                                                                                \
+            hipLaunchKernelGGL((bpr_hogwild_kernel<LPR, E, LOADP, UPD, TabPtr>), dim3(blocks), dim3(256), 0, st, \
+                               P, Q, pb, qb, u, i, j, n, chunk, n_chunks, groups, rate, loss);              \
+    } while (0)
     switch (variant) {
         case QREC_HW_PLAIN_RMW: QREC_HW_LAUNCH(LD_PLAIN, UP_STORE); break;
         case QREC_HW_SC1_RMW: QREC_HW_LAUNCH(LD_SC1, UP_STORE_SC1); break;
@@ -561,7 +605,7 @@ int qrec_mf_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
                              : dispatch_mf<float>(variant, d_P, d_Q, d_Bu, d_Bi, d, ld, d_u, d_i, d_rating, n, lr, regU, regI, regB, global_mean, d_loss, st);
 }
 
-int qrec_bpr_sgd_hogwild(float *d_P, float *d_Q, int32_t d, int32_t ld, const int32_t *d_u,
+int qrec_bpr_sgd_hogwild(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld, const int32_t *d_u,
                          const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
                          int32_t grid_groups, float lr, float regU, float regI, double *d_loss,
                          int variant, const double *d_driver_state, void *stream) {
@@ -572,21 +616,22 @@ int qrec_bpr_sgd_hogwild(float *d_P, float *d_Q, int32_t d, int32_t ld, const in
                  "qrec_bpr_sgd_hogwild: row stride must be 32, 64, 128 or 256 floats (pad d=%d up; got ld=%d)", d, ld);
     QREC_REQUIRE(chunk >= 1 && chunk <= kMaxChunk, "qrec_bpr_sgd_hogwild: chunk must be in 1..%d", kMaxChunk);
     if (n == 0) return QREC_OK;
-    // Buffer descriptors address 32 bits: callers with bigger tables shard them (one
-    // shard per GPU is far below this) -- rows are only bounds-checked, never wrapped.
-    // The row count is not known here; the caller guarantees ids < rows; we bound by 4 GiB.
-    const uint32_t full = 0xffffffffu;
+    // tables below 4 GiB go through a buffer descriptor sized to the table (ids >= rows are dropped by the hardware
+    // bounds check); larger ones through 64-bit addressing
+    QREC_REQUIRE(n_users >= 1 && n_items >= 1, "qrec_bpr_sgd_hogwild: table row counts must be given");
+    const int64_t full_p = n_users * (int64_t)ld * 4, full_q = n_items * (int64_t)ld * 4;
     hipStream_t st = as_stream(stream);
     const HwRate rate{lr, regU, regI, d_driver_state};
     switch (ld) {
-        case 32: return launch_hogwild<16, 2>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, rate, d_loss, variant, st);
-        case 64: return launch_hogwild<16, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, rate, d_loss, variant, st);
-        case 128: return launch_hogwild<32, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, rate, d_loss, variant, st);
-        default: return launch_hogwild<64, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, rate, d_loss, variant, st);
+        case 32: return launch_hogwild<16, 2>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, chunk, grid_groups, rate, d_loss, variant, st);
+        case 64: return launch_hogwild<16, 4>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, chunk, grid_groups, rate, d_loss, variant, st);
+        case 128: return launch_hogwild<32, 4>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, chunk, grid_groups, rate, d_loss, variant, st);
+        default: return launch_hogwild<64, 4>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, chunk, grid_groups, rate, d_loss, variant, st);
     }
 }
 
-int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int32_t d, int32_t ld, const int32_t *d_u,
+int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld,
+                                    const int32_t *d_u,
                                     const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
                                     int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
                                     double *d_loss, const double *d_driver_state, void *stream) {
@@ -597,14 +642,15 @@ int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int32_t d, int32_t l
                  "qrec_bpr_sgd_hogwild_item_major: row stride must be 32, 64, 128 or 256 floats (got ld=%d)", ld);
     QREC_REQUIRE(chunk >= 1 && chunk <= kMaxChunk && flush_every >= 1, "qrec_bpr_sgd_hogwild_item_major: bad chunk / flush interval");
     if (n == 0) return QREC_OK;
-    const uint32_t full = 0xffffffffu;
+    QREC_REQUIRE(n_users >= 1 && n_items >= 1, "qrec_bpr_sgd_hogwild_item_major: table row counts must be given");
+    const int64_t full_p = n_users * (int64_t)ld * 4, full_q = n_items * (int64_t)ld * 4;
     hipStream_t st = as_stream(stream);
     const HwRate rate{lr, regU, regI, d_driver_state};
     switch (ld) {
-        case 32: return launch_hogwild_item<16, 2>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, st);
-        case 64: return launch_hogwild_item<16, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, st);
-        case 128: return launch_hogwild_item<32, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, st);
-        default: return launch_hogwild_item<64, 4>(d_P, d_Q, full, full, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, st);
+        case 32: return launch_hogwild_item<16, 2>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, st);
+        case 64: return launch_hogwild_item<16, 4>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, st);
+        case 128: return launch_hogwild_item<32, 4>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, st);
+        default: return launch_hogwild_item<64, 4>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, st);
     }
 }
 

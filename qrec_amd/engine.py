@@ -34,8 +34,6 @@ class DeviceTables:
         self.n_items = Q.shape[0]
         assert Q.shape[1] == self.d
         self.ld = padded_ld(self.d, self.dtype)
-        if max(self.n_users, self.n_items) * self.ld * self.dtype.itemsize >= 2 ** 32:
-            raise ValueError("a table exceeds the 4 GiB buffer-descriptor range; shard it across GPUs")
         self.P = DeviceBuffer.from_numpy(self._pad(P))
         self.Q = DeviceBuffer.from_numpy(self._pad(Q))
 

@@ -737,3 +737,37 @@ def test_two_rank_bench_path_on_one_device(tmp_path):
     np.testing.assert_array_equal(r0["log"][:, :2], r1["log"][:, :2])         # same loss, same lr on both ranks
     assert r0["log"].shape[0] == 5 and float(r0["lr"]) == float(r1["lr"])
     assert (np.diff(r0["log"][:, 0]) < 0).all()                               # the summed loss goes down
+
+
+@pytest.mark.parametrize("schedule", ["user", "item"])
+def test_tables_beyond_4_gib_use_64_bit_addressing(schedule):
+    """A 4.35 GB user table (17 M rows x 64 floats): the throughput kernels switch from the 32-bit-offset buffer
+    descriptor to 64-bit addresses; training the LAST rows of the table (byte offsets past 2^32) with one group must
+    reproduce the sequential recurrence, and the rows before them must stay untouched."""
+    U, I, dim, n_act = 17_000_000, 1200, 64, 800
+    rng = np.random.default_rng(17)
+    P_tail = (rng.random((n_act, dim)) / 3).astype(np.float32); Q0 = (rng.random((I, dim)) / 3).astype(np.float32)
+    d_P = DB.zeros((U, dim), np.float32)
+    d_P.write_rows(U - n_act, P_tail)
+    d_Q = DB.from_numpy(Q0)
+    n = 6000
+    u_loc = np.sort(rng.integers(0, n_act, n)).astype(np.int32)
+    i = rng.integers(0, I, n).astype(np.int32); j = rng.integers(0, I, n).astype(np.int32)
+    if schedule == "item":
+        order = np.argsort(i, kind="stable"); u_loc, i, j = u_loc[order], i[order], j[order]
+    u = (u_loc.astype(np.int64) + (U - n_act)).astype(np.int32)
+    Pr, Qr = P_tail.astype(np.float64), Q0.astype(np.float64)
+    want = O.bpr_sgd(Pr, Qr, np.ascontiguousarray(u_loc), i, j, 0.05, 0.01, 0.02)
+    d_u, d_i, d_j, loss = DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), DB.zeros(1, np.float64)
+    if schedule == "item":
+        capi.bpr_sgd_hogwild_item_major(d_P, d_Q, dim, dim, d_u, d_i, d_j, n, 32, 1, 8, 0.05, 0.01, 0.02, loss)
+    else:
+        capi.bpr_sgd_hogwild(d_P, d_Q, dim, dim, d_u, d_i, d_j, n, 32, 1, 0.05, 0.01, 0.02, loss)
+    got_P = d_P.read_rows(U - n_act, n_act)
+    if schedule == "user":     # the item-major single-group run follows ITS visiting order (chunk stride), not the array order
+        assert rel_err(got_P, Pr) < F32_TOL and rel_err(d_Q.numpy(), Qr) < F32_TOL
+        assert abs(loss.numpy()[0] - want) / want < F32_TOL
+    else:
+        assert rel_err(got_P, Pr) < 0.05 and np.isfinite(got_P).all() and not np.array_equal(got_P, P_tail)
+    assert not d_P.read_rows(U - n_act - 1000, 1000).any()       # the zero rows just before the active block
+    assert not d_P.read_rows(0, 1000).any()                       # and where a 32-bit offset would have wrapped to
