@@ -186,6 +186,14 @@ int qrec_mf_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
                         double lr, double *d_loss, int variant, double regU, double regI, void *d_Bu,
                         void *d_Bi, double regB, double global_mean, void *stream);
 
+/* model/rating/SVDPlusPlus.py:25-62,70-86, order-exact: the implicit-feedback table d_Y [n_items][ld] next to P, Q and
+ * the biases; d_rated_indptr/d_rated_items = each user's train items in data.userRated order (CSR over all users).
+ * *d_loss receives sum(error^2); the epoch-end regularisers (:64-65) are qrec_sumsq.                        */
+int qrec_svdpp_sgd_ordered(void *d_P, void *d_Q, void *d_Y, void *d_Bu, void *d_Bi, int dtype, int32_t d, int32_t ld,
+                           const int64_t *d_rated_indptr, const int32_t *d_rated_items, const int32_t *d_u,
+                           const int32_t *d_i, const double *d_rating, int64_t n, double lr, double regU, double regI,
+                           double regB, double regY, double global_mean, double *d_loss, void *stream);
+
 /* sum(x*x) over rows x d of a table (epoch-end regulariser, BPR.py:40); *d_out
  * (double) is overwritten. */
 int qrec_sumsq(const void *d_x, int dtype, int64_t rows, int32_t d, int32_t ld, double *d_out,

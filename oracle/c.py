@@ -52,6 +52,8 @@ def lib():
         L.orc_mf_sgd_f64.restype = f64
         L.orc_mf_sgd_var_f64.argtypes = [C.c_int, vp, vp, vp, vp, i32, vp, vp, vp, i64, f64, f64, f64, f64, f64]
         L.orc_mf_sgd_var_f64.restype = f64
+        L.orc_svdpp_sgd_f64.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, f64]
+        L.orc_svdpp_sgd_f64.restype = f64
         L.orc_find_k_largest.argtypes = [i32, vp, i32, vp, vp]
         L.orc_find_k_largest.restype = C.c_int
         _lib = L
@@ -185,6 +187,15 @@ def mf_sgd_variant(variant: int, P, Q, u, i, r, lr, regU=0.0, regI=0.0, Bu=None,
     return lib().orc_mf_sgd_var_f64(variant, _p(P), _p(Q), _p(Bu) if Bu is not None else None,
                                     _p(Bi) if Bi is not None else None, P.shape[1], _p(u), _p(i), _p(r), u.size,
                                     lr, regU, regI, regB, gmean)
+
+
+def svdpp_sgd(P, Q, Y, Bu, Bi, rated_indptr, rated_items, u, i, r, lr, regU, regI, regB, regY, gmean) -> float:
+    """model/rating/SVDPlusPlus.py:25-62 over n ratings (fp64, in place); rated_*: data.userRated order as CSR."""
+    for a in (P, Q, Y, Bu, Bi, r):
+        _chk(a, np.float64)
+    _chk(rated_indptr, np.int64); _chk(rated_items, np.int32); _chk(u, np.int32); _chk(i, np.int32)
+    return lib().orc_svdpp_sgd_f64(_p(P), _p(Q), _p(Y), _p(Bu), _p(Bi), P.shape[1], _p(rated_indptr), _p(rated_items),
+                                   _p(u), _p(i), _p(r), u.size, lr, regU, regI, regB, regY, gmean)
 
 
 def find_k_largest(K: int, cand):

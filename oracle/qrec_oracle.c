@@ -415,6 +415,63 @@ double orc_mf_sgd_var_f64(int variant, double *P, double *Q, double *Bu, double 
     return loss;
 }
 
+/* model/rating/SVDPlusPlus.py:25-62,70-86, one pass over the ratings in array order (fp64, in place).
+ * rated_indptr/rated_items: each user's train items in dict order (data.userRated), w = their count.
+ *   pred  = ((sum_j Y[j]) / w) . Q[i]  +  (((P[u].Q[i] + mean) + Bi[i]) + Bu[u])          (:70-86; the sum over ALL w items)
+ *   Bu, Bi from their old values; if w > 1, over the user's OTHER items (indexes, dict order):
+ *         sum2 = y_0 + y_1 + ... ;  Y[j] = y_j + lr*((err*q)/(w-1) - regY*y_j) ;  Q[i] += ((lr*err)*sum2)/(w-1)
+ *   P[u] += lr*(err*q - regU*p)  (q: the UPDATED Q[i], a view) ;  Q[i] += lr*(err*p - regI*q)  (p: the UPDATED P[u])
+ * Returns sum(err^2). */
+double orc_svdpp_sgd_f64(double *P, double *Q, double *Y, double *Bu, double *Bi, int32_t d,
+                         const int64_t *rated_indptr, const int32_t *rated_items,
+                         const int32_t *u_idx, const int32_t *i_idx, const double *rating, int64_t n,
+                         double lr, double regU, double regI, double regB, double regY, double gmean) {
+    double loss = 0.0;
+    double *sum = (double *)malloc(sizeof(double) * (size_t)d), *tmp = (double *)malloc(sizeof(double) * (size_t)d);
+    int64_t t, k;
+    int c;
+    for (t = 0; t < n; t++) {
+        const int32_t u = u_idx[t], i = i_idx[t];
+        double *p = P + (int64_t)u * d, *q = Q + (int64_t)i * d;
+        const int64_t b = rated_indptr[u], e = rated_indptr[u + 1];
+        const int64_t w = e - b;
+        double a = 0.0, dot = 0.0, pred, err, bu = Bu[u], bi = Bi[i];
+        if (w > 0) {
+            for (c = 0; c < d; c++) sum[c] = 0.0;
+            for (k = b; k < e; k++) { const double *y = Y + (int64_t)rated_items[k] * d; for (c = 0; c < d; c++) sum[c] += y[c]; }
+            for (c = 0; c < d; c++) a += (sum[c] / (double)w) * q[c];
+        }
+        for (c = 0; c < d; c++) dot += p[c] * q[c];
+        pred = a + (((dot + gmean) + bi) + bu);
+        err = rating[t] - pred;
+        loss += err * err;
+        Bu[u] += lr * (err - regB * bu);
+        Bi[i] += lr * (err - regB * bi);
+        if (w > 1) {
+            int first = 1;
+            for (k = b; k < e; k++) {
+                const double *y;
+                if (rated_items[k] == i) continue;
+                y = Y + (int64_t)rated_items[k] * d;
+                if (first) { for (c = 0; c < d; c++) sum[c] = y[c]; first = 0; }
+                else for (c = 0; c < d; c++) sum[c] += y[c];
+            }
+            for (c = 0; c < d; c++) tmp[c] = (err * q[c]) / (double)(w - 1);
+            for (k = b; k < e; k++) {
+                double *y;
+                if (rated_items[k] == i) continue;
+                y = Y + (int64_t)rated_items[k] * d;
+                for (c = 0; c < d; c++) y[c] = y[c] + lr * (tmp[c] - regY * y[c]);
+            }
+            if (!first) for (c = 0; c < d; c++) q[c] += ((lr * err) * sum[c]) / (double)(w - 1);
+        }
+        for (c = 0; c < d; c++) p[c] += lr * (err * q[c] - regU * p[c]);
+        for (c = 0; c < d; c++) q[c] += lr * (err * p[c] - regI * q[c]);
+    }
+    free(sum); free(tmp);
+    return loss;
+}
+
 /* ------------------------------------------------------------------------------------
  * a-15  find_k_largest: util/qmath.py:134-146, including CPython heapq's exact sift
  * order (Lib/heapq.py) because ties are resolved by the heap layout:

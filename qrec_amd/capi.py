@@ -54,6 +54,8 @@ _SIGNATURES = {
     "qrec_epoch_sums": [_vp, _i64, _vp, _i64, C.c_int, _i32, _vp, _vp, _vp],
     "qrec_epoch_decide": [_vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
     "qrec_mf_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _vp, C.c_int, _f64, _f64, _vp, _vp, _f64, _f64, _vp],
+    "qrec_svdpp_sgd_ordered": [_vp, _vp, _vp, _vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64,
+                               _f64, _f64, _f64, _vp, _vp],
     "qrec_sumsq": [_vp, C.c_int, _i64, _i32, _i32, _vp, _vp],
     "qrec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _vp, _vp],
     "qrec_mark_batch_rows": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
@@ -432,6 +434,14 @@ def mf_sgd_ordered(d_P, d_Q, dtype: int, d: int, ld: int, d_u, d_i, d_rating, n:
     _check(load().qrec_mf_sgd_ordered(_dp(d_P), _dp(d_Q), dtype, d, ld, _dp(d_u), _dp(d_i), _dp(d_rating),
                                       n, lr, _dp(d_loss), variant, regU, regI, _dp(d_Bu), _dp(d_Bi), regB,
                                       global_mean, _sh(stream)))
+
+
+def svdpp_sgd_ordered(d_P, d_Q, d_Y, d_Bu, d_Bi, dtype: int, d: int, ld: int, d_rated_indptr, d_rated_items, d_u, d_i,
+                      d_rating, n: int, lr: float, regU: float, regI: float, regB: float, regY: float, global_mean: float,
+                      d_loss, stream=None):
+    _check(load().qrec_svdpp_sgd_ordered(_dp(d_P), _dp(d_Q), _dp(d_Y), _dp(d_Bu), _dp(d_Bi), dtype, d, ld, _dp(d_rated_indptr),
+                                         _dp(d_rated_items), _dp(d_u), _dp(d_i), _dp(d_rating), n, lr, regU, regI, regB, regY,
+                                         global_mean, _dp(d_loss), _sh(stream)))
 
 
 def sumsq(d_x, dtype: int, rows: int, d: int, ld: int, d_out, stream=None):

@@ -181,6 +181,82 @@ __global__ __launch_bounds__(64) void mf_ordered_kernel(
     if (lane == 0) *loss_out = loss;
 }
 
+// model/rating/SVDPlusPlus.py:25-62,70-86, order-exact (one wavefront, lane = column).  Per rating the user's
+// rated items (data.userRated order, CSR) are walked twice: sum_j Y[j] for the prediction, then -- over the OTHER
+// items -- their sum, the Y updates and the implicit-feedback term of Q[i].  p and q are views in the reference: the
+// P[u] update sees the already updated Q[i], the final Q[i] update the updated P[u].
+template <typename T, int EPL>
+__global__ __launch_bounds__(64) void svdpp_ordered_kernel(
+    T *__restrict__ P, T *__restrict__ Q, T *__restrict__ Y, T *__restrict__ Bu, T *__restrict__ Bi, int d, int ld,
+    const int64_t *__restrict__ rated_indptr, const int32_t *__restrict__ rated_items,
+    const int32_t *__restrict__ u_idx, const int32_t *__restrict__ i_idx, const double *__restrict__ rating, int64_t n,
+    T lr, T regU, T regI, T regB, T regY, T gmean, double *__restrict__ loss_out) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x;
+    double loss = 0.0;
+    for (int64_t t = 0; t < n; t++) {
+        const int u = u_idx[t], i = i_idx[t];
+        T *p = P + (int64_t)u * ld + lane;
+        T *q = Q + (int64_t)i * ld + lane;
+        const int64_t b = rated_indptr[u], e_ = rated_indptr[u + 1];
+        const T w = (T)(e_ - b);
+        T pv[EPL], qv[EPL], sum[EPL];
+        bool ok[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            ok[e] = (lane + 64 * e) < d;
+            pv[e] = ok[e] ? p[64 * e] : T(0);
+            qv[e] = ok[e] ? q[64 * e] : T(0);
+            sum[e] = T(0);
+        }
+        for (int64_t k = b; k < e_; k++) {
+            const T *y = Y + (int64_t)rated_items[k] * ld + lane;
+#pragma unroll
+            for (int e = 0; e < EPL; e++) sum[e] += ok[e] ? y[64 * e] : T(0);
+        }
+        T a = 0, dot = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            if (e_ > b) a += (sum[e] / w) * qv[e];
+            dot += pv[e] * qv[e];
+        }
+        a = wave_allreduce_sum(a);
+        dot = wave_allreduce_sum(dot);
+        const T bu = Bu[u], bi = Bi[i];
+        const T pred = a + (((dot + gmean) + bi) + bu);
+        const T err = (T)rating[t] - pred;
+        loss += (double)err * (double)err;
+        if (lane == 0) { Bu[u] = bu + lr * (err - regB * bu); Bi[i] = bi + lr * (err - regB * bi); }
+        if (e_ - b > 1) {
+            const T wm1 = (T)(e_ - b - 1);
+            bool first = true;
+            for (int64_t k = b; k < e_; k++) {
+                const int j = rated_items[k];
+                if (j == i) continue;
+                T *y = Y + (int64_t)j * ld + lane;
+#pragma unroll
+                for (int e = 0; e < EPL; e++) {
+                    const T yv = ok[e] ? y[64 * e] : T(0);
+                    sum[e] = first ? yv : sum[e] + yv;
+                    if (ok[e]) y[64 * e] = yv + lr * ((err * qv[e]) / wm1 - regY * yv);
+                }
+                first = false;
+            }
+            if (!first) {
+#pragma unroll
+                for (int e = 0; e < EPL; e++) qv[e] += ((lr * err) * sum[e]) / wm1;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            pv[e] += lr * (err * qv[e] - regU * pv[e]);
+            qv[e] += lr * (err * pv[e] - regI * qv[e]);
+            if (ok[e]) { p[64 * e] = pv[e]; q[64 * e] = qv[e]; }
+        }
+    }
+    if (lane == 0) *loss_out = loss;
+}
+
 // ------------------------------------------------------------------------------------
 // throughput kernel
 // ------------------------------------------------------------------------------------
@@ -603,6 +679,27 @@ int qrec_mf_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
     if (n == 0) { QREC_HIP_CHECK(hipMemsetAsync(d_loss, 0, sizeof(double), st)); return QREC_OK; }
     return dtype == QREC_F64 ? dispatch_mf<double>(variant, d_P, d_Q, d_Bu, d_Bi, d, ld, d_u, d_i, d_rating, n, lr, regU, regI, regB, global_mean, d_loss, st)
                              : dispatch_mf<float>(variant, d_P, d_Q, d_Bu, d_Bi, d, ld, d_u, d_i, d_rating, n, lr, regU, regI, regB, global_mean, d_loss, st);
+}
+
+int qrec_svdpp_sgd_ordered(void *d_P, void *d_Q, void *d_Y, void *d_Bu, void *d_Bi, int dtype, int32_t d, int32_t ld,
+                           const int64_t *d_rated_indptr, const int32_t *d_rated_items, const int32_t *d_u,
+                           const int32_t *d_i, const double *d_rating, int64_t n, double lr, double regU, double regI,
+                           double regB, double regY, double global_mean, double *d_loss, void *stream) {
+    QREC_REQUIRE(d_P && d_Q && d_Y && d_Bu && d_Bi && d_rated_indptr && d_loss && n >= 0, "qrec_svdpp_sgd_ordered: null argument");
+    QREC_REQUIRE(n == 0 || (d_u && d_i && d_rating && d_rated_items), "qrec_svdpp_sgd_ordered: null index array");
+    QREC_REQUIRE(d >= 1 && d <= 256 && ld >= d, "qrec_svdpp_sgd_ordered: need 1 <= d <= 256, ld >= d");
+    QREC_REQUIRE(dtype == QREC_F32 || dtype == QREC_F64, "qrec_svdpp_sgd_ordered: bad dtype %d", dtype);
+    hipStream_t st = as_stream(stream);
+    if (n == 0) { QREC_HIP_CHECK(hipMemsetAsync(d_loss, 0, sizeof(double), st)); return QREC_OK; }
+#define QREC_SVDPP(T, EPL)                                                                                              \
+    hipLaunchKernelGGL((svdpp_ordered_kernel<T, EPL>), dim3(1), dim3(64), 0, st, (T *)d_P, (T *)d_Q, (T *)d_Y, (T *)d_Bu, \
+                       (T *)d_Bi, d, ld, d_rated_indptr, d_rated_items, d_u, d_i, d_rating, n, (T)lr, (T)regU, (T)regI,    \
+                       (T)regB, (T)regY, (T)global_mean, d_loss)
+    if (dtype == QREC_F64) { if (d <= 64) QREC_SVDPP(double, 1); else if (d <= 128) QREC_SVDPP(double, 2); else QREC_SVDPP(double, 4); }
+    else { if (d <= 64) QREC_SVDPP(float, 1); else if (d <= 128) QREC_SVDPP(float, 2); else QREC_SVDPP(float, 4); }
+#undef QREC_SVDPP
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
 }
 
 int qrec_bpr_sgd_hogwild(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld, const int32_t *d_u,

@@ -321,3 +321,43 @@ class MfSgd:
 
     def biases(self):
         return self.d_Bu.numpy().astype(np.float64), self.d_Bi.numpy().astype(np.float64)
+
+
+class SvdppSgd:
+    """SVD++ on the device, order-exact (model/rating/SVDPlusPlus.py:25-62): P, Q, the implicit-feedback table Y and
+    the biases stay resident; ``rated`` = every user's train items in ``data.userRated`` order."""
+
+    def __init__(self, tables: DeviceTables, Y, Bu, Bi, rated: CSR, n: int):
+        self.t, self.n = tables, n
+        dt = tables.dtype
+        Yp = np.zeros((Y.shape[0], tables.ld), dtype=dt); Yp[:, :tables.d] = Y
+        self.d_Y = DeviceBuffer.from_numpy(Yp)
+        self.d_Bu = DeviceBuffer.from_numpy(np.ascontiguousarray(Bu, dtype=dt))
+        self.d_Bi = DeviceBuffer.from_numpy(np.ascontiguousarray(Bi, dtype=dt))
+        self.d_indptr = DeviceBuffer.from_numpy(rated.indptr.astype(np.int64))
+        self.d_items = DeviceBuffer.from_numpy(rated.indices.astype(np.int32) if rated.indices.size else np.zeros(1, np.int32))
+        self.d_u = DeviceBuffer(max(n, 1), np.int32); self.d_i = DeviceBuffer(max(n, 1), np.int32)
+        self.d_r = DeviceBuffer(max(n, 1), np.float64)
+        self.d_stats = DeviceBuffer.zeros(6, np.float64)     # err^2, sum P^2, Q^2, Y^2, Bu^2, Bi^2
+
+    def epoch(self, u, i, r, lr, regU, regI, regB, regY, global_mean, stream=None) -> float:
+        self.d_u.upload(np.ascontiguousarray(u, dtype=np.int32), stream)
+        self.d_i.upload(np.ascontiguousarray(i, dtype=np.int32), stream)
+        self.d_r.upload(np.ascontiguousarray(r, dtype=np.float64), stream)
+        t = self.t
+        capi.svdpp_sgd_ordered(t.P, t.Q, self.d_Y, self.d_Bu, self.d_Bi, t.code, t.d, t.ld, self.d_indptr, self.d_items,
+                               self.d_u, self.d_i, self.d_r, self.n, lr, regU, regI, regB, regY, global_mean, self.d_stats, stream)
+        return float(self.d_stats.head(1, stream)[0])
+
+    def sumsq_terms(self, stream=None):
+        """(sum P^2, sum Q^2, sum Y^2, sum Bu^2, sum Bi^2) -- SVDPlusPlus.py:64-65"""
+        t = self.t
+        for k, (buf, rows, d, ld) in enumerate(((t.P, t.n_users, t.d, t.ld), (t.Q, t.n_items, t.d, t.ld), (self.d_Y, t.n_items, t.d, t.ld),
+                                                (self.d_Bu, t.n_users, 1, 1), (self.d_Bi, t.n_items, 1, 1))):
+            capi.sumsq(buf, t.code, rows, d, ld, self.d_stats.ptr + 8 * (k + 1), stream)
+        s = self.d_stats.numpy(stream)
+        return tuple(float(x) for x in s[1:6])
+
+    def download(self):
+        return (self.d_Y.numpy()[:, :self.t.d].astype(np.float64), self.d_Bu.numpy().astype(np.float64),
+                self.d_Bi.numpy().astype(np.float64))

@@ -76,6 +76,7 @@ def run_numpy_model(conf_path, seed, model_mod, model_name, hook_attr):
                                   lr_next=float(self.lRate), converged=bool(r),
                                   P=self.P.copy(), Q=self.Q.copy(),
                                   **({"Bu": self.Bu.copy(), "Bi": self.Bi.copy()} if hasattr(self, "Bu") else {}),
+                                  **({"Y": self.Y.copy()} if hasattr(self, "Y") else {}),
                                   order=[(self.data.user[a], self.data.item[b], c)
                                          for a, b, c in self.data.trainingData]
                                   if hook_attr == "mf" else None))
@@ -86,6 +87,8 @@ def run_numpy_model(conf_path, seed, model_mod, model_name, hook_attr):
         orig_init(self); rec["P0"] = self.P.copy(); rec["Q0"] = self.Q.copy()
         if hasattr(self, "Bu"):
             rec["Bu0"] = self.Bu.copy(); rec["Bi0"] = self.Bi.copy()
+        if hasattr(self, "Y"):
+            rec["Y0"] = self.Y.copy()
         rec["order0"] = [(self.data.user[a], self.data.item[b], c) for a, b, c in self.data.trainingData]
     cls.initModel = initModel
     orig_eval = cls.evalRanking
@@ -212,13 +215,13 @@ def case_bpr_lastfm(tmp):
     return meta
 
 
-def _case_rating_mf(tmp, model, fixture, seed, factors, lr, reg, epochs=3):
+def _case_rating_mf(tmp, model, fixture, seed, factors, lr, reg, epochs=3, **extra):
     conf = os.path.join(tmp, fixture + ".conf")
     write_conf(conf, ratings="./dataset/FilmTrust/trainset.txt", ratings__setup="-columns 0 1 2",
                model__name=model, evaluation__setup="-testSet ./dataset/FilmTrust/testset.txt",
                item__ranking="off -topN 10", num__factors=str(factors), num__max__epoch=str(epochs),
                batch_size="1024", learnRate="-init %s -max 1" % lr,
-               reg__lambda=reg, output__setup="off -dir ./results/")
+               reg__lambda=reg, output__setup="off -dir ./results/", **extra)
     rec = run_numpy_model(conf, seed, "model.rating." + model, model, "mf")
     m = rec["model"]
     arrays = dict(P0=rec["P0"], Q0=rec["Q0"],
@@ -230,6 +233,10 @@ def _case_rating_mf(tmp, model, fixture, seed, factors, lr, reg, epochs=3):
         arrays[f"order{k+1}"] = np.array([(a, b) for a, b, _ in e["order"]], dtype=np.int32)
         if "Bu" in e:
             arrays[f"Bu{k+1}"] = e["Bu"]; arrays[f"Bi{k+1}"] = e["Bi"]
+        if "Y" in e:
+            arrays[f"Y{k+1}"] = e["Y"]
+    if "Y0" in rec:
+        arrays["Y0"] = rec["Y0"]
     if "Bu0" in rec:
         arrays["Bu0"] = rec["Bu0"]; arrays["Bi0"] = rec["Bi0"]
     # test predictions appended by evalRatings: [user,item,rating,pred]
@@ -240,7 +247,7 @@ def _case_rating_mf(tmp, model, fixture, seed, factors, lr, reg, epochs=3):
     np.savez_compressed(os.path.join(OUT, fixture + ".npz"), **arrays)
     return dict(name=fixture, seed=seed, conf=open(conf).read(),
                 n_users=len(m.data.user), n_items=len(m.data.item), n_train=len(rec["train_rows"]),
-                epochs=[{k: v for k, v in e.items() if k not in ("P", "Q", "order", "Bu", "Bi")} for e in rec["epochs"]],
+                epochs=[{k: v for k, v in e.items() if k not in ("P", "Q", "order", "Bu", "Bi", "Y")} for e in rec["epochs"]],
                 measure=rec["measure"], globalMean=m.data.globalMean,
                 rScale=[float(x) for x in m.data.rScale], regU=m.regU, regI=m.regI, regB=m.regB)
 
@@ -260,6 +267,13 @@ def case_svd(tmp):
 
 def case_ee(tmp):
     return _case_rating_mf(tmp, "EE", "ee_filmtrust", 4, 10, 0.005, "-u 0.005 -i 0.005 -b 0.005 -s 0.1")
+
+
+def case_svdpp(tmp):
+    out = _case_rating_mf(tmp, "SVDPlusPlus", "svdpp_filmtrust", 5, 10, 0.02, "-u 0.01 -i 0.01 -b 0.1 -s 0.1", epochs=2,
+                          SVDPlusPlus="-y 0.01")
+    out["regY"] = 0.01
+    return out
 
 
 def case_pairwise_and_adj(tmp):
@@ -338,7 +352,7 @@ def main():
     os.symlink(os.path.join(REF, "dataset"), os.path.join(tmp, "dataset"))
     os.chdir(tmp)
     only = sys.argv[1:]
-    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pmf, case_svd, case_ee, case_pairwise_and_adj, case_sgl_subgraph]
+    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pmf, case_svd, case_ee, case_svdpp, case_pairwise_and_adj, case_sgl_subgraph]
     if only:   # regenerate a subset, keep the other entries of golden_meta.json
         cases = [c for c in cases if c.__name__ in only]
         old = json.load(open(os.path.join(OUT, "golden_meta.json")))

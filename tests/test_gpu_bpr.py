@@ -771,3 +771,42 @@ def test_tables_beyond_4_gib_use_64_bit_addressing(schedule):
         assert rel_err(got_P, Pr) < 0.05 and np.isfinite(got_P).all() and not np.array_equal(got_P, P_tail)
     assert not d_P.read_rows(U - n_act - 1000, 1000).any()       # the zero rows just before the active block
     assert not d_P.read_rows(0, 1000).any()                       # and where a 32-bit offset would have wrapped to
+
+
+def test_svdpp_kernel_and_model_reproduce_the_reference_run():
+    """model/rating/SVDPlusPlus.py on FilmTrust: the order-exact kernel against the oracle on synthetic ratings (fp64 and
+    fp32), then the drop-in class against the recorded run of the unmodified reference."""
+    from qrec_amd.engine import SvdppSgd
+    from qrec_amd.model.rating.SVDPlusPlus import SVDPlusPlus
+    rng = np.random.default_rng(55)
+    U, I, n, dim = 200, 300, 6000, 12
+    u = rng.integers(0, U, n, dtype=np.int32); i = rng.integers(0, I, n, dtype=np.int32)
+    r = rng.integers(1, 11, n).astype(np.float64) / 2
+    rated = user_item_csr(u, i, r, U, I)
+    P0, Q0, Y0 = rng.random((U, dim)) / 3, rng.random((I, dim)) / 3, rng.random((I, dim)) / 3
+    Bu0, Bi0 = rng.random(U) / 5, rng.random(I) / 5
+    for dtype, tol in ((np.float64, F64_TOL), (np.float32, 5e-5)):
+        Pr, Qr, Yr, Bur, Bir = P0.copy(), Q0.copy(), Y0.copy(), Bu0.copy(), Bi0.copy()
+        want = O.svdpp_sgd(Pr, Qr, Yr, Bur, Bir, rated.indptr, rated.indices, u, i, r, 0.01, 0.01, 0.02, 0.05, 0.03, float(r.mean()))
+        t = DeviceTables(P0, Q0, dtype)
+        sgd = SvdppSgd(t, Y0, Bu0, Bi0, rated, n)
+        got = sgd.epoch(u, i, r, 0.01, 0.01, 0.02, 0.05, 0.03, float(r.mean()))
+        Pg, Qg = t.download(np.float64); Yg, Bug, Big = sgd.download()
+        assert abs(got - want) / want < tol
+        for a, b in ((Pg, Pr), (Qg, Qr), (Yg, Yr), (Bug, Bur), (Big, Bir)):
+            assert rel_err(a, b) < tol
+    meta, z = load_golden("svdpp_filmtrust")
+    rows = [[f"u{a}", f"i{b}", float(c)] for (a, b), c in zip(z["order0"].tolist(), z["rating0"].tolist())]
+    test = [[f"u{a}" if a >= 0 else f"xu{k}", f"i{b}" if b >= 0 else f"xi{k}", float(c)]
+            for k, (a, b, c) in enumerate(zip(z["test_uid"].tolist(), z["test_iid"].tolist(), z["test_rating"].tolist()))]
+    random.seed(meta["seed"]); np.random.seed(meta["seed"])
+    with redirect_stdout(io.StringIO()):
+        m = SVDPlusPlus(conf_from_text(meta["conf"]), rows, test)
+        measure = m.execute()
+    last = len(meta["epochs"])
+    for name in ("P", "Q", "Y", "Bu", "Bi"):
+        np.testing.assert_allclose(getattr(m, name), z[f"{name}{last}"], rtol=1e-10, atol=1e-13)
+    assert m.lastLoss == pytest.approx(meta["epochs"][-1]["loss"], rel=1e-11)
+    for g, w in zip(measure, meta["measure"]):
+        assert float(g.split(":")[1]) == pytest.approx(float(w.split(":")[1]), rel=1e-9)
+    assert np.array_equal(capi.state_from_python(random.getstate()), z["py_state"])

@@ -235,3 +235,31 @@ def test_find_k_largest_on_reference_reclists(golden_dir):
         ids, sc = O.find_k_largest(N, cand)
         assert np.array_equal(ids, z["rec_ids"][row])
         np.testing.assert_allclose(sc, z["rec_scores"][row], rtol=1e-12)
+
+
+def test_svdpp_filmtrust(golden_dir):
+    """model/rating/SVDPlusPlus.py:25-86 through the oracle against the recorded reference run: P, Q, Y, biases,
+    losses, learning-rate schedule, shuffle stream."""
+    meta, z = _load(golden_dir, "svdpp_filmtrust")
+    P, Q, Y, Bu, Bi = (z[k].copy() for k in ("P0", "Q0", "Y0", "Bu0", "Bi0"))
+    regU, regI, regB, regY, gm = meta["regU"], meta["regI"], meta["regB"], meta["regY"], meta["globalMean"]
+    U, I = meta["n_users"], meta["n_items"]
+    u0 = np.ascontiguousarray(z["order0"][:, 0]); i0 = np.ascontiguousarray(z["order0"][:, 1]); r0 = z["rating0"]
+    rated = user_item_csr(u0, i0, r0, U, I)           # trainSet_u in dict order == userRated()
+    mt = O.MT.cpython_seed(meta["seed"])
+    n = u0.size
+    perm = np.arange(n, dtype=np.int64)
+    lr = meta["epochs"][0]["lr_used"]; last_loss = 0.0
+    for k, ep in enumerate(meta["epochs"]):
+        u = np.ascontiguousarray(u0[perm]); i = np.ascontiguousarray(i0[perm]); r = np.ascontiguousarray(r0[perm])
+        assert np.array_equal(np.stack([u, i], 1), z[f"order{k}"])
+        loss = O.svdpp_sgd(P, Q, Y, Bu, Bi, rated.indptr, rated.indices, u, i, r, lr, regU, regI, regB, regY, gm)
+        loss += regU * O.sumsq(P) + regI * O.sumsq(Q) + regY * O.sumsq(Y) + regB * (O.sumsq(Bu) + O.sumsq(Bi))
+        assert loss == pytest.approx(ep["loss"], rel=1e-11)
+        for got, name in ((P, "P"), (Q, "Q"), (Y, "Y"), (Bu, "Bu"), (Bi, "Bi")):
+            np.testing.assert_allclose(got, z[f"{name}{k+1}"], rtol=1e-10, atol=1e-13)
+        lr = _bold_driver(lr, last_loss, loss, ep["epoch"])
+        assert lr == pytest.approx(ep["lr_next"], rel=1e-15)
+        last_loss = loss
+        mt.shuffle(n, perm)
+    assert np.array_equal(mt.words625(), z["py_state"])
