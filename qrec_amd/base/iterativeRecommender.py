@@ -134,13 +134,22 @@ class IterativeRecommender(Recommender):
                 warm_uid=np.fromiter((self.data.user[users[k]] for k in warm_pos), dtype=np.int32, count=len(warm_pos)))
         cuts = sorted({min(n, N, self.num_items) for n in top})
         per_n = {n: (np.zeros(len(users), np.int64), np.zeros(len(users), np.float64)) for n in top}
+        dp = self.data_parallel() if hasattr(self, "data_parallel") else None
         if cache["warm_uid"].size:
             ranker = self._device_ranker(U, V)
             if ranker.test is None:
                 ranker.set_test(cache["test"])
-            _, _, per_cut = ranker.topk(cache["warm_uid"], min(N, self.num_items), cuts=cuts, want_lists=False)
+            # multi-GPU run: the test users are split over the ranks (the tables are replicated); the per-user hit
+            # counts / DCG sums of the shares are disjoint, so their sum over the ranks is exact
+            lo, cnt = dp.share(cache["warm_uid"].size) if dp else (0, cache["warm_uid"].size)
+            mine = slice(lo, lo + cnt)
+            per_cut = ranker.topk(cache["warm_uid"][mine], min(N, self.num_items), cuts=cuts, want_lists=False)[2] if cnt else {}
             for n in top:
-                hits, dcg = per_cut[min(n, N, self.num_items)]
+                hits = np.zeros(cache["warm_uid"].size, np.int64); dcg = np.zeros(cache["warm_uid"].size, np.float64)
+                if cnt:
+                    hits[mine], dcg[mine] = per_cut[min(n, N, self.num_items)]
+                if dp:
+                    hits, dcg = dp.all_reduce_host(hits), dp.all_reduce_host(dcg)
                 per_n[n][0][cache["warm_pos"]] = hits; per_n[n][1][cache["warm_pos"]] = dcg
         if cache["warm_pos"].size < len(users):
             warm = set(cache["warm_pos"].tolist())

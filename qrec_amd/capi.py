@@ -139,16 +139,22 @@ def _req(a, dtype, name):
 
 # ---- runtime ------------------------------------------------------------------------------
 _initialised = False
+_device = 0
 
 
 def init(device: int | None = None):
     """Select the device (env QREC_DEVICE, default 0).  Never called at import or from a
     model constructor: QRec forks per CV fold after constructing models (QRec.py:76-89)."""
-    global _initialised
+    global _initialised, _device
     if device is None:
         device = int(os.environ.get("QREC_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     _check(load().qrec_init(device))
-    _initialised = True
+    _initialised, _device = True, device
+
+
+def current_device() -> int:
+    ensure_init()
+    return _device
 
 
 def ensure_init():
@@ -261,6 +267,11 @@ class DeviceBuffer:
         """zero-copy view for torch.as_tensor(buf, device="cuda") (multi-GPU collectives)"""
         return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False),
                 "version": 2, "strides": None}
+
+    def head_view(self, n: int):
+        """borrowed view of the first ``n`` elements, for torch.as_tensor (a collective on part of a buffer)"""
+        owner, itf = self, {"shape": (n,), "typestr": self.dtype.str, "data": (self.ptr, False), "version": 2, "strides": None}
+        return type("DeviceView", (), {"__cuda_array_interface__": itf, "owner": owner})()
 
     def upload(self, a: np.ndarray, stream=None):
         a = np.ascontiguousarray(a, dtype=self.dtype)

@@ -116,6 +116,7 @@ class LightGCNTrainer:
         f = np.float32
         self.b1, self.b2, self.adam_eps = f(0.9), f(0.999), f(1e-8)
         self.b1p, self.b2p = self.b1, self.b2          # fp32 beta powers, as TF keeps them
+        self.dp = None                                  # dist.BatchParallel: this rank trains a share of every step's rows
 
     # ---- pieces -----------------------------------------------------------------------------
     def forward_sum(self, stream=None, last_rows=None):
@@ -149,13 +150,17 @@ class LightGCNTrainer:
     def train_step_async(self, d_u, d_i, d_j, B: int, stream=None):
         """u/i/j: device pointers (int32[B]); enqueue only, read the loss with ``loss()``."""
         self.row_mask.fill_bytes(0, stream)
-        capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)    # rows {u, nu+i, nu+j} of the batch
+        if B:
+            capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)    # rows {u, nu+i, nu+j} of the batch
         self.forward_sum(stream, last_rows=self.row_mask)
         self.dE.fill_bytes(0, stream)
         self.d_loss.fill_bytes(0, stream)
-        capi.bpr_batch_loss_grad(self.S, float(self.L + 1), self.nu, self.n, self.ld, d_u, d_i, d_j, B,
-                                 self.loss_eps, self.reg, self.dE, self.d_loss, stream, d_row_mask=self.row_mask)
+        if B:
+            capi.bpr_batch_loss_grad(self.S, float(self.L + 1), self.nu, self.n, self.ld, d_u, d_i, d_j, B,
+                                     self.loss_eps, self.reg, self.dE, self.d_loss, stream, d_row_mask=self.row_mask)
         g = self.backward_from_dE(stream)
+        if self.dp is not None:        # the step's gradient and loss = sums over the ranks' shares of its rows
+            self.dp.all_reduce(g); self.dp.all_reduce(self.d_loss)
         capi.adam_step(self.E, self.m, self.v, g, self.n * self.ld, 1.0 / (self.L + 1), self.adam_alpha(),
                        float(self.b1), float(self.b2), float(self.adam_eps), stream)
         self.t += 1
@@ -252,6 +257,7 @@ class SimGCLTrainer:
         self.b1, self.b2, self.adam_eps = f(0.9), f(0.999), f(1e-8)
         self.b1p, self.b2p = self.b1, self.b2
         self.step_no = 0
+        self.dp = None          # dist.BatchParallel
 
     def _encode(self, S, view: int, noises=None, stream=None, last_rows=None):
         """S = sum_k emb_k over the L propagated layers (view 0 = clean; 1, 2 = perturbed).  ``last_rows``: row
@@ -301,24 +307,32 @@ class SimGCLTrainer:
         return float(f(f(self.lr) * np.sqrt(f(1) - self.b2p, dtype=f) / (f(1) - self.b1p)))
 
     def train_step_async(self, d_u, d_i, d_j, B: int, d_uniq_users, n_uu: int, d_uniq_items, n_ui: int,
-                         noises=None, stream=None):
+                         noises=None, stream=None, share=None):
         """u/i/j int32[B]; d_uniq_users: distinct user rows; d_uniq_items: distinct item rows
-        ALREADY offset by n_users; noises: optional list of 2L device buffers [N][ld] (tests)."""
+        ALREADY offset by n_users; noises: optional list of 2L device buffers [N][ld] (tests).
+        ``share`` = (offset, count), data-parallel runs: the BPR term covers this rank's rows of the step only; the
+        InfoNCE terms (which couple all the step's unique rows) are formed by every rank on the whole step with
+        weight cl_rate / world, so the all-reduced gradient carries them exactly once."""
         if max(n_uu, n_ui) > self.max_unique:
             raise ValueError("more unique rows in the batch than the InfoNCE workspace holds")
         L = float(self.L)
+        lo, cnt = (0, B) if share is None else share
+        cl_rate = self.cl_rate if self.dp is None else self.cl_rate / self.dp.world
         self.row_mask.fill_bytes(0, stream)
         capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)
         self._encode_three(noises, stream, self.row_mask)
         self.dOut.fill_bytes(0, stream)
         self.d_loss.fill_bytes(0, stream)
         # the InfoNCE rows (unique batch users / positive items) are a subset of the rows marked above
-        capi.bpr_batch_loss_grad(self.Sm, L, self.nu, self.n, self.ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
-                                 self.dOut, self.d_loss, stream, d_row_mask=self.row_mask)
+        if share is not None:
+            d_u, d_i, d_j = (capi._dp(p) + 4 * lo for p in (d_u, d_i, d_j))
+        if cnt:
+            capi.bpr_batch_loss_grad(self.Sm, L, self.nu, self.n, self.ld, d_u, d_i, d_j, cnt,
+                                     self.loss_eps, self.reg, self.dOut, self.d_loss, stream, d_row_mask=self.row_mask)
         cl = self.d_loss.ptr + 8
-        capi.info_nce_loss_grad(self.S1, self.S2, L, d_uniq_users, n_uu, self.ld, self.tau, self.cl_rate, self.ws,
+        capi.info_nce_loss_grad(self.S1, self.S2, L, d_uniq_users, n_uu, self.ld, self.tau, cl_rate, self.ws,
                                 self.dOut, cl, stream)
-        capi.info_nce_loss_grad(self.S1, self.S2, L, d_uniq_items, n_ui, self.ld, self.tau, self.cl_rate, self.ws,
+        capi.info_nce_loss_grad(self.S1, self.S2, L, d_uniq_items, n_ui, self.ld, self.tau, cl_rate, self.ws,
                                 self.dOut, cl, stream)
         # dE0 = (1/L) sum_{k=1..L} A^k dOut :  W_0 = dOut, W_k = dOut + A W_{k-1}, G = A W_{L-1}
         x = self.dOut
@@ -329,6 +343,9 @@ class SimGCLTrainer:
             x = y
         g = self.B if x is self.A else self.A
         capi.spmm_csr(self.plan, x, g, self.ld, stream=stream, d_x_row_mask=self.row_mask if self.L == 1 else None)
+        if self.dp is not None:
+            self.dp.all_reduce(g)
+            self.dp.all_reduce(self.d_loss.head_view(1))      # rec term: shares add up; the cl term is whole on every rank
         capi.adam_step(self.E, self.m, self.v, g, self.n * self.ld, 1.0 / L, self.adam_alpha(), float(self.b1),
                        float(self.b2), float(self.adam_eps), stream)
         self.b1p = np.float32(self.b1p * self.b1); self.b2p = np.float32(self.b2p * self.b2)
@@ -404,6 +421,7 @@ class NGCFTrainer:
         self.d_loss = DeviceBuffer.zeros(1, np.float64)
         self.row_mask = DeviceBuffer.zeros((self.n + 31) // 32, np.uint32)
         self.step_no = 0
+        self.dp = None          # dist.BatchParallel
 
     def forward(self, training: bool, masks=None, stream=None, last_rows=None):
         """fills E_1, E_2, side, gate, inv and the wide table All = [E_0 | z_1 | z_2].  ``last_rows`` (training):
@@ -423,11 +441,13 @@ class NGCFTrainer:
     def train_step_async(self, d_u, d_i, d_j, B: int, masks=None, stream=None):
         n, d, ld = self.n, self.d, self.ld
         self.row_mask.fill_bytes(0, stream)
-        capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)
+        if B:
+            capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)
         self.forward(True, masks, stream, last_rows=self.row_mask)
         self.dAll.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
-        capi.bpr_batch_loss_grad(self.All, 1.0, self.nu, n, self.wide_ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
-                                 self.dAll, self.d_loss, stream, d_row_mask=self.row_mask)
+        if B:
+            capi.bpr_batch_loss_grad(self.All, 1.0, self.nu, n, self.wide_ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
+                                     self.dAll, self.d_loss, stream, d_row_mask=self.row_mask)
         dnext = None
         for k in (1, 0):
             dE = self.dEa if k == 1 else self.dEb
@@ -440,6 +460,11 @@ class NGCFTrainer:
                           d_x_row_mask=self.row_mask if k == 1 else None)
             dnext = dE
         capi.copy_cols(dnext, ld, self.dAll, self.wide_ld, 0, n, d, True, stream)                    # + ego block of the concat
+        if self.dp is not None:     # table gradient + the four d x d weight gradients ("all-reduce for the dense layers")
+            self.dp.all_reduce(dnext); self.dp.all_reduce(self.d_loss)
+            for pair in self.gW:
+                for gw in pair:
+                    self.dp.all_reduce(gw)
         self.optE.step(dnext, stream=stream)
         for k in range(2):
             for t in range(2):

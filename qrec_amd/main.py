@@ -12,6 +12,8 @@ def main(argv=None):
     if len(argv) != 1:
         print("usage: python -m qrec_amd.main <path/to/model.conf>")
         return 2
+    from .dist import init_from_env
+    init_from_env()          # one process per GPU under torch.distributed.run; nothing happens otherwise
     start = time.time()
     QRec(ModelConf(argv[0])).execute()
     print("Running time: %f s" % (time.time() - start))

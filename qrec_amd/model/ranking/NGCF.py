@@ -30,11 +30,13 @@ class NGCF(GraphRecommender):
     def trainModel(self):
         quiet = os.environ.get("QREC_QUIET") == "1"
         tr = self.trainer
+        dp = tr.dp = self.data_parallel()              # one process per GPU: a step = batch_size x world rows, this rank's share
+        step_rows = self.batch_size * (dp.world if dp else 1)
         for epoch, (u, i, j) in enumerate(self.iter_epoch_samples(self.maxEpoch)):
             d_u, d_i, d_j = DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i), DeviceBuffer.from_numpy(j)
-            for n, s in enumerate(range(0, u.size, self.batch_size)):
-                B = min(self.batch_size, u.size - s)
-                tr.train_step_async(d_u.ptr + 4 * s, d_i.ptr + 4 * s, d_j.ptr + 4 * s, B)
+            for n, s in enumerate(range(0, u.size, step_rows)):
+                lo, B = self.step_share(dp, min(step_rows, u.size - s))
+                tr.train_step_async(d_u.ptr + 4 * (s + lo), d_i.ptr + 4 * (s + lo), d_j.ptr + 4 * (s + lo), B)
                 if not quiet:
                     print("training:", epoch + 1, "batch", n, "loss:", tr.loss())
         # the reference scores with sess.run(self.test, isTraining=0) per user (NGCF.py:65-69);

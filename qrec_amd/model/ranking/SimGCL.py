@@ -38,7 +38,12 @@ class SimGCL(GraphRecommender):
         self.item_embeddings = xavier_uniform((self.num_items, self.emb_size))
         self.trainer = SimGCLTrainer(self.user_embeddings, self.item_embeddings, self.create_joint_sparse_adjaceny(),
                                      self.n_layers, self.lRate, self.regU, self.cl_rate, self.eps,
-                                     seed=int(os.environ.get("QREC_SEED", "0")), max_unique=max(self.batch_size, 64))
+                                     seed=int(os.environ.get("QREC_SEED", "0")), max_unique=max(self._step_rows(), 64))
+
+    def _step_rows(self) -> int:
+        """rows of the batch stream one training step covers: batch_size, times the world size in a multi-GPU run"""
+        dp = self.data_parallel()
+        return self.batch_size * (dp.world if dp else 1)
 
     def saveModel(self):
         self.bestU, self.bestV = self.U, self.V
@@ -50,23 +55,27 @@ class SimGCL(GraphRecommender):
         two epochs with the GPU idle."""
         u, i, j = self.sample_epoch_pairwise()
         nu = self.num_users
-        starts = list(range(0, u.size, self.batch_size))
-        uu = [unique_first_appearance(u[s:s + self.batch_size]) for s in starts]
-        vv = [unique_first_appearance(i[s:s + self.batch_size]) + nu for s in starts]
+        rows = self._step_rows()
+        starts = list(range(0, u.size, rows))
+        uu = [unique_first_appearance(u[s:s + rows]) for s in starts]
+        vv = [unique_first_appearance(i[s:s + rows]) + nu for s in starts]
         off_u = np.concatenate([[0], np.cumsum([x.size for x in uu])]); off_v = np.concatenate([[0], np.cumsum([x.size for x in vv])])
         return (u, i, j, starts, np.concatenate(uu).astype(np.int32), off_u, np.concatenate(vv).astype(np.int32), off_v)
 
     def trainModel(self):
         quiet = os.environ.get("QREC_QUIET") == "1"
         tr = self.trainer
+        dp = tr.dp = self.data_parallel()
+        rows = self._step_rows()
         for epoch, (u, i, j, starts, uu, off_u, vv, off_v) in enumerate(self.iter_epoch_samples(self.maxEpoch, self._draw_epoch)):
             d_u, d_i, d_j = DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i), DeviceBuffer.from_numpy(j)
             d_uu, d_vv = DeviceBuffer.from_numpy(uu), DeviceBuffer.from_numpy(vv)
             for n, s in enumerate(starts):
-                B = min(self.batch_size, u.size - s)
+                B = min(rows, u.size - s)
                 tr.train_step_async(d_u.ptr + 4 * s, d_i.ptr + 4 * s, d_j.ptr + 4 * s, B,
                                     d_uu.ptr + 4 * int(off_u[n]), int(off_u[n + 1] - off_u[n]),
-                                    d_vv.ptr + 4 * int(off_v[n]), int(off_v[n + 1] - off_v[n]))
+                                    d_vv.ptr + 4 * int(off_v[n]), int(off_v[n + 1] - off_v[n]),
+                                    share=self.step_share(dp, B) if dp else None)
                 if not quiet:
                     l, rec_l, cl_l = tr.losses()
                     print("training:", epoch + 1, "batch", n, "total_loss:", l, "rec_loss:", rec_l, "cl_loss", cl_l)

@@ -15,6 +15,9 @@ from .config import OptionConf
 class FileIO:
     @staticmethod
     def writeFile(dir: str, file: str, content, op: str = "w") -> None:
+        from ..dist import is_output_rank
+        if not is_output_rank():       # multi-GPU run: the ranks hold identical results, rank 0 writes them
+            return
         os.makedirs(dir, exist_ok=True)
         with open(dir + file, op) as fh:
             fh.writelines(content)

@@ -1,0 +1,53 @@
+"""Worker of test_gpu_graph.py::test_graph_models_data_parallel_two_ranks_equal_one_rank_with_double_batch (not a test
+module).  ``python -m torch.distributed.run --nproc-per-node 2 tests/graph_dp_worker.py <Model> <batch> <outdir>``
+trains the drop-in class one process per rank (both on device 0 over gloo under QREC_DIST_TEST_ONE_DEVICE=1); run
+directly it is the single-GPU run.  Every rank dumps its tables, measures and printed losses."""
+import io
+import os
+import random
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from helpers import conf_from_text, load_golden, rows_from_golden  # noqa: E402
+from qrec_amd.QRec import resolve_model  # noqa: E402
+from qrec_amd.dist import init_from_env  # noqa: E402
+
+EXTRA = {"LightGCN": {"LightGCN": "-n_layer 2"}, "NGCF": {}, "SimGCL": {"SimGCL": "-n_layer 2 -lambda 0.5 -eps 0.1"}}
+
+
+def main():
+    name, batch, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    seed = int(os.environ["QREC_SEED"])
+    world = init_from_env()
+    if world == 1:
+        random.seed(seed); np.random.seed(seed)
+    rank = int(os.environ.get("RANK", "0"))
+    meta, z = load_golden("bpr_filmtrust")
+    train, test = rows_from_golden(z)
+    conf = conf_from_text(meta["conf"])
+    conf["model.name"] = name; conf["num.factors"] = "16"; conf["num.max.epoch"] = "2"; conf["batch_size"] = str(batch)
+    conf["learnRate"] = "-init 0.002 -max 1"; conf["reg.lambda"] = "-u 0.001 -i 0.001 -b 0.2 -s 0.2"
+    conf["item.ranking"] = "on -topN 10,20"; conf["output.setup"] = "on -dir " + os.path.join(out, "results") + "/"
+    for k, v in EXTRA[name].items():
+        conf[k] = v
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        m = resolve_model(name)(conf, train, test)
+        measure = m.execute()
+    lines = [l for l in buf.getvalue().splitlines() if "loss:" in l]
+    losses = [float(l.split("loss:")[1].split()[0]) for l in lines]
+    E = m.trainer.E[0] if isinstance(m.trainer.E, list) else m.trainer.E
+    np.savez(os.path.join(out, f"rank{rank}.npz"), U=m.U, V=m.V, E=E.numpy(), losses=np.array(losses),
+             measure=np.array([float(x.split(":")[1]) for x in measure if ":" in x]))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -88,3 +88,52 @@ def test_two_rank_step_equals_definition():
         np.testing.assert_allclose(Qr, Q, rtol=1e-12, atol=1e-15)       # replicas agree and equal the definition
         np.testing.assert_allclose(Pr, P[lo:hi], rtol=1e-12, atol=1e-15)
     assert not np.allclose(Q, Q0)
+
+
+# ---- graph models: batch-sharded data parallelism (qrec_amd.dist.BatchParallel) -----------------------------------
+def _graph_problem():
+    import scipy.sparse as sp
+    from oracle import tfmodels as T
+    from qrec_amd.graph import joint_norm_adjacency
+    d = make_dataset("tiny")
+    indptr, idx, val = joint_norm_adjacency(d["n_users"], d["n_items"], d["train_u"], d["train_i"])
+    n = d["n_users"] + d["n_items"]
+    A = sp.csr_matrix((val, idx, indptr), shape=(n, n))
+    rng = np.random.default_rng(5)
+    U0 = (rng.standard_normal((d["n_users"], 8)) * 0.1).astype(np.float32)
+    V0 = (rng.standard_normal((d["n_items"], 8)) * 0.1).astype(np.float32)
+    B = 96
+    u = rng.integers(0, d["n_users"], B); i = rng.integers(0, d["n_items"], B); j = rng.integers(0, d["n_items"], B)
+    return T.LightGCN(U0, V0, A, 2, lr=0.01, reg=1e-3), u, i, j
+
+
+def _graph_worker(rank, world, port, out):
+    from qrec_amd.dist import BatchParallel, is_output_rank
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dp = BatchParallel(device_index=0)
+    model, u, i, j = _graph_problem()
+    steps = []
+    for step in range(2):
+        lo, cnt = dp.share(u.size)
+        loss, g = model.loss_and_grad(u[lo:lo + cnt], i[lo:lo + cnt], j[lo:lo + cnt])     # this rank's share of the step
+        g = dp.all_reduce_host(g); loss = float(dp.all_reduce_host(np.array([loss], np.float64))[0])
+        model.opt.step(model.E, g)                                                          # same update on every replica
+        steps.append(loss)
+    out[rank] = (dp.share(u.size), steps, model.E.copy(), is_output_rank())
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_graph_batch_parallel_equals_the_whole_step():
+    """two ranks, each with a share of the step's rows + gradient all-reduce == one process on the whole step"""
+    world = 2
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_graph_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    model, u, i, j = _graph_problem()
+    want = [model.train_step(u, i, j) for _ in range(2)]
+    shares = [out[r][0] for r in range(world)]
+    assert shares[0][0] == 0 and shares[0][1] + shares[1][1] == u.size and shares[1][0] == shares[0][1]
+    assert np.array_equal(out[0][2], out[1][2])                         # replicas identical
+    np.testing.assert_allclose(out[0][1], want, rtol=1e-5)
+    np.testing.assert_allclose(out[0][2], model.E, rtol=0, atol=2e-5)
+    assert out[0][3] is True and out[1][3] is False                     # rank 0 alone writes result files

@@ -639,3 +639,32 @@ def test_buir_class_runs_stock_conf_shape_and_replays_the_generator():
                 neg = random.choice(items)
     want_state = random.getstate()
     assert np.array_equal(capi.state_from_python(want_state), capi.state_from_python(m._final_py_state))
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["LightGCN", "NGCF", "SimGCL"])
+def test_graph_models_data_parallel_two_ranks_equal_one_rank_with_double_batch(name, tmp_path):
+    """one process per GPU, every step's rows split over the ranks, ONE all-reduce of the dense
+    table gradient (+ NGCF's weight gradients) per step, test users sharded at evaluation.  Two real processes (both on
+    device 0, gloo) with batch_size B must give what one process gives with batch_size 2B -- same batch stream, same
+    initial tables, same dropout / noise streams -- up to fp32 summation order, and the replicas must stay IDENTICAL."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = os.path.join(root, "tests", "graph_dp_worker.py")
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    env = dict(os.environ, QREC_SEED="11", QREC_DIST_TEST_ONE_DEVICE="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r1 = subprocess.run([sys.executable, worker, name, "2048", str(one)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-3000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29547", worker, name, "1024", str(two)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-3000:]
+    a, b0, b1 = np.load(one / "rank0.npz"), np.load(two / "rank0.npz"), np.load(two / "rank1.npz")
+    for k in ("U", "V", "E", "losses", "measure"):
+        assert np.array_equal(b0[k], b1[k]), k                      # replicas bit-identical, same measures on both ranks
+    assert a["losses"].size == b0["losses"].size > 0
+    np.testing.assert_allclose(b0["losses"], a["losses"], rtol=2e-5)
+    assert rel_err(b0["E"], a["E"]) < 2e-4 and rel_err(b0["U"], a["U"]) < 2e-4 and rel_err(b0["V"], a["V"]) < 2e-4
+    np.testing.assert_allclose(b0["measure"], a["measure"], atol=2e-3)
+    assert len(os.listdir(two / "results")) == len(os.listdir(one / "results"))      # rank 0 alone wrote the result files
