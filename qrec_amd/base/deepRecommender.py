@@ -67,19 +67,6 @@ class DeepRecommender(IterativeRecommender):
                     pending = pool.submit(draw)
                 yield sample
 
-    def data_parallel(self):
-        """dist.BatchParallel when the run was started one process per GPU (qrec_amd.main under torch.distributed.run),
-        else None.  Looked up at training time, never in a constructor (the device is bound per process)."""
-        if not hasattr(self, "_dp"):
-            from ..dist import BatchParallel
-            self._dp = BatchParallel.from_env()
-        return self._dp
-
-    @staticmethod
-    def step_share(dp, n_rows: int):
-        """(offset, count): this rank's share of a step's rows"""
-        return dp.share(n_rows) if dp else (0, n_rows)
-
     def next_batch_pairwise(self):
         """Generator with the reference's signature: yields (u_idx, i_idx, j_idx) lists."""
         u, i, j = self.sample_epoch_pairwise()

@@ -108,6 +108,19 @@ class IterativeRecommender(Recommender):
             ranker = self._ranker = DeviceRanker(U, V, self.data.rated_csr())
         return ranker
 
+    def data_parallel(self):
+        """dist.BatchParallel when the run was started one process per GPU (qrec_amd.main under torch.distributed.run),
+        else None.  Looked up at training time, never in a constructor (the device is bound per process)."""
+        if not hasattr(self, "_dp"):
+            from ..dist import BatchParallel
+            self._dp = BatchParallel.from_env()
+        return self._dp
+
+    @staticmethod
+    def step_share(dp, n_rows: int):
+        """(offset, count): this rank's share of a step's rows"""
+        return dp.share(n_rows) if dp else (0, n_rows)
+
     def rank_measure_all_test_users(self, top, N):
         """Measure.rankingMeasure(testSet_u, recList, top) (base/recommender.py:167, util/measure.py:24-49) without
         the recList: per-user hit counts and DCG sums are taken from the top-N lists on the device
@@ -134,7 +147,7 @@ class IterativeRecommender(Recommender):
                 warm_uid=np.fromiter((self.data.user[users[k]] for k in warm_pos), dtype=np.int32, count=len(warm_pos)))
         cuts = sorted({min(n, N, self.num_items) for n in top})
         per_n = {n: (np.zeros(len(users), np.int64), np.zeros(len(users), np.float64)) for n in top}
-        dp = self.data_parallel() if hasattr(self, "data_parallel") else None
+        dp = self.data_parallel()
         if cache["warm_uid"].size:
             ranker = self._device_ranker(U, V)
             if ranker.test is None:

@@ -54,6 +54,15 @@ class BPR(IterativeRecommender):
         print("Preparing item sets...")
         pos = self.data.positive_csr()           # PositiveSet, BPR.py:21-25
         u, i = pos.row_ids(), pos.indices
+        dp = self.data_parallel()
+        if dp is not None:       # one process per GPU: this rank trains its block of users (qrec_amd/dist.py)
+            if self.mode != "throughput":
+                print("exact mode is single-GPU only: run with QREC_MODE=throughput on several GPUs")
+                raise SystemExit(-1)
+            from ...dist import user_block
+            lo, hi = user_block(pos.indptr.size - 1, dp.world, dp.rank)
+            u, i = u[pos.indptr[lo]:pos.indptr[hi]], i[pos.indptr[lo]:pos.indptr[hi]]
+            self.sampler_seed += 7919 * dp.rank
         print("training...")
         tables = DeviceTables(self.P, self.Q, self.table_dtype)
         schedule = self.schedule
@@ -63,8 +72,8 @@ class BPR(IterativeRecommender):
         sgd = BprSgd(tables, u, i, pos, schedule=schedule)
         n_items = len(self.data.item)
         epoch = 0
-        if self.mode == "throughput" and self.ranking.isMainOn():
-            self._train_throughput_pipelined(sgd)
+        if self.mode == "throughput" and (self.ranking.isMainOn() or dp is not None):
+            self._train_throughput_pipelined(sgd, dp=dp)
             self.P, self.Q = tables.download(np.float64)
             return
         if self.mode == "throughput":
@@ -88,15 +97,33 @@ class BPR(IterativeRecommender):
                 break
         self.P, self.Q = tables.download(np.float64)
 
-    def _train_throughput_pipelined(self, sgd, depth: int = 3):
+    def _train_throughput_pipelined(self, sgd, depth: int = 3, dp=None):
         """Throughput mode without a host round trip per epoch: the epoch's loss (BPR.py:40,53), isConverged and
         updateLearningRate (base/iterativeRecommender.py:56-63,88-104) run on the device (qrec_epoch_close); the
         host enqueues epochs ``depth`` ahead and prints the reference's per-epoch line from the device log as the
         epochs retire.  Epochs enqueued past the converged one are no-ops on the device, so the tables are
         those of the converged epoch exactly as if the loop had stopped there.  (The reference's per-epoch
-        ``shuffle(trainingData)`` has no effect on this model's visiting order and is not replayed here.)"""
+        ``shuffle(trainingData)`` has no effect on this model's visiting order and is not replayed here.)
+        ``dp`` (one process per GPU): every rank keeps both tables whole and trains its own users' triplets; after the
+        SGD kernel the replicas are reconciled by summing the ranks' deltas (users' rows: disjoint, exact; item rows:
+        every rank's updates kept -- qrec_amd/dist.py), sum(-log sigma) is added over the ranks, and every rank's
+        device-side driver then takes the same decision on identical tables."""
         from ...engine import balanced_chunk
         chunk = balanced_chunk(sgd.n)
+        between = None
+        if dp is not None:
+            import torch
+            import torch.distributed as dist
+            from ...dist import ReplicatedTableSync
+            syncs = [ReplicatedTableSync(torch.as_tensor(t, device=dp.device), dp.group) for t in (sgd.t.P, sgd.t.Q)]
+            nll = torch.as_tensor(sgd.d_stats, device=dp.device)[0:1]
+
+            def between(stage):
+                if stage == "tables":
+                    for s in syncs:
+                        s.sync()
+                else:
+                    dist.all_reduce(nll, group=dp.group)
         sgd.start_device_driver(self.lRate, log_capacity=self.maxEpoch)
         sgd.prefetch_negatives_device(self.sampler_seed, 0)
         closed = []
@@ -119,7 +146,7 @@ class BPR(IterativeRecommender):
         done, retired = False, 0
         for epoch in range(self.maxEpoch):
             sgd.take_prefetched_negatives(epoch)
-            sgd.epoch_device_async(self.regU, self.regI, self.maxLRate, tol=1e-3, chunk=chunk)
+            sgd.epoch_device_async(self.regU, self.regI, self.maxLRate, tol=1e-3, chunk=chunk, between=between)
             sgd.prefetch_negatives_device(self.sampler_seed, epoch + 1)      # released under this epoch's SGD kernel
             ev = capi.Event(); ev.record(); closed.append(ev)
             if epoch >= depth:

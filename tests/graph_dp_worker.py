@@ -17,7 +17,8 @@ from helpers import conf_from_text, load_golden, rows_from_golden  # noqa: E402
 from qrec_amd.QRec import resolve_model  # noqa: E402
 from qrec_amd.dist import init_from_env  # noqa: E402
 
-EXTRA = {"LightGCN": {"LightGCN": "-n_layer 2"}, "NGCF": {}, "SimGCL": {"SimGCL": "-n_layer 2 -lambda 0.5 -eps 0.1"}}
+EXTRA = {"LightGCN": {"LightGCN": "-n_layer 2"}, "NGCF": {}, "SimGCL": {"SimGCL": "-n_layer 2 -lambda 0.5 -eps 0.1"},
+         "BPR": {"num.max.epoch": "60", "learnRate": "-init 0.02 -max 0.02", "reg.lambda": "-u 0.01 -i 0.01 -b 0.2 -s 0.2"}}
 
 
 def main():
@@ -39,10 +40,14 @@ def main():
     with redirect_stdout(buf):
         m = resolve_model(name)(conf, train, test)
         measure = m.execute()
-    lines = [l for l in buf.getvalue().splitlines() if "loss:" in l]
-    losses = [float(l.split("loss:")[1].split()[0]) for l in lines]
-    E = m.trainer.E[0] if isinstance(m.trainer.E, list) else m.trainer.E
-    np.savez(os.path.join(out, f"rank{rank}.npz"), U=m.U, V=m.V, E=E.numpy(), losses=np.array(losses),
+    if name == "BPR":        # "... epoch k: loss = x, delta_loss = ..." (base/iterativeRecommender.py:98-99)
+        losses = [float(l.split("loss = ")[1].split(",")[0]) for l in buf.getvalue().splitlines() if "loss = " in l]
+        U, V, E = m.P, m.Q, np.concatenate([m.P, m.Q])
+    else:
+        losses = [float(l.split("loss:")[1].split()[0]) for l in buf.getvalue().splitlines() if "loss:" in l]
+        E = m.trainer.E[0] if isinstance(m.trainer.E, list) else m.trainer.E
+        U, V, E = m.U, m.V, E.numpy()
+    np.savez(os.path.join(out, f"rank{rank}.npz"), U=U, V=V, E=E, losses=np.array(losses),
              measure=np.array([float(x.split(":")[1]) for x in measure if ":" in x]))
     if world > 1:
         import torch.distributed as dist
