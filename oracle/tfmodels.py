@@ -473,3 +473,163 @@ class BUIR:
         online = self._mean_prop(adj, self.E)
         q = np.tanh(online @ self.W + self.b, dtype=np.float32)
         return q[:self.nu], q[self.nu:], online[:self.nu], online[self.nu:]
+
+
+# ======================================================================================
+# SEPT  (model/ranking/SEPT.py:19-323) -- social data, four LightGCN-style views with per-layer
+# l2-normalisation, tri-training pseudo-labels (top-k of averaged softmax rows), neighbour-
+# discrimination contrastive loss with several positives, two Adam optimizers.
+# The graph builders are pure scipy in the reference and ARE pinned to it
+# (tests/golden/sept_graphs_filmtrust.npz); the TF arithmetic is restated (unpinned, see header).
+# ======================================================================================
+def sept_row_normalised(M: sp.spmatrix) -> sp.csr_matrix:
+    """``normalization`` of SEPT.py:53-59 / the tail of get_adj_mat (:107-113): D^-1/2 M D^-1/2 with D = ROW sums
+    (M need not be symmetric), inf -> 0, in M's dtype."""
+    rowsum = np.array(M.sum(1))
+    with np.errstate(divide="ignore"):
+        d_inv = np.power(rowsum, -0.5).flatten()
+    d_inv[np.isinf(d_inv)] = 0.0
+    D = sp.diags(d_inv)
+    return D.dot(M).dot(D).tocsr()
+
+
+def sept_social_views(n_users: int, n_items: int, uid, iid, follower, followee):
+    """get_birectional_social_matrix + buildSparseRatingMatrix + get_social_related_views (SEPT.py:32-67):
+    B = A o A (A = follower->followee counts, so B is A for 0/1 data -- the name notwithstanding, nothing is made
+    bidirectional); friend view = (B B) o B + I, sharing view = (R R^T) o B + I, both row-normalised.
+    Returns (social, sharing) CSR float64 (the reference converts to float32 when it builds the tensors, :117)."""
+    follower, followee = np.asarray(follower), np.asarray(followee)
+    tmp = sp.csr_matrix((np.ones_like(follower, dtype=np.float32), (follower, followee)), shape=(n_users, n_users))
+    B = tmp.multiply(tmp)
+    R = sp.coo_matrix((np.ones(len(uid), np.float32), (np.asarray(uid), np.asarray(iid))), shape=(n_users, n_items), dtype=np.float32)
+    social = B.dot(B).multiply(B) + sp.eye(n_users)
+    sharing = R.dot(R.T).multiply(B) + sp.eye(n_users)
+    return sept_row_normalised(social), sept_row_normalised(sharing)
+
+
+def sept_sub_adjacency(n_users: int, n_items: int, uid, iid, follower, followee, keep_idx=None, skeep_idx=None):
+    """get_adj_mat (SEPT.py:79-114).  With keep lists (is_subgraph, drop_rate > 0): kept rating edges both ways plus
+    the kept follow edges, squared, in the user-user block, row-normalised; without: the plain joint adjacency."""
+    n = n_users + n_items
+    uid, iid = np.asarray(uid), np.asarray(iid)
+    if keep_idx is not None:
+        u, i = uid[keep_idx], iid[keep_idx]
+        tmp = sp.csr_matrix((np.ones_like(u, dtype=np.float32), (u, n_users + i)), shape=(n, n))
+        adj = tmp + tmp.T
+        fo, fe = np.asarray(follower)[skeep_idx], np.asarray(followee)[skeep_idx]
+        soc = sp.csr_matrix((np.ones_like(fo, dtype=np.float32), (fo, fe)), shape=(n, n))
+        adj = adj + soc.multiply(soc)
+    else:
+        tmp = sp.csr_matrix((np.ones_like(uid, dtype=np.float32), (uid, iid + n_users)), shape=(n, n))
+        adj = tmp + tmp.T
+    return sept_row_normalised(adj)
+
+
+def l2_normalize_bwd(x, inv, d):
+    """gradient of z = x * rsqrt(max(sum x^2, 1e-12)) given dz: (dz - z (z.dz)) * inv (rows at the clamp are all-zero
+    rows here, where this reduces to dz * inv as TF's does)"""
+    f = np.float32
+    z = (x * inv[:, None]).astype(f)
+    return ((d - z * (z * d).sum(1, dtype=f)[:, None]) * inv[:, None]).astype(f)
+
+
+def top_k_rows(score, k):
+    """tf.math.top_k(score, k)[1]: the k largest per row, equal values in index order"""
+    return np.argsort(-score, axis=1, kind="stable")[:, :k]
+
+
+def neighbour_discrimination(z, a, pos, tau=np.float32(0.1)):
+    """SEPT.neighbor_discrimination (SEPT.py:233-248) on normalised rows z (one encoder) and a (the augmented view),
+    pos[i] = the row's pseudo-labelled positives:  -sum_i log( sum_{k in pos[i]} e^{z_i.a_k/tau} / sum_j e^{z_i.a_j/tau} ).
+    Returns (loss, dz, da), hand-derived."""
+    f = np.float32
+    E = np.exp((z @ a.T).astype(f) / f(tau), dtype=f)
+    ttl = E.sum(1, dtype=f)
+    Ep = np.take_along_axis(E, pos, 1)
+    ps = Ep.sum(1, dtype=f)
+    loss = float(-np.log(ps / ttl, dtype=f).sum(dtype=np.float64))
+    G = (E / ttl[:, None]).astype(f)
+    np.put_along_axis(G, pos, np.take_along_axis(G, pos, 1) - Ep / ps[:, None], 1)
+    return loss, (G @ a).astype(f) / f(tau), (G.T @ z).astype(f) / f(tau)
+
+
+class SEPT:
+    """model/ranking/SEPT.py restated (LightGCN-structured views, the NGCF-structured block is commented out in the
+    reference).  Variables Uv, Vv; every view starts from Uv/2, Vv/2 (:129-130)."""
+
+    def __init__(self, U0, V0, adj, social, sharing, n_layers, lr, reg, ss_rate, ins_cnt):
+        f = np.float32
+        self.nu, self.ni = U0.shape[0], V0.shape[0]
+        self.W = np.concatenate([U0, V0]).astype(f)                    # the two tf.Variables, stacked
+        self.adj, self.social, self.sharing = (m.astype(f).tocsr() for m in (adj, social, sharing))
+        self.L, self.reg, self.ss_rate, self.k = n_layers, float(reg), f(ss_rate), int(ins_cnt)
+        self.opt1, self.opt2 = AdamTF114(self.W.shape, lr), AdamTF114(self.W.shape, lr)   # v1_opt / v2_opt (:267-270)
+
+    # ---- one view: x_0 = X0; x_k = M x_{k-1}; S = x_0 + sum_k l2_normalize(x_k)   (SEPT.py:142-160, 205-211)
+    def chain(self, M, X0):
+        xs, invs, S = [X0], [], X0.copy()
+        for _ in range(self.L):
+            x = M.dot(xs[-1]).astype(np.float32)
+            z, inv = l2_normalize_rows(x)
+            S += z; xs.append(x); invs.append(inv)
+        return S, xs, invs
+
+    def chain_bwd(self, M, xs, invs, dS):
+        g = None
+        for k in range(self.L, 0, -1):
+            nb = l2_normalize_bwd(xs[k], invs[k - 1], dS)
+            g = nb if g is None else (nb + M.T.dot(g)).astype(np.float32)
+        return (dS + M.T.dot(g)).astype(np.float32)
+
+    def rec_embeddings(self):
+        """(rec_user_embeddings, rec_item_embeddings): what the reference ranks with (SEPT.py:207-208, 307)"""
+        S, _, _ = self.chain(self.adj, (self.W / np.float32(2)).astype(np.float32))
+        return S[:self.nu], S[self.nu:]
+
+    def loss_and_grad(self, u_idx, i_idx, j_idx, sub_adj=None):
+        """sub_adj None: rec_loss only (epochs <= maxEpoch/3); else rec_loss + ss_rate * neighbor_dis_loss.
+        Returns (rec_loss, neighbor_dis_loss, dW, pseudo-label index lists)."""
+        f = np.float32
+        nu = self.nu
+        E0 = (self.W / f(2)).astype(f)
+        Se, xe, ie = self.chain(self.adj, E0)
+        ui, ii, ji = np.asarray(u_idx), np.asarray(i_idx) + nu, np.asarray(j_idx) + nu
+        rec, du, di, dj = bpr_batch_loss_and_grads(Se[ui], Se[ii], Se[ji], 0.0)
+        rec += self.reg * 0.5 * float((E0.astype(np.float64) ** 2).sum())            # regU (l2(U/2) + l2(V/2)), :252
+        dSe = np.zeros_like(Se)
+        np.add.at(dSe, ui, du); np.add.at(dSe, ii, di); np.add.at(dSe, ji, dj)
+        dE0 = f(self.reg) * E0
+        nd, labels = 0.0, None
+        if sub_adj is not None:
+            sub = sub_adj.astype(f).tocsr()
+            Sf, xf, if_ = self.chain(self.social, E0[:nu]); Sh, xh, ih = self.chain(self.sharing, E0[:nu])
+            Sg, xg, ig = self.chain(sub, E0)
+            rows = unique_first_appearance(u_idx)
+            a, ra = l2_normalize_rows(Sg[rows])
+            zs, rs = zip(*(l2_normalize_rows(S[rows]) for S in (Sf, Sh, Se)))
+
+            def prob(z):                                                               # label_prediction, :214-224
+                x = (z @ a.T).astype(f)
+                e = np.exp(x - x.max(1, keepdims=True), dtype=f)
+                return (e / e.sum(1, dtype=f)[:, None]).astype(f)
+            p_soc, p_sh, p_rec = (prob(z) for z in zs)
+            labels = [top_k_rows((p_sh + p_rec) / f(2), self.k), top_k_rows((p_soc + p_rec) / f(2), self.k),
+                      top_k_rows((p_soc + p_sh) / f(2), self.k)]                     # f_pos, sh_pos, r_pos (:258-260)
+            da = np.zeros_like(a); dz = []
+            for z, pos in zip(zs, labels):
+                l, dzi, dai = neighbour_discrimination(z, a, pos)
+                nd += l; dz.append(dzi); da += dai
+            dSf, dSh, dSg = np.zeros_like(Sf), np.zeros_like(Sh), np.zeros_like(Sg)
+            w = self.ss_rate
+            dSf[rows] = w * l2_normalize_bwd(Sf[rows], rs[0], dz[0]); dSh[rows] = w * l2_normalize_bwd(Sh[rows], rs[1], dz[1])
+            dSe[rows] += w * l2_normalize_bwd(Se[rows], rs[2], dz[2]); dSg[rows] = w * l2_normalize_bwd(Sg[rows], ra, da)
+            dE0[:nu] += self.chain_bwd(self.social, xf, if_, dSf) + self.chain_bwd(self.sharing, xh, ih, dSh)
+            dE0 += self.chain_bwd(sub, xg, ig, dSg)
+        dE0 += self.chain_bwd(self.adj, xe, ie, dSe)
+        return rec, nd, (dE0 / f(2)).astype(f), labels
+
+    def train_step(self, u_idx, i_idx, j_idx, sub_adj=None):
+        """returns (rec_loss, ss_rate * neighbor_dis_loss) as the reference prints them (SEPT.py:292, 301)"""
+        rec, nd, g, _ = self.loss_and_grad(u_idx, i_idx, j_idx, sub_adj)
+        (self.opt1 if sub_adj is None else self.opt2).step(self.W, g)
+        return rec, float(self.ss_rate) * nd

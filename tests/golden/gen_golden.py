@@ -346,13 +346,55 @@ def case_sgl_subgraph(tmp):
                 n_items=len(m.data.item), n_train=len(m.data.trainingData), drop_rate=m.drop_rate)
 
 
+def case_sept_graphs(tmp):
+    """model/ranking/SEPT.py:32-114 graph builders (pure scipy + random.sample) on FilmTrust + trust.txt, and what
+    SocialRecommender.__init__ (base/socialRecommender.py:6-41) keeps of the relation list."""
+    from QRec import QRec
+    from util.config import ModelConf
+    from model.ranking.SEPT import SEPT
+    conf = os.path.join(tmp, "sept.conf")
+    write_conf(conf, ratings="./dataset/FilmTrust/trainset.txt", social="./dataset/FilmTrust/trust.txt",
+               ratings__setup="-columns 0 1 2", social__setup="-columns 0 1 2",
+               model__name="SEPT", evaluation__setup="-testSet ./dataset/FilmTrust/testset.txt -b 1",
+               item__ranking="on -topN 10", num__factors="8", num__max__epoch="3", batch_size="2000",
+               learnRate="-init 0.001 -max 1", SEPT="-n_layer 2 -ss_rate 0.005 -drop_rate 0.3 -ins_cnt 10",
+               reg__lambda="-u 0.001 -i 0.01 -b 0.2 -s 0.2", output__setup="off -dir ./results/")
+    random.seed(13); np.random.seed(13)
+    with redirect_stdout(io.StringIO()):
+        q = QRec(ModelConf(conf))
+        n_loaded = len(q.relation)
+        m = SEPT(q.config, q.trainingData, q.testData, q.relation)
+        m.readConfiguration()
+        m.num_users, m.num_items, m.train_size = m.data.trainingSize()
+    def csr(prefix, A, arrays):
+        A = A.tocsr(); A.sort_indices()
+        arrays[prefix + "_indptr"] = A.indptr.astype(np.int64); arrays[prefix + "_indices"] = A.indices.astype(np.int32)
+        arrays[prefix + "_data"] = A.data.astype(np.float64)
+    arrays = dict(train_uid=np.array([m.data.user[r[0]] for r in m.data.trainingData], dtype=np.int32),
+                  train_iid=np.array([m.data.item[r[1]] for r in m.data.trainingData], dtype=np.int32),
+                  follower=np.array([m.data.user[r[0]] for r in m.social.relation], dtype=np.int32),
+                  followee=np.array([m.data.user[r[1]] for r in m.social.relation], dtype=np.int32))
+    bs = m.get_birectional_social_matrix()
+    social, sharing = m.get_social_related_views(bs, m.buildSparseRatingMatrix())
+    csr("social", social, arrays); csr("sharing", sharing, arrays)
+    csr("full", m.get_adj_mat(), arrays)
+    for tag in ("sub1", "sub2"):
+        arrays[f"state_before_{tag}"] = np.array(random.getstate()[1], dtype=np.uint32)
+        csr(tag, m.get_adj_mat(is_subgraph=True), arrays)
+    arrays["state_after"] = np.array(random.getstate()[1], dtype=np.uint32)
+    np.savez_compressed(os.path.join(OUT, "sept_graphs_filmtrust.npz"), **arrays)
+    return dict(name="sept_graphs_filmtrust", seed=13, conf=open(conf).read(), n_users=len(m.data.user), n_items=len(m.data.item),
+                n_train=len(m.data.trainingData), relations_loaded=n_loaded, relations_kept=len(m.social.relation),
+                social_users=len(m.social.user), drop_rate=m.drop_rate, regS=m.regS)
+
+
 def main():
     install_stubs()
     tmp = tempfile.mkdtemp(prefix="qrec_golden_")
     os.symlink(os.path.join(REF, "dataset"), os.path.join(tmp, "dataset"))
     os.chdir(tmp)
     only = sys.argv[1:]
-    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pmf, case_svd, case_ee, case_svdpp, case_pairwise_and_adj, case_sgl_subgraph]
+    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pmf, case_svd, case_ee, case_svdpp, case_pairwise_and_adj, case_sgl_subgraph, case_sept_graphs]
     if only:   # regenerate a subset, keep the other entries of golden_meta.json
         cases = [c for c in cases if c.__name__ in only]
         old = json.load(open(os.path.join(OUT, "golden_meta.json")))

@@ -263,3 +263,30 @@ def test_svdpp_filmtrust(golden_dir):
         last_loss = loss
         mt.shuffle(n, perm)
     assert np.array_equal(mt.words625(), z["py_state"])
+
+
+def test_sept_graph_builders_match_the_reference(golden_dir):
+    """model/ranking/SEPT.py:32-114 (pure scipy + random.sample in the reference): friend / sharing views, the joint
+    adjacency and two sampled sub-adjacencies recorded from the live reference; the restatement must reproduce them
+    (structure exactly, values to the last bit in the reference's dtype) with the CPython stream replayed by the oracle."""
+    import scipy.sparse as sp
+    from oracle import tfmodels as T
+    meta, z = _load(golden_dir, "sept_graphs_filmtrust")
+    U, I = meta["n_users"], meta["n_items"]
+    uid, iid, fo, fe = z["train_uid"], z["train_iid"], z["follower"], z["followee"]
+
+    def same(A, tag, dtype):
+        A = sp.csr_matrix(A); A.sort_indices()
+        assert np.array_equal(A.indptr, z[tag + "_indptr"]) and np.array_equal(A.indices, z[tag + "_indices"]), tag
+        assert A.data.dtype == dtype and np.array_equal(A.data.astype(np.float64), z[tag + "_data"]), tag
+    social, sharing = T.sept_social_views(U, I, uid, iid, fo, fe)
+    same(social, "social", np.float64); same(sharing, "sharing", np.float64)
+    same(T.sept_sub_adjacency(U, I, uid, iid, fo, fe), "full", np.float32)
+    m = O.MT.from_python_state((3, tuple(int(x) for x in z["state_before_sub1"]), None))
+    for tag in ("sub1", "sub2"):
+        assert np.array_equal(m.words625(), z[f"state_before_{tag}"])
+        keep = m.sample_range(uid.size, int(uid.size * (1 - meta["drop_rate"])))        # SEPT.py:86
+        skeep = m.sample_range(fo.size, int(fo.size * (1 - meta["drop_rate"])))         # SEPT.py:92
+        same(T.sept_sub_adjacency(U, I, uid, iid, fo, fe, keep, skeep), tag, np.float32)
+    assert np.array_equal(m.words625(), z["state_after"])
+    assert meta["relations_kept"] == fo.size < meta["relations_loaded"]

@@ -256,3 +256,59 @@ def test_buir_gradient_matches_autograd(L):
     assert last < first
     qu, qi, ou, oi = m.final_tables(adj)
     assert qu.shape == (nu, d) and qi.shape == (ni, d) and ou.shape == (nu, d) and oi.shape == (ni, d)
+
+
+@pytest.mark.parametrize("joint", [False, True])
+def test_sept_gradient_matches_autograd(joint):
+    """model/ranking/SEPT.py:124-270: hand-derived gradient of the two variables through the four normalised-layer
+    views, the several-positives contrastive loss and the Variable/2 scaling vs torch autograd of the same graph (the
+    pseudo-label indices are data: taken from the restatement's own top-k); the two Adam optimizers keep separate slots."""
+    rng = np.random.default_rng(131)
+    nu, ni, d, B, L, k = 40, 50, 8, 64, 2, 5
+    uid = rng.integers(0, nu, 300); iid = rng.integers(0, ni, 300)
+    fo = rng.integers(0, nu, 200); fe = rng.integers(0, nu, 200)
+    social, sharing = T.sept_social_views(nu, ni, uid, iid, fo, fe)
+    adj = T.sept_sub_adjacency(nu, ni, uid, iid, fo, fe)
+    sub = T.sept_sub_adjacency(nu, ni, uid, iid, fo, fe, rng.permutation(300)[:210], rng.permutation(200)[:140])
+    assert abs(sub - sub.T).max() > 0                              # the follow edges make it non-symmetric: backward uses M^T
+    U0 = (rng.standard_normal((nu, d)) * 0.2).astype(np.float32); V0 = (rng.standard_normal((ni, d)) * 0.2).astype(np.float32)
+    m = T.SEPT(U0, V0, adj, social, sharing, L, lr=0.001, reg=0.01, ss_rate=0.05, ins_cnt=k)
+    u = rng.integers(0, nu, B); i = rng.integers(0, ni, B); j = rng.integers(0, ni, B)
+    rec, nd, g, labels = m.loss_and_grad(u, i, j, sub if joint else None)
+
+    def tsp(a):
+        coo = a.tocoo(); return torch.sparse_coo_tensor(np.vstack([coo.row, coo.col]), coo.data.astype(np.float64), a.shape).coalesce()
+    nz = lambda x: torch.nn.functional.normalize(x, dim=1, eps=1e-6)
+    W = torch.tensor(m.W.astype(np.float64), requires_grad=True)
+    E0 = W / 2
+
+    def view(mat, X):
+        out, cur = [X], X
+        for _ in range(L):
+            cur = torch.sparse.mm(tsp(mat), cur); out.append(nz(cur))
+        return torch.stack(out).sum(0)
+    Se = view(m.adj, E0)
+    tu, ti, tj = torch.tensor(u), torch.tensor(i) + nu, torch.tensor(j) + nu
+    trec = -torch.log(torch.sigmoid((Se[tu] * Se[ti]).sum(1) - (Se[tu] * Se[tj]).sum(1)) + 1e-7).sum() + 0.01 * 0.5 * (E0 ** 2).sum()
+    tnd = torch.zeros((), dtype=torch.float64)
+    if joint:
+        rows = torch.tensor(T.unique_first_appearance(u))
+        a = nz(view(sub.astype(np.float32), E0)[rows])
+        for S, pos in zip((view(m.social, E0[:nu]), view(m.sharing, E0[:nu]), Se), labels):
+            z = nz(S[rows]); e = torch.exp(z @ a.T / 0.1)
+            tnd = tnd - torch.log(torch.gather(e, 1, torch.tensor(pos)).sum(1) / e.sum(1)).sum()
+        assert all(p.shape == (rows.numel(), k) and (np.sort(p, 1)[:, 1:] != np.sort(p, 1)[:, :-1]).all() for p in labels)
+    (trec + 0.05 * tnd).backward()
+    assert rec == pytest.approx(float(trec.detach()), rel=1e-5) and nd == pytest.approx(float(tnd.detach()), rel=1e-4, abs=1e-9)
+    np.testing.assert_allclose(g, W.grad.numpy(), rtol=3e-3, atol=3e-6)
+    # pseudo labels: the k best of the averaged softmax rows, ties in index order
+    s = np.array([[0.2, 0.5, 0.5, 0.1, 0.5], [0.3, 0.3, 0.1, 0.9, 0.0]], np.float32)
+    assert T.top_k_rows(s, 3).tolist() == [[1, 2, 4], [3, 0, 1]]
+    # two optimizers, separate slots and step counts (v1_op before maxEpoch/3, v2_op after)
+    first = m.train_step(u, i, j)
+    assert m.opt1.t == 1 and m.opt2.t == 0 and not m.opt2.m.any()
+    m.train_step(u, i, j, sub)
+    assert m.opt1.t == 1 and m.opt2.t == 1 and m.opt2.m.any()
+    for _ in range(25):
+        last = m.train_step(u, i, j)
+    assert last[0] < first[0] and last[1] == 0.0
