@@ -353,6 +353,28 @@ int qrec_ratings_copy(const qrec_ratings *h, int32_t *user_out, int32_t *item_ou
 int qrec_ratings_names(const qrec_ratings *h, int32_t which, char *out);
 void qrec_ratings_free(qrec_ratings *h);
 
+/* ---- SEPT (model/ranking/SEPT.py): per-layer normalised views, pseudo labels, several-positives contrastive loss ----
+ * qrec_l2norm_rows_accum: inv[r] = rsqrt(max(|X[r]|^2, 1e-12)), S[r] += X[r] * inv[r]  -- one propagated layer entering a
+ *   view's sum as tf.math.l2_normalize(x, axis=1) (SEPT.py:144-160).  qrec_l2norm_rows_bwd: its gradient w.r.t. X[r],
+ *   out[r] = (dS[r] - z (z . dS[r])) * inv[r], z = X[r] * inv[r] (autodiff of the same lines).  qrec_scale_copy:
+ *   dst = alpha * src (the Variable / 2 of SEPT.py:129-130).  ld in {32, 64, 128, 256} floats, rows zero-padded. */
+int qrec_l2norm_rows_accum(const float *d_X, int64_t n_rows, int32_t ld, float *d_S, float *d_inv, void *stream);
+int qrec_l2norm_rows_bwd(const float *d_X, const float *d_inv, const float *d_dS, int64_t n_rows, int32_t ld, float *d_out,
+                         void *stream);
+int qrec_scale_copy(float *d_dst, const float *d_src, int64_t n_elems, float alpha, void *stream);
+/* qrec_sept_ssl_loss_grad: label_prediction + generate_pesudo_labels + neighbor_discrimination (SEPT.py:214-262) on the
+ *   n distinct users of a batch (d_rows, tf.unique order).  z_v = l2_normalize(S_v[rows]) for the friend / sharing /
+ *   preference views, a = l2_normalize(S_aug[rows]); prob_v = softmax(z_v a^T); labels_v = top_k of the OTHER two
+ *   encoders' averaged prob (k = ins_cnt, equal scores in index order);
+ *   loss += -sum_i log( sum_{l in labels_v[i]} e^{z_v[i].a[l]/0.1} / sum_j e^{z_v[i].a[j]/0.1} ) over the three encoders
+ *   (UNSCALED, added to *d_loss); dS_v[rows[i]] += ss_rate * d loss / d S_v[rows[i]] for the four tables.
+ *   d_labels (nullable): int32 [3][n][k] pseudo labels (positions in d_rows) for inspection. */
+int qrec_sept_ssl_workspace_bytes(int32_t n, int32_t ld, int32_t k, int64_t *bytes);
+int qrec_sept_ssl_loss_grad(const float *d_S_friend, const float *d_S_sharing, const float *d_S_pref, const float *d_S_aug,
+                            const int32_t *d_rows, int32_t n, int32_t ld, int32_t k, float ss_rate, void *d_workspace,
+                            float *d_dS_friend, float *d_dS_sharing, float *d_dS_pref, float *d_dS_aug, double *d_loss,
+                            int32_t *d_labels, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -553,6 +553,30 @@ def neighbour_discrimination(z, a, pos, tau=np.float32(0.1)):
     return loss, (G @ a).astype(f) / f(tau), (G.T @ z).astype(f) / f(tau)
 
 
+def sept_ssl_loss_and_grads(xf, xh, xe, xg, k, labels=None):
+    """label_prediction + generate_pesudo_labels + neighbor_discrimination (SEPT.py:214-262) on the gathered rows of the
+    friend / sharing / preference view sums and of the perturbed-graph view (xg).  Returns (loss, labels,
+    [dxf, dxh, dxe, dxg]) -- unscaled gradients w.r.t. the gathered rows; labels = [f_pos, sh_pos, r_pos]."""
+    f = np.float32
+    a, ra = l2_normalize_rows(xg)
+    zs, rs = zip(*(l2_normalize_rows(x) for x in (xf, xh, xe)))
+    if labels is None:
+        def prob(z):                                                               # tf.nn.softmax(emb aug^T), :219-223
+            x = (z @ a.T).astype(f)
+            e = np.exp(x - x.max(1, keepdims=True), dtype=f)
+            return (e / e.sum(1, dtype=f)[:, None]).astype(f)
+        p_soc, p_sh, p_rec = (prob(z) for z in zs)
+        labels = [top_k_rows((p_sh + p_rec) / f(2), k), top_k_rows((p_soc + p_rec) / f(2), k),
+                  top_k_rows((p_soc + p_sh) / f(2), k)]                             # f_pos, sh_pos, r_pos (:258-260)
+    nd, da, dx = 0.0, np.zeros_like(a), []
+    for z, r, pos in zip(zs, rs, labels):
+        l, dz, dai = neighbour_discrimination(z, a, np.asarray(pos))
+        nd += l; da += dai
+        dx.append(((dz - z * (z * dz).sum(1, dtype=f)[:, None]) * r[:, None]).astype(f))
+    dx.append(((da - a * (a * da).sum(1, dtype=f)[:, None]) * ra[:, None]).astype(f))
+    return nd, labels, dx
+
+
 class SEPT:
     """model/ranking/SEPT.py restated (LightGCN-structured views, the NGCF-structured block is commented out in the
     reference).  Variables Uv, Vv; every view starts from Uv/2, Vv/2 (:129-130)."""
@@ -586,8 +610,10 @@ class SEPT:
         S, _, _ = self.chain(self.adj, (self.W / np.float32(2)).astype(np.float32))
         return S[:self.nu], S[self.nu:]
 
-    def loss_and_grad(self, u_idx, i_idx, j_idx, sub_adj=None):
+    def loss_and_grad(self, u_idx, i_idx, j_idx, sub_adj=None, labels=None):
         """sub_adj None: rec_loss only (epochs <= maxEpoch/3); else rec_loss + ss_rate * neighbor_dis_loss.
+        ``labels``: use these pseudo labels instead of computing them (they carry no gradient; tests pass the other
+        implementation's so that a near-tie in the top-k cannot fork the two trajectories).
         Returns (rec_loss, neighbor_dis_loss, dW, pseudo-label index lists)."""
         f = np.float32
         nu = self.nu
@@ -599,37 +625,23 @@ class SEPT:
         dSe = np.zeros_like(Se)
         np.add.at(dSe, ui, du); np.add.at(dSe, ii, di); np.add.at(dSe, ji, dj)
         dE0 = f(self.reg) * E0
-        nd, labels = 0.0, None
+        nd = 0.0
         if sub_adj is not None:
             sub = sub_adj.astype(f).tocsr()
             Sf, xf, if_ = self.chain(self.social, E0[:nu]); Sh, xh, ih = self.chain(self.sharing, E0[:nu])
             Sg, xg, ig = self.chain(sub, E0)
             rows = unique_first_appearance(u_idx)
-            a, ra = l2_normalize_rows(Sg[rows])
-            zs, rs = zip(*(l2_normalize_rows(S[rows]) for S in (Sf, Sh, Se)))
-
-            def prob(z):                                                               # label_prediction, :214-224
-                x = (z @ a.T).astype(f)
-                e = np.exp(x - x.max(1, keepdims=True), dtype=f)
-                return (e / e.sum(1, dtype=f)[:, None]).astype(f)
-            p_soc, p_sh, p_rec = (prob(z) for z in zs)
-            labels = [top_k_rows((p_sh + p_rec) / f(2), self.k), top_k_rows((p_soc + p_rec) / f(2), self.k),
-                      top_k_rows((p_soc + p_sh) / f(2), self.k)]                     # f_pos, sh_pos, r_pos (:258-260)
-            da = np.zeros_like(a); dz = []
-            for z, pos in zip(zs, labels):
-                l, dzi, dai = neighbour_discrimination(z, a, pos)
-                nd += l; dz.append(dzi); da += dai
+            nd, labels, (dxf, dxh, dxe, dxg) = sept_ssl_loss_and_grads(Sf[rows], Sh[rows], Se[rows], Sg[rows], self.k, labels)
             dSf, dSh, dSg = np.zeros_like(Sf), np.zeros_like(Sh), np.zeros_like(Sg)
             w = self.ss_rate
-            dSf[rows] = w * l2_normalize_bwd(Sf[rows], rs[0], dz[0]); dSh[rows] = w * l2_normalize_bwd(Sh[rows], rs[1], dz[1])
-            dSe[rows] += w * l2_normalize_bwd(Se[rows], rs[2], dz[2]); dSg[rows] = w * l2_normalize_bwd(Sg[rows], ra, da)
+            dSf[rows] = w * dxf; dSh[rows] = w * dxh; dSe[rows] += w * dxe; dSg[rows] = w * dxg
             dE0[:nu] += self.chain_bwd(self.social, xf, if_, dSf) + self.chain_bwd(self.sharing, xh, ih, dSh)
             dE0 += self.chain_bwd(sub, xg, ig, dSg)
         dE0 += self.chain_bwd(self.adj, xe, ie, dSe)
         return rec, nd, (dE0 / f(2)).astype(f), labels
 
-    def train_step(self, u_idx, i_idx, j_idx, sub_adj=None):
+    def train_step(self, u_idx, i_idx, j_idx, sub_adj=None, labels=None):
         """returns (rec_loss, ss_rate * neighbor_dis_loss) as the reference prints them (SEPT.py:292, 301)"""
-        rec, nd, g, _ = self.loss_and_grad(u_idx, i_idx, j_idx, sub_adj)
+        rec, nd, g, _ = self.loss_and_grad(u_idx, i_idx, j_idx, sub_adj, labels)
         (self.opt1 if sub_adj is None else self.opt2).step(self.W, g)
         return rec, float(self.ss_rate) * nd

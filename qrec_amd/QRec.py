@@ -22,7 +22,7 @@ def resolve_model(name: str):
             return getattr(importlib.import_module(f"qrec_amd.model.{pkg}.{name}"), name)
         except ModuleNotFoundError:
             continue
-    raise ImportError(f"model {name} is not provided by qrec_amd (hot-path models: BPR, BasicMF, PMF, SVD, SVDPlusPlus, EE, LightGCN, NGCF, SimGCL, SGL, BUIR)")
+    raise ImportError(f"model {name} is not provided by qrec_amd (hot-path models: BPR, BasicMF, PMF, SVD, SVDPlusPlus, EE, LightGCN, NGCF, SimGCL, SGL, BUIR, SEPT)")
 
 
 def _run_fold(results, model, order, spread=False):
@@ -58,12 +58,18 @@ class QRec:
         elif ev.contains("-predict"):
             self.trainingData = load(config["ratings"])
             self.testData = FileIO.loadUserList(ev["-predict"])
+        if config.contains("social"):                      # QRec.py:44-46
+            self.socialConfig = OptionConf(config["social.setup"])
+            self.relation = FileIO.loadRelationship(config, config["social"])
         print("Reading data and preprocessing...")
 
     def execute(self):
         cls = resolve_model(self.config["model.name"])
         ev = self.evaluation
+        social = self.config.contains("social")            # social models take the relation list (QRec.py:72-75,110-113)
         if not ev.contains("-cv"):
+            if social:
+                return cls(self.config, self.trainingData, self.testData, self.relation).execute()
             return cls(self.config, self.trainingData, self.testData).execute()
         k = int(ev["-cv"])
         if k < 2 or k > 10:
@@ -73,7 +79,8 @@ class QRec:
         binarized = ev.contains("-b")
         tasks = []
         for order, (train, test) in enumerate(DataSplit.crossValidation(self.trainingData, k, binarized=binarized), 1):
-            model = cls(self.config, train, test, "[" + str(order) + "]")   # built in the parent, run in the child
+            fold = "[" + str(order) + "]"
+            model = cls(self.config, train, test, self.relation, fold) if social else cls(self.config, train, test, fold)   # built in the parent, run in the child
             tasks.append(Process(target=_run_fold, args=(results, model, order, ev.contains("-p"))))
         for p in tasks:
             p.start()

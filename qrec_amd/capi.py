@@ -63,6 +63,11 @@ _SIGNATURES = {
     "qrec_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
     "qrec_perturb_rows": [_vp, _vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp],
     "qrec_info_nce_workspace_bytes": [_i32, _i32, _vp],
+    "qrec_l2norm_rows_accum": [_vp, _i64, _i32, _vp, _vp, _vp],
+    "qrec_l2norm_rows_bwd": [_vp, _vp, _vp, _i64, _i32, _vp, _vp],
+    "qrec_scale_copy": [_vp, _vp, _i64, _f32, _vp],
+    "qrec_sept_ssl_workspace_bytes": [_i32, _i32, _i32, _vp],
+    "qrec_sept_ssl_loss_grad": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "qrec_info_nce_loss_grad": [_vp, _vp, _f32, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "qrec_ngcf_dense_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
     "qrec_ngcf_activate": [_vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _i32, _i32, _vp, _vp],
@@ -307,10 +312,16 @@ class DeviceBuffer:
             raise ValueError("upload_head: larger than the buffer")
         _check(load().qrec_memcpy_h2d(self.ptr, _hp(a), a.nbytes, _sh(stream)))
 
-    def copy_from(self, other: "DeviceBuffer", stream=None):
-        if other.nbytes != self.nbytes:
-            raise ValueError("copy_from size mismatch")
-        _check(load().qrec_memcpy_d2d(self.ptr, other.ptr, self.nbytes, _sh(stream)))
+    def copy_from(self, other: "DeviceBuffer", stream=None, nbytes: int | None = None):
+        """device-to-device copy of the whole buffer, or of the first ``nbytes`` bytes of both"""
+        if nbytes is None:
+            if other.nbytes != self.nbytes:
+                raise ValueError("copy_from size mismatch")
+            nbytes = self.nbytes
+        elif nbytes > min(self.nbytes, other.nbytes):
+            raise ValueError("copy_from: more bytes than the buffers hold")
+        if nbytes:
+            _check(load().qrec_memcpy_d2d(self.ptr, other.ptr, nbytes, _sh(stream)))
 
     def fill_bytes(self, byte: int = 0, stream=None):
         _check(load().qrec_memset(self.ptr, byte, self.nbytes, _sh(stream)))
@@ -550,6 +561,33 @@ def info_nce_loss_grad(d_S1, d_S2, div: float, d_rows, n: int, ld: int, tau: flo
                        d_out, d_loss, stream=None, d_out2=None):
     _check(load().qrec_info_nce_loss_grad(_dp(d_S1), _dp(d_S2), div, _dp(d_rows), n, ld, tau, cl_rate,
                                           _dp(d_workspace), _dp(d_out), _dp(d_out2), _dp(d_loss), _sh(stream)))
+
+
+def l2norm_rows_accum(d_X, n_rows: int, ld: int, d_S, d_inv, stream=None):
+    """S[r] += l2_normalize(X[r]); inv[r] = 1 / max(|X[r]|, 1e-6)   (SEPT.py:144-160)"""
+    _check(load().qrec_l2norm_rows_accum(_dp(d_X), n_rows, ld, _dp(d_S), _dp(d_inv), _sh(stream)))
+
+
+def l2norm_rows_bwd(d_X, d_inv, d_dS, n_rows: int, ld: int, d_out, stream=None):
+    _check(load().qrec_l2norm_rows_bwd(_dp(d_X), _dp(d_inv), _dp(d_dS), n_rows, ld, _dp(d_out), _sh(stream)))
+
+
+def scale_copy(d_dst, d_src, n_elems: int, alpha: float, stream=None):
+    _check(load().qrec_scale_copy(_dp(d_dst), _dp(d_src), n_elems, alpha, _sh(stream)))
+
+
+def sept_ssl_workspace_bytes(n: int, ld: int, k: int) -> int:
+    out = C.c_int64(0)
+    _check(load().qrec_sept_ssl_workspace_bytes(n, ld, k, C.byref(out)))
+    return out.value
+
+
+def sept_ssl_loss_grad(d_S_friend, d_S_sharing, d_S_pref, d_S_aug, d_rows, n: int, ld: int, k: int, ss_rate: float, d_workspace,
+                       d_dS_friend, d_dS_sharing, d_dS_pref, d_dS_aug, d_loss, d_labels=None, stream=None):
+    """SEPT.py:214-262 on the batch's unique users (see include/qrec_hip.h)"""
+    _check(load().qrec_sept_ssl_loss_grad(_dp(d_S_friend), _dp(d_S_sharing), _dp(d_S_pref), _dp(d_S_aug), _dp(d_rows), n, ld, k,
+                                          ss_rate, _dp(d_workspace), _dp(d_dS_friend), _dp(d_dS_sharing), _dp(d_dS_pref),
+                                          _dp(d_dS_aug), _dp(d_loss), _dp(d_labels), _sh(stream)))
 
 
 def ngcf_dense_fwd(d_E, d_side, d_W1, d_W2, n_rows: int, ld: int, d_pre, stream=None):

@@ -187,7 +187,7 @@ constexpr int kSplitK = 16;   // K = n is cut into 16 slices -> 16x more wavefro
 template <int MODE>
 __global__ __launch_bounds__(256) void grad_z_kernel(const float *__restrict__ EA, const float *__restrict__ inv_ttl,
                                                      const float *__restrict__ z, int n, int n_pad, int ld, float inv_tau,
-                                                     float *__restrict__ out_parts) {
+                                                     float diag, float *__restrict__ out_parts) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
     const int ks = blockIdx.z * 4 + wave;                 // K slice
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void grad_z_kernel(const float *__restrict__ E
         // 32 consecutive floats of the lane's own row -> 8 float4 loads
         const f32x4 *pe = reinterpret_cast<const f32x4 *>(EA + (int64_t)i * n_pad + k0);
         const f32x4 *pt = reinterpret_cast<const f32x4 *>(inv_ttl + k0);
-        const float dgl = i < n ? 1.f : 0.f;
+        const float dgl = i < n ? diag : 0.f;      // diag = 1: the positive is the row's own column (SimGCL); 0: none here (SEPT)
         // a chunk's operands first (8 float4 of the lane's E row, 32 coalesced dwords of z), then its 32 MFMAs: with
         // one load issued per MFMA the compiler keeps it a single MFMA ahead and the wavefront sits in load latency
         float ga[32], zb[32];
@@ -286,11 +286,244 @@ int run_info_nce(const float *S1, const float *S2, float div, const int32_t *row
     hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((n_pad * 8 + 255) / 256)), dim3(256), 0, st, psum, n, n_pad, dotp, inv_tau, inv_ttl, loss);
     QREC_LAUNCH_CHECK();
     const dim3 gg((unsigned)(n_pad / 32), (unsigned)((ld + 31) / 32), (unsigned)(kSplitK / 4));
-    hipLaunchKernelGGL((grad_z_kernel<0>), gg, dim3(256), 0, st, Ex, inv_ttl, z2, n, n_pad, ld, inv_tau, dz1);
+    hipLaunchKernelGGL((grad_z_kernel<0>), gg, dim3(256), 0, st, Ex, inv_ttl, z2, n, n_pad, ld, inv_tau, 1.f, dz1);
     QREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL((grad_z_kernel<1>), gg, dim3(256), 0, st, ExT, inv_ttl, z1, n, n_pad, ld, inv_tau, dz2);
+    hipLaunchKernelGGL((grad_z_kernel<1>), gg, dim3(256), 0, st, ExT, inv_ttl, z1, n, n_pad, ld, inv_tau, 1.f, dz2);
     QREC_LAUNCH_CHECK();
     hipLaunchKernelGGL((normalize_bwd_kernel<LPR>), dim3(row_blocks), dim3(256), 0, st, z1, z2, dz1, dz2, r1, r2, rows, n, tab, cl_rate, d_out, d_out2);
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+// =============================================================================================
+// SEPT (model/ranking/SEPT.py:214-262): tri-training pseudo labels and the neighbour-discrimination loss on the
+// batch's unique users.  z_v = l2_normalize(S_v[rows]) for the three encoders (friend, sharing, preference view),
+// a = l2_normalize(S_aug[rows]).  Reuses gather_normalize / exp_logits / grad_z above.
+//   row_total_kernel      ttl[i] = sum_j Ex[i][j] from the per-tile partial sums
+//   topk_pair_kernel      labels[i][0..k) = top_k((softmax_p[i] + softmax_q[i]) / 2), equal scores in index order
+//   sept_pos_kernel       pos[i] = sum_t Ex[i][labels[i][t]];  loss += -log(pos[i] / ttl[i])
+//   sept_sparse_kernel    the positives' part of the gradient: dzc[i] = -(1/tau) sum_t (Ex[i][l]/pos[i]) a[l],
+//                         dac[l] -= (1/tau) (Ex[i][l]/pos[i]) z[i]   (l = labels[i][t]; atomics: rows share positives)
+//   sept_normalize_bwd    d_out[rows[i]] += scale * (dz - z (z.dz)) * r,  dz = sum of the split-K parts (+ sparse part)
+// =============================================================================================
+__global__ __launch_bounds__(256) void row_total_kernel(const float *__restrict__ psum, int n, int n_pad, float *__restrict__ ttl,
+                                                        float *__restrict__ inv_ttl) {
+    const int a = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, t0 = threadIdx.x & 7;
+    float s = 0.f;
+    if (a < n)
+        for (int t = t0; t < n_pad / 32; t += 8) s += psum[(int64_t)t * n_pad + a];
+    s += __shfl_xor(s, 1, kWave); s += __shfl_xor(s, 2, kWave); s += __shfl_xor(s, 4, kWave);
+    if (t0 == 0 && a < n_pad) {
+        ttl[a] = a < n ? s : 1.f;
+        if (inv_ttl) inv_ttl[a] = a < n ? 1.0f / s : 0.f;
+    }
+}
+
+// One wavefront per row.  The row's n averaged scores are formed once and kept in registers (EPL per lane, column
+// j = e * 64 + lane); a selection round is a register scan + a (value, index) butterfly, the winner's slot is then
+// closed.  Ties go to the lower column, as tf.math.top_k's.  EPL = 0: rows longer than 4096 columns re-read the two
+// score rows from L2 in every round instead.
+template <int EPL>
+__global__ __launch_bounds__(256) void topk_pair_kernel(const float *__restrict__ Ep, const float *__restrict__ tp,
+                                                        const float *__restrict__ Eq, const float *__restrict__ tq,
+                                                        int n, int n_pad, int k, int32_t *__restrict__ labels) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float *p = Ep + (int64_t)i * n_pad, *q = Eq + (int64_t)i * n_pad;
+    const float sp = tp[i], sq = tq[i];
+    auto score = [&](int j) { return (p[j] / sp + q[j] / sq) / 2.0f; };      // (prob1 + prob2) / 2, SEPT.py:229
+    auto wave_best = [&](float &bv, int &bj) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float ov = __shfl_xor(bv, m, kWave);
+            const int oj = __shfl_xor(bj, m, kWave);
+            if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+        }
+    };
+    if constexpr (EPL > 0) {
+        float v[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const int j = e * kWave + lane;
+            v[e] = j < n ? score(j) : -INFINITY;
+        }
+        for (int t = 0; t < k; t++) {
+            float bv = -INFINITY;
+            int bj = 0x7fffffff;
+#pragma unroll
+            for (int e = 0; e < EPL; e++)
+                if (v[e] > bv) { bv = v[e]; bj = e * kWave + lane; }          // ascending columns: the first of equals stays
+            wave_best(bv, bj);
+            if (lane == 0) labels[(int64_t)i * k + t] = bj;
+#pragma unroll
+            for (int e = 0; e < EPL; e++)
+                if (e * kWave + lane == bj) v[e] = -INFINITY;
+        }
+    } else {
+        float last_v = INFINITY;
+        int last_j = -1;
+        for (int t = 0; t < k; t++) {
+            float bv = -INFINITY;
+            int bj = 0x7fffffff;
+            for (int j = lane; j < n; j += kWave) {
+                const float v = score(j);
+                const bool open = v < last_v || (v == last_v && j > last_j);   // not selected in an earlier round
+                if (open && (v > bv || (v == bv && j < bj))) { bv = v; bj = j; }
+            }
+            wave_best(bv, bj);
+            if (lane == 0) labels[(int64_t)i * k + t] = bj;
+            last_v = bv; last_j = bj;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sept_pos_kernel(const float *__restrict__ Ex, const float *__restrict__ ttl,
+                                                       const int32_t *__restrict__ labels, int n, int n_pad, int k,
+                                                       float *__restrict__ inv_pos, double *__restrict__ loss_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double l = 0.0;
+    if (i < n) {
+        float ps = 0.f;
+        for (int t = 0; t < k; t++) ps += Ex[(int64_t)i * n_pad + labels[(int64_t)i * k + t]];
+        inv_pos[i] = 1.0f / ps;
+        l = (double)(-logf(ps / ttl[i]));
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) l += __shfl_xor(l, m, kWave);
+    if ((threadIdx.x & 63) == 0 && l != 0.0) atomicAdd(loss_out, l);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void sept_sparse_kernel(const float *__restrict__ Ex, const float *__restrict__ inv_pos,
+                                                          const int32_t *__restrict__ labels, const float *__restrict__ z,
+                                                          const float *__restrict__ a, int n, int n_pad, int k, float inv_tau,
+                                                          float *__restrict__ dzc, float *__restrict__ dac) {
+    constexpr int GPW = kWave / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
+    const int64_t i = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
+    if (i >= n) return;
+    const f32x4 zi = *reinterpret_cast<const f32x4 *>(z + i * (4 * LPR) + 4 * r);
+    const float ip = inv_pos[i];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < k; t++) {
+        const int l = labels[i * k + t];
+        const float c = Ex[i * n_pad + l] * ip * inv_tau;
+        const f32x4 al = *reinterpret_cast<const f32x4 *>(a + (int64_t)l * (4 * LPR) + 4 * r);
+        acc = acc - c * al;
+        float *dst = dac + (int64_t)l * (4 * LPR) + 4 * r;
+        unsafeAtomicAdd(dst + 0, -c * zi.x); unsafeAtomicAdd(dst + 1, -c * zi.y);
+        unsafeAtomicAdd(dst + 2, -c * zi.z); unsafeAtomicAdd(dst + 3, -c * zi.w);
+    }
+    *reinterpret_cast<f32x4 *>(dzc + i * (4 * LPR) + 4 * r) = acc;
+}
+
+// dz = sum over n_parts split-K partials (part_stride apart) + extra;  d_out[rows[i]] += scale * (dz - z (z.dz)) * r
+template <int LPR>
+__global__ __launch_bounds__(256) void sept_normalize_bwd_kernel(const float *__restrict__ z, const float *__restrict__ parts,
+                                                                 int n_parts, int64_t part_stride, const float *__restrict__ extra,
+                                                                 const float *__restrict__ rinv, const int32_t *__restrict__ rows,
+                                                                 int n, float scale, float *__restrict__ d_out) {
+    constexpr int GPW = kWave / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
+    const int64_t i = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
+    if (i >= n) return;
+    const int64_t src = i * (4 * LPR) + 4 * r, dst = (int64_t)rows[i] * (4 * LPR) + 4 * r;
+    const f32x4 zi = *reinterpret_cast<const f32x4 *>(z + src);
+    f32x4 d = *reinterpret_cast<const f32x4 *>(extra + src);
+    for (int p = 0; p < n_parts; p++) d = d + *reinterpret_cast<const f32x4 *>(parts + (int64_t)p * part_stride + src);
+    float dot = zi.x * d.x + zi.y * d.y + zi.z * d.z + zi.w * d.w;
+    dot = row_allreduce_sum<LPR>(dot);
+    const f32x4 dx = (d - zi * dot) * rinv[i];
+    f32x4 o = *reinterpret_cast<const f32x4 *>(d_out + dst);          // rows[] are distinct
+    o = o + scale * dx;
+    *reinterpret_cast<f32x4 *>(d_out + dst) = o;
+}
+
+inline int64_t sept_ws_floats(int64_t n, int64_t ld, int64_t k) {
+    const int64_t n_pad = (n + 63) / 64 * 64, tab = n_pad * ld;
+    // z x4, dzc, dac, dz parts (1 set), da parts (3 sets), r x4 + dotp scratch, ttl1 x3, ttl, inv_ttl, inv_pos, psum, Ex1 x3, Ex, ExT, labels
+    return 6 * tab + 4 * kSplitK * tab + 11 * n_pad + (n_pad / 32) * n_pad + 5 * n_pad * n_pad + 3 * n_pad * k;
+}
+
+template <int LPR>
+int run_sept_ssl(const float *const S[4], const int32_t *rows, int n, int ld, int k, float ss_rate, float *ws,
+                 float *const dS[4], double *loss, int32_t *labels_out, hipStream_t st) {
+    constexpr int GPW = kWave / LPR;
+    const int n_pad = (n + 63) / 64 * 64;
+    const int64_t tab = (int64_t)n_pad * ld, sq = (int64_t)n_pad * n_pad;
+    float *z[4]; float *p = ws;
+    for (int v = 0; v < 4; v++) { z[v] = p; p += tab; }
+    float *dzc = p; p += tab;
+    float *dac = p; p += tab;
+    float *dzp = p; p += kSplitK * tab;
+    float *dap = p; p += 3 * kSplitK * tab;
+    float *rinv[4];
+    for (int v = 0; v < 4; v++) { rinv[v] = p; p += n_pad; }
+    float *dotp = p; p += n_pad;
+    float *ttl1[3];
+    for (int v = 0; v < 3; v++) { ttl1[v] = p; p += n_pad; }
+    float *ttl = p; p += n_pad;
+    float *inv_ttl = p; p += n_pad;
+    float *inv_pos = p; p += n_pad;
+    float *psum = p; p += (int64_t)(n_pad / 32) * n_pad;
+    float *Ex1[3];
+    for (int v = 0; v < 3; v++) { Ex1[v] = p; p += sq; }
+    float *Ex = p; p += sq;
+    float *ExT = p; p += sq;
+    int32_t *labels = reinterpret_cast<int32_t *>(p);                       // [3][n][k]
+    const float inv_tau = 10.0f;                                            // tau = 0.1, SEPT.py:245-246
+    const unsigned row_blocks = (unsigned)((n + 4 * GPW - 1) / (4 * GPW)), pad_blocks = (unsigned)((n_pad + 4 * GPW - 1) / (4 * GPW));
+    const dim3 eg((unsigned)(n_pad / 32), (unsigned)((n_pad / 32 + 3) / 4));
+    const dim3 gg((unsigned)(n_pad / 32), (unsigned)((ld + 31) / 32), (unsigned)(kSplitK / 4));
+    const unsigned stat_blocks = (unsigned)((n_pad * 8 + 255) / 256);
+    // z_f, z_h | z_e, a   (S[0] friend, S[1] sharing, S[2] preference, S[3] augmented view)
+    hipLaunchKernelGGL((gather_normalize_kernel<LPR>), dim3(pad_blocks), dim3(256), 0, st, S[0], S[1], 1.0f, rows, n, n_pad, z[0], z[1], rinv[0], rinv[1], dotp);
+    QREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL((gather_normalize_kernel<LPR>), dim3(pad_blocks), dim3(256), 0, st, S[2], S[3], 1.0f, rows, n, n_pad, z[2], z[3], rinv[2], rinv[3], dotp);
+    QREC_LAUNCH_CHECK();
+    // label_prediction (SEPT.py:214-224): softmax rows of z_v a^T -> exp and row totals, tau = 1
+    for (int v = 0; v < 3; v++) {
+        hipLaunchKernelGGL(exp_logits_kernel, eg, dim3(256), 0, st, z[v], z[3], n, n_pad, ld, 1.0f, ExT, Ex1[v], psum);
+        QREC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(row_total_kernel, dim3(stat_blocks), dim3(256), 0, st, psum, n, n_pad, ttl1[v], (float *)nullptr);
+        QREC_LAUNCH_CHECK();
+    }
+    // pseudo labels of encoder v = top-k of the OTHER two encoders' averaged predictions (SEPT.py:258-260)
+    const int other[3][2] = {{1, 2}, {0, 2}, {0, 1}};
+    for (int v = 0; v < 3; v++) {
+#define QREC_TOPK(EPL)                                                                                                        \
+    hipLaunchKernelGGL((topk_pair_kernel<EPL>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, Ex1[other[v][0]], ttl1[other[v][0]], \
+                       Ex1[other[v][1]], ttl1[other[v][1]], n, n_pad, k, labels + (int64_t)v * n * k)
+        if (n_pad <= 512) QREC_TOPK(8);
+        else if (n_pad <= 1024) QREC_TOPK(16);
+        else if (n_pad <= 2048) QREC_TOPK(32);
+        else if (n_pad <= 4096) QREC_TOPK(64);
+        else QREC_TOPK(0);
+#undef QREC_TOPK
+        QREC_LAUNCH_CHECK();
+    }
+    if (labels_out) QREC_HIP_CHECK(hipMemcpyAsync(labels_out, labels, sizeof(int32_t) * 3 * (size_t)n * k, hipMemcpyDeviceToDevice, st));
+    QREC_HIP_CHECK(hipMemsetAsync(dac, 0, sizeof(float) * tab, st));
+    // neighbor_discrimination per encoder (SEPT.py:233-248), tau = 0.1
+    for (int v = 0; v < 3; v++) {
+        const int32_t *lab = labels + (int64_t)v * n * k;
+        hipLaunchKernelGGL(exp_logits_kernel, eg, dim3(256), 0, st, z[v], z[3], n, n_pad, ld, inv_tau, ExT, Ex, psum);
+        QREC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(row_total_kernel, dim3(stat_blocks), dim3(256), 0, st, psum, n, n_pad, ttl, inv_ttl);
+        QREC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sept_pos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Ex, ttl, lab, n, n_pad, k, inv_pos, loss);
+        QREC_LAUNCH_CHECK();
+        hipLaunchKernelGGL((grad_z_kernel<0>), gg, dim3(256), 0, st, Ex, inv_ttl, z[3], n, n_pad, ld, inv_tau, 0.f, dzp);
+        QREC_LAUNCH_CHECK();
+        hipLaunchKernelGGL((grad_z_kernel<1>), gg, dim3(256), 0, st, ExT, inv_ttl, z[v], n, n_pad, ld, inv_tau, 0.f, dap + (int64_t)v * kSplitK * tab);
+        QREC_LAUNCH_CHECK();
+        hipLaunchKernelGGL((sept_sparse_kernel<LPR>), dim3(row_blocks), dim3(256), 0, st, Ex, inv_pos, lab, z[v], z[3], n, n_pad, k, inv_tau, dzc, dac);
+        QREC_LAUNCH_CHECK();
+        hipLaunchKernelGGL((sept_normalize_bwd_kernel<LPR>), dim3(row_blocks), dim3(256), 0, st, z[v], dzp, kSplitK, tab, dzc, rinv[v], rows, n, ss_rate, dS[v]);
+        QREC_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL((sept_normalize_bwd_kernel<LPR>), dim3(row_blocks), dim3(256), 0, st, z[3], dap, 3 * kSplitK, tab, dac, rinv[3], rows, n, ss_rate, dS[3]);
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }
@@ -344,6 +577,35 @@ int qrec_info_nce_loss_grad(const float *d_S1, const float *d_S2, float div, con
         case 128: return run_info_nce<32>(d_S1, d_S2, div, d_rows, n, ld, tau, cl_rate, ws, d_out, d_out2, d_loss, st);
         case 256: return run_info_nce<64>(d_S1, d_S2, div, d_rows, n, ld, tau, cl_rate, ws, d_out, d_out2, d_loss, st);
         default: set_error("qrec_info_nce_loss_grad: row stride must be 32, 64, 128 or 256 floats (got %d)", ld); return QREC_ERR_INVALID;
+    }
+}
+
+int qrec_sept_ssl_workspace_bytes(int32_t n, int32_t ld, int32_t k, int64_t *bytes) {
+    QREC_REQUIRE(bytes && n >= 0 && ld > 0 && k >= 1, "qrec_sept_ssl_workspace_bytes: bad argument");
+    *bytes = 4 * sept_ws_floats(n, ld, k);
+    return QREC_OK;
+}
+
+int qrec_sept_ssl_loss_grad(const float *d_S_friend, const float *d_S_sharing, const float *d_S_pref, const float *d_S_aug,
+                            const int32_t *d_rows, int32_t n, int32_t ld, int32_t k, float ss_rate, void *d_workspace,
+                            float *d_dS_friend, float *d_dS_sharing, float *d_dS_pref, float *d_dS_aug, double *d_loss,
+                            int32_t *d_labels, void *stream) {
+    QREC_REQUIRE(d_S_friend && d_S_sharing && d_S_pref && d_S_aug && d_workspace && d_dS_friend && d_dS_sharing && d_dS_pref &&
+                 d_dS_aug && d_loss && n >= 0, "qrec_sept_ssl_loss_grad: bad argument");
+    QREC_REQUIRE(n == 0 || d_rows, "qrec_sept_ssl_loss_grad: null row list");
+    QREC_REQUIRE(n <= 16384, "qrec_sept_ssl_loss_grad: at most 16384 unique rows per call");
+    if (n == 0) return QREC_OK;
+    QREC_REQUIRE(k >= 1 && k <= n, "qrec_sept_ssl_loss_grad: need 1 <= ins_cnt <= unique users in the batch (got %d, %d)", k, n);
+    hipStream_t st = as_stream(stream);
+    float *ws = static_cast<float *>(d_workspace);
+    const float *const S[4] = {d_S_friend, d_S_sharing, d_S_pref, d_S_aug};
+    float *const dS[4] = {d_dS_friend, d_dS_sharing, d_dS_pref, d_dS_aug};
+    switch (ld) {
+        case 32: return run_sept_ssl<8>(S, d_rows, n, ld, k, ss_rate, ws, dS, d_loss, d_labels, st);
+        case 64: return run_sept_ssl<16>(S, d_rows, n, ld, k, ss_rate, ws, dS, d_loss, d_labels, st);
+        case 128: return run_sept_ssl<32>(S, d_rows, n, ld, k, ss_rate, ws, dS, d_loss, d_labels, st);
+        case 256: return run_sept_ssl<64>(S, d_rows, n, ld, k, ss_rate, ws, dS, d_loss, d_labels, st);
+        default: set_error("qrec_sept_ssl_loss_grad: row stride must be 32, 64, 128 or 256 floats (got %d)", ld); return QREC_ERR_INVALID;
     }
 }
 

@@ -276,6 +276,54 @@ int launch_spmm(const int32_t *seg_row, const int64_t *seg_beg, const int32_t *s
     return QREC_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Per-layer l2-normalised propagation (SEPT.py:142-160: every propagated layer enters the view's sum as
+// tf.math.l2_normalize(x, axis=1) = x * rsqrt(max(sum x^2, 1e-12))), forward and backward.  LPR lanes per row.
+//   l2norm_accum_kernel   inv[row] = rsqrt(max(|x|^2, 1e-12));  S[row] += x * inv
+//   l2norm_bwd_kernel     out[row] = (dS - z (z.dS)) * inv,  z = x * inv     (gradient w.r.t. x of the term above)
+//   scale_copy_kernel     dst = alpha * src                                   (the Variable / 2 of SEPT.py:129-130)
+// ---------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void l2norm_accum_kernel(const float *__restrict__ X, int64_t n_rows, float *__restrict__ S,
+                                                           float *__restrict__ inv) {
+#pragma clang fp contract(off)
+    constexpr int GPW = kWave / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
+    for (int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g; row < n_rows; row += (int64_t)gridDim.x * 4 * GPW) {
+        const int64_t off = row * (4 * LPR) + 4 * r;
+        const f32x4 x = *reinterpret_cast<const f32x4 *>(X + off);
+        float ss = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+        ss = row_allreduce_sum<LPR>(ss);
+        const float iv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        f32x4 s = *reinterpret_cast<const f32x4 *>(S + off);
+        s = s + x * iv;
+        *reinterpret_cast<f32x4 *>(S + off) = s;
+        if (r == 0) inv[row] = iv;
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float *__restrict__ X, const float *__restrict__ inv,
+                                                         const float *__restrict__ dS, int64_t n_rows, float *__restrict__ out) {
+#pragma clang fp contract(off)
+    constexpr int GPW = kWave / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
+    for (int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g; row < n_rows; row += (int64_t)gridDim.x * 4 * GPW) {
+        const int64_t off = row * (4 * LPR) + 4 * r;
+        const float iv = inv[row];
+        const f32x4 z = *reinterpret_cast<const f32x4 *>(X + off) * iv;
+        const f32x4 d = *reinterpret_cast<const f32x4 *>(dS + off);
+        float dot = z.x * d.x + z.y * d.y + z.z * d.z + z.w * d.w;
+        dot = row_allreduce_sum<LPR>(dot);
+        *reinterpret_cast<f32x4 *>(out + off) = (d - z * dot) * iv;
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_copy_kernel(float *__restrict__ dst, const float *__restrict__ src, int64_t n4, float alpha) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += (int64_t)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4 *>(dst)[k] = alpha * reinterpret_cast<const f32x4 *>(src)[k];
+}
+
 }  // namespace
 
 extern "C" {
@@ -336,6 +384,55 @@ int qrec_bpr_batch_loss_grad(const float *d_S, float div, int32_t n_users, int64
         default: set_error("qrec_bpr_batch_loss_grad: row stride must be 32, 64, 128 or 256 floats (got %d)", ld); return QREC_ERR_INVALID;
     }
 #undef QREC_BB
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+int qrec_l2norm_rows_accum(const float *d_X, int64_t n_rows, int32_t ld, float *d_S, float *d_inv, void *stream) {
+    QREC_REQUIRE(d_X && d_S && d_inv && n_rows >= 0, "qrec_l2norm_rows_accum: bad argument");
+    if (n_rows == 0) return QREC_OK;
+    int64_t blocks;
+#define QREC_LN(LPR)                                                                                                  \
+    blocks = (n_rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)); if (blocks > 4096) blocks = 4096;                       \
+    hipLaunchKernelGGL((l2norm_accum_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), d_X, n_rows, d_S, d_inv)
+    switch (ld) {
+        case 32: QREC_LN(8); break;
+        case 64: QREC_LN(16); break;
+        case 128: QREC_LN(32); break;
+        case 256: QREC_LN(64); break;
+        default: set_error("qrec_l2norm_rows_accum: row stride must be 32, 64, 128 or 256 floats (got %d)", ld); return QREC_ERR_INVALID;
+    }
+#undef QREC_LN
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+int qrec_l2norm_rows_bwd(const float *d_X, const float *d_inv, const float *d_dS, int64_t n_rows, int32_t ld, float *d_out,
+                         void *stream) {
+    QREC_REQUIRE(d_X && d_inv && d_dS && d_out && n_rows >= 0, "qrec_l2norm_rows_bwd: bad argument");
+    if (n_rows == 0) return QREC_OK;
+    int64_t blocks;
+#define QREC_LB(LPR)                                                                                                  \
+    blocks = (n_rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)); if (blocks > 4096) blocks = 4096;                       \
+    hipLaunchKernelGGL((l2norm_bwd_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), d_X, d_inv, d_dS, n_rows, d_out)
+    switch (ld) {
+        case 32: QREC_LB(8); break;
+        case 64: QREC_LB(16); break;
+        case 128: QREC_LB(32); break;
+        case 256: QREC_LB(64); break;
+        default: set_error("qrec_l2norm_rows_bwd: row stride must be 32, 64, 128 or 256 floats (got %d)", ld); return QREC_ERR_INVALID;
+    }
+#undef QREC_LB
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+int qrec_scale_copy(float *d_dst, const float *d_src, int64_t n_elems, float alpha, void *stream) {
+    QREC_REQUIRE(d_dst && d_src && n_elems >= 0 && n_elems % 4 == 0, "qrec_scale_copy: bad argument (element count must be a multiple of 4)");
+    if (n_elems == 0) return QREC_OK;
+    int64_t blocks = (n_elems / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), d_dst, d_src, n_elems / 4, alpha);
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }

@@ -378,11 +378,11 @@ class _Adam:
         self.b1p, self.b2p = self.b1, self.b2
         self.n = int(np.prod(theta.shape))
 
-    def step(self, grad, grad_scale=1.0, stream=None):
+    def step(self, grad, grad_scale=1.0, stream=None, grad_l2=0.0):
         f = np.float32
         alpha = float(f(self.lr * np.sqrt(f(1) - self.b2p, dtype=f) / (f(1) - self.b1p)))
         capi.adam_step(self.theta, self.m, self.v, grad, self.n, grad_scale, alpha, float(self.b1), float(self.b2),
-                       float(self.eps), stream)
+                       float(self.eps), stream, grad_l2=grad_l2)
         self.b1p = f(self.b1p * self.b1); self.b2p = f(self.b2p * self.b2)
 
 
@@ -681,3 +681,192 @@ class BUIRTrainer:
         W, b = self.weights()
         q = np.tanh(online @ W + b[None, :], dtype=np.float32)
         return q[:self.nu], q[self.nu:], online[:self.nu], online[self.nu:]
+
+
+# ======================================================================================================================
+# SEPT (model/ranking/SEPT.py): social views, the per-epoch perturbed graph, the four-view trainer
+# ======================================================================================================================
+def _csr_triple(M, dtype=np.float32):
+    """(indptr int64, indices int32, values) of a scipy matrix, columns ascending inside each row"""
+    M = M.tocsr(); M.sort_indices()
+    return M.indptr.astype(np.int64), M.indices.astype(np.int32), M.data.astype(dtype)
+
+
+def _scaled_by_row_sums(M):
+    """diag(s) M diag(s), s = rowsum^-1/2 with inf -> 0, in M's dtype: the ``normalization`` helper of SEPT.py:53-59 and
+    the tail of get_adj_mat (:107-113).  ROW sums on both sides even when M is not symmetric."""
+    import scipy.sparse as sp
+    s = np.asarray(M.sum(axis=1)).ravel()
+    with np.errstate(divide="ignore"):
+        s = np.power(s, -0.5)
+    s[np.isinf(s)] = 0.0
+    D = sp.diags(s)
+    return D.dot(M).dot(D)
+
+
+def sept_user_views(n_users: int, n_items: int, uid, iid, follower, followee):
+    """The friend view and the sharing view of SEPT (get_birectional_social_matrix, get_social_related_views,
+    SEPT.py:42-67) as scipy CSR float64 (the reference builds its float32 tensors from these, :117):
+      B       = follow counts squared element-wise (0/1 data: the follow graph itself, directed);
+      friend  = (#two-step follow paths u -> w -> v) on the edges u -> v of B, plus the identity;
+      sharing = (#items u and v both consumed) on the edges of B, plus the identity;
+    both scaled by their row sums on either side."""
+    import scipy.sparse as sp
+    fo, fe = np.asarray(follower, np.int64), np.asarray(followee, np.int64)
+    F = sp.csr_matrix((np.ones(fo.size, np.float32), (fo, fe)), shape=(n_users, n_users))
+    B = F.multiply(F).tocsr()
+    R = sp.csr_matrix((np.ones(len(uid), np.float32), (np.asarray(uid, np.int64), np.asarray(iid, np.int64))), shape=(n_users, n_items))
+    eye = sp.eye(n_users)
+    friend = (B @ B).multiply(B) + eye
+    sharing = (R @ R.T).multiply(B) + eye
+    return _scaled_by_row_sums(friend).tocsr(), _scaled_by_row_sums(sharing).tocsr()
+
+
+def sept_perturbed_adjacency(state625, n_users: int, n_items: int, uid, iid, follower, followee, drop_rate: float):
+    """get_adj_mat(is_subgraph=True) (SEPT.py:79-114): random.sample keeps int(E (1 - rate)) rating edges, then
+    int(R (1 - rate)) follow edges (``state625``, the CPython generator, advances in place); the kept rating edges
+    go in both ways, the kept follow edges (counts squared) into the user-user block, one way; scaled by row sums.
+    float32 throughout, as in the reference.  scipy CSR over the N = n_users + n_items nodes."""
+    import scipy.sparse as sp
+    n = n_users + n_items
+    uid, iid = np.asarray(uid, np.int64), np.asarray(iid, np.int64)
+    fo, fe = np.asarray(follower, np.int64), np.asarray(followee, np.int64)
+    if drop_rate > 0:
+        keep = capi.mt_sample_range(state625, uid.size, int(uid.size * (1 - drop_rate)))
+        skeep = capi.mt_sample_range(state625, fo.size, int(fo.size * (1 - drop_rate)))
+        up = sp.csr_matrix((np.ones(keep.size, np.float32), (uid[keep], n_users + iid[keep])), shape=(n, n))
+        soc = sp.csr_matrix((np.ones(skeep.size, np.float32), (fo[skeep], fe[skeep])), shape=(n, n))
+        A = up + up.T + soc.multiply(soc)
+    else:
+        up = sp.csr_matrix((np.ones(uid.size, np.float32), (uid, n_users + iid)), shape=(n, n))
+        A = up + up.T
+    return _scaled_by_row_sums(A).tocsr()
+
+
+class _View:
+    """one SEPT view: x_0 = X0, x_k = M x_{k-1}, S = x_0 + sum_k l2_normalize(x_k) over ``rows`` rows; ``planT`` = M^T
+    for the backward pass (the friend, sharing and perturbed graphs are not symmetric)."""
+
+    def __init__(self, rows: int, ld: int, L: int):
+        self.rows, self.ld, self.L = rows, ld, L
+        z = lambda: DeviceBuffer.zeros((max(rows, 1), ld), np.float32)
+        self.S, self.dS = z(), z()
+        self.x = [z() for _ in range(L)]
+        self.inv = [DeviceBuffer.zeros(max(rows, 1), np.float32) for _ in range(L)]
+        self.plan = self.planT = None
+
+    def set_matrix(self, M):
+        """M: scipy CSR (rows x rows)"""
+        self.plan = SpmmPlan(*_csr_triple(M), self.ld)
+        self.planT = self.plan if (abs(M - M.T)).nnz == 0 else SpmmPlan(*_csr_triple(M.T), self.ld)
+
+    def forward(self, X0, stream=None, last_rows=None):
+        """``last_rows`` (row bitmap, training): the last layer is only formed at those rows -- S is read at the batch's
+        rows and nowhere else, and x_L feeds nothing further (other rows of x_L / S keep stale, finite values)."""
+        self.S.copy_from(X0, stream, nbytes=self.rows * self.ld * 4)
+        prev = X0
+        for k in range(self.L):
+            capi.spmm_csr(self.plan, prev, self.x[k], self.ld, stream=stream,
+                          d_y_row_mask=last_rows if k == self.L - 1 else None)
+            capi.l2norm_rows_accum(self.x[k], self.rows, self.ld, self.S, self.inv[k], stream)
+            prev = self.x[k]
+
+    def backward(self, T, G, d_total, stream=None, ds_rows=None):
+        """d_total[:rows] += dS + M^T g_1, g_k = normalize_bwd_k(dS) + M^T g_{k+1}  (T, G = [G0, G1]: scratch, rows x ld).
+        ``ds_rows``: bitmap of the rows where dS is non-zero; g_L = normalize_bwd_L(dS) is zero elsewhere, so the first
+        product skips those operand rows (bit-identical)."""
+        g, first = None, True
+        for k in range(self.L - 1, -1, -1):
+            capi.l2norm_rows_bwd(self.x[k], self.inv[k], self.dS, self.rows, self.ld, T, stream)
+            if g is None:
+                T, G[0] = G[0], T
+                g = G[0]
+            else:
+                out = G[1] if g is G[0] else G[0]
+                capi.spmm_csr(self.planT, g, out, self.ld, d_addend=T, addend_scale=1.0, stream=stream,
+                              d_x_row_mask=ds_rows if first else None)
+                g, first = out, False
+        out = G[1] if g is G[0] else G[0]
+        capi.spmm_csr(self.planT, g, out, self.ld, d_addend=self.dS, addend_scale=1.0, d_accum=d_total, stream=stream,
+                      d_x_row_mask=ds_rows if first else None)
+        return T
+
+
+class SEPTTrainer:
+    """model/ranking/SEPT.py:124-307 on the device.  Variables W = [U; V]; all four views start from W / 2.
+    ``train_step_async(..., joint=False)``: recommendation task only (BPR on the preference view + regU l2 of the halved
+    tables, Adam #1); ``joint=True``: plus ss_rate x the neighbour-discrimination loss of the three encoders against the
+    perturbed-graph view (qrec_sept_ssl_loss_grad), Adam #2 -- two optimizers with their own slots, as in the reference."""
+
+    def __init__(self, U0, V0, adj, friend, sharing, n_layers: int, lr: float, reg: float, ss_rate: float, ins_cnt: int,
+                 loss_eps: float = 1e-7, max_unique: int = 4096):
+        self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
+        self.n = self.nu + self.ni
+        self.ld = padded_ld(self.d, np.float32)
+        self.L, self.lr, self.reg, self.ss_rate, self.k, self.loss_eps = n_layers, lr, reg, ss_rate, ins_cnt, loss_eps
+        W0 = np.zeros((self.n, self.ld), np.float32)
+        W0[:self.nu, :self.d] = U0; W0[self.nu:, :self.d] = V0
+        self.W = DeviceBuffer.from_numpy(W0)
+        z = lambda: DeviceBuffer.zeros((self.n, self.ld), np.float32)
+        self.E0, self.dE0, self.T, self.G = z(), z(), z(), [z(), z()]
+        self.pref, self.aug = _View(self.n, self.ld, n_layers), _View(self.n, self.ld, n_layers)
+        self.friend, self.sharing = _View(self.nu, self.ld, n_layers), _View(self.nu, self.ld, n_layers)
+        self.pref.set_matrix(adj); self.friend.set_matrix(friend); self.sharing.set_matrix(sharing)
+        self.opt = [_Adam(self.W, lr), _Adam(self.W, lr)]          # v1_opt (rec_loss), v2_opt (rec + ss), SEPT.py:267-270
+        self.d_loss = DeviceBuffer.zeros(3, np.float64)             # [bpr term, sum W^2, neighbour-discrimination (unscaled)]
+        self.row_mask = DeviceBuffer.zeros((self.n + 31) // 32, np.uint32)   # the batch's rows {u, nu+i, nu+j}
+        self.max_unique = max_unique
+        self.ws = DeviceBuffer(capi.sept_ssl_workspace_bytes(max_unique, self.ld, ins_cnt), np.uint8)
+        self.d_labels = None
+
+    def set_perturbed_graph(self, M):
+        """the epoch's get_adj_mat(is_subgraph=True) (scipy CSR, N x N)"""
+        self.aug.set_matrix(M)
+
+    def _halve(self, stream=None):
+        capi.scale_copy(self.E0, self.W, self.n * self.ld, 0.5, stream)
+
+    def train_step_async(self, d_u, d_i, d_j, B: int, joint: bool = False, d_uniq_users=None, n_uu: int = 0, stream=None,
+                         keep_labels: bool = False):
+        if joint and n_uu > self.max_unique:
+            raise ValueError("more unique users in the batch than the SEPT workspace holds")
+        if joint and self.aug.plan is None:
+            raise RuntimeError("set_perturbed_graph() first")
+        self._halve(stream)
+        self.row_mask.fill_bytes(0, stream)
+        capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)   # every S is read at these rows only (the
+        mask = self.row_mask                                                      # unique users are among them)
+        self.pref.forward(self.E0, stream, last_rows=mask)
+        self.pref.dS.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream); self.dE0.fill_bytes(0, stream)
+        capi.bpr_batch_loss_grad(self.pref.S, 1.0, self.nu, self.n, self.ld, d_u, d_i, d_j, B, self.loss_eps, 0.0,
+                                 self.pref.dS, self.d_loss, stream)
+        capi.sumsq(self.W, capi.F32, self.n, self.d, self.ld, self.d_loss.ptr + 8, stream)     # regU (l2(U/2) + l2(V/2)) = regU sum W^2 / 8
+        if joint:
+            for v in (self.friend, self.sharing, self.aug):
+                v.forward(self.E0, stream, last_rows=mask); v.dS.fill_bytes(0, stream)
+            if keep_labels:
+                self.d_labels = DeviceBuffer((3, n_uu, self.k), np.int32)
+            capi.sept_ssl_loss_grad(self.friend.S, self.sharing.S, self.pref.S, self.aug.S, d_uniq_users, n_uu, self.ld, self.k,
+                                    self.ss_rate, self.ws, self.friend.dS, self.sharing.dS, self.pref.dS, self.aug.dS,
+                                    self.d_loss.ptr + 16, self.d_labels if keep_labels else None, stream)
+            for v in (self.friend, self.sharing, self.aug):
+                self.T = v.backward(self.T, self.G, self.dE0, stream, ds_rows=mask)
+        self.T = self.pref.backward(self.T, self.G, self.dE0, stream, ds_rows=mask)
+        # d/dW = (dE0 + regU E0) / 2 = dE0 / 2 + regU W / 4
+        self.opt[1 if joint else 0].step(self.dE0, grad_scale=0.5, stream=stream, grad_l2=self.reg / 4.0)
+
+    def losses(self, stream=None):
+        """(rec_loss, ss_rate * neighbor_dis_loss) as the reference prints them (SEPT.py:292, 301)"""
+        bpr, ss, nd = self.d_loss.numpy(stream)
+        return float(bpr + self.reg * ss / 8.0), float(self.ss_rate * nd)
+
+    def rec_embeddings(self):
+        """(rec_user_embeddings, rec_item_embeddings) (SEPT.py:207-208): layer SUM of the preference view"""
+        self._halve()
+        self.pref.forward(self.E0)
+        S = self.pref.S.numpy()[:, :self.d]
+        return np.ascontiguousarray(S[:self.nu]), np.ascontiguousarray(S[self.nu:])
+
+    def variables(self):
+        W = self.W.numpy()[:, :self.d]
+        return W[:self.nu].copy(), W[self.nu:].copy()

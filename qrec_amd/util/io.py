@@ -62,6 +62,28 @@ class FileIO:
         return rows
 
     @staticmethod
+    def loadRelationship(conf, filePath: str):
+        """``follower followee [weight]`` rows of the ``social`` file (util/io.py:88-111): same splitting, ``-columns``
+        and ``-header`` handling as the ratings; weight 1 when no third column is configured."""
+        setup = OptionConf(conf["social.setup"])
+        print("loading social data...")
+        with open(filePath) as fh:
+            lines = fh.readlines()
+        if setup.contains("-header"):
+            lines = lines[1:]
+        order = setup["-columns"].strip().split()
+        splitter = re.compile(" |,|\t")
+        relation = []
+        for lineNo, line in enumerate(lines):
+            fields = splitter.split(line.strip())
+            if len(order) < 2:
+                print("The social file is not in a correct format. Error: Line num %d" % lineNo)
+                sys.exit(-1)
+            weight = 1 if len(order) < 3 else float(fields[int(order[2])])
+            relation.append([fields[int(order[0])], fields[int(order[1])], weight])
+        return relation
+
+    @staticmethod
     def _load_native(setup, file, bTest, binarized, threshold):
         """The same rows through libqrec_hip's parser (qrec_ratings_load), as a ``RatingRows``; None whenever the
         conf or the file asks for something only the Python path reproduces exactly (regex ``-delim``, non-ASCII

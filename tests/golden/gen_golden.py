@@ -363,6 +363,7 @@ def case_sept_graphs(tmp):
     with redirect_stdout(io.StringIO()):
         q = QRec(ModelConf(conf))
         n_loaded = len(q.relation)
+        raw = [list(r) for r in q.relation]                      # before SocialRecommender.__init__ prunes the list in place
         m = SEPT(q.config, q.trainingData, q.testData, q.relation)
         m.readConfiguration()
         m.num_users, m.num_items, m.train_size = m.data.trainingSize()
@@ -374,6 +375,11 @@ def case_sept_graphs(tmp):
                   train_iid=np.array([m.data.item[r[1]] for r in m.data.trainingData], dtype=np.int32),
                   follower=np.array([m.data.user[r[0]] for r in m.social.relation], dtype=np.int32),
                   followee=np.array([m.data.user[r[1]] for r in m.social.relation], dtype=np.int32))
+    unknown = {}
+    code = lambda name: m.data.user[name] if name in m.data.user else -1 - unknown.setdefault(name, len(unknown))
+    arrays["raw_follower"] = np.array([code(r[0]) for r in raw], dtype=np.int64)     # >= 0: training-user id; < 0: a user
+    arrays["raw_followee"] = np.array([code(r[1]) for r in raw], dtype=np.int64)     # that never occurs in the training data
+    arrays["raw_weight"] = np.array([r[2] for r in raw], dtype=np.float64)
     bs = m.get_birectional_social_matrix()
     social, sharing = m.get_social_related_views(bs, m.buildSparseRatingMatrix())
     csr("social", social, arrays); csr("sharing", sharing, arrays)

@@ -668,3 +668,153 @@ def test_graph_models_data_parallel_two_ranks_equal_one_rank_with_double_batch(n
     assert rel_err(b0["E"], a["E"]) < 2e-4 and rel_err(b0["U"], a["U"]) < 2e-4 and rel_err(b0["V"], a["V"]) < 2e-4
     np.testing.assert_allclose(b0["measure"], a["measure"], atol=2e-3)
     assert len(os.listdir(two / "results")) == len(os.listdir(one / "results"))      # rank 0 alone wrote the result files
+
+
+# ---------------------------------------------------------------------------------------------
+# SEPT (model/ranking/SEPT.py)
+# ---------------------------------------------------------------------------------------------
+from qrec_amd.graph import SEPTTrainer  # noqa: E402
+
+
+def _sept_problem(rng, nu=300, ni=400, E=5000, R=1500):
+    uid = rng.integers(0, nu, E); iid = rng.integers(0, ni, E)
+    fo = rng.integers(0, nu, R); fe = rng.integers(0, nu, R)
+    social, sharing = T.sept_social_views(nu, ni, uid, iid, fo, fe)
+    adj = T.sept_sub_adjacency(nu, ni, uid, iid, fo, fe)
+    sub = T.sept_sub_adjacency(nu, ni, uid, iid, fo, fe, rng.permutation(E)[:int(E * 0.7)], rng.permutation(R)[:int(R * 0.7)])
+    return nu, ni, adj, social, sharing, sub
+
+
+@pytest.mark.parametrize("dim,ld", [(16, 32), (50, 64), (64, 64)])
+def test_l2norm_layer_kernels_match_restatement(dim, ld):
+    """qrec_l2norm_rows_accum / _bwd / qrec_scale_copy: S += l2_normalize(x) with tf's 1e-12 clamp (all-zero rows
+    included) and its gradient, vs the restatement."""
+    rng = np.random.default_rng(3)
+    n = 1000
+    X = rng.standard_normal((n, dim)).astype(np.float32); X[5] = 0; X[77] *= 1e-4
+    S0 = rng.standard_normal((n, dim)).astype(np.float32); dS = rng.standard_normal((n, dim)).astype(np.float32)
+    z, inv = T.l2_normalize_rows(X)
+    d_S, d_inv = DB.from_numpy(pad_cols(S0, ld)), DB.zeros(n, np.float32)
+    d_X = DB.from_numpy(pad_cols(X, ld))
+    capi.l2norm_rows_accum(d_X, n, ld, d_S, d_inv)
+    np.testing.assert_allclose(d_inv.numpy(), inv, rtol=2e-6)
+    np.testing.assert_allclose(d_S.numpy()[:, :dim], S0 + z, rtol=1e-5, atol=1e-6)
+    assert not d_S.numpy()[:, dim:].any() and d_inv.numpy()[5] == np.float32(1e6)
+    d_out = DB.zeros((n, ld), np.float32)
+    capi.l2norm_rows_bwd(d_X, d_inv, DB.from_numpy(pad_cols(dS, ld)), n, ld, d_out)
+    want = T.l2_normalize_bwd(X, inv, dS)
+    assert rel_err(d_out.numpy()[:, :dim], want) < 2e-6
+    np.testing.assert_array_equal(d_out.numpy()[5, :dim], dS[5] * np.float32(1e6))      # at the clamp: d * 1e6, like tf
+    capi.scale_copy(d_out, d_X, n * ld, 0.5)
+    np.testing.assert_array_equal(d_out.numpy()[:, :dim], X / np.float32(2))
+
+
+@pytest.mark.parametrize("n,dim,ld,k", [(700, 50, 64, 10), (64, 16, 32, 3), (1999, 64, 64, 10), (4200, 16, 32, 4)])
+def test_sept_pseudo_labels_and_neighbour_discrimination_match_restatement(n, dim, ld, k):
+    """qrec_sept_ssl_loss_grad vs SEPT.py:214-262 restated: pseudo labels (top-k of the other two encoders' averaged
+    softmax rows; a near-tie may legitimately resolve differently, so agreement is checked at 99.5 % and the loss /
+    gradients with the device's own labels), the several-positives InfoNCE loss and the gradients of all four tables."""
+    rng = np.random.default_rng(n)
+    N = 6000
+    tabs = [(rng.standard_normal((N, dim)) * rng.uniform(0.5, 2.0)).astype(np.float32) for _ in range(4)]
+    tabs[3] = (0.6 * tabs[2] + 0.8 * tabs[3]).astype(np.float32)              # correlated views: informative predictions
+    rows = rng.permutation(N)[:n].astype(np.int32)
+    d_S = [DB.from_numpy(pad_cols(t, ld)) for t in tabs]
+    d_dS = [DB.zeros((N, ld), np.float32) for _ in range(4)]
+    ws = DB(capi.sept_ssl_workspace_bytes(n, ld, k), np.uint8)
+    loss, labels = DB.zeros(1, np.float64), DB((3, n, k), np.int32)
+    capi.sept_ssl_loss_grad(*d_S, DB.from_numpy(rows), n, ld, k, 0.25, ws, *d_dS, loss, labels)
+    got_labels = labels.numpy()
+    _, ref_labels, _ = T.sept_ssl_loss_and_grads(*(t[rows] for t in tabs), k)
+    agree = np.mean([np.array_equal(a, b) for a, b in zip(got_labels.reshape(-1, k), np.asarray(ref_labels).reshape(-1, k))])
+    assert agree > 0.995, agree
+    assert all(len(set(r)) == k and min(r) >= 0 and max(r) < n for r in got_labels.reshape(-1, k).tolist())
+    nd, _, dx = T.sept_ssl_loss_and_grads(*(t[rows] for t in tabs), k, labels=list(got_labels))
+    assert float(loss.numpy()[0]) == pytest.approx(nd, rel=2e-5)
+    for d_d, g in zip(d_dS, dx):
+        out = d_d.numpy()
+        assert rel_err(out[rows, :dim], np.float32(0.25) * g) < 5e-5
+        rest = np.ones(N, bool); rest[rows] = False
+        assert not out[rest].any() and not out[:, dim:].any()
+    with pytest.raises(capi.QRecError, match="ins_cnt"):
+        capi.sept_ssl_loss_grad(*d_S, DB.from_numpy(rows), 2, ld, 3, 0.25, ws, *d_dS, loss, None)
+
+
+@pytest.mark.parametrize("L", [1, 2])
+def test_sept_training_steps_match_restatement(L):
+    """SEPTTrainer vs the restated model: recommendation-only steps (Adam #1), then joint steps on a perturbed graph
+    (Adam #2; non-symmetric views -> transposed plans in the backward pass), losses and variables."""
+    rng = np.random.default_rng(40 + L)
+    nu, ni, adj, social, sharing, sub = _sept_problem(rng)
+    dim, B, k = 24, 256, 5
+    U0 = (rng.standard_normal((nu, dim)) * 0.1).astype(np.float32); V0 = (rng.standard_normal((ni, dim)) * 0.1).astype(np.float32)
+    ref = T.SEPT(U0, V0, adj, social, sharing, L, lr=0.002, reg=0.01, ss_rate=0.05, ins_cnt=k)
+    tr = SEPTTrainer(U0, V0, adj.astype(np.float32), social, sharing, L, 0.002, 0.01, 0.05, k, max_unique=B)
+    tr.set_perturbed_graph(sub)
+    assert tr.aug.planT is not tr.aug.plan and tr.friend.planT is not tr.friend.plan
+    for step in range(6):
+        u = rng.integers(0, nu, B).astype(np.int32); i = rng.integers(0, ni, B).astype(np.int32); j = rng.integers(0, ni, B).astype(np.int32)
+        joint = step >= 3
+        uu = T.unique_first_appearance(u).astype(np.int32)
+        tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, joint, DB.from_numpy(uu), uu.size, keep_labels=joint)
+        got = tr.losses()
+        want = ref.train_step(u, i, j, sub if joint else None, labels=list(tr.d_labels.numpy()) if joint else None)
+        assert got[0] == pytest.approx(want[0], rel=2e-5) and got[1] == pytest.approx(want[1], rel=1e-4, abs=1e-9)
+        Ug, Vg = tr.variables()
+        assert rel_err(np.concatenate([Ug, Vg]), ref.W) < 2e-4, step
+    assert ref.opt1.t == 3 and ref.opt2.t == 3
+    Ur, Vr = ref.rec_embeddings(); Ud, Vd = tr.rec_embeddings()
+    assert rel_err(Ud, Ur) < 2e-4 and rel_err(Vd, Vr) < 2e-4
+
+
+def test_sept_class_runs_stock_conf_shape_with_social_data_and_replays_the_generator(tmp_path):
+    """Drop-in SEPT with config/SEPT.conf's keys on FilmTrust + its trust file (the fixture's raw relation list):
+    relation loader -> SocialRecommender pruning -> views -> first third of the epochs recommendation only, then joint
+    training on a per-epoch perturbed graph; evaluated every epoch, best epoch kept; the CPython generator must end
+    where a pure-Python replay of the reference's draws (SEPT.py:86,92 + deepRecommender.py:29-52) ends."""
+    from qrec_amd.model.ranking.SEPT import SEPT
+    from qrec_amd.util.io import FileIO
+    meta, z = load_golden("sept_graphs_filmtrust")
+    name = lambda c: f"u{c}" if c >= 0 else f"x{-1 - c}"
+    path = tmp_path / "trust.txt"
+    path.write_text("".join(f"{name(a)} {name(b)} {w:g}\n" for a, b, w in zip(z["raw_follower"].tolist(), z["raw_followee"].tolist(), z["raw_weight"].tolist())))
+    conf = conf_from_text(meta["conf"])
+    conf["num.factors"] = "16"; conf["num.max.epoch"] = "6"; conf["batch_size"] = "2000"; conf["learnRate"] = "-init 0.002 -max 1"
+    conf["SEPT"] = "-n_layer 2 -ss_rate 0.005 -drop_rate 0.3 -ins_cnt 10"
+    uid, iid = z["train_uid"].tolist(), z["train_iid"].tolist()
+    train = [[f"u{u}", f"i{i}", 1.0] for u, i in zip(uid, iid)]
+    test = [[f"u{u}", f"i{(i * 7 + 3) % meta['n_items']}", 1.0] for u, i in zip(uid[::19], iid[::19])]
+
+    def run():
+        random.seed(21); np.random.seed(21)
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            m = SEPT(conf, [list(r) for r in train], [list(r) for r in test], FileIO.loadRelationship(conf, str(path)))
+            measure = m.execute()
+        return m, measure, buf.getvalue()
+    m, measure, out = run()
+    assert len(m.social.relation) == meta["relations_kept"]
+    rec = [float(l.split("rec loss:")[1].split()[0]) for l in out.splitlines() if "rec loss:" in l]
+    con = [float(l.split("con_loss:")[1]) for l in out.splitlines() if "con_loss:" in l]
+    n_batches = -(-len(train) // 2000)
+    assert len(rec) == 6 * n_batches and len(con) == 3 * n_batches             # epochs 0-2 alone, 3-5 joint (epoch > 6/3)
+    assert np.isfinite(rec).all() and np.isfinite(con).all() and rec[-1] < rec[0] and all(c > 0 for c in con)
+    assert out.count("Quick Ranking Performance") == 6 and any(x.startswith("Recall") for x in measure)
+    assert m.U is m.bestU and m.U.shape == (meta["n_users"], 16) and m.trainer.opt[0].n and m.trainer.opt[1].b1p < m.trainer.opt[1].b1
+    # replay of the random consumption
+    E, R, I = len(train), meta["relations_kept"], meta["n_items"]
+    random.seed(21)
+    rows = list(range(E)); rated = {}
+    for uu, ii in zip(uid, iid):
+        rated.setdefault(uu, set()).add(ii)
+    for ep in range(6):
+        if ep > 6 / 3:
+            random.sample(list(range(E)), int(E * 0.7)); random.sample(list(range(R)), int(R * 0.7))
+        random.shuffle(rows)
+        for r in rows:
+            neg = random.choice(range(I))
+            while neg in rated[uid[r]]:
+                neg = random.choice(range(I))
+    want = capi.state_from_python(random.getstate())
+    run()
+    assert np.array_equal(capi.state_from_python(random.getstate()), want)

@@ -412,3 +412,56 @@ def test_splits_on_rating_rows_equal_the_reference_loops():
         assert isinstance(tr_r, RatingRows) and tr_r == tr_l and te_r == te_l and s_l == s_r
         for (a_tr, a_te), (b_tr, b_te) in zip(DataSplit.crossValidation(lst, 3, binarized=binarized), DataSplit.crossValidation(rows, 3, binarized=binarized)):
             assert b_tr == a_tr and b_te == a_te
+
+
+def test_social_data_model_and_recommender_keep_what_the_reference_keeps(tmp_path):
+    """data/social.py + base/socialRecommender.py:6-41 + util/io.py:88-111 on FilmTrust's trust file as the reference
+    loaded it (fixture: the raw relation list in id form, users unknown to the training data marked): the relation
+    file parser, the pruning to training users (list filtered in place, ``social.user`` keeps everyone) and the
+    follower/followee id arrays the graph builders start from."""
+    from qrec_amd.base.socialRecommender import SocialRecommender
+    from qrec_amd.util.io import FileIO
+    meta, z = load_golden("sept_graphs_filmtrust")
+    name = lambda c: f"u{c}" if c >= 0 else f"x{-1 - c}"
+    path = tmp_path / "trust.txt"
+    path.write_text("".join(f"{name(a)} {name(b)} {w:g}\n" for a, b, w in zip(z["raw_follower"].tolist(), z["raw_followee"].tolist(), z["raw_weight"].tolist())))
+    conf = conf_from_text(meta["conf"])
+    with redirect_stdout(io.StringIO()):
+        relation = FileIO.loadRelationship(conf, str(path))
+    assert len(relation) == meta["relations_loaded"] and relation[0] == [name(int(z["raw_follower"][0])), name(int(z["raw_followee"][0])), 1.0]
+    train = [[f"u{u}", f"i{i}", 1.0] for u, i in zip(z["train_uid"].tolist(), z["train_iid"].tolist())]
+    with redirect_stdout(io.StringIO()):
+        m = SocialRecommender(conf, train, [[train[0][0], train[0][1], 1.0]], relation)
+        m.readConfiguration()
+    assert m.social.relation is relation and len(relation) == meta["relations_kept"]        # pruned in place
+    assert len(m.social.user) == meta["social_users"] and m.regS == meta["regS"]
+    fo, fe = m.relation_ids()
+    assert np.array_equal(fo, z["follower"]) and np.array_equal(fe, z["followee"])
+    assert all(u in m.data.user for u in m.social.followees) and all(v in m.data.user for u in m.social.followees for v in m.social.followees[u])
+    a, b = relation[0][0], relation[0][1]
+    assert m.social.hasFollowee(a, b) and m.social.hasFollower(b, a) and m.social.weight(a, b) == 1.0 and m.social.weight(b, "nobody") == 0
+    assert m.social.row(a).shape == (1, m.social.trustSize()[1]) and m.social.row(a)[0, m.social.user[b]] == 1.0
+    assert m.social.col(b)[0, m.social.user[a]] == 1.0 and m.social.getFollowees("nobody") == {}
+
+
+def test_sept_graph_builders_of_the_product_match_the_reference_bitwise():
+    """qrec_amd.graph.sept_user_views / sept_perturbed_adjacency (host side of model/ranking/SEPT.py:42-114) against the
+    reference's own matrices: structure and every value bit, the CPython generator consumed exactly as its two
+    random.sample calls do."""
+    from qrec_amd.graph import sept_perturbed_adjacency, sept_user_views
+    meta, z = load_golden("sept_graphs_filmtrust")
+    U, I = meta["n_users"], meta["n_items"]
+    args = (U, I, z["train_uid"], z["train_iid"], z["follower"], z["followee"])
+
+    def same(A, tag, dtype):
+        A = A.tocsr(); A.sort_indices()
+        return (A.data.dtype == dtype and np.array_equal(A.indptr, z[tag + "_indptr"]) and np.array_equal(A.indices, z[tag + "_indices"])
+                and np.array_equal(A.data.astype(np.float64), z[tag + "_data"]))
+    friend, sharing = sept_user_views(*args)
+    assert same(friend, "social", np.float64) and same(sharing, "sharing", np.float64)
+    st = z["state_before_sub1"].copy()
+    assert same(sept_perturbed_adjacency(st, *args, meta["drop_rate"]), "sub1", np.float32)
+    assert np.array_equal(st, z["state_before_sub2"])
+    assert same(sept_perturbed_adjacency(st, *args, meta["drop_rate"]), "sub2", np.float32)
+    assert np.array_equal(st, z["state_after"])
+    assert same(sept_perturbed_adjacency(st, *args, 0.0), "full", np.float32) and np.array_equal(st, z["state_after"])
