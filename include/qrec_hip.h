@@ -375,6 +375,23 @@ int qrec_sept_ssl_loss_grad(const float *d_S_friend, const float *d_S_sharing, c
                             float *d_dS_friend, float *d_dS_sharing, float *d_dS_pref, float *d_dS_aug, double *d_loss,
                             int32_t *d_labels, void *stream);
 
+/* ---- TBPR: model/ranking/TBPR.py (numpy path) -----------------------------------------------------------------
+ * qrec_mt_tbpr_sample_epoch (host): the sampling loop TBPR.py:131-158 on the CPython MT19937 stream -- per user and
+ *   positive item the chain [i, choice(joint)?, choice(weak)?, choice(strong)?, k] (k: random item, redrawn while
+ *   positive); writes the (u, a, b) updates of consecutive chain members.  The three item lists are CSR over users.
+ * qrec_tbpr_sgd_ordered: TBPR.optimization (TBPR.py:40-48) over those triplets strictly in order (a == b occurs and is
+ *   applied as two sequential updates of one row), d_loss2[0] = sum(-log s), d_loss2[1] = sum over users of
+ *   regU*sum(P*P) + regI*sum(Q*Q) taken after each user's updates (TBPR.py:159); d_sums_in = {sum(P*P), sum(Q*Q)}
+ *   of the tables at launch (qrec_sumsq).                                                                            */
+int qrec_mt_tbpr_sample_epoch(uint32_t *state625, const int64_t *pos_indptr, const int32_t *pos_items, int32_t n_users,
+                              int32_t n_items, const int64_t *joint_indptr, const int32_t *joint_items,
+                              const int64_t *weak_indptr, const int32_t *weak_items, const int64_t *strong_indptr,
+                              const int32_t *strong_items, int64_t capacity, int32_t *u_out, int32_t *a_out, int32_t *b_out,
+                              int64_t *n_out);
+int qrec_tbpr_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld, const int32_t *d_u, const int32_t *d_a,
+                          const int32_t *d_b, int64_t n, double lr, double regU, double regI, const double *d_sums_in,
+                          double *d_loss2, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,6 +167,31 @@ def bpr_sgd(P, Q, u, i, j, lr, regU, regI) -> float:
     return lib().orc_bpr_sgd_f32(_p(P), _p(Q), d, _p(u), _p(i), _p(j), u.size, lr, regU, regI)
 
 
+def tbpr_sample_epoch(mt: MT, pos_indptr, pos_items, n_items: int, joint, weak, strong):
+    """model/ranking/TBPR.py:131-158 -- the epoch's chained (u, a, b) triplets; joint/weak/strong = (indptr, items)."""
+    _chk(pos_indptr, np.int64); _chk(pos_items, np.int32)
+    for ptr, items in (joint, weak, strong):
+        _chk(ptr, np.int64); _chk(items, np.int32)
+    cap = 4 * pos_items.size
+    u, a, b = (np.empty(cap, dtype=np.int32) for _ in range(3))
+    L = lib()
+    L.orc_tbpr_sample_epoch.restype = C.c_int64
+    L.orc_tbpr_sample_epoch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 9
+    n = L.orc_tbpr_sample_epoch(mt.ptr, _p(pos_indptr), _p(pos_items), pos_indptr.size - 1, n_items, _p(joint[0]), _p(joint[1]),
+                                _p(weak[0]), _p(weak[1]), _p(strong[0]), _p(strong[1]), _p(u), _p(a), _p(b))
+    return u[:n].copy(), a[:n].copy(), b[:n].copy()
+
+
+def tbpr_epoch(P, Q, u, a, b, lr, regU, regI) -> float:
+    """TBPR.optimization over the chained triplets + the per-user regularisation terms of the loss (TBPR.py:157-159)"""
+    _chk(P, np.float64); _chk(Q, np.float64); _chk(u, np.int32); _chk(a, np.int32); _chk(b, np.int32)
+    L = lib()
+    L.orc_tbpr_epoch_f64.restype = C.c_double
+    L.orc_tbpr_epoch_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int64, C.c_double, C.c_double, C.c_double]
+    return L.orc_tbpr_epoch_f64(_p(P), _p(Q), P.shape[1], P.shape[0], Q.shape[0], _p(u), _p(a), _p(b), u.size, lr, regU, regI)
+
+
 def sumsq(x) -> float:
     x = np.ascontiguousarray(x, dtype=np.float64)
     return lib().orc_sumsq_f64(_p(x), x.size)

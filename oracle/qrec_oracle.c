@@ -311,6 +311,72 @@ double orc_bpr_sgd_f64(double *P, double *Q, int32_t d, const int32_t *u_idx,
     return loss;
 }
 
+/* ------------------------------------------------------------------------------------
+ * TBPR (model/ranking/TBPR.py:111-166): per user (PositiveSet order) and positive item the chain
+ * [i, choice(jointItems)?, choice(weakItems)?, choice(strongItems)?, k] with k = choice(itemList) redrawn while positive
+ * (:137-155); consecutive members form the (u, a, b) updates of TBPR.optimization (:157-158).  Lists are CSR over users.
+ * Returns the number of triplets written (<= 4 per positive).
+ */
+int64_t orc_tbpr_sample_epoch(orc_mt *s, const int64_t *pos_indptr, const int32_t *pos_items, int32_t n_users, int32_t n_items,
+                              const int64_t *j_ptr, const int32_t *j_items, const int64_t *w_ptr, const int32_t *w_items,
+                              const int64_t *s_ptr, const int32_t *s_items, int32_t *u_out, int32_t *a_out, int32_t *b_out) {
+    int32_t *stamp = (int32_t *)calloc((size_t)n_items, sizeof(int32_t));
+    const int kbits = bit_length_u32((uint32_t)n_items);
+    int64_t n = 0, e;
+    int32_t u;
+    const int64_t *ptrs[3];
+    const int32_t *lists[3];
+    ptrs[0] = j_ptr; ptrs[1] = w_ptr; ptrs[2] = s_ptr; lists[0] = j_items; lists[1] = w_items; lists[2] = s_items;
+    for (u = 0; u < n_users; u++) {
+        for (e = pos_indptr[u]; e < pos_indptr[u + 1]; e++) stamp[pos_items[e]] = u + 1;
+        for (e = pos_indptr[u]; e < pos_indptr[u + 1]; e++) {
+            int32_t chain[5];
+            int len = 0, c;
+            uint32_t r;
+            chain[len++] = pos_items[e];
+            for (c = 0; c < 3; c++) {
+                const int64_t cnt = ptrs[c][u + 1] - ptrs[c][u];
+                if (cnt > 0) {                                       /* choice(list) = list[_randbelow(len)] */
+                    const int kb = bit_length_u32((uint32_t)cnt);
+                    do { r = mt_u32(s) >> (32 - kb); } while (r >= (uint32_t)cnt);
+                    chain[len++] = lists[c][ptrs[c][u] + r];
+                }
+            }
+            for (;;) {
+                r = mt_u32(s) >> (32 - kbits);
+                if (r >= (uint32_t)n_items) continue;
+                if (stamp[r] == u + 1) continue;
+                break;
+            }
+            chain[len++] = (int32_t)r;
+            for (c = 0; c + 1 < len; c++) { u_out[n] = u; a_out[n] = chain[c]; b_out[n] = chain[c + 1]; n++; }
+        }
+    }
+    free(stamp);
+    return n;
+}
+
+/* TBPR.optimization over the chained triplets (same arithmetic as BPR.optimization, and a == b can occur: the last draw
+ * may repeat a social item; rows then alias exactly as numpy's in-place row updates do), plus the reference's loss:
+ * sum(-log s) and, after EVERY user's updates, regU*sum(P*P) + regI*sum(Q*Q) over the whole tables (TBPR.py:159 sits
+ * inside the user loop). */
+double orc_tbpr_epoch_f64(double *P, double *Q, int32_t d, int32_t n_users, int32_t n_items, const int32_t *u_idx,
+                          const int32_t *a_idx, const int32_t *b_idx, int64_t n, double lr, double regU, double regI) {
+    double loss = 0.0;
+    int64_t t = 0;
+    while (t < n) {
+        int64_t e = t, k;
+        double sp = 0.0, sq = 0.0;
+        while (e < n && u_idx[e] == u_idx[t]) e++;
+        loss += orc_bpr_sgd_f64(P, Q, d, u_idx + t, a_idx + t, b_idx + t, e - t, lr, regU, regI);
+        for (k = 0; k < (int64_t)n_users * d; k++) sp += P[k] * P[k];
+        for (k = 0; k < (int64_t)n_items * d; k++) sq += Q[k] * Q[k];
+        loss += regU * sp + regI * sq;
+        t = e;
+    }
+    return loss;
+}
+
 /* Same recurrence carried out in fp32 storage/arithmetic (fp64 loss accumulator): the
  * tight comparator for the fp32 HIP kernels (dot-product summation order still differs
  * from the wave butterfly, so agreement is to rounding, not bitwise). */

@@ -43,6 +43,8 @@ _SIGNATURES = {
     "qrec_stream_wait_event": [_vp, _vp],
     "qrec_event_elapsed_ms": [_vp, _vp, _vp],
     "qrec_mt_bpr_sample_epoch": [_vp, _vp, _vp, _i32, _i32, _vp],
+    "qrec_mt_tbpr_sample_epoch": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "qrec_tbpr_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _vp, _vp, _vp],
     "qrec_mt_shuffle": [_vp, _i64, _vp],
     "qrec_mt_sample_range": [_vp, _i64, _i64, _vp],
     "qrec_mt_pairwise_sample_epoch": [_vp, _vp, _i64, _vp, _vp, _i32, _vp],
@@ -366,6 +368,30 @@ def mt_bpr_sample_epoch(state625: np.ndarray, pos_indptr, pos_indices, n_items: 
     _check(load().qrec_mt_bpr_sample_epoch(_hp(state625), _hp(pos_indptr), _hp(pos_indices),
                                            pos_indptr.size - 1, n_items, _hp(j)))
     return j
+
+
+def mt_tbpr_sample_epoch(state625: np.ndarray, pos_indptr, pos_items, n_items: int, joint, weak, strong):
+    """TBPR.py:131-158 on the CPython stream: the epoch's chained (u, a, b) updates.  joint / weak / strong:
+    (indptr int64, items int32) CSR over users of the three candidate lists."""
+    _req(state625, np.uint32, "state625"); _req(pos_indptr, np.int64, "pos_indptr"); _req(pos_items, np.int32, "pos_items")
+    for name, (ptr, items) in (("joint", joint), ("weak", weak), ("strong", strong)):
+        _req(ptr, np.int64, name + " indptr"); _req(items, np.int32, name + " items")
+        if ptr.size != pos_indptr.size:
+            raise ValueError(f"{name} list: one row per user expected")
+    cap = 4 * int(pos_items.size)
+    u, a, b = (np.empty(max(cap, 1), dtype=np.int32) for _ in range(3))
+    n = C.c_int64(0)
+    _check(load().qrec_mt_tbpr_sample_epoch(_hp(state625), _hp(pos_indptr), _hp(pos_items), pos_indptr.size - 1, n_items,
+                                            _hp(joint[0]), _hp(joint[1]), _hp(weak[0]), _hp(weak[1]), _hp(strong[0]),
+                                            _hp(strong[1]), cap, _hp(u), _hp(a), _hp(b), C.byref(n)))
+    return u[:n.value].copy(), a[:n.value].copy(), b[:n.value].copy()
+
+
+def tbpr_sgd_ordered(d_P, d_Q, dtype: int, d: int, ld: int, d_u, d_a, d_b, n: int, lr: float, regU: float, regI: float,
+                     d_sums_in, d_loss2, stream=None):
+    """TBPR.py:40-48,157-159 over the chained triplets, strictly in order (see include/qrec_hip.h)"""
+    _check(load().qrec_tbpr_sgd_ordered(_dp(d_P), _dp(d_Q), dtype, d, ld, _dp(d_u), _dp(d_a), _dp(d_b), n, lr, regU, regI,
+                                        _dp(d_sums_in), _dp(d_loss2), _sh(stream)))
 
 
 def mt_data_split(state625: np.ndarray, n: int, ratio: float) -> np.ndarray:

@@ -123,6 +123,113 @@ __global__ __launch_bounds__(64) void bpr_ordered_kernel(
     if (lane == 0) *loss_out = loss;
 }
 
+// TBPR (model/ranking/TBPR.py:40-48,131-159), order-exact: the same per-triplet arithmetic over the chained
+// (u, a, b) updates, with two things BPR never needs:
+//   * a == b happens (the closing random item may repeat the chain's last social item): the two row updates then hit
+//     ONE row in sequence, as numpy's in-place row statements do;
+//   * the loss takes regU*sum(P*P) + regI*sum(Q*Q) over the WHOLE tables after every user (TBPR.py:159 is inside the
+//     user loop).  The sums are carried along instead of recomputed: sums_in = {sum P*P, sum Q*Q} before the launch,
+//     every row update adds (|new row|^2 - |old row|^2) in fp64.
+// loss_out[0] = sum(-log s), loss_out[1] = sum over users of (regU*sumP2 + regI*sumQ2).
+template <typename T, int EPL>
+__global__ __launch_bounds__(64) void tbpr_ordered_kernel(
+    T *__restrict__ P, T *__restrict__ Q, int d, int ld, const int32_t *__restrict__ u_idx,
+    const int32_t *__restrict__ a_idx, const int32_t *__restrict__ b_idx, int64_t n, T lr, T cu, T ci,
+    double regU, double regI, const double *__restrict__ sums_in, double *__restrict__ loss_out) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x;
+    bool valid[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) valid[e] = (lane + 64 * e) < d;
+    auto load_row = [&](const T *tab, int row, T (&dst)[EPL]) {
+        const T *p = tab + (int64_t)row * ld + lane;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) dst[e] = valid[e] ? p[64 * e] : T(0);
+    };
+    auto store_row = [&](T *tab, int row, const T (&src)[EPL]) {
+        T *p = tab + (int64_t)row * ld + lane;
+#pragma unroll
+        for (int e = 0; e < EPL; e++)
+            if (valid[e]) p[64 * e] = src[e];
+    };
+    auto norm2 = [&](const T (&r)[EPL]) {
+        double v = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) v += (double)r[e] * (double)r[e];
+        return wave_allreduce_sum(v);
+    };
+    T pu[EPL], qa[EPL], qb[EPL], nqa[EPL], nqb[EPL];
+    double loss = 0.0, reg = 0.0, sP = sums_in[0], sQ = sums_in[1], pu_loaded = 0.0;
+    int cur_u = -1;
+    if (n > 0) { load_row(Q, a_idx[0], qa); load_row(Q, b_idx[0], qb); }
+    for (int64_t t = 0; t < n; t++) {
+        const int ut = u_idx[t], at = a_idx[t], bt = b_idx[t];
+        if (ut != cur_u) {
+            if (cur_u >= 0) {
+                store_row(P, cur_u, pu);
+                sP += norm2(pu) - pu_loaded;
+                reg += regU * sP + regI * sQ;
+            }
+            load_row(P, ut, pu);
+            pu_loaded = norm2(pu);
+            cur_u = ut;
+        }
+        int an = -1, bn = -1;
+        if (t + 1 < n) { an = a_idx[t + 1]; bn = b_idx[t + 1]; load_row(Q, an, nqa); load_row(Q, bn, nqb); }
+        const bool alias = at == bt;
+        const double q_old = norm2(qa) + (alias ? 0.0 : norm2(qb));
+        T da = 0, db = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) { da += pu[e] * qa[e]; db += pu[e] * qb[e]; }
+        da = wave_allreduce_sum(da); db = wave_allreduce_sum(db);
+        const T s = T(1) / (T(1) + dev_exp<T>(-(da - db)));
+        const T g = lr * (T(1) - s);
+        if (!alias) {
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                pu[e] += g * (qa[e] - qb[e]);
+                qa[e] += g * pu[e];
+                qb[e] -= g * pu[e];
+                pu[e] -= cu * pu[e];
+                qa[e] -= ci * qa[e];
+                qb[e] -= ci * qb[e];
+            }
+            store_row(Q, at, qa); store_row(Q, bt, qb);
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                T r = qa[e];
+                pu[e] += g * (r - r);
+                r += g * pu[e];
+                r -= g * pu[e];
+                pu[e] -= cu * pu[e];
+                r -= ci * r;
+                r -= ci * r;
+                qa[e] = r; qb[e] = r;
+            }
+            store_row(Q, at, qa);
+        }
+        sQ += norm2(qa) + (alias ? 0.0 : norm2(qb)) - q_old;
+        if constexpr (sizeof(T) == 8) loss += -log((double)s);
+        else loss += neg_log_sigmoid((double)(da - db));
+        if (t + 1 < n) {
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                T x = nqa[e], y = nqb[e];
+                if (an == at) x = qa[e]; else if (an == bt) x = qb[e];
+                if (bn == at) y = qa[e]; else if (bn == bt) y = qb[e];
+                qa[e] = x; qb[e] = y;
+            }
+        }
+    }
+    if (cur_u >= 0) {
+        store_row(P, cur_u, pu);
+        sP += norm2(pu) - pu_loaded;
+        reg += regU * sP + regI * sQ;
+    }
+    if (lane == 0) { loss_out[0] = loss; loss_out[1] = reg; }
+}
+
 // Rating-prediction MF family, order-exact, same structure (one wavefront, lane = column):
 //   VAR 0  model/rating/BasicMF.py:9-26   P[u] += (lr*e)*q ;            Q[i] += (lr*e)*p
 //   VAR 1  model/rating/PMF.py:9-28       P[u] += lr*(e*q - regU*p) ;   Q[i] += lr*(e*p - regI*q)
@@ -647,6 +754,21 @@ int dispatch_mf(int variant, void *P, void *Q, void *Bu, void *Bi, int d, int ld
     }
 }
 
+template <typename T>
+int launch_tbpr(void *P, void *Q, int d, int ld, const int32_t *u, const int32_t *a, const int32_t *b, int64_t n, double lr,
+                double regU, double regI, const double *sums_in, double *loss, hipStream_t st) {
+    const T tlr = (T)lr, cu = (T)lr * (T)regU, ci = (T)lr * (T)regI;
+#define QREC_TBPR_LAUNCH(EPL)                                                                                          \
+    hipLaunchKernelGGL((tbpr_ordered_kernel<T, EPL>), dim3(1), dim3(64), 0, st, (T *)P, (T *)Q, d, ld, u, a, b, n, tlr, cu, ci, \
+                       regU, regI, sums_in, loss)
+    if (d <= 64) QREC_TBPR_LAUNCH(1);
+    else if (d <= 128) QREC_TBPR_LAUNCH(2);
+    else QREC_TBPR_LAUNCH(4);
+#undef QREC_TBPR_LAUNCH
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -663,6 +785,19 @@ int qrec_bpr_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
     return dtype == QREC_F64
                ? launch_ordered<double>(d_P, d_Q, d, ld, d_u, d_i, d_j, n, lr, regU, regI, d_loss, st)
                : launch_ordered<float>(d_P, d_Q, d, ld, d_u, d_i, d_j, n, lr, regU, regI, d_loss, st);
+}
+
+int qrec_tbpr_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld, const int32_t *d_u, const int32_t *d_a,
+                          const int32_t *d_b, int64_t n, double lr, double regU, double regI, const double *d_sums_in,
+                          double *d_loss2, void *stream) {
+    QREC_REQUIRE(d_P && d_Q && d_sums_in && d_loss2 && n >= 0, "qrec_tbpr_sgd_ordered: null argument");
+    QREC_REQUIRE(n == 0 || (d_u && d_a && d_b), "qrec_tbpr_sgd_ordered: null index array");
+    QREC_REQUIRE(d >= 1 && d <= 256 && ld >= d, "qrec_tbpr_sgd_ordered: need 1 <= d <= 256, ld >= d (got d=%d ld=%d)", d, ld);
+    QREC_REQUIRE(dtype == QREC_F32 || dtype == QREC_F64, "qrec_tbpr_sgd_ordered: bad dtype %d", dtype);
+    hipStream_t st = as_stream(stream);
+    if (n == 0) { QREC_HIP_CHECK(hipMemsetAsync(d_loss2, 0, 2 * sizeof(double), st)); return QREC_OK; }
+    return dtype == QREC_F64 ? launch_tbpr<double>(d_P, d_Q, d, ld, d_u, d_a, d_b, n, lr, regU, regI, d_sums_in, d_loss2, st)
+                             : launch_tbpr<float>(d_P, d_Q, d, ld, d_u, d_a, d_b, n, lr, regU, regI, d_sums_in, d_loss2, st);
 }
 
 int qrec_mf_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,

@@ -54,7 +54,7 @@ def write_conf(path, **kv):
             f.write(f"{k.replace('__', '.')}={v}\n")
 
 
-def run_numpy_model(conf_path, seed, model_mod, model_name, hook_attr):
+def run_numpy_model(conf_path, seed, model_mod, model_name, hook_attr, social=False):
     """Run QRec(conf) end to end with instrumentation of the per-sample step."""
     from QRec import QRec
     from util.config import ModelConf
@@ -106,7 +106,8 @@ def run_numpy_model(conf_path, seed, model_mod, model_name, hook_attr):
         q = QRec(ModelConf(conf_path))
         # QRec.execute() instantiates through eval(); do the same thing by hand to keep
         # a handle on the model object
-        m = cls(q.config, q.trainingData, q.testData)
+        rec["raw_relation"] = [list(r) for r in q.relation] if social else None     # before the model prunes the list in place
+        m = cls(q.config, q.trainingData, q.testData, q.relation) if social else cls(q.config, q.trainingData, q.testData)
         measure = m.execute()
     cls.isConverged = orig_conv; cls.initModel = orig_init
     br.Measure.rankingMeasure = staticmethod(orig_rm)
@@ -276,6 +277,39 @@ def case_svdpp(tmp):
     return out
 
 
+def case_tbpr_filmtrust(tmp):
+    """model/ranking/TBPR.py (numpy path, runs unmodified): tie strengths, strong / weak / joint item sets, the chained
+    pairwise updates per positive item and the per-user regularisation terms of the loss, on FilmTrust + trust.txt.
+    The order of every user's joint-item list comes from a Python set of strings (hash-seed dependent, so it differs
+    from process to process in the reference itself): the lists of THIS run are recorded."""
+    conf = os.path.join(tmp, "tbpr_ft.conf")
+    write_conf(conf, ratings="./dataset/FilmTrust/trainset.txt", social="./dataset/FilmTrust/trust.txt",
+               ratings__setup="-columns 0 1 2", social__setup="-columns 0 1 2",
+               model__name="TBPR", evaluation__setup="-testSet ./dataset/FilmTrust/testset.txt -b 1",
+               item__ranking="on -topN 10,20", num__factors="8", num__max__epoch="3", learnRate="-init 0.03 -max 1",
+               reg__lambda="-u 0.01 -i 0.01 -b 0.2 -s 0.2", TBPR="-regT 0.01", output__setup="off -dir ./results/")
+    rec = run_numpy_model(conf, 77, "model.ranking.TBPR", "TBPR", "optimization", social=True)
+    meta = pack_bpr(rec, "tbpr_filmtrust", keep_full_stream=True)
+    m = rec["model"]
+    z = dict(np.load(os.path.join(OUT, "tbpr_filmtrust.npz")))
+    unknown = {}
+    code = lambda name: m.data.user[name] if name in m.data.user else -1 - unknown.setdefault(name, len(unknown))
+    z["raw_follower"] = np.array([code(r[0]) for r in rec["raw_relation"]], dtype=np.int64)
+    z["raw_followee"] = np.array([code(r[1]) for r in rec["raw_relation"]], dtype=np.int64)
+    z["raw_weight"] = np.array([r[2] for r in rec["raw_relation"]], dtype=np.float64)
+    for tag, book in (("joint", m.jointSet), ("weak", m.weakSet), ("strong", m.strongSet)):
+        ptr, items = [0], []
+        for user in m.data.user:                                   # id order
+            items += [m.data.item[it] for it in (book[user].keys() if user in book else [])]
+            ptr.append(len(items))
+        z[tag + "_indptr"] = np.array(ptr, dtype=np.int64); z[tag + "_items"] = np.array(items, dtype=np.int32)
+    z["tie_weights"] = np.asarray(m.weights, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "tbpr_filmtrust.npz"), **z)
+    meta.update(seed=77, conf=open(conf).read(), theta=float(m.theta), t_s=float(m.t_s), t_w=float(m.t_w), g_theta=float(m.g_theta),
+                relations_loaded=len(rec["raw_relation"]), relations_kept=len(m.social.relation))
+    return meta
+
+
 def case_pairwise_and_adj(tmp):
     """base/deepRecommender.py:29-52 sampler and base/graphRecommender.py:10-29 adjacency,
     both pure python/scipy -> executable with the tensorflow stub."""
@@ -400,7 +434,7 @@ def main():
     os.symlink(os.path.join(REF, "dataset"), os.path.join(tmp, "dataset"))
     os.chdir(tmp)
     only = sys.argv[1:]
-    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pmf, case_svd, case_ee, case_svdpp, case_pairwise_and_adj, case_sgl_subgraph, case_sept_graphs]
+    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pmf, case_svd, case_ee, case_svdpp, case_pairwise_and_adj, case_sgl_subgraph, case_sept_graphs, case_tbpr_filmtrust]
     if only:   # regenerate a subset, keep the other entries of golden_meta.json
         cases = [c for c in cases if c.__name__ in only]
         old = json.load(open(os.path.join(OUT, "golden_meta.json")))

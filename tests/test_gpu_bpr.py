@@ -844,3 +844,95 @@ def test_bpr_class_on_two_ranks_keeps_replicas_identical_and_trains_like_one_ran
     r3 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                          "--master-port", "29551", worker, "BPR", "0", str(two)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r3.returncode != 0
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, F64_TOL), (np.float32, 5e-5)])
+def test_tbpr_ordered_kernel_matches_oracle_including_aliased_rows(dtype, tol):
+    """qrec_tbpr_sgd_ordered vs the restated TBPR.optimization loop: chained triplets per user, a == b rows (two
+    sequential updates of ONE row), consecutive triplets sharing rows, and the per-user regularisation terms carried as
+    running sums of squares."""
+    rng = np.random.default_rng(12)
+    U, I, dim = 120, 90, 20
+    u_list, a_list, b_list = [], [], []
+    for user in rng.permutation(U)[:100]:
+        for _ in range(rng.integers(1, 6)):
+            chain = rng.integers(0, I, rng.integers(2, 6)).tolist()
+            if rng.random() < 0.3:
+                chain[-1] = chain[-2]                      # the closing draw repeats the last social item
+            for x, y in zip(chain[:-1], chain[1:]):
+                u_list.append(user); a_list.append(x); b_list.append(y)
+    u, a, b = (np.array(v, np.int32) for v in (u_list, a_list, b_list))
+    assert (a == b).sum() > 10
+    P0, Q0 = rng.random((U, dim)) / 3, rng.random((I, dim)) / 3
+    Pr, Qr = P0.copy(), Q0.copy()
+    want = O.tbpr_epoch(Pr, Qr, u, a, b, 0.05, 0.02, 0.03)
+    t = DeviceTables(P0, Q0, dtype)
+    sums, loss2 = DB.zeros(2, np.float64), DB.zeros(2, np.float64)
+    capi.sumsq(t.P, t.code, U, dim, t.ld, sums.ptr); capi.sumsq(t.Q, t.code, I, dim, t.ld, sums.ptr + 8)
+    capi.tbpr_sgd_ordered(t.P, t.Q, t.code, dim, t.ld, DB.from_numpy(u), DB.from_numpy(a), DB.from_numpy(b), u.size, 0.05, 0.02, 0.03, sums, loss2)
+    nll, reg = loss2.numpy()
+    assert abs(nll + reg - want) / want < tol
+    Pg, Qg = t.download(np.float64)
+    assert rel_err(Pg, Pr) < tol and rel_err(Qg, Qr) < tol
+    # the regularisation part alone: per-user sums of squares of the evolving tables
+    Pc, Qc = P0.copy(), Q0.copy()
+    only_nll = sum(O.bpr_sgd(Pc, Qc, u[k:k + 1], a[k:k + 1], b[k:k + 1], 0.05, 0.02, 0.03) for k in range(u.size))
+    assert abs(nll - only_nll) / only_nll < tol and abs(reg - (want - only_nll)) / (want - only_nll) < max(tol, 1e-12)
+
+
+def test_tbpr_model_reproduces_the_reference_run(tmp_path):
+    """Drop-in TBPR on FilmTrust + trust.txt against the recorded run of the unmodified reference.  The joint-item
+    lists are ordered by a Python set of strings in the reference (process dependent), so the class' own lists are
+    checked as what they are -- weak and strong lists exactly, joint lists as sets -- and the recorded order is then
+    injected: chained triplet stream bit-exact, P and Q 1e-10, loss incl. the per-user terms, measures, generator."""
+    from qrec_amd.model.ranking.TBPR import TBPR
+    from qrec_amd.util.io import FileIO
+    meta, z = load_golden("tbpr_filmtrust")
+    name = lambda c: f"u{c}" if c >= 0 else f"x{-1 - c}"
+    path = tmp_path / "trust.txt"
+    path.write_text("".join(f"{name(x)} {name(y)} {w:g}\n" for x, y, w in zip(z["raw_follower"].tolist(), z["raw_followee"].tolist(), z["raw_weight"].tolist())))
+    train, test = rows_from_golden(z)
+    conf = conf_from_text(meta["conf"])
+    fixture_sets = tuple((z[t + "_indptr"], z[t + "_items"]) for t in ("joint", "weak", "strong"))
+    seen = {}
+
+    class Recorded(TBPR):
+        def _item_sets(self):
+            seen["own"] = TBPR._item_sets(self)
+            return fixture_sets
+    orig = capi.mt_tbpr_sample_epoch
+    streams = []
+
+    def spy(*args):
+        out = orig(*args); streams.append(np.stack(out, axis=1)); return out
+    capi.mt_tbpr_sample_epoch = spy
+    try:
+        random.seed(meta["seed"]); np.random.seed(meta["seed"])
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            m = Recorded(conf, train, test, FileIO.loadRelationship(conf, str(path)))
+            measure = m.execute()
+    finally:
+        capi.mt_tbpr_sample_epoch = orig
+    assert len(m.social.relation) == meta["relations_kept"]
+    assert m.theta == meta["theta"] and m.t_s == pytest.approx(meta["t_s"], rel=1e-15) and m.t_w == meta["t_w"] and m.g_theta == meta["g_theta"]
+    np.testing.assert_array_equal(m.weights, z["tie_weights"])
+    (jp, ji), (wp, wi), (sp_, si) = seen["own"]
+    assert np.array_equal(wp, fixture_sets[1][0]) and np.array_equal(wi, fixture_sets[1][1])
+    assert np.array_equal(sp_, fixture_sets[2][0]) and np.array_equal(si, fixture_sets[2][1])
+    assert np.array_equal(jp, fixture_sets[0][0])
+    for r in range(jp.size - 1):
+        assert set(ji[jp[r]:jp[r + 1]].tolist()) == set(fixture_sets[0][1][jp[r]:jp[r + 1]].tolist())
+    assert np.array_equal(np.concatenate(streams), z["steps"])
+    last = len(meta["epochs"])
+    np.testing.assert_allclose(m.P, z[f"P{last}"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(m.Q, z[f"Q{last}"], rtol=1e-10, atol=1e-13)
+    out = buf.getvalue()
+    losses = [float(l.split("loss = ")[1].split(",")[0]) for l in out.splitlines() if "loss = " in l]
+    np.testing.assert_allclose(losses, [round(e["loss"], 4) for e in meta["epochs"]], rtol=0, atol=1.01e-4)
+    assert m.lastLoss == pytest.approx(meta["epochs"][-1]["loss"], rel=1e-11) and m.lRate == pytest.approx(meta["epochs"][-1]["lr_next"], rel=1e-15)
+    assert out.count("Theta: 0.0") == last and out.count("g_theta: 0.0") == last
+    for g, w in zip(measure, meta["measure"]):
+        if ":" in w:
+            assert float(g.split(":")[1]) == pytest.approx(float(w.split(":")[1]), rel=1e-9)
+    assert np.array_equal(capi.state_from_python(random.getstate()), z["py_state"])

@@ -465,3 +465,23 @@ def test_sept_graph_builders_of_the_product_match_the_reference_bitwise():
     assert same(sept_perturbed_adjacency(st, *args, meta["drop_rate"]), "sub2", np.float32)
     assert np.array_equal(st, z["state_after"])
     assert same(sept_perturbed_adjacency(st, *args, 0.0), "full", np.float32) and np.array_equal(st, z["state_after"])
+
+
+def test_tbpr_native_sampler_reproduces_the_reference_stream():
+    """qrec_mt_tbpr_sample_epoch (host side of model/ranking/TBPR.py:131-158) on the recorded run: every epoch's chained
+    (u, a, b) triplets bit-exact, the generator left where the reference's was after its per-epoch shuffle."""
+    meta, z = load_golden("tbpr_filmtrust")
+    U, I = meta["n_users"], meta["n_items"]
+    pos = user_item_csr(z["train_uid"], z["train_iid"], z["train_r"], U, I, min_rating=1)
+    sets = [(z[t + "_indptr"], z[t + "_items"]) for t in ("joint", "weak", "strong")]
+    random.seed(meta["seed"])
+    words = capi.state_from_python(random.getstate())
+    got = []
+    for _ in meta["epochs"]:
+        u, a, b = capi.mt_tbpr_sample_epoch(words, pos.indptr, pos.indices, I, *sets)
+        got.append(np.stack([u, a, b], axis=1))
+        capi.mt_shuffle(words, meta["n_train"])                      # isConverged: shuffle(trainingData)
+    assert np.array_equal(np.concatenate(got), z["steps"])
+    assert np.array_equal(words, z["py_state"])
+    with pytest.raises(ValueError, match="one row per user"):
+        capi.mt_tbpr_sample_epoch(words, pos.indptr, pos.indices, I, (sets[0][0][:-1], sets[0][1]), sets[1], sets[2])

@@ -290,3 +290,36 @@ def test_sept_graph_builders_match_the_reference(golden_dir):
         same(T.sept_sub_adjacency(U, I, uid, iid, fo, fe, keep, skeep), tag, np.float32)
     assert np.array_equal(m.words625(), z["state_after"])
     assert meta["relations_kept"] == fo.size < meta["relations_loaded"]
+
+
+def test_tbpr_filmtrust_stream_tables_and_loss(golden_dir):
+    """model/ranking/TBPR.py (numpy path) through the oracle against the recorded run of the unmodified reference: the
+    chained triplet stream bit-exact (joint / weak / strong item lists as that process ordered them), P and Q after
+    every epoch, the loss with its per-user regularisation terms, the learning-rate schedule, the generator state."""
+    meta, z = _load(golden_dir, "tbpr_filmtrust")
+    U, I = meta["n_users"], meta["n_items"]
+    P, Q = z["P0"].copy(), z["Q0"].copy()
+    pos = user_item_csr(z["train_uid"], z["train_iid"], z["train_r"], U, I, min_rating=1)
+    sets = [(z[t + "_indptr"], z[t + "_items"]) for t in ("joint", "weak", "strong")]
+    mt = O.MT.cpython_seed(meta["seed"])
+    lr, last, streams = meta["epochs"][0]["lr_used"], 0.0, []
+    for ep in meta["epochs"]:
+        u, a, b = O.tbpr_sample_epoch(mt, pos.indptr, pos.indices, I, *sets)
+        assert u.size == meta["triplets_per_epoch"]
+        loss = O.tbpr_epoch(P, Q, u, a, b, lr, meta["regU"], meta["regI"])
+        k = ep["epoch"]
+        np.testing.assert_allclose(P, z[f"P{k}"], rtol=1e-11, atol=1e-14)
+        np.testing.assert_allclose(Q, z[f"Q{k}"], rtol=1e-11, atol=1e-14)
+        assert loss == pytest.approx(ep["loss"], rel=1e-12) and lr == pytest.approx(ep["lr_used"], rel=1e-15)
+        if not abs(last - loss) < 1e-3:                     # base/iterativeRecommender.py:88-104
+            if k > 1:
+                lr = lr * 1.05 if abs(last) > abs(loss) else lr * 0.5
+            lr = min(lr, 1.0)
+        assert lr == pytest.approx(ep["lr_next"], rel=1e-15)
+        last = loss
+        mt.shuffle(meta["n_train"])
+        streams.append(np.stack([u, a, b], axis=1))
+    stream = np.concatenate(streams)
+    assert np.array_equal(stream, z["steps"]) and _sha(stream) == meta["stream_sha256"]
+    assert np.array_equal(mt.words625()[:624], z["py_state"][:624]) and mt.words625()[624] == z["py_state"][624]
+    assert (stream[:, 1] == stream[:, 2]).any()             # the last draw does repeat a social item now and then: rows alias
