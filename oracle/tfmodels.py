@@ -645,3 +645,196 @@ class SEPT:
         rec, nd, g, _ = self.loss_and_grad(u_idx, i_idx, j_idx, sub_adj, labels)
         (self.opt1 if sub_adj is None else self.opt2).step(self.W, g)
         return rec, float(self.ss_rate) * nd
+
+
+# ======================================================================================
+# MHCN  (model/ranking/MHCN.py:15-240) -- multi-channel hypergraph convolution over three motif-induced user-user
+# adjacencies plus the user-item graph, self-gating, channel attention, hierarchical mutual-information maximisation.
+# The graph builders are pure scipy / python in the reference and ARE pinned to it (tests/golden/mhcn_graphs_filmtrust.npz);
+# the TF arithmetic is restated (unpinned, see header).  tf.random.shuffle is not reproducible outside TF: the five
+# permutations each hierarchical_self_supervision call draws per step are inputs here.
+# ======================================================================================
+def mhcn_motif_adjacencies(n_users: int, n_items: int, uid, iid, follower, followee):
+    """buildSparseRelationMatrix / buildSparseRatingMatrix / buildMotifInducedAdjacencyMatrix (MHCN.py:26-85):
+    the ten triangle motifs over the follow graph S and the purchase graph Y, summed into the social (H_s), joint (H_j)
+    and purchase (H_p, co-purchase counts > 1) channels, each divided by its row sums.  float32 CSR."""
+    S = sp.coo_matrix((np.ones(len(follower), np.float32), (np.asarray(follower), np.asarray(followee))), shape=(n_users, n_users), dtype=np.float32)
+    Y = sp.coo_matrix((np.ones(len(uid), np.float32), (np.asarray(uid), np.asarray(iid))), shape=(n_users, n_items), dtype=np.float32)
+    B = S.multiply(S.T)
+    U = S - B
+    C1 = (U.dot(U)).multiply(U.T); A1 = C1 + C1.T
+    C2 = (B.dot(U)).multiply(U.T) + (U.dot(B)).multiply(U.T) + (U.dot(U)).multiply(B); A2 = C2 + C2.T
+    C3 = (B.dot(B)).multiply(U) + (B.dot(U)).multiply(B) + (U.dot(B)).multiply(B); A3 = C3 + C3.T
+    A4 = (B.dot(B)).multiply(B)
+    C5 = (U.dot(U)).multiply(U) + (U.dot(U.T)).multiply(U) + (U.T.dot(U)).multiply(U); A5 = C5 + C5.T
+    A6 = (U.dot(B)).multiply(U) + (B.dot(U.T)).multiply(U.T) + (U.T.dot(U)).multiply(B)
+    A7 = (U.T.dot(B)).multiply(U.T) + (B.dot(U)).multiply(U) + (U.dot(U.T)).multiply(B)
+    A8 = (Y.dot(Y.T)).multiply(B)
+    A9 = (Y.dot(Y.T)).multiply(U); A9 = A9 + A9.T
+    A10 = Y.dot(Y.T) - A8 - A9
+    with np.errstate(divide="ignore"):
+        H_s = sum([A1, A2, A3, A4, A5, A6, A7]); H_s = H_s.multiply(1.0 / H_s.sum(axis=1).reshape(-1, 1))
+        H_j = sum([A8, A9]); H_j = H_j.multiply(1.0 / H_j.sum(axis=1).reshape(-1, 1))
+        H_p = A10.multiply(A10 > 1); H_p = H_p.multiply(1.0 / H_p.sum(axis=1).reshape(-1, 1))
+    return [sp.csr_matrix(H) for H in (H_s, H_j, H_p)]
+
+
+def mhcn_joint_adjacency(n_users: int, n_items: int, uid, iid, ratings):
+    """buildJointAdjacency (MHCN.py:46-52): one entry per training row, rating / sqrt(#items of u) / sqrt(#users of i)
+    (counts of DISTINCT partners, python floats -> float32 tensor); duplicate rows add up in the sparse product."""
+    uid, iid = np.asarray(uid), np.asarray(iid)
+    pairs = np.unique(np.stack([uid, iid], 1), axis=0)
+    du = np.bincount(pairs[:, 0], minlength=n_users); di = np.bincount(pairs[:, 1], minlength=n_items)
+    from math import sqrt
+    vals = [float(r) / sqrt(du[u]) / sqrt(di[i]) for u, i, r in zip(uid.tolist(), iid.tolist(), np.asarray(ratings).tolist())]
+    return sp.csr_matrix((np.asarray(vals, np.float32), (uid, iid)), shape=(n_users, n_items))
+
+
+def _sigmoid(x):
+    return (np.float32(1) / (np.float32(1) + np.exp(-x, dtype=np.float32))).astype(np.float32)
+
+
+def _nls(x):
+    """-log(sigmoid(x)) as tf evaluates it: -log(1 / (1 + exp(-x)))"""
+    return -np.log(_sigmoid(x), dtype=np.float32)
+
+
+class MHCN:
+    """model/ranking/MHCN.py:93-229 restated.  ``weights``: dict with the reference's keys (gating1-4, gating_bias1-4,
+    sgating1-4, sgating_bias1-4, attention, attention_mat).  ``perms`` for a step: for each of the three channels
+    (row_pi1, col_k2, row_pi2, col_k3, row_pi3) -- row_shuffle, row_column_shuffle (neg2), row_column_shuffle (global)."""
+
+    def __init__(self, U0, V0, weights, H, R, n_layers, lr, reg, ss_rate):
+        f = np.float32
+        self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
+        self.U, self.V = U0.astype(f).copy(), V0.astype(f).copy()
+        self.w = {k: np.asarray(v, f).copy() for k, v in weights.items()}
+        self.H = [h.astype(f).tocsr() for h in H]; self.R = R.astype(f).tocsr()
+        self.L, self.reg, self.ss_rate = n_layers, f(reg), f(ss_rate)
+        self.opt = {k: AdamTF114(v.shape, lr) for k, v in list(self.w.items()) + [("U", self.U), ("V", self.V)]}
+
+    # ---- pieces with their backward closures ----------------------------------------------------------------
+    def gate(self, X, W, b):
+        s = _sigmoid((X @ W + b).astype(np.float32))
+        def bwd(dY):
+            q = (dY * X * s * (np.float32(1) - s)).astype(np.float32)
+            return (dY * s + q @ W.T).astype(np.float32), (X.T @ q).astype(np.float32), q.sum(0, keepdims=True).astype(np.float32)
+        return (X * s).astype(np.float32), bwd
+
+    def attention(self, es):
+        f = np.float32
+        a, M = self.w["attention"], self.w["attention_mat"]
+        v = (M @ a[0]).astype(f)                                        # sum(a * (e M), 1) = e . (M a)
+        w = np.stack([(e @ M * a).sum(1, dtype=f) for e in es], 1)      # [n, 3], as the reference evaluates it
+        ex = np.exp(w - w.max(1, keepdims=True), dtype=f)
+        sc = (ex / ex.sum(1, keepdims=True, dtype=f)).astype(f)
+        out = sum(sc[:, k:k + 1] * es[k] for k in range(3)).astype(f)
+        def bwd(dOut):
+            dsc = np.stack([(dOut * e).sum(1, dtype=f) for e in es], 1)
+            dw = (sc * (dsc - (sc * dsc).sum(1, keepdims=True, dtype=f))).astype(f)
+            des = [(sc[:, k:k + 1] * dOut + dw[:, k:k + 1] * v[None, :]).astype(f) for k in range(3)]
+            dv = sum((dw[:, k:k + 1] * es[k]).sum(0, dtype=f) for k in range(3)).astype(f)
+            return des, (M.T @ dv)[None, :].astype(f), np.outer(dv, a[0]).astype(f)      # d attention, d attention_mat
+        return out, sc, bwd
+
+    def hss(self, em, H, perm):
+        """hierarchical_self_supervision (MHCN.py:184-206); returns (loss, d em)"""
+        f = np.float32
+        p1, k2, p2, k3, p3 = perm
+        n = em.shape[0]
+        edge = H.dot(em).astype(f)
+        e2, e3 = edge[:, k2][p2], edge[:, k3][p3]
+        pos, neg1, neg2 = (em * edge).sum(1, dtype=f), (em[p1] * edge).sum(1, dtype=f), (e2 * em).sum(1, dtype=f)
+        graph = edge.mean(0, dtype=f)
+        pg, ng = edge @ graph, e3 @ graph
+        loss = float((_nls(pos - neg1) + _nls(neg1 - neg2)).sum(dtype=np.float64) + _nls(pg - ng).sum(dtype=np.float64))
+        c1, c2, c3 = -(f(1) - _sigmoid(pos - neg1)), -(f(1) - _sigmoid(neg1 - neg2)), -(f(1) - _sigmoid(pg - ng))
+        d_pos, d_neg1, d_neg2 = c1, c2 - c1, -c2
+        dem = (d_pos[:, None] * edge + d_neg2[:, None] * e2).astype(f)
+        np.add.at(dem, p1, d_neg1[:, None] * edge)
+        dedge = (d_pos[:, None] * em + d_neg1[:, None] * em[p1] + c3[:, None] * graph[None, :]).astype(f)
+        t = np.zeros_like(edge); np.add.at(t, p2, d_neg2[:, None] * em)                  # back through rows p2 ...
+        inv2 = np.empty_like(k2); inv2[k2] = np.arange(k2.size); dedge += t[:, inv2]         # ... and columns k2
+        t = np.zeros_like(edge); np.add.at(t, p3, (-c3)[:, None] * graph[None, :])
+        inv3 = np.empty_like(k3); inv3[k3] = np.arange(k3.size); dedge += t[:, inv3]
+        dgraph = (c3[:, None] * (edge - e3)).sum(0, dtype=f)
+        dedge += dgraph[None, :] / f(n)
+        return loss, (dem + H.T.dot(dedge)).astype(f)
+
+    def forward(self):
+        """-> final_user, final_item, cache"""
+        f = np.float32
+        w = self.w
+        gates = [self.gate(self.U, w[f"gating{k}"], w[f"gating_bias{k}"]) for k in (1, 2, 3, 4)]
+        c = [g[0] for g in gates[:3]]; s = gates[3][0]; t = self.V
+        lay = dict(c=[c], s=[s], t=[t], att=[])
+        sums = [x.copy() for x in c] + [s.copy(), t.copy()]
+        invs = []
+        for _ in range(self.L):
+            mix, _, att_b = self.attention(c)
+            mixed = (mix + s / f(2)).astype(f)
+            c = [self.H[k].dot(c[k]).astype(f) for k in range(3)]
+            t_new = self.R.T.dot(mixed).astype(f)
+            s = self.R.dot(t).astype(f)
+            t = t_new
+            inv = []
+            for idx, x in enumerate(c + [s, t]):
+                z, r = l2_normalize_rows(x); sums[idx] += z; inv.append(r)
+            invs.append(inv); lay["c"].append(c); lay["s"].append(s); lay["t"].append(t); lay["att"].append(att_b)
+        fu, score, att_f = self.attention(sums[:3])
+        fu = (fu + sums[3] / f(2)).astype(f)
+        return fu, sums[4], dict(gates=gates, lay=lay, invs=invs, att_f=att_f, score=score)
+
+    def loss_and_grads(self, u_idx, i_idx, j_idx, perms):
+        """-> (rec_loss, ss_loss, reg_loss, grads dict keyed like self.opt)"""
+        f = np.float32
+        w = self.w
+        fu, fi, cache = self.forward()
+        ub, ib, jb = fu[u_idx], fi[i_idx], fi[j_idx]
+        rec, du, di, dj = bpr_batch_loss_and_grads(ub, ib, jb, 0.0)
+        dfu, dfi = np.zeros_like(fu), np.zeros_like(fi)
+        np.add.at(dfu, u_idx, du); np.add.at(dfi, i_idx, di); np.add.at(dfi, j_idx, dj)
+        g = {k: (f(0.001) * v).astype(f) for k, v in w.items()}                         # 0.001 * l2_loss of every weight (:211-212)
+        reg = 0.001 * 0.5 * float(sum((v.astype(np.float64) ** 2).sum() for v in w.values()))
+        reg += float(self.reg) * 0.5 * float((self.U.astype(np.float64) ** 2).sum() + (self.V.astype(np.float64) ** 2).sum())
+        ss = 0.0
+        for k in range(3):
+            sg, sg_b = self.gate(fu, w[f"sgating{k + 1}"], w[f"sgating_bias{k + 1}"])
+            l, dsg = self.hss(sg, self.H[k], perms[k])
+            ss += l
+            dx, dW, db = sg_b(self.ss_rate * dsg)
+            dfu += dx; g[f"sgating{k + 1}"] += dW; g[f"sgating_bias{k + 1}"] += db
+        # final aggregation
+        des, da, dM = cache["att_f"](dfu)
+        g["attention"] += da; g["attention_mat"] += dM
+        dsum = des + [(dfu / f(2)).astype(f), dfi]                                     # d sums of c1, c2, c3, s, t
+        lay, invs = cache["lay"], cache["invs"]
+        L = self.L
+        gc = [None] * 3; gs = gt = None
+        for l in range(L, 0, -1):
+            nb = [l2_normalize_bwd(x, r, d) for x, r, d in zip(lay["c"][l] + [lay["s"][l], lay["t"][l]], invs[l - 1], dsum)]
+            gc = [nb[k] if gc[k] is None else (nb[k] + gc[k]).astype(f) for k in range(3)]
+            gs = nb[3] if gs is None else (nb[3] + gs).astype(f)
+            gt = nb[4] if gt is None else (nb[4] + gt).astype(f)
+            dmixed = self.R.dot(gt).astype(f)                                            # t^(l) = R^T mixed
+            gt_prev = self.R.T.dot(gs).astype(f)                                         # s^(l) = R t^(l-1)
+            gc_prev = [self.H[k].T.dot(gc[k]).astype(f) for k in range(3)]               # c^(l) = H c^(l-1)
+            des, da, dM = lay["att"][l - 1](dmixed)
+            g["attention"] += da; g["attention_mat"] += dM
+            gc = [(gc_prev[k] + des[k]).astype(f) for k in range(3)]; gs = (dmixed / f(2)).astype(f); gt = gt_prev
+        dG = [dsum[k] if gc[k] is None else (dsum[k] + gc[k]).astype(f) for k in range(3)]
+        dG.append(dsum[3] if gs is None else (dsum[3] + gs).astype(f))
+        dV = dsum[4] if gt is None else (dsum[4] + gt).astype(f)
+        dU = (self.reg * self.U).astype(f)
+        for k in range(4):
+            dx, dW, db = cache["gates"][k][1](dG[k])
+            dU += dx; g[f"gating{k + 1}"] += dW; g[f"gating_bias{k + 1}"] += db
+        g["U"] = dU; g["V"] = (dV + self.reg * self.V).astype(f)
+        return rec, ss, reg, g
+
+    def train_step(self, u_idx, i_idx, j_idx, perms):
+        """returns rec_loss, what the reference prints (MHCN.py:223-225)"""
+        rec, ss, reg, g = self.loss_and_grads(u_idx, i_idx, j_idx, perms)
+        for k, opt in self.opt.items():
+            opt.step(self.U if k == "U" else self.V if k == "V" else self.w[k], g[k])
+        return rec

@@ -428,13 +428,55 @@ def case_sept_graphs(tmp):
                 social_users=len(m.social.user), drop_rate=m.drop_rate, regS=m.regS)
 
 
+def case_mhcn_graphs(tmp):
+    """model/ranking/MHCN.py:26-85 (pure scipy): the three motif-induced hypergraph adjacencies H_s, H_j, H_p, and the
+    value list of buildJointAdjacency (:46-52; tf.SparseTensor is replaced by a recorder for this one call)."""
+    import tensorflow as tf
+    from QRec import QRec
+    from util.config import ModelConf
+    from model.ranking.MHCN import MHCN
+    conf = os.path.join(tmp, "mhcn.conf")
+    write_conf(conf, ratings="./dataset/FilmTrust/trainset.txt", social="./dataset/FilmTrust/trust.txt",
+               ratings__setup="-columns 0 1 2", social__setup="-columns 0 1 2",
+               model__name="MHCN", evaluation__setup="-testSet ./dataset/FilmTrust/testset.txt -b 1",
+               item__ranking="on -topN 10", num__factors="8", num__max__epoch="2", batch_size="2000",
+               learnRate="-init 0.001 -max 1", MHCN="-n_layer 2 -ss_rate 0.01",
+               reg__lambda="-u 0.001 -i 0.01 -b 0.2 -s 0.2", output__setup="off -dir ./results/")
+    random.seed(17); np.random.seed(17)
+    with redirect_stdout(io.StringIO()):
+        q = QRec(ModelConf(conf))
+        m = MHCN(q.config, q.trainingData, q.testData, q.relation)
+        m.readConfiguration()
+        m.num_users, m.num_items, m.train_size = m.data.trainingSize()
+    arrays = dict(train_uid=np.array([m.data.user[r[0]] for r in m.data.trainingData], dtype=np.int32),
+                  train_iid=np.array([m.data.item[r[1]] for r in m.data.trainingData], dtype=np.int32),
+                  train_r=np.array([r[2] for r in m.data.trainingData], dtype=np.float64),
+                  follower=np.array([m.data.user[r[0]] for r in m.social.relation], dtype=np.int32),
+                  followee=np.array([m.data.user[r[1]] for r in m.social.relation], dtype=np.int32))
+    with np.errstate(divide="ignore"):
+        H = m.buildMotifInducedAdjacencyMatrix()
+    for tag, A in zip(("Hs", "Hj", "Hp"), H):
+        A = A.tocsr(); A.sort_indices()
+        assert A.data.dtype == np.float32 and A.shape[1] < 32768
+        arrays[tag + "_indptr"] = A.indptr.astype(np.int64); arrays[tag + "_indices"] = A.indices.astype(np.int16)
+        arrays[tag + "_data"] = A.data                                # float32, as the reference holds them
+    tf.SparseTensor = lambda indices, values, dense_shape: (indices, values, dense_shape)
+    idx, vals, shape = m.buildJointAdjacency()
+    del tf.SparseTensor
+    arrays["R_indices"] = np.array(idx, dtype=np.int32); arrays["R_values"] = np.array(vals, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "mhcn_graphs_filmtrust.npz"), **arrays)
+    return dict(name="mhcn_graphs_filmtrust", seed=17, conf=open(conf).read(), n_users=len(m.data.user), n_items=len(m.data.item),
+                n_train=len(m.data.trainingData), relations_kept=len(m.social.relation), R_shape=[int(x) for x in shape],
+                nnz=[int(A.nnz) for A in H])
+
+
 def main():
     install_stubs()
     tmp = tempfile.mkdtemp(prefix="qrec_golden_")
     os.symlink(os.path.join(REF, "dataset"), os.path.join(tmp, "dataset"))
     os.chdir(tmp)
     only = sys.argv[1:]
-    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pmf, case_svd, case_ee, case_svdpp, case_pairwise_and_adj, case_sgl_subgraph, case_sept_graphs, case_tbpr_filmtrust]
+    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pmf, case_svd, case_ee, case_svdpp, case_pairwise_and_adj, case_sgl_subgraph, case_sept_graphs, case_tbpr_filmtrust, case_mhcn_graphs]
     if only:   # regenerate a subset, keep the other entries of golden_meta.json
         cases = [c for c in cases if c.__name__ in only]
         old = json.load(open(os.path.join(OUT, "golden_meta.json")))

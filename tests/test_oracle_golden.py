@@ -323,3 +323,20 @@ def test_tbpr_filmtrust_stream_tables_and_loss(golden_dir):
     assert np.array_equal(stream, z["steps"]) and _sha(stream) == meta["stream_sha256"]
     assert np.array_equal(mt.words625()[:624], z["py_state"][:624]) and mt.words625()[624] == z["py_state"][624]
     assert (stream[:, 1] == stream[:, 2]).any()             # the last draw does repeat a social item now and then: rows alias
+
+
+def test_mhcn_graph_builders_match_the_reference(golden_dir):
+    """model/ranking/MHCN.py:26-85 (pure scipy / python in the reference): the three motif-induced channel adjacencies
+    and the value list of buildJointAdjacency, bit for bit in the reference's float32."""
+    from oracle import tfmodels as T
+    meta, z = _load(golden_dir, "mhcn_graphs_filmtrust")
+    U, I = meta["n_users"], meta["n_items"]
+    H = T.mhcn_motif_adjacencies(U, I, z["train_uid"], z["train_iid"], z["follower"], z["followee"])
+    for tag, A, nnz in zip(("Hs", "Hj", "Hp"), H, meta["nnz"]):
+        A.sort_indices()
+        assert A.nnz == nnz and A.data.dtype == np.float32
+        assert np.array_equal(A.indptr, z[tag + "_indptr"]) and np.array_equal(A.indices, z[tag + "_indices"]) and np.array_equal(A.data, z[tag + "_data"])
+    R = T.mhcn_joint_adjacency(U, I, z["train_uid"], z["train_iid"], z["train_r"]).tocoo()
+    want = {(int(u), int(i)): np.float32(v) for (u, i), v in zip(z["R_indices"], z["R_values"])}
+    assert R.shape == tuple(meta["R_shape"]) and R.nnz == len(want)
+    assert all(want[(int(u), int(i))] == v for u, i, v in zip(R.row, R.col, R.data))

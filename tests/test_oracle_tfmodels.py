@@ -312,3 +312,87 @@ def test_sept_gradient_matches_autograd(joint):
     for _ in range(25):
         last = m.train_step(u, i, j)
     assert last[0] < first[0] and last[1] == 0.0
+
+
+def _mhcn_problem(rng, nu=40, ni=50, d=8, E=400, R=260):
+    uid = rng.integers(0, nu, E); iid = rng.integers(0, ni, E)
+    pairs = np.unique(np.stack([uid, iid], 1), axis=0); uid, iid = pairs[:, 0], pairs[:, 1]
+    fo = rng.integers(0, nu, R); fe = rng.integers(0, nu, R)
+    keep = fo != fe
+    rel = np.unique(np.stack([fo[keep], fe[keep]], 1), axis=0)
+    H = T.mhcn_motif_adjacencies(nu, ni, uid, iid, rel[:, 0], rel[:, 1])
+    Rm = T.mhcn_joint_adjacency(nu, ni, uid, iid, np.ones(uid.size))
+    lim = np.sqrt(6.0 / (2 * d))
+    w = {}
+    for k in (1, 2, 3, 4):
+        for pre in ("gating", "sgating"):
+            w[f"{pre}{k}"] = rng.uniform(-lim, lim, (d, d)).astype(np.float32)
+            w[f"{pre}_bias{k}"] = rng.uniform(-0.5, 0.5, (1, d)).astype(np.float32)
+    w["attention"] = rng.uniform(-0.5, 0.5, (1, d)).astype(np.float32); w["attention_mat"] = rng.uniform(-lim, lim, (d, d)).astype(np.float32)
+    U0 = (rng.standard_normal((nu, d)) * 0.3).astype(np.float32); V0 = (rng.standard_normal((ni, d)) * 0.3).astype(np.float32)
+    perms = [(rng.permutation(nu), rng.permutation(d), rng.permutation(nu), rng.permutation(d), rng.permutation(nu)) for _ in range(3)]
+    return nu, ni, d, H, Rm, w, U0, V0, perms
+
+
+@pytest.mark.parametrize("L", [1, 2])
+def test_mhcn_gradients_match_autograd(L):
+    """model/ranking/MHCN.py:93-216: hand-derived gradients of U, V and all 18 weight tensors (self-gating, channel
+    attention, three hypergraph channels + the user-item channel with per-layer normalisation, hierarchical mutual
+    information with injected shuffles, weight and table L2) vs torch autograd of the same graph."""
+    rng = np.random.default_rng(170 + L)
+    nu, ni, d, H, Rm, w, U0, V0, perms = _mhcn_problem(rng)
+    assert all(h.nnz > 0 for h in H)
+    m = T.MHCN(U0, V0, w, H, Rm, L, lr=0.001, reg=0.01, ss_rate=0.05)
+    B = 64
+    u = rng.integers(0, nu, B); i = rng.integers(0, ni, B); j = rng.integers(0, ni, B)
+    rec, ss, reg, g = m.loss_and_grads(u, i, j, perms)
+
+    def tsp(a):
+        coo = a.tocoo(); return torch.sparse_coo_tensor(np.vstack([coo.row, coo.col]), coo.data.astype(np.float64), a.shape).coalesce()
+    tw = {k: torch.tensor(v.astype(np.float64), requires_grad=True) for k, v in w.items()}
+    tU = torch.tensor(U0.astype(np.float64), requires_grad=True); tV = torch.tensor(V0.astype(np.float64), requires_grad=True)
+    tH = [tsp(h) for h in m.H]; tR = tsp(m.R); tRT = tsp(m.R.T.tocsr())
+    nz = lambda x: torch.nn.functional.normalize(x, dim=1, eps=1e-6)
+    gate = lambda x, pre, k: x * torch.sigmoid(x @ tw[f"{pre}{k}"] + tw[f"{pre}_bias{k}"])
+
+    def att(es):
+        ws = torch.stack([(tw["attention"] * (e @ tw["attention_mat"])).sum(1) for e in es], 1)
+        sc = torch.softmax(ws, 1)
+        return sum(sc[:, k:k + 1] * es[k] for k in range(3))
+    c = [gate(tU, "gating", k) for k in (1, 2, 3)]; s = gate(tU, "gating", 4); t = tV
+    allc = [[x] for x in c]; alls = [s]; allt = [t]
+    for _ in range(L):
+        mixed = att(c) + s / 2
+        c = [torch.sparse.mm(tH[k], c[k]) for k in range(3)]
+        for k in range(3):
+            allc[k].append(nz(c[k]))
+        t_new = torch.sparse.mm(tRT, mixed); allt.append(nz(t_new))
+        s = torch.sparse.mm(tR, t); alls.append(nz(s))
+        t = t_new
+    fu = att([torch.stack(x).sum(0) for x in allc]) + torch.stack(alls).sum(0) / 2
+    fi = torch.stack(allt).sum(0)
+    tss = torch.zeros((), dtype=torch.float64)
+    ls = lambda x: -torch.log(torch.sigmoid(x))
+    for k in range(3):
+        em = gate(fu, "sgating", k + 1)
+        p1, k2, p2, k3, p3 = (torch.tensor(x) for x in perms[k])
+        edge = torch.sparse.mm(tH[k], em)
+        pos, neg1, neg2 = (em * edge).sum(1), (em[p1] * edge).sum(1), (edge[:, k2][p2] * em).sum(1)
+        graph = edge.mean(0)
+        tss = tss + (ls(pos - neg1) + ls(neg1 - neg2)).sum() + ls(edge @ graph - edge[:, k3][p3] @ graph).sum()
+    tu, ti, tj = torch.tensor(u), torch.tensor(i), torch.tensor(j)
+    trec = -torch.log(torch.sigmoid((fu[tu] * fi[ti]).sum(1) - (fu[tu] * fi[tj]).sum(1)) + 1e-7).sum()
+    treg = 0.001 * sum(0.5 * (v ** 2).sum() for v in tw.values()) + 0.01 * 0.5 * ((tU ** 2).sum() + (tV ** 2).sum())
+    (trec + treg + 0.05 * tss).backward()
+    assert rec == pytest.approx(float(trec.detach()), rel=1e-5) and ss == pytest.approx(float(tss.detach()), rel=1e-5)
+    assert reg == pytest.approx(float(treg.detach()), rel=1e-6)
+    for k, v in tw.items():
+        np.testing.assert_allclose(g[k], v.grad.numpy(), rtol=3e-3, atol=3e-6, err_msg=k)
+    np.testing.assert_allclose(g["U"], tU.grad.numpy(), rtol=3e-3, atol=3e-6)
+    np.testing.assert_allclose(g["V"], tV.grad.numpy(), rtol=3e-3, atol=3e-6)
+    # sgating4 exists (n_channel = 4) but only three self-supervised gates are used: it sees its L2 term alone
+    np.testing.assert_allclose(g["sgating4"], np.float32(0.001) * w["sgating4"], rtol=1e-6)
+    first = m.train_step(u, i, j, perms)
+    for _ in range(30):
+        last = m.train_step(u, i, j, perms)
+    assert last < first
