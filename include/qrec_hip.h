@@ -392,6 +392,44 @@ int qrec_tbpr_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld
                           const int32_t *d_b, int64_t n, double lr, double regU, double regI, const double *d_sums_in,
                           double *d_loss2, void *stream);
 
+/* ---- MHCN: model/ranking/MHCN.py:93-216 (self-gating, channel attention, hierarchical self-supervision) ---------------
+ * Tables [rows][ld] fp32, ld in {32, 64, 128, 256}, columns >= d zero; d x d weights zero-padded to [ld][ld], biases [ld].
+ * qrec_gate_fwd:  Y = X * sigmoid(X W + b), S = sigmoid(.)  -- self_gating / self_supervised_gating (MHCN.py:109-112).
+ * qrec_gate_bwd:  Q = (dy_scale dY) * X * S (1 - S);  dX (+)= dy_scale dY * S + Q W^T.  The weight gradients are
+ *   dW = X^T Q, db = column sums of Q: qrec_buir_wgrad(X, Q, ...).
+ * qrec_channel_attention_fwd (MHCN.py:113-121): v = att_mat att^T (d_v, [ld] scratch kept for the backward pass),
+ *   score = softmax_k(e_k . v) ([rows][4], 4th unused), out = sum_k score_k e_k + half / 2 (half nullable).
+ * qrec_channel_attention_bwd: de_k (+)= score_k dOut + dw_k v (accumulate flag), dhalf (+)= dOut / 2 (nullable),
+ *   g_att += att_mat^T dv, g_att_mat += dv (x) att with dv = sum_rows sum_k dw_k e_k (d_dv_scratch: 256 floats).
+ * qrec_hss_loss_grad: hierarchical_self_supervision (MHCN.py:184-206) given edge = H em and the call's five shuffles
+ *   (row p1; column k2 then row p2; column k3 then row p3 -- tf.random.shuffle of range(n) / range(d)) with their
+ *   inverses: *d_loss += local + global MIM loss (unscaled); d_dem / d_dedge = scale * gradient w.r.t. em / edge
+ *   (overwritten).  d_scratch: qrec_hss_scratch_bytes(n).
+ * qrec_random_permutation: a uniformly random permutation of range(n) (64-bit Philox keys, rocPRIM radix sort) and its
+ *   inverse; qrec_small_permutations: `count` Fisher-Yates permutations of range(n <= 4096) with inverses. */
+int qrec_gate_fwd(const float *d_X, const float *d_W, const float *d_bias, int64_t n_rows, int32_t ld, float *d_Y, float *d_S,
+                  void *stream);
+int qrec_gate_bwd(const float *d_X, const float *d_S, const float *d_dY, const float *d_W, int64_t n_rows, int32_t d, int32_t ld,
+                  float dy_scale, float *d_Q, float *d_dX, int32_t accumulate, void *stream);
+int qrec_channel_attention_fwd(const float *d_e1, const float *d_e2, const float *d_e3, const float *d_att, const float *d_att_mat,
+                               const float *d_half, int64_t n_rows, int32_t ld, float *d_v, float *d_score, float *d_out,
+                               void *stream);
+int qrec_channel_attention_bwd(const float *d_dOut, const float *d_e1, const float *d_e2, const float *d_e3, const float *d_score,
+                               const float *d_v, const float *d_att, const float *d_att_mat, int64_t n_rows, int32_t ld,
+                               float *d_de1, float *d_de2, float *d_de3, int32_t accumulate, float *d_dhalf, int32_t half_accumulate,
+                               float *d_dv_scratch, float *d_g_att, float *d_g_att_mat, void *stream);
+int qrec_hss_scratch_bytes(int64_t n_rows, int64_t *bytes);
+int qrec_hss_loss_grad(const float *d_em, const float *d_edge, int64_t n_rows, int32_t d, int32_t ld, const int32_t *d_p1,
+                       const int32_t *d_p1inv, const int32_t *d_p2, const int32_t *d_p2inv, const int32_t *d_k2,
+                       const int32_t *d_k2inv, const int32_t *d_p3, const int32_t *d_p3inv, const int32_t *d_k3,
+                       const int32_t *d_k3inv, float scale, float *d_scratch, float *d_dem, float *d_dedge, double *d_loss,
+                       void *stream);
+int qrec_random_permutation_scratch_bytes(int64_t n, int64_t *bytes);
+int qrec_random_permutation(int64_t n, uint64_t seed, uint64_t stream_id, void *d_scratch, int32_t *d_perm, int32_t *d_inv,
+                            void *stream);
+int qrec_small_permutations(int32_t n, int32_t count, uint64_t seed, uint64_t stream_id, int32_t *d_perms, int32_t *d_invs,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,15 @@ _SIGNATURES = {
     "qrec_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
     "qrec_perturb_rows": [_vp, _vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp],
     "qrec_info_nce_workspace_bytes": [_i32, _i32, _vp],
+    "qrec_gate_fwd": [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
+    "qrec_gate_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp],
+    "qrec_channel_attention_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp],
+    "qrec_channel_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp],
+    "qrec_hss_scratch_bytes": [_i64, _vp],
+    "qrec_hss_loss_grad": [_vp, _vp, _i64, _i32, _i32] + [_vp] * 10 + [_f32, _vp, _vp, _vp, _vp, _vp],
+    "qrec_random_permutation_scratch_bytes": [_i64, _vp],
+    "qrec_random_permutation": [_i64, _u64, _u64, _vp, _vp, _vp, _vp],
+    "qrec_small_permutations": [_i32, _i32, _u64, _u64, _vp, _vp, _vp],
     "qrec_l2norm_rows_accum": [_vp, _i64, _i32, _vp, _vp, _vp],
     "qrec_l2norm_rows_bwd": [_vp, _vp, _vp, _i64, _i32, _vp, _vp],
     "qrec_scale_copy": [_vp, _vp, _i64, _f32, _vp],
@@ -587,6 +596,55 @@ def info_nce_loss_grad(d_S1, d_S2, div: float, d_rows, n: int, ld: int, tau: flo
                        d_out, d_loss, stream=None, d_out2=None):
     _check(load().qrec_info_nce_loss_grad(_dp(d_S1), _dp(d_S2), div, _dp(d_rows), n, ld, tau, cl_rate,
                                           _dp(d_workspace), _dp(d_out), _dp(d_out2), _dp(d_loss), _sh(stream)))
+
+
+def gate_fwd(d_X, d_W, d_bias, n_rows: int, ld: int, d_Y, d_S, stream=None):
+    """Y = X * sigmoid(X W + b), S = the sigmoid (MHCN.py:109-112)"""
+    _check(load().qrec_gate_fwd(_dp(d_X), _dp(d_W), _dp(d_bias), n_rows, ld, _dp(d_Y), _dp(d_S), _sh(stream)))
+
+
+def gate_bwd(d_X, d_S, d_dY, d_W, n_rows: int, d: int, ld: int, d_Q, d_dX, accumulate: bool, dy_scale: float = 1.0, stream=None):
+    _check(load().qrec_gate_bwd(_dp(d_X), _dp(d_S), _dp(d_dY), _dp(d_W), n_rows, d, ld, dy_scale, _dp(d_Q), _dp(d_dX),
+                                1 if accumulate else 0, _sh(stream)))
+
+
+def channel_attention_fwd(d_e, d_att, d_att_mat, d_half, n_rows: int, ld: int, d_v, d_score, d_out, stream=None):
+    _check(load().qrec_channel_attention_fwd(_dp(d_e[0]), _dp(d_e[1]), _dp(d_e[2]), _dp(d_att), _dp(d_att_mat), _dp(d_half), n_rows, ld,
+                                             _dp(d_v), _dp(d_score), _dp(d_out), _sh(stream)))
+
+
+def channel_attention_bwd(d_dOut, d_e, d_score, d_v, d_att, d_att_mat, n_rows: int, ld: int, d_de, accumulate: bool, d_dhalf,
+                          half_accumulate: bool, d_dv_scratch, d_g_att, d_g_att_mat, stream=None):
+    _check(load().qrec_channel_attention_bwd(_dp(d_dOut), _dp(d_e[0]), _dp(d_e[1]), _dp(d_e[2]), _dp(d_score), _dp(d_v), _dp(d_att),
+                                             _dp(d_att_mat), n_rows, ld, _dp(d_de[0]), _dp(d_de[1]), _dp(d_de[2]), 1 if accumulate else 0,
+                                             _dp(d_dhalf), 1 if half_accumulate else 0, _dp(d_dv_scratch), _dp(d_g_att),
+                                             _dp(d_g_att_mat), _sh(stream)))
+
+
+def hss_scratch_bytes(n_rows: int) -> int:
+    out = C.c_int64(0)
+    _check(load().qrec_hss_scratch_bytes(n_rows, C.byref(out)))
+    return out.value
+
+
+def hss_loss_grad(d_em, d_edge, n_rows: int, d: int, ld: int, perms, scale: float, d_scratch, d_dem, d_dedge, d_loss, stream=None):
+    """perms: device pointers (p1, p1inv, p2, p2inv, k2, k2inv, p3, p3inv, k3, k3inv) -- MHCN.py:184-206"""
+    _check(load().qrec_hss_loss_grad(_dp(d_em), _dp(d_edge), n_rows, d, ld, *[_dp(p) for p in perms], scale, _dp(d_scratch),
+                                     _dp(d_dem), _dp(d_dedge), _dp(d_loss), _sh(stream)))
+
+
+def random_permutation_scratch_bytes(n: int) -> int:
+    out = C.c_int64(0)
+    _check(load().qrec_random_permutation_scratch_bytes(n, C.byref(out)))
+    return out.value
+
+
+def random_permutation(n: int, seed: int, stream_id: int, d_scratch, d_perm, d_inv=None, stream=None):
+    _check(load().qrec_random_permutation(n, seed & (2**64 - 1), stream_id & (2**64 - 1), _dp(d_scratch), _dp(d_perm), _dp(d_inv), _sh(stream)))
+
+
+def small_permutations(n: int, count: int, seed: int, stream_id: int, d_perms, d_invs, stream=None):
+    _check(load().qrec_small_permutations(n, count, seed & (2**64 - 1), stream_id & (2**64 - 1), _dp(d_perms), _dp(d_invs), _sh(stream)))
 
 
 def l2norm_rows_accum(d_X, n_rows: int, ld: int, d_S, d_inv, stream=None):

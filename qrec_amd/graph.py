@@ -870,3 +870,240 @@ class SEPTTrainer:
     def variables(self):
         W = self.W.numpy()[:, :self.d]
         return W[:self.nu].copy(), W[self.nu:].copy()
+
+
+# ======================================================================================================================
+# MHCN (model/ranking/MHCN.py): motif-induced channel graphs, the multi-channel trainer
+# ======================================================================================================================
+def mhcn_channel_graphs(n_users: int, n_items: int, uid, iid, ratings, follower, followee):
+    """Host side of MHCN.initModel: the three motif-induced user-user adjacencies of buildMotifInducedAdjacencyMatrix
+    (MHCN.py:54-85) and the user-item matrix of buildJointAdjacency (:46-52), scipy CSR float32.
+    S = follow graph, B = its mutual part, D = S - B its one-way part, Y = purchases.  Social channel: the seven triangle
+    motifs over B and D; joint channel: friends (mutual or one-way, symmetrised) who share an item, weighted by the
+    number of shared items; purchase channel: non-friends sharing MORE than one item.  Each divided by its row sums."""
+    import scipy.sparse as sp
+    f32 = np.float32
+    fo, fe = np.asarray(follower, np.int64), np.asarray(followee, np.int64)
+    uid, iid = np.asarray(uid, np.int64), np.asarray(iid, np.int64)
+    S = sp.coo_matrix((np.ones(fo.size, f32), (fo, fe)), shape=(n_users, n_users), dtype=f32)
+    Y = sp.coo_matrix((np.ones(uid.size, f32), (uid, iid)), shape=(n_users, n_items), dtype=f32)
+    B = S.multiply(S.T)
+    D = S - B
+    DT = D.T
+    sym = lambda C: C + C.T
+    m1 = sym((D @ D).multiply(DT))
+    m2 = sym((B @ D).multiply(DT) + (D @ B).multiply(DT) + (D @ D).multiply(B))
+    m3 = sym((B @ B).multiply(D) + (B @ D).multiply(B) + (D @ B).multiply(B))
+    m4 = (B @ B).multiply(B)
+    m5 = sym((D @ D).multiply(D) + (D @ DT).multiply(D) + (DT @ D).multiply(D))
+    m6 = (D @ B).multiply(D) + (B @ DT).multiply(DT) + (DT @ D).multiply(B)
+    m7 = (DT @ B).multiply(DT) + (B @ D).multiply(D) + (D @ DT).multiply(B)
+    co = Y @ Y.T
+    m8 = co.multiply(B)
+    m9 = sym(co.multiply(D))
+    m10 = co - m8 - m9
+    def by_row_sums(M):
+        with np.errstate(divide="ignore"):
+            return sp.csr_matrix(M.multiply(1.0 / M.sum(axis=1).reshape(-1, 1)))
+    H_s = by_row_sums(m1 + m2 + m3 + m4 + m5 + m6 + m7)        # same association as sum([...]): left to right
+    H_j = by_row_sums(m8 + m9)
+    H_p = by_row_sums(m10.multiply(m10 > 1))
+    # user-item matrix: rating / sqrt(#distinct items of u) / sqrt(#distinct users of i) per training row, python floats
+    from math import sqrt
+    pairs = np.unique(np.stack([uid, iid], 1), axis=0)
+    du = np.bincount(pairs[:, 0], minlength=n_users); di = np.bincount(pairs[:, 1], minlength=n_items)
+    vals = np.fromiter((float(r) / sqrt(du[u]) / sqrt(di[i]) for u, i, r in zip(uid.tolist(), iid.tolist(), np.asarray(ratings).tolist())),
+                       dtype=np.float64, count=uid.size)
+    R = sp.csr_matrix((vals.astype(f32), (uid, iid)), shape=(n_users, n_items))
+    return [H_s, H_j, H_p], R
+
+
+class MHCNTrainer:
+    """model/ranking/MHCN.py:93-229 on the device.  ``weights``: dict with the reference's keys (gating1-4, gating_bias1-4,
+    sgating1-4, sgating_bias1-4, attention, attention_mat).  One ``train_step_async`` = self-gating of the four channels,
+    L layers of {channel attention -> mixed users -> items; three hypergraph convolutions; user-item convolution}, every
+    layer l2-normalised into its channel's sum, final attention, BPR on the batch, the hierarchical mutual-information
+    loss of the three channels with fresh shuffles, the whole backward pass, Adam on U, V and the 18 weight tensors."""
+
+    W_L2 = 0.001            # reg_loss += 0.001 * l2_loss(weight) for every weight (MHCN.py:211-212)
+
+    def __init__(self, U0, V0, weights, H, R, n_layers: int, lr: float, reg: float, ss_rate: float, loss_eps: float = 1e-7,
+                 seed: int = 0):
+        self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
+        self.n = self.nu + self.ni
+        ld = self.ld = padded_ld(self.d, np.float32)
+        self.L, self.lr, self.reg, self.ss_rate, self.loss_eps, self.seed = n_layers, lr, reg, ss_rate, loss_eps, seed
+        zu = lambda: DeviceBuffer.zeros((self.nu, ld), np.float32)
+        zi = lambda: DeviceBuffer.zeros((self.ni, ld), np.float32)
+        pad2 = lambda w: np.pad(np.asarray(w, np.float32), ((0, ld - self.d), (0, ld - self.d)))
+        pad1 = lambda b: np.pad(np.asarray(b, np.float32).reshape(-1), (0, ld - self.d))
+        self.U = DeviceBuffer.from_numpy(np.pad(np.asarray(U0, np.float32), ((0, 0), (0, ld - self.d))))
+        self.V = DeviceBuffer.from_numpy(np.pad(np.asarray(V0, np.float32), ((0, 0), (0, ld - self.d))))
+        self.w, self.g, self.opt = {}, {}, {}
+        for key, val in weights.items():
+            arr = pad1(val) if np.asarray(val).shape[0] == 1 else pad2(val)
+            self.w[key] = DeviceBuffer.from_numpy(arr)
+            self.g[key] = DeviceBuffer.zeros(arr.shape, np.float32)
+            self.opt[key] = _Adam(self.w[key], lr)
+        self.optU, self.optV = _Adam(self.U, lr), _Adam(self.V, lr)
+        self.planH = [SpmmPlan(*_csr_triple(h), ld) for h in H]
+        self.planHT = [SpmmPlan(*_csr_triple(h.T), ld) for h in H]
+        self.planR, self.planRT = SpmmPlan(*_csr_triple(R), ld), SpmmPlan(*_csr_triple(R.T), ld)
+        L = n_layers
+        # forward state
+        self.G, self.Gs = [zu() for _ in range(4)], [zu() for _ in range(4)]          # gated tables, their sigmoids
+        self.c = [[self.G[k] for k in range(3)]] + [[zu() for _ in range(3)] for _ in range(L)]
+        self.s = [self.G[3]] + [zu() for _ in range(L)]
+        self.t = [self.V] + [zi() for _ in range(L)]
+        self.inv_c = [[DeviceBuffer.zeros(self.nu, np.float32) for _ in range(3)] for _ in range(L)]
+        self.inv_s = [DeviceBuffer.zeros(self.nu, np.float32) for _ in range(L)]
+        self.inv_t = [DeviceBuffer.zeros(self.ni, np.float32) for _ in range(L)]
+        self.sum_c, self.sum_s = [zu() for _ in range(3)], zu()
+        self.F = DeviceBuffer.zeros((self.n, ld), np.float32)                       # [final users ; final items (= sum_t)]
+        self.dF = DeviceBuffer.zeros((self.n, ld), np.float32)
+        self.score = [DeviceBuffer.zeros((self.nu, 4), np.float32) for _ in range(L + 1)]
+        self.v = DeviceBuffer.zeros(256, np.float32); self.dv = DeviceBuffer.zeros(256, np.float32)
+        self.mixed = zu()
+        # self-supervision state
+        self.SG, self.SGs, self.edge, self.dem, self.dedge, self.dSG, self.Q = zu(), zu(), zu(), zu(), zu(), zu(), zu()
+        self.hss_ws = DeviceBuffer(capi.hss_scratch_bytes(self.nu), np.uint8)
+        self.wg_ws = DeviceBuffer(capi.buir_wgrad_scratch_bytes(ld), np.uint8)
+        self.perm_ws = DeviceBuffer(capi.random_permutation_scratch_bytes(self.nu), np.uint8)
+        self.rowp = [[DeviceBuffer(max(self.nu, 1), np.int32) for _ in range(6)] for _ in range(3)]     # p1,q1,p2,q2,p3,q3
+        self.colp = [DeviceBuffer((2, self.d), np.int32) for _ in range(3)], [DeviceBuffer((2, self.d), np.int32) for _ in range(3)]
+        # backward state
+        self.dsum_c, self.dsum_s = [zu() for _ in range(3)], zu()
+        self.gc = [[zu() for _ in range(3)] for _ in range(2)]
+        self.gs, self.gt = [zu(), zu()], [zi(), zi()]
+        self.Tu, self.Ti, self.dmixed, self.dU = zu(), zi(), zu(), zu()
+        self.d_loss = DeviceBuffer.zeros(2, np.float64)             # [rec, self-supervised (unscaled)]
+        self.step_no = 0
+
+    # ---- pointers into the stacked final table ---------------------------------------------------------------
+    @property
+    def _FI(self):
+        return self.F.ptr + self.nu * self.ld * 4
+
+    @property
+    def _dFI(self):
+        return self.dF.ptr + self.nu * self.ld * 4
+
+    def forward(self, stream=None):
+        """fills F = [final_user_embeddings ; final_item_embeddings] (MHCN.py:130-174)"""
+        nu, ni, ld, L, w = self.nu, self.ni, self.ld, self.L, self.w
+        for k in range(4):
+            capi.gate_fwd(self.U, w[f"gating{k + 1}"], w[f"gating_bias{k + 1}"], nu, ld, self.G[k], self.Gs[k], stream)
+        for k in range(3):
+            self.sum_c[k].copy_from(self.G[k], stream)
+        self.sum_s.copy_from(self.G[3], stream)
+        capi._check(capi.load().qrec_memcpy_d2d(self._FI, self.V.ptr, ni * ld * 4, capi._sh(stream)))
+        for l in range(1, L + 1):
+            capi.channel_attention_fwd(self.c[l - 1], w["attention"], w["attention_mat"], self.s[l - 1], nu, ld, self.v,
+                                       self.score[l - 1], self.mixed, stream)
+            for k in range(3):
+                capi.spmm_csr(self.planH[k], self.c[l - 1][k], self.c[l][k], ld, stream=stream)
+                capi.l2norm_rows_accum(self.c[l][k], nu, ld, self.sum_c[k], self.inv_c[l - 1][k], stream)
+            capi.spmm_csr(self.planRT, self.mixed, self.t[l], ld, stream=stream)
+            capi.l2norm_rows_accum(self.t[l], ni, ld, self._FI, self.inv_t[l - 1], stream)
+            capi.spmm_csr(self.planR, self.t[l - 1], self.s[l], ld, stream=stream)
+            capi.l2norm_rows_accum(self.s[l], nu, ld, self.sum_s, self.inv_s[l - 1], stream)
+        capi.channel_attention_fwd(self.sum_c, w["attention"], w["attention_mat"], self.sum_s, nu, ld, self.v, self.score[L],
+                                   self.F, stream)
+
+    def _draw_shuffles(self, perms, stream):
+        """device pointers (p1, p1inv, p2, p2inv, k2, k2inv, p3, p3inv, k3, k3inv) per channel.  ``perms`` (tests): host
+        arrays [(p1, k2, p2, k3, p3)] x 3; otherwise fresh uniform shuffles are drawn on the device."""
+        out = []
+        for k in range(3):
+            rp, (ck, cki) = self.rowp[k], (self.colp[0][k], self.colp[1][k])
+            if perms is not None:
+                p1, k2, p2, k3, p3 = (np.asarray(x, np.int32) for x in perms[k])
+                inv = lambda p: np.argsort(p).astype(np.int32)
+                for buf, arr in zip(rp, (p1, inv(p1), p2, inv(p2), p3, inv(p3))):
+                    buf.upload(arr, stream)
+                ck.upload(np.stack([k2, k3]), stream); cki.upload(np.stack([inv(k2), inv(k3)]), stream)
+            else:
+                sid = (self.step_no * 3 + k) * 4
+                for j in range(3):
+                    capi.random_permutation(self.nu, self.seed, sid + j, self.perm_ws, rp[2 * j], rp[2 * j + 1], stream)
+                capi.small_permutations(self.d, 2, self.seed, sid + 3, ck, cki, stream)
+            dcol = self.d * 4
+            out.append((rp[0], rp[1], rp[2], rp[3], ck.ptr, cki.ptr, rp[4], rp[5], ck.ptr + dcol, cki.ptr + dcol))
+        return out
+
+    def train_step_async(self, d_u, d_i, d_j, B: int, perms=None, stream=None):
+        nu, ni, ld, d, L, w, g = self.nu, self.ni, self.ld, self.d, self.L, self.w, self.g
+        self.forward(stream)
+        self.dF.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
+        g["attention"].fill_bytes(0, stream); g["attention_mat"].fill_bytes(0, stream)
+        for k in (1, 2, 3, 4):        # sgating4 is created but unused: its gradient is its L2 term alone
+            g[f"sgating{k}"].fill_bytes(0, stream); g[f"sgating_bias{k}"].fill_bytes(0, stream)
+        capi.bpr_batch_loss_grad(self.F, 1.0, nu, self.n, ld, d_u, d_i, d_j, B, self.loss_eps, 0.0, self.dF, self.d_loss, stream)
+        # hierarchical self-supervision of the three channels (MHCN.py:176-178, 184-206)
+        for k, shuffles in enumerate(self._draw_shuffles(perms, stream)):
+            Ws, bs = w[f"sgating{k + 1}"], w[f"sgating_bias{k + 1}"]
+            capi.gate_fwd(self.F, Ws, bs, nu, ld, self.SG, self.SGs, stream)
+            capi.spmm_csr(self.planH[k], self.SG, self.edge, ld, stream=stream)
+            capi.hss_loss_grad(self.SG, self.edge, nu, d, ld, shuffles, self.ss_rate, self.hss_ws, self.dem, self.dedge,
+                               self.d_loss.ptr + 8, stream)
+            capi.spmm_csr(self.planHT[k], self.dedge, self.dSG, ld, d_addend=self.dem, addend_scale=1.0, stream=stream)
+            capi.gate_bwd(self.F, self.SGs, self.dSG, Ws, nu, d, ld, self.Q, self.dF, True, stream=stream)
+            capi.buir_wgrad(self.F, self.Q, nu, ld, self.wg_ws, g[f"sgating{k + 1}"], g[f"sgating_bias{k + 1}"], stream)
+        # final aggregation (MHCN.py:173-174): dsum_c, dsum_s; dsum_t is the item half of dF
+        capi.channel_attention_bwd(self.dF, self.sum_c, self.score[L], self.v, w["attention"], w["attention_mat"], nu, ld,
+                                   self.dsum_c, False, self.dsum_s, False, self.dv, g["attention"], g["attention_mat"], stream)
+        a = 0
+        for k in range(3):
+            capi.l2norm_rows_bwd(self.c[L][k], self.inv_c[L - 1][k], self.dsum_c[k], nu, ld, self.gc[a][k], stream)
+        capi.l2norm_rows_bwd(self.s[L], self.inv_s[L - 1], self.dsum_s, nu, ld, self.gs[a], stream)
+        capi.l2norm_rows_bwd(self.t[L], self.inv_t[L - 1], self._dFI, ni, ld, self.gt[a], stream)
+        for l in range(L, 0, -1):          # gradients of level l -> level l-1
+            b = 1 - a
+            first = l - 1 == 0             # level 0 enters the sums un-normalised
+            capi.spmm_csr(self.planR, self.gt[a], self.dmixed, ld, stream=stream)                      # t^(l) = R^T mixed^(l)
+            if first:
+                base_t = self._dFI
+            else:
+                capi.l2norm_rows_bwd(self.t[l - 1], self.inv_t[l - 2], self._dFI, ni, ld, self.Ti, stream); base_t = self.Ti
+            capi.spmm_csr(self.planRT, self.gs[a], self.gt[b], ld, d_addend=base_t, addend_scale=1.0, stream=stream)   # s^(l) = R t^(l-1)
+            for k in range(3):                                                                          # c^(l) = H c^(l-1)
+                if first:
+                    base_c = self.dsum_c[k]
+                else:
+                    capi.l2norm_rows_bwd(self.c[l - 1][k], self.inv_c[l - 2][k], self.dsum_c[k], nu, ld, self.Tu, stream); base_c = self.Tu
+                capi.spmm_csr(self.planHT[k], self.gc[a][k], self.gc[b][k], ld, d_addend=base_c, addend_scale=1.0, stream=stream)
+            if first:
+                self.gs[b].copy_from(self.dsum_s, stream)
+            else:
+                capi.l2norm_rows_bwd(self.s[l - 1], self.inv_s[l - 2], self.dsum_s, nu, ld, self.gs[b], stream)
+            # mixed^(l) = attention(c^(l-1)) + s^(l-1) / 2
+            capi.channel_attention_bwd(self.dmixed, self.c[l - 1], self.score[l - 1], self.v, w["attention"], w["attention_mat"], nu, ld,
+                                       self.gc[b], True, self.gs[b], True, self.dv, g["attention"], g["attention_mat"], stream)
+            a = b
+        # self-gating of the four channels (MHCN.py:131-134)
+        for k in range(4):
+            dG = self.gc[a][k] if k < 3 else self.gs[a]
+            capi.gate_bwd(self.U, self.Gs[k], dG, w[f"gating{k + 1}"], nu, d, ld, self.Q, self.dU, k > 0, stream=stream)
+            capi.buir_wgrad(self.U, self.Q, nu, ld, self.wg_ws, g[f"gating{k + 1}"], g[f"gating_bias{k + 1}"], stream)
+        self.optU.step(self.dU, stream=stream, grad_l2=self.reg)
+        self.optV.step(self.gt[a], stream=stream, grad_l2=self.reg)
+        for key, opt in self.opt.items():
+            opt.step(g[key], stream=stream, grad_l2=self.W_L2)
+        self.step_no += 1
+
+    def losses(self, stream=None):
+        """(rec_loss -- what the reference prints, MHCN.py:223-225 --, ss_loss unscaled)"""
+        rec, ss = self.d_loss.numpy(stream)
+        return float(rec), float(ss)
+
+    def final_embeddings(self):
+        """(final_user_embeddings, final_item_embeddings) (MHCN.py:172-174, 226)"""
+        self.forward()
+        F = self.F.numpy()[:, :self.d]
+        return np.ascontiguousarray(F[:self.nu]), np.ascontiguousarray(F[self.nu:])
+
+    def parameters(self):
+        d = self.d
+        out = {k: (b.numpy()[:d, :d].copy() if len(b.shape) == 2 else b.numpy()[None, :d].copy()) for k, b in self.w.items()}
+        out["U"], out["V"] = self.U.numpy()[:, :d].copy(), self.V.numpy()[:, :d].copy()
+        return out

@@ -818,3 +818,197 @@ def test_sept_class_runs_stock_conf_shape_with_social_data_and_replays_the_gener
     want = capi.state_from_python(random.getstate())
     run()
     assert np.array_equal(capi.state_from_python(random.getstate()), want)
+
+
+# ---------------------------------------------------------------------------------------------
+# MHCN (model/ranking/MHCN.py)
+# ---------------------------------------------------------------------------------------------
+from qrec_amd.graph import MHCNTrainer  # noqa: E402
+
+
+def _mhcn_problem(rng, nu=300, ni=260, d=24, E=5000, Rn=1800):
+    uid = rng.integers(0, nu, E); iid = rng.integers(0, ni, E)
+    pairs = np.unique(np.stack([uid, iid], 1), axis=0); uid, iid = pairs[:, 0], pairs[:, 1]
+    fo = rng.integers(0, nu, Rn); fe = rng.integers(0, nu, Rn)
+    rel = np.unique(np.stack([fo[fo != fe], fe[fo != fe]], 1), axis=0)
+    H = T.mhcn_motif_adjacencies(nu, ni, uid, iid, rel[:, 0], rel[:, 1])
+    Rm = T.mhcn_joint_adjacency(nu, ni, uid, iid, np.ones(uid.size))
+    lim = np.sqrt(6.0 / (2 * d))
+    w = {}
+    for k in (1, 2, 3, 4):
+        for pre in ("gating", "sgating"):
+            w[f"{pre}{k}"] = rng.uniform(-lim, lim, (d, d)).astype(np.float32)
+            w[f"{pre}_bias{k}"] = rng.uniform(-0.5, 0.5, (1, d)).astype(np.float32)
+    w["attention"] = rng.uniform(-0.5, 0.5, (1, d)).astype(np.float32); w["attention_mat"] = rng.uniform(-lim, lim, (d, d)).astype(np.float32)
+    U0 = (rng.standard_normal((nu, d)) * 0.3).astype(np.float32); V0 = (rng.standard_normal((ni, d)) * 0.3).astype(np.float32)
+    return nu, ni, d, H, Rm, w, U0, V0
+
+
+def _perms(rng, nu, d):
+    return [(rng.permutation(nu), rng.permutation(d), rng.permutation(nu), rng.permutation(d), rng.permutation(nu)) for _ in range(3)]
+
+
+@pytest.mark.parametrize("dim,ld", [(24, 32), (50, 64), (64, 64)])
+def test_mhcn_gate_attention_and_mim_kernels_match_restatement(dim, ld):
+    """qrec_gate_fwd/_bwd (+ qrec_buir_wgrad for dW, db), qrec_channel_attention_fwd/_bwd and qrec_hss_loss_grad against
+    the restated pieces of MHCN.py:109-121,184-206, one by one."""
+    rng = np.random.default_rng(dim)
+    nu, ni, d, H, Rm, w, U0, V0 = _mhcn_problem(rng, d=dim)
+    m = T.MHCN(U0, V0, w, H, Rm, 1, lr=0.001, reg=0.01, ss_rate=0.05)
+    pad2 = lambda a: pad_cols(np.pad(a, ((0, ld - dim), (0, 0))), ld)
+    # --- gate
+    W, b = w["gating2"], w["gating_bias2"]
+    Y, bwd = m.gate(U0, W, b)
+    dY = rng.standard_normal((nu, dim)).astype(np.float32)
+    dX, dW, db = bwd(dY)
+    d_X, d_W, d_b = DB.from_numpy(pad_cols(U0, ld)), DB.from_numpy(pad2(W)), DB.from_numpy(pad_cols(b, ld)[0])
+    d_Y, d_S, d_Q, d_dX = (DB.zeros((nu, ld), np.float32) for _ in range(4))
+    capi.gate_fwd(d_X, d_W, d_b, nu, ld, d_Y, d_S)
+    assert rel_err(d_Y.numpy()[:, :dim], Y) < 2e-6 and not d_Y.numpy()[:, dim:].any()
+    prev = rng.standard_normal((nu, dim)).astype(np.float32); d_dX.upload(pad_cols(prev, ld))
+    capi.gate_bwd(d_X, d_S, DB.from_numpy(pad_cols(dY, ld)), d_W, nu, dim, ld, d_Q, d_dX, True)
+    assert rel_err(d_dX.numpy()[:, :dim], prev + dX) < 5e-6 and not d_dX.numpy()[:, dim:].any()
+    gW, gb = DB.zeros((ld, ld), np.float32), DB.zeros(ld, np.float32)
+    capi.buir_wgrad(d_X, d_Q, nu, ld, DB(capi.buir_wgrad_scratch_bytes(ld), np.uint8), gW, gb)
+    assert rel_err(gW.numpy()[:dim, :dim], dW) < 2e-5 and rel_err(gb.numpy()[:dim], db[0]) < 2e-5
+    # --- channel attention
+    es = [rng.standard_normal((nu, dim)).astype(np.float32) for _ in range(3)]
+    half = rng.standard_normal((nu, dim)).astype(np.float32)
+    out, score, abwd = m.attention(es)
+    dOut = rng.standard_normal((nu, dim)).astype(np.float32)
+    des, da, dM = abwd(dOut)
+    d_e = [DB.from_numpy(pad_cols(e, ld)) for e in es]
+    d_a, d_M = DB.from_numpy(pad_cols(w["attention"], ld)[0]), DB.from_numpy(pad2(w["attention_mat"]))
+    d_v, d_dv, d_sc, d_out = DB.zeros(256, np.float32), DB.zeros(256, np.float32), DB.zeros((nu, 4), np.float32), DB.zeros((nu, ld), np.float32)
+    capi.channel_attention_fwd(d_e, d_a, d_M, DB.from_numpy(pad_cols(half, ld)), nu, ld, d_v, d_sc, d_out)
+    assert rel_err(d_out.numpy()[:, :dim], out + half / 2) < 5e-6 and rel_err(d_sc.numpy()[:, :3], score) < 5e-6
+    d_de = [DB.zeros((nu, ld), np.float32) for _ in range(3)]
+    d_dh = DB.from_numpy(pad_cols(prev, ld))
+    g_a, g_M = DB.zeros(ld, np.float32), DB.zeros((ld, ld), np.float32)
+    capi.channel_attention_bwd(DB.from_numpy(pad_cols(dOut, ld)), d_e, d_sc, d_v, d_a, d_M, nu, ld, d_de, False, d_dh, True, d_dv, g_a, g_M)
+    for k in range(3):
+        assert rel_err(d_de[k].numpy()[:, :dim], des[k]) < 1e-5
+    assert rel_err(d_dh.numpy()[:, :dim], prev + dOut / 2) < 1e-6
+    assert rel_err(g_a.numpy()[:dim], da[0]) < 5e-5 and rel_err(g_M.numpy()[:dim, :dim], dM) < 5e-5
+    # --- hierarchical mutual information, channel 0 and the dense purchase channel
+    for ch in (0, 2):
+        em = (rng.standard_normal((nu, dim)) * 0.5).astype(np.float32)
+        perm = _perms(rng, nu, dim)[0]
+        want_loss, want_dem = m.hss(em, m.H[ch], perm)
+        from qrec_amd.graph import SpmmPlan, _csr_triple
+        plan, planT = SpmmPlan(*_csr_triple(H[ch]), ld), SpmmPlan(*_csr_triple(H[ch].T), ld)
+        d_em, d_edge, d_dem, d_dedge, d_tot = (DB.zeros((nu, ld), np.float32) for _ in range(5))
+        d_em.upload(pad_cols(em, ld))
+        capi.spmm_csr(plan, d_em, d_edge, ld)
+        p1, k2, p2, k3, p3 = (np.asarray(x, np.int32) for x in perm)
+        inv = lambda p: np.argsort(p).astype(np.int32)
+        bufs = [DB.from_numpy(x) for x in (p1, inv(p1), p2, inv(p2), k2, inv(k2), p3, inv(p3), k3, inv(k3))]
+        loss = DB.zeros(1, np.float64)
+        capi.hss_loss_grad(d_em, d_edge, nu, dim, ld, bufs, 1.0, DB(capi.hss_scratch_bytes(nu), np.uint8), d_dem, d_dedge, loss)
+        capi.spmm_csr(planT, d_dedge, d_tot, ld, d_addend=d_dem, addend_scale=1.0)
+        assert float(loss.numpy()[0]) == pytest.approx(want_loss, rel=2e-5)
+        assert rel_err(d_tot.numpy()[:, :dim], want_dem) < 3e-5 and not d_tot.numpy()[:, dim:].any()
+
+
+def test_device_permutations_are_permutations_and_look_uniform():
+    """qrec_random_permutation (Philox keys + rocPRIM radix sort) and qrec_small_permutations (Fisher-Yates): valid
+    permutations with correct inverses, different per stream id, reproducible, positions uniformly spread."""
+    n = 31668
+    ws = DB(capi.random_permutation_scratch_bytes(n), np.uint8)
+    p, q = DB(n, np.int32), DB(n, np.int32)
+    seen = []
+    for sid in range(6):
+        capi.random_permutation(n, 7, sid, ws, p, q)
+        a, b = p.numpy(), q.numpy()
+        assert np.array_equal(np.sort(a), np.arange(n)) and np.array_equal(a[b], np.arange(n))
+        seen.append(a)
+    capi.random_permutation(n, 7, 5, ws, p, None)
+    assert np.array_equal(p.numpy(), seen[5]) and not np.array_equal(seen[0], seen[1])
+    first = np.array([s[0] for s in seen]); assert len(set(first.tolist())) == 6
+    # mean displacement of a uniform permutation is n/3
+    disp = np.mean([np.abs(s - np.arange(n)).mean() for s in seen])
+    assert abs(disp / (n / 3) - 1) < 0.02
+    cp, ci = DB((64, 50), np.int32), DB((64, 50), np.int32)
+    capi.small_permutations(50, 64, 3, 9, cp, ci)
+    P_, I_ = cp.numpy(), ci.numpy()
+    assert all(np.array_equal(np.sort(r), np.arange(50)) for r in P_) and all(np.array_equal(r[i], np.arange(50)) for r, i in zip(P_, I_))
+    counts = np.bincount(P_[:, 0], minlength=50); assert counts.max() <= 8            # 64 draws over 50 values
+
+
+@pytest.mark.parametrize("L", [1, 2])
+def test_mhcn_training_steps_match_restatement(L):
+    """MHCNTrainer vs the restated model over several steps with the same injected shuffles: rec loss, self-supervised
+    loss, and after Adam all 20 parameter tensors."""
+    rng = np.random.default_rng(60 + L)
+    nu, ni, d, H, Rm, w, U0, V0 = _mhcn_problem(rng)
+    ref = T.MHCN(U0, V0, w, H, Rm, L, lr=0.002, reg=0.01, ss_rate=0.05)
+    tr = MHCNTrainer(U0, V0, w, H, Rm, L, 0.002, 0.01, 0.05)
+    B = 256
+    for step in range(4):
+        u = rng.integers(0, nu, B).astype(np.int32); i = rng.integers(0, ni, B).astype(np.int32); j = rng.integers(0, ni, B).astype(np.int32)
+        perms = _perms(rng, nu, d)
+        want_rec, want_ss, _, _ = ref.loss_and_grads(u, i, j, perms)
+        ref.train_step(u, i, j, perms)
+        tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, perms=perms)
+        rec, ss = tr.losses()
+        assert rec == pytest.approx(want_rec, rel=3e-5) and ss == pytest.approx(want_ss, rel=3e-5), step
+        got = tr.parameters()
+        for k in ref.w:
+            assert rel_err(got[k], ref.w[k]) < 3e-4, (step, k)
+        assert rel_err(got["U"], ref.U) < 3e-4 and rel_err(got["V"], ref.V) < 3e-4, step
+    fu, fi, _ = ref.forward()
+    Ud, Vd = tr.final_embeddings()
+    assert rel_err(Ud, fu) < 3e-4 and rel_err(Vd, fi) < 3e-4
+    # without injected shuffles the device draws its own, new ones every step
+    tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B)
+    a = tr.rowp[0][0].numpy().copy()
+    tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B)
+    b = tr.rowp[0][0].numpy()
+    assert np.array_equal(np.sort(a), np.arange(nu)) and not np.array_equal(a, b) and np.isfinite(tr.losses()).all()
+
+
+def test_mhcn_class_runs_stock_conf_shape_with_social_data(tmp_path):
+    """Drop-in MHCN with config/MHCN.conf's keys on FilmTrust + its trust file: relation loader -> pruning -> motif
+    graphs -> training with device-drawn shuffles, evaluated every epoch, best epoch kept; the CPython generator ends
+    where the batch stream alone leaves it (the shuffles of the mutual-information loss are TF-side randomness)."""
+    from qrec_amd.model.ranking.MHCN import MHCN
+    from qrec_amd.util.io import FileIO
+    meta, z = load_golden("mhcn_graphs_filmtrust")
+    sz = load_golden("sept_graphs_filmtrust")[1]
+    name = lambda c: f"u{c}" if c >= 0 else f"x{-1 - c}"
+    path = tmp_path / "trust.txt"
+    path.write_text("".join(f"{name(a)} {name(b)} {w:g}\n" for a, b, w in zip(sz["raw_follower"].tolist(), sz["raw_followee"].tolist(), sz["raw_weight"].tolist())))
+    conf = conf_from_text(meta["conf"])
+    conf["num.factors"] = "16"; conf["num.max.epoch"] = "3"; conf["learnRate"] = "-init 0.002 -max 1"
+    uid, iid = z["train_uid"].tolist(), z["train_iid"].tolist()
+    train = [[f"u{u}", f"i{i}", 1.0] for u, i in zip(uid, iid)]
+    test = [[f"u{u}", f"i{(i * 7 + 3) % meta['n_items']}", 1.0] for u, i in zip(uid[::19], iid[::19])]
+    random.seed(23); np.random.seed(23)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        m = MHCN(conf, train, test, FileIO.loadRelationship(conf, str(path)))
+        measure = m.execute()
+    out = buf.getvalue()
+    assert len(m.social.relation) == meta["relations_kept"]
+    rec = [float(l.split("rec loss:")[1]) for l in out.splitlines() if "rec loss:" in l]
+    n_batches = -(-len(train) // 2000)
+    assert len(rec) == 3 * n_batches and np.isfinite(rec).all() and np.mean(rec[-n_batches:]) < np.mean(rec[:n_batches])
+    assert out.count("Quick Ranking Performance") == 3 and any(x.startswith("Recall") for x in measure)
+    assert m.U is m.bestU and m.U.shape == (meta["n_users"], 16) and m.V.shape == (meta["n_items"], 16)
+    # generator: shuffle + negatives only
+    E, I = len(train), meta["n_items"]
+    random.seed(23)
+    rows = list(range(E)); rated = {}
+    for uu, ii in zip(uid, iid):
+        rated.setdefault(uu, set()).add(ii)
+    for ep in range(3):
+        random.shuffle(rows)
+        for r in rows:
+            neg = random.choice(range(I))
+            while neg in rated[uid[r]]:
+                neg = random.choice(range(I))
+    want = capi.state_from_python(random.getstate())
+    random.seed(23); np.random.seed(23)
+    with redirect_stdout(io.StringIO()):
+        MHCN(conf, train, test, FileIO.loadRelationship(conf, str(path))).execute()
+    assert np.array_equal(capi.state_from_python(random.getstate()), want)

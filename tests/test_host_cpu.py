@@ -485,3 +485,22 @@ def test_tbpr_native_sampler_reproduces_the_reference_stream():
     assert np.array_equal(words, z["py_state"])
     with pytest.raises(ValueError, match="one row per user"):
         capi.mt_tbpr_sample_epoch(words, pos.indptr, pos.indices, I, (sets[0][0][:-1], sets[0][1]), sets[1], sets[2])
+
+
+def test_mhcn_graph_builders_of_the_product_match_the_reference_bitwise():
+    """qrec_amd.graph.mhcn_channel_graphs (host side of model/ranking/MHCN.py:26-85, 46-52) against the reference's own
+    matrices on FilmTrust + trust.txt: the three motif-induced channel adjacencies bit for bit, the user-item values."""
+    from qrec_amd.graph import mhcn_channel_graphs
+    meta, z = load_golden("mhcn_graphs_filmtrust")
+    U, I = meta["n_users"], meta["n_items"]
+    H, R = mhcn_channel_graphs(U, I, z["train_uid"], z["train_iid"], z["train_r"], z["follower"], z["followee"])
+    for tag, A, nnz in zip(("Hs", "Hj", "Hp"), H, meta["nnz"]):
+        A = A.tocsr(); A.sort_indices()
+        assert A.nnz == nnz and A.data.dtype == np.float32
+        assert np.array_equal(A.indptr, z[tag + "_indptr"]) and np.array_equal(A.indices, z[tag + "_indices"]) and np.array_equal(A.data, z[tag + "_data"])
+    want = {}
+    for (u, i), v in zip(z["R_indices"].tolist(), z["R_values"].tolist()):
+        want[(u, i)] = np.float32(want.get((u, i), np.float32(0)) + np.float32(v))
+    Rc = R.tocoo()
+    assert Rc.shape == tuple(meta["R_shape"]) and Rc.nnz == len(want) and Rc.data.dtype == np.float32
+    assert all(want[(int(u), int(i))] == v for u, i, v in zip(Rc.row, Rc.col, Rc.data))
