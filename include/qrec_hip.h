@@ -405,8 +405,8 @@ int qrec_tbpr_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld
  *   (row p1; column k2 then row p2; column k3 then row p3 -- tf.random.shuffle of range(n) / range(d)) with their
  *   inverses: *d_loss += local + global MIM loss (unscaled); d_dem / d_dedge = scale * gradient w.r.t. em / edge
  *   (overwritten).  d_scratch: qrec_hss_scratch_bytes(n).
- * qrec_random_permutation: a uniformly random permutation of range(n) (64-bit Philox keys, rocPRIM radix sort) and its
- *   inverse; qrec_small_permutations: `count` Fisher-Yates permutations of range(n <= 4096) with inverses. */
+ * qrec_random_permutations: `count` uniformly random permutations of range(n) ([count][n]) and their inverses from ONE
+ *   rocPRIM radix sort (key = permutation number << 40 | 40 Philox bits); qrec_small_permutations: `count` Fisher-Yates permutations of range(n <= 4096) with inverses. */
 int qrec_gate_fwd(const float *d_X, const float *d_W, const float *d_bias, int64_t n_rows, int32_t ld, float *d_Y, float *d_S,
                   void *stream);
 int qrec_gate_bwd(const float *d_X, const float *d_S, const float *d_dY, const float *d_W, int64_t n_rows, int32_t d, int32_t ld,
@@ -424,9 +424,9 @@ int qrec_hss_loss_grad(const float *d_em, const float *d_edge, int64_t n_rows, i
                        const int32_t *d_k2inv, const int32_t *d_p3, const int32_t *d_p3inv, const int32_t *d_k3,
                        const int32_t *d_k3inv, float scale, float *d_scratch, float *d_dem, float *d_dedge, double *d_loss,
                        void *stream);
-int qrec_random_permutation_scratch_bytes(int64_t n, int64_t *bytes);
-int qrec_random_permutation(int64_t n, uint64_t seed, uint64_t stream_id, void *d_scratch, int32_t *d_perm, int32_t *d_inv,
-                            void *stream);
+int qrec_random_permutations_scratch_bytes(int64_t n, int32_t count, int64_t *bytes);
+int qrec_random_permutations(int64_t n, int32_t count, uint64_t seed, uint64_t stream_id, void *d_scratch, int32_t *d_perms,
+                             int32_t *d_invs, void *stream);
 int qrec_small_permutations(int32_t n, int32_t count, uint64_t seed, uint64_t stream_id, int32_t *d_perms, int32_t *d_invs,
                             void *stream);
 

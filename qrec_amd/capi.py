@@ -71,8 +71,8 @@ _SIGNATURES = {
     "qrec_channel_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp],
     "qrec_hss_scratch_bytes": [_i64, _vp],
     "qrec_hss_loss_grad": [_vp, _vp, _i64, _i32, _i32] + [_vp] * 10 + [_f32, _vp, _vp, _vp, _vp, _vp],
-    "qrec_random_permutation_scratch_bytes": [_i64, _vp],
-    "qrec_random_permutation": [_i64, _u64, _u64, _vp, _vp, _vp, _vp],
+    "qrec_random_permutations_scratch_bytes": [_i64, _i32, _vp],
+    "qrec_random_permutations": [_i64, _i32, _u64, _u64, _vp, _vp, _vp, _vp],
     "qrec_small_permutations": [_i32, _i32, _u64, _u64, _vp, _vp, _vp],
     "qrec_l2norm_rows_accum": [_vp, _i64, _i32, _vp, _vp, _vp],
     "qrec_l2norm_rows_bwd": [_vp, _vp, _vp, _i64, _i32, _vp, _vp],
@@ -633,14 +633,16 @@ def hss_loss_grad(d_em, d_edge, n_rows: int, d: int, ld: int, perms, scale: floa
                                      _dp(d_dem), _dp(d_dedge), _dp(d_loss), _sh(stream)))
 
 
-def random_permutation_scratch_bytes(n: int) -> int:
+def random_permutations_scratch_bytes(n: int, count: int) -> int:
     out = C.c_int64(0)
-    _check(load().qrec_random_permutation_scratch_bytes(n, C.byref(out)))
+    _check(load().qrec_random_permutations_scratch_bytes(n, count, C.byref(out)))
     return out.value
 
 
-def random_permutation(n: int, seed: int, stream_id: int, d_scratch, d_perm, d_inv=None, stream=None):
-    _check(load().qrec_random_permutation(n, seed & (2**64 - 1), stream_id & (2**64 - 1), _dp(d_scratch), _dp(d_perm), _dp(d_inv), _sh(stream)))
+def random_permutations(n: int, count: int, seed: int, stream_id: int, d_scratch, d_perms, d_invs=None, stream=None):
+    """``count`` uniform shuffles of range(n) ([count][n]) with their inverses, one device sort"""
+    _check(load().qrec_random_permutations(n, count, seed & (2**64 - 1), stream_id & (2**64 - 1), _dp(d_scratch), _dp(d_perms),
+                                           _dp(d_invs), _sh(stream)))
 
 
 def small_permutations(n: int, count: int, seed: int, stream_id: int, d_perms, d_invs, stream=None):

@@ -322,17 +322,21 @@ __global__ __launch_bounds__(256) void hss_grad_kernel(const float *__restrict__
 }
 
 // ---- random permutations (tf.random.shuffle of range(n)) --------------------------------------------------------------
-__global__ void perm_keys_kernel(int64_t n, uint64_t seed, uint64_t stream_id, uint64_t *__restrict__ keys, int32_t *__restrict__ idx) {
+// `count` permutations of range(n) from ONE sort: key = (permutation number << 40) | 40 random bits, value = position
+// inside the permutation; after the sort, slots [s n, (s+1) n) hold permutation s (ties -- 2^-40 per pair -- keep index order)
+__global__ void perm_keys_kernel(int64_t n, int64_t total, uint64_t seed, uint64_t stream_id, uint64_t *__restrict__ keys,
+                                 int32_t *__restrict__ idx) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= total) return;
     uint32_t c[4] = {(uint32_t)i, (uint32_t)(i >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
     philox10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    keys[i] = ((uint64_t)c[0] << 32) | c[1];
-    idx[i] = (int32_t)i;
+    const uint64_t seg = (uint64_t)(i / n);
+    keys[i] = (seg << 40) | ((((uint64_t)c[0] << 32) | c[1]) >> 24);
+    idx[i] = (int32_t)(i % n);
 }
-__global__ void invert_perm_kernel(const int32_t *__restrict__ p, int64_t n, int32_t *__restrict__ inv) {
+__global__ void invert_perm_kernel(const int32_t *__restrict__ p, int64_t n, int64_t total, int32_t *__restrict__ inv) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) inv[p[i]] = (int32_t)i;
+    if (i < total) inv[(i / n) * n + p[i]] = (int32_t)(i % n);
 }
 // Fisher-Yates on a few hundred elements: one thread per permutation (count of them), 24-bit Philox draws
 __global__ void small_perm_kernel(int32_t n, int32_t count, uint64_t seed, uint64_t stream_id, int32_t *__restrict__ perms,
@@ -465,30 +469,32 @@ int qrec_hss_scratch_bytes(int64_t n_rows, int64_t *bytes) {
     return QREC_OK;
 }
 
-int qrec_random_permutation_scratch_bytes(int64_t n, int64_t *bytes) {
-    QREC_REQUIRE(bytes && n >= 0 && n < ((int64_t)1 << 31), "qrec_random_permutation_scratch_bytes: bad argument");
+int qrec_random_permutations_scratch_bytes(int64_t n, int32_t count, int64_t *bytes) {
+    QREC_REQUIRE(bytes && n >= 0 && count >= 0 && count < (1 << 20) && n * count < ((int64_t)1 << 31), "qrec_random_permutations_scratch_bytes: bad argument");
+    const size_t total = (size_t)n * (size_t)count;
     size_t tmp = 0;
-    QREC_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp, (uint64_t *)nullptr, (uint64_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (size_t)n));
-    *bytes = (int64_t)(((tmp + 255) / 256) * 256 + (size_t)n * (8 + 8 + 4));
+    QREC_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp, (uint64_t *)nullptr, (uint64_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, total));
+    *bytes = (int64_t)(((tmp + 255) / 256) * 256 + total * (8 + 8 + 4));
     return QREC_OK;
 }
 
-int qrec_random_permutation(int64_t n, uint64_t seed, uint64_t stream_id, void *d_scratch, int32_t *d_perm, int32_t *d_inv,
-                            void *stream) {
-    QREC_REQUIRE(d_scratch && d_perm && n >= 0 && n < ((int64_t)1 << 31), "qrec_random_permutation: bad argument");
-    if (n == 0) return QREC_OK;
+int qrec_random_permutations(int64_t n, int32_t count, uint64_t seed, uint64_t stream_id, void *d_scratch, int32_t *d_perms,
+                             int32_t *d_invs, void *stream) {
+    QREC_REQUIRE(d_scratch && d_perms && n >= 0 && count >= 0 && count < (1 << 20) && n * count < ((int64_t)1 << 31), "qrec_random_permutations: bad argument");
+    const int64_t total = n * count;
+    if (total == 0) return QREC_OK;
     hipStream_t st = as_stream(stream);
     size_t tmp = 0;
-    QREC_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp, (uint64_t *)nullptr, (uint64_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (size_t)n));
+    QREC_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp, (uint64_t *)nullptr, (uint64_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (size_t)total));
     char *base = static_cast<char *>(d_scratch);
     const size_t tmp_pad = ((tmp + 255) / 256) * 256;
-    uint64_t *keys_in = reinterpret_cast<uint64_t *>(base + tmp_pad), *keys_out = keys_in + n;
-    int32_t *idx = reinterpret_cast<int32_t *>(keys_out + n);
-    hipLaunchKernelGGL(perm_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, seed, stream_id, keys_in, idx);
+    uint64_t *keys_in = reinterpret_cast<uint64_t *>(base + tmp_pad), *keys_out = keys_in + total;
+    int32_t *idx = reinterpret_cast<int32_t *>(keys_out + total);
+    hipLaunchKernelGGL(perm_keys_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, n, total, seed, stream_id, keys_in, idx);
     QREC_LAUNCH_CHECK();
-    QREC_HIP_CHECK(rocprim::radix_sort_pairs(base, tmp, keys_in, keys_out, idx, d_perm, (size_t)n, 0, 64, st));
-    if (d_inv) {
-        hipLaunchKernelGGL(invert_perm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_perm, n, d_inv);
+    QREC_HIP_CHECK(rocprim::radix_sort_pairs(base, tmp, keys_in, keys_out, idx, d_perms, (size_t)total, 0, 64, st));
+    if (d_invs) {
+        hipLaunchKernelGGL(invert_perm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_perms, n, total, d_invs);
         QREC_LAUNCH_CHECK();
     }
     return QREC_OK;

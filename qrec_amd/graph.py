@@ -968,9 +968,9 @@ class MHCNTrainer:
         self.SG, self.SGs, self.edge, self.dem, self.dedge, self.dSG, self.Q = zu(), zu(), zu(), zu(), zu(), zu(), zu()
         self.hss_ws = DeviceBuffer(capi.hss_scratch_bytes(self.nu), np.uint8)
         self.wg_ws = DeviceBuffer(capi.buir_wgrad_scratch_bytes(ld), np.uint8)
-        self.perm_ws = DeviceBuffer(capi.random_permutation_scratch_bytes(self.nu), np.uint8)
-        self.rowp = [[DeviceBuffer(max(self.nu, 1), np.int32) for _ in range(6)] for _ in range(3)]     # p1,q1,p2,q2,p3,q3
-        self.colp = [DeviceBuffer((2, self.d), np.int32) for _ in range(3)], [DeviceBuffer((2, self.d), np.int32) for _ in range(3)]
+        self.perm_ws = DeviceBuffer(capi.random_permutations_scratch_bytes(self.nu, 9), np.uint8)
+        self.rowp, self.rowq = DeviceBuffer((9, self.nu), np.int32), DeviceBuffer((9, self.nu), np.int32)   # (p1, p2, p3) x 3 channels; inverses
+        self.colp, self.colq = DeviceBuffer((6, self.d), np.int32), DeviceBuffer((6, self.d), np.int32)    # (k2, k3) x 3 channels; inverses
         # backward state
         self.dsum_c, self.dsum_s = [zu() for _ in range(3)], zu()
         self.gc = [[zu() for _ in range(3)] for _ in range(2)]
@@ -1013,22 +1013,21 @@ class MHCNTrainer:
     def _draw_shuffles(self, perms, stream):
         """device pointers (p1, p1inv, p2, p2inv, k2, k2inv, p3, p3inv, k3, k3inv) per channel.  ``perms`` (tests): host
         arrays [(p1, k2, p2, k3, p3)] x 3; otherwise fresh uniform shuffles are drawn on the device."""
+        if perms is not None:
+            inv = lambda p: np.argsort(p).astype(np.int32)
+            rows = [np.asarray(perms[k][j], np.int32) for k in range(3) for j in (0, 2, 4)]
+            cols = [np.asarray(perms[k][j], np.int32) for k in range(3) for j in (1, 3)]
+            self.rowp.upload(np.stack(rows), stream); self.rowq.upload(np.stack([inv(p) for p in rows]), stream)
+            self.colp.upload(np.stack(cols), stream); self.colq.upload(np.stack([inv(p) for p in cols]), stream)
+        else:       # all nine row shuffles of the step from one sort, the six column shuffles from one small kernel
+            capi.random_permutations(self.nu, 9, self.seed, 2 * self.step_no, self.perm_ws, self.rowp, self.rowq, stream)
+            capi.small_permutations(self.d, 6, self.seed, 2 * self.step_no + 1, self.colp, self.colq, stream)
+        rb, cb = 4 * self.nu, 4 * self.d
         out = []
         for k in range(3):
-            rp, (ck, cki) = self.rowp[k], (self.colp[0][k], self.colp[1][k])
-            if perms is not None:
-                p1, k2, p2, k3, p3 = (np.asarray(x, np.int32) for x in perms[k])
-                inv = lambda p: np.argsort(p).astype(np.int32)
-                for buf, arr in zip(rp, (p1, inv(p1), p2, inv(p2), p3, inv(p3))):
-                    buf.upload(arr, stream)
-                ck.upload(np.stack([k2, k3]), stream); cki.upload(np.stack([inv(k2), inv(k3)]), stream)
-            else:
-                sid = (self.step_no * 3 + k) * 4
-                for j in range(3):
-                    capi.random_permutation(self.nu, self.seed, sid + j, self.perm_ws, rp[2 * j], rp[2 * j + 1], stream)
-                capi.small_permutations(self.d, 2, self.seed, sid + 3, ck, cki, stream)
-            dcol = self.d * 4
-            out.append((rp[0], rp[1], rp[2], rp[3], ck.ptr, cki.ptr, rp[4], rp[5], ck.ptr + dcol, cki.ptr + dcol))
+            rp = [self.rowp.ptr + (3 * k + j) * rb for j in range(3)]; rq = [self.rowq.ptr + (3 * k + j) * rb for j in range(3)]
+            cp = [self.colp.ptr + (2 * k + j) * cb for j in range(2)]; cq = [self.colq.ptr + (2 * k + j) * cb for j in range(2)]
+            out.append((rp[0], rq[0], rp[1], rq[1], cp[0], cq[0], rp[2], rq[2], cp[1], cq[1]))
         return out
 
     def train_step_async(self, d_u, d_i, d_j, B: int, perms=None, stream=None):

@@ -914,16 +914,16 @@ def test_device_permutations_are_permutations_and_look_uniform():
     """qrec_random_permutation (Philox keys + rocPRIM radix sort) and qrec_small_permutations (Fisher-Yates): valid
     permutations with correct inverses, different per stream id, reproducible, positions uniformly spread."""
     n = 31668
-    ws = DB(capi.random_permutation_scratch_bytes(n), np.uint8)
-    p, q = DB(n, np.int32), DB(n, np.int32)
-    seen = []
-    for sid in range(6):
-        capi.random_permutation(n, 7, sid, ws, p, q)
-        a, b = p.numpy(), q.numpy()
+    ws = DB(capi.random_permutations_scratch_bytes(n, 6), np.uint8)
+    p, q = DB((6, n), np.int32), DB((6, n), np.int32)
+    capi.random_permutations(n, 6, 7, 3, ws, p, q)
+    seen = [r.copy() for r in p.numpy()]
+    for a, b in zip(seen, q.numpy()):
         assert np.array_equal(np.sort(a), np.arange(n)) and np.array_equal(a[b], np.arange(n))
-        seen.append(a)
-    capi.random_permutation(n, 7, 5, ws, p, None)
-    assert np.array_equal(p.numpy(), seen[5]) and not np.array_equal(seen[0], seen[1])
+    capi.random_permutations(n, 6, 7, 3, ws, p, None)
+    assert np.array_equal(p.numpy()[5], seen[5]) and not np.array_equal(seen[0], seen[1])
+    capi.random_permutations(n, 6, 7, 4, ws, p, None)
+    assert not np.array_equal(p.numpy()[0], seen[0])
     first = np.array([s[0] for s in seen]); assert len(set(first.tolist())) == 6
     # mean displacement of a uniform permutation is n/3
     disp = np.mean([np.abs(s - np.arange(n)).mean() for s in seen])
@@ -961,10 +961,11 @@ def test_mhcn_training_steps_match_restatement(L):
     assert rel_err(Ud, fu) < 3e-4 and rel_err(Vd, fi) < 3e-4
     # without injected shuffles the device draws its own, new ones every step
     tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B)
-    a = tr.rowp[0][0].numpy().copy()
+    a = tr.rowp.numpy().copy()
     tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B)
-    b = tr.rowp[0][0].numpy()
-    assert np.array_equal(np.sort(a), np.arange(nu)) and not np.array_equal(a, b) and np.isfinite(tr.losses()).all()
+    b = tr.rowp.numpy()
+    assert all(np.array_equal(np.sort(r), np.arange(nu)) for r in a) and not np.array_equal(a, b) and np.isfinite(tr.losses()).all()
+    assert len({tuple(r[:8]) for r in a}) == 9
 
 
 def test_mhcn_class_runs_stock_conf_shape_with_social_data(tmp_path):
