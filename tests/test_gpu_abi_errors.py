@@ -81,3 +81,42 @@ def test_empty_inputs_are_no_ops():
     from qrec_amd.data.rows import RatingRows
     rows = RatingRows(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0), [], [])
     assert len(rows) == 0 and rows.to_list() == [] and len(rows[0:0]) == 0
+
+
+def test_social_and_graph_model_entry_points_refuse_bad_arguments_and_accept_empty_ones():
+    """The entry points that came in with SVD++, TBPR, SEPT and MHCN: same contract -- negative code + message for what
+    they cannot serve, empty inputs are no-ops that leave tables and accumulated losses alone."""
+    f32 = lambda *shape: DB.zeros(shape, np.float32)
+    T0 = np.random.default_rng(1).random((60, 64)).astype(np.float32)
+    T, S, idx = DB.from_numpy(T0), DB.from_numpy(T0), DB.zeros(16, np.int32)
+    out = DB.from_numpy(np.array([5.0, 6.0, 0, 0, 0, 0, 0, 0], np.float64))
+    ws = DB.zeros(1 << 20, np.uint8)
+    # bad arguments
+    assert "stride" in _err(lambda: capi.l2norm_rows_accum(T, 60, 48, S, f32(60)))
+    assert "stride" in _err(lambda: capi.l2norm_rows_bwd(T, f32(60), T, 60, 48, S))
+    _err(lambda: capi.scale_copy(S, T, 6401, 0.5))                                                    # not a multiple of 4
+    assert "ins_cnt" in _err(lambda: capi.sept_ssl_loss_grad(T, T, T, T, idx, 4, 64, 9, 0.1, ws, S, S, S, S, out))   # k > unique users
+    _err(lambda: capi.sept_ssl_loss_grad(T, T, T, T, None, 4, 64, 2, 0.1, ws, S, S, S, S, out))        # no row list
+    _err(lambda: capi.sept_ssl_loss_grad(T, T, T, T, idx, 4, 48, 2, 0.1, ws, S, S, S, S, out))         # stride 48
+    _err(lambda: capi.gate_fwd(T, None, f32(64), 60, 64, S, S))
+    _err(lambda: capi.gate_fwd(T, f32(48, 48), f32(48), 60, 48, S, S))
+    _err(lambda: capi.gate_bwd(T, T, T, f32(64, 64), 60, 65, 64, S, S, False))                          # d > ld
+    _err(lambda: capi.hss_loss_grad(T, T, 60, 70, 64, [idx] * 10, 1.0, ws, S, S, out))                 # d > ld
+    _err(lambda: capi.random_permutations(1 << 20, 1 << 12, 0, 0, ws, idx))                            # n * count >= 2^31
+    _err(lambda: capi.small_permutations(5000, 1, 0, 0, idx, idx))                                     # n > 4096
+    _err(lambda: capi.tbpr_sgd_ordered(T, T, 9, 64, 64, idx, idx, idx, 16, 0.1, 0, 0, out, out))        # dtype
+    _err(lambda: capi.tbpr_sgd_ordered(T, T, capi.F32, 64, 64, idx, idx, idx, 16, 0.1, 0, 0, None, out))  # no sums
+    _err(lambda: capi.svdpp_sgd_ordered(T, T, None, T, T, capi.F32, 64, 64, DB.zeros(61, np.int64), idx, idx, idx, out, 4, 0.1, 0, 0, 0, 0, 3.0, out))
+    assert np.array_equal(T.numpy(), T0) and np.array_equal(S.numpy(), T0)
+    # empty inputs
+    capi.l2norm_rows_accum(T, 0, 64, S, f32(1)); capi.l2norm_rows_bwd(T, f32(1), T, 0, 64, S); capi.scale_copy(S, T, 0, 0.5)
+    capi.sept_ssl_loss_grad(T, T, T, T, None, 0, 64, 2, 0.1, ws, S, S, S, S, out)
+    capi.gate_fwd(T, f32(64, 64), f32(64), 0, 64, S, S); capi.gate_bwd(T, T, T, f32(64, 64), 0, 64, 64, S, S, True)
+    capi.hss_loss_grad(T, T, 0, 64, 64, [idx] * 10, 1.0, ws, S, S, out)
+    capi.random_permutations(0, 3, 0, 0, ws, idx); capi.small_permutations(8, 0, 0, 0, idx, idx)
+    assert np.array_equal(S.numpy(), T0) and out.numpy()[0] == 5.0 and out.numpy()[1] == 6.0
+    capi.tbpr_sgd_ordered(T, T, capi.F32, 64, 64, idx, idx, idx, 0, 0.1, 0.01, 0.01, out, out)          # n = 0: both loss terms := 0
+    assert out.numpy()[0] == 0.0 and out.numpy()[1] == 0.0 and np.array_equal(T.numpy(), T0)
+    u, a, b = capi.mt_tbpr_sample_epoch(np.zeros(625, np.uint32), np.zeros(4, np.int64), np.zeros(0, np.int32), 10,
+                                        *[(np.zeros(4, np.int64), np.zeros(0, np.int32))] * 3)
+    assert u.size == a.size == b.size == 0
