@@ -736,7 +736,7 @@ def test_two_rank_bench_path_on_one_device(tmp_path):
     assert not np.array_equal(r0["P"], r1["P"])                               # different user shards
     np.testing.assert_array_equal(r0["log"][:, :2], r1["log"][:, :2])         # same loss, same lr on both ranks
     assert r0["log"].shape[0] == 5 and float(r0["lr"]) == float(r1["lr"])
-    assert (np.diff(r0["log"][:, 0]) < 0).all()                               # the summed loss goes down
+    assert r0["log"][-1, 0] < r0["log"][0, 0]                                 # the summed loss goes down (not every step: the bold driver may halve first)
 
 
 @pytest.mark.parametrize("schedule", ["user", "item"])
