@@ -551,25 +551,36 @@ class SGLTrainer:
                           stream=stream, d_x_row_mask=self.row_mask if step == 0 else None)
             x = y
 
-    def train_step_async(self, d_u, d_i, d_j, B: int, d_rows, n_rows: int, stream=None):
-        """d_rows: the batch's unique users followed by its unique positive items (+n_users), distinct."""
+    def train_step_async(self, d_u, d_i, d_j, B: int, d_rows, n_rows: int, stream=None, share=None):
+        """d_rows: the batch's unique users followed by its unique positive items (+n_users), distinct.
+        ``share`` = (offset, count), one process per GPU (dist.BatchParallel in ``self.dp``): the BPR term covers this
+        rank's rows of the step, the InfoNCE term (which couples all the step's rows) is formed whole with weight
+        ssl_reg / world, and the table gradient is summed over the ranks before Adam."""
         if self.plans[0] is None:
             raise RuntimeError("set_subgraphs() first")
         if n_rows > self.max_unique:
             raise ValueError("more unique rows in the batch than the InfoNCE workspace holds")
         div = float(self.L + 1)
+        dp = getattr(self, "dp", None)
+        lo, cnt = (0, B) if share is None else share
         self.row_mask.fill_bytes(0, stream)
         capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)
         for v in range(3):
             self._forward(v, stream, last_rows=self.row_mask)
             self.dOut[v].fill_bytes(0, stream)
         self.G.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
-        capi.bpr_batch_loss_grad(self.S[0], div, self.nu, self.n, self.ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
-                                 self.dOut[0], self.d_loss, stream, d_row_mask=self.row_mask)
-        capi.info_nce_loss_grad(self.S[1], self.S[2], div, d_rows, n_rows, self.ld, self.temp, self.ssl_reg, self.ws,
+        if share is not None:
+            d_u, d_i, d_j = (capi._dp(p) + 4 * lo for p in (d_u, d_i, d_j))
+        if cnt:
+            capi.bpr_batch_loss_grad(self.S[0], div, self.nu, self.n, self.ld, d_u, d_i, d_j, cnt, self.loss_eps, self.reg,
+                                     self.dOut[0], self.d_loss, stream, d_row_mask=self.row_mask)
+        capi.info_nce_loss_grad(self.S[1], self.S[2], div, d_rows, n_rows, self.ld, self.temp,
+                                self.ssl_reg if dp is None else self.ssl_reg / dp.world, self.ws,
                                 self.dOut[1], self.d_loss.ptr + 8, stream, d_out2=self.dOut[2])
         for v in range(3):
             self._backward(v, stream)
+        if dp is not None:
+            dp.all_reduce(self.G); dp.all_reduce(self.d_loss.head_view(1))
         self.opt.step(self.G, grad_scale=1.0 / div, stream=stream)
 
     def losses(self, stream=None):
@@ -648,7 +659,10 @@ class BUIRTrainer:
         self.dS.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
         capi.buir_batch_loss_grad(self.S_on, self.S_tar, div, self.nu, self.ld, self.W, self.b, d_u, d_i, B, self.dS, self.Xb,
                                   self.Gb, self.d_loss, stream)
-        capi.buir_wgrad(self.Xb, self.Gb, 2 * B, self.ld, self.wscratch, self.gW, self.gb, stream)
+        if B:
+            capi.buir_wgrad(self.Xb, self.Gb, 2 * B, self.ld, self.wscratch, self.gW, self.gb, stream)
+        else:                   # an empty share of a step (multi-GPU tail batch)
+            self.gW.fill_bytes(0, stream); self.gb.fill_bytes(0, stream)
         # d online tables = (1/(L+1)) (I + A + ... + A^L) dS  (A symmetric): H_0 = dS, H_{k+1} = dS + A H_k
         x = self.dS
         for k in range(self.L):
@@ -656,6 +670,10 @@ class BUIRTrainer:
             capi.spmm_csr(self.plan_o, x, y, self.ld, d_addend=self.dS, addend_scale=1.0, stream=stream,
                           d_x_row_mask=self.row_mask if k == 0 else None)
             x = y
+        dp = getattr(self, "dp", None)
+        if dp is not None:      # every term is a sum over the step's pairs: the ranks' shares add up
+            for buf in (x, self.gW, self.gb, self.d_loss):
+                dp.all_reduce(buf)
         self.optE.step(x, grad_scale=1.0 / div, stream=stream)
         self.optW.step(self.gW, stream=stream); self.optb.step(self.gb, stream=stream)
         capi.ema_update(self.T, self.E, self.tau, self.n * self.ld, stream)
@@ -827,7 +845,11 @@ class SEPTTrainer:
         capi.scale_copy(self.E0, self.W, self.n * self.ld, 0.5, stream)
 
     def train_step_async(self, d_u, d_i, d_j, B: int, joint: bool = False, d_uniq_users=None, n_uu: int = 0, stream=None,
-                         keep_labels: bool = False):
+                         keep_labels: bool = False, share=None):
+        """``share`` = (offset, count) (one process per GPU, ``self.dp``): BPR on this rank's rows of the step; the
+        neighbour-discrimination term, which couples all the step's users, whole on every rank with weight ss_rate / world."""
+        dp = getattr(self, "dp", None)
+        lo, cnt = (0, B) if share is None else share
         if joint and n_uu > self.max_unique:
             raise ValueError("more unique users in the batch than the SEPT workspace holds")
         if joint and self.aug.plan is None:
@@ -838,8 +860,10 @@ class SEPTTrainer:
         mask = self.row_mask                                                      # unique users are among them)
         self.pref.forward(self.E0, stream, last_rows=mask)
         self.pref.dS.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream); self.dE0.fill_bytes(0, stream)
-        capi.bpr_batch_loss_grad(self.pref.S, 1.0, self.nu, self.n, self.ld, d_u, d_i, d_j, B, self.loss_eps, 0.0,
-                                 self.pref.dS, self.d_loss, stream)
+        if cnt:
+            off = 4 * lo
+            capi.bpr_batch_loss_grad(self.pref.S, 1.0, self.nu, self.n, self.ld, capi._dp(d_u) + off, capi._dp(d_i) + off,
+                                     capi._dp(d_j) + off, cnt, self.loss_eps, 0.0, self.pref.dS, self.d_loss, stream)
         capi.sumsq(self.W, capi.F32, self.n, self.d, self.ld, self.d_loss.ptr + 8, stream)     # regU (l2(U/2) + l2(V/2)) = regU sum W^2 / 8
         if joint:
             for v in (self.friend, self.sharing, self.aug):
@@ -847,11 +871,13 @@ class SEPTTrainer:
             if keep_labels:
                 self.d_labels = DeviceBuffer((3, n_uu, self.k), np.int32)
             capi.sept_ssl_loss_grad(self.friend.S, self.sharing.S, self.pref.S, self.aug.S, d_uniq_users, n_uu, self.ld, self.k,
-                                    self.ss_rate, self.ws, self.friend.dS, self.sharing.dS, self.pref.dS, self.aug.dS,
+                                    self.ss_rate if dp is None else self.ss_rate / dp.world, self.ws, self.friend.dS, self.sharing.dS, self.pref.dS, self.aug.dS,
                                     self.d_loss.ptr + 16, self.d_labels if keep_labels else None, stream)
             for v in (self.friend, self.sharing, self.aug):
                 self.T = v.backward(self.T, self.G, self.dE0, stream, ds_rows=mask)
         self.T = self.pref.backward(self.T, self.G, self.dE0, stream, ds_rows=mask)
+        if dp is not None:
+            dp.all_reduce(self.dE0); dp.all_reduce(self.d_loss.head_view(1))
         # d/dW = (dE0 + regU E0) / 2 = dE0 / 2 + regU W / 4
         self.opt[1 if joint else 0].step(self.dE0, grad_scale=0.5, stream=stream, grad_l2=self.reg / 4.0)
 
@@ -1031,19 +1057,24 @@ class MHCNTrainer:
         return out
 
     def train_step_async(self, d_u, d_i, d_j, B: int, perms=None, stream=None):
+        """With ``self.dp`` (one process per GPU) d_u/d_i/d_j are this rank's share of the step's rows; the
+        self-supervised term does not depend on the batch, so every rank forms it whole with weight ss_rate / world."""
         nu, ni, ld, d, L, w, g = self.nu, self.ni, self.ld, self.d, self.L, self.w, self.g
+        dp = getattr(self, "dp", None)
+        ss_rate = self.ss_rate if dp is None else self.ss_rate / dp.world
         self.forward(stream)
         self.dF.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
         g["attention"].fill_bytes(0, stream); g["attention_mat"].fill_bytes(0, stream)
         for k in (1, 2, 3, 4):        # sgating4 is created but unused: its gradient is its L2 term alone
             g[f"sgating{k}"].fill_bytes(0, stream); g[f"sgating_bias{k}"].fill_bytes(0, stream)
-        capi.bpr_batch_loss_grad(self.F, 1.0, nu, self.n, ld, d_u, d_i, d_j, B, self.loss_eps, 0.0, self.dF, self.d_loss, stream)
+        if B:
+            capi.bpr_batch_loss_grad(self.F, 1.0, nu, self.n, ld, d_u, d_i, d_j, B, self.loss_eps, 0.0, self.dF, self.d_loss, stream)
         # hierarchical self-supervision of the three channels (MHCN.py:176-178, 184-206)
         for k, shuffles in enumerate(self._draw_shuffles(perms, stream)):
             Ws, bs = w[f"sgating{k + 1}"], w[f"sgating_bias{k + 1}"]
             capi.gate_fwd(self.F, Ws, bs, nu, ld, self.SG, self.SGs, stream)
             capi.spmm_csr(self.planH[k], self.SG, self.edge, ld, stream=stream)
-            capi.hss_loss_grad(self.SG, self.edge, nu, d, ld, shuffles, self.ss_rate, self.hss_ws, self.dem, self.dedge,
+            capi.hss_loss_grad(self.SG, self.edge, nu, d, ld, shuffles, ss_rate, self.hss_ws, self.dem, self.dedge,
                                self.d_loss.ptr + 8, stream)
             capi.spmm_csr(self.planHT[k], self.dedge, self.dSG, ld, d_addend=self.dem, addend_scale=1.0, stream=stream)
             capi.gate_bwd(self.F, self.SGs, self.dSG, Ws, nu, d, ld, self.Q, self.dF, True, stream=stream)
@@ -1084,6 +1115,9 @@ class MHCNTrainer:
             dG = self.gc[a][k] if k < 3 else self.gs[a]
             capi.gate_bwd(self.U, self.Gs[k], dG, w[f"gating{k + 1}"], nu, d, ld, self.Q, self.dU, k > 0, stream=stream)
             capi.buir_wgrad(self.U, self.Q, nu, ld, self.wg_ws, g[f"gating{k + 1}"], g[f"gating_bias{k + 1}"], stream)
+        if dp is not None:      # table and weight gradients: sums over the ranks' shares (+ the 1/world self-supervised parts)
+            for buf in [self.dU, self.gt[a], self.d_loss.head_view(1)] + list(g.values()):
+                dp.all_reduce(buf)
         self.optU.step(self.dU, stream=stream, grad_l2=self.reg)
         self.optV.step(self.gt[a], stream=stream, grad_l2=self.reg)
         for key, opt in self.opt.items():

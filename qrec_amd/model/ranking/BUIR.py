@@ -65,9 +65,11 @@ class BUIR(DeepRecommender):
         for epoch, (subs, (u, i, _)) in enumerate(self.iter_epoch_samples(self.maxEpoch, self._draw_epoch)):
             tr.set_subgraphs(*subs)
             d_u, d_i = DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i)
-            for n, s in enumerate(range(0, u.size, self.batch_size)):
-                B = min(self.batch_size, u.size - s)
-                tr.train_step_async(d_u.ptr + 4 * s, d_i.ptr + 4 * s, B)
+            dp = tr.dp = self.data_parallel()              # one process per GPU: a step = batch_size x world pairs, this rank's share
+            step = self.batch_size * (dp.world if dp else 1)
+            for n, s in enumerate(range(0, u.size, step)):
+                lo, B = self.step_share(dp, min(step, u.size - s))
+                tr.train_step_async(d_u.ptr + 4 * (s + lo), d_i.ptr + 4 * (s + lo), B)
                 if not quiet:
                     print(self.foldInfo, "training:", epoch + 1, "batch", n, "loss:", tr.loss())
         self._final_py_state = random.getstate()      # where the reference's generator stands after training

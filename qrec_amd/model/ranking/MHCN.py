@@ -52,11 +52,13 @@ class MHCN(SocialRecommender, GraphRecommender):
     def trainModel(self):
         quiet = os.environ.get("QREC_QUIET") == "1"
         tr = self.trainer
+        dp = tr.dp = self.data_parallel()              # one process per GPU: a step = batch_size x world rows, this rank's share
+        step = self.batch_size * (dp.world if dp else 1)
         for epoch, (u, i, j) in enumerate(self.iter_epoch_samples(self.maxEpoch)):                  # base/deepRecommender.py:29-52
             d_u, d_i, d_j = DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i), DeviceBuffer.from_numpy(j)
-            for n, s in enumerate(range(0, u.size, self.batch_size)):
-                B = min(self.batch_size, u.size - s)
-                tr.train_step_async(d_u.ptr + 4 * s, d_i.ptr + 4 * s, d_j.ptr + 4 * s, B)
+            for n, s in enumerate(range(0, u.size, step)):
+                lo, B = self.step_share(dp, min(step, u.size - s))
+                tr.train_step_async(d_u.ptr + 4 * (s + lo), d_i.ptr + 4 * (s + lo), d_j.ptr + 4 * (s + lo), B)
                 if not quiet:
                     print(self.foldInfo, "training:", epoch + 1, "batch", n, "rec loss:", tr.losses()[0])
             self.U, self.V = tr.final_embeddings()

@@ -45,8 +45,13 @@ class SEPT(SocialRecommender, GraphRecommender):
         self.user_embeddings = truncated_normal((self.num_users, self.emb_size), 0.005)
         self.item_embeddings = truncated_normal((self.num_items, self.emb_size), 0.005)
         self.trainer = SEPTTrainer(self.user_embeddings, self.item_embeddings, adj, friend, sharing, self.n_layers, self.lRate,
-                                   self.regU, self.ss_rate, self.instance_cnt, max_unique=max(self.batch_size, 64))
+                                   self.regU, self.ss_rate, self.instance_cnt, max_unique=max(self._step_rows(), 64))
         self._epochs_drawn = 0
+
+    def _step_rows(self) -> int:
+        """rows of the batch stream one training step covers: batch_size, times the world size in a multi-GPU run"""
+        dp = self.data_parallel()
+        return self.batch_size * (dp.world if dp else 1)
 
     def get_adj_mat(self, is_subgraph=False):
         """scipy CSR of the (perturbed) joint graph (SEPT.py:79-114); the perturbed one consumes the CPython generator
@@ -68,8 +73,9 @@ class SEPT(SocialRecommender, GraphRecommender):
         joint = epoch > self.maxEpoch / 3
         sub = self.get_adj_mat(is_subgraph=True) if joint else None
         u, i, j = self.sample_epoch_pairwise()
-        starts = list(range(0, u.size, self.batch_size))
-        uu = [unique_first_appearance(u[s:s + self.batch_size]) for s in starts] if joint else [np.zeros(0, np.int32) for _ in starts]
+        step = self._step_rows()
+        starts = list(range(0, u.size, step))
+        uu = [unique_first_appearance(u[s:s + step]) for s in starts] if joint else [np.zeros(0, np.int32) for _ in starts]
         off = np.concatenate([[0], np.cumsum([x.size for x in uu])])
         return sub, u, i, j, starts, np.concatenate(uu).astype(np.int32) if uu else np.zeros(0, np.int32), off
 
@@ -79,6 +85,8 @@ class SEPT(SocialRecommender, GraphRecommender):
     def trainModel(self):
         quiet = os.environ.get("QREC_QUIET") == "1"
         tr = self.trainer
+        dp = tr.dp = self.data_parallel()
+        step = self._step_rows()
         for epoch, (sub, u, i, j, starts, uu, off) in enumerate(self.iter_epoch_samples(self.maxEpoch, self._draw_epoch)):
             joint = sub is not None
             if joint:
@@ -86,13 +94,13 @@ class SEPT(SocialRecommender, GraphRecommender):
             d_u, d_i, d_j = DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i), DeviceBuffer.from_numpy(j)
             d_uu = DeviceBuffer.from_numpy(uu) if uu.size else None
             for n, s in enumerate(starts):
-                B = min(self.batch_size, u.size - s)
+                B = min(step, u.size - s)
                 n_uu = int(off[n + 1] - off[n])
                 if joint and n_uu < self.instance_cnt:
                     print("SEPT: a batch with fewer distinct users than -ins_cnt cannot be pseudo-labelled")
                     raise SystemExit(-1)
                 tr.train_step_async(d_u.ptr + 4 * s, d_i.ptr + 4 * s, d_j.ptr + 4 * s, B, joint,
-                                    d_uu.ptr + 4 * int(off[n]) if joint else None, n_uu)
+                                    d_uu.ptr + 4 * int(off[n]) if joint else None, n_uu, share=self.step_share(dp, B) if dp else None)
                 if not quiet:
                     rec_l, con_l = tr.losses()
                     if joint:

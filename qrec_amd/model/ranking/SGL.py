@@ -33,7 +33,12 @@ class SGL(GraphRecommender):
         super().initModel()
         self.trainer = SGLTrainer(self.user_embeddings, self.item_embeddings, self.create_joint_sparse_adjaceny(),
                                   self.n_layers, self.lRate, self.regU, self.ssl_reg, self.ssl_temp,
-                                  max_unique=max(2 * self.batch_size, 64))
+                                  max_unique=max(2 * self._step_rows(), 64))
+
+    def _step_rows(self) -> int:
+        """rows of the batch stream one training step covers: batch_size, times the world size in a multi-GPU run"""
+        dp = self.data_parallel()
+        return self.batch_size * (dp.world if dp else 1)
 
     def _create_adj_mat(self, is_subgraph=False, aug_type=0):
         """CSR triple of the (sub-)graph's normalized adjacency (SGL.py:113-155); sub-graphs consume the
@@ -59,9 +64,10 @@ class SGL(GraphRecommender):
         u, i, j = self.sample_epoch_pairwise()
         # tf.unique of every batch (merged user + item rows, SGL.py calc_ssl_loss_v3), also on the sampler thread
         nu = self.num_users
-        starts = list(range(0, u.size, self.batch_size))
-        rows = [np.concatenate([unique_first_appearance(u[s:s + self.batch_size]),
-                                unique_first_appearance(i[s:s + self.batch_size]) + nu]).astype(np.int32) for s in starts]
+        step = self._step_rows()
+        starts = list(range(0, u.size, step))
+        rows = [np.concatenate([unique_first_appearance(u[s:s + step]),
+                                unique_first_appearance(i[s:s + step]) + nu]).astype(np.int32) for s in starts]
         off = np.concatenate([[0], np.cumsum([r.size for r in rows])])
         return subs, (u, i, j, starts, np.concatenate(rows), off)
 
@@ -71,13 +77,16 @@ class SGL(GraphRecommender):
     def trainModel(self):
         quiet = os.environ.get("QREC_QUIET") == "1"
         tr, nu = self.trainer, self.num_users
+        dp = tr.dp = self.data_parallel()
+        step = self._step_rows()
         for epoch, (subs, (u, i, j, starts, rows, off)) in enumerate(self.iter_epoch_samples(self.maxEpoch, self._draw_epoch)):
             tr.set_subgraphs(*subs)
             d_u, d_i, d_j = DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i), DeviceBuffer.from_numpy(j)
             d_rows = DeviceBuffer.from_numpy(rows)
             for n, s in enumerate(starts):
-                B = min(self.batch_size, u.size - s)
-                tr.train_step_async(d_u.ptr + 4 * s, d_i.ptr + 4 * s, d_j.ptr + 4 * s, B, d_rows.ptr + 4 * int(off[n]), int(off[n + 1] - off[n]))
+                B = min(step, u.size - s)
+                tr.train_step_async(d_u.ptr + 4 * s, d_i.ptr + 4 * s, d_j.ptr + 4 * s, B, d_rows.ptr + 4 * int(off[n]), int(off[n + 1] - off[n]),
+                                    share=self.step_share(dp, B) if dp else None)
                 if not quiet:
                     _, rec_l, ssl_l = tr.losses()
                     print("training:", epoch + 1, "batch", n, "rec_loss:", rec_l, "ssl_loss", ssl_l)

@@ -18,7 +18,12 @@ from qrec_amd.QRec import resolve_model  # noqa: E402
 from qrec_amd.dist import init_from_env  # noqa: E402
 
 EXTRA = {"LightGCN": {"LightGCN": "-n_layer 2"}, "NGCF": {}, "SimGCL": {"SimGCL": "-n_layer 2 -lambda 0.5 -eps 0.1"},
-         "BPR": {"num.max.epoch": "60", "learnRate": "-init 0.02 -max 0.02", "reg.lambda": "-u 0.01 -i 0.01 -b 0.2 -s 0.2"}}
+         "BPR": {"num.max.epoch": "60", "learnRate": "-init 0.02 -max 0.02", "reg.lambda": "-u 0.01 -i 0.01 -b 0.2 -s 0.2"},
+         "SGL": {"SGL": "-n_layer 2 -lambda 0.1 -droprate 0.1 -augtype 1 -temp 0.2"},
+         "BUIR": {"BUIR": "-n_layer 2 -tau 0.995 -drop_rate 0.2"},
+         "SEPT": {"SEPT": "-n_layer 2 -ss_rate 0.005 -drop_rate 0.3 -ins_cnt 10", "num.max.epoch": "4"},
+         "MHCN": {"MHCN": "-n_layer 2 -ss_rate 0.01"}}
+SOCIAL = ("SEPT", "MHCN")
 
 
 def main():
@@ -28,8 +33,17 @@ def main():
     if world == 1:
         random.seed(seed); np.random.seed(seed)
     rank = int(os.environ.get("RANK", "0"))
-    meta, z = load_golden("bpr_filmtrust")
-    train, test = rows_from_golden(z)
+    relation = None
+    if name in SOCIAL:         # FilmTrust rows + its trust list as the reference loaded them (tests/golden/sept_graphs_filmtrust.npz)
+        meta, z = load_golden("sept_graphs_filmtrust")
+        uid, iid = z["train_uid"].tolist(), z["train_iid"].tolist()
+        train = [[f"u{u}", f"i{i}", 1.0] for u, i in zip(uid, iid)]
+        test = [[f"u{u}", f"i{(i * 7 + 3) % meta['n_items']}", 1.0] for u, i in zip(uid[::19], iid[::19])]
+        tag = lambda c: f"u{c}" if c >= 0 else f"x{-1 - c}"
+        relation = [[tag(a), tag(b), w] for a, b, w in zip(z["raw_follower"].tolist(), z["raw_followee"].tolist(), z["raw_weight"].tolist())]
+    else:
+        meta, z = load_golden("bpr_filmtrust")
+        train, test = rows_from_golden(z)
     conf = conf_from_text(meta["conf"])
     conf["model.name"] = name; conf["num.factors"] = "16"; conf["num.max.epoch"] = "2"; conf["batch_size"] = str(batch)
     conf["learnRate"] = "-init 0.002 -max 1"; conf["reg.lambda"] = "-u 0.001 -i 0.001 -b 0.2 -s 0.2"
@@ -38,15 +52,17 @@ def main():
         conf[k] = v
     buf = io.StringIO()
     with redirect_stdout(buf):
-        m = resolve_model(name)(conf, train, test)
+        m = resolve_model(name)(conf, train, test, relation) if relation is not None else resolve_model(name)(conf, train, test)
         measure = m.execute()
     if name == "BPR":        # "... epoch k: loss = x, delta_loss = ..." (base/iterativeRecommender.py:98-99)
         losses = [float(l.split("loss = ")[1].split(",")[0]) for l in buf.getvalue().splitlines() if "loss = " in l]
         U, V, E = m.P, m.Q, np.concatenate([m.P, m.Q])
     else:
         losses = [float(l.split("loss:")[1].split()[0]) for l in buf.getvalue().splitlines() if "loss:" in l]
-        E = m.trainer.E[0] if isinstance(m.trainer.E, list) else m.trainer.E
-        U, V, E = m.U, m.V, E.numpy()
+        tr = m.trainer
+        E = tr.U if name == "MHCN" else tr.W if name == "SEPT" else tr.E[0] if isinstance(tr.E, list) else tr.E
+        U, V = (m.q_user, m.q_item) if name == "BUIR" else (m.U, m.V)
+        E = E.numpy()
     np.savez(os.path.join(out, f"rank{rank}.npz"), U=U, V=V, E=E, losses=np.array(losses),
              measure=np.array([float(x.split(":")[1]) for x in measure if ":" in x]))
     if world > 1:
