@@ -265,6 +265,7 @@ int launch_spmm(const int32_t *seg_row, const int64_t *seg_beg, const int32_t *s
     constexpr int GPW = kWave / LPR;
     int64_t blocks = (n_segs + 4 * GPW - 1) / (4 * GPW);
     if (blocks > 256 * 8) blocks = 256 * 8;
+    blocks = (blocks + 7) & ~(int64_t)7;     // a multiple of the 8 XCDs: segment p always lands on XCD (p / groups per block) % 8
     hipLaunchKernelGGL((spmm_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, seg_row, seg_beg, seg_len,
                        seg_slot, n_segs, indices, values, X, Y, partial, addend, addend_scale, accum, x_row_mask, y_row_mask);
     QREC_LAUNCH_CHECK();

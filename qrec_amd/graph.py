@@ -3,6 +3,8 @@
 step of model/ranking/LightGCN.py:11-41 driven entirely through the C ABI."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import capi
@@ -60,7 +62,12 @@ def sample_subgraph_edges(state625: np.ndarray, uid: np.ndarray, iid: np.ndarray
 class SpmmPlan:
     """Device-resident CSR plus its segment decomposition (include/qrec_hip.h, qrec_spmm_csr)."""
 
-    def __init__(self, indptr: np.ndarray, indices: np.ndarray, values: np.ndarray, ld: int, seg_len: int = 128):
+    def __init__(self, indptr: np.ndarray, indices: np.ndarray, values: np.ndarray, ld: int, seg_len: int = 128,
+                 split_row: int | None = None):
+        """``split_row`` (bipartite joint adjacency: the number of users): rows below it only gather operand rows
+        at or above it and vice versa, so the two kinds of rows are dealt to different XCDs -- workgroups go round-robin
+        over the 8 XCDs, each with its own 4 MiB L2, and the kernel is bound by L2 misses: an XCD that only
+        runs user rows caches only the item half of the operand."""
         n_rows = indptr.size - 1
         nnz_row = np.diff(indptr)
         n_seg_row = np.maximum(1, -(-nnz_row // seg_len)).astype(np.int64)     # ceil, >=1 (empty rows write zeros)
@@ -77,6 +84,8 @@ class SpmmPlan:
         long_first = np.concatenate([[0], np.cumsum(long_count)[:-1]]).astype(np.int32) if long_rows.size else np.zeros(0, np.int32)
         # longest segments first: the heavy work starts early, the tail is made of short rows
         order = np.argsort(-seg_len_arr, kind="stable")
+        if split_row is not None and 0 < split_row < n_rows:
+            order = self._deal_by_xcd(order, seg_row[order] >= split_row, 4 * (64 // (ld // 4)))
         self.n_rows, self.nnz, self.ld = n_rows, int(indices.size), ld
         self.n_segs, self.n_long = int(seg_row.size), int(long_rows.size)
         up = DeviceBuffer.from_numpy
@@ -87,6 +96,26 @@ class SpmmPlan:
         self.long_count = up(long_count) if self.n_long else None
         self.partial = DeviceBuffer((max(int(is_long.sum()), 1), ld), np.float32)
         self.indices, self.values = up(indices.astype(np.int32)), up(values.astype(np.float32))
+
+    @staticmethod
+    def _deal_by_xcd(order: np.ndarray, is_second: np.ndarray, groups_per_block: int) -> np.ndarray:
+        """Segment p of the list is processed by workgroup (p // groups_per_block) of the persistent grid (a multiple
+        of 8 workgroups), which runs on XCD (p // groups_per_block) % 8.  Positions on XCDs 0-3 receive the first class'
+        segments, positions on XCDs 4-7 the second's, each class keeping its longest-first order; whatever does not
+        fit (unequal class sizes) fills the remaining positions."""
+        n = order.size
+        pos_second = ((np.arange(n) // groups_per_block) % 8) >= 4
+        out = np.empty(n, dtype=order.dtype)
+        free = np.ones(n, bool)
+        rest = []
+        for cls in (False, True):
+            segs = order[is_second == cls]
+            slots = np.nonzero(pos_second == cls)[0]
+            k = min(segs.size, slots.size)
+            out[slots[:k]] = segs[:k]; free[slots[:k]] = False
+            rest.append(segs[k:])
+        out[np.nonzero(free)[0]] = np.concatenate(rest)
+        return out
 
     def bytes_algorithmic(self, d: int) -> int:
         """nnz*(4+4) + 4*(N+1) + 2*N*d*4 (every dense row read once, written once)."""
@@ -104,7 +133,7 @@ class LightGCNTrainer:
         self.n = self.nu + self.ni
         self.ld = padded_ld(self.d, np.float32)
         self.L, self.lr, self.reg, self.loss_eps = n_layers, lr, reg, loss_eps
-        self.plan = SpmmPlan(adj[0], adj[1], adj[2], self.ld)
+        self.plan = SpmmPlan(adj[0], adj[1], adj[2], self.ld, split_row=self.nu)
         E0 = np.zeros((self.n, self.ld), np.float32)
         E0[:self.nu, :self.d] = U0; E0[self.nu:, :self.d] = V0
         self.E = DeviceBuffer.from_numpy(E0)
@@ -241,7 +270,7 @@ class SimGCLTrainer:
         self.ld = padded_ld(self.d, np.float32)
         self.L, self.lr, self.reg, self.cl_rate, self.eps, self.tau = n_layers, lr, reg, cl_rate, eps, tau
         self.loss_eps, self.seed = loss_eps, seed
-        self.plan = SpmmPlan(adj[0], adj[1], adj[2], self.ld)
+        self.plan = SpmmPlan(adj[0], adj[1], adj[2], self.ld, split_row=self.nu)
         E0 = np.zeros((self.n, self.ld), np.float32)
         E0[:self.nu, :self.d] = U0; E0[self.nu:, :self.d] = V0
         self.E = DeviceBuffer.from_numpy(E0)
@@ -402,7 +431,7 @@ class NGCFTrainer:
         self.ld = padded_ld(self.d, np.float32)
         self.wide_d, self.wide_ld = 3 * self.d, padded_ld(3 * self.d, np.float32)
         self.lr, self.reg, self.loss_eps, self.seed = lr, reg, loss_eps, seed
-        self.plan = SpmmPlan(adj[0], adj[1], adj[2], self.ld)
+        self.plan = SpmmPlan(adj[0], adj[1], adj[2], self.ld, split_row=self.nu)
         E0 = np.zeros((self.n, self.ld), np.float32)
         E0[:self.nu, :self.d] = U0; E0[self.nu:, :self.d] = V0
         z = lambda: DeviceBuffer.zeros((self.n, self.ld), np.float32)
@@ -498,7 +527,7 @@ class SGLTrainer:
         self.n = self.nu + self.ni
         self.ld = padded_ld(self.d, np.float32)
         self.L, self.reg, self.ssl_reg, self.temp, self.loss_eps = n_layers, reg, ssl_reg, temp, loss_eps
-        self.main_plan = SpmmPlan(adj[0], adj[1], adj[2], self.ld)
+        self.main_plan = SpmmPlan(adj[0], adj[1], adj[2], self.ld, split_row=self.nu)
         self.plans = [None, None]                 # per view: list of L plans
         E0 = np.zeros((self.n, self.ld), np.float32)
         E0[:self.nu, :self.d] = U0; E0[self.nu:, :self.d] = V0
@@ -517,10 +546,10 @@ class SGLTrainer:
         """adjs*: one (indptr, indices, values) triple, or a list of L of them (random walk)."""
         def plans(adjs):
             if isinstance(adjs, tuple):
-                p = SpmmPlan(adjs[0], adjs[1], adjs[2], self.ld)
+                p = SpmmPlan(adjs[0], adjs[1], adjs[2], self.ld, split_row=self.nu)
                 return [p] * self.L
             assert len(adjs) == self.L
-            return [SpmmPlan(a[0], a[1], a[2], self.ld) for a in adjs]
+            return [SpmmPlan(a[0], a[1], a[2], self.ld, split_row=self.nu) for a in adjs]
         self.plans = [plans(adjs1), plans(adjs2)]
 
     def _view_plans(self, v):
@@ -633,8 +662,8 @@ class BUIRTrainer:
 
     def set_subgraphs(self, adj_o, adj_t):
         """this epoch's two normalized sub-graph adjacencies (CSR triples), BUIR.py:139-146"""
-        self.plan_o = SpmmPlan(adj_o[0], adj_o[1], adj_o[2], self.ld)
-        self.plan_t = SpmmPlan(adj_t[0], adj_t[1], adj_t[2], self.ld)
+        self.plan_o = SpmmPlan(adj_o[0], adj_o[1], adj_o[2], self.ld, split_row=self.nu)
+        self.plan_t = SpmmPlan(adj_t[0], adj_t[1], adj_t[2], self.ld, split_row=self.nu)
 
     def _mean_sum(self, plan, X, S, stream=None, last_rows=None):
         """S = X + A X + ... + A^L X (the mean's 1/(L+1) is applied where S is used)"""
@@ -773,10 +802,10 @@ class _View:
         self.inv = [DeviceBuffer.zeros(max(rows, 1), np.float32) for _ in range(L)]
         self.plan = self.planT = None
 
-    def set_matrix(self, M):
-        """M: scipy CSR (rows x rows)"""
-        self.plan = SpmmPlan(*_csr_triple(M), self.ld)
-        self.planT = self.plan if (abs(M - M.T)).nnz == 0 else SpmmPlan(*_csr_triple(M.T), self.ld)
+    def set_matrix(self, M, split_row=None):
+        """M: scipy CSR (rows x rows); ``split_row``: see SpmmPlan (joint user-item graphs)"""
+        self.plan = SpmmPlan(*_csr_triple(M), self.ld, split_row=split_row)
+        self.planT = self.plan if (abs(M - M.T)).nnz == 0 else SpmmPlan(*_csr_triple(M.T), self.ld, split_row=split_row)
 
     def forward(self, X0, stream=None, last_rows=None):
         """``last_rows`` (row bitmap, training): the last layer is only formed at those rows -- S is read at the batch's
@@ -829,7 +858,7 @@ class SEPTTrainer:
         self.E0, self.dE0, self.T, self.G = z(), z(), z(), [z(), z()]
         self.pref, self.aug = _View(self.n, self.ld, n_layers), _View(self.n, self.ld, n_layers)
         self.friend, self.sharing = _View(self.nu, self.ld, n_layers), _View(self.nu, self.ld, n_layers)
-        self.pref.set_matrix(adj); self.friend.set_matrix(friend); self.sharing.set_matrix(sharing)
+        self.pref.set_matrix(adj, split_row=self.nu); self.friend.set_matrix(friend); self.sharing.set_matrix(sharing)
         self.opt = [_Adam(self.W, lr), _Adam(self.W, lr)]          # v1_opt (rec_loss), v2_opt (rec + ss), SEPT.py:267-270
         self.d_loss = DeviceBuffer.zeros(3, np.float64)             # [bpr term, sum W^2, neighbour-discrimination (unscaled)]
         self.row_mask = DeviceBuffer.zeros((self.n + 31) // 32, np.uint32)   # the batch's rows {u, nu+i, nu+j}
@@ -839,7 +868,7 @@ class SEPTTrainer:
 
     def set_perturbed_graph(self, M):
         """the epoch's get_adj_mat(is_subgraph=True) (scipy CSR, N x N)"""
-        self.aug.set_matrix(M)
+        self.aug.set_matrix(M, split_row=self.nu)
 
     def _halve(self, stream=None):
         capi.scale_copy(self.E0, self.W, self.n * self.ld, 0.5, stream)
