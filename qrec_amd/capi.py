@@ -191,6 +191,19 @@ def device_info() -> dict:
     return dict(name=name.value.decode(), arch=arch.value.decode(), n_cu=ncu.value, hbm_bytes=hbm.value)
 
 
+def device_ptr(x) -> int:
+    """device address of a DeviceBuffer / torch tensor / raw int -- for pointer arithmetic into a larger buffer"""
+    return int(_dp(x))
+
+
+def memcpy_d2d(dst, src, nbytes: int, stream=None):
+    _check(load().qrec_memcpy_d2d(_dp(dst), _dp(src), nbytes, _sh(stream)))
+
+
+def memset(dst, byte: int, nbytes: int, stream=None):
+    _check(load().qrec_memset(_dp(dst), byte, nbytes, _sh(stream)))
+
+
 def device_sync():
     _check(load().qrec_device_sync())
 

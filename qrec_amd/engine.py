@@ -196,7 +196,7 @@ class BprSgd:
         Q[j] -- ~20% faster because the atomic units see flatter target rows."""
         if self.t.dtype != np.float32:
             raise TypeError("throughput mode needs fp32 tables")
-        capi._check(capi.load().qrec_memset(self.d_stats.ptr, 0, 8, capi._sh(stream)))
+        capi.memset(self.d_stats.ptr, 0, 8, stream)
         if self.schedule == "item":
             capi.bpr_sgd_hogwild_item_major(self.t.P, self.t.Q, self.t.d, self.t.ld, self.d_u, self.d_i, self.d_j,
                                             self.n, chunk, groups, flush_every, lr, regU, regI, self.d_stats, stream)

@@ -354,7 +354,7 @@ class SimGCLTrainer:
         self.d_loss.fill_bytes(0, stream)
         # the InfoNCE rows (unique batch users / positive items) are a subset of the rows marked above
         if share is not None:
-            d_u, d_i, d_j = (capi._dp(p) + 4 * lo for p in (d_u, d_i, d_j))
+            d_u, d_i, d_j = (capi.device_ptr(p) + 4 * lo for p in (d_u, d_i, d_j))
         if cnt:
             capi.bpr_batch_loss_grad(self.Sm, L, self.nu, self.n, self.ld, d_u, d_i, d_j, cnt,
                                      self.loss_eps, self.reg, self.dOut, self.d_loss, stream, d_row_mask=self.row_mask)
@@ -599,7 +599,7 @@ class SGLTrainer:
             self.dOut[v].fill_bytes(0, stream)
         self.G.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
         if share is not None:
-            d_u, d_i, d_j = (capi._dp(p) + 4 * lo for p in (d_u, d_i, d_j))
+            d_u, d_i, d_j = (capi.device_ptr(p) + 4 * lo for p in (d_u, d_i, d_j))
         if cnt:
             capi.bpr_batch_loss_grad(self.S[0], div, self.nu, self.n, self.ld, d_u, d_i, d_j, cnt, self.loss_eps, self.reg,
                                      self.dOut[0], self.d_loss, stream, d_row_mask=self.row_mask)
@@ -891,8 +891,8 @@ class SEPTTrainer:
         self.pref.dS.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream); self.dE0.fill_bytes(0, stream)
         if cnt:
             off = 4 * lo
-            capi.bpr_batch_loss_grad(self.pref.S, 1.0, self.nu, self.n, self.ld, capi._dp(d_u) + off, capi._dp(d_i) + off,
-                                     capi._dp(d_j) + off, cnt, self.loss_eps, 0.0, self.pref.dS, self.d_loss, stream)
+            capi.bpr_batch_loss_grad(self.pref.S, 1.0, self.nu, self.n, self.ld, capi.device_ptr(d_u) + off, capi.device_ptr(d_i) + off,
+                                     capi.device_ptr(d_j) + off, cnt, self.loss_eps, 0.0, self.pref.dS, self.d_loss, stream)
         capi.sumsq(self.W, capi.F32, self.n, self.d, self.ld, self.d_loss.ptr + 8, stream)     # regU (l2(U/2) + l2(V/2)) = regU sum W^2 / 8
         if joint:
             for v in (self.friend, self.sharing, self.aug):
@@ -1051,7 +1051,7 @@ class MHCNTrainer:
         for k in range(3):
             self.sum_c[k].copy_from(self.G[k], stream)
         self.sum_s.copy_from(self.G[3], stream)
-        capi._check(capi.load().qrec_memcpy_d2d(self._FI, self.V.ptr, ni * ld * 4, capi._sh(stream)))
+        capi.memcpy_d2d(self._FI, self.V.ptr, ni * ld * 4, stream)
         for l in range(1, L + 1):
             capi.channel_attention_fwd(self.c[l - 1], w["attention"], w["attention_mat"], self.s[l - 1], nu, ld, self.v,
                                        self.score[l - 1], self.mixed, stream)
