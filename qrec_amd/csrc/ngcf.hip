@@ -207,6 +207,18 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const float *__restrict_
         for (int t = 0; t < NT; t++)
 #pragma unroll
             for (int q = 0; q < 16; q++) { a1[t][q] = 0.f; a2[t][q] = 0.f; }
+        // the epilogue's E / side values (C layout) are fetched BEFORE the MFMA loop: a wavefront owns a single tile, so
+        // nothing else can hide their latency (62 -> 3x us per call when they were loaded after the products)
+        float ev[NT][16], sv[NT][16];
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                int64_t orow = row0 + cd_row(q, h);
+                if (orow >= n_rows) orow = n_rows - 1;
+                const int64_t o = orow * LD + 32 * t + r;
+                ev[t][q] = E[o]; sv[t][q] = side[o];
+            }
 #pragma unroll
         for (int c = 0; c < LD; c += 64) {
             const int k0 = c + 32 * h;
@@ -237,9 +249,8 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const float *__restrict_
                 const int64_t orow = row0 + cd_row(q, h);
                 if (orow < n_rows) {
                     const int64_t o = orow * LD + 32 * t + r;
-                    const float e = E[o], sd = side[o];
-                    dside[o] = a1[t][q] + a2[t][q] * e;
-                    dE[o] = a1[t][q] + a2[t][q] * sd;
+                    dside[o] = a1[t][q] + a2[t][q] * ev[t][q];
+                    dE[o] = a1[t][q] + a2[t][q] * sv[t][q];
                 }
             }
     }
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const float *__restrict_
 // dpre, i.e. 2*NT MFMAs per k-step from 2 + NT coalesced dword loads (the first version issued 3 loads per MFMA from
 // one wavefront per SIMD and sat in load latency: 98 us for 1.1 GFLOP).  A chunk's 32 k-steps are fetched first, then
 // its MFMAs run.  Rows past the end feed a = 0.
-constexpr int kWaveRows = 128;                 // rows one wavefront accumulates
+constexpr int kWaveRows = 128;                 // rows one wavefront accumulates (64 gives the same 36 us and doubles the partial slabs)
 constexpr int kSlabRows = 4 * kWaveRows;       // rows per block = per partial slab (4 wavefronts, summed through LDS)
 template <int NT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ E, const float *__restrict__ side,
