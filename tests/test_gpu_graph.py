@@ -1016,3 +1016,32 @@ def test_mhcn_class_runs_stock_conf_shape_with_social_data(tmp_path):
     with redirect_stdout(io.StringIO()):
         MHCN(conf, train, test, FileIO.loadRelationship(conf, str(path))).execute()
     assert np.array_equal(capi.state_from_python(random.getstate()), want)
+
+
+@pytest.mark.parametrize("model,extra", [("SEPT", "SEPT=-n_layer 2 -ss_rate 0.005 -drop_rate 0.3 -ins_cnt 5"), ("TBPR", "TBPR=-regT 0.01")])
+def test_social_models_run_from_conf_files_with_cross_validation(tmp_path, model, extra):
+    """``python -m qrec_amd.main <conf>`` with a ``social`` file and ``-cv 2`` (QRec.py:44-46, 62-101): the relation list is
+    loaded once, every fold's model is built in the parent WITH it (and prunes it to its own training users), runs in its
+    own process, and the averaged measures are written."""
+    import os, subprocess, sys
+    rng = np.random.default_rng(33)
+    n = 6000
+    rows = [f"user{u} item{i} {r}" for u, i, r in zip(rng.integers(0, 150, n), rng.integers(0, 220, n), rng.choice([1, 2, 3, 4, 5], n))]
+    (tmp_path / "ratings.txt").write_text("\n".join(rows) + "\n")
+    rel = {(int(a), int(b)) for a, b in zip(rng.integers(0, 170, 900), rng.integers(0, 170, 900)) if a != b}     # users 150..169 never rate
+    (tmp_path / "trust.txt").write_text("".join(f"user{a}\tuser{b}\n" for a, b in sorted(rel)))
+    conf = {"ratings": "./ratings.txt", "social": "./trust.txt", "ratings.setup": "-columns 0 1 2", "social.setup": "-columns 0 1",
+            "model.name": model, "evaluation.setup": "-cv 2 -b 1", "item.ranking": "on -topN 10", "num.factors": "16",
+            "num.max.epoch": "3", "batch_size": "512", "learnRate": "-init 0.01 -max 1", "reg.lambda": "-u 0.01 -i 0.01 -b 0.2 -s 0.2",
+            "output.setup": "off -dir ./results/"}
+    (tmp_path / "m.conf").write_text("".join(f"{k}={v}\n" for k, v in conf.items()) + extra + "\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), QREC_QUIET="1")
+    run = subprocess.run([sys.executable, "-m", "qrec_amd.main", "m.conf"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
+    assert "loading social data..." in run.stdout and "The result of 2-fold cross validation:" in run.stdout
+    out = list((tmp_path / "results").glob(f"{model}@*-2-fold-cv.txt"))
+    assert len(out) == 1
+    res = out[0].read_text().splitlines()
+    assert [r.split(":")[0] for r in res] == ["Top 10", "Precision", "Recall", "F1", "NDCG"]
+    assert all(0.0 <= float(r.split(":")[1]) <= 1.0 for r in res[1:])
