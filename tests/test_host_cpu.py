@@ -504,3 +504,40 @@ def test_mhcn_graph_builders_of_the_product_match_the_reference_bitwise():
     Rc = R.tocoo()
     assert Rc.shape == tuple(meta["R_shape"]) and Rc.nnz == len(want) and Rc.data.dtype == np.float32
     assert all(want[(int(u), int(i))] == v for u, i, v in zip(Rc.row, Rc.col, Rc.data))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_tbpr_native_sampler_equals_cpython_random_on_random_problems(seed):
+    """qrec_mt_tbpr_sample_epoch against the statements of model/ranking/TBPR.py:137-158 executed with Python's own
+    ``random`` module (choice over lists of every length incl. 1 and empty, rejection against the positives), several
+    epochs with the per-epoch shuffle in between: same triplets, same generator state."""
+    rng = np.random.default_rng(seed)
+    U, I = 40, 23
+    pos_lists = [sorted(rng.choice(I, rng.integers(0, 6), replace=False).tolist()) for _ in range(U)]
+    def side_lists():
+        return [rng.choice(I, rng.integers(0, 5), replace=False).tolist() if rng.random() < 0.7 else [] for _ in range(U)]
+    J, W, S = side_lists(), side_lists(), side_lists()
+    csr = lambda lists: (np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int64),
+                         np.array([y for x in lists for y in x], dtype=np.int32))
+    pos_ptr, pos_items = csr(pos_lists)
+    n_train = int(pos_items.size)
+    random.seed(seed)
+    words = capi.state_from_python(random.getstate())
+    for epoch in range(3):
+        want = []
+        for u in range(U):
+            for i in pos_lists[u]:
+                chain = [i]
+                for lst in (J[u], W[u], S[u]):
+                    if len(lst) > 0:
+                        chain.append(random.choice(lst))
+                k = random.choice(range(I))
+                while k in pos_lists[u]:
+                    k = random.choice(range(I))
+                chain.append(k)
+                want += [(u, a, b) for a, b in zip(chain[:-1], chain[1:])]
+        rows = list(range(n_train)); random.shuffle(rows)
+        u_, a_, b_ = capi.mt_tbpr_sample_epoch(words, pos_ptr, pos_items, I, csr(J), csr(W), csr(S))
+        capi.mt_shuffle(words, n_train)
+        assert list(zip(u_.tolist(), a_.tolist(), b_.tolist())) == want
+        assert np.array_equal(words, capi.state_from_python(random.getstate()))
