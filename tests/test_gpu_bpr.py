@@ -936,3 +936,25 @@ def test_tbpr_model_reproduces_the_reference_run(tmp_path):
         if ":" in w:
             assert float(g.split(":")[1]) == pytest.approx(float(w.split(":")[1]), rel=1e-9)
     assert np.array_equal(capi.state_from_python(random.getstate()), z["py_state"])
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-12), (np.float32, 2e-5)])
+@pytest.mark.parametrize("n_items,n", [(3, 257), (6, 1000), (40, 4099)])
+def test_ordered_kernel_is_order_exact_under_heavy_aliasing(dtype, tol, n_items, n):
+    """With a handful of items nearly every row a triplet reads was written by one of the triplets just before it (the
+    prefetched rows must be patched from registers), users switch back and forth, and n is odd: the result must still
+    be the sequential recurrence."""
+    rng = np.random.default_rng(n_items * 1000 + n)
+    U, dim = 5, 24
+    u = rng.integers(0, U, n).astype(np.int32)
+    u[: n // 2] = np.sort(u[: n // 2])                         # runs of one user, then switching at every triplet
+    i = rng.integers(0, n_items, n).astype(np.int32)
+    j = ((i + 1 + rng.integers(0, n_items - 1, n)) % n_items).astype(np.int32)      # j != i
+    P0, Q0 = rng.random((U, dim)) / 3, rng.random((n_items, dim)) / 3
+    Pr, Qr = P0.astype(dtype), Q0.astype(dtype)
+    want = O.bpr_sgd(Pr, Qr, u, i, j, 0.02, 0.01, 0.02)
+    t = DeviceTables(P0, Q0, dtype)
+    loss = DB.zeros(1, np.float64)
+    capi.bpr_sgd_ordered(t.P, t.Q, t.code, dim, t.ld, DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), n, 0.02, 0.01, 0.02, loss)
+    Pg, Qg = t.download(np.float64)
+    assert rel_err(Pg, Pr) < tol and rel_err(Qg, Qr) < tol and abs(float(loss.numpy()[0]) - want) / want < tol
