@@ -124,6 +124,13 @@ def main():
                     help="visiting order of the epoch's triplets in the Hogwild kernel (DESIGN.md s4)")
     args = ap.parse_args()
 
+    # stdout carries ONE line, the result.  Libraries print there too -- RCCL writes its version banner to C stdio's
+    # stdout, flushed at exit, i.e. AFTER a Python print -- so file descriptor 1 is pointed at stderr for the whole run and
+    # the JSON line goes to the saved original descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -270,7 +277,7 @@ def main():
             out["recall_at_20"] = {"gpu_throughput_mode": r_gpu, "cpu_port_exact_order": r_cpu,
                                    "abs_diff": abs(r_gpu - r_cpu), "epochs": total,
                                    "final_loss_gpu": state["loss"], "final_loss_cpu": loss_c}
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
