@@ -1,33 +1,40 @@
 #!/usr/bin/env python3
 """bench.py -- BPR triplet-updates/sec on the MI355X hot path (BASELINE.json metric).
 
-One *step* = one full pass of the reference's BPR epoch (model/ranking/BPR.py:29-43) over
-the synthetic Yelp2018-shape interaction matrix (31,668 x 38,048, ~1.25 M train triplets,
-d=64): negative sampling for every triplet (device Philox sampler) -> fused gather / dot /
-sigmoid / SGD scatter kernel (throughput mode) -> epoch-end regulariser reductions ->
-loss read-back -> bold-driver learning-rate update on the host (the reference's
-isConverged, minus the data shuffle BPR never looks at).  Inputs are resident in HBM
-before the timed region.
+One EPOCH = one full pass of the reference's BPR epoch (model/ranking/BPR.py:29-43) over the synthetic
+Yelp2018-shape interaction matrix (31,668 x 38,048, ~1.25 M train triplets, d=64): negative sampling for every
+triplet (device Philox sampler) -> fused gather / dot / sigmoid / SGD scatter kernel (throughput mode) -> epoch-end
+regulariser reductions -> loss, convergence test and bold-driver learning-rate update (the reference's isConverged)
+on the device.  Inputs are resident in HBM before the timed region; the host only enqueues.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+One STEP = `epochs_per_step` consecutive epochs: an epoch is 0.6 ms, so K = 20 single epochs would be a 12 ms sample;
+the bench repeats epochs inside a step until the K timed steps cover >= --min-seconds (0.3 s).  `value` does not
+depend on that grouping (triplets / second); `ms_per_step` is per step, `config.ms_per_epoch` per epoch.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1 (weak scaling): every rank owns its own population of 31,668 users (its rows of P
-and its 1.25 M triplets per step); the item table Q is replicated and re-synchronised
-every step by one all-reduce of the per-rank Q deltas over RCCL/xGMI.  `value` counts
-the triplets of all ranks over the max-over-ranks time.
+N > 1, one process per GPU (qrec_amd/dist.py; collectives are RCCL bound directly by libqrec_hip.so, torch.distributed
+/gloo is only the control plane).  Users (rows of P, triplets, sampler) are sharded by rank.  --dist-mode replicated
+(default): item table replicated, ONE fused all-reduce of the per-rank deltas + loss terms per epoch.  --dist-mode
+sharded: item table row-sharded, per batch an all-to-all of the distinct rows a rank's triplets touch and of their
+updates.  --scaling weak (default): every rank its own 31,668 users; strong: the same 31,668 users split over ranks.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     -- the SGD kernel's algorithmic bytes/launch over its mean launch time
-                  (HIP events on the launch stream) against 8 TB/s HBM peak;
-  cpu_baseline -- the CPU port of the same epoch (oracle/, plain C, fp64, 1 thread) timed
-                  on this box's host cores on a bounded sample.
+  roofline     -- the SGD kernel's algorithmic bytes/launch over its mean launch time (HIP events on the launch
+                  stream) against 8 TB/s HBM peak;  roofline_hbm_resident -- the same kernel on an HBM-sized problem
+                  (a single-GPU slice of BASELINE config #4: 1.25 M x 1 M, d=128, 1.15 GB of tables);
+  exact_mode   -- the order-exact mode (the one that meets the bit-exact-stream / 1e-5 numeric contract) timed on
+                  the same workload;
+  cpu_baseline -- the CPU port of the same epoch (oracle/, plain C, fp64, 1 thread) timed on this box's host cores
+                  on a bounded sample, next to the Python reference's own figure (another host).
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -37,16 +44,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from qrec_amd import capi  # noqa: E402
-from qrec_amd.capi import DeviceBuffer  # noqa: E402
-from qrec_amd.engine import BprSgd, DeviceTables, balanced_chunk  # noqa: E402
-from qrec_amd.interactions import CSR  # noqa: E402
-from qrec_amd.synth import make_dataset, to_csr  # noqa: E402
-
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 DIM = 64
 LR0, MAX_LR, REG_U, REG_I = 0.01, 1.0, 0.001, 0.001   # config/BPR.conf:9-10
 FLUSH_EVERY = 16
+SEED = 2018
 
 
 def bytes_per_triplet(d: int) -> int:
@@ -65,6 +67,7 @@ def recall_at_n(ids: np.ndarray, users: np.ndarray, test_u: np.ndarray, test_i: 
 
 def evaluate_recall(P, Q, data, indptr, items, N=20):
     """Recall@N of (P, Q) on the held-out edges through the product's device ranker."""
+    from qrec_amd.interactions import CSR
     from qrec_amd.ranking import DeviceRanker
     users = np.unique(data["test_u"]).astype(np.int32)
     ids, _ = DeviceRanker(np.ascontiguousarray(P, dtype=np.float32), np.ascontiguousarray(Q, dtype=np.float32),
@@ -89,12 +92,13 @@ def cpu_baseline(u, i, indptr, n_items, U, seconds=12.0):
             break
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "triplet-updates/s", "cores": 1, "kind": "port",
-            "sample": f"{epochs} full epochs ({done} triplets, {dt:.1f} s) of the same Yelp2018-shape workload; "
-                      "plain-C fp64 port of model/ranking/BPR.py:29-53 incl. the CPython-stream sampler "
-                      "(the Python reference itself cannot travel to this box; it measured 58.9k/s on 1 core, BASELINE.md)"}
+            "sample": f"{epochs} epochs ({done} triplets, {dt:.1f} s), C fp64 port of BPR.py:29-53 + CPython-stream sampler",
+            "reference_python": {"value": 58930.0, "unit": "triplet-updates/s", "cores": 1,
+                                 "host": "survey container (8 vCPU Xeon 2.1 GHz KVM), not this box: the Python reference cannot travel",
+                                 "source": "BASELINE.md s2: unmodified BPR.trainModel, same shape, fp64"}}
 
 
-def cpu_exact_order_reference(sgd, u, i, n_items, P0, Q0, epochs, seed):
+def cpu_exact_order_reference(sgd, u, i, P0, Q0, epochs, seed):
     """Recall@20 reference: order-exact fp64 training on the host for the same number of epochs, from
     the same initial tables, with the reference's bold-driver schedule and -- paired design -- the very
     negatives the GPU run used (the device Philox stream for (seed, epoch) is re-generated and read back)."""
@@ -111,17 +115,83 @@ def cpu_exact_order_reference(sgd, u, i, n_items, P0, Q0, epochs, seed):
     return P, Q, last
 
 
+def recall_check(capi, sgd, tables, data, u, items, indptr, P0, Q0, chunk, flush_every, variant, epochs=25):
+    """The metric's second half: a fresh `epochs`-epoch throughput-mode run vs the order-exact CPU port on the same
+    negatives, same initial tables and schedule; both ranked by the device ranker."""
+    tables.upload(P0, Q0)
+    sgd.start_device_driver(LR0, log_capacity=epochs)
+    for k in range(epochs):
+        sgd.sample_negatives_device(SEED, k)
+        sgd.epoch_device_async(REG_U, REG_I, MAX_LR, tol=0.0, chunk=chunk, variant=variant, flush_every=flush_every)
+    capi.device_sync()
+    loss_g = float(sgd.driver_log()[-1, 0])
+    Pg, Qg = tables.download(np.float32)
+    Pc, Qc, loss_c = cpu_exact_order_reference(sgd, u, items, P0, Q0, epochs, SEED)
+    r_gpu = evaluate_recall(Pg, Qg, data, indptr, items)
+    r_cpu = evaluate_recall(Pc, Qc, data, indptr, items)
+    return {"gpu_throughput_mode": r_gpu, "cpu_port_exact_order": r_cpu, "abs_diff": abs(r_gpu - r_cpu), "epochs": epochs,
+            "final_loss_gpu": loss_g, "final_loss_cpu": loss_c}
+
+
+def exact_mode_rate(capi, u, items, indptr, n_items, P0, Q0):
+    """The order-exact mode on the same workload: CPython-stream negatives from the native host replay, triplets
+    applied strictly in the reference's order on the device (fp64 tables, the drop-in classes' default)."""
+    import random
+    from qrec_amd.engine import BprSgd, DeviceTables
+    words = capi.state_from_python(random.Random(1).getstate())
+    t0 = time.perf_counter()
+    j = capi.mt_bpr_sample_epoch(words, indptr, items, n_items)
+    t_sample = time.perf_counter() - t0
+    t = DeviceTables(P0.astype(np.float64), Q0.astype(np.float64), np.float64)
+    s = BprSgd(t, u, items); s.set_negatives(j)
+    capi.device_sync()
+    t0 = time.perf_counter()
+    s.epoch_ordered(LR0, REG_U, REG_I)            # synchronous: reads the loss back
+    dt = time.perf_counter() - t0
+    return {"value": u.size / dt, "unit": "triplet-updates/s", "dtype": "f64", "epoch_s": dt, "host_sampler_s": t_sample,
+            "parity": "index stream bit-exact vs the recorded reference run; P, Q 1e-10, loss 1e-11 (tests/test_gpu_bpr.py)"}
+
+
+def hbm_resident_roofline(capi, schedule="user"):
+    """BASELINE config #4, single-GPU slice (U=1.25 M, I=1 M, d=128, 25 M triplets, uniform items): 1.15 GB of tables,
+    far beyond the 256 MiB Infinity Cache, so the gather+SGD kernel's traffic is real HBM traffic."""
+    from qrec_amd.engine import BprSgd, DeviceTables
+    rng = np.random.default_rng(0)
+    U2, I2, n2, d2 = 1_250_000, 1_000_000, 25_000_000, 128
+    u2 = np.sort(rng.integers(0, U2, n2, dtype=np.int32)); i2 = rng.integers(0, I2, n2, dtype=np.int32)
+    blk = (rng.random((50_000, d2)) / 3).astype(np.float32)
+    P2 = np.empty((U2, d2), np.float32); Q2 = np.empty((I2, d2), np.float32)
+    for a in (P2, Q2):
+        for k in range(0, a.shape[0], 50_000):
+            a[k:k + 50_000] = blk[:min(50_000, a.shape[0] - k)]
+    t = DeviceTables(P2, Q2, np.float32); s = BprSgd(t, u2, i2, None, schedule=schedule)
+    s.set_negatives(rng.integers(0, I2, n2, dtype=np.int32))
+    e0, e1 = capi.Event(), capi.Event(); ts = []
+    for _ in range(5):
+        e0.record(); s.epoch_throughput_async(LR0, REG_U, REG_I); e1.record(); e1.sync(); ts.append(e1.elapsed_ms_since(e0))
+    ms = float(np.median(ts[1:])); alg = n2 * bytes_per_triplet(d2)
+    return {"workload": f"BPR d={d2}, {U2}x{I2}, {n2} triplets/epoch, {schedule}-major (config #4 single-GPU slice, tables 1.15 GB)",
+            "bound": "hbm", "achieved": alg / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / ms / 1e6 / HBM_PEAK_GBPS,
+            "avg_launch_ms": ms, "algorithmic_bytes_per_launch": alg, "triplet_updates_per_s": n2 / ms * 1e3}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--shape", default="yelp2018")
+    ap.add_argument("--min-seconds", type=float, default=0.3, help="epochs are repeated inside a step until the timed region lasts this long")
+    ap.add_argument("--epochs-per-step", type=int, default=0, help="fix the inner repeat instead of calibrating it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", type=int, default=capi.HW_DEFAULT)
+    ap.add_argument("--no-extras", action="store_true", help="skip exact_mode / roofline_hbm_resident / recall_at_20")
+    ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--flush-every", type=int, default=0, help="item-major schedule: triplets between flushes of the register-resident Q[i] (0 = default)")
     ap.add_argument("--schedule", choices=("item", "user"), default="item",
                     help="visiting order of the epoch's triplets in the Hogwild kernel (DESIGN.md s4)")
+    ap.add_argument("--dist-mode", choices=("replicated", "sharded"), default=os.environ.get("QREC_DIST_MODE", "replicated"))
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--shard-batch", type=int, default=1 << 18, help="sharded mode: triplets per exchange batch and rank")
     args = ap.parse_args()
 
     # stdout carries ONE line, the result.  Libraries print there too -- RCCL writes its version banner to C stdio's
@@ -134,153 +204,188 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    dist = torch = None
-    # QREC_FORCE_DIST=1 drives the torch.distributed/RCCL branch with world size 1 (the gpurun
-    # boxes have one GPU): same code path as N>1, the all-reduce degenerates to a copy.
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # QREC_FORCE_DIST=1 drives the multi-GPU branch with world size 1 (the gpurun boxes have one GPU): same code path
+    # as N > 1 -- delta / apply kernels, the real RCCL communicator -- the collectives degenerate to copies.
     use_dist = world > 1 or os.environ.get("QREC_FORCE_DIST") == "1"
-    # Test hook for the 1-GPU development boxes: QREC_DIST_TEST_ONE_DEVICE=1 puts every rank on device 0 and uses the
-    # gloo backend (RCCL refuses two ranks on one device), so that the N > 1 code path -- user sharding, delta
-    # all-reduce, summed loss terms, per-rank device-side driver -- runs end to end on real hardware.  Numbers from
-    # such a run are NOT bench results (the ranks share one GPU); the output line says so.
+    # Test hook for the 1-GPU development boxes: QREC_DIST_TEST_ONE_DEVICE=1 puts every rank on device 0 with the staged
+    # gloo transport (RCCL refuses two ranks on one device).  Not a bench result; the output line says so.
     one_device = os.environ.get("QREC_DIST_TEST_ONE_DEVICE") == "1"
     if one_device:
         local_rank = 0
+    control = comm = qd = None
     if use_dist:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29571")
-        torch.cuda.set_device(local_rank)
-        if one_device:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        import torch  # noqa: F401  -- BEFORE libqrec_hip.so is loaded: the process then runs on ONE HIP runtime (comm.cpp)
+        from qrec_amd import dist as qd
+        control = qd.ControlPlane.from_env()
+    from qrec_amd import capi
+    from qrec_amd.engine import BprSgd, DeviceTables, balanced_chunk
+    from qrec_amd.interactions import CSR
+    from qrec_amd.synth import make_dataset, to_csr
     capi.init(local_rank)
+    if use_dist:
+        comm = qd.make_comm(control)
 
     # ---- workload: resident in HBM before timing ------------------------------------------
     data = make_dataset(args.shape)
     U, I = data["n_users"], data["n_items"]
     indptr, items = to_csr(U, data["train_u"], data["train_i"])
     u = np.repeat(np.arange(U, dtype=np.int32), np.diff(indptr)).astype(np.int32)
-    n = int(items.size)
-    rng = np.random.default_rng(1000 + rank)
-    P0 = (rng.random((U, DIM)) / 3).astype(np.float32)          # rand/3, iterativeRecommender.py:37-38
-    Q0 = (np.random.default_rng(999).random((I, DIM)) / 3).astype(np.float32)  # same on all ranks
-    tables = DeviceTables(P0, Q0, np.float32)
-    sgd = BprSgd(tables, u, items, CSR(indptr, items), schedule=args.schedule)
-    total = args.warmup + args.steps
+    n_full = int(items.size)
+    Q0 = (np.random.default_rng(999).random((I, DIM)) / 3).astype(np.float32)    # same on all ranks
+    strong = args.scaling == "strong" and world > 1
+    if strong:     # the SAME users split over the ranks: rank r trains the r-th contiguous block (qrec_amd/dist.py)
+        lo, hi, l_indptr, l_items = qd.shard_positive_csr(indptr, items, world, rank)
+        l_u = np.repeat(np.arange(hi - lo, dtype=np.int32), np.diff(l_indptr)).astype(np.int32)
+        P0 = (np.random.default_rng(1000).random((U, DIM)) / 3).astype(np.float32)[lo:hi]
+    else:          # weak: every rank its own population of U users with the same interaction structure
+        l_indptr, l_items, l_u = indptr, items, u
+        P0 = (np.random.default_rng(1000 + rank).random((U, DIM)) / 3).astype(np.float32)   # rand/3, iterativeRecommender.py:37-38
+    n = int(l_items.size)
+    sharded = use_dist and args.dist_mode == "sharded"
+    tables = DeviceTables(P0, qd.shard_item_rows(Q0, world, rank) if sharded else Q0, np.float32)
+    sgd = BprSgd(tables, l_u, l_items, CSR(l_indptr, l_items), schedule=args.schedule, n_items=I)
     flush_every = args.flush_every or FLUSH_EVERY
     CHUNK = balanced_chunk(n)     # triplets per work item: the count that spreads evenly over the 4,096 persistent groups
-    ev = [(capi.Event(), capi.Event()) for _ in range(total)]
+    sampler_seed = SEED + 7919 * rank
 
-    q_sync = stats_view = None
-    if use_dist:   # replicated item table, reconciled once per step (qrec_amd/dist.py)
-        from qrec_amd.dist import ReplicatedTableSync
-        q_sync = ReplicatedTableSync(torch.as_tensor(tables.Q, device=torch.device("cuda", local_rank)))
-        stats_view = torch.as_tensor(sgd.d_stats, device=torch.device("cuda", local_rank))   # [nll, sum P^2, sum Q^2] f64
+    dstep = None
+    if use_dist and sharded:
+        n_batches = qd.agree_on_batches(control, n, args.shard_batch)
+        dstep = qd.ShardedStep(comm, qd.ShardedItemExchange(comm, I, tables.ld, tables.Q), n_batches)
+    elif use_dist:
+        dstep = qd.ReplicatedStep(comm, qd.ReplicatedTableSync(comm, tables.Q))
 
-    state = {"lr": LR0, "last": 0.0, "loss": 0.0}
+    ev, pool = [], []
+    counter = {"epoch": 0}
 
-    def between(stage: str):
-        """N > 1, enqueue only: after the SGD kernel the ranks' Q deltas are summed (the path's one collective, RCCL
-        all-reduce), after the local loss sums sum(-log sigma) and sum P*P are added over ranks (Q is replicated), so
-        every rank's device-side driver takes the same decision."""
-        if stage == "tables":
-            q_sync.sync()
-        else:
-            dist.all_reduce(stats_view[0:2])
-
-    def step(k: int):
-        """sampler (side stream) | SGD kernel -> [N > 1: delta all-reduce] -> epoch close (BPR.py:40 loss terms,
-        isConverged, updateLearningRate) all on the device; the host only enqueues.  tol = 0: the K timed steps all run."""
-        sgd.take_prefetched_negatives(k)                            # BPR.py:35-37 (sampled under step k-1)
+    def epoch():
+        """sampler (side stream) | SGD kernel -> [N > 1: collectives] -> epoch close (BPR.py:40 loss terms, isConverged,
+        updateLearningRate) all on the device; the host only enqueues (sharded mode: plus ONE read-back of the exchange's
+        row counts per epoch).  tol = 0: every epoch runs."""
+        k = counter["epoch"]; counter["epoch"] += 1
+        pair = pool.pop() if pool else (capi.Event(), capi.Event())
+        ev.append(pair)
+        sgd.take_prefetched_negatives(k)                            # BPR.py:35-37 (sampled under epoch k-1)
+        if sharded:
+            dstep.prepare(sgd)
         sgd.epoch_device_async(REG_U, REG_I, MAX_LR, tol=0.0, chunk=CHUNK, variant=args.variant,
-                               flush_every=flush_every, events=ev[k],   # BPR.py:45-53,40 + iterativeRecommender.py:88-104
-                               between=between if use_dist else None)
-        sgd.prefetch_negatives_device(2018, k + 1)                  # side stream, under the SGD kernel
-
-    sgd.start_device_driver(LR0, log_capacity=total)
+                               flush_every=flush_every, events=pair, dist=dstep)   # BPR.py:45-53,40 + iterativeRecommender.py:88-104
+        sgd.prefetch_negatives_device(sampler_seed, k + 1)          # side stream, under the SGD kernel
 
     def sync_all():
         if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
+            control.barrier()
         capi.device_sync()
+        if use_dist and world > 1 and not one_device:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        if use_dist:
+            control.barrier()
 
-    sgd.prefetch_negatives_device(2018, 0)
-    for k in range(args.warmup):
-        step(k)
-    sync_all()
+    # calibration: how many epochs make a step, so that K steps last >= --min-seconds (same on every rank)
+    cal = 5
+    inner_max = 400
+    log_cap = cal + (args.warmup + args.steps) * (args.epochs_per_step or inner_max)
+    sgd.start_device_driver(LR0, log_capacity=log_cap)
+    sgd.prefetch_negatives_device(sampler_seed, 0)
+    epoch(); epoch(); sync_all()
     t0 = time.perf_counter()
-    for k in range(args.warmup, total):
-        step(k)
+    for _ in range(cal - 2):
+        epoch()
+    sync_all()
+    t_epoch = (time.perf_counter() - t0) / (cal - 2)
+    if args.epochs_per_step:
+        inner = args.epochs_per_step
+    else:
+        inner = min(inner_max, max(1, math.ceil(args.min_seconds / (args.steps * t_epoch))))
+        if use_dist:
+            inner = int(control.allreduce_host(np.array([inner], dtype=np.int64), op="max")[0])
+
+    pool.extend((capi.Event(), capi.Event()) for _ in range((args.warmup + args.steps) * inner))   # not inside the timed loop
+    for _ in range(args.warmup * inner):
+        epoch()
+    sync_all()
+    first_timed = counter["epoch"]
+    t0 = time.perf_counter()
+    for _ in range(args.steps * inner):
+        epoch()
     sync_all()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = float(control.allreduce_host(np.array([elapsed]), op="max")[0])
+    total = counter["epoch"]
 
     drv = sgd.driver_state()
     if drv["failed"]:
         raise SystemExit("Loss = NaN or Infinity")            # iterativeRecommender.py:84-86
     assert drv["epochs"] == total and not drv["converged"], drv
     log = sgd.driver_log()
-    state["loss"], state["lr"] = float(log[-1, 0]), drv["lr"]
-    if os.environ.get("QREC_DIST_TEST_DUMP"):     # functional tests: every rank leaves its replica and its driver log behind
+    final_loss, final_lr = float(log[-1, 0]), drv["lr"]
+    if os.environ.get("QREC_DIST_TEST_DUMP"):     # functional tests: every rank leaves its tables and its driver log behind
         np.savez(os.path.join(os.environ["QREC_DIST_TEST_DUMP"], f"rank{rank}.npz"), Q=tables.Q.numpy(), P=tables.P.numpy(),
-                 log=log, lr=drv["lr"])
-    kernel_ms = [ev[k][1].elapsed_ms_since(ev[k][0]) for k in range(args.warmup, total)]
+                 log=log, lr=drv["lr"], epochs_per_step=inner)
+    kernel_ms = [ev[k][1].elapsed_ms_since(ev[k][0]) for k in range(first_timed, total)]
     avg_kernel_ms = float(np.mean(kernel_ms))
     alg_bytes = n * bytes_per_triplet(DIM)
+    moved = None
+    if sharded:
+        moved = float(control.allreduce_host(np.array([dstep.exchange.bytes_moved / max(total, 1)]))[0])
 
     if rank == 0:
-        value = world * n * args.steps / elapsed
+        n_job = n_full if strong else world * n
+        value = n_job * args.steps * inner / elapsed
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and not sharded:
             tj = json.load(open(tfile))
             if tj.get("workload") == f"bpr-{args.shape}-d{DIM}-{args.schedule}":
                 traffic = tj.get("bytes_per_launch")
+        kernel = "bpr_hogwild_item_kernel<16,4>" if args.schedule == "item" else "bpr_hogwild_kernel<16,4,plain-load,atomic>"
+        if world == 1:
+            par = "1 GPU" + (f" (QREC_FORCE_DIST: {args.dist_mode} multi-GPU path at world 1)" if use_dist else "")
+        elif sharded:
+            par = f"users x{world}, item table row-sharded x{world}: per-batch RCCL all-to-all of distinct rows + their updates"
+        else:
+            par = f"users x{world}, item table replicated: one fused RCCL all-reduce of deltas + loss terms per epoch"
         out = {
             **({"INVALID_AS_BENCH": "QREC_DIST_TEST_ONE_DEVICE: all ranks shared one GPU over gloo (functional test only)"} if one_device else {}),
             "metric": "BPR triplet-updates/sec", "value": value, "unit": "triplet-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BPR d={DIM} on synthetic Yelp2018-shape ({U}x{I}, {n} train triplets/epoch), "
-                                   f"throughput mode (device Philox sampler + Hogwild atomic-delta SGD, {args.schedule}-major schedule)",
-                       "triplets_per_step_per_gpu": n, "chunk": CHUNK,
-                       "parallelism": "1 GPU" if world == 1 else f"user-sharded x{world}, replicated item table, per-step delta all-reduce (RCCL)",
-                       "lr": LR0, "reg": REG_U, "final_loss": state["loss"], "final_lr": state["lr"],
-                       "epoch_close": "device (no host sync inside the timed region)"},
-            "roofline": {"bound": "hbm", "kernel": "bpr_hogwild_item_kernel<16,4>" if args.schedule == "item" else "bpr_hogwild_kernel<16,4,plain-load,atomic>",
+            "config": {"workload": f"BPR d={DIM} Yelp2018-shape {U}x{I}" if args.shape == "yelp2018" else f"BPR d={DIM} {args.shape} {U}x{I}",
+                       "mode": f"throughput: device Philox sampler + Hogwild atomic-delta SGD, {args.schedule}-major",
+                       "triplets_per_epoch_per_gpu": n, "epochs_per_step": inner, "ms_per_epoch": elapsed / (args.steps * inner) * 1e3,
+                       "timed_seconds": elapsed, "chunk": CHUNK, "parallelism": par,
+                       "lr": LR0, "reg": REG_U, "final_loss": final_loss, "final_lr": final_lr,
+                       "epoch_close": "device (no host sync inside the timed region)" if not sharded else "device; one row-count read-back per epoch for the exchange",
+                       **({"xgmi_bytes_per_epoch_all_ranks": moved, "batches_per_epoch": dstep.n_batches} if sharded else {})},
+            "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_kernel_ms,
-                         "note": "tables (17.8 MB) are L2/Infinity-Cache resident at this shape; the binding "
-                                 "resource is the L2 atomic units (~1 dword/clk/channel), see DESIGN.md"},
+                         "note": ("events bracket the epoch's batches incl. their exchanges" if sharded else
+                                  "tables (17.8 MB) are cache resident at this shape; bound = L2 atomic units, see DESIGN.md")},
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(u, items, indptr, I, U)
-            out["vs_cpu_port"] = value / out["cpu_baseline"]["value"]
-            # Recall@20 (the metric's second half): GPU throughput mode vs the order-exact CPU port on the
-            # same negatives, same initial tables, same epochs and schedule; both ranked by the device ranker.
-            Pg, Qg = tables.download(np.float32)
-            Pc, Qc, loss_c = cpu_exact_order_reference(sgd, u, items, I, P0, Q0, total, 2018)
-            r_gpu = evaluate_recall(Pg, Qg, data, indptr, items)
-            r_cpu = evaluate_recall(Pc, Qc, data, indptr, items)
-            out["recall_at_20"] = {"gpu_throughput_mode": r_gpu, "cpu_port_exact_order": r_cpu,
-                                   "abs_diff": abs(r_gpu - r_cpu), "epochs": total,
-                                   "final_loss_gpu": state["loss"], "final_loss_cpu": loss_c}
+        if world == 1 and not use_dist:
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(u, items, indptr, I, U)
+                out["vs_cpu_port"] = value / out["cpu_baseline"]["value"]
+            if not args.no_extras:
+                out["recall_at_20"] = recall_check(capi, sgd, tables, data, u, items, indptr, P0, Q0, CHUNK, flush_every, args.variant)
+                out["exact_mode"] = exact_mode_rate(capi, u, items, indptr, I, P0, Q0)
+                del sgd, tables
+                out["roofline_hbm_resident"] = hbm_resident_roofline(capi)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        control.barrier()
+        if comm is not None:
+            comm.destroy()
+        control.shutdown()
 
 
 if __name__ == "__main__":

@@ -38,6 +38,7 @@ extern "C" {
 
 #define QREC_F32 0
 #define QREC_F64 1
+#define QREC_I32 2      /* collectives only */
 
 /* ---- runtime ------------------------------------------------------------------------ */
 int qrec_version(void);
@@ -175,6 +176,9 @@ int qrec_epoch_sums(const void *d_P, int64_t p_rows, const void *d_Q, int64_t q_
                     double *d_stats, const double *d_state, void *stream);
 int qrec_epoch_decide(double *d_stats, double *d_state, double regU, double regI, double max_lr, double tol,
                       double *d_log, int64_t log_capacity, void *stream);
+/* one table's (deterministic) sum of squares into d_stats[slot], slot 1 = sum P*P, 2 = sum Q*Q; the other slot is left alone */
+int qrec_epoch_sum_table(const void *d_X, int64_t rows, int dtype, int32_t ld, double *d_stats, int slot,
+                         const double *d_state, void *stream);
 
 /* Rating-prediction MF family, order-exact: variant 0 = model/rating/BasicMF.py:9-26 (config #1),
  * 1 = model/rating/PMF.py:9-28 (regU, regI), 2 = model/rating/SVD.py:13-35 (biases d_Bu/d_Bi of the
@@ -429,6 +433,59 @@ int qrec_random_permutations(int64_t n, int32_t count, uint64_t seed, uint64_t s
                              int32_t *d_invs, void *stream);
 int qrec_small_permutations(int32_t n, int32_t count, uint64_t seed, uint64_t stream_id, int32_t *d_perms, int32_t *d_invs,
                             void *stream);
+
+/* ---- multi-GPU: collectives and the kernels around them ------------------------------------- *
+ * The reference has no distributed code (its only parallelism is one process per CV fold, QRec.py:57-89); the
+ * contract is BASELINE.json's north star: one process per GPU, embedding tables row-sharded, RCCL over xGMI.  librccl
+ * is bound directly (dlopen'ed on first use from the directory of the HIP runtime this library runs on; QREC_RCCL_LIB
+ * overrides) -- no torch tensor or torch kernel is involved.  Every collective only ENQUEUES on `stream`.
+ *   qrec_comm_unique_id : rank 0 makes the 128-byte id, the launcher's control plane hands it to every rank;
+ *   qrec_comm_init      : collective over all ranks, binds the device selected by qrec_init;
+ *   qrec_allreduce      : in-place sum (QREC_F32 / QREC_F64 / QREC_I32);  _pair: two buffers, ONE fused launch (the
+ *                         item-table deltas + the epoch's loss terms);
+ *   qrec_allgather / qrec_reduce_scatter : `count` elements per rank (graph models: operand rows of a row-partitioned
+ *                         propagation and the transposed product of its backward pass);
+ *   qrec_alltoall_rows  : segment p of d_send (h_send_rows[p] rows of row_bytes, segments back to back in rank order)
+ *                         goes to rank p, segment p of d_recv comes from rank p -- cross-shard row lookups and the
+ *                         return of their updates.  Counts are HOST arrays of `world` entries.                       */
+#define QREC_COMM_UID_BYTES 128
+int qrec_comm_library(char *path_out, int path_len, int *version);
+int qrec_comm_unique_id(uint8_t *h_uid);
+int qrec_comm_init(int32_t world, int32_t rank, const uint8_t *h_uid, void **comm);
+int qrec_comm_destroy(void *comm);
+int qrec_comm_info(void *comm, int32_t *world, int32_t *rank);
+int qrec_allreduce(void *comm, void *d_buf, int64_t count, int dtype, void *stream);
+int qrec_allreduce_pair(void *comm, void *d_a, int64_t count_a, int dtype_a, void *d_b, int64_t count_b, int dtype_b,
+                        void *stream);
+int qrec_allgather(void *comm, const void *d_send, void *d_recv, int64_t count, int dtype, void *stream);
+int qrec_reduce_scatter(void *comm, const void *d_send, void *d_recv, int64_t count, int dtype, void *stream);
+int qrec_alltoall_rows(void *comm, const void *d_send, const int64_t *h_send_rows, void *d_recv,
+                       const int64_t *h_recv_rows, int64_t row_bytes, void *stream);
+
+/* Replicated item table (every rank trains its own users against a full copy of Q): after a step
+ *     delta = Q - Q_start;  all-reduce(delta);  Q_start += delta;  Q = Q_start
+ * so that every rank's updates are kept and the replicas stay bit-identical.  n = rows*ld floats (multiple of 4).     */
+int qrec_table_delta(const float *d_table, const float *d_start, float *d_delta, int64_t n, void *stream);
+int qrec_table_apply(float *d_table, float *d_start, const float *d_delta, int64_t n, void *stream);
+
+/* Row-sharded item table: item id = r*world + o is local row r of rank o (interleaved, so that popular items spread
+ * over the ranks).  qrec_shard_rows = rows a rank holds.
+ * qrec_shard_plan_batch, for n triplets with global item ids d_i / d_j:
+ *   d_req_rows : the DISTINCT items the batch touches as local rows at their owner, grouped by owner in rank order and
+ *                ascending inside a group (capacity min(2n, n_items));  d_counts[world] = rows per owner;
+ *   d_ci, d_cj : the triplets' item ids rewritten as positions in d_req_rows, i.e. rows of the batch's row cache.
+ * Everything stays on the device; the caller reads d_counts back when it needs the sizes of the exchange.
+ * qrec_gather_rows: d_out[k] = d_table[d_rows[k]] (an owner answering a request).
+ * qrec_scatter_add_row_deltas: d_table[d_rows[k]] += d_fresh[k] - d_sent[k] with f32 atomics (an owner taking back the
+ *   rows it lent: several ranks may return the same row, every rank's updates are kept).                             */
+int qrec_shard_rows(int64_t n_items, int32_t world, int32_t rank, int64_t *rows);
+int qrec_shard_plan_scratch_bytes(int64_t n_items, int32_t world, int64_t *bytes);
+int qrec_shard_plan_batch(const int32_t *d_i, const int32_t *d_j, int64_t n, int64_t n_items, int32_t world,
+                          void *d_scratch, int32_t *d_req_rows, int32_t *d_counts, int32_t *d_ci, int32_t *d_cj,
+                          void *stream);
+int qrec_gather_rows(const float *d_table, int32_t ld, const int32_t *d_rows, int64_t n, float *d_out, void *stream);
+int qrec_scatter_add_row_deltas(float *d_table, int32_t ld, const int32_t *d_rows, int64_t n, const float *d_fresh,
+                                const float *d_sent, void *stream);
 
 #ifdef __cplusplus
 }

@@ -75,19 +75,29 @@ class QRec:
         if k < 2 or k > 10:
             print("k for cross-validation should not be greater than 10 or less than 2")
             sys.exit(-1)
-        results = Manager().dict()
         binarized = ev.contains("-b")
-        tasks = []
-        for order, (train, test) in enumerate(DataSplit.crossValidation(self.trainingData, k, binarized=binarized), 1):
-            fold = "[" + str(order) + "]"
-            model = cls(self.config, train, test, self.relation, fold) if social else cls(self.config, train, test, fold)   # built in the parent, run in the child
-            tasks.append(Process(target=_run_fold, args=(results, model, order, ev.contains("-p"))))
-        for p in tasks:
-            p.start()
-            if not ev.contains("-p"):
+        folds = enumerate(DataSplit.crossValidation(self.trainingData, k, binarized=binarized), 1)
+        build = lambda train, test, fold: (cls(self.config, train, test, self.relation, fold) if social
+                                           else cls(self.config, train, test, fold))
+        from .dist import BatchParallel
+        if BatchParallel.from_env() is not None:
+            # one process per GPU (torch.distributed.run): this process already holds a device context and an RCCL
+            # communicator, neither of which survives a fork, and every rank must issue the same collectives in the
+            # same order -- so the folds run one after another IN this process, each of them data-parallel over the
+            # ranks (``-p`` has nothing left to spread: all GPUs work on the current fold).
+            results = {order: build(train, test, "[" + str(order) + "]").execute() for order, (train, test) in folds}
+        else:
+            results = Manager().dict()
+            tasks = []
+            for order, (train, test) in folds:
+                model = build(train, test, "[" + str(order) + "]")     # built in the parent, run in the child
+                tasks.append(Process(target=_run_fold, args=(results, model, order, ev.contains("-p"))))
+            for p in tasks:
+                p.start()
+                if not ev.contains("-p"):
+                    p.join()
+            for p in tasks:
                 p.join()
-        for p in tasks:
-            p.join()
         self.measure = [dict(results)[f] for f in range(1, k + 1)]
         res = []
         for pos, line in enumerate(self.measure[0]):

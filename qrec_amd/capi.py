@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libqrec_hip.so")
 
-F32, F64 = 0, 1
+F32, F64, I32 = 0, 1, 2
 HW_DEFAULT, HW_PLAIN_RMW, HW_SC1_RMW, HW_ATOMIC, HW_SC1_ATOMIC = 0, 1, 2, 3, 4
 
 _vp, _i32, _i64, _u64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
@@ -55,6 +55,7 @@ _SIGNATURES = {
     "qrec_epoch_close": [_vp, _i64, _vp, _i64, C.c_int, _i32, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
     "qrec_epoch_sums": [_vp, _i64, _vp, _i64, C.c_int, _i32, _vp, _vp, _vp],
     "qrec_epoch_decide": [_vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
+    "qrec_epoch_sum_table": [_vp, _i64, C.c_int, _i32, _vp, C.c_int, _vp, _vp],
     "qrec_mf_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _vp, C.c_int, _f64, _f64, _vp, _vp, _f64, _f64, _vp],
     "qrec_svdpp_sgd_ordered": [_vp, _vp, _vp, _vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64,
                                _f64, _f64, _f64, _vp, _vp],
@@ -100,6 +101,23 @@ _SIGNATURES = {
     "qrec_ratings_copy": [_vp, _vp, _vp, _vp],
     "qrec_ratings_names": [_vp, _i32, _vp],
     "qrec_ratings_free": [_vp],
+    "qrec_comm_library": [_vp, C.c_int, _vp],
+    "qrec_comm_unique_id": [_vp],
+    "qrec_comm_init": [_i32, _i32, _vp, _vp],
+    "qrec_comm_destroy": [_vp],
+    "qrec_comm_info": [_vp, _vp, _vp],
+    "qrec_allreduce": [_vp, _vp, _i64, C.c_int, _vp],
+    "qrec_allreduce_pair": [_vp, _vp, _i64, C.c_int, _vp, _i64, C.c_int, _vp],
+    "qrec_allgather": [_vp, _vp, _vp, _i64, C.c_int, _vp],
+    "qrec_reduce_scatter": [_vp, _vp, _vp, _i64, C.c_int, _vp],
+    "qrec_alltoall_rows": [_vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "qrec_table_delta": [_vp, _vp, _vp, _i64, _vp],
+    "qrec_table_apply": [_vp, _vp, _vp, _i64, _vp],
+    "qrec_shard_rows": [_i64, _i32, _i32, _vp],
+    "qrec_shard_plan_scratch_bytes": [_i64, _i32, _vp],
+    "qrec_shard_plan_batch": [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "qrec_gather_rows": [_vp, _i32, _vp, _i64, _vp, _vp],
+    "qrec_scatter_add_row_deltas": [_vp, _i32, _vp, _i64, _vp, _vp, _vp],
 }
 _RESTYPES = {"qrec_last_error": C.c_char_p, "qrec_ratings_rows": C.c_int64, "qrec_ratings_count": C.c_int32,
              "qrec_ratings_names_bytes": C.c_int64, "qrec_ratings_free": None}
@@ -489,8 +507,9 @@ def _table_rows(buf, ld: int) -> int:
 
 def bpr_sgd_hogwild(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int, chunk: int, grid_groups: int,
                     lr: float, regU: float, regI: float, d_loss, variant: int = HW_DEFAULT, stream=None,
-                    d_driver_state=None):
-    _check(load().qrec_bpr_sgd_hogwild(_dp(d_P), _dp(d_Q), _table_rows(d_P, ld), _table_rows(d_Q, ld), d, ld, _dp(d_u), _dp(d_i), _dp(d_j), n,
+                    d_driver_state=None, p_rows: int | None = None, q_rows: int | None = None):
+    """``p_rows`` / ``q_rows``: rows of the tables when they are not whole DeviceBuffers (a shard's row cache)"""
+    _check(load().qrec_bpr_sgd_hogwild(_dp(d_P), _dp(d_Q), p_rows or _table_rows(d_P, ld), q_rows or _table_rows(d_Q, ld), d, ld, _dp(d_u), _dp(d_i), _dp(d_j), n,
                                        chunk, grid_groups, lr, regU, regI, _dp(d_loss), variant,
                                        _dp(d_driver_state), _sh(stream)))
 
@@ -533,6 +552,19 @@ def score_topk(d_U, d_V, dtype: int, d: int, ld: int, n_items: int, d_user_ids, 
 
 def epoch_sums(d_P, p_rows: int, d_Q, q_rows: int, dtype: int, ld: int, d_stats, d_state=None, stream=None):
     _check(load().qrec_epoch_sums(_dp(d_P), p_rows, _dp(d_Q), q_rows, dtype, ld, _dp(d_stats), _dp(d_state), _sh(stream)))
+
+
+def epoch_sum_table(d_X, rows: int, dtype: int, ld: int, d_stats, slot: int, d_state=None, stream=None):
+    _check(load().qrec_epoch_sum_table(_dp(d_X), rows, dtype, ld, _dp(d_stats), slot, _dp(d_state), _sh(stream)))
+
+
+def memcpy_d2h(host: np.ndarray, src, nbytes: int, stream=None):
+    """device -> caller-owned host array (synchronous on ``stream``)"""
+    _check(load().qrec_memcpy_d2h(_hp(host), _dp(src), nbytes, _sh(stream)))
+
+
+def memcpy_h2d(dst, host: np.ndarray, nbytes: int, stream=None):
+    _check(load().qrec_memcpy_h2d(_dp(dst), _hp(host), nbytes, _sh(stream)))
 
 
 def epoch_decide(d_stats, d_state, regU: float, regI: float, max_lr: float, tol: float, d_log=None,
@@ -722,8 +754,8 @@ def copy_cols(d_dst, dst_ld: int, d_src, src_ld: int, src_col_off: int, n_rows: 
 
 def bpr_sgd_hogwild_item_major(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int, chunk: int, grid_groups: int,
                                flush_every: int, lr: float, regU: float, regI: float, d_loss, stream=None,
-                               d_driver_state=None):
-    _check(load().qrec_bpr_sgd_hogwild_item_major(_dp(d_P), _dp(d_Q), _table_rows(d_P, ld), _table_rows(d_Q, ld), d, ld, _dp(d_u), _dp(d_i), _dp(d_j), n, chunk,
+                               d_driver_state=None, p_rows: int | None = None, q_rows: int | None = None):
+    _check(load().qrec_bpr_sgd_hogwild_item_major(_dp(d_P), _dp(d_Q), p_rows or _table_rows(d_P, ld), q_rows or _table_rows(d_Q, ld), d, ld, _dp(d_u), _dp(d_i), _dp(d_j), n, chunk,
                                                   grid_groups, flush_every, lr, regU, regI, _dp(d_loss),
                                                   _dp(d_driver_state), _sh(stream)))
 
@@ -744,3 +776,95 @@ def mt_sample_range(state625: np.ndarray, n: int, k: int) -> np.ndarray:
     out = np.empty(k, dtype=np.int64)
     _check(load().qrec_mt_sample_range(_hp(state625), n, k, _hp(out)))
     return out
+
+
+# ---- multi-GPU: RCCL collectives and the kernels around them (include/qrec_hip.h, last section) -----------------
+COMM_UID_BYTES = 128
+
+
+def comm_library() -> tuple[str, int]:
+    """(path of the librccl this process bound, its version code); raises when RCCL cannot be loaded"""
+    path = C.create_string_buffer(1024); ver = C.c_int(0)
+    _check(load().qrec_comm_library(path, 1024, C.byref(ver)))
+    return path.value.decode(), ver.value
+
+
+def comm_unique_id() -> bytes:
+    uid = C.create_string_buffer(COMM_UID_BYTES)
+    _check(load().qrec_comm_unique_id(uid))
+    return uid.raw
+
+
+class Comm:
+    """One RCCL communicator (one process per GPU).  Every method only enqueues on ``stream``; buffers are DeviceBuffers
+    or raw device addresses.  Row counts of ``alltoall_rows`` are host sequences of ``world`` entries."""
+
+    def __init__(self, world: int, rank: int, uid: bytes):
+        ensure_init()
+        if len(uid) != COMM_UID_BYTES:
+            raise ValueError("comm uid must be 128 bytes")
+        h = C.c_void_p()
+        _check(load().qrec_comm_init(world, rank, C.create_string_buffer(uid, COMM_UID_BYTES), C.byref(h)))
+        self.handle, self.world, self.rank = h.value, world, rank
+
+    def allreduce(self, buf, count: int, dtype: int = F32, stream=None):
+        _check(load().qrec_allreduce(self.handle, _dp(buf), count, dtype, _sh(stream)))
+
+    def allreduce_pair(self, a, count_a: int, dtype_a: int, b, count_b: int, dtype_b: int, stream=None):
+        _check(load().qrec_allreduce_pair(self.handle, _dp(a), count_a, dtype_a, _dp(b), count_b, dtype_b, _sh(stream)))
+
+    def allgather(self, send, recv, count: int, dtype: int = F32, stream=None):
+        _check(load().qrec_allgather(self.handle, _dp(send), _dp(recv), count, dtype, _sh(stream)))
+
+    def reduce_scatter(self, send, recv, count: int, dtype: int = F32, stream=None):
+        _check(load().qrec_reduce_scatter(self.handle, _dp(send), _dp(recv), count, dtype, _sh(stream)))
+
+    def alltoall_rows(self, send, send_rows, recv, recv_rows, row_bytes: int, stream=None):
+        s = np.ascontiguousarray(send_rows, dtype=np.int64); r = np.ascontiguousarray(recv_rows, dtype=np.int64)
+        if s.size != self.world or r.size != self.world:
+            raise ValueError("alltoall_rows: one row count per rank expected")
+        _check(load().qrec_alltoall_rows(self.handle, _dp(send), _hp(s), _dp(recv), _hp(r), row_bytes, _sh(stream)))
+
+    def destroy(self):
+        if getattr(self, "handle", None):
+            load().qrec_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def table_delta(d_table, d_start, d_delta, n: int, stream=None):
+    _check(load().qrec_table_delta(_dp(d_table), _dp(d_start), _dp(d_delta), n, _sh(stream)))
+
+
+def table_apply(d_table, d_start, d_delta, n: int, stream=None):
+    _check(load().qrec_table_apply(_dp(d_table), _dp(d_start), _dp(d_delta), n, _sh(stream)))
+
+
+def shard_rows(n_items: int, world: int, rank: int) -> int:
+    out = C.c_int64(0)
+    _check(load().qrec_shard_rows(n_items, world, rank, C.byref(out)))
+    return out.value
+
+
+def shard_plan_scratch_bytes(n_items: int, world: int) -> int:
+    out = C.c_int64(0)
+    _check(load().qrec_shard_plan_scratch_bytes(n_items, world, C.byref(out)))
+    return out.value
+
+
+def shard_plan_batch(d_i, d_j, n: int, n_items: int, world: int, d_scratch, d_req_rows, d_counts, d_ci, d_cj, stream=None):
+    _check(load().qrec_shard_plan_batch(_dp(d_i), _dp(d_j), n, n_items, world, _dp(d_scratch), _dp(d_req_rows), _dp(d_counts),
+                                        _dp(d_ci), _dp(d_cj), _sh(stream)))
+
+
+def gather_rows(d_table, ld: int, d_rows, n: int, d_out, stream=None):
+    _check(load().qrec_gather_rows(_dp(d_table), ld, _dp(d_rows), n, _dp(d_out), _sh(stream)))
+
+
+def scatter_add_row_deltas(d_table, ld: int, d_rows, n: int, d_fresh, d_sent, stream=None):
+    _check(load().qrec_scatter_add_row_deltas(_dp(d_table), ld, _dp(d_rows), n, _dp(d_fresh), _dp(d_sent), _sh(stream)))

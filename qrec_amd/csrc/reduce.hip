@@ -119,9 +119,10 @@ __global__ __launch_bounds__(256) void epoch_close_kernel(const T *__restrict__ 
     if (threadIdx.x != 0) return;
     tp = s_tot[0][0] + s_tot[0][1] + s_tot[0][2] + s_tot[0][3];
     tq = s_tot[1][0] + s_tot[1][1] + s_tot[1][2] + s_tot[1][3];
-    stats[1] = tp; stats[2] = tq;
+    if (!(decide & 2)) stats[1] = tp;
+    if (!(decide & 4)) stats[2] = tq;
     *ticket = 0u;
-    if (decide) driver_decide(stats, state, regU, regI, max_lr, tol, log, log_capacity);
+    if (decide & 1) driver_decide(stats, state, regU, regI, max_lr, tol, log, log_capacity);
 }
 
 __global__ void epoch_decide_kernel(double *__restrict__ stats, double *__restrict__ state, double regU, double regI,
@@ -170,6 +171,18 @@ extern "C" int qrec_epoch_sums(const void *d_P, int64_t p_rows, const void *d_Q,
     QREC_REQUIRE(dtype == QREC_F32 || dtype == QREC_F64, "qrec_epoch_sums: bad dtype %d", dtype);
     return launch_epoch_close(d_P, p_rows, d_Q, q_rows, dtype, ld, d_stats, const_cast<double *>(d_state), 0, 0, 0, 0,
                               nullptr, 0, 0, as_stream(stream));
+}
+// One table's deterministic sum of squares into d_stats[slot] (slot 1 = users, 2 = items), leaving the other slot alone:
+// lets a multi-GPU step take sum P*P before its one fused collective and sum Q*Q after the item table is reconciled.
+extern "C" int qrec_epoch_sum_table(const void *d_X, int64_t rows, int dtype, int32_t ld, double *d_stats, int slot,
+                                    const double *d_state, void *stream) {
+    QREC_REQUIRE(d_X && d_stats && rows >= 0 && ld >= 4 && ld % 4 == 0, "qrec_epoch_sum_table: bad arguments");
+    QREC_REQUIRE(dtype == QREC_F32 || dtype == QREC_F64, "qrec_epoch_sum_table: bad dtype %d", dtype);
+    QREC_REQUIRE(slot == 1 || slot == 2, "qrec_epoch_sum_table: slot must be 1 (sum P*P) or 2 (sum Q*Q)");
+    return slot == 1 ? launch_epoch_close(d_X, rows, d_X, 0, dtype, ld, d_stats, const_cast<double *>(d_state), 0, 0, 0, 0, nullptr,
+                                          0, 4, as_stream(stream))
+                     : launch_epoch_close(d_X, 0, d_X, rows, dtype, ld, d_stats, const_cast<double *>(d_state), 0, 0, 0, 0, nullptr,
+                                          0, 2, as_stream(stream));
 }
 extern "C" int qrec_epoch_decide(double *d_stats, double *d_state, double regU, double regI, double max_lr, double tol,
                                  double *d_log, int64_t log_capacity, void *stream) {

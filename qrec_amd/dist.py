@@ -1,23 +1,35 @@
-"""Multi-GPU data parallelism of the BPR hot path -- one process per GPU,
-``torch.distributed`` (backend "nccl" = RCCL over xGMI on the device, "gloo" in CPU tests).
+"""Multi-GPU execution of the embedding-training hot path -- one process per GPU.
 
-Sharding: users are split into contiguous id blocks, one per rank.  A rank owns its users'
-rows of ``P``, their triplets (the PositiveSet CSR is user-major, so this is a row split) and
-their negative sampling: no exchange on that side.  The item table ``Q`` is replicated; every
-rank applies its own triplets to its replica and, at the end of a step, the replicas are
-reconciled by summing the per-rank deltas:
+Data plane: RCCL over xGMI, bound directly by libqrec_hip.so (``capi.Comm``: qrec_comm_init / qrec_allreduce /
+qrec_alltoall_rows ...) and enqueued on the same HIP stream as the kernels; no torch tensor or torch kernel is on it.
+Control plane: ``torch.distributed`` with the gloo backend (TCP between the ranks' hosts) -- it hands out the RCCL id
+and the seeds, and carries barriers and a few host integers; never embedding data.
 
-    Q  <-  Q_start + sum_r (Q_r - Q_start)            (one all-reduce of |Q| floats)
+BPR (config #4).  Users are split into contiguous id blocks, one per rank: a rank owns its users' rows of ``P``, their
+triplets (the PositiveSet CSR is user-major, so this is a row split) and their negative sampling -- no exchange on that
+side.  The item table ``Q`` has two layouts:
 
-i.e. every rank's updates are kept (none is averaged away), and an item row read during a step
-lags other ranks' updates by at most one step -- the same bounded-staleness contract the
-single-GPU throughput kernel has inside a launch.  Q is 9.7 MB at the Yelp2018 shape and
-0.5 GB at config #4: small next to 288 GB of HBM, and one ring all-reduce per step moves far
-fewer bytes over the point-to-point xGMI links than fetching two remote rows per triplet.
+``replicated``  every rank holds all of ``Q`` and trains its triplets on its copy; after the SGD kernel the copies are
+    reconciled by summing the ranks' deltas,  Q <- Q_start + sum_r (Q_r - Q_start)  (ReplicatedTableSync: delta kernel,
+    ONE fused all-reduce that also carries the epoch's loss terms, apply kernel).  Every rank's updates are kept, a row
+    read during a step lags the other ranks' updates by at most one step.  Traffic: |Q| floats per step and rank.
+``sharded``     item ``r*G + o`` is local row ``r`` of rank ``o`` (BASELINE.json's north star: row-sharded tables, RCCL
+    all-to-all for cross-shard lookups).  An epoch is cut into batches; per batch a rank asks the owners for the distinct
+    item rows its triplets touch (all-to-all of row ids), receives them into a row cache (all-to-all of rows), runs the
+    unchanged SGD kernel on (P, cache), and returns the cache; owners add ``returned - sent`` into their rows
+    (ShardedItemExchange).  Same contract at batch granularity:  Q <- Q + sum_r (cache_r_after - cache_r_before).
+    Memory per rank: |Q|/G + the cache of one batch.  Traffic: 2 rows per DISTINCT item a batch touches.
+
+Graph models (config #5): ``BatchParallel`` (batch-sharded steps, one gradient all-reduce) and ``RowPartition``
+(1-D row partition of the propagation: all-gather of the operand per layer, reduce-scatter in the backward pass).
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
+
+from . import capi as _capi
 
 
 def user_block(n_users: int, world: int, rank: int) -> tuple[int, int]:
@@ -36,28 +48,257 @@ def shard_positive_csr(indptr: np.ndarray, indices: np.ndarray, world: int, rank
     return lo, hi, (indptr[lo:hi + 1] - indptr[lo]).astype(np.int64), np.ascontiguousarray(indices[b:e])
 
 
-class ReplicatedTableSync:
-    """Delta all-reduce of a replicated table held in a torch tensor (cpu or cuda).
+def item_owner(items: np.ndarray, world: int):
+    """(owner rank, local row at the owner) of global item ids under the interleaved row sharding"""
+    items = np.asarray(items)
+    return items % world, items // world
 
-    ``sync()`` after each step makes every replica equal to start + sum of all ranks' deltas and
-    re-arms the snapshot.  With world size 1 it is a no-op apart from refreshing the snapshot."""
 
-    def __init__(self, table, group=None):
+def shard_item_rows(Q: np.ndarray, world: int, rank: int) -> np.ndarray:
+    """the rows of a [n_items, d] table that live on ``rank`` (items rank, rank+world, ...), in local row order"""
+    return np.ascontiguousarray(Q[rank::world])
+
+
+# ---- control plane ------------------------------------------------------------------------------------------------
+class ControlPlane:
+    """Host-side rendezvous of the ranks over torch.distributed/gloo (env MASTER_ADDR, MASTER_PORT, RANK, WORLD_SIZE as
+    set by ``torch.distributed.run``).  Small host values only."""
+
+    def __init__(self, group=None):
+        import torch
         import torch.distributed as dist
-        self._dist = dist
-        self.table = table
-        self.group = group
-        self.start = table.clone()
+        self._torch, self._dist, self.group = torch, dist, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
 
-    def sync(self):
-        delta = self.table - self.start
-        if self._dist.is_initialized() and self._dist.get_world_size(self.group) > 1:
-            self._dist.all_reduce(delta, group=self.group)
-        self.start.add_(delta)
-        self.table.copy_(self.start)
+    @classmethod
+    def from_env(cls):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29571")
+            dist.init_process_group("gloo", rank=int(os.environ.get("RANK", "0")),
+                                    world_size=int(os.environ.get("WORLD_SIZE", "1")))
+        return cls()
+
+    def barrier(self):
+        self._dist.barrier(group=self.group)
+
+    def broadcast_bytes(self, payload: bytes | None, n: int, src: int = 0) -> bytes:
+        t = self._torch.zeros(n, dtype=self._torch.uint8)
+        if self.rank == src:
+            t.copy_(self._torch.frombuffer(bytearray(payload), dtype=self._torch.uint8))
+        self._dist.broadcast(t, src=src, group=self.group)
+        return bytes(t.numpy().tobytes())
+
+    def allreduce_host(self, arr: np.ndarray, op: str = "sum") -> np.ndarray:
+        t = self._torch.from_numpy(np.array(arr, copy=True))
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX if op == "max" else self._dist.ReduceOp.SUM, group=self.group)
+        return t.numpy()
+
+    def allgather_host(self, arr: np.ndarray) -> np.ndarray:
+        """[world, *arr.shape]; every rank passes the same shape"""
+        t = self._torch.from_numpy(np.ascontiguousarray(arr))
+        out = [self._torch.empty_like(t) for _ in range(self.world)]
+        self._dist.all_gather(out, t, group=self.group)
+        return np.stack([o.numpy() for o in out])
+
+    def shutdown(self):
+        if self._dist.is_initialized():
+            self._dist.barrier(group=self.group)
+            self._dist.destroy_process_group()
 
 
-# ---- graph models (LightGCN / NGCF / SimGCL): batch-sharded data parallelism -------------------------------------
+class GlooStagedComm:
+    """FUNCTIONAL-TEST transport with ``capi.Comm``'s interface: device buffers are staged through the host and the
+    control plane's gloo group.  Exists because RCCL refuses two ranks on one device and the development boxes have one
+    GPU (QREC_DIST_TEST_ONE_DEVICE=1 puts every rank on device 0) -- it lets the N > 1 control flow, kernels and
+    exchange bookkeeping run end to end on real hardware.  Synchronous; numbers from such runs are not bench results."""
+
+    _NP = {_capi.F32: np.float32, _capi.F64: np.float64, _capi.I32: np.int32}
+
+    def __init__(self, control: ControlPlane, kern=_capi):
+        self.cp, self.k = control, kern
+        self.world, self.rank = control.world, control.rank
+
+    def _get(self, ptr, count, dtype, stream):
+        out = np.empty(count, dtype=dtype)
+        if count:
+            self.k.memcpy_d2h(out, ptr, out.nbytes, stream)
+        return out
+
+    def _put(self, ptr, arr, stream):
+        if arr.size:
+            self.k.memcpy_h2d(ptr, np.ascontiguousarray(arr), arr.nbytes, stream)
+
+    def allreduce(self, buf, count, dtype=_capi.F32, stream=None):
+        self._put(buf, self.cp.allreduce_host(self._get(buf, count, self._NP[dtype], stream)), stream)
+
+    def allreduce_pair(self, a, count_a, dtype_a, b, count_b, dtype_b, stream=None):
+        self.allreduce(a, count_a, dtype_a, stream); self.allreduce(b, count_b, dtype_b, stream)
+
+    def allgather(self, send, recv, count, dtype=_capi.F32, stream=None):
+        self._put(recv, self.cp.allgather_host(self._get(send, count, self._NP[dtype], stream)).ravel(), stream)
+
+    def reduce_scatter(self, send, recv, count, dtype=_capi.F32, stream=None):
+        full = self.cp.allreduce_host(self._get(send, count * self.world, self._NP[dtype], stream))
+        self._put(recv, full[self.rank * count:(self.rank + 1) * count], stream)
+
+    def alltoall_rows(self, send, send_rows, recv, recv_rows, row_bytes, stream=None):
+        torch, dist = self.cp._torch, self.cp._dist
+        s = [int(x) * row_bytes for x in send_rows]; r = [int(x) * row_bytes for x in recv_rows]
+        src = torch.from_numpy(self._get(send, sum(s), np.uint8, stream)); dst = torch.empty(sum(r), dtype=torch.uint8)
+        dist.all_to_all_single(dst, src, r, s, group=self.cp.group)
+        self._put(recv, dst.numpy(), stream)
+
+    def destroy(self):
+        pass
+
+
+def make_comm(control: ControlPlane):
+    """the data-plane communicator of this process: RCCL (rank 0's id travels over the control plane); the staged gloo
+    transport only under QREC_DIST_TEST_ONE_DEVICE=1"""
+    if os.environ.get("QREC_DIST_TEST_ONE_DEVICE") == "1":
+        return GlooStagedComm(control)
+    uid = control.broadcast_bytes(_capi.comm_unique_id() if control.rank == 0 else None, _capi.COMM_UID_BYTES)
+    return _capi.Comm(control.world, control.rank, uid)
+
+
+# ---- BPR, replicated item table ------------------------------------------------------------------------------------
+class ReplicatedTableSync:
+    """Delta all-reduce of a replicated fp32 table resident on the device.  ``sync()`` after a step makes every replica
+    equal to start + sum of all ranks' deltas and re-arms the snapshot: three enqueues on the caller's stream (delta
+    kernel, all-reduce, apply kernel), nothing on the host.  ``extra`` = (buffer, count, dtype) rides in the same fused
+    collective launch (the epoch's loss terms)."""
+
+    def __init__(self, comm, table, n_floats: int | None = None, kern=_capi, stream=None):
+        self.comm, self.k, self.table = comm, kern, table
+        self.n = int(n_floats if n_floats is not None else table.nbytes // 4)
+        self.start = kern.DeviceBuffer(self.n, np.float32)
+        self.delta = kern.DeviceBuffer(self.n, np.float32)
+        kern.memcpy_d2d(self.start, table, self.n * 4, stream)
+
+    def sync(self, stream=None, extra=None):
+        k = self.k
+        k.table_delta(self.table, self.start, self.delta, self.n, stream)
+        if extra is None:
+            self.comm.allreduce(self.delta, self.n, k.F32, stream)
+        else:
+            self.comm.allreduce_pair(self.delta, self.n, k.F32, extra[0], extra[1], extra[2], stream)
+        k.table_apply(self.table, self.start, self.delta, self.n, stream)
+
+
+# ---- BPR, row-sharded item table -----------------------------------------------------------------------------------
+class ShardedItemExchange:
+    """Cross-shard row lookups of one rank for an epoch of BPR triplets (module docstring, ``sharded``).
+
+    ``plan_epoch`` runs on the device for every batch (distinct rows per owner, triplet ids rewritten to cache slots)
+    and costs ONE host synchronisation per epoch: the row counts, which size the exchanges.  ``run_epoch`` then only
+    enqueues -- per batch: ids to the owners, rows back, ``sgd_batch`` on the cache, cache back, owners add the deltas.
+    Every rank must call both with the same ``n_batches`` (ranks hold different triplet counts; a rank that has run out
+    of triplets still serves its rows).  ``kern`` is the C ABI binding (tests substitute a host emulation to check the
+    protocol on CPU over gloo)."""
+
+    def __init__(self, comm, n_items: int, ld: int, q_local, kern=_capi):
+        self.comm, self.k = comm, kern
+        self.world, self.rank = comm.world, comm.rank
+        self.n_items, self.ld, self.q_local = int(n_items), int(ld), q_local
+        self.rows_local = kern.shard_rows(self.n_items, self.world, self.rank)
+        self.d_scratch = kern.DeviceBuffer(kern.shard_plan_scratch_bytes(self.n_items, self.world), np.uint8)
+        self._cap = {}
+        self.n = self.n_batches = 0
+        self.bounds = self.send = self.recv = self.req_off = None
+        self.bytes_moved = 0
+
+    def _buf(self, name: str, elems: int, dtype):
+        """grow-only device buffer"""
+        b = self._cap.get(name)
+        if b is None or b.nbytes < elems * np.dtype(dtype).itemsize:
+            b = self._cap[name] = self.k.DeviceBuffer(max(int(elems * 1.25), 1), dtype)
+        return b
+
+    def plan_epoch(self, d_i, d_j, n: int, n_batches: int, stream=None):
+        k, G = self.k, self.world
+        self.n, self.n_batches = int(n), int(n_batches)
+        per = -(-self.n // self.n_batches) if self.n else 0
+        self.bounds = [min(b * per, self.n) for b in range(self.n_batches + 1)]
+        caps = [min(2 * (self.bounds[b + 1] - self.bounds[b]), self.n_items) for b in range(self.n_batches)]
+        self.req_off = np.concatenate([[0], np.cumsum(caps)]).astype(np.int64)
+        d_req = self._buf("req", int(self.req_off[-1]), np.int32)
+        d_ci, d_cj = self._buf("ci", self.n, np.int32), self._buf("cj", self.n, np.int32)
+        d_counts = self._buf("counts", self.n_batches * G, np.int32)
+        d_all = self._buf("all_counts", self.n_batches * G * G, np.int32)
+        pi, pj = k.device_ptr(d_i), k.device_ptr(d_j)
+        for b in range(self.n_batches):
+            t0, nb = self.bounds[b], self.bounds[b + 1] - self.bounds[b]
+            k.shard_plan_batch(pi + 4 * t0, pj + 4 * t0, nb, self.n_items, G, self.d_scratch,
+                               k.device_ptr(d_req) + 4 * int(self.req_off[b]), k.device_ptr(d_counts) + 4 * b * G,
+                               k.device_ptr(d_ci) + 4 * t0, k.device_ptr(d_cj) + 4 * t0, stream)
+        self.comm.allgather(d_counts, d_all, self.n_batches * G, k.I32, stream)
+        counts = d_all.head(G * self.n_batches * G, stream).reshape(G, self.n_batches, G)      # the epoch's one host sync
+        self.send = counts[self.rank].astype(np.int64)                   # [batch][owner]: rows I ask of each owner
+        self.recv = counts[:, :, self.rank].T.astype(np.int64).copy()    # [batch][peer]:  rows each peer asks of me
+        r_in, r_out = int(self.recv.sum(1).max(initial=0)), int(self.send.sum(1).max(initial=0))
+        self._buf("req_in", r_in, np.int32)
+        self._buf("rows_out", r_in * self.ld, np.float32); self._buf("rows_ret", r_in * self.ld, np.float32)
+        self._buf("cache", r_out * self.ld, np.float32)
+
+    def run_epoch(self, sgd_batch, stream=None):
+        """``sgd_batch(t0, n, d_cache, cache_rows, ci_ptr, cj_ptr, stream)`` trains triplets [t0, t0+n) whose item ids
+        are rows of ``d_cache`` (addresses of the rewritten id arrays are passed)."""
+        k, c, ld = self.k, self._cap, self.ld
+        req, ci, cj = k.device_ptr(c["req"]), k.device_ptr(c["ci"]), k.device_ptr(c["cj"])
+        for b in range(self.n_batches):
+            t0, nb = self.bounds[b], self.bounds[b + 1] - self.bounds[b]
+            S, R = self.send[b], self.recv[b]
+            n_out, n_in = int(S.sum()), int(R.sum())
+            self.comm.alltoall_rows(req + 4 * int(self.req_off[b]), S, c["req_in"], R, 4, stream)      # ids -> owners
+            k.gather_rows(self.q_local, ld, c["req_in"], n_in, c["rows_out"], stream)
+            self.comm.alltoall_rows(c["rows_out"], R, c["cache"], S, ld * 4, stream)                    # rows -> requesters
+            if nb:
+                sgd_batch(t0, nb, c["cache"], n_out, ci + 4 * t0, cj + 4 * t0, stream)
+            self.comm.alltoall_rows(c["cache"], S, c["rows_ret"], R, ld * 4, stream)                    # rows -> owners
+            k.scatter_add_row_deltas(self.q_local, ld, c["req_in"], n_in, c["rows_ret"], c["rows_out"], stream)
+            off = n_out - int(S[self.rank])
+            self.bytes_moved += off * (4 + 2 * ld * 4)        # what left this rank for other ranks
+
+
+class ReplicatedStep:
+    """what ``BprSgd.epoch_device_async(dist=...)`` needs for the replicated layout: the item table's sync and, when the
+    user table is replicated too (drop-in classes), its sync"""
+    mode = "replicated"
+
+    def __init__(self, comm, sync_q: ReplicatedTableSync, sync_p: ReplicatedTableSync | None = None):
+        self.comm, self.sync_q, self.sync_p = comm, sync_q, sync_p
+
+
+class ShardedStep:
+    """... and for the row-sharded layout: the exchange and the number of batches per epoch every rank agreed on.
+    ``prepare`` (after the epoch's negatives are on the device, before ``epoch_device_async``) plans the epoch."""
+    mode = "sharded"
+
+    def __init__(self, comm, exchange: ShardedItemExchange, n_batches: int):
+        self.comm, self.exchange, self.n_batches = comm, exchange, int(n_batches)
+
+    def prepare(self, sgd, stream=None):
+        self.exchange.plan_epoch(sgd.d_i, sgd.d_j, sgd.n, self.n_batches, stream)
+
+
+def agree_on_batches(control: ControlPlane, n_local: int, batch: int) -> int:
+    """batches per epoch such that no rank's batch exceeds ``batch`` triplets (the rank with the most triplets decides)"""
+    n_max = int(control.allreduce_host(np.array([n_local], dtype=np.int64), op="max")[0])
+    return max(1, -(-n_max // max(int(batch), 1)))
+
+
+# ---- graph models (LightGCN / NGCF / SimGCL ...) ---------------------------------------------------------------------
+def _buffer_view(buf):
+    """(device address, element count, capi dtype code) of a DeviceBuffer or a ``head_view``"""
+    itf = getattr(buf, "__cuda_array_interface__", None)
+    if itf is None:
+        raise TypeError("all_reduce needs a DeviceBuffer or a DeviceBuffer.head_view")
+    code = {"<f4": _capi.F32, "<f8": _capi.F64, "<i4": _capi.I32}[itf["typestr"]]
+    return itf["data"][0], int(np.prod(itf["shape"], dtype=np.int64)), code
+
+
 class BatchParallel:
     """SURVEY s8e, config #5.  Every rank holds the whole embedding table (17.8 MB at the Yelp2018 shape), the graph
     and the Adam slots, and propagates the whole graph; a training step covers ``batch_size x world`` consecutive
@@ -69,75 +310,83 @@ class BatchParallel:
     A run on G ranks with ``batch_size = B`` therefore equals a single-GPU run with ``batch_size = G B`` up to fp32
     summation order.  Evaluation shards the test users; the per-user hit / DCG sums are disjoint and add exactly."""
 
-    def __init__(self, group=None, device_index: int | None = None):
-        import torch
-        import torch.distributed as dist
-        from . import capi
-        self._torch, self._dist, self.group = torch, dist, group
-        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        self.device = torch.device("cuda", capi.current_device() if device_index is None else device_index)
-        self._host_via_device = dist.get_backend(group) == "nccl"
+    def __init__(self, control: ControlPlane, comm):
+        self.control, self.comm = control, comm
+        self.world, self.rank = control.world, control.rank
 
     @classmethod
     def from_env(cls):
-        """the process group ``init_from_env`` made, or None on one GPU (torch is not imported then)"""
-        import sys
-        dist = sys.modules.get("torch.distributed")
-        if dist is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
-            return None
-        return cls()
+        """the communicator ``init_from_env`` made, or None on one GPU"""
+        return _STATE.get("dp")
 
     def share(self, n_rows: int) -> tuple[int, int]:
         """(offset, count) of this rank's contiguous share of a step's rows (counts differ by <= 1)"""
         lo, hi = user_block(n_rows, self.world, self.rank)
         return lo, hi - lo
 
-    def all_reduce(self, buf):
-        """sum a device buffer over the ranks in place; ordered after the kernels enqueued so far (default stream)"""
-        self._dist.all_reduce(self._torch.as_tensor(buf, device=self.device), group=self.group)
+    def all_reduce(self, buf, stream=None):
+        """sum a device buffer over the ranks in place; ordered after the kernels enqueued so far on ``stream``"""
+        ptr, count, code = _buffer_view(buf)
+        self.comm.allreduce(ptr, count, code, stream)
 
     def all_reduce_host(self, arr: np.ndarray) -> np.ndarray:
-        t = self._torch.from_numpy(np.ascontiguousarray(arr))
-        if self._host_via_device:
-            t = t.to(self.device)
-        self._dist.all_reduce(t, group=self.group)
-        return t.cpu().numpy()
+        return self.control.allreduce_host(np.ascontiguousarray(arr))
+
+
+class RowPartition:
+    """1-D row partition of a propagation  Y = A X  over the ranks: rank r owns the contiguous row
+    block [lo_r, hi_r) of A, of X and of Y, padded to ``rows_pad`` rows per rank so that the collectives are uniform.
+    Forward: all-gather of the operand blocks, local SpMM of the rank's rows.  Backward (dX = A^T dY with only the
+    rank's rows of dY): local product of the transposed row block into a full-height buffer, reduce-scatter."""
+
+    def __init__(self, comm, n_rows: int, ld: int, kern=_capi):
+        self.comm, self.k, self.n_rows, self.ld = comm, kern, int(n_rows), int(ld)
+        self.world, self.rank = comm.world, comm.rank
+        self.rows_pad = -(-self.n_rows // self.world)
+        self.lo = min(self.rank * self.rows_pad, self.n_rows)
+        self.hi = min(self.lo + self.rows_pad, self.n_rows)
+
+    def gather_operand(self, d_block, d_full, stream=None):
+        """d_block [rows_pad][ld] (this rank's rows, pad rows zero) -> d_full [world*rows_pad][ld]"""
+        self.comm.allgather(d_block, d_full, self.rows_pad * self.ld, self.k.F32, stream)
+
+    def scatter_sum(self, d_full, d_block, stream=None):
+        """d_full [world*rows_pad][ld] partial products of every rank -> d_block = this rank's rows of their sum"""
+        self.comm.reduce_scatter(d_full, d_block, self.rows_pad * self.ld, self.k.F32, stream)
+
+
+_STATE: dict = {}
 
 
 def init_from_env():
-    """``python -m torch.distributed.run --nproc-per-node G -m qrec_amd.main <conf>``: one process per GPU.  Joins
-    the process group (RCCL; gloo with every rank on device 0 under QREC_DIST_TEST_ONE_DEVICE=1, the functional test
-    on 1-GPU boxes), binds the rank's device and gives every rank the same ``random`` / ``numpy.random`` streams --
-    the reference never seeds, so rank 0's choice (QREC_SEED or the clock) is broadcast.  Returns the
-    world size; 1 (and no torch import) when not launched that way."""
-    import os
+    """``python -m torch.distributed.run --nproc-per-node G -m qrec_amd.main <conf>``: one process per GPU.  Joins the
+    control plane, binds the rank's device, creates the RCCL communicator and gives every rank the same ``random`` /
+    ``numpy.random`` streams -- the reference never seeds, so rank 0's choice (QREC_SEED or the clock) is
+    broadcast.  Returns the world size; 1 (and no torch import) when not launched that way."""
     import random
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         return 1
     import time
-    import torch
-    import torch.distributed as dist
-    from . import capi
+    control = ControlPlane.from_env()
     one_device = os.environ.get("QREC_DIST_TEST_ONE_DEVICE") == "1"
     local = 0 if one_device else int(os.environ.get("LOCAL_RANK", "0"))
     os.environ["QREC_DEVICE"] = str(local)
-    torch.cuda.set_device(local)
-    if one_device:
-        dist.init_process_group("gloo")
-    else:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    capi.init(local)
-    seed = torch.tensor([int(os.environ.get("QREC_SEED", time.time_ns() % (2 ** 31)))], dtype=torch.int64)
-    if not one_device:
-        seed = seed.cuda()
-    dist.broadcast(seed, src=0)
-    random.seed(int(seed.item())); np.random.seed(int(seed.item()) % (2 ** 32))
+    _capi.init(local)
+    comm = make_comm(control)
+    seed = int(control.allreduce_host(np.array([int(os.environ.get("QREC_SEED", time.time_ns() % (2 ** 31)))
+                                                if control.rank == 0 else 0], dtype=np.int64))[0])
+    random.seed(seed); np.random.seed(seed % (2 ** 32))
+    attach(control, comm)
     return world
+
+
+def attach(control: ControlPlane, comm):
+    """make (control, comm) this process's multi-GPU context: what ``BatchParallel.from_env`` / ``is_output_rank`` see"""
+    _STATE.update(control=control, comm=comm, dp=BatchParallel(control, comm) if control.world > 1 else None)
 
 
 def is_output_rank() -> bool:
     """result / measure files are written by rank 0 only"""
-    import sys
-    dist = sys.modules.get("torch.distributed")
-    return dist is None or not dist.is_initialized() or dist.get_rank() == 0
+    control = _STATE.get("control")
+    return control is None or control.rank == 0

@@ -92,13 +92,16 @@ class BprSgd:
     so they overlap almost perfectly."""
 
     def __init__(self, tables: DeviceTables, u: np.ndarray, i: np.ndarray, pos: CSR | None = None,
-                 schedule: str = "user"):
+                 schedule: str = "user", n_items: int | None = None):
         """``schedule``: "user" keeps the reference's user-major order (required by the order-exact
         kernel); "item" stores the same triplets sorted by positive item for the item-major
         throughput kernel (``self.perm`` maps scheduled position -> reference position)."""
         if schedule not in ("user", "item"):
             raise ValueError("schedule must be 'user' or 'item'")
         self.t = tables
+        # size of the item catalogue the triplets' ids refer to: the table's rows, except when this process holds only a
+        # row shard of the item table (qrec_amd/dist.py) and the ids are global
+        self.n_items = int(n_items) if n_items is not None else tables.n_items
         self.n = int(u.size)
         self.schedule = schedule
         self.perm = None
@@ -144,7 +147,7 @@ class BprSgd:
     def sample_negatives_device(self, seed: int, epoch: int, stream=None):
         if self._pos_dev is None:
             raise RuntimeError("BprSgd was built without the positives CSR")
-        capi.philox_bpr_sample(self._pos_dev[0], self._pos_dev[1], self.d_u, self.n, self.t.n_items,
+        capi.philox_bpr_sample(self._pos_dev[0], self._pos_dev[1], self.d_u, self.n, self.n_items,
                                seed, epoch, self.d_j, stream)
 
     def prefetch_negatives_device(self, seed: int, epoch: int):
@@ -158,7 +161,7 @@ class BprSgd:
             capi.stream_wait_event(self._side, self._consumed[1])
         if self._sgd_start is not None:
             capi.stream_wait_event(self._side, self._sgd_start)
-        capi.philox_bpr_sample(self._pos_dev[0], self._pos_dev[1], self.d_u, self.n, self.t.n_items,
+        capi.philox_bpr_sample(self._pos_dev[0], self._pos_dev[1], self.d_u, self.n, self.n_items,
                                seed, epoch, self.d_j_next, self._side)
         self._sampled.record(self._side)
         self._prefetched_epoch = epoch
@@ -216,12 +219,11 @@ class BprSgd:
 
     def epoch_device_async(self, regU: float, regI: float, max_lr: float, tol: float = 1e-3, chunk: int = 32,
                            variant: int = capi.HW_DEFAULT, stream=None, groups: int = 0, flush_every: int = 16,
-                           events=None, between=None):
+                           events=None, dist=None):
         """One throughput epoch with everything after it (BPR.py:40 loss terms, isConverged,
         updateLearningRate) enqueued on the device: no host synchronisation.  ``events`` = (before, after)
-        capi.Event pair recorded around the SGD kernel.  ``between(stage)`` (one process per GPU) is called with
-        "tables" right after the SGD kernel (reconcile replicated tables) and with "stats" after the local sums
-        (all-reduce ``d_stats[0:2]``); both must only ENQUEUE work on the same stream."""
+        capi.Event pair recorded around the SGD kernel.  ``dist`` (one process per GPU, qrec_amd/dist.py): a
+        ``ReplicatedStep`` or ``ShardedStep`` -- the collectives are enqueued on the same stream, between the kernels."""
         if self.d_drv is None:
             raise RuntimeError("call start_device_driver() first")
         t = self.t
@@ -232,23 +234,41 @@ class BprSgd:
         start, end = events if events else (self._own_events[0], self._own_events[1])
         start.record(stream)
         self._sgd_start = start
-        if self.schedule == "item":
-            capi.bpr_sgd_hogwild_item_major(t.P, t.Q, t.d, t.ld, self.d_u, self.d_i, self.d_j, self.n, chunk, groups,
-                                            flush_every, 0.0, regU, regI, self.d_stats, stream, self.d_drv)
+        if dist is not None and dist.mode == "sharded":
+            dist.exchange.run_epoch(lambda t0, nb, cache, rows, ci, cj, st: self._launch_sgd(
+                t.P, cache, self.d_u.ptr + 4 * t0, ci, cj, nb, chunk, groups, flush_every, regU, regI, variant, st, q_rows=rows), stream)
         else:
-            capi.bpr_sgd_hogwild(t.P, t.Q, t.d, t.ld, self.d_u, self.d_i, self.d_j, self.n, chunk, groups, 0.0, regU,
-                                 regI, self.d_stats, variant, stream, self.d_drv)
+            self._launch_sgd(t.P, t.Q, self.d_u, self.d_i, self.d_j, self.n, chunk, groups, flush_every, regU, regI, variant, stream)
         end.record(stream)
         self._consumed[0] = end
         self._own_events.reverse()
-        if between is None:
+        if dist is None:
             capi.epoch_close(t.P, t.n_users, t.Q, t.n_items, t.code, t.ld, self.d_stats, self.d_drv, regU, regI, max_lr,
                              tol, self.d_log, self._log_capacity, stream)
-        else:    # multi-GPU: reconcile the replicas / sum the loss terms over ranks between the sums and the decision
-            between("tables")
+            return
+        if dist.mode == "sharded":      # sum P*P and sum Q*Q are over disjoint row shards: all three terms add over ranks
             capi.epoch_sums(t.P, t.n_users, t.Q, t.n_items, t.code, t.ld, self.d_stats, self.d_drv, stream)
-            between("stats")
-            capi.epoch_decide(self.d_stats, self.d_drv, regU, regI, max_lr, tol, self.d_log, self._log_capacity, stream)
+            dist.comm.allreduce(self.d_stats, 3, capi.F64, stream)
+        elif dist.sync_p is None:       # users sharded, items replicated: the delta all-reduce carries {sum -log sigma, sum P*P}
+            capi.epoch_sum_table(t.P, t.n_users, t.code, t.ld, self.d_stats, 1, self.d_drv, stream)
+            dist.sync_q.sync(stream, extra=(self.d_stats, 2, capi.F64))
+            capi.epoch_sum_table(t.Q, t.n_items, t.code, t.ld, self.d_stats, 2, self.d_drv, stream)
+        else:                           # both tables replicated (drop-in classes: every rank evaluates from whole tables)
+            dist.sync_p.sync(stream)
+            dist.sync_q.sync(stream, extra=(self.d_stats, 1, capi.F64))
+            capi.epoch_sums(t.P, t.n_users, t.Q, t.n_items, t.code, t.ld, self.d_stats, self.d_drv, stream)
+        capi.epoch_decide(self.d_stats, self.d_drv, regU, regI, max_lr, tol, self.d_log, self._log_capacity, stream)
+
+    def _launch_sgd(self, P, Q, d_u, d_i, d_j, n, chunk, groups, flush_every, regU, regI, variant, stream, q_rows=None):
+        """the throughput kernel of the schedule on (P, Q) -- Q is the item table, or a shard's row cache with the
+        triplets' item ids rewritten to its rows; learning rate and stop flags come from the device-side driver"""
+        t = self.t
+        if self.schedule == "item":
+            capi.bpr_sgd_hogwild_item_major(P, Q, t.d, t.ld, d_u, d_i, d_j, n, chunk, groups, flush_every, 0.0, regU, regI,
+                                            self.d_stats, stream, self.d_drv, p_rows=t.n_users, q_rows=q_rows)
+        else:
+            capi.bpr_sgd_hogwild(P, Q, t.d, t.ld, d_u, d_i, d_j, n, chunk, groups, 0.0, regU, regI, self.d_stats, variant,
+                                 stream, self.d_drv, p_rows=t.n_users, q_rows=q_rows)
 
     def driver_state(self, stream=None) -> dict:
         s = self.d_drv.numpy(stream)

@@ -110,20 +110,10 @@ class BPR(IterativeRecommender):
         device-side driver then takes the same decision on identical tables."""
         from ...engine import balanced_chunk
         chunk = balanced_chunk(sgd.n)
-        between = None
+        step = None
         if dp is not None:
-            import torch
-            import torch.distributed as dist
-            from ...dist import ReplicatedTableSync
-            syncs = [ReplicatedTableSync(torch.as_tensor(t, device=dp.device), dp.group) for t in (sgd.t.P, sgd.t.Q)]
-            nll = torch.as_tensor(sgd.d_stats, device=dp.device)[0:1]
-
-            def between(stage):
-                if stage == "tables":
-                    for s in syncs:
-                        s.sync()
-                else:
-                    dist.all_reduce(nll, group=dp.group)
+            from ...dist import ReplicatedStep, ReplicatedTableSync
+            step = ReplicatedStep(dp.comm, ReplicatedTableSync(dp.comm, sgd.t.Q), ReplicatedTableSync(dp.comm, sgd.t.P))
         sgd.start_device_driver(self.lRate, log_capacity=self.maxEpoch)
         sgd.prefetch_negatives_device(self.sampler_seed, 0)
         closed = []
@@ -146,7 +136,7 @@ class BPR(IterativeRecommender):
         done, retired = False, 0
         for epoch in range(self.maxEpoch):
             sgd.take_prefetched_negatives(epoch)
-            sgd.epoch_device_async(self.regU, self.regI, self.maxLRate, tol=1e-3, chunk=chunk, between=between)
+            sgd.epoch_device_async(self.regU, self.regI, self.maxLRate, tol=1e-3, chunk=chunk, dist=step)
             sgd.prefetch_negatives_device(self.sampler_seed, epoch + 1)      # released under this epoch's SGD kernel
             ev = capi.Event(); ev.record(); closed.append(ev)
             if epoch >= depth:

@@ -1,18 +1,24 @@
-"""world_size-2 test of the multi-GPU scheme on CPU (gloo): user sharding is a partition,
-and a sharded step with the replicated-Q delta all-reduce equals the single-process
-definition  Q_start + sum_r (Q_r - Q_start)  with each shard's P rows updated locally."""
+"""world_size-2 tests of the multi-GPU schemes on CPU (gloo).  The orchestration under test is the product's
+(qrec_amd/dist.py: ReplicatedTableSync, ShardedItemExchange, BatchParallel, RowPartition); the kernels it enqueues are
+replaced by tests/hostkern.py (numpy, same entry points) and the SGD by the oracle, so that what is checked here is the
+protocol: user sharding is a partition, and a sharded step equals the single-process definition
+    replicated:  Q_start + sum_r (Q_r - Q_start)                    per epoch
+    sharded:     Q + sum_r (cache_r_after - cache_r_before)         per batch, rows fetched from / returned to their owners."""
 import os
 import socket
 
 import numpy as np
 import pytest
-import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import c as O
+from qrec_amd import dist as qd
 from qrec_amd.dist import ReplicatedTableSync, shard_positive_csr, user_block
 from qrec_amd.synth import make_dataset, to_csr
+from tests import hostkern as HK
+
+D, LD = 16, 32
 
 
 def _free_port():
@@ -23,34 +29,57 @@ def _problem():
     d = make_dataset("tiny")
     indptr, ind = to_csr(d["n_users"], d["train_u"], d["train_i"])
     rng = np.random.default_rng(0)
-    P0 = rng.random((d["n_users"], 16)) / 3; Q0 = rng.random((d["n_items"], 16)) / 3
+    P0 = rng.random((d["n_users"], D)) / 3; Q0 = (rng.random((d["n_items"], D)) / 3).astype(np.float32)
     return d, indptr, ind, P0, Q0
 
 
-def _local_epoch(indptr, ind, lo, hi, P0, Q, n_items, seed):
-    """one rank's work: its users' triplets, own sampler stream, order-exact on its replica"""
+def _pad(Q):
+    out = np.zeros((Q.shape[0], LD), np.float32); out[:, :Q.shape[1]] = Q
+    return out
+
+
+def _shard(indptr, ind, lo, hi, n_items, seed):
     lp, li = (indptr[lo:hi + 1] - indptr[lo]).astype(np.int64), np.ascontiguousarray(ind[indptr[lo]:indptr[hi]])
     u = np.repeat(np.arange(hi - lo, dtype=np.int32), np.diff(lp)).astype(np.int32)
     j = O.bpr_sample_epoch(O.MT.cpython_seed(seed), lp, li, n_items)
+    return u, li, j
+
+
+def _sgd_on(P, Qpad, u, i, j):
+    """order-exact oracle SGD on (P fp64, a [rows][LD] fp32 table or row cache): the rank's 'kernel'"""
+    Q = Qpad[:, :D].astype(np.float64)
+    O.bpr_sgd(P, Q, np.ascontiguousarray(u, np.int32), np.ascontiguousarray(i, np.int32), np.ascontiguousarray(j, np.int32), 0.05, 0.01, 0.01)
+    Qpad[:, :D] = Q.astype(np.float32)
+
+
+def _local_epoch(indptr, ind, lo, hi, P0, Qpad, n_items, seed):
+    """one rank's work: its users' triplets, own sampler stream, order-exact on its replica"""
+    u, li, j = _shard(indptr, ind, lo, hi, n_items, seed)
     P = P0[lo:hi].copy()
-    O.bpr_sgd(P, Q, u, li, j, 0.05, 0.01, 0.01)
+    _sgd_on(P, Qpad, u, li, j)
     return P
 
 
+def _join(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    control = qd.ControlPlane.from_env()
+    return control, qd.GlooStagedComm(control, kern=HK)
+
+
 def _worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    control, comm = _join(rank, world, port)
     d, indptr, ind, P0, Q0 = _problem()
     lo, hi, lp, li = shard_positive_csr(indptr, ind, world, rank)
-    q = torch.from_numpy(Q0.copy())
-    sync = ReplicatedTableSync(q)
+    q = HK.DeviceBuffer.from_numpy(_pad(Q0))
+    stats = HK.DeviceBuffer.from_numpy(np.array([1.0 + rank, 10.0 * (rank + 1)]))
+    sync = ReplicatedTableSync(comm, q, kern=HK)
     P = None
     for step in range(2):
         P0_step = P0 if P is None else np.concatenate([P0[:lo], P, P0[hi:]])
-        P = _local_epoch(indptr, ind, lo, hi, P0_step, q.numpy(), d["n_items"], 100 * step + rank)
-        sync.sync()
-    out[rank] = (lo, hi, P, q.numpy().copy())
-    dist.barrier(); dist.destroy_process_group()
+        P = _local_epoch(indptr, ind, lo, hi, P0_step, q.a, d["n_items"], 100 * step + rank)
+        sync.sync(extra=(stats, 2, HK.F64) if step == 1 else None)
+    out[rank] = (lo, hi, P, q.a.copy(), stats.a.copy())
+    control.shutdown()
 
 
 def test_user_blocks_partition():
@@ -67,13 +96,24 @@ def test_user_blocks_partition():
     assert sum(p[2][-1] for p in parts) == ind.size
 
 
+def test_item_rows_are_partitioned_interleaved():
+    Q = np.arange(23 * 2, dtype=np.float32).reshape(23, 2)
+    for w in (1, 2, 3, 8):
+        parts = [qd.shard_item_rows(Q, w, r) for r in range(w)]
+        assert sum(p.shape[0] for p in parts) == 23
+        assert [p.shape[0] for p in parts] == [HK.shard_rows(23, w, r) for r in range(w)]
+        owner, row = qd.item_owner(np.arange(23), w)
+        for it in range(23):
+            assert np.array_equal(parts[owner[it]][row[it]], Q[it])
+
+
 def test_two_rank_step_equals_definition():
     world = 2
     mgr = mp.Manager(); out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     d, indptr, ind, P0, Q0 = _problem()
     # single-process statement of the same semantics
-    Q = Q0.copy(); P = P0.copy()
+    Q = _pad(Q0); P = P0.copy()
     for step in range(2):
         deltas = []
         newP = P.copy()
@@ -83,11 +123,78 @@ def test_two_rank_step_equals_definition():
             newP[lo:hi] = _local_epoch(indptr, ind, lo, hi, P, Qr, d["n_items"], 100 * step + r)
             deltas.append(Qr - Q)
         Q = Q + sum(deltas); P = newP
+    assert np.array_equal(out[0][3], out[1][3])                          # replicas bit-identical
     for r in range(world):
-        lo, hi, Pr, Qr = out[r]
-        np.testing.assert_allclose(Qr, Q, rtol=1e-12, atol=1e-15)       # replicas agree and equal the definition
-        np.testing.assert_allclose(Pr, P[lo:hi], rtol=1e-12, atol=1e-15)
-    assert not np.allclose(Q, Q0)
+        lo, hi, Pr, Qr, stats = out[r]
+        np.testing.assert_allclose(Qr, Q, rtol=0, atol=1e-7)             # ... and equal to the definition
+        np.testing.assert_allclose(Pr, P[lo:hi], rtol=1e-6, atol=1e-8)
+        assert np.array_equal(stats, [3.0, 30.0])                        # the loss terms rode in the same collective
+    assert not np.allclose(Q, _pad(Q0))
+
+
+# ---- row-sharded item table: all-to-all row lookups + return of the updates ------------------------------------------
+N_BATCHES = 3
+
+
+def _sharded_worker(rank, world, port, out):
+    control, comm = _join(rank, world, port)
+    d, indptr, ind, P0, Q0 = _problem()
+    I = d["n_items"]
+    lo, hi = user_block(d["n_users"], world, rank)
+    q_local = HK.DeviceBuffer.from_numpy(_pad(qd.shard_item_rows(Q0, world, rank)))
+    ex = qd.ShardedItemExchange(comm, I, LD, q_local, kern=HK)
+    assert ex.rows_local == q_local.a.shape[0]
+    P = P0[lo:hi].copy()
+    for step in range(2):
+        u, li, j = _shard(indptr, ind, lo, hi, I, 100 * step + rank)
+        if rank == 1 and step == 1:            # ragged: this rank runs out of triplets before the others do
+            u, li, j = u[:5], li[:5], j[:5]
+        d_i, d_j = HK.DeviceBuffer.from_numpy(li), HK.DeviceBuffer.from_numpy(j)
+        ex.plan_epoch(d_i, d_j, u.size, N_BATCHES)
+
+        def sgd_batch(t0, nb, cache, rows, ci, cj, stream):
+            c = HK._view(cache, rows * LD, np.float32).reshape(rows, LD)
+            _sgd_on(P, c, u[t0:t0 + nb], HK._view(ci, nb, np.int32), HK._view(cj, nb, np.int32))
+        ex.run_epoch(sgd_batch)
+    out[rank] = (lo, hi, P, q_local.a.copy(), ex.bytes_moved)
+    control.shutdown()
+
+
+def test_two_rank_sharded_item_table_equals_definition():
+    world = 2
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_sharded_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    d, indptr, ind, P0, Q0 = _problem()
+    I = d["n_items"]
+    Q = _pad(Q0); P = P0.copy()
+    for step in range(2):
+        work = []
+        for r in range(world):
+            lo, hi = user_block(d["n_users"], world, r)
+            u, li, j = _shard(indptr, ind, lo, hi, I, 100 * step + r)
+            if r == 1 and step == 1:
+                u, li, j = u[:5], li[:5], j[:5]
+            per = -(-u.size // N_BATCHES)
+            work.append((lo, hi, u, li, j, per))
+        for b in range(N_BATCHES):
+            deltas = np.zeros_like(Q)
+            for lo, hi, u, li, j, per in work:
+                t0, t1 = min(b * per, u.size), min((b + 1) * per, u.size)
+                if t1 == t0:
+                    continue
+                items = np.unique(np.concatenate([li[t0:t1], j[t0:t1]]))
+                slot = np.full(I, -1); slot[items] = np.arange(items.size)
+                cache = Q[items].copy()                                   # the batch-start rows, wherever they live
+                Pr = P[lo:hi]
+                _sgd_on(Pr, cache, u[t0:t1], slot[li[t0:t1]], slot[j[t0:t1]])
+                deltas[items] += cache - Q[items]
+            Q = Q + deltas
+    for r in range(world):
+        lo, hi, Pr, Qr, moved = out[r]
+        np.testing.assert_allclose(Qr, Q[r::world], rtol=0, atol=2e-7)    # every owner holds the definition's rows
+        np.testing.assert_allclose(Pr, P[lo:hi], rtol=1e-6, atol=1e-8)
+        assert moved > 0
+    assert not np.allclose(Q, _pad(Q0))
 
 
 # ---- graph models: batch-sharded data parallelism (qrec_amd.dist.BatchParallel) -----------------------------------
@@ -104,15 +211,14 @@ def _graph_problem():
     V0 = (rng.standard_normal((d["n_items"], 8)) * 0.1).astype(np.float32)
     B = 96
     u = rng.integers(0, d["n_users"], B); i = rng.integers(0, d["n_items"], B); j = rng.integers(0, d["n_items"], B)
-    return T.LightGCN(U0, V0, A, 2, lr=0.01, reg=1e-3), u, i, j
+    return T.LightGCN(U0, V0, A, 2, lr=0.01, reg=1e-3), u, i, j, A
 
 
 def _graph_worker(rank, world, port, out):
-    from qrec_amd.dist import BatchParallel, is_output_rank
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    dp = BatchParallel(device_index=0)
-    model, u, i, j = _graph_problem()
+    control, comm = _join(rank, world, port)
+    qd.attach(control, comm)
+    dp = qd.BatchParallel.from_env()
+    model, u, i, j, _ = _graph_problem()
     steps = []
     for step in range(2):
         lo, cnt = dp.share(u.size)
@@ -120,8 +226,8 @@ def _graph_worker(rank, world, port, out):
         g = dp.all_reduce_host(g); loss = float(dp.all_reduce_host(np.array([loss], np.float64))[0])
         model.opt.step(model.E, g)                                                          # same update on every replica
         steps.append(loss)
-    out[rank] = (dp.share(u.size), steps, model.E.copy(), is_output_rank())
-    dist.barrier(); dist.destroy_process_group()
+    out[rank] = (dp.share(u.size), steps, model.E.copy(), qd.is_output_rank())
+    control.shutdown()
 
 
 def test_graph_batch_parallel_equals_the_whole_step():
@@ -129,7 +235,7 @@ def test_graph_batch_parallel_equals_the_whole_step():
     world = 2
     mgr = mp.Manager(); out = mgr.dict()
     mp.spawn(_graph_worker, args=(world, _free_port(), out), nprocs=world, join=True)
-    model, u, i, j = _graph_problem()
+    model, u, i, j, _ = _graph_problem()
     want = [model.train_step(u, i, j) for _ in range(2)]
     shares = [out[r][0] for r in range(world)]
     assert shares[0][0] == 0 and shares[0][1] + shares[1][1] == u.size and shares[1][0] == shares[0][1]
@@ -137,3 +243,40 @@ def test_graph_batch_parallel_equals_the_whole_step():
     np.testing.assert_allclose(out[0][1], want, rtol=1e-5)
     np.testing.assert_allclose(out[0][2], model.E, rtol=0, atol=2e-5)
     assert out[0][3] is True and out[1][3] is False                     # rank 0 alone writes result files
+
+
+# ---- graph models: 1-D row partition of the propagation (qrec_amd.dist.RowPartition) ------------------------------
+def _rowpart_worker(rank, world, port, out):
+    control, comm = _join(rank, world, port)
+    _, _, _, _, A = _graph_problem()
+    n, ld = A.shape[0], 8
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((n, ld)).astype(np.float32); dY = rng.standard_normal((n, ld)).astype(np.float32)
+    rp = qd.RowPartition(comm, n, ld, kern=HK)
+    pad = rp.rows_pad
+    blk = np.zeros((pad, ld), np.float32); blk[:rp.hi - rp.lo] = X[rp.lo:rp.hi]
+    d_blk, d_full = HK.DeviceBuffer.from_numpy(blk), HK.DeviceBuffer((world * pad, ld), np.float32)
+    rp.gather_operand(d_blk, d_full)                                     # forward: all-gather, then the rank's rows of A
+    Y_rows = A[rp.lo:rp.hi] @ d_full.a[:n]
+    part = np.zeros((world * pad, ld), np.float32)                       # backward: A[rows]^T dY[rows], reduce-scatter
+    part[:n] = A[rp.lo:rp.hi].T @ dY[rp.lo:rp.hi]
+    d_part, d_dx = HK.DeviceBuffer.from_numpy(part), HK.DeviceBuffer((pad, ld), np.float32)
+    rp.scatter_sum(d_part, d_dx)
+    out[rank] = (rp.lo, rp.hi, Y_rows, d_dx.a[:rp.hi - rp.lo].copy())
+    control.shutdown()
+
+
+def test_row_partitioned_propagation_equals_the_whole_product():
+    world = 2
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_rowpart_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    _, _, _, _, A = _graph_problem()
+    n, ld = A.shape[0], 8
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((n, ld)).astype(np.float32); dY = rng.standard_normal((n, ld)).astype(np.float32)
+    Y, dX = A @ X, A.T @ dY
+    assert out[0][0] == 0 and out[0][1] == out[1][0] and out[1][1] == n
+    for r in range(world):
+        lo, hi, Yr, dXr = out[r]
+        np.testing.assert_allclose(Yr, Y[lo:hi], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(dXr, dX[lo:hi], rtol=0, atol=2e-6)

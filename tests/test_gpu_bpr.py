@@ -714,31 +714,6 @@ def test_cross_validation_folds_run_in_child_processes(tmp_path, parallel):
     assert all(0.0 <= float(r.split(":")[1]) <= 1.0 for r in res[1:])
 
 
-def test_two_rank_bench_path_on_one_device(tmp_path):
-    """bench.py's N > 1 path with two real processes (QREC_DIST_TEST_ONE_DEVICE: both on device 0, gloo): users are
-    sharded, the item-table replicas must be IDENTICAL after every step's delta all-reduce, the loss terms are summed
-    over ranks so both device-side drivers log the same losses and take the same learning-rate decisions, and the
-    user tables differ (each rank trains its own users)."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, QREC_DIST_TEST_ONE_DEVICE="1", QREC_DIST_TEST_DUMP=str(tmp_path))
-    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4",
-                          "--warmup", "1", "--no-cpu-baseline", "--shape", "ml1m"], cwd=root, env=env, capture_output=True,
-                         text=True, timeout=600)
-    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
-    line = [l for l in run.stdout.splitlines() if l.startswith("{")][-1]
-    import json
-    out = json.loads(line)
-    assert out["n_gpus"] == 2 and "INVALID_AS_BENCH" in out and out["value"] > 0
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    assert np.array_equal(r0["Q"], r1["Q"])                                   # replicas reconciled exactly
-    assert not np.array_equal(r0["P"], r1["P"])                               # different user shards
-    np.testing.assert_array_equal(r0["log"][:, :2], r1["log"][:, :2])         # same loss, same lr on both ranks
-    assert r0["log"].shape[0] == 5 and float(r0["lr"]) == float(r1["lr"])
-    assert r0["log"][-1, 0] < r0["log"][0, 0]                                 # the summed loss goes down (not every step: the bold driver may halve first)
-
-
 @pytest.mark.parametrize("schedule", ["user", "item"])
 def test_tables_beyond_4_gib_use_64_bit_addressing(schedule):
     """A 4.35 GB user table (17 M rows x 64 floats): the throughput kernels switch from the 32-bit-offset buffer

@@ -1,0 +1,333 @@
+"""GPU tests of the multi-GPU BPR path on the one device the test boxes have:
+
+* the kernels around the collectives (delta / apply, the shard plan, row gather, return of row deltas) against
+  tests/hostkern.py, the numpy statement of the same entry points;
+* the real RCCL binding (qrec_comm_*) with a world of one;
+* the row-sharded exchange with G logical ranks IN ONE PROCESS (threads + an in-process fake collective that copies
+  device to device), the real kernels and the real SGD kernel, against the single-process definition
+      per batch:  Q <- Q + sum_r (cache_r_after - cache_r_before);
+* bench.py's N > 1 paths with two real processes on the one device (staged gloo transport) and with
+  QREC_FORCE_DIST=1 (real RCCL, world 1)."""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import c as O
+from qrec_amd import capi
+from qrec_amd import dist as qd
+from qrec_amd.capi import DeviceBuffer as DB
+from qrec_amd.dist import user_block
+from qrec_amd.synth import make_dataset, to_csr
+from tests import hostkern as HK
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    capi.init(0)
+    yield
+
+
+def test_table_delta_and_apply():
+    rng = np.random.default_rng(0)
+    n = 4 * 12345
+    table, start, other = (rng.standard_normal(n).astype(np.float32) for _ in range(3))
+    d_t, d_s, d_d = DB.from_numpy(table), DB.from_numpy(start), DB(n, np.float32)
+    capi.table_delta(d_t, d_s, d_d, n)
+    assert np.array_equal(d_d.numpy(), table - start)
+    d_d.upload(other)
+    capi.table_apply(d_t, d_s, d_d, n)
+    assert np.array_equal(d_s.numpy(), start + other) and np.array_equal(d_t.numpy(), start + other)
+    with pytest.raises(capi.QRecError):
+        capi.table_delta(d_t, d_s, d_d, 7)
+
+
+@pytest.mark.parametrize("n_items,world,n", [(200, 1, 500), (200, 2, 500), (38048, 8, 150_000), (1_000_003, 8, 400_000),
+                                              (5, 8, 40), (3000, 3, 0), (1025, 2, 1)])
+def test_shard_plan_matches_the_host_statement(n_items, world, n):
+    rng = np.random.default_rng(n_items + world)
+    i = rng.integers(0, n_items, n).astype(np.int32); j = rng.integers(0, n_items, n).astype(np.int32)
+    cap = max(min(2 * n, n_items), 1)
+    d_scr = DB(capi.shard_plan_scratch_bytes(n_items, world), np.uint8)
+    d_req, d_cnt = DB(cap, np.int32), DB(world, np.int32)
+    d_ci, d_cj = DB(max(n, 1), np.int32), DB(max(n, 1), np.int32)
+    d_i, d_j = DB.from_numpy(i if n else np.zeros(1, np.int32)), DB.from_numpy(j if n else np.zeros(1, np.int32))
+    for _ in range(2):            # twice: the scratch map is reused from batch to batch
+        capi.shard_plan_batch(d_i, d_j, n, n_items, world, d_scr, d_req, d_cnt, d_ci, d_cj)
+    h = {k: HK.DeviceBuffer(s, np.int32) for k, s in (("req", cap), ("cnt", world), ("ci", max(n, 1)), ("cj", max(n, 1)))}
+    HK.shard_plan_batch(HK.DeviceBuffer.from_numpy(i), HK.DeviceBuffer.from_numpy(j), n, n_items, world, None, h["req"], h["cnt"],
+                        h["ci"], h["cj"])
+    cnt = d_cnt.numpy()
+    assert np.array_equal(cnt, h["cnt"].a)
+    r = int(cnt.sum())
+    assert np.array_equal(d_req.numpy()[:r], h["req"].a[:r])
+    if n:
+        assert np.array_equal(d_ci.numpy()[:n], h["ci"].a[:n]) and np.array_equal(d_cj.numpy()[:n], h["cj"].a[:n])
+        # what the plan is for: slot -> (owner, row) -> item id gives the triplet's item back
+        owner = np.repeat(np.arange(world), cnt)
+        item_of_slot = d_req.numpy()[:r].astype(np.int64) * world + owner
+        assert np.array_equal(item_of_slot[d_ci.numpy()[:n]], i) and np.array_equal(item_of_slot[d_cj.numpy()[:n]], j)
+
+
+@pytest.mark.parametrize("ld", [32, 64, 128, 256])
+def test_row_gather_and_return_of_deltas(ld):
+    rng = np.random.default_rng(ld)
+    rows_total, n = 5000, 3000
+    table = rng.standard_normal((rows_total, ld)).astype(np.float32)
+    rows = rng.integers(0, rows_total, n).astype(np.int32)             # with repeats: several ranks return the same row
+    d_table, d_rows, d_out = DB.from_numpy(table), DB.from_numpy(rows), DB((n, ld), np.float32)
+    capi.gather_rows(d_table, ld, d_rows, n, d_out)
+    assert np.array_equal(d_out.numpy(), table[rows])
+    fresh = table[rows] + (rng.standard_normal((n, ld)) * 1e-2).astype(np.float32)
+    fresh[::7] = table[rows][::7]                                      # untouched rows come back as they left
+    capi.scatter_add_row_deltas(d_table, ld, d_rows, n, DB.from_numpy(fresh), d_out)
+    want = table.astype(np.float64); np.add.at(want, rows, (fresh - table[rows]).astype(np.float64))
+    np.testing.assert_allclose(d_table.numpy(), want, rtol=0, atol=2e-6)
+    untouched = np.setdiff1d(np.arange(rows_total), rows)
+    assert np.array_equal(d_table.numpy()[untouched], table[untouched])
+    capi.gather_rows(d_table, ld, d_rows, 0, d_out); capi.scatter_add_row_deltas(d_table, ld, d_rows, 0, d_out, d_out)
+    with pytest.raises(capi.QRecError):
+        capi.gather_rows(d_table, 48, d_rows, n, d_out)
+
+
+def test_rccl_binding_with_a_world_of_one():
+    """the real communicator (qrec_comm_init on librccl): every collective of the C ABI, degenerate but live"""
+    path, version = capi.comm_library()
+    assert "rccl" in path and version > 20000
+    comm = capi.Comm(1, 0, capi.comm_unique_id())
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal(4096).astype(np.float32); s = np.array([1.5, -2.0, 7.0])
+    d_a, d_s = DB.from_numpy(a), DB.from_numpy(s)
+    comm.allreduce(d_a, a.size, capi.F32)
+    comm.allreduce_pair(d_a, a.size, capi.F32, d_s, 2, capi.F64)
+    assert np.array_equal(d_a.numpy(), a) and np.array_equal(d_s.numpy(), s)
+    d_b = DB(a.size, np.float32)
+    comm.allgather(d_a, d_b, a.size, capi.F32)
+    assert np.array_equal(d_b.numpy(), a)
+    d_b.fill_bytes(0); comm.reduce_scatter(d_a, d_b, a.size, capi.F32)
+    assert np.array_equal(d_b.numpy(), a)
+    rows = rng.integers(0, 1 << 30, (100, 64)).astype(np.int32)
+    d_r, d_o = DB.from_numpy(rows), DB((100, 64), np.int32)
+    st = capi.Stream()
+    comm.alltoall_rows(d_r, [100], d_o, [100], 256, st); st.sync()
+    assert np.array_equal(d_o.numpy(), rows)
+    comm.alltoall_rows(d_r, [0], d_o, [0], 256)
+    with pytest.raises(ValueError):
+        comm.alltoall_rows(d_r, [1, 2], d_o, [1, 2], 256)
+    with pytest.raises(capi.QRecError):
+        comm.allreduce(d_a, a.size, 9)
+    comm.destroy()
+    with pytest.raises(capi.QRecError):
+        capi.Comm(2, 5, capi.comm_unique_id())
+
+
+# ---- G logical ranks in one process -------------------------------------------------------------------------------
+class _Group:
+    def __init__(self, world):
+        self.world, self.barrier, self.slots = world, threading.Barrier(world), [None] * world
+
+
+class ThreadComm:
+    """in-process fake collective (SURVEY s8e 'testing without a multi-GPU box'): every logical rank is a thread, a
+    collective is a rendezvous + device-to-device copies.  capi.Comm's interface."""
+
+    def __init__(self, group, rank):
+        self.g, self.world, self.rank = group, group.world, rank
+
+    def _swap(self, payload):
+        capi.device_sync()
+        self.g.slots[self.rank] = payload
+        self.g.barrier.wait()
+        everyone = list(self.g.slots)
+        self.g.barrier.wait()
+        return everyone
+
+    def _done(self):
+        capi.device_sync()
+        self.g.barrier.wait()
+
+    def alltoall_rows(self, send, send_rows, recv, recv_rows, row_bytes, stream=None):
+        everyone = self._swap((capi.device_ptr(send) if send is not None else 0, [int(x) for x in send_rows]))
+        off = 0
+        for p, (ptr, rows) in enumerate(everyone):
+            assert rows[self.rank] == int(recv_rows[p])
+            nb = rows[self.rank] * row_bytes
+            if nb:
+                capi.memcpy_d2d(capi.device_ptr(recv) + off, ptr + sum(rows[:self.rank]) * row_bytes, nb)
+            off += nb
+        self._done()
+
+    def allgather(self, send, recv, count, dtype=capi.F32, stream=None):
+        size = {capi.F32: 4, capi.F64: 8, capi.I32: 4}[dtype] * count
+        for p, ptr in enumerate(self._swap(capi.device_ptr(send))):
+            capi.memcpy_d2d(capi.device_ptr(recv) + p * size, ptr, size)
+        self._done()
+
+    def allreduce(self, buf, count, dtype=capi.F32, stream=None):
+        npdt = {capi.F32: np.float32, capi.F64: np.float64, capi.I32: np.int32}[dtype]
+        mine = np.empty(count, npdt); capi.memcpy_d2h(mine, buf, mine.nbytes)
+        total = sum(self._swap(mine))
+        capi.memcpy_h2d(buf, np.ascontiguousarray(total, dtype=npdt), mine.nbytes)
+        self._done()
+
+
+def _tiny_problem(dim):
+    d = make_dataset("small")
+    indptr, ind = to_csr(d["n_users"], d["train_u"], d["train_i"])
+    rng = np.random.default_rng(4)
+    return d, indptr, ind, rng.random((d["n_users"], dim)) / 3, (rng.random((d["n_items"], dim)) / 3).astype(np.float32)
+
+
+def _rank_triplets(indptr, ind, lo, hi, n_items, seed, schedule):
+    lp, li = (indptr[lo:hi + 1] - indptr[lo]).astype(np.int64), np.ascontiguousarray(ind[indptr[lo]:indptr[hi]])
+    u = np.repeat(np.arange(hi - lo, dtype=np.int32), np.diff(lp)).astype(np.int32)
+    j = O.bpr_sample_epoch(O.MT.cpython_seed(seed), lp, li, n_items)
+    if schedule == "item":
+        perm = np.argsort(li, kind="stable")
+        u, li, j = u[perm], li[perm], j[perm]
+    return np.ascontiguousarray(u), np.ascontiguousarray(li), np.ascontiguousarray(j)
+
+
+@pytest.mark.parametrize("world,n_batches,dim", [(2, 3, 16), (3, 2, 64), (1, 2, 16)])
+def test_sharded_item_table_with_logical_ranks_equals_the_definition(world, n_batches, dim):
+    """ShardedItemExchange + the real kernels, G logical ranks on one device.  The SGD kernel runs with ONE group, where
+    it is the sequential recurrence, so the whole protocol is deterministic and comparable to the oracle."""
+    from qrec_amd.engine import padded_ld
+    d, indptr, ind, P0, Q0 = _tiny_problem(dim)
+    U, I = d["n_users"], d["n_items"]
+    ld = padded_ld(dim, np.float32)
+    lr, ru, ri = 0.05, 0.01, 0.02
+    group = _Group(world)
+    result, errors = [None] * world, []
+
+    def pad(a):
+        out = np.zeros((a.shape[0], ld), np.float32); out[:, :a.shape[1]] = a
+        return out
+
+    def run(rank):
+        try:
+            capi.init(0)
+            comm = ThreadComm(group, rank)
+            lo, hi = user_block(U, world, rank)
+            d_P = DB.from_numpy(pad(P0[lo:hi].astype(np.float32)))
+            d_Q = DB.from_numpy(pad(qd.shard_item_rows(Q0, world, rank)))
+            ex = qd.ShardedItemExchange(comm, I, ld, d_Q)
+            d_loss = DB.zeros(1, np.float64)
+            for step in range(2):
+                u, li, j = _rank_triplets(indptr, ind, lo, hi, I, 100 * step + rank, "user")
+                d_u, d_i, d_j = DB.from_numpy(u), DB.from_numpy(li), DB.from_numpy(j)
+                ex.plan_epoch(d_i, d_j, u.size, n_batches)
+                ex.run_epoch(lambda t0, nb, cache, rows, ci, cj, st: capi.bpr_sgd_hogwild(
+                    d_P, cache, dim, ld, d_u.ptr + 4 * t0, ci, cj, nb, 32, 1, lr, ru, ri, d_loss, capi.HW_ATOMIC, st,
+                    p_rows=hi - lo, q_rows=rows))
+            capi.device_sync()
+            result[rank] = (lo, hi, d_P.numpy()[:, :dim], d_Q.numpy()[:, :dim], float(d_loss.numpy()[0]), ex.bytes_moved)
+        except Exception as e:      # noqa: BLE001 -- a failing rank must not leave the others at the barrier
+            errors.append(e); group.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    # single-process statement
+    Q = Q0.astype(np.float64); P = P0.copy(); loss = 0.0
+    for step in range(2):
+        work = []
+        for r in range(world):
+            lo, hi = user_block(U, world, r)
+            u, li, j = _rank_triplets(indptr, ind, lo, hi, I, 100 * step + r, "user")
+            work.append((lo, hi, u, li, j, -(-u.size // n_batches)))
+        for b in range(n_batches):
+            deltas = np.zeros_like(Q)
+            for lo, hi, u, li, j, per in work:
+                t0, t1 = min(b * per, u.size), min((b + 1) * per, u.size)
+                if t1 == t0:
+                    continue
+                items = np.unique(np.concatenate([li[t0:t1], j[t0:t1]]))
+                slot = np.full(I, -1, np.int32); slot[items] = np.arange(items.size, dtype=np.int32)
+                cache = Q[items].copy(); Pr = P[lo:hi].copy()
+                loss += O.bpr_sgd(Pr, cache, u[t0:t1], slot[li[t0:t1]], slot[j[t0:t1]], lr, ru, ri)
+                P[lo:hi] = Pr
+                deltas[items] += cache - Q[items]
+            Q += deltas
+    got_loss = 0.0
+    for r in range(world):
+        lo, hi, Pr, Qr, l, moved = result[r]
+        assert rel_err(Pr, P[lo:hi]) < 1e-5 and rel_err(Qr, Q[r::world]) < 1e-5
+        assert (moved > 0) == (world > 1)
+        got_loss += l
+    assert abs(got_loss - loss) / loss < 1e-5
+    assert rel_err(Q, Q0.astype(np.float64)) > 1e-3
+
+
+# ---- bench.py's N > 1 paths on the one device ----------------------------------------------------------------------
+def _bench(args, env_extra, nproc=None, port=29541, timeout=900):
+    env = dict(os.environ, **env_extra)
+    cmd = [sys.executable]
+    if nproc:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    cmd += [os.path.join(ROOT, "bench.py")] + args
+    run = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
+    return json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_two_rank_bench_path_on_one_device(tmp_path):
+    """replicated item table, two real processes (both on device 0, staged gloo transport): users are sharded, the
+    item-table replicas must be IDENTICAL after every epoch's delta all-reduce, the loss terms ride in the same
+    collective so both device-side drivers log the same losses and take the same learning-rate decisions, and the
+    user tables differ (each rank trains its own users)."""
+    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs-per-step", "2", "--no-cpu-baseline", "--shape", "ml1m"],
+                 {"QREC_DIST_TEST_ONE_DEVICE": "1", "QREC_DIST_TEST_DUMP": str(tmp_path)}, nproc=2)
+    assert out["n_gpus"] == 2 and "INVALID_AS_BENCH" in out and out["value"] > 0 and out["scaling"] == "weak"
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["Q"], r1["Q"])                                   # replicas reconciled exactly
+    assert not np.array_equal(r0["P"], r1["P"])                               # different user shards
+    np.testing.assert_array_equal(r0["log"][:, :2], r1["log"][:, :2])         # same loss, same lr on both ranks
+    assert r0["log"].shape[0] == 5 + 3 * 2 and float(r0["lr"]) == float(r1["lr"])
+    assert r0["log"][-1, 0] < r0["log"][0, 0]                                 # the summed loss goes down (not every step: the bold driver may halve first)
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_two_rank_bench_path_with_row_sharded_item_table(tmp_path, scaling):
+    """--dist-mode sharded: each rank holds half of the item rows; the epoch's batches fetch and return rows through
+    the all-to-all exchange.  Both drivers see the same all-reduced loss terms; the run trains (loss goes down) and
+    the two shards together are a table that moved on every row the epoch touched."""
+    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs-per-step", "2", "--no-cpu-baseline", "--shape", "ml1m",
+                  "--dist-mode", "sharded", "--shard-batch", "100000", "--scaling", scaling],
+                 {"QREC_DIST_TEST_ONE_DEVICE": "1", "QREC_DIST_TEST_DUMP": str(tmp_path)}, nproc=2, port=29543)
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["value"] > 0
+    assert out["config"]["batches_per_epoch"] >= (5 if scaling == "strong" else 10) and out["config"]["xgmi_bytes_per_epoch_all_ranks"] > 0
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    I = 3706
+    assert r0["Q"].shape[0] == (I + 1) // 2 and r1["Q"].shape[0] == I // 2    # items 0,2,4.. / 1,3,5..
+    np.testing.assert_array_equal(r0["log"][:, :2], r1["log"][:, :2])
+    assert np.isfinite(r0["Q"]).all() and np.isfinite(r1["Q"]).all()
+    assert r0["log"][-1, 0] < r0["log"][0, 0]
+    Q0 = (np.random.default_rng(999).random((I, 64)) / 3).astype(np.float32)
+    assert (np.abs(r0["Q"][:, :64] - Q0[0::2]).max(1) > 0).mean() > 0.99 and (np.abs(r1["Q"][:, :64] - Q0[1::2]).max(1) > 0).mean() > 0.99
+
+
+@pytest.mark.parametrize("mode", ["replicated", "sharded"])
+def test_bench_multi_gpu_path_on_real_rccl_world_one(mode):
+    """QREC_FORCE_DIST=1: the N > 1 code path on the real RCCL communicator (world 1): delta / apply kernels or the
+    all-to-all exchange with itself.  Must train exactly like the plain single-GPU path does (same seeds, same kernels):
+    the loss after the same number of epochs agrees closely (Hogwild timing aside)."""
+    a = _bench(["--steps", "2", "--warmup", "1", "--epochs-per-step", "3", "--no-cpu-baseline", "--no-extras", "--shape", "ml1m",
+                "--dist-mode", mode], {"QREC_FORCE_DIST": "1", "MASTER_PORT": "29547"})
+    b = _bench(["--steps", "2", "--warmup", "1", "--epochs-per-step", "3", "--no-cpu-baseline", "--no-extras", "--shape", "ml1m"], {})
+    assert a["n_gpus"] == 1 and "FORCE_DIST" in a["config"]["parallelism"]
+    assert a["config"]["final_loss"] == pytest.approx(b["config"]["final_loss"], rel=0.02)
+    assert a["config"]["final_lr"] == b["config"]["final_lr"]

@@ -3,7 +3,7 @@
 committed under profiles/.  usage: tools/summarize_prof.py <round-tag> [workload-tag]"""
 import json, os, sqlite3, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-workload = sys.argv[2] if len(sys.argv) > 2 else "bpr-yelp2018-d64"
+workload = sys.argv[2] if len(sys.argv) > 2 else "bpr-yelp2018-d64-item"
 G = "gpurun_out"; os.makedirs("profiles", exist_ok=True)
 def q(db, sql):
     con = sqlite3.connect(db); rows = list(con.execute(sql)); con.close(); return rows
