@@ -112,6 +112,28 @@ int qrec_bpr_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
                          const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int64_t n,
                          double lr, double regU, double regI, double *d_loss, void *stream);
 
+/* Order-exact mode beyond one wavefront.  The negatives are drawn before the first update (sampling never looks at the
+ * embeddings), so the epoch's dependence DAG -- triplet t waits for the previous toucher of P[u], Q[i], Q[j], nothing
+ * else -- is known up front.  qrec_bpr_exact_schedule (host) list-schedules the triplets, in the reference's order, into
+ * steps of at most `width` mutually independent triplets and records for every row where its current value will be
+ * (LDS forwarding slot of one of the last two steps, or the table); qrec_bpr_sgd_scheduled executes the steps with one
+ * workgroup of `width` wavefronts, one barrier per step.  Every row sees exactly the reference's sequence of updates:
+ * results equal qrec_bpr_sgd_ordered's bit for bit (same per-triplet arithmetic), the loss up to its summation order.
+ *   h_entries   : int32[n][8] out, step-major: {u, i, j, t, src_P, src_Qi, src_Qj, 0}
+ *   h_step_off  : int32[n + 1] capacity out; entries of step s are [h_step_off[s], h_step_off[s+1])
+ *   width       : <= qrec_bpr_exact_width(dtype, d) (what the CU's LDS holds), <= QREC_EXACT_MAX_WIDTH
+ *   d_xlog      : table-dtype[n + QREC_EXACT_XLOG_PAD] scratch (x per triplet, then the dummy rows idle wavefronts work on),
+ *   d_scratch   : double[QREC_EXACT_SCRATCH_WORDS], zero before first use */
+#define QREC_EXACT_MAX_WIDTH 16
+#define QREC_EXACT_XLOG_PAD (16 * 256 + 64)
+#define QREC_EXACT_SCRATCH_WORDS 130
+int qrec_bpr_exact_width(int dtype, int32_t d, int32_t *width);
+int qrec_bpr_exact_schedule(const int32_t *h_u, const int32_t *h_i, const int32_t *h_j, int64_t n, int32_t n_users,
+                            int32_t n_items, int32_t width, int32_t *h_entries, int32_t *h_step_off, int64_t *n_steps);
+int qrec_bpr_sgd_scheduled(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld, const int32_t *d_entries,
+                           const int32_t *d_step_off, int64_t n_steps, int32_t width, int64_t n, double lr, double regU,
+                           double regI, void *d_xlog, double *d_scratch, double *d_loss, void *stream);
+
 /* Throughput mode (fp32): triplets are cut into chunks of `chunk` consecutive entries;
  * one 16-lane (d<=64) / 32-lane (d<=128) group owns a chunk, keeps P[u] in registers
  * along a user run, and applies every row update as an atomic add of the exact
@@ -465,6 +487,16 @@ int qrec_alltoall_rows(void *comm, const void *d_send, const int64_t *h_send_row
 /* Replicated item table (every rank trains its own users against a full copy of Q): after a step
  *     delta = Q - Q_start;  all-reduce(delta);  Q_start += delta;  Q = Q_start
  * so that every rank's updates are kept and the replicas stay bit-identical.  n = rows*ld floats (multiple of 4).     */
+/* The same around the step's ONE collective, fused with the epoch's loss terms (fp32 tables; users sharded, items
+ * replicated): qrec_dist_epoch_pre = { delta = Q - Q_start; d_stats[1] = sum P*P of this rank's users }, the caller
+ * all-reduces {d_delta, d_stats[0..1]} (qrec_allreduce_pair), qrec_dist_epoch_post = { Q_start += delta; Q = Q_start;
+ * d_stats[2] = sum Q*Q; the reference's epoch decision as in qrec_epoch_close }.  Sums are taken in block order:
+ * every rank computes the same bits and takes the same decision.                                                    */
+int qrec_dist_epoch_pre(const float *d_P, int64_t p_rows, int32_t ld, const float *d_Q, const float *d_Q_start,
+                        float *d_delta, int64_t q_rows, double *d_stats, const double *d_state, void *stream);
+int qrec_dist_epoch_post(float *d_Q, float *d_Q_start, const float *d_delta, int64_t q_rows, int32_t ld, double *d_stats,
+                         double *d_state, double regU, double regI, double max_lr, double tol, double *d_log,
+                         int64_t log_capacity, void *stream);
 int qrec_table_delta(const float *d_table, const float *d_start, float *d_delta, int64_t n, void *stream);
 int qrec_table_apply(float *d_table, float *d_start, const float *d_delta, int64_t n, void *stream);
 

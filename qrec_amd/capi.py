@@ -50,6 +50,9 @@ _SIGNATURES = {
     "qrec_mt_pairwise_sample_epoch": [_vp, _vp, _i64, _vp, _vp, _i32, _vp],
     "qrec_philox_bpr_sample": [_vp, _vp, _vp, _i64, _i32, _u64, _u64, _vp, _vp],
     "qrec_bpr_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _vp, _vp],
+    "qrec_bpr_exact_width": [C.c_int, _i32, _vp],
+    "qrec_bpr_exact_schedule": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
+    "qrec_bpr_sgd_scheduled": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _i64, _i32, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp],
     "qrec_bpr_sgd_hogwild": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _vp, C.c_int, _vp, _vp],
     "qrec_bpr_sgd_hogwild_item_major": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp],
     "qrec_epoch_close": [_vp, _i64, _vp, _i64, C.c_int, _i32, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
@@ -111,6 +114,8 @@ _SIGNATURES = {
     "qrec_allgather": [_vp, _vp, _vp, _i64, C.c_int, _vp],
     "qrec_reduce_scatter": [_vp, _vp, _vp, _i64, C.c_int, _vp],
     "qrec_alltoall_rows": [_vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "qrec_dist_epoch_pre": [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "qrec_dist_epoch_post": [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
     "qrec_table_delta": [_vp, _vp, _vp, _i64, _vp],
     "qrec_table_apply": [_vp, _vp, _vp, _i64, _vp],
     "qrec_shard_rows": [_i64, _i32, _i32, _vp],
@@ -500,6 +505,31 @@ def bpr_sgd_ordered(d_P, d_Q, dtype: int, d: int, ld: int, d_u, d_i, d_j, n: int
                                        n, lr, regU, regI, _dp(d_loss), _sh(stream)))
 
 
+EXACT_MAX_WIDTH, EXACT_SCRATCH_WORDS, EXACT_XLOG_PAD = 16, 130, 16 * 256 + 64
+
+
+def bpr_exact_width(dtype: int, d: int) -> int:
+    w = _i32(0)
+    _check(load().qrec_bpr_exact_width(dtype, d, C.byref(w)))
+    return w.value
+
+
+def bpr_exact_schedule(u: np.ndarray, i: np.ndarray, j: np.ndarray, n_users: int, n_items: int, width: int):
+    """static schedule of an epoch's triplets (include/qrec_hip.h): (entries int32[n, 8] step-major, step_off int32[n_steps + 1])"""
+    _req(u, np.int32, "u"); _req(i, np.int32, "i"); _req(j, np.int32, "j")
+    n = int(u.size)
+    entries = np.empty((max(n, 1), 8), dtype=np.int32); off = np.empty(n + 2, dtype=np.int32)
+    steps = C.c_int64(0)
+    _check(load().qrec_bpr_exact_schedule(_hp(u), _hp(i), _hp(j), n, n_users, n_items, width, _hp(entries), _hp(off), C.byref(steps)))
+    return entries[:n], off[:steps.value + 1].copy()
+
+
+def bpr_sgd_scheduled(d_P, d_Q, dtype: int, d: int, ld: int, d_entries, d_step_off, n_steps: int, width: int, n: int, lr: float,
+                      regU: float, regI: float, d_xlog, d_scratch, d_loss, stream=None):
+    _check(load().qrec_bpr_sgd_scheduled(_dp(d_P), _dp(d_Q), dtype, d, ld, _dp(d_entries), _dp(d_step_off), n_steps, width, n, lr, regU,
+                                         regI, _dp(d_xlog), _dp(d_scratch), _dp(d_loss), _sh(stream)))
+
+
 def _table_rows(buf, ld: int) -> int:
     """rows of a [rows][ld] fp32 table held in a DeviceBuffer"""
     return int(buf.nbytes // (4 * ld))
@@ -835,6 +865,17 @@ class Comm:
             self.destroy()
         except Exception:
             pass
+
+
+def dist_epoch_pre(d_P, p_rows: int, ld: int, d_Q, d_Q_start, d_delta, q_rows: int, d_stats, d_state=None, stream=None):
+    _check(load().qrec_dist_epoch_pre(_dp(d_P), p_rows, ld, _dp(d_Q), _dp(d_Q_start), _dp(d_delta), q_rows, _dp(d_stats),
+                                      _dp(d_state), _sh(stream)))
+
+
+def dist_epoch_post(d_Q, d_Q_start, d_delta, q_rows: int, ld: int, d_stats, d_state, regU: float, regI: float, max_lr: float,
+                    tol: float, d_log=None, log_capacity: int = 0, stream=None):
+    _check(load().qrec_dist_epoch_post(_dp(d_Q), _dp(d_Q_start), _dp(d_delta), q_rows, ld, _dp(d_stats), _dp(d_state), regU, regI,
+                                       max_lr, tol, _dp(d_log), log_capacity, _sh(stream)))
 
 
 def table_delta(d_table, d_start, d_delta, n: int, stream=None):

@@ -131,6 +131,80 @@ __global__ void epoch_decide_kernel(double *__restrict__ stats, double *__restri
     driver_decide(stats, state, regU, regI, max_lr, tol, log, log_capacity);
 }
 
+
+// ---- multi-GPU epoch close, replicated item table (qrec_amd/dist.py) -------------------------------------------------
+// Two launches around the step's one collective instead of five:
+//   dist_pre :  delta = Q - Q_start  and  stats[1] = sum P*P              (P is this rank's user shard)
+//   ... all-reduce {delta, stats[0..1]} ...
+//   dist_post:  Q_start += delta; Q = Q_start;  stats[2] = sum Q*Q of the reconciled table;  the reference's decision.
+// Block partials are added in block order by the last block (ticket), so the sums -- hence the decision -- are
+// bit-identical on every rank.
+__device__ inline bool last_block_total(double mine, int lane_of_pair, double *__restrict__ stats, double *total) {
+    __shared__ bool s_last;
+    __shared__ double s_tot[4];
+    double *part = stats + QREC_STATS_PARTIALS;
+    unsigned int *ticket = reinterpret_cast<unsigned int *>(stats + 3);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(part + 2 * blockIdx.x + lane_of_pair, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return false;
+    __threadfence();
+    double t = 0.0;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x)
+        t += __hip_atomic_load(part + 2 * b + lane_of_pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, kWave);
+    if ((threadIdx.x & 63) == 0) s_tot[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x != 0) return false;
+    *total = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+    *ticket = 0u;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void dist_pre_kernel(const float *__restrict__ P, int64_t p_elems, const float4 *__restrict__ Q,
+                                                       const float4 *__restrict__ start, float4 *__restrict__ delta,
+                                                       int64_t q4, double *__restrict__ stats, const double *__restrict__ state) {
+    if (state && (state[QREC_DRV_CONVERGED] != 0.0 || state[QREC_DRV_FAILED] != 0.0)) return;
+    __shared__ double s_part[4];
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < q4; k += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = Q[k], b = start[k];
+        delta[k] = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+    }
+    const double sp = block_sumsq<float, float4>(P, p_elems, s_part);
+    double total;
+    if (last_block_total(sp, 0, stats, &total)) stats[1] = total;
+}
+
+__global__ __launch_bounds__(256) void dist_post_kernel(float4 *__restrict__ Q, float4 *__restrict__ start,
+                                                        const float4 *__restrict__ delta, int64_t q4, double *__restrict__ stats,
+                                                        double *__restrict__ state, double regU, double regI, double max_lr,
+                                                        double tol, double *__restrict__ log, int64_t log_capacity) {
+    if (state[QREC_DRV_CONVERGED] != 0.0 || state[QREC_DRV_FAILED] != 0.0) return;
+    double acc = 0.0;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < q4; k += (int64_t)gridDim.x * blockDim.x) {
+        const float4 s = start[k], d = delta[k];
+        const float4 r = make_float4(s.x + d.x, s.y + d.y, s.z + d.z, s.w + d.w);
+        start[k] = r;
+        Q[k] = r;
+        acc += (double)r.x * r.x + (double)r.y * r.y + (double)r.z * r.z + (double)r.w * r.w;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, kWave);
+    __shared__ double s_part[4];
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    const double sq = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    double total;
+    if (last_block_total(sq, 1, stats, &total)) {
+        stats[2] = total;
+        driver_decide(stats, state, regU, regI, max_lr, tol, log, log_capacity);
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -212,6 +286,36 @@ extern "C" int qrec_sumsq(const void *d_x, int dtype, int64_t rows, int32_t d, i
     else
         hipLaunchKernelGGL((sumsq_kernel<double, double4>), dim3((unsigned)blocks), dim3(256), 0, st,
                            (const double *)d_x, n, d_out);
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+extern "C" int qrec_dist_epoch_pre(const float *d_P, int64_t p_rows, int32_t ld, const float *d_Q, const float *d_Q_start,
+                                   float *d_delta, int64_t q_rows, double *d_stats, const double *d_state, void *stream) {
+    QREC_REQUIRE(d_P && d_Q && d_Q_start && d_delta && d_stats && p_rows >= 0 && q_rows >= 0 && ld >= 4 && ld % 4 == 0,
+                 "qrec_dist_epoch_pre: bad arguments");
+    const int64_t pe = p_rows * (int64_t)ld, q4 = q_rows * (int64_t)ld / 4;
+    int64_t blocks = ((pe / 4 > q4 ? pe / 4 : q4) + 255) / 256;
+    if (blocks > QREC_STATS_MAX_BLOCKS) blocks = QREC_STATS_MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(dist_pre_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), d_P, pe, (const float4 *)d_Q,
+                       (const float4 *)d_Q_start, (float4 *)d_delta, q4, d_stats, d_state);
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+extern "C" int qrec_dist_epoch_post(float *d_Q, float *d_Q_start, const float *d_delta, int64_t q_rows, int32_t ld,
+                                    double *d_stats, double *d_state, double regU, double regI, double max_lr, double tol,
+                                    double *d_log, int64_t log_capacity, void *stream) {
+    QREC_REQUIRE(d_Q && d_Q_start && d_delta && d_stats && d_state && q_rows >= 0 && ld >= 4 && ld % 4 == 0,
+                 "qrec_dist_epoch_post: bad arguments");
+    QREC_REQUIRE(log_capacity == 0 || d_log, "qrec_dist_epoch_post: log capacity without a log");
+    const int64_t q4 = q_rows * (int64_t)ld / 4;
+    int64_t blocks = (q4 + 255) / 256;
+    if (blocks > QREC_STATS_MAX_BLOCKS) blocks = QREC_STATS_MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(dist_post_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (float4 *)d_Q, (float4 *)d_Q_start,
+                       (const float4 *)d_delta, q4, d_stats, d_state, regU, regI, max_lr, tol, d_log, log_capacity);
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }

@@ -216,11 +216,14 @@ class ShardedItemExchange:
             b = self._cap[name] = self.k.DeviceBuffer(max(int(elems * 1.25), 1), dtype)
         return b
 
-    def plan_epoch(self, d_i, d_j, n: int, n_batches: int, stream=None):
+    def plan_epoch(self, d_i, d_j, n: int, n_batches: int, stream=None, bounds=None):
+        """``bounds``: the batches' triplet ranges (n_batches + 1 offsets); default = equal consecutive ranges"""
         k, G = self.k, self.world
         self.n, self.n_batches = int(n), int(n_batches)
         per = -(-self.n // self.n_batches) if self.n else 0
-        self.bounds = [min(b * per, self.n) for b in range(self.n_batches + 1)]
+        self.bounds = [int(x) for x in bounds] if bounds is not None else [min(b * per, self.n) for b in range(self.n_batches + 1)]
+        if len(self.bounds) != self.n_batches + 1 or self.bounds[0] != 0 or self.bounds[-1] != self.n:
+            raise ValueError("plan_epoch: bounds must run from 0 to n in n_batches steps")
         caps = [min(2 * (self.bounds[b + 1] - self.bounds[b]), self.n_items) for b in range(self.n_batches)]
         self.req_off = np.concatenate([[0], np.cumsum(caps)]).astype(np.int64)
         d_req = self._buf("req", int(self.req_off[-1]), np.int32)
@@ -280,7 +283,7 @@ class ShardedStep:
         self.comm, self.exchange, self.n_batches = comm, exchange, int(n_batches)
 
     def prepare(self, sgd, stream=None):
-        self.exchange.plan_epoch(sgd.d_i, sgd.d_j, sgd.n, self.n_batches, stream)
+        self.exchange.plan_epoch(sgd.d_i, sgd.d_j, sgd.n, self.n_batches, stream, bounds=sgd.batch_bounds)
 
 
 def agree_on_batches(control: ControlPlane, n_local: int, batch: int) -> int:

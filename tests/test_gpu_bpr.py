@@ -933,3 +933,64 @@ def test_ordered_kernel_is_order_exact_under_heavy_aliasing(dtype, tol, n_items,
     capi.bpr_sgd_ordered(t.P, t.Q, t.code, dim, t.ld, DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), n, 0.02, 0.01, 0.02, loss)
     Pg, Qg = t.download(np.float64)
     assert rel_err(Pg, Pr) < tol and rel_err(Qg, Qr) < tol and abs(float(loss.numpy()[0]) - want) / want < tol
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("dim", [64, 24, 128, 200])
+def test_scheduled_exact_kernel_equals_the_walker_bit_for_bit(dtype, dim):
+    """Order-exact mode beyond one wavefront (qrec_bpr_exact_schedule + qrec_bpr_sgd_scheduled): the same triplets, every
+    row seeing the same sequence of updates with the same per-triplet arithmetic as the one-wavefront walker -- so P and
+    Q must be IDENTICAL for every width (forwarding through LDS, prefetched table rows, idle wavefronts on dummy rows),
+    and the loss equal up to its summation order."""
+    d, indptr, ind, u, j = _synthetic("small")
+    U, I, n = d["n_users"], d["n_items"], ind.size
+    rng = np.random.default_rng(dim)
+    P0 = rng.random((U, dim)) / 3; Q0 = rng.random((I, dim)) / 3
+    lr, ru, ri = 0.05, 0.01, 0.02
+    t = DeviceTables(P0, Q0, dtype)
+    sgd = BprSgd(t, u, ind); sgd.set_negatives(j)
+    want_loss = sgd.epoch_ordered(lr, ru, ri, width=1)              # the walker
+    Pw, Qw = t.P.numpy(), t.Q.numpy()
+    for width in (2, 5, 8, 16):
+        width = min(width, capi.bpr_exact_width(t.code, dim))
+        t.upload(P0, Q0)
+        loss = sgd.epoch_ordered(lr, ru, ri, width=width)
+        assert np.array_equal(t.P.numpy(), Pw) and np.array_equal(t.Q.numpy(), Qw), width
+        assert loss == pytest.approx(want_loss, rel=1e-12 if dtype == np.float64 else 1e-6)
+        assert sgd.exact_steps < n                                   # it did overlap independent triplets
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, F64_TOL), (np.float32, 5e-5)])
+@pytest.mark.parametrize("n_items,n", [(2, 301), (3, 1000), (7, 4097)])
+def test_scheduled_exact_kernel_under_heavy_aliasing(dtype, tol, n_items, n):
+    """a handful of items: almost every row comes out of the forwarding buffers of the last two steps"""
+    rng = np.random.default_rng(n_items * 1000 + n)
+    U, dim = 5, 24
+    u = np.sort(rng.integers(0, U, n)).astype(np.int32)
+    i = rng.integers(0, n_items, n).astype(np.int32)
+    j = ((i + 1 + rng.integers(0, n_items - 1, n)) % n_items).astype(np.int32)      # j != i
+    P0, Q0 = rng.random((U, dim)) / 3, rng.random((n_items, dim)) / 3
+    Pr, Qr = P0.astype(dtype), Q0.astype(dtype)
+    want = O.bpr_sgd(Pr, Qr, u, i, j, 0.02, 0.01, 0.02)
+    t = DeviceTables(P0, Q0, dtype)
+    sgd = BprSgd(t, u, i); sgd.set_negatives(j)
+    loss = sgd.epoch_ordered(0.02, 0.01, 0.02, width=16)
+    Pg, Qg = t.download(np.float64)
+    assert rel_err(Pg, Pr) < tol and rel_err(Qg, Qr) < tol and abs(loss - want) / want < tol
+
+
+def test_scheduled_exact_kernel_full_yelp_epoch_matches_the_oracle():
+    """BASELINE.json's shape (1.25 M triplets, d=64), fp64: the whole epoch against the plain-C restatement of
+    model/ranking/BPR.py:29-53 -- the numeric contract (1e-10) at full size, ~209 k steps for 1.25 M triplets."""
+    d, indptr, ind, u, j = _synthetic("yelp2018")
+    U, I = d["n_users"], d["n_items"]
+    rng = np.random.default_rng(3)
+    P0 = rng.random((U, 64)) / 3; Q0 = rng.random((I, 64)) / 3
+    Pr, Qr = P0.copy(), Q0.copy()
+    want = O.bpr_sgd(Pr, Qr, u, ind, j, 0.01, 0.001, 0.001)
+    t = DeviceTables(P0, Q0, np.float64)
+    sgd = BprSgd(t, u, ind); sgd.set_negatives(j)
+    loss = sgd.epoch_ordered(0.01, 0.001, 0.001)
+    Pg, Qg = t.download()
+    assert rel_err(Pg, Pr) < 1e-10 and rel_err(Qg, Qr) < 1e-10 and abs(loss - want) / want < F64_TOL
+    assert sgd.exact_steps < ind.size // 4

@@ -289,14 +289,14 @@ def test_two_rank_bench_path_on_one_device(tmp_path):
     item-table replicas must be IDENTICAL after every epoch's delta all-reduce, the loss terms ride in the same
     collective so both device-side drivers log the same losses and take the same learning-rate decisions, and the
     user tables differ (each rank trains its own users)."""
-    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs-per-step", "2", "--no-cpu-baseline", "--shape", "ml1m"],
+    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs-per-step", "3", "--no-cpu-baseline", "--shape", "ml1m"],
                  {"QREC_DIST_TEST_ONE_DEVICE": "1", "QREC_DIST_TEST_DUMP": str(tmp_path)}, nproc=2)
     assert out["n_gpus"] == 2 and "INVALID_AS_BENCH" in out and out["value"] > 0 and out["scaling"] == "weak"
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     assert np.array_equal(r0["Q"], r1["Q"])                                   # replicas reconciled exactly
     assert not np.array_equal(r0["P"], r1["P"])                               # different user shards
     np.testing.assert_array_equal(r0["log"][:, :2], r1["log"][:, :2])         # same loss, same lr on both ranks
-    assert r0["log"].shape[0] == 5 + 3 * 2 and float(r0["lr"]) == float(r1["lr"])
+    assert r0["log"].shape[0] == 3 and float(r0["lr"]) == float(r1["lr"])        # the last step's epochs (every step restarts)
     assert r0["log"][-1, 0] < r0["log"][0, 0]                                 # the summed loss goes down (not every step: the bold driver may halve first)
 
 
@@ -305,7 +305,7 @@ def test_two_rank_bench_path_with_row_sharded_item_table(tmp_path, scaling):
     """--dist-mode sharded: each rank holds half of the item rows; the epoch's batches fetch and return rows through
     the all-to-all exchange.  Both drivers see the same all-reduced loss terms; the run trains (loss goes down) and
     the two shards together are a table that moved on every row the epoch touched."""
-    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs-per-step", "2", "--no-cpu-baseline", "--shape", "ml1m",
+    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs-per-step", "3", "--no-cpu-baseline", "--shape", "ml1m",
                   "--dist-mode", "sharded", "--shard-batch", "100000", "--scaling", scaling],
                  {"QREC_DIST_TEST_ONE_DEVICE": "1", "QREC_DIST_TEST_DUMP": str(tmp_path)}, nproc=2, port=29543)
     assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["value"] > 0
@@ -323,11 +323,12 @@ def test_two_rank_bench_path_with_row_sharded_item_table(tmp_path, scaling):
 @pytest.mark.parametrize("mode", ["replicated", "sharded"])
 def test_bench_multi_gpu_path_on_real_rccl_world_one(mode):
     """QREC_FORCE_DIST=1: the N > 1 code path on the real RCCL communicator (world 1): delta / apply kernels or the
-    all-to-all exchange with itself.  Must train exactly like the plain single-GPU path does (same seeds, same kernels):
-    the loss after the same number of epochs agrees closely (Hogwild timing aside)."""
+    all-to-all exchange with itself.  Must train like the plain single-GPU path does (same seeds, same kernels): the
+    loss after the same number of epochs agrees closely (Hogwild timing, and for the sharded layout the batch-start
+    snapshots of the item rows, aside)."""
     a = _bench(["--steps", "2", "--warmup", "1", "--epochs-per-step", "3", "--no-cpu-baseline", "--no-extras", "--shape", "ml1m",
                 "--dist-mode", mode], {"QREC_FORCE_DIST": "1", "MASTER_PORT": "29547"})
     b = _bench(["--steps", "2", "--warmup", "1", "--epochs-per-step", "3", "--no-cpu-baseline", "--no-extras", "--shape", "ml1m"], {})
     assert a["n_gpus"] == 1 and "FORCE_DIST" in a["config"]["parallelism"]
-    assert a["config"]["final_loss"] == pytest.approx(b["config"]["final_loss"], rel=0.02)
+    assert a["config"]["final_loss"] == pytest.approx(b["config"]["final_loss"], rel=0.03)
     assert a["config"]["final_lr"] == b["config"]["final_lr"]

@@ -541,3 +541,48 @@ def test_tbpr_native_sampler_equals_cpython_random_on_random_problems(seed):
         capi.mt_shuffle(words, n_train)
         assert list(zip(u_.tolist(), a_.tolist(), b_.tolist())) == want
         assert np.array_equal(words, capi.state_from_python(random.getstate()))
+
+
+@pytest.mark.parametrize("width", [1, 3, 16])
+def test_exact_schedule_respects_every_dependence(width):
+    """qrec_bpr_exact_schedule (order-exact mode beyond one wavefront): a partition of the epoch's triplets into steps
+    of <= width, every row's touchers in strictly increasing steps in the reference's order, and every source code
+    pointing at that row's previous toucher (forwarding slot when it is 1 or 2 steps back, the table otherwise)."""
+    from qrec_amd import capi
+    rng = np.random.default_rng(width)
+    U, I, n = 40, 25, 3000                      # few rows: long chains, plenty of forwarding
+    u = np.sort(rng.integers(0, U, n)).astype(np.int32)
+    i = rng.integers(0, I, n).astype(np.int32)
+    j = ((i + 1 + rng.integers(0, I - 1, n)) % I).astype(np.int32)
+    ent, off = capi.bpr_exact_schedule(u, i, j, U, I, width)
+    steps = off.size - 1
+    assert off[0] == 0 and off[-1] == n and (np.diff(off) >= 1).all() and np.diff(off).max() <= width
+    assert sorted(ent[:, 3].tolist()) == list(range(n))
+    t = ent[:, 3]
+    assert np.array_equal(ent[:, 0], u[t]) and np.array_equal(ent[:, 1], i[t]) and np.array_equal(ent[:, 2], j[t])
+    step_of = np.empty(n, np.int64); slot_of = np.empty(n, np.int64)
+    pos = np.arange(n); st = np.searchsorted(off, pos, side="right") - 1
+    step_of[t] = st; slot_of[t] = pos - off[st]
+    src_of = np.empty((n, 3), np.int64); src_of[t] = ent[:, 4:7]
+    last = {}
+    for k in range(n):
+        for which, row in enumerate((("P", u[k]), ("Q", i[k]), ("Q", j[k]))):
+            prev = last.get(row)
+            code = src_of[k, which]
+            if prev is None:
+                assert code == -1
+            else:
+                pk, pwhich = prev
+                dist = step_of[k] - step_of[pk]
+                assert dist >= 1
+                if dist <= 2:
+                    assert code == ((dist - 1) * capi.EXACT_MAX_WIDTH + slot_of[pk]) * 3 + pwhich
+                else:
+                    assert code == -1
+            last[row] = (k, which)
+    if width == 1:
+        assert steps == n and np.array_equal(t, np.arange(n))       # one triplet per step = the reference's order
+    with pytest.raises(capi.QRecError):
+        capi.bpr_exact_schedule(u, i, i.copy(), U, I, width)        # i == j never happens in BPR and is refused
+    e0, o0 = capi.bpr_exact_schedule(u[:0], i[:0], j[:0], U, I, width)
+    assert e0.shape == (0, 8) and o0.tolist() == [0]
