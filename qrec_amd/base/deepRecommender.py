@@ -54,11 +54,23 @@ class DeepRecommender(IterativeRecommender):
         """Yield ``draw()`` (default ``sample_epoch_pairwise``) for epochs 0..n_epochs-1, computing epoch
         k+1 on a worker thread while the caller trains on epoch k.  The draw sequence does not depend on
         the model, so running it ahead leaves the CPython stream exactly where the reference's would be;
-        nothing is drawn beyond the last epoch."""
+        nothing is drawn beyond the last epoch.
+        The draw reads and writes process-global state -- the ``random`` generator and the order of
+        ``self.data.trainingData`` -- so it holds ``self.sampling_lock`` while it runs.  Code on the training thread that
+        touches either between two epochs (a subclass hook calling ``random``, ``training_arrays()``, ...) must take the
+        same lock; what it then sees is the state one epoch AHEAD of the reference's at that point (the draws of the
+        next epoch have been consumed already): the stream as a whole is the reference's, its interleaving with such
+        calls is not.  The drop-in models make no such calls."""
+        import threading
         from concurrent.futures import ThreadPoolExecutor
-        draw = draw or self.sample_epoch_pairwise
+        inner = draw or self.sample_epoch_pairwise
         if n_epochs <= 0:
             return
+        lock = self.sampling_lock = getattr(self, "sampling_lock", None) or threading.RLock()
+
+        def draw():
+            with lock:
+                return inner()
         with ThreadPoolExecutor(max_workers=1) as pool:
             pending = pool.submit(draw)
             for epoch in range(n_epochs):

@@ -81,6 +81,10 @@ class IterativeRecommender(Recommender):
         list (base/iterativeRecommender.py:79-80) on the host."""
         from ..ranking import DeviceRanker
         from ..util.qmath import find_k_largest
+        if min(N, self.num_items) > 100:
+            # only the per-epoch ranking_performance can ask for this (it takes max(-topN) unclamped, as the reference
+            # does; the final evalRanking clamps to 10): the device ranker serves N <= 100, the reference's own loop the rest
+            return super().rank_all_test_users(N)
         U, V = self.ranking_tables()
         users = list(self.data.testSet_u)
         warm = [u for u in users if self.data.containsUser(u)]
@@ -129,6 +133,8 @@ class IterativeRecommender(Recommender):
         from ..ranking import ranking_measure_strings
         from ..util.qmath import find_k_largest
         import math
+        if min(N, self.num_items) > 100:
+            return None                      # host path (see rank_all_test_users)
         U, V = self.ranking_tables()
         U, V = np.ascontiguousarray(U), np.ascontiguousarray(V)
         users = list(self.data.testSet_u)

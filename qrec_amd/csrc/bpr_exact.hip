@@ -114,34 +114,37 @@ __global__ __launch_bounds__(1024) void bpr_levels_kernel(T *__restrict__ P, T *
         // the schedule entry of step s+4 first: it takes this entry's registers at the end of the step, and by then --
         // a whole step later -- the copy no longer has to wait for it (issued last it would drain the row loads too)
         const Entry later = load_entry(s + 4);
-        T row[3][EPL];
+        T row[3][EPL] = {};
+        T x = 0;
+        if (en.valid) {      // an idle wavefront skips the arithmetic (not the memory operations: their count stays fixed)
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const int sk = en.src(k), code = sk < 0 ? 0 : sk;
-            // forwarded: written `dist` steps ago by slot `slot` as its row `which`
-            const int which = code % 3, slot = (code / 3) % QREC_EXACT_MAX_WIDTH, dist = code / (3 * QREC_EXACT_MAX_WIDTH) + 1;
-            const T *f = fwd + (((int64_t)((s + 3 - dist) % 3) * nw + slot) * 3 + which) * ROW + lane;
+            for (int k = 0; k < 3; k++) {
+                const int sk = en.src(k), code = sk < 0 ? 0 : sk;
+                // forwarded: written `dist` steps ago by slot `slot` as its row `which`
+                const int which = code % 3, slot = (code / 3) % QREC_EXACT_MAX_WIDTH, dist = code / (3 * QREC_EXACT_MAX_WIDTH) + 1;
+                const T *f = fwd + (((int64_t)((s + 3 - dist) % 3) * nw + slot) * 3 + which) * ROW + lane;
+#pragma unroll
+                for (int e = 0; e < EPL; e++) {
+                    const T v = f[64 * e];
+                    row[k][e] = sk < 0 ? (col_ok[e] ? r[k][e] : T(0)) : v;     // lanes past d read the dummy row: they hold 0
+                }
+            }
+            T di = 0, dj = 0;
+#pragma unroll
+            for (int e = 0; e < EPL; e++) { di += row[0][e] * row[1][e]; dj += row[0][e] * row[2][e]; }
+            di = wave_allreduce_sum(di); dj = wave_allreduce_sum(dj);
+            x = di - dj;
+            const T sg = T(1) / (T(1) + dev_exp<T>(-x));
+            const T g = lr * (T(1) - sg);
 #pragma unroll
             for (int e = 0; e < EPL; e++) {
-                const T v = f[64 * e];
-                row[k][e] = sk < 0 ? r[k][e] : v;
+                row[0][e] += g * (row[1][e] - row[2][e]);
+                row[1][e] += g * row[0][e];
+                row[2][e] -= g * row[0][e];
+                row[0][e] -= cu * row[0][e];
+                row[1][e] -= ci * row[1][e];
+                row[2][e] -= ci * row[2][e];
             }
-        }
-        T di = 0, dj = 0;
-#pragma unroll
-        for (int e = 0; e < EPL; e++) { di += row[0][e] * row[1][e]; dj += row[0][e] * row[2][e]; }
-        di = wave_allreduce_sum(di); dj = wave_allreduce_sum(dj);
-        const T x = di - dj;
-        const T sg = T(1) / (T(1) + dev_exp<T>(-x));
-        const T g = lr * (T(1) - sg);
-#pragma unroll
-        for (int e = 0; e < EPL; e++) {
-            row[0][e] += g * (row[1][e] - row[2][e]);
-            row[1][e] += g * row[0][e];
-            row[2][e] -= g * row[0][e];
-            row[0][e] -= cu * row[0][e];
-            row[1][e] -= ci * row[1][e];
-            row[2][e] -= ci * row[2][e];
         }
         T *f = fwd + ((int64_t)(s % 3) * nw + w) * 3 * ROW + lane;
 #pragma unroll

@@ -122,8 +122,8 @@ class BprSgd:
                 whole = np.arange(n_chunks - 1 if tail else n_chunks)
                 dealt = [whole[b::batches] for b in range(batches)]
                 order = np.concatenate(dealt + ([np.array([n_chunks - 1])] if tail else []))
-                pos = (order[:, None] * chunk + np.arange(chunk)[None, :]).ravel()
-                self.perm = self.perm[pos[pos < self.n]]
+                at = (order[:, None] * chunk + np.arange(chunk)[None, :]).ravel()
+                self.perm = self.perm[at[at < self.n]]
                 sizes = [len(x) * chunk for x in dealt]
                 sizes[-1] += tail
                 self.batch_bounds = [0] + np.cumsum(sizes).tolist()
@@ -216,7 +216,7 @@ class BprSgd:
             raise RuntimeError("the order-exact kernel needs the reference's user-major order")
         t = self.t
         if width is None:
-            width = int(os.environ.get("QREC_EXACT_WIDTH", "0")) or capi.EXACT_MAX_WIDTH
+            width = int(os.environ.get("QREC_EXACT_WIDTH", "0")) or 8     # measured: 8 wavefronts cover the DAG's width (214 k steps vs 209 k at 16) at 2/3 of the step time
         width = min(width, capi.bpr_exact_width(t.code, t.d))
         if width <= 1 or self.n == 0 or self.h_j is None:
             capi.bpr_sgd_ordered(t.P, t.Q, t.code, t.d, t.ld, self.d_u, self.d_i, self.d_j, self.n, lr, regU, regI,

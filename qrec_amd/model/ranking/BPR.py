@@ -93,6 +93,8 @@ class BPR(IterativeRecommender):
             nll, sp, sq = sgd.epoch_stats()
             self.loss = nll + self.regU * sp + self.regI * sq
             epoch += 1
+            if not self.ranking.isMainOn():      # isConverged then prints MAE/RMSE from the host tables (reference: live values)
+                self.P, self.Q = tables.download(np.float64)
             if self.isConverged(epoch):
                 break
         self.P, self.Q = tables.download(np.float64)

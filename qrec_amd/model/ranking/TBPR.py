@@ -129,6 +129,8 @@ class TBPR(SocialRecommender):
             nll, reg = d_loss.numpy()
             self.loss = float(nll) + float(reg)
             epoch += 1
+            if not self.ranking.isMainOn():      # isConverged then prints MAE/RMSE from the host tables (reference: live values)
+                self.P, self.Q = tables.download(np.float64)
             if self.isConverged(epoch):
                 break
         self.P, self.Q = tables.download(np.float64)

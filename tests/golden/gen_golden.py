@@ -470,13 +470,55 @@ def case_mhcn_graphs(tmp):
                 nnz=[int(A.nnz) for A in H])
 
 
+def loader_inputs():
+    """the rating files (as text) and load options the loader fixture covers: util/io.py:31-76's splitting rule (every
+    single delimiter character splits, so two blanks make an empty field), -columns orders, -header, -delim, -b
+    thresholds, train / test flag, universal newlines, float literals, empty file"""
+    rng = np.random.default_rng(0)
+    lits = ["1", "2.5", "4", "0.5", "5.0", "1e0", ".5", "+3", "3.", "-1"]
+    big = "\n".join(f"u{u} i{i} {r}" for u, i, r in zip(rng.integers(0, 50, 400), rng.integers(0, 70, 400), rng.choice(lits, 400))) + "\n"
+    return [
+        dict(name="plain", text=big, setup="-columns 0 1 2"),
+        dict(name="test_flag", text=big, setup="-columns 0 1 2", bTest=True),
+        dict(name="binarized_2.5", text=big, setup="-columns 0 1 2", binarized=True, threshold=2.5),
+        dict(name="binarized_default_threshold", text=big, setup="-columns 0 1 2", binarized=True),
+        dict(name="binarized_test", text=big, setup="-columns 0 1 2", binarized=True, threshold=1.0, bTest=True),
+        dict(name="mixed_delims_crlf_cr_no_final_newline_swapped_columns", text="a,b\t3\r\nc d,4.5  \r\n  e\tf 2\rg,h,1", setup="-columns 1 0 2"),
+        dict(name="two_blanks_make_an_empty_field", text="u1 i1 3 9\nu2  i2 4\n", setup="-columns 0 1 3"),
+        dict(name="header_no_rating_column", text="user item\nu1 i1\nu2 i1\n", setup="-columns 0 1 -header"),
+        dict(name="header_with_ratings", text="user,item,rating\nu1,i1,3\nu2,i1,0.5\n", setup="-columns 0 1 2 -header"),
+        dict(name="custom_delim", text="u1;i1;3\nu2;i2;4\n", setup="-columns 0 1 2 -delim ;"),
+        dict(name="rating_in_column_3_of_5", text="7 u1 i1 3.5 x\n8 u2 i2 1 y\n", setup="-columns 1 2 3"),
+        dict(name="tabs_only", text="u1\ti1\t2\nu1\ti2\t5\n", setup="-columns 0 1 2"),
+        dict(name="repeated_pairs_keep_every_row", text="u1 i1 1\nu1 i1 4\nu1 i1 1\n", setup="-columns 0 1 2"),
+        dict(name="empty_file", text="", setup="-columns 0 1 2"),
+    ]
+
+
+def case_loader(tmp):
+    """FileIO.loadDataSet (util/io.py:31-76) of the unmodified reference on the files above: the rows it returns"""
+    from util.io import FileIO
+    cases = []
+    for c in loader_inputs():
+        path = os.path.join(tmp, "loader_case.txt")
+        with open(path, "w", newline="") as f:
+            f.write(c["text"])
+        kw = {k: c[k] for k in ("bTest", "binarized", "threshold") if k in c}
+        with redirect_stdout(io.StringIO()):
+            rows = FileIO.loadDataSet({"ratings.setup": c["setup"]}, path, **kw)
+        cases.append(dict(c, rows=rows))
+    with open(os.path.join(OUT, "loader_cases.json"), "w") as f:
+        json.dump(cases, f, indent=0)
+    return dict(name="loader", n_cases=len(cases), n_rows=sum(len(c["rows"]) for c in cases))
+
+
 def main():
     install_stubs()
     tmp = tempfile.mkdtemp(prefix="qrec_golden_")
     os.symlink(os.path.join(REF, "dataset"), os.path.join(tmp, "dataset"))
     os.chdir(tmp)
     only = sys.argv[1:]
-    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pmf, case_svd, case_ee, case_svdpp, case_pairwise_and_adj, case_sgl_subgraph, case_sept_graphs, case_tbpr_filmtrust, case_mhcn_graphs]
+    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pmf, case_svd, case_ee, case_svdpp, case_pairwise_and_adj, case_sgl_subgraph, case_sept_graphs, case_tbpr_filmtrust, case_mhcn_graphs, case_loader]
     if only:   # regenerate a subset, keep the other entries of golden_meta.json
         cases = [c for c in cases if c.__name__ in only]
         old = json.load(open(os.path.join(OUT, "golden_meta.json")))

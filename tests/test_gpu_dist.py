@@ -103,7 +103,7 @@ def test_rccl_binding_with_a_world_of_one():
     """the real communicator (qrec_comm_init on librccl): every collective of the C ABI, degenerate but live"""
     path, version = capi.comm_library()
     assert "rccl" in path and version > 20000
-    comm = capi.Comm(1, 0, capi.comm_unique_id())
+    comm = capi.Comm(1, 0, capi.comm_unique_id(), identity_shortcut=False)
     rng = np.random.default_rng(1)
     a = rng.standard_normal(4096).astype(np.float32); s = np.array([1.5, -2.0, 7.0])
     d_a, d_s = DB.from_numpy(a), DB.from_numpy(s)

@@ -586,3 +586,29 @@ def test_exact_schedule_respects_every_dependence(width):
         capi.bpr_exact_schedule(u, i, i.copy(), U, I, width)        # i == j never happens in BPR and is refused
     e0, o0 = capi.bpr_exact_schedule(u[:0], i[:0], j[:0], U, I, width)
     assert e0.shape == (0, 8) and o0.tolist() == [0]
+
+
+def test_native_loader_reproduces_the_reference_loaders_rows(tmp_path, monkeypatch):
+    """tests/golden/loader_cases.json: rows the UNMODIFIED reference's FileIO.loadDataSet (util/io.py:31-76) returned for
+    14 files / option sets (tests/golden/gen_golden.py::case_loader).  Both product routes -- the native C++ loader
+    (qrec_ratings_load) and the Python loop it falls back to -- must return exactly those rows."""
+    import json
+    from qrec_amd.data.rows import RatingRows
+    from qrec_amd.util.io import FileIO
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "loader_cases.json")))
+    assert len(cases) >= 14
+    native_seen = 0
+    for c in cases:
+        f = tmp_path / "ratings.txt"
+        with open(f, "w", newline="") as fh:
+            fh.write(c["text"])
+        kw = {k: c[k] for k in ("bTest", "binarized", "threshold") if k in c}
+        conf = {"ratings.setup": c["setup"]}
+        for route in ("1", "0"):
+            monkeypatch.setenv("QREC_NATIVE_LOADER", route)
+            got = FileIO.loadDataSet(conf, str(f), **kw)
+            if route == "1" and isinstance(got, RatingRows):
+                native_seen += 1
+            assert list(got) == c["rows"], (c["name"], route)
+            assert all(type(r[2]) is float for r in got)
+    assert native_seen >= 12          # the native parser really took these files
