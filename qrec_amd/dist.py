@@ -371,6 +371,7 @@ def init_from_env():
     if world <= 1:
         return 1
     import time
+    _capi.load()      # before torch: bind /opt/rocm's HIP runtime and its librccl, not the ones bundled with torch (comm.cpp)
     control = ControlPlane.from_env()
     one_device = os.environ.get("QREC_DIST_TEST_ONE_DEVICE") == "1"
     local = 0 if one_device else int(os.environ.get("LOCAL_RANK", "0"))
