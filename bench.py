@@ -227,7 +227,10 @@ def main():
     from qrec_amd.interactions import CSR
     from qrec_amd.synth import make_dataset, to_csr
     capi.init(local_rank)
-    if use_dist:
+    if use_dist and os.environ.get("QREC_BENCH_NO_COMM") == "1":      # diagnosis only: the multi-GPU code path without a communicator
+        comm = type("NoComm", (), {"world": 1, "rank": 0, "allreduce": lambda *a, **k: None, "allreduce_pair": lambda *a, **k: None,
+                                   "destroy": lambda self: None})()
+    elif use_dist:
         comm = qd.make_comm(control)
 
     # ---- workload: resident in HBM before timing ------------------------------------------
@@ -265,6 +268,11 @@ def main():
 
     ev, pool = [], []
     counter = {"epoch": 0}
+    # The step's kernels and collectives run on an explicit non-blocking stream, not the null stream: the legacy null
+    # stream synchronises implicitly with every blocking stream of the process, and an RCCL communicator brings its own --
+    # measured at world 1 (QREC_FORCE_DIST=1): 0.670 ms/epoch on the null stream, 0.626 on this one, 0.610 with no
+    # communicator in the process at all (QREC_BENCH_NULL_STREAM=1 / QREC_BENCH_NO_COMM=1 reproduce the two ends).
+    main = None if os.environ.get("QREC_BENCH_NULL_STREAM") == "1" else capi.Stream()
 
     def epoch():
         """sampler (side stream) | SGD kernel -> [N > 1: collectives] -> epoch close (BPR.py:40 loss terms, isConverged,
@@ -273,10 +281,10 @@ def main():
         k = counter["epoch"]; counter["epoch"] += 1
         pair = pool.pop() if pool else (capi.Event(), capi.Event())
         ev.append(pair)
-        sgd.take_prefetched_negatives(k)                            # BPR.py:35-37 (sampled under epoch k-1)
+        sgd.take_prefetched_negatives(k, main)                      # BPR.py:35-37 (sampled under epoch k-1)
         if sharded:
-            dstep.prepare(sgd)
-        sgd.epoch_device_async(REG_U, REG_I, MAX_LR, tol=0.0, chunk=CHUNK, variant=args.variant,
+            dstep.prepare(sgd, main)
+        sgd.epoch_device_async(REG_U, REG_I, MAX_LR, tol=0.0, chunk=CHUNK, variant=args.variant, stream=main,
                                flush_every=flush_every, events=pair, dist=dstep)   # BPR.py:45-53,40 + iterativeRecommender.py:88-104
         sgd.prefetch_negatives_device(sampler_seed, k + 1)          # side stream, under the SGD kernel
 
@@ -292,16 +300,17 @@ def main():
         device copies inside the timed region -- extra work, not skipped work): the bold driver (BPR.conf: -max 1) halves
         the rate whenever sampling noise raises the loss, so a single run of many hundred epochs ends at a vanishing
         rate, while the reference trains 100 epochs at most; this keeps every timed epoch in the regime of a real run."""
-        capi.memcpy_d2d(tables.P, d_P0, d_P0.nbytes); capi.memcpy_d2d(tables.Q, d_Q0, d_Q0.nbytes)
+        capi.memcpy_d2d(tables.P, d_P0, d_P0.nbytes, main); capi.memcpy_d2d(tables.Q, d_Q0, d_Q0.nbytes, main)
         if dstep is not None and dstep.mode == "replicated":
-            capi.memcpy_d2d(dstep.sync_q.start, d_Q0, d_Q0.nbytes)
-        capi.memcpy_d2d(sgd.d_drv, d_drv0, d_drv0.nbytes)
+            capi.memcpy_d2d(dstep.sync_q.start, d_Q0, d_Q0.nbytes, main)
+        capi.memcpy_d2d(sgd.d_drv, d_drv0, d_drv0.nbytes, main)
 
     # calibration: how many epochs make a step, so that K steps last >= --min-seconds (same on every rank)
     cal = 5
     inner_max = 400
     sgd.start_device_driver(LR0, log_capacity=args.epochs_per_step or inner_max)
     d_drv0 = DeviceBuffer.from_numpy(sgd.d_drv.numpy())
+    capi.device_sync()            # set-up work sits on the null stream; the epochs run on `main`
     sgd.prefetch_negatives_device(sampler_seed, 0)
     epoch(); epoch(); sync_all()
     t0 = time.perf_counter()

@@ -119,17 +119,21 @@ class BPR(IterativeRecommender):
         sgd.start_device_driver(self.lRate, log_capacity=self.maxEpoch)
         sgd.prefetch_negatives_device(self.sampler_seed, 0)
         closed = []
+        # several ranks: an explicit stream -- the null stream synchronises implicitly with the communicator's own
+        # streams (60 us per epoch measured, bench.py)
+        stream = capi.Stream() if dp is not None else None
+        capi.device_sync()                  # set-up work (uploads, clears) sits on the null stream
 
         def retire(k):
             """print epoch k+1 once the device has closed it; True when training is over"""
             closed[k].sync()
-            st = sgd.driver_state()
+            st = sgd.driver_state(stream)
             if st["failed"]:
                 print("Loss = NaN or Infinity: current settings does not fit the recommender! Change the settings and try again!")
                 raise SystemExit(-1)
             if st["epochs"] <= k:            # an earlier epoch converged: this one never ran
                 return True
-            loss, lr_used, _, delta = sgd.d_log.numpy()[k, :4]
+            loss, lr_used, _, delta = sgd.d_log.numpy(stream)[k, :4]
             self.loss, self.lastLoss = float(loss), float(loss)
             print("%s %s epoch %d: loss = %.4f, delta_loss = %.5f learning_Rate = %.5f"
                   % (self.modelName, self.foldInfo, k + 1, loss, delta, lr_used))
@@ -137,17 +141,19 @@ class BPR(IterativeRecommender):
 
         done, retired = False, 0
         for epoch in range(self.maxEpoch):
-            sgd.take_prefetched_negatives(epoch)
-            sgd.epoch_device_async(self.regU, self.regI, self.maxLRate, tol=1e-3, chunk=chunk, dist=step)
+            sgd.take_prefetched_negatives(epoch, stream)
+            sgd.epoch_device_async(self.regU, self.regI, self.maxLRate, tol=1e-3, chunk=chunk, dist=step, stream=stream)
             sgd.prefetch_negatives_device(self.sampler_seed, epoch + 1)      # released under this epoch's SGD kernel
-            ev = capi.Event(); ev.record(); closed.append(ev)
+            ev = capi.Event(); ev.record(stream); closed.append(ev)
             if epoch >= depth:
                 done = retire(retired); retired += 1
                 if done:
                     break
         while not done and retired < len(closed):
             done = retire(retired); retired += 1
-        self.lRate = sgd.driver_state()["lr"]
+        if stream is not None:
+            stream.sync()
+        self.lRate = sgd.driver_state(stream)["lr"]
 
     def trainModel_tf(self):
         """The reference's TensorFlow variant (model/ranking/BPR.py:77-96), taken when the conf has
