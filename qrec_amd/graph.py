@@ -209,6 +209,98 @@ class LightGCNTrainer:
         return E[:self.nu, :self.d].copy(), E[self.nu:, :self.d].copy()
 
 
+class RowPartitionedLightGCNTrainer:
+    """LightGCN with the propagation ROW-PARTITIONED over the ranks: rank r owns the contiguous
+    rows [lo, hi) of the joint adjacency, of E = [U; V], of the Adam slots and of every propagated layer.  One step at
+    the reference's batch size:
+
+        forward   per layer: all-gather of the operand blocks -> the rank's rows of  A_hat X  (same SpMM kernel, same
+                  segment order, so each row is the bits the single-GPU product gives); layer sum kept per block;
+        loss      all-gather of the layer sum S, then every rank evaluates the whole batch (B rows, replicated: it is
+                  ~1 % of a step) and keeps its rows of dE;
+        backward  H_0 = dE, H_{k+1} = dE + A_hat H_k  -- A_hat is symmetric, so the backward product is again
+                  all-gather + the rank's rows (no transposed product, no reduce-scatter);
+        Adam      on the rank's rows.
+
+    Unlike ``dist.BatchParallel`` the step is the SAME step as on one GPU (same batch, same update), the SpMM work per
+    rank is 1/G, and no rank holds more than its rows of E, m, v (the gathered operand is a transient).  The price is
+    2L + 1 all-gathers of N x ld floats per step: at the Yelp2018 shape (17.8 MB each, L = 3: 125 MB per step and rank
+    against a 0.38 ms single-GPU step) the links lose to one GPU's cache hierarchy; it is the layout for graphs whose
+    operand no longer fits one GPU's caches or memory.  DESIGN.md s7 has the numbers."""
+
+    def __init__(self, comm, U0: np.ndarray, V0: np.ndarray, adj, n_layers: int, lr: float, reg: float,
+                 loss_eps: float = 1e-7):
+        from .dist import RowPartition
+        self.comm = comm
+        self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
+        self.n = self.nu + self.ni
+        self.ld = padded_ld(self.d, np.float32)
+        self.L, self.lr, self.reg, self.loss_eps = n_layers, lr, reg, loss_eps
+        rp = self.rp = RowPartition(comm, self.n, self.ld)
+        lo, hi, pad = rp.lo, rp.hi, rp.rows_pad
+        indptr, indices, values = adj
+        blk_ptr = (indptr[lo:hi + 1] - indptr[lo]).astype(np.int64)
+        blk_ptr = np.concatenate([blk_ptr, np.full(pad - (hi - lo), blk_ptr[-1] if hi > lo else 0, np.int64)])   # pad rows: empty
+        sel = slice(int(indptr[lo]), int(indptr[hi]))
+        self.plan = SpmmPlan(blk_ptr, indices[sel], values[sel], self.ld)     # rows = this rank's block, columns global
+        E0 = np.zeros((self.n, self.ld), np.float32)
+        E0[:self.nu, :self.d] = U0; E0[self.nu:, :self.d] = V0
+        blk = np.zeros((pad, self.ld), np.float32); blk[:hi - lo] = E0[lo:hi]
+        self.E = DeviceBuffer.from_numpy(blk)
+        zb = lambda: DeviceBuffer.zeros((pad, self.ld), np.float32)
+        self.m, self.v, self.S, self.A, self.B = zb(), zb(), zb(), zb(), zb()
+        full = lambda: DeviceBuffer.zeros((rp.world * pad, self.ld), np.float32)
+        self.X_full, self.S_full, self.dE_full = full(), full(), full()
+        self.d_loss = DeviceBuffer.zeros(1, np.float64)
+        f = np.float32
+        self.b1, self.b2, self.adam_eps = f(0.9), f(0.999), f(1e-8)
+        self.b1p, self.b2p = self.b1, self.b2
+
+    def _propagate(self, x, addend, accum, stream):
+        """L layers from the block ``x``: y = A_hat[lo:hi] gather(x) (+ addend), accumulated into ``accum`` if given"""
+        for k in range(self.L):
+            y = self.A if k % 2 == 0 else self.B
+            self.rp.gather_operand(x, self.X_full, stream)
+            capi.spmm_csr(self.plan, self.X_full, y, self.ld, d_addend=addend, addend_scale=1.0 if addend is not None else 0.0,
+                          d_accum=accum, stream=stream)
+            x = y
+        return x
+
+    def forward_sum(self, stream=None):
+        self.S.copy_from(self.E, stream)
+        self._propagate(self.E, None, self.S, stream)
+
+    def train_step_async(self, d_u, d_i, d_j, B: int, stream=None):
+        rp, ld = self.rp, self.ld
+        self.forward_sum(stream)
+        rp.gather_operand(self.S, self.S_full, stream)
+        self.dE_full.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
+        if B:
+            capi.bpr_batch_loss_grad(self.S_full, float(self.L + 1), self.nu, self.n, ld, d_u, d_i, d_j, B, self.loss_eps,
+                                     self.reg, self.dE_full, self.d_loss, stream)
+        dE_blk = self.dE_full.ptr + rp.lo * ld * 4                       # this rank's rows of the batch gradient, in place
+        g = self._propagate(dE_blk, dE_blk, None, stream)
+        f = np.float32
+        alpha = float(f(f(self.lr) * np.sqrt(f(1) - self.b2p, dtype=f) / (f(1) - self.b1p)))
+        capi.adam_step(self.E, self.m, self.v, g, (rp.hi - rp.lo) * ld, 1.0 / (self.L + 1), alpha, float(self.b1), float(self.b2),
+                       float(self.adam_eps), stream)
+        self.b1p = f(self.b1p * self.b1); self.b2p = f(self.b2p * self.b2)
+
+    def loss(self, stream=None) -> float:
+        return float(self.d_loss.numpy(stream)[0])
+
+    def final_embeddings(self):
+        """(U, V) = split(mean(E0..EL)) (LightGCN.py:41), whole, on every rank"""
+        self.forward_sum()
+        self.rp.gather_operand(self.S, self.S_full)
+        Ebar = (self.S_full.numpy()[:self.n, :self.d] / np.float32(self.L + 1)).astype(np.float32)
+        return np.ascontiguousarray(Ebar[:self.nu]), np.ascontiguousarray(Ebar[self.nu:])
+
+    def block(self, buf) -> np.ndarray:
+        """this rank's rows of a block buffer (pad rows and pad columns dropped)"""
+        return buf.numpy()[:self.rp.hi - self.rp.lo, :self.d].copy()
+
+
 class BprTfTrainer:
     """BPR.trainModel_tf (model/ranking/BPR.py:77-96): batch loss
     -sum log(sigmoid(y) + 1e-6) + reg*(l2_loss(U) + l2_loss(V)) over the FULL tables, Adam.

@@ -22,13 +22,26 @@ class LightGCN(GraphRecommender):
 
     def initModel(self):
         super().initModel()
+        dp = self.data_parallel()
+        self.row_partitioned = dp is not None and os.environ.get("QREC_GRAPH_DIST", "batch") == "rows"
+        if self.row_partitioned:
+            # one process per GPU, QREC_GRAPH_DIST=rows: the reference's own batch size, the propagation row-partitioned
+            # over the ranks (qrec_amd/graph.py); default is the batch-sharded scheme (dist.BatchParallel)
+            from ...graph import RowPartitionedLightGCNTrainer
+            self.trainer = RowPartitionedLightGCNTrainer(dp.comm, self.user_embeddings, self.item_embeddings,
+                                                         self.create_joint_sparse_adjaceny(), self.n_layers, self.lRate, self.regU)
+            return
         self.trainer = LightGCNTrainer(self.user_embeddings, self.item_embeddings,
                                        self.create_joint_sparse_adjaceny(), self.n_layers, self.lRate, self.regU)
 
     def trainModel(self):
         quiet = os.environ.get("QREC_QUIET") == "1"
         tr = self.trainer
-        dp = tr.dp = self.data_parallel()              # one process per GPU: a step = batch_size x world rows, this rank's share
+        dp = self.data_parallel()
+        if self.row_partitioned:
+            dp = None                                  # every rank takes the whole step; the SpMM rows are what is split
+        else:
+            tr.dp = dp                                 # one process per GPU: a step = batch_size x world rows, this rank's share
         step_rows = self.batch_size * (dp.world if dp else 1)
         for epoch, (u, i, j) in enumerate(self.iter_epoch_samples(self.maxEpoch)):                 # base/deepRecommender.py:29-52
             d_u, d_i, d_j = DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i), DeviceBuffer.from_numpy(j)

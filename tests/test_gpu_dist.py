@@ -335,3 +335,57 @@ def test_bench_multi_gpu_path_on_real_rccl_world_one(mode):
     assert a["n_gpus"] == 1 and "FORCE_DIST" in a["config"]["parallelism"]
     assert a["config"]["final_loss"] == pytest.approx(b["config"]["final_loss"], rel=0.03)
     assert a["config"]["final_lr"] == b["config"]["final_lr"]
+
+
+# ---- graph models: 1-D row partition of the propagation --------------------------------------------
+@pytest.mark.parametrize("world,layers,dim", [(3, 2, 16), (2, 3, 64), (8, 2, 50)])
+def test_row_partitioned_lightgcn_step_equals_the_single_gpu_step(world, layers, dim):
+    """RowPartitionedLightGCNTrainer with G logical ranks (threads + in-process collective): every rank holds its rows of
+    the adjacency, of E and of the Adam slots; layers are all-gathered.  Same batch, same step as LightGCNTrainer on
+    one GPU: the propagated layer sum is bit-identical row for row (same SpMM kernel, same segment order), the tables
+    after two steps agree to the summation order of the batch gradient's float atomics."""
+    from qrec_amd.graph import LightGCNTrainer, RowPartitionedLightGCNTrainer, joint_norm_adjacency
+    d = make_dataset("small")
+    nu, ni = d["n_users"], d["n_items"]
+    adj = joint_norm_adjacency(nu, ni, d["train_u"], d["train_i"])
+    rng = np.random.default_rng(world)
+    U0 = (rng.standard_normal((nu, dim)) * 0.1).astype(np.float32); V0 = (rng.standard_normal((ni, dim)) * 0.1).astype(np.float32)
+    B = 512
+    batches = [(rng.integers(0, nu, B).astype(np.int32), rng.integers(0, ni, B).astype(np.int32), rng.integers(0, ni, B).astype(np.int32))
+               for _ in range(2)]
+    one = LightGCNTrainer(U0, V0, adj, layers, lr=0.01, reg=1e-3)
+    one.forward_sum()
+    S_one = one.S.numpy()[:, :dim].copy()
+    losses_one = []
+    for u, i, j in batches:
+        one.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B); losses_one.append(one.loss())
+    E_one = one.E.numpy()[:, :dim]
+    group = _Group(world)
+    result, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            capi.init(0)
+            tr = RowPartitionedLightGCNTrainer(ThreadComm(group, rank), U0, V0, adj, layers, lr=0.01, reg=1e-3)
+            tr.forward_sum(); S_blk = tr.block(tr.S)
+            losses = []
+            for u, i, j in batches:
+                tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B); losses.append(tr.loss())
+            capi.device_sync()
+            result[rank] = (tr.rp.lo, tr.rp.hi, S_blk, tr.block(tr.E), losses)
+        except Exception as e:      # noqa: BLE001
+            errors.append(e); group.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    covered = 0
+    for lo, hi, S_blk, E_blk, losses in result:
+        assert np.array_equal(S_blk, S_one[lo:hi])                         # forward propagation: the same bits
+        np.testing.assert_allclose(E_blk, E_one[lo:hi], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(losses, losses_one, rtol=2e-6)
+        covered += hi - lo
+    assert covered == nu + ni and not np.allclose(E_one[:nu], U0)
