@@ -691,8 +691,9 @@ def test_lightgcn_class_row_partitioned_two_ranks_equal_one_rank_at_the_same_bat
                          "--master-port", "29553", worker, "LightGCN", "1024", str(two)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-3000:]
     a, b0, b1 = np.load(one / "rank0.npz"), np.load(two / "rank0.npz"), np.load(two / "rank1.npz")
-    for k in ("U", "V", "losses", "measure"):
+    for k in ("U", "V", "measure"):
         assert np.array_equal(b0[k], b1[k]), k                      # both ranks gathered the same tables, same measures
+    np.testing.assert_allclose(b0["losses"], b1["losses"], rtol=1e-6)   # every rank sums the batch loss itself (float atomics: own order)
     assert a["losses"].size == b0["losses"].size > 0
     np.testing.assert_allclose(b0["losses"], a["losses"], rtol=1e-5)
     assert rel_err(b0["U"], a["U"]) < 2e-5 and rel_err(b0["V"], a["V"]) < 2e-5
