@@ -344,9 +344,16 @@ int qrec_ema_update(float *d_target, const float *d_online, float tau, int64_t n
  * N items, strict '>' replacement, stable descending sort -- ties included, so ids are
  * bit-identical to the reference's.  Outputs [n_batch_users][N] (ids -1 padded when
  * n_items < N).  Tables are [rows][ld] with ld a multiple of 32 floats / 16 doubles and columns [d, ld) zero.
- * d_scratch holds the transposed score block; size it with
- * qrec_score_topk_scratch_bytes.  N <= 100 as in base/recommender.py:132-134.          */
-int qrec_score_topk_scratch_bytes(int dtype, int32_t n_items, int32_t n_batch_users, int64_t *bytes);
+ * N <= 100 as in base/recommender.py:132-134.  Two routes, same lists:
+ *   fused (fp32, ld <= 128, N <= 63, n_items >= 16,384): a per-user threshold from every 8th item tile, then ONE pass
+ *     that scores on the MFMA and keeps only what reaches the threshold and is not rated -- no users x items block is
+ *     ever written; users whose N+1 best scores are not pairwise distinct (the only case in which the heap's history
+ *     shows) are redone by the block route, a few hundred at a time.  The rated CSR must then have ASCENDING item ids
+ *     inside a row.  The call synchronises `stream` once (it reads back how many such users there are).
+ *   block (everything else; forced by env QREC_EVAL_BLOCK_PATH): scores into a transposed users x items block in
+ *     d_scratch, mask, sliced top-N with exact fallbacks.
+ * Size d_scratch with qrec_score_topk_scratch_bytes (same dtype / sizes / ld / N).                                  */
+int qrec_score_topk_scratch_bytes(int dtype, int32_t n_items, int32_t n_batch_users, int32_t ld, int32_t N, int64_t *bytes);
 int qrec_score_topk(const void *d_U, const void *d_V, int dtype, int32_t d, int32_t ld, int32_t n_items,
                     const int32_t *d_user_ids, int32_t n_batch_users, const int64_t *d_rated_indptr,
                     const int32_t *d_rated_items, int32_t N, void *d_scratch, int32_t *d_ids_out,

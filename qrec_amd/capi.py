@@ -567,9 +567,9 @@ def sumsq(d_x, dtype: int, rows: int, d: int, ld: int, d_out, stream=None):
     _check(load().qrec_sumsq(_dp(d_x), dtype, rows, d, ld, _dp(d_out), _sh(stream)))
 
 
-def score_topk_scratch_bytes(dtype: int, n_items: int, n_batch_users: int) -> int:
+def score_topk_scratch_bytes(dtype: int, n_items: int, n_batch_users: int, ld: int, N: int) -> int:
     out = C.c_int64(0)
-    _check(load().qrec_score_topk_scratch_bytes(dtype, n_items, n_batch_users, C.byref(out)))
+    _check(load().qrec_score_topk_scratch_bytes(dtype, n_items, n_batch_users, ld, N, C.byref(out)))
     return out.value
 
 

@@ -16,6 +16,8 @@
 //
 // Bytes: (1) writes I*B*s, reads V once per user tile from cache; (3) reads I*B*s.
 // FLOPs: 2*B*I*d on the matrix pipe.
+#include <cstdlib>
+
 #include "common.h"
 
 using namespace qrec;
@@ -38,7 +40,9 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void score_kernel_f32(
     const float *__restrict__ U, const float *__restrict__ V, int ld, int n_items,
     const int32_t *__restrict__ user_ids, int n_b, int b_pad, int item_tiles_per_wave,
-    float *__restrict__ S_T) {
+    float *__restrict__ S_T, int tile_stride) {
+    // tile_stride > 1 (threshold pass of the fused evaluation): block row 32*t + q is item 32*t*tile_stride + q, i.e.
+    // only every tile_stride-th item tile is scored.
     // One wavefront serves TWO 32-user tiles per item tile: the item operand (re-read from L2 by every user tile that
     // needs it -- 990 user tiles x 9.7 MB at the Yelp shape) is fetched half as often.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(256) void score_kernel_f32(
     const int b0 = upair * 64 + r, b1 = b0 + 32;
     const int64_t uid0 = user_ids[b0 < n_b ? b0 : n_b - 1], uid1 = user_ids[b1 < n_b ? b1 : n_b - 1];   // columns >= n_b are never read
     const int n_chunks = (ld + 63) / 64;                // 64 columns per chunk
-    const int n_item_tiles = (n_items + 31) / 32;
+    const int n_item_tiles = ((n_items + 31) / 32 + tile_stride - 1) / tile_stride;
     const int t_begin = (blockIdx.y * 4 + wave) * item_tiles_per_wave;
     int t_end = t_begin + item_tiles_per_wave;
     if (t_end > n_item_tiles) t_end = n_item_tiles;
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void score_kernel_f32(
             for (int q = 0; q < 8; q++) { ua[q] = p0[q] * keep; ub[q] = p1[q] * keep; }
         }
         auto tile_ptr = [&](int t) {
-            const int item = t * 32 + r;
+            const int item = t * tile_stride * 32 + r;
             return reinterpret_cast<const f32x4 *>(V + (int64_t)(item < n_items ? item : n_items - 1) * ld + kb);
         };
         {
@@ -81,6 +85,7 @@ __global__ __launch_bounds__(256) void score_kernel_f32(
             }
             f32x16 acc0, acc1;
             float *out = S_T + (int64_t)(t * 32) * b_pad + upair * 64;
+            const int item0 = t * tile_stride * 32;
             if (c == 0) {
 #pragma unroll
                 for (int q = 0; q < 16; q++) { acc0[q] = 0.f; acc1[q] = 0.f; }
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(256) void score_kernel_f32(
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
-                    const bool in = t * 32 + row < n_items;
+                    const bool in = item0 + row < n_items;
                     acc0[q] = in ? out[(int64_t)row * b_pad + r] : 0.f;
                     acc1[q] = in ? out[(int64_t)row * b_pad + 32 + r] : 0.f;
                 }
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(256) void score_kernel_f32(
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (t * 32 + row < n_items) {
+                if (item0 + row < n_items) {
                     out[(int64_t)row * b_pad + r] = acc0[q];
                     out[(int64_t)row * b_pad + 32 + r] = acc1[q];
                 }
@@ -195,13 +200,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void mask_kernel(const int32_t *__restrict__ user_ids, int n_b,
                                                    const int64_t *__restrict__ rated_indptr,
                                                    const int32_t *__restrict__ rated_items, int b_pad,
-                                                   T *__restrict__ S_T) {
-    // one wavefront per user of the batch
+                                                   T *__restrict__ S_T, int tile, int tile_stride) {
+    // one wavefront per user of the batch.  tile_stride > 1: the block holds every tile_stride-th item tile only.
     const int b = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (b >= n_b) return;
     const int uid = user_ids[b];
     const int64_t beg = rated_indptr[uid], end = rated_indptr[uid + 1];
-    for (int64_t e = beg + (threadIdx.x & 63); e < end; e += 64) S_T[(int64_t)rated_items[e] * b_pad + b] = T(0);
+    for (int64_t e = beg + (threadIdx.x & 63); e < end; e += 64) {
+        const int it = rated_items[e], t = it / tile;
+        if (t % tile_stride == 0) S_T[((int64_t)(t / tile_stride) * tile + it % tile) * b_pad + b] = T(0);
+    }
 }
 
 // ---- (3) the reference's heap top-K, one lane per user ------------------------------------
@@ -534,6 +542,229 @@ __global__ __launch_bounds__(64) void exact_wave_kernel(const T *__restrict__ S_
     }
 }
 
+// ---- fused evaluation (fp32): score -> mask -> threshold filter in one pass, no B x I block ---------------------------
+// base/recommender.py:143-150 + util/qmath.py:134-146 again, for the common case that a user's N+1 best scores are
+// pairwise distinct (then find_k_largest returns exactly the N best, descending):
+//   (A) threshold: score every kSampleStride-th item tile only (a block 1/8 the size), mask it, and take tau[b] = the
+//       (N+1)-th largest of 64 range maxima of that sample -- N+1 DIFFERENT items reach tau, so the user's N+1 best do;
+//       about (N+1) x kSampleStride x 1.1 items of the whole catalogue reach it;
+//   (B) score_filter_kernel_f32: the scoring kernel with the store replaced by a compare against tau in the MFMA
+//       accumulators; an item that reaches tau and is not a rated item of the user (those count as 0 < tau) is appended
+//       to the lane's private candidate list.  Nothing else is written: the kernel is bound by the matrix pipe;
+//   (C) select_topk_kernel: one wavefront per user gathers the user's candidates (a few hundred) and extracts the N+1
+//       largest by repeated wave-wide maximum; equal scores among them, an overflowed list or tau <= 0 (rated items,
+//       masked to 0, would compete) flag the user;
+//   (D) flagged users -- the cases where the heap's history matters -- go through the block path above (MFMA scores of
+//       THOSE users, mask, the exact heap emulation), a few hundred at a time, and their rows are patched in.
+constexpr int kSampleStride = 8;
+constexpr int kListCap = 48;        // candidates per lane-private list (expected ~10)
+
+template <int NC>    // column chunks of 64 (ld <= 64 * NC)
+__global__ __launch_bounds__(256) void score_filter_kernel_f32(
+    const float *__restrict__ U, const float *__restrict__ V, int ld, int n_items, const int32_t *__restrict__ user_ids,
+    int n_b, int item_tiles_per_wave, const float *__restrict__ tau, const int64_t *__restrict__ rated_indptr,
+    const int32_t *__restrict__ rated_sorted, int n_lists, float *__restrict__ cand_s, int32_t *__restrict__ cand_i,
+    int32_t *__restrict__ cand_n) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int upair = blockIdx.x;
+    const int b0 = upair * 64 + r, b1 = b0 + 32;
+    const int list = (blockIdx.y * 4 + wave) * 2 + h;
+    // wavefront w of the user pair takes item tiles w, w + W, w + 2W, ... (W = wavefronts per user pair): every candidate
+    // list samples the whole catalogue, so ids that correlate with popularity cannot overflow one list
+    const int n_item_tiles = (n_items + 31) / 32;
+    const int t_step = gridDim.y * 4;
+    const int t_begin = blockIdx.y * 4 + wave, t_end = n_item_tiles;
+    (void)item_tiles_per_wave;
+    const bool live0 = b0 < n_b, live1 = b1 < n_b;
+    const int64_t uid0 = user_ids[live0 ? b0 : n_b - 1], uid1 = user_ids[live1 ? b1 : n_b - 1];
+    int cnt0 = 0, cnt1 = 0;
+    if (t_begin < t_end) {
+        const float th0 = live0 ? tau[b0] : __builtin_huge_valf(), th1 = live1 ? tau[b1] : __builtin_huge_valf();
+        int64_t rb0 = 0, re0 = 0, rb1 = 0, re1 = 0;
+        if (rated_indptr) { rb0 = rated_indptr[uid0]; re0 = rated_indptr[uid0 + 1]; rb1 = rated_indptr[uid1]; re1 = rated_indptr[uid1 + 1]; }
+        auto rated_has = [&](int64_t beg, int64_t end, int item) {
+            int64_t lo = beg, hi = end;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (rated_sorted[mid] < item) lo = mid + 1; else hi = mid;
+            }
+            return lo < end && rated_sorted[lo] == item;
+        };
+        f32x4 ua[NC][8], ub[NC][8];
+        int kb[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int col0 = 64 * c + 32 * h;
+            const bool kv = col0 < ld;
+            kb[c] = kv ? col0 : 0;
+            const float keep = kv ? 1.f : 0.f;
+            const f32x4 *p0 = reinterpret_cast<const f32x4 *>(U + uid0 * ld + kb[c]), *p1 = reinterpret_cast<const f32x4 *>(U + uid1 * ld + kb[c]);
+#pragma unroll
+            for (int q = 0; q < 8; q++) { ua[c][q] = p0[q] * keep; ub[c][q] = p1[q] * keep; }
+        }
+        auto tile_row = [&](int t) {
+            const int item = t * 32 + r;
+            return V + (int64_t)(item < n_items ? item : n_items - 1) * ld;
+        };
+        f32x4 va[NC][8], vn[NC][8];
+        {
+            const float *row = tile_row(t_begin);
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int q = 0; q < 8; q++) va[c][q] = reinterpret_cast<const f32x4 *>(row + kb[c])[q];
+        }
+        float *cs0 = cand_s + ((int64_t)b0 * n_lists + list) * kListCap, *cs1 = cand_s + ((int64_t)b1 * n_lists + list) * kListCap;
+        int32_t *ci0 = cand_i + ((int64_t)b0 * n_lists + list) * kListCap, *ci1 = cand_i + ((int64_t)b1 * n_lists + list) * kListCap;
+        for (int t = t_begin; t < t_end; t += t_step) {
+            if (t + t_step < t_end) {
+                const float *row = tile_row(t + t_step);
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+#pragma unroll
+                    for (int q = 0; q < 8; q++) vn[c][q] = reinterpret_cast<const f32x4 *>(row + kb[c])[q];
+            }
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int q = 0; q < 16; q++) { acc0[q] = 0.f; acc1[q] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].x, ua[c][q].x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].x, ub[c][q].x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].y, ua[c][q].y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].y, ub[c][q].y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].z, ua[c][q].z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].z, ub[c][q].z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].w, ua[c][q].w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].w, ub[c][q].w, acc1, 0, 0, 0);
+                }
+            // C/D: col = lane&31 (user), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (item); items visited in ascending id per lane
+            const int item_base = t * 32 + 4 * h;
+            float m0 = acc0[0], m1 = acc1[0];
+#pragma unroll
+            for (int q = 1; q < 16; q++) { m0 = fmaxf(m0, acc0[q]); m1 = fmaxf(m1, acc1[q]); }
+            if (m0 >= th0) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int item = item_base + (q & 3) + 8 * (q >> 2);
+                    if (acc0[q] >= th0 && item < n_items && !rated_has(rb0, re0, item)) {
+                        if (cnt0 < kListCap) { cs0[cnt0] = acc0[q]; ci0[cnt0] = item; }
+                        cnt0++;
+                    }
+                }
+            }
+            if (m1 >= th1) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int item = item_base + (q & 3) + 8 * (q >> 2);
+                    if (acc1[q] >= th1 && item < n_items && !rated_has(rb1, re1, item)) {
+                        if (cnt1 < kListCap) { cs1[cnt1] = acc1[q]; ci1[cnt1] = item; }
+                        cnt1++;
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int q = 0; q < 8; q++) va[c][q] = vn[c][q];
+        }
+    }
+    if (live0) cand_n[(int64_t)b0 * n_lists + list] = cnt0;
+    if (live1) cand_n[(int64_t)b1 * n_lists + list] = cnt1;
+}
+
+// (C) one wavefront per user: gather the candidates of the user's lists into LDS, take the K+1 largest by repeated
+// wave-wide maximum of (score, lower id first); flag ties among them / overflow / tau <= 0.
+constexpr int kSelectWaves = 4;
+__global__ __launch_bounds__(64 * kSelectWaves) void select_topk_kernel(
+    const float *__restrict__ cand_s, const int32_t *__restrict__ cand_i, const int32_t *__restrict__ cand_n, int n_lists,
+    const float *__restrict__ tau, int n_b, int K, int32_t *__restrict__ ids_out, float *__restrict__ scores_out,
+    int32_t *__restrict__ flags, int32_t *__restrict__ n_flagged, int32_t *__restrict__ flagged_list) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * kSelectWaves + wave;
+    if (b >= n_b) return;                                         // whole wavefront
+    const int cap_total = n_lists * kListCap;
+    unsigned long long *pool = reinterpret_cast<unsigned long long *>(smem) + (int64_t)wave * cap_total;
+    // key: score mapped to an order-preserving unsigned, then ~id so that among equal scores the LOWER id is larger
+    auto key_of = [](float s, int32_t id) {
+        unsigned u = __float_as_uint(s);
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        return ((unsigned long long)u << 32) | (unsigned)(0x7fffffff - id);
+    };
+    bool bad = !(tau[b] > 0.f);
+    int total = 0;
+    for (int l0 = 0; l0 < n_lists; l0 += 64) {                    // counts -> offsets (wave scan), candidates -> pool
+        const int l = l0 + lane;
+        int n = l < n_lists ? cand_n[(int64_t)b * n_lists + l] : 0;
+        if (n > kListCap) { bad = true; n = kListCap; }
+        int inc = n;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const int o = __shfl_up(inc, sft, 64);
+            if (lane >= sft) inc += o;
+        }
+        const int off = total + inc - n;
+        for (int c = 0; c < n; c++) {
+            const int64_t at = ((int64_t)b * n_lists + l) * kListCap + c;
+            pool[off + c] = key_of(cand_s[at], cand_i[at]);
+        }
+        total += __shfl(inc, 63, 64);
+    }
+    bad = __any(bad);
+    const int M = K + 1;
+    if (total < M) bad = true;                                    // only after an overflow
+    // each lane owns pool[lane], pool[lane + 64], ...
+    unsigned long long prev = 0;
+    bool tie = false;
+    const int take = total < M ? total : M;
+    for (int rank = 0; rank < take; rank++) {
+        unsigned long long best = 0;
+        int where = -1;
+        for (int e = lane; e < total; e += 64) {
+            const unsigned long long k = pool[e];
+            if (k > best) { best = k; where = e; }
+        }
+        unsigned long long wbest = best;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned long long o = __shfl_xor(wbest, m, 64);
+            wbest = o > wbest ? o : wbest;
+        }
+        if (best == wbest && where >= 0) pool[where] = 0;          // keys are unique (ids differ): exactly one lane
+        if (rank > 0 && (wbest >> 32) == (prev >> 32)) tie = true;
+        prev = wbest;
+        if (rank < K && lane == 0) {
+            unsigned u = (unsigned)(wbest >> 32);
+            u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+            ids_out[(int64_t)b * K + rank] = 0x7fffffff - (int32_t)(unsigned)(wbest & 0xffffffffu);
+            scores_out[(int64_t)b * K + rank] = __uint_as_float(u);
+        }
+    }
+    if (lane == 0) {
+        const bool flag = bad || tie;
+        flags[b] = flag ? 1 : 0;
+        if (flag) flagged_list[atomicAdd(n_flagged, 1)] = b;
+    }
+}
+
+__global__ void gather_user_ids_kernel(const int32_t *__restrict__ user_ids, const int32_t *__restrict__ flagged_list, int off, int n,
+                                       int32_t *__restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = user_ids[flagged_list[off + k]];
+}
+__global__ void scatter_rows_kernel(const int32_t *__restrict__ flagged_list, int off, int n, int K, const int32_t *__restrict__ ids_in,
+                                    const float *__restrict__ sc_in, int32_t *__restrict__ ids_out, float *__restrict__ sc_out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * K) return;
+    const int64_t dst = (int64_t)flagged_list[off + t / K] * K + t % K;
+    ids_out[dst] = ids_in[t];
+    sc_out[dst] = sc_in[t];
+}
+
 template <typename T>
 int run_score_topk(const void *U, const void *V, int d, int ld, int n_items, const int32_t *user_ids,
                    int n_b, const int64_t *rated_indptr, const int32_t *rated_items, int K, void *scratch,
@@ -552,14 +783,14 @@ int run_score_topk(const void *U, const void *V, int d, int ld, int n_items, con
     T *S_T = static_cast<T *>(scratch);
     if constexpr (sizeof(T) == 4)
         hipLaunchKernelGGL(score_kernel_f32, grid, dim3(256), 0, st, (const float *)U, (const float *)V, ld,
-                           n_items, user_ids, n_b, b_pad, per_wave, S_T);
+                           n_items, user_ids, n_b, b_pad, per_wave, S_T, 1);
     else
         hipLaunchKernelGGL(score_kernel_f64, grid, dim3(256), 0, st, (const double *)U, (const double *)V, ld,
                            n_items, user_ids, n_b, b_pad, per_wave, S_T);
     QREC_LAUNCH_CHECK();
     if (rated_indptr) {
         hipLaunchKernelGGL(mask_kernel<T>, dim3((unsigned)((n_b + 3) / 4)), dim3(256), 0, st, user_ids, n_b,
-                           rated_indptr, rated_items, b_pad, S_T);
+                           rated_indptr, rated_items, b_pad, S_T, TILE, 1);
         QREC_LAUNCH_CHECK();
     }
     const size_t lds = (size_t)K * kHeapThreads * (sizeof(T) + sizeof(int32_t));
@@ -619,6 +850,123 @@ int run_score_topk(const void *U, const void *V, int d, int ld, int n_items, con
     return QREC_OK;
 }
 
+// geometry shared by the scratch-size query and the launch
+struct FusedGeom {
+    int b_pad, n_utiles, n_item_tiles, grid_y, n_lists, n_s_tiles, n_s, fb_users;
+    size_t off_gmax, off_tau, off_cs, off_ci, off_cn, off_flags, off_list, off_nf, off_fbu, off_fbi, off_fbs, off_fb, total;
+};
+__host__ inline bool fused_ok(int dtype, int ld, int n_items, int K) {
+    return dtype == QREC_F32 && ld <= 128 && K + 1 <= kGroups && n_items >= 64 * kSampleStride * 32;
+}
+__host__ inline size_t block_path_bytes(size_t elem, int n_items, int n_b) {
+    const size_t b_pad = ((size_t)n_b + 63) / 64 * 64;
+    return score_block_bytes(elem, n_items, n_b) + (size_t)(kGroups + 1) * b_pad * elem + (size_t)kSlices * kSliceCap * b_pad * (elem + 4) +
+           (size_t)(kSlices + 2) * b_pad * 4 + 64;
+}
+__host__ inline FusedGeom fused_geometry(int n_items, int n_b) {
+    FusedGeom g;
+    g.b_pad = (n_b + 63) / 64 * 64;
+    g.n_utiles = (n_b + 63) / 64;
+    g.n_item_tiles = (n_items + 31) / 32;
+    int waves = (4096 + g.n_utiles - 1) / g.n_utiles;                 // wavefronts per user pair: fill 1,024 SIMDs a few times over
+    if (waves > g.n_item_tiles / 8) waves = g.n_item_tiles / 8 > 0 ? g.n_item_tiles / 8 : 1;
+    g.grid_y = (waves + 3) / 4;
+    g.n_lists = g.grid_y * 4 * 2;
+    g.n_s_tiles = (g.n_item_tiles + kSampleStride - 1) / kSampleStride;
+    const int first_of_last = (g.n_s_tiles - 1) * kSampleStride * 32;
+    const int valid_last = n_items - first_of_last < 32 ? n_items - first_of_last : 32;
+    g.n_s = (g.n_s_tiles - 1) * 32 + valid_last;
+    g.fb_users = (n_b / 16 > 256 ? n_b / 16 : 256);
+    if (g.fb_users > n_b) g.fb_users = n_b;
+    g.fb_users = (g.fb_users + 63) / 64 * 64;
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    size_t o = up((size_t)g.n_s_tiles * 32 * g.b_pad * 4);            // sampled score block
+    g.off_gmax = o; o += up((size_t)kGroups * g.b_pad * 4);
+    g.off_tau = o; o += up((size_t)g.b_pad * 4);
+    g.off_cs = o; o += up((size_t)g.b_pad * g.n_lists * kListCap * 4);
+    g.off_ci = o; o += up((size_t)g.b_pad * g.n_lists * kListCap * 4);
+    g.off_cn = o; o += up((size_t)g.b_pad * g.n_lists * 4);
+    g.off_flags = o; o += up((size_t)g.b_pad * 4);
+    g.off_list = o; o += up((size_t)g.b_pad * 4);
+    g.off_nf = o; o += 256;
+    g.off_fbu = o; o += up((size_t)g.fb_users * 4);
+    g.off_fbi = o; o += up((size_t)g.fb_users * 100 * 4);
+    g.off_fbs = o; o += up((size_t)g.fb_users * 100 * 4);
+    g.off_fb = o; o += up(block_path_bytes(4, n_items, g.fb_users));
+    g.total = o;
+    return g;
+}
+
+int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_items, const int32_t *user_ids, int n_b,
+                       const int64_t *rated_indptr, const int32_t *rated_sorted, int K, void *scratch, int32_t *ids_out,
+                       float *scores_out, hipStream_t st) {
+    const FusedGeom g = fused_geometry(n_items, n_b);
+    unsigned char *base = static_cast<unsigned char *>(scratch);
+    float *S_s = reinterpret_cast<float *>(base);
+    float *gmax = reinterpret_cast<float *>(base + g.off_gmax), *tau = reinterpret_cast<float *>(base + g.off_tau);
+    float *cand_s = reinterpret_cast<float *>(base + g.off_cs);
+    int32_t *cand_i = reinterpret_cast<int32_t *>(base + g.off_ci), *cand_n = reinterpret_cast<int32_t *>(base + g.off_cn);
+    int32_t *flags = reinterpret_cast<int32_t *>(base + g.off_flags), *flagged_list = reinterpret_cast<int32_t *>(base + g.off_list);
+    int32_t *n_flagged = reinterpret_cast<int32_t *>(base + g.off_nf);
+    const int M = K + 1;
+    // (A) threshold from every kSampleStride-th item tile
+    {
+        int splits = (4096 + g.n_utiles - 1) / g.n_utiles;
+        int per_wave = (g.n_s_tiles + splits - 1) / splits;
+        if (per_wave < 8) per_wave = g.n_s_tiles < 8 ? g.n_s_tiles : 8;
+        const int waves_per_utile = (g.n_s_tiles + per_wave - 1) / per_wave;
+        hipLaunchKernelGGL(score_kernel_f32, dim3((unsigned)g.n_utiles, (unsigned)((waves_per_utile + 3) / 4)), dim3(256), 0, st, U, V, ld,
+                           n_items, user_ids, n_b, g.b_pad, per_wave, S_s, kSampleStride);
+        QREC_LAUNCH_CHECK();
+        if (rated_indptr) {
+            hipLaunchKernelGGL(mask_kernel<float>, dim3((unsigned)((n_b + 3) / 4)), dim3(256), 0, st, user_ids, n_b, rated_indptr,
+                               rated_sorted, g.b_pad, S_s, 32, kSampleStride);
+            QREC_LAUNCH_CHECK();
+        }
+        const int per_group = (g.n_s + kGroups - 1) / kGroups, n_groups_used = (g.n_s + per_group - 1) / per_group;
+        const unsigned lane_blocks = (unsigned)((n_b + 255) / 256);
+        if (n_groups_used < kGroups)
+            hipLaunchKernelGGL(fill_neg_inf_kernel<float>, dim3(lane_blocks, kGroups - n_groups_used), dim3(256), 0, st,
+                               gmax + (size_t)n_groups_used * g.b_pad, g.b_pad, n_b);
+        hipLaunchKernelGGL(group_max_kernel<float>, dim3(lane_blocks, (unsigned)n_groups_used), dim3(256), 0, st, S_s, g.n_s, g.b_pad, n_b,
+                           per_group, gmax);
+        hipLaunchKernelGGL(threshold_kernel<float>, dim3(lane_blocks), dim3(256), 0, st, gmax, g.b_pad, n_b, M, tau);
+        QREC_LAUNCH_CHECK();
+    }
+    // (B) score + filter, (C) select
+    QREC_HIP_CHECK(hipMemsetAsync(n_flagged, 0, sizeof(int32_t), st));
+    const dim3 grid((unsigned)g.n_utiles, (unsigned)g.grid_y);
+    if (ld <= 64)
+        hipLaunchKernelGGL((score_filter_kernel_f32<1>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, 0, tau, rated_indptr,
+                           rated_sorted, g.n_lists, cand_s, cand_i, cand_n);
+    else
+        hipLaunchKernelGGL((score_filter_kernel_f32<2>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, 0, tau, rated_indptr,
+                           rated_sorted, g.n_lists, cand_s, cand_i, cand_n);
+    QREC_LAUNCH_CHECK();
+    const size_t lds = (size_t)kSelectWaves * g.n_lists * kListCap * sizeof(unsigned long long);
+    QREC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)((n_b + kSelectWaves - 1) / kSelectWaves)), dim3(64 * kSelectWaves), lds, st, cand_s,
+                       cand_i, cand_n, g.n_lists, tau, n_b, K, ids_out, scores_out, flags, n_flagged, flagged_list);
+    QREC_LAUNCH_CHECK();
+    // (D) users whose heap history matters: the block path, fb_users at a time
+    int32_t h_nf = 0;
+    QREC_HIP_CHECK(hipMemcpyAsync(&h_nf, n_flagged, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    QREC_HIP_CHECK(hipStreamSynchronize(st));
+    int32_t *fb_users = reinterpret_cast<int32_t *>(base + g.off_fbu), *fb_ids = reinterpret_cast<int32_t *>(base + g.off_fbi);
+    float *fb_sc = reinterpret_cast<float *>(base + g.off_fbs);
+    for (int off = 0; off < h_nf; off += g.fb_users) {
+        const int n = h_nf - off < g.fb_users ? h_nf - off : g.fb_users;
+        hipLaunchKernelGGL(gather_user_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, user_ids, flagged_list, off, n, fb_users);
+        QREC_LAUNCH_CHECK();
+        const int rc = run_score_topk<float>(U, V, d, ld, n_items, fb_users, n, rated_indptr, rated_sorted, K, base + g.off_fb, fb_ids, fb_sc, st);
+        if (rc != QREC_OK) return rc;
+        hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n * K + 255) / 256)), dim3(256), 0, st, flagged_list, off, n, K, fb_ids, fb_sc,
+                           ids_out, scores_out);
+        QREC_LAUNCH_CHECK();
+    }
+    return QREC_OK;
+}
+
 // Measure.hits (util/measure.py:15-21) and the DCG sum of Measure.NDCG (util/measure.py:70-82) for the lists a
 // previous qrec_score_topk left on the device: one lane per user walks its first n_cut recommendations in rank
 // order, looks each id up in the user's sorted test items and adds the caller's discount[pos] (the host passes
@@ -653,14 +1001,16 @@ __global__ __launch_bounds__(256) void rank_hits_kernel(const int32_t *__restric
 
 extern "C" {
 
-int qrec_score_topk_scratch_bytes(int dtype, int32_t n_items, int32_t n_batch_users, int64_t *bytes) {
+int qrec_score_topk_scratch_bytes(int dtype, int32_t n_items, int32_t n_batch_users, int32_t ld, int32_t K, int64_t *bytes) {
     QREC_REQUIRE(bytes && n_items >= 0 && n_batch_users >= 0, "qrec_score_topk_scratch_bytes: bad arguments");
     QREC_REQUIRE(dtype == QREC_F32 || dtype == QREC_F64, "qrec_score_topk_scratch_bytes: bad dtype %d", dtype);
-    const int64_t b_pad = ((int64_t)n_batch_users + 63) / 64 * 64;
-    const int64_t elem = dtype == QREC_F64 ? 8 : 4;
+    if (fused_ok(dtype, ld, n_items, K) && n_batch_users > 0) {
+        // fused path: the sampled block (1/8), candidate lists, and a block-path scratch for the flagged users' rounds
+        *bytes = (int64_t)fused_geometry(n_items, n_batch_users).total;
+        return QREC_OK;
+    }
     // the transposed score block, then the sliced top-N's candidates (scores + ids), flags, flagged list, counter
-    *bytes = (int64_t)score_block_bytes((size_t)elem, n_items, n_batch_users) + (int64_t)(kGroups + 1) * b_pad * elem +
-             (int64_t)kSlices * kSliceCap * b_pad * (elem + 4) + (kSlices + 2) * b_pad * 4 + 64;
+    *bytes = (int64_t)block_path_bytes(dtype == QREC_F64 ? 8 : 4, n_items, n_batch_users);
     return QREC_OK;
 }
 
@@ -677,6 +1027,9 @@ int qrec_score_topk(const void *d_U, const void *d_V, int dtype, int32_t d, int3
     QREC_REQUIRE((d_rated_indptr == nullptr) == (d_rated_items == nullptr), "qrec_score_topk: rated CSR incomplete");
     if (n_batch_users == 0) return QREC_OK;
     hipStream_t st = as_stream(stream);
+    if (fused_ok(dtype, ld, n_items, K) && !getenv("QREC_EVAL_BLOCK_PATH"))
+        return run_fused_topk_f32((const float *)d_U, (const float *)d_V, d, ld, n_items, d_user_ids, n_batch_users, d_rated_indptr,
+                                  d_rated_items, K, d_scratch, d_ids_out, (float *)d_scores_out, st);
     return dtype == QREC_F64
                ? run_score_topk<double>(d_U, d_V, d, ld, n_items, d_user_ids, n_batch_users, d_rated_indptr,
                                         d_rated_items, K, d_scratch, d_ids_out, d_scores_out, st)

@@ -38,8 +38,9 @@ class DeviceRanker:
         self.rated = None
         self.test = None
         if rated is not None:
+            rated = rated.sorted_rows()        # the fused route looks rated items up by bisection (include/qrec_hip.h)
             self.rated = (DeviceBuffer.from_numpy(rated.indptr.astype(np.int64)),
-                          DeviceBuffer.from_numpy(rated.indices.astype(np.int32)))
+                          DeviceBuffer.from_numpy(rated.indices.astype(np.int32) if rated.indices.size else np.zeros(1, np.int32)))
 
     def _pad(self, a: np.ndarray) -> np.ndarray:
         if a.shape[1] == self.ld:
@@ -83,11 +84,13 @@ class DeviceRanker:
             return (ids, scores) if cuts is None else (ids, scores, per_cut)
         if user_ids.min() < 0 or user_ids.max() >= self.n_users:
             raise ValueError("user id out of range")
-        per_user = capi.score_topk_scratch_bytes(self.code, self.n_items, 64) // 64
+        # users per call: as many as the scratch budget allows (fused route: ~15 KB per user at the Yelp2018 shape,
+        # block route: the whole score column, 150 KB)
+        per_user = capi.score_topk_scratch_bytes(self.code, self.n_items, 4096, self.ld, N) // 4096
         batch = int(max(64, min(n, (_SCRATCH_BUDGET // max(per_user, 1)) // 64 * 64)))
         nb = min(batch, n)
-        if self._cap[0] < nb or self._cap[1] < N:      # the 4-10 GB score block is kept across calls
-            self._scratch = DeviceBuffer(capi.score_topk_scratch_bytes(self.code, self.n_items, nb), np.uint8)
+        if self._cap[0] < nb or self._cap[1] != N:     # kept across calls (per-epoch evaluation)
+            self._scratch = DeviceBuffer(capi.score_topk_scratch_bytes(self.code, self.n_items, nb, self.ld, N), np.uint8)
             self._d_ids = DeviceBuffer((nb, N), np.int32); self._d_sc = DeviceBuffer((nb, N), self.dtype)
             self._cap = (nb, N)
         scratch, d_ids, d_sc = self._scratch, self._d_ids, self._d_sc

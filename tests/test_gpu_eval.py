@@ -185,3 +185,29 @@ def test_sliced_topk_and_its_exact_fallbacks(dtype, n_tied_users, N):
     oi, os_ = _oracle_topk(U, V, rated, users, N)
     assert np.array_equal(ids, oi)
     assert np.array_equal(sc.astype(np.float64), os_)
+
+
+@pytest.mark.parametrize("d,N", [(64, 20), (100, 10), (128, 63), (32, 1)])
+def test_fused_route_equals_the_block_route(d, N, monkeypatch):
+    """The fused evaluation (threshold from every 8th item tile, score + filter in one MFMA pass, wave-per-user
+    selection, flagged users through the block route) against the block route (QREC_EVAL_BLOCK_PATH=1) on the same
+    tables: identical ids and scores -- with item ids sorted by popularity (the best scores crowd the low ids), users
+    whose scores are all negative (threshold <= 0: rated items, masked to 0, outrank everything), users with ties in
+    their top N, and a ragged batch."""
+    rng = np.random.default_rng(d * 1000 + N)
+    n_users, n_items = 700, 20_000
+    pop = (np.arange(n_items, dtype=np.float64) + 1) ** -0.5                  # item id ~ popularity rank
+    V = (rng.standard_normal((n_items, d)) * 0.3 + pop[:, None] * 2.0).astype(np.float32)
+    U = (rng.standard_normal((n_users, d)) * 0.3 + 0.5).astype(np.float32)
+    U[::7] = -np.abs(U[::7])                                                  # every score of these users is negative
+    U[3::50] = 0.0                                                            # all scores tie at 0
+    V[5000:5040] = V[100:140]                                                 # exact duplicates: ties inside many top lists
+    uu = rng.integers(0, n_users, 30 * n_users); ii = (rng.integers(0, n_items, 30 * n_users) ** 2 // n_items).astype(np.int64)
+    rated = user_item_csr(uu, ii, np.ones(uu.size), n_users, n_items)
+    users = rng.permutation(n_users)[:651].astype(np.int32)
+    ids_f, sc_f = DeviceRanker(U, V, rated).topk(users, N)
+    monkeypatch.setenv("QREC_EVAL_BLOCK_PATH", "1")
+    ids_b, sc_b = DeviceRanker(U, V, rated).topk(users, N)
+    assert np.array_equal(ids_f, ids_b) and np.array_equal(sc_f, sc_b)
+    neg = np.isin(users, np.arange(0, n_users, 7))
+    assert (sc_b[neg][:, 0] <= 0).all() and (sc_b[~neg & ~np.isin(users, np.arange(3, n_users, 50))][:, 0] > 0).all()
