@@ -870,6 +870,7 @@ __host__ inline FusedGeom fused_geometry(int n_items, int n_b) {
     g.n_item_tiles = (n_items + 31) / 32;
     int waves = (4096 + g.n_utiles - 1) / g.n_utiles;                 // wavefronts per user pair: fill 1,024 SIMDs a few times over
     if (waves > g.n_item_tiles / 8) waves = g.n_item_tiles / 8 > 0 ? g.n_item_tiles / 8 : 1;
+    if (waves > 32) waves = 32;              // <= 64 candidate lists per user: the selection kernel gathers them in LDS
     g.grid_y = (waves + 3) / 4;
     g.n_lists = g.grid_y * 4 * 2;
     g.n_s_tiles = (g.n_item_tiles + kSampleStride - 1) / kSampleStride;
