@@ -856,7 +856,8 @@ struct FusedGeom {
     size_t off_gmax, off_tau, off_cs, off_ci, off_cn, off_flags, off_list, off_nf, off_fbu, off_fbi, off_fbs, off_fb, total;
 };
 __host__ inline bool fused_ok(int dtype, int ld, int n_items, int K) {
-    return dtype == QREC_F32 && ld <= 128 && K + 1 <= kGroups && n_items >= 64 * kSampleStride * 32;
+    // one predicate for the scratch-size query and the launch (QREC_EVAL_BLOCK_PATH forces the block route in both)
+    return dtype == QREC_F32 && ld <= 128 && K + 1 <= kGroups && n_items >= 64 * kSampleStride * 32 && !getenv("QREC_EVAL_BLOCK_PATH");
 }
 __host__ inline size_t block_path_bytes(size_t elem, int n_items, int n_b) {
     const size_t b_pad = ((size_t)n_b + 63) / 64 * 64;
@@ -1028,7 +1029,7 @@ int qrec_score_topk(const void *d_U, const void *d_V, int dtype, int32_t d, int3
     QREC_REQUIRE((d_rated_indptr == nullptr) == (d_rated_items == nullptr), "qrec_score_topk: rated CSR incomplete");
     if (n_batch_users == 0) return QREC_OK;
     hipStream_t st = as_stream(stream);
-    if (fused_ok(dtype, ld, n_items, K) && !getenv("QREC_EVAL_BLOCK_PATH"))
+    if (fused_ok(dtype, ld, n_items, K))
         return run_fused_topk_f32((const float *)d_U, (const float *)d_V, d, ld, n_items, d_user_ids, n_batch_users, d_rated_indptr,
                                   d_rated_items, K, d_scratch, d_ids_out, (float *)d_scores_out, st);
     return dtype == QREC_F64
