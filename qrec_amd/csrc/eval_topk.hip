@@ -549,11 +549,13 @@ __global__ __launch_bounds__(64) void exact_wave_kernel(const T *__restrict__ S_
 //       (N+1)-th largest of 64 range maxima of that sample -- N+1 DIFFERENT items reach tau, so the user's N+1 best do;
 //       about (N+1) x kSampleStride x 1.1 items of the whole catalogue reach it;
 //   (B) score_filter_kernel_f32: the scoring kernel with the store replaced by a compare against tau in the MFMA
-//       accumulators; an item that reaches tau and is not a rated item of the user (those count as 0 < tau) is appended
-//       to the lane's private candidate list.  Nothing else is written: the kernel is bound by the matrix pipe;
-//   (C) select_topk_kernel: one wavefront per user gathers the user's candidates (a few hundred) and extracts the N+1
-//       largest by repeated wave-wide maximum; equal scores among them, an overflowed list or tau <= 0 (rated items,
-//       masked to 0, would compete) flag the user;
+//       accumulators; an item that reaches tau is appended to the lane's private candidate list.  Nothing else is
+//       written: the kernel is bound by the matrix pipe.  (Rated items are NOT looked up here: a bisection per hit in
+//       the epilogue -- six dependent loads under divergence -- cost 2x the tile's MFMA time, measured 3.6 ms.)
+//   (C) select_topk_kernel: one wavefront per user gathers the user's candidates (a few hundred), drops the user's
+//       rated items (they count as 0 < tau; bisection, all lanes in parallel) and extracts the N+1 largest by repeated
+//       wave-wide maximum; equal scores among them, an overflowed list or tau <= 0 (rated items, masked to 0, would
+//       compete) flag the user;
 //   (D) flagged users -- the cases where the heap's history matters -- go through the block path above (MFMA scores of
 //       THOSE users, mask, the exact heap emulation), a few hundred at a time, and their rows are patched in.
 constexpr int kSampleStride = 8;
@@ -562,9 +564,8 @@ constexpr int kListCap = 48;        // candidates per lane-private list (expecte
 template <int NC>    // column chunks of 64 (ld <= 64 * NC)
 __global__ __launch_bounds__(256) void score_filter_kernel_f32(
     const float *__restrict__ U, const float *__restrict__ V, int ld, int n_items, const int32_t *__restrict__ user_ids,
-    int n_b, int item_tiles_per_wave, const float *__restrict__ tau, const int64_t *__restrict__ rated_indptr,
-    const int32_t *__restrict__ rated_sorted, int n_lists, float *__restrict__ cand_s, int32_t *__restrict__ cand_i,
-    int32_t *__restrict__ cand_n) {
+    int n_b, int item_tiles_per_wave, const float *__restrict__ tau, int n_lists, float *__restrict__ cand_s,
+    int32_t *__restrict__ cand_i, int32_t *__restrict__ cand_n) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int upair = blockIdx.x;
@@ -581,16 +582,6 @@ __global__ __launch_bounds__(256) void score_filter_kernel_f32(
     int cnt0 = 0, cnt1 = 0;
     if (t_begin < t_end) {
         const float th0 = live0 ? tau[b0] : __builtin_huge_valf(), th1 = live1 ? tau[b1] : __builtin_huge_valf();
-        int64_t rb0 = 0, re0 = 0, rb1 = 0, re1 = 0;
-        if (rated_indptr) { rb0 = rated_indptr[uid0]; re0 = rated_indptr[uid0 + 1]; rb1 = rated_indptr[uid1]; re1 = rated_indptr[uid1 + 1]; }
-        auto rated_has = [&](int64_t beg, int64_t end, int item) {
-            int64_t lo = beg, hi = end;
-            while (lo < hi) {
-                const int64_t mid = (lo + hi) >> 1;
-                if (rated_sorted[mid] < item) lo = mid + 1; else hi = mid;
-            }
-            return lo < end && rated_sorted[lo] == item;
-        };
         f32x4 ua[NC][8], ub[NC][8];
         int kb[NC];
 #pragma unroll
@@ -650,7 +641,7 @@ __global__ __launch_bounds__(256) void score_filter_kernel_f32(
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     const int item = item_base + (q & 3) + 8 * (q >> 2);
-                    if (acc0[q] >= th0 && item < n_items && !rated_has(rb0, re0, item)) {
+                    if (acc0[q] >= th0 && item < n_items) {
                         if (cnt0 < kListCap) { cs0[cnt0] = acc0[q]; ci0[cnt0] = item; }
                         cnt0++;
                     }
@@ -660,7 +651,7 @@ __global__ __launch_bounds__(256) void score_filter_kernel_f32(
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     const int item = item_base + (q & 3) + 8 * (q >> 2);
-                    if (acc1[q] >= th1 && item < n_items && !rated_has(rb1, re1, item)) {
+                    if (acc1[q] >= th1 && item < n_items) {
                         if (cnt1 < kListCap) { cs1[cnt1] = acc1[q]; ci1[cnt1] = item; }
                         cnt1++;
                     }
@@ -681,7 +672,8 @@ __global__ __launch_bounds__(256) void score_filter_kernel_f32(
 constexpr int kSelectWaves = 4;
 __global__ __launch_bounds__(64 * kSelectWaves) void select_topk_kernel(
     const float *__restrict__ cand_s, const int32_t *__restrict__ cand_i, const int32_t *__restrict__ cand_n, int n_lists,
-    const float *__restrict__ tau, int n_b, int K, int32_t *__restrict__ ids_out, float *__restrict__ scores_out,
+    const float *__restrict__ tau, const int32_t *__restrict__ user_ids, const int64_t *__restrict__ rated_indptr,
+    const int32_t *__restrict__ rated_sorted, int n_b, int K, int32_t *__restrict__ ids_out, float *__restrict__ scores_out,
     int32_t *__restrict__ flags, int32_t *__restrict__ n_flagged, int32_t *__restrict__ flagged_list) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -696,7 +688,9 @@ __global__ __launch_bounds__(64 * kSelectWaves) void select_topk_kernel(
         return ((unsigned long long)u << 32) | (unsigned)(0x7fffffff - id);
     };
     bool bad = !(tau[b] > 0.f);
-    int total = 0;
+    int64_t rbeg = 0, rend = 0;
+    if (rated_indptr) { const int uid = user_ids[b]; rbeg = rated_indptr[uid]; rend = rated_indptr[uid + 1]; }
+    int total = 0, kept = 0;
     for (int l0 = 0; l0 < n_lists; l0 += 64) {                    // counts -> offsets (wave scan), candidates -> pool
         const int l = l0 + lane;
         int n = l < n_lists ? cand_n[(int64_t)b * n_lists + l] : 0;
@@ -710,17 +704,27 @@ __global__ __launch_bounds__(64 * kSelectWaves) void select_topk_kernel(
         const int off = total + inc - n;
         for (int c = 0; c < n; c++) {
             const int64_t at = ((int64_t)b * n_lists + l) * kListCap + c;
-            pool[off + c] = key_of(cand_s[at], cand_i[at]);
+            const int32_t item = cand_i[at];
+            int64_t lo = rbeg, hi = rend;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (rated_sorted[mid] < item) lo = mid + 1; else hi = mid;
+            }
+            const bool rated = lo < rend && rated_sorted[lo] == item;
+            pool[off + c] = rated ? 0ull : key_of(cand_s[at], item);     // rated: masked to 0 < tau, not a candidate
+            kept += rated ? 0 : 1;
         }
         total += __shfl(inc, 63, 64);
     }
     bad = __any(bad);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) kept += __shfl_xor(kept, m, 64);
     const int M = K + 1;
-    if (total < M) bad = true;                                    // only after an overflow
+    if (kept < M) bad = true;                                     // only after an overflow
     // each lane owns pool[lane], pool[lane + 64], ...
     unsigned long long prev = 0;
     bool tie = false;
-    const int take = total < M ? total : M;
+    const int take = kept < M ? kept : M;
     for (int rank = 0; rank < take; rank++) {
         unsigned long long best = 0;
         int where = -1;
@@ -939,16 +943,17 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
     QREC_HIP_CHECK(hipMemsetAsync(n_flagged, 0, sizeof(int32_t), st));
     const dim3 grid((unsigned)g.n_utiles, (unsigned)g.grid_y);
     if (ld <= 64)
-        hipLaunchKernelGGL((score_filter_kernel_f32<1>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, 0, tau, rated_indptr,
-                           rated_sorted, g.n_lists, cand_s, cand_i, cand_n);
+        hipLaunchKernelGGL((score_filter_kernel_f32<1>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, 0, tau, g.n_lists, cand_s,
+                           cand_i, cand_n);
     else
-        hipLaunchKernelGGL((score_filter_kernel_f32<2>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, 0, tau, rated_indptr,
-                           rated_sorted, g.n_lists, cand_s, cand_i, cand_n);
+        hipLaunchKernelGGL((score_filter_kernel_f32<2>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, 0, tau, g.n_lists, cand_s,
+                           cand_i, cand_n);
     QREC_LAUNCH_CHECK();
     const size_t lds = (size_t)kSelectWaves * g.n_lists * kListCap * sizeof(unsigned long long);
     QREC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)((n_b + kSelectWaves - 1) / kSelectWaves)), dim3(64 * kSelectWaves), lds, st, cand_s,
-                       cand_i, cand_n, g.n_lists, tau, n_b, K, ids_out, scores_out, flags, n_flagged, flagged_list);
+                       cand_i, cand_n, g.n_lists, tau, user_ids, rated_indptr, rated_sorted, n_b, K, ids_out, scores_out, flags, n_flagged,
+                       flagged_list);
     QREC_LAUNCH_CHECK();
     // (D) users whose heap history matters: the block path, fb_users at a time
     int32_t h_nf = 0;
