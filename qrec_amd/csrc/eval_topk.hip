@@ -653,6 +653,113 @@ __global__ __launch_bounds__(256, 2) void score_filter_kernel_f32(
     if (live0) cand_n[(int64_t)b0 * n_lists + list] = cnt0;
 }
 
+// two 32-user tiles per wavefront (two interleaved accumulator chains); OCC = wavefronts per SIMD the registers are capped for
+template <int NC, int OCC>
+__global__ __launch_bounds__(256, OCC) void score_filter2_kernel_f32(
+    const float *__restrict__ U, const float *__restrict__ V, int ld, int n_items, const int32_t *__restrict__ user_ids,
+    int n_b, int item_tiles_per_wave, const float *__restrict__ tau, int n_lists, float *__restrict__ cand_s,
+    int32_t *__restrict__ cand_i, int32_t *__restrict__ cand_n) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int upair = blockIdx.x;
+    const int b0 = upair * 64 + r, b1 = b0 + 32;
+    const int list = (blockIdx.y * 4 + wave) * 2 + h;
+    // wavefront w of the user pair takes item tiles w, w + W, w + 2W, ... (W = wavefronts per user pair): every candidate
+    // list samples the whole catalogue, so ids that correlate with popularity cannot overflow one list
+    const int n_item_tiles = (n_items + 31) / 32;
+    const int t_step = gridDim.y * 4;
+    const int t_begin = blockIdx.y * 4 + wave, t_end = n_item_tiles;
+    (void)item_tiles_per_wave;
+    const bool live0 = b0 < n_b, live1 = b1 < n_b;
+    const int64_t uid0 = user_ids[live0 ? b0 : n_b - 1], uid1 = user_ids[live1 ? b1 : n_b - 1];
+    int cnt0 = 0, cnt1 = 0;
+    if (t_begin < t_end) {
+        const float th0 = live0 ? tau[b0] : __builtin_huge_valf(), th1 = live1 ? tau[b1] : __builtin_huge_valf();
+        f32x4 ua[NC][8], ub[NC][8];
+        int kb[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int col0 = 64 * c + 32 * h;
+            const bool kv = col0 < ld;
+            kb[c] = kv ? col0 : 0;
+            const float keep = kv ? 1.f : 0.f;
+            const f32x4 *p0 = reinterpret_cast<const f32x4 *>(U + uid0 * ld + kb[c]), *p1 = reinterpret_cast<const f32x4 *>(U + uid1 * ld + kb[c]);
+#pragma unroll
+            for (int q = 0; q < 8; q++) { ua[c][q] = p0[q] * keep; ub[c][q] = p1[q] * keep; }
+        }
+        auto tile_row = [&](int t) {
+            const int item = t * 32 + r;
+            return V + (int64_t)(item < n_items ? item : n_items - 1) * ld;
+        };
+        f32x4 va[NC][8], vn[NC][8];
+        {
+            const float *row = tile_row(t_begin);
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int q = 0; q < 8; q++) va[c][q] = reinterpret_cast<const f32x4 *>(row + kb[c])[q];
+        }
+        float *cs0 = cand_s + ((int64_t)b0 * n_lists + list) * kListCap, *cs1 = cand_s + ((int64_t)b1 * n_lists + list) * kListCap;
+        int32_t *ci0 = cand_i + ((int64_t)b0 * n_lists + list) * kListCap, *ci1 = cand_i + ((int64_t)b1 * n_lists + list) * kListCap;
+        for (int t = t_begin; t < t_end; t += t_step) {
+            if (t + t_step < t_end) {
+                const float *row = tile_row(t + t_step);
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+#pragma unroll
+                    for (int q = 0; q < 8; q++) vn[c][q] = reinterpret_cast<const f32x4 *>(row + kb[c])[q];
+            }
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int q = 0; q < 16; q++) { acc0[q] = 0.f; acc1[q] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].x, ua[c][q].x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].x, ub[c][q].x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].y, ua[c][q].y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].y, ub[c][q].y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].z, ua[c][q].z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].z, ub[c][q].z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].w, ua[c][q].w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].w, ub[c][q].w, acc1, 0, 0, 0);
+                }
+            // C/D: col = lane&31 (user), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (item); items visited in ascending id per lane
+            const int item_base = t * 32 + 4 * h;
+            float m0 = acc0[0], m1 = acc1[0];
+#pragma unroll
+            for (int q = 1; q < 16; q++) { m0 = fmaxf(m0, acc0[q]); m1 = fmaxf(m1, acc1[q]); }
+            if (m0 >= th0) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int item = item_base + (q & 3) + 8 * (q >> 2);
+                    if (acc0[q] >= th0 && item < n_items) {
+                        if (cnt0 < kListCap) { cs0[cnt0] = acc0[q]; ci0[cnt0] = item; }
+                        cnt0++;
+                    }
+                }
+            }
+            if (m1 >= th1) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int item = item_base + (q & 3) + 8 * (q >> 2);
+                    if (acc1[q] >= th1 && item < n_items) {
+                        if (cnt1 < kListCap) { cs1[cnt1] = acc1[q]; ci1[cnt1] = item; }
+                        cnt1++;
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int q = 0; q < 8; q++) va[c][q] = vn[c][q];
+        }
+    }
+    if (live0) cand_n[(int64_t)b0 * n_lists + list] = cnt0;
+    if (live1) cand_n[(int64_t)b1 * n_lists + list] = cnt1;
+}
+
 // (C) one wavefront per user: gather the candidates of the user's lists into LDS, take the K+1 largest by repeated
 // wave-wide maximum of (score, lower id first); flag ties among them / overflow / tau <= 0.
 constexpr int kSelectWaves = 4;
@@ -859,13 +966,18 @@ __host__ inline size_t block_path_bytes(size_t elem, int n_items, int n_b) {
     return score_block_bytes(elem, n_items, n_b) + (size_t)(kGroups + 1) * b_pad * elem + (size_t)kSlices * kSliceCap * b_pad * (elem + 4) +
            (size_t)(kSlices + 2) * b_pad * 4 + 64;
 }
+__host__ inline int fused_variant() {
+    const char *e = getenv("QREC_EVAL_VARIANT");
+    return e ? atoi(e) : 1;
+}
 __host__ inline FusedGeom fused_geometry(int n_items, int n_b) {
     FusedGeom g;
     g.b_pad = (n_b + 63) / 64 * 64;
     g.n_utiles = (n_b + 63) / 64;                                       // 64-user tiles of the block-route kernels (threshold pass)
     g.n_item_tiles = (n_items + 31) / 32;
     const int n_tiles32 = (n_b + 31) / 32;                             // 32-user tiles of the fused kernel
-    int waves = (8192 + n_tiles32 - 1) / n_tiles32;                    // wavefronts per user tile: 1,024 SIMDs x 2 a few times over
+    int waves = fused_variant() == 0 ? (8192 + n_tiles32 - 1) / n_tiles32      // wavefronts per user tile: 1,024 SIMDs x 2 a few times over
+                                     : (4096 + g.n_utiles - 1) / g.n_utiles;   // ... per user pair
     if (waves > g.n_item_tiles / 8) waves = g.n_item_tiles / 8 > 0 ? g.n_item_tiles / 8 : 1;
     if (waves > 32) waves = 32;              // <= 64 candidate lists per user: the selection kernel gathers them in LDS
     g.grid_y = (waves + 3) / 4;
@@ -933,13 +1045,23 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
     }
     // (B) score + filter, (C) select
     QREC_HIP_CHECK(hipMemsetAsync(n_flagged, 0, sizeof(int32_t), st));
-    const dim3 grid((unsigned)((n_b + 31) / 32), (unsigned)g.grid_y);
-    if (ld <= 64)
-        hipLaunchKernelGGL((score_filter_kernel_f32<1>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, tau, g.n_lists, cand_s,
-                           cand_i, cand_n);
-    else
-        hipLaunchKernelGGL((score_filter_kernel_f32<2>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, tau, g.n_lists, cand_s,
-                           cand_i, cand_n);
+    const int variant = fused_variant();
+    if (variant == 0) {
+        const dim3 grid((unsigned)((n_b + 31) / 32), (unsigned)g.grid_y);
+        if (ld <= 64)
+            hipLaunchKernelGGL((score_filter_kernel_f32<1>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, tau, g.n_lists, cand_s,
+                               cand_i, cand_n);
+        else
+            hipLaunchKernelGGL((score_filter_kernel_f32<2>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, tau, g.n_lists, cand_s,
+                               cand_i, cand_n);
+    } else {
+        const dim3 grid((unsigned)g.n_utiles, (unsigned)g.grid_y);
+#define QREC_SF2(NC, OCC) hipLaunchKernelGGL((score_filter2_kernel_f32<NC, OCC>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, 0, tau, \
+                                             g.n_lists, cand_s, cand_i, cand_n)
+        if (ld <= 64) { if (variant == 2) QREC_SF2(1, 2); else QREC_SF2(1, 1); }
+        else QREC_SF2(2, 1);
+#undef QREC_SF2
+    }
     QREC_LAUNCH_CHECK();
     const size_t lds = (size_t)kSelectWaves * g.n_lists * kListCap * sizeof(unsigned long long);
     QREC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
