@@ -511,9 +511,18 @@ __global__ __launch_bounds__(64) void exact_wave_kernel(const T *__restrict__ S_
         for (int t = k / 2 - 1; t >= 0; t--) sift_up(hp, k, t);
     __syncthreads();
     T root = hp.S(0);
+    // the user's scores sit b_pad elements apart: a step's 64 loads are 64 cache lines and a full memory round trip, so
+    // the values of the next kDepth steps are kept in flight (one wavefront per user: nothing else hides the latency)
+    constexpr int kDepth = 8;
+    T ahead[kDepth];
+#pragma unroll
+    for (int q = 0; q < kDepth; q++) { const int t = k + 64 * q + lane; ahead[q] = t < n_items ? col[(int64_t)t * b_pad] : T(0); }
     for (int t0 = k; t0 < n_items; t0 += 64) {
         const int t = t0 + lane;
-        const T v = t < n_items ? col[(int64_t)t * b_pad] : T(0);
+        const T v = ahead[0];
+#pragma unroll
+        for (int q = 0; q + 1 < kDepth; q++) ahead[q] = ahead[q + 1];
+        { const int tn = t0 + 64 * kDepth + lane; ahead[kDepth - 1] = tn < n_items ? col[(int64_t)tn * b_pad] : T(0); }
         bool live = t < n_items;
         while (true) {
             const unsigned long long mask = __ballot(live && v > root);
@@ -687,28 +696,20 @@ __global__ __launch_bounds__(256, OCC) void score_filter2_kernel_f32(
 #pragma unroll
             for (int q = 0; q < 8; q++) { ua[c][q] = p0[q] * keep; ub[c][q] = p1[q] * keep; }
         }
-        auto tile_row = [&](int t) {
+        auto load_tile = [&](int t, f32x4 (&dst)[NC][8]) {
             const int item = t * 32 + r;
-            return V + (int64_t)(item < n_items ? item : n_items - 1) * ld;
-        };
-        f32x4 va[NC][8], vn[NC][8];
-        {
-            const float *row = tile_row(t_begin);
+            const float *row = V + (int64_t)(item < n_items ? item : n_items - 1) * ld;
 #pragma unroll
             for (int c = 0; c < NC; c++)
 #pragma unroll
-                for (int q = 0; q < 8; q++) va[c][q] = reinterpret_cast<const f32x4 *>(row + kb[c])[q];
-        }
+                for (int q = 0; q < 8; q++) dst[c][q] = reinterpret_cast<const f32x4 *>(row + kb[c])[q];
+        };
         float *cs0 = cand_s + ((int64_t)b0 * n_lists + list) * kListCap, *cs1 = cand_s + ((int64_t)b1 * n_lists + list) * kListCap;
         int32_t *ci0 = cand_i + ((int64_t)b0 * n_lists + list) * kListCap, *ci1 = cand_i + ((int64_t)b1 * n_lists + list) * kListCap;
-        for (int t = t_begin; t < t_end; t += t_step) {
-            if (t + t_step < t_end) {
-                const float *row = tile_row(t + t_step);
-#pragma unroll
-                for (int c = 0; c < NC; c++)
-#pragma unroll
-                    for (int q = 0; q < 8; q++) vn[c][q] = reinterpret_cast<const f32x4 *>(row + kb[c])[q];
-            }
+        // one item tile: 64 MFMAs, then the accumulators against the two thresholds.  Every executed VALU instruction of
+        // the epilogue costs matrix-pipe time (measured), so: the element tests are entered only when some lane's
+        // 16-element maximum reaches its threshold, the item-range test exists only in the catalogue's last tile.
+        auto do_tile = [&](int t, const f32x4 (&v)[NC][8]) {
             f32x16 acc0, acc1;
 #pragma unroll
             for (int q = 0; q < 16; q++) { acc0[q] = 0.f; acc1[q] = 0.f; }
@@ -716,44 +717,55 @@ __global__ __launch_bounds__(256, OCC) void score_filter2_kernel_f32(
             for (int c = 0; c < NC; c++)
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].x, ua[c][q].x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].x, ub[c][q].x, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].y, ua[c][q].y, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].y, ub[c][q].y, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].z, ua[c][q].z, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].z, ub[c][q].z, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].w, ua[c][q].w, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].w, ub[c][q].w, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].x, ua[c][q].x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].x, ub[c][q].x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].y, ua[c][q].y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].y, ub[c][q].y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].z, ua[c][q].z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].z, ub[c][q].z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].w, ua[c][q].w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].w, ub[c][q].w, acc1, 0, 0, 0);
                 }
             // C/D: col = lane&31 (user), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (item); items visited in ascending id per lane
             const int item_base = t * 32 + 4 * h;
+            if (t * 32 + 32 > n_items) {              // the last, partial tile: rows past the catalogue repeat its last item
+#pragma unroll
+                for (int q = 0; q < 16; q++)
+                    if (item_base + (q & 3) + 8 * (q >> 2) >= n_items) { acc0[q] = -__builtin_huge_valf(); acc1[q] = -__builtin_huge_valf(); }
+            }
             float m0 = acc0[0], m1 = acc1[0];
 #pragma unroll
             for (int q = 1; q < 16; q++) { m0 = fmaxf(m0, acc0[q]); m1 = fmaxf(m1, acc1[q]); }
             if (m0 >= th0) {
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int item = item_base + (q & 3) + 8 * (q >> 2);
-                    if (acc0[q] >= th0 && item < n_items) {
-                        if (cnt0 < kListCap) { cs0[cnt0] = acc0[q]; ci0[cnt0] = item; }
+                for (int q = 0; q < 16; q++)
+                    if (acc0[q] >= th0) {
+                        if (cnt0 < kListCap) { cs0[cnt0] = acc0[q]; ci0[cnt0] = item_base + (q & 3) + 8 * (q >> 2); }
                         cnt0++;
                     }
-                }
             }
             if (m1 >= th1) {
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int item = item_base + (q & 3) + 8 * (q >> 2);
-                    if (acc1[q] >= th1 && item < n_items) {
-                        if (cnt1 < kListCap) { cs1[cnt1] = acc1[q]; ci1[cnt1] = item; }
+                for (int q = 0; q < 16; q++)
+                    if (acc1[q] >= th1) {
+                        if (cnt1 < kListCap) { cs1[cnt1] = acc1[q]; ci1[cnt1] = item_base + (q & 3) + 8 * (q >> 2); }
                         cnt1++;
                     }
-                }
             }
-#pragma unroll
-            for (int c = 0; c < NC; c++)
-#pragma unroll
-                for (int q = 0; q < 8; q++) va[c][q] = vn[c][q];
+        };
+        // two operand buffers, used alternately (no register copies): tile t from one while tile t + t_step loads into the other
+        f32x4 va[NC][8], vb[NC][8];
+        load_tile(t_begin, va);
+        int t = t_begin;
+        while (true) {
+            if (t + t_step < t_end) load_tile(t + t_step, vb);
+            do_tile(t, va);
+            t += t_step;
+            if (t >= t_end) break;
+            if (t + t_step < t_end) load_tile(t + t_step, va);
+            do_tile(t, vb);
+            t += t_step;
+            if (t >= t_end) break;
         }
     }
     if (live0) cand_n[(int64_t)b0 * n_lists + list] = cnt0;
