@@ -557,7 +557,7 @@ __global__ __launch_bounds__(64) void exact_wave_kernel(const T *__restrict__ S_
 //   (A) threshold: score every kSampleStride-th item tile only (a block 1/8 the size), mask it, and take tau[b] = the
 //       (N+1)-th largest of 64 range maxima of that sample -- N+1 DIFFERENT items reach tau, so the user's N+1 best do;
 //       about (N+1) x kSampleStride x 1.1 items of the whole catalogue reach it;
-//   (B) score_filter_kernel_f32: the scoring kernel with the store replaced by a compare against tau in the MFMA
+//   (B) score_filter2_kernel_f32: the scoring kernel with the store replaced by a compare against tau in the MFMA
 //       accumulators; an item that reaches tau is appended to the lane's private candidate list.  Nothing else is
 //       written: the kernel is bound by the matrix pipe.  (Rated items are NOT looked up here: a bisection per hit in
 //       the epilogue -- six dependent loads under divergence -- cost 2x the tile's MFMA time, measured 3.6 ms.)
@@ -569,98 +569,6 @@ __global__ __launch_bounds__(64) void exact_wave_kernel(const T *__restrict__ S_
 //       THOSE users, mask, the exact heap emulation), a few hundred at a time, and their rows are patched in.
 constexpr int kSampleStride = 8;
 constexpr int kListCap = 48;        // candidates per lane-private list (expected ~10)
-
-template <int NC>    // column chunks of 64 (ld <= 64 * NC)
-__global__ __launch_bounds__(256, 2) void score_filter_kernel_f32(
-    const float *__restrict__ U, const float *__restrict__ V, int ld, int n_items, const int32_t *__restrict__ user_ids,
-    int n_b, const float *__restrict__ tau, int n_lists, float *__restrict__ cand_s, int32_t *__restrict__ cand_i,
-    int32_t *__restrict__ cand_n) {
-    // ONE 32-user tile per wavefront (the block route's scoring kernel serves two): half the registers, so two
-    // wavefronts share a SIMD and one's compare / append epilogue runs under the other's MFMAs (measured: one tile pair per
-    // wavefront at one wavefront per SIMD left the matrix pipe idle 40 % of the time).
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int b0 = blockIdx.x * 32 + r;
-    const int list = (blockIdx.y * 4 + wave) * 2 + h;
-    // wavefront w of the user tile takes item tiles w, w + W, w + 2W, ... (W = wavefronts per user tile): every candidate
-    // list samples the whole catalogue, so ids that correlate with popularity cannot overflow one list
-    const int n_item_tiles = (n_items + 31) / 32;
-    const int t_step = gridDim.y * 4;
-    const int t_begin = blockIdx.y * 4 + wave, t_end = n_item_tiles;
-    const bool live0 = b0 < n_b;
-    const int64_t uid0 = user_ids[live0 ? b0 : n_b - 1];
-    int cnt0 = 0;
-    if (t_begin < t_end) {
-        const float th0 = live0 ? tau[b0] : __builtin_huge_valf();
-        f32x4 ua[NC][8];
-        int kb[NC];
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-            const int col0 = 64 * c + 32 * h;
-            const bool kv = col0 < ld;
-            kb[c] = kv ? col0 : 0;
-            const float keep = kv ? 1.f : 0.f;
-            const f32x4 *p0 = reinterpret_cast<const f32x4 *>(U + uid0 * ld + kb[c]);
-#pragma unroll
-            for (int q = 0; q < 8; q++) ua[c][q] = p0[q] * keep;
-        }
-        auto tile_row = [&](int t) {
-            const int item = t * 32 + r;
-            return V + (int64_t)(item < n_items ? item : n_items - 1) * ld;
-        };
-        f32x4 va[NC][8], vn[NC][8];
-        {
-            const float *row = tile_row(t_begin);
-#pragma unroll
-            for (int c = 0; c < NC; c++)
-#pragma unroll
-                for (int q = 0; q < 8; q++) va[c][q] = reinterpret_cast<const f32x4 *>(row + kb[c])[q];
-        }
-        float *cs0 = cand_s + ((int64_t)b0 * n_lists + list) * kListCap;
-        int32_t *ci0 = cand_i + ((int64_t)b0 * n_lists + list) * kListCap;
-        for (int t = t_begin; t < t_end; t += t_step) {
-            if (t + t_step < t_end) {
-                const float *row = tile_row(t + t_step);
-#pragma unroll
-                for (int c = 0; c < NC; c++)
-#pragma unroll
-                    for (int q = 0; q < 8; q++) vn[c][q] = reinterpret_cast<const f32x4 *>(row + kb[c])[q];
-            }
-            f32x16 acc0;
-#pragma unroll
-            for (int q = 0; q < 16; q++) acc0[q] = 0.f;
-#pragma unroll
-            for (int c = 0; c < NC; c++)
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].x, ua[c][q].x, acc0, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].y, ua[c][q].y, acc0, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].z, ua[c][q].z, acc0, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][q].w, ua[c][q].w, acc0, 0, 0, 0);
-                }
-            // C/D: col = lane&31 (user), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (item); items visited in ascending id per lane
-            const int item_base = t * 32 + 4 * h;
-            float m0 = acc0[0];
-#pragma unroll
-            for (int q = 1; q < 16; q++) m0 = fmaxf(m0, acc0[q]);
-            if (m0 >= th0) {
-#pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int item = item_base + (q & 3) + 8 * (q >> 2);
-                    if (acc0[q] >= th0 && item < n_items) {
-                        if (cnt0 < kListCap) { cs0[cnt0] = acc0[q]; ci0[cnt0] = item; }
-                        cnt0++;
-                    }
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < NC; c++)
-#pragma unroll
-                for (int q = 0; q < 8; q++) va[c][q] = vn[c][q];
-        }
-    }
-    if (live0) cand_n[(int64_t)b0 * n_lists + list] = cnt0;
-}
 
 // two 32-user tiles per wavefront (two interleaved accumulator chains); OCC = wavefronts per SIMD the registers are capped for
 template <int NC, int OCC>
@@ -978,18 +886,12 @@ __host__ inline size_t block_path_bytes(size_t elem, int n_items, int n_b) {
     return score_block_bytes(elem, n_items, n_b) + (size_t)(kGroups + 1) * b_pad * elem + (size_t)kSlices * kSliceCap * b_pad * (elem + 4) +
            (size_t)(kSlices + 2) * b_pad * 4 + 64;
 }
-__host__ inline int fused_variant() {
-    const char *e = getenv("QREC_EVAL_VARIANT");
-    return e ? atoi(e) : 1;
-}
 __host__ inline FusedGeom fused_geometry(int n_items, int n_b) {
     FusedGeom g;
     g.b_pad = (n_b + 63) / 64 * 64;
-    g.n_utiles = (n_b + 63) / 64;                                       // 64-user tiles of the block-route kernels (threshold pass)
+    g.n_utiles = (n_b + 63) / 64;
     g.n_item_tiles = (n_items + 31) / 32;
-    const int n_tiles32 = (n_b + 31) / 32;                             // 32-user tiles of the fused kernel
-    int waves = fused_variant() == 0 ? (8192 + n_tiles32 - 1) / n_tiles32      // wavefronts per user tile: 1,024 SIMDs x 2 a few times over
-                                     : (4096 + g.n_utiles - 1) / g.n_utiles;   // ... per user pair
+    int waves = (4096 + g.n_utiles - 1) / g.n_utiles;                 // wavefronts per user pair: fill 1,024 SIMDs a few times over
     if (waves > g.n_item_tiles / 8) waves = g.n_item_tiles / 8 > 0 ? g.n_item_tiles / 8 : 1;
     if (waves > 32) waves = 32;              // <= 64 candidate lists per user: the selection kernel gathers them in LDS
     g.grid_y = (waves + 3) / 4;
@@ -1057,23 +959,15 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
     }
     // (B) score + filter, (C) select
     QREC_HIP_CHECK(hipMemsetAsync(n_flagged, 0, sizeof(int32_t), st));
-    const int variant = fused_variant();
-    if (variant == 0) {
-        const dim3 grid((unsigned)((n_b + 31) / 32), (unsigned)g.grid_y);
-        if (ld <= 64)
-            hipLaunchKernelGGL((score_filter_kernel_f32<1>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, tau, g.n_lists, cand_s,
-                               cand_i, cand_n);
-        else
-            hipLaunchKernelGGL((score_filter_kernel_f32<2>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, tau, g.n_lists, cand_s,
-                               cand_i, cand_n);
-    } else {
-        const dim3 grid((unsigned)g.n_utiles, (unsigned)g.grid_y);
-#define QREC_SF2(NC, OCC) hipLaunchKernelGGL((score_filter2_kernel_f32<NC, OCC>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, 0, tau, \
-                                             g.n_lists, cand_s, cand_i, cand_n)
-        if (ld <= 64) { if (variant == 2) QREC_SF2(1, 2); else QREC_SF2(1, 1); }
-        else QREC_SF2(2, 1);
-#undef QREC_SF2
-    }
+    // measured at the Yelp2018 shape (kernel time): one user tile per wavefront at 4 wavefronts per SIMD 2.49 ms (a single
+    // dependent accumulator chain), two tiles at one wavefront per SIMD 1.72, two tiles at two wavefronts per SIMD 1.67
+    const dim3 grid((unsigned)g.n_utiles, (unsigned)g.grid_y);
+    if (ld <= 64)
+        hipLaunchKernelGGL((score_filter2_kernel_f32<1, 2>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, 0, tau, g.n_lists,
+                           cand_s, cand_i, cand_n);
+    else
+        hipLaunchKernelGGL((score_filter2_kernel_f32<2, 1>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, 0, tau, g.n_lists,
+                           cand_s, cand_i, cand_n);
     QREC_LAUNCH_CHECK();
     const size_t lds = (size_t)kSelectWaves * g.n_lists * kListCap * sizeof(unsigned long long);
     QREC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
