@@ -102,6 +102,13 @@ int qrec_philox_bpr_sample(const int64_t *d_pos_indptr, const int32_t *d_pos_sor
                            const int32_t *d_row_user, int64_t n, int32_t n_items, uint64_t seed,
                            uint64_t epoch, int32_t *d_j_out, void *stream);
 
+/* Throughput mode of the pairwise (TF-path) models, base/deepRecommender.py:29-52 on the device: the epoch's row order
+ * from qrec_random_permutations (a uniform shuffle, one device sort), the rows gathered into that order here, one
+ * negative per row from qrec_philox_bpr_sample with the rated CSR as the exclusion set.  Same distribution as
+ * shuffle + choice-with-rejection, not the CPython stream.                                                          */
+int qrec_gather_pairs(const int32_t *d_perm, const int32_t *d_u, const int32_t *d_i, int64_t n, int32_t *d_u_out,
+                      int32_t *d_i_out, void *stream);
+
 /* ---- BPR SGD: model/ranking/BPR.py:45-53 --------------------------------------------- */
 
 /* Order-exact mode: the n triplets are applied strictly one after another, in array

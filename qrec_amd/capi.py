@@ -48,6 +48,7 @@ _SIGNATURES = {
     "qrec_mt_shuffle": [_vp, _i64, _vp],
     "qrec_mt_sample_range": [_vp, _i64, _i64, _vp],
     "qrec_mt_pairwise_sample_epoch": [_vp, _vp, _i64, _vp, _vp, _i32, _vp],
+    "qrec_gather_pairs": [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "qrec_philox_bpr_sample": [_vp, _vp, _vp, _i64, _i32, _u64, _u64, _vp, _vp],
     "qrec_bpr_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _vp, _vp],
     "qrec_bpr_exact_width": [C.c_int, _i32, _vp],
@@ -497,6 +498,10 @@ def philox_bpr_sample(d_indptr, d_sorted, d_row_user, n: int, n_items: int, seed
                       d_j_out, stream=None):
     _check(load().qrec_philox_bpr_sample(_dp(d_indptr), _dp(d_sorted), _dp(d_row_user), n, n_items,
                                          seed & (2**64 - 1), epoch & (2**64 - 1), _dp(d_j_out), _sh(stream)))
+
+
+def gather_pairs(d_perm, d_u, d_i, n: int, d_u_out, d_i_out, stream=None):
+    _check(load().qrec_gather_pairs(_dp(d_perm), _dp(d_u), _dp(d_i), n, _dp(d_u_out), _dp(d_i_out), _sh(stream)))
 
 
 def bpr_sgd_ordered(d_P, d_Q, dtype: int, d: int, ld: int, d_u, d_i, d_j, n: int, lr: float,

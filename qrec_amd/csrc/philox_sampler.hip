@@ -65,7 +65,31 @@ __global__ __launch_bounds__(256) void philox_bpr_sample_kernel(
     }
 }
 
+__global__ __launch_bounds__(256) void gather_pairs_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ u,
+                                                           const int32_t *__restrict__ i, int64_t n, int32_t *__restrict__ u_out,
+                                                           int32_t *__restrict__ i_out) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t k = perm[t];
+        u_out[t] = u[k];
+        i_out[t] = i[k];
+    }
+}
+
 }  // namespace
+
+// rows of the training data in a device-drawn order: (u_out, i_out)[t] = (u, i)[perm[t]] -- the device twin of
+// shuffle(self.data.trainingData) for the throughput mode of the pairwise models (base/deepRecommender.py:30)
+extern "C" int qrec_gather_pairs(const int32_t *d_perm, const int32_t *d_u, const int32_t *d_i, int64_t n, int32_t *d_u_out,
+                                 int32_t *d_i_out, void *stream) {
+    QREC_REQUIRE(n >= 0, "qrec_gather_pairs: negative count");
+    if (n == 0) return QREC_OK;
+    QREC_REQUIRE(d_perm && d_u && d_i && d_u_out && d_i_out, "qrec_gather_pairs: null argument");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(gather_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, qrec::as_stream(stream), d_perm, d_u, d_i, n, d_u_out, d_i_out);
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
 
 extern "C" int qrec_philox_bpr_sample(const int64_t *d_indptr, const int32_t *d_sorted,
                                       const int32_t *d_row_user, int64_t n, int32_t n_items,

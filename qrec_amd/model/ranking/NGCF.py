@@ -32,10 +32,9 @@ class NGCF(GraphRecommender):
         tr = self.trainer
         dp = tr.dp = self.data_parallel()              # one process per GPU: a step = batch_size x world rows, this rank's share
         step_rows = self.batch_size * (dp.world if dp else 1)
-        for epoch, (u, i, j) in enumerate(self.iter_epoch_samples(self.maxEpoch)):
-            d_u, d_i, d_j = DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i), DeviceBuffer.from_numpy(j)
-            for n, s in enumerate(range(0, u.size, step_rows)):
-                lo, B = self.step_share(dp, min(step_rows, u.size - s))
+        for epoch, (n_rows, d_u, d_i, d_j) in enumerate(self.iter_epoch_device_samples(self.maxEpoch)):     # base/deepRecommender.py:29-52
+            for n, s in enumerate(range(0, n_rows, step_rows)):
+                lo, B = self.step_share(dp, min(step_rows, n_rows - s))
                 tr.train_step_async(d_u.ptr + 4 * (s + lo), d_i.ptr + 4 * (s + lo), d_j.ptr + 4 * (s + lo), B)
                 if not quiet:
                     print("training:", epoch + 1, "batch", n, "loss:", tr.loss())

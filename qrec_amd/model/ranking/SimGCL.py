@@ -54,6 +54,9 @@ class SimGCL(GraphRecommender):
         items (SimGCL.py:61-64) -- 1,210 np.unique calls per epoch at the Yelp shape, ~0.1 s that used to sit between
         two epochs with the GPU idle."""
         u, i, j = self.sample_epoch_pairwise()
+        return self._with_batch_uniques(u, i, j)
+
+    def _with_batch_uniques(self, u, i, j):
         nu = self.num_users
         rows = self._step_rows()
         starts = list(range(0, u.size, rows))
@@ -67,11 +70,21 @@ class SimGCL(GraphRecommender):
         tr = self.trainer
         dp = tr.dp = self.data_parallel()
         rows = self._step_rows()
-        for epoch, (u, i, j, starts, uu, off_u, vv, off_v) in enumerate(self.iter_epoch_samples(self.maxEpoch, self._draw_epoch)):
-            d_u, d_i, d_j = DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i), DeviceBuffer.from_numpy(j)
+        if self.throughput_mode():
+            # batch stream drawn on the device (base/deepRecommender.py); tf.unique of every batch stays on the host, fed by
+            # one read-back of the epoch's row order
+            def epochs():
+                for d_u, d_i, d_j in self.iter_epoch_samples_device(self.maxEpoch):
+                    yield (d_u, d_i, d_j) + self._with_batch_uniques(d_u.numpy(), d_i.numpy(), None)[3:]
+        else:
+            def epochs():
+                for u, i, j, *rest in self.iter_epoch_samples(self.maxEpoch, self._draw_epoch):
+                    yield (DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i), DeviceBuffer.from_numpy(j)) + tuple(rest)
+        for epoch, (d_u, d_i, d_j, starts, uu, off_u, vv, off_v) in enumerate(epochs()):
+            n_rows = d_u.shape[0]
             d_uu, d_vv = DeviceBuffer.from_numpy(uu), DeviceBuffer.from_numpy(vv)
             for n, s in enumerate(starts):
-                B = min(rows, u.size - s)
+                B = min(rows, n_rows - s)
                 tr.train_step_async(d_u.ptr + 4 * s, d_i.ptr + 4 * s, d_j.ptr + 4 * s, B,
                                     d_uu.ptr + 4 * int(off_u[n]), int(off_u[n + 1] - off_u[n]),
                                     d_vv.ptr + 4 * int(off_v[n]), int(off_v[n + 1] - off_v[n]),

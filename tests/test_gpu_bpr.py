@@ -714,6 +714,36 @@ def test_cross_validation_folds_run_in_child_processes(tmp_path, parallel):
     assert all(0.0 <= float(r.split(":")[1]) <= 1.0 for r in res[1:])
 
 
+def test_cross_validation_on_two_ranks_runs_the_folds_in_process(tmp_path):
+    """``-cv k`` under ``torch.distributed.run``: the ranks hold a device context and a communicator, which
+    do not survive a fork, and must issue the same collectives in the same order -- so the folds run one after another
+    in every rank's process, each of them data-parallel; rank 0 alone writes the averaged measure file.  Two processes
+    on the one device (staged gloo transport)."""
+    import os, subprocess, sys
+    rng = np.random.default_rng(33)
+    n = 4000
+    rows = [f"user{u} item{i} {r}" for u, i, r in zip(rng.integers(0, 200, n), rng.integers(0, 300, n), rng.choice([1, 2, 3, 4, 5], n))]
+    (tmp_path / "ratings.txt").write_text("\n".join(rows) + "\n")
+    conf = {"ratings": "./ratings.txt", "ratings.setup": "-columns 0 1 2", "model.name": "BPR",
+            "evaluation.setup": "-cv 3 -b 1 -p on", "item.ranking": "on -topN 10",
+            "num.factors": "16", "num.max.epoch": "3", "learnRate": "-init 0.05 -max 1",
+            "reg.lambda": "-u 0.01 -i 0.01 -b 0.2 -s 0.2", "output.setup": "off -dir ./results/"}
+    (tmp_path / "BPR.conf").write_text("".join(f"{k}={v}\n" for k, v in conf.items()))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), QREC_DIST_TEST_ONE_DEVICE="1",
+               QREC_MODE="throughput", QREC_SEED="4")
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29557", "-m", "qrec_amd.main", "BPR.conf"], cwd=tmp_path, env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
+    assert run.stdout.count("The result of 3-fold cross validation:") == 2           # both ranks got there
+    out = list((tmp_path / "results").glob("BPR@*-3-fold-cv.txt"))
+    assert len(out) == 1                                                               # written once
+    res = out[0].read_text().splitlines()
+    assert [r.split(":")[0] for r in res] == ["Top 10", "Precision", "Recall", "F1", "NDCG"]
+    assert all(0.0 <= float(r.split(":")[1]) <= 1.0 for r in res[1:])
+
+
 @pytest.mark.parametrize("schedule", ["user", "item"])
 def test_tables_beyond_4_gib_use_64_bit_addressing(schedule):
     """A 4.35 GB user table (17 M rows x 64 floats): the throughput kernels switch from the 32-bit-offset buffer

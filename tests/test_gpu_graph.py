@@ -159,6 +159,54 @@ def test_lightgcn_class_end_to_end_against_restatement_with_reference_sampler_st
     assert np.array_equal(capi.state_from_python(random.getstate()), z["py_state"])   # sampler stayed in lock-step
 
 
+@pytest.mark.parametrize("name", ["LightGCN", "NGCF", "SimGCL"])
+def test_throughput_mode_of_the_pairwise_models_draws_its_batches_on_the_device(name, monkeypatch):
+    """QREC_MODE=throughput (base/deepRecommender.py:29-52 on the device): every epoch is a uniform shuffle of the
+    training rows with one negative per row that the user has not rated -- a permutation of the rows, valid negatives,
+    reproducible per (seed, epoch), different from epoch to epoch -- Python's generator is left alone, and the class
+    trains to the quality of the exact mode (same conf, same initial tables; measures within sampling noise)."""
+    from qrec_amd.QRec import resolve_model
+    meta, z = load_golden("pairwise_adj_filmtrust")
+    gz = load_golden("bpr_filmtrust")[1]
+    train, test = rows_from_golden(gz)
+    conf = conf_from_text(meta["conf"]); conf["model.name"] = name; conf["num.max.epoch"] = "6"; conf["num.factors"] = "16"
+    conf["item.ranking"] = "on -topN 10"; conf["learnRate"] = "-init 0.002 -max 1"
+    if name == "SimGCL":
+        conf["SimGCL"] = "-n_layer 2 -lambda 0.5 -eps 0.1"
+    monkeypatch.setenv("QREC_QUIET", "1"); monkeypatch.setenv("QREC_SEED", "5")
+    cls = resolve_model(name)
+
+    def run(mode):
+        monkeypatch.setenv("QREC_MODE", mode)
+        random.seed(3); np.random.seed(3)
+        with redirect_stdout(io.StringIO()):
+            m = cls(conf, train, test)
+            measure = m.execute()
+        return m, [float(x.split(":")[1]) for x in measure if ":" in x], random.getstate()
+    m, got, _ = run("throughput")
+    _, want, _ = run("exact")
+    assert m.throughput_mode()
+    np.testing.assert_allclose(got, want, atol=0.02)                       # Precision / Recall / F1 / NDCG at 10
+    assert got[1] > 0.05                                                   # it learned something (Recall@10 on FilmTrust)
+    # the stream itself
+    u0, i0, _ = m.data.training_arrays()
+    rated = m.data.rated_csr()
+    want_pairs = np.sort(u0.astype(np.int64) * m.num_items + i0)
+    state = random.getstate()
+    epochs = [tuple(b.numpy() for b in bufs) for bufs in m.iter_epoch_samples_device(3)]
+    assert random.getstate() == state                                      # no CPython draws
+    again = [tuple(b.numpy() for b in bufs) for bufs in m.iter_epoch_samples_device(2)]
+    for k, (u, i, j) in enumerate(epochs):
+        assert np.array_equal(np.sort(u.astype(np.int64) * m.num_items + i), want_pairs)       # a permutation of the rows
+        assert ((j >= 0) & (j < m.num_items)).all()
+        is_rated = np.zeros((m.num_users, m.num_items), bool); is_rated[rated.row_ids(), rated.indices] = True
+        assert not is_rated[u, j].any()                                                          # negatives are not rated
+        if k < 2:
+            assert all(np.array_equal(a, b) for a, b in zip(epochs[k], again[k]))                # reproducible
+    assert not np.array_equal(epochs[0][0], epochs[1][0]) and not np.array_equal(epochs[0][2], epochs[1][2])
+    assert not np.array_equal(epochs[0][0], u0)                                                  # and it is shuffled
+
+
 # ---------------------------------------------------------------------------------------------
 # SimGCL
 # ---------------------------------------------------------------------------------------------
