@@ -183,8 +183,8 @@ def test_throughput_mode_of_the_pairwise_models_draws_its_batches_on_the_device(
             m = cls(conf, train, test)
             measure = m.execute()
         return m, [float(x.split(":")[1]) for x in measure if ":" in x], random.getstate()
-    m, got, _ = run("throughput")
     _, want, _ = run("exact")
+    m, got, _ = run("throughput")
     assert m.throughput_mode()
     np.testing.assert_allclose(got, want, atol=0.02)                       # Precision / Recall / F1 / NDCG at 10
     assert got[1] > 0.05                                                   # it learned something (Recall@10 on FilmTrust)
