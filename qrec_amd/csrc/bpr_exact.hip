@@ -31,11 +31,7 @@ template <> __device__ inline double dev_exp<double>(double x) { return exp(x); 
 __device__ inline double neg_log_sigmoid_d(double x) { return x >= 0.0 ? log1p(exp(-x)) : (-x + log1p(exp(x))); }
 
 template <typename T>
-__device__ inline T wave_allreduce_sum(T v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
-    return v;
-}
+__device__ inline T wave_allreduce_sum(T v) { return wave_sum_dpp(v); }   // common.h: DPP, not the LDS crossbar
 
 struct Entry {      // as loaded: nothing is computed from a/b before the step that uses them (a use is a wait)
     int4 a, b;      // {u, i, j, t}, {src_P, src_Qi, src_Qj, -}

@@ -44,11 +44,7 @@ __device__ inline double neg_log_sigmoid(double x) {
 }
 
 template <typename T>
-__device__ inline T wave_allreduce_sum(T v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
-    return v;
-}
+__device__ inline T wave_allreduce_sum(T v) { return wave_sum_dpp(v); }   // common.h: DPP, not the LDS crossbar
 
 // EPL = elements per lane; lane l owns columns l, l+64, ...  (d <= 64*EPL)
 template <typename T, int EPL>

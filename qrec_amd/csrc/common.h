@@ -69,4 +69,38 @@ __device__ inline T row_allreduce_sum(T v) {
     return v;
 }
 
+// Sum over the 64 lanes of a wavefront, every lane receives it.  DPP adds inside the 16-lane rows (row_shr 1,2,3 of the
+// input, then row_shr 4 and 8 of the running sum), row_bcast 15 / 31 across the rows, total read from lane 63: six
+// VALU-rate steps.  The xor butterfly this replaces goes through ds_bpermute -- the LDS crossbar, >100 clocks per step and
+// two of them per fp64 value: a third of the order-exact kernels' per-triplet chain (measured).
+// A fixed summation tree, so the result is deterministic; it is NOT the butterfly's tree (last-bit differences).
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ inline float dpp_take(float v) {      // lanes without a source (bounds, masks) receive 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, true));
+}
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ inline double dpp_take(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, BANK_MASK, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, BANK_MASK, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ inline float read_lane63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
+__device__ inline double read_lane63(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <typename T>
+__device__ inline T wave_sum_dpp(T v) {
+    T t = v + dpp_take<0x111, 0xf, 0xf>(v);          // row_shr:1
+    t = t + dpp_take<0x112, 0xf, 0xf>(v);            // row_shr:2
+    t = t + dpp_take<0x113, 0xf, 0xf>(v);            // row_shr:3   -> lanes 3, 7, 11, 15 of a row hold their quad's sum
+    t = t + dpp_take<0x114, 0xf, 0xe>(t);            // row_shr:4, banks 1-3
+    t = t + dpp_take<0x118, 0xf, 0xc>(t);            // row_shr:8, banks 2-3 -> lane 15 of a row holds the row's sum
+    t = t + dpp_take<0x142, 0xa, 0xf>(t);            // row_bcast:15 into rows 1 and 3
+    t = t + dpp_take<0x143, 0xc, 0xf>(t);            // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return read_lane63(t);
+}
+
 }  // namespace qrec
