@@ -615,11 +615,13 @@ __global__ __launch_bounds__(256, OCC) void score_filter2_kernel_f32(
         };
         float *cs0 = cand_s + ((int64_t)b0 * n_lists + list) * kListCap, *cs1 = cand_s + ((int64_t)b1 * n_lists + list) * kListCap;
         int32_t *ci0 = cand_i + ((int64_t)b0 * n_lists + list) * kListCap, *ci1 = cand_i + ((int64_t)b1 * n_lists + list) * kListCap;
-        // one item tile: 64 MFMAs, then the accumulators against the two thresholds.  Every executed VALU instruction of
-        // the epilogue costs matrix-pipe time (measured), so: the element tests are entered only when some lane's
-        // 16-element maximum reaches its threshold, the item-range test exists only in the catalogue's last tile.
-        auto do_tile = [&](int t, const f32x4 (&v)[NC][8]) {
-            f32x16 acc0, acc1;
+        // One item tile = 64 MFMAs into a pair of accumulators, then the pair against the two thresholds.  The tiles are
+        // software-pipelined over TWO accumulator pairs: tile t+1's MFMAs are issued BEFORE tile t's compare / append
+        // epilogue, which then executes under them (MFMA and VALU co-execute; an epilogue placed between two tiles' MFMAs
+        // leaves the matrix pipe idle while it runs -- tools/ubench/mfma_tile.hip: 92 -> 112 TFLOP/s for this loop shape).
+        // The element tests are entered only when some lane's 16-element maximum reaches its threshold; the item-range
+        // test exists only in the catalogue's last tile.
+        auto mfmas = [&](const f32x4 (&v)[NC][8], f32x16 &acc0, f32x16 &acc1) {
 #pragma unroll
             for (int q = 0; q < 16; q++) { acc0[q] = 0.f; acc1[q] = 0.f; }
 #pragma unroll
@@ -635,6 +637,8 @@ __global__ __launch_bounds__(256, OCC) void score_filter2_kernel_f32(
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].w, ua[c][q].w, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].w, ub[c][q].w, acc1, 0, 0, 0);
                 }
+        };
+        auto epilogue = [&](int t, f32x16 &acc0, f32x16 &acc1) {
             // C/D: col = lane&31 (user), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (item); items visited in ascending id per lane
             const int item_base = t * 32 + 4 * h;
             if (t * 32 + 32 > n_items) {              // the last, partial tile: rows past the catalogue repeat its last item
@@ -662,136 +666,30 @@ __global__ __launch_bounds__(256, OCC) void score_filter2_kernel_f32(
                     }
             }
         };
-        // two operand buffers, used alternately (no register copies): tile t from one while tile t + t_step loads into the other
+        // two operand buffers and two accumulator pairs, used alternately (no register copies)
         f32x4 va[NC][8], vb[NC][8];
-        load_tile(t_begin, va);
-        int t = t_begin;
+        f32x16 A0, A1, B0, B1;
+        int t = t_begin;                                   // the tile whose products sit in (A0, A1)
+        load_tile(t, va);
+        if (t + t_step < t_end) load_tile(t + t_step, vb);
+        mfmas(va, A0, A1);
         while (true) {
-            if (t + t_step < t_end) load_tile(t + t_step, vb);
-            do_tile(t, va);
-            t += t_step;
-            if (t >= t_end) break;
-            if (t + t_step < t_end) load_tile(t + t_step, va);
-            do_tile(t, vb);
-            t += t_step;
-            if (t >= t_end) break;
-        }
-    }
-    if (live0) cand_n[(int64_t)b0 * n_lists + list] = cnt0;
-    if (live1) cand_n[(int64_t)b1 * n_lists + list] = cnt1;
-}
-
-// The same pass with the item tile SHARED by the block's four wavefronts (four user pairs per block, all walking the same
-// item tiles): the tile is fetched once per block with row-contiguous 16-byte loads (every cache line requested once),
-// staged in LDS (row stride padded by 4 floats: the 8 lanes a ds_read_b128 serves together hit 8 different bank groups) and
-// read back in the MFMA operand layout.  In the per-wavefront version above each wavefront fetched its own tile with
-// 64 cache lines per load instruction, every line requested four times, through a 32 KB L1 that eight 8 KB tiles in flight
-// overflow: 1.66 ms whether or not any element reached its threshold (measured with the thresholds set to +inf), against
-// 0.98 ms of MFMA time -- tools/ubench/mfma_f32.hip sustains 143-155 TFLOP/s with this instruction from registers.
-template <int NC>
-__global__ __launch_bounds__(256) void score_filter3_kernel_f32(
-    const float *__restrict__ U, const float *__restrict__ V, int ld, int n_items, const int32_t *__restrict__ user_ids,
-    int n_b, const float *__restrict__ tau, int n_lists, float *__restrict__ cand_s, int32_t *__restrict__ cand_i,
-    int32_t *__restrict__ cand_n) {
-    constexpr int COLS = 64 * NC, STRIDE = COLS + 4, TILE4 = 32 * COLS / 4, PER = TILE4 / 256;   // f32x4 per thread and tile
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *lds = reinterpret_cast<float *>(smem);                       // [2][32][STRIDE]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int upair = blockIdx.x * 4 + wave;
-    const int b0 = upair * 64 + r, b1 = b0 + 32;
-    const int list = blockIdx.y * 2 + h;
-    const int n_item_tiles = (n_items + 31) / 32;
-    const int t_step = gridDim.y;
-    const bool live0 = b0 < n_b, live1 = b1 < n_b;
-    const int64_t uid0 = user_ids[live0 ? b0 : n_b - 1], uid1 = user_ids[live1 ? b1 : n_b - 1];
-    const float th0 = live0 ? tau[b0] : __builtin_huge_valf(), th1 = live1 ? tau[b1] : __builtin_huge_valf();
-    int cnt0 = 0, cnt1 = 0;
-    f32x4 ua[NC][8], ub[NC][8];
-    int kb[NC];
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        const int col0 = 64 * c + 32 * h;
-        const bool kv = col0 < ld;
-        kb[c] = kv ? col0 : 0;
-        const float keep = kv ? 1.f : 0.f;
-        const f32x4 *p0 = reinterpret_cast<const f32x4 *>(U + uid0 * ld + kb[c]), *p1 = reinterpret_cast<const f32x4 *>(U + uid1 * ld + kb[c]);
-#pragma unroll
-        for (int q = 0; q < 8; q++) { ua[c][q] = p0[q] * keep; ub[c][q] = p1[q] * keep; }
-    }
-    // cooperative tile fetch: thread x takes f32x4 number x, x + 256, ... of the [32][COLS] tile (row-major, columns >= ld
-    // read as 0 through the clamp below: ld is a multiple of 32, COLS of 64)
-    f32x4 stage[PER];
-    auto fetch = [&](int t) {
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int x = threadIdx.x + 256 * k, row = x / (COLS / 4), c4 = x % (COLS / 4);
-            const int item = t * 32 + row;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(V + (int64_t)(item < n_items ? item : n_items - 1) * ld + (4 * c4 < ld ? 4 * c4 : 0));
-            stage[k] = 4 * c4 < ld ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int x = threadIdx.x + 256 * k, row = x / (COLS / 4), c4 = x % (COLS / 4);
-            *reinterpret_cast<f32x4 *>(lds + (buf * 32 + row) * STRIDE + 4 * c4) = stage[k];
-        }
-    };
-    float *cs0 = cand_s + ((int64_t)b0 * n_lists + list) * kListCap, *cs1 = cand_s + ((int64_t)b1 * n_lists + list) * kListCap;
-    int32_t *ci0 = cand_i + ((int64_t)b0 * n_lists + list) * kListCap, *ci1 = cand_i + ((int64_t)b1 * n_lists + list) * kListCap;
-    int t = blockIdx.y, buf = 0;
-    if (t < n_item_tiles) { fetch(t); stash(0); }
-    __syncthreads();
-    for (; t < n_item_tiles; t += t_step) {
-        const bool more = t + t_step < n_item_tiles;
-        if (more) fetch(t + t_step);                         // in flight under this tile's MFMAs
-        f32x16 acc0, acc1;
-#pragma unroll
-        for (int q = 0; q < 16; q++) { acc0[q] = 0.f; acc1[q] = 0.f; }
-        const float *row = lds + (buf * 32 + r) * STRIDE;
-#pragma unroll
-        for (int c = 0; c < NC; c++)
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(row + kb[c] + 4 * q);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, ua[c][q].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, ub[c][q].x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, ua[c][q].y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, ub[c][q].y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, ua[c][q].z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, ub[c][q].z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, ua[c][q].w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, ub[c][q].w, acc1, 0, 0, 0);
+            const int t1 = t + t_step;
+            if (t1 < t_end) {
+                if (t1 + t_step < t_end) load_tile(t1 + t_step, va);     // va is free: its MFMAs have been issued
+                mfmas(vb, B0, B1);
             }
-        const int item_base = t * 32 + 4 * h;
-        if (t * 32 + 32 > n_items) {              // the last, partial tile: rows past the catalogue repeat its last item
-#pragma unroll
-            for (int q = 0; q < 16; q++)
-                if (item_base + (q & 3) + 8 * (q >> 2) >= n_items) { acc0[q] = -__builtin_huge_valf(); acc1[q] = -__builtin_huge_valf(); }
+            epilogue(t, A0, A1);                           // under tile t1's MFMAs
+            if (t1 >= t_end) break;
+            const int t2 = t1 + t_step;
+            if (t2 < t_end) {
+                if (t2 + t_step < t_end) load_tile(t2 + t_step, vb);
+                mfmas(va, A0, A1);
+            }
+            epilogue(t1, B0, B1);
+            if (t2 >= t_end) break;
+            t = t2;
         }
-        float m0 = acc0[0], m1 = acc1[0];
-#pragma unroll
-        for (int q = 1; q < 16; q++) { m0 = fmaxf(m0, acc0[q]); m1 = fmaxf(m1, acc1[q]); }
-        if (m0 >= th0) {
-#pragma unroll
-            for (int q = 0; q < 16; q++)
-                if (acc0[q] >= th0) {
-                    if (cnt0 < kListCap) { cs0[cnt0] = acc0[q]; ci0[cnt0] = item_base + (q & 3) + 8 * (q >> 2); }
-                    cnt0++;
-                }
-        }
-        if (m1 >= th1) {
-#pragma unroll
-            for (int q = 0; q < 16; q++)
-                if (acc1[q] >= th1) {
-                    if (cnt1 < kListCap) { cs1[cnt1] = acc1[q]; ci1[cnt1] = item_base + (q & 3) + 8 * (q >> 2); }
-                    cnt1++;
-                }
-        }
-        if (more) stash(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
     }
     if (live0) cand_n[(int64_t)b0 * n_lists + list] = cnt0;
     if (live1) cand_n[(int64_t)b1 * n_lists + list] = cnt1;
@@ -1011,8 +909,8 @@ __host__ inline FusedGeom fused_geometry(int n_items, int n_b) {
     int waves = (4096 + g.n_utiles - 1) / g.n_utiles;                 // wavefronts per user pair: fill 1,024 SIMDs a few times over
     if (waves > g.n_item_tiles / 8) waves = g.n_item_tiles / 8 > 0 ? g.n_item_tiles / 8 : 1;
     if (waves > 32) waves = 32;              // <= 64 candidate lists per user: the selection kernel gathers them in LDS
-    g.grid_y = waves;                        // blocks (of four user pairs) that share the catalogue's tiles round-robin
-    g.n_lists = g.grid_y * 2;
+    g.grid_y = (waves + 3) / 4;
+    g.n_lists = g.grid_y * 4 * 2;
     g.n_s_tiles = (g.n_item_tiles + kSampleStride - 1) / kSampleStride;
     const int first_of_last = (g.n_s_tiles - 1) * kSampleStride * 32;
     const int valid_last = n_items - first_of_last < 32 ? n_items - first_of_last : 32;
@@ -1081,18 +979,17 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
     }
     // (B) score + filter, (C) select
     QREC_HIP_CHECK(hipMemsetAsync(n_flagged, 0, sizeof(int32_t), st));
-    // measured at the Yelp2018 shape (kernel time): per-wavefront item tiles 1.67-1.72 ms (score_filter2, kept for reference);
-    // one user tile per wavefront 2.49 ms; the block-shared tile through LDS (score_filter3): see DESIGN.md
-    const dim3 grid((unsigned)((g.n_utiles + 3) / 4), (unsigned)g.grid_y);
-    if (ld <= 64) {
-        const size_t lds_b = (size_t)2 * 32 * (64 + 4) * 4;
-        hipLaunchKernelGGL((score_filter3_kernel_f32<1>), grid, dim3(256), lds_b, st, U, V, ld, n_items, user_ids, n_b, tau, g.n_lists,
+    // measured at the Yelp2018 shape (kernel time of this pass): one user tile per wavefront 2.49 ms (twice the operand loads per
+    // MFMA); two tiles per wavefront, epilogue between the tiles' MFMAs 1.67-1.72 ms; the item tile shared by the block's
+    // wavefronts through LDS (coalesced fetch, one barrier per tile) 1.89 ms; two tiles per wavefront with the epilogue
+    // software-pipelined under the next tile's MFMAs: what is launched here (DESIGN.md s4 has the numbers)
+    const dim3 grid((unsigned)g.n_utiles, (unsigned)g.grid_y);
+    if (ld <= 64)
+        hipLaunchKernelGGL((score_filter2_kernel_f32<1, 1>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, 0, tau, g.n_lists,
                            cand_s, cand_i, cand_n);
-    } else {
-        const size_t lds_b = (size_t)2 * 32 * (128 + 4) * 4;
-        hipLaunchKernelGGL((score_filter3_kernel_f32<2>), grid, dim3(256), lds_b, st, U, V, ld, n_items, user_ids, n_b, tau, g.n_lists,
+    else
+        hipLaunchKernelGGL((score_filter2_kernel_f32<2, 1>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, 0, tau, g.n_lists,
                            cand_s, cand_i, cand_n);
-    }
     QREC_LAUNCH_CHECK();
     const size_t lds = (size_t)kSelectWaves * g.n_lists * kListCap * sizeof(unsigned long long);
     QREC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
