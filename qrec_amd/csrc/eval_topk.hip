@@ -17,7 +17,6 @@
 // Bytes: (1) writes I*B*s, reads V once per user tile from cache; (3) reads I*B*s.
 // FLOPs: 2*B*I*d on the matrix pipe.
 #include <cstdlib>
-#include <vector>
 
 #include "common.h"
 
@@ -615,13 +614,11 @@ __global__ __launch_bounds__(256, OCC) void score_filter2_kernel_f32(
         };
         float *cs0 = cand_s + ((int64_t)b0 * n_lists + list) * kListCap, *cs1 = cand_s + ((int64_t)b1 * n_lists + list) * kListCap;
         int32_t *ci0 = cand_i + ((int64_t)b0 * n_lists + list) * kListCap, *ci1 = cand_i + ((int64_t)b1 * n_lists + list) * kListCap;
-        // One item tile = 64 MFMAs into a pair of accumulators, then the pair against the two thresholds.  The tiles are
-        // software-pipelined over TWO accumulator pairs: tile t+1's MFMAs are issued BEFORE tile t's compare / append
-        // epilogue, which then executes under them (MFMA and VALU co-execute; an epilogue placed between two tiles' MFMAs
-        // leaves the matrix pipe idle while it runs -- tools/ubench/mfma_tile.hip: 92 -> 112 TFLOP/s for this loop shape).
-        // The element tests are entered only when some lane's 16-element maximum reaches its threshold; the item-range
-        // test exists only in the catalogue's last tile.
-        auto mfmas = [&](const f32x4 (&v)[NC][8], f32x16 &acc0, f32x16 &acc1) {
+        // one item tile: 64 MFMAs, then the accumulators against the two thresholds.  Every executed VALU instruction of
+        // the epilogue costs matrix-pipe time (measured), so: the element tests are entered only when some lane's
+        // 16-element maximum reaches its threshold, the item-range test exists only in the catalogue's last tile.
+        auto do_tile = [&](int t, const f32x4 (&v)[NC][8]) {
+            f32x16 acc0, acc1;
 #pragma unroll
             for (int q = 0; q < 16; q++) { acc0[q] = 0.f; acc1[q] = 0.f; }
 #pragma unroll
@@ -637,8 +634,6 @@ __global__ __launch_bounds__(256, OCC) void score_filter2_kernel_f32(
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].w, ua[c][q].w, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].w, ub[c][q].w, acc1, 0, 0, 0);
                 }
-        };
-        auto epilogue = [&](int t, f32x16 &acc0, f32x16 &acc1) {
             // C/D: col = lane&31 (user), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (item); items visited in ascending id per lane
             const int item_base = t * 32 + 4 * h;
             if (t * 32 + 32 > n_items) {              // the last, partial tile: rows past the catalogue repeat its last item
@@ -666,29 +661,19 @@ __global__ __launch_bounds__(256, OCC) void score_filter2_kernel_f32(
                     }
             }
         };
-        // two operand buffers and two accumulator pairs, used alternately (no register copies)
+        // two operand buffers, used alternately (no register copies): tile t from one while tile t + t_step loads into the other
         f32x4 va[NC][8], vb[NC][8];
-        f32x16 A0, A1, B0, B1;
-        int t = t_begin;                                   // the tile whose products sit in (A0, A1)
-        load_tile(t, va);
-        if (t + t_step < t_end) load_tile(t + t_step, vb);
-        mfmas(va, A0, A1);
+        load_tile(t_begin, va);
+        int t = t_begin;
         while (true) {
-            const int t1 = t + t_step;
-            if (t1 < t_end) {
-                if (t1 + t_step < t_end) load_tile(t1 + t_step, va);     // va is free: its MFMAs have been issued
-                mfmas(vb, B0, B1);
-            }
-            epilogue(t, A0, A1);                           // under tile t1's MFMAs
-            if (t1 >= t_end) break;
-            const int t2 = t1 + t_step;
-            if (t2 < t_end) {
-                if (t2 + t_step < t_end) load_tile(t2 + t_step, vb);
-                mfmas(va, A0, A1);
-            }
-            epilogue(t1, B0, B1);
-            if (t2 >= t_end) break;
-            t = t2;
+            if (t + t_step < t_end) load_tile(t + t_step, vb);
+            do_tile(t, va);
+            t += t_step;
+            if (t >= t_end) break;
+            if (t + t_step < t_end) load_tile(t + t_step, va);
+            do_tile(t, vb);
+            t += t_step;
+            if (t >= t_end) break;
         }
     }
     if (live0) cand_n[(int64_t)b0 * n_lists + list] = cnt0;
@@ -972,20 +957,18 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
         hipLaunchKernelGGL(threshold_kernel<float>, dim3(lane_blocks), dim3(256), 0, st, gmax, g.b_pad, n_b, M, tau);
         QREC_LAUNCH_CHECK();
     }
-    if (getenv("QREC_EVAL_EXPERIMENT_INF_TAU")) {      // measurement only: no element ever reaches its threshold -> the scoring kernel's pure MFMA + load time
-        std::vector<float> inf((size_t)g.b_pad, __builtin_huge_valf());
-        QREC_HIP_CHECK(hipMemcpyAsync(tau, inf.data(), inf.size() * 4, hipMemcpyHostToDevice, st));
-        QREC_HIP_CHECK(hipStreamSynchronize(st));
-    }
     // (B) score + filter, (C) select
     QREC_HIP_CHECK(hipMemsetAsync(n_flagged, 0, sizeof(int32_t), st));
-    // measured at the Yelp2018 shape (kernel time of this pass): one user tile per wavefront 2.49 ms (twice the operand loads per
-    // MFMA); two tiles per wavefront, epilogue between the tiles' MFMAs 1.67-1.72 ms; the item tile shared by the block's
-    // wavefronts through LDS (coalesced fetch, one barrier per tile) 1.89 ms; two tiles per wavefront with the epilogue
-    // software-pipelined under the next tile's MFMAs: what is launched here (DESIGN.md s4 has the numbers)
+    // measured at the Yelp2018 shape (kernel time of this pass; 0.98 ms of pure MFMA time): one user tile per wavefront at 4
+    // wavefronts per SIMD 2.49 ms (twice the operand loads per MFMA); two tiles at one wavefront per SIMD 1.72, at two
+    // wavefronts per SIMD 1.67 (launched here); the item tile shared by a block's wavefronts through LDS (coalesced fetch,
+    // one barrier per tile) 1.89; the epilogue software-pipelined under the next tile's MFMAs over two accumulator pairs
+    // 1.92 (448 registers, accumulators shuttling between AGPRs and VGPRs) although the same loop shape gains 22 % in
+    // tools/ubench/mfma_tile.hip; thresholds at +inf (no element ever appended) 1.66: the pass is bound by the per-lane-row
+    // operand fetch interleaved with the accumulator read-out, not by the compare / append work
     const dim3 grid((unsigned)g.n_utiles, (unsigned)g.grid_y);
     if (ld <= 64)
-        hipLaunchKernelGGL((score_filter2_kernel_f32<1, 1>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, 0, tau, g.n_lists,
+        hipLaunchKernelGGL((score_filter2_kernel_f32<1, 2>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, 0, tau, g.n_lists,
                            cand_s, cand_i, cand_n);
     else
         hipLaunchKernelGGL((score_filter2_kernel_f32<2, 1>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, 0, tau, g.n_lists,
