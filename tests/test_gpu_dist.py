@@ -308,8 +308,11 @@ def test_two_rank_bench_path_with_row_sharded_item_table(tmp_path, scaling):
     """--dist-mode sharded: each rank holds half of the item rows; the epoch's batches fetch and return rows through
     the all-to-all exchange.  Both drivers see the same all-reduced loss terms; the run trains (loss goes down) and
     the two shards together are a table that moved on every row the epoch touched."""
+    # weak layout: both ranks' populations hit the SAME hot items in the same batch; with the item-major schedule every
+    # chunk of a hot item reads the batch-start row (DESIGN.md s7), so this case runs user-major; strong runs item-major
     out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs-per-step", "3", "--no-cpu-baseline", "--shape", "ml1m",
-                  "--dist-mode", "sharded", "--shard-batch", "250000", "--scaling", scaling],
+                  "--dist-mode", "sharded", "--shard-batch", "250000", "--scaling", scaling,
+                  "--schedule", "user" if scaling == "weak" else "item"],
                  {"QREC_DIST_TEST_ONE_DEVICE": "1", "QREC_DIST_TEST_DUMP": str(tmp_path)}, nproc=2, port=29543)
     assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["value"] > 0
     assert out["config"]["batches_per_epoch"] >= (2 if scaling == "strong" else 4) and out["config"]["xgmi_bytes_per_epoch_all_ranks"] > 0
