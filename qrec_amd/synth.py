@@ -21,6 +21,9 @@ SHAPES = {
     # name: (users, items, train_edges, test_edges, seed)
     "ml1m": (6040, 3706, 1000209, 0, 1000),
     "yelp2018": (31668, 38048, 1237259, 324147, 2018),
+    # same sizes, but 64 planted communities: 80 % of a user's interactions fall on items of the user's own community
+    # (gen_edges_clustered) -- a graph WITH locality to harvest, next to the structureless one (SpMM L2 work)
+    "yelp2018-clustered": (31668, 38048, 1237259, 324147, 2018),
     "tiny": (300, 200, 6000, 1500, 7),
     "small": (2000, 1500, 60000, 15000, 11),
 }
@@ -58,6 +61,49 @@ def gen_edges(n_users: int, n_items: int, n_edges: int, seed: int,
     return u[first], i[first]
 
 
+def gen_edges_clustered(n_users: int, n_items: int, n_edges: int, seed: int, n_clusters: int = 64, p_in: float = 0.8,
+                        alpha_user: float = 0.4, alpha_item: float = 0.6):
+    """As ``gen_edges`` but with planted communities: users and items are assigned to ``n_clusters`` communities at
+    random; a draw picks the user by popularity and, with probability ``p_in``, an item OF THE USER'S COMMUNITY by
+    (within-community) popularity, otherwise any item by popularity.  Ids stay randomly permuted, so the locality is
+    in the graph, not in the numbering."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pu = _zipf_probs(n_users, alpha_user, rng)
+    pi = _zipf_probs(n_items, alpha_item, rng)
+    cl_u = rng.integers(0, n_clusters, n_users)
+    cl_i = rng.integers(0, n_clusters, n_items)
+    by_cl = np.argsort(cl_i, kind="stable")                         # items grouped by community
+    start = np.searchsorted(cl_i[by_cl], np.arange(n_clusters + 1))
+    w = pi[by_cl]
+    tot = np.add.reduceat(w, start[:-1])
+    cdf = np.cumsum(w) - np.repeat(np.concatenate([[0.0], np.cumsum(tot)[:-1]]), np.diff(start))
+    cdf = cdf / np.repeat(tot, np.diff(start)) + np.repeat(np.arange(n_clusters), np.diff(start))   # community c: (c, c+1]
+
+    def draw_items(users):
+        glob = rng.choice(n_items, size=users.size, p=pi)
+        c = cl_u[users]
+        k = np.searchsorted(cdf, c + rng.random(users.size) * (1 - 1e-12), side="left")
+        k = np.clip(k, start[c], start[c + 1] - 1)
+        return np.where(rng.random(users.size) < p_in, by_cl[k], glob)
+
+    cu = np.arange(n_users, dtype=np.int64)
+    ci = draw_items(cu)
+    du = rng.choice(n_users, size=n_items, p=pu)
+    di = np.arange(n_items, dtype=np.int64)
+    m = int(1.4 * n_edges)
+    ru = rng.choice(n_users, size=m, p=pu)
+    ri = draw_items(ru)
+    u = np.concatenate([cu, du, ru])
+    i = np.concatenate([ci, di, ri])
+    key = u * np.int64(n_items) + i
+    _, first = np.unique(key, return_index=True)
+    first.sort()
+    if first.size < n_edges:
+        raise ValueError("not enough distinct pairs; raise the oversampling factor")
+    first = first[:n_edges]
+    return u[first], i[first]
+
+
 def relabel_first_appearance(u: np.ndarray, i: np.ndarray):
     """Relabel users/items by first appearance while walking the rows in order — exactly
     the id assignment of the reference data model (data/rating.py:48-54)."""
@@ -81,7 +127,7 @@ def make_dataset(shape: str = "yelp2018", *, test_fraction: float | None = None)
     """
     n_users, n_items, e_train, e_test, seed = SHAPES[shape]
     total = e_train + e_test
-    u, i = gen_edges(n_users, n_items, total, seed)
+    u, i = (gen_edges_clustered if shape.endswith("-clustered") else gen_edges)(n_users, n_items, total, seed)
     # group by user, stable (keeps each user's draw order)
     order = np.argsort(u, kind="stable")
     u, i = u[order], i[order]

@@ -63,6 +63,41 @@ def test_spmm_matches_scipy(dim, ld, seg_len):
         capi.spmm_csr(plan, dX, dX, ld)
 
 
+@pytest.mark.parametrize("chunks", [2, 4])
+@pytest.mark.parametrize("seg_len", [128, 7])
+def test_spmm_row_chunks_do_not_change_a_bit(chunks, seg_len):
+    """SpmmPlan(chunks=...) only reorders the segment list (rows of one spectral-key run on XCDs of their own): plain,
+    with the fused epilogues, with the sparse-operand bitmap and with the wanted-rows bitmap the output is bit for bit
+    the output of the plain order."""
+    d, adj, A = _graph("small")
+    n, ld = A.shape[0], 64
+    rng = np.random.default_rng(chunks)
+    X = rng.standard_normal((n, ld)).astype(np.float32); Z = rng.standard_normal((n, ld)).astype(np.float32)
+    S0 = rng.standard_normal((n, ld)).astype(np.float32)
+    xmask_rows = rng.random(n) < 0.2
+    Xs = X * xmask_rows[:, None]
+    bits = lambda rows: np.packbits(np.pad(rows, (0, (-n) % 32)).reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).ravel()
+    ymask_rows = rng.random(n) < 0.3
+    out = {}
+    for c in (1, chunks):
+        plan = SpmmPlan(adj[0], adj[1], adj[2], ld, seg_len=seg_len, split_row=d["n_users"], chunks=c)
+        assert plan.chunks == c
+        dX, dY = DB.from_numpy(X), DB.zeros((n, ld), np.float32)
+        capi.spmm_csr(plan, dX, dY, ld); plain = dY.numpy()
+        dZ, dS = DB.from_numpy(Z), DB.from_numpy(S0)
+        capi.spmm_csr(plan, dX, dY, ld, d_addend=dZ, addend_scale=0.5, d_accum=dS); fused = (dY.numpy(), dS.numpy())
+        capi.spmm_csr(plan, DB.from_numpy(Xs), dY, ld, d_x_row_mask=DB.from_numpy(bits(xmask_rows))); sparse = dY.numpy()
+        dY2 = DB.from_numpy(np.full((n, ld), 7, np.float32))
+        capi.spmm_csr(plan, dX, dY2, ld, d_y_row_mask=DB.from_numpy(bits(ymask_rows))); wanted = dY2.numpy()
+        out[c] = (plain, fused[0], fused[1], sparse, wanted)
+    for a, b in zip(out[1], out[chunks]):
+        assert np.array_equal(a, b)
+    assert rel_err(out[chunks][0], A.dot(X)) < TOL
+    assert (out[chunks][4][~ymask_rows] == 7).all() and np.array_equal(out[chunks][4][ymask_rows], out[chunks][0][ymask_rows])
+    with pytest.raises(ValueError):
+        SpmmPlan(adj[0], adj[1], adj[2], ld, chunks=2)          # chunks need the bipartite split
+
+
 def test_spmm_empty_rows_and_heavy_row():
     # node 0 connected to everything (one very long row), nodes without edges (empty rows)
     n = 3000

@@ -612,3 +612,22 @@ def test_native_loader_reproduces_the_reference_loaders_rows(tmp_path, monkeypat
             assert list(got) == c["rows"], (c["name"], route)
             assert all(type(r[2]) is float for r in got)
     assert native_seen >= 12          # the native parser really took these files
+
+
+def test_spmm_plan_deals_classes_to_xcds():
+    """SpmmPlan._deal_by_xcd (host side of qrec_spmm_csr's XCD-aware order): a permutation; the list positions that
+    land on a class' XCDs ((p // groups per block) % 8, XCDs split evenly among the classes) carry that class'
+    entries, in the order given, until the class runs out."""
+    from qrec_amd.graph import SpmmPlan
+    rng = np.random.default_rng(0)
+    for n_cls, gpb, n in [(2, 16, 5000), (4, 32, 9001), (8, 64, 20000), (1, 16, 100)]:
+        cls = rng.integers(0, n_cls, n)
+        deal = SpmmPlan._deal_by_xcd(cls, n_cls, gpb)
+        assert np.array_equal(np.sort(deal), np.arange(n))
+        pos_cls = ((np.arange(n) // gpb) % 8) * n_cls // 8
+        for c in range(n_cls):
+            slots = np.nonzero(pos_cls == c)[0]; ents = np.nonzero(cls == c)[0]
+            k = min(slots.size, ents.size)
+            assert np.array_equal(deal[slots[:k]], ents[:k])
+        # balanced classes: nearly every position holds its own class
+        assert (cls[deal] == pos_cls).mean() > 0.9

@@ -11,9 +11,10 @@ from qrec_amd.graph import LightGCNTrainer, joint_norm_adjacency
 from qrec_amd.synth import make_dataset
 ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=100); ap.add_argument("--layers", type=int, default=3)
 ap.add_argument("--batch", type=int, default=2048); ap.add_argument("--cpu", action="store_true"); ap.add_argument("--dim", type=int, default=64)
+ap.add_argument("--shape", default="yelp2018", help="yelp2018 (structureless Zipf) or yelp2018-clustered (64 planted communities)")
 a = ap.parse_args()
 capi.init(0)
-d = make_dataset("yelp2018"); nu, ni = d["n_users"], d["n_items"]
+d = make_dataset(a.shape); nu, ni = d["n_users"], d["n_items"]
 adj = joint_norm_adjacency(nu, ni, d["train_u"], d["train_i"])
 rng = np.random.default_rng(0)
 U0 = (rng.standard_normal((nu, a.dim)) * 0.005).astype(np.float32); V0 = (rng.standard_normal((ni, a.dim)) * 0.005).astype(np.float32)
@@ -46,7 +47,7 @@ for rep in range(20):
     e0.record(); capi.adam_step(tr.E, tr.m, tr.v, tr.A, N * tr.ld, 0.25, 1e-9); e1.record(); e1.sync(); ts.append(e1.elapsed_ms_since(e0))
 adam_ms = float(np.median(ts))
 alg = tr.plan.bytes_algorithmic(a.dim) + N * a.dim * 4   # + accum RMW read
-out = dict(workload=f"LightGCN L={a.layers} d={a.dim} batch={B} Yelp2018-shape N={N} nnz={nnz}", ms_per_step=dt * 1e3, host_enqueue_ms_per_step=t_host * 1e3, ms_per_step_with_loss_readback=dt_sync * 1e3,
+out = dict(workload=f"LightGCN L={a.layers} d={a.dim} batch={B} {a.shape}-shape N={N} nnz={nnz}", spmm_chunks=tr.plan.chunks, ms_per_step=dt * 1e3, host_enqueue_ms_per_step=t_host * 1e3, ms_per_step_with_loss_readback=dt_sync * 1e3,
            triplets_per_s=B / dt, steps_per_epoch=-(-n // B), epoch_s=dt * -(-n // B),
            spmm_ms=spmm_ms, spmm_algorithmic_GBps=alg / spmm_ms / 1e6, spmm_gather_GBps=(nnz * (8 + a.dim * 4) + 2 * N * a.dim * 4) / spmm_ms / 1e6,
            spmm_gflops=2 * nnz * a.dim / spmm_ms / 1e6, adam_ms=adam_ms, adam_GBps=7 * 4 * N * tr.ld / adam_ms / 1e6, segments=tr.plan.n_segs, long_rows=tr.plan.n_long)
