@@ -256,6 +256,256 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const float *__restrict_
     }
 }
 
+// =============================================================================================
+// LD <= 64 (NT = 1, 2): the versions that run.  Same products in the same order as dense_fwd_kernel / dense_bwd_kernel
+// above (which stay for ld = 128), but
+//  * the A operand no longer comes from per-lane-row global loads: a 32 x LD tile is fetched with LD/8 fully coalesced
+//    float4 loads per lane (4 whole rows per instruction), parked in a wave-private LDS tile (row stride LD + 4 floats:
+//    the per-row 16-byte reads of the fragment fall on distinct bank groups) and read back in fragment order; the next
+//    tile's global loads are issued before the current tile's MFMA loop;
+//  * the weights never change inside a launch and a wavefront's B fragments of BOTH matrices are only 2 * NT * 32
+//    values per lane, so they live in registers for the whole launch (one wavefront per SIMD, a persistent loop over
+//    tiles): the MFMA loop reads nothing from memory.  (B values read from LDS right before their MFMA -- 64 ds_read2
+//    per tile, the round-1 kernel and the first LDS version -- measured 17 us of the kernel's 25; with B in registers
+//    the same 128 MFMAs take 8 us.)
+// =============================================================================================
+constexpr int kTilePad = 4;
+
+template <int LD>
+struct RowTile {                                  // a wavefront's view of one 32 x LD tile
+    static constexpr int RS = LD + kTilePad;      // LDS row stride (floats)
+    static constexpr int LPRW = LD / 4;           // lanes per row in the load layout
+    static constexpr int RPI = kWave / LPRW;      // rows per load instruction
+    static constexpr int NV = 32 / RPI;           // float4 per lane per tile
+    int lrow, lcol;
+    __device__ explicit RowTile(int lane) : lrow(lane / LPRW), lcol(4 * (lane % LPRW)) {}
+    __device__ void load(const float *__restrict__ X, int64_t row0, int64_t n_rows, f32x4 (&v)[NV]) const {
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            int64_t row = row0 + k * RPI + lrow;
+            if (row >= n_rows) row = n_rows - 1;                 // rows past the end: a copy of the last row, never stored
+            v[k] = *reinterpret_cast<const f32x4 *>(X + row * LD + lcol);
+        }
+    }
+    __device__ void park(float *tile, const f32x4 (&v)[NV]) const {
+#pragma unroll
+        for (int k = 0; k < NV; k++) *reinterpret_cast<f32x4 *>(tile + (k * RPI + lrow) * RS + lcol) = v[k];
+    }
+    // MFMA A fragment of lane (r, h): columns [32h, 32h + 32) of row r (LD = 32: the upper k-slot feeds zeros)
+    __device__ static void fragment(const float *tile, int r, int h, float (&a)[32]) {
+        const bool kv = 32 * h < LD;
+        const float keep = kv ? 1.f : 0.f;
+        const float *p = tile + r * RS + (kv ? 32 * h : 0);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(p + 4 * q);
+            a[4 * q] = v.x * keep; a[4 * q + 1] = v.y * keep; a[4 * q + 2] = v.z * keep; a[4 * q + 3] = v.w * keep;
+        }
+    }
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void dense_fwd_lds_kernel(const float *__restrict__ E, const float *__restrict__ side,
+                                                            const float *__restrict__ W1, const float *__restrict__ W2,
+                                                            int64_t n_rows, float *__restrict__ pre) {
+    constexpr int LD = 32 * NT;
+    using Tile = RowTile<LD>;
+    extern __shared__ float s_mem[];                // one tile per wavefront
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    float *tile_mem = s_mem + (threadIdx.x >> 6) * (32 * Tile::RS);
+    const Tile tl(lane);
+    const int kb = 32 * h < LD ? 32 * h : 0;        // ld = 32: the upper k-slot has no columns; its A values are zeros
+    const int64_t n_tiles = (n_rows + 31) / 32, stride = (int64_t)gridDim.x * 4;
+    int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    f32x4 e[Tile::NV], sd[Tile::NV];
+    if (tile < n_tiles) { tl.load(E, tile * 32, n_rows, e); tl.load(side, tile * 32, n_rows, sd); }
+    float b1[NT][32], b2[NT][32];                   // B fragments: W[kb + s][32 t + r]
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int s = 0; s < 32; s++) {
+            b1[t][s] = W1[(kb + s) * LD + 32 * t + r];
+            b2[t][s] = W2[(kb + s) * LD + 32 * t + r];
+        }
+    for (; tile < n_tiles; tile += stride) {
+        const int64_t row0 = tile * 32;
+        f32x4 t1[Tile::NV], t2[Tile::NV];
+#pragma unroll
+        for (int k = 0; k < Tile::NV; k++) { t1[k] = sd[k] + e[k]; t2[k] = e[k] * sd[k]; }
+        float a1[32], a2[32];
+        tl.park(tile_mem, t1); Tile::fragment(tile_mem, r, h, a1);
+        tl.park(tile_mem, t2); Tile::fragment(tile_mem, r, h, a2);     // same wavefront, LDS operations complete in order
+        if (tile + stride < n_tiles) { tl.load(E, (tile + stride) * 32, n_rows, e); tl.load(side, (tile + stride) * 32, n_rows, sd); }
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int s = 0; s < 32; s++) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[t][s], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], b2[t][s], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int64_t orow = row0 + cd_row(q, h);
+                if (orow < n_rows) pre[orow * LD + 32 * t + r] = acc[t][q];
+            }
+    }
+}
+
+// B[k][j] = W[j][k]: lane (r, h) holds W[32 t + r][kb .. kb + 32) of both matrices -- its own row, 8 float4 loads each.
+template <int NT>
+__global__ __launch_bounds__(256) void dense_bwd_lds_kernel(const float *__restrict__ dpre, const float *__restrict__ W1,
+                                                            const float *__restrict__ W2, const float *__restrict__ E,
+                                                            const float *__restrict__ side, int64_t n_rows,
+                                                            float *__restrict__ dside, float *__restrict__ dE) {
+    constexpr int LD = 32 * NT;
+    using Tile = RowTile<LD>;
+    extern __shared__ float s_mem[];                // one tile per wavefront
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    float *tile_mem = s_mem + (threadIdx.x >> 6) * (32 * Tile::RS);
+    const Tile tl(lane);
+    const int kb = 32 * h < LD ? 32 * h : 0;
+    const int64_t n_tiles = (n_rows + 31) / 32, stride = (int64_t)gridDim.x * 4;
+    int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    f32x4 gn[Tile::NV];
+    if (tile < n_tiles) tl.load(dpre, tile * 32, n_rows, gn);
+    float b1[NT][32], b2[NT][32];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(W1 + (32 * t + r) * LD + kb + 4 * q);
+            const f32x4 v2 = *reinterpret_cast<const f32x4 *>(W2 + (32 * t + r) * LD + kb + 4 * q);
+            b1[t][4 * q] = v1.x; b1[t][4 * q + 1] = v1.y; b1[t][4 * q + 2] = v1.z; b1[t][4 * q + 3] = v1.w;
+            b2[t][4 * q] = v2.x; b2[t][4 * q + 1] = v2.y; b2[t][4 * q + 2] = v2.z; b2[t][4 * q + 3] = v2.w;
+        }
+    for (; tile < n_tiles; tile += stride) {
+        const int64_t row0 = tile * 32;
+        float g[32];
+        tl.park(tile_mem, gn); Tile::fragment(tile_mem, r, h, g);
+        // the epilogue's E / side values (C layout: 128-byte runs) and the next tile go out before the MFMA loop
+        float ev[NT][16], sv[NT][16];
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                int64_t orow = row0 + cd_row(q, h);
+                if (orow >= n_rows) orow = n_rows - 1;
+                const int64_t o = orow * LD + 32 * t + r;
+                ev[t][q] = E[o]; sv[t][q] = side[o];
+            }
+        if (tile + stride < n_tiles) tl.load(dpre, (tile + stride) * 32, n_rows, gn);
+        f32x16 a1[NT], a2[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) { a1[t][q] = 0.f; a2[t][q] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int s = 0; s < 32; s++) {
+                a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[s], b1[t][s], a1[t], 0, 0, 0);
+                a2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[s], b2[t][s], a2[t], 0, 0, 0);
+            }
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int64_t orow = row0 + cd_row(q, h);
+                if (orow < n_rows) {
+                    const int64_t o = orow * LD + 32 * t + r;
+                    dside[o] = a1[t][q] + a2[t][q] * ev[t][q];
+                    dE[o] = a1[t][q] + a2[t][q] * sv[t][q];
+                }
+            }
+    }
+}
+
+// Weight gradients, LD <= 64.  A block owns kBlockRows rows; its 256 threads fetch a stage of 32 rows of E, side and
+// dpre with coalesced float4 loads (6 per thread) into a double-buffered LDS stage while the previous stage is being
+// multiplied; wavefront w owns the output block (which = w / NT, ti = w % NT) -- 32 rows of gW_which, all LD columns --
+// so nothing is summed across wavefronts.  Per stage and wavefront: 16 k-steps (row 2s + h of the stage), two LDS reads
+// for the A value ((side + E) or E * side at column 32 ti + r), NT for B, NT MFMAs.
+// partial[slab][which][i][j] as before (slab = block), then wgrad_reduce_kernel.
+constexpr int kBlockRows = 128;
+template <int NT>
+__global__ __launch_bounds__(256) void wgrad_lds_kernel(const float *__restrict__ E, const float *__restrict__ side,
+                                                        const float *__restrict__ dpre, int64_t n_rows,
+                                                        float *__restrict__ partial) {
+    constexpr int LD = 32 * NT, RS = LD + kTilePad;
+    constexpr int NV = 32 * LD / 4 / 256;          // float4 per thread, array and stage (LD = 64: 2, LD = 32: 1)
+    constexpr int kStage = 3 * 32 * RS;            // floats per stage buffer: E, side, dpre
+    extern __shared__ float s_mem[];               // [2][3][32][RS]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int which = wave / NT, ti = wave % NT;
+    const bool owner = wave < 2 * NT;              // LD = 32: two output blocks, wavefronts 2 and 3 only help fetching
+    const int64_t n0 = (int64_t)blockIdx.x * kBlockRows;
+    f32x4 ve[NV], vs[NV], vd[NV];
+    auto fetch = [&](int st) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const int idx = threadIdx.x + 256 * k, row = idx / (LD / 4), c4 = 4 * (idx % (LD / 4));
+            const int64_t n = n0 + 32 * st + row;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            if (n < n_rows) {
+                ve[k] = *reinterpret_cast<const f32x4 *>(E + n * LD + c4);
+                vs[k] = *reinterpret_cast<const f32x4 *>(side + n * LD + c4);
+                vd[k] = *reinterpret_cast<const f32x4 *>(dpre + n * LD + c4);
+            } else { ve[k] = zero; vs[k] = zero; vd[k] = zero; }      // rows past the end contribute 0
+        }
+    };
+    auto park = [&](int buf) {
+        float *b = s_mem + buf * kStage;
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const int idx = threadIdx.x + 256 * k, row = idx / (LD / 4), c4 = 4 * (idx % (LD / 4));
+            *reinterpret_cast<f32x4 *>(b + row * RS + c4) = ve[k];
+            *reinterpret_cast<f32x4 *>(b + 32 * RS + row * RS + c4) = vs[k];
+            *reinterpret_cast<f32x4 *>(b + 64 * RS + row * RS + c4) = vd[k];
+        }
+    };
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
+    constexpr int kStages = kBlockRows / 32;
+    fetch(0); park(0);
+    __syncthreads();
+    for (int st = 0; st < kStages; st++) {
+        const bool more = st + 1 < kStages && n0 + 32 * (st + 1) < n_rows;
+        if (more) fetch(st + 1);
+        if (owner) {
+            const float *b = s_mem + (st & 1) * kStage;
+            const float *pe = b + h * RS + 32 * ti + r, *ps = pe + 32 * RS, *pd = b + 64 * RS + h * RS + r;
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                const float e = pe[2 * s * RS], sd = ps[2 * s * RS];
+                const float a = which == 0 ? sd + e : e * sd;
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pd[2 * s * RS + 32 * t], acc[t], 0, 0, 0);
+            }
+        }
+        if (more) park((st + 1) & 1);
+        __syncthreads();
+        if (!more) break;
+    }
+    if (owner) {
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                partial[(((int64_t)blockIdx.x * 2 + which) * LD + 32 * ti + cd_row(q, h)) * LD + 32 * t + r] = acc[t][q];
+    }
+}
+
 // partial[slab][which][i][j] = sum over the slab's rows n of A_which[n][i] * dpre[n][j]
 //   which = 0: A = side + E ; 1: A = E * side.
 // One wavefront per (slab of 128 rows, 32-column block ti of A): it forms BOTH products for ALL NT column tiles of
@@ -344,9 +594,9 @@ __global__ __launch_bounds__(256) void add_cols_kernel(float *__restrict__ dst, 
 
 // persistent grid of the dense-layer kernels: every block stages the weights in LDS once, so no more blocks than
 // the chip keeps resident (2 per CU; 1 when the weights take 128 KB), and never more than there are 128-row groups
-unsigned dense_grid(int64_t n_rows, int ld) {
+unsigned dense_grid(int64_t n_rows, int ld, bool one_per_cu = false) {
     const int64_t groups = (n_rows + 127) / 128;
-    const int64_t resident = ld >= 128 ? 256 : 512;
+    const int64_t resident = ld >= 128 || one_per_cu ? 256 : 512;
     return (unsigned)(groups < resident ? groups : resident);
 }
 hipError_t allow_big_lds(const void *kernel, size_t bytes) {
@@ -364,9 +614,11 @@ int qrec_ngcf_dense_fwd(const float *d_E, const float *d_side, const float *d_W1
     hipStream_t st = as_stream(stream);
     const unsigned blocks = dense_grid(n_rows, ld);
     const size_t lds = (size_t)2 * ld * ld * sizeof(float);
+    const unsigned pblocks = dense_grid(n_rows, ld, true);          // ld <= 64: weights in registers, one wavefront per SIMD
+    const size_t lds_tiles = (size_t)4 * 32 * (ld + kTilePad) * sizeof(float);
     switch (ld) {
-        case 32: hipLaunchKernelGGL(dense_fwd_kernel<1>, dim3(blocks), dim3(256), lds, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre); break;
-        case 64: hipLaunchKernelGGL(dense_fwd_kernel<2>, dim3(blocks), dim3(256), lds, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre); break;
+        case 32: hipLaunchKernelGGL(dense_fwd_lds_kernel<1>, dim3(pblocks), dim3(256), lds_tiles, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre); break;
+        case 64: hipLaunchKernelGGL(dense_fwd_lds_kernel<2>, dim3(pblocks), dim3(256), lds_tiles, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre); break;
         case 128:
             QREC_HIP_CHECK(allow_big_lds(reinterpret_cast<const void *>(&dense_fwd_kernel<4>), lds));
             hipLaunchKernelGGL(dense_fwd_kernel<4>, dim3(blocks), dim3(256), lds, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre); break;
@@ -413,11 +665,12 @@ int qrec_ngcf_layer_bwd(const float *d_dE_next, const float *d_dWide, const floa
     blocks = (n_rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)); if (blocks > 2048) blocks = 2048;                    \
     hipLaunchKernelGGL((dpre_rows_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, d_dE_next, d_dWide, d_wide, \
                        wide_ld, col_off, d_inv_norm, d_gate, n_rows, d, d_dpre)
-    const unsigned gblocks = dense_grid(n_rows, ld);
+    const unsigned gblocks = dense_grid(n_rows, ld, ld <= 64);      // ld <= 64: weights in registers, one wavefront per SIMD
     const size_t lds = (size_t)2 * ld * (ld + 1) * sizeof(float);
+    const size_t lds_tiles = (size_t)4 * 32 * (ld + kTilePad) * sizeof(float);
     switch (ld) {
-        case 32: QREC_DP(8); hipLaunchKernelGGL(dense_bwd_kernel<1>, dim3(gblocks), dim3(256), lds, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE); break;
-        case 64: QREC_DP(16); hipLaunchKernelGGL(dense_bwd_kernel<2>, dim3(gblocks), dim3(256), lds, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE); break;
+        case 32: QREC_DP(8); hipLaunchKernelGGL(dense_bwd_lds_kernel<1>, dim3(gblocks), dim3(256), lds_tiles, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE); break;
+        case 64: QREC_DP(16); hipLaunchKernelGGL(dense_bwd_lds_kernel<2>, dim3(gblocks), dim3(256), lds_tiles, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE); break;
         case 128:
             QREC_DP(32);
             QREC_HIP_CHECK(allow_big_lds(reinterpret_cast<const void *>(&dense_bwd_kernel<4>), lds));
@@ -426,10 +679,11 @@ int qrec_ngcf_layer_bwd(const float *d_dE_next, const float *d_dWide, const floa
     }
 #undef QREC_DP
     QREC_LAUNCH_CHECK();
-    const int n_slabs = (int)((n_rows + kSlabRows - 1) / kSlabRows), nt = ld / 32;
-    const size_t wlds = (size_t)4 * 2 * nt * 16 * 64 * sizeof(float);
-    if (nt == 1) hipLaunchKernelGGL(wgrad_kernel<1>, dim3((unsigned)n_slabs, 1), dim3(256), wlds, st, d_E, d_side, d_dpre, n_rows, d_partial);
-    else if (nt == 2) hipLaunchKernelGGL(wgrad_kernel<2>, dim3((unsigned)n_slabs, 2), dim3(256), wlds, st, d_E, d_side, d_dpre, n_rows, d_partial);
+    const int nt = ld / 32;
+    const int n_slabs = (int)(nt == 4 ? (n_rows + kSlabRows - 1) / kSlabRows : (n_rows + kBlockRows - 1) / kBlockRows);
+    const size_t wlds = nt == 4 ? (size_t)4 * 2 * nt * 16 * 64 * sizeof(float) : (size_t)2 * 3 * 32 * (ld + kTilePad) * sizeof(float);
+    if (nt == 1) hipLaunchKernelGGL(wgrad_lds_kernel<1>, dim3((unsigned)n_slabs), dim3(256), wlds, st, d_E, d_side, d_dpre, n_rows, d_partial);
+    else if (nt == 2) hipLaunchKernelGGL(wgrad_lds_kernel<2>, dim3((unsigned)n_slabs), dim3(256), wlds, st, d_E, d_side, d_dpre, n_rows, d_partial);
     else {
         QREC_HIP_CHECK(allow_big_lds(reinterpret_cast<const void *>(&wgrad_kernel<4>), wlds));
         hipLaunchKernelGGL(wgrad_kernel<4>, dim3((unsigned)n_slabs, 4), dim3(256), wlds, st, d_E, d_side, d_dpre, n_rows, d_partial);
@@ -443,7 +697,8 @@ int qrec_ngcf_layer_bwd(const float *d_dE_next, const float *d_dWide, const floa
 
 int qrec_ngcf_wgrad_partial_bytes(int64_t n_rows, int32_t ld, int64_t *bytes) {
     QREC_REQUIRE(bytes && n_rows >= 0 && ld > 0, "qrec_ngcf_wgrad_partial_bytes: bad argument");
-    *bytes = ((n_rows + kSlabRows - 1) / kSlabRows) * 2 * (int64_t)ld * ld * 4;
+    const int64_t slab_rows = ld >= 128 ? kSlabRows : kBlockRows;
+    *bytes = ((n_rows + slab_rows - 1) / slab_rows) * 2 * (int64_t)ld * ld * 4;
     return QREC_OK;
 }
 
