@@ -266,8 +266,11 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const float *__restrict_
 //  * the weights never change inside a launch and a wavefront's B fragments of BOTH matrices are only 2 * NT * 32
 //    values per lane, so they live in registers for the whole launch (one wavefront per SIMD, a persistent loop over
 //    tiles): the MFMA loop reads nothing from memory.  (B values read from LDS right before their MFMA -- 64 ds_read2
-//    per tile, the round-1 kernel and the first LDS version -- measured 17 us of the kernel's 25; with B in registers
-//    the same 128 MFMAs take 8 us.)
+//    per tile, the round-1 kernel and the first LDS version -- cost 14 us of the kernel's 25.)
+// Timeline of dense_fwd at the Yelp2018 shape (wall_clock64 stamps per wavefront, 1024 wavefronts, 2179 tiles): weights
+// + first tile 3.6 us, then per tile 0.6 (park / fragment) + 4.5 (128 MFMAs) + 0.9 (stores); every wavefront has two
+// tiles and 131 have a third: 21.4 us, of which 5 are that ragged third round.  Two wavefronts per SIMD without the
+// prefetch: 24.6 us.
 // =============================================================================================
 constexpr int kTilePad = 4;
 
@@ -567,18 +570,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ E,
     }
 }
 
-// gW[which][i][j] = sum_slab partial[slab][which][i][j]: 8 lanes per element (lane t adds slabs t, t+8, ... in
-// order), folded in a fixed butterfly -- deterministic, 8x shorter dependent chain
+// gW[which][i][j] = sum_slab partial[slab][which][i][j].  A thread owns four consecutive elements (float4) of one of
+// kSplit slab classes (slabs c, c + kSplit, ...: coalesced 16-byte loads, added in slab order); the kSplit class sums
+// of an element meet in LDS and are added in class order -- deterministic.
+constexpr int kSplit = 16;
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int n_slabs, int ld,
                                                            float *__restrict__ gW1, float *__restrict__ gW2) {
-    const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, t0 = threadIdx.x & 7;
-    const bool ok = idx < 2 * ld * ld;
-    const int which = ok ? idx / (ld * ld) : 0, ij = ok ? idx % (ld * ld) : 0;
-    float acc = 0.f;
-    if (ok)
-        for (int s = t0; s < n_slabs; s += 8) acc += partial[((int64_t)s * 2 + which) * ld * ld + ij];
-    acc += __shfl_xor(acc, 1, kWave); acc += __shfl_xor(acc, 2, kWave); acc += __shfl_xor(acc, 4, kWave);
-    if (ok && t0 == 0) (which == 0 ? gW1 : gW2)[ij] = acc;
+    __shared__ f32x4 s_part[256];
+    const int n4 = 2 * ld * ld / 4;                                     // float4 elements of [2][ld][ld]
+    const int e4 = blockIdx.x * (256 / kSplit) + threadIdx.x / kSplit, c = threadIdx.x % kSplit;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (e4 < n4)
+        for (int s = c; s < n_slabs; s += kSplit) acc = acc + reinterpret_cast<const f32x4 *>(partial)[(int64_t)s * n4 + e4];
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    if (c == 0 && e4 < n4) {
+        f32x4 t = s_part[threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < kSplit; k++) t = t + s_part[threadIdx.x + k];
+        const int per = ld * ld / 4;
+        reinterpret_cast<f32x4 *>(e4 < per ? gW1 : gW2)[e4 < per ? e4 : e4 - per] = t;
+    }
 }
 
 // dst[row][c] += src[row][off + c], c < d     (gradient of the ego block of the wide table)
@@ -689,8 +701,8 @@ int qrec_ngcf_layer_bwd(const float *d_dE_next, const float *d_dWide, const floa
         hipLaunchKernelGGL(wgrad_kernel<4>, dim3((unsigned)n_slabs, 4), dim3(256), wlds, st, d_E, d_side, d_dpre, n_rows, d_partial);
     }
     QREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((2 * ld * ld * 8 + 255) / 256)), dim3(256), 0, st, d_partial, n_slabs,
-                       ld, d_gW1, d_gW2);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((2 * ld * ld / 4 + 256 / kSplit - 1) / (256 / kSplit))), dim3(256), 0, st,
+                       d_partial, n_slabs, ld, d_gW1, d_gW2);
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }
