@@ -284,7 +284,16 @@ int qrec_adam_step(float *d_theta, float *d_m, float *d_v, const float *d_grad, 
  * Philox4x32-10(key=seed, counter={row, lane, stream_id}) -- same distribution as
  * tf.random.uniform, not TF's stream.                                                    */
 int qrec_perturb_rows(float *d_emb, const float *d_src, int64_t n_rows, int32_t d, int32_t ld, float eps,
-                      const float *d_noise, uint64_t seed, uint64_t stream_id, float *d_accum, void *stream);
+                      const float *d_noise, uint64_t seed, uint64_t stream_id, float *d_accum, const int32_t *d_row_ids,
+                      const int32_t *d_n_row_ids, int32_t max_row_ids, void *stream);
+/* The FIRST layer of SimGCL's three encoders in one pass (they share the product A E, SimGCL.py:23-36): emb_v = the
+ * perturbed d_src (v = 1, 2: own noise / Philox stream each), and the three layer sums START here -- sum_v = emb_v,
+ * src_sum = d_src (assigned, not accumulated: no zero-fill of the sums).  Row subset as for the NGCF calls below
+ * (d_row_ids may be NULL): the last layer of a training step is read at the batch's rows only. */
+int qrec_perturb_two_views(const float *d_src, float *d_emb1, float *d_emb2, int64_t n_rows, int32_t d, int32_t ld, float eps,
+                           const float *d_noise1, const float *d_noise2, uint64_t seed, uint64_t stream_id1, uint64_t stream_id2,
+                           float *d_sum1, float *d_sum2, float *d_src_sum, const int32_t *d_row_ids, const int32_t *d_n_row_ids,
+                           int32_t max_row_ids, void *stream);
 
 /* One side (users or items) of SimGCL.calc_cl_loss (SimGCL.py:60-90) with its gradients.
  * x1 = S1[rows]/div, x2 = S2[rows]/div (the two perturbed views' rows of the batch's UNIQUE
@@ -301,28 +310,57 @@ int qrec_info_nce_loss_grad(const float *d_S1, const float *d_S2, float div, con
 /* ---- NGCF dense layers (model/ranking/NGCF.py:27-42) ------------------------------------ *
  * Tables [rows][ld] fp32, ld in {32,64,128}; weights zero-padded to [ld][ld].             */
 
+/* ROW SUBSETS.  The last layer of a TRAINING step is only read at the batch's rows (embedding_lookup, NGCF.py:44-46)
+ * and its backward is zero everywhere else, so the three calls below take an optional ascending row list
+ * d_row_ids[0 .. *d_n_row_ids) (device memory, built by qrec_compact_marked_rows; max_row_ids = the host's upper
+ * bound on the count, used for the launch geometry): only the listed rows are read, computed and written, and the
+ * weight gradients sum over the listed rows only.  d_row_ids == NULL: all n_rows rows.  Needs ld <= 64 for the two
+ * MFMA calls.  Rows are addressed by their table index either way (no compacted copies).                    */
+
+/* rows[0 .. *d_count) = the rows whose bit is set in a row bitmap (qrec_mark_batch_rows), ascending; at most
+ * `capacity` rows are written and counted. */
+int qrec_compact_marked_rows(const uint32_t *d_row_mask, int64_t n_rows, int32_t *d_rows, int32_t *d_count, int32_t capacity,
+                             void *stream);
+
+/* The row bitmap of a batch (as memset + qrec_mark_batch_rows would leave it) AND its ascending row list in one launch
+ * (tables up to 2^20 rows: the bitmap is built in LDS; larger tables take the three separate steps). */
+int qrec_mark_compact_batch_rows(const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int32_t B, int32_t n_users,
+                                 int64_t n_rows, uint32_t *d_row_mask, int32_t *d_rows, int32_t *d_count, int32_t capacity,
+                                 void *stream);
+
 /* pre = (side + E) W1 + (E * side) W2   (NGCF.py:29-31; side = A E from qrec_spmm_csr). f32 MFMA. */
 int qrec_ngcf_dense_fwd(const float *d_E, const float *d_side, const float *d_W1, const float *d_W2, int64_t n_rows,
-                        int32_t ld, float *d_pre, void *stream);
+                        int32_t ld, float *d_pre, const int32_t *d_row_ids, const int32_t *d_n_row_ids, int32_t max_row_ids,
+                        void *stream);
 /* In place on d_pre_gate (in: pre, out: backward gate): nxt = dropout(leaky_relu(pre, 0.2), keep)
  * (NGCF.py:32-38; keep = 1 for the inference graph; d_mask = injected 0/1 keep decisions or NULL
  * for device Philox draws), z = l2_normalize(nxt) written to columns [col_off, col_off+d) of the
  * wide table (the concat of NGCF.py:42), 1/|nxt| to d_inv_norm.                          */
 int qrec_ngcf_activate(float *d_pre_gate, int64_t n_rows, int32_t d, int32_t ld, float keep, const float *d_mask,
                        uint64_t seed, uint64_t stream_id, float *d_next, float *d_wide, int32_t wide_ld,
-                       int32_t col_off, float *d_inv_norm, void *stream);
+                       int32_t col_off, float *d_inv_norm, const int32_t *d_row_ids, const int32_t *d_n_row_ids,
+                       int32_t max_row_ids, void *stream);
 /* Backward of one layer: dnxt = dE_next (may be NULL) + normalize_bwd(dWide block); dpre = dnxt*gate;
  * dside = dpre W1^T + (dpre W2^T)*E ; dE = dpre W1^T + (dpre W2^T)*side (caller adds A^T dside);
- * gW1 = (side+E)^T dpre, gW2 = (E*side)^T dpre (deterministic two-stage reduction over nodes).  */
+ * gW1 = (side+E)^T dpre, gW2 = (E*side)^T dpre (deterministic two-stage reduction over nodes).
+ * With a row subset d_dpre / d_dside / d_dE are written at the listed rows only (the caller zero-fills what it reads
+ * elsewhere); d_partial must hold qrec_ngcf_wgrad_partial_bytes(n_rows, ld) bytes either way.
+ * d_wide_row_mask (may be NULL): row bitmap of the rows at which d_dWide is defined (the batch's rows, cleared with
+ * qrec_zero_rows before the loss scatter instead of zero-filling the whole wide table); elsewhere its block counts as 0. */
 int qrec_ngcf_layer_bwd(const float *d_dE_next, const float *d_dWide, const float *d_wide, int32_t wide_ld,
                         int32_t col_off, const float *d_inv_norm, const float *d_gate, const float *d_E,
                         const float *d_side, const float *d_W1, const float *d_W2, int64_t n_rows, int32_t d,
                         int32_t ld, float *d_dpre, float *d_dside, float *d_dE, float *d_partial, float *d_gW1,
-                        float *d_gW2, void *stream);
+                        float *d_gW2, const int32_t *d_row_ids, const int32_t *d_n_row_ids, int32_t max_row_ids,
+                        const uint32_t *d_wide_row_mask, void *stream);
 int qrec_ngcf_wgrad_partial_bytes(int64_t n_rows, int32_t ld, int64_t *bytes);
-/* dst[row][c] (=|+=) src[row][src_col_off + c], c < d : moves the ego block in and out of the wide table */
+/* dst[row][c] (=|+=) src[row][src_col_off + c], c < d : moves the ego block in and out of the wide table; with a row
+ * subset (see above) only the listed rows are touched. */
 int qrec_copy_cols(float *d_dst, int32_t dst_ld, const float *d_src, int32_t src_ld, int32_t src_col_off, int64_t n_rows,
-                   int32_t d, int32_t accumulate, void *stream);
+                   int32_t d, int32_t accumulate, const int32_t *d_row_ids, const int32_t *d_n_row_ids, int32_t max_row_ids,
+                   void *stream);
+/* X[row][0 .. ld) = 0 for the listed rows (a row subset as above): clears a gradient table where the next scatter lands */
+int qrec_zero_rows(float *d_X, int32_t ld, const int32_t *d_row_ids, const int32_t *d_n_row_ids, int32_t max_row_ids, void *stream);
 
 /* ---- BUIR (model/ranking/BUIR.py) ------------------------------------------------------------------ *
  * The propagation of both encoders is qrec_spmm_csr on the epoch's two sub-graphs.  What the model adds:      */

@@ -68,7 +68,8 @@ _SIGNATURES = {
     "qrec_mark_batch_rows": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "qrec_bpr_batch_loss_grad": [_vp, _f32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
     "qrec_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
-    "qrec_perturb_rows": [_vp, _vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp],
+    "qrec_perturb_rows": [_vp, _vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _vp, _i32, _vp],
+    "qrec_perturb_two_views": [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "qrec_info_nce_workspace_bytes": [_i32, _i32, _vp],
     "qrec_gate_fwd": [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "qrec_gate_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp],
@@ -85,11 +86,14 @@ _SIGNATURES = {
     "qrec_sept_ssl_workspace_bytes": [_i32, _i32, _i32, _vp],
     "qrec_sept_ssl_loss_grad": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "qrec_info_nce_loss_grad": [_vp, _vp, _f32, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
-    "qrec_ngcf_dense_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
-    "qrec_ngcf_activate": [_vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _i32, _i32, _vp, _vp],
-    "qrec_ngcf_layer_bwd": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "qrec_ngcf_dense_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp],
+    "qrec_compact_marked_rows": [_vp, _i64, _vp, _vp, _i32, _vp],
+    "qrec_mark_compact_batch_rows": [_vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _i32, _vp],
+    "qrec_ngcf_activate": [_vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp],
+    "qrec_ngcf_layer_bwd": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "qrec_ngcf_wgrad_partial_bytes": [_i64, _i32, _vp],
-    "qrec_copy_cols": [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _i32, _vp],
+    "qrec_copy_cols": [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _i32, _vp],
+    "qrec_zero_rows": [_vp, _i32, _vp, _vp, _i32, _vp],
     "qrec_score_topk_scratch_bytes": [C.c_int, _i32, _i32, _vp],
     "qrec_score_topk": [_vp, _vp, C.c_int, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "qrec_rank_hits": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -386,6 +390,23 @@ class DeviceBuffer:
             pass
 
 
+class DeviceSlice(DeviceBuffer):
+    """Non-owning window [offset, offset + prod(shape)) (elements) of a DeviceBuffer: several small tables carved out
+    of one allocation so that one kernel launch can cover all of them (e.g. the four NGCF weight matrices in Adam)."""
+
+    def __init__(self, owner: DeviceBuffer, offset_elems: int, shape):
+        self.owner = owner
+        self.shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = owner.dtype
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        if offset_elems < 0 or offset_elems * self.dtype.itemsize + self.nbytes > owner.nbytes:
+            raise ValueError("DeviceSlice outside its owner")
+        self.ptr = owner.ptr + offset_elems * self.dtype.itemsize
+
+    def free(self):           # the owner frees
+        self.ptr = 0
+
+
 def _dp(x):
     """device pointer of a DeviceBuffer / int / object with data_ptr() (torch tensor)"""
     if x is None:
@@ -661,9 +682,18 @@ def adam_step(d_theta, d_m, d_v, d_grad, n_elems: int, grad_scale: float, alpha:
 
 
 def perturb_rows(d_emb, n_rows: int, d: int, ld: int, eps: float, d_noise=None, seed: int = 0, stream_id: int = 0,
-                 d_accum=None, stream=None, d_src=None):
+                 d_accum=None, stream=None, d_src=None, rows=None):
     _check(load().qrec_perturb_rows(_dp(d_emb), _dp(d_src), n_rows, d, ld, eps, _dp(d_noise), seed & (2**64 - 1),
-                                    stream_id & (2**64 - 1), _dp(d_accum), _sh(stream)))
+                                    stream_id & (2**64 - 1), _dp(d_accum), *_subset(rows), _sh(stream)))
+
+
+def perturb_two_views(d_src, d_emb1, d_emb2, n_rows: int, d: int, ld: int, eps: float, d_noise1, d_noise2, seed: int,
+                      stream_id1: int, stream_id2: int, d_sum1, d_sum2, d_src_sum, stream=None, rows=None):
+    """first layer of SimGCL's three encoders: both perturbed views of d_src, and the three layer sums START here"""
+    m = 2**64 - 1
+    _check(load().qrec_perturb_two_views(_dp(d_src), _dp(d_emb1), _dp(d_emb2), n_rows, d, ld, eps, _dp(d_noise1), _dp(d_noise2),
+                                         seed & m, stream_id1 & m, stream_id2 & m, _dp(d_sum1), _dp(d_sum2), _dp(d_src_sum),
+                                         *_subset(rows), _sh(stream)))
 
 
 def info_nce_workspace_bytes(n: int, ld: int) -> int:
@@ -756,23 +786,55 @@ def sept_ssl_loss_grad(d_S_friend, d_S_sharing, d_S_pref, d_S_aug, d_rows, n: in
                                           _dp(d_dS_aug), _dp(d_loss), _dp(d_labels), _sh(stream)))
 
 
-def ngcf_dense_fwd(d_E, d_side, d_W1, d_W2, n_rows: int, ld: int, d_pre, stream=None):
-    _check(load().qrec_ngcf_dense_fwd(_dp(d_E), _dp(d_side), _dp(d_W1), _dp(d_W2), n_rows, ld, _dp(d_pre), _sh(stream)))
+class RowSubset:
+    """An ascending device-resident list of table rows (qrec_compact_marked_rows): the NGCF layer calls take one to
+    restrict themselves to the batch's rows.  ``bound`` = the host's upper bound on the count (launch geometry)."""
+
+    def __init__(self, capacity: int):
+        self.rows = DeviceBuffer(max(capacity, 1), np.int32)
+        self.count = DeviceBuffer.zeros(1, np.int32)
+        self.capacity, self.bound = capacity, 0
+
+    def from_mask(self, d_row_mask, n_rows: int, bound: int, stream=None):
+        if bound > self.capacity:
+            raise ValueError("RowSubset: bound above the capacity")
+        _check(load().qrec_compact_marked_rows(_dp(d_row_mask), n_rows, _dp(self.rows), _dp(self.count), self.capacity, _sh(stream)))
+        self.bound = bound
+        return self
+
+
+def mark_compact_batch_rows(d_u, d_i, d_j, B: int, n_users: int, n_rows: int, d_row_mask, rows: RowSubset, bound: int, stream=None):
+    """row bitmap of the batch (cleared first) + its row list, one launch"""
+    if bound > rows.capacity:
+        raise ValueError("RowSubset: bound above the capacity")
+    _check(load().qrec_mark_compact_batch_rows(_dp(d_u), _dp(d_i), _dp(d_j), B, n_users, n_rows, _dp(d_row_mask), _dp(rows.rows),
+                                               _dp(rows.count), rows.capacity, _sh(stream)))
+    rows.bound = bound
+    return rows
+
+
+def _subset(rows):
+    return (None, None, 0) if rows is None else (_dp(rows.rows), _dp(rows.count), rows.bound)
+
+
+def ngcf_dense_fwd(d_E, d_side, d_W1, d_W2, n_rows: int, ld: int, d_pre, stream=None, rows: RowSubset | None = None):
+    _check(load().qrec_ngcf_dense_fwd(_dp(d_E), _dp(d_side), _dp(d_W1), _dp(d_W2), n_rows, ld, _dp(d_pre), *_subset(rows), _sh(stream)))
 
 
 def ngcf_activate(d_pre_gate, n_rows: int, d: int, ld: int, keep: float, d_mask, seed: int, stream_id: int, d_next,
-                  d_wide, wide_ld: int, col_off: int, d_inv_norm, stream=None):
+                  d_wide, wide_ld: int, col_off: int, d_inv_norm, stream=None, rows: RowSubset | None = None):
     _check(load().qrec_ngcf_activate(_dp(d_pre_gate), n_rows, d, ld, keep, _dp(d_mask), seed & (2**64 - 1),
                                      stream_id & (2**64 - 1), _dp(d_next), _dp(d_wide), wide_ld, col_off,
-                                     _dp(d_inv_norm), _sh(stream)))
+                                     _dp(d_inv_norm), *_subset(rows), _sh(stream)))
 
 
 def ngcf_layer_bwd(d_dE_next, d_dWide, d_wide, wide_ld: int, col_off: int, d_inv_norm, d_gate, d_E, d_side, d_W1, d_W2,
-                   n_rows: int, d: int, ld: int, d_dpre, d_dside, d_dE, d_partial, d_gW1, d_gW2, stream=None):
+                   n_rows: int, d: int, ld: int, d_dpre, d_dside, d_dE, d_partial, d_gW1, d_gW2, stream=None,
+                   rows: RowSubset | None = None, d_wide_row_mask=None):
     _check(load().qrec_ngcf_layer_bwd(_dp(d_dE_next), _dp(d_dWide), _dp(d_wide), wide_ld, col_off, _dp(d_inv_norm),
                                       _dp(d_gate), _dp(d_E), _dp(d_side), _dp(d_W1), _dp(d_W2), n_rows, d, ld,
                                       _dp(d_dpre), _dp(d_dside), _dp(d_dE), _dp(d_partial), _dp(d_gW1), _dp(d_gW2),
-                                      _sh(stream)))
+                                      *_subset(rows), _dp(d_wide_row_mask), _sh(stream)))
 
 
 def ngcf_wgrad_partial_bytes(n_rows: int, ld: int) -> int:
@@ -782,9 +844,13 @@ def ngcf_wgrad_partial_bytes(n_rows: int, ld: int) -> int:
 
 
 def copy_cols(d_dst, dst_ld: int, d_src, src_ld: int, src_col_off: int, n_rows: int, d: int, accumulate: bool,
-              stream=None):
+              stream=None, rows=None):
     _check(load().qrec_copy_cols(_dp(d_dst), dst_ld, _dp(d_src), src_ld, src_col_off, n_rows, d, 1 if accumulate else 0,
-                                 _sh(stream)))
+                                 *_subset(rows), _sh(stream)))
+
+
+def zero_rows(d_X, ld: int, rows: RowSubset, stream=None):
+    _check(load().qrec_zero_rows(_dp(d_X), ld, *_subset(rows), _sh(stream)))
 
 
 def bpr_sgd_hogwild_item_major(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int, chunk: int, grid_groups: int,

@@ -31,44 +31,62 @@ __device__ __forceinline__ void philox10(uint32_t (&c)[4], uint32_t k0, uint32_t
     }
 }
 
-// One group of LPR lanes per row, float4 per lane (ld = 4*LPR).
-//   noise != nullptr : use the given U[0,1) numbers (parity tests inject TF-side noise)
-//   noise == nullptr : Philox(counter = {row, lane, stream_lo, stream_hi}, key = seed) -> 4 x 24-bit uniforms
-template <int LPR>
-__global__ __launch_bounds__(256) void perturb_kernel(float *__restrict__ emb, const float *__restrict__ src, int64_t n_rows,
-                                                      int d, float eps, const float *__restrict__ noise, uint64_t seed,
-                                                      uint64_t stream_id, float *__restrict__ accum) {
+// One group of LPR lanes per row, float4 per lane (ld = 4*LPR).  V views are formed from the same source row in one pass.
+//   noise[v] != nullptr : use the given U[0,1) numbers (parity tests inject TF-side noise)
+//   noise[v] == nullptr : Philox(counter = {row, lane, stream_lo, stream_hi}, key = seed) -> 4 x 24-bit uniforms
+//   src == nullptr      : in place on emb[0] (V = 1)
+//   assign              : sum[v] = emb_v instead of sum[v] += emb_v, and src_sum (if given) = the source row: the FIRST layer
+//                         of the three encoders starts their layer sums, which therefore need no zero-fill
+//   row_ids             : only the listed rows (the last layer of a training step is read at the batch's rows only)
+struct PerturbViews {
+    float *emb[2];
+    const float *noise[2];
+    uint64_t stream_id[2];
+    float *sum[2];
+};
+template <int LPR, int V>
+__global__ __launch_bounds__(256) void perturb_kernel(PerturbViews pv, const float *__restrict__ src, int64_t n_rows,
+                                                      int d, float eps, uint64_t seed, int assign, float *__restrict__ src_sum,
+                                                      const int32_t *__restrict__ row_ids, const int32_t *__restrict__ n_ids) {
     constexpr int GPW = kWave / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
     const int64_t gid = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
     const int64_t n_groups = (int64_t)gridDim.x * 4 * GPW;
-    for (int64_t row = gid; row < n_rows; row += n_groups) {
+    const int64_t n_todo = row_ids ? *n_ids : n_rows;
+    for (int64_t k = gid; k < n_todo; k += n_groups) {
+        const int64_t row = row_ids ? (int64_t)row_ids[k] : k;
         const int64_t off = row * (4 * LPR) + 4 * r;
-        f32x4 nz;
-        if (noise) {
-            nz = *reinterpret_cast<const f32x4 *>(noise + off);
-        } else {
-            uint32_t c[4] = {(uint32_t)row, (uint32_t)(row >> 32) ^ ((uint32_t)r << 8), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
-            philox10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-            nz.x = (float)(c[0] >> 8) * 0x1p-24f; nz.y = (float)(c[1] >> 8) * 0x1p-24f;
-            nz.z = (float)(c[2] >> 8) * 0x1p-24f; nz.w = (float)(c[3] >> 8) * 0x1p-24f;
-        }
-        if (4 * r + 0 >= d) nz.x = 0.f;
-        if (4 * r + 1 >= d) nz.y = 0.f;
-        if (4 * r + 2 >= d) nz.z = 0.f;
-        if (4 * r + 3 >= d) nz.w = 0.f;
-        float ss = nz.x * nz.x + nz.y * nz.y + nz.z * nz.z + nz.w * nz.w;
-        ss = row_allreduce_sum<LPR>(ss);
-        const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));     // tf.nn.l2_normalize epsilon
-        f32x4 e = *reinterpret_cast<const f32x4 *>((src ? src : emb) + off);
-        auto sgn = [](float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); };
-        e.x += sgn(e.x) * (nz.x * inv) * eps; e.y += sgn(e.y) * (nz.y * inv) * eps;
-        e.z += sgn(e.z) * (nz.z * inv) * eps; e.w += sgn(e.w) * (nz.w * inv) * eps;
-        *reinterpret_cast<f32x4 *>(emb + off) = e;
-        if (accum) {
-            f32x4 s = *reinterpret_cast<const f32x4 *>(accum + off);
-            s = s + e;
-            *reinterpret_cast<f32x4 *>(accum + off) = s;
+        const f32x4 x = *reinterpret_cast<const f32x4 *>((src ? src : pv.emb[0]) + off);
+        if (src_sum) *reinterpret_cast<f32x4 *>(src_sum + off) = x;
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            f32x4 nz;
+            if (pv.noise[v]) {
+                nz = *reinterpret_cast<const f32x4 *>(pv.noise[v] + off);
+            } else {
+                const uint64_t sid = pv.stream_id[v];
+                uint32_t c[4] = {(uint32_t)row, (uint32_t)(row >> 32) ^ ((uint32_t)r << 8), (uint32_t)sid, (uint32_t)(sid >> 32)};
+                philox10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+                nz.x = (float)(c[0] >> 8) * 0x1p-24f; nz.y = (float)(c[1] >> 8) * 0x1p-24f;
+                nz.z = (float)(c[2] >> 8) * 0x1p-24f; nz.w = (float)(c[3] >> 8) * 0x1p-24f;
+            }
+            if (4 * r + 0 >= d) nz.x = 0.f;
+            if (4 * r + 1 >= d) nz.y = 0.f;
+            if (4 * r + 2 >= d) nz.z = 0.f;
+            if (4 * r + 3 >= d) nz.w = 0.f;
+            float ss = nz.x * nz.x + nz.y * nz.y + nz.z * nz.z + nz.w * nz.w;
+            ss = row_allreduce_sum<LPR>(ss);
+            const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));     // tf.nn.l2_normalize epsilon
+            auto sgn = [](float t) { return t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f); };
+            f32x4 e = x;
+            e.x += sgn(e.x) * (nz.x * inv) * eps; e.y += sgn(e.y) * (nz.y * inv) * eps;
+            e.z += sgn(e.z) * (nz.z * inv) * eps; e.w += sgn(e.w) * (nz.w * inv) * eps;
+            *reinterpret_cast<f32x4 *>(pv.emb[v] + off) = e;
+            if (pv.sum[v]) {
+                f32x4 t = e;
+                if (!assign) t = t + *reinterpret_cast<const f32x4 *>(pv.sum[v] + off);
+                *reinterpret_cast<f32x4 *>(pv.sum[v] + off) = t;
+            }
         }
     }
 }
@@ -530,18 +548,18 @@ int run_sept_ssl(const float *const S[4], const int32_t *rows, int n, int ld, in
 
 }  // namespace
 
-extern "C" {
-
-int qrec_perturb_rows(float *d_emb, const float *d_src, int64_t n_rows, int32_t d, int32_t ld, float eps,
-                      const float *d_noise, uint64_t seed, uint64_t stream_id, float *d_accum, void *stream) {
-    QREC_REQUIRE(d_emb && n_rows >= 0 && d >= 1 && ld >= d, "qrec_perturb_rows: bad argument");
-    if (n_rows == 0) return QREC_OK;
-    hipStream_t st = as_stream(stream);
+namespace {
+template <int V>
+int launch_perturb(const PerturbViews &pv, const float *d_src, int64_t n_rows, int32_t d, int32_t ld, float eps, uint64_t seed,
+                   int assign, float *d_src_sum, const int32_t *d_row_ids, const int32_t *d_n_row_ids, int32_t max_row_ids,
+                   hipStream_t st) {
+    const int64_t work_rows = d_row_ids ? max_row_ids : n_rows;
+    if (work_rows == 0) return QREC_OK;
     int64_t blocks;
 #define QREC_PT(LPR)                                                                                              \
-    blocks = (n_rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)); if (blocks > 2048) blocks = 2048;                    \
-    hipLaunchKernelGGL((perturb_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, d_emb, d_src, n_rows, d, eps, d_noise, \
-                       seed, stream_id, d_accum)
+    blocks = (work_rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)); if (blocks > 2048) blocks = 2048;                 \
+    hipLaunchKernelGGL((perturb_kernel<LPR, V>), dim3((unsigned)blocks), dim3(256), 0, st, pv, d_src, n_rows, d, eps, seed, \
+                       assign, d_src_sum, d_row_ids, d_n_row_ids)
     switch (ld) {
         case 32: QREC_PT(8); break;
         case 64: QREC_PT(16); break;
@@ -552,6 +570,28 @@ int qrec_perturb_rows(float *d_emb, const float *d_src, int64_t n_rows, int32_t 
 #undef QREC_PT
     QREC_LAUNCH_CHECK();
     return QREC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int qrec_perturb_rows(float *d_emb, const float *d_src, int64_t n_rows, int32_t d, int32_t ld, float eps,
+                      const float *d_noise, uint64_t seed, uint64_t stream_id, float *d_accum, const int32_t *d_row_ids,
+                      const int32_t *d_n_row_ids, int32_t max_row_ids, void *stream) {
+    QREC_REQUIRE(d_emb && n_rows >= 0 && d >= 1 && ld >= d, "qrec_perturb_rows: bad argument");
+    QREC_REQUIRE(!d_row_ids || (d_n_row_ids && max_row_ids >= 0), "qrec_perturb_rows: a row subset needs its count and a bound");
+    PerturbViews pv = {{d_emb, nullptr}, {d_noise, nullptr}, {stream_id, 0}, {d_accum, nullptr}};
+    return launch_perturb<1>(pv, d_src, n_rows, d, ld, eps, seed, 0, nullptr, d_row_ids, d_n_row_ids, max_row_ids, as_stream(stream));
+}
+
+int qrec_perturb_two_views(const float *d_src, float *d_emb1, float *d_emb2, int64_t n_rows, int32_t d, int32_t ld, float eps,
+                           const float *d_noise1, const float *d_noise2, uint64_t seed, uint64_t stream_id1, uint64_t stream_id2,
+                           float *d_sum1, float *d_sum2, float *d_src_sum, const int32_t *d_row_ids, const int32_t *d_n_row_ids,
+                           int32_t max_row_ids, void *stream) {
+    QREC_REQUIRE(d_src && d_emb1 && d_emb2 && d_emb1 != d_emb2 && n_rows >= 0 && d >= 1 && ld >= d, "qrec_perturb_two_views: bad argument");
+    QREC_REQUIRE(!d_row_ids || (d_n_row_ids && max_row_ids >= 0), "qrec_perturb_two_views: a row subset needs its count and a bound");
+    PerturbViews pv = {{d_emb1, d_emb2}, {d_noise1, d_noise2}, {stream_id1, stream_id2}, {d_sum1, d_sum2}};
+    return launch_perturb<2>(pv, d_src, n_rows, d, ld, eps, seed, 1, d_src_sum, d_row_ids, d_n_row_ids, max_row_ids, as_stream(stream));
 }
 
 int qrec_info_nce_workspace_bytes(int32_t n, int32_t ld, int64_t *bytes) {

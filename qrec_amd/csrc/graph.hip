@@ -225,9 +225,17 @@ __global__ __launch_bounds__(256) void bpr_batch_kernel(
             __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(-gsc * ub[e] + reg * jb[e], rs, (int)((uint32_t)rj * LD * 4u + col), 0, 0);
         }
     }
+    // one fp64 atomic per BLOCK: same-address atomics are serialised in L2 (~10 ns each); one per wavefront was
+    // two thirds of this kernel's 30 us at ld = 256 (a wavefront per triplet, 2,048 of them)
+    __shared__ double s_loss[4];
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) loss += __shfl_xor(loss, m, kWave);
-    if (lane == 0 && loss != 0.0) atomicAdd(loss_out, loss);
+    if (lane == 0) s_loss[threadIdx.x >> 6] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]);
+        if (t != 0.0) atomicAdd(loss_out, t);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -375,8 +383,10 @@ int qrec_bpr_batch_loss_grad(const float *d_S, float div, int32_t n_users, int64
     hipStream_t st = as_stream(stream);
     const uint32_t bytes = (uint32_t)(n_rows * ld * 4);
 #define QREC_BB(LPR, E)                                                                                          \
-    hipLaunchKernelGGL((bpr_batch_kernel<LPR, E>), dim3((unsigned)((B + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), \
+    blocks = (B + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)); if (blocks > 256) blocks = 256;                          \
+    hipLaunchKernelGGL((bpr_batch_kernel<LPR, E>), dim3((unsigned)blocks),                                         \
                        dim3(256), 0, st, d_S, div, n_users, d_u, d_i, d_j, B, eps, reg, d_dE, bytes, d_loss, d_row_mask)
+    int64_t blocks;
     switch (ld) {
         case 32: QREC_BB(16, 2); break;
         case 64: QREC_BB(16, 4); break;

@@ -108,12 +108,15 @@ template <int LPR>
 __global__ __launch_bounds__(256) void activate_rows_kernel(float *__restrict__ pre_gate, int64_t n_rows, int d, float keep,
                                                             const float *__restrict__ mask, uint64_t seed, uint64_t stream_id,
                                                             float *__restrict__ nxt, float *__restrict__ out, int out_ld,
-                                                            int out_off, float *__restrict__ inv_norm) {
+                                                            int out_off, float *__restrict__ inv_norm,
+                                                            const int32_t *__restrict__ row_ids, const int32_t *__restrict__ n_ids) {
     constexpr int GPW = kWave / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
     const int64_t gid = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
     const int64_t n_groups = (int64_t)gridDim.x * 4 * GPW;
-    for (int64_t row = gid; row < n_rows; row += n_groups) {
+    const int64_t n_todo = row_ids ? *n_ids : n_rows;
+    for (int64_t v = gid; v < n_todo; v += n_groups) {
+        const int64_t row = row_ids ? (int64_t)row_ids[v] : v;
         const int64_t off = row * (4 * LPR) + 4 * r;
         const f32x4 p = *reinterpret_cast<const f32x4 *>(pre_gate + off);
         f32x4 fac = {1.f, 1.f, 1.f, 1.f};
@@ -159,19 +162,27 @@ template <int LPR>
 __global__ __launch_bounds__(256) void dpre_rows_kernel(const float *__restrict__ dE_next, const float *__restrict__ dAll,
                                                         const float *__restrict__ All, int wide_ld, int col_off,
                                                         const float *__restrict__ inv_norm, const float *__restrict__ gate,
-                                                        int64_t n_rows, int d, float *__restrict__ dpre) {
+                                                        int64_t n_rows, int d, float *__restrict__ dpre,
+                                                        const int32_t *__restrict__ row_ids, const int32_t *__restrict__ n_ids,
+                                                        const uint32_t *__restrict__ wide_row_mask) {
     constexpr int GPW = kWave / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
     const int64_t gid = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
     const int64_t n_groups = (int64_t)gridDim.x * 4 * GPW;
-    for (int64_t row = gid; row < n_rows; row += n_groups) {
+    const int64_t n_todo = row_ids ? *n_ids : n_rows;
+    for (int64_t v = gid; v < n_todo; v += n_groups) {
+        const int64_t row = row_ids ? (int64_t)row_ids[v] : v;
         const int64_t off = row * (4 * LPR) + 4 * r;
         const float *dzp = dAll + row * wide_ld + col_off + 4 * r, *zp = All + row * wide_ld + col_off + 4 * r;
         f32x4 dz = {0.f, 0.f, 0.f, 0.f}, z = dz;
-        if (4 * r + 0 < d) { dz.x = dzp[0]; z.x = zp[0]; }
-        if (4 * r + 1 < d) { dz.y = dzp[1]; z.y = zp[1]; }
-        if (4 * r + 2 < d) { dz.z = dzp[2]; z.z = zp[2]; }
-        if (4 * r + 3 < d) { dz.w = dzp[3]; z.w = zp[3]; }
+        // wide_row_mask: the wide gradient is only defined (and only non-zero) at the marked rows; elsewhere dz = 0
+        const bool has = !wide_row_mask || ((wide_row_mask[row >> 5] >> (row & 31)) & 1u);
+        if (has) {
+            if (4 * r + 0 < d) { dz.x = dzp[0]; z.x = zp[0]; }
+            if (4 * r + 1 < d) { dz.y = dzp[1]; z.y = zp[1]; }
+            if (4 * r + 2 < d) { dz.z = dzp[2]; z.z = zp[2]; }
+            if (4 * r + 3 < d) { dz.w = dzp[3]; z.w = zp[3]; }
+        }
         float dot = z.x * dz.x + z.y * dz.y + z.z * dz.z + z.w * dz.w;
         dot = row_allreduce_sum<LPR>(dot);
         f32x4 dn = (dz - z * dot) * inv_norm[row];
@@ -282,11 +293,14 @@ struct RowTile {                                  // a wavefront's view of one 3
     static constexpr int NV = 32 / RPI;           // float4 per lane per tile
     int lrow, lcol;
     __device__ explicit RowTile(int lane) : lrow(lane / LPRW), lcol(4 * (lane % LPRW)) {}
-    __device__ void load(const float *__restrict__ X, int64_t row0, int64_t n_rows, f32x4 (&v)[NV]) const {
+    // row_ids (may be null): the tile's rows are row_ids[row0 ...] instead of row0 ... (a listed subset of the table)
+    __device__ void load(const float *__restrict__ X, int64_t row0, int64_t n_rows, f32x4 (&v)[NV],
+                         const int32_t *__restrict__ row_ids = nullptr) const {
 #pragma unroll
         for (int k = 0; k < NV; k++) {
             int64_t row = row0 + k * RPI + lrow;
             if (row >= n_rows) row = n_rows - 1;                 // rows past the end: a copy of the last row, never stored
+            if (row_ids) row = row_ids[row];
             v[k] = *reinterpret_cast<const f32x4 *>(X + row * LD + lcol);
         }
     }
@@ -310,7 +324,8 @@ struct RowTile {                                  // a wavefront's view of one 3
 template <int NT>
 __global__ __launch_bounds__(256) void dense_fwd_lds_kernel(const float *__restrict__ E, const float *__restrict__ side,
                                                             const float *__restrict__ W1, const float *__restrict__ W2,
-                                                            int64_t n_rows, float *__restrict__ pre) {
+                                                            int64_t n_all, float *__restrict__ pre,
+                                                            const int32_t *__restrict__ row_ids, const int32_t *__restrict__ n_ids) {
     constexpr int LD = 32 * NT;
     using Tile = RowTile<LD>;
     extern __shared__ float s_mem[];                // one tile per wavefront
@@ -318,10 +333,11 @@ __global__ __launch_bounds__(256) void dense_fwd_lds_kernel(const float *__restr
     float *tile_mem = s_mem + (threadIdx.x >> 6) * (32 * Tile::RS);
     const Tile tl(lane);
     const int kb = 32 * h < LD ? 32 * h : 0;        // ld = 32: the upper k-slot has no columns; its A values are zeros
+    const int64_t n_rows = row_ids ? *n_ids : n_all;            // rows to process: the listed ones, or all
     const int64_t n_tiles = (n_rows + 31) / 32, stride = (int64_t)gridDim.x * 4;
     int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     f32x4 e[Tile::NV], sd[Tile::NV];
-    if (tile < n_tiles) { tl.load(E, tile * 32, n_rows, e); tl.load(side, tile * 32, n_rows, sd); }
+    if (tile < n_tiles) { tl.load(E, tile * 32, n_rows, e, row_ids); tl.load(side, tile * 32, n_rows, sd, row_ids); }
     float b1[NT][32], b2[NT][32];                   // B fragments: W[kb + s][32 t + r]
 #pragma unroll
     for (int t = 0; t < NT; t++)
@@ -338,7 +354,7 @@ __global__ __launch_bounds__(256) void dense_fwd_lds_kernel(const float *__restr
         float a1[32], a2[32];
         tl.park(tile_mem, t1); Tile::fragment(tile_mem, r, h, a1);
         tl.park(tile_mem, t2); Tile::fragment(tile_mem, r, h, a2);     // same wavefront, LDS operations complete in order
-        if (tile + stride < n_tiles) { tl.load(E, (tile + stride) * 32, n_rows, e); tl.load(side, (tile + stride) * 32, n_rows, sd); }
+        if (tile + stride < n_tiles) { tl.load(E, (tile + stride) * 32, n_rows, e, row_ids); tl.load(side, (tile + stride) * 32, n_rows, sd, row_ids); }
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; t++)
@@ -352,12 +368,14 @@ __global__ __launch_bounds__(256) void dense_fwd_lds_kernel(const float *__restr
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], b2[t][s], acc[t], 0, 0, 0);
             }
 #pragma unroll
-        for (int t = 0; t < NT; t++)
+        for (int q = 0; q < 16; q++) {
+            int64_t orow = row0 + cd_row(q, h);
+            if (orow < n_rows) {
+                if (row_ids) orow = row_ids[orow];
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int64_t orow = row0 + cd_row(q, h);
-                if (orow < n_rows) pre[orow * LD + 32 * t + r] = acc[t][q];
+                for (int t = 0; t < NT; t++) pre[orow * LD + 32 * t + r] = acc[t][q];
             }
+        }
     }
 }
 
@@ -365,8 +383,9 @@ __global__ __launch_bounds__(256) void dense_fwd_lds_kernel(const float *__restr
 template <int NT>
 __global__ __launch_bounds__(256) void dense_bwd_lds_kernel(const float *__restrict__ dpre, const float *__restrict__ W1,
                                                             const float *__restrict__ W2, const float *__restrict__ E,
-                                                            const float *__restrict__ side, int64_t n_rows,
-                                                            float *__restrict__ dside, float *__restrict__ dE) {
+                                                            const float *__restrict__ side, int64_t n_all,
+                                                            float *__restrict__ dside, float *__restrict__ dE,
+                                                            const int32_t *__restrict__ row_ids, const int32_t *__restrict__ n_ids) {
     constexpr int LD = 32 * NT;
     using Tile = RowTile<LD>;
     extern __shared__ float s_mem[];                // one tile per wavefront
@@ -374,10 +393,11 @@ __global__ __launch_bounds__(256) void dense_bwd_lds_kernel(const float *__restr
     float *tile_mem = s_mem + (threadIdx.x >> 6) * (32 * Tile::RS);
     const Tile tl(lane);
     const int kb = 32 * h < LD ? 32 * h : 0;
+    const int64_t n_rows = row_ids ? *n_ids : n_all;
     const int64_t n_tiles = (n_rows + 31) / 32, stride = (int64_t)gridDim.x * 4;
     int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     f32x4 gn[Tile::NV];
-    if (tile < n_tiles) tl.load(dpre, tile * 32, n_rows, gn);
+    if (tile < n_tiles) tl.load(dpre, tile * 32, n_rows, gn, row_ids);
     float b1[NT][32], b2[NT][32];
 #pragma unroll
     for (int t = 0; t < NT; t++)
@@ -394,16 +414,21 @@ __global__ __launch_bounds__(256) void dense_bwd_lds_kernel(const float *__restr
         tl.park(tile_mem, gn); Tile::fragment(tile_mem, r, h, g);
         // the epilogue's E / side values (C layout: 128-byte runs) and the next tile go out before the MFMA loop
         float ev[NT][16], sv[NT][16];
+        int64_t prow[16];                              // physical rows of this lane's 16 output rows
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            int64_t orow = row0 + cd_row(q, h);
+            if (orow >= n_rows) orow = n_rows - 1;
+            prow[q] = row_ids ? (int64_t)row_ids[orow] : orow;
+        }
 #pragma unroll
         for (int t = 0; t < NT; t++)
 #pragma unroll
             for (int q = 0; q < 16; q++) {
-                int64_t orow = row0 + cd_row(q, h);
-                if (orow >= n_rows) orow = n_rows - 1;
-                const int64_t o = orow * LD + 32 * t + r;
+                const int64_t o = prow[q] * LD + 32 * t + r;
                 ev[t][q] = E[o]; sv[t][q] = side[o];
             }
-        if (tile + stride < n_tiles) tl.load(dpre, (tile + stride) * 32, n_rows, gn);
+        if (tile + stride < n_tiles) tl.load(dpre, (tile + stride) * 32, n_rows, gn, row_ids);
         f32x16 a1[NT], a2[NT];
 #pragma unroll
         for (int t = 0; t < NT; t++)
@@ -420,9 +445,8 @@ __global__ __launch_bounds__(256) void dense_bwd_lds_kernel(const float *__restr
         for (int t = 0; t < NT; t++)
 #pragma unroll
             for (int q = 0; q < 16; q++) {
-                const int64_t orow = row0 + cd_row(q, h);
-                if (orow < n_rows) {
-                    const int64_t o = orow * LD + 32 * t + r;
+                if (row0 + cd_row(q, h) < n_rows) {
+                    const int64_t o = prow[q] * LD + 32 * t + r;
                     dside[o] = a1[t][q] + a2[t][q] * ev[t][q];
                     dE[o] = a1[t][q] + a2[t][q] * sv[t][q];
                 }
@@ -439,9 +463,11 @@ __global__ __launch_bounds__(256) void dense_bwd_lds_kernel(const float *__restr
 constexpr int kBlockRows = 128;
 template <int NT>
 __global__ __launch_bounds__(256) void wgrad_lds_kernel(const float *__restrict__ E, const float *__restrict__ side,
-                                                        const float *__restrict__ dpre, int64_t n_rows,
-                                                        float *__restrict__ partial) {
+                                                        const float *__restrict__ dpre, int64_t n_all,
+                                                        float *__restrict__ partial, const int32_t *__restrict__ row_ids,
+                                                        const int32_t *__restrict__ n_ids) {
     constexpr int LD = 32 * NT, RS = LD + kTilePad;
+    const int64_t n_rows = row_ids ? *n_ids : n_all;
     constexpr int NV = 32 * LD / 4 / 256;          // float4 per thread, array and stage (LD = 64: 2, LD = 32: 1)
     constexpr int kStage = 3 * 32 * RS;            // floats per stage buffer: E, side, dpre
     extern __shared__ float s_mem[];               // [2][3][32][RS]
@@ -454,9 +480,10 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const float *__restrict_
 #pragma unroll
         for (int k = 0; k < NV; k++) {
             const int idx = threadIdx.x + 256 * k, row = idx / (LD / 4), c4 = 4 * (idx % (LD / 4));
-            const int64_t n = n0 + 32 * st + row;
+            int64_t n = n0 + 32 * st + row;
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             if (n < n_rows) {
+                if (row_ids) n = row_ids[n];
                 ve[k] = *reinterpret_cast<const f32x4 *>(E + n * LD + c4);
                 vs[k] = *reinterpret_cast<const f32x4 *>(side + n * LD + c4);
                 vd[k] = *reinterpret_cast<const f32x4 *>(dpre + n * LD + c4);
@@ -593,16 +620,108 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     }
 }
 
-// dst[row][c] += src[row][off + c], c < d     (gradient of the ego block of the wide table)
+// dst[row][c] (=|+=) src[row][off + c], c < d     (the ego block of the wide table, in and out).  row_ids (may be null):
+// only the listed rows are touched
 __global__ __launch_bounds__(256) void add_cols_kernel(float *__restrict__ dst, int dst_ld, const float *__restrict__ src,
-                                                       int src_ld, int off, int64_t n_rows, int d, int assign) {
-    const int64_t total = n_rows * d;
+                                                       int src_ld, int off, int64_t n_rows, int d, int assign,
+                                                       const int32_t *__restrict__ row_ids, const int32_t *__restrict__ n_ids) {
+    const int64_t total = (row_ids ? (int64_t)*n_ids : n_rows) * d;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = k / d; const int c = (int)(k % d);
+        const int64_t row = row_ids ? (int64_t)row_ids[k / d] : k / d; const int c = (int)(k % d);
         const float v = src[row * src_ld + off + c];
         if (assign) dst[row * dst_ld + c] = v; else dst[row * dst_ld + c] += v;
     }
 }
+
+// X[row][0 .. ld) = 0 for the listed rows: one float4 per thread
+__global__ __launch_bounds__(256) void zero_rows_kernel(float *__restrict__ X, int ld, const int32_t *__restrict__ row_ids,
+                                                        const int32_t *__restrict__ n_ids) {
+    const int per_row = ld / 4;
+    const int64_t total = (int64_t)*n_ids * per_row;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x)
+        *reinterpret_cast<f32x4 *>(X + (int64_t)row_ids[k / per_row] * ld + 4 * (k % per_row)) = zero;
+}
+
+// rows[0 .. count) = the set bits of a row bitmap, ascending.  One block: thread t owns a contiguous run of mask words,
+// counts its bits, the block scans the counts, every thread writes its rows.
+__global__ __launch_bounds__(1024) void compact_rows_kernel(const uint32_t *__restrict__ mask, int64_t n_rows,
+                                                            int32_t *__restrict__ rows, int32_t *__restrict__ count, int capacity) {
+    __shared__ int s_wave[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_words = (n_rows + 31) / 32;
+    const int64_t per = (n_words + 1023) / 1024, w0 = per * threadIdx.x, w1 = w0 + per < n_words ? w0 + per : n_words;
+    auto word = [&](int64_t w) {
+        uint32_t m = mask[w];
+        if (w == n_words - 1 && (n_rows & 31)) m &= (1u << (n_rows & 31)) - 1u;      // bits past the last row do not count
+        return m;
+    };
+    int mine = 0;
+    for (int64_t w = w0; w < w1; w++) mine += __popc(word(w));
+    int incl = mine;                                     // inclusive scan inside the wavefront, then over the 16 wavefronts
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, kWave); if (lane >= off) incl += v; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const int v = s_wave[k]; if (k < wave) base += v; total += v; }
+    int pos = base + incl - mine;
+    for (int64_t w = w0; w < w1; w++) {
+        uint32_t m = word(w);
+        while (m) {
+            const int b = __ffs(m) - 1; m &= m - 1;
+            if (pos < capacity) rows[pos] = (int32_t)(w * 32 + b);
+            pos++;
+        }
+    }
+    if (threadIdx.x == 0) *count = total < capacity ? total : capacity;
+}
+
+// The whole "which rows does this batch touch" step in one launch, for tables whose bitmap fits the LDS: clear the
+// bitmap, mark u / n_users + i / n_users + j, publish the bitmap, emit the ascending row list.  (As three launches --
+// memset, qrec_mark_batch_rows, compaction -- it is three launch latencies, ~14 us, for a few KB of work.)
+__global__ __launch_bounds__(1024) void mark_compact_kernel(const int32_t *__restrict__ u, const int32_t *__restrict__ i,
+                                                            const int32_t *__restrict__ j, int B, int n_users, int64_t n_rows,
+                                                            uint32_t *__restrict__ mask_out, int32_t *__restrict__ rows,
+                                                            int32_t *__restrict__ count, int capacity) {
+    extern __shared__ uint32_t s_mask[];               // n_words words, then 16 wave sums
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_words = (n_rows + 31) / 32;
+    int *s_wave = reinterpret_cast<int *>(s_mask + n_words);
+    for (int64_t w = threadIdx.x; w < n_words; w += 1024) s_mask[w] = 0u;
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += 1024) {
+        const int ru = u[b], ri = n_users + i[b], rj = n_users + j[b];
+        atomicOr(&s_mask[ru >> 5], 1u << (ru & 31));
+        atomicOr(&s_mask[ri >> 5], 1u << (ri & 31));
+        atomicOr(&s_mask[rj >> 5], 1u << (rj & 31));
+    }
+    __syncthreads();
+    for (int64_t w = threadIdx.x; w < n_words; w += 1024) mask_out[w] = s_mask[w];
+    const int64_t per = (n_words + 1023) / 1024, w0 = per * threadIdx.x, w1 = w0 + per < n_words ? w0 + per : n_words;
+    int mine = 0;
+    for (int64_t w = w0; w < w1; w++) mine += __popc(s_mask[w]);
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, kWave); if (lane >= off) incl += v; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const int v = s_wave[k]; if (k < wave) base += v; total += v; }
+    int pos = base + incl - mine;
+    for (int64_t w = w0; w < w1; w++) {
+        uint32_t m = s_mask[w];
+        while (m) {
+            const int b = __ffs(m) - 1; m &= m - 1;
+            if (pos < capacity) rows[pos] = (int32_t)(w * 32 + b);
+            pos++;
+        }
+    }
+    if (threadIdx.x == 0) *count = total < capacity ? total : capacity;
+}
+constexpr int64_t kLdsMaskRows = 1 << 20;              // 128 KB of bitmap
 
 // persistent grid of the dense-layer kernels: every block stages the weights in LDS once, so no more blocks than
 // the chip keeps resident (2 per CU; 1 when the weights take 128 KB), and never more than there are 128-row groups
@@ -620,17 +739,20 @@ hipError_t allow_big_lds(const void *kernel, size_t bytes) {
 extern "C" {
 
 int qrec_ngcf_dense_fwd(const float *d_E, const float *d_side, const float *d_W1, const float *d_W2, int64_t n_rows,
-                        int32_t ld, float *d_pre, void *stream) {
+                        int32_t ld, float *d_pre, const int32_t *d_row_ids, const int32_t *d_n_row_ids, int32_t max_row_ids,
+                        void *stream) {
     QREC_REQUIRE(d_E && d_side && d_W1 && d_W2 && d_pre && n_rows >= 0, "qrec_ngcf_dense_fwd: bad argument");
-    if (n_rows == 0) return QREC_OK;
+    QREC_REQUIRE(!d_row_ids || (d_n_row_ids && max_row_ids >= 0 && ld <= 64), "qrec_ngcf_dense_fwd: a row subset needs its count, a bound, and ld <= 64");
+    const int64_t work_rows = d_row_ids ? max_row_ids : n_rows;
+    if (work_rows == 0) return QREC_OK;
     hipStream_t st = as_stream(stream);
     const unsigned blocks = dense_grid(n_rows, ld);
     const size_t lds = (size_t)2 * ld * ld * sizeof(float);
-    const unsigned pblocks = dense_grid(n_rows, ld, true);          // ld <= 64: weights in registers, one wavefront per SIMD
+    const unsigned pblocks = dense_grid(work_rows, ld, true);       // ld <= 64: weights in registers, one wavefront per SIMD
     const size_t lds_tiles = (size_t)4 * 32 * (ld + kTilePad) * sizeof(float);
     switch (ld) {
-        case 32: hipLaunchKernelGGL(dense_fwd_lds_kernel<1>, dim3(pblocks), dim3(256), lds_tiles, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre); break;
-        case 64: hipLaunchKernelGGL(dense_fwd_lds_kernel<2>, dim3(pblocks), dim3(256), lds_tiles, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre); break;
+        case 32: hipLaunchKernelGGL(dense_fwd_lds_kernel<1>, dim3(pblocks), dim3(256), lds_tiles, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre, d_row_ids, d_n_row_ids); break;
+        case 64: hipLaunchKernelGGL(dense_fwd_lds_kernel<2>, dim3(pblocks), dim3(256), lds_tiles, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre, d_row_ids, d_n_row_ids); break;
         case 128:
             QREC_HIP_CHECK(allow_big_lds(reinterpret_cast<const void *>(&dense_fwd_kernel<4>), lds));
             hipLaunchKernelGGL(dense_fwd_kernel<4>, dim3(blocks), dim3(256), lds, st, d_E, d_side, d_W1, d_W2, n_rows, d_pre); break;
@@ -642,17 +764,20 @@ int qrec_ngcf_dense_fwd(const float *d_E, const float *d_side, const float *d_W1
 
 int qrec_ngcf_activate(float *d_pre_gate, int64_t n_rows, int32_t d, int32_t ld, float keep, const float *d_mask,
                        uint64_t seed, uint64_t stream_id, float *d_next, float *d_wide, int32_t wide_ld,
-                       int32_t col_off, float *d_inv_norm, void *stream) {
+                       int32_t col_off, float *d_inv_norm, const int32_t *d_row_ids, const int32_t *d_n_row_ids,
+                       int32_t max_row_ids, void *stream) {
     QREC_REQUIRE(d_pre_gate && d_next && d_wide && d_inv_norm && n_rows >= 0 && d >= 1 && ld >= d && keep > 0.f && keep <= 1.f,
                  "qrec_ngcf_activate: bad argument");
     QREC_REQUIRE(col_off >= 0 && col_off + d <= wide_ld, "qrec_ngcf_activate: column block outside the wide table");
-    if (n_rows == 0) return QREC_OK;
+    QREC_REQUIRE(!d_row_ids || (d_n_row_ids && max_row_ids >= 0), "qrec_ngcf_activate: a row subset needs its count and a bound");
+    const int64_t work_rows = d_row_ids ? max_row_ids : n_rows;
+    if (work_rows == 0) return QREC_OK;
     hipStream_t st = as_stream(stream);
     int64_t blocks;
 #define QREC_ACT(LPR)                                                                                              \
-    blocks = (n_rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)); if (blocks > 2048) blocks = 2048;                     \
+    blocks = (work_rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)); if (blocks > 2048) blocks = 2048;                  \
     hipLaunchKernelGGL((activate_rows_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, d_pre_gate, n_rows, d, keep, \
-                       d_mask, seed, stream_id, d_next, d_wide, wide_ld, col_off, d_inv_norm)
+                       d_mask, seed, stream_id, d_next, d_wide, wide_ld, col_off, d_inv_norm, d_row_ids, d_n_row_ids)
     switch (ld) {
         case 32: QREC_ACT(8); break;
         case 64: QREC_ACT(16); break;
@@ -668,21 +793,24 @@ int qrec_ngcf_layer_bwd(const float *d_dE_next, const float *d_dWide, const floa
                         int32_t col_off, const float *d_inv_norm, const float *d_gate, const float *d_E,
                         const float *d_side, const float *d_W1, const float *d_W2, int64_t n_rows, int32_t d,
                         int32_t ld, float *d_dpre, float *d_dside, float *d_dE, float *d_partial, float *d_gW1,
-                        float *d_gW2, void *stream) {
+                        float *d_gW2, const int32_t *d_row_ids, const int32_t *d_n_row_ids, int32_t max_row_ids,
+                        const uint32_t *d_wide_row_mask, void *stream) {
     QREC_REQUIRE(d_dWide && d_wide && d_inv_norm && d_gate && d_E && d_side && d_W1 && d_W2 && d_dpre && d_dside && d_dE &&
                      d_partial && d_gW1 && d_gW2 && n_rows > 0, "qrec_ngcf_layer_bwd: bad argument");
+    QREC_REQUIRE(!d_row_ids || (d_n_row_ids && max_row_ids > 0 && ld <= 64), "qrec_ngcf_layer_bwd: a row subset needs its count, a bound > 0, and ld <= 64");
+    const int64_t work_rows = d_row_ids ? max_row_ids : n_rows;
     hipStream_t st = as_stream(stream);
     int64_t blocks;
 #define QREC_DP(LPR)                                                                                              \
-    blocks = (n_rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)); if (blocks > 2048) blocks = 2048;                    \
+    blocks = (work_rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)); if (blocks > 2048) blocks = 2048;                 \
     hipLaunchKernelGGL((dpre_rows_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, d_dE_next, d_dWide, d_wide, \
-                       wide_ld, col_off, d_inv_norm, d_gate, n_rows, d, d_dpre)
-    const unsigned gblocks = dense_grid(n_rows, ld, ld <= 64);      // ld <= 64: weights in registers, one wavefront per SIMD
+                       wide_ld, col_off, d_inv_norm, d_gate, n_rows, d, d_dpre, d_row_ids, d_n_row_ids, d_wide_row_mask)
+    const unsigned gblocks = dense_grid(work_rows, ld, ld <= 64);   // ld <= 64: weights in registers, one wavefront per SIMD
     const size_t lds = (size_t)2 * ld * (ld + 1) * sizeof(float);
     const size_t lds_tiles = (size_t)4 * 32 * (ld + kTilePad) * sizeof(float);
     switch (ld) {
-        case 32: QREC_DP(8); hipLaunchKernelGGL(dense_bwd_lds_kernel<1>, dim3(gblocks), dim3(256), lds_tiles, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE); break;
-        case 64: QREC_DP(16); hipLaunchKernelGGL(dense_bwd_lds_kernel<2>, dim3(gblocks), dim3(256), lds_tiles, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE); break;
+        case 32: QREC_DP(8); hipLaunchKernelGGL(dense_bwd_lds_kernel<1>, dim3(gblocks), dim3(256), lds_tiles, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE, d_row_ids, d_n_row_ids); break;
+        case 64: QREC_DP(16); hipLaunchKernelGGL(dense_bwd_lds_kernel<2>, dim3(gblocks), dim3(256), lds_tiles, st, d_dpre, d_W1, d_W2, d_E, d_side, n_rows, d_dside, d_dE, d_row_ids, d_n_row_ids); break;
         case 128:
             QREC_DP(32);
             QREC_HIP_CHECK(allow_big_lds(reinterpret_cast<const void *>(&dense_bwd_kernel<4>), lds));
@@ -692,10 +820,10 @@ int qrec_ngcf_layer_bwd(const float *d_dE_next, const float *d_dWide, const floa
 #undef QREC_DP
     QREC_LAUNCH_CHECK();
     const int nt = ld / 32;
-    const int n_slabs = (int)(nt == 4 ? (n_rows + kSlabRows - 1) / kSlabRows : (n_rows + kBlockRows - 1) / kBlockRows);
+    const int n_slabs = (int)(nt == 4 ? (n_rows + kSlabRows - 1) / kSlabRows : (work_rows + kBlockRows - 1) / kBlockRows);
     const size_t wlds = nt == 4 ? (size_t)4 * 2 * nt * 16 * 64 * sizeof(float) : (size_t)2 * 3 * 32 * (ld + kTilePad) * sizeof(float);
-    if (nt == 1) hipLaunchKernelGGL(wgrad_lds_kernel<1>, dim3((unsigned)n_slabs), dim3(256), wlds, st, d_E, d_side, d_dpre, n_rows, d_partial);
-    else if (nt == 2) hipLaunchKernelGGL(wgrad_lds_kernel<2>, dim3((unsigned)n_slabs), dim3(256), wlds, st, d_E, d_side, d_dpre, n_rows, d_partial);
+    if (nt == 1) hipLaunchKernelGGL(wgrad_lds_kernel<1>, dim3((unsigned)n_slabs), dim3(256), wlds, st, d_E, d_side, d_dpre, n_rows, d_partial, d_row_ids, d_n_row_ids);
+    else if (nt == 2) hipLaunchKernelGGL(wgrad_lds_kernel<2>, dim3((unsigned)n_slabs), dim3(256), wlds, st, d_E, d_side, d_dpre, n_rows, d_partial, d_row_ids, d_n_row_ids);
     else {
         QREC_HIP_CHECK(allow_big_lds(reinterpret_cast<const void *>(&wgrad_kernel<4>), wlds));
         hipLaunchKernelGGL(wgrad_kernel<4>, dim3((unsigned)n_slabs, 4), dim3(256), wlds, st, d_E, d_side, d_dpre, n_rows, d_partial);
@@ -714,15 +842,58 @@ int qrec_ngcf_wgrad_partial_bytes(int64_t n_rows, int32_t ld, int64_t *bytes) {
     return QREC_OK;
 }
 
+int qrec_compact_marked_rows(const uint32_t *d_row_mask, int64_t n_rows, int32_t *d_rows, int32_t *d_count, int32_t capacity,
+                             void *stream) {
+    QREC_REQUIRE(d_row_mask && d_rows && d_count && n_rows >= 0 && n_rows < (1ll << 31) && capacity >= 0, "qrec_compact_marked_rows: bad argument");
+    hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d_row_mask, n_rows, d_rows, d_count, capacity);
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+int qrec_mark_compact_batch_rows(const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int32_t B, int32_t n_users,
+                                 int64_t n_rows, uint32_t *d_row_mask, int32_t *d_rows, int32_t *d_count, int32_t capacity,
+                                 void *stream) {
+    QREC_REQUIRE(d_row_mask && d_rows && d_count && B >= 0 && n_users >= 0 && n_rows >= n_users && n_rows < (1ll << 31) && capacity >= 0,
+                 "qrec_mark_compact_batch_rows: bad argument");
+    QREC_REQUIRE(B == 0 || (d_u && d_i && d_j), "qrec_mark_compact_batch_rows: null index array");
+    hipStream_t st = as_stream(stream);
+    const int64_t n_words = (n_rows + 31) / 32;
+    if (n_rows <= kLdsMaskRows) {
+        const size_t lds = (size_t)n_words * 4 + 64;
+        QREC_HIP_CHECK(allow_big_lds(reinterpret_cast<const void *>(&mark_compact_kernel), lds));
+        hipLaunchKernelGGL(mark_compact_kernel, dim3(1), dim3(1024), lds, st, d_u, d_i, d_j, B, n_users, n_rows, d_row_mask, d_rows,
+                           d_count, capacity);
+        QREC_LAUNCH_CHECK();
+        return QREC_OK;
+    }
+    QREC_HIP_CHECK(hipMemsetAsync(d_row_mask, 0, (size_t)n_words * 4, st));
+    int rc = qrec_mark_batch_rows(d_u, d_i, d_j, B, n_users, d_row_mask, stream);
+    if (rc != QREC_OK) return rc;
+    return qrec_compact_marked_rows(d_row_mask, n_rows, d_rows, d_count, capacity, stream);
+}
+
 int qrec_copy_cols(float *d_dst, int32_t dst_ld, const float *d_src, int32_t src_ld, int32_t src_col_off, int64_t n_rows,
-                   int32_t d, int32_t accumulate, void *stream) {
+                   int32_t d, int32_t accumulate, const int32_t *d_row_ids, const int32_t *d_n_row_ids, int32_t max_row_ids,
+                   void *stream) {
     QREC_REQUIRE(d_dst && d_src && n_rows >= 0 && d >= 1 && d <= dst_ld && src_col_off >= 0 && src_col_off + d <= src_ld,
                  "qrec_copy_cols: bad argument");
-    if (n_rows == 0) return QREC_OK;
-    int64_t blocks = (n_rows * d + 255) / 256;
+    QREC_REQUIRE(!d_row_ids || (d_n_row_ids && max_row_ids >= 0), "qrec_copy_cols: a row subset needs its count and a bound");
+    const int64_t work_rows = d_row_ids ? max_row_ids : n_rows;
+    if (work_rows == 0) return QREC_OK;
+    int64_t blocks = (work_rows * d + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(add_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), d_dst, dst_ld, d_src, src_ld,
-                       src_col_off, n_rows, d, accumulate ? 0 : 1);
+                       src_col_off, n_rows, d, accumulate ? 0 : 1, d_row_ids, d_n_row_ids);
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+int qrec_zero_rows(float *d_X, int32_t ld, const int32_t *d_row_ids, const int32_t *d_n_row_ids, int32_t max_row_ids, void *stream) {
+    QREC_REQUIRE(d_X && d_row_ids && d_n_row_ids && ld > 0 && ld % 4 == 0 && max_row_ids >= 0, "qrec_zero_rows: bad argument");
+    if (max_row_ids == 0) return QREC_OK;
+    int64_t blocks = ((int64_t)max_row_ids * (ld / 4) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), d_X, ld, d_row_ids, d_n_row_ids);
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }

@@ -439,6 +439,11 @@ class SimGCLTrainer:
         self.row_mask = DeviceBuffer.zeros((self.n + 31) // 32, np.uint32)   # non-zero rows of dOut (batch rows)
         self.max_unique = max_unique
         self.ws = DeviceBuffer(capi.info_nce_workspace_bytes(max_unique, self.ld), np.uint8)
+        # the user-side and item-side InfoNCE terms are independent chains of small kernels: the item side runs on a
+        # second HIP stream (own workspace), forked and joined with events -- no host synchronisation
+        self.ws_items = DeviceBuffer(capi.info_nce_workspace_bytes(max_unique, self.ld), np.uint8)
+        self.side_stream, self.ev_fork, self.ev_join = capi.Stream(), capi.Event(), capi.Event()
+        self.batch_rows = None  # capi.RowSubset of the step's rows
         f = np.float32
         self.b1, self.b2, self.adam_eps = f(0.9), f(0.999), f(1e-8)
         self.b1p, self.b2p = self.b1, self.b2
@@ -463,28 +468,32 @@ class SimGCLTrainer:
                                   (self.step_no * 2 + (view - 1)) * 64 + k, d_accum=S, stream=stream)
             x = y
 
-    def _encode_three(self, noises, stream, last_rows):
+    def _encode_three(self, noises, stream, last_rows, last_subset=None):
         """The clean and the two perturbed encoders of one training step (SimGCL.py:23-36).  All three start from the
-        same E, so the first product A E is formed once and perturbed twice (out of place); from the second layer on
-        each view has its own operand: 3L-2 SpMMs instead of 3L (L=2: 1 full + 3 row-masked instead of 3 + 3)."""
-        for S in (self.Sm, self.S1, self.S2):
-            S.fill_bytes(0, stream)
+        same E, so the first product A E is formed once and perturbed twice in one pass, which also STARTS the three layer
+        sums (no zero-fill); from the second layer on each view has its own operand: 3L-2 SpMMs instead of 3L (L=2: 1 full
+        + 3 row-masked instead of 3 + 3).  The last layer is computed -- and perturbed -- at the batch's rows only."""
         x = [self.E, self.E, self.E]
+        sums = [self.Sm, self.S1, self.S2]
+        nz = lambda v, k: None if noises is None else noises[(v - 1) * self.L + k]
+        sid = lambda v, k: (self.step_no * 2 + (v - 1)) * 64 + k
         for k in range(self.L):
-            ymask = last_rows if k == self.L - 1 else None
+            last = k == self.L - 1
+            ymask, rows = (last_rows, last_subset) if last else (None, None)
             y0 = self.A if k % 2 == 0 else self.B
+            if k == 0:
+                capi.spmm_csr(self.plan, self.E, y0, self.ld, stream=stream, d_y_row_mask=ymask)
+                y1, y2 = self.V[0][0], self.V[1][0]
+                capi.perturb_two_views(y0, y1, y2, self.n, self.d, self.ld, self.eps, nz(1, 0), nz(2, 0), self.seed, sid(1, 0), sid(2, 0),
+                                       self.S1, self.S2, self.Sm, stream, rows=rows)
+                x = [y0, y1, y2]
+                continue
             capi.spmm_csr(self.plan, x[0], y0, self.ld, d_accum=self.Sm, stream=stream, d_y_row_mask=ymask)
             for v in (1, 2):
                 yv = self.V[v - 1][k % 2]
-                noise = None if noises is None else noises[(v - 1) * self.L + k]
-                sid = (self.step_no * 2 + (v - 1)) * 64 + k
-                if k == 0:      # same operand as the clean view: reuse its product
-                    capi.perturb_rows(yv, self.n, self.d, self.ld, self.eps, noise, self.seed, sid, d_accum=[self.S1, self.S2][v - 1],
-                                      stream=stream, d_src=y0)
-                else:
-                    capi.spmm_csr(self.plan, x[v], yv, self.ld, stream=stream, d_y_row_mask=ymask)
-                    capi.perturb_rows(yv, self.n, self.d, self.ld, self.eps, noise, self.seed, sid, d_accum=[self.S1, self.S2][v - 1],
-                                      stream=stream)
+                capi.spmm_csr(self.plan, x[v], yv, self.ld, stream=stream, d_y_row_mask=ymask)
+                capi.perturb_rows(yv, self.n, self.d, self.ld, self.eps, nz(v, k), self.seed, sid(v, k), d_accum=sums[v],
+                                  stream=stream, rows=rows)
                 x[v] = yv
             x[0] = y0
 
@@ -504,9 +513,11 @@ class SimGCLTrainer:
         L = float(self.L)
         lo, cnt = (0, B) if share is None else share
         cl_rate = self.cl_rate if self.dp is None else self.cl_rate / self.dp.world
-        self.row_mask.fill_bytes(0, stream)
-        capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)
-        self._encode_three(noises, stream, self.row_mask)
+        bound = min(3 * B, self.n)
+        if self.batch_rows is None or self.batch_rows.capacity < bound:
+            self.batch_rows = capi.RowSubset(bound)
+        subset = capi.mark_compact_batch_rows(d_u, d_i, d_j, B, self.nu, self.n, self.row_mask, self.batch_rows, bound, stream)
+        self._encode_three(noises, stream, self.row_mask, subset)
         self.dOut.fill_bytes(0, stream)
         self.d_loss.fill_bytes(0, stream)
         # the InfoNCE rows (unique batch users / positive items) are a subset of the rows marked above
@@ -516,10 +527,13 @@ class SimGCLTrainer:
             capi.bpr_batch_loss_grad(self.Sm, L, self.nu, self.n, self.ld, d_u, d_i, d_j, cnt,
                                      self.loss_eps, self.reg, self.dOut, self.d_loss, stream, d_row_mask=self.row_mask)
         cl = self.d_loss.ptr + 8
+        side = self.side_stream.handle
+        self.ev_fork.record(stream); self.side_stream.wait_event(self.ev_fork)
+        capi.info_nce_loss_grad(self.S1, self.S2, L, d_uniq_items, n_ui, self.ld, self.tau, cl_rate, self.ws_items,
+                                self.dOut, cl, side)          # item rows: disjoint from the user rows written below
         capi.info_nce_loss_grad(self.S1, self.S2, L, d_uniq_users, n_uu, self.ld, self.tau, cl_rate, self.ws,
                                 self.dOut, cl, stream)
-        capi.info_nce_loss_grad(self.S1, self.S2, L, d_uniq_items, n_ui, self.ld, self.tau, cl_rate, self.ws,
-                                self.dOut, cl, stream)
+        self.ev_join.record(side); capi.stream_wait_event(stream, self.ev_join)
         # dE0 = (1/L) sum_{k=1..L} A^k dOut :  W_0 = dOut, W_k = dOut + A W_{k-1}, G = A W_{L-1}
         x = self.dOut
         for k in range(self.L - 1):
@@ -599,62 +613,83 @@ class NGCFTrainer:
         self.All = DeviceBuffer.zeros((self.n, self.wide_ld), np.float32)
         self.dAll = DeviceBuffer.zeros((self.n, self.wide_ld), np.float32)
         pad = lambda w: np.pad(np.asarray(w, np.float32), ((0, self.ld - self.d), (0, self.ld - self.d)))
-        self.W = [[DeviceBuffer.from_numpy(pad(w)) for w in pair] for pair in W]
-        self.gW = [[DeviceBuffer.zeros((self.ld, self.ld), np.float32) for _ in range(2)] for _ in range(2)]
+        # the four d x d weights (and their gradients) are windows of ONE buffer each: one Adam launch updates all four
+        ll = self.ld * self.ld
+        self.W_all = DeviceBuffer.from_numpy(np.stack([pad(w) for pair in W for w in pair]))
+        self.gW_all = DeviceBuffer.zeros((4, self.ld, self.ld), np.float32)
+        self.W = [[capi.DeviceSlice(self.W_all, (2 * k + t) * ll, (self.ld, self.ld)) for t in range(2)] for k in range(2)]
+        self.gW = [[capi.DeviceSlice(self.gW_all, (2 * k + t) * ll, (self.ld, self.ld)) for t in range(2)] for k in range(2)]
         self.partial = DeviceBuffer(capi.ngcf_wgrad_partial_bytes(self.n, self.ld), np.uint8)
         self.optE = _Adam(self.E[0], lr)
-        self.optW = [[_Adam(w, lr) for w in pair] for pair in self.W]
+        self.optW = _Adam(self.W_all, lr)
         self.d_loss = DeviceBuffer.zeros(1, np.float64)
         self.row_mask = DeviceBuffer.zeros((self.n + 31) // 32, np.uint32)
+        self.batch_rows = None  # capi.RowSubset of the step's rows (ld <= 64: the last layer runs on these rows only)
         self.step_no = 0
         self.dp = None          # dist.BatchParallel
 
-    def forward(self, training: bool, masks=None, stream=None, last_rows=None):
+    def forward(self, training: bool, masks=None, stream=None, last_rows=None, last_subset=None):
         """fills E_1, E_2, side, gate, inv and the wide table All = [E_0 | z_1 | z_2].  ``last_rows`` (training):
         the last layer's neighbourhood sum is only formed at the batch's rows -- its output block z_2 is read there
         and nowhere else, and its backward only touches rows with a non-zero gradient, which are the same rows
-        (the other rows of side/gate/E_2 keep older, finite values whose gradient weight is exactly 0)."""
+        (the other rows of side/gate/E_2 keep older, finite values whose gradient weight is exactly 0).
+        ``last_subset`` (the same rows as a list): the last layer's dense product and activation also run on those
+        rows only -- about 6 k of 70 k rows at the reference's batch size."""
         n, d, ld = self.n, self.d, self.ld
-        capi.copy_cols(self.All, self.wide_ld, self.E[0], ld, 0, n, d, False, stream)
+        capi.copy_cols(self.All, self.wide_ld, self.E[0], ld, 0, n, d, False, stream, rows=last_subset)   # the ego block: read where the batch looks
         for k in range(self.N_LAYERS):
-            capi.spmm_csr(self.plan, self.E[k], self.side[k], ld, stream=stream,
-                          d_y_row_mask=last_rows if k == self.N_LAYERS - 1 else None)
-            capi.ngcf_dense_fwd(self.E[k], self.side[k], self.W[k][0], self.W[k][1], n, ld, self.gate[k], stream)
+            last = k == self.N_LAYERS - 1
+            rows = last_subset if last else None
+            capi.spmm_csr(self.plan, self.E[k], self.side[k], ld, stream=stream, d_y_row_mask=last_rows if last else None)
+            capi.ngcf_dense_fwd(self.E[k], self.side[k], self.W[k][0], self.W[k][1], n, ld, self.gate[k], stream, rows=rows)
             capi.ngcf_activate(self.gate[k], n, d, ld, self.KEEP if training else 1.0,
                                None if masks is None else masks[k], self.seed, self.step_no * 8 + k, self.E[k + 1],
-                               self.All, self.wide_ld, (k + 1) * d, self.inv[k], stream)
+                               self.All, self.wide_ld, (k + 1) * d, self.inv[k], stream, rows=rows)
 
     def train_step_async(self, d_u, d_i, d_j, B: int, masks=None, stream=None):
         n, d, ld = self.n, self.d, self.ld
-        self.row_mask.fill_bytes(0, stream)
-        if B:
-            capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)
-        self.forward(True, masks, stream, last_rows=self.row_mask)
-        self.dAll.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
+        subset = None
+        if B and ld <= 64:
+            bound = min(3 * B, n)
+            if self.batch_rows is None or self.batch_rows.capacity < bound:
+                self.batch_rows = capi.RowSubset(bound)
+            subset = capi.mark_compact_batch_rows(d_u, d_i, d_j, B, self.nu, n, self.row_mask, self.batch_rows, bound, stream)
+        else:
+            self.row_mask.fill_bytes(0, stream)
+            if B:
+                capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)
+        self.forward(True, masks, stream, last_rows=self.row_mask, last_subset=subset)
+        # the loss scatters into the batch's rows of dAll and nothing reads another row of it (wide_mask below): clearing
+        # those ~6 k rows replaces a 71 MB fill of the wide table
+        wide_mask = self.row_mask if subset is not None else None
+        if subset is not None:
+            capi.zero_rows(self.dAll, self.wide_ld, subset, stream)
+        else:
+            self.dAll.fill_bytes(0, stream)
+        self.d_loss.fill_bytes(0, stream)
         if B:
             capi.bpr_batch_loss_grad(self.All, 1.0, self.nu, n, self.wide_ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
                                      self.dAll, self.d_loss, stream, d_row_mask=self.row_mask)
         dnext = None
         for k in (1, 0):
             dE = self.dEa if k == 1 else self.dEb
+            rows = subset if k == self.N_LAYERS - 1 else None
+            if rows is not None:
+                dE.fill_bytes(0, stream)        # written at the batch's rows only; the SpMM below adds to ALL rows of it
             capi.ngcf_layer_bwd(dnext, self.dAll, self.All, self.wide_ld, (k + 1) * d, self.inv[k], self.gate[k], self.E[k],
                                 self.side[k], self.W[k][0], self.W[k][1], n, d, ld, self.dpre, self.dside, dE, self.partial,
-                                self.gW[k][0], self.gW[k][1], stream)
+                                self.gW[k][0], self.gW[k][1], stream, rows=rows, d_wide_row_mask=wide_mask)
             # dE += A^T dside.  For the last layer dside is non-zero only on the batch rows (its gradient
             # comes from the concat block alone), so that SpMM skips the other operand rows.
             capi.spmm_csr(self.plan, self.dside, dE, ld, d_addend=dE, addend_scale=1.0, stream=stream,
                           d_x_row_mask=self.row_mask if k == 1 else None)
             dnext = dE
-        capi.copy_cols(dnext, ld, self.dAll, self.wide_ld, 0, n, d, True, stream)                    # + ego block of the concat
+        capi.copy_cols(dnext, ld, self.dAll, self.wide_ld, 0, n, d, True, stream, rows=subset)          # + ego block of the concat
         if self.dp is not None:     # table gradient + the four d x d weight gradients ("all-reduce for the dense layers")
             self.dp.all_reduce(dnext); self.dp.all_reduce(self.d_loss)
-            for pair in self.gW:
-                for gw in pair:
-                    self.dp.all_reduce(gw)
+            self.dp.all_reduce(self.gW_all)
         self.optE.step(dnext, stream=stream)
-        for k in range(2):
-            for t in range(2):
-                self.optW[k][t].step(self.gW[k][t], stream=stream)
+        self.optW.step(self.gW_all, stream=stream)
         self.step_no += 1
 
     def loss(self, stream=None) -> float:

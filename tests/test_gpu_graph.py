@@ -391,7 +391,50 @@ def test_bpr_tf_variant_matches_restatement_and_runs_from_conf():
 from qrec_amd.graph import NGCFTrainer  # noqa: E402
 
 
-@pytest.mark.parametrize("dim", [64, 50, 8])
+def test_row_subset_helpers():
+    """qrec_compact_marked_rows (bitmap -> ascending row list, capacity respected, bits past the last row ignored),
+    qrec_zero_rows, and qrec_copy_cols with a source row mask."""
+    rng = np.random.default_rng(5)
+    for n in (1, 31, 32, 33, 1000, 69716):
+        marked = rng.random(n) < (0.5 if n < 100 else 0.09)
+        words = np.zeros((n + 31) // 32, np.uint32)
+        idx = np.nonzero(marked)[0]
+        np.bitwise_or.at(words, idx >> 5, (np.uint32(1) << (idx & 31).astype(np.uint32)))
+        if n % 32:
+            words[-1] |= np.uint32(0xFFFFFFFF) << np.uint32(n % 32)           # garbage past the last row
+        sub = capi.RowSubset(n).from_mask(DB.from_numpy(words), n, n)
+        cnt = int(sub.count.numpy()[0])
+        assert cnt == idx.size and np.array_equal(sub.rows.numpy()[:cnt], idx)
+        small = capi.RowSubset(max(idx.size // 2, 1)).from_mask(DB.from_numpy(words), n, max(idx.size // 2, 1))
+        c2 = int(small.count.numpy()[0])
+        assert c2 == min(idx.size, small.capacity) and np.array_equal(small.rows.numpy()[:c2], idx[:c2])
+        X = rng.standard_normal((n, 64)).astype(np.float32)
+        dX = DB.from_numpy(X); capi.zero_rows(dX, 64, sub)
+        want = X.copy(); want[idx] = 0
+        assert np.array_equal(dX.numpy(), want)
+        src = rng.standard_normal((n, 256)).astype(np.float32); dst = rng.standard_normal((n, 64)).astype(np.float32)
+        dD = DB.from_numpy(dst)
+        capi.copy_cols(dD, 64, DB.from_numpy(src), 256, 3, n, 50, True, rows=sub)
+        want = dst.copy(); want[idx, :50] += src[idx, 3:53]
+        assert np.array_equal(dD.numpy(), want)
+        capi.copy_cols(dD, 64, DB.from_numpy(src), 256, 7, n, 50, False, rows=sub)
+        want[idx, :50] = src[idx, 7:57]
+        assert np.array_equal(dD.numpy(), want)
+        # the fused form: bitmap + list from a batch's (u, i, j)
+        nu = n // 2
+        if nu >= 1 and n - nu >= 1:
+            B = min(500, n)
+            u = rng.integers(0, nu, B).astype(np.int32); i = rng.integers(0, n - nu, B).astype(np.int32); j = rng.integers(0, n - nu, B).astype(np.int32)
+            dmask = DB.from_numpy(words)            # stale contents: the call clears it
+            fused = capi.mark_compact_batch_rows(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, nu, n, dmask, capi.RowSubset(min(3 * B, n)), min(3 * B, n))
+            touched = np.unique(np.concatenate([u, nu + i, nu + j]))
+            c3 = int(fused.count.numpy()[0])
+            assert c3 == touched.size and np.array_equal(fused.rows.numpy()[:c3], touched)
+            wm = np.zeros_like(words); np.bitwise_or.at(wm, touched >> 5, (np.uint32(1) << (touched & 31).astype(np.uint32)))
+            assert np.array_equal(dmask.numpy(), wm)
+
+
+@pytest.mark.parametrize("dim", [64, 50, 8, 70])
 def test_ngcf_gradients_and_training_steps_match_restatement(dim):
     d, adj, A = _graph("small")
     nu, ni, B = d["n_users"], d["n_items"], 1024
