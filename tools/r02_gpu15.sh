@@ -2,16 +2,11 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-grep -n -E "GRBM_GUI_ACTIVE|MfmaUtil" -A3 $O/counters_avail.txt | head -30
-REPS=1 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_CYCLES --kernel-trace -d $O/pmc_gui -o r02 -- python $R/tools/bench_eval.py child > $O/pmc_gui.log 2>&1; echo "pmc exit $?"
-python - <<PY
+rm -rf $O/prof_simgcl
+rocprofv3 --kernel-trace --stats -d $O/prof_simgcl -o simgcl -- python $R/tools/bench_eval_simgcl.py --skip-eval > $O/prof_simgcl.log 2>&1; echo "exit $?"
+python - <<'P'
 import sqlite3
-con=sqlite3.connect("$O/pmc_gui/r02_results.db")
-for r in con.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection where kernel_name like '%score_filter%' group by kernel_name, counter_name"):
-    print("   %-24s n=%d avg=%.5g"%(r[1],r[2],r[3]))
-try:
-    for r in con.execute("select name, average from top_kernels where name like '%score_filter%'"): print("   avg duration us", r[1])
-except Exception as e:
-    cols=[r for r in con.execute("select name from sqlite_master where type in ('table','view')")]
-    print(cols[:40])
-PY
+con=sqlite3.connect('/root/repo/gpurun_out/prof_simgcl/simgcl_results.db')
+for name,calls,t,avg,pct in list(con.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))[:24]:
+    print(f"{calls:6d} {t/1e3:10.1f} {avg/1e3:9.2f} {pct:6.2f}  {name[:70]}")
+P
