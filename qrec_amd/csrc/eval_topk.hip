@@ -18,6 +18,8 @@
 // FLOPs: 2*B*I*d on the matrix pipe.
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "common.h"
 
 using namespace qrec;
@@ -40,9 +42,12 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void score_kernel_f32(
     const float *__restrict__ U, const float *__restrict__ V, int ld, int n_items,
     const int32_t *__restrict__ user_ids, int n_b, int b_pad, int item_tiles_per_wave,
-    float *__restrict__ S_T, int tile_stride) {
+    float *__restrict__ S_T, int tile_stride, int64_t upair_stride) {
     // tile_stride > 1 (threshold pass of the fused evaluation): block row 32*t + q is item 32*t*tile_stride + q, i.e.
     // only every tile_stride-th item tile is scored.
+    // Layout: score of (block row, user b) at S_T[row * b_pad + (b / 64) * upair_stride + b % 64].  upair_stride = 64:
+    // the plain [rows][b_pad] block.  b_pad = 64 with upair_stride = rows * 64: 64-user panels one after another -- a
+    // user's column then strides 256 B and shares every cache line with 31 neighbours (the exact per-user walk).
     // One wavefront serves TWO 32-user tiles per item tile: the item operand (re-read from L2 by every user tile that
     // needs it -- 990 user tiles x 9.7 MB at the Yelp shape) is fetched half as often.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(256) void score_kernel_f32(
                 for (int q = 0; q < 8; q++) vn[q] = pv[q];
             }
             f32x16 acc0, acc1;
-            float *out = S_T + (int64_t)(t * 32) * b_pad + upair * 64;
+            float *out = S_T + (int64_t)(t * 32) * b_pad + upair * upair_stride;
             const int item0 = t * tile_stride * 32;
             if (c == 0) {
 #pragma unroll
@@ -200,7 +205,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void mask_kernel(const int32_t *__restrict__ user_ids, int n_b,
                                                    const int64_t *__restrict__ rated_indptr,
                                                    const int32_t *__restrict__ rated_items, int b_pad,
-                                                   T *__restrict__ S_T, int tile, int tile_stride) {
+                                                   T *__restrict__ S_T, int tile, int tile_stride, int64_t upair_stride) {
     // one wavefront per user of the batch.  tile_stride > 1: the block holds every tile_stride-th item tile only.
     const int b = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (b >= n_b) return;
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256) void mask_kernel(const int32_t *__restrict__ u
     const int64_t beg = rated_indptr[uid], end = rated_indptr[uid + 1];
     for (int64_t e = beg + (threadIdx.x & 63); e < end; e += 64) {
         const int it = rated_items[e], t = it / tile;
-        if (t % tile_stride == 0) S_T[((int64_t)(t / tile_stride) * tile + it % tile) * b_pad + b] = T(0);
+        if (t % tile_stride == 0) S_T[((int64_t)(t / tile_stride) * tile + it % tile) * b_pad + (b >> 6) * upair_stride + (b & 63)] = T(0);
     }
 }
 
@@ -482,19 +487,45 @@ __global__ __launch_bounds__(kHeapThreads) void merge_topk_kernel(const T *__res
     if (tie) flagged_list[atomicAdd(n_flagged, 1)] = b;
 }
 
+// A heap of <= 64 entries spread over the lanes of one wavefront: entry k lives in lane k's registers and is read /
+// read with v_readlane, written by a per-lane select (k is wave-uniform: every lane runs the same sift).  An update costs a few
+// dozen cross-lane moves instead of lane 0 chasing LDS latencies behind a barrier.
+template <typename T>
+struct LaneHeap {
+    T s;             // this lane's entry
+    int32_t id;
+    int lane;
+    static __device__ int rl(int v, int k) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(k)); }
+    __device__ T S(int k) const {
+        if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, rl(__builtin_bit_cast(int, s), k));
+        else {
+            const unsigned long long b = __builtin_bit_cast(unsigned long long, s);
+            const unsigned lo = (unsigned)rl((int)(unsigned)b, k), hi = (unsigned)rl((int)(unsigned)(b >> 32), k);
+            return __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo);
+        }
+    }
+    __device__ int32_t I(int k) const { return rl(id, k); }
+    __device__ void set(int k, T sv, int32_t iv) {          // k, sv, iv wave-uniform: lane k takes the value
+        const bool me = lane == k;
+        s = me ? sv : s; id = me ? iv : id;
+    }
+};
+
 // Exact sequential emulation for ONE user per wavefront (the users merge_topk_kernel flagged, when they are few).
 // Same algorithm as heap_topk_kernel, 64 items per step: every lane holds one score, a ballot finds the first lane
 // whose score beats the heap root, lane 0 performs heapq's replace in LDS, the root is re-read and the remaining
 // lanes of the step are tested again.  The user's scores are b_pad*sizeof(T) bytes apart (64 cache lines per step):
 // fine for a handful of users, 16x read amplification if used for all -- hence the `many` gate.
-template <typename T>
+template <typename T, bool REG>      // REG: K <= 64, the heap lives in the wavefront's registers (LaneHeap); else in LDS
 __global__ __launch_bounds__(64) void exact_wave_kernel(const T *__restrict__ S_T, int n_items, int b_pad, int K,
                                                         const int32_t *__restrict__ n_flagged, const int32_t *__restrict__ flagged_list,
-                                                        int many, int32_t *__restrict__ ids_out, T *__restrict__ scores_out) {
+                                                        int many, int32_t *__restrict__ ids_out, T *__restrict__ scores_out,
+                                                        int64_t upair_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int nf = *n_flagged;
+    // n_flagged == nullptr: every user of the block (one wavefront each) -- the fused route's fallback batch
+    const int nf = n_flagged ? *n_flagged : (int)gridDim.x;
     if (nf > many || (int)blockIdx.x >= nf) return;
-    const int b = flagged_list[blockIdx.x], lane = threadIdx.x;
+    const int b = n_flagged ? flagged_list[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;
     T *hs = reinterpret_cast<T *>(smem);                                       // heap of this wavefront: [K] scores, [K] ids
     int32_t *hi = reinterpret_cast<int32_t *>(smem + (size_t)K * sizeof(T));
     struct WHeap {   // same interface as Heap<T>, one heap per block
@@ -502,52 +533,81 @@ __global__ __launch_bounds__(64) void exact_wave_kernel(const T *__restrict__ S_
         __device__ T S(int k) const { return s[k]; }
         __device__ int32_t I(int k) const { return id[k]; }
         __device__ void set(int k, T sv, int32_t iv) { s[k] = sv; id[k] = iv; }
-    } hp{hs, hi};
-    const T *col = S_T + b;
+    };
+    typename std::conditional<REG, LaneHeap<T>, WHeap>::type hp;
+    const T *col = S_T + (b >> 6) * upair_stride + (b & 63);
     const int k = K < n_items ? K : n_items;
-    for (int t = lane; t < k; t += 64) hp.set(t, col[(int64_t)t * b_pad], t);
-    __syncthreads();
-    if (lane == 0)
+    if constexpr (REG) {
+        hp.s = lane < k ? col[(int64_t)lane * b_pad] : T(0); hp.id = lane; hp.lane = lane;
         for (int t = k / 2 - 1; t >= 0; t--) sift_up(hp, k, t);
-    __syncthreads();
+    } else {
+        hp.s = hs; hp.id = hi;
+        for (int t = lane; t < k; t += 64) hp.set(t, col[(int64_t)t * b_pad], t);
+        __syncthreads();
+        if (lane == 0)
+            for (int t = k / 2 - 1; t >= 0; t--) sift_up(hp, k, t);
+        __syncthreads();
+    }
     T root = hp.S(0);
-    // the user's scores sit b_pad elements apart: a step's 64 loads are 64 cache lines and a full memory round trip, so
-    // the values of the next kDepth steps are kept in flight (one wavefront per user: nothing else hides the latency)
-    constexpr int kDepth = 8;
-    T ahead[kDepth];
+    // One wavefront per user and nothing else on the SIMD: the walk is a chain of memory round trips unless the loads of many
+    // steps are in flight.  Steps go in groups of kGroup: the next group's kGroup loads per lane are issued before the
+    // current group is examined (8 steps ahead, shifted through registers, measured 0.65 us per step = 0.39 ms per user).
+    constexpr int kGroup = 32;
+    T cur[kGroup], nxt[kGroup];
+    auto fetch = [&](int t0, T (&dst)[kGroup]) {
 #pragma unroll
-    for (int q = 0; q < kDepth; q++) { const int t = k + 64 * q + lane; ahead[q] = t < n_items ? col[(int64_t)t * b_pad] : T(0); }
-    for (int t0 = k; t0 < n_items; t0 += 64) {
-        const int t = t0 + lane;
-        const T v = ahead[0];
+        for (int q = 0; q < kGroup; q++) { const int t = t0 + 64 * q + lane; dst[q] = t < n_items ? col[(int64_t)t * b_pad] : T(0); }
+    };
+    fetch(k, cur);
+    for (int g0 = k; g0 < n_items; g0 += 64 * kGroup) {
+        if (g0 + 64 * kGroup < n_items) fetch(g0 + 64 * kGroup, nxt);
 #pragma unroll
-        for (int q = 0; q + 1 < kDepth; q++) ahead[q] = ahead[q + 1];
-        { const int tn = t0 + 64 * kDepth + lane; ahead[kDepth - 1] = tn < n_items ? col[(int64_t)tn * b_pad] : T(0); }
-        bool live = t < n_items;
-        while (true) {
-            const unsigned long long mask = __ballot(live && v > root);
-            if (!mask) break;
-            const int first = __builtin_ctzll(mask);
-            const T fv = __shfl(v, first, kWave);
-            if (lane == 0) { hp.set(0, fv, t0 + first); sift_up(hp, k, 0); }
-            __syncthreads();
-            root = hp.S(0);
-            live = live && lane > first;
+        for (int q = 0; q < kGroup; q++) {
+            const int t0 = g0 + 64 * q, t = t0 + lane;
+            const T v = cur[q];
+            bool live = t < n_items;
+            while (true) {
+                const unsigned long long mask = __ballot(live && v > root);
+                if (!mask) break;
+                const int first = __builtin_ctzll(mask);
+                const T fv = __shfl(v, first, kWave);
+                if constexpr (REG) {
+                    hp.set(0, fv, t0 + first); sift_up(hp, k, 0);
+                } else {
+                    if (lane == 0) { hp.set(0, fv, t0 + first); sift_up(hp, k, 0); }
+                    __syncthreads();
+                }
+                root = hp.S(0);
+                live = live && lane > first;
+            }
         }
+#pragma unroll
+        for (int q = 0; q < kGroup; q++) cur[q] = nxt[q];
     }
-    __syncthreads();
-    if (lane == 0) {
-        for (int a = 1; a < k; a++) {               // list.sort(key=score, reverse=True): stable, descending
-            const T xs = hp.S(a); const int32_t xi = hp.I(a);
-            int c = a - 1;
-            while (c >= 0 && hp.S(c) < xs) { hp.set(c + 1, hp.S(c), hp.I(c)); c--; }
-            hp.set(c + 1, xs, xi);
+    if constexpr (REG) {
+        // list.sort(key=score, reverse=True), stable: entry a's rank = how many entries beat it or tie it from the left
+        int rank = 0;
+        for (int c = 0; c < k; c++) {
+            const T cs = hp.S(c);
+            rank += (cs > hp.s || (cs == hp.s && c < lane)) ? 1 : 0;
         }
-    }
-    __syncthreads();
-    for (int a = lane; a < K; a += 64) {
-        ids_out[(int64_t)b * K + a] = a < k ? hp.I(a) : -1;
-        scores_out[(int64_t)b * K + a] = a < k ? hp.S(a) : T(0);
+        if (lane < k) { ids_out[(int64_t)b * K + rank] = hp.id; scores_out[(int64_t)b * K + rank] = hp.s; }
+        for (int a = k + lane; a < K; a += 64) { ids_out[(int64_t)b * K + a] = -1; scores_out[(int64_t)b * K + a] = T(0); }
+    } else {
+        __syncthreads();
+        if (lane == 0) {
+            for (int a = 1; a < k; a++) {               // list.sort(key=score, reverse=True): stable, descending
+                const T xs = hp.S(a); const int32_t xi = hp.I(a);
+                int c = a - 1;
+                while (c >= 0 && hp.S(c) < xs) { hp.set(c + 1, hp.S(c), hp.I(c)); c--; }
+                hp.set(c + 1, xs, xi);
+            }
+        }
+        __syncthreads();
+        for (int a = lane; a < K; a += 64) {
+            ids_out[(int64_t)b * K + a] = a < k ? hp.I(a) : -1;
+            scores_out[(int64_t)b * K + a] = a < k ? hp.S(a) : T(0);
+        }
     }
 }
 
@@ -805,14 +865,14 @@ int run_score_topk(const void *U, const void *V, int d, int ld, int n_items, con
     T *S_T = static_cast<T *>(scratch);
     if constexpr (sizeof(T) == 4)
         hipLaunchKernelGGL(score_kernel_f32, grid, dim3(256), 0, st, (const float *)U, (const float *)V, ld,
-                           n_items, user_ids, n_b, b_pad, per_wave, S_T, 1);
+                           n_items, user_ids, n_b, b_pad, per_wave, S_T, 1, (int64_t)64);
     else
         hipLaunchKernelGGL(score_kernel_f64, grid, dim3(256), 0, st, (const double *)U, (const double *)V, ld,
                            n_items, user_ids, n_b, b_pad, per_wave, S_T);
     QREC_LAUNCH_CHECK();
     if (rated_indptr) {
         hipLaunchKernelGGL(mask_kernel<T>, dim3((unsigned)((n_b + 3) / 4)), dim3(256), 0, st, user_ids, n_b,
-                           rated_indptr, rated_items, b_pad, S_T, TILE, 1);
+                           rated_indptr, rated_items, b_pad, S_T, TILE, 1, (int64_t)64);
         QREC_LAUNCH_CHECK();
     }
     const size_t lds = (size_t)K * kHeapThreads * (sizeof(T) + sizeof(int32_t));
@@ -863,8 +923,12 @@ int run_score_topk(const void *U, const void *V, int d, int ld, int n_items, con
     // users whose N+1 best scores are not pairwise distinct: exact emulation (device-side choice of the regime)
     const int many = n_b / 16 > 256 ? n_b / 16 : 256;
     const int wave_blocks = n_b < many ? n_b : many;
-    hipLaunchKernelGGL(exact_wave_kernel<T>, dim3((unsigned)wave_blocks), dim3(64), (size_t)K * (sizeof(T) + sizeof(int32_t)), st, S_T,
-                       n_items, b_pad, K, n_flagged, flagged_list, many, ids_out, (T *)scores_out);
+    if (K <= 64)
+        hipLaunchKernelGGL((exact_wave_kernel<T, true>), dim3((unsigned)wave_blocks), dim3(64), 0, st, S_T,
+                           n_items, b_pad, K, n_flagged, flagged_list, many, ids_out, (T *)scores_out, (int64_t)64);
+    else
+        hipLaunchKernelGGL((exact_wave_kernel<T, false>), dim3((unsigned)wave_blocks), dim3(64), (size_t)K * (sizeof(T) + sizeof(int32_t)), st, S_T,
+                           n_items, b_pad, K, n_flagged, flagged_list, many, ids_out, (T *)scores_out, (int64_t)64);
     QREC_LAUNCH_CHECK();
     hipLaunchKernelGGL(heap_topk_kernel<T>, dim3(user_blocks), dim3(kHeapThreads), lds, st, S_T, n_items, b_pad, n_b, K, ids_out,
                        (T *)scores_out, flags, n_flagged, many);
@@ -940,11 +1004,11 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
         if (per_wave < 8) per_wave = g.n_s_tiles < 8 ? g.n_s_tiles : 8;
         const int waves_per_utile = (g.n_s_tiles + per_wave - 1) / per_wave;
         hipLaunchKernelGGL(score_kernel_f32, dim3((unsigned)g.n_utiles, (unsigned)((waves_per_utile + 3) / 4)), dim3(256), 0, st, U, V, ld,
-                           n_items, user_ids, n_b, g.b_pad, per_wave, S_s, kSampleStride);
+                           n_items, user_ids, n_b, g.b_pad, per_wave, S_s, kSampleStride, (int64_t)64);
         QREC_LAUNCH_CHECK();
         if (rated_indptr) {
             hipLaunchKernelGGL(mask_kernel<float>, dim3((unsigned)((n_b + 3) / 4)), dim3(256), 0, st, user_ids, n_b, rated_indptr,
-                               rated_sorted, g.b_pad, S_s, 32, kSampleStride);
+                               rated_sorted, g.b_pad, S_s, 32, kSampleStride, (int64_t)64);
             QREC_LAUNCH_CHECK();
         }
         const int per_group = (g.n_s + kGroups - 1) / kGroups, n_groups_used = (g.n_s + per_group - 1) / per_group;
@@ -986,12 +1050,32 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
     QREC_HIP_CHECK(hipStreamSynchronize(st));
     int32_t *fb_users = reinterpret_cast<int32_t *>(base + g.off_fbu), *fb_ids = reinterpret_cast<int32_t *>(base + g.off_fbi);
     float *fb_sc = reinterpret_cast<float *>(base + g.off_fbs);
+    // Their scores as 64-user panels ([panel][item][64]: a user's column strides 256 B and every cache line is shared by
+    // 32 users whose wavefronts walk in step), masked, then the exact sequential emulation, one wavefront per user --
+    // three launches.  (Through the whole block route -- sliced top-N, flags, then exact_wave_kernel on a [item][b_pad]
+    // block where each of a step's 64 loads is its own cache line -- this fallback was 0.8 ms of the evaluation's 3.05.)
+    float *fb_block = reinterpret_cast<float *>(base + g.off_fb);
+    const int64_t panel = (int64_t)g.n_item_tiles * 32 * 64;
     for (int off = 0; off < h_nf; off += g.fb_users) {
         const int n = h_nf - off < g.fb_users ? h_nf - off : g.fb_users;
         hipLaunchKernelGGL(gather_user_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, user_ids, flagged_list, off, n, fb_users);
         QREC_LAUNCH_CHECK();
-        const int rc = run_score_topk<float>(U, V, d, ld, n_items, fb_users, n, rated_indptr, rated_sorted, K, base + g.off_fb, fb_ids, fb_sc, st);
-        if (rc != QREC_OK) return rc;
+        const int n_utiles = (n + 63) / 64;
+        int splits = (4096 + n_utiles - 1) / n_utiles;
+        int per_wave = (g.n_item_tiles + splits - 1) / splits;
+        if (per_wave < 8) per_wave = g.n_item_tiles < 8 ? g.n_item_tiles : 8;
+        const int waves_per_utile = (g.n_item_tiles + per_wave - 1) / per_wave;
+        hipLaunchKernelGGL(score_kernel_f32, dim3((unsigned)n_utiles, (unsigned)((waves_per_utile + 3) / 4)), dim3(256), 0, st, U, V, ld,
+                           n_items, fb_users, n, 64, per_wave, fb_block, 1, panel);
+        QREC_LAUNCH_CHECK();
+        if (rated_indptr) {
+            hipLaunchKernelGGL(mask_kernel<float>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, fb_users, n, rated_indptr, rated_sorted,
+                               64, fb_block, 32, 1, panel);
+            QREC_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL((exact_wave_kernel<float, true>), dim3((unsigned)n), dim3(64), 0, st, fb_block,         // fused route: K + 1 <= 64
+                           n_items, 64, K, (const int32_t *)nullptr, (const int32_t *)nullptr, 1 << 30, fb_ids, fb_sc, panel);
+        QREC_LAUNCH_CHECK();
         hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n * K + 255) / 256)), dim3(256), 0, st, flagged_list, off, n, K, fb_ids, fb_sc,
                            ids_out, scores_out);
         QREC_LAUNCH_CHECK();
