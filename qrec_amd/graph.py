@@ -102,7 +102,7 @@ class SpmmPlan:
     """Device-resident CSR plus its segment decomposition (include/qrec_hip.h, qrec_spmm_csr)."""
 
     def __init__(self, indptr: np.ndarray, indices: np.ndarray, values: np.ndarray, ld: int, seg_len: int = 128,
-                 split_row: int | None = None, chunks: int | None = None):
+                 split_row: int | None = None, chunks: int | None = None, row_chunk: np.ndarray | None = None):
         """``split_row`` (bipartite joint adjacency: the number of users): rows below it only gather operand rows
         at or above it and vice versa, so the two kinds of rows are dealt to different XCDs -- workgroups go round-robin
         over the 8 XCDs, each with its own 4 MiB L2, and the kernel is bound by L2 misses: an XCD that only
@@ -111,7 +111,9 @@ class SpmmPlan:
         the order of a spectral key (``spectral_row_key``: rows of one community end up next to each other) and cut
         into that many runs of equal non-zeros, each run on XCDs of its own -- on a graph with community structure an
         XCD then gathers mostly its own communities' operand rows (measured: -20 % on a planted-community graph,
-        nothing lost on a structureless one).  Only the order of the segment list changes: same results."""
+        nothing lost on a structureless one).  Only the order of the segment list changes: same results.
+        ``row_chunk``: the row -> run map of another plan over the same nodes (``plan.row_chunk``): per-epoch sub-graphs
+        (SGL, BUIR) reuse the full graph's map instead of paying the 0.3 s of power iterations for every new plan."""
         n_rows = indptr.size - 1
         nnz_row = np.diff(indptr)
         n_seg_row = np.maximum(1, -(-nnz_row // seg_len)).astype(np.int64)     # ceil, >=1 (empty rows write zeros)
@@ -129,14 +131,19 @@ class SpmmPlan:
         # longest segments first: the heavy work starts early, the tail is made of short rows
         order = np.argsort(-seg_len_arr, kind="stable")
         bipartite = split_row is not None and 0 < split_row < n_rows
+        if row_chunk is not None and (not bipartite or row_chunk.size != n_rows):
+            raise ValueError("SpmmPlan: row_chunk needs split_row and one entry per row")
         if chunks is None:
-            chunks = int(os.environ.get("QREC_SPMM_CHUNKS", "4")) if bipartite and indices.size > 0 else 1
+            chunks = (int(row_chunk.max()) + 1 if row_chunk is not None and row_chunk.size else
+                      int(os.environ.get("QREC_SPMM_CHUNKS", "4")) if bipartite and indices.size > 0 else 1)
         if chunks not in (1, 2, 4) or (chunks > 1 and not bipartite):
             raise ValueError(f"SpmmPlan: chunks must be 1, 2 or 4 and needs split_row (got {chunks})")
+        self.row_chunk = None
         if bipartite:
             cls = (seg_row[order] >= split_row).astype(np.int64)
             if chunks > 1:
-                cls = cls * chunks + self._row_chunks(indptr, indices, values, split_row, chunks)[seg_row[order]]
+                self.row_chunk = row_chunk if row_chunk is not None else self._row_chunks(indptr, indices, values, split_row, chunks)
+                cls = cls * chunks + self.row_chunk[seg_row[order]]
             order = order[self._deal_by_xcd(cls, 2 * chunks, 4 * (64 // (ld // 4)))]
         self.n_rows, self.nnz, self.ld, self.chunks = n_rows, int(indices.size), ld, chunks
         self.n_segs, self.n_long = int(seg_row.size), int(long_rows.size)
@@ -738,10 +745,10 @@ class SGLTrainer:
         """adjs*: one (indptr, indices, values) triple, or a list of L of them (random walk)."""
         def plans(adjs):
             if isinstance(adjs, tuple):
-                p = SpmmPlan(adjs[0], adjs[1], adjs[2], self.ld, split_row=self.nu)
+                p = SpmmPlan(adjs[0], adjs[1], adjs[2], self.ld, split_row=self.nu, row_chunk=self.main_plan.row_chunk)
                 return [p] * self.L
             assert len(adjs) == self.L
-            return [SpmmPlan(a[0], a[1], a[2], self.ld, split_row=self.nu) for a in adjs]
+            return [SpmmPlan(a[0], a[1], a[2], self.ld, split_row=self.nu, row_chunk=self.main_plan.row_chunk) for a in adjs]
         self.plans = [plans(adjs1), plans(adjs2)]
 
     def _view_plans(self, v):
@@ -854,8 +861,10 @@ class BUIRTrainer:
 
     def set_subgraphs(self, adj_o, adj_t):
         """this epoch's two normalized sub-graph adjacencies (CSR triples), BUIR.py:139-146"""
-        self.plan_o = SpmmPlan(adj_o[0], adj_o[1], adj_o[2], self.ld, split_row=self.nu)
-        self.plan_t = SpmmPlan(adj_t[0], adj_t[1], adj_t[2], self.ld, split_row=self.nu)
+        # the row -> XCD-run map is computed on the first sub-graph and kept: every later epoch's sub-graphs are draws from the same graph
+        self.plan_o = SpmmPlan(adj_o[0], adj_o[1], adj_o[2], self.ld, split_row=self.nu, row_chunk=getattr(self, "_row_chunk", None))
+        self._row_chunk = self.plan_o.row_chunk
+        self.plan_t = SpmmPlan(adj_t[0], adj_t[1], adj_t[2], self.ld, split_row=self.nu, row_chunk=self._row_chunk)
 
     def _mean_sum(self, plan, X, S, stream=None, last_rows=None):
         """S = X + A X + ... + A^L X (the mean's 1/(L+1) is applied where S is used)"""
@@ -996,8 +1005,14 @@ class _View:
 
     def set_matrix(self, M, split_row=None):
         """M: scipy CSR (rows x rows); ``split_row``: see SpmmPlan (joint user-item graphs)"""
-        self.plan = SpmmPlan(*_csr_triple(M), self.ld, split_row=split_row)
-        self.planT = self.plan if (abs(M - M.T)).nnz == 0 else SpmmPlan(*_csr_triple(M.T), self.ld, split_row=split_row)
+        # the row -> XCD-run map of the first matrix is kept for later ones of the same shape (per-epoch perturbed graphs)
+        cached = getattr(self, "_row_chunk", None)
+        if cached is not None and (split_row is None or cached[0] != (M.shape[0], split_row)):
+            cached = None
+        self.plan = SpmmPlan(*_csr_triple(M), self.ld, split_row=split_row, row_chunk=None if cached is None else cached[1])
+        if split_row is not None and self.plan.row_chunk is not None:
+            self._row_chunk = ((M.shape[0], split_row), self.plan.row_chunk)
+        self.planT = self.plan if (abs(M - M.T)).nnz == 0 else SpmmPlan(*_csr_triple(M.T), self.ld, split_row=split_row, row_chunk=self.plan.row_chunk)
 
     def forward(self, X0, stream=None, last_rows=None):
         """``last_rows`` (row bitmap, training): the last layer is only formed at those rows -- S is read at the batch's
