@@ -335,11 +335,13 @@ int qrec_ngcf_dense_fwd(const float *d_E, const float *d_side, const float *d_W1
 /* In place on d_pre_gate (in: pre, out: backward gate): nxt = dropout(leaky_relu(pre, 0.2), keep)
  * (NGCF.py:32-38; keep = 1 for the inference graph; d_mask = injected 0/1 keep decisions or NULL
  * for device Philox draws), z = l2_normalize(nxt) written to columns [col_off, col_off+d) of the
- * wide table (the concat of NGCF.py:42), 1/|nxt| to d_inv_norm.                          */
+ * wide table (the concat of NGCF.py:42), 1/|nxt| to d_inv_norm.  philox_row0: row r of these tables is row
+ * philox_row0 + r of the whole model (a rank's block of row-partitioned tables): the Philox draws are keyed by that row,
+ * so a partitioned run drops the same entries as the single-GPU run.                      */
 int qrec_ngcf_activate(float *d_pre_gate, int64_t n_rows, int32_t d, int32_t ld, float keep, const float *d_mask,
                        uint64_t seed, uint64_t stream_id, float *d_next, float *d_wide, int32_t wide_ld,
                        int32_t col_off, float *d_inv_norm, const int32_t *d_row_ids, const int32_t *d_n_row_ids,
-                       int32_t max_row_ids, void *stream);
+                       int32_t max_row_ids, int64_t philox_row0, void *stream);
 /* Backward of one layer: dnxt = dE_next (may be NULL) + normalize_bwd(dWide block); dpre = dnxt*gate;
  * dside = dpre W1^T + (dpre W2^T)*E ; dE = dpre W1^T + (dpre W2^T)*side (caller adds A^T dside);
  * gW1 = (side+E)^T dpre, gW2 = (E*side)^T dpre (deterministic two-stage reduction over nodes).

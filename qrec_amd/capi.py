@@ -89,7 +89,7 @@ _SIGNATURES = {
     "qrec_ngcf_dense_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp],
     "qrec_compact_marked_rows": [_vp, _i64, _vp, _vp, _i32, _vp],
     "qrec_mark_compact_batch_rows": [_vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _i32, _vp],
-    "qrec_ngcf_activate": [_vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp],
+    "qrec_ngcf_activate": [_vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _vp],
     "qrec_ngcf_layer_bwd": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "qrec_ngcf_wgrad_partial_bytes": [_i64, _i32, _vp],
     "qrec_copy_cols": [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _i32, _vp],
@@ -822,10 +822,10 @@ def ngcf_dense_fwd(d_E, d_side, d_W1, d_W2, n_rows: int, ld: int, d_pre, stream=
 
 
 def ngcf_activate(d_pre_gate, n_rows: int, d: int, ld: int, keep: float, d_mask, seed: int, stream_id: int, d_next,
-                  d_wide, wide_ld: int, col_off: int, d_inv_norm, stream=None, rows: RowSubset | None = None):
+                  d_wide, wide_ld: int, col_off: int, d_inv_norm, stream=None, rows: RowSubset | None = None, philox_row0: int = 0):
     _check(load().qrec_ngcf_activate(_dp(d_pre_gate), n_rows, d, ld, keep, _dp(d_mask), seed & (2**64 - 1),
                                      stream_id & (2**64 - 1), _dp(d_next), _dp(d_wide), wide_ld, col_off,
-                                     _dp(d_inv_norm), *_subset(rows), _sh(stream)))
+                                     _dp(d_inv_norm), *_subset(rows), philox_row0, _sh(stream)))
 
 
 def ngcf_layer_bwd(d_dE_next, d_dWide, d_wide, wide_ld: int, col_off: int, d_inv_norm, d_gate, d_E, d_side, d_W1, d_W2,

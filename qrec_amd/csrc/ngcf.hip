@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void activate_rows_kernel(float *__restrict__ 
                                                             const float *__restrict__ mask, uint64_t seed, uint64_t stream_id,
                                                             float *__restrict__ nxt, float *__restrict__ out, int out_ld,
                                                             int out_off, float *__restrict__ inv_norm,
-                                                            const int32_t *__restrict__ row_ids, const int32_t *__restrict__ n_ids) {
+                                                            const int32_t *__restrict__ row_ids, const int32_t *__restrict__ n_ids,
+                                                            int64_t philox_row0) {
     constexpr int GPW = kWave / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
     const int64_t gid = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
@@ -126,7 +127,8 @@ __global__ __launch_bounds__(256) void activate_rows_kernel(float *__restrict__ 
                 u = *reinterpret_cast<const f32x4 *>(mask + off);       // injected 0/1 keep decisions
                 fac = u / keep;
             } else {
-                uint32_t c[4] = {(uint32_t)row, (uint32_t)(row >> 32) ^ ((uint32_t)r << 8), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+                const int64_t grow = row + philox_row0;      // the table row this block row stands for (row-partitioned tables)
+                uint32_t c[4] = {(uint32_t)grow, (uint32_t)(grow >> 32) ^ ((uint32_t)r << 8), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
                 philox10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
                 // tf.nn.dropout: keep iff uniform >= 1 - keep_prob
                 fac.x = ((float)(c[0] >> 8) * 0x1p-24f >= 1.f - keep) ? 1.f / keep : 0.f;
@@ -765,7 +767,7 @@ int qrec_ngcf_dense_fwd(const float *d_E, const float *d_side, const float *d_W1
 int qrec_ngcf_activate(float *d_pre_gate, int64_t n_rows, int32_t d, int32_t ld, float keep, const float *d_mask,
                        uint64_t seed, uint64_t stream_id, float *d_next, float *d_wide, int32_t wide_ld,
                        int32_t col_off, float *d_inv_norm, const int32_t *d_row_ids, const int32_t *d_n_row_ids,
-                       int32_t max_row_ids, void *stream) {
+                       int32_t max_row_ids, int64_t philox_row0, void *stream) {
     QREC_REQUIRE(d_pre_gate && d_next && d_wide && d_inv_norm && n_rows >= 0 && d >= 1 && ld >= d && keep > 0.f && keep <= 1.f,
                  "qrec_ngcf_activate: bad argument");
     QREC_REQUIRE(col_off >= 0 && col_off + d <= wide_ld, "qrec_ngcf_activate: column block outside the wide table");
@@ -777,7 +779,7 @@ int qrec_ngcf_activate(float *d_pre_gate, int64_t n_rows, int32_t d, int32_t ld,
 #define QREC_ACT(LPR)                                                                                              \
     blocks = (work_rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)); if (blocks > 2048) blocks = 2048;                  \
     hipLaunchKernelGGL((activate_rows_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, d_pre_gate, n_rows, d, keep, \
-                       d_mask, seed, stream_id, d_next, d_wide, wide_ld, col_off, d_inv_norm, d_row_ids, d_n_row_ids)
+                       d_mask, seed, stream_id, d_next, d_wide, wide_ld, col_off, d_inv_norm, d_row_ids, d_n_row_ids, philox_row0)
     switch (ld) {
         case 32: QREC_ACT(8); break;
         case 64: QREC_ACT(16); break;

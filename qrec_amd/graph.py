@@ -713,6 +713,126 @@ class NGCFTrainer:
         return E[:self.nu].copy(), E[self.nu:].copy(), [[w.numpy()[:self.d, :self.d].copy() for w in pair] for pair in self.W]
 
 
+class RowPartitionedNGCFTrainer:
+    """NGCF with every node table ROW-PARTITIONED over the ranks (BASELINE config #5: "row-shard the tables,
+    all-reduce for the dense layers").  Rank r owns rows [lo, hi) of E_0 and its Adam slots, of the adjacency, and of every
+    per-layer table (side, gate, E_k, 1/|.|); the four d x d weights and their Adam slots are replicated.  One step at
+    the reference's batch size, the same step as ``NGCFTrainer``:
+
+        forward   per layer: all-gather of the E_k blocks -> side = the rank's rows of A_hat E_k -> the dense product and
+                  the activation on the rank's rows (dropout keyed by the TABLE row, so the same entries drop as on one GPU);
+                  the normalised block z_k is all-gathered into every rank's copy of the wide table [E_0 | z_1 | z_2];
+        loss      every rank evaluates the whole batch on its copy (B rows: ~2 % of a step) and keeps its rows of the gradient;
+        backward  per layer on the rank's rows: dpre, the two MFMA products, the weight gradients summed over the rank's rows;
+                  dE += A_hat dside is again all-gather + the rank's rows (A_hat is symmetric);
+        update    ONE all-reduce of the four weight gradients ("all-reduce for the dense layers"), Adam on the replicated
+                  weights (identical on every rank) and on the rank's rows of E_0.
+
+    Per step and rank: 2L all-gathers of N x ld floats for the propagation, L for the z blocks (17.8 MB each at the
+    Yelp2018 shape) and a 64 KB all-reduce.  No rank holds more than its rows of the parameters and per-layer tables;
+    the gathered operand and the wide table are transients of the step."""
+
+    KEEP = 0.9
+    N_LAYERS = 2
+
+    def __init__(self, comm, U0, V0, W, adj, lr: float, reg: float, loss_eps: float = 1e-7, seed: int = 0):
+        from .dist import RowPartition
+        self.comm = comm
+        self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
+        self.n = self.nu + self.ni
+        if 3 * self.d > 256:
+            raise ValueError("NGCF on the device supports embedding sizes up to 85 (3d <= 256)")
+        self.ld = padded_ld(self.d, np.float32)
+        self.wide_d, self.wide_ld = 3 * self.d, padded_ld(3 * self.d, np.float32)
+        self.lr, self.reg, self.loss_eps, self.seed = lr, reg, loss_eps, seed
+        rp = self.rp = RowPartition(comm, self.n, self.ld)
+        lo, hi, pad = rp.lo, rp.hi, rp.rows_pad
+        indptr, indices, values = adj
+        blk_ptr = (indptr[lo:hi + 1] - indptr[lo]).astype(np.int64)
+        blk_ptr = np.concatenate([blk_ptr, np.full(pad - (hi - lo), blk_ptr[-1] if hi > lo else 0, np.int64)])   # pad rows: empty
+        sel = slice(int(indptr[lo]), int(indptr[hi]))
+        self.plan = SpmmPlan(blk_ptr, indices[sel], values[sel], self.ld)     # rows = this rank's block, columns global
+        E0 = np.zeros((self.n, self.ld), np.float32)
+        E0[:self.nu, :self.d] = U0; E0[self.nu:, :self.d] = V0
+        blk = np.zeros((pad, self.ld), np.float32); blk[:hi - lo] = E0[lo:hi]
+        zb = lambda: DeviceBuffer.zeros((pad, self.ld), np.float32)
+        self.E = [DeviceBuffer.from_numpy(blk), zb(), zb()]
+        self.side = [zb(), zb()]; self.gate = [zb(), zb()]; self.z = [zb(), zb()]
+        self.inv = [DeviceBuffer.zeros(pad, np.float32), DeviceBuffer.zeros(pad, np.float32)]
+        self.dpre, self.dside, self.dEa, self.dEb = zb(), zb(), zb(), zb()
+        rows_full = rp.world * pad
+        self.X_full = DeviceBuffer.zeros((rows_full, self.ld), np.float32)
+        self.All_full = DeviceBuffer.zeros((rows_full, self.wide_ld), np.float32)
+        self.dAll_full = DeviceBuffer.zeros((rows_full, self.wide_ld), np.float32)
+        ll = self.ld * self.ld
+        padw = lambda w: np.pad(np.asarray(w, np.float32), ((0, self.ld - self.d), (0, self.ld - self.d)))
+        self.W_all = DeviceBuffer.from_numpy(np.stack([padw(w) for pair in W for w in pair]))
+        self.gW_all = DeviceBuffer.zeros((4, self.ld, self.ld), np.float32)
+        self.W = [[capi.DeviceSlice(self.W_all, (2 * k + t) * ll, (self.ld, self.ld)) for t in range(2)] for k in range(2)]
+        self.gW = [[capi.DeviceSlice(self.gW_all, (2 * k + t) * ll, (self.ld, self.ld)) for t in range(2)] for k in range(2)]
+        self.partial = DeviceBuffer(capi.ngcf_wgrad_partial_bytes(pad, self.ld), np.uint8)
+        self.optE, self.optW = _Adam(self.E[0], lr), _Adam(self.W_all, lr)
+        self.d_loss = DeviceBuffer.zeros(1, np.float64)
+        self.step_no = 0
+
+    def forward(self, training: bool, masks=None, stream=None):
+        """E_1, E_2, side, gate, inv on the rank's rows; the wide table All = [E_0 | z_1 | z_2] whole on every rank.
+        ``masks``: per layer, THIS RANK'S rows [pad][ld] of the injected keep decisions (tests)."""
+        rp, d, ld, pad = self.rp, self.d, self.ld, self.rp.rows_pad
+        rows_full = rp.world * pad
+        for k in range(self.N_LAYERS):
+            rp.gather_operand(self.E[k], self.X_full, stream)
+            if k == 0:      # the ego block of the concat: the gathered E_0
+                capi.copy_cols(self.All_full, self.wide_ld, self.X_full, ld, 0, rows_full, d, False, stream)
+            capi.spmm_csr(self.plan, self.X_full, self.side[k], ld, stream=stream)
+            capi.ngcf_dense_fwd(self.E[k], self.side[k], self.W[k][0], self.W[k][1], pad, ld, self.gate[k], stream)
+            capi.ngcf_activate(self.gate[k], pad, d, ld, self.KEEP if training else 1.0, None if masks is None else masks[k],
+                               self.seed, self.step_no * 8 + k, self.E[k + 1], self.z[k], ld, 0, self.inv[k], stream,
+                               philox_row0=rp.lo)
+            rp.gather_operand(self.z[k], self.X_full, stream)
+            capi.copy_cols(self.All_full.ptr + 4 * (k + 1) * d, self.wide_ld, self.X_full, ld, 0, rows_full, d, False, stream)
+
+    def train_step_async(self, d_u, d_i, d_j, B: int, masks=None, stream=None):
+        rp, d, ld, pad = self.rp, self.d, self.ld, self.rp.rows_pad
+        rows_full = rp.world * pad
+        self.forward(True, masks, stream)
+        self.dAll_full.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
+        if B:
+            capi.bpr_batch_loss_grad(self.All_full, 1.0, self.nu, rows_full, self.wide_ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
+                                     self.dAll_full, self.d_loss, stream)
+        mine = 4 * rp.lo * self.wide_ld                 # byte offset of this rank's rows in the wide tables
+        dnext = None
+        for k in (1, 0):
+            dE = self.dEa if k == 1 else self.dEb
+            capi.ngcf_layer_bwd(dnext, self.dAll_full.ptr + mine, self.All_full.ptr + mine, self.wide_ld, (k + 1) * d, self.inv[k],
+                                self.gate[k], self.E[k], self.side[k], self.W[k][0], self.W[k][1], pad, d, ld, self.dpre, self.dside, dE,
+                                self.partial, self.gW[k][0], self.gW[k][1], stream)
+            rp.gather_operand(self.dside, self.X_full, stream)           # dE += (A_hat dside)[lo:hi]
+            capi.spmm_csr(self.plan, self.X_full, dE, ld, d_addend=dE, addend_scale=1.0, stream=stream)
+            dnext = dE
+        capi.copy_cols(dnext, ld, self.dAll_full.ptr + mine, self.wide_ld, 0, pad, d, True, stream)   # + ego block of the concat
+        self.comm.allreduce(self.gW_all, 4 * ld * ld, capi.F32, stream)  # each rank summed its own rows: the dense layers' all-reduce
+        self.optE.step(dnext, stream=stream)
+        self.optW.step(self.gW_all, stream=stream)
+        self.step_no += 1
+
+    def loss(self, stream=None) -> float:
+        return float(self.d_loss.numpy(stream)[0])
+
+    def inference_embeddings(self):
+        """3d-wide (U, V) of the inference graph (isTraining = 0, NGCF.py:65-69), whole, on every rank"""
+        self.forward(False)
+        A = self.All_full.numpy()[:self.n, :self.wide_d]
+        return np.ascontiguousarray(A[:self.nu]), np.ascontiguousarray(A[self.nu:])
+
+    def block(self, buf) -> np.ndarray:
+        """this rank's rows of a block buffer (pad rows and pad columns dropped)"""
+        return buf.numpy()[:self.rp.hi - self.rp.lo, :self.d].copy()
+
+    def weights(self):
+        return [[w.numpy()[:self.d, :self.d].copy() for w in pair] for pair in self.W]
+
+
 class SGLTrainer:
     """model/ranking/SGL.py on the device: the recommendation view (LightGCN over the full adjacency) plus
     two views over per-epoch augmented sub-graphs, BPR on the main view, InfoNCE (users and items of the

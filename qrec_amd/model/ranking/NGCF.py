@@ -23,6 +23,17 @@ class NGCF(GraphRecommender):
         d = self.emb_size
         self.n_layers = 2                                                   # NGCF.py:19
         self.weights = [[xavier_uniform((d, d)), xavier_uniform((d, d))] for _ in range(self.n_layers)]   # W_k_1, W_k_2
+        dp = self.data_parallel()
+        self.row_partitioned = dp is not None and os.environ.get("QREC_GRAPH_DIST", "batch") == "rows"
+        if self.row_partitioned:
+            # one process per GPU, QREC_GRAPH_DIST=rows: the reference's own batch size, every node table row-partitioned over
+            # the ranks, the d x d weights replicated and their gradients all-reduced (qrec_amd/graph.py); the default is the
+            # batch-sharded scheme (dist.BatchParallel)
+            from ...graph import RowPartitionedNGCFTrainer
+            self.trainer = RowPartitionedNGCFTrainer(dp.comm, self.user_embeddings, self.item_embeddings, self.weights,
+                                                     self.create_joint_sparse_adjaceny(), self.lRate, self.regU,
+                                                     seed=int(os.environ.get("QREC_SEED", "0")))
+            return
         self.trainer = NGCFTrainer(self.user_embeddings, self.item_embeddings, self.weights,
                                    self.create_joint_sparse_adjaceny(), self.lRate, self.regU,
                                    seed=int(os.environ.get("QREC_SEED", "0")))
@@ -30,7 +41,10 @@ class NGCF(GraphRecommender):
     def trainModel(self):
         quiet = os.environ.get("QREC_QUIET") == "1"
         tr = self.trainer
-        dp = tr.dp = self.data_parallel()              # one process per GPU: a step = batch_size x world rows, this rank's share
+        if self.row_partitioned:
+            dp = None                                  # every rank takes the whole step; the node tables are what is split
+        else:
+            dp = tr.dp = self.data_parallel()          # one process per GPU: a step = batch_size x world rows, this rank's share
         step_rows = self.batch_size * (dp.world if dp else 1)
         for epoch, (n_rows, d_u, d_i, d_j) in enumerate(self.iter_epoch_device_samples(self.maxEpoch)):     # base/deepRecommender.py:29-52
             for n, s in enumerate(range(0, n_rows, step_rows)):

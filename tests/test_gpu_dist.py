@@ -197,6 +197,75 @@ def _rank_triplets(indptr, ind, lo, hi, n_items, seed, schedule):
     return np.ascontiguousarray(u), np.ascontiguousarray(li), np.ascontiguousarray(j)
 
 
+@pytest.mark.parametrize("world,dim", [(2, 64), (3, 50), (1, 8)])
+def test_row_partitioned_ngcf_step_equals_the_single_gpu_step(world, dim):
+    """RowPartitionedNGCFTrainer with G logical ranks: every rank holds its rows of E_0, the Adam slots, the adjacency and
+    the per-layer tables; weights replicated, their gradients all-reduced.  Same batch, same injected dropout decisions,
+    same step as NGCFTrainer on one GPU: losses, the rank's rows of E_0, the four weights and the inference embeddings
+    agree to fp32 summation order (atomics of the batch gradient, the slab order of the weight gradients)."""
+    from qrec_amd.graph import NGCFTrainer, RowPartitionedNGCFTrainer, joint_norm_adjacency
+    from qrec_amd.engine import padded_ld
+    d = make_dataset("small")
+    nu, ni = d["n_users"], d["n_items"]
+    N = nu + ni
+    adj = joint_norm_adjacency(nu, ni, d["train_u"], d["train_i"])
+    rng = np.random.default_rng(world + dim)
+    U0 = (rng.standard_normal((nu, dim)) * 0.1).astype(np.float32); V0 = (rng.standard_normal((ni, dim)) * 0.1).astype(np.float32)
+    lim = np.sqrt(6.0 / (2 * dim))
+    W = [[rng.uniform(-lim, lim, (dim, dim)).astype(np.float32) for _ in range(2)] for _ in range(2)]
+    B, ld = 512, padded_ld(dim, np.float32)
+    steps = []
+    for _ in range(2):
+        sel = rng.integers(0, d["train_u"].size, B)
+        steps.append((d["train_u"][sel].astype(np.int32), d["train_i"][sel].astype(np.int32), rng.integers(0, ni, B).astype(np.int32),
+                      [np.pad((rng.random((N, dim)) < 0.9).astype(np.float32), ((0, 0), (0, ld - dim))) for _ in range(2)]))
+    one = NGCFTrainer(U0, V0, W, adj, lr=0.002, reg=1e-3)
+    losses_one = []
+    for u, i, j, masks in steps:
+        one.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, masks=[DB.from_numpy(m) for m in masks])
+        losses_one.append(one.loss())
+    U1, V1, W1 = one.parameters()
+    E_one = np.concatenate([U1, V1])
+    Ui, Vi = one.inference_embeddings()
+    group = _Group(world)
+    result, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            capi.init(0)
+            tr = RowPartitionedNGCFTrainer(ThreadComm(group, rank), U0, V0, W, adj, lr=0.002, reg=1e-3)
+            lo, hi, pad = tr.rp.lo, tr.rp.hi, tr.rp.rows_pad
+            losses = []
+            for u, i, j, masks in steps:
+                mine = [np.zeros((pad, ld), np.float32) for _ in masks]
+                for m_blk, m in zip(mine, masks):
+                    m_blk[:hi - lo] = m[lo:hi]
+                tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, masks=[DB.from_numpy(m) for m in mine])
+                losses.append(tr.loss())
+            inf = tr.inference_embeddings()
+            capi.device_sync()
+            result[rank] = (lo, hi, tr.block(tr.E[0]), tr.weights(), losses, inf)
+        except Exception as e:      # noqa: BLE001
+            errors.append(e); group.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    covered = 0
+    for lo, hi, E_blk, Wr, losses, (Ur, Vr) in result:
+        np.testing.assert_allclose(losses, losses_one, rtol=2e-5)
+        assert rel_err(E_blk, E_one[lo:hi]) < 5e-5
+        for k in range(2):
+            for t in range(2):
+                assert rel_err(Wr[k][t], W1[k][t]) < 5e-5
+        assert rel_err(Ur, Ui) < 1e-4 and rel_err(Vr, Vi) < 1e-4
+        covered += hi - lo
+    assert covered == N and not np.allclose(E_one[:nu], U0)
+
+
 @pytest.mark.parametrize("world,n_batches,dim,same_users", [(2, 3, 16, False), (3, 2, 64, False), (1, 2, 16, False), (2, 4, 64, True)])
 def test_sharded_item_table_with_logical_ranks_equals_the_definition(world, n_batches, dim, same_users):
     """ShardedItemExchange + the real kernels, G logical ranks on one device.  The SGD kernel runs with ONE group, where

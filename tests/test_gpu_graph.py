@@ -799,11 +799,13 @@ def test_graph_models_data_parallel_two_ranks_equal_one_rank_with_double_batch(n
     assert len(os.listdir(two / "results")) == len(os.listdir(one / "results"))      # rank 0 alone wrote the result files
 
 
-def test_lightgcn_class_row_partitioned_two_ranks_equal_one_rank_at_the_same_batch_size(tmp_path):
-    """QREC_GRAPH_DIST=rows: the drop-in LightGCN class on two ranks with the propagation row-
-    partitioned -- the reference's own batch size on every rank, each rank's SpMM over its rows only -- must train what
-    one rank trains with that batch size (not 2x the batch, as the batch-sharded scheme does): same losses, same final
-    embeddings and measures up to fp32 summation order."""
+@pytest.mark.parametrize("model,port", [("LightGCN", 29553), ("NGCF", 29557)])
+def test_graph_class_row_partitioned_two_ranks_equal_one_rank_at_the_same_batch_size(tmp_path, model, port):
+    """QREC_GRAPH_DIST=rows: the drop-in LightGCN / NGCF class on two ranks with the node tables row-
+    partitioned -- the reference's own batch size on every rank, each rank's SpMM (and, NGCF, dense layers) over its rows
+    only, NGCF's weight gradients all-reduced -- must train what one rank trains with that batch size (not 2x the batch, as
+    the batch-sharded scheme does): same losses, same final embeddings and measures up to fp32 summation order.  NGCF's
+    device-drawn dropout is keyed by the table row, so both runs drop the same entries."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     worker = os.path.join(root, "tests", "graph_dp_worker.py")
@@ -811,20 +813,21 @@ def test_lightgcn_class_row_partitioned_two_ranks_equal_one_rank_at_the_same_bat
     one.mkdir(); two.mkdir()
     env = dict(os.environ, QREC_SEED="11", QREC_DIST_TEST_ONE_DEVICE="1", QREC_GRAPH_DIST="rows")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
-    r1 = subprocess.run([sys.executable, worker, "LightGCN", "1024", str(one)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    r1 = subprocess.run([sys.executable, worker, model, "1024", str(one)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-3000:]
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                         "--master-port", "29553", worker, "LightGCN", "1024", str(two)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+                         "--master-port", str(port), worker, model, "1024", str(two)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-3000:]
     a, b0, b1 = np.load(one / "rank0.npz"), np.load(two / "rank0.npz"), np.load(two / "rank1.npz")
     for k in ("U", "V", "measure"):
         assert np.array_equal(b0[k], b1[k]), k                      # both ranks gathered the same tables, same measures
     np.testing.assert_allclose(b0["losses"], b1["losses"], rtol=1e-6)   # every rank sums the batch loss itself (float atomics: own order)
     assert a["losses"].size == b0["losses"].size > 0
-    np.testing.assert_allclose(b0["losses"], a["losses"], rtol=1e-5)
-    assert rel_err(b0["U"], a["U"]) < 2e-5 and rel_err(b0["V"], a["V"]) < 2e-5
+    np.testing.assert_allclose(b0["losses"], a["losses"], rtol=1e-5 if model == "LightGCN" else 1e-4)
+    tol = 2e-5 if model == "LightGCN" else 1e-3        # NGCF: ~70 Adam steps on weights AND tables carry the summation-order differences along
+    assert rel_err(b0["U"], a["U"]) < tol and rel_err(b0["V"], a["V"]) < tol
     assert not np.array_equal(b0["E"], b1["E"]) and b0["E"].shape[0] + b1["E"].shape[0] >= a["E"].shape[0]   # each rank holds ITS rows
-    np.testing.assert_allclose(b0["measure"], a["measure"], atol=1e-4)
+    np.testing.assert_allclose(b0["measure"], a["measure"], atol=1e-4 if model == "LightGCN" else 2e-3)
 
 
 # ---------------------------------------------------------------------------------------------
