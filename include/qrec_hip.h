@@ -285,15 +285,17 @@ int qrec_adam_step(float *d_theta, float *d_m, float *d_v, const float *d_grad, 
  * tf.random.uniform, not TF's stream.                                                    */
 int qrec_perturb_rows(float *d_emb, const float *d_src, int64_t n_rows, int32_t d, int32_t ld, float eps,
                       const float *d_noise, uint64_t seed, uint64_t stream_id, float *d_accum, const int32_t *d_row_ids,
-                      const int32_t *d_n_row_ids, int32_t max_row_ids, void *stream);
+                      const int32_t *d_n_row_ids, int32_t max_row_ids, int64_t philox_row0, void *stream);
 /* The FIRST layer of SimGCL's three encoders in one pass (they share the product A E, SimGCL.py:23-36): emb_v = the
  * perturbed d_src (v = 1, 2: own noise / Philox stream each), and the three layer sums START here -- sum_v = emb_v,
  * src_sum = d_src (assigned, not accumulated: no zero-fill of the sums).  Row subset as for the NGCF calls below
- * (d_row_ids may be NULL): the last layer of a training step is read at the batch's rows only. */
+ * (d_row_ids may be NULL): the last layer of a training step is read at the batch's rows only.  philox_row0 (both
+ * calls): row r of these tables is row philox_row0 + r of the whole model (a rank's block of row-partitioned tables);
+ * the Philox draws are keyed by that row. */
 int qrec_perturb_two_views(const float *d_src, float *d_emb1, float *d_emb2, int64_t n_rows, int32_t d, int32_t ld, float eps,
                            const float *d_noise1, const float *d_noise2, uint64_t seed, uint64_t stream_id1, uint64_t stream_id2,
                            float *d_sum1, float *d_sum2, float *d_src_sum, const int32_t *d_row_ids, const int32_t *d_n_row_ids,
-                           int32_t max_row_ids, void *stream);
+                           int32_t max_row_ids, int64_t philox_row0, void *stream);
 
 /* One side (users or items) of SimGCL.calc_cl_loss (SimGCL.py:60-90) with its gradients.
  * x1 = S1[rows]/div, x2 = S2[rows]/div (the two perturbed views' rows of the batch's UNIQUE

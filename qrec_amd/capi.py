@@ -68,8 +68,8 @@ _SIGNATURES = {
     "qrec_mark_batch_rows": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "qrec_bpr_batch_loss_grad": [_vp, _f32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
     "qrec_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
-    "qrec_perturb_rows": [_vp, _vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _vp, _i32, _vp],
-    "qrec_perturb_two_views": [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
+    "qrec_perturb_rows": [_vp, _vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _vp, _i32, _i64, _vp],
+    "qrec_perturb_two_views": [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp],
     "qrec_info_nce_workspace_bytes": [_i32, _i32, _vp],
     "qrec_gate_fwd": [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "qrec_gate_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp],
@@ -682,18 +682,18 @@ def adam_step(d_theta, d_m, d_v, d_grad, n_elems: int, grad_scale: float, alpha:
 
 
 def perturb_rows(d_emb, n_rows: int, d: int, ld: int, eps: float, d_noise=None, seed: int = 0, stream_id: int = 0,
-                 d_accum=None, stream=None, d_src=None, rows=None):
+                 d_accum=None, stream=None, d_src=None, rows=None, philox_row0: int = 0):
     _check(load().qrec_perturb_rows(_dp(d_emb), _dp(d_src), n_rows, d, ld, eps, _dp(d_noise), seed & (2**64 - 1),
-                                    stream_id & (2**64 - 1), _dp(d_accum), *_subset(rows), _sh(stream)))
+                                    stream_id & (2**64 - 1), _dp(d_accum), *_subset(rows), philox_row0, _sh(stream)))
 
 
 def perturb_two_views(d_src, d_emb1, d_emb2, n_rows: int, d: int, ld: int, eps: float, d_noise1, d_noise2, seed: int,
-                      stream_id1: int, stream_id2: int, d_sum1, d_sum2, d_src_sum, stream=None, rows=None):
+                      stream_id1: int, stream_id2: int, d_sum1, d_sum2, d_src_sum, stream=None, rows=None, philox_row0: int = 0):
     """first layer of SimGCL's three encoders: both perturbed views of d_src, and the three layer sums START here"""
     m = 2**64 - 1
     _check(load().qrec_perturb_two_views(_dp(d_src), _dp(d_emb1), _dp(d_emb2), n_rows, d, ld, eps, _dp(d_noise1), _dp(d_noise2),
                                          seed & m, stream_id1 & m, stream_id2 & m, _dp(d_sum1), _dp(d_sum2), _dp(d_src_sum),
-                                         *_subset(rows), _sh(stream)))
+                                         *_subset(rows), philox_row0, _sh(stream)))
 
 
 def info_nce_workspace_bytes(n: int, ld: int) -> int:

@@ -47,7 +47,8 @@ struct PerturbViews {
 template <int LPR, int V>
 __global__ __launch_bounds__(256) void perturb_kernel(PerturbViews pv, const float *__restrict__ src, int64_t n_rows,
                                                       int d, float eps, uint64_t seed, int assign, float *__restrict__ src_sum,
-                                                      const int32_t *__restrict__ row_ids, const int32_t *__restrict__ n_ids) {
+                                                      const int32_t *__restrict__ row_ids, const int32_t *__restrict__ n_ids,
+                                                      int64_t philox_row0) {
     constexpr int GPW = kWave / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
     const int64_t gid = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(256) void perturb_kernel(PerturbViews pv, const flo
                 nz = *reinterpret_cast<const f32x4 *>(pv.noise[v] + off);
             } else {
                 const uint64_t sid = pv.stream_id[v];
-                uint32_t c[4] = {(uint32_t)row, (uint32_t)(row >> 32) ^ ((uint32_t)r << 8), (uint32_t)sid, (uint32_t)(sid >> 32)};
+                const int64_t grow = row + philox_row0;      // the table row this block row stands for (row-partitioned tables)
+                uint32_t c[4] = {(uint32_t)grow, (uint32_t)(grow >> 32) ^ ((uint32_t)r << 8), (uint32_t)sid, (uint32_t)(sid >> 32)};
                 philox10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
                 nz.x = (float)(c[0] >> 8) * 0x1p-24f; nz.y = (float)(c[1] >> 8) * 0x1p-24f;
                 nz.z = (float)(c[2] >> 8) * 0x1p-24f; nz.w = (float)(c[3] >> 8) * 0x1p-24f;
@@ -552,14 +554,14 @@ namespace {
 template <int V>
 int launch_perturb(const PerturbViews &pv, const float *d_src, int64_t n_rows, int32_t d, int32_t ld, float eps, uint64_t seed,
                    int assign, float *d_src_sum, const int32_t *d_row_ids, const int32_t *d_n_row_ids, int32_t max_row_ids,
-                   hipStream_t st) {
+                   int64_t philox_row0, hipStream_t st) {
     const int64_t work_rows = d_row_ids ? max_row_ids : n_rows;
     if (work_rows == 0) return QREC_OK;
     int64_t blocks;
 #define QREC_PT(LPR)                                                                                              \
     blocks = (work_rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)); if (blocks > 2048) blocks = 2048;                 \
     hipLaunchKernelGGL((perturb_kernel<LPR, V>), dim3((unsigned)blocks), dim3(256), 0, st, pv, d_src, n_rows, d, eps, seed, \
-                       assign, d_src_sum, d_row_ids, d_n_row_ids)
+                       assign, d_src_sum, d_row_ids, d_n_row_ids, philox_row0)
     switch (ld) {
         case 32: QREC_PT(8); break;
         case 64: QREC_PT(16); break;
@@ -577,21 +579,21 @@ extern "C" {
 
 int qrec_perturb_rows(float *d_emb, const float *d_src, int64_t n_rows, int32_t d, int32_t ld, float eps,
                       const float *d_noise, uint64_t seed, uint64_t stream_id, float *d_accum, const int32_t *d_row_ids,
-                      const int32_t *d_n_row_ids, int32_t max_row_ids, void *stream) {
+                      const int32_t *d_n_row_ids, int32_t max_row_ids, int64_t philox_row0, void *stream) {
     QREC_REQUIRE(d_emb && n_rows >= 0 && d >= 1 && ld >= d, "qrec_perturb_rows: bad argument");
     QREC_REQUIRE(!d_row_ids || (d_n_row_ids && max_row_ids >= 0), "qrec_perturb_rows: a row subset needs its count and a bound");
     PerturbViews pv = {{d_emb, nullptr}, {d_noise, nullptr}, {stream_id, 0}, {d_accum, nullptr}};
-    return launch_perturb<1>(pv, d_src, n_rows, d, ld, eps, seed, 0, nullptr, d_row_ids, d_n_row_ids, max_row_ids, as_stream(stream));
+    return launch_perturb<1>(pv, d_src, n_rows, d, ld, eps, seed, 0, nullptr, d_row_ids, d_n_row_ids, max_row_ids, philox_row0, as_stream(stream));
 }
 
 int qrec_perturb_two_views(const float *d_src, float *d_emb1, float *d_emb2, int64_t n_rows, int32_t d, int32_t ld, float eps,
                            const float *d_noise1, const float *d_noise2, uint64_t seed, uint64_t stream_id1, uint64_t stream_id2,
                            float *d_sum1, float *d_sum2, float *d_src_sum, const int32_t *d_row_ids, const int32_t *d_n_row_ids,
-                           int32_t max_row_ids, void *stream) {
+                           int32_t max_row_ids, int64_t philox_row0, void *stream) {
     QREC_REQUIRE(d_src && d_emb1 && d_emb2 && d_emb1 != d_emb2 && n_rows >= 0 && d >= 1 && ld >= d, "qrec_perturb_two_views: bad argument");
     QREC_REQUIRE(!d_row_ids || (d_n_row_ids && max_row_ids >= 0), "qrec_perturb_two_views: a row subset needs its count and a bound");
     PerturbViews pv = {{d_emb1, d_emb2}, {d_noise1, d_noise2}, {stream_id1, stream_id2}, {d_sum1, d_sum2}};
-    return launch_perturb<2>(pv, d_src, n_rows, d, ld, eps, seed, 1, d_src_sum, d_row_ids, d_n_row_ids, max_row_ids, as_stream(stream));
+    return launch_perturb<2>(pv, d_src, n_rows, d, ld, eps, seed, 1, d_src_sum, d_row_ids, d_n_row_ids, max_row_ids, philox_row0, as_stream(stream));
 }
 
 int qrec_info_nce_workspace_bytes(int32_t n, int32_t ld, int64_t *bytes) {

@@ -574,6 +574,138 @@ class SimGCLTrainer:
         return E[:self.nu, :self.d].copy(), E[self.nu:, :self.d].copy()
 
 
+class RowPartitionedSimGCLTrainer:
+    """SimGCL with every node table ROW-PARTITIONED over the ranks (BASELINE config #5).  Rank r owns rows
+    [lo, hi) of E and its Adam slots, of the adjacency, and of the three encoders' layer outputs and layer sums.  One step
+    at the reference's batch size, the same step as ``SimGCLTrainer``:
+
+        forward   per layer and encoder: all-gather of the operand blocks -> the rank's rows of A_hat X -> (views 1, 2) the
+                  perturbation of those rows, noise keyed by the TABLE row; the first product A_hat E is shared by the three
+                  encoders as on one GPU;
+        loss      the three layer sums are all-gathered; every rank evaluates the batch's BPR term and both InfoNCE terms on
+                  the whole batch (a few thousand rows) and keeps its rows of the gradient;
+        backward  the three encoders share one linear backward operator: W_0 = dOut, W_k = dOut + A_hat W_{k-1}, each product
+                  all-gather + the rank's rows (A_hat symmetric);
+        Adam      on the rank's rows.
+
+    1 + 3 (L - 1) + 3 + L all-gathers of N x ld floats per step (L = 2: nine of 17.8 MB at the Yelp2018 shape)."""
+
+    def __init__(self, comm, U0, V0, adj, n_layers: int, lr: float, reg: float, cl_rate: float, eps: float,
+                 tau: float = 0.2, loss_eps: float = 1e-7, seed: int = 0, max_unique: int = 4096):
+        from .dist import RowPartition
+        self.comm = comm
+        self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
+        self.n = self.nu + self.ni
+        self.ld = padded_ld(self.d, np.float32)
+        self.L, self.lr, self.reg, self.cl_rate, self.eps, self.tau = n_layers, lr, reg, cl_rate, eps, tau
+        self.loss_eps, self.seed = loss_eps, seed
+        rp = self.rp = RowPartition(comm, self.n, self.ld)
+        lo, hi, pad = rp.lo, rp.hi, rp.rows_pad
+        indptr, indices, values = adj
+        blk_ptr = (indptr[lo:hi + 1] - indptr[lo]).astype(np.int64)
+        blk_ptr = np.concatenate([blk_ptr, np.full(pad - (hi - lo), blk_ptr[-1] if hi > lo else 0, np.int64)])   # pad rows: empty
+        sel = slice(int(indptr[lo]), int(indptr[hi]))
+        self.plan = SpmmPlan(blk_ptr, indices[sel], values[sel], self.ld)     # rows = this rank's block, columns global
+        E0 = np.zeros((self.n, self.ld), np.float32)
+        E0[:self.nu, :self.d] = U0; E0[self.nu:, :self.d] = V0
+        blk = np.zeros((pad, self.ld), np.float32); blk[:hi - lo] = E0[lo:hi]
+        self.E = DeviceBuffer.from_numpy(blk)
+        zb = lambda: DeviceBuffer.zeros((pad, self.ld), np.float32)
+        self.m, self.v = zb(), zb()
+        self.Sm, self.S1, self.S2, self.A, self.B = zb(), zb(), zb(), zb(), zb()
+        self.V = [[zb(), zb()], [zb(), zb()]]
+        full = lambda: DeviceBuffer.zeros((rp.world * pad, self.ld), np.float32)
+        self.X_full, self.Sm_full, self.S1_full, self.S2_full, self.dOut_full = full(), full(), full(), full(), full()
+        self.d_loss = DeviceBuffer.zeros(2, np.float64)         # [rec, cl (unscaled)]
+        self.max_unique = max_unique
+        self.ws = DeviceBuffer(capi.info_nce_workspace_bytes(max_unique, self.ld), np.uint8)
+        f = np.float32
+        self.b1, self.b2, self.adam_eps = f(0.9), f(0.999), f(1e-8)
+        self.b1p, self.b2p = self.b1, self.b2
+        self.step_no = 0
+
+    def _product(self, x, y, stream, accum=None, addend=None):
+        """y = the rank's rows of A_hat gather(x) (+ addend); accum += y"""
+        self.rp.gather_operand(x, self.X_full, stream)
+        capi.spmm_csr(self.plan, self.X_full, y, self.ld, d_addend=addend, addend_scale=1.0 if addend is not None else 0.0,
+                      d_accum=accum, stream=stream)
+
+    def _encode_three(self, noises, stream):
+        """``noises``: optional 2L buffers [pad][ld], THIS RANK'S rows of the injected uniforms (tests)"""
+        pad, lo = self.rp.rows_pad, self.rp.lo
+        nz = lambda v, k: None if noises is None else noises[(v - 1) * self.L + k]
+        sid = lambda v, k: (self.step_no * 2 + (v - 1)) * 64 + k
+        sums = [self.Sm, self.S1, self.S2]
+        x = None
+        for k in range(self.L):
+            y0 = self.A if k % 2 == 0 else self.B
+            if k == 0:
+                self._product(self.E, y0, stream)
+                y1, y2 = self.V[0][0], self.V[1][0]
+                capi.perturb_two_views(y0, y1, y2, pad, self.d, self.ld, self.eps, nz(1, 0), nz(2, 0), self.seed, sid(1, 0), sid(2, 0),
+                                       self.S1, self.S2, self.Sm, stream, philox_row0=lo)
+                x = [y0, y1, y2]
+                continue
+            self._product(x[0], y0, stream, accum=self.Sm)
+            for v in (1, 2):
+                yv = self.V[v - 1][k % 2]
+                self._product(x[v], yv, stream)
+                capi.perturb_rows(yv, pad, self.d, self.ld, self.eps, nz(v, k), self.seed, sid(v, k), d_accum=sums[v], stream=stream,
+                                  philox_row0=lo)
+                x[v] = yv
+            x[0] = y0
+
+    def train_step_async(self, d_u, d_i, d_j, B: int, d_uniq_users, n_uu: int, d_uniq_items, n_ui: int, noises=None, stream=None):
+        """as SimGCLTrainer.train_step_async; the row ids are ids of the WHOLE tables"""
+        if max(n_uu, n_ui) > self.max_unique:
+            raise ValueError("more unique rows in the batch than the InfoNCE workspace holds")
+        rp, ld, L = self.rp, self.ld, float(self.L)
+        self._encode_three(noises, stream)
+        for blk, full in ((self.Sm, self.Sm_full), (self.S1, self.S1_full), (self.S2, self.S2_full)):
+            rp.gather_operand(blk, full, stream)
+        self.dOut_full.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
+        rows_full = rp.world * rp.rows_pad
+        if B:
+            capi.bpr_batch_loss_grad(self.Sm_full, L, self.nu, rows_full, ld, d_u, d_i, d_j, B, self.loss_eps, self.reg, self.dOut_full,
+                                     self.d_loss, stream)
+        cl = self.d_loss.ptr + 8
+        capi.info_nce_loss_grad(self.S1_full, self.S2_full, L, d_uniq_users, n_uu, ld, self.tau, self.cl_rate, self.ws, self.dOut_full, cl, stream)
+        capi.info_nce_loss_grad(self.S1_full, self.S2_full, L, d_uniq_items, n_ui, ld, self.tau, self.cl_rate, self.ws, self.dOut_full, cl, stream)
+        dOut_blk = self.dOut_full.ptr + 4 * rp.lo * ld                  # this rank's rows of the output gradient, in place
+        x = dOut_blk
+        for k in range(self.L - 1):
+            y = self.A if k % 2 == 0 else self.B
+            self._product(x, y, stream, addend=dOut_blk)
+            x = y
+        g = self.B if x is self.A else self.A
+        self._product(x, g, stream)
+        f = np.float32
+        alpha = float(f(f(self.lr) * np.sqrt(f(1) - self.b2p, dtype=f) / (f(1) - self.b1p)))
+        capi.adam_step(self.E, self.m, self.v, g, (rp.hi - rp.lo) * ld, 1.0 / L, alpha, float(self.b1), float(self.b2), float(self.adam_eps), stream)
+        self.b1p = f(self.b1p * self.b1); self.b2p = f(self.b2p * self.b2)
+        self.step_no += 1
+
+    def losses(self, stream=None):
+        rec, cl = self.d_loss.numpy(stream)
+        cl *= self.cl_rate
+        return float(rec + cl), float(rec), float(cl)
+
+    def main_embeddings(self):
+        """(U, V) of the clean encoder (SimGCL.py:23-27), whole, on every rank"""
+        x = self.E
+        self.Sm.fill_bytes(0)
+        for k in range(self.L):
+            y = self.A if k % 2 == 0 else self.B
+            self._product(x, y, None, accum=self.Sm)
+            x = y
+        self.rp.gather_operand(self.Sm, self.Sm_full)
+        m = (self.Sm_full.numpy()[:self.n, :self.d] / np.float32(self.L)).astype(np.float32)
+        return np.ascontiguousarray(m[:self.nu]), np.ascontiguousarray(m[self.nu:])
+
+    def block(self, buf) -> np.ndarray:
+        return buf.numpy()[:self.rp.hi - self.rp.lo, :self.d].copy()
+
+
 class _Adam:
     """host-side bookkeeping of one TF-1.14 Adam slot set (fp32 beta powers)"""
 

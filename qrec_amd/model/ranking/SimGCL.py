@@ -36,13 +36,26 @@ class SimGCL(GraphRecommender):
         super().initModel()
         self.user_embeddings = xavier_uniform((self.num_users, self.emb_size))
         self.item_embeddings = xavier_uniform((self.num_items, self.emb_size))
+        dp = self.data_parallel()
+        self.row_partitioned = dp is not None and os.environ.get("QREC_GRAPH_DIST", "batch") == "rows"
+        if self.row_partitioned:
+            # one process per GPU, QREC_GRAPH_DIST=rows: the reference's own batch size, every node table row-partitioned over
+            # the ranks (qrec_amd/graph.py); the default is the batch-sharded scheme (dist.BatchParallel)
+            from ...graph import RowPartitionedSimGCLTrainer
+            self.trainer = RowPartitionedSimGCLTrainer(dp.comm, self.user_embeddings, self.item_embeddings, self.create_joint_sparse_adjaceny(),
+                                                       self.n_layers, self.lRate, self.regU, self.cl_rate, self.eps,
+                                                       seed=int(os.environ.get("QREC_SEED", "0")), max_unique=max(self.batch_size, 64))
+            return
         self.trainer = SimGCLTrainer(self.user_embeddings, self.item_embeddings, self.create_joint_sparse_adjaceny(),
                                      self.n_layers, self.lRate, self.regU, self.cl_rate, self.eps,
                                      seed=int(os.environ.get("QREC_SEED", "0")), max_unique=max(self._step_rows(), 64))
 
     def _step_rows(self) -> int:
-        """rows of the batch stream one training step covers: batch_size, times the world size in a multi-GPU run"""
+        """rows of the batch stream one training step covers: batch_size, times the world size in a batch-sharded
+        multi-GPU run (the row-partitioned layout keeps the reference's batch size)"""
         dp = self.data_parallel()
+        if os.environ.get("QREC_GRAPH_DIST", "batch") == "rows":
+            dp = None
         return self.batch_size * (dp.world if dp else 1)
 
     def saveModel(self):
@@ -68,7 +81,10 @@ class SimGCL(GraphRecommender):
     def trainModel(self):
         quiet = os.environ.get("QREC_QUIET") == "1"
         tr = self.trainer
-        dp = tr.dp = self.data_parallel()
+        if self.row_partitioned:
+            dp = None                                   # every rank takes the whole step; the node tables are what is split
+        else:
+            dp = tr.dp = self.data_parallel()
         rows = self._step_rows()
         if self.throughput_mode():
             # batch stream drawn on the device (base/deepRecommender.py); tf.unique of every batch stays on the host, fed by
@@ -85,10 +101,10 @@ class SimGCL(GraphRecommender):
             d_uu, d_vv = DeviceBuffer.from_numpy(uu), DeviceBuffer.from_numpy(vv)
             for n, s in enumerate(starts):
                 B = min(rows, n_rows - s)
+                extra = dict(share=self.step_share(dp, B)) if dp else {}
                 tr.train_step_async(d_u.ptr + 4 * s, d_i.ptr + 4 * s, d_j.ptr + 4 * s, B,
                                     d_uu.ptr + 4 * int(off_u[n]), int(off_u[n + 1] - off_u[n]),
-                                    d_vv.ptr + 4 * int(off_v[n]), int(off_v[n + 1] - off_v[n]),
-                                    share=self.step_share(dp, B) if dp else None)
+                                    d_vv.ptr + 4 * int(off_v[n]), int(off_v[n + 1] - off_v[n]), **extra)
                 if not quiet:
                     l, rec_l, cl_l = tr.losses()
                     print("training:", epoch + 1, "batch", n, "total_loss:", l, "rec_loss:", rec_l, "cl_loss", cl_l)

@@ -266,6 +266,71 @@ def test_row_partitioned_ngcf_step_equals_the_single_gpu_step(world, dim):
     assert covered == N and not np.allclose(E_one[:nu], U0)
 
 
+@pytest.mark.parametrize("world,layers", [(2, 2), (3, 1), (2, 3)])
+def test_row_partitioned_simgcl_step_equals_the_single_gpu_step(world, layers):
+    """RowPartitionedSimGCLTrainer with G logical ranks against SimGCLTrainer on one GPU: same batch, same injected noise
+    (each rank is handed its rows of it), same unique-row lists.  BPR and InfoNCE losses, the rank's rows of E after three
+    steps and the clean encoder's embeddings agree to fp32 summation order."""
+    from qrec_amd.graph import RowPartitionedSimGCLTrainer, SimGCLTrainer, joint_norm_adjacency, unique_first_appearance
+    d = make_dataset("small")
+    nu, ni, dim, B = d["n_users"], d["n_items"], 64, 512
+    N = nu + ni
+    adj = joint_norm_adjacency(nu, ni, d["train_u"], d["train_i"])
+    rng = np.random.default_rng(30 + world)
+    lim = np.sqrt(6.0 / (nu + dim))
+    U0 = rng.uniform(-lim, lim, (nu, dim)).astype(np.float32); V0 = rng.uniform(-lim, lim, (ni, dim)).astype(np.float32)
+    steps = []
+    for _ in range(3):
+        sel = rng.integers(0, d["train_u"].size, B)
+        u = d["train_u"][sel].astype(np.int32); i = d["train_i"][sel].astype(np.int32); j = rng.integers(0, ni, B).astype(np.int32)
+        steps.append((u, i, j, unique_first_appearance(u), (unique_first_appearance(i) + nu).astype(np.int32),
+                      [rng.random((N, dim)).astype(np.float32) for _ in range(2 * layers)]))
+    hp = dict(lr=0.001, reg=1e-4, cl_rate=0.5, eps=0.1, max_unique=B)
+    one = SimGCLTrainer(U0, V0, adj, layers, **hp)
+    losses_one = []
+    for u, i, j, uu, vv, noises in steps:
+        one.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, DB.from_numpy(uu), uu.size, DB.from_numpy(vv), vv.size,
+                             noises=[DB.from_numpy(x) for x in noises])
+        losses_one.append(one.losses())
+    E_one = np.concatenate(one.ego_embeddings())
+    Um, Vm = one.main_embeddings()
+    group = _Group(world)
+    result, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            capi.init(0)
+            tr = RowPartitionedSimGCLTrainer(ThreadComm(group, rank), U0, V0, adj, layers, **hp)
+            lo, hi, pad = tr.rp.lo, tr.rp.hi, tr.rp.rows_pad
+            losses = []
+            for u, i, j, uu, vv, noises in steps:
+                mine = []
+                for x in noises:
+                    blk = np.zeros((pad, dim), np.float32); blk[:hi - lo] = x[lo:hi]; mine.append(DB.from_numpy(blk))
+                tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, DB.from_numpy(uu), uu.size, DB.from_numpy(vv), vv.size,
+                                    noises=mine)
+                losses.append(tr.losses())
+            emb = tr.main_embeddings()
+            capi.device_sync()
+            result[rank] = (lo, hi, tr.block(tr.E), losses, emb)
+        except Exception as e:      # noqa: BLE001
+            errors.append(e); group.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    covered = 0
+    for lo, hi, E_blk, losses, (Ur, Vr) in result:
+        np.testing.assert_allclose(np.array(losses), np.array(losses_one), rtol=2e-5)
+        assert rel_err(E_blk, E_one[lo:hi]) < 5e-5
+        assert rel_err(Ur, Um) < 1e-4 and rel_err(Vr, Vm) < 1e-4
+        covered += hi - lo
+    assert covered == N and not np.allclose(E_one[:nu], U0)
+
+
 @pytest.mark.parametrize("world,n_batches,dim,same_users", [(2, 3, 16, False), (3, 2, 64, False), (1, 2, 16, False), (2, 4, 64, True)])
 def test_sharded_item_table_with_logical_ranks_equals_the_definition(world, n_batches, dim, same_users):
     """ShardedItemExchange + the real kernels, G logical ranks on one device.  The SGD kernel runs with ONE group, where

