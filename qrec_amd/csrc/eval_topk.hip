@@ -937,9 +937,145 @@ int run_score_topk(const void *U, const void *V, int d, int ld, int n_items, con
 }
 
 // geometry shared by the scratch-size query and the launch
+// ---- (A) of the fused evaluation: the threshold without a sampled score block --------------------------------------------
+// sample_max_kernel_f32: the scoring loop over every kSampleStride-th item tile, but nothing is stored: per GROUP of
+// `tiles_per_group` consecutive sampled tiles every user keeps the largest (unmasked) score and its item.
+// validate_gmax_kernel: a group whose best item is one the user has rated is discarded (-inf) -- the remaining maxima are
+// scores of DISTINCT UNRATED items, so their (N+1)-th largest is a threshold the user's N+1 best masked scores reach.
+// (First version: the sampled tiles written out as a 600 MB block, masked there, group maxima in a second streaming pass:
+// 0.45 ms of the evaluation; a discarded group only lowers tau a little: ~7 % of the groups of a 40-item user.)
+constexpr int kMaxGroups = 128;
+template <int NC>
+__global__ __launch_bounds__(256) void sample_max_kernel_f32(
+    const float *__restrict__ U, const float *__restrict__ V, int ld, int n_items, const int32_t *__restrict__ user_ids,
+    int n_b, int b_pad, int n_s_tiles, int tiles_per_group, int n_groups, float *__restrict__ gmax, int32_t *__restrict__ garg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int upair = blockIdx.x;
+    const int b0 = upair * 64 + r, b1 = b0 + 32;
+    const bool live0 = b0 < n_b, live1 = b1 < n_b;
+    const int64_t uid0 = user_ids[live0 ? b0 : n_b - 1], uid1 = user_ids[live1 ? b1 : n_b - 1];
+    const int g_step = gridDim.y * 4;
+    int g = blockIdx.y * 4 + wave;
+    if (g >= n_groups) return;
+    f32x4 ua[NC][8], ub[NC][8];
+    int kb[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int col0 = 64 * c + 32 * h;
+        const bool kv = col0 < ld;
+        kb[c] = kv ? col0 : 0;
+        const float keep = kv ? 1.f : 0.f;
+        const f32x4 *p0 = reinterpret_cast<const f32x4 *>(U + uid0 * ld + kb[c]), *p1 = reinterpret_cast<const f32x4 *>(U + uid1 * ld + kb[c]);
+#pragma unroll
+        for (int q = 0; q < 8; q++) { ua[c][q] = p0[q] * keep; ub[c][q] = p1[q] * keep; }
+    }
+    auto load_tile = [&](int s_tile, f32x4 (&dst)[NC][8]) {        // sampled tile s -> item tile s * kSampleStride
+        const int item = s_tile * kSampleStride * 32 + r;
+        const float *row = V + (int64_t)(item < n_items ? item : n_items - 1) * ld;
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) dst[c][q] = reinterpret_cast<const f32x4 *>(row + kb[c])[q];
+    };
+    f32x4 v[NC][8], vn[NC][8];
+    bool first = true;
+    for (; g < n_groups; g += g_step) {
+        const int s_begin = g * tiles_per_group;
+        int s_end = s_begin + tiles_per_group;
+        if (s_end > n_s_tiles) s_end = n_s_tiles;
+        float m0 = -__builtin_huge_valf(), m1 = m0;
+        int a0 = 0, a1 = 0;
+        if (first) { load_tile(s_begin, v); first = false; }
+        for (int st = s_begin; st < s_end; st++) {
+            // the next tile to come (this group's, or the first of the wavefront's next group) loads under this tile's MFMAs
+            const int nxt = st + 1 < s_end ? st + 1 : (g + g_step) * tiles_per_group;
+            const bool more = nxt < n_s_tiles && (st + 1 < s_end || g + g_step < n_groups);
+            if (more) load_tile(nxt, vn);
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int q = 0; q < 16; q++) { acc0[q] = 0.f; acc1[q] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].x, ua[c][q].x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].x, ub[c][q].x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].y, ua[c][q].y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].y, ub[c][q].y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].z, ua[c][q].z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].z, ub[c][q].z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].w, ua[c][q].w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][q].w, ub[c][q].w, acc1, 0, 0, 0);
+                }
+            const int item_base = st * kSampleStride * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int item = item_base + (q & 3) + 8 * (q >> 2);
+                const bool in = item < n_items;                    // rows past the catalogue repeat its last item
+                if (in && acc0[q] > m0) { m0 = acc0[q]; a0 = item; }
+                if (in && acc1[q] > m1) { m1 = acc1[q]; a1 = item; }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[c][q] = vn[c][q];
+        }
+        // the two k-slot halves of a column hold different item rows of the same user: fold them
+        const float o0 = __shfl_xor(m0, 32, kWave), o1 = __shfl_xor(m1, 32, kWave);
+        const int oa0 = __shfl_xor(a0, 32, kWave), oa1 = __shfl_xor(a1, 32, kWave);
+        if (o0 > m0) { m0 = o0; a0 = oa0; }
+        if (o1 > m1) { m1 = o1; a1 = oa1; }
+        if (h == 0) {
+            if (live0) { gmax[(int64_t)g * b_pad + b0] = m0; garg[(int64_t)g * b_pad + b0] = a0; }
+            if (live1) { gmax[(int64_t)g * b_pad + b1] = m1; garg[(int64_t)g * b_pad + b1] = a1; }
+        }
+    }
+}
+
+// one thread per (group, user): is the group's best item one of the user's rated items (sorted CSR)?  then the group is out
+__global__ __launch_bounds__(256) void validate_gmax_kernel(const int32_t *__restrict__ user_ids, int n_b, int b_pad, int n_groups,
+                                                            const int64_t *__restrict__ rated_indptr, const int32_t *__restrict__ rated_sorted,
+                                                            const int32_t *__restrict__ garg, float *__restrict__ gmax) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (b >= n_b || g >= n_groups) return;
+    const int item = garg[(int64_t)g * b_pad + b];
+    const int uid = user_ids[b];
+    int64_t lo = rated_indptr[uid], hi = rated_indptr[uid + 1];
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const int v = rated_sorted[mid];
+        if (v < item) lo = mid + 1; else hi = mid;
+    }
+    if (lo < rated_indptr[uid + 1] && rated_sorted[lo] == item) gmax[(int64_t)g * b_pad + b] = -__builtin_huge_valf();
+}
+
+// tau[b] = the M-th largest of the user's n_groups (<= kMaxGroups) group maxima
+__global__ __launch_bounds__(256) void threshold_var_kernel(const float *__restrict__ gmax, int b_pad, int n_b, int n_groups, int M,
+                                                            float *__restrict__ tau) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_b) return;
+    float v[kMaxGroups];
+#pragma unroll
+    for (int g = 0; g < kMaxGroups; g++) v[g] = g < n_groups ? gmax[(int64_t)g * b_pad + b] : -__builtin_huge_valf();
+    float th = 0.f;
+    for (int r = 0; r < M; r++) {
+        int arg = 0;
+        float best = v[0];
+#pragma unroll
+        for (int g = 1; g < kMaxGroups; g++)
+            if (v[g] > best) { best = v[g]; arg = g; }
+        th = best;
+#pragma unroll
+        for (int g = 0; g < kMaxGroups; g++)
+            if (g == arg) v[g] = -__builtin_huge_valf();
+    }
+    tau[b] = th;
+}
+
 struct FusedGeom {
     int b_pad, n_utiles, n_item_tiles, grid_y, n_lists, n_s_tiles, n_s, fb_users;
-    size_t off_gmax, off_tau, off_cs, off_ci, off_cn, off_flags, off_list, off_nf, off_fbu, off_fbi, off_fbs, off_fb, total;
+    size_t off_gmax, off_garg, off_tau, off_cs, off_ci, off_cn, off_flags, off_list, off_nf, off_fbu, off_fbi, off_fbs, off_fb, total;
 };
 __host__ inline bool fused_ok(int dtype, int ld, int n_items, int K) {
     // one predicate for the scratch-size query and the launch (QREC_EVAL_BLOCK_PATH forces the block route in both)
@@ -968,8 +1104,9 @@ __host__ inline FusedGeom fused_geometry(int n_items, int n_b) {
     if (g.fb_users > n_b) g.fb_users = n_b;
     g.fb_users = (g.fb_users + 63) / 64 * 64;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-    size_t o = up((size_t)g.n_s_tiles * 32 * g.b_pad * 4);            // sampled score block
-    g.off_gmax = o; o += up((size_t)kGroups * g.b_pad * 4);
+    size_t o = 0;
+    g.off_gmax = o; o += up((size_t)kMaxGroups * g.b_pad * 4);
+    g.off_garg = o; o += up((size_t)kMaxGroups * g.b_pad * 4);
     g.off_tau = o; o += up((size_t)g.b_pad * 4);
     g.off_cs = o; o += up((size_t)g.b_pad * g.n_lists * kListCap * 4);
     g.off_ci = o; o += up((size_t)g.b_pad * g.n_lists * kListCap * 4);
@@ -990,35 +1127,34 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
                        float *scores_out, hipStream_t st) {
     const FusedGeom g = fused_geometry(n_items, n_b);
     unsigned char *base = static_cast<unsigned char *>(scratch);
-    float *S_s = reinterpret_cast<float *>(base);
     float *gmax = reinterpret_cast<float *>(base + g.off_gmax), *tau = reinterpret_cast<float *>(base + g.off_tau);
     float *cand_s = reinterpret_cast<float *>(base + g.off_cs);
     int32_t *cand_i = reinterpret_cast<int32_t *>(base + g.off_ci), *cand_n = reinterpret_cast<int32_t *>(base + g.off_cn);
     int32_t *flags = reinterpret_cast<int32_t *>(base + g.off_flags), *flagged_list = reinterpret_cast<int32_t *>(base + g.off_list);
     int32_t *n_flagged = reinterpret_cast<int32_t *>(base + g.off_nf);
     const int M = K + 1;
-    // (A) threshold from every kSampleStride-th item tile
+    // (A) threshold from every kSampleStride-th item tile: group maxima straight from the scoring loop
     {
-        int splits = (4096 + g.n_utiles - 1) / g.n_utiles;
-        int per_wave = (g.n_s_tiles + splits - 1) / splits;
-        if (per_wave < 8) per_wave = g.n_s_tiles < 8 ? g.n_s_tiles : 8;
-        const int waves_per_utile = (g.n_s_tiles + per_wave - 1) / per_wave;
-        hipLaunchKernelGGL(score_kernel_f32, dim3((unsigned)g.n_utiles, (unsigned)((waves_per_utile + 3) / 4)), dim3(256), 0, st, U, V, ld,
-                           n_items, user_ids, n_b, g.b_pad, per_wave, S_s, kSampleStride, (int64_t)64);
+        int tpg = g.n_s_tiles / 64; if (tpg < 1) tpg = 1;
+        int n_groups = (g.n_s_tiles + tpg - 1) / tpg;
+        while (n_groups > kMaxGroups) { tpg++; n_groups = (g.n_s_tiles + tpg - 1) / tpg; }
+        int waves = (2048 + g.n_utiles - 1) / g.n_utiles;              // a few groups per wavefront: its user rows are fetched once
+        if (waves > n_groups) waves = n_groups;
+        if (waves < 1) waves = 1;
+        const dim3 sgrid((unsigned)g.n_utiles, (unsigned)((waves + 3) / 4));
+        int32_t *garg = reinterpret_cast<int32_t *>(base + g.off_garg);
+        if (ld <= 64)
+            hipLaunchKernelGGL(sample_max_kernel_f32<1>, sgrid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, g.b_pad, g.n_s_tiles, tpg, n_groups, gmax, garg);
+        else
+            hipLaunchKernelGGL(sample_max_kernel_f32<2>, sgrid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, g.b_pad, g.n_s_tiles, tpg, n_groups, gmax, garg);
         QREC_LAUNCH_CHECK();
+        const unsigned lane_blocks = (unsigned)((n_b + 255) / 256);
         if (rated_indptr) {
-            hipLaunchKernelGGL(mask_kernel<float>, dim3((unsigned)((n_b + 3) / 4)), dim3(256), 0, st, user_ids, n_b, rated_indptr,
-                               rated_sorted, g.b_pad, S_s, 32, kSampleStride, (int64_t)64);
+            hipLaunchKernelGGL(validate_gmax_kernel, dim3(lane_blocks, (unsigned)n_groups), dim3(256), 0, st, user_ids, n_b, g.b_pad, n_groups,
+                               rated_indptr, rated_sorted, garg, gmax);
             QREC_LAUNCH_CHECK();
         }
-        const int per_group = (g.n_s + kGroups - 1) / kGroups, n_groups_used = (g.n_s + per_group - 1) / per_group;
-        const unsigned lane_blocks = (unsigned)((n_b + 255) / 256);
-        if (n_groups_used < kGroups)
-            hipLaunchKernelGGL(fill_neg_inf_kernel<float>, dim3(lane_blocks, kGroups - n_groups_used), dim3(256), 0, st,
-                               gmax + (size_t)n_groups_used * g.b_pad, g.b_pad, n_b);
-        hipLaunchKernelGGL(group_max_kernel<float>, dim3(lane_blocks, (unsigned)n_groups_used), dim3(256), 0, st, S_s, g.n_s, g.b_pad, n_b,
-                           per_group, gmax);
-        hipLaunchKernelGGL(threshold_kernel<float>, dim3(lane_blocks), dim3(256), 0, st, gmax, g.b_pad, n_b, M, tau);
+        hipLaunchKernelGGL(threshold_var_kernel, dim3(lane_blocks), dim3(256), 0, st, gmax, g.b_pad, n_b, n_groups, M, tau);
         QREC_LAUNCH_CHECK();
     }
     // (B) score + filter, (C) select
