@@ -222,19 +222,53 @@ class BprSgd:
             capi.bpr_sgd_ordered(t.P, t.Q, t.code, t.d, t.ld, self.d_u, self.d_i, self.d_j, self.n, lr, regU, regI,
                                  self.d_stats, stream)
             return float(self.d_stats.head(1, stream)[0])
-        entries, off = capi.bpr_exact_schedule(self.h_u, self.h_i, self.h_j, t.n_users, self.n_items, width)
+        prep = self.prepare_ordered(self.h_j, width=width, slot=0, stream=stream, reorder=False)
+        self.run_prepared(prep, lr, regU, regI, stream)
+        return float(self.d_stats.head(1, stream)[0])
+
+    # -- order-exact epochs, pipelined: the host side of epoch k + 1 under the kernel of epoch k ---------------------
+    def exact_width(self, width: int | None = None) -> int:
+        import os
+        if width is None:
+            width = int(os.environ.get("QREC_EXACT_WIDTH", "0")) or 8
+        return min(width, capi.bpr_exact_width(self.t.code, self.t.d))
+
+    def prepare_ordered(self, j: np.ndarray, width: int | None = None, slot: int = 0, stream=None, reorder: bool = True):
+        """Host side of one order-exact epoch: the dependence DAG of (u, i, j) list-scheduled (``qrec_bpr_exact_schedule``)
+        and uploaded into schedule buffer ``slot`` (0 / 1) on ``stream``.  Sampling does not look at the embeddings, so
+        this can run while the PREVIOUS epoch's kernel is still executing (pass a side stream: a copy on the kernel's
+        stream would queue behind it).  ``j``: negatives in the reference's triplet order.  Returns the handle for
+        ``run_prepared``; None when the one-wavefront walker has to be used (width <= 1)."""
+        if self.schedule != "user":
+            raise RuntimeError("the order-exact kernel needs the reference's user-major order")
+        t = self.t
+        width = self.exact_width(width)
+        j = np.ascontiguousarray(j, dtype=np.int32)
+        if reorder and self.perm is not None:
+            j = np.ascontiguousarray(j[self.perm])
+        if width <= 1 or self.n == 0:
+            return None
+        entries, off = capi.bpr_exact_schedule(self.h_u, self.h_i, j, t.n_users, self.n_items, width)
         x = self._exact
-        if not x:
-            x["entries"] = DeviceBuffer((self.n, 8), np.int32)
-            x["off"] = DeviceBuffer(self.n + 2, np.int32)
+        if "xlog" not in x:
             x["xlog"] = DeviceBuffer(self.n + capi.EXACT_XLOG_PAD, t.dtype)
             x["scratch"] = DeviceBuffer.zeros(capi.EXACT_SCRATCH_WORDS, np.float64)
-        x["entries"].upload(entries, stream)
-        x["off"].upload_head(off, stream)
-        self.exact_steps = int(off.size - 1)
-        capi.bpr_sgd_scheduled(t.P, t.Q, t.code, t.d, t.ld, x["entries"], x["off"], self.exact_steps, width, self.n, lr, regU, regI,
+        key = f"slot{slot}"
+        if key not in x:
+            x[key] = (DeviceBuffer((self.n, 8), np.int32), DeviceBuffer(self.n + 2, np.int32))
+        d_entries, d_off = x[key]
+        d_entries.upload(entries, stream)
+        d_off.upload_head(off, stream)
+        # the host arrays stay referenced by the handle: an asynchronous copy may still be reading them when this returns
+        return {"entries": d_entries, "off": d_off, "steps": int(off.size - 1), "width": width, "j": j, "host": (entries, off)}
+
+    def run_prepared(self, prep, lr: float, regU: float, regI: float, stream=None):
+        """enqueue the scheduled kernel of a prepared epoch (no host synchronisation; the loss lands in the stats buffer)"""
+        t, x = self.t, self._exact
+        self.h_j = prep["j"]
+        self.exact_steps = prep["steps"]
+        capi.bpr_sgd_scheduled(t.P, t.Q, t.code, t.d, t.ld, prep["entries"], prep["off"], prep["steps"], prep["width"], self.n, lr, regU, regI,
                                x["xlog"], x["scratch"], self.d_stats, stream)
-        return float(self.d_stats.head(1, stream)[0])
 
     def epoch_throughput_async(self, lr: float, regU: float, regI: float, chunk: int = 32,
                                variant: int = capi.HW_DEFAULT, stream=None, groups: int = 0, flush_every: int = 16):

@@ -78,8 +78,43 @@ class BPR(IterativeRecommender):
             return
         if self.mode == "throughput":
             sgd.prefetch_negatives_device(self.sampler_seed, 0)
+
+        # Exact mode, pipelined: the reference draws epoch k's negatives when epoch k starts, from the global `random` stream,
+        # and neither the draws nor the shuffle that closes an epoch (isConverged) look at the embeddings -- so the host side of
+        # epoch k + 1 (the shuffle's draws replayed on a scratch permutation, the CPython-stream negatives, the list schedule,
+        # the upload into the other schedule buffer on a side stream) runs while the kernel of epoch k executes.  The global
+        # stream itself is only ever moved by the code that moves it in the reference: a prefetched draw is committed when its
+        # epoch starts AND the stream is where the prefetch assumed it would be; otherwise it is dropped and redone in place.
+        def draw(state):
+            words = capi.state_from_python(state)
+            jj = capi.mt_bpr_sample_epoch(words, pos.indptr, pos.indices, n_items)
+            return jj, capi.state_to_python(words, state[2])
+
+        def after_epoch_close(state):              # base/iterativeRecommender.py:101 shuffle(trainingData): its draws only
+            words = capi.state_from_python(state)
+            capi.mt_shuffle(words, self.data.elemCount(), np.arange(self.data.elemCount(), dtype=np.int64))
+            return capi.state_to_python(words, state[2])
+
+        pipelined = self.mode == "exact" and sgd.exact_width() > 1 and u.size > 0
+        ahead = None
+        if pipelined:
+            side = capi.Stream()
         while epoch < self.maxEpoch:
-            if self.mode == "exact":
+            if pipelined:
+                now = random.getstate()
+                if ahead is None or ahead[0] != now:                                      # first epoch, or the stream is not where assumed
+                    j, after = draw(now)
+                    prep = sgd.prepare_ordered(j, slot=epoch & 1, stream=side.handle); side.sync()
+                else:
+                    _, j, after, prep = ahead
+                random.setstate(after)
+                sgd.run_prepared(prep, self.lRate, self.regU, self.regI)                  # enqueued; the host goes on
+                ahead = None
+                if epoch + 1 < self.maxEpoch:
+                    start2 = after_epoch_close(after)
+                    j2, after2 = draw(start2)
+                    ahead = (start2, j2, after2, sgd.prepare_ordered(j2, slot=(epoch + 1) & 1, stream=side.handle)); side.sync()
+            elif self.mode == "exact":
                 state = random.getstate()
                 words = capi.state_from_python(state)
                 j = capi.mt_bpr_sample_epoch(words, pos.indptr, pos.indices, n_items)

@@ -122,6 +122,38 @@ def test_bpr_model_end_to_end_reproduces_reference_run():
             assert g == w
 
 
+def test_pipelined_exact_epochs_follow_the_global_random_stream(monkeypatch):
+    """The BPR class prefetches epoch k + 1's negatives and schedule under epoch k's kernel, assuming the global `random`
+    stream moves only through the epoch-closing shuffle.  If anything else draws from it between two epochs (here: a hook
+    in isConverged), the prefetch must be dropped and the epoch redone from the stream as it is -- the run then equals the
+    unpipelined one (one-wavefront walker, QREC_EXACT_WIDTH=1), tables bit for bit."""
+    from qrec_amd.model.ranking.BPR import BPR
+    meta, z = load_golden("bpr_filmtrust")
+    train, test = rows_from_golden(z)
+
+    def run(width, meddle):
+        monkeypatch.setenv("QREC_EXACT_WIDTH", str(width))
+        conf = conf_from_text(meta["conf"])
+        random.seed(5); np.random.seed(5)
+        with redirect_stdout(io.StringIO()):
+            m = BPR(conf, train, test)
+            if meddle:
+                orig = m.isConverged
+                def hooked(epoch):
+                    r = orig(epoch)
+                    random.random()                # somebody else uses the global stream between two epochs
+                    return r
+                m.isConverged = hooked
+            m.execute()
+        return m.P.copy(), m.Q.copy(), capi.state_from_python(random.getstate())
+
+    for meddle in (False, True):
+        Pa, Qa, sa = run(8, meddle)
+        Pb, Qb, sb = run(1, meddle)
+        assert np.array_equal(Pa, Pb) and np.array_equal(Qa, Qb) and np.array_equal(sa, sb), meddle
+    assert not np.array_equal(run(8, False)[0], run(8, True)[0])         # the hook does change the run
+
+
 def test_basicmf_model_end_to_end_reproduces_reference_run():
     """BASELINE.json config #1 (BasicMF, FilmTrust, d=10) through the drop-in class."""
     from qrec_amd.model.rating.BasicMF import BasicMF
