@@ -330,6 +330,12 @@ int qrec_mark_compact_batch_rows(const int32_t *d_u, const int32_t *d_i, const i
                                  int64_t n_rows, uint32_t *d_row_mask, int32_t *d_rows, int32_t *d_count, int32_t capacity,
                                  void *stream);
 
+/* tf.unique of EVERY batch of an epoch's id stream (SimGCL.py:61-64), one launch: for batch b = ids[b*batch .. ) the
+ * distinct ids in [0, id_range) (id_range <= 2^20), ascending, + out_offset, go to d_rows[b*batch ..) and their number to
+ * d_counts[b].  Ascending instead of tf.unique's first-appearance order: the consumers (InfoNCE sums) are order-free. */
+int qrec_unique_per_batch(const int32_t *d_ids, int64_t n, int32_t batch, int32_t id_range, int32_t out_offset, int32_t *d_rows,
+                          int32_t *d_counts, void *stream);
+
 /* pre = (side + E) W1 + (E * side) W2   (NGCF.py:29-31; side = A E from qrec_spmm_csr). f32 MFMA. */
 int qrec_ngcf_dense_fwd(const float *d_E, const float *d_side, const float *d_W1, const float *d_W2, int64_t n_rows,
                         int32_t ld, float *d_pre, const int32_t *d_row_ids, const int32_t *d_n_row_ids, int32_t max_row_ids,

@@ -88,6 +88,7 @@ _SIGNATURES = {
     "qrec_info_nce_loss_grad": [_vp, _vp, _f32, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "qrec_ngcf_dense_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp],
     "qrec_compact_marked_rows": [_vp, _i64, _vp, _vp, _i32, _vp],
+    "qrec_unique_per_batch": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
     "qrec_mark_compact_batch_rows": [_vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _i32, _vp],
     "qrec_ngcf_activate": [_vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _vp],
     "qrec_ngcf_layer_bwd": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
@@ -811,6 +812,11 @@ def mark_compact_batch_rows(d_u, d_i, d_j, B: int, n_users: int, n_rows: int, d_
                                                _dp(rows.count), rows.capacity, _sh(stream)))
     rows.bound = bound
     return rows
+
+
+def unique_per_batch(d_ids, n: int, batch: int, id_range: int, out_offset: int, d_rows, d_counts, stream=None):
+    """distinct ids of every batch of an id stream, ascending, + out_offset: d_rows[b*batch ..), d_counts[b]"""
+    _check(load().qrec_unique_per_batch(_dp(d_ids), n, batch, id_range, out_offset, _dp(d_rows), _dp(d_counts), _sh(stream)))
 
 
 def _subset(rows):

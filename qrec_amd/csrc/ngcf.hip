@@ -725,6 +725,44 @@ __global__ __launch_bounds__(1024) void mark_compact_kernel(const int32_t *__res
 }
 constexpr int64_t kLdsMaskRows = 1 << 20;              // 128 KB of bitmap
 
+// tf.unique of every batch of an epoch's id stream in one launch (SimGCL.py:61-64 on a device-drawn batch stream): block b
+// marks ids[b * batch ...] in an LDS bitmap over [0, id_range) and emits the distinct ids, ascending and shifted by
+// out_offset, to rows[b * batch ...]; counts[b] = how many.  (tf.unique keeps first-appearance order; the InfoNCE sums
+// that consume the list do not depend on the order beyond fp32 rounding.)
+__global__ __launch_bounds__(1024) void unique_per_batch_kernel(const int32_t *__restrict__ ids, int64_t n, int batch, int id_range,
+                                                                int out_offset, int32_t *__restrict__ rows, int32_t *__restrict__ counts) {
+    extern __shared__ uint32_t s_mask[];               // n_words words, then 16 wave sums
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_words = (id_range + 31) / 32;
+    int *s_wave = reinterpret_cast<int *>(s_mask + n_words);
+    const int64_t b0 = (int64_t)blockIdx.x * batch;
+    const int B = (int)(n - b0 < batch ? n - b0 : batch);
+    for (int w = threadIdx.x; w < n_words; w += 1024) s_mask[w] = 0u;
+    __syncthreads();
+    for (int k = threadIdx.x; k < B; k += 1024) { const int v = ids[b0 + k]; atomicOr(&s_mask[v >> 5], 1u << (v & 31)); }
+    __syncthreads();
+    const int per = (n_words + 1023) / 1024, w0 = per * (int)threadIdx.x, w1 = w0 + per < n_words ? w0 + per : n_words;
+    int mine = 0;
+    for (int w = w0; w < w1; w++) mine += __popc(s_mask[w]);
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, kWave); if (lane >= off) incl += v; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const int v = s_wave[k]; if (k < wave) base += v; total += v; }
+    int pos = base + incl - mine;
+    for (int w = w0; w < w1; w++) {
+        uint32_t m = s_mask[w];
+        while (m) {
+            const int b = __ffs(m) - 1; m &= m - 1;
+            rows[b0 + pos++] = w * 32 + b + out_offset;
+        }
+    }
+    if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+
 // persistent grid of the dense-layer kernels: every block stages the weights in LDS once, so no more blocks than
 // the chip keeps resident (2 per CU; 1 when the weights take 128 KB), and never more than there are 128-row groups
 unsigned dense_grid(int64_t n_rows, int ld, bool one_per_cu = false) {
@@ -872,6 +910,19 @@ int qrec_mark_compact_batch_rows(const int32_t *d_u, const int32_t *d_i, const i
     int rc = qrec_mark_batch_rows(d_u, d_i, d_j, B, n_users, d_row_mask, stream);
     if (rc != QREC_OK) return rc;
     return qrec_compact_marked_rows(d_row_mask, n_rows, d_rows, d_count, capacity, stream);
+}
+
+int qrec_unique_per_batch(const int32_t *d_ids, int64_t n, int32_t batch, int32_t id_range, int32_t out_offset, int32_t *d_rows,
+                          int32_t *d_counts, void *stream) {
+    QREC_REQUIRE(n >= 0 && batch >= 1 && id_range >= 1 && id_range <= kLdsMaskRows, "qrec_unique_per_batch: bad sizes (id_range <= 2^20)");
+    QREC_REQUIRE(n == 0 || (d_ids && d_rows && d_counts), "qrec_unique_per_batch: null argument");
+    if (n == 0) return QREC_OK;
+    const size_t lds = (size_t)((id_range + 31) / 32) * 4 + 64;
+    QREC_HIP_CHECK(allow_big_lds(reinterpret_cast<const void *>(&unique_per_batch_kernel), lds));
+    hipLaunchKernelGGL(unique_per_batch_kernel, dim3((unsigned)((n + batch - 1) / batch)), dim3(1024), lds, as_stream(stream), d_ids, n, batch,
+                       id_range, out_offset, d_rows, d_counts);
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
 }
 
 int qrec_copy_cols(float *d_dst, int32_t dst_ld, const float *d_src, int32_t src_ld, int32_t src_col_off, int64_t n_rows,

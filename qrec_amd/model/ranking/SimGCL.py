@@ -70,13 +70,32 @@ class SimGCL(GraphRecommender):
         return self._with_batch_uniques(u, i, j)
 
     def _with_batch_uniques(self, u, i, j):
+        """host arrays: (u, i, j, batch starts, unique user rows, their start and count per batch, unique item rows, start, count)"""
         nu = self.num_users
         rows = self._step_rows()
         starts = list(range(0, u.size, rows))
         uu = [unique_first_appearance(u[s:s + rows]) for s in starts]
         vv = [unique_first_appearance(i[s:s + rows]) + nu for s in starts]
-        off_u = np.concatenate([[0], np.cumsum([x.size for x in uu])]); off_v = np.concatenate([[0], np.cumsum([x.size for x in vv])])
-        return (u, i, j, starts, np.concatenate(uu).astype(np.int32), off_u, np.concatenate(vv).astype(np.int32), off_v)
+        cu, cv = np.array([x.size for x in uu], np.int64), np.array([x.size for x in vv], np.int64)
+        su, sv = np.concatenate([[0], np.cumsum(cu)[:-1]]), np.concatenate([[0], np.cumsum(cv)[:-1]])
+        return (u, i, j, starts, np.concatenate(uu).astype(np.int32), su, cu, np.concatenate(vv).astype(np.int32), sv, cv)
+
+    def _device_batch_uniques(self, d_u, d_i):
+        """the same lists for a device-drawn batch stream, formed on the device (qrec_unique_per_batch: ascending ids, one
+        launch per side and epoch); the host reads back the counts only"""
+        from ... import capi
+        n, rows = d_u.shape[0], self._step_rows()
+        n_batches = -(-n // rows)
+        out = []
+        for d_ids, id_range, offset in ((d_u, self.num_users, 0), (d_i, self.num_items, self.num_users)):
+            d_rows, d_cnt = DeviceBuffer(max(n, 1), np.int32), DeviceBuffer(max(n_batches, 1), np.int32)
+            capi.unique_per_batch(d_ids, n, rows, id_range, offset, d_rows, d_cnt)
+            out.append((d_rows, d_cnt))
+        starts = list(range(0, n, rows))
+        res = [starts]
+        for d_rows, d_cnt in out:
+            res += [d_rows, np.asarray(starts, np.int64), d_cnt.numpy().astype(np.int64)]
+        return tuple(res)
 
     def trainModel(self):
         quiet = os.environ.get("QREC_QUIET") == "1"
@@ -87,24 +106,22 @@ class SimGCL(GraphRecommender):
             dp = tr.dp = self.data_parallel()
         rows = self._step_rows()
         if self.throughput_mode():
-            # batch stream drawn on the device (base/deepRecommender.py); tf.unique of every batch stays on the host, fed by
-            # one read-back of the epoch's row order
+            # batch stream drawn on the device (base/deepRecommender.py), tf.unique of every batch on the device as well
             def epochs():
                 for d_u, d_i, d_j in self.iter_epoch_samples_device(self.maxEpoch):
-                    yield (d_u, d_i, d_j) + self._with_batch_uniques(d_u.numpy(), d_i.numpy(), None)[3:]
+                    yield (d_u, d_i, d_j) + self._device_batch_uniques(d_u, d_i)
         else:
             def epochs():
-                for u, i, j, *rest in self.iter_epoch_samples(self.maxEpoch, self._draw_epoch):
-                    yield (DeviceBuffer.from_numpy(u), DeviceBuffer.from_numpy(i), DeviceBuffer.from_numpy(j)) + tuple(rest)
-        for epoch, (d_u, d_i, d_j, starts, uu, off_u, vv, off_v) in enumerate(epochs()):
+                up = DeviceBuffer.from_numpy
+                for u, i, j, starts, uu, su, cu, vv, sv, cv in self.iter_epoch_samples(self.maxEpoch, self._draw_epoch):
+                    yield up(u), up(i), up(j), starts, up(uu), su, cu, up(vv), sv, cv
+        for epoch, (d_u, d_i, d_j, starts, d_uu, su, cu, d_vv, sv, cv) in enumerate(epochs()):
             n_rows = d_u.shape[0]
-            d_uu, d_vv = DeviceBuffer.from_numpy(uu), DeviceBuffer.from_numpy(vv)
             for n, s in enumerate(starts):
                 B = min(rows, n_rows - s)
                 extra = dict(share=self.step_share(dp, B)) if dp else {}
                 tr.train_step_async(d_u.ptr + 4 * s, d_i.ptr + 4 * s, d_j.ptr + 4 * s, B,
-                                    d_uu.ptr + 4 * int(off_u[n]), int(off_u[n + 1] - off_u[n]),
-                                    d_vv.ptr + 4 * int(off_v[n]), int(off_v[n + 1] - off_v[n]), **extra)
+                                    d_uu.ptr + 4 * int(su[n]), int(cu[n]), d_vv.ptr + 4 * int(sv[n]), int(cv[n]), **extra)
                 if not quiet:
                     l, rec_l, cl_l = tr.losses()
                     print("training:", epoch + 1, "batch", n, "total_loss:", l, "rec_loss:", rec_l, "cl_loss", cl_l)

@@ -434,6 +434,21 @@ def test_row_subset_helpers():
             assert np.array_equal(dmask.numpy(), wm)
 
 
+def test_unique_per_batch_matches_numpy():
+    """qrec_unique_per_batch (tf.unique of every batch of an epoch's id stream, SimGCL.py:61-64, ascending): against
+    np.unique per batch, ragged last batch, ids offset into the joint table"""
+    rng = np.random.default_rng(9)
+    for n, batch, id_range, off in ((10000, 2048, 31668, 0), (5000, 512, 700, 31668), (3, 2048, 10, 5), (4096, 4096, 100000, 1)):
+        ids = rng.integers(0, id_range, n).astype(np.int32)
+        nb = -(-n // batch)
+        d_rows, d_cnt = DB.zeros(n, np.int32), DB.zeros(nb, np.int32)
+        capi.unique_per_batch(DB.from_numpy(ids), n, batch, id_range, off, d_rows, d_cnt)
+        rows, cnt = d_rows.numpy(), d_cnt.numpy()
+        for b in range(nb):
+            want = np.unique(ids[b * batch:(b + 1) * batch]) + off
+            assert cnt[b] == want.size and np.array_equal(rows[b * batch:b * batch + cnt[b]], want)
+
+
 @pytest.mark.parametrize("dim", [64, 50, 8, 70])
 def test_ngcf_gradients_and_training_steps_match_restatement(dim):
     d, adj, A = _graph("small")
