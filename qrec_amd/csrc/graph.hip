@@ -49,6 +49,12 @@ __device__ inline void spmm_epilogue(f32x4 acc, int row, int r, float *__restric
     }
 }
 
+// broadcast of lane N of every 16-lane row to the row (DPP row_newbcast: VALU rate, no LDS crossbar)
+template <int N>
+__device__ __forceinline__ int row16_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xf, 0xf, false); }
+template <int N>
+__device__ __forceinline__ float row16_bcast(float v) { return __builtin_bit_cast(float, row16_bcast<N>(__builtin_bit_cast(int, v))); }
+
 template <int LPR>
 __global__ __launch_bounds__(256) void spmm_kernel(
     const int32_t *__restrict__ seg_row, const int64_t *__restrict__ seg_beg,
@@ -76,6 +82,26 @@ __global__ __launch_bounds__(256) void spmm_kernel(
             const float my_v = mine < len ? values[beg + mine] : 0.f;
             const int cnt = (len - e0) < LPR ? (len - e0) : LPR;
             int k = 0;
+            if constexpr (LPR == 16) {
+                // ld = 64: a group IS a 16-lane DPP row, so (col, val) of entry K reach the group by row_newbcast:K -- eight
+                // ds_bpermute per four non-zeros become eight VALU moves.  Entries past the segment's end carry value 0 and
+                // the column of the batch's first entry (a row gathered anyway; acc + 0*x = acc), so the gathers always go
+                // out four at a time.
+                if (mine >= len) my_c = row16_bcast<0>(my_c);
+                if (x_row_mask && !((x_row_mask[my_c >> 5] >> (my_c & 31)) & 1u)) my_c = -1;      // exactly-zero operand row: not fetched
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#define QREC_QUAD(K)                                                                                                     \
+                if (K < cnt) {                                                                                           \
+                    const int c0 = row16_bcast<K>(my_c), c1 = row16_bcast<K + 1>(my_c), c2 = row16_bcast<K + 2>(my_c), c3 = row16_bcast<K + 3>(my_c); \
+                    const float v0 = row16_bcast<K>(my_v), v1 = row16_bcast<K + 1>(my_v), v2 = row16_bcast<K + 2>(my_v), v3 = row16_bcast<K + 3>(my_v); \
+                    const f32x4 x0 = c0 >= 0 ? ld_row4<LPR>(X, c0, r) : zero, x1 = c1 >= 0 ? ld_row4<LPR>(X, c1, r) : zero;       \
+                    const f32x4 x2 = c2 >= 0 ? ld_row4<LPR>(X, c2, r) : zero, x3 = c3 >= 0 ? ld_row4<LPR>(X, c3, r) : zero;       \
+                    acc = acc + v0 * x0; acc = acc + v1 * x1; acc = acc + v2 * x2; acc = acc + v3 * x3;                   \
+                }
+                QREC_QUAD(0) QREC_QUAD(4) QREC_QUAD(8) QREC_QUAD(12)
+#undef QREC_QUAD
+                continue;
+            }
             if (x_row_mask) {
                 // sparse operand (first backward SpMM: X = the batch gradient, <= 3B non-zero rows): a
                 // clear mask bit means the row is exactly zero; it is not fetched and contributes +0
