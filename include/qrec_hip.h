@@ -247,13 +247,15 @@ int qrec_sumsq(const void *d_x, int dtype, int64_t rows, int32_t d, int32_t ld, 
  * less traffic) -- used for the first backward SpMM, whose operand is the sparse batch gradient.
  * d_y_row_mask (may be NULL): bitmap of the OUTPUT rows that are wanted; the others are neither computed nor
  * written (Y, accum keep what they held) -- the last propagation layer of a training step is only read at the
- * batch's rows (embedding_lookup, LightGCN.py:22-24; qrec_mark_batch_rows builds the bitmap).          */
+ * batch's rows (embedding_lookup, LightGCN.py:22-24; qrec_mark_batch_rows builds the bitmap).
+ * d_accum_init (may be NULL; needs d_accum): accum = accum_init + Y instead of accum += Y -- the first layer starts the
+ * layer sum from the input table (LightGCN.py:15-19: all_embeddings = [ego_embeddings]), no copy before it.       */
 int qrec_spmm_csr(const int32_t *d_seg_row, const int64_t *d_seg_beg, const int32_t *d_seg_len,
                   const int32_t *d_seg_slot, int64_t n_segs, const int32_t *d_long_row,
                   const int32_t *d_long_first, const int32_t *d_long_count, int32_t n_long,
                   const int32_t *d_indices, const float *d_values, const float *d_X, float *d_Y,
                   float *d_partial, int32_t ld, const float *d_addend, float addend_scale, float *d_accum,
-                  const uint32_t *d_x_row_mask, const uint32_t *d_y_row_mask, void *stream);
+                  const float *d_accum_init, const uint32_t *d_x_row_mask, const uint32_t *d_y_row_mask, void *stream);
 /* d_row_mask |= bits of rows u[b], n_users+i[b], n_users+j[b] (bitmap over the joint [U;V] row space; clear it first) */
 int qrec_mark_batch_rows(const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int32_t B, int32_t n_users,
                          uint32_t *d_row_mask, void *stream);
@@ -325,10 +327,12 @@ int qrec_compact_marked_rows(const uint32_t *d_row_mask, int64_t n_rows, int32_t
                              void *stream);
 
 /* The row bitmap of a batch (as memset + qrec_mark_batch_rows would leave it) AND its ascending row list in one launch
- * (tables up to 2^20 rows: the bitmap is built in LDS; larger tables take the three separate steps). */
+ * (tables up to 2^20 rows: the bitmap is built in LDS; larger tables take the three separate steps).  d_rows / d_count may
+ * both be NULL (bitmap only).  d_zero8[0 .. n_zero8) (n_zero8 <= 64, may be 0): doubles cleared by the same launch -- the
+ * step's loss accumulators, which would otherwise cost a memset launch of their own. */
 int qrec_mark_compact_batch_rows(const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int32_t B, int32_t n_users,
                                  int64_t n_rows, uint32_t *d_row_mask, int32_t *d_rows, int32_t *d_count, int32_t capacity,
-                                 void *stream);
+                                 double *d_zero8, int32_t n_zero8, void *stream);
 
 /* tf.unique of EVERY batch of an epoch's id stream (SimGCL.py:61-64), one launch: for batch b = ids[b*batch .. ) the
  * distinct ids in [0, id_range) (id_range <= 2^20), ascending, + out_offset, go to d_rows[b*batch ..) and their number to

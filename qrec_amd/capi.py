@@ -64,7 +64,7 @@ _SIGNATURES = {
     "qrec_svdpp_sgd_ordered": [_vp, _vp, _vp, _vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64,
                                _f64, _f64, _f64, _vp, _vp],
     "qrec_sumsq": [_vp, C.c_int, _i64, _i32, _i32, _vp, _vp],
-    "qrec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _vp, _vp],
+    "qrec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _vp, _vp, _vp],
     "qrec_mark_batch_rows": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "qrec_bpr_batch_loss_grad": [_vp, _f32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
     "qrec_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
@@ -89,7 +89,7 @@ _SIGNATURES = {
     "qrec_ngcf_dense_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp],
     "qrec_compact_marked_rows": [_vp, _i64, _vp, _vp, _i32, _vp],
     "qrec_unique_per_batch": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
-    "qrec_mark_compact_batch_rows": [_vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _i32, _vp],
+    "qrec_mark_compact_batch_rows": [_vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _i32, _vp, _i32, _vp],
     "qrec_ngcf_activate": [_vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _vp],
     "qrec_ngcf_layer_bwd": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "qrec_ngcf_wgrad_partial_bytes": [_i64, _i32, _vp],
@@ -661,12 +661,12 @@ def mark_batch_rows(d_u, d_i, d_j, B: int, n_users: int, d_row_mask, stream=None
 
 
 def spmm_csr(plan, d_X, d_Y, ld: int, d_addend=None, addend_scale: float = 0.0, d_accum=None, stream=None,
-             d_x_row_mask=None, d_y_row_mask=None):
+             d_x_row_mask=None, d_y_row_mask=None, d_accum_init=None):
     """plan: qrec_amd.graph.SpmmPlan (device-resident segment arrays)"""
     _check(load().qrec_spmm_csr(_dp(plan.seg_row), _dp(plan.seg_beg), _dp(plan.seg_len), _dp(plan.seg_slot),
                                 plan.n_segs, _dp(plan.long_row), _dp(plan.long_first), _dp(plan.long_count),
                                 plan.n_long, _dp(plan.indices), _dp(plan.values), _dp(d_X), _dp(d_Y),
-                                _dp(plan.partial), ld, _dp(d_addend), addend_scale, _dp(d_accum), _dp(d_x_row_mask),
+                                _dp(plan.partial), ld, _dp(d_addend), addend_scale, _dp(d_accum), _dp(d_accum_init), _dp(d_x_row_mask),
                                 _dp(d_y_row_mask), _sh(stream)))
 
 
@@ -804,13 +804,17 @@ class RowSubset:
         return self
 
 
-def mark_compact_batch_rows(d_u, d_i, d_j, B: int, n_users: int, n_rows: int, d_row_mask, rows: RowSubset, bound: int, stream=None):
-    """row bitmap of the batch (cleared first) + its row list, one launch"""
-    if bound > rows.capacity:
+def mark_compact_batch_rows(d_u, d_i, d_j, B: int, n_users: int, n_rows: int, d_row_mask, rows=None, bound: int = 0, stream=None,
+                            d_zero8=None, n_zero8: int = 0):
+    """row bitmap of the batch (cleared first) + (``rows``: a RowSubset) its row list, one launch; ``d_zero8``: n_zero8 doubles
+    cleared by the same launch (the step's loss accumulators)"""
+    if rows is not None and bound > rows.capacity:
         raise ValueError("RowSubset: bound above the capacity")
-    _check(load().qrec_mark_compact_batch_rows(_dp(d_u), _dp(d_i), _dp(d_j), B, n_users, n_rows, _dp(d_row_mask), _dp(rows.rows),
-                                               _dp(rows.count), rows.capacity, _sh(stream)))
-    rows.bound = bound
+    _check(load().qrec_mark_compact_batch_rows(_dp(d_u), _dp(d_i), _dp(d_j), B, n_users, n_rows, _dp(d_row_mask),
+                                               _dp(rows.rows) if rows is not None else None, _dp(rows.count) if rows is not None else None,
+                                               rows.capacity if rows is not None else 0, _dp(d_zero8), n_zero8, _sh(stream)))
+    if rows is not None:
+        rows.bound = bound
     return rows
 
 

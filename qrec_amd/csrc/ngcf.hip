@@ -686,8 +686,10 @@ __global__ __launch_bounds__(1024) void compact_rows_kernel(const uint32_t *__re
 __global__ __launch_bounds__(1024) void mark_compact_kernel(const int32_t *__restrict__ u, const int32_t *__restrict__ i,
                                                             const int32_t *__restrict__ j, int B, int n_users, int64_t n_rows,
                                                             uint32_t *__restrict__ mask_out, int32_t *__restrict__ rows,
-                                                            int32_t *__restrict__ count, int capacity) {
+                                                            int32_t *__restrict__ count, int capacity,
+                                                            double *__restrict__ zero8, int n_zero8) {
     extern __shared__ uint32_t s_mask[];               // n_words words, then 16 wave sums
+    if ((int)threadIdx.x < n_zero8) zero8[threadIdx.x] = 0.0;      // the step's scalar accumulators (loss terms): no memset launch for 8 bytes
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t n_words = (n_rows + 31) / 32;
     int *s_wave = reinterpret_cast<int *>(s_mask + n_words);
@@ -717,11 +719,11 @@ __global__ __launch_bounds__(1024) void mark_compact_kernel(const int32_t *__res
         uint32_t m = s_mask[w];
         while (m) {
             const int b = __ffs(m) - 1; m &= m - 1;
-            if (pos < capacity) rows[pos] = (int32_t)(w * 32 + b);
+            if (rows && pos < capacity) rows[pos] = (int32_t)(w * 32 + b);
             pos++;
         }
     }
-    if (threadIdx.x == 0) *count = total < capacity ? total : capacity;
+    if (count && threadIdx.x == 0) *count = total < capacity ? total : capacity;
 }
 constexpr int64_t kLdsMaskRows = 1 << 20;              // 128 KB of bitmap
 
@@ -892,8 +894,9 @@ int qrec_compact_marked_rows(const uint32_t *d_row_mask, int64_t n_rows, int32_t
 
 int qrec_mark_compact_batch_rows(const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int32_t B, int32_t n_users,
                                  int64_t n_rows, uint32_t *d_row_mask, int32_t *d_rows, int32_t *d_count, int32_t capacity,
-                                 void *stream) {
-    QREC_REQUIRE(d_row_mask && d_rows && d_count && B >= 0 && n_users >= 0 && n_rows >= n_users && n_rows < (1ll << 31) && capacity >= 0,
+                                 double *d_zero8, int32_t n_zero8, void *stream) {
+    QREC_REQUIRE(d_row_mask && B >= 0 && n_users >= 0 && n_rows >= n_users && n_rows < (1ll << 31) && capacity >= 0 &&
+                 (!d_rows == !d_count) && n_zero8 >= 0 && n_zero8 <= 64 && (n_zero8 == 0 || d_zero8),
                  "qrec_mark_compact_batch_rows: bad argument");
     QREC_REQUIRE(B == 0 || (d_u && d_i && d_j), "qrec_mark_compact_batch_rows: null index array");
     hipStream_t st = as_stream(stream);
@@ -902,13 +905,14 @@ int qrec_mark_compact_batch_rows(const int32_t *d_u, const int32_t *d_i, const i
         const size_t lds = (size_t)n_words * 4 + 64;
         QREC_HIP_CHECK(allow_big_lds(reinterpret_cast<const void *>(&mark_compact_kernel), lds));
         hipLaunchKernelGGL(mark_compact_kernel, dim3(1), dim3(1024), lds, st, d_u, d_i, d_j, B, n_users, n_rows, d_row_mask, d_rows,
-                           d_count, capacity);
+                           d_count, capacity, d_zero8, n_zero8);
         QREC_LAUNCH_CHECK();
         return QREC_OK;
     }
+    if (n_zero8) QREC_HIP_CHECK(hipMemsetAsync(d_zero8, 0, (size_t)n_zero8 * 8, st));
     QREC_HIP_CHECK(hipMemsetAsync(d_row_mask, 0, (size_t)n_words * 4, st));
     int rc = qrec_mark_batch_rows(d_u, d_i, d_j, B, n_users, d_row_mask, stream);
-    if (rc != QREC_OK) return rc;
+    if (rc != QREC_OK || !d_rows) return rc;
     return qrec_compact_marked_rows(d_row_mask, n_rows, d_rows, d_count, capacity, stream);
 }
 

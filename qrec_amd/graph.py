@@ -224,13 +224,14 @@ class LightGCNTrainer:
         """S = E0 + E1 + ... + EL  (divide by L+1 at the point of use).  ``last_rows`` (row bitmap): the last
         layer is only computed at those rows -- a training step reads S at the batch's rows and nowhere else
         (embedding_lookup, LightGCN.py:22-24), and E_L feeds nothing further."""
-        self.S.copy_from(self.E, stream)
         x = self.E
         for k in range(self.L):
             y = self.A if k % 2 == 0 else self.B
-            capi.spmm_csr(self.plan, x, y, self.ld, d_accum=self.S, stream=stream,
+            capi.spmm_csr(self.plan, x, y, self.ld, d_accum=self.S, stream=stream, d_accum_init=self.E if k == 0 else None,   # S = E + A E, no copy
                           d_y_row_mask=last_rows if k == self.L - 1 else None)
             x = y
+        if self.L == 0:
+            self.S.copy_from(self.E, stream)
 
     def backward_from_dE(self, stream=None):
         """H_L with H_0 = dE, H_{k+1} = dE + A H_k; the gradient of E is H_L / (L+1)."""
@@ -250,12 +251,10 @@ class LightGCNTrainer:
 
     def train_step_async(self, d_u, d_i, d_j, B: int, stream=None):
         """u/i/j: device pointers (int32[B]); enqueue only, read the loss with ``loss()``."""
-        self.row_mask.fill_bytes(0, stream)
-        if B:
-            capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)    # rows {u, nu+i, nu+j} of the batch
+        # one launch: the bitmap of the rows {u, nu+i, nu+j} of the batch, cleared first, and the loss accumulator cleared
+        capi.mark_compact_batch_rows(d_u, d_i, d_j, B, self.nu, self.n, self.row_mask, stream=stream, d_zero8=self.d_loss, n_zero8=1)
         self.forward_sum(stream, last_rows=self.row_mask)
         self.dE.fill_bytes(0, stream)
-        self.d_loss.fill_bytes(0, stream)
         if B:
             capi.bpr_batch_loss_grad(self.S, float(self.L + 1), self.nu, self.n, self.ld, d_u, d_i, d_j, B,
                                      self.loss_eps, self.reg, self.dE, self.d_loss, stream, d_row_mask=self.row_mask)
@@ -523,10 +522,10 @@ class SimGCLTrainer:
         bound = min(3 * B, self.n)
         if self.batch_rows is None or self.batch_rows.capacity < bound:
             self.batch_rows = capi.RowSubset(bound)
-        subset = capi.mark_compact_batch_rows(d_u, d_i, d_j, B, self.nu, self.n, self.row_mask, self.batch_rows, bound, stream)
+        subset = capi.mark_compact_batch_rows(d_u, d_i, d_j, B, self.nu, self.n, self.row_mask, self.batch_rows, bound, stream,
+                                              d_zero8=self.d_loss, n_zero8=2)          # ... and both loss accumulators cleared
         self._encode_three(noises, stream, self.row_mask, subset)
         self.dOut.fill_bytes(0, stream)
-        self.d_loss.fill_bytes(0, stream)
         # the InfoNCE rows (unique batch users / positive items) are a subset of the rows marked above
         if share is not None:
             d_u, d_i, d_j = (capi.device_ptr(p) + 4 * lo for p in (d_u, d_i, d_j))
@@ -792,9 +791,10 @@ class NGCFTrainer:
             bound = min(3 * B, n)
             if self.batch_rows is None or self.batch_rows.capacity < bound:
                 self.batch_rows = capi.RowSubset(bound)
-            subset = capi.mark_compact_batch_rows(d_u, d_i, d_j, B, self.nu, n, self.row_mask, self.batch_rows, bound, stream)
+            subset = capi.mark_compact_batch_rows(d_u, d_i, d_j, B, self.nu, n, self.row_mask, self.batch_rows, bound, stream,
+                                                  d_zero8=self.d_loss, n_zero8=1)
         else:
-            self.row_mask.fill_bytes(0, stream)
+            self.row_mask.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
             if B:
                 capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)
         self.forward(True, masks, stream, last_rows=self.row_mask, last_subset=subset)
@@ -805,7 +805,6 @@ class NGCFTrainer:
             capi.zero_rows(self.dAll, self.wide_ld, subset, stream)
         else:
             self.dAll.fill_bytes(0, stream)
-        self.d_loss.fill_bytes(0, stream)
         if B:
             capi.bpr_batch_loss_grad(self.All, 1.0, self.nu, n, self.wide_ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
                                      self.dAll, self.d_loss, stream, d_row_mask=self.row_mask)
