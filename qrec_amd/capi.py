@@ -193,6 +193,12 @@ def init(device: int | None = None):
     global _initialised, _device
     if device is None:
         device = int(os.environ.get("QREC_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    # a launcher that pins one GPU per process (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES) leaves every rank with a
+    # single visible device, index 0, while LOCAL_RANK still counts up: take the rank's device modulo what is visible
+    n = C.c_int(0)
+    _check(load().qrec_device_count(C.byref(n)))
+    if n.value > 0 and device >= n.value:
+        device %= n.value
     _check(load().qrec_init(device))
     _initialised, _device = True, device
 
