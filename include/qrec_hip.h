@@ -249,13 +249,16 @@ int qrec_sumsq(const void *d_x, int dtype, int64_t rows, int32_t d, int32_t ld, 
  * written (Y, accum keep what they held) -- the last propagation layer of a training step is only read at the
  * batch's rows (embedding_lookup, LightGCN.py:22-24; qrec_mark_batch_rows builds the bitmap).
  * d_accum_init (may be NULL; needs d_accum): accum = accum_init + Y instead of accum += Y -- the first layer starts the
- * layer sum from the input table (LightGCN.py:15-19: all_embeddings = [ego_embeddings]), no copy before it.       */
+ * layer sum from the input table (LightGCN.py:15-19: all_embeddings = [ego_embeddings]), no copy before it.
+ * d_addend_row_mask (may be NULL; needs d_addend): bitmap of the rows at which the addend is defined; elsewhere it counts as
+ * zero and is not read -- the addend of the backward recurrences is the batch gradient, non-zero at the batch's rows only. */
 int qrec_spmm_csr(const int32_t *d_seg_row, const int64_t *d_seg_beg, const int32_t *d_seg_len,
                   const int32_t *d_seg_slot, int64_t n_segs, const int32_t *d_long_row,
                   const int32_t *d_long_first, const int32_t *d_long_count, int32_t n_long,
                   const int32_t *d_indices, const float *d_values, const float *d_X, float *d_Y,
                   float *d_partial, int32_t ld, const float *d_addend, float addend_scale, float *d_accum,
-                  const float *d_accum_init, const uint32_t *d_x_row_mask, const uint32_t *d_y_row_mask, void *stream);
+                  const float *d_accum_init, const uint32_t *d_x_row_mask, const uint32_t *d_y_row_mask,
+                  const uint32_t *d_addend_row_mask, void *stream);
 /* d_row_mask |= bits of rows u[b], n_users+i[b], n_users+j[b] (bitmap over the joint [U;V] row space; clear it first) */
 int qrec_mark_batch_rows(const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int32_t B, int32_t n_users,
                          uint32_t *d_row_mask, void *stream);

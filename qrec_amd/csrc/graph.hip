@@ -34,10 +34,12 @@ __device__ inline f32x4 ld_row4(const float *__restrict__ X, int row, int r) {
 template <int LPR>
 __device__ inline void spmm_epilogue(f32x4 acc, int row, int r, float *__restrict__ Y,
                                      const float *__restrict__ addend, float addend_scale,
-                                     float *__restrict__ accum, const float *__restrict__ accum_init) {
+                                     float *__restrict__ accum, const float *__restrict__ accum_init,
+                                     const uint32_t *__restrict__ addend_row_mask = nullptr) {
 #pragma clang fp contract(off)
     const int64_t off = (int64_t)row * (4 * LPR) + 4 * r;
-    if (addend) {
+    // addend_row_mask: the addend is only defined (and only non-zero) at the marked rows -- the batch gradient of a training step
+    if (addend && (!addend_row_mask || ((addend_row_mask[row >> 5] >> (row & 31)) & 1u))) {
         const f32x4 a = *reinterpret_cast<const f32x4 *>(addend + off);
         acc = acc + addend_scale * a;
     }
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(
     const int32_t *__restrict__ indices, const float *__restrict__ values,
     const float *__restrict__ X, float *__restrict__ Y, float *__restrict__ partial,
     const float *__restrict__ addend, float addend_scale, float *__restrict__ accum, const float *__restrict__ accum_init,
-    const uint32_t *__restrict__ x_row_mask, const uint32_t *__restrict__ y_row_mask) {
+    const uint32_t *__restrict__ x_row_mask, const uint32_t *__restrict__ y_row_mask, const uint32_t *__restrict__ addend_row_mask) {
 #pragma clang fp contract(off)
     constexpr int GPW = kWave / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(
             }
         }
         const int slot = seg_slot[s];
-        if (slot < 0) spmm_epilogue<LPR>(acc, seg_row[s], r, Y, addend, addend_scale, accum, accum_init);
+        if (slot < 0) spmm_epilogue<LPR>(acc, seg_row[s], r, Y, addend, addend_scale, accum, accum_init, addend_row_mask);
         else *reinterpret_cast<f32x4 *>(partial + (int64_t)slot * (4 * LPR) + 4 * r) = acc;
     }
 }
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restri
                                                          const float *__restrict__ partial, float *__restrict__ Y,
                                                          const float *__restrict__ addend, float addend_scale,
                                                          float *__restrict__ accum, const float *__restrict__ accum_init,
-                                                         const uint32_t *__restrict__ y_row_mask) {
+                                                         const uint32_t *__restrict__ y_row_mask, const uint32_t *__restrict__ addend_row_mask) {
 #pragma clang fp contract(off)
     constexpr int GPW = kWave / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restri
         acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
         acc.z += __shfl_xor(acc.z, m, kWave); acc.w += __shfl_xor(acc.w, m, kWave);
     }
-    if (g == 0) spmm_epilogue<LPR>(acc, long_row[wid], r, Y, addend, addend_scale, accum, accum_init);
+    if (g == 0) spmm_epilogue<LPR>(acc, long_row[wid], r, Y, addend, addend_scale, accum, accum_init, addend_row_mask);
 }
 
 // Bitmap of the rows a batch touches: users u, items n_users+i and n_users+j (the caller clears it first).  These
@@ -296,17 +298,17 @@ int launch_spmm(const int32_t *seg_row, const int64_t *seg_beg, const int32_t *s
                 int64_t n_segs, const int32_t *long_row, const int32_t *long_first, const int32_t *long_count,
                 int n_long, const int32_t *indices, const float *values, const float *X, float *Y, float *partial,
                 const float *addend, float addend_scale, float *accum, const float *accum_init, const uint32_t *x_row_mask,
-                const uint32_t *y_row_mask, hipStream_t st) {
+                const uint32_t *y_row_mask, const uint32_t *addend_row_mask, hipStream_t st) {
     constexpr int GPW = kWave / LPR;
     int64_t blocks = (n_segs + 4 * GPW - 1) / (4 * GPW);
     if (blocks > 256 * 8) blocks = 256 * 8;
     blocks = (blocks + 7) & ~(int64_t)7;     // a multiple of the 8 XCDs: segment p always lands on XCD (p / groups per block) % 8
     hipLaunchKernelGGL((spmm_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, seg_row, seg_beg, seg_len,
-                       seg_slot, n_segs, indices, values, X, Y, partial, addend, addend_scale, accum, accum_init, x_row_mask, y_row_mask);
+                       seg_slot, n_segs, indices, values, X, Y, partial, addend, addend_scale, accum, accum_init, x_row_mask, y_row_mask, addend_row_mask);
     QREC_LAUNCH_CHECK();
     if (n_long > 0) {
         hipLaunchKernelGGL((spmm_fixup_kernel<LPR>), dim3((unsigned)((n_long + 3) / 4)), dim3(256),
-                           0, st, long_row, long_first, long_count, n_long, partial, Y, addend, addend_scale, accum, accum_init, y_row_mask);
+                           0, st, long_row, long_first, long_count, n_long, partial, Y, addend, addend_scale, accum, accum_init, y_row_mask, addend_row_mask);
         QREC_LAUNCH_CHECK();
     }
     return QREC_OK;
@@ -369,17 +371,19 @@ int qrec_spmm_csr(const int32_t *d_seg_row, const int64_t *d_seg_beg, const int3
                   const int32_t *d_long_first, const int32_t *d_long_count, int32_t n_long,
                   const int32_t *d_indices, const float *d_values, const float *d_X, float *d_Y,
                   float *d_partial, int32_t ld, const float *d_addend, float addend_scale, float *d_accum,
-                  const float *d_accum_init, const uint32_t *d_x_row_mask, const uint32_t *d_y_row_mask, void *stream) {
+                  const float *d_accum_init, const uint32_t *d_x_row_mask, const uint32_t *d_y_row_mask,
+                  const uint32_t *d_addend_row_mask, void *stream) {
     QREC_REQUIRE(d_seg_row && d_seg_beg && d_seg_len && d_seg_slot && d_indices && d_values && d_X && d_Y,
                  "qrec_spmm_csr: null argument");
     QREC_REQUIRE(n_long == 0 || (d_long_row && d_long_first && d_long_count && d_partial), "qrec_spmm_csr: long-row plan incomplete");
     QREC_REQUIRE(d_X != d_Y, "qrec_spmm_csr: in-place SpMM is not supported (Y may alias addend, not X)");
     QREC_REQUIRE(!d_accum_init || d_accum, "qrec_spmm_csr: d_accum_init without d_accum");
+    QREC_REQUIRE(!d_addend_row_mask || d_addend, "qrec_spmm_csr: d_addend_row_mask without d_addend");
     if (n_segs == 0) return QREC_OK;
     hipStream_t st = as_stream(stream);
 #define QREC_SPMM(LPR) return launch_spmm<LPR>(d_seg_row, d_seg_beg, d_seg_len, d_seg_slot, n_segs, d_long_row, d_long_first, \
                                                d_long_count, n_long, d_indices, d_values, d_X, d_Y, d_partial, d_addend,       \
-                                               addend_scale, d_accum, d_accum_init, d_x_row_mask, d_y_row_mask, st)
+                                               addend_scale, d_accum, d_accum_init, d_x_row_mask, d_y_row_mask, d_addend_row_mask, st)
     switch (ld) {
         case 32: QREC_SPMM(8);
         case 64: QREC_SPMM(16);

@@ -213,6 +213,7 @@ class LightGCNTrainer:
         self.m, self.v, self.S, self.dE, self.A, self.B = z(), z(), z(), z(), z(), z()
         self.d_loss = DeviceBuffer.zeros(1, np.float64)
         self.row_mask = DeviceBuffer.zeros((self.n + 31) // 32, np.uint32)   # non-zero rows of the batch gradient
+        self.batch_rows = None  # capi.RowSubset: the same rows as a list
         self.t = 0
         f = np.float32
         self.b1, self.b2, self.adam_eps = f(0.9), f(0.999), f(1e-8)
@@ -240,7 +241,7 @@ class LightGCNTrainer:
             y = self.A if k % 2 == 0 else self.B
             # the first operand is the batch gradient itself: <= 3B non-zero rows, the rest is skipped
             capi.spmm_csr(self.plan, x, y, self.ld, d_addend=self.dE, addend_scale=1.0, stream=stream,
-                          d_x_row_mask=self.row_mask if k == 0 else None)
+                          d_x_row_mask=self.row_mask if k == 0 else None, d_addend_row_mask=self.row_mask)
             x = y
         return x
 
@@ -252,9 +253,15 @@ class LightGCNTrainer:
     def train_step_async(self, d_u, d_i, d_j, B: int, stream=None):
         """u/i/j: device pointers (int32[B]); enqueue only, read the loss with ``loss()``."""
         # one launch: the bitmap of the rows {u, nu+i, nu+j} of the batch, cleared first, and the loss accumulator cleared
-        capi.mark_compact_batch_rows(d_u, d_i, d_j, B, self.nu, self.n, self.row_mask, stream=stream, d_zero8=self.d_loss, n_zero8=1)
+        bound = min(3 * B, self.n)
+        if self.batch_rows is None or self.batch_rows.capacity < bound:
+            self.batch_rows = capi.RowSubset(bound)
+        subset = capi.mark_compact_batch_rows(d_u, d_i, d_j, B, self.nu, self.n, self.row_mask, self.batch_rows, bound, stream,
+                                              d_zero8=self.d_loss, n_zero8=1)
         self.forward_sum(stream, last_rows=self.row_mask)
-        self.dE.fill_bytes(0, stream)
+        # dE is written at the batch's rows (loss scatter) and read at the batch's rows only (operand mask of the first
+        # backward product, addend mask of all of them): clearing those ~6 k rows replaces a 17.8 MB fill
+        capi.zero_rows(self.dE, self.ld, subset, stream)
         if B:
             capi.bpr_batch_loss_grad(self.S, float(self.L + 1), self.nu, self.n, self.ld, d_u, d_i, d_j, B,
                                      self.loss_eps, self.reg, self.dE, self.d_loss, stream, d_row_mask=self.row_mask)
@@ -525,7 +532,7 @@ class SimGCLTrainer:
         subset = capi.mark_compact_batch_rows(d_u, d_i, d_j, B, self.nu, self.n, self.row_mask, self.batch_rows, bound, stream,
                                               d_zero8=self.d_loss, n_zero8=2)          # ... and both loss accumulators cleared
         self._encode_three(noises, stream, self.row_mask, subset)
-        self.dOut.fill_bytes(0, stream)
+        capi.zero_rows(self.dOut, self.ld, subset, stream)      # written and read at the batch's rows only (masks below)
         # the InfoNCE rows (unique batch users / positive items) are a subset of the rows marked above
         if share is not None:
             d_u, d_i, d_j = (capi.device_ptr(p) + 4 * lo for p in (d_u, d_i, d_j))
@@ -545,7 +552,7 @@ class SimGCLTrainer:
         for k in range(self.L - 1):
             y = self.A if k % 2 == 0 else self.B
             capi.spmm_csr(self.plan, x, y, self.ld, d_addend=self.dOut, addend_scale=1.0, stream=stream,
-                          d_x_row_mask=self.row_mask if k == 0 else None)      # operand = sparse batch gradient
+                          d_x_row_mask=self.row_mask if k == 0 else None, d_addend_row_mask=self.row_mask)   # operand = sparse batch gradient
             x = y
         g = self.B if x is self.A else self.A
         capi.spmm_csr(self.plan, x, g, self.ld, stream=stream, d_x_row_mask=self.row_mask if self.L == 1 else None)
@@ -812,15 +819,14 @@ class NGCFTrainer:
         for k in (1, 0):
             dE = self.dEa if k == 1 else self.dEb
             rows = subset if k == self.N_LAYERS - 1 else None
-            if rows is not None:
-                dE.fill_bytes(0, stream)        # written at the batch's rows only; the SpMM below adds to ALL rows of it
             capi.ngcf_layer_bwd(dnext, self.dAll, self.All, self.wide_ld, (k + 1) * d, self.inv[k], self.gate[k], self.E[k],
                                 self.side[k], self.W[k][0], self.W[k][1], n, d, ld, self.dpre, self.dside, dE, self.partial,
                                 self.gW[k][0], self.gW[k][1], stream, rows=rows, d_wide_row_mask=wide_mask)
             # dE += A^T dside.  For the last layer dside is non-zero only on the batch rows (its gradient
             # comes from the concat block alone), so that SpMM skips the other operand rows.
             capi.spmm_csr(self.plan, self.dside, dE, ld, d_addend=dE, addend_scale=1.0, stream=stream,
-                          d_x_row_mask=self.row_mask if k == 1 else None)
+                          d_x_row_mask=self.row_mask if k == 1 else None,
+                          d_addend_row_mask=self.row_mask if rows is not None else None)   # last layer: dE holds the batch's rows only
             dnext = dE
         capi.copy_cols(dnext, ld, self.dAll, self.wide_ld, 0, n, d, True, stream, rows=subset)          # + ego block of the concat
         if self.dp is not None:     # table gradient + the four d x d weight gradients ("all-reduce for the dense layers")
