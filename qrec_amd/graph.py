@@ -1013,12 +1013,11 @@ class SGLTrainer:
 
     def _forward(self, v, stream=None, last_rows=None):
         S = self.S[v]
-        S.copy_from(self.E, stream)
         x = self.E
         plans = self._view_plans(v)
         for k, plan in enumerate(plans):
             y = self.A if k % 2 == 0 else self.B
-            capi.spmm_csr(plan, x, y, self.ld, d_accum=S, stream=stream,
+            capi.spmm_csr(plan, x, y, self.ld, d_accum=S, stream=stream, d_accum_init=self.E if k == 0 else None,   # S = E + M_1 E: no copy
                           d_y_row_mask=last_rows if k == len(plans) - 1 else None)   # last layer: batch rows only
             x = y
 
@@ -1033,7 +1032,7 @@ class SGLTrainer:
             last = (k == 0)
             y = self.A if step % 2 == 0 else self.B
             capi.spmm_csr(plans[k], x, y, self.ld, d_addend=d, addend_scale=1.0, d_accum=self.G if last else None,
-                          stream=stream, d_x_row_mask=self.row_mask if step == 0 else None)
+                          stream=stream, d_x_row_mask=self.row_mask if step == 0 else None, d_addend_row_mask=self.row_mask)
             x = y
 
     def train_step_async(self, d_u, d_i, d_j, B: int, d_rows, n_rows: int, stream=None, share=None):
@@ -1048,12 +1047,17 @@ class SGLTrainer:
         div = float(self.L + 1)
         dp = getattr(self, "dp", None)
         lo, cnt = (0, B) if share is None else share
-        self.row_mask.fill_bytes(0, stream)
-        capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)
+        # the batch's rows as bitmap + list (one launch, loss accumulators cleared with it): the three output gradients are written
+        # and read at those rows only (operand / addend masks of the backward products), so only those rows are cleared
+        bound = min(3 * B, self.n)
+        if getattr(self, "batch_rows", None) is None or self.batch_rows.capacity < bound:
+            self.batch_rows = capi.RowSubset(bound)
+        subset = capi.mark_compact_batch_rows(d_u, d_i, d_j, B, self.nu, self.n, self.row_mask, self.batch_rows, bound, stream,
+                                              d_zero8=self.d_loss, n_zero8=2)
         for v in range(3):
             self._forward(v, stream, last_rows=self.row_mask)
-            self.dOut[v].fill_bytes(0, stream)
-        self.G.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
+            capi.zero_rows(self.dOut[v], self.ld, subset, stream)
+        self.G.fill_bytes(0, stream)
         if share is not None:
             d_u, d_i, d_j = (capi.device_ptr(p) + 4 * lo for p in (d_u, d_i, d_j))
         if cnt:
