@@ -1129,11 +1129,13 @@ class BUIRTrainer:
 
     def _mean_sum(self, plan, X, S, stream=None, last_rows=None):
         """S = X + A X + ... + A^L X (the mean's 1/(L+1) is applied where S is used)"""
-        S.copy_from(X, stream)
+        if self.L == 0:
+            S.copy_from(X, stream)
         x = X
         for k in range(self.L):
             y = self.A if k % 2 == 0 else self.B
-            capi.spmm_csr(plan, x, y, self.ld, d_accum=S, stream=stream, d_y_row_mask=last_rows if k == self.L - 1 else None)
+            capi.spmm_csr(plan, x, y, self.ld, d_accum=S, stream=stream, d_accum_init=X if k == 0 else None,    # S = X + A X: no copy
+                          d_y_row_mask=last_rows if k == self.L - 1 else None)
             x = y
 
     def train_step_async(self, d_u, d_i, B: int, stream=None):
@@ -1143,11 +1145,16 @@ class BUIRTrainer:
             self.Xb, self.Gb = DeviceBuffer((2 * B, self.ld), np.float32), DeviceBuffer((2 * B, self.ld), np.float32)
             self._cap = B
         div = float(self.L + 1)
-        self.row_mask.fill_bytes(0, stream)
-        capi.mark_batch_rows(d_u, d_i, d_i, B, self.nu, self.row_mask, stream)           # rows {u, nu+i}
+        # rows {u, nu+i} of the batch as bitmap + list, loss accumulator cleared by the same launch; dS is written and read at
+        # those rows only (operand / addend masks below), so only those rows are cleared
+        bound = min(2 * B, self.n)
+        if getattr(self, "batch_rows", None) is None or self.batch_rows.capacity < bound:
+            self.batch_rows = capi.RowSubset(max(bound, 1))
+        subset = capi.mark_compact_batch_rows(d_u, d_i, d_i, B, self.nu, self.n, self.row_mask, self.batch_rows, bound, stream,
+                                              d_zero8=self.d_loss, n_zero8=1)
         self._mean_sum(self.plan_o, self.E, self.S_on, stream, self.row_mask)
         self._mean_sum(self.plan_t, self.T, self.S_tar, stream, self.row_mask)
-        self.dS.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
+        capi.zero_rows(self.dS, self.ld, subset, stream)
         capi.buir_batch_loss_grad(self.S_on, self.S_tar, div, self.nu, self.ld, self.W, self.b, d_u, d_i, B, self.dS, self.Xb,
                                   self.Gb, self.d_loss, stream)
         if B:
@@ -1159,7 +1166,7 @@ class BUIRTrainer:
         for k in range(self.L):
             y = self.A if k % 2 == 0 else self.B
             capi.spmm_csr(self.plan_o, x, y, self.ld, d_addend=self.dS, addend_scale=1.0, stream=stream,
-                          d_x_row_mask=self.row_mask if k == 0 else None)
+                          d_x_row_mask=self.row_mask if k == 0 else None, d_addend_row_mask=self.row_mask)
             x = y
         dp = getattr(self, "dp", None)
         if dp is not None:      # every term is a sum over the step's pairs: the ranks' shares add up
