@@ -631,3 +631,83 @@ def test_spmm_plan_deals_classes_to_xcds():
             assert np.array_equal(deal[slots[:k]], ents[:k])
         # balanced classes: nearly every position holds its own class
         assert (cls[deal] == pos_cls).mean() > 0.9
+
+
+def _fake_device_buffers(monkeypatch):
+    """SpmmPlan's host logic without a device: DeviceBuffer.from_numpy keeps the array"""
+    import qrec_amd.graph as G
+
+    class Held:
+        def __init__(self, shape=None, dtype=None):
+            self.host = None
+        @classmethod
+        def from_numpy(cls, a):
+            b = cls(); b.host = np.array(a, copy=True); return b
+    monkeypatch.setattr(G, "DeviceBuffer", Held)
+    return G
+
+
+def test_spmm_plan_covers_every_non_zero_once(monkeypatch):
+    """SpmmPlan (host side of qrec_spmm_csr): the segments tile every row's non-zeros exactly once in order, rows longer than
+    seg_len are cut into slices with consecutive partial slots, empty rows get one empty segment, and the XCD-aware orders
+    (operand side, spectral row chunks, a reused row -> chunk map) are permutations of the same segment set."""
+    G = _fake_device_buffers(monkeypatch)
+    from qrec_amd.synth import make_dataset
+    d = make_dataset("small")
+    nu, ni = d["n_users"], d["n_items"]
+    adj = G.joint_norm_adjacency(nu, ni, d["train_u"], d["train_i"])
+    indptr = adj[0]
+    nnz_row = np.diff(indptr)
+
+    def segments(plan):
+        return sorted(zip(plan.seg_row.host.tolist(), plan.seg_beg.host.tolist(), plan.seg_len.host.tolist(), plan.seg_slot.host.tolist()))
+
+    base = None
+    for seg_len, kw in ((128, {}), (7, {}), (7, dict(split_row=nu, chunks=1)), (7, dict(split_row=nu, chunks=4)), (128, dict(split_row=nu, chunks=2))):
+        plan = G.SpmmPlan(adj[0], adj[1], adj[2], 64, seg_len=seg_len, **kw)
+        segs = segments(plan)
+        cover = np.zeros(adj[1].size, np.int32)
+        per_row = {}
+        for row, beg, ln, slot in segs:
+            assert 0 <= ln <= seg_len and indptr[row] <= beg and beg + ln <= indptr[row + 1]
+            cover[beg:beg + ln] += 1
+            per_row.setdefault(row, []).append((beg, ln, slot))
+        assert (cover == 1).all() and len(per_row) == nnz_row.size                     # every non-zero once, every row present
+        for row, parts in per_row.items():
+            if nnz_row[row] <= seg_len:
+                assert len(parts) == 1 and parts[0][2] == -1
+            else:                                                                       # consecutive slices, consecutive slots
+                assert [p[0] for p in parts] == list(range(int(indptr[row]), int(indptr[row + 1]), seg_len))
+                assert [p[2] for p in parts] == list(range(parts[0][2], parts[0][2] + len(parts)))
+        if seg_len == 7:
+            base = segs if base is None else base
+            assert segs == base                                                         # the orders differ, the segments do not
+    main = G.SpmmPlan(adj[0], adj[1], adj[2], 64, split_row=nu, chunks=4)
+    again = G.SpmmPlan(adj[0], adj[1], adj[2], 64, split_row=nu, row_chunk=main.row_chunk)
+    assert again.chunks == 4 and np.array_equal(again.seg_row.host, main.seg_row.host)  # the reused map gives the same order
+    with pytest.raises(ValueError):
+        G.SpmmPlan(adj[0], adj[1], adj[2], 64, chunks=2)
+
+
+def test_spectral_row_key_lines_up_planted_communities():
+    """qrec_amd.graph.spectral_row_key + SpmmPlan._row_chunks: on a graph with planted communities the rows of one community
+    land in the same run and most non-zeros stay inside a run (user run = item run); on a structureless graph the runs are
+    still balanced in non-zeros.  qrec_amd.synth.gen_edges_clustered is what the locality measurements use."""
+    from qrec_amd.graph import SpmmPlan, joint_norm_adjacency
+    from qrec_amd.synth import gen_edges, gen_edges_clustered
+    nu, ni, E = 3000, 3600, 120000
+    for gen, floor in ((gen_edges_clustered, 0.7), (gen_edges, 0.0)):
+        kw = dict(n_clusters=8) if gen is gen_edges_clustered else {}
+        u, i = gen(nu, ni, E, 5, **kw)
+        assert np.unique(u * ni + i).size == E and np.unique(u).size == nu and np.unique(i).size == ni    # distinct pairs, full coverage
+        u2, i2 = gen(nu, ni, E, 5, **kw)
+        assert np.array_equal(u, u2) and np.array_equal(i, i2)                                               # deterministic
+        adj = joint_norm_adjacency(nu, ni, u, i)
+        ch = SpmmPlan._row_chunks(adj[0], adj[1], adj[2], nu, 2)
+        rows = np.repeat(np.arange(nu + ni), np.diff(adj[0]))
+        same = (ch[rows] == ch[adj[1]]).mean()
+        assert same > floor, (gen.__name__, same)
+        nnz_row = np.diff(adj[0])
+        for lo, hi in ((0, nu), (nu, nu + ni)):
+            per = [nnz_row[lo:hi][ch[lo:hi] == c].sum() for c in (0, 1)]
+            assert abs(per[0] - per[1]) <= 0.02 * sum(per) + nnz_row.max()
