@@ -742,18 +742,146 @@ __global__ __launch_bounds__(256, OCC) void score_filter2_kernel_f32(
 
 // (C) one wavefront per user: gather the candidates of the user's lists into LDS, take the K+1 largest by repeated
 // wave-wide maximum of (score, lower id first); flag ties among them / overflow / tau <= 0.
+// ---- (B') the scoring pass as a bf16 FILTER ------------------------------------------------------------------------------
+// The pass only has to find every item whose fp32 score reaches tau; the scores themselves are re-formed afterwards (select
+// kernel, the SAME fp32 MFMA sequence as score_kernel_f32, so ids and scores stay bit-identical to the block route).  So it
+// runs on bf16 copies of the two tables -- v_mfma_f32_32x32x16_bf16: 1/16 of the matrix-pipe time of the f32 form, half the
+// operand bytes -- against a threshold lowered by a bound on what the rounding can cost a score:
+//   u^ = u (1 + d), |d| <= 2^-8 (round to nearest, 8-bit significand), same for v  =>  |u^.v^ - u.v| <= (2^-7 + 2^-16) sum |u_k v_k|
+//   <= (2^-7 + 2^-16) |u| |v|;  the fp32 accumulation inside the MFMAs adds < 64 * 2^-24 of the same sum.
+// eps[b] = 2^-7 * 1.02 * |u_b| * max_items |v| -- every item with u.v >= tau has u^.v^ >= tau - eps.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+// rows [rows][ld] fp32 (row_ids: gather, may be null) -> bf16 copy [rows][ld]; norm[row] = |x| (fp32); pad rows (>= rows) zero
+template <int LPR>
+__global__ __launch_bounds__(256) void to_bf16_kernel(const float *__restrict__ X, const int32_t *__restrict__ row_ids, int rows, int rows_pad,
+                                                      __bf16 *__restrict__ out, float *__restrict__ norm, float *__restrict__ norm_max) {
+    constexpr int GPW = kWave / LPR;
+    const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
+    const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
+    if (k >= rows_pad) return;
+    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+    if (k < rows) x = *reinterpret_cast<const f32x4 *>(X + (int64_t)(row_ids ? row_ids[k] : k) * (4 * LPR) + 4 * r);
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    bf16x4 o = {(__bf16)x.x, (__bf16)x.y, (__bf16)x.z, (__bf16)x.w};
+    *reinterpret_cast<bf16x4 *>(out + k * (4 * LPR) + 4 * r) = o;
+    float ss = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+    ss = row_allreduce_sum<LPR>(ss);
+    if (r == 0) {
+        const float nrm = sqrtf(ss) * 1.0001f;
+        if (norm) norm[k] = nrm;
+        if (norm_max && k < rows) atomicMax(reinterpret_cast<int *>(norm_max), __float_as_int(nrm));      // non-negative floats order as ints
+    }
+}
+
+__global__ __launch_bounds__(256) void lowered_tau_kernel(const float *__restrict__ tau, const float *__restrict__ u_norm,
+                                                          const float *__restrict__ v_norm_max, int n_b, float *__restrict__ tau_low) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n_b) tau_low[b] = tau[b] - 0x1p-7f * 1.02f * u_norm[b] * *v_norm_max;
+}
+
+// score_filter2_kernel_f32's loop on the bf16 copies: NM = ld / 16 MFMAs per 32 x 32 tile (lane (r, h): columns 16 m + 8 h .. + 8 of
+// its row); what reaches the LOWERED threshold goes to the lane-private lists as an id (its approximate score only for inspection)
+template <int NM>
+__global__ __launch_bounds__(256, 2) void score_filter_bf16_kernel(
+    const __bf16 *__restrict__ Ub, const __bf16 *__restrict__ Vb, int n_items, int n_b, const float *__restrict__ tau_low, int n_lists,
+    float *__restrict__ cand_s, int32_t *__restrict__ cand_i, int32_t *__restrict__ cand_n) {
+    constexpr int LD = 16 * NM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int upair = blockIdx.x;
+    const int b0 = upair * 64 + r, b1 = b0 + 32;
+    const int list = (blockIdx.y * 4 + wave) * 2 + h;
+    const int n_item_tiles = (n_items + 31) / 32;
+    const int t_step = gridDim.y * 4;
+    const int t_begin = blockIdx.y * 4 + wave, t_end = n_item_tiles;
+    const bool live0 = b0 < n_b, live1 = b1 < n_b;
+    int cnt0 = 0, cnt1 = 0;
+    if (t_begin < t_end) {
+        const float th0 = live0 ? tau_low[b0] : __builtin_huge_valf(), th1 = live1 ? tau_low[b1] : __builtin_huge_valf();
+        bf16x8 ua[NM], ub[NM];                       // Ub is padded to whole 64-user pairs (zero rows)
+#pragma unroll
+        for (int m = 0; m < NM; m++) {
+            ua[m] = *reinterpret_cast<const bf16x8 *>(Ub + (int64_t)b0 * LD + 16 * m + 8 * h);
+            ub[m] = *reinterpret_cast<const bf16x8 *>(Ub + (int64_t)b1 * LD + 16 * m + 8 * h);
+        }
+        auto load_tile = [&](int t, bf16x8 (&dst)[NM]) {          // Vb is padded to whole 32-item tiles (zero rows)
+            const __bf16 *row = Vb + (int64_t)(t * 32 + r) * LD + 8 * h;
+#pragma unroll
+            for (int m = 0; m < NM; m++) dst[m] = *reinterpret_cast<const bf16x8 *>(row + 16 * m);
+        };
+        float *cs0 = cand_s + ((int64_t)b0 * n_lists + list) * kListCap, *cs1 = cand_s + ((int64_t)b1 * n_lists + list) * kListCap;
+        int32_t *ci0 = cand_i + ((int64_t)b0 * n_lists + list) * kListCap, *ci1 = cand_i + ((int64_t)b1 * n_lists + list) * kListCap;
+        auto do_tile = [&](int t, const bf16x8 (&v)[NM]) {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int q = 0; q < 16; q++) { acc0[q] = 0.f; acc1[q] = 0.f; }
+#pragma unroll
+            for (int m = 0; m < NM; m++) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[m], ua[m], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[m], ub[m], acc1, 0, 0, 0);
+            }
+            const int item_base = t * 32 + 4 * h;
+            if (t * 32 + 32 > n_items) {              // the last, partial tile: pad rows are zero vectors, score 0 -- never candidates
+#pragma unroll
+                for (int q = 0; q < 16; q++)
+                    if (item_base + (q & 3) + 8 * (q >> 2) >= n_items) { acc0[q] = -__builtin_huge_valf(); acc1[q] = -__builtin_huge_valf(); }
+            }
+            float m0 = acc0[0], m1 = acc1[0];
+#pragma unroll
+            for (int q = 1; q < 16; q++) { m0 = fmaxf(m0, acc0[q]); m1 = fmaxf(m1, acc1[q]); }
+            if (m0 >= th0) {
+#pragma unroll
+                for (int q = 0; q < 16; q++)
+                    if (acc0[q] >= th0) {
+                        if (cnt0 < kListCap) { cs0[cnt0] = acc0[q]; ci0[cnt0] = item_base + (q & 3) + 8 * (q >> 2); }
+                        cnt0++;
+                    }
+            }
+            if (m1 >= th1) {
+#pragma unroll
+                for (int q = 0; q < 16; q++)
+                    if (acc1[q] >= th1) {
+                        if (cnt1 < kListCap) { cs1[cnt1] = acc1[q]; ci1[cnt1] = item_base + (q & 3) + 8 * (q >> 2); }
+                        cnt1++;
+                    }
+            }
+        };
+        bf16x8 va[NM], vb[NM];
+        load_tile(t_begin, va);
+        int t = t_begin;
+        while (true) {
+            if (t + t_step < t_end) load_tile(t + t_step, vb);
+            do_tile(t, va);
+            t += t_step;
+            if (t >= t_end) break;
+            if (t + t_step < t_end) load_tile(t + t_step, va);
+            do_tile(t, vb);
+            t += t_step;
+            if (t >= t_end) break;
+        }
+    }
+    if (live0) cand_n[(int64_t)b0 * n_lists + list] = cnt0;
+    if (live1) cand_n[(int64_t)b1 * n_lists + list] = cnt1;
+}
+
 constexpr int kSelectWaves = 4;
+template <int NC>       // column chunks of 64 in the re-scoring (ld <= 64: 1, ld = 128: 2)
 __global__ __launch_bounds__(64 * kSelectWaves) void select_topk_kernel(
     const float *__restrict__ cand_s, const int32_t *__restrict__ cand_i, const int32_t *__restrict__ cand_n, int n_lists,
     const float *__restrict__ tau, const int32_t *__restrict__ user_ids, const int64_t *__restrict__ rated_indptr,
     const int32_t *__restrict__ rated_sorted, int n_b, int K, int32_t *__restrict__ ids_out, float *__restrict__ scores_out,
-    int32_t *__restrict__ flags, int32_t *__restrict__ n_flagged, int32_t *__restrict__ flagged_list) {
+    int32_t *__restrict__ flags, int32_t *__restrict__ n_flagged, int32_t *__restrict__ flagged_list,
+    const float *__restrict__ U, const float *__restrict__ V, int ld, int pool_cap, const float *__restrict__ tau_low) {
+    // pool_cap: LDS entries per user (a user with more candidates is flagged and redone exactly); the lists' worst case,
+    // n_lists * kListCap, would leave one wavefront per SIMD.
+    // U != null: the candidates come from the bf16 filter -- their fp32 scores are formed here, by the MFMA sequence of
+    // score_kernel_f32 (32 candidates as the item rows of a tile, the user's row broadcast over its 32 columns)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * kSelectWaves + wave;
     if (b >= n_b) return;                                         // whole wavefront
-    const int cap_total = n_lists * kListCap;
-    unsigned long long *pool = reinterpret_cast<unsigned long long *>(smem) + (int64_t)wave * cap_total;
+    unsigned long long *pool = reinterpret_cast<unsigned long long *>(smem) + (int64_t)wave * pool_cap;
     // key: score mapped to an order-preserving unsigned, then ~id so that among equal scores the LOWER id is larger
     auto key_of = [](float s, int32_t id) {
         unsigned u = __float_as_uint(s);
@@ -777,10 +905,11 @@ __global__ __launch_bounds__(64 * kSelectWaves) void select_topk_kernel(
         const int off = total + inc - n;
         for (int c = 0; c < n; c++) {
             const int64_t at = ((int64_t)b * n_lists + l) * kListCap + c;
-            pool[off + c] = key_of(cand_s[at], cand_i[at]);
+            if (off + c < pool_cap) pool[off + c] = key_of(cand_s[at], cand_i[at]);
         }
         total += __shfl(inc, 63, 64);
     }
+    if (total > pool_cap) { bad = true; total = pool_cap; }
     // rated items are masked to 0 < tau: not candidates.  The lists are uneven, the pool is not: every lane bisects its
     // share of the pool (a few elements each)
     for (int e = lane; e < total; e += 64) {
@@ -793,6 +922,104 @@ __global__ __launch_bounds__(64 * kSelectWaves) void select_topk_kernel(
         const bool rated = lo < rend && rated_sorted[lo] == item;
         if (rated) pool[e] = 0ull;
         kept += rated ? 0 : 1;
+    }
+    if (U) {
+        // Which candidates can still be among the N + 1 best?  Their bf16 scores s^ are within eps of the fp32 scores.  Let L be
+        // the (N+1)-th largest s^: N + 1 candidates have fp32 scores >= L - eps, so the fp32 (N+1)-th best is >= L - eps and a
+        // candidate with s^ < L - 2 eps (fp32 score < L - eps) is out.  Only the others are re-scored: ~30 of ~250.
+        const float eps = (tau[b] - tau_low[b]) * 1.01f;
+        const int Mq = K + 1;
+        unsigned long long below = ~0ull;
+        for (int rank = 0; rank < Mq; rank++) {                    // the Mq-th largest key, non-destructively
+            unsigned long long best = 0;
+            for (int e = lane; e < total; e += 64) {
+                const unsigned long long k = pool[e];
+                if (k < below && k > best) best = k;
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const unsigned long long o = __shfl_xor(best, m, 64);
+                best = o > best ? o : best;
+            }
+            below = best;
+            if (!best) break;                                      // fewer than Mq candidates (only after an overflow)
+        }
+        if (below) {
+            unsigned ub_ = (unsigned)(below >> 32);
+            ub_ = (ub_ & 0x80000000u) ? (ub_ & 0x7fffffffu) : ~ub_;
+            const float cut = __uint_as_float(ub_) - 2.f * eps;
+            const unsigned long long cut_key = key_of(cut, 0x7fffffff);          // the smallest key with that score
+            int n_keep = 0;
+            for (int e0 = 0; e0 < total; e0 += 64) {               // in-place forward compaction, chunk by chunk
+                const int e = e0 + lane;
+                const unsigned long long k = e < total ? pool[e] : 0ull;
+                const bool keep = k != 0ull && k >= cut_key;
+                const unsigned long long mask = __ballot(keep);
+                const int pos = n_keep + __popcll(mask & ((1ull << lane) - 1ull));
+                if (keep) pool[pos] = k;                           // pos <= e: never ahead of what is still to be read
+                n_keep += __popcll(mask);
+            }
+            total = n_keep;
+            kept = lane == 0 ? n_keep : 0;                         // survivors are unrated: the count the checks below sum up
+        }
+        const int r = lane & 31, h = lane >> 5;
+        const int64_t uid = user_ids[b];
+        f32x4 uu[NC][8];                                           // the user's operand: the same for every tile
+        int kbs[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int col0 = 64 * c + 32 * h;
+            const bool kv = col0 < ld;
+            kbs[c] = kv ? col0 : 0;
+            const float keep = kv ? 1.f : 0.f;
+            const f32x4 *pu = reinterpret_cast<const f32x4 *>(U + uid * ld + kbs[c]);
+#pragma unroll
+            for (int q = 0; q < 8; q++) uu[c][q] = pu[q] * keep;
+        }
+        auto item_of = [&](int e) -> int64_t {
+            const unsigned long long k = e < total ? pool[e] : 0ull;
+            return k ? (int64_t)(0x7fffffff - (int32_t)(unsigned)(k & 0xffffffffu)) : 0;
+        };
+        auto load_rows = [&](int64_t item, f32x4 (&dst)[NC][8]) {
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const f32x4 *pv = reinterpret_cast<const f32x4 *>(V + item * ld + kbs[c]);
+#pragma unroll
+                for (int q = 0; q < 8; q++) dst[c][q] = pv[q];
+            }
+        };
+        f32x4 vv[NC][8], vn[NC][8];
+        load_rows(item_of(r), vv);
+        for (int e0 = 0; e0 < total; e0 += 32) {
+            if (e0 + 32 < total) load_rows(item_of(e0 + 32 + r), vn);        // the next tile's rows under this tile's MFMAs
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[q] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; c++)                                // the operand walk of score_kernel_f32, term for term
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[c][q].x, uu[c][q].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[c][q].y, uu[c][q].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[c][q].z, uu[c][q].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[c][q].w, uu[c][q].w, acc, 0, 0, 0);
+                }
+            // every column of the tile is this user: lanes 0 and 32 hold the 32 rows between them
+            if (r == 0) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int ee = e0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                    if (ee < total) {
+                        const unsigned long long old = pool[ee];
+                        if (old) pool[ee] = key_of(acc[q], 0x7fffffff - (int32_t)(unsigned)(old & 0xffffffffu));
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int q = 0; q < 8; q++) vv[c][q] = vn[c][q];
+        }
     }
     bad = __any(bad);
 #pragma unroll
@@ -1075,7 +1302,7 @@ __global__ __launch_bounds__(256) void threshold_var_kernel(const float *__restr
 
 struct FusedGeom {
     int b_pad, n_utiles, n_item_tiles, grid_y, n_lists, n_s_tiles, n_s, fb_users;
-    size_t off_gmax, off_garg, off_tau, off_cs, off_ci, off_cn, off_flags, off_list, off_nf, off_fbu, off_fbi, off_fbs, off_fb, total;
+    size_t off_ub, off_vb, off_un, off_vmax, off_taul, off_gmax, off_garg, off_tau, off_cs, off_ci, off_cn, off_flags, off_list, off_nf, off_fbu, off_fbi, off_fbs, off_fb, total;
 };
 __host__ inline bool fused_ok(int dtype, int ld, int n_items, int K) {
     // one predicate for the scratch-size query and the launch (QREC_EVAL_BLOCK_PATH forces the block route in both)
@@ -1086,7 +1313,7 @@ __host__ inline size_t block_path_bytes(size_t elem, int n_items, int n_b) {
     return score_block_bytes(elem, n_items, n_b) + (size_t)(kGroups + 1) * b_pad * elem + (size_t)kSlices * kSliceCap * b_pad * (elem + 4) +
            (size_t)(kSlices + 2) * b_pad * 4 + 64;
 }
-__host__ inline FusedGeom fused_geometry(int n_items, int n_b) {
+__host__ inline FusedGeom fused_geometry(int n_items, int n_b, int ld) {
     FusedGeom g;
     g.b_pad = (n_b + 63) / 64 * 64;
     g.n_utiles = (n_b + 63) / 64;
@@ -1105,6 +1332,11 @@ __host__ inline FusedGeom fused_geometry(int n_items, int n_b) {
     g.fb_users = (g.fb_users + 63) / 64 * 64;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     size_t o = 0;
+    g.off_ub = o; o += up((size_t)g.b_pad * ld * 2);                          // bf16 copies of the batch's user rows and of the items
+    g.off_vb = o; o += up((size_t)g.n_item_tiles * 32 * ld * 2);
+    g.off_un = o; o += up((size_t)g.b_pad * 4);
+    g.off_vmax = o; o += 256;
+    g.off_taul = o; o += up((size_t)g.b_pad * 4);
     g.off_gmax = o; o += up((size_t)kMaxGroups * g.b_pad * 4);
     g.off_garg = o; o += up((size_t)kMaxGroups * g.b_pad * 4);
     g.off_tau = o; o += up((size_t)g.b_pad * 4);
@@ -1125,7 +1357,7 @@ __host__ inline FusedGeom fused_geometry(int n_items, int n_b) {
 int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_items, const int32_t *user_ids, int n_b,
                        const int64_t *rated_indptr, const int32_t *rated_sorted, int K, void *scratch, int32_t *ids_out,
                        float *scores_out, hipStream_t st) {
-    const FusedGeom g = fused_geometry(n_items, n_b);
+    const FusedGeom g = fused_geometry(n_items, n_b, ld);
     unsigned char *base = static_cast<unsigned char *>(scratch);
     float *gmax = reinterpret_cast<float *>(base + g.off_gmax), *tau = reinterpret_cast<float *>(base + g.off_tau);
     float *cand_s = reinterpret_cast<float *>(base + g.off_cs);
@@ -1167,18 +1399,49 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
     // tools/ubench/mfma_tile.hip; thresholds at +inf (no element ever appended) 1.66: the pass is bound by the per-lane-row
     // operand fetch interleaved with the accumulator read-out, not by the compare / append work
     const dim3 grid((unsigned)g.n_utiles, (unsigned)g.grid_y);
-    if (ld <= 64)
+    static const bool bf16_filter = getenv("QREC_EVAL_F32_FILTER") == nullptr && true;
+    const bool use_bf16 = bf16_filter && (ld == 32 || ld == 64 || ld == 128);
+    if (use_bf16) {
+        // (B') bf16 copies (the batch's user rows gathered), the lowered thresholds, the filter on v_mfma_f32_32x32x16_bf16
+        __bf16 *Ub = reinterpret_cast<__bf16 *>(base + g.off_ub), *Vb = reinterpret_cast<__bf16 *>(base + g.off_vb);
+        float *u_norm = reinterpret_cast<float *>(base + g.off_un), *v_max = reinterpret_cast<float *>(base + g.off_vmax);
+        float *tau_low = reinterpret_cast<float *>(base + g.off_taul);
+        QREC_HIP_CHECK(hipMemsetAsync(v_max, 0, sizeof(float), st));
+        const int v_rows_pad = g.n_item_tiles * 32;
+#define QREC_BF(LPR, NM)                                                                                                              \
+        hipLaunchKernelGGL((to_bf16_kernel<LPR>), dim3((unsigned)((g.b_pad + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), dim3(256), 0, st, U,   \
+                           user_ids, n_b, g.b_pad, Ub, u_norm, (float *)nullptr);                                                     \
+        hipLaunchKernelGGL((to_bf16_kernel<LPR>), dim3((unsigned)((v_rows_pad + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), dim3(256), 0, st, V, \
+                           (const int32_t *)nullptr, n_items, v_rows_pad, Vb, (float *)nullptr, v_max);                               \
+        hipLaunchKernelGGL(lowered_tau_kernel, dim3((unsigned)((n_b + 255) / 256)), dim3(256), 0, st, tau, u_norm, v_max, n_b, tau_low); \
+        hipLaunchKernelGGL((score_filter_bf16_kernel<NM>), grid, dim3(256), 0, st, Ub, Vb, n_items, n_b, tau_low, g.n_lists, cand_s, cand_i, cand_n)
+        if (ld == 32) { QREC_BF(8, 2); } else if (ld == 64) { QREC_BF(16, 4); } else { QREC_BF(32, 8); }
+#undef QREC_BF
+    } else if (ld <= 64)
         hipLaunchKernelGGL((score_filter2_kernel_f32<1, 2>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, 0, tau, g.n_lists,
                            cand_s, cand_i, cand_n);
     else
         hipLaunchKernelGGL((score_filter2_kernel_f32<2, 1>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, 0, tau, g.n_lists,
                            cand_s, cand_i, cand_n);
     QREC_LAUNCH_CHECK();
-    const size_t lds = (size_t)kSelectWaves * g.n_lists * kListCap * sizeof(unsigned long long);
-    QREC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)((n_b + kSelectWaves - 1) / kSelectWaves)), dim3(64 * kSelectWaves), lds, st, cand_s,
-                       cand_i, cand_n, g.n_lists, tau, user_ids, rated_indptr, rated_sorted, n_b, K, ids_out, scores_out, flags, n_flagged,
-                       flagged_list);
+    // candidates per user: ~ (N + 1) * kSampleStride * 1.1, times ~1.4 behind the bf16 filter; the pool holds 4x that
+    int pool_cap = g.n_lists * kListCap;
+    const int want = 4 * (int)((K + 1) * kSampleStride * 1.6);
+    if (pool_cap > want) pool_cap = want < 256 ? 256 : want;
+    const size_t lds = (size_t)kSelectWaves * pool_cap * sizeof(unsigned long long);
+    const dim3 sgrid((unsigned)((n_b + kSelectWaves - 1) / kSelectWaves));
+    const float *Ur = use_bf16 ? U : (const float *)nullptr;
+    if (ld <= 64) {
+        QREC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_topk_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(select_topk_kernel<1>, sgrid, dim3(64 * kSelectWaves), lds, st, cand_s, cand_i, cand_n, g.n_lists, tau, user_ids, rated_indptr,
+                           rated_sorted, n_b, K, ids_out, scores_out, flags, n_flagged, flagged_list, Ur, V, ld, pool_cap,
+                           reinterpret_cast<const float *>(base + g.off_taul));
+    } else {
+        QREC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_topk_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(select_topk_kernel<2>, sgrid, dim3(64 * kSelectWaves), lds, st, cand_s, cand_i, cand_n, g.n_lists, tau, user_ids, rated_indptr,
+                           rated_sorted, n_b, K, ids_out, scores_out, flags, n_flagged, flagged_list, Ur, V, ld, pool_cap,
+                           reinterpret_cast<const float *>(base + g.off_taul));
+    }
     QREC_LAUNCH_CHECK();
     // (D) users whose heap history matters: the block path, fb_users at a time
     int32_t h_nf = 0;
@@ -1258,7 +1521,7 @@ int qrec_score_topk_scratch_bytes(int dtype, int32_t n_items, int32_t n_batch_us
     QREC_REQUIRE(dtype == QREC_F32 || dtype == QREC_F64, "qrec_score_topk_scratch_bytes: bad dtype %d", dtype);
     if (fused_ok(dtype, ld, n_items, K) && n_batch_users > 0) {
         // fused path: the sampled block (1/8), candidate lists, and a block-path scratch for the flagged users' rounds
-        *bytes = (int64_t)fused_geometry(n_items, n_batch_users).total;
+        *bytes = (int64_t)fused_geometry(n_items, n_batch_users, ld).total;
         return QREC_OK;
     }
     // the transposed score block, then the sliced top-N's candidates (scores + ids), flags, flagged list, counter
