@@ -780,71 +780,186 @@ __global__ __launch_bounds__(256) void lowered_tau_kernel(const float *__restric
     if (b < n_b) tau_low[b] = tau[b] - 0x1p-7f * 1.02f * u_norm[b] * *v_norm_max;
 }
 
-// score_filter2_kernel_f32's loop on the bf16 copies: NM = ld / 16 MFMAs per 32 x 32 tile (lane (r, h): columns 16 m + 8 h .. + 8 of
-// its row); what reaches the LOWERED threshold goes to the lane-private lists as an id (its approximate score only for inspection)
-template <int NM>
-__global__ __launch_bounds__(256, 2) void score_filter_bf16_kernel(
-    const __bf16 *__restrict__ Ub, const __bf16 *__restrict__ Vb, int n_items, int n_b, const float *__restrict__ tau_low, int n_lists,
-    float *__restrict__ cand_s, int32_t *__restrict__ cand_i, int32_t *__restrict__ cand_n) {
+// the same when tau_hat itself comes from bf16 scores (sample_max_bf16_kernel): N + 1 distinct unrated items have bf16 scores
+// >= tau_hat, so fp32 scores >= tau_hat - eps =: tau (a threshold the user's N + 1 best fp32 scores reach); every item whose
+// fp32 score reaches tau has a bf16 score >= tau - eps =: tau_low
+__global__ __launch_bounds__(256) void lowered_tau2_kernel(float *__restrict__ tau, const float *__restrict__ u_norm,
+                                                           const float *__restrict__ v_norm_max, int n_b, float *__restrict__ tau_low) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n_b) {
+        const float eps = 0x1p-7f * 1.02f * u_norm[b] * *v_norm_max, t = tau[b] - eps;
+        tau[b] = t;
+        tau_low[b] = t - eps;
+    }
+}
+
+// sample_max_kernel_f32 on the bf16 copies, every `stride`-th item tile (stride 1: the whole catalogue -- the pass costs 1/16 of
+// the fp32 matrix-pipe time, so a denser sample, a higher threshold and fewer candidates are affordable).  The accumulator
+// register number rides in the low 4 mantissa bits of the score (relative 2^-19: inside eps's 2 % slack), so the per-tile
+// maximum is 16 v_and_or + 8 v_max3 and the best item is recovered from (tile, register, half).
+template <int NM, int NU>      // NU user tiles of 32 per wavefront
+__global__ __launch_bounds__(256, 2) void sample_max_bf16_kernel(
+    const __bf16 *__restrict__ Ub, const __bf16 *__restrict__ Vb, int n_items, int n_b, int b_pad, int stride, int n_s_tiles,
+    int tiles_per_group, int n_groups, float *__restrict__ gmax, int32_t *__restrict__ garg) {
     constexpr int LD = 16 * NM;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int upair = blockIdx.x;
-    const int b0 = upair * 64 + r, b1 = b0 + 32;
+    const int g_step = gridDim.y * 4;
+    int g = blockIdx.y * 4 + wave;
+    if (g >= n_groups) return;
+    int bs[NU];
+    bf16x8 uu[NU][NM];
+#pragma unroll
+    for (int k = 0; k < NU; k++) {
+        bs[k] = (blockIdx.x * NU + k) * 32 + r;
+        const int bl = bs[k] < b_pad ? bs[k] : b_pad - 1;         // Ub holds b_pad rows (zero rows past n_b)
+#pragma unroll
+        for (int m = 0; m < NM; m++) uu[k][m] = *reinterpret_cast<const bf16x8 *>(Ub + (int64_t)bl * LD + 16 * m + 8 * h);
+    }
+    auto load_tile = [&](int s_tile, bf16x8 (&dst)[NM]) {         // Vb is padded to whole 32-item tiles
+        const __bf16 *row = Vb + ((int64_t)s_tile * stride * 32 + r) * LD + 8 * h;
+#pragma unroll
+        for (int m = 0; m < NM; m++) dst[m] = *reinterpret_cast<const bf16x8 *>(row + 16 * m);
+    };
+    auto tagged_max = [](const f32x16 &a) {
+        float t[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) t[q] = __uint_as_float((__float_as_uint(a[q]) & ~15u) | (unsigned)q);
+        const float x0 = fmaxf(fmaxf(t[0], t[1]), t[2]), x1 = fmaxf(fmaxf(t[3], t[4]), t[5]), x2 = fmaxf(fmaxf(t[6], t[7]), t[8]);
+        const float x3 = fmaxf(fmaxf(t[9], t[10]), t[11]), x4 = fmaxf(fmaxf(t[12], t[13]), t[14]);
+        return fmaxf(fmaxf(fmaxf(x0, x1), fmaxf(x2, x3)), fmaxf(x4, t[15]));
+    };
+    bf16x8 v[NM], vn[NM];
+    bool first = true;
+    for (; g < n_groups; g += g_step) {
+        const int s_begin = g * tiles_per_group;
+        int s_end = s_begin + tiles_per_group;
+        if (s_end > n_s_tiles) s_end = n_s_tiles;
+        float mx[NU];
+        int ts[NU];
+#pragma unroll
+        for (int k = 0; k < NU; k++) { mx[k] = -__builtin_huge_valf(); ts[k] = s_begin; }
+        if (first) { load_tile(s_begin, v); first = false; }
+        for (int st = s_begin; st < s_end; st++) {
+            const int nxt = st + 1 < s_end ? st + 1 : (g + g_step) * tiles_per_group;
+            const bool more = nxt < n_s_tiles && (st + 1 < s_end || g + g_step < n_groups);
+            if (more) load_tile(nxt, vn);
+            f32x16 acc[NU];
+#pragma unroll
+            for (int k = 0; k < NU; k++)
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc[k][q] = 0.f;
+#pragma unroll
+            for (int m = 0; m < NM; m++)
+#pragma unroll
+                for (int k = 0; k < NU; k++) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[m], uu[k][m], acc[k], 0, 0, 0);
+            const int item_base = st * stride * 32 + 4 * h;
+            if (st * stride * 32 + 32 > n_items) {                 // the last, partial tile: pad rows are not items
+#pragma unroll
+                for (int q = 0; q < 16; q++)
+                    if (item_base + (q & 3) + 8 * (q >> 2) >= n_items) {
+#pragma unroll
+                        for (int k = 0; k < NU; k++) acc[k][q] = -__builtin_huge_valf();
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < NU; k++) {
+                const float x = tagged_max(acc[k]);
+                if (x > mx[k]) { mx[k] = x; ts[k] = st; }
+            }
+#pragma unroll
+            for (int m = 0; m < NM; m++) v[m] = vn[m];
+        }
+#pragma unroll
+        for (int k = 0; k < NU; k++) {
+            const int q = (int)(__float_as_uint(mx[k]) & 15u);
+            int a = ts[k] * stride * 32 + 4 * h + (q & 3) + 8 * (q >> 2);
+            float m = mx[k];
+            const float o = __shfl_xor(m, 32, kWave);
+            const int oa = __shfl_xor(a, 32, kWave);
+            if (o > m) { m = o; a = oa; }
+            if (h == 0 && bs[k] < n_b) { gmax[(int64_t)g * b_pad + bs[k]] = m; garg[(int64_t)g * b_pad + bs[k]] = a; }
+        }
+    }
+}
+
+// score_filter2_kernel_f32's loop on the bf16 copies: NM = ld / 16 MFMAs per 32 x 32 tile (lane (r, h): columns 16 m + 8 h .. + 8 of
+// its row); what reaches the LOWERED threshold goes to the lane-private lists as an id (its approximate score only for inspection)
+template <int NM, int NU>      // NU user tiles of 32 per wavefront: one fetched item tile feeds NU * NM MFMAs
+__global__ __launch_bounds__(256, 2) void score_filter_bf16_kernel(
+    const __bf16 *__restrict__ Ub, int b_pad, const __bf16 *__restrict__ Vb, int n_items, int n_b, const float *__restrict__ tau_low, int n_lists,
+    int list_cap, float *__restrict__ cand_s, int32_t *__restrict__ cand_i, int32_t *__restrict__ cand_n) {
+    constexpr int LD = 16 * NM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
     const int list = (blockIdx.y * 4 + wave) * 2 + h;
     const int n_item_tiles = (n_items + 31) / 32;
     const int t_step = gridDim.y * 4;
     const int t_begin = blockIdx.y * 4 + wave, t_end = n_item_tiles;
-    const bool live0 = b0 < n_b, live1 = b1 < n_b;
-    int cnt0 = 0, cnt1 = 0;
-    if (t_begin < t_end) {
-        const float th0 = live0 ? tau_low[b0] : __builtin_huge_valf(), th1 = live1 ? tau_low[b1] : __builtin_huge_valf();
-        bf16x8 ua[NM], ub[NM];                       // Ub is padded to whole 64-user pairs (zero rows)
+    int bs[NU], cnt[NU];
+    bool live[NU];
 #pragma unroll
-        for (int m = 0; m < NM; m++) {
-            ua[m] = *reinterpret_cast<const bf16x8 *>(Ub + (int64_t)b0 * LD + 16 * m + 8 * h);
-            ub[m] = *reinterpret_cast<const bf16x8 *>(Ub + (int64_t)b1 * LD + 16 * m + 8 * h);
+    for (int k = 0; k < NU; k++) { bs[k] = (blockIdx.x * NU + k) * 32 + r; live[k] = bs[k] < n_b; cnt[k] = 0; }
+    if (t_begin < t_end) {
+        float th[NU];
+        bf16x8 uu[NU][NM];                           // Ub holds b_pad rows (zero rows past n_b)
+        float *cs[NU];
+        int32_t *ci[NU];
+#pragma unroll
+        for (int k = 0; k < NU; k++) {
+            th[k] = live[k] ? tau_low[bs[k]] : __builtin_huge_valf();
+            const int bl = bs[k] < b_pad ? bs[k] : b_pad - 1;
+#pragma unroll
+            for (int m = 0; m < NM; m++) uu[k][m] = *reinterpret_cast<const bf16x8 *>(Ub + (int64_t)bl * LD + 16 * m + 8 * h);
+            cs[k] = cand_s + ((int64_t)bs[k] * n_lists + list) * list_cap;
+            ci[k] = cand_i + ((int64_t)bs[k] * n_lists + list) * list_cap;
         }
         auto load_tile = [&](int t, bf16x8 (&dst)[NM]) {          // Vb is padded to whole 32-item tiles (zero rows)
             const __bf16 *row = Vb + (int64_t)(t * 32 + r) * LD + 8 * h;
 #pragma unroll
             for (int m = 0; m < NM; m++) dst[m] = *reinterpret_cast<const bf16x8 *>(row + 16 * m);
         };
-        float *cs0 = cand_s + ((int64_t)b0 * n_lists + list) * kListCap, *cs1 = cand_s + ((int64_t)b1 * n_lists + list) * kListCap;
-        int32_t *ci0 = cand_i + ((int64_t)b0 * n_lists + list) * kListCap, *ci1 = cand_i + ((int64_t)b1 * n_lists + list) * kListCap;
         auto do_tile = [&](int t, const bf16x8 (&v)[NM]) {
-            f32x16 acc0, acc1;
+            f32x16 acc[NU];
 #pragma unroll
-            for (int q = 0; q < 16; q++) { acc0[q] = 0.f; acc1[q] = 0.f; }
+            for (int k = 0; k < NU; k++)
 #pragma unroll
-            for (int m = 0; m < NM; m++) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[m], ua[m], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[m], ub[m], acc1, 0, 0, 0);
-            }
+                for (int q = 0; q < 16; q++) acc[k][q] = 0.f;
+#pragma unroll
+            for (int m = 0; m < NM; m++)
+#pragma unroll
+                for (int k = 0; k < NU; k++) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[m], uu[k][m], acc[k], 0, 0, 0);
             const int item_base = t * 32 + 4 * h;
-            if (t * 32 + 32 > n_items) {              // the last, partial tile: pad rows are zero vectors, score 0 -- never candidates
+            if (t * 32 + 32 > n_items) {              // the last, partial tile: its pad rows are never candidates
 #pragma unroll
                 for (int q = 0; q < 16; q++)
-                    if (item_base + (q & 3) + 8 * (q >> 2) >= n_items) { acc0[q] = -__builtin_huge_valf(); acc1[q] = -__builtin_huge_valf(); }
-            }
-            float m0 = acc0[0], m1 = acc1[0];
+                    if (item_base + (q & 3) + 8 * (q >> 2) >= n_items) {
 #pragma unroll
-            for (int q = 1; q < 16; q++) { m0 = fmaxf(m0, acc0[q]); m1 = fmaxf(m1, acc1[q]); }
-            if (m0 >= th0) {
-#pragma unroll
-                for (int q = 0; q < 16; q++)
-                    if (acc0[q] >= th0) {
-                        if (cnt0 < kListCap) { cs0[cnt0] = acc0[q]; ci0[cnt0] = item_base + (q & 3) + 8 * (q >> 2); }
-                        cnt0++;
+                        for (int k = 0; k < NU; k++) acc[k][q] = -__builtin_huge_valf();
                     }
             }
-            if (m1 >= th1) {
+            // hits are rare (about one per 32 x 32 tile): a tile is tested by the maximum of its 16 accumulator registers (v_max3
+            // chains, one compare, one scalar branch on the wave's mask); a tile with a hit narrows down by register quads --
+            // not 16 dependent compare / branch pairs per tile, which cost 2.5x the tile's MFMA time
 #pragma unroll
-                for (int q = 0; q < 16; q++)
-                    if (acc1[q] >= th1) {
-                        if (cnt1 < kListCap) { cs1[cnt1] = acc1[q]; ci1[cnt1] = item_base + (q & 3) + 8 * (q >> 2); }
-                        cnt1++;
-                    }
+            for (int k = 0; k < NU; k++) {
+                const f32x16 &a = acc[k];
+                float gq[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) gq[j] = fmaxf(fmaxf(fmaxf(a[4 * j], a[4 * j + 1]), a[4 * j + 2]), a[4 * j + 3]);
+                const float mx = fmaxf(fmaxf(fmaxf(gq[0], gq[1]), gq[2]), gq[3]);
+                if (__ballot(mx >= th[k])) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (__ballot(gq[j] >= th[k])) {
+#pragma unroll
+                            for (int q = 4 * j; q < 4 * j + 4; q++)
+                                if (a[q] >= th[k]) {
+                                    if (cnt[k] < list_cap) { cs[k][cnt[k]] = a[q]; ci[k][cnt[k]] = item_base + (q & 3) + 8 * (q >> 2); }
+                                    cnt[k]++;
+                                }
+                        }
+                }
             }
         };
         bf16x8 va[NM], vb[NM];
@@ -861,8 +976,9 @@ __global__ __launch_bounds__(256, 2) void score_filter_bf16_kernel(
             if (t >= t_end) break;
         }
     }
-    if (live0) cand_n[(int64_t)b0 * n_lists + list] = cnt0;
-    if (live1) cand_n[(int64_t)b1 * n_lists + list] = cnt1;
+#pragma unroll
+    for (int k = 0; k < NU; k++)
+        if (live[k]) cand_n[(int64_t)bs[k] * n_lists + list] = cnt[k];
 }
 
 constexpr int kSelectWaves = 4;
@@ -872,9 +988,9 @@ __global__ __launch_bounds__(64 * kSelectWaves) void select_topk_kernel(
     const float *__restrict__ tau, const int32_t *__restrict__ user_ids, const int64_t *__restrict__ rated_indptr,
     const int32_t *__restrict__ rated_sorted, int n_b, int K, int32_t *__restrict__ ids_out, float *__restrict__ scores_out,
     int32_t *__restrict__ flags, int32_t *__restrict__ n_flagged, int32_t *__restrict__ flagged_list,
-    const float *__restrict__ U, const float *__restrict__ V, int ld, int pool_cap, const float *__restrict__ tau_low) {
+    const float *__restrict__ U, const float *__restrict__ V, int ld, int pool_cap, const float *__restrict__ tau_low, int list_cap) {
     // pool_cap: LDS entries per user (a user with more candidates is flagged and redone exactly); the lists' worst case,
-    // n_lists * kListCap, would leave one wavefront per SIMD.
+    // n_lists * list_cap, would leave one wavefront per SIMD.
     // U != null: the candidates come from the bf16 filter -- their fp32 scores are formed here, by the MFMA sequence of
     // score_kernel_f32 (32 candidates as the item rows of a tile, the user's row broadcast over its 32 columns)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -895,7 +1011,7 @@ __global__ __launch_bounds__(64 * kSelectWaves) void select_topk_kernel(
     for (int l0 = 0; l0 < n_lists; l0 += 64) {                    // counts -> offsets (wave scan), candidates -> pool
         const int l = l0 + lane;
         int n = l < n_lists ? cand_n[(int64_t)b * n_lists + l] : 0;
-        if (n > kListCap) { bad = true; n = kListCap; }
+        if (n > list_cap) { bad = true; n = list_cap; }
         int inc = n;
 #pragma unroll
         for (int sft = 1; sft < 64; sft <<= 1) {
@@ -904,7 +1020,7 @@ __global__ __launch_bounds__(64 * kSelectWaves) void select_topk_kernel(
         }
         const int off = total + inc - n;
         for (int c = 0; c < n; c++) {
-            const int64_t at = ((int64_t)b * n_lists + l) * kListCap + c;
+            const int64_t at = ((int64_t)b * n_lists + l) * list_cap + c;
             if (off + c < pool_cap) pool[off + c] = key_of(cand_s[at], cand_i[at]);
         }
         total += __shfl(inc, 63, 64);
@@ -1301,7 +1417,8 @@ __global__ __launch_bounds__(256) void threshold_var_kernel(const float *__restr
 }
 
 struct FusedGeom {
-    int b_pad, n_utiles, n_item_tiles, grid_y, n_lists, n_s_tiles, n_s, fb_users;
+    int b_pad, n_utiles, n_item_tiles, grid_x, grid_y, n_lists, list_cap, nu, n_s_tiles, n_s, fb_users;
+    bool use_bf16;
     size_t off_ub, off_vb, off_un, off_vmax, off_taul, off_gmax, off_garg, off_tau, off_cs, off_ci, off_cn, off_flags, off_list, off_nf, off_fbu, off_fbi, off_fbs, off_fb, total;
 };
 __host__ inline bool fused_ok(int dtype, int ld, int n_items, int K) {
@@ -1318,7 +1435,15 @@ __host__ inline FusedGeom fused_geometry(int n_items, int n_b, int ld) {
     g.b_pad = (n_b + 63) / 64 * 64;
     g.n_utiles = (n_b + 63) / 64;
     g.n_item_tiles = (n_items + 31) / 32;
-    int waves = (4096 + g.n_utiles - 1) / g.n_utiles;                 // wavefronts per user pair: fill 1,024 SIMDs a few times over
+    // the bf16 route (default): NU user tiles of 32 per wavefront, short candidate lists (its threshold comes from the whole
+    // catalogue: a few dozen candidates per user); the fp32 route (QREC_EVAL_F32_FILTER): two tiles, ~200 candidates per user
+    static const bool bf16_filter = getenv("QREC_EVAL_F32_FILTER") == nullptr;
+    static const int eval_nu = getenv("QREC_EVAL_NU") ? atoi(getenv("QREC_EVAL_NU")) : 4;
+    g.use_bf16 = bf16_filter && (ld == 32 || ld == 64 || ld == 128);
+    g.nu = g.use_bf16 ? (ld == 128 || (ld == 64 && eval_nu == 2) ? 2 : 4) : 2;
+    g.list_cap = g.use_bf16 ? 16 : kListCap;
+    g.grid_x = (n_b + 32 * g.nu - 1) / (32 * g.nu);
+    int waves = ((g.use_bf16 ? 8192 : 4096) + g.grid_x - 1) / g.grid_x;   // wavefronts per user group: fill 1,024 SIMDs a few times over
     if (waves > g.n_item_tiles / 8) waves = g.n_item_tiles / 8 > 0 ? g.n_item_tiles / 8 : 1;
     if (waves > 32) waves = 32;              // <= 64 candidate lists per user: the selection kernel gathers them in LDS
     g.grid_y = (waves + 3) / 4;
@@ -1340,8 +1465,8 @@ __host__ inline FusedGeom fused_geometry(int n_items, int n_b, int ld) {
     g.off_gmax = o; o += up((size_t)kMaxGroups * g.b_pad * 4);
     g.off_garg = o; o += up((size_t)kMaxGroups * g.b_pad * 4);
     g.off_tau = o; o += up((size_t)g.b_pad * 4);
-    g.off_cs = o; o += up((size_t)g.b_pad * g.n_lists * kListCap * 4);
-    g.off_ci = o; o += up((size_t)g.b_pad * g.n_lists * kListCap * 4);
+    g.off_cs = o; o += up((size_t)g.b_pad * g.n_lists * g.list_cap * 4);
+    g.off_ci = o; o += up((size_t)g.b_pad * g.n_lists * g.list_cap * 4);
     g.off_cn = o; o += up((size_t)g.b_pad * g.n_lists * 4);
     g.off_flags = o; o += up((size_t)g.b_pad * 4);
     g.off_list = o; o += up((size_t)g.b_pad * 4);
@@ -1365,20 +1490,50 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
     int32_t *flags = reinterpret_cast<int32_t *>(base + g.off_flags), *flagged_list = reinterpret_cast<int32_t *>(base + g.off_list);
     int32_t *n_flagged = reinterpret_cast<int32_t *>(base + g.off_nf);
     const int M = K + 1;
-    // (A) threshold from every kSampleStride-th item tile: group maxima straight from the scoring loop
+    static const int bf16_stride_env = getenv("QREC_EVAL_BF16_STRIDE") ? atoi(getenv("QREC_EVAL_BF16_STRIDE")) : 1;
+    const bool use_bf16 = g.use_bf16;
+    const int bf16_stride = bf16_stride_env < 1 ? 1 : (bf16_stride_env > kSampleStride ? kSampleStride : bf16_stride_env);
+    __bf16 *Ub = reinterpret_cast<__bf16 *>(base + g.off_ub), *Vb = reinterpret_cast<__bf16 *>(base + g.off_vb);
+    float *u_norm = reinterpret_cast<float *>(base + g.off_un), *v_max = reinterpret_cast<float *>(base + g.off_vmax);
+    float *tau_low = reinterpret_cast<float *>(base + g.off_taul);
+    if (use_bf16) {
+        // bf16 copies of the batch's user rows (gathered) and of the items, with |u_b| and max |v|
+        QREC_HIP_CHECK(hipMemsetAsync(v_max, 0, sizeof(float), st));
+        const int v_rows_pad = g.n_item_tiles * 32;
+#define QREC_BF(LPR)                                                                                                                  \
+        hipLaunchKernelGGL((to_bf16_kernel<LPR>), dim3((unsigned)((g.b_pad + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), dim3(256), 0, st, U,   \
+                           user_ids, n_b, g.b_pad, Ub, u_norm, (float *)nullptr);                                                     \
+        hipLaunchKernelGGL((to_bf16_kernel<LPR>), dim3((unsigned)((v_rows_pad + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), dim3(256), 0, st, V, \
+                           (const int32_t *)nullptr, n_items, v_rows_pad, Vb, (float *)nullptr, v_max)
+        if (ld == 32) { QREC_BF(8); } else if (ld == 64) { QREC_BF(16); } else { QREC_BF(32); }
+#undef QREC_BF
+        QREC_LAUNCH_CHECK();
+    }
+    // (A) threshold: group maxima straight from a scoring loop -- fp32 over every kSampleStride-th item tile, or (bf16 route)
+    // bf16 over every bf16_stride-th tile (default: all of them)
     {
-        int tpg = g.n_s_tiles / 64; if (tpg < 1) tpg = 1;
-        int n_groups = (g.n_s_tiles + tpg - 1) / tpg;
-        while (n_groups > kMaxGroups) { tpg++; n_groups = (g.n_s_tiles + tpg - 1) / tpg; }
-        int waves = (2048 + g.n_utiles - 1) / g.n_utiles;              // a few groups per wavefront: its user rows are fetched once
+        const int n_s_tiles = use_bf16 ? (g.n_item_tiles + bf16_stride - 1) / bf16_stride : g.n_s_tiles;
+        int tpg = use_bf16 ? (n_s_tiles + kMaxGroups - 1) / kMaxGroups : n_s_tiles / 64;
+        if (tpg < 1) tpg = 1;
+        int n_groups = (n_s_tiles + tpg - 1) / tpg;
+        while (n_groups > kMaxGroups) { tpg++; n_groups = (n_s_tiles + tpg - 1) / tpg; }
+        int waves = ((use_bf16 ? 8192 : 2048) + g.grid_x - 1) / g.grid_x;           // a few groups per wavefront: its user rows are fetched once
         if (waves > n_groups) waves = n_groups;
         if (waves < 1) waves = 1;
-        const dim3 sgrid((unsigned)g.n_utiles, (unsigned)((waves + 3) / 4));
+        const dim3 sgrid((unsigned)g.grid_x, (unsigned)((waves + 3) / 4));
         int32_t *garg = reinterpret_cast<int32_t *>(base + g.off_garg);
-        if (ld <= 64)
-            hipLaunchKernelGGL(sample_max_kernel_f32<1>, sgrid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, g.b_pad, g.n_s_tiles, tpg, n_groups, gmax, garg);
+        if (use_bf16) {
+#define QREC_SM(NM, NU)                                                                                                               \
+            hipLaunchKernelGGL((sample_max_bf16_kernel<NM, NU>), sgrid, dim3(256), 0, st, Ub, Vb,                                      \
+                               n_items, n_b, g.b_pad, bf16_stride, n_s_tiles, tpg, n_groups, gmax, garg)
+            if (ld == 32) { QREC_SM(2, 4); }
+            else if (ld == 64) { if (g.nu == 2) { QREC_SM(4, 2); } else { QREC_SM(4, 4); } }
+            else { QREC_SM(8, 2); }
+#undef QREC_SM
+        } else if (ld <= 64)
+            hipLaunchKernelGGL(sample_max_kernel_f32<1>, sgrid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, g.b_pad, n_s_tiles, tpg, n_groups, gmax, garg);
         else
-            hipLaunchKernelGGL(sample_max_kernel_f32<2>, sgrid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, g.b_pad, g.n_s_tiles, tpg, n_groups, gmax, garg);
+            hipLaunchKernelGGL(sample_max_kernel_f32<2>, sgrid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, g.b_pad, n_s_tiles, tpg, n_groups, gmax, garg);
         QREC_LAUNCH_CHECK();
         const unsigned lane_blocks = (unsigned)((n_b + 255) / 256);
         if (rated_indptr) {
@@ -1388,6 +1543,10 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
         }
         hipLaunchKernelGGL(threshold_var_kernel, dim3(lane_blocks), dim3(256), 0, st, gmax, g.b_pad, n_b, n_groups, M, tau);
         QREC_LAUNCH_CHECK();
+        if (use_bf16) {
+            hipLaunchKernelGGL(lowered_tau2_kernel, dim3(lane_blocks), dim3(256), 0, st, tau, u_norm, v_max, n_b, tau_low);
+            QREC_LAUNCH_CHECK();
+        }
     }
     // (B) score + filter, (C) select
     QREC_HIP_CHECK(hipMemsetAsync(n_flagged, 0, sizeof(int32_t), st));
@@ -1398,24 +1557,15 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
     // 1.92 (448 registers, accumulators shuttling between AGPRs and VGPRs) although the same loop shape gains 22 % in
     // tools/ubench/mfma_tile.hip; thresholds at +inf (no element ever appended) 1.66: the pass is bound by the per-lane-row
     // operand fetch interleaved with the accumulator read-out, not by the compare / append work
-    const dim3 grid((unsigned)g.n_utiles, (unsigned)g.grid_y);
-    static const bool bf16_filter = getenv("QREC_EVAL_F32_FILTER") == nullptr && true;
-    const bool use_bf16 = bf16_filter && (ld == 32 || ld == 64 || ld == 128);
+    const dim3 grid((unsigned)g.grid_x, (unsigned)g.grid_y);
     if (use_bf16) {
-        // (B') bf16 copies (the batch's user rows gathered), the lowered thresholds, the filter on v_mfma_f32_32x32x16_bf16
-        __bf16 *Ub = reinterpret_cast<__bf16 *>(base + g.off_ub), *Vb = reinterpret_cast<__bf16 *>(base + g.off_vb);
-        float *u_norm = reinterpret_cast<float *>(base + g.off_un), *v_max = reinterpret_cast<float *>(base + g.off_vmax);
-        float *tau_low = reinterpret_cast<float *>(base + g.off_taul);
-        QREC_HIP_CHECK(hipMemsetAsync(v_max, 0, sizeof(float), st));
-        const int v_rows_pad = g.n_item_tiles * 32;
-#define QREC_BF(LPR, NM)                                                                                                              \
-        hipLaunchKernelGGL((to_bf16_kernel<LPR>), dim3((unsigned)((g.b_pad + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), dim3(256), 0, st, U,   \
-                           user_ids, n_b, g.b_pad, Ub, u_norm, (float *)nullptr);                                                     \
-        hipLaunchKernelGGL((to_bf16_kernel<LPR>), dim3((unsigned)((v_rows_pad + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), dim3(256), 0, st, V, \
-                           (const int32_t *)nullptr, n_items, v_rows_pad, Vb, (float *)nullptr, v_max);                               \
-        hipLaunchKernelGGL(lowered_tau_kernel, dim3((unsigned)((n_b + 255) / 256)), dim3(256), 0, st, tau, u_norm, v_max, n_b, tau_low); \
-        hipLaunchKernelGGL((score_filter_bf16_kernel<NM>), grid, dim3(256), 0, st, Ub, Vb, n_items, n_b, tau_low, g.n_lists, cand_s, cand_i, cand_n)
-        if (ld == 32) { QREC_BF(8, 2); } else if (ld == 64) { QREC_BF(16, 4); } else { QREC_BF(32, 8); }
+        // (B') the filter on v_mfma_f32_32x32x16_bf16 against the lowered thresholds
+#define QREC_BF(NM, NU)                                                                                                               \
+        hipLaunchKernelGGL((score_filter_bf16_kernel<NM, NU>), grid, dim3(256), 0, st, Ub, (int)g.b_pad, Vb, n_items, n_b, tau_low, g.n_lists,     \
+                           g.list_cap, cand_s, cand_i, cand_n)
+        if (ld == 32) { QREC_BF(2, 4); }
+        else if (ld == 64) { if (g.nu == 2) { QREC_BF(4, 2); } else { QREC_BF(4, 4); } }
+        else { QREC_BF(8, 2); }
 #undef QREC_BF
     } else if (ld <= 64)
         hipLaunchKernelGGL((score_filter2_kernel_f32<1, 2>), grid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, 0, tau, g.n_lists,
@@ -1425,8 +1575,8 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
                            cand_s, cand_i, cand_n);
     QREC_LAUNCH_CHECK();
     // candidates per user: ~ (N + 1) * kSampleStride * 1.1, times ~1.4 behind the bf16 filter; the pool holds 4x that
-    int pool_cap = g.n_lists * kListCap;
-    const int want = 4 * (int)((K + 1) * kSampleStride * 1.6);
+    int pool_cap = g.n_lists * g.list_cap;
+    const int want = 4 * (int)((K + 1) * (use_bf16 ? bf16_stride : kSampleStride) * 1.6);
     if (pool_cap > want) pool_cap = want < 256 ? 256 : want;
     const size_t lds = (size_t)kSelectWaves * pool_cap * sizeof(unsigned long long);
     const dim3 sgrid((unsigned)((n_b + kSelectWaves - 1) / kSelectWaves));
@@ -1435,12 +1585,12 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
         QREC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_topk_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(select_topk_kernel<1>, sgrid, dim3(64 * kSelectWaves), lds, st, cand_s, cand_i, cand_n, g.n_lists, tau, user_ids, rated_indptr,
                            rated_sorted, n_b, K, ids_out, scores_out, flags, n_flagged, flagged_list, Ur, V, ld, pool_cap,
-                           reinterpret_cast<const float *>(base + g.off_taul));
+                           reinterpret_cast<const float *>(base + g.off_taul), g.list_cap);
     } else {
         QREC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_topk_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(select_topk_kernel<2>, sgrid, dim3(64 * kSelectWaves), lds, st, cand_s, cand_i, cand_n, g.n_lists, tau, user_ids, rated_indptr,
                            rated_sorted, n_b, K, ids_out, scores_out, flags, n_flagged, flagged_list, Ur, V, ld, pool_cap,
-                           reinterpret_cast<const float *>(base + g.off_taul));
+                           reinterpret_cast<const float *>(base + g.off_taul), g.list_cap);
     }
     QREC_LAUNCH_CHECK();
     // (D) users whose heap history matters: the block path, fb_users at a time

@@ -1,0 +1,19 @@
+#!/bin/bash
+# eval (bf16 sample pass): tests at the default stride, fused timing at strides 1 / 2 / 4, kernel stats for the default
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out; mkdir -p $O
+cd $R
+timeout 1500 python -m pytest tests/test_gpu_eval.py -q -x > $O/t_eval.log 2>&1; echo "eval tests exit $?"; tail -3 $O/t_eval.log
+for s in 1 2 4; do
+  QREC_EVAL_BF16_STRIDE=$s python tools/bench_eval.py > $O/eval_s$s.json 2>$O/eval.err || tail -5 $O/eval.err; echo "stride $s: $(cut -c1-60 $O/eval_s$s.json)"
+done
+cp $O/eval_s1.json $O/eval.json
+cd /tmp && export TMPDIR=/tmp
+rm -rf $O/prof_eval
+rocprofv3 --kernel-trace --stats -d $O/prof_eval -o eval -- python $R/tools/bench_eval.py child > $O/prof_eval.log 2>&1; echo "exit $?"
+python - <<'P'
+import sqlite3
+con=sqlite3.connect('/root/repo/gpurun_out/prof_eval/eval_results.db')
+for name,calls,t,avg,pct in list(con.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))[:10]:
+    print(f"{calls:6d} {t/1e3:10.1f} {avg/1e3:9.2f} {pct:6.2f}  {name[:80]}")
+P
