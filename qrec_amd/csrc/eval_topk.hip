@@ -981,6 +981,24 @@ __global__ __launch_bounds__(256, 2) void score_filter_bf16_kernel(
         if (live[k]) cand_n[(int64_t)bs[k] * n_lists + list] = cnt[k];
 }
 
+// rank of this lane's key among the 64 keys of the wavefront (how many are larger): 64 x (2 v_readlane, compare, add) -- no LDS
+// round trips, no dependent shuffles
+__device__ __forceinline__ int wave_rank_u64(unsigned long long key) {
+    const int lo = (int)(unsigned)key, hi = (int)(unsigned)(key >> 32);
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+        const unsigned long long o = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, j) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, j);
+        rank += o > key ? 1 : 0;
+    }
+    return rank;
+}
+__device__ __forceinline__ unsigned long long wave_read_u64(unsigned long long key, int src) {
+    const int s = __builtin_amdgcn_readfirstlane(src);
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), s) << 32) |
+           (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, s);
+}
+
 constexpr int kSelectWaves = 4;
 template <int NC>       // column chunks of 64 in the re-scoring (ld <= 64: 1, ld = 128: 2)
 __global__ __launch_bounds__(64 * kSelectWaves) void select_topk_kernel(
@@ -1046,6 +1064,12 @@ __global__ __launch_bounds__(64 * kSelectWaves) void select_topk_kernel(
         const float eps = (tau[b] - tau_low[b]) * 1.01f;
         const int Mq = K + 1;
         unsigned long long below = ~0ull;
+        if (total <= 64) {                                         // the usual case: one key per lane, ranks by v_readlane
+            const unsigned long long key = lane < total ? pool[lane] : 0ull;
+            const int rk = wave_rank_u64(key);
+            const unsigned long long at = __ballot(key != 0ull && rk == Mq - 1);
+            below = at ? wave_read_u64(key, __builtin_ctzll(at)) : 0ull;
+        } else
         for (int rank = 0; rank < Mq; rank++) {                    // the Mq-th largest key, non-destructively
             unsigned long long best = 0;
             for (int e = lane; e < total; e += 64) {
@@ -1146,6 +1170,18 @@ __global__ __launch_bounds__(64 * kSelectWaves) void select_topk_kernel(
     unsigned long long prev = 0;
     bool tie = false;
     const int take = kept < M ? kept : M;
+    if (total <= 64) {                                            // one key per lane: its rank is its place in the output
+        const unsigned long long key = lane < total ? pool[lane] : 0ull;
+        const int rk = wave_rank_u64(key);                        // rated / empty slots (0) rank behind every candidate
+        if (key != 0ull && rk < take) pool[rk] = key;             // every lane has read its key: the pool can take the sorted run
+        if (key != 0ull && rk < K && rk < take) {
+            unsigned u = (unsigned)(key >> 32);
+            u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+            ids_out[(int64_t)b * K + rk] = 0x7fffffff - (int32_t)(unsigned)(key & 0xffffffffu);
+            scores_out[(int64_t)b * K + rk] = __uint_as_float(u);
+        }
+        tie = __any(lane >= 1 && lane < take && (pool[lane] >> 32) == (pool[lane - 1] >> 32));
+    } else
     for (int rank = 0; rank < take; rank++) {
         unsigned long long best = 0;
         int where = -1;

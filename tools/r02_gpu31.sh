@@ -4,7 +4,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out; mkdir -p $O
 cd $R
 timeout 1500 python -m pytest tests/test_gpu_eval.py -q -x > $O/t_eval.log 2>&1; echo "eval tests exit $?"; tail -3 $O/t_eval.log
-for nu in 4 2; do for s in 1 2; do
+QREC_EVAL_F32_FILTER=1 timeout 1500 python -m pytest tests/test_gpu_eval.py -q -x > $O/t_eval_f32.log 2>&1; echo "eval tests (fp32 filter) exit $?"; tail -1 $O/t_eval_f32.log
+QREC_EVAL_BF16_STRIDE=8 timeout 1500 python -m pytest tests/test_gpu_eval.py -q -x > $O/t_eval_s8.log 2>&1; echo "eval tests (bf16, stride 8) exit $?"; tail -1 $O/t_eval_s8.log
+for nu in 4; do for s in 1 2; do
   QREC_EVAL_NU=$nu QREC_EVAL_BF16_STRIDE=$s python tools/bench_eval.py > $O/eval_n${nu}s$s.json 2>$O/eval.err || tail -5 $O/eval.err; echo "nu $nu stride $s: $(cut -c1-60 $O/eval_n${nu}s$s.json)"
 done; done
 python tools/bench_eval.py > $O/eval.json 2>$O/eval.err
