@@ -42,9 +42,12 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void score_kernel_f32(
     const float *__restrict__ U, const float *__restrict__ V, int ld, int n_items,
     const int32_t *__restrict__ user_ids, int n_b, int b_pad, int item_tiles_per_wave,
-    float *__restrict__ S_T, int tile_stride, int64_t upair_stride) {
+    float *__restrict__ S_T, int tile_stride, int64_t upair_stride, int64_t u_stride) {
     // tile_stride > 1 (threshold pass of the fused evaluation): block row 32*t + q is item 32*t*tile_stride + q, i.e.
     // only every tile_stride-th item tile is scored.
+    // General address of (block row, user b): S_T[row * b_pad + (b / 64) * upair_stride + (b % 64) * u_stride].  u_stride = 1 in the
+    // layouts below; b_pad = 1, u_stride = row length, upair_stride = 64 row lengths: USER-MAJOR rows (a user's scores contiguous:
+    // what the exact per-user walk of a handful of flagged users wants -- its 64 loads per step are one 256-B access).
     // Layout: score of (block row, user b) at S_T[row * b_pad + (b / 64) * upair_stride + b % 64].  upair_stride = 64:
     // the plain [rows][b_pad] block.  b_pad = 64 with upair_stride = rows * 64: 64-user panels one after another -- a
     // user's column then strides 256 B and shares every cache line with 31 neighbours (the exact per-user walk).
@@ -99,8 +102,8 @@ __global__ __launch_bounds__(256) void score_kernel_f32(
                 for (int q = 0; q < 16; q++) {
                     const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
                     const bool in = item0 + row < n_items;
-                    acc0[q] = in ? out[(int64_t)row * b_pad + r] : 0.f;
-                    acc1[q] = in ? out[(int64_t)row * b_pad + 32 + r] : 0.f;
+                    acc0[q] = in ? out[(int64_t)row * b_pad + r * u_stride] : 0.f;
+                    acc1[q] = in ? out[(int64_t)row * b_pad + (32 + r) * u_stride] : 0.f;
                 }
             }
 #pragma unroll
@@ -119,8 +122,8 @@ __global__ __launch_bounds__(256) void score_kernel_f32(
             for (int q = 0; q < 16; q++) {
                 const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
                 if (item0 + row < n_items) {
-                    out[(int64_t)row * b_pad + r] = acc0[q];
-                    out[(int64_t)row * b_pad + 32 + r] = acc1[q];
+                    out[(int64_t)row * b_pad + r * u_stride] = acc0[q];
+                    out[(int64_t)row * b_pad + (32 + r) * u_stride] = acc1[q];
                 }
             }
 #pragma unroll
@@ -205,7 +208,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void mask_kernel(const int32_t *__restrict__ user_ids, int n_b,
                                                    const int64_t *__restrict__ rated_indptr,
                                                    const int32_t *__restrict__ rated_items, int b_pad,
-                                                   T *__restrict__ S_T, int tile, int tile_stride, int64_t upair_stride) {
+                                                   T *__restrict__ S_T, int tile, int tile_stride, int64_t upair_stride, int64_t u_stride) {
     // one wavefront per user of the batch.  tile_stride > 1: the block holds every tile_stride-th item tile only.
     const int b = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (b >= n_b) return;
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256) void mask_kernel(const int32_t *__restrict__ u
     const int64_t beg = rated_indptr[uid], end = rated_indptr[uid + 1];
     for (int64_t e = beg + (threadIdx.x & 63); e < end; e += 64) {
         const int it = rated_items[e], t = it / tile;
-        if (t % tile_stride == 0) S_T[((int64_t)(t / tile_stride) * tile + it % tile) * b_pad + (b >> 6) * upair_stride + (b & 63)] = T(0);
+        if (t % tile_stride == 0) S_T[((int64_t)(t / tile_stride) * tile + it % tile) * b_pad + (b >> 6) * upair_stride + (b & 63) * u_stride] = T(0);
     }
 }
 
@@ -520,7 +523,7 @@ template <typename T, bool REG>      // REG: K <= 64, the heap lives in the wave
 __global__ __launch_bounds__(64) void exact_wave_kernel(const T *__restrict__ S_T, int n_items, int b_pad, int K,
                                                         const int32_t *__restrict__ n_flagged, const int32_t *__restrict__ flagged_list,
                                                         int many, int32_t *__restrict__ ids_out, T *__restrict__ scores_out,
-                                                        int64_t upair_stride) {
+                                                        int64_t upair_stride, int64_t u_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // n_flagged == nullptr: every user of the block (one wavefront each) -- the fused route's fallback batch
     const int nf = n_flagged ? *n_flagged : (int)gridDim.x;
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(64) void exact_wave_kernel(const T *__restrict__ S_
         __device__ void set(int k, T sv, int32_t iv) { s[k] = sv; id[k] = iv; }
     };
     typename std::conditional<REG, LaneHeap<T>, WHeap>::type hp;
-    const T *col = S_T + (b >> 6) * upair_stride + (b & 63);
+    const T *col = S_T + (b >> 6) * upair_stride + (b & 63) * u_stride;
     const int k = K < n_items ? K : n_items;
     if constexpr (REG) {
         hp.s = lane < k ? col[(int64_t)lane * b_pad] : T(0); hp.id = lane; hp.lane = lane;
@@ -1244,14 +1247,14 @@ int run_score_topk(const void *U, const void *V, int d, int ld, int n_items, con
     T *S_T = static_cast<T *>(scratch);
     if constexpr (sizeof(T) == 4)
         hipLaunchKernelGGL(score_kernel_f32, grid, dim3(256), 0, st, (const float *)U, (const float *)V, ld,
-                           n_items, user_ids, n_b, b_pad, per_wave, S_T, 1, (int64_t)64);
+                           n_items, user_ids, n_b, b_pad, per_wave, S_T, 1, (int64_t)64, (int64_t)1);
     else
         hipLaunchKernelGGL(score_kernel_f64, grid, dim3(256), 0, st, (const double *)U, (const double *)V, ld,
                            n_items, user_ids, n_b, b_pad, per_wave, S_T);
     QREC_LAUNCH_CHECK();
     if (rated_indptr) {
         hipLaunchKernelGGL(mask_kernel<T>, dim3((unsigned)((n_b + 3) / 4)), dim3(256), 0, st, user_ids, n_b,
-                           rated_indptr, rated_items, b_pad, S_T, TILE, 1, (int64_t)64);
+                           rated_indptr, rated_items, b_pad, S_T, TILE, 1, (int64_t)64, (int64_t)1);
         QREC_LAUNCH_CHECK();
     }
     const size_t lds = (size_t)K * kHeapThreads * (sizeof(T) + sizeof(int32_t));
@@ -1304,10 +1307,10 @@ int run_score_topk(const void *U, const void *V, int d, int ld, int n_items, con
     const int wave_blocks = n_b < many ? n_b : many;
     if (K <= 64)
         hipLaunchKernelGGL((exact_wave_kernel<T, true>), dim3((unsigned)wave_blocks), dim3(64), 0, st, S_T,
-                           n_items, b_pad, K, n_flagged, flagged_list, many, ids_out, (T *)scores_out, (int64_t)64);
+                           n_items, b_pad, K, n_flagged, flagged_list, many, ids_out, (T *)scores_out, (int64_t)64, (int64_t)1);
     else
         hipLaunchKernelGGL((exact_wave_kernel<T, false>), dim3((unsigned)wave_blocks), dim3(64), (size_t)K * (sizeof(T) + sizeof(int32_t)), st, S_T,
-                           n_items, b_pad, K, n_flagged, flagged_list, many, ids_out, (T *)scores_out, (int64_t)64);
+                           n_items, b_pad, K, n_flagged, flagged_list, many, ids_out, (T *)scores_out, (int64_t)64, (int64_t)1);
     QREC_LAUNCH_CHECK();
     hipLaunchKernelGGL(heap_topk_kernel<T>, dim3(user_blocks), dim3(kHeapThreads), lds, st, S_T, n_items, b_pad, n_b, K, ids_out,
                        (T *)scores_out, flags, n_flagged, many);
@@ -1635,12 +1638,12 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
     QREC_HIP_CHECK(hipStreamSynchronize(st));
     int32_t *fb_users = reinterpret_cast<int32_t *>(base + g.off_fbu), *fb_ids = reinterpret_cast<int32_t *>(base + g.off_fbi);
     float *fb_sc = reinterpret_cast<float *>(base + g.off_fbs);
-    // Their scores as 64-user panels ([panel][item][64]: a user's column strides 256 B and every cache line is shared by
-    // 32 users whose wavefronts walk in step), masked, then the exact sequential emulation, one wavefront per user --
-    // three launches.  (Through the whole block route -- sliced top-N, flags, then exact_wave_kernel on a [item][b_pad]
-    // block where each of a step's 64 loads is its own cache line -- this fallback was 0.8 ms of the evaluation's 3.05.)
+    // Their scores as USER-MAJOR rows ([user][item]: a step of the walk -- 64 consecutive items -- is one 256-B access), masked,
+    // then the exact sequential emulation, one wavefront per user: three launches.  (History: through the whole block route --
+    // sliced top-N, flags, exact_wave_kernel on an [item][b_pad] block, every load of a step its own cache line -- the fallback
+    // was 0.8 ms of the evaluation's 3.05; as [panel][item][64] panels, a column striding 256 B, 0.18 ms for a handful of users.)
     float *fb_block = reinterpret_cast<float *>(base + g.off_fb);
-    const int64_t panel = (int64_t)g.n_item_tiles * 32 * 64;
+    const int64_t row_len = (int64_t)g.n_item_tiles * 32, panel = row_len * 64;
     for (int off = 0; off < h_nf; off += g.fb_users) {
         const int n = h_nf - off < g.fb_users ? h_nf - off : g.fb_users;
         hipLaunchKernelGGL(gather_user_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, user_ids, flagged_list, off, n, fb_users);
@@ -1650,16 +1653,17 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
         int per_wave = (g.n_item_tiles + splits - 1) / splits;
         if (per_wave < 8) per_wave = g.n_item_tiles < 8 ? g.n_item_tiles : 8;
         const int waves_per_utile = (g.n_item_tiles + per_wave - 1) / per_wave;
+        // user-major rows (see score_kernel_f32): item stride 1, user stride row_len
         hipLaunchKernelGGL(score_kernel_f32, dim3((unsigned)n_utiles, (unsigned)((waves_per_utile + 3) / 4)), dim3(256), 0, st, U, V, ld,
-                           n_items, fb_users, n, 64, per_wave, fb_block, 1, panel);
+                           n_items, fb_users, n, 1, per_wave, fb_block, 1, panel, row_len);
         QREC_LAUNCH_CHECK();
         if (rated_indptr) {
             hipLaunchKernelGGL(mask_kernel<float>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, fb_users, n, rated_indptr, rated_sorted,
-                               64, fb_block, 32, 1, panel);
+                               1, fb_block, 32, 1, panel, row_len);
             QREC_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL((exact_wave_kernel<float, true>), dim3((unsigned)n), dim3(64), 0, st, fb_block,         // fused route: K + 1 <= 64
-                           n_items, 64, K, (const int32_t *)nullptr, (const int32_t *)nullptr, 1 << 30, fb_ids, fb_sc, panel);
+                           n_items, 1, K, (const int32_t *)nullptr, (const int32_t *)nullptr, 1 << 30, fb_ids, fb_sc, panel, row_len);
         QREC_LAUNCH_CHECK();
         hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n * K + 255) / 256)), dim3(256), 0, st, flagged_list, off, n, K, fb_ids, fb_sc,
                            ids_out, scores_out);
