@@ -762,18 +762,23 @@ __global__ __launch_bounds__(256) void to_bf16_kernel(const float *__restrict__ 
     constexpr int GPW = kWave / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
     const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
-    if (k >= rows_pad) return;
     f32x4 x = {0.f, 0.f, 0.f, 0.f};
     if (k < rows) x = *reinterpret_cast<const f32x4 *>(X + (int64_t)(row_ids ? row_ids[k] : k) * (4 * LPR) + 4 * r);
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
     bf16x4 o = {(__bf16)x.x, (__bf16)x.y, (__bf16)x.z, (__bf16)x.w};
-    *reinterpret_cast<bf16x4 *>(out + k * (4 * LPR) + 4 * r) = o;
+    if (k < rows_pad) *reinterpret_cast<bf16x4 *>(out + k * (4 * LPR) + 4 * r) = o;
     float ss = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
     ss = row_allreduce_sum<LPR>(ss);
-    if (r == 0) {
-        const float nrm = sqrtf(ss) * 1.0001f;
-        if (norm) norm[k] = nrm;
-        if (norm_max && k < rows) atomicMax(reinterpret_cast<int *>(norm_max), __float_as_int(nrm));      // non-negative floats order as ints
+    float nrm = sqrtf(ss) * 1.0001f;                               // rows past `rows`: 0
+    if (r == 0 && norm && k < rows_pad) norm[k] = nrm;
+    if (norm_max) {                                                // one atomic per block (one per row serialises: 110 us for 38,048 rows)
+        __shared__ float s_max[4];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) nrm = fmaxf(nrm, __shfl_xor(nrm, m, kWave));
+        if (lane == 0) s_max[threadIdx.x >> 6] = nrm;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicMax(reinterpret_cast<int *>(norm_max), __float_as_int(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]))));   // non-negative floats order as ints
     }
 }
 
@@ -1322,7 +1327,7 @@ int run_score_topk(const void *U, const void *V, int d, int ld, int n_items, con
 // ---- (A) of the fused evaluation: the threshold without a sampled score block --------------------------------------------
 // sample_max_kernel_f32: the scoring loop over every kSampleStride-th item tile, but nothing is stored: per GROUP of
 // `tiles_per_group` consecutive sampled tiles every user keeps the largest (unmasked) score and its item.
-// validate_gmax_kernel: a group whose best item is one the user has rated is discarded (-inf) -- the remaining maxima are
+// threshold_var_kernel: a group whose best item is one the user has rated is discarded -- the remaining maxima are
 // scores of DISTINCT UNRATED items, so their (N+1)-th largest is a threshold the user's N+1 best masked scores reach.
 // (First version: the sampled tiles written out as a 600 MB block, masked there, group maxima in a second streaming pass:
 // 0.45 ms of the evaluation; a discarded group only lowers tau a little: ~7 % of the groups of a 40-item user.)
@@ -1415,44 +1420,45 @@ __global__ __launch_bounds__(256) void sample_max_kernel_f32(
     }
 }
 
-// one thread per (group, user): is the group's best item one of the user's rated items (sorted CSR)?  then the group is out
-__global__ __launch_bounds__(256) void validate_gmax_kernel(const int32_t *__restrict__ user_ids, int n_b, int b_pad, int n_groups,
-                                                            const int64_t *__restrict__ rated_indptr, const int32_t *__restrict__ rated_sorted,
-                                                            const int32_t *__restrict__ garg, float *__restrict__ gmax) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
-    if (b >= n_b || g >= n_groups) return;
-    const int item = garg[(int64_t)g * b_pad + b];
-    const int uid = user_ids[b];
-    int64_t lo = rated_indptr[uid], hi = rated_indptr[uid + 1];
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        const int v = rated_sorted[mid];
-        if (v < item) lo = mid + 1; else hi = mid;
-    }
-    if (lo < rated_indptr[uid + 1] && rated_sorted[lo] == item) gmax[(int64_t)g * b_pad + b] = -__builtin_huge_valf();
-}
-
-// tau[b] = the M-th largest of the user's n_groups (<= kMaxGroups) group maxima
-__global__ __launch_bounds__(256) void threshold_var_kernel(const float *__restrict__ gmax, int b_pad, int n_b, int n_groups, int M,
+// tau[b] = the M-th largest of the user's n_groups (<= kMaxGroups) group maxima, not counting groups whose best item is one the
+// user has rated (bisection in the user's sorted rated items -- only for the groups that come up, ~M of them: as a kernel of its
+// own over all (group, user) pairs the check was 88 us)
+__global__ __launch_bounds__(256) void threshold_var_kernel(const float *__restrict__ gmax, const int32_t *__restrict__ garg,
+                                                            const int32_t *__restrict__ user_ids, const int64_t *__restrict__ rated_indptr,
+                                                            const int32_t *__restrict__ rated_sorted, int b_pad, int n_b, int n_groups, int M,
                                                             float *__restrict__ tau) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_b) return;
     float v[kMaxGroups];
 #pragma unroll
     for (int g = 0; g < kMaxGroups; g++) v[g] = g < n_groups ? gmax[(int64_t)g * b_pad + b] : -__builtin_huge_valf();
-    float th = 0.f;
-    for (int r = 0; r < M; r++) {
+    int64_t rbeg = 0, rend = 0;
+    if (rated_indptr) { const int uid = user_ids[b]; rbeg = rated_indptr[uid]; rend = rated_indptr[uid + 1]; }
+    float th = -__builtin_huge_valf();
+    int found = 0;
+    for (int it = 0; it < n_groups && found < M; it++) {
         int arg = 0;
         float best = v[0];
 #pragma unroll
         for (int g = 1; g < kMaxGroups; g++)
             if (v[g] > best) { best = v[g]; arg = g; }
-        th = best;
 #pragma unroll
         for (int g = 0; g < kMaxGroups; g++)
             if (g == arg) v[g] = -__builtin_huge_valf();
+        if (!(best > -__builtin_huge_valf())) break;
+        if (rated_indptr) {
+            const int item = garg[(int64_t)arg * b_pad + b];
+            int64_t lo = rbeg, hi = rend;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (rated_sorted[mid] < item) lo = mid + 1; else hi = mid;
+            }
+            if (lo < rend && rated_sorted[lo] == item) continue;   // the group's best is a rated item: the group is out
+        }
+        th = best;
+        found++;
     }
-    tau[b] = th;
+    tau[b] = found == M ? th : -__builtin_huge_valf();            // fewer than M groups left: tau <= 0, the user goes the exact way
 }
 
 struct FusedGeom {
@@ -1575,12 +1581,8 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
             hipLaunchKernelGGL(sample_max_kernel_f32<2>, sgrid, dim3(256), 0, st, U, V, ld, n_items, user_ids, n_b, g.b_pad, n_s_tiles, tpg, n_groups, gmax, garg);
         QREC_LAUNCH_CHECK();
         const unsigned lane_blocks = (unsigned)((n_b + 255) / 256);
-        if (rated_indptr) {
-            hipLaunchKernelGGL(validate_gmax_kernel, dim3(lane_blocks, (unsigned)n_groups), dim3(256), 0, st, user_ids, n_b, g.b_pad, n_groups,
-                               rated_indptr, rated_sorted, garg, gmax);
-            QREC_LAUNCH_CHECK();
-        }
-        hipLaunchKernelGGL(threshold_var_kernel, dim3(lane_blocks), dim3(256), 0, st, gmax, g.b_pad, n_b, n_groups, M, tau);
+        hipLaunchKernelGGL(threshold_var_kernel, dim3(lane_blocks), dim3(256), 0, st, gmax, garg, user_ids, rated_indptr, rated_sorted, g.b_pad, n_b,
+                           n_groups, M, tau);
         QREC_LAUNCH_CHECK();
         if (use_bf16) {
             hipLaunchKernelGGL(lowered_tau2_kernel, dim3(lane_blocks), dim3(256), 0, st, tau, u_norm, v_max, n_b, tau_low);
@@ -1651,7 +1653,7 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
         const int n_utiles = (n + 63) / 64;
         int splits = (4096 + n_utiles - 1) / n_utiles;
         int per_wave = (g.n_item_tiles + splits - 1) / splits;
-        if (per_wave < 8) per_wave = g.n_item_tiles < 8 ? g.n_item_tiles : 8;
+        if (per_wave < 2) per_wave = g.n_item_tiles < 2 ? g.n_item_tiles : 2;      // a handful of users: many short wavefronts
         const int waves_per_utile = (g.n_item_tiles + per_wave - 1) / per_wave;
         // user-major rows (see score_kernel_f32): item stride 1, user stride row_len
         hipLaunchKernelGGL(score_kernel_f32, dim3((unsigned)n_utiles, (unsigned)((waves_per_utile + 3) / 4)), dim3(256), 0, st, U, V, ld,
