@@ -514,6 +514,64 @@ struct LaneHeap {
     }
 };
 
+// rank of this lane's key among the 64 keys of the wavefront (how many are larger): 64 x (2 v_readlane, compare, add) -- no LDS
+// round trips, no dependent shuffles
+__device__ __forceinline__ int wave_rank_u64(unsigned long long key) {
+    const int lo = (int)(unsigned)key, hi = (int)(unsigned)(key >> 32);
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+        const unsigned long long o = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, j) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, j);
+        rank += o > key ? 1 : 0;
+    }
+    return rank;
+}
+__device__ __forceinline__ unsigned long long wave_read_u64(unsigned long long key, int src) {
+    const int s = __builtin_amdgcn_readfirstlane(src);
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), s) << 32) |
+           (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, s);
+}
+
+// The same heap for fp32 scores as ONE 64-bit key per lane: (order-preserving image of the score) << 32 | id, so Python's tuple
+// order on (score, id) is the unsigned order of the keys.  heapq._siftup(heap, pos) -- bubble the smaller child up to a leaf, then
+// sift the item back down -- nets out to an insertion along the smaller-child path: the path's entries grow downwards (the
+// subtree below pos is a heap), so the item passes exactly those smaller than itself, each moving up one level, and lands where
+// the next one is larger.  Every lane finds its smaller child at once (two 64-bit cross-lane reads), the path is five chained
+// v_readlane, and how far the item travels is one ballot: no loop, no branch (the level-by-level loop over the same data cost
+// 0.75 us per root replacement, mostly VALU <-> SALU hand-offs; tools/ubench/exact_walk_probe.hip).
+struct KeyHeap {
+    unsigned long long key;      // this lane's entry (lanes >= k: unused)
+    int lane, k;
+    static __device__ unsigned long long make(float s, int32_t id) {
+        unsigned u = __float_as_uint(s + 0.f);                     // -0 -> +0: Python compares them equal
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        return ((unsigned long long)u << 32) | (unsigned)id;
+    }
+    static __device__ float score_of(unsigned long long kk) {
+        unsigned u = (unsigned)(kk >> 32);
+        u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+        return __uint_as_float(u);
+    }
+    __device__ unsigned long long at(int i) const { return wave_read_u64(key, i); }
+    __device__ void sift(int pos, unsigned long long item) {       // pos, item wave-uniform; heap[pos] is taken to hold `item`
+        const int c1 = 2 * lane + 1, c2 = c1 + 1;
+        const unsigned long long k1 = __shfl(key, c1 & 63, kWave), k2 = __shfl(key, c2 & 63, kWave);
+        const bool right = c2 < k && !(k1 < k2);                   // heapq: the right child unless left < right
+        const int sc = c1 < k ? (right ? c2 : c1) : lane;          // a leaf points at itself
+        const unsigned long long ck = right ? k2 : k1;             // the smaller child's key
+        // the smaller-child path from pos (k <= 64: at most five levels below the root); no branches, five chained v_readlane
+        const int p0 = __builtin_amdgcn_readfirstlane(pos);
+        const int p1 = __builtin_amdgcn_readlane(sc, p0), p2 = __builtin_amdgcn_readlane(sc, p1), p3 = __builtin_amdgcn_readlane(sc, p2);
+        const int p4 = __builtin_amdgcn_readlane(sc, p3), p5 = __builtin_amdgcn_readlane(sc, p4);
+        const int rel = (31 - __builtin_clz(lane + 1)) - (31 - __builtin_clz(p0 + 1));      // this lane's level below pos
+        const int pl = rel == 0 ? p0 : rel == 1 ? p1 : rel == 2 ? p2 : rel == 3 ? p3 : rel == 4 ? p4 : rel == 5 ? p5 : -1;
+        const bool on = pl == lane;                                // the path holds one node per level
+        // the path's keys grow downwards: those below `item` are a prefix; each moves up one level, the item lands behind them
+        const int f = __popcll(__ballot(on && rel >= 1 && key < item));
+        key = on && rel < f ? ck : (on && rel == f ? item : key);
+    }
+};
+
 // Exact sequential emulation for ONE user per wavefront (the users merge_topk_kernel flagged, when they are few).
 // Same algorithm as heap_topk_kernel, 64 items per step: every lane holds one score, a ballot finds the first lane
 // whose score beats the heap root, lane 0 performs heapq's replace in LDS, the root is re-read and the remaining
@@ -538,9 +596,15 @@ __global__ __launch_bounds__(64) void exact_wave_kernel(const T *__restrict__ S_
         __device__ void set(int k, T sv, int32_t iv) { s[k] = sv; id[k] = iv; }
     };
     typename std::conditional<REG, LaneHeap<T>, WHeap>::type hp;
+    constexpr bool KEYED = REG && sizeof(T) == 4;                 // fp32, K <= 64: the heap as one 64-bit key per lane
+    KeyHeap kh;
     const T *col = S_T + (b >> 6) * upair_stride + (b & 63) * u_stride;
     const int k = K < n_items ? K : n_items;
-    if constexpr (REG) {
+    if constexpr (KEYED) {
+        kh.lane = lane; kh.k = k;
+        kh.key = lane < k ? KeyHeap::make((float)col[(int64_t)lane * b_pad], lane) : ~0ull;
+        for (int t = k / 2 - 1; t >= 0; t--) kh.sift(t, kh.at(t));                 // heapq.heapify
+    } else if constexpr (REG) {
         hp.s = lane < k ? col[(int64_t)lane * b_pad] : T(0); hp.id = lane; hp.lane = lane;
         for (int t = k / 2 - 1; t >= 0; t--) sift_up(hp, k, t);
     } else {
@@ -551,7 +615,8 @@ __global__ __launch_bounds__(64) void exact_wave_kernel(const T *__restrict__ S_
             for (int t = k / 2 - 1; t >= 0; t--) sift_up(hp, k, t);
         __syncthreads();
     }
-    T root = hp.S(0);
+    T root;
+    if constexpr (KEYED) root = (T)KeyHeap::score_of(kh.at(0)); else root = hp.S(0);
     // One wavefront per user and nothing else on the SIMD: the walk is a chain of memory round trips unless the loads of many
     // steps are in flight.  Steps go in groups of kGroup: the next group's kGroup loads per lane are issued before the
     // current group is examined (8 steps ahead, shifted through registers, measured 0.65 us per step = 0.39 ms per user).
@@ -574,20 +639,34 @@ __global__ __launch_bounds__(64) void exact_wave_kernel(const T *__restrict__ S_
                 if (!mask) break;
                 const int first = __builtin_ctzll(mask);
                 const T fv = __shfl(v, first, kWave);
-                if constexpr (REG) {
+                if constexpr (KEYED) {
+                    kh.sift(0, KeyHeap::make((float)fv, t0 + first));                  // heapq.heapreplace
+                    root = (T)KeyHeap::score_of(kh.at(0));
+                } else if constexpr (REG) {
                     hp.set(0, fv, t0 + first); sift_up(hp, k, 0);
+                    root = hp.S(0);
                 } else {
                     if (lane == 0) { hp.set(0, fv, t0 + first); sift_up(hp, k, 0); }
                     __syncthreads();
+                    root = hp.S(0);
                 }
-                root = hp.S(0);
                 live = live && lane > first;
             }
         }
 #pragma unroll
         for (int q = 0; q < kGroup; q++) cur[q] = nxt[q];
     }
-    if constexpr (REG) {
+    if constexpr (KEYED) {
+        // list.sort(key=score, reverse=True), stable: entry a's rank = how many entries beat it or tie it from the left
+        const float mine = KeyHeap::score_of(kh.key);
+        int rank = 0;
+        for (int c = 0; c < k; c++) {
+            const float cs = KeyHeap::score_of(kh.at(c));
+            rank += (cs > mine || (cs == mine && c < lane)) ? 1 : 0;
+        }
+        if (lane < k) { ids_out[(int64_t)b * K + rank] = (int32_t)(unsigned)(kh.key & 0xffffffffu); scores_out[(int64_t)b * K + rank] = (T)mine; }
+        for (int a = k + lane; a < K; a += 64) { ids_out[(int64_t)b * K + a] = -1; scores_out[(int64_t)b * K + a] = T(0); }
+    } else if constexpr (REG) {
         // list.sort(key=score, reverse=True), stable: entry a's rank = how many entries beat it or tie it from the left
         int rank = 0;
         for (int c = 0; c < k; c++) {
@@ -612,6 +691,92 @@ __global__ __launch_bounds__(64) void exact_wave_kernel(const T *__restrict__ S_
             scores_out[(int64_t)b * K + a] = a < k ? hp.S(a) : T(0);
         }
     }
+}
+
+// The exact walk for the fused route's flagged users (fp32, K <= 64, user-major rows): a block per user stages the user's row in
+// LDS -- 156 KB at a time, all four wavefronts copying with 16-byte accesses, dozens of loads in flight -- and its first
+// wavefront walks it from there.  (exact_wave_kernel reads global memory one group of steps ahead: the group's loads must have
+// landed before the next group starts, one memory round trip per 2,048 items -- 150 us for a 38,048-item row however the row is
+// laid out.)  Steps are tested eight at a time: late in the row almost no item beats the heap's root.
+constexpr int kWalkChunk = 39936;      // items per LDS stage
+#ifdef QREC_WALK_PROBE                 // tools/ubench/exact_walk_probe.hip: phase stamps (100 MHz wall clock) and counts per block
+__device__ long long g_walk_probe[8 * 4096];
+#define QREC_WP(slot, val) do { if (threadIdx.x == 0) g_walk_probe[blockIdx.x * 8 + (slot)] = (val); } while (0)
+#else
+#define QREC_WP(slot, val) do { } while (0)
+#endif
+__global__ __launch_bounds__(256) void exact_walk_lds_kernel(const float *__restrict__ rows, int64_t row_len, int n_items, int K,
+                                                             int32_t *__restrict__ ids_out, float *__restrict__ scores_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *stage = reinterpret_cast<float *>(smem);
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *row = rows + (int64_t)b * row_len;               // row_len: a multiple of 32, rows 128-byte aligned
+    const int k = K < n_items ? K : n_items;
+    KeyHeap kh;
+    kh.lane = lane; kh.k = k; kh.key = ~0ull;
+    float root = 0.f;
+    [[maybe_unused]] long long n_updates = 0, n_groups_hit = 0;
+    QREC_WP(0, (long long)wall_clock64());
+    for (int c0 = 0; c0 < n_items; c0 += kWalkChunk) {
+        const int n = n_items - c0 < kWalkChunk ? n_items - c0 : kWalkChunk;
+        __syncthreads();                                          // the previous stage has been walked
+        for (int i = threadIdx.x * 4; i < n; i += 1024)           // the row is padded to whole tiles: the last vector may run into the pad
+            *reinterpret_cast<f32x4 *>(stage + i) = *reinterpret_cast<const f32x4 *>(row + c0 + i);
+        __syncthreads();
+        if (wave != 0) continue;
+        if (c0 == 0) QREC_WP(1, (long long)wall_clock64());
+        int i0 = 0;
+        if (c0 == 0) {                                            // heapq.heapify of the first k items (k <= 64 <= n)
+            kh.key = lane < k ? KeyHeap::make(stage[lane], lane) : ~0ull;
+            for (int t = k / 2 - 1; t >= 0; t--) kh.sift(t, kh.at(t));
+            root = KeyHeap::score_of(kh.at(0));
+            i0 = k;
+            QREC_WP(2, (long long)wall_clock64());
+        }
+        constexpr int kAhead = 8;
+        for (; i0 < n; i0 += 64 * kAhead) {
+            float v[kAhead];
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < kAhead; q++) {
+                const int i = i0 + 64 * q + lane;
+                v[q] = i < n ? stage[i] : -__builtin_huge_valf();
+                any |= v[q] > root;
+            }
+            if (!__any(any)) continue;
+#ifdef QREC_WALK_PROBE
+            n_groups_hit++;
+#endif
+#pragma unroll
+            for (int q = 0; q < kAhead; q++) {
+                const int t0 = c0 + i0 + 64 * q;
+                bool live = true;
+                while (true) {
+                    const unsigned long long mask = __ballot(live && v[q] > root);
+                    if (!mask) break;
+                    const int first = __builtin_ctzll(mask);
+                    const float fv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[q]), first));
+                    kh.sift(0, KeyHeap::make(fv, t0 + first));                     // heapq.heapreplace
+                    root = KeyHeap::score_of(kh.at(0));
+                    live = live && lane > first;
+#ifdef QREC_WALK_PROBE
+                    n_updates++;
+#endif
+                }
+            }
+        }
+    }
+    if (wave != 0) return;
+    QREC_WP(3, (long long)wall_clock64()); QREC_WP(4, n_updates); QREC_WP(5, n_groups_hit);
+    // list.sort(key=score, reverse=True), stable: entry a's rank = how many entries beat it or tie it from the left
+    const float mine = KeyHeap::score_of(kh.key);
+    int rank = 0;
+    for (int c = 0; c < k; c++) {
+        const float cs = KeyHeap::score_of(kh.at(c));
+        rank += (cs > mine || (cs == mine && c < lane)) ? 1 : 0;
+    }
+    if (lane < k) { ids_out[(int64_t)b * K + rank] = (int32_t)(unsigned)(kh.key & 0xffffffffu); scores_out[(int64_t)b * K + rank] = mine; }
+    for (int a = k + lane; a < K; a += 64) { ids_out[(int64_t)b * K + a] = -1; scores_out[(int64_t)b * K + a] = 0.f; }
 }
 
 // ---- fused evaluation (fp32): score -> mask -> threshold filter in one pass, no B x I block ---------------------------
@@ -987,24 +1152,6 @@ __global__ __launch_bounds__(256, 2) void score_filter_bf16_kernel(
 #pragma unroll
     for (int k = 0; k < NU; k++)
         if (live[k]) cand_n[(int64_t)bs[k] * n_lists + list] = cnt[k];
-}
-
-// rank of this lane's key among the 64 keys of the wavefront (how many are larger): 64 x (2 v_readlane, compare, add) -- no LDS
-// round trips, no dependent shuffles
-__device__ __forceinline__ int wave_rank_u64(unsigned long long key) {
-    const int lo = (int)(unsigned)key, hi = (int)(unsigned)(key >> 32);
-    int rank = 0;
-#pragma unroll
-    for (int j = 0; j < 64; j++) {
-        const unsigned long long o = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, j) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, j);
-        rank += o > key ? 1 : 0;
-    }
-    return rank;
-}
-__device__ __forceinline__ unsigned long long wave_read_u64(unsigned long long key, int src) {
-    const int s = __builtin_amdgcn_readfirstlane(src);
-    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), s) << 32) |
-           (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, s);
 }
 
 constexpr int kSelectWaves = 4;
@@ -1664,8 +1811,12 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
                                1, fb_block, 32, 1, panel, row_len);
             QREC_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL((exact_wave_kernel<float, true>), dim3((unsigned)n), dim3(64), 0, st, fb_block,         // fused route: K + 1 <= 64
-                           n_items, 1, K, (const int32_t *)nullptr, (const int32_t *)nullptr, 1 << 30, fb_ids, fb_sc, panel, row_len);
+        {                                                         // fused route: K + 1 <= 64
+            const int stage_items = n_items < kWalkChunk ? (n_items + 3) / 4 * 4 : kWalkChunk;
+            const size_t walk_lds = (size_t)stage_items * sizeof(float);
+            QREC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&exact_walk_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds));
+            hipLaunchKernelGGL(exact_walk_lds_kernel, dim3((unsigned)n), dim3(256), walk_lds, st, fb_block, row_len, n_items, K, fb_ids, fb_sc);
+        }
         QREC_LAUNCH_CHECK();
         hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n * K + 255) / 256)), dim3(256), 0, st, flagged_list, off, n, K, fb_ids, fb_sc,
                            ids_out, scores_out);
