@@ -407,11 +407,14 @@ int qrec_ema_update(float *d_target, const float *d_online, float tau, int64_t n
  * bit-identical to the reference's.  Outputs [n_batch_users][N] (ids -1 padded when
  * n_items < N).  Tables are [rows][ld] with ld a multiple of 32 floats / 16 doubles and columns [d, ld) zero.
  * N <= 100 as in base/recommender.py:132-134.  Two routes, same lists:
- *   fused (fp32, ld <= 128, N <= 63, n_items >= 16,384): a per-user threshold from every 8th item tile, then ONE pass
- *     that scores on the MFMA and keeps only what reaches the threshold and is not rated -- no users x items block is
- *     ever written; users whose N+1 best scores are not pairwise distinct (the only case in which the heap's history
- *     shows) are redone by the block route, a few hundred at a time.  The rated CSR must then have ASCENDING item ids
- *     inside a row.  The call synchronises `stream` once (it reads back how many such users there are).
+ *   fused (fp32, ld <= 128, N <= 63, n_items >= 16,384): a per-user threshold, then a pass that keeps only the items
+ *     whose score reaches it -- no users x items block is ever written.  For ld = 32 / 64 / 128 both passes run on bf16
+ *     copies of the tables (v_mfma_f32_32x32x16_bf16) against thresholds lowered by a proven bound on the rounding, and the
+ *     few dozen survivors per user are re-scored by the block route's own fp32 MFMA sequence, so ids and scores are
+ *     bit-identical to the block route's (env QREC_EVAL_F32_FILTER: both passes in fp32, as for other ld).  Users whose
+ *     N+1 best scores are not pairwise distinct (the only case in which the heap's history shows) get the exact
+ *     sequential walk, a few hundred at a time.  The rated CSR must then have ASCENDING item ids inside a row.  The call
+ *     synchronises `stream` once (it reads back how many such users there are).
  *   block (everything else; forced by env QREC_EVAL_BLOCK_PATH): scores into a transposed users x items block in
  *     d_scratch, mask, sliced top-N with exact fallbacks.
  * Size d_scratch with qrec_score_topk_scratch_bytes (same dtype / sizes / ld / N).                                  */
