@@ -694,10 +694,11 @@ __global__ __launch_bounds__(64) void exact_wave_kernel(const T *__restrict__ S_
 }
 
 // The exact walk for the fused route's flagged users (fp32, K <= 64, user-major rows): a block per user stages the user's row in
-// LDS -- 156 KB at a time, all four wavefronts copying with 16-byte accesses, dozens of loads in flight -- and its first
-// wavefront walks it from there.  (exact_wave_kernel reads global memory one group of steps ahead: the group's loads must have
-// landed before the next group starts, one memory round trip per 2,048 items -- 150 us for a 38,048-item row however the row is
-// laid out.)  Steps are tested eight at a time: late in the row almost no item beats the heap's root.
+// LDS -- 156 KB at a time, all four wavefronts copying with 16-byte accesses, dozens of loads in flight (5 us) -- and its first
+// wavefront walks it from there, eight steps tested at a time: late in the row almost no item beats the heap's root.
+// Measured at 38,048 items (tools/ubench/exact_walk_probe.hip): exact_wave_kernel 154 us whether a step's 64 loads were 64 cache
+// lines or one; this kernel with the level-by-level sift 130 us (walk 119 us for 160 root replacements); with KeyHeap's
+// branch-free sift 100 us -- what is left is one wavefront's dependent instruction chain, ~0.3 us per replacement.
 constexpr int kWalkChunk = 39936;      // items per LDS stage
 #ifdef QREC_WALK_PROBE                 // tools/ubench/exact_walk_probe.hip: phase stamps (100 MHz wall clock) and counts per block
 __device__ long long g_walk_probe[8 * 4096];
@@ -1765,7 +1766,7 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
     // candidates per user: ~ (N + 1) * kSampleStride * 1.1, times ~1.4 behind the bf16 filter; the pool holds 4x that
     int pool_cap = g.n_lists * g.list_cap;
     const int want = 4 * (int)((K + 1) * (use_bf16 ? bf16_stride : kSampleStride) * 1.6);
-    if (pool_cap > want) pool_cap = want < 256 ? 256 : want;
+    if (pool_cap > want) pool_cap = want < 512 ? 512 : want;      // trained tables (uneven item norms) loosen the bound: keep room
     const size_t lds = (size_t)kSelectWaves * pool_cap * sizeof(unsigned long long);
     const dim3 sgrid((unsigned)((n_b + kSelectWaves - 1) / kSelectWaves));
     const float *Ur = use_bf16 ? U : (const float *)nullptr;
