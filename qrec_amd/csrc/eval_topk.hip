@@ -1630,8 +1630,8 @@ __host__ inline FusedGeom fused_geometry(int n_items, int n_b, int ld) {
     g.n_item_tiles = (n_items + 31) / 32;
     // the bf16 route (default): NU user tiles of 32 per wavefront, short candidate lists (its threshold comes from the whole
     // catalogue: a few dozen candidates per user); the fp32 route (QREC_EVAL_F32_FILTER): two tiles, ~200 candidates per user
-    static const bool bf16_filter = getenv("QREC_EVAL_F32_FILTER") == nullptr;
-    static const int eval_nu = getenv("QREC_EVAL_NU") ? atoi(getenv("QREC_EVAL_NU")) : 4;
+    const bool bf16_filter = getenv("QREC_EVAL_F32_FILTER") == nullptr;          // read per call: the tests switch routes in-process
+    const int eval_nu = getenv("QREC_EVAL_NU") ? atoi(getenv("QREC_EVAL_NU")) : 4;
     g.use_bf16 = bf16_filter && (ld == 32 || ld == 64 || ld == 128);
     g.nu = g.use_bf16 ? (ld == 128 || (ld == 64 && eval_nu == 2) ? 2 : 4) : 2;
     g.list_cap = g.use_bf16 ? 16 : kListCap;
@@ -1683,7 +1683,7 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
     int32_t *flags = reinterpret_cast<int32_t *>(base + g.off_flags), *flagged_list = reinterpret_cast<int32_t *>(base + g.off_list);
     int32_t *n_flagged = reinterpret_cast<int32_t *>(base + g.off_nf);
     const int M = K + 1;
-    static const int bf16_stride_env = getenv("QREC_EVAL_BF16_STRIDE") ? atoi(getenv("QREC_EVAL_BF16_STRIDE")) : 1;
+    const int bf16_stride_env = getenv("QREC_EVAL_BF16_STRIDE") ? atoi(getenv("QREC_EVAL_BF16_STRIDE")) : 1;
     const bool use_bf16 = g.use_bf16;
     const int bf16_stride = bf16_stride_env < 1 ? 1 : (bf16_stride_env > kSampleStride ? kSampleStride : bf16_stride_env);
     __bf16 *Ub = reinterpret_cast<__bf16 *>(base + g.off_ub), *Vb = reinterpret_cast<__bf16 *>(base + g.off_vb);

@@ -187,13 +187,44 @@ def test_sliced_topk_and_its_exact_fallbacks(dtype, n_tied_users, N):
     assert np.array_equal(sc.astype(np.float64), os_)
 
 
+def test_exact_walk_spans_several_lds_stages(monkeypatch):
+    """45,000 items: the exact per-user walk of the fused route stages a row in LDS 39,936 items at a time -- the heap must
+    carry over from one stage to the next.  A third of the users have only negative scores (threshold <= 0, so they take the
+    walk), every 11th ties everywhere; lists equal to the block route's (which the other tests tie to the reference's procedure)."""
+    rng = np.random.default_rng(45)
+    n_users, n_items, d, N = 200, 45_000, 64, 20
+    V = (rng.standard_normal((n_items, d)) * 0.3 + 0.2).astype(np.float32)
+    V[40_100:40_140] = V[200:240]                                             # duplicates on both sides of the stage boundary
+    U = (rng.standard_normal((n_users, d)) * 0.3 + 0.5).astype(np.float32)
+    U[::3] = -np.abs(U[::3])
+    U[5::11] = 0.0
+    uu = rng.integers(0, n_users, 40 * n_users); ii = rng.integers(0, n_items, 40 * n_users)
+    rated = user_item_csr(uu, ii, np.ones(uu.size), n_users, n_items)
+    users = rng.permutation(n_users)[:187].astype(np.int32)
+    ids_f, sc_f = DeviceRanker(U, V, rated).topk(users, N)
+    monkeypatch.setenv("QREC_EVAL_BLOCK_PATH", "1")
+    ids_b, sc_b = DeviceRanker(U, V, rated).topk(users, N)
+    assert np.array_equal(ids_f, ids_b) and np.array_equal(sc_f, sc_b)
+
+
+_FUSED_ROUTES = {
+    "bf16": {},                                     # the default: bf16 threshold + filter passes, exact fp32 re-scoring
+    "f32-filter": {"QREC_EVAL_F32_FILTER": "1"},    # both passes in fp32 (what d = 100 takes anyway)
+    "bf16-sparse-sample": {"QREC_EVAL_BF16_STRIDE": "8"},   # long candidate lists: pool > 64, selection by wave-wide maxima
+    "bf16-two-tiles": {"QREC_EVAL_NU": "2"},        # two user tiles per wavefront instead of four
+}
+
+
+@pytest.mark.parametrize("route", list(_FUSED_ROUTES))
 @pytest.mark.parametrize("d,N", [(64, 20), (100, 10), (128, 63), (32, 1)])
-def test_fused_route_equals_the_block_route(d, N, monkeypatch):
-    """The fused evaluation (threshold from every 8th item tile, score + filter in one MFMA pass, wave-per-user
-    selection, flagged users through the block route) against the block route (QREC_EVAL_BLOCK_PATH=1) on the same
-    tables: identical ids and scores -- with item ids sorted by popularity (the best scores crowd the low ids), users
-    whose scores are all negative (threshold <= 0: rated items, masked to 0, outrank everything), users with ties in
-    their top N, and a ragged batch."""
+def test_fused_route_equals_the_block_route(d, N, route, monkeypatch):
+    """The fused evaluation (per-user threshold, score + filter without a users x items block, wave-per-user selection
+    with exact fp32 re-scoring behind the bf16 filter, flagged users through the exact walk) against the block route
+    (QREC_EVAL_BLOCK_PATH=1) on the same tables: identical ids and scores -- with item ids sorted by popularity (the best
+    scores crowd the low ids), users whose scores are all negative (threshold <= 0: rated items, masked to 0, outrank
+    everything), users with ties in their top N, and a ragged batch.  Every variant of the fused route is held to it."""
+    for k, v in _FUSED_ROUTES[route].items():
+        monkeypatch.setenv(k, v)
     rng = np.random.default_rng(d * 1000 + N)
     n_users, n_items = 700, 20_000
     pop = (np.arange(n_items, dtype=np.float64) + 1) ** -0.5                  # item id ~ popularity rank
