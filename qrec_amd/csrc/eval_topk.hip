@@ -1172,6 +1172,20 @@ __global__ __launch_bounds__(64 * kSelectWaves) void select_topk_kernel(
     const int b = blockIdx.x * kSelectWaves + wave;
     if (b >= n_b) return;                                         // whole wavefront
     unsigned long long *pool = reinterpret_cast<unsigned long long *>(smem) + (int64_t)wave * pool_cap;
+    // the re-scoring's user operand (the same for every tile): fetched first, its latency under the pooling below
+    const int r = lane & 31, h = lane >> 5;
+    f32x4 uu[NC][8];
+    int kbs[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int col0 = 64 * c + 32 * h;
+        const bool kv = col0 < ld;
+        kbs[c] = kv ? col0 : 0;
+        const float keep = kv ? 1.f : 0.f;
+        const f32x4 *pu = reinterpret_cast<const f32x4 *>((U ? U : V) + (U ? (int64_t)user_ids[b] : 0) * ld + kbs[c]);
+#pragma unroll
+        for (int q = 0; q < 8; q++) uu[c][q] = pu[q] * keep;
+    }
     // key: score mapped to an order-preserving unsigned, then ~id so that among equal scores the LOWER id is larger
     auto key_of = [](float s, int32_t id) {
         unsigned u = __float_as_uint(s);
@@ -1257,20 +1271,6 @@ __global__ __launch_bounds__(64 * kSelectWaves) void select_topk_kernel(
             }
             total = n_keep;
             kept = lane == 0 ? n_keep : 0;                         // survivors are unrated: the count the checks below sum up
-        }
-        const int r = lane & 31, h = lane >> 5;
-        const int64_t uid = user_ids[b];
-        f32x4 uu[NC][8];                                           // the user's operand: the same for every tile
-        int kbs[NC];
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-            const int col0 = 64 * c + 32 * h;
-            const bool kv = col0 < ld;
-            kbs[c] = kv ? col0 : 0;
-            const float keep = kv ? 1.f : 0.f;
-            const f32x4 *pu = reinterpret_cast<const f32x4 *>(U + uid * ld + kbs[c]);
-#pragma unroll
-            for (int q = 0; q < 8; q++) uu[c][q] = pu[q] * keep;
         }
         auto item_of = [&](int e) -> int64_t {
             const unsigned long long k = e < total ? pool[e] : 0ull;
