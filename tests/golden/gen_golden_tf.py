@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Golden vectors for the reference's TensorFlow-path models, produced by running the reference's OWN model classes
+(model/ranking/{BPR,LightGCN,NGCF,SimGCL}.py, base/{deepRecommender,graphRecommender}.py, util/loss.py) unmodified, with
+``tests/golden/tf1shim.py`` standing in for the ``tensorflow`` module (TF 1.14 is not installable here; see the shim's
+header for what it restates -- primitive op semantics -- and what it does not -- the models).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden_tf.py
+
+Needs /root/reference (build container only).  Writes tf_<model>_filmtrust.npz + one entry per model in golden_tf.json
+next to this file; tests/test_oracle_tf_golden.py checks oracle/tfmodels.py against them.
+
+Per case: a FilmTrust subset (the first 300 users of dataset/FilmTrust/ratings.txt, written to a scratch file, split by the
+reference's own ``-ap 0.2``), a handful of training steps at a small embedding size.  Captured: the id-mapped training
+pairs, every variable's initial and final value, each step's (u, i, j) batch as the reference's sampler drew it, the losses
+the reference printed, the Session.run index of each step (the key to regenerate the step's random draws:
+``tf1shim.random_uniform(seed, run_index, op_index, shape)``), the embeddings the reference scores with, and its measures.
+"""
+import io
+import json
+import os
+import random
+import sys
+import tempfile
+from contextlib import redirect_stdout
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import gen_golden as G          # noqa: E402  (install_stubs, write_conf)
+import tf1shim                  # noqa: E402
+
+REF = G.REF
+N_SUBSET_USERS = 300
+
+
+def make_subset(tmp):
+    """the rows of the first N_SUBSET_USERS distinct users of FilmTrust's ratings file, order kept"""
+    src = os.path.join(REF, "dataset", "FilmTrust", "ratings.txt")
+    users, rows = {}, []
+    with open(src) as f:
+        for line in f:
+            u = line.split()[0]
+            if u not in users:
+                if len(users) == N_SUBSET_USERS:
+                    continue
+                users[u] = 1
+            rows.append(line)
+    os.makedirs(os.path.join(tmp, "sub"), exist_ok=True)
+    path = os.path.join(tmp, "sub", "ratings.txt")
+    with open(path, "w") as f:
+        f.writelines(rows)
+    return "./sub/ratings.txt", len(rows)
+
+
+def run_tf_model(conf_path, seed, module, cls_name, after=None):
+    """QRec(conf) -> model.execute() with the shim as tensorflow; every Session.run that carries a train op is logged"""
+    import importlib
+    from QRec import QRec
+    from util.config import ModelConf
+    tf1shim.reset(seed)
+    mod = importlib.import_module(module)
+    cls = getattr(mod, cls_name)
+    steps = []
+    orig_run = tf1shim.Session.run
+
+    def run(self, fetches, feed_dict=None, **kw):
+        idx = tf1shim.STATE.run_index
+        out = orig_run(self, fetches, feed_dict, **kw)
+        fl = fetches if isinstance(fetches, (list, tuple)) else [fetches]
+        if any(isinstance(t, tf1shim._TrainOp) for t in fl):
+            feeds = {getattr(k, "name", None): np.asarray(v) for k, v in (feed_dict or {}).items()}
+            steps.append(dict(run_index=idx, feeds=feeds, out=[o for o in out if o is not None],
+                              random=list(tf1shim.STATE.run_log[-1][1])))
+        return out
+    tf1shim.Session.run = run
+    rec = {}
+    orig_init = cls.initModel
+
+    def initModel(self):
+        orig_init(self)
+        rec["order0"] = [(self.data.user[a], self.data.item[b]) for a, b, _ in self.data.trainingData]
+    cls.initModel = initModel
+    random.seed(seed); np.random.seed(seed)
+    buf = io.StringIO()
+    try:
+        with redirect_stdout(buf):
+            q = QRec(ModelConf(conf_path))
+            m = cls(q.config, q.trainingData, q.testData)
+            measure = m.execute()
+            extra = after(m) if after else {}
+    finally:
+        tf1shim.Session.run = orig_run
+        cls.initModel = orig_init
+    rec.update(model=m, measure=measure, steps=steps, extra=extra, stdout=buf.getvalue())
+    return rec
+
+
+def pack(rec, name, var_names, conf_text, seed, params):
+    m = rec["model"]
+    order0 = np.array(rec["order0"], dtype=np.int32)
+    arrays = dict(train_uid=order0[:, 0], train_iid=order0[:, 1])
+    vs = {v.name: v for v in tf1shim.all_variables()}
+    used = []
+    for vn in var_names:
+        # a name may have been given to several variables (iterativeRecommender.py:47-48 names three 'U'): the LAST one with the
+        # requested name that received gradients is the model's
+        cands = [v for v in tf1shim.all_variables() if v.name == vn]
+        v = cands[0] if len(cands) == 1 else [c for c in cands if not np.array_equal(c.initial, c.value.detach().numpy())][0]
+        arrays[f"init_{vn}"] = v.initial.astype(np.float32)
+        arrays[f"final_{vn}"] = v.value.detach().numpy().astype(np.float32)
+        used.append(dict(name=vn, index=v.index, init=list(v.init_spec[:1]) + [list(v.init_spec[1]), v.init_spec[2]]))
+    del vs
+    u = [s["feeds"]["u_idx"].astype(np.int32) for s in rec["steps"]]
+    arrays["batch_offsets"] = np.concatenate([[0], np.cumsum([x.size for x in u])]).astype(np.int64)
+    arrays["batch_u"] = np.concatenate(u)
+    arrays["batch_i"] = np.concatenate([s["feeds"]["v_idx"].astype(np.int32) for s in rec["steps"]])
+    arrays["batch_j"] = np.concatenate([s["feeds"]["neg_holder"].astype(np.int32) for s in rec["steps"]])
+    arrays["losses"] = np.array([[float(x) for x in s["out"]] for s in rec["steps"]], dtype=np.float64)
+    arrays["run_index"] = np.array([s["run_index"] for s in rec["steps"]], dtype=np.int64)
+    for k, v in rec["extra"].items():
+        arrays[k] = v
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    return dict(name=name, seed=seed, shim_dtype=str(tf1shim.DT), n_users=len(m.data.user), n_items=len(m.data.item), n_train=int(order0.shape[0]),
+                n_steps=len(rec["steps"]), emb_size=m.emb_size, lr=m.lRate, regU=m.regU, batch_size=m.batch_size,
+                variables=used, random_ops=[[list(map(lambda t: list(t) if isinstance(t, tuple) else t, r)) for r in s["random"]] for s in rec["steps"][:1]],
+                measure=rec["measure"], conf=conf_text, **params)
+
+
+def base_conf(tmp, ratings, **kv):
+    conf = os.path.join(tmp, kv["model__name"] + "_tf.conf")
+    d = dict(ratings=ratings, ratings__setup="-columns 0 1 2", evaluation__setup="-ap 0.2 -b 1", item__ranking="on -topN 10",
+             num__factors="8", num__max__epoch="2", batch_size="1000", learnRate="-init 0.01 -max 1",
+             reg__lambda="-u 0.01 -i 0.01 -b 0.2 -s 0.2", output__setup="off -dir ./results/")
+    d.update(kv)
+    G.write_conf(conf, **d)
+    return conf
+
+
+def case_lightgcn(tmp, ratings):
+    conf = base_conf(tmp, ratings, model__name="LightGCN", LightGCN="-n_layer 2")
+    rec = run_tf_model(conf, 101, "model.ranking.LightGCN", "LightGCN",
+                       after=lambda m: dict(score_U=np.asarray(m.U, np.float32), score_V=np.asarray(m.V, np.float32)))
+    return pack(rec, "tf_lightgcn_filmtrust", ["U", "V"], open(conf).read(), 101, dict(n_layers=2))
+
+
+def case_bpr_tf(tmp, ratings):
+    conf = base_conf(tmp, ratings, model__name="BPR", evaluation__setup="-ap 0.2 -b 1 -tf")
+    rec = run_tf_model(conf, 102, "model.ranking.BPR", "BPR",
+                       after=lambda m: dict(score_U=np.asarray(m.P, np.float32), score_V=np.asarray(m.Q, np.float32)))
+    return pack(rec, "tf_bpr_filmtrust", ["U", "V"], open(conf).read(), 102, {})
+
+
+def case_ngcf(tmp, ratings):
+    conf = base_conf(tmp, ratings, model__name="NGCF")
+
+    def after(m):        # the tables the reference scores with: the inference graph (isTraining = 0, NGCF.py:65-69)
+        U, V = m.sess.run([m.multi_user_embeddings, m.multi_item_embeddings], feed_dict={m.isTraining: 0})
+        return dict(score_U=U.astype(np.float32), score_V=V.astype(np.float32))
+    rec = run_tf_model(conf, 103, "model.ranking.NGCF", "NGCF", after=after)
+    return pack(rec, "tf_ngcf_filmtrust", ["U", "V", "W_0_1", "W_0_2", "W_1_1", "W_1_2"], open(conf).read(), 103, dict(keep_prob=0.9))
+
+
+def case_simgcl(tmp, ratings):
+    conf = base_conf(tmp, ratings, model__name="SimGCL", SimGCL="-n_layer 2 -lambda 0.5 -eps 0.1")
+
+    def after(m):
+        U, V = m.sess.run([m.main_user_embeddings, m.main_item_embeddings])
+        return dict(score_U=U.astype(np.float32), score_V=V.astype(np.float32), best_U=np.asarray(m.U, np.float32), best_V=np.asarray(m.V, np.float32))
+    rec = run_tf_model(conf, 104, "model.ranking.SimGCL", "SimGCL", after=after)
+    # SimGCL.initModel replaces the base class's U / V variables by unnamed Xavier ones (SimGCL.py:42-44): the shim names
+    # unnamed variables Variable_<index>; the two that moved are the model's
+    moved = [v.name for v in tf1shim.all_variables() if not np.array_equal(v.initial, v.value.detach().numpy())]
+    assert len(moved) == 2, moved
+    return pack(rec, "tf_simgcl_filmtrust", moved, open(conf).read(), 104, dict(n_layers=2, cl_rate=0.5, eps=0.1, var_roles=dict(zip(moved, ["U", "V"]))))
+
+
+def main():
+    G.install_stubs()
+    sys.modules["tensorflow"] = tf1shim
+    metas = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        os.symlink(os.path.join(REF, "dataset"), os.path.join(tmp, "dataset"))
+        cwd = os.getcwd(); os.chdir(tmp)
+        try:
+            ratings, n_rows = make_subset(tmp)
+            for case in (case_lightgcn, case_bpr_tf, case_ngcf, case_simgcl):
+                meta = case(tmp, ratings)
+                meta["subset"] = dict(source="dataset/FilmTrust/ratings.txt", first_users=N_SUBSET_USERS, rows=n_rows)
+                metas[meta["name"]] = meta
+                print(meta["name"], "steps", meta["n_steps"], "users", meta["n_users"], "items", meta["n_items"])
+        finally:
+            os.chdir(cwd)
+    with open(os.path.join(HERE, "golden_tf.json"), "w") as f:
+        json.dump(metas, f, indent=1, sort_keys=True, default=str)
+
+
+if __name__ == "__main__":
+    main()

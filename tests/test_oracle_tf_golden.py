@@ -1,0 +1,124 @@
+"""The TensorFlow-path oracle (oracle/tfmodels.py, a numpy restatement) against runs of the REFERENCE'S OWN model classes.
+
+tests/golden/gen_golden_tf.py executes model/ranking/{BPR (trainModel_tf), LightGCN, NGCF, SimGCL}.py of the reference
+unmodified -- QRec(conf) -> model.execute(), the reference's sampler, its adjacency builder, its graph construction, its
+training loop -- with tests/golden/tf1shim.py in place of the tensorflow module (TF 1.14 is not installable here; the shim
+restates the primitive ops the reference calls and evaluates them with torch autograd in float32).  The fixtures hold what
+those runs saw and produced; here the restatement is driven with the same initial values, the same batches and the same
+random draws and must reproduce the losses the reference printed at every step, every trained variable and the tables the
+reference scores with.
+
+Tolerances: both sides compute in float32 with different summation orders (torch sparse / dense kernels vs scipy / numpy);
+Adam divides by sqrt(v), which amplifies rounding noise of near-zero gradient entries early on.  A wrong constant, a missing
+term or a different update order shows up at 1e-2 and above; the bars below are 50x tighter than that.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import tfmodels as T
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, HERE)
+import tf1shim  # noqa: E402  (only random_uniform: the regenerable draws)
+
+META = json.load(open(os.path.join(HERE, "golden_tf.json")))
+
+
+def load(name):
+    return META[name], np.load(os.path.join(HERE, name + ".npz"))
+
+
+def batches(z):
+    off = z["batch_offsets"]
+    for k in range(off.size - 1):
+        s = slice(off[k], off[k + 1])
+        yield k, z["batch_u"][s], z["batch_i"][s], z["batch_j"][s]
+
+
+def close(a, b, what, rtol=2e-4, atol=2e-6):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
+
+
+def test_shim_draws_are_regenerable():
+    """the fixtures store run indices, not noise: the same key must give the same numbers on any machine"""
+    a = tf1shim.random_uniform(104, 3, 1, (5, 4))
+    assert a.dtype == np.float32 and a.shape == (5, 4)
+    assert np.array_equal(a, tf1shim.random_uniform(104, 3, 1, (5, 4)))
+    i = tf1shim.initial_draw(7, 2, "truncated_normal", (1000, 4), 0.005)
+    assert np.abs(i).max() <= 0.01 + 1e-9 and abs(float(i.std()) - 0.0044) < 4e-4        # truncated at two sigma
+
+
+def test_lightgcn_restatement_follows_the_reference_run():
+    m, z = load("tf_lightgcn_filmtrust")
+    adj = T.joint_norm_adjacency(m["n_users"], m["n_items"], z["train_uid"], z["train_iid"])
+    o = T.LightGCN(z["init_U"], z["init_V"], adj, m["n_layers"], m["lr"], m["regU"])
+    for k, u, i, j in batches(z):
+        loss = o.train_step(u, i, j)
+        close(loss, z["losses"][k, 0], f"loss of step {k}", rtol=2e-5)
+    close(o.E[:m["n_users"]], z["final_U"], "user variable after 12 steps")
+    close(o.E[m["n_users"]:], z["final_V"], "item variable after 12 steps")
+    U, V = o.final_embeddings()
+    close(U, z["score_U"], "self.U"); close(V, z["score_V"], "self.V")
+
+
+def test_bpr_tf_restatement_follows_the_reference_run():
+    m, z = load("tf_bpr_filmtrust")
+    o = T.BprTF(z["init_U"], z["init_V"], m["lr"], m["regU"])
+    for k, u, i, j in batches(z):
+        loss = o.train_step(u, i, j)
+        close(loss, z["losses"][k, 0], f"loss of step {k}", rtol=2e-5)
+    close(o.E[:m["n_users"]], z["final_U"], "U after 12 steps")
+    close(o.E[m["n_users"]:], z["final_V"], "V after 12 steps")
+    close(o.E[:m["n_users"]], z["score_U"], "self.P"); close(o.E[m["n_users"]:], z["score_V"], "self.Q")
+
+
+def test_ngcf_restatement_follows_the_reference_run():
+    m, z = load("tf_ngcf_filmtrust")
+    n = m["n_users"] + m["n_items"]
+    adj = T.joint_norm_adjacency(m["n_users"], m["n_items"], z["train_uid"], z["train_iid"])
+    W = [[z["init_W_0_1"], z["init_W_0_2"]], [z["init_W_1_1"], z["init_W_1_2"]]]
+    o = T.NGCF(z["init_U"], z["init_V"], W, adj, m["lr"], m["regU"])
+    rate = 1.0 - m["keep_prob"]                     # nn.dropout(x, keep_prob) -> rate = 1 - keep_prob; keep where uniform >= rate
+    ops = [r[0] for r in m["random_ops"][0]]
+    assert [r[1] for r in m["random_ops"][0]] == ["dropout", "dropout"] and all(tuple(r[2]) == (n, m["emb_size"]) for r in m["random_ops"][0])
+    for k, u, i, j in batches(z):
+        masks = [(tf1shim.random_uniform(m["seed"], z["run_index"][k], op, (n, m["emb_size"])) >= np.float32(rate)).astype(np.float32) for op in ops]
+        loss = o.train_step(u, i, j, masks)
+        close(loss, z["losses"][k, 0], f"loss of step {k}", rtol=1e-4)
+    close(o.E[:m["n_users"]], z["final_U"], "U after 12 steps", rtol=2e-3, atol=2e-5)
+    close(o.E[m["n_users"]:], z["final_V"], "V after 12 steps", rtol=2e-3, atol=2e-5)
+    for a in range(2):
+        for b in range(2):
+            close(o.W[a][b], z[f"final_W_{a}_{b + 1}"], f"W_{a}_{b + 1} after 12 steps", rtol=2e-3, atol=2e-5)
+    U, V = o.inference_embeddings()
+    close(U, z["score_U"], "inference user table", rtol=2e-3, atol=2e-5); close(V, z["score_V"], "inference item table", rtol=2e-3, atol=2e-5)
+
+
+def test_simgcl_restatement_follows_the_reference_run():
+    m, z = load("tf_simgcl_filmtrust")
+    n = m["n_users"] + m["n_items"]
+    names = {role: name for name, role in m["var_roles"].items()}
+    adj = T.joint_norm_adjacency(m["n_users"], m["n_items"], z["train_uid"], z["train_iid"])
+    o = T.SimGCL(z["init_" + names["U"]], z["init_" + names["V"]], adj, m["n_layers"], m["lr"], m["regU"], m["cl_rate"], m["eps"])
+    ops = [r[0] for r in m["random_ops"][0]]       # creation order in SimGCL.py: view 1 layer 1, layer 2, view 2 layer 1, layer 2
+    assert len(ops) == 2 * m["n_layers"] and all(r[1] == "random_uniform" for r in m["random_ops"][0])
+    # sign(emb) in the perturbation (SimGCL.py:35) is discontinuous: an entry of the propagated embedding within rounding of zero
+    # takes opposite signs in the two float32 evaluations and shifts that step's contrastive loss by ~1e-4 relative (seen: one
+    # step of twelve).  So: every step within 1e-3 (an algorithmic difference is >= 1e-2), all but at most two within 1e-5.
+    worst = []
+    for k, u, i, j in batches(z):
+        noises = [tf1shim.random_uniform(m["seed"], z["run_index"][k], op, (n, m["emb_size"])) for op in ops]
+        loss, rec, cl = o.train_step(u, i, j, noises)
+        close([loss, rec, cl], z["losses"][k], f"total / rec / cl loss of step {k}", rtol=1e-3)
+        worst.append(np.max(np.abs(np.array([loss, rec, cl]) - z["losses"][k]) / z["losses"][k]))
+    assert np.sum(np.array(worst) > 1e-5) <= 2, worst
+    E = np.concatenate([z["final_" + names["U"]], z["final_" + names["V"]]])
+    d = np.abs(o.E - E)
+    # the flipped step's gradient reaches many rows through the propagation, by little: entries are O(0.1)
+    assert d.max() < 5e-3 and np.mean(d > 2e-4) < 0.01 and np.median(d) < 5e-6, (d.max(), np.mean(d > 2e-4), np.median(d))
+    U, V = o.final_embeddings()
+    close(U, z["score_U"], "main user embeddings", rtol=2e-2, atol=1e-3); close(V, z["score_V"], "main item embeddings", rtol=2e-2, atol=1e-3)
