@@ -62,6 +62,7 @@ def run_tf_model(conf_path, seed, module, cls_name, after=None):
     mod = importlib.import_module(module)
     cls = getattr(mod, cls_name)
     steps = []
+    self_model = []
     orig_run = tf1shim.Session.run
 
     def run(self, fetches, feed_dict=None, **kw):
@@ -70,7 +71,9 @@ def run_tf_model(conf_path, seed, module, cls_name, after=None):
         fl = fetches if isinstance(fetches, (list, tuple)) else [fetches]
         if any(isinstance(t, tf1shim._TrainOp) for t in fl):
             feeds = {getattr(k, "name", None): np.asarray(v) for k, v in (feed_dict or {}).items()}
-            steps.append(dict(run_index=idx, feeds=feeds, out=[o for o in out if o is not None],
+            labels = {id(t): key for key, t in getattr(self_model[0], "sub_mat", {}).items()} if self_model else {}
+            feeds_all = {labels.get(id(k), getattr(k, "name", None)): v for k, v in (feed_dict or {}).items()}
+            steps.append(dict(run_index=idx, feeds=feeds, feeds_all=feeds_all, out=[o for o in out if o is not None],
                               random=list(tf1shim.STATE.run_log[-1][1])))
         return out
     tf1shim.Session.run = run
@@ -79,6 +82,7 @@ def run_tf_model(conf_path, seed, module, cls_name, after=None):
 
     def initModel(self):
         orig_init(self)
+        self_model.append(self)
         rec["order0"] = [(self.data.user[a], self.data.item[b]) for a, b, _ in self.data.trainingData]
     cls.initModel = initModel
     random.seed(seed); np.random.seed(seed)
@@ -175,16 +179,63 @@ def case_simgcl(tmp, ratings):
     return pack(rec, "tf_simgcl_filmtrust", moved, open(conf).read(), 104, dict(n_layers=2, cl_rate=0.5, eps=0.1, var_roles=dict(zip(moved, ["U", "V"]))))
 
 
+def case_sgl(tmp, ratings):
+    """edge dropout (-augtype 1): two sub-graphs per epoch, drawn with random.sample (SGL.py:136-140); the kept edge lists are
+    recorded (the test rebuilds the normalised sub-adjacencies from them and checks them against the hash of what was fed)"""
+    conf = base_conf(tmp, ratings, model__name="SGL", SGL="-n_layer 2 -lambda 0.1 -droprate 0.1 -augtype 1 -temp 0.2")
+    kept = []
+    orig_sample = random.sample
+
+    def sample(population, k, **kw):
+        r = orig_sample(population, k, **kw)
+        kept.append(np.array(r, dtype=np.int32))
+        return r
+    random.sample = sample
+    # next_batch_pairwise shuffles self.data.trainingData in place (deepRecommender.py:30) and _create_adj_mat indexes the CURRENT
+    # order: the order at every sub-graph draw is recorded too
+    from model.ranking.SGL import SGL
+    orders = []
+    orig_adj = SGL._create_adj_mat
+
+    def _create_adj_mat(self, is_subgraph=False, aug_type=0):
+        if is_subgraph:
+            orders.append([(self.data.user[a], self.data.item[b]) for a, b, _ in self.data.trainingData])
+        return orig_adj(self, is_subgraph, aug_type)
+    SGL._create_adj_mat = _create_adj_mat
+    try:
+        def after(m):
+            U, V = m.sess.run([m.main_user_embeddings, m.main_item_embeddings])
+            return dict(score_U=U.astype(np.float32), score_V=V.astype(np.float32))
+        rec = run_tf_model(conf, 105, "model.ranking.SGL", "SGL", after=after)
+    finally:
+        random.sample = orig_sample
+        SGL._create_adj_mat = orig_adj
+    pos = {p: k for k, p in enumerate(rec["order0"])}
+    for k, o in enumerate(orders):       # as a permutation of the initial order (pairs are distinct)
+        rec["extra"][f"order_{k}"] = np.array([pos[p] for p in o], dtype=np.int32)
+    # which sub-graph each step was fed: hash of (indices, values) of view 1 and view 2
+    fed = []
+    for s in rec["steps"]:
+        fed.append([G.sha(np.asarray(s["feeds_all"][k])) for k in ("adj_indices_sub1", "adj_values_sub1", "adj_indices_sub2", "adj_values_sub2")])
+    rec["extra"].update({f"keep_{k}": v for k, v in enumerate(kept)})
+    meta = pack(rec, "tf_sgl_filmtrust", ["U", "V"], open(conf).read(), 105, dict(n_layers=2, ssl_reg=0.1, temp=0.2, drop_rate=0.1, aug_type=1))
+    meta["n_keep_lists"] = len(kept)
+    meta["fed_sha256"] = fed
+    return meta
+
+
 def main():
     G.install_stubs()
     sys.modules["tensorflow"] = tf1shim
+    if not hasattr(np, "mat"):
+        np.mat = np.asmatrix          # removed in NumPy 2.0; SGL.py:85,90 still call it (the reference pins numpy 1.x)
     metas = {}
     with tempfile.TemporaryDirectory() as tmp:
         os.symlink(os.path.join(REF, "dataset"), os.path.join(tmp, "dataset"))
         cwd = os.getcwd(); os.chdir(tmp)
         try:
             ratings, n_rows = make_subset(tmp)
-            for case in (case_lightgcn, case_bpr_tf, case_ngcf, case_simgcl):
+            for case in (case_lightgcn, case_bpr_tf, case_ngcf, case_simgcl, case_sgl):
                 meta = case(tmp, ratings)
                 meta["subset"] = dict(source="dataset/FilmTrust/ratings.txt", first_users=N_SUBSET_USERS, rows=n_rows)
                 metas[meta["name"]] = meta

@@ -133,11 +133,22 @@ class Tensor:
 
 
 class SparseTensor:
+    """indices / values / dense_shape given as arrays (a constant matrix) or as tensors, e.g. placeholders (SGL.py:36-55 feeds
+    a fresh sub-graph every epoch): then the matrix is assembled when a run needs it"""
+
     def __init__(self, indices, values, dense_shape):
+        self.dynamic = any(isinstance(a, Tensor) for a in (indices, values, dense_shape))
+        if self.dynamic:
+            self.parts = [_t(indices), _t(values), _t(dense_shape)]
+            return
         idx = np.asarray(indices, dtype=np.int64)
         self.dense_shape = tuple(int(s) for s in dense_shape)
         self.indices, self.values = idx, np.asarray(values)
-        self._t = torch.sparse_coo_tensor(torch.from_numpy(idx.T.copy()), torch.as_tensor(self.values, dtype=DT), self.dense_shape).coalesce()
+        self._t = self._assemble(torch.from_numpy(idx.copy()), torch.as_tensor(self.values, dtype=DT), self.dense_shape)
+
+    @staticmethod
+    def _assemble(idx, val, shape):
+        return torch.sparse_coo_tensor(idx.to(torch.int64).T, val.to(DT), tuple(int(s) for s in shape)).coalesce()
 
 
 def _const(x):
@@ -348,6 +359,11 @@ def matrix_diag(x, name=None):
 
 def sparse_tensor_dense_matmul(sp_a, b, adjoint_a=False, adjoint_b=False, name=None):
     assert isinstance(sp_a, SparseTensor) and not adjoint_b
+    if sp_a.dynamic:
+        def f(ctx, idx, val, shp, x):
+            A = SparseTensor._assemble(idx, val, shp.tolist())
+            return torch.sparse.mm(A.t().coalesce() if adjoint_a else A, x)
+        return Tensor(f, sp_a.parts + [_t(b)])
     A = sp_a._t.t().coalesce() if adjoint_a else sp_a._t
     return Tensor(lambda ctx, x: torch.sparse.mm(A, x), [_t(b)])
 

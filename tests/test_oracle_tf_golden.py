@@ -122,3 +122,39 @@ def test_simgcl_restatement_follows_the_reference_run():
     assert d.max() < 5e-3 and np.mean(d > 2e-4) < 0.01 and np.median(d) < 5e-6, (d.max(), np.mean(d > 2e-4), np.median(d))
     U, V = o.final_embeddings()
     close(U, z["score_U"], "main user embeddings", rtol=2e-2, atol=1e-3); close(V, z["score_V"], "main item embeddings", rtol=2e-2, atol=1e-3)
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_sgl_restatement_follows_the_reference_run():
+    """SGL with edge dropout: the reference draws two sub-graphs per epoch (random.sample of the edge list, SGL.py:136-140) and
+    feeds them as sparse-tensor placeholders.  The fixture keeps the kept-edge lists; the sub-adjacencies are rebuilt here and must
+    hash to what the reference fed before they drive the restatement."""
+    m, z = load("tf_sgl_filmtrust")
+    nu, ni, L = m["n_users"], m["n_items"], m["n_layers"]
+    adj = T.joint_norm_adjacency(nu, ni, z["train_uid"], z["train_iid"])
+    o = T.SGL(z["init_U"], z["init_V"], adj, L, m["lr"], m["regU"], m["ssl_reg"], m["temp"])
+    steps_per_epoch = m["n_steps"] // 2
+    assert m["n_keep_lists"] == 4
+    subs = []
+    with np.errstate(divide="ignore"):
+        for k in range(4):
+            keep = z[f"order_{k}"][z[f"keep_{k}"]]      # the sampler shuffles the training list in place: positions are in the order of the draw
+            subs.append(T.joint_norm_adjacency(nu, ni, z["train_uid"][keep], z["train_iid"][keep]))
+    worst = []
+    for k, u, i, j in batches(z):
+        e = k // steps_per_epoch
+        m1, m2 = subs[2 * e], subs[2 * e + 1]
+        if k % steps_per_epoch == 0:
+            for mat, (h_idx, h_val) in ((m1, m["fed_sha256"][k][:2]), (m2, m["fed_sha256"][k][2:])):
+                coo = mat.tocoo()
+                assert _sha(np.stack([coo.row, coo.col], axis=1)) == h_idx and _sha(coo.data) == h_val
+        loss, rec, ssl = o.train_step(u, i, j, [m1] * L, [m2] * L)
+        close([loss, rec, ssl], z["losses"][k], f"total / rec / ssl loss of step {k}", rtol=2e-5)
+    close(o.E[:nu], z["final_U"], "user variable after 12 steps", rtol=2e-3, atol=2e-5)
+    close(o.E[nu:], z["final_V"], "item variable after 12 steps", rtol=2e-3, atol=2e-5)
+    U, V = o.final_embeddings()
+    close(U, z["score_U"], "main user embeddings", rtol=2e-3, atol=2e-5); close(V, z["score_V"], "main item embeddings", rtol=2e-3, atol=2e-5)
