@@ -119,7 +119,8 @@ def pack(rec, name, var_names, conf_text, seed, params):
     arrays["batch_offsets"] = np.concatenate([[0], np.cumsum([x.size for x in u])]).astype(np.int64)
     arrays["batch_u"] = np.concatenate(u)
     arrays["batch_i"] = np.concatenate([s["feeds"]["v_idx"].astype(np.int32) for s in rec["steps"]])
-    arrays["batch_j"] = np.concatenate([s["feeds"]["neg_holder"].astype(np.int32) for s in rec["steps"]])
+    if "neg_holder" in rec["steps"][0]["feeds"]:
+        arrays["batch_j"] = np.concatenate([s["feeds"]["neg_holder"].astype(np.int32) for s in rec["steps"]])
     arrays["losses"] = np.array([[float(x) for x in s["out"]] for s in rec["steps"]], dtype=np.float64)
     arrays["run_index"] = np.array([s["run_index"] for s in rec["steps"]], dtype=np.int64)
     for k, v in rec["extra"].items():
@@ -224,6 +225,57 @@ def case_sgl(tmp, ratings):
     return meta
 
 
+def record_subgraph_draws(cls, method):
+    """wrap random.sample and cls.<method>(is_subgraph=True): the kept-edge lists and the order of the (in-place shuffled) training
+    list at every draw; returns (kept, orders, restore)"""
+    kept, orders = [], []
+    orig_sample, orig_m = random.sample, getattr(cls, method)
+
+    def sample(population, k, **kw):
+        r = orig_sample(population, k, **kw)
+        kept.append(np.array(r, dtype=np.int32))
+        return r
+
+    def wrapped(self, is_subgraph=False, *a, **kw):
+        if is_subgraph:
+            orders.append([(self.data.user[x], self.data.item[y]) for x, y, _ in self.data.trainingData])
+        return orig_m(self, is_subgraph, *a, **kw)
+    random.sample = sample
+    setattr(cls, method, wrapped)
+
+    def restore():
+        random.sample = orig_sample
+        setattr(cls, method, orig_m)
+    return kept, orders, restore
+
+
+def case_buir(tmp, ratings):
+    conf = base_conf(tmp, ratings, model__name="BUIR", BUIR="-n_layer 2 -tau 0.995 -drop_rate 0.2")
+    from model.ranking.BUIR import BUIR
+    kept, orders, restore = record_subgraph_draws(BUIR, "get_adj_mat")
+    try:
+        def after(m):
+            return dict(q_user=m.q_user.astype(np.float32), q_item=m.q_item.astype(np.float32), o_user=m.o_user.astype(np.float32), o_item=m.o_item.astype(np.float32))
+        rec = run_tf_model(conf, 106, "model.ranking.BUIR", "BUIR", after=after)
+    finally:
+        restore()
+    pos = {p: k for k, p in enumerate(rec["order0"])}
+    for k, (kp, o) in enumerate(zip(kept, orders)):
+        rec["extra"][f"keep_{k}"] = kp
+        rec["extra"][f"order_{k}"] = np.array([pos[p] for p in o], dtype=np.int32)
+    fed = [[G.sha(np.asarray(s["feeds_all"][k])) for k in ("adj_indices_sub_o", "adj_values_sub_o", "adj_indices_sub_t", "adj_values_sub_t")] for s in rec["steps"]]
+    vs = tf1shim.all_variables()
+    byname = lambda n: [v for v in vs if v.name == n and not np.array_equal(v.initial, v.value.detach().numpy())][0]   # noqa: E731
+    U, V, tU, tV = byname("U"), byname("V"), byname("t_U"), byname("t_V")
+    W = [v for v in vs if v.initial.shape == (8, 8) and v.name.startswith("Variable_")][0]
+    b = [v for v in vs if v.initial.shape == (1, 8) and v.name.startswith("Variable_")][0]
+    W.name, b.name = "online_mat", "online_bias"
+    meta = pack(rec, "tf_buir_filmtrust", ["U", "V", "t_U", "t_V", "online_mat", "online_bias"], open(conf).read(), 106, dict(n_layers=2, tau=0.995, drop_rate=0.2))
+    meta["n_keep_lists"] = len(kept)
+    meta["fed_sha256"] = fed
+    return meta
+
+
 def main():
     G.install_stubs()
     sys.modules["tensorflow"] = tf1shim
@@ -235,7 +287,7 @@ def main():
         cwd = os.getcwd(); os.chdir(tmp)
         try:
             ratings, n_rows = make_subset(tmp)
-            for case in (case_lightgcn, case_bpr_tf, case_ngcf, case_simgcl, case_sgl):
+            for case in (case_lightgcn, case_bpr_tf, case_ngcf, case_simgcl, case_sgl, case_buir):
                 meta = case(tmp, ratings)
                 meta["subset"] = dict(source="dataset/FilmTrust/ratings.txt", first_users=N_SUBSET_USERS, rows=n_rows)
                 metas[meta["name"]] = meta

@@ -229,6 +229,17 @@ class Variable(Tensor):
         super().__init__(lambda ctx: self.value, name=name or f"Variable_{idx}", dtype=float32)
         STATE.variables.append(self)
 
+    def initialized_value(self):
+        return self.initial.copy()
+
+    def assign(self, value, use_locking=None, name=None):
+        """an op: evaluated in a run, it replaces the variable's value (BUIR.py:122-123, the target tables' moving average)"""
+        def f(ctx, v):
+            with torch.no_grad():
+                self.value.copy_(v.detach())
+            return self.value
+        return Tensor(f, [_t(value)], name="assign")
+
 
 def global_variables_initializer():
     return Tensor(lambda ctx: None, name="init")           # variables hold their initial values from creation on

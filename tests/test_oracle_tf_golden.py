@@ -158,3 +158,43 @@ def test_sgl_restatement_follows_the_reference_run():
     close(o.E[nu:], z["final_V"], "item variable after 12 steps", rtol=2e-3, atol=2e-5)
     U, V = o.final_embeddings()
     close(U, z["score_U"], "main user embeddings", rtol=2e-3, atol=2e-5); close(V, z["score_V"], "main item embeddings", rtol=2e-3, atol=2e-5)
+
+
+def _rebuilt_subgraphs(m, z):
+    nu, ni = m["n_users"], m["n_items"]
+    subs = []
+    with np.errstate(divide="ignore"):
+        for k in range(m["n_keep_lists"]):
+            keep = z[f"order_{k}"][z[f"keep_{k}"]]       # positions in the training list as it stood (shuffled in place) at the draw
+            subs.append(T.joint_norm_adjacency(nu, ni, z["train_uid"][keep], z["train_iid"][keep]))
+    return subs
+
+
+def _assert_fed(mat, h_idx, h_val):
+    coo = mat.tocoo()
+    assert _sha(np.stack([coo.row, coo.col], axis=1)) == h_idx and _sha(coo.data) == h_val
+
+
+def test_buir_restatement_follows_the_reference_run():
+    """BUIR: online / target encoders over two edge-dropout sub-graphs per epoch, tanh predictor, cosine loss, Adam on the online
+    side, moving-average target tables (Variable.assign after every step)."""
+    m, z = load("tf_buir_filmtrust")
+    nu, L = m["n_users"], m["n_layers"]
+    o = T.BUIR(z["init_U"], z["init_V"], z["init_online_mat"], z["init_online_bias"], L, m["lr"], m["tau"])
+    assert np.array_equal(z["init_t_U"], z["init_U"]) and np.array_equal(z["init_t_V"], z["init_V"])      # initialized_value()
+    subs = _rebuilt_subgraphs(m, z)
+    steps_per_epoch = m["n_steps"] // 2
+    for k, u, i, _ in ((k, z["batch_u"][z["batch_offsets"][k]:z["batch_offsets"][k + 1]], z["batch_i"][z["batch_offsets"][k]:z["batch_offsets"][k + 1]], None)
+                       for k in range(m["n_steps"])):
+        e = k // steps_per_epoch
+        mo, mt = subs[2 * e], subs[2 * e + 1]
+        if k % steps_per_epoch == 0:
+            _assert_fed(mo, *m["fed_sha256"][k][:2]); _assert_fed(mt, *m["fed_sha256"][k][2:])
+        loss = o.train_step(u, i, mo, mt)
+        close(loss, z["losses"][k, 0], f"loss of step {k}", rtol=5e-5)
+    close(o.E[:nu], z["final_U"], "online user table", rtol=2e-3, atol=2e-5); close(o.E[nu:], z["final_V"], "online item table", rtol=2e-3, atol=2e-5)
+    close(o.T[:nu], z["final_t_U"], "target user table", rtol=2e-3, atol=2e-5); close(o.T[nu:], z["final_t_V"], "target item table", rtol=2e-3, atol=2e-5)
+    close(o.W, z["final_online_mat"], "predictor weight", rtol=2e-3, atol=2e-5); close(o.b, z["final_online_bias"], "predictor bias", rtol=2e-3, atol=2e-5)
+    adj = T.joint_norm_adjacency(nu, m["n_items"], z["train_uid"], z["train_iid"])
+    for got, key in zip(o.final_tables(adj), ("q_user", "q_item", "o_user", "o_item")):
+        close(got, z[key], key, rtol=2e-3, atol=2e-5)
