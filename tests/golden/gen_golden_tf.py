@@ -53,7 +53,7 @@ def make_subset(tmp):
     return "./sub/ratings.txt", len(rows)
 
 
-def run_tf_model(conf_path, seed, module, cls_name, after=None):
+def run_tf_model(conf_path, seed, module, cls_name, after=None, social=False):
     """QRec(conf) -> model.execute() with the shim as tensorflow; every Session.run that carries a train op is logged"""
     import importlib
     from QRec import QRec
@@ -90,7 +90,7 @@ def run_tf_model(conf_path, seed, module, cls_name, after=None):
     try:
         with redirect_stdout(buf):
             q = QRec(ModelConf(conf_path))
-            m = cls(q.config, q.trainingData, q.testData)
+            m = cls(q.config, q.trainingData, q.testData, q.relation) if social else cls(q.config, q.trainingData, q.testData)
             measure = m.execute()
             extra = after(m) if after else {}
     finally:
@@ -121,7 +121,8 @@ def pack(rec, name, var_names, conf_text, seed, params):
     arrays["batch_i"] = np.concatenate([s["feeds"]["v_idx"].astype(np.int32) for s in rec["steps"]])
     if "neg_holder" in rec["steps"][0]["feeds"]:
         arrays["batch_j"] = np.concatenate([s["feeds"]["neg_holder"].astype(np.int32) for s in rec["steps"]])
-    arrays["losses"] = np.array([[float(x) for x in s["out"]] for s in rec["steps"]], dtype=np.float64)
+    width = max(len(s["out"]) for s in rec["steps"])
+    arrays["losses"] = np.array([[float(x) for x in s["out"]] + [np.nan] * (width - len(s["out"])) for s in rec["steps"]], dtype=np.float64)
     arrays["run_index"] = np.array([s["run_index"] for s in rec["steps"]], dtype=np.int64)
     for k, v in rec["extra"].items():
         arrays[k] = v
@@ -276,6 +277,37 @@ def case_buir(tmp, ratings):
     return meta
 
 
+def social_conf(tmp, ratings, **kv):
+    return base_conf(tmp, ratings, social="./dataset/FilmTrust/trust.txt", social__setup="-columns 0 1 2", **kv)
+
+
+def case_sept(tmp, ratings):
+    """three epochs: the first trains the recommendation task alone (v1_op), the other two the joint objective (v2_op) over a
+    fresh perturbed graph each (two random.sample draws: rating edges, follow edges; SEPT.py:85-96, 276-292)"""
+    conf = social_conf(tmp, ratings, model__name="SEPT", num__max__epoch="3", SEPT="-n_layer 2 -ss_rate 0.005 -drop_rate 0.3 -ins_cnt 10")
+    from model.ranking.SEPT import SEPT
+    kept, orders, restore = record_subgraph_draws(SEPT, "get_adj_mat")
+    try:
+        def after(m):
+            U, V = m.sess.run([m.rec_user_embeddings, m.rec_item_embeddings])
+            return dict(score_U=U.astype(np.float32), score_V=V.astype(np.float32),
+                        follower=np.array([m.data.user[r[0]] for r in m.social.relation], dtype=np.int32),
+                        followee=np.array([m.data.user[r[1]] for r in m.social.relation], dtype=np.int32))
+        rec = run_tf_model(conf, 107, "model.ranking.SEPT", "SEPT", after=after, social=True)
+    finally:
+        restore()
+    assert len(kept) == 2 * len(orders)
+    pos = {p: k for k, p in enumerate(rec["order0"])}
+    for k, o in enumerate(orders):
+        rec["extra"][f"keep_{k}"] = kept[2 * k]; rec["extra"][f"skeep_{k}"] = kept[2 * k + 1]
+        rec["extra"][f"order_{k}"] = np.array([pos[p] for p in o], dtype=np.int32)
+    fed = [[G.sha(np.asarray(s["feeds_all"][k])) for k in ("adj_indices_sub", "adj_values_sub")] if "adj_indices_sub" in s["feeds_all"] else [] for s in rec["steps"]]
+    meta = pack(rec, "tf_sept_filmtrust", ["U", "V"], open(conf).read(), 107, dict(n_layers=2, ss_rate=0.005, drop_rate=0.3, ins_cnt=10))
+    meta["n_subgraphs"] = len(orders)
+    meta["fed_sha256"] = fed
+    return meta
+
+
 def main():
     G.install_stubs()
     sys.modules["tensorflow"] = tf1shim
@@ -287,7 +319,7 @@ def main():
         cwd = os.getcwd(); os.chdir(tmp)
         try:
             ratings, n_rows = make_subset(tmp)
-            for case in (case_lightgcn, case_bpr_tf, case_ngcf, case_simgcl, case_sgl, case_buir):
+            for case in (case_lightgcn, case_bpr_tf, case_ngcf, case_simgcl, case_sgl, case_buir, case_sept):
                 meta = case(tmp, ratings)
                 meta["subset"] = dict(source="dataset/FilmTrust/ratings.txt", first_users=N_SUBSET_USERS, rows=n_rows)
                 metas[meta["name"]] = meta

@@ -198,3 +198,37 @@ def test_buir_restatement_follows_the_reference_run():
     adj = T.joint_norm_adjacency(nu, m["n_items"], z["train_uid"], z["train_iid"])
     for got, key in zip(o.final_tables(adj), ("q_user", "q_item", "o_user", "o_item")):
         close(got, z[key], key, rtol=2e-3, atol=2e-5)
+
+
+def test_sept_restatement_follows_the_reference_run():
+    """SEPT on FilmTrust's trust network: the epochs up to maxEpoch / 3 train the recommendation task alone (v1_opt), the rest the
+    joint objective (v2_opt: tri-training pseudo labels from softmax rows + neighbour discrimination) over a perturbed graph."""
+    m, z = load("tf_sept_filmtrust")
+    nu, ni, L = m["n_users"], m["n_items"], m["n_layers"]
+    uid, iid, fo, fe = z["train_uid"], z["train_iid"], z["follower"], z["followee"]
+    adj = T.joint_norm_adjacency(nu, ni, uid, iid)
+    social, sharing = T.sept_social_views(nu, ni, uid, iid, fo, fe)
+    o = T.SEPT(z["init_U"], z["init_V"], adj, social, sharing, L, m["lr"], m["regU"], m["ss_rate"], m["ins_cnt"])
+    n_epochs = 3
+    steps_per_epoch = m["n_steps"] // n_epochs
+    joint = [e for e in range(n_epochs) if e > n_epochs / 3]      # SEPT.py:276
+    assert len(joint) == m["n_subgraphs"]
+    subs = []
+    for k in range(m["n_subgraphs"]):
+        order = z[f"order_{k}"]
+        subs.append(T.sept_sub_adjacency(nu, ni, uid[order], iid[order], fo, fe, z[f"keep_{k}"], z[f"skeep_{k}"]))
+    for k, u, i, j in batches(z):
+        e = k // steps_per_epoch
+        sub = subs[joint.index(e)] if e in joint else None
+        if sub is not None and k % steps_per_epoch == 0:
+            _assert_fed(sub, *m["fed_sha256"][k])
+        rec, ssl = o.train_step(u, i, j, sub)
+        close(rec, z["losses"][k, 0], f"rec loss of step {k}", rtol=2e-5)
+        if sub is None:
+            assert np.isnan(z["losses"][k, 1])
+        else:
+            close(ssl, m["ss_rate"] * z["losses"][k, 1], f"contrastive loss of step {k}", rtol=1e-4)
+    # 18 Adam steps on entries whose gradient is rounding noise in some steps: a handful of entries (of O(0.1)) drift by a few 1e-5
+    close(o.W[:nu], z["final_U"], "user variable", rtol=2e-3, atol=1e-4); close(o.W[nu:], z["final_V"], "item variable", rtol=2e-3, atol=1e-4)
+    U, V = o.rec_embeddings()
+    close(U, z["score_U"], "rec_user_embeddings", rtol=2e-3, atol=2e-4); close(V, z["score_V"], "rec_item_embeddings", rtol=2e-3, atol=2e-4)
