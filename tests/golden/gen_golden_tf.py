@@ -84,6 +84,7 @@ def run_tf_model(conf_path, seed, module, cls_name, after=None, social=False):
         orig_init(self)
         self_model.append(self)
         rec["order0"] = [(self.data.user[a], self.data.item[b]) for a, b, _ in self.data.trainingData]
+        rec["rating0"] = [float(r) for _, _, r in self.data.trainingData]
     cls.initModel = initModel
     random.seed(seed); np.random.seed(seed)
     buf = io.StringIO()
@@ -308,6 +309,21 @@ def case_sept(tmp, ratings):
     return meta
 
 
+def case_mhcn(tmp, ratings):
+    conf = social_conf(tmp, ratings, model__name="MHCN", MHCN="-n_layer 2 -ss_rate 0.01")
+
+    def after(m):
+        U, V = m.sess.run([m.final_user_embeddings, m.final_item_embeddings])
+        return dict(score_U=U.astype(np.float32), score_V=V.astype(np.float32),
+                    follower=np.array([m.data.user[r[0]] for r in m.social.relation], dtype=np.int32),
+                    followee=np.array([m.data.user[r[1]] for r in m.social.relation], dtype=np.int32))
+    with np.errstate(divide="ignore"):
+        rec = run_tf_model(conf, 108, "model.ranking.MHCN", "MHCN", after=after, social=True)
+    rec["extra"]["train_r"] = np.array(rec["rating0"], dtype=np.float64)
+    names = ["U", "V", "at", "atm"] + [f"{p}_{k}_1" for k in (1, 2, 3, 4) for p in ("g_W", "g_W_b", "sg_W", "sg_W_b")]
+    return pack(rec, "tf_mhcn_filmtrust", names, open(conf).read(), 108, dict(n_layers=2, ss_rate=0.01))
+
+
 def main():
     G.install_stubs()
     sys.modules["tensorflow"] = tf1shim
@@ -319,7 +335,7 @@ def main():
         cwd = os.getcwd(); os.chdir(tmp)
         try:
             ratings, n_rows = make_subset(tmp)
-            for case in (case_lightgcn, case_bpr_tf, case_ngcf, case_simgcl, case_sgl, case_buir, case_sept):
+            for case in (case_lightgcn, case_bpr_tf, case_ngcf, case_simgcl, case_sgl, case_buir, case_sept, case_mhcn):
                 meta = case(tmp, ratings)
                 meta["subset"] = dict(source="dataset/FilmTrust/ratings.txt", first_users=N_SUBSET_USERS, rows=n_rows)
                 metas[meta["name"]] = meta

@@ -125,6 +125,7 @@ class Tensor:
     def __truediv__(self, o): return _binary(torch.div, self, o)
     def __rtruediv__(self, o): return _binary(torch.div, o, self)
     def __neg__(self): return Tensor(lambda ctx, a: -a, [self])
+    def __getitem__(self, k): return Tensor(lambda ctx, a: a[k], [self], dtype=self.dtype)
     def __matmul__(self, o): return matmul(self, o)
     __hash__ = object.__hash__
 
@@ -380,7 +381,8 @@ def sparse_tensor_dense_matmul(sp_a, b, adjoint_a=False, adjoint_b=False, name=N
 
 
 def _sparse_transpose(sp_a):
-    return SparseTensor(sp_a.indices[:, ::-1], sp_a.values, sp_a.dense_shape[::-1])
+    assert not sp_a.dynamic
+    return SparseTensor(np.ascontiguousarray(sp_a.indices[:, ::-1]), sp_a.values, sp_a.dense_shape[::-1])
 
 
 # ---- random ops ------------------------------------------------------------------------------------------------------

@@ -83,7 +83,7 @@ def test_ngcf_restatement_follows_the_reference_run():
     W = [[z["init_W_0_1"], z["init_W_0_2"]], [z["init_W_1_1"], z["init_W_1_2"]]]
     o = T.NGCF(z["init_U"], z["init_V"], W, adj, m["lr"], m["regU"])
     rate = 1.0 - m["keep_prob"]                     # nn.dropout(x, keep_prob) -> rate = 1 - keep_prob; keep where uniform >= rate
-    ops = [r[0] for r in m["random_ops"][0]]
+    ops = sorted(r[0] for r in m["random_ops"][0])       # op index = creation order: layer 1's dropout, layer 2's
     assert [r[1] for r in m["random_ops"][0]] == ["dropout", "dropout"] and all(tuple(r[2]) == (n, m["emb_size"]) for r in m["random_ops"][0])
     for k, u, i, j in batches(z):
         masks = [(tf1shim.random_uniform(m["seed"], z["run_index"][k], op, (n, m["emb_size"])) >= np.float32(rate)).astype(np.float32) for op in ops]
@@ -104,7 +104,7 @@ def test_simgcl_restatement_follows_the_reference_run():
     names = {role: name for name, role in m["var_roles"].items()}
     adj = T.joint_norm_adjacency(m["n_users"], m["n_items"], z["train_uid"], z["train_iid"])
     o = T.SimGCL(z["init_" + names["U"]], z["init_" + names["V"]], adj, m["n_layers"], m["lr"], m["regU"], m["cl_rate"], m["eps"])
-    ops = [r[0] for r in m["random_ops"][0]]       # creation order in SimGCL.py: view 1 layer 1, layer 2, view 2 layer 1, layer 2
+    ops = sorted(r[0] for r in m["random_ops"][0])       # creation order in SimGCL.py: view 1 layer 1, layer 2, view 2 layer 1, layer 2
     assert len(ops) == 2 * m["n_layers"] and all(r[1] == "random_uniform" for r in m["random_ops"][0])
     # sign(emb) in the perturbation (SimGCL.py:35) is discontinuous: an entry of the propagated embedding within rounding of zero
     # takes opposite signs in the two float32 evaluations and shifts that step's contrastive loss by ~1e-4 relative (seen: one
@@ -232,3 +232,35 @@ def test_sept_restatement_follows_the_reference_run():
     close(o.W[:nu], z["final_U"], "user variable", rtol=2e-3, atol=1e-4); close(o.W[nu:], z["final_V"], "item variable", rtol=2e-3, atol=1e-4)
     U, V = o.rec_embeddings()
     close(U, z["score_U"], "rec_user_embeddings", rtol=2e-3, atol=2e-4); close(V, z["score_V"], "rec_item_embeddings", rtol=2e-3, atol=2e-4)
+
+
+def test_mhcn_restatement_follows_the_reference_run():
+    """MHCN: three motif channels + the user-item channel, self-gating, channel attention, hierarchical mutual-information loss
+    with fifteen in-graph shuffles per step (tf.random.shuffle: here the argsort of a regenerable uniform draw)."""
+    m, z = load("tf_mhcn_filmtrust")
+    nu, ni, L = m["n_users"], m["n_items"], m["n_layers"]
+    uid, iid = z["train_uid"], z["train_iid"]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        H = T.mhcn_motif_adjacencies(nu, ni, uid, iid, z["follower"], z["followee"])
+    R = T.mhcn_joint_adjacency(nu, ni, uid, iid, z["train_r"])
+    key = {}
+    for k in (1, 2, 3, 4):
+        key[f"gating{k}"] = f"g_W_{k}_1"; key[f"gating_bias{k}"] = f"g_W_b_{k}_1"
+        key[f"sgating{k}"] = f"sg_W_{k}_1"; key[f"sgating_bias{k}"] = f"sg_W_b_{k}_1"
+    key["attention"] = "at"; key["attention_mat"] = "atm"
+    o = T.MHCN(z["init_U"], z["init_V"], {a: z["init_" + b] for a, b in key.items()}, H, R, L, m["lr"], m["regU"], m["ss_rate"])
+    ops = sorted(m["random_ops"][0])                # recorded in evaluation order; the op index is the creation order
+    assert len(ops) == 15 and all(r[1] == "random_shuffle" for r in ops)
+    d = m["emb_size"]
+    want_shapes = [nu, d, nu, d, nu] * 3            # per channel: row_shuffle; row_column_shuffle = columns then rows, twice (MHCN.py:185-190)
+    assert [r[2][0] for r in ops] == want_shapes
+    for k, u, i, j in batches(z):
+        draws = [np.argsort(tf1shim.random_uniform(m["seed"], z["run_index"][k], r[0], r[2]), kind="stable") for r in ops]
+        perms = [tuple(draws[5 * c:5 * c + 5]) for c in range(3)]
+        rec = o.train_step(u, i, j, perms)
+        close(rec, z["losses"][k, 0], f"rec loss of step {k}", rtol=5e-5)
+    close(o.U, z["final_U"], "user table", rtol=2e-3, atol=1e-4); close(o.V, z["final_V"], "item table", rtol=2e-3, atol=1e-4)
+    for a, b in key.items():
+        close(o.w[a], z["final_" + b], a, rtol=2e-3, atol=1e-4)
+    fu, fi, _ = o.forward()
+    close(fu, z["score_U"], "final_user_embeddings", rtol=2e-3, atol=2e-4); close(fi, z["score_V"], "final_item_embeddings", rtol=2e-3, atol=2e-4)
