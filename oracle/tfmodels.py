@@ -1,12 +1,16 @@
 """numpy/scipy restatement of the reference's TensorFlow-1.14 graph models (LightGCN first).
 TEST INFRASTRUCTURE ONLY (see oracle/qrec_oracle.c header).
 
-PARITY STATUS: **partly unpinned.**  tensorflow==1.14.0 (README.md:57) cannot be installed
-here (no cp310 wheel, no network), so the TF arithmetic below is a restatement of TF's
-published op semantics, anchored on the reference's call sites; it is cross-checked against
-torch-CPU autograd (tests/test_oracle_tfmodels.py), not against a TF run.  What IS pinned to
-the live reference: the joint normalized adjacency (base/graphRecommender.py:10-29 is pure
-scipy -> tests/golden/pairwise_adj_filmtrust.npz) and the batch sampler stream
+PARITY STATUS: **pinned to runs of the reference's own model classes, executed through a stand-in for the tensorflow
+module.**  tensorflow==1.14.0 (README.md:57) cannot be installed here (no cp310 wheel, no network).  tests/golden/tf1shim.py
+provides the TF-1.14 API names the reference's eight TF-path classes call, as a lazy graph evaluated with torch (float32,
+autograd); tests/golden/gen_golden_tf.py runs model/ranking/{BPR (trainModel_tf), LightGCN, NGCF, SimGCL, SGL, BUIR, SEPT,
+MHCN}.py unmodified through it and commits initial / final variables, batches, printed losses, scoring tables and the keys
+of every random draw; tests/test_oracle_tf_golden.py holds every class below to those runs, step by step.  What remains a
+restatement of published semantics is each primitive op (and TF's float32 summation orders, inside the tolerances); the
+model graphs are the reference's code.  Also cross-checked against torch-CPU autograd written independently
+(tests/test_oracle_tfmodels.py).  Pinned to the live reference as well: the joint normalized adjacency
+(base/graphRecommender.py:10-29 is pure scipy -> tests/golden/pairwise_adj_filmtrust.npz) and the batch sampler stream
 (base/deepRecommender.py:29-52 -> same fixture, via oracle/qrec_oracle.c).
 
 TF 1.14 op semantics used (third-party, not vendored):
@@ -399,8 +403,8 @@ class SGL:
 
 
 class BUIR:
-    """model/ranking/BUIR.py:13-172 restated (TF 1.14 absent: parity unpinned, gradients cross-checked against
-    torch autograd in tests/test_oracle_tfmodels.py).
+    """model/ranking/BUIR.py:13-172 restated (pinned to a run of the reference's class through tests/golden/tf1shim.py,
+    tests/test_oracle_tf_golden.py; gradients also cross-checked against torch autograd in tests/test_oracle_tfmodels.py).
 
     Online encoder: LightGCN over this epoch's sub-graph ``mat_o`` (mean over [E0..EL], BUIR.py:90-103), then
     q = tanh(online W + b) (:105-107).  Target encoder: the same propagation of the TARGET tables over ``mat_t``,
@@ -480,7 +484,7 @@ class BUIR:
 # l2-normalisation, tri-training pseudo-labels (top-k of averaged softmax rows), neighbour-
 # discrimination contrastive loss with several positives, two Adam optimizers.
 # The graph builders are pure scipy in the reference and ARE pinned to it
-# (tests/golden/sept_graphs_filmtrust.npz); the TF arithmetic is restated (unpinned, see header).
+# (tests/golden/sept_graphs_filmtrust.npz); the TF arithmetic is restated and held to a run of the reference's class (see header).
 # ======================================================================================
 def sept_row_normalised(M: sp.spmatrix) -> sp.csr_matrix:
     """``normalization`` of SEPT.py:53-59 / the tail of get_adj_mat (:107-113): D^-1/2 M D^-1/2 with D = ROW sums
@@ -651,7 +655,7 @@ class SEPT:
 # MHCN  (model/ranking/MHCN.py:15-240) -- multi-channel hypergraph convolution over three motif-induced user-user
 # adjacencies plus the user-item graph, self-gating, channel attention, hierarchical mutual-information maximisation.
 # The graph builders are pure scipy / python in the reference and ARE pinned to it (tests/golden/mhcn_graphs_filmtrust.npz);
-# the TF arithmetic is restated (unpinned, see header).  tf.random.shuffle is not reproducible outside TF: the five
+# the TF arithmetic is restated and held to a run of the reference's class (see header).  tf.random.shuffle is not reproducible outside TF: the five
 # permutations each hierarchical_self_supervision call draws per step are inputs here.
 # ======================================================================================
 def mhcn_motif_adjacencies(n_users: int, n_items: int, uid, iid, follower, followee):
