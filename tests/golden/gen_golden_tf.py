@@ -182,49 +182,44 @@ def case_simgcl(tmp, ratings):
     return pack(rec, "tf_simgcl_filmtrust", moved, open(conf).read(), 104, dict(n_layers=2, cl_rate=0.5, eps=0.1, var_roles=dict(zip(moved, ["U", "V"]))))
 
 
-def case_sgl(tmp, ratings):
-    """edge dropout (-augtype 1): two sub-graphs per epoch, drawn with random.sample (SGL.py:136-140); the kept edge lists are
-    recorded (the test rebuilds the normalised sub-adjacencies from them and checks them against the hash of what was fed)"""
-    conf = base_conf(tmp, ratings, model__name="SGL", SGL="-n_layer 2 -lambda 0.1 -droprate 0.1 -augtype 1 -temp 0.2")
-    kept = []
-    orig_sample = random.sample
-
-    def sample(population, k, **kw):
-        r = orig_sample(population, k, **kw)
-        kept.append(np.array(r, dtype=np.int32))
-        return r
-    random.sample = sample
-    # next_batch_pairwise shuffles self.data.trainingData in place (deepRecommender.py:30) and _create_adj_mat indexes the CURRENT
-    # order: the order at every sub-graph draw is recorded too
+def _case_sgl(tmp, ratings, aug, name, seed):
+    """-augtype 1 (edge dropout): two sub-graphs per epoch; 2 (random walk): two per layer and epoch; 0 (node dropout): two per
+    epoch, each from a dropped-user and a dropped-item list -- all drawn with random.sample (SGL.py:118-140).  The drawn lists
+    are recorded (the test rebuilds the normalised sub-adjacencies from them and checks them against the hash of what was fed)."""
+    conf = base_conf(tmp, ratings, model__name="SGL", SGL=f"-n_layer 2 -lambda 0.1 -droprate 0.1 -augtype {aug} -temp 0.2")
     from model.ranking.SGL import SGL
-    orders = []
-    orig_adj = SGL._create_adj_mat
-
-    def _create_adj_mat(self, is_subgraph=False, aug_type=0):
-        if is_subgraph:
-            orders.append([(self.data.user[a], self.data.item[b]) for a, b, _ in self.data.trainingData])
-        return orig_adj(self, is_subgraph, aug_type)
-    SGL._create_adj_mat = _create_adj_mat
+    kept, orders, restore = record_subgraph_draws(SGL, "_create_adj_mat")
     try:
         def after(m):
             U, V = m.sess.run([m.main_user_embeddings, m.main_item_embeddings])
             return dict(score_U=U.astype(np.float32), score_V=V.astype(np.float32))
-        rec = run_tf_model(conf, 105, "model.ranking.SGL", "SGL", after=after)
+        with np.errstate(divide="ignore"):
+            rec = run_tf_model(conf, seed, "model.ranking.SGL", "SGL", after=after)
     finally:
-        random.sample = orig_sample
-        SGL._create_adj_mat = orig_adj
+        restore()
     pos = {p: k for k, p in enumerate(rec["order0"])}
-    for k, o in enumerate(orders):       # as a permutation of the initial order (pairs are distinct)
+    for k, o in enumerate(orders):       # the training list is shuffled in place by the sampler: as a permutation of the initial order
         rec["extra"][f"order_{k}"] = np.array([pos[p] for p in o], dtype=np.int32)
-    # which sub-graph each step was fed: hash of (indices, values) of view 1 and view 2
-    fed = []
-    for s in rec["steps"]:
-        fed.append([G.sha(np.asarray(s["feeds_all"][k])) for k in ("adj_indices_sub1", "adj_values_sub1", "adj_indices_sub2", "adj_values_sub2")])
     rec["extra"].update({f"keep_{k}": v for k, v in enumerate(kept)})
-    meta = pack(rec, "tf_sgl_filmtrust", ["U", "V"], open(conf).read(), 105, dict(n_layers=2, ssl_reg=0.1, temp=0.2, drop_rate=0.1, aug_type=1))
-    meta["n_keep_lists"] = len(kept)
-    meta["fed_sha256"] = fed
+    keys = [f"adj_{w}_sub{v}" for v in (1, 2) for w in ("indices", "values")] if aug in (0, 1) else \
+           [f"adj_{w}_sub{v}{k}" for k in range(2) for v in (1, 2) for w in ("indices", "values")]
+    fed = [[G.sha(np.asarray(s["feeds_all"][k])) for k in keys] for s in rec["steps"]]
+    meta = pack(rec, name, ["U", "V"], open(conf).read(), seed, dict(n_layers=2, ssl_reg=0.1, temp=0.2, drop_rate=0.1, aug_type=aug))
+    meta["n_keep_lists"] = len(kept); meta["n_subgraphs"] = len(orders)
+    meta["fed_sha256"] = fed; meta["fed_keys"] = keys
     return meta
+
+
+def case_sgl(tmp, ratings):
+    return _case_sgl(tmp, ratings, 1, "tf_sgl_filmtrust", 105)
+
+
+def case_sgl_random_walk(tmp, ratings):
+    return _case_sgl(tmp, ratings, 2, "tf_sgl_rw_filmtrust", 109)
+
+
+def case_sgl_node_dropout(tmp, ratings):
+    return _case_sgl(tmp, ratings, 0, "tf_sgl_nd_filmtrust", 110)
 
 
 def record_subgraph_draws(cls, method):
@@ -335,7 +330,7 @@ def main():
         cwd = os.getcwd(); os.chdir(tmp)
         try:
             ratings, n_rows = make_subset(tmp)
-            for case in (case_lightgcn, case_bpr_tf, case_ngcf, case_simgcl, case_sgl, case_buir, case_sept, case_mhcn):
+            for case in (case_lightgcn, case_bpr_tf, case_ngcf, case_simgcl, case_sgl, case_buir, case_sept, case_mhcn, case_sgl_random_walk, case_sgl_node_dropout):
                 meta = case(tmp, ratings)
                 meta["subset"] = dict(source="dataset/FilmTrust/ratings.txt", first_users=N_SUBSET_USERS, rows=n_rows)
                 metas[meta["name"]] = meta

@@ -129,30 +129,41 @@ def _sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def test_sgl_restatement_follows_the_reference_run():
-    """SGL with edge dropout: the reference draws two sub-graphs per epoch (random.sample of the edge list, SGL.py:136-140) and
-    feeds them as sparse-tensor placeholders.  The fixture keeps the kept-edge lists; the sub-adjacencies are rebuilt here and must
-    hash to what the reference fed before they drive the restatement."""
-    m, z = load("tf_sgl_filmtrust")
-    nu, ni, L = m["n_users"], m["n_items"], m["n_layers"]
+@pytest.mark.parametrize("name", ["tf_sgl_filmtrust", "tf_sgl_rw_filmtrust", "tf_sgl_nd_filmtrust"])
+def test_sgl_restatement_follows_the_reference_run(name):
+    """SGL with edge dropout (-augtype 1), random walk (2: a fresh edge dropout per layer) and node dropout (0): the reference draws
+    its sub-graphs with random.sample every epoch (SGL.py:118-140) and feeds them as sparse-tensor placeholders.  The fixture keeps
+    the drawn lists; the sub-adjacencies are rebuilt here and must hash to what the reference fed before they drive the restatement."""
+    m, z = load(name)
+    nu, ni, L, aug = m["n_users"], m["n_items"], m["n_layers"], m["aug_type"]
     adj = T.joint_norm_adjacency(nu, ni, z["train_uid"], z["train_iid"])
     o = T.SGL(z["init_U"], z["init_V"], adj, L, m["lr"], m["regU"], m["ssl_reg"], m["temp"])
-    steps_per_epoch = m["n_steps"] // 2
-    assert m["n_keep_lists"] == 4
+    n_epochs = 2
+    steps_per_epoch = m["n_steps"] // n_epochs
+    per_epoch = m["n_subgraphs"] // n_epochs
+    assert per_epoch == (2 * L if aug == 2 else 2) and m["n_keep_lists"] == m["n_subgraphs"] * (2 if aug == 0 else 1)
     subs = []
     with np.errstate(divide="ignore"):
-        for k in range(4):
-            keep = z[f"order_{k}"][z[f"keep_{k}"]]      # the sampler shuffles the training list in place: positions are in the order of the draw
-            subs.append(T.joint_norm_adjacency(nu, ni, z["train_uid"][keep], z["train_iid"][keep]))
-    worst = []
+        for k in range(m["n_subgraphs"]):
+            uid, iid = z["train_uid"][z[f"order_{k}"]], z["train_iid"][z[f"order_{k}"]]       # the training list as it stood at the draw
+            if aug == 0:        # dropped users, then dropped items: an edge survives when neither end was dropped
+                alive = ~np.isin(uid, z[f"keep_{2 * k}"]) & ~np.isin(iid, z[f"keep_{2 * k + 1}"])
+                subs.append(T.joint_norm_adjacency(nu, ni, uid[alive], iid[alive]))
+            else:
+                subs.append(T.joint_norm_adjacency(nu, ni, uid[z[f"keep_{k}"]], iid[z[f"keep_{k}"]]))
     for k, u, i, j in batches(z):
         e = k // steps_per_epoch
-        m1, m2 = subs[2 * e], subs[2 * e + 1]
+        mine = subs[per_epoch * e:per_epoch * (e + 1)]
+        # draw order inside an epoch: (view 1, view 2), or for the random walk (layer 0 view 1, layer 0 view 2, layer 1 view 1, ...)
+        mats1 = [mine[2 * l] for l in range(L)] if aug == 2 else [mine[0]] * L
+        mats2 = [mine[2 * l + 1] for l in range(L)] if aug == 2 else [mine[1]] * L
         if k % steps_per_epoch == 0:
-            for mat, (h_idx, h_val) in ((m1, m["fed_sha256"][k][:2]), (m2, m["fed_sha256"][k][2:])):
-                coo = mat.tocoo()
-                assert _sha(np.stack([coo.row, coo.col], axis=1)) == h_idx and _sha(coo.data) == h_val
-        loss, rec, ssl = o.train_step(u, i, j, [m1] * L, [m2] * L)
+            fed = dict(zip(m["fed_keys"], m["fed_sha256"][k]))
+            for v, mats in ((1, mats1), (2, mats2)):
+                for l in (range(L) if aug == 2 else [None]):
+                    tag = f"sub{v}" + ("" if l is None else str(l))
+                    _assert_fed(mats[0 if l is None else l], fed[f"adj_indices_{tag}"], fed[f"adj_values_{tag}"])
+        loss, rec, ssl = o.train_step(u, i, j, mats1, mats2)
         close([loss, rec, ssl], z["losses"][k], f"total / rec / ssl loss of step {k}", rtol=2e-5)
     close(o.E[:nu], z["final_U"], "user variable after 12 steps", rtol=2e-3, atol=2e-5)
     close(o.E[nu:], z["final_V"], "item variable after 12 steps", rtol=2e-3, atol=2e-5)
