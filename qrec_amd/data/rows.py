@@ -57,7 +57,16 @@ class RatingRows(Sequence):
         remap = np.full(n_names, -1, dtype=np.int32)
         if idx.size == 0:
             return np.zeros(0, np.int64), remap
-        uniq, first = np.unique(idx, return_index=True)
-        order = uniq[np.argsort(first, kind="stable")]
+        # first[v] = position of v's first occurrence: assign positions back to front -- of repeated indices the last
+        # assignment stands, which is the earliest position (one pass instead of np.unique's sort of all rows)
+        first = np.full(n_names, idx.size, dtype=np.int64)
+        pos = np.arange(idx.size, dtype=np.int64)
+        first[idx[::-1]] = pos[::-1]
+        if (first[idx] > pos).any():                  # numpy does not promise the order of repeated assignments: checked, not assumed
+            uniq, f = np.unique(idx, return_index=True)
+            first[:] = idx.size
+            first[uniq] = f
+        present = np.flatnonzero(first < idx.size)
+        order = present[np.argsort(first[present], kind="stable")].astype(idx.dtype, copy=False)
         remap[order] = np.arange(order.size, dtype=np.int32)
         return order, remap

@@ -53,6 +53,10 @@ def dedup_user_item(uid: np.ndarray, iid: np.ndarray, rating: np.ndarray, n_item
     the FIRST occurrence, rating of the LAST.  Returns (u, i, r) in global first-occurrence
     order (which, grouped stably by u, is each user's dict order)."""
     key = uid.astype(np.int64) * np.int64(n_items) + iid.astype(np.int64)
+    if key.size:                                      # the usual file has no duplicate (user, item) rows: a plain sort
+        ks = np.sort(key)                             # (vectorised, unstable is fine) settles that several times faster
+        if not (ks[1:] == ks[:-1]).any():             # than the stable argsort the general case needs
+            return uid, iid, rating
     order = np.argsort(key, kind="stable")            # one sort; equal keys stay in file order
     ks = key[order]
     start = np.ones(ks.size, dtype=bool)

@@ -331,6 +331,29 @@ def test_native_loader_equals_python_loader(tmp_path, monkeypatch):
     assert len(nat) == 0 and py == []
 
 
+def test_native_loader_name_table_long_names_shared_prefixes_and_growth(tmp_path, monkeypatch):
+    """The loader's name table keeps a name's first eight bytes inline and compares the rest in the file buffer, tries the
+    previous row's name first and doubles as it fills: names of 1..24 characters, thousands of them sharing their first eight
+    (and first sixteen) bytes, grouped and ungrouped rows, more distinct names than the initial table holds -- same rows,
+    same first-appearance ids as the Python loop."""
+    from qrec_amd.data.rows import RatingRows
+    rng = np.random.default_rng(12)
+    stems = ["", "x", "prefix__", "prefix__prefix__", "abcdefg", "abcdefgh", "abcdefghi"]
+    users = [stems[k % len(stems)] + format(int(v), "x") for k, v in enumerate(rng.integers(0, 1 << 40, 9000))]
+    items = [stems[(k * 3) % len(stems)] + str(int(v)) for k, v in enumerate(rng.integers(0, 10 ** 9, 7000))]
+    u = rng.integers(0, len(users), 60000); i = rng.integers(0, len(items), 60000)
+    grouped = np.sort(u[:30000])                                   # runs of the same user, then a shuffled tail
+    u = np.concatenate([grouped, u[30000:]])
+    text = "".join(f"{users[a]} {items[b]} {1 + (a + b) % 5}\n" for a, b in zip(u.tolist(), i.tolist()))
+    py, nat = _load_both(tmp_path, text, "-columns 0 1 2", monkeypatch)
+    assert isinstance(nat, RatingRows) and len(nat) == 60000 and nat == py
+    seen_u, seen_i = {}, {}
+    for a, b, _ in py:
+        seen_u.setdefault(a, len(seen_u)); seen_i.setdefault(b, len(seen_i))
+    assert nat.user_names == list(seen_u) and nat.item_names == list(seen_i)
+    assert np.array_equal(nat.user_idx, [seen_u[r[0]] for r in py]) and np.array_equal(nat.item_idx, [seen_i[r[1]] for r in py])
+
+
 def test_native_loader_hands_unusual_files_to_the_python_path(tmp_path, monkeypatch):
     """Whatever CPython would parse by its own rules is parsed by CPython: same rows, or the same failure."""
     py, nat = _load_both(tmp_path, "üser i1 3\nu2 i2 4\n", "-columns 0 1 2", monkeypatch)
