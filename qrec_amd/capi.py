@@ -95,7 +95,7 @@ _SIGNATURES = {
     "qrec_ngcf_wgrad_partial_bytes": [_i64, _i32, _vp],
     "qrec_copy_cols": [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _i32, _vp],
     "qrec_zero_rows": [_vp, _i32, _vp, _vp, _i32, _vp],
-    "qrec_score_topk_scratch_bytes": [C.c_int, _i32, _i32, _vp],
+    "qrec_score_topk_scratch_bytes": [C.c_int, _i32, _i32, _i32, _i32, _vp],
     "qrec_score_topk": [_vp, _vp, C.c_int, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "qrec_rank_hits": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "qrec_buir_batch_loss_grad": [_vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],

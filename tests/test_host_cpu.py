@@ -31,6 +31,30 @@ def test_abi_exports_every_declared_symbol():
     assert lib.qrec_version() >= 100
 
 
+def test_ctypes_signatures_agree_with_the_header():
+    """Every prototype of include/qrec_hip.h against the argtypes capi.py binds it with: the same number of parameters, pointers
+    bound as pointers and scalars as scalars.  (ctypes accepts surplus arguments for cdecl functions, so a short argtypes list
+    goes unnoticed until an argument is mis-sized: qrec_score_topk_scratch_bytes was bound with four of its six parameters.)"""
+    import ctypes as C
+    h = open(os.path.join(ROOT, "include", "qrec_hip.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    h = re.sub(r"//[^\n]*", "", h)
+    protos = re.findall(r"\b(qrec_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", h, flags=re.S)
+    names = [n for n, _ in protos]
+    assert len(names) == len(set(names)) and set(names) == set(capi.EXPORTED_SYMBOLS)
+    checked = 0
+    for name, params in protos:
+        ps = [x.strip() for x in params.replace("\n", " ").split(",")] if params.strip() not in ("", "void") else []
+        at = capi._SIGNATURES.get(name)
+        if at is None:
+            continue                      # bound ad hoc (restype-only helpers); still exported, see the test above
+        assert len(at) == len(ps), (name, len(at), len(ps))
+        for k, (a, prm) in enumerate(zip(at, ps)):
+            assert ("*" in prm) == (a in (C.c_void_p, C.c_char_p)), (name, k, prm, a)
+        checked += 1
+    assert checked >= 100
+
+
 def test_option_conf_matches_reference_on_all_stock_conf_lines():
     cases = json.load(open(os.path.join(GOLDEN, "optionconf_cases.json")))
     assert len(cases) > 100
@@ -329,6 +353,31 @@ def test_native_loader_equals_python_loader(tmp_path, monkeypatch):
     # empty file
     py, nat = _load_both(tmp_path, "", "-columns 0 1 2", monkeypatch)
     assert len(nat) == 0 and py == []
+
+
+def test_evaluation_scratch_sizes_by_route(monkeypatch):
+    """qrec_score_topk_scratch_bytes is host arithmetic (no GPU needed): the fused routes never hold a users x items block --
+    0.62 GB (bf16 filter, the default) / 0.65 GB (fp32 filter) against 4.96 GB for the block route at the Yelp2018 shape -- and
+    the environment switches that select a route at launch select the same route here (the caller sizes its buffer with this)."""
+    for k in ("QREC_EVAL_F32_FILTER", "QREC_EVAL_BLOCK_PATH", "QREC_EVAL_NU", "QREC_EVAL_BF16_STRIDE"):
+        monkeypatch.delenv(k, raising=False)
+    nu, ni = 31668, 38048
+    bf16 = capi.score_topk_scratch_bytes(capi.F32, ni, nu, 64, 20)
+    monkeypatch.setenv("QREC_EVAL_F32_FILTER", "1")
+    f32 = capi.score_topk_scratch_bytes(capi.F32, ni, nu, 64, 20)
+    monkeypatch.delenv("QREC_EVAL_F32_FILTER")
+    monkeypatch.setenv("QREC_EVAL_BLOCK_PATH", "1")
+    block = capi.score_topk_scratch_bytes(capi.F32, ni, nu, 64, 20)
+    monkeypatch.delenv("QREC_EVAL_BLOCK_PATH")
+    assert 0.5e9 < bf16 < 0.7e9 and 0.55e9 < f32 < 0.75e9 and bf16 != f32
+    assert block > ni * nu * 4 and block < 1.1 * ni * nu * 4 + 2e8          # the block itself dominates
+    # what cannot take the fused route sizes as the block route: fp64 tables, N + 1 > 64, a small catalogue, ld > 128
+    assert capi.score_topk_scratch_bytes(capi.F64, ni, 2048, 64, 20) > ni * 2048 * 8
+    assert capi.score_topk_scratch_bytes(capi.F32, ni, 2048, 64, 100) > ni * 2048 * 4
+    assert capi.score_topk_scratch_bytes(capi.F32, 5000, 2048, 64, 20) > 5000 * 2048 * 4
+    assert capi.score_topk_scratch_bytes(capi.F32, ni, 2048, 256, 20) > ni * 2048 * 4
+    small, large = capi.score_topk_scratch_bytes(capi.F32, ni, 2048, 64, 20), capi.score_topk_scratch_bytes(capi.F32, ni, 8192, 64, 20)
+    assert small < large < 0.3e9
 
 
 def test_native_loader_name_table_long_names_shared_prefixes_and_growth(tmp_path, monkeypatch):
