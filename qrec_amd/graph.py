@@ -18,20 +18,27 @@ def joint_norm_adjacency(n_users: int, n_items: int, uid: np.ndarray, iid: np.nd
     float32 ones and duplicated (u,i) rows add up, degrees are float32 row sums,
     d = float32(rowsum ** -0.5) with inf -> 0, and each value is fl32(fl32(d_r * a) * d_c)
     (base/graphRecommender.py:15-28).  Columns ascending inside each row."""
+    import scipy.sparse as sp
     n = n_users + n_items
-    uid = np.asarray(uid, dtype=np.int64); iid = np.asarray(iid, dtype=np.int64) + n_users
+    uid = np.asarray(uid, dtype=np.int32); iid = np.asarray(iid, dtype=np.int32) + np.int32(n_users)
     rows = np.concatenate([uid, iid]); cols = np.concatenate([iid, uid])
-    key = rows * n + cols
-    uniq, counts = np.unique(key, return_counts=True)          # sorted by (row, col); duplicates summed
-    r = (uniq // n).astype(np.int64); c = (uniq % n).astype(np.int32)
-    a = counts.astype(np.float32)
-    rowsum = np.bincount(r, weights=a, minlength=n).astype(np.float32)
+    # structure by scipy's counting-sort COO -> CSR (duplicates summed: float32 sums of ones, exact), columns sorted per row;
+    # 0.09 s at the Yelp2018 shape where np.unique over 2.5 M (row, col) keys + a weighted bincount took 0.28-0.5 s -- this runs
+    # twice per epoch in SGL / BUIR and once in SEPT.  The values are formed below with the reference's float32 arithmetic.
+    M = sp.coo_matrix((np.ones(rows.size, np.float32), (rows, cols)), shape=(n, n)).tocsr()
+    M.sort_indices()
+    a = M.data
+    indptr = M.indptr.astype(np.int64); c = M.indices.astype(np.int32)
+    cnt = np.diff(indptr)
+    rowsum = np.zeros(n, np.float32)
+    nz = np.flatnonzero(cnt)
+    if nz.size:
+        rowsum[nz] = np.add.reduceat(a, indptr[:-1][nz])        # integer-valued float32 entries: the sum is exact in any order
     with np.errstate(divide="ignore"):
         d_inv = np.power(rowsum, -0.5)                          # float32 ** python float -> float32
     d_inv[np.isinf(d_inv)] = 0.0
+    r = np.repeat(np.arange(n, dtype=np.int64), cnt)
     vals = (d_inv[r] * a).astype(np.float32) * d_inv[c]
-    indptr = np.zeros(n + 1, dtype=np.int64)
-    np.cumsum(np.bincount(r, minlength=n), out=indptr[1:])
     return indptr, c, vals.astype(np.float32)
 
 
@@ -65,18 +72,12 @@ def spectral_row_key(indptr: np.ndarray, indices: np.ndarray, values: np.ndarray
     sit together: power iteration on A^2 (users -> users, items -> items) with the two trivial eigenvectors
     (sqrt(degree) on either side) projected out, i.e. a vector from the span of the leading non-trivial eigenvectors.
     With planted communities that span is block-constant per community, so sorting by the key lines the communities
-    up; on a structureless graph it is noise and costs nothing but the ~0.5 s of host time.  numpy only."""
+    up; on a structureless graph it is noise and costs nothing but ~0.15 s of host time."""
+    import scipy.sparse as sp
     n = indptr.size - 1
     nnz_row = np.diff(indptr)
-    nonempty = np.nonzero(nnz_row > 0)[0]
-    starts = indptr[:-1][nonempty]
-    idx = indices.astype(np.int64)
-    val = values.astype(np.float64)
-
-    def matvec(x):
-        y = np.zeros(n)
-        y[nonempty] = np.add.reduceat(val * x[idx], starts)
-        return y
+    A = sp.csr_matrix((values.astype(np.float64), indices, indptr), shape=(n, n))
+    matvec = A.dot                               # 25 products: 0.12 s at the Yelp2018 shape (gather + np.add.reduceat: 0.47 s)
 
     def unit_sqrt_deg(lo, hi):
         t = np.zeros(n); t[lo:hi] = np.sqrt(nnz_row[lo:hi])
