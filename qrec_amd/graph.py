@@ -114,7 +114,7 @@ class SpmmPlan:
         XCD then gathers mostly its own communities' operand rows (measured: -20 % on a planted-community graph,
         nothing lost on a structureless one).  Only the order of the segment list changes: same results.
         ``row_chunk``: the row -> run map of another plan over the same nodes (``plan.row_chunk``): per-epoch sub-graphs
-        (SGL, BUIR) reuse the full graph's map instead of paying the 0.3 s of power iterations for every new plan."""
+        (SGL, BUIR) reuse the full graph's map instead of paying the 0.24 s of power iterations for every new plan."""
         n_rows = indptr.size - 1
         nnz_row = np.diff(indptr)
         n_seg_row = np.maximum(1, -(-nnz_row // seg_len)).astype(np.int64)     # ceil, >=1 (empty rows write zeros)
