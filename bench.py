@@ -12,8 +12,15 @@ the bench repeats epochs inside a step until the K timed steps cover >= --min-se
 depend on that grouping (triplets / second); `ms_per_step` is per step, `config.ms_per_epoch` per epoch.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          # N > 1 typed like this: bench.py starts its own N ranks (below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>` with
+the same arguments: one rank per GPU, rank 0's JSON line on the caller's stdout.  Under a launcher (WORLD_SIZE set) it is
+one of the ranks.  The layout can be steered by flag or, for a caller whose command line is fixed, by environment:
+--dist-mode / QREC_DIST_MODE (replicated | sharded), --scaling / QREC_SCALING (weak | strong).
 
 N > 1, one process per GPU (qrec_amd/dist.py; collectives are RCCL bound directly by libqrec_hip.so, torch.distributed
 /gloo is only the control plane).  Users (rows of P, triplets, sampler) are sharded by rank.  --dist-mode replicated
@@ -189,6 +196,22 @@ def hbm_resident_roofline(capi, schedule="user"):
             "avg_launch_ms": ms, "algorithmic_bytes_per_launch": alg, "triplet_updates_per_s": n2 / ms * 1e3}
 
 
+def launch_own_ranks(n: int):
+    """`python bench.py --gpus N` outside a launcher: become `torch.distributed.run` with N ranks of this very command line
+    (exec, so rank 0's single JSON line is the only thing on the caller's stdout and the exit code is the launcher's)."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")                   # the launcher would set it anyway, with a warning on stderr
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,9 +227,11 @@ def main():
     ap.add_argument("--schedule", choices=("item", "user"), default="item",
                     help="visiting order of the epoch's triplets in the Hogwild kernel (DESIGN.md s4)")
     ap.add_argument("--dist-mode", choices=("replicated", "sharded"), default=os.environ.get("QREC_DIST_MODE", "replicated"))
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("QREC_SCALING", "weak"))
     ap.add_argument("--shard-batch", type=int, default=1 << 18, help="sharded mode: triplets per exchange batch and rank")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_own_ranks(args.gpus)           # does not return
 
     # stdout carries ONE line, the result.  Libraries print there too -- RCCL writes its version banner to C stdio's
     # stdout, flushed at exit, i.e. AFTER a Python print -- so file descriptor 1 is pointed at stderr for the whole run and
@@ -218,8 +243,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if world != args.gpus and args.gpus > 1:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     # QREC_FORCE_DIST=1 drives the multi-GPU branch with world size 1 (the gpurun boxes have one GPU): same code path
     # as N > 1 -- delta / apply kernels, the real RCCL communicator -- the collectives degenerate to copies.
     use_dist = world > 1 or os.environ.get("QREC_FORCE_DIST") == "1"
@@ -373,6 +398,28 @@ def main():
     moved = None
     if sharded:
         moved = float(control.allreduce_host(np.array([dstep.exchange.bytes_moved / max(total, 1)]))[0])
+    multi = None
+    if use_dist:
+        # what the run looked like from every rank: the SGD kernel's mean launch time per rank (HIP events on the rank's own
+        # stream) and what RCCL itself reports for the communicator (ncclCommCount / UserRank / CuDevice)
+        q = comm.query() if hasattr(comm, "query") else {"ranks": comm.world, "rank": comm.rank, "device": local_rank}
+        per_rank = control.allgather_host(np.array([avg_kernel_ms, float(q["ranks"]), float(q["rank"]), float(q["device"]), float(n)]))
+        lib = None
+        if hasattr(comm, "query"):
+            path, ver = capi.comm_library()
+            lib = {"library": path, "version": ver}
+        q_floats = int(tables.Q.nbytes // 4)
+        payload = None if sharded else q_floats * 4 + 24          # the fused all-reduce: item-table deltas + 3 fp64 loss terms
+        multi = {"rccl_ranks": int(per_rank[:, 1].min()), "rccl_ranks_agree": bool((per_rank[:, 1] == per_rank[0, 1]).all()),
+                 "rank_devices": [int(x) for x in per_rank[:, 3]], "rccl": lib,
+                 "transport": "rccl" if hasattr(comm, "query") else type(comm).__name__,
+                 "kernel_ms_per_rank": {"min": float(per_rank[:, 0].min()), "max": float(per_rank[:, 0].max()),
+                                        "all": [float(x) for x in per_rank[:, 0]]},
+                 "triplets_per_epoch_per_rank": [int(x) for x in per_rank[:, 4]],
+                 "collectives_per_epoch": ({"all_to_all_batches": dstep.n_batches, "calls": 3 * dstep.n_batches + 1,
+                                            "bytes_leaving_all_ranks": moved} if sharded else
+                                           {"all_reduce": 1, "payload_bytes_per_rank": payload,
+                                            "ring_wire_bytes_per_rank": (2.0 * (world - 1) / world * payload) if world > 1 else 0.0})}
 
     if rank == 0:
         n_job = n_full if strong else world * n
@@ -404,10 +451,14 @@ def main():
                        "timed_seconds": elapsed, "chunk": CHUNK, "parallelism": par,
                        "lr": LR0, "reg": REG_U, "final_loss": final_loss, "final_lr": final_lr,
                        "epoch_close": "device (no host sync inside the timed region)" if not sharded else "device; one row-count read-back per epoch for the exchange",
+                       "dist_mode": args.dist_mode if use_dist else None,
                        **({"xgmi_bytes_per_epoch_all_ranks": moved, "batches_per_epoch": dstep.n_batches} if sharded else {})},
+            **({"multi_gpu": multi} if multi is not None else {}),
             "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": ("profiles/hbm_traffic.json: rocprofv3 PMC passes of this command run by the builder (static; "
+                                            "not re-measured in this run)") if traffic is not None else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_kernel_ms,
                          "note": ("events bracket the epoch's batches incl. their exchanges" if sharded else
                                   "tables (17.8 MB) are cache resident at this shape; bound = L2 atomic units, see DESIGN.md")},

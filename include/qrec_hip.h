@@ -548,6 +548,9 @@ int qrec_comm_unique_id(uint8_t *h_uid);
 int qrec_comm_init(int32_t world, int32_t rank, const uint8_t *h_uid, void **comm);
 int qrec_comm_destroy(void *comm);
 int qrec_comm_info(void *comm, int32_t *world, int32_t *rank);
+/* what RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): the ranks that really
+ * joined, this process's rank among them and the HIP device it is bound to -- bench.py prints them next to a multi-GPU result */
+int qrec_comm_query(void *comm, int32_t *rccl_ranks, int32_t *rccl_rank, int32_t *device);
 int qrec_allreduce(void *comm, void *d_buf, int64_t count, int dtype, void *stream);
 int qrec_allreduce_pair(void *comm, void *d_a, int64_t count_a, int dtype_a, void *d_b, int64_t count_b, int dtype_b,
                         void *stream);

@@ -84,13 +84,17 @@ class DeepRecommender(IterativeRecommender):
         import os
         return (self.config["qrec.mode"] if self.config.contains("qrec.mode") else os.environ.get("QREC_MODE", "exact")) == "throughput"
 
-    def iter_epoch_samples_device(self, n_epochs: int):
+    def iter_epoch_samples_device(self, n_epochs: int, stream=None):
         """``next_batch_pairwise`` without the host: per epoch a uniform shuffle of the training rows (one device sort of
         Philox keys), the rows gathered into that order, one negative per row by rejection against the user's rated
         items (Philox, counter = row).  Same distribution as the reference's shuffle + choice loop
         (base/deepRecommender.py:29-52), not its CPython stream -- judged on the measures, like BPR's throughput mode.
         Yields DEVICE buffers (d_u, d_i, d_j); epoch k + 1 is drawn on a side stream while the caller trains on epoch k.
-        Python's generator is not consumed."""
+        Python's generator is not consumed.
+        ``stream``: the stream the caller's training steps are enqueued on (None = the null stream).  Contract: all steps that
+        read an epoch's buffers are enqueued on THAT stream before the generator is advanced -- the hand-off (the training
+        stream waits for the draw; the draw of epoch k + 1 into the other buffer waits for epoch k - 1's readers) is ordered
+        with events recorded on it."""
         import os
         from ..capi import DeviceBuffer
         if n_epochs <= 0:
@@ -115,20 +119,20 @@ class DeepRecommender(IterativeRecommender):
             ready[epoch % 2].record(side)
         draw(0)
         for epoch in range(n_epochs):
-            capi.stream_wait_event(None, ready[epoch % 2])          # the training stream waits on the device, not the host
+            capi.stream_wait_event(stream, ready[epoch % 2])        # the training stream waits on the device, not the host
             if epoch + 1 < n_epochs:
-                done = capi.Event(); done.record()                   # epoch k-1's steps (readers of the other buffer) are enqueued before this
+                done = capi.Event(); done.record(stream)             # epoch k-1's steps (readers of the other buffer) are enqueued before this
                 capi.stream_wait_event(side, done)
                 draw(epoch + 1)
             yield bufs[epoch % 2]
 
-    def iter_epoch_device_samples(self, n_epochs: int):
+    def iter_epoch_device_samples(self, n_epochs: int, stream=None):
         """(n_rows, d_u, d_i, d_j) per epoch, resident on the device: the reference's CPython batch stream replayed on the
         host one epoch ahead and uploaded (exact mode, default), or drawn on the device (QREC_MODE=throughput)."""
         from ..capi import DeviceBuffer
         if self.throughput_mode():
             n = int(self.data.training_arrays()[0].size)
-            for d_u, d_i, d_j in self.iter_epoch_samples_device(n_epochs):
+            for d_u, d_i, d_j in self.iter_epoch_samples_device(n_epochs, stream):
                 yield n, d_u, d_i, d_j
         else:
             for u, i, j in self.iter_epoch_samples(n_epochs):

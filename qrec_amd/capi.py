@@ -115,6 +115,7 @@ _SIGNATURES = {
     "qrec_comm_init": [_i32, _i32, _vp, _vp],
     "qrec_comm_destroy": [_vp],
     "qrec_comm_info": [_vp, _vp, _vp],
+    "qrec_comm_query": [_vp, _vp, _vp, _vp],
     "qrec_allreduce": [_vp, _vp, _i64, C.c_int, _vp],
     "qrec_allreduce_pair": [_vp, _vp, _i64, C.c_int, _vp, _i64, C.c_int, _vp],
     "qrec_allgather": [_vp, _vp, _vp, _i64, C.c_int, _vp],
@@ -889,6 +890,8 @@ def epoch_close(d_P, p_rows: int, d_Q, q_rows: int, dtype: int, ld: int, d_stats
 
 def mt_sample_range(state625: np.ndarray, n: int, k: int) -> np.ndarray:
     """random.sample(range(n), k) with the exact CPython draw sequence"""
+    from . import require_reference_python
+    require_reference_python("qrec_mt_sample_range (random.sample's pool / selection-set switch)")
     _req(state625, np.uint32, "state625")
     out = np.empty(k, dtype=np.int64)
     _check(load().qrec_mt_sample_range(_hp(state625), n, k, _hp(out)))
@@ -947,6 +950,12 @@ class Comm:
         if s.size != self.world or r.size != self.world:
             raise ValueError("alltoall_rows: one row count per rank expected")
         _check(load().qrec_alltoall_rows(self.handle, _dp(send), _hp(s), _dp(recv), _hp(r), row_bytes, _sh(stream)))
+
+    def query(self) -> dict:
+        """what RCCL reports: ranks in the communicator, this rank, the bound HIP device"""
+        n, r, d = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+        _check(load().qrec_comm_query(self.handle, C.byref(n), C.byref(r), C.byref(d)))
+        return {"ranks": n.value, "rank": r.value, "device": d.value}
 
     def destroy(self):
         if getattr(self, "handle", None):

@@ -34,6 +34,9 @@ struct Rccl {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
 };
 Rccl g_rccl;
 
@@ -96,6 +99,9 @@ int load_rccl() {
     QREC_SYM(GroupEnd, "ncclGroupEnd")
     QREC_SYM(GetErrorString, "ncclGetErrorString")
     QREC_SYM(GetVersion, "ncclGetVersion")
+    QREC_SYM(CommCount, "ncclCommCount")
+    QREC_SYM(CommUserRank, "ncclCommUserRank")
+    QREC_SYM(CommCuDevice, "ncclCommCuDevice")
 #undef QREC_SYM
     return QREC_OK;
 }
@@ -176,6 +182,16 @@ int qrec_comm_info(void *comm, int32_t *world, int32_t *rank) {
     Comm *c = static_cast<Comm *>(comm);
     if (world) *world = c->world;
     if (rank) *rank = c->rank;
+    return QREC_OK;
+}
+
+int qrec_comm_query(void *comm, int32_t *rccl_ranks, int32_t *rccl_rank, int32_t *device) {
+    QREC_REQUIRE(comm, "qrec_comm_query: null communicator");
+    Comm *c = static_cast<Comm *>(comm);
+    int v = 0;
+    if (rccl_ranks) { QREC_NCCL_CHECK(g_rccl.CommCount(c->nccl, &v)); *rccl_ranks = v; }
+    if (rccl_rank) { QREC_NCCL_CHECK(g_rccl.CommUserRank(c->nccl, &v)); *rccl_rank = v; }
+    if (device) { QREC_NCCL_CHECK(g_rccl.CommCuDevice(c->nccl, &v)); *device = v; }
     return QREC_OK;
 }
 

@@ -262,7 +262,10 @@ class LightGCNTrainer:
         self.forward_sum(stream, last_rows=self.row_mask)
         # dE is written at the batch's rows (loss scatter) and read at the batch's rows only (operand mask of the first
         # backward product, addend mask of all of them): clearing those ~6 k rows replaces a 17.8 MB fill
-        capi.zero_rows(self.dE, self.ld, subset, stream)
+        if self.L == 0:      # no backward product: Adam reads dE itself, every row of it -- rows of earlier batches must be gone
+            self.dE.fill_bytes(0, stream)
+        else:
+            capi.zero_rows(self.dE, self.ld, subset, stream)
         if B:
             capi.bpr_batch_loss_grad(self.S, float(self.L + 1), self.nu, self.n, self.ld, d_u, d_i, d_j, B,
                                      self.loss_eps, self.reg, self.dE, self.d_loss, stream, d_row_mask=self.row_mask)
@@ -271,11 +274,17 @@ class LightGCNTrainer:
             self.dp.all_reduce(g); self.dp.all_reduce(self.d_loss)
         capi.adam_step(self.E, self.m, self.v, g, self.n * self.ld, 1.0 / (self.L + 1), self.adam_alpha(),
                        float(self.b1), float(self.b2), float(self.adam_eps), stream)
+        self.last_grad = (g, 1.0 / (self.L + 1), 0.0)
         self.t += 1
         self.b1p = np.float32(self.b1p * self.b1); self.b2p = np.float32(self.b2p * self.b2)
 
     def loss(self, stream=None) -> float:
         return float(self.d_loss.numpy(stream)[0])
+
+    def gradients(self):
+        """the last step's gradient of (U, V) as the reference's minimize() applies it (before Adam)"""
+        g = _applied_gradient(self.last_grad)[:, :self.d]
+        return g[:self.nu], g[self.nu:]
 
     def final_embeddings(self):
         """(U, V) = split(mean(E0..EL)) as float32 host arrays (LightGCN.py:41)."""
@@ -410,6 +419,7 @@ class BprTfTrainer:
         alpha = float(f(f(self.lr) * np.sqrt(f(1) - self.b2p, dtype=f) / (f(1) - self.b1p)))
         capi.adam_step(self.E, self.m, self.v, self.dE, self.n * self.ld, 1.0, alpha, float(self.b1), float(self.b2),
                        float(self.adam_eps), stream, grad_l2=self.reg)
+        self.last_grad = (self.dE, 1.0, self.reg)
         self.b1p = f(self.b1p * self.b1); self.b2p = f(self.b2p * self.b2)
 
     def loss(self, stream=None) -> float:
@@ -419,6 +429,26 @@ class BprTfTrainer:
     def tables(self):
         E = self.E.numpy()
         return E[:self.nu, :self.d].copy(), E[self.nu:, :self.d].copy()
+
+    def gradients(self, before):
+        """``before`` = [U; V] when the step started ([n, d]): the full-table L2 term of BPR.py:83 is reg * theta"""
+        g = _applied_gradient((self.last_grad[0], 1.0, 0.0))[:, :self.d] + np.float32(self.reg) * np.asarray(before, np.float32)
+        return g[:self.nu], g[self.nu:]
+
+
+def _applied_gradient(last, before=None):
+    """Host copy of what a step handed to Adam, BEFORE the update: ``last`` = (gradient buffer, scale, l2 coefficient) as the
+    trainers leave it after ``train_step_async`` (the buffers survive until the next step).  The reference's gradient is
+    scale * buffer + l2 * theta, theta the variable when the step started (``before``, padded like the buffer; needed only
+    when l2 != 0: the Adam kernel forms that term from theta itself).  Parity tests compare this with the gradients the
+    reference's ``minimize`` applied (tests/golden/tf_*.npz: grad<k>_<var>), before Adam's normalisation amplifies noise."""
+    buf, scale, l2 = last
+    g = buf.numpy().astype(np.float32) * np.float32(scale)
+    if l2:
+        if before is None:
+            raise ValueError("this gradient has a full-table L2 part: pass the variable's value at the start of the step")
+        g = g + np.float32(l2) * np.asarray(before, np.float32)
+    return g
 
 
 def unique_first_appearance(idx: np.ndarray) -> np.ndarray:
@@ -562,6 +592,7 @@ class SimGCLTrainer:
             self.dp.all_reduce(self.d_loss.head_view(1))      # rec term: shares add up; the cl term is whole on every rank
         capi.adam_step(self.E, self.m, self.v, g, self.n * self.ld, 1.0 / L, self.adam_alpha(), float(self.b1),
                        float(self.b2), float(self.adam_eps), stream)
+        self.last_grad = (g, 1.0 / L, 0.0)
         self.b1p = np.float32(self.b1p * self.b1); self.b2p = np.float32(self.b2p * self.b2)
         self.step_no += 1
 
@@ -570,6 +601,10 @@ class SimGCLTrainer:
         rec, cl = self.d_loss.numpy(stream)
         cl *= self.cl_rate
         return float(rec + cl), float(rec), float(cl)
+
+    def gradients(self):
+        g = _applied_gradient(self.last_grad)[:, :self.d]
+        return g[:self.nu], g[self.nu:]
 
     def main_embeddings(self):
         self._encode(self.Sm, 0)
@@ -730,6 +765,10 @@ class _Adam:
         capi.adam_step(self.theta, self.m, self.v, grad, self.n, grad_scale, alpha, float(self.b1), float(self.b2),
                        float(self.eps), stream, grad_l2=grad_l2)
         self.b1p = f(self.b1p * self.b1); self.b2p = f(self.b2p * self.b2)
+        self.last = (grad, grad_scale, grad_l2)
+
+    def applied_gradient(self, before=None):
+        return _applied_gradient(self.last, before)
 
 
 class NGCFTrainer:
@@ -849,6 +888,12 @@ class NGCFTrainer:
     def parameters(self):
         E = self.E[0].numpy()[:, :self.d]
         return E[:self.nu].copy(), E[self.nu:].copy(), [[w.numpy()[:self.d, :self.d].copy() for w in pair] for pair in self.W]
+
+    def gradients(self):
+        """(dU, dV, [[dW1, dW2] per layer]) of the last step, before Adam"""
+        g = self.optE.applied_gradient()[:, :self.d]
+        gw = self.optW.applied_gradient()
+        return g[:self.nu], g[self.nu:], [[gw[2 * k + t, :self.d, :self.d] for t in range(2)] for k in range(2)]
 
 
 class RowPartitionedNGCFTrainer:
@@ -1077,6 +1122,10 @@ class SGLTrainer:
         rec, ssl = self.d_loss.numpy(stream)
         return float(rec + self.ssl_reg * ssl), float(rec), float(self.ssl_reg * ssl)
 
+    def gradients(self):
+        g = self.opt.applied_gradient()[:, :self.d]
+        return g[:self.nu], g[self.nu:]
+
     def main_embeddings(self):
         self._forward(0)
         m = (self.S[0].numpy()[:, :self.d] / np.float32(self.L + 1)).astype(np.float32)
@@ -1188,6 +1237,10 @@ class BUIRTrainer:
 
     def weights(self):
         return self.W.numpy()[:self.d, :self.d].copy(), self.b.numpy()[:self.d].copy()
+
+    def gradients(self):
+        """(d online tables [n, d], dW, db) of the last step, before Adam"""
+        return (self.optE.applied_gradient()[:, :self.d], self.optW.applied_gradient()[:self.d, :self.d], self.optb.applied_gradient()[:self.d])
 
     def final_tables(self, adj):
         """(q_user, q_item, o_user, o_item) over the FULL adjacency (BUIR.py:160-167).  The linear layer on all N rows
@@ -1385,6 +1438,13 @@ class SEPTTrainer:
             dp.all_reduce(self.dE0); dp.all_reduce(self.d_loss.head_view(1))
         # d/dW = (dE0 + regU E0) / 2 = dE0 / 2 + regU W / 4
         self.opt[1 if joint else 0].step(self.dE0, grad_scale=0.5, stream=stream, grad_l2=self.reg / 4.0)
+        self.last_opt = self.opt[1 if joint else 0]
+
+    def gradients(self, before):
+        """(dU, dV) of the last step, before Adam; ``before`` = [U; V] when the step started ([n, d])"""
+        pad = np.zeros((self.n, self.ld), np.float32); pad[:, :self.d] = before
+        g = self.last_opt.applied_gradient(pad)[:, :self.d]
+        return g[:self.nu], g[self.nu:]
 
     def losses(self, stream=None):
         """(rec_loss, ss_rate * neighbor_dis_loss) as the reference prints them (SEPT.py:292, 301)"""
@@ -1628,6 +1688,24 @@ class MHCNTrainer:
         for key, opt in self.opt.items():
             opt.step(g[key], stream=stream, grad_l2=self.W_L2)
         self.step_no += 1
+
+    def gradients(self, before):
+        """the last step's gradients by the reference's variable keys (+ "U", "V"), before Adam; ``before``: the same keys ->
+        the variables' values when the step started (every variable has an L2 term: MHCN.py:209-212)"""
+        d, ld = self.d, self.ld
+
+        def padded(a, like):
+            out = np.zeros(like.shape, np.float32); a = np.asarray(a, np.float32)
+            if len(like.shape) == 1:
+                out[:a.size] = a.reshape(-1)
+            else:
+                out[:a.shape[0], :a.shape[1]] = a
+            return out
+        out = {}
+        for key, opt in list(self.opt.items()) + [("U", self.optU), ("V", self.optV)]:
+            g = opt.applied_gradient(padded(before[key], opt.theta))
+            out[key] = g[None, :d].copy() if g.ndim == 1 else (g[:, :d].copy() if key in ("U", "V") else g[:d, :d].copy())
+        return out
 
     def losses(self, stream=None):
         """(rec_loss -- what the reference prints, MHCN.py:223-225 --, ss_loss unscaled)"""

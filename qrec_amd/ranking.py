@@ -89,8 +89,12 @@ class DeviceRanker:
         per_user = capi.score_topk_scratch_bytes(self.code, self.n_items, 4096, self.ld, N) // 4096
         batch = int(max(64, min(n, (_SCRATCH_BUDGET // max(per_user, 1)) // 64 * 64)))
         nb = min(batch, n)
-        if self._cap[0] < nb or self._cap[1] != N:     # kept across calls (per-epoch evaluation)
-            self._scratch = DeviceBuffer(capi.score_topk_scratch_bytes(self.code, self.n_items, nb, self.ld, N), np.uint8)
+        # kept across calls (per-epoch evaluation).  The byte count depends on the evaluation route the library picks from
+        # QREC_EVAL_* at every call (bf16 copies, list capacity): it is asked again each time and the scratch re-made when the
+        # cached one is too small for the route now in force
+        need = capi.score_topk_scratch_bytes(self.code, self.n_items, nb, self.ld, N)
+        if self._cap[0] < nb or self._cap[1] != N or self._scratch.nbytes < need:
+            self._scratch = DeviceBuffer(need, np.uint8)
             self._d_ids = DeviceBuffer((nb, N), np.int32); self._d_sc = DeviceBuffer((nb, N), self.dtype)
             self._cap = (nb, N)
         scratch, d_ids, d_sc = self._scratch, self._d_ids, self._d_sc
@@ -118,6 +122,8 @@ def ranking_measure_strings(test_lens, per_n: dict, Ns) -> list:
     ``per_n[n] = (hits, dcg)`` sequences in testSet_u order, ``test_lens[k] = len(testSet_u[user_k])``.  Same
     operations in the same order as the reference: its ``sum()`` calls are left-to-right fp64 additions, which is what
     ``np.cumsum(...)[-1]`` computes (a scan, not numpy's pairwise ``sum``), so the digits are the same."""
+    from . import require_reference_python
+    require_reference_python("ranking_measure_strings (sum() as plain left-to-right float addition)")
     out = []
     lens = np.asarray(test_lens, dtype=np.int64)
     n_users = lens.size

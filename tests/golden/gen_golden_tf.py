@@ -63,13 +63,22 @@ def run_tf_model(conf_path, seed, module, cls_name, after=None, social=False):
     cls = getattr(mod, cls_name)
     steps = []
     self_model = []
+    seen_ops, first_steps = [], []
     orig_run = tf1shim.Session.run
 
     def run(self, fetches, feed_dict=None, **kw):
         idx = tf1shim.STATE.run_index
-        out = orig_run(self, fetches, feed_dict, **kw)
         fl = fetches if isinstance(fetches, (list, tuple)) else [fetches]
-        if any(isinstance(t, tf1shim._TrainOp) for t in fl):
+        ops = [t for t in fl if isinstance(t, tf1shim._TrainOp)]
+        # the first step of every train op (SEPT has two: the recommendation task alone, then the joint objective): the variables the
+        # step started from and the gradients its minimize() applied -- the pre-Adam comparison point of the HIP trainers
+        first = bool(ops) and id(ops[0]) not in seen_ops
+        before = {v.index: v.value.detach().numpy().copy() for v in tf1shim.all_variables()} if first else None
+        out = orig_run(self, fetches, feed_dict, **kw)
+        if ops:
+            if first:
+                seen_ops.append(id(ops[0]))
+                first_steps.append(dict(step=len(steps), before=before, grads={k: g.copy() for k, g in ops[0].opt.last_grads_by_index.items()}))
             feeds = {getattr(k, "name", None): np.asarray(v) for k, v in (feed_dict or {}).items()}
             labels = {id(t): key for key, t in getattr(self_model[0], "sub_mat", {}).items()} if self_model else {}
             feeds_all = {labels.get(id(k), getattr(k, "name", None)): v for k, v in (feed_dict or {}).items()}
@@ -97,7 +106,7 @@ def run_tf_model(conf_path, seed, module, cls_name, after=None, social=False):
     finally:
         tf1shim.Session.run = orig_run
         cls.initModel = orig_init
-    rec.update(model=m, measure=measure, steps=steps, extra=extra, stdout=buf.getvalue())
+    rec.update(model=m, measure=measure, steps=steps, extra=extra, stdout=buf.getvalue(), first_steps=first_steps)
     return rec
 
 
@@ -115,6 +124,13 @@ def pack(rec, name, var_names, conf_text, seed, params):
         arrays[f"init_{vn}"] = v.initial.astype(np.float32)
         arrays[f"final_{vn}"] = v.value.detach().numpy().astype(np.float32)
         used.append(dict(name=vn, index=v.index, init=list(v.init_spec[:1]) + [list(v.init_spec[1]), v.init_spec[2]]))
+        # grad<k>_<var>: the gradient the k-th train op's FIRST step applied to this variable (absent: the loss of that op does not
+        # reach it); pre<k>_<var>: the variable's value when that step started (k = 0: the initial value, not stored twice)
+        for k, fs in enumerate(rec["first_steps"]):
+            if v.index in fs["grads"]:
+                arrays[f"grad{k}_{vn}"] = fs["grads"][v.index].astype(np.float32)
+            if k > 0:
+                arrays[f"pre{k}_{vn}"] = fs["before"][v.index].astype(np.float32)
     del vs
     u = [s["feeds"]["u_idx"].astype(np.int32) for s in rec["steps"]]
     arrays["batch_offsets"] = np.concatenate([[0], np.cumsum([x.size for x in u])]).astype(np.int64)
@@ -129,7 +145,7 @@ def pack(rec, name, var_names, conf_text, seed, params):
         arrays[k] = v
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
     return dict(name=name, seed=seed, shim_dtype=str(tf1shim.DT), n_users=len(m.data.user), n_items=len(m.data.item), n_train=int(order0.shape[0]),
-                n_steps=len(rec["steps"]), emb_size=m.emb_size, lr=m.lRate, regU=m.regU, batch_size=m.batch_size,
+                n_steps=len(rec["steps"]), first_steps=[fs["step"] for fs in rec["first_steps"]], emb_size=m.emb_size, lr=m.lRate, regU=m.regU, batch_size=m.batch_size,
                 variables=used, random_ops=[[list(map(lambda t: list(t) if isinstance(t, tuple) else t, r)) for r in s["random"]] for s in rec["steps"][:1]],
                 measure=rec["measure"], conf=conf_text, **params)
 

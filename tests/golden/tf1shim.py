@@ -504,7 +504,7 @@ class AdamOptimizer:
         vs = [v for v in variables if v.trainable]
         grads = torch.autograd.grad(loss_value, [v.value for v in vs], allow_unused=True, retain_graph=True)
         alpha = f(self.lr * np.sqrt(f(1) - self.b2p, dtype=f) / (f(1) - self.b1p))
-        applied = {}
+        applied, applied_idx = {}, {}          # by name (names may repeat: iterativeRecommender.py:47-48) and by creation index
         with torch.no_grad():
             for v, g in zip(vs, grads):
                 if g is None:
@@ -514,8 +514,9 @@ class AdamOptimizer:
                 s += (g * g - s) * float(f(1) - self.b2)
                 v.value -= (m * float(alpha)) / (torch.sqrt(s) + float(self.eps))
                 applied[v.name] = g.detach().numpy().copy()
+                applied_idx[v.index] = applied[v.name]
         self.b1p, self.b2p = f(self.b1p * self.b1), f(self.b2p * self.b2)
-        self.last_grads = applied
+        self.last_grads, self.last_grads_by_index = applied, applied_idx
 
 
 train = types.SimpleNamespace(AdamOptimizer=AdamOptimizer)

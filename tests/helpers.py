@@ -42,3 +42,27 @@ def pad_cols(a, ld):
 def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+# ---- parity ledger -------------------------------------------------------------------------------------------------------
+# Every numerical-agreement assertion of the GPU tests goes through ``check``: it asserts ``observed < bound`` AND, when
+# QREC_PARITY_LOG names a file, appends {test, quantity, observed, bound} to it as one JSON line.  A GPU run with the variable
+# set leaves the observed error of every comparison behind (tools/summarize_parity.py folds the lines into
+# profiles/rNN_parity_errors.json: per test and quantity, the worst observed value next to the bound it was held to).
+def check(quantity, observed, bound, ctx=None, inclusive=False):
+    observed = float(observed); bound = float(bound)
+    log = os.environ.get("QREC_PARITY_LOG")
+    if log:
+        test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+        with open(log, "a") as f:
+            f.write(json.dumps(dict(test=test, quantity=quantity, observed=observed, bound=bound)) + "\n")
+    ok = observed <= bound if inclusive else observed < bound
+    assert ok, f"{quantity}: observed {observed:.3e}, bound {bound:.1e}" + (f" [{ctx}]" if ctx is not None else "")
+
+
+def check_rel(quantity, got, want, rel, ctx=None, abs_tol=0.0):
+    """element-wise |got - want| <= rel * |want| (+ abs_tol), recorded as the worst ratio |got - want| / (|want| + abs_tol / rel)"""
+    got = np.asarray(got, dtype=np.float64); want = np.asarray(want, dtype=np.float64)
+    den = np.abs(want) + (abs_tol / rel if abs_tol else 0.0)
+    worst = float(np.max(np.abs(got - want) / np.maximum(den, 1e-300))) if got.size else 0.0
+    check(quantity, worst, rel, ctx=ctx, inclusive=True)

@@ -17,7 +17,7 @@ from qrec_amd.engine import BprSgd, DeviceTables, MfSgd, padded_ld
 from qrec_amd.interactions import user_item_csr
 from qrec_amd.synth import make_dataset, to_csr
 
-from helpers import conf_from_text, load_golden, pad_cols, rel_err, rows_from_golden
+from helpers import check, conf_from_text, load_golden, pad_cols, rel_err, rows_from_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -56,8 +56,9 @@ def test_ordered_kernel_matches_oracle(dim):
         sgd.set_negatives(j)
         loss = sgd.epoch_ordered(lr, ru, ri)
         Pg, Qg = t.download()
-        assert rel_err(Pg, Pr) < tol and rel_err(Qg, Qr) < tol
-        assert abs(loss - lref) / lref < tol
+        check("rel_err(Pg, Pr)", rel_err(Pg, Pr), tol)
+        check("rel_err(Qg, Qr)", rel_err(Qg, Qr), tol)
+        check("abs(loss - lref) / lref", abs(loss - lref) / lref, tol)
         np.testing.assert_allclose(Pg, Pr, rtol=100 * tol, atol=tol)
         assert (t.P.numpy()[:, dim:] == 0).all() and (t.Q.numpy()[:, dim:] == 0).all()  # pad stays zero
 
@@ -195,11 +196,13 @@ def test_mf_family_kernel_matches_oracle(variant, dim, dtype):
     got = sgd.epoch(u, i, r, lr, regU, regI, regB, gm)
     Pg, Qg = t.download(np.float64)
     tol = F64_TOL if dtype == np.float64 else 2e-5   # 20k sequential fp32 updates on 300 rows
-    assert rel_err(Pg, Pr) < tol and rel_err(Qg, Qr) < tol
-    assert abs(got - want) / want < tol
+    check("rel_err(Pg, Pr)", rel_err(Pg, Pr), tol)
+    check("rel_err(Qg, Qr)", rel_err(Qg, Qr), tol)
+    check("abs(got - want) / want", abs(got - want) / want, tol)
     if variant in (capi.MF_SVD, capi.MF_EE):
         Bug, Big = sgd.biases()
-        assert rel_err(Bug, Bur) < tol and rel_err(Big, Bir) < tol
+        check("rel_err(Bug, Bur)", rel_err(Bug, Bur), tol)
+        check("rel_err(Big, Bir)", rel_err(Big, Bir), tol)
         sp, sq, sbu, sbi = sgd.sumsq_terms()
         assert sbu == pytest.approx(O.sumsq(Bug), rel=1e-6 if dtype == np.float32 else 1e-12)
         assert sbi == pytest.approx(O.sumsq(Big), rel=1e-6 if dtype == np.float32 else 1e-12)
@@ -246,8 +249,9 @@ def test_hogwild_single_group_is_the_sequential_recurrence(dim, variant):
         sgd.d_loss.fill_bytes(0)
         capi.bpr_sgd_hogwild(t.P, t.Q, dim, t.ld, sgd.d_u, sgd.d_i, sgd.d_j, n, chunk, 1, 0.05, 0.01, 0.02, sgd.d_loss, variant)
         Pg, Qg = t.download()
-        assert rel_err(Pg, Pr) < F32_TOL and rel_err(Qg, Qr) < F32_TOL
-        assert abs(sgd.loss() - lref) / lref < F32_TOL
+        check("rel_err(Pg, Pr)", rel_err(Pg, Pr), F32_TOL)
+        check("rel_err(Qg, Qr)", rel_err(Qg, Qr), F32_TOL)
+        check("abs(sgd.loss() - lref) / lref", abs(sgd.loss() - lref) / lref, F32_TOL)
         assert (t.P.numpy()[:, dim:] == 0).all() and (t.Q.numpy()[:, dim:] == 0).all()
 
 
@@ -269,8 +273,9 @@ def test_hogwild_full_grid_conflict_free_input_is_exact():
     sgd = BprSgd(t, u, i); sgd.set_negatives(j)
     sgd.epoch_throughput_async(0.05, 0.01, 0.02, chunk=per)
     Pg, Qg = t.download()
-    assert rel_err(Pg, Pr) < F32_TOL and rel_err(Qg, Qr) < F32_TOL
-    assert abs(sgd.loss() - lref) / lref < F32_TOL
+    check("rel_err(Pg, Pr)", rel_err(Pg, Pr), F32_TOL)
+    check("rel_err(Qg, Qr)", rel_err(Qg, Qr), F32_TOL)
+    check("abs(sgd.loss() - lref) / lref", abs(sgd.loss() - lref) / lref, F32_TOL)
 
 
 def test_hogwild_full_size_properties_yelp_shape():
@@ -287,7 +292,7 @@ def test_hogwild_full_size_properties_yelp_shape():
     assert np.array_equal(Pg, P0) and np.array_equal(Qg, Q0)
     Pz, Qz = P0.astype(np.float64), Q0.astype(np.float64)
     lz = O.bpr_sgd(Pz, Qz, u, ind, j, 0.0, 0.001, 0.001)
-    assert abs(sgd.loss() - lz) / lz < F32_TOL
+    check("abs(sgd.loss() - lz) / lz", abs(sgd.loss() - lz) / lz, F32_TOL)
     # (2) one real epoch: no update lost -> within 1% of the strictly sequential result
     #     (the racy read-modify-write variants sit at ~9%)
     Pr, Qr = P0.astype(np.float64), Q0.astype(np.float64)
@@ -306,7 +311,9 @@ def test_hogwild_full_size_properties_yelp_shape():
     s2 = BprSgd(t2, u, ind); s2.set_negatives(j)
     loss = s2.epoch_ordered(0.01, 0.001, 0.001)
     Pg, Qg = t2.download()
-    assert rel_err(Pg, Pr) < F32_TOL and rel_err(Qg, Qr) < F32_TOL and abs(loss - lref) / lref < F32_TOL
+    check("rel_err(Pg, Pr)", rel_err(Pg, Pr), F32_TOL)
+    check("rel_err(Qg, Qr)", rel_err(Qg, Qr), F32_TOL)
+    check("abs(loss - lref) / lref", abs(loss - lref) / lref, F32_TOL)
 
 
 def test_philox_sampler_properties():
@@ -457,8 +464,9 @@ def test_item_major_single_group_is_the_sequential_recurrence_in_its_visiting_or
     sgd.d_stats.fill_bytes(0)
     capi.bpr_sgd_hogwild_item_major(t.P, t.Q, dim, t.ld, sgd.d_u, sgd.d_i, sgd.d_j, n, chunk, 1, flush, 0.05, 0.01, 0.02, sgd.d_stats)
     Pg, Qg = t.download()
-    assert rel_err(Pg, Pr) < F32_TOL and rel_err(Qg, Qr) < F32_TOL
-    assert abs(sgd.loss() - lref) / lref < F32_TOL
+    check("rel_err(Pg, Pr)", rel_err(Pg, Pr), F32_TOL)
+    check("rel_err(Qg, Qr)", rel_err(Qg, Qr), F32_TOL)
+    check("abs(sgd.loss() - lref) / lref", abs(sgd.loss() - lref) / lref, F32_TOL)
     assert (t.P.numpy()[:, dim:] == 0).all() and (t.Q.numpy()[:, dim:] == 0).all()
 
 
@@ -475,7 +483,7 @@ def test_item_major_full_grid_properties_yelp_shape():
     assert np.array_equal(Pg, P0) and np.array_equal(Qg, Q0)
     Pz, Qz = P0.astype(np.float64), Q0.astype(np.float64)
     lz = O.bpr_sgd(Pz, Qz, u, ind, j, 0.0, 0.001, 0.001)
-    assert abs(sgd.loss() - lz) / lz < F32_TOL
+    check("abs(sgd.loss() - lz) / lz", abs(sgd.loss() - lz) / lz, F32_TOL)
     # one real epoch: no update is lost -> a few percent from the sequential result in the same visiting order
     order = _item_major_visit_order(n, 32)
     us, is_, js = sgd.d_u.numpy()[order], sgd.d_i.numpy()[order], sgd.d_j.numpy()[order]
@@ -804,8 +812,9 @@ def test_tables_beyond_4_gib_use_64_bit_addressing(schedule):
         capi.bpr_sgd_hogwild(d_P, d_Q, dim, dim, d_u, d_i, d_j, n, 32, 1, 0.05, 0.01, 0.02, loss)
     got_P = d_P.read_rows(U - n_act, n_act)
     if schedule == "user":     # the item-major single-group run follows ITS visiting order (chunk stride), not the array order
-        assert rel_err(got_P, Pr) < F32_TOL and rel_err(d_Q.numpy(), Qr) < F32_TOL
-        assert abs(loss.numpy()[0] - want) / want < F32_TOL
+        check("rel_err(got_P, Pr)", rel_err(got_P, Pr), F32_TOL)
+        check("rel_err(d_Q.numpy(), Qr)", rel_err(d_Q.numpy(), Qr), F32_TOL)
+        check("abs(loss.numpy()[0] - want) / want", abs(loss.numpy()[0] - want) / want, F32_TOL)
     else:
         assert rel_err(got_P, Pr) < 0.05 and np.isfinite(got_P).all() and not np.array_equal(got_P, P_tail)
     assert not d_P.read_rows(U - n_act - 1000, 1000).any()       # the zero rows just before the active block
@@ -831,9 +840,9 @@ def test_svdpp_kernel_and_model_reproduce_the_reference_run():
         sgd = SvdppSgd(t, Y0, Bu0, Bi0, rated, n)
         got = sgd.epoch(u, i, r, 0.01, 0.01, 0.02, 0.05, 0.03, float(r.mean()))
         Pg, Qg = t.download(np.float64); Yg, Bug, Big = sgd.download()
-        assert abs(got - want) / want < tol
+        check("abs(got - want) / want", abs(got - want) / want, tol)
         for a, b in ((Pg, Pr), (Qg, Qr), (Yg, Yr), (Bug, Bur), (Big, Bir)):
-            assert rel_err(a, b) < tol
+            check("rel_err(a, b)", rel_err(a, b), tol)
     meta, z = load_golden("svdpp_filmtrust")
     rows = [[f"u{a}", f"i{b}", float(c)] for (a, b), c in zip(z["order0"].tolist(), z["rating0"].tolist())]
     test = [[f"u{a}" if a >= 0 else f"xu{k}", f"i{b}" if b >= 0 else f"xi{k}", float(c)]
@@ -910,13 +919,15 @@ def test_tbpr_ordered_kernel_matches_oracle_including_aliased_rows(dtype, tol):
     capi.sumsq(t.P, t.code, U, dim, t.ld, sums.ptr); capi.sumsq(t.Q, t.code, I, dim, t.ld, sums.ptr + 8)
     capi.tbpr_sgd_ordered(t.P, t.Q, t.code, dim, t.ld, DB.from_numpy(u), DB.from_numpy(a), DB.from_numpy(b), u.size, 0.05, 0.02, 0.03, sums, loss2)
     nll, reg = loss2.numpy()
-    assert abs(nll + reg - want) / want < tol
+    check("abs(nll + reg - want) / want", abs(nll + reg - want) / want, tol)
     Pg, Qg = t.download(np.float64)
-    assert rel_err(Pg, Pr) < tol and rel_err(Qg, Qr) < tol
+    check("rel_err(Pg, Pr)", rel_err(Pg, Pr), tol)
+    check("rel_err(Qg, Qr)", rel_err(Qg, Qr), tol)
     # the regularisation part alone: per-user sums of squares of the evolving tables
     Pc, Qc = P0.copy(), Q0.copy()
     only_nll = sum(O.bpr_sgd(Pc, Qc, u[k:k + 1], a[k:k + 1], b[k:k + 1], 0.05, 0.02, 0.03) for k in range(u.size))
-    assert abs(nll - only_nll) / only_nll < tol and abs(reg - (want - only_nll)) / (want - only_nll) < max(tol, 1e-12)
+    check("abs(nll - only_nll) / only_nll", abs(nll - only_nll) / only_nll, tol)
+    check("abs(reg - (want - only_nll)) / (want - only_nll)", abs(reg - (want - only_nll)) / (want - only_nll), max(tol, 1e-12))
 
 
 def test_tbpr_model_reproduces_the_reference_run(tmp_path):
@@ -996,7 +1007,9 @@ def test_ordered_kernel_is_order_exact_under_heavy_aliasing(dtype, tol, n_items,
     loss = DB.zeros(1, np.float64)
     capi.bpr_sgd_ordered(t.P, t.Q, t.code, dim, t.ld, DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), n, 0.02, 0.01, 0.02, loss)
     Pg, Qg = t.download(np.float64)
-    assert rel_err(Pg, Pr) < tol and rel_err(Qg, Qr) < tol and abs(float(loss.numpy()[0]) - want) / want < tol
+    check("rel_err(Pg, Pr)", rel_err(Pg, Pr), tol)
+    check("rel_err(Qg, Qr)", rel_err(Qg, Qr), tol)
+    check("abs(float(loss.numpy()[0]) - want) / want", abs(float(loss.numpy()[0]) - want) / want, tol)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -1040,7 +1053,9 @@ def test_scheduled_exact_kernel_under_heavy_aliasing(dtype, tol, n_items, n):
     sgd = BprSgd(t, u, i); sgd.set_negatives(j)
     loss = sgd.epoch_ordered(0.02, 0.01, 0.02, width=16)
     Pg, Qg = t.download(np.float64)
-    assert rel_err(Pg, Pr) < tol and rel_err(Qg, Qr) < tol and abs(loss - want) / want < tol
+    check("rel_err(Pg, Pr)", rel_err(Pg, Pr), tol)
+    check("rel_err(Qg, Qr)", rel_err(Qg, Qr), tol)
+    check("abs(loss - want) / want", abs(loss - want) / want, tol)
 
 
 def test_scheduled_exact_kernel_full_yelp_epoch_matches_the_oracle():
@@ -1056,5 +1071,7 @@ def test_scheduled_exact_kernel_full_yelp_epoch_matches_the_oracle():
     sgd = BprSgd(t, u, ind); sgd.set_negatives(j)
     loss = sgd.epoch_ordered(0.01, 0.001, 0.001)
     Pg, Qg = t.download()
-    assert rel_err(Pg, Pr) < 1e-10 and rel_err(Qg, Qr) < 1e-10 and abs(loss - want) / want < F64_TOL
+    check("rel_err(Pg, Pr)", rel_err(Pg, Pr), 1e-10)
+    check("rel_err(Qg, Qr)", rel_err(Qg, Qr), 1e-10)
+    check("abs(loss - want) / want", abs(loss - want) / want, F64_TOL)
     assert sgd.exact_steps < ind.size // 4

@@ -15,7 +15,7 @@ from qrec_amd.capi import DeviceBuffer as DB
 from qrec_amd.graph import LightGCNTrainer, SpmmPlan, joint_norm_adjacency
 from qrec_amd.synth import make_dataset
 
-from helpers import conf_from_text, load_golden, pad_cols, rel_err, rows_from_golden
+from helpers import check, check_rel, conf_from_text, load_golden, pad_cols, rel_err, rows_from_golden
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -48,15 +48,16 @@ def test_spmm_matches_scipy(dim, ld, seg_len):
     capi.spmm_csr(plan, dX, dY, ld)
     ref = A.dot(X)
     got = dY.numpy()
-    assert rel_err(got[:, :dim], ref) < TOL and (got[:, dim:] == 0).all()
+    check("rel_err(got[:, :dim], ref)", rel_err(got[:, :dim], ref), TOL)
+    assert (got[:, dim:] == 0).all()
     # rows that are not segmented accumulate in CSR order exactly like scipy: bit-identical
     whole = np.diff(adj[0]) <= seg_len
     assert np.array_equal(got[whole][:, :dim], ref[whole])
     # fused epilogues: Y = A X + 0.5 Z ; accum += Y
     dZ, dS = DB.from_numpy(pad_cols(Z, ld)), DB.from_numpy(pad_cols(S0, ld))
     capi.spmm_csr(plan, dX, dY, ld, d_addend=dZ, addend_scale=0.5, d_accum=dS)
-    assert rel_err(dY.numpy()[:, :dim], ref + np.float32(0.5) * Z) < TOL
-    assert rel_err(dS.numpy()[:, :dim], S0 + (ref + np.float32(0.5) * Z)) < TOL
+    check("rel_err(dY.numpy()[:, :dim], ref + np.float32(0.5) * Z)", rel_err(dY.numpy()[:, :dim], ref + np.float32(0.5) * Z), TOL)
+    check("rel_err(dS.numpy()[:, :dim], S0 + (ref + np.float32(0.5) * Z))", rel_err(dS.numpy()[:, :dim], S0 + (ref + np.float32(0.5) * Z)), TOL)
     # deterministic
     capi.spmm_csr(plan, dX, dY, ld); a = dY.numpy(); capi.spmm_csr(plan, dX, dY, ld); assert np.array_equal(a, dY.numpy())
     with pytest.raises(capi.QRecError):
@@ -92,7 +93,7 @@ def test_spmm_row_chunks_do_not_change_a_bit(chunks, seg_len):
         out[c] = (plain, fused[0], fused[1], sparse, wanted)
     for a, b in zip(out[1], out[chunks]):
         assert np.array_equal(a, b)
-    assert rel_err(out[chunks][0], A.dot(X)) < TOL
+    check("rel_err(out[chunks][0], A.dot(X))", rel_err(out[chunks][0], A.dot(X)), TOL)
     assert (out[chunks][4][~ymask_rows] == 7).all() and np.array_equal(out[chunks][4][ymask_rows], out[chunks][0][ymask_rows])
     with pytest.raises(ValueError):
         SpmmPlan(adj[0], adj[1], adj[2], ld, chunks=2)          # chunks need the bipartite split
@@ -109,7 +110,8 @@ def test_spmm_empty_rows_and_heavy_row():
     dX, dY = DB.from_numpy(X), DB.from_numpy(np.full((n, 64), 7, np.float32))
     capi.spmm_csr(plan, dX, dY, 64)
     got = dY.numpy()
-    assert rel_err(got, A.dot(X)) < TOL and (got[1:10] == 0).all()
+    check("rel_err(got, A.dot(X))", rel_err(got, A.dot(X)), TOL)
+    assert (got[1:10] == 0).all()
 
 
 def test_batch_loss_grad_and_adam_match_restatement():
@@ -123,8 +125,9 @@ def test_batch_loss_grad_and_adam_match_restatement():
     dS, dE, dl = DB.from_numpy(pad_cols(S, ld)), DB.zeros((nu + ni, ld), np.float32), DB.zeros(1, np.float64)
     capi.bpr_batch_loss_grad(dS, float(L + 1), nu, nu + ni, ld, DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, 1e-7, 0.01, dE, dl)
     got = dE.numpy()
-    assert rel_err(got[:, :dim], dref) < TOL and (got[:, dim:] == 0).all()
-    assert abs(dl.numpy()[0] - loss) / abs(loss) < TOL
+    check("rel_err(got[:, :dim], dref)", rel_err(got[:, :dim], dref), TOL)
+    assert (got[:, dim:] == 0).all()
+    check("abs(dl.numpy()[0] - loss) / abs(loss)", abs(dl.numpy()[0] - loss) / abs(loss), TOL)
     # Adam, several steps
     theta = rng.standard_normal((nu + ni, ld)).astype(np.float32); ref = theta.copy()
     opt = T.AdamTF114(theta.shape, lr=0.01)
@@ -134,7 +137,9 @@ def test_batch_loss_grad_and_adam_match_restatement():
         alpha = float(opt.alpha())
         opt.step(ref, (np.float32(1 / 3) * g).astype(np.float32))
         capi.adam_step(dT, dM, dV, DB.from_numpy(g), theta.size, 1 / 3, alpha)
-    assert rel_err(dT.numpy(), ref) < TOL and rel_err(dM.numpy(), opt.m) < TOL and rel_err(dV.numpy(), opt.v) < TOL
+    check("rel_err(dT.numpy(), ref)", rel_err(dT.numpy(), ref), TOL)
+    check("rel_err(dM.numpy(), opt.m)", rel_err(dM.numpy(), opt.m), TOL)
+    check("rel_err(dV.numpy(), opt.v)", rel_err(dV.numpy(), opt.v), TOL)
 
 
 @pytest.mark.parametrize("L", [1, 2, 3])
@@ -150,13 +155,14 @@ def test_lightgcn_training_steps_match_restatement(L):
         u = d["train_u"][sel].astype(np.int32); i = d["train_i"][sel].astype(np.int32); j = rng.integers(0, ni, B).astype(np.int32)
         lref = ref.train_step(u, i, j)
         tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B)
-        assert abs(tr.loss() - lref) / abs(lref) < TOL
+        check("abs(tr.loss() - lref) / abs(lref)", abs(tr.loss() - lref) / abs(lref), TOL)
     Ug, Vg = tr.ego_embeddings()
     # Adam normalises every coordinate's step to ~lr, so agreement is measured on the update
-    assert rel_err(np.concatenate([Ug, Vg]) - np.concatenate([U0, V0]), ref.E - np.concatenate([U0, V0])) < 1e-3
-    assert rel_err(np.concatenate([Ug, Vg]), ref.E) < TOL
+    check("rel_err(np.concatenate([Ug, Vg]) - np.concatenate([U0, V0]), ref.E - np.concatenate([U0, V0]))", rel_err(np.concatenate([Ug, Vg]) - np.concatenate([U0, V0]), ref.E - np.concatenate([U0, V0])), 1e-5)
+    check("rel_err(np.concatenate([Ug, Vg]), ref.E)", rel_err(np.concatenate([Ug, Vg]), ref.E), TOL)
     Uf, Vf = tr.final_embeddings(); Ur, Vr = ref.final_embeddings()
-    assert rel_err(Uf, Ur) < 1e-4 and rel_err(Vf, Vr) < 1e-4
+    check("rel_err(Uf, Ur)", rel_err(Uf, Ur), 1e-5)
+    check("rel_err(Vf, Vr)", rel_err(Vf, Vr), 1e-5)
 
 
 def test_lightgcn_class_end_to_end_against_restatement_with_reference_sampler_stream():
@@ -188,9 +194,10 @@ def test_lightgcn_class_end_to_end_against_restatement_with_reference_sampler_st
         b = st[pos:pos + bs]; pos += bs
         ref_losses.append(ref.train_step(b[:, 0], b[:, 1], b[:, 2]))
     assert len(losses) == len(ref_losses)
-    np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
+    check_rel("class losses vs restatement on the reference stream", losses, ref_losses, 1e-5)
     Ur, Vr = ref.final_embeddings()
-    assert rel_err(m.U, Ur) < 1e-4 and rel_err(m.V, Vr) < 1e-4
+    check("rel_err(m.U, Ur)", rel_err(m.U, Ur), 1e-5)
+    check("rel_err(m.V, Vr)", rel_err(m.V, Vr), 1e-5)
     assert np.array_equal(capi.state_from_python(random.getstate()), z["py_state"])   # sampler stayed in lock-step
 
 
@@ -260,8 +267,9 @@ def test_perturb_rows_matches_restatement_and_philox_is_uniform(dim, ld):
     dE, dN, dA = DB.from_numpy(pad_cols(emb, ld)), DB.from_numpy(pad_cols(noise, ld)), DB.from_numpy(pad_cols(acc0, ld))
     capi.perturb_rows(dE, n, dim, ld, 0.1, dN, d_accum=dA)
     got = dE.numpy()
-    assert rel_err(got[:, :dim], want) < TOL and (got[:, dim:] == 0).all()
-    assert rel_err(dA.numpy()[:, :dim], acc0 + want) < TOL
+    check("rel_err(got[:, :dim], want)", rel_err(got[:, :dim], want), TOL)
+    assert (got[:, dim:] == 0).all()
+    check("rel_err(dA.numpy()[:, :dim], acc0 + want)", rel_err(dA.numpy()[:, :dim], acc0 + want), TOL)
     # device-drawn noise: |delta| = eps * unit vector, all components same sign as emb, reproducible
     dE2 = DB.from_numpy(pad_cols(emb, ld)); capi.perturb_rows(dE2, n, dim, ld, 0.1, None, seed=3, stream_id=7)
     delta = dE2.numpy()[:, :dim] - emb
@@ -292,8 +300,9 @@ def test_info_nce_matches_restatement(n, dim, ld):
     capi.info_nce_loss_grad(DB.from_numpy(pad_cols(S1, ld)), DB.from_numpy(pad_cols(S2, ld)), 2.0, DB.from_numpy(rows), n, ld,
                             0.2, 0.5, ws, dOut, dl)
     got = dOut.numpy()
-    assert abs(dl.numpy()[0] - loss) <= 2e-5 * max(abs(loss), 1.0)
-    assert rel_err(got[:, :dim] - base, want - base) < 5e-5 and (got[:, dim:] == 0).all()
+    check("InfoNCE loss vs restatement, relative", abs(dl.numpy()[0] - loss) / max(abs(loss), 1.0), TOL)
+    check("rel_err(got[:, :dim] - base, want - base)", rel_err(got[:, :dim] - base, want - base), 5e-5)
+    assert (got[:, dim:] == 0).all()
     untouched = np.ones(N, bool); untouched[rows] = False
     assert np.array_equal(got[untouched][:, :dim], base[untouched])
 
@@ -317,17 +326,19 @@ def test_simgcl_training_steps_match_restatement(L):
         tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, DB.from_numpy(uu), uu.size,
                             DB.from_numpy(vv), vv.size, noises=[DB.from_numpy(x) for x in noises])
         tot, rec, cl = tr.losses()
-        assert abs(rec - rec_ref) / abs(rec_ref) < 2e-5 and abs(cl - cl_ref) / abs(cl_ref) < 2e-5
+        check("abs(rec - rec_ref) / abs(rec_ref)", abs(rec - rec_ref) / abs(rec_ref), 1e-5)
+        check("abs(cl - cl_ref) / abs(cl_ref)", abs(cl - cl_ref) / abs(cl_ref), 1e-5)
     Ug, Vg = tr.ego_embeddings()
     E0 = np.concatenate([U0, V0])
     # Adam divides by sqrt(v): on coordinates whose gradient is at rounding-noise level the step is
     # +-alpha whatever the implementation, so two correct fp32 pipelines (different summation order
     # in the SpMM / MFMA) drift apart by ~alpha*sqrt(steps) there.  Losses above are held to 2e-5;
     # the tables to 5e-5 after 5 steps.
-    assert rel_err(np.concatenate([Ug, Vg]) - E0, ref.E - E0) < 2e-3
-    assert rel_err(np.concatenate([Ug, Vg]), ref.E) < 5e-5
+    check("rel_err(np.concatenate([Ug, Vg]) - E0, ref.E - E0)", rel_err(np.concatenate([Ug, Vg]) - E0, ref.E - E0), 0.001)
+    check("rel_err(np.concatenate([Ug, Vg]), ref.E)", rel_err(np.concatenate([Ug, Vg]), ref.E), 5e-5)
     Um, Vm = tr.main_embeddings(); Ur, Vr = ref.final_embeddings()
-    assert rel_err(Um, Ur) < 1e-4 and rel_err(Vm, Vr) < 1e-4
+    check("rel_err(Um, Ur)", rel_err(Um, Ur), 1e-5)
+    check("rel_err(Vm, Vr)", rel_err(Vm, Vr), 1e-4)
 
 
 def test_simgcl_class_runs_stock_conf_shape_and_keeps_best_epoch():
@@ -367,9 +378,9 @@ def test_bpr_tf_variant_matches_restatement_and_runs_from_conf():
         u = rng.integers(0, nu, B).astype(np.int32); i = rng.integers(0, ni, B).astype(np.int32); j = rng.integers(0, ni, B).astype(np.int32)
         lref = ref.train_step(u, i, j)
         tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B)
-        assert abs(tr.loss() - lref) / abs(lref) < TOL
+        check("abs(tr.loss() - lref) / abs(lref)", abs(tr.loss() - lref) / abs(lref), TOL)
     Ug, Vg = tr.tables()
-    assert rel_err(np.concatenate([Ug, Vg]), ref.E) < 5e-5
+    check("rel_err(np.concatenate([Ug, Vg]), ref.E)", rel_err(np.concatenate([Ug, Vg]), ref.E), 1e-5)
     # through the class: `-tf` selects trainModel_tf (base/recommender.py:194-201)
     from qrec_amd.model.ranking.BPR import BPR
     meta, z = load_golden("bpr_filmtrust")
@@ -469,20 +480,23 @@ def test_ngcf_gradients_and_training_steps_match_restatement(dim):
             loss0, gE, gW = ref.loss_and_grads(u, i, j, masks)
         lref = ref.train_step(u, i, j, masks)
         tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, masks=[DB.from_numpy(pad_cols(m, ld)) for m in masks])
-        assert abs(tr.loss() - lref) / abs(lref) < 2e-5
+        check("abs(tr.loss() - lref) / abs(lref)", abs(tr.loss() - lref) / abs(lref), 1e-5)
         if step == 0:
-            assert rel_err(tr.dEb.numpy()[:, :dim], gE) < 1e-4
+            check("rel_err(tr.dEb.numpy()[:, :dim], gE)", rel_err(tr.dEb.numpy()[:, :dim], gE), 1e-5)
             for k in range(2):
                 for t in range(2):
                     got = tr.gW[k][t].numpy()
-                    assert rel_err(got[:dim, :dim], gW[k][t]) < 1e-4 and (got[dim:] == 0).all() and (got[:, dim:] == 0).all()
+                    check("rel_err(got[:dim, :dim], gW[k][t])", rel_err(got[:dim, :dim], gW[k][t]), 1e-5)
+                    assert (got[dim:] == 0).all() and (got[:, dim:] == 0).all()
     Ug, Vg, Wg = tr.parameters()
-    assert rel_err(np.concatenate([Ug, Vg]), ref.E) < 5e-5
+    check("rel_err(np.concatenate([Ug, Vg]), ref.E)", rel_err(np.concatenate([Ug, Vg]), ref.E), 2e-5)
     for k in range(2):
         for t in range(2):
-            assert rel_err(Wg[k][t], ref.W[k][t]) < 5e-5
+            check("rel_err(Wg[k][t], ref.W[k][t])", rel_err(Wg[k][t], ref.W[k][t]), 2e-5)
     Ui, Vi = tr.inference_embeddings(); Ur, Vr = ref.inference_embeddings()
-    assert Ui.shape == (nu, 3 * dim) and rel_err(Ui, Ur) < 1e-4 and rel_err(Vi, Vr) < 1e-4
+    check("rel_err(Ui, Ur)", rel_err(Ui, Ur), 2e-5)
+    check("rel_err(Vi, Vr)", rel_err(Vi, Vr), 1e-5)
+    assert Ui.shape == (nu, 3 * dim)
 
 
 def test_ngcf_class_trains_and_evaluates_with_device_dropout():
@@ -520,7 +534,7 @@ def test_spmm_sparse_operand_mask_is_bit_identical():
     capi.spmm_csr(plan, dX, dY1, 64, d_addend=dX, addend_scale=1.0)
     capi.spmm_csr(plan, dX, dY2, 64, d_addend=dX, addend_scale=1.0, d_x_row_mask=DB.from_numpy(mask))
     assert np.array_equal(dY1.numpy(), dY2.numpy())
-    assert rel_err(dY1.numpy(), A.dot(X) + X) < TOL
+    check("rel_err(dY1.numpy(), A.dot(X) + X)", rel_err(dY1.numpy(), A.dot(X) + X), TOL)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -552,12 +566,14 @@ def test_sgl_training_steps_match_restatement(per_layer):
         rows = np.concatenate([unique_first_appearance(u), unique_first_appearance(i) + nu]).astype(np.int32)
         tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, DB.from_numpy(rows), rows.size)
         tot, rec, ssl = tr.losses()
-        assert abs(rec - rec_ref) / abs(rec_ref) < 2e-5 and abs(ssl - ssl_ref) / abs(ssl_ref) < 2e-5
+        check("abs(rec - rec_ref) / abs(rec_ref)", abs(rec - rec_ref) / abs(rec_ref), 1e-5)
+        check("abs(ssl - ssl_ref) / abs(ssl_ref)", abs(ssl - ssl_ref) / abs(ssl_ref), 1e-5)
     Ug, Vg = tr.ego_embeddings(); E0 = np.concatenate([U0, V0])
-    assert rel_err(np.concatenate([Ug, Vg]) - E0, ref.E - E0) < 2e-3
-    assert rel_err(np.concatenate([Ug, Vg]), ref.E) < 5e-5
+    check("rel_err(np.concatenate([Ug, Vg]) - E0, ref.E - E0)", rel_err(np.concatenate([Ug, Vg]) - E0, ref.E - E0), 0.0005)
+    check("rel_err(np.concatenate([Ug, Vg]), ref.E)", rel_err(np.concatenate([Ug, Vg]), ref.E), 5e-5)
     Um, Vm = tr.main_embeddings(); Ur, Vr = ref.final_embeddings()
-    assert rel_err(Um, Ur) < 1e-4 and rel_err(Vm, Vr) < 1e-4
+    check("rel_err(Um, Ur)", rel_err(Um, Ur), 2e-5)
+    check("rel_err(Vm, Vr)", rel_err(Vm, Vr), 5e-5)
 
 
 @pytest.mark.parametrize("aug", [1, 0, 2])
@@ -625,16 +641,16 @@ def test_spmm_yelp_shape_vs_scipy_and_operator_properties(yelp_graph):
     dX, dY, dO, dO2 = DB.from_numpy(X), DB.from_numpy(Y), DB.zeros((n, 64), np.float32), DB.zeros((n, 64), np.float32)
     capi.spmm_csr(plan, dX, dO, 64); AX = dO.numpy()
     ref = A.dot(X)
-    assert rel_err(AX, ref) < TOL
+    check("rel_err(AX, ref)", rel_err(AX, ref), TOL)
     whole = np.diff(adj[0]) <= 128
     assert whole.sum() > 0.95 * n and np.array_equal(AX[whole], ref[whole])
     capi.spmm_csr(plan, dY, dO2, 64); AY = dO2.numpy()
     dS = DB.from_numpy(X + Y); capi.spmm_csr(plan, dS, dO, 64)
-    assert rel_err(dO.numpy(), AX + AY) < 2e-6                                   # linearity
+    check("rel_err(dO.numpy(), AX + AY)", rel_err(dO.numpy(), AX + AY), 2e-6)                                   # linearity
     lhs = float((AX.astype(np.float64) * Y).sum()); rhs = float((X.astype(np.float64) * AY).sum())
-    assert abs(lhs - rhs) / max(abs(lhs), 1.0) < 1e-5                            # symmetry
+    check("abs(lhs - rhs) / max(abs(lhs), 1.0)", abs(lhs - rhs) / max(abs(lhs), 1.0), 1e-5)                            # symmetry
     ones = DB.from_numpy(np.ones((n, 64), np.float32)); capi.spmm_csr(plan, ones, dO, 64)
-    np.testing.assert_allclose(dO.numpy()[:, 0], np.asarray(A.sum(axis=1)).ravel(), rtol=2e-6)
+    check_rel("A 1 vs row sums", dO.numpy()[:, 0], np.asarray(A.sum(axis=1)).ravel(), 2e-6)
 
 
 def test_lightgcn_and_simgcl_steps_at_yelp_shape_match_restatement(yelp_graph):
@@ -654,12 +670,12 @@ def test_lightgcn_and_simgcl_steps_at_yelp_shape_match_restatement(yelp_graph):
     tr = LightGCNTrainer(U0, V0, adj, 3, lr=0.001, reg=1e-4)
     lref = ref.train_step(u, i, j)
     tr.train_step_async(du, di, dj, B)
-    assert abs(tr.loss() - lref) / abs(lref) < 2e-5
+    check("abs(tr.loss() - lref) / abs(lref)", abs(tr.loss() - lref) / abs(lref), 1e-5)
     Eg = np.concatenate(tr.ego_embeddings())
     step_ref, step_gpu = ref.E - E0, Eg - E0
     solid = np.abs(ref.opt.m) > 1e-3 * np.abs(ref.opt.m).max()        # first Adam step = -lr*sign(g): compare where g is not noise
     assert solid.mean() > 0.2 and np.array_equal(np.sign(step_gpu[solid]), np.sign(step_ref[solid]))
-    np.testing.assert_allclose(step_gpu[solid], step_ref[solid], rtol=1e-3)
+    check_rel("Adam step on solid coordinates", step_gpu[solid], step_ref[solid], 2e-5)
     # SimGCL
     lim = np.sqrt(6.0 / (nu + dim))
     U1 = rng.uniform(-lim, lim, (nu, dim)).astype(np.float32); V1 = rng.uniform(-lim, lim, (ni, dim)).astype(np.float32)
@@ -670,7 +686,8 @@ def test_lightgcn_and_simgcl_steps_at_yelp_shape_match_restatement(yelp_graph):
     uu = unique_first_appearance(u); vv = (unique_first_appearance(i) + nu).astype(np.int32)
     tr2.train_step_async(du, di, dj, B, DB.from_numpy(uu), uu.size, DB.from_numpy(vv), vv.size, noises=[DB.from_numpy(x) for x in noises])
     _, rec, cl = tr2.losses()
-    assert abs(rec - rec_ref) / abs(rec_ref) < 2e-5 and abs(cl - cl_ref) / abs(cl_ref) < 2e-5
+    check("abs(rec - rec_ref) / abs(rec_ref)", abs(rec - rec_ref) / abs(rec_ref), 1e-5)
+    check("abs(cl - cl_ref) / abs(cl_ref)", abs(cl - cl_ref) / abs(cl_ref), 1e-5)
 
 
 @pytest.mark.parametrize("seg_len", [128, 7])
@@ -733,16 +750,18 @@ def test_buir_training_steps_match_restatement(L, dim):
         u = d["train_u"][sel].astype(np.int32); i = d["train_i"][sel].astype(np.int32)
         lref = ref.train_step(u, i, Ao, At)
         tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), B)
-        assert abs(tr.loss() - lref) / abs(lref) < 2e-5
+        check("abs(tr.loss() - lref) / abs(lref)", abs(tr.loss() - lref) / abs(lref), 1e-5)
     E0 = np.concatenate([U0, V0])
     Eg, Tg = tr.online_tables(), tr.target_tables()
     Wg, bg = tr.weights()
-    assert rel_err(Eg - E0, ref.E - E0) < 2e-3 and rel_err(Eg, ref.E) < 5e-5       # Adam: see the SimGCL test's note
-    assert rel_err(Tg, ref.T) < 5e-5
-    assert rel_err(Wg, ref.W) < 5e-5 and rel_err(bg, ref.b.ravel()) < 5e-4
+    check("rel_err(Eg - E0, ref.E - E0)", rel_err(Eg - E0, ref.E - E0), 5e-5)       # Adam: see the SimGCL test's note
+    check("rel_err(Eg, ref.E)", rel_err(Eg, ref.E), 1e-5)
+    check("rel_err(Tg, ref.T)", rel_err(Tg, ref.T), 1e-5)
+    check("rel_err(Wg, ref.W)", rel_err(Wg, ref.W), 1e-5)
+    check("rel_err(bg, ref.b.ravel())", rel_err(bg, ref.b.ravel()), 1e-5)
     got, want = tr.final_tables(adj), ref.final_tables(A)
     for g, w in zip(got, want):
-        assert rel_err(g, w) < 1e-4
+        check("rel_err(g, w)", rel_err(g, w), 1e-5)
 
 
 def test_buir_class_runs_stock_conf_shape_and_replays_the_generator():
@@ -807,9 +826,13 @@ def test_graph_models_data_parallel_two_ranks_equal_one_rank_with_double_batch(n
     assert a["losses"].size == b0["losses"].size > 0
     # SEPT's pseudo labels are discrete: a near-tie in the averaged softmax can resolve differently under another
     # summation order and move that row's positives, so its two runs agree to a looser bound (the replicas above do not)
-    np.testing.assert_allclose(b0["losses"], a["losses"], rtol=2e-3 if name == "SEPT" else 1e-4)
-    tol = 2e-2 if name == "SEPT" else 1e-3 if name == "MHCN" else 2e-4       # Adam on 0.005-sized tables
-    assert rel_err(b0["E"], a["E"]) < tol and rel_err(b0["U"], a["U"]) < tol and rel_err(b0["V"], a["V"]) < tol
+    # (observed, profiles/r03_parity_errors.json: every model but SEPT <= 7e-8 on the losses and <= 6e-7 on the tables; SEPT
+    # 2.3e-5 / 2.2e-3 -- a moved pseudo label is a different positive set for that row from then on)
+    check_rel("two ranks vs one rank, losses", b0["losses"], a["losses"], 2e-4 if name == "SEPT" else TOL)
+    tol = 2e-2 if name == "SEPT" else TOL
+    check("rel_err(b0['E'], a['E'])", rel_err(b0["E"], a["E"]), tol)
+    check("rel_err(b0['U'], a['U'])", rel_err(b0["U"], a["U"]), tol)
+    check("rel_err(b0['V'], a['V'])", rel_err(b0["V"], a["V"]), tol)
     np.testing.assert_allclose(b0["measure"], a["measure"], atol=2e-3)
     assert len(os.listdir(two / "results")) == len(os.listdir(one / "results"))      # rank 0 alone wrote the result files
 
@@ -836,14 +859,15 @@ def test_graph_class_row_partitioned_two_ranks_equal_one_rank_at_the_same_batch_
     a, b0, b1 = np.load(one / "rank0.npz"), np.load(two / "rank0.npz"), np.load(two / "rank1.npz")
     for k in ("U", "V", "measure"):
         assert np.array_equal(b0[k], b1[k]), k                      # both ranks gathered the same tables, same measures
-    np.testing.assert_allclose(b0["losses"], b1["losses"], rtol=1e-6)   # every rank sums the batch loss itself (float atomics: own order)
+    check_rel("rank 0 vs rank 1 losses", b0["losses"], b1["losses"], 1e-6)   # every rank sums the batch loss itself (float atomics: own order)
     assert a["losses"].size == b0["losses"].size > 0
-    np.testing.assert_allclose(b0["losses"], a["losses"], rtol=1e-5 if model == "LightGCN" else 5e-4)
+    check_rel("row-partitioned vs one rank, losses", b0["losses"], a["losses"], 5e-4 if model == "NGCF" else TOL)
     # NGCF / SimGCL: ~70 Adam steps carry the summation-order differences of the float atomics along (coordinates with a
     # rounding-noise gradient move by +-alpha per step whatever the implementation; run-to-run 2e-4 .. 2e-3); the step-level
     # equivalence at 5e-5 is tests/test_gpu_dist.py::test_row_partitioned_{ngcf,simgcl}_step_equals_the_single_gpu_step
-    tol = 2e-5 if model == "LightGCN" else 1e-2
-    assert rel_err(b0["U"], a["U"]) < tol and rel_err(b0["V"], a["V"]) < tol
+    tol = 1e-2 if model == "NGCF" else TOL      # observed: LightGCN 6e-8, SimGCL 9e-8, NGCF 5e-3 (see the note above)
+    check("rel_err(b0['U'], a['U'])", rel_err(b0["U"], a["U"]), tol)
+    check("rel_err(b0['V'], a['V'])", rel_err(b0["V"], a["V"]), tol)
     assert not np.array_equal(b0["E"], b1["E"]) and b0["E"].shape[0] + b1["E"].shape[0] >= a["E"].shape[0]   # each rank holds ITS rows
     np.testing.assert_allclose(b0["measure"], a["measure"], atol=1e-4 if model == "LightGCN" else 5e-3)
 
@@ -875,13 +899,13 @@ def test_l2norm_layer_kernels_match_restatement(dim, ld):
     d_S, d_inv = DB.from_numpy(pad_cols(S0, ld)), DB.zeros(n, np.float32)
     d_X = DB.from_numpy(pad_cols(X, ld))
     capi.l2norm_rows_accum(d_X, n, ld, d_S, d_inv)
-    np.testing.assert_allclose(d_inv.numpy(), inv, rtol=2e-6)
-    np.testing.assert_allclose(d_S.numpy()[:, :dim], S0 + z, rtol=1e-5, atol=1e-6)
+    check_rel("1/|row|", d_inv.numpy(), inv, 2e-6)
+    check_rel("S0 + normalised rows", d_S.numpy()[:, :dim], S0 + z, 1e-5, abs_tol=1e-6)
     assert not d_S.numpy()[:, dim:].any() and d_inv.numpy()[5] == np.float32(1e6)
     d_out = DB.zeros((n, ld), np.float32)
     capi.l2norm_rows_bwd(d_X, d_inv, DB.from_numpy(pad_cols(dS, ld)), n, ld, d_out)
     want = T.l2_normalize_bwd(X, inv, dS)
-    assert rel_err(d_out.numpy()[:, :dim], want) < 2e-6
+    check("rel_err(d_out.numpy()[:, :dim], want)", rel_err(d_out.numpy()[:, :dim], want), 2e-6)
     np.testing.assert_array_equal(d_out.numpy()[5, :dim], dS[5] * np.float32(1e6))      # at the clamp: d * 1e6, like tf
     capi.scale_copy(d_out, d_X, n * ld, 0.5)
     np.testing.assert_array_equal(d_out.numpy()[:, :dim], X / np.float32(2))
@@ -908,10 +932,10 @@ def test_sept_pseudo_labels_and_neighbour_discrimination_match_restatement(n, di
     assert agree > 0.995, agree
     assert all(len(set(r)) == k and min(r) >= 0 and max(r) < n for r in got_labels.reshape(-1, k).tolist())
     nd, _, dx = T.sept_ssl_loss_and_grads(*(t[rows] for t in tabs), k, labels=list(got_labels))
-    assert float(loss.numpy()[0]) == pytest.approx(nd, rel=2e-5)
+    check_rel("neighbour-discrimination loss", float(loss.numpy()[0]), nd, 1e-5)
     for d_d, g in zip(d_dS, dx):
         out = d_d.numpy()
-        assert rel_err(out[rows, :dim], np.float32(0.25) * g) < 5e-5
+        check("rel_err(out[rows, :dim], np.float32(0.25) * g)", rel_err(out[rows, :dim], np.float32(0.25) * g), 1e-5)
         rest = np.ones(N, bool); rest[rows] = False
         assert not out[rest].any() and not out[:, dim:].any()
     with pytest.raises(capi.QRecError, match="ins_cnt"):
@@ -937,12 +961,13 @@ def test_sept_training_steps_match_restatement(L):
         tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, joint, DB.from_numpy(uu), uu.size, keep_labels=joint)
         got = tr.losses()
         want = ref.train_step(u, i, j, sub if joint else None, labels=list(tr.d_labels.numpy()) if joint else None)
-        assert got[0] == pytest.approx(want[0], rel=2e-5) and got[1] == pytest.approx(want[1], rel=1e-4, abs=1e-9)
+        check_rel("SEPT rec loss", got[0], want[0], 1e-5); check_rel("SEPT ssl loss", got[1], want[1], 1e-5, abs_tol=1e-9)
         Ug, Vg = tr.variables()
-        assert rel_err(np.concatenate([Ug, Vg]), ref.W) < 2e-4, step
+        check("rel_err(np.concatenate([Ug, Vg]), ref.W)", rel_err(np.concatenate([Ug, Vg]), ref.W), 1e-5, ctx=step)
     assert ref.opt1.t == 3 and ref.opt2.t == 3
     Ur, Vr = ref.rec_embeddings(); Ud, Vd = tr.rec_embeddings()
-    assert rel_err(Ud, Ur) < 2e-4 and rel_err(Vd, Vr) < 2e-4
+    check("rel_err(Ud, Ur)", rel_err(Ud, Ur), 1e-5)
+    check("rel_err(Vd, Vr)", rel_err(Vd, Vr), 1e-5)
 
 
 def test_sept_class_runs_stock_conf_shape_with_social_data_and_replays_the_generator(tmp_path):
@@ -1042,13 +1067,16 @@ def test_mhcn_gate_attention_and_mim_kernels_match_restatement(dim, ld):
     d_X, d_W, d_b = DB.from_numpy(pad_cols(U0, ld)), DB.from_numpy(pad2(W)), DB.from_numpy(pad_cols(b, ld)[0])
     d_Y, d_S, d_Q, d_dX = (DB.zeros((nu, ld), np.float32) for _ in range(4))
     capi.gate_fwd(d_X, d_W, d_b, nu, ld, d_Y, d_S)
-    assert rel_err(d_Y.numpy()[:, :dim], Y) < 2e-6 and not d_Y.numpy()[:, dim:].any()
+    check("rel_err(d_Y.numpy()[:, :dim], Y)", rel_err(d_Y.numpy()[:, :dim], Y), 2e-6)
+    assert not d_Y.numpy()[:, dim:].any()
     prev = rng.standard_normal((nu, dim)).astype(np.float32); d_dX.upload(pad_cols(prev, ld))
     capi.gate_bwd(d_X, d_S, DB.from_numpy(pad_cols(dY, ld)), d_W, nu, dim, ld, d_Q, d_dX, True)
-    assert rel_err(d_dX.numpy()[:, :dim], prev + dX) < 5e-6 and not d_dX.numpy()[:, dim:].any()
+    check("rel_err(d_dX.numpy()[:, :dim], prev + dX)", rel_err(d_dX.numpy()[:, :dim], prev + dX), 5e-6)
+    assert not d_dX.numpy()[:, dim:].any()
     gW, gb = DB.zeros((ld, ld), np.float32), DB.zeros(ld, np.float32)
     capi.buir_wgrad(d_X, d_Q, nu, ld, DB(capi.buir_wgrad_scratch_bytes(ld), np.uint8), gW, gb)
-    assert rel_err(gW.numpy()[:dim, :dim], dW) < 2e-5 and rel_err(gb.numpy()[:dim], db[0]) < 2e-5
+    check("rel_err(gW.numpy()[:dim, :dim], dW)", rel_err(gW.numpy()[:dim, :dim], dW), 1e-5)
+    check("rel_err(gb.numpy()[:dim], db[0])", rel_err(gb.numpy()[:dim], db[0]), 1e-5)
     # --- channel attention
     es = [rng.standard_normal((nu, dim)).astype(np.float32) for _ in range(3)]
     half = rng.standard_normal((nu, dim)).astype(np.float32)
@@ -1059,15 +1087,17 @@ def test_mhcn_gate_attention_and_mim_kernels_match_restatement(dim, ld):
     d_a, d_M = DB.from_numpy(pad_cols(w["attention"], ld)[0]), DB.from_numpy(pad2(w["attention_mat"]))
     d_v, d_dv, d_sc, d_out = DB.zeros(256, np.float32), DB.zeros(256, np.float32), DB.zeros((nu, 4), np.float32), DB.zeros((nu, ld), np.float32)
     capi.channel_attention_fwd(d_e, d_a, d_M, DB.from_numpy(pad_cols(half, ld)), nu, ld, d_v, d_sc, d_out)
-    assert rel_err(d_out.numpy()[:, :dim], out + half / 2) < 5e-6 and rel_err(d_sc.numpy()[:, :3], score) < 5e-6
+    check("rel_err(d_out.numpy()[:, :dim], out + half / 2)", rel_err(d_out.numpy()[:, :dim], out + half / 2), 5e-6)
+    check("rel_err(d_sc.numpy()[:, :3], score)", rel_err(d_sc.numpy()[:, :3], score), 5e-6)
     d_de = [DB.zeros((nu, ld), np.float32) for _ in range(3)]
     d_dh = DB.from_numpy(pad_cols(prev, ld))
     g_a, g_M = DB.zeros(ld, np.float32), DB.zeros((ld, ld), np.float32)
     capi.channel_attention_bwd(DB.from_numpy(pad_cols(dOut, ld)), d_e, d_sc, d_v, d_a, d_M, nu, ld, d_de, False, d_dh, True, d_dv, g_a, g_M)
     for k in range(3):
-        assert rel_err(d_de[k].numpy()[:, :dim], des[k]) < 1e-5
-    assert rel_err(d_dh.numpy()[:, :dim], prev + dOut / 2) < 1e-6
-    assert rel_err(g_a.numpy()[:dim], da[0]) < 5e-5 and rel_err(g_M.numpy()[:dim, :dim], dM) < 5e-5
+        check("rel_err(d_de[k].numpy()[:, :dim], des[k])", rel_err(d_de[k].numpy()[:, :dim], des[k]), 1e-5)
+    check("rel_err(d_dh.numpy()[:, :dim], prev + dOut / 2)", rel_err(d_dh.numpy()[:, :dim], prev + dOut / 2), 1e-6)
+    check("rel_err(g_a.numpy()[:dim], da[0])", rel_err(g_a.numpy()[:dim], da[0]), 1e-5)
+    check("rel_err(g_M.numpy()[:dim, :dim], dM)", rel_err(g_M.numpy()[:dim, :dim], dM), 1e-5)
     # --- hierarchical mutual information, channel 0 and the dense purchase channel
     for ch in (0, 2):
         em = (rng.standard_normal((nu, dim)) * 0.5).astype(np.float32)
@@ -1084,8 +1114,9 @@ def test_mhcn_gate_attention_and_mim_kernels_match_restatement(dim, ld):
         loss = DB.zeros(1, np.float64)
         capi.hss_loss_grad(d_em, d_edge, nu, dim, ld, bufs, 1.0, DB(capi.hss_scratch_bytes(nu), np.uint8), d_dem, d_dedge, loss)
         capi.spmm_csr(planT, d_dedge, d_tot, ld, d_addend=d_dem, addend_scale=1.0)
-        assert float(loss.numpy()[0]) == pytest.approx(want_loss, rel=2e-5)
-        assert rel_err(d_tot.numpy()[:, :dim], want_dem) < 3e-5 and not d_tot.numpy()[:, dim:].any()
+        check_rel("MIM loss", float(loss.numpy()[0]), want_loss, 1e-5)
+        check("rel_err(d_tot.numpy()[:, :dim], want_dem)", rel_err(d_tot.numpy()[:, :dim], want_dem), 1e-5)
+        assert not d_tot.numpy()[:, dim:].any()
 
 
 def test_device_permutations_are_permutations_and_look_uniform():
@@ -1129,14 +1160,16 @@ def test_mhcn_training_steps_match_restatement(L):
         ref.train_step(u, i, j, perms)
         tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, perms=perms)
         rec, ss = tr.losses()
-        assert rec == pytest.approx(want_rec, rel=3e-5) and ss == pytest.approx(want_ss, rel=3e-5), step
+        check_rel("MHCN rec loss", rec, want_rec, 1e-5, ctx=step); check_rel("MHCN ss loss", ss, want_ss, 1e-5, ctx=step)
         got = tr.parameters()
         for k in ref.w:
-            assert rel_err(got[k], ref.w[k]) < 3e-4, (step, k)
-        assert rel_err(got["U"], ref.U) < 3e-4 and rel_err(got["V"], ref.V) < 3e-4, step
+            check("rel_err(got[k], ref.w[k])", rel_err(got[k], ref.w[k]), 1e-5, ctx=(step, k))
+        check("rel_err(got['U'], ref.U)", rel_err(got["U"], ref.U), 1e-5, ctx=step)
+        check("rel_err(got['V'], ref.V)", rel_err(got["V"], ref.V), 1e-5, ctx=step)
     fu, fi, _ = ref.forward()
     Ud, Vd = tr.final_embeddings()
-    assert rel_err(Ud, fu) < 3e-4 and rel_err(Vd, fi) < 3e-4
+    check("rel_err(Ud, fu)", rel_err(Ud, fu), 1e-5)
+    check("rel_err(Vd, fi)", rel_err(Vd, fi), 1e-5)
     # without injected shuffles the device draws its own, new ones every step
     tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B)
     a = tr.rowp.numpy().copy()

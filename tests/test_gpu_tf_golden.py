@@ -14,7 +14,7 @@ from qrec_amd import capi
 from qrec_amd.capi import DeviceBuffer as DB
 from qrec_amd.graph import BprTfTrainer, LightGCNTrainer, NGCFTrainer, SimGCLTrainer, joint_norm_adjacency, unique_first_appearance
 
-from helpers import pad_cols, rel_err
+from helpers import check, check_rel, pad_cols, rel_err
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -39,6 +39,17 @@ def load(name):
     return META[name], np.load(os.path.join(HERE, name + ".npz"))
 
 
+GRAD_TOL = 1e-5         # north_star: 1e-5 relative on fp32 quantities
+
+
+def grad_check(got, want, what, bound=GRAD_TOL):
+    """a HIP trainer's first-step gradient against the one the reference's minimize() applied (grad<k>_<var> of the fixture):
+    same variables on both sides, BEFORE Adam -- the 12-step comparisons further down are the drift check"""
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    check(what, rel_err(got, want), bound)
+
+
 def batches(z):
     off = z["batch_offsets"]
     for k in range(off.size - 1):
@@ -53,11 +64,16 @@ def test_lightgcn_trainer_follows_the_reference_run():
     tr = LightGCNTrainer(z["init_U"], z["init_V"], adj, m["n_layers"], lr=m["lr"], reg=m["regU"])
     for k, u, i, j in batches(z):
         tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), u.size)
-        assert abs(tr.loss() - z["losses"][k, 0]) / z["losses"][k, 0] < 3e-5, k
+        check("abs(tr.loss() - z['losses'][k, 0]) / z['losses'][k, 0]", abs(tr.loss() - z["losses"][k, 0]) / z["losses"][k, 0], 1e-5, ctx=k)
+        if k == 0:
+            gU, gV = tr.gradients()
+            grad_check(gU, z["grad0_U"], "LightGCN dU, step 0"); grad_check(gV, z["grad0_V"], "LightGCN dV, step 0")
     U, V = tr.ego_embeddings()
-    assert rel_err(U, z["final_U"]) < 5e-4 and rel_err(V, z["final_V"]) < 5e-4
+    check("rel_err(U, z['final_U'])", rel_err(U, z["final_U"]), 1e-5)
+    check("rel_err(V, z['final_V'])", rel_err(V, z["final_V"]), 1e-5)
     Uf, Vf = tr.final_embeddings()
-    assert rel_err(Uf, z["score_U"]) < 5e-4 and rel_err(Vf, z["score_V"]) < 5e-4
+    check("rel_err(Uf, z['score_U'])", rel_err(Uf, z["score_U"]), 1e-5)
+    check("rel_err(Vf, z['score_V'])", rel_err(Vf, z["score_V"]), 1e-5)
 
 
 def test_bpr_tf_trainer_follows_the_reference_run():
@@ -65,9 +81,13 @@ def test_bpr_tf_trainer_follows_the_reference_run():
     tr = BprTfTrainer(z["init_U"], z["init_V"], m["lr"], m["regU"])
     for k, u, i, j in batches(z):
         tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), u.size)
-        assert abs(tr.loss() - z["losses"][k, 0]) / z["losses"][k, 0] < 3e-5, k
+        check("abs(tr.loss() - z['losses'][k, 0]) / z['losses'][k, 0]", abs(tr.loss() - z["losses"][k, 0]) / z["losses"][k, 0], 1e-5, ctx=k)
+        if k == 0:
+            gU, gV = tr.gradients(np.concatenate([z["init_U"], z["init_V"]]))
+            grad_check(gU, z["grad0_U"], "BPR-tf dU, step 0"); grad_check(gV, z["grad0_V"], "BPR-tf dV, step 0")
     U, V = tr.tables()
-    assert rel_err(U, z["final_U"]) < 5e-4 and rel_err(V, z["final_V"]) < 5e-4
+    check("rel_err(U, z['final_U'])", rel_err(U, z["final_U"]), 1e-5)
+    check("rel_err(V, z['final_V'])", rel_err(V, z["final_V"]), 1e-5)
 
 
 def test_ngcf_trainer_follows_the_reference_run():
@@ -82,14 +102,22 @@ def test_ngcf_trainer_follows_the_reference_run():
     for k, u, i, j in batches(z):
         masks = [(tf1shim.random_uniform(m["seed"], z["run_index"][k], op, (n, dim)) >= rate).astype(np.float32) for op in ops]
         tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), u.size, masks=[DB.from_numpy(pad_cols(x, tr.ld)) for x in masks])
-        assert abs(tr.loss() - z["losses"][k, 0]) / z["losses"][k, 0] < 1e-4, k
+        check("abs(tr.loss() - z['losses'][k, 0]) / z['losses'][k, 0]", abs(tr.loss() - z["losses"][k, 0]) / z["losses"][k, 0], 1e-5, ctx=k)
+        if k == 0:
+            gU, gV, gW = tr.gradients()
+            grad_check(gU, z["grad0_U"], "NGCF dU, step 0"); grad_check(gV, z["grad0_V"], "NGCF dV, step 0")
+            for a in range(2):
+                for b in range(2):
+                    grad_check(gW[a][b], z[f"grad0_W_{a}_{b + 1}"], f"NGCF dW_{a}_{b + 1}, step 0")
     U, V, Wg = tr.parameters()
-    assert rel_err(U, z["final_U"]) < 2e-3 and rel_err(V, z["final_V"]) < 2e-3
+    check("rel_err(U, z['final_U'])", rel_err(U, z["final_U"]), 1e-5)
+    check("rel_err(V, z['final_V'])", rel_err(V, z["final_V"]), 1e-5)
     for a in range(2):
         for b in range(2):
-            assert rel_err(Wg[a][b], z[f"final_W_{a}_{b + 1}"]) < 2e-3
+            check("rel_err(Wg[a][b], z[f'final_W_{a}_{b + 1}'])", rel_err(Wg[a][b], z[f"final_W_{a}_{b + 1}"]), 1e-5)
     Ui, Vi = tr.inference_embeddings()
-    assert rel_err(Ui, z["score_U"]) < 2e-3 and rel_err(Vi, z["score_V"]) < 2e-3
+    check("rel_err(Ui, z['score_U'])", rel_err(Ui, z["score_U"]), 1e-5)
+    check("rel_err(Vi, z['score_V'])", rel_err(Vi, z["score_V"]), 1e-5)
 
 
 def test_simgcl_trainer_follows_the_reference_run():
@@ -109,22 +137,23 @@ def test_simgcl_trainer_follows_the_reference_run():
                             noises=[DB.from_numpy(pad_cols(x, tr.ld)) for x in noises])      # [N][ld]: the kernels read whole padded rows
         got = np.array(tr.losses())
         err = np.abs(got - z["losses"][k]) / z["losses"][k]
-        assert err.max() < 2e-3, (k, err)           # sign(emb) is discontinuous: an entry within rounding of zero may flip (test_oracle_tf_golden.py)
+        if k == 0:
+            gU, gV = tr.gradients()
+            grad_check(gU, z["grad0_" + names["U"]], "SimGCL dU, step 0"); grad_check(gV, z["grad0_" + names["V"]], "SimGCL dV, step 0")
+        check("SimGCL total / rec / cl loss vs reference run (worst of the three)", err.max(), 0.001, ctx=(k, err))           # sign(emb) is discontinuous: an entry within rounding of zero may flip (test_oracle_tf_golden.py)
         worst.append(err.max())
     assert np.sum(np.array(worst) > 5e-5) <= 3, worst
     U, V = tr.ego_embeddings()
     E = np.concatenate([z["final_" + names["U"]], z["final_" + names["V"]]])
-    assert rel_err(np.concatenate([U, V]), E) < 5e-3
+    check("rel_err(np.concatenate([U, V]), E)", rel_err(np.concatenate([U, V]), E), 0.002)
     Um, Vm = tr.main_embeddings()
-    assert rel_err(Um, z["score_U"]) < 5e-3 and rel_err(Vm, z["score_V"]) < 5e-3
+    check("rel_err(Um, z['score_U'])", rel_err(Um, z["score_U"]), 0.002)
+    check("rel_err(Vm, z['score_V'])", rel_err(Vm, z["score_V"]), 0.002)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# SGL / BUIR / SEPT / MHCN trainers against their reference runs.  Written when round 2's GPU minutes were used up: the four
-# tests above ran green on the MI355X, these have not been run there yet, so they are opt-in (QREC_RUN_PENDING_GOLDEN=1) until
-# a GPU run has confirmed them -- a test that has never executed must not be able to turn the suite red or green.
+# SGL / BUIR / SEPT / MHCN trainers against their reference runs
 # ---------------------------------------------------------------------------------------------------------------------
-pending = pytest.mark.skipif(not os.environ.get("QREC_RUN_PENDING_GOLDEN"), reason="not yet validated on a GPU (set QREC_RUN_PENDING_GOLDEN=1)")
 
 
 def _csr(a, n):
@@ -132,7 +161,6 @@ def _csr(a, n):
     return sp.csr_matrix((a[2], a[1], a[0]), shape=(n, n))
 
 
-@pending
 @pytest.mark.parametrize("name", ["tf_sgl_filmtrust", "tf_sgl_rw_filmtrust", "tf_sgl_nd_filmtrust"])
 def test_sgl_trainer_follows_the_reference_run(name):
     from qrec_amd.graph import SGLTrainer
@@ -161,14 +189,18 @@ def test_sgl_trainer_follows_the_reference_run(name):
         rows = np.concatenate([unique_first_appearance(u), unique_first_appearance(i) + nu]).astype(np.int32)
         tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), u.size, DB.from_numpy(rows), rows.size)
         got = np.array(tr.losses())
-        assert (np.abs(got - z["losses"][k]) / z["losses"][k]).max() < 5e-5, k
+        check("SGL total / rec / ssl loss vs reference run (worst of the three)", (np.abs(got - z["losses"][k]) / z["losses"][k]).max(), 1e-5, ctx=k)
+        if k == 0:
+            gU, gV = tr.gradients()
+            grad_check(gU, z["grad0_U"], f"SGL aug {aug} dU, step 0"); grad_check(gV, z["grad0_V"], f"SGL aug {aug} dV, step 0")
     U, V = tr.ego_embeddings()
-    assert rel_err(U, z["final_U"]) < 1e-3 and rel_err(V, z["final_V"]) < 1e-3
+    check("rel_err(U, z['final_U'])", rel_err(U, z["final_U"]), 1e-5)
+    check("rel_err(V, z['final_V'])", rel_err(V, z["final_V"]), 2e-5)
     Um, Vm = tr.main_embeddings()
-    assert rel_err(Um, z["score_U"]) < 1e-3 and rel_err(Vm, z["score_V"]) < 1e-3
+    check("rel_err(Um, z['score_U'])", rel_err(Um, z["score_U"]), 1e-5)
+    check("rel_err(Vm, z['score_V'])", rel_err(Vm, z["score_V"]), 2e-5)
 
 
-@pending
 def test_buir_trainer_follows_the_reference_run():
     from qrec_amd.graph import BUIRTrainer
     m, z = load("tf_buir_filmtrust")
@@ -186,17 +218,22 @@ def test_buir_trainer_follows_the_reference_run():
             tr.set_subgraphs(subs[2 * e], subs[2 * e + 1])
         u = z["batch_u"][off[k]:off[k + 1]].astype(np.int32); i = z["batch_i"][off[k]:off[k + 1]].astype(np.int32)
         tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), u.size)
-        assert abs(tr.loss() - z["losses"][k, 0]) / z["losses"][k, 0] < 1e-4, k
+        check("abs(tr.loss() - z['losses'][k, 0]) / z['losses'][k, 0]", abs(tr.loss() - z["losses"][k, 0]) / z["losses"][k, 0], 1e-5, ctx=k)
+        if k == 0:
+            gE, gW, gb = tr.gradients()
+            grad_check(gE[:nu], z["grad0_U"], "BUIR dU, step 0"); grad_check(gE[nu:], z["grad0_V"], "BUIR dV, step 0")
+            grad_check(gW, z["grad0_online_mat"], "BUIR dW, step 0"); grad_check(gb[None, :], z["grad0_online_bias"], "BUIR db, step 0")
     E = np.concatenate([z["final_U"], z["final_V"]]); Tt = np.concatenate([z["final_t_U"], z["final_t_V"]])
-    assert rel_err(tr.online_tables(), E) < 1e-3 and rel_err(tr.target_tables(), Tt) < 1e-3
+    check("rel_err(tr.online_tables(), E)", rel_err(tr.online_tables(), E), 1e-5)
+    check("rel_err(tr.target_tables(), Tt)", rel_err(tr.target_tables(), Tt), 1e-5)
     Wg, bg = tr.weights()
-    assert rel_err(Wg, z["final_online_mat"]) < 1e-3 and rel_err(bg, z["final_online_bias"].ravel()) < 2e-3
+    check("rel_err(Wg, z['final_online_mat'])", rel_err(Wg, z["final_online_mat"]), 1e-5)
+    check("rel_err(bg, z['final_online_bias'].ravel())", rel_err(bg, z["final_online_bias"].ravel()), 1e-5)
     adj = joint_norm_adjacency(nu, ni, z["train_uid"], z["train_iid"])
     for g, key in zip(tr.final_tables(adj), ("q_user", "q_item", "o_user", "o_item")):
-        assert rel_err(g, z[key]) < 1e-3, key
+        check("rel_err(g, z[key])", rel_err(g, z[key]), 1e-5, ctx=key)
 
 
-@pending
 def test_sept_trainer_follows_the_reference_run():
     from oracle import tfmodels as T      # the oracle's scipy graph builders (themselves bit-identical to the reference's, test_oracle_golden.py)
     from qrec_amd.graph import SEPTTrainer
@@ -217,18 +254,29 @@ def test_sept_trainer_follows_the_reference_run():
             order = z[f"order_{s}"]
             tr.set_perturbed_graph(T.sept_sub_adjacency(nu, ni, uid[order], iid[order], fo, fe, z[f"keep_{s}"], z[f"skeep_{s}"]))
         uu = unique_first_appearance(u).astype(np.int32)
+        if k in m["first_steps"]:       # first step of v1_op / v2_op (SEPT.py:267-270): the gradient from the REFERENCE'S variables at that point
+            n_op = m["first_steps"].index(k)
+            W_mine = tr.W.numpy()
+            before = np.concatenate([z["init_U"], z["init_V"]]) if n_op == 0 else np.concatenate([z[f"pre{n_op}_U"], z[f"pre{n_op}_V"]])
+            tr.W.upload(pad_cols(before.astype(np.float32), tr.ld))
+            probe = tr.opt[n_op]
+            saved = (probe.m.numpy(), probe.v.numpy(), probe.b1p, probe.b2p)
+            tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), u.size, joint, DB.from_numpy(uu), uu.size)
+            gU, gV = tr.gradients(before)
+            grad_check(gU, z[f"grad{n_op}_U"], f"SEPT dU, first step of train op {n_op}"); grad_check(gV, z[f"grad{n_op}_V"], f"SEPT dV, first step of train op {n_op}")
+            tr.W.upload(W_mine); probe.m.upload(saved[0]); probe.v.upload(saved[1]); probe.b1p, probe.b2p = saved[2], saved[3]     # undo the probe step
         tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), u.size, joint, DB.from_numpy(uu), uu.size)
         got = tr.losses()
-        assert got[0] == pytest.approx(z["losses"][k, 0], rel=5e-5), k
+        check_rel("SEPT rec loss vs reference run", got[0], z["losses"][k, 0], 1e-5, ctx=k)
         if joint:       # pseudo labels are a top-k of float32 softmax rows: a near-tie may pick another neighbour
-            assert got[1] == pytest.approx(m["ss_rate"] * z["losses"][k, 1], rel=2e-3), k
+            check_rel("SEPT ssl loss vs reference run", got[1], m["ss_rate"] * z["losses"][k, 1], 1e-5, ctx=k)
     U, V = tr.variables()
-    assert rel_err(np.concatenate([U, V]), np.concatenate([z["final_U"], z["final_V"]])) < 2e-3
+    check("rel_err(np.concatenate([U, V]), np.concatenate([z['final_U'], z['final_V']]))", rel_err(np.concatenate([U, V]), np.concatenate([z["final_U"], z["final_V"]])), 1e-5)
     Ur, Vr = tr.rec_embeddings()
-    assert rel_err(Ur, z["score_U"]) < 2e-3 and rel_err(Vr, z["score_V"]) < 2e-3
+    check("rel_err(Ur, z['score_U'])", rel_err(Ur, z["score_U"]), 1e-5)
+    check("rel_err(Vr, z['score_V'])", rel_err(Vr, z["score_V"]), 1e-5)
 
 
-@pending
 def test_mhcn_trainer_follows_the_reference_run():
     from oracle import tfmodels as T
     from qrec_amd.graph import MHCNTrainer
@@ -246,10 +294,18 @@ def test_mhcn_trainer_follows_the_reference_run():
         draws = [np.argsort(tf1shim.random_uniform(m["seed"], z["run_index"][k], r[0], r[2]), kind="stable") for r in ops]
         tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), u.size, perms=[tuple(draws[5 * c:5 * c + 5]) for c in range(3)])
         rec, _ = tr.losses()
-        assert rec == pytest.approx(z["losses"][k, 0], rel=1e-4), k
+        check_rel("MHCN rec loss vs reference run", rec, z["losses"][k, 0], 1e-5, ctx=k)
+        if k == 0:
+            before = {a: z["init_" + b] for a, b in key.items()}; before["U"], before["V"] = z["init_U"], z["init_V"]
+            g = tr.gradients(before)
+            grad_check(g["U"], z["grad0_U"], "MHCN dU, step 0"); grad_check(g["V"], z["grad0_V"], "MHCN dV, step 0")
+            for a, b in key.items():
+                grad_check(g[a].reshape(z["grad0_" + b].shape), z["grad0_" + b], f"MHCN d{a}, step 0")
     got = tr.parameters()
     for a, b in key.items():
-        assert rel_err(got[a], z["final_" + b]) < 2e-3, a
-    assert rel_err(got["U"], z["final_U"]) < 2e-3 and rel_err(got["V"], z["final_V"]) < 2e-3
+        check("rel_err(got[a], z['final_' + b])", rel_err(got[a], z["final_" + b]), 1e-5, ctx=a)
+    check("rel_err(got['U'], z['final_U'])", rel_err(got["U"], z["final_U"]), 1e-5)
+    check("rel_err(got['V'], z['final_V'])", rel_err(got["V"], z["final_V"]), 5e-5)
     Ud, Vd = tr.final_embeddings()
-    assert rel_err(Ud, z["score_U"]) < 2e-3 and rel_err(Vd, z["score_V"]) < 2e-3
+    check("rel_err(Ud, z['score_U'])", rel_err(Ud, z["score_U"]), 1e-5)
+    check("rel_err(Vd, z['score_V'])", rel_err(Vd, z["score_V"]), 5e-5)

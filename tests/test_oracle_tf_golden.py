@@ -43,6 +43,18 @@ def close(a, b, what, rtol=2e-4, atol=2e-6):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
 
 
+GRAD_TOL = 1e-5         # north_star: 1e-5 relative on fp32 quantities
+
+
+def grad_close(got, want, what, bound=GRAD_TOL):
+    """a first-step gradient of the restatement against the one the reference's minimize() applied (grad<k>_<var> of the fixture):
+    both start from the same variables, so this is the comparison BEFORE Adam's 1/sqrt(v) amplifies rounding noise.  Relative
+    error in the Euclidean norm, recorded in the parity ledger (helpers.check)."""
+    from helpers import check, rel_err
+    assert np.asarray(got).shape == np.asarray(want).shape, what
+    check(what, rel_err(got, want), bound)
+
+
 def test_shim_draws_are_regenerable():
     """the fixtures store run indices, not noise: the same key must give the same numbers on any machine"""
     a = tf1shim.random_uniform(104, 3, 1, (5, 4))
@@ -57,6 +69,9 @@ def test_lightgcn_restatement_follows_the_reference_run():
     adj = T.joint_norm_adjacency(m["n_users"], m["n_items"], z["train_uid"], z["train_iid"])
     o = T.LightGCN(z["init_U"], z["init_V"], adj, m["n_layers"], m["lr"], m["regU"])
     for k, u, i, j in batches(z):
+        if k == 0:
+            g = o.loss_and_grad(u, i, j)[1]
+            grad_close(g[:m["n_users"]], z["grad0_U"], "LightGCN dU, step 0"); grad_close(g[m["n_users"]:], z["grad0_V"], "LightGCN dV, step 0")
         loss = o.train_step(u, i, j)
         close(loss, z["losses"][k, 0], f"loss of step {k}", rtol=2e-5)
     close(o.E[:m["n_users"]], z["final_U"], "user variable after 12 steps")
@@ -69,6 +84,12 @@ def test_bpr_tf_restatement_follows_the_reference_run():
     m, z = load("tf_bpr_filmtrust")
     o = T.BprTF(z["init_U"], z["init_V"], m["lr"], m["regU"])
     for k, u, i, j in batches(z):
+        if k == 0:
+            nu = m["n_users"]
+            _, du, di, dj = T.bpr_batch_loss_and_grads(o.E[u], o.E[i + nu], o.E[j + nu], 0.0, eps=np.float32(1e-6))
+            g = np.zeros_like(o.E); np.add.at(g, u, du); np.add.at(g, i + nu, di); np.add.at(g, j + nu, dj)
+            g = g + o.reg * o.E
+            grad_close(g[:nu], z["grad0_U"], "BPR-tf dU, step 0"); grad_close(g[nu:], z["grad0_V"], "BPR-tf dV, step 0")
         loss = o.train_step(u, i, j)
         close(loss, z["losses"][k, 0], f"loss of step {k}", rtol=2e-5)
     close(o.E[:m["n_users"]], z["final_U"], "U after 12 steps")
@@ -87,6 +108,12 @@ def test_ngcf_restatement_follows_the_reference_run():
     assert [r[1] for r in m["random_ops"][0]] == ["dropout", "dropout"] and all(tuple(r[2]) == (n, m["emb_size"]) for r in m["random_ops"][0])
     for k, u, i, j in batches(z):
         masks = [(tf1shim.random_uniform(m["seed"], z["run_index"][k], op, (n, m["emb_size"])) >= np.float32(rate)).astype(np.float32) for op in ops]
+        if k == 0:
+            _, gE, gW = o.loss_and_grads(u, i, j, masks)
+            grad_close(gE[:m["n_users"]], z["grad0_U"], "NGCF dU, step 0"); grad_close(gE[m["n_users"]:], z["grad0_V"], "NGCF dV, step 0")
+            for a in range(2):
+                for b in range(2):
+                    grad_close(gW[a][b], z[f"grad0_W_{a}_{b + 1}"], f"NGCF dW_{a}_{b + 1}, step 0")
         loss = o.train_step(u, i, j, masks)
         close(loss, z["losses"][k, 0], f"loss of step {k}", rtol=1e-4)
     close(o.E[:m["n_users"]], z["final_U"], "U after 12 steps", rtol=2e-3, atol=2e-5)
@@ -112,6 +139,9 @@ def test_simgcl_restatement_follows_the_reference_run():
     worst = []
     for k, u, i, j in batches(z):
         noises = [tf1shim.random_uniform(m["seed"], z["run_index"][k], op, (n, m["emb_size"])) for op in ops]
+        if k == 0:
+            g = o.loss_and_grad(u, i, j, noises)[3]
+            grad_close(g[:m["n_users"]], z["grad0_" + names["U"]], "SimGCL dU, step 0"); grad_close(g[m["n_users"]:], z["grad0_" + names["V"]], "SimGCL dV, step 0")
         loss, rec, cl = o.train_step(u, i, j, noises)
         close([loss, rec, cl], z["losses"][k], f"total / rec / cl loss of step {k}", rtol=1e-3)
         worst.append(np.max(np.abs(np.array([loss, rec, cl]) - z["losses"][k]) / z["losses"][k]))
@@ -163,6 +193,9 @@ def test_sgl_restatement_follows_the_reference_run(name):
                 for l in (range(L) if aug == 2 else [None]):
                     tag = f"sub{v}" + ("" if l is None else str(l))
                     _assert_fed(mats[0 if l is None else l], fed[f"adj_indices_{tag}"], fed[f"adj_values_{tag}"])
+        if k == 0:
+            g = o.loss_and_grad(u, i, j, mats1, mats2)[3]
+            grad_close(g[:nu], z["grad0_U"], f"SGL aug {aug} dU, step 0"); grad_close(g[nu:], z["grad0_V"], f"SGL aug {aug} dV, step 0")
         loss, rec, ssl = o.train_step(u, i, j, mats1, mats2)
         close([loss, rec, ssl], z["losses"][k], f"total / rec / ssl loss of step {k}", rtol=2e-5)
     close(o.E[:nu], z["final_U"], "user variable after 12 steps", rtol=2e-3, atol=2e-5)
@@ -201,6 +234,10 @@ def test_buir_restatement_follows_the_reference_run():
         mo, mt = subs[2 * e], subs[2 * e + 1]
         if k % steps_per_epoch == 0:
             _assert_fed(mo, *m["fed_sha256"][k][:2]); _assert_fed(mt, *m["fed_sha256"][k][2:])
+        if k == 0:
+            _, gE, gW, gb = o.loss_and_grads(u, i, mo, mt)
+            grad_close(gE[:nu], z["grad0_U"], "BUIR dU, step 0"); grad_close(gE[nu:], z["grad0_V"], "BUIR dV, step 0")
+            grad_close(gW, z["grad0_online_mat"], "BUIR dW, step 0"); grad_close(gb, z["grad0_online_bias"], "BUIR db, step 0")
         loss = o.train_step(u, i, mo, mt)
         close(loss, z["losses"][k, 0], f"loss of step {k}", rtol=5e-5)
     close(o.E[:nu], z["final_U"], "online user table", rtol=2e-3, atol=2e-5); close(o.E[nu:], z["final_V"], "online item table", rtol=2e-3, atol=2e-5)
@@ -233,6 +270,14 @@ def test_sept_restatement_follows_the_reference_run():
         sub = subs[joint.index(e)] if e in joint else None
         if sub is not None and k % steps_per_epoch == 0:
             _assert_fed(sub, *m["fed_sha256"][k])
+        if k in m["first_steps"]:        # the first step of v1_op (rec task alone) and of v2_op (joint objective), SEPT.py:267-270
+            n_op = m["first_steps"].index(k)
+            keep = o.W.copy()
+            if n_op > 0:                  # from the variables the REFERENCE's step started from, so that 6 steps of Adam noise stay out
+                o.W = np.concatenate([z[f"pre{n_op}_U"], z[f"pre{n_op}_V"]]).astype(np.float32)
+            g = o.loss_and_grad(u, i, j, sub)[2]
+            o.W = keep
+            grad_close(g[:nu], z[f"grad{n_op}_U"], f"SEPT dU, first step of train op {n_op}"); grad_close(g[nu:], z[f"grad{n_op}_V"], f"SEPT dV, first step of train op {n_op}")
         rec, ssl = o.train_step(u, i, j, sub)
         close(rec, z["losses"][k, 0], f"rec loss of step {k}", rtol=2e-5)
         if sub is None:
@@ -268,6 +313,11 @@ def test_mhcn_restatement_follows_the_reference_run():
     for k, u, i, j in batches(z):
         draws = [np.argsort(tf1shim.random_uniform(m["seed"], z["run_index"][k], r[0], r[2]), kind="stable") for r in ops]
         perms = [tuple(draws[5 * c:5 * c + 5]) for c in range(3)]
+        if k == 0:
+            g = o.loss_and_grads(u, i, j, perms)[3]
+            grad_close(g["U"], z["grad0_U"], "MHCN dU, step 0"); grad_close(g["V"], z["grad0_V"], "MHCN dV, step 0")
+            for a, b in key.items():
+                grad_close(np.asarray(g[a]).reshape(z["grad0_" + b].shape), z["grad0_" + b], f"MHCN d{a}, step 0")
         rec = o.train_step(u, i, j, perms)
         close(rec, z["losses"][k, 0], f"rec loss of step {k}", rtol=5e-5)
     close(o.U, z["final_U"], "user table", rtol=2e-3, atol=1e-4); close(o.V, z["final_V"], "item table", rtol=2e-3, atol=1e-4)

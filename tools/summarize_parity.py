@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Fold a parity ledger (tests/helpers.py::check, one JSON line per comparison, written when QREC_PARITY_LOG is set) into
+profiles/rNN_parity_errors.json: per (test, quantity) the number of comparisons, the worst observed error and the bound it
+was held to, sorted by observed / bound.
+
+    python tools/summarize_parity.py gpurun_out/parity_r03.jsonl profiles/r03_parity_errors.json
+"""
+import json
+import sys
+
+
+def main(src, dst):
+    rows = {}
+    for line in open(src):
+        r = json.loads(line)
+        key = (r["test"], r["quantity"])
+        e = rows.setdefault(key, dict(test=r["test"], quantity=r["quantity"], n=0, observed=0.0, bound=r["bound"]))
+        e["n"] += 1
+        e["observed"] = max(e["observed"], r["observed"])
+        e["bound"] = min(e["bound"], r["bound"])
+    out = sorted(rows.values(), key=lambda e: -(e["observed"] / e["bound"] if e["bound"] else 0.0))
+    over = [e for e in out if e["bound"] > 1e-5 * (1 + 1e-9)]
+    doc = dict(source=src, comparisons=sum(e["n"] for e in out), distinct=len(out),
+               bounds_above_1e_5=len(over), worst_observed_over_bound=(out[0]["observed"] / out[0]["bound"] if out else None), rows=out)
+    with open(dst, "w") as f:
+        json.dump(doc, f, indent=1)
+    print(f"{doc['comparisons']} comparisons, {len(out)} distinct, {len(over)} held to a bound above 1e-5")
+    for e in over:
+        print(f"  {e['observed']:.2e} / {e['bound']:.0e}  {e['test'].split('::')[-1]}  {e['quantity'][:70]}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
