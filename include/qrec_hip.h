@@ -131,7 +131,7 @@ int qrec_bpr_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
  *   width       : <= qrec_bpr_exact_width(dtype, d) (what the CU's LDS holds), <= QREC_EXACT_MAX_WIDTH
  *   d_xlog      : table-dtype[n + QREC_EXACT_XLOG_PAD] scratch (x per triplet, then the dummy rows idle wavefronts work on),
  *   d_scratch   : double[QREC_EXACT_SCRATCH_WORDS], zero before first use */
-#define QREC_EXACT_MAX_WIDTH 16
+#define QREC_EXACT_MAX_WIDTH 16       /* a power of two: a source code is ((dist - 1) * 16 + slot) * 4 + row, or -1 = the table */
 #define QREC_EXACT_XLOG_PAD (16 * 256 + 64)
 #define QREC_EXACT_SCRATCH_WORDS 130
 int qrec_bpr_exact_width(int dtype, int32_t d, int32_t *width);
@@ -140,6 +140,32 @@ int qrec_bpr_exact_schedule(const int32_t *h_u, const int32_t *h_i, const int32_
 int qrec_bpr_sgd_scheduled(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld, const int32_t *d_entries,
                            const int32_t *d_step_off, int64_t n_steps, int32_t width, int64_t n, double lr, double regU,
                            double regI, void *d_xlog, double *d_scratch, double *d_loss, void *stream);
+/* Four triplets per wavefront (round 3; rows of 16, 32, 64 or 128 elements): a triplet on the 16 lanes of one DPP row, rows handed
+ * on in registers or through the table, nothing in LDS (bpr_exact.hip).  Same order, same values as qrec_bpr_sgd_scheduled up to
+ * the last bits (own summation tree and exp: 1e-13 apart in fp64); identical bits across widths.  2.4 x the steps per second.
+ *   qrec_bpr_exact_kind       : which kernel serves (dtype, ld, width): 0 = qrec_bpr_exact_schedule + qrec_bpr_sgd_scheduled
+ *                               (above), 1 = the three calls below; slots = 4 * ceil(width / 4) for kind 1.
+ *                               Env QREC_EXACT_KERNEL=w64 forces 0 (measurement).
+ *   qrec_bpr_exact_schedule_reg : host; arguments and entry format of qrec_bpr_exact_schedule, but h_step_off needs 3 n + 2
+ *                               entries (steps may stay empty: n_steps <= 3 n).  A user's run stays on one slot and hands P[u]
+ *                               on in that group's registers (src_P = -2); every other row is read from the table, so
+ *                               touches of a row by different slots are kept >= 3 steps apart.  Entry word 7 = bit 0 (P goes
+ *                               on in registers: no table store) | slot << 8 | 0x1000.
+ *   qrec_bpr_exact_expand     : d_entries / d_step_off (device copies of that schedule) -> the fixed-width layout the kernel
+ *                               reads: d_wide int32[(n_steps + QREC_EXACT_WIDE_PAD) * slots * 8], QREC_EXACT_WIDE_LEAD empty
+ *                               steps in front, empty slots u = -1;
+ *   qrec_bpr_sgd_scheduled_wide : the epoch; d_xlog / d_scratch / d_loss as above.  The tables are addressed through
+ *                               bounds-checked 32-bit offsets: each of P, Q below 4 GiB (else kind 0).                        */
+#define QREC_EXACT_WIDE_PAD 16
+#define QREC_EXACT_WIDE_LEAD 4
+int qrec_bpr_exact_kind(int dtype, int32_t ld, int32_t width, int32_t *kind, int32_t *slots);
+int qrec_bpr_exact_schedule_reg(const int32_t *h_u, const int32_t *h_i, const int32_t *h_j, int64_t n, int32_t n_users,
+                                int32_t n_items, int32_t width, int32_t *h_entries, int32_t *h_step_off, int64_t *n_steps);
+int qrec_bpr_exact_expand(const int32_t *d_entries, const int32_t *d_step_off, int64_t n_steps, int32_t slots, int32_t *d_wide,
+                          void *stream);
+int qrec_bpr_sgd_scheduled_wide(void *d_P, void *d_Q, int64_t n_users, int64_t n_items, int dtype, int32_t d, int32_t ld,
+                                const int32_t *d_wide, int64_t n_steps, int32_t slots, int64_t n, double lr, double regU, double regI,
+                                void *d_xlog, double *d_scratch, double *d_loss, void *stream);
 
 /* Throughput mode (fp32): triplets are cut into chunks of `chunk` consecutive entries;
  * one 16-lane (d<=64) / 32-lane (d<=128) group owns a chunk, keeps P[u] in registers

@@ -54,6 +54,10 @@ _SIGNATURES = {
     "qrec_bpr_exact_width": [C.c_int, _i32, _vp],
     "qrec_bpr_exact_schedule": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
     "qrec_bpr_sgd_scheduled": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _i64, _i32, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp],
+    "qrec_bpr_exact_kind": [C.c_int, _i32, _i32, _vp, _vp],
+    "qrec_bpr_exact_schedule_reg": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
+    "qrec_bpr_exact_expand": [_vp, _vp, _i64, _i32, _vp, _vp],
+    "qrec_bpr_sgd_scheduled_wide": [_vp, _vp, _i64, _i64, C.c_int, _i32, _i32, _vp, _i64, _i32, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp],
     "qrec_bpr_sgd_hogwild": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _vp, C.c_int, _vp, _vp],
     "qrec_bpr_sgd_hogwild_item_major": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp],
     "qrec_epoch_close": [_vp, _i64, _vp, _i64, C.c_int, _i32, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
@@ -539,7 +543,7 @@ def bpr_sgd_ordered(d_P, d_Q, dtype: int, d: int, ld: int, d_u, d_i, d_j, n: int
                                        n, lr, regU, regI, _dp(d_loss), _sh(stream)))
 
 
-EXACT_MAX_WIDTH, EXACT_SCRATCH_WORDS, EXACT_XLOG_PAD = 16, 130, 16 * 256 + 64
+EXACT_MAX_WIDTH, EXACT_SCRATCH_WORDS, EXACT_XLOG_PAD, EXACT_WIDE_PAD = 16, 130, 16 * 256 + 64, 16
 
 
 def bpr_exact_width(dtype: int, d: int) -> int:
@@ -548,13 +552,16 @@ def bpr_exact_width(dtype: int, d: int) -> int:
     return w.value
 
 
-def bpr_exact_schedule(u: np.ndarray, i: np.ndarray, j: np.ndarray, n_users: int, n_items: int, width: int):
-    """static schedule of an epoch's triplets (include/qrec_hip.h): (entries int32[n, 8] step-major, step_off int32[n_steps + 1])"""
+def bpr_exact_schedule(u: np.ndarray, i: np.ndarray, j: np.ndarray, n_users: int, n_items: int, width: int, registers: bool = False):
+    """static schedule of an epoch's triplets (include/qrec_hip.h): (entries int32[n, 8] step-major, step_off int32[n_steps + 1]).
+    ``registers``: the schedule of the four-triplets-per-wavefront kernel (qrec_bpr_exact_schedule_reg, kind 1)."""
     _req(u, np.int32, "u"); _req(i, np.int32, "i"); _req(j, np.int32, "j")
     n = int(u.size)
-    entries = np.empty((max(n, 1), 8), dtype=np.int32); off = np.empty(n + 2, dtype=np.int32)
+    entries = np.empty((max(n, 1), 8), dtype=np.int32)
+    off = np.empty((3 * n if registers else n) + 2, dtype=np.int32)      # the register schedule may leave steps empty: <= 3 n steps
     steps = C.c_int64(0)
-    _check(load().qrec_bpr_exact_schedule(_hp(u), _hp(i), _hp(j), n, n_users, n_items, width, _hp(entries), _hp(off), C.byref(steps)))
+    f = load().qrec_bpr_exact_schedule_reg if registers else load().qrec_bpr_exact_schedule
+    _check(f(_hp(u), _hp(i), _hp(j), n, n_users, n_items, width, _hp(entries), _hp(off), C.byref(steps)))
     return entries[:n], off[:steps.value + 1].copy()
 
 
@@ -562,6 +569,25 @@ def bpr_sgd_scheduled(d_P, d_Q, dtype: int, d: int, ld: int, d_entries, d_step_o
                       regU: float, regI: float, d_xlog, d_scratch, d_loss, stream=None):
     _check(load().qrec_bpr_sgd_scheduled(_dp(d_P), _dp(d_Q), dtype, d, ld, _dp(d_entries), _dp(d_step_off), n_steps, width, n, lr, regU,
                                          regI, _dp(d_xlog), _dp(d_scratch), _dp(d_loss), _sh(stream)))
+
+
+def bpr_exact_kind(dtype: int, ld: int, width: int) -> tuple[int, int]:
+    """(kind, slots): which kernel executes an order-exact epoch of (dtype, ld, width) -- 0 one triplet per wavefront
+    (bpr_exact_schedule + bpr_sgd_scheduled), 1 four per wavefront (bpr_exact_schedule(registers=True) + bpr_exact_expand +
+    bpr_sgd_scheduled_wide) -- and the slots per step of the wide schedule layout (0 for kind 0)"""
+    k, s = _i32(0), _i32(0)
+    _check(load().qrec_bpr_exact_kind(dtype, ld, width, C.byref(k), C.byref(s)))
+    return k.value, s.value
+
+
+def bpr_exact_expand(d_entries, d_step_off, n_steps: int, slots: int, d_wide, stream=None):
+    _check(load().qrec_bpr_exact_expand(_dp(d_entries), _dp(d_step_off), n_steps, slots, _dp(d_wide), _sh(stream)))
+
+
+def bpr_sgd_scheduled_wide(d_P, d_Q, n_users: int, n_items: int, dtype: int, d: int, ld: int, d_wide, n_steps: int, slots: int,
+                           n: int, lr: float, regU: float, regI: float, d_xlog, d_scratch, d_loss, stream=None):
+    _check(load().qrec_bpr_sgd_scheduled_wide(_dp(d_P), _dp(d_Q), n_users, n_items, dtype, d, ld, _dp(d_wide), n_steps, slots, n, lr,
+                                              regU, regI, _dp(d_xlog), _dp(d_scratch), _dp(d_loss), _sh(stream)))
 
 
 def _table_rows(buf, ld: int) -> int:

@@ -17,8 +17,13 @@ from .interactions import CSR
 
 def padded_ld(d: int, dtype) -> int:
     """Row stride in elements.  fp32 tables use 32/64/128/256 so that the throughput kernel
-    can map a row onto 16/32/64 lanes; fp64 (order-exact kernel only) needs no padding."""
+    can map a row onto 16/32/64 lanes; fp64 tables (order-exact kernels only) 16/32/64/128 so that the scheduled kernel
+    can put a row on the 16 lanes of one DPP row with 16-byte accesses (four triplets per wavefront, bpr_exact.hip);
+    wider fp64 rows stay unpadded (one triplet per wavefront).  Pad columns are zero and stay zero under every update."""
     if np.dtype(dtype) == np.float64:
+        for ld in (16, 32, 64, 128):
+            if d <= ld:
+                return ld
         return d
     for ld in (32, 64, 128, 256):
         if d <= ld:
@@ -248,27 +253,46 @@ class BprSgd:
             j = np.ascontiguousarray(j[self.perm])
         if width <= 1 or self.n == 0:
             return None
-        entries, off = capi.bpr_exact_schedule(self.h_u, self.h_i, j, t.n_users, self.n_items, width)
+        kind, slots = capi.bpr_exact_kind(t.code, t.ld, width)
+        if kind and max(t.n_users, t.n_items) * t.ld * t.dtype.itemsize >= 0xFFFFFF00:
+            kind, slots = 0, 0            # the four-per-wavefront kernel addresses the tables with 32-bit offsets
+        entries, off = capi.bpr_exact_schedule(self.h_u, self.h_i, j, t.n_users, self.n_items, width, registers=bool(kind))
         x = self._exact
         if "xlog" not in x:
             x["xlog"] = DeviceBuffer(self.n + capi.EXACT_XLOG_PAD, t.dtype)
             x["scratch"] = DeviceBuffer.zeros(capi.EXACT_SCRATCH_WORDS, np.float64)
         key = f"slot{slot}"
         if key not in x:
-            x[key] = (DeviceBuffer((self.n, 8), np.int32), DeviceBuffer(self.n + 2, np.int32))
+            x[key] = (DeviceBuffer((self.n, 8), np.int32), DeviceBuffer(3 * self.n + 2, np.int32))     # step offsets: the register schedule may leave steps empty (<= 3 n steps)
         d_entries, d_off = x[key]
         d_entries.upload(entries, stream)
         d_off.upload_head(off, stream)
+        steps = int(off.size - 1)
+        # four triplets per wavefront (rows of 16 .. 128 elements): the schedule goes on in the fixed-width layout, expanded on the
+        # device behind the upload (same stream)
+        d_wide = None
+        if kind:
+            need = (steps + capi.EXACT_WIDE_PAD) * slots * 8
+            wkey = f"wide{slot}"
+            if wkey not in x or x[wkey].shape[0] < need:
+                x[wkey] = DeviceBuffer(int(need * 1.1) + 64, np.int32)
+            d_wide = x[wkey]
+            capi.bpr_exact_expand(d_entries, d_off, steps, slots, d_wide, stream)
         # the host arrays stay referenced by the handle: an asynchronous copy may still be reading them when this returns
-        return {"entries": d_entries, "off": d_off, "steps": int(off.size - 1), "width": width, "j": j, "host": (entries, off)}
+        return {"entries": d_entries, "off": d_off, "steps": steps, "width": width, "j": j, "host": (entries, off), "slots": slots, "wide": d_wide,
+                "kind": kind}
 
     def run_prepared(self, prep, lr: float, regU: float, regI: float, stream=None):
         """enqueue the scheduled kernel of a prepared epoch (no host synchronisation; the loss lands in the stats buffer)"""
         t, x = self.t, self._exact
         self.h_j = prep["j"]
         self.exact_steps = prep["steps"]
-        capi.bpr_sgd_scheduled(t.P, t.Q, t.code, t.d, t.ld, prep["entries"], prep["off"], prep["steps"], prep["width"], self.n, lr, regU, regI,
-                               x["xlog"], x["scratch"], self.d_stats, stream)
+        if prep.get("kind"):
+            capi.bpr_sgd_scheduled_wide(t.P, t.Q, t.n_users, t.n_items, t.code, t.d, t.ld, prep["wide"], prep["steps"],
+                                        prep["slots"], self.n, lr, regU, regI, x["xlog"], x["scratch"], self.d_stats, stream)
+        else:
+            capi.bpr_sgd_scheduled(t.P, t.Q, t.code, t.d, t.ld, prep["entries"], prep["off"], prep["steps"], prep["width"], self.n, lr, regU, regI,
+                                   x["xlog"], x["scratch"], self.d_stats, stream)
 
     def epoch_throughput_async(self, lr: float, regU: float, regI: float, chunk: int = 32,
                                variant: int = capi.HW_DEFAULT, stream=None, groups: int = 0, flush_every: int = 16):

@@ -463,7 +463,12 @@ def _softmax(logits, axis=-1, name=None):
 
 
 def _top_k(input, k=1, sorted=True, name=None):      # noqa: A002
-    whole = Tensor(lambda ctx, a: torch.topk(a, int(k), dim=-1, largest=True, sorted=True), [_t(input)])
+    """nn_ops.top_k: "If two elements are equal, the lower-index element appears first" -- torch.topk gives no such promise
+    (found by tests/test_tf1shim.py's anchor from TF's topk_op_test.py), a stable descending sort does"""
+    def f(ctx, a):
+        vals, idx = torch.sort(a, dim=-1, descending=True, stable=True)
+        return vals[..., :int(k)], idx[..., :int(k)]
+    whole = Tensor(f, [_t(input)])
     return (Tensor(lambda ctx, p: p[0], [whole]), Tensor(lambda ctx, p: p[1], [whole], dtype=int32))
 
 

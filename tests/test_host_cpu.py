@@ -648,7 +648,7 @@ def test_exact_schedule_respects_every_dependence(width):
                 dist = step_of[k] - step_of[pk]
                 assert dist >= 1
                 if dist <= 2:
-                    assert code == ((dist - 1) * capi.EXACT_MAX_WIDTH + slot_of[pk]) * 3 + pwhich
+                    assert code == ((dist - 1) * capi.EXACT_MAX_WIDTH + slot_of[pk]) * 4 + pwhich
                 else:
                     assert code == -1
             last[row] = (k, which)
@@ -657,6 +657,56 @@ def test_exact_schedule_respects_every_dependence(width):
     with pytest.raises(capi.QRecError):
         capi.bpr_exact_schedule(u, i, i.copy(), U, I, width)        # i == j never happens in BPR and is refused
     e0, o0 = capi.bpr_exact_schedule(u[:0], i[:0], j[:0], U, I, width)
+    assert e0.shape == (0, 8) and o0.tolist() == [0]
+
+
+@pytest.mark.parametrize("width", [1, 3, 4, 8, 16])
+def test_exact_register_schedule_respects_every_dependence(width):
+    """qrec_bpr_exact_schedule_reg (round 3: four triplets per wavefront, nothing in LDS): a partition of the epoch into steps of
+    <= width triplets on distinct slots; every row's touchers in strictly increasing steps in the reference's order; P[u] reaches
+    its next toucher through the registers of the SAME slot in the NEXT step (src -2, and the writer is told not to store it) or
+    through the table, and then -- like every item row -- only when its last toucher is at least three steps back."""
+    from qrec_amd import capi
+    rng = np.random.default_rng(100 + width)
+    U, I, n = 40, 25, 3000
+    u = np.sort(rng.integers(0, U, n)).astype(np.int32)
+    i = rng.integers(0, I, n).astype(np.int32)
+    j = ((i + 1 + rng.integers(0, I - 1, n)) % I).astype(np.int32)
+    ent, off = capi.bpr_exact_schedule(u, i, j, U, I, width, registers=True)
+    assert off[0] == 0 and off[-1] == n and (np.diff(off) >= 0).all() and np.diff(off).max() <= width
+    assert sorted(ent[:, 3].tolist()) == list(range(n))
+    t = ent[:, 3]
+    assert np.array_equal(ent[:, 0], u[t]) and np.array_equal(ent[:, 1], i[t]) and np.array_equal(ent[:, 2], j[t])
+    assert (ent[:, 7] & 0x1000).all() and (ent[:, 5] == -1).all() and (ent[:, 6] == -1).all()
+    pos = np.arange(n); st = np.searchsorted(off, pos, side="right") - 1
+    step_of = np.empty(n, np.int64); slot_of = np.empty(n, np.int64); src_p = np.empty(n, np.int64); handed = np.empty(n, np.int64)
+    step_of[t] = st; slot_of[t] = (ent[:, 7] >> 8) & 15; src_p[t] = ent[:, 4]; handed[t] = ent[:, 7] & 1
+    assert slot_of.max() < width
+    for s in range(off.size - 1):                                   # distinct slots inside a step
+        sl = ((ent[off[s]:off[s + 1], 7] >> 8) & 15).tolist()
+        assert len(set(sl)) == len(sl)
+    last = {}
+    expect_handed = np.zeros(n, np.int64)
+    for k in range(n):
+        for which, row in enumerate((("P", u[k]), ("Q", i[k]), ("Q", j[k]))):
+            prev = last.get(row)
+            if prev is not None:
+                dist = step_of[k] - step_of[prev]
+                assert dist >= 1
+                if which == 0 and src_p[k] == -2:
+                    assert dist == 1 and slot_of[prev] == slot_of[k]
+                    expect_handed[prev] = 1
+                else:
+                    assert dist >= 3, (k, which, dist)             # the table copy is current for a load issued two steps ahead
+            else:
+                assert which != 0 or src_p[k] == -1
+            last[row] = k
+        assert src_p[k] in (-1, -2)
+    assert np.array_equal(handed, expect_handed)
+    assert (src_p == -2).mean() > 0.5                               # user runs do ride in registers
+    with pytest.raises(capi.QRecError):
+        capi.bpr_exact_schedule(u, i, i.copy(), U, I, width, registers=True)
+    e0, o0 = capi.bpr_exact_schedule(u[:0], i[:0], j[:0], U, I, width, registers=True)
     assert e0.shape == (0, 8) and o0.tolist() == [0]
 
 

@@ -119,3 +119,143 @@ def test_reduce_mean_of_a_list_stacks_it_and_variable_assign_is_an_op():
     run(upd)
     np.testing.assert_allclose(run(b), [2.0, 4.0])
     np.testing.assert_allclose(tf.Variable(a.initialized_value()).initial, [1.0, 2.0])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Independent anchors (round 3): expected values that are NOT derived in this repository.  Each case restates a test of
+# TensorFlow's own test-suite (r1.14 branch) -- its input vectors, and as the expectation the reference implementation that
+# TF's test itself compares against, copied verbatim -- or an example printed in TF's API documentation.  A misconception
+# shared by this stand-in and by oracle/tfmodels.py (both written here) cannot pass these.
+# ---------------------------------------------------------------------------------------------------------------------
+def adam_update_numpy(param, g_t, t, m, v, alpha=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8):
+    """tensorflow/python/training/adam_test.py (r1.14), lines 41-49, verbatim: the numpy reference TF's own AdamOptimizer
+    tests are held to"""
+    alpha_t = alpha * np.sqrt(1 - beta2**t) / (1 - beta1**t)
+
+    m_t = beta1 * m + (1 - beta1) * g_t
+    v_t = beta2 * v + (1 - beta2) * g_t * g_t
+
+    param_t = param - alpha_t * m_t / (np.sqrt(v_t) + epsilon)
+    return param_t, m_t, v_t
+
+
+def test_adam_is_tfs_own_adam_test_basic():
+    """adam_test.py::AdamOptimizerTest.doTestBasic (r1.14): var0 = [1.0, 2.0], grads0 = [0.1, 0.1], var1 = [3.0, 4.0],
+    grads1 = [0.01, 0.01], default hyper-parameters, three steps; after step t the variables equal adam_update_numpy's and
+    the beta powers are 0.9**(t+1), 0.999**(t+1) (TF asserts the powers BEFORE each step: 0.9**t, 0.999**t)."""
+    var0_np, grads0_np = np.array([1.0, 2.0], np.float32), np.array([0.1, 0.1], np.float32)
+    var1_np, grads1_np = np.array([3.0, 4.0], np.float32), np.array([0.01, 0.01], np.float32)
+    var0, var1 = tf.Variable(var0_np.copy(), name="var0"), tf.Variable(var1_np.copy(), name="var1")
+    # constant gradients, as the TF test feeds them: loss = sum(var0 * grads0) + sum(var1 * grads1)
+    loss = tf.reduce_sum(tf.multiply(var0, grads0_np)) + tf.reduce_sum(tf.multiply(var1, grads1_np))
+    opt = tf.train.AdamOptimizer()
+    update = opt.minimize(loss)
+    m0, v0, m1, v1 = 0.0, 0.0, 0.0, 0.0
+    with tf.Session() as s:
+        for t in range(1, 4):
+            assert opt.b1p == pytest.approx(0.9 ** t, rel=1e-6) and opt.b2p == pytest.approx(0.999 ** t, rel=1e-6)
+            s.run(update)
+            var0_np, m0, v0 = adam_update_numpy(var0_np, grads0_np, t, m0, v0)
+            var1_np, m1, v1 = adam_update_numpy(var1_np, grads1_np, t, m1, v1)
+            np.testing.assert_allclose(s.run(var0), var0_np, rtol=1e-6)          # assertAllCloseAccordingToType: float32 -> 1e-6
+            np.testing.assert_allclose(s.run(var1), var1_np, rtol=1e-6)
+
+
+def test_adam_sparse_is_tfs_own_adam_test_sparse_and_repeated_indices():
+    """adam_test.py::testSparse: the same vectors through IndexedSlices(grads, indices=[0, 1]) -- here: the gradient of an
+    embedding_lookup, which is what produces IndexedSlices in the reference's models (BPR.py:80).
+    ::testSparseRepeatedIndices: var = [[1.0], [2.0]]; the gradient [[0.1], [0.1]] at indices [1, 1] must move the variable
+    exactly like the aggregated gradient [[0.2]] at index [1], over three steps."""
+    var0_np, grads0_np = np.array([1.0, 2.0], np.float32), np.array([0.1, 0.1], np.float32)
+    var0 = tf.Variable(var0_np.reshape(2, 1).copy(), name="var0")
+    ids = tf.placeholder(tf.int32)
+    loss = tf.reduce_sum(tf.nn.embedding_lookup(var0, ids) * grads0_np.reshape(2, 1))
+    update = tf.train.AdamOptimizer().minimize(loss)
+    m0 = v0 = 0.0
+    with tf.Session() as s:
+        for t in range(1, 4):
+            s.run(update, feed_dict={ids: [0, 1]})
+            var0_np, m0, v0 = adam_update_numpy(var0_np, grads0_np, t, m0, v0)
+            np.testing.assert_allclose(s.run(var0).ravel(), var0_np, rtol=1e-6)
+    tf.reset(3)
+    rep = tf.Variable(np.array([[1.0], [2.0]], np.float32), name="repeated")
+    agg = tf.Variable(np.array([[1.0], [2.0]], np.float32), name="aggregated")
+    ids = tf.placeholder(tf.int32)
+    up_rep = tf.train.AdamOptimizer().minimize(tf.reduce_sum(tf.nn.embedding_lookup(rep, ids) * np.float32(0.1)))
+    up_agg = tf.train.AdamOptimizer().minimize(tf.reduce_sum(tf.nn.embedding_lookup(agg, [1]) * np.float32(0.2)))
+    with tf.Session() as s:
+        np.testing.assert_array_equal(s.run(rep), s.run(agg))
+        for _ in range(3):
+            s.run(up_rep, feed_dict={ids: [1, 1]}); s.run(up_agg)
+            np.testing.assert_allclose(s.run(rep), s.run(agg), rtol=1e-7)       # TF: assertAllClose
+        # TF 1.14's sparse Adam (_apply_sparse_shared) updates m, v and the variable over ALL rows (m_t = assign(m, m * beta1) ...
+        # var_update = assign_sub(var, lr * m_t / (sqrt(v_t) + epsilon))): a row that never received a gradient has m = v = 0 and
+        # stays where it is, in TF as in the dense functor the stand-in applies
+        assert s.run(rep)[0, 0] == 1.0 and s.run(agg)[0, 0] == 1.0
+
+
+def test_top_k_is_tfs_own_topk_op_test_including_the_tie_rule():
+    """tensorflow/python/kernel_tests/topk_op_test.py (r1.14): testTop2 / testTop3 / testTopAll vectors, and the documented
+    tie rule of nn_ops.top_k ("If two elements are equal, the lower-index element appears first") on its stable-sort vector."""
+    X = tf.placeholder(tf.float32)
+    def topk(x, k):
+        v, i = tf.math.top_k(X, k)
+        vv, iv = run(v, i, feed={X: x})
+        return np.asarray(vv).tolist(), np.asarray(iv).tolist()
+    inputs = [[0.1, 0.3, 0.2, 0.4], [0.1, 0.3, 0.4, 0.2]]
+    v, i = topk(inputs, 2)
+    assert i == [[3, 1], [2, 1]]; np.testing.assert_allclose(v, [[0.4, 0.3], [0.4, 0.3]], rtol=1e-6)           # testTop2
+    v, i = topk(inputs, 3)
+    assert i == [[3, 1, 2], [2, 1, 3]]; np.testing.assert_allclose(v, [[0.4, 0.3, 0.2], [0.4, 0.3, 0.2]], rtol=1e-6)     # testTop3
+    ties = [[0.1, 0.3, 0.2, 0.4], [0.1, 0.3, 0.3, 0.2]]
+    v, i = topk(ties, 4)
+    assert i == [[3, 1, 2, 0], [1, 2, 3, 0]]                                                                    # testTopAll: equal 0.3s -> index 1 before 2
+    v, i = topk([[5.0, 5.0, 5.0, 5.0, 5.0, 5.0, 5.0, 5.0]], 3)
+    assert i == [[0, 1, 2]]                                                                                     # all tied: the lowest indices, ascending
+
+
+def test_dropout_is_tfs_own_nn_test_dropout():
+    """tensorflow/python/ops/nn_test.py::DropoutTest.testDropout (r1.14): a 40 x 30 tensor of ones, keep_prob in
+    {0.1, 0.5, 0.8}: every output is either 0 or 1 / keep_prob, and the kept fraction is keep_prob within 15 % relative."""
+    x_dim, y_dim, num_iter = 40, 30, 10
+    for keep_prob in (0.1, 0.5, 0.8):
+        tf.reset(7)
+        t = tf.placeholder(tf.float32)
+        d = tf.nn.dropout(t, keep_prob)
+        final_count = 0
+        with tf.Session() as s:
+            for _ in range(num_iter):
+                value = s.run(d, feed_dict={t: np.ones((x_dim, y_dim), np.float32)})
+                final_count += np.count_nonzero(value)
+                sorted_value = np.unique(np.sort(value))
+                assert sorted_value[0] == 0
+                np.testing.assert_allclose(1 / keep_prob, sorted_value[1], rtol=1e-6)
+        expected_count = x_dim * y_dim * keep_prob * num_iter
+        assert abs(final_count - expected_count) / expected_count < 0.15
+
+
+def test_sparse_tensor_dense_matmul_sums_duplicate_entries_like_tfs_kernel():
+    """tensorflow/core/kernels/sparse_tensor_dense_matmul_op.cc (r1.14), the CPU functor: ``for i in range(nnz): for n:
+    out(m, n) += a_values(i) * b(k, n)`` with (m, k) = a_indices(i) -- entries with the same (m, k) ADD UP, in any order of
+    the index list (no canonical ordering is required by this op).  base/graphRecommender.py:36-38 feeds scipy's index list."""
+    A = tf.SparseTensor(indices=[[1, 2], [0, 1], [1, 2], [1, 0]], values=[4.0, 2.0, 0.5, 3.0], dense_shape=[2, 3])     # (1, 2) twice, unsorted
+    X = tf.placeholder(tf.float32)
+    xv = np.arange(6, dtype=np.float32).reshape(3, 2)
+    want = np.zeros((2, 2), np.float32)
+    for (m, k), a in zip([[1, 2], [0, 1], [1, 2], [1, 0]], [4.0, 2.0, 0.5, 3.0]):
+        want[m] += np.float32(a) * xv[k]
+    np.testing.assert_allclose(run(tf.sparse_tensor_dense_matmul(A, X), feed={X: xv}), want, rtol=1e-6)
+    # sparse_ops.sparse_tensor_dense_matmul docstring: "A is sparse, B is dense; computes A * B" with adjoint_a = False
+    np.testing.assert_allclose(want, np.array([[0, 2, 0], [3, 0, 4.5]], np.float32) @ xv, rtol=1e-6)
+
+
+def test_l2_normalize_is_tfs_own_nn_test_reference():
+    """nn_test.py::L2NormalizeTest._l2Normalize (r1.14): ``norm = np.apply_along_axis(np.linalg.norm, dim, x); return x /
+    np.expand_dims(norm, dim)`` on a random [20, 7, 3] tensor, every dim"""
+    rng = np.random.RandomState(0)
+    x_np = rng.random_sample((20, 7, 3)).astype(np.float32)
+    for dim in range(3):
+        norm = np.apply_along_axis(np.linalg.norm, dim, x_np)
+        want = x_np / np.expand_dims(norm, dim)
+        X = tf.placeholder(tf.float32)
+        np.testing.assert_allclose(run(tf.nn.l2_normalize(X, dim), feed={X: x_np}), want, rtol=1e-5)

@@ -14,9 +14,17 @@ u = np.repeat(np.arange(U, dtype=np.int32), np.diff(indptr)).astype(np.int32); n
 j = capi.mt_bpr_sample_epoch(capi.state_from_python(random.Random(1).getstate()), indptr, items, I)
 rng = np.random.default_rng(0); P0 = rng.random((U, 64)) / 3; Q0 = rng.random((I, 64)) / 3
 out = {"n": int(n)}
-for dtype, tag in ((np.float64, "f64"), (np.float32, "f32")):
-    t = DeviceTables(P0, Q0, dtype); s = BprSgd(t, u, items); s.set_negatives(j)
-    for width in (1, 2, 4, 6, 8, 12, 16):
+# QREC_EXACT_KERNEL: reg = four triplets per wavefront (round 3, the default), w64 = one per wavefront (round 2)
+combos = [(k, dt, w) for k in os.environ.get("PROBE_KERNELS", "reg,w64").split(",") for dt in ((np.float64, "f64"), (np.float32, "f32"))
+          for w in ((4, 8, 12, 16) if k == "reg" else (8,))]
+tabs = {}
+for kernel, (dtype, tag0), width in combos:
+    os.environ["QREC_EXACT_KERNEL"] = kernel
+    tag = f"{kernel}_{tag0}"
+    if tag0 not in tabs:
+        tabs[tag0] = DeviceTables(P0, Q0, dtype)
+    t = tabs[tag0]; s = BprSgd(t, u, items); s.set_negatives(j)
+    for width in (width,):
         t.upload(P0, Q0); capi.device_sync()
         t0 = time.perf_counter(); ent, off = capi.bpr_exact_schedule(s.h_u, s.h_i, s.h_j, U, I, width) if width > 1 else (None, None); ts = time.perf_counter() - t0
         t0 = time.perf_counter(); loss = s.epoch_ordered(0.01, 0.001, 0.001, width=width); dt = time.perf_counter() - t0
