@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const float *__restrict_
         for (int t = 0; t < NT; t++)
 #pragma unroll
             for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
-#pragma unroll
+        // ld = 128 (NT = 4) has two 64-column chunks: kept a LOOP there -- unrolled, both chunks' 2 x 32 A values are live next to the
+        // 64 accumulator registers and the kernel spilled 126 VGPRs (508 B of scratch per lane)
+#pragma unroll 1
         for (int c = 0; c < LD; c += 64) {
             const int k0 = c + 32 * h;
             const bool kv = k0 < LD;                 // ld = 32: the upper k-slot has no columns and feeds zeros
