@@ -228,7 +228,10 @@ def main():
                     help="visiting order of the epoch's triplets in the Hogwild kernel (DESIGN.md s4)")
     ap.add_argument("--dist-mode", choices=("replicated", "sharded"), default=os.environ.get("QREC_DIST_MODE", "replicated"))
     ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("QREC_SCALING", "weak"))
-    ap.add_argument("--shard-batch", type=int, default=1 << 18, help="sharded mode: triplets per exchange batch and rank")
+    ap.add_argument("--shard-batch", type=int, default=1 << 19, help="sharded mode: triplets per exchange batch and rank")
+    ap.add_argument("--no-shard-pipeline", action="store_true",
+                    help="sharded mode: fetch batch k + 1 only after batch k has been applied (default: under batch k's SGD kernel, on a "
+                         "second stream and communicator; one more batch of staleness)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_own_ranks(args.gpus)           # does not return
@@ -299,7 +302,11 @@ def main():
 
     dstep = None
     if use_dist and sharded:
-        dstep = qd.ShardedStep(comm, qd.ShardedItemExchange(comm, I, tables.ld, tables.Q), n_batches)
+        pipe = None
+        if not args.no_shard_pipeline and os.environ.get("QREC_BENCH_NO_COMM") != "1":
+            # a second communicator for the fetch stream: two collectives of ONE communicator must not be in flight on two streams
+            pipe = (comm if one_device else qd.make_comm(control), capi.Stream())
+        dstep = qd.ShardedStep(comm, qd.ShardedItemExchange(comm, I, tables.ld, tables.Q, pipeline=pipe), n_batches)
     elif use_dist:
         dstep = qd.ReplicatedStep(comm, qd.ReplicatedTableSync(comm, tables.Q))
     # device copies of the initial state: every step restarts training from it (see step())
@@ -452,7 +459,8 @@ def main():
                        "lr": LR0, "reg": REG_U, "final_loss": final_loss, "final_lr": final_lr,
                        "epoch_close": "device (no host sync inside the timed region)" if not sharded else "device; one row-count read-back per epoch for the exchange",
                        "dist_mode": args.dist_mode if use_dist else None,
-                       **({"xgmi_bytes_per_epoch_all_ranks": moved, "batches_per_epoch": dstep.n_batches} if sharded else {})},
+                       **({"xgmi_bytes_per_epoch_all_ranks": moved, "batches_per_epoch": dstep.n_batches,
+                           "fetch_pipelined": dstep.exchange.pipeline is not None} if sharded else {})},
             **({"multi_gpu": multi} if multi is not None else {}),
             "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -475,6 +483,8 @@ def main():
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         control.barrier()
+        if sharded and dstep.exchange.pipeline is not None and dstep.exchange.pipeline[0] is not comm:
+            dstep.exchange.pipeline[0].destroy()
         if comm is not None:
             comm.destroy()
         control.shutdown()

@@ -584,6 +584,12 @@ int qrec_allgather(void *comm, const void *d_send, void *d_recv, int64_t count, 
 int qrec_reduce_scatter(void *comm, const void *d_send, void *d_recv, int64_t count, int dtype, void *stream);
 int qrec_alltoall_rows(void *comm, const void *d_send, const int64_t *h_send_rows, void *d_recv,
                        const int64_t *h_recv_rows, int64_t row_bytes, void *stream);
+/* One fused launch of arbitrary point-to-point segments: send k = h_send_bytes[k] bytes at d_send + h_send_off[k] to rank
+ * h_send_peer[k]; receive k likewise.  Between two ranks sends and receives are matched in list order (both sides list a pair's
+ * segments in the same order).  The row-sharded BPR layout ships the request ids of ALL batches of an epoch with it.       */
+int qrec_sendrecv_segments(void *comm, const void *d_send, const int32_t *h_send_peer, const int64_t *h_send_off,
+                           const int64_t *h_send_bytes, int32_t n_send, void *d_recv, const int32_t *h_recv_peer,
+                           const int64_t *h_recv_off, const int64_t *h_recv_bytes, int32_t n_recv, void *stream);
 
 /* Replicated item table (every rank trains its own users against a full copy of Q): after a step
  *     delta = Q - Q_start;  all-reduce(delta);  Q_start += delta;  Q = Q_start
@@ -608,6 +614,9 @@ int qrec_table_apply(float *d_table, float *d_start, const float *d_delta, int64
  *                ascending inside a group (capacity min(2n, n_items));  d_counts[world] = rows per owner;
  *   d_ci, d_cj : the triplets' item ids rewritten as positions in d_req_rows, i.e. rows of the batch's row cache.
  * Everything stays on the device; the caller reads d_counts back when it needs the sizes of the exchange.
+ * qrec_shard_plan_epoch: the same plan for ALL n_batches batches of an epoch in one set of launches -- batch b = triplets
+ *   [d_bounds[b], d_bounds[b + 1]) (device int64[n_batches + 1]), its request list at d_req_rows + d_req_off[b] (device
+ *   int64[n_batches]), its counts at d_counts[b * world]; scratch: qrec_shard_plan_epoch_scratch_bytes.
  * qrec_gather_rows: d_out[k] = d_table[d_rows[k]] (an owner answering a request).
  * qrec_scatter_add_row_deltas: d_table[d_rows[k]] += d_fresh[k] - d_sent[k] with f32 atomics (an owner taking back the
  *   rows it lent: several ranks may return the same row, every rank's updates are kept).                             */
@@ -616,6 +625,10 @@ int qrec_shard_plan_scratch_bytes(int64_t n_items, int32_t world, int64_t *bytes
 int qrec_shard_plan_batch(const int32_t *d_i, const int32_t *d_j, int64_t n, int64_t n_items, int32_t world,
                           void *d_scratch, int32_t *d_req_rows, int32_t *d_counts, int32_t *d_ci, int32_t *d_cj,
                           void *stream);
+int qrec_shard_plan_epoch_scratch_bytes(int64_t n_items, int32_t world, int32_t n_batches, int64_t *bytes);
+int qrec_shard_plan_epoch(const int32_t *d_i, const int32_t *d_j, const int64_t *d_bounds, int32_t n_batches, int64_t n,
+                          int64_t n_items, int32_t world, void *d_scratch, int32_t *d_req_rows, const int64_t *d_req_off,
+                          int32_t *d_counts, int32_t *d_ci, int32_t *d_cj, void *stream);
 int qrec_gather_rows(const float *d_table, int32_t ld, const int32_t *d_rows, int64_t n, float *d_out, void *stream);
 int qrec_scatter_add_row_deltas(float *d_table, int32_t ld, const int32_t *d_rows, int64_t n, const float *d_fresh,
                                 const float *d_sent, void *stream);

@@ -125,6 +125,7 @@ _SIGNATURES = {
     "qrec_allgather": [_vp, _vp, _vp, _i64, C.c_int, _vp],
     "qrec_reduce_scatter": [_vp, _vp, _vp, _i64, C.c_int, _vp],
     "qrec_alltoall_rows": [_vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "qrec_sendrecv_segments": [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp],
     "qrec_dist_epoch_pre": [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "qrec_dist_epoch_post": [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
     "qrec_table_delta": [_vp, _vp, _vp, _i64, _vp],
@@ -132,6 +133,8 @@ _SIGNATURES = {
     "qrec_shard_rows": [_i64, _i32, _i32, _vp],
     "qrec_shard_plan_scratch_bytes": [_i64, _i32, _vp],
     "qrec_shard_plan_batch": [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "qrec_shard_plan_epoch_scratch_bytes": [_i64, _i32, _i32, _vp],
+    "qrec_shard_plan_epoch": [_vp, _vp, _vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "qrec_gather_rows": [_vp, _i32, _vp, _i64, _vp, _vp],
     "qrec_scatter_add_row_deltas": [_vp, _i32, _vp, _i64, _vp, _vp, _vp],
 }
@@ -947,8 +950,9 @@ class Comm:
 
     def __init__(self, world: int, rank: int, uid: bytes, identity_shortcut: bool = True):
         """``identity_shortcut``: with a world of one an in-place all-reduce is the identity and is not handed to RCCL
-        (measured: RCCL's one-rank path launches no kernel but costs ~90 us of stream time per grouped call);
-        False sends it through anyway (the binding's own test)."""
+        (measured: RCCL's one-rank path launches no kernel but costs ~90 us of stream time per grouped call), and the
+        row exchanges are device-to-device copies of the rank's own segments; False sends everything through RCCL anyway
+        (the binding's own test)."""
         ensure_init()
         if len(uid) != COMM_UID_BYTES:
             raise ValueError("comm uid must be 128 bytes")
@@ -975,7 +979,27 @@ class Comm:
         s = np.ascontiguousarray(send_rows, dtype=np.int64); r = np.ascontiguousarray(recv_rows, dtype=np.int64)
         if s.size != self.world or r.size != self.world:
             raise ValueError("alltoall_rows: one row count per rank expected")
+        if self._skip_identity:
+            if int(s[0]) != int(r[0]):
+                raise ValueError("alltoall_rows: a rank sends itself as many rows as it receives")
+            if int(s[0]):
+                memcpy_d2d(recv, send, int(s[0]) * row_bytes, stream)
+            return
         _check(load().qrec_alltoall_rows(self.handle, _dp(send), _hp(s), _dp(recv), _hp(r), row_bytes, _sh(stream)))
+
+    def sendrecv_segments(self, send, sends, recv, recvs, stream=None):
+        """``sends`` / ``recvs``: lists of (peer, byte offset, bytes); one fused launch (qrec_sendrecv_segments)"""
+        if self._skip_identity:
+            if [b for _, _, b in sends] != [b for _, _, b in recvs]:
+                raise ValueError("sendrecv_segments: a rank's segments to itself must match one by one")
+            for (_, so, nb), (_, ro, _) in zip(sends, recvs):
+                if nb:
+                    memcpy_d2d(device_ptr(recv) + ro, device_ptr(send) + so, nb, stream)
+            return
+        sp = np.array([p for p, _, _ in sends], np.int32); so = np.array([o for _, o, _ in sends], np.int64); sb = np.array([b for _, _, b in sends], np.int64)
+        rp = np.array([p for p, _, _ in recvs], np.int32); ro = np.array([o for _, o, _ in recvs], np.int64); rb = np.array([b for _, _, b in recvs], np.int64)
+        _check(load().qrec_sendrecv_segments(self.handle, _dp(send), _hp(sp), _hp(so), _hp(sb), len(sends), _dp(recv), _hp(rp), _hp(ro), _hp(rb),
+                                             len(recvs), _sh(stream)))
 
     def query(self) -> dict:
         """what RCCL reports: ranks in the communicator, this rank, the bound HIP device"""
@@ -1029,6 +1053,18 @@ def shard_plan_scratch_bytes(n_items: int, world: int) -> int:
 def shard_plan_batch(d_i, d_j, n: int, n_items: int, world: int, d_scratch, d_req_rows, d_counts, d_ci, d_cj, stream=None):
     _check(load().qrec_shard_plan_batch(_dp(d_i), _dp(d_j), n, n_items, world, _dp(d_scratch), _dp(d_req_rows), _dp(d_counts),
                                         _dp(d_ci), _dp(d_cj), _sh(stream)))
+
+
+def shard_plan_epoch_scratch_bytes(n_items: int, world: int, n_batches: int) -> int:
+    out = C.c_int64(0)
+    _check(load().qrec_shard_plan_epoch_scratch_bytes(n_items, world, n_batches, C.byref(out)))
+    return out.value
+
+
+def shard_plan_epoch(d_i, d_j, d_bounds, n_batches: int, n: int, n_items: int, world: int, d_scratch, d_req_rows, d_req_off, d_counts,
+                     d_ci, d_cj, stream=None):
+    _check(load().qrec_shard_plan_epoch(_dp(d_i), _dp(d_j), _dp(d_bounds), n_batches, n, n_items, world, _dp(d_scratch), _dp(d_req_rows),
+                                        _dp(d_req_off), _dp(d_counts), _dp(d_ci), _dp(d_cj), _sh(stream)))
 
 
 def gather_rows(d_table, ld: int, d_rows, n: int, d_out, stream=None):

@@ -282,4 +282,46 @@ int qrec_alltoall_rows(void *comm, const void *d_send, const int64_t *h_send_row
     return QREC_OK;
 }
 
+int qrec_sendrecv_segments(void *comm, const void *d_send, const int32_t *h_send_peer, const int64_t *h_send_off,
+                           const int64_t *h_send_bytes, int32_t n_send, void *d_recv, const int32_t *h_recv_peer,
+                           const int64_t *h_recv_off, const int64_t *h_recv_bytes, int32_t n_recv, void *stream) {
+    QREC_REQUIRE(comm && n_send >= 0 && n_recv >= 0, "qrec_sendrecv_segments: bad arguments");
+    QREC_REQUIRE((n_send == 0 || (h_send_peer && h_send_off && h_send_bytes)) && (n_recv == 0 || (h_recv_peer && h_recv_off && h_recv_bytes)),
+                 "qrec_sendrecv_segments: null segment list");
+    Comm *c = static_cast<Comm *>(comm);
+    int64_t s_total = 0, r_total = 0;
+    for (int k = 0; k < n_send; ++k) {
+        QREC_REQUIRE(h_send_peer[k] >= 0 && h_send_peer[k] < c->world && h_send_off[k] >= 0 && h_send_bytes[k] >= 0,
+                     "qrec_sendrecv_segments: bad send segment %d", k);
+        s_total += h_send_bytes[k];
+    }
+    for (int k = 0; k < n_recv; ++k) {
+        QREC_REQUIRE(h_recv_peer[k] >= 0 && h_recv_peer[k] < c->world && h_recv_off[k] >= 0 && h_recv_bytes[k] >= 0,
+                     "qrec_sendrecv_segments: bad recv segment %d", k);
+        r_total += h_recv_bytes[k];
+    }
+    QREC_REQUIRE((d_send || !s_total) && (d_recv || !r_total), "qrec_sendrecv_segments: null buffer");
+    if (s_total == 0 && r_total == 0) return QREC_OK;
+    // ONE group = one fused launch.  Between two ranks sends and receives are matched in the order they are listed, so both
+    // sides list their segments for a pair in the same order (dist.py: batch by batch).
+    ncclResult_t first_bad = ncclSuccess;
+    QREC_NCCL_CHECK(g_rccl.GroupStart());
+    for (int k = 0; k < n_send; ++k)
+        if (h_send_bytes[k]) {
+            ncclResult_t e = g_rccl.Send(static_cast<const char *>(d_send) + h_send_off[k], (size_t)h_send_bytes[k], ncclInt8, h_send_peer[k],
+                                         c->nccl, as_stream(stream));
+            if (e != ncclSuccess && first_bad == ncclSuccess) first_bad = e;
+        }
+    for (int k = 0; k < n_recv; ++k)
+        if (h_recv_bytes[k]) {
+            ncclResult_t e = g_rccl.Recv(static_cast<char *>(d_recv) + h_recv_off[k], (size_t)h_recv_bytes[k], ncclInt8, h_recv_peer[k],
+                                         c->nccl, as_stream(stream));
+            if (e != ncclSuccess && first_bad == ncclSuccess) first_bad = e;
+        }
+    ncclResult_t e = g_rccl.GroupEnd();
+    QREC_NCCL_CHECK(first_bad);
+    QREC_NCCL_CHECK(e);
+    return QREC_OK;
+}
+
 }  // extern "C"

@@ -128,6 +128,89 @@ __global__ void plan_remap_kernel(const int32_t *__restrict__ i, const int32_t *
     }
 }
 
+// ---- the same plan for ALL batches of an epoch in one set of launches (blockIdx.y / blockIdx.x = batch) ---------------------
+// batch b covers the triplets [bounds[b], bounds[b + 1]); its flags / tile counters live at b * stride in the scratch, its request
+// list starts at req_off[b], its counts at counts[b * world].  Five launches per epoch instead of five per batch.
+__global__ void plan_mark_epoch_kernel(const int32_t *__restrict__ i, const int32_t *__restrict__ j, const int64_t *__restrict__ bounds,
+                                       int32_t world, int64_t rows_pad, int32_t *__restrict__ flags, int64_t flag_stride) {
+    const int b = blockIdx.y;
+    const int64_t t0 = bounds[b], t1 = bounds[b + 1];
+    int32_t *f = flags + b * flag_stride;
+    for (int64_t t = t0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < t1; t += (int64_t)gridDim.x * blockDim.x) {
+        f[item_pos(i[t], world, rows_pad)] = 1;
+        f[item_pos(j[t], world, rows_pad)] = 1;
+    }
+}
+
+__global__ void plan_count_epoch_kernel(const int32_t *__restrict__ flags, int64_t flag_stride, int32_t *__restrict__ tile_cnt,
+                                        int64_t tile_stride) {
+    __shared__ int lds[4];
+    const int b = blockIdx.y;
+    const int4 f = reinterpret_cast<const int4 *>(flags + b * flag_stride)[blockIdx.x * (int64_t)kPlanBlock + threadIdx.x];
+    int total;
+    block_exclusive_scan((f.x != 0) + (f.y != 0) + (f.z != 0) + (f.w != 0), lds, &total);
+    if (threadIdx.x == 0) tile_cnt[b * tile_stride + blockIdx.x] = total;
+}
+
+__global__ void plan_scan_epoch_kernel(int32_t *__restrict__ tile_cnt_all, int64_t tile_stride, int32_t ntiles, int32_t tiles_per_owner,
+                                       int32_t world, int32_t *__restrict__ counts_all) {
+    __shared__ int lds[4];
+    __shared__ int carry;
+    int32_t *tile_cnt = tile_cnt_all + blockIdx.x * tile_stride;
+    int32_t *counts = counts_all + blockIdx.x * world;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < ntiles; base += kPlanBlock) {
+        const int k = base + threadIdx.x;
+        const int v = k < ntiles ? tile_cnt[k] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, lds, &total);
+        const int c = carry;
+        if (k < ntiles) tile_cnt[k] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_cnt[ntiles] = carry;
+    __syncthreads();
+    for (int o = threadIdx.x; o < world; o += blockDim.x)
+        counts[o] = tile_cnt[(o + 1) * tiles_per_owner] - tile_cnt[o * tiles_per_owner];
+}
+
+__global__ void plan_fill_epoch_kernel(int32_t *__restrict__ flags_all, int64_t flag_stride, const int32_t *__restrict__ tile_all,
+                                       int64_t tile_stride, int64_t rows_pad, int32_t *__restrict__ req_rows,
+                                       const int64_t *__restrict__ req_off) {
+    __shared__ int lds[4];
+    const int b = blockIdx.y;
+    int32_t *flags = flags_all + b * flag_stride;
+    int32_t *req = req_rows + req_off[b];
+    const int64_t p4 = blockIdx.x * (int64_t)kPlanBlock + threadIdx.x;
+    int4 f = reinterpret_cast<int4 *>(flags)[p4];
+    int total;
+    int slot = tile_all[b * tile_stride + blockIdx.x] + block_exclusive_scan((f.x != 0) + (f.y != 0) + (f.z != 0) + (f.w != 0), lds, &total);
+    if (f.x | f.y | f.z | f.w) {
+        const int64_t pos = p4 * 4;
+        const int32_t row0 = (int32_t)(pos % rows_pad);
+        if (f.x) { req[slot] = row0; f.x = ++slot; }
+        if (f.y) { req[slot] = row0 + 1; f.y = ++slot; }
+        if (f.z) { req[slot] = row0 + 2; f.z = ++slot; }
+        if (f.w) { req[slot] = row0 + 3; f.w = ++slot; }
+        reinterpret_cast<int4 *>(flags)[p4] = f;
+    }
+}
+
+__global__ void plan_remap_epoch_kernel(const int32_t *__restrict__ i, const int32_t *__restrict__ j, const int64_t *__restrict__ bounds,
+                                        int32_t world, int64_t rows_pad, const int32_t *__restrict__ flags_all, int64_t flag_stride,
+                                        int32_t *__restrict__ ci, int32_t *__restrict__ cj) {
+    const int b = blockIdx.y;
+    const int64_t t0 = bounds[b], t1 = bounds[b + 1];
+    const int32_t *flags = flags_all + b * flag_stride;
+    for (int64_t t = t0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < t1; t += (int64_t)gridDim.x * blockDim.x) {
+        ci[t] = flags[item_pos(i[t], world, rows_pad)] - 1;
+        cj[t] = flags[item_pos(j[t], world, rows_pad)] - 1;
+    }
+}
+
 // ---- rows in and out of a shard ----------------------------------------------------------------------------------
 template <int LD4>   // float4s per row
 __global__ void gather_rows_kernel(const float4 *__restrict__ table, const int32_t *__restrict__ rows, int64_t n,
@@ -216,6 +299,44 @@ int qrec_shard_plan_batch(const int32_t *d_i, const int32_t *d_j, int64_t n, int
         hipLaunchKernelGGL(plan_fill_kernel, dim3(ntiles), dim3(kPlanBlock), 0, st, flags, tile, rows_pad, d_req_rows);
         hipLaunchKernelGGL(plan_remap_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, d_i, d_j, n, world, rows_pad, flags,
                            d_ci, d_cj);
+    }
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+int qrec_shard_plan_epoch_scratch_bytes(int64_t n_items, int32_t world, int32_t n_batches, int64_t *bytes) {
+    QREC_REQUIRE(bytes && world >= 1 && n_items >= 1 && n_batches >= 1 && n_batches <= 65535, "qrec_shard_plan_epoch_scratch_bytes: bad arguments");
+    int64_t one = 0;
+    int rc = qrec_shard_plan_scratch_bytes(n_items, world, &one);
+    if (rc != QREC_OK) return rc;
+    *bytes = one * n_batches;
+    return QREC_OK;
+}
+
+int qrec_shard_plan_epoch(const int32_t *d_i, const int32_t *d_j, const int64_t *d_bounds, int32_t n_batches, int64_t n,
+                          int64_t n_items, int32_t world, void *d_scratch, int32_t *d_req_rows, const int64_t *d_req_off,
+                          int32_t *d_counts, int32_t *d_ci, int32_t *d_cj, void *stream) {
+    QREC_REQUIRE(world >= 1 && n_items >= 1 && n >= 0 && n_batches >= 1 && n_batches <= 65535, "qrec_shard_plan_epoch: bad sizes");
+    QREC_REQUIRE(d_scratch && d_counts && d_bounds && d_req_off, "qrec_shard_plan_epoch: null argument");
+    QREC_REQUIRE(n == 0 || (d_i && d_j && d_req_rows && d_ci && d_cj), "qrec_shard_plan_epoch: null array");
+    hipStream_t st = as_stream(stream);
+    const int64_t rows_pad = rows_pad_of(n_items, world), npos = rows_pad * world;
+    const int32_t ntiles = (int32_t)(npos / kTile), tpo = (int32_t)(rows_pad / kTile);
+    int64_t one = 0;
+    qrec_shard_plan_scratch_bytes(n_items, world, &one);
+    // scratch of batch b: [npos flags][ntiles + 1 tile counters, padded], `one` bytes each, back to back
+    const int64_t stride_words = one / 4;
+    int32_t *flags = static_cast<int32_t *>(d_scratch), *tile = flags + npos;
+    QREC_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)one * n_batches, st));
+    const int gx = grid_for((n + n_batches - 1) / n_batches, 256);
+    if (n) hipLaunchKernelGGL(plan_mark_epoch_kernel, dim3(gx, n_batches), dim3(256), 0, st, d_i, d_j, d_bounds, world, rows_pad, flags, stride_words);
+    hipLaunchKernelGGL(plan_count_epoch_kernel, dim3(ntiles, n_batches), dim3(kPlanBlock), 0, st, flags, stride_words, tile, stride_words);
+    hipLaunchKernelGGL(plan_scan_epoch_kernel, dim3(n_batches), dim3(kPlanBlock), 0, st, tile, stride_words, ntiles, tpo, world, d_counts);
+    if (n) {
+        hipLaunchKernelGGL(plan_fill_epoch_kernel, dim3(ntiles, n_batches), dim3(kPlanBlock), 0, st, flags, stride_words, tile, stride_words,
+                           rows_pad, d_req_rows, d_req_off);
+        hipLaunchKernelGGL(plan_remap_epoch_kernel, dim3(gx, n_batches), dim3(256), 0, st, d_i, d_j, d_bounds, world, rows_pad, flags,
+                           stride_words, d_ci, d_cj);
     }
     QREC_LAUNCH_CHECK();
     return QREC_OK;

@@ -150,6 +150,23 @@ class GlooStagedComm:
         dist.all_to_all_single(dst, src, r, s, group=self.cp.group)
         self._put(recv, dst.numpy(), stream)
 
+    def sendrecv_segments(self, send, sends, recv, recvs, stream=None):
+        """(peer, byte offset, bytes) lists, matched per pair in list order: one all_to_all_single of the per-peer concatenations"""
+        torch, dist = self.cp._torch, self.cp._dist
+        base_s, base_r = self.k.device_ptr(send) if send is not None else 0, self.k.device_ptr(recv) if recv is not None else 0
+        out, s_sizes = [], []
+        for p in range(self.world):
+            seg = [self._get(base_s + o, nb, np.uint8, stream) for q, o, nb in sends if q == p and nb]
+            out += seg; s_sizes.append(int(sum(x.size for x in seg)))
+        r_sizes = [int(sum(nb for q, _, nb in recvs if q == p)) for p in range(self.world)]
+        src = torch.from_numpy(np.concatenate(out) if out else np.zeros(0, np.uint8)); dst = torch.empty(sum(r_sizes), dtype=torch.uint8)
+        dist.all_to_all_single(dst, src, r_sizes, s_sizes, group=self.cp.group)
+        got, at = dst.numpy(), 0
+        for p in range(self.world):
+            for q, o, nb in recvs:
+                if q == p and nb:
+                    self._put(base_r + o, got[at:at + nb], stream); at += nb
+
     def destroy(self):
         pass
 
@@ -191,23 +208,39 @@ class ReplicatedTableSync:
 class ShardedItemExchange:
     """Cross-shard row lookups of one rank for an epoch of BPR triplets (module docstring, ``sharded``).
 
-    ``plan_epoch`` runs on the device for every batch (distinct rows per owner, triplet ids rewritten to cache slots)
-    and costs ONE host synchronisation per epoch: the row counts, which size the exchanges.  ``run_epoch`` then only
-    enqueues -- per batch: ids to the owners, rows back, ``sgd_batch`` on the cache, cache back, owners add the deltas.
-    Every rank must call both with the same ``n_batches`` (ranks hold different triplet counts; a rank that has run out
-    of triplets still serves its rows).  ``kern`` is the C ABI binding (tests substitute a host emulation to check the
-    protocol on CPU over gloo)."""
+    ``plan_epoch`` runs on the device for ALL batches in one set of launches (distinct rows per owner, triplet ids rewritten
+    to cache slots), costs ONE host synchronisation per epoch -- the row counts, which size the exchanges -- and ships the
+    request ids of every batch to their owners in one fused launch (``sendrecv_segments``).  ``run_epoch`` then only enqueues,
+    per batch: owners gather the requested rows, rows travel to the requesters' cache, ``sgd_batch`` trains on the cache,
+    the cache travels back, owners add ``returned - sent`` into their rows.
+    Every rank must call both with the same ``n_batches`` (ranks hold different triplet counts; a rank that has run out of
+    triplets still serves its rows).  ``kern`` is the C ABI binding (tests substitute a host emulation to check the protocol
+    on CPU over gloo).
 
-    def __init__(self, comm, n_items: int, ld: int, q_local, kern=_capi):
+    ``pipeline`` = (second communicator, fetch stream), round 3 ("overlap step k+1 fetch with step k compute"):
+    the fetch of batch k + 1 (gather + row exchange into the OTHER cache buffer) is enqueued on the fetch stream and runs
+    under batch k's SGD kernel; ordered by events so that it is deterministic -- the gather of batch k + 1 happens after the
+    owners applied batch k - 1 and before they apply batch k: a batch sees the item table as of TWO batches back (one more
+    batch of staleness than the unpipelined protocol, the same kind the replicated layout has per epoch).  Nothing is lost:
+    owners still add ``returned - sent`` of every batch.  The second communicator exists because two collectives of one
+    communicator must not be in flight on two streams."""
+
+    def __init__(self, comm, n_items: int, ld: int, q_local, kern=_capi, pipeline=None):
         self.comm, self.k = comm, kern
         self.world, self.rank = comm.world, comm.rank
         self.n_items, self.ld, self.q_local = int(n_items), int(ld), q_local
         self.rows_local = kern.shard_rows(self.n_items, self.world, self.rank)
-        self.d_scratch = kern.DeviceBuffer(kern.shard_plan_scratch_bytes(self.n_items, self.world), np.uint8)
         self._cap = {}
+        self._scratch_batches = 0
         self.n = self.n_batches = 0
-        self.bounds = self.send = self.recv = self.req_off = None
+        self.bounds = self.send = self.recv = self.req_off = self.in_off = None
         self.bytes_moved = 0
+        self.pipeline = pipeline
+        if pipeline is not None:
+            self.comm_f, self.stream_f = pipeline
+            ev = kern.Event
+            self.ev_fetched, self.ev_gathered, self.ev_free = [ev(), ev()], [ev(), ev()], [ev(), ev()]
+            self.ev_epoch_start = ev()
 
     def _buf(self, name: str, elems: int, dtype):
         """grow-only device buffer"""
@@ -220,47 +253,89 @@ class ShardedItemExchange:
         """``bounds``: the batches' triplet ranges (n_batches + 1 offsets); default = equal consecutive ranges"""
         k, G = self.k, self.world
         self.n, self.n_batches = int(n), int(n_batches)
-        per = -(-self.n // self.n_batches) if self.n else 0
-        self.bounds = [int(x) for x in bounds] if bounds is not None else [min(b * per, self.n) for b in range(self.n_batches + 1)]
-        if len(self.bounds) != self.n_batches + 1 or self.bounds[0] != 0 or self.bounds[-1] != self.n:
+        nb = self.n_batches
+        per = -(-self.n // nb) if self.n else 0
+        self.bounds = [int(x) for x in bounds] if bounds is not None else [min(b * per, self.n) for b in range(nb + 1)]
+        if len(self.bounds) != nb + 1 or self.bounds[0] != 0 or self.bounds[-1] != self.n:
             raise ValueError("plan_epoch: bounds must run from 0 to n in n_batches steps")
-        caps = [min(2 * (self.bounds[b + 1] - self.bounds[b]), self.n_items) for b in range(self.n_batches)]
+        caps = [min(2 * (self.bounds[b + 1] - self.bounds[b]), self.n_items) for b in range(nb)]
         self.req_off = np.concatenate([[0], np.cumsum(caps)]).astype(np.int64)
         d_req = self._buf("req", int(self.req_off[-1]), np.int32)
         d_ci, d_cj = self._buf("ci", self.n, np.int32), self._buf("cj", self.n, np.int32)
-        d_counts = self._buf("counts", self.n_batches * G, np.int32)
-        d_all = self._buf("all_counts", self.n_batches * G * G, np.int32)
-        pi, pj = k.device_ptr(d_i), k.device_ptr(d_j)
-        for b in range(self.n_batches):
-            t0, nb = self.bounds[b], self.bounds[b + 1] - self.bounds[b]
-            k.shard_plan_batch(pi + 4 * t0, pj + 4 * t0, nb, self.n_items, G, self.d_scratch,
-                               k.device_ptr(d_req) + 4 * int(self.req_off[b]), k.device_ptr(d_counts) + 4 * b * G,
-                               k.device_ptr(d_ci) + 4 * t0, k.device_ptr(d_cj) + 4 * t0, stream)
-        self.comm.allgather(d_counts, d_all, self.n_batches * G, k.I32, stream)
-        counts = d_all.head(G * self.n_batches * G, stream).reshape(G, self.n_batches, G)      # the epoch's one host sync
+        d_counts = self._buf("counts", nb * G, np.int32)
+        d_all = self._buf("all_counts", nb * G * G, np.int32)
+        if self._scratch_batches < nb:
+            self._cap["scratch"] = k.DeviceBuffer(k.shard_plan_epoch_scratch_bytes(self.n_items, G, nb), np.uint8)
+            self._scratch_batches = nb
+        d_bounds = self._buf("bounds", nb + 1, np.int64); d_roff = self._buf("req_off", nb + 1, np.int64)
+        k.memcpy_h2d(d_bounds, np.array(self.bounds, np.int64), 8 * (nb + 1), stream)
+        k.memcpy_h2d(d_roff, self.req_off, 8 * (nb + 1), stream)
+        k.shard_plan_epoch(d_i, d_j, d_bounds, nb, self.n, self.n_items, G, self._cap["scratch"], d_req, d_roff, d_counts, d_ci, d_cj, stream)
+        self.comm.allgather(d_counts, d_all, nb * G, k.I32, stream)
+        counts = d_all.head(G * nb * G, stream).reshape(G, nb, G)      # the epoch's one host sync
         self.send = counts[self.rank].astype(np.int64)                   # [batch][owner]: rows I ask of each owner
         self.recv = counts[:, :, self.rank].T.astype(np.int64).copy()    # [batch][peer]:  rows each peer asks of me
-        r_in, r_out = int(self.recv.sum(1).max(initial=0)), int(self.send.sum(1).max(initial=0))
-        self._buf("req_in", r_in, np.int32)
-        self._buf("rows_out", r_in * self.ld, np.float32); self._buf("rows_ret", r_in * self.ld, np.float32)
-        self._buf("cache", r_out * self.ld, np.float32)
+        in_rows = self.recv.sum(1)
+        self.in_off = np.concatenate([[0], np.cumsum(in_rows)]).astype(np.int64)
+        r_in, r_out = int(in_rows.max(initial=0)), int(self.send.sum(1).max(initial=0))
+        d_req_in = self._buf("req_in", int(self.in_off[-1]), np.int32)
+        copies = 2 if self.pipeline is not None else 1
+        for c in range(copies):
+            self._buf(f"rows_out{c}", r_in * self.ld, np.float32); self._buf(f"cache{c}", r_out * self.ld, np.float32)
+        self._buf("rows_ret", r_in * self.ld, np.float32)
+        # the request ids of ALL batches in one fused launch: for every (batch, peer) one send and one receive, both sides in batch order
+        sends, recvs = [], []
+        for b in range(nb):
+            so, ro = int(self.req_off[b]), int(self.in_off[b])
+            for p in range(G):
+                sends.append((p, 4 * so, 4 * int(self.send[b, p]))); so += int(self.send[b, p])
+                recvs.append((p, 4 * ro, 4 * int(self.recv[b, p]))); ro += int(self.recv[b, p])
+        self.comm.sendrecv_segments(d_req, sends, d_req_in, recvs, stream)
+
+    def _fetch(self, b, comm, stream):
+        """owners answer batch b: gather the requested rows, ship them to the requesters' cache (buffer b % copies)"""
+        k, c, ld = self.k, self._cap, self.ld
+        cp = b & 1 if self.pipeline is not None else 0
+        n_in = int(self.recv[b].sum())
+        k.gather_rows(self.q_local, ld, k.device_ptr(c["req_in"]) + 4 * int(self.in_off[b]), n_in, c[f"rows_out{cp}"], stream)
+        if self.pipeline is not None:
+            self.ev_gathered[cp].record(stream)
+        comm.alltoall_rows(c[f"rows_out{cp}"], self.recv[b], c[f"cache{cp}"], self.send[b], ld * 4, stream)
+        return cp
 
     def run_epoch(self, sgd_batch, stream=None):
         """``sgd_batch(t0, n, d_cache, cache_rows, ci_ptr, cj_ptr, stream)`` trains triplets [t0, t0+n) whose item ids
         are rows of ``d_cache`` (addresses of the rewritten id arrays are passed)."""
         k, c, ld = self.k, self._cap, self.ld
-        req, ci, cj = k.device_ptr(c["req"]), k.device_ptr(c["ci"]), k.device_ptr(c["cj"])
+        ci, cj = k.device_ptr(c["ci"]), k.device_ptr(c["cj"])
+        piped = self.pipeline is not None
+        if piped:
+            F = self.stream_f
+            # everything enqueued on `stream` so far -- the plan, the id exchange, the previous epoch's last batch -- comes first
+            self.ev_epoch_start.record(stream); k.stream_wait_event(F, self.ev_epoch_start)
+            self._fetch(0, self.comm_f, F); self.ev_fetched[0].record(F)
         for b in range(self.n_batches):
             t0, nb = self.bounds[b], self.bounds[b + 1] - self.bounds[b]
             S, R = self.send[b], self.recv[b]
             n_out, n_in = int(S.sum()), int(R.sum())
-            self.comm.alltoall_rows(req + 4 * int(self.req_off[b]), S, c["req_in"], R, 4, stream)      # ids -> owners
-            k.gather_rows(self.q_local, ld, c["req_in"], n_in, c["rows_out"], stream)
-            self.comm.alltoall_rows(c["rows_out"], R, c["cache"], S, ld * 4, stream)                    # rows -> requesters
+            if piped:
+                cp = b & 1
+                if b + 1 < self.n_batches:      # the next batch's fetch goes out now, into the other buffer (free once batch b - 1 was applied)
+                    if b >= 1:
+                        k.stream_wait_event(F, self.ev_free[(b + 1) & 1])
+                    self._fetch(b + 1, self.comm_f, F); self.ev_fetched[(b + 1) & 1].record(F)
+                k.stream_wait_event(stream, self.ev_fetched[cp])
+            else:
+                cp = self._fetch(b, self.comm, stream)
+            cache, rows_out = c[f"cache{cp}"], c[f"rows_out{cp}"]
             if nb:
-                sgd_batch(t0, nb, c["cache"], n_out, ci + 4 * t0, cj + 4 * t0, stream)
-            self.comm.alltoall_rows(c["cache"], S, c["rows_ret"], R, ld * 4, stream)                    # rows -> owners
-            k.scatter_add_row_deltas(self.q_local, ld, c["req_in"], n_in, c["rows_ret"], c["rows_out"], stream)
+                sgd_batch(t0, nb, cache, n_out, ci + 4 * t0, cj + 4 * t0, stream)
+            self.comm.alltoall_rows(cache, S, c["rows_ret"], R, ld * 4, stream)                          # rows -> owners
+            if piped and b + 1 < self.n_batches:
+                k.stream_wait_event(stream, self.ev_gathered[(b + 1) & 1])     # batch b + 1 was gathered BEFORE batch b is applied
+            k.scatter_add_row_deltas(self.q_local, ld, k.device_ptr(c["req_in"]) + 4 * int(self.in_off[b]), n_in, c["rows_ret"], rows_out, stream)
+            if piped:
+                self.ev_free[cp].record(stream)
             off = n_out - int(S[self.rank])
             self.bytes_moved += off * (4 + 2 * ld * 4)        # what left this rank for other ranks
 
@@ -356,6 +431,44 @@ class RowPartition:
     def scatter_sum(self, d_full, d_block, stream=None):
         """d_full [world*rows_pad][ld] partial products of every rank -> d_block = this rank's rows of their sum"""
         self.comm.reduce_scatter(d_full, d_block, self.rows_pad * self.ld, self.k.F32, stream)
+
+    # ---- referenced rows only (SURVEY s8e, graph row: "or all-to-all of only referenced remote rows"), round 3 ---------------
+    def reference(self, indptr: np.ndarray, indices: np.ndarray):
+        """Prepare the exchange that ships, per product, only the operand rows this rank's block of the adjacency refers to.
+        ``(indptr, indices)``: the WHOLE adjacency (every rank holds it when the trainer is built, so every rank can work out
+        every other rank's needs without talking).  Returns the block's column indices renumbered into the compact operand
+        [own rows_pad rows | rows needed from rank 0 | from rank 1 | ...] (ascending global row inside a peer's segment), in the
+        block's stored order -- the SpMM then adds a row's terms in the same order as with global columns: same bits."""
+        k, G, pad = self.k, self.world, self.rows_pad
+        blocks = [(min(p * pad, self.n_rows), min(min(p * pad, self.n_rows) + pad, self.n_rows)) for p in range(G)]
+        need = []
+        for lo, hi in blocks:
+            c = np.unique(indices[int(indptr[lo]):int(indptr[hi])])
+            need.append(c[(c < lo) | (c >= hi)])
+        mine = need[self.rank]
+        owner = np.minimum(mine // pad, G - 1) if mine.size else np.zeros(0, np.int64)
+        self.ref_recv_rows = np.bincount(owner, minlength=G).astype(np.int64)             # rows I receive from each peer
+        sends = [need[p][(need[p] >= self.lo) & (need[p] < self.hi)] - self.lo for p in range(G)]      # my local rows each peer needs
+        self.ref_send_rows = np.array([x.size for x in sends], np.int64)
+        self.ref_send_ids = k.DeviceBuffer.from_numpy(np.concatenate(sends).astype(np.int32) if sum(x.size for x in sends) else np.zeros(1, np.int32))
+        self.ref_send_buf = k.DeviceBuffer((max(int(self.ref_send_rows.sum()), 1), self.ld), np.float32)
+        self.ref_rows = pad + int(mine.size)                                                 # height of the compact operand
+        col_map = np.full(self.n_rows, -1, np.int64)
+        col_map[self.lo:self.hi] = np.arange(self.hi - self.lo)
+        col_map[mine] = pad + np.arange(mine.size)            # `mine` is ascending: grouped by owner, ascending inside a group
+        blk = indices[int(indptr[self.lo]):int(indptr[self.hi])]
+        self.ref_bytes_per_product = int(self.ref_send_rows.sum() - self.ref_send_rows[self.rank]) * self.ld * 4
+        return col_map[blk].astype(np.int32)
+
+    def gather_referenced(self, d_block, d_compact, stream=None):
+        """d_block [rows_pad][ld] -> d_compact [ref_rows][ld]: own rows in front, behind them the remote rows the block refers to"""
+        k, ld = self.k, self.ld
+        k.memcpy_d2d(d_compact, d_block, self.rows_pad * ld * 4, stream)
+        n_send = int(self.ref_send_rows.sum())
+        if n_send:
+            k.gather_rows(d_block, ld, self.ref_send_ids, n_send, self.ref_send_buf, stream)
+        self.comm.alltoall_rows(self.ref_send_buf, self.ref_send_rows, k.device_ptr(d_compact) + self.rows_pad * ld * 4, self.ref_recv_rows,
+                                ld * 4, stream)
 
 
 _STATE: dict = {}

@@ -297,6 +297,31 @@ class LightGCNTrainer:
         return E[:self.nu, :self.d].copy(), E[self.nu:, :self.d].copy()
 
 
+def _setup_row_exchange(tr, adj, blk_ptr, sel):
+    """How a row-partitioned trainer gets the operand rows of a propagation product (env QREC_GRAPH_EXCHANGE):
+    ``allgather`` (default): every rank receives every block, N x ld floats per product and rank;
+    ``referenced`` (round 3; SURVEY s8e "all-to-all of only referenced remote rows"): a rank receives the distinct remote rows its
+    block of the adjacency refers to -- worked out once per graph (dist.RowPartition.reference), one row gather + one row
+    all-to-all per product into a compact operand whose column numbering the block's CSR is rewritten to.  Same products,
+    same bits; fewer bytes where the graph has locality (DESIGN.md s7 has both synthetic graphs)."""
+    tr.exchange = os.environ.get("QREC_GRAPH_EXCHANGE", "allgather")
+    if tr.exchange not in ("allgather", "referenced"):
+        raise ValueError("QREC_GRAPH_EXCHANGE must be allgather or referenced")
+    if tr.exchange == "referenced":
+        cols = tr.rp.reference(adj[0], adj[1])
+        tr.plan_ref = SpmmPlan(blk_ptr, cols, adj[2][sel], tr.ld)
+        tr.X_ref = DeviceBuffer.zeros((tr.rp.ref_rows, tr.ld), np.float32)
+
+
+def _row_operand(tr, x, stream):
+    """(plan, operand) for  y = A_hat[lo:hi] X  with this rank's block ``x`` of X: the exchange of the operand rows goes out here"""
+    if tr.exchange == "referenced":
+        tr.rp.gather_referenced(x, tr.X_ref, stream)
+        return tr.plan_ref, tr.X_ref
+    tr.rp.gather_operand(x, tr.X_full, stream)
+    return tr.plan, tr.X_full
+
+
 class RowPartitionedLightGCNTrainer:
     """LightGCN with the propagation ROW-PARTITIONED over the ranks: rank r owns the contiguous
     rows [lo, hi) of the joint adjacency, of E = [U; V], of the Adam slots and of every propagated layer.  One step at
@@ -331,6 +356,7 @@ class RowPartitionedLightGCNTrainer:
         blk_ptr = np.concatenate([blk_ptr, np.full(pad - (hi - lo), blk_ptr[-1] if hi > lo else 0, np.int64)])   # pad rows: empty
         sel = slice(int(indptr[lo]), int(indptr[hi]))
         self.plan = SpmmPlan(blk_ptr, indices[sel], values[sel], self.ld)     # rows = this rank's block, columns global
+        _setup_row_exchange(self, adj, blk_ptr, sel)
         E0 = np.zeros((self.n, self.ld), np.float32)
         E0[:self.nu, :self.d] = U0; E0[self.nu:, :self.d] = V0
         blk = np.zeros((pad, self.ld), np.float32); blk[:hi - lo] = E0[lo:hi]
@@ -348,8 +374,8 @@ class RowPartitionedLightGCNTrainer:
         """L layers from the block ``x``: y = A_hat[lo:hi] gather(x) (+ addend), accumulated into ``accum`` if given"""
         for k in range(self.L):
             y = self.A if k % 2 == 0 else self.B
-            self.rp.gather_operand(x, self.X_full, stream)
-            capi.spmm_csr(self.plan, self.X_full, y, self.ld, d_addend=addend, addend_scale=1.0 if addend is not None else 0.0,
+            plan, X = _row_operand(self, x, stream)
+            capi.spmm_csr(plan, X, y, self.ld, d_addend=addend, addend_scale=1.0 if addend is not None else 0.0,
                           d_accum=accum, stream=stream)
             x = y
         return x
@@ -648,6 +674,7 @@ class RowPartitionedSimGCLTrainer:
         blk_ptr = np.concatenate([blk_ptr, np.full(pad - (hi - lo), blk_ptr[-1] if hi > lo else 0, np.int64)])   # pad rows: empty
         sel = slice(int(indptr[lo]), int(indptr[hi]))
         self.plan = SpmmPlan(blk_ptr, indices[sel], values[sel], self.ld)     # rows = this rank's block, columns global
+        _setup_row_exchange(self, adj, blk_ptr, sel)
         E0 = np.zeros((self.n, self.ld), np.float32)
         E0[:self.nu, :self.d] = U0; E0[self.nu:, :self.d] = V0
         blk = np.zeros((pad, self.ld), np.float32); blk[:hi - lo] = E0[lo:hi]
@@ -668,8 +695,8 @@ class RowPartitionedSimGCLTrainer:
 
     def _product(self, x, y, stream, accum=None, addend=None):
         """y = the rank's rows of A_hat gather(x) (+ addend); accum += y"""
-        self.rp.gather_operand(x, self.X_full, stream)
-        capi.spmm_csr(self.plan, self.X_full, y, self.ld, d_addend=addend, addend_scale=1.0 if addend is not None else 0.0,
+        plan, X = _row_operand(self, x, stream)
+        capi.spmm_csr(plan, X, y, self.ld, d_addend=addend, addend_scale=1.0 if addend is not None else 0.0,
                       d_accum=accum, stream=stream)
 
     def _encode_three(self, noises, stream):
@@ -935,6 +962,7 @@ class RowPartitionedNGCFTrainer:
         blk_ptr = np.concatenate([blk_ptr, np.full(pad - (hi - lo), blk_ptr[-1] if hi > lo else 0, np.int64)])   # pad rows: empty
         sel = slice(int(indptr[lo]), int(indptr[hi]))
         self.plan = SpmmPlan(blk_ptr, indices[sel], values[sel], self.ld)     # rows = this rank's block, columns global
+        _setup_row_exchange(self, adj, blk_ptr, sel)
         E0 = np.zeros((self.n, self.ld), np.float32)
         E0[:self.nu, :self.d] = U0; E0[self.nu:, :self.d] = V0
         blk = np.zeros((pad, self.ld), np.float32); blk[:hi - lo] = E0[lo:hi]
@@ -964,10 +992,13 @@ class RowPartitionedNGCFTrainer:
         rp, d, ld, pad = self.rp, self.d, self.ld, self.rp.rows_pad
         rows_full = rp.world * pad
         for k in range(self.N_LAYERS):
-            rp.gather_operand(self.E[k], self.X_full, stream)
-            if k == 0:      # the ego block of the concat: the gathered E_0
+            if k == 0:      # the ego block of the concat is the WHOLE E_0 (the loss looks up any row): this product's operand is gathered whole
+                rp.gather_operand(self.E[k], self.X_full, stream)
                 capi.copy_cols(self.All_full, self.wide_ld, self.X_full, ld, 0, rows_full, d, False, stream)
-            capi.spmm_csr(self.plan, self.X_full, self.side[k], ld, stream=stream)
+                plan, X = self.plan, self.X_full
+            else:
+                plan, X = _row_operand(self, self.E[k], stream)
+            capi.spmm_csr(plan, X, self.side[k], ld, stream=stream)
             capi.ngcf_dense_fwd(self.E[k], self.side[k], self.W[k][0], self.W[k][1], pad, ld, self.gate[k], stream)
             capi.ngcf_activate(self.gate[k], pad, d, ld, self.KEEP if training else 1.0, None if masks is None else masks[k],
                                self.seed, self.step_no * 8 + k, self.E[k + 1], self.z[k], ld, 0, self.inv[k], stream,
@@ -990,8 +1021,8 @@ class RowPartitionedNGCFTrainer:
             capi.ngcf_layer_bwd(dnext, self.dAll_full.ptr + mine, self.All_full.ptr + mine, self.wide_ld, (k + 1) * d, self.inv[k],
                                 self.gate[k], self.E[k], self.side[k], self.W[k][0], self.W[k][1], pad, d, ld, self.dpre, self.dside, dE,
                                 self.partial, self.gW[k][0], self.gW[k][1], stream)
-            rp.gather_operand(self.dside, self.X_full, stream)           # dE += (A_hat dside)[lo:hi]
-            capi.spmm_csr(self.plan, self.X_full, dE, ld, d_addend=dE, addend_scale=1.0, stream=stream)
+            plan, X = _row_operand(self, self.dside, stream)             # dE += (A_hat dside)[lo:hi]
+            capi.spmm_csr(plan, X, dE, ld, d_addend=dE, addend_scale=1.0, stream=stream)
             dnext = dE
         capi.copy_cols(dnext, ld, self.dAll_full.ptr + mine, self.wide_ld, 0, pad, d, True, stream)   # + ego block of the concat
         self.comm.allreduce(self.gW_all, 4 * ld * ld, capi.F32, stream)  # each rank summed its own rows: the dense layers' all-reduce

@@ -88,6 +88,29 @@ def shard_plan_batch(d_i, d_j, n, n_items, world, d_scratch, d_req_rows, d_count
         _view(d_cj, n, np.int32)[:] = slot[j]
 
 
+def shard_plan_epoch_scratch_bytes(n_items, world, n_batches):
+    return 16
+
+
+def shard_plan_epoch(d_i, d_j, d_bounds, n_batches, n, n_items, world, d_scratch, d_req_rows, d_req_off, d_counts, d_ci, d_cj, stream=None):
+    """include/qrec_hip.h qrec_shard_plan_epoch: qrec_shard_plan_batch for every batch [bounds[b], bounds[b + 1])"""
+    bounds, roff = _view(d_bounds, n_batches + 1, np.int64), _view(d_req_off, n_batches, np.int64)
+    for b in range(n_batches):
+        t0, nb = int(bounds[b]), int(bounds[b + 1] - bounds[b])
+        shard_plan_batch(device_ptr(d_i) + 4 * t0, device_ptr(d_j) + 4 * t0, nb, n_items, world, d_scratch, device_ptr(d_req_rows) + 4 * int(roff[b]),
+                         device_ptr(d_counts) + 4 * b * world, device_ptr(d_ci) + 4 * t0, device_ptr(d_cj) + 4 * t0)
+
+
+class Event:
+    """host emulation: every "enqueue" has already happened when it returns, so events order nothing"""
+    def record(self, stream=None):
+        pass
+
+
+def stream_wait_event(stream, ev):
+    pass
+
+
 def gather_rows(table, ld, d_rows, n, d_out, stream=None):
     rows = _view(d_rows, n, np.int32)
     if n:

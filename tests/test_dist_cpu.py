@@ -142,13 +142,13 @@ def _rank_users(n_users, world, rank, same_users):
     return (0, n_users) if same_users else user_block(n_users, world, rank)
 
 
-def _sharded_worker(rank, world, port, out, same_users=False):
+def _sharded_worker(rank, world, port, out, same_users=False, pipeline=False):
     control, comm = _join(rank, world, port)
     d, indptr, ind, P0, Q0 = _problem()
     I = d["n_items"]
     lo, hi = _rank_users(d["n_users"], world, rank, same_users)
     q_local = HK.DeviceBuffer.from_numpy(_pad(qd.shard_item_rows(Q0, world, rank)))
-    ex = qd.ShardedItemExchange(comm, I, LD, q_local, kern=HK)
+    ex = qd.ShardedItemExchange(comm, I, LD, q_local, kern=HK, pipeline=(comm, None) if pipeline else None)
     assert ex.rows_local == q_local.a.shape[0]
     P = P0[lo:hi].copy()
     for step in range(2):
@@ -166,11 +166,13 @@ def _sharded_worker(rank, world, port, out, same_users=False):
     control.shutdown()
 
 
-@pytest.mark.parametrize("same_users", [False, True])
-def test_two_rank_sharded_item_table_equals_definition(same_users):
+@pytest.mark.parametrize("same_users,pipeline", [(False, False), (True, False), (False, True), (True, True)])
+def test_two_rank_sharded_item_table_equals_definition(same_users, pipeline):
+    """``pipeline``: the fetch of batch b + 1 is issued under batch b's SGD, ordered after the owners applied batch b - 1 and before
+    they apply batch b -- a batch sees the table as of TWO batches back inside an epoch (everything at an epoch's start)."""
     world = 2
     mgr = mp.Manager(); out = mgr.dict()
-    mp.spawn(_sharded_worker, args=(world, _free_port(), out, same_users), nprocs=world, join=True)
+    mp.spawn(_sharded_worker, args=(world, _free_port(), out, same_users, pipeline), nprocs=world, join=True)
     d, indptr, ind, P0, Q0 = _problem()
     I = d["n_items"]
     Q = _pad(Q0); Pr_all = [P0.copy() for _ in range(world)]       # weak layout: every rank its own copy of the user rows
@@ -183,6 +185,7 @@ def test_two_rank_sharded_item_table_equals_definition(same_users):
                 u, li, j = u[:5], li[:5], j[:5]
             per = -(-u.size // N_BATCHES)
             work.append((r, lo, hi, u, li, j, per))
+        waiting = []            # pipelined: batches fetched but not yet applied when the next fetch goes out (at most one)
         for b in range(N_BATCHES):
             deltas = np.zeros_like(Q)
             for r, lo, hi, u, li, j, per in work:
@@ -191,11 +194,18 @@ def test_two_rank_sharded_item_table_equals_definition(same_users):
                     continue
                 items = np.unique(np.concatenate([li[t0:t1], j[t0:t1]]))
                 slot = np.full(I, -1); slot[items] = np.arange(items.size)
-                cache = Q[items].copy()                                   # the batch-start rows, wherever they live
+                cache = Q[items].copy()                                   # the rows as the owners hold them when they answer
                 Pr = Pr_all[r][lo:hi]
                 _sgd_on(Pr, cache, u[t0:t1], slot[li[t0:t1]], slot[j[t0:t1]])
                 deltas[items] += cache - Q[items]
-            Q = Q + deltas
+            if pipeline:        # batch b is applied only after batch b + 1 has been fetched
+                waiting.append(deltas)
+                if len(waiting) == 2:
+                    Q = Q + waiting.pop(0)
+            else:
+                Q = Q + deltas
+        for dlt in waiting:
+            Q = Q + dlt
     for r in range(world):
         lo, hi, Pr, Qr, moved = out[r]
         np.testing.assert_allclose(Qr, Q[r::world], rtol=0, atol=3e-7)    # every owner holds the definition's rows
@@ -269,7 +279,17 @@ def _rowpart_worker(rank, world, port, out):
     part[:n] = A[rp.lo:rp.hi].T @ dY[rp.lo:rp.hi]
     d_part, d_dx = HK.DeviceBuffer.from_numpy(part), HK.DeviceBuffer((pad, ld), np.float32)
     rp.scatter_sum(d_part, d_dx)
-    out[rank] = (rp.lo, rp.hi, Y_rows, d_dx.a[:rp.hi - rp.lo].copy())
+    # referenced rows only (round 3): the block's columns renumbered into [own rows | remote rows it refers to], the operand assembled
+    # by one row gather + one row all-to-all -- the same product from fewer bytes
+    A_csr = A.tocsr(); A_csr.sort_indices()
+    cols = rp.reference(A_csr.indptr.astype(np.int64), A_csr.indices.astype(np.int32))
+    d_cmp = HK.DeviceBuffer((rp.ref_rows, ld), np.float32)
+    rp.gather_referenced(d_blk, d_cmp)
+    ptr = A_csr.indptr[rp.lo:rp.hi + 1] - A_csr.indptr[rp.lo]
+    vals = A_csr.data[A_csr.indptr[rp.lo]:A_csr.indptr[rp.hi]]
+    import scipy.sparse as sp
+    Y_ref = sp.csr_matrix((vals, cols, ptr), shape=(rp.hi - rp.lo, rp.ref_rows)) @ d_cmp.a
+    out[rank] = (rp.lo, rp.hi, Y_rows, d_dx.a[:rp.hi - rp.lo].copy(), Y_ref, rp.ref_rows, rp.ref_bytes_per_product)
     control.shutdown()
 
 
@@ -284,6 +304,8 @@ def test_row_partitioned_propagation_equals_the_whole_product():
     Y, dX = A @ X, A.T @ dY
     assert out[0][0] == 0 and out[0][1] == out[1][0] and out[1][1] == n
     for r in range(world):
-        lo, hi, Yr, dXr = out[r]
+        lo, hi, Yr, dXr, Yref, ref_rows, ref_bytes = out[r]
         np.testing.assert_allclose(Yr, Y[lo:hi], rtol=0, atol=1e-6)
         np.testing.assert_allclose(dXr, dX[lo:hi], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(Yref, Y[lo:hi], rtol=0, atol=1e-6)        # referenced-rows exchange: the same rows of the product
+        assert ref_rows <= n + (hi - lo) and 0 < ref_bytes <= (n - (hi - lo)) * ld * 4     # never more than the other ranks' rows

@@ -121,6 +121,13 @@ def test_rccl_binding_with_a_world_of_one():
     comm.alltoall_rows(d_r, [100], d_o, [100], 256, st); st.sync()
     assert np.array_equal(d_o.numpy(), rows)
     comm.alltoall_rows(d_r, [0], d_o, [0], 256)
+    # arbitrary segments in one fused launch (the request ids of all batches of an epoch): two segments to itself, out of order
+    d_o.fill_bytes(0)
+    comm.sendrecv_segments(d_r, [(0, 256 * 10, 256 * 5), (0, 0, 256 * 3)], d_o, [(0, 0, 256 * 5), (0, 256 * 50, 256 * 3)], st); st.sync()
+    got = d_o.numpy()
+    assert np.array_equal(got[:5], rows[10:15]) and np.array_equal(got[50:53], rows[:3]) and not got[5:50].any()
+    with pytest.raises(capi.QRecError):
+        comm.sendrecv_segments(d_r, [(3, 0, 16)], d_o, [], st)                 # peer outside the world
     with pytest.raises(ValueError):
         comm.alltoall_rows(d_r, [1, 2], d_o, [1, 2], 256)
     with pytest.raises(capi.QRecError):
@@ -166,6 +173,17 @@ class ThreadComm:
             off += nb
         self._done()
 
+    def sendrecv_segments(self, send, sends, recv, recvs, stream=None):
+        everyone = self._swap((capi.device_ptr(send) if send is not None else 0, [tuple(int(x) for x in s) for s in sends]))
+        for p, (ptr, their) in enumerate(everyone):
+            to_me = [(o, nb) for q, o, nb in their if q == self.rank]            # what rank p sends me, in its list order
+            mine = [(o, nb) for q, o, nb in recvs if q == p]                     # what I receive from rank p, in my list order
+            assert [nb for _, nb in to_me] == [nb for _, nb in mine]
+            for (so, nb), (ro, _) in zip(to_me, mine):
+                if nb:
+                    capi.memcpy_d2d(capi.device_ptr(recv) + ro, ptr + so, nb)
+        self._done()
+
     def allgather(self, send, recv, count, dtype=capi.F32, stream=None):
         size = {capi.F32: 4, capi.F64: 8, capi.I32: 4}[dtype] * count
         for p, ptr in enumerate(self._swap(capi.device_ptr(send))):
@@ -198,11 +216,13 @@ def _rank_triplets(indptr, ind, lo, hi, n_items, seed, schedule):
 
 
 @pytest.mark.parametrize("world,dim", [(2, 64), (3, 50), (1, 8)])
-def test_row_partitioned_ngcf_step_equals_the_single_gpu_step(world, dim):
+@pytest.mark.parametrize("exchange", ["allgather", "referenced"])
+def test_row_partitioned_ngcf_step_equals_the_single_gpu_step(world, dim, exchange, monkeypatch):
     """RowPartitionedNGCFTrainer with G logical ranks: every rank holds its rows of E_0, the Adam slots, the adjacency and
     the per-layer tables; weights replicated, their gradients all-reduced.  Same batch, same injected dropout decisions,
     same step as NGCFTrainer on one GPU: losses, the rank's rows of E_0, the four weights and the inference embeddings
     agree to fp32 summation order (atomics of the batch gradient, the slab order of the weight gradients)."""
+    monkeypatch.setenv("QREC_GRAPH_EXCHANGE", exchange)      # referenced: only the remote rows a rank's block refers to travel (round 3)
     from qrec_amd.graph import NGCFTrainer, RowPartitionedNGCFTrainer, joint_norm_adjacency
     from qrec_amd.engine import padded_ld
     d = make_dataset("small")
@@ -268,10 +288,12 @@ def test_row_partitioned_ngcf_step_equals_the_single_gpu_step(world, dim):
 
 
 @pytest.mark.parametrize("world,layers", [(2, 2), (3, 1), (2, 3)])
-def test_row_partitioned_simgcl_step_equals_the_single_gpu_step(world, layers):
+@pytest.mark.parametrize("exchange", ["allgather", "referenced"])
+def test_row_partitioned_simgcl_step_equals_the_single_gpu_step(world, layers, exchange, monkeypatch):
     """RowPartitionedSimGCLTrainer with G logical ranks against SimGCLTrainer on one GPU: same batch, same injected noise
     (each rank is handed its rows of it), same unique-row lists.  BPR and InfoNCE losses, the rank's rows of E after three
     steps and the clean encoder's embeddings agree to fp32 summation order."""
+    monkeypatch.setenv("QREC_GRAPH_EXCHANGE", exchange)      # referenced: only the remote rows a rank's block refers to travel (round 3)
     from qrec_amd.graph import RowPartitionedSimGCLTrainer, SimGCLTrainer, joint_norm_adjacency, unique_first_appearance
     d = make_dataset("small")
     nu, ni, dim, B = d["n_users"], d["n_items"], 64, 512
@@ -333,18 +355,21 @@ def test_row_partitioned_simgcl_step_equals_the_single_gpu_step(world, layers):
     assert covered == N and not np.allclose(E_one[:nu], U0)
 
 
+@pytest.mark.parametrize("pipeline", [False, True])
 @pytest.mark.parametrize("world,n_batches,dim,same_users", [(2, 3, 16, False), (3, 2, 64, False), (1, 2, 16, False), (2, 4, 64, True)])
-def test_sharded_item_table_with_logical_ranks_equals_the_definition(world, n_batches, dim, same_users):
+def test_sharded_item_table_with_logical_ranks_equals_the_definition(world, n_batches, dim, same_users, pipeline):
     """ShardedItemExchange + the real kernels, G logical ranks on one device.  The SGD kernel runs with ONE group, where
     it is the sequential recurrence, so the whole protocol is deterministic and comparable to the oracle.  ``same_users``:
     the weak-scaling layout -- every rank its own population with the SAME interaction structure, so all ranks ask the
-    owners for the same positive rows in the same batches and every returned row arrives once per rank."""
+    owners for the same positive rows in the same batches and every returned row arrives once per rank.
+    ``pipeline`` (round 3): batch b + 1 is fetched on a second stream / communicator under batch b's SGD, after the owners applied
+    batch b - 1 and before they apply batch b: the definition with the table as of two batches back inside an epoch."""
     from qrec_amd.engine import padded_ld
     d, indptr, ind, P0, Q0 = _tiny_problem(dim)
     U, I = d["n_users"], d["n_items"]
     ld = padded_ld(dim, np.float32)
     lr, ru, ri = 0.05, 0.01, 0.02
-    group = _Group(world)
+    group, group_f = _Group(world), _Group(world)
     result, errors = [None] * world, []
 
     def pad(a):
@@ -358,7 +383,7 @@ def test_sharded_item_table_with_logical_ranks_equals_the_definition(world, n_ba
             lo, hi = (0, U) if same_users else user_block(U, world, rank)
             d_P = DB.from_numpy(pad((P0[lo:hi] * (1 + 0.1 * rank * same_users)).astype(np.float32)))
             d_Q = DB.from_numpy(pad(qd.shard_item_rows(Q0, world, rank)))
-            ex = qd.ShardedItemExchange(comm, I, ld, d_Q)
+            ex = qd.ShardedItemExchange(comm, I, ld, d_Q, pipeline=(ThreadComm(group_f, rank), capi.Stream()) if pipeline else None)
             d_loss = DB.zeros(1, np.float64)
             for step in range(2):
                 u, li, j = _rank_triplets(indptr, ind, lo, hi, I, 100 * step + rank, "user")
@@ -387,6 +412,7 @@ def test_sharded_item_table_with_logical_ranks_equals_the_definition(world, n_ba
             lo, hi = (0, U) if same_users else user_block(U, world, r)
             u, li, j = _rank_triplets(indptr, ind, lo, hi, I, 100 * step + r, "user")
             work.append((r, lo, hi, u, li, j, -(-u.size // n_batches)))
+        waiting = []
         for b in range(n_batches):
             deltas = np.zeros_like(Q)
             for r, lo, hi, u, li, j, per in work:
@@ -399,7 +425,14 @@ def test_sharded_item_table_with_logical_ranks_equals_the_definition(world, n_ba
                 loss += O.bpr_sgd(Pr, cache, u[t0:t1], slot[li[t0:t1]], slot[j[t0:t1]], lr, ru, ri)
                 Ps[r][lo:hi] = Pr
                 deltas[items] += cache - Q[items]
-            Q += deltas
+            if pipeline:        # batch b is applied only after batch b + 1 has been fetched
+                waiting.append(deltas)
+                if len(waiting) == 2:
+                    Q += waiting.pop(0)
+            else:
+                Q += deltas
+        for dlt in waiting:
+            Q += dlt
     got_loss = 0.0
     for r in range(world):
         lo, hi, Pr, Qr, l, moved = result[r]
@@ -502,11 +535,13 @@ def test_bench_multi_gpu_path_on_real_rccl_world_one(mode):
 
 # ---- graph models: 1-D row partition of the propagation --------------------------------------------
 @pytest.mark.parametrize("world,layers,dim", [(3, 2, 16), (2, 3, 64), (8, 2, 50)])
-def test_row_partitioned_lightgcn_step_equals_the_single_gpu_step(world, layers, dim):
+@pytest.mark.parametrize("exchange", ["allgather", "referenced"])
+def test_row_partitioned_lightgcn_step_equals_the_single_gpu_step(world, layers, dim, exchange, monkeypatch):
     """RowPartitionedLightGCNTrainer with G logical ranks (threads + in-process collective): every rank holds its rows of
     the adjacency, of E and of the Adam slots; layers are all-gathered.  Same batch, same step as LightGCNTrainer on
     one GPU: the propagated layer sum is bit-identical row for row (same SpMM kernel, same segment order), the tables
     after two steps agree to the summation order of the batch gradient's float atomics."""
+    monkeypatch.setenv("QREC_GRAPH_EXCHANGE", exchange)      # referenced: only the remote rows a rank's block refers to travel (round 3)
     from qrec_amd.graph import LightGCNTrainer, RowPartitionedLightGCNTrainer, joint_norm_adjacency
     d = make_dataset("small")
     nu, ni = d["n_users"], d["n_items"]

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Bytes a rank receives per propagation product under the two operand exchanges of the row-partitioned graph trainers
+(qrec_amd/graph.py::_setup_row_exchange): all-gather of every block vs only the remote rows the rank's block of the adjacency
+refers to (dist.RowPartition.reference).  Host arithmetic on the two synthetic Yelp2018-shape graphs, world 8, d = 64 -- no
+GPU needed; prints one JSON object (committed as profiles/r03_graph_exchange_bytes.json)."""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import hostkern as HK
+from qrec_amd import dist as qd
+from qrec_amd.graph import joint_norm_adjacency, spectral_row_key
+from qrec_amd.synth import make_dataset
+
+
+class FakeComm:
+    def __init__(self, world, rank): self.world, self.rank = world, rank
+
+
+def bytes_for(adj, n, ld, world):
+    per_rank = []
+    for r in range(world):
+        rp = qd.RowPartition(FakeComm(world, r), n, ld, kern=HK)
+        rp.reference(adj[0], adj[1])
+        per_rank.append(dict(rows_referenced=int(rp.ref_recv_rows.sum()), bytes_received=int(rp.ref_recv_rows.sum() - rp.ref_recv_rows[r]) * ld * 4))
+    return per_rank
+
+
+out = {"world": 8, "ld": 64, "graphs": {}}
+for shape in ("yelp2018", "yelp2018-clustered"):
+    d = make_dataset(shape); nu, ni = d["n_users"], d["n_items"]; n = nu + ni
+    adj = joint_norm_adjacency(nu, ni, d["train_u"], d["train_i"])
+    allgather = (8 - 1) * (-(-n // 8)) * 64 * 4
+    res = {"allgather_bytes_received_per_product": allgather, "as_numbered": bytes_for(adj, n, 64, 8)}
+    # the same graph with users and items renumbered along the spectral key (communities become id ranges); the partition is
+    # still [users ; items] cut into 8 contiguous blocks, so a block of user rows still needs item rows from the item ranks
+    key = spectral_row_key(adj[0], adj[1], adj[2], nu)
+    pu, pi = np.argsort(key[:nu], kind="stable"), np.argsort(key[nu:], kind="stable")
+    inv_u, inv_i = np.empty(nu, np.int64), np.empty(ni, np.int64); inv_u[pu] = np.arange(nu); inv_i[pi] = np.arange(ni)
+    adj2 = joint_norm_adjacency(nu, ni, inv_u[d["train_u"]], inv_i[d["train_i"]])
+    res["spectral_renumbered"] = bytes_for(adj2, n, 64, 8)
+    for k in ("as_numbered", "spectral_renumbered"):
+        b = [x["bytes_received"] for x in res[k]]
+        res[k + "_summary"] = {"max_MB": max(b) / 1e6, "mean_MB": float(np.mean(b)) / 1e6, "vs_allgather": float(np.mean(b)) / allgather}
+    L = 3
+    res["lightgcn_L3_step_MB_per_rank"] = {"allgather_form": (2 * L + 1) * (allgather / 1e6),
+                                           "referenced_as_numbered": 2 * L * res["as_numbered_summary"]["mean_MB"] + allgather / 1e6,
+                                           "referenced_spectral": 2 * L * res["spectral_renumbered_summary"]["mean_MB"] + allgather / 1e6,
+                                           "note": "2L propagation products + one all-gather of the layer sum for the batch loss (every rank evaluates the whole batch)"}
+    out["graphs"][shape] = res
+print(json.dumps(out, indent=1))

@@ -20,6 +20,28 @@ __device__ inline void row_atomic(float* tab, int row, int r, float v) { float* 
 __device__ inline float row_load(const float* tab, int row, int r) { const float* p = tab + (long)row * LD; float s = 0; for (int e = 0; e < 4; e++) s += p[r + 16 * e]; return s; }
 // generic walker: a group of 16 lanes takes chunks of CH consecutive triplets of the given order.  a_row: the row kept in
 // registers along its run (atomic at run end / every `flush`), b_row and c_row: loaded per triplet; b_atomic / c_atomic: updated per triplet
+template <bool LOADS>
+__global__ __launch_bounds__(256) void walk_t(float* A, float* B, float* C, const int* a_row, const int* b_row, const int* c_row, long n, int CH, int flush,
+                                              int b_atomic, int c_atomic, float* glog, long stride) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
+  const long grp = (((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4 + g, ngrp = (((long)gridDim.x * blockDim.x) >> 6) * 4;
+  const long nch = (n + CH - 1) / CH;
+  for (long s = grp; s < nch; s += ngrp) {
+    const long c = (s * stride) % nch;
+    const long t0 = c * CH, t1 = t0 + CH < n ? t0 + CH : n;
+    int cur = a_row[t0], since = 0; float acc = LOADS ? row_load(A, cur, r) : 1.f;
+    for (long t = t0; t < t1; t++) {
+      const int a = a_row[t];
+      if (a != cur || since == flush) { row_atomic(A, cur, r, acc * 1e-9f); cur = a; since = 0; if (LOADS) acc = row_load(A, cur, r); }
+      const float vb = LOADS ? row_load(B, b_row[t], r) : 1.f, vc = (LOADS && c_row) ? row_load(C, c_row[t], r) : 1.f;
+      acc += vb + vc; since++;
+      if (b_atomic) row_atomic(B, b_row[t], r, vc * 1e-9f);
+      if (c_atomic) row_atomic(C, c_row[t], r, vb * 1e-9f);
+      if (glog && r == 0) glog[t] = vb;
+    }
+    row_atomic(A, cur, r, acc * 1e-9f);
+  }
+}
 __global__ __launch_bounds__(256) void walk(float* A, float* B, float* C, const int* a_row, const int* b_row, const int* c_row, long n, int CH, int flush,
                                             int b_atomic, int c_atomic, float* glog, long stride) {
   const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
@@ -83,7 +105,7 @@ int main() {
   float *P, *Q, *glog; hipMalloc(&P, U * LD * 4); hipMalloc(&Q, I * LD * 4); hipMalloc(&glog, n * 4); hipMemset(P, 0, U * LD * 4); hipMemset(Q, 0, I * LD * 4);
   int *du, *di, *dj; hipMalloc(&du, n * 4); hipMalloc(&di, n * 4); hipMalloc(&dj, n * 4);
   auto up = [&](const std::vector<int>& a, const std::vector<int>& b, const std::vector<int>& c) { hipMemcpy(du, a.data(), n * 4, hipMemcpyHostToDevice); hipMemcpy(di, b.data(), n * 4, hipMemcpyHostToDevice); hipMemcpy(dj, c.data(), n * 4, hipMemcpyHostToDevice); };
-  const int CH = 34, BLK = 256; const long nch = (n + CH - 1) / CH; long stride = (long)(nch * 0.6180339887); while (std::gcd(stride, nch) != 1) stride++;
+  const int CH = 34; int BLK = 256; const long nch = (n + CH - 1) / CH; long stride = (long)(nch * 0.6180339887); while (std::gcd(stride, nch) != 1) stride++;
   auto report = [&](const char* name, float ms, double atomics) { printf("%-58s %.3f ms   %.2f row-atomics/triplet   normalised %.2f of 8 TB/s\n", name, ms, atomics, 1548.0 * n / (ms * 1e-3) / 8e12); };
   // atomics per triplet of each schedule, counted on the host
   auto runs = [&](const std::vector<int>& key, int flush) { long a = 0; for (long c = 0; c < nch; c++) { long t0 = c * CH, t1 = std::min(n, t0 + CH); int cur = key[t0], since = 0; for (long t = t0; t < t1; t++) { if (key[t] != cur || since == flush) { a++; cur = key[t]; since = 0; } since++; } a++; } return (double)a; };
@@ -93,7 +115,13 @@ int main() {
   auto oi = sorted_by([&](long t) { return i[t]; }); auto iu = take(u, oi), ii = take(i, oi), ij = take(j, oi);
   { up(iu, ii, ij);
     float ms = time_ms([&] { hipLaunchKernelGGL(walk, dim3(BLK), dim3(256), 0, 0, Q, P, Q, di, du, dj, n, CH, 16, 1, 1, (float*)nullptr, stride); });
-    report("item-major (shipped): Q[i] run / 16, atomics P[u] + Q[j]", ms, 2.0 + runs(ii, 16) / n); }
+    report("item-major (shipped): Q[i] run / 16, atomics P[u] + Q[j]", ms, 2.0 + runs(ii, 16) / n);
+    for (int blocks : {256, 1024}) {
+      float m0 = time_ms([&] { hipLaunchKernelGGL(walk_t<false>, dim3(blocks), dim3(256), 0, 0, Q, P, Q, di, du, dj, n, CH, 16, 1, 1, (float*)nullptr, stride); });
+      char nm[96]; snprintf(nm, 96, "  the same stream, ATOMICS ONLY (no row loads), %d blocks", blocks); report(nm, m0, 2.0 + runs(ii, 16) / n);
+      float m1 = time_ms([&] { hipLaunchKernelGGL(walk_t<true>, dim3(blocks), dim3(256), 0, 0, Q, P, Q, di, du, dj, n, CH, 16, 0, 0, (float*)nullptr, stride); });
+      snprintf(nm, 96, "  the same stream, LOADS ONLY (run-end atomics kept), %d blocks", blocks); report(nm, m1, runs(ii, 16) / n);
+    } }
   for (int B : {64, 128, 256}) {
     std::vector<int> ub(B + 1), blk_of(U); for (int b = 0; b <= B; b++) ub[b] = (int)((long)U * b / B); for (int b = 0; b < B; b++) for (int x = ub[b]; x < ub[b + 1]; x++) blk_of[x] = b;
     auto o = sorted_by([&](long t) { return (long)blk_of[u[t]] * I + i[t]; }); auto su = take(u, o), si = take(i, o), sj = take(j, o);
@@ -106,6 +134,7 @@ int main() {
     char name[96]; snprintf(name, 96, "owner-computes users (%d blocks x %d thr): LDS P, atomics Q[i]-runs + Q[j]", B, threads); report(name, ms, 1.0 + a / n);
   }
   { up(iu, ii, ij);     // deferred negatives, whole epoch and 4 sub-epochs
+    for (int BLK : {256, 1024})
     for (int S : {1, 4}) {
       const long per = (n + S - 1) / S; double atoms = 0; float total = 0;
       for (int s = 0; s < S; s++) {
@@ -123,7 +152,7 @@ int main() {
         long ai = 0; for (long c = 0; c < nchs; c++) { long t0 = c * CH, t1 = std::min(cnt, t0 + CH); int cur = subi[t0], since = 0; for (long t = t0; t < t1; t++) { if (subi[t] != cur || since == 16) { ai++; cur = subi[t]; since = 0; } since++; } ai++; }
         atoms += a + ai + cnt; hipFree(dju); hipFree(djj);
       }
-      char name[96]; snprintf(name, 96, "deferred negatives, %d sub-epoch(s): pass A item-major + pass B j-runs", S); report(name, total, atoms / n);
+      char name[128]; snprintf(name, 128, "deferred negatives, %d sub-epoch(s), %d blocks: pass A item-major + pass B j-runs", S, BLK); report(name, total, atoms / n);
     }
   }
   return 0;
