@@ -140,6 +140,47 @@ def recall_check(capi, sgd, tables, data, u, items, indptr, P0, Q0, chunk, flush
             "final_loss_gpu": loss_g, "final_loss_cpu": loss_c}
 
 
+def deferred_variant(capi, data, u, items, indptr, n_items, P0, Q0, chunk, flush_every, seed, runs=3, epochs=100):
+    """The same workload under the opt-in schedule "item-deferred" (qrec_bpr_sgd_hogwild_item_major_deferred: one atomic row update
+    per triplet instead of two, the negative-side terms applied by a second, j-ordered pass -- DESIGN.md s4), timed like the main
+    line: `runs` fresh `epochs`-epoch trainings, sampler + j sort on the side stream, epoch close on the device, no host sync
+    inside.  Reported NEXT to `value`, not as it: the deferral is a change of algorithm beyond Hogwild's (tests/test_gpu_bpr.py
+    pins its effect on Recall@20: inside +-0.002 at BPR.conf's rate, outside at five times that), so BPR does not run it by default."""
+    from qrec_amd.capi import DeviceBuffer
+    from qrec_amd.engine import BprSgd, DeviceTables
+    from qrec_amd.interactions import CSR
+    t = DeviceTables(P0, Q0, np.float32)
+    s = BprSgd(t, u, items, CSR(indptr, items), schedule="item-deferred", n_items=n_items, chunk=chunk)
+    d_P0, d_Q0 = DeviceBuffer.from_numpy(t._pad(P0)), DeviceBuffer.from_numpy(t._pad(Q0))
+    main = capi.Stream()
+    s.start_device_driver(LR0, log_capacity=epochs)
+    d_drv0 = DeviceBuffer.from_numpy(s.d_drv.numpy())
+    capi.device_sync()
+    evs = [(capi.Event(), capi.Event()) for _ in range((runs + 1) * epochs)]
+    k = 0
+    s.prefetch_negatives_device(seed, 0)
+    t0 = 0.0
+    for r in range(runs + 1):                   # run 0: warm-up
+        if r == 1:
+            capi.device_sync(); t0 = time.perf_counter()
+        capi.memcpy_d2d(t.P, d_P0, d_P0.nbytes, main); capi.memcpy_d2d(t.Q, d_Q0, d_Q0.nbytes, main)
+        capi.memcpy_d2d(s.d_drv, d_drv0, d_drv0.nbytes, main)
+        for _ in range(epochs):
+            s.take_prefetched_negatives(k, main)
+            s.epoch_device_async(REG_U, REG_I, MAX_LR, tol=0.0, chunk=chunk, stream=main, flush_every=flush_every, events=evs[k])
+            s.prefetch_negatives_device(seed, k + 1)
+            k += 1
+    capi.device_sync()
+    dt = time.perf_counter() - t0
+    ms = float(np.mean([b.elapsed_ms_since(a) for a, b in evs[epochs:]]))
+    alg = u.size * bytes_per_triplet(P0.shape[1])
+    rec = recall_check(capi, s, t, data, u, items, indptr, P0, Q0, chunk, flush_every, capi.HW_DEFAULT)
+    return {"schedule": "item-deferred", "value": u.size * runs * epochs / dt, "unit": "triplet-updates/s", "ms_per_epoch": dt / (runs * epochs) * 1e3,
+            "kernels": "bpr_hogwild_item_kernel<16,4,defer> + bpr_deferred_negatives_kernel<16,4> (j order: rocPRIM radix sort on the sampler's stream)",
+            "avg_launch_ms": ms, "roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "recall_at_20": rec,
+            "default": False, "why_not_default": "Recall@20 vs exact-order training: within 0.002 at lr0 = 0.01, 0.0058 apart at lr0 = 0.05 (12-epoch paired runs, tests/test_gpu_bpr.py)"}
+
+
 def exact_mode_rate(capi, u, items, indptr, n_items, P0, Q0):
     """The order-exact mode on the same workload: CPython-stream negatives from the native host replay, triplets
     applied strictly in the reference's order on the device (fp64 tables, the drop-in classes' default)."""
@@ -224,7 +265,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip exact_mode / roofline_hbm_resident / recall_at_20")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--flush-every", type=int, default=0, help="item-major schedule: triplets between flushes of the register-resident Q[i] (0 = default)")
-    ap.add_argument("--schedule", choices=("item", "user"), default="item",
+    ap.add_argument("--schedule", choices=("item", "user", "item-deferred"), default=os.environ.get("QREC_BENCH_SCHEDULE", "item"),
                     help="visiting order of the epoch's triplets in the Hogwild kernel (DESIGN.md s4)")
     ap.add_argument("--dist-mode", choices=("replicated", "sharded"), default=os.environ.get("QREC_DIST_MODE", "replicated"))
     ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("QREC_SCALING", "weak"))
@@ -438,7 +479,8 @@ def main():
             tj = json.load(open(tfile))
             if tj.get("workload") == f"bpr-{args.shape}-d{DIM}-{args.schedule}":
                 traffic = tj.get("bytes_per_launch")
-        kernel = "bpr_hogwild_item_kernel<16,4>" if args.schedule == "item" else "bpr_hogwild_kernel<16,4,plain-load,atomic>"
+        kernel = {"item": "bpr_hogwild_item_kernel<16,4>", "user": "bpr_hogwild_kernel<16,4,plain-load,atomic>",
+                  "item-deferred": "bpr_hogwild_item_kernel<16,4,defer> + bpr_deferred_negatives_kernel<16,4>"}[args.schedule]
         if world == 1:
             par = "1 GPU" + (f" (QREC_FORCE_DIST: {args.dist_mode} multi-GPU path at world 1)" if use_dist else "")
         elif sharded:
@@ -469,7 +511,10 @@ def main():
                                             "not re-measured in this run)") if traffic is not None else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_kernel_ms,
                          "note": ("events bracket the epoch's batches incl. their exchanges" if sharded else
-                                  "tables (17.8 MB) are cache resident at this shape; bound = L2 atomic units, see DESIGN.md")},
+                                  "tables (17.8 MB) are cache resident at this shape; bound = L2 atomic units, see DESIGN.md"),
+                         **({"atomic_unit_floor": {"ms": 0.547, "of_this_kernel": 0.547 / avg_kernel_ms, "source": "profiles/r03_ubench_atomics4.txt "
+                                                   "(static, builder-measured): this epoch's two atomic row updates per triplet ALONE, no loads, no arithmetic"}}
+                            if args.schedule == "item" and args.shape == "yelp2018" and not use_dist else {})},
         }
         if world == 1 and not use_dist:
             if not args.no_cpu_baseline:
@@ -478,6 +523,8 @@ def main():
             if not args.no_extras:
                 out["recall_at_20"] = recall_check(capi, sgd, tables, data, u, items, indptr, P0, Q0, CHUNK, flush_every, args.variant)
                 out["exact_mode"] = exact_mode_rate(capi, u, items, indptr, I, P0, Q0)
+                if args.schedule == "item" and args.shape == "yelp2018":
+                    out["deferred_negatives"] = deferred_variant(capi, data, u, items, indptr, I, P0, Q0, CHUNK, flush_every, sampler_seed)
                 del sgd, tables
                 out["roofline_hbm_resident"] = hbm_resident_roofline(capi)
         os.write(result_fd, (json.dumps(out) + "\n").encode())

@@ -198,6 +198,24 @@ int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int64_t n_users, int
                                     const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
                                     int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
                                     double *d_loss, const double *d_driver_state, void *stream);
+/* Deferred negatives (round 3): the same epoch in two passes -- the item-major pass applies the updates of P[u] and Q[i] and
+ * logs every triplet's coefficient lr (1 - sigma(x)); a second pass walks the triplets in j order (a counting sort of the
+ * epoch's negatives, on the device) with Q[j] in registers and applies  Q[j] -= g P[u]; Q[j] -= lr regI Q[j].  One atomic
+ * row update per triplet instead of two (the item-major kernel sits at the atomic units' ceiling: DESIGN.md s4).  The
+ * negative-side updates of an epoch are applied after its positive-side ones, with the epoch-end P[u]: a reordering of
+ * the same terms.  d_work: qrec_bpr_deferred_work_bytes(n, n_items) bytes of scratch, laid out as
+ *   float g[n] | int32 order[n] | int32 j_sorted[n] (each rounded up to 256 bytes) | the sort's own scratch.
+ * qrec_bpr_deferred_sort puts the j order of the negatives d_j into d_work: a STABLE sort by j (inside a run of equal j
+ * the triplets keep their storage order), so pass B is a deterministic function of the arrays; the engine runs it on the
+ * sampler's side stream, under the previous epoch.  `sorted` = 0 makes qrec_bpr_sgd_hogwild_item_major_deferred do it
+ * first, on its own stream.                                                                                               */
+int qrec_bpr_deferred_work_bytes(int64_t n, int64_t n_items, int64_t *bytes);
+int qrec_bpr_deferred_sort(const int32_t *d_j, int64_t n, int64_t n_items, void *d_work, void *stream);
+int qrec_bpr_sgd_hogwild_item_major_deferred(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld,
+                                             const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
+                                             int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
+                                             double *d_loss, const double *d_driver_state, void *d_work, int32_t sorted,
+                                             void *stream);
 
 /* Device-resident epoch close of the numpy-path models: model/ranking/BPR.py:40 (loss += regU*sum(P*P) +
  * regI*sum(Q*Q)) followed by isConverged / updateLearningRate (base/iterativeRecommender.py:56-63,88-104),

@@ -312,6 +312,48 @@ double orc_bpr_sgd_f64(double *P, double *Q, int32_t d, const int32_t *u_idx,
 }
 
 /* ------------------------------------------------------------------------------------
+ * NOT a reference function: the sequential DEFINITION of the product's "deferred negatives" epoch (qrec_amd/csrc/bpr_sgd.hip,
+ * round 3), which the tests hold the two-pass kernels to.  The per-triplet terms are BPR.optimization's (BPR.py:45-53); what
+ * differs is when the negative item's row is updated:
+ *   pass A, triplets in the given (item-major) order:  s, g = lr (1 - s);  P[u] += g (Q[i] - Q[j]);  Q[i] += g P[u];
+ *           P[u] -= lr regU P[u];  Q[i] -= lr regI Q[i];  loss += -log(s)          -- Q[j] is read, not written; g is kept
+ *   pass B, the same triplets in the order j_order:   Q[j] -= g P[u];  Q[j] -= lr regI Q[j]     with the P[u] pass A left.
+ * Returns sum of -log(s). */
+double orc_bpr_sgd_deferred_f64(double *P, double *Q, int32_t d, const int32_t *u_idx, const int32_t *i_idx, const int32_t *j_idx,
+                                const int64_t *j_order, int64_t n, double lr, double regU, double regI) {
+    double loss = 0.0;
+    double *g_of = (double *)malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+    int64_t t, k;
+    int c;
+    for (t = 0; t < n; t++) {
+        double *pu = P + (int64_t)u_idx[t] * d;
+        double *qi = Q + (int64_t)i_idx[t] * d;
+        const double *qj = Q + (int64_t)j_idx[t] * d;
+        double xi = 0.0, xj = 0.0, s, g;
+        for (c = 0; c < d; c++) { xi += pu[c] * qi[c]; xj += pu[c] * qj[c]; }
+        s = 1.0 / (1.0 + exp(-(xi - xj)));
+        g = lr * (1.0 - s);
+        g_of[t] = g;
+        for (c = 0; c < d; c++) pu[c] += g * (qi[c] - qj[c]);
+        for (c = 0; c < d; c++) qi[c] += g * pu[c];
+        for (c = 0; c < d; c++) pu[c] -= (lr * regU) * pu[c];
+        for (c = 0; c < d; c++) qi[c] -= (lr * regI) * qi[c];
+        loss += -log(s);
+    }
+    for (k = 0; k < n; k++) {
+        const double *pu;
+        double *qj;
+        t = j_order[k];
+        pu = P + (int64_t)u_idx[t] * d;
+        qj = Q + (int64_t)j_idx[t] * d;
+        for (c = 0; c < d; c++) qj[c] -= g_of[t] * pu[c];
+        for (c = 0; c < d; c++) qj[c] -= (lr * regI) * qj[c];
+    }
+    free(g_of);
+    return loss;
+}
+
+/* ------------------------------------------------------------------------------------
  * TBPR (model/ranking/TBPR.py:111-166): per user (PositiveSet order) and positive item the chain
  * [i, choice(jointItems)?, choice(weakItems)?, choice(strongItems)?, k] with k = choice(itemList) redrawn while positive
  * (:137-155); consecutive members form the (u, a, b) updates of TBPR.optimization (:157-158).  Lists are CSR over users.

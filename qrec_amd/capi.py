@@ -60,6 +60,9 @@ _SIGNATURES = {
     "qrec_bpr_sgd_scheduled_wide": [_vp, _vp, _i64, _i64, C.c_int, _i32, _i32, _vp, _i64, _i32, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp],
     "qrec_bpr_sgd_hogwild": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _vp, C.c_int, _vp, _vp],
     "qrec_bpr_sgd_hogwild_item_major": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp],
+    "qrec_bpr_deferred_work_bytes": [_i64, _i64, _vp],
+    "qrec_bpr_deferred_sort": [_vp, _i64, _i64, _vp, _vp],
+    "qrec_bpr_sgd_hogwild_item_major_deferred": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _i32, _vp],
     "qrec_epoch_close": [_vp, _i64, _vp, _i64, C.c_int, _i32, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
     "qrec_epoch_sums": [_vp, _i64, _vp, _i64, C.c_int, _i32, _vp, _vp, _vp],
     "qrec_epoch_decide": [_vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
@@ -905,6 +908,26 @@ def bpr_sgd_hogwild_item_major(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int,
     _check(load().qrec_bpr_sgd_hogwild_item_major(_dp(d_P), _dp(d_Q), p_rows or _table_rows(d_P, ld), q_rows or _table_rows(d_Q, ld), d, ld, _dp(d_u), _dp(d_i), _dp(d_j), n, chunk,
                                                   grid_groups, flush_every, lr, regU, regI, _dp(d_loss),
                                                   _dp(d_driver_state), _sh(stream)))
+
+
+def bpr_deferred_work_bytes(n: int, n_items: int) -> int:
+    out = C.c_int64(0)
+    _check(load().qrec_bpr_deferred_work_bytes(n, n_items, C.byref(out)))
+    return out.value
+
+
+def bpr_deferred_sort(d_j, n: int, n_items: int, d_work, stream=None):
+    _check(load().qrec_bpr_deferred_sort(_dp(d_j), n, n_items, _dp(d_work), _sh(stream)))
+
+
+def bpr_sgd_hogwild_item_major_deferred(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int, chunk: int, grid_groups: int,
+                                        flush_every: int, lr: float, regU: float, regI: float, d_loss, d_work, stream=None,
+                                        d_driver_state=None, p_rows: int | None = None, q_rows: int | None = None, is_sorted: bool = False):
+    """the item-major epoch with the negative-side updates deferred to a second, j-ordered pass (include/qrec_hip.h);
+    ``is_sorted``: ``bpr_deferred_sort`` has already put these negatives' j order into ``d_work``"""
+    _check(load().qrec_bpr_sgd_hogwild_item_major_deferred(_dp(d_P), _dp(d_Q), p_rows or _table_rows(d_P, ld), q_rows or _table_rows(d_Q, ld), d, ld,
+                                                           _dp(d_u), _dp(d_i), _dp(d_j), n, chunk, grid_groups, flush_every, lr, regU, regI,
+                                                           _dp(d_loss), _dp(d_driver_state), _dp(d_work), 1 if is_sorted else 0, _sh(stream)))
 
 
 DRV_LR, DRV_LAST_LOSS, DRV_EPOCHS, DRV_CONVERGED, DRV_FAILED, DRV_WORDS = 0, 1, 2, 3, 4, 8

@@ -20,6 +20,11 @@
 //    Algorithmic bytes per triplet: 6*d*4 + 12.
 #include <cmath>
 
+#include <algorithm>
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
 #include "common.h"
 
 using namespace qrec;
@@ -556,12 +561,15 @@ __global__ __launch_bounds__(256) void bpr_hogwild_kernel(
 // (stride coprime to n_chunks, ~0.618 n_chunks), which spreads the ~200 chunks of a hot item over
 // the whole epoch instead of running them all at once.
 // ------------------------------------------------------------------------------------
-template <int LPR, int E, typename TAB>
+// DEFER (round 3, "deferred negatives"): the update of Q[j] is NOT applied here -- the triplet's coefficient lr (1 - sigma(x)) is
+// logged (glog[t], 4 B) and bpr_deferred_negatives_kernel applies all of an epoch's negative-side updates afterwards, walking the
+// triplets in j order with Q[j] in registers.  One atomic row update per triplet instead of two: see that kernel's comment.
+template <int LPR, int E, typename TAB, bool DEFER = false>
 __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
     float *__restrict__ P, float *__restrict__ Q, int64_t p_bytes, int64_t q_bytes,
     const int32_t *__restrict__ u_idx, const int32_t *__restrict__ i_idx,
     const int32_t *__restrict__ j_idx, int64_t n, int chunk, int64_t n_chunks, int64_t chunk_stride,
-    int64_t groups_active, int flush_every, HwRate rate, double *__restrict__ loss_out) {
+    int64_t groups_active, int flush_every, HwRate rate, double *__restrict__ loss_out, float *__restrict__ glog = nullptr) {
     constexpr int GPW = kWave / LPR;
     float lr, cu, ci;
     if (!hw_rate_resolve(rate, lr, cu, ci)) return;
@@ -620,14 +628,15 @@ __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
                 pun.v[e] = p1 - cu * p1;
             }
             hw_update_row<LPR, E, UP_ATOMIC>(rsP, ut, r, pu, pun);
-            hw_update_row<LPR, E, UP_ATOMIC>(rsQ, jt, r, qj, qjn);
+            if constexpr (DEFER) { if (r == 0) glog[t0 + k] = gsc; }
+            else hw_update_row<LPR, E, UP_ATOMIC>(rsQ, jt, r, qj, qjn);
             loss += neg_log_sigmoid(di - dj);
             since_flush++;
             if (more) {   // rows this group just changed supersede the prefetched copy
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     if (un == ut) npu.v[e] = pun.v[e];
-                    if (jn == jt) nqj.v[e] = qjn.v[e]; else if (jn == cur_i) nqj.v[e] = qi.v[e];
+                    if (!DEFER && jn == jt) nqj.v[e] = qjn.v[e]; else if (jn == cur_i) nqj.v[e] = qi.v[e];
                 }
             }
             pu = npu; qj = nqj; ut = un; jt = jn;
@@ -640,6 +649,143 @@ __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) loss_acc += __shfl_xor(loss_acc, m, kWave);
     if (lane == 0 && loss_acc != 0.0) atomicAdd(loss_out, loss_acc);
+}
+
+// ------------------------------------------------------------------------------------
+// Deferred negatives (round 3).  The item-major kernel is pinned to the memory-side atomic units: its epoch's atomic stream
+// ALONE (no loads, no arithmetic) takes 0.55 ms of its 0.57 (tools/ubench/atomics4.hip, profiles/r03_ubench_atomics4.txt) --
+// two atomic row updates per triplet (P[u], Q[j]), the third row (Q[i]) riding in registers along the item's run.  A triplet's
+// three rows cannot all ride in registers in ONE visiting order, but they can in two: pass A (item order) updates P[u] and
+// Q[i] and logs the triplet's coefficient g = lr (1 - sigma(x)); pass B (this kernel) walks the same triplets in j order
+// (a counting sort of the epoch's negatives, three small launches) with Q[j] in registers along j's run:
+//     Q[j] -= g P[u];  Q[j] -= lr regI Q[j]          (BPR.py:49, :52)
+// One atomic row update per triplet in pass A, one per run segment (~1/30 per triplet) here, one extra row read (P[u]).
+// What changes in the algorithm: within an epoch the negative-side updates of the item table are applied after the positive-
+// side ones, with the epoch-end P[u] -- a reordering of the same per-triplet terms (nothing is dropped, nothing is added),
+// larger than Hogwild's staleness and judged the same way: the properties in tests/test_gpu_bpr.py (one group = the sequential
+// statement of THIS order, conflict-free input exact, lr = 0 leaves the tables bit-identical) and the paired Recall@20 /
+// loss-trajectory runs against the order-exact CPU training.
+// ------------------------------------------------------------------------------------
+template <int LPR, int E, typename TAB>
+__global__ __launch_bounds__(256) void bpr_deferred_negatives_kernel(
+    float *__restrict__ P, float *__restrict__ Q, int64_t p_bytes, int64_t q_bytes, const int32_t *__restrict__ u_idx,
+    const int32_t *__restrict__ j_sorted, const float *__restrict__ glog, const int32_t *__restrict__ perm, int64_t n, int chunk,
+    int64_t n_chunks, int64_t groups_active, HwRate rate) {
+    constexpr int GPW = kWave / LPR;
+    float lr, cu, ci;
+    if (!hw_rate_resolve(rate, lr, cu, ci)) return;
+    __shared__ int32_t s_idx[4][GPW][2][kMaxChunk];
+    __shared__ float s_g[4][GPW][kMaxChunk];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane / LPR, r = lane % LPR;
+    const int64_t gid = ((int64_t)blockIdx.x * 4 + wave) * GPW + g;
+    int32_t *su = s_idx[wave][g][0], *sj = s_idx[wave][g][1];
+    float *sg = s_g[wave][g];
+    const TAB rsP = TAB::make(P, p_bytes), rsQ = TAB::make(Q, q_bytes);
+    for (int64_t c = gid; c < n_chunks && gid < groups_active; c += groups_active) {
+        const int64_t p0 = c * chunk;
+        const int len = (int)((n - p0) < chunk ? (n - p0) : chunk);
+        for (int k = r; k < len; k += LPR) { const int32_t t = perm[p0 + k]; su[k] = u_idx[t]; sj[k] = j_sorted[p0 + k]; sg[k] = glog[t]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int cur_j = -1;
+        Row<E> qj, qj0;
+#pragma unroll
+        for (int e = 0; e < E; e++) qj.v[e] = qj0.v[e] = 0.f;
+        Row<E> pu = hw_load_row<LPR, E, LD_PLAIN>(rsP, su[0], r);
+        for (int k = 0; k < len; k++) {
+            const int jt = sj[k];
+            if (jt != cur_j) {
+                if (cur_j >= 0) hw_update_row<LPR, E, UP_ATOMIC>(rsQ, cur_j, r, qj0, qj);
+                qj = hw_load_row<LPR, E, LD_SC1>(rsQ, jt, r);      // past L1: pass A's last flushes of this row (as a positive item)
+                qj0 = qj; cur_j = jt;
+            }
+            Row<E> npu = pu;
+            if (k + 1 < len) npu = hw_load_row<LPR, E, LD_PLAIN>(rsP, su[k + 1], r);
+            const float gsc = sg[k];
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const float b = qj.v[e] - gsc * pu.v[e];
+                qj.v[e] = b - ci * b;
+            }
+            pu = npu;
+        }
+        if (cur_j >= 0) hw_update_row<LPR, E, UP_ATOMIC>(rsQ, cur_j, r, qj0, qj);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// the epoch's triplets in j order: a STABLE radix sort of (j, position) pairs over the bits the item ids use (rocPRIM, two 8-bit
+// passes at the Yelp2018 shape) -- inside a run the triplets keep their item-major order, so pass B is a deterministic function of
+// the sampled arrays.  (The first version was a counting sort whose fill used global atomics: 0.19 ms alone, 3x that when it ran
+// under pass A's atomic stream, and a run order that changed from launch to launch -- with lr regI m ~ 1e-2 over a run of m
+// terms that moved Q rows by 1e-3.)  A call of its own: the engine runs it on the sampler's side stream.
+struct DeferredWork {
+    float *glog; int32_t *perm; int32_t *jsorted; void *temp; size_t temp_bytes;
+};
+static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+static inline unsigned key_bits(int64_t n_keys) { unsigned b = 1; while (((int64_t)1 << b) < n_keys) b++; return b; }
+int deferred_temp_bytes(int64_t n, int64_t n_keys, size_t *bytes) {
+    size_t tb = 0;
+    const hipError_t e = rocprim::radix_sort_pairs(nullptr, tb, (const int32_t *)nullptr, (int32_t *)nullptr,
+                                                   rocprim::counting_iterator<int32_t>(0), (int32_t *)nullptr, (size_t)n, 0u,
+                                                   key_bits(n_keys), (hipStream_t)0);
+    QREC_REQUIRE(e == hipSuccess, "qrec_bpr_deferred: rocprim::radix_sort_pairs size query failed");
+    *bytes = align256(tb ? tb : 256);
+    return QREC_OK;
+}
+int deferred_carve(void *work, int64_t n, int64_t n_keys, DeferredWork *w) {
+    char *p = (char *)work;
+    w->glog = (float *)p; p += align256((size_t)n * 4);
+    w->perm = (int32_t *)p; p += align256((size_t)n * 4);
+    w->jsorted = (int32_t *)p; p += align256((size_t)n * 4);
+    w->temp = p;
+    return deferred_temp_bytes(n, n_keys, &w->temp_bytes);
+}
+int sort_by_negative(const int32_t *j, int64_t n, int64_t n_keys, const DeferredWork &w, hipStream_t st) {
+    if (n == 0) return QREC_OK;
+    size_t tb = w.temp_bytes;
+    const hipError_t e = rocprim::radix_sort_pairs(w.temp, tb, j, w.jsorted, rocprim::counting_iterator<int32_t>(0), w.perm, (size_t)n,
+                                                   0u, key_bits(n_keys), st);
+    QREC_REQUIRE(e == hipSuccess, "qrec_bpr_deferred_sort: rocprim::radix_sort_pairs failed");
+    return QREC_OK;
+}
+
+template <int LPR, int E>
+int launch_hogwild_item_deferred(float *P, float *Q, int64_t pb, int64_t qb, const int32_t *u, const int32_t *i, const int32_t *j,
+                                 int64_t n, int64_t n_keys, int chunk, int64_t groups, int flush_every, HwRate rate, double *loss,
+                                 const DeferredWork &w, bool sorted, hipStream_t st) {
+    constexpr int GPW = kWave / LPR;
+    const int64_t n_chunks = (n + chunk - 1) / chunk;
+    // fewer atomics per triplet: the passes lean on the row loads, which scale with the groups in flight (measured, atomics4.hip:
+    // 0.41 ms of loads at 256 blocks, 0.18 at 1024) -- four blocks per CU by default
+    const int64_t default_groups = (int64_t)1024 * 4 * GPW, max_groups = (int64_t)256 * 8 * 4 * GPW;
+    if (groups <= 0) groups = default_groups;
+    if (groups > max_groups) groups = max_groups;
+    if (groups > n_chunks) groups = n_chunks;
+    int64_t stride = (int64_t)((double)n_chunks * 0.6180339887498949);
+    if (stride < 1) stride = 1;
+    auto gcd = [](int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; };
+    while (gcd(stride, n_chunks) != 1) stride++;
+    const unsigned blocks = (unsigned)((groups + 4 * GPW - 1) / (4 * GPW));
+    if (!sorted) {
+        const int rc = sort_by_negative(j, n, n_keys, w, st);
+        if (rc != QREC_OK) return rc;
+    }
+    if (pb < kBufLimit && qb < kBufLimit) {
+        hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E, TabBuf, true>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, chunk,
+                           n_chunks, stride, groups, flush_every, rate, loss, w.glog);
+        hipLaunchKernelGGL((bpr_deferred_negatives_kernel<LPR, E, TabBuf>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, w.jsorted, w.glog, w.perm, n,
+                           chunk, n_chunks, groups, rate);
+    } else {
+        hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E, TabPtr, true>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, chunk,
+                           n_chunks, stride, groups, flush_every, rate, loss, w.glog);
+        hipLaunchKernelGGL((bpr_deferred_negatives_kernel<LPR, E, TabPtr>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, w.jsorted, w.glog, w.perm, n,
+                           chunk, n_chunks, groups, rate);
+    }
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
 }
 
 template <int LPR, int E>
@@ -880,6 +1026,56 @@ int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int64_t n_users, int
         case 128: return launch_hogwild_item<32, 4>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, st);
         default: return launch_hogwild_item<64, 4>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, st);
     }
+}
+
+int qrec_bpr_deferred_work_bytes(int64_t n, int64_t n_items, int64_t *bytes) {
+    QREC_REQUIRE(bytes && n >= 0 && n < (1ll << 31) && n_items >= 1 && n_items < (1ll << 31) - 2, "qrec_bpr_deferred_work_bytes: bad arguments");
+    // glog float[n] | perm int32[n] | j_sorted int32[n] (each rounded up to 256 bytes) | the radix sort's scratch
+    size_t tb = 0;
+    const int rc = deferred_temp_bytes(n, n_items, &tb);
+    if (rc != QREC_OK) return rc;
+    *bytes = (int64_t)(3 * align256((size_t)n * 4) + tb);
+    return QREC_OK;
+}
+
+int qrec_bpr_deferred_sort(const int32_t *d_j, int64_t n, int64_t n_items, void *d_work, void *stream) {
+    QREC_REQUIRE(n >= 0 && n < (1ll << 31) && n_items >= 1 && n_items < (1ll << 31) - 2, "qrec_bpr_deferred_sort: bad sizes");
+    if (n == 0) return QREC_OK;
+    QREC_REQUIRE(d_j && d_work, "qrec_bpr_deferred_sort: null argument");
+    DeferredWork w;
+    const int rc = deferred_carve(d_work, n, n_items, &w);
+    if (rc != QREC_OK) return rc;
+    return sort_by_negative(d_j, n, n_items, w, as_stream(stream));
+}
+
+int qrec_bpr_sgd_hogwild_item_major_deferred(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld,
+                                             const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
+                                             int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
+                                             double *d_loss, const double *d_driver_state, void *d_work, int32_t sorted,
+                                             void *stream) {
+    QREC_REQUIRE(d_P && d_Q && d_loss && n >= 0 && n < (1ll << 31), "qrec_bpr_sgd_hogwild_item_major_deferred: bad argument");
+    QREC_REQUIRE(n == 0 || (d_u && d_i && d_j && d_work), "qrec_bpr_sgd_hogwild_item_major_deferred: null array");
+    QREC_REQUIRE(ld >= d && d >= 1, "qrec_bpr_sgd_hogwild_item_major_deferred: need ld >= d >= 1");
+    QREC_REQUIRE(ld == 32 || ld == 64 || ld == 128 || ld == 256,
+                 "qrec_bpr_sgd_hogwild_item_major_deferred: row stride must be 32, 64, 128 or 256 floats (got ld=%d)", ld);
+    QREC_REQUIRE(chunk >= 1 && chunk <= kMaxChunk && flush_every >= 1, "qrec_bpr_sgd_hogwild_item_major_deferred: bad chunk / flush interval");
+    if (n == 0) return QREC_OK;
+    QREC_REQUIRE(n_users >= 1 && n_items >= 1 && n_items < (1ll << 31) - 2, "qrec_bpr_sgd_hogwild_item_major_deferred: table row counts must be given");
+    const int64_t full_p = n_users * (int64_t)ld * 4, full_q = n_items * (int64_t)ld * 4;
+    hipStream_t st = as_stream(stream);
+    const HwRate rate{lr, regU, regI, d_driver_state};
+    DeferredWork w;
+    const int rcw = deferred_carve(d_work, n, n_items, &w);
+    if (rcw != QREC_OK) return rcw;
+#define QREC_DEF(LPR, E) launch_hogwild_item_deferred<LPR, E>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, n_items, chunk, grid_groups, \
+                                                               flush_every, rate, d_loss, w, sorted != 0, st)
+    switch (ld) {
+        case 32: return QREC_DEF(16, 2);
+        case 64: return QREC_DEF(16, 4);
+        case 128: return QREC_DEF(32, 4);
+        default: return QREC_DEF(64, 4);
+    }
+#undef QREC_DEF
 }
 
 }  // extern "C"

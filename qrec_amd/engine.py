@@ -107,8 +107,13 @@ class BprSgd:
         all batches exactly as the kernel's strided visiting order spreads them over a single launch (a batch of
         CONSECUTIVE item-sorted triplets would put all work on a hot row into one launch: measured, 16 % higher loss
         after 14 epochs on the ML-1M shape); batch starts stay multiples of ``chunk``, item runs stay intact."""
-        if schedule not in ("user", "item"):
-            raise ValueError("schedule must be 'user' or 'item'")
+        if schedule not in ("user", "item", "item-deferred"):
+            raise ValueError("schedule must be 'user', 'item' or 'item-deferred'")
+        # "item-deferred" (round 3): the item-major order with the negative-side updates applied by a second, j-ordered pass
+        # (qrec_bpr_sgd_hogwild_item_major_deferred); everything about the ORDER of the stored triplets is "item"
+        self.deferred = schedule == "item-deferred"
+        if self.deferred:
+            schedule = "item"
         self.t = tables
         # size of the item catalogue the triplets' ids refer to: the table's rows, except when this process holds only a
         # row shard of the item table (qrec_amd/dist.py) and the ids are global
@@ -138,6 +143,10 @@ class BprSgd:
         self.d_u = DeviceBuffer.from_numpy(u)
         self.d_i = DeviceBuffer.from_numpy(i)
         self.d_j = DeviceBuffer(max(self.n, 1), np.int32)
+        # deferred negatives: per negatives buffer a work area {coefficient log, j order, counters}; `_sorted`: the j order of the
+        # current negatives is already in d_work (computed next to the sampler, on its side stream)
+        self.d_work = DeviceBuffer(capi.bpr_deferred_work_bytes(self.n, self.n_items), np.uint8) if self.deferred else None
+        self.d_work_next, self._sorted = None, False
         self.d_j_next = None
         self.d_stats = DeviceBuffer.zeros(capi.STATS_WORDS, np.float64)
         self.d_loss = self.d_stats          # element 0
@@ -162,6 +171,7 @@ class BprSgd:
             j = np.ascontiguousarray(j[self.perm])
         self.h_j = j
         self.d_j.upload(j, stream)
+        self._sorted = False
 
     def negatives_reference_order(self) -> np.ndarray:
         """current negatives as a host array in the reference's triplet order"""
@@ -176,6 +186,7 @@ class BprSgd:
             raise RuntimeError("BprSgd was built without the positives CSR")
         capi.philox_bpr_sample(self._pos_dev[0], self._pos_dev[1], self.d_u, self.n, self.n_items,
                                seed, epoch, self.d_j, stream)
+        self._sorted = False
 
     def prefetch_negatives_device(self, seed: int, epoch: int):
         """Enqueue the sampler for `epoch` on the side stream into the spare buffer."""
@@ -184,12 +195,16 @@ class BprSgd:
         if self._side is None:
             self._side = capi.Stream(); self._sampled = capi.Event()
             self.d_j_next = DeviceBuffer(max(self.n, 1), np.int32)
+            if self.deferred:
+                self.d_work_next = DeviceBuffer(capi.bpr_deferred_work_bytes(self.n, self.n_items), np.uint8)
         if self._consumed[1] is not None:      # the spare buffer may still be read by an enqueued SGD kernel
             capi.stream_wait_event(self._side, self._consumed[1])
         if self._sgd_start is not None:
             capi.stream_wait_event(self._side, self._sgd_start)
         capi.philox_bpr_sample(self._pos_dev[0], self._pos_dev[1], self.d_u, self.n, self.n_items,
                                seed, epoch, self.d_j_next, self._side)
+        if self.deferred:        # the j order of these negatives, next to the sampler: both run under the current epoch's kernels
+            capi.bpr_deferred_sort(self.d_j_next, self.n, self.n_items, self.d_work_next, self._side)
         self._sampled.record(self._side)
         self._prefetched_epoch = epoch
 
@@ -199,6 +214,8 @@ class BprSgd:
             raise RuntimeError(f"negatives of epoch {epoch} were not prefetched")
         capi.stream_wait_event(stream, self._sampled)
         self.d_j, self.d_j_next = self.d_j_next, self.d_j
+        if self.deferred:
+            self.d_work, self.d_work_next, self._sorted = self.d_work_next, self.d_work, True
         self._consumed.reverse()
         self._prefetched_epoch = None
 
@@ -303,7 +320,11 @@ class BprSgd:
         if self.t.dtype != np.float32:
             raise TypeError("throughput mode needs fp32 tables")
         capi.memset(self.d_stats.ptr, 0, 8, stream)
-        if self.schedule == "item":
+        if self.deferred:
+            capi.bpr_sgd_hogwild_item_major_deferred(self.t.P, self.t.Q, self.t.d, self.t.ld, self.d_u, self.d_i, self.d_j,
+                                                     self.n, chunk, groups, flush_every, lr, regU, regI, self.d_stats, self.d_work, stream,
+                                                     is_sorted=self._sorted)
+        elif self.schedule == "item":
             capi.bpr_sgd_hogwild_item_major(self.t.P, self.t.Q, self.t.d, self.t.ld, self.d_u, self.d_i, self.d_j,
                                             self.n, chunk, groups, flush_every, lr, regU, regI, self.d_stats, stream)
         else:
@@ -369,7 +390,10 @@ class BprSgd:
         """the throughput kernel of the schedule on (P, Q) -- Q is the item table, or a shard's row cache with the
         triplets' item ids rewritten to its rows; learning rate and stop flags come from the device-side driver"""
         t = self.t
-        if self.schedule == "item":
+        if self.deferred and q_rows is None:         # (a shard's row cache -- q_rows given -- keeps the one-pass kernel: its ids are cache slots)
+            capi.bpr_sgd_hogwild_item_major_deferred(P, Q, t.d, t.ld, d_u, d_i, d_j, n, chunk, groups, flush_every, 0.0, regU, regI,
+                                                     self.d_stats, self.d_work, stream, self.d_drv, p_rows=t.n_users, is_sorted=self._sorted)
+        elif self.schedule == "item":
             capi.bpr_sgd_hogwild_item_major(P, Q, t.d, t.ld, d_u, d_i, d_j, n, chunk, groups, flush_every, 0.0, regU, regI,
                                             self.d_stats, stream, self.d_drv, p_rows=t.n_users, q_rows=q_rows)
         else:
