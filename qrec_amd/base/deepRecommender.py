@@ -145,6 +145,33 @@ class DeepRecommender(IterativeRecommender):
             e = min(s + self.batch_size, u.size)
             yield u[s:e].tolist(), i[s:e].tolist(), j[s:e].tolist()
 
+    def sample_epoch_pointwise(self, negatives: int = 4):
+        """One pass of ``next_batch_pointwise`` (base/deepRecommender.py:54-77) as three int32 arrays of length
+        (1 + negatives) * n: per training row -- in stored order, this sampler does not shuffle -- the positive (label 1), then
+        ``negatives`` items drawn with ``randint(0, num_items - 1)`` and redrawn while the user rated them (label 0).
+        ``randint(0, n - 1)`` and ``choice`` of an n-list both come down to ``_randbelow(n)``, so the native replay of the
+        pairwise draw loop over every row repeated ``negatives`` times IS this stream; the Python generator stays in lock-step."""
+        u, i, _ = self.data.training_arrays()
+        rated = self._rated_sorted()
+        state = random.getstate()
+        words = capi.state_from_python(state)
+        neg = capi.mt_pairwise_sample_epoch(words, np.repeat(u, negatives), rated.indptr, rated.indices, self.num_items)
+        random.setstate(capi.state_to_python(words, state[2]))
+        n, w = int(u.size), 1 + negatives
+        uu = np.repeat(u, w).astype(np.int32)
+        ii = np.empty(n * w, np.int32); ii.reshape(n, w)[:, 0] = i; ii.reshape(n, w)[:, 1:] = neg.reshape(n, negatives)
+        y = np.zeros(n * w, np.int32); y[::w] = 1
+        return uu, ii, y
+
+    def next_batch_pointwise(self):
+        """Generator with the reference's signature: yields (u_idx, i_idx, y) lists, 5 entries per training row, batches of
+        ``batch_size`` ROWS (base/deepRecommender.py:54-77)."""
+        uu, ii, y = self.sample_epoch_pointwise(4)
+        step = 5 * self.batch_size
+        for s in range(0, uu.size, step):
+            e = min(s + step, uu.size)
+            yield uu[s:e].tolist(), ii[s:e].tolist(), y[s:e].tolist()
+
     def _rated_sorted(self):
         if not hasattr(self, "_rated_sorted_csr"):
             self._rated_sorted_csr = self.data.rated_csr().sorted_rows()

@@ -727,12 +727,17 @@ struct DeferredWork {
 static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 static inline unsigned key_bits(int64_t n_keys) { unsigned b = 1; while (((int64_t)1 << b) < n_keys) b++; return b; }
 int deferred_temp_bytes(int64_t n, int64_t n_keys, size_t *bytes) {
+    // the query walks rocPRIM's config dispatch (device properties): once per shape, not once per epoch
+    static thread_local int64_t last_n = -1, last_keys = -1;
+    static thread_local size_t last_bytes = 0;
+    if (n == last_n && n_keys == last_keys) { *bytes = last_bytes; return QREC_OK; }
     size_t tb = 0;
     const hipError_t e = rocprim::radix_sort_pairs(nullptr, tb, (const int32_t *)nullptr, (int32_t *)nullptr,
                                                    rocprim::counting_iterator<int32_t>(0), (int32_t *)nullptr, (size_t)n, 0u,
                                                    key_bits(n_keys), (hipStream_t)0);
     QREC_REQUIRE(e == hipSuccess, "qrec_bpr_deferred: rocprim::radix_sort_pairs size query failed");
     *bytes = align256(tb ? tb : 256);
+    last_n = n; last_keys = n_keys; last_bytes = *bytes;
     return QREC_OK;
 }
 int deferred_carve(void *work, int64_t n, int64_t n_keys, DeferredWork *w) {

@@ -919,6 +919,17 @@ __global__ __launch_bounds__(256, OCC) void score_filter2_kernel_f32(
 //   u^ = u (1 + d), |d| <= 2^-8 (round to nearest, 8-bit significand), same for v  =>  |u^.v^ - u.v| <= (2^-7 + 2^-16) sum |u_k v_k|
 //   <= (2^-7 + 2^-16) |u| |v|;  the fp32 accumulation inside the MFMAs adds < 64 * 2^-24 of the same sum.
 // eps[b] = 2^-7 * 1.02 * |u_b| * max_items |v| -- every item with u.v >= tau has u^.v^ >= tau - eps.
+// The budget behind the 2 %, in units of |u| |v|: the bound proper is 2^-7 = 7.8125e-3 and the slack 0.02 * 2^-7 = 1.56e-4; it
+// has to hold (i) the cross term 2^-16 = 1.5e-5, (ii) the fp32 accumulation inside and between the MFMAs, d/16 steps of
+// 2^-24 each on the running sum: <= 128 * 2^-24 = 7.6e-6 up to d = 128 -- whatever order the matrix pipe adds in, each partial
+// sum is bounded by sum |u^_k v^_k|, (iii) the candidate lists' 4-bit score tag (selection compares re-formed fp32 scores, the
+// tag only orders the bf16 ones inside a list: 15 ulp of fp32 = 1.8e-6 relative), (iv) the norms' own rounding, covered by their
+// factor 1.0001 (to_bf16_kernel).  Sum ~ 2.5e-5, a sixth of the slack.  tests/test_eval_bf16_bound.py checks the inequality
+// numerically on the CPU; tests/test_gpu_eval.py::test_bf16_filter_is_complete_on_adversarial_tables holds the hardware's own
+// accumulation to it (item and user norms over six decades, cancelling coordinates, clusters of near-ties at the threshold).
+// Non-finite tables (a diverged run -- the reference stops such a run at the loss check, iterativeRecommender.py:84-86, before
+// any evaluation): a norm is inf/NaN, tau_low = tau - inf/NaN admits nothing or everything, the user's lists come back empty or
+// overflowed and the select kernel flags the user for the exact walk -- slow, not wrong.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 // rows [rows][ld] fp32 (row_ids: gather, may be null) -> bf16 copy [rows][ld]; norm[row] = |x| (fp32); pad rows (>= rows) zero

@@ -350,6 +350,38 @@ def case_pairwise_and_adj(tmp):
                 adj_dtype=str(adj.dtype), adj_nnz=int(adj.nnz))
 
 
+def case_pointwise(tmp):
+    """base/deepRecommender.py:54-77, the other sampler of the same base class: no shuffle, per training row the positive
+    (label 1) followed by four randint negatives (label 0), redrawn while rated.  Two passes of the generator, the
+    interpreter's generator state after them."""
+    from QRec import QRec
+    from util.config import ModelConf
+    from model.ranking.LightGCN import LightGCN
+    conf = os.path.join(tmp, "lgcn_pw.conf")
+    write_conf(conf, ratings="./dataset/FilmTrust/trainset.txt", ratings__setup="-columns 0 1 2",
+               model__name="LightGCN", evaluation__setup="-testSet ./dataset/FilmTrust/testset.txt -b 1",
+               item__ranking="on -topN 20", num__factors="8", num__max__epoch="1", batch_size="1500",
+               learnRate="-init 0.001 -max 1", LightGCN="-n_layer 2",
+               reg__lambda="-u 0.001 -i 0.001 -b 0.2 -s 0.2", output__setup="off -dir ./results/")
+    random.seed(11); np.random.seed(11)
+    with redirect_stdout(io.StringIO()):
+        q = QRec(ModelConf(conf))
+        m = LightGCN(q.config, q.trainingData, q.testData)
+        m.readConfiguration()
+    train_uid = np.array([m.data.user[r[0]] for r in m.data.trainingData], dtype=np.int32)
+    train_iid = np.array([m.data.item[r[1]] for r in m.data.trainingData], dtype=np.int32)
+    batches = []
+    for ep in range(2):
+        for b in m.next_batch_pointwise():
+            batches.append(np.array(b, dtype=np.int32).T)  # [5B,3]: u, i, y
+    stream = np.concatenate(batches)
+    np.savez_compressed(os.path.join(OUT, "pointwise_filmtrust.npz"), train_uid=train_uid, train_iid=train_iid, stream=stream,
+                        batch_sizes=np.array([b.shape[0] for b in batches], dtype=np.int32),
+                        py_state=np.array(random.getstate()[1], dtype=np.uint32))
+    return dict(name="pointwise_filmtrust", seed=11, conf=open(conf).read(), n_users=len(m.data.user), n_items=len(m.data.item),
+                n_train=len(m.data.trainingData), batch_size=m.batch_size, epochs_sampled=2, stream_sha256=sha(stream))
+
+
 def case_sgl_subgraph(tmp):
     """model/ranking/SGL.py:113-155 _create_adj_mat(is_subgraph=True): node dropout (aug 0) and edge
     dropout (aug 1) sub-adjacencies, drawn with random.sample from the seeded CPython generator."""
@@ -518,7 +550,7 @@ def main():
     os.symlink(os.path.join(REF, "dataset"), os.path.join(tmp, "dataset"))
     os.chdir(tmp)
     only = sys.argv[1:]
-    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pmf, case_svd, case_ee, case_svdpp, case_pairwise_and_adj, case_sgl_subgraph, case_sept_graphs, case_tbpr_filmtrust, case_mhcn_graphs, case_loader]
+    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pmf, case_svd, case_ee, case_svdpp, case_pairwise_and_adj, case_pointwise, case_sgl_subgraph, case_sept_graphs, case_tbpr_filmtrust, case_mhcn_graphs, case_loader]
     if only:   # regenerate a subset, keep the other entries of golden_meta.json
         cases = [c for c in cases if c.__name__ in only]
         old = json.load(open(os.path.join(OUT, "golden_meta.json")))

@@ -242,3 +242,36 @@ def test_fused_route_equals_the_block_route(d, N, route, monkeypatch):
     assert np.array_equal(ids_f, ids_b) and np.array_equal(sc_f, sc_b)
     zero = np.isin(users, np.arange(3, n_users, 50))
     assert (sc_b[zero] == 0).all() and (sc_b[~zero][:, 0] != 0).any()
+
+
+@pytest.mark.parametrize("route", ["bf16", "bf16-sparse-sample"])
+@pytest.mark.parametrize("d,N", [(64, 20), (128, 10)])
+def test_bf16_filter_is_complete_on_adversarial_tables(d, N, route, monkeypatch):
+    """What the bf16 filter's bound (eval_topk.hip, eps = 2^-7 * 1.02 * |u| * max|v|) has to survive on the hardware, not in a
+    model of it: item norms spread over six decades (eps is set by the LARGEST item, the deciding scores by small ones), users
+    likewise, large cancelling coordinates (sum |u_k v_k| >> |u.v|: the rounding error is large against the score), and clusters
+    of items whose fp32 scores sit within a few ulp of each other around every user's threshold.  A candidate the filter drops
+    would change an id or a score against the block route; they have to be identical."""
+    for k, v in _FUSED_ROUTES[route].items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(17 * d + N)
+    n_users, n_items = 300, 12_000
+    V = rng.standard_normal((n_items, d))
+    V *= np.exp(rng.uniform(np.log(1e-3), np.log(1e3), n_items))[:, None]
+    U = rng.standard_normal((n_users, d)) * np.exp(rng.uniform(np.log(1e-3), np.log(1e3), n_users))[:, None]
+    # cancellation: a huge +c, -c pair of coordinates on both sides
+    U[:, 0] += 50.0 * np.abs(U).max(1); U[:, 1] = -U[:, 0] + rng.standard_normal(n_users) * 1e-3
+    V[::5, 0] = 7.0; V[::5, 1] = 7.0
+    # near-ties: 400 copies of a strong item, perturbed in the last bits of one coordinate
+    base = np.abs(rng.standard_normal(d)) + 0.5
+    for c in range(400):
+        V[2000 + c] = base; V[2000 + c, 2 + c % (d - 2)] *= 1.0 + (c // 7) * 2.0 ** -22
+    U32, V32 = U.astype(np.float32), V.astype(np.float32)
+    uu = rng.integers(0, n_users, 20 * n_users); ii = rng.integers(0, n_items, 20 * n_users)
+    rated = user_item_csr(uu, ii, np.ones(uu.size), n_users, n_items)
+    users = np.arange(n_users, dtype=np.int32)
+    ids_f, sc_f = DeviceRanker(U32, V32, rated).topk(users, N)
+    monkeypatch.setenv("QREC_EVAL_BLOCK_PATH", "1")
+    ids_b, sc_b = DeviceRanker(U32, V32, rated).topk(users, N)
+    assert np.isfinite(sc_b).all()
+    assert np.array_equal(ids_f, ids_b) and np.array_equal(sc_f, sc_b)

@@ -135,6 +135,32 @@ def test_product_pairwise_sampler_and_shuffle_reproduce_reference():
     assert np.array_equal(st, z["py_state"])
 
 
+def test_product_pointwise_sampler_reproduces_reference():
+    """base/deepRecommender.py:54-77 run by the reference itself (tests/golden/gen_golden.py::case_pointwise): two passes of the
+    class's generator -- batch boundaries, (u, i, y) rows and the interpreter's generator state afterwards."""
+    from qrec_amd.base.deepRecommender import DeepRecommender
+    meta, z = load_golden("pointwise_filmtrust")
+    train = [[f"u{a}", f"i{b}", 1.0] for a, b in zip(z["train_uid"].tolist(), z["train_iid"].tolist())]
+    with redirect_stdout(io.StringIO()):
+        m = DeepRecommender(conf_from_text(meta["conf"]), train, [])
+        m.readConfiguration()
+    assert [m.data.user[r[0]] for r in m.data.trainingData] == z["train_uid"].tolist()
+    random.seed(meta["seed"])
+    batches = []
+    for _ in range(meta["epochs_sampled"]):
+        for u_idx, i_idx, y in m.next_batch_pointwise():
+            assert isinstance(u_idx, list) and len(u_idx) == len(i_idx) == len(y)
+            batches.append(np.array([u_idx, i_idx, y], dtype=np.int32).T)
+    assert [b.shape[0] for b in batches] == z["batch_sizes"].tolist()
+    assert np.array_equal(np.concatenate(batches), z["stream"])
+    assert np.array_equal(capi.state_from_python(random.getstate()), z["py_state"])
+    # no negative is an item its user rated; five entries per row, the positive first
+    st = z["stream"].reshape(-1, 5, 3)
+    assert (st[:, 0, 2] == 1).all() and (st[:, 1:, 2] == 0).all() and (st[:, :, 0] == st[:, :1, 0]).all()
+    rated = set(zip(z["train_uid"].tolist(), z["train_iid"].tolist()))
+    assert not any((int(a), int(b)) in rated for a, b in st[:, 1:, :2].reshape(-1, 2)[:5000])
+
+
 def test_exact_sampler_edge_cases():
     st = capi.state_from_python(random.Random(3).getstate())
     # empty epoch, single item universe impossible (user positive on every item) -> error
