@@ -269,10 +269,24 @@ def main():
                     help="visiting order of the epoch's triplets in the Hogwild kernel (DESIGN.md s4)")
     ap.add_argument("--dist-mode", choices=("replicated", "sharded"), default=os.environ.get("QREC_DIST_MODE", "replicated"))
     ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("QREC_SCALING", "weak"))
-    ap.add_argument("--shard-batch", type=int, default=1 << 19, help="sharded mode: triplets per exchange batch and rank")
-    ap.add_argument("--no-shard-pipeline", action="store_true",
-                    help="sharded mode: fetch batch k + 1 only after batch k has been applied (default: under batch k's SGD kernel, on a "
-                         "second stream and communicator; one more batch of staleness)")
+    ap.add_argument("--shard-batch", type=int, default=1 << 20,
+                    help="sharded mode: triplets per exchange batch and rank (2^20: at most 2^21 distinct item rows in a rank's cache, 1 GiB at "
+                         "d = 128; an epoch of 2^19 triplets or more is split into at least two batches, so that the next epoch's plan hides "
+                         "in front of the last one)")
+    ap.add_argument("--shard-pipeline", action="store_true", default=os.environ.get("QREC_SHARD_PIPELINE") == "1",
+                    help="sharded mode: fetch batch k + 1 under batch k's SGD kernel, on a second stream and communicator (one more batch of "
+                         "staleness).  Off by default: at the Yelp2018 shape the fetch is 10 MB per batch and the gather/copy kernels "
+                         "running beside the atomic-bound SGD grid cost it more than they hide (world 1: 0.85 vs 0.75 ms/epoch, "
+                         "profiles/r03_sharded_world1.json); it is for shapes whose exchange outlasts the batch's SGD (config #4)")
+    ap.add_argument("--no-shard-pipeline", action="store_true", help="(accepted for compatibility: the default)")
+    ap.add_argument("--no-plan-inside", action="store_true",
+                    help="sharded mode: plan every epoch at its own start, with the host waiting for the stream to run dry (default: the "
+                         "next epoch's plan is enqueued in front of the current epoch's last batch, its row counts read back behind an event)")
+    ap.add_argument("--plan-ahead", action="store_true", default=os.environ.get("QREC_SHARD_PLAN_AHEAD") == "1",
+                    help="sharded mode: plan every epoch (distinct rows per owner, one host read-back, id exchange) under the PREVIOUS epoch, on "
+                         "a third stream and communicator (default: at its own start, on the training stream -- measured at world 1: the plan "
+                         "kernels running beside the atomic-bound SGD grid cost it more than the host round trip they hide, "
+                         "profiles/r03_sharded_world1.json)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_own_ranks(args.gpus)           # does not return
@@ -337,17 +351,22 @@ def main():
     tables = DeviceTables(P0, Q0_local, np.float32)
     flush_every = args.flush_every or FLUSH_EVERY
     CHUNK = balanced_chunk(n)     # triplets per work item: the count that spreads evenly over the 4,096 persistent groups
-    n_batches = qd.agree_on_batches(control, n, args.shard_batch) if sharded else 1
+    n_batches = qd.agree_on_batches(control, n, args.shard_batch, split_from=1 << 19) if sharded else 1
     sgd = BprSgd(tables, l_u, l_items, CSR(l_indptr, l_items), schedule=args.schedule, n_items=I, batches=n_batches, chunk=CHUNK)
     sampler_seed = SEED + 7919 * rank
 
     dstep = None
     if use_dist and sharded:
         pipe = None
-        if not args.no_shard_pipeline and os.environ.get("QREC_BENCH_NO_COMM") != "1":
+        if args.shard_pipeline and not args.no_shard_pipeline and os.environ.get("QREC_BENCH_NO_COMM") != "1":
             # a second communicator for the fetch stream: two collectives of ONE communicator must not be in flight on two streams
             pipe = (comm if one_device else qd.make_comm(control), capi.Stream())
-        dstep = qd.ShardedStep(comm, qd.ShardedItemExchange(comm, I, tables.ld, tables.Q, pipeline=pipe), n_batches)
+        ahead = None
+        if args.plan_ahead and os.environ.get("QREC_BENCH_NO_COMM") != "1":
+            # ... and a third one for the plan of the NEXT epoch (row counts, id exchange), which runs under the current epoch
+            ahead = (comm if one_device else qd.make_comm(control), capi.Stream())
+        dstep = qd.ShardedStep(comm, qd.ShardedItemExchange(comm, I, tables.ld, tables.Q, pipeline=pipe, plan_ahead=ahead), n_batches,
+                               plan_inside=not args.no_plan_inside)
     elif use_dist:
         dstep = qd.ReplicatedStep(comm, qd.ReplicatedTableSync(comm, tables.Q))
     # device copies of the initial state: every step restarts training from it (see step())
@@ -371,6 +390,12 @@ def main():
         sgd.take_prefetched_negatives(k, main)                      # BPR.py:35-37 (sampled under epoch k-1)
         if sharded:
             dstep.prepare(sgd, main)
+        if sharded:      # the next epoch's sampler is enqueued from inside (same place on the device: behind the start event) -- the
+            # epoch's last batch is preceded by the next epoch's plan, which waits for those negatives
+            sgd.epoch_device_async(REG_U, REG_I, MAX_LR, tol=0.0, chunk=CHUNK, variant=args.variant, stream=main, flush_every=flush_every,
+                                   events=pair, dist=dstep, after_start=lambda: sgd.prefetch_negatives_device(sampler_seed, k + 1))
+            dstep.prepare_ahead(sgd)                                # --plan-ahead: on the plan stream instead
+            return
         sgd.epoch_device_async(REG_U, REG_I, MAX_LR, tol=0.0, chunk=CHUNK, variant=args.variant, stream=main,
                                flush_every=flush_every, events=pair, dist=dstep)   # BPR.py:45-53,40 + iterativeRecommender.py:88-104
         sgd.prefetch_negatives_device(sampler_seed, k + 1)          # side stream, under the SGD kernel
@@ -502,7 +527,10 @@ def main():
                        "epoch_close": "device (no host sync inside the timed region)" if not sharded else "device; one row-count read-back per epoch for the exchange",
                        "dist_mode": args.dist_mode if use_dist else None,
                        **({"xgmi_bytes_per_epoch_all_ranks": moved, "batches_per_epoch": dstep.n_batches,
-                           "fetch_pipelined": dstep.exchange.pipeline is not None} if sharded else {})},
+                           "fetch_pipelined": dstep.exchange.pipeline is not None,
+                           "plan": ("ahead, on a plan stream" if dstep.exchange.plan_ahead is not None else
+                                    "inside the previous epoch, in front of its last batch" if dstep.plan_inside and dstep.n_batches >= 2 else
+                                    "at the epoch's start")} if sharded else {})},
             **({"multi_gpu": multi} if multi is not None else {}),
             "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -530,8 +558,9 @@ def main():
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         control.barrier()
-        if sharded and dstep.exchange.pipeline is not None and dstep.exchange.pipeline[0] is not comm:
-            dstep.exchange.pipeline[0].destroy()
+        for extra in ((dstep.exchange.pipeline, dstep.exchange.plan_ahead) if sharded else ()):
+            if extra is not None and extra[0] is not comm:
+                extra[0].destroy()
         if comm is not None:
             comm.destroy()
         control.shutdown()

@@ -54,6 +54,12 @@ int qrec_free(void *d_ptr);
 int qrec_memcpy_h2d(void *d_dst, const void *h_src, int64_t bytes, void *stream);
 int qrec_memcpy_d2h(void *h_dst, const void *d_src, int64_t bytes, void *stream);
 int qrec_memcpy_d2d(void *d_dst, const void *d_src, int64_t bytes, void *stream);
+/* Page-locked host memory and a device-to-host copy into it that only ENQUEUES (qrec_memcpy_d2h returns after the copy, i.e.
+ * drains the stream): the host reads h_pinned after an event recorded behind the copy.  For the small read-backs a run-ahead
+ * host needs while the stream carries on (the row counts of a sharded exchange plan, qrec_amd/dist.py). */
+int qrec_host_alloc(int64_t bytes, void **h_ptr);
+int qrec_host_free(void *h_ptr);
+int qrec_memcpy_d2h_async(void *h_pinned, const void *d_src, int64_t bytes, void *stream);
 int qrec_memset(void *d_dst, int byte, int64_t bytes, void *stream);
 int qrec_stream_create(void **stream);
 int qrec_stream_destroy(void *stream);

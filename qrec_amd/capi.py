@@ -31,6 +31,9 @@ _SIGNATURES = {
     "qrec_memcpy_h2d": [_vp, _vp, _i64, _vp],
     "qrec_memcpy_d2h": [_vp, _vp, _i64, _vp],
     "qrec_memcpy_d2d": [_vp, _vp, _i64, _vp],
+    "qrec_host_alloc": [_i64, _vp],
+    "qrec_host_free": [_vp],
+    "qrec_memcpy_d2h_async": [_vp, _vp, _i64, _vp],
     "qrec_memset": [_vp, C.c_int, _i64, _vp],
     "qrec_stream_create": [_vp],
     "qrec_stream_destroy": [_vp],
@@ -652,6 +655,34 @@ def epoch_sums(d_P, p_rows: int, d_Q, q_rows: int, dtype: int, ld: int, d_stats,
 
 def epoch_sum_table(d_X, rows: int, dtype: int, ld: int, d_stats, slot: int, d_state=None, stream=None):
     _check(load().qrec_epoch_sum_table(_dp(d_X), rows, dtype, ld, _dp(d_stats), slot, _dp(d_state), _sh(stream)))
+
+
+class PinnedBuffer:
+    """page-locked host array (qrec_host_alloc); ``a`` is a numpy view of it"""
+
+    def __init__(self, n: int, dtype):
+        ensure_init()
+        self.dtype = np.dtype(dtype)
+        self.nbytes = max(int(n), 1) * self.dtype.itemsize
+        h = C.c_void_p()
+        _check(load().qrec_host_alloc(self.nbytes, C.byref(h)))
+        self.ptr = h.value
+        self.a = np.frombuffer((C.c_char * self.nbytes).from_address(self.ptr), dtype=self.dtype)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                self.a = None
+                load().qrec_host_free(C.c_void_p(self.ptr)); self.ptr = None
+        except Exception:       # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+def memcpy_d2h_async(pinned: PinnedBuffer, src, nbytes: int, stream=None):
+    """device -> page-locked host buffer, enqueue only: read ``pinned.a`` after an event recorded behind this call"""
+    if nbytes > pinned.nbytes:
+        raise ValueError("memcpy_d2h_async: pinned buffer too small")
+    _check(load().qrec_memcpy_d2h_async(C.c_void_p(pinned.ptr), _dp(src), nbytes, _sh(stream)))
 
 
 def memcpy_d2h(host: np.ndarray, src, nbytes: int, stream=None):

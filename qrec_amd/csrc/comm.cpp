@@ -164,6 +164,10 @@ int qrec_comm_init(int32_t world, int32_t rank, const uint8_t *h_uid, void **com
         delete c;
         return QREC_ERR_HIP;
     }
+    // RCCL's own set-up may leave a (harmless, handled) HIP error as the thread's "last error" -- seen under rocprofv3:
+    // "invalid device symbol" -- which this library's launch checks (hipGetLastError after a launch) would then report
+    // as theirs.  Read it away.
+    (void)hipGetLastError();
     *comm = c;
     return QREC_OK;
 }

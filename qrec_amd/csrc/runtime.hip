@@ -79,6 +79,24 @@ int qrec_memcpy_d2h(void *h, const void *d, int64_t bytes, void *stream) {
     QREC_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
     return QREC_OK;
 }
+// page-locked host memory + a device-to-host copy that only enqueues: small read-backs (row counts of an exchange plan) that the
+// host picks up behind an event while the stream carries on
+int qrec_host_alloc(int64_t bytes, void **h_ptr) {
+    QREC_REQUIRE(h_ptr && bytes > 0, "qrec_host_alloc: bad arguments");
+    *h_ptr = nullptr;
+    QREC_HIP_CHECK(hipHostMalloc(h_ptr, (size_t)bytes, hipHostMallocDefault));
+    return QREC_OK;
+}
+int qrec_host_free(void *h_ptr) {
+    if (h_ptr) QREC_HIP_CHECK(hipHostFree(h_ptr));
+    return QREC_OK;
+}
+int qrec_memcpy_d2h_async(void *h_pinned, const void *d, int64_t bytes, void *stream) {
+    if (bytes == 0) return QREC_OK;
+    QREC_REQUIRE(d && h_pinned && bytes > 0, "qrec_memcpy_d2h_async: bad arguments");
+    QREC_HIP_CHECK(hipMemcpyAsync(h_pinned, d, (size_t)bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    return QREC_OK;
+}
 int qrec_memcpy_d2d(void *dst, const void *src, int64_t bytes, void *stream) {
     if (bytes == 0) return QREC_OK;
     QREC_REQUIRE(dst && src && bytes > 0, "qrec_memcpy_d2d: bad arguments");

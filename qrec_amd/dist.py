@@ -225,13 +225,14 @@ class ShardedItemExchange:
     owners still add ``returned - sent`` of every batch.  The second communicator exists because two collectives of one
     communicator must not be in flight on two streams."""
 
-    def __init__(self, comm, n_items: int, ld: int, q_local, kern=_capi, pipeline=None):
+    def __init__(self, comm, n_items: int, ld: int, q_local, kern=_capi, pipeline=None, plan_ahead=None):
         self.comm, self.k = comm, kern
         self.world, self.rank = comm.world, comm.rank
         self.n_items, self.ld, self.q_local = int(n_items), int(ld), q_local
         self.rows_local = kern.shard_rows(self.n_items, self.world, self.rank)
         self._cap = {}
         self._scratch_batches = 0
+        self._uploaded = {}
         self.n = self.n_batches = 0
         self.bounds = self.send = self.recv = self.req_off = self.in_off = None
         self.bytes_moved = 0
@@ -241,6 +242,16 @@ class ShardedItemExchange:
             ev = kern.Event
             self.ev_fetched, self.ev_gathered, self.ev_free = [ev(), ev()], [ev(), ev()], [ev(), ev()]
             self.ev_epoch_start = ev()
+        # ``plan_ahead`` = (third communicator, plan stream), round 3: the plan of epoch k + 1 -- it depends on nothing but that
+        # epoch's negatives, which the sampler draws under epoch k -- runs on the plan stream under epoch k, its one host read-back
+        # and its id exchange included; the training stream only waits for an event.  Plan buffers alternate between two slots.
+        self.plan_ahead = plan_ahead
+        self._slot, self._ahead = 0, None
+        self._pinned, self._counted = {}, {}
+        if plan_ahead is not None:
+            self.comm_p, self.stream_p = plan_ahead
+            self.ev_planned = [kern.Event(), kern.Event()]
+            self.ev_plan_free = [None, None]        # recorded on the training stream after the last reader of a slot's id arrays
 
     def _buf(self, name: str, elems: int, dtype):
         """grow-only device buffer"""
@@ -249,65 +260,136 @@ class ShardedItemExchange:
             b = self._cap[name] = self.k.DeviceBuffer(max(int(elems * 1.25), 1), dtype)
         return b
 
-    def plan_epoch(self, d_i, d_j, n: int, n_batches: int, stream=None, bounds=None):
-        """``bounds``: the batches' triplet ranges (n_batches + 1 offsets); default = equal consecutive ranges"""
+    def _const(self, name: str, values: np.ndarray, stream):
+        """small host array kept on the device; uploaded again only when its contents change (qrec_memcpy_h2d returns after
+        the copy, i.e. it drains the stream: two of them per epoch kept the host from ever running ahead of the device)"""
+        values = np.ascontiguousarray(values)
+        d = self._buf(name, values.size, values.dtype)
+        old = self._uploaded.get(name)
+        if old is None or old[0] is not d or not np.array_equal(old[1], values):
+            self.k.memcpy_h2d(d, values, values.nbytes, stream)        # (returns after the copy: the host array is borrowed)
+            self._uploaded[name] = (d, values.copy())
+        return d
+
+    def _plan_begin(self, d_i, d_j, n: int, n_batches: int, bounds, comm, stream, slot: int):
+        """the device part of a plan, enqueued on (comm, stream) into the buffers of ``slot``: distinct rows per owner and batch,
+        triplet ids rewritten to cache slots, the counts of every rank gathered and on their way to page-locked host memory,
+        an event behind that copy.  Returns the plan's description so far."""
         k, G = self.k, self.world
-        self.n, self.n_batches = int(n), int(n_batches)
-        nb = self.n_batches
-        per = -(-self.n // nb) if self.n else 0
-        self.bounds = [int(x) for x in bounds] if bounds is not None else [min(b * per, self.n) for b in range(nb + 1)]
-        if len(self.bounds) != nb + 1 or self.bounds[0] != 0 or self.bounds[-1] != self.n:
+        n, nb = int(n), int(n_batches)
+        per = -(-n // nb) if n else 0
+        bounds = [int(x) for x in bounds] if bounds is not None else [min(b * per, n) for b in range(nb + 1)]
+        if len(bounds) != nb + 1 or bounds[0] != 0 or bounds[-1] != n:
             raise ValueError("plan_epoch: bounds must run from 0 to n in n_batches steps")
-        caps = [min(2 * (self.bounds[b + 1] - self.bounds[b]), self.n_items) for b in range(nb)]
-        self.req_off = np.concatenate([[0], np.cumsum(caps)]).astype(np.int64)
-        d_req = self._buf("req", int(self.req_off[-1]), np.int32)
-        d_ci, d_cj = self._buf("ci", self.n, np.int32), self._buf("cj", self.n, np.int32)
-        d_counts = self._buf("counts", nb * G, np.int32)
-        d_all = self._buf("all_counts", nb * G * G, np.int32)
+        caps = [min(2 * (bounds[b + 1] - bounds[b]), self.n_items) for b in range(nb)]
+        req_off = np.concatenate([[0], np.cumsum(caps)]).astype(np.int64)
+        sfx = f"@{slot}"
+        d_req = self._buf("req" + sfx, int(req_off[-1]), np.int32)
+        d_ci, d_cj = self._buf("ci" + sfx, n, np.int32), self._buf("cj" + sfx, n, np.int32)
+        d_counts = self._buf("counts" + sfx, nb * G, np.int32)
+        d_all = self._buf("all_counts" + sfx, nb * G * G, np.int32)
         if self._scratch_batches < nb:
             self._cap["scratch"] = k.DeviceBuffer(k.shard_plan_epoch_scratch_bytes(self.n_items, G, nb), np.uint8)
             self._scratch_batches = nb
-        d_bounds = self._buf("bounds", nb + 1, np.int64); d_roff = self._buf("req_off", nb + 1, np.int64)
-        k.memcpy_h2d(d_bounds, np.array(self.bounds, np.int64), 8 * (nb + 1), stream)
-        k.memcpy_h2d(d_roff, self.req_off, 8 * (nb + 1), stream)
-        k.shard_plan_epoch(d_i, d_j, d_bounds, nb, self.n, self.n_items, G, self._cap["scratch"], d_req, d_roff, d_counts, d_ci, d_cj, stream)
-        self.comm.allgather(d_counts, d_all, nb * G, k.I32, stream)
-        counts = d_all.head(G * nb * G, stream).reshape(G, nb, G)      # the epoch's one host sync
-        self.send = counts[self.rank].astype(np.int64)                   # [batch][owner]: rows I ask of each owner
-        self.recv = counts[:, :, self.rank].T.astype(np.int64).copy()    # [batch][peer]:  rows each peer asks of me
-        in_rows = self.recv.sum(1)
-        self.in_off = np.concatenate([[0], np.cumsum(in_rows)]).astype(np.int64)
-        r_in, r_out = int(in_rows.max(initial=0)), int(self.send.sum(1).max(initial=0))
-        d_req_in = self._buf("req_in", int(self.in_off[-1]), np.int32)
+        d_bounds = self._const("bounds", np.array(bounds, np.int64), stream)
+        d_roff = self._const("req_off", req_off, stream)
+        k.shard_plan_epoch(d_i, d_j, d_bounds, nb, n, self.n_items, G, self._cap["scratch"], d_req, d_roff, d_counts, d_ci, d_cj, stream)
+        comm.allgather(d_counts, d_all, nb * G, k.I32, stream)
+        pin = self._pinned.get(slot)
+        if pin is None or pin.nbytes < 4 * nb * G * G:
+            pin = self._pinned[slot] = k.PinnedBuffer(nb * G * G, np.int32)
+            self._counted[slot] = k.Event()
+        k.memcpy_d2h_async(pin, d_all, 4 * nb * G * G, stream)
+        self._counted[slot].record(stream)
+        return dict(n=n, n_batches=nb, bounds=bounds, req_off=req_off, slot=slot, d_j=d_j, finished=False)
+
+    def _plan_finish(self, plan, comm, stream):
+        """the host part: wait for the counts (the plan's one host synchronisation -- of the copy's event, not of the stream),
+        size the exchanges, ship the request ids of ALL batches to their owners in one fused launch on (comm, stream)"""
+        k, G, nb, slot = self.k, self.world, plan["n_batches"], plan["slot"]
+        self._counted[slot].sync()
+        counts = self._pinned[slot].a[:G * nb * G].reshape(G, nb, G)
+        send = counts[self.rank].astype(np.int64)                        # [batch][owner]: rows I ask of each owner
+        recv = counts[:, :, self.rank].T.astype(np.int64).copy()         # [batch][peer]:  rows each peer asks of me
+        in_off = np.concatenate([[0], np.cumsum(recv.sum(1))]).astype(np.int64)
+        d_req, d_req_in = self._cap[f"req@{slot}"], self._buf(f"req_in@{slot}", int(in_off[-1]), np.int32)
+        sends, recvs = [], []       # for every (batch, peer) one send and one receive, both sides in batch order
+        for b in range(nb):
+            so, ro = int(plan["req_off"][b]), int(in_off[b])
+            for p in range(G):
+                sends.append((p, 4 * so, 4 * int(send[b, p]))); so += int(send[b, p])
+                recvs.append((p, 4 * ro, 4 * int(recv[b, p]))); ro += int(recv[b, p])
+        comm.sendrecv_segments(d_req, sends, d_req_in, recvs, stream)
+        plan.update(send=send, recv=recv, in_off=in_off, finished=True)
+        return plan
+
+    def _plan(self, d_i, d_j, n: int, n_batches: int, bounds, comm, stream, slot: int):
+        return self._plan_finish(self._plan_begin(d_i, d_j, n, n_batches, bounds, comm, stream, slot), comm, stream)
+
+    def _adopt(self, plan):
+        """make ``plan`` the epoch ``run_epoch`` runs; size the row buffers for it"""
+        self.n, self.n_batches, self.bounds = plan["n"], plan["n_batches"], plan["bounds"]
+        self.req_off, self.send, self.recv, self.in_off = plan["req_off"], plan["send"], plan["recv"], plan["in_off"]
+        self._slot = plan["slot"]
+        r_in, r_out = int(self.recv.sum(1).max(initial=0)), int(self.send.sum(1).max(initial=0))
         copies = 2 if self.pipeline is not None else 1
         for c in range(copies):
             self._buf(f"rows_out{c}", r_in * self.ld, np.float32); self._buf(f"cache{c}", r_out * self.ld, np.float32)
         self._buf("rows_ret", r_in * self.ld, np.float32)
-        # the request ids of ALL batches in one fused launch: for every (batch, peer) one send and one receive, both sides in batch order
-        sends, recvs = [], []
-        for b in range(nb):
-            so, ro = int(self.req_off[b]), int(self.in_off[b])
-            for p in range(G):
-                sends.append((p, 4 * so, 4 * int(self.send[b, p]))); so += int(self.send[b, p])
-                recvs.append((p, 4 * ro, 4 * int(self.recv[b, p]))); ro += int(self.recv[b, p])
-        self.comm.sendrecv_segments(d_req, sends, d_req_in, recvs, stream)
+
+    def plan_epoch(self, d_i, d_j, n: int, n_batches: int, stream=None, bounds=None):
+        """``bounds``: the batches' triplet ranges (n_batches + 1 offsets); default = equal consecutive ranges.
+        With a plan made ahead for exactly these negatives (``plan_epoch_ahead``) this only makes ``stream`` wait for it."""
+        ahead, self._ahead = self._ahead, None
+        if ahead is not None and ahead["d_j"] is d_j and ahead["n"] == int(n) and ahead["n_batches"] == int(n_batches):
+            if ahead["finished"]:        # made on the plan stream (plan_epoch_ahead)
+                self.k.stream_wait_event(stream, self.ev_planned[ahead["slot"]])
+            else:                        # begun inside the previous epoch, on this stream (run_epoch(next_epoch=...)): its counts are on
+                self._plan_finish(ahead, self.comm, stream)       # the host long before the stream runs dry
+            self._adopt(ahead)
+            return
+        if ahead is not None:            # a plan for other negatives: its stream work must not outlive its buffers' next use
+            (self.ev_planned[ahead["slot"]] if ahead["finished"] else self._counted[ahead["slot"]]).sync()
+        # the slot that no plan in flight can be using
+        self._adopt(self._plan(d_i, d_j, n, n_batches, bounds, self.comm, stream, self._slot ^ 1))
+
+    def plan_epoch_ahead(self, d_i, d_j_next, n: int, n_batches: int, after, bounds=None):
+        """Plan the NEXT epoch from its negatives ``d_j_next`` on the plan stream: ``after`` = the event recorded behind the sampler
+        that draws them.  Blocks the host until that plan's row counts are known -- the device meanwhile runs the current epoch --
+        and leaves the plan for the ``plan_epoch`` call of the next epoch."""
+        if self.plan_ahead is None:
+            raise RuntimeError("ShardedItemExchange was built without plan_ahead=(communicator, stream)")
+        slot = self._slot ^ 1
+        P = self.stream_p
+        self.k.stream_wait_event(P, after)
+        if self.ev_plan_free[slot] is not None:      # the epoch that last trained from this slot's id arrays
+            self.k.stream_wait_event(P, self.ev_plan_free[slot])
+        self._ahead = self._plan(d_i, d_j_next, n, n_batches, bounds, self.comm_p, P, slot)
+        self.ev_planned[slot].record(P)
 
     def _fetch(self, b, comm, stream):
         """owners answer batch b: gather the requested rows, ship them to the requesters' cache (buffer b % copies)"""
         k, c, ld = self.k, self._cap, self.ld
         cp = b & 1 if self.pipeline is not None else 0
         n_in = int(self.recv[b].sum())
-        k.gather_rows(self.q_local, ld, k.device_ptr(c["req_in"]) + 4 * int(self.in_off[b]), n_in, c[f"rows_out{cp}"], stream)
+        k.gather_rows(self.q_local, ld, k.device_ptr(c[f"req_in@{self._slot}"]) + 4 * int(self.in_off[b]), n_in, c[f"rows_out{cp}"], stream)
         if self.pipeline is not None:
             self.ev_gathered[cp].record(stream)
         comm.alltoall_rows(c[f"rows_out{cp}"], self.recv[b], c[f"cache{cp}"], self.send[b], ld * 4, stream)
         return cp
 
-    def run_epoch(self, sgd_batch, stream=None):
+    def run_epoch(self, sgd_batch, stream=None, next_epoch=None):
         """``sgd_batch(t0, n, d_cache, cache_rows, ci_ptr, cj_ptr, stream)`` trains triplets [t0, t0+n) whose item ids
-        are rows of ``d_cache`` (addresses of the rewritten id arrays are passed)."""
+        are rows of ``d_cache`` (addresses of the rewritten id arrays are passed).
+
+        ``next_epoch`` = dict(d_i, d_j, n, n_batches, bounds, after) -- the NEXT epoch's triplets, ``after`` the event behind the
+        sampler that draws its negatives (round 3): the device part of that epoch's plan is enqueued on ``stream`` in front of
+        this epoch's LAST batch, so that its row counts reach the host while that batch still trains and the next
+        ``plan_epoch`` finds them there -- the host never waits for the stream to run dry, and no plan kernel runs beside an SGD
+        grid (which costs the atomic-bound grid more than it hides: profiles/r03_sharded_world1.json).  Epochs of one batch
+        have no "in front of the last batch" that the sampler could be ready for; they plan at their own start."""
         k, c, ld = self.k, self._cap, self.ld
-        ci, cj = k.device_ptr(c["ci"]), k.device_ptr(c["cj"])
+        ci, cj = k.device_ptr(c[f"ci@{self._slot}"]), k.device_ptr(c[f"cj@{self._slot}"])
         piped = self.pipeline is not None
         if piped:
             F = self.stream_f
@@ -318,6 +400,12 @@ class ShardedItemExchange:
             t0, nb = self.bounds[b], self.bounds[b + 1] - self.bounds[b]
             S, R = self.send[b], self.recv[b]
             n_out, n_in = int(S.sum()), int(R.sum())
+            ne = None
+            if next_epoch is not None and b == self.n_batches - 1 and b >= 1:
+                ne = next_epoch() if callable(next_epoch) else next_epoch     # (callable: asked only now -- the sampler it waits for was enqueued by the first batch)
+            if ne is not None:
+                k.stream_wait_event(stream, ne["after"])
+                self._ahead = self._plan_begin(ne["d_i"], ne["d_j"], ne["n"], ne["n_batches"], ne.get("bounds"), self.comm, stream, self._slot ^ 1)
             if piped:
                 cp = b & 1
                 if b + 1 < self.n_batches:      # the next batch's fetch goes out now, into the other buffer (free once batch b - 1 was applied)
@@ -333,11 +421,15 @@ class ShardedItemExchange:
             self.comm.alltoall_rows(cache, S, c["rows_ret"], R, ld * 4, stream)                          # rows -> owners
             if piped and b + 1 < self.n_batches:
                 k.stream_wait_event(stream, self.ev_gathered[(b + 1) & 1])     # batch b + 1 was gathered BEFORE batch b is applied
-            k.scatter_add_row_deltas(self.q_local, ld, k.device_ptr(c["req_in"]) + 4 * int(self.in_off[b]), n_in, c["rows_ret"], rows_out, stream)
+            k.scatter_add_row_deltas(self.q_local, ld, k.device_ptr(c[f"req_in@{self._slot}"]) + 4 * int(self.in_off[b]), n_in, c["rows_ret"], rows_out, stream)
             if piped:
                 self.ev_free[cp].record(stream)
             off = n_out - int(S[self.rank])
             self.bytes_moved += off * (4 + 2 * ld * 4)        # what left this rank for other ranks
+        if self.plan_ahead is not None:       # this slot's id arrays are free for the plan after next once the stream gets here
+            if self.ev_plan_free[self._slot] is None:
+                self.ev_plan_free[self._slot] = k.Event()
+            self.ev_plan_free[self._slot].record(stream)
 
 
 class ReplicatedStep:
@@ -354,17 +446,31 @@ class ShardedStep:
     ``prepare`` (after the epoch's negatives are on the device, before ``epoch_device_async``) plans the epoch."""
     mode = "sharded"
 
-    def __init__(self, comm, exchange: ShardedItemExchange, n_batches: int):
-        self.comm, self.exchange, self.n_batches = comm, exchange, int(n_batches)
+    def __init__(self, comm, exchange: ShardedItemExchange, n_batches: int, plan_inside: bool = True):
+        self.comm, self.exchange, self.n_batches, self.plan_inside = comm, exchange, int(n_batches), bool(plan_inside)
 
     def prepare(self, sgd, stream=None):
         self.exchange.plan_epoch(sgd.d_i, sgd.d_j, sgd.n, self.n_batches, stream, bounds=sgd.batch_bounds)
 
+    def prepare_ahead(self, sgd):
+        """after ``sgd.prefetch_negatives_device``: plan the next epoch from the negatives being drawn (no-op without plan_ahead)"""
+        if self.exchange.plan_ahead is not None:
+            self.exchange.plan_epoch_ahead(sgd.d_i, sgd.d_j_next, sgd.n, self.n_batches, sgd._sampled, bounds=sgd.batch_bounds)
 
-def agree_on_batches(control: ControlPlane, n_local: int, batch: int) -> int:
-    """batches per epoch such that no rank's batch exceeds ``batch`` triplets (the rank with the most triplets decides)"""
+    def next_epoch(self, sgd):
+        """what ``run_epoch(next_epoch=...)`` needs, when the next epoch's negatives are being drawn already and no plan stream is in use"""
+        if self.exchange.plan_ahead is not None or getattr(sgd, "_prefetched_epoch", None) is None or not self.plan_inside:
+            return None
+        return dict(d_i=sgd.d_i, d_j=sgd.d_j_next, n=sgd.n, n_batches=self.n_batches, bounds=sgd.batch_bounds, after=sgd._sampled)
+
+
+def agree_on_batches(control: ControlPlane, n_local: int, batch: int, split_from: int = 0) -> int:
+    """batches per epoch such that no rank's batch exceeds ``batch`` triplets (the rank with the most triplets decides);
+    ``split_from`` > 0: at least two batches once that rank holds ``split_from`` triplets -- with two or more batches the next
+    epoch's plan hides in front of the last one (``ShardedItemExchange.run_epoch``)"""
     n_max = int(control.allreduce_host(np.array([n_local], dtype=np.int64), op="max")[0])
-    return max(1, -(-n_max // max(int(batch), 1)))
+    nb = max(1, -(-n_max // max(int(batch), 1)))
+    return max(nb, 2) if split_from and n_max >= split_from else nb
 
 
 # ---- graph models (LightGCN / NGCF / SimGCL ...) ---------------------------------------------------------------------

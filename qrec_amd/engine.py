@@ -339,15 +339,19 @@ class BprSgd:
         self.d_log = DeviceBuffer.zeros((max(log_capacity, 1), capi.DRV_LOG_WORDS), np.float64)
         self._log_capacity = log_capacity
         self._own_events = [capi.Event() for _ in range(4)]
+        self._grid_events = [capi.Event(), capi.Event()]
         self.d_stats.fill_bytes(0)
 
     def epoch_device_async(self, regU: float, regI: float, max_lr: float, tol: float = 1e-3, chunk: int = 32,
                            variant: int = capi.HW_DEFAULT, stream=None, groups: int = 0, flush_every: int = 16,
-                           events=None, dist=None):
+                           events=None, dist=None, after_start=None):
         """One throughput epoch with everything after it (BPR.py:40 loss terms, isConverged,
         updateLearningRate) enqueued on the device: no host synchronisation.  ``events`` = (before, after)
         capi.Event pair recorded around the SGD kernel.  ``dist`` (one process per GPU, qrec_amd/dist.py): a
-        ``ReplicatedStep`` or ``ShardedStep`` -- the collectives are enqueued on the same stream, between the kernels."""
+        ``ReplicatedStep`` or ``ShardedStep`` -- the collectives are enqueued on the same stream, between the kernels.
+        ``after_start``: called once the event that releases the next epoch's sampler is recorded (in front of the epoch's first
+        SGD grid) -- the place to enqueue that sampler (``prefetch_negatives_device``) when something inside this epoch is to
+        wait for it: the sharded layout plans the next epoch in front of this epoch's last batch."""
         if self.d_drv is None:
             raise RuntimeError("call start_device_driver() first")
         t = self.t
@@ -359,9 +363,23 @@ class BprSgd:
         start.record(stream)
         self._sgd_start = start
         if dist is not None and dist.mode == "sharded":
-            dist.exchange.run_epoch(lambda t0, nb, cache, rows, ci, cj, st: self._launch_sgd(
-                t.P, cache, self.d_u.ptr + 4 * t0, ci, cj, nb, chunk, groups, flush_every, regU, regI, variant, st, q_rows=rows), stream)
+            # the first batch's SGD grid comes behind its fetch (gather, exchange): the sampler must not be released by the epoch's
+            # start event -- it would sit on the CUs when the grid arrives (the 30% case above; measured again in round 3, 0.83 vs
+            # 0.79 ms/epoch) -- but by one recorded right in front of that grid
+            pending = [after_start]
+
+            def batch(t0, nb, cache, rows, ci, cj, st):
+                if pending[0] is not None:
+                    grid = self._grid_events[0]; self._grid_events.reverse()
+                    grid.record(st); self._sgd_start = grid
+                    pending[0](); pending[0] = None
+                self._launch_sgd(t.P, cache, self.d_u.ptr + 4 * t0, ci, cj, nb, chunk, groups, flush_every, regU, regI, variant, st, q_rows=rows)
+            dist.exchange.run_epoch(batch, stream, next_epoch=(lambda: dist.next_epoch(self)))
+            if pending[0] is not None:       # a rank without triplets
+                pending[0]()
         else:
+            if after_start is not None:
+                after_start()
             self._launch_sgd(t.P, t.Q, self.d_u, self.d_i, self.d_j, self.n, chunk, groups, flush_every, regU, regI, variant, stream)
         end.record(stream)
         self._consumed[0] = end

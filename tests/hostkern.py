@@ -43,6 +43,15 @@ def _view(x, count, dtype):
     return np.frombuffer(buf, dtype=dtype, count=count)
 
 
+class PinnedBuffer:
+    def __init__(self, n, dtype):
+        self.a = np.zeros(max(int(n), 1), dtype); self.nbytes = self.a.nbytes
+
+
+def memcpy_d2h_async(pinned, src, nbytes, stream=None):
+    pinned.a.view(np.uint8)[:nbytes] = _view(src, nbytes, np.uint8)
+
+
 def memcpy_d2h(host, src, nbytes, stream=None):
     host.view(np.uint8).ravel()[:nbytes] = _view(src, nbytes, np.uint8)
 
@@ -104,6 +113,9 @@ def shard_plan_epoch(d_i, d_j, d_bounds, n_batches, n, n_items, world, d_scratch
 class Event:
     """host emulation: every "enqueue" has already happened when it returns, so events order nothing"""
     def record(self, stream=None):
+        pass
+
+    def sync(self):
         pass
 
 

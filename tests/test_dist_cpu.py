@@ -142,41 +142,58 @@ def _rank_users(n_users, world, rank, same_users):
     return (0, n_users) if same_users else user_block(n_users, world, rank)
 
 
-def _sharded_worker(rank, world, port, out, same_users=False, pipeline=False):
+def _sharded_worker(rank, world, port, out, same_users=False, pipeline=False, plan_ahead=False):
     control, comm = _join(rank, world, port)
     d, indptr, ind, P0, Q0 = _problem()
     I = d["n_items"]
     lo, hi = _rank_users(d["n_users"], world, rank, same_users)
     q_local = HK.DeviceBuffer.from_numpy(_pad(qd.shard_item_rows(Q0, world, rank)))
-    ex = qd.ShardedItemExchange(comm, I, LD, q_local, kern=HK, pipeline=(comm, None) if pipeline else None)
+    ex = qd.ShardedItemExchange(comm, I, LD, q_local, kern=HK, pipeline=(comm, None) if pipeline else None,
+                                plan_ahead=(comm, None) if plan_ahead == "ahead" else None)
     assert ex.rows_local == q_local.a.shape[0]
     P = P0[lo:hi].copy()
-    for step in range(2):
+    steps = []
+    for step in range(3 if plan_ahead else 2):
         u, li, j = _shard(indptr, ind, lo, hi, I, 100 * step + rank)
         if rank == 1 and step == 1:            # ragged: this rank runs out of triplets before the others do
             u, li, j = u[:5], li[:5], j[:5]
-        d_i, d_j = HK.DeviceBuffer.from_numpy(li), HK.DeviceBuffer.from_numpy(j)
-        ex.plan_epoch(d_i, d_j, u.size, N_BATCHES)
+        steps.append((u, HK.DeviceBuffer.from_numpy(li), HK.DeviceBuffer.from_numpy(j)))
+    for step, (u, d_i, d_j) in enumerate(steps):
+        ex.plan_epoch(d_i, d_j, u.size, N_BATCHES)          # plan_ahead: adopts the plan made under / inside the previous epoch
+        assert ex._slot == (step + 1) % 2                   # the plans alternate between the two slots
+        nxt = None
+        if plan_ahead and step + 1 < len(steps):
+            un, d_in, d_jn = steps[step + 1]
+            if plan_ahead == "ahead":                       # (on the device this is enqueued behind run_epoch; the host emulation has no "behind")
+                ex.plan_epoch_ahead(d_in, d_jn, un.size, N_BATCHES, HK.Event())
+            else:                                           # "inside": begun by run_epoch in front of its last batch, finished by the next plan_epoch
+                nxt = dict(d_i=d_in, d_j=d_jn, n=un.size, n_batches=N_BATCHES, after=HK.Event())
 
         def sgd_batch(t0, nb, cache, rows, ci, cj, stream):
             c = HK._view(cache, rows * LD, np.float32).reshape(rows, LD)
             _sgd_on(P, c, u[t0:t0 + nb], HK._view(ci, nb, np.int32), HK._view(cj, nb, np.int32))
-        ex.run_epoch(sgd_batch)
+        ex.run_epoch(sgd_batch, next_epoch=nxt)
+        if nxt is not None:
+            assert ex._ahead is not None and not ex._ahead["finished"] and ex._ahead["slot"] != ex._slot
     out[rank] = (lo, hi, P, q_local.a.copy(), ex.bytes_moved)
     control.shutdown()
 
 
-@pytest.mark.parametrize("same_users,pipeline", [(False, False), (True, False), (False, True), (True, True)])
-def test_two_rank_sharded_item_table_equals_definition(same_users, pipeline):
+@pytest.mark.parametrize("same_users,pipeline,plan_ahead", [(False, False, ""), (True, False, ""), (False, True, ""), (True, True, ""),
+                                                             (False, False, "ahead"), (True, True, "ahead"), (False, False, "inside"), (True, True, "inside")])
+def test_two_rank_sharded_item_table_equals_definition(same_users, pipeline, plan_ahead):
     """``pipeline``: the fetch of batch b + 1 is issued under batch b's SGD, ordered after the owners applied batch b - 1 and before
-    they apply batch b -- a batch sees the table as of TWO batches back inside an epoch (everything at an epoch's start)."""
+    they apply batch b -- a batch sees the table as of TWO batches back inside an epoch (everything at an epoch's start).
+    ``plan_ahead``: every epoch's plan (distinct rows, id exchange) is made one epoch early, into the other slot of the plan
+    buffers -- "ahead": all of it, on a plan stream / communicator; "inside": its device part in front of the previous epoch's
+    last batch, its host part by the epoch's own ``plan_epoch`` -- which changes when the plan is computed, not what the epoch does."""
     world = 2
     mgr = mp.Manager(); out = mgr.dict()
-    mp.spawn(_sharded_worker, args=(world, _free_port(), out, same_users, pipeline), nprocs=world, join=True)
+    mp.spawn(_sharded_worker, args=(world, _free_port(), out, same_users, pipeline, plan_ahead), nprocs=world, join=True)
     d, indptr, ind, P0, Q0 = _problem()
     I = d["n_items"]
     Q = _pad(Q0); Pr_all = [P0.copy() for _ in range(world)]       # weak layout: every rank its own copy of the user rows
-    for step in range(2):
+    for step in range(3 if plan_ahead else 2):
         work = []
         for r in range(world):
             lo, hi = _rank_users(d["n_users"], world, r, same_users)

@@ -355,21 +355,26 @@ def test_row_partitioned_simgcl_step_equals_the_single_gpu_step(world, layers, e
     assert covered == N and not np.allclose(E_one[:nu], U0)
 
 
-@pytest.mark.parametrize("pipeline", [False, True])
+@pytest.mark.parametrize("pipeline,plan_ahead", [(False, ""), (True, ""), (False, "ahead"), (True, "ahead"), (False, "inside"), (True, "inside")])
 @pytest.mark.parametrize("world,n_batches,dim,same_users", [(2, 3, 16, False), (3, 2, 64, False), (1, 2, 16, False), (2, 4, 64, True)])
-def test_sharded_item_table_with_logical_ranks_equals_the_definition(world, n_batches, dim, same_users, pipeline):
+def test_sharded_item_table_with_logical_ranks_equals_the_definition(world, n_batches, dim, same_users, pipeline, plan_ahead):
     """ShardedItemExchange + the real kernels, G logical ranks on one device.  The SGD kernel runs with ONE group, where
     it is the sequential recurrence, so the whole protocol is deterministic and comparable to the oracle.  ``same_users``:
     the weak-scaling layout -- every rank its own population with the SAME interaction structure, so all ranks ask the
     owners for the same positive rows in the same batches and every returned row arrives once per rank.
     ``pipeline`` (round 3): batch b + 1 is fetched on a second stream / communicator under batch b's SGD, after the owners applied
-    batch b - 1 and before they apply batch b: the definition with the table as of two batches back inside an epoch."""
+    batch b - 1 and before they apply batch b: the definition with the table as of two batches back inside an epoch.
+    ``plan_ahead`` (round 3): the plan of epoch k + 1 (distinct rows per owner, rewritten ids, the id exchange) runs on a third
+    stream / communicator while epoch k trains ("ahead"), or its device part in front of epoch k's last batch on the training
+    stream, the row counts read back behind an event ("inside", what bench.py runs) -- into the other slot of the plan buffers:
+    same epochs, planned earlier."""
     from qrec_amd.engine import padded_ld
     d, indptr, ind, P0, Q0 = _tiny_problem(dim)
     U, I = d["n_users"], d["n_items"]
     ld = padded_ld(dim, np.float32)
     lr, ru, ri = 0.05, 0.01, 0.02
-    group, group_f = _Group(world), _Group(world)
+    group, group_f, group_p = _Group(world), _Group(world), _Group(world)
+    n_steps = 3 if plan_ahead else 2
     result, errors = [None] * world, []
 
     def pad(a):
@@ -383,15 +388,26 @@ def test_sharded_item_table_with_logical_ranks_equals_the_definition(world, n_ba
             lo, hi = (0, U) if same_users else user_block(U, world, rank)
             d_P = DB.from_numpy(pad((P0[lo:hi] * (1 + 0.1 * rank * same_users)).astype(np.float32)))
             d_Q = DB.from_numpy(pad(qd.shard_item_rows(Q0, world, rank)))
-            ex = qd.ShardedItemExchange(comm, I, ld, d_Q, pipeline=(ThreadComm(group_f, rank), capi.Stream()) if pipeline else None)
+            ex = qd.ShardedItemExchange(comm, I, ld, d_Q, pipeline=(ThreadComm(group_f, rank), capi.Stream()) if pipeline else None,
+                                        plan_ahead=(ThreadComm(group_p, rank), capi.Stream()) if plan_ahead == "ahead" else None)
             d_loss = DB.zeros(1, np.float64)
-            for step in range(2):
+            steps = []
+            for step in range(n_steps):
                 u, li, j = _rank_triplets(indptr, ind, lo, hi, I, 100 * step + rank, "user")
-                d_u, d_i, d_j = DB.from_numpy(u), DB.from_numpy(li), DB.from_numpy(j)
-                ex.plan_epoch(d_i, d_j, u.size, n_batches)
+                steps.append((u.size, DB.from_numpy(u), DB.from_numpy(li), DB.from_numpy(j)))
+            uploaded = capi.Event(); uploaded.record(None)
+            for step, (n_t, d_u, d_i, d_j) in enumerate(steps):
+                ex.plan_epoch(d_i, d_j, n_t, n_batches)           # plan_ahead, step >= 1: adopts the plan made under / inside the previous epoch
+                nxt = None
+                if plan_ahead == "inside" and step + 1 < n_steps:
+                    nxt = dict(d_i=steps[step + 1][2], d_j=steps[step + 1][3], n=steps[step + 1][0], n_batches=n_batches, after=uploaded)
                 ex.run_epoch(lambda t0, nb, cache, rows, ci, cj, st: capi.bpr_sgd_hogwild(
                     d_P, cache, dim, ld, d_u.ptr + 4 * t0, ci, cj, nb, 32, 1, lr, ru, ri, d_loss, capi.HW_ATOMIC, st,
-                    p_rows=hi - lo, q_rows=rows))
+                    p_rows=hi - lo, q_rows=rows), next_epoch=nxt)
+                if plan_ahead == "ahead" and step + 1 < n_steps:
+                    ex.plan_epoch_ahead(steps[step + 1][2], steps[step + 1][3], steps[step + 1][0], n_batches, uploaded)
+                if plan_ahead and step + 1 < n_steps:
+                    assert ex._ahead is not None and ex._ahead["slot"] != ex._slot and ex._ahead["finished"] == (plan_ahead == "ahead")
             capi.device_sync()
             result[rank] = (lo, hi, d_P.numpy()[:, :dim], d_Q.numpy()[:, :dim], float(d_loss.numpy()[0]), ex.bytes_moved)
         except Exception as e:      # noqa: BLE001 -- a failing rank must not leave the others at the barrier
@@ -406,7 +422,7 @@ def test_sharded_item_table_with_logical_ranks_equals_the_definition(world, n_ba
     # single-process statement
     Q = Q0.astype(np.float64); loss = 0.0
     Ps = [P0 * (1 + 0.1 * r * same_users) for r in range(world)]          # weak layout: each rank its own user rows
-    for step in range(2):
+    for step in range(n_steps):
         work = []
         for r in range(world):
             lo, hi = (0, U) if same_users else user_block(U, world, r)
@@ -505,10 +521,11 @@ def test_two_rank_bench_path_with_row_sharded_item_table(tmp_path, scaling):
     # chunk of a hot item reads the batch-start row, so this case runs user-major; strong runs item-major
     out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs-per-step", "3", "--no-cpu-baseline", "--shape", "ml1m",
                   "--dist-mode", "sharded", "--shard-batch", "250000", "--scaling", scaling,
-                  "--schedule", "user" if scaling == "weak" else "item"],
+                  "--schedule", "user" if scaling == "weak" else "item"] + (["--shard-pipeline"] if scaling == "strong" else []),
                  {"QREC_DIST_TEST_ONE_DEVICE": "1", "QREC_DIST_TEST_DUMP": str(tmp_path)}, nproc=2, port=29543)
     assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["value"] > 0
     assert out["config"]["batches_per_epoch"] >= (2 if scaling == "strong" else 4) and out["config"]["xgmi_bytes_per_epoch_all_ranks"] > 0
+    assert out["config"]["fetch_pipelined"] == (scaling == "strong") and out["config"]["plan"].startswith("inside")
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     I = 3706
     assert r0["Q"].shape[0] == (I + 1) // 2 and r1["Q"].shape[0] == I // 2    # items 0,2,4.. / 1,3,5..
