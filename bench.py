@@ -140,7 +140,7 @@ def recall_check(capi, sgd, tables, data, u, items, indptr, P0, Q0, chunk, flush
             "final_loss_gpu": loss_g, "final_loss_cpu": loss_c}
 
 
-def deferred_variant(capi, data, u, items, indptr, n_items, P0, Q0, chunk, flush_every, seed, runs=3, epochs=100):
+def deferred_variant(capi, data, u, items, indptr, n_items, P0, Q0, chunk, flush_every, seed, main, runs=3, epochs=100):
     """The same workload under the opt-in schedule "item-deferred" (qrec_bpr_sgd_hogwild_item_major_deferred: one atomic row update
     per triplet instead of two, the negative-side terms applied by a second, j-ordered pass -- DESIGN.md s4), timed like the main
     line: `runs` fresh `epochs`-epoch trainings, sampler + j sort on the side stream, epoch close on the device, no host sync
@@ -152,7 +152,6 @@ def deferred_variant(capi, data, u, items, indptr, n_items, P0, Q0, chunk, flush
     t = DeviceTables(P0, Q0, np.float32)
     s = BprSgd(t, u, items, CSR(indptr, items), schedule="item-deferred", n_items=n_items, chunk=chunk)
     d_P0, d_Q0 = DeviceBuffer.from_numpy(t._pad(P0)), DeviceBuffer.from_numpy(t._pad(Q0))
-    main = capi.Stream()
     s.start_device_driver(LR0, log_capacity=epochs)
     d_drv0 = DeviceBuffer.from_numpy(s.d_drv.numpy())
     capi.device_sync()
@@ -170,6 +169,7 @@ def deferred_variant(capi, data, u, items, indptr, n_items, P0, Q0, chunk, flush
             s.epoch_device_async(REG_U, REG_I, MAX_LR, tol=0.0, chunk=chunk, stream=main, flush_every=flush_every, events=evs[k])
             s.prefetch_negatives_device(seed, k + 1)
             k += 1
+    t_enq = time.perf_counter() - t0
     capi.device_sync()
     dt = time.perf_counter() - t0
     ms = float(np.mean([b.elapsed_ms_since(a) for a, b in evs[epochs:]]))
@@ -178,6 +178,7 @@ def deferred_variant(capi, data, u, items, indptr, n_items, P0, Q0, chunk, flush
     return {"schedule": "item-deferred", "value": u.size * runs * epochs / dt, "unit": "triplet-updates/s", "ms_per_epoch": dt / (runs * epochs) * 1e3,
             "kernels": "bpr_hogwild_item_kernel<16,4,defer> + bpr_deferred_negatives_kernel<16,4> (j order: rocPRIM radix sort on the sampler's stream)",
             "avg_launch_ms": ms, "roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "recall_at_20": rec,
+            "host_enqueue_ms_per_epoch": t_enq / (runs * epochs) * 1e3,
             "default": False, "why_not_default": "Recall@20 vs exact-order training: within 0.002 at lr0 = 0.01, 0.0058 apart at lr0 = 0.05 (12-epoch paired runs, tests/test_gpu_bpr.py)"}
 
 
@@ -551,9 +552,12 @@ def main():
             if not args.no_extras:
                 out["recall_at_20"] = recall_check(capi, sgd, tables, data, u, items, indptr, P0, Q0, CHUNK, flush_every, args.variant)
                 out["exact_mode"] = exact_mode_rate(capi, u, items, indptr, I, P0, Q0)
+                # the main run's objects go first, their streams with them: a process maps its streams onto a handful of hardware
+                # queues (4 by default), and with the main run's two still alive the leg's sampler stream shared a queue with its
+                # training stream -- sampler and sort ran BEHIND the SGD kernels instead of under them (0.57 instead of 0.49 ms/epoch)
+                del sgd, tables, d_P0, d_Q0
                 if args.schedule == "item" and args.shape == "yelp2018":
-                    out["deferred_negatives"] = deferred_variant(capi, data, u, items, indptr, I, P0, Q0, CHUNK, flush_every, sampler_seed)
-                del sgd, tables
+                    out["deferred_negatives"] = deferred_variant(capi, data, u, items, indptr, I, P0, Q0, CHUNK, flush_every, sampler_seed, main)
                 out["roofline_hbm_resident"] = hbm_resident_roofline(capi)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:

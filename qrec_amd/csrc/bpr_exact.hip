@@ -228,7 +228,9 @@ template <> struct Fast<double> {
     }
 };
 template <> struct Fast<float> {
-    static __device__ inline float exp_(float y) { return expf(y); }
+    // y clamped to <= 88: e^88 = 1.65e38 is finite in fp32, so 1 + e^y stays finite and rcp_'s Newton step never sees
+    // inf * 0 (x = -120: sigma is 0 either way -- tests/test_gpu_bpr.py::test_loss_is_finite_where_fp32_sigmoid_underflows)
+    static __device__ inline float exp_(float y) { return expf(__builtin_fminf(y, 88.0f)); }
     static __device__ inline float rcp_(float a) {
         float r = __builtin_amdgcn_rcpf(a);
         return __builtin_fmaf(__builtin_fmaf(-a, r, 1.f), r, r);

