@@ -378,7 +378,7 @@ class ShardedItemExchange:
         comm.alltoall_rows(c[f"rows_out{cp}"], self.recv[b], c[f"cache{cp}"], self.send[b], ld * 4, stream)
         return cp
 
-    def run_epoch(self, sgd_batch, stream=None, next_epoch=None):
+    def run_epoch(self, sgd_batch, stream=None, next_epoch=None, before_first_sgd=None):
         """``sgd_batch(t0, n, d_cache, cache_rows, ci_ptr, cj_ptr, stream)`` trains triplets [t0, t0+n) whose item ids
         are rows of ``d_cache`` (addresses of the rewritten id arrays are passed).
 
@@ -387,7 +387,8 @@ class ShardedItemExchange:
         this epoch's LAST batch, so that its row counts reach the host while that batch still trains and the next
         ``plan_epoch`` finds them there -- the host never waits for the stream to run dry, and no plan kernel runs beside an SGD
         grid (which costs the atomic-bound grid more than it hides: profiles/r03_sharded_world1.json).  Epochs of one batch
-        have no "in front of the last batch" that the sampler could be ready for; they plan at their own start."""
+        have no "in front of the last batch" that the sampler could be ready for; they plan at their own start.
+        ``before_first_sgd(stream)``: called where the first batch's SGD grid goes, behind its fetch."""
         k, c, ld = self.k, self._cap, self.ld
         ci, cj = k.device_ptr(c[f"ci@{self._slot}"]), k.device_ptr(c[f"cj@{self._slot}"])
         piped = self.pipeline is not None
@@ -416,6 +417,9 @@ class ShardedItemExchange:
             else:
                 cp = self._fetch(b, self.comm, stream)
             cache, rows_out = c[f"cache{cp}"], c[f"rows_out{cp}"]
+            if b == 0 and before_first_sgd is not None:
+                before_first_sgd(stream)         # on every rank, with or without triplets in this batch: what it enqueues (the next epoch's
+                                                 # sampler) decides whether the rank joins the plan's collectives in front of the last batch
             if nb:
                 sgd_batch(t0, nb, cache, n_out, ci + 4 * t0, cj + 4 * t0, stream)
             self.comm.alltoall_rows(cache, S, c["rows_ret"], R, ld * 4, stream)                          # rows -> owners

@@ -366,17 +366,15 @@ class BprSgd:
             # the first batch's SGD grid comes behind its fetch (gather, exchange): the sampler must not be released by the epoch's
             # start event -- it would sit on the CUs when the grid arrives (the 30% case above; measured again in round 3, 0.83 vs
             # 0.79 ms/epoch) -- but by one recorded right in front of that grid
-            pending = [after_start]
-
-            def batch(t0, nb, cache, rows, ci, cj, st):
-                if pending[0] is not None:
+            def first_grid(st):
+                if after_start is not None:
                     grid = self._grid_events[0]; self._grid_events.reverse()
                     grid.record(st); self._sgd_start = grid
-                    pending[0](); pending[0] = None
-                self._launch_sgd(t.P, cache, self.d_u.ptr + 4 * t0, ci, cj, nb, chunk, groups, flush_every, regU, regI, variant, st, q_rows=rows)
-            dist.exchange.run_epoch(batch, stream, next_epoch=(lambda: dist.next_epoch(self)))
-            if pending[0] is not None:       # a rank without triplets
-                pending[0]()
+                    after_start()
+
+            dist.exchange.run_epoch(lambda t0, nb, cache, rows, ci, cj, st: self._launch_sgd(
+                t.P, cache, self.d_u.ptr + 4 * t0, ci, cj, nb, chunk, groups, flush_every, regU, regI, variant, st, q_rows=rows), stream,
+                next_epoch=(lambda: dist.next_epoch(self)), before_first_sgd=first_grid)
         else:
             if after_start is not None:
                 after_start()
