@@ -98,8 +98,20 @@ def cpu_baseline(u, i, indptr, n_items, U, seconds=12.0):
         if time.perf_counter() - t0 >= seconds:
             break
     dt = time.perf_counter() - t0
+    # ... and the interpreter-bound form the reference itself runs in (oracle/npref.py: one Python iteration and seven numpy row
+    # statements per triplet, random.choice negatives), timed HERE on a bounded sample -- the reference cannot travel to this box
+    from oracle import npref
+    import random as _random
+    Pn = rng.random((U, DIM)) / 3; Qn = rng.random((n_items, DIM)) / 3
+    t1 = time.perf_counter()
+    _, n_loop, _ = npref.bpr_epoch(Pn, Qn, indptr, i, n_items, LR0, REG_U, REG_I, rng=_random.Random(0), max_triplets=200_000)
+    dt_loop = time.perf_counter() - t1
     return {"value": done / dt, "unit": "triplet-updates/s", "cores": 1, "kind": "port",
             "sample": f"{epochs} epochs ({done} triplets, {dt:.1f} s), C fp64 port of BPR.py:29-53 + CPython-stream sampler",
+            "reference_loop_here": {"value": n_loop / dt_loop, "unit": "triplet-updates/s", "cores": 1, "kind": "port",
+                                    "what": "the reference's own form -- per triplet one CPython iteration, random.choice, seven numpy row "
+                                            "statements (BPR.py:28-53) -- restated in oracle/npref.py and timed on this host",
+                                    "sample": f"{n_loop} triplets of the same epoch ({dt_loop:.1f} s), d = {DIM}, fp64"},
             "reference_python": {"value": 58930.0, "unit": "triplet-updates/s", "cores": 1,
                                  "host": "survey container (8 vCPU Xeon 2.1 GHz KVM), not this box: the Python reference cannot travel",
                                  "source": "BASELINE.md s2: unmodified BPR.trainModel, same shape, fp64"}}
@@ -549,6 +561,7 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(u, items, indptr, I, U)
                 out["vs_cpu_port"] = value / out["cpu_baseline"]["value"]
+                out["vs_reference_loop_here"] = value / out["cpu_baseline"]["reference_loop_here"]["value"]
             if not args.no_extras:
                 out["recall_at_20"] = recall_check(capi, sgd, tables, data, u, items, indptr, P0, Q0, CHUNK, flush_every, args.variant)
                 out["exact_mode"] = exact_mode_rate(capi, u, items, indptr, I, P0, Q0)

@@ -342,3 +342,25 @@ def test_mhcn_graph_builders_match_the_reference(golden_dir):
         want[(u, i)] = np.float32(want.get((u, i), np.float32(0)) + np.float32(v))
     assert R.shape == tuple(meta["R_shape"]) and R.nnz == len(want) < z["R_values"].size
     assert all(want[(int(u), int(i))] == v for u, i, v in zip(R.row, R.col, R.data))
+
+
+def test_numpy_level_restatement_of_the_reference_loop_equals_the_c_restatement():
+    """oracle/npref.py (what bench.py times as the interpreter-bound CPU form, model/ranking/BPR.py:28-53) against the C oracle:
+    the same negatives from the same generator state, tables and loss to rounding; a bounded sample stops where it is told to."""
+    import random
+    from oracle import npref
+    from qrec_amd.synth import make_dataset, to_csr
+    d = make_dataset("small"); U, I = d["n_users"], d["n_items"]
+    indptr, ind = to_csr(U, d["train_u"], d["train_i"])
+    u = np.repeat(np.arange(U, dtype=np.int32), np.diff(indptr)).astype(np.int32)
+    rng = np.random.default_rng(0); P0 = rng.random((U, 10)) / 3; Q0 = rng.random((I, 10)) / 3
+    P, Q = P0.copy(), Q0.copy()
+    nll, done, negs = npref.bpr_epoch(P, Q, indptr, ind, I, 0.05, 0.01, 0.02, rng=random.Random(5))
+    assert done == ind.size
+    j = O.bpr_sample_epoch(O.MT.from_python_state(random.Random(5).getstate()), indptr, ind, I)
+    assert np.array_equal(j, negs)
+    Pc, Qc = P0.copy(), Q0.copy()
+    lref = O.bpr_sgd(Pc, Qc, u, ind, j, 0.05, 0.01, 0.02)
+    assert abs(nll - lref) / lref < 1e-12 and np.abs(P - Pc).max() < 1e-12 and np.abs(Q - Qc).max() < 1e-12
+    _, part, negs2 = npref.bpr_epoch(P0.copy(), Q0.copy(), indptr, ind, I, 0.05, 0.01, 0.02, rng=random.Random(5), max_triplets=1000)
+    assert part == 1000 and np.array_equal(negs2, negs[:1000])
