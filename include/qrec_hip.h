@@ -213,14 +213,20 @@ int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int64_t n_users, int
  *   float g[n] | int32 order[n] | int32 j_sorted[n] (each rounded up to 256 bytes) | the sort's own scratch.
  * qrec_bpr_deferred_sort puts the j order of the negatives d_j into d_work: a STABLE sort by j (inside a run of equal j
  * the triplets keep their storage order), so pass B is a deterministic function of the arrays; the engine runs it on the
- * sampler's side stream, under the previous epoch.  `sorted` = 0 makes qrec_bpr_sgd_hogwild_item_major_deferred do it
- * first, on its own stream.                                                                                               */
+ * sampler's side stream, under the previous epoch.  `flags`: bit 0 (QREC_DEFERRED_SORTED) -- d_work already holds the j order
+ * of these negatives (qrec_bpr_deferred_sort); without it the call sorts first, on its own stream.  Bit 1
+ * (QREC_DEFERRED_FRESH; also switched on by the environment variable QREC_DEFERRED_FRESH=1) -- pass A logs P[u].Q[i] instead of
+ * g and pass B forms g' = lr (1 - sigma(P[u].Q[i] - P[u].Q[j])) against the Q[j] its run has reached: the negative item's row
+ * takes its updates one after the other as in the reference (measured: halves the drift of Recall@20 at 5x BPR.conf's rate,
+ * changes nothing at BPR.conf's rate).                                                                     */
+#define QREC_DEFERRED_SORTED 1
+#define QREC_DEFERRED_FRESH 2
 int qrec_bpr_deferred_work_bytes(int64_t n, int64_t n_items, int64_t *bytes);
 int qrec_bpr_deferred_sort(const int32_t *d_j, int64_t n, int64_t n_items, void *d_work, void *stream);
 int qrec_bpr_sgd_hogwild_item_major_deferred(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld,
                                              const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
                                              int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
-                                             double *d_loss, const double *d_driver_state, void *d_work, int32_t sorted,
+                                             double *d_loss, const double *d_driver_state, void *d_work, int32_t flags,
                                              void *stream);
 
 /* Device-resident epoch close of the numpy-path models: model/ranking/BPR.py:40 (loss += regU*sum(P*P) +

@@ -167,14 +167,14 @@ def bpr_sgd(P, Q, u, i, j, lr, regU, regI) -> float:
     return lib().orc_bpr_sgd_f32(_p(P), _p(Q), d, _p(u), _p(i), _p(j), u.size, lr, regU, regI)
 
 
-def bpr_sgd_deferred(P, Q, u, i, j, j_order, lr, regU, regI) -> float:
+def bpr_sgd_deferred(P, Q, u, i, j, j_order, lr, regU, regI, fresh: int = 0) -> float:
     """NOT a reference function: the sequential definition of the product's deferred-negatives epoch (qrec_oracle.c), fp64, in place.
     ``j_order``: int64 permutation -- the order pass B applies the negative-side updates in (the kernels: sorted by j)."""
     _chk(u, np.int32); _chk(i, np.int32); _chk(j, np.int32); _chk(j_order, np.int64); _chk(P, np.float64); _chk(Q, np.float64)
     L = lib()
-    L.orc_bpr_sgd_deferred_f64.argtypes = [C.c_void_p] * 2 + [C.c_int32] + [C.c_void_p] * 4 + [C.c_int64] + [C.c_double] * 3
+    L.orc_bpr_sgd_deferred_f64.argtypes = [C.c_void_p] * 2 + [C.c_int32] + [C.c_void_p] * 4 + [C.c_int64] + [C.c_double] * 3 + [C.c_int32]
     L.orc_bpr_sgd_deferred_f64.restype = C.c_double
-    return L.orc_bpr_sgd_deferred_f64(_p(P), _p(Q), P.shape[1], _p(u), _p(i), _p(j), _p(j_order), u.size, lr, regU, regI)
+    return L.orc_bpr_sgd_deferred_f64(_p(P), _p(Q), P.shape[1], _p(u), _p(i), _p(j), _p(j_order), u.size, lr, regU, regI, int(fresh))
 
 
 def tbpr_sample_epoch(mt: MT, pos_indptr, pos_items, n_items: int, joint, weak, strong):

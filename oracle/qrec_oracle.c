@@ -318,9 +318,12 @@ double orc_bpr_sgd_f64(double *P, double *Q, int32_t d, const int32_t *u_idx,
  *   pass A, triplets in the given (item-major) order:  s, g = lr (1 - s);  P[u] += g (Q[i] - Q[j]);  Q[i] += g P[u];
  *           P[u] -= lr regU P[u];  Q[i] -= lr regI Q[i];  loss += -log(s)          -- Q[j] is read, not written; g is kept
  *   pass B, the same triplets in the order j_order:   Q[j] -= g P[u];  Q[j] -= lr regI Q[j]     with the P[u] pass A left.
+ * fresh != 0: pass A keeps xi = P[u].Q[i] instead of g, and pass B forms g' = lr (1 - sigmoid(xi - P[u].Q[j])) with the P[u]
+ * pass A left and the Q[j] the pass has reached -- the negative item's row takes its updates one after the other, each seeing
+ * the previous ones, as in the reference; the user's and the positive item's rows saw Q[j] as the epoch found it.
  * Returns sum of -log(s). */
 double orc_bpr_sgd_deferred_f64(double *P, double *Q, int32_t d, const int32_t *u_idx, const int32_t *i_idx, const int32_t *j_idx,
-                                const int64_t *j_order, int64_t n, double lr, double regU, double regI) {
+                                const int64_t *j_order, int64_t n, double lr, double regU, double regI, int32_t fresh) {
     double loss = 0.0;
     double *g_of = (double *)malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
     int64_t t, k;
@@ -333,7 +336,7 @@ double orc_bpr_sgd_deferred_f64(double *P, double *Q, int32_t d, const int32_t *
         for (c = 0; c < d; c++) { xi += pu[c] * qi[c]; xj += pu[c] * qj[c]; }
         s = 1.0 / (1.0 + exp(-(xi - xj)));
         g = lr * (1.0 - s);
-        g_of[t] = g;
+        g_of[t] = fresh ? xi : g;
         for (c = 0; c < d; c++) pu[c] += g * (qi[c] - qj[c]);
         for (c = 0; c < d; c++) qi[c] += g * pu[c];
         for (c = 0; c < d; c++) pu[c] -= (lr * regU) * pu[c];
@@ -344,9 +347,15 @@ double orc_bpr_sgd_deferred_f64(double *P, double *Q, int32_t d, const int32_t *
         const double *pu;
         double *qj;
         t = j_order[k];
+        double g = g_of[t];
         pu = P + (int64_t)u_idx[t] * d;
         qj = Q + (int64_t)j_idx[t] * d;
-        for (c = 0; c < d; c++) qj[c] -= g_of[t] * pu[c];
+        if (fresh) {       /* the negative's side of x against the row as it is NOW: x' = (P[u].Q[i] as pass A saw it) - P[u].Q[j] */
+            double xj = 0.0;
+            for (c = 0; c < d; c++) xj += pu[c] * qj[c];
+            g = lr * (1.0 - 1.0 / (1.0 + exp(-(g - xj))));
+        }
+        for (c = 0; c < d; c++) qj[c] -= g * pu[c];
         for (c = 0; c < d; c++) qj[c] -= (lr * regI) * qj[c];
     }
     free(g_of);

@@ -953,12 +953,13 @@ def bpr_deferred_sort(d_j, n: int, n_items: int, d_work, stream=None):
 
 def bpr_sgd_hogwild_item_major_deferred(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int, chunk: int, grid_groups: int,
                                         flush_every: int, lr: float, regU: float, regI: float, d_loss, d_work, stream=None,
-                                        d_driver_state=None, p_rows: int | None = None, q_rows: int | None = None, is_sorted: bool = False):
+                                        d_driver_state=None, p_rows: int | None = None, q_rows: int | None = None, is_sorted: bool = False, fresh: bool = False):
     """the item-major epoch with the negative-side updates deferred to a second, j-ordered pass (include/qrec_hip.h);
-    ``is_sorted``: ``bpr_deferred_sort`` has already put these negatives' j order into ``d_work``"""
+    ``is_sorted``: ``bpr_deferred_sort`` has already put these negatives' j order into ``d_work``; ``fresh``: pass B re-forms the
+    coefficient against the negative item's row as its run left it (include/qrec_hip.h QREC_DEFERRED_FRESH)"""
     _check(load().qrec_bpr_sgd_hogwild_item_major_deferred(_dp(d_P), _dp(d_Q), p_rows or _table_rows(d_P, ld), q_rows or _table_rows(d_Q, ld), d, ld,
                                                            _dp(d_u), _dp(d_i), _dp(d_j), n, chunk, grid_groups, flush_every, lr, regU, regI,
-                                                           _dp(d_loss), _dp(d_driver_state), _dp(d_work), 1 if is_sorted else 0, _sh(stream)))
+                                                           _dp(d_loss), _dp(d_driver_state), _dp(d_work), (1 if is_sorted else 0) | (2 if fresh else 0), _sh(stream)))
 
 
 DRV_LR, DRV_LAST_LOSS, DRV_EPOCHS, DRV_CONVERGED, DRV_FAILED, DRV_WORDS = 0, 1, 2, 3, 4, 8

@@ -569,7 +569,8 @@ __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
     float *__restrict__ P, float *__restrict__ Q, int64_t p_bytes, int64_t q_bytes,
     const int32_t *__restrict__ u_idx, const int32_t *__restrict__ i_idx,
     const int32_t *__restrict__ j_idx, int64_t n, int chunk, int64_t n_chunks, int64_t chunk_stride,
-    int64_t groups_active, int flush_every, HwRate rate, double *__restrict__ loss_out, float *__restrict__ glog = nullptr) {
+    int64_t groups_active, int flush_every, HwRate rate, double *__restrict__ loss_out, float *__restrict__ glog = nullptr,
+    int log_dot = 0) {
     constexpr int GPW = kWave / LPR;
     float lr, cu, ci;
     if (!hw_rate_resolve(rate, lr, cu, ci)) return;
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
                 pun.v[e] = p1 - cu * p1;
             }
             hw_update_row<LPR, E, UP_ATOMIC>(rsP, ut, r, pu, pun);
-            if constexpr (DEFER) { if (r == 0) glog[t0 + k] = gsc; }
+            if constexpr (DEFER) { if (r == 0) glog[t0 + k] = log_dot ? di : gsc; }
             else hw_update_row<LPR, E, UP_ATOMIC>(rsQ, jt, r, qj, qjn);
             loss += neg_log_sigmoid(di - dj);
             since_flush++;
@@ -670,7 +671,7 @@ template <int LPR, int E, typename TAB>
 __global__ __launch_bounds__(256) void bpr_deferred_negatives_kernel(
     float *__restrict__ P, float *__restrict__ Q, int64_t p_bytes, int64_t q_bytes, const int32_t *__restrict__ u_idx,
     const int32_t *__restrict__ j_sorted, const float *__restrict__ glog, const int32_t *__restrict__ perm, int64_t n, int chunk,
-    int64_t n_chunks, int64_t groups_active, HwRate rate) {
+    int64_t n_chunks, int64_t groups_active, HwRate rate, int fresh) {
     constexpr int GPW = kWave / LPR;
     float lr, cu, ci;
     if (!hw_rate_resolve(rate, lr, cu, ci)) return;
@@ -703,7 +704,14 @@ __global__ __launch_bounds__(256) void bpr_deferred_negatives_kernel(
             }
             Row<E> npu = pu;
             if (k + 1 < len) npu = hw_load_row<LPR, E, LD_PLAIN>(rsP, su[k + 1], r);
-            const float gsc = sg[k];
+            float gsc = sg[k];
+            if (fresh) {      // the log holds P[u].Q[i] as pass A saw it; the negative's side of x is formed HERE, against the row as this run left it
+                float dj = 0.f;
+#pragma unroll
+                for (int e = 0; e < E; e++) dj += pu.v[e] * qj.v[e];
+                dj = row_allreduce_sum<LPR>(dj);
+                gsc = lr * (1.0f - 1.0f / (1.0f + expf(-(gsc - dj))));
+            }
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 const float b = qj.v[e] - gsc * pu.v[e];
@@ -760,7 +768,7 @@ int sort_by_negative(const int32_t *j, int64_t n, int64_t n_keys, const Deferred
 template <int LPR, int E>
 int launch_hogwild_item_deferred(float *P, float *Q, int64_t pb, int64_t qb, const int32_t *u, const int32_t *i, const int32_t *j,
                                  int64_t n, int64_t n_keys, int chunk, int64_t groups, int flush_every, HwRate rate, double *loss,
-                                 const DeferredWork &w, bool sorted, hipStream_t st) {
+                                 const DeferredWork &w, bool sorted, int fresh, hipStream_t st) {
     constexpr int GPW = kWave / LPR;
     const int64_t n_chunks = (n + chunk - 1) / chunk;
     // fewer atomics per triplet: the passes lean on the row loads, which scale with the groups in flight (measured, atomics4.hip:
@@ -780,14 +788,14 @@ int launch_hogwild_item_deferred(float *P, float *Q, int64_t pb, int64_t qb, con
     }
     if (pb < kBufLimit && qb < kBufLimit) {
         hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E, TabBuf, true>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, chunk,
-                           n_chunks, stride, groups, flush_every, rate, loss, w.glog);
+                           n_chunks, stride, groups, flush_every, rate, loss, w.glog, fresh);
         hipLaunchKernelGGL((bpr_deferred_negatives_kernel<LPR, E, TabBuf>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, w.jsorted, w.glog, w.perm, n,
-                           chunk, n_chunks, groups, rate);
+                           chunk, n_chunks, groups, rate, fresh);
     } else {
         hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E, TabPtr, true>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, chunk,
-                           n_chunks, stride, groups, flush_every, rate, loss, w.glog);
+                           n_chunks, stride, groups, flush_every, rate, loss, w.glog, fresh);
         hipLaunchKernelGGL((bpr_deferred_negatives_kernel<LPR, E, TabPtr>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, w.jsorted, w.glog, w.perm, n,
-                           chunk, n_chunks, groups, rate);
+                           chunk, n_chunks, groups, rate, fresh);
     }
     QREC_LAUNCH_CHECK();
     return QREC_OK;
@@ -1056,7 +1064,7 @@ int qrec_bpr_deferred_sort(const int32_t *d_j, int64_t n, int64_t n_items, void 
 int qrec_bpr_sgd_hogwild_item_major_deferred(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld,
                                              const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
                                              int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
-                                             double *d_loss, const double *d_driver_state, void *d_work, int32_t sorted,
+                                             double *d_loss, const double *d_driver_state, void *d_work, int32_t flags,
                                              void *stream) {
     QREC_REQUIRE(d_P && d_Q && d_loss && n >= 0 && n < (1ll << 31), "qrec_bpr_sgd_hogwild_item_major_deferred: bad argument");
     QREC_REQUIRE(n == 0 || (d_u && d_i && d_j && d_work), "qrec_bpr_sgd_hogwild_item_major_deferred: null array");
@@ -1072,8 +1080,11 @@ int qrec_bpr_sgd_hogwild_item_major_deferred(float *d_P, float *d_Q, int64_t n_u
     DeferredWork w;
     const int rcw = deferred_carve(d_work, n, n_items, &w);
     if (rcw != QREC_OK) return rcw;
+    static const int env_fresh = [] { const char *e = getenv("QREC_DEFERRED_FRESH"); return e ? atoi(e) : 0; }();
+    const int fresh = (flags & QREC_DEFERRED_FRESH) ? 1 : env_fresh;
+    const int sorted = flags & QREC_DEFERRED_SORTED;
 #define QREC_DEF(LPR, E) launch_hogwild_item_deferred<LPR, E>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, n_items, chunk, grid_groups, \
-                                                               flush_every, rate, d_loss, w, sorted != 0, st)
+                                                               flush_every, rate, d_loss, w, sorted != 0, fresh, st)
     switch (ld) {
         case 32: return QREC_DEF(16, 2);
         case 64: return QREC_DEF(16, 4);

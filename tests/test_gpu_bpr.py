@@ -551,10 +551,39 @@ def test_item_major_recall_matches_exact_order_training(lr0, seed, flush):
 # terms, reordered) is what the kernels are held to, property by property like the one-pass schedule above; what the reordering
 # does to training is judged on the measures (paired runs against the order-exact CPU training).
 # ---------------------------------------------------------------------------------------------
+_DEFERRED_FRESH = int(os.environ.get("QREC_DEFERRED_FRESH", "0"))
+
+
 def _deferred_perm(d_work, n):
     """the j order inside a deferred work area (include/qrec_hip.h: coefficient log | order | sorted ids, each rounded up to 256 bytes)"""
     seg = (4 * n + 255) // 256 * 256
     return d_work.numpy()[seg:seg + 4 * n].view(np.int32)
+
+
+@pytest.mark.parametrize("dim,chunk,flush", [(64, 32, 8), (50, 7, 3)])
+def test_deferred_fresh_coefficient_single_group_is_its_sequential_statement(dim, chunk, flush):
+    """QREC_DEFERRED_FRESH (flags bit 1): pass A logs P[u].Q[i], pass B forms the coefficient against the negative item's row as its
+    run left it -- held to the oracle's statement of exactly that (orc_bpr_sgd_deferred_f64, fresh = 1)."""
+    d, indptr, ind, u, j = _synthetic("small")
+    U, I, n = d["n_users"], d["n_items"], ind.size
+    rng = np.random.default_rng(dim)
+    P0 = rng.random((U, dim)) / 3; Q0 = rng.random((I, dim)) / 3
+    t = DeviceTables(P0, Q0, np.float32)
+    sgd = BprSgd(t, u, ind, schedule="item-deferred"); sgd.set_negatives(j)
+    order = _item_major_visit_order(n, chunk)
+    ua, ia, ja = (np.ascontiguousarray(x[order]) for x in (sgd.d_u.numpy(), sgd.d_i.numpy(), sgd.d_j.numpy()))
+    Pr, Qr = P0.copy(), Q0.copy()
+    lref = O.bpr_sgd_deferred(Pr, Qr, ua, ia, ja, np.lexsort((order, ja)).astype(np.int64), 0.05, 0.01, 0.02, fresh=1)
+    Pz, Qz = P0.copy(), Q0.copy()
+    O.bpr_sgd_deferred(Pz, Qz, ua, ia, ja, np.lexsort((order, ja)).astype(np.int64), 0.05, 0.01, 0.02, fresh=0)
+    assert rel_err(Qz, Qr) > 1e-4            # the two statements differ by far more than the tolerance they are held to
+    sgd.d_stats.fill_bytes(0)
+    capi.bpr_sgd_hogwild_item_major_deferred(t.P, t.Q, dim, t.ld, sgd.d_u, sgd.d_i, sgd.d_j, n, chunk, 1, flush, 0.05, 0.01, 0.02, sgd.d_stats, sgd.d_work,
+                                             fresh=True)
+    Pg, Qg = t.download()
+    check("deferred (fresh coefficient), one group: P vs its sequential statement", rel_err(Pg, Pr), F32_TOL)
+    check("deferred (fresh coefficient), one group: Q vs its sequential statement", rel_err(Qg, Qr), F32_TOL)
+    check("deferred (fresh coefficient), one group: loss vs its sequential statement", abs(sgd.loss() - lref) / lref, F32_TOL)
 
 
 @pytest.mark.parametrize("dim", [64, 50, 128, 8])
@@ -572,7 +601,7 @@ def test_deferred_single_group_is_the_sequential_statement_of_its_order(dim, chu
     Pr, Qr = P0.copy(), Q0.copy()
     # pass B's order: by j, inside a j run by STORAGE position (the device sort is stable) -- with lr * regI * (run length) ~ 5e-2
     # here the order inside a run is worth 1e-3 on a Q row, so the statement has to name it
-    lref = O.bpr_sgd_deferred(Pr, Qr, ua, ia, ja, np.lexsort((order, ja)).astype(np.int64), 0.05, 0.01, 0.02)
+    lref = O.bpr_sgd_deferred(Pr, Qr, ua, ia, ja, np.lexsort((order, ja)).astype(np.int64), 0.05, 0.01, 0.02, fresh=_DEFERRED_FRESH)
     sgd.d_stats.fill_bytes(0)
     capi.bpr_sgd_hogwild_item_major_deferred(t.P, t.Q, dim, t.ld, sgd.d_u, sgd.d_i, sgd.d_j, n, chunk, 1, flush, 0.05, 0.01, 0.02, sgd.d_stats, sgd.d_work)
     Pg, Qg = t.download()
@@ -603,7 +632,7 @@ def test_deferred_full_grid_properties_yelp_shape():
     order = _item_major_visit_order(n, 32)
     ua, ia, ja = (np.ascontiguousarray(x[order]) for x in (sgd.d_u.numpy(), sgd.d_i.numpy(), sgd.d_j.numpy()))
     Pr, Qr = P0.astype(np.float64), Q0.astype(np.float64)
-    lref = O.bpr_sgd_deferred(Pr, Qr, ua, ia, ja, np.lexsort((order, ja)).astype(np.int64), 0.01, 0.001, 0.001)
+    lref = O.bpr_sgd_deferred(Pr, Qr, ua, ia, ja, np.lexsort((order, ja)).astype(np.int64), 0.01, 0.001, 0.001, fresh=_DEFERRED_FRESH)
     sgd.epoch_throughput_async(0.01, 0.001, 0.001)
     Pg, Qg = t.download()
     assert np.isfinite(Pg).all() and np.isfinite(Qg).all()
