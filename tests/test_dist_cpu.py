@@ -157,6 +157,8 @@ def _sharded_worker(rank, world, port, out, same_users=False, pipeline=False, pl
         u, li, j = _shard(indptr, ind, lo, hi, I, 100 * step + rank)
         if rank == 1 and step == 1:            # ragged: this rank runs out of triplets before the others do
             u, li, j = u[:5], li[:5], j[:5]
+        if rank == 1 and step == 2:            # ... and has none at all in the third epoch: it still plans, answers and applies
+            u, li, j = u[:0], li[:0], j[:0]
         steps.append((u, HK.DeviceBuffer.from_numpy(li), HK.DeviceBuffer.from_numpy(j)))
     for step, (u, d_i, d_j) in enumerate(steps):
         ex.plan_epoch(d_i, d_j, u.size, N_BATCHES)          # plan_ahead: adopts the plan made under / inside the previous epoch
@@ -200,6 +202,8 @@ def test_two_rank_sharded_item_table_equals_definition(same_users, pipeline, pla
             u, li, j = _shard(indptr, ind, lo, hi, I, 100 * step + r)
             if r == 1 and step == 1:
                 u, li, j = u[:5], li[:5], j[:5]
+            if r == 1 and step == 2:
+                u, li, j = u[:0], li[:0], j[:0]
             per = -(-u.size // N_BATCHES)
             work.append((r, lo, hi, u, li, j, per))
         waiting = []            # pipelined: batches fetched but not yet applied when the next fetch goes out (at most one)
