@@ -15,6 +15,9 @@ Two execution modes, chosen by the optional conf key ``qrec.mode`` or env ``QREC
     reference's user-major visiting order): item-major wins when a few items collect most interactions (their rows
     would take the per-triplet atomics), user-major when popularity is flat (measured: 2.1 vs 1.6 G/s at the
     Zipf-0.6 Yelp2018 shape, 1.16 vs 1.21 G/s on a uniform 1 M-item catalogue); ``auto`` looks at max/mean item degree.
+    ``item-deferred`` (opt-in, never chosen by ``auto``): item-major with the negative-side updates applied by a second,
+    j-ordered pass -- 2.56 G/s, a reordering of the per-triplet terms beyond Hogwild's whose effect on Recall@20 is inside
+    +-0.002 at BPR.conf's rate and outside at five times that rate.
 """
 from __future__ import annotations
 
@@ -43,8 +46,8 @@ class BPR(IterativeRecommender):
         self.table_dtype = np.float64 if (dt == "f64" and mode == "exact") else np.float32
         self.sampler_seed = int(os.environ.get("QREC_SEED", "0"))
         self.schedule = os.environ.get("QREC_SCHEDULE", "auto") if mode == "throughput" else "user"
-        if self.schedule not in ("auto", "item", "user"):
-            print("QREC_SCHEDULE must be auto, item or user")
+        if self.schedule not in ("auto", "item", "user", "item-deferred"):
+            print("QREC_SCHEDULE must be auto, item, user or item-deferred")
             raise SystemExit(-1)
 
     def initModel(self):
