@@ -35,7 +35,13 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   exact_mode   -- the order-exact mode (the one that meets the bit-exact-stream / 1e-5 numeric contract) timed on
                   the same workload;
   cpu_baseline -- the CPU port of the same epoch (oracle/, plain C, fp64, 1 thread) timed on this box's host cores
-                  on a bounded sample, next to the Python reference's own figure (another host).
+                  on a bounded sample; reference_loop_here: the reference's own interpreter-bound form (oracle/npref.py)
+                  timed on this host; reference_python: the unmodified reference's figure (another host, BASELINE.md);
+  recall_at_20 -- a fresh 25-epoch run of the timed mode against order-exact fp64 training on the same negatives;
+  deferred_negatives -- the opt-in schedule `--schedule item-deferred` (one atomic row update per triplet) timed like the
+                  main line, with its own Recall check (DESIGN.md s4 says why it is not the default);
+  multi_gpu    -- N > 1: what RCCL reports per rank, kernel time per rank, collectives and bytes per epoch.
+Sharded layout options: --shard-batch, --shard-pipeline, --plan-ahead, --no-plan-inside.
 """
 from __future__ import annotations
 

@@ -19,9 +19,15 @@ side.  The item table ``Q`` has two layouts:
     unchanged SGD kernel on (P, cache), and returns the cache; owners add ``returned - sent`` into their rows
     (ShardedItemExchange).  Same contract at batch granularity:  Q <- Q + sum_r (cache_r_after - cache_r_before).
     Memory per rank: |Q|/G + the cache of one batch.  Traffic: 2 rows per DISTINCT item a batch touches.
+    Round 3: all batches of an epoch are planned in one set of launches with ONE id exchange; the next epoch's plan is begun
+    in front of the current epoch's last batch and its row counts reach the host behind an event, so no epoch waits for a
+    drained stream; optional: the fetch of batch k + 1 under batch k's SGD kernel (second stream + communicator), the whole
+    plan on a third stream + communicator (ShardedItemExchange's ``pipeline`` / ``plan_ahead``).
 
 Graph models (config #5): ``BatchParallel`` (batch-sharded steps, one gradient all-reduce) and ``RowPartition``
-(1-D row partition of the propagation: all-gather of the operand per layer, reduce-scatter in the backward pass).
+(1-D row partition of the propagation: all-gather of the operand per layer -- or, ``RowPartition.reference`` /
+``gather_referenced``, a grouped send/recv of only the operand rows a rank's block of the adjacency refers to --,
+reduce-scatter in the backward pass).
 """
 from __future__ import annotations
 
