@@ -859,3 +859,30 @@ def test_spectral_row_key_lines_up_planted_communities():
         for lo, hi in ((0, nu), (nu, nu + ni)):
             per = [nnz_row[lo:hi][ch[lo:hi] == c].sum() for c in (0, 1)]
             assert abs(per[0] - per[1]) <= 0.02 * sum(per) + nnz_row.max()
+
+
+def test_bench_typed_with_gpus_n_becomes_its_own_launcher(monkeypatch):
+    """`python bench.py --gpus 4 ...` outside a launcher: bench.py re-executes itself under torch.distributed.run with four ranks on
+    127.0.0.1 and a free port, the caller's arguments unchanged, dmabuf IPC switched on (the exec itself is checked on the GPU box:
+    tests/test_gpu_dist.py::test_bench_typed_with_gpus_2_starts_its_own_ranks)."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_exec(file, argv, env):
+        seen.update(file=file, argv=list(argv), env=dict(env))
+        raise SystemExit(0)
+    monkeypatch.setattr(os, "execvpe", fake_exec)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2", "--dist-mode", "sharded"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False); monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    with pytest.raises(SystemExit):
+        bench.launch_own_ranks(4)
+    a = seen["argv"]
+    assert seen["file"] == sys.executable and a[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in a and "--nproc-per-node=4" in a and a[a.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(a[a.index("--master-port") + 1]) < 65536
+    k = a.index(os.path.join(ROOT, "bench.py"))
+    assert a[k + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2", "--dist-mode", "sharded"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
