@@ -210,7 +210,7 @@ int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int64_t n_users, int
  * row update per triplet instead of two (the item-major kernel sits at the atomic units' ceiling: DESIGN.md s4).  The
  * negative-side updates of an epoch are applied after its positive-side ones, with the epoch-end P[u]: a reordering of
  * the same terms.  d_work: qrec_bpr_deferred_work_bytes(n, n_items) bytes of scratch, laid out as
- *   float g[n] | int32 order[n] | int32 j_sorted[n] (each rounded up to 256 bytes) | the sort's own scratch.
+ *   float g[n] | int32 order[n] | int32 j_sorted[n] | int32 keys[n] (each rounded up to 256 bytes) | the sort's own scratch.
  * qrec_bpr_deferred_sort puts the j order of the negatives d_j into d_work: a STABLE sort by j (inside a run of equal j
  * the triplets keep their storage order), so pass B is a deterministic function of the arrays; the engine runs it on the
  * sampler's side stream, under the previous epoch.  `flags`: bit 0 (QREC_DEFERRED_SORTED) -- d_work already holds the j order
@@ -221,6 +221,20 @@ int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int64_t n_users, int
  * changes nothing at BPR.conf's rate).                                                                     */
 #define QREC_DEFERRED_SORTED 1
 #define QREC_DEFERRED_FRESH 2
+/* Sub-epochs (sub_epochs = S in 1..16): the epoch's time slots -- the order the item-major kernel visits its chunks in -- are cut
+ * into S consecutive ranges; range s is one launch of pass A followed by one of pass B over that range's triplets (sorted by
+ * (range, j): qrec_bpr_deferred_sort_sub with the SAME chunk and S).  With stream_b != NULL pass B of range s runs on stream_b,
+ * under pass A of range s + 1 on `stream` (`stream` waits for the last pass B at the end): the negative item's row lags the rest
+ * by about one range instead of one epoch, and pass B's time hides under pass A's.  stream_b == NULL: everything in order on
+ * `stream` -- the sequential statement of the sub-epoch schedule (tests).  d_work's layout gains a key array:
+ *   float g[n] | int32 order[n] | int32 sorted keys[n] | int32 keys[n] (each rounded up to 256 bytes) | the sort's scratch.   */
+int qrec_bpr_deferred_sort_sub(const int32_t *d_j, int64_t n, int64_t n_items, int32_t chunk, int32_t sub_epochs, void *d_work,
+                               void *stream);
+int qrec_bpr_sgd_hogwild_item_major_deferred_sub(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld,
+                                                 const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
+                                                 int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
+                                                 double *d_loss, const double *d_driver_state, void *d_work, int32_t flags,
+                                                 int32_t sub_epochs, void *stream_b, void *stream);
 int qrec_bpr_deferred_work_bytes(int64_t n, int64_t n_items, int64_t *bytes);
 int qrec_bpr_deferred_sort(const int32_t *d_j, int64_t n, int64_t n_items, void *d_work, void *stream);
 int qrec_bpr_sgd_hogwild_item_major_deferred(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld,

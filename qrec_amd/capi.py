@@ -65,6 +65,8 @@ _SIGNATURES = {
     "qrec_bpr_sgd_hogwild_item_major": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp],
     "qrec_bpr_deferred_work_bytes": [_i64, _i64, _vp],
     "qrec_bpr_deferred_sort": [_vp, _i64, _i64, _vp, _vp],
+    "qrec_bpr_deferred_sort_sub": [_vp, _i64, _i64, _i32, _i32, _vp, _vp],
+    "qrec_bpr_sgd_hogwild_item_major_deferred_sub": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "qrec_bpr_sgd_hogwild_item_major_deferred": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _i32, _vp],
     "qrec_epoch_close": [_vp, _i64, _vp, _i64, C.c_int, _i32, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
     "qrec_epoch_sums": [_vp, _i64, _vp, _i64, C.c_int, _i32, _vp, _vp, _vp],
@@ -960,6 +962,23 @@ def bpr_sgd_hogwild_item_major_deferred(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j
     _check(load().qrec_bpr_sgd_hogwild_item_major_deferred(_dp(d_P), _dp(d_Q), p_rows or _table_rows(d_P, ld), q_rows or _table_rows(d_Q, ld), d, ld,
                                                            _dp(d_u), _dp(d_i), _dp(d_j), n, chunk, grid_groups, flush_every, lr, regU, regI,
                                                            _dp(d_loss), _dp(d_driver_state), _dp(d_work), (1 if is_sorted else 0) | (2 if fresh else 0), _sh(stream)))
+
+
+def bpr_deferred_sort_sub(d_j, n: int, n_items: int, chunk: int, sub_epochs: int, d_work, stream=None):
+    """the (sub-epoch, j) order of the negatives for ``bpr_sgd_hogwild_item_major_deferred_sub`` with the SAME chunk and sub-epoch count"""
+    _check(load().qrec_bpr_deferred_sort_sub(_dp(d_j), n, n_items, chunk, sub_epochs, _dp(d_work), _sh(stream)))
+
+
+def bpr_sgd_hogwild_item_major_deferred_sub(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int, chunk: int, grid_groups: int,
+                                            flush_every: int, lr: float, regU: float, regI: float, d_loss, d_work, sub_epochs: int,
+                                            stream=None, stream_b=None, d_driver_state=None, p_rows: int | None = None,
+                                            q_rows: int | None = None, is_sorted: bool = False, fresh: bool = False):
+    """deferred negatives in ``sub_epochs`` ranges of the epoch's time slots; ``stream_b``: pass B of a range runs there, under pass
+    A of the next range on ``stream`` (None: everything in order on ``stream``)"""
+    _check(load().qrec_bpr_sgd_hogwild_item_major_deferred_sub(
+        _dp(d_P), _dp(d_Q), p_rows or _table_rows(d_P, ld), q_rows or _table_rows(d_Q, ld), d, ld, _dp(d_u), _dp(d_i), _dp(d_j), n, chunk,
+        grid_groups, flush_every, lr, regU, regI, _dp(d_loss), _dp(d_driver_state), _dp(d_work), (1 if is_sorted else 0) | (2 if fresh else 0),
+        sub_epochs, _sh(stream_b), _sh(stream)))
 
 
 DRV_LR, DRV_LAST_LOSS, DRV_EPOCHS, DRV_CONVERGED, DRV_FAILED, DRV_WORDS = 0, 1, 2, 3, 4, 8

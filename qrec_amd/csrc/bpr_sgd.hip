@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
     const int32_t *__restrict__ u_idx, const int32_t *__restrict__ i_idx,
     const int32_t *__restrict__ j_idx, int64_t n, int chunk, int64_t n_chunks, int64_t chunk_stride,
     int64_t groups_active, int flush_every, HwRate rate, double *__restrict__ loss_out, float *__restrict__ glog = nullptr,
-    int log_dot = 0) {
+    int log_dot = 0, int64_t slot_lo = 0, int64_t slot_hi = -1) {
     constexpr int GPW = kWave / LPR;
     float lr, cu, ci;
     if (!hw_rate_resolve(rate, lr, cu, ci)) return;
@@ -583,7 +583,8 @@ __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
     float loss = 0.f;
     double loss_acc = 0.0;
 
-    for (int64_t slot = gid; slot < n_chunks && gid < groups_active; slot += groups_active) {
+    if (slot_hi < 0) slot_hi = n_chunks;       // a sub-epoch of the deferred schedule runs the time slots [slot_lo, slot_hi) only
+    for (int64_t slot = slot_lo + gid; slot < slot_hi && gid < groups_active; slot += groups_active) {
         const int64_t c = (int64_t)(((unsigned __int128)slot * (unsigned __int128)chunk_stride) % (unsigned __int128)n_chunks);
         const int64_t t0 = c * chunk;
         const int len = (int)((n - t0) < chunk ? (n - t0) : chunk);
@@ -671,7 +672,8 @@ template <int LPR, int E, typename TAB>
 __global__ __launch_bounds__(256) void bpr_deferred_negatives_kernel(
     float *__restrict__ P, float *__restrict__ Q, int64_t p_bytes, int64_t q_bytes, const int32_t *__restrict__ u_idx,
     const int32_t *__restrict__ j_sorted, const float *__restrict__ glog, const int32_t *__restrict__ perm, int64_t n, int chunk,
-    int64_t n_chunks, int64_t groups_active, HwRate rate, int fresh) {
+    int64_t n_chunks, int64_t groups_active, HwRate rate, int fresh, int64_t first = 0, int32_t j_mask = 0x7fffffff) {
+    // the sorted positions [first, first + n): a sub-epoch's triplets (the keys carry the sub-epoch above the item id: j_mask)
     constexpr int GPW = kWave / LPR;
     float lr, cu, ci;
     if (!hw_rate_resolve(rate, lr, cu, ci)) return;
@@ -686,7 +688,7 @@ __global__ __launch_bounds__(256) void bpr_deferred_negatives_kernel(
     for (int64_t c = gid; c < n_chunks && gid < groups_active; c += groups_active) {
         const int64_t p0 = c * chunk;
         const int len = (int)((n - p0) < chunk ? (n - p0) : chunk);
-        for (int k = r; k < len; k += LPR) { const int32_t t = perm[p0 + k]; su[k] = u_idx[t]; sj[k] = j_sorted[p0 + k]; sg[k] = glog[t]; }
+        for (int k = r; k < len; k += LPR) { const int32_t t = perm[first + p0 + k]; su[k] = u_idx[t]; sj[k] = j_sorted[first + p0 + k] & j_mask; sg[k] = glog[t]; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -730,8 +732,9 @@ __global__ __launch_bounds__(256) void bpr_deferred_negatives_kernel(
 // under pass A's atomic stream, and a run order that changed from launch to launch -- with lr regI m ~ 1e-2 over a run of m
 // terms that moved Q rows by 1e-3.)  A call of its own: the engine runs it on the sampler's side stream.
 struct DeferredWork {
-    float *glog; int32_t *perm; int32_t *jsorted; void *temp; size_t temp_bytes;
+    float *glog; int32_t *perm; int32_t *jsorted; int32_t *keys; void *temp; size_t temp_bytes;
 };
+constexpr int kMaxSubEpochs = 16;
 static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 static inline unsigned key_bits(int64_t n_keys) { unsigned b = 1; while (((int64_t)1 << b) < n_keys) b++; return b; }
 int deferred_temp_bytes(int64_t n, int64_t n_keys, size_t *bytes) {
@@ -753,8 +756,9 @@ int deferred_carve(void *work, int64_t n, int64_t n_keys, DeferredWork *w) {
     w->glog = (float *)p; p += align256((size_t)n * 4);
     w->perm = (int32_t *)p; p += align256((size_t)n * 4);
     w->jsorted = (int32_t *)p; p += align256((size_t)n * 4);
+    w->keys = (int32_t *)p; p += align256((size_t)n * 4);
     w->temp = p;
-    return deferred_temp_bytes(n, n_keys, &w->temp_bytes);
+    return deferred_temp_bytes(n, n_keys * kMaxSubEpochs, &w->temp_bytes);      // room for the sub-epoch bits above the item id
 }
 int sort_by_negative(const int32_t *j, int64_t n, int64_t n_keys, const DeferredWork &w, hipStream_t st) {
     if (n == 0) return QREC_OK;
@@ -762,6 +766,116 @@ int sort_by_negative(const int32_t *j, int64_t n, int64_t n_keys, const Deferred
     const hipError_t e = rocprim::radix_sort_pairs(w.temp, tb, j, w.jsorted, rocprim::counting_iterator<int32_t>(0), w.perm, (size_t)n,
                                                    0u, key_bits(n_keys), st);
     QREC_REQUIRE(e == hipSuccess, "qrec_bpr_deferred_sort: rocprim::radix_sort_pairs failed");
+    return QREC_OK;
+}
+
+// ---- sub-epochs (round 3): the epoch's time slots cut into S consecutive ranges; pass B of range s runs on a second stream under
+// pass A of range s + 1.  The negative item's row then lags the positive side by about one range instead of one epoch, and pass
+// B's time disappears under pass A's.  Sort key of triplet t = (sub-epoch of its chunk's time slot) above (its negative item).
+struct SubPlan {
+    int S; int64_t n_chunks, stride, inv; int bits_j;
+    int64_t slot_bound[kMaxSubEpochs + 1], first[kMaxSubEpochs + 1];
+};
+static int64_t chunk_stride_of(int64_t n_chunks) {
+    int64_t stride = (int64_t)((double)n_chunks * 0.6180339887498949);
+    if (stride < 1) stride = 1;
+    auto gcd = [](int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; };
+    while (gcd(stride, n_chunks) != 1) stride++;
+    return stride;
+}
+static SubPlan make_sub_plan(int64_t n, int chunk, int S, int64_t n_keys) {
+    SubPlan p{};
+    p.S = S; p.n_chunks = (n + chunk - 1) / chunk; p.stride = chunk_stride_of(p.n_chunks); p.bits_j = (int)key_bits(n_keys);
+    // inv = stride^-1 mod n_chunks (extended Euclid): the time slot of chunk c is c * inv mod n_chunks
+    int64_t a = p.stride % p.n_chunks, m = p.n_chunks, x0 = 1, x1 = 0;
+    while (m > 0 && a > 1) { const int64_t q = a / m, t = m; m = a % m; a = t; const int64_t tx = x1; x1 = x0 - q * x1; x0 = tx; }
+    p.inv = p.n_chunks == 1 ? 0 : ((x0 % p.n_chunks) + p.n_chunks) % p.n_chunks;
+    const int64_t last_len = n - (p.n_chunks - 1) * (int64_t)chunk;
+    const int64_t last_slot = (int64_t)(((unsigned __int128)(p.n_chunks - 1) * (unsigned __int128)p.inv) % (unsigned __int128)p.n_chunks);
+    p.first[0] = 0;
+    for (int s = 0; s <= S; s++) p.slot_bound[s] = ((int64_t)s * p.n_chunks + S - 1) / S;      // sub(slot) = slot * S / n_chunks
+    for (int s = 0; s < S; s++) {
+        int64_t cnt = (p.slot_bound[s + 1] - p.slot_bound[s]) * (int64_t)chunk;
+        if (last_slot >= p.slot_bound[s] && last_slot < p.slot_bound[s + 1]) cnt -= chunk - last_len;
+        p.first[s + 1] = p.first[s] + cnt;
+    }
+    return p;
+}
+__global__ void deferred_keys_kernel(const int32_t *__restrict__ j, int64_t n, int chunk, int64_t n_chunks, int64_t inv, int S, int bits_j,
+                                     int32_t *__restrict__ keys) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = t / chunk;
+        const int64_t slot = (int64_t)(((unsigned __int128)c * (unsigned __int128)inv) % (unsigned __int128)n_chunks);
+        const int32_t sub = (int32_t)((slot * S) / n_chunks);
+        keys[t] = (sub << bits_j) | j[t];
+    }
+}
+int sort_by_sub_and_negative(const int32_t *j, int64_t n, int64_t n_keys, int chunk, int S, const DeferredWork &w, hipStream_t st) {
+    if (n == 0) return QREC_OK;
+    const SubPlan p = make_sub_plan(n, chunk, S, n_keys);
+    int sub_bits = 0; while ((1 << sub_bits) < S) sub_bits++;
+    QREC_REQUIRE(p.bits_j + sub_bits <= 31, "qrec_bpr_deferred_sort_sub: item ids and sub-epochs do not fit a 31-bit key");
+    hipLaunchKernelGGL(deferred_keys_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, j, n, chunk, p.n_chunks,
+                       p.inv, S, p.bits_j, w.keys);
+    size_t tb = w.temp_bytes;
+    const hipError_t e = rocprim::radix_sort_pairs(w.temp, tb, (const int32_t *)w.keys, w.jsorted, rocprim::counting_iterator<int32_t>(0), w.perm,
+                                                   (size_t)n, 0u, (unsigned)(p.bits_j + sub_bits), st);
+    QREC_REQUIRE(e == hipSuccess, "qrec_bpr_deferred_sort_sub: rocprim::radix_sort_pairs failed");
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+template <int LPR, int E>
+int launch_hogwild_item_deferred_sub(float *P, float *Q, int64_t pb, int64_t qb, const int32_t *u, const int32_t *i, const int32_t *j,
+                                     int64_t n, int64_t n_keys, int chunk, int64_t groups, int flush_every, HwRate rate, double *loss,
+                                     const DeferredWork &w, bool sorted, int fresh, int S, hipStream_t st, hipStream_t st_b) {
+    constexpr int GPW = kWave / LPR;
+    const SubPlan p = make_sub_plan(n, chunk, S, n_keys);
+    const int64_t default_groups = (int64_t)1024 * 4 * GPW, max_groups = (int64_t)256 * 8 * 4 * GPW;
+    if (groups <= 0) groups = default_groups;
+    if (groups > max_groups) groups = max_groups;
+    if (!sorted) {
+        const int rc = sort_by_sub_and_negative(j, n, n_keys, chunk, S, w, st);
+        if (rc != QREC_OK) return rc;
+    }
+    static thread_local hipEvent_t ev[kMaxSubEpochs + 2] = {};
+    if (st_b && !ev[0])
+        for (auto &e : ev) QREC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    constexpr int kChunkB = 32;                      // pass B walks runs of equal j: its chunks need not be pass A's
+    const int32_t j_mask = (int32_t)((1u << p.bits_j) - 1);
+    if (st_b) {     // pass B's stream starts behind everything enqueued so far (the sort, the previous epoch)
+        QREC_HIP_CHECK(hipEventRecord(ev[kMaxSubEpochs + 1], st));
+        QREC_HIP_CHECK(hipStreamWaitEvent(st_b, ev[kMaxSubEpochs + 1], 0));
+    }
+    for (int s = 0; s < S; s++) {
+        const int64_t slots = p.slot_bound[s + 1] - p.slot_bound[s], cnt = p.first[s + 1] - p.first[s];
+        if (slots <= 0) continue;
+        const int64_t ga = std::min<int64_t>(groups, slots);
+        const unsigned blocks_a = (unsigned)((ga + 4 * GPW - 1) / (4 * GPW));
+        const int64_t chunks_b = (cnt + kChunkB - 1) / kChunkB, gb = std::min<int64_t>(groups, chunks_b);
+        const unsigned blocks_b = (unsigned)((gb + 4 * GPW - 1) / (4 * GPW));
+        hipStream_t sb = st_b ? st_b : st;
+        if (pb < kBufLimit && qb < kBufLimit) {
+            hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E, TabBuf, true>), dim3(blocks_a), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, chunk,
+                               p.n_chunks, p.stride, ga, flush_every, rate, loss, w.glog, fresh, p.slot_bound[s], p.slot_bound[s + 1]);
+            if (st_b) { QREC_HIP_CHECK(hipEventRecord(ev[s], st)); QREC_HIP_CHECK(hipStreamWaitEvent(st_b, ev[s], 0)); }
+            if (cnt > 0)
+                hipLaunchKernelGGL((bpr_deferred_negatives_kernel<LPR, E, TabBuf>), dim3(blocks_b), dim3(256), 0, sb, P, Q, pb, qb, u, w.jsorted, w.glog,
+                                   w.perm, cnt, kChunkB, chunks_b, gb, rate, fresh, p.first[s], j_mask);
+        } else {
+            hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E, TabPtr, true>), dim3(blocks_a), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, chunk,
+                               p.n_chunks, p.stride, ga, flush_every, rate, loss, w.glog, fresh, p.slot_bound[s], p.slot_bound[s + 1]);
+            if (st_b) { QREC_HIP_CHECK(hipEventRecord(ev[s], st)); QREC_HIP_CHECK(hipStreamWaitEvent(st_b, ev[s], 0)); }
+            if (cnt > 0)
+                hipLaunchKernelGGL((bpr_deferred_negatives_kernel<LPR, E, TabPtr>), dim3(blocks_b), dim3(256), 0, sb, P, Q, pb, qb, u, w.jsorted, w.glog,
+                                   w.perm, cnt, kChunkB, chunks_b, gb, rate, fresh, p.first[s], j_mask);
+        }
+    }
+    if (st_b) {     // the epoch is over when the last pass B is: the caller's stream waits for it
+        QREC_HIP_CHECK(hipEventRecord(ev[kMaxSubEpochs], st_b));
+        QREC_HIP_CHECK(hipStreamWaitEvent(st, ev[kMaxSubEpochs], 0));
+    }
+    QREC_LAUNCH_CHECK();
     return QREC_OK;
 }
 
@@ -1043,11 +1157,11 @@ int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int64_t n_users, int
 
 int qrec_bpr_deferred_work_bytes(int64_t n, int64_t n_items, int64_t *bytes) {
     QREC_REQUIRE(bytes && n >= 0 && n < (1ll << 31) && n_items >= 1 && n_items < (1ll << 31) - 2, "qrec_bpr_deferred_work_bytes: bad arguments");
-    // glog float[n] | perm int32[n] | j_sorted int32[n] (each rounded up to 256 bytes) | the radix sort's scratch
+    // glog float[n] | perm int32[n] | j_sorted int32[n] | sort keys int32[n] (each rounded up to 256 bytes) | the radix sort's scratch
     size_t tb = 0;
-    const int rc = deferred_temp_bytes(n, n_items, &tb);
+    const int rc = deferred_temp_bytes(n, n_items * kMaxSubEpochs, &tb);
     if (rc != QREC_OK) return rc;
-    *bytes = (int64_t)(3 * align256((size_t)n * 4) + tb);
+    *bytes = (int64_t)(4 * align256((size_t)n * 4) + tb);
     return QREC_OK;
 }
 
@@ -1085,6 +1199,49 @@ int qrec_bpr_sgd_hogwild_item_major_deferred(float *d_P, float *d_Q, int64_t n_u
     const int sorted = flags & QREC_DEFERRED_SORTED;
 #define QREC_DEF(LPR, E) launch_hogwild_item_deferred<LPR, E>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, n_items, chunk, grid_groups, \
                                                                flush_every, rate, d_loss, w, sorted != 0, fresh, st)
+    switch (ld) {
+        case 32: return QREC_DEF(16, 2);
+        case 64: return QREC_DEF(16, 4);
+        case 128: return QREC_DEF(32, 4);
+        default: return QREC_DEF(64, 4);
+    }
+#undef QREC_DEF
+}
+
+int qrec_bpr_deferred_sort_sub(const int32_t *d_j, int64_t n, int64_t n_items, int32_t chunk, int32_t sub_epochs, void *d_work, void *stream) {
+    QREC_REQUIRE(n >= 0 && n < (1ll << 31) && n_items >= 1 && n_items < (1ll << 31) - 2, "qrec_bpr_deferred_sort_sub: bad sizes");
+    QREC_REQUIRE(chunk >= 1 && chunk <= kMaxChunk && sub_epochs >= 1 && sub_epochs <= kMaxSubEpochs, "qrec_bpr_deferred_sort_sub: chunk in 1..%d, sub-epochs in 1..%d", kMaxChunk, kMaxSubEpochs);
+    if (n == 0) return QREC_OK;
+    QREC_REQUIRE(d_j && d_work, "qrec_bpr_deferred_sort_sub: null argument");
+    DeferredWork w;
+    const int rc = deferred_carve(d_work, n, n_items, &w);
+    if (rc != QREC_OK) return rc;
+    return sort_by_sub_and_negative(d_j, n, n_items, chunk, sub_epochs, w, as_stream(stream));
+}
+
+int qrec_bpr_sgd_hogwild_item_major_deferred_sub(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld,
+                                                 const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
+                                                 int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
+                                                 double *d_loss, const double *d_driver_state, void *d_work, int32_t flags,
+                                                 int32_t sub_epochs, void *stream_b, void *stream) {
+    QREC_REQUIRE(d_P && d_Q && d_loss && n >= 0 && n < (1ll << 31), "qrec_bpr_sgd_hogwild_item_major_deferred_sub: bad argument");
+    QREC_REQUIRE(n == 0 || (d_u && d_i && d_j && d_work), "qrec_bpr_sgd_hogwild_item_major_deferred_sub: null array");
+    QREC_REQUIRE(ld >= d && d >= 1, "qrec_bpr_sgd_hogwild_item_major_deferred_sub: need ld >= d >= 1");
+    QREC_REQUIRE(ld == 32 || ld == 64 || ld == 128 || ld == 256,
+                 "qrec_bpr_sgd_hogwild_item_major_deferred_sub: row stride must be 32, 64, 128 or 256 floats (got ld=%d)", ld);
+    QREC_REQUIRE(chunk >= 1 && chunk <= kMaxChunk && flush_every >= 1, "qrec_bpr_sgd_hogwild_item_major_deferred_sub: bad chunk / flush interval");
+    QREC_REQUIRE(sub_epochs >= 1 && sub_epochs <= kMaxSubEpochs, "qrec_bpr_sgd_hogwild_item_major_deferred_sub: sub-epochs in 1..%d", kMaxSubEpochs);
+    if (n == 0) return QREC_OK;
+    QREC_REQUIRE(n_users >= 1 && n_items >= 1 && n_items < (1ll << 31) - 2, "qrec_bpr_sgd_hogwild_item_major_deferred_sub: table row counts must be given");
+    const int64_t full_p = n_users * (int64_t)ld * 4, full_q = n_items * (int64_t)ld * 4;
+    const HwRate rate{lr, regU, regI, d_driver_state};
+    DeferredWork w;
+    const int rcw = deferred_carve(d_work, n, n_items, &w);
+    if (rcw != QREC_OK) return rcw;
+    const int fresh = (flags & QREC_DEFERRED_FRESH) ? 1 : 0;
+    const bool sorted = (flags & QREC_DEFERRED_SORTED) != 0;
+#define QREC_DEF(LPR, E) launch_hogwild_item_deferred_sub<LPR, E>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, n_items, chunk, grid_groups, flush_every, \
+                                                                   rate, d_loss, w, sorted, fresh, sub_epochs, as_stream(stream), as_stream(stream_b))
     switch (ld) {
         case 32: return QREC_DEF(16, 2);
         case 64: return QREC_DEF(16, 4);

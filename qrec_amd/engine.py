@@ -97,7 +97,8 @@ class BprSgd:
     so they overlap almost perfectly."""
 
     def __init__(self, tables: DeviceTables, u: np.ndarray, i: np.ndarray, pos: CSR | None = None,
-                 schedule: str = "user", n_items: int | None = None, batches: int = 1, chunk: int = 32):
+                 schedule: str = "user", n_items: int | None = None, batches: int = 1, chunk: int = 32,
+                 sub_epochs: int | None = None, sub_chunk: int | None = None, overlap_passes: bool = True):
         """``schedule``: "user" keeps the reference's user-major order (required by the order-exact
         kernel); "item" stores the same triplets sorted by positive item for the item-major
         throughput kernel (``self.perm`` maps scheduled position -> reference position).
@@ -114,6 +115,16 @@ class BprSgd:
         self.deferred = schedule == "item-deferred"
         if self.deferred:
             schedule = "item"
+        # sub-epochs of the deferred schedule (include/qrec_hip.h qrec_bpr_sgd_hogwild_item_major_deferred_sub): the epoch's time slots
+        # in S ranges, pass B of a range on a second stream under pass A of the next; pass A then runs on chunks of `sub_chunk`
+        # triplets (a range must still fill the grid a few times over), whatever chunk the epoch calls pass
+        import os as _os
+        self.sub_epochs = int(sub_epochs if sub_epochs is not None else _os.environ.get("QREC_DEFERRED_SUB", "1")) if self.deferred else 1
+        # (32-triplet chunks while a range still fills the 16,384-group grid four times over, else 8: measured)
+        auto_chunk = 32 if int(u.size) // max(self.sub_epochs, 1) >= (1 << 21) else 8
+        self.sub_chunk = int(sub_chunk if sub_chunk is not None else _os.environ.get("QREC_DEFERRED_SUB_CHUNK", auto_chunk))
+        self._overlap_passes = bool(overlap_passes) and _os.environ.get("QREC_DEFERRED_SERIAL") != "1"
+        self._stream_b = None
         self.t = tables
         # size of the item catalogue the triplets' ids refer to: the table's rows, except when this process holds only a
         # row shard of the item table (qrec_amd/dist.py) and the ids are global
@@ -204,9 +215,29 @@ class BprSgd:
         capi.philox_bpr_sample(self._pos_dev[0], self._pos_dev[1], self.d_u, self.n, self.n_items,
                                seed, epoch, self.d_j_next, self._side)
         if self.deferred:        # the j order of these negatives, next to the sampler: both run under the current epoch's kernels
-            capi.bpr_deferred_sort(self.d_j_next, self.n, self.n_items, self.d_work_next, self._side)
+            self._sort_negatives(self.d_j_next, self.d_work_next, self._side)
         self._sampled.record(self._side)
         self._prefetched_epoch = epoch
+
+    def _sort_negatives(self, d_j, d_work, stream):
+        if self.sub_epochs > 1:
+            capi.bpr_deferred_sort_sub(d_j, self.n, self.n_items, self.sub_chunk, self.sub_epochs, d_work, stream)
+        else:
+            capi.bpr_deferred_sort(d_j, self.n, self.n_items, d_work, stream)
+
+    def _deferred_epoch(self, P, Q, d_u, d_i, d_j, n, chunk, groups, flush_every, lr, regU, regI, stream, d_drv=None, p_rows=None):
+        """both passes of the deferred schedule (all sub-epochs) on (P, Q)"""
+        t = self.t
+        if self.sub_epochs > 1:
+            if self._overlap_passes and self._stream_b is None:
+                self._stream_b = capi.Stream()
+            capi.bpr_sgd_hogwild_item_major_deferred_sub(P, Q, t.d, t.ld, d_u, d_i, d_j, n, self.sub_chunk, groups, min(flush_every, self.sub_chunk),
+                                                         lr, regU, regI, self.d_stats, self.d_work, self.sub_epochs, stream,
+                                                         self._stream_b if self._overlap_passes else None, d_drv, p_rows=p_rows,
+                                                         is_sorted=self._sorted)
+        else:
+            capi.bpr_sgd_hogwild_item_major_deferred(P, Q, t.d, t.ld, d_u, d_i, d_j, n, chunk, groups, flush_every, lr, regU, regI,
+                                                     self.d_stats, self.d_work, stream, d_drv, p_rows=p_rows, is_sorted=self._sorted)
 
     def take_prefetched_negatives(self, epoch: int, stream=None):
         """Make `stream` wait for the prefetched negatives of `epoch` and switch to them."""
@@ -321,9 +352,7 @@ class BprSgd:
             raise TypeError("throughput mode needs fp32 tables")
         capi.memset(self.d_stats.ptr, 0, 8, stream)
         if self.deferred:
-            capi.bpr_sgd_hogwild_item_major_deferred(self.t.P, self.t.Q, self.t.d, self.t.ld, self.d_u, self.d_i, self.d_j,
-                                                     self.n, chunk, groups, flush_every, lr, regU, regI, self.d_stats, self.d_work, stream,
-                                                     is_sorted=self._sorted)
+            self._deferred_epoch(self.t.P, self.t.Q, self.d_u, self.d_i, self.d_j, self.n, chunk, groups, flush_every, lr, regU, regI, stream)
         elif self.schedule == "item":
             capi.bpr_sgd_hogwild_item_major(self.t.P, self.t.Q, self.t.d, self.t.ld, self.d_u, self.d_i, self.d_j,
                                             self.n, chunk, groups, flush_every, lr, regU, regI, self.d_stats, stream)
@@ -407,8 +436,7 @@ class BprSgd:
         triplets' item ids rewritten to its rows; learning rate and stop flags come from the device-side driver"""
         t = self.t
         if self.deferred and q_rows is None:         # (a shard's row cache -- q_rows given -- keeps the one-pass kernel: its ids are cache slots)
-            capi.bpr_sgd_hogwild_item_major_deferred(P, Q, t.d, t.ld, d_u, d_i, d_j, n, chunk, groups, flush_every, 0.0, regU, regI,
-                                                     self.d_stats, self.d_work, stream, self.d_drv, p_rows=t.n_users, is_sorted=self._sorted)
+            self._deferred_epoch(P, Q, d_u, d_i, d_j, n, chunk, groups, flush_every, 0.0, regU, regI, stream, self.d_drv, p_rows=t.n_users)
         elif self.schedule == "item":
             capi.bpr_sgd_hogwild_item_major(P, Q, t.d, t.ld, d_u, d_i, d_j, n, chunk, groups, flush_every, 0.0, regU, regI,
                                             self.d_stats, stream, self.d_drv, p_rows=t.n_users, q_rows=q_rows)

@@ -586,6 +586,95 @@ def test_deferred_fresh_coefficient_single_group_is_its_sequential_statement(dim
     check("deferred (fresh coefficient), one group: loss vs its sequential statement", abs(sgd.loss() - lref) / lref, F32_TOL)
 
 
+def _sub_epoch_ranges(n, chunk, S):
+    """positions (into the visiting order of _item_major_visit_order) where the S sub-epochs of the deferred schedule begin:
+    sub-epoch s = the time slots [ceil(s n_chunks / S), ceil((s + 1) n_chunks / S))  (bpr_sgd.hip make_sub_plan)"""
+    from math import gcd
+    n_chunks = -(-n // chunk)
+    stride = max(1, int(n_chunks * 0.6180339887498949))
+    while gcd(stride, n_chunks) != 1:
+        stride += 1
+    bounds = [-(-s * n_chunks // S) for s in range(S + 1)]
+    first, at = [0], 0
+    for s in range(S):
+        for slot in range(bounds[s], bounds[s + 1]):
+            c = (slot * stride) % n_chunks
+            at += min((c + 1) * chunk, n) - c * chunk
+        first.append(at)
+    return first
+
+
+@pytest.mark.parametrize("dim,chunk,flush,S,fresh", [(64, 8, 8, 4, False), (50, 7, 3, 3, False), (128, 16, 16, 2, True), (8, 5, 2, 16, False)])
+def test_deferred_sub_epochs_single_group_in_order_is_their_sequential_statement(dim, chunk, flush, S, fresh):
+    """qrec_bpr_sgd_hogwild_item_major_deferred_sub with ONE group and no second stream: sub-epoch after sub-epoch, pass A over the
+    range's time slots then pass B over the range's triplets by (j, storage position) -- the statement composed from the oracle's
+    two-pass definition, range by range.  The device sort is held to the same (range, j, position) order."""
+    d, indptr, ind, u, j = _synthetic("small")
+    U, I, n = d["n_users"], d["n_items"], ind.size
+    rng = np.random.default_rng(dim + S)
+    P0 = rng.random((U, dim)) / 3; Q0 = rng.random((I, dim)) / 3
+    t = DeviceTables(P0, Q0, np.float32)
+    sgd = BprSgd(t, u, ind, schedule="item-deferred", sub_epochs=S, sub_chunk=chunk, overlap_passes=False); sgd.set_negatives(j)
+    us, is_, js = sgd.d_u.numpy(), sgd.d_i.numpy(), sgd.d_j.numpy()
+    order = _item_major_visit_order(n, chunk)
+    first = _sub_epoch_ranges(n, chunk, S)
+    assert first[-1] == n
+    Pr, Qr = P0.copy(), Q0.copy(); lref = 0.0; want_perm = []
+    for s in range(S):
+        o = order[first[s]:first[s + 1]]
+        ua, ia, ja = (np.ascontiguousarray(x[o]) for x in (us, is_, js))
+        jo = np.lexsort((o, ja)).astype(np.int64)
+        want_perm.append(o[jo])
+        lref += O.bpr_sgd_deferred(Pr, Qr, ua, ia, ja, jo, 0.05, 0.01, 0.02, fresh=int(fresh))
+    sgd.d_stats.fill_bytes(0)
+    capi.bpr_sgd_hogwild_item_major_deferred_sub(t.P, t.Q, dim, t.ld, sgd.d_u, sgd.d_i, sgd.d_j, n, chunk, 1, flush, 0.05, 0.01, 0.02, sgd.d_stats,
+                                                 sgd.d_work, S, fresh=fresh)
+    Pg, Qg = t.download()
+    check("deferred sub-epochs, one group: P vs the sequential statement", rel_err(Pg, Pr), F32_TOL)
+    check("deferred sub-epochs, one group: Q vs the sequential statement", rel_err(Qg, Qr), F32_TOL)
+    check("deferred sub-epochs, one group: loss vs the sequential statement", abs(sgd.loss() - lref) / lref, F32_TOL)
+    assert np.array_equal(_deferred_perm(sgd.d_work, n), np.concatenate(want_perm))
+    assert (t.P.numpy()[:, dim:] == 0).all() and (t.Q.numpy()[:, dim:] == 0).all()
+
+
+def test_deferred_sub_epochs_overlapped_full_grid_properties():
+    """the production form -- pass B of a range on a second stream under pass A of the next -- at the Yelp2018 shape: lr = 0 moves
+    nothing and reports the static loss; a real epoch loses no update (finite, untouched rows bit-identical, a few percent from the
+    in-order statement); the prefetch path sorts next to the sampler."""
+    from qrec_amd.interactions import CSR
+    d, indptr, ind, u, j = _synthetic("yelp2018", seed=1)
+    U, I, n, dim, S, chunk = d["n_users"], d["n_items"], ind.size, 64, 4, 8
+    rng = np.random.default_rng(0)
+    P0 = (rng.random((U, dim)) / 3).astype(np.float32); Q0 = (rng.random((I, dim)) / 3).astype(np.float32)
+    t = DeviceTables(P0, Q0, np.float32)
+    sgd = BprSgd(t, u, ind, CSR(indptr, ind), schedule="item-deferred", sub_epochs=S, sub_chunk=chunk); sgd.set_negatives(j)
+    sgd.epoch_throughput_async(0.0, 0.001, 0.001); capi.device_sync()
+    Pg, Qg = t.download(np.float32)
+    assert np.array_equal(Pg, P0) and np.array_equal(Qg, Q0)
+    lz = O.bpr_sgd(P0.astype(np.float64), Q0.astype(np.float64), u, ind, j, 0.0, 0.001, 0.001)
+    check("deferred sub-epochs: static loss at lr = 0", abs(sgd.loss() - lz) / lz, F32_TOL)
+    order = _item_major_visit_order(n, chunk); first = _sub_epoch_ranges(n, chunk, S)
+    us, is_, js = sgd.d_u.numpy(), sgd.d_i.numpy(), sgd.d_j.numpy()
+    Pr, Qr = P0.astype(np.float64), Q0.astype(np.float64); lref = 0.0
+    for s in range(S):
+        o = order[first[s]:first[s + 1]]
+        ua, ia, ja = (np.ascontiguousarray(x[o]) for x in (us, is_, js))
+        lref += O.bpr_sgd_deferred(Pr, Qr, ua, ia, ja, np.lexsort((o, ja)).astype(np.int64), 0.01, 0.001, 0.001)
+    sgd.epoch_throughput_async(0.01, 0.001, 0.001); capi.device_sync()
+    Pg, Qg = t.download()
+    assert np.isfinite(Pg).all() and np.isfinite(Qg).all()
+    print("deferred sub-epochs full grid vs the in-order statement: P", rel_err(Pg, Pr), "Q", rel_err(Qg, Qr), "loss", abs(sgd.loss() - lref) / lref)
+    assert rel_err(Pg, Pr) < 0.02 and rel_err(Qg, Qr) < 0.05 and abs(sgd.loss() - lref) / lref < 0.06
+    touched = np.zeros(I, bool); touched[ind] = True; touched[j] = True
+    if (~touched).any():
+        assert np.array_equal(t.Q.numpy()[~touched][:, :dim], Q0[~touched])
+    s2 = BprSgd(t, u, ind, CSR(indptr, ind), schedule="item-deferred", sub_epochs=S, sub_chunk=chunk)
+    s2.prefetch_negatives_device(3, 0); s2.take_prefetched_negatives(0)
+    assert s2._sorted
+    s2.epoch_throughput_async(0.01, 0.001, 0.001); capi.device_sync()
+    assert np.isfinite(t.download()[1]).all()
+
+
 @pytest.mark.parametrize("dim", [64, 50, 128, 8])
 @pytest.mark.parametrize("chunk,flush", [(32, 8), (7, 3), (64, 64)])
 def test_deferred_single_group_is_the_sequential_statement_of_its_order(dim, chunk, flush):
@@ -672,7 +761,7 @@ def test_deferred_recall_against_exact_order_training(lr0, seed, bound):
     P0 = (rng.random((U, dim)) / 3).astype(np.float32); Q0 = (rng.random((I, dim)) / 3).astype(np.float32)
     Pc, Qc = P0.astype(np.float64), Q0.astype(np.float64)
     t = DeviceTables(P0, Q0, np.float32)
-    sgd = BprSgd(t, u, ind, CSR(indptr, ind), schedule="item-deferred")
+    sgd = BprSgd(t, u, ind, CSR(indptr, ind), schedule="item-deferred")       # (QREC_DEFERRED_SUB / _SUB_CHUNK / _FRESH select the variant)
     lr_c = lr_g = lr0; last_c = last_g = 0.0
     for k in range(epochs):
         sgd.sample_negatives_device(seed, k)
