@@ -67,13 +67,20 @@ class BPR(IterativeRecommender):
             u, i = u[pos.indptr[lo]:pos.indptr[hi]], i[pos.indptr[lo]:pos.indptr[hi]]
             self.sampler_seed += 7919 * dp.rank
         print("training...")
-        tables = DeviceTables(self.P, self.Q, self.table_dtype)
         schedule = self.schedule
         if schedule == "auto":
             deg = np.bincount(i, minlength=len(self.data.item))
             schedule = "item" if deg.size and deg.max() > 20 * max(deg.mean(), 1e-9) else "user"
-        sgd = BprSgd(tables, u, i, pos, schedule=schedule)
         n_items = len(self.data.item)
+        layout = os.environ.get("QREC_DIST_MODE", "replicated")
+        if layout not in ("replicated", "sharded"):
+            print("QREC_DIST_MODE must be replicated or sharded")
+            raise SystemExit(-1)
+        if dp is not None and layout == "sharded":
+            self._train_sharded(pos, schedule, n_items, dp)
+            return
+        tables = DeviceTables(self.P, self.Q, self.table_dtype)
+        sgd = BprSgd(tables, u, i, pos, schedule=schedule)
         epoch = 0
         if self.mode == "throughput" and (self.ranking.isMainOn() or dp is not None):
             self._train_throughput_pipelined(sgd, dp=dp)
@@ -137,7 +144,39 @@ class BPR(IterativeRecommender):
                 break
         self.P, self.Q = tables.download(np.float64)
 
-    def _train_throughput_pipelined(self, sgd, depth: int = 3, dp=None):
+    def _train_sharded(self, pos, schedule, n_items, dp):
+        """``QREC_DIST_MODE=sharded`` (BASELINE.json's north star layout, round 3 for the drop-in class): a rank holds ITS users'
+        rows of P and its interleaved share of the item rows (item r * G + o = local row r of rank o); an epoch's batches fetch
+        the distinct item rows they touch from the owners and return their updates (qrec_amd/dist.py ShardedItemExchange).
+        Nothing is whole during training; the tables are assembled on every rank afterwards, because every rank evaluates
+        (test users are sharded, the item side of a ranking is the whole catalogue)."""
+        from ...dist import ShardedItemExchange, ShardedStep, agree_on_batches, shard_item_rows, shard_positive_csr
+        from ...engine import balanced_chunk
+        from ...interactions import CSR
+        G, rank = dp.world, dp.rank
+        lo, hi, lp, li = shard_positive_csr(pos.indptr, pos.indices, G, rank)
+        u = np.repeat(np.arange(hi - lo, dtype=np.int32), np.diff(lp)).astype(np.int32)
+        tables = DeviceTables(np.ascontiguousarray(self.P[lo:hi]), shard_item_rows(self.Q, G, rank), self.table_dtype)
+        chunk = balanced_chunk(int(u.size))
+        n_batches = agree_on_batches(dp.control, int(u.size), 1 << 20, split_from=1 << 19)
+        sgd = BprSgd(tables, u, li, CSR(lp, li), schedule="item" if schedule == "item-deferred" else schedule, n_items=n_items,
+                     batches=n_batches, chunk=chunk)
+        step = ShardedStep(dp.comm, ShardedItemExchange(dp.comm, n_items, tables.ld, tables.Q), n_batches)
+        self._train_throughput_pipelined(sgd, dp=dp, step=step)
+        P_loc, Q_loc = tables.download(np.float64)
+        # assemble: user blocks in rank order, item rows interleaved (host control plane; sizes differ by at most one row)
+        d = P_loc.shape[1]
+        rows_p, rows_q = -(-len(self.data.user) // G), -(-n_items // G)
+        pad = lambda a, r: np.concatenate([a, np.zeros((r - a.shape[0], d))]) if a.shape[0] < r else a
+        allP, allQ = dp.control.allgather_host(pad(P_loc, rows_p)), dp.control.allgather_host(pad(Q_loc, rows_q))
+        from ...dist import user_block
+        self.P = np.concatenate([allP[r][:user_block(len(self.data.user), G, r)[1] - user_block(len(self.data.user), G, r)[0]] for r in range(G)])
+        Q = np.empty((n_items, d))
+        for r in range(G):
+            Q[r::G] = allQ[r][:len(range(r, n_items, G))]
+        self.Q = Q
+
+    def _train_throughput_pipelined(self, sgd, depth: int = 3, dp=None, step=None):
         """Throughput mode without a host round trip per epoch: the epoch's loss (BPR.py:40,53), isConverged and
         updateLearningRate (base/iterativeRecommender.py:56-63,88-104) run on the device (qrec_epoch_close); the
         host enqueues epochs ``depth`` ahead and prints the reference's per-epoch line from the device log as the
@@ -150,8 +189,8 @@ class BPR(IterativeRecommender):
         device-side driver then takes the same decision on identical tables."""
         from ...engine import balanced_chunk
         chunk = balanced_chunk(sgd.n)
-        step = None
-        if dp is not None:
+        sharded = step is not None
+        if dp is not None and step is None:
             from ...dist import ReplicatedStep, ReplicatedTableSync
             step = ReplicatedStep(dp.comm, ReplicatedTableSync(dp.comm, sgd.t.Q), ReplicatedTableSync(dp.comm, sgd.t.P))
         sgd.start_device_driver(self.lRate, log_capacity=self.maxEpoch)
@@ -180,8 +219,13 @@ class BPR(IterativeRecommender):
         done, retired = False, 0
         for epoch in range(self.maxEpoch):
             sgd.take_prefetched_negatives(epoch, stream)
-            sgd.epoch_device_async(self.regU, self.regI, self.maxLRate, tol=1e-3, chunk=chunk, dist=step, stream=stream)
-            sgd.prefetch_negatives_device(self.sampler_seed, epoch + 1)      # released under this epoch's SGD kernel
+            if sharded:        # plan (adopting the one begun inside the previous epoch), then the batches; the next epoch's sampler is
+                step.prepare(sgd, stream)         # enqueued from inside, in front of the first SGD grid (engine.epoch_device_async)
+                sgd.epoch_device_async(self.regU, self.regI, self.maxLRate, tol=1e-3, chunk=chunk, dist=step, stream=stream,
+                                       after_start=lambda e=epoch: sgd.prefetch_negatives_device(self.sampler_seed, e + 1))
+            else:
+                sgd.epoch_device_async(self.regU, self.regI, self.maxLRate, tol=1e-3, chunk=chunk, dist=step, stream=stream)
+                sgd.prefetch_negatives_device(self.sampler_seed, epoch + 1)      # released under this epoch's SGD kernel
             ev = capi.Event(); ev.record(stream); closed.append(ev)
             if epoch >= depth:
                 done = retire(retired); retired += 1

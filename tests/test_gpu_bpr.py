@@ -1106,23 +1106,28 @@ def test_svdpp_kernel_and_model_reproduce_the_reference_run():
     assert np.array_equal(capi.state_from_python(random.getstate()), z["py_state"])
 
 
-def test_bpr_class_on_two_ranks_keeps_replicas_identical_and_trains_like_one_rank(tmp_path):
+@pytest.mark.parametrize("layout", ["replicated", "sharded"])
+def test_bpr_class_on_two_ranks_keeps_replicas_identical_and_trains_like_one_rank(tmp_path, layout):
     """``python -m torch.distributed.run ... qrec_amd.main BPR.conf`` path of the drop-in class (throughput mode): users
     split over the ranks, both tables reconciled by the delta all-reduce after every epoch, sum(-log sigma) added over
     the ranks so both device-side drivers take the same decisions, test users sharded at evaluation.  Two real
     processes on one device (gloo): identical tables, losses and measures on both ranks; the run behaves like the
-    one-rank run (same loss level -- different sampler streams, bounded staleness -- and the same Precision/Recall/NDCG)."""
+    one-rank run (same loss level -- different sampler streams, bounded staleness -- and the same Precision/Recall/NDCG).
+    ``layout`` = sharded (QREC_DIST_MODE, round 3): every rank holds its users' rows of P and its interleaved share of the item rows
+    while it trains, the batches' rows travel through the exchange, and the whole tables are assembled on every rank for the
+    evaluation -- the same statements hold."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     worker = os.path.join(root, "tests", "graph_dp_worker.py")
     one, two = tmp_path / "one", tmp_path / "two"
     one.mkdir(); two.mkdir()
-    env = dict(os.environ, QREC_SEED="11", QREC_DIST_TEST_ONE_DEVICE="1", QREC_MODE="throughput")
+    env = dict(os.environ, QREC_SEED="11", QREC_DIST_TEST_ONE_DEVICE="1", QREC_MODE="throughput", QREC_DIST_MODE=layout)
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    port = 29549 if layout == "replicated" else 29553
     r1 = subprocess.run([sys.executable, worker, "BPR", "0", str(one)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-3000:]
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                         "--master-port", "29549", worker, "BPR", "0", str(two)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+                         "--master-port", str(port), worker, "BPR", "0", str(two)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-3000:]
     a, b0, b1 = np.load(one / "rank0.npz"), np.load(two / "rank0.npz"), np.load(two / "rank1.npz")
     for k in ("U", "V", "losses", "measure"):
@@ -1133,6 +1138,8 @@ def test_bpr_class_on_two_ranks_keeps_replicas_identical_and_trains_like_one_ran
     print("final loss 1 rank / 2 ranks:", a["losses"][-1], b0["losses"][-1], "measures:", a["measure"], b0["measure"])
     assert a["losses"][-1] < 0.8 * a["losses"][0] and abs(b0["losses"][-1] / a["losses"][-1] - 1) < 0.5
     np.testing.assert_allclose(b0["measure"], a["measure"], atol=0.01)      # measured: within 0.0012
+    if layout == "sharded":
+        return
     # exact mode refuses to run on several ranks
     env["QREC_MODE"] = "exact"
     r3 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
