@@ -561,7 +561,8 @@ def main():
                          "note": ("events bracket the epoch's batches incl. their exchanges" if sharded else
                                   "tables (17.8 MB) are cache resident at this shape; bound = L2 atomic units, see DESIGN.md"),
                          **({"atomic_unit_floor": {"ms": 0.547, "of_this_kernel": 0.547 / avg_kernel_ms, "source": "profiles/r03_ubench_atomics4.txt "
-                                                   "(static, builder-measured): this epoch's two atomic row updates per triplet ALONE, no loads, no arithmetic"}}
+                                                   "(static, builder-measured): this epoch's two atomic row updates per triplet ALONE, no loads, no arithmetic "
+                                                   "= 308 G dword atomics/s = one dword per clock on each of the 128 L2 channels"}}
                             if args.schedule == "item" and args.shape == "yelp2018" and not use_dist else {})},
         }
         if world == 1 and not use_dist:

@@ -228,6 +228,10 @@ int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int64_t n_users, int
  * by about one range instead of one epoch, and pass B's time hides under pass A's.  stream_b == NULL: everything in order on
  * `stream` -- the sequential statement of the sub-epoch schedule (tests).  d_work's layout gains a key array:
  *   float g[n] | int32 order[n] | int32 sorted keys[n] | int32 keys[n] (each rounded up to 256 bytes) | the sort's scratch.   */
+/* Host only: where the sub-epochs of an epoch of n triplets lie -- h_slot_bound[S + 1] (time slots), h_first[S + 1] (positions in the
+ * (sub-epoch, j) order), h_stride_inv[3] = {the visiting order's stride, its inverse modulo the number of chunks, the number of chunks}. */
+int qrec_bpr_deferred_sub_plan(int64_t n, int64_t n_items, int32_t chunk, int32_t sub_epochs, int64_t *h_slot_bound, int64_t *h_first,
+                               int64_t *h_stride_inv);
 int qrec_bpr_deferred_sort_sub(const int32_t *d_j, int64_t n, int64_t n_items, int32_t chunk, int32_t sub_epochs, void *d_work,
                                void *stream);
 int qrec_bpr_sgd_hogwild_item_major_deferred_sub(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld,

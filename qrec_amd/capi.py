@@ -66,6 +66,7 @@ _SIGNATURES = {
     "qrec_bpr_deferred_work_bytes": [_i64, _i64, _vp],
     "qrec_bpr_deferred_sort": [_vp, _i64, _i64, _vp, _vp],
     "qrec_bpr_deferred_sort_sub": [_vp, _i64, _i64, _i32, _i32, _vp, _vp],
+    "qrec_bpr_deferred_sub_plan": [_i64, _i64, _i32, _i32, _vp, _vp, _vp],
     "qrec_bpr_sgd_hogwild_item_major_deferred_sub": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "qrec_bpr_sgd_hogwild_item_major_deferred": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _i32, _vp],
     "qrec_epoch_close": [_vp, _i64, _vp, _i64, C.c_int, _i32, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
@@ -962,6 +963,13 @@ def bpr_sgd_hogwild_item_major_deferred(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j
     _check(load().qrec_bpr_sgd_hogwild_item_major_deferred(_dp(d_P), _dp(d_Q), p_rows or _table_rows(d_P, ld), q_rows or _table_rows(d_Q, ld), d, ld,
                                                            _dp(d_u), _dp(d_i), _dp(d_j), n, chunk, grid_groups, flush_every, lr, regU, regI,
                                                            _dp(d_loss), _dp(d_driver_state), _dp(d_work), (1 if is_sorted else 0) | (2 if fresh else 0), _sh(stream)))
+
+
+def bpr_deferred_sub_plan(n: int, n_items: int, chunk: int, sub_epochs: int):
+    """(slot bounds [S + 1], first positions [S + 1], stride, stride^-1 mod n_chunks, n_chunks) of the sub-epoch schedule; host only"""
+    sb, fi, si = np.zeros(sub_epochs + 1, np.int64), np.zeros(sub_epochs + 1, np.int64), np.zeros(3, np.int64)
+    _check(load().qrec_bpr_deferred_sub_plan(n, n_items, chunk, sub_epochs, _hp(sb), _hp(fi), _hp(si)))
+    return sb, fi, int(si[0]), int(si[1]), int(si[2])
 
 
 def bpr_deferred_sort_sub(d_j, n: int, n_items: int, chunk: int, sub_epochs: int, d_work, stream=None):

@@ -1208,6 +1208,17 @@ int qrec_bpr_sgd_hogwild_item_major_deferred(float *d_P, float *d_Q, int64_t n_u
 #undef QREC_DEF
 }
 
+int qrec_bpr_deferred_sub_plan(int64_t n, int64_t n_items, int32_t chunk, int32_t sub_epochs, int64_t *h_slot_bound, int64_t *h_first,
+                               int64_t *h_stride_inv) {
+    QREC_REQUIRE(n >= 1 && n < (1ll << 31) && n_items >= 1 && chunk >= 1 && chunk <= kMaxChunk && sub_epochs >= 1 && sub_epochs <= kMaxSubEpochs,
+                 "qrec_bpr_deferred_sub_plan: bad arguments");
+    QREC_REQUIRE(h_slot_bound && h_first && h_stride_inv, "qrec_bpr_deferred_sub_plan: null output");
+    const SubPlan p = make_sub_plan(n, chunk, sub_epochs, n_items);
+    for (int s = 0; s <= sub_epochs; s++) { h_slot_bound[s] = p.slot_bound[s]; h_first[s] = p.first[s]; }
+    h_stride_inv[0] = p.stride; h_stride_inv[1] = p.inv; h_stride_inv[2] = p.n_chunks;
+    return QREC_OK;
+}
+
 int qrec_bpr_deferred_sort_sub(const int32_t *d_j, int64_t n, int64_t n_items, int32_t chunk, int32_t sub_epochs, void *d_work, void *stream) {
     QREC_REQUIRE(n >= 0 && n < (1ll << 31) && n_items >= 1 && n_items < (1ll << 31) - 2, "qrec_bpr_deferred_sort_sub: bad sizes");
     QREC_REQUIRE(chunk >= 1 && chunk <= kMaxChunk && sub_epochs >= 1 && sub_epochs <= kMaxSubEpochs, "qrec_bpr_deferred_sort_sub: chunk in 1..%d, sub-epochs in 1..%d", kMaxChunk, kMaxSubEpochs);

@@ -886,3 +886,24 @@ def test_bench_typed_with_gpus_n_becomes_its_own_launcher(monkeypatch):
     k = a.index(os.path.join(ROOT, "bench.py"))
     assert a[k + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2", "--dist-mode", "sharded"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+@pytest.mark.parametrize("n,chunk,S", [(60_797, 8, 4), (1_252_669, 34, 4), (1000, 7, 3), (5, 8, 2), (64, 8, 16), (33, 32, 2), (1, 1, 1)])
+def test_deferred_sub_epoch_plan(n, chunk, S):
+    """the host half of the sub-epoch schedule (bpr_sgd.hip make_sub_plan): the stride's modular inverse, the time-slot ranges
+    sub(slot) = slot * S // n_chunks, and where each range's triplets start in the (range, j) order -- against a plain recount"""
+    from math import gcd
+    sb, first, stride, inv, n_chunks = capi.bpr_deferred_sub_plan(n, 5000, chunk, S)
+    assert n_chunks == -(-n // chunk) and gcd(stride, n_chunks) == 1
+    assert n_chunks == 1 or (stride * inv) % n_chunks == 1
+    slot_of = [(c * inv) % n_chunks for c in range(n_chunks)] if n_chunks <= 200_000 else None
+    if slot_of is not None:
+        assert sorted(slot_of) == list(range(n_chunks))
+        assert all((s * stride) % n_chunks == c for c, s in enumerate(slot_of))      # slot s visits chunk s * stride mod n_chunks
+        count = [0] * S
+        for c, s in enumerate(slot_of):
+            count[s * S // n_chunks] += min((c + 1) * chunk, n) - c * chunk
+        assert first.tolist() == [0] + np.cumsum(count).tolist()
+    assert sb[0] == 0 and sb[-1] == n_chunks and first[0] == 0 and first[-1] == n
+    for s in range(S + 1):
+        assert sb[s] == -(-s * n_chunks // S)
