@@ -215,7 +215,7 @@ int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int64_t n_users, int
  * the triplets keep their storage order), so pass B is a deterministic function of the arrays; the engine runs it on the
  * sampler's side stream, under the previous epoch.  `flags`: bit 0 (QREC_DEFERRED_SORTED) -- d_work already holds the j order
  * of these negatives (qrec_bpr_deferred_sort); without it the call sorts first, on its own stream.  Bit 1
- * (QREC_DEFERRED_FRESH; also switched on by the environment variable QREC_DEFERRED_FRESH=1) -- pass A logs P[u].Q[i] instead of
+ * (QREC_DEFERRED_FRESH) -- pass A logs P[u].Q[i] instead of
  * g and pass B forms g' = lr (1 - sigma(P[u].Q[i] - P[u].Q[j])) against the Q[j] its run has reached: the negative item's row
  * takes its updates one after the other as in the reference (measured: halves the drift of Recall@20 at 5x BPR.conf's rate,
  * changes nothing at BPR.conf's rate).                                                                     */
@@ -361,7 +361,11 @@ int qrec_adam_step(float *d_theta, float *d_m, float *d_v, const float *d_grad, 
  * The out-of-place form lets the two perturbed encoders share the first product A E with the clean one.
  * d_noise = [n_rows][ld] U[0,1) numbers, or NULL to draw them on the device with
  * Philox4x32-10(key=seed, counter={row, lane, stream_id}) -- same distribution as
- * tf.random.uniform, not TF's stream.                                                    */
+ * tf.random.uniform, not TF's stream.
+ * Injected noise may carry the sign to use in place of sign(x) (parity tests that follow a recorded run of the
+ * reference: sign() is discontinuous at 0, so an entry of x within rounding of zero can take the other sign here
+ * than it did there): a value v in [0, 1) is plain noise; +-(2 + u), u in [0, 1): noise u with the sign forced to
+ * +-1; 4 + u: noise u with the sign forced to 0.  The l2_normalize of the row uses u.          */
 int qrec_perturb_rows(float *d_emb, const float *d_src, int64_t n_rows, int32_t d, int32_t ld, float eps,
                       const float *d_noise, uint64_t seed, uint64_t stream_id, float *d_accum, const int32_t *d_row_ids,
                       const int32_t *d_n_row_ids, int32_t max_row_ids, int64_t philox_row0, void *stream);

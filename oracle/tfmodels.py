@@ -185,24 +185,27 @@ class SimGCL:
         self.L, self.reg, self.cl_rate, self.eps = n_layers, reg, np.float32(cl_rate), np.float32(eps)
         self.opt = AdamTF114(self.E.shape, lr)
 
-    def encoder(self, noises=None):
+    def encoder(self, noises=None, signs=None):
         """LightGCN_encoder / perturbed_LightGCN_encoder (SimGCL.py:22-38): mean over the L
         propagated layers (ego layer excluded); with noise, emb += sign(emb)*normalize(noise)*eps
-        after every layer and the perturbed emb feeds the next one."""
+        after every layer and the perturbed emb feeds the next one.  ``signs`` (L arrays [N, d] of -1 / 0 / +1): use these
+        in place of sign(emb) -- the pattern a recorded run of the reference used (sign() is discontinuous at 0)."""
         emb = self.E
         acc = np.zeros_like(emb)
         for k in range(self.L):
             emb = self.adj.dot(emb).astype(np.float32)
             if noises is not None:
                 nz, _ = l2_normalize_rows(noises[k].astype(np.float32))
-                emb = (emb + (np.sign(emb) * nz) * self.eps).astype(np.float32)
+                sg = np.sign(emb) if signs is None else signs[k].astype(np.float32)
+                emb = (emb + (sg * nz) * self.eps).astype(np.float32)
             acc += emb
         return (acc / np.float32(self.L)).astype(np.float32)
 
-    def loss_and_grad(self, u_idx, i_idx, j_idx, noises):
+    def loss_and_grad(self, u_idx, i_idx, j_idx, noises, signs=None):
         nu = self.nu
         main = self.encoder()
-        p1 = self.encoder(noises[:self.L]); p2 = self.encoder(noises[self.L:])
+        p1 = self.encoder(noises[:self.L], None if signs is None else signs[:self.L])
+        p2 = self.encoder(noises[self.L:], None if signs is None else signs[self.L:])
         ui, ii, ji = np.asarray(u_idx), np.asarray(i_idx) + nu, np.asarray(j_idx) + nu
         rec, du, di, dj = bpr_batch_loss_and_grads(main[ui], main[ii], main[ji], self.reg)
         d_out = np.zeros_like(main)                     # gradients w.r.t. the three encoder outputs, summed:
@@ -223,8 +226,8 @@ class SimGCL:
         G = self.adj.T.dot(W).astype(np.float32)
         return rec + cl, rec, cl, G
 
-    def train_step(self, u_idx, i_idx, j_idx, noises):
-        loss, rec, cl, g = self.loss_and_grad(u_idx, i_idx, j_idx, noises)
+    def train_step(self, u_idx, i_idx, j_idx, noises, signs=None):
+        loss, rec, cl, g = self.loss_and_grad(u_idx, i_idx, j_idx, noises, signs)
         self.opt.step(self.E, g)
         return loss, rec, cl
 

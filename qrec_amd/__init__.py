@@ -1,12 +1,12 @@
 
 import sys as _sys
 
-# Bit-parity with the reference rests on CPython <= 3.11 behaviour that the native replays and the measure strings
-# hard-code: random.sample's pool / selection-set switch (qrec_amd/csrc/mt_sampler.cpp) and sum()'s plain left-to-right
-# float addition (3.12 made it compensated; qrec_amd/ranking.py emulates the plain one).  The reference itself pins 3.x
-# era packages (README.md:47-58).  Refuse to run silently different -- but only where bit parity is claimed: the exact-mode
-# samplers and the measure strings call ``require_reference_python()``; the throughput mode, the graph trainers, bench.py
-# and the tools do not depend on either and only get a warning.
+# Bit-parity with the reference rests on CPython <= 3.11 behaviour that one native replay hard-codes: random.sample's pool /
+# selection-set switch (qrec_amd/csrc/mt_sampler.cpp qrec_mt_sample_range: the -ap data split and SEPT's samples).  choice / shuffle /
+# _randbelow, which the BPR and pairwise samplers replay, have not changed; sum()'s plain left-to-right float addition (3.12 made it
+# compensated) is EMULATED with numpy in qrec_amd/ranking.py, so the measure strings do not depend on the interpreter either.  The
+# reference itself pins 3.x era packages (README.md:47-58).  Refuse to run silently different -- but only where it matters:
+# ``qrec_mt_sample_range`` calls ``require_reference_python()``; everything else runs on any interpreter.
 PYTHON_MATCHES_REFERENCE = _sys.version_info < (3, 12)
 
 
@@ -19,5 +19,5 @@ def require_reference_python(what: str):
 
 if not PYTHON_MATCHES_REFERENCE:
     import warnings as _warnings
-    _warnings.warn("qrec_amd: Python %d.%d -- the exact-mode samplers and the measure strings are bit-exact on CPython <= 3.11 "
-                   "only and will refuse to run; throughput mode and the trainers are unaffected" % _sys.version_info[:2])
+    _warnings.warn("qrec_amd: Python %d.%d -- the replay of random.sample (the -ap split, SEPT's samples) is bit-exact on CPython <= 3.11 "
+                   "only and will refuse to run; everything else is unaffected" % _sys.version_info[:2])

@@ -445,8 +445,10 @@ int launch_levels_wide(void *P, void *Q, int64_t p_rows, int64_t q_rows, const i
                        double regU, double regI, void *xlog, int64_t n, hipStream_t st) {
     const T tlr = (T)lr, cu = (T)lr * (T)regU, ci = (T)lr * (T)regI;
     const int nw = slots / 4;
+#ifdef QREC_EXACT_PROBE      // build of tools/probe_exact_dbg.py only (make PROBE=1): timing variants with pieces removed -- their RESULTS ARE WRONG
     const char *dbg = getenv("QREC_EXACT_DBG");
     const int code = (dbg && sizeof(T) == 8 && EPG == 4) ? atoi(dbg) : 0;
+#endif
     const size_t row_bytes = (size_t)16 * EPG * sizeof(T);
     QREC_REQUIRE((size_t)p_rows * row_bytes < 0xFFFFFF00ull && (size_t)q_rows * row_bytes < 0xFFFFFF00ull && (size_t)n * sizeof(T) < 0xFFFFFF00ull,
                  "qrec_bpr_sgd_scheduled_wide: the tables are addressed with 32-bit offsets (each below 4 GiB; use qrec_bpr_sgd_scheduled)");
@@ -454,6 +456,7 @@ int launch_levels_wide(void *P, void *Q, int64_t p_rows, int64_t q_rows, const i
 #define QREC_REG_LAUNCH(C)                                                                                                     \
     hipLaunchKernelGGL((bpr_levels_reg_kernel<T, EPG, C>), dim3(1), dim3(64 * nw), 0, st, (T *)P, (T *)Q, pb, qb, (const int4 *)wide,   \
                        n_steps + QREC_EXACT_WIDE_LEAD, tlr, cu, ci, (T *)xlog, xb);
+#ifdef QREC_EXACT_PROBE
     if constexpr (sizeof(T) == 8 && EPG == 4) {      // timing experiments (results are wrong): QREC_EXACT_DBG, see the kernel
         switch (code) {
             case 1: QREC_REG_LAUNCH(1) break;
@@ -467,6 +470,9 @@ int launch_levels_wide(void *P, void *Q, int64_t p_rows, int64_t q_rows, const i
     } else {
         QREC_REG_LAUNCH(0)
     }
+#else        // the product build has no such variants: a stale environment variable cannot corrupt an exact-mode run
+    QREC_REG_LAUNCH(0)
+#endif
 #undef QREC_REG_LAUNCH
     QREC_LAUNCH_CHECK();
     return QREC_OK;

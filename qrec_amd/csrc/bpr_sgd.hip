@@ -741,14 +741,17 @@ int deferred_temp_bytes(int64_t n, int64_t n_keys, size_t *bytes) {
     // the query walks rocPRIM's config dispatch (device properties): once per shape, not once per epoch
     static thread_local int64_t last_n = -1, last_keys = -1;
     static thread_local size_t last_bytes = 0;
-    if (n == last_n && n_keys == last_keys) { *bytes = last_bytes; return QREC_OK; }
+    static thread_local int last_dev = -1;
+    int dev = 0;
+    QREC_HIP_CHECK(hipGetDevice(&dev));
+    if (n == last_n && n_keys == last_keys && dev == last_dev) { *bytes = last_bytes; return QREC_OK; }
     size_t tb = 0;
     const hipError_t e = rocprim::radix_sort_pairs(nullptr, tb, (const int32_t *)nullptr, (int32_t *)nullptr,
                                                    rocprim::counting_iterator<int32_t>(0), (int32_t *)nullptr, (size_t)n, 0u,
                                                    key_bits(n_keys), (hipStream_t)0);
     QREC_REQUIRE(e == hipSuccess, "qrec_bpr_deferred: rocprim::radix_sort_pairs size query failed");
     *bytes = align256(tb ? tb : 256);
-    last_n = n; last_keys = n_keys; last_bytes = *bytes;
+    last_n = n; last_keys = n_keys; last_bytes = *bytes; last_dev = dev;
     return QREC_OK;
 }
 int deferred_carve(void *work, int64_t n, int64_t n_keys, DeferredWork *w) {
@@ -838,9 +841,15 @@ int launch_hogwild_item_deferred_sub(float *P, float *Q, int64_t pb, int64_t qb,
         const int rc = sort_by_sub_and_negative(j, n, n_keys, chunk, S, w, st);
         if (rc != QREC_OK) return rc;
     }
-    static thread_local hipEvent_t ev[kMaxSubEpochs + 2] = {};
+    // events of the current device (an event belongs to the device it was created on: a thread that drives several devices gets a set per device)
+    constexpr int kMaxDevices = 64;
+    static thread_local hipEvent_t ev_dev[kMaxDevices][kMaxSubEpochs + 2] = {};
+    int dev = 0;
+    QREC_HIP_CHECK(hipGetDevice(&dev));
+    QREC_REQUIRE(dev >= 0 && dev < kMaxDevices, "qrec_bpr_sgd_hogwild_item_major_deferred_sub: device ordinal %d out of range", dev);
+    hipEvent_t *ev = ev_dev[dev];
     if (st_b && !ev[0])
-        for (auto &e : ev) QREC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (int k = 0; k < kMaxSubEpochs + 2; k++) QREC_HIP_CHECK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
     constexpr int kChunkB = 32;                      // pass B walks runs of equal j: its chunks need not be pass A's
     const int32_t j_mask = (int32_t)((1u << p.bits_j) - 1);
     if (st_b) {     // pass B's stream starts behind everything enqueued so far (the sort, the previous epoch)
@@ -1194,8 +1203,7 @@ int qrec_bpr_sgd_hogwild_item_major_deferred(float *d_P, float *d_Q, int64_t n_u
     DeferredWork w;
     const int rcw = deferred_carve(d_work, n, n_items, &w);
     if (rcw != QREC_OK) return rcw;
-    static const int env_fresh = [] { const char *e = getenv("QREC_DEFERRED_FRESH"); return e ? atoi(e) : 0; }();
-    const int fresh = (flags & QREC_DEFERRED_FRESH) ? 1 : env_fresh;
+    const int fresh = (flags & QREC_DEFERRED_FRESH) ? 1 : 0;       // (an environment variable of the same name selected it in round 3: removed)
     const int sorted = flags & QREC_DEFERRED_SORTED;
 #define QREC_DEF(LPR, E) launch_hogwild_item_deferred<LPR, E>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, n_items, chunk, grid_groups, \
                                                                flush_every, rate, d_loss, w, sorted != 0, fresh, st)

@@ -32,7 +32,10 @@ __device__ __forceinline__ void philox10(uint32_t (&c)[4], uint32_t k0, uint32_t
 }
 
 // One group of LPR lanes per row, float4 per lane (ld = 4*LPR).  V views are formed from the same source row in one pass.
-//   noise[v] != nullptr : use the given U[0,1) numbers (parity tests inject TF-side noise)
+//   noise[v] != nullptr : use the given U[0,1) numbers (parity tests inject TF-side noise).  An injected value may also carry the SIGN
+//                         the perturbation is to use instead of sign(emb) -- sign() is discontinuous, and a test that follows a
+//                         recorded reference run past an entry within rounding of zero feeds the recorded pattern (include/qrec_hip.h):
+//                         v in [0, 1) natural;  +-(2 + u): magnitude u, sign forced to +-1;  4 + u: magnitude u, sign forced to 0
 //   noise[v] == nullptr : Philox(counter = {row, lane, stream_lo, stream_hi}, key = seed) -> 4 x 24-bit uniforms
 //   src == nullptr      : in place on emb[0] (V = 1)
 //   assign              : sum[v] = emb_v instead of sum[v] += emb_v, and src_sum (if given) = the source row: the FIRST layer
@@ -62,8 +65,13 @@ __global__ __launch_bounds__(256) void perturb_kernel(PerturbViews pv, const flo
 #pragma unroll
         for (int v = 0; v < V; v++) {
             f32x4 nz;
+            f32x4 forced = {2.f, 2.f, 2.f, 2.f};          // 2 = not forced
             if (pv.noise[v]) {
                 nz = *reinterpret_cast<const f32x4 *>(pv.noise[v] + off);
+                auto mag = [](float t) { const float a = fabsf(t); return a >= 4.f ? a - 4.f : (a >= 2.f ? a - 2.f : t); };
+                auto frc = [](float t) { const float a = fabsf(t); return a >= 4.f ? 0.f : (a >= 2.f ? (t > 0.f ? 1.f : -1.f) : 2.f); };
+                forced.x = frc(nz.x); forced.y = frc(nz.y); forced.z = frc(nz.z); forced.w = frc(nz.w);
+                nz.x = mag(nz.x); nz.y = mag(nz.y); nz.z = mag(nz.z); nz.w = mag(nz.w);
             } else {
                 const uint64_t sid = pv.stream_id[v];
                 const int64_t grow = row + philox_row0;      // the table row this block row stands for (row-partitioned tables)
@@ -79,10 +87,10 @@ __global__ __launch_bounds__(256) void perturb_kernel(PerturbViews pv, const flo
             float ss = nz.x * nz.x + nz.y * nz.y + nz.z * nz.z + nz.w * nz.w;
             ss = row_allreduce_sum<LPR>(ss);
             const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));     // tf.nn.l2_normalize epsilon
-            auto sgn = [](float t) { return t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f); };
+            auto sgn = [](float t, float f) { return f != 2.f ? f : (t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f)); };
             f32x4 e = x;
-            e.x += sgn(e.x) * (nz.x * inv) * eps; e.y += sgn(e.y) * (nz.y * inv) * eps;
-            e.z += sgn(e.z) * (nz.z * inv) * eps; e.w += sgn(e.w) * (nz.w * inv) * eps;
+            e.x += sgn(e.x, forced.x) * (nz.x * inv) * eps; e.y += sgn(e.y, forced.y) * (nz.y * inv) * eps;
+            e.z += sgn(e.z, forced.z) * (nz.z * inv) * eps; e.w += sgn(e.w, forced.w) * (nz.w * inv) * eps;
             *reinterpret_cast<f32x4 *>(pv.emb[v] + off) = e;
             if (pv.sum[v]) {
                 f32x4 t = e;

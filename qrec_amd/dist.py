@@ -450,6 +450,13 @@ class ReplicatedStep:
     def __init__(self, comm, sync_q: ReplicatedTableSync, sync_p: ReplicatedTableSync | None = None):
         self.comm, self.sync_q, self.sync_p = comm, sync_q, sync_p
 
+    def sync_tables(self, stream=None):
+        """reconcile the replicas INSIDE an epoch (``BprSgd(batches=K)``: after each of the first K - 1 batches; the last batch's
+        sync is the epoch close's fused collective)"""
+        self.sync_q.sync(stream)
+        if self.sync_p is not None:
+            self.sync_p.sync(stream)
+
 
 class ShardedStep:
     """... and for the row-sharded layout: the exchange and the number of batches per epoch every rank agreed on.

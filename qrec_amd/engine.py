@@ -83,6 +83,48 @@ def balanced_chunk(n: int, groups: int = 4096, lo: int = 26, hi: int = 40, prefe
     return best
 
 
+# `auto` (QREC_SCHEDULE unset): which throughput schedule an epoch of `n` triplets runs under.
+#   n >= DEFER_MIN_TRIPLETS   "item-deferred" in DEFER_SUB_EPOCHS sub-epochs: one atomic row update per triplet instead of two (0.63 vs
+#                              0.47 of the roofline on the HBM-resident slice of config #4), the negative item's row lagging a quarter
+#                              epoch.  The lag only costs nothing when a sub-epoch still fills the 16,384-group grid several times over
+#                              (measured free at 25 M triplets, profiles/r03_deferred_sub_epochs.json; at the Yelp2018 shape's 1.25 M the
+#                              grid's window is 44 % of the epoch and the sub-epochs cost more than the deferral wins), and its fidelity
+#                              at this regime is pinned by tests/test_gpu_bpr.py::test_auto_schedule_at_5m_triplets_keeps_recall
+#                              (paired Recall@20 / loss on a 6 M-triplet planted-community graph, bound 0.002).
+#   otherwise                  "item" when a few items collect most interactions (their rows would take the per-triplet atomics of the
+#                              user-major kernel), else "user" -- measured 2.1 vs 1.6 G/s at the Zipf-0.6 Yelp2018 shape.
+DEFER_MIN_TRIPLETS = 5_000_000
+DEFER_SUB_EPOCHS = 4
+
+
+def resolve_schedule(n_triplets: int, item_degrees=None, requested: str = "auto"):
+    """(schedule, sub_epochs or None) for ``BprSgd``; ``item_degrees``: positives per item (None = unknown: treated as skewed)"""
+    if requested != "auto":
+        return requested, None
+    if n_triplets >= DEFER_MIN_TRIPLETS:
+        return "item-deferred", DEFER_SUB_EPOCHS
+    if item_degrees is None:
+        return "item", None
+    deg = np.asarray(item_degrees)
+    return ("item" if deg.size and deg.max() > 20 * max(deg.mean(), 1e-9) else "user"), None
+
+
+def stride_runs(n: int, run: int) -> np.ndarray:
+    """positions 0..n-1 cut into runs of ``run`` consecutive ones, the runs in golden-ratio stride order (run r of the result is
+    run (r * stride) mod n_runs of the input, stride ~ 0.618 n_runs made coprime): consecutive runs of the result are far apart in
+    the input.  A short tail (n mod run positions) goes last, so every run of the result starts at a multiple of ``run``."""
+    import math
+    n_runs = n // run
+    if n_runs == 0:
+        return np.arange(n, dtype=np.int64)
+    stride = max(int(n_runs * 0.6180339887498949), 1)
+    while math.gcd(stride, n_runs) != 1:
+        stride += 1
+    slots = (np.arange(n_runs, dtype=np.int64) * stride) % n_runs
+    at = (slots[:, None] * run + np.arange(run, dtype=np.int64)[None, :]).ravel()
+    return np.concatenate([at, np.arange(n_runs * run, n, dtype=np.int64)])
+
+
 class BprSgd:
     """One BPR epoch per call over a fixed (u, i) triplet list (user-major PositiveSet
     order, model/ranking/BPR.py:31-34); negatives ``j`` come per epoch either from the
@@ -98,7 +140,8 @@ class BprSgd:
 
     def __init__(self, tables: DeviceTables, u: np.ndarray, i: np.ndarray, pos: CSR | None = None,
                  schedule: str = "user", n_items: int | None = None, batches: int = 1, chunk: int = 32,
-                 sub_epochs: int | None = None, sub_chunk: int | None = None, overlap_passes: bool = True):
+                 sub_epochs: int | None = None, sub_chunk: int | None = None, overlap_passes: bool = True,
+                 item_run: int | None = None):
         """``schedule``: "user" keeps the reference's user-major order (required by the order-exact
         kernel); "item" stores the same triplets sorted by positive item for the item-major
         throughput kernel (``self.perm`` maps scheduled position -> reference position).
@@ -120,10 +163,11 @@ class BprSgd:
         # triplets (a range must still fill the grid a few times over), whatever chunk the epoch calls pass
         import os as _os
         self.sub_epochs = int(sub_epochs if sub_epochs is not None else _os.environ.get("QREC_DEFERRED_SUB", "1")) if self.deferred else 1
-        # (32-triplet chunks while a range still fills the 16,384-group grid four times over, else 8: measured)
-        auto_chunk = 32 if int(u.size) // max(self.sub_epochs, 1) >= (1 << 21) else 8
+        # (the longest chunk, 8 ... 32 triplets, with which a range still fills the 16,384-group grid four times over: measured at both
+        # ends, DESIGN.md s4 -- 32 at 6.25 M triplets per range is free, 8 at the Yelp2018 shape's 0.31 M is what a range needs to mean anything)
+        auto_chunk = max(8, min(32, (int(u.size) // max(self.sub_epochs, 1)) // (4 * 16384)))
         self.sub_chunk = int(sub_chunk if sub_chunk is not None else _os.environ.get("QREC_DEFERRED_SUB_CHUNK", auto_chunk))
-        self._overlap_passes = bool(overlap_passes) and _os.environ.get("QREC_DEFERRED_SERIAL") != "1"
+        self._overlap_passes = bool(overlap_passes)
         self._stream_b = None
         self.t = tables
         # size of the item catalogue the triplets' ids refer to: the table's rows, except when this process holds only a
@@ -136,8 +180,19 @@ class BprSgd:
         batches = max(1, int(batches))
         per = -(-self.n // batches) if self.n else 0
         self.batch_bounds = [min(b * per, self.n) for b in range(batches + 1)]
+        # Item-major stored order (round 4): the item-sorted list is cut into RUNS of `item_run` triplets and the runs are laid out
+        # in golden-ratio stride order, so that consecutive runs belong to different items -- a chunk of 32 is four runs of 8.  A
+        # positive item's row still rides in registers along its run (one atomic flush per run), but it takes 8 steps in a row
+        # instead of 32: measured with NO GPU involved (tools/order_sensitivity.py, profiles/r04_order_sensitivity.json), sequential
+        # fp64 training in the 32-run order ends 0.003-0.004 of Recall@20 away from the reference's user-major order on data with
+        # structure -- above the +-0.002 bar before any parallel execution -- while the 8-run order stays as close as a random
+        # order does.  0 / None with QREC_ITEM_RUN unset = 8; QREC_ITEM_RUN=0 keeps whole item runs (rounds 1-3).
+        import os as _os0
+        self.item_run = int(item_run if item_run is not None else _os0.environ.get("QREC_ITEM_RUN", "16"))
         if schedule == "item":
             self.perm = np.argsort(i, kind="stable")
+            if self.item_run > 0 and self.n > self.item_run:
+                self.perm = self.perm[stride_runs(self.n, self.item_run)]
             if batches > 1 and self.n:
                 n_chunks, tail = -(-self.n // chunk), self.n % chunk
                 whole = np.arange(n_chunks - 1 if tail else n_chunks)
@@ -302,8 +357,8 @@ class BprSgd:
         if width <= 1 or self.n == 0:
             return None
         kind, slots = capi.bpr_exact_kind(t.code, t.ld, width)
-        if kind and max(t.n_users, t.n_items) * t.ld * t.dtype.itemsize >= 0xFFFFFF00:
-            kind, slots = 0, 0            # the four-per-wavefront kernel addresses the tables with 32-bit offsets
+        if kind and max(max(t.n_users, t.n_items) * t.ld, self.n) * t.dtype.itemsize >= 0xFFFFFF00:
+            kind, slots = 0, 0            # the four-per-wavefront kernel addresses the tables AND its per-triplet log with 32-bit offsets
         entries, off = capi.bpr_exact_schedule(self.h_u, self.h_i, j, t.n_users, self.n_items, width, registers=bool(kind))
         x = self._exact
         if "xlog" not in x:
@@ -407,7 +462,24 @@ class BprSgd:
         else:
             if after_start is not None:
                 after_start()
-            self._launch_sgd(t.P, t.Q, self.d_u, self.d_i, self.d_j, self.n, chunk, groups, flush_every, regU, regI, variant, stream)
+            K = len(self.batch_bounds) - 1
+            if dist is not None and dist.mode == "replicated" and K > 1:
+                # replicated item table reconciled K times per epoch (round 4): between two syncs a rank does not see the other
+                # ranks' updates of the rows they share, and with ONE sync per epoch that window is the whole epoch -- measured on
+                # data with structure (tools/paired_recall.py, profiles/r04_paired_recall.json) the summed stale deltas overshoot
+                # and training diverges at five times BPR.conf's rate.  Batch b = the b-th range of the stored order (item-major:
+                # chunks dealt round-robin, so every batch sees every hot item); the last batch's sync is the fused epoch close.
+                if self.deferred:
+                    raise RuntimeError("the deferred schedule runs the epoch as one unit: it cannot be cut into replicated sync batches")
+                for b in range(K):
+                    t0, nb = self.batch_bounds[b], self.batch_bounds[b + 1] - self.batch_bounds[b]
+                    if nb:
+                        self._launch_sgd(t.P, t.Q, self.d_u.ptr + 4 * t0, self.d_i.ptr + 4 * t0, self.d_j.ptr + 4 * t0, nb, chunk, groups,
+                                         flush_every, regU, regI, variant, stream)
+                    if b + 1 < K:
+                        dist.sync_tables(stream)
+            else:
+                self._launch_sgd(t.P, t.Q, self.d_u, self.d_i, self.d_j, self.n, chunk, groups, flush_every, regU, regI, variant, stream)
         end.record(stream)
         self._consumed[0] = end
         self._own_events.reverse()

@@ -15,9 +15,10 @@ Two execution modes, chosen by the optional conf key ``qrec.mode`` or env ``QREC
     reference's user-major visiting order): item-major wins when a few items collect most interactions (their rows
     would take the per-triplet atomics), user-major when popularity is flat (measured: 2.1 vs 1.6 G/s at the
     Zipf-0.6 Yelp2018 shape, 1.16 vs 1.21 G/s on a uniform 1 M-item catalogue); ``auto`` looks at max/mean item degree.
-    ``item-deferred`` (opt-in, never chosen by ``auto``): item-major with the negative-side updates applied by a second,
-    j-ordered pass -- 2.56 G/s, a reordering of the per-triplet terms beyond Hogwild's whose effect on Recall@20 is inside
-    +-0.002 at BPR.conf's rate and outside at five times that rate.
+    ``item-deferred``: item-major with the negative-side updates applied by a second, j-ordered pass (one atomic row update per
+    triplet instead of two).  ``auto`` picks it, in four sub-epochs, from 5 M triplets per epoch on (engine.resolve_schedule: there
+    the sub-epochs are free and the paired Recall@20 runs stay inside +-0.002); below that it is opt-in -- at the Yelp2018 shape the
+    negative item's row would lag a whole epoch.
 """
 from __future__ import annotations
 
@@ -67,10 +68,8 @@ class BPR(IterativeRecommender):
             u, i = u[pos.indptr[lo]:pos.indptr[hi]], i[pos.indptr[lo]:pos.indptr[hi]]
             self.sampler_seed += 7919 * dp.rank
         print("training...")
-        schedule = self.schedule
-        if schedule == "auto":
-            deg = np.bincount(i, minlength=len(self.data.item))
-            schedule = "item" if deg.size and deg.max() > 20 * max(deg.mean(), 1e-9) else "user"
+        from ...engine import resolve_schedule
+        schedule, sub_epochs = resolve_schedule(int(u.size), np.bincount(i, minlength=len(self.data.item)), self.schedule)
         n_items = len(self.data.item)
         layout = os.environ.get("QREC_DIST_MODE", "replicated")
         if layout not in ("replicated", "sharded"):
@@ -80,7 +79,7 @@ class BPR(IterativeRecommender):
             self._train_sharded(pos, schedule, n_items, dp)
             return
         tables = DeviceTables(self.P, self.Q, self.table_dtype)
-        sgd = BprSgd(tables, u, i, pos, schedule=schedule)
+        sgd = BprSgd(tables, u, i, pos, schedule=schedule, sub_epochs=sub_epochs)
         epoch = 0
         if self.mode == "throughput" and (self.ranking.isMainOn() or dp is not None):
             self._train_throughput_pipelined(sgd, dp=dp)

@@ -24,6 +24,9 @@ SHAPES = {
     # same sizes, but 64 planted communities: 80 % of a user's interactions fall on items of the user's own community
     # (gen_edges_clustered) -- a graph WITH locality to harvest, next to the structureless one (SpMM L2 work)
     "yelp2018-clustered": (31668, 38048, 1237259, 324147, 2018),
+    # a planted-community graph whose epoch (6 M triplets) is in the regime where `auto` picks the deferred schedule in sub-epochs
+    # (engine.resolve_schedule: >= 5 M triplets per epoch); the fidelity tests of that choice run on it
+    "xl6m-clustered": (160000, 100000, 6000000, 1500000, 6006),
     "tiny": (300, 200, 6000, 1500, 7),
     "small": (2000, 1500, 60000, 15000, 11),
 }

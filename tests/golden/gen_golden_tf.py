@@ -83,7 +83,8 @@ def run_tf_model(conf_path, seed, module, cls_name, after=None, social=False):
             labels = {id(t): key for key, t in getattr(self_model[0], "sub_mat", {}).items()} if self_model else {}
             feeds_all = {labels.get(id(k), getattr(k, "name", None)): v for k, v in (feed_dict or {}).items()}
             steps.append(dict(run_index=idx, feeds=feeds, feeds_all=feeds_all, out=[o for o in out if o is not None],
-                              random=list(tf1shim.STATE.run_log[-1][1])))
+                              random=list(tf1shim.STATE.run_log[-1][1]), signs=tf1shim.STATE.sign_log.pop(idx, {})))
+        tf1shim.STATE.sign_log.pop(idx, None)
         return out
     tf1shim.Session.run = run
     rec = {}
@@ -191,6 +192,15 @@ def case_simgcl(tmp, ratings):
         U, V = m.sess.run([m.main_user_embeddings, m.main_item_embeddings])
         return dict(score_U=U.astype(np.float32), score_V=V.astype(np.float32), best_U=np.asarray(m.U, np.float32), best_V=np.asarray(m.V, np.float32))
     rec = run_tf_model(conf, 104, "model.ranking.SimGCL", "SimGCL", after=after)
+    # the sign pattern every perturbation of every training step used (SimGCL.py:35 `tf.sign(emb)`), sign ops in creation order =
+    # view 1 layer 1, layer 2, view 2 layer 1, layer 2 (the random ops' order): bit planes "negative" and "exactly zero" --
+    # sign() is discontinuous, and a trainer that is to follow this run past an entry within rounding of zero needs the pattern
+    ops = sorted(rec["steps"][0]["signs"])
+    assert len(ops) == 4 and all(sorted(s["signs"]) == ops for s in rec["steps"]), ops
+    sg = np.stack([np.stack([s["signs"][o] for o in ops]) for s in rec["steps"]])          # [steps, 4, N, d] int8
+    rec["extra"]["sign_neg_bits"] = np.packbits(sg < 0, axis=None)
+    rec["extra"]["sign_zero_bits"] = np.packbits(sg == 0, axis=None)
+    rec["extra"]["sign_shape"] = np.array(sg.shape, dtype=np.int64)
     # SimGCL.initModel replaces the base class's U / V variables by unnamed Xavier ones (SimGCL.py:42-44): the shim names
     # unnamed variables Variable_<index>; the two that moved are the model's
     moved = [v.name for v in tf1shim.all_variables() if not np.array_equal(v.initial, v.value.detach().numpy())]

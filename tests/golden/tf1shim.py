@@ -57,6 +57,8 @@ class _State:
         self.n_random_ops = 0
         self.run_index = 0
         self.run_log = []            # (run_index, [names of random ops evaluated]) per Session.run
+        self.n_sign_ops = 0
+        self.sign_log = {}           # run_index -> {sign op index (creation order): int8 array of the signs it produced}
 
 
 STATE = _State()
@@ -254,7 +256,21 @@ def all_variables():
 exp = _unary(torch.exp)
 log = _unary(torch.log)
 sigmoid = _unary(torch.sigmoid)
-sign = _unary(torch.sign)
+def sign(x, name=None):
+    """tf.sign.  Its OUTPUT is recorded per Session.run (STATE.sign_log): sign() is discontinuous, so an input within rounding of
+    zero may come out with the other sign in another float32 evaluation of the same graph -- a test that wants to follow a recorded
+    run past such a step feeds the recorded pattern to the implementation under test (SimGCL.py:35)."""
+    op_index = STATE.n_sign_ops
+    STATE.n_sign_ops += 1
+
+    def f(ctx, a):
+        out = torch.sign(a)
+        if ctx.get("__run__", (1 << 31) - 1) != (1 << 31) - 1:
+            STATE.sign_log.setdefault(ctx["__run__"], {})[op_index] = out.detach().numpy().astype(np.int8)
+        return out
+    return Tensor(f, [_t(x)], name=name)
+
+
 tanh = _unary(torch.tanh)
 square = _unary(torch.square)
 sqrt = _unary(torch.sqrt)

@@ -66,3 +66,21 @@ def check_rel(quantity, got, want, rel, ctx=None, abs_tol=0.0):
     den = np.abs(want) + (abs_tol / rel if abs_tol else 0.0)
     worst = float(np.max(np.abs(got - want) / np.maximum(den, 1e-300))) if got.size else 0.0
     check(quantity, worst, rel, ctx=ctx, inclusive=True)
+
+
+def simgcl_recorded_signs(z, step):
+    """the sign pattern (-1 / 0 / +1, int8 [N, d]) each of the four perturbations of training step ``step`` used in the recorded run of
+    the reference's SimGCL (tests/golden/tf_simgcl_filmtrust.npz: sign ops in creation order = view 1 layer 1, layer 2, view 2 layer 1, 2)"""
+    shape = tuple(int(x) for x in z["sign_shape"])
+    n = int(np.prod(shape))
+    neg = np.unpackbits(z["sign_neg_bits"])[:n].reshape(shape)[step].astype(bool)
+    zero = np.unpackbits(z["sign_zero_bits"])[:n].reshape(shape)[step].astype(bool)
+    sg = np.where(neg, -1, 1).astype(np.int8)
+    sg[zero] = 0
+    return [sg[k] for k in range(shape[1])]
+
+
+def encode_forced_signs(noise, sign):
+    """injected noise that carries the sign to use (include/qrec_hip.h, qrec_perturb_rows): u -> +-(2 + u) / 4 + u"""
+    noise = np.asarray(noise, dtype=np.float32)
+    return np.where(sign > 0, 2 + noise, np.where(sign < 0, -(2 + noise), 4 + noise)).astype(np.float32)

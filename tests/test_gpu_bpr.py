@@ -451,16 +451,27 @@ def _item_major_visit_order(i_sorted_len, chunk):
 
 
 @pytest.mark.parametrize("dim", [64, 50, 128, 8])
-@pytest.mark.parametrize("chunk,flush", [(32, 8), (7, 3), (64, 64)])
-def test_item_major_single_group_is_the_sequential_recurrence_in_its_visiting_order(dim, chunk, flush):
+@pytest.mark.parametrize("chunk,flush,item_run", [(32, 8, 8), (7, 3, 0), (64, 64, 16), (32, 16, 0)])
+def test_item_major_single_group_is_the_sequential_recurrence_in_its_visiting_order(dim, chunk, flush, item_run):
+    """``item_run`` (round 4): the stored order = the item-sorted list in runs of that many triplets, runs in stride order (0: whole
+    item runs, the order of rounds 1-3) -- whatever the stored order, ONE group executes it as the sequential recurrence."""
     d, indptr, ind, u, j = _synthetic("small")
     U, I, n = d["n_users"], d["n_items"], ind.size
     rng = np.random.default_rng(dim)
     P0 = rng.random((U, dim)) / 3; Q0 = rng.random((I, dim)) / 3
     t = DeviceTables(P0, Q0, np.float32)
-    sgd = BprSgd(t, u, ind, schedule="item"); sgd.set_negatives(j)
+    sgd = BprSgd(t, u, ind, schedule="item", item_run=item_run); sgd.set_negatives(j)
     us, is_, js = sgd.d_u.numpy(), sgd.d_i.numpy(), sgd.d_j.numpy()
-    assert (np.diff(is_) >= 0).all() and np.array_equal(js, j[sgd.perm]) and np.array_equal(sgd.negatives_reference_order(), j)
+    assert np.array_equal(np.sort(sgd.perm), np.arange(n)) and np.array_equal(us, u[sgd.perm]) and np.array_equal(is_, ind[sgd.perm])
+    assert np.array_equal(js, j[sgd.perm]) and np.array_equal(sgd.negatives_reference_order(), j)
+    if item_run == 0:
+        assert (np.diff(is_) >= 0).all()
+    else:       # inside a run the item-sorted order is kept; a run holds at most two... items only where the sorted list changes item
+        by_item = np.argsort(ind, kind="stable")
+        runs = [sgd.perm[k:k + item_run] for k in range(0, n, item_run)]
+        pos = {int(t_): k for k, t_ in enumerate(by_item)}
+        firsts = sorted(pos[int(r[0])] for r in runs)
+        assert all(np.array_equal(r, by_item[pos[int(r[0])]:pos[int(r[0])] + len(r)]) for r in runs) and firsts == list(range(0, n, item_run))
     order = _item_major_visit_order(n, chunk)
     assert np.array_equal(np.sort(order), np.arange(n))            # every triplet exactly once
     Pr, Qr = P0.copy(), Q0.copy()

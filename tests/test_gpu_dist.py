@@ -137,65 +137,7 @@ def test_rccl_binding_with_a_world_of_one():
         capi.Comm(2, 5, capi.comm_unique_id())
 
 
-# ---- G logical ranks in one process -------------------------------------------------------------------------------
-class _Group:
-    def __init__(self, world):
-        self.world, self.barrier, self.slots = world, threading.Barrier(world), [None] * world
-
-
-class ThreadComm:
-    """in-process fake collective (SURVEY s8e 'testing without a multi-GPU box'): every logical rank is a thread, a
-    collective is a rendezvous + device-to-device copies.  capi.Comm's interface."""
-
-    def __init__(self, group, rank):
-        self.g, self.world, self.rank = group, group.world, rank
-
-    def _swap(self, payload):
-        capi.device_sync()
-        self.g.slots[self.rank] = payload
-        self.g.barrier.wait()
-        everyone = list(self.g.slots)
-        self.g.barrier.wait()
-        return everyone
-
-    def _done(self):
-        capi.device_sync()
-        self.g.barrier.wait()
-
-    def alltoall_rows(self, send, send_rows, recv, recv_rows, row_bytes, stream=None):
-        everyone = self._swap((capi.device_ptr(send) if send is not None else 0, [int(x) for x in send_rows]))
-        off = 0
-        for p, (ptr, rows) in enumerate(everyone):
-            assert rows[self.rank] == int(recv_rows[p])
-            nb = rows[self.rank] * row_bytes
-            if nb:
-                capi.memcpy_d2d(capi.device_ptr(recv) + off, ptr + sum(rows[:self.rank]) * row_bytes, nb)
-            off += nb
-        self._done()
-
-    def sendrecv_segments(self, send, sends, recv, recvs, stream=None):
-        everyone = self._swap((capi.device_ptr(send) if send is not None else 0, [tuple(int(x) for x in s) for s in sends]))
-        for p, (ptr, their) in enumerate(everyone):
-            to_me = [(o, nb) for q, o, nb in their if q == self.rank]            # what rank p sends me, in its list order
-            mine = [(o, nb) for q, o, nb in recvs if q == p]                     # what I receive from rank p, in my list order
-            assert [nb for _, nb in to_me] == [nb for _, nb in mine]
-            for (so, nb), (ro, _) in zip(to_me, mine):
-                if nb:
-                    capi.memcpy_d2d(capi.device_ptr(recv) + ro, ptr + so, nb)
-        self._done()
-
-    def allgather(self, send, recv, count, dtype=capi.F32, stream=None):
-        size = {capi.F32: 4, capi.F64: 8, capi.I32: 4}[dtype] * count
-        for p, ptr in enumerate(self._swap(capi.device_ptr(send))):
-            capi.memcpy_d2d(capi.device_ptr(recv) + p * size, ptr, size)
-        self._done()
-
-    def allreduce(self, buf, count, dtype=capi.F32, stream=None):
-        npdt = {capi.F32: np.float32, capi.F64: np.float64, capi.I32: np.int32}[dtype]
-        mine = np.empty(count, npdt); capi.memcpy_d2h(mine, buf, mine.nbytes)
-        total = sum(self._swap(mine))
-        capi.memcpy_h2d(buf, np.ascontiguousarray(total, dtype=npdt), mine.nbytes)
-        self._done()
+from tests.logical_ranks import ThreadComm, _Group      # G logical ranks in one process
 
 
 def _tiny_problem(dim):
@@ -478,9 +420,10 @@ def test_two_rank_bench_path_on_one_device(tmp_path):
     item-table replicas must be IDENTICAL after every epoch's delta all-reduce, the loss terms ride in the same
     collective so both device-side drivers log the same losses and take the same learning-rate decisions, and the
     user tables differ (each rank trains its own users)."""
-    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs-per-step", "3", "--no-cpu-baseline", "--shape", "ml1m"],
+    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs-per-step", "3", "--no-cpu-baseline", "--shape", "ml1m", "--scaling", "weak"],
                  {"QREC_DIST_TEST_ONE_DEVICE": "1", "QREC_DIST_TEST_DUMP": str(tmp_path)}, nproc=2)
     assert out["n_gpus"] == 2 and "INVALID_AS_BENCH" in out and out["value"] > 0 and out["scaling"] == "weak"
+    assert "12080x3706" in out["config"]["workload"] and "weak scaling" in out["config"]["workload"]        # labelled with its aggregate shape
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     assert np.array_equal(r0["Q"], r1["Q"])                                   # replicas reconciled exactly
     assert not np.array_equal(r0["P"], r1["P"])                               # different user shards
@@ -495,9 +438,11 @@ def test_bench_typed_with_gpus_2_starts_its_own_ranks(tmp_path):
     test hook: both ranks on device 0 over the staged transport.)  The layout is steered by environment here, as a caller with a
     fixed command line would."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(QREC_DIST_TEST_ONE_DEVICE="1", QREC_DIST_TEST_DUMP=str(tmp_path), QREC_DIST_MODE="replicated", QREC_SCALING="strong")
+    env.update(QREC_DIST_TEST_ONE_DEVICE="1", QREC_DIST_TEST_DUMP=str(tmp_path), QREC_DIST_MODE="replicated")
+    env.pop("QREC_SCALING", None)            # the default answers BASELINE.json's question: the ONE problem over N GPUs
     run = subprocess.run(["python3", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs-per-step", "2", "--no-cpu-baseline",
-                          "--shape", "ml1m"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                          "--shape", "ml1m", "--recall-dataset", "lastfm", "--recall-epochs", "10"], cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=900)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
     lines = [l for l in run.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines                                             # ONE line on stdout, whatever the launcher and RCCL print
@@ -510,6 +455,20 @@ def test_bench_typed_with_gpus_2_starts_its_own_ranks(tmp_path):
     assert sum(mg["triplets_per_epoch_per_rank"]) == out["config"]["triplets_per_epoch_per_gpu"] + mg["triplets_per_epoch_per_rank"][1]
     assert mg["collectives_per_epoch"]["all_reduce"] == 1 and mg["collectives_per_epoch"]["payload_bytes_per_rank"] > 3706 * 64 * 4
     assert (tmp_path / "rank0.npz").exists() and (tmp_path / "rank1.npz").exists()
+    # round 4: strong scaling is the default and the workload string says what is being scaled; the weak-scaling figure stands next
+    # to it under its aggregate shape; the collectives' bytes come with the link-time arithmetic; and the metric's second half --
+    # Recall@20 against order-exact training of the whole problem, trained through this very communicator -- is on the line
+    assert "strong scaling" in out["config"]["workload"] and "6040x3706" in out["config"]["workload"]
+    assert out["config"]["triplets_per_epoch_job"] == sum(mg["triplets_per_epoch_per_rank"])
+    ws = out["weak_scaling"]
+    assert ws["value"] > 0 and "12080x3706" in ws["workload"]
+    pl = mg["predicted_link_ms_per_epoch"]
+    assert pl["one_ring_153GBps"] > pl["seven_rings_1071GBps"] > 0 and mg["collectives_per_epoch"]["ring_wire_bytes_per_rank"] == mg["collectives_per_epoch"]["payload_bytes_per_rank"]
+    rc = out["recall_at_20"]
+    assert rc["dataset"] == "lastfm" and rc["ranks"] == 2 and rc["layout"] == "replicated" and rc["epochs"] == 10 and rc["bar"] == 0.002
+    assert 0.05 < rc["recall_exact_order"] < 0.2 and 0.05 < rc["recall"] < 0.2 and rc["abs_diff"] == pytest.approx(abs(rc["recall"] - rc["recall_exact_order"]))
+    assert rc["rel_diff"] == pytest.approx(rc["abs_diff"] / rc["recall_exact_order"]) and rc["final"]["epoch"] == 10
+    check("bench.py --gpus 2 (one device, staged transport): |Recall@20 - exact-order| at the peak epoch, lastfm, lr0 0.01", rc["abs_diff"], 0.002, inclusive=True)
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])

@@ -690,6 +690,50 @@ def test_lightgcn_and_simgcl_steps_at_yelp_shape_match_restatement(yelp_graph):
     check("abs(cl - cl_ref) / abs(cl_ref)", abs(cl - cl_ref) / abs(cl_ref), 1e-5)
 
 
+def test_ngcf_step_at_yelp_shape_matches_restatement(yelp_graph):
+    """One config-#5 NGCF step (two layers, fixed by model/ranking/NGCF.py:19; batch 2048, d = 64, keep 0.9) at the FULL Yelp2018
+    shape -- N = 69,716 rows through the dense MFMA kernels (ngcf.hip), the row-subset last layer and the weight-gradient partial
+    sums, none of which the FilmTrust-sized golden run reaches at this size -- against the numpy/scipy restatement with the SAME
+    injected dropout masks: loss, dU / dV / the four dW before Adam at 1e-5, and the first Adam step's direction and size on every
+    coordinate whose gradient is not rounding noise (the first Adam step is -lr * g / (|g| + eps): a sign function of g)."""
+    from helpers import pad_cols
+    d, adj, A = yelp_graph
+    nu, ni, dim, B = d["n_users"], d["n_items"], 64, 2048
+    N = nu + ni
+    rng = np.random.default_rng(17)
+    sel = rng.integers(0, d["train_u"].size, B)
+    u = d["train_u"][sel].astype(np.int32); i = d["train_i"][sel].astype(np.int32); j = rng.integers(0, ni, B).astype(np.int32)
+    U0 = (rng.standard_normal((nu, dim)) * 0.1).astype(np.float32); V0 = (rng.standard_normal((ni, dim)) * 0.1).astype(np.float32)
+    lim = np.sqrt(6.0 / (2 * dim))
+    W = [[rng.uniform(-lim, lim, (dim, dim)).astype(np.float32) for _ in range(2)] for _ in range(2)]
+    masks = [(rng.random((N, dim)) < 0.9).astype(np.float32) for _ in range(2)]
+    ref = T.NGCF(U0, V0, W, A, lr=0.002, reg=1e-3)
+    tr = NGCFTrainer(U0, V0, W, adj, lr=0.002, reg=1e-3)
+    lref, gE, gW = ref.loss_and_grads(u, i, j, masks)           # (20 s of numpy at this size: once; then train_step's own body)
+    ref.optE.step(ref.E, gE)
+    for k in range(2):
+        for t in range(2):
+            ref.optW[k][t].step(ref.W[k][t], gW[k][t])
+    tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, masks=[DB.from_numpy(pad_cols(m, tr.ld)) for m in masks])
+    check("NGCF loss at the Yelp2018 shape", abs(tr.loss() - lref) / abs(lref), 1e-5)
+    gU, gV, gWg = tr.gradients()
+    check("NGCF dU at the Yelp2018 shape", rel_err(gU, gE[:nu]), 1e-5)
+    check("NGCF dV at the Yelp2018 shape", rel_err(gV, gE[nu:]), 1e-5)
+    for k in range(2):
+        for t in range(2):
+            check(f"NGCF dW{t + 1} of layer {k} at the Yelp2018 shape", rel_err(gWg[k][t], gW[k][t]), 1e-5)
+    Ug, Vg, Wg = tr.parameters()
+    E0 = np.concatenate([U0, V0])
+    step_ref, step_gpu = ref.E - E0, np.concatenate([Ug, Vg]) - E0
+    solid = np.abs(gE) > 1e-3 * np.abs(gE).max()
+    assert solid.mean() > 0.01 and np.array_equal(np.sign(step_gpu[solid]), np.sign(step_ref[solid]))
+    check_rel("NGCF first Adam step on solid coordinates (tables)", step_gpu[solid], step_ref[solid], 2e-5)
+    for k in range(2):
+        for t in range(2):
+            sw = np.abs(gW[k][t]) > 1e-3 * np.abs(gW[k][t]).max()
+            check_rel(f"NGCF first Adam step on solid coordinates (W{t + 1} of layer {k})", (Wg[k][t] - W[k][t])[sw], (ref.W[k][t] - W[k][t])[sw], 2e-5)
+
+
 @pytest.mark.parametrize("seg_len", [128, 7])
 def test_spmm_output_row_mask_computes_exactly_the_marked_rows(seg_len):
     """d_y_row_mask: marked rows equal the unmasked product bit for bit (long rows included), all other rows of Y

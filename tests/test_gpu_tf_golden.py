@@ -151,6 +151,38 @@ def test_simgcl_trainer_follows_the_reference_run():
     check("rel_err(Vm, z['score_V'])", rel_err(Vm, z["score_V"]), 0.002)
 
 
+def test_simgcl_trainer_with_the_recorded_sign_pattern_follows_the_reference_run_throughout():
+    """The test above allows three steps out of twelve to leave 5e-5 because `sign(emb)` (SimGCL.py:35) is discontinuous at 0 -- the
+    CPU restatement names the flip: step 10, view 2, layer 2, row 805, column 1, an entry of -2.1e-6 in a row of magnitude 0.07
+    (tests/test_oracle_tf_golden.py).  Here the excuse is removed: the noise fed to the kernels carries the sign every perturbation of
+    the reference's own run used (recorded from its `tf.sign` ops by the generator; include/qrec_hip.h, qrec_perturb_rows), and the
+    HIP trainer is held to the run at 1e-5 on the three losses of ALL twelve steps; the trained tables to the 5e-5 of the other
+    contrastive models (twelve Adam steps on rounding-noise coordinates)."""
+    from helpers import encode_forced_signs, simgcl_recorded_signs
+    m, z = load("tf_simgcl_filmtrust")
+    nu, ni, dim, L = m["n_users"], m["n_items"], m["emb_size"], m["n_layers"]
+    n = nu + ni
+    names = {role: name for name, role in m["var_roles"].items()}
+    adj = joint_norm_adjacency(nu, ni, z["train_uid"], z["train_iid"])
+    tr = SimGCLTrainer(z["init_" + names["U"]], z["init_" + names["V"]], adj, L, lr=m["lr"], reg=m["regU"], cl_rate=m["cl_rate"], eps=m["eps"],
+                       max_unique=m["batch_size"])
+    ops = sorted(r[0] for r in m["random_ops"][0])
+    for k, u, i, j in batches(z):
+        signs = simgcl_recorded_signs(z, k)
+        noises = [encode_forced_signs(tf1shim.random_uniform(m["seed"], z["run_index"][k], op, (n, dim)), sg) for op, sg in zip(ops, signs)]
+        uu = unique_first_appearance(u).astype(np.int32); vv = (unique_first_appearance(i) + nu).astype(np.int32)
+        tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), u.size, DB.from_numpy(uu), uu.size, DB.from_numpy(vv), vv.size,
+                            noises=[DB.from_numpy(pad_cols(x, tr.ld)) for x in noises])
+        err = np.abs(np.array(tr.losses()) - z["losses"][k]) / z["losses"][k]
+        check("SimGCL total / rec / cl loss vs reference run under its recorded sign pattern (worst of the three)", err.max(), 1e-5, ctx=(k, err))
+    U, V = tr.ego_embeddings()
+    E = np.concatenate([z["final_" + names["U"]], z["final_" + names["V"]]])
+    check("SimGCL tables after 12 steps under the recorded sign pattern", rel_err(np.concatenate([U, V]), E), 5e-5)
+    Um, Vm = tr.main_embeddings()
+    check("SimGCL main user embeddings under the recorded sign pattern", rel_err(Um, z["score_U"]), 5e-5)
+    check("SimGCL main item embeddings under the recorded sign pattern", rel_err(Vm, z["score_V"]), 5e-5)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # SGL / BUIR / SEPT / MHCN trainers against their reference runs
 # ---------------------------------------------------------------------------------------------------------------------

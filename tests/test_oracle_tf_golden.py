@@ -154,6 +154,48 @@ def test_simgcl_restatement_follows_the_reference_run():
     close(U, z["score_U"], "main user embeddings", rtol=2e-2, atol=1e-3); close(V, z["score_V"], "main item embeddings", rtol=2e-2, atol=1e-3)
 
 
+def test_simgcl_restatement_with_the_recorded_sign_pattern_follows_the_reference_run_throughout():
+    """The one excuse of the test above, removed: fed the sign pattern the reference's run itself used in every perturbation
+    (recorded by the generator from the `tf.sign` ops, SimGCL.py:35), the restatement follows the run at the 1e-5 of every other
+    model -- all twelve steps, the trained tables and the scoring tables.  And the flip is named: the steps at which the
+    restatement's own sign(emb) differs from the recorded one, the coordinates, and how close to zero the entries are."""
+    from helpers import simgcl_recorded_signs
+    m, z = load("tf_simgcl_filmtrust")
+    n = m["n_users"] + m["n_items"]
+    names = {role: name for name, role in m["var_roles"].items()}
+    adj = T.joint_norm_adjacency(m["n_users"], m["n_items"], z["train_uid"], z["train_iid"])
+    o = T.SimGCL(z["init_" + names["U"]], z["init_" + names["V"]], adj, m["n_layers"], m["lr"], m["regU"], m["cl_rate"], m["eps"])
+    ops = sorted(r[0] for r in m["random_ops"][0])
+    flips = []
+    for k, u, i, j in batches(z):
+        noises = [tf1shim.random_uniform(m["seed"], z["run_index"][k], op, (n, m["emb_size"])) for op in ops]
+        signs = simgcl_recorded_signs(z, k)
+        # where would the restatement's own sign() have differed?  (view v: layers in order, the perturbed output feeding the next)
+        for v in range(2):
+            emb = o.E
+            for l in range(o.L):
+                emb = o.adj.dot(emb).astype(np.float32)
+                own = np.sign(emb).astype(np.int8)
+                bad = np.argwhere(own != signs[v * o.L + l])
+                for r, c in bad:
+                    flips.append((k, v, l, int(r), int(c), float(emb[r, c]), float(np.abs(emb[r]).max())))
+                nz, _ = T.l2_normalize_rows(noises[v * o.L + l].astype(np.float32))
+                emb = (emb + signs[v * o.L + l].astype(np.float32) * nz * o.eps).astype(np.float32)
+        loss, rec, cl = o.train_step(u, i, j, noises, signs)
+        close([loss, rec, cl], z["losses"][k], f"total / rec / cl loss of step {k} under the recorded signs", rtol=1e-5)
+    print("sign flips (step, view, layer, row, col, value, row max):", flips)
+    assert 1 <= len(flips) <= 4, flips                      # the flip exists (it is what the test above tolerates) ...
+    assert all(abs(f[5]) < 1e-4 * f[6] for f in flips), flips        # ... at entries within the run-to-run rounding of the tables (1e-5 relative) of zero
+    E = np.concatenate([z["final_" + names["U"]], z["final_" + names["V"]]])
+    from helpers import check, rel_err
+    # (twelve Adam steps: a coordinate whose gradient is rounding noise still moves by ~lr per step in a direction the noise decides --
+    # the same 5e-5 the other contrastive models' trained tables are held to; without the recorded signs: 2.8e-4 ... 4.2e-4)
+    check("SimGCL restatement under the recorded signs: tables after 12 steps", rel_err(o.E, E), 5e-5)
+    U, V = o.final_embeddings()
+    check("SimGCL restatement under the recorded signs: main user embeddings", rel_err(U, z["score_U"]), 5e-5)
+    check("SimGCL restatement under the recorded signs: main item embeddings", rel_err(V, z["score_V"]), 5e-5)
+
+
 def _sha(a):
     import hashlib
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
