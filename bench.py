@@ -454,8 +454,10 @@ def main():
                     help="N > 1.  strong (default; BASELINE.json quotes the metric on THE Yelp2018 shape at 1/2/4/8 GPUs): the same 31,668 users "
                          "split over the ranks -- `value`; a weak-scaling leg (every rank its own 31,668 users: an N x 31,668-user problem) is "
                          "timed next to it and reported as `weak_scaling`.  weak: that leg alone, as `value`, labelled with its aggregate shape")
-    ap.add_argument("--sync-per-epoch", type=int, default=int(os.environ.get("QREC_REPLICATED_SYNCS", "1")),
-                    help="replicated layout: reconciliations of the item table per epoch (1 = the epoch close's fused all-reduce alone)")
+    ap.add_argument("--sync-per-epoch", type=int, default=int(os.environ.get("QREC_REPLICATED_SYNCS", "0")),
+                    help="reconciliations of the ranks' item rows per epoch: delta all-reduces of the replicated layout, minimum number of exchange "
+                         "batches of the sharded one.  0 = dist.reconciliations_per_epoch: one per rank (one per epoch leaves the +-0.002 Recall@20 "
+                         "bar at 4 ranks, profiles/r04_paired_recall.json); 1 = the epoch close's fused all-reduce alone")
     ap.add_argument("--recall-dataset", default="auto", help="N > 1: dataset of the Recall@20 leg (auto: yelp2018-clustered for the Yelp2018 shape)")
     ap.add_argument("--recall-epochs", type=int, default=0, help="epochs of that leg (0: 40 at BPR.conf's rate on the clustered graph, else 25)")
     ap.add_argument("--shard-batch", type=int, default=1 << 20,
@@ -556,10 +558,11 @@ def main():
         Q0_local = qd.shard_item_rows(Q0, world, rank) if sharded else Q0
         tables = DeviceTables(P0, Q0_local, np.float32)
         CHUNK = balanced_chunk(n)     # triplets per work item: the count that spreads evenly over the 4,096 persistent groups
+        syncs = qd.reconciliations_per_epoch(world, args.sync_per_epoch) if use_dist else 1
         if sharded:
-            n_batches = qd.agree_on_batches(control, n, args.shard_batch, split_from=1 << 19)
+            n_batches = qd.agree_on_batches(control, n, args.shard_batch, split_from=1 << 19, min_batches=syncs)
         else:
-            n_batches = max(1, args.sync_per_epoch) if use_dist else 1
+            n_batches = syncs
         sgd = BprSgd(tables, l_u, l_items, CSR(l_indptr, l_items), schedule=args.schedule, n_items=I, batches=n_batches, chunk=CHUNK)
         sampler_seed = SEED + 7919 * rank
         dstep = None
@@ -718,7 +721,7 @@ def main():
         if ds is not None:
             ep = args.recall_epochs or (40 if ds == "yelp2018-clustered" else 25)
             recall_multi = multi_gpu_recall(capi, qd, control, comm, world, rank, args.dist_mode if use_dist else "replicated", args.schedule, ds,
-                                            LR0, ep, 5, args.shard_batch, max(1, args.sync_per_epoch))
+                                            LR0, ep, 5, args.shard_batch, qd.reconciliations_per_epoch(world, args.sync_per_epoch))
 
     if rank == 0:
         n_job = n_full if (strong or world == 1) else world * n

@@ -682,6 +682,17 @@ int qrec_shard_plan_epoch(const int32_t *d_i, const int32_t *d_j, const int64_t 
                           int64_t n_items, int32_t world, void *d_scratch, int32_t *d_req_rows, const int64_t *d_req_off,
                           int32_t *d_counts, int32_t *d_ci, int32_t *d_cj, void *stream);
 int qrec_gather_rows(const float *d_table, int32_t ld, const int32_t *d_rows, int64_t n, float *d_out, void *stream);
+/* The rows of a training batch out of / into ROW-PARTITIONED tables (graph models; the rows tf.nn.embedding_lookup
+ * reads, model/ranking/LightGCN.py:22-24).  Batch row k of 3B is table row u[k] (k < B), n_users + i[k - B] (k < 2B) or
+ * n_users + j[k - 2B]; d_block holds the table's rows [lo, hi).
+ * qrec_batch_rows_gather:       d_out[k] = the row if lo <= row < hi, else zeros ([3B][ld]): summed over the ranks (one all-reduce of
+ *                               3B rows) these are the batch's rows of the whole table -- instead of an all-gather of the table;
+ * qrec_batch_rows_scatter_add:  d_block[row(k) - lo] += d_src[k] for every k whose row lies in [lo, hi) (f32 atomics: a batch
+ *                               repeats rows; lo = 0, hi = N scatters into a whole table).                                      */
+int qrec_batch_rows_gather(const float *d_block, int32_t ld, int64_t lo, int64_t hi, const int32_t *d_u, const int32_t *d_i,
+                           const int32_t *d_j, int32_t B, int64_t n_users, float *d_out, void *stream);
+int qrec_batch_rows_scatter_add(float *d_block, int32_t ld, int64_t lo, int64_t hi, const int32_t *d_u, const int32_t *d_i,
+                                const int32_t *d_j, int32_t B, int64_t n_users, const float *d_src, void *stream);
 int qrec_scatter_add_row_deltas(float *d_table, int32_t ld, const int32_t *d_rows, int64_t n, const float *d_fresh,
                                 const float *d_sent, void *stream);
 

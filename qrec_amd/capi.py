@@ -145,6 +145,8 @@ _SIGNATURES = {
     "qrec_shard_plan_epoch_scratch_bytes": [_i64, _i32, _i32, _vp],
     "qrec_shard_plan_epoch": [_vp, _vp, _vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "qrec_gather_rows": [_vp, _i32, _vp, _i64, _vp, _vp],
+    "qrec_batch_rows_gather": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _i64, _vp, _vp],
+    "qrec_batch_rows_scatter_add": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _i64, _vp, _vp],
     "qrec_scatter_add_row_deltas": [_vp, _i32, _vp, _i64, _vp, _vp, _vp],
 }
 _RESTYPES = {"qrec_last_error": C.c_char_p, "qrec_ratings_rows": C.c_int64, "qrec_ratings_count": C.c_int32,
@@ -1151,6 +1153,16 @@ def shard_plan_epoch(d_i, d_j, d_bounds, n_batches: int, n: int, n_items: int, w
 
 def gather_rows(d_table, ld: int, d_rows, n: int, d_out, stream=None):
     _check(load().qrec_gather_rows(_dp(d_table), ld, _dp(d_rows), n, _dp(d_out), _sh(stream)))
+
+
+def batch_rows_gather(d_block, ld: int, lo: int, hi: int, d_u, d_i, d_j, B: int, n_users: int, d_out, stream=None):
+    """d_out[3B][ld] = the batch's rows {u, n_users + i, n_users + j} of a table whose rows [lo, hi) are d_block; rows held elsewhere: zeros"""
+    _check(load().qrec_batch_rows_gather(_dp(d_block), ld, lo, hi, _dp(d_u), _dp(d_i), _dp(d_j), B, n_users, _dp(d_out), _sh(stream)))
+
+
+def batch_rows_scatter_add(d_block, ld: int, lo: int, hi: int, d_u, d_i, d_j, B: int, n_users: int, d_src, stream=None):
+    """d_block[row - lo] += d_src[k] for the batch rows that lie in [lo, hi)"""
+    _check(load().qrec_batch_rows_scatter_add(_dp(d_block), ld, lo, hi, _dp(d_u), _dp(d_i), _dp(d_j), B, n_users, _dp(d_src), _sh(stream)))
 
 
 def scatter_add_row_deltas(d_table, ld: int, d_rows, n: int, d_fresh, d_sent, stream=None):

@@ -48,8 +48,11 @@ struct Entry {      // as loaded: nothing is computed from a/b before the step t
 // stay in flight across the barriers, waited for with s_waitcnt vmcnt(N > 0) right where they are used, instead of
 // vmcnt(0) at every control-flow merge.  Register sets are renamed by unrolling (entries: 4 sets, rows: 2), never copied:
 // a copy would be a use.
+// (launch bound: 16 wavefronts, except rows of 256 fp64 elements -- EPL = 4 doubles per lane: qrec_bpr_exact_width caps those at 8
+// wavefronts by their LDS footprint anyway, and under the 128-VGPR budget of a 1024-thread block that instantiation spilled 24
+// VGPRs / 84 B of scratch per lane; a 512-thread bound gives it 256)
 template <typename T, int EPL>
-__global__ __launch_bounds__(1024) void bpr_levels_kernel(T *__restrict__ P, T *__restrict__ Q, int d, int ld,
+__global__ __launch_bounds__((sizeof(T) * EPL >= 32) ? 512 : 1024) void bpr_levels_kernel(T *__restrict__ P, T *__restrict__ Q, int d, int ld,
                                                           const int4 *__restrict__ entries, const int32_t *__restrict__ step_off,
                                                           int n_steps, int nw, T lr, T cu, T ci, T *__restrict__ xlog,
                                                           T *__restrict__ dummy) {

@@ -233,6 +233,36 @@ __global__ void row_delta_kernel(float *__restrict__ table, const int32_t *__res
     }
 }
 
+// ---- the rows of a training batch out of / into row-partitioned tables (graph models, round 4) -------------------------------
+// Batch row k of 3B: k < B -> table row u[k];  k < 2B -> n_users + i[k - B];  else n_users + j[k - 2B]  (the rows embedding_lookup
+// reads, LightGCN.py:22-24).  Gather: out[k] = the row if this rank's block [lo, hi) holds it, else zeros -- the sum over the ranks of
+// these 3B-row tables IS the batch's rows of the whole table (one small all-reduce instead of an all-gather of the table).
+// Scatter: table[row(k)] += src[k] for every k whose row lies in [lo, hi) (f32 atomics: a batch repeats rows).
+__device__ __forceinline__ int64_t batch_row_id(const int32_t *u, const int32_t *i, const int32_t *j, int B, int64_t n_users, int64_t k) {
+    return k < B ? (int64_t)u[k] : (k < 2 * (int64_t)B ? n_users + i[k - B] : n_users + j[k - 2 * (int64_t)B]);
+}
+template <int LD4>
+__global__ void batch_rows_gather_kernel(const float4 *__restrict__ block, int64_t lo, int64_t hi, const int32_t *__restrict__ u,
+                                         const int32_t *__restrict__ i, const int32_t *__restrict__ j, int B, int64_t n_users,
+                                         float4 *__restrict__ out) {
+    const int64_t total = 3 * (int64_t)B * LD4;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = t / LD4, row = batch_row_id(u, i, j, B, n_users, k);
+        out[t] = (row >= lo && row < hi) ? block[(row - lo) * LD4 + (t % LD4)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int LD>
+__global__ void batch_rows_scatter_kernel(float *__restrict__ block, int64_t lo, int64_t hi, const int32_t *__restrict__ u,
+                                          const int32_t *__restrict__ i, const int32_t *__restrict__ j, int B, int64_t n_users,
+                                          const float *__restrict__ src) {
+    const int64_t total = 3 * (int64_t)B * LD;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = batch_row_id(u, i, j, B, n_users, t / LD);
+        const float v = src[t];
+        if (row >= lo && row < hi && v != 0.0f) atomicAdd(block + (row - lo) * LD + (t % LD), v);
+    }
+}
+
 inline int grid_for(int64_t work, int block) {
     int64_t g = (work + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
@@ -377,6 +407,44 @@ int qrec_scatter_add_row_deltas(float *d_table, int32_t ld, const int32_t *d_row
         default: QREC_DELTA(256); break;
     }
 #undef QREC_DELTA
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+int qrec_batch_rows_gather(const float *d_block, int32_t ld, int64_t lo, int64_t hi, const int32_t *d_u, const int32_t *d_i,
+                           const int32_t *d_j, int32_t B, int64_t n_users, float *d_out, void *stream) {
+    QREC_REQUIRE(B >= 0 && lo >= 0 && hi >= lo && n_users >= 0, "qrec_batch_rows_gather: bad arguments");
+    QREC_REQUIRE(ld == 32 || ld == 64 || ld == 128 || ld == 256, "qrec_batch_rows_gather: row stride must be 32, 64, 128 or 256 floats (got %d)", ld);
+    if (B == 0) return QREC_OK;
+    QREC_REQUIRE(d_block && d_u && d_i && d_j && d_out, "qrec_batch_rows_gather: null argument");
+    const dim3 g(grid_for(3 * (int64_t)B * (ld / 4), 256)), b(256);
+#define QREC_BG(L4) hipLaunchKernelGGL((batch_rows_gather_kernel<L4>), g, b, 0, as_stream(stream), (const float4 *)d_block, lo, hi, d_u, d_i, d_j, B, n_users, (float4 *)d_out)
+    switch (ld) {
+        case 32: QREC_BG(8); break;
+        case 64: QREC_BG(16); break;
+        case 128: QREC_BG(32); break;
+        default: QREC_BG(64); break;
+    }
+#undef QREC_BG
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+int qrec_batch_rows_scatter_add(float *d_block, int32_t ld, int64_t lo, int64_t hi, const int32_t *d_u, const int32_t *d_i,
+                                const int32_t *d_j, int32_t B, int64_t n_users, const float *d_src, void *stream) {
+    QREC_REQUIRE(B >= 0 && lo >= 0 && hi >= lo && n_users >= 0, "qrec_batch_rows_scatter_add: bad arguments");
+    QREC_REQUIRE(ld == 32 || ld == 64 || ld == 128 || ld == 256, "qrec_batch_rows_scatter_add: row stride must be 32, 64, 128 or 256 floats (got %d)", ld);
+    if (B == 0) return QREC_OK;
+    QREC_REQUIRE(d_block && d_u && d_i && d_j && d_src, "qrec_batch_rows_scatter_add: null argument");
+    const dim3 g(grid_for(3 * (int64_t)B * ld, 256)), b(256);
+#define QREC_BS(L) hipLaunchKernelGGL((batch_rows_scatter_kernel<L>), g, b, 0, as_stream(stream), d_block, lo, hi, d_u, d_i, d_j, B, n_users, d_src)
+    switch (ld) {
+        case 32: QREC_BS(32); break;
+        case 64: QREC_BS(64); break;
+        case 128: QREC_BS(128); break;
+        default: QREC_BS(256); break;
+    }
+#undef QREC_BS
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }

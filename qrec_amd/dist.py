@@ -481,13 +481,24 @@ class ShardedStep:
         return dict(d_i=sgd.d_i, d_j=sgd.d_j_next, n=sgd.n, n_batches=self.n_batches, bounds=sgd.batch_bounds, after=sgd._sampled)
 
 
-def agree_on_batches(control: ControlPlane, n_local: int, batch: int, split_from: int = 0) -> int:
+def agree_on_batches(control: ControlPlane, n_local: int, batch: int, split_from: int = 0, min_batches: int = 0) -> int:
     """batches per epoch such that no rank's batch exceeds ``batch`` triplets (the rank with the most triplets decides);
     ``split_from`` > 0: at least two batches once that rank holds ``split_from`` triplets -- with two or more batches the next
-    epoch's plan hides in front of the last one (``ShardedItemExchange.run_epoch``)"""
+    epoch's plan hides in front of the last one (``ShardedItemExchange.run_epoch``); ``min_batches``: at least that many
+    (``reconciliations_per_epoch``)"""
     n_max = int(control.allreduce_host(np.array([n_local], dtype=np.int64), op="max")[0])
-    nb = max(1, -(-n_max // max(int(batch), 1)))
+    nb = max(1, -(-n_max // max(int(batch), 1)), int(min_batches))
     return max(nb, 2) if split_from and n_max >= split_from else nb
+
+
+def reconciliations_per_epoch(world: int, requested: int = 0) -> int:
+    """How many times per epoch the ranks' copies of the item rows are reconciled (replicated layout: delta all-reduces; sharded
+    layout: at least that many exchange batches).  0 = the default: ``world``.  Measured with the paired Recall@20 design on the
+    planted-community graph (tools/paired_recall.py, profiles/r04_paired_recall.json; |Recall@20 - order-exact training of the whole
+    problem| at the peak epoch, BPR.conf's rate): ONE reconciliation per epoch is 0.0011 / 0.0029 / 0.0016 away at 2 / 4 / 8 ranks
+    (outside the +-0.002 bar at 4), ``world`` reconciliations 0.0003 / 0.0006 / 0.0002 -- between two of them a rank does not see what
+    the others did to the rows they share, and that window has to shrink as the ranks multiply."""
+    return int(requested) if int(requested) > 0 else max(1, int(world))
 
 
 # ---- graph models (LightGCN / NGCF / SimGCL ...) ---------------------------------------------------------------------
@@ -543,7 +554,9 @@ class RowPartition:
     def __init__(self, comm, n_rows: int, ld: int, kern=_capi):
         self.comm, self.k, self.n_rows, self.ld = comm, kern, int(n_rows), int(ld)
         self.world, self.rank = comm.world, comm.rank
-        self.rows_pad = -(-self.n_rows // self.world)
+        # rows per rank, rounded up to a multiple of 32: a block then starts on a word boundary of a row BITMAP over the whole table, so the
+        # batch-row masks of the single-GPU steps (qrec_mark_batch_rows) address a block's rows by a pointer offset (round 4)
+        self.rows_pad = (-(-self.n_rows // self.world) + 31) // 32 * 32
         self.lo = min(self.rank * self.rows_pad, self.n_rows)
         self.hi = min(self.lo + self.rows_pad, self.n_rows)
 

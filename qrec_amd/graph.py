@@ -336,19 +336,30 @@ class RowPartitionedLightGCNTrainer:
         Adam      on the rank's rows.
 
     Unlike ``dist.BatchParallel`` the step is the SAME step as on one GPU (same batch, same update), the SpMM work per
-    rank is 1/G, and no rank holds more than its rows of E, m, v (the gathered operand is a transient).  The price is
+    rank is 1/G, and no rank holds more than its rows of E, m, v (the gathered operand is a transient).  The price was
     2L + 1 all-gathers of N x ld floats per step: at the Yelp2018 shape (17.8 MB each, L = 3: 125 MB per step and rank
     against a 0.38 ms single-GPU step) the links lose to one GPU's cache hierarchy; it is the layout for graphs whose
-    operand no longer fits one GPU's caches or memory.  DESIGN.md s7 has the numbers."""
+    operand no longer fits one GPU's caches or memory.  DESIGN.md s7 has the numbers.
+
+    Round 4 -- the batch-row economies of the single-GPU step (``batch_rows=True``, the default):
+      * the loss reads the layer sum at the batch's <= 3B rows only (embedding_lookup, LightGCN.py:22-24): every rank contributes its
+        rows of those 3B (zeros elsewhere) and ONE all-reduce of 3B x ld floats (1.5 MB at B = 2048) replaces the all-gather of S;
+      * every rank evaluates the whole batch, so every rank HOLDS the whole batch gradient (<= 3B non-zero rows): the first backward
+        product takes it as its operand directly -- no exchange at all -- with the row mask that skips the zero rows;
+      * the last forward layer is computed at the rank's batch rows only (its other rows feed nothing).
+    2L - 1 operand exchanges + 1.5 MB instead of 2L + 1: L = 3 at the Yelp2018 shape 125 -> 92 MB per step and rank (all-gather),
+    72 -> 54 MB (referenced rows)."""
 
     def __init__(self, comm, U0: np.ndarray, V0: np.ndarray, adj, n_layers: int, lr: float, reg: float,
-                 loss_eps: float = 1e-7):
+                 loss_eps: float = 1e-7, batch_rows: bool = True):
         from .dist import RowPartition
         self.comm = comm
         self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
         self.n = self.nu + self.ni
         self.ld = padded_ld(self.d, np.float32)
         self.L, self.lr, self.reg, self.loss_eps = n_layers, lr, reg, loss_eps
+        self.batch_rows = bool(batch_rows)
+        self._batch = {}
         rp = self.rp = RowPartition(comm, self.n, self.ld)
         lo, hi, pad = rp.lo, rp.hi, rp.rows_pad
         indptr, indices, values = adj
@@ -370,21 +381,69 @@ class RowPartitionedLightGCNTrainer:
         self.b1, self.b2, self.adam_eps = f(0.9), f(0.999), f(1e-8)
         self.b1p, self.b2p = self.b1, self.b2
 
-    def _propagate(self, x, addend, accum, stream):
-        """L layers from the block ``x``: y = A_hat[lo:hi] gather(x) (+ addend), accumulated into ``accum`` if given"""
+    def _propagate(self, x, addend, accum, stream, whole_first=None, first_x_mask=None, last_y_mask=None):
+        """L layers from the block ``x``: y = A_hat[lo:hi] gather(x) (+ addend), accumulated into ``accum`` if given.
+        ``whole_first``: the first operand is already whole on every rank (the batch gradient): no exchange for that product;
+        ``first_x_mask``: row bitmap of its non-zero rows; ``last_y_mask``: the last product only at these rows of the block."""
         for k in range(self.L):
             y = self.A if k % 2 == 0 else self.B
-            plan, X = _row_operand(self, x, stream)
+            if k == 0 and whole_first is not None:
+                plan, X = self.plan, whole_first
+            else:
+                plan, X = _row_operand(self, x, stream)
             capi.spmm_csr(plan, X, y, self.ld, d_addend=addend, addend_scale=1.0 if addend is not None else 0.0,
-                          d_accum=accum, stream=stream)
+                          d_accum=accum, stream=stream, d_x_row_mask=first_x_mask if (k == 0 and whole_first is not None) else None,
+                          d_y_row_mask=last_y_mask if k == self.L - 1 else None)
             x = y
         return x
 
-    def forward_sum(self, stream=None):
+    def forward_sum(self, stream=None, last_y_mask=None):
         self.S.copy_from(self.E, stream)
-        self._propagate(self.E, None, self.S, stream)
+        self._propagate(self.E, None, self.S, stream, last_y_mask=last_y_mask)
+
+    def _batch_buffers(self, B: int):
+        """per batch size: the 3B-row tables of the compact loss and the index arrays that address them as (u, i, j) = (k, k, B + k)"""
+        b = self._batch.get(B)
+        if b is None:
+            ar = np.arange(B, dtype=np.int32)
+            b = self._batch[B] = dict(S=DeviceBuffer.zeros((3 * max(B, 1), self.ld), np.float32), dE=DeviceBuffer.zeros((3 * max(B, 1), self.ld), np.float32),
+                                      u=DeviceBuffer.from_numpy(ar if B else np.zeros(1, np.int32)), j=DeviceBuffer.from_numpy(ar + B if B else np.zeros(1, np.int32)))
+        return b
 
     def train_step_async(self, d_u, d_i, d_j, B: int, stream=None):
+        rp, ld = self.rp, self.ld
+        if not self.batch_rows or B == 0 or self.L == 0:
+            return self._train_step_full(d_u, d_i, d_j, B, stream)
+        if getattr(self, "row_mask", None) is None:
+            self.row_mask = DeviceBuffer.zeros((rp.world * rp.rows_pad + 31) // 32, np.uint32)
+        capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)         # bitmap of {u, nu + i, nu + j} over the whole table
+        blk_mask = self.row_mask.ptr + (rp.lo // 32) * 4                                # the block starts on a word boundary (rows_pad % 32 == 0)
+        self.forward_sum(stream, last_y_mask=blk_mask)
+        b = self._batch_buffers(B)
+        # the batch's rows of S: every rank its own (zeros elsewhere), summed over the ranks
+        capi.batch_rows_gather(self.S, ld, rp.lo, rp.hi, d_u, d_i, d_j, B, self.nu, b["S"], stream)
+        self.comm.allreduce(b["S"], 3 * B * ld, capi.F32, stream)
+        b["dE"].fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
+        # the loss on the compact table: batch row k is the user, B + k the positive, 2B + k the negative item of triplet k (n_users = B)
+        capi.bpr_batch_loss_grad(b["S"], float(self.L + 1), B, 3 * B, ld, b["u"], b["u"], b["j"], B, self.loss_eps, self.reg, b["dE"], self.d_loss, stream)
+        # every rank holds the whole batch gradient: scattered into a whole-height operand (repeated rows add up), which the first
+        # backward product reads directly; this rank's rows of it are the addend of all of them
+        self.dE_full.fill_bytes(0, stream)
+        capi.batch_rows_scatter_add(self.dE_full, ld, 0, self.n, d_u, d_i, d_j, B, self.nu, b["dE"], stream)
+        dE_blk = self.dE_full.ptr + rp.lo * ld * 4
+        g = self._propagate(dE_blk, dE_blk, None, stream, whole_first=self.dE_full, first_x_mask=self.row_mask)
+        self._adam(g, stream)
+
+    def _adam(self, g, stream):
+        rp, ld = self.rp, self.ld
+        f = np.float32
+        alpha = float(f(f(self.lr) * np.sqrt(f(1) - self.b2p, dtype=f) / (f(1) - self.b1p)))
+        capi.adam_step(self.E, self.m, self.v, g, (rp.hi - rp.lo) * ld, 1.0 / (self.L + 1), alpha, float(self.b1), float(self.b2),
+                       float(self.adam_eps), stream)
+        self.b1p = f(self.b1p * self.b1); self.b2p = f(self.b2p * self.b2)
+
+    def _train_step_full(self, d_u, d_i, d_j, B: int, stream=None):
+        """the step of rounds 2-3: every layer in full, the layer sum all-gathered, the batch gradient exchanged like any operand"""
         rp, ld = self.rp, self.ld
         self.forward_sum(stream)
         rp.gather_operand(self.S, self.S_full, stream)
@@ -394,11 +453,7 @@ class RowPartitionedLightGCNTrainer:
                                      self.reg, self.dE_full, self.d_loss, stream)
         dE_blk = self.dE_full.ptr + rp.lo * ld * 4                       # this rank's rows of the batch gradient, in place
         g = self._propagate(dE_blk, dE_blk, None, stream)
-        f = np.float32
-        alpha = float(f(f(self.lr) * np.sqrt(f(1) - self.b2p, dtype=f) / (f(1) - self.b1p)))
-        capi.adam_step(self.E, self.m, self.v, g, (rp.hi - rp.lo) * ld, 1.0 / (self.L + 1), alpha, float(self.b1), float(self.b2),
-                       float(self.adam_eps), stream)
-        self.b1p = f(self.b1p * self.b1); self.b2p = f(self.b2p * self.b2)
+        self._adam(g, stream)
 
     def loss(self, stream=None) -> float:
         return float(self.d_loss.numpy(stream)[0])

@@ -79,7 +79,17 @@ class BPR(IterativeRecommender):
             self._train_sharded(pos, schedule, n_items, dp)
             return
         tables = DeviceTables(self.P, self.Q, self.table_dtype)
-        sgd = BprSgd(tables, u, i, pos, schedule=schedule, sub_epochs=sub_epochs)
+        # several ranks, replicated tables: QREC_REPLICATED_SYNCS = K reconciliations of the replicas per epoch (default 0 = one per rank,
+        # dist.reconciliations_per_epoch: with ONE per epoch the paired Recall@20 runs leave the +-0.002 bar at 4 ranks)
+        from ...dist import reconciliations_per_epoch
+        syncs = reconciliations_per_epoch(dp.world, int(os.environ.get("QREC_REPLICATED_SYNCS", "0"))) if dp is not None else 1
+        if syncs > 1 and schedule == "item-deferred":
+            if self.schedule == "auto":
+                schedule, sub_epochs = "item", None      # the deferred schedule runs the epoch as one unit: it cannot be cut into sync batches
+            else:
+                print("QREC_SCHEDULE=item-deferred on several ranks needs QREC_REPLICATED_SYNCS=1 (the epoch as one unit)")
+                raise SystemExit(-1)
+        sgd = BprSgd(tables, u, i, pos, schedule=schedule, sub_epochs=sub_epochs, batches=syncs)
         epoch = 0
         if self.mode == "throughput" and (self.ranking.isMainOn() or dp is not None):
             self._train_throughput_pipelined(sgd, dp=dp)
@@ -157,7 +167,9 @@ class BPR(IterativeRecommender):
         u = np.repeat(np.arange(hi - lo, dtype=np.int32), np.diff(lp)).astype(np.int32)
         tables = DeviceTables(np.ascontiguousarray(self.P[lo:hi]), shard_item_rows(self.Q, G, rank), self.table_dtype)
         chunk = balanced_chunk(int(u.size))
-        n_batches = agree_on_batches(dp.control, int(u.size), 1 << 20, split_from=1 << 19)
+        from ...dist import reconciliations_per_epoch
+        n_batches = agree_on_batches(dp.control, int(u.size), 1 << 20, split_from=1 << 19,
+                                     min_batches=reconciliations_per_epoch(G, int(os.environ.get("QREC_REPLICATED_SYNCS", "0"))))
         sgd = BprSgd(tables, u, li, CSR(lp, li), schedule="item" if schedule == "item-deferred" else schedule, n_items=n_items,
                      batches=n_batches, chunk=chunk)
         step = ShardedStep(dp.comm, ShardedItemExchange(dp.comm, n_items, tables.ld, tables.Q), n_batches)

@@ -329,4 +329,6 @@ def test_row_partitioned_propagation_equals_the_whole_product():
         np.testing.assert_allclose(Yr, Y[lo:hi], rtol=0, atol=1e-6)
         np.testing.assert_allclose(dXr, dX[lo:hi], rtol=0, atol=2e-6)
         np.testing.assert_allclose(Yref, Y[lo:hi], rtol=0, atol=1e-6)        # referenced-rows exchange: the same rows of the product
-        assert ref_rows <= n + (hi - lo) and 0 < ref_bytes <= (n - (hi - lo)) * ld * 4     # never more than the other ranks' rows
+        # the compact operand never holds more than the whole table beside the rank's own (padded) block; the bytes a rank SENDS per
+        # product are rows of its own block, at most once to every other rank
+        assert ref_rows <= n + (hi - lo) + 32 and 0 < ref_bytes <= (hi - lo) * (world - 1) * ld * 4

@@ -799,6 +799,92 @@ def test_deferred_recall_against_exact_order_training(lr0, seed, bound):
 
 
 # ---------------------------------------------------------------------------------------------
+# Recall@20 on data WITH structure (round 4): tools/paired_recall.py -- same negatives, same tables, same bold driver; the reference is
+# order-exact fp64 training.  The structureless Zipf graph of the tests above peaks at Recall@20 0.034 ("the bar cannot fail there",
+# VERDICT r3); the planted-community graph of the same shape reaches 0.12 and the reference's lastfm split 0.11.
+# ---------------------------------------------------------------------------------------------
+_PAIRED = {"cache": {}, "datasets": {}}
+
+
+def _paired(case):
+    from tools import paired_recall as PR
+    return PR.run_case(case, _PAIRED["cache"], _PAIRED["datasets"])
+
+
+@pytest.mark.parametrize("dataset,lr0,epochs,every", [("yelp2018-clustered", 0.01, 40, 5), ("yelp2018-clustered", 0.05, 20, 5), ("lastfm", 0.01, 24, 4)])
+@pytest.mark.parametrize("mode", ["item", "user"])
+def test_throughput_schedules_keep_recall_on_structured_data(dataset, lr0, epochs, every, mode):
+    """The default throughput schedules against order-exact training where there is something to learn: |dRecall@20| at the
+    reference's peak epoch inside +-0.002, at BPR.conf's rate and at five times it, same bold-driver decisions on both sides.
+    `item` = item-major in runs of 16 (the round-4 stored order: with whole item runs, rounds 1-3, the 0.05 case ends 0.0038 away --
+    0.003 of which is the visiting order alone, sequential fp64, no GPU: profiles/r04_order_sensitivity.json)."""
+    if mode == "user" and dataset == "lastfm":
+        pytest.skip("one dataset is enough for the user-major kernel")
+    r = _paired(dict(dataset=dataset, lr0=lr0, seed=7, mode=mode, epochs=epochs, eval_every=every))
+    print(dataset, lr0, mode, "curve (epoch, gpu, exact-order):", [(m, round(a, 4), round(b, 4)) for m, a, b in r["curve"]])
+    assert r["same_bold_driver_decisions"] and r["peak"]["recall_exact_order"] > 0.1
+    check(f"{mode}-major throughput mode, {dataset}, lr0 = {lr0}: |Recall@20 - exact-order| at the reference's peak epoch", r["peak"]["abs_diff"], 0.002, inclusive=True)
+    check(f"{mode}-major throughput mode, {dataset}, lr0 = {lr0}: relative loss gap after the last epoch", r["final"]["loss_rel_gap"], 0.03)
+
+
+def test_item_major_whole_item_runs_show_the_order_effect():
+    """What the runs of 16 are for, pinned: the same kernel on the rounds-1-3 stored order (whole item runs) at five times BPR.conf's rate on the
+    planted-community graph is measurably further from the reference (0.0038) than the default (0.0004) -- and most of that distance is
+    there WITHOUT the GPU: sequential fp64 training in that order against sequential fp64 training in the reference's order."""
+    base = dict(dataset="yelp2018-clustered", lr0=0.05, seed=7, mode="item", epochs=20, eval_every=5)
+    whole = _paired(dict(base, item_run=0, own_order=True))
+    dflt = _paired(dict(base))
+    print("whole runs:", whole["peak"]["abs_diff"], "order alone:", whole["order_effect_alone"]["max_abs_diff"], "vs own order:",
+          whole["vs_sequential_in_own_order"]["peak"]["abs_diff"], "| runs of 16:", dflt["peak"]["abs_diff"])
+    assert whole["peak"]["abs_diff"] > dflt["peak"]["abs_diff"]
+    assert whole["order_effect_alone"]["max_abs_diff"] > 0.002            # the visiting order alone leaves the bar
+    check("item-major, whole item runs, lr0 = 0.05: |Recall@20 - sequential fp64 in the kernel's OWN order| at the peak (the parallel execution's share)",
+          whole["vs_sequential_in_own_order"]["peak"]["abs_diff"], 0.002, inclusive=True)
+
+
+@pytest.mark.parametrize("world,layout", [(2, "replicated"), (4, "replicated"), (4, "sharded"), (8, "sharded")])
+def test_multi_rank_layouts_keep_recall_on_structured_data(world, layout):
+    """north_star's metric at N > 1 (asserted at atol 0.01, on FilmTrust, against the wrong reference): G logical ranks in
+    this process -- threads, the real kernels, delta / exchange code and device-side drivers, an in-process collective -- train the
+    planted-community graph at BPR.conf's rate; the reference is order-exact fp64 training of the WHOLE problem on the ranks' own
+    negatives.  The ranks' item rows are reconciled G times per epoch, the default (dist.reconciliations_per_epoch).
+    Bound: the +-0.002 of the north star."""
+    r = _paired(dict(dataset="yelp2018-clustered", lr0=0.01, seed=7, mode="item", epochs=40, eval_every=5, world=world, layout=layout))
+    print(world, layout, "curve:", [(m, round(a, 4), round(b, 4)) for m, a, b in r["curve"]])
+    assert r["same_bold_driver_decisions"] and r["peak"]["recall_exact_order"] > 0.1
+    check(f"{world} ranks, item table {layout}, lr0 = 0.01: |Recall@20 - exact-order training of the whole problem| at the peak epoch",
+          r["peak"]["abs_diff"], 0.002, inclusive=True)
+
+
+def test_one_reconciliation_per_epoch_is_not_enough_at_four_ranks():
+    """... and why the default is one reconciliation per RANK: with ONE per epoch (rounds 2-3) the same four-rank run trails the
+    reference through the steep part of the learning curve and is still 0.003 below it at the peak -- outside the bar.  Pinned, so that a
+    change in the effect is seen."""
+    one = _paired(dict(dataset="yelp2018-clustered", lr0=0.01, seed=7, mode="item", epochs=40, eval_every=5, world=4, layout="replicated", syncs=1))
+    dflt = _paired(dict(dataset="yelp2018-clustered", lr0=0.01, seed=7, mode="item", epochs=40, eval_every=5, world=4, layout="replicated"))
+    print("4 ranks, one sync per epoch:", one["peak"]["abs_diff"], "four:", dflt["peak"]["abs_diff"])
+    assert one["peak"]["abs_diff"] > 0.002 > dflt["peak"]["abs_diff"]
+    assert one["worst_mark"]["abs_diff"] > 2 * dflt["worst_mark"]["abs_diff"]
+
+
+def test_auto_schedule_at_5m_triplets_keeps_recall():
+    """`auto` (engine.resolve_schedule) picks the deferred-negatives schedule in four sub-epochs from 5 M triplets per epoch on.  Its
+    fidelity AT THAT REGIME: a 6 M-triplet planted-community graph (160 k x 100 k), five times BPR.conf's rate (the harder case; the
+    ledger profiles/r04_paired_recall.json also has BPR.conf's rate: 0.0003), bound 0.002 at the reference's peak epoch."""
+    from qrec_amd.engine import resolve_schedule
+    from tools import paired_recall as PR
+    d = _PAIRED["datasets"].setdefault("xl6m-clustered", PR.load_dataset("xl6m-clustered"))
+    sch, sub = resolve_schedule(int(d["items"].size), np.bincount(d["items"], minlength=d["n_items"]))
+    assert (sch, sub) == ("item-deferred", 4) and resolve_schedule(1_252_669, None)[0] == "item"
+    r = _paired(dict(dataset="xl6m-clustered", lr0=0.05, seed=7, mode=f"{sch}:{sub}", epochs=12, eval_every=3))
+    print("auto regime curve:", [(m, round(a, 4), round(b, 4)) for m, a, b in r["curve"]])
+    assert r["same_bold_driver_decisions"] and r["peak"]["recall_exact_order"] > 0.05
+    check("auto schedule (item-deferred, 4 sub-epochs) at 6 M triplets per epoch, lr0 = 0.05: |Recall@20 - exact-order| at the peak epoch", r["peak"]["abs_diff"], 0.002,
+          inclusive=True)
+    check("auto schedule at 6 M triplets per epoch, lr0 = 0.05: relative loss gap after the last epoch", r["final"]["loss_rel_gap"], 0.03)
+
+
+# ---------------------------------------------------------------------------------------------
 # device-resident epoch close: loss terms + isConverged + updateLearningRate
 # (model/ranking/BPR.py:40, base/iterativeRecommender.py:56-63,88-104)
 # ---------------------------------------------------------------------------------------------
@@ -1148,7 +1234,10 @@ def test_bpr_class_on_two_ranks_keeps_replicas_identical_and_trains_like_one_ran
     # both), but the same training: it converges to the same loss level and the same ranking quality
     print("final loss 1 rank / 2 ranks:", a["losses"][-1], b0["losses"][-1], "measures:", a["measure"], b0["measure"])
     assert a["losses"][-1] < 0.8 * a["losses"][0] and abs(b0["losses"][-1] / a["losses"][-1] - 1) < 0.5
-    np.testing.assert_allclose(b0["measure"], a["measure"], atol=0.01)      # measured: within 0.0012
+    # (no Recall tolerance is claimed HERE: the one-rank and the two-rank run draw different negatives.  The metric at N > 1 is held to the
+    # +-0.002 bar by the paired design -- same negatives, order-exact training of the whole problem as the reference -- in
+    # test_multi_rank_layouts_keep_recall_on_structured_data and on bench.py's N > 1 line)
+    assert np.isfinite(b0["measure"]).all() and (b0["measure"] > 0).all()
     if layout == "sharded":
         return
     # exact mode refuses to run on several ranks

@@ -218,18 +218,31 @@ def test_throughput_mode_of_the_pairwise_models_draws_its_batches_on_the_device(
     monkeypatch.setenv("QREC_QUIET", "1"); monkeypatch.setenv("QREC_SEED", "5")
     cls = resolve_model(name)
 
-    def run(mode):
-        monkeypatch.setenv("QREC_MODE", mode)
-        random.seed(3); np.random.seed(3)
+    def run(mode, stream_seed):
+        """same conf, same initial tables (numpy's generator, seed 3); ``stream_seed`` moves the SAMPLING stream only: Python's generator
+        in exact mode (the reference's next_batch_pairwise replayed), the device stream's seed in throughput mode"""
+        monkeypatch.setenv("QREC_MODE", mode); monkeypatch.setenv("QREC_SEED", str(stream_seed))
+        random.seed(stream_seed); np.random.seed(3)
         with redirect_stdout(io.StringIO()):
             m = cls(conf, train, test)
             measure = m.execute()
-        return m, [float(x.split(":")[1]) for x in measure if ":" in x], random.getstate()
-    _, want, _ = run("exact")
-    m, got, _ = run("throughput")
+        return m, [float(x.split(":")[1]) for x in measure if ":" in x]
+    # The two modes run the SAME training step (held to the reference at 1e-5 elsewhere); what differs is which uniform shuffle /
+    # which unrated negatives an epoch sees.  So the statement is statistical, and it is made against the exact mode's own
+    # stream-to-stream spread (round 3 asserted +-0.02 on one seed): S streams per mode, Recall@10 = measure[1];
+    # |mean_throughput - mean_exact| must be inside 0.002 + two standard errors of the difference.
+    S = 3
+    exact = np.array([run("exact", 3 + k)[1] for k in range(S)])
+    runs = [run("throughput", 5 + k) for k in range(S)]
+    m, thr = runs[0][0], np.array([r[1] for r in runs])
     assert m.throughput_mode()
-    np.testing.assert_allclose(got, want, atol=0.02)                       # Precision / Recall / F1 / NDCG at 10
-    assert got[1] > 0.05                                                   # it learned something (Recall@10 on FilmTrust)
+    se = np.sqrt(exact.var(0, ddof=1) / S + thr.var(0, ddof=1) / S)
+    gap = np.abs(thr.mean(0) - exact.mean(0))
+    print(name, "Recall@10 exact", exact[:, 1], "throughput", thr[:, 1], "gap", gap[1], "se", se[1])
+    for k, what in enumerate(("Precision", "Recall", "F1", "NDCG")):
+        check(f"{name} throughput-mode vs exact-mode {what}@10, |difference of the means over {S} sampling streams| (bound = 0.002 + 2 standard errors; "
+              f"exact mode's own stream-to-stream std {exact[:, k].std(ddof=1):.4f})", gap[k], 0.002 + 2 * se[k], inclusive=True)
+    assert thr[:, 1].min() > 0.05                                          # it learned something (Recall@10 on FilmTrust)
     # the stream itself
     u0, i0, _ = m.data.training_arrays()
     rated = m.data.rated_csr()

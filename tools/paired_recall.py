@@ -86,7 +86,7 @@ def n_batches_for(d, world, layout, shard_batch, syncs):
         return 1
     if layout == "sharded":
         n_max = max(int(_rank_problem(d, world, r)[3].size) for r in range(world))
-        nb = max(1, -(-n_max // shard_batch))
+        nb = max(1, -(-n_max // shard_batch), int(syncs))
         return max(nb, 2) if n_max >= (1 << 19) else nb
     return max(1, int(syncs))
 
@@ -255,7 +255,9 @@ def run_case(case: dict, cache: dict, datasets: dict) -> dict:
     d = datasets[name]
     P0, Q0 = initial_tables(d, 3)
     t0 = time.perf_counter()
-    g = gpu_run(d, mode, lr0, seed, epochs, marks, world, layout, P0, Q0, shard_batch=case.get("shard_batch", 1 << 20), syncs=case.get("syncs", 1),
+    from qrec_amd.dist import reconciliations_per_epoch
+    g = gpu_run(d, mode, lr0, seed, epochs, marks, world, layout, P0, Q0, shard_batch=case.get("shard_batch", 1 << 20),
+                syncs=reconciliations_per_epoch(world, case.get("syncs", 0)),
                 item_run=case.get("item_run"))
     t1 = time.perf_counter()
     key = (name, lr0, seed, epochs, every) + g["perm_key"]
@@ -278,18 +280,32 @@ def run_case(case: dict, cache: dict, datasets: dict) -> dict:
 
 
 def plan_full():
+    """the ledger of profiles/r04_paired_recall.json: every mode that is not order-exact, on both structured datasets, at BPR.conf's rate
+    and five times it; N = 2 / 4 (/ 8) logical ranks in both layouts; the 6 M-triplet regime `auto` switches schedules in"""
+    Y, L, X = "yelp2018-clustered", "lastfm", "xl6m-clustered"
+    runs = {Y: ((0.01, 40, 5), (0.05, 20, 5)), L: ((0.01, 40, 4), (0.05, 20, 2))}
     cases = []
-    for ds, runs in (("yelp2018-clustered", ((0.01, 40), (0.05, 20))), ("lastfm", ((0.01, 40), (0.05, 20)))):
-        for lr0, epochs in runs:
+    for ds in (Y, L):
+        for lr0, epochs, every in runs[ds]:
             for seed in (7, 11):
-                for mode in ("item", "item-deferred", "item-deferred:4"):
-                    cases.append(dict(dataset=ds, lr0=lr0, seed=seed, mode=mode, epochs=epochs, eval_every=5))
-    for ds in ("yelp2018-clustered", "lastfm"):
-        for lr0, epochs in ((0.01, 40), (0.05, 20)):
+                for mode in ("item", "user"):
+                    cases.append(dict(dataset=ds, lr0=lr0, seed=seed, mode=mode, epochs=epochs, eval_every=every))
+            for mode in ("item-deferred", "item-deferred:4"):
+                cases.append(dict(dataset=ds, lr0=lr0, seed=7, mode=mode, epochs=epochs, eval_every=every))
+            cases.append(dict(dataset=ds, lr0=lr0, seed=7, mode="item", epochs=epochs, eval_every=every, item_run=0, own_order=True))
+    for ds in (Y, L):
+        for lr0, epochs, every in runs[ds]:
             for world in (2, 4):
                 for layout in ("replicated", "sharded"):
-                    cases.append(dict(dataset=ds, lr0=lr0, seed=7, mode="item", epochs=epochs, eval_every=5, world=world, layout=layout,
-                                      **({"shard_batch": 1 << 14} if ds == "lastfm" and layout == "sharded" else {})))
+                    cases.append(dict(dataset=ds, lr0=lr0, seed=7, mode="item", epochs=epochs, eval_every=every, world=world, layout=layout,
+                                      **({"shard_batch": 1 << 14} if ds == L and layout == "sharded" else {})))
+    for world in (2, 4):
+        cases.append(dict(dataset=Y, lr0=0.05, seed=7, mode="item", epochs=20, eval_every=5, world=world, layout="replicated", syncs=4))
+    for layout in ("replicated", "sharded"):
+        cases.append(dict(dataset=Y, lr0=0.01, seed=7, mode="item", epochs=40, eval_every=5, world=8, layout=layout))
+    for lr0, epochs, every in ((0.05, 15, 3), (0.01, 40, 5)):
+        for mode in ("item", "item-deferred:4"):
+            cases.append(dict(dataset=X, lr0=lr0, seed=7, mode=mode, epochs=epochs, eval_every=every))
     return cases
 
 
