@@ -115,8 +115,10 @@ def cpu_baseline(u, i, indptr, n_items, U, seconds=12.0):
     return {"value": done / dt, "unit": "triplet-updates/s", "cores": 1, "kind": "port",
             "sample": f"{epochs} epochs ({done} triplets, {dt:.1f} s), C fp64 port of BPR.py:29-53 + CPython-stream sampler",
             "reference_loop_here": {"value": n_loop / dt_loop, "unit": "triplet-updates/s", "cores": 1, "kind": "port",
-                                    "what": "the reference's own form -- per triplet one CPython iteration, random.choice, seven numpy row "
-                                            "statements (BPR.py:28-53) -- restated in oracle/npref.py and timed on this host",
+                                    "what": "a RESTATEMENT of the reference's interpreter-bound loop, leaner than the reference's own (ints instead of "
+                                            "string-keyed dict look-ups, locals instead of attribute access, no method call per triplet): per triplet one "
+                                            "CPython iteration, random.choice, seven numpy row statements (BPR.py:28-53) -- oracle/npref.py, timed on this "
+                                            "host; the unmodified reference is `reference_python` (another host)",
                                     "sample": f"{n_loop} triplets of the same epoch ({dt_loop:.1f} s), d = {DIM}, fp64"},
             "reference_python": {"value": 58930.0, "unit": "triplet-updates/s", "cores": 1,
                                  "host": "survey container (8 vCPU Xeon 2.1 GHz KVM), not this box: the Python reference cannot travel",

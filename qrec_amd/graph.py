@@ -416,6 +416,7 @@ class RowPartitionedLightGCNTrainer:
             return self._train_step_full(d_u, d_i, d_j, B, stream)
         if getattr(self, "row_mask", None) is None:
             self.row_mask = DeviceBuffer.zeros((rp.world * rp.rows_pad + 31) // 32, np.uint32)
+        self.row_mask.fill_bytes(0, stream)
         capi.mark_batch_rows(d_u, d_i, d_j, B, self.nu, self.row_mask, stream)         # bitmap of {u, nu + i, nu + j} over the whole table
         blk_mask = self.row_mask.ptr + (rp.lo // 32) * 4                                # the block starts on a word boundary (rows_pad % 32 == 0)
         self.forward_sum(stream, last_y_mask=blk_mask)
@@ -1000,7 +1001,7 @@ class RowPartitionedNGCFTrainer:
     KEEP = 0.9
     N_LAYERS = 2
 
-    def __init__(self, comm, U0, V0, W, adj, lr: float, reg: float, loss_eps: float = 1e-7, seed: int = 0):
+    def __init__(self, comm, U0, V0, W, adj, lr: float, reg: float, loss_eps: float = 1e-7, seed: int = 0, batch_rows: bool = True):
         from .dist import RowPartition
         self.comm = comm
         self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
@@ -1010,6 +1011,7 @@ class RowPartitionedNGCFTrainer:
         self.ld = padded_ld(self.d, np.float32)
         self.wide_d, self.wide_ld = 3 * self.d, padded_ld(3 * self.d, np.float32)
         self.lr, self.reg, self.loss_eps, self.seed = lr, reg, loss_eps, seed
+        self.batch_rows, self._batch = bool(batch_rows), {}
         rp = self.rp = RowPartition(comm, self.n, self.ld)
         lo, hi, pad = rp.lo, rp.hi, rp.rows_pad
         indptr, indices, values = adj
@@ -1041,11 +1043,14 @@ class RowPartitionedNGCFTrainer:
         self.d_loss = DeviceBuffer.zeros(1, np.float64)
         self.step_no = 0
 
-    def forward(self, training: bool, masks=None, stream=None):
-        """E_1, E_2, side, gate, inv on the rank's rows; the wide table All = [E_0 | z_1 | z_2] whole on every rank.
+    def forward(self, training: bool, masks=None, stream=None, own_rows_only: bool = False):
+        """E_1, E_2, side, gate, inv on the rank's rows; the wide table All = [E_0 | z_1 | z_2] whole on every rank -- or, with
+        ``own_rows_only`` (the training step, round 4), only this rank's rows of it: the loss needs the batch's rows, which travel
+        separately (``train_step_async``), not two all-gathers of N x ld floats.
         ``masks``: per layer, THIS RANK'S rows [pad][ld] of the injected keep decisions (tests)."""
         rp, d, ld, pad = self.rp, self.d, self.ld, self.rp.rows_pad
         rows_full = rp.world * pad
+        mine = 4 * rp.lo * self.wide_ld
         for k in range(self.N_LAYERS):
             if k == 0:      # the ego block of the concat is the WHOLE E_0 (the loss looks up any row): this product's operand is gathered whole
                 rp.gather_operand(self.E[k], self.X_full, stream)
@@ -1058,18 +1063,42 @@ class RowPartitionedNGCFTrainer:
             capi.ngcf_activate(self.gate[k], pad, d, ld, self.KEEP if training else 1.0, None if masks is None else masks[k],
                                self.seed, self.step_no * 8 + k, self.E[k + 1], self.z[k], ld, 0, self.inv[k], stream,
                                philox_row0=rp.lo)
-            rp.gather_operand(self.z[k], self.X_full, stream)
-            capi.copy_cols(self.All_full.ptr + 4 * (k + 1) * d, self.wide_ld, self.X_full, ld, 0, rows_full, d, False, stream)
+            if own_rows_only:
+                capi.copy_cols(self.All_full.ptr + mine + 4 * (k + 1) * d, self.wide_ld, self.z[k], ld, 0, pad, d, False, stream)
+            else:
+                rp.gather_operand(self.z[k], self.X_full, stream)
+                capi.copy_cols(self.All_full.ptr + 4 * (k + 1) * d, self.wide_ld, self.X_full, ld, 0, rows_full, d, False, stream)
+
+    def _batch_buffers(self, B: int):
+        b = self._batch.get(B)
+        if b is None:
+            ar = np.arange(max(B, 1), dtype=np.int32)
+            b = self._batch[B] = dict(S=DeviceBuffer.zeros((3 * max(B, 1), self.wide_ld), np.float32), dS=DeviceBuffer.zeros((3 * max(B, 1), self.wide_ld), np.float32),
+                                      u=DeviceBuffer.from_numpy(ar), j=DeviceBuffer.from_numpy(ar + B))
+        return b
 
     def train_step_async(self, d_u, d_i, d_j, B: int, masks=None, stream=None):
         rp, d, ld, pad = self.rp, self.d, self.ld, self.rp.rows_pad
         rows_full = rp.world * pad
-        self.forward(True, masks, stream)
-        self.dAll_full.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
-        if B:
-            capi.bpr_batch_loss_grad(self.All_full, 1.0, self.nu, rows_full, self.wide_ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
-                                     self.dAll_full, self.d_loss, stream)
         mine = 4 * rp.lo * self.wide_ld                 # byte offset of this rank's rows in the wide tables
+        if self.batch_rows and B:
+            # round 4: the two all-gathers of the normalised blocks z_k are gone -- every rank contributes its rows of the batch's 3B rows of
+            # the wide table (zeros elsewhere), ONE all-reduce of 3B x wide_ld floats makes them whole everywhere, every rank evaluates the
+            # whole batch on that compact table and scatters its own rows of the gradient back into its block
+            self.forward(True, masks, stream, own_rows_only=True)
+            b = self._batch_buffers(B)
+            capi.batch_rows_gather(self.All_full.ptr + mine, self.wide_ld, rp.lo, rp.hi, d_u, d_i, d_j, B, self.nu, b["S"], stream)
+            self.comm.allreduce(b["S"], 3 * B * self.wide_ld, capi.F32, stream)
+            b["dS"].fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
+            capi.bpr_batch_loss_grad(b["S"], 1.0, B, 3 * B, self.wide_ld, b["u"], b["u"], b["j"], B, self.loss_eps, self.reg, b["dS"], self.d_loss, stream)
+            capi.memset(self.dAll_full.ptr + mine, 0, pad * self.wide_ld * 4, stream)
+            capi.batch_rows_scatter_add(self.dAll_full.ptr + mine, self.wide_ld, rp.lo, rp.hi, d_u, d_i, d_j, B, self.nu, b["dS"], stream)
+        else:
+            self.forward(True, masks, stream)
+            self.dAll_full.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
+            if B:
+                capi.bpr_batch_loss_grad(self.All_full, 1.0, self.nu, rows_full, self.wide_ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
+                                         self.dAll_full, self.d_loss, stream)
         dnext = None
         for k in (1, 0):
             dE = self.dEa if k == 1 else self.dEb

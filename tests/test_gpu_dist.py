@@ -507,7 +507,10 @@ def test_bench_multi_gpu_path_on_real_rccl_world_one(mode):
     b = _bench(["--steps", "2", "--warmup", "1", "--epochs-per-step", "3", "--no-cpu-baseline", "--no-extras", "--shape", "ml1m"], {})
     assert a["n_gpus"] == 1 and "FORCE_DIST" in a["config"]["parallelism"]
     assert a["config"]["final_loss"] == pytest.approx(b["config"]["final_loss"], rel=0.03)
-    assert a["config"]["final_lr"] == b["config"]["final_lr"]
+    # (the bold driver's decisions are usually the same ones; on this structureless shape the first epochs' losses differ by 1e-3, so a
+    # Hogwild-timing-sized difference may flip ONE x1.05 / x0.5 decision of the three -- seen once in round 4 -- without moving the loss level)
+    ratio = a["config"]["final_lr"] / b["config"]["final_lr"]
+    assert ratio == pytest.approx(1.0) or ratio == pytest.approx(0.5 / 1.05) or ratio == pytest.approx(1.05 / 0.5)
 
 
 # ---- graph models: 1-D row partition of the propagation --------------------------------------------

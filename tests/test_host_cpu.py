@@ -314,6 +314,13 @@ def test_product_never_imports_the_oracle():
     for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
         uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
         assert (not uses) or fn.name in allowed, fn.name
+    # the paired Recall@20 harness (tools/paired_recall.py, which bench.py's recall legs and the GPU tests call) touches the oracle in
+    # exactly one function: the reference side of the comparison
+    tree_pr = ast.parse(open(os.path.join(ROOT, "tools", "paired_recall.py")).read())
+    for fn in [n for n in ast.walk(tree_pr) if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
+        assert (not uses) or fn.name == "reference_run", fn.name
+    assert not any(isinstance(n, (ast.Import, ast.ImportFrom)) and "oracle" in ((getattr(n, "module", "") or "") + " ".join(a.name for a in n.names)) for n in tree_pr.body)
     top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
     assert not any(("oracle" in (getattr(n, "module", "") or "")) or any("oracle" in a.name for a in n.names) for n in top)
     entry = ast.parse(open(os.path.join(ROOT, "__graft_entry__.py")).read())
@@ -907,3 +914,30 @@ def test_deferred_sub_epoch_plan(n, chunk, S):
     assert sb[0] == 0 and sb[-1] == n_chunks and first[0] == 0 and first[-1] == n
     for s in range(S + 1):
         assert sb[s] == -(-s * n_chunks // S)
+
+
+# ---------------------------------------------------------------------------------------------
+# round 4: stored order of the item-major schedule, `auto`, reconciliations per epoch (host logic, no device)
+# ---------------------------------------------------------------------------------------------
+def test_stride_runs_is_a_permutation_of_whole_runs():
+    from qrec_amd.engine import stride_runs
+    for n, run in ((100, 8), (97, 8), (5, 8), (64, 16), (1_252_669, 16), (16, 16), (17, 16), (0, 16)):
+        a = stride_runs(n, run)
+        assert np.array_equal(np.sort(a), np.arange(n))
+        whole = n // run * run
+        assert all(a[k] % run == 0 and np.array_equal(a[k:k + run], np.arange(a[k], a[k] + run)) for k in range(0, whole, run))
+        assert np.array_equal(a[whole:], np.arange(whole, n))                     # the short tail goes last
+    a = stride_runs(1_252_669, 16)
+    gaps = np.abs(np.diff(a[::16]))
+    assert np.median(gaps) > 1000 * 16                                             # consecutive runs come from far-apart places of the sorted list
+
+
+def test_auto_schedule_rule_and_reconciliations():
+    from qrec_amd.dist import reconciliations_per_epoch
+    from qrec_amd.engine import DEFER_MIN_TRIPLETS, resolve_schedule
+    skew = np.ones(1000); skew[0] = 5000
+    assert resolve_schedule(1_252_669, skew) == ("item", None) and resolve_schedule(1_000_000, np.ones(1000)) == ("user", None)
+    assert resolve_schedule(DEFER_MIN_TRIPLETS, np.ones(10)) == ("item-deferred", 4) and resolve_schedule(25_000_000, None) == ("item-deferred", 4)
+    assert resolve_schedule(DEFER_MIN_TRIPLETS - 1, None) == ("item", None)
+    assert resolve_schedule(10 ** 9, None, "user") == ("user", None)              # an explicit choice is never overridden
+    assert [reconciliations_per_epoch(g) for g in (1, 2, 4, 8)] == [1, 2, 4, 8] and reconciliations_per_epoch(8, 1) == 1 and reconciliations_per_epoch(2, 5) == 5

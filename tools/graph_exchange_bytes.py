@@ -2,7 +2,7 @@
 """Bytes a rank receives per propagation product under the two operand exchanges of the row-partitioned graph trainers
 (qrec_amd/graph.py::_setup_row_exchange): all-gather of every block vs only the remote rows the rank's block of the adjacency
 refers to (dist.RowPartition.reference).  Host arithmetic on the two synthetic Yelp2018-shape graphs, world 8, d = 64 -- no
-GPU needed; prints one JSON object (committed as profiles/r03_graph_exchange_bytes.json)."""
+GPU needed; prints one JSON object (committed as profiles/r03_graph_exchange_bytes.json; round 4 adds the batch-row economies: profiles/r04_graph_exchange_bytes.json)."""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -47,5 +47,22 @@ for shape in ("yelp2018", "yelp2018-clustered"):
                                            "referenced_as_numbered": 2 * L * res["as_numbered_summary"]["mean_MB"] + allgather / 1e6,
                                            "referenced_spectral": 2 * L * res["spectral_renumbered_summary"]["mean_MB"] + allgather / 1e6,
                                            "note": "2L propagation products + one all-gather of the layer sum for the batch loss (every rank evaluates the whole batch)"}
+    # round 4 -- the batch-row economies of the row-partitioned steps (graph.RowPartitionedLightGCNTrainer / NGCFTrainer, batch_rows=True):
+    # the layer sum travels as ONE all-reduce of the batch's 3B rows (ring: 2 (G-1)/G x payload received per rank), the first backward
+    # product takes the batch gradient every rank already holds (no exchange); NGCF: the two all-gathers of the normalised blocks
+    # become one all-reduce of 3B rows of the 3d-wide table (padded to 256 floats)
+    B, G = 2048, 8
+    small = 2 * (G - 1) / G * 3 * B * 64 * 4 / 1e6
+    wide = 2 * (G - 1) / G * 3 * B * 256 * 4 / 1e6
+    ag, ref = allgather / 1e6, res["as_numbered_summary"]["mean_MB"]
+    res["round4_batch_rows"] = {
+        "batch": B, "allreduce_3B_rows_MB_received": small, "allreduce_3B_wide_rows_MB_received": wide,
+        "lightgcn_L3_step_MB_per_rank": {"allgather_form": {"round3": (2 * L + 1) * ag, "round4": (2 * L - 1) * ag + small},
+                                         "referenced_as_numbered": {"round3": 2 * L * ref + ag, "round4": (2 * L - 1) * ref + small}},
+        "ngcf_step_MB_per_rank": {"allgather_form": {"round3": 6 * ag, "round4": 4 * ag + wide},
+                                  "referenced_as_numbered": {"round3": 3 * ag + 3 * ref, "round4": ag + 3 * ref + wide},
+                                  "note": "round 3: E_0 gathered whole (operand of layer 1 and ego block), z_1 and z_2 all-gathered, 3 more operand exchanges (E_1 forward, "
+                                          "dside of both layers backward); round 4: the z gathers replaced by the 3B-row all-reduce"},
+        "simgcl": "unchanged (three all-gathers of the layer sums per step are the remaining candidate: its InfoNCE reads the batch's unique rows only)"}
     out["graphs"][shape] = res
 print(json.dumps(out, indent=1))
