@@ -258,7 +258,7 @@ def hbm_resident_roofline(capi, schedule="user", sub_epochs=None):
         e0.record(); s.epoch_throughput_async(LR0, REG_U, REG_I); e1.record(); e1.sync(); ts.append(e1.elapsed_ms_since(e0))
     ms = float(np.median(ts[1:])); alg = n2 * bytes_per_triplet(d2)
     return {"workload": f"BPR d={d2}, {U2}x{I2}, {n2} triplets/epoch, {schedule}-major" + (f", {sub_epochs} sub-epochs" if sub_epochs else "")
-                        + " (config #4 single-GPU slice, tables 1.15 GB)",
+                        + " (config #4 single-GPU slice, tables 1.15 GB)", "schedule": schedule, "sub_epochs": int(s.sub_epochs),
             "bound": "hbm", "achieved": alg / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / ms / 1e6 / HBM_PEAK_GBPS,
             "avg_launch_ms": ms, "algorithmic_bytes_per_launch": alg, "triplet_updates_per_s": n2 / ms * 1e3}
 
