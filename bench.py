@@ -460,6 +460,11 @@ def main():
                     help="reconciliations of the ranks' item rows per epoch: delta all-reduces of the replicated layout, minimum number of exchange "
                          "batches of the sharded one.  0 = dist.reconciliations_per_epoch: one per rank (one per epoch leaves the +-0.002 Recall@20 "
                          "bar at 4 ranks, profiles/r04_paired_recall.json); 1 = the epoch close's fused all-reduce alone")
+    ap.add_argument("--hot-rows", type=int, default=int(os.environ.get("QREC_REPLICATED_HOT_ROWS", "0")),
+                    help="replicated layout: the reconciliations INSIDE an epoch cover only this many item rows, the ones with the most positives (the "
+                         "epoch close still reconciles the whole table).  0 = whole table every time (default).  Measured (paired Recall@20, "
+                         "planted-community graph, profiles/r04_paired_recall_studies.json part C): 4 ranks at BPR.conf's rate 0.0029 with no inner "
+                         "reconciliation, 0.0014 with 1,024 hot rows (1/37 of the bytes), 0.0008 with 12,288, 0.0006 with the whole table")
     ap.add_argument("--recall-dataset", default="auto", help="N > 1: dataset of the Recall@20 leg (auto: yelp2018-clustered for the Yelp2018 shape)")
     ap.add_argument("--recall-epochs", type=int, default=0, help="epochs of that leg (0: 40 at BPR.conf's rate on the clustered graph, else 25)")
     ap.add_argument("--shard-batch", type=int, default=1 << 20,
@@ -581,7 +586,8 @@ def main():
             dstep = qd.ShardedStep(comm, qd.ShardedItemExchange(comm, I, tables.ld, tables.Q, pipeline=pipe, plan_ahead=ahead), n_batches,
                                    plan_inside=not args.no_plan_inside)
         elif use_dist:
-            dstep = qd.ReplicatedStep(comm, qd.ReplicatedTableSync(comm, tables.Q))
+            hot = qd.hot_item_rows(np.bincount(items, minlength=I), args.hot_rows) if args.hot_rows > 0 and n_batches > 1 else None
+            dstep = qd.ReplicatedStep(comm, qd.ReplicatedTableSync(comm, tables.Q), hot_rows=hot, ld=tables.ld)
         # device copies of the initial state: every step restarts training from it (see step())
         d_P0, d_Q0 = DeviceBuffer.from_numpy(tables._pad(P0)), DeviceBuffer.from_numpy(tables._pad(Q0_local))
         ev, pool = [], []
@@ -694,10 +700,11 @@ def main():
             lib = {"library": path, "version": ver}
         payload = None if sharded else leg["q_floats"] * 4 + 24          # the fused all-reduce: item-table deltas + 3 fp64 loss terms
         syncs = leg["n_batches"] if not sharded else None
+        inner_payload = payload if not (args.hot_rows > 0) else min(args.hot_rows, I) * leg["ld"] * 4      # an inner reconciliation: the whole table, or the hot rows
         # link-time arithmetic for the collectives of one epoch (NOT a measurement): a ring all-reduce moves 2 (G-1)/G x payload over
         # each rank's links; xGMI is point-to-point, 7 links x ~153 GB/s per GPU (MI355X_MICROARCH.md) -- one ring uses one link per
         # direction, a fully connected 8-GPU node can run up to 7 rings side by side
-        wire = (2.0 * (world - 1) / world * payload * syncs) if (payload and world > 1) else 0.0
+        wire = (2.0 * (world - 1) / world * (payload + (syncs - 1) * inner_payload)) if (payload and world > 1) else 0.0
         predicted = None if sharded else {"one_ring_153GBps": wire / 153e9 * 1e3, "seven_rings_1071GBps": wire / 1071e9 * 1e3,
                                           "what": "ring all-reduce wire bytes per rank and epoch / link rate; arithmetic, not measured"}
         if sharded and moved is not None and world > 1:
@@ -712,6 +719,7 @@ def main():
                  "collectives_per_epoch": ({"all_to_all_batches": leg["n_batches"], "calls": 3 * leg["n_batches"] + 1,
                                             "bytes_leaving_all_ranks": moved} if sharded else
                                            {"all_reduce": syncs, "payload_bytes_per_rank": payload,
+                                            "inner_payload_bytes_per_rank": inner_payload, "hot_rows": args.hot_rows if args.hot_rows > 0 else None,
                                             "ring_wire_bytes_per_rank": wire}),
                  "predicted_link_ms_per_epoch": predicted}
 

@@ -51,6 +51,45 @@ def test_table_delta_and_apply():
         capi.table_delta(d_t, d_s, d_d, 7)
 
 
+@pytest.mark.parametrize("ld", [32, 64, 256])
+def test_row_subset_reconciliation_and_batch_row_kernels(ld):
+    """round 4: (a) qrec_table_rows_delta / _reconcile -- the replicated table's reconciliation restricted to a row list: afterwards table
+    and snapshot agree on those rows and table - snapshot of every other row is untouched; (b) qrec_batch_rows_gather / _scatter_add -- the
+    rows {u, nu + i, nu + j} of a batch out of / into a block [lo, hi) of a row-partitioned table, repeated rows adding up."""
+    rng = np.random.default_rng(ld)
+    n_rows, H = 5000, 700
+    table = rng.standard_normal((n_rows, ld)).astype(np.float32); start = rng.standard_normal((n_rows, ld)).astype(np.float32)
+    rows = np.sort(rng.choice(n_rows, H, replace=False)).astype(np.int32)
+    other = rng.standard_normal((H, ld)).astype(np.float32)                     # what another rank would contribute
+    d_t, d_s, d_r, d_d = DB.from_numpy(table), DB.from_numpy(start), DB.from_numpy(rows), DB((H, ld), np.float32)
+    capi.table_rows_delta(d_t, d_s, ld, d_r, H, d_d)
+    assert np.array_equal(d_d.numpy(), table[rows] - start[rows])
+    d_d.upload((table[rows] - start[rows]) + other)                             # the "all-reduced" sum
+    capi.table_rows_reconcile(d_t, d_s, ld, d_r, H, d_d)
+    want = start[rows] + ((table[rows] - start[rows]) + other)
+    t2, s2 = d_t.numpy(), d_s.numpy()
+    assert np.array_equal(t2[rows], want) and np.array_equal(s2[rows], want)
+    keep = np.setdiff1d(np.arange(n_rows), rows)
+    assert np.array_equal(t2[keep], table[keep]) and np.array_equal(s2[keep], start[keep])
+    # (b)
+    nu, B, lo, hi = 2000, 333, 1500, 3700
+    u = rng.integers(0, nu, B).astype(np.int32); i = rng.integers(0, n_rows - nu, B).astype(np.int32); j = rng.integers(0, n_rows - nu, B).astype(np.int32)
+    ids = np.concatenate([u, nu + i, nu + j]).astype(np.int64)
+    d_u, d_i, d_j = DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j)
+    block = table[lo:hi].copy(); d_b = DB.from_numpy(block); d_o = DB((3 * B, ld), np.float32)
+    capi.batch_rows_gather(d_b, ld, lo, hi, d_u, d_i, d_j, B, nu, d_o)
+    own = (ids >= lo) & (ids < hi)
+    want = np.where(own[:, None], table[np.clip(ids, 0, n_rows - 1)], 0).astype(np.float32)
+    assert np.array_equal(d_o.numpy(), want) and 0 < own.sum() < ids.size
+    src = rng.standard_normal((3 * B, ld)).astype(np.float32)
+    capi.batch_rows_scatter_add(d_b, ld, lo, hi, d_u, d_i, d_j, B, nu, DB.from_numpy(src))
+    ref = block.astype(np.float64)
+    np.add.at(ref, ids[own] - lo, src[own].astype(np.float64))
+    check("rel_err(batch_rows_scatter_add, numpy add.at)", rel_err(d_b.numpy(), ref), 1e-6)
+    with pytest.raises(capi.QRecError):
+        capi.batch_rows_gather(d_b, 48, lo, hi, d_u, d_i, d_j, B, nu, d_o)
+
+
 @pytest.mark.parametrize("n_items,world,n", [(200, 1, 500), (200, 2, 500), (38048, 8, 150_000), (1_000_003, 8, 400_000),
                                               (5, 8, 40), (3000, 3, 0), (1025, 2, 1)])
 def test_shard_plan_matches_the_host_statement(n_items, world, n):
