@@ -696,6 +696,9 @@ int qrec_gather_rows(const float *d_table, int32_t ld, const int32_t *d_rows, in
  *                               3B rows) these are the batch's rows of the whole table -- instead of an all-gather of the table;
  * qrec_batch_rows_scatter_add:  d_block[row(k) - lo] += d_src[k] for every k whose row lies in [lo, hi) (f32 atomics: a batch
  *                               repeats rows; lo = 0, hi = N scatters into a whole table).                                      */
+/* ... and for an arbitrary list of table rows d_ids[n] (SimGCL's InfoNCE reads the batch's UNIQUE users / items, SimGCL.py:61-64) */
+int qrec_rows_gather_owned(const float *d_block, int32_t ld, int64_t lo, int64_t hi, const int32_t *d_ids, int64_t n, float *d_out, void *stream);
+int qrec_rows_scatter_add_owned(float *d_block, int32_t ld, int64_t lo, int64_t hi, const int32_t *d_ids, int64_t n, const float *d_src, void *stream);
 int qrec_batch_rows_gather(const float *d_block, int32_t ld, int64_t lo, int64_t hi, const int32_t *d_u, const int32_t *d_i,
                            const int32_t *d_j, int32_t B, int64_t n_users, float *d_out, void *stream);
 int qrec_batch_rows_scatter_add(float *d_block, int32_t ld, int64_t lo, int64_t hi, const int32_t *d_u, const int32_t *d_i,

@@ -147,6 +147,8 @@ _SIGNATURES = {
     "qrec_gather_rows": [_vp, _i32, _vp, _i64, _vp, _vp],
     "qrec_table_rows_delta": [_vp, _vp, _i32, _vp, _i64, _vp, _vp],
     "qrec_table_rows_reconcile": [_vp, _vp, _i32, _vp, _i64, _vp, _vp],
+    "qrec_rows_gather_owned": [_vp, _i32, _i64, _i64, _vp, _i64, _vp, _vp],
+    "qrec_rows_scatter_add_owned": [_vp, _i32, _i64, _i64, _vp, _i64, _vp, _vp],
     "qrec_batch_rows_gather": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _i64, _vp, _vp],
     "qrec_batch_rows_scatter_add": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _i64, _vp, _vp],
     "qrec_scatter_add_row_deltas": [_vp, _i32, _vp, _i64, _vp, _vp, _vp],
@@ -1163,6 +1165,15 @@ def table_rows_delta(d_table, d_start, ld: int, d_rows, n: int, d_delta, stream=
 
 def table_rows_reconcile(d_table, d_start, ld: int, d_rows, n: int, d_delta_sum, stream=None):
     _check(load().qrec_table_rows_reconcile(_dp(d_table), _dp(d_start), ld, _dp(d_rows), n, _dp(d_delta_sum), _sh(stream)))
+
+
+def rows_gather_owned(d_block, ld: int, lo: int, hi: int, d_ids, n: int, d_out, stream=None):
+    """d_out[k] = row d_ids[k] of a table whose rows [lo, hi) are d_block; rows held elsewhere: zeros"""
+    _check(load().qrec_rows_gather_owned(_dp(d_block), ld, lo, hi, _dp(d_ids), n, _dp(d_out), _sh(stream)))
+
+
+def rows_scatter_add_owned(d_block, ld: int, lo: int, hi: int, d_ids, n: int, d_src, stream=None):
+    _check(load().qrec_rows_scatter_add_owned(_dp(d_block), ld, lo, hi, _dp(d_ids), n, _dp(d_src), _sh(stream)))
 
 
 def batch_rows_gather(d_block, ld: int, lo: int, hi: int, d_u, d_i, d_j, B: int, n_users: int, d_out, stream=None):

@@ -289,6 +289,27 @@ __global__ void rows_reconcile_kernel(float4 *__restrict__ table, float4 *__rest
     }
 }
 
+// the same two operations for an arbitrary list of table rows (SimGCL's InfoNCE reads the batch's UNIQUE users / items, SimGCL.py:61-64)
+template <int LD4>
+__global__ void rows_gather_owned_kernel(const float4 *__restrict__ block, int64_t lo, int64_t hi, const int32_t *__restrict__ ids, int64_t n,
+                                         float4 *__restrict__ out) {
+    const int64_t total = n * LD4;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = ids[t / LD4];
+        out[t] = (row >= lo && row < hi) ? block[(row - lo) * LD4 + (t % LD4)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int LD>
+__global__ void rows_scatter_owned_kernel(float *__restrict__ block, int64_t lo, int64_t hi, const int32_t *__restrict__ ids, int64_t n,
+                                          const float *__restrict__ src) {
+    const int64_t total = n * LD;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = ids[t / LD];
+        const float v = src[t];
+        if (row >= lo && row < hi && v != 0.0f) atomicAdd(block + (row - lo) * LD + (t % LD), v);
+    }
+}
+
 inline int grid_for(int64_t work, int block) {
     int64_t g = (work + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
@@ -469,6 +490,42 @@ int qrec_table_rows_reconcile(float *d_table, float *d_start, int32_t ld, const 
         default: QREC_RR(64); break;
     }
 #undef QREC_RR
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+int qrec_rows_gather_owned(const float *d_block, int32_t ld, int64_t lo, int64_t hi, const int32_t *d_ids, int64_t n, float *d_out, void *stream) {
+    QREC_REQUIRE(n >= 0 && lo >= 0 && hi >= lo, "qrec_rows_gather_owned: bad arguments");
+    QREC_REQUIRE(ld == 32 || ld == 64 || ld == 128 || ld == 256, "qrec_rows_gather_owned: row stride must be 32, 64, 128 or 256 floats (got %d)", ld);
+    if (n == 0) return QREC_OK;
+    QREC_REQUIRE(d_block && d_ids && d_out, "qrec_rows_gather_owned: null argument");
+    const dim3 g(grid_for(n * (ld / 4), 256)), b(256);
+#define QREC_RG(L4) hipLaunchKernelGGL((rows_gather_owned_kernel<L4>), g, b, 0, as_stream(stream), (const float4 *)d_block, lo, hi, d_ids, n, (float4 *)d_out)
+    switch (ld) {
+        case 32: QREC_RG(8); break;
+        case 64: QREC_RG(16); break;
+        case 128: QREC_RG(32); break;
+        default: QREC_RG(64); break;
+    }
+#undef QREC_RG
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+int qrec_rows_scatter_add_owned(float *d_block, int32_t ld, int64_t lo, int64_t hi, const int32_t *d_ids, int64_t n, const float *d_src, void *stream) {
+    QREC_REQUIRE(n >= 0 && lo >= 0 && hi >= lo, "qrec_rows_scatter_add_owned: bad arguments");
+    QREC_REQUIRE(ld == 32 || ld == 64 || ld == 128 || ld == 256, "qrec_rows_scatter_add_owned: row stride must be 32, 64, 128 or 256 floats (got %d)", ld);
+    if (n == 0) return QREC_OK;
+    QREC_REQUIRE(d_block && d_ids && d_src, "qrec_rows_scatter_add_owned: null argument");
+    const dim3 g(grid_for(n * ld, 256)), b(256);
+#define QREC_RS(L) hipLaunchKernelGGL((rows_scatter_owned_kernel<L>), g, b, 0, as_stream(stream), d_block, lo, hi, d_ids, n, d_src)
+    switch (ld) {
+        case 32: QREC_RS(32); break;
+        case 64: QREC_RS(64); break;
+        case 128: QREC_RS(128); break;
+        default: QREC_RS(256); break;
+    }
+#undef QREC_RS
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }

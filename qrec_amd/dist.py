@@ -314,8 +314,8 @@ class ShardedItemExchange:
         if self._scratch_batches < nb:
             self._cap["scratch"] = k.DeviceBuffer(k.shard_plan_epoch_scratch_bytes(self.n_items, G, nb), np.uint8)
             self._scratch_batches = nb
-        d_bounds = self._const("bounds", np.array(bounds, np.int64), stream)
-        d_roff = self._const("req_off", req_off, stream)
+        d_bounds = self._const("bounds" + sfx, np.array(bounds, np.int64), stream)      # per plan slot: a re-upload for one slot (plan stream) must
+        d_roff = self._const("req_off" + sfx, req_off, stream)                          # not race a plan kernel of the other (training stream)
         k.shard_plan_epoch(d_i, d_j, d_bounds, nb, n, self.n_items, G, self._cap["scratch"], d_req, d_roff, d_counts, d_ci, d_cj, stream)
         comm.allgather(d_counts, d_all, nb * G, k.I32, stream)
         pin = self._pinned.get(slot)

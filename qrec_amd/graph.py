@@ -715,7 +715,7 @@ class RowPartitionedSimGCLTrainer:
     1 + 3 (L - 1) + 3 + L all-gathers of N x ld floats per step (L = 2: nine of 17.8 MB at the Yelp2018 shape)."""
 
     def __init__(self, comm, U0, V0, adj, n_layers: int, lr: float, reg: float, cl_rate: float, eps: float,
-                 tau: float = 0.2, loss_eps: float = 1e-7, seed: int = 0, max_unique: int = 4096):
+                 tau: float = 0.2, loss_eps: float = 1e-7, seed: int = 0, max_unique: int = 4096, batch_rows: bool = True):
         from .dist import RowPartition
         self.comm = comm
         self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
@@ -742,6 +742,7 @@ class RowPartitionedSimGCLTrainer:
         full = lambda: DeviceBuffer.zeros((rp.world * pad, self.ld), np.float32)
         self.X_full, self.Sm_full, self.S1_full, self.S2_full, self.dOut_full = full(), full(), full(), full(), full()
         self.d_loss = DeviceBuffer.zeros(2, np.float64)         # [rec, cl (unscaled)]
+        self.batch_rows, self._cmp = bool(batch_rows), None
         self.max_unique = max_unique
         self.ws = DeviceBuffer(capi.info_nce_workspace_bytes(max_unique, self.ld), np.uint8)
         f = np.float32
@@ -786,24 +787,61 @@ class RowPartitionedSimGCLTrainer:
             raise ValueError("more unique rows in the batch than the InfoNCE workspace holds")
         rp, ld, L = self.rp, self.ld, float(self.L)
         self._encode_three(noises, stream)
-        for blk, full in ((self.Sm, self.Sm_full), (self.S1, self.S1_full), (self.S2, self.S2_full)):
-            rp.gather_operand(blk, full, stream)
-        self.dOut_full.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
-        rows_full = rp.world * rp.rows_pad
-        if B:
-            capi.bpr_batch_loss_grad(self.Sm_full, L, self.nu, rows_full, ld, d_u, d_i, d_j, B, self.loss_eps, self.reg, self.dOut_full,
-                                     self.d_loss, stream)
         cl = self.d_loss.ptr + 8
-        capi.info_nce_loss_grad(self.S1_full, self.S2_full, L, d_uniq_users, n_uu, ld, self.tau, self.cl_rate, self.ws, self.dOut_full, cl, stream)
-        capi.info_nce_loss_grad(self.S1_full, self.S2_full, L, d_uniq_items, n_ui, ld, self.tau, self.cl_rate, self.ws, self.dOut_full, cl, stream)
+        whole_first = getattr(self, "batch_rows", True) and B > 0
+        if whole_first:
+            # round 4 -- the losses read the three layer sums at the batch's rows only: Sm at {u, nu + i, nu + j} (3B rows), S1 / S2 at the batch's
+            # unique users and items.  Every rank contributes its rows of those (zeros elsewhere) into ONE packed buffer
+            # [Sm: 3B | S1: n_uu + n_ui | S2: n_uu + n_ui] x ld, ONE all-reduce makes it whole everywhere (3.4 MB at B = 2048 instead of three
+            # all-gathers of N x ld = 53 MB), the losses run on it with the rows addressed by position, and every rank -- holding the whole
+            # batch gradient -- scatters it into a whole-height operand that the first backward product reads without any exchange
+            M = self.max_unique
+            if getattr(self, "_cmp", None) is None or self._cmp["B"] != B:
+                ar = np.arange(max(3 * B, 2 * M), dtype=np.int32)
+                self._cmp = dict(B=B, S=DeviceBuffer.zeros((3 * B + 4 * M, ld), np.float32), dSm=DeviceBuffer.zeros((3 * B, ld), np.float32),
+                                 dC=DeviceBuffer.zeros((2 * M, ld), np.float32), ar=DeviceBuffer.from_numpy(ar), arB=DeviceBuffer.from_numpy(ar[:B] + B))
+            c = self._cmp
+            row = ld * 4
+            nC = n_uu + n_ui
+            pS1, pS2 = c["S"].ptr + 3 * B * row, c["S"].ptr + (3 * B + nC) * row
+            capi.batch_rows_gather(self.Sm, ld, rp.lo, rp.hi, d_u, d_i, d_j, B, self.nu, c["S"], stream)
+            for blk, base in ((self.S1, pS1), (self.S2, pS2)):
+                capi.rows_gather_owned(blk, ld, rp.lo, rp.hi, d_uniq_users, n_uu, base, stream)
+                capi.rows_gather_owned(blk, ld, rp.lo, rp.hi, d_uniq_items, n_ui, base + n_uu * row, stream)
+            self.comm.allreduce(c["S"], (3 * B + 2 * nC) * ld, capi.F32, stream)
+            c["dSm"].fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
+            capi.memset(c["dC"].ptr, 0, max(nC, 1) * row, stream)
+            capi.bpr_batch_loss_grad(c["S"], L, B, 3 * B, ld, c["ar"], c["ar"], c["arB"], B, self.loss_eps, self.reg, c["dSm"], self.d_loss, stream)
+            capi.info_nce_loss_grad(pS1, pS2, L, c["ar"], n_uu, ld, self.tau, self.cl_rate, self.ws, c["dC"], cl, stream)
+            capi.info_nce_loss_grad(pS1, pS2, L, c["ar"].ptr + 4 * n_uu, n_ui, ld, self.tau, self.cl_rate, self.ws, c["dC"], cl, stream)
+            self.dOut_full.fill_bytes(0, stream)
+            capi.batch_rows_scatter_add(self.dOut_full, ld, 0, self.n, d_u, d_i, d_j, B, self.nu, c["dSm"], stream)
+            capi.rows_scatter_add_owned(self.dOut_full, ld, 0, self.n, d_uniq_users, n_uu, c["dC"], stream)
+            capi.rows_scatter_add_owned(self.dOut_full, ld, 0, self.n, d_uniq_items, n_ui, c["dC"].ptr + n_uu * row, stream)
+        else:
+            for blk, full in ((self.Sm, self.Sm_full), (self.S1, self.S1_full), (self.S2, self.S2_full)):
+                rp.gather_operand(blk, full, stream)
+            self.dOut_full.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
+            rows_full = rp.world * rp.rows_pad
+            if B:
+                capi.bpr_batch_loss_grad(self.Sm_full, L, self.nu, rows_full, ld, d_u, d_i, d_j, B, self.loss_eps, self.reg, self.dOut_full,
+                                         self.d_loss, stream)
+            capi.info_nce_loss_grad(self.S1_full, self.S2_full, L, d_uniq_users, n_uu, ld, self.tau, self.cl_rate, self.ws, self.dOut_full, cl, stream)
+            capi.info_nce_loss_grad(self.S1_full, self.S2_full, L, d_uniq_items, n_ui, ld, self.tau, self.cl_rate, self.ws, self.dOut_full, cl, stream)
         dOut_blk = self.dOut_full.ptr + 4 * rp.lo * ld                  # this rank's rows of the output gradient, in place
+
+        def product(x, y, addend, first):
+            if first and whole_first:       # the operand is the whole batch gradient, already on this rank
+                capi.spmm_csr(self.plan, self.dOut_full, y, ld, d_addend=addend, addend_scale=1.0 if addend is not None else 0.0, stream=stream)
+            else:
+                self._product(x, y, stream, addend=addend)
         x = dOut_blk
         for k in range(self.L - 1):
             y = self.A if k % 2 == 0 else self.B
-            self._product(x, y, stream, addend=dOut_blk)
+            product(x, y, dOut_blk, k == 0)
             x = y
         g = self.B if x is self.A else self.A
-        self._product(x, g, stream)
+        product(x, g, None, self.L == 1)
         f = np.float32
         alpha = float(f(f(self.lr) * np.sqrt(f(1) - self.b2p, dtype=f) / (f(1) - self.b1p)))
         capi.adam_step(self.E, self.m, self.v, g, (rp.hi - rp.lo) * ld, 1.0 / L, alpha, float(self.b1), float(self.b2), float(self.adam_eps), stream)

@@ -63,6 +63,10 @@ for shape in ("yelp2018", "yelp2018-clustered"):
                                   "referenced_as_numbered": {"round3": 3 * ag + 3 * ref, "round4": ag + 3 * ref + wide},
                                   "note": "round 3: E_0 gathered whole (operand of layer 1 and ego block), z_1 and z_2 all-gathered, 3 more operand exchanges (E_1 forward, "
                                           "dside of both layers backward); round 4: the z gathers replaced by the 3B-row all-reduce"},
-        "simgcl": "unchanged (three all-gathers of the layer sums per step are the remaining candidate: its InfoNCE reads the batch's unique rows only)"}
+        "simgcl_L2_step_MB_per_rank": {"allgather_form": {"round3": 9 * ag, "round4": 5 * ag + 2 * (G - 1) / G * (3 * B + 2 * 3900) * 64 * 4 / 1e6},
+                                       "referenced_as_numbered": {"round3": 6 * ref + 3 * ag, "round4": 5 * ref + 2 * (G - 1) / G * (3 * B + 2 * 3900) * 64 * 4 / 1e6},
+                                       "note": "round 3: 4 forward operand exchanges (the shared first product + 3), three all-gathers of the layer sums Sm / S1 / S2, 2 backward; "
+                                               "round 4: the three gathers become ONE all-reduce of [Sm: 3B | S1, S2: the batch's ~3,900 unique users + items] rows and the first "
+                                               "backward product reads the batch gradient every rank holds (no exchange)"}}
     out["graphs"][shape] = res
 print(json.dumps(out, indent=1))
