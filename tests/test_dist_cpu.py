@@ -82,6 +82,49 @@ def _worker(rank, world, port, out):
     control.shutdown()
 
 
+def _hot_worker(rank, world, port, out):
+    """K = 3 batches per epoch: two INNER reconciliations over the hot rows only, then the full one (what engine.epoch_device_async enqueues
+    for the replicated layout with ReplicatedStep(hot_rows=...)); the 'SGD' of a batch is a rank- and batch-specific additive change"""
+    control, comm = _join(rank, world, port)
+    rng = np.random.default_rng(0)
+    n_rows, ld = 300, 8
+    Q0 = rng.standard_normal((n_rows, ld)).astype(np.float32)
+    q = HK.DeviceBuffer.from_numpy(Q0)
+    step = qd.ReplicatedStep(comm, ReplicatedTableSync(comm, q, kern=HK), hot_rows=_HOT, ld=ld)
+    for b in range(3):
+        q.a += _batch_change(rank, b, n_rows, ld)
+        if b < 2:
+            step.sync_tables()
+        else:
+            step.sync_q.sync()
+    out[rank] = q.a.copy()
+    control.shutdown()
+
+
+_HOT = np.array([3, 7, 8, 100, 299], np.int32)
+
+
+def _batch_change(rank, b, n_rows, ld):
+    return np.random.default_rng(1000 * rank + b).standard_normal((n_rows, ld)).astype(np.float32) * 0.1
+
+
+def test_inner_reconciliation_of_hot_rows_counts_nothing_twice():
+    """round 4 (dist.ReplicatedTableSync.sync_rows): after two inner reconciliations restricted to a row list and the epoch's full one, every
+    replica equals start + the sum of EVERY rank's change of EVERY batch -- the hot rows' inner deltas are not added again by the full sync --
+    and, in between, the hot rows of both replicas agree while the others still differ."""
+    world = 2
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_hot_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    rng = np.random.default_rng(0)
+    n_rows, ld = 300, 8
+    want = rng.standard_normal((n_rows, ld)).astype(np.float32).astype(np.float64)
+    for r in range(world):
+        for b in range(3):
+            want += _batch_change(r, b, n_rows, ld)
+    assert np.array_equal(out[0], out[1])
+    np.testing.assert_allclose(out[0], want, rtol=0, atol=2e-6)
+
+
 def test_user_blocks_partition():
     for n in (0, 1, 7, 31668, 10_000_000):
         for w in (1, 2, 3, 8):
