@@ -868,7 +868,8 @@ def test_one_reconciliation_per_epoch_is_not_enough_at_four_ranks():
     one = _paired(dict(dataset="yelp2018-clustered", lr0=0.01, seed=7, mode="item", epochs=40, eval_every=5, world=4, layout="replicated", syncs=1))
     dflt = _paired(dict(dataset="yelp2018-clustered", lr0=0.01, seed=7, mode="item", epochs=40, eval_every=5, world=4, layout="replicated"))
     print("4 ranks, one sync per epoch:", one["peak"]["abs_diff"], "four:", dflt["peak"]["abs_diff"])
-    assert one["peak"]["abs_diff"] > 0.002 > dflt["peak"]["abs_diff"]
+    # measured: 0.0029 / 0.0028 / 0.0029 against 0.0006 (peak), 0.0060 against 0.0018 (worst mark); asserted with room for Hogwild's timing
+    assert dflt["peak"]["abs_diff"] <= 0.002 and one["peak"]["abs_diff"] > dflt["peak"]["abs_diff"] + 0.001
     assert one["worst_mark"]["abs_diff"] > 2 * dflt["worst_mark"]["abs_diff"]
 
 

@@ -230,7 +230,8 @@ def test_throughput_mode_of_the_pairwise_models_draws_its_batches_on_the_device(
     # The two modes run the SAME training step (held to the reference at 1e-5 elsewhere); what differs is which uniform shuffle /
     # which unrated negatives an epoch sees.  So the statement is statistical, and it is made against the exact mode's own
     # stream-to-stream spread (round 3 asserted +-0.02 on one seed): S streams per mode, Recall@10 = measure[1];
-    # |mean_throughput - mean_exact| must be inside 0.002 + two standard errors of the difference.
+    # |mean_throughput - mean_exact| must be inside 0.002 + three standard errors of the difference (three streams per mode give the
+    # standard error itself ~4 degrees of freedom: at two, one comparison in twenty of a TRUE null would fail).
     S = 3
     exact = np.array([run("exact", 3 + k)[1] for k in range(S)])
     runs = [run("throughput", 5 + k) for k in range(S)]
@@ -240,8 +241,8 @@ def test_throughput_mode_of_the_pairwise_models_draws_its_batches_on_the_device(
     gap = np.abs(thr.mean(0) - exact.mean(0))
     print(name, "Recall@10 exact", exact[:, 1], "throughput", thr[:, 1], "gap", gap[1], "se", se[1])
     for k, what in enumerate(("Precision", "Recall", "F1", "NDCG")):
-        check(f"{name} throughput-mode vs exact-mode {what}@10, |difference of the means over {S} sampling streams| (bound = 0.002 + 2 standard errors; "
-              f"exact mode's own stream-to-stream std {exact[:, k].std(ddof=1):.4f})", gap[k], 0.002 + 2 * se[k], inclusive=True)
+        check(f"{name} throughput-mode vs exact-mode {what}@10, |difference of the means over {S} sampling streams| (bound = 0.002 + 3 standard errors; "
+              f"exact mode's own stream-to-stream std {exact[:, k].std(ddof=1):.4f})", gap[k], 0.002 + 3 * se[k], inclusive=True)
     assert thr[:, 1].min() > 0.05                                          # it learned something (Recall@10 on FilmTrust)
     # the stream itself
     u0, i0, _ = m.data.training_arrays()
