@@ -480,8 +480,8 @@ class ReplicatedStep:
             self.sync_q.sync_rows(stream)
         else:
             self.sync_q.sync(stream)
-        if self.sync_p is not None:
-            self.sync_p.sync(stream)
+        # (the user table, when it is replicated too -- the drop-in classes -- is NOT reconciled here: users are sharded over the ranks,
+        # no two ranks touch the same row of P, so its one delta-sum at the epoch close is exact whenever it happens)
 
 
 def hot_item_rows(item_degrees: np.ndarray, n_rows: int) -> np.ndarray:
