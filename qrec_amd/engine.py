@@ -109,6 +109,16 @@ def resolve_schedule(n_triplets: int, item_degrees=None, requested: str = "auto"
     return ("item" if deg.size and deg.max() > 20 * max(deg.mean(), 1e-9) else "user"), None
 
 
+def launch_chunk(n: int, chunk: int, groups: int = 4096, lo: int = 4) -> int:
+    """Chunk length for ONE launch over n triplets of an epoch that is cut into batches (several ranks: reconciliation / exchange batches).
+    A batch of a few ten thousand triplets in chunks of 32 occupies a fraction of the 4,096 persistent groups for one chunk's latency
+    (measured, tools/probe_strong_scaling_bound.py: 19.5 k-triplet batches at 8 ranks, 38 us each however small); shorter chunks spread
+    the same triplets over the idle groups.  Never longer than the epoch's chunk; at least `lo`."""
+    if n >= 2 * groups * chunk:
+        return chunk
+    return int(max(lo, min(chunk, -(-n // groups))))
+
+
 def stride_runs(n: int, run: int) -> np.ndarray:
     """positions 0..n-1 cut into runs of ``run`` consecutive ones, the runs in golden-ratio stride order (run r of the result is
     run (r * stride) mod n_runs of the input, stride ~ 0.618 n_runs made coprime): consecutive runs of the result are far apart in
@@ -457,7 +467,7 @@ class BprSgd:
                     after_start()
 
             dist.exchange.run_epoch(lambda t0, nb, cache, rows, ci, cj, st: self._launch_sgd(
-                t.P, cache, self.d_u.ptr + 4 * t0, ci, cj, nb, chunk, groups, flush_every, regU, regI, variant, st, q_rows=rows), stream,
+                t.P, cache, self.d_u.ptr + 4 * t0, ci, cj, nb, launch_chunk(nb, chunk), groups, flush_every, regU, regI, variant, st, q_rows=rows), stream,
                 next_epoch=(lambda: dist.next_epoch(self)), before_first_sgd=first_grid)
         else:
             if after_start is not None:
@@ -474,7 +484,7 @@ class BprSgd:
                 for b in range(K):
                     t0, nb = self.batch_bounds[b], self.batch_bounds[b + 1] - self.batch_bounds[b]
                     if nb:
-                        self._launch_sgd(t.P, t.Q, self.d_u.ptr + 4 * t0, self.d_i.ptr + 4 * t0, self.d_j.ptr + 4 * t0, nb, chunk, groups,
+                        self._launch_sgd(t.P, t.Q, self.d_u.ptr + 4 * t0, self.d_i.ptr + 4 * t0, self.d_j.ptr + 4 * t0, nb, launch_chunk(nb, chunk), groups,
                                          flush_every, regU, regI, variant, stream)
                     if b + 1 < K:
                         dist.sync_tables(stream)
