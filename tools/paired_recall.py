@@ -158,7 +158,8 @@ def negatives_of(samplers, seed):
 def gpu_run(d, mode, lr0, seed, epochs, marks, world=1, layout="replicated", P0=None, Q0=None, shard_batch=1 << 20, syncs=1, item_run=None, hot_rows=0):
     """world = 1, or G logical ranks in this process.  Returns {recall: {mark: r}, loss: [...], lr: [...], negatives: k -> j}."""
     from qrec_amd import capi
-    from tests.logical_ranks import ThreadComm, run_ranks
+    if world > 1:        # G logical ranks: the in-process test transport (never needed by bench.py's N = 1 legs)
+        from tests.logical_ranks import ThreadComm, run_ranks
     state = {"recall": {}, "P": [None] * world, "Q": [None] * world, "sgd": [None] * world, "log": None}
 
     def rank_main(rank, group):
