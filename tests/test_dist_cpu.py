@@ -90,14 +90,16 @@ def _hot_worker(rank, world, port, out):
     n_rows, ld = 300, 8
     Q0 = rng.standard_normal((n_rows, ld)).astype(np.float32)
     q = HK.DeviceBuffer.from_numpy(Q0)
-    step = qd.ReplicatedStep(comm, ReplicatedTableSync(comm, q, kern=HK), hot_rows=_HOT, ld=ld)
+    step = qd.ReplicatedStep(comm, ReplicatedTableSync(comm, q, kern=HK), hot_rows=_HOT if os.environ.get("QREC_TEST_HOT") == "1" else None, ld=ld)
+    mid = []
     for b in range(3):
         q.a += _batch_change(rank, b, n_rows, ld)
         if b < 2:
             step.sync_tables()
+            mid.append(q.a.copy())
         else:
             step.sync_q.sync()
-    out[rank] = q.a.copy()
+    out[rank] = (q.a.copy(), mid)
     control.shutdown()
 
 
@@ -108,10 +110,13 @@ def _batch_change(rank, b, n_rows, ld):
     return np.random.default_rng(1000 * rank + b).standard_normal((n_rows, ld)).astype(np.float32) * 0.1
 
 
-def test_inner_reconciliation_of_hot_rows_counts_nothing_twice():
-    """round 4 (dist.ReplicatedTableSync.sync_rows): after two inner reconciliations restricted to a row list and the epoch's full one, every
-    replica equals start + the sum of EVERY rank's change of EVERY batch -- the hot rows' inner deltas are not added again by the full sync --
-    and, in between, the hot rows of both replicas agree while the others still differ."""
+@pytest.mark.parametrize("hot", [True, False])
+def test_inner_reconciliations_count_nothing_twice(hot, monkeypatch):
+    """round 4 (engine.epoch_device_async, replicated layout with K = 3 batches): two inner reconciliations -- over the WHOLE table (the
+    default) or restricted to a row list (dist.ReplicatedTableSync.sync_rows) -- and the epoch's full one.  Afterwards every replica equals
+    start + the sum of EVERY rank's change of EVERY batch (no inner delta is added again by the full sync); in between the reconciled rows
+    of both replicas agree, and with the row list the other rows still differ."""
+    monkeypatch.setenv("QREC_TEST_HOT", "1" if hot else "0")
     world = 2
     mgr = mp.Manager(); out = mgr.dict()
     mp.spawn(_hot_worker, args=(world, _free_port(), out), nprocs=world, join=True)
@@ -121,8 +126,14 @@ def test_inner_reconciliation_of_hot_rows_counts_nothing_twice():
     for r in range(world):
         for b in range(3):
             want += _batch_change(r, b, n_rows, ld)
-    assert np.array_equal(out[0], out[1])
-    np.testing.assert_allclose(out[0], want, rtol=0, atol=2e-6)
+    (q0, mid0), (q1, mid1) = out[0], out[1]
+    assert np.array_equal(q0, q1)
+    np.testing.assert_allclose(q0, want, rtol=0, atol=2e-6)
+    rows = _HOT if hot else np.arange(n_rows)
+    others = np.setdiff1d(np.arange(n_rows), rows)
+    for a, b in zip(mid0, mid1):
+        assert np.array_equal(a[rows], b[rows])
+        assert others.size == 0 or not np.array_equal(a[others], b[others])
 
 
 def test_user_blocks_partition():
