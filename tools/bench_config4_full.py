@@ -21,7 +21,11 @@ for a in (P0, Q0):
 out["host_prepare_s"] = time.perf_counter() - t0
 t0 = time.perf_counter()
 t = DeviceTables(P0, Q0, np.float32); del P0, Q0
-s = BprSgd(t, u, i, None, schedule="user")
+from qrec_amd.engine import resolve_schedule
+want = sys.argv[1] if len(sys.argv) > 1 else "user"            # "auto": what engine.resolve_schedule picks at this size (round 4)
+sched, sub = resolve_schedule(n, None, want)
+out["schedule"], out["sub_epochs"] = sched, sub
+s = BprSgd(t, u, i, None, schedule=sched, sub_epochs=sub)
 s.set_negatives(j)
 capi.device_sync(); out["upload_s"] = time.perf_counter() - t0
 e0, e1 = capi.Event(), capi.Event(); ts, losses = [], []
