@@ -479,11 +479,16 @@ class BprSgd:
                 # data with structure (tools/paired_recall.py, profiles/r04_paired_recall.json) the summed stale deltas overshoot
                 # and training diverges at five times BPR.conf's rate.  Batch b = the b-th range of the stored order (item-major:
                 # chunks dealt round-robin, so every batch sees every hot item); the last batch's sync is the fused epoch close.
-                if self.deferred:
-                    raise RuntimeError("the deferred schedule runs the epoch as one unit: it cannot be cut into replicated sync batches")
+                # (the deferred schedule, round 4: every batch is ONE unit of it -- pass A over the batch, the batch's negatives sorted by j on
+                # this stream, pass B -- so the negative item's row lags by a batch, 1 / K of an epoch: finer than the four sub-epochs of the
+                # single-GPU form.  The sort is not prefetched here: ~5 % of a 3 M-triplet batch.)
                 for b in range(K):
                     t0, nb = self.batch_bounds[b], self.batch_bounds[b + 1] - self.batch_bounds[b]
-                    if nb:
+                    if nb and self.deferred:
+                        capi.bpr_sgd_hogwild_item_major_deferred(t.P, t.Q, t.d, t.ld, self.d_u.ptr + 4 * t0, self.d_i.ptr + 4 * t0, self.d_j.ptr + 4 * t0, nb,
+                                                                 launch_chunk(nb, chunk, groups=16384), groups, flush_every, 0.0, regU, regI, self.d_stats,
+                                                                 self.d_work, stream, self.d_drv, p_rows=t.n_users, is_sorted=False)
+                    elif nb:
                         self._launch_sgd(t.P, t.Q, self.d_u.ptr + 4 * t0, self.d_i.ptr + 4 * t0, self.d_j.ptr + 4 * t0, nb, launch_chunk(nb, chunk), groups,
                                          flush_every, regU, regI, variant, stream)
                     if b + 1 < K:

@@ -85,10 +85,13 @@ class BPR(IterativeRecommender):
         syncs = reconciliations_per_epoch(dp.world, int(os.environ.get("QREC_REPLICATED_SYNCS", "0"))) if dp is not None else 1
         if syncs > 1 and schedule == "item-deferred":
             if self.schedule == "auto":
-                schedule, sub_epochs = "item", None      # the deferred schedule runs the epoch as one unit: it cannot be cut into sync batches
+                # several ranks: `auto` stays with the one-pass kernel.  The deferred schedule CAN run inside the reconciliation batches (every
+                # batch one unit of it: QREC_SCHEDULE=item-deferred; 22.4 against 26.7 ms per epoch on one rank's share of config #4, links
+                # excluded, profiles/r04_config4_rank_share.jsonl), but its paired Recall runs at N > 1 are not better than the one-pass
+                # kernel's (0.0006 / 0.0028 at 4 ranks, 0.0022 on the 6 M-triplet graph at 2) and the evidence is three runs
+                schedule, sub_epochs = "item", None
             else:
-                print("QREC_SCHEDULE=item-deferred on several ranks needs QREC_REPLICATED_SYNCS=1 (the epoch as one unit)")
-                raise SystemExit(-1)
+                sub_epochs = 1      # every reconciliation batch is one unit of the deferred schedule (engine.epoch_device_async): no sub-epochs inside
         sgd = BprSgd(tables, u, i, pos, schedule=schedule, sub_epochs=sub_epochs, batches=syncs)
         epoch = 0
         if self.mode == "throughput" and (self.ranking.isMainOn() or dp is not None):
