@@ -713,6 +713,49 @@ def test_deferred_single_group_is_the_sequential_statement_of_its_order(dim, chu
     assert np.array_equal(_deferred_perm(sgd.d_work, n), np.argsort(js, kind="stable"))
 
 
+class _NoLinks:
+    """capi.Comm's interface for a world in which this rank is alone with its data: every collective is the identity"""
+    def __init__(self, world): self.world, self.rank = world, 0
+    def allreduce(self, *a, **k): pass
+    def allreduce_pair(self, *a, **k): pass
+
+
+@pytest.mark.parametrize("schedule", ["item", "item-deferred"])
+def test_epoch_cut_into_reconciliation_batches_is_the_sequence_of_its_batches(schedule):
+    """round 4 (engine.epoch_device_async, replicated layout, K batches per epoch): with ONE group and a communicator that moves nothing the
+    epoch is exactly K launches over the K ranges of the stored order, each in the launch's own visiting order -- for the deferred schedule
+    each batch one unit of it (pass A, the batch's negatives sorted by j, pass B) -- followed by the device-side epoch close."""
+    from qrec_amd.dist import ReplicatedStep, ReplicatedTableSync
+    from qrec_amd.engine import launch_chunk
+    d, indptr, ind, u, j = _synthetic("small")
+    U, I, n, dim, K, chunk = d["n_users"], d["n_items"], ind.size, 16, 3, 32
+    rng = np.random.default_rng(2)
+    P0 = rng.random((U, dim)) / 3; Q0 = rng.random((I, dim)) / 3
+    t = DeviceTables(P0, Q0, np.float32)
+    sgd = BprSgd(t, u, ind, schedule=schedule, batches=K, chunk=chunk, sub_epochs=1); sgd.set_negatives(j)
+    step = ReplicatedStep(_NoLinks(4), ReplicatedTableSync(_NoLinks(4), t.Q))
+    sgd.start_device_driver(0.05, log_capacity=4)
+    sgd.epoch_device_async(0.01, 0.02, 1.0, tol=0.0, chunk=chunk, groups=1, flush_every=8, dist=step)
+    capi.device_sync()
+    us, is_, js = sgd.d_u.numpy(), sgd.d_i.numpy(), sgd.d_j.numpy()
+    assert len(sgd.batch_bounds) == K + 1 and sgd.batch_bounds[-1] == n
+    Pr, Qr, lref = P0.copy(), Q0.copy(), 0.0
+    for b in range(K):
+        t0, t1 = sgd.batch_bounds[b], sgd.batch_bounds[b + 1]
+        c = launch_chunk(t1 - t0, chunk, groups=16384 if schedule == "item-deferred" else 4096)
+        order = t0 + _item_major_visit_order(t1 - t0, c)
+        ua, ia, ja = (np.ascontiguousarray(x[order]) for x in (us, is_, js))
+        if schedule == "item":
+            lref += O.bpr_sgd(Pr, Qr, ua, ia, ja, 0.05, 0.01, 0.02)
+        else:
+            lref += O.bpr_sgd_deferred(Pr, Qr, ua, ia, ja, np.lexsort((order, ja)).astype(np.int64), 0.05, 0.01, 0.02)
+    Pg, Qg = t.download()
+    check(f"{schedule}, epoch in {K} reconciliation batches, one group: P vs the sequence of its batches", rel_err(Pg, Pr), F32_TOL)
+    check(f"{schedule}, epoch in {K} reconciliation batches, one group: Q vs the sequence of its batches", rel_err(Qg, Qr), F32_TOL)
+    want = lref + 0.01 * O.sumsq(Pr) + 0.02 * O.sumsq(Qr)
+    check(f"{schedule}, epoch in {K} reconciliation batches: the epoch loss the device-side driver logged", abs(float(sgd.driver_log()[0, 0]) - want) / want, F32_TOL)
+
+
 def test_deferred_full_grid_properties_yelp_shape():
     d, indptr, ind, u, j = _synthetic("yelp2018", seed=1)
     U, I, n, dim = d["n_users"], d["n_items"], ind.size, 64
