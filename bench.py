@@ -448,6 +448,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip exact_mode / roofline_hbm_resident / recall_at_20 / other_configs / the weak-scaling leg")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--chunk", type=int, default=0, help="triplets per work item of the SGD kernel (0 = engine.balanced_chunk: the length in 26..40 that spreads the "
+                                                         "epoch's chunks most evenly over the persistent groups)")
     ap.add_argument("--flush-every", type=int, default=0, help="item-major schedule: triplets between flushes of the register-resident Q[i] (0 = default)")
     ap.add_argument("--schedule", choices=("item", "user", "item-deferred"), default=os.environ.get("QREC_BENCH_SCHEDULE", "item"),
                     help="visiting order of the epoch's triplets in the Hogwild kernel (DESIGN.md s4)")
@@ -564,7 +566,7 @@ def main():
         n = int(l_items.size)
         Q0_local = qd.shard_item_rows(Q0, world, rank) if sharded else Q0
         tables = DeviceTables(P0, Q0_local, np.float32)
-        CHUNK = balanced_chunk(n)     # triplets per work item: the count that spreads evenly over the 4,096 persistent groups
+        CHUNK = args.chunk or balanced_chunk(n)     # triplets per work item: the count that spreads evenly over the 4,096 persistent groups
         syncs = qd.reconciliations_per_epoch(world, args.sync_per_epoch) if use_dist else 1
         if sharded:
             n_batches = qd.agree_on_batches(control, n, args.shard_batch, split_from=1 << 19, min_batches=syncs)
