@@ -471,6 +471,23 @@ def test_two_rank_bench_path_on_one_device(tmp_path):
     assert r0["log"][-1, 0] < r0["log"][0, 0]                                 # the summed loss goes down (not every step: the bold driver may halve first)
 
 
+def test_two_rank_bench_path_with_hot_row_reconciliations(tmp_path):
+    """--sync-per-epoch 3 --hot-rows 512 (round 4): two inner reconciliations per epoch over the 512 item rows with the most positives, the
+    whole table at the epoch close.  The replicas must still be IDENTICAL after every epoch (the hot rows' inner sums are not counted again),
+    both drivers log the same losses, and the line states the inner payload."""
+    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs-per-step", "3", "--no-cpu-baseline", "--no-extras", "--shape", "ml1m",
+                  "--sync-per-epoch", "3", "--hot-rows", "512"],
+                 {"QREC_DIST_TEST_ONE_DEVICE": "1", "QREC_DIST_TEST_DUMP": str(tmp_path)}, nproc=2, port=29561)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    c = out["multi_gpu"]["collectives_per_epoch"]
+    assert c["all_reduce"] == 3 and c["hot_rows"] == 512 and c["inner_payload_bytes_per_rank"] == 512 * 64 * 4 < c["payload_bytes_per_rank"]
+    assert c["ring_wire_bytes_per_rank"] == pytest.approx(2.0 * 1 / 2 * (c["payload_bytes_per_rank"] + 2 * c["inner_payload_bytes_per_rank"]))
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["Q"], r1["Q"]) and not np.array_equal(r0["P"], r1["P"])
+    np.testing.assert_array_equal(r0["log"][:, :2], r1["log"][:, :2])
+    assert np.isfinite(r0["Q"]).all() and r0["log"][-1, 0] < r0["log"][0, 0] * 1.01
+
+
 def test_bench_typed_with_gpus_2_starts_its_own_ranks(tmp_path):
     """`python3 bench.py --gpus 2 ...` exactly as the driver types it for N = 1 -- no launcher, no WORLD_SIZE: bench.py re-executes
     itself under torch.distributed.run with two ranks and rank 0's ONE JSON line is what the caller reads on stdout.  (One-device
