@@ -941,3 +941,42 @@ def test_auto_schedule_rule_and_reconciliations():
     assert resolve_schedule(DEFER_MIN_TRIPLETS - 1, None) == ("item", None)
     assert resolve_schedule(10 ** 9, None, "user") == ("user", None)              # an explicit choice is never overridden
     assert [reconciliations_per_epoch(g) for g in (1, 2, 4, 8)] == [1, 2, 4, 8] and reconciliations_per_epoch(8, 1) == 1 and reconciliations_per_epoch(2, 5) == 5
+
+
+def test_paired_recall_harness_host_logic():
+    """tools/paired_recall.py without a device: the comparison record (peak chosen on the REFERENCE's curve, absolute / relative gaps,
+    the worst mark, bold-driver agreement), the kernel's visiting order as a sequence, the batch rule, the full plan's coverage."""
+    from types import SimpleNamespace
+    from tools import paired_recall as PR
+    g = {"recall": {5: 0.020, 10: 0.100, 15: 0.1130, 20: 0.1040}, "loss": [float(100 - k) for k in range(20)], "lr": [0.05 * 1.05 ** k for k in range(20)]}
+    r = {"recall": {5: 0.021, 10: 0.104, 15: 0.1135, 20: 0.1050}, "loss": [float(100 - k) * 1.001 for k in range(20)], "lr": [0.05 * 1.05 ** k for k in range(20)]}
+    c = PR.compare({"dataset": "x"}, g, r)
+    assert c["peak"]["epoch"] == 15 and c["peak"]["abs_diff"] == pytest.approx(0.0005) and c["peak"]["rel_diff"] == pytest.approx(0.0005 / 0.1135)
+    assert c["final"]["epoch"] == 20 and c["final"]["abs_diff"] == pytest.approx(0.001) and c["worst_mark"]["epoch"] == 10
+    assert c["within_bar_at_peak"] and not c["within_bar_at_every_mark"] and c["same_bold_driver_decisions"] and c["bar"] == 0.002
+    assert c["final"]["loss_rel_gap"] == pytest.approx(0.001 / 1.001, rel=1e-6)
+    g2 = dict(g, lr=[x * (0.5 if k == 7 else 1.0) for k, x in enumerate(g["lr"])])
+    assert not PR.compare({}, g2, r)["same_bold_driver_decisions"]
+    # the one-pass item-major kernel's time order: every stored position once, chunk by chunk in the launcher's stride order
+    n, chunk = 1000, 32
+    sgd = SimpleNamespace(n=n, perm=np.random.default_rng(0).permutation(n))
+    order = PR.item_major_visit_order(sgd, chunk)
+    assert np.array_equal(np.sort(order), np.arange(n))
+    from math import gcd
+    n_chunks = -(-n // chunk); stride = max(1, int(n_chunks * 0.6180339887498949))
+    while gcd(stride, n_chunks) != 1:
+        stride += 1
+    want = np.concatenate([np.arange(c * chunk, min((c + 1) * chunk, n)) for c in ((s_ * stride) % n_chunks for s_ in range(n_chunks))])
+    assert np.array_equal(order, sgd.perm[want])                  # time slot s runs chunk (s * stride) mod n_chunks of the stored list
+    # batches: replicated = the reconciliations asked for; sharded = at least that many, no batch above the cap, two from 2^19 triplets on
+    d = {"n_users": 10, "indptr": np.arange(0, 11 * 100_000, 100_000, dtype=np.int64), "items": np.zeros(1_000_000, np.int32), "u": np.zeros(1_000_000, np.int32)}
+    assert PR.n_batches_for(d, 1, "replicated", 1 << 20, 4) == 1 and PR.n_batches_for(d, 2, "replicated", 1 << 20, 2) == 2
+    assert PR.n_batches_for(d, 2, "sharded", 1 << 20, 1) == 1 and PR.n_batches_for(d, 2, "sharded", 1 << 18, 1) == 2 and PR.n_batches_for(d, 2, "sharded", 1 << 20, 4) == 4
+    assert PR.n_batches_for({**d, "indptr": d["indptr"] * 2, "items": np.zeros(2_000_000, np.int32)}, 2, "sharded", 1 << 20, 1) == 2      # 1 M per rank >= 2^19
+    plan = PR.plan_full()
+    keys = {(c["dataset"], c["lr0"], c["mode"], c.get("world", 1), c.get("layout", "")) for c in plan}
+    for ds in ("yelp2018-clustered", "lastfm"):
+        for lr0 in (0.01, 0.05):
+            assert {(ds, lr0, m, 1, "") for m in ("item", "user", "item-deferred", "item-deferred:4")} <= keys
+            assert {(ds, lr0, "item", w, l) for w in (2, 4) for l in ("replicated", "sharded")} <= keys
+    assert PR.parse_mode("item-deferred:4:19") == ("item-deferred", 4, 19) and PR.parse_mode("item") == ("item", None, None)
