@@ -24,9 +24,12 @@ one of the ranks.  The layout can be steered by flag or, for a caller whose comm
 
 N > 1, one process per GPU (qrec_amd/dist.py; collectives are RCCL bound directly by libqrec_hip.so, torch.distributed
 /gloo is only the control plane).  Users (rows of P, triplets, sampler) are sharded by rank.  --dist-mode replicated
-(default): item table replicated, ONE fused all-reduce of the per-rank deltas + loss terms per epoch.  --dist-mode
+(default): item table replicated, a delta all-reduce per reconciliation, the epoch's last one fused with the loss terms.  --dist-mode
 sharded: item table row-sharded, per batch an all-to-all of the distinct rows a rank's triplets touch and of their
-updates.  --scaling weak (default): every rank its own 31,668 users; strong: the same 31,668 users split over ranks.
+updates.  --scaling strong (default since round 4: BASELINE.json quotes the metric on THE Yelp2018 shape at 1/2/4/8 GPUs): the same
+31,668 users split over the ranks = `value`; the weak-scaling figure (every rank its own 31,668 users) is timed next to it and
+reported as `weak_scaling` under its aggregate shape; --scaling weak makes that leg `value`.  --sync-per-epoch (default: one per rank)
+/ --hot-rows: how often, and over which rows, the ranks' item rows are reconciled inside an epoch.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     -- the SGD kernel's algorithmic bytes/launch over its mean launch time (HIP events on the launch
@@ -37,7 +40,10 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   cpu_baseline -- the CPU port of the same epoch (oracle/, plain C, fp64, 1 thread) timed on this box's host cores
                   on a bounded sample; reference_loop_here: the reference's own interpreter-bound form (oracle/npref.py)
                   timed on this host; reference_python: the unmodified reference's figure (another host, BASELINE.md);
-  recall_at_20 -- a fresh 25-epoch run of the timed mode against order-exact fp64 training on the same negatives;
+  recall_at_20 -- the paired harness (tools/paired_recall.py): fresh runs of the timed mode against order-exact fp64 training on the same
+                  negatives, on the bench's own graph and on the planted-community graph of the same shape (datasets[]: recall, abs_diff,
+                  rel_diff at the reference's peak epoch and at the last one); N > 1: the same over the real communicator;
+  other_configs -- BASELINE configs #2, #3, #5 and the evaluation, measured by this very run (HIP events, >= 20 repetitions);
   deferred_negatives -- the opt-in schedule `--schedule item-deferred` (one atomic row update per triplet) timed like the
                   main line, with its own Recall check (DESIGN.md s4 says why it is not the default);
   multi_gpu    -- N > 1: what RCCL reports per rank, kernel time per rank, collectives and bytes per epoch.
