@@ -409,7 +409,7 @@ def multi_gpu_recall(capi, qd, control, comm, world, rank, layout, mode, dataset
     from tools import paired_recall as PR
     d = PR.load_dataset(dataset)
     P0, Q0 = PR.initial_tables(d, 3)
-    t, sgd, chunk, lo, hi = PR.build_rank(d, mode, world, rank, layout, P0, Q0, shard_batch, syncs)
+    t, sgd, chunk, lo, hi, groups = PR.build_rank(d, mode, world, rank, layout, P0, Q0, shard_batch, syncs)
     marks = set(range(every, epochs + 1, every)) | {epochs}
     rows_p, rows_q = -(-d["n_users"] // world), -(-d["n_items"] // world)
     pad = lambda a, r: np.concatenate([a, np.zeros((r - a.shape[0], a.shape[1]), a.dtype)]) if a.shape[0] < r else a
@@ -423,7 +423,7 @@ def multi_gpu_recall(capi, qd, control, comm, world, rank, layout, mode, dataset
             Qp = [allQ[r] for r in range(world)] if allQ is not None else [Qr]
             rec[epoch] = PR.recall20(*PR.assemble(Pp, Qp, world, layout, d["n_items"]), d)
 
-    log = PR.train_rank(d, sgd, t, chunk, lr0, SEED, epochs, marks, world, rank, comm, layout, on_mark, capi.Stream())
+    log = PR.train_rank(d, sgd, t, chunk, lr0, SEED, epochs, marks, world, rank, comm, layout, on_mark, capi.Stream(), groups=groups)
     control.barrier()
     out = None
     if rank == 0:

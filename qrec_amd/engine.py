@@ -109,6 +109,26 @@ def resolve_schedule(n_triplets: int, item_degrees=None, requested: str = "auto"
     return ("item" if deg.size and deg.max() > 20 * max(deg.mean(), 1e-9) else "user"), None
 
 
+MIN_ROUNDS = 8
+
+
+def grid_for_epoch(n: int, chunk: int, min_rounds: int = MIN_ROUNDS, groups: int = 4096, min_chunk: int = 8):
+    """(chunk, groups) of ONE launch over a whole epoch of n triplets such that every persistent group walks at least ``min_rounds``
+    chunks one after the other, whatever the epoch's size (round 5).  The kernels' launchers clamp the groups to the number of chunks:
+    an epoch with fewer chunks than groups (the reference's lastfm split: 74 k triplets = 2.3 k chunks of 32) is in flight ALL AT ONCE --
+    one round of the grid, where the Yelp2018 shape's 1.25 M triplets make ~9.5.  Shorter chunks first (down to ``min_chunk``), then
+    fewer groups.  ``groups`` 0 in the result = the launcher's default (nothing to cap).  ``min_rounds`` <= 1: unchanged."""
+    if min_rounds <= 1 or n <= 0:
+        return chunk, 0
+    c = chunk
+    while c > min_chunk and -(-n // c) < min_rounds * groups:
+        c = max(min_chunk, c // 2)
+    n_chunks = -(-n // c)
+    if n_chunks >= min_rounds * groups:
+        return c, 0
+    return c, int(max(1, n_chunks // min_rounds))
+
+
 def launch_chunk(n: int, chunk: int, groups: int = 4096, lo: int = 4) -> int:
     """Chunk length for ONE launch over n triplets of an epoch that is cut into batches (several ranks: reconciliation / exchange batches).
     A batch of a few ten thousand triplets in chunks of 32 occupies a fraction of the 4,096 persistent groups for one chunk's latency
@@ -185,6 +205,10 @@ class BprSgd:
         self.n_items = int(n_items) if n_items is not None else tables.n_items
         self.n = int(u.size)
         self.schedule = schedule
+        self.chunk = int(chunk)             # the chunk the stored order is dealt to the batches in = the chunk to launch epochs with
+        # groups a reconciliation batch (replicated layout, K > 1) spreads over: a batch of a few ten thousand triplets is bound by the
+        # per-group chain of dependent row reads (~1.9 us per triplet), not by the atomic units -- more groups, shorter chains
+        self.batch_groups = 4096
         self.perm = None
         u = np.ascontiguousarray(u, dtype=np.int32); i = np.ascontiguousarray(i, dtype=np.int32)
         batches = max(1, int(batches))
@@ -489,8 +513,9 @@ class BprSgd:
                                                                  launch_chunk(nb, chunk, groups=16384), groups, flush_every, 0.0, regU, regI, self.d_stats,
                                                                  self.d_work, stream, self.d_drv, p_rows=t.n_users, is_sorted=False)
                     elif nb:
-                        self._launch_sgd(t.P, t.Q, self.d_u.ptr + 4 * t0, self.d_i.ptr + 4 * t0, self.d_j.ptr + 4 * t0, nb, launch_chunk(nb, chunk), groups,
-                                         flush_every, regU, regI, variant, stream)
+                        bg = self.batch_groups
+                        self._launch_sgd(t.P, t.Q, self.d_u.ptr + 4 * t0, self.d_i.ptr + 4 * t0, self.d_j.ptr + 4 * t0, nb, launch_chunk(nb, chunk, groups=bg),
+                                         groups if groups else (bg if bg != 4096 else 0), flush_every, regU, regI, variant, stream)
                     if b + 1 < K:
                         dist.sync_tables(stream)
             else:

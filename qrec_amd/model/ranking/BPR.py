@@ -92,7 +92,10 @@ class BPR(IterativeRecommender):
                 schedule, sub_epochs = "item", None
             else:
                 sub_epochs = 1      # every reconciliation batch is one unit of the deferred schedule (engine.epoch_device_async): no sub-epochs inside
-        sgd = BprSgd(tables, u, i, pos, schedule=schedule, sub_epochs=sub_epochs, batches=syncs)
+        # the chunk the epoch is LAUNCHED with is the chunk the item-major list is dealt to the reconciliation batches in (the
+        # constructor's default 32 against balanced_chunk's 26..40 at launch left launch chunks straddling the dealt ones)
+        from ...engine import balanced_chunk
+        sgd = BprSgd(tables, u, i, pos, schedule=schedule, sub_epochs=sub_epochs, batches=syncs, chunk=balanced_chunk(int(u.size)))
         epoch = 0
         if self.mode == "throughput" and (self.ranking.isMainOn() or dp is not None):
             self._train_throughput_pipelined(sgd, dp=dp)
@@ -201,8 +204,7 @@ class BPR(IterativeRecommender):
         SGD kernel the replicas are reconciled by summing the ranks' deltas (users' rows: disjoint, exact; item rows:
         every rank's updates kept -- qrec_amd/dist.py), sum(-log sigma) is added over the ranks, and every rank's
         device-side driver then takes the same decision on identical tables."""
-        from ...engine import balanced_chunk
-        chunk = balanced_chunk(sgd.n)
+        chunk = sgd.chunk          # the chunk the stored order was dealt in (BprSgd.__init__)
         sharded = step is not None
         if dp is not None and step is None:
             from ...dist import ReplicatedStep, ReplicatedTableSync

@@ -20,7 +20,7 @@ N > 1: G logical ranks in this process (threads + tests/logical_ranks.ThreadComm
 "replicated" (users sharded, item table replicated, per-epoch delta all-reduce) and "sharded" (item table row-sharded, per-batch
 row exchange) -- bench.py's layouts.
 
-usage: paired_recall.py <out.json> [plan]      plan = "full" (default) | "quick" | JSON list of cases
+usage: paired_recall.py <out.json> [plan]      plan = "full" (default) | "quick" | "bpr-conf" | JSON list of cases (or a file holding one)
 """
 from __future__ import annotations
 
@@ -56,14 +56,14 @@ def load_dataset(name: str) -> dict:
     return d
 
 
-def initial_tables(d: dict, seed: int = 3):
+def initial_tables(d: dict, seed: int = 3, dim: int = DIM):
     rng = np.random.default_rng(seed)                      # rand/3, base/iterativeRecommender.py:37-38
-    return (rng.random((d["n_users"], DIM)) / 3).astype(np.float32), (rng.random((d["n_items"], DIM)) / 3).astype(np.float32)
+    return (rng.random((d["n_users"], dim)) / 3).astype(np.float32), (rng.random((d["n_items"], dim)) / 3).astype(np.float32)
 
 
-def recall20(P, Q, d) -> float:
+def recall20(P, Q, d, N: int = 20) -> float:
     import bench as B
-    return B.evaluate_recall(P, Q, d, d["indptr"], d["items"])
+    return B.evaluate_recall(P, Q, d, d["indptr"], d["items"], N=N)
 
 
 def parse_mode(mode: str):
@@ -91,22 +91,27 @@ def n_batches_for(d, world, layout, shard_batch, syncs):
     return max(1, int(syncs))
 
 
-def build_rank(d, mode, world, rank, layout, P0, Q0, shard_batch=1 << 20, syncs=1, item_run=None):
-    """(tables, sgd, chunk, lo, hi) of one rank: its users' rows of P, the item table whole (replicated) or its row shard"""
+def build_rank(d, mode, world, rank, layout, P0, Q0, shard_batch=1 << 20, syncs=1, item_run=None, rounds=None):
+    """(tables, sgd, chunk, lo, hi, groups) of one rank: its users' rows of P, the item table whole (replicated) or its row shard.
+    ``rounds``: engine.grid_for_epoch's min_rounds (None = the engine's default, 0 / 1 = the launcher's own grid, rounds 1-4)"""
     from qrec_amd import dist as qd
-    from qrec_amd.engine import BprSgd, DeviceTables, balanced_chunk
+    from qrec_amd.engine import MIN_ROUNDS, BprSgd, DeviceTables, balanced_chunk, grid_for_epoch
     from qrec_amd.interactions import CSR
     schedule, S, sub_chunk = parse_mode(mode)
     lo, hi, lp, li, lu = _rank_problem(d, world, rank)
     sharded = world > 1 and layout == "sharded"
     t = DeviceTables(P0[lo:hi], qd.shard_item_rows(Q0, world, rank) if sharded else Q0, np.float32)
     chunk = balanced_chunk(int(li.size))
-    sgd = BprSgd(t, lu, li, CSR(lp, li), schedule=schedule, n_items=d["n_items"], batches=n_batches_for(d, world, layout, shard_batch, syncs),
+    batches = n_batches_for(d, world, layout, shard_batch, syncs)
+    groups = 0
+    if batches == 1 and schedule != "item-deferred":        # (an epoch in batches: engine.launch_chunk per batch, unchanged)
+        chunk, groups = grid_for_epoch(int(li.size), chunk, MIN_ROUNDS if rounds is None else rounds)
+    sgd = BprSgd(t, lu, li, CSR(lp, li), schedule=schedule, n_items=d["n_items"], batches=batches,
                  chunk=chunk, sub_epochs=S, sub_chunk=sub_chunk, item_run=item_run)
-    return t, sgd, chunk, lo, hi
+    return t, sgd, chunk, lo, hi, groups
 
 
-def train_rank(d, sgd, t, chunk, lr0, seed, epochs, marks, world, rank, comm, layout, on_mark, stream=None, hot_rows=0):
+def train_rank(d, sgd, t, chunk, lr0, seed, epochs, marks, world, rank, comm, layout, on_mark, stream=None, hot_rows=0, groups=0):
     """``epochs`` epochs of one rank in throughput mode as bench.py's epoch runs them: device sampler, SGD kernel(s), the layout's
     collectives, device-side epoch close with the bold driver.  ``on_mark(epoch, P_local, Q_local)`` at the epochs in ``marks``
     (every rank calls it).  Returns the device driver's log."""
@@ -124,7 +129,7 @@ def train_rank(d, sgd, t, chunk, lr0, seed, epochs, marks, world, rank, comm, la
         sgd.sample_negatives_device(seed + 7919 * rank, k, stream)
         if sharded:
             dstep.prepare(sgd, stream)
-        sgd.epoch_device_async(REG, REG, MAX_LR, tol=0.0, chunk=chunk, flush_every=FLUSH, stream=stream, dist=dstep)
+        sgd.epoch_device_async(REG, REG, MAX_LR, tol=0.0, chunk=chunk, flush_every=FLUSH, stream=stream, dist=dstep, groups=groups)
         if k + 1 in marks:
             capi.device_sync()
             Pr, Qr = t.download(np.float32)
@@ -155,7 +160,8 @@ def negatives_of(samplers, seed):
     return negatives
 
 
-def gpu_run(d, mode, lr0, seed, epochs, marks, world=1, layout="replicated", P0=None, Q0=None, shard_batch=1 << 20, syncs=1, item_run=None, hot_rows=0):
+def gpu_run(d, mode, lr0, seed, epochs, marks, world=1, layout="replicated", P0=None, Q0=None, shard_batch=1 << 20, syncs=1, item_run=None, hot_rows=0,
+            rounds=None, extra_topn=()):
     """world = 1, or G logical ranks in this process.  Returns {recall: {mark: r}, loss: [...], lr: [...], negatives: k -> j}."""
     from qrec_amd import capi
     if world > 1:        # G logical ranks: the in-process test transport (never needed by bench.py's N = 1 legs)
@@ -163,20 +169,24 @@ def gpu_run(d, mode, lr0, seed, epochs, marks, world=1, layout="replicated", P0=
     state = {"recall": {}, "P": [None] * world, "Q": [None] * world, "sgd": [None] * world, "log": None}
 
     def rank_main(rank, group):
-        t, sgd, chunk, lo, hi = build_rank(d, mode, world, rank, layout, P0, Q0, shard_batch, syncs, item_run)
+        t, sgd, chunk, lo, hi, groups = build_rank(d, mode, world, rank, layout, P0, Q0, shard_batch, syncs, item_run, rounds)
         state["sgd"][rank] = sgd
+        state["grid"] = (chunk, groups)
 
         def on_mark(epoch, Pr, Qr):
             state["P"][rank], state["Q"][rank] = Pr, Qr
             if world > 1:
                 group.barrier.wait()
             if rank == 0:
-                state["recall"][epoch] = recall20(*assemble(state["P"], state["Q"], world, layout, d["n_items"]), d)
+                PQ = assemble(state["P"], state["Q"], world, layout, d["n_items"])
+                state["recall"][epoch] = recall20(*PQ, d)
+                if epoch == epochs:
+                    state["final_topn"] = {int(N): recall20(*PQ, d, N=int(N)) for N in extra_topn}
             if world > 1:
                 group.barrier.wait()
 
         log = train_rank(d, sgd, t, chunk, lr0, seed, epochs, marks, world, rank, ThreadComm(group, rank) if world > 1 else None, layout,
-                         on_mark, capi.Stream() if world > 1 else None, hot_rows=hot_rows)
+                         on_mark, capi.Stream() if world > 1 else None, hot_rows=hot_rows, groups=groups)
         if rank == 0:
             state["log"] = log
 
@@ -186,12 +196,13 @@ def gpu_run(d, mode, lr0, seed, epochs, marks, world=1, layout="replicated", P0=
     else:
         run_ranks(world, rank_main)
     log = state["log"]
-    return {"recall": state["recall"], "loss": [float(x) for x in log[:, 0]], "lr": [float(x) for x in log[:, 1]],
+    return {"recall": state["recall"], "loss": [float(x) for x in log[:, 0]], "lr": [float(x) for x in log[:, 1]], "grid": state.get("grid"),
+            "final_topn": state.get("final_topn", {}),
             "negatives": negatives_of(state["sgd"], seed), "samplers": state["sgd"],
             "perm_key": (parse_mode(mode)[0].split("-")[0], world, layout if world > 1 else "", len(state["sgd"][0].batch_bounds), state["sgd"][0].item_run)}
 
 
-def reference_run(d, negatives, lr0, epochs, marks, P0, Q0, order=None):
+def reference_run(d, negatives, lr0, epochs, marks, P0, Q0, order=None, extra_topn=()):
     """order-exact fp64 training (oracle C restatement of BPR.py:45-53,40) on the same negatives, bold driver of
     iterativeRecommender.py:56-63 (isConverged's threshold is not applied: every epoch runs, as on the GPU side with tol = 0).
     ``order``: visit the same triplets sequentially in ANOTHER order (indices into the reference's order) -- not the reference any
@@ -211,7 +222,7 @@ def reference_run(d, negatives, lr0, epochs, marks, P0, Q0, order=None):
         lr = min(lr, MAX_LR); last = loss
         if k + 1 in marks:
             rec[k + 1] = recall20(P, Q, d)
-    return {"recall": rec, "loss": losses, "lr": lrs}
+    return {"recall": rec, "loss": losses, "lr": lrs, "final_topn": {int(N): recall20(P, Q, d, N=int(N)) for N in extra_topn}}
 
 
 def item_major_visit_order(sgd, chunk: int) -> np.ndarray:
@@ -237,10 +248,14 @@ def compare(case: dict, g: dict, r: dict) -> dict:
     def at(m):
         a, b = g["recall"][m], r["recall"][m]
         return {"epoch": m, "recall_gpu": a, "recall_exact_order": b, "abs_diff": abs(a - b), "rel_diff": abs(a - b) / max(b, 1e-12),
+                "signed_diff": a - b,
                 "loss_gpu": g["loss"][m - 1], "loss_exact_order": r["loss"][m - 1], "loss_rel_gap": abs(g["loss"][m - 1] - r["loss"][m - 1]) / abs(r["loss"][m - 1])}
     worst = max(marks, key=lambda m: abs(g["recall"][m] - r["recall"][m]))
     same_lr = bool(np.allclose(g["lr"], r["lr"], rtol=1e-9))
-    return {**case, "peak": at(peak), "final": at(final), "worst_mark": at(worst), "bar": BAR,
+    topn = {str(N): {"recall_gpu": g["final_topn"][N], "recall_exact_order": r["final_topn"][N], "signed_diff": g["final_topn"][N] - r["final_topn"][N]}
+            for N in g.get("final_topn", {}) if N in r.get("final_topn", {})}
+    return {**case, "peak": at(peak), "final": at(final), "worst_mark": at(worst), "bar": BAR, "grid_chunk_groups": g.get("grid"),
+            **({"final_other_topn": topn} if topn else {}),
             "within_bar_at_peak": abs(g["recall"][peak] - r["recall"][peak]) <= BAR,
             "within_bar_at_every_mark": abs(g["recall"][worst] - r["recall"][worst]) <= BAR,
             "same_bold_driver_decisions": same_lr,
@@ -255,17 +270,28 @@ def run_case(case: dict, cache: dict, datasets: dict) -> dict:
     if name not in datasets:
         datasets[name] = load_dataset(name)
     d = datasets[name]
-    P0, Q0 = initial_tables(d, 3)
+    P0, Q0 = initial_tables(d, case.get("init_seed", 3), case.get("dim", DIM))
+    topn = tuple(case.get("extra_topn", ()))
     t0 = time.perf_counter()
     from qrec_amd.dist import reconciliations_per_epoch
     g = gpu_run(d, mode, lr0, seed, epochs, marks, world, layout, P0, Q0, shard_batch=case.get("shard_batch", 1 << 20),
                 syncs=reconciliations_per_epoch(world, case.get("syncs", 0)),
-                item_run=case.get("item_run"), hot_rows=case.get("hot_rows", 0))
+                item_run=case.get("item_run"), hot_rows=case.get("hot_rows", 0), rounds=case.get("rounds"), extra_topn=topn)
     t1 = time.perf_counter()
-    key = (name, lr0, seed, epochs, every) + g["perm_key"]
+    key = (name, lr0, seed, epochs, every, case.get("init_seed", 3), case.get("dim", DIM), topn) + g["perm_key"]
     if key not in cache:      # the negatives are a function of (seed, epoch, stored order): modes with the same order share a reference
-        cache[key] = reference_run(d, g["negatives"], lr0, epochs, marks, P0, Q0)
+        cache[key] = reference_run(d, g["negatives"], lr0, epochs, marks, P0, Q0, extra_topn=topn)
     out = compare({k: v for k, v in case.items()}, g, cache[key])
+    if case.get("order_null"):
+        # the yardstick (no GPU involved): the SAME sequential fp64 training on the same negatives with the epoch's triplets visited in one
+        # fixed random order instead of the reference's -- how far the reference's own measure moves under a reordering at this setting
+        nkey = key + ("null",)
+        if nkey not in cache:
+            order = np.random.default_rng(1_000_003 + seed).permutation(d["items"].size)
+            cache[nkey] = reference_run(d, g["negatives"], lr0, epochs, marks, P0, Q0, order=order)
+        fin = max(cache[key]["recall"])
+        out["order_null"] = {"what": "sequential fp64, one fixed random visiting order, minus sequential fp64 in the reference's order (final epoch)",
+                             "signed_diff": cache[nkey]["recall"][fin] - cache[key]["recall"][fin]}
     if case.get("own_order") and world == 1 and mode == "item":
         from qrec_amd.engine import balanced_chunk
         okey = key + ("own",)
@@ -311,6 +337,55 @@ def plan_full():
     return cases
 
 
+def plan_bpr_conf(seeds=range(1, 17), rounds=(0, 8, 32), modes=("item",), epochs=100, dataset="lastfm"):
+    """The reference's OWN BPR workload (round 5): config/BPR.conf -- lastfm, num.factors 50, learnRate 0.01 (-max 1),
+    reg 0.001, 100 epochs -- scored where the reference scores it: once, after the LAST epoch (model/ranking/BPR.py:28-43 ->
+    base/recommender.py:181-212).  One run per seed (the seed draws the initial tables AND the negatives); Recall@20 (north_star) and
+    Recall@10 (the conf's -topN 10) at the final epoch.  ``rounds``: engine.grid_for_epoch's minimum rounds of the grid (0 = rounds 1-4:
+    the whole 74 k-triplet epoch in flight at once)."""
+    cases = []
+    for seed in seeds:
+        for mode in modes:
+            for r in rounds:
+                cases.append(dict(dataset=dataset, lr0=0.01, seed=int(seed), init_seed=int(seed), dim=50, mode=mode, epochs=epochs, eval_every=10,
+                                  rounds=int(r), extra_topn=[10], order_null=True))
+    return cases
+
+
+def summarize_seeds(results, keys=("dataset", "lr0", "mode", "rounds", "world", "layout", "syncs", "dim", "epochs")):
+    """groups of cases that differ only in the seed -> signed final-epoch gap (GPU - reference): n, mean, sd, se, mean |gap|, max |gap|;
+    same for the order-only yardstick where it was run"""
+    groups = {}
+    for r in results:
+        if "final" in r:
+            groups.setdefault(tuple((k, r.get(k)) for k in keys if r.get(k) is not None), []).append(r)
+    out = []
+    for k, rs in groups.items():
+        if len(rs) < 2:
+            continue
+
+        def stats(x):
+            x = np.asarray(x, dtype=np.float64)
+            return {"n": int(x.size), "mean_signed": float(x.mean()), "sd": float(x.std(ddof=1)), "se": float(x.std(ddof=1) / np.sqrt(x.size)),
+                    "mean_abs": float(np.abs(x).mean()), "max_abs": float(np.abs(x).max())}
+        row = dict(k)
+        row["seeds"] = [r["seed"] for r in rs]
+        row["recall_exact_order_mean"] = float(np.mean([r["final"]["recall_exact_order"] for r in rs]))
+        row["recall_exact_order_sd_over_seeds"] = float(np.std([r["final"]["recall_exact_order"] for r in rs], ddof=1))
+        row["final_gap"] = stats([r["final"]["signed_diff"] for r in rs])
+        row["peak_gap"] = stats([r["peak"]["signed_diff"] for r in rs])
+        row["final_loss_rel_gap_mean"] = float(np.mean([r["final"]["loss_rel_gap"] for r in rs]))
+        row["same_bold_driver_decisions"] = int(sum(bool(r["same_bold_driver_decisions"]) for r in rs))
+        tn = [r["final_other_topn"] for r in rs if "final_other_topn" in r]
+        if tn:
+            row["final_gap_other_topn"] = {N: stats([t[N]["signed_diff"] for t in tn]) for N in tn[0]}
+        nulls = [r["order_null"]["signed_diff"] for r in rs if "order_null" in r]
+        if nulls:
+            row["order_null_final_gap"] = stats(nulls)
+        out.append(row)
+    return out
+
+
 def plan_quick():
     return [dict(dataset="lastfm", lr0=0.05, seed=7, mode=m, epochs=10, eval_every=5) for m in ("item", "item-deferred")] + \
            [dict(dataset="lastfm", lr0=0.05, seed=7, mode="item", epochs=10, eval_every=5, world=2, layout=l, shard_batch=1 << 14)
@@ -320,7 +395,8 @@ def plan_quick():
 def main():
     out_path = sys.argv[1]
     plan = sys.argv[2] if len(sys.argv) > 2 else "full"
-    cases = plan_full() if plan == "full" else plan_quick() if plan == "quick" else json.loads(open(plan).read() if os.path.exists(plan) else plan)
+    cases = (plan_full() if plan == "full" else plan_quick() if plan == "quick" else plan_bpr_conf() if plan == "bpr-conf"
+             else json.loads(open(plan).read() if os.path.exists(plan) else plan))
     from qrec_amd import capi
     capi.init(0)
     cache, datasets, results = {}, {}, []
@@ -337,7 +413,9 @@ def main():
         else:
             brief["error"] = res["error"]
         print(json.dumps(brief), flush=True)
-        json.dump({"_what": __doc__.split("\n\n")[0], "bar": BAR, "cases": results}, open(out_path, "w"), indent=1)
+        json.dump({"_what": __doc__.split("\n\n")[0], "bar": BAR, "over_seeds": summarize_seeds(results), "cases": results}, open(out_path, "w"), indent=1)
+    for row in summarize_seeds(results):
+        print("over seeds:", json.dumps(row), flush=True)
 
 
 if __name__ == "__main__":
