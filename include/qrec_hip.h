@@ -568,6 +568,24 @@ int qrec_tbpr_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld
                           const int32_t *d_b, int64_t n, double lr, double regU, double regI, const double *d_sums_in,
                           double *d_loss2, void *stream);
 
+/* ---- SBPR: model/ranking/SBPR.py:31-78 (numpy path) ------------------------------------------------------------------
+ * The reference's file raises TypeError at :46 (`self.FPSet[user][kItems]`, a dict indexed with a list) for the first user who has
+ * social feedback; both entry points implement the loop with that subscript read as `item_k` and everything else as written
+ * (tests/golden/gen_golden.py case_sbpr_filmtrust: the reference's own source with that one token replaced is the fixture).
+ * qrec_mt_sbpr_sample_epoch (host): the draws of SBPR.py:37-55,69-72 on the CPython MT19937 stream -> rows (u, i, k or -1, j, Suk),
+ *   int32 [n][5].  ps_users: user ids in PositiveSet's key order; fp_*: FPSet as CSR over user ids (items in dict order, counts);
+ *   item_key_user[j]: id of the user whose NAME equals item j's name or -1, is_key[user] (in/out): that user is a key of the
+ *   defaultdict FPSet by now -- the negative's rejection test `item_j in self.FPSet` (:52) is an item name looked up among user names.
+ * qrec_sbpr_sgd_ordered: SBPR.py:41-74 over those rows strictly in order (rows with i < 0: a bare visit of a user without positives).
+ *   d_bias: the item biases b [n_items] in the tables' dtype (never updated by the reference); bias_sumsq = b.b;
+ *   d_loss2[0] = sum of the -log terms (:57-58, :73), d_loss2[1] = sum over users of regU*sum(P*P) + regI*sum(Q*Q) + b.b (:74);
+ *   d_sums_in = {sum(P*P), sum(Q*Q)} of the tables at launch (qrec_sumsq).                                                       */
+int qrec_mt_sbpr_sample_epoch(uint32_t *state625, const int32_t *ps_users, int32_t n_ps, const int64_t *pos_indptr, const int32_t *pos_items,
+                              int32_t n_users, int32_t n_items, const int64_t *fp_indptr, const int32_t *fp_items, const int32_t *fp_counts,
+                              const int32_t *item_key_user, uint8_t *is_key, int64_t capacity, int32_t *rows_out, int64_t *n_out);
+int qrec_sbpr_sgd_ordered(void *d_P, void *d_Q, const void *d_bias, int dtype, int32_t d, int32_t ld, const int32_t *d_rows, int64_t n, double lr,
+                          double regU, double regI, double bias_sumsq, const double *d_sums_in, double *d_loss2, void *stream);
+
 /* ---- MHCN: model/ranking/MHCN.py:93-216 (self-gating, channel attention, hierarchical self-supervision) ---------------
  * Tables [rows][ld] fp32, ld in {32, 64, 128, 256}, columns >= d zero; d x d weights zero-padded to [ld][ld], biases [ld].
  * qrec_gate_fwd:  Y = X * sigmoid(X W + b), S = sigmoid(.)  -- self_gating / self_supervised_gating (MHCN.py:109-112).

@@ -22,7 +22,7 @@ def resolve_model(name: str):
             return getattr(importlib.import_module(f"qrec_amd.model.{pkg}.{name}"), name)
         except ModuleNotFoundError:
             continue
-    raise ImportError(f"model {name} is not provided by qrec_amd (hot-path models: BPR, TBPR, BasicMF, PMF, SVD, SVDPlusPlus, EE, LightGCN, NGCF, SimGCL, SGL, BUIR, SEPT, MHCN)")
+    raise ImportError(f"model {name} is not provided by qrec_amd (hot-path models: BPR, TBPR, SBPR, BasicMF, PMF, SVD, SVDPlusPlus, EE, LightGCN, NGCF, SimGCL, SGL, BUIR, SEPT, MHCN)")
 
 
 def _run_fold(results, model, order, spread=False):

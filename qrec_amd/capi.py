@@ -48,6 +48,8 @@ _SIGNATURES = {
     "qrec_mt_bpr_sample_epoch": [_vp, _vp, _vp, _i32, _i32, _vp],
     "qrec_mt_tbpr_sample_epoch": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "qrec_tbpr_sgd_ordered": [_vp, _vp, C.c_int, _i32, _i32, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _vp, _vp, _vp],
+    "qrec_mt_sbpr_sample_epoch": [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    "qrec_sbpr_sgd_ordered": [_vp, _vp, _vp, C.c_int, _i32, _i32, _vp, _i64, _f64, _f64, _f64, _f64, _vp, _vp, _vp],
     "qrec_mt_shuffle": [_vp, _i64, _vp],
     "qrec_mt_sample_range": [_vp, _i64, _i64, _vp],
     "qrec_mt_pairwise_sample_epoch": [_vp, _vp, _i64, _vp, _vp, _i32, _vp],
@@ -488,6 +490,31 @@ def tbpr_sgd_ordered(d_P, d_Q, dtype: int, d: int, ld: int, d_u, d_a, d_b, n: in
                      d_sums_in, d_loss2, stream=None):
     """TBPR.py:40-48,157-159 over the chained triplets, strictly in order (see include/qrec_hip.h)"""
     _check(load().qrec_tbpr_sgd_ordered(_dp(d_P), _dp(d_Q), dtype, d, ld, _dp(d_u), _dp(d_a), _dp(d_b), n, lr, regU, regI,
+                                        _dp(d_sums_in), _dp(d_loss2), _sh(stream)))
+
+
+def mt_sbpr_sample_epoch(state625: np.ndarray, ps_users, pos_indptr, pos_items, n_items: int, fp_indptr, fp_items, fp_counts, item_key_user,
+                         is_key) -> np.ndarray:
+    """SBPR.py:37-55,69-72 on the CPython stream: rows (u, i, k or -1, j, Suk) of one epoch, int32 [n, 5] (include/qrec_hip.h).
+    ``is_key`` (uint8 per user) is updated in place."""
+    _req(state625, np.uint32, "state625"); _req(ps_users, np.int32, "ps_users"); _req(pos_indptr, np.int64, "pos_indptr")
+    _req(pos_items, np.int32, "pos_items"); _req(fp_indptr, np.int64, "fp_indptr"); _req(fp_items, np.int32, "fp_items")
+    _req(fp_counts, np.int32, "fp_counts"); _req(item_key_user, np.int32, "item_key_user"); _req(is_key, np.uint8, "is_key")
+    n_users = pos_indptr.size - 1
+    if fp_indptr.size != pos_indptr.size or is_key.size != n_users or item_key_user.size != n_items or fp_counts.size != fp_items.size:
+        raise ValueError("mt_sbpr_sample_epoch: one FPSet row and one key flag per user, one name link per item expected")
+    cap = int(pos_items.size)
+    rows = np.empty((max(cap, 1), 5), dtype=np.int32)
+    n = C.c_int64(0)
+    _check(load().qrec_mt_sbpr_sample_epoch(_hp(state625), _hp(ps_users), ps_users.size, _hp(pos_indptr), _hp(pos_items), n_users, n_items,
+                                            _hp(fp_indptr), _hp(fp_items), _hp(fp_counts), _hp(item_key_user), _hp(is_key), cap, _hp(rows), C.byref(n)))
+    return rows[:n.value].copy()
+
+
+def sbpr_sgd_ordered(d_P, d_Q, d_bias, dtype: int, d: int, ld: int, d_rows, n: int, lr: float, regU: float, regI: float, bias_sumsq: float,
+                     d_sums_in, d_loss2, stream=None):
+    """SBPR.py:41-74 over the epoch's rows, strictly in order (see include/qrec_hip.h)"""
+    _check(load().qrec_sbpr_sgd_ordered(_dp(d_P), _dp(d_Q), _dp(d_bias), dtype, d, ld, _dp(d_rows), n, lr, regU, regI, bias_sumsq,
                                         _dp(d_sums_in), _dp(d_loss2), _sh(stream)))
 
 

@@ -231,6 +231,126 @@ __global__ __launch_bounds__(64) void tbpr_ordered_kernel(
     if (lane == 0) { loss_out[0] = loss; loss_out[1] = reg; }
 }
 
+// SBPR (model/ranking/SBPR.py:41-74, numpy path), order-exact, one wavefront, lane = column.  Rows (u, i, k, j, Suk) in the
+// reference's visiting order; k < 0: the user has no social feedback (:68-73, plain BPR step with the item biases in the
+// score and NO decay); i < 0: a bare visit of a user without positives (only the per-user loss terms).  With k >= 0 the two
+// chained pairs of :45-55 -- (i over k) scaled by 1 / (Suk + 1), then (k over j) -- then the four decays (:56-59, in the
+// order P[u], Q[i], Q[j], Q[k]) and the loss of :57-58 from the UPDATED rows, without the biases.  j == k happens (the
+// negative's rejection test does not look at the user's own feedback list): the row is then updated in sequence, as numpy's
+// in-place statements do, and decays twice.  The biases b never change (no statement updates them).  After every user:
+// regU*sum(P*P) + regI*sum(Q*Q) + b.b over the WHOLE tables (:74 sits inside the user loop) -- sums carried along as in
+// tbpr_ordered_kernel.  loss_out[0] = sum of the -log terms, loss_out[1] = sum over users of the table terms.
+template <typename T, int EPL>
+__global__ __launch_bounds__(64) void sbpr_ordered_kernel(
+    T *__restrict__ P, T *__restrict__ Q, const T *__restrict__ bias, int d, int ld, const int32_t *__restrict__ rows, int64_t n, T lr, T cu, T ci,
+    double regU, double regI, double bb, const double *__restrict__ sums_in, double *__restrict__ loss_out) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x;
+    bool valid[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) valid[e] = (lane + 64 * e) < d;
+    auto load_row = [&](const T *tab, int row, T (&dst)[EPL]) {
+        const T *p = tab + (int64_t)row * ld + lane;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) dst[e] = valid[e] ? p[64 * e] : T(0);
+    };
+    auto store_row = [&](T *tab, int row, const T (&src)[EPL]) {
+        T *p = tab + (int64_t)row * ld + lane;
+#pragma unroll
+        for (int e = 0; e < EPL; e++)
+            if (valid[e]) p[64 * e] = src[e];
+    };
+    auto norm2 = [&](const T (&r)[EPL]) {
+        double v = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) v += (double)r[e] * (double)r[e];
+        return wave_allreduce_sum(v);
+    };
+    auto dot = [&](const T (&a)[EPL], const T (&b)[EPL]) {
+        T v = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) v += a[e] * b[e];
+        return wave_allreduce_sum(v);
+    };
+    // a pairwise step on (pu, hi, lo) with coefficient c: P[u] += c (hi - lo); hi += c P[u]; lo -= c P[u]   (:46-48, :53-55, :70-72)
+    auto pair_step = [&](T (&pu)[EPL], T (&hi)[EPL], T (&lo)[EPL], T c) {
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            pu[e] += c * (hi[e] - lo[e]);
+            hi[e] += c * pu[e];
+            lo[e] -= c * pu[e];
+        }
+    };
+    auto decay = [&](T (&r)[EPL], T c) {
+#pragma unroll
+        for (int e = 0; e < EPL; e++) r[e] -= c * r[e];
+    };
+    auto sigmoid = [&](T x) { return T(1) / (T(1) + dev_exp<T>(-x)); };
+    T pu[EPL], qi[EPL], qk[EPL], qj[EPL];
+    double loss = 0.0, reg = 0.0, sP = sums_in[0], sQ = sums_in[1], pu_loaded = 0.0;
+    int cur_u = -1;
+    for (int64_t t = 0; t < n; t++) {
+        const int32_t *row = rows + 5 * t;
+        const int ut = row[0], it = row[1], kt = row[2], jt = row[3];
+        const T scale = T(1) / (T)(row[4] + 1);
+        if (ut != cur_u) {
+            if (cur_u >= 0) {
+                store_row(P, cur_u, pu);
+                sP += norm2(pu) - pu_loaded;
+                reg += regU * sP + regI * sQ + bb;
+            }
+            load_row(P, ut, pu);
+            pu_loaded = norm2(pu);
+            cur_u = ut;
+        }
+        if (it < 0) continue;
+        load_row(Q, it, qi); load_row(Q, jt, qj);
+        if (kt < 0) {
+            const double q_old = norm2(qi) + norm2(qj);
+            const T s = sigmoid(((dot(pu, qi) - dot(pu, qj)) + bias[it]) - bias[jt]);
+            pair_step(pu, qi, qj, lr * (T(1) - s));
+            store_row(Q, it, qi); store_row(Q, jt, qj);
+            sQ += norm2(qi) + norm2(qj) - q_old;
+            if constexpr (sizeof(T) == 8) loss += -log((double)s);
+            else loss += neg_log_sigmoid((double)(((dot(pu, qi) - dot(pu, qj)) + bias[it]) - bias[jt]));   // (fp32 tables: the stable form, pre-update score not kept -- fp64 is the parity mode)
+            continue;
+        }
+        const bool alias = jt == kt;
+        load_row(Q, kt, qk);
+        const double q_old = norm2(qi) + norm2(qk) + (alias ? 0.0 : norm2(qj));
+        const T s = sigmoid((((dot(pu, qi) - dot(pu, qk)) + bias[it]) - bias[kt]) / (T)(row[4] + 1));     // the reference divides (:45) ...
+        pair_step(pu, qi, qk, (scale * lr) * (T(1) - s));                                  // ... and multiplies here: 1 / (Suk+1) * lRate * (1 - s), left to right (:46)
+        if (alias) {
+            const T s2 = sigmoid(((dot(pu, qk) - dot(pu, qk)) + bias[kt]) - bias[jt]);
+            const T c2 = lr * (T(1) - s2);
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                pu[e] += c2 * (qk[e] - qk[e]);
+                qk[e] += c2 * pu[e];
+                qk[e] -= c2 * pu[e];
+            }
+            decay(pu, cu); decay(qi, ci); decay(qk, ci); decay(qk, ci);
+        } else {
+            const T s2 = sigmoid(((dot(pu, qk) - dot(pu, qj)) + bias[kt]) - bias[jt]);
+            pair_step(pu, qk, qj, lr * (T(1) - s2));
+            decay(pu, cu); decay(qi, ci); decay(qj, ci); decay(qk, ci);
+        }
+        const T x1 = (dot(pu, qi) - dot(pu, qk)) / (T)(row[4] + 1);
+        const T x2 = alias ? (dot(pu, qk) - dot(pu, qk)) : (dot(pu, qk) - dot(pu, qj));
+        if constexpr (sizeof(T) == 8) loss += -log((double)sigmoid(x1)) - log((double)sigmoid(x2));
+        else loss += neg_log_sigmoid((double)x1) + neg_log_sigmoid((double)x2);
+        store_row(Q, it, qi); store_row(Q, kt, qk);
+        if (!alias) store_row(Q, jt, qj);
+        sQ += norm2(qi) + norm2(qk) + (alias ? 0.0 : norm2(qj)) - q_old;
+    }
+    if (cur_u >= 0) {
+        store_row(P, cur_u, pu);
+        sP += norm2(pu) - pu_loaded;
+        reg += regU * sP + regI * sQ + bb;
+    }
+    if (lane == 0) { loss_out[0] = loss; loss_out[1] = reg; }
+}
+
 // Rating-prediction MF family, order-exact, same structure (one wavefront, lane = column):
 //   VAR 0  model/rating/BasicMF.py:9-26   P[u] += (lr*e)*q ;            Q[i] += (lr*e)*p
 //   VAR 1  model/rating/PMF.py:9-28       P[u] += lr*(e*q - regU*p) ;   Q[i] += lr*(e*p - regI*q)
@@ -1033,6 +1153,21 @@ int dispatch_mf(int variant, void *P, void *Q, void *Bu, void *Bi, int d, int ld
 }
 
 template <typename T>
+int launch_sbpr(void *P, void *Q, const void *bias, int d, int ld, const int32_t *rows, int64_t n, double lr, double regU, double regI, double bb,
+                const double *sums_in, double *loss2, hipStream_t st) {
+    const T tlr = (T)lr, cu = (T)lr * (T)regU, ci = (T)lr * (T)regI;
+#define QREC_SBPR_LAUNCH(EPL)                                                                                                      \
+    hipLaunchKernelGGL((sbpr_ordered_kernel<T, EPL>), dim3(1), dim3(64), 0, st, (T *)P, (T *)Q, (const T *)bias, d, ld, rows, n, tlr, cu, ci, \
+                       regU, regI, bb, sums_in, loss2)
+    if (d <= 64) QREC_SBPR_LAUNCH(1);
+    else if (d <= 128) QREC_SBPR_LAUNCH(2);
+    else QREC_SBPR_LAUNCH(4);
+#undef QREC_SBPR_LAUNCH
+    QREC_LAUNCH_CHECK();
+    return QREC_OK;
+}
+
+template <typename T>
 int launch_tbpr(void *P, void *Q, int d, int ld, const int32_t *u, const int32_t *a, const int32_t *b, int64_t n, double lr,
                 double regU, double regI, const double *sums_in, double *loss, hipStream_t st) {
     const T tlr = (T)lr, cu = (T)lr * (T)regU, ci = (T)lr * (T)regI;
@@ -1063,6 +1198,17 @@ int qrec_bpr_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld,
     return dtype == QREC_F64
                ? launch_ordered<double>(d_P, d_Q, d, ld, d_u, d_i, d_j, n, lr, regU, regI, d_loss, st)
                : launch_ordered<float>(d_P, d_Q, d, ld, d_u, d_i, d_j, n, lr, regU, regI, d_loss, st);
+}
+
+int qrec_sbpr_sgd_ordered(void *d_P, void *d_Q, const void *d_bias, int dtype, int32_t d, int32_t ld, const int32_t *d_rows, int64_t n, double lr,
+                          double regU, double regI, double bias_sumsq, const double *d_sums_in, double *d_loss2, void *stream) {
+    QREC_REQUIRE(d_P && d_Q && d_bias && d_sums_in && d_loss2 && n >= 0, "qrec_sbpr_sgd_ordered: null argument");
+    QREC_REQUIRE(n == 0 || d_rows, "qrec_sbpr_sgd_ordered: null row array");
+    QREC_REQUIRE(d >= 1 && d <= 256 && ld >= d, "qrec_sbpr_sgd_ordered: need 1 <= d <= 256, ld >= d (got d=%d ld=%d)", d, ld);
+    QREC_REQUIRE(dtype == QREC_F32 || dtype == QREC_F64, "qrec_sbpr_sgd_ordered: bad dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == QREC_F64 ? launch_sbpr<double>(d_P, d_Q, d_bias, d, ld, d_rows, n, lr, regU, regI, bias_sumsq, d_sums_in, d_loss2, st)
+                             : launch_sbpr<float>(d_P, d_Q, d_bias, d, ld, d_rows, n, lr, regU, regI, bias_sumsq, d_sums_in, d_loss2, st);
 }
 
 int qrec_tbpr_sgd_ordered(void *d_P, void *d_Q, int dtype, int32_t d, int32_t ld, const int32_t *d_u, const int32_t *d_a,

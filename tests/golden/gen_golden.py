@@ -310,6 +310,94 @@ def case_tbpr_filmtrust(tmp):
     return meta
 
 
+def case_sbpr_filmtrust(tmp):
+    """model/ranking/SBPR.py, numpy path (trainModel :31-78), FilmTrust + trust.txt.  The UNMODIFIED file cannot produce this fixture:
+    `Suk = self.FPSet[user][kItems]` (SBPR.py:46) indexes a dict with a list and raises TypeError for the first user who has social
+    feedback -- recorded below by running it.  The fixture is the run of the same source with that ONE token replaced (`kItems` ->
+    `item_k`: the count the friend-consumed item was drawn with, the statement's evident meaning); everything else -- including the
+    negative's rejection test `item_j in self.FPSet`, which looks the ITEM name up among the USER names that are keys of FPSet so far
+    -- runs as written.  The per-positive (u, i, k, j, Suk) stream is recovered from the order of `choice` and `sigmoid` calls
+    (an accepted draw is a `choice` followed directly by a `sigmoid`)."""
+    import importlib
+    import traceback
+    conf = os.path.join(tmp, "sbpr_ft.conf")
+    write_conf(conf, ratings="./dataset/FilmTrust/trainset.txt", social="./dataset/FilmTrust/trust.txt",
+               ratings__setup="-columns 0 1 2", social__setup="-columns 0 1 2",
+               model__name="SBPR", evaluation__setup="-testSet ./dataset/FilmTrust/testset.txt -b 1",
+               item__ranking="on -topN 10,20", num__factors="8", num__max__epoch="3", learnRate="-init 0.03 -max 1",
+               reg__lambda="-u 0.01 -i 0.01 -b 0.2 -s 0.2", output__setup="off -dir ./results/")
+    # 1. the file as it is
+    raised = None
+    try:
+        run_numpy_model(conf, 91, "model.ranking.SBPR", "SBPR", "none", social=True)
+    except TypeError as e:
+        tb = traceback.extract_tb(e.__traceback__)[-1]
+        raised = dict(type="TypeError", message=str(e), file=os.path.relpath(tb.filename, REF), line=tb.lineno, statement=tb.line)
+    assert raised is not None and raised["line"] == 46, raised
+    # (run_numpy_model restores its hooks only on success)
+    importlib.reload(importlib.import_module("model.ranking.SBPR"))
+    import base.recommender as br
+    from util.measure import Measure
+    br.Measure = Measure
+    # 2. the same source, one token replaced
+    path = os.path.join(REF, "model", "ranking", "SBPR.py")
+    src = open(path).read()
+    assert src.count("self.FPSet[user][kItems]") == 1
+    mod = types.ModuleType("model.ranking.SBPR_line46")
+    exec(compile(src.replace("self.FPSet[user][kItems]", "self.FPSet[user][item_k]"), path + " (line 46: kItems -> item_k)", "exec"), mod.__dict__)
+    sys.modules["model.ranking.SBPR_line46"] = mod
+    events = []
+    ref_choice, ref_sigmoid = mod.choice, mod.sigmoid
+    mod.choice = lambda seq: (lambda r: (events.append((len(seq), r)), r)[1])(ref_choice(seq))
+    mod.sigmoid = lambda x: (events.append(None), ref_sigmoid(x))[1]
+    rec = run_numpy_model(conf, 91, "model.ranking.SBPR_line46", "SBPR", "none", social=True)
+    m = rec["model"]
+    I = len(m.data.item)
+    # accepted draws = a choice directly followed by a sigmoid; a draw from a list shorter than the catalogue is the friend-consumed item
+    acc = [events[t] for t in range(len(events) - 1) if events[t] is not None and events[t + 1] is None]
+    stream, it = [], iter(acc)
+    n_epochs = len(rec["epochs"])
+    for _ in range(n_epochs):
+        for user in m.PositiveSet:
+            u = m.data.user[user]
+            for item in m.PositiveSet[user]:
+                ln, name = next(it)
+                if len(m.FPSet[user]) > 0:
+                    assert ln == len(m.FPSet[user]) and name in m.FPSet[user]
+                    k, w = m.data.item[name], m.FPSet[user][name]
+                    ln, name = next(it)
+                else:
+                    k, w = -1, 0
+                assert ln == I
+                stream.append((u, m.data.item[item], k, m.data.item[name], w))
+    assert next(it, None) is None
+    rec["steps"] = [(a, b, d) for a, b, c, d, e in stream]
+    meta = pack_bpr(rec, "sbpr_filmtrust", keep_full_stream=False)
+    z = dict(np.load(os.path.join(OUT, "sbpr_filmtrust.npz")))
+    z.pop("steps_head", None); z.pop("steps_tail", None)
+    z["stream"] = np.array(stream, dtype=np.int32)                     # (u, i, k or -1, j, Suk) per positive and epoch
+    z["b"] = np.asarray(m.b, dtype=np.float64)
+    unknown = {}
+    code = lambda name: m.data.user[name] if name in m.data.user else -1 - unknown.setdefault(name, len(unknown))
+    z["raw_follower"] = np.array([code(r[0]) for r in rec["raw_relation"]], dtype=np.int64)
+    z["raw_followee"] = np.array([code(r[1]) for r in rec["raw_relation"]], dtype=np.int64)
+    z["raw_weight"] = np.array([r[2] for r in rec["raw_relation"]], dtype=np.float64)
+    ptr, items, cnt = [0], [], []
+    for user in m.data.user:                                           # id order
+        book = m.FPSet[user] if user in m.FPSet else {}
+        items += [m.data.item[x] for x in book]; cnt += list(book.values())
+        ptr.append(len(items))
+    z["fp_indptr"] = np.array(ptr, dtype=np.int64); z["fp_items"] = np.array(items, dtype=np.int32); z["fp_counts"] = np.array(cnt, dtype=np.int32)
+    z["positive_set_users"] = np.array([m.data.user[x] for x in m.PositiveSet], dtype=np.int32)
+    z["user_names"] = np.array(list(m.data.user.keys())); z["item_names"] = np.array(list(m.data.item.keys()))      # id order
+    np.savez_compressed(os.path.join(OUT, "sbpr_filmtrust.npz"), **z)
+    meta.update(seed=91, conf=open(conf).read(), unmodified_reference_raises=raised,
+                fixture_source="model/ranking/SBPR.py with line 46 `self.FPSet[user][kItems]` -> `self.FPSet[user][item_k]`; nothing else changed",
+                users_with_social_feedback=int(sum(1 for x in m.PositiveSet if len(m.FPSet[x]) > 0)), stream_sha256=sha(z["stream"]),
+                relations_loaded=len(rec["raw_relation"]), relations_kept=len(m.social.relation))
+    return meta
+
+
 def case_pairwise_and_adj(tmp):
     """base/deepRecommender.py:29-52 sampler and base/graphRecommender.py:10-29 adjacency,
     both pure python/scipy -> executable with the tensorflow stub."""
@@ -550,7 +638,7 @@ def main():
     os.symlink(os.path.join(REF, "dataset"), os.path.join(tmp, "dataset"))
     os.chdir(tmp)
     only = sys.argv[1:]
-    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pmf, case_svd, case_ee, case_svdpp, case_pairwise_and_adj, case_pointwise, case_sgl_subgraph, case_sept_graphs, case_tbpr_filmtrust, case_mhcn_graphs, case_loader]
+    cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pmf, case_svd, case_ee, case_svdpp, case_pairwise_and_adj, case_pointwise, case_sgl_subgraph, case_sept_graphs, case_tbpr_filmtrust, case_sbpr_filmtrust, case_mhcn_graphs, case_loader]
     if only:   # regenerate a subset, keep the other entries of golden_meta.json
         cases = [c for c in cases if c.__name__ in only]
         old = json.load(open(os.path.join(OUT, "golden_meta.json")))

@@ -107,6 +107,9 @@ def test_social_and_graph_model_entry_points_refuse_bad_arguments_and_accept_emp
     _err(lambda: capi.tbpr_sgd_ordered(T, T, 9, 64, 64, idx, idx, idx, 16, 0.1, 0, 0, out, out))        # dtype
     _err(lambda: capi.tbpr_sgd_ordered(T, T, capi.F32, 64, 64, idx, idx, idx, 16, 0.1, 0, 0, None, out))  # no sums
     _err(lambda: capi.svdpp_sgd_ordered(T, T, None, T, T, capi.F32, 64, 64, DB.zeros(61, np.int64), idx, idx, idx, out, 4, 0.1, 0, 0, 0, 0, 3.0, out))
+    _err(lambda: capi.sbpr_sgd_ordered(T, T, T, 9, 64, 64, idx, 3, 0.1, 0, 0, 0.0, out, out))               # dtype
+    _err(lambda: capi.sbpr_sgd_ordered(T, T, None, capi.F32, 64, 64, idx, 3, 0.1, 0, 0, 0.0, out, out))     # no biases
+    _err(lambda: capi.sbpr_sgd_ordered(T, T, T, capi.F32, 64, 64, None, 3, 0.1, 0, 0, 0.0, out, out))        # rows missing
     assert np.array_equal(T.numpy(), T0) and np.array_equal(S.numpy(), T0)
     # empty inputs
     capi.l2norm_rows_accum(T, 0, 64, S, f32(1)); capi.l2norm_rows_bwd(T, f32(1), T, 0, 64, S); capi.scale_copy(S, T, 0, 0.5)
@@ -120,6 +123,11 @@ def test_social_and_graph_model_entry_points_refuse_bad_arguments_and_accept_emp
     u, a, b = capi.mt_tbpr_sample_epoch(np.zeros(625, np.uint32), np.zeros(4, np.int64), np.zeros(0, np.int32), 10,
                                         *[(np.zeros(4, np.int64), np.zeros(0, np.int32))] * 3)
     assert u.size == a.size == b.size == 0
+    capi.sbpr_sgd_ordered(T, T, T, capi.F32, 64, 64, None, 0, 0.1, 0.01, 0.01, 2.0, out, out)               # n = 0: no user visited, both loss terms := 0
+    assert out.numpy()[0] == 0.0 and out.numpy()[1] == 0.0 and np.array_equal(T.numpy(), T0)
+    rows = capi.mt_sbpr_sample_epoch(np.zeros(625, np.uint32), np.zeros(0, np.int32), np.zeros(4, np.int64), np.zeros(0, np.int32), 10,
+                                     np.zeros(4, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32), np.full(10, -1, np.int32), np.zeros(3, np.uint8))
+    assert rows.shape == (0, 5)
 
 
 def test_round_3_entry_points_refuse_what_they_cannot_serve():

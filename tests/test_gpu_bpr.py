@@ -1390,6 +1390,96 @@ def test_tbpr_model_reproduces_the_reference_run(tmp_path):
     assert np.array_equal(capi.state_from_python(random.getstate()), z["py_state"])
 
 
+@pytest.mark.parametrize("dtype,tol", [(np.float64, F64_TOL), (np.float32, 5e-5)])
+def test_sbpr_ordered_kernel_matches_oracle_including_aliased_rows(dtype, tol):
+    """qrec_sbpr_sgd_ordered vs the restated SBPR loop (oracle/npref.py, itself pinned to the reference run): users with and without
+    social feedback, j == k rows (the negative repeats the friend-consumed item: one row updated in sequence and decayed twice), users
+    without any positive (a bare visit: only the per-user loss terms), the running sums of squares."""
+    from oracle import npref
+    rng = np.random.default_rng(21)
+    U, I, dim = 90, 70, 20
+    rows, ps = [], rng.permutation(U)[:80].tolist()
+    for user in ps:
+        n = int(rng.integers(0, 6))
+        social = rng.random() < 0.6
+        mine = rng.permutation(I)[:n].tolist()
+        for i in mine:
+            if social:
+                k = int(rng.choice([x for x in range(I) if x not in mine]))
+                j = k if rng.random() < 0.25 else int(rng.choice([x for x in range(I) if x not in mine]))
+                rows.append((user, i, k, j, int(rng.integers(1, 5))))
+            else:
+                rows.append((user, i, -1, int(rng.choice([x for x in range(I) if x not in mine])), 0))
+    rows = np.array(rows, np.int32)
+    assert ((rows[:, 2] == rows[:, 3]) & (rows[:, 2] >= 0)).sum() > 5 and (rows[:, 2] < 0).sum() > 20
+    have = set(rows[:, 0].tolist())
+    visits = np.array([(u, -1, -1, -1, 0) for u in ps if u not in have], np.int32).reshape(-1, 5)
+    assert visits.shape[0] > 0
+    place = np.full(U, -1); place[ps] = np.arange(len(ps))
+    both = np.concatenate([rows, visits])
+    seq = np.ascontiguousarray(both[np.argsort(place[both[:, 0]], kind="stable")])
+    P0, Q0, b = rng.random((U, dim)) / 3, rng.random((I, dim)) / 3, rng.random(I)
+    Pr, Qr = P0.copy(), Q0.copy()
+    want = npref.sbpr_epoch(Pr, Qr, b, np.array(ps, np.int32), rows, 0.05, 0.02, 0.03)
+    t = DeviceTables(P0, Q0, dtype)
+    sums, loss2 = DB.zeros(2, np.float64), DB.zeros(2, np.float64)
+    capi.sumsq(t.P, t.code, U, dim, t.ld, sums.ptr); capi.sumsq(t.Q, t.code, I, dim, t.ld, sums.ptr + 8)
+    capi.sbpr_sgd_ordered(t.P, t.Q, DB.from_numpy(b.astype(dtype)), t.code, dim, t.ld, DB.from_numpy(seq), seq.shape[0], 0.05, 0.02, 0.03, float(b.dot(b)),
+                          sums, loss2)
+    nll, reg = loss2.numpy()
+    check("abs(nll + reg - want) / want", abs(nll + reg - want) / want, tol)
+    Pg, Qg = t.download(np.float64)
+    check("rel_err(Pg, Pr)", rel_err(Pg, Pr), tol)
+    check("rel_err(Qg, Qr)", rel_err(Qg, Qr), tol)
+
+
+def test_sbpr_model_reproduces_the_reference_run(tmp_path):
+    """Drop-in SBPR on FilmTrust + trust.txt (the reference's own user / item NAMES: its negative-rejection test compares them) against
+    the recorded run of the reference's source with the one token of line 46 replaced (tests/golden/gen_golden.py case_sbpr_filmtrust;
+    the file as it is raises TypeError there): PositiveSet / FPSet as the reference built them, the (u, i, k, j, Suk) rows bit-exact, the
+    biases, P and Q 1e-10, the loss incl. the per-user terms, the learning-rate schedule, measures, generator."""
+    from qrec_amd.model.ranking.SBPR import SBPR
+    from qrec_amd.util.io import FileIO
+    meta, z = load_golden("sbpr_filmtrust")
+    un, inn = z["user_names"].tolist(), z["item_names"].tolist()
+    name = lambda c: un[c] if c >= 0 else f"x{-1 - c}"
+    path = tmp_path / "trust.txt"
+    path.write_text("".join(f"{name(x)} {name(y)} {w:g}\n" for x, y, w in zip(z["raw_follower"].tolist(), z["raw_followee"].tolist(), z["raw_weight"].tolist())))
+    train = [[un[u], inn[i], float(r)] for u, i, r in zip(z["train_uid"].tolist(), z["train_iid"].tolist(), z["train_r"].tolist())]
+    test = [[un[u] if u >= 0 else str(a), inn[i] if i >= 0 else str(c), 1.0]
+            for u, i, a, c in zip(z["test_uid"].tolist(), z["test_iid"].tolist(), z["test_uname"].tolist(), z["test_iname"].tolist())]
+    conf = conf_from_text(meta["conf"])
+    orig, streams = capi.mt_sbpr_sample_epoch, []
+
+    def spy(*args):
+        out = orig(*args); streams.append(out); return out
+    capi.mt_sbpr_sample_epoch = spy
+    try:
+        random.seed(meta["seed"]); np.random.seed(meta["seed"])
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            m = SBPR(conf, train, test, FileIO.loadRelationship(conf, str(path)))
+            measure = m.execute()
+    finally:
+        capi.mt_sbpr_sample_epoch = orig
+    assert len(m.social.relation) == meta["relations_kept"]
+    assert np.array_equal(m._fp[0], z["fp_indptr"]) and np.array_equal(m._fp[1], z["fp_items"]) and np.array_equal(m._fp[2], z["fp_counts"])
+    assert np.array_equal(m._ps_users, z["positive_set_users"])
+    assert np.array_equal(np.concatenate(streams), z["stream"])
+    np.testing.assert_array_equal(m.b, z["b"])
+    last = len(meta["epochs"])
+    np.testing.assert_allclose(m.P, z[f"P{last}"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(m.Q, z[f"Q{last}"], rtol=1e-10, atol=1e-13)
+    out = buf.getvalue()
+    losses = [float(l.split("loss = ")[1].split(",")[0]) for l in out.splitlines() if "loss = " in l]
+    np.testing.assert_allclose(losses, [round(e["loss"], 4) for e in meta["epochs"]], rtol=0, atol=1.01e-4)
+    assert m.lastLoss == pytest.approx(meta["epochs"][-1]["loss"], rel=1e-11) and m.lRate == pytest.approx(meta["epochs"][-1]["lr_next"], rel=1e-15)
+    for g, w in zip(measure, meta["measure"]):
+        if ":" in w:
+            assert float(g.split(":")[1]) == pytest.approx(float(w.split(":")[1]), rel=1e-9)
+    assert np.array_equal(capi.state_from_python(random.getstate()), z["py_state"])
+
+
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-12), (np.float32, 2e-5)])
 @pytest.mark.parametrize("n_items,n", [(3, 257), (6, 1000), (40, 4099)])
 def test_ordered_kernel_is_order_exact_under_heavy_aliasing(dtype, tol, n_items, n):

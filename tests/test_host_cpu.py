@@ -592,6 +592,35 @@ def test_tbpr_native_sampler_reproduces_the_reference_stream():
         capi.mt_tbpr_sample_epoch(words, pos.indptr, pos.indices, I, (sets[0][0][:-1], sets[0][1]), sets[1], sets[2])
 
 
+def test_sbpr_native_sampler_reproduces_the_reference_stream():
+    """qrec_mt_sbpr_sample_epoch (host side of model/ranking/SBPR.py:37-55,69-72) on the recorded run: every epoch's (u, i, k, j, Suk) rows
+    bit-exact -- including the negatives the reference rejects because their NAME is a user name among FPSet's keys -- and the generator
+    left where the reference's was after its per-epoch shuffle."""
+    meta, z = load_golden("sbpr_filmtrust")
+    U, I = meta["n_users"], meta["n_items"]
+    pos = user_item_csr(z["train_uid"], z["train_iid"], z["train_r"], U, I, min_rating=1)
+    name2user = {n: k for k, n in enumerate(z["user_names"].tolist())}
+    link = np.array([name2user.get(n, -1) for n in z["item_names"].tolist()], dtype=np.int32)
+    is_key = (np.diff(z["fp_indptr"]) > 0).astype(np.uint8)
+    random.seed(meta["seed"])
+    words = capi.state_from_python(random.getstate())
+    got = []
+    for _ in meta["epochs"]:
+        got.append(capi.mt_sbpr_sample_epoch(words, z["positive_set_users"], pos.indptr, pos.indices, I, z["fp_indptr"], z["fp_items"], z["fp_counts"],
+                                             link, is_key))
+        capi.mt_shuffle(words, meta["n_train"])                      # isConverged: shuffle(trainingData)
+    assert np.array_equal(np.concatenate(got), z["stream"])
+    assert np.array_equal(words, z["py_state"]) and is_key[z["positive_set_users"]].all()
+    # without the name links the stream is another one (the rule is not a no-op on this data)
+    random.seed(meta["seed"])
+    words = capi.state_from_python(random.getstate())
+    other = capi.mt_sbpr_sample_epoch(words, z["positive_set_users"], pos.indptr, pos.indices, I, z["fp_indptr"], z["fp_items"], z["fp_counts"],
+                                      np.full(I, -1, np.int32), (np.diff(z["fp_indptr"]) > 0).astype(np.uint8))
+    assert not np.array_equal(other, got[0])
+    with pytest.raises(ValueError, match="one FPSet row"):
+        capi.mt_sbpr_sample_epoch(words, z["positive_set_users"], pos.indptr, pos.indices, I, z["fp_indptr"][:-1], z["fp_items"], z["fp_counts"], link, is_key)
+
+
 def test_mhcn_graph_builders_of_the_product_match_the_reference_bitwise():
     """qrec_amd.graph.mhcn_channel_graphs (host side of model/ranking/MHCN.py:26-85, 46-52) against the reference's own
     matrices on FilmTrust + trust.txt: the three motif-induced channel adjacencies bit for bit, the user-item values."""

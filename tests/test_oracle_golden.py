@@ -325,6 +325,53 @@ def test_tbpr_filmtrust_stream_tables_and_loss(golden_dir):
     assert (stream[:, 1] == stream[:, 2]).any()             # the last draw does repeat a social item now and then: rows alias
 
 
+def _sbpr_inputs(meta, z):
+    """what the SBPR loop reads, rebuilt from the fixture: PositiveSet CSR, FPSet CSR + counts, the item-name -> user-id links of
+    `item_j in self.FPSet`, the keys FPSet has after initModel"""
+    U, I = meta["n_users"], meta["n_items"]
+    pos = user_item_csr(z["train_uid"], z["train_iid"], z["train_r"], U, I, min_rating=1)
+    name2user = {n: k for k, n in enumerate(z["user_names"].tolist())}
+    link = np.array([name2user.get(n, -1) for n in z["item_names"].tolist()], dtype=np.int32)
+    is_key = (np.diff(z["fp_indptr"]) > 0).astype(np.uint8)
+    return pos, link, is_key
+
+
+def test_sbpr_filmtrust_stream_tables_and_loss(golden_dir):
+    """model/ranking/SBPR.py (numpy path) through the oracle's restatement (oracle/npref.py) against the recorded run of the
+    reference's source with the ONE token of line 46 replaced (the file as it is raises TypeError there -- the fixture records that
+    too): the (u, i, k, j, Suk) rows bit-exact, P and Q after every epoch, the loss, the learning-rate schedule, the generator."""
+    import random
+    from oracle import npref
+    meta, z = _load(golden_dir, "sbpr_filmtrust")
+    raised = meta["unmodified_reference_raises"]
+    assert raised["type"] == "TypeError" and raised["line"] == 46 and "kItems" in raised["statement"]
+    pos, link, is_key = _sbpr_inputs(meta, z)
+    assert (link >= 0).sum() > 1000                        # FilmTrust: most item names ARE user names -- the :52 test bites
+    rng = random.Random(); rng.seed(meta["seed"])
+    P, Q, b = z["P0"].copy(), z["Q0"].copy(), z["b"]
+    per = z["stream"].shape[0] // len(meta["epochs"])
+    lr, last = meta["epochs"][0]["lr_used"], 0.0
+    for ep in meta["epochs"]:
+        k = ep["epoch"]
+        rows = npref.sbpr_sample_epoch(rng, z["positive_set_users"], pos.indptr, pos.indices, z["fp_indptr"], z["fp_items"], z["fp_counts"],
+                                       meta["n_items"], link, is_key)
+        assert np.array_equal(rows, z["stream"][(k - 1) * per:k * per])
+        loss = npref.sbpr_epoch(P, Q, b, z["positive_set_users"], rows, lr, meta["regU"], meta["regI"])
+        np.testing.assert_allclose(P, z[f"P{k}"], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(Q, z[f"Q{k}"], rtol=1e-12, atol=1e-15)
+        assert loss == pytest.approx(ep["loss"], rel=1e-13) and lr == pytest.approx(ep["lr_used"], rel=1e-15)
+        if not abs(last - loss) < 1e-3:                     # base/iterativeRecommender.py:88-104
+            if k > 1:
+                lr = lr * 1.05 if abs(last) > abs(loss) else lr * 0.5
+            lr = min(lr, 1.0)
+        assert lr == pytest.approx(ep["lr_next"], rel=1e-15)
+        last = loss
+        order = list(range(meta["n_train"])); rng.shuffle(order)        # isConverged: shuffle(trainingData)
+    assert np.array_equal(np.array(rng.getstate()[1], dtype=np.uint32), z["py_state"])
+    st = z["stream"]
+    assert _sha(st) == meta["stream_sha256"] and (st[:, 2] >= 0).mean() > 0.3 and ((st[:, 2] == st[:, 3]) & (st[:, 2] >= 0)).any()
+
+
 def test_mhcn_graph_builders_match_the_reference(golden_dir):
     """model/ranking/MHCN.py:26-85 (pure scipy / python in the reference): the three motif-induced channel adjacencies
     and the value list of buildJointAdjacency, bit for bit in the reference's float32."""

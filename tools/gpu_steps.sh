@@ -12,6 +12,7 @@
 #   mfma-util            MfmaUtil per MFMA kernel (NGCF step, evaluation, SimGCL step) -> <tag>_mfma_util.json
 #   stats:<m>            rocprofv3 --kernel-trace --stats of one config's step (m: lightgcn | simgcl | ngcf | eval) -> <tag>_<m>_kernel_stats.txt
 #   py:<script>[:args]   python tools/<script>.py args... (args separated by ':'), stdout -> <tag>_<script>.log
+#   profpy:<script>[:args]  the same under rocprofv3 --kernel-trace --stats -> <tag>_<script>_kernel_stats.txt
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out; mkdir -p $O
@@ -62,6 +63,12 @@ for STEP in "$@"; do
     py)
       S=${ARG%%:*}; A=""; [[ "$ARG" == *:* ]] && A=${ARG#*:}
       cd $R; timeout 3000 python tools/$S.py ${A//:/ } > $O/${TAG}_$S.log 2>&1; echo "$S exit $?"; tail -25 $O/${TAG}_$S.log | cut -c1-600; cd /tmp;;
+    profpy)
+      S=${ARG%%:*}; A=""; [[ "$ARG" == *:* ]] && A=${ARG#*:}
+      rm -rf $O/prof_$S
+      rocprofv3 --kernel-trace --stats -d $O/prof_$S -o $S -- python $R/tools/$S.py ${A//:/ } > $O/prof_$S.log 2>&1; echo "$S exit $?"
+      db=$(ls $O/prof_$S/*_results.db $O/prof_$S/*/*_results.db 2>/dev/null | head -1)
+      python $R/tools/summarize_stats.py $db $O/${TAG}_${S}_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python tools/$S.py ${A//:/ }   [$TAG; profiled run]" | head -24;;
     *) echo "unknown step $STEP";;
   esac
   echo "[$STEP: $(( $(date +%s) - T0 )) s]"
