@@ -28,7 +28,7 @@ N > 1, one process per GPU (qrec_amd/dist.py; collectives are RCCL bound directl
 sharded: item table row-sharded, per batch an all-to-all of the distinct rows a rank's triplets touch and of their
 updates.  --scaling strong (default since round 4: BASELINE.json quotes the metric on THE Yelp2018 shape at 1/2/4/8 GPUs): the same
 31,668 users split over the ranks = `value`; the weak-scaling figure (every rank its own 31,668 users) is timed next to it and
-reported as `weak_scaling` under its aggregate shape; --scaling weak makes that leg `value`.  --sync-per-epoch (default: one per rank)
+reported as `weak_scaling` under its aggregate shape; --scaling weak makes that leg `value`.  --sync-per-epoch (default: 1 up to two ranks, 2 beyond)
 / --hot-rows: how often, and over which rows, the ranks' item rows are reconciled inside an epoch.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
@@ -443,6 +443,67 @@ def multi_gpu_recall(capi, qd, control, comm, world, rank, layout, mode, dataset
     return out
 
 
+def config4_sharded_leg(capi, qd, control, comm, world, rank, shard_batch, syncs, users=1_250_000, items=1_000_000, triplets=25_000_000, d=128, epochs=3):
+    """BASELINE.json config #4 in north_star's layout, on the ranks of THIS run (round 5): every rank holds its own `users` users' rows of P
+    and its interleaved 1 / world share of the `items` item rows (d = 128), trains `triplets` triplets per epoch whose items are uniform
+    over the WHOLE catalogue, and fetches / returns the distinct item rows of every exchange batch over the communicator
+    (qrec_amd/dist.py ShardedItemExchange: per batch an all-to-all of row ids' rows out and of their updates back).  At world 8 this IS
+    config #4: 10 M users x 1 M items, 200 M triplets per epoch, 5.6 GB of tables.  Negatives are drawn once on the host (the device
+    sampler is the main leg's business); `epochs` timed epochs after one warm-up, barrier + device sync on both sides, max over ranks."""
+    from qrec_amd.engine import BprSgd, DeviceTables, balanced_chunk
+    rng = np.random.default_rng(4000 + rank)
+    u2 = np.sort(rng.integers(0, users, triplets, dtype=np.int32)); i2 = rng.integers(0, items, triplets, dtype=np.int32)
+    j2 = rng.integers(0, items, triplets, dtype=np.int32)
+    rows_q = len(range(rank, items, world))
+    blk = (rng.random((min(50_000, max(users, rows_q)), d)) / 3).astype(np.float32)
+    P2 = np.empty((users, d), np.float32); Q2 = np.empty((rows_q, d), np.float32)
+    for a in (P2, Q2):
+        for k in range(0, a.shape[0], blk.shape[0]):
+            a[k:k + blk.shape[0]] = blk[:min(blk.shape[0], a.shape[0] - k)]
+    t = DeviceTables(P2, Q2, np.float32)
+    del P2, Q2
+    n_batches = qd.agree_on_batches(control, triplets, shard_batch, split_from=1 << 19, min_batches=syncs)
+    chunk = balanced_chunk(triplets)
+    sgd = BprSgd(t, u2, i2, None, schedule="item", n_items=items, batches=n_batches, chunk=chunk)
+    sgd.set_negatives(j2)
+    step = qd.ShardedStep(comm, qd.ShardedItemExchange(comm, items, t.ld, t.Q), n_batches)
+    stream = capi.Stream()
+    sgd.start_device_driver(LR0, log_capacity=epochs + 2)
+    capi.device_sync()
+    pairs = []
+
+    def run(m):
+        for _ in range(m):
+            pair = (capi.Event(), capi.Event()); pairs.append(pair)
+            step.prepare(sgd, stream)
+            sgd.epoch_device_async(REG_U, REG_I, MAX_LR, tol=0.0, chunk=chunk, flush_every=FLUSH_EVERY, stream=stream, dist=step, events=pair)
+
+    def sync():
+        control.barrier(); stream.sync(); capi.device_sync(); control.barrier()
+    run(1); sync()
+    moved0 = step.exchange.bytes_moved
+    t0 = time.perf_counter(); run(epochs); sync()
+    dt = float(control.allreduce_host(np.array([time.perf_counter() - t0]), op="max")[0]) / epochs
+    moved = float(control.allreduce_host(np.array([(step.exchange.bytes_moved - moved0) / epochs]))[0])
+    kernel_ms = float(np.mean([b.elapsed_ms_since(a) for a, b in pairs[1:]]))
+    per_rank = control.allgather_host(np.array([kernel_ms]))[:, 0]
+    loss = float(sgd.driver_log()[-1, 0])
+    alg = triplets * bytes_per_triplet(d)
+    out = {"workload": f"BPR d={d}, {world} x {users} users x {items} items, {world} x {triplets} triplets/epoch; item table row-sharded x{world} "
+                       f"({rows_q} rows = {rows_q * t.ld * 4 / 1e6:.0f} MB per rank), {n_batches} exchange batches per epoch and rank"
+                       + (" = BASELINE config #4" if (world, users, items, triplets, d) == (8, 1_250_000, 1_000_000, 25_000_000, 128) else ""),
+           "ms_per_epoch": dt * 1e3, "triplet_updates_per_s_job": world * triplets / dt, "batches_per_epoch": n_batches,
+           "bytes_leaving_all_ranks_per_epoch": moved, "bytes_leaving_one_rank_per_triplet": moved / world / triplets,
+           "epoch_ms_per_rank_by_events": {"min": float(per_rank.min()), "max": float(per_rank.max()), "all": [float(x) for x in per_rank],
+                                           "what": "HIP events around a rank's whole epoch on its stream: SGD batches + gathers + exchanges + applies"},
+           "algorithmic_GBps_per_rank": alg / dt / 1e9, "frac_of_8TBps_per_rank": alg / dt / 1e9 / HBM_PEAK_GBPS,
+           "predicted_link_ms_per_epoch": {"all_links_1071GBps": moved / world / 1071e9 * 1e3, "one_link_153GBps": moved / world / 153e9 * 1e3,
+                                           "what": "bytes leaving one rank per epoch / link rate; arithmetic, not measured"},
+           "final_loss_rank0": loss, "negatives": "uniform, drawn once on the host", "epochs_timed": epochs}
+    del sgd, step, t
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -466,8 +527,9 @@ def main():
                          "timed next to it and reported as `weak_scaling`.  weak: that leg alone, as `value`, labelled with its aggregate shape")
     ap.add_argument("--sync-per-epoch", type=int, default=int(os.environ.get("QREC_REPLICATED_SYNCS", "0")),
                     help="reconciliations of the ranks' item rows per epoch: delta all-reduces of the replicated layout, minimum number of exchange "
-                         "batches of the sharded one.  0 = dist.reconciliations_per_epoch: one per rank (one per epoch leaves the +-0.002 Recall@20 "
-                         "bar at 4 ranks, profiles/r04_paired_recall.json); 1 = the epoch close's fused all-reduce alone")
+                         "batches of the sharded one.  0 = dist.reconciliations_per_epoch: 1 up to two ranks, 2 beyond (the smallest count whose paired "
+                         "Recall@20 runs stay inside +-0.002 at the peak and at the last epoch: the table in that function's docstring); "
+                         "1 = the epoch close's fused all-reduce alone")
     ap.add_argument("--hot-rows", type=int, default=int(os.environ.get("QREC_REPLICATED_HOT_ROWS", "0")),
                     help="replicated layout: the reconciliations INSIDE an epoch cover only this many item rows, the ones with the most positives (the "
                          "epoch close still reconciles the whole table).  0 = whole table every time (default).  Measured (paired Recall@20, "
@@ -479,6 +541,9 @@ def main():
                     help="sharded mode: triplets per exchange batch and rank (2^20: at most 2^21 distinct item rows in a rank's cache, 1 GiB at "
                          "d = 128; an epoch of 2^19 triplets or more is split into at least two batches, so that the next epoch's plan hides "
                          "in front of the last one)")
+    ap.add_argument("--config4-triplets", type=int, default=-1,
+                    help="N > 1: triplets per epoch and rank of the `config4_sharded` leg (its users and items scale along: 25 M = BASELINE config "
+                         "#4's share of one of 8 GPUs = the default; the one-device functional tests default to 0 and pass a small number; 0 skips it)")
     ap.add_argument("--shard-pipeline", action="store_true", default=os.environ.get("QREC_SHARD_PIPELINE") == "1",
                     help="sharded mode: fetch batch k + 1 under batch k's SGD kernel, on a second stream and communicator (one more batch of "
                          "staleness).  Off by default: at the Yelp2018 shape the fetch is 10 MB per batch and the gather/copy kernels "
@@ -536,6 +601,9 @@ def main():
                                    "destroy": lambda self: None})()
     elif use_dist:
         comm = qd.make_comm(control)
+    # first contact with the communicator, before anything is timed: a tiny all-reduce and a ragged all-to-all round trip, checked, under a
+    # watchdog -- a wrong value raises, a hang ends the process with one line on stderr (qrec_amd/dist.py preflight)
+    pre = qd.preflight(comm, stream=None, timeout_s=float(os.environ.get("QREC_PREFLIGHT_TIMEOUT", "90"))) if (use_dist and not no_comm) else None
 
     # ---- workload: resident in HBM before timing ------------------------------------------
     data = make_dataset(args.shape)
@@ -579,6 +647,9 @@ def main():
         else:
             n_batches = syncs
         sgd = BprSgd(tables, l_u, l_items, CSR(l_indptr, l_items), schedule=args.schedule, n_items=I, batches=n_batches, chunk=CHUNK)
+        # one launch per epoch: at least 8 rounds of the persistent grid whatever the epoch's size (engine.grid_for_epoch; nothing changes at
+        # the Yelp2018 shape's 1.25 M triplets, a two-rank share of it runs chunks of 16)
+        CHUNK, GROUPS = (CHUNK, 0) if args.chunk else sgd.launch_grid()
         sampler_seed = SEED + 7919 * rank
         dstep = None
         if use_dist and sharded:
@@ -619,7 +690,7 @@ def main():
                 dstep.prepare_ahead(sgd)                                # --plan-ahead: on the plan stream instead
                 return
             sgd.epoch_device_async(REG_U, REG_I, MAX_LR, tol=0.0, chunk=CHUNK, variant=args.variant, stream=main,
-                                   flush_every=flush_every, events=pair, dist=dstep)   # BPR.py:45-53,40 + iterativeRecommender.py:88-104
+                                   flush_every=flush_every, events=pair, dist=dstep, groups=GROUPS)   # BPR.py:45-53,40 + iterativeRecommender.py:88-104
             sgd.prefetch_negatives_device(sampler_seed, k + 1)          # side stream, under the SGD kernel
 
         def restart():
@@ -718,7 +789,7 @@ def main():
         if sharded and moved is not None and world > 1:
             predicted = {"all_links_1071GBps": moved / world / 1071e9 * 1e3, "one_link_153GBps": moved / world / 153e9 * 1e3,
                          "what": "bytes leaving one rank per epoch / link rate; arithmetic, not measured"}
-        multi = {"rccl_ranks": int(per_rank[:, 1].min()), "rccl_ranks_agree": bool((per_rank[:, 1] == per_rank[0, 1]).all()),
+        multi = {"preflight": pre, "rccl_ranks": int(per_rank[:, 1].min()), "rccl_ranks_agree": bool((per_rank[:, 1] == per_rank[0, 1]).all()),
                  "rank_devices": [int(x) for x in per_rank[:, 3]], "rccl": lib,
                  "transport": "rccl" if hasattr(comm, "query") else type(comm).__name__,
                  "kernel_ms_per_rank": {"min": float(per_rank[:, 0].min()), "max": float(per_rank[:, 0].max()),
@@ -740,6 +811,22 @@ def main():
             ep = args.recall_epochs or (40 if ds == "yelp2018-clustered" else 25)
             recall_multi = multi_gpu_recall(capi, qd, control, comm, world, rank, args.dist_mode if use_dist else "replicated", args.schedule, ds,
                                             LR0, ep, 5, args.shard_batch, qd.reconciliations_per_epoch(world, args.sync_per_epoch))
+
+    config4 = None
+    if args.config4_triplets < 0:
+        args.config4_triplets = 0 if one_device else 25_000_000
+    if world > 1 and not args.no_extras and args.config4_triplets > 0 and not no_comm:      # every rank takes part
+        scale = args.config4_triplets / 25_000_000
+        config4 = config4_sharded_leg(capi, qd, control, comm, world, rank, args.shard_batch, qd.reconciliations_per_epoch(world, args.sync_per_epoch),
+                                      users=max(1000, int(1_250_000 * scale)), items=max(1000, int(1_000_000 * scale)), triplets=args.config4_triplets)
+        if strong and recall_multi is not None and args.dist_mode != "sharded":
+            # ... and the Recall@20 of THAT layout: the paired run of the strong-scaling leg again with the item table row-sharded (at config
+            # #4's own size a CPU reference is 30 s per epoch: the layout is judged at the Yelp2018 shape, like the replicated one)
+            ds = "yelp2018-clustered" if args.recall_dataset == "auto" else args.recall_dataset
+            rs = multi_gpu_recall(capi, qd, control, comm, world, rank, "sharded", args.schedule, ds, LR0, args.recall_epochs or (40 if ds == "yelp2018-clustered" else 25), 5,
+                                  args.shard_batch, qd.reconciliations_per_epoch(world, args.sync_per_epoch))
+            if rank == 0:
+                config4["recall_at_20_of_the_layout"] = rs
 
     if rank == 0:
         n_job = n_full if (strong or world == 1) else world * n
@@ -805,6 +892,8 @@ def main():
                                    "epochs_per_step": weak_leg["inner"], "kernel_ms": weak_leg["avg_kernel_ms"]}
         if recall_multi is not None:
             out["recall_at_20"] = recall_multi
+        if config4 is not None:
+            out.setdefault("other_configs", {})["config4_sharded"] = config4
         if world == 1 and not use_dist:
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(u, items, indptr, I, U)

@@ -186,6 +186,70 @@ def make_comm(control: ControlPlane):
     return _capi.Comm(control.world, control.rank, uid)
 
 
+def preflight(comm, kern=_capi, stream=None, timeout_s: float = 90.0, on_hang=None) -> dict:
+    """First contact with the data-plane communicator, before anything is timed (round 5): a tiny all-reduce and an
+    ``alltoall_rows`` round trip with ragged row counts, both checked against what they must return, under a watchdog.
+
+    * all-reduce: 256 floats, element k = rank + 1 + k  ->  world (world + 1) / 2 + world k on every rank;
+    * all-to-all: rank r sends peer p  1 + (r + p) % 3  rows of 64 floats, every float = 1000 r + p + 1; what arrives from p must be
+      1000 p + r + 1; the rows then travel BACK and must equal what was sent.
+    A wrong value raises RuntimeError naming the collective, the rank and the first bad element.  A collective that never completes
+    (mismatched ranks, an IPC mode the driver refuses, a dead peer) would otherwise hang the job silently: the checks run in a
+    daemon thread, and when it has not finished after ``timeout_s`` seconds ``on_hang(reason)`` is called -- by default one line on
+    stderr and ``os._exit(3)`` (a blocked HIP stream synchronise cannot be interrupted from Python).  Returns what was exchanged."""
+    import threading
+    world, rank = int(comm.world), int(comm.rank)
+    result: dict = {}
+
+    def checks():
+        try:
+            n = 256
+            mine = (np.arange(n, dtype=np.float32) + (rank + 1)).astype(np.float32)
+            buf = kern.DeviceBuffer.from_numpy(mine)
+            comm.allreduce(buf, n, kern.F32, stream)
+            got = buf.numpy(stream)
+            want = (world * (world + 1) / 2 + world * np.arange(n)).astype(np.float32)
+            if not np.array_equal(got, want):
+                k = int(np.flatnonzero(got != want)[0])
+                raise RuntimeError(f"preflight all-reduce: rank {rank} of {world} got {got[k]!r} at element {k}, expected {want[k]!r}")
+            cols = 64
+            s_rows = [1 + (rank + p) % 3 for p in range(world)]
+            r_rows = list(s_rows)                                             # 1 + (p + r) % 3 is symmetric in (r, p)
+            send = np.concatenate([np.full((s_rows[p], cols), 1000 * rank + p + 1, np.float32) for p in range(world)])
+            want_in = np.concatenate([np.full((r_rows[p], cols), 1000 * p + rank + 1, np.float32) for p in range(world)])
+            d_send, d_recv, d_back = kern.DeviceBuffer.from_numpy(send), kern.DeviceBuffer(want_in.shape, np.float32), kern.DeviceBuffer(send.shape, np.float32)
+            comm.alltoall_rows(d_send, s_rows, d_recv, r_rows, cols * 4, stream)
+            got_in = d_recv.numpy(stream)
+            if not np.array_equal(got_in, want_in):
+                k = int(np.flatnonzero((got_in != want_in).any(1))[0])
+                raise RuntimeError(f"preflight all-to-all: rank {rank} of {world} received {got_in[k, 0]!r} in row {k}, expected {want_in[k, 0]!r}")
+            comm.alltoall_rows(d_recv, r_rows, d_back, s_rows, cols * 4, stream)
+            back = d_back.numpy(stream)
+            if not np.array_equal(back, send):
+                k = int(np.flatnonzero((back != send).any(1))[0])
+                raise RuntimeError(f"preflight all-to-all round trip: rank {rank} of {world} got row {k} back as {back[k, 0]!r}, sent {send[k, 0]!r}")
+            result.update(ok=True, world=world, allreduce_floats=n, alltoall_rows_sent=int(sum(s_rows)), row_bytes=cols * 4,
+                          checksum=float(np.float64(got.sum()) + np.float64(got_in.sum())))
+        except BaseException as e:      # noqa: BLE001 -- handed to the caller's thread
+            result["error"] = e
+
+    th = threading.Thread(target=checks, name="qrec-preflight", daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        reason = (f"qrec preflight: rank {rank} of {world}: the first collectives did not complete within {timeout_s:.0f} s "
+                  f"(communicator {type(comm).__name__}; check that all {world} ranks started, HSA_ENABLE_IPC_MODE_LEGACY=0, one GPU per rank)")
+        if on_hang is not None:
+            on_hang(reason)
+            return {"ok": False, "reason": reason}
+        import sys as _sys
+        print(reason, file=_sys.stderr, flush=True)
+        os._exit(3)
+    if "error" in result:
+        raise result["error"]
+    return result
+
+
 # ---- BPR, replicated item table ------------------------------------------------------------------------------------
 class ReplicatedTableSync:
     """Delta all-reduce of a replicated fp32 table resident on the device.  ``sync()`` after a step makes every replica
@@ -528,12 +592,30 @@ def agree_on_batches(control: ControlPlane, n_local: int, batch: int, split_from
 
 def reconciliations_per_epoch(world: int, requested: int = 0) -> int:
     """How many times per epoch the ranks' copies of the item rows are reconciled (replicated layout: delta all-reduces; sharded
-    layout: at least that many exchange batches).  0 = the default: ``world``.  Measured with the paired Recall@20 design on the
-    planted-community graph (tools/paired_recall.py, profiles/r04_paired_recall.json; |Recall@20 - order-exact training of the whole
-    problem| at the peak epoch, BPR.conf's rate): ONE reconciliation per epoch is 0.0011 / 0.0029 / 0.0016 away at 2 / 4 / 8 ranks
-    (outside the +-0.002 bar at 4), ``world`` reconciliations 0.0003 / 0.0006 / 0.0002 -- between two of them a rank does not see what
-    the others did to the rows they share, and that window has to shrink as the ranks multiply."""
-    return int(requested) if int(requested) > 0 else max(1, int(world))
+    layout: at least that many exchange batches).  0 = the default: 1 up to two ranks, 2 beyond.
+
+    Between two reconciliations a rank does not see what the others did to the rows they share: of the T updates an item row takes per
+    epoch, a rank misses (G - 1) / G of those in its window of 1 / K epoch -- a share (G - 1) / (G K) of T.  Measured with the paired
+    Recall@20 design on the planted-community graph at BPR.conf's rate (tools/paired_recall.py; |Recall@20 - order-exact training of
+    the whole problem| at the reference's peak epoch / at the last epoch, two seeds where two numbers are given):
+
+        G  K   missed share   peak            final            epoch (one rank's share, links excluded)
+        2  1   0.50           0.0009 0.0008   0.0011 0.0007    0.373 ms  1.71x
+        4  1   0.75           0.0029          0.0016           0.224 ms  2.84x      <- outside the +-0.002 bar
+        4  2   0.38           0.0013 0.0010   0.0007 0.0012    0.252 ms  2.53x
+        4  4   0.19           0.0006          0.0000           0.288 ms  2.21x
+        8  1   0.88           0.0016          0.0031           0.158 ms  4.02x      <- outside
+        8  2   0.44           0.0007 0.0008   0.0007 0.0009    0.178 ms  3.58x
+        8  4   0.22           0.0003 0.0004   0.0004 0.0003    0.218 ms  2.92x
+        8  8   0.11           0.0002          0.0000           0.310 ms  2.05x
+
+    (profiles/r04_paired_recall_studies.json part B, profiles/r05_scaling_recall.json, profiles/r05_strong_scaling_bound.json).  Every
+    setting with a missed share of 0.5 or less is inside the bar at the peak AND at the last epoch; rounds 1-4 reconciled once per rank
+    (K = G: the safest row of each block and the slowest -- eight whole-table delta / apply passes and eight launches of 19 k triplets
+    at 8 ranks).  The default is now the smallest K with (G - 1) / (G K) <= 0.5."""
+    if int(requested) > 0:
+        return int(requested)
+    return 1 if int(world) <= 2 else 2
 
 
 # ---- graph models (LightGCN / NGCF / SimGCL ...) ---------------------------------------------------------------------

@@ -209,6 +209,9 @@ class BprSgd:
         # groups a reconciliation batch (replicated layout, K > 1) spreads over: a batch of a few ten thousand triplets is bound by the
         # per-group chain of dependent row reads (~1.9 us per triplet), not by the atomic units -- more groups, shorter chains
         self.batch_groups = 4096
+        # ONE launch per epoch: at least MIN_ROUNDS rounds of the grid whatever the epoch's size (grid_for_epoch); `launch_grid()` is what
+        # the epoch drivers pass to the kernels
+        self._epoch_grid = grid_for_epoch(self.n, self.chunk) if (max(1, int(batches)) == 1 and schedule != "item-deferred") else (self.chunk, 0)
         self.perm = None
         u = np.ascontiguousarray(u, dtype=np.int32); i = np.ascontiguousarray(i, dtype=np.int32)
         batches = max(1, int(batches))
@@ -262,6 +265,12 @@ class BprSgd:
         if pos is not None:
             srt = pos.sorted_rows()
             self._pos_dev = (DeviceBuffer.from_numpy(srt.indptr), DeviceBuffer.from_numpy(srt.indices))
+
+    def launch_grid(self, min_rounds: int | None = None):
+        """(chunk, groups) for the whole-epoch launch of the one-pass schedules (groups 0 = the launcher's default grid)"""
+        if min_rounds is None:
+            return self._epoch_grid
+        return grid_for_epoch(self.n, self.chunk, min_rounds) if len(self.batch_bounds) == 2 and not self.deferred else (self.chunk, 0)
 
     # -- negatives ---------------------------------------------------------------------------
     def set_negatives(self, j: np.ndarray, stream=None):

@@ -79,8 +79,8 @@ class BPR(IterativeRecommender):
             self._train_sharded(pos, schedule, n_items, dp)
             return
         tables = DeviceTables(self.P, self.Q, self.table_dtype)
-        # several ranks, replicated tables: QREC_REPLICATED_SYNCS = K reconciliations of the replicas per epoch (default 0 = one per rank,
-        # dist.reconciliations_per_epoch: with ONE per epoch the paired Recall@20 runs leave the +-0.002 bar at 4 ranks)
+        # several ranks, replicated tables: QREC_REPLICATED_SYNCS = K reconciliations of the replicas per epoch (default 0 = 1 up to two ranks,
+        # 2 beyond -- dist.reconciliations_per_epoch: with ONE per epoch the paired Recall@20 runs leave the +-0.002 bar at 4 and 8 ranks)
         from ...dist import reconciliations_per_epoch
         syncs = reconciliations_per_epoch(dp.world, int(os.environ.get("QREC_REPLICATED_SYNCS", "0"))) if dp is not None else 1
         if syncs > 1 and schedule == "item-deferred":
@@ -148,7 +148,7 @@ class BPR(IterativeRecommender):
                 sgd.epoch_ordered(self.lRate, self.regU, self.regI)
             else:
                 sgd.take_prefetched_negatives(epoch)
-                sgd.epoch_throughput_async(self.lRate, self.regU, self.regI)
+                sgd.epoch_throughput_async(self.lRate, self.regU, self.regI, chunk=sgd.launch_grid()[0], groups=sgd.launch_grid()[1])
                 sgd.prefetch_negatives_device(self.sampler_seed, epoch + 1)   # overlaps the SGD kernel
             nll, sp, sq = sgd.epoch_stats()
             self.loss = nll + self.regU * sp + self.regI * sq
@@ -204,7 +204,7 @@ class BPR(IterativeRecommender):
         SGD kernel the replicas are reconciled by summing the ranks' deltas (users' rows: disjoint, exact; item rows:
         every rank's updates kept -- qrec_amd/dist.py), sum(-log sigma) is added over the ranks, and every rank's
         device-side driver then takes the same decision on identical tables."""
-        chunk = sgd.chunk          # the chunk the stored order was dealt in (BprSgd.__init__)
+        chunk, groups = sgd.launch_grid()      # the chunk the stored order was dealt in; one launch per epoch: >= 8 rounds of the grid (engine.grid_for_epoch)
         sharded = step is not None
         if dp is not None and step is None:
             from ...dist import ReplicatedStep, ReplicatedTableSync
@@ -244,7 +244,7 @@ class BPR(IterativeRecommender):
                 sgd.epoch_device_async(self.regU, self.regI, self.maxLRate, tol=1e-3, chunk=chunk, dist=step, stream=stream,
                                        after_start=lambda e=epoch: sgd.prefetch_negatives_device(self.sampler_seed, e + 1))
             else:
-                sgd.epoch_device_async(self.regU, self.regI, self.maxLRate, tol=1e-3, chunk=chunk, dist=step, stream=stream)
+                sgd.epoch_device_async(self.regU, self.regI, self.maxLRate, tol=1e-3, chunk=chunk, dist=step, stream=stream, groups=groups)
                 sgd.prefetch_negatives_device(self.sampler_seed, epoch + 1)      # released under this epoch's SGD kernel
             ev = capi.Event(); ev.record(stream); closed.append(ev)
             if epoch >= depth:

@@ -103,6 +103,52 @@ def _hot_worker(rank, world, port, out):
     control.shutdown()
 
 
+def _preflight_worker(rank, world, port, out):
+    control, comm = _join(rank, world, port)
+    out[rank] = qd.preflight(comm, kern=HK, timeout_s=60)
+    control.shutdown()
+
+
+def test_preflight_round_trip_over_two_processes():
+    """dist.preflight (round 5: what `bench.py --gpus N` and the drop-in classes run before anything is timed) over two gloo processes: the
+    tiny all-reduce and the ragged all-to-all round trip return what they must; both ranks report the same all-reduce share of the checksum"""
+    world = 2
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_preflight_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert out[0]["ok"] and out[1]["ok"] and out[0]["world"] == 2 and out[0]["allreduce_floats"] == 256
+    assert out[0]["alltoall_rows_sent"] == (1 + 0) + (1 + 1) and out[1]["alltoall_rows_sent"] == (1 + 1) + (1 + 2)
+
+
+def test_preflight_names_a_wrong_collective_and_a_hung_one():
+    """... a transport that loses the all-to-all's payload is named (collective, rank, row); one that never returns trips the watchdog
+    with a one-line reason instead of hanging the job"""
+    import time
+
+    class Alone:
+        world, rank = 1, 0
+        def allreduce(self, *a, **k): pass                                     # world 1: the identity IS right
+        def alltoall_rows(self, send, s_rows, recv, r_rows, row_bytes, stream=None):
+            HK.memcpy_h2d(recv, send.a, send.nbytes)
+
+    assert qd.preflight(Alone(), kern=HK, timeout_s=30)["ok"]
+
+    class Lossy(Alone):
+        def alltoall_rows(self, *a, **k): pass
+    with pytest.raises(RuntimeError, match="preflight all-to-all: rank 0 of 1 received"):
+        qd.preflight(Lossy(), kern=HK, timeout_s=30)
+
+    class Wrong(Alone):
+        world = 2                                                              # claims two ranks, sums one
+    with pytest.raises(RuntimeError, match="preflight all-reduce: rank 0 of 2 got"):
+        qd.preflight(Wrong(), kern=HK, timeout_s=30)
+
+    class Hung(Alone):
+        def allreduce(self, *a, **k): time.sleep(5)
+    said = []
+    r = qd.preflight(Hung(), kern=HK, timeout_s=0.3, on_hang=said.append)
+    assert r["ok"] is False and len(said) == 1 and "did not complete within" in said[0] and "\n" not in said[0]
+
+
 _HOT = np.array([3, 7, 8, 100, 299], np.int32)
 
 

@@ -497,7 +497,7 @@ def test_bench_typed_with_gpus_2_starts_its_own_ranks(tmp_path):
     env.update(QREC_DIST_TEST_ONE_DEVICE="1", QREC_DIST_TEST_DUMP=str(tmp_path), QREC_DIST_MODE="replicated")
     env.pop("QREC_SCALING", None)            # the default answers BASELINE.json's question: the ONE problem over N GPUs
     run = subprocess.run(["python3", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs-per-step", "2", "--no-cpu-baseline",
-                          "--shape", "ml1m", "--recall-dataset", "lastfm", "--recall-epochs", "10"], cwd=ROOT, env=env, capture_output=True, text=True,
+                          "--shape", "ml1m", "--recall-dataset", "lastfm", "--recall-epochs", "10", "--config4-triplets", "150000"], cwd=ROOT, env=env, capture_output=True, text=True,
                          timeout=900)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
     lines = [l for l in run.stdout.splitlines() if l.strip()]
@@ -509,7 +509,7 @@ def test_bench_typed_with_gpus_2_starts_its_own_ranks(tmp_path):
     assert mg["rccl_ranks"] == 2 and mg["rccl_ranks_agree"] and len(mg["kernel_ms_per_rank"]["all"]) == 2
     assert mg["kernel_ms_per_rank"]["min"] > 0 and mg["kernel_ms_per_rank"]["max"] >= mg["kernel_ms_per_rank"]["min"]
     assert sum(mg["triplets_per_epoch_per_rank"]) == out["config"]["triplets_per_epoch_per_gpu"] + mg["triplets_per_epoch_per_rank"][1]
-    assert mg["collectives_per_epoch"]["all_reduce"] == 2 and mg["collectives_per_epoch"]["payload_bytes_per_rank"] > 3706 * 64 * 4    # one reconciliation per rank
+    assert mg["collectives_per_epoch"]["all_reduce"] == 1 and mg["collectives_per_epoch"]["payload_bytes_per_rank"] > 3706 * 64 * 4    # two ranks: the epoch close's fused all-reduce alone (dist.reconciliations_per_epoch)
     assert (tmp_path / "rank0.npz").exists() and (tmp_path / "rank1.npz").exists()
     # round 4: strong scaling is the default and the workload string says what is being scaled; the weak-scaling figure stands next
     # to it under its aggregate shape; the collectives' bytes come with the link-time arithmetic; and the metric's second half --
@@ -520,7 +520,16 @@ def test_bench_typed_with_gpus_2_starts_its_own_ranks(tmp_path):
     assert ws["value"] > 0 and "12080x3706" in ws["workload"]
     pl = mg["predicted_link_ms_per_epoch"]
     assert pl["one_ring_153GBps"] > pl["seven_rings_1071GBps"] > 0
-    assert mg["collectives_per_epoch"]["ring_wire_bytes_per_rank"] == 2 * mg["collectives_per_epoch"]["payload_bytes_per_rank"]     # 2 (G - 1) / G x payload x 2 syncs at G = 2
+    assert mg["collectives_per_epoch"]["ring_wire_bytes_per_rank"] == mg["collectives_per_epoch"]["payload_bytes_per_rank"]     # 2 (G - 1) / G x payload x 1 sync at G = 2
+    # round 5: first contact with the communicator is a checked, timed-out preflight; and the line carries north_star's layout -- a (here
+    # scaled-down) share of config #4 per rank, item table row-sharded, per-batch all-to-all -- with bytes moved, time per rank, and the
+    # layout's own paired Recall@20
+    assert mg["preflight"]["ok"] and mg["preflight"]["world"] == 2 and mg["preflight"]["alltoall_rows_sent"] == 3
+    c4 = out["other_configs"]["config4_sharded"]
+    assert "row-sharded x2" in c4["workload"] and c4["batches_per_epoch"] >= 1 and c4["bytes_leaving_all_ranks_per_epoch"] > 0 and c4["ms_per_epoch"] > 0
+    assert len(c4["epoch_ms_per_rank_by_events"]["all"]) == 2 and c4["triplet_updates_per_s_job"] == pytest.approx(2 * 150000 / (c4["ms_per_epoch"] * 1e-3))
+    rs = c4["recall_at_20_of_the_layout"]
+    assert rs["layout"] == "sharded" and rs["ranks"] == 2 and rs["dataset"] == "lastfm" and 0.05 < rs["recall"] < 0.2
     rc = out["recall_at_20"]
     assert rc["dataset"] == "lastfm" and rc["ranks"] == 2 and rc["layout"] == "replicated" and rc["epochs"] == 10 and rc["bar"] == 0.002
     assert 0.05 < rc["recall_exact_order"] < 0.2 and 0.05 < rc["recall"] < 0.2 and rc["abs_diff"] == pytest.approx(abs(rc["recall"] - rc["recall_exact_order"]))

@@ -969,7 +969,7 @@ def test_auto_schedule_rule_and_reconciliations():
     assert resolve_schedule(DEFER_MIN_TRIPLETS, np.ones(10)) == ("item-deferred", 4) and resolve_schedule(25_000_000, None) == ("item-deferred", 4)
     assert resolve_schedule(DEFER_MIN_TRIPLETS - 1, None) == ("item", None)
     assert resolve_schedule(10 ** 9, None, "user") == ("user", None)              # an explicit choice is never overridden
-    assert [reconciliations_per_epoch(g) for g in (1, 2, 4, 8)] == [1, 2, 4, 8] and reconciliations_per_epoch(8, 1) == 1 and reconciliations_per_epoch(2, 5) == 5
+    assert [reconciliations_per_epoch(g) for g in (1, 2, 4, 8)] == [1, 1, 2, 2] and reconciliations_per_epoch(8, 1) == 1 and reconciliations_per_epoch(2, 5) == 5
 
 
 def test_paired_recall_harness_host_logic():

@@ -95,7 +95,7 @@ def build_rank(d, mode, world, rank, layout, P0, Q0, shard_batch=1 << 20, syncs=
     """(tables, sgd, chunk, lo, hi, groups) of one rank: its users' rows of P, the item table whole (replicated) or its row shard.
     ``rounds``: engine.grid_for_epoch's min_rounds (None = the engine's default, 0 / 1 = the launcher's own grid, rounds 1-4)"""
     from qrec_amd import dist as qd
-    from qrec_amd.engine import MIN_ROUNDS, BprSgd, DeviceTables, balanced_chunk, grid_for_epoch
+    from qrec_amd.engine import BprSgd, DeviceTables, balanced_chunk
     from qrec_amd.interactions import CSR
     schedule, S, sub_chunk = parse_mode(mode)
     lo, hi, lp, li, lu = _rank_problem(d, world, rank)
@@ -103,11 +103,9 @@ def build_rank(d, mode, world, rank, layout, P0, Q0, shard_batch=1 << 20, syncs=
     t = DeviceTables(P0[lo:hi], qd.shard_item_rows(Q0, world, rank) if sharded else Q0, np.float32)
     chunk = balanced_chunk(int(li.size))
     batches = n_batches_for(d, world, layout, shard_batch, syncs)
-    groups = 0
-    if batches == 1 and schedule != "item-deferred":        # (an epoch in batches: engine.launch_chunk per batch, unchanged)
-        chunk, groups = grid_for_epoch(int(li.size), chunk, MIN_ROUNDS if rounds is None else rounds)
     sgd = BprSgd(t, lu, li, CSR(lp, li), schedule=schedule, n_items=d["n_items"], batches=batches,
                  chunk=chunk, sub_epochs=S, sub_chunk=sub_chunk, item_run=item_run)
+    chunk, groups = sgd.launch_grid(rounds)                 # (an epoch in batches: engine.launch_chunk per batch, unchanged)
     return t, sgd, chunk, lo, hi, groups
 
 
@@ -348,7 +346,7 @@ def plan_bpr_conf(seeds=range(1, 17), rounds=(0, 8, 32), modes=("item",), epochs
         for mode in modes:
             for r in rounds:
                 cases.append(dict(dataset=dataset, lr0=0.01, seed=int(seed), init_seed=int(seed), dim=50, mode=mode, epochs=epochs, eval_every=10,
-                                  rounds=int(r), extra_topn=[10], order_null=True))
+                                  **({} if r is None else {"rounds": int(r)}), extra_topn=[10], order_null=True))      # (rounds None: the engine's default)
     return cases
 
 
