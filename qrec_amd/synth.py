@@ -27,6 +27,8 @@ SHAPES = {
     # a planted-community graph whose epoch (6 M triplets) is in the regime where `auto` picks the deferred schedule in sub-epochs
     # (engine.resolve_schedule: >= 5 M triplets per epoch); the fidelity tests of that choice run on it
     "xl6m-clustered": (160000, 100000, 6000000, 1500000, 6006),
+    # ... and one at the size the HBM-resident roofline figure is quoted on (25 M triplets per epoch; with d = 128 its tables are 0.54 GB)
+    "xl25m-clustered": (650000, 400000, 25000000, 6250000, 2525),
     "tiny": (300, 200, 6000, 1500, 7),
     "small": (2000, 1500, 60000, 15000, 11),
 }
