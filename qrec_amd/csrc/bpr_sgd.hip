@@ -307,12 +307,13 @@ __global__ __launch_bounds__(64) void sbpr_ordered_kernel(
         load_row(Q, it, qi); load_row(Q, jt, qj);
         if (kt < 0) {
             const double q_old = norm2(qi) + norm2(qj);
-            const T s = sigmoid(((dot(pu, qi) - dot(pu, qj)) + bias[it]) - bias[jt]);
+            const T x = ((dot(pu, qi) - dot(pu, qj)) + bias[it]) - bias[jt];
+            const T s = sigmoid(x);
             pair_step(pu, qi, qj, lr * (T(1) - s));
             store_row(Q, it, qi); store_row(Q, jt, qj);
             sQ += norm2(qi) + norm2(qj) - q_old;
             if constexpr (sizeof(T) == 8) loss += -log((double)s);
-            else loss += neg_log_sigmoid((double)(((dot(pu, qi) - dot(pu, qj)) + bias[it]) - bias[jt]));   // (fp32 tables: the stable form, pre-update score not kept -- fp64 is the parity mode)
+            else loss += neg_log_sigmoid((double)x);      // fp32 tables: the stable form of -log(sigmoid(x)) (bpr_ordered_kernel)
             continue;
         }
         const bool alias = jt == kt;

@@ -50,6 +50,26 @@ def grad_check(got, want, what, bound=GRAD_TOL):
     check(what, rel_err(got, want), bound)
 
 
+SOLID_FLOOR = 1e-2
+
+
+def solid_check(what, got, ref, grad0, loose, solid_bound=GRAD_TOL):
+    """Trained variables after the fixture's 12-18 Adam steps.  Adam's step is lr * m / (sqrt(v) + eps): on a
+    coordinate whose gradient is rounding noise the step is ~lr in a direction the noise decides, so two correct fp32 implementations
+    end |lr x steps| apart there whatever their parity.  SOLID coordinates -- |first-step gradient| >= SOLID_FLOOR x the variable's
+    largest |first-step gradient| (the fixture's grad0) -- are held to north_star's 1e-5; the whole variable to the documented looser
+    bound ``loose``."""
+    got, ref, g = np.asarray(got, np.float64), np.asarray(ref, np.float64), np.abs(np.asarray(grad0, np.float64))
+    assert got.shape == ref.shape == g.shape, (what, got.shape, ref.shape, g.shape)
+    if os.environ.get("QREC_SOLID_PROBE"):      # development: the error by floor, into the ledger
+        for fl in (1e-3, 1e-2, 3e-2, 1e-1, 3e-1):
+            mk = g >= fl * g.max()
+            check(f"probe {what} floor {fl:g} share {mk.mean():.3f}", rel_err(got[mk], ref[mk]), 1.0)
+    solid = g >= SOLID_FLOOR * g.max()
+    check(f"{what}: solid coordinates (|first-step gradient| >= {SOLID_FLOOR:g} of its maximum)", rel_err(got[solid], ref[solid]), solid_bound, ctx=float(solid.mean()))
+    check(f"{what}: all coordinates", rel_err(got, ref), loose)
+
+
 def batches(z):
     off = z["batch_offsets"]
     for k in range(off.size - 1):
@@ -180,7 +200,8 @@ def test_simgcl_trainer_with_the_recorded_sign_pattern_follows_the_reference_run
     # (observed: losses <= 7e-7 on all twelve steps; tables 3e-5, main embeddings 6e-5 -- the CPU restatement under the same signs: 2.7e-5 /
     # 3.5e-5; without the recorded signs: 2.8e-4 ... 4.2e-4.  Twelve Adam steps move a coordinate whose gradient is rounding noise by
     # ~lr per step in a direction the noise decides; the main embeddings are two propagations of those tables)
-    check("SimGCL tables after 12 steps under the recorded sign pattern", rel_err(np.concatenate([U, V]), E), 1e-4)
+    solid_check("SimGCL tables after 12 steps under the recorded sign pattern", np.concatenate([U, V]), E,
+                np.concatenate([z["grad0_" + names["U"]], z["grad0_" + names["V"]]]), 1e-4)
     Um, Vm = tr.main_embeddings()
     check("SimGCL main user embeddings under the recorded sign pattern", rel_err(Um, z["score_U"]), 1e-4)
     check("SimGCL main item embeddings under the recorded sign pattern", rel_err(Vm, z["score_V"]), 1e-4)
@@ -229,8 +250,8 @@ def test_sgl_trainer_follows_the_reference_run(name):
             gU, gV = tr.gradients()
             grad_check(gU, z["grad0_U"], f"SGL aug {aug} dU, step 0"); grad_check(gV, z["grad0_V"], f"SGL aug {aug} dV, step 0")
     U, V = tr.ego_embeddings()
-    check("rel_err(U, z['final_U'])", rel_err(U, z["final_U"]), 1e-5)
-    check("rel_err(V, z['final_V'])", rel_err(V, z["final_V"]), 2e-5)
+    solid_check(f"SGL aug {aug} user table after the run", U, z["final_U"], z["grad0_U"], 1e-5)
+    solid_check(f"SGL aug {aug} item table after the run", V, z["final_V"], z["grad0_V"], 2e-5)
     Um, Vm = tr.main_embeddings()
     check("rel_err(Um, z['score_U'])", rel_err(Um, z["score_U"]), 1e-5)
     check("rel_err(Vm, z['score_V'])", rel_err(Vm, z["score_V"]), 2e-5)
@@ -259,7 +280,7 @@ def test_buir_trainer_follows_the_reference_run():
             grad_check(gE[:nu], z["grad0_U"], "BUIR dU, step 0"); grad_check(gE[nu:], z["grad0_V"], "BUIR dV, step 0")
             grad_check(gW, z["grad0_online_mat"], "BUIR dW, step 0"); grad_check(gb[None, :], z["grad0_online_bias"], "BUIR db, step 0")
     E = np.concatenate([z["final_U"], z["final_V"]]); Tt = np.concatenate([z["final_t_U"], z["final_t_V"]])
-    check("rel_err(tr.online_tables(), E)", rel_err(tr.online_tables(), E), 1e-5)
+    solid_check("BUIR online tables after the run", tr.online_tables(), E, np.concatenate([z["grad0_U"], z["grad0_V"]]), 1e-5)
     check("rel_err(tr.target_tables(), Tt)", rel_err(tr.target_tables(), Tt), 1e-5)
     Wg, bg = tr.weights()
     check("rel_err(Wg, z['final_online_mat'])", rel_err(Wg, z["final_online_mat"]), 1e-5)
@@ -321,7 +342,7 @@ def test_sept_trainer_follows_the_reference_run():
     # trained tables carry what Adam makes of last-bit gradient differences on coordinates whose gradient is ~0 (the step is
     # normalised to lr whatever the gradient's size) and of the float atomics' summation order, which changes from launch to
     # launch -- observed 2.5e-6 ... 1.3e-5 over the runs of this round
-    check("rel_err(np.concatenate([U, V]), np.concatenate([z['final_U'], z['final_V']]))", rel_err(np.concatenate([U, V]), np.concatenate([z["final_U"], z["final_V"]])), 5e-5)
+    solid_check("SEPT tables after 18 steps", np.concatenate([U, V]), np.concatenate([z["final_U"], z["final_V"]]), np.concatenate([z["grad0_U"], z["grad0_V"]]), 5e-5)
     Ur, Vr = tr.rec_embeddings()
     check("rel_err(Ur, z['score_U'])", rel_err(Ur, z["score_U"]), 5e-5)
     check("rel_err(Vr, z['score_V'])", rel_err(Vr, z["score_V"]), 5e-5)
@@ -354,8 +375,8 @@ def test_mhcn_trainer_follows_the_reference_run():
     got = tr.parameters()
     for a, b in key.items():
         check("rel_err(got[a], z['final_' + b])", rel_err(got[a], z["final_" + b]), 1e-5, ctx=a)
-    check("rel_err(got['U'], z['final_U'])", rel_err(got["U"], z["final_U"]), 1e-5)
-    check("rel_err(got['V'], z['final_V'])", rel_err(got["V"], z["final_V"]), 5e-5)
+    solid_check("MHCN user table after the run", got["U"], z["final_U"], z["grad0_U"], 1e-5)
+    solid_check("MHCN item table after the run", got["V"], z["final_V"], z["grad0_V"], 5e-5)
     Ud, Vd = tr.final_embeddings()
     check("rel_err(Ud, z['score_U'])", rel_err(Ud, z["score_U"]), 1e-5)
     check("rel_err(Vd, z['score_V'])", rel_err(Vd, z["score_V"]), 5e-5)
