@@ -28,8 +28,8 @@ N > 1, one process per GPU (qrec_amd/dist.py; collectives are RCCL bound directl
 sharded: item table row-sharded, per batch an all-to-all of the distinct rows a rank's triplets touch and of their
 updates.  --scaling strong (default since round 4: BASELINE.json quotes the metric on THE Yelp2018 shape at 1/2/4/8 GPUs): the same
 31,668 users split over the ranks = `value`; the weak-scaling figure (every rank its own 31,668 users) is timed next to it and
-reported as `weak_scaling` under its aggregate shape; --scaling weak makes that leg `value`.  --sync-per-epoch (default: 1 up to two ranks, 2 beyond)
-/ --hot-rows: how often, and over which rows, the ranks' item rows are reconciled inside an epoch.
+reported as `weak_scaling` under its aggregate shape; --scaling weak makes that leg `value`.  --sync-per-epoch (default: 1 up to two ranks, 2 beyond):
+how often the ranks' item rows are reconciled inside an epoch.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     -- the SGD kernel's algorithmic bytes/launch over its mean launch time (HIP events on the launch
@@ -555,11 +555,6 @@ def main():
                          "batches of the sharded one.  0 = dist.reconciliations_per_epoch: 1 up to two ranks, 2 beyond (the smallest count whose paired "
                          "Recall@20 runs stay inside +-0.002 at the peak and at the last epoch: the table in that function's docstring); "
                          "1 = the epoch close's fused all-reduce alone")
-    ap.add_argument("--hot-rows", type=int, default=int(os.environ.get("QREC_REPLICATED_HOT_ROWS", "0")),
-                    help="replicated layout: the reconciliations INSIDE an epoch cover only this many item rows, the ones with the most positives (the "
-                         "epoch close still reconciles the whole table).  0 = whole table every time (default).  Measured (paired Recall@20, "
-                         "planted-community graph, profiles/r04_paired_recall_studies.json part C): 4 ranks at BPR.conf's rate 0.0029 with no inner "
-                         "reconciliation, 0.0014 with 1,024 hot rows (1/37 of the bytes), 0.0008 with 12,288, 0.0006 with the whole table")
     ap.add_argument("--recall-dataset", default="auto", help="N > 1: dataset of the Recall@20 leg (auto: yelp2018-clustered for the Yelp2018 shape)")
     ap.add_argument("--recall-epochs", type=int, default=0, help="epochs of that leg (0: 40 at BPR.conf's rate on the clustered graph, else 25)")
     ap.add_argument("--shard-batch", type=int, default=1 << 20,
@@ -690,8 +685,7 @@ def main():
             dstep = qd.ShardedStep(comm, qd.ShardedItemExchange(comm, I, tables.ld, tables.Q, pipeline=pipe, plan_ahead=ahead), n_batches,
                                    plan_inside=not args.no_plan_inside)
         elif use_dist:
-            hot = qd.hot_item_rows(np.bincount(items, minlength=I), args.hot_rows) if args.hot_rows > 0 and n_batches > 1 else None
-            dstep = qd.ReplicatedStep(comm, qd.ReplicatedTableSync(comm, tables.Q), hot_rows=hot, ld=tables.ld)
+            dstep = qd.ReplicatedStep(comm, qd.ReplicatedTableSync(comm, tables.Q))
         # device copies of the initial state: every step restarts training from it (see step())
         d_P0, d_Q0 = DeviceBuffer.from_numpy(tables._pad(P0)), DeviceBuffer.from_numpy(tables._pad(Q0_local))
         ev, pool = [], []
@@ -804,7 +798,7 @@ def main():
             lib = {"library": path, "version": ver}
         payload = None if sharded else leg["q_floats"] * 4 + 24          # the fused all-reduce: item-table deltas + 3 fp64 loss terms
         syncs = leg["n_batches"] if not sharded else None
-        inner_payload = payload if not (args.hot_rows > 0) else min(args.hot_rows, I) * leg["ld"] * 4      # an inner reconciliation: the whole table, or the hot rows
+        inner_payload = payload                                                  # an inner reconciliation covers the whole table too
         # link-time arithmetic for the collectives of one epoch (NOT a measurement): a ring all-reduce moves 2 (G-1)/G x payload over
         # each rank's links; xGMI is point-to-point, 7 links x ~153 GB/s per GPU (MI355X_MICROARCH.md) -- one ring uses one link per
         # direction, a fully connected 8-GPU node can run up to 7 rings side by side
@@ -823,7 +817,7 @@ def main():
                  "collectives_per_epoch": ({"all_to_all_batches": leg["n_batches"], "calls": 3 * leg["n_batches"] + 1,
                                             "bytes_leaving_all_ranks": moved} if sharded else
                                            {"all_reduce": syncs, "payload_bytes_per_rank": payload,
-                                            "inner_payload_bytes_per_rank": inner_payload, "hot_rows": args.hot_rows if args.hot_rows > 0 else None,
+                                            "inner_payload_bytes_per_rank": inner_payload,
                                             "ring_wire_bytes_per_rank": wire}),
                  "predicted_link_ms_per_epoch": predicted}
 

@@ -686,13 +686,6 @@ int qrec_dist_epoch_post(float *d_Q, float *d_Q_start, const float *d_delta, int
                          int64_t log_capacity, void *stream);
 int qrec_table_delta(const float *d_table, const float *d_start, float *d_delta, int64_t n, void *stream);
 int qrec_table_apply(float *d_table, float *d_start, const float *d_delta, int64_t n, void *stream);
-/* The same reconciliation for a SUBSET of rows, between two full ones (round 4: the hot item rows carry most of the cross-rank conflict,
- * dist.ReplicatedTableSync.sync_rows).  d_rows: n distinct row ids, the same list on every rank.
- *   qrec_table_rows_delta:      d_delta[k] = d_table[d_rows[k]] - d_start[d_rows[k]]          ([n][ld]; all-reduce it)
- *   qrec_table_rows_reconcile:  d_table[d_rows[k]] = d_start[d_rows[k]] = d_start[d_rows[k]] + d_delta_sum[k]
- * Afterwards table - start of these rows holds only what happens from now on, so the epoch's full reconciliation counts nothing twice. */
-int qrec_table_rows_delta(const float *d_table, const float *d_start, int32_t ld, const int32_t *d_rows, int64_t n, float *d_delta, void *stream);
-int qrec_table_rows_reconcile(float *d_table, float *d_start, int32_t ld, const int32_t *d_rows, int64_t n, const float *d_delta_sum, void *stream);
 
 /* Row-sharded item table: item id = r*world + o is local row r of rank o (interleaved, so that popular items spread
  * over the ranks).  qrec_shard_rows = rows a rank holds.

@@ -148,8 +148,6 @@ _SIGNATURES = {
     "qrec_shard_plan_epoch_scratch_bytes": [_i64, _i32, _i32, _vp],
     "qrec_shard_plan_epoch": [_vp, _vp, _vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "qrec_gather_rows": [_vp, _i32, _vp, _i64, _vp, _vp],
-    "qrec_table_rows_delta": [_vp, _vp, _i32, _vp, _i64, _vp, _vp],
-    "qrec_table_rows_reconcile": [_vp, _vp, _i32, _vp, _i64, _vp, _vp],
     "qrec_rows_gather_owned": [_vp, _i32, _i64, _i64, _vp, _i64, _vp, _vp],
     "qrec_rows_scatter_add_owned": [_vp, _i32, _i64, _i64, _vp, _i64, _vp, _vp],
     "qrec_batch_rows_gather": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _i64, _vp, _vp],
@@ -1188,14 +1186,6 @@ def shard_plan_epoch(d_i, d_j, d_bounds, n_batches: int, n: int, n_items: int, w
 
 def gather_rows(d_table, ld: int, d_rows, n: int, d_out, stream=None):
     _check(load().qrec_gather_rows(_dp(d_table), ld, _dp(d_rows), n, _dp(d_out), _sh(stream)))
-
-
-def table_rows_delta(d_table, d_start, ld: int, d_rows, n: int, d_delta, stream=None):
-    _check(load().qrec_table_rows_delta(_dp(d_table), _dp(d_start), ld, _dp(d_rows), n, _dp(d_delta), _sh(stream)))
-
-
-def table_rows_reconcile(d_table, d_start, ld: int, d_rows, n: int, d_delta_sum, stream=None):
-    _check(load().qrec_table_rows_reconcile(_dp(d_table), _dp(d_start), ld, _dp(d_rows), n, _dp(d_delta_sum), _sh(stream)))
 
 
 def rows_gather_owned(d_block, ld: int, lo: int, hi: int, d_ids, n: int, d_out, stream=None):

@@ -263,32 +263,6 @@ __global__ void batch_rows_scatter_kernel(float *__restrict__ block, int64_t lo,
     }
 }
 
-// ---- replicated table: reconcile a SUBSET of rows between two full reconciliations (round 4) ----------------------------------
-// rows_delta:      delta[k] = table[rows[k]] - start[rows[k]]            (this rank's change of those rows since they were last reconciled)
-// rows_reconcile:  table[rows[k]] = start[rows[k]] = start[rows[k]] + delta_sum[k]   (delta_sum = the all-reduced deltas): afterwards the
-//                  full-table delta of the epoch close (table - start) holds, for these rows, only what happened since -- nothing twice
-template <int LD4>
-__global__ void rows_delta_kernel(const float4 *__restrict__ table, const float4 *__restrict__ start, const int32_t *__restrict__ rows,
-                                  int64_t n, float4 *__restrict__ delta) {
-    const int64_t total = n * LD4;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t at = (int64_t)rows[t / LD4] * LD4 + (t % LD4);
-        const float4 a = table[at], b = start[at];
-        delta[t] = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
-    }
-}
-template <int LD4>
-__global__ void rows_reconcile_kernel(float4 *__restrict__ table, float4 *__restrict__ start, const int32_t *__restrict__ rows, int64_t n,
-                                      const float4 *__restrict__ delta_sum) {
-    const int64_t total = n * LD4;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t at = (int64_t)rows[t / LD4] * LD4 + (t % LD4);
-        const float4 s = start[at], d = delta_sum[t];
-        const float4 r = make_float4(s.x + d.x, s.y + d.y, s.z + d.z, s.w + d.w);
-        start[at] = r; table[at] = r;
-    }
-}
-
 // the same two operations for an arbitrary list of table rows (SimGCL's InfoNCE reads the batch's UNIQUE users / items, SimGCL.py:61-64)
 template <int LD4>
 __global__ void rows_gather_owned_kernel(const float4 *__restrict__ block, int64_t lo, int64_t hi, const int32_t *__restrict__ ids, int64_t n,
@@ -454,42 +428,6 @@ int qrec_scatter_add_row_deltas(float *d_table, int32_t ld, const int32_t *d_row
         default: QREC_DELTA(256); break;
     }
 #undef QREC_DELTA
-    QREC_LAUNCH_CHECK();
-    return QREC_OK;
-}
-
-int qrec_table_rows_delta(const float *d_table, const float *d_start, int32_t ld, const int32_t *d_rows, int64_t n, float *d_delta, void *stream) {
-    QREC_REQUIRE(n >= 0, "qrec_table_rows_delta: negative count");
-    QREC_REQUIRE(ld == 32 || ld == 64 || ld == 128 || ld == 256, "qrec_table_rows_delta: row stride must be 32, 64, 128 or 256 floats (got %d)", ld);
-    if (n == 0) return QREC_OK;
-    QREC_REQUIRE(d_table && d_start && d_rows && d_delta, "qrec_table_rows_delta: null argument");
-    const dim3 g(grid_for(n * (ld / 4), 256)), b(256);
-#define QREC_RD(L4) hipLaunchKernelGGL((rows_delta_kernel<L4>), g, b, 0, as_stream(stream), (const float4 *)d_table, (const float4 *)d_start, d_rows, n, (float4 *)d_delta)
-    switch (ld) {
-        case 32: QREC_RD(8); break;
-        case 64: QREC_RD(16); break;
-        case 128: QREC_RD(32); break;
-        default: QREC_RD(64); break;
-    }
-#undef QREC_RD
-    QREC_LAUNCH_CHECK();
-    return QREC_OK;
-}
-
-int qrec_table_rows_reconcile(float *d_table, float *d_start, int32_t ld, const int32_t *d_rows, int64_t n, const float *d_delta_sum, void *stream) {
-    QREC_REQUIRE(n >= 0, "qrec_table_rows_reconcile: negative count");
-    QREC_REQUIRE(ld == 32 || ld == 64 || ld == 128 || ld == 256, "qrec_table_rows_reconcile: row stride must be 32, 64, 128 or 256 floats (got %d)", ld);
-    if (n == 0) return QREC_OK;
-    QREC_REQUIRE(d_table && d_start && d_rows && d_delta_sum, "qrec_table_rows_reconcile: null argument");
-    const dim3 g(grid_for(n * (ld / 4), 256)), b(256);
-#define QREC_RR(L4) hipLaunchKernelGGL((rows_reconcile_kernel<L4>), g, b, 0, as_stream(stream), (float4 *)d_table, (float4 *)d_start, d_rows, n, (const float4 *)d_delta_sum)
-    switch (ld) {
-        case 32: QREC_RR(8); break;
-        case 64: QREC_RR(16); break;
-        case 128: QREC_RR(32); break;
-        default: QREC_RR(64); break;
-    }
-#undef QREC_RR
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }

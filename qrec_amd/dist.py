@@ -264,23 +264,6 @@ class ReplicatedTableSync:
         self.delta = kern.DeviceBuffer(self.n, np.float32)
         kern.memcpy_d2d(self.start, table, self.n * 4, stream)
 
-    def set_rows(self, rows: np.ndarray, ld: int):
-        """the rows ``sync_rows`` reconciles (the same list on every rank): distinct row ids of the table"""
-        rows = np.ascontiguousarray(rows, dtype=np.int32)
-        self.rows_n, self.rows_ld = int(rows.size), int(ld)
-        self.d_rows = self.k.DeviceBuffer.from_numpy(rows if rows.size else np.zeros(1, np.int32))
-        self.rows_delta = self.k.DeviceBuffer(max(self.rows_n * self.rows_ld, 1), np.float32)
-
-    def sync_rows(self, stream=None):
-        """reconcile only the rows of ``set_rows`` (between two full ``sync`` calls): delta of those rows, all-reduce of rows x ld floats,
-        the sum applied to the table AND to the snapshot -- the next full sync then counts, for these rows, only what happened since"""
-        k = self.k
-        if not getattr(self, "rows_n", 0):
-            return
-        k.table_rows_delta(self.table, self.start, self.rows_ld, self.d_rows, self.rows_n, self.rows_delta, stream)
-        self.comm.allreduce(self.rows_delta, self.rows_n * self.rows_ld, k.F32, stream)
-        k.table_rows_reconcile(self.table, self.start, self.rows_ld, self.d_rows, self.rows_n, self.rows_delta, stream)
-
     def sync(self, stream=None, extra=None):
         k = self.k
         k.table_delta(self.table, self.start, self.delta, self.n, stream)
@@ -528,33 +511,17 @@ class ReplicatedStep:
     user table is replicated too (drop-in classes), its sync"""
     mode = "replicated"
 
-    def __init__(self, comm, sync_q: ReplicatedTableSync, sync_p: ReplicatedTableSync | None = None, hot_rows: np.ndarray | None = None,
-                 ld: int | None = None):
-        """``hot_rows`` (+ the table's row stride ``ld``): the reconciliations INSIDE an epoch cover these item rows only (the epoch close
-        still reconciles the whole table) -- round 4, see ``hot_item_rows``"""
+    def __init__(self, comm, sync_q: ReplicatedTableSync, sync_p: ReplicatedTableSync | None = None):
         self.comm, self.sync_q, self.sync_p = comm, sync_q, sync_p
-        self.hot = hot_rows is not None
-        if self.hot:
-            sync_q.set_rows(hot_rows, ld)
 
     def sync_tables(self, stream=None):
         """reconcile the replicas INSIDE an epoch (``BprSgd(batches=K)``: after each of the first K - 1 batches; the last batch's
         sync is the epoch close's fused collective)"""
-        if self.hot:
-            self.sync_q.sync_rows(stream)
-        else:
-            self.sync_q.sync(stream)
+        # (round 4 could restrict the inner reconciliations to the rows with the most positives; round 5 removed it: 4 % of the epoch at 8
+        # ranks for a Recall gap twice the whole table's -- profiles/r05_strong_scaling_bound.json, r05_scaling_recall.json)
+        self.sync_q.sync(stream)
         # (the user table, when it is replicated too -- the drop-in classes -- is NOT reconciled here: users are sharded over the ranks,
         # no two ranks touch the same row of P, so its one delta-sum at the epoch close is exact whenever it happens)
-
-
-def hot_item_rows(item_degrees: np.ndarray, n_rows: int) -> np.ndarray:
-    """the ``n_rows`` item rows with the most positives (ties by id), ascending -- the same list on every rank when every rank passes the
-    degrees of the WHOLE training set"""
-    deg = np.asarray(item_degrees)
-    n_rows = int(min(max(n_rows, 0), deg.size))
-    top = np.argsort(-deg.astype(np.int64), kind="stable")[:n_rows]
-    return np.sort(top).astype(np.int32)
 
 
 class ShardedStep:

@@ -208,11 +208,7 @@ class BPR(IterativeRecommender):
         sharded = step is not None
         if dp is not None and step is None:
             from ...dist import ReplicatedStep, ReplicatedTableSync
-            hot = int(os.environ.get("QREC_REPLICATED_HOT_ROWS", "0"))     # inner reconciliations over the hottest item rows only (0: whole table)
-            from ...dist import hot_item_rows
-            step = ReplicatedStep(dp.comm, ReplicatedTableSync(dp.comm, sgd.t.Q), ReplicatedTableSync(dp.comm, sgd.t.P),
-                                  hot_rows=hot_item_rows(np.bincount(self.data.positive_csr().indices, minlength=len(self.data.item)), hot) if hot > 0 else None,
-                                  ld=sgd.t.ld)
+            step = ReplicatedStep(dp.comm, ReplicatedTableSync(dp.comm, sgd.t.Q), ReplicatedTableSync(dp.comm, sgd.t.P))
         sgd.start_device_driver(self.lRate, log_capacity=self.maxEpoch)
         sgd.prefetch_negatives_device(self.sampler_seed, 0)
         closed = []

@@ -74,21 +74,6 @@ def table_apply(table, start, delta, n, stream=None):
     _view(table, n, np.float32)[:] = s
 
 
-def table_rows_delta(table, start, ld, d_rows, n, delta, stream=None):
-    rows = _view(d_rows, n, np.int32).astype(np.int64)
-    total = (int(rows.max()) + 1) * ld if n else 0
-    t, s = _view(table, total, np.float32).reshape(-1, ld), _view(start, total, np.float32).reshape(-1, ld)
-    _view(delta, n * ld, np.float32).reshape(n, ld)[:] = t[rows] - s[rows]
-
-
-def table_rows_reconcile(table, start, ld, d_rows, n, delta_sum, stream=None):
-    rows = _view(d_rows, n, np.int32).astype(np.int64)
-    total = (int(rows.max()) + 1) * ld if n else 0
-    t, s = _view(table, total, np.float32).reshape(-1, ld), _view(start, total, np.float32).reshape(-1, ld)
-    new = s[rows] + _view(delta_sum, n * ld, np.float32).reshape(n, ld)
-    s[rows] = new; t[rows] = new
-
-
 def shard_rows(n_items, world, rank):
     return n_items // world + (1 if rank < n_items % world else 0)
 

@@ -83,14 +83,14 @@ def _worker(rank, world, port, out):
 
 
 def _hot_worker(rank, world, port, out):
-    """K = 3 batches per epoch: two INNER reconciliations over the hot rows only, then the full one (what engine.epoch_device_async enqueues
-    for the replicated layout with ReplicatedStep(hot_rows=...)); the 'SGD' of a batch is a rank- and batch-specific additive change"""
+    """K = 3 batches per epoch: two INNER reconciliations, then the full one (what engine.epoch_device_async enqueues for the replicated
+    layout); the 'SGD' of a batch is a rank- and batch-specific additive change"""
     control, comm = _join(rank, world, port)
     rng = np.random.default_rng(0)
     n_rows, ld = 300, 8
     Q0 = rng.standard_normal((n_rows, ld)).astype(np.float32)
     q = HK.DeviceBuffer.from_numpy(Q0)
-    step = qd.ReplicatedStep(comm, ReplicatedTableSync(comm, q, kern=HK), hot_rows=_HOT if os.environ.get("QREC_TEST_HOT") == "1" else None, ld=ld)
+    step = qd.ReplicatedStep(comm, ReplicatedTableSync(comm, q, kern=HK))
     mid = []
     for b in range(3):
         q.a += _batch_change(rank, b, n_rows, ld)
@@ -149,20 +149,14 @@ def test_preflight_names_a_wrong_collective_and_a_hung_one():
     assert r["ok"] is False and len(said) == 1 and "did not complete within" in said[0] and "\n" not in said[0]
 
 
-_HOT = np.array([3, 7, 8, 100, 299], np.int32)
-
-
 def _batch_change(rank, b, n_rows, ld):
     return np.random.default_rng(1000 * rank + b).standard_normal((n_rows, ld)).astype(np.float32) * 0.1
 
 
-@pytest.mark.parametrize("hot", [True, False])
-def test_inner_reconciliations_count_nothing_twice(hot, monkeypatch):
-    """round 4 (engine.epoch_device_async, replicated layout with K = 3 batches): two inner reconciliations -- over the WHOLE table (the
-    default) or restricted to a row list (dist.ReplicatedTableSync.sync_rows) -- and the epoch's full one.  Afterwards every replica equals
-    start + the sum of EVERY rank's change of EVERY batch (no inner delta is added again by the full sync); in between the reconciled rows
-    of both replicas agree, and with the row list the other rows still differ."""
-    monkeypatch.setenv("QREC_TEST_HOT", "1" if hot else "0")
+def test_inner_reconciliations_count_nothing_twice():
+    """engine.epoch_device_async, replicated layout with K = 3 batches: two inner reconciliations of the whole table and the epoch's full
+    one.  Afterwards every replica equals start + the sum of EVERY rank's change of EVERY batch (no inner delta is added again by the
+    full sync); in between the replicas agree."""
     world = 2
     mgr = mp.Manager(); out = mgr.dict()
     mp.spawn(_hot_worker, args=(world, _free_port(), out), nprocs=world, join=True)
@@ -175,11 +169,8 @@ def test_inner_reconciliations_count_nothing_twice(hot, monkeypatch):
     (q0, mid0), (q1, mid1) = out[0], out[1]
     assert np.array_equal(q0, q1)
     np.testing.assert_allclose(q0, want, rtol=0, atol=2e-6)
-    rows = _HOT if hot else np.arange(n_rows)
-    others = np.setdiff1d(np.arange(n_rows), rows)
     for a, b in zip(mid0, mid1):
-        assert np.array_equal(a[rows], b[rows])
-        assert others.size == 0 or not np.array_equal(a[others], b[others])
+        assert np.array_equal(a, b)
 
 
 def test_user_blocks_partition():

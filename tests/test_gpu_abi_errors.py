@@ -165,27 +165,20 @@ def test_round_3_entry_points_refuse_what_they_cannot_serve():
 
 
 def test_round4_entry_points_refuse_bad_arguments_and_treat_empty_inputs_as_no_ops():
-    """qrec_table_rows_delta / _reconcile (reconciliation of a row subset), qrec_batch_rows_gather / _scatter_add and
-    qrec_rows_gather_owned / _scatter_add_owned (a batch's rows out of / into row-partitioned tables)."""
+    """qrec_batch_rows_gather / _scatter_add and qrec_rows_gather_owned / _scatter_add_owned (a batch's rows out of / into row-partitioned tables)."""
     f32 = lambda *shape: DB.zeros(shape, np.float32)
     T, S, idx, out = f32(100, 64), f32(100, 64), DB.from_numpy(np.arange(16, dtype=np.int32)), f32(48, 64)
-    for call in (lambda ld: capi.table_rows_delta(T, S, ld, idx, 16, out),
-                 lambda ld: capi.table_rows_reconcile(T, S, ld, idx, 16, out),
-                 lambda ld: capi.batch_rows_gather(T, ld, 0, 100, idx, idx, idx, 16, 50, out),
+    for call in (lambda ld: capi.batch_rows_gather(T, ld, 0, 100, idx, idx, idx, 16, 50, out),
                  lambda ld: capi.batch_rows_scatter_add(T, ld, 0, 100, idx, idx, idx, 16, 50, out),
                  lambda ld: capi.rows_gather_owned(T, ld, 0, 100, idx, 16, out),
                  lambda ld: capi.rows_scatter_add_owned(T, ld, 0, 100, idx, 16, out)):
         assert "stride" in _err(lambda: call(48))                         # a row stride the kernels have no lane mapping for
-    assert "null" in _err(lambda: capi.table_rows_delta(None, S, 64, idx, 16, out))
-    assert "null" in _err(lambda: capi.table_rows_reconcile(T, S, 64, None, 16, out))
     assert "null" in _err(lambda: capi.batch_rows_gather(T, 64, 0, 100, idx, None, idx, 16, 50, out))
     assert "null" in _err(lambda: capi.rows_gather_owned(T, 64, 0, 100, idx, 16, None))
-    _err(lambda: capi.table_rows_delta(T, S, 64, idx, -1, out))                         # negative count
     _err(lambda: capi.batch_rows_gather(T, 64, 10, 5, idx, idx, idx, 16, 50, out))      # hi < lo
     _err(lambda: capi.rows_scatter_add_owned(T, 64, -1, 100, idx, 16, out))             # lo < 0
     # empty inputs: nothing is touched, nothing is dereferenced
     before = T.numpy().copy()
-    capi.table_rows_delta(None, None, 64, None, 0, None); capi.table_rows_reconcile(None, None, 64, None, 0, None)
     capi.batch_rows_gather(None, 64, 0, 0, None, None, None, 0, 0, None); capi.batch_rows_scatter_add(None, 64, 0, 0, None, None, None, 0, 0, None)
     capi.rows_gather_owned(None, 64, 0, 0, None, 0, None); capi.rows_scatter_add_owned(None, 64, 0, 0, None, 0, None)
     capi.device_sync()

@@ -109,7 +109,7 @@ def build_rank(d, mode, world, rank, layout, P0, Q0, shard_batch=1 << 20, syncs=
     return t, sgd, chunk, lo, hi, groups
 
 
-def train_rank(d, sgd, t, chunk, lr0, seed, epochs, marks, world, rank, comm, layout, on_mark, stream=None, hot_rows=0, groups=0):
+def train_rank(d, sgd, t, chunk, lr0, seed, epochs, marks, world, rank, comm, layout, on_mark, stream=None, groups=0):
     """``epochs`` epochs of one rank in throughput mode as bench.py's epoch runs them: device sampler, SGD kernel(s), the layout's
     collectives, device-side epoch close with the bold driver.  ``on_mark(epoch, P_local, Q_local)`` at the epochs in ``marks``
     (every rank calls it).  Returns the device driver's log."""
@@ -119,8 +119,7 @@ def train_rank(d, sgd, t, chunk, lr0, seed, epochs, marks, world, rank, comm, la
     if sharded:
         dstep = qd.ShardedStep(comm, qd.ShardedItemExchange(comm, d["n_items"], t.ld, t.Q), len(sgd.batch_bounds) - 1)
     elif world > 1:
-        hot = qd.hot_item_rows(np.bincount(d["items"], minlength=d["n_items"]), hot_rows) if hot_rows else None
-        dstep = qd.ReplicatedStep(comm, qd.ReplicatedTableSync(comm, t.Q), hot_rows=hot, ld=t.ld)
+        dstep = qd.ReplicatedStep(comm, qd.ReplicatedTableSync(comm, t.Q))
     sgd.start_device_driver(lr0, log_capacity=epochs)
     capi.device_sync()
     for k in range(epochs):
@@ -158,7 +157,7 @@ def negatives_of(samplers, seed):
     return negatives
 
 
-def gpu_run(d, mode, lr0, seed, epochs, marks, world=1, layout="replicated", P0=None, Q0=None, shard_batch=1 << 20, syncs=1, item_run=None, hot_rows=0,
+def gpu_run(d, mode, lr0, seed, epochs, marks, world=1, layout="replicated", P0=None, Q0=None, shard_batch=1 << 20, syncs=1, item_run=None,
             rounds=None, extra_topn=()):
     """world = 1, or G logical ranks in this process.  Returns {recall: {mark: r}, loss: [...], lr: [...], negatives: k -> j}."""
     from qrec_amd import capi
@@ -184,7 +183,7 @@ def gpu_run(d, mode, lr0, seed, epochs, marks, world=1, layout="replicated", P0=
                 group.barrier.wait()
 
         log = train_rank(d, sgd, t, chunk, lr0, seed, epochs, marks, world, rank, ThreadComm(group, rank) if world > 1 else None, layout,
-                         on_mark, capi.Stream() if world > 1 else None, hot_rows=hot_rows, groups=groups)
+                         on_mark, capi.Stream() if world > 1 else None, groups=groups)
         if rank == 0:
             state["log"] = log
 
@@ -274,7 +273,7 @@ def run_case(case: dict, cache: dict, datasets: dict) -> dict:
     from qrec_amd.dist import reconciliations_per_epoch
     g = gpu_run(d, mode, lr0, seed, epochs, marks, world, layout, P0, Q0, shard_batch=case.get("shard_batch", 1 << 20),
                 syncs=reconciliations_per_epoch(world, case.get("syncs", 0)),
-                item_run=case.get("item_run"), hot_rows=case.get("hot_rows", 0), rounds=case.get("rounds"), extra_topn=topn)
+                item_run=case.get("item_run"), rounds=case.get("rounds"), extra_topn=topn)
     t1 = time.perf_counter()
     key = (name, lr0, seed, epochs, every, case.get("init_seed", 3), case.get("dim", DIM), topn) + g["perm_key"]
     if key not in cache:      # the negatives are a function of (seed, epoch, stored order): modes with the same order share a reference
@@ -404,7 +403,7 @@ def main():
         except Exception as e:      # noqa: BLE001 -- a failing case must not lose the others' results
             res = {**c, "error": repr(e)}
         results.append(res)
-        brief = {k: res.get(k) for k in ("dataset", "lr0", "seed", "mode", "world", "layout", "syncs", "item_run", "hot_rows") if res.get(k) is not None}
+        brief = {k: res.get(k) for k in ("dataset", "lr0", "seed", "mode", "world", "layout", "syncs", "item_run", "rounds") if res.get(k) is not None}
         if "peak" in res:
             brief.update(peak_epoch=res["peak"]["epoch"], recall=round(res["peak"]["recall_exact_order"], 5), abs_diff=round(res["peak"]["abs_diff"], 5),
                          rel=round(res["peak"]["rel_diff"], 4), worst=round(res["worst_mark"]["abs_diff"], 5), loss_gap=round(res["final"]["loss_rel_gap"], 4))

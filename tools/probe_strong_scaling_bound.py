@@ -22,20 +22,18 @@ capi.init(0)
 shape = sys.argv[1] if len(sys.argv) > 1 else "yelp2018"
 d = PR.load_dataset(shape)
 P0, Q0 = PR.initial_tables(d, 3)
-out = {"hot_rows": int(os.environ.get("PROBE_HOT_ROWS", "0")), "shape": shape, "users": d["n_users"], "items": d["n_items"], "triplets_per_epoch": int(d["items"].size), "ranks": {}}
-HOT = int(os.environ.get("PROBE_HOT_ROWS", "0"))
-# plan: JSON list of {"N":, "K":, "hot": rows of the inner reconciliations (0 = whole table), "groups": grid of a batch launch, "lo": min chunk}
+out = {"shape": shape, "users": d["n_users"], "items": d["n_items"], "triplets_per_epoch": int(d["items"].size), "ranks": {}}
+# plan: JSON list of {"N":, "K":, "groups": grid of a batch launch, "lo": min chunk, "rounds": engine.grid_for_epoch's minimum}
 PLAN = json.load(open(sys.argv[2])) if len(sys.argv) > 2 else json.loads(os.environ["PROBE_PLAN"]) if os.environ.get("PROBE_PLAN") else \
-    [{"N": N, "K": K, "hot": HOT} for N in (1, 2, 4, 8) for K in sorted({1, N})]
+    [{"N": N, "K": K} for N in (1, 2, 4, 8) for K in sorted({1, 2, N})]
 import qrec_amd.engine as E
 _launch_chunk = E.launch_chunk
 for cfg in PLAN:
-        N, K, hot_n, bg, lo = cfg["N"], cfg["K"], cfg.get("hot", 0), cfg.get("groups", 4096), cfg.get("lo", 4)
+        N, K, bg, lo = cfg["N"], cfg["K"], cfg.get("groups", 4096), cfg.get("lo", 4)
         E.launch_chunk = lambda n, chunk, groups=4096, lo_=lo, **kw: _launch_chunk(n, chunk, groups=groups, lo=lo_)
         t, sgd, chunk, lo_u, hi_u, _groups = PR.build_rank(d, "item", N, 0, "replicated", P0, Q0, syncs=K, rounds=cfg.get("rounds", 0))
         sgd.batch_groups = bg
-        hot = qd.hot_item_rows(np.bincount(d["items"], minlength=d["n_items"]), hot_n) if (hot_n and K > 1) else None
-        step = qd.ReplicatedStep(NoLinks(N), qd.ReplicatedTableSync(NoLinks(N), t.Q), hot_rows=hot, ld=t.ld) if N > 1 else None
+        step = qd.ReplicatedStep(NoLinks(N), qd.ReplicatedTableSync(NoLinks(N), t.Q)) if N > 1 else None
         stream = capi.Stream()
         epochs = 60
         sgd.start_device_driver(0.01, log_capacity=epochs + 10)
@@ -47,9 +45,9 @@ for cfg in PLAN:
         run(0, 10); stream.sync()
         t0 = time.perf_counter(); run(10, 10 + epochs - 10); stream.sync(); dt = (time.perf_counter() - t0) / (epochs - 10)
         payload = d["n_items"] * t.ld * 4 + 24
-        inner = payload if hot is None else int(hot.size) * t.ld * 4
+        inner = payload
         wire = 2.0 * (N - 1) / N * (payload + (K - 1) * inner) if N > 1 else 0.0
-        key = f"N={N},K={K}" + (f",hot={hot_n}" if hot is not None else "") + (f",groups={bg}" if bg != 4096 else "") + (f",lo={lo}" if lo != 4 else "") + (f",rounds={cfg['rounds']}" if cfg.get("rounds") else "")
+        key = f"N={N},K={K}" + (f",groups={bg}" if bg != 4096 else "") + (f",lo={lo}" if lo != 4 else "") + (f",rounds={cfg['rounds']}" if cfg.get("rounds") else "")
         out["ranks"][key] = {"rank0_triplets": int(sgd.n), "reconciliations_per_epoch": K, "ms_per_epoch_no_links": dt * 1e3,
                                         "ring_wire_MB_per_rank_per_epoch": wire / 1e6, "collectives_per_epoch": K,
                                         "link_ms_arithmetic": {"one_ring_153GBps": wire / 153e9 * 1e3, "seven_rings_1071GBps": wire / 1071e9 * 1e3}}
