@@ -20,7 +20,7 @@ depend on that grouping (triplets / second); `ms_per_step` is per step, `config.
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>` with
 the same arguments: one rank per GPU, rank 0's JSON line on the caller's stdout.  Under a launcher (WORLD_SIZE set) it is
 one of the ranks.  The layout can be steered by flag or, for a caller whose command line is fixed, by environment:
---dist-mode / QREC_DIST_MODE (replicated | sharded), --scaling / QREC_SCALING (weak | strong).
+--dist-mode / QREC_DIST_MODE (replicated | sharded), --scaling (weak | strong).
 
 N > 1, one process per GPU (qrec_amd/dist.py; collectives are RCCL bound directly by libqrec_hip.so, torch.distributed
 /gloo is only the control plane).  Users (rows of P, triplets, sampler) are sharded by rank.  --dist-mode replicated
@@ -357,17 +357,21 @@ def other_configs(capi, yelp, budget_s=14.0):
     spmm_ms = _time_events(capi, lambda: capi.spmm_csr(tr.plan, tr.E, tr.A, tr.ld, d_accum=tr.S), 20)
     nnz = int(tr.plan.nnz); alg = 8 * nnz + 4 * (N + 1) + 2 * N * DIM * 4
     traffic = None
-    cfile = os.path.join(ROOT, "profiles", "r02_lightgcn_hbm_counters.json")
+    cfile = os.path.join(ROOT, "profiles", "r05_lightgcn_hbm_counters.json")
     if os.path.exists(cfile):
-        for k, v in json.load(open(cfile)).get("yelp2018", {}).items():
-            if "spmm_kernel" in k:
-                traffic = v.get("l2_miss_MB_per_launch", 0) * 1e6
+        traffic = json.load(open(cfile)).get("spmm_forward_with_layer_sum", {}).get("l2_miss_MB_per_launch", 0) * 1e6 or None
+    ACHIEVABLE_GBPS = 6300.0        # /opt/skills/guides/MI355X_MICROARCH.md: ~6.3 TB/s achievable of the 8 TB/s spec
     out["lightgcn_step"] = {"workload": f"LightGCN L=3 d={DIM} batch {B} Yelp2018-shape N={N} nnz={nnz}", "ms_per_step": ms, "steps_timed": 40,
                             "triplets_per_s": B / ms * 1e3, "epoch_s": ms * -(-nn // B) / 1e3,
                             "spmm": {"kernel": "spmm_kernel<16> + spmm_fixup_kernel<16>", "avg_us": spmm_ms * 1e3, "reps": 20, "algorithmic_bytes": alg,
                                      "achieved_GBps": alg / spmm_ms / 1e6, "frac": alg / spmm_ms / 1e6 / HBM_PEAK_GBPS, "bound": "hbm (normalised: the operand is cache resident)",
-                                     "traffic": traffic, "traffic_source": "profiles/r02_lightgcn_hbm_counters.json (static: rocprofv3 PMC passes run by the builder on "
-                                                                            "this kernel, unchanged since; bytes past the XCD L2s per launch)" if traffic else None}}
+                                     "traffic": traffic, "traffic_source": "profiles/r05_lightgcn_hbm_counters.json (static: rocprofv3 PMC passes run by the builder on "
+                                                                            "this kernel in round 5; bytes past the XCD L2s per launch of THIS launch type, FETCH_SIZE doubled)" if traffic else None,
+                                     # the bound the kernel is actually on: every XCD's 4 MiB L2 misses most of the gathered operand, the misses are served by the
+                                     # Infinity Cache / HBM side at what that side achieves
+                                     "roofline_l2miss": ({"bound": "bytes past the XCD L2s (counters) / live time, against the ~6.3 TB/s the memory side achieves",
+                                                          "achieved": traffic / spmm_ms / 1e6, "peak": ACHIEVABLE_GBPS, "unit": "GB/s", "frac": traffic / spmm_ms / 1e6 / ACHIEVABLE_GBPS,
+                                                          "over_fetch_vs_algorithmic": traffic / alg} if traffic else None)}}
     del tr
     if time.perf_counter() - t_begin < budget_s:
         lim = np.sqrt(6 / 128)
@@ -543,10 +547,10 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="triplets per work item of the SGD kernel (0 = engine.balanced_chunk: the length in 26..40 that spreads the "
                                                          "epoch's chunks most evenly over the persistent groups)")
     ap.add_argument("--flush-every", type=int, default=0, help="item-major schedule: triplets between flushes of the register-resident Q[i] (0 = default)")
-    ap.add_argument("--schedule", choices=("item", "user", "item-deferred"), default=os.environ.get("QREC_BENCH_SCHEDULE", "item"),
+    ap.add_argument("--schedule", choices=("item", "user", "item-deferred"), default="item",
                     help="visiting order of the epoch's triplets in the Hogwild kernel (DESIGN.md s4)")
     ap.add_argument("--dist-mode", choices=("replicated", "sharded"), default=os.environ.get("QREC_DIST_MODE", "replicated"))
-    ap.add_argument("--scaling", choices=("strong", "weak"), default=os.environ.get("QREC_SCALING", "strong"),
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N > 1.  strong (default; BASELINE.json quotes the metric on THE Yelp2018 shape at 1/2/4/8 GPUs): the same 31,668 users "
                          "split over the ranks -- `value`; a weak-scaling leg (every rank its own 31,668 users: an N x 31,668-user problem) is "
                          "timed next to it and reported as `weak_scaling`.  weak: that leg alone, as `value`, labelled with its aggregate shape")
@@ -564,7 +568,7 @@ def main():
     ap.add_argument("--config4-triplets", type=int, default=-1,
                     help="N > 1: triplets per epoch and rank of the `config4_sharded` leg (its users and items scale along: 25 M = BASELINE config "
                          "#4's share of one of 8 GPUs = the default; the one-device functional tests default to 0 and pass a small number; 0 skips it)")
-    ap.add_argument("--shard-pipeline", action="store_true", default=os.environ.get("QREC_SHARD_PIPELINE") == "1",
+    ap.add_argument("--shard-pipeline", action="store_true",
                     help="sharded mode: fetch batch k + 1 under batch k's SGD kernel, on a second stream and communicator (one more batch of "
                          "staleness).  Off by default: at the Yelp2018 shape the fetch is 10 MB per batch and the gather/copy kernels "
                          "running beside the atomic-bound SGD grid cost it more than they hide (world 1: 0.85 vs 0.75 ms/epoch, "
@@ -573,11 +577,6 @@ def main():
     ap.add_argument("--no-plan-inside", action="store_true",
                     help="sharded mode: plan every epoch at its own start, with the host waiting for the stream to run dry (default: the "
                          "next epoch's plan is enqueued in front of the current epoch's last batch, its row counts read back behind an event)")
-    ap.add_argument("--plan-ahead", action="store_true", default=os.environ.get("QREC_SHARD_PLAN_AHEAD") == "1",
-                    help="sharded mode: plan every epoch (distinct rows per owner, one host read-back, id exchange) under the PREVIOUS epoch, on "
-                         "a third stream and communicator (default: at its own start, on the training stream -- measured at world 1: the plan "
-                         "kernels running beside the atomic-bound SGD grid cost it more than the host round trip they hide, "
-                         "profiles/r03_sharded_world1.json)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_own_ranks(args.gpus)           # does not return
@@ -615,15 +614,11 @@ def main():
     from qrec_amd.interactions import CSR
     from qrec_amd.synth import make_dataset, to_csr
     capi.init(local_rank)
-    no_comm = os.environ.get("QREC_BENCH_NO_COMM") == "1"
-    if use_dist and no_comm:      # diagnosis only: the multi-GPU code path without a communicator
-        comm = type("NoComm", (), {"world": 1, "rank": 0, "allreduce": lambda *a, **k: None, "allreduce_pair": lambda *a, **k: None,
-                                   "destroy": lambda self: None})()
-    elif use_dist:
+    if use_dist:
         comm = qd.make_comm(control)
     # first contact with the communicator, before anything is timed: a tiny all-reduce and a ragged all-to-all round trip, checked, under a
     # watchdog -- a wrong value raises, a hang ends the process with one line on stderr (qrec_amd/dist.py preflight)
-    pre = qd.preflight(comm, stream=None, timeout_s=float(os.environ.get("QREC_PREFLIGHT_TIMEOUT", "90"))) if (use_dist and not no_comm) else None
+    pre = qd.preflight(comm, stream=None, timeout_s=float(os.environ.get("QREC_PREFLIGHT_TIMEOUT", "90"))) if use_dist else None
 
     # ---- workload: resident in HBM before timing ------------------------------------------
     data = make_dataset(args.shape)
@@ -638,8 +633,8 @@ def main():
     # The step's kernels and collectives run on an explicit non-blocking stream, not the null stream: the legacy null
     # stream synchronises implicitly with every blocking stream of the process, and an RCCL communicator brings its own --
     # measured at world 1 (QREC_FORCE_DIST=1): 0.670 ms/epoch on the null stream, 0.626 on this one, 0.610 with no
-    # communicator in the process at all (QREC_BENCH_NULL_STREAM=1 / QREC_BENCH_NO_COMM=1 reproduce the two ends).
-    main_stream = None if os.environ.get("QREC_BENCH_NULL_STREAM") == "1" else capi.Stream()
+    # communicator in the process at all.
+    main_stream = capi.Stream()
 
     def sync_all():
         if use_dist:
@@ -674,15 +669,11 @@ def main():
         dstep = None
         if use_dist and sharded:
             pipe = None
-            if args.shard_pipeline and not args.no_shard_pipeline and not no_comm:
+            if args.shard_pipeline and not args.no_shard_pipeline:
                 # a second communicator for the fetch stream: two collectives of ONE communicator must not be in flight on two streams
                 pipe = (comm if one_device else qd.make_comm(control), capi.Stream())
-            ahead = None
-            if args.plan_ahead and not no_comm:
-                # ... and a third one for the plan of the NEXT epoch (row counts, id exchange), which runs under the current epoch
-                ahead = (comm if one_device else qd.make_comm(control), capi.Stream())
-            extra_comms.extend(x[0] for x in (pipe, ahead) if x is not None and x[0] is not comm)
-            dstep = qd.ShardedStep(comm, qd.ShardedItemExchange(comm, I, tables.ld, tables.Q, pipeline=pipe, plan_ahead=ahead), n_batches,
+            extra_comms.extend(x[0] for x in (pipe,) if x is not None and x[0] is not comm)
+            dstep = qd.ShardedStep(comm, qd.ShardedItemExchange(comm, I, tables.ld, tables.Q, pipeline=pipe), n_batches,
                                    plan_inside=not args.no_plan_inside)
         elif use_dist:
             dstep = qd.ReplicatedStep(comm, qd.ReplicatedTableSync(comm, tables.Q))
@@ -706,7 +697,6 @@ def main():
                 # epoch's last batch is preceded by the next epoch's plan, which waits for those negatives
                 sgd.epoch_device_async(REG_U, REG_I, MAX_LR, tol=0.0, chunk=CHUNK, variant=args.variant, stream=main, flush_every=flush_every,
                                        events=pair, dist=dstep, after_start=lambda: sgd.prefetch_negatives_device(sampler_seed, k + 1))
-                dstep.prepare_ahead(sgd)                                # --plan-ahead: on the plan stream instead
                 return
             sgd.epoch_device_async(REG_U, REG_I, MAX_LR, tol=0.0, chunk=CHUNK, variant=args.variant, stream=main,
                                    flush_every=flush_every, events=pair, dist=dstep, groups=GROUPS)   # BPR.py:45-53,40 + iterativeRecommender.py:88-104
@@ -834,7 +824,7 @@ def main():
     config4 = None
     if args.config4_triplets < 0:
         args.config4_triplets = 0 if one_device else 25_000_000
-    if world > 1 and not args.no_extras and args.config4_triplets > 0 and not no_comm:      # every rank takes part
+    if world > 1 and not args.no_extras and args.config4_triplets > 0:      # every rank takes part
         scale = args.config4_triplets / 25_000_000
         config4 = config4_sharded_leg(capi, qd, control, comm, world, rank, args.shard_batch, qd.reconciliations_per_epoch(world, args.sync_per_epoch),
                                       users=max(1000, int(1_250_000 * scale)), items=max(1000, int(1_000_000 * scale)), triplets=args.config4_triplets)

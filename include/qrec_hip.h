@@ -333,16 +333,6 @@ int qrec_spmm_csr(const int32_t *d_seg_row, const int64_t *d_seg_beg, const int3
                   float *d_partial, int32_t ld, const float *d_addend, float addend_scale, float *d_accum,
                   const float *d_accum_init, const uint32_t *d_x_row_mask, const uint32_t *d_y_row_mask,
                   const uint32_t *d_addend_row_mask, void *stream);
-/* The same product for a matrix that IS D^-1/2 A D^-1/2 of a 0/1 graph (base/graphRecommender.py:21-28), without its value array (round 5):
- * d_dinv[n] = the float32 vector rowsum^-1/2 the reference scaled with; entry (r, c) is recomputed as fl32(fl32(d_dinv[r] * 1) * d_dinv[c]) --
- * the reference's own two float32 products, hence the same bits.  Everything else as qrec_spmm_csr. */
-int qrec_spmm_csr_degree_norm(const int32_t *d_seg_row, const int64_t *d_seg_beg, const int32_t *d_seg_len,
-                              const int32_t *d_seg_slot, int64_t n_segs, const int32_t *d_long_row,
-                              const int32_t *d_long_first, const int32_t *d_long_count, int32_t n_long,
-                              const int32_t *d_indices, const float *d_dinv, const float *d_X, float *d_Y,
-                              float *d_partial, int32_t ld, const float *d_addend, float addend_scale, float *d_accum,
-                              const float *d_accum_init, const uint32_t *d_x_row_mask, const uint32_t *d_y_row_mask,
-                              const uint32_t *d_addend_row_mask, void *stream);
 /* d_row_mask |= bits of rows u[b], n_users+i[b], n_users+j[b] (bitmap over the joint [U;V] row space; clear it first) */
 int qrec_mark_batch_rows(const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int32_t B, int32_t n_users,
                          uint32_t *d_row_mask, void *stream);

@@ -80,7 +80,6 @@ _SIGNATURES = {
                                _f64, _f64, _f64, _vp, _vp],
     "qrec_sumsq": [_vp, C.c_int, _i64, _i32, _i32, _vp, _vp],
     "qrec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
-    "qrec_spmm_csr_degree_norm": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     "qrec_mark_batch_rows": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "qrec_bpr_batch_loss_grad": [_vp, _f32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
     "qrec_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
@@ -767,13 +766,10 @@ def mark_batch_rows(d_u, d_i, d_j, B: int, n_users: int, d_row_mask, stream=None
 
 def spmm_csr(plan, d_X, d_Y, ld: int, d_addend=None, addend_scale: float = 0.0, d_accum=None, stream=None,
              d_x_row_mask=None, d_y_row_mask=None, d_accum_init=None, d_addend_row_mask=None):
-    """plan: qrec_amd.graph.SpmmPlan (device-resident segment arrays); a plan that carries ``dinv`` (the matrix is D^-1/2 A D^-1/2 of a 0/1
-    graph) runs without its value array (qrec_spmm_csr_degree_norm)"""
-    norm = getattr(plan, "dinv", None) is not None
-    fn = load().qrec_spmm_csr_degree_norm if norm else load().qrec_spmm_csr
-    _check(fn(_dp(plan.seg_row), _dp(plan.seg_beg), _dp(plan.seg_len), _dp(plan.seg_slot),
+    """plan: qrec_amd.graph.SpmmPlan (device-resident segment arrays)"""
+    _check(load().qrec_spmm_csr(_dp(plan.seg_row), _dp(plan.seg_beg), _dp(plan.seg_len), _dp(plan.seg_slot),
                                 plan.n_segs, _dp(plan.long_row), _dp(plan.long_first), _dp(plan.long_count),
-                                plan.n_long, _dp(plan.indices), _dp(plan.dinv if norm else plan.values), _dp(d_X), _dp(d_Y),
+                                plan.n_long, _dp(plan.indices), _dp(plan.values), _dp(d_X), _dp(d_Y),
                                 _dp(plan.partial), ld, _dp(d_addend), addend_scale, _dp(d_accum), _dp(d_accum_init), _dp(d_x_row_mask),
                                 _dp(d_y_row_mask), _dp(d_addend_row_mask), _sh(stream)))
 

@@ -57,11 +57,10 @@ __device__ __forceinline__ int row16_bcast(int v) { return __builtin_amdgcn_upda
 template <int N>
 __device__ __forceinline__ float row16_bcast(float v) { return __builtin_bit_cast(float, row16_bcast<N>(__builtin_bit_cast(int, v))); }
 
-// NORM (round 5): the matrix is the symmetrically normalised adjacency D^-1/2 A D^-1/2 of a 0/1 graph (base/graphRecommender.py:21-28) and
-// `values` is not the nnz-long value array but the vector dinv[n] = rowsum^-1/2 the reference scaled with: entry (r, c) is recomputed as
-// fl32(fl32(dinv[r] * 1) * dinv[c]) -- the reference's own two float32 products, so the same bits -- and the 4 B per non-zero of the
-// value stream (10 MB per launch at the Yelp2018 shape) become a gather from a 279 KB vector.
-template <int LPR, bool NORM = false>
+// (round 5, measured and removed: recomputing every value in the kernel as fl32(dinv[r]) * dinv[c] from the 279 KB degree vector instead
+// of streaming the value array -- the same bits, 72.4 us against 70.3: the 4 B per non-zero of a coalesced stream become a gathered 4 B per
+// non-zero, one more L2 transaction next to the two of the operand row it scales.  DESIGN.md s5.)
+template <int LPR>
 __global__ __launch_bounds__(256) void spmm_kernel(
     const int32_t *__restrict__ seg_row, const int64_t *__restrict__ seg_beg,
     const int32_t *__restrict__ seg_len, const int32_t *__restrict__ seg_slot, int64_t n_segs,
@@ -82,14 +81,10 @@ __global__ __launch_bounds__(256) void spmm_kernel(
         const int64_t beg = seg_beg[s];
         const int len = seg_len[s];
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        float d_row = 0.f;
-        if constexpr (NORM) d_row = values[seg_row[s]];
         for (int e0 = 0; e0 < len; e0 += LPR) {
             const int mine = e0 + r;
             int my_c = mine < len ? indices[beg + mine] : 0;
-            float my_v;
-            if constexpr (NORM) my_v = mine < len ? d_row * values[my_c] : 0.f;
-            else my_v = mine < len ? values[beg + mine] : 0.f;
+            const float my_v = mine < len ? values[beg + mine] : 0.f;
             const int cnt = (len - e0) < LPR ? (len - e0) : LPR;
             int k = 0;
             if constexpr (LPR == 16) {
@@ -301,7 +296,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ theta, fl
     }
 }
 
-template <int LPR, bool NORM = false>
+template <int LPR>
 int launch_spmm(const int32_t *seg_row, const int64_t *seg_beg, const int32_t *seg_len, const int32_t *seg_slot,
                 int64_t n_segs, const int32_t *long_row, const int32_t *long_first, const int32_t *long_count,
                 int n_long, const int32_t *indices, const float *values, const float *X, float *Y, float *partial,
@@ -311,7 +306,7 @@ int launch_spmm(const int32_t *seg_row, const int64_t *seg_beg, const int32_t *s
     int64_t blocks = (n_segs + 4 * GPW - 1) / (4 * GPW);
     if (blocks > 256 * 8) blocks = 256 * 8;
     blocks = (blocks + 7) & ~(int64_t)7;     // a multiple of the 8 XCDs: segment p always lands on XCD (p / groups per block) % 8
-    hipLaunchKernelGGL((spmm_kernel<LPR, NORM>), dim3((unsigned)blocks), dim3(256), 0, st, seg_row, seg_beg, seg_len,
+    hipLaunchKernelGGL((spmm_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, seg_row, seg_beg, seg_len,
                        seg_slot, n_segs, indices, values, X, Y, partial, addend, addend_scale, accum, accum_init, x_row_mask, y_row_mask, addend_row_mask);
     QREC_LAUNCH_CHECK();
     if (n_long > 0) {
@@ -398,34 +393,6 @@ int qrec_spmm_csr(const int32_t *d_seg_row, const int64_t *d_seg_beg, const int3
         case 128: QREC_SPMM(32);
         case 256: QREC_SPMM(64);
         default: set_error("qrec_spmm_csr: row stride must be 32, 64, 128 or 256 floats (got %d)", ld); return QREC_ERR_INVALID;
-    }
-#undef QREC_SPMM
-}
-
-int qrec_spmm_csr_degree_norm(const int32_t *d_seg_row, const int64_t *d_seg_beg, const int32_t *d_seg_len,
-                              const int32_t *d_seg_slot, int64_t n_segs, const int32_t *d_long_row,
-                              const int32_t *d_long_first, const int32_t *d_long_count, int32_t n_long,
-                              const int32_t *d_indices, const float *d_dinv, const float *d_X, float *d_Y,
-                              float *d_partial, int32_t ld, const float *d_addend, float addend_scale, float *d_accum,
-                              const float *d_accum_init, const uint32_t *d_x_row_mask, const uint32_t *d_y_row_mask,
-                              const uint32_t *d_addend_row_mask, void *stream) {
-    QREC_REQUIRE(d_seg_row && d_seg_beg && d_seg_len && d_seg_slot && d_indices && d_dinv && d_X && d_Y,
-                 "qrec_spmm_csr_degree_norm: null argument");
-    QREC_REQUIRE(n_long == 0 || (d_long_row && d_long_first && d_long_count && d_partial), "qrec_spmm_csr_degree_norm: long-row plan incomplete");
-    QREC_REQUIRE(d_X != d_Y, "qrec_spmm_csr_degree_norm: in-place SpMM is not supported (Y may alias addend, not X)");
-    QREC_REQUIRE(!d_accum_init || d_accum, "qrec_spmm_csr_degree_norm: d_accum_init without d_accum");
-    QREC_REQUIRE(!d_addend_row_mask || d_addend, "qrec_spmm_csr_degree_norm: d_addend_row_mask without d_addend");
-    if (n_segs == 0) return QREC_OK;
-    hipStream_t st = as_stream(stream);
-#define QREC_SPMM(LPR) return (launch_spmm<LPR, true>(d_seg_row, d_seg_beg, d_seg_len, d_seg_slot, n_segs, d_long_row, d_long_first, \
-                                                     d_long_count, n_long, d_indices, d_dinv, d_X, d_Y, d_partial, d_addend,       \
-                                                     addend_scale, d_accum, d_accum_init, d_x_row_mask, d_y_row_mask, d_addend_row_mask, st))
-    switch (ld) {
-        case 32: QREC_SPMM(8);
-        case 64: QREC_SPMM(16);
-        case 128: QREC_SPMM(32);
-        case 256: QREC_SPMM(64);
-        default: set_error("qrec_spmm_csr_degree_norm: row stride must be 32, 64, 128 or 256 floats (got %d)", ld); return QREC_ERR_INVALID;
     }
 #undef QREC_SPMM
 }

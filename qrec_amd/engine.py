@@ -110,6 +110,7 @@ def resolve_schedule(n_triplets: int, item_degrees=None, requested: str = "auto"
 
 
 MIN_ROUNDS = 8
+ITEM_RUN = 16           # item-major stored order: the item-sorted list in runs of this many triplets (BprSgd.__init__)
 
 
 def grid_for_epoch(n: int, chunk: int, min_rounds: int = MIN_ROUNDS, groups: int = 4096, min_chunk: int = 8):
@@ -191,12 +192,11 @@ class BprSgd:
         # sub-epochs of the deferred schedule (include/qrec_hip.h qrec_bpr_sgd_hogwild_item_major_deferred_sub): the epoch's time slots
         # in S ranges, pass B of a range on a second stream under pass A of the next; pass A then runs on chunks of `sub_chunk`
         # triplets (a range must still fill the grid a few times over), whatever chunk the epoch calls pass
-        import os as _os
-        self.sub_epochs = int(sub_epochs if sub_epochs is not None else _os.environ.get("QREC_DEFERRED_SUB", "1")) if self.deferred else 1
+        self.sub_epochs = int(sub_epochs if sub_epochs is not None else 1) if self.deferred else 1
         # (the longest chunk, 8 ... 32 triplets, with which a range still fills the 16,384-group grid four times over: measured at both
         # ends, DESIGN.md s4 -- 32 at 6.25 M triplets per range is free, 8 at the Yelp2018 shape's 0.31 M is what a range needs to mean anything)
         auto_chunk = max(8, min(32, (int(u.size) // max(self.sub_epochs, 1)) // (4 * 16384)))
-        self.sub_chunk = int(sub_chunk if sub_chunk is not None else _os.environ.get("QREC_DEFERRED_SUB_CHUNK", auto_chunk))
+        self.sub_chunk = int(sub_chunk if sub_chunk is not None else auto_chunk)
         self._overlap_passes = bool(overlap_passes)
         self._stream_b = None
         self.t = tables
@@ -218,14 +218,15 @@ class BprSgd:
         per = -(-self.n // batches) if self.n else 0
         self.batch_bounds = [min(b * per, self.n) for b in range(batches + 1)]
         # Item-major stored order (round 4): the item-sorted list is cut into RUNS of `item_run` triplets and the runs are laid out
-        # in golden-ratio stride order, so that consecutive runs belong to different items -- a chunk of 32 is four runs of 8.  A
-        # positive item's row still rides in registers along its run (one atomic flush per run), but it takes 8 steps in a row
+        # in golden-ratio stride order, so that consecutive runs belong to different items -- a chunk of 32 is two runs of 16.  A
+        # positive item's row still rides in registers along its run (one atomic flush per run), but it takes 16 steps in a row
         # instead of 32: measured with NO GPU involved (tools/order_sensitivity.py, profiles/r04_order_sensitivity.json), sequential
         # fp64 training in the 32-run order ends 0.003-0.004 of Recall@20 away from the reference's user-major order on data with
         # structure -- above the +-0.002 bar before any parallel execution -- while the 8-run order stays as close as a random
-        # order does.  0 / None with QREC_ITEM_RUN unset = 8; QREC_ITEM_RUN=0 keeps whole item runs (rounds 1-3).
-        import os as _os0
-        self.item_run = int(item_run if item_run is not None else _os0.environ.get("QREC_ITEM_RUN", "16"))
+        # order does; runs of 16 cost nothing measurable either way and are the default (profiles/r04_item_run_timing.txt).  item_run = 0
+        # keeps whole item runs (rounds 1-3).  A constructor parameter only: the sampler's negatives depend on the stored order, so an
+        # environment variable here would change results behind the caller's back.
+        self.item_run = int(item_run if item_run is not None else ITEM_RUN)
         if schedule == "item":
             self.perm = np.argsort(i, kind="stable")
             if self.item_run > 0 and self.n > self.item_run:

@@ -103,12 +103,12 @@ class SpmmPlan:
     """Device-resident CSR plus its segment decomposition (include/qrec_hip.h, qrec_spmm_csr)."""
 
     def __init__(self, indptr: np.ndarray, indices: np.ndarray, values: np.ndarray, ld: int, seg_len: int = 128,
-                 split_row: int | None = None, chunks: int | None = None, row_chunk: np.ndarray | None = None, degree_norm: bool | None = None):
+                 split_row: int | None = None, chunks: int | None = None, row_chunk: np.ndarray | None = None):
         """``split_row`` (bipartite joint adjacency: the number of users): rows below it only gather operand rows
         at or above it and vice versa, so the two kinds of rows are dealt to different XCDs -- workgroups go round-robin
         over the 8 XCDs, each with its own 4 MiB L2, and the kernel is bound by L2 misses: an XCD that only
         runs user rows caches only the item half of the operand.
-        ``chunks`` (1, 2 or 4, bipartite plans only; env QREC_SPMM_CHUNKS, default 4): the rows of each side are put in
+        ``chunks`` (1, 2 or 4, bipartite plans only; default 4): the rows of each side are put in
         the order of a spectral key (``spectral_row_key``: rows of one community end up next to each other) and cut
         into that many runs of equal non-zeros, each run on XCDs of its own -- on a graph with community structure an
         XCD then gathers mostly its own communities' operand rows (measured: -20 % on a planted-community graph,
@@ -136,7 +136,7 @@ class SpmmPlan:
             raise ValueError("SpmmPlan: row_chunk needs split_row and one entry per row")
         if chunks is None:
             chunks = (int(row_chunk.max()) + 1 if row_chunk is not None and row_chunk.size else
-                      int(os.environ.get("QREC_SPMM_CHUNKS", "4")) if bipartite and indices.size > 0 else 1)
+                      4 if bipartite and indices.size > 0 else 1)
         if chunks not in (1, 2, 4) or (chunks > 1 and not bipartite):
             raise ValueError(f"SpmmPlan: chunks must be 1, 2 or 4 and needs split_row (got {chunks})")
         self.row_chunk = None
@@ -156,20 +156,6 @@ class SpmmPlan:
         self.long_count = up(long_count) if self.n_long else None
         self.partial = DeviceBuffer((max(int(is_long.sum()), 1), ld), np.float32)
         self.indices, self.values = up(indices.astype(np.int32)), up(values.astype(np.float32))
-        # ``degree_norm`` (round 5; env QREC_SPMM_DEGREE_NORM=1, default off -- measured slower): when the matrix IS
-        # D^-1/2 A D^-1/2 of a 0/1 graph (joint_norm_adjacency without duplicated training rows) the product can recompute every value as
-        # fl32(dinv[r]) * dinv[c], dinv = float32(nnz_row ** -0.5), instead of streaming the value array (qrec_spmm_csr_degree_norm).
-        # Taken only if that formula reproduces EVERY stored value bit for bit.
-        self.dinv = None
-        if degree_norm is None:
-            degree_norm = os.environ.get("QREC_SPMM_DEGREE_NORM") == "1"
-        if degree_norm and indices.size and indices.size == int(nnz_row.sum()) and n_rows > int(indices.max()):
-            with np.errstate(divide="ignore"):
-                dinv = np.power(nnz_row.astype(np.float32), -0.5)
-            dinv[np.isinf(dinv)] = 0.0
-            rows = np.repeat(np.arange(n_rows), nnz_row)
-            if np.array_equal((dinv[rows] * np.float32(1.0)) * dinv[indices], values.astype(np.float32)):
-                self.dinv = up(dinv.astype(np.float32))
 
     @staticmethod
     def _row_chunks(indptr, indices, values, split_row: int, chunks: int) -> np.ndarray:

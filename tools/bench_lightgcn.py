@@ -47,21 +47,9 @@ for rep in range(20):
     e0.record(); capi.adam_step(tr.E, tr.m, tr.v, tr.A, N * tr.ld, 0.25, 1e-9); e1.record(); e1.sync(); ts.append(e1.elapsed_ms_since(e0))
 adam_ms = float(np.median(ts))
 alg = tr.plan.bytes_algorithmic(a.dim) + N * a.dim * 4   # + accum RMW read
-# the same product without the value array (qrec_spmm_csr_degree_norm: values recomputed from the degree vector), round 5
-from qrec_amd.graph import SpmmPlan
-plan_dn = SpmmPlan(adj[0], adj[1], adj[2], tr.ld, split_row=nu, row_chunk=tr.plan.row_chunk, degree_norm=True)
-spmm_dn_ms = same_bits = None
-if plan_dn.dinv is not None:
-    Y2 = DB.zeros((N, tr.ld), np.float32)
-    capi.spmm_csr(plan_dn, tr.E, Y2, tr.ld); capi.spmm_csr(tr.plan, tr.E, tr.A, tr.ld)
-    same_bits = bool(np.array_equal(Y2.numpy(), tr.A.numpy()))
-    ts = []
-    for rep in range(20):
-        e0.record(); capi.spmm_csr(plan_dn, tr.E, tr.A, tr.ld, d_accum=tr.S); e1.record(); e1.sync(); ts.append(e1.elapsed_ms_since(e0))
-    spmm_dn_ms = float(np.median(ts))
 out = dict(workload=f"LightGCN L={a.layers} d={a.dim} batch={B} {a.shape}-shape N={N} nnz={nnz}", spmm_chunks=tr.plan.chunks, ms_per_step=dt * 1e3, host_enqueue_ms_per_step=t_host * 1e3, ms_per_step_with_loss_readback=dt_sync * 1e3,
            triplets_per_s=B / dt, steps_per_epoch=-(-n // B), epoch_s=dt * -(-n // B),
-           spmm_degree_norm_ms=spmm_dn_ms, spmm_degree_norm_same_bits=same_bits, spmm_ms=spmm_ms, spmm_algorithmic_GBps=alg / spmm_ms / 1e6, spmm_gather_GBps=(nnz * (8 + a.dim * 4) + 2 * N * a.dim * 4) / spmm_ms / 1e6,
+           spmm_ms=spmm_ms, spmm_algorithmic_GBps=alg / spmm_ms / 1e6, spmm_gather_GBps=(nnz * (8 + a.dim * 4) + 2 * N * a.dim * 4) / spmm_ms / 1e6,
            spmm_gflops=2 * nnz * a.dim / spmm_ms / 1e6, adam_ms=adam_ms, adam_GBps=7 * 4 * N * tr.ld / adam_ms / 1e6, segments=tr.plan.n_segs, long_rows=tr.plan.n_long)
 if a.cpu:
     import scipy.sparse as sp
