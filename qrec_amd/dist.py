@@ -200,9 +200,14 @@ def preflight(comm, kern=_capi, stream=None, timeout_s: float = 90.0, on_hang=No
     import threading
     world, rank = int(comm.world), int(comm.rank)
     result: dict = {}
+    # HIP's current device is a property of the HOST THREAD: the checks run in a thread of their own, which would otherwise talk to device 0
+    # whatever device this rank selected
+    device = kern.current_device() if hasattr(kern, "current_device") else None
 
     def checks():
         try:
+            if device is not None:
+                kern.init(device)
             n = 256
             mine = (np.arange(n, dtype=np.float32) + (rank + 1)).astype(np.float32)
             buf = kern.DeviceBuffer.from_numpy(mine)

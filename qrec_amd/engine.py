@@ -83,26 +83,22 @@ def balanced_chunk(n: int, groups: int = 4096, lo: int = 26, hi: int = 40, prefe
     return best
 
 
-# `auto` (QREC_SCHEDULE unset): which throughput schedule an epoch of `n` triplets runs under.
-#   n >= DEFER_MIN_TRIPLETS   "item-deferred" in DEFER_SUB_EPOCHS sub-epochs: one atomic row update per triplet instead of two (0.63 vs
-#                              0.47 of the roofline on the HBM-resident slice of config #4), the negative item's row lagging a quarter
-#                              epoch.  The lag only costs nothing when a sub-epoch still fills the 16,384-group grid several times over
-#                              (measured free at 25 M triplets, profiles/r03_deferred_sub_epochs.json; at the Yelp2018 shape's 1.25 M the
-#                              grid's window is 44 % of the epoch and the sub-epochs cost more than the deferral wins), and its fidelity
-#                              at this regime is pinned by tests/test_gpu_bpr.py::test_auto_schedule_at_5m_triplets_keeps_recall
-#                              (paired Recall@20 / loss on a 6 M-triplet planted-community graph, bound 0.002).
-#   otherwise                  "item" when a few items collect most interactions (their rows would take the per-triplet atomics of the
-#                              user-major kernel), else "user" -- measured 2.1 vs 1.6 G/s at the Zipf-0.6 Yelp2018 shape.
-DEFER_MIN_TRIPLETS = 5_000_000
-DEFER_SUB_EPOCHS = 4
+# `auto` (QREC_SCHEDULE unset): which throughput schedule an epoch runs under -- ONE-PASS always: "item" when a few items collect most
+# interactions (their rows would take the per-triplet atomics of the user-major kernel), else "user" (measured 2.1 vs 1.6 G/s at the
+# Zipf-0.6 Yelp2018 shape).
+# The deferred-negatives schedule ("item-deferred": one atomic row update per triplet instead of two, 0.62 vs 0.47 of the roofline on tables
+# that live in HBM) is OPT-IN at every size since round 5.  Rounds 3-4 let `auto` pick it in four sub-epochs from 5 M triplets per epoch on,
+# on the evidence of a 6 M-triplet graph at d = 64 (peak-epoch gap 0.0003 / 0.0012).  Measured in round 5 at the size the 0.62 is quoted on
+# (25 M triplets per epoch, d = 128, planted-community graph, profiles/r05_auto_regime_25m.json): paired Recall@20 gap at the reference's
+# peak / at the last epoch 0.0032 / 0.0079 at BPR.conf's rate and 0.0050 / 0.0045 at five times it (8 sub-epochs: 0.0010 / 0.0032 and
+# 0.0028 / 0.0020) against 0.0008 / 0.0002 and 0.0010 / 0.0003 for the one-pass kernel -- outside the +-0.002 bar.  A negative item's row
+# lagging a quarter of an epoch is not free once the learning curve is steep.
 
 
 def resolve_schedule(n_triplets: int, item_degrees=None, requested: str = "auto"):
     """(schedule, sub_epochs or None) for ``BprSgd``; ``item_degrees``: positives per item (None = unknown: treated as skewed)"""
     if requested != "auto":
         return requested, None
-    if n_triplets >= DEFER_MIN_TRIPLETS:
-        return "item-deferred", DEFER_SUB_EPOCHS
     if item_degrees is None:
         return "item", None
     deg = np.asarray(item_degrees)

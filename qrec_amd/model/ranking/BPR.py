@@ -16,9 +16,8 @@ Two execution modes, chosen by the optional conf key ``qrec.mode`` or env ``QREC
     would take the per-triplet atomics), user-major when popularity is flat (measured: 2.1 vs 1.6 G/s at the
     Zipf-0.6 Yelp2018 shape, 1.16 vs 1.21 G/s on a uniform 1 M-item catalogue); ``auto`` looks at max/mean item degree.
     ``item-deferred``: item-major with the negative-side updates applied by a second, j-ordered pass (one atomic row update per
-    triplet instead of two).  ``auto`` picks it, in four sub-epochs, from 5 M triplets per epoch on (engine.resolve_schedule: there
-    the sub-epochs are free and the paired Recall@20 runs stay inside +-0.002); below that it is opt-in -- at the Yelp2018 shape the
-    negative item's row would lag a whole epoch.
+    triplet instead of two: 0.62 vs 0.47 of the roofline on tables that live in HBM).  OPT-IN at every size since round 5: at the size that
+    figure is quoted on its paired Recall@20 gap is 0.003-0.008 (engine.resolve_schedule's comment, profiles/r05_auto_regime_25m.json).
 """
 from __future__ import annotations
 

@@ -24,8 +24,8 @@ SHAPES = {
     # same sizes, but 64 planted communities: 80 % of a user's interactions fall on items of the user's own community
     # (gen_edges_clustered) -- a graph WITH locality to harvest, next to the structureless one (SpMM L2 work)
     "yelp2018-clustered": (31668, 38048, 1237259, 324147, 2018),
-    # a planted-community graph whose epoch (6 M triplets) is in the regime where `auto` picks the deferred schedule in sub-epochs
-    # (engine.resolve_schedule: >= 5 M triplets per epoch); the fidelity tests of that choice run on it
+    # a planted-community graph with a 6 M-triplet epoch (the regime in which rounds 3-4 let `auto` pick the deferred schedule; the fidelity
+    # test of the choice `auto` makes there runs on it)
     "xl6m-clustered": (160000, 100000, 6000000, 1500000, 6006),
     # ... and one at the size the HBM-resident roofline figure is quoted on (25 M triplets per epoch; with d = 128 its tables are 0.54 GB)
     "xl25m-clustered": (650000, 400000, 25000000, 6250000, 2525),

@@ -947,21 +947,22 @@ def test_one_reconciliation_per_epoch_is_not_enough_at_four_ranks():
     assert one["worst_mark"]["abs_diff"] > 1.5 * dflt["worst_mark"]["abs_diff"]
 
 
-def test_auto_schedule_at_5m_triplets_keeps_recall():
-    """`auto` (engine.resolve_schedule) picks the deferred-negatives schedule in four sub-epochs from 5 M triplets per epoch on.  Its
-    fidelity AT THAT REGIME: a 6 M-triplet planted-community graph (160 k x 100 k), five times BPR.conf's rate (the harder case; the
-    ledger profiles/r04_paired_recall.json also has BPR.conf's rate: 0.0003), bound 0.002 at the reference's peak epoch."""
+def test_auto_schedule_at_6m_triplets_keeps_recall():
+    """`auto` (engine.resolve_schedule) at 6 M triplets per epoch (planted-community graph, 160 k x 100 k), five times BPR.conf's rate (the
+    harder case): one-pass item-major since round 5 -- rounds 3-4 picked the deferred-negatives schedule in four sub-epochs from 5 M triplets
+    on, which holds the bar at the reference's peak epoch here (0.0012) but not at the last epoch at BPR.conf's rate (0.0028) and not at all at
+    the size its roofline figure is quoted on (25 M triplets, d = 128: 0.0032 / 0.0079, profiles/r05_auto_regime_25m.json).  Bound 0.002 at the
+    LAST epoch and at the reference's peak epoch."""
     from qrec_amd.engine import resolve_schedule
     from tools import paired_recall as PR
     d = _PAIRED["datasets"].setdefault("xl6m-clustered", PR.load_dataset("xl6m-clustered"))
     sch, sub = resolve_schedule(int(d["items"].size), np.bincount(d["items"], minlength=d["n_items"]))
-    assert (sch, sub) == ("item-deferred", 4) and resolve_schedule(1_252_669, None)[0] == "item"
-    r = _paired(dict(dataset="xl6m-clustered", lr0=0.05, seed=7, mode=f"{sch}:{sub}", epochs=12, eval_every=3))
+    assert sub is None and sch in ("item", "user") and resolve_schedule(1_252_669, None)[0] == "item" and resolve_schedule(25_000_000, None) == ("item", None)
+    r = _paired(dict(dataset="xl6m-clustered", lr0=0.05, seed=7, mode=sch, epochs=12, eval_every=3))
     print("auto regime curve:", [(m, round(a, 4), round(b, 4)) for m, a, b in r["curve"]])
     assert r["same_bold_driver_decisions"] and r["peak"]["recall_exact_order"] > 0.05
-    check("auto schedule (item-deferred, 4 sub-epochs) at 6 M triplets per epoch, lr0 = 0.05: |Recall@20 - exact-order| at the peak epoch", r["peak"]["abs_diff"], 0.002,
-          inclusive=True)
-    check("auto schedule at 6 M triplets per epoch, lr0 = 0.05: relative loss gap after the last epoch", r["final"]["loss_rel_gap"], 0.03)
+    check(f"auto schedule ({sch}-major, one pass) at 6 M triplets per epoch, lr0 = 0.05: |Recall@20 - exact-order| after the last epoch", r["final"]["abs_diff"], 0.002, inclusive=True)
+    check(f"auto schedule ({sch}-major, one pass) at 6 M triplets per epoch, lr0 = 0.05: |Recall@20 - exact-order| at the peak epoch", r["peak"]["abs_diff"], 0.002, inclusive=True)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -156,6 +156,10 @@ def test_rccl_binding_with_a_world_of_one():
         comm.sendrecv_segments(d_r, [(3, 0, 16)], d_o, [], st)                 # peer outside the world
     with pytest.raises(ValueError):
         comm.alltoall_rows(d_r, [1, 2], d_o, [1, 2], 256)
+    # dist.preflight (round 5): the checked first contact bench.py --gpus N makes, here through RCCL itself (no identity short cut)
+    from qrec_amd import dist as qd
+    pre = qd.preflight(comm, stream=st, timeout_s=60)
+    assert pre["ok"] and pre["world"] == 1 and pre["alltoall_rows_sent"] == 1 and pre["allreduce_floats"] == 256
     with pytest.raises(capi.QRecError):
         comm.allreduce(d_a, a.size, 9)
     comm.destroy()

@@ -963,11 +963,12 @@ def test_stride_runs_is_a_permutation_of_whole_runs():
 
 def test_auto_schedule_rule_and_reconciliations():
     from qrec_amd.dist import reconciliations_per_epoch
-    from qrec_amd.engine import DEFER_MIN_TRIPLETS, resolve_schedule
+    from qrec_amd.engine import resolve_schedule
     skew = np.ones(1000); skew[0] = 5000
     assert resolve_schedule(1_252_669, skew) == ("item", None) and resolve_schedule(1_000_000, np.ones(1000)) == ("user", None)
-    assert resolve_schedule(DEFER_MIN_TRIPLETS, np.ones(10)) == ("item-deferred", 4) and resolve_schedule(25_000_000, None) == ("item-deferred", 4)
-    assert resolve_schedule(DEFER_MIN_TRIPLETS - 1, None) == ("item", None)
+    # round 5: `auto` never picks the deferred-negatives schedule (profiles/r05_auto_regime_25m.json: outside the Recall bar at 25 M triplets, d = 128)
+    assert resolve_schedule(6_000_000, np.ones(10)) == ("user", None) and resolve_schedule(25_000_000, None) == ("item", None)
+    assert resolve_schedule(25_000_000, None, "item-deferred") == ("item-deferred", None)
     assert resolve_schedule(10 ** 9, None, "user") == ("user", None)              # an explicit choice is never overridden
     assert [reconciliations_per_epoch(g) for g in (1, 2, 4, 8)] == [1, 1, 2, 2] and reconciliations_per_epoch(8, 1) == 1 and reconciliations_per_epoch(2, 5) == 5
 
