@@ -276,127 +276,14 @@ __global__ __launch_bounds__(256) void grad_z_kernel(const float *__restrict__ E
     }
 }
 
-// =============================================================================================
-// InfoNCE without the n x n block (round 5; ld = 64).  exp_logits_kernel stores the exponentiated logits in both orientations (2 x 16.7 MB
-// at n = 2,048) and the two gradient products read them back: 66 us per side, bound by moving that block through L2, MfmaUtil 10 %.  Here
-// every consumer RECOMPUTES its 32 x 32 tile of logits from the two 0.5 MB operand tables (32 fp32 MFMAs) and keeps it in registers:
-//   nce_rowsum_kernel      psum[split][a] = sum over the split's b of exp(z1[a].z2[b] / tau)
-//   nce_grad_kernel<0>     dz1[a][:] = 1/tau sum_b (E[a][b] / ttl[a] - [a == b]) z2[b][:]
-//   nce_grad_kernel<1>     dz2[b][:] = 1/tau sum_a (E[a][b] / ttl[a] - [a == b]) z1[a][:]
-// A wavefront owns 32 consecutive indices of ONE side (the tile's columns: col = lane & 31) and walks the other side (the tile's rows) in
-// 32-row tiles, its share of kNceSplit slices of them.  The logits tile comes out of v_mfma_f32_32x32x2f32 in the C layout -- lane (r, h)
-// holds rows (q & 3) + 8 (q >> 2) + 4 h, q = 0..15, of column r -- and that IS the layout of the B operand of the next MFMA when the
-// reduction runs over the tile's rows in that same order: step s contracts the row pair {row(s, 0), row(s, 1)}, lane (r, h) supplies
-// B[row(s, h)][r] = its own element s and A[j][row(s, h)] = z[row(s, h)][j0 + r] (a coalesced dword load).  So the tile never leaves the
-// registers, the product comes out transposed (rows <-> embedding columns j, columns <-> the owned indices), and lane (r, h) stores float4
-// pieces of its owned row.  Same logits, bit for bit, as exp_logits_kernel (same operands in the same k order); the sums over b / a run
-// in another order (fp32 rounding).  3 x 0.54 + 2 x 0.54 GFLOP of fp32 MFMA per side instead of 2 x 33 MB of L2 traffic.
-// =============================================================================================
-constexpr int kNceSplit = 16;
-
-__device__ __forceinline__ f32x16 nce_logits_tile(const f32x4 (&loop_rows)[8], const f32x4 (&own_rows)[8]) {
-    f32x16 t;
-#pragma unroll
-    for (int q = 0; q < 16; q++) t[q] = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        t = __builtin_amdgcn_mfma_f32_32x32x2f32(loop_rows[q].x, own_rows[q].x, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x2f32(loop_rows[q].y, own_rows[q].y, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x2f32(loop_rows[q].z, own_rows[q].z, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x2f32(loop_rows[q].w, own_rows[q].w, t, 0, 0, 0);
-    }
-    return t;
-}
-
-// z1, z2: [n_pad][64], pad rows zero.  grid (n_pad / 32, kNceSplit / 4), 256 threads: wavefront = (own block, split)
-__global__ __launch_bounds__(256) void nce_rowsum_kernel(const float *__restrict__ z1, const float *__restrict__ z2, int n, int n_pad,
-                                                         float inv_tau, float *__restrict__ psum) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-    const int a0 = blockIdx.x * 32, split = blockIdx.y * 4 + wave;
-    const int tiles = n_pad / 32, per = (tiles + kNceSplit - 1) / kNceSplit;
-    const int t_beg = split * per, t_end = (t_beg + per) < tiles ? (t_beg + per) : tiles;
-    f32x4 own[8];
-    const f32x4 *po = reinterpret_cast<const f32x4 *>(z1 + (int64_t)(a0 + r) * 64 + 32 * h);
-#pragma unroll
-    for (int q = 0; q < 8; q++) own[q] = po[q];
-    const int a = a0 + r;
-    float sum = 0.f;
-    for (int t = t_beg; t < t_end; t++) {
-        const int b0 = t * 32;
-        f32x4 lp[8];
-        const f32x4 *pl = reinterpret_cast<const f32x4 *>(z2 + (int64_t)(b0 + r) * 64 + 32 * h);
-#pragma unroll
-        for (int q = 0; q < 8; q++) lp[q] = pl[q];
-        const f32x16 T = nce_logits_tile(lp, own);
-#pragma unroll
-        for (int s = 0; s < 16; s++) {
-            const int b = b0 + (s & 3) + 8 * (s >> 2) + 4 * h;
-            sum += (a < n && b < n) ? expf(T[s] * inv_tau) : 0.f;
-        }
-    }
-    sum += __shfl_xor(sum, 32, kWave);
-    if (h == 0) psum[(int64_t)split * n_pad + a] = sum;
-}
-
-// MODE 0: own = z1 (index a), loop = z2 (index b), out = dz1 parts.  MODE 1: own = z2 (b), loop = z1 (a), out = dz2 parts.
-// out_parts [kNceSplit][n_pad][64]; diag as in grad_z_kernel (1: the positive is the own index itself)
-template <int MODE>
-__global__ __launch_bounds__(256) void nce_grad_kernel(const float *__restrict__ z_own, const float *__restrict__ z_loop,
-                                                       const float *__restrict__ inv_ttl, int n, int n_pad, float inv_tau, float diag,
-                                                       float *__restrict__ out_parts) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-    const int o0 = blockIdx.x * 32, split = blockIdx.y * 4 + wave;
-    const int tiles = n_pad / 32, per = (tiles + kNceSplit - 1) / kNceSplit;
-    const int t_beg = split * per, t_end = (t_beg + per) < tiles ? (t_beg + per) : tiles;
-    f32x4 own[8];
-    const f32x4 *po = reinterpret_cast<const f32x4 *>(z_own + (int64_t)(o0 + r) * 64 + 32 * h);
-#pragma unroll
-    for (int q = 0; q < 8; q++) own[q] = po[q];
-    const int o = o0 + r;
-    const float my_inv = MODE == 0 ? inv_ttl[o] : 0.f;       // inv_ttl is indexed by a: the own index in MODE 0, the loop index in MODE 1
-    const float dgl = o < n ? diag : 0.f;
-    f32x16 out0, out1;                                         // rows <-> embedding columns [0, 32) / [32, 64), columns <-> own indices
-#pragma unroll
-    for (int q = 0; q < 16; q++) { out0[q] = 0.f; out1[q] = 0.f; }
-    for (int t = t_beg; t < t_end; t++) {
-        const int l0 = t * 32;
-        f32x4 lp[8];
-        const f32x4 *pl = reinterpret_cast<const f32x4 *>(z_loop + (int64_t)(l0 + r) * 64 + 32 * h);
-#pragma unroll
-        for (int q = 0; q < 8; q++) lp[q] = pl[q];
-        // the second product's A operand: z_loop[l0 + row(s, h)][r] and [32 + r]: issued before the first product's MFMAs
-        float za[16], zb[16];
-#pragma unroll
-        for (int s = 0; s < 16; s++) {
-            const float *pz = z_loop + (int64_t)(l0 + (s & 3) + 8 * (s >> 2) + 4 * h) * 64 + r;
-            za[s] = pz[0]; zb[s] = pz[32];
-        }
-        f32x4 inv4[4];
-        if (MODE == 1) {
-#pragma unroll
-            for (int g = 0; g < 4; g++) inv4[g] = *reinterpret_cast<const f32x4 *>(inv_ttl + l0 + 8 * g + 4 * h);
-        }
-        const f32x16 T = nce_logits_tile(lp, own);
-#pragma unroll
-        for (int s = 0; s < 16; s++) {
-            const int li = l0 + (s & 3) + 8 * (s >> 2) + 4 * h;
-            const float e = (o < n && li < n) ? expf(T[s] * inv_tau) : 0.f;
-            const float inv = MODE == 0 ? my_inv : inv4[s >> 2][s & 3];
-            const float p = e * inv - (li == o ? dgl : 0.f);
-            out0 = __builtin_amdgcn_mfma_f32_32x32x2f32(za[s], p, out0, 0, 0, 0);
-            out1 = __builtin_amdgcn_mfma_f32_32x32x2f32(zb[s], p, out1, 0, 0, 0);
-        }
-    }
-    float *out = out_parts + ((int64_t)split * n_pad + o) * 64;
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        f32x4 v0 = {out0[4 * g] * inv_tau, out0[4 * g + 1] * inv_tau, out0[4 * g + 2] * inv_tau, out0[4 * g + 3] * inv_tau};
-        f32x4 v1 = {out1[4 * g] * inv_tau, out1[4 * g + 1] * inv_tau, out1[4 * g + 2] * inv_tau, out1[4 * g + 3] * inv_tau};
-        *reinterpret_cast<f32x4 *>(out + 8 * g + 4 * h) = v0;
-        *reinterpret_cast<f32x4 *>(out + 32 + 8 * g + 4 * h) = v1;
-    }
-}
-
+// (Round 5, built, measured and removed: InfoNCE WITHOUT the n x n block -- every consumer recomputes its 32 x 32 tile of logits from the two
+// 0.5 MB operand tables and keeps it in registers; the C layout of v_mfma_f32_32x32x2f32 is the B-operand layout of the next MFMA when the
+// reduction walks the tile's rows in that order, so the tile never leaves the registers.  Correct on the first run (same tests, same bounds),
+// and not faster at n = 2,048: row sums 19.0 us + the two gradient products 28.2 + 24.8 us = 72 us against exp_logits 21.4 + grad_z 20.7 +
+// 20.4 = 62.5 us -- 96 dependent fp32 MFMAs per tile at 64 clocks each are 2.6 us per tile and wavefront, one wavefront per SIMD, and the
+// operand loads of the next tile could not be hidden behind them (double-buffered: 29 + 38 us, 292 registers).  At K = d = 64 the fp32 MFMA
+// rate, not the 33 MB of logits, is the floor of this formulation.  profiles/r05_simgcl_flash_nce*_kernel_stats.txt; the kernels are in
+// git history (commit "auto never picks the deferred-negatives schedule ...").)
 // d_out[rows[k]] += scale * ( (dz1 - z1 (z1.dz1)) r1 + (dz2 - z2 (z2.dz2)) r2 )
 template <int LPR>
 __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float *__restrict__ z1, const float *__restrict__ z2,
@@ -445,31 +332,16 @@ int run_info_nce(const float *S1, const float *S2, float div, const int32_t *row
     const unsigned row_blocks = (unsigned)((n + 4 * GPW - 1) / (4 * GPW)), pad_blocks = (unsigned)((n_pad + 4 * GPW - 1) / (4 * GPW));
     hipLaunchKernelGGL((gather_normalize_kernel<LPR>), dim3(pad_blocks), dim3(256), 0, st, S1, S2, div, rows, n, n_pad, z1, z2, r1, r2, dotp);
     QREC_LAUNCH_CHECK();
-    if (ld == 64) {
-        // the n x n block is never formed (nce_* kernels above); the split partial sums live where ExT would (n_pad >= 64 > kNceSplit)
-        static_assert(kNceSplit == kSplitK, "normalize_bwd_kernel adds kSplitK partial tables");
-        float *ps = ExT;
-        const dim3 ng((unsigned)(n_pad / 32), (unsigned)(kNceSplit / 4));
-        hipLaunchKernelGGL(nce_rowsum_kernel, ng, dim3(256), 0, st, z1, z2, n, n_pad, inv_tau, ps);
-        QREC_LAUNCH_CHECK();
-        hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, ps, kNceSplit, n, n_pad, dotp, inv_tau, inv_ttl, loss);
-        QREC_LAUNCH_CHECK();
-        hipLaunchKernelGGL((nce_grad_kernel<0>), ng, dim3(256), 0, st, z1, z2, inv_ttl, n, n_pad, inv_tau, 1.f, dz1);
-        QREC_LAUNCH_CHECK();
-        hipLaunchKernelGGL((nce_grad_kernel<1>), ng, dim3(256), 0, st, z2, z1, inv_ttl, n, n_pad, inv_tau, 1.f, dz2);
-        QREC_LAUNCH_CHECK();
-    } else {
-        hipLaunchKernelGGL(exp_logits_kernel, dim3((unsigned)(n_pad / 32), (unsigned)((n_pad / 32 + 3) / 4)), dim3(256), 0, st,
-                           z1, z2, n, n_pad, ld, inv_tau, ExT, Ex, psum);
-        QREC_LAUNCH_CHECK();
-        hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, psum, n_pad / 32, n, n_pad, dotp, inv_tau, inv_ttl, loss);
-        QREC_LAUNCH_CHECK();
-        const dim3 gg((unsigned)(n_pad / 32), (unsigned)((ld + 31) / 32), (unsigned)(kSplitK / 4));
-        hipLaunchKernelGGL((grad_z_kernel<0>), gg, dim3(256), 0, st, Ex, inv_ttl, z2, n, n_pad, ld, inv_tau, 1.f, dz1);
-        QREC_LAUNCH_CHECK();
-        hipLaunchKernelGGL((grad_z_kernel<1>), gg, dim3(256), 0, st, ExT, inv_ttl, z1, n, n_pad, ld, inv_tau, 1.f, dz2);
-        QREC_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(exp_logits_kernel, dim3((unsigned)(n_pad / 32), (unsigned)((n_pad / 32 + 3) / 4)), dim3(256), 0, st,
+                       z1, z2, n, n_pad, ld, inv_tau, ExT, Ex, psum);
+    QREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, psum, n_pad / 32, n, n_pad, dotp, inv_tau, inv_ttl, loss);
+    QREC_LAUNCH_CHECK();
+    const dim3 gg((unsigned)(n_pad / 32), (unsigned)((ld + 31) / 32), (unsigned)(kSplitK / 4));
+    hipLaunchKernelGGL((grad_z_kernel<0>), gg, dim3(256), 0, st, Ex, inv_ttl, z2, n, n_pad, ld, inv_tau, 1.f, dz1);
+    QREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL((grad_z_kernel<1>), gg, dim3(256), 0, st, ExT, inv_ttl, z1, n, n_pad, ld, inv_tau, 1.f, dz2);
+    QREC_LAUNCH_CHECK();
     hipLaunchKernelGGL((normalize_bwd_kernel<LPR>), dim3(row_blocks), dim3(256), 0, st, z1, z2, dz1, dz2, r1, r2, rows, n, tab, cl_rate, d_out, d_out2);
     QREC_LAUNCH_CHECK();
     return QREC_OK;
