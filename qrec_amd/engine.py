@@ -168,7 +168,7 @@ class BprSgd:
     def __init__(self, tables: DeviceTables, u: np.ndarray, i: np.ndarray, pos: CSR | None = None,
                  schedule: str = "user", n_items: int | None = None, batches: int = 1, chunk: int = 32,
                  sub_epochs: int | None = None, sub_chunk: int | None = None, overlap_passes: bool = True,
-                 item_run: int | None = None):
+                 item_run: int | None = None, fresh: bool = False):
         """``schedule``: "user" keeps the reference's user-major order (required by the order-exact
         kernel); "item" stores the same triplets sorted by positive item for the item-major
         throughput kernel (``self.perm`` maps scheduled position -> reference position).
@@ -194,6 +194,10 @@ class BprSgd:
         auto_chunk = max(8, min(32, (int(u.size) // max(self.sub_epochs, 1)) // (4 * 16384)))
         self.sub_chunk = int(sub_chunk if sub_chunk is not None else auto_chunk)
         self._overlap_passes = bool(overlap_passes)
+        # deferred schedule only: pass B re-forms every coefficient against the negative item's row as its j-run left it (the log then holds
+        # P[u].Q[i] instead of the coefficient; include/qrec_hip.h QREC_DEFERRED_FRESH) -- the negative-side terms of a row stop being computed
+        # all against the row as the (sub-)epoch found it
+        self.fresh = bool(fresh) and self.deferred
         self._stream_b = None
         self.t = tables
         # size of the item catalogue the triplets' ids refer to: the table's rows, except when this process holds only a
@@ -329,10 +333,10 @@ class BprSgd:
             capi.bpr_sgd_hogwild_item_major_deferred_sub(P, Q, t.d, t.ld, d_u, d_i, d_j, n, self.sub_chunk, groups, min(flush_every, self.sub_chunk),
                                                          lr, regU, regI, self.d_stats, self.d_work, self.sub_epochs, stream,
                                                          self._stream_b if self._overlap_passes else None, d_drv, p_rows=p_rows,
-                                                         is_sorted=self._sorted)
+                                                         is_sorted=self._sorted, fresh=self.fresh)
         else:
             capi.bpr_sgd_hogwild_item_major_deferred(P, Q, t.d, t.ld, d_u, d_i, d_j, n, chunk, groups, flush_every, lr, regU, regI,
-                                                     self.d_stats, self.d_work, stream, d_drv, p_rows=p_rows, is_sorted=self._sorted)
+                                                     self.d_stats, self.d_work, stream, d_drv, p_rows=p_rows, is_sorted=self._sorted, fresh=self.fresh)
 
     def take_prefetched_negatives(self, epoch: int, stream=None):
         """Make `stream` wait for the prefetched negatives of `epoch` and switch to them."""

@@ -1009,4 +1009,5 @@ def test_paired_recall_harness_host_logic():
         for lr0 in (0.01, 0.05):
             assert {(ds, lr0, m, 1, "") for m in ("item", "user", "item-deferred", "item-deferred:4")} <= keys
             assert {(ds, lr0, "item", w, l) for w in (2, 4) for l in ("replicated", "sharded")} <= keys
-    assert PR.parse_mode("item-deferred:4:19") == ("item-deferred", 4, 19) and PR.parse_mode("item") == ("item", None, None)
+    assert PR.parse_mode("item-deferred:4:19") == ("item-deferred", 4, 19, False) and PR.parse_mode("item") == ("item", None, None, False)
+    assert PR.parse_mode("item-deferred:4:fresh") == ("item-deferred", 4, None, True) and PR.parse_mode("item-deferred:8:32:fresh") == ("item-deferred", 8, 32, True)

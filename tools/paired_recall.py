@@ -67,8 +67,12 @@ def recall20(P, Q, d, N: int = 20) -> float:
 
 
 def parse_mode(mode: str):
+    """"item-deferred:S[:chunk][:fresh]" -> (schedule, sub-epochs, pass-A chunk, fresh coefficient)"""
     parts = mode.split(":")
-    return parts[0], (int(parts[1]) if len(parts) > 1 else None), (int(parts[2]) if len(parts) > 2 else None)
+    fresh = parts[-1] == "fresh"
+    if fresh:
+        parts = parts[:-1]
+    return parts[0], (int(parts[1]) if len(parts) > 1 and parts[1] else None), (int(parts[2]) if len(parts) > 2 and parts[2] else None), fresh
 
 
 def _rank_problem(d, world, rank):
@@ -97,14 +101,14 @@ def build_rank(d, mode, world, rank, layout, P0, Q0, shard_batch=1 << 20, syncs=
     from qrec_amd import dist as qd
     from qrec_amd.engine import BprSgd, DeviceTables, balanced_chunk
     from qrec_amd.interactions import CSR
-    schedule, S, sub_chunk = parse_mode(mode)
+    schedule, S, sub_chunk, fresh = parse_mode(mode)
     lo, hi, lp, li, lu = _rank_problem(d, world, rank)
     sharded = world > 1 and layout == "sharded"
     t = DeviceTables(P0[lo:hi], qd.shard_item_rows(Q0, world, rank) if sharded else Q0, np.float32)
     chunk = balanced_chunk(int(li.size))
     batches = n_batches_for(d, world, layout, shard_batch, syncs)
     sgd = BprSgd(t, lu, li, CSR(lp, li), schedule=schedule, n_items=d["n_items"], batches=batches,
-                 chunk=chunk, sub_epochs=S, sub_chunk=sub_chunk, item_run=item_run)
+                 chunk=chunk, sub_epochs=S, sub_chunk=sub_chunk, item_run=item_run, fresh=fresh)
     chunk, groups = sgd.launch_grid(rounds)                 # (an epoch in batches: engine.launch_chunk per batch, unchanged)
     return t, sgd, chunk, lo, hi, groups
 

@@ -20,8 +20,8 @@ j2 = rng.integers(0, I2, n2, dtype=np.int32)
 t = DeviceTables(P2, Q2, np.float32)
 alg = n2 * B.bytes_per_triplet(d2)
 e0, e1 = capi.Event(), capi.Event()
-for cfg in json.loads(sys.argv[1]):
-    s = BprSgd(t, u2, i2, None, schedule=cfg.get("schedule", "item-deferred"), sub_epochs=cfg.get("S", 4), sub_chunk=cfg.get("sub_chunk"), item_run=cfg.get("item_run"))
+for cfg in (json.load(open(sys.argv[1])) if os.path.exists(sys.argv[1]) else json.loads(sys.argv[1])):
+    s = BprSgd(t, u2, i2, None, schedule=cfg.get("schedule", "item-deferred"), sub_epochs=cfg.get("S", 4), sub_chunk=cfg.get("sub_chunk"), item_run=cfg.get("item_run"), fresh=cfg.get("fresh", False))
     s.set_negatives(j2)
     ts = []
     for _ in range(4):
