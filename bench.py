@@ -617,7 +617,8 @@ def main():
     from qrec_amd.synth import make_dataset, to_csr
     capi.init(local_rank)
     if use_dist:
-        comm = qd.make_comm(control)
+        with qd.watchdog(f"rank {rank} of {world}: creating the RCCL communicator (ncclCommInitRank waits for ALL ranks)", float(os.environ.get("QREC_PREFLIGHT_TIMEOUT", "90"))):
+            comm = qd.make_comm(control)
     # first contact with the communicator, before anything is timed: a tiny all-reduce and a ragged all-to-all round trip, checked, under a
     # watchdog -- a wrong value raises, a hang ends the process with one line on stderr (qrec_amd/dist.py preflight)
     pre = qd.preflight(comm, stream=None, timeout_s=float(os.environ.get("QREC_PREFLIGHT_TIMEOUT", "90"))) if use_dist else None

@@ -186,6 +186,35 @@ def make_comm(control: ControlPlane):
     return _capi.Comm(control.world, control.rank, uid)
 
 
+class watchdog:
+    """``with watchdog("what", seconds):`` -- if the block has not finished after ``seconds``, one line on stderr and ``os._exit(3)``.  For the
+    calls of a multi-process start-up that block inside a library when the ranks do not all arrive (``ncclCommInitRank``): a hung job says
+    nothing, a dead one says why.  ``on_hang(reason)`` replaces the exit (tests)."""
+
+    def __init__(self, what: str, seconds: float, on_hang=None):
+        self.what, self.seconds, self.on_hang, self._timer = what, float(seconds), on_hang, None
+
+    def _fire(self):
+        reason = f"qrec watchdog: {self.what} did not complete within {self.seconds:.0f} s"
+        if self.on_hang is not None:
+            self.on_hang(reason)
+            return
+        import sys as _sys
+        print(reason, file=_sys.stderr, flush=True)
+        os._exit(3)
+
+    def __enter__(self):
+        import threading
+        self._timer = threading.Timer(self.seconds, self._fire)
+        self._timer.daemon = True
+        self._timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._timer.cancel()
+        return False
+
+
 def preflight(comm, kern=_capi, stream=None, timeout_s: float = 90.0, on_hang=None) -> dict:
     """First contact with the data-plane communicator, before anything is timed (round 5): a tiny all-reduce and an
     ``alltoall_rows`` round trip with ragged row counts, both checked against what they must return, under a watchdog.
@@ -715,7 +744,10 @@ def init_from_env():
     local = 0 if one_device else int(os.environ.get("LOCAL_RANK", "0"))
     os.environ["QREC_DEVICE"] = str(local)
     _capi.init(local)
-    comm = make_comm(control)
+    limit = float(os.environ.get("QREC_PREFLIGHT_TIMEOUT", "90"))
+    with watchdog(f"rank {control.rank} of {world}: creating the RCCL communicator (ncclCommInitRank waits for ALL ranks)", limit):
+        comm = make_comm(control)
+    preflight(comm, timeout_s=limit)          # a tiny all-reduce and a ragged all-to-all round trip, checked, before anything trains
     seed = int(control.allreduce_host(np.array([int(os.environ.get("QREC_SEED", time.time_ns() % (2 ** 31)))
                                                 if control.rank == 0 else 0], dtype=np.int64))[0])
     random.seed(seed); np.random.seed(seed % (2 ** 32))

@@ -147,6 +147,14 @@ def test_preflight_names_a_wrong_collective_and_a_hung_one():
     said = []
     r = qd.preflight(Hung(), kern=HK, timeout_s=0.3, on_hang=said.append)
     assert r["ok"] is False and len(said) == 1 and "did not complete within" in said[0] and "\n" not in said[0]
+    # the same guard around a blocking start-up call (bench.py wraps the communicator's creation in it)
+    said = []
+    with qd.watchdog("creating the communicator", 0.2, on_hang=said.append):
+        time.sleep(0.6)
+    with qd.watchdog("something quick", 5.0, on_hang=said.append):
+        pass
+    time.sleep(0.1)
+    assert len(said) == 1 and "creating the communicator did not complete within" in said[0]
 
 
 def _batch_change(rank, b, n_rows, ld):
