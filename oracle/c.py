@@ -56,6 +56,8 @@ def lib():
         L.orc_svdpp_sgd_f64.restype = f64
         L.orc_find_k_largest.argtypes = [i32, vp, i32, vp, vp]
         L.orc_find_k_largest.restype = C.c_int
+        L.orc_philox4x32_10.argtypes = [vp, vp, vp]
+        L.orc_philox_bpr_sample.argtypes = [vp, vp, vp, i64, i32, u64, u64, vp]
         _lib = L
     return _lib
 
@@ -240,3 +242,20 @@ def find_k_largest(K: int, cand):
     ids = np.empty(k, dtype=np.int32); sc = np.empty(k, dtype=np.float64)
     lib().orc_find_k_largest(K, _p(cand), cand.size, _p(ids), _p(sc))
     return ids, sc
+
+
+def philox4x32_10(ctr, key) -> np.ndarray:
+    """one Philox4x32-10 block (Random123): 4 counter words, 2 key words -> 4 output words"""
+    c, k, out = np.asarray(ctr, dtype=np.uint32).copy(), np.asarray(key, dtype=np.uint32).copy(), np.zeros(4, dtype=np.uint32)
+    assert c.size == 4 and k.size == 2
+    lib().orc_philox4x32_10(_p(c), _p(k), _p(out))
+    return out
+
+
+def philox_bpr_sample(indptr, sorted_items, row_user, n_items: int, seed: int, epoch: int) -> np.ndarray:
+    """the throughput-mode negative sampler (qrec_philox_bpr_sample) on the CPU: j[t] for every stored position t"""
+    _chk(indptr, np.int64); _chk(sorted_items, np.int32); _chk(row_user, np.int32)
+    out = np.empty(row_user.size, dtype=np.int32)
+    lib().orc_philox_bpr_sample(_p(indptr), _p(sorted_items), _p(row_user), row_user.size, n_items,
+                                int(seed) & 0xFFFFFFFFFFFFFFFF, int(epoch) & 0xFFFFFFFFFFFFFFFF, _p(out))
+    return out

@@ -241,6 +241,55 @@ int64_t orc_bpr_sample_epoch(orc_mt *s, const int64_t *pos_indptr, const int32_t
     return words;
 }
 
+/* a-1, throughput mode: the counter-based negative sampler of include/qrec_hip.h (qrec_philox_bpr_sample).  NOT the
+ * reference's stream (that is orc_bpr_sample_epoch above) -- the same DISTRIBUTION as BPR.py:35-37 (uniform over the items
+ * that are not positives of the user, by rejection) drawn so that a triplet's negative depends on (seed, epoch, t) alone.
+ * Third-party algorithm, restated from its publication: Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random
+ * numbers: as easy as 1, 2, 3", SC'11; Random123 1.x philox.h) -- multipliers 0xD2511F53 / 0xCD9E8D57, Weyl key bumps
+ * 0x9E3779B9 / 0xBB67AE85, ten rounds; pinned to Random123's known-answer vectors in tests/test_oracle_rng.py.
+ * Contract of the sampler (the device kernel is held to this function bit for bit):
+ *   counter = {t_lo, t_hi, block, epoch_lo}, key = {seed_lo, seed_hi ^ epoch_hi}, block = 0, 1, ...
+ *   the block's four words in order: candidate = word >> (32 - bit_length(n_items)); skipped if >= n_items or if it is a
+ *   positive of row_user[t] (sorted CSR row); the first survivor is j[t].  None in blocks 0 .. 4096: -1 (every item positive). */
+static inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    int r;
+    for (r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+void orc_philox4x32_10(const uint32_t *ctr, const uint32_t *key, uint32_t *out) {
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+    philox4x32_10(c, key[0], key[1]);
+    memcpy(out, c, sizeof c);
+}
+static int row_contains(const int32_t *a, int64_t n, int32_t x);
+void orc_philox_bpr_sample(const int64_t *indptr, const int32_t *sorted_items, const int32_t *row_user, int64_t n,
+                           int32_t n_items, uint64_t seed, uint64_t epoch, int32_t *j_out) {
+    const int shift = 32 - bit_length_u32((uint32_t)n_items);
+    int64_t t;
+    for (t = 0; t < n; t++) {
+        const int32_t u = row_user[t];
+        const int32_t *row = sorted_items + indptr[u];
+        const int64_t len = indptr[u + 1] - indptr[u];
+        int32_t pick = -1;
+        uint32_t block;
+        for (block = 0; pick < 0 && block <= 4096; block++) {
+            uint32_t c[4] = {(uint32_t)t, (uint32_t)((uint64_t)t >> 32), block, (uint32_t)epoch};
+            int w;
+            philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(epoch >> 32));
+            for (w = 0; w < 4 && pick < 0; w++) {
+                const uint32_t r = shift ? (c[w] >> shift) : c[w];
+                if (r >= (uint32_t)n_items || row_contains(row, len, (int32_t)r)) continue;
+                pick = (int32_t)r;
+            }
+        }
+        j_out[t] = pick;
+    }
+}
+
 /* a-2  Triplet sampler, TF path: base/deepRecommender.py:29-52 (next_batch_pairwise).
  * The caller applies shuffle(trainingData) first (orc_shuffle on a row permutation);
  * this function then walks the rows in the shuffled order and draws one negative per

@@ -383,9 +383,11 @@ def test_graph_batch_parallel_equals_the_whole_step():
 
 
 # ---- graph models: 1-D row partition of the propagation (qrec_amd.dist.RowPartition) ------------------------------
-def _rowpart_worker(rank, world, port, out):
+def _rowpart_worker(rank, world, port, out, n_sub=None):
     control, comm = _join(rank, world, port)
     _, _, _, _, A = _graph_problem()
+    if n_sub:
+        A = A[:n_sub, :n_sub]
     n, ld = A.shape[0], 8
     rng = np.random.default_rng(3)
     X = rng.standard_normal((n, ld)).astype(np.float32); dY = rng.standard_normal((n, ld)).astype(np.float32)
@@ -431,3 +433,26 @@ def test_row_partitioned_propagation_equals_the_whole_product():
         # the compact operand never holds more than the whole table beside the rank's own (padded) block; the bytes a rank SENDS per
         # product are rows of its own block, at most once to every other rank
         assert ref_rows <= n + (hi - lo) + 32 and 0 < ref_bytes <= (hi - lo) * (world - 1) * ld * 4
+
+
+def test_row_partition_with_empty_trailing_ranks():
+    """rows per rank are rounded up to a multiple of 32 (bitmap word boundary), so on a table of fewer than 32 x world rows the
+    trailing ranks own NOTHING (lo == hi == n_rows).  70 rows over 4 ranks = blocks of 32 / 32 / 6 / 0: every collective keeps its uniform
+    shape, the empty rank contributes zeros, refers to nothing and is sent nothing, and the others' products are the whole product's rows."""
+    world, n = 4, 70
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_rowpart_worker, args=(world, _free_port(), out, n), nprocs=world, join=True)
+    _, _, _, _, A = _graph_problem()
+    A = A[:n, :n]
+    ld = 8
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((n, ld)).astype(np.float32); dY = rng.standard_normal((n, ld)).astype(np.float32)
+    Y, dX = A @ X, A.T @ dY
+    assert [(out[r][0], out[r][1]) for r in range(world)] == [(0, 32), (32, 64), (64, 70), (70, 70)]
+    for r in range(world):
+        lo, hi, Yr, dXr, Yref, ref_rows, ref_bytes = out[r]
+        assert Yr.shape == (hi - lo, ld) and dXr.shape == (hi - lo, ld) and Yref.shape == (hi - lo, ld)
+        np.testing.assert_allclose(Yr, Y[lo:hi], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(dXr, dX[lo:hi], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(Yref, Y[lo:hi], rtol=0, atol=1e-6)
+    assert out[3][5] == 32 and out[3][6] == 0            # the empty rank: a compact operand of its own (all-pad) block, nothing sent

@@ -343,6 +343,30 @@ def test_philox_sampler_properties():
     assert chi2 < 120, chi2   # 49 dof; positives thin some bins slightly
 
 
+@pytest.mark.parametrize("n_items,seed,epoch", [(1500, 1234, 0), (1024, 2 ** 40 + 17, 3), (1025, 99, 2 ** 33 + 1), (38048, 2 ** 63 + 5, 99), (5, 7, 1)])
+def test_philox_sampler_stream_equals_the_oracle(n_items, seed, epoch):
+    """north_star: "bit-exact on the sampled index stream".  The throughput mode's stream is not the reference's (exact mode replays
+    that one word for word); it is a function of (seed, epoch, stored position) stated by the oracle (orc_philox_bpr_sample, Philox4x32-10
+    pinned to Random123's known answers on the CPU) -- the device sampler is held to it bit for bit: item counts at and next to a power of
+    two, 64-bit seeds and epochs, a user with every item positive (-1), any stored order."""
+    from oracle import c as O
+    rng = np.random.default_rng(n_items)
+    U = 400
+    rows = [np.sort(rng.choice(n_items, size=int(rng.integers(1, max(2, min(n_items // 2, 300)))), replace=False)).astype(np.int32) for _ in range(U)]
+    rows[17] = np.arange(n_items, dtype=np.int32) if n_items <= 2048 else rows[17]
+    indptr = np.concatenate([[0], np.cumsum([r.size for r in rows])]).astype(np.int64)
+    items = np.concatenate(rows)
+    row_user = rng.permutation(np.repeat(np.arange(U, dtype=np.int32), np.diff(indptr))).astype(np.int32)
+    d_j = DB(row_user.size, np.int32)
+    capi.philox_bpr_sample(DB.from_numpy(indptr), DB.from_numpy(items), DB.from_numpy(row_user), row_user.size, n_items, seed, epoch, d_j)
+    capi.device_sync()
+    want = O.philox_bpr_sample(indptr, items, row_user, n_items, seed, epoch)
+    assert np.array_equal(d_j.numpy(), want)
+    if n_items <= 2048:
+        assert (want[row_user == 17] == -1).all()
+    assert (want[row_user != 17] >= 0).all()
+
+
 def test_sumsq_and_runtime_errors():
     rng = np.random.default_rng(0)
     for dtype in (np.float32, np.float64):

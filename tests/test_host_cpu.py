@@ -987,6 +987,18 @@ def test_paired_recall_harness_host_logic():
     assert c["final"]["loss_rel_gap"] == pytest.approx(0.001 / 1.001, rel=1e-6)
     g2 = dict(g, lr=[x * (0.5 if k == 7 else 1.0) for k, x in enumerate(g["lr"])])
     assert not PR.compare({}, g2, r)["same_bold_driver_decisions"]
+    # the reference side of an earlier results file (a 25 M-triplet reference is 7 min of the GPU box's host): same dataset / seed / rate /
+    # epochs / dimension and a mode of the same stored order -> that case's curve; no loss or learning rates -> those comparisons stay empty
+    case = {"dataset": "xl25m-clustered", "lr0": 0.01, "seed": 7, "mode": "item-deferred:4:fresh", "epochs": 30, "eval_every": 5, "dim": 128}
+    cr = PR.cached_reference("profiles/r05_auto_regime_25m.json", case, "item")
+    assert sorted(cr["recall"]) == [5, 10, 15, 20, 25, 30] and cr["loss"] is None and "r05_auto_regime_25m" in cr["cached_from"]
+    g3 = {"recall": {m: v + 0.001 for m, v in cr["recall"].items()}, "loss": [1.0] * 30, "lr": [0.01] * 30}
+    c3 = PR.compare(case, g3, cr)
+    assert c3["final"]["abs_diff"] == pytest.approx(0.001) and c3["final"]["loss_rel_gap"] is None and c3["same_bold_driver_decisions"] is None
+    with pytest.raises(KeyError):
+        PR.cached_reference("profiles/r05_auto_regime_25m.json", dict(case, seed=8), "item")
+    with pytest.raises(KeyError):
+        PR.cached_reference("profiles/r05_auto_regime_25m.json", case, "user")
     # the one-pass item-major kernel's time order: every stored position once, chunk by chunk in the launcher's stride order
     n, chunk = 1000, 32
     sgd = SimpleNamespace(n=n, perm=np.random.default_rng(0).permutation(n))

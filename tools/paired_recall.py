@@ -241,18 +241,38 @@ def item_major_visit_order(sgd, chunk: int) -> np.ndarray:
     return sgd.perm[at[at < n]]
 
 
+def cached_reference(path: str, case: dict, perm_schedule: str):
+    """The reference side of an EARLIER run of this harness (a results file under profiles/), for a case whose reference costs minutes of
+    the GPU box's time (25 M triplets x 30 epochs of sequential fp64: 7 min): the reference run is a function of (dataset, seed, rate, epochs,
+    dimension, stored order) alone -- the negatives are the counter-based device stream, the tables and the dataset are seeded -- so a case
+    of that file with the same values and a mode of the same stored order holds the same curve.  Recall at the marks only (the file keeps
+    the loss at three marks and no learning rates): the result says so and leaves the loss gap / bold-driver comparison empty."""
+    same = ("dataset", "lr0", "seed", "epochs")
+    for c in json.load(open(os.path.join(ROOT, path)))["cases"]:
+        if "curve" not in c or any(c.get(k) != case.get(k) for k in same) or c.get("eval_every", 5) != case.get("eval_every", 5):
+            continue
+        if c.get("dim", DIM) != case.get("dim", DIM) or c.get("init_seed", 3) != case.get("init_seed", 3) or c.get("world", 1) != 1:
+            continue
+        if parse_mode(c["mode"])[0].split("-")[0] != perm_schedule or c.get("item_run") != case.get("item_run"):
+            continue
+        return {"recall": {int(m): float(r) for m, _, r in c["curve"]}, "loss": None, "lr": None, "final_topn": {},
+                "cached_from": f"{path}: case mode {c['mode']!r} (recall at the marks only)"}
+    raise KeyError(f"{path} holds no case with the reference of {case}")
+
+
 def compare(case: dict, g: dict, r: dict) -> dict:
     marks = sorted(r["recall"])
     peak = max(marks, key=lambda m: r["recall"][m])
     final = marks[-1]
+    have_log = r.get("loss") is not None
 
     def at(m):
         a, b = g["recall"][m], r["recall"][m]
         return {"epoch": m, "recall_gpu": a, "recall_exact_order": b, "abs_diff": abs(a - b), "rel_diff": abs(a - b) / max(b, 1e-12),
-                "signed_diff": a - b,
-                "loss_gpu": g["loss"][m - 1], "loss_exact_order": r["loss"][m - 1], "loss_rel_gap": abs(g["loss"][m - 1] - r["loss"][m - 1]) / abs(r["loss"][m - 1])}
+                "signed_diff": a - b, "loss_gpu": g["loss"][m - 1], "loss_exact_order": r["loss"][m - 1] if have_log else None,
+                "loss_rel_gap": abs(g["loss"][m - 1] - r["loss"][m - 1]) / abs(r["loss"][m - 1]) if have_log else None}
     worst = max(marks, key=lambda m: abs(g["recall"][m] - r["recall"][m]))
-    same_lr = bool(np.allclose(g["lr"], r["lr"], rtol=1e-9))
+    same_lr = bool(np.allclose(g["lr"], r["lr"], rtol=1e-9)) if have_log else None
     topn = {str(N): {"recall_gpu": g["final_topn"][N], "recall_exact_order": r["final_topn"][N], "signed_diff": g["final_topn"][N] - r["final_topn"][N]}
             for N in g.get("final_topn", {}) if N in r.get("final_topn", {})}
     return {**case, "peak": at(peak), "final": at(final), "worst_mark": at(worst), "bar": BAR, "grid_chunk_groups": g.get("grid"),
@@ -281,8 +301,16 @@ def run_case(case: dict, cache: dict, datasets: dict) -> dict:
     t1 = time.perf_counter()
     key = (name, lr0, seed, epochs, every, case.get("init_seed", 3), case.get("dim", DIM), topn) + g["perm_key"]
     if key not in cache:      # the negatives are a function of (seed, epoch, stored order): modes with the same order share a reference
-        cache[key] = reference_run(d, g["negatives"], lr0, epochs, marks, P0, Q0, extra_topn=topn)
+        if case.get("reference_from"):
+            cache[key] = cached_reference(case["reference_from"], case, g["perm_key"][0])
+        else:
+            cache[key] = reference_run(d, g["negatives"], lr0, epochs, marks, P0, Q0, extra_topn=topn)
     out = compare({k: v for k, v in case.items()}, g, cache[key])
+    if cache[key].get("cached_from"):
+        out["reference_side"] = cache[key]["cached_from"]
+    else:           # kept whole, so that a later run can take this reference from the results file
+        out["reference_log"] = {"loss": cache[key]["loss"], "lr": cache[key]["lr"]}
+    out["gpu_log"] = {"loss": g["loss"], "lr": g["lr"]}
     if case.get("order_null"):
         # the yardstick (no GPU involved): the SAME sequential fp64 training on the same negatives with the epoch's triplets visited in one
         # fixed random order instead of the reference's -- how far the reference's own measure moves under a reordering at this setting
@@ -375,7 +403,8 @@ def summarize_seeds(results, keys=("dataset", "lr0", "mode", "rounds", "world", 
         row["recall_exact_order_sd_over_seeds"] = float(np.std([r["final"]["recall_exact_order"] for r in rs], ddof=1))
         row["final_gap"] = stats([r["final"]["signed_diff"] for r in rs])
         row["peak_gap"] = stats([r["peak"]["signed_diff"] for r in rs])
-        row["final_loss_rel_gap_mean"] = float(np.mean([r["final"]["loss_rel_gap"] for r in rs]))
+        gaps = [r["final"]["loss_rel_gap"] for r in rs if r["final"]["loss_rel_gap"] is not None]
+        row["final_loss_rel_gap_mean"] = float(np.mean(gaps)) if gaps else None
         row["same_bold_driver_decisions"] = int(sum(bool(r["same_bold_driver_decisions"]) for r in rs))
         tn = [r["final_other_topn"] for r in rs if "final_other_topn" in r]
         if tn:
@@ -410,7 +439,8 @@ def main():
         brief = {k: res.get(k) for k in ("dataset", "lr0", "seed", "mode", "world", "layout", "syncs", "item_run", "rounds") if res.get(k) is not None}
         if "peak" in res:
             brief.update(peak_epoch=res["peak"]["epoch"], recall=round(res["peak"]["recall_exact_order"], 5), abs_diff=round(res["peak"]["abs_diff"], 5),
-                         rel=round(res["peak"]["rel_diff"], 4), worst=round(res["worst_mark"]["abs_diff"], 5), loss_gap=round(res["final"]["loss_rel_gap"], 4))
+                         rel=round(res["peak"]["rel_diff"], 4), worst=round(res["worst_mark"]["abs_diff"], 5), final=round(res["final"]["abs_diff"], 5),
+                         loss_gap=None if res["final"]["loss_rel_gap"] is None else round(res["final"]["loss_rel_gap"], 4))
         else:
             brief["error"] = res["error"]
         print(json.dumps(brief), flush=True)
