@@ -954,7 +954,12 @@ def main():
                     "abs_diff_peak_and_last_epoch": {"lr0 0.01, 4 sub-epochs": [0.0032, 0.0079], "lr0 0.05, 4 sub-epochs": [0.0050, 0.0045],
                                                      "lr0 0.01, 8 sub-epochs": [0.0010, 0.0032], "lr0 0.05, 8 sub-epochs": [0.0028, 0.0020],
                                                      "lr0 0.01, one-pass item-major": [0.0008, 0.0002], "lr0 0.05, one-pass item-major": [0.0010, 0.0003]},
-                    "bar": 0.002, "verdict": "outside the bar: opt-in only (QREC_SCHEDULE=item-deferred), not what `auto` runs"}
+                    "fresh_coefficient_variant": {
+                        "source": "profiles/r05_fresh_coefficient_25m.json (static: builder-measured in round 5; pass B re-forms lr (1 - sigma(x)) against the row as its "
+                                  "run left it, BprSgd(fresh=True); same epoch time: 15.5 vs 15.4 ms)",
+                        "abs_diff_peak_and_last_epoch": {"lr0 0.01, 4 sub-epochs": [0.0008, 0.0050], "lr0 0.01, 8 sub-epochs": [0.0003, 0.0023],
+                                                         "lr0 0.01, 2 sub-epochs": [0.0050, 0.0099], "lr0 0.01, 1 sub-epoch": [0.0162, 0.0257]}},
+                    "bar": 0.002, "verdict": "outside the bar at the last epoch in every setting measured: opt-in only (QREC_SCHEDULE=item-deferred), not what `auto` runs"}
                 if args.shape == "yelp2018":
                     out["other_configs"] = other_configs(capi, data)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
