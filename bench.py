@@ -29,7 +29,7 @@ sharded: item table row-sharded, per batch an all-to-all of the distinct rows a 
 updates.  --scaling strong (default since round 4: BASELINE.json quotes the metric on THE Yelp2018 shape at 1/2/4/8 GPUs): the same
 31,668 users split over the ranks = `value`; the weak-scaling figure (every rank its own 31,668 users) is timed next to it and
 reported as `weak_scaling` under its aggregate shape; --scaling weak makes that leg `value`.  --sync-per-epoch (default: 1 up to two ranks, 2 beyond):
-how often the ranks' item rows are reconciled inside an epoch (DESIGN.md s7).
+how often the ranks' item rows are reconciled inside an epoch (DESIGN.md s8).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     -- the SGD kernel's algorithmic bytes/launch over its mean launch time (HIP events on the launch
@@ -45,9 +45,11 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                   rel_diff at the reference's peak epoch and at the last one); N > 1: the same over the real communicator;
   other_configs -- BASELINE configs #2, #3, #5 and the evaluation, measured by this very run (HIP events, >= 20 repetitions);
   deferred_negatives -- the opt-in schedule `--schedule item-deferred` (one atomic row update per triplet) timed like the
-                  main line, with its own Recall check (DESIGN.md s4 says why it is not the default);
+                  main line, with its own Recall check (DESIGN.md s5.1 / s7 say why it is not the default);
   multi_gpu    -- N > 1: what RCCL reports per rank, kernel time per rank, collectives and bytes per epoch.
-Sharded layout options: --shard-batch, --shard-pipeline, --plan-ahead, --no-plan-inside.
+Sharded layout options: --shard-batch, --shard-pipeline, --no-plan-inside.  N > 1 also carries other_configs.config4_sharded:
+each rank's share of BASELINE config #4 in north_star's layout (row-sharded item table, per-batch all-to-all) and that layout's paired Recall@20.
+Every timed region starts from a collected Python heap with the cyclic collector off (settled_heap).
 """
 from __future__ import annotations
 

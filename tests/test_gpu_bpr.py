@@ -839,7 +839,7 @@ def test_deferred_recall_against_exact_order_training(lr0, seed, bound):
     P0 = (rng.random((U, dim)) / 3).astype(np.float32); Q0 = (rng.random((I, dim)) / 3).astype(np.float32)
     Pc, Qc = P0.astype(np.float64), Q0.astype(np.float64)
     t = DeviceTables(P0, Q0, np.float32)
-    sgd = BprSgd(t, u, ind, CSR(indptr, ind), schedule="item-deferred")       # (QREC_DEFERRED_SUB / _SUB_CHUNK / _FRESH select the variant)
+    sgd = BprSgd(t, u, ind, CSR(indptr, ind), schedule="item-deferred")       # (sub_epochs / sub_chunk / fresh of BprSgd select the variant)
     lr_c = lr_g = lr0; last_c = last_g = 0.0
     for k in range(epochs):
         sgd.sample_negatives_device(seed, k)
