@@ -75,21 +75,59 @@ class ControlPlane:
         import torch.distributed as dist
         self._torch, self._dist, self.group = torch, dist, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        # every collective is preceded by an exchange of (operation, call site) tags (``_agree``): ranks that have stopped calling the SAME
+        # collective -- one in an all-gather, the other already at a barrier -- raise at once, naming both sites, instead of waiting for each
+        # other until the transport's timeout (round 5: a leg of bench.py behind a condition only rank 0 satisfied hung the N > 1 line)
+        self.check = os.environ.get("QREC_CONTROL_CHECK", "1") != "0" and self.world > 1
+        self._warned_sites = False
 
     @classmethod
     def from_env(cls):
         import torch.distributed as dist
         if not dist.is_initialized():
+            import datetime
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29571")
-            dist.init_process_group("gloo", rank=int(os.environ.get("RANK", "0")),
-                                    world_size=int(os.environ.get("WORLD_SIZE", "1")))
+            # a collective the other ranks never join fails after QREC_CONTROL_TIMEOUT seconds (gloo's own default is half an hour)
+            dist.init_process_group("gloo", rank=int(os.environ.get("RANK", "0")), world_size=int(os.environ.get("WORLD_SIZE", "1")),
+                                    timeout=datetime.timedelta(seconds=float(os.environ.get("QREC_CONTROL_TIMEOUT", "900"))))
         return cls()
 
+    def _agree(self, op: str):
+        """all ranks are about to run the same collective: exchange crc32(op), crc32(call site); a different OPERATION on some rank raises
+        RuntimeError on every rank with each rank's operation and site; the same operation from different sites only warns (once)."""
+        if not self.check:
+            return
+        import sys as _sys
+        import zlib
+        f = _sys._getframe(2)
+        here = os.path.abspath(__file__)
+        while f.f_back is not None and os.path.abspath(f.f_code.co_filename) == here:      # the caller outside this module
+            f = f.f_back
+        site = f"{os.path.basename(f.f_code.co_filename)}:{f.f_code.co_name}:{f.f_lineno}"
+        t = self._torch.tensor([zlib.crc32(op.encode()), zlib.crc32(site.encode())], dtype=self._torch.int64)
+        tags = [self._torch.empty_like(t) for _ in range(self.world)]
+        self._dist.all_gather(tags, t, group=self.group)
+        ops, sites = {int(x[0]) for x in tags}, {int(x[1]) for x in tags}
+        if len(ops) == 1 and (len(sites) == 1 or self._warned_sites):
+            return
+        text = f"{op} at {site}".encode()[:200]
+        mine = self._torch.zeros(200, dtype=self._torch.uint8)
+        mine[:len(text)] = self._torch.frombuffer(bytearray(text), dtype=self._torch.uint8)
+        everyone = [self._torch.empty_like(mine) for _ in range(self.world)]
+        self._dist.all_gather(everyone, mine, group=self.group)
+        where = "; ".join(f"rank {r}: {bytes(x.numpy().tobytes()).rstrip(bytes(1)).decode(errors='replace')}" for r, x in enumerate(everyone))
+        if len(ops) > 1:
+            raise RuntimeError(f"control-plane collectives diverged -- the ranks are not in the same collective: {where}")
+        self._warned_sites = True
+        print(f"qrec control plane (rank {self.rank}): the same collective from different call sites: {where}", file=_sys.stderr, flush=True)
+
     def barrier(self):
+        self._agree("barrier")
         self._dist.barrier(group=self.group)
 
     def broadcast_bytes(self, payload: bytes | None, n: int, src: int = 0) -> bytes:
+        self._agree("broadcast_bytes")
         t = self._torch.zeros(n, dtype=self._torch.uint8)
         if self.rank == src:
             t.copy_(self._torch.frombuffer(bytearray(payload), dtype=self._torch.uint8))
@@ -97,12 +135,14 @@ class ControlPlane:
         return bytes(t.numpy().tobytes())
 
     def allreduce_host(self, arr: np.ndarray, op: str = "sum") -> np.ndarray:
+        self._agree("allreduce_host")
         t = self._torch.from_numpy(np.array(arr, copy=True))
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX if op == "max" else self._dist.ReduceOp.SUM, group=self.group)
         return t.numpy()
 
     def allgather_host(self, arr: np.ndarray) -> np.ndarray:
         """[world, *arr.shape]; every rank passes the same shape"""
+        self._agree("allgather_host")
         t = self._torch.from_numpy(np.ascontiguousarray(arr))
         out = [self._torch.empty_like(t) for _ in range(self.world)]
         self._dist.all_gather(out, t, group=self.group)
@@ -110,6 +150,7 @@ class ControlPlane:
 
     def shutdown(self):
         if self._dist.is_initialized():
+            self._agree("shutdown")
             self._dist.barrier(group=self.group)
             self._dist.destroy_process_group()
 
@@ -153,6 +194,7 @@ class GlooStagedComm:
         torch, dist = self.cp._torch, self.cp._dist
         s = [int(x) * row_bytes for x in send_rows]; r = [int(x) * row_bytes for x in recv_rows]
         src = torch.from_numpy(self._get(send, sum(s), np.uint8, stream)); dst = torch.empty(sum(r), dtype=torch.uint8)
+        self.cp._agree("alltoall_rows")
         dist.all_to_all_single(dst, src, r, s, group=self.cp.group)
         self._put(recv, dst.numpy(), stream)
 
@@ -166,6 +208,7 @@ class GlooStagedComm:
             out += seg; s_sizes.append(int(sum(x.size for x in seg)))
         r_sizes = [int(sum(nb for q, _, nb in recvs if q == p)) for p in range(self.world)]
         src = torch.from_numpy(np.concatenate(out) if out else np.zeros(0, np.uint8)); dst = torch.empty(sum(r_sizes), dtype=torch.uint8)
+        self.cp._agree("sendrecv_segments")
         dist.all_to_all_single(dst, src, r_sizes, s_sizes, group=self.cp.group)
         got, at = dst.numpy(), 0
         for p in range(self.world):

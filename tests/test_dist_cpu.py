@@ -109,6 +109,42 @@ def _preflight_worker(rank, world, port, out):
     control.shutdown()
 
 
+def _diverging_worker(rank, world, port, out):
+    control, _ = _join(rank, world, port)
+    got = {}
+    assert control.allreduce_host(np.array([1.0 + rank]))[0] == 3.0                  # the same collective from the same site: nothing said
+    try:                                                                            # rank 0 gathers, rank 1 is already at a barrier
+        if rank == 0:
+            control.allgather_host(np.zeros(3))
+        else:
+            control.barrier()
+        got["diverged"] = None
+    except RuntimeError as e:
+        got["diverged"] = str(e)
+    # the same collective from two different call sites is legal (it completes): said once on stderr, never raised
+    if rank == 0:
+        a = control.allreduce_host(np.array([2.0]))
+    else:
+        a = control.allreduce_host(np.array([5.0]))
+    got["two_sites"] = float(a[0]); got["warned"] = control._warned_sites
+    out[rank] = got
+    control.shutdown()
+
+
+def test_ranks_in_different_collectives_raise_instead_of_hanging():
+    """round 5: `bench.py --gpus 2` hung for its whole 900 s limit because a collective leg sat behind a condition only rank 0 satisfied --
+    rank 0 waited in an all-gather, rank 1 at the final barrier.  The control plane now exchanges (operation, call site) tags in front of every
+    collective: ranks in DIFFERENT collectives raise on every rank at once, each rank's operation and site in the message."""
+    world = 2
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_diverging_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        msg = out[r]["diverged"]
+        assert msg is not None and "not in the same collective" in msg
+        assert "rank 0: allgather_host at test_dist_cpu.py:_diverging_worker" in msg and "rank 1: barrier at test_dist_cpu.py:_diverging_worker" in msg
+        assert out[r]["two_sites"] == 7.0 and out[r]["warned"] is True
+
+
 def test_preflight_round_trip_over_two_processes():
     """dist.preflight (round 5: what `bench.py --gpus N` and the drop-in classes run before anything is timed) over two gloo processes: the
     tiny all-reduce and the ragged all-to-all round trip return what they must; both ranks report the same all-reduce share of the checksum"""
