@@ -103,7 +103,11 @@ int qrec_mt_sample_range(uint32_t *state625, int64_t n, int64_t k, int64_t *h_ou
 /* ---- throughput sampler, device side -------------------------------------------------- *
  * Same distribution as BPR.py:35-37 (uniform over the items that are not positives of
  * the user, by rejection), counter-based Philox4x32-10 keyed by (seed, epoch, triplet
- * index): reproducible and order-independent, but NOT the CPython stream.              */
+ * index): reproducible and order-independent, but NOT the CPython stream.
+ * The stream is a contract: counter = {t_lo, t_hi, block, epoch_lo}, key = {seed_lo, seed_hi ^ epoch_hi}, block = 0, 1, ...;
+ * the block's four words in order, candidate = word >> (32 - bit_length(n_items)), skipped when >= n_items or a positive of
+ * d_row_user[t]; first survivor = d_j_out[t]; none in blocks 0 .. 4096: -1.  oracle/qrec_oracle.c orc_philox_bpr_sample
+ * restates it (Philox pinned to Random123's known answers) and the kernel is held to it bit for bit.                        */
 int qrec_philox_bpr_sample(const int64_t *d_pos_indptr, const int32_t *d_pos_sorted,
                            const int32_t *d_row_user, int64_t n, int32_t n_items, uint64_t seed,
                            uint64_t epoch, int32_t *d_j_out, void *stream);
