@@ -345,10 +345,27 @@ int qrec_mark_batch_rows(const int32_t *d_u, const int32_t *d_i, const int32_t *
  * (LightGCN.py:22-30): rows are S[row]/div (div = n_layers+1 folds the layer mean in), users
  * at rows [0,n_users), items at n_users+id.  dE (pre-zeroed, [n_rows][ld]) receives the
  * scatter-added row gradients; *d_loss (double) is ACCUMULATED into.  d_row_mask (may be NULL;
- * pre-zeroed, (n_rows+31)/32 words): bit r is set for every row of dE that receives a gradient. */
+ * pre-zeroed, (n_rows+31)/32 words): bit r is set for every row of dE that receives a gradient.
+ * d_ordered_ws (may be NULL): NULL = the row gradients are added with float atomics (throughput mode: right to fp32
+ * rounding, summation order differs from launch to launch); a workspace of qrec_ordered_scatter_workspace_bytes(3 B, ld)
+ * bytes = parity mode: every row's gradient is the sum of its lookups' slots in batch order, one lookup (u, i, j) at a
+ * time -- the order of the reference's CPU scatter (UnsortedSegmentSum per IndexedSlices) -- same bits on every launch. */
 int qrec_bpr_batch_loss_grad(const float *d_S, float div, int32_t n_users, int64_t n_rows, int32_t ld,
                              const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int32_t B, float eps,
-                             float reg, float *d_dE, double *d_loss, uint32_t *d_row_mask, void *stream);
+                             float reg, float *d_dE, double *d_loss, uint32_t *d_row_mask, void *d_ordered_ws,
+                             int64_t ordered_ws_bytes, void *stream);
+
+/* Ordered scatter-add of rows (csrc/ordered.hip), the deterministic form of the gradient of tf.nn.embedding_lookup
+ * (LightGCN.py:22-24, BUIR.py:88-95, SEPT.py:239; TF's UnsortedSegmentSum walks the slots in order on the CPU):
+ *   d_out[d_dst_rows[s]] += sum of d_src[s][.] over the slots s with that destination, ascending s, class by class
+ *   (class = s / class_size, the classes' sums added in class order; class_size 0 = one class); rows < 0 are skipped.
+ * One stable rocPRIM radix sort of (row, slot) + one walk per run; fp32 adds in exactly that order, no contraction:
+ * the result equals numpy's np.add.at(out, rows, src) bit for bit when out starts at zero.
+ * Workspace: qrec_ordered_scatter_workspace_bytes(n_slots, ld) (also the size the d_ordered_ws arguments of
+ * qrec_bpr_batch_loss_grad / qrec_buir_batch_loss_grad / qrec_sept_ssl_loss_grad take: 3 B, 2 B, n k slots). */
+int qrec_ordered_scatter_workspace_bytes(int64_t n_slots, int32_t ld, int64_t *bytes);
+int qrec_scatter_add_rows_ordered(const float *d_src, const int32_t *d_dst_rows, int64_t n_slots, int32_t ld, int64_t class_size,
+                                  float *d_out, void *d_workspace, int64_t workspace_bytes, void *stream);
 
 /* tf.train.AdamOptimizer dense update (LightGCN.py:31-32) in TF 1.14's ApplyAdam form, fp32,
  * with g = grad_scale * d_grad + grad_l2 * theta (grad_l2 = reg folds in d/dtheta of
@@ -469,10 +486,13 @@ int qrec_zero_rows(float *d_X, int32_t ld, const int32_t *d_row_ids, const int32
  * *d_loss += [(1 - cos(q_u, t_i)) + (1 - cos(q_i, t_u))] / 2 (:127-129, tf.math.l2_normalize eps 1e-12), the gradient
  * w.r.t. the online mean rows is scatter-added into d_dS (un-divided: the caller folds 1/div into its optimizer
  * step), and the (x, dpre) pairs go to d_X / d_dPre rows b (user side) and B + b (item side) for qrec_buir_wgrad.
- * d_W [ld][ld], d_bias [ld], zero-padded; tables [rows][ld], ld in {32, 64, 128}.                        */
+ * d_W [ld][ld], d_bias [ld], zero-padded; tables [rows][ld], ld in {32, 64, 128}.
+ * d_ordered_ws (nullable, qrec_ordered_scatter_workspace_bytes(2 B, ld)): parity mode -- the scatter into d_dS adds each
+ * row's slots in batch order instead of with float atomics (see qrec_bpr_batch_loss_grad).                */
 int qrec_buir_batch_loss_grad(const float *d_S_online, const float *d_S_target, float div, int32_t n_users, int32_t ld,
                               const float *d_W, const float *d_bias, const int32_t *d_u, const int32_t *d_i, int32_t B,
-                              float *d_dS, float *d_X, float *d_dPre, double *d_loss, void *stream);
+                              float *d_dS, float *d_X, float *d_dPre, double *d_loss, void *d_ordered_ws, int64_t ordered_ws_bytes,
+                              void *stream);
 /* d_gW = X^T dPre, d_gb = column sums of dPre over n_rows (= 2B) pairs; deterministic two-stage sum through
  * d_scratch (qrec_buir_wgrad_scratch_bytes).                                                              */
 int qrec_buir_wgrad_scratch_bytes(int32_t ld, int64_t *bytes);
@@ -548,12 +568,14 @@ int qrec_scale_copy(float *d_dst, const float *d_src, int64_t n_elems, float alp
  *   encoders' averaged prob (k = ins_cnt, equal scores in index order);
  *   loss += -sum_i log( sum_{l in labels_v[i]} e^{z_v[i].a[l]/0.1} / sum_j e^{z_v[i].a[j]/0.1} ) over the three encoders
  *   (UNSCALED, added to *d_loss); dS_v[rows[i]] += ss_rate * d loss / d S_v[rows[i]] for the four tables.
- *   d_labels (nullable): int32 [3][n][k] pseudo labels (positions in d_rows) for inspection. */
+ *   d_labels (nullable): int32 [3][n][k] pseudo labels (positions in d_rows) for inspection.
+ *   d_ordered_ws (nullable, qrec_ordered_scatter_workspace_bytes(n k, ld)): parity mode -- the positives' part of the augmented
+ *   view's gradient (rows shared by several users' label sets) is added per row in (user, label) order instead of with float atomics. */
 int qrec_sept_ssl_workspace_bytes(int32_t n, int32_t ld, int32_t k, int64_t *bytes);
 int qrec_sept_ssl_loss_grad(const float *d_S_friend, const float *d_S_sharing, const float *d_S_pref, const float *d_S_aug,
                             const int32_t *d_rows, int32_t n, int32_t ld, int32_t k, float ss_rate, void *d_workspace,
                             float *d_dS_friend, float *d_dS_sharing, float *d_dS_pref, float *d_dS_aug, double *d_loss,
-                            int32_t *d_labels, void *stream);
+                            int32_t *d_labels, void *d_ordered_ws, int64_t ordered_ws_bytes, void *stream);
 
 /* ---- TBPR: model/ranking/TBPR.py (numpy path) -----------------------------------------------------------------
  * qrec_mt_tbpr_sample_epoch (host): the sampling loop TBPR.py:131-158 on the CPython MT19937 stream -- per user and
@@ -598,7 +620,9 @@ int qrec_sbpr_sgd_ordered(void *d_P, void *d_Q, const void *d_bias, int dtype, i
  * qrec_channel_attention_fwd (MHCN.py:113-121): v = att_mat att^T (d_v, [ld] scratch kept for the backward pass),
  *   score = softmax_k(e_k . v) ([rows][4], 4th unused), out = sum_k score_k e_k + half / 2 (half nullable).
  * qrec_channel_attention_bwd: de_k (+)= score_k dOut + dw_k v (accumulate flag), dhalf (+)= dOut / 2 (nullable),
- *   g_att += att_mat^T dv, g_att_mat += dv (x) att with dv = sum_rows sum_k dw_k e_k (d_dv_scratch: 256 floats).
+ *   g_att += att_mat^T dv, g_att_mat += dv (x) att with dv = sum_rows sum_k dw_k e_k (d_dv_scratch:
+ *   qrec_channel_attention_scratch_bytes; the column sums dv, graph, d graph are formed in a fixed order -- per-block partials
+ *   added in block order, no float atomics -- so the weight gradients have the same bits on every launch).
  * qrec_hss_loss_grad: hierarchical_self_supervision (MHCN.py:184-206) given edge = H em and the call's five shuffles
  *   (row p1; column k2 then row p2; column k3 then row p3 -- tf.random.shuffle of range(n) / range(d)) with their
  *   inverses: *d_loss += local + global MIM loss (unscaled); d_dem / d_dedge = scale * gradient w.r.t. em / edge
@@ -616,6 +640,7 @@ int qrec_channel_attention_bwd(const float *d_dOut, const float *d_e1, const flo
                                const float *d_v, const float *d_att, const float *d_att_mat, int64_t n_rows, int32_t ld,
                                float *d_de1, float *d_de2, float *d_de3, int32_t accumulate, float *d_dhalf, int32_t half_accumulate,
                                float *d_dv_scratch, float *d_g_att, float *d_g_att_mat, void *stream);
+int qrec_channel_attention_scratch_bytes(int64_t *bytes);
 int qrec_hss_scratch_bytes(int64_t n_rows, int64_t *bytes);
 int qrec_hss_loss_grad(const float *d_em, const float *d_edge, int64_t n_rows, int32_t d, int32_t ld, const int32_t *d_p1,
                        const int32_t *d_p1inv, const int32_t *d_p2, const int32_t *d_p2inv, const int32_t *d_k2,

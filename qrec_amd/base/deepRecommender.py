@@ -36,6 +36,15 @@ class DeepRecommender(IterativeRecommender):
         self.user_embeddings = truncated_normal((self.num_users, self.emb_size), 0.005)
         self.item_embeddings = truncated_normal((self.num_items, self.emb_size), 0.005)
 
+    def build_trainer(self, cls, *args, **kwargs):
+        """exact mode (the default) = parity mode: the trainer adds its batch gradients in the reference's CPU order (csrc/ordered.hip),
+        bit-reproducible from run to run; throughput mode keeps the float atomics"""
+        import os
+        from ..graph import ordered_reductions
+        forced = os.environ.get("QREC_REDUCTIONS")            # "ordered" / "atomic": override the mode's choice (measurements)
+        with ordered_reductions(forced == "ordered" if forced in ("ordered", "atomic") else not self.throughput_mode()):
+            return cls(*args, **kwargs)
+
     def sample_epoch_pairwise(self):
         """One epoch of ``next_batch_pairwise`` (base/deepRecommender.py:29-52) as three int32
         arrays in visiting order: ``shuffle(trainingData)``, then one negative per row, with

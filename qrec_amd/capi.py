@@ -81,7 +81,9 @@ _SIGNATURES = {
     "qrec_sumsq": [_vp, C.c_int, _i64, _i32, _i32, _vp, _vp],
     "qrec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     "qrec_mark_batch_rows": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
-    "qrec_bpr_batch_loss_grad": [_vp, _f32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
+    "qrec_bpr_batch_loss_grad": [_vp, _f32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _i64, _vp],
+    "qrec_ordered_scatter_workspace_bytes": [_i64, _i32, _vp],
+    "qrec_scatter_add_rows_ordered": [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _i64, _vp],
     "qrec_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
     "qrec_perturb_rows": [_vp, _vp, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _vp, _i32, _i64, _vp],
     "qrec_perturb_two_views": [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp],
@@ -90,6 +92,7 @@ _SIGNATURES = {
     "qrec_gate_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp],
     "qrec_channel_attention_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp],
     "qrec_channel_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp],
+    "qrec_channel_attention_scratch_bytes": [_vp],
     "qrec_hss_scratch_bytes": [_i64, _vp],
     "qrec_hss_loss_grad": [_vp, _vp, _i64, _i32, _i32] + [_vp] * 10 + [_f32, _vp, _vp, _vp, _vp, _vp],
     "qrec_random_permutations_scratch_bytes": [_i64, _i32, _vp],
@@ -99,7 +102,7 @@ _SIGNATURES = {
     "qrec_l2norm_rows_bwd": [_vp, _vp, _vp, _i64, _i32, _vp, _vp],
     "qrec_scale_copy": [_vp, _vp, _i64, _f32, _vp],
     "qrec_sept_ssl_workspace_bytes": [_i32, _i32, _i32, _vp],
-    "qrec_sept_ssl_loss_grad": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "qrec_sept_ssl_loss_grad": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "qrec_info_nce_loss_grad": [_vp, _vp, _f32, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "qrec_ngcf_dense_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp],
     "qrec_compact_marked_rows": [_vp, _i64, _vp, _vp, _i32, _vp],
@@ -113,7 +116,7 @@ _SIGNATURES = {
     "qrec_score_topk_scratch_bytes": [C.c_int, _i32, _i32, _i32, _i32, _vp],
     "qrec_score_topk": [_vp, _vp, C.c_int, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "qrec_rank_hits": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "qrec_buir_batch_loss_grad": [_vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
+    "qrec_buir_batch_loss_grad": [_vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "qrec_buir_wgrad_scratch_bytes": [_i32, _vp],
     "qrec_buir_wgrad": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
     "qrec_ema_update": [_vp, _vp, _f32, _i64, _vp],
@@ -735,9 +738,10 @@ def epoch_decide(d_stats, d_state, regU: float, regI: float, max_lr: float, tol:
 
 
 def buir_batch_loss_grad(d_S_on, d_S_tar, div: float, n_users: int, ld: int, d_W, d_bias, d_u, d_i, B: int, d_dS, d_X,
-                         d_dPre, d_loss, stream=None):
+                         d_dPre, d_loss, stream=None, ordered=None):
+    ws, nb = ordered.reserve(2 * B, ld) if ordered is not None else (0, 0)
     _check(load().qrec_buir_batch_loss_grad(_dp(d_S_on), _dp(d_S_tar), div, n_users, ld, _dp(d_W), _dp(d_bias), _dp(d_u),
-                                            _dp(d_i), B, _dp(d_dS), _dp(d_X), _dp(d_dPre), _dp(d_loss), _sh(stream)))
+                                            _dp(d_i), B, _dp(d_dS), _dp(d_X), _dp(d_dPre), _dp(d_loss), ws, nb, _sh(stream)))
 
 
 def buir_wgrad_scratch_bytes(ld: int) -> int:
@@ -774,10 +778,34 @@ def spmm_csr(plan, d_X, d_Y, ld: int, d_addend=None, addend_scale: float = 0.0, 
                                 _dp(d_y_row_mask), _dp(d_addend_row_mask), _sh(stream)))
 
 
+class OrderedScatter:
+    """Workspace of the ordered (deterministic) gradient scatters -- the parity mode of qrec_bpr_batch_loss_grad,
+    qrec_buir_batch_loss_grad and qrec_sept_ssl_loss_grad (include/qrec_hip.h, csrc/ordered.hip).  One per trainer: the calls
+    that take ``ordered=`` run on the trainer's stream one after another and share it; grown on demand."""
+
+    def __init__(self):
+        self.buf = None
+
+    def reserve(self, n_slots: int, ld: int):
+        out = C.c_int64(0)
+        _check(load().qrec_ordered_scatter_workspace_bytes(max(int(n_slots), 1), ld, C.byref(out)))
+        if self.buf is None or self.buf.nbytes < out.value:
+            device_sync()                   # a launch in flight may still be using the old workspace
+            self.buf = DeviceBuffer(out.value, np.uint8)
+        return self.buf.ptr, self.buf.nbytes
+
+
+def scatter_add_rows_ordered(d_src, d_dst_rows, n_slots: int, ld: int, d_out, ordered: "OrderedScatter", class_size: int = 0, stream=None):
+    """d_out[dst_rows[s]] += d_src[s], every row's slots in ascending s (class by class): np.add.at's order, bit for bit"""
+    ws, nb = ordered.reserve(n_slots, ld)
+    _check(load().qrec_scatter_add_rows_ordered(_dp(d_src), _dp(d_dst_rows), n_slots, ld, class_size, _dp(d_out), ws, nb, _sh(stream)))
+
+
 def bpr_batch_loss_grad(d_S, div: float, n_users: int, n_rows: int, ld: int, d_u, d_i, d_j, B: int, eps: float,
-                        reg: float, d_dE, d_loss, stream=None, d_row_mask=None):
+                        reg: float, d_dE, d_loss, stream=None, d_row_mask=None, ordered=None):
+    ws, nb = ordered.reserve(3 * B, ld) if ordered is not None else (0, 0)
     _check(load().qrec_bpr_batch_loss_grad(_dp(d_S), div, n_users, n_rows, ld, _dp(d_u), _dp(d_i), _dp(d_j), B,
-                                           eps, reg, _dp(d_dE), _dp(d_loss), _dp(d_row_mask), _sh(stream)))
+                                           eps, reg, _dp(d_dE), _dp(d_loss), _dp(d_row_mask), ws, nb, _sh(stream)))
 
 
 def adam_step(d_theta, d_m, d_v, d_grad, n_elems: int, grad_scale: float, alpha: float, beta1: float = 0.9,
@@ -836,6 +864,12 @@ def channel_attention_bwd(d_dOut, d_e, d_score, d_v, d_att, d_att_mat, n_rows: i
                                              _dp(d_g_att_mat), _sh(stream)))
 
 
+def channel_attention_scratch_floats() -> int:
+    out = C.c_int64(0)
+    _check(load().qrec_channel_attention_scratch_bytes(C.byref(out)))
+    return out.value // 4
+
+
 def hss_scratch_bytes(n_rows: int) -> int:
     out = C.c_int64(0)
     _check(load().qrec_hss_scratch_bytes(n_rows, C.byref(out)))
@@ -884,11 +918,12 @@ def sept_ssl_workspace_bytes(n: int, ld: int, k: int) -> int:
 
 
 def sept_ssl_loss_grad(d_S_friend, d_S_sharing, d_S_pref, d_S_aug, d_rows, n: int, ld: int, k: int, ss_rate: float, d_workspace,
-                       d_dS_friend, d_dS_sharing, d_dS_pref, d_dS_aug, d_loss, d_labels=None, stream=None):
+                       d_dS_friend, d_dS_sharing, d_dS_pref, d_dS_aug, d_loss, d_labels=None, stream=None, ordered=None):
     """SEPT.py:214-262 on the batch's unique users (see include/qrec_hip.h)"""
+    ws, nb = ordered.reserve(n * k, ld) if ordered is not None else (0, 0)
     _check(load().qrec_sept_ssl_loss_grad(_dp(d_S_friend), _dp(d_S_sharing), _dp(d_S_pref), _dp(d_S_aug), _dp(d_rows), n, ld, k,
                                           ss_rate, _dp(d_workspace), _dp(d_dS_friend), _dp(d_dS_sharing), _dp(d_dS_pref),
-                                          _dp(d_dS_aug), _dp(d_loss), _dp(d_labels), _sh(stream)))
+                                          _dp(d_dS_aug), _dp(d_loss), _dp(d_labels), ws, nb, _sh(stream)))
 
 
 class RowSubset:

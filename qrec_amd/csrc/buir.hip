@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void buir_batch_kernel(
     const float *__restrict__ S_on, const float *__restrict__ S_tar, float div, int n_users,
     const float *__restrict__ W, const float *__restrict__ bias, const int32_t *__restrict__ u_idx,
     const int32_t *__restrict__ i_idx, int B, float *__restrict__ dS, float *__restrict__ Xb,
-    float *__restrict__ Gb, double *__restrict__ loss_out) {
+    float *__restrict__ Gb, double *__restrict__ loss_out, float *__restrict__ contrib, int32_t *__restrict__ keys) {
     constexpr int LD = 4 * LPR, GPW = kWave / LPR;
     extern __shared__ float s_w[];                       // [LD][LD] W, then [LD][LD+1] W^T (padded)
     float *s_wt = s_w + LD * LD;
@@ -85,8 +85,13 @@ __global__ __launch_bounds__(256) void buir_batch_kernel(
                 dx.w += d0 * w0[3] + d1 * w0[LD + 4] + d2 * w0[2 * (LD + 1) + 3] + d3 * w0[3 * (LD + 1) + 3];
             }
             // d online-mean row (the 1/(L+1) of the mean is applied by the caller's Adam grad_scale): scatter-add
-            float *dst = dS + rx * LD + 4 * r;
-            atomicAdd(dst + 0, dx.x); atomicAdd(dst + 1, dx.y); atomicAdd(dst + 2, dx.z); atomicAdd(dst + 3, dx.w);
+            if (contrib) {          // parity mode: slot's row into the ordered-scatter workspace (ordered.hip), added per row in slot order
+                *reinterpret_cast<f32x4 *>(contrib + slot * LD + 4 * r) = dx;
+                if (r == 0) keys[slot] = (int32_t)rx;
+            } else {
+                float *dst = dS + rx * LD + 4 * r;
+                atomicAdd(dst + 0, dx.x); atomicAdd(dst + 1, dx.y); atomicAdd(dst + 2, dx.z); atomicAdd(dst + 3, dx.w);
+            }
         }
     }
 #pragma unroll
@@ -140,7 +145,8 @@ __global__ __launch_bounds__(256) void ema_kernel(float *__restrict__ target, co
 
 template <int LPR>
 int launch_batch(const float *S_on, const float *S_tar, float div, int n_users, const float *W, const float *bias,
-                 const int32_t *u, const int32_t *i, int B, float *dS, float *Xb, float *Gb, double *loss, hipStream_t st) {
+                 const int32_t *u, const int32_t *i, int B, float *dS, float *Xb, float *Gb, double *loss, float *contrib, int32_t *keys,
+                 hipStream_t st) {
     constexpr int LD = 4 * LPR, GPW = kWave / LPR;
     const size_t lds = (size_t)(LD * LD + LD * (LD + 1)) * sizeof(float);
     if (lds > 64 * 1024)
@@ -149,7 +155,7 @@ int launch_batch(const float *S_on, const float *S_tar, float div, int n_users, 
     int64_t blocks = ((int64_t)B + 4 * GPW - 1) / (4 * GPW);
     if (blocks > 256) blocks = 256;          // every block stages the weights once
     hipLaunchKernelGGL((buir_batch_kernel<LPR>), dim3((unsigned)blocks), dim3(256), lds, st, S_on, S_tar, div, n_users, W, bias, u,
-                       i, B, dS, Xb, Gb, loss);
+                       i, B, dS, Xb, Gb, loss, contrib, keys);
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }
@@ -160,18 +166,27 @@ extern "C" {
 
 int qrec_buir_batch_loss_grad(const float *d_S_online, const float *d_S_target, float div, int32_t n_users, int32_t ld,
                               const float *d_W, const float *d_bias, const int32_t *d_u, const int32_t *d_i, int32_t B,
-                              float *d_dS, float *d_X, float *d_dPre, double *d_loss, void *stream) {
+                              float *d_dS, float *d_X, float *d_dPre, double *d_loss, void *d_ordered_ws, int64_t ordered_ws_bytes,
+                              void *stream) {
     QREC_REQUIRE(d_S_online && d_S_target && d_W && d_bias && d_dS && d_X && d_dPre && d_loss && B >= 0 && div != 0.f,
                  "qrec_buir_batch_loss_grad: bad argument");
     QREC_REQUIRE(B == 0 || (d_u && d_i), "qrec_buir_batch_loss_grad: null index array");
     if (B == 0) return QREC_OK;
+    QREC_REQUIRE(ld == 32 || ld == 64 || ld == 128, "qrec_buir_batch_loss_grad: row stride must be 32, 64 or 128 floats (got %d)", ld);
     hipStream_t st = as_stream(stream);
-    switch (ld) {
-        case 32: return launch_batch<8>(d_S_online, d_S_target, div, n_users, d_W, d_bias, d_u, d_i, B, d_dS, d_X, d_dPre, d_loss, st);
-        case 64: return launch_batch<16>(d_S_online, d_S_target, div, n_users, d_W, d_bias, d_u, d_i, B, d_dS, d_X, d_dPre, d_loss, st);
-        case 128: return launch_batch<32>(d_S_online, d_S_target, div, n_users, d_W, d_bias, d_u, d_i, B, d_dS, d_X, d_dPre, d_loss, st);
-        default: set_error("qrec_buir_batch_loss_grad: row stride must be 32, 64 or 128 floats (got %d)", ld); return QREC_ERR_INVALID;
+    OrderedScatterWs ow = {};
+    if (d_ordered_ws) {
+        const int rc = ordered_ws_carve(d_ordered_ws, ordered_ws_bytes, 2 * (int64_t)B, ld, &ow);
+        if (rc != QREC_OK) return rc;
     }
+    int rc = QREC_OK;
+    switch (ld) {
+        case 32: rc = launch_batch<8>(d_S_online, d_S_target, div, n_users, d_W, d_bias, d_u, d_i, B, d_dS, d_X, d_dPre, d_loss, ow.contrib, ow.keys, st); break;
+        case 64: rc = launch_batch<16>(d_S_online, d_S_target, div, n_users, d_W, d_bias, d_u, d_i, B, d_dS, d_X, d_dPre, d_loss, ow.contrib, ow.keys, st); break;
+        default: rc = launch_batch<32>(d_S_online, d_S_target, div, n_users, d_W, d_bias, d_u, d_i, B, d_dS, d_X, d_dPre, d_loss, ow.contrib, ow.keys, st); break;
+    }
+    if (rc != QREC_OK || !d_ordered_ws) return rc;
+    return ordered_scatter_run(ow, 2 * (int64_t)B, ld, B, d_dS, st);      // slots [0, B): the users' online rows, [B, 2B): the items'
 }
 
 int qrec_buir_wgrad_scratch_bytes(int32_t ld, int64_t *bytes) {

@@ -36,6 +36,16 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
+// ---- ordered scatter-add (ordered.hip): the deterministic counterpart of the float-atomic gradient scatters.  A producer
+// writes slot s's row to contrib[s][ld] and its destination row to keys[s] (< 0: none); ordered_scatter_run sorts (key, slot)
+// stably and adds each row's slots in ascending slot order, class by class (class = slot / class_size; 0: one class).
+struct OrderedScatterWs {
+    float *contrib; int32_t *keys, *keys_sorted, *slots_sorted; void *temp; size_t temp_bytes;
+};
+int ordered_ws_bytes(int64_t n_slots, int ld, int64_t *bytes);
+int ordered_ws_carve(void *ws, int64_t ws_bytes, int64_t n_slots, int ld, OrderedScatterWs *w);
+int ordered_scatter_run(const OrderedScatterWs &w, int64_t n_slots, int ld, int64_t class_size, float *out, hipStream_t st);
+
 // ---- buffer resources: the only way to get 16-byte loads/stores with an explicit cache
 // policy (sc1 = bypass the non-coherent per-XCD caches) and compiler-tracked waitcnts.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

@@ -450,7 +450,8 @@ template <int LPR>
 __global__ __launch_bounds__(256) void sept_sparse_kernel(const float *__restrict__ Ex, const float *__restrict__ inv_pos,
                                                           const int32_t *__restrict__ labels, const float *__restrict__ z,
                                                           const float *__restrict__ a, int n, int n_pad, int k, float inv_tau,
-                                                          float *__restrict__ dzc, float *__restrict__ dac) {
+                                                          float *__restrict__ dzc, float *__restrict__ dac, float *__restrict__ contrib,
+                                                          int32_t *__restrict__ keys) {
     constexpr int GPW = kWave / LPR;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
     const int64_t i = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g;
@@ -463,9 +464,14 @@ __global__ __launch_bounds__(256) void sept_sparse_kernel(const float *__restric
         const float c = Ex[i * n_pad + l] * ip * inv_tau;
         const f32x4 al = *reinterpret_cast<const f32x4 *>(a + (int64_t)l * (4 * LPR) + 4 * r);
         acc = acc - c * al;
-        float *dst = dac + (int64_t)l * (4 * LPR) + 4 * r;
-        unsafeAtomicAdd(dst + 0, -c * zi.x); unsafeAtomicAdd(dst + 1, -c * zi.y);
-        unsafeAtomicAdd(dst + 2, -c * zi.z); unsafeAtomicAdd(dst + 3, -c * zi.w);
+        if (contrib) {      // parity mode: slot (i, t) of the ordered-scatter workspace; ordered.hip adds a positive's rows in (i, t) order
+            *reinterpret_cast<f32x4 *>(contrib + (i * k + t) * (4 * LPR) + 4 * r) = -c * zi;
+            if (r == 0) keys[i * k + t] = l;
+        } else {
+            float *dst = dac + (int64_t)l * (4 * LPR) + 4 * r;
+            unsafeAtomicAdd(dst + 0, -c * zi.x); unsafeAtomicAdd(dst + 1, -c * zi.y);
+            unsafeAtomicAdd(dst + 2, -c * zi.z); unsafeAtomicAdd(dst + 3, -c * zi.w);
+        }
     }
     *reinterpret_cast<f32x4 *>(dzc + i * (4 * LPR) + 4 * r) = acc;
 }
@@ -500,7 +506,7 @@ inline int64_t sept_ws_floats(int64_t n, int64_t ld, int64_t k) {
 
 template <int LPR>
 int run_sept_ssl(const float *const S[4], const int32_t *rows, int n, int ld, int k, float ss_rate, float *ws,
-                 float *const dS[4], double *loss, int32_t *labels_out, hipStream_t st) {
+                 float *const dS[4], double *loss, int32_t *labels_out, const OrderedScatterWs *ow, hipStream_t st) {
     constexpr int GPW = kWave / LPR;
     const int n_pad = (n + 63) / 64 * 64;
     const int64_t tab = (int64_t)n_pad * ld, sq = (int64_t)n_pad * n_pad;
@@ -570,8 +576,13 @@ int run_sept_ssl(const float *const S[4], const int32_t *rows, int n, int ld, in
         QREC_LAUNCH_CHECK();
         hipLaunchKernelGGL((grad_z_kernel<1>), gg, dim3(256), 0, st, ExT, inv_ttl, z[v], n, n_pad, ld, inv_tau, 0.f, dap + (int64_t)v * kSplitK * tab);
         QREC_LAUNCH_CHECK();
-        hipLaunchKernelGGL((sept_sparse_kernel<LPR>), dim3(row_blocks), dim3(256), 0, st, Ex, inv_pos, lab, z[v], z[3], n, n_pad, k, inv_tau, dzc, dac);
+        hipLaunchKernelGGL((sept_sparse_kernel<LPR>), dim3(row_blocks), dim3(256), 0, st, Ex, inv_pos, lab, z[v], z[3], n, n_pad, k, inv_tau, dzc, dac,
+                           ow ? ow->contrib : (float *)nullptr, ow ? ow->keys : (int32_t *)nullptr);
         QREC_LAUNCH_CHECK();
+        if (ow) {
+            const int rc = ordered_scatter_run(*ow, (int64_t)n * k, ld, 0, dac, st);
+            if (rc != QREC_OK) return rc;
+        }
         hipLaunchKernelGGL((sept_normalize_bwd_kernel<LPR>), dim3(row_blocks), dim3(256), 0, st, z[v], dzp, kSplitK, tab, dzc, rinv[v], rows, n, ss_rate, dS[v]);
         QREC_LAUNCH_CHECK();
     }
@@ -663,7 +674,7 @@ int qrec_sept_ssl_workspace_bytes(int32_t n, int32_t ld, int32_t k, int64_t *byt
 int qrec_sept_ssl_loss_grad(const float *d_S_friend, const float *d_S_sharing, const float *d_S_pref, const float *d_S_aug,
                             const int32_t *d_rows, int32_t n, int32_t ld, int32_t k, float ss_rate, void *d_workspace,
                             float *d_dS_friend, float *d_dS_sharing, float *d_dS_pref, float *d_dS_aug, double *d_loss,
-                            int32_t *d_labels, void *stream) {
+                            int32_t *d_labels, void *d_ordered_ws, int64_t ordered_ws_bytes, void *stream) {
     QREC_REQUIRE(d_S_friend && d_S_sharing && d_S_pref && d_S_aug && d_workspace && d_dS_friend && d_dS_sharing && d_dS_pref &&
                  d_dS_aug && d_loss && n >= 0, "qrec_sept_ssl_loss_grad: bad argument");
     QREC_REQUIRE(n == 0 || d_rows, "qrec_sept_ssl_loss_grad: null row list");
@@ -674,11 +685,18 @@ int qrec_sept_ssl_loss_grad(const float *d_S_friend, const float *d_S_sharing, c
     float *ws = static_cast<float *>(d_workspace);
     const float *const S[4] = {d_S_friend, d_S_sharing, d_S_pref, d_S_aug};
     float *const dS[4] = {d_dS_friend, d_dS_sharing, d_dS_pref, d_dS_aug};
+    OrderedScatterWs ow = {};
+    if (d_ordered_ws) {
+        QREC_REQUIRE(ld == 32 || ld == 64 || ld == 128 || ld == 256, "qrec_sept_ssl_loss_grad: row stride must be 32, 64, 128 or 256 floats (got %d)", ld);
+        const int rc = ordered_ws_carve(d_ordered_ws, ordered_ws_bytes, (int64_t)n * k, ld, &ow);
+        if (rc != QREC_OK) return rc;
+    }
+    const OrderedScatterWs *owp = d_ordered_ws ? &ow : nullptr;
     switch (ld) {
-        case 32: return run_sept_ssl<8>(S, d_rows, n, ld, k, ss_rate, ws, dS, d_loss, d_labels, st);
-        case 64: return run_sept_ssl<16>(S, d_rows, n, ld, k, ss_rate, ws, dS, d_loss, d_labels, st);
-        case 128: return run_sept_ssl<32>(S, d_rows, n, ld, k, ss_rate, ws, dS, d_loss, d_labels, st);
-        case 256: return run_sept_ssl<64>(S, d_rows, n, ld, k, ss_rate, ws, dS, d_loss, d_labels, st);
+        case 32: return run_sept_ssl<8>(S, d_rows, n, ld, k, ss_rate, ws, dS, d_loss, d_labels, owp, st);
+        case 64: return run_sept_ssl<16>(S, d_rows, n, ld, k, ss_rate, ws, dS, d_loss, d_labels, owp, st);
+        case 128: return run_sept_ssl<32>(S, d_rows, n, ld, k, ss_rate, ws, dS, d_loss, d_labels, owp, st);
+        case 256: return run_sept_ssl<64>(S, d_rows, n, ld, k, ss_rate, ws, dS, d_loss, d_labels, owp, st);
         default: set_error("qrec_sept_ssl_loss_grad: row stride must be 32, 64, 128 or 256 floats (got %d)", ld); return QREC_ERR_INVALID;
     }
 }

@@ -214,12 +214,15 @@ __global__ void mark_batch_rows_kernel(const int32_t *__restrict__ u, const int3
 //   g = -s(1-s)/(s+eps)
 //   dE[u] += g (ib - jb) + reg ub ;  dE[nu+i] += g ub + reg ib ;  dE[nu+j] += -g ub + reg jb
 // Bytes: 3 rows read + 3 rows of atomics per triplet.
+// ORDERED (parity mode): the three row gradients go to slots b, B + b, 2B + b of an ordered-scatter workspace instead
+// (contrib / keys; ordered.hip adds them row by row in slot order, one lookup at a time): same bits on every launch.
 // ---------------------------------------------------------------------------------------
-template <int LPR, int E>
+template <int LPR, int E, bool ORDERED>
 __global__ __launch_bounds__(256) void bpr_batch_kernel(
     const float *__restrict__ S, float div, int n_users, const int32_t *__restrict__ u_idx,
     const int32_t *__restrict__ i_idx, const int32_t *__restrict__ j_idx, int B, float eps, float reg,
-    float *__restrict__ dE, uint32_t de_bytes, double *__restrict__ loss_out, uint32_t *__restrict__ row_mask) {
+    float *__restrict__ dE, uint32_t de_bytes, double *__restrict__ loss_out, uint32_t *__restrict__ row_mask,
+    float *__restrict__ contrib, int32_t *__restrict__ keys) {
     constexpr int GPW = kWave / LPR;
     constexpr int LD = LPR * E;
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
@@ -249,12 +252,24 @@ __global__ __launch_bounds__(256) void bpr_batch_kernel(
                 atomicOr(row_mask + (rj >> 5), 1u << (rj & 31));
             }
         }
+        if constexpr (ORDERED) {
+#pragma clang fp contract(off)
+            if (r == 0) { keys[b] = ru; keys[(int64_t)B + b] = ri; keys[2 * (int64_t)B + b] = rj; }
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const uint32_t col = (uint32_t)(r + LPR * e) * 4u;
-            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(gsc * (ib[e] - jb[e]) + reg * ub[e], rs, (int)((uint32_t)ru * LD * 4u + col), 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(gsc * ub[e] + reg * ib[e], rs, (int)((uint32_t)ri * LD * 4u + col), 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(-gsc * ub[e] + reg * jb[e], rs, (int)((uint32_t)rj * LD * 4u + col), 0, 0);
+            for (int e = 0; e < E; e++) {
+                const int col = r + LPR * e;
+                contrib[b * LD + col] = gsc * (ib[e] - jb[e]) + reg * ub[e];
+                contrib[((int64_t)B + b) * LD + col] = gsc * ub[e] + reg * ib[e];
+                contrib[(2 * (int64_t)B + b) * LD + col] = -gsc * ub[e] + reg * jb[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const uint32_t col = (uint32_t)(r + LPR * e) * 4u;
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(gsc * (ib[e] - jb[e]) + reg * ub[e], rs, (int)((uint32_t)ru * LD * 4u + col), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(gsc * ub[e] + reg * ib[e], rs, (int)((uint32_t)ri * LD * 4u + col), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(-gsc * ub[e] + reg * jb[e], rs, (int)((uint32_t)rj * LD * 4u + col), 0, 0);
+            }
         }
     }
     // one fp64 atomic per BLOCK: same-address atomics are serialised in L2 (~10 ns each); one per wavefront was
@@ -410,17 +425,28 @@ int qrec_mark_batch_rows(const int32_t *d_u, const int32_t *d_i, const int32_t *
 
 int qrec_bpr_batch_loss_grad(const float *d_S, float div, int32_t n_users, int64_t n_rows, int32_t ld,
                              const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int32_t B, float eps,
-                             float reg, float *d_dE, double *d_loss, uint32_t *d_row_mask, void *stream) {
+                             float reg, float *d_dE, double *d_loss, uint32_t *d_row_mask, void *d_ordered_ws,
+                             int64_t ordered_ws_bytes, void *stream) {
     QREC_REQUIRE(d_S && d_dE && d_loss && B >= 0 && div != 0.f, "qrec_bpr_batch_loss_grad: bad argument");
     QREC_REQUIRE(B == 0 || (d_u && d_i && d_j), "qrec_bpr_batch_loss_grad: null index array");
     QREC_REQUIRE(n_rows * (int64_t)ld * 4 < ((int64_t)1 << 32), "qrec_bpr_batch_loss_grad: table exceeds 4 GiB");
     if (B == 0) return QREC_OK;
     hipStream_t st = as_stream(stream);
     const uint32_t bytes = (uint32_t)(n_rows * ld * 4);
+    OrderedScatterWs ow = {};
+    if (d_ordered_ws) {
+        QREC_REQUIRE(ld == 32 || ld == 64 || ld == 128 || ld == 256, "qrec_bpr_batch_loss_grad: row stride must be 32, 64, 128 or 256 floats (got %d)", ld);
+        const int rc = ordered_ws_carve(d_ordered_ws, ordered_ws_bytes, 3 * (int64_t)B, ld, &ow);
+        if (rc != QREC_OK) return rc;
+    }
 #define QREC_BB(LPR, E)                                                                                          \
     blocks = (B + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)); if (blocks > 256) blocks = 256;                          \
-    hipLaunchKernelGGL((bpr_batch_kernel<LPR, E>), dim3((unsigned)blocks),                                         \
-                       dim3(256), 0, st, d_S, div, n_users, d_u, d_i, d_j, B, eps, reg, d_dE, bytes, d_loss, d_row_mask)
+    if (d_ordered_ws)                                                                                              \
+        hipLaunchKernelGGL((bpr_batch_kernel<LPR, E, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_S, div, n_users, d_u, d_i, d_j, B, \
+                           eps, reg, d_dE, bytes, d_loss, d_row_mask, ow.contrib, ow.keys);                        \
+    else                                                                                                           \
+        hipLaunchKernelGGL((bpr_batch_kernel<LPR, E, false>), dim3((unsigned)blocks), dim3(256), 0, st, d_S, div, n_users, d_u, d_i, d_j, B, \
+                           eps, reg, d_dE, bytes, d_loss, d_row_mask, (float *)nullptr, (int32_t *)nullptr)
     int64_t blocks;
     switch (ld) {
         case 32: QREC_BB(16, 2); break;
@@ -431,6 +457,7 @@ int qrec_bpr_batch_loss_grad(const float *d_S, float div, int32_t n_users, int64
     }
 #undef QREC_BB
     QREC_LAUNCH_CHECK();
+    if (d_ordered_ws) return ordered_scatter_run(ow, 3 * (int64_t)B, ld, B, d_dE, st);     // one class per lookup (u, i, j)
     return QREC_OK;
 }
 

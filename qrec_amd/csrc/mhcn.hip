@@ -119,6 +119,32 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float *__restrict__
     }
 }
 
+// ---- column sums over rows without float atomics (round 6): every group's f32x4 partial through LDS, added in group order by
+// the first LD threads -> part[block][256]; colsum_finish_kernel adds the blocks in block order.  The row -> group assignment is
+// a function of (n, grid) alone, so the sums come out with the same bits on every launch (MHCN's attention / global-MIM
+// gradients used LDS + global float atomics before: right to rounding, different from launch to launch).
+constexpr int kColBlocks = 512;         // the launches below cap their grids here
+template <int LPR>
+__device__ __forceinline__ void block_colsum_store(const f32x4 &mine, float *s_part, float *__restrict__ part) {
+    constexpr int LD = 4 * LPR, NG = 256 / LPR;
+    *reinterpret_cast<f32x4 *>(s_part + 4 * threadIdx.x) = mine;          // thread = group * LPR + r holds columns 4r .. 4r+3
+    __syncthreads();
+    if (threadIdx.x < LD) {
+        float t = 0.f;
+#pragma unroll 4
+        for (int g = 0; g < NG; g++) t += s_part[(g * LPR + (threadIdx.x >> 2)) * 4 + (threadIdx.x & 3)];
+        part[(int64_t)blockIdx.x * 256 + threadIdx.x] = t;
+    }
+}
+// out[c] (+)= scale * sum_b part[b][c], blocks in order
+__global__ void colsum_finish_kernel(const float *__restrict__ part, int n_blocks, int ld, float scale, int accumulate, float *__restrict__ out) {
+    const int c = threadIdx.x;
+    if (c >= ld) return;
+    float t = 0.f;
+    for (int b = 0; b < n_blocks; b++) t += part[(int64_t)b * 256 + c];
+    out[c] = accumulate ? out[c] + scale * t : scale * t;
+}
+
 __global__ void att_vec_kernel(const float *__restrict__ M, const float *__restrict__ a, int ld, float *__restrict__ v) {
     const int j = threadIdx.x;
     if (j >= ld) return;
@@ -158,12 +184,10 @@ __global__ __launch_bounds__(256) void att_bwd_kernel(const float *__restrict__ 
                                                       const float *__restrict__ score, const float *__restrict__ v, int64_t n,
                                                       float *__restrict__ de1, float *__restrict__ de2, float *__restrict__ de3,
                                                       int accumulate, float *__restrict__ dhalf, int half_accumulate,
-                                                      float *__restrict__ dv) {
+                                                      float *__restrict__ dv_part) {
     constexpr int LD = 4 * LPR, GPW = kWave / LPR;
-    __shared__ float s_dv[256];
+    __shared__ float s_dv[1024];
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
-    for (int k = threadIdx.x; k < 256; k += blockDim.x) s_dv[k] = 0.f;
-    __syncthreads();
     const f32x4 v4 = *reinterpret_cast<const f32x4 *>(v + 4 * r);
     f32x4 dvl = {0.f, 0.f, 0.f, 0.f};
     for (int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g; row < n; row += (int64_t)gridDim.x * 4 * GPW) {
@@ -190,9 +214,7 @@ __global__ __launch_bounds__(256) void att_bwd_kernel(const float *__restrict__ 
         }
         dvl = dvl + wa * a + wb * b + wc * c;
     }
-    atomicAdd(&s_dv[4 * r + 0], dvl.x); atomicAdd(&s_dv[4 * r + 1], dvl.y); atomicAdd(&s_dv[4 * r + 2], dvl.z); atomicAdd(&s_dv[4 * r + 3], dvl.w);
-    __syncthreads();
-    if (threadIdx.x < LD) unsafeAtomicAdd(dv + threadIdx.x, s_dv[threadIdx.x]);
+    block_colsum_store<LPR>(dvl, s_dv, dv_part);
 }
 
 // gM[j][c] += dv[j] a[c];  ga[c] += sum_j dv[j] M[j][c]      (one block of ld x ... threads; tiny)
@@ -206,20 +228,16 @@ __global__ void att_param_kernel(const float *__restrict__ dv, const float *__re
     }
 }
 
-// out[c] += scale * sum_rows X[row][c]   (out zeroed by the caller)
+// part[block][c] = sum of this block's rows of X[.][c]   (colsum_finish_kernel adds the blocks and scales)
 template <int LPR>
-__global__ __launch_bounds__(256) void col_sum_kernel(const float *__restrict__ X, int64_t n, float scale, float *__restrict__ out) {
+__global__ __launch_bounds__(256) void col_sum_kernel(const float *__restrict__ X, int64_t n, float *__restrict__ part) {
     constexpr int LD = 4 * LPR, GPW = kWave / LPR;
-    __shared__ float s_acc[256];
+    __shared__ float s_acc[1024];
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
-    for (int k = threadIdx.x; k < 256; k += blockDim.x) s_acc[k] = 0.f;
-    __syncthreads();
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + g; row < n; row += (int64_t)gridDim.x * 4 * GPW)
         acc = acc + *reinterpret_cast<const f32x4 *>(X + row * LD + 4 * r);
-    atomicAdd(&s_acc[4 * r + 0], acc.x); atomicAdd(&s_acc[4 * r + 1], acc.y); atomicAdd(&s_acc[4 * r + 2], acc.z); atomicAdd(&s_acc[4 * r + 3], acc.w);
-    __syncthreads();
-    if (threadIdx.x < LD) unsafeAtomicAdd(out + threadIdx.x, scale * s_acc[threadIdx.x]);
+    block_colsum_store<LPR>(acc, s_acc, part);
 }
 
 // hierarchical_self_supervision (MHCN.py:184-206) scores per row r:
@@ -232,13 +250,11 @@ __global__ __launch_bounds__(256) void hss_coef_kernel(const float *__restrict__
                                                        const int32_t *__restrict__ p1, const int32_t *__restrict__ p2,
                                                        const int32_t *__restrict__ k2, const int32_t *__restrict__ p3,
                                                        const int32_t *__restrict__ k3, const float *__restrict__ graph, int d,
-                                                       int64_t n, float *__restrict__ coef, float *__restrict__ dgraph,
+                                                       int64_t n, float *__restrict__ coef, float *__restrict__ dgraph_part,
                                                        double *__restrict__ loss_out) {
     constexpr int LD = 4 * LPR, GPW = kWave / LPR;
-    __shared__ float s_dg[256];
+    __shared__ float s_dg[1024];
     const int lane = threadIdx.x & 63, g = lane / LPR, r = lane % LPR;
-    for (int k = threadIdx.x; k < 256; k += blockDim.x) s_dg[k] = 0.f;
-    __syncthreads();
     const f32x4 gr = *reinterpret_cast<const f32x4 *>(graph + 4 * r);
     int kc2[4], kc3[4];
 #pragma unroll
@@ -264,12 +280,10 @@ __global__ __launch_bounds__(256) void hss_coef_kernel(const float *__restrict__
         }
         dgl = dgl + c3 * (e - e3);
     }
-    atomicAdd(&s_dg[4 * r + 0], dgl.x); atomicAdd(&s_dg[4 * r + 1], dgl.y); atomicAdd(&s_dg[4 * r + 2], dgl.z); atomicAdd(&s_dg[4 * r + 3], dgl.w);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) loss += __shfl_xor(loss, m, kWave);
     if (lane == 0 && loss != 0.0) atomicAdd(loss_out, loss);
-    __syncthreads();
-    if (threadIdx.x < LD) unsafeAtomicAdd(dgraph + threadIdx.x, s_dg[threadIdx.x]);
+    block_colsum_store<LPR>(dgl, s_dg, dgraph_part);
 }
 
 // Gradients of the block above w.r.t. em and edge, gathered through the inverse permutations (q = p^-1):
@@ -426,15 +440,18 @@ int qrec_channel_attention_bwd(const float *d_dOut, const float *d_e1, const flo
     QREC_REQUIRE(d_dOut && d_e1 && d_e2 && d_e3 && d_score && d_v && d_att && d_att_mat && d_de1 && d_de2 && d_de3 && d_dv_scratch &&
                  d_g_att && d_g_att_mat && n_rows >= 0, "qrec_channel_attention_bwd: bad argument");
     hipStream_t st = as_stream(stream);
-    QREC_HIP_CHECK(hipMemsetAsync(d_dv_scratch, 0, sizeof(float) * 256, st));
+    QREC_REQUIRE(ld == 32 || ld == 64 || ld == 128 || ld == 256, "qrec_channel_attention_bwd: row stride must be 32, 64, 128 or 256 floats (got %d)", ld);
+    int blocks = 0;
     if (n_rows > 0) {
         QREC_MHCN_LD_SWITCH("qrec_channel_attention_bwd", {
-            int blocks = launch_rows<LPR>(n_rows); if (blocks > 512) blocks = 512;
+            blocks = launch_rows<LPR>(n_rows); if (blocks > kColBlocks) blocks = kColBlocks;
             hipLaunchKernelGGL((att_bwd_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, d_dOut, d_e1, d_e2, d_e3, d_score, d_v, n_rows,
-                               d_de1, d_de2, d_de3, accumulate, d_dhalf, half_accumulate, d_dv_scratch);
+                               d_de1, d_de2, d_de3, accumulate, d_dhalf, half_accumulate, d_dv_scratch + 256);
         })
         QREC_LAUNCH_CHECK();
     }
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(1), dim3(256), 0, st, d_dv_scratch + 256, blocks, ld, 1.0f, 0, d_dv_scratch);
+    QREC_LAUNCH_CHECK();
     hipLaunchKernelGGL(att_param_kernel, dim3(1), dim3(256), 0, st, d_dv_scratch, d_att_mat, d_att, ld, d_g_att_mat, d_g_att);
     QREC_LAUNCH_CHECK();
     return QREC_OK;
@@ -449,13 +466,15 @@ int qrec_hss_loss_grad(const float *d_em, const float *d_edge, int64_t n_rows, i
                  d_scratch && d_dem && d_dedge && d_loss && n_rows >= 0 && d >= 1 && d <= ld, "qrec_hss_loss_grad: bad argument");
     if (n_rows == 0) return QREC_OK;
     hipStream_t st = as_stream(stream);
-    float *graph = d_scratch, *dgraph = d_scratch + 256, *coef = d_scratch + 512;       // [256] [256] [n][4]
-    QREC_HIP_CHECK(hipMemsetAsync(d_scratch, 0, sizeof(float) * 512, st));
+    float *graph = d_scratch, *dgraph = d_scratch + 256, *part = d_scratch + 512, *coef = part + kColBlocks * 256;   // [256] [256] [512][256] [n][4]
+    QREC_HIP_CHECK(hipMemsetAsync(d_scratch, 0, sizeof(float) * 512, st));       // the pad columns of graph / dgraph stay zero
     QREC_MHCN_LD_SWITCH("qrec_hss_loss_grad", {
-        int blocks = launch_rows<LPR>(n_rows); if (blocks > 512) blocks = 512;
-        hipLaunchKernelGGL((col_sum_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, d_edge, n_rows, 1.0f / (float)n_rows, graph);
+        int blocks = launch_rows<LPR>(n_rows); if (blocks > kColBlocks) blocks = kColBlocks;
+        hipLaunchKernelGGL((col_sum_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, d_edge, n_rows, part);
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3(1), dim3(256), 0, st, part, blocks, ld, 1.0f / (float)n_rows, 0, graph);
         hipLaunchKernelGGL((hss_coef_kernel<LPR>), dim3((unsigned)blocks), dim3(256), 0, st, d_em, d_edge, d_p1, d_p2, d_k2, d_p3, d_k3, graph, d,
-                           n_rows, coef, dgraph, d_loss);
+                           n_rows, coef, part, d_loss);
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3(1), dim3(256), 0, st, part, blocks, ld, 1.0f, 0, dgraph);
         hipLaunchKernelGGL((hss_grad_kernel<LPR>), dim3((unsigned)launch_rows<LPR>(n_rows)), dim3(256), 0, st, d_em, d_edge, coef, d_p1, d_p1inv,
                            d_p2, d_p2inv, d_k2, d_k2inv, d_p3inv, d_k3inv, graph, dgraph, d, n_rows, scale, d_dem, d_dedge);
     })
@@ -465,7 +484,13 @@ int qrec_hss_loss_grad(const float *d_em, const float *d_edge, int64_t n_rows, i
 
 int qrec_hss_scratch_bytes(int64_t n_rows, int64_t *bytes) {
     QREC_REQUIRE(bytes && n_rows >= 0, "qrec_hss_scratch_bytes: bad argument");
-    *bytes = (int64_t)sizeof(float) * (512 + 4 * n_rows);
+    *bytes = (int64_t)sizeof(float) * (512 + kColBlocks * 256 + 4 * n_rows);
+    return QREC_OK;
+}
+
+int qrec_channel_attention_scratch_bytes(int64_t *bytes) {
+    QREC_REQUIRE(bytes, "qrec_channel_attention_scratch_bytes: bad argument");
+    *bytes = (int64_t)sizeof(float) * (256 + kColBlocks * 256);       // dv, then the blocks' partial column sums
     return QREC_OK;
 }
 

@@ -3,13 +3,37 @@
 step of model/ranking/LightGCN.py:11-41 driven entirely through the C ABI."""
 from __future__ import annotations
 
+import contextlib
 import os
+import threading
 
 import numpy as np
 
 from . import capi
 from .capi import DeviceBuffer
 from .engine import padded_ld
+
+# ---- reduction order of the batch-gradient scatters ------------------------------------------------------------------------
+# Throughput mode adds a batch's row gradients into the table gradient with float atomics (right to fp32 rounding; the order,
+# and with it the last bits, change from launch to launch).  Parity mode -- the exact mode of the drop-in classes, the golden-run
+# tests -- adds every row's lookups in batch order, one lookup at a time, as the reference's CPU scatter does
+# (csrc/ordered.hip): same inputs, same bits, every run.  A trainer takes the setting of the thread that constructs it.
+_REDUCTIONS = threading.local()
+
+
+@contextlib.contextmanager
+def ordered_reductions(on: bool = True):
+    """``with ordered_reductions(): tr = SEPTTrainer(...)`` -- trainers built inside run their gradient scatters in parity mode"""
+    before = getattr(_REDUCTIONS, "ordered", False)
+    _REDUCTIONS.ordered = bool(on)
+    try:
+        yield
+    finally:
+        _REDUCTIONS.ordered = before
+
+
+def _ordered_ws():
+    return capi.OrderedScatter() if getattr(_REDUCTIONS, "ordered", False) else None
 
 
 def joint_norm_adjacency(n_users: int, n_items: int, uid: np.ndarray, iid: np.ndarray):
@@ -202,6 +226,7 @@ class LightGCNTrainer:
 
     def __init__(self, U0: np.ndarray, V0: np.ndarray, adj, n_layers: int, lr: float, reg: float,
                  loss_eps: float = 1e-7):
+        self.ows = _ordered_ws()      # parity mode (ordered_reductions()): workspace of the ordered gradient scatters; None = float atomics
         self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
         self.n = self.nu + self.ni
         self.ld = padded_ld(self.d, np.float32)
@@ -268,7 +293,7 @@ class LightGCNTrainer:
             capi.zero_rows(self.dE, self.ld, subset, stream)
         if B:
             capi.bpr_batch_loss_grad(self.S, float(self.L + 1), self.nu, self.n, self.ld, d_u, d_i, d_j, B,
-                                     self.loss_eps, self.reg, self.dE, self.d_loss, stream, d_row_mask=self.row_mask)
+                                     self.loss_eps, self.reg, self.dE, self.d_loss, stream, d_row_mask=self.row_mask, ordered=self.ows)
         g = self.backward_from_dE(stream)
         if self.dp is not None:        # the step's gradient and loss = sums over the ranks' shares of its rows
             self.dp.all_reduce(g); self.dp.all_reduce(self.d_loss)
@@ -352,6 +377,7 @@ class RowPartitionedLightGCNTrainer:
 
     def __init__(self, comm, U0: np.ndarray, V0: np.ndarray, adj, n_layers: int, lr: float, reg: float,
                  loss_eps: float = 1e-7, batch_rows: bool = True):
+        self.ows = _ordered_ws()      # parity mode (ordered_reductions()): workspace of the ordered gradient scatters; None = float atomics
         from .dist import RowPartition
         self.comm = comm
         self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
@@ -426,7 +452,7 @@ class RowPartitionedLightGCNTrainer:
         self.comm.allreduce(b["S"], 3 * B * ld, capi.F32, stream)
         b["dE"].fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
         # the loss on the compact table: batch row k is the user, B + k the positive, 2B + k the negative item of triplet k (n_users = B)
-        capi.bpr_batch_loss_grad(b["S"], float(self.L + 1), B, 3 * B, ld, b["u"], b["u"], b["j"], B, self.loss_eps, self.reg, b["dE"], self.d_loss, stream)
+        capi.bpr_batch_loss_grad(b["S"], float(self.L + 1), B, 3 * B, ld, b["u"], b["u"], b["j"], B, self.loss_eps, self.reg, b["dE"], self.d_loss, stream, ordered=self.ows)
         # every rank holds the whole batch gradient: scattered into a whole-height operand (repeated rows add up), which the first
         # backward product reads directly; this rank's rows of it are the addend of all of them
         self.dE_full.fill_bytes(0, stream)
@@ -451,7 +477,7 @@ class RowPartitionedLightGCNTrainer:
         self.dE_full.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
         if B:
             capi.bpr_batch_loss_grad(self.S_full, float(self.L + 1), self.nu, self.n, ld, d_u, d_i, d_j, B, self.loss_eps,
-                                     self.reg, self.dE_full, self.d_loss, stream)
+                                     self.reg, self.dE_full, self.d_loss, stream, ordered=self.ows)
         dE_blk = self.dE_full.ptr + rp.lo * ld * 4                       # this rank's rows of the batch gradient, in place
         g = self._propagate(dE_blk, dE_blk, None, stream)
         self._adam(g, stream)
@@ -478,6 +504,7 @@ class BprTfTrainer:
     folded into the Adam kernel and its loss term comes from qrec_sumsq."""
 
     def __init__(self, U0, V0, lr: float, reg: float, loss_eps: float = 1e-6):
+        self.ows = _ordered_ws()      # parity mode (ordered_reductions()): workspace of the ordered gradient scatters; None = float atomics
         self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
         self.n = self.nu + self.ni
         self.ld = padded_ld(self.d, np.float32)
@@ -496,7 +523,7 @@ class BprTfTrainer:
         f = np.float32
         self.dE.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
         capi.bpr_batch_loss_grad(self.E, 1.0, self.nu, self.n, self.ld, d_u, d_i, d_j, B, self.loss_eps, 0.0,
-                                 self.dE, self.d_loss, stream)
+                                 self.dE, self.d_loss, stream, ordered=self.ows)
         capi.sumsq(self.E, capi.F32, self.n, self.d, self.ld, self.d_loss.ptr + 8, stream)   # loss is of the pre-update tables
         alpha = float(f(f(self.lr) * np.sqrt(f(1) - self.b2p, dtype=f) / (f(1) - self.b1p)))
         capi.adam_step(self.E, self.m, self.v, self.dE, self.n * self.ld, 1.0, alpha, float(self.b1), float(self.b2),
@@ -548,6 +575,7 @@ class SimGCLTrainer:
 
     def __init__(self, U0, V0, adj, n_layers: int, lr: float, reg: float, cl_rate: float, eps: float,
                  tau: float = 0.2, loss_eps: float = 1e-7, seed: int = 0, max_unique: int = 4096):
+        self.ows = _ordered_ws()      # parity mode (ordered_reductions()): workspace of the ordered gradient scatters; None = float atomics
         self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
         self.n = self.nu + self.ni
         self.ld = padded_ld(self.d, np.float32)
@@ -651,7 +679,7 @@ class SimGCLTrainer:
             d_u, d_i, d_j = (capi.device_ptr(p) + 4 * lo for p in (d_u, d_i, d_j))
         if cnt:
             capi.bpr_batch_loss_grad(self.Sm, L, self.nu, self.n, self.ld, d_u, d_i, d_j, cnt,
-                                     self.loss_eps, self.reg, self.dOut, self.d_loss, stream, d_row_mask=self.row_mask)
+                                     self.loss_eps, self.reg, self.dOut, self.d_loss, stream, d_row_mask=self.row_mask, ordered=self.ows)
         cl = self.d_loss.ptr + 8
         side = self.side_stream.handle
         self.ev_fork.record(stream); self.side_stream.wait_event(self.ev_fork)
@@ -716,6 +744,7 @@ class RowPartitionedSimGCLTrainer:
 
     def __init__(self, comm, U0, V0, adj, n_layers: int, lr: float, reg: float, cl_rate: float, eps: float,
                  tau: float = 0.2, loss_eps: float = 1e-7, seed: int = 0, max_unique: int = 4096, batch_rows: bool = True):
+        self.ows = _ordered_ws()      # parity mode (ordered_reductions()): workspace of the ordered gradient scatters; None = float atomics
         from .dist import RowPartition
         self.comm = comm
         self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
@@ -811,7 +840,7 @@ class RowPartitionedSimGCLTrainer:
             self.comm.allreduce(c["S"], (3 * B + 2 * nC) * ld, capi.F32, stream)
             c["dSm"].fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
             capi.memset(c["dC"].ptr, 0, max(nC, 1) * row, stream)
-            capi.bpr_batch_loss_grad(c["S"], L, B, 3 * B, ld, c["ar"], c["ar"], c["arB"], B, self.loss_eps, self.reg, c["dSm"], self.d_loss, stream)
+            capi.bpr_batch_loss_grad(c["S"], L, B, 3 * B, ld, c["ar"], c["ar"], c["arB"], B, self.loss_eps, self.reg, c["dSm"], self.d_loss, stream, ordered=self.ows)
             capi.info_nce_loss_grad(pS1, pS2, L, c["ar"], n_uu, ld, self.tau, self.cl_rate, self.ws, c["dC"], cl, stream)
             capi.info_nce_loss_grad(pS1, pS2, L, c["ar"].ptr + 4 * n_uu, n_ui, ld, self.tau, self.cl_rate, self.ws, c["dC"], cl, stream)
             self.dOut_full.fill_bytes(0, stream)
@@ -825,7 +854,7 @@ class RowPartitionedSimGCLTrainer:
             rows_full = rp.world * rp.rows_pad
             if B:
                 capi.bpr_batch_loss_grad(self.Sm_full, L, self.nu, rows_full, ld, d_u, d_i, d_j, B, self.loss_eps, self.reg, self.dOut_full,
-                                         self.d_loss, stream)
+                                         self.d_loss, stream, ordered=self.ows)
             capi.info_nce_loss_grad(self.S1_full, self.S2_full, L, d_uniq_users, n_uu, ld, self.tau, self.cl_rate, self.ws, self.dOut_full, cl, stream)
             capi.info_nce_loss_grad(self.S1_full, self.S2_full, L, d_uniq_items, n_ui, ld, self.tau, self.cl_rate, self.ws, self.dOut_full, cl, stream)
         dOut_blk = self.dOut_full.ptr + 4 * rp.lo * ld                  # this rank's rows of the output gradient, in place
@@ -901,6 +930,7 @@ class NGCFTrainer:
     N_LAYERS = 2
 
     def __init__(self, U0, V0, W, adj, lr: float, reg: float, loss_eps: float = 1e-7, seed: int = 0):
+        self.ows = _ordered_ws()      # parity mode (ordered_reductions()): workspace of the ordered gradient scatters; None = float atomics
         self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
         self.n = self.nu + self.ni
         if 3 * self.d > 256:
@@ -975,7 +1005,7 @@ class NGCFTrainer:
             self.dAll.fill_bytes(0, stream)
         if B:
             capi.bpr_batch_loss_grad(self.All, 1.0, self.nu, n, self.wide_ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
-                                     self.dAll, self.d_loss, stream, d_row_mask=self.row_mask)
+                                     self.dAll, self.d_loss, stream, d_row_mask=self.row_mask, ordered=self.ows)
         dnext = None
         for k in (1, 0):
             dE = self.dEa if k == 1 else self.dEb
@@ -1040,6 +1070,7 @@ class RowPartitionedNGCFTrainer:
     N_LAYERS = 2
 
     def __init__(self, comm, U0, V0, W, adj, lr: float, reg: float, loss_eps: float = 1e-7, seed: int = 0, batch_rows: bool = True):
+        self.ows = _ordered_ws()      # parity mode (ordered_reductions()): workspace of the ordered gradient scatters; None = float atomics
         from .dist import RowPartition
         self.comm = comm
         self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
@@ -1128,7 +1159,7 @@ class RowPartitionedNGCFTrainer:
             capi.batch_rows_gather(self.All_full.ptr + mine, self.wide_ld, rp.lo, rp.hi, d_u, d_i, d_j, B, self.nu, b["S"], stream)
             self.comm.allreduce(b["S"], 3 * B * self.wide_ld, capi.F32, stream)
             b["dS"].fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
-            capi.bpr_batch_loss_grad(b["S"], 1.0, B, 3 * B, self.wide_ld, b["u"], b["u"], b["j"], B, self.loss_eps, self.reg, b["dS"], self.d_loss, stream)
+            capi.bpr_batch_loss_grad(b["S"], 1.0, B, 3 * B, self.wide_ld, b["u"], b["u"], b["j"], B, self.loss_eps, self.reg, b["dS"], self.d_loss, stream, ordered=self.ows)
             capi.memset(self.dAll_full.ptr + mine, 0, pad * self.wide_ld * 4, stream)
             capi.batch_rows_scatter_add(self.dAll_full.ptr + mine, self.wide_ld, rp.lo, rp.hi, d_u, d_i, d_j, B, self.nu, b["dS"], stream)
         else:
@@ -1136,7 +1167,7 @@ class RowPartitionedNGCFTrainer:
             self.dAll_full.fill_bytes(0, stream); self.d_loss.fill_bytes(0, stream)
             if B:
                 capi.bpr_batch_loss_grad(self.All_full, 1.0, self.nu, rows_full, self.wide_ld, d_u, d_i, d_j, B, self.loss_eps, self.reg,
-                                         self.dAll_full, self.d_loss, stream)
+                                         self.dAll_full, self.d_loss, stream, ordered=self.ows)
         dnext = None
         for k in (1, 0):
             dE = self.dEa if k == 1 else self.dEb
@@ -1178,6 +1209,7 @@ class SGLTrainer:
 
     def __init__(self, U0, V0, adj, n_layers: int, lr: float, reg: float, ssl_reg: float, temp: float,
                  loss_eps: float = 1e-7, max_unique: int = 8192):
+        self.ows = _ordered_ws()      # parity mode (ordered_reductions()): workspace of the ordered gradient scatters; None = float atomics
         self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
         self.n = self.nu + self.ni
         self.ld = padded_ld(self.d, np.float32)
@@ -1261,7 +1293,7 @@ class SGLTrainer:
             d_u, d_i, d_j = (capi.device_ptr(p) + 4 * lo for p in (d_u, d_i, d_j))
         if cnt:
             capi.bpr_batch_loss_grad(self.S[0], div, self.nu, self.n, self.ld, d_u, d_i, d_j, cnt, self.loss_eps, self.reg,
-                                     self.dOut[0], self.d_loss, stream, d_row_mask=self.row_mask)
+                                     self.dOut[0], self.d_loss, stream, d_row_mask=self.row_mask, ordered=self.ows)
         capi.info_nce_loss_grad(self.S[1], self.S[2], div, d_rows, n_rows, self.ld, self.temp,
                                 self.ssl_reg if dp is None else self.ssl_reg / dp.world, self.ws,
                                 self.dOut[1], self.d_loss.ptr + 8, stream, d_out2=self.dOut[2])
@@ -1298,6 +1330,7 @@ class BUIRTrainer:
     computed at the batch's rows only."""
 
     def __init__(self, U0, V0, W0, b0, n_layers: int, lr: float, tau: float):
+        self.ows = _ordered_ws()      # parity mode (ordered_reductions()): workspace of the ordered gradient scatters; None = float atomics
         self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
         self.n = self.nu + self.ni
         self.ld = padded_ld(self.d, np.float32)
@@ -1359,7 +1392,7 @@ class BUIRTrainer:
         self._mean_sum(self.plan_t, self.T, self.S_tar, stream, self.row_mask)
         capi.zero_rows(self.dS, self.ld, subset, stream)
         capi.buir_batch_loss_grad(self.S_on, self.S_tar, div, self.nu, self.ld, self.W, self.b, d_u, d_i, B, self.dS, self.Xb,
-                                  self.Gb, self.d_loss, stream)
+                                  self.Gb, self.d_loss, stream, ordered=self.ows)
         if B:
             capi.buir_wgrad(self.Xb, self.Gb, 2 * B, self.ld, self.wscratch, self.gW, self.gb, stream)
         else:                   # an empty share of a step (multi-GPU tail batch)
@@ -1529,6 +1562,7 @@ class SEPTTrainer:
 
     def __init__(self, U0, V0, adj, friend, sharing, n_layers: int, lr: float, reg: float, ss_rate: float, ins_cnt: int,
                  loss_eps: float = 1e-7, max_unique: int = 4096):
+        self.ows = _ordered_ws()      # parity mode (ordered_reductions()): workspace of the ordered gradient scatters; None = float atomics
         self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
         self.n = self.nu + self.ni
         self.ld = padded_ld(self.d, np.float32)
@@ -1574,7 +1608,7 @@ class SEPTTrainer:
         if cnt:
             off = 4 * lo
             capi.bpr_batch_loss_grad(self.pref.S, 1.0, self.nu, self.n, self.ld, capi.device_ptr(d_u) + off, capi.device_ptr(d_i) + off,
-                                     capi.device_ptr(d_j) + off, cnt, self.loss_eps, 0.0, self.pref.dS, self.d_loss, stream)
+                                     capi.device_ptr(d_j) + off, cnt, self.loss_eps, 0.0, self.pref.dS, self.d_loss, stream, ordered=self.ows)
         capi.sumsq(self.W, capi.F32, self.n, self.d, self.ld, self.d_loss.ptr + 8, stream)     # regU (l2(U/2) + l2(V/2)) = regU sum W^2 / 8
         if joint:
             for v in (self.friend, self.sharing, self.aug):
@@ -1583,7 +1617,7 @@ class SEPTTrainer:
                 self.d_labels = DeviceBuffer((3, n_uu, self.k), np.int32)
             capi.sept_ssl_loss_grad(self.friend.S, self.sharing.S, self.pref.S, self.aug.S, d_uniq_users, n_uu, self.ld, self.k,
                                     self.ss_rate if dp is None else self.ss_rate / dp.world, self.ws, self.friend.dS, self.sharing.dS, self.pref.dS, self.aug.dS,
-                                    self.d_loss.ptr + 16, self.d_labels if keep_labels else None, stream)
+                                    self.d_loss.ptr + 16, self.d_labels if keep_labels else None, stream, ordered=self.ows)
             for v in (self.friend, self.sharing, self.aug):
                 self.T = v.backward(self.T, self.G, self.dE0, stream, ds_rows=mask)
         self.T = self.pref.backward(self.T, self.G, self.dE0, stream, ds_rows=mask)
@@ -1673,6 +1707,7 @@ class MHCNTrainer:
 
     def __init__(self, U0, V0, weights, H, R, n_layers: int, lr: float, reg: float, ss_rate: float, loss_eps: float = 1e-7,
                  seed: int = 0):
+        self.ows = _ordered_ws()      # parity mode (ordered_reductions()): workspace of the ordered gradient scatters; None = float atomics
         self.nu, self.ni, self.d = U0.shape[0], V0.shape[0], U0.shape[1]
         self.n = self.nu + self.ni
         ld = self.ld = padded_ld(self.d, np.float32)
@@ -1706,7 +1741,7 @@ class MHCNTrainer:
         self.F = DeviceBuffer.zeros((self.n, ld), np.float32)                       # [final users ; final items (= sum_t)]
         self.dF = DeviceBuffer.zeros((self.n, ld), np.float32)
         self.score = [DeviceBuffer.zeros((self.nu, 4), np.float32) for _ in range(L + 1)]
-        self.v = DeviceBuffer.zeros(256, np.float32); self.dv = DeviceBuffer.zeros(256, np.float32)
+        self.v = DeviceBuffer.zeros(256, np.float32); self.dv = DeviceBuffer.zeros(capi.channel_attention_scratch_floats(), np.float32)
         self.mixed = zu()
         # self-supervision state
         self.SG, self.SGs, self.edge, self.dem, self.dedge, self.dSG, self.Q = zu(), zu(), zu(), zu(), zu(), zu(), zu()
@@ -1786,7 +1821,7 @@ class MHCNTrainer:
         for k in (1, 2, 3, 4):        # sgating4 is created but unused: its gradient is its L2 term alone
             g[f"sgating{k}"].fill_bytes(0, stream); g[f"sgating_bias{k}"].fill_bytes(0, stream)
         if B:
-            capi.bpr_batch_loss_grad(self.F, 1.0, nu, self.n, ld, d_u, d_i, d_j, B, self.loss_eps, 0.0, self.dF, self.d_loss, stream)
+            capi.bpr_batch_loss_grad(self.F, 1.0, nu, self.n, ld, d_u, d_i, d_j, B, self.loss_eps, 0.0, self.dF, self.d_loss, stream, ordered=self.ows)
         # hierarchical self-supervision of the three channels (MHCN.py:176-178, 184-206)
         for k, shuffles in enumerate(self._draw_shuffles(perms, stream)):
             Ws, bs = w[f"sgating{k + 1}"], w[f"sgating_bias{k + 1}"]

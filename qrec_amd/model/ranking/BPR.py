@@ -260,11 +260,12 @@ class BPR(IterativeRecommender):
         learning rate, no convergence test."""
         from ...base.deepRecommender import truncated_normal
         from ...capi import DeviceBuffer
-        from ...graph import BprTfTrainer
+        from ...graph import BprTfTrainer, ordered_reductions
         self.batch_size = int(self.config["batch_size"])
         U0 = truncated_normal((self.num_users, self.emb_size), 0.005)
         V0 = truncated_normal((self.num_items, self.emb_size), 0.005)
-        tr = self._tf_trainer = BprTfTrainer(U0, V0, self.lRate, self.regU)
+        with ordered_reductions():          # the -tf path replays the CPython stream: always the parity mode (bit-reproducible gradient sums)
+            tr = self._tf_trainer = BprTfTrainer(U0, V0, self.lRate, self.regU)
         rated = self.data.rated_csr().sorted_rows()
         quiet = os.environ.get("QREC_QUIET") == "1"
         for epoch in range(self.maxEpoch):

@@ -40,7 +40,7 @@ class BUIR(DeepRecommender):
         d = self.emb_size
         self.online_mat, self.online_bias = _xavier((d, d), rng), _xavier((1, d), rng)          # BUIR.py:81-82
         U0, V0 = _xavier((self.num_users, d), rng), _xavier((self.num_items, d), rng)            # BUIR.py:83-84
-        self.trainer = BUIRTrainer(U0, V0, self.online_mat, self.online_bias, self.n_layers, self.lRate, self.tau)
+        self.trainer = self.build_trainer(BUIRTrainer, U0, V0, self.online_mat, self.online_bias, self.n_layers, self.lRate, self.tau)
 
     def get_adj_mat(self, is_subgraph=False):
         """CSR triple of the normalized (sub-)graph adjacency (BUIR.py:41-65); a sub-graph keeps

@@ -28,10 +28,10 @@ class LightGCN(GraphRecommender):
             # one process per GPU, QREC_GRAPH_DIST=rows: the reference's own batch size, the propagation row-partitioned
             # over the ranks (qrec_amd/graph.py); default is the batch-sharded scheme (dist.BatchParallel)
             from ...graph import RowPartitionedLightGCNTrainer
-            self.trainer = RowPartitionedLightGCNTrainer(dp.comm, self.user_embeddings, self.item_embeddings,
+            self.trainer = self.build_trainer(RowPartitionedLightGCNTrainer, dp.comm, self.user_embeddings, self.item_embeddings,
                                                          self.create_joint_sparse_adjaceny(), self.n_layers, self.lRate, self.regU)
             return
-        self.trainer = LightGCNTrainer(self.user_embeddings, self.item_embeddings,
+        self.trainer = self.build_trainer(LightGCNTrainer, self.user_embeddings, self.item_embeddings,
                                        self.create_joint_sparse_adjaceny(), self.n_layers, self.lRate, self.regU)
 
     def trainModel(self):

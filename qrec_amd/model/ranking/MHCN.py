@@ -43,7 +43,7 @@ class MHCN(SocialRecommender, GraphRecommender):
             weights[f"gating{k}"] = _xavier((d, d)); weights[f"gating_bias{k}"] = _xavier((1, d))
             weights[f"sgating{k}"] = _xavier((d, d)); weights[f"sgating_bias{k}"] = _xavier((1, d))
         weights["attention"] = _xavier((1, d)); weights["attention_mat"] = _xavier((d, d))
-        self.trainer = MHCNTrainer(self.user_embeddings, self.item_embeddings, weights, H, R, self.n_layers, self.lRate, self.regU,
+        self.trainer = self.build_trainer(MHCNTrainer, self.user_embeddings, self.item_embeddings, weights, H, R, self.n_layers, self.lRate, self.regU,
                                    self.ss_rate, seed=int(os.environ.get("QREC_SEED", "0")))
 
     def saveModel(self):

@@ -30,11 +30,11 @@ class NGCF(GraphRecommender):
             # the ranks, the d x d weights replicated and their gradients all-reduced (qrec_amd/graph.py); the default is the
             # batch-sharded scheme (dist.BatchParallel)
             from ...graph import RowPartitionedNGCFTrainer
-            self.trainer = RowPartitionedNGCFTrainer(dp.comm, self.user_embeddings, self.item_embeddings, self.weights,
+            self.trainer = self.build_trainer(RowPartitionedNGCFTrainer, dp.comm, self.user_embeddings, self.item_embeddings, self.weights,
                                                      self.create_joint_sparse_adjaceny(), self.lRate, self.regU,
                                                      seed=int(os.environ.get("QREC_SEED", "0")))
             return
-        self.trainer = NGCFTrainer(self.user_embeddings, self.item_embeddings, self.weights,
+        self.trainer = self.build_trainer(NGCFTrainer, self.user_embeddings, self.item_embeddings, self.weights,
                                    self.create_joint_sparse_adjaceny(), self.lRate, self.regU,
                                    seed=int(os.environ.get("QREC_SEED", "0")))
 

@@ -44,7 +44,7 @@ class SEPT(SocialRecommender, GraphRecommender):
         # the reference re-creates both variables here (SEPT.py:129-130); every view starts from Variable / 2
         self.user_embeddings = truncated_normal((self.num_users, self.emb_size), 0.005)
         self.item_embeddings = truncated_normal((self.num_items, self.emb_size), 0.005)
-        self.trainer = SEPTTrainer(self.user_embeddings, self.item_embeddings, adj, friend, sharing, self.n_layers, self.lRate,
+        self.trainer = self.build_trainer(SEPTTrainer, self.user_embeddings, self.item_embeddings, adj, friend, sharing, self.n_layers, self.lRate,
                                    self.regU, self.ss_rate, self.instance_cnt, max_unique=max(self._step_rows(), 64))
         self._epochs_drawn = 0
 

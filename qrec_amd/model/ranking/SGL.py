@@ -31,7 +31,7 @@ class SGL(GraphRecommender):
 
     def initModel(self):
         super().initModel()
-        self.trainer = SGLTrainer(self.user_embeddings, self.item_embeddings, self.create_joint_sparse_adjaceny(),
+        self.trainer = self.build_trainer(SGLTrainer, self.user_embeddings, self.item_embeddings, self.create_joint_sparse_adjaceny(),
                                   self.n_layers, self.lRate, self.regU, self.ssl_reg, self.ssl_temp,
                                   max_unique=max(2 * self._step_rows(), 64))
 

@@ -42,11 +42,11 @@ class SimGCL(GraphRecommender):
             # one process per GPU, QREC_GRAPH_DIST=rows: the reference's own batch size, every node table row-partitioned over
             # the ranks (qrec_amd/graph.py); the default is the batch-sharded scheme (dist.BatchParallel)
             from ...graph import RowPartitionedSimGCLTrainer
-            self.trainer = RowPartitionedSimGCLTrainer(dp.comm, self.user_embeddings, self.item_embeddings, self.create_joint_sparse_adjaceny(),
+            self.trainer = self.build_trainer(RowPartitionedSimGCLTrainer, dp.comm, self.user_embeddings, self.item_embeddings, self.create_joint_sparse_adjaceny(),
                                                        self.n_layers, self.lRate, self.regU, self.cl_rate, self.eps,
                                                        seed=int(os.environ.get("QREC_SEED", "0")), max_unique=max(self.batch_size, 64))
             return
-        self.trainer = SimGCLTrainer(self.user_embeddings, self.item_embeddings, self.create_joint_sparse_adjaceny(),
+        self.trainer = self.build_trainer(SimGCLTrainer, self.user_embeddings, self.item_embeddings, self.create_joint_sparse_adjaceny(),
                                      self.n_layers, self.lRate, self.regU, self.cl_rate, self.eps,
                                      seed=int(os.environ.get("QREC_SEED", "0")), max_unique=max(self._step_rows(), 64))
 

@@ -345,7 +345,63 @@ def case_mhcn(tmp, ratings):
     return pack(rec, "tf_mhcn_filmtrust", names, open(conf).read(), 108, dict(n_layers=2, ss_rate=0.01))
 
 
+CASES = None        # filled below main(): the case functions in generation order
+
+
+def yardstick_main():
+    """``--float64-yardstick``: the SAME runs of the reference's classes with the stand-in's arithmetic in float64 (TF1SHIM_DTYPE=float64;
+    same seeds, so the same split, batches, negatives, dropout masks and shuffles -- asserted), SimGCL under the sign pattern its
+    committed float32 run recorded (sign() is discontinuous; a float64 replay that re-decided an entry within rounding of zero
+    would leave the float32 run by more than any rounding).  Written: tf_f64_yardstick.npz -- per model the trained variables and
+    the scoring tables of that run, rounded to float32.  What it is for: |fixture - yardstick| is the distance of the reference's
+    OWN float32 run from exact arithmetic, i.e. how far a correct implementation in any other summation order may land from the
+    fixture (tests/test_gpu_tf_golden.py holds the HIP trainers to 1e-5 of the fixture where that distance allows it, and reports
+    both distances everywhere).  Needs the committed float32 fixtures next to this file (it reads SimGCL's signs from there)."""
+    global HERE
+    if os.environ.get("TF1SHIM_DTYPE") != "float64":
+        os.environ["TF1SHIM_DTYPE"] = "float64"
+        os.execv(sys.executable, [sys.executable] + sys.argv)
+    committed = HERE
+    z = np.load(os.path.join(committed, "tf_simgcl_filmtrust.npz"))
+    shape = tuple(int(x) for x in z["sign_shape"]); n = int(np.prod(shape))
+    neg = np.unpackbits(z["sign_neg_bits"])[:n].reshape(shape).astype(bool)
+    zero = np.unpackbits(z["sign_zero_bits"])[:n].reshape(shape).astype(bool)
+    sg = np.where(zero, 0, np.where(neg, -1, 1)).astype(np.int8)                        # [steps, 4 sign ops, N, d]
+    G.install_stubs()
+    sys.modules["tensorflow"] = tf1shim
+    if not hasattr(np, "mat"):
+        np.mat = np.asmatrix
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp, tempfile.TemporaryDirectory() as scratch:
+        HERE = scratch                                                                   # pack() writes the float64 runs' files there
+        os.symlink(os.path.join(REF, "dataset"), os.path.join(tmp, "dataset"))
+        cwd = os.getcwd(); os.chdir(tmp)
+        try:
+            ratings, _ = make_subset(tmp)
+            for case in CASES:
+                tf1shim.FORCED_SIGNS.clear()
+                if case is case_simgcl:
+                    for step, run in enumerate(z["run_index"]):
+                        for op in range(shape[1]):
+                            tf1shim.FORCED_SIGNS[(int(run), op)] = sg[step, op]
+                meta = case(tmp, ratings)
+                name = meta["name"]
+                a, b = np.load(os.path.join(committed, name + ".npz")), np.load(os.path.join(scratch, name + ".npz"))
+                for k in ("train_uid", "train_iid", "batch_u", "batch_i", "batch_j", "run_index"):
+                    assert k not in a.files or np.array_equal(a[k], b[k]), (name, k, "the float64 run left the float32 run's inputs")
+                for k in b.files:
+                    if k.startswith(("final_", "score_")):
+                        out[f"{name}/{k}"] = b[k].astype(np.float32)
+                print(name, "float32 run vs float64 run:", {k: float(np.linalg.norm(a[k].astype(np.float64) - b[k]) / np.linalg.norm(b[k])) for k in b.files
+                                                              if k.startswith("final_") and b[k].size > 64})
+        finally:
+            os.chdir(cwd); HERE = committed
+    np.savez_compressed(os.path.join(committed, "tf_f64_yardstick.npz"), **out)
+
+
 def main():
+    if "--float64-yardstick" in sys.argv:
+        return yardstick_main()
     G.install_stubs()
     sys.modules["tensorflow"] = tf1shim
     if not hasattr(np, "mat"):
@@ -356,7 +412,7 @@ def main():
         cwd = os.getcwd(); os.chdir(tmp)
         try:
             ratings, n_rows = make_subset(tmp)
-            for case in (case_lightgcn, case_bpr_tf, case_ngcf, case_simgcl, case_sgl, case_buir, case_sept, case_mhcn, case_sgl_random_walk, case_sgl_node_dropout):
+            for case in CASES:
                 meta = case(tmp, ratings)
                 meta["subset"] = dict(source="dataset/FilmTrust/ratings.txt", first_users=N_SUBSET_USERS, rows=n_rows)
                 metas[meta["name"]] = meta
@@ -366,6 +422,8 @@ def main():
     with open(os.path.join(HERE, "golden_tf.json"), "w") as f:
         json.dump(metas, f, indent=1, sort_keys=True, default=str)
 
+
+CASES = (case_lightgcn, case_bpr_tf, case_ngcf, case_simgcl, case_sgl, case_buir, case_sept, case_mhcn, case_sgl_random_walk, case_sgl_node_dropout)
 
 if __name__ == "__main__":
     main()

@@ -46,26 +46,38 @@ def rel_err(a, b):
 
 # ---- parity ledger -------------------------------------------------------------------------------------------------------
 # Every numerical-agreement assertion of the GPU tests goes through ``check``: it asserts ``observed < bound`` AND, when
-# QREC_PARITY_LOG names a file, appends {test, quantity, observed, bound} to it as one JSON line.  A GPU run with the variable
+# QREC_PARITY_LOG names a file, appends {test, quantity, observed, bound, kind} to it as one JSON line.  A GPU run with the variable
 # set leaves the observed error of every comparison behind (tools/summarize_parity.py folds the lines into
 # profiles/rNN_parity_errors.json: per test and quantity, the worst observed value next to the bound it was held to).
-def check(quantity, observed, bound, ctx=None, inclusive=False):
+# ``kind`` says what sort of statement the row is, so that the summary can count the parity contract on its own:
+#   parity        same inputs, same algorithm, the reference's (or the oracle's) result: north_star's 1e-5 / bit-exact contract
+#   floor         a bound derived from the reference's OWN distance to exact arithmetic (tf_f64_yardstick.npz): the quantity cannot
+#                 be closer to the fixture than the fixture is to the truth
+#   discontinuity a run that may legitimately leave the recorded one at a discontinuous op (sign(), top_k) -- the recorded-pattern
+#                 variant of the same test is the parity row
+#   statistical   throughput-mode quantities (another random stream / visiting order): Recall@20 and loss gaps, means over seeds
+#   info          recorded, never a contract (bound is a sanity ceiling)
+KINDS = ("parity", "floor", "discontinuity", "statistical", "info")
+
+
+def check(quantity, observed, bound, ctx=None, inclusive=False, kind="parity"):
+    assert kind in KINDS, kind
     observed = float(observed); bound = float(bound)
     log = os.environ.get("QREC_PARITY_LOG")
     if log:
         test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
         with open(log, "a") as f:
-            f.write(json.dumps(dict(test=test, quantity=quantity, observed=observed, bound=bound)) + "\n")
+            f.write(json.dumps(dict(test=test, quantity=quantity, observed=observed, bound=bound, kind=kind)) + "\n")
     ok = observed <= bound if inclusive else observed < bound
     assert ok, f"{quantity}: observed {observed:.3e}, bound {bound:.1e}" + (f" [{ctx}]" if ctx is not None else "")
 
 
-def check_rel(quantity, got, want, rel, ctx=None, abs_tol=0.0):
+def check_rel(quantity, got, want, rel, ctx=None, abs_tol=0.0, kind="parity"):
     """element-wise |got - want| <= rel * |want| (+ abs_tol), recorded as the worst ratio |got - want| / (|want| + abs_tol / rel)"""
     got = np.asarray(got, dtype=np.float64); want = np.asarray(want, dtype=np.float64)
     den = np.abs(want) + (abs_tol / rel if abs_tol else 0.0)
     worst = float(np.max(np.abs(got - want) / np.maximum(den, 1e-300))) if got.size else 0.0
-    check(quantity, worst, rel, ctx=ctx, inclusive=True)
+    check(quantity, worst, rel, ctx=ctx, inclusive=True, kind=kind)
 
 
 def simgcl_recorded_signs(z, step):
@@ -84,3 +96,13 @@ def encode_forced_signs(noise, sign):
     """injected noise that carries the sign to use (include/qrec_hip.h, qrec_perturb_rows): u -> +-(2 + u) / 4 + u"""
     noise = np.asarray(noise, dtype=np.float32)
     return np.where(sign > 0, 2 + noise, np.where(sign < 0, -(2 + noise), 4 + noise)).astype(np.float32)
+
+
+def same_bits(what, a: dict, b: dict):
+    """two runs of a parity-mode trainer from the same inputs: every returned array bit-identical"""
+    assert a.keys() == b.keys()
+    for k in a:
+        x, y = np.asarray(a[k]), np.asarray(b[k])
+        assert x.shape == y.shape and x.dtype == y.dtype, (what, k)
+        diff = int(np.count_nonzero(x.view(np.uint8) != y.view(np.uint8))) if x.size else 0
+        check(f"{what}: bytes of '{k}' that differ between two runs from the same inputs (ordered reductions)", diff, 0, inclusive=True)

@@ -2,6 +2,7 @@
 (oracle/tfmodels.py): SpMM, batch BPR loss/grad, Adam, whole training steps, the drop-in class.
 fp32 tolerance 1e-5 relative (north_star)."""
 import io
+import os
 import random
 from contextlib import redirect_stdout
 
@@ -12,7 +13,7 @@ import scipy.sparse as sp
 from oracle import tfmodels as T
 from qrec_amd import capi
 from qrec_amd.capi import DeviceBuffer as DB
-from qrec_amd.graph import LightGCNTrainer, SpmmPlan, joint_norm_adjacency
+from qrec_amd.graph import LightGCNTrainer, SpmmPlan, joint_norm_adjacency, ordered_reductions
 from qrec_amd.synth import make_dataset
 
 from helpers import check, check_rel, conf_from_text, load_golden, pad_cols, rel_err, rows_from_golden
@@ -25,6 +26,14 @@ TOL = 1e-5
 def _device():
     capi.init(0)
     yield
+
+
+@pytest.fixture(autouse=True)
+def _parity_mode():
+    """trainers these tests construct directly run with ordered reductions (csrc/ordered.hip: the parity mode, the exact mode of the
+    drop-in classes); the drop-in classes choose for themselves (DeepRecommender.build_trainer), logical-rank threads keep the atomics"""
+    with ordered_reductions():
+        yield
 
 
 def _graph(shape):
@@ -211,7 +220,7 @@ def test_throughput_mode_of_the_pairwise_models_draws_its_batches_on_the_device(
     meta, z = load_golden("pairwise_adj_filmtrust")
     gz = load_golden("bpr_filmtrust")[1]
     train, test = rows_from_golden(gz)
-    conf = conf_from_text(meta["conf"]); conf["model.name"] = name; conf["num.max.epoch"] = "6"; conf["num.factors"] = "16"
+    conf = conf_from_text(meta["conf"]); conf["model.name"] = name; conf["num.max.epoch"] = os.environ.get("QREC_TEST_EPOCHS", "20"); conf["num.factors"] = "16"
     conf["item.ranking"] = "on -topN 10"; conf["learnRate"] = "-init 0.002 -max 1"
     if name == "SimGCL":
         conf["SimGCL"] = "-n_layer 2 -lambda 0.5 -eps 0.1"
@@ -228,21 +237,32 @@ def test_throughput_mode_of_the_pairwise_models_draws_its_batches_on_the_device(
             measure = m.execute()
         return m, [float(x.split(":")[1]) for x in measure if ":" in x]
     # The two modes run the SAME training step (held to the reference at 1e-5 elsewhere); what differs is which uniform shuffle /
-    # which unrated negatives an epoch sees.  So the statement is statistical, and it is made against the exact mode's own
-    # stream-to-stream spread (round 3 asserted +-0.02 on one seed): S streams per mode, Recall@10 = measure[1];
-    # |mean_throughput - mean_exact| must be inside 0.002 + three standard errors of the difference (three streams per mode give the
-    # standard error itself ~4 degrees of freedom: at two, one comparison in twenty of a TRUE null would fail).
-    S = 3
-    exact = np.array([run("exact", 3 + k)[1] for k in range(S)])
-    runs = [run("throughput", 5 + k) for k in range(S)]
-    m, thr = runs[0][0], np.array([r[1] for r in runs])
+    # which unrated negatives an epoch sees.  So the statement is statistical: the difference of the two modes' MEAN measures over S
+    # sampling streams per mode, inside a FLAT bound.  Round 5 ran three streams and allowed 0.002 + three standard errors, which
+    # let 0.02-0.05 through for NGCF / SimGCL; measured since (tools/probe_mode_gap.py, 64 streams): one run's Recall@10 spreads 0.020-0.024
+    # (sd) from stream to stream on this 1,500-user set in EITHER mode, NDCG 0.034, the reduction order (ordered / atomic) moves nothing.
+    # A flat 0.005 needs the difference of the means known to ~0.0017 (3 sigma): streams are added in blocks of 32 per mode until the
+    # standard error of the Recall difference is there (a run is 0.15 s; LightGCN stops at the first block, NGCF needs ~10).
+    block, s_max = 32, int(os.environ.get("QREC_TEST_MAX_STREAMS", "512"))
+    exact, thr, m = [], [], None
+    while True:
+        k0 = len(exact)
+        exact += [run("exact", 3 + k)[1] for k in range(k0, k0 + block)]
+        for k in range(k0, k0 + block):
+            m, meas = run("throughput", 100003 + k)
+            thr.append(meas)
+        S = len(exact)
+        e, t = np.array(exact), np.array(thr)
+        se = np.sqrt(e.var(0, ddof=1) / S + t.var(0, ddof=1) / S)
+        if se[1] <= 0.0017 or S >= s_max:
+            break
+    exact, thr = e, t
     assert m.throughput_mode()
-    se = np.sqrt(exact.var(0, ddof=1) / S + thr.var(0, ddof=1) / S)
     gap = np.abs(thr.mean(0) - exact.mean(0))
-    print(name, "Recall@10 exact", exact[:, 1], "throughput", thr[:, 1], "gap", gap[1], "se", se[1])
-    for k, what in enumerate(("Precision", "Recall", "F1", "NDCG")):
-        check(f"{name} throughput-mode vs exact-mode {what}@10, |difference of the means over {S} sampling streams| (bound = 0.002 + 3 standard errors; "
-              f"exact mode's own stream-to-stream std {exact[:, k].std(ddof=1):.4f})", gap[k], 0.002 + 3 * se[k], inclusive=True)
+    print(name, "streams per mode", S, "exact mean", exact.mean(0), "sd", exact.std(0, ddof=1), "throughput mean", thr.mean(0), "sd", thr.std(0, ddof=1), "gap", gap, "se", se)
+    for k, (what, bound) in enumerate((("Precision", 0.005), ("Recall", 0.005), ("F1", 0.005), ("NDCG", 0.01))):   # NDCG's own stream-to-stream sd is 1.7x Recall's
+        check(f"{name} throughput-mode vs exact-mode {what}@10, |difference of the means over the sampling streams|", gap[k], bound, inclusive=True, kind="statistical", ctx=(S, se[k]))
+    check(f"{name} Recall@10: standard error of that difference", se[1], 0.0025, inclusive=True, kind="statistical", ctx=S)
     assert thr[:, 1].min() > 0.05                                          # it learned something (Recall@10 on FilmTrust)
     # the stream itself
     u0, i0, _ = m.data.training_arrays()
@@ -315,7 +335,7 @@ def test_info_nce_matches_restatement(n, dim, ld):
                             0.2, 0.5, ws, dOut, dl)
     got = dOut.numpy()
     check("InfoNCE loss vs restatement, relative", abs(dl.numpy()[0] - loss) / max(abs(loss), 1.0), TOL)
-    check("rel_err(got[:, :dim] - base, want - base)", rel_err(got[:, :dim] - base, want - base), 5e-5)
+    check("InfoNCE gradient rows vs restatement", rel_err(got[:, :dim] - base, want - base), TOL)
     assert (got[:, dim:] == 0).all()
     untouched = np.ones(N, bool); untouched[rows] = False
     assert np.array_equal(got[untouched][:, :dim], base[untouched])
@@ -323,36 +343,51 @@ def test_info_nce_matches_restatement(n, dim, ld):
 
 @pytest.mark.parametrize("L", [1, 2, 3])
 def test_simgcl_training_steps_match_restatement(L):
+    """Five steps, EVERY one from the restatement's state (table and Adam slots uploaded before the step): losses and the gradient
+    minimize() applies at 1e-5, step by step -- the parity statement (Adam itself: test_adam_matches_restatement).  Not compared: a table after five
+    FREE-running steps.  Adam divides by sqrt(v); on a coordinate whose gradient is cancellation noise of InfoNCE's softmax-weighted
+    sums the step is ~lr in a direction the summation order decides, in any float32 implementation -- the reference's own float32 run
+    sits 3e-5 from the same run in float64 after twelve steps (tests/golden/tf_f64_yardstick.npz; test_gpu_tf_golden.py holds the
+    free-running HIP trainer to that measured floor).  The free-running distance is recorded (kind "info")."""
     d, adj, A = _graph("small")
     nu, ni, dim, B = d["n_users"], d["n_items"], 64, 1024
     N = nu + ni
-    rng = np.random.default_rng(20 + L)
     lim = np.sqrt(6.0 / (nu + dim))
-    U0 = rng.uniform(-lim, lim, (nu, dim)).astype(np.float32); V0 = rng.uniform(-lim, lim, (ni, dim)).astype(np.float32)
-    ref = T.SimGCL(U0, V0, A, L, lr=0.001, reg=1e-4, cl_rate=0.5, eps=0.1)
-    tr = SimGCLTrainer(U0, V0, adj, L, lr=0.001, reg=1e-4, cl_rate=0.5, eps=0.1, max_unique=B)
-    for step in range(5):
-        sel = rng.integers(0, d["train_u"].size, B)
-        u = d["train_u"][sel].astype(np.int32); i = d["train_i"][sel].astype(np.int32); j = rng.integers(0, ni, B).astype(np.int32)
-        noises = [rng.random((N, dim)).astype(np.float32) for _ in range(2 * L)]
-        lref, rec_ref, cl_ref = ref.train_step(u, i, j, noises)
-        uu = unique_first_appearance(u); vv = (unique_first_appearance(i) + nu).astype(np.int32)
-        tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, DB.from_numpy(uu), uu.size,
-                            DB.from_numpy(vv), vv.size, noises=[DB.from_numpy(x) for x in noises])
-        tot, rec, cl = tr.losses()
-        check("abs(rec - rec_ref) / abs(rec_ref)", abs(rec - rec_ref) / abs(rec_ref), 1e-5)
-        check("abs(cl - cl_ref) / abs(cl_ref)", abs(cl - cl_ref) / abs(cl_ref), 1e-5)
-    Ug, Vg = tr.ego_embeddings()
-    E0 = np.concatenate([U0, V0])
-    # Adam divides by sqrt(v): on coordinates whose gradient is at rounding-noise level the step is
-    # +-alpha whatever the implementation, so two correct fp32 pipelines (different summation order
-    # in the SpMM / MFMA) drift apart by ~alpha*sqrt(steps) there.  Losses above are held to 2e-5;
-    # the tables to 5e-5 after 5 steps.
-    check("rel_err(np.concatenate([Ug, Vg]) - E0, ref.E - E0)", rel_err(np.concatenate([Ug, Vg]) - E0, ref.E - E0), 0.001)
-    check("rel_err(np.concatenate([Ug, Vg]), ref.E)", rel_err(np.concatenate([Ug, Vg]), ref.E), 5e-5)
+
+    def run(forced):
+        rng = np.random.default_rng(20 + L)
+        U0 = rng.uniform(-lim, lim, (nu, dim)).astype(np.float32); V0 = rng.uniform(-lim, lim, (ni, dim)).astype(np.float32)
+        ref = T.SimGCL(U0, V0, A, L, lr=0.001, reg=1e-4, cl_rate=0.5, eps=0.1)
+        tr = SimGCLTrainer(U0, V0, adj, L, lr=0.001, reg=1e-4, cl_rate=0.5, eps=0.1, max_unique=B)
+        for step in range(5):
+            sel = rng.integers(0, d["train_u"].size, B)
+            u = d["train_u"][sel].astype(np.int32); i = d["train_i"][sel].astype(np.int32); j = rng.integers(0, ni, B).astype(np.int32)
+            noises = [rng.random((N, dim)).astype(np.float32) for _ in range(2 * L)]
+            if forced:
+                tr.E.upload(pad_cols(ref.E, tr.ld)); tr.m.upload(pad_cols(ref.opt.m, tr.ld)); tr.v.upload(pad_cols(ref.opt.v, tr.ld))
+                assert tr.b1p == ref.opt.b1p and tr.b2p == ref.opt.b2p
+                _, _, _, g_ref = ref.loss_and_grad(u, i, j, noises)
+            lref, rec_ref, cl_ref = ref.train_step(u, i, j, noises)
+            uu = unique_first_appearance(u); vv = (unique_first_appearance(i) + nu).astype(np.int32)
+            tr.train_step_async(DB.from_numpy(u), DB.from_numpy(i), DB.from_numpy(j), B, DB.from_numpy(uu), uu.size,
+                                DB.from_numpy(vv), vv.size, noises=[DB.from_numpy(x) for x in noises])
+            tot, rec, cl = tr.losses()
+            if forced:
+                check("SimGCL rec loss, step from the restatement's state", abs(rec - rec_ref) / abs(rec_ref), 1e-5, ctx=step)
+                check("SimGCL cl loss, step from the restatement's state", abs(cl - cl_ref) / abs(cl_ref), 1e-5, ctx=step)
+                check("SimGCL gradient (before Adam), step from the restatement's state", rel_err(np.concatenate(tr.gradients()), g_ref), 1e-5, ctx=step)
+                # (the table after the step is NOT a parity quantity: the first Adam step is -lr sign(g) exactly, and a coordinate whose gradient
+                # is rounding noise takes the sign the summation order gives it -- recorded)
+                check("SimGCL table after the step, from the restatement's state", rel_err(np.concatenate(tr.ego_embeddings()), ref.E), 1e-3, ctx=step, kind="info")
+        return tr, ref, np.concatenate([U0, V0])
+    tr, ref, E0 = run(forced=True)
     Um, Vm = tr.main_embeddings(); Ur, Vr = ref.final_embeddings()
-    check("rel_err(Um, Ur)", rel_err(Um, Ur), 1e-5)
-    check("rel_err(Vm, Vr)", rel_err(Vm, Vr), 1e-4)
+    check("SimGCL main user embeddings after the forced steps", rel_err(Um, Ur), 1e-3, kind="info")
+    check("SimGCL main item embeddings after the forced steps", rel_err(Vm, Vr), 1e-3, kind="info")
+    tr, ref, E0 = run(forced=False)
+    Eg = np.concatenate(tr.ego_embeddings())
+    check("SimGCL, five free-running steps: table vs restatement (two float32 summation orders under Adam)", rel_err(Eg, ref.E), 1e-3, kind="info")
+    check("SimGCL, five free-running steps: update vs restatement's update", rel_err(Eg - E0, ref.E - E0), 1e-2, kind="info")
 
 
 def test_simgcl_class_runs_stock_conf_shape_and_keeps_best_epoch():
@@ -503,12 +538,12 @@ def test_ngcf_gradients_and_training_steps_match_restatement(dim):
                     check("rel_err(got[:dim, :dim], gW[k][t])", rel_err(got[:dim, :dim], gW[k][t]), 1e-5)
                     assert (got[dim:] == 0).all() and (got[:, dim:] == 0).all()
     Ug, Vg, Wg = tr.parameters()
-    check("rel_err(np.concatenate([Ug, Vg]), ref.E)", rel_err(np.concatenate([Ug, Vg]), ref.E), 2e-5)
+    check("rel_err(np.concatenate([Ug, Vg]), ref.E)", rel_err(np.concatenate([Ug, Vg]), ref.E), TOL)
     for k in range(2):
         for t in range(2):
-            check("rel_err(Wg[k][t], ref.W[k][t])", rel_err(Wg[k][t], ref.W[k][t]), 2e-5)
+            check("rel_err(Wg[k][t], ref.W[k][t])", rel_err(Wg[k][t], ref.W[k][t]), TOL)
     Ui, Vi = tr.inference_embeddings(); Ur, Vr = ref.inference_embeddings()
-    check("rel_err(Ui, Ur)", rel_err(Ui, Ur), 2e-5)
+    check("rel_err(Ui, Ur)", rel_err(Ui, Ur), TOL)
     check("rel_err(Vi, Vr)", rel_err(Vi, Vr), 1e-5)
     assert Ui.shape == (nu, 3 * dim)
 
@@ -583,11 +618,11 @@ def test_sgl_training_steps_match_restatement(per_layer):
         check("abs(rec - rec_ref) / abs(rec_ref)", abs(rec - rec_ref) / abs(rec_ref), 1e-5)
         check("abs(ssl - ssl_ref) / abs(ssl_ref)", abs(ssl - ssl_ref) / abs(ssl_ref), 1e-5)
     Ug, Vg = tr.ego_embeddings(); E0 = np.concatenate([U0, V0])
-    check("rel_err(np.concatenate([Ug, Vg]) - E0, ref.E - E0)", rel_err(np.concatenate([Ug, Vg]) - E0, ref.E - E0), 0.0005)
-    check("rel_err(np.concatenate([Ug, Vg]), ref.E)", rel_err(np.concatenate([Ug, Vg]), ref.E), 5e-5)
+    check("SGL, five steps: update vs restatement's update (relative to the MOVEMENT, not the table)", rel_err(np.concatenate([Ug, Vg]) - E0, ref.E - E0), 0.0005, kind="info")
+    check("rel_err(np.concatenate([Ug, Vg]), ref.E)", rel_err(np.concatenate([Ug, Vg]), ref.E), TOL)
     Um, Vm = tr.main_embeddings(); Ur, Vr = ref.final_embeddings()
-    check("rel_err(Um, Ur)", rel_err(Um, Ur), 2e-5)
-    check("rel_err(Vm, Vr)", rel_err(Vm, Vr), 5e-5)
+    check("rel_err(Um, Ur)", rel_err(Um, Ur), TOL)
+    check("rel_err(Vm, Vr)", rel_err(Vm, Vr), TOL)
 
 
 @pytest.mark.parametrize("aug", [1, 0, 2])
@@ -689,7 +724,8 @@ def test_lightgcn_and_simgcl_steps_at_yelp_shape_match_restatement(yelp_graph):
     step_ref, step_gpu = ref.E - E0, Eg - E0
     solid = np.abs(ref.opt.m) > 1e-3 * np.abs(ref.opt.m).max()        # first Adam step = -lr*sign(g): compare where g is not noise
     assert solid.mean() > 0.2 and np.array_equal(np.sign(step_gpu[solid]), np.sign(step_ref[solid]))
-    check_rel("Adam step on solid coordinates", step_gpu[solid], step_ref[solid], 2e-5)
+    check("LightGCN first Adam step where the gradient is not rounding noise (|m| > 1e-3 max), norm-wise", rel_err(step_gpu[solid], step_ref[solid]), TOL)
+    check_rel("... element by element", step_gpu[solid], step_ref[solid], 1e-4, kind="info")
     # SimGCL
     lim = np.sqrt(6.0 / (nu + dim))
     U1 = rng.uniform(-lim, lim, (nu, dim)).astype(np.float32); V1 = rng.uniform(-lim, lim, (ni, dim)).astype(np.float32)
@@ -741,11 +777,12 @@ def test_ngcf_step_at_yelp_shape_matches_restatement(yelp_graph):
     step_ref, step_gpu = ref.E - E0, np.concatenate([Ug, Vg]) - E0
     solid = np.abs(gE) > 1e-3 * np.abs(gE).max()
     assert solid.mean() > 0.01 and np.array_equal(np.sign(step_gpu[solid]), np.sign(step_ref[solid]))
-    check_rel("NGCF first Adam step on solid coordinates (tables)", step_gpu[solid], step_ref[solid], 2e-5)
+    check("NGCF first Adam step where the gradient is not rounding noise (tables), norm-wise", rel_err(step_gpu[solid], step_ref[solid]), TOL)
+    check_rel("... element by element", step_gpu[solid], step_ref[solid], 1e-4, kind="info")
     for k in range(2):
         for t in range(2):
             sw = np.abs(gW[k][t]) > 1e-3 * np.abs(gW[k][t]).max()
-            check_rel(f"NGCF first Adam step on solid coordinates (W{t + 1} of layer {k})", (Wg[k][t] - W[k][t])[sw], (ref.W[k][t] - W[k][t])[sw], 2e-5)
+            check(f"NGCF first Adam step where the gradient is not rounding noise (W{t + 1} of layer {k}), norm-wise", rel_err((Wg[k][t] - W[k][t])[sw], (ref.W[k][t] - W[k][t])[sw]), TOL)
 
 
 @pytest.mark.parametrize("seg_len", [128, 7])
@@ -812,7 +849,7 @@ def test_buir_training_steps_match_restatement(L, dim):
     E0 = np.concatenate([U0, V0])
     Eg, Tg = tr.online_tables(), tr.target_tables()
     Wg, bg = tr.weights()
-    check("rel_err(Eg - E0, ref.E - E0)", rel_err(Eg - E0, ref.E - E0), 5e-5)       # Adam: see the SimGCL test's note
+    check("BUIR, six steps: update vs restatement's update (relative to the MOVEMENT, not the table)", rel_err(Eg - E0, ref.E - E0), 5e-5, kind="info")
     check("rel_err(Eg, ref.E)", rel_err(Eg, ref.E), 1e-5)
     check("rel_err(Tg, ref.T)", rel_err(Tg, ref.T), 1e-5)
     check("rel_err(Wg, ref.W)", rel_err(Wg, ref.W), 1e-5)
@@ -1143,7 +1180,7 @@ def test_mhcn_gate_attention_and_mim_kernels_match_restatement(dim, ld):
     des, da, dM = abwd(dOut)
     d_e = [DB.from_numpy(pad_cols(e, ld)) for e in es]
     d_a, d_M = DB.from_numpy(pad_cols(w["attention"], ld)[0]), DB.from_numpy(pad2(w["attention_mat"]))
-    d_v, d_dv, d_sc, d_out = DB.zeros(256, np.float32), DB.zeros(256, np.float32), DB.zeros((nu, 4), np.float32), DB.zeros((nu, ld), np.float32)
+    d_v, d_dv, d_sc, d_out = DB.zeros(256, np.float32), DB.zeros(capi.channel_attention_scratch_floats(), np.float32), DB.zeros((nu, 4), np.float32), DB.zeros((nu, ld), np.float32)
     capi.channel_attention_fwd(d_e, d_a, d_M, DB.from_numpy(pad_cols(half, ld)), nu, ld, d_v, d_sc, d_out)
     check("rel_err(d_out.numpy()[:, :dim], out + half / 2)", rel_err(d_out.numpy()[:, :dim], out + half / 2), 5e-6)
     check("rel_err(d_sc.numpy()[:, :3], score)", rel_err(d_sc.numpy()[:, :3], score), 5e-6)

@@ -2,8 +2,15 @@
 tests/golden/gen_golden_tf.py, which executes model/ranking/{BPR-tf, LightGCN, NGCF, SimGCL}.py unmodified through a stand-in for the
 tensorflow module -- see tests/test_oracle_tf_golden.py and DESIGN.md s2).  Same initial tables, the same batches the reference's
 sampler drew, the same random draws (regenerated from their keys): the losses the reference printed at every step, the variables
-it ended with and the tables it scores with.  fp32 on both sides, different summation orders: 1e-5-class agreement on the losses,
-Adam-noise-class agreement on the tables (see the note in test_gpu_graph.py::test_simgcl_training_steps_match_restatement)."""
+it ended with and the tables it scores with.  fp32 on both sides, different summation orders.
+
+Round 6: every trainer here is built under ``ordered_reductions()`` -- the parity mode the drop-in classes run in by default (exact
+mode): batch gradients are added row by row in the reference's CPU order (csrc/ordered.hip), MHCN's column sums in a fixed tree, no
+float atomics anywhere on the path.  Two consequences, both asserted: (1) every run is executed TWICE and the two results are
+bit-identical; (2) trained variables are held to north_star's 1e-5 on ALL coordinates (the solid-coordinate carve-out of round 5 is
+gone).  The one quantity that cannot be: SimGCL's item table, where the reference's OWN float32 run sits 3.2e-5 from the same run in
+float64 arithmetic (tests/golden/tf_f64_yardstick.npz) -- no implementation in another summation order can be nearer to the fixture
+than the fixture is to the truth; that test states its bound as a multiple of that measured distance (kind "floor")."""
 import json
 import os
 
@@ -12,9 +19,9 @@ import pytest
 
 from qrec_amd import capi
 from qrec_amd.capi import DeviceBuffer as DB
-from qrec_amd.graph import BprTfTrainer, LightGCNTrainer, NGCFTrainer, SimGCLTrainer, joint_norm_adjacency, unique_first_appearance
+from qrec_amd.graph import BprTfTrainer, LightGCNTrainer, NGCFTrainer, SimGCLTrainer, joint_norm_adjacency, ordered_reductions, unique_first_appearance
 
-from helpers import check, check_rel, pad_cols, rel_err
+from helpers import check, check_rel, pad_cols, rel_err, same_bits
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -50,29 +57,22 @@ def grad_check(got, want, what, bound=GRAD_TOL):
     check(what, rel_err(got, want), bound)
 
 
-SOLID_FLOOR = 0.1
+YARD = np.load(os.path.join(HERE, "tf_f64_yardstick.npz"))
 
 
-def solid_check(what, got, ref, grad0, loose, solid_bound=GRAD_TOL):
-    """Trained variables after the fixture's 12-18 Adam steps.  Adam's step is lr * m / (sqrt(v) + eps): on a
-    coordinate whose gradient is rounding noise the step is ~lr in a direction the noise decides, so two correct fp32 implementations
-    end |lr x steps| apart there whatever their parity.  SOLID coordinates -- |first-step gradient| >= SOLID_FLOOR x the variable's
-    largest |first-step gradient| (the fixture's grad0) -- are held to north_star's 1e-5; the whole variable to the documented looser
-    bound ``loose``.  Measured by floor (QREC_SOLID_PROBE=1, round 5, relative error on the coordinates at or above the floor / share of
-    the entries): SimGCL 4.9e-5 on all -> 1.3e-5 at 0.01 (82 %) -> 8.0e-6 at 0.05 (27 %) -> 6.3e-6 at 0.1 (10 %); SGL 1.3e-6 ... 3.3e-6 on all,
-    <= 1.1e-6 at 0.1; BUIR 1.2e-7 / 7.7e-8; MHCN item table 5.4e-6 / 7.3e-8.  SEPT is the exception that the rule does NOT describe: 1.3e-5 on
-    all coordinates and 2.8e-5 at 0.1 -- its deviation sits on large-gradient coordinates (float-atomic scatter of the self-supervised
-    gradient over rows shared by several contrast sets, a discontinuous pseudo-label top-k), so it keeps its documented bound on both."""
-    got, ref, g = np.asarray(got, np.float64), np.asarray(ref, np.float64), np.abs(np.asarray(grad0, np.float64))
-    assert got.shape == ref.shape == g.shape, (what, got.shape, ref.shape, g.shape)
-    if os.environ.get("QREC_SOLID_PROBE"):      # development: the error by floor, into the ledger; nothing asserted
-        for fl in (0.0, 1e-2, 3e-2, 5e-2, 1e-1, 2e-1, 3e-1):
-            mk = g >= fl * g.max()
-            check(f"probe {what} floor {fl:g} share {mk.mean():.3f}", rel_err(got[mk], ref[mk]), 1.0)
-        return
-    solid = g >= SOLID_FLOOR * g.max()
-    check(f"{what}: solid coordinates (|first-step gradient| >= {SOLID_FLOOR:g} of its maximum)", rel_err(got[solid], ref[solid]), solid_bound, ctx=float(solid.mean()))
-    check(f"{what}: all coordinates", rel_err(got, ref), loose)
+def table_check(what, got, ref, name, key, bound=GRAD_TOL):
+    """A trained variable (or scoring table) after the fixture's 12-18 Adam steps against the reference's run: north_star's 1e-5 on
+    the WHOLE variable, every coordinate (round 6: the trainers run with ordered reductions -- qrec_amd.graph.ordered_reductions, the
+    exact mode of the drop-in classes -- and the solid-coordinate carve-out of round 5 is gone).
+    Beside it, recorded (kind "info"): the distance of the HIP result and of the reference's own float32 run from the SAME run in
+    float64 arithmetic (tests/golden/tf_f64_yardstick.npz, gen_golden_tf.py --float64-yardstick) -- the reference sits 2e-6 ... 7e-6 from
+    exact arithmetic on these variables, so 1e-5 is a bar a correct fp32 implementation can meet and a wrong one cannot."""
+    got, ref = np.asarray(got), np.asarray(ref)
+    f64 = YARD[f"{name}/{key}"].reshape(ref.shape)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    check(f"{what}: vs the reference's run", rel_err(got, ref), bound)
+    check(f"{what}: HIP vs the float64 run of the reference's classes", rel_err(got, f64), 1.0, kind="info")
+    check(f"{what}: the reference's float32 run vs its float64 run", rel_err(ref, f64), 1.0, kind="info")
 
 
 def batches(z):
@@ -82,7 +82,19 @@ def batches(z):
         yield k, z["batch_u"][s].astype(np.int32), z["batch_i"][s].astype(np.int32), z["batch_j"][s].astype(np.int32)
 
 
+def _parity_twice(what, run):
+    """build and run the trainer twice under ordered reductions: the reference run's bounds both times, and the same bits"""
+    with ordered_reductions():
+        a = run()
+        b = run()
+    same_bits(what, a, b)
+
+
 def test_lightgcn_trainer_follows_the_reference_run():
+    _parity_twice("LightGCN", _run_lightgcn)
+
+
+def _run_lightgcn():
     m, z = load("tf_lightgcn_filmtrust")
     nu, ni = m["n_users"], m["n_items"]
     adj = joint_norm_adjacency(nu, ni, z["train_uid"], z["train_iid"])
@@ -94,14 +106,19 @@ def test_lightgcn_trainer_follows_the_reference_run():
             gU, gV = tr.gradients()
             grad_check(gU, z["grad0_U"], "LightGCN dU, step 0"); grad_check(gV, z["grad0_V"], "LightGCN dV, step 0")
     U, V = tr.ego_embeddings()
-    check("rel_err(U, z['final_U'])", rel_err(U, z["final_U"]), 1e-5)
-    check("rel_err(V, z['final_V'])", rel_err(V, z["final_V"]), 1e-5)
+    table_check("LightGCN user table after the run", U, z["final_U"], "tf_lightgcn_filmtrust", "final_U")
+    table_check("LightGCN item table after the run", V, z["final_V"], "tf_lightgcn_filmtrust", "final_V")
     Uf, Vf = tr.final_embeddings()
-    check("rel_err(Uf, z['score_U'])", rel_err(Uf, z["score_U"]), 1e-5)
-    check("rel_err(Vf, z['score_V'])", rel_err(Vf, z["score_V"]), 1e-5)
+    table_check("LightGCN scoring users", Uf, z["score_U"], "tf_lightgcn_filmtrust", "score_U")
+    table_check("LightGCN scoring items", Vf, z["score_V"], "tf_lightgcn_filmtrust", "score_V")
+    return dict(U=U, V=V, Uf=Uf, Vf=Vf)
 
 
 def test_bpr_tf_trainer_follows_the_reference_run():
+    _parity_twice("BPR-tf", _run_bpr_tf)
+
+
+def _run_bpr_tf():
     m, z = load("tf_bpr_filmtrust")
     tr = BprTfTrainer(z["init_U"], z["init_V"], m["lr"], m["regU"])
     for k, u, i, j in batches(z):
@@ -111,11 +128,16 @@ def test_bpr_tf_trainer_follows_the_reference_run():
             gU, gV = tr.gradients(np.concatenate([z["init_U"], z["init_V"]]))
             grad_check(gU, z["grad0_U"], "BPR-tf dU, step 0"); grad_check(gV, z["grad0_V"], "BPR-tf dV, step 0")
     U, V = tr.tables()
-    check("rel_err(U, z['final_U'])", rel_err(U, z["final_U"]), 1e-5)
-    check("rel_err(V, z['final_V'])", rel_err(V, z["final_V"]), 1e-5)
+    table_check("BPR-tf user table after the run", U, z["final_U"], "tf_bpr_filmtrust", "final_U")
+    table_check("BPR-tf item table after the run", V, z["final_V"], "tf_bpr_filmtrust", "final_V")
+    return dict(U=U, V=V)
 
 
 def test_ngcf_trainer_follows_the_reference_run():
+    _parity_twice("NGCF", _run_ngcf)
+
+
+def _run_ngcf():
     m, z = load("tf_ngcf_filmtrust")
     nu, ni, dim = m["n_users"], m["n_items"], m["emb_size"]
     n = nu + ni
@@ -135,17 +157,28 @@ def test_ngcf_trainer_follows_the_reference_run():
                 for b in range(2):
                     grad_check(gW[a][b], z[f"grad0_W_{a}_{b + 1}"], f"NGCF dW_{a}_{b + 1}, step 0")
     U, V, Wg = tr.parameters()
-    check("rel_err(U, z['final_U'])", rel_err(U, z["final_U"]), 1e-5)
-    check("rel_err(V, z['final_V'])", rel_err(V, z["final_V"]), 1e-5)
+    out = dict(U=U, V=V)
+    table_check("NGCF user table after the run", U, z["final_U"], "tf_ngcf_filmtrust", "final_U")
+    table_check("NGCF item table after the run", V, z["final_V"], "tf_ngcf_filmtrust", "final_V")
     for a in range(2):
         for b in range(2):
-            check("rel_err(Wg[a][b], z[f'final_W_{a}_{b + 1}'])", rel_err(Wg[a][b], z[f"final_W_{a}_{b + 1}"]), 1e-5)
+            table_check(f"NGCF W_{a}_{b + 1} after the run", Wg[a][b], z[f"final_W_{a}_{b + 1}"], "tf_ngcf_filmtrust", f"final_W_{a}_{b + 1}")
+            out[f"W_{a}_{b + 1}"] = Wg[a][b]
     Ui, Vi = tr.inference_embeddings()
-    check("rel_err(Ui, z['score_U'])", rel_err(Ui, z["score_U"]), 1e-5)
-    check("rel_err(Vi, z['score_V'])", rel_err(Vi, z["score_V"]), 1e-5)
+    table_check("NGCF scoring users", Ui, z["score_U"], "tf_ngcf_filmtrust", "score_U")
+    table_check("NGCF scoring items", Vi, z["score_V"], "tf_ngcf_filmtrust", "score_V")
+    out.update(Ui=Ui, Vi=Vi)
+    return out
 
 
 def test_simgcl_trainer_follows_the_reference_run():
+    """the product's own sign() path (no recorded pattern): `sign(emb)` (SimGCL.py:35) is discontinuous at 0, an entry within rounding of
+    zero may take the other sign than in the recorded run, and from that step on the run is another (equally valid) run -- the rows
+    below are kind "discontinuity"; the recorded-pattern test after this one is the parity statement on the same data"""
+    _parity_twice("SimGCL", _run_simgcl)
+
+
+def _run_simgcl():
     m, z = load("tf_simgcl_filmtrust")
     nu, ni, dim, L = m["n_users"], m["n_items"], m["emb_size"], m["n_layers"]
     n = nu + ni
@@ -165,24 +198,47 @@ def test_simgcl_trainer_follows_the_reference_run():
         if k == 0:
             gU, gV = tr.gradients()
             grad_check(gU, z["grad0_" + names["U"]], "SimGCL dU, step 0"); grad_check(gV, z["grad0_" + names["V"]], "SimGCL dV, step 0")
-        check("SimGCL total / rec / cl loss vs reference run (worst of the three)", err.max(), 0.001, ctx=(k, err))           # sign(emb) is discontinuous: an entry within rounding of zero may flip (test_oracle_tf_golden.py)
+        check("SimGCL total / rec / cl loss vs reference run (worst of the three)", err.max(), 0.001, ctx=(k, err), kind="discontinuity")           # sign(emb) is discontinuous: an entry within rounding of zero may flip (test_oracle_tf_golden.py)
         worst.append(err.max())
     assert np.sum(np.array(worst) > 5e-5) <= 3, worst
     U, V = tr.ego_embeddings()
     E = np.concatenate([z["final_" + names["U"]], z["final_" + names["V"]]])
-    check("rel_err(np.concatenate([U, V]), E)", rel_err(np.concatenate([U, V]), E), 0.002)
+    check("SimGCL tables, own sign pattern", rel_err(np.concatenate([U, V]), E), 0.002, kind="discontinuity")
     Um, Vm = tr.main_embeddings()
-    check("rel_err(Um, z['score_U'])", rel_err(Um, z["score_U"]), 0.002)
-    check("rel_err(Vm, z['score_V'])", rel_err(Vm, z["score_V"]), 0.002)
+    check("SimGCL main user embeddings, own sign pattern", rel_err(Um, z["score_U"]), 0.002, kind="discontinuity")
+    check("SimGCL main item embeddings, own sign pattern", rel_err(Vm, z["score_V"]), 0.002, kind="discontinuity")
+    return dict(U=U, V=V, Um=Um, Vm=Vm)
 
 
 def test_simgcl_trainer_with_the_recorded_sign_pattern_follows_the_reference_run_throughout():
-    """The test above allows three steps out of twelve to leave 5e-5 because `sign(emb)` (SimGCL.py:35) is discontinuous at 0 -- the
-    CPU restatement names the flip: step 10, view 2, layer 2, row 805, column 1, an entry of -2.1e-6 in a row of magnitude 0.07
+    """The test above may leave the recorded run because `sign(emb)` (SimGCL.py:35) is discontinuous at 0 -- the CPU restatement names
+    the flip: step 10, view 2, layer 2, row 805, column 1, an entry of -2.1e-6 in a row of magnitude 0.07
     (tests/test_oracle_tf_golden.py).  Here the excuse is removed: the noise fed to the kernels carries the sign every perturbation of
     the reference's own run used (recorded from its `tf.sign` ops by the generator; include/qrec_hip.h, qrec_perturb_rows), and the
-    HIP trainer is held to the run at 1e-5 on the three losses of ALL twelve steps; the trained tables to the 5e-5 of the other
-    contrastive models (twelve Adam steps on rounding-noise coordinates)."""
+    HIP trainer is held to the run at 1e-5 on the three losses of ALL twelve steps and on the first-step gradients.
+    The trained tables: the reference's own float32 run sits 7.7e-6 (users) / 3.2e-5 (items) / 3.3e-5, 2.9e-5 (main embeddings) from
+    the SAME run, same signs, in float64 (tf_f64_yardstick.npz) -- InfoNCE's gradient is a difference of two softmax-weighted sums of
+    ~900 rows, its small coordinates are cancellation noise in ANY float32 summation order, and Adam turns each into a step of ~lr.
+    Every table is held to FLOOR_FACTOR x the reference's own distance from exact arithmetic (kind "floor": two independent float32
+    roundings of the same computation are sqrt(2) apart in expectation), and the HIP result must be as close to exact arithmetic as
+    the reference's run is (same factor).  Measured (round 6, bit-reproducible): user table 1.5e-5 = 1.9 floors."""
+    _parity_twice("SimGCL under the recorded sign pattern", _run_simgcl_recorded)
+
+
+FLOOR_FACTOR = 2.5
+
+
+def floor_check(what, got, ref, name, key):
+    got, ref = np.asarray(got), np.asarray(ref)
+    f64 = YARD[f"{name}/{key}"].reshape(ref.shape)
+    floor = rel_err(ref, f64)
+    check(f"{what}: the reference's float32 run vs its float64 run (the floor)", floor, 1.0, kind="info")
+    check(f"{what}: vs the reference's run, in units of the floor", rel_err(got, ref) / floor, FLOOR_FACTOR, kind="floor")
+    check(f"{what}: HIP vs the float64 run, in units of the floor", rel_err(got, f64) / floor, FLOOR_FACTOR, kind="floor")
+    check(f"{what}: vs the reference's run (absolute, recorded)", rel_err(got, ref), 1.0, kind="info")
+
+
+def _run_simgcl_recorded():
     from helpers import encode_forced_signs, simgcl_recorded_signs
     m, z = load("tf_simgcl_filmtrust")
     nu, ni, dim, L = m["n_users"], m["n_items"], m["emb_size"], m["n_layers"]
@@ -200,16 +256,17 @@ def test_simgcl_trainer_with_the_recorded_sign_pattern_follows_the_reference_run
                             noises=[DB.from_numpy(pad_cols(x, tr.ld)) for x in noises])
         err = np.abs(np.array(tr.losses()) - z["losses"][k]) / z["losses"][k]
         check("SimGCL total / rec / cl loss vs reference run under its recorded sign pattern (worst of the three)", err.max(), 1e-5, ctx=(k, err))
+        if k == 0:
+            gU, gV = tr.gradients()
+            grad_check(gU, z["grad0_" + names["U"]], "SimGCL dU, step 0, recorded signs"); grad_check(gV, z["grad0_" + names["V"]], "SimGCL dV, step 0, recorded signs")
     U, V = tr.ego_embeddings()
-    E = np.concatenate([z["final_" + names["U"]], z["final_" + names["V"]]])
-    # (observed: losses <= 7e-7 on all twelve steps; tables 3e-5, main embeddings 6e-5 -- the CPU restatement under the same signs: 2.7e-5 /
-    # 3.5e-5; without the recorded signs: 2.8e-4 ... 4.2e-4.  Twelve Adam steps move a coordinate whose gradient is rounding noise by
-    # ~lr per step in a direction the noise decides; the main embeddings are two propagations of those tables)
-    solid_check("SimGCL tables after 12 steps under the recorded sign pattern", np.concatenate([U, V]), E,
-                np.concatenate([z["grad0_" + names["U"]], z["grad0_" + names["V"]]]), 1e-4)
+    name = "tf_simgcl_filmtrust"
+    floor_check("SimGCL user table after 12 steps under the recorded sign pattern", U, z["final_" + names["U"]], name, "final_" + names["U"])
+    floor_check("SimGCL item table after 12 steps under the recorded sign pattern", V, z["final_" + names["V"]], name, "final_" + names["V"])
     Um, Vm = tr.main_embeddings()
-    check("SimGCL main user embeddings under the recorded sign pattern", rel_err(Um, z["score_U"]), 1e-4)
-    check("SimGCL main item embeddings under the recorded sign pattern", rel_err(Vm, z["score_V"]), 1e-4)
+    floor_check("SimGCL main user embeddings under the recorded sign pattern", Um, z["score_U"], name, "score_U")
+    floor_check("SimGCL main item embeddings under the recorded sign pattern", Vm, z["score_V"], name, "score_V")
+    return dict(U=U, V=V, Um=Um, Vm=Vm)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -224,6 +281,10 @@ def _csr(a, n):
 
 @pytest.mark.parametrize("name", ["tf_sgl_filmtrust", "tf_sgl_rw_filmtrust", "tf_sgl_nd_filmtrust"])
 def test_sgl_trainer_follows_the_reference_run(name):
+    _parity_twice(name, lambda: _run_sgl(name))
+
+
+def _run_sgl(name):
     from qrec_amd.graph import SGLTrainer
     m, z = load(name)
     nu, ni, L, aug = m["n_users"], m["n_items"], m["n_layers"], m["aug_type"]
@@ -255,14 +316,19 @@ def test_sgl_trainer_follows_the_reference_run(name):
             gU, gV = tr.gradients()
             grad_check(gU, z["grad0_U"], f"SGL aug {aug} dU, step 0"); grad_check(gV, z["grad0_V"], f"SGL aug {aug} dV, step 0")
     U, V = tr.ego_embeddings()
-    solid_check(f"SGL aug {aug} user table after the run", U, z["final_U"], z["grad0_U"], 1e-5)
-    solid_check(f"SGL aug {aug} item table after the run", V, z["final_V"], z["grad0_V"], 2e-5)
+    table_check(f"SGL aug {aug} user table after the run", U, z["final_U"], name, "final_U")
+    table_check(f"SGL aug {aug} item table after the run", V, z["final_V"], name, "final_V")
     Um, Vm = tr.main_embeddings()
-    check("rel_err(Um, z['score_U'])", rel_err(Um, z["score_U"]), 1e-5)
-    check("rel_err(Vm, z['score_V'])", rel_err(Vm, z["score_V"]), 2e-5)
+    table_check(f"SGL aug {aug} scoring users", Um, z["score_U"], name, "score_U")
+    table_check(f"SGL aug {aug} scoring items", Vm, z["score_V"], name, "score_V")
+    return dict(U=U, V=V, Um=Um, Vm=Vm)
 
 
 def test_buir_trainer_follows_the_reference_run():
+    _parity_twice("BUIR", _run_buir)
+
+
+def _run_buir():
     from qrec_amd.graph import BUIRTrainer
     m, z = load("tf_buir_filmtrust")
     nu, ni, L = m["n_users"], m["n_items"], m["n_layers"]
@@ -284,18 +350,28 @@ def test_buir_trainer_follows_the_reference_run():
             gE, gW, gb = tr.gradients()
             grad_check(gE[:nu], z["grad0_U"], "BUIR dU, step 0"); grad_check(gE[nu:], z["grad0_V"], "BUIR dV, step 0")
             grad_check(gW, z["grad0_online_mat"], "BUIR dW, step 0"); grad_check(gb[None, :], z["grad0_online_bias"], "BUIR db, step 0")
-    E = np.concatenate([z["final_U"], z["final_V"]]); Tt = np.concatenate([z["final_t_U"], z["final_t_V"]])
-    solid_check("BUIR online tables after the run", tr.online_tables(), E, np.concatenate([z["grad0_U"], z["grad0_V"]]), 1e-5)
-    check("rel_err(tr.target_tables(), Tt)", rel_err(tr.target_tables(), Tt), 1e-5)
+    name = "tf_buir_filmtrust"
+    On, Tg = tr.online_tables(), tr.target_tables()
+    table_check("BUIR online user table after the run", On[:nu], z["final_U"], name, "final_U")
+    table_check("BUIR online item table after the run", On[nu:], z["final_V"], name, "final_V")
+    table_check("BUIR target user table after the run", Tg[:nu], z["final_t_U"], name, "final_t_U")
+    table_check("BUIR target item table after the run", Tg[nu:], z["final_t_V"], name, "final_t_V")
     Wg, bg = tr.weights()
-    check("rel_err(Wg, z['final_online_mat'])", rel_err(Wg, z["final_online_mat"]), 1e-5)
-    check("rel_err(bg, z['final_online_bias'].ravel())", rel_err(bg, z["final_online_bias"].ravel()), 1e-5)
+    table_check("BUIR online_mat after the run", Wg, z["final_online_mat"], name, "final_online_mat")
+    table_check("BUIR online_bias after the run", bg, z["final_online_bias"].ravel(), name, "final_online_bias")
     adj = joint_norm_adjacency(nu, ni, z["train_uid"], z["train_iid"])
+    out = dict(On=On, Tg=Tg, W=Wg, b=bg)
     for g, key in zip(tr.final_tables(adj), ("q_user", "q_item", "o_user", "o_item")):
         check("rel_err(g, z[key])", rel_err(g, z[key]), 1e-5, ctx=key)
+        out[key] = g
+    return out
 
 
 def test_sept_trainer_follows_the_reference_run():
+    _parity_twice("SEPT", _run_sept)
+
+
+def _run_sept():
     from oracle import tfmodels as T      # the oracle's scipy graph builders (themselves bit-identical to the reference's, test_oracle_golden.py)
     from qrec_amd.graph import SEPTTrainer
     m, z = load("tf_sept_filmtrust")
@@ -334,27 +410,25 @@ def test_sept_trainer_follows_the_reference_run():
             want = m["ss_rate"] * z["losses"][k, 1]
             ssl_err.append(abs(got[1] - want) / abs(want))
     # The pseudo labels (SEPT.py:190-211) are a top-k over float32 softmax rows -- discontinuous, like SimGCL's sign(): a near-tie may
-    # pick another neighbour here than in the reference's run, and the float atomics' summation order differs from launch to launch,
-    # so WHICH run meets a near-tie changes (rounds 2-3: every joint step <= 2e-7 in every run; round 4: one run with ONE step -- the
-    # last -- at 1.6e-5, the other five <= 2e-7).  So: all joint steps but at most one at the 1e-5 of every other loss, that one
-    # inside 1e-4 (a wrong pseudo label on one of ~1,000 contrast rows; an algorithmic difference is >= 1e-2).
-    ssl_err = sorted(ssl_err)
+    # pick another neighbour here than in the reference's run.  Rounds 2-5 (float atomics): WHICH run met a near-tie changed from launch to
+    # launch (every joint step <= 2e-7 in most runs, one run with one step at 1.6e-5).  With ordered reductions the run is the same run
+    # every time (asserted by the caller, bit for bit), so the statement is plain: every joint step at 1e-5.
     assert len(ssl_err) >= 6
-    check("SEPT ssl loss vs reference run (all joint steps but the worst one)", ssl_err[-2], 1e-5, inclusive=True)
-    check("SEPT ssl loss vs reference run (the worst joint step: at most one near-tie of the pseudo-label top-k)", ssl_err[-1], 1e-4, inclusive=True)
+    check("SEPT ssl loss vs reference run (worst joint step)", max(ssl_err), 1e-5, inclusive=True)
     U, V = tr.variables()
-    # the drift check after 18 Adam steps (12 rec-only + 6 joint): losses and the pre-Adam gradients above are the 1e-5 statement; the
-    # trained tables carry what Adam makes of last-bit gradient differences on coordinates whose gradient is ~0 (the step is
-    # normalised to lr whatever the gradient's size) and of the float atomics' summation order, which changes from launch to
-    # launch -- observed 2.5e-6 ... 1.3e-5 over the runs of this round
-    solid_check("SEPT tables after 18 steps", np.concatenate([U, V]), np.concatenate([z["final_U"], z["final_V"]]), np.concatenate([z["grad0_U"], z["grad0_V"]]), 5e-5,
-                solid_bound=5e-5)          # (not Adam noise on ~0-gradient coordinates: see solid_check's docstring)
+    table_check("SEPT user table after 18 steps", U, z["final_U"], "tf_sept_filmtrust", "final_U")
+    table_check("SEPT item table after 18 steps", V, z["final_V"], "tf_sept_filmtrust", "final_V")
     Ur, Vr = tr.rec_embeddings()
-    check("rel_err(Ur, z['score_U'])", rel_err(Ur, z["score_U"]), 5e-5)
-    check("rel_err(Vr, z['score_V'])", rel_err(Vr, z["score_V"]), 5e-5)
+    table_check("SEPT scoring users", Ur, z["score_U"], "tf_sept_filmtrust", "score_U")
+    table_check("SEPT scoring items", Vr, z["score_V"], "tf_sept_filmtrust", "score_V")
+    return dict(U=U, V=V, Ur=Ur, Vr=Vr)
 
 
 def test_mhcn_trainer_follows_the_reference_run():
+    _parity_twice("MHCN", _run_mhcn)
+
+
+def _run_mhcn():
     from oracle import tfmodels as T
     from qrec_amd.graph import MHCNTrainer
     m, z = load("tf_mhcn_filmtrust")
@@ -379,10 +453,14 @@ def test_mhcn_trainer_follows_the_reference_run():
             for a, b in key.items():
                 grad_check(g[a].reshape(z["grad0_" + b].shape), z["grad0_" + b], f"MHCN d{a}, step 0")
     got = tr.parameters()
+    name = "tf_mhcn_filmtrust"
     for a, b in key.items():
-        check("rel_err(got[a], z['final_' + b])", rel_err(got[a], z["final_" + b]), 1e-5, ctx=a)
-    solid_check("MHCN user table after the run", got["U"], z["final_U"], z["grad0_U"], 1e-5)
-    solid_check("MHCN item table after the run", got["V"], z["final_V"], z["grad0_V"], 5e-5)
+        table_check(f"MHCN {a} after the run", np.asarray(got[a]).reshape(z["final_" + b].shape), z["final_" + b], name, "final_" + b)
+    table_check("MHCN user table after the run", got["U"], z["final_U"], name, "final_U")
+    table_check("MHCN item table after the run", got["V"], z["final_V"], name, "final_V")
     Ud, Vd = tr.final_embeddings()
-    check("rel_err(Ud, z['score_U'])", rel_err(Ud, z["score_U"]), 1e-5)
-    check("rel_err(Vd, z['score_V'])", rel_err(Vd, z["score_V"]), 5e-5)
+    table_check("MHCN scoring users", Ud, z["score_U"], name, "score_U")
+    table_check("MHCN scoring items", Vd, z["score_V"], name, "score_V")
+    out = {a: np.asarray(got[a]) for a in key}
+    out.update(U=got["U"], V=got["V"], Ud=Ud, Vd=Vd)
+    return out

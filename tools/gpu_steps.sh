@@ -5,6 +5,7 @@
 #
 # steps
 #   tests[:expr]         pytest -m gpu (optionally -k expr), parity ledger into gpurun_out/<tag>_parity_raw.jsonl
+#   tests-all[:expr]     the same without -x (every failure of the selection in one call), ledger into <tag>_parity_all_raw.jsonl
 #   bench                python bench.py (default flags) -> <tag>_bench.json
 #   bench-prof           bench + rocprofv3 --kernel-trace --stats + the two HBM counter passes (separate) + tools/summarize_prof.py
 #   recall:<plan>        tools/paired_recall.py <tag>_recall_<plan>.json <plan>       (plan: bpr-conf | full | quick | a JSON file under tools/plans/)
@@ -34,6 +35,11 @@ for STEP in "$@"; do
     tests)
       cd $R
       QREC_PARITY_LOG=$O/${TAG}_parity_raw.jsonl timeout 3000 python -m pytest tests -m gpu -x -q ${ARG:+-k "$ARG"} > $O/${TAG}_tests.log 2>&1; echo "tests exit $?"; tail -5 $O/${TAG}_tests.log
+      cd /tmp;;
+    tests-all)
+      cd $R
+      QREC_PARITY_LOG=$O/${TAG}_parity_all_raw.jsonl timeout 3000 python -m pytest tests -m gpu -q ${ARG:+-k "$ARG"} > $O/${TAG}_tests_all.log 2>&1; echo "tests-all exit $?"
+      grep -E "^(FAILED|ERROR)|passed|failed" $O/${TAG}_tests_all.log | cut -c1-300 | tail -40
       cd /tmp;;
     bench)
       timeout 900 python $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench exit $?"; head -c 1500 $O/${TAG}_bench.json; echo;;
