@@ -44,8 +44,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                   negatives, on the bench's own graph and on the planted-community graph of the same shape (datasets[]: recall, abs_diff,
                   rel_diff at the reference's peak epoch and at the last one); N > 1: the same over the real communicator;
   other_configs -- BASELINE configs #2, #3, #5 and the evaluation, measured by this very run (HIP events, >= 20 repetitions);
-  deferred_negatives -- the opt-in schedule `--schedule item-deferred` (one atomic row update per triplet) timed like the
-                  main line, with its own Recall check (DESIGN.md s5.1 / s7 say why it is not the default);
+  roofline_hbm_resident.p_update -- how the item-major kernel writes P[u] there ("rmw": sc1 load + store instead of an atomic delta, chosen by
+                  engine.resolve_p_update from the collision density; `roofline_hbm_resident_atomic` = the same slice with atomic deltas);
   multi_gpu    -- N > 1: what RCCL reports per rank, kernel time per rank, collectives and bytes per epoch.
 Sharded layout options: --shard-batch, --shard-pipeline, --no-plan-inside.  N > 1 also carries other_configs.config4_sharded:
 each rank's share of BASELINE config #4 in north_star's layout (row-sharded item table, per-batch all-to-all) and that layout's paired Recall@20.
@@ -196,51 +196,6 @@ def recall_legs(mode, shape):
             "datasets": legs, "harness": "tools/paired_recall.py (same negatives, same tables, same bold driver; reference = order-exact fp64)"}
 
 
-def deferred_variant(capi, data, u, items, indptr, n_items, P0, Q0, chunk, flush_every, seed, main, runs=3, epochs=100):
-    """The same workload under the opt-in schedule "item-deferred" (qrec_bpr_sgd_hogwild_item_major_deferred: one atomic row update
-    per triplet instead of two, the negative-side terms applied by a second, j-ordered pass -- DESIGN.md s4), timed like the main
-    line: `runs` fresh `epochs`-epoch trainings, sampler + j sort on the side stream, epoch close on the device, no host sync
-    inside.  Reported NEXT to `value`, not as it: the deferral is a change of algorithm beyond Hogwild's (tests/test_gpu_bpr.py
-    pins its effect on Recall@20: inside +-0.002 at BPR.conf's rate, outside at five times that), so BPR does not run it by default."""
-    from qrec_amd.capi import DeviceBuffer
-    from qrec_amd.engine import BprSgd, DeviceTables
-    from qrec_amd.interactions import CSR
-    t = DeviceTables(P0, Q0, np.float32)
-    s = BprSgd(t, u, items, CSR(indptr, items), schedule="item-deferred", n_items=n_items, chunk=chunk)
-    d_P0, d_Q0 = DeviceBuffer.from_numpy(t._pad(P0)), DeviceBuffer.from_numpy(t._pad(Q0))
-    s.start_device_driver(LR0, log_capacity=epochs)
-    d_drv0 = DeviceBuffer.from_numpy(s.d_drv.numpy())
-    capi.device_sync()
-    evs = [(capi.Event(), capi.Event()) for _ in range((runs + 1) * epochs)]
-    k = 0
-    s.prefetch_negatives_device(seed, 0)
-    t0 = 0.0
-    for r in range(runs + 1):                   # run 0: warm-up
-        if r == 1:
-            capi.device_sync(); t0 = time.perf_counter()
-        capi.memcpy_d2d(t.P, d_P0, d_P0.nbytes, main); capi.memcpy_d2d(t.Q, d_Q0, d_Q0.nbytes, main)
-        capi.memcpy_d2d(s.d_drv, d_drv0, d_drv0.nbytes, main)
-        for _ in range(epochs):
-            s.take_prefetched_negatives(k, main)
-            s.epoch_device_async(REG_U, REG_I, MAX_LR, tol=0.0, chunk=chunk, stream=main, flush_every=flush_every, events=evs[k])
-            s.prefetch_negatives_device(seed, k + 1)
-            k += 1
-    t_enq = time.perf_counter() - t0
-    capi.device_sync()
-    dt = time.perf_counter() - t0
-    ms = float(np.mean([b.elapsed_ms_since(a) for a, b in evs[epochs:]]))
-    alg = u.size * bytes_per_triplet(P0.shape[1])
-    del s, t
-    rec = recall_legs("item-deferred", "yelp2018")
-    return {"schedule": "item-deferred", "sub_epochs": 1, "value": u.size * runs * epochs / dt, "unit": "triplet-updates/s", "ms_per_epoch": dt / (runs * epochs) * 1e3,
-            "kernels": "bpr_hogwild_item_kernel<16,4,defer> + bpr_deferred_negatives_kernel<16,4> (j order: rocPRIM radix sort on the sampler's stream)",
-            "avg_launch_ms": ms, "roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "recall_at_20": rec,
-            "host_enqueue_ms_per_epoch": t_enq / (runs * epochs) * 1e3,
-            "default": False, "why_not_default": "at the Yelp2018 shape one epoch is 2.25 rounds of the grid: the negative item's row lags by the whole epoch; "
-                                                  "on the structureless graph the paired runs are 0.0058 apart at lr0 = 0.05 (tests/test_gpu_bpr.py).  `auto` "
-                                                  "picks the schedule in 4 sub-epochs from 5 M triplets per epoch on, where the lag is a quarter epoch and free"}
-
-
 def exact_mode_rate(capi, u, items, indptr, n_items, P0, Q0):
     """The order-exact mode on the same workload: CPython-stream negatives from the native host replay, triplets
     applied strictly in the reference's order on the device (fp64 tables, the drop-in classes' default)."""
@@ -274,7 +229,7 @@ def exact_mode_rate(capi, u, items, indptr, n_items, P0, Q0):
             "parity": "index stream bit-exact vs the recorded reference run; P, Q 1e-10, loss 1e-11 (tests/test_gpu_bpr.py)"}
 
 
-def hbm_resident_roofline(capi, schedule="user", sub_epochs=None):
+def hbm_resident_roofline(capi, schedule="user", p_update="atomic"):
     """BASELINE config #4, single-GPU slice (U=1.25 M, I=1 M, d=128, 25 M triplets, uniform items): 1.15 GB of tables,
     far beyond the 256 MiB Infinity Cache, so the gather+SGD kernel's traffic is real HBM traffic."""
     from qrec_amd.engine import BprSgd, DeviceTables
@@ -286,15 +241,15 @@ def hbm_resident_roofline(capi, schedule="user", sub_epochs=None):
     for a in (P2, Q2):
         for k in range(0, a.shape[0], 50_000):
             a[k:k + 50_000] = blk[:min(50_000, a.shape[0] - k)]
-    t = DeviceTables(P2, Q2, np.float32); s = BprSgd(t, u2, i2, None, schedule=schedule, sub_epochs=sub_epochs)
+    t = DeviceTables(P2, Q2, np.float32); s = BprSgd(t, u2, i2, None, schedule=schedule, p_update=p_update)
     s.set_negatives(rng.integers(0, I2, n2, dtype=np.int32))
     e0, e1 = capi.Event(), capi.Event(); ts = []
     with settled_heap(capi):
         for _ in range(5):
             e0.record(); s.epoch_throughput_async(LR0, REG_U, REG_I); e1.record(); e1.sync(); ts.append(e1.elapsed_ms_since(e0))
     ms = float(np.median(ts[1:])); alg = n2 * bytes_per_triplet(d2)
-    return {"workload": f"BPR d={d2}, {U2}x{I2}, {n2} triplets/epoch, {schedule}-major" + (f", {sub_epochs} sub-epochs" if sub_epochs else "")
-                        + " (config #4 single-GPU slice, tables 1.15 GB)", "schedule": schedule, "sub_epochs": int(s.sub_epochs),
+    return {"workload": f"BPR d={d2}, {U2}x{I2}, {n2} triplets/epoch, {schedule}-major (config #4 single-GPU slice, tables 1.15 GB)", "schedule": schedule,
+            "p_update": s.p_update, "p_update_requested": p_update, "collision_density": s.collision,
             "bound": "hbm", "achieved": alg / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / ms / 1e6 / HBM_PEAK_GBPS,
             "avg_launch_ms": ms, "algorithmic_bytes_per_launch": alg, "triplet_updates_per_s": n2 / ms * 1e3}
 
@@ -575,8 +530,11 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="triplets per work item of the SGD kernel (0 = engine.balanced_chunk: the length in 26..40 that spreads the "
                                                          "epoch's chunks most evenly over the persistent groups)")
     ap.add_argument("--flush-every", type=int, default=0, help="item-major schedule: triplets between flushes of the register-resident Q[i] (0 = default)")
-    ap.add_argument("--schedule", choices=("item", "user", "item-deferred"), default="item",
+    ap.add_argument("--schedule", choices=("item", "user"), default="item",
                     help="visiting order of the epoch's triplets in the Hogwild kernel (DESIGN.md s4)")
+    ap.add_argument("--p-update", choices=("auto", "atomic", "rmw"), default="auto",
+                    help="item-major: how P[u] is written -- atomic delta, sc1 load + store, or by the collision density (engine.resolve_p_update; "
+                         "the Yelp2018 shape resolves to atomic)")
     ap.add_argument("--dist-mode", choices=("replicated", "sharded"), default=os.environ.get("QREC_DIST_MODE", "replicated"))
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N > 1.  strong (default; BASELINE.json quotes the metric on THE Yelp2018 shape at 1/2/4/8 GPUs): the same 31,668 users "
@@ -690,7 +648,7 @@ def main():
             n_batches = qd.agree_on_batches(control, n, args.shard_batch, split_from=1 << 19, min_batches=syncs)
         else:
             n_batches = syncs
-        sgd = BprSgd(tables, l_u, l_items, CSR(l_indptr, l_items), schedule=args.schedule, n_items=I, batches=n_batches, chunk=CHUNK)
+        sgd = BprSgd(tables, l_u, l_items, CSR(l_indptr, l_items), schedule=args.schedule, n_items=I, batches=n_batches, chunk=CHUNK, p_update=args.p_update)
         # one launch per epoch: at least 8 rounds of the persistent grid whatever the epoch's size (engine.grid_for_epoch; nothing changes at
         # the Yelp2018 shape's 1.25 M triplets, a two-rank share of it runs chunks of 16)
         CHUNK, GROUPS = (CHUNK, 0) if args.chunk else sgd.launch_grid()
@@ -790,7 +748,7 @@ def main():
         kernel_ms = [ev[k][1].elapsed_ms_since(ev[k][0]) for k in range(first_timed, total)]
         leg = {"n": n, "chunk": CHUNK, "inner": inner, "elapsed": elapsed, "steps": steps, "final_loss": float(log[-1, 0]), "final_lr": drv["lr"],
                "avg_kernel_ms": float(np.mean(kernel_ms)), "n_batches": n_batches, "q_floats": int(tables.Q.nbytes // 4), "moved": None,
-               "fetch_pipelined": False, "plan": None, "ld": tables.ld, "P0": P0}
+               "fetch_pipelined": False, "plan": None, "ld": tables.ld, "P0": P0, "p_update": sgd.p_update, "collision_density": sgd.collision}
         if sharded:
             leg["moved"] = float(control.allreduce_host(np.array([dstep.exchange.bytes_moved / max(total, 1)]))[0])
             leg["fetch_pipelined"] = dstep.exchange.pipeline is not None
@@ -878,8 +836,8 @@ def main():
             tj = json.load(open(tfile))
             if tj.get("workload") == f"bpr-{args.shape}-d{DIM}-{args.schedule}":
                 traffic = tj.get("bytes_per_launch")
-        kernel = {"item": "bpr_hogwild_item_kernel<16,4>", "user": "bpr_hogwild_kernel<16,4,plain-load,atomic>",
-                  "item-deferred": "bpr_hogwild_item_kernel<16,4,defer> + bpr_deferred_negatives_kernel<16,4>"}[args.schedule]
+        kernel = {"item": "bpr_hogwild_item_kernel<16,4>" + (" (P[u] by sc1 load + store)" if leg.get("p_update") == "rmw" else ""),
+                  "user": "bpr_hogwild_kernel<16,4,plain-load,atomic>"}[args.schedule]
         shape_name = "Yelp2018-shape" if args.shape == "yelp2018" else args.shape
         if world == 1:
             par = "1 GPU" + (f" (QREC_FORCE_DIST: {args.dist_mode} multi-GPU path at world 1)" if use_dist else "")
@@ -901,6 +859,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "mode": f"throughput: device Philox sampler + Hogwild atomic-delta SGD, {args.schedule}-major",
+                       "p_update": leg["p_update"], "collision_density": leg["collision_density"],
                        "triplets_per_epoch_per_gpu": n, "triplets_per_epoch_job": n_job, "epochs_per_step": inner,
                        "step": f"a fresh {inner}-epoch training run from the initial tables and learning rate", "ms_per_epoch": elapsed / (args.steps * inner) * 1e3,
                        "timed_seconds": elapsed, "chunk": CHUNK, "parallelism": par,
@@ -942,26 +901,21 @@ def main():
             if not args.no_extras:
                 out["recall_at_20"] = recall_legs(args.schedule, args.shape)
                 out["exact_mode"] = exact_mode_rate(capi, u, items, indptr, I, leg["P0"], Q0)
-                if args.schedule == "item" and args.shape == "yelp2018":
-                    out["deferred_negatives"] = deferred_variant(capi, data, u, items, indptr, I, leg["P0"], Q0, CHUNK, flush_every, SEED, main_stream)
-                # the HBM-resident slice of config #4 (1.15 GB of tables: real HBM traffic) under the schedule `auto` resolves to at that size
-                # (engine.resolve_schedule: one-pass since round 5), and under the opt-in deferred-negatives schedule with what it costs in Recall
-                from qrec_amd.engine import resolve_schedule
-                sch, sub = resolve_schedule(25_000_000, None)
-                out["roofline_hbm_resident"] = hbm_resident_roofline(capi, schedule=sch, sub_epochs=sub)
-                out["roofline_hbm_resident"]["schedule_chosen_by"] = "engine.resolve_schedule (QREC_SCHEDULE=auto) for 25 M triplets per epoch"
-                out["roofline_hbm_resident_deferred_opt_in"] = hbm_resident_roofline(capi, schedule="item-deferred", sub_epochs=4)
-                out["roofline_hbm_resident_deferred_opt_in"]["recall_at_20_at_this_size"] = {
-                    "source": "profiles/r05_auto_regime_25m.json (static: builder-measured in round 5; xl25m-clustered, d = 128, paired runs)",
-                    "abs_diff_peak_and_last_epoch": {"lr0 0.01, 4 sub-epochs": [0.0032, 0.0079], "lr0 0.05, 4 sub-epochs": [0.0050, 0.0045],
-                                                     "lr0 0.01, 8 sub-epochs": [0.0010, 0.0032], "lr0 0.05, 8 sub-epochs": [0.0028, 0.0020],
-                                                     "lr0 0.01, one-pass item-major": [0.0008, 0.0002], "lr0 0.05, one-pass item-major": [0.0010, 0.0003]},
-                    "fresh_coefficient_variant": {
-                        "source": "profiles/r05_fresh_coefficient_25m.json (static: builder-measured in round 5; pass B re-forms lr (1 - sigma(x)) against the row as its "
-                                  "run left it, BprSgd(fresh=True); same epoch time: 15.5 vs 15.4 ms)",
-                        "abs_diff_peak_and_last_epoch": {"lr0 0.01, 4 sub-epochs": [0.0008, 0.0050], "lr0 0.01, 8 sub-epochs": [0.0003, 0.0023],
-                                                         "lr0 0.01, 2 sub-epochs": [0.0050, 0.0099], "lr0 0.01, 1 sub-epoch": [0.0162, 0.0257]}},
-                    "bar": 0.002, "verdict": "outside the bar at the last epoch in every setting measured: opt-in only (QREC_SCHEDULE=item-deferred), not what `auto` runs"}
+                # the HBM-resident slice of config #4 (1.15 GB of tables: real HBM traffic) under what `auto` resolves to at that size: item-major,
+                # P[u] written by sc1 load + store where users rarely collide (engine.resolve_p_update: collision density 0.003 there) -- and, beside
+                # it, the same slice with atomic deltas (what rounds 1-5 ran)
+                from qrec_amd.engine import P_RMW_MAX_COLLISION, resolve_schedule
+                sch, _ = resolve_schedule(25_000_000, None)
+                out["roofline_hbm_resident"] = hbm_resident_roofline(capi, schedule=sch, p_update="auto")
+                out["roofline_hbm_resident"]["chosen_by"] = (f"engine.resolve_schedule + engine.resolve_p_update (QREC_SCHEDULE / QREC_P_UPDATE = auto): "
+                                                             f"load + store where groups x sum_u p_u^2 <= {P_RMW_MAX_COLLISION}")
+                out["roofline_hbm_resident"]["recall_at_20_at_this_size"] = {
+                    "source": "profiles/r06_item_rmw.json (builder-measured in round 6, tools/paired_recall.py: xl25m-clustered, 650 k users, 25.3 M triplets per epoch, "
+                              "d = 128, collision density 0.008, against order-exact fp64 training on the same negatives; static here)",
+                    "abs_diff_peak_and_last_epoch": {"lr0 0.01, 30 epochs, load + store": [0.0010, 0.0002], "lr0 0.05, 12 epochs, load + store": [0.0011, 0.0002],
+                                                     "lr0 0.01, 30 epochs, atomic deltas": [0.0008, 0.0002], "lr0 0.05, 12 epochs, atomic deltas": [0.0010, 0.0003]},
+                    "bar": 0.002}
+                out["roofline_hbm_resident_atomic"] = hbm_resident_roofline(capi, schedule=sch, p_update="atomic")
                 if args.shape == "yelp2018":
                     out["other_configs"] = other_configs(capi, data)
         os.write(result_fd, (json.dumps(out) + "\n").encode())

@@ -192,6 +192,8 @@ int qrec_bpr_sgd_scheduled_wide(void *d_P, void *d_Q, int64_t n_users, int64_t n
 #define QREC_HW_SC1_RMW 2       /* sc1 loads, sc1 write-through stores                    */
 #define QREC_HW_ATOMIC 3        /* plain loads, f32 atomic-add deltas                     */
 #define QREC_HW_SC1_ATOMIC 4    /* sc1 loads, f32 atomic-add deltas                       */
+#define QREC_HW_P_RMW 5         /* item-major only: P[u] by sc1 load + sc1 store (racy), Q[i] / Q[j] by atomic deltas */
+#define QREC_HW_PQ_RMW 6        /* item-major only: P[u] and Q[j] by sc1 load + sc1 store (measurements)              */
 int qrec_bpr_sgd_hogwild(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld, const int32_t *d_u,
                          const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
                          int32_t grid_groups, float lr, float regU, float regI, double *d_loss,
@@ -203,54 +205,16 @@ int qrec_bpr_sgd_hogwild(float *d_P, float *d_Q, int64_t n_users, int64_t n_item
  * per-triplet atomics off the hot item rows (Zipf 0.6) onto user rows (Zipf 0.4) and uniform
  * negatives, which the L2 atomic units retire ~25% faster.  Chunks are visited in a golden-ratio
  * stride order so that the chunks of one hot item are spread over the epoch.  With grid_groups == 1
- * and chunk order aside, each row still sees exactly the reference recurrence.              */
+ * and chunk order aside, each row still sees exactly the reference recurrence.
+ * `variant`: QREC_HW_DEFAULT / QREC_HW_ATOMIC = the above.  QREC_HW_P_RMW (round 6): P[u] is read with sc1 loads and written back
+ * with sc1 write-through stores instead of atomic deltas -- one atomic row update per triplet instead of two (0.63-0.64 of the
+ * HBM roofline instead of 0.43-0.46), at the price that a P[u] update landing between another group's load and store of the same
+ * row is lost.  The expected share of such updates is the collision density c = groups in flight x sum_u (n_u / n)^2; the host
+ * takes this variant only where c <= 0.01 (qrec_amd/engine.py resolve_p_update; measured Recall@20 gaps by c in DESIGN.md s5.1). */
 int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld,
                                     const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
                                     int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
-                                    double *d_loss, const double *d_driver_state, void *stream);
-/* Deferred negatives (round 3): the same epoch in two passes -- the item-major pass applies the updates of P[u] and Q[i] and
- * logs every triplet's coefficient lr (1 - sigma(x)); a second pass walks the triplets in j order (a counting sort of the
- * epoch's negatives, on the device) with Q[j] in registers and applies  Q[j] -= g P[u]; Q[j] -= lr regI Q[j].  One atomic
- * row update per triplet instead of two (the item-major kernel sits at the atomic units' ceiling: DESIGN.md s4).  The
- * negative-side updates of an epoch are applied after its positive-side ones, with the epoch-end P[u]: a reordering of
- * the same terms.  d_work: qrec_bpr_deferred_work_bytes(n, n_items) bytes of scratch, laid out as
- *   float g[n] | int32 order[n] | int32 j_sorted[n] | int32 keys[n] (each rounded up to 256 bytes) | the sort's own scratch.
- * qrec_bpr_deferred_sort puts the j order of the negatives d_j into d_work: a STABLE sort by j (inside a run of equal j
- * the triplets keep their storage order), so pass B is a deterministic function of the arrays; the engine runs it on the
- * sampler's side stream, under the previous epoch.  `flags`: bit 0 (QREC_DEFERRED_SORTED) -- d_work already holds the j order
- * of these negatives (qrec_bpr_deferred_sort); without it the call sorts first, on its own stream.  Bit 1
- * (QREC_DEFERRED_FRESH) -- pass A logs P[u].Q[i] instead of
- * g and pass B forms g' = lr (1 - sigma(P[u].Q[i] - P[u].Q[j])) against the Q[j] its run has reached: the negative item's row
- * takes its updates one after the other as in the reference (measured: halves the drift of Recall@20 at 5x BPR.conf's rate,
- * changes nothing at BPR.conf's rate).                                                                     */
-#define QREC_DEFERRED_SORTED 1
-#define QREC_DEFERRED_FRESH 2
-/* Sub-epochs (sub_epochs = S in 1..16): the epoch's time slots -- the order the item-major kernel visits its chunks in -- are cut
- * into S consecutive ranges; range s is one launch of pass A followed by one of pass B over that range's triplets (sorted by
- * (range, j): qrec_bpr_deferred_sort_sub with the SAME chunk and S).  With stream_b != NULL pass B of range s runs on stream_b,
- * under pass A of range s + 1 on `stream` (`stream` waits for the last pass B at the end): the negative item's row lags the rest
- * by about one range instead of one epoch, and pass B's time hides under pass A's.  stream_b == NULL: everything in order on
- * `stream` -- the sequential statement of the sub-epoch schedule (tests).  d_work's layout gains a key array:
- *   float g[n] | int32 order[n] | int32 sorted keys[n] | int32 keys[n] (each rounded up to 256 bytes) | the sort's scratch.   */
-/* Host only: where the sub-epochs of an epoch of n triplets lie -- h_slot_bound[S + 1] (time slots), h_first[S + 1] (positions in the
- * (sub-epoch, j) order), h_stride_inv[3] = {the visiting order's stride, its inverse modulo the number of chunks, the number of chunks}. */
-int qrec_bpr_deferred_sub_plan(int64_t n, int64_t n_items, int32_t chunk, int32_t sub_epochs, int64_t *h_slot_bound, int64_t *h_first,
-                               int64_t *h_stride_inv);
-int qrec_bpr_deferred_sort_sub(const int32_t *d_j, int64_t n, int64_t n_items, int32_t chunk, int32_t sub_epochs, void *d_work,
-                               void *stream);
-int qrec_bpr_sgd_hogwild_item_major_deferred_sub(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld,
-                                                 const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
-                                                 int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
-                                                 double *d_loss, const double *d_driver_state, void *d_work, int32_t flags,
-                                                 int32_t sub_epochs, void *stream_b, void *stream);
-int qrec_bpr_deferred_work_bytes(int64_t n, int64_t n_items, int64_t *bytes);
-int qrec_bpr_deferred_sort(const int32_t *d_j, int64_t n, int64_t n_items, void *d_work, void *stream);
-int qrec_bpr_sgd_hogwild_item_major_deferred(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld,
-                                             const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
-                                             int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
-                                             double *d_loss, const double *d_driver_state, void *d_work, int32_t flags,
-                                             void *stream);
-
+                                    double *d_loss, int variant, const double *d_driver_state, void *stream);
 /* Device-resident epoch close of the numpy-path models: model/ranking/BPR.py:40 (loss += regU*sum(P*P) +
  * regI*sum(Q*Q)) followed by isConverged / updateLearningRate (base/iterativeRecommender.py:56-63,88-104),
  * so that a run can be enqueued epoch after epoch without a host round trip.
@@ -477,6 +441,22 @@ int qrec_copy_cols(float *d_dst, int32_t dst_ld, const float *d_src, int32_t src
                    void *stream);
 /* X[row][0 .. ld) = 0 for the listed rows (a row subset as above): clears a gradient table where the next scatter lands */
 int qrec_zero_rows(float *d_X, int32_t ld, const int32_t *d_row_ids, const int32_t *d_n_row_ids, int32_t max_row_ids, void *stream);
+
+/* ---- per-epoch graph augmentation on the device (SGL.py:113-155, BUIR.py:41-65; throughput mode) ----------------------------
+ * A sub-graph of the training graph as a VALUE array over the full graph's CSR structure (csrc/augment.hip): entry e of the joint
+ * adjacency gets fl32(fl32(d'_r a'_e) d'_c) with a'_e = the number of kept training rows that map to it and d' = deg'^-1/2 of the
+ * kept edges (0 for isolated nodes), dropped entries 0 -- the reference's re-normalised sub-adjacency, laid out for the SpMM plan
+ * that already exists.  d_u / d_i: the training rows (user id, item id), d_pos_ui / d_pos_iu: the CSR positions of a row's two
+ * entries (u, U + i) and (U + i, u); d_row_of_nnz / d_indices: row and column of every CSR entry; d_dinv_table[k] = float32
+ * power(k, -0.5) for k = 0 .. max_deg (inf -> 0; formed by the host with numpy, so the values carry the reference's bits).
+ * The draw is the caller's (qrec_random_permutations): d_keep_rows = n_keep kept training rows (edge dropout, random walk) OR
+ * d_drop_users / d_drop_items = dropped node ids (node dropout; d_flags: n_users + n_items bytes of scratch) OR neither (the full
+ * graph).  Scratch: d_cnt int32[nnz], d_deg int32[n_users + n_items].  Integer atomics only: the result is deterministic. */
+int qrec_subgraph_values(const int32_t *d_u, const int32_t *d_i, const int32_t *d_pos_ui, const int32_t *d_pos_iu, int64_t n_edges,
+                         int32_t n_users, int32_t n_items, const int32_t *d_keep_rows, int64_t n_keep, const int32_t *d_drop_users,
+                         int64_t n_drop_users, const int32_t *d_drop_items, int64_t n_drop_items, const int32_t *d_row_of_nnz,
+                         const int32_t *d_indices, int64_t nnz, const float *d_dinv_table, int32_t max_deg, int32_t *d_cnt,
+                         int32_t *d_deg, uint8_t *d_flags, float *d_values, void *stream);
 
 /* ---- BUIR (model/ranking/BUIR.py) ------------------------------------------------------------------ *
  * The propagation of both encoders is qrec_spmm_csr on the epoch's two sub-graphs.  What the model adds:      */

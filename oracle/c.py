@@ -58,6 +58,7 @@ def lib():
         L.orc_find_k_largest.restype = C.c_int
         L.orc_philox4x32_10.argtypes = [vp, vp, vp]
         L.orc_philox_bpr_sample.argtypes = [vp, vp, vp, i64, i32, u64, u64, vp]
+        L.orc_philox_perm_keys.argtypes = [i64, u64, u64, vp]
         _lib = L
     return _lib
 
@@ -169,16 +170,6 @@ def bpr_sgd(P, Q, u, i, j, lr, regU, regI) -> float:
     return lib().orc_bpr_sgd_f32(_p(P), _p(Q), d, _p(u), _p(i), _p(j), u.size, lr, regU, regI)
 
 
-def bpr_sgd_deferred(P, Q, u, i, j, j_order, lr, regU, regI, fresh: int = 0) -> float:
-    """NOT a reference function: the sequential definition of the product's deferred-negatives epoch (qrec_oracle.c), fp64, in place.
-    ``j_order``: int64 permutation -- the order pass B applies the negative-side updates in (the kernels: sorted by j)."""
-    _chk(u, np.int32); _chk(i, np.int32); _chk(j, np.int32); _chk(j_order, np.int64); _chk(P, np.float64); _chk(Q, np.float64)
-    L = lib()
-    L.orc_bpr_sgd_deferred_f64.argtypes = [C.c_void_p] * 2 + [C.c_int32] + [C.c_void_p] * 4 + [C.c_int64] + [C.c_double] * 3 + [C.c_int32]
-    L.orc_bpr_sgd_deferred_f64.restype = C.c_double
-    return L.orc_bpr_sgd_deferred_f64(_p(P), _p(Q), P.shape[1], _p(u), _p(i), _p(j), _p(j_order), u.size, lr, regU, regI, int(fresh))
-
-
 def tbpr_sample_epoch(mt: MT, pos_indptr, pos_items, n_items: int, joint, weak, strong):
     """model/ranking/TBPR.py:131-158 -- the epoch's chained (u, a, b) triplets; joint/weak/strong = (indptr, items)."""
     _chk(pos_indptr, np.int64); _chk(pos_items, np.int32)
@@ -250,6 +241,13 @@ def philox4x32_10(ctr, key) -> np.ndarray:
     assert c.size == 4 and k.size == 2
     lib().orc_philox4x32_10(_p(c), _p(k), _p(out))
     return out
+
+
+def philox_permutation(n: int, seed: int, stream_id: int) -> np.ndarray:
+    """the device's uniform permutation of range(n) (qrec_random_permutations, count = 1) on the CPU: stable argsort of the Philox keys"""
+    keys = np.empty(n, dtype=np.uint64)
+    lib().orc_philox_perm_keys(n, int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id) & 0xFFFFFFFFFFFFFFFF, _p(keys))
+    return np.argsort(keys, kind="stable").astype(np.int32)
 
 
 def philox_bpr_sample(indptr, sorted_items, row_user, n_items: int, seed: int, epoch: int) -> np.ndarray:

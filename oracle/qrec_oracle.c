@@ -290,6 +290,20 @@ void orc_philox_bpr_sample(const int64_t *indptr, const int32_t *sorted_items, c
     }
 }
 
+/* f-2, throughput mode: the sort keys of the device's uniform permutations (include/qrec_hip.h, qrec_random_permutations with
+ * count = 1; csrc/mhcn.hip perm_keys_kernel): key[i] = the top 40 bits of the first two Philox words of
+ * counter {i_lo, i_hi, stream_lo, stream_hi}, key {seed_lo, seed_hi}.  The permutation is the STABLE argsort of the keys (equal
+ * keys -- 2^-40 per pair -- keep index order); a sub-graph of SGL / BUIR keeps / drops the first K entries of it
+ * (SGL.py:118-130's random.sample subsets, drawn from this stream instead of CPython's). */
+void orc_philox_perm_keys(int64_t n, uint64_t seed, uint64_t stream_id, uint64_t *keys_out) {
+    int64_t i;
+    for (i = 0; i < n; i++) {
+        uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        keys_out[i] = (((uint64_t)c[0] << 32) | c[1]) >> 24;
+    }
+}
+
 /* a-2  Triplet sampler, TF path: base/deepRecommender.py:29-52 (next_batch_pairwise).
  * The caller applies shuffle(trainingData) first (orc_shuffle on a row permutation);
  * this function then walks the rows in the shuffled order and draws one negative per
@@ -357,57 +371,6 @@ double orc_bpr_sgd_f64(double *P, double *Q, int32_t d, const int32_t *u_idx,
         for (c = 0; c < d; c++) qj[c] -= (lr * regI) * qj[c];
         loss += -log(s);
     }
-    return loss;
-}
-
-/* ------------------------------------------------------------------------------------
- * NOT a reference function: the sequential DEFINITION of the product's "deferred negatives" epoch (qrec_amd/csrc/bpr_sgd.hip,
- * round 3), which the tests hold the two-pass kernels to.  The per-triplet terms are BPR.optimization's (BPR.py:45-53); what
- * differs is when the negative item's row is updated:
- *   pass A, triplets in the given (item-major) order:  s, g = lr (1 - s);  P[u] += g (Q[i] - Q[j]);  Q[i] += g P[u];
- *           P[u] -= lr regU P[u];  Q[i] -= lr regI Q[i];  loss += -log(s)          -- Q[j] is read, not written; g is kept
- *   pass B, the same triplets in the order j_order:   Q[j] -= g P[u];  Q[j] -= lr regI Q[j]     with the P[u] pass A left.
- * fresh != 0: pass A keeps xi = P[u].Q[i] instead of g, and pass B forms g' = lr (1 - sigmoid(xi - P[u].Q[j])) with the P[u]
- * pass A left and the Q[j] the pass has reached -- the negative item's row takes its updates one after the other, each seeing
- * the previous ones, as in the reference; the user's and the positive item's rows saw Q[j] as the epoch found it.
- * Returns sum of -log(s). */
-double orc_bpr_sgd_deferred_f64(double *P, double *Q, int32_t d, const int32_t *u_idx, const int32_t *i_idx, const int32_t *j_idx,
-                                const int64_t *j_order, int64_t n, double lr, double regU, double regI, int32_t fresh) {
-    double loss = 0.0;
-    double *g_of = (double *)malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
-    int64_t t, k;
-    int c;
-    for (t = 0; t < n; t++) {
-        double *pu = P + (int64_t)u_idx[t] * d;
-        double *qi = Q + (int64_t)i_idx[t] * d;
-        const double *qj = Q + (int64_t)j_idx[t] * d;
-        double xi = 0.0, xj = 0.0, s, g;
-        for (c = 0; c < d; c++) { xi += pu[c] * qi[c]; xj += pu[c] * qj[c]; }
-        s = 1.0 / (1.0 + exp(-(xi - xj)));
-        g = lr * (1.0 - s);
-        g_of[t] = fresh ? xi : g;
-        for (c = 0; c < d; c++) pu[c] += g * (qi[c] - qj[c]);
-        for (c = 0; c < d; c++) qi[c] += g * pu[c];
-        for (c = 0; c < d; c++) pu[c] -= (lr * regU) * pu[c];
-        for (c = 0; c < d; c++) qi[c] -= (lr * regI) * qi[c];
-        loss += -log(s);
-    }
-    for (k = 0; k < n; k++) {
-        const double *pu;
-        double *qj;
-        t = j_order[k];
-        double g = g_of[t];
-        pu = P + (int64_t)u_idx[t] * d;
-        qj = Q + (int64_t)j_idx[t] * d;
-        if (fresh) {       /* the negative's side of x against the row as it is NOW: x' = (P[u].Q[i] as pass A saw it) - P[u].Q[j] */
-            double xj = 0.0;
-            for (c = 0; c < d; c++) xj += pu[c] * qj[c];
-            g = lr * (1.0 - 1.0 / (1.0 + exp(-(g - xj))));
-        }
-        for (c = 0; c < d; c++) qj[c] -= g * pu[c];
-        for (c = 0; c < d; c++) qj[c] -= (lr * regI) * qj[c];
-    }
-    free(g_of);
     return loss;
 }
 

@@ -43,6 +43,45 @@ def joint_norm_adjacency(n_users: int, n_items: int, uid: np.ndarray, iid: np.nd
     return D.dot(A).dot(D).tocsr()
 
 
+def philox_subgraph_rows(n_users: int, n_items: int, uid, iid, aug_type: int, drop_rate: float, seed: int, stream_id: int) -> np.ndarray:
+    """The training rows a device-drawn sub-graph keeps (throughput mode of SGL / BUIR; qrec_amd.graph.SubgraphSampler's contract,
+    restated): the subsets of SGL.py:118-130 / BUIR.py:46 -- random.sample of int(U rate) users and int(I rate) items to drop, or of
+    int(E (1 - rate)) rows to keep -- taken as the first K entries of the Philox permutation of (seed, stream_id) [items: stream_id + 1]
+    instead of CPython's stream.  Returns the kept row indices in ascending order."""
+    from . import c as O
+    uid, iid = np.asarray(uid), np.asarray(iid)
+    if drop_rate <= 0:
+        return np.arange(uid.size)
+    if aug_type == 0:
+        drop_u = O.philox_permutation(n_users, seed, stream_id)[:int(n_users * drop_rate)]
+        drop_i = O.philox_permutation(n_items, seed, stream_id + 1)[:int(n_items * drop_rate)]
+        ku = np.ones(n_users, bool); ku[drop_u] = False
+        ki = np.ones(n_items, bool); ki[drop_i] = False
+        return np.flatnonzero(ku[uid] & ki[iid])
+    if aug_type in (1, 2):
+        return np.sort(O.philox_permutation(uid.size, seed, stream_id)[:int(uid.size * (1 - drop_rate))])
+    raise ValueError(aug_type)
+
+
+def subgraph_values_on_full_structure(n_users: int, n_items: int, uid, iid, kept_rows) -> np.ndarray:
+    """The reference's re-normalised sub-adjacency of the kept training rows (SGL.py:131-155: R' + R'^T, d = rowsum^-1/2, inf -> 0,
+    diag(d) A diag(d), float32, scipy CSR) as a value array over the FULL graph's sorted CSR structure -- the layout the device
+    augmentation writes (csrc/augment.hip): kept entries carry the sub-graph's values, every other entry of the full graph is 0."""
+    uid, iid = np.asarray(uid), np.asarray(iid)
+    full = joint_norm_adjacency(n_users, n_items, uid, iid)
+    with np.errstate(divide="ignore"):
+        sub = joint_norm_adjacency(n_users, n_items, uid[kept_rows], iid[kept_rows])
+    full.sort_indices(); sub.sort_indices()
+    n = n_users + n_items
+    fk = np.repeat(np.arange(n, dtype=np.int64), np.diff(full.indptr)) * n + full.indices
+    sk = np.repeat(np.arange(n, dtype=np.int64), np.diff(sub.indptr)) * n + sub.indices
+    out = np.zeros(fk.size, np.float32)
+    pos = np.searchsorted(fk, sk)
+    assert np.array_equal(fk[pos], sk)
+    out[pos] = sub.data
+    return out
+
+
 def bpr_batch_loss_and_grads(u_b, i_b, j_b, reg, eps=np.float32(1e-7)):
     """util/loss.py:3-6 (eps = 10e-8) + the batch L2 term of model/ranking/LightGCN.py:28-30;
     returns (loss, du_b, di_b, dj_b) -- hand-derived gradients, fp32."""

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libqrec_hip.so")
 
 F32, F64, I32 = 0, 1, 2
-HW_DEFAULT, HW_PLAIN_RMW, HW_SC1_RMW, HW_ATOMIC, HW_SC1_ATOMIC = 0, 1, 2, 3, 4
+HW_DEFAULT, HW_PLAIN_RMW, HW_SC1_RMW, HW_ATOMIC, HW_SC1_ATOMIC, HW_P_RMW, HW_PQ_RMW = 0, 1, 2, 3, 4, 5, 6
 
 _vp, _i32, _i64, _u64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
 
@@ -64,13 +64,7 @@ _SIGNATURES = {
     "qrec_bpr_exact_expand": [_vp, _vp, _i64, _i32, _vp, _vp],
     "qrec_bpr_sgd_scheduled_wide": [_vp, _vp, _i64, _i64, C.c_int, _i32, _i32, _vp, _i64, _i32, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp],
     "qrec_bpr_sgd_hogwild": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _vp, C.c_int, _vp, _vp],
-    "qrec_bpr_sgd_hogwild_item_major": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp],
-    "qrec_bpr_deferred_work_bytes": [_i64, _i64, _vp],
-    "qrec_bpr_deferred_sort": [_vp, _i64, _i64, _vp, _vp],
-    "qrec_bpr_deferred_sort_sub": [_vp, _i64, _i64, _i32, _i32, _vp, _vp],
-    "qrec_bpr_deferred_sub_plan": [_i64, _i64, _i32, _i32, _vp, _vp, _vp],
-    "qrec_bpr_sgd_hogwild_item_major_deferred_sub": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
-    "qrec_bpr_sgd_hogwild_item_major_deferred": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _i32, _vp],
+    "qrec_bpr_sgd_hogwild_item_major": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, C.c_int, _vp, _vp],
     "qrec_epoch_close": [_vp, _i64, _vp, _i64, C.c_int, _i32, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
     "qrec_epoch_sums": [_vp, _i64, _vp, _i64, C.c_int, _i32, _vp, _vp, _vp],
     "qrec_epoch_decide": [_vp, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp],
@@ -82,6 +76,7 @@ _SIGNATURES = {
     "qrec_spmm_csr": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     "qrec_mark_batch_rows": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "qrec_bpr_batch_loss_grad": [_vp, _f32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _i64, _vp],
+    "qrec_subgraph_values": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "qrec_ordered_scatter_workspace_bytes": [_i64, _i32, _vp],
     "qrec_scatter_add_rows_ordered": [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _i64, _vp],
     "qrec_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
@@ -778,6 +773,15 @@ def spmm_csr(plan, d_X, d_Y, ld: int, d_addend=None, addend_scale: float = 0.0, 
                                 _dp(d_y_row_mask), _dp(d_addend_row_mask), _sh(stream)))
 
 
+def subgraph_values(d_u, d_i, d_pos_ui, d_pos_iu, n_edges: int, n_users: int, n_items: int, d_row_of_nnz, d_indices, nnz: int,
+                    d_dinv_table, max_deg: int, d_cnt, d_deg, d_values, d_keep_rows=None, n_keep: int = 0, d_drop_users=None,
+                    n_drop_users: int = 0, d_drop_items=None, n_drop_items: int = 0, d_flags=None, stream=None):
+    """value array of a sub-graph over the full graph's CSR structure (include/qrec_hip.h, csrc/augment.hip)"""
+    _check(load().qrec_subgraph_values(_dp(d_u), _dp(d_i), _dp(d_pos_ui), _dp(d_pos_iu), n_edges, n_users, n_items, _dp(d_keep_rows), n_keep,
+                                       _dp(d_drop_users), n_drop_users, _dp(d_drop_items), n_drop_items, _dp(d_row_of_nnz), _dp(d_indices), nnz,
+                                       _dp(d_dinv_table), max_deg, _dp(d_cnt), _dp(d_deg), _dp(d_flags), _dp(d_values), _sh(stream)))
+
+
 class OrderedScatter:
     """Workspace of the ordered (deterministic) gradient scatters -- the parity mode of qrec_bpr_batch_loss_grad,
     qrec_buir_batch_loss_grad and qrec_sept_ssl_loss_grad (include/qrec_hip.h, csrc/ordered.hip).  One per trainer: the calls
@@ -1004,55 +1008,11 @@ def zero_rows(d_X, ld: int, rows: RowSubset, stream=None):
 
 def bpr_sgd_hogwild_item_major(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int, chunk: int, grid_groups: int,
                                flush_every: int, lr: float, regU: float, regI: float, d_loss, stream=None,
-                               d_driver_state=None, p_rows: int | None = None, q_rows: int | None = None):
+                               d_driver_state=None, p_rows: int | None = None, q_rows: int | None = None, variant: int = HW_DEFAULT):
+    """``variant``: HW_DEFAULT (atomic deltas on P[u] and Q[j]) or HW_P_RMW (P[u] by sc1 load + store: include/qrec_hip.h)"""
     _check(load().qrec_bpr_sgd_hogwild_item_major(_dp(d_P), _dp(d_Q), p_rows or _table_rows(d_P, ld), q_rows or _table_rows(d_Q, ld), d, ld, _dp(d_u), _dp(d_i), _dp(d_j), n, chunk,
-                                                  grid_groups, flush_every, lr, regU, regI, _dp(d_loss),
+                                                  grid_groups, flush_every, lr, regU, regI, _dp(d_loss), variant,
                                                   _dp(d_driver_state), _sh(stream)))
-
-
-def bpr_deferred_work_bytes(n: int, n_items: int) -> int:
-    out = C.c_int64(0)
-    _check(load().qrec_bpr_deferred_work_bytes(n, n_items, C.byref(out)))
-    return out.value
-
-
-def bpr_deferred_sort(d_j, n: int, n_items: int, d_work, stream=None):
-    _check(load().qrec_bpr_deferred_sort(_dp(d_j), n, n_items, _dp(d_work), _sh(stream)))
-
-
-def bpr_sgd_hogwild_item_major_deferred(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int, chunk: int, grid_groups: int,
-                                        flush_every: int, lr: float, regU: float, regI: float, d_loss, d_work, stream=None,
-                                        d_driver_state=None, p_rows: int | None = None, q_rows: int | None = None, is_sorted: bool = False, fresh: bool = False):
-    """the item-major epoch with the negative-side updates deferred to a second, j-ordered pass (include/qrec_hip.h);
-    ``is_sorted``: ``bpr_deferred_sort`` has already put these negatives' j order into ``d_work``; ``fresh``: pass B re-forms the
-    coefficient against the negative item's row as its run left it (include/qrec_hip.h QREC_DEFERRED_FRESH)"""
-    _check(load().qrec_bpr_sgd_hogwild_item_major_deferred(_dp(d_P), _dp(d_Q), p_rows or _table_rows(d_P, ld), q_rows or _table_rows(d_Q, ld), d, ld,
-                                                           _dp(d_u), _dp(d_i), _dp(d_j), n, chunk, grid_groups, flush_every, lr, regU, regI,
-                                                           _dp(d_loss), _dp(d_driver_state), _dp(d_work), (1 if is_sorted else 0) | (2 if fresh else 0), _sh(stream)))
-
-
-def bpr_deferred_sub_plan(n: int, n_items: int, chunk: int, sub_epochs: int):
-    """(slot bounds [S + 1], first positions [S + 1], stride, stride^-1 mod n_chunks, n_chunks) of the sub-epoch schedule; host only"""
-    sb, fi, si = np.zeros(sub_epochs + 1, np.int64), np.zeros(sub_epochs + 1, np.int64), np.zeros(3, np.int64)
-    _check(load().qrec_bpr_deferred_sub_plan(n, n_items, chunk, sub_epochs, _hp(sb), _hp(fi), _hp(si)))
-    return sb, fi, int(si[0]), int(si[1]), int(si[2])
-
-
-def bpr_deferred_sort_sub(d_j, n: int, n_items: int, chunk: int, sub_epochs: int, d_work, stream=None):
-    """the (sub-epoch, j) order of the negatives for ``bpr_sgd_hogwild_item_major_deferred_sub`` with the SAME chunk and sub-epoch count"""
-    _check(load().qrec_bpr_deferred_sort_sub(_dp(d_j), n, n_items, chunk, sub_epochs, _dp(d_work), _sh(stream)))
-
-
-def bpr_sgd_hogwild_item_major_deferred_sub(d_P, d_Q, d: int, ld: int, d_u, d_i, d_j, n: int, chunk: int, grid_groups: int,
-                                            flush_every: int, lr: float, regU: float, regI: float, d_loss, d_work, sub_epochs: int,
-                                            stream=None, stream_b=None, d_driver_state=None, p_rows: int | None = None,
-                                            q_rows: int | None = None, is_sorted: bool = False, fresh: bool = False):
-    """deferred negatives in ``sub_epochs`` ranges of the epoch's time slots; ``stream_b``: pass B of a range runs there, under pass
-    A of the next range on ``stream`` (None: everything in order on ``stream``)"""
-    _check(load().qrec_bpr_sgd_hogwild_item_major_deferred_sub(
-        _dp(d_P), _dp(d_Q), p_rows or _table_rows(d_P, ld), q_rows or _table_rows(d_Q, ld), d, ld, _dp(d_u), _dp(d_i), _dp(d_j), n, chunk,
-        grid_groups, flush_every, lr, regU, regI, _dp(d_loss), _dp(d_driver_state), _dp(d_work), (1 if is_sorted else 0) | (2 if fresh else 0),
-        sub_epochs, _sh(stream_b), _sh(stream)))
 
 
 DRV_LR, DRV_LAST_LOSS, DRV_EPOCHS, DRV_CONVERGED, DRV_FAILED, DRV_WORDS = 0, 1, 2, 3, 4, 8

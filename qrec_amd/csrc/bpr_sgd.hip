@@ -682,16 +682,21 @@ __global__ __launch_bounds__(256) void bpr_hogwild_kernel(
 // (stride coprime to n_chunks, ~0.618 n_chunks), which spreads the ~200 chunks of a hot item over
 // the whole epoch instead of running them all at once.
 // ------------------------------------------------------------------------------------
-// DEFER (round 3, "deferred negatives"): the update of Q[j] is NOT applied here -- the triplet's coefficient lr (1 - sigma(x)) is
-// logged (glog[t], 4 B) and bpr_deferred_negatives_kernel applies all of an epoch's negative-side updates afterwards, walking the
-// triplets in j order with Q[j] in registers.  One atomic row update per triplet instead of two: see that kernel's comment.
-template <int LPR, int E, typename TAB, bool DEFER = false>
+// RMW (round 6; bit 0: P[u], bit 1: Q[j]): the row is updated by an sc1 load + an sc1 write-through STORE of the new value instead of
+// an atomic delta -- no atomic unit involved, and an update of the same row that lands between this group's load and its store is
+// LOST (racy Hogwild).  Measured (tools/probe_item_rmw.py, profiles/r06_item_rmw.json): with P[u] by RMW the Yelp2018-shape epoch
+// takes 0.376 ms instead of 0.569 (0.64 of the roofline instead of 0.43) and the HBM-resident slice 15.3 ms instead of 20.9 (0.63
+// instead of 0.46); Q[j] by RMW as well adds 1 %.  What it costs is a function of the COLLISION DENSITY c = groups in flight x
+// sum_u p_u^2 (the expected number of other groups working on the same user while one holds it): c = 0.008 (650 k users): paired
+// Recall@20 gaps equal to the atomic kernel's; c = 0.033 (160 k users): inside the bar, visibly worse (0.0010 vs 0.0001); c = 0.17
+// (Yelp2018 shape): inside on the planted-community graph with a 10 % loss gap; lastfm under BPR.conf (1.9 k users): -0.019, far outside.
+// So the host selects it by c (engine.resolve_p_update: c <= 0.01), never by shape; bit 1 (Q[j]) is kept for measurements only.
+template <int LPR, int E, typename TAB, int RMW = 0>
 __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
     float *__restrict__ P, float *__restrict__ Q, int64_t p_bytes, int64_t q_bytes,
     const int32_t *__restrict__ u_idx, const int32_t *__restrict__ i_idx,
     const int32_t *__restrict__ j_idx, int64_t n, int chunk, int64_t n_chunks, int64_t chunk_stride,
-    int64_t groups_active, int flush_every, HwRate rate, double *__restrict__ loss_out, float *__restrict__ glog = nullptr,
-    int log_dot = 0, int64_t slot_lo = 0, int64_t slot_hi = -1) {
+    int64_t groups_active, int flush_every, HwRate rate, double *__restrict__ loss_out) {
     constexpr int GPW = kWave / LPR;
     float lr, cu, ci;
     if (!hw_rate_resolve(rate, lr, cu, ci)) return;
@@ -704,8 +709,7 @@ __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
     float loss = 0.f;
     double loss_acc = 0.0;
 
-    if (slot_hi < 0) slot_hi = n_chunks;       // a sub-epoch of the deferred schedule runs the time slots [slot_lo, slot_hi) only
-    for (int64_t slot = slot_lo + gid; slot < slot_hi && gid < groups_active; slot += groups_active) {
+    for (int64_t slot = gid; slot < n_chunks && gid < groups_active; slot += groups_active) {
         const int64_t c = (int64_t)(((unsigned __int128)slot * (unsigned __int128)chunk_stride) % (unsigned __int128)n_chunks);
         const int64_t t0 = c * chunk;
         const int len = (int)((n - t0) < chunk ? (n - t0) : chunk);
@@ -719,8 +723,10 @@ __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
 #pragma unroll
         for (int e = 0; e < E; e++) qi.v[e] = qi0.v[e] = 0.f;
         int ut = su[0], jt = sj[0];
-        Row<E> pu = hw_load_row<LPR, E, LD_PLAIN>(rsP, ut, r);
-        Row<E> qj = hw_load_row<LPR, E, LD_PLAIN>(rsQ, jt, r);
+        constexpr int LDP = (RMW & 1) ? LD_SC1 : LD_PLAIN, LDJ = (RMW & 2) ? LD_SC1 : LD_PLAIN;
+        constexpr int UPP = (RMW & 1) ? UP_STORE_SC1 : UP_ATOMIC, UPJ = (RMW & 2) ? UP_STORE_SC1 : UP_ATOMIC;
+        Row<E> pu = hw_load_row<LPR, E, LDP>(rsP, ut, r);
+        Row<E> qj = hw_load_row<LPR, E, LDJ>(rsQ, jt, r);
         for (int k = 0; k < len; k++) {
             const int it = si[k];
             if (it != cur_i || since_flush >= flush_every) {
@@ -733,8 +739,8 @@ __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
             const bool more = (k + 1 < len);
             if (more) {
                 un = su[k + 1]; jn = sj[k + 1];
-                npu = hw_load_row<LPR, E, LD_PLAIN>(rsP, un, r);
-                nqj = hw_load_row<LPR, E, LD_PLAIN>(rsQ, jn, r);
+                npu = hw_load_row<LPR, E, LDP>(rsP, un, r);
+                nqj = hw_load_row<LPR, E, LDJ>(rsQ, jn, r);
             }
             float di = 0.f, dj = 0.f;
 #pragma unroll
@@ -750,16 +756,15 @@ __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
                 qi.v[e] = a - ci * a; qjn.v[e] = b - ci * b;
                 pun.v[e] = p1 - cu * p1;
             }
-            hw_update_row<LPR, E, UP_ATOMIC>(rsP, ut, r, pu, pun);
-            if constexpr (DEFER) { if (r == 0) glog[t0 + k] = log_dot ? di : gsc; }
-            else hw_update_row<LPR, E, UP_ATOMIC>(rsQ, jt, r, qj, qjn);
+            hw_update_row<LPR, E, UPP>(rsP, ut, r, pu, pun);
+            hw_update_row<LPR, E, UPJ>(rsQ, jt, r, qj, qjn);
             loss += neg_log_sigmoid(di - dj);
             since_flush++;
             if (more) {   // rows this group just changed supersede the prefetched copy
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     if (un == ut) npu.v[e] = pun.v[e];
-                    if (!DEFER && jn == jt) nqj.v[e] = qjn.v[e]; else if (jn == cur_i) nqj.v[e] = qi.v[e];
+                    if (jn == jt) nqj.v[e] = qjn.v[e]; else if (jn == cur_i) nqj.v[e] = qi.v[e];
                 }
             }
             pu = npu; qj = nqj; ut = un; jt = jn;
@@ -774,281 +779,10 @@ __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
     if (lane == 0 && loss_acc != 0.0) atomicAdd(loss_out, loss_acc);
 }
 
-// ------------------------------------------------------------------------------------
-// Deferred negatives (round 3).  The item-major kernel is pinned to the memory-side atomic units: its epoch's atomic stream
-// ALONE (no loads, no arithmetic) takes 0.55 ms of its 0.57 (tools/ubench/atomics4.hip, profiles/r03_ubench_atomics4.txt) --
-// two atomic row updates per triplet (P[u], Q[j]), the third row (Q[i]) riding in registers along the item's run.  A triplet's
-// three rows cannot all ride in registers in ONE visiting order, but they can in two: pass A (item order) updates P[u] and
-// Q[i] and logs the triplet's coefficient g = lr (1 - sigma(x)); pass B (this kernel) walks the same triplets in j order
-// (a counting sort of the epoch's negatives, three small launches) with Q[j] in registers along j's run:
-//     Q[j] -= g P[u];  Q[j] -= lr regI Q[j]          (BPR.py:49, :52)
-// One atomic row update per triplet in pass A, one per run segment (~1/30 per triplet) here, one extra row read (P[u]).
-// What changes in the algorithm: within an epoch the negative-side updates of the item table are applied after the positive-
-// side ones, with the epoch-end P[u] -- a reordering of the same per-triplet terms (nothing is dropped, nothing is added),
-// larger than Hogwild's staleness and judged the same way: the properties in tests/test_gpu_bpr.py (one group = the sequential
-// statement of THIS order, conflict-free input exact, lr = 0 leaves the tables bit-identical) and the paired Recall@20 /
-// loss-trajectory runs against the order-exact CPU training.
-// ------------------------------------------------------------------------------------
-template <int LPR, int E, typename TAB>
-__global__ __launch_bounds__(256) void bpr_deferred_negatives_kernel(
-    float *__restrict__ P, float *__restrict__ Q, int64_t p_bytes, int64_t q_bytes, const int32_t *__restrict__ u_idx,
-    const int32_t *__restrict__ j_sorted, const float *__restrict__ glog, const int32_t *__restrict__ perm, int64_t n, int chunk,
-    int64_t n_chunks, int64_t groups_active, HwRate rate, int fresh, int64_t first = 0, int32_t j_mask = 0x7fffffff) {
-    // the sorted positions [first, first + n): a sub-epoch's triplets (the keys carry the sub-epoch above the item id: j_mask)
-    constexpr int GPW = kWave / LPR;
-    float lr, cu, ci;
-    if (!hw_rate_resolve(rate, lr, cu, ci)) return;
-    __shared__ int32_t s_idx[4][GPW][2][kMaxChunk];
-    __shared__ float s_g[4][GPW][kMaxChunk];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = lane / LPR, r = lane % LPR;
-    const int64_t gid = ((int64_t)blockIdx.x * 4 + wave) * GPW + g;
-    int32_t *su = s_idx[wave][g][0], *sj = s_idx[wave][g][1];
-    float *sg = s_g[wave][g];
-    const TAB rsP = TAB::make(P, p_bytes), rsQ = TAB::make(Q, q_bytes);
-    for (int64_t c = gid; c < n_chunks && gid < groups_active; c += groups_active) {
-        const int64_t p0 = c * chunk;
-        const int len = (int)((n - p0) < chunk ? (n - p0) : chunk);
-        for (int k = r; k < len; k += LPR) { const int32_t t = perm[first + p0 + k]; su[k] = u_idx[t]; sj[k] = j_sorted[first + p0 + k] & j_mask; sg[k] = glog[t]; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        int cur_j = -1;
-        Row<E> qj, qj0;
-#pragma unroll
-        for (int e = 0; e < E; e++) qj.v[e] = qj0.v[e] = 0.f;
-        Row<E> pu = hw_load_row<LPR, E, LD_PLAIN>(rsP, su[0], r);
-        for (int k = 0; k < len; k++) {
-            const int jt = sj[k];
-            if (jt != cur_j) {
-                if (cur_j >= 0) hw_update_row<LPR, E, UP_ATOMIC>(rsQ, cur_j, r, qj0, qj);
-                qj = hw_load_row<LPR, E, LD_SC1>(rsQ, jt, r);      // past L1: pass A's last flushes of this row (as a positive item)
-                qj0 = qj; cur_j = jt;
-            }
-            Row<E> npu = pu;
-            if (k + 1 < len) npu = hw_load_row<LPR, E, LD_PLAIN>(rsP, su[k + 1], r);
-            float gsc = sg[k];
-            if (fresh) {      // the log holds P[u].Q[i] as pass A saw it; the negative's side of x is formed HERE, against the row as this run left it
-                float dj = 0.f;
-#pragma unroll
-                for (int e = 0; e < E; e++) dj += pu.v[e] * qj.v[e];
-                dj = row_allreduce_sum<LPR>(dj);
-                gsc = lr * (1.0f - 1.0f / (1.0f + expf(-(gsc - dj))));
-            }
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-                const float b = qj.v[e] - gsc * pu.v[e];
-                qj.v[e] = b - ci * b;
-            }
-            pu = npu;
-        }
-        if (cur_j >= 0) hw_update_row<LPR, E, UP_ATOMIC>(rsQ, cur_j, r, qj0, qj);
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// the epoch's triplets in j order: a STABLE radix sort of (j, position) pairs over the bits the item ids use (rocPRIM, two 8-bit
-// passes at the Yelp2018 shape) -- inside a run the triplets keep their item-major order, so pass B is a deterministic function of
-// the sampled arrays.  (The first version was a counting sort whose fill used global atomics: 0.19 ms alone, 3x that when it ran
-// under pass A's atomic stream, and a run order that changed from launch to launch -- with lr regI m ~ 1e-2 over a run of m
-// terms that moved Q rows by 1e-3.)  A call of its own: the engine runs it on the sampler's side stream.
-struct DeferredWork {
-    float *glog; int32_t *perm; int32_t *jsorted; int32_t *keys; void *temp; size_t temp_bytes;
-};
-constexpr int kMaxSubEpochs = 16;
-static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
-static inline unsigned key_bits(int64_t n_keys) { unsigned b = 1; while (((int64_t)1 << b) < n_keys) b++; return b; }
-int deferred_temp_bytes(int64_t n, int64_t n_keys, size_t *bytes) {
-    // the query walks rocPRIM's config dispatch (device properties): once per shape, not once per epoch
-    static thread_local int64_t last_n = -1, last_keys = -1;
-    static thread_local size_t last_bytes = 0;
-    static thread_local int last_dev = -1;
-    int dev = 0;
-    QREC_HIP_CHECK(hipGetDevice(&dev));
-    if (n == last_n && n_keys == last_keys && dev == last_dev) { *bytes = last_bytes; return QREC_OK; }
-    size_t tb = 0;
-    const hipError_t e = rocprim::radix_sort_pairs(nullptr, tb, (const int32_t *)nullptr, (int32_t *)nullptr,
-                                                   rocprim::counting_iterator<int32_t>(0), (int32_t *)nullptr, (size_t)n, 0u,
-                                                   key_bits(n_keys), (hipStream_t)0);
-    QREC_REQUIRE(e == hipSuccess, "qrec_bpr_deferred: rocprim::radix_sort_pairs size query failed");
-    *bytes = align256(tb ? tb : 256);
-    last_n = n; last_keys = n_keys; last_bytes = *bytes; last_dev = dev;
-    return QREC_OK;
-}
-int deferred_carve(void *work, int64_t n, int64_t n_keys, DeferredWork *w) {
-    char *p = (char *)work;
-    w->glog = (float *)p; p += align256((size_t)n * 4);
-    w->perm = (int32_t *)p; p += align256((size_t)n * 4);
-    w->jsorted = (int32_t *)p; p += align256((size_t)n * 4);
-    w->keys = (int32_t *)p; p += align256((size_t)n * 4);
-    w->temp = p;
-    return deferred_temp_bytes(n, n_keys * kMaxSubEpochs, &w->temp_bytes);      // room for the sub-epoch bits above the item id
-}
-int sort_by_negative(const int32_t *j, int64_t n, int64_t n_keys, const DeferredWork &w, hipStream_t st) {
-    if (n == 0) return QREC_OK;
-    size_t tb = w.temp_bytes;
-    const hipError_t e = rocprim::radix_sort_pairs(w.temp, tb, j, w.jsorted, rocprim::counting_iterator<int32_t>(0), w.perm, (size_t)n,
-                                                   0u, key_bits(n_keys), st);
-    QREC_REQUIRE(e == hipSuccess, "qrec_bpr_deferred_sort: rocprim::radix_sort_pairs failed");
-    return QREC_OK;
-}
-
-// ---- sub-epochs (round 3): the epoch's time slots cut into S consecutive ranges; pass B of range s runs on a second stream under
-// pass A of range s + 1.  The negative item's row then lags the positive side by about one range instead of one epoch, and pass
-// B's time disappears under pass A's.  Sort key of triplet t = (sub-epoch of its chunk's time slot) above (its negative item).
-struct SubPlan {
-    int S; int64_t n_chunks, stride, inv; int bits_j;
-    int64_t slot_bound[kMaxSubEpochs + 1], first[kMaxSubEpochs + 1];
-};
-static int64_t chunk_stride_of(int64_t n_chunks) {
-    int64_t stride = (int64_t)((double)n_chunks * 0.6180339887498949);
-    if (stride < 1) stride = 1;
-    auto gcd = [](int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; };
-    while (gcd(stride, n_chunks) != 1) stride++;
-    return stride;
-}
-static SubPlan make_sub_plan(int64_t n, int chunk, int S, int64_t n_keys) {
-    SubPlan p{};
-    p.S = S; p.n_chunks = (n + chunk - 1) / chunk; p.stride = chunk_stride_of(p.n_chunks); p.bits_j = (int)key_bits(n_keys);
-    // inv = stride^-1 mod n_chunks (extended Euclid): the time slot of chunk c is c * inv mod n_chunks
-    int64_t a = p.stride % p.n_chunks, m = p.n_chunks, x0 = 1, x1 = 0;
-    while (m > 0 && a > 1) { const int64_t q = a / m, t = m; m = a % m; a = t; const int64_t tx = x1; x1 = x0 - q * x1; x0 = tx; }
-    p.inv = p.n_chunks == 1 ? 0 : ((x0 % p.n_chunks) + p.n_chunks) % p.n_chunks;
-    const int64_t last_len = n - (p.n_chunks - 1) * (int64_t)chunk;
-    const int64_t last_slot = (int64_t)(((unsigned __int128)(p.n_chunks - 1) * (unsigned __int128)p.inv) % (unsigned __int128)p.n_chunks);
-    p.first[0] = 0;
-    for (int s = 0; s <= S; s++) p.slot_bound[s] = ((int64_t)s * p.n_chunks + S - 1) / S;      // sub(slot) = slot * S / n_chunks
-    for (int s = 0; s < S; s++) {
-        int64_t cnt = (p.slot_bound[s + 1] - p.slot_bound[s]) * (int64_t)chunk;
-        if (last_slot >= p.slot_bound[s] && last_slot < p.slot_bound[s + 1]) cnt -= chunk - last_len;
-        p.first[s + 1] = p.first[s] + cnt;
-    }
-    return p;
-}
-__global__ void deferred_keys_kernel(const int32_t *__restrict__ j, int64_t n, int chunk, int64_t n_chunks, int64_t inv, int S, int bits_j,
-                                     int32_t *__restrict__ keys) {
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t c = t / chunk;
-        const int64_t slot = (int64_t)(((unsigned __int128)c * (unsigned __int128)inv) % (unsigned __int128)n_chunks);
-        const int32_t sub = (int32_t)((slot * S) / n_chunks);
-        keys[t] = (sub << bits_j) | j[t];
-    }
-}
-int sort_by_sub_and_negative(const int32_t *j, int64_t n, int64_t n_keys, int chunk, int S, const DeferredWork &w, hipStream_t st) {
-    if (n == 0) return QREC_OK;
-    const SubPlan p = make_sub_plan(n, chunk, S, n_keys);
-    int sub_bits = 0; while ((1 << sub_bits) < S) sub_bits++;
-    QREC_REQUIRE(p.bits_j + sub_bits <= 31, "qrec_bpr_deferred_sort_sub: item ids and sub-epochs do not fit a 31-bit key");
-    hipLaunchKernelGGL(deferred_keys_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, j, n, chunk, p.n_chunks,
-                       p.inv, S, p.bits_j, w.keys);
-    size_t tb = w.temp_bytes;
-    const hipError_t e = rocprim::radix_sort_pairs(w.temp, tb, (const int32_t *)w.keys, w.jsorted, rocprim::counting_iterator<int32_t>(0), w.perm,
-                                                   (size_t)n, 0u, (unsigned)(p.bits_j + sub_bits), st);
-    QREC_REQUIRE(e == hipSuccess, "qrec_bpr_deferred_sort_sub: rocprim::radix_sort_pairs failed");
-    QREC_LAUNCH_CHECK();
-    return QREC_OK;
-}
-
-template <int LPR, int E>
-int launch_hogwild_item_deferred_sub(float *P, float *Q, int64_t pb, int64_t qb, const int32_t *u, const int32_t *i, const int32_t *j,
-                                     int64_t n, int64_t n_keys, int chunk, int64_t groups, int flush_every, HwRate rate, double *loss,
-                                     const DeferredWork &w, bool sorted, int fresh, int S, hipStream_t st, hipStream_t st_b) {
-    constexpr int GPW = kWave / LPR;
-    const SubPlan p = make_sub_plan(n, chunk, S, n_keys);
-    const int64_t default_groups = (int64_t)1024 * 4 * GPW, max_groups = (int64_t)256 * 8 * 4 * GPW;
-    if (groups <= 0) groups = default_groups;
-    if (groups > max_groups) groups = max_groups;
-    if (!sorted) {
-        const int rc = sort_by_sub_and_negative(j, n, n_keys, chunk, S, w, st);
-        if (rc != QREC_OK) return rc;
-    }
-    // events of the current device (an event belongs to the device it was created on: a thread that drives several devices gets a set per device)
-    constexpr int kMaxDevices = 64;
-    static thread_local hipEvent_t ev_dev[kMaxDevices][kMaxSubEpochs + 2] = {};
-    int dev = 0;
-    QREC_HIP_CHECK(hipGetDevice(&dev));
-    QREC_REQUIRE(dev >= 0 && dev < kMaxDevices, "qrec_bpr_sgd_hogwild_item_major_deferred_sub: device ordinal %d out of range", dev);
-    hipEvent_t *ev = ev_dev[dev];
-    if (st_b && !ev[0])
-        for (int k = 0; k < kMaxSubEpochs + 2; k++) QREC_HIP_CHECK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
-    constexpr int kChunkB = 32;                      // pass B walks runs of equal j: its chunks need not be pass A's
-    const int32_t j_mask = (int32_t)((1u << p.bits_j) - 1);
-    if (st_b) {     // pass B's stream starts behind everything enqueued so far (the sort, the previous epoch)
-        QREC_HIP_CHECK(hipEventRecord(ev[kMaxSubEpochs + 1], st));
-        QREC_HIP_CHECK(hipStreamWaitEvent(st_b, ev[kMaxSubEpochs + 1], 0));
-    }
-    for (int s = 0; s < S; s++) {
-        const int64_t slots = p.slot_bound[s + 1] - p.slot_bound[s], cnt = p.first[s + 1] - p.first[s];
-        if (slots <= 0) continue;
-        const int64_t ga = std::min<int64_t>(groups, slots);
-        const unsigned blocks_a = (unsigned)((ga + 4 * GPW - 1) / (4 * GPW));
-        const int64_t chunks_b = (cnt + kChunkB - 1) / kChunkB, gb = std::min<int64_t>(groups, chunks_b);
-        const unsigned blocks_b = (unsigned)((gb + 4 * GPW - 1) / (4 * GPW));
-        hipStream_t sb = st_b ? st_b : st;
-        if (pb < kBufLimit && qb < kBufLimit) {
-            hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E, TabBuf, true>), dim3(blocks_a), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, chunk,
-                               p.n_chunks, p.stride, ga, flush_every, rate, loss, w.glog, fresh, p.slot_bound[s], p.slot_bound[s + 1]);
-            if (st_b) { QREC_HIP_CHECK(hipEventRecord(ev[s], st)); QREC_HIP_CHECK(hipStreamWaitEvent(st_b, ev[s], 0)); }
-            if (cnt > 0)
-                hipLaunchKernelGGL((bpr_deferred_negatives_kernel<LPR, E, TabBuf>), dim3(blocks_b), dim3(256), 0, sb, P, Q, pb, qb, u, w.jsorted, w.glog,
-                                   w.perm, cnt, kChunkB, chunks_b, gb, rate, fresh, p.first[s], j_mask);
-        } else {
-            hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E, TabPtr, true>), dim3(blocks_a), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, chunk,
-                               p.n_chunks, p.stride, ga, flush_every, rate, loss, w.glog, fresh, p.slot_bound[s], p.slot_bound[s + 1]);
-            if (st_b) { QREC_HIP_CHECK(hipEventRecord(ev[s], st)); QREC_HIP_CHECK(hipStreamWaitEvent(st_b, ev[s], 0)); }
-            if (cnt > 0)
-                hipLaunchKernelGGL((bpr_deferred_negatives_kernel<LPR, E, TabPtr>), dim3(blocks_b), dim3(256), 0, sb, P, Q, pb, qb, u, w.jsorted, w.glog,
-                                   w.perm, cnt, kChunkB, chunks_b, gb, rate, fresh, p.first[s], j_mask);
-        }
-    }
-    if (st_b) {     // the epoch is over when the last pass B is: the caller's stream waits for it
-        QREC_HIP_CHECK(hipEventRecord(ev[kMaxSubEpochs], st_b));
-        QREC_HIP_CHECK(hipStreamWaitEvent(st, ev[kMaxSubEpochs], 0));
-    }
-    QREC_LAUNCH_CHECK();
-    return QREC_OK;
-}
-
-template <int LPR, int E>
-int launch_hogwild_item_deferred(float *P, float *Q, int64_t pb, int64_t qb, const int32_t *u, const int32_t *i, const int32_t *j,
-                                 int64_t n, int64_t n_keys, int chunk, int64_t groups, int flush_every, HwRate rate, double *loss,
-                                 const DeferredWork &w, bool sorted, int fresh, hipStream_t st) {
-    constexpr int GPW = kWave / LPR;
-    const int64_t n_chunks = (n + chunk - 1) / chunk;
-    // fewer atomics per triplet: the passes lean on the row loads, which scale with the groups in flight (measured, atomics4.hip:
-    // 0.41 ms of loads at 256 blocks, 0.18 at 1024) -- four blocks per CU by default
-    const int64_t default_groups = (int64_t)1024 * 4 * GPW, max_groups = (int64_t)256 * 8 * 4 * GPW;
-    if (groups <= 0) groups = default_groups;
-    if (groups > max_groups) groups = max_groups;
-    if (groups > n_chunks) groups = n_chunks;
-    int64_t stride = (int64_t)((double)n_chunks * 0.6180339887498949);
-    if (stride < 1) stride = 1;
-    auto gcd = [](int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; };
-    while (gcd(stride, n_chunks) != 1) stride++;
-    const unsigned blocks = (unsigned)((groups + 4 * GPW - 1) / (4 * GPW));
-    if (!sorted) {
-        const int rc = sort_by_negative(j, n, n_keys, w, st);
-        if (rc != QREC_OK) return rc;
-    }
-    if (pb < kBufLimit && qb < kBufLimit) {
-        hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E, TabBuf, true>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, chunk,
-                           n_chunks, stride, groups, flush_every, rate, loss, w.glog, fresh);
-        hipLaunchKernelGGL((bpr_deferred_negatives_kernel<LPR, E, TabBuf>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, w.jsorted, w.glog, w.perm, n,
-                           chunk, n_chunks, groups, rate, fresh);
-    } else {
-        hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E, TabPtr, true>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, chunk,
-                           n_chunks, stride, groups, flush_every, rate, loss, w.glog, fresh);
-        hipLaunchKernelGGL((bpr_deferred_negatives_kernel<LPR, E, TabPtr>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, w.jsorted, w.glog, w.perm, n,
-                           chunk, n_chunks, groups, rate, fresh);
-    }
-    QREC_LAUNCH_CHECK();
-    return QREC_OK;
-}
-
 template <int LPR, int E>
 int launch_hogwild_item(float *P, float *Q, int64_t pb, int64_t qb, const int32_t *u, const int32_t *i,
                         const int32_t *j, int64_t n, int chunk, int64_t groups, int flush_every, HwRate rate,
-                        double *loss, hipStream_t st) {
+                        double *loss, int variant, hipStream_t st) {
     constexpr int GPW = kWave / LPR;
     const int64_t n_chunks = (n + chunk - 1) / chunk;
     const int64_t default_groups = (int64_t)256 * 4 * GPW, max_groups = (int64_t)256 * 8 * 4 * GPW;
@@ -1061,12 +795,23 @@ int launch_hogwild_item(float *P, float *Q, int64_t pb, int64_t qb, const int32_
     auto gcd = [](int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; };
     while (gcd(stride, n_chunks) != 1) stride++;
     const unsigned blocks = (unsigned)((groups + 4 * GPW - 1) / (4 * GPW));
-    if (pb < kBufLimit && qb < kBufLimit)
-        hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E, TabBuf>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, chunk,
-                           n_chunks, stride, groups, flush_every, rate, loss);
-    else
-        hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E, TabPtr>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, chunk,
-                           n_chunks, stride, groups, flush_every, rate, loss);
+#define QREC_ITEM_LAUNCH(RMW)                                                                                                     \
+    do {                                                                                                                          \
+        if (pb < kBufLimit && qb < kBufLimit)                                                                                     \
+            hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E, TabBuf, RMW>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, \
+                               chunk, n_chunks, stride, groups, flush_every, rate, loss);                                         \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E, TabPtr, RMW>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, \
+                               chunk, n_chunks, stride, groups, flush_every, rate, loss);                                         \
+    } while (0)
+    switch (variant) {
+        case QREC_HW_DEFAULT:
+        case QREC_HW_ATOMIC: QREC_ITEM_LAUNCH(0); break;
+        case QREC_HW_P_RMW: QREC_ITEM_LAUNCH(1); break;
+        case QREC_HW_PQ_RMW: QREC_ITEM_LAUNCH(3); break;
+        default: set_error("qrec_bpr_sgd_hogwild_item_major: unknown variant %d", variant); return QREC_ERR_INVALID;
+    }
+#undef QREC_ITEM_LAUNCH
     QREC_LAUNCH_CHECK();
     return QREC_OK;
 }
@@ -1291,7 +1036,7 @@ int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int64_t n_users, int
                                     const int32_t *d_u,
                                     const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
                                     int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
-                                    double *d_loss, const double *d_driver_state, void *stream) {
+                                    double *d_loss, int variant, const double *d_driver_state, void *stream) {
     QREC_REQUIRE(d_P && d_Q && d_loss && n >= 0, "qrec_bpr_sgd_hogwild_item_major: null argument");
     QREC_REQUIRE(n == 0 || (d_u && d_i && d_j), "qrec_bpr_sgd_hogwild_item_major: null index array");
     QREC_REQUIRE(ld >= d && d >= 1, "qrec_bpr_sgd_hogwild_item_major: need ld >= d >= 1");
@@ -1304,117 +1049,11 @@ int qrec_bpr_sgd_hogwild_item_major(float *d_P, float *d_Q, int64_t n_users, int
     hipStream_t st = as_stream(stream);
     const HwRate rate{lr, regU, regI, d_driver_state};
     switch (ld) {
-        case 32: return launch_hogwild_item<16, 2>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, st);
-        case 64: return launch_hogwild_item<16, 4>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, st);
-        case 128: return launch_hogwild_item<32, 4>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, st);
-        default: return launch_hogwild_item<64, 4>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, st);
+        case 32: return launch_hogwild_item<16, 2>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, variant, st);
+        case 64: return launch_hogwild_item<16, 4>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, variant, st);
+        case 128: return launch_hogwild_item<32, 4>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, variant, st);
+        default: return launch_hogwild_item<64, 4>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, chunk, grid_groups, flush_every, rate, d_loss, variant, st);
     }
-}
-
-int qrec_bpr_deferred_work_bytes(int64_t n, int64_t n_items, int64_t *bytes) {
-    QREC_REQUIRE(bytes && n >= 0 && n < (1ll << 31) && n_items >= 1 && n_items < (1ll << 31) - 2, "qrec_bpr_deferred_work_bytes: bad arguments");
-    // glog float[n] | perm int32[n] | j_sorted int32[n] | sort keys int32[n] (each rounded up to 256 bytes) | the radix sort's scratch
-    size_t tb = 0;
-    const int rc = deferred_temp_bytes(n, n_items * kMaxSubEpochs, &tb);
-    if (rc != QREC_OK) return rc;
-    *bytes = (int64_t)(4 * align256((size_t)n * 4) + tb);
-    return QREC_OK;
-}
-
-int qrec_bpr_deferred_sort(const int32_t *d_j, int64_t n, int64_t n_items, void *d_work, void *stream) {
-    QREC_REQUIRE(n >= 0 && n < (1ll << 31) && n_items >= 1 && n_items < (1ll << 31) - 2, "qrec_bpr_deferred_sort: bad sizes");
-    if (n == 0) return QREC_OK;
-    QREC_REQUIRE(d_j && d_work, "qrec_bpr_deferred_sort: null argument");
-    DeferredWork w;
-    const int rc = deferred_carve(d_work, n, n_items, &w);
-    if (rc != QREC_OK) return rc;
-    return sort_by_negative(d_j, n, n_items, w, as_stream(stream));
-}
-
-int qrec_bpr_sgd_hogwild_item_major_deferred(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld,
-                                             const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
-                                             int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
-                                             double *d_loss, const double *d_driver_state, void *d_work, int32_t flags,
-                                             void *stream) {
-    QREC_REQUIRE(d_P && d_Q && d_loss && n >= 0 && n < (1ll << 31), "qrec_bpr_sgd_hogwild_item_major_deferred: bad argument");
-    QREC_REQUIRE(n == 0 || (d_u && d_i && d_j && d_work), "qrec_bpr_sgd_hogwild_item_major_deferred: null array");
-    QREC_REQUIRE(ld >= d && d >= 1, "qrec_bpr_sgd_hogwild_item_major_deferred: need ld >= d >= 1");
-    QREC_REQUIRE(ld == 32 || ld == 64 || ld == 128 || ld == 256,
-                 "qrec_bpr_sgd_hogwild_item_major_deferred: row stride must be 32, 64, 128 or 256 floats (got ld=%d)", ld);
-    QREC_REQUIRE(chunk >= 1 && chunk <= kMaxChunk && flush_every >= 1, "qrec_bpr_sgd_hogwild_item_major_deferred: bad chunk / flush interval");
-    if (n == 0) return QREC_OK;
-    QREC_REQUIRE(n_users >= 1 && n_items >= 1 && n_items < (1ll << 31) - 2, "qrec_bpr_sgd_hogwild_item_major_deferred: table row counts must be given");
-    const int64_t full_p = n_users * (int64_t)ld * 4, full_q = n_items * (int64_t)ld * 4;
-    hipStream_t st = as_stream(stream);
-    const HwRate rate{lr, regU, regI, d_driver_state};
-    DeferredWork w;
-    const int rcw = deferred_carve(d_work, n, n_items, &w);
-    if (rcw != QREC_OK) return rcw;
-    const int fresh = (flags & QREC_DEFERRED_FRESH) ? 1 : 0;       // (an environment variable of the same name selected it in round 3: removed)
-    const int sorted = flags & QREC_DEFERRED_SORTED;
-#define QREC_DEF(LPR, E) launch_hogwild_item_deferred<LPR, E>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, n_items, chunk, grid_groups, \
-                                                               flush_every, rate, d_loss, w, sorted != 0, fresh, st)
-    switch (ld) {
-        case 32: return QREC_DEF(16, 2);
-        case 64: return QREC_DEF(16, 4);
-        case 128: return QREC_DEF(32, 4);
-        default: return QREC_DEF(64, 4);
-    }
-#undef QREC_DEF
-}
-
-int qrec_bpr_deferred_sub_plan(int64_t n, int64_t n_items, int32_t chunk, int32_t sub_epochs, int64_t *h_slot_bound, int64_t *h_first,
-                               int64_t *h_stride_inv) {
-    QREC_REQUIRE(n >= 1 && n < (1ll << 31) && n_items >= 1 && chunk >= 1 && chunk <= kMaxChunk && sub_epochs >= 1 && sub_epochs <= kMaxSubEpochs,
-                 "qrec_bpr_deferred_sub_plan: bad arguments");
-    QREC_REQUIRE(h_slot_bound && h_first && h_stride_inv, "qrec_bpr_deferred_sub_plan: null output");
-    const SubPlan p = make_sub_plan(n, chunk, sub_epochs, n_items);
-    for (int s = 0; s <= sub_epochs; s++) { h_slot_bound[s] = p.slot_bound[s]; h_first[s] = p.first[s]; }
-    h_stride_inv[0] = p.stride; h_stride_inv[1] = p.inv; h_stride_inv[2] = p.n_chunks;
-    return QREC_OK;
-}
-
-int qrec_bpr_deferred_sort_sub(const int32_t *d_j, int64_t n, int64_t n_items, int32_t chunk, int32_t sub_epochs, void *d_work, void *stream) {
-    QREC_REQUIRE(n >= 0 && n < (1ll << 31) && n_items >= 1 && n_items < (1ll << 31) - 2, "qrec_bpr_deferred_sort_sub: bad sizes");
-    QREC_REQUIRE(chunk >= 1 && chunk <= kMaxChunk && sub_epochs >= 1 && sub_epochs <= kMaxSubEpochs, "qrec_bpr_deferred_sort_sub: chunk in 1..%d, sub-epochs in 1..%d", kMaxChunk, kMaxSubEpochs);
-    if (n == 0) return QREC_OK;
-    QREC_REQUIRE(d_j && d_work, "qrec_bpr_deferred_sort_sub: null argument");
-    DeferredWork w;
-    const int rc = deferred_carve(d_work, n, n_items, &w);
-    if (rc != QREC_OK) return rc;
-    return sort_by_sub_and_negative(d_j, n, n_items, chunk, sub_epochs, w, as_stream(stream));
-}
-
-int qrec_bpr_sgd_hogwild_item_major_deferred_sub(float *d_P, float *d_Q, int64_t n_users, int64_t n_items, int32_t d, int32_t ld,
-                                                 const int32_t *d_u, const int32_t *d_i, const int32_t *d_j, int64_t n, int32_t chunk,
-                                                 int32_t grid_groups, int32_t flush_every, float lr, float regU, float regI,
-                                                 double *d_loss, const double *d_driver_state, void *d_work, int32_t flags,
-                                                 int32_t sub_epochs, void *stream_b, void *stream) {
-    QREC_REQUIRE(d_P && d_Q && d_loss && n >= 0 && n < (1ll << 31), "qrec_bpr_sgd_hogwild_item_major_deferred_sub: bad argument");
-    QREC_REQUIRE(n == 0 || (d_u && d_i && d_j && d_work), "qrec_bpr_sgd_hogwild_item_major_deferred_sub: null array");
-    QREC_REQUIRE(ld >= d && d >= 1, "qrec_bpr_sgd_hogwild_item_major_deferred_sub: need ld >= d >= 1");
-    QREC_REQUIRE(ld == 32 || ld == 64 || ld == 128 || ld == 256,
-                 "qrec_bpr_sgd_hogwild_item_major_deferred_sub: row stride must be 32, 64, 128 or 256 floats (got ld=%d)", ld);
-    QREC_REQUIRE(chunk >= 1 && chunk <= kMaxChunk && flush_every >= 1, "qrec_bpr_sgd_hogwild_item_major_deferred_sub: bad chunk / flush interval");
-    QREC_REQUIRE(sub_epochs >= 1 && sub_epochs <= kMaxSubEpochs, "qrec_bpr_sgd_hogwild_item_major_deferred_sub: sub-epochs in 1..%d", kMaxSubEpochs);
-    if (n == 0) return QREC_OK;
-    QREC_REQUIRE(n_users >= 1 && n_items >= 1 && n_items < (1ll << 31) - 2, "qrec_bpr_sgd_hogwild_item_major_deferred_sub: table row counts must be given");
-    const int64_t full_p = n_users * (int64_t)ld * 4, full_q = n_items * (int64_t)ld * 4;
-    const HwRate rate{lr, regU, regI, d_driver_state};
-    DeferredWork w;
-    const int rcw = deferred_carve(d_work, n, n_items, &w);
-    if (rcw != QREC_OK) return rcw;
-    const int fresh = (flags & QREC_DEFERRED_FRESH) ? 1 : 0;
-    const bool sorted = (flags & QREC_DEFERRED_SORTED) != 0;
-#define QREC_DEF(LPR, E) launch_hogwild_item_deferred_sub<LPR, E>(d_P, d_Q, full_p, full_q, d_u, d_i, d_j, n, n_items, chunk, grid_groups, flush_every, \
-                                                                   rate, d_loss, w, sorted, fresh, sub_epochs, as_stream(stream), as_stream(stream_b))
-    switch (ld) {
-        case 32: return QREC_DEF(16, 2);
-        case 64: return QREC_DEF(16, 4);
-        case 128: return QREC_DEF(32, 4);
-        default: return QREC_DEF(64, 4);
-    }
-#undef QREC_DEF
 }
 
 }  // extern "C"

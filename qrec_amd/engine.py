@@ -86,23 +86,51 @@ def balanced_chunk(n: int, groups: int = 4096, lo: int = 26, hi: int = 40, prefe
 # `auto` (QREC_SCHEDULE unset): which throughput schedule an epoch runs under -- ONE-PASS always: "item" when a few items collect most
 # interactions (their rows would take the per-triplet atomics of the user-major kernel), else "user" (measured 2.1 vs 1.6 G/s at the
 # Zipf-0.6 Yelp2018 shape).
-# The deferred-negatives schedule ("item-deferred": one atomic row update per triplet instead of two, 0.62 vs 0.47 of the roofline on tables
-# that live in HBM) is OPT-IN at every size since round 5.  Rounds 3-4 let `auto` pick it in four sub-epochs from 5 M triplets per epoch on,
-# on the evidence of a 6 M-triplet graph at d = 64 (peak-epoch gap 0.0003 / 0.0012).  Measured in round 5 at the size the 0.62 is quoted on
-# (25 M triplets per epoch, d = 128, planted-community graph, profiles/r05_auto_regime_25m.json): paired Recall@20 gap at the reference's
-# peak / at the last epoch 0.0032 / 0.0079 at BPR.conf's rate and 0.0050 / 0.0045 at five times it (8 sub-epochs: 0.0010 / 0.0032 and
-# 0.0028 / 0.0020) against 0.0008 / 0.0002 and 0.0010 / 0.0003 for the one-pass kernel -- outside the +-0.002 bar.  A negative item's row
-# lagging a quarter of an epoch is not free once the learning curve is steep.
+# (The two-pass "deferred negatives" schedule of rounds 3-5 -- one atomic row update per triplet, 0.62 of the roofline on tables that
+# live in HBM -- is gone: outside the +-0.002 Recall bar at the last epoch in every setting measured at the size that figure was quoted on,
+# profiles/r05_auto_regime_25m.json, r05_fresh_coefficient_25m.json.  Round 6 reaches the same 0.63 with ONE pass: resolve_p_update below.)
 
 
 def resolve_schedule(n_triplets: int, item_degrees=None, requested: str = "auto"):
-    """(schedule, sub_epochs or None) for ``BprSgd``; ``item_degrees``: positives per item (None = unknown: treated as skewed)"""
+    """(schedule, None) for ``BprSgd`` (the second entry was the deferred schedule's sub-epoch count, rounds 3-5); ``item_degrees``: positives per item (None = unknown: treated as skewed)"""
     if requested != "auto":
         return requested, None
     if item_degrees is None:
         return "item", None
     deg = np.asarray(item_degrees)
     return ("item" if deg.size and deg.max() > 20 * max(deg.mean(), 1e-9) else "user"), None
+
+
+# How P[u] is written by the item-major kernel (round 6).  "atomic": the exact per-sample delta through the L2 atomic units (two atomic
+# row updates per triplet: the kernel's bound, 0.43-0.46 of the HBM roofline).  "rmw": sc1 load + sc1 write-through store (QREC_HW_P_RMW,
+# include/qrec_hip.h) -- ONE atomic row update per triplet, 0.63-0.64 of the roofline; an update of the same user's row that lands between
+# another group's load and store is lost.  How many are: the collision density
+#     c = (groups in flight) x sum_u (n_u / n)^2         (expected number of other groups holding the same user while one does)
+# Measured, paired Recall@20 against order-exact training (profiles/r06_item_rmw.json; |gap| at the reference's peak / at the last epoch):
+#     c = 0.003 .. 0.008  (650 k users, 25 M triplets, d = 128)   rmw 0.0010 / 0.0002, 0.0011 / 0.0002   atomic 0.0008 / 0.0002, 0.0010 / 0.0003
+#     c = 0.033           (160 k users, 6 M triplets)              rmw 0.0010 / 0.0010, 0.0018 / 0.0003   atomic 0.0001 / 0.0001, 0.0015 / 0.0005
+#     c = 0.17            (Yelp2018 shape, 31.7 k users)           rmw 0.0005 / 0.0009 with a 10 % loss gap   atomic 0.0004 / 0.0000, loss gap 0.2 %
+#     c ~ 0.2 .. 2        (lastfm under BPR.conf, 1.9 k users)     rmw mean gap over 16 seeds -0.019 +- 0.001   atomic +0.0000 +- 0.0008
+# `auto` therefore takes "rmw" only where c <= P_RMW_MAX_COLLISION = 0.01 -- config #4's shape (10 M users: c = 0.0005), its single-GPU
+# slice (0.003), never the Yelp2018 shape, never the reference's own small datasets.
+P_RMW_MAX_COLLISION = 0.01
+DEFAULT_GROUPS = 4096
+
+
+def collision_density(user_counts, groups: int = DEFAULT_GROUPS) -> float:
+    """groups x sum_u (n_u / n)^2 for the triplets-per-user counts of an epoch"""
+    c = np.asarray(user_counts, dtype=np.float64)
+    n = float(c.sum())
+    return float(groups * np.square(c / n).sum()) if n > 0 else 0.0
+
+
+def resolve_p_update(user_counts, groups: int = DEFAULT_GROUPS, requested: str = "auto") -> str:
+    """"atomic" or "rmw" for the item-major kernel's P[u] updates; ``requested``: "auto" (by collision density), or one of the two"""
+    if requested in ("atomic", "rmw"):
+        return requested
+    if requested != "auto":
+        raise ValueError("p_update must be 'auto', 'atomic' or 'rmw'")
+    return "rmw" if collision_density(user_counts, groups) <= P_RMW_MAX_COLLISION else "atomic"
 
 
 MIN_ROUNDS = 8
@@ -167,8 +195,7 @@ class BprSgd:
 
     def __init__(self, tables: DeviceTables, u: np.ndarray, i: np.ndarray, pos: CSR | None = None,
                  schedule: str = "user", n_items: int | None = None, batches: int = 1, chunk: int = 32,
-                 sub_epochs: int | None = None, sub_chunk: int | None = None, overlap_passes: bool = True,
-                 item_run: int | None = None, fresh: bool = False):
+                 item_run: int | None = None, p_update: str = "atomic"):
         """``schedule``: "user" keeps the reference's user-major order (required by the order-exact
         kernel); "item" stores the same triplets sorted by positive item for the item-major
         throughput kernel (``self.perm`` maps scheduled position -> reference position).
@@ -178,27 +205,8 @@ class BprSgd:
         all batches exactly as the kernel's strided visiting order spreads them over a single launch (a batch of
         CONSECUTIVE item-sorted triplets would put all work on a hot row into one launch: measured, 16 % higher loss
         after 14 epochs on the ML-1M shape); batch starts stay multiples of ``chunk``, item runs stay intact."""
-        if schedule not in ("user", "item", "item-deferred"):
-            raise ValueError("schedule must be 'user', 'item' or 'item-deferred'")
-        # "item-deferred" (round 3): the item-major order with the negative-side updates applied by a second, j-ordered pass
-        # (qrec_bpr_sgd_hogwild_item_major_deferred); everything about the ORDER of the stored triplets is "item"
-        self.deferred = schedule == "item-deferred"
-        if self.deferred:
-            schedule = "item"
-        # sub-epochs of the deferred schedule (include/qrec_hip.h qrec_bpr_sgd_hogwild_item_major_deferred_sub): the epoch's time slots
-        # in S ranges, pass B of a range on a second stream under pass A of the next; pass A then runs on chunks of `sub_chunk`
-        # triplets (a range must still fill the grid a few times over), whatever chunk the epoch calls pass
-        self.sub_epochs = int(sub_epochs if sub_epochs is not None else 1) if self.deferred else 1
-        # (the longest chunk, 8 ... 32 triplets, with which a range still fills the 16,384-group grid four times over: measured at both
-        # ends, DESIGN.md s4 -- 32 at 6.25 M triplets per range is free, 8 at the Yelp2018 shape's 0.31 M is what a range needs to mean anything)
-        auto_chunk = max(8, min(32, (int(u.size) // max(self.sub_epochs, 1)) // (4 * 16384)))
-        self.sub_chunk = int(sub_chunk if sub_chunk is not None else auto_chunk)
-        self._overlap_passes = bool(overlap_passes)
-        # deferred schedule only: pass B re-forms every coefficient against the negative item's row as its j-run left it (the log then holds
-        # P[u].Q[i] instead of the coefficient; include/qrec_hip.h QREC_DEFERRED_FRESH) -- the negative-side terms of a row stop being computed
-        # all against the row as the (sub-)epoch found it
-        self.fresh = bool(fresh) and self.deferred
-        self._stream_b = None
+        if schedule not in ("user", "item"):
+            raise ValueError("schedule must be 'user' or 'item'")
         self.t = tables
         # size of the item catalogue the triplets' ids refer to: the table's rows, except when this process holds only a
         # row shard of the item table (qrec_amd/dist.py) and the ids are global
@@ -211,7 +219,13 @@ class BprSgd:
         self.batch_groups = 4096
         # ONE launch per epoch: at least MIN_ROUNDS rounds of the grid whatever the epoch's size (grid_for_epoch); `launch_grid()` is what
         # the epoch drivers pass to the kernels
-        self._epoch_grid = grid_for_epoch(self.n, self.chunk) if (max(1, int(batches)) == 1 and schedule != "item-deferred") else (self.chunk, 0)
+        self._epoch_grid = grid_for_epoch(self.n, self.chunk) if max(1, int(batches)) == 1 else (self.chunk, 0)
+        # item-major only: how P[u] is written (resolve_p_update above; "auto" decides by the collision density of THESE triplets under the
+        # launcher's default grid).  Explicit "atomic" is the constructor's default: callers opt in to "auto" (the drop-in BPR class and
+        # bench.py do), so that a test or a measurement never changes kernels behind the caller's back.
+        self.collision = collision_density(np.bincount(np.asarray(u), minlength=1)) if self.n else 0.0
+        self.p_update = resolve_p_update(np.bincount(np.asarray(u), minlength=1) if self.n else [], requested=p_update) if schedule == "item" else "atomic"
+        self.item_variant = capi.HW_P_RMW if self.p_update == "rmw" else capi.HW_DEFAULT
         self.perm = None
         u = np.ascontiguousarray(u, dtype=np.int32); i = np.ascontiguousarray(i, dtype=np.int32)
         batches = max(1, int(batches))
@@ -247,10 +261,6 @@ class BprSgd:
         self.d_u = DeviceBuffer.from_numpy(u)
         self.d_i = DeviceBuffer.from_numpy(i)
         self.d_j = DeviceBuffer(max(self.n, 1), np.int32)
-        # deferred negatives: per negatives buffer a work area {coefficient log, j order, counters}; `_sorted`: the j order of the
-        # current negatives is already in d_work (computed next to the sampler, on its side stream)
-        self.d_work = DeviceBuffer(capi.bpr_deferred_work_bytes(self.n, self.n_items), np.uint8) if self.deferred else None
-        self.d_work_next, self._sorted = None, False
         self.d_j_next = None
         self.d_stats = DeviceBuffer.zeros(capi.STATS_WORDS, np.float64)
         self.d_loss = self.d_stats          # element 0
@@ -271,7 +281,7 @@ class BprSgd:
         """(chunk, groups) for the whole-epoch launch of the one-pass schedules (groups 0 = the launcher's default grid)"""
         if min_rounds is None:
             return self._epoch_grid
-        return grid_for_epoch(self.n, self.chunk, min_rounds) if len(self.batch_bounds) == 2 and not self.deferred else (self.chunk, 0)
+        return grid_for_epoch(self.n, self.chunk, min_rounds) if len(self.batch_bounds) == 2 else (self.chunk, 0)
 
     # -- negatives ---------------------------------------------------------------------------
     def set_negatives(self, j: np.ndarray, stream=None):
@@ -281,7 +291,6 @@ class BprSgd:
             j = np.ascontiguousarray(j[self.perm])
         self.h_j = j
         self.d_j.upload(j, stream)
-        self._sorted = False
 
     def negatives_reference_order(self) -> np.ndarray:
         """current negatives as a host array in the reference's triplet order"""
@@ -296,7 +305,6 @@ class BprSgd:
             raise RuntimeError("BprSgd was built without the positives CSR")
         capi.philox_bpr_sample(self._pos_dev[0], self._pos_dev[1], self.d_u, self.n, self.n_items,
                                seed, epoch, self.d_j, stream)
-        self._sorted = False
 
     def prefetch_negatives_device(self, seed: int, epoch: int):
         """Enqueue the sampler for `epoch` on the side stream into the spare buffer."""
@@ -305,38 +313,14 @@ class BprSgd:
         if self._side is None:
             self._side = capi.Stream(); self._sampled = capi.Event()
             self.d_j_next = DeviceBuffer(max(self.n, 1), np.int32)
-            if self.deferred:
-                self.d_work_next = DeviceBuffer(capi.bpr_deferred_work_bytes(self.n, self.n_items), np.uint8)
         if self._consumed[1] is not None:      # the spare buffer may still be read by an enqueued SGD kernel
             capi.stream_wait_event(self._side, self._consumed[1])
         if self._sgd_start is not None:
             capi.stream_wait_event(self._side, self._sgd_start)
         capi.philox_bpr_sample(self._pos_dev[0], self._pos_dev[1], self.d_u, self.n, self.n_items,
                                seed, epoch, self.d_j_next, self._side)
-        if self.deferred:        # the j order of these negatives, next to the sampler: both run under the current epoch's kernels
-            self._sort_negatives(self.d_j_next, self.d_work_next, self._side)
         self._sampled.record(self._side)
         self._prefetched_epoch = epoch
-
-    def _sort_negatives(self, d_j, d_work, stream):
-        if self.sub_epochs > 1:
-            capi.bpr_deferred_sort_sub(d_j, self.n, self.n_items, self.sub_chunk, self.sub_epochs, d_work, stream)
-        else:
-            capi.bpr_deferred_sort(d_j, self.n, self.n_items, d_work, stream)
-
-    def _deferred_epoch(self, P, Q, d_u, d_i, d_j, n, chunk, groups, flush_every, lr, regU, regI, stream, d_drv=None, p_rows=None):
-        """both passes of the deferred schedule (all sub-epochs) on (P, Q)"""
-        t = self.t
-        if self.sub_epochs > 1:
-            if self._overlap_passes and self._stream_b is None:
-                self._stream_b = capi.Stream()
-            capi.bpr_sgd_hogwild_item_major_deferred_sub(P, Q, t.d, t.ld, d_u, d_i, d_j, n, self.sub_chunk, groups, min(flush_every, self.sub_chunk),
-                                                         lr, regU, regI, self.d_stats, self.d_work, self.sub_epochs, stream,
-                                                         self._stream_b if self._overlap_passes else None, d_drv, p_rows=p_rows,
-                                                         is_sorted=self._sorted, fresh=self.fresh)
-        else:
-            capi.bpr_sgd_hogwild_item_major_deferred(P, Q, t.d, t.ld, d_u, d_i, d_j, n, chunk, groups, flush_every, lr, regU, regI,
-                                                     self.d_stats, self.d_work, stream, d_drv, p_rows=p_rows, is_sorted=self._sorted, fresh=self.fresh)
 
     def take_prefetched_negatives(self, epoch: int, stream=None):
         """Make `stream` wait for the prefetched negatives of `epoch` and switch to them."""
@@ -344,8 +328,6 @@ class BprSgd:
             raise RuntimeError(f"negatives of epoch {epoch} were not prefetched")
         capi.stream_wait_event(stream, self._sampled)
         self.d_j, self.d_j_next = self.d_j_next, self.d_j
-        if self.deferred:
-            self.d_work, self.d_work_next, self._sorted = self.d_work_next, self.d_work, True
         self._consumed.reverse()
         self._prefetched_epoch = None
 
@@ -450,11 +432,9 @@ class BprSgd:
         if self.t.dtype != np.float32:
             raise TypeError("throughput mode needs fp32 tables")
         capi.memset(self.d_stats.ptr, 0, 8, stream)
-        if self.deferred:
-            self._deferred_epoch(self.t.P, self.t.Q, self.d_u, self.d_i, self.d_j, self.n, chunk, groups, flush_every, lr, regU, regI, stream)
-        elif self.schedule == "item":
+        if self.schedule == "item":
             capi.bpr_sgd_hogwild_item_major(self.t.P, self.t.Q, self.t.d, self.t.ld, self.d_u, self.d_i, self.d_j,
-                                            self.n, chunk, groups, flush_every, lr, regU, regI, self.d_stats, stream)
+                                            self.n, chunk, groups, flush_every, lr, regU, regI, self.d_stats, stream, variant=self.item_variant)
         else:
             capi.bpr_sgd_hogwild(self.t.P, self.t.Q, self.t.d, self.t.ld, self.d_u, self.d_i, self.d_j,
                                  self.n, chunk, groups, lr, regU, regI, self.d_stats, variant, stream)
@@ -513,16 +493,9 @@ class BprSgd:
                 # data with structure (tools/paired_recall.py, profiles/r04_paired_recall.json) the summed stale deltas overshoot
                 # and training diverges at five times BPR.conf's rate.  Batch b = the b-th range of the stored order (item-major:
                 # chunks dealt round-robin, so every batch sees every hot item); the last batch's sync is the fused epoch close.
-                # (the deferred schedule, round 4: every batch is ONE unit of it -- pass A over the batch, the batch's negatives sorted by j on
-                # this stream, pass B -- so the negative item's row lags by a batch, 1 / K of an epoch: finer than the four sub-epochs of the
-                # single-GPU form.  The sort is not prefetched here: ~5 % of a 3 M-triplet batch.)
                 for b in range(K):
                     t0, nb = self.batch_bounds[b], self.batch_bounds[b + 1] - self.batch_bounds[b]
-                    if nb and self.deferred:
-                        capi.bpr_sgd_hogwild_item_major_deferred(t.P, t.Q, t.d, t.ld, self.d_u.ptr + 4 * t0, self.d_i.ptr + 4 * t0, self.d_j.ptr + 4 * t0, nb,
-                                                                 launch_chunk(nb, chunk, groups=16384), groups, flush_every, 0.0, regU, regI, self.d_stats,
-                                                                 self.d_work, stream, self.d_drv, p_rows=t.n_users, is_sorted=False)
-                    elif nb:
+                    if nb:
                         bg = self.batch_groups
                         self._launch_sgd(t.P, t.Q, self.d_u.ptr + 4 * t0, self.d_i.ptr + 4 * t0, self.d_j.ptr + 4 * t0, nb, launch_chunk(nb, chunk, groups=bg),
                                          groups if groups else (bg if bg != 4096 else 0), flush_every, regU, regI, variant, stream)
@@ -557,11 +530,9 @@ class BprSgd:
         """the throughput kernel of the schedule on (P, Q) -- Q is the item table, or a shard's row cache with the
         triplets' item ids rewritten to its rows; learning rate and stop flags come from the device-side driver"""
         t = self.t
-        if self.deferred and q_rows is None:         # (a shard's row cache -- q_rows given -- keeps the one-pass kernel: its ids are cache slots)
-            self._deferred_epoch(P, Q, d_u, d_i, d_j, n, chunk, groups, flush_every, 0.0, regU, regI, stream, self.d_drv, p_rows=t.n_users)
-        elif self.schedule == "item":
+        if self.schedule == "item":
             capi.bpr_sgd_hogwild_item_major(P, Q, t.d, t.ld, d_u, d_i, d_j, n, chunk, groups, flush_every, 0.0, regU, regI,
-                                            self.d_stats, stream, self.d_drv, p_rows=t.n_users, q_rows=q_rows)
+                                            self.d_stats, stream, self.d_drv, p_rows=t.n_users, q_rows=q_rows, variant=self.item_variant)
         else:
             capi.bpr_sgd_hogwild(P, Q, t.d, t.ld, d_u, d_i, d_j, n, chunk, groups, 0.0, regU, regI, self.d_stats, variant,
                                  stream, self.d_drv, p_rows=t.n_users, q_rows=q_rows)

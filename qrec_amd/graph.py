@@ -90,6 +90,71 @@ def sample_subgraph_edges(state625: np.ndarray, uid: np.ndarray, iid: np.ndarray
     raise ValueError("aug_type must be 0 (node dropout), 1 (edge dropout) or 2 (random walk)")
 
 
+class SubgraphSampler:
+    """Per-epoch graph augmentation on the device (SGL.py:113-155, BUIR.py:41-65; the throughput mode of SGL and BUIR, csrc/augment.hip):
+    a sub-graph is a VALUE array over the full graph's CSR structure, so the full graph's SpMM plan serves every sub-graph
+    (``SpmmPlan.with_values``) and nothing is rebuilt.  Host work, once: where each training row's two entries sit in the CSR, the row of
+    every CSR entry, numpy's own float32 power(k, -0.5) table.  Per draw: one device permutation (the exact-size random subset of
+    random.sample, from the throughput mode's Philox stream) + two small kernels.
+
+    ``draw(aug_type, drop_rate, seed, stream_id)`` -> DeviceBuffer float32[nnz]; the stream is a function of (seed, stream_id) alone:
+      aug 1 / 2 (edge dropout / random walk): kept rows = the first int(E (1 - rate)) entries of permutation(E; seed, stream_id)
+      aug 0 (node dropout): dropped users = the first int(U rate) entries of permutation(U; seed, stream_id), dropped items = the first
+                            int(I rate) of permutation(I; seed, stream_id + 1)."""
+
+    def __init__(self, n_users: int, n_items: int, uid: np.ndarray, iid: np.ndarray, adj):
+        indptr, indices, _ = adj
+        self.nu, self.ni, self.n = int(n_users), int(n_items), int(n_users + n_items)
+        self.n_edges, self.nnz = int(uid.size), int(indices.size)
+        if self.nnz >= 2 ** 31 or self.n_edges >= 2 ** 31:
+            raise ValueError("SubgraphSampler: 32-bit CSR positions")
+        uid = np.asarray(uid, np.int64); iid = np.asarray(iid, np.int64)
+        row_of = np.repeat(np.arange(self.n, dtype=np.int64), np.diff(indptr))
+        csr_keys = row_of * self.n + indices                                    # ascending: rows ascending, columns ascending inside a row
+        pos_ui = np.searchsorted(csr_keys, uid * self.n + (iid + self.nu))
+        pos_iu = np.searchsorted(csr_keys, (iid + self.nu) * self.n + uid)
+        assert np.array_equal(csr_keys[pos_ui], uid * self.n + iid + self.nu) and np.array_equal(csr_keys[pos_iu], (iid + self.nu) * self.n + uid)
+        self.max_deg = int(np.bincount(np.concatenate([uid, iid + self.nu]), minlength=self.n).max()) if self.n_edges else 0
+        with np.errstate(divide="ignore"):
+            dinv = np.power(np.arange(self.max_deg + 1, dtype=np.float32), -0.5)  # float32 ** python float -> float32: the reference's d_inv
+        dinv[np.isinf(dinv)] = 0.0
+        up = DeviceBuffer.from_numpy
+        self.d_u, self.d_i = up(uid.astype(np.int32)), up(iid.astype(np.int32))
+        self.d_pos_ui, self.d_pos_iu = up(pos_ui.astype(np.int32)), up(pos_iu.astype(np.int32))
+        self.d_row_of, self.d_indices, self.d_dinv = up(row_of.astype(np.int32)), up(np.asarray(indices, np.int32)), up(dinv.astype(np.float32))
+        self.d_cnt, self.d_deg = DeviceBuffer(max(self.nnz, 1), np.int32), DeviceBuffer(max(self.n, 1), np.int32)
+        self.d_flags = DeviceBuffer(max(self.n, 1), np.uint8)
+        m = max(self.n_edges, self.nu, self.ni, 1)
+        self.scratch = DeviceBuffer(capi.random_permutations_scratch_bytes(m, 1), np.uint8)
+        self.d_perm, self.d_perm2 = DeviceBuffer(m, np.int32), DeviceBuffer(max(self.ni, 1), np.int32)
+
+    def sizes(self, aug_type: int, drop_rate: float):
+        """(kept rows) for edge dropout / random walk, (dropped users, dropped items) for node dropout: SGL.py:118-130's int() truncations"""
+        if aug_type == 0:
+            return int(self.nu * drop_rate), int(self.ni * drop_rate)
+        return (int(self.n_edges * (1 - drop_rate)),)
+
+    def draw(self, aug_type: int, drop_rate: float, seed: int, stream_id: int, out: DeviceBuffer | None = None, stream=None) -> DeviceBuffer:
+        out = out if out is not None else DeviceBuffer(max(self.nnz, 1), np.float32)
+        common = (self.d_u, self.d_i, self.d_pos_ui, self.d_pos_iu, self.n_edges, self.nu, self.ni, self.d_row_of, self.d_indices, self.nnz,
+                  self.d_dinv, self.max_deg, self.d_cnt, self.d_deg, out)
+        if drop_rate <= 0:
+            capi.subgraph_values(*common, stream=stream)
+        elif aug_type == 0:
+            ku, ki = self.sizes(0, drop_rate)
+            capi.random_permutations(self.nu, 1, seed, stream_id, self.scratch, self.d_perm, None, stream)
+            capi.random_permutations(self.ni, 1, seed, stream_id + 1, self.scratch, self.d_perm2, None, stream)
+            capi.subgraph_values(*common, d_drop_users=self.d_perm, n_drop_users=ku, d_drop_items=self.d_perm2, n_drop_items=ki,
+                                 d_flags=self.d_flags, stream=stream)
+        elif aug_type in (1, 2):
+            (k,) = self.sizes(aug_type, drop_rate)
+            capi.random_permutations(self.n_edges, 1, seed, stream_id, self.scratch, self.d_perm, None, stream)
+            capi.subgraph_values(*common, d_keep_rows=self.d_perm, n_keep=k, stream=stream)
+        else:
+            raise ValueError("aug_type must be 0 (node dropout), 1 (edge dropout) or 2 (random walk)")
+        return out
+
+
 def spectral_row_key(indptr: np.ndarray, indices: np.ndarray, values: np.ndarray, split_row: int, n_iter: int = 12,
                      seed: int = 0) -> np.ndarray:
     """A 1-D embedding of the nodes of a bipartite, symmetrically normalised adjacency in which the nodes of one community
@@ -180,6 +245,16 @@ class SpmmPlan:
         self.long_count = up(long_count) if self.n_long else None
         self.partial = DeviceBuffer((max(int(is_long.sum()), 1), ld), np.float32)
         self.indices, self.values = up(indices.astype(np.int32)), up(values.astype(np.float32))
+
+    def with_values(self, d_values: DeviceBuffer) -> "SpmmPlan":
+        """this plan's structure (segments, XCD dealing, index array -- shared, not copied) over another value array: a sub-graph of
+        the same graph drawn on the device (SubgraphSampler), dropped entries 0"""
+        import copy
+        if int(np.prod(d_values.shape)) < max(self.nnz, 1):
+            raise ValueError("with_values: value array shorter than the plan's non-zeros")
+        p = copy.copy(self)
+        p.values = d_values
+        return p
 
     @staticmethod
     def _row_chunks(indptr, indices, values, split_row: int, chunks: int) -> np.ndarray:
@@ -1239,6 +1314,15 @@ class SGLTrainer:
             return [SpmmPlan(a[0], a[1], a[2], self.ld, split_row=self.nu, row_chunk=self.main_plan.row_chunk) for a in adjs]
         self.plans = [plans(adjs1), plans(adjs2)]
 
+    def set_subgraph_values(self, vals1, vals2):
+        """device-drawn sub-graphs (SubgraphSampler.draw over THIS trainer's full graph): one value array per view, or a list of L"""
+        def plans(vals):
+            if isinstance(vals, DeviceBuffer):
+                return [self.main_plan.with_values(vals)] * self.L
+            assert len(vals) == self.L
+            return [self.main_plan.with_values(v) for v in vals]
+        self.plans = [plans(vals1), plans(vals2)]
+
     def _view_plans(self, v):
         return [self.main_plan] * self.L if v == 0 else self.plans[v - 1]
 
@@ -1362,6 +1446,14 @@ class BUIRTrainer:
         self.plan_o = SpmmPlan(adj_o[0], adj_o[1], adj_o[2], self.ld, split_row=self.nu, row_chunk=getattr(self, "_row_chunk", None))
         self._row_chunk = self.plan_o.row_chunk
         self.plan_t = SpmmPlan(adj_t[0], adj_t[1], adj_t[2], self.ld, split_row=self.nu, row_chunk=self._row_chunk)
+
+    def set_full_graph(self, adj):
+        """throughput mode: the plan of the FULL graph, whose structure every device-drawn sub-graph reuses (set_subgraph_values)"""
+        self.full_plan = SpmmPlan(adj[0], adj[1], adj[2], self.ld, split_row=self.nu)
+        self._row_chunk = self.full_plan.row_chunk
+
+    def set_subgraph_values(self, vals_o: DeviceBuffer, vals_t: DeviceBuffer):
+        self.plan_o, self.plan_t = self.full_plan.with_values(vals_o), self.full_plan.with_values(vals_t)
 
     def _mean_sum(self, plan, X, S, stream=None, last_rows=None):
         """S = X + A X + ... + A^L X (the mean's 1/(L+1) is applied where S is used)"""

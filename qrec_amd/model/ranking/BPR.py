@@ -15,9 +15,10 @@ Two execution modes, chosen by the optional conf key ``qrec.mode`` or env ``QREC
     reference's user-major visiting order): item-major wins when a few items collect most interactions (their rows
     would take the per-triplet atomics), user-major when popularity is flat (measured: 2.1 vs 1.6 G/s at the
     Zipf-0.6 Yelp2018 shape, 1.16 vs 1.21 G/s on a uniform 1 M-item catalogue); ``auto`` looks at max/mean item degree.
-    ``item-deferred``: item-major with the negative-side updates applied by a second, j-ordered pass (one atomic row update per
-    triplet instead of two: 0.62 vs 0.47 of the roofline on tables that live in HBM).  OPT-IN at every size since round 5: at the size that
-    figure is quoted on its paired Recall@20 gap is 0.003-0.008 (engine.resolve_schedule's comment, profiles/r05_auto_regime_25m.json).
+    ``QREC_P_UPDATE=auto`` (default), ``atomic`` or ``rmw`` (item-major only): how a user's row is written -- an atomic delta, or an
+    sc1 load + store (one atomic row update per triplet instead of two: 0.63 vs 0.46 of the roofline on tables that live in HBM) that
+    loses an update when two groups hold the same user at once; ``auto`` takes it only where that is rare (collision density
+    <= 0.01: engine.resolve_p_update and the measurements in its comment) -- never at the reference's own dataset sizes.
 """
 from __future__ import annotations
 
@@ -46,8 +47,12 @@ class BPR(IterativeRecommender):
         self.table_dtype = np.float64 if (dt == "f64" and mode == "exact") else np.float32
         self.sampler_seed = int(os.environ.get("QREC_SEED", "0"))
         self.schedule = os.environ.get("QREC_SCHEDULE", "auto") if mode == "throughput" else "user"
-        if self.schedule not in ("auto", "item", "user", "item-deferred"):
-            print("QREC_SCHEDULE must be auto, item, user or item-deferred")
+        if self.schedule not in ("auto", "item", "user"):
+            print("QREC_SCHEDULE must be auto, item or user")
+            raise SystemExit(-1)
+        self.p_update = os.environ.get("QREC_P_UPDATE", "auto") if mode == "throughput" else "atomic"
+        if self.p_update not in ("auto", "atomic", "rmw"):
+            print("QREC_P_UPDATE must be auto, atomic or rmw")
             raise SystemExit(-1)
 
     def initModel(self):
@@ -68,7 +73,7 @@ class BPR(IterativeRecommender):
             self.sampler_seed += 7919 * dp.rank
         print("training...")
         from ...engine import resolve_schedule
-        schedule, sub_epochs = resolve_schedule(int(u.size), np.bincount(i, minlength=len(self.data.item)), self.schedule)
+        schedule, _ = resolve_schedule(int(u.size), np.bincount(i, minlength=len(self.data.item)), self.schedule)
         n_items = len(self.data.item)
         layout = os.environ.get("QREC_DIST_MODE", "replicated")
         if layout not in ("replicated", "sharded"):
@@ -82,19 +87,10 @@ class BPR(IterativeRecommender):
         # 2 beyond -- dist.reconciliations_per_epoch: with ONE per epoch the paired Recall@20 runs leave the +-0.002 bar at 4 and 8 ranks)
         from ...dist import reconciliations_per_epoch
         syncs = reconciliations_per_epoch(dp.world, int(os.environ.get("QREC_REPLICATED_SYNCS", "0"))) if dp is not None else 1
-        if syncs > 1 and schedule == "item-deferred":
-            if self.schedule == "auto":
-                # several ranks: `auto` stays with the one-pass kernel.  The deferred schedule CAN run inside the reconciliation batches (every
-                # batch one unit of it: QREC_SCHEDULE=item-deferred; 22.4 against 26.7 ms per epoch on one rank's share of config #4, links
-                # excluded, profiles/r04_config4_rank_share.jsonl), but its paired Recall runs at N > 1 are not better than the one-pass
-                # kernel's (0.0006 / 0.0028 at 4 ranks, 0.0022 on the 6 M-triplet graph at 2) and the evidence is three runs
-                schedule, sub_epochs = "item", None
-            else:
-                sub_epochs = 1      # every reconciliation batch is one unit of the deferred schedule (engine.epoch_device_async): no sub-epochs inside
         # the chunk the epoch is LAUNCHED with is the chunk the item-major list is dealt to the reconciliation batches in (the
         # constructor's default 32 against balanced_chunk's 26..40 at launch left launch chunks straddling the dealt ones)
         from ...engine import balanced_chunk
-        sgd = BprSgd(tables, u, i, pos, schedule=schedule, sub_epochs=sub_epochs, batches=syncs, chunk=balanced_chunk(int(u.size)))
+        sgd = BprSgd(tables, u, i, pos, schedule=schedule, batches=syncs, chunk=balanced_chunk(int(u.size)), p_update=self.p_update)
         epoch = 0
         if self.mode == "throughput" and (self.ranking.isMainOn() or dp is not None):
             self._train_throughput_pipelined(sgd, dp=dp)
@@ -175,8 +171,7 @@ class BPR(IterativeRecommender):
         from ...dist import reconciliations_per_epoch
         n_batches = agree_on_batches(dp.control, int(u.size), 1 << 20, split_from=1 << 19,
                                      min_batches=reconciliations_per_epoch(G, int(os.environ.get("QREC_REPLICATED_SYNCS", "0"))))
-        sgd = BprSgd(tables, u, li, CSR(lp, li), schedule="item" if schedule == "item-deferred" else schedule, n_items=n_items,
-                     batches=n_batches, chunk=chunk)
+        sgd = BprSgd(tables, u, li, CSR(lp, li), schedule=schedule, n_items=n_items, batches=n_batches, chunk=chunk, p_update=self.p_update)
         step = ShardedStep(dp.comm, ShardedItemExchange(dp.comm, n_items, tables.ld, tables.Q), n_batches)
         self._train_throughput_pipelined(sgd, dp=dp, step=step)
         P_loc, Q_loc = tables.download(np.float64)

@@ -12,7 +12,7 @@ import numpy as np
 from ... import capi
 from ...base.deepRecommender import DeepRecommender
 from ...capi import DeviceBuffer
-from ...graph import BUIRTrainer, joint_norm_adjacency, sample_subgraph_edges
+from ...graph import BUIRTrainer, SubgraphSampler, joint_norm_adjacency, sample_subgraph_edges
 from ...util import config
 
 
@@ -41,6 +41,14 @@ class BUIR(DeepRecommender):
         self.online_mat, self.online_bias = _xavier((d, d), rng), _xavier((1, d), rng)          # BUIR.py:81-82
         U0, V0 = _xavier((self.num_users, d), rng), _xavier((self.num_items, d), rng)            # BUIR.py:83-84
         self.trainer = self.build_trainer(BUIRTrainer, U0, V0, self.online_mat, self.online_bias, self.n_layers, self.lRate, self.tau)
+        self.sampler = None
+        if self.throughput_mode():
+            # the epoch's two edge-dropped sub-graphs are drawn on the device as value arrays over the FULL graph's plan
+            # (qrec_amd.graph.SubgraphSampler, csrc/augment.hip); the batch stream too (base/deepRecommender.py)
+            uid, iid, _ = self.data.training_arrays()
+            adj = self.get_adj_mat()
+            self.trainer.set_full_graph(adj)
+            self.sampler = SubgraphSampler(self.num_users, self.num_items, uid, iid, adj)
 
     def get_adj_mat(self, is_subgraph=False):
         """CSR triple of the normalized (sub-)graph adjacency (BUIR.py:41-65); a sub-graph keeps
@@ -59,7 +67,29 @@ class BUIR(DeepRecommender):
         subs = (self.get_adj_mat(True), self.get_adj_mat(True))
         return subs, self.sample_epoch_pairwise()
 
+    def _train_throughput(self):
+        quiet = os.environ.get("QREC_QUIET") == "1"
+        tr = self.trainer
+        seed = int(os.environ.get("QREC_SEED", "0"))
+        vals = [None, None]
+        for epoch, (d_u, d_i, _) in enumerate(self.iter_epoch_samples_device(self.maxEpoch)):
+            for k in range(2):          # sub-graph O, then T (BUIR.py:139-147); stream ids apart from the batch stream's 2 * epoch (+ 1)
+                vals[k] = self.sampler.draw(1, self.drop_rate, seed, (1 << 32) + 2 * epoch + k, out=vals[k])
+            tr.set_subgraph_values(vals[0], vals[1])
+            dp = tr.dp = self.data_parallel()
+            step = self.batch_size * (dp.world if dp else 1)
+            n_rows = d_u.shape[0]
+            for n, s in enumerate(range(0, n_rows, step)):
+                lo, B = self.step_share(dp, min(step, n_rows - s))
+                tr.train_step_async(d_u.ptr + 4 * (s + lo), d_i.ptr + 4 * (s + lo), B)
+                if not quiet:
+                    print(self.foldInfo, "training:", epoch + 1, "batch", n, "loss:", tr.loss())
+        self._final_py_state = random.getstate()      # untouched: no CPython draws in this mode
+        self.q_user, self.q_item, self.o_user, self.o_item = tr.final_tables(self.get_adj_mat())
+
     def trainModel(self):
+        if self.sampler is not None:
+            return self._train_throughput()
         quiet = os.environ.get("QREC_QUIET") == "1"
         tr = self.trainer
         for epoch, (subs, (u, i, _)) in enumerate(self.iter_epoch_samples(self.maxEpoch, self._draw_epoch)):

@@ -24,11 +24,13 @@ SHAPES = {
     # same sizes, but 64 planted communities: 80 % of a user's interactions fall on items of the user's own community
     # (gen_edges_clustered) -- a graph WITH locality to harvest, next to the structureless one (SpMM L2 work)
     "yelp2018-clustered": (31668, 38048, 1237259, 324147, 2018),
-    # a planted-community graph with a 6 M-triplet epoch (the regime in which rounds 3-4 let `auto` pick the deferred schedule; the fidelity
-    # test of the choice `auto` makes there runs on it)
+    # a planted-community graph with a 6 M-triplet epoch (160 k users: collision density 0.03 -- P[u] stays with atomic deltas there,
+    # engine.resolve_p_update; the fidelity test of the choice `auto` makes at this size runs on it)
     "xl6m-clustered": (160000, 100000, 6000000, 1500000, 6006),
     # ... and one at the size the HBM-resident roofline figure is quoted on (25 M triplets per epoch; with d = 128 its tables are 0.54 GB)
     "xl25m-clustered": (650000, 400000, 25000000, 6250000, 2525),
+    # a second graph on which `auto` writes P[u] by load + store (1 M users: collision density 0.005), small enough for several paired runs
+    "xl12m-clustered": (1000000, 200000, 12000000, 3000000, 1212),
     "tiny": (300, 200, 6000, 1500, 7),
     "small": (2000, 1500, 60000, 15000, 11),
 }

@@ -32,7 +32,7 @@ from contextlib import redirect_stdout
 import numpy as np
 
 REF = "/root/reference"
-OUT = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("QREC_GOLDEN_OUT") or os.path.dirname(os.path.abspath(__file__))      # QREC_GOLDEN_OUT: regenerate into another directory (tests/test_oracle_golden.py compares)
 
 
 def install_stubs():
@@ -281,7 +281,8 @@ def case_tbpr_filmtrust(tmp):
     """model/ranking/TBPR.py (numpy path, runs unmodified): tie strengths, strong / weak / joint item sets, the chained
     pairwise updates per positive item and the per-user regularisation terms of the loss, on FilmTrust + trust.txt.
     The order of every user's joint-item list comes from a Python set of strings (hash-seed dependent, so it differs
-    from process to process in the reference itself): the lists of THIS run are recorded."""
+    from process to process in the reference itself): the lists of THIS run are recorded, and the run is made under
+    PYTHONHASHSEED=0 (main() re-executes the interpreter with it) so that it can be repeated."""
     conf = os.path.join(tmp, "tbpr_ft.conf")
     write_conf(conf, ratings="./dataset/FilmTrust/trainset.txt", social="./dataset/FilmTrust/trust.txt",
                ratings__setup="-columns 0 1 2", social__setup="-columns 0 1 2",
@@ -306,7 +307,8 @@ def case_tbpr_filmtrust(tmp):
     z["tie_weights"] = np.asarray(m.weights, dtype=np.float64)
     np.savez_compressed(os.path.join(OUT, "tbpr_filmtrust.npz"), **z)
     meta.update(seed=77, conf=open(conf).read(), theta=float(m.theta), t_s=float(m.t_s), t_w=float(m.t_w), g_theta=float(m.g_theta),
-                relations_loaded=len(rec["raw_relation"]), relations_kept=len(m.social.relation))
+                relations_loaded=len(rec["raw_relation"]), relations_kept=len(m.social.relation),
+                python_hash_seed=os.environ.get("PYTHONHASHSEED"))           # the joint-item lists' order depends on it (see main())
     return meta
 
 
@@ -394,7 +396,8 @@ def case_sbpr_filmtrust(tmp):
     meta.update(seed=91, conf=open(conf).read(), unmodified_reference_raises=raised,
                 fixture_source="model/ranking/SBPR.py with line 46 `self.FPSet[user][kItems]` -> `self.FPSet[user][item_k]`; nothing else changed",
                 users_with_social_feedback=int(sum(1 for x in m.PositiveSet if len(m.FPSet[x]) > 0)), stream_sha256=sha(z["stream"]),
-                relations_loaded=len(rec["raw_relation"]), relations_kept=len(m.social.relation))
+                relations_loaded=len(rec["raw_relation"]), relations_kept=len(m.social.relation),
+                python_hash_seed=os.environ.get("PYTHONHASHSEED"))           # the joint-item lists' order depends on it (see main())
     return meta
 
 
@@ -633,6 +636,12 @@ def case_loader(tmp):
 
 
 def main():
+    # TBPR.py:122 orders every user's joint items by iterating a Python SET OF STRINGS: the reference's own run depends on the
+    # interpreter's string-hash seed.  The fixtures are recorded under PYTHONHASHSEED=0 (written into golden_meta.json), so that an
+    # unchanged reference regenerates byte-identical files.
+    if os.environ.get("PYTHONHASHSEED") != "0":
+        os.environ["PYTHONHASHSEED"] = "0"
+        os.execv(sys.executable, [sys.executable] + sys.argv)
     install_stubs()
     tmp = tempfile.mkdtemp(prefix="qrec_golden_")
     os.symlink(os.path.join(REF, "dataset"), os.path.join(tmp, "dataset"))
@@ -641,7 +650,7 @@ def main():
     cases = [case_bpr_filmtrust, case_bpr_lastfm, case_basicmf, case_pmf, case_svd, case_ee, case_svdpp, case_pairwise_and_adj, case_pointwise, case_sgl_subgraph, case_sept_graphs, case_tbpr_filmtrust, case_sbpr_filmtrust, case_mhcn_graphs, case_loader]
     if only:   # regenerate a subset, keep the other entries of golden_meta.json
         cases = [c for c in cases if c.__name__ in only]
-        old = json.load(open(os.path.join(OUT, "golden_meta.json")))
+        old = json.load(open(os.path.join(OUT, "golden_meta.json"))) if os.path.exists(os.path.join(OUT, "golden_meta.json")) else {}
         metas = [c(tmp) for c in cases]
         old.update({m["name"]: m for m in metas})
         with open(os.path.join(OUT, "golden_meta.json"), "w") as f:

@@ -131,25 +131,12 @@ def test_social_and_graph_model_entry_points_refuse_bad_arguments_and_accept_emp
 
 
 def test_round_3_entry_points_refuse_what_they_cannot_serve():
-    """the deferred-negatives family, the exact mode's wide layout, page-locked memory and the grouped send/recv"""
+    """the item-major kernel's update policies, the exact mode's wide layout, page-locked memory and the grouped send/recv"""
     L = capi.load()
     T, idx, out = DB.zeros((100, 64), np.float32), DB.zeros(16, np.int32), DB.zeros(8, np.float64)
-    work = DB(capi.bpr_deferred_work_bytes(16, 100), np.uint8)
-    _err(lambda: capi.bpr_deferred_sort_sub(idx, 16, 100, 0, 4, work))                    # chunk 0
-    _err(lambda: capi.bpr_deferred_sort_sub(idx, 16, 100, 8, 17, work))                   # more sub-epochs than the key holds
-    _err(lambda: capi.bpr_deferred_sort_sub(idx, 16, 100, 8, 0, work))
-    _err(lambda: capi.bpr_sgd_hogwild_item_major_deferred(T, T, 64, 48, idx, idx, idx, 16, 32, 0, 16, 0.1, 0, 0, out, work))      # stride 48
-    _err(lambda: capi.bpr_sgd_hogwild_item_major_deferred(T, T, 64, 64, idx, idx, idx, 16, 32, 0, 0, 0.1, 0, 0, out, work))       # flush 0
-    _err(lambda: capi.bpr_sgd_hogwild_item_major_deferred(T, T, 64, 64, idx, idx, idx, 16, 32, 0, 16, 0.1, 0, 0, out, None))      # no work area
-    _err(lambda: capi.bpr_sgd_hogwild_item_major_deferred_sub(T, T, 64, 64, idx, idx, idx, 16, 8, 0, 8, 0.1, 0, 0, out, work, 0)) # S = 0
-    _err(lambda: capi.bpr_sgd_hogwild_item_major_deferred_sub(T, T, 64, 64, idx, idx, idx, 16, 8, 0, 8, 0.1, 0, 0, out, work, 99))
-    with pytest.raises(capi.QRecError):
-        capi.bpr_deferred_sub_plan(0, 100, 8, 4)                                          # no triplets: nothing to plan
-    with pytest.raises(capi.QRecError):
-        capi.bpr_deferred_sub_plan(100, 100, 8, 17)
-    # empty epochs are no-ops
-    capi.bpr_deferred_sort_sub(idx, 0, 100, 8, 4, work)
-    capi.bpr_sgd_hogwild_item_major_deferred_sub(T, T, 64, 64, idx, idx, idx, 0, 8, 0, 8, 0.1, 0, 0, out, work, 4)
+    _err(lambda: capi.bpr_sgd_hogwild_item_major(T, T, 64, 64, idx, idx, idx, 16, 32, 0, 16, 0.1, 0, 0, out, variant=99))          # unknown update policy
+    _err(lambda: capi.bpr_sgd_hogwild_item_major(T, T, 64, 64, idx, idx, idx, 16, 32, 0, 16, 0.1, 0, 0, out, variant=capi.HW_SC1_RMW))   # a user-major policy
+    capi.bpr_sgd_hogwild_item_major(T, T, 64, 64, idx, idx, idx, 0, 32, 0, 16, 0.1, 0, 0, out, variant=capi.HW_P_RMW)               # an empty epoch is a no-op
     assert not T.numpy().any()
     # page-locked memory
     h = C.c_void_p()

@@ -924,27 +924,6 @@ def test_bench_typed_with_gpus_n_becomes_its_own_launcher(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
-@pytest.mark.parametrize("n,chunk,S", [(60_797, 8, 4), (1_252_669, 34, 4), (1000, 7, 3), (5, 8, 2), (64, 8, 16), (33, 32, 2), (1, 1, 1)])
-def test_deferred_sub_epoch_plan(n, chunk, S):
-    """the host half of the sub-epoch schedule (bpr_sgd.hip make_sub_plan): the stride's modular inverse, the time-slot ranges
-    sub(slot) = slot * S // n_chunks, and where each range's triplets start in the (range, j) order -- against a plain recount"""
-    from math import gcd
-    sb, first, stride, inv, n_chunks = capi.bpr_deferred_sub_plan(n, 5000, chunk, S)
-    assert n_chunks == -(-n // chunk) and gcd(stride, n_chunks) == 1
-    assert n_chunks == 1 or (stride * inv) % n_chunks == 1
-    slot_of = [(c * inv) % n_chunks for c in range(n_chunks)] if n_chunks <= 200_000 else None
-    if slot_of is not None:
-        assert sorted(slot_of) == list(range(n_chunks))
-        assert all((s * stride) % n_chunks == c for c, s in enumerate(slot_of))      # slot s visits chunk s * stride mod n_chunks
-        count = [0] * S
-        for c, s in enumerate(slot_of):
-            count[s * S // n_chunks] += min((c + 1) * chunk, n) - c * chunk
-        assert first.tolist() == [0] + np.cumsum(count).tolist()
-    assert sb[0] == 0 and sb[-1] == n_chunks and first[0] == 0 and first[-1] == n
-    for s in range(S + 1):
-        assert sb[s] == -(-s * n_chunks // S)
-
-
 # ---------------------------------------------------------------------------------------------
 # round 4: stored order of the item-major schedule, `auto`, reconciliations per epoch (host logic, no device)
 # ---------------------------------------------------------------------------------------------
@@ -966,11 +945,27 @@ def test_auto_schedule_rule_and_reconciliations():
     from qrec_amd.engine import resolve_schedule
     skew = np.ones(1000); skew[0] = 5000
     assert resolve_schedule(1_252_669, skew) == ("item", None) and resolve_schedule(1_000_000, np.ones(1000)) == ("user", None)
-    # round 5: `auto` never picks the deferred-negatives schedule (profiles/r05_auto_regime_25m.json: outside the Recall bar at 25 M triplets, d = 128)
     assert resolve_schedule(6_000_000, np.ones(10)) == ("user", None) and resolve_schedule(25_000_000, None) == ("item", None)
-    assert resolve_schedule(25_000_000, None, "item-deferred") == ("item-deferred", None)
     assert resolve_schedule(10 ** 9, None, "user") == ("user", None)              # an explicit choice is never overridden
     assert [reconciliations_per_epoch(g) for g in (1, 2, 4, 8)] == [1, 1, 2, 2] and reconciliations_per_epoch(8, 1) == 1 and reconciliations_per_epoch(2, 5) == 5
+
+
+def test_p_update_policy_follows_the_collision_density():
+    """engine.resolve_p_update (round 6): P[u] by load + store only where two groups rarely hold the same user at once --
+    c = groups x sum_u (n_u / n)^2 <= 0.01; the shapes of the measurements in its comment land on the side they were measured on"""
+    from qrec_amd.engine import P_RMW_MAX_COLLISION, collision_density, resolve_p_update
+    assert collision_density(np.full(1000, 7)) == pytest.approx(4096 / 1000) and collision_density([]) == 0.0
+    assert collision_density(np.full(1_250_000, 20)) == pytest.approx(4096 / 1_250_000)
+    assert resolve_p_update(np.full(10_000_000, 20)) == "rmw"                      # BASELINE config #4: c = 0.0004
+    assert resolve_p_update(np.full(1_250_000, 20)) == "rmw"                       # its single-GPU slice: c = 0.0033
+    assert resolve_p_update(np.full(160_000, 38)) == "atomic"                      # 6 M triplets over 160 k users: c = 0.026 > 0.01
+    assert resolve_p_update(np.full(31_668, 40)) == "atomic" and resolve_p_update(np.full(1_892, 39)) == "atomic"    # Yelp2018 shape, lastfm
+    skew = np.ones(2_000_000); skew[:100] = 200_000                                 # many users, but a hundred of them hold almost every triplet
+    assert collision_density(skew) > 1 and resolve_p_update(skew) == "atomic"
+    assert resolve_p_update(np.full(10, 5), requested="rmw") == "rmw" and resolve_p_update(np.full(10 ** 7, 5), requested="atomic") == "atomic"
+    with pytest.raises(ValueError):
+        resolve_p_update([1], requested="sometimes")
+    assert P_RMW_MAX_COLLISION == 0.01
 
 
 def test_paired_recall_harness_host_logic():
@@ -990,15 +985,20 @@ def test_paired_recall_harness_host_logic():
     # the reference side of an earlier results file (a 25 M-triplet reference is 7 min of the GPU box's host): same dataset / seed / rate /
     # epochs / dimension and a mode of the same stored order -> that case's curve; no loss or learning rates -> those comparisons stay empty
     case = {"dataset": "xl25m-clustered", "lr0": 0.01, "seed": 7, "mode": "item-deferred:4:fresh", "epochs": 30, "eval_every": 5, "dim": 128}
-    cr = PR.cached_reference("profiles/r05_auto_regime_25m.json", case, "item")
+    cr = PR.cached_reference("profiles/r05_auto_regime_25m.json", case, ("item", 1, "", 2, None))
     assert sorted(cr["recall"]) == [5, 10, 15, 20, 25, 30] and cr["loss"] is None and "r05_auto_regime_25m" in cr["cached_from"]
     g3 = {"recall": {m: v + 0.001 for m, v in cr["recall"].items()}, "loss": [1.0] * 30, "lr": [0.01] * 30}
     c3 = PR.compare(case, g3, cr)
     assert c3["final"]["abs_diff"] == pytest.approx(0.001) and c3["final"]["loss_rel_gap"] is None and c3["same_bold_driver_decisions"] is None
     with pytest.raises(KeyError):
-        PR.cached_reference("profiles/r05_auto_regime_25m.json", dict(case, seed=8), "item")
+        PR.cached_reference("profiles/r05_auto_regime_25m.json", dict(case, seed=8), ("item", 1, "", 2, None))
     with pytest.raises(KeyError):
-        PR.cached_reference("profiles/r05_auto_regime_25m.json", case, "user")
+        PR.cached_reference("profiles/r05_auto_regime_25m.json", case, ("user", 1, "", 2, None))
+    #  a case on several ranks, or one whose epoch is cut into batches, never takes a cached single-rank curve
+    with pytest.raises(KeyError):
+        PR.cached_reference("profiles/r05_auto_regime_25m.json", dict(case, world=2), ("item", 2, "replicated", 2, None))
+    with pytest.raises(KeyError):
+        PR.cached_reference("profiles/r05_auto_regime_25m.json", case, ("item", 1, "", 5, None))
     # the one-pass item-major kernel's time order: every stored position once, chunk by chunk in the launcher's stride order
     n, chunk = 1000, 32
     sgd = SimpleNamespace(n=n, perm=np.random.default_rng(0).permutation(n))
@@ -1019,7 +1019,7 @@ def test_paired_recall_harness_host_logic():
     keys = {(c["dataset"], c["lr0"], c["mode"], c.get("world", 1), c.get("layout", "")) for c in plan}
     for ds in ("yelp2018-clustered", "lastfm"):
         for lr0 in (0.01, 0.05):
-            assert {(ds, lr0, m, 1, "") for m in ("item", "user", "item-deferred", "item-deferred:4")} <= keys
+            assert {(ds, lr0, m, 1, "") for m in ("item", "user")} <= keys
             assert {(ds, lr0, "item", w, l) for w in (2, 4) for l in ("replicated", "sharded")} <= keys
-    assert PR.parse_mode("item-deferred:4:19") == ("item-deferred", 4, 19, False) and PR.parse_mode("item") == ("item", None, None, False)
-    assert PR.parse_mode("item-deferred:4:fresh") == ("item-deferred", 4, None, True) and PR.parse_mode("item-deferred:8:32:fresh") == ("item-deferred", 8, 32, True)
+    assert PR.parse_mode("item") == ("item", "atomic") and PR.parse_mode("item:rmw") == ("item", "rmw") and PR.parse_mode("user") == ("user", "atomic")
+    assert PR.parse_mode("item-deferred:4:fresh") == ("item", "atomic")           # a mode of rounds 3-5's result files: its stored order

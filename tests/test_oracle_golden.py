@@ -411,3 +411,24 @@ def test_numpy_level_restatement_of_the_reference_loop_equals_the_c_restatement(
     assert abs(nll - lref) / lref < 1e-12 and np.abs(P - Pc).max() < 1e-12 and np.abs(Q - Qc).max() < 1e-12
     _, part, negs2 = npref.bpr_epoch(P0.copy(), Q0.copy(), indptr, ind, I, 0.05, 0.01, 0.02, rng=random.Random(5), max_triplets=1000)
     assert part == 1000 and np.array_equal(negs2, negs[:1000])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree exists in the build container only")
+def test_golden_generator_reproduces_the_committed_fixtures_byte_for_byte(tmp_path):
+    """tests/golden/README.md's claim, checked: the generator re-run against the unchanged reference writes the committed bytes.  Two
+    cases in a few seconds: the pointwise sampler, and TBPR -- the one run whose course depends on the interpreter's string-hash seed
+    (TBPR.py:122 iterates a set of item names), which the generator pins to PYTHONHASHSEED=0 and records."""
+    import hashlib
+    import subprocess
+    import sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    env = dict(os.environ, QREC_GOLDEN_OUT=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
+    env.pop("PYTHONHASHSEED", None)
+    subprocess.run([sys.executable, os.path.join(here, "gen_golden.py"), "case_tbpr_filmtrust", "case_pointwise"], check=True, env=env,
+                   capture_output=True, timeout=600)
+    sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()
+    for name in ("tbpr_filmtrust.npz", "pointwise_filmtrust.npz"):
+        assert sha(os.path.join(str(tmp_path), name)) == sha(os.path.join(here, name)), name
+    new = json.load(open(os.path.join(str(tmp_path), "golden_meta.json"))); old = json.load(open(os.path.join(here, "golden_meta.json")))
+    assert new["tbpr_filmtrust"] == old["tbpr_filmtrust"] and new["pointwise_filmtrust"] == old["pointwise_filmtrust"]
+    assert old["tbpr_filmtrust"]["python_hash_seed"] == "0"

@@ -15,7 +15,9 @@ Datasets -- ground on which the bar CAN fail (the structureless Zipf
                        74,272 train / 18,562 test rows): the reference reaches 0.099 after two epochs (golden_meta.json);
   yelp2018             the structureless graph of the bench line, for continuity.
 
-Modes: "item" (one-pass item-major, the default), "user", "item-deferred" (S = 1), "item-deferred:S[:chunk]" (sub-epochs).
+Modes: "item" (item-major, the default; P[u] by atomic deltas), "user", "item:rmw" / "item:auto" (P[u] by sc1 load + store / chosen by the
+collision density: engine.resolve_p_update; round 6).  (The two-pass "item-deferred" modes of rounds 3-5 are gone with their kernels; result
+files of those rounds under profiles/ still name them, and `reference_from` reads such files for the reference curve of the same stored order.)
 N > 1: G logical ranks in this process (threads + tests/logical_ranks.ThreadComm, the real kernels and exchange code), layouts
 "replicated" (users sharded, item table replicated, per-epoch delta all-reduce) and "sharded" (item table row-sharded, per-batch
 row exchange) -- bench.py's layouts.
@@ -67,12 +69,12 @@ def recall20(P, Q, d, N: int = 20) -> float:
 
 
 def parse_mode(mode: str):
-    """"item-deferred:S[:chunk][:fresh]" -> (schedule, sub-epochs, pass-A chunk, fresh coefficient)"""
+    """"item[:rmw|:auto|:atomic]" / "user" -> (schedule, P[u] update policy).  Modes of rounds 3-5's result files ("item-deferred:4:fresh")
+    parse to their stored order: ("item", "atomic")."""
     parts = mode.split(":")
-    fresh = parts[-1] == "fresh"
-    if fresh:
-        parts = parts[:-1]
-    return parts[0], (int(parts[1]) if len(parts) > 1 and parts[1] else None), (int(parts[2]) if len(parts) > 2 and parts[2] else None), fresh
+    schedule = parts[0].split("-")[0]
+    p_update = parts[1] if len(parts) > 1 and parts[1] in ("rmw", "auto", "atomic") else "atomic"
+    return schedule, p_update
 
 
 def _rank_problem(d, world, rank):
@@ -101,14 +103,14 @@ def build_rank(d, mode, world, rank, layout, P0, Q0, shard_batch=1 << 20, syncs=
     from qrec_amd import dist as qd
     from qrec_amd.engine import BprSgd, DeviceTables, balanced_chunk
     from qrec_amd.interactions import CSR
-    schedule, S, sub_chunk, fresh = parse_mode(mode)
+    schedule, p_update = parse_mode(mode)
     lo, hi, lp, li, lu = _rank_problem(d, world, rank)
     sharded = world > 1 and layout == "sharded"
     t = DeviceTables(P0[lo:hi], qd.shard_item_rows(Q0, world, rank) if sharded else Q0, np.float32)
     chunk = balanced_chunk(int(li.size))
     batches = n_batches_for(d, world, layout, shard_batch, syncs)
     sgd = BprSgd(t, lu, li, CSR(lp, li), schedule=schedule, n_items=d["n_items"], batches=batches,
-                 chunk=chunk, sub_epochs=S, sub_chunk=sub_chunk, item_run=item_run, fresh=fresh)
+                 chunk=chunk, item_run=item_run, p_update=p_update)
     chunk, groups = sgd.launch_grid(rounds)                 # (an epoch in batches: engine.launch_chunk per batch, unchanged)
     return t, sgd, chunk, lo, hi, groups
 
@@ -200,7 +202,8 @@ def gpu_run(d, mode, lr0, seed, epochs, marks, world=1, layout="replicated", P0=
     return {"recall": state["recall"], "loss": [float(x) for x in log[:, 0]], "lr": [float(x) for x in log[:, 1]], "grid": state.get("grid"),
             "final_topn": state.get("final_topn", {}),
             "negatives": negatives_of(state["sgd"], seed), "samplers": state["sgd"],
-            "perm_key": (parse_mode(mode)[0].split("-")[0], world, layout if world > 1 else "", len(state["sgd"][0].batch_bounds), state["sgd"][0].item_run)}
+            "perm_key": (parse_mode(mode)[0], world, layout if world > 1 else "", len(state["sgd"][0].batch_bounds), state["sgd"][0].item_run),
+            "p_update": state["sgd"][0].p_update, "collision_density": state["sgd"][0].collision}
 
 
 def reference_run(d, negatives, lr0, epochs, marks, P0, Q0, order=None, extra_topn=()):
@@ -241,19 +244,24 @@ def item_major_visit_order(sgd, chunk: int) -> np.ndarray:
     return sgd.perm[at[at < n]]
 
 
-def cached_reference(path: str, case: dict, perm_schedule: str):
+def cached_reference(path: str, case: dict, perm_key):
     """The reference side of an EARLIER run of this harness (a results file under profiles/), for a case whose reference costs minutes of
     the GPU box's time (25 M triplets x 30 epochs of sequential fp64: 7 min): the reference run is a function of (dataset, seed, rate, epochs,
     dimension, stored order) alone -- the negatives are the counter-based device stream, the tables and the dataset are seeded -- so a case
     of that file with the same values and a mode of the same stored order holds the same curve.  Recall at the marks only (the file keeps
     the loss at three marks and no learning rates): the result says so and leaves the loss gap / bold-driver comparison empty."""
     same = ("dataset", "lr0", "seed", "epochs")
+    perm_schedule, world, layout, n_bounds, item_run = perm_key
+    # (ADVICE r5) the negatives -- and so the reference curve -- depend on the per-rank seeds and on the stored order: only a single-rank,
+    # single-batch case may take a cached curve, and only from a case of the same stored order
+    if case.get("world", 1) != 1 or world != 1 or n_bounds != 2:
+        raise KeyError(f"reference_from needs a single-rank, single-batch case (got world {case.get('world', 1)}, {n_bounds - 1} batches)")
     for c in json.load(open(os.path.join(ROOT, path)))["cases"]:
         if "curve" not in c or any(c.get(k) != case.get(k) for k in same) or c.get("eval_every", 5) != case.get("eval_every", 5):
             continue
         if c.get("dim", DIM) != case.get("dim", DIM) or c.get("init_seed", 3) != case.get("init_seed", 3) or c.get("world", 1) != 1:
             continue
-        if parse_mode(c["mode"])[0].split("-")[0] != perm_schedule or c.get("item_run") != case.get("item_run"):
+        if parse_mode(c["mode"])[0] != perm_schedule or c.get("item_run") != case.get("item_run") or c.get("layout", "replicated") != case.get("layout", "replicated"):
             continue
         return {"recall": {int(m): float(r) for m, _, r in c["curve"]}, "loss": None, "lr": None, "final_topn": {},
                 "cached_from": f"{path}: case mode {c['mode']!r} (recall at the marks only)"}
@@ -302,7 +310,7 @@ def run_case(case: dict, cache: dict, datasets: dict) -> dict:
     key = (name, lr0, seed, epochs, every, case.get("init_seed", 3), case.get("dim", DIM), topn) + g["perm_key"]
     if key not in cache:      # the negatives are a function of (seed, epoch, stored order): modes with the same order share a reference
         if case.get("reference_from"):
-            cache[key] = cached_reference(case["reference_from"], case, g["perm_key"][0])
+            cache[key] = cached_reference(case["reference_from"], case, g["perm_key"])
         else:
             cache[key] = reference_run(d, g["negatives"], lr0, epochs, marks, P0, Q0, extra_topn=topn)
     out = compare({k: v for k, v in case.items()}, g, cache[key])
@@ -311,6 +319,7 @@ def run_case(case: dict, cache: dict, datasets: dict) -> dict:
     else:           # kept whole, so that a later run can take this reference from the results file
         out["reference_log"] = {"loss": cache[key]["loss"], "lr": cache[key]["lr"]}
     out["gpu_log"] = {"loss": g["loss"], "lr": g["lr"]}
+    out["p_update"], out["collision_density"] = g["p_update"], g["collision_density"]
     if case.get("order_null"):
         # the yardstick (no GPU involved): the SAME sequential fp64 training on the same negatives with the epoch's triplets visited in one
         # fixed random order instead of the reference's -- how far the reference's own measure moves under a reordering at this setting
@@ -347,8 +356,6 @@ def plan_full():
             for seed in (7, 11):
                 for mode in ("item", "user"):
                     cases.append(dict(dataset=ds, lr0=lr0, seed=seed, mode=mode, epochs=epochs, eval_every=every))
-            for mode in ("item-deferred", "item-deferred:4"):
-                cases.append(dict(dataset=ds, lr0=lr0, seed=7, mode=mode, epochs=epochs, eval_every=every))
             cases.append(dict(dataset=ds, lr0=lr0, seed=7, mode="item", epochs=epochs, eval_every=every, item_run=0, own_order=True))
     for ds in (Y, L):
         for lr0, epochs, every in runs[ds]:
@@ -361,7 +368,7 @@ def plan_full():
     for layout in ("replicated", "sharded"):
         cases.append(dict(dataset=Y, lr0=0.01, seed=7, mode="item", epochs=40, eval_every=5, world=8, layout=layout))
     for lr0, epochs, every in ((0.05, 15, 3), (0.01, 40, 5)):
-        for mode in ("item", "item-deferred:4"):
+        for mode in ("item", "item:rmw"):
             cases.append(dict(dataset=X, lr0=lr0, seed=7, mode=mode, epochs=epochs, eval_every=every))
     return cases
 
@@ -417,7 +424,7 @@ def summarize_seeds(results, keys=("dataset", "lr0", "mode", "rounds", "world", 
 
 
 def plan_quick():
-    return [dict(dataset="lastfm", lr0=0.05, seed=7, mode=m, epochs=10, eval_every=5) for m in ("item", "item-deferred")] + \
+    return [dict(dataset="lastfm", lr0=0.05, seed=7, mode=m, epochs=10, eval_every=5) for m in ("item", "item:rmw")] + \
            [dict(dataset="lastfm", lr0=0.05, seed=7, mode="item", epochs=10, eval_every=5, world=2, layout=l, shard_batch=1 << 14)
             for l in ("replicated", "sharded")]
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One rank's share of BASELINE config #4 on 8 GPUs (1.25 M users x 1 M items, d = 128, 25 M triplets per epoch: the HBM-resident slice) run
 the way the replicated layout runs it by default -- 8 reconciliation batches per epoch through an identity communicator (no links) -- under the
-one-pass item-major kernel and under the deferred schedule (every batch one unit of it, round 4).  One JSON line per schedule."""
+item-major kernel with P[u] written by atomic deltas and by load + store (engine.resolve_p_update, round 6).  One JSON line per setting."""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,8 +29,8 @@ j2 = rng.integers(0, I2, n2, dtype=np.int32)
 t = DeviceTables(P2, Q2, np.float32)
 alg = n2 * B.bytes_per_triplet(d2)
 chunk = balanced_chunk(n2)
-for sched, K in (("item", 1), ("item", 8), ("item-deferred", 8), ("item-deferred", 1)):
-    s = BprSgd(t, u2, i2, None, schedule=sched, batches=K, chunk=chunk, sub_epochs=1 if K > 1 else 4)
+for sched, K in (("item/atomic", 1), ("item/atomic", 8), ("item/rmw", 8), ("item/rmw", 1)):
+    s = BprSgd(t, u2, i2, None, schedule="item", batches=K, chunk=chunk, p_update=sched.split("/")[1])
     s.set_negatives(j2)
     step = qd.ReplicatedStep(NoLinks(8), qd.ReplicatedTableSync(NoLinks(8), t.Q))
     stream = capi.Stream()
