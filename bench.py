@@ -164,10 +164,14 @@ def recall_bpr_conf(mode, seeds=16):
     res = [PR.run_case(c, recall_case.cache, recall_case.datasets) for c in cases]
     (row,) = PR.summarize_seeds(res)
     g = row["final_gap"]
+    per_seed = np.abs(np.array([r["final"]["signed_diff"] for r in res if "final" in r]))
     return {"dataset": "lastfm", "conf": "config/BPR.conf (num.factors 50, learnRate -init 0.01 -max 1, reg 0.001, 100 epochs), Recall after the last epoch",
             "mode": mode, "lr0": 0.01, "epochs": 100, "seeds": row["seeds"],
             "recall_exact_order_mean": row["recall_exact_order_mean"], "recall_exact_order_sd_over_seeds": row["recall_exact_order_sd_over_seeds"],
             "final_gap_signed": {k: g[k] for k in ("n", "mean_signed", "se", "sd", "mean_abs", "max_abs")},
+            # what ONE run looks like (the reader is to see 0.002-0.006, not only the mean's 0.0004)
+            "per_seed_abs_gap": {"mean": float(per_seed.mean()), "p90": float(np.quantile(per_seed, 0.9)), "max": float(per_seed.max()),
+                                 "runs_inside_the_bar": int((per_seed <= 0.002).sum()), "runs": int(per_seed.size)},
             "abs_diff": abs(g["mean_signed"]), "abs_diff_is": "|mean over seeds of the signed final-epoch gap|", "bar": 0.002,
             "within_bar": bool(abs(g["mean_signed"]) <= 0.002),
             "final_gap_recall_at_10": row["final_gap_other_topn"]["10"],
@@ -231,7 +235,8 @@ def exact_mode_rate(capi, u, items, indptr, n_items, P0, Q0):
 
 def hbm_resident_roofline(capi, schedule="user", p_update="atomic"):
     """BASELINE config #4, single-GPU slice (U=1.25 M, I=1 M, d=128, 25 M triplets, uniform items): 1.15 GB of tables,
-    far beyond the 256 MiB Infinity Cache, so the gather+SGD kernel's traffic is real HBM traffic."""
+    far beyond the 256 MiB Infinity Cache, so the gather+SGD kernel's traffic is real HBM traffic.
+    ``p_update``: one policy, or a tuple of policies timed on the same arrays (a dict keyed by policy is returned)."""
     from qrec_amd.engine import BprSgd, DeviceTables
     rng = np.random.default_rng(0)
     U2, I2, n2, d2 = 1_250_000, 1_000_000, 25_000_000, 128
@@ -241,17 +246,24 @@ def hbm_resident_roofline(capi, schedule="user", p_update="atomic"):
     for a in (P2, Q2):
         for k in range(0, a.shape[0], 50_000):
             a[k:k + 50_000] = blk[:min(50_000, a.shape[0] - k)]
-    t = DeviceTables(P2, Q2, np.float32); s = BprSgd(t, u2, i2, None, schedule=schedule, p_update=p_update)
-    s.set_negatives(rng.integers(0, I2, n2, dtype=np.int32))
-    e0, e1 = capi.Event(), capi.Event(); ts = []
-    with settled_heap(capi):
-        for _ in range(5):
-            e0.record(); s.epoch_throughput_async(LR0, REG_U, REG_I); e1.record(); e1.sync(); ts.append(e1.elapsed_ms_since(e0))
-    ms = float(np.median(ts[1:])); alg = n2 * bytes_per_triplet(d2)
-    return {"workload": f"BPR d={d2}, {U2}x{I2}, {n2} triplets/epoch, {schedule}-major (config #4 single-GPU slice, tables 1.15 GB)", "schedule": schedule,
-            "p_update": s.p_update, "p_update_requested": p_update, "collision_density": s.collision,
-            "bound": "hbm", "achieved": alg / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / ms / 1e6 / HBM_PEAK_GBPS,
-            "avg_launch_ms": ms, "algorithmic_bytes_per_launch": alg, "triplet_updates_per_s": n2 / ms * 1e3}
+    j2 = rng.integers(0, I2, n2, dtype=np.int32)
+    t = DeviceTables(P2, Q2, np.float32)
+    out = {}
+    for pol in ((p_update,) if isinstance(p_update, str) else tuple(p_update)):
+        t.upload(P2, Q2)
+        s = BprSgd(t, u2, i2, None, schedule=schedule, p_update=pol)
+        s.set_negatives(j2)
+        e0, e1 = capi.Event(), capi.Event(); ts = []
+        with settled_heap(capi):
+            for _ in range(5):
+                e0.record(); s.epoch_throughput_async(LR0, REG_U, REG_I); e1.record(); e1.sync(); ts.append(e1.elapsed_ms_since(e0))
+        ms = float(np.median(ts[1:])); alg = n2 * bytes_per_triplet(d2)
+        out[pol] = {"workload": f"BPR d={d2}, {U2}x{I2}, {n2} triplets/epoch, {schedule}-major (config #4 single-GPU slice, tables 1.15 GB)", "schedule": schedule,
+                    "p_update": s.p_update, "p_update_requested": pol, "collision_density": s.collision,
+                    "bound": "hbm", "achieved": alg / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / ms / 1e6 / HBM_PEAK_GBPS,
+                    "avg_launch_ms": ms, "algorithmic_bytes_per_launch": alg, "triplet_updates_per_s": n2 / ms * 1e3}
+        del s
+    return out[p_update] if isinstance(p_update, str) else out
 
 
 @contextlib.contextmanager
@@ -630,8 +642,12 @@ def main():
         if use_dist:
             control.barrier()
 
-    def run_leg(strong: bool, steps: int, warmup: int, min_seconds: float, dump: bool):
-        """one timed run: warm-up steps, then EXACTLY `steps` steps between barrier + device sync on both sides, max over ranks"""
+    layout_of_the_line = sharded
+
+    def run_leg(strong: bool, steps: int, warmup: int, min_seconds: float, dump: bool, layout_sharded: bool | None = None):
+        """one timed run: warm-up steps, then EXACTLY `steps` steps between barrier + device sync on both sides, max over ranks.
+        ``layout_sharded``: the item table's layout for THIS leg (None = the line's own, --dist-mode)"""
+        sharded = layout_of_the_line if layout_sharded is None else (layout_sharded and use_dist)
         if strong and world > 1:     # the SAME users split over the ranks: rank r trains the r-th contiguous block (qrec_amd/dist.py)
             lo, hi, l_indptr, l_items = qd.shard_positive_csr(indptr, items, world, rank)
             l_u = np.repeat(np.arange(hi - lo, dtype=np.int32), np.diff(l_indptr)).astype(np.int32)
@@ -762,6 +778,11 @@ def main():
     weak_leg = None
     if strong and not args.no_extras:       # the weak-scaling figure next to it: every rank its own U users (an N x U-user problem)
         weak_leg = run_leg(False, max(2, args.steps // 2), 1, args.min_seconds / 2, dump=False)
+    # north_star's layout as a first-class figure of the same line: the SAME strong-scaling problem with the item table
+    # row-sharded and a per-batch all-to-all -- `value_sharded` beside `value` (which runs the replicated layout unless --dist-mode says otherwise)
+    other_layout_leg = None
+    if use_dist and world > 1 and strong and not args.no_extras:
+        other_layout_leg = run_leg(True, max(2, args.steps // 2), 1, args.min_seconds / 2, dump=False, layout_sharded=not sharded)
     alg_bytes = n * bytes_per_triplet(DIM)
     moved = leg["moved"]
     multi = None
@@ -786,6 +807,12 @@ def main():
         if sharded and moved is not None and world > 1:
             predicted = {"all_links_1071GBps": moved / world / 1071e9 * 1e3, "one_link_153GBps": moved / world / 153e9 * 1e3,
                          "what": "bytes leaving one rank per epoch / link rate; arithmetic, not measured"}
+        # the line is only a multi-GPU line if RCCL says so: every rank in a communicator of `world` ranks, every rank on its own device
+        # (the one-device functional test shares device 0 over the staged transport and says so in the line)
+        devices = [int(x) for x in per_rank[:, 3]]
+        if not one_device and (int(per_rank[:, 1].min()) != world or int(per_rank[:, 1].max()) != world or len(set(devices)) != world):
+            raise SystemExit(f"bench.py --gpus {world}: the communicator reports {sorted(set(int(x) for x in per_rank[:, 1]))} ranks on devices {devices}; "
+                             f"expected {world} ranks on {world} distinct devices -- no line is printed for a run that was not what it claims to be")
         multi = {"preflight": pre, "rccl_ranks": int(per_rank[:, 1].min()), "rccl_ranks_agree": bool((per_rank[:, 1] == per_rank[0, 1]).all()),
                  "rank_devices": [int(x) for x in per_rank[:, 3]], "rccl": lib,
                  "transport": "rccl" if hasattr(comm, "query") else type(comm).__name__,
@@ -820,8 +847,8 @@ def main():
         if strong and recall_ran and args.dist_mode != "sharded":      # (a condition every rank evaluates alike: the leg is collective)
             # ... and the Recall@20 of THAT layout: the paired run of the strong-scaling leg again with the item table row-sharded (at config
             # #4's own size a CPU reference is 30 s per epoch: the layout is judged at the Yelp2018 shape, like the replicated one)
-            ds = "yelp2018-clustered" if args.recall_dataset == "auto" else args.recall_dataset
-            rs = multi_gpu_recall(capi, qd, control, comm, world, rank, "sharded", args.schedule, ds, LR0, args.recall_epochs or (40 if ds == "yelp2018-clustered" else 25), 5,
+            # (the dataset and epochs the first Recall leg resolved, not a second resolution of "auto")
+            rs = multi_gpu_recall(capi, qd, control, comm, world, rank, "sharded", args.schedule, ds, LR0, ep, 5,
                                   args.shard_batch, qd.reconciliations_per_epoch(world, args.sync_per_epoch))
             if rank == 0:
                 config4["recall_at_20_of_the_layout"] = rs
@@ -889,6 +916,16 @@ def main():
                                    f"{world * weak_leg['n']} triplets/epoch: every rank its own {U}-user population (NOT the Yelp2018 problem: {world} of them side by side)",
                                    "ms_per_epoch": weak_leg["elapsed"] / (weak_leg["steps"] * weak_leg["inner"]) * 1e3, "steps": weak_leg["steps"],
                                    "epochs_per_step": weak_leg["inner"], "kernel_ms": weak_leg["avg_kernel_ms"]}
+        if other_layout_leg is not None:
+            ol = other_layout_leg
+            key = "value_replicated" if sharded else "value_sharded"
+            out[key] = {"value": n_full * ol["steps"] * ol["inner"] / ol["elapsed"], "unit": "triplet-updates/s",
+                        "layout": ("item table replicated, delta all-reduce per reconciliation" if sharded else
+                                   f"item table row-sharded x{world}, per-batch RCCL all-to-all of distinct rows + their updates (north_star's layout)"),
+                        "workload": f"the same strong-scaling problem: BPR d={DIM} {shape_name} {U}x{I} over {world} GPUs",
+                        "ms_per_epoch": ol["elapsed"] / (ol["steps"] * ol["inner"]) * 1e3, "steps": ol["steps"], "epochs_per_step": ol["inner"],
+                        "kernel_ms": ol["avg_kernel_ms"], "batches_per_epoch": ol["n_batches"],
+                        **({"xgmi_bytes_per_epoch_all_ranks": ol["moved"]} if ol["moved"] is not None else {})}
         if recall_multi is not None:
             out["recall_at_20"] = recall_multi
         if config4 is not None:
@@ -906,7 +943,8 @@ def main():
                 # it, the same slice with atomic deltas (what rounds 1-5 ran)
                 from qrec_amd.engine import P_RMW_MAX_COLLISION, resolve_schedule
                 sch, _ = resolve_schedule(25_000_000, None)
-                out["roofline_hbm_resident"] = hbm_resident_roofline(capi, schedule=sch, p_update="auto")
+                both = hbm_resident_roofline(capi, schedule=sch, p_update=("auto", "atomic"))
+                out["roofline_hbm_resident"] = both["auto"]
                 out["roofline_hbm_resident"]["chosen_by"] = (f"engine.resolve_schedule + engine.resolve_p_update (QREC_SCHEDULE / QREC_P_UPDATE = auto): "
                                                              f"load + store where groups x sum_u p_u^2 <= {P_RMW_MAX_COLLISION}")
                 out["roofline_hbm_resident"]["recall_at_20_at_this_size"] = {
@@ -915,7 +953,7 @@ def main():
                     "abs_diff_peak_and_last_epoch": {"lr0 0.01, 30 epochs, load + store": [0.0010, 0.0002], "lr0 0.05, 12 epochs, load + store": [0.0011, 0.0002],
                                                      "lr0 0.01, 30 epochs, atomic deltas": [0.0008, 0.0002], "lr0 0.05, 12 epochs, atomic deltas": [0.0010, 0.0003]},
                     "bar": 0.002}
-                out["roofline_hbm_resident_atomic"] = hbm_resident_roofline(capi, schedule=sch, p_update="atomic")
+                out["roofline_hbm_resident_atomic"] = both["atomic"]
                 if args.shape == "yelp2018":
                     out["other_configs"] = other_configs(capi, data)
         os.write(result_fd, (json.dumps(out) + "\n").encode())

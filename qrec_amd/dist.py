@@ -88,9 +88,12 @@ class ControlPlane:
             import datetime
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29571")
-            # a collective the other ranks never join fails after QREC_CONTROL_TIMEOUT seconds (gloo's own default is half an hour)
+            # a collective the other ranks never join fails after QREC_CONTROL_TIMEOUT seconds.  Default = gloo's own half hour (round 5's
+            # 900 s could kill a healthy job whose rank 0 spends longer than that between two collectives -- an fp64 reference run at 25 M
+            # triplets, an evaluation on a large test set); ranks in DIFFERENT collectives are caught at once by the tag exchange (_agree), a
+            # dead communicator by the preflight's watchdog -- the transport's timeout is only the last resort
             dist.init_process_group("gloo", rank=int(os.environ.get("RANK", "0")), world_size=int(os.environ.get("WORLD_SIZE", "1")),
-                                    timeout=datetime.timedelta(seconds=float(os.environ.get("QREC_CONTROL_TIMEOUT", "900"))))
+                                    timeout=datetime.timedelta(seconds=float(os.environ.get("QREC_CONTROL_TIMEOUT", "1800"))))
         return cls()
 
     def _agree(self, op: str):

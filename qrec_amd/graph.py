@@ -218,7 +218,10 @@ class SpmmPlan:
         long_rows = np.nonzero(n_seg_row > 1)[0].astype(np.int32)
         long_count = n_seg_row[long_rows].astype(np.int32)
         long_first = np.concatenate([[0], np.cumsum(long_count)[:-1]]).astype(np.int32) if long_rows.size else np.zeros(0, np.int32)
-        # longest segments first: the heavy work starts early, the tail is made of short rows
+        # longest segments first: the heavy work starts early, the tail is made of short rows.  (Round 6 measured the alternative the locality
+        # argument suggests -- inside an XCD's class the segments in spectral-key order, rows of one community next to each other in time:
+        # 68.8 -> 87.7 us on the structureless graph, 57.6 -> 76.5 us on the planted-community one, profiles/r06_spmm_order.jsonl: neighbouring
+        # groups then ask for the same operand lines at the same moment, and the launch is ~2 rounds of the grid deep, so "in time" means little.)
         order = np.argsort(-seg_len_arr, kind="stable")
         bipartite = split_row is not None and 0 < split_row < n_rows
         if row_chunk is not None and (not bipartite or row_chunk.size != n_rows):

@@ -572,7 +572,7 @@ def test_p_update_auto_takes_load_store_only_where_users_rarely_collide():
     print("one epoch vs the order-exact result, relative to the epoch's movement (P, Q, loss):", dist)
     check("P[u] by load + store (auto at collision density 0.004) vs atomic deltas: distance of P's update from the order-exact one, ratio", dist["auto"][0] / dist["atomic"][0], 1.25, kind="statistical")
     check("... of Q's update, ratio", dist["auto"][1] / dist["atomic"][1], 1.25, kind="statistical")
-    check("... epoch loss vs the order-exact epoch's", dist["auto"][2], 0.01, kind="statistical")
+    check("... of the epoch loss, ratio", dist["auto"][2] / dist["atomic"][2], 1.25, kind="statistical")
 
 
 @pytest.mark.parametrize("flush", [8, 16, 34])
@@ -679,11 +679,22 @@ def test_throughput_schedules_keep_recall_on_structured_data(lr0, epochs, every,
     base/recommender.py:181-212) -- and at the reference's peak epoch, at BPR.conf's rate and at five times it, same bold-driver decisions
     on both sides.  `item` = item-major in runs of 16 (with whole item runs, rounds 1-3, the 0.05 case ends 0.0038 away -- 0.003 of which
     is the visiting order alone, sequential fp64, no GPU: profiles/r04_order_sensitivity.json).
-    (user-major at five times the rate is not run here: it is not what `auto` picks at this shape, and the ledger has it ON the bar at
-    the peak epoch -- 0.0019 ... 0.0021 over three runs, 0.0010 ... 0.0014 at the last epoch, profiles/r04_paired_recall.json.)"""
-    if mode == "user" and lr0 > 0.01:
-        pytest.skip("see the docstring: user-major at five times BPR.conf's rate is documented in the ledger, not asserted")
+    user-major at five times the rate sits ON the bar at the peak epoch run by run (0.0019 ... 0.0021 over three runs, round 4; skipped in
+    round 5): asserted since round 6 over EIGHT seeds -- the mean gap inside the bar at the peak and at the last epoch, no single run
+    beyond 1.5 bars."""
     dataset = "yelp2018-clustered"
+    if mode == "user" and lr0 > 0.01:
+        seeds = (7, 11, 13, 17, 19, 23, 29, 31)
+        rs = [_paired(dict(dataset=dataset, lr0=lr0, seed=sd, mode=mode, epochs=epochs, eval_every=every)) for sd in seeds]
+        fin = np.array([r["final"]["abs_diff"] for r in rs]); peak = np.array([r["peak"]["abs_diff"] for r in rs])
+        sfin = np.array([r["final"]["signed_diff"] for r in rs]); speak = np.array([r["peak"]["signed_diff"] for r in rs])
+        print(dataset, lr0, mode, "8 seeds: |gap| last epoch", np.round(fin, 4), "peak", np.round(peak, 4), "signed means", sfin.mean(), speak.mean())
+        assert all(r["peak"]["recall_exact_order"] > 0.1 for r in rs)
+        check(f"user-major, {dataset}, lr0 = {lr0}, 8 seeds: |mean signed Recall@20 gap| after the last epoch", abs(sfin.mean()), 0.002, inclusive=True, kind="statistical")
+        check(f"user-major, {dataset}, lr0 = {lr0}, 8 seeds: |mean signed Recall@20 gap| at the reference's peak epoch", abs(speak.mean()), 0.002, inclusive=True, kind="statistical")
+        check(f"user-major, {dataset}, lr0 = {lr0}, 8 seeds: mean |gap| after the last epoch", fin.mean(), 0.002, inclusive=True, kind="statistical")
+        check(f"user-major, {dataset}, lr0 = {lr0}, 8 seeds: largest single-run |gap| (peak or last epoch)", max(fin.max(), peak.max()), 0.003, inclusive=True, kind="statistical")
+        return
     r = _paired(dict(dataset=dataset, lr0=lr0, seed=7, mode=mode, epochs=epochs, eval_every=every))
     print(dataset, lr0, mode, "curve (epoch, gpu, exact-order):", [(m, round(a, 4), round(b, 4)) for m, a, b in r["curve"]])
     assert r["same_bold_driver_decisions"] and r["peak"]["recall_exact_order"] > 0.1

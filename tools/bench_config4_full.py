@@ -22,10 +22,11 @@ out["host_prepare_s"] = time.perf_counter() - t0
 t0 = time.perf_counter()
 t = DeviceTables(P0, Q0, np.float32); del P0, Q0
 from qrec_amd.engine import resolve_schedule
-want = sys.argv[1] if len(sys.argv) > 1 else "user"            # "auto": what engine.resolve_schedule picks at this size (round 4)
-sched, sub = resolve_schedule(n, None, want)
-out["schedule"], out["sub_epochs"] = sched, sub
-s = BprSgd(t, u, i, None, schedule=sched, sub_epochs=sub)
+want = sys.argv[1] if len(sys.argv) > 1 else "auto"            # "auto": what engine.resolve_schedule picks at this size
+p_update = sys.argv[2] if len(sys.argv) > 2 else "auto"         # P[u]: "auto" (engine.resolve_p_update: load + store at this collision density), "atomic", "rmw"
+sched, _ = resolve_schedule(n, None, want)
+s = BprSgd(t, u, i, None, schedule=sched, p_update=p_update)
+out["schedule"], out["p_update"], out["collision_density"] = sched, s.p_update, s.collision
 s.set_negatives(j)
 capi.device_sync(); out["upload_s"] = time.perf_counter() - t0
 e0, e1 = capi.Event(), capi.Event(); ts, losses = [], []

@@ -12,6 +12,9 @@
 #   spmm-counters        FETCH_SIZE / WRITE_SIZE (separate passes) per kernel of the LightGCN step -> <tag>_lightgcn_pmc.json
 #   mfma-util            MfmaUtil per MFMA kernel (NGCF step, evaluation, SimGCL step) -> <tag>_mfma_util.json
 #   stats:<m>            rocprofv3 --kernel-trace --stats of one config's step (m: lightgcn | simgcl | ngcf | eval) -> <tag>_<m>_kernel_stats.txt
+#   bpr-counters         the item-major BPR kernel under rocprofv3: kernel stats + one --pmc pass PER counter (atomic / request / busy / wait
+#                        counters that `rocprofv3 -L` lists on this box; FETCH_SIZE, WRITE_SIZE) at the Yelp2018 shape and on the HBM-resident
+#                        slice, atomic and load+store P[u] -> <tag>_bpr_counters.json, <tag>_bpr_<w>_<p>_kernel_stats.txt, <tag>_counters_available.txt
 #   py:<script>[:args]   python tools/<script>.py args... (args separated by ':'), stdout -> <tag>_<script>.log
 #   profpy:<script>[:args]  the same under rocprofv3 --kernel-trace --stats -> <tag>_<script>_kernel_stats.txt
 TAG=$1; shift
@@ -66,6 +69,28 @@ for STEP in "$@"; do
       rocprofv3 --kernel-trace --stats -d $O/prof_$ARG -o $ARG -- $(step_cmd $ARG) > $O/prof_$ARG.log 2>&1; echo "$ARG exit $?"
       db=$(ls $O/prof_$ARG/*_results.db $O/prof_$ARG/*/*_results.db 2>/dev/null | head -1)
       python $R/tools/summarize_stats.py $db $O/${TAG}_${ARG}_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- $(step_cmd $ARG)   [$TAG, Yelp2018 shape d=64; profiled run]" | head -12;;
+    bpr-counters)
+      rocprofv3 -L > $O/${TAG}_counters_list_full.txt 2>&1
+      grep -oE "\b(TCC|TCP|SQ|GRBM|TA|TD)_[A-Za-z0-9_]+" $O/${TAG}_counters_list_full.txt | sort -u > $O/${TAG}_counters_available.txt
+      wc -l $O/${TAG}_counters_available.txt
+      WANT="TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum TCC_EA0_ATOMIC_LEVEL_sum TCC_EA_ATOMIC_sum TCC_REQ_sum TCC_BUSY_sum TCC_BUSY_avr TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_64B_sum TCC_WRITE_sum TCC_READ_sum TCC_TAG_STALL_sum SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE FETCH_SIZE WRITE_SIZE"
+      HAVE=""; for c in $WANT; do grep -qx "$c" $O/${TAG}_counters_available.txt && HAVE="$HAVE $c"; done
+      echo "counters used:$HAVE"
+      SPECS=""
+      for W in yelp hbm; do for P in atomic rmw; do
+        EP=10; [ $W = hbm ] && EP=4
+        rm -rf $O/prof_bpr_${W}_$P
+        rocprofv3 --kernel-trace --stats -d $O/prof_bpr_${W}_$P -o k -- python $R/tools/prof_bpr_kernel.py $W $P $EP > $O/${TAG}_bpr_${W}_${P}_timing.log 2>&1; echo "stats $W $P exit $?"
+        db=$(ls $O/prof_bpr_${W}_$P/*_results.db $O/prof_bpr_${W}_$P/*/*_results.db 2>/dev/null | head -1)
+        python $R/tools/summarize_stats.py $db $O/${TAG}_bpr_${W}_${P}_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python tools/prof_bpr_kernel.py $W $P $EP   [$TAG; profiled run]" | head -4
+        for c in $HAVE; do
+          rm -rf $O/pmc_bpr_${W}_${P}_$c
+          timeout 300 rocprofv3 --pmc $c --kernel-trace -d $O/pmc_bpr_${W}_${P}_$c -o k -- python $R/tools/prof_bpr_kernel.py $W $P $EP > $O/pmc_bpr_${W}_${P}_$c.log 2>&1 || echo "$c $W $P failed"
+        done
+        python $R/tools/summarize_pmc.py $O/${TAG}_bpr_counters_${W}_${P}.json $(for c in $HAVE; do echo -n "$c=$O/pmc_bpr_${W}_${P}_$c "; done) | grep -i hogwild | cut -c1-200
+        rm -rf $O/pmc_bpr_${W}_${P}_* $O/prof_bpr_${W}_$P          # the rocpd databases are tens of MB each: gpurun copies back 64 MiB at most
+      done; done
+      rm -f $O/${TAG}_counters_list_full.txt;;
     py)
       S=${ARG%%:*}; A=""; [[ "$ARG" == *:* ]] && A=${ARG#*:}
       cd $R; timeout 3000 python tools/$S.py ${A//:/ } > $O/${TAG}_$S.log 2>&1; echo "$S exit $?"; tail -25 $O/${TAG}_$S.log | cut -c1-600; cd /tmp;;
