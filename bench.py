@@ -296,7 +296,7 @@ def _time_events(capi, fn, reps, warm=3):
     return float(np.median(ts))
 
 
-def other_configs(capi, yelp, budget_s=14.0):
+def other_configs(capi, yelp, budget_s=22.0):
     """SURVEY s8(d) configs #2, #3, #5 and the evaluation, measured HERE by the driver's own run (round 4; rounds 1-3 had them only as
     builder-run files under profiles/): HIP events, >= 20 repetitions each, bounded to ~`budget_s` seconds of wall clock.
       #2  BPR d=64 on the ML-1M shape (6,040 x 3,706, 1,000,209 triplets/epoch): one epoch of the default schedule;
@@ -348,23 +348,37 @@ def other_configs(capi, yelp, budget_s=14.0):
     ms = step_ms(lambda k: tr.train_step_async(du.ptr + 4 * k * B, di.ptr + 4 * k * B, dj.ptr + 4 * k * B, B))
     spmm_ms = _time_events(capi, lambda: capi.spmm_csr(tr.plan, tr.E, tr.A, tr.ld, d_accum=tr.S), 20)
     nnz = int(tr.plan.nnz); alg = 8 * nnz + 4 * (N + 1) + 2 * N * DIM * 4
-    traffic = None
-    cfile = os.path.join(ROOT, "profiles", "r05_lightgcn_hbm_counters.json")
+    traffic = traffic_c = None
+    cfile = os.path.join(ROOT, "profiles", "r06_lightgcn_hbm_counters.json")
     if os.path.exists(cfile):
-        traffic = json.load(open(cfile)).get("spmm_forward_with_layer_sum", {}).get("l2_miss_MB_per_launch", 0) * 1e6 or None
+        cj = json.load(open(cfile))
+        traffic = cj.get("yelp2018", {}).get("spmm_forward_with_layer_sum", {}).get("l2_miss_MB_per_launch", 0) * 1e6 or None
+        traffic_c = cj.get("yelp2018-clustered", {}).get("spmm_forward_with_layer_sum", {}).get("l2_miss_MB_per_launch", 0) * 1e6 or None
+    # the same product on a graph WITH structure (both graphs on the line): the planted-community graph of the same shape
+    dc = make_dataset("yelp2018-clustered")
+    adj_c = joint_norm_adjacency(dc["n_users"], dc["n_items"], dc["train_u"], dc["train_i"])
+    from qrec_amd.graph import SpmmPlan
+    plan_c = SpmmPlan(adj_c[0], adj_c[1], adj_c[2], tr.ld, split_row=dc["n_users"])
+    spmm_c_ms = _time_events(capi, lambda: capi.spmm_csr(plan_c, tr.E, tr.A, tr.ld, d_accum=tr.S), 20)
+    alg_c = 8 * int(plan_c.nnz) + 4 * (N + 1) + 2 * N * DIM * 4
     ACHIEVABLE_GBPS = 6300.0        # /opt/skills/guides/MI355X_MICROARCH.md: ~6.3 TB/s achievable of the 8 TB/s spec
     out["lightgcn_step"] = {"workload": f"LightGCN L=3 d={DIM} batch {B} Yelp2018-shape N={N} nnz={nnz}", "ms_per_step": ms, "steps_timed": 40,
                             "triplets_per_s": B / ms * 1e3, "epoch_s": ms * -(-nn // B) / 1e3,
                             "spmm": {"kernel": "spmm_kernel<16> + spmm_fixup_kernel<16>", "avg_us": spmm_ms * 1e3, "reps": 20, "algorithmic_bytes": alg,
                                      "achieved_GBps": alg / spmm_ms / 1e6, "frac": alg / spmm_ms / 1e6 / HBM_PEAK_GBPS, "bound": "hbm (normalised: the operand is cache resident)",
-                                     "traffic": traffic, "traffic_source": "profiles/r05_lightgcn_hbm_counters.json (static: rocprofv3 PMC passes run by the builder on "
-                                                                            "this kernel in round 5; bytes past the XCD L2s per launch of THIS launch type, FETCH_SIZE doubled)" if traffic else None,
+                                     "traffic": traffic, "traffic_source": "profiles/r06_lightgcn_hbm_counters.json (static: rocprofv3 PMC passes run by the builder on "
+                                                                            "this kernel in round 6; bytes past the XCD L2s per launch of THIS launch type, FETCH_SIZE doubled)" if traffic else None,
+                                     "graph": "structureless (Zipf degrees, no communities): the worst case for locality",
+                                     "on_the_planted_community_graph": {"graph": "yelp2018-clustered: same shape, 64 planted communities, 80 % of a user's edges inside the user's community",
+                                                                        "avg_us": spmm_c_ms * 1e3, "algorithmic_bytes": alg_c, "frac": alg_c / spmm_c_ms / 1e6 / HBM_PEAK_GBPS,
+                                                                        "traffic": traffic_c, "over_fetch_vs_algorithmic": (traffic_c / alg_c) if traffic_c else None,
+                                                                        "roofline_l2miss_frac": (traffic_c / spmm_c_ms / 1e6 / 6300.0) if traffic_c else None},
                                      # the bound the kernel is actually on: every XCD's 4 MiB L2 misses most of the gathered operand, the misses are served by the
                                      # Infinity Cache / HBM side at what that side achieves
                                      "roofline_l2miss": ({"bound": "bytes past the XCD L2s (counters) / live time, against the ~6.3 TB/s the memory side achieves",
                                                           "achieved": traffic / spmm_ms / 1e6, "peak": ACHIEVABLE_GBPS, "unit": "GB/s", "frac": traffic / spmm_ms / 1e6 / ACHIEVABLE_GBPS,
                                                           "over_fetch_vs_algorithmic": traffic / alg} if traffic else None)}}
-    del tr
+    del tr, plan_c
     if time.perf_counter() - t_begin < budget_s:
         lim = np.sqrt(6 / 128)
         W = [[rng.uniform(-lim, lim, (DIM, DIM)).astype(np.float32) for _ in range(2)] for _ in range(2)]

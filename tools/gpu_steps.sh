@@ -9,7 +9,8 @@
 #   bench                python bench.py (default flags) -> <tag>_bench.json
 #   bench-prof           bench + rocprofv3 --kernel-trace --stats + the two HBM counter passes (separate) + tools/summarize_prof.py
 #   recall:<plan>        tools/paired_recall.py <tag>_recall_<plan>.json <plan>       (plan: bpr-conf | full | quick | a JSON file under tools/plans/)
-#   spmm-counters        FETCH_SIZE / WRITE_SIZE (separate passes) per kernel of the LightGCN step -> <tag>_lightgcn_pmc.json
+#   spmm-counters        FETCH_SIZE / WRITE_SIZE (separate passes) of the forward SpMM on the structureless and the planted-community graph
+#                        -> <tag>_lightgcn_hbm_counters.json (bytes past the XCD L2s per launch, over-fetch vs algorithmic bytes)
 #   mfma-util            MfmaUtil per MFMA kernel (NGCF step, evaluation, SimGCL step) -> <tag>_mfma_util.json
 #   stats:<m>            rocprofv3 --kernel-trace --stats of one config's step (m: lightgcn | simgcl | ngcf | eval) -> <tag>_<m>_kernel_stats.txt
 #   bpr-counters         the item-major BPR kernel under rocprofv3: kernel stats + one --pmc pass PER counter (atomic / request / busy / wait
@@ -53,11 +54,16 @@ for STEP in "$@"; do
       cd $R; timeout 3000 python tools/paired_recall.py $O/${TAG}_recall_${ARG}.json $PLAN > $O/${TAG}_recall_${ARG}.log 2>&1; echo "recall $ARG exit $?"
       grep "over seeds" $O/${TAG}_recall_${ARG}.log | cut -c1-900; tail -3 $O/${TAG}_recall_${ARG}.log | cut -c1-400; cd /tmp;;
     spmm-counters)
-      for ctr in FETCH_SIZE WRITE_SIZE; do
-        rm -rf $O/pmc_lg_$ctr
-        rocprofv3 --pmc $ctr --kernel-trace -d $O/pmc_lg_$ctr -o lg -- python $R/tools/bench_lightgcn.py --steps 20 --shape yelp2018 > $O/pmc_lg_$ctr.log 2>&1; echo "$ctr exit $?"
+      SPECS=""
+      for SH in yelp2018 yelp2018-clustered; do
+        for ctr in FETCH_SIZE WRITE_SIZE; do
+          rm -rf $O/pmc_lg_${SH}_$ctr
+          rocprofv3 --pmc $ctr --kernel-trace -d $O/pmc_lg_${SH}_$ctr -o lg -- python $R/tools/bench_lightgcn.py --steps 20 --shape $SH > $O/pmc_lg_${SH}_$ctr.log 2>&1; echo "$SH $ctr exit $?"
+        done
+        SPECS="$SPECS $SH=$O/pmc_lg_${SH}_FETCH_SIZE,$O/pmc_lg_${SH}_WRITE_SIZE"
       done
-      python $R/tools/summarize_pmc.py $O/${TAG}_lightgcn_pmc.json FETCH_SIZE=$O/pmc_lg_FETCH_SIZE WRITE_SIZE=$O/pmc_lg_WRITE_SIZE | grep -i spmm;;
+      python $R/tools/summarize_spmm_counters.py $O/${TAG}_lightgcn_hbm_counters.json $SPECS
+      rm -rf $O/pmc_lg_*_FETCH_SIZE $O/pmc_lg_*_WRITE_SIZE;;
     mfma-util)
       for m in ngcf eval simgcl; do
         rm -rf $O/pmc_mfma_$m
