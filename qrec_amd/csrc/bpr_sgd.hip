@@ -497,6 +497,9 @@ __global__ __launch_bounds__(64) void svdpp_ordered_kernel(
 // 16 B (the float4-per-lane layout) -- atomic cost is per request, not per byte.
 constexpr int kMaxChunk = 64;
 constexpr int64_t kBufLimit = (int64_t)1 << 32;   // a buffer descriptor addresses 32-bit byte offsets
+// test hook (README switch table): QREC_FORCE_64BIT_ADDRESSING=1 sends tables of any size down the >= 4 GiB flavour (TabPtr), so that
+// its parity tests and timings do not need a 4 GiB table
+static inline bool force_64bit_addressing() { const char *e = getenv("QREC_FORCE_64BIT_ADDRESSING"); return e && e[0] == '1'; }
 
 enum : int { LD_PLAIN = 0, LD_SC1 = 1 };
 enum : int { UP_STORE = 0, UP_STORE_SC1 = 1, UP_ATOMIC = 2 };
@@ -507,11 +510,14 @@ template <int E> struct Row { float v[E]; };
 //   TabBuf  a buffer descriptor sized to the table (32-bit byte offsets, so < 4 GiB): out-of-range row ids are
 //           dropped by the hardware bounds check instead of corrupting memory, and address arithmetic is one VALU op;
 //   TabPtr  64-bit global addressing for tables of 4 GiB and more (measured 2-5% slower: tools/bench_configs.py).
+// kPrefetchAlways: how the triplet loops issue the next triplet's row loads (see the item-major kernel)
 struct TabBuf {
+    static constexpr bool kPrefetchAlways = false;
     __amdgpu_buffer_rsrc_t rs;
     static __device__ inline TabBuf make(float *p, int64_t bytes) { return TabBuf{make_rsrc(p, (uint32_t)bytes)}; }
 };
 struct TabPtr {
+    static constexpr bool kPrefetchAlways = true;
     float *base;
     static __device__ inline TabPtr make(float *p, int64_t) { return TabPtr{p}; }
 };
@@ -625,11 +631,13 @@ __global__ __launch_bounds__(256) void bpr_hogwild_kernel(
                 pu = hw_load_row<LPR, E, LOADP>(rsP, ut, r);
                 pu0 = pu; cur_u = ut;
             }
+            // next triplet's rows are in flight under this one's math (the form of the prefetch per addressing flavour: see the item-major kernel)
+            const bool more = (k + 1 < len);
             int in = it, jn = jt;
             Row<E> nqi = qi, nqj = qj;
-            const bool more = (k + 1 < len);
-            if (more) {  // next triplet's rows are in flight under this one's math
-                in = si[k + 1]; jn = sj[k + 1];
+            if (TAB::kPrefetchAlways || more) {
+                const int kn = more ? k + 1 : k;
+                in = si[kn]; jn = sj[kn];
                 nqi = hw_load_row<LPR, E, LOADP>(rsQ, in, r);
                 nqj = hw_load_row<LPR, E, LOADP>(rsQ, jn, r);
             }
@@ -734,11 +742,18 @@ __global__ __launch_bounds__(256) void bpr_hogwild_item_kernel(
                 qi = hw_load_row<LPR, E, LD_SC1>(rsQ, it, r);      // bypass L1: pick up other runs' flushes
                 qi0 = qi; cur_i = it; since_flush = 0;
             }
+            // The next triplet's rows go in flight under this one's math.  The 64-bit addressing flavour (TabPtr) issues them UNCONDITIONALLY
+            // (the chunk's last triplet re-reads its own rows, unused): under `if (more)` its loads were if-converted into loads + selects,
+            // the selects waited for the loads on the spot (s_waitcnt vmcnt(0) right behind the prefetch) and the software pipelining was
+            // gone -- 168.9 instead of 120.5 ms on the 10 M-user HBM-resident slice with P[u] by load + store (round 6,
+            // tools/probe_p_table_size.py).  The buffer-descriptor flavour keeps the branch: its loads stay behind a real skip, and the
+            // unconditional form measured 11 % slower there (16.6 against 14.9 ms at 1.25 M users).
+            const bool more = (k + 1 < len);
             int un = ut, jn = jt;
             Row<E> npu = pu, nqj = qj;
-            const bool more = (k + 1 < len);
-            if (more) {
-                un = su[k + 1]; jn = sj[k + 1];
+            if (TAB::kPrefetchAlways || more) {
+                const int kn = more ? k + 1 : k;
+                un = su[kn]; jn = sj[kn];
                 npu = hw_load_row<LPR, E, LDP>(rsP, un, r);
                 nqj = hw_load_row<LPR, E, LDJ>(rsQ, jn, r);
             }
@@ -797,7 +812,7 @@ int launch_hogwild_item(float *P, float *Q, int64_t pb, int64_t qb, const int32_
     const unsigned blocks = (unsigned)((groups + 4 * GPW - 1) / (4 * GPW));
 #define QREC_ITEM_LAUNCH(RMW)                                                                                                     \
     do {                                                                                                                          \
-        if (pb < kBufLimit && qb < kBufLimit)                                                                                     \
+        if (pb < kBufLimit && qb < kBufLimit && !force_64bit_addressing())                                                        \
             hipLaunchKernelGGL((bpr_hogwild_item_kernel<LPR, E, TabBuf, RMW>), dim3(blocks), dim3(256), 0, st, P, Q, pb, qb, u, i, j, n, \
                                chunk, n_chunks, stride, groups, flush_every, rate, loss);                                         \
         else                                                                                                                      \
@@ -835,7 +850,7 @@ int launch_hogwild(float *P, float *Q, int64_t pb, int64_t qb, const int32_t *u,
     const unsigned blocks = (unsigned)((groups + 4 * GPW - 1) / (4 * GPW));
 #define QREC_HW_LAUNCH(LOADP, UPD)                                                                          \
     do {                                                                                                    \
-        if (pb < kBufLimit && qb < kBufLimit)                                                               \
+        if (pb < kBufLimit && qb < kBufLimit && !force_64bit_addressing())                                  \
             hipLaunchKernelGGL((bpr_hogwild_kernel<LPR, E, LOADP, UPD, TabBuf>), dim3(blocks), dim3(256), 0, st, \
                                P, Q, pb, qb, u, i, j, n, chunk, n_chunks, groups, rate, loss);              \
         else                                                                                                \

@@ -56,8 +56,10 @@ def rel_err(a, b):
 #   discontinuity a run that may legitimately leave the recorded one at a discontinuous op (sign(), top_k) -- the recorded-pattern
 #                 variant of the same test is the parity row
 #   statistical   throughput-mode quantities (another random stream / visiting order): Recall@20 and loss gaps, means over seeds
+#   partition     the same step / run of THIS repository under another partition of the rows or of the batch over ranks, against its own
+#                 single-GPU run (not against the reference): another fp32 summation structure, carried through the Adam steps in between
 #   info          recorded, never a contract (bound is a sanity ceiling)
-KINDS = ("parity", "floor", "discontinuity", "statistical", "info")
+KINDS = ("parity", "floor", "discontinuity", "statistical", "partition", "info")
 
 
 def check(quantity, observed, bound, ctx=None, inclusive=False, kind="parity"):

@@ -543,6 +543,42 @@ def test_item_major_full_grid_properties_yelp_shape():
         sgd.epoch_ordered(0.01, 0.0, 0.0)          # the order-exact kernel refuses a non-reference order
 
 
+@pytest.mark.parametrize("schedule", ["item", "user"])
+def test_64_bit_addressing_flavour_is_the_same_recurrence(schedule, monkeypatch):
+    """tables of 4 GiB and more are addressed through 64-bit pointers instead of buffer descriptors (csrc/bpr_sgd.hip TabPtr); the test hook
+    QREC_FORCE_64BIT_ADDRESSING sends a small problem down that flavour: ONE group = the sequential recurrence for every update policy, and the
+    full grid gives finite tables with the loss of the descriptor flavour to Hogwild noise"""
+    d, indptr, ind, u, j = _synthetic("small")
+    U, I, n, dim = d["n_users"], d["n_items"], ind.size, 64
+    rng = np.random.default_rng(8)
+    P0 = rng.random((U, dim)) / 3; Q0 = rng.random((I, dim)) / 3
+    t = DeviceTables(P0, Q0, np.float32)
+    sgd = BprSgd(t, u, ind, schedule=schedule); sgd.set_negatives(j)
+    us, is_, js = sgd.d_u.numpy(), sgd.d_i.numpy(), sgd.d_j.numpy()
+    order = _item_major_visit_order(n, 32) if schedule == "item" else np.arange(n)
+    Pr, Qr = P0.copy(), Q0.copy()
+    lref = O.bpr_sgd(Pr, Qr, np.ascontiguousarray(us[order]), np.ascontiguousarray(is_[order]), np.ascontiguousarray(js[order]), 0.05, 0.01, 0.02)
+    monkeypatch.setenv("QREC_FORCE_64BIT_ADDRESSING", "1")
+    variants = (capi.HW_DEFAULT, capi.HW_P_RMW, capi.HW_PQ_RMW) if schedule == "item" else (capi.HW_DEFAULT, capi.HW_SC1_RMW, capi.HW_SC1_ATOMIC)
+    for variant in variants:
+        t.upload(P0, Q0); sgd.d_stats.fill_bytes(0)
+        if schedule == "item":
+            capi.bpr_sgd_hogwild_item_major(t.P, t.Q, dim, t.ld, sgd.d_u, sgd.d_i, sgd.d_j, n, 32, 1, 8, 0.05, 0.01, 0.02, sgd.d_stats, variant=variant)
+        else:
+            capi.bpr_sgd_hogwild(t.P, t.Q, dim, t.ld, sgd.d_u, sgd.d_i, sgd.d_j, n, 32, 1, 0.05, 0.01, 0.02, sgd.d_stats, variant)
+        Pg, Qg = t.download()
+        check(f"64-bit addressing, {schedule}-major, variant {variant}, one group: P vs the sequential recurrence", rel_err(Pg, Pr), F32_TOL)
+        check(f"64-bit addressing, {schedule}-major, variant {variant}, one group: Q vs the sequential recurrence", rel_err(Qg, Qr), F32_TOL)
+        check(f"64-bit addressing, {schedule}-major, variant {variant}, one group: loss", abs(sgd.loss() - lref) / lref, F32_TOL)
+    t.upload(P0, Q0); sgd.d_stats.fill_bytes(0)
+    sgd.epoch_throughput_async(0.05, 0.01, 0.02)
+    loss64 = sgd.loss()
+    monkeypatch.delenv("QREC_FORCE_64BIT_ADDRESSING")
+    t.upload(P0, Q0); sgd.d_stats.fill_bytes(0)
+    sgd.epoch_throughput_async(0.05, 0.01, 0.02)
+    assert np.isfinite(t.download()[0]).all() and abs(loss64 - sgd.loss()) / sgd.loss() < 0.02
+
+
 def test_p_update_auto_takes_load_store_only_where_users_rarely_collide():
     """engine.resolve_p_update on real BprSgd objects: the Yelp2018 shape (31.7 k users: collision density 0.17) stays with atomic deltas,
     a flat 1 M-user epoch (0.004) takes P[u] by load + store -- and there, on the full grid, one epoch lands as close to the order-exact

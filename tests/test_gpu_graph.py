@@ -923,11 +923,11 @@ def test_graph_models_data_parallel_two_ranks_equal_one_rank_with_double_batch(n
     # summation order and move that row's positives, so its two runs agree to a looser bound (the replicas above do not)
     # (observed, profiles/r03_parity_errors.json: every model but SEPT <= 7e-8 on the losses and <= 6e-7 on the tables; SEPT
     # 2.3e-5 / 2.2e-3 -- a moved pseudo label is a different positive set for that row from then on)
-    check_rel("two ranks vs one rank, losses", b0["losses"], a["losses"], 2e-4 if name == "SEPT" else TOL)
+    check_rel(f"{name}: two ranks (batch split) vs one rank (double batch), losses of the whole run", b0["losses"], a["losses"], 2e-4 if name == "SEPT" else TOL, kind="partition")
     tol = 2e-2 if name == "SEPT" else TOL
-    check("rel_err(b0['E'], a['E'])", rel_err(b0["E"], a["E"]), tol)
-    check("rel_err(b0['U'], a['U'])", rel_err(b0["U"], a["U"]), tol)
-    check("rel_err(b0['V'], a['V'])", rel_err(b0["V"], a["V"]), tol)
+    check(f"{name}: two ranks vs one rank, ego table after the run", rel_err(b0["E"], a["E"]), tol, kind="partition")
+    check(f"{name}: two ranks vs one rank, scoring users after the run", rel_err(b0["U"], a["U"]), tol, kind="partition")
+    check(f"{name}: two ranks vs one rank, scoring items after the run", rel_err(b0["V"], a["V"]), tol, kind="partition")
     np.testing.assert_allclose(b0["measure"], a["measure"], atol=2e-3)
     assert len(os.listdir(two / "results")) == len(os.listdir(one / "results"))      # rank 0 alone wrote the result files
 
@@ -956,13 +956,13 @@ def test_graph_class_row_partitioned_two_ranks_equal_one_rank_at_the_same_batch_
         assert np.array_equal(b0[k], b1[k]), k                      # both ranks gathered the same tables, same measures
     check_rel("rank 0 vs rank 1 losses", b0["losses"], b1["losses"], 1e-6)   # every rank sums the batch loss itself (float atomics: own order)
     assert a["losses"].size == b0["losses"].size > 0
-    check_rel("row-partitioned vs one rank, losses", b0["losses"], a["losses"], 5e-4 if model == "NGCF" else TOL)
+    check_rel(f"{model}: row-partitioned two ranks vs one rank, losses of the whole run", b0["losses"], a["losses"], 5e-4 if model == "NGCF" else TOL, kind="partition")
     # NGCF / SimGCL: ~70 Adam steps carry the summation-order differences of the float atomics along (coordinates with a
     # rounding-noise gradient move by +-alpha per step whatever the implementation; run-to-run 2e-4 .. 2e-3); the step-level
     # equivalence at 5e-5 is tests/test_gpu_dist.py::test_row_partitioned_{ngcf,simgcl}_step_equals_the_single_gpu_step
     tol = 1e-2 if model == "NGCF" else TOL      # observed: LightGCN 6e-8, SimGCL 9e-8, NGCF 5e-3 (see the note above)
-    check("rel_err(b0['U'], a['U'])", rel_err(b0["U"], a["U"]), tol)
-    check("rel_err(b0['V'], a['V'])", rel_err(b0["V"], a["V"]), tol)
+    check(f"{model}: row-partitioned two ranks vs one rank, scoring users after ~70 Adam steps", rel_err(b0["U"], a["U"]), tol, kind="partition")
+    check(f"{model}: row-partitioned two ranks vs one rank, scoring items after ~70 Adam steps", rel_err(b0["V"], a["V"]), tol, kind="partition")
     assert not np.array_equal(b0["E"], b1["E"]) and b0["E"].shape[0] + b1["E"].shape[0] >= a["E"].shape[0]   # each rank holds ITS rows
     np.testing.assert_allclose(b0["measure"], a["measure"], atol=1e-4 if model == "LightGCN" else 5e-3)
 

@@ -29,7 +29,7 @@ def main(src, dst):
                bounds_above_1e_5=len(over), by_kind=by_kind,
                kinds="tests/helpers.py::check -- parity: the 1e-5 / bit-exact contract; floor: bound derived from the reference's own distance to exact "
                      "arithmetic; discontinuity: may leave the recorded run at sign() / top_k (its recorded-pattern twin is the parity row); "
-                     "statistical: throughput-mode Recall / loss gaps; info: recorded only",
+                     "statistical: throughput-mode Recall / loss gaps; partition: this repository's multi-rank partitions against its own single-GPU run; info: recorded only",
                worst_observed_over_bound=(out[0]["observed"] / out[0]["bound"] if out else None), rows=out)
     with open(dst, "w") as f:
         json.dump(doc, f, indent=1)
