@@ -895,11 +895,11 @@ __global__ __launch_bounds__(256, OCC) void score_filter2_kernel_f32(
         load_tile(t_begin, va);
         int t = t_begin;
         while (true) {
-            if (t + t_step < t_end) load_tile(t + t_step, vb);
+            load_tile(t + t_step < t_end ? t + t_step : t_end - 1, vb);
             do_tile(t, va);
             t += t_step;
             if (t >= t_end) break;
-            if (t + t_step < t_end) load_tile(t + t_step, va);
+            load_tile(t + t_step < t_end ? t + t_step : t_end - 1, va);
             do_tile(t, vb);
             t += t_step;
             if (t >= t_end) break;
@@ -932,8 +932,13 @@ __global__ __launch_bounds__(256, OCC) void score_filter2_kernel_f32(
 // overflowed and the select kernel flags the user for the exact walk -- slow, not wrong.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
-// rows [rows][ld] fp32 (row_ids: gather, may be null) -> bf16 copy [rows][ld]; norm[row] = |x| (fp32); pad rows (>= rows) zero
-template <int LPR>
+// rows [rows][ld] fp32 (row_ids: gather, may be null) -> bf16 copy [rows][ld]; norm[row] = |x| (fp32); pad rows (>= rows) zero.
+// TILED (the item table): the copy is laid out in the order the MFMA loops fetch it -- 32-row tile t, 16-column slice m, then the
+// 64 lanes' 16-byte operand fragments (lane (r, h): columns 16 m + 8 h .. + 8 of row 32 t + r) -- so that one global_load_dwordx4 of
+// a wavefront reads ONE contiguous KiB (8 cache lines) instead of 32 bytes from each of 32 rows (32 lines): with the row-major copy
+// the two bf16 passes kept the texture-address unit stalled on the L1 half of the time and waited 2,000 cycles for a tile they had
+// requested a whole iteration earlier (round 6: TA_ADDR_STALLED_BY_TC, SQ_WAIT_ANY; the matrix pipe at 22 / 35 %)
+template <int LPR, bool TILED>
 __global__ __launch_bounds__(256) void to_bf16_kernel(const float *__restrict__ X, const int32_t *__restrict__ row_ids, int rows, int rows_pad,
                                                       __bf16 *__restrict__ out, float *__restrict__ norm, float *__restrict__ norm_max) {
     constexpr int GPW = kWave / LPR;
@@ -943,7 +948,15 @@ __global__ __launch_bounds__(256) void to_bf16_kernel(const float *__restrict__ 
     if (k < rows) x = *reinterpret_cast<const f32x4 *>(X + (int64_t)(row_ids ? row_ids[k] : k) * (4 * LPR) + 4 * r);
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
     bf16x4 o = {(__bf16)x.x, (__bf16)x.y, (__bf16)x.z, (__bf16)x.w};
-    if (k < rows_pad) *reinterpret_cast<bf16x4 *>(out + k * (4 * LPR) + 4 * r) = o;
+    if (k < rows_pad) {
+        if constexpr (TILED) {
+            constexpr int NM = LPR / 4;
+            const int c = 4 * r;
+            *reinterpret_cast<bf16x4 *>(out + ((((k >> 5) * NM + (c >> 4)) * 64 + ((c >> 3) & 1) * 32 + (k & 31)) << 3) + (c & 7)) = o;
+        } else {
+            *reinterpret_cast<bf16x4 *>(out + k * (4 * LPR) + 4 * r) = o;
+        }
+    }
     float ss = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
     ss = row_allreduce_sum<LPR>(ss);
     float nrm = sqrtf(ss) * 1.0001f;                               // rows past `rows`: 0
@@ -1001,10 +1014,10 @@ __global__ __launch_bounds__(256, 2) void sample_max_bf16_kernel(
 #pragma unroll
         for (int m = 0; m < NM; m++) uu[k][m] = *reinterpret_cast<const bf16x8 *>(Ub + (int64_t)bl * LD + 16 * m + 8 * h);
     }
-    auto load_tile = [&](int s_tile, bf16x8 (&dst)[NM]) {         // Vb is padded to whole 32-item tiles
-        const __bf16 *row = Vb + ((int64_t)s_tile * stride * 32 + r) * LD + 8 * h;
+    auto load_tile = [&](int s_tile, bf16x8 (&dst)[NM]) {         // Vb: whole 32-item tiles in fragment order (to_bf16_kernel<., true>)
+        const __bf16 *frag = Vb + (((int64_t)s_tile * stride * NM) * 64 + lane) * 8;
 #pragma unroll
-        for (int m = 0; m < NM; m++) dst[m] = *reinterpret_cast<const bf16x8 *>(row + 16 * m);
+        for (int m = 0; m < NM; m++) dst[m] = *reinterpret_cast<const bf16x8 *>(frag + m * 512);
     };
     auto tagged_max = [](const f32x16 &a) {
         float t[16];
@@ -1028,7 +1041,7 @@ __global__ __launch_bounds__(256, 2) void sample_max_bf16_kernel(
         for (int st = s_begin; st < s_end; st++) {
             const int nxt = st + 1 < s_end ? st + 1 : (g + g_step) * tiles_per_group;
             const bool more = nxt < n_s_tiles && (st + 1 < s_end || g + g_step < n_groups);
-            if (more) load_tile(nxt, vn);
+            load_tile(more ? nxt : st, vn);          // unconditional: see score_filter_bf16_kernel
             f32x16 acc[NU];
 #pragma unroll
             for (int k = 0; k < NU; k++)
@@ -1099,10 +1112,10 @@ __global__ __launch_bounds__(256, 2) void score_filter_bf16_kernel(
             cs[k] = cand_s + ((int64_t)bs[k] * n_lists + list) * list_cap;
             ci[k] = cand_i + ((int64_t)bs[k] * n_lists + list) * list_cap;
         }
-        auto load_tile = [&](int t, bf16x8 (&dst)[NM]) {          // Vb is padded to whole 32-item tiles (zero rows)
-            const __bf16 *row = Vb + (int64_t)(t * 32 + r) * LD + 8 * h;
+        auto load_tile = [&](int t, bf16x8 (&dst)[NM]) {          // Vb: whole 32-item tiles (zero pad rows) in fragment order
+            const __bf16 *frag = Vb + (((int64_t)t * NM) * 64 + lane) * 8;
 #pragma unroll
-            for (int m = 0; m < NM; m++) dst[m] = *reinterpret_cast<const bf16x8 *>(row + 16 * m);
+            for (int m = 0; m < NM; m++) dst[m] = *reinterpret_cast<const bf16x8 *>(frag + m * 512);
         };
         auto do_tile = [&](int t, const bf16x8 (&v)[NM]) {
             f32x16 acc[NU];
@@ -1147,15 +1160,19 @@ __global__ __launch_bounds__(256, 2) void score_filter_bf16_kernel(
                 }
             }
         };
+        // The next tile is fetched UNCONDITIONALLY (past the end: the last tile again, unused).  Under `if (t + t_step < t_end)` the
+        // compiler cannot know at the merge how many loads are outstanding, assumes the fewest, and waits for the tile it has just
+        // requested together with the one it is about to use (s_waitcnt vmcnt(3..0) in front of the MFMAs): no software pipelining
+        // (round 6; the same finding as the BPR kernels' 64-bit flavour).  All four tile loops of this file fetch this way.
         bf16x8 va[NM], vb[NM];
         load_tile(t_begin, va);
         int t = t_begin;
         while (true) {
-            if (t + t_step < t_end) load_tile(t + t_step, vb);
+            load_tile(t + t_step < t_end ? t + t_step : t_end - 1, vb);
             do_tile(t, va);
             t += t_step;
             if (t >= t_end) break;
-            if (t + t_step < t_end) load_tile(t + t_step, va);
+            load_tile(t + t_step < t_end ? t + t_step : t_end - 1, va);
             do_tile(t, vb);
             t += t_step;
             if (t >= t_end) break;
@@ -1537,7 +1554,7 @@ __global__ __launch_bounds__(256) void sample_max_kernel_f32(
             // the next tile to come (this group's, or the first of the wavefront's next group) loads under this tile's MFMAs
             const int nxt = st + 1 < s_end ? st + 1 : (g + g_step) * tiles_per_group;
             const bool more = nxt < n_s_tiles && (st + 1 < s_end || g + g_step < n_groups);
-            if (more) load_tile(nxt, vn);
+            load_tile(more ? nxt : st, vn);          // unconditional: see score_filter_bf16_kernel
             f32x16 acc0, acc1;
 #pragma unroll
             for (int q = 0; q < 16; q++) { acc0[q] = 0.f; acc1[q] = 0.f; }
@@ -1705,9 +1722,9 @@ int run_fused_topk_f32(const float *U, const float *V, int d, int ld, int n_item
         QREC_HIP_CHECK(hipMemsetAsync(v_max, 0, sizeof(float), st));
         const int v_rows_pad = g.n_item_tiles * 32;
 #define QREC_BF(LPR)                                                                                                                  \
-        hipLaunchKernelGGL((to_bf16_kernel<LPR>), dim3((unsigned)((g.b_pad + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), dim3(256), 0, st, U,   \
+        hipLaunchKernelGGL((to_bf16_kernel<LPR, false>), dim3((unsigned)((g.b_pad + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), dim3(256), 0, st, U,   \
                            user_ids, n_b, g.b_pad, Ub, u_norm, (float *)nullptr);                                                     \
-        hipLaunchKernelGGL((to_bf16_kernel<LPR>), dim3((unsigned)((v_rows_pad + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), dim3(256), 0, st, V, \
+        hipLaunchKernelGGL((to_bf16_kernel<LPR, true>), dim3((unsigned)((v_rows_pad + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), dim3(256), 0, st, V, \
                            (const int32_t *)nullptr, n_items, v_rows_pad, Vb, (float *)nullptr, v_max)
         if (ld == 32) { QREC_BF(8); } else if (ld == 64) { QREC_BF(16); } else { QREC_BF(32); }
 #undef QREC_BF

@@ -12,6 +12,7 @@
 #   spmm-counters        FETCH_SIZE / WRITE_SIZE (separate passes) of the forward SpMM on the structureless and the planted-community graph
 #                        -> <tag>_lightgcn_hbm_counters.json (bytes past the XCD L2s per launch, over-fetch vs algorithmic bytes)
 #   mfma-util            MfmaUtil per MFMA kernel (NGCF step, evaluation, SimGCL step) -> <tag>_mfma_util.json
+#   pmc:<m>:<C1,C2,..>   one --pmc pass per counter over one config's step -> <tag>_<m>_counters.json
 #   stats:<m>            rocprofv3 --kernel-trace --stats of one config's step (m: lightgcn | simgcl | ngcf | eval) -> <tag>_<m>_kernel_stats.txt
 #   bpr-counters         the item-major BPR kernel under rocprofv3: kernel stats + one --pmc pass PER counter (atomic / request / busy / wait
 #                        counters that `rocprofv3 -L` lists on this box; FETCH_SIZE, WRITE_SIZE) at the Yelp2018 shape and on the HBM-resident
@@ -70,6 +71,16 @@ for STEP in "$@"; do
         rocprofv3 --pmc MfmaUtil --kernel-trace -d $O/pmc_mfma_$m -o m -- $(step_cmd $m) > $O/pmc_mfma_$m.log 2>&1; echo "$m exit $?"
       done
       python $R/tools/summarize_pmc.py $O/${TAG}_mfma_util.json MfmaUtil=$O/pmc_mfma_ngcf MfmaUtil=$O/pmc_mfma_eval MfmaUtil=$O/pmc_mfma_simgcl;;
+    pmc)
+      # pmc:<m>:<C1,C2,...>   one rocprofv3 --pmc pass PER counter over one config's step (m as in stats:) -> <tag>_<m>_counters.json
+      M=${ARG%%:*}; CS=${ARG#*:}; SPECS=""
+      for c in ${CS//,/ }; do
+        rm -rf $O/pmc_${M}_$c
+        timeout 300 rocprofv3 --pmc $c --kernel-trace -d $O/pmc_${M}_$c -o k -- $(step_cmd $M) > $O/pmc_${M}_$c.log 2>&1 || echo "$c failed"
+        SPECS="$SPECS $c=$O/pmc_${M}_$c"
+      done
+      python $R/tools/summarize_pmc.py $O/${TAG}_${M}_counters.json $SPECS | cut -c1-250 | head -40
+      rm -rf $O/pmc_${M}_*;;
     stats)
       rm -rf $O/prof_$ARG
       rocprofv3 --kernel-trace --stats -d $O/prof_$ARG -o $ARG -- $(step_cmd $ARG) > $O/prof_$ARG.log 2>&1; echo "$ARG exit $?"
