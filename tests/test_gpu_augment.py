@@ -200,3 +200,42 @@ def test_buir_class_in_throughput_mode_trains_on_device_drawn_subgraphs(monkeypa
     want = T.subgraph_values_on_full_structure(m.num_users, m.num_items, uid, iid, kept)
     check("BUIR class, throughput mode: the target encoder's sub-graph of the last epoch vs the oracle, words that differ",
           _words_differ(m.trainer.plan_t.values.numpy()[:want.size], want), 0, inclusive=True)
+
+
+def test_subgraph_values_refuses_bad_arguments_and_handles_degenerate_draws():
+    """include/qrec_hip.h, qrec_subgraph_values: null / contradictory arguments are refused with a message and nothing is written;
+    an empty keep list and "every node dropped" give the all-zero value array (the reference's empty csr_matrix: SGL.py:131-139 with
+    no kept row), a node draw that drops nobody gives the full graph's own values."""
+    nu, ni, uid, iid = _synthetic_with_duplicates()
+    adj = joint_norm_adjacency(nu, ni, uid, iid)
+    smp = SubgraphSampler(nu, ni, uid, iid, adj)
+    lib = capi.load()
+    out = DB.from_numpy(np.full(smp.nnz, 7.0, np.float32))
+    common = lambda: (smp.d_u.ptr, smp.d_i.ptr, smp.d_pos_ui.ptr, smp.d_pos_iu.ptr, smp.n_edges, smp.nu, smp.ni)
+    tail = lambda: (smp.d_row_of.ptr, smp.d_indices.ptr, smp.nnz, smp.d_dinv.ptr, smp.max_deg, smp.d_cnt.ptr, smp.d_deg.ptr)
+    keep = DB.from_numpy(np.arange(smp.n_edges, dtype=np.int32)); ids = DB.from_numpy(np.arange(max(nu, ni), dtype=np.int32))
+
+    def call(keep_ptr, n_keep, du, ndu, di, ndi, flags, values=out.ptr, u_ptr=None):
+        c = list(common())
+        if u_ptr is not None:
+            c[0] = u_ptr
+        return lib.qrec_subgraph_values(*c, keep_ptr, n_keep, du, ndu, di, ndi, *tail(), flags, values, None)
+
+    assert call(None, 0, None, 0, None, 0, None, values=None) < 0 and "null" in lib.qrec_last_error().decode()
+    assert call(keep.ptr, smp.n_edges + 1, None, 0, None, 0, None) < 0 and "keep" in lib.qrec_last_error().decode()
+    assert call(keep.ptr, -1, None, 0, None, 0, None) < 0
+    assert call(keep.ptr, 5, ids.ptr, 3, ids.ptr, 3, smp.d_flags.ptr) < 0 and "not both" in lib.qrec_last_error().decode()
+    assert call(None, 0, ids.ptr, 3, ids.ptr, 3, None) < 0 and "flag" in lib.qrec_last_error().decode()           # node dropout without its scratch
+    assert call(None, 0, ids.ptr, nu + 1, ids.ptr, 0, smp.d_flags.ptr) < 0                                         # more users dropped than there are
+    assert call(None, 0, ids.ptr, 3, None, 2, smp.d_flags.ptr) < 0                                                 # a count without its list
+    check("refused calls wrote nothing: entries of the value array that changed", int(np.count_nonzero(out.numpy() != 7.0)), 0, inclusive=True)
+    # degenerate draws
+    assert call(keep.ptr, 0, None, 0, None, 0, None) == 0
+    check("empty keep list: non-zero values", int(np.count_nonzero(out.numpy())), 0, inclusive=True)
+    out.upload(np.full(smp.nnz, 7.0, np.float32))
+    assert call(None, 0, ids.ptr, nu, ids.ptr, ni, smp.d_flags.ptr) == 0
+    check("every node dropped: non-zero values", int(np.count_nonzero(out.numpy())), 0, inclusive=True)
+    assert call(None, 0, ids.ptr, 0, ids.ptr, 0, smp.d_flags.ptr) == 0
+    check("node draw that drops nobody: words that differ from the full graph's values", _words_differ(out.numpy()[:adj[2].size], adj[2]), 0, inclusive=True)
+    assert call(keep.ptr, smp.n_edges, None, 0, None, 0, None) == 0
+    check("every row kept: words that differ from the full graph's values", _words_differ(out.numpy()[:adj[2].size], adj[2]), 0, inclusive=True)
